@@ -1,0 +1,218 @@
+// dev_common.h — device-side helpers shared by the gfx950 kernels.
+// wave = 64 lanes on CDNA4; all wave-width constants are hard-coded to 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dbhip.h"
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+#define DBHIP_WAVE 64
+
+// ---------------------------------------------------------------------------
+// group hash (reference: src/query/expression/src/aggregate/group_hash.rs)
+// ---------------------------------------------------------------------------
+#define DBHIP_NULL_HASH_VAL 0xd1cefa08eb382d69ULL  // group_hash.rs:38
+
+// impl_agg_hash_for_primitive_types (group_hash.rs:555-570); x is the value
+// cast `as u64` (sign-extended for signed types).
+__host__ __device__ __forceinline__ uint64_t agg_hash_u64(uint64_t x) {
+  x ^= x >> 32;
+  x *= 0xd6e8feb86659fd93ULL;
+  x ^= x >> 32;
+  x *= 0xd6e8feb86659fd93ULL;
+  x ^= x >> 32;
+  return x;
+}
+
+// impl AggHash for [u8] (group_hash.rs:522-553): MurmurHash64A-style, but the
+// tail bytes are folded big-endian-ordered: byte i of a tail of length L is
+// shifted by 8*(L-i-1).
+__host__ __device__ __forceinline__ uint64_t agg_hash_bytes(const uint8_t* p, uint32_t len) {
+  const uint64_t M = 0xc6a4a7935bd1e995ULL;
+  const uint64_t SEED = 0xe17a1465ULL;
+  const int R = 47;
+  uint64_t h = SEED ^ ((uint64_t)len * M);
+  uint32_t nblocks = len / 8;
+  for (uint32_t i = 0; i < nblocks; ++i) {
+    uint64_t k = 0;
+    for (int b = 0; b < 8; ++b) k |= (uint64_t)p[i * 8 + b] << (8 * b);  // read_unaligned LE
+    k *= M;
+    k ^= k >> R;
+    k *= M;
+    h ^= k;
+    h *= M;
+  }
+  uint32_t tail = len - nblocks * 8;
+  const uint8_t* t = p + nblocks * 8;
+  for (uint32_t i = 0; i < tail; ++i) h ^= (uint64_t)t[i] << (8 * (tail - i - 1));
+  h ^= h >> R;
+  h *= M;
+  h ^= h >> R;
+  return h;
+}
+
+// Same hash for a string that sits inline in a 16-byte view (len <= 12):
+// w1..w3 are the view's dwords 1..3 (bytes 0..11 of the string, little endian).
+__device__ __forceinline__ uint64_t agg_hash_inline_view(uint32_t len, uint32_t w1, uint32_t w2,
+                                                         uint32_t w3) {
+  const uint64_t M = 0xc6a4a7935bd1e995ULL;
+  const uint64_t SEED = 0xe17a1465ULL;
+  const int R = 47;
+  uint64_t h = SEED ^ ((uint64_t)len * M);
+  uint64_t lo = ((uint64_t)w2 << 32) | w1;
+  uint32_t tail_len = len;
+  uint64_t tail_src = lo;  // little-endian bytes of the tail
+  if (len >= 8) {
+    uint64_t k = lo;
+    k *= M;
+    k ^= k >> R;
+    k *= M;
+    h ^= k;
+    h *= M;
+    tail_len = len - 8;
+    tail_src = w3;
+  }
+  // tail byte i (LE position i) is shifted by 8*(tail_len-i-1): i.e. the byte-reversed
+  // value of the low tail_len bytes.
+  uint64_t folded = 0;
+  for (uint32_t i = 0; i < 7; ++i) {
+    if (i < tail_len) folded |= ((tail_src >> (8 * i)) & 0xff) << (8 * (tail_len - i - 1));
+  }
+  h ^= folded;
+  h ^= h >> R;
+  h *= M;
+  h ^= h >> R;
+  return h;
+}
+
+// i128 hashes as its 16 little-endian bytes (group_hash.rs:587-591).
+__device__ __forceinline__ uint64_t agg_hash_i128(i128 v) {
+  const uint64_t M = 0xc6a4a7935bd1e995ULL;
+  const uint64_t SEED = 0xe17a1465ULL;
+  const int R = 47;
+  uint64_t h = SEED ^ (16ULL * M);
+  uint64_t w[2] = {(uint64_t)(u128)v, (uint64_t)((u128)v >> 64)};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    uint64_t k = w[i];
+    k *= M;
+    k ^= k >> R;
+    k *= M;
+    h ^= k;
+    h *= M;
+  }
+  h ^= h >> R;
+  h *= M;
+  h ^= h >> R;
+  return h;
+}
+
+__host__ __device__ __forceinline__ uint64_t merge_hash(uint64_t a, uint64_t b) {
+  return a * DBHIP_NULL_HASH_VAL ^ b;  // group_hash.rs:509-511
+}
+
+// ---------------------------------------------------------------------------
+// bitmaps (LSB-first, src/common/column/src/bitmap/immutable.rs:78-85)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool bit_get(const uint8_t* bm, int64_t i) {
+  return (bm[i >> 3] >> (i & 7)) & 1;
+}
+
+// ---------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ u128 wave_sum_u128(u128 v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint64_t lo = __shfl_xor((uint64_t)v, off, 64);
+    uint64_t hi = __shfl_xor((uint64_t)(v >> 64), off, 64);
+    v += ((u128)hi << 64) | lo;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------------------
+// 256-bit helper for Decimal128 rounding paths (types/decimal.rs:1024-1060 use
+// ethnum i256). Sign-magnitude: callers split sign and magnitude first.
+// ---------------------------------------------------------------------------
+struct u256 {
+  u128 lo, hi;
+};
+
+__host__ __device__ __forceinline__ u256 u256_mul_128(u128 a, u128 b) {
+  uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64);
+  uint64_t b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
+  u128 p00 = (u128)a0 * b0;
+  u128 p01 = (u128)a0 * b1;
+  u128 p10 = (u128)a1 * b0;
+  u128 p11 = (u128)a1 * b1;
+  u128 mid = (p00 >> 64) + (uint64_t)p01 + (uint64_t)p10;
+  u256 r;
+  r.lo = ((u128)(uint64_t)mid << 64) | (uint64_t)p00;
+  r.hi = p11 + (p01 >> 64) + (p10 >> 64) + (mid >> 64);
+  return r;
+}
+
+__host__ __device__ __forceinline__ u256 u256_add_128(u256 a, u128 b) {
+  u256 r;
+  r.lo = a.lo + b;
+  r.hi = a.hi + (r.lo < a.lo ? 1 : 0);
+  return r;
+}
+
+__host__ __device__ __forceinline__ bool u256_lt_128(u256 a, u128 b) { return a.hi == 0 && a.lo < b; }
+
+// a -= b (b 128-bit), requires a >= b
+__host__ __device__ __forceinline__ u256 u256_sub_128(u256 a, u128 b) {
+  u256 r;
+  r.lo = a.lo - b;
+  r.hi = a.hi - (a.lo < b ? 1 : 0);
+  return r;
+}
+
+// q = a / d (d != 0), binary long division; *rem gets the remainder.
+__host__ __device__ inline u256 u256_div_128(u256 a, u128 d, u128* rem) {
+  u256 q;
+  q.lo = 0;
+  q.hi = 0;
+  if (a.hi == 0) {
+    q.lo = a.lo / d;
+    if (rem) *rem = a.lo % d;
+    return q;
+  }
+  // r holds up to 129 bits: track overflow bit separately
+  u128 r = 0;
+  for (int i = 255; i >= 0; --i) {
+    bool carry = (r >> 127) & 1;
+    r <<= 1;
+    u128 bit = (i >= 128) ? ((a.hi >> (i - 128)) & 1) : ((a.lo >> i) & 1);
+    r |= bit;
+    if (carry || r >= d) {
+      r -= d;
+      if (i >= 128)
+        q.hi |= ((u128)1 << (i - 128));
+      else
+        q.lo |= ((u128)1 << i);
+    }
+  }
+  if (rem) *rem = r;
+  return q;
+}
+
+// 10^k as i128 for k in [0, 38]
+__host__ __device__ __forceinline__ i128 pow10_i128(int k) {
+  i128 r = 1;
+  for (int i = 0; i < k; ++i) r *= 10;
+  return r;
+}

@@ -1,0 +1,158 @@
+// gb_device.h — device functions shared by the hash-aggregation kernels
+// (k_groupby.hip) and the fused Q1 pipeline (k_q1.hip).
+#pragma once
+#include "dev_common.h"
+#include "gb_layout.h"
+
+// order-preserving u64 key for MIN/MAX states: signed ints flip the sign bit,
+// floats use the OrderedFloat total order (NaN largest, types/number.rs:47-48).
+__device__ __forceinline__ uint64_t ord_encode(uint64_t raw, int type) {
+  switch (type) {
+    case DBHIP_T_U8: case DBHIP_T_U16: case DBHIP_T_U32: case DBHIP_T_U64: case DBHIP_T_BOOL:
+      return raw;
+    case DBHIP_T_F32: {
+      float f = __uint_as_float((uint32_t)raw);
+      if (f != f) return ~0ULL;
+      double d = (double)f;
+      uint64_t b = (uint64_t)__double_as_longlong(d);
+      return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+    }
+    case DBHIP_T_F64: {
+      double d = __longlong_as_double((long long)raw);
+      if (d != d) return ~0ULL;
+      return (raw >> 63) ? ~raw : (raw | 0x8000000000000000ULL);
+    }
+    default:
+      return raw ^ 0x8000000000000000ULL;
+  }
+}
+
+__device__ __forceinline__ uint64_t ord_decode(uint64_t enc, int type) {
+  switch (type) {
+    case DBHIP_T_U8: case DBHIP_T_U16: case DBHIP_T_U32: case DBHIP_T_U64: case DBHIP_T_BOOL:
+      return enc;
+    case DBHIP_T_F32: {
+      if (enc == ~0ULL) return 0x7fc00000u;
+      uint64_t b = (enc >> 63) ? (enc & 0x7fffffffffffffffULL) : ~enc;
+      return (uint64_t)__float_as_uint((float)__longlong_as_double((long long)b));
+    }
+    case DBHIP_T_F64: {
+      if (enc == ~0ULL) return 0x7ff8000000000000ULL;
+      return (enc >> 63) ? (enc & 0x7fffffffffffffffULL) : ~enc;
+    }
+    default:
+      return enc ^ 0x8000000000000000ULL;
+  }
+}
+
+// Loads the value of `col` at `row` as canonical words (see gb_layout.h).
+// Returns false for strings longer than 12 bytes (unsupported as keys).
+__device__ __forceinline__ bool gb_load_words(const GbCol& c, int64_t row, uint64_t w[2], bool* valid) {
+  int64_t j = c.is_scalar ? 0 : row;
+  *valid = !c.validity || bit_get(c.validity, c.voff + j);
+  w[0] = 0;
+  w[1] = 0;
+  switch (c.type) {
+    case DBHIP_T_BOOL: w[0] = bit_get((const uint8_t*)c.data, j); break;
+    case DBHIP_T_I8: w[0] = (uint64_t)(int64_t)((const int8_t*)c.data)[j]; break;
+    case DBHIP_T_I16: w[0] = (uint64_t)(int64_t)((const int16_t*)c.data)[j]; break;
+    case DBHIP_T_I32: case DBHIP_T_DATE: w[0] = (uint64_t)(int64_t)((const int32_t*)c.data)[j]; break;
+    case DBHIP_T_I64: case DBHIP_T_TIMESTAMP: case DBHIP_T_DEC64:
+      w[0] = (uint64_t)((const int64_t*)c.data)[j]; break;
+    case DBHIP_T_U8: w[0] = ((const uint8_t*)c.data)[j]; break;
+    case DBHIP_T_U16: w[0] = ((const uint16_t*)c.data)[j]; break;
+    case DBHIP_T_U32: case DBHIP_T_F32: w[0] = ((const uint32_t*)c.data)[j]; break;
+    case DBHIP_T_U64: case DBHIP_T_F64: w[0] = ((const uint64_t*)c.data)[j]; break;
+    case DBHIP_T_DEC128: {
+      const uint64_t* p = (const uint64_t*)c.data + 2 * j;
+      w[0] = p[0];
+      w[1] = p[1];
+    } break;
+    case DBHIP_T_STRING: {
+      const uint32_t* p = (const uint32_t*)c.data + 4 * j;
+      uint32_t len = p[0];
+      if (len > 12) return false;
+      uint32_t d1 = p[1], d2 = p[2], d3 = p[3];
+      // zero the bytes past len so equal strings are equal words
+      if (len < 4) { d1 &= (len == 0) ? 0u : (0xffffffffu >> (8 * (4 - len))); d2 = 0; d3 = 0; }
+      else if (len < 8) { d2 &= (len == 4) ? 0u : (0xffffffffu >> (8 * (8 - len))); d3 = 0; }
+      else if (len < 12) { d3 &= (len == 8) ? 0u : (0xffffffffu >> (8 * (12 - len))); }
+      w[0] = ((uint64_t)d1 << 32) | len;
+      w[1] = ((uint64_t)d3 << 32) | d2;
+    } break;
+    default: return false;
+  }
+  if (!*valid) { w[0] = 0; w[1] = 0; }
+  return true;
+}
+
+// AggHash of one key value given its canonical words (group_hash.rs:513-632).
+__device__ __forceinline__ uint64_t gb_hash_words(int type, const uint64_t w[2], bool valid) {
+  if (!valid) return DBHIP_NULL_HASH_VAL;
+  switch (type) {
+    case DBHIP_T_BOOL: return w[0];                                   // :581-585
+    case DBHIP_T_F32: {                                               // :599-609
+      float f = __uint_as_float((uint32_t)w[0]);
+      uint32_t bits = (f != f) ? 0x7fc00000u : (uint32_t)w[0];
+      return agg_hash_u64((uint64_t)bits);
+    }
+    case DBHIP_T_F64: {                                               // :611-620
+      double d = __longlong_as_double((long long)w[0]);
+      uint64_t bits = (d != d) ? 0x7ff8000000000000ULL : w[0];
+      return agg_hash_u64(bits);
+    }
+    case DBHIP_T_DEC128:                                              // :587-591
+      return agg_hash_i128((i128)(((u128)w[1] << 64) | w[0]));
+    case DBHIP_T_STRING: {                                            // :522-553
+      uint32_t len = (uint32_t)w[0];
+      return agg_hash_inline_view(len, (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+    }
+    default:
+      return agg_hash_u64(w[0]);                                      // :555-570
+  }
+}
+
+// 128-bit wrapping add into two adjacent u64 words with global atomics.
+__device__ __forceinline__ void atomic_add_u128(uint64_t* p, uint64_t lo, uint64_t hi) {
+  unsigned long long old = atomicAdd((unsigned long long*)p, (unsigned long long)lo);
+  uint64_t carry = ((uint64_t)old + lo) < lo ? 1 : 0;
+  uint64_t addhi = hi + carry;
+  if (addhi) atomicAdd((unsigned long long*)(p + 1), (unsigned long long)addhi);
+}
+
+// merge one state contribution `v` (agg_words words) into the state at `dst`
+__device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64_t* dst,
+                                                const uint64_t* v) {
+  switch (L.agg_kind[a]) {
+    case DBHIP_AGG_COUNT:
+      if (v[0]) atomicAdd((unsigned long long*)dst, (unsigned long long)v[0]);
+      break;
+    case DBHIP_AGG_SUM:
+      if (L.agg_words[a] == 2) {
+        if (v[0] | v[1]) atomic_add_u128(dst, v[0], v[1]);
+      } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
+        atomicAdd((double*)dst, __longlong_as_double((long long)v[0]));
+      } else if (v[0]) {
+        atomicAdd((unsigned long long*)dst, (unsigned long long)v[0]);
+      }
+      break;
+    case DBHIP_AGG_MIN:
+      if (v[1]) {
+        atomicMin((unsigned long long*)dst, (unsigned long long)v[0]);
+        atomicOr((unsigned long long*)(dst + 1), 1ULL);
+      }
+      break;
+    default:  // MAX
+      if (v[1]) {
+        atomicMax((unsigned long long*)dst, (unsigned long long)v[0]);
+        atomicOr((unsigned long long*)(dst + 1), 1ULL);
+      }
+      break;
+  }
+}
+
+// identity element of a state
+__device__ __forceinline__ void gb_state_identity(const GbLayout& L, int a, uint64_t* dst) {
+  for (int k = 0; k < L.agg_words[a]; ++k) dst[k] = 0;
+  if (L.agg_kind[a] == DBHIP_AGG_MIN) dst[0] = ~0ULL;
+}

@@ -1,0 +1,59 @@
+// gb_layout.h — device row layout of the hash-aggregation table (the HBM analogue
+// of the reference's Payload row, src/query/expression/src/aggregate/payload.rs:47-72,
+// payload_row.rs:51-215): every field is a whole number of u64 words
+//
+//   [key words ...][validity word (only if a key is nullable)][hash][state words ...]
+//
+// key encodings (canonical, so that key equality is word equality):
+//   ints/date/timestamp/dec64/bool : 1 word, value widened (sign-/zero-extended)
+//   f32/f64                        : 1 word, raw bits zero-extended
+//   dec128                         : 2 words (lo, hi)
+//   string (len <= 12)             : 2 words = the 16-byte inline view, bytes past len zeroed
+//   NULL key                       : value words zeroed, bit `k` of the validity word cleared
+// state encodings:
+//   COUNT                : 1 word u64
+//   SUM int/dec64        : 1 word (wrapping i64/u64)        (aggregate_sum.rs:113-129,203-216)
+//   SUM f32/f64          : 1 word f64
+//   SUM dec128           : 2 words (wrapping i128; overflow is checked at merge_result)
+//   MIN/MAX              : 2 words [order-preserving key][has value]
+// The same row is the unit of exchange between ranks (serialized partial state).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/dbhip.h"
+
+#define GB_MAX_KEYS 16
+#define GB_MAX_AGGS 24
+
+struct GbLayout {
+  int32_t nkeys, naggs;
+  int32_t key_type[GB_MAX_KEYS];
+  int32_t key_off[GB_MAX_KEYS];    // word offset
+  int32_t key_words[GB_MAX_KEYS];
+  int32_t key_nullable[GB_MAX_KEYS];
+  int32_t validity_word;           // -1 when no key is nullable
+  int32_t nkey_words;              // key words + validity word (everything compared for equality)
+  int32_t hash_word;
+  int32_t agg_kind[GB_MAX_AGGS];
+  int32_t agg_type[GB_MAX_AGGS];
+  int32_t agg_off[GB_MAX_AGGS];
+  int32_t agg_words[GB_MAX_AGGS];
+  int32_t agg_nullable[GB_MAX_AGGS];
+  int32_t agg_precision[GB_MAX_AGGS];
+  int32_t agg_scale[GB_MAX_AGGS];
+  int32_t W;                       // words per row
+};
+
+struct GbCol {  // by-value copy of dbhip_col for kernel arguments
+  const void* data;
+  const uint8_t* validity;
+  int64_t voff;
+  const void* const* buffers;
+  int32_t type;
+  int32_t is_scalar;
+};
+
+struct GbCols {
+  GbCol key[GB_MAX_KEYS];
+  GbCol arg[GB_MAX_AGGS];
+};

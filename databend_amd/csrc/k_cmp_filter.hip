@@ -1,0 +1,407 @@
+// k_cmp_filter.hip — comparisons -> Bitmap (a5), bitmap ops, filter ->
+// selection vector and take/gather (a6).
+// Reference semantics:
+//   vectorize_cmp_2_arg + Bitmap::collect_bool   register_comparison.rs:52-96,
+//                                                bitmap/immutable.rs:474 (LSB-first)
+//   OrderedFloat total order (NaN == NaN, NaN largest)   types/number.rs:47-48
+//   FilterExecutor::select -> ascending u32 row ids      filter/filter_executor.rs:81-118
+//   DataBlock::take                                      kernels/take.rs:43
+#include "dev_common.h"
+#include "dev_load.h"
+#include "runtime.h"
+
+using namespace dbhip;
+
+namespace {
+
+// -1 / 0 / +1 three-way compare helpers ------------------------------------
+__device__ __forceinline__ int cmp3_i64(int64_t a, int64_t b) { return (a > b) - (a < b); }
+__device__ __forceinline__ int cmp3_u64(uint64_t a, uint64_t b) { return (a > b) - (a < b); }
+__device__ __forceinline__ int cmp3_f64(double a, double b) {
+  bool an = a != a, bn = b != b;
+  if (an || bn) return (int)an - (int)bn;  // NaN is the largest, NaN == NaN
+  return (a > b) - (a < b);
+}
+__device__ __forceinline__ int cmp3_i128(i128 a, i128 b) { return (a > b) - (a < b); }
+
+__device__ __forceinline__ bool apply_cmp(int op, int c) {
+  switch (op) {
+    case DBHIP_CMP_EQ: return c == 0;
+    case DBHIP_CMP_NOTEQ: return c != 0;
+    case DBHIP_CMP_LT: return c < 0;
+    case DBHIP_CMP_LTE: return c <= 0;
+    case DBHIP_CMP_GT: return c > 0;
+    default: return c >= 0;
+  }
+}
+
+struct View {
+  uint32_t len, w1, w2, w3;  // binview/view.rs:30-42: inline bytes in w1..w3 when len<=12,
+};                            // else w1=prefix, w2=buffer_idx, w3=offset
+
+__device__ __forceinline__ const uint8_t* view_ptr(const View& v, const View* self,
+                                                   const void* const* buffers) {
+  if (v.len <= 12) return (const uint8_t*)self + 4;
+  return (const uint8_t*)buffers[v.w2] + v.w3;
+}
+
+__device__ int cmp3_views(const View* a, const void* const* abuf, const View* b,
+                          const void* const* bbuf) {
+  View va = *a, vb = *b;
+  const uint8_t* pa = view_ptr(va, a, abuf);
+  const uint8_t* pb = view_ptr(vb, b, bbuf);
+  uint32_t m = va.len < vb.len ? va.len : vb.len;
+  for (uint32_t i = 0; i < m; ++i) {
+    int d = (int)pa[i] - (int)pb[i];
+    if (d) return d < 0 ? -1 : 1;
+  }
+  return (va.len > vb.len) - (va.len < vb.len);
+}
+
+struct CmpParams {
+  const void* a;
+  const void* b;
+  const void* const* abuf;
+  const void* const* bbuf;
+  uint8_t* out;
+  int64_t n;
+  int64_t out_bytes;
+  int type, a_scalar, b_scalar, op;
+};
+
+// Pack the 4 result bits of each lane: 8 lanes -> one u32 (rows are lane*4+k).
+__device__ __forceinline__ void store_nibbles(uint8_t* out, int64_t out_bytes, int64_t quad,
+                                              uint32_t nib) {
+  uint32_t w = nib << (4 * (lane_id() & 7));
+  w |= __shfl_xor(w, 1, 64);
+  w |= __shfl_xor(w, 2, 64);
+  w |= __shfl_xor(w, 4, 64);
+  if ((lane_id() & 7) == 0) {
+    int64_t byte0 = (quad >> 3) * 4;  // quad index of lane group start / 8 -> u32 index
+    if (byte0 + 4 <= out_bytes) {
+      *(uint32_t*)(out + byte0) = w;
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (byte0 + k < out_bytes) out[byte0 + k] = (uint8_t)(w >> (8 * k));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cmp_kernel(CmpParams p) {
+  const int cls = type_class(p.type);
+  const int64_t nquads = (p.n + 3) >> 2;
+  // all lanes of a wave iterate together so the shuffles in store_nibbles are convergent
+  const int64_t nquads_pad = (nquads + 63) & ~63LL;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads_pad;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q << 2;
+    uint32_t nib = 0;
+    if (q < nquads) {
+      if (p.type == DBHIP_T_DEC128) {
+        const i128* a = (const i128*)p.a;
+        const i128* b = (const i128*)p.b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (i0 + k < p.n) {
+            i128 x = a[p.a_scalar ? 0 : i0 + k], y = b[p.b_scalar ? 0 : i0 + k];
+            nib |= (uint32_t)apply_cmp(p.op, cmp3_i128(x, y)) << k;
+          }
+        }
+      } else if (p.type == DBHIP_T_STRING) {
+        const View* a = (const View*)p.a;
+        const View* b = (const View*)p.b;
+        for (int k = 0; k < 4; ++k) {
+          if (i0 + k < p.n) {
+            int c = cmp3_views(a + (p.a_scalar ? 0 : i0 + k), p.abuf, b + (p.b_scalar ? 0 : i0 + k),
+                               p.bbuf);
+            nib |= (uint32_t)apply_cmp(p.op, c) << k;
+          }
+        }
+      } else if (p.type == DBHIP_T_BOOL) {
+        const uint8_t* a = (const uint8_t*)p.a;
+        const uint8_t* b = (const uint8_t*)p.b;
+        for (int k = 0; k < 4; ++k) {
+          if (i0 + k < p.n) {
+            int x = bit_get(a, p.a_scalar ? 0 : i0 + k), y = bit_get(b, p.b_scalar ? 0 : i0 + k);
+            nib |= (uint32_t)apply_cmp(p.op, x - y) << k;
+          }
+        }
+      } else {
+        uint64_t a[4], b[4];
+        load4_wide(p.a, p.type, p.a_scalar, i0, p.n, a);
+        load4_wide(p.b, p.type, p.b_scalar, i0, p.n, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int c;
+          if (cls == CLS_SIGNED) c = cmp3_i64((int64_t)a[k], (int64_t)b[k]);
+          else if (cls == CLS_UNSIGNED) c = cmp3_u64(a[k], b[k]);
+          else c = cmp3_f64(__longlong_as_double((long long)a[k]), __longlong_as_double((long long)b[k]));
+          nib |= (uint32_t)(apply_cmp(p.op, c) && (i0 + k < p.n)) << k;
+        }
+      }
+    }
+    store_nibbles(p.out, p.out_bytes, q & ~7LL, nib);
+  }
+}
+
+__global__ __launch_bounds__(256) void bitmap_binary_kernel(const uint8_t* a, const uint8_t* b,
+                                                            uint8_t* out, int64_t nbytes, int64_t n,
+                                                            int is_or) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint8_t v = is_or ? (a[i] | b[i]) : (a[i] & b[i]);
+    if (i == nbytes - 1 && (n & 7)) v &= (uint8_t)((1u << (n & 7)) - 1);
+    out[i] = v;
+  }
+}
+
+// Read up to 64 bits starting at absolute bit `pos` of `bm`; bits past `end` are 0.
+__device__ __forceinline__ uint64_t load_bits64(const uint8_t* bm, int64_t pos, int64_t end) {
+  if (pos >= end) return 0;
+  int64_t nb = end - pos;
+  if (nb > 64) nb = 64;
+  uintptr_t addr = (uintptr_t)(bm + (pos >> 3));
+  const uint64_t* w = (const uint64_t*)(addr & ~(uintptr_t)7);
+  int sh = (int)((addr & 7) * 8 + (pos & 7));
+  uint64_t v = w[0] >> sh;
+  if (sh + nb > 64) v |= w[1] << (64 - sh);
+  if (nb < 64) v &= (1ULL << nb) - 1;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void bitmap_count_kernel(const uint8_t* bm, int64_t off, int64_t n,
+                                                           unsigned long long* out) {
+  const int64_t nwords = (n + 63) >> 6;
+  uint64_t acc = 0;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
+       w += (int64_t)gridDim.x * blockDim.x)
+    acc += __popcll(load_bits64(bm, off + w * 64, off + n));
+  acc = wave_sum_u64(acc);
+  if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+
+// ---- filter_select: 3 phases --------------------------------------------------
+// A block owns SEL_WORDS_PER_BLOCK 64-bit words (= 16384 rows).
+#define SEL_WORDS_PER_BLOCK 256
+
+__global__ __launch_bounds__(256) void sel_count_kernel(const uint8_t* bm, int64_t off, int64_t n,
+                                                        uint32_t* block_counts) {
+  const int64_t w = (int64_t)blockIdx.x * SEL_WORDS_PER_BLOCK + threadIdx.x;
+  uint64_t c = __popcll(load_bits64(bm, off + w * 64, off + n));
+  c = wave_sum_u64(c);
+  __shared__ uint32_t part[4];
+  if (lane_id() == 0) part[threadIdx.x >> 6] = (uint32_t)c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// single-block exclusive scan of block counts (u32 counts, u64 offsets)
+__global__ __launch_bounds__(1024) void sel_scan_kernel(const uint32_t* counts, uint64_t* offsets,
+                                                        int64_t nblocks, unsigned long long* total) {
+  __shared__ uint64_t wave_tot[16];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblocks; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    uint64_t v = i < nblocks ? counts[i] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint64_t t = __shfl_up(incl, d, 64);
+      if (lane_id() >= d) incl += t;
+    }
+    if (lane_id() == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wbase = 0;
+    for (int k = 0; k < (threadIdx.x >> 6); ++k) wbase += wave_tot[k];
+    uint64_t c = carry;
+    if (i < nblocks) offsets[i] = c + wbase + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void sel_write_kernel(const uint8_t* bm, int64_t off, int64_t n,
+                                                        const uint64_t* block_offsets,
+                                                        uint32_t* out_sel) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int64_t w = (int64_t)blockIdx.x * SEL_WORDS_PER_BLOCK + threadIdx.x;
+  const uint64_t bits = load_bits64(bm, off + w * 64, off + n);
+  const uint32_t cnt = __popcll(bits);
+  // exclusive scan of cnt inside the block
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  __shared__ uint32_t wave_tot[4];
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int k = 0; k < wave; ++k) wbase += wave_tot[k];
+  const uint64_t my_off = block_offsets[blockIdx.x] + wbase + incl - cnt;
+  // wave-cooperative expansion: word j of this wave is handled by all 64 lanes,
+  // lane l tests bit l -> coalesced stores of ascending row ids
+  for (int j = 0; j < 64; ++j) {
+    uint64_t wj = __shfl(bits, j, 64);
+    if (wj == 0) continue;
+    uint64_t oj = __shfl(my_off, j, 64);
+    if ((wj >> lane) & 1) {
+      uint32_t rank = __popcll(wj & ((1ULL << lane) - 1));
+      int64_t row = ((int64_t)blockIdx.x * SEL_WORDS_PER_BLOCK + wave * 64 + j) * 64 + lane;
+      out_sel[oj + rank] = (uint32_t)row;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void take_kernel(const T* __restrict__ src,
+                                                   const uint32_t* __restrict__ sel, int64_t n,
+                                                   T* __restrict__ out) {
+  const int64_t nquads = (n + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i0 = q << 2;
+    if (i0 + 4 <= n) {
+      VecT<uint32_t, 4> s = *(const VecT<uint32_t, 4>*)(sel + i0);
+      T v0 = src[s.v[0]], v1 = src[s.v[1]], v2 = src[s.v[2]], v3 = src[s.v[3]];
+      out[i0] = v0; out[i0 + 1] = v1; out[i0 + 2] = v2; out[i0 + 3] = v3;
+    } else {
+      for (int64_t i = i0; i < n; ++i) out[i] = src[sel[i]];
+    }
+  }
+}
+
+struct alignas(16) B16 {
+  uint64_t a, b;
+};
+
+__global__ __launch_bounds__(256) void take_bitmap_kernel(const uint8_t* src, int64_t off,
+                                                          const uint32_t* sel, int64_t n,
+                                                          uint8_t* out, int64_t out_bytes) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    bool b = i < n && bit_get(src, off + sel[i]);
+    uint64_t m = __ballot(b);
+    if (lane_id() == 0) {
+      int64_t byte0 = (i >> 6) * 8;
+      for (int k = 0; k < 8; ++k)
+        if (byte0 + k < out_bytes) out[byte0 + k] = (uint8_t)(m >> (8 * k));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n,
+                  uint8_t* out_bitmap, void* stream) {
+  DBHIP_REQUIRE(lhs && rhs && (out_bitmap || n == 0), "dbhip_cmp: NULL argument");
+  DBHIP_REQUIRE(op >= DBHIP_CMP_EQ && op <= DBHIP_CMP_GTE, "dbhip_cmp: bad operator");
+  if (lhs->type != rhs->type) {
+    set_error("dbhip_cmp: operand types differ (%d vs %d); the planner casts to a common type",
+              lhs->type, rhs->type);
+    return DBHIP_ERR_INVALID;
+  }
+  DBHIP_REQUIRE(type_class(lhs->type) >= 0 || lhs->type == DBHIP_T_DEC128 ||
+                    lhs->type == DBHIP_T_STRING || lhs->type == DBHIP_T_BOOL,
+                "dbhip_cmp: unsupported type");
+  if (n == 0) return DBHIP_OK;
+  CmpParams p;
+  p.a = lhs->data; p.b = rhs->data;
+  p.abuf = lhs->buffers; p.bbuf = rhs->buffers;
+  p.out = out_bitmap; p.n = n; p.out_bytes = ceil_div(n, 8);
+  p.type = lhs->type; p.a_scalar = lhs->is_scalar; p.b_scalar = rhs->is_scalar; p.op = op;
+  int grid = grid_for(ceil_div(n, 4), 256);
+  hipLaunchKernelGGL(cmp_kernel, dim3(grid), dim3(256), 0, resolve_stream(stream), p);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_bitmap_binary(int32_t is_or, const uint8_t* a, const uint8_t* b, int64_t n,
+                            uint8_t* out, void* stream) {
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(a && b && out, "dbhip_bitmap_binary: NULL argument");
+  int64_t nbytes = ceil_div(n, 8);
+  hipLaunchKernelGGL(bitmap_binary_kernel, dim3(grid_for(nbytes, 256)), dim3(256), 0,
+                     resolve_stream(stream), a, b, out, nbytes, n, is_or);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_bitmap_count(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
+                           uint64_t* out_count_dev, void* stream) {
+  DBHIP_REQUIRE(out_count_dev, "dbhip_bitmap_count: NULL out");
+  hipStream_t s = resolve_stream(stream);
+  DBHIP_CHECK(hipMemsetAsync(out_count_dev, 0, 8, s));
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(bitmap, "dbhip_bitmap_count: NULL bitmap");
+  hipLaunchKernelGGL(bitmap_count_kernel, dim3(grid_for(ceil_div(n, 64), 256)), dim3(256), 0, s,
+                     bitmap, bit_offset, n, (unsigned long long*)out_count_dev);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_filter_select(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
+                            uint32_t* out_sel, uint64_t* out_count_dev, void* stream) {
+  DBHIP_REQUIRE(out_count_dev, "dbhip_filter_select: NULL out_count");
+  DBHIP_REQUIRE(n <= 0xFFFFFFFFLL, "dbhip_filter_select: more than 2^32 rows in one block");
+  hipStream_t s = resolve_stream(stream);
+  if (n == 0) {
+    DBHIP_CHECK(hipMemsetAsync(out_count_dev, 0, 8, s));
+    return DBHIP_OK;
+  }
+  DBHIP_REQUIRE(bitmap && out_sel, "dbhip_filter_select: NULL argument");
+  int64_t nwords = ceil_div(n, 64);
+  int64_t nblocks = ceil_div(nwords, SEL_WORDS_PER_BLOCK);
+  uint8_t* ws = (uint8_t*)scratch((size_t)nblocks * 12 + 64, 1);
+  if (!ws) return DBHIP_ERR_HIP;
+  uint64_t* offsets = (uint64_t*)ws;
+  uint32_t* counts = (uint32_t*)(ws + nblocks * 8);
+  hipLaunchKernelGGL(sel_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, bitmap, bit_offset,
+                     n, counts);
+  hipLaunchKernelGGL(sel_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, nblocks,
+                     (unsigned long long*)out_count_dev);
+  hipLaunchKernelGGL(sel_write_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, bitmap, bit_offset,
+                     n, offsets, out_sel);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int64_t n_sel,
+                   void* out, void* stream) {
+  if (n_sel == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(src && sel && out, "dbhip_take: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  int grid = grid_for(ceil_div(n_sel, 4), 256);
+  switch (elem_size) {
+    case 1: hipLaunchKernelGGL(take_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, sel, n_sel, (uint8_t*)out); break;
+    case 2: hipLaunchKernelGGL(take_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, sel, n_sel, (uint16_t*)out); break;
+    case 4: hipLaunchKernelGGL(take_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, (const uint32_t*)src, sel, n_sel, (uint32_t*)out); break;
+    case 8: hipLaunchKernelGGL(take_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, (const uint64_t*)src, sel, n_sel, (uint64_t*)out); break;
+    case 16: hipLaunchKernelGGL(take_kernel<B16>, dim3(grid), dim3(256), 0, s, (const B16*)src, sel, n_sel, (B16*)out); break;
+    default:
+      set_error("dbhip_take: unsupported element size %d", elem_size);
+      return DBHIP_ERR_INVALID;
+  }
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_take_bitmap(const uint8_t* src, int64_t bit_offset, const uint32_t* sel,
+                          int64_t n_sel, uint8_t* out, void* stream) {
+  if (n_sel == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(src && sel && out, "dbhip_take_bitmap: NULL argument");
+  hipLaunchKernelGGL(take_bitmap_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0,
+                     resolve_stream(stream), src, bit_offset, sel, n_sel, out, ceil_div(n_sel, 8));
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+}  // extern "C"

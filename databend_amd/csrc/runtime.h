@@ -1,0 +1,58 @@
+// runtime.h — host-side plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dbhip.h"
+
+namespace dbhip {
+
+void set_error(const char* fmt, ...);
+hipStream_t resolve_stream(void* stream);  // NULL -> library stream
+int32_t hip_fail(hipError_t e, const char* what);
+
+// Scratch arena bound to the library (grown on demand, reused across calls on
+// the same thread; callers must not hold it across dbhip calls).
+void* scratch(size_t bytes, int slot);
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs
+// with 8 blocks each (guide §6 G11), never more than the work needs.
+inline int grid_for(int64_t n_items_per_thread_units, int block) {
+  int64_t need = ceil_div(n_items_per_thread_units, block);
+  if (need < 1) need = 1;
+  if (need > 2048) need = 2048;
+  return (int)need;
+}
+
+inline int type_size(int32_t t) {
+  switch (t) {
+    case DBHIP_T_I8: case DBHIP_T_U8: return 1;
+    case DBHIP_T_I16: case DBHIP_T_U16: return 2;
+    case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_F32: case DBHIP_T_DATE: return 4;
+    case DBHIP_T_I64: case DBHIP_T_U64: case DBHIP_T_F64: case DBHIP_T_TIMESTAMP:
+    case DBHIP_T_DEC64: return 8;
+    case DBHIP_T_DEC128: case DBHIP_T_STRING: return 16;
+    default: return 0;
+  }
+}
+
+}  // namespace dbhip
+
+#define DBHIP_CHECK(expr)                                   \
+  do {                                                      \
+    hipError_t _e = (expr);                                 \
+    if (_e != hipSuccess) return dbhip::hip_fail(_e, #expr); \
+  } while (0)
+
+#define DBHIP_REQUIRE(cond, msg)      \
+  do {                                \
+    if (!(cond)) {                    \
+      dbhip::set_error("%s", msg);    \
+      return DBHIP_ERR_INVALID;       \
+    }                                 \
+  } while (0)
+
+#define DBHIP_LAUNCH_CHECK() DBHIP_CHECK(hipGetLastError())

@@ -1,0 +1,185 @@
+// runtime.hip — device binding, memory, streams, events, error reporting.
+// There is deliberately no CPU fallback anywhere in this library: without a
+// visible gfx950 device dbhip_init fails and every other entry point fails too.
+#include "runtime.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+namespace dbhip {
+
+static thread_local char g_err[512] = "";
+static hipStream_t g_stream = nullptr;
+static int g_device = -1;
+static std::mutex g_mu;
+
+struct Scratch {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+static thread_local Scratch g_scratch[8];
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int32_t hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return DBHIP_ERR_HIP;
+}
+
+hipStream_t resolve_stream(void* stream) {
+  if (stream) return (hipStream_t)stream;
+  return g_stream;
+}
+
+void* scratch(size_t bytes, int slot) {
+  Scratch& s = g_scratch[slot];
+  if (s.cap < bytes) {
+    if (s.p) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(s.p);
+    }
+    size_t cap = bytes + (bytes >> 2) + 4096;
+    if (hipMalloc(&s.p, cap) != hipSuccess) {
+      s.p = nullptr;
+      s.cap = 0;
+      set_error("scratch allocation of %zu bytes failed", cap);
+      return nullptr;
+    }
+    s.cap = cap;
+  }
+  return s.p;
+}
+
+}  // namespace dbhip
+
+using namespace dbhip;
+
+extern "C" {
+
+int32_t dbhip_abi_version(void) { return DBHIP_ABI_VERSION; }
+
+const char* dbhip_last_error(void) { return g_err; }
+
+int32_t dbhip_device_count(int32_t* out_count_host) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  if (out_count_host) *out_count_host = n;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_init(int32_t device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device visible (hipGetDeviceCount -> %d, n=%d): libdbhip has no CPU fallback",
+              (int)e, n);
+    return DBHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range (0..%d)", device, n - 1);
+    return DBHIP_ERR_INVALID;
+  }
+  DBHIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  DBHIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return DBHIP_ERR_NO_DEVICE;
+  }
+  if (g_device != device || !g_stream) {
+    if (g_stream) (void)hipStreamDestroy(g_stream);
+    DBHIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+  }
+  return DBHIP_OK;
+}
+
+int32_t dbhip_alloc(size_t bytes, void** out) {
+  DBHIP_REQUIRE(out, "dbhip_alloc: out is NULL");
+  if (bytes == 0) bytes = 16;
+  DBHIP_CHECK(hipMalloc(out, bytes));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_free(void* p) {
+  if (!p) return DBHIP_OK;
+  DBHIP_CHECK(hipFree(p));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  DBHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  DBHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_memset(void* dst, int32_t byte, size_t bytes, void* stream) {
+  if (bytes == 0) return DBHIP_OK;
+  DBHIP_CHECK(hipMemsetAsync(dst, byte, bytes, resolve_stream(stream)));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_stream_create(void** out) {
+  DBHIP_REQUIRE(out, "dbhip_stream_create: out is NULL");
+  hipStream_t s;
+  DBHIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = (void*)s;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_stream_destroy(void* stream) {
+  if (!stream) return DBHIP_OK;
+  DBHIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_stream_sync(void* stream) {
+  DBHIP_CHECK(hipStreamSynchronize(resolve_stream(stream)));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_event_create(void** out) {
+  DBHIP_REQUIRE(out, "dbhip_event_create: out is NULL");
+  hipEvent_t e;
+  DBHIP_CHECK(hipEventCreate(&e));
+  *out = (void*)e;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_event_record(void* event, void* stream) {
+  DBHIP_CHECK(hipEventRecord((hipEvent_t)event, resolve_stream(stream)));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_event_elapsed_ms(void* start, void* stop, float* out_ms) {
+  DBHIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+  DBHIP_CHECK(hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_event_destroy(void* event) {
+  if (!event) return DBHIP_OK;
+  DBHIP_CHECK(hipEventDestroy((hipEvent_t)event));
+  return DBHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+/*
+ * dbhip.h — C-ABI of libdbhip.so: MI355X (gfx950) kernels for the Databend
+ * column-batch execution hot path.
+ *
+ * Boundary rules (mirrors the only Rust→C precedent in the reference,
+ * src/query/storages/common/index/src/hnsw_index/quantization/encoded_vectors_u8.rs:415-428:
+ * plain pointers + lengths, scalar status return, no ownership transfer, callable
+ * from any thread):
+ *   - every entry point returns int32 status (DBHIP_OK == 0); the message of the
+ *     last failure on the calling thread is available from dbhip_last_error();
+ *   - no Rust/C++ type, exception or panic crosses the ABI;
+ *   - all `const void* / void*` buffer arguments are DEVICE pointers (HBM) unless
+ *     the parameter name ends in `_host`; Arrow-layout host buffers
+ *     (Buffer<T>::as_ptr(), Bitmap::as_slice()) are moved with
+ *     dbhip_memcpy_h2d/d2h — columns are meant to stay resident in HBM between
+ *     operators;
+ *   - buffers are borrowed for the duration of the call; outputs are written into
+ *     caller-provided device buffers (allocated with dbhip_alloc or by any other
+ *     allocator of the same HIP context, e.g. a torch tensor's data_ptr());
+ *   - `stream` is a hipStream_t passed as void* (NULL = the library's own
+ *     per-device stream). Calls are asynchronous on that stream unless they
+ *     return a host value, in which case they synchronise the stream.
+ *
+ * Each group of functions cites the reference interface it replaces
+ * (paths relative to the Databend source tree).
+ */
+#ifndef DBHIP_H
+#define DBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DBHIP_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  DBHIP_OK = 0,
+  DBHIP_ERR_INVALID = 1,      /* bad argument / unsupported type combination     */
+  DBHIP_ERR_HIP = 2,          /* a HIP runtime call failed                       */
+  DBHIP_ERR_NO_DEVICE = 3,    /* no gfx950 device visible                        */
+  DBHIP_ERR_ROW_ERRORS = 4,   /* per-row errors were raised (see err bitmap)     */
+  DBHIP_ERR_OVERFLOW = 5,     /* aggregate decimal overflow (aggregate_sum.rs:203-216) */
+  DBHIP_ERR_CAPACITY = 6,     /* fixed-capacity fast path overflowed; retry general path */
+  DBHIP_ERR_UNSUPPORTED = 7   /* caller must keep the CPU closure for this case  */
+};
+
+/* ---- physical types (src/query/expression/src/types.rs:234 DataType,
+ *      src/common/column/src/{buffer,bitmap,binview}) ------------------------ */
+typedef enum {
+  DBHIP_T_BOOL = 1,      /* Bitmap, LSB-first, 1 bit per row                     */
+  DBHIP_T_I8 = 2, DBHIP_T_I16 = 3, DBHIP_T_I32 = 4, DBHIP_T_I64 = 5,
+  DBHIP_T_U8 = 6, DBHIP_T_U16 = 7, DBHIP_T_U32 = 8, DBHIP_T_U64 = 9,
+  DBHIP_T_F32 = 10, DBHIP_T_F64 = 11,
+  DBHIP_T_DATE = 12,     /* i32 days (DateType)                                  */
+  DBHIP_T_TIMESTAMP = 13,/* i64 micros                                           */
+  DBHIP_T_DEC64 = 14,    /* DecimalColumn::Decimal64  (i64)                      */
+  DBHIP_T_DEC128 = 15,   /* DecimalColumn::Decimal128 (i128, little endian)      */
+  DBHIP_T_STRING = 16    /* BinaryViewColumn: 16-byte View{len,prefix,buf,off}   */
+} dbhip_type;
+
+/* binary operators (numeric_basic_arithmetic.rs:255-544, decimal/arithmetic.rs:44-49) */
+typedef enum {
+  DBHIP_OP_PLUS = 0, DBHIP_OP_MINUS = 1, DBHIP_OP_MULTIPLY = 2,
+  DBHIP_OP_DIVIDE = 3,   /* '/' : always f64, "divided by zero" row error        */
+  DBHIP_OP_INTDIV = 4,   /* 'div'                                                */
+  DBHIP_OP_MODULO = 5
+} dbhip_arith_op;
+
+/* comparison operators (src/query/functions/src/scalars/comparison.rs:98-112) */
+typedef enum {
+  DBHIP_CMP_EQ = 0, DBHIP_CMP_NOTEQ = 1, DBHIP_CMP_LT = 2,
+  DBHIP_CMP_LTE = 3, DBHIP_CMP_GT = 4, DBHIP_CMP_GTE = 5
+} dbhip_cmp_op;
+
+/* A column argument. `data` points at n values (or at ONE value when is_scalar
+ * is set — Value::Scalar, src/query/expression/src/values.rs:122). For
+ * DBHIP_T_STRING `data` points at 16-byte views and `buffers` at a device array
+ * of device pointers to the data buffers (binview/view.rs:30-42).
+ * `validity` (may be NULL) is an LSB-first bitmap read from bit `validity_offset`
+ * (bitmap/immutable.rs:78-85). */
+typedef struct {
+  int32_t type;                 /* dbhip_type                                     */
+  int32_t is_scalar;            /* 1: `data` holds a single value                 */
+  const void* data;
+  const uint8_t* validity;
+  int64_t validity_offset;
+  const void* const* buffers;   /* STRING only                                    */
+  int32_t n_buffers;
+  uint8_t precision;            /* DEC64/DEC128 only (DecimalSize)                */
+  uint8_t scale;
+  uint8_t _pad[2];
+} dbhip_col;
+
+/* ---- runtime ------------------------------------------------------------- */
+int32_t dbhip_abi_version(void);
+/* Binds the calling process to `device` and creates the library stream.
+ * Fails with DBHIP_ERR_NO_DEVICE when no GPU is visible: there is no CPU fallback. */
+int32_t dbhip_init(int32_t device);
+int32_t dbhip_device_count(int32_t* out_count_host);
+const char* dbhip_last_error(void);
+int32_t dbhip_alloc(size_t bytes, void** out_dev_ptr_host);
+int32_t dbhip_free(void* dev_ptr);
+int32_t dbhip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int32_t dbhip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int32_t dbhip_memset(void* dst_dev, int32_t byte, size_t bytes, void* stream);
+int32_t dbhip_stream_create(void** out_stream_host);
+int32_t dbhip_stream_destroy(void* stream);
+int32_t dbhip_stream_sync(void* stream);
+/* HIP-event timing on `stream` (bench.py's roofline figure): */
+int32_t dbhip_event_create(void** out_event_host);
+int32_t dbhip_event_record(void* event, void* stream);
+int32_t dbhip_event_elapsed_ms(void* start, void* stop, float* out_ms_host);
+int32_t dbhip_event_destroy(void* event);
+
+/* ---- a2/a3: numeric arithmetic -------------------------------------------
+ * Replaces the closures registered by register_plus/minus/multiply/divide/div/modulo
+ * (numeric_basic_arithmetic.rs:255-544) that vectorize_2_arg drives
+ * (src/query/expression/src/function/register_vectorize.rs:110-216).
+ * lhs/rhs types must be numeric; out_type must be the ResultTypeOfBinary entry
+ * (utils/arithmetics_type.rs) — checked. Integer arithmetic wraps
+ * (Cargo.toml:577 overflow-checks=false). For DIVIDE/INTDIV/MODULO a zero divisor
+ * raises the row error "divided by zero": bit `i` of `err_bitmap` (LSB-first,
+ * 1 = row ok; may be NULL) is cleared and `*err_count_dev` incremented
+ * (EvalContext::set_error, src/query/expression/src/function.rs:534-556);
+ * rows whose validity bit is 0 never raise. Payload is computed for all rows
+ * (passthrough_nullable, register_vectorize.rs:447-471). */
+int32_t dbhip_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs,
+                    int64_t n, int32_t out_type, void* out,
+                    uint8_t* err_bitmap, uint64_t* err_count_dev, void* stream);
+/* Result type table: returns dbhip_type or -1 (arithmetics_type.rs / codegen
+ * src/query/codegen/src/writes/arithmetics_type.rs:222-250). */
+int32_t dbhip_arith_result_type(int32_t op, int32_t lhs_type, int32_t rhs_type);
+
+/* Fused config-1 twin: out[0] = wrapping sum over rows of a[i] + b[i]*c[i] (Int64).
+ * Replaces plus∘multiply (3.1 of SURVEY) followed by NumberSumState::add_batch
+ * (aggregate_sum.rs:71-129) without materialising intermediates. `out_sum_dev`
+ * must be zeroed by the caller (it is accumulated into). */
+int32_t dbhip_sum_a_plus_b_mul_c_i64(const int64_t* a, const int64_t* b, const int64_t* c,
+                                     int64_t n, int64_t* out_sum_dev, void* stream);
+/* sum(column) for any numeric type into the ResultTypeOfUnary::Sum type
+ * (i64/u64 wrapping, f64 pairwise — see DESIGN.md for the float caveat). */
+int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stream);
+
+/* ---- a4: decimal arithmetic ------------------------------------------------
+ * Replaces binary_decimal (decimal/src/arithmetic.rs:190-316) after the operands
+ * were brought to (left_size, right_size) by ArithmeticOp::result_size (:80-139).
+ * `lhs`/`rhs` are DEC64/DEC128 columns (or integer columns, converted like
+ * other_to_decimal) carrying their own precision/scale; the result storage class
+ * and DecimalSize come from dbhip_decimal_result_size. Row errors as dbhip_arith
+ * ("Decimal overflow", "Decimal multiply overflow", "divided by zero",
+ * "Decimal div overflow"). */
+int32_t dbhip_decimal_result_size(int32_t op, uint8_t lp, uint8_t ls, uint8_t rp, uint8_t rs,
+                                  uint8_t* out_precision_host, uint8_t* out_scale_host);
+int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs,
+                            int64_t n, int32_t out_type, uint8_t out_precision,
+                            uint8_t out_scale, void* out,
+                            uint8_t* err_bitmap, uint64_t* err_count_dev, void* stream);
+
+/* ---- a5: comparisons -> Bitmap --------------------------------------------
+ * Replaces vectorize_cmp_2_arg + Bitmap::collect_bool
+ * (register_comparison.rs:52-96, bitmap/immutable.rs:474). Both sides must have
+ * the same physical type (the planner inserts casts); floats compare as
+ * OrderedFloat (NaN largest, types/number.rs:47-48). `out_bitmap` holds
+ * ceil(n/8) bytes, LSB-first, trailing bits zero. */
+int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n,
+                  uint8_t* out_bitmap, void* stream);
+/* Bitmap AND / OR / NOT for and_filters / validity merging (evaluator.rs:284-305). */
+int32_t dbhip_bitmap_binary(int32_t is_or, const uint8_t* a, const uint8_t* b, int64_t n,
+                            uint8_t* out, void* stream);
+int32_t dbhip_bitmap_count(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
+                           uint64_t* out_count_dev, void* stream);
+
+/* ---- a6: filter -> selection vector, take ---------------------------------
+ * Replaces FilterExecutor::filter/select (filter/filter_executor.rs:81-118) for a
+ * boolean predicate column: ascending u32 row ids of set bits (Selector output
+ * order), count written to *out_count_dev. Scratch is managed internally. */
+int32_t dbhip_filter_select(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
+                            uint32_t* out_sel, uint64_t* out_count_dev, void* stream);
+/* DataBlock::take (kernels/take.rs:43): out[i] = src[sel[i]], elem_size in
+ * {1,2,4,8,16} (16 covers i128 and string views). */
+int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int64_t n_sel,
+                   void* out, void* stream);
+/* take for Bitmap columns (bool / validity). */
+int32_t dbhip_take_bitmap(const uint8_t* src, int64_t bit_offset, const uint32_t* sel,
+                          int64_t n_sel, uint8_t* out, void* stream);
+
+/* ---- a7: group hash ---------------------------------------------------------
+ * Replaces group_hash_entries (aggregate/group_hash.rs:40-61): per-row u64 over
+ * `ncols` key columns, combined as h = h*NULL_HASH_VAL ^ h_col (:509-511), NULL ->
+ * 0xd1cefa08eb382d69 (:38,180-207), ints via the 2-round multiply-xorshift
+ * (:555-570), bytes/i128 via the Murmur64A variant (:522-553), floats by bits
+ * with canonical NaN (:599-620), bool 0/1 (:581-585). */
+int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n,
+                         uint64_t* out_hashes, void* stream);
+
+/* ---- a8-a13: hash aggregation ---------------------------------------------
+ * Replaces AggregateHashTable behind TransformPartialAggregate /
+ * TransformFinalAggregate (aggregate_hashtable.rs:168-408,
+ * transform_aggregate_partial.rs:179-303, transform_aggregate_final.rs:510+).
+ * The table lives in HBM; aggregate states are fixed-width words next to the
+ * group's key row (the device analogue of Payload rows, payload.rs:47-72).
+ * Output of flush == the serialized-state block of Payload::aggregate_flush
+ * (payload_flush.rs:151-181): one column per state + the group key columns +
+ * the group hash column. Group order is unspecified (reference tests compare as
+ * sorted sets: tests/it/aggregates/agg_hashtable.rs assert_block_value_sort_eq). */
+typedef enum {
+  DBHIP_AGG_COUNT = 0,       /* count(*) / count(col): u64 (aggregate_count.rs:47-150) */
+  DBHIP_AGG_SUM = 1,         /* sum: i64/u64 wrapping, f64, DEC64->i64 wrapping,
+                                DEC128 -> i128 with overflow check when arg precision>18
+                                (aggregate_sum.rs:51-300,386-441)                    */
+  DBHIP_AGG_MIN = 2, DBHIP_AGG_MAX = 3
+} dbhip_agg_kind;
+
+typedef struct {
+  int32_t kind;       /* dbhip_agg_kind                                            */
+  int32_t arg_type;   /* dbhip_type of the argument (ignored for count(*))         */
+  uint8_t arg_precision, arg_scale; /* decimals                                    */
+  uint8_t arg_nullable;             /* count(col)/sum(col) skip NULL rows          */
+  uint8_t _pad;
+} dbhip_agg_desc;
+
+typedef struct dbhip_groupby dbhip_groupby;  /* opaque */
+
+/* key_types: fixed-width types and DBHIP_T_STRING (strings up to 12 bytes are
+ * kept inline; longer strings make add_block return DBHIP_ERR_UNSUPPORTED). */
+int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_nullable_host,
+                             int32_t nkeys, const dbhip_agg_desc* aggs_host, int32_t naggs,
+                             int64_t initial_capacity, dbhip_groupby** out_host);
+/* AggregateHashTable::add_groups: `args[i]` is the argument column of aggs[i]
+ * (ignored for count(*)). Grows (rehashes) like resize() (:463-490) when the load
+ * factor 1/1.35 (mod.rs:55) would be exceeded. */
+int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
+                                int64_t n, void* stream);
+/* combine_payload (:349-380): merge serialized partial states (as produced by
+ * dbhip_groupby_flush_serialized on any rank) into this table. */
+int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows,
+                                       void* stream);
+int32_t dbhip_groupby_num_groups(dbhip_groupby* g, int64_t* out_host, void* stream);
+/* Bytes per serialized row: [keys (fixed width, strings as 16-B inline views)]
+ * [validity byte per nullable key][hash u64][state words]. */
+int32_t dbhip_groupby_row_bytes(dbhip_groupby* g, int64_t* out_host);
+int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int64_t max_rows,
+                                       int64_t* out_n_rows_host, void* stream);
+/* merge_result (:382-408): final values as columns. out_keys[i]/out_aggs[i] are
+ * device buffers of max_rows elements of the key / result type
+ * (dbhip_groupby_result_type). Returns DBHIP_ERR_OVERFLOW if a checked decimal
+ * sum left [DECIMAL_MIN, DECIMAL_MAX]. */
+int32_t dbhip_groupby_result_type(const dbhip_agg_desc* agg_host, int32_t* out_type_host,
+                                  uint8_t* out_precision_host, uint8_t* out_scale_host);
+int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
+                                   uint8_t* const* out_key_validity_host,
+                                   void* const* out_aggs_host, uint64_t* out_hashes,
+                                   int64_t max_rows, int64_t* out_n_rows_host, void* stream);
+int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream);
+int32_t dbhip_groupby_destroy(dbhip_groupby* g);
+
+/* ---- fused TPC-H Q1 pipeline (BASELINE.json configs[1]) --------
+ * One pass over lineitem: TransformFilter (l_shipdate <= cutoff,
+ * filters/filter_predicate.rs:71-96) -> CompoundBlockOperator decimal maps
+ * (1-l_discount, *, 1+l_tax; decimal/arithmetic.rs:155-316) -> TransformPartialAggregate
+ * with group keys (l_returnflag, l_linestatus) and states
+ * [sum(qty) i64, sum(price) i64, sum(disc_price) i128, sum(charge) i128,
+ *  sum(discount) i64, count(*) u64]. Partial states are merged INTO the given
+ * group-by table (which must have been created with exactly that key/agg layout:
+ * see dbhip_q1_create_groupby), so the same flush/merge/exchange entry points
+ * serve the fused and the operator-at-a-time paths. Reads 68 B/row. */
+int32_t dbhip_q1_create_groupby(dbhip_groupby** out_host);
+int32_t dbhip_q1_fused(dbhip_groupby* g,
+                       const int64_t* l_quantity, const int64_t* l_extendedprice,
+                       const int64_t* l_discount, const int64_t* l_tax,
+                       const void* l_returnflag_views, const void* l_linestatus_views,
+                       const int32_t* l_shipdate, int32_t shipdate_cutoff,
+                       int64_t n, void* stream);
+
+/* ---- a14/a15: hash join -----------------------------------------------------
+ * Replaces HashJoinHashTable<u64> build/probe behind trait Join
+ * (hash_join_table/hashjoin_hashtable.rs:26-344,
+ * new_hash_join/hashtable/fixed_keys.rs:47-269, memory/inner_join.rs:122-271) for
+ * KeysU64 (method_fixed_keys.rs:58-139). Inner join; emits (probe_idx, build_row)
+ * pairs. Pair order is unspecified in the reference across threads; this library
+ * returns them sorted by (probe_idx, build_row). */
+typedef struct dbhip_join dbhip_join;
+int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host);
+int32_t dbhip_join_add_build(dbhip_join* j, const uint64_t* keys, const uint8_t* validity,
+                             int64_t n, void* stream);
+int32_t dbhip_join_finalize(dbhip_join* j, void* stream);
+int32_t dbhip_join_probe_count(dbhip_join* j, const uint64_t* keys, const uint8_t* validity,
+                               int64_t n, uint64_t* out_total_host, void* stream);
+int32_t dbhip_join_probe(dbhip_join* j, const uint64_t* keys, const uint8_t* validity, int64_t n,
+                         uint32_t* out_probe_idx, uint32_t* out_build_row, int64_t max_pairs,
+                         uint64_t* out_n_pairs_host, void* stream);
+int32_t dbhip_join_destroy(dbhip_join* j);
+
+/* ---- a16: sort / top-k --------------------------------------------------------
+ * Replaces DataBlock::sort_with_type / SortCompare
+ * (kernels/sort.rs:91-113, kernels/sort_compare.rs:33-283): permutation of row ids
+ * ordered by up to 4 fixed-width key columns with per-key asc/desc and
+ * nulls_first; `limit` (0 = none) keeps the first `limit` rows (LimitType::LimitRows).
+ * The reference uses sort_unstable_by, so only the key sequence is part of the
+ * contract; this implementation is stable (ties by ascending row id). */
+int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host,
+                        const uint8_t* nulls_first_host, int32_t nkeys, int64_t n,
+                        int64_t limit, uint32_t* out_perm, void* stream);
+
+/* ---- a17/a18: vector distance ------------------------------------------------
+ * Replaces cosine_distance / l2_distance / inner_product / l1_distance
+ * (src/common/vector/src/distance.rs:19-165) driven by
+ * functions/src/scalars/vector.rs:497-560, batched over queries:
+ * out[q*n + i] = metric(base[i], query[q]) for flat row-major f32
+ * (VectorColumn::Float32, types/vector.rs:377-380). The dot products run on
+ * v_mfma_f32_32x32x2_f32 (exact f32). */
+typedef enum { DBHIP_VEC_COSINE = 0, DBHIP_VEC_L2 = 1, DBHIP_VEC_DOT = 2, DBHIP_VEC_L1 = 3 } dbhip_vec_metric;
+int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t dim,
+                           const float* queries, int32_t nq, float* out, void* stream);
+/* ORDER BY distance LIMIT k (sort_compare.rs:197-209): per query the k smallest
+ * distances, ties by lower row id; never materialises the n*nq matrix. */
+int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim,
+                       const float* queries, int32_t nq, int32_t k,
+                       uint32_t* out_idx, float* out_dist, void* stream);
+/* u8-quantised scoring (cpp/avx2.c:45,87 impl_score_dot_avx / impl_score_l1_avx). */
+int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base, int64_t n,
+                       int32_t dim, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBHIP_H */

@@ -1,0 +1,1157 @@
+/*
+ * oracle.c — CPU restatement of the reference algorithms (TEST INFRASTRUCTURE,
+ * see oracle.h). Plain scalar C, one row at a time, written to mirror the
+ * reference's structure rather than to be fast. gcc -O2.
+ */
+#define _GNU_SOURCE
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------ */
+/* typed scalar values with Rust `as` cast semantics                          */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int cls; /* 0 signed, 1 unsigned, 2 float */
+  int bits;
+  int64_t i;
+  uint64_t u;
+  double f; /* f32 values are kept exactly in a double */
+} val;
+
+static int t_cls(int t) {
+  switch (t) {
+    case ORC_T_I8: case ORC_T_I16: case ORC_T_I32: case ORC_T_I64: case ORC_T_DATE: case ORC_T_TIMESTAMP:
+    case ORC_T_DEC64: return 0;
+    case ORC_T_U8: case ORC_T_U16: case ORC_T_U32: case ORC_T_U64: return 1;
+    case ORC_T_F32: case ORC_T_F64: return 2;
+  }
+  return -1;
+}
+static int t_bits(int t) {
+  switch (t) {
+    case ORC_T_I8: case ORC_T_U8: return 8;
+    case ORC_T_I16: case ORC_T_U16: return 16;
+    case ORC_T_I32: case ORC_T_U32: case ORC_T_F32: case ORC_T_DATE: return 32;
+    default: return 64;
+  }
+}
+static int t_size(int t) {
+  if (t == ORC_T_DEC128 || t == ORC_T_STRING) return 16;
+  return t_bits(t) / 8;
+}
+static int bit_get(const uint8_t* bm, int64_t i) { return (bm[i >> 3] >> (i & 7)) & 1; }
+static int col_valid(const orc_col* c, int64_t i) {
+  return !c->validity || bit_get(c->validity, c->validity_offset + (c->is_scalar ? 0 : i));
+}
+
+static val load_val(const orc_col* c, int64_t i) {
+  int64_t j = c->is_scalar ? 0 : i;
+  val v; memset(&v, 0, sizeof v);
+  v.cls = t_cls(c->type); v.bits = t_bits(c->type);
+  switch (c->type) {
+    case ORC_T_I8: v.i = ((const int8_t*)c->data)[j]; break;
+    case ORC_T_I16: v.i = ((const int16_t*)c->data)[j]; break;
+    case ORC_T_I32: case ORC_T_DATE: v.i = ((const int32_t*)c->data)[j]; break;
+    case ORC_T_I64: case ORC_T_TIMESTAMP: case ORC_T_DEC64: v.i = ((const int64_t*)c->data)[j]; break;
+    case ORC_T_U8: v.u = ((const uint8_t*)c->data)[j]; break;
+    case ORC_T_U16: v.u = ((const uint16_t*)c->data)[j]; break;
+    case ORC_T_U32: v.u = ((const uint32_t*)c->data)[j]; break;
+    case ORC_T_U64: v.u = ((const uint64_t*)c->data)[j]; break;
+    case ORC_T_F32: v.f = ((const float*)c->data)[j]; break;
+    case ORC_T_F64: v.f = ((const double*)c->data)[j]; break;
+  }
+  return v;
+}
+
+/* Rust float -> int `as`: truncate, saturate, NaN -> 0 */
+static int64_t f_to_i(double x, int bits) {
+  if (x != x) return 0;
+  double lo = -ldexp(1.0, bits - 1), hi = ldexp(1.0, bits - 1);
+  if (x <= lo) return bits == 64 ? INT64_MIN : -((int64_t)1 << (bits - 1));
+  if (x >= hi) return bits == 64 ? INT64_MAX : (((int64_t)1 << (bits - 1)) - 1);
+  return (int64_t)x;
+}
+static uint64_t f_to_u(double x, int bits) {
+  if (x != x || x <= 0.0) return 0;
+  if (x >= ldexp(1.0, bits)) return bits == 64 ? UINT64_MAX : (((uint64_t)1 << bits) - 1);
+  return (uint64_t)x;
+}
+static int64_t wrap_i(uint64_t w, int bits) {
+  switch (bits) {
+    case 8: return (int8_t)w;
+    case 16: return (int16_t)w;
+    case 32: return (int32_t)w;
+    default: return (int64_t)w;
+  }
+}
+static uint64_t wrap_u(uint64_t w, int bits) { return bits == 64 ? w : (w & (((uint64_t)1 << bits) - 1)); }
+
+/* `v as T` */
+static val cast_val(val v, int to_type) {
+  val r; memset(&r, 0, sizeof r);
+  r.cls = t_cls(to_type); r.bits = t_bits(to_type);
+  if (r.cls == 2) {
+    double d = v.cls == 2 ? v.f : (v.cls == 0 ? (double)v.i : (double)v.u);
+    if (r.bits == 32) d = (double)(float)(v.cls == 2 ? v.f : (v.cls == 0 ? (float)v.i : (float)v.u));
+    r.f = d;
+  } else if (r.cls == 0) {
+    r.i = v.cls == 2 ? f_to_i(v.f, r.bits) : wrap_i(v.cls == 0 ? (uint64_t)v.i : v.u, r.bits);
+  } else {
+    r.u = v.cls == 2 ? f_to_u(v.f, r.bits) : wrap_u(v.cls == 0 ? (uint64_t)v.i : v.u, r.bits);
+  }
+  return r;
+}
+
+static void store_val(void* out, int type, int64_t i, val v) {
+  switch (type) {
+    case ORC_T_I8: ((int8_t*)out)[i] = (int8_t)v.i; break;
+    case ORC_T_I16: ((int16_t*)out)[i] = (int16_t)v.i; break;
+    case ORC_T_I32: case ORC_T_DATE: ((int32_t*)out)[i] = (int32_t)v.i; break;
+    case ORC_T_I64: case ORC_T_TIMESTAMP: case ORC_T_DEC64: ((int64_t*)out)[i] = v.i; break;
+    case ORC_T_U8: ((uint8_t*)out)[i] = (uint8_t)v.u; break;
+    case ORC_T_U16: ((uint16_t*)out)[i] = (uint16_t)v.u; break;
+    case ORC_T_U32: ((uint32_t*)out)[i] = (uint32_t)v.u; break;
+    case ORC_T_U64: ((uint64_t*)out)[i] = v.u; break;
+    case ORC_T_F32: ((float*)out)[i] = (float)v.f; break;
+    case ORC_T_F64: ((double*)out)[i] = v.f; break;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* numeric arithmetic: numeric_basic_arithmetic.rs:255-544, arithmetic_modulo.rs */
+/* result types: src/query/codegen/src/writes/arithmetics_type.rs:222-250      */
+/* ------------------------------------------------------------------------ */
+static int next_bits(int w) { return w < 64 ? w * 2 : 64; }
+static int mk_num(int bits, int is_signed, int is_float) {
+  if (is_float) return bits == 32 ? ORC_T_F32 : (bits == 64 ? ORC_T_F64 : -1);
+  switch (bits) {
+    case 8: return is_signed ? ORC_T_I8 : ORC_T_U8;
+    case 16: return is_signed ? ORC_T_I16 : ORC_T_U16;
+    case 32: return is_signed ? ORC_T_I32 : ORC_T_U32;
+    case 64: return is_signed ? ORC_T_I64 : ORC_T_U64;
+  }
+  return -1;
+}
+static int is_number(int t) { return t >= ORC_T_I8 && t <= ORC_T_F64; }
+static int coerce(int op, int a, int b) {
+  if (!is_number(a) || !is_number(b)) return -1;
+  int as = t_cls(a) != 1, bs = t_cls(b) != 1, af = t_cls(a) == 2, bf = t_cls(b) == 2;
+  int sg = as || bs, fl = af || bf;
+  int bw = t_bits(a) > t_bits(b) ? t_bits(a) : t_bits(b);
+  switch (op) {
+    case ORC_OP_PLUS: case ORC_OP_MULTIPLY: return mk_num(next_bits(bw), sg, fl);
+    case ORC_OP_MINUS: return mk_num(next_bits(bw), 1, fl);
+    case ORC_OP_DIVIDE: return ORC_T_F64;
+    case ORC_OP_INTDIV: return mk_num(bw, sg, 0);
+    case ORC_OP_MODULO:
+      if (fl) return ORC_T_F64;
+      return mk_num(as ? next_bits(t_bits(b)) : t_bits(b), as, 0);
+    case 100: return mk_num(bw, sg, fl); /* LeastSuper */
+  }
+  return -1;
+}
+int orc_arith_result_type(int op, int l, int r) { return coerce(op, l, r); }
+
+static void raise_err(const orc_col* a, const orc_col* b, int64_t i, uint8_t* err, uint64_t* cnt) {
+  /* EvalContext::set_error ignores NULL rows (function.rs:534-556) */
+  if (!col_valid(a, i) || !col_valid(b, i)) return;
+  if (err) err[i >> 3] &= (uint8_t)~(1u << (i & 7));
+  if (cnt) (*cnt)++;
+}
+
+int orc_arith(int op, const orc_col* lhs, const orc_col* rhs, int64_t n, int out_type, void* out,
+              uint8_t* err, uint64_t* err_count) {
+  if (coerce(op, lhs->type, rhs->type) != out_type) return 1;
+  if (err) memset(err, 0xFF, (size_t)((n + 31) / 32) * 4);
+  int mtype = coerce(100, lhs->type, rhs->type);
+  for (int64_t i = 0; i < n; ++i) {
+    val a = load_val(lhs, i), b = load_val(rhs, i), r;
+    memset(&r, 0, sizeof r);
+    r.cls = t_cls(out_type); r.bits = t_bits(out_type);
+    switch (op) {
+      case ORC_OP_PLUS: case ORC_OP_MINUS: case ORC_OP_MULTIPLY: {
+        val x = cast_val(a, out_type), y = cast_val(b, out_type);
+        if (r.cls == 2) r.f = op == ORC_OP_PLUS ? x.f + y.f : (op == ORC_OP_MINUS ? x.f - y.f : x.f * y.f);
+        else {
+          uint64_t xu = r.cls == 0 ? (uint64_t)x.i : x.u, yu = r.cls == 0 ? (uint64_t)y.i : y.u;
+          uint64_t z = op == ORC_OP_PLUS ? xu + yu : (op == ORC_OP_MINUS ? xu - yu : xu * yu);
+          if (r.cls == 0) r.i = wrap_i(z, r.bits); else r.u = wrap_u(z, r.bits);
+        }
+      } break;
+      case ORC_OP_DIVIDE: { /* divide_function :410-427 */
+        double y = cast_val(b, ORC_T_F64).f;
+        if (y == 0.0) { raise_err(lhs, rhs, i, err, err_count); r.f = 0.0; }
+        else r.f = cast_val(a, ORC_T_F64).f / y;
+      } break;
+      case ORC_OP_INTDIV: { /* register_intdiv :459-490 */
+        double y = cast_val(b, ORC_T_F64).f;
+        if (y == 0.0) raise_err(lhs, rhs, i, err, err_count);
+        else {
+          val q; memset(&q, 0, sizeof q); q.cls = 2; q.bits = 64; q.f = cast_val(a, ORC_T_F64).f / y;
+          r = cast_val(q, out_type);
+        }
+      } break;
+      default: { /* push_modulo_result arithmetic_modulo.rs:70-95 */
+        int zero = b.cls == 2 ? (b.f == 0.0) : (b.cls == 0 ? b.i == 0 : b.u == 0);
+        if (zero) { raise_err(lhs, rhs, i, err, err_count); break; }
+        val x = cast_val(a, mtype), y = cast_val(b, mtype), m;
+        memset(&m, 0, sizeof m); m.cls = x.cls; m.bits = x.bits;
+        if (x.cls == 2) m.f = x.bits == 32 ? (double)fmodf((float)x.f, (float)y.f) : fmod(x.f, y.f);
+        else if (x.cls == 0) {
+          int64_t mn = x.bits == 64 ? INT64_MIN : -((int64_t)1 << (x.bits - 1));
+          m.i = (x.i == mn && y.i == -1) ? 0 : x.i % y.i;
+        } else m.u = x.u % y.u;
+        r = cast_val(m, out_type);
+      } break;
+    }
+    store_val(out, out_type, i, r);
+  }
+  return 0;
+}
+
+/* config 1 in the reference's shape: per block of block_rows rows, materialise b*c, then a+(b*c), then
+ * NumberSumState::add_batch (aggregate_sum.rs:71-129); all i64 wrapping (Cargo.toml:577). */
+int64_t orc_sum_a_plus_b_mul_c_i64(const int64_t* a, const int64_t* b, const int64_t* c, int64_t n,
+                                   int64_t block_rows) {
+  uint64_t state = 0;
+  int64_t* t1 = (int64_t*)malloc(sizeof(int64_t) * (size_t)block_rows);
+  int64_t* t2 = (int64_t*)malloc(sizeof(int64_t) * (size_t)block_rows);
+  for (int64_t s = 0; s < n; s += block_rows) {
+    int64_t m = n - s < block_rows ? n - s : block_rows;
+    for (int64_t i = 0; i < m; ++i) t1[i] = (int64_t)((uint64_t)b[s + i] * (uint64_t)c[s + i]);
+    for (int64_t i = 0; i < m; ++i) t2[i] = (int64_t)((uint64_t)a[s + i] + (uint64_t)t1[i]);
+    uint64_t sum = 0;
+    for (int64_t i = 0; i < m; ++i) sum += (uint64_t)t2[i];
+    state += sum;
+  }
+  free(t1); free(t2);
+  return (int64_t)state;
+}
+
+/* ------------------------------------------------------------------------ */
+/* decimal: decimal/src/arithmetic.rs:80-316, types/decimal.rs:759-797,1024-1060 */
+/* ------------------------------------------------------------------------ */
+static i128 e10(int k) { i128 r = 1; while (k-- > 0) r *= 10; return r; }
+
+/* minimal signed 256-bit integer: 4 little-endian u64 limbs, two's complement */
+typedef struct { uint64_t w[4]; } i256;
+static i256 i256_from_i128(i128 v) {
+  i256 r; r.w[0] = (uint64_t)v; r.w[1] = (uint64_t)((u128)v >> 64);
+  r.w[2] = r.w[3] = v < 0 ? ~(uint64_t)0 : 0; return r;
+}
+static int i256_neg_p(i256 a) { return (a.w[3] >> 63) & 1; }
+static i256 i256_add(i256 a, i256 b) {
+  i256 r; u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a.w[i] + b.w[i]; r.w[i] = (uint64_t)c; c >>= 64; }
+  return r;
+}
+static i256 i256_negate(i256 a) {
+  i256 one = {{1, 0, 0, 0}};
+  for (int i = 0; i < 4; ++i) a.w[i] = ~a.w[i];
+  return i256_add(a, one);
+}
+static i256 i256_sub(i256 a, i256 b) { return i256_add(a, i256_negate(b)); }
+static i256 i256_mul(i256 a, i256 b) { /* wrapping */
+  i256 r = {{0, 0, 0, 0}};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; i + j < 4; ++j) {
+      c += (u128)a.w[i] * b.w[j] + r.w[i + j];
+      r.w[i + j] = (uint64_t)c; c >>= 64;
+    }
+  }
+  return r;
+}
+static int u256_ge(const uint64_t* a, const uint64_t* b) {
+  for (int i = 3; i >= 0; --i) { if (a[i] != b[i]) return a[i] > b[i]; }
+  return 1;
+}
+/* truncating signed division */
+static i256 i256_div(i256 a, i256 b) {
+  int na = i256_neg_p(a), nb = i256_neg_p(b);
+  if (na) a = i256_negate(a);
+  if (nb) b = i256_negate(b);
+  i256 q = {{0, 0, 0, 0}}, r = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; --bit) {
+    /* r = (r << 1) | bit(a) */
+    for (int i = 3; i > 0; --i) r.w[i] = (r.w[i] << 1) | (r.w[i - 1] >> 63);
+    r.w[0] = (r.w[0] << 1) | ((a.w[bit >> 6] >> (bit & 63)) & 1);
+    if (u256_ge(r.w, b.w)) { r = i256_sub(r, b); q.w[bit >> 6] |= (uint64_t)1 << (bit & 63); }
+  }
+  return (na != nb) ? i256_negate(q) : q;
+}
+static int i256_fits_i128(i256 a) {
+  uint64_t ext = (a.w[1] >> 63) ? ~(uint64_t)0 : 0;
+  return a.w[2] == ext && a.w[3] == ext;
+}
+static i128 i256_low128(i256 a) { return (i128)(((u128)a.w[1] << 64) | a.w[0]); }
+
+typedef struct { int p, s; } dsize;
+static int dec_props(int type, int p, int s, dsize* o) {
+  switch (type) {
+    case ORC_T_DEC64: case ORC_T_DEC128: o->p = p; o->s = s; return 1;
+    case ORC_T_I8: case ORC_T_U8: o->p = 3; o->s = 0; return 1; /* number.rs:452-465 */
+    case ORC_T_I16: case ORC_T_U16: o->p = 5; o->s = 0; return 1;
+    case ORC_T_I32: case ORC_T_U32: o->p = 10; o->s = 0; return 1;
+    case ORC_T_I64: o->p = 19; o->s = 0; return 1;
+    case ORC_T_U64: o->p = 20; o->s = 0; return 1;
+  }
+  return 0;
+}
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+/* ArithmeticOp::result_size arithmetic.rs:80-139 */
+static int result_size(int op, dsize a, dsize b, dsize* l, dsize* r, dsize* ret) {
+  int precision, scale, la = a.p - a.s, lb = b.p - b.s;
+  switch (op) {
+    case ORC_OP_MULTIPLY: scale = imin(a.s + b.s, imax(imax(a.s, b.s), 12)); precision = la + lb + scale; break;
+    case ORC_OP_DIVIDE: scale = imax(a.s, imin(a.s + 6, 12)); precision = la + b.s + scale; break;
+    case ORC_OP_PLUS: case ORC_OP_MINUS: scale = imax(a.s, b.s); precision = imax(la, lb) + scale + 1; break;
+    default: return 0;
+  }
+  precision = imin(precision, 38);
+  if (precision < 1 || scale > precision) return 0;
+  ret->p = precision; ret->s = scale;
+  if (op == ORC_OP_MULTIPLY) { l->p = precision; l->s = a.s; r->p = precision; r->s = b.s; }
+  else if (op == ORC_OP_DIVIDE) { int pp = imax(precision, imax(a.p, b.p)); l->p = pp; l->s = a.s; r->p = pp; r->s = b.s; }
+  else { *l = *ret; *r = *ret; }
+  return 1;
+}
+int orc_decimal_result_size(int op, int lp, int ls, int rp, int rs, int* out_p, int* out_s) {
+  dsize a = {lp, ls}, b = {rp, rs}, l, r, ret;
+  if (!result_size(op, a, b, &l, &r, &ret)) return 1;
+  *out_p = ret.p; *out_s = ret.s; return 0;
+}
+
+static i128 load_dec(const orc_col* c, int64_t i) {
+  int64_t j = c->is_scalar ? 0 : i;
+  if (c->type == ORC_T_DEC128) return ((const i128*)c->data)[j];
+  val v = load_val(c, i);
+  return v.cls == 0 ? (i128)v.i : (i128)v.u;
+}
+static int checked_mul_t(i128 x, i128 f, int t128, i128* out) {
+  if (!t128) { i128 r = x * f; if (r > INT64_MAX || r < INT64_MIN) return 0; *out = r; return 1; }
+  i128 r;
+  if (__builtin_mul_overflow(x, f, &r)) return 0;
+  *out = r; return 1;
+}
+static i128 wrap_t(i128 v, int t128) { return t128 ? v : (i128)(int64_t)v; }
+/* convert_to_decimal arithmetic.rs:141-153 -> integer_to_decimal cast.rs:701-753 / decimal_expand_cast :901-979 */
+static int convert_operand(i128 x, int is_dec, int from_s, dsize to, int t128, i128* out) {
+  i128 mx = e10(to.p) - 1;
+  if (!is_dec) {
+    if (to.s == 0) { *out = wrap_t(x, t128); return 1; }
+    if (!t128 && (x > INT64_MAX || x < INT64_MIN)) return 0;
+    i128 r; if (!checked_mul_t(x, e10(to.s), t128, &r)) return 0;
+    if (r > mx || r < -mx) return 0;
+    *out = r; return 1;
+  }
+  if (from_s == to.s) { *out = wrap_t(x, t128); return 1; }
+  i128 r; if (!checked_mul_t(wrap_t(x, t128), e10(to.s - from_s), t128, &r)) return 0;
+  if (r > mx || r < -mx) return 0;
+  *out = r; return 1;
+}
+
+int orc_decimal_arith(int op, const orc_col* lhs, const orc_col* rhs, int64_t n, int out_type, int out_p,
+                      int out_s, void* out, uint8_t* err, uint64_t* err_count) {
+  dsize a, b, l, r, ret;
+  if (!dec_props(lhs->type, lhs->precision, lhs->scale, &a) || !dec_props(rhs->type, rhs->precision, rhs->scale, &b)) return 1;
+  if (!result_size(op, a, b, &l, &r, &ret)) return 1;
+  int t128 = ret.p > 18;
+  if (ret.p != out_p || ret.s != out_s || out_type != (t128 ? ORC_T_DEC128 : ORC_T_DEC64)) return 1;
+  int a_dec = lhs->type == ORC_T_DEC64 || lhs->type == ORC_T_DEC128;
+  int b_dec = rhs->type == ORC_T_DEC64 || rhs->type == ORC_T_DEC128;
+  int overflow = ret.p == (t128 ? 38 : 18); /* binary_decimal :203 */
+  if (err) memset(err, 0xFF, (size_t)((n + 31) / 32) * 4);
+  for (int64_t i = 0; i < n; ++i) {
+    i128 x, y, res = 1;
+    int ok = convert_operand(load_dec(lhs, i), a_dec, a.s, l, t128, &x);
+    ok = convert_operand(load_dec(rhs, i), b_dec, b.s, r, t128, &y) && ok;
+    if (ok) switch (op) {
+      case ORC_OP_PLUS: case ORC_OP_MINUS: {
+        i128 t = wrap_t(op == ORC_OP_PLUS ? (i128)((u128)x + (u128)y) : (i128)((u128)x - (u128)y), t128);
+        if (overflow) { i128 mx = e10(ret.p) - 1; if (t < -mx || t > mx) ok = 0; }
+        res = t;
+      } break;
+      case ORC_OP_MULTIPLY: {
+        int sm = a.s + b.s - ret.s;
+        if (sm == 0) res = wrap_t((i128)((u128)x * (u128)y), t128);
+        else if (!t128) { /* i64 do_round_mul decimal.rs:759-786 */
+          if (!overflow) {
+            int64_t d = (int64_t)e10(sm);
+            int64_t pr = (int64_t)((uint64_t)(int64_t)x * (uint64_t)(int64_t)y);
+            int64_t num = ((x < 0) == (y < 0)) ? (int64_t)((uint64_t)pr + (uint64_t)(d / 2))
+                                               : (int64_t)((uint64_t)pr - (uint64_t)(d / 2));
+            res = num / d;
+          } else {
+            i128 d = e10(sm);
+            i128 q = (((x < 0) == (y < 0)) ? x * y + d / 2 : x * y - d / 2) / d;
+            i128 mx = e10(18) - 1;
+            if (q < -mx || q > mx) ok = 0;
+            res = q;
+          }
+        } else { /* i128 do_round_mul decimal.rs:1024-1054 */
+          i128 d = e10(sm);
+          if (!overflow) {
+            i128 pr = (i128)((u128)x * (u128)y);
+            i128 num = ((x < 0) == (y < 0)) ? (i128)((u128)pr + (u128)(d / 2)) : (i128)((u128)pr - (u128)(d / 2));
+            res = num / d;
+          } else {
+            i256 D = i256_from_i128(d), half = i256_from_i128(d / 2);
+            i256 pr = i256_mul(i256_from_i128(x), i256_from_i128(y));
+            i256 q = i256_div(((x < 0) == (y < 0)) ? i256_add(pr, half) : i256_sub(pr, half), D);
+            if (!i256_fits_i128(q)) ok = 0;
+            res = i256_low128(q);
+          }
+        }
+      } break;
+      default: { /* divide :212-243 */
+        int sm = b.s + ret.s - a.s;
+        if (y == 0) ok = 0;
+        else if (!t128) { /* i64 do_round_div decimal.rs:788-797 */
+          i128 am = (i128)((u128)x * (u128)e10(sm));
+          i128 num = ((x < 0) == (y < 0)) ? (i128)((u128)am + (u128)(y / 2)) : (i128)((u128)am - (u128)(y / 2));
+          res = (i128)(int64_t)(num / y);
+        } else { /* i128 do_round_div decimal.rs:1056-1064 */
+          i256 Y = i256_from_i128(y), half = i256_from_i128(y / 2);
+          i256 am = i256_mul(i256_from_i128(x), i256_from_i128(e10(sm)));
+          i256 q = i256_div(((x < 0) == (y < 0)) ? i256_add(am, half) : i256_sub(am, half), Y);
+          res = i256_low128(q);
+        }
+      } break;
+    }
+    if (!ok) { raise_err(lhs, rhs, i, err, err_count); res = 1; }
+    if (t128) ((i128*)out)[i] = res; else ((int64_t*)out)[i] = (int64_t)res;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* comparisons -> Bitmap (register_comparison.rs:52-96, bitmap/immutable.rs:474) */
+/* ------------------------------------------------------------------------ */
+static const uint8_t* view_bytes(const uint32_t* v, const void* const* buffers, uint32_t* len) {
+  *len = v[0];
+  if (*len <= 12) return (const uint8_t*)(v + 1);
+  return (const uint8_t*)buffers[v[2]] + v[3];
+}
+static int cmp3_col(const orc_col* a, const orc_col* b, int64_t i) {
+  int64_t ja = a->is_scalar ? 0 : i, jb = b->is_scalar ? 0 : i;
+  switch (a->type) {
+    case ORC_T_DEC128: { i128 x = ((const i128*)a->data)[ja], y = ((const i128*)b->data)[jb]; return (x > y) - (x < y); }
+    case ORC_T_BOOL: { int x = bit_get((const uint8_t*)a->data, ja), y = bit_get((const uint8_t*)b->data, jb); return x - y; }
+    case ORC_T_STRING: {
+      uint32_t la, lb;
+      const uint8_t* pa = view_bytes((const uint32_t*)a->data + 4 * ja, a->buffers, &la);
+      const uint8_t* pb = view_bytes((const uint32_t*)b->data + 4 * jb, b->buffers, &lb);
+      int c = memcmp(pa, pb, la < lb ? la : lb);
+      if (c) return c < 0 ? -1 : 1;
+      return (la > lb) - (la < lb);
+    }
+  }
+  val x = load_val(a, i), y = load_val(b, i);
+  if (x.cls == 0) return (x.i > y.i) - (x.i < y.i);
+  if (x.cls == 1) return (x.u > y.u) - (x.u < y.u);
+  int xn = x.f != x.f, yn = y.f != y.f; /* OrderedFloat: NaN == NaN, NaN largest */
+  if (xn || yn) return xn - yn;
+  return (x.f > y.f) - (x.f < y.f);
+}
+int orc_cmp(int op, const orc_col* lhs, const orc_col* rhs, int64_t n, uint8_t* out) {
+  if (lhs->type != rhs->type) return 1;
+  memset(out, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) {
+    int c = cmp3_col(lhs, rhs, i), r;
+    switch (op) {
+      case ORC_CMP_EQ: r = c == 0; break;
+      case ORC_CMP_NOTEQ: r = c != 0; break;
+      case ORC_CMP_LT: r = c < 0; break;
+      case ORC_CMP_LTE: r = c <= 0; break;
+      case ORC_CMP_GT: r = c > 0; break;
+      default: r = c >= 0; break;
+    }
+    if (r) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+  }
+  return 0;
+}
+int64_t orc_filter_select(const uint8_t* bm, int64_t off, int64_t n, uint32_t* out_sel) {
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; ++i) if (bit_get(bm, off + i)) out_sel[k++] = (uint32_t)i;
+  return k;
+}
+void orc_take(const void* src, int es, const uint32_t* sel, int64_t n, void* out) {
+  for (int64_t i = 0; i < n; ++i) memcpy((uint8_t*)out + i * es, (const uint8_t*)src + (size_t)sel[i] * es, (size_t)es);
+}
+
+/* ------------------------------------------------------------------------ */
+/* group hash: aggregate/group_hash.rs:38,180-207,267-281,509-632              */
+/* ------------------------------------------------------------------------ */
+#define NULL_HASH_VAL 0xd1cefa08eb382d69ULL
+uint64_t orc_agg_hash_bytes(const uint8_t* p, uint64_t len) { /* :522-553 */
+  const uint64_t M = 0xc6a4a7935bd1e995ULL, SEED = 0xe17a1465ULL; const int R = 47;
+  uint64_t h = SEED ^ (len * M);
+  uint64_t nblocks = len / 8;
+  for (uint64_t i = 0; i < nblocks; ++i) {
+    uint64_t k; memcpy(&k, p + i * 8, 8);
+    k *= M; k ^= k >> R; k *= M;
+    h ^= k; h *= M;
+  }
+  const uint8_t* d = p + nblocks * 8; uint64_t dl = len - nblocks * 8;
+  for (uint64_t i = 0; i < dl; ++i) h ^= (uint64_t)d[i] << (8 * (dl - i - 1));
+  h ^= h >> R; h *= M; h ^= h >> R;
+  return h;
+}
+uint64_t orc_agg_hash_u64(uint64_t x) { /* :555-570 */
+  x ^= x >> 32; x *= 0xd6e8feb86659fd93ULL; x ^= x >> 32; x *= 0xd6e8feb86659fd93ULL; x ^= x >> 32;
+  return x;
+}
+static uint64_t hash_col_row(const orc_col* c, int64_t i) {
+  if (!col_valid(c, i)) return NULL_HASH_VAL;
+  int64_t j = c->is_scalar ? 0 : i;
+  switch (c->type) {
+    case ORC_T_BOOL: return (uint64_t)bit_get((const uint8_t*)c->data, j); /* :581-585 */
+    case ORC_T_F32: { /* :599-609 */
+      float f = ((const float*)c->data)[j]; uint32_t b; memcpy(&b, &f, 4);
+      if (f != f) b = 0x7fc00000u; /* f32::NAN.to_bits() */
+      return orc_agg_hash_u64(b);
+    }
+    case ORC_T_F64: { /* :611-620 */
+      double f = ((const double*)c->data)[j]; uint64_t b; memcpy(&b, &f, 8);
+      if (f != f) b = 0x7ff8000000000000ULL;
+      return orc_agg_hash_u64(b);
+    }
+    case ORC_T_DEC128: return orc_agg_hash_bytes((const uint8_t*)c->data + 16 * j, 16); /* :587-591 */
+    case ORC_T_STRING: { uint32_t len; const uint8_t* p = view_bytes((const uint32_t*)c->data + 4 * j, c->buffers, &len);
+                         return orc_agg_hash_bytes(p, len); }
+  }
+  val v = load_val(c, i);
+  return orc_agg_hash_u64(v.cls == 0 ? (uint64_t)v.i : v.u); /* `*self as u64` */
+}
+int orc_group_hash(const orc_col* cols, int ncols, int64_t n, uint64_t* out) { /* group_hash_entries :40-61 */
+  for (int k = 0; k < ncols; ++k)
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t h = hash_col_row(&cols[k], i);
+      out[i] = k == 0 ? h : (out[i] * NULL_HASH_VAL ^ h);
+    }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* AggregateHashTable restatement                                             */
+/*   HashIndex          hash_index/index.rs:26-236, group.rs:25-52, bitmask.rs */
+/*   Payload rows       payload.rs:192-248,361-486 ; payload_row.rs:51-215,324+ */
+/*   add_groups         aggregate_hashtable.rs:168-333                          */
+/*   states             aggregate_sum.rs, aggregate_count.rs, aggregate_unary.rs */
+/* ------------------------------------------------------------------------ */
+#define BATCH_SIZE 2048
+#define GROUP_WIDTH 8
+#define TAG_EMPTY 0xFF
+#define LOAD_FACTOR 1.35
+#define MAXK 16
+#define MAXA 24
+
+struct orc_hashagg {
+  int nkeys, naggs;
+  int key_type[MAXK], key_nullable[MAXK], key_off[MAXK], key_size[MAXK], validity_off[MAXK];
+  orc_agg_desc aggs[MAXA];
+  int state_off[MAXA], state_size;
+  int hash_off, state_ptr_off, tuple_size;
+  /* hash index */
+  uint8_t* ctrls; uint8_t** pointers; size_t capacity, mask, count;
+  int resize_count;
+  /* payload: one growing array of rows + one of states (arena) */
+  uint8_t* rows; size_t nrows, rows_cap;
+  uint8_t* states; size_t states_len, states_cap;
+  /* string arena */
+  uint8_t* strs; size_t strs_len, strs_cap;
+};
+
+static int rowformat_size(int t) { /* payload_row.rs:51-83 */
+  switch (t) {
+    case ORC_T_BOOL: return 1;
+    case ORC_T_STRING: return 12; /* u32 len + address */
+    case ORC_T_DEC128: return 16;
+    default: return t_size(t);
+  }
+}
+static int agg_state_size(const orc_agg_desc* d) {
+  if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return 16;
+  if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return 16; /* value + has flag */
+  return 8;
+}
+
+static void index_alloc(orc_hashagg* h, size_t cap) {
+  h->capacity = cap; h->mask = cap - 1; h->count = 0;
+  h->ctrls = (uint8_t*)malloc(cap + GROUP_WIDTH);
+  memset(h->ctrls, TAG_EMPTY, cap + GROUP_WIDTH);
+  h->pointers = (uint8_t**)calloc(cap, sizeof(uint8_t*));
+}
+
+orc_hashagg* orc_hashagg_create(const int32_t* key_types, const uint8_t* key_nullable, int nkeys,
+                                const orc_agg_desc* aggs, int naggs) {
+  if (nkeys < 1 || nkeys > MAXK || naggs > MAXA) return NULL;
+  orc_hashagg* h = (orc_hashagg*)calloc(1, sizeof(*h));
+  h->nkeys = nkeys; h->naggs = naggs;
+  int ts = 0;
+  for (int k = 0; k < nkeys; ++k) { /* Payload::new payload.rs:192-248 */
+    h->key_type[k] = key_types[k]; h->key_nullable[k] = key_nullable ? key_nullable[k] : 0;
+    if (h->key_nullable[k]) { h->validity_off[k] = ts; ts += 1; }
+  }
+  for (int k = 0; k < nkeys; ++k) { h->key_off[k] = ts; h->key_size[k] = rowformat_size(key_types[k]); ts += h->key_size[k]; }
+  h->hash_off = ts; ts += 8;
+  h->state_ptr_off = ts; if (naggs) ts += 8;
+  h->tuple_size = ts;
+  int so = 0;
+  for (int a = 0; a < naggs; ++a) {
+    h->aggs[a] = aggs[a];
+    int sz = agg_state_size(&aggs[a]);
+    so = (so + sz - 1) / sz * sz; /* natural alignment */
+    h->state_off[a] = so; so += sz;
+  }
+  h->state_size = (so + 15) / 16 * 16;
+  index_alloc(h, 32768); /* aggregate_hashtable.rs:492-494 */
+  return h;
+}
+
+static void set_ctrl(orc_hashagg* h, size_t index, uint8_t tag) { /* index.rs:65-72 */
+  size_t index2 = ((index - GROUP_WIDTH) & h->mask) + GROUP_WIDTH;
+  h->ctrls[index] = tag; h->ctrls[index2] = tag;
+}
+static uint8_t tag_full(uint64_t hash) { return (uint8_t)((hash >> 57) & 0x7f); } /* bitmask.rs:90-93 */
+
+/* find_or_insert index.rs:92-110: scan 8-byte groups for the tag, else first empty */
+static size_t find_or_insert(orc_hashagg* h, size_t pos, uint64_t hash, int* is_new) {
+  uint8_t tag = tag_full(hash);
+  for (;;) {
+    const uint8_t* g = h->ctrls + pos;
+    for (int b = 0; b < GROUP_WIDTH; ++b)
+      if (g[b] == tag) { *is_new = 0; return (pos + b) & h->mask; }
+    for (int b = 0; b < GROUP_WIDTH; ++b)
+      if (g[b] & 0x80) { size_t idx = (pos + b) & h->mask; set_ctrl(h, idx, tag); *is_new = 1; return idx; }
+    pos = (pos + GROUP_WIDTH) & h->mask;
+  }
+}
+static size_t probe_empty(orc_hashagg* h, uint64_t hash) { /* index.rs:134-146 */
+  size_t pos = hash & h->mask;
+  for (;;) { if (h->ctrls[pos] == TAG_EMPTY) { set_ctrl(h, pos, tag_full(hash)); return pos; } pos = (pos + 1) & h->mask; }
+}
+
+static void key_field(const orc_hashagg* h, const orc_col* c, int k, int64_t i, uint8_t* dst, orc_hashagg* arena) {
+  int64_t j = c->is_scalar ? 0 : i;
+  switch (h->key_type[k]) {
+    case ORC_T_BOOL: dst[0] = (uint8_t)bit_get((const uint8_t*)c->data, j); break;
+    case ORC_T_STRING: {
+      uint32_t len; const uint8_t* p = view_bytes((const uint32_t*)c->data + 4 * j, c->buffers, &len);
+      memcpy(dst, &len, 4);
+      if (arena) { /* copy var-len data into the arena, store its offset (stands in for the address) */
+        if (arena->strs_len + len > arena->strs_cap) {
+          arena->strs_cap = (arena->strs_len + len) * 2 + 64; arena->strs = (uint8_t*)realloc(arena->strs, arena->strs_cap);
+        }
+        memcpy(arena->strs + arena->strs_len, p, len);
+        uint64_t off = arena->strs_len; memcpy(dst + 4, &off, 8); arena->strs_len += len;
+      }
+    } break;
+    default: memcpy(dst, (const uint8_t*)c->data + (size_t)j * h->key_size[k], (size_t)h->key_size[k]); break;
+  }
+}
+/* row_match_entries payload_row.rs:324+: compare stored row with the probing row */
+static int row_match(const orc_hashagg* h, const uint8_t* row, const orc_col* keys, int64_t i) {
+  for (int k = 0; k < h->nkeys; ++k) {
+    int valid = col_valid(&keys[k], i);
+    if (h->key_nullable[k]) { if (row[h->validity_off[k]] != (uint8_t)valid) return 0; if (!valid) continue; }
+    const uint8_t* f = row + h->key_off[k];
+    if (h->key_type[k] == ORC_T_STRING) {
+      int64_t j = keys[k].is_scalar ? 0 : i;
+      uint32_t len, slen; const uint8_t* p = view_bytes((const uint32_t*)keys[k].data + 4 * j, keys[k].buffers, &len);
+      memcpy(&slen, f, 4); if (slen != len) return 0;
+      uint64_t off; memcpy(&off, f + 4, 8);
+      if (memcmp(h->strs + off, p, len)) return 0;
+    } else {
+      uint8_t tmp[16]; key_field(h, &keys[k], k, i, tmp, NULL);
+      if (memcmp(tmp, f, (size_t)h->key_size[k])) return 0;
+    }
+  }
+  return 1;
+}
+static uint8_t* append_row(orc_hashagg* h, const orc_col* keys, int64_t i, uint64_t hash) { /* payload.rs:361-486 */
+  if (h->nrows == h->rows_cap) { h->rows_cap = h->rows_cap ? h->rows_cap * 2 : 1024; h->rows = (uint8_t*)realloc(h->rows, h->rows_cap * h->tuple_size); }
+  if (h->states_len + h->state_size > h->states_cap) { h->states_cap = h->states_cap ? h->states_cap * 2 : (size_t)h->state_size * 1024; h->states = (uint8_t*)realloc(h->states, h->states_cap); }
+  uint8_t* row = h->rows + h->nrows * h->tuple_size;
+  memset(row, 0, (size_t)h->tuple_size);
+  for (int k = 0; k < h->nkeys; ++k) {
+    int valid = col_valid(&keys[k], i);
+    if (h->key_nullable[k]) row[h->validity_off[k]] = (uint8_t)valid;
+    if (valid) key_field(h, &keys[k], k, i, row + h->key_off[k], h);
+  }
+  memcpy(row + h->hash_off, &hash, 8);
+  uint64_t soff = h->states_len; /* StateAddr as offset into the arena */
+  if (h->naggs) {
+    memcpy(row + h->state_ptr_off, &soff, 8);
+    uint8_t* st = h->states + soff; memset(st, 0, (size_t)h->state_size); /* init_state */
+    h->states_len += h->state_size;
+  }
+  h->nrows++;
+  return (uint8_t*)(uintptr_t)(h->nrows); /* row index + 1 (rows may move on realloc) */
+}
+
+static void resize_index(orc_hashagg* h, size_t new_cap) { /* aggregate_hashtable.rs:463-490 */
+  free(h->ctrls); free(h->pointers);
+  index_alloc(h, new_cap);
+  for (size_t r = 0; r < h->nrows; ++r) {
+    uint64_t hash; memcpy(&hash, h->rows + r * h->tuple_size + h->hash_off, 8);
+    size_t idx = probe_empty(h, hash);
+    h->pointers[idx] = (uint8_t*)(uintptr_t)(r + 1);
+  }
+  h->count = h->nrows;
+}
+
+/* accumulate one row into one state (accumulate_keys: aggregate_unary.rs:208-222) */
+static int state_add(const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int64_t i) {
+  int valid = !arg || !arg->data || col_valid(arg, i);
+  switch (d->kind) {
+    case ORC_AGG_COUNT: if (valid) { uint64_t c; memcpy(&c, st, 8); c++; memcpy(st, &c, 8); } return 0;
+    case ORC_AGG_SUM:
+      if (!valid) return 0;
+      if (d->arg_type == ORC_T_DEC128) { /* DecimalSumState::add aggregate_sum.rs:203-216 */
+        i128 s; memcpy(&s, st, 16);
+        s = (i128)((u128)s + (u128)((const i128*)arg->data)[arg->is_scalar ? 0 : i]);
+        int check = d->arg_precision > 18;
+        i128 mx = e10(38) - 1;
+        memcpy(st, &s, 16);
+        if (check && (s > mx || s < -mx)) return 5;
+        return 0;
+      } else {
+        val v = load_val(arg, i);
+        if (v.cls == 2) { double s; memcpy(&s, st, 8); s += v.f; memcpy(st, &s, 8); }
+        else { uint64_t s; memcpy(&s, st, 8); s += v.cls == 0 ? (uint64_t)v.i : v.u; memcpy(st, &s, 8); }
+        return 0;
+      }
+    default: { /* MIN / MAX over OrderedFloat / ints */
+      if (!valid) return 0;
+      uint64_t has; memcpy(&has, st + 8, 8);
+      val v = load_val(arg, i);
+      val cur; memset(&cur, 0, sizeof cur); cur.cls = v.cls; cur.bits = v.bits;
+      if (v.cls == 2) memcpy(&cur.f, st, 8); else if (v.cls == 0) memcpy(&cur.i, st, 8); else memcpy(&cur.u, st, 8);
+      int c;
+      if (v.cls == 0) c = (v.i > cur.i) - (v.i < cur.i);
+      else if (v.cls == 1) c = (v.u > cur.u) - (v.u < cur.u);
+      else { int xn = v.f != v.f, yn = cur.f != cur.f; c = (xn || yn) ? xn - yn : (v.f > cur.f) - (v.f < cur.f); }
+      int take = !has || (d->kind == ORC_AGG_MIN ? c < 0 : c > 0);
+      if (take) { if (v.cls == 2) memcpy(st, &v.f, 8); else if (v.cls == 0) memcpy(st, &v.i, 8); else memcpy(st, &v.u, 8); }
+      has = 1; memcpy(st + 8, &has, 8);
+      return 0;
+    }
+  }
+}
+
+static int add_groups_inner(orc_hashagg* h, const orc_col* keys, const orc_col* args, int64_t start, int64_t rc) {
+  static __thread uint64_t hashes[BATCH_SIZE];
+  static __thread size_t slots[BATCH_SIZE], addr[BATCH_SIZE];
+  static __thread int no_match[BATCH_SIZE], empty_v[BATCH_SIZE], cmp_v[BATCH_SIZE];
+  /* group_hash_entries */
+  for (int k = 0; k < h->nkeys; ++k)
+    for (int64_t r = 0; r < rc; ++r) {
+      uint64_t hv = hash_col_row(&keys[k], start + r);
+      hashes[r] = k == 0 ? hv : (hashes[r] * NULL_HASH_VAL ^ hv);
+    }
+  /* probe_and_create aggregate_hashtable.rs:294-312 */
+  if ((size_t)rc + h->count > (size_t)((double)h->capacity / LOAD_FACTOR)) {
+    size_t nc = h->resize_count < 4 ? h->capacity * 4 : h->capacity * 2; /* :314-333 */
+    h->resize_count++;
+    resize_index(h, nc);
+  }
+  /* HashIndex::probe_and_create index.rs:148-216 */
+  for (int64_t r = 0; r < rc; ++r) { no_match[r] = (int)r; slots[r] = hashes[r] & h->mask; }
+  int64_t remaining = rc;
+  while (remaining > 0) {
+    int n_new = 0, n_cmp = 0, n_nomatch = 0;
+    for (int64_t t = 0; t < remaining; ++t) {
+      int row = no_match[t], is_new;
+      slots[row] = find_or_insert(h, slots[row], hashes[row], &is_new);
+      if (is_new) empty_v[n_new++] = row; else cmp_v[n_cmp++] = row;
+    }
+    for (int t = 0; t < n_new; ++t) { /* adapter.append_rows */
+      int row = empty_v[t];
+      addr[row] = (size_t)(uintptr_t)append_row(h, keys, start + row, hashes[row]);
+      h->pointers[slots[row]] = (uint8_t*)(uintptr_t)addr[row];
+    }
+    for (int t = 0; t < n_cmp; ++t) { /* adapter.compare */
+      int row = cmp_v[t];
+      addr[row] = (size_t)(uintptr_t)h->pointers[slots[row]];
+      const uint8_t* stored = h->rows + (addr[row] - 1) * h->tuple_size;
+      if (!row_match(h, stored, keys, start + row)) no_match[n_nomatch++] = row;
+    }
+    for (int t = 0; t < n_nomatch; ++t) slots[no_match[t]] = (slots[no_match[t]] + 1) & h->mask;
+    h->count += (size_t)n_new;
+    remaining = n_nomatch;
+  }
+  /* accumulate_keys per aggregate */
+  int rcode = 0;
+  for (int a = 0; a < h->naggs; ++a)
+    for (int64_t r = 0; r < rc; ++r) {
+      uint64_t soff; memcpy(&soff, h->rows + (addr[r] - 1) * h->tuple_size + h->state_ptr_off, 8);
+      int e = state_add(&h->aggs[a], h->states + soff + h->state_off[a], args ? &args[a] : NULL, start + r);
+      if (e) rcode = e;
+    }
+  return rcode;
+}
+
+int orc_hashagg_add_block(orc_hashagg* h, const orc_col* keys, const orc_col* args, int64_t n) { /* add_groups :168-207 */
+  int rc = 0;
+  for (int64_t s = 0; s < n; s += BATCH_SIZE) {
+    int64_t m = n - s < BATCH_SIZE ? n - s : BATCH_SIZE;
+    int e = add_groups_inner(h, keys, args, s, m);
+    if (e) rc = e;
+  }
+  return rc;
+}
+int64_t orc_hashagg_num_groups(orc_hashagg* h) { return (int64_t)h->nrows; }
+
+/* materialise the groups of `h` as columns (payload_flush.rs:50-240) */
+typedef struct { void* keys[MAXK]; uint8_t* valid[MAXK]; void* bufs[MAXK]; } flushed;
+
+int orc_hashagg_result(orc_hashagg* h, void* const* out_keys, uint8_t* const* out_key_valid,
+                       void* const* out_aggs, uint64_t* out_hashes) {
+  int rc = 0;
+  for (size_t r = 0; r < h->nrows; ++r) {
+    const uint8_t* row = h->rows + r * h->tuple_size;
+    for (int k = 0; k < h->nkeys; ++k) {
+      int valid = h->key_nullable[k] ? row[h->validity_off[k]] : 1;
+      if (out_key_valid && out_key_valid[k]) out_key_valid[k][r] = (uint8_t)valid;
+      if (!out_keys || !out_keys[k]) continue;
+      const uint8_t* f = row + h->key_off[k];
+      if (h->key_type[k] == ORC_T_STRING) {
+        uint8_t* v = (uint8_t*)out_keys[k] + 16 * r; memset(v, 0, 16);
+        uint32_t len; memcpy(&len, f, 4); uint64_t off; memcpy(&off, f + 4, 8);
+        memcpy(v, &len, 4);
+        if (valid && len <= 12) memcpy(v + 4, h->strs + off, len);
+      } else {
+        memcpy((uint8_t*)out_keys[k] + r * h->key_size[k], f, (size_t)h->key_size[k]);
+      }
+    }
+    if (out_hashes) memcpy(&out_hashes[r], row + h->hash_off, 8);
+    if (!h->naggs) continue;
+    uint64_t soff; memcpy(&soff, row + h->state_ptr_off, 8);
+    for (int a = 0; a < h->naggs; ++a) {
+      if (!out_aggs || !out_aggs[a]) continue;
+      const uint8_t* st = h->states + soff + h->state_off[a];
+      const orc_agg_desc* d = &h->aggs[a];
+      if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16);
+      else if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) {
+        int sz = t_size(d->arg_type);
+        val v; memset(&v, 0, sizeof v); v.cls = t_cls(d->arg_type);
+        if (v.cls == 2) memcpy(&v.f, st, 8); else if (v.cls == 0) memcpy(&v.i, st, 8); else memcpy(&v.u, st, 8);
+        store_val(out_aggs[a], d->arg_type, (int64_t)r, v); (void)sz;
+      } else memcpy((uint8_t*)out_aggs[a] + 8 * r, st, 8);
+    }
+  }
+  return rc;
+}
+
+/* combine_payload aggregate_hashtable.rs:349-380: re-probe the other table's groups and merge states */
+int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
+  int rc = 0;
+  size_t n = src->nrows;
+  if (!n) return 0;
+  /* flush src rows to key columns */
+  orc_col keys[MAXK]; memset(keys, 0, sizeof keys);
+  void* kb[MAXK]; uint8_t* kv[MAXK]; uint8_t* kbits[MAXK];
+  for (int k = 0; k < src->nkeys; ++k) {
+    int es = src->key_type[k] == ORC_T_STRING ? 16 : src->key_size[k];
+    kb[k] = calloc(n + 8, (size_t)es); kv[k] = (uint8_t*)calloc(n + 8, 1); kbits[k] = (uint8_t*)calloc((n + 7) / 8 + 8, 1);
+  }
+  orc_hashagg_result(src, kb, kv, NULL, NULL);
+  for (int k = 0; k < src->nkeys; ++k) {
+    keys[k].type = src->key_type[k]; keys[k].data = kb[k];
+    if (src->key_type[k] == ORC_T_BOOL) { /* bytes -> bitmap */
+      uint8_t* bm = (uint8_t*)calloc((n + 7) / 8 + 8, 1);
+      for (size_t r = 0; r < n; ++r) if (((uint8_t*)kb[k])[r]) bm[r >> 3] |= (uint8_t)(1u << (r & 7));
+      free(kb[k]); kb[k] = bm; keys[k].data = bm;
+    }
+    if (src->key_nullable[k]) {
+      for (size_t r = 0; r < n; ++r) if (kv[k][r]) kbits[k][r >> 3] |= (uint8_t)(1u << (r & 7));
+      keys[k].validity = kbits[k];
+    }
+  }
+  /* insert groups without accumulating, then merge states (batch_merge_states) */
+  int saved = dst->naggs;
+  for (size_t s = 0; s < n; s += BATCH_SIZE) {
+    size_t m = n - s < BATCH_SIZE ? n - s : BATCH_SIZE;
+    /* probe with naggs temporarily 0 would skip state allocation, so probe normally with no-op args */
+    static __thread size_t addrs[BATCH_SIZE];
+    /* replicate add_groups_inner's probe, capturing addresses */
+    dst->naggs = saved;
+    {
+      static __thread uint64_t hashes[BATCH_SIZE];
+      static __thread size_t slots[BATCH_SIZE];
+      static __thread int no_match[BATCH_SIZE], empty_v[BATCH_SIZE], cmp_v[BATCH_SIZE];
+      for (size_t r = 0; r < m; ++r) memcpy(&hashes[r], src->rows + (s + r) * src->tuple_size + src->hash_off, 8);
+      if (m + dst->count > (size_t)((double)dst->capacity / LOAD_FACTOR)) {
+        size_t nc = dst->resize_count < 4 ? dst->capacity * 4 : dst->capacity * 2; dst->resize_count++; resize_index(dst, nc);
+      }
+      for (size_t r = 0; r < m; ++r) { no_match[r] = (int)r; slots[r] = hashes[r] & dst->mask; }
+      size_t remaining = m;
+      while (remaining > 0) {
+        int n_new = 0, n_cmp = 0, n_nomatch = 0;
+        for (size_t t = 0; t < remaining; ++t) {
+          int row = no_match[t], is_new;
+          slots[row] = find_or_insert(dst, slots[row], hashes[row], &is_new);
+          if (is_new) empty_v[n_new++] = row; else cmp_v[n_cmp++] = row;
+        }
+        for (int t = 0; t < n_new; ++t) {
+          int row = empty_v[t];
+          addrs[row] = (size_t)(uintptr_t)append_row(dst, keys, (int64_t)(s + row), hashes[row]);
+          dst->pointers[slots[row]] = (uint8_t*)(uintptr_t)addrs[row];
+        }
+        for (int t = 0; t < n_cmp; ++t) {
+          int row = cmp_v[t];
+          addrs[row] = (size_t)(uintptr_t)dst->pointers[slots[row]];
+          if (!row_match(dst, dst->rows + (addrs[row] - 1) * dst->tuple_size, keys, (int64_t)(s + row))) no_match[n_nomatch++] = row;
+        }
+        for (int t = 0; t < n_nomatch; ++t) slots[no_match[t]] = (slots[no_match[t]] + 1) & dst->mask;
+        dst->count += (size_t)n_new;
+        remaining = (size_t)n_nomatch;
+      }
+    }
+    for (size_t r = 0; r < m; ++r) {
+      uint64_t so_s, so_d;
+      memcpy(&so_s, src->rows + (s + r) * src->tuple_size + src->state_ptr_off, 8);
+      memcpy(&so_d, dst->rows + (addrs[r] - 1) * dst->tuple_size + dst->state_ptr_off, 8);
+      for (int a = 0; a < dst->naggs; ++a) {
+        uint8_t* d = dst->states + so_d + dst->state_off[a];
+        const uint8_t* sp = src->states + so_s + src->state_off[a];
+        const orc_agg_desc* ad = &dst->aggs[a];
+        if (ad->kind == ORC_AGG_COUNT) { uint64_t x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
+        else if (ad->kind == ORC_AGG_SUM) {
+          if (ad->arg_type == ORC_T_DEC128) { /* DecimalSumState::merge -> add (with the overflow check) */
+            i128 x, y; memcpy(&x, d, 16); memcpy(&y, sp, 16); x = (i128)((u128)x + (u128)y); memcpy(d, &x, 16);
+            i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;
+          } else if (t_cls(ad->arg_type) == 2) { double x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
+          else { uint64_t x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
+        } else {
+          uint64_t hs; memcpy(&hs, sp + 8, 8);
+          if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1;
+            uint8_t buf[8]; val v; memset(&v, 0, sizeof v); v.cls = t_cls(ad->arg_type);
+            if (v.cls == 2) memcpy(&v.f, sp, 8); else if (v.cls == 0) memcpy(&v.i, sp, 8); else memcpy(&v.u, sp, 8);
+            store_val(buf, ad->arg_type, 0, v); tmp.data = buf; state_add(ad, d, &tmp, 0); }
+        }
+      }
+    }
+  }
+  for (int k = 0; k < src->nkeys; ++k) { free(kb[k]); free(kv[k]); free(kbits[k]); }
+  return rc;
+}
+
+void orc_hashagg_destroy(orc_hashagg* h) {
+  if (!h) return;
+  free(h->ctrls); free(h->pointers); free(h->rows); free(h->states); free(h->strs); free(h);
+}
+
+/* ------------------------------------------------------------------------ */
+/* TPC-H Q1: filter -> take -> maps -> partial agg per thread, final merge     */
+/* (physical_aggregate_partial.rs:194-234, transform_aggregate_final.rs:160-175) */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const int64_t *qty, *price, *disc, *tax; const uint8_t *rf, *ls; const int32_t* sd;
+  int32_t cutoff; int64_t n, block_rows; int tid, nthreads; orc_hashagg* ht; int rc;
+} q1_worker;
+
+static orc_hashagg* q1_table(void) {
+  int32_t kt[2] = {ORC_T_STRING, ORC_T_STRING};
+  orc_agg_desc ag[6]; memset(ag, 0, sizeof ag);
+  ag[0].kind = ORC_AGG_SUM; ag[0].arg_type = ORC_T_DEC64; ag[0].arg_precision = 15; ag[0].arg_scale = 2;
+  ag[1] = ag[0];
+  ag[2].kind = ORC_AGG_SUM; ag[2].arg_type = ORC_T_DEC128; ag[2].arg_precision = 31; ag[2].arg_scale = 4;
+  ag[3].kind = ORC_AGG_SUM; ag[3].arg_type = ORC_T_DEC128; ag[3].arg_precision = 38; ag[3].arg_scale = 6;
+  ag[4] = ag[0];
+  ag[5].kind = ORC_AGG_COUNT;
+  return orc_hashagg_create(kt, NULL, 2, ag, 6);
+}
+
+static void* q1_work(void* p) {
+  q1_worker* w = (q1_worker*)p;
+  int64_t B = w->block_rows;
+  uint8_t* bm = (uint8_t*)malloc((size_t)(B + 63) / 8 + 8);
+  uint32_t* sel = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)B);
+  int64_t *tq = malloc(8 * (size_t)B), *tp = malloc(8 * (size_t)B), *td = malloc(8 * (size_t)B), *tt = malloc(8 * (size_t)B);
+  uint8_t *trf = malloc(16 * (size_t)B), *tls = malloc(16 * (size_t)B);
+  int64_t *omd = malloc(8 * (size_t)B), *opt = malloc(8 * (size_t)B);
+  i128 *dp = malloc(16 * (size_t)B), *ch = malloc(16 * (size_t)B);
+  int64_t nblocks = (w->n + B - 1) / B;
+  for (int64_t b = w->tid; b < nblocks; b += w->nthreads) {
+    int64_t s = b * B, m = w->n - s < B ? w->n - s : B;
+    /* TransformFilter: l_shipdate <= cutoff */
+    orc_col sd = {ORC_T_DATE, 0, w->sd + s, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+    orc_col cut = {ORC_T_DATE, 1, &w->cutoff, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+    orc_cmp(ORC_CMP_LTE, &sd, &cut, m, bm);
+    int64_t k = orc_filter_select(bm, 0, m, sel);
+    orc_take(w->qty + s, 8, sel, k, tq); orc_take(w->price + s, 8, sel, k, tp);
+    orc_take(w->disc + s, 8, sel, k, td); orc_take(w->tax + s, 8, sel, k, tt);
+    orc_take(w->rf + 16 * s, 16, sel, k, trf); orc_take(w->ls + 16 * s, 16, sel, k, tls);
+    /* CompoundBlockOperator: one materialised column per call node */
+    uint8_t one = 1;
+    orc_col c_one = {ORC_T_U8, 1, &one, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+    orc_col c_disc = {ORC_T_DEC64, 0, td, NULL, 0, NULL, 0, 15, 2, {0, 0}};
+    orc_col c_tax = {ORC_T_DEC64, 0, tt, NULL, 0, NULL, 0, 15, 2, {0, 0}};
+    orc_col c_price = {ORC_T_DEC64, 0, tp, NULL, 0, NULL, 0, 15, 2, {0, 0}};
+    int e = 0;
+    e |= orc_decimal_arith(ORC_OP_MINUS, &c_one, &c_disc, k, ORC_T_DEC64, 16, 2, omd, NULL, NULL);
+    orc_col c_omd = {ORC_T_DEC64, 0, omd, NULL, 0, NULL, 0, 16, 2, {0, 0}};
+    e |= orc_decimal_arith(ORC_OP_MULTIPLY, &c_price, &c_omd, k, ORC_T_DEC128, 31, 4, dp, NULL, NULL);
+    e |= orc_decimal_arith(ORC_OP_PLUS, &c_one, &c_tax, k, ORC_T_DEC64, 16, 2, opt, NULL, NULL);
+    orc_col c_opt = {ORC_T_DEC64, 0, opt, NULL, 0, NULL, 0, 16, 2, {0, 0}};
+    orc_col c_dp = {ORC_T_DEC128, 0, dp, NULL, 0, NULL, 0, 31, 4, {0, 0}};
+    e |= orc_decimal_arith(ORC_OP_MULTIPLY, &c_dp, &c_opt, k, ORC_T_DEC128, 38, 6, ch, NULL, NULL);
+    if (e) w->rc = e;
+    /* TransformPartialAggregate */
+    orc_col keys[2] = {{ORC_T_STRING, 0, trf, NULL, 0, NULL, 0, 0, 0, {0, 0}}, {ORC_T_STRING, 0, tls, NULL, 0, NULL, 0, 0, 0, {0, 0}}};
+    orc_col args[6]; memset(args, 0, sizeof args);
+    orc_col c_qty = {ORC_T_DEC64, 0, tq, NULL, 0, NULL, 0, 15, 2, {0, 0}};
+    orc_col c_ch = {ORC_T_DEC128, 0, ch, NULL, 0, NULL, 0, 38, 6, {0, 0}};
+    args[0] = c_qty; args[1] = c_price; args[2] = c_dp; args[3] = c_ch; args[4] = c_disc;
+    int e2 = orc_hashagg_add_block(w->ht, keys, args, k);
+    if (e2) w->rc = e2;
+  }
+  free(bm); free(sel); free(tq); free(tp); free(td); free(tt); free(trf); free(tls); free(omd); free(opt); free(dp); free(ch);
+  return NULL;
+}
+
+int orc_q1_run(const int64_t* qty, const int64_t* price, const int64_t* disc, const int64_t* tax,
+               const void* rf_views, const void* ls_views, const int32_t* shipdate, int32_t cutoff,
+               int64_t n, int threads, int64_t block_rows, orc_q1_result* out) {
+  if (threads < 1) threads = 1;
+  q1_worker* ws = (q1_worker*)calloc((size_t)threads, sizeof(q1_worker));
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  for (int t = 0; t < threads; ++t) {
+    q1_worker w = {qty, price, disc, tax, (const uint8_t*)rf_views, (const uint8_t*)ls_views, shipdate, cutoff, n, block_rows, t, threads, q1_table(), 0};
+    ws[t] = w;
+    if (threads == 1) q1_work(&ws[t]); else pthread_create(&th[t], NULL, q1_work, &ws[t]);
+  }
+  if (threads > 1) for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+  /* TransformFinalAggregate: combine all partial tables */
+  orc_hashagg* fin = ws[0].ht;
+  int rc = ws[0].rc;
+  for (int t = 1; t < threads; ++t) { int e = orc_hashagg_combine(fin, ws[t].ht); if (e) rc = e; if (ws[t].rc) rc = ws[t].rc; orc_hashagg_destroy(ws[t].ht); }
+  int64_t g = orc_hashagg_num_groups(fin);
+  if (g > 16) { orc_hashagg_destroy(fin); free(ws); free(th); return -1; }
+  memset(out, 0, sizeof(*out));
+  void* keys[2] = {out->returnflag, out->linestatus};
+  void* aggs[6] = {out->sum_qty, out->sum_price, out->sum_disc_price, out->sum_charge, out->sum_disc, out->count};
+  orc_hashagg_result(fin, keys, NULL, aggs, NULL);
+  orc_hashagg_destroy(fin);
+  free(ws); free(th);
+  return rc ? -rc - 100 : (int)g;
+}
+
+/* ------------------------------------------------------------------------ */
+/* sort: kernels/sort_compare.rs:33-283 (key sequence; ties unordered there,   */
+/* here stable by row id)                                                     */
+/* ------------------------------------------------------------------------ */
+typedef struct { const orc_col* keys; const uint8_t* desc; const uint8_t* nf; int nkeys; } sort_ctx;
+static __thread sort_ctx g_sort;
+static int sort_cmp(const void* pa, const void* pb) {
+  uint32_t a = *(const uint32_t*)pa, b = *(const uint32_t*)pb;
+  for (int k = 0; k < g_sort.nkeys; ++k) {
+    const orc_col* c = &g_sort.keys[k];
+    int va = col_valid(c, a), vb = col_valid(c, b);
+    if (!va || !vb) {
+      if (va == vb) continue;
+      int a_first = (!va) ? g_sort.nf[k] : !g_sort.nf[k]; /* NULL ordering is independent of asc/desc */
+      return a_first ? -1 : 1;
+    }
+    orc_col ca = *c, cb = *c;
+    ca.is_scalar = 1; cb.is_scalar = 1;
+    int es = c->type == ORC_T_BOOL ? 0 : t_size(c->type);
+    int r;
+    if (c->type == ORC_T_BOOL) r = bit_get((const uint8_t*)c->data, a) - bit_get((const uint8_t*)c->data, b);
+    else { ca.data = (const uint8_t*)c->data + (size_t)a * es; cb.data = (const uint8_t*)c->data + (size_t)b * es; ca.validity = cb.validity = NULL; r = cmp3_col(&ca, &cb, 0); }
+    if (r) return g_sort.desc[k] ? -r : r;
+  }
+  return (a > b) - (a < b);
+}
+int orc_sort_perm(const orc_col* keys, const uint8_t* desc, const uint8_t* nulls_first, int nkeys, int64_t n,
+                  int64_t limit, uint32_t* out_perm) {
+  uint32_t* p = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+  for (int64_t i = 0; i < n; ++i) p[i] = (uint32_t)i;
+  g_sort.keys = keys; g_sort.desc = desc; g_sort.nf = nulls_first; g_sort.nkeys = nkeys;
+  qsort(p, (size_t)n, sizeof(uint32_t), sort_cmp);
+  int64_t m = (limit > 0 && limit < n) ? limit : n;
+  memcpy(out_perm, p, sizeof(uint32_t) * (size_t)m);
+  free(p);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* inner hash join on u64 keys: hashjoin_hashtable.rs:95-137 (chained buckets,  */
+/* prepend insert), fixed_keys.rs:209-269 (chain walk, key ==). Output sorted   */
+/* by (probe_idx, build_row).                                                   */
+/* ------------------------------------------------------------------------ */
+int64_t orc_join_inner_u64(const uint64_t* build, const uint8_t* bv, int64_t nb, const uint64_t* probe,
+                           const uint8_t* pv, int64_t np, uint32_t* out_p, uint32_t* out_b, int64_t max_pairs) {
+  size_t cap = 1024; while (cap < (size_t)nb * 2) cap <<= 1; /* :95-108 */
+  int64_t* head = (int64_t*)malloc(sizeof(int64_t) * cap);
+  int64_t* next = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nb ? nb : 1));
+  for (size_t i = 0; i < cap; ++i) head[i] = -1;
+  int shift = 64 - __builtin_ctzll(cap);
+  for (int64_t r = 0; r < nb; ++r) {
+    if (bv && !bit_get(bv, r)) continue; /* NULL keys never match */
+    uint64_t hsh = orc_agg_hash_u64(build[r]) ; size_t idx = (size_t)(hsh >> shift);
+    next[r] = head[idx]; head[idx] = r;
+  }
+  int64_t k = 0;
+  for (int64_t i = 0; i < np; ++i) {
+    if (pv && !bit_get(pv, i)) continue;
+    size_t idx = (size_t)(orc_agg_hash_u64(probe[i]) >> shift);
+    int64_t first = k;
+    for (int64_t r = head[idx]; r >= 0; r = next[r])
+      if (build[r] == probe[i]) { if (k < max_pairs) { out_p[k] = (uint32_t)i; out_b[k] = (uint32_t)r; } k++; }
+    /* chain order is newest-first; sort this probe row's matches ascending */
+    int64_t hi = k < max_pairs ? k : max_pairs;
+    for (int64_t x = first + 1; x < hi; ++x) { uint32_t v = out_b[x]; int64_t y = x - 1; while (y >= first && out_b[y] > v) { out_b[y + 1] = out_b[y]; y--; } out_b[y + 1] = v; }
+  }
+  free(head); free(next);
+  return k;
+}
+
+/* ------------------------------------------------------------------------ */
+/* vector distances: src/common/vector/src/distance.rs:19-95. (&a*&b).sum() is  */
+/* ndarray 0.15.6 (Cargo.lock:12641) numeric_util::unrolled_fold: 8 partial     */
+/* sums, combined (p0+p4)+(p1+p5)+(p2+p6)+(p3+p7), then the tail sequentially.  */
+/* ------------------------------------------------------------------------ */
+static float nd_sum_prod(const float* a, const float* b, int n) {
+  float p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc = 0.0f;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) for (int j = 0; j < 8; ++j) p[j] = p[j] + a[i + j] * b[i + j];
+  acc = acc + (p[0] + p[4]); acc = acc + (p[1] + p[5]); acc = acc + (p[2] + p[6]); acc = acc + (p[3] + p[7]);
+  for (; i < n; ++i) acc = acc + a[i] * b[i];
+  return acc;
+}
+void orc_vec_distance(int metric, const float* base, int64_t n, int dim, const float* queries, int nq, float* out) {
+  for (int q = 0; q < nq; ++q) {
+    const float* b = queries + (size_t)q * dim;
+    for (int64_t i = 0; i < n; ++i) {
+      const float* a = base + (size_t)i * dim;
+      float r;
+      switch (metric) {
+        case 0: { float aa = nd_sum_prod(a, a, dim), bb = nd_sum_prod(b, b, dim); r = 1.0f - nd_sum_prod(a, b, dim) / (sqrtf(aa) * sqrtf(bb)); } break;
+        case 1: { float s = 0.0f; for (int k = 0; k < dim; ++k) { float d = a[k] - b[k]; s += d * d; } r = sqrtf(s); } break;
+        case 2: r = nd_sum_prod(a, b, dim); break;
+        default: { float s = 0.0f; for (int k = 0; k < dim; ++k) s += fabsf(a[k] - b[k]); r = s; } break;
+      }
+      out[(size_t)q * n + i] = r;
+    }
+  }
+}
+/* scalar statement of cpp/avx2.c:45-139 impl_score_dot_avx / impl_score_l1_avx (exact integer sums) */
+void orc_score_u8(int is_l1, const uint8_t* q, const uint8_t* base, int64_t n, int dim, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint8_t* v = base + (size_t)i * dim; int64_t s = 0;
+    for (int k = 0; k < dim; ++k) s += is_l1 ? (q[k] > v[k] ? q[k] - v[k] : v[k] - q[k]) : (int64_t)q[k] * v[k];
+    out[i] = (float)s;
+  }
+}
