@@ -1,0 +1,89 @@
+"""ctypes binding of include/dbhip.h (the drop-in C-ABI).  Fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DbhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dbhip error {code}: {msg}")
+        self.code = code
+
+
+# status codes (include/dbhip.h)
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ROW_ERRORS, ERR_OVERFLOW, ERR_CAPACITY, ERR_UNSUPPORTED = range(8)
+
+# dbhip_type
+T_BOOL, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F32, T_F64, T_DATE, T_TIMESTAMP, T_DEC64, T_DEC128, T_STRING = range(1, 17)
+OP_PLUS, OP_MINUS, OP_MULTIPLY, OP_DIVIDE, OP_INTDIV, OP_MODULO = range(6)
+CMP_EQ, CMP_NOTEQ, CMP_LT, CMP_LTE, CMP_GT, CMP_GTE = range(6)
+AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = range(4)
+VEC_COSINE, VEC_L2, VEC_DOT, VEC_L1 = range(4)
+
+
+class Col(C.Structure):
+    """dbhip_col"""
+    _fields_ = [
+        ("type", C.c_int32), ("is_scalar", C.c_int32), ("data", C.c_void_p),
+        ("validity", C.c_void_p), ("validity_offset", C.c_int64),
+        ("buffers", C.c_void_p), ("n_buffers", C.c_int32),
+        ("precision", C.c_uint8), ("scale", C.c_uint8), ("_pad", C.c_uint8 * 2),
+    ]
+
+
+class AggDesc(C.Structure):
+    """dbhip_agg_desc"""
+    _fields_ = [("kind", C.c_int32), ("arg_type", C.c_int32), ("arg_precision", C.c_uint8),
+                ("arg_scale", C.c_uint8), ("arg_nullable", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libdbhip.so")
+
+
+# every symbol include/dbhip.h declares (tests check that the built library exports all of them)
+SYMBOLS = [
+    "dbhip_abi_version", "dbhip_init", "dbhip_device_count", "dbhip_last_error", "dbhip_alloc", "dbhip_free",
+    "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy",
+    "dbhip_stream_sync", "dbhip_event_create", "dbhip_event_record", "dbhip_event_elapsed_ms",
+    "dbhip_event_destroy", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",
+    "dbhip_sum", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_cmp", "dbhip_bitmap_binary",
+    "dbhip_bitmap_count", "dbhip_filter_select", "dbhip_take", "dbhip_take_bitmap", "dbhip_group_hash",
+    "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized",
+    "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized",
+    "dbhip_groupby_result_type", "dbhip_groupby_flush_result", "dbhip_groupby_reset",
+    "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_join_create",
+    "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
+    "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
+]
+
+
+def load_library():
+    """dlopen libdbhip.so (no GPU needed to load; compute entry points need one)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise DbhipError(ERR_NO_DEVICE, f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                       "(there is no CPU fallback)")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    L.dbhip_last_error.restype = C.c_char_p
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name != "dbhip_last_error":
+            fn.restype = C.c_int32
+    _LIB = L
+    return L
+
+
+def lib():
+    return load_library()
+
+
+def check(rc):
+    if rc != OK:
+        raise DbhipError(rc, load_library().dbhip_last_error().decode("utf-8", "replace"))
+    return rc
