@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — TPC-H Q1 hash-aggregation throughput (rows/s) on synthetic lineitem.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--sf 10]
+
+A "step" is one pass of the fused Q1 pipeline (filter -> decimal maps -> partial hash
+aggregation) over one rank's lineitem shard that is already resident in HBM, followed
+by the partial-state exchange (all-gather of the <= handful of serialized group rows over
+RCCL when N > 1) and the final merge on every rank. N=1 workload = BASELINE.json
+configs[1] (SF10, 59,986,052 rows). N>1: every rank holds an SF10-sized row-range shard
+(weak scaling; 8 ranks = 479.9 M rows ~ SF80).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_ROW = 68  # 4 x Decimal64 + 2 x 16-B view + Date32
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sf", type=float, default=10.0)
+    ap.add_argument("--rows", type=int, default=0, help="override rows per rank")
+    ap.add_argument("--cpu-rows", type=int, default=16_000_000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libdbhip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from databend_amd import device as D, tpch
+    from databend_amd import dist as DX
+    from databend_amd._lib import check, lib
+    D.init(local_rank)
+    L = lib()
+
+    n = args.rows or tpch.rows_for_sf(args.sf)
+    host = tpch.gen_lineitem(n, seed=2 + rank)
+    li = tpch.LineitemDevice(host)
+    g = D.GroupBy.q1()
+
+    stream = C.c_void_p()
+    check(L.dbhip_stream_create(C.byref(stream)))
+    ev = [C.c_void_p() for _ in range(2 * (args.steps + 1))]
+    for e in ev:
+        check(L.dbhip_event_create(C.byref(e)))
+
+    def step(record=None):
+        g.reset()
+        if record is not None:
+            check(L.dbhip_event_record(record[0], stream))
+        D.q1_fused(g, li.qty, li.price, li.disc, li.tax, li.rf, li.ls, li.ship, tpch.Q1_CUTOFF, stream=stream)
+        if record is not None:
+            check(L.dbhip_event_record(record[1], stream))
+        if world > 1:
+            DX.exchange_partials_nccl(g, dist, torch)
+        return g
+
+    for _ in range(args.warmup):
+        step()
+    check(L.dbhip_stream_sync(stream))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step((ev[2 * i], ev[2 * i + 1]))
+    check(L.dbhip_stream_sync(stream))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-launch region of the dominant kernel (q1_fused_kernel + its tiny merge), HIP events on its stream
+    kms = []
+    for i in range(args.steps):
+        ms = C.c_float()
+        check(L.dbhip_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
+        kms.append(ms.value)
+    kernel_ms = float(np.mean(kms)) if kms else 0.0
+
+    rows_total = n * world * args.steps
+    value = rows_total / dt
+    result = tpch.q1_rows(g)
+
+    out = None
+    if rank == 0:
+        achieved = (n * BYTES_PER_ROW) / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "q1_traffic.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                if tj.get("rows") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        cpu = None
+        if not args.no_cpu and world == 1:
+            from tests import oracle_lib
+            cn = min(args.cpu_rows, n)
+            cores = os.cpu_count() or 1
+            oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=cores, n=min(cn, 1_000_000))  # warm
+            c0 = time.perf_counter()
+            cres = oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=cores, n=cn)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": cn / cdt, "unit": "rows/s", "cores": cores, "kind": "port",
+                   "sample": f"first {cn} rows of the same lineitem shard, {cores} threads x 65536-row blocks "
+                             f"(filter->take->decimal maps->partial AggregateHashTable->final merge), C restatement gcc -O2"}
+            if cn == n:
+                assert cres == result, "GPU result differs from the CPU restatement"
+        out = {
+            "metric": "rows/s TPC-H Q1 hash-agg", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i64/i128 decimal", "data": "synthetic",
+            "config": {"workload": f"TPC-H Q1 hash-aggregation, SF{args.sf:g} synthetic lineitem per GPU "
+                                   f"({n} rows/rank, 68 B/row, fused filter+decimal maps+group-by, "
+                                   f"{'all-gather of partial states over RCCL + final merge' if world > 1 else 'single GPU'})",
+                       "rows_per_rank": n, "groups": len(result)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "q1_fused_kernel",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": n * BYTES_PER_ROW},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,495 @@
+"""Python host mirror of the reference's column vocabulary on top of the C-ABI.
+
+Column / DataBlock here are HBM-resident (the device analogue of
+src/query/expression/src/values.rs:192 `Column` and block.rs:49-59 `DataBlock`);
+every operation goes through libdbhip.so — there is no numpy compute path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import AggDesc, Col, check, lib
+
+NP_OF = {
+    L.T_I8: np.int8, L.T_I16: np.int16, L.T_I32: np.int32, L.T_I64: np.int64,
+    L.T_U8: np.uint8, L.T_U16: np.uint16, L.T_U32: np.uint32, L.T_U64: np.uint64,
+    L.T_F32: np.float32, L.T_F64: np.float64, L.T_DATE: np.int32, L.T_TIMESTAMP: np.int64,
+    L.T_DEC64: np.int64,
+}
+TYPE_OF_NP = {np.dtype(v): k for k, v in NP_OF.items() if k not in (L.T_DATE, L.T_TIMESTAMP, L.T_DEC64)}
+ELEM_SIZE = {L.T_DEC128: 16, L.T_STRING: 16}
+for _t, _d in NP_OF.items():
+    ELEM_SIZE[_t] = np.dtype(_d).itemsize
+
+_initialised = False
+
+
+def init(device=0):
+    global _initialised
+    check(lib().dbhip_init(int(device)))
+    _initialised = True
+
+
+def _ensure():
+    if not _initialised:
+        init(0)
+
+
+class DeviceBuffer:
+    """Owned HBM allocation (dbhip_alloc / dbhip_free)."""
+
+    def __init__(self, nbytes):
+        _ensure()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().dbhip_alloc(C.c_size_t(max(self.nbytes, 16)), C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        if arr.nbytes:
+            check(lib().dbhip_memcpy_h2d(C.c_void_p(b.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), None))
+        return b
+
+    def to_numpy(self, dtype, count=None):
+        dtype = np.dtype(dtype)
+        n = self.nbytes // dtype.itemsize if count is None else int(count)
+        out = np.empty(n, dtype=dtype)
+        if n:
+            check(lib().dbhip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(n * dtype.itemsize), None))
+        return out
+
+    def zero(self):
+        check(lib().dbhip_memset(C.c_void_p(self.ptr), 0, C.c_size_t(max(self.nbytes, 1)), None))
+        return self
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().dbhip_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pack_bits(bools):
+    """bool array -> LSB-first Bitmap bytes (padded to a multiple of 8 bytes)."""
+    bools = np.asarray(bools, dtype=bool)
+    by = np.packbits(bools, bitorder="little")
+    pad = (-len(by)) % 8
+    if pad or len(by) == 0:
+        by = np.concatenate([by, np.zeros(pad if len(by) else 8, np.uint8)])
+    return by
+
+
+def unpack_bits(by, n):
+    return np.unpackbits(np.asarray(by, dtype=np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def make_views(strings):
+    """list of bytes (each <= 12 bytes) -> (n,16) uint8 inline BinaryView array
+    (src/common/column/src/binview/view.rs:30-42)."""
+    n = len(strings)
+    v = np.zeros((n, 16), dtype=np.uint8)
+    for i, s in enumerate(strings):
+        assert len(s) <= 12, "only inline views here"
+        v[i, 0:4] = np.frombuffer(np.uint32(len(s)).tobytes(), np.uint8)
+        v[i, 4:4 + len(s)] = np.frombuffer(s, np.uint8)
+    return v
+
+
+def make_views_general(strings):
+    """Any-length strings -> (views (n,16) u8, data buffer u8): long strings go to buffer 0."""
+    n = len(strings)
+    v = np.zeros((n, 16), dtype=np.uint8)
+    buf = bytearray()
+    for i, s in enumerate(strings):
+        v[i, 0:4] = np.frombuffer(np.uint32(len(s)).tobytes(), np.uint8)
+        if len(s) <= 12:
+            v[i, 4:4 + len(s)] = np.frombuffer(s, np.uint8)
+        else:
+            v[i, 4:8] = np.frombuffer(s[:4], np.uint8)
+            v[i, 8:12] = np.frombuffer(np.uint32(0).tobytes(), np.uint8)
+            v[i, 12:16] = np.frombuffer(np.uint32(len(buf)).tobytes(), np.uint8)
+            buf += s
+    return v, np.frombuffer(bytes(buf) + b"\0" * 16, dtype=np.uint8).copy()
+
+
+def view_strings(views):
+    views = np.asarray(views, dtype=np.uint8).reshape(-1, 16)
+    out = []
+    for r in views:
+        ln = int(np.frombuffer(r[0:4].tobytes(), np.uint32)[0])
+        out.append(bytes(r[4:4 + ln]))
+    return out
+
+
+class Column:
+    """HBM-resident column: values + optional validity Bitmap (NullableColumn)."""
+
+    def __init__(self, dtype, n, data, validity=None, precision=0, scale=0, is_scalar=False, buffers=None, keep=()):
+        self.dtype, self.n, self.data, self.validity = dtype, int(n), data, validity
+        self.precision, self.scale, self.is_scalar = int(precision), int(scale), bool(is_scalar)
+        self.buffers = buffers  # DeviceBuffer holding an array of device pointers (strings)
+        self._keep = keep
+
+    # ---- constructors -----------------------------------------------------------------
+    @classmethod
+    def from_numpy(cls, arr, dtype=None, validity=None, precision=0, scale=0):
+        arr = np.ascontiguousarray(arr)
+        if dtype is None:
+            dtype = TYPE_OF_NP[arr.dtype]
+        n = len(arr)
+        vb = DeviceBuffer.from_numpy(pack_bits(validity)) if validity is not None else None
+        return cls(dtype, n, DeviceBuffer.from_numpy(arr), vb, precision, scale)
+
+    @classmethod
+    def scalar(cls, value, dtype, precision=0, scale=0):
+        if dtype == L.T_DEC128:
+            arr = i128_to_bytes([int(value)])
+        else:
+            arr = np.array([value], dtype=NP_OF[dtype])
+        return cls(dtype, 1, DeviceBuffer.from_numpy(arr), None, precision, scale, is_scalar=True)
+
+    @classmethod
+    def decimal128(cls, ints, precision, scale, validity=None):
+        vb = DeviceBuffer.from_numpy(pack_bits(validity)) if validity is not None else None
+        return cls(L.T_DEC128, len(ints), DeviceBuffer.from_numpy(i128_to_bytes(ints)), vb, precision, scale)
+
+    @classmethod
+    def boolean(cls, bools, validity=None):
+        vb = DeviceBuffer.from_numpy(pack_bits(validity)) if validity is not None else None
+        return cls(L.T_BOOL, len(bools), DeviceBuffer.from_numpy(pack_bits(bools)), vb)
+
+    @classmethod
+    def strings(cls, strings, validity=None):
+        views, buf = make_views_general(strings)
+        dbuf = DeviceBuffer.from_numpy(buf)
+        ptrs = DeviceBuffer.from_numpy(np.array([dbuf.ptr], dtype=np.uint64))
+        vb = DeviceBuffer.from_numpy(pack_bits(validity)) if validity is not None else None
+        return cls(L.T_STRING, len(strings), DeviceBuffer.from_numpy(views), vb, buffers=ptrs, keep=(dbuf,))
+
+    @classmethod
+    def from_views(cls, views):
+        views = np.ascontiguousarray(views, dtype=np.uint8).reshape(-1, 16)
+        return cls(L.T_STRING, len(views), DeviceBuffer.from_numpy(views))
+
+    # ---- access ---------------------------------------------------------------------------
+    def c(self):
+        col = Col()
+        col.type = self.dtype
+        col.is_scalar = 1 if self.is_scalar else 0
+        col.data = self.data.ptr
+        col.validity = self.validity.ptr if self.validity is not None else None
+        col.validity_offset = 0
+        col.buffers = self.buffers.ptr if self.buffers is not None else None
+        col.n_buffers = 1 if self.buffers is not None else 0
+        col.precision, col.scale = self.precision, self.scale
+        return col
+
+    def to_numpy(self):
+        if self.dtype == L.T_DEC128:
+            return bytes_to_i128(self.data.to_numpy(np.uint8, 16 * self.n))
+        if self.dtype == L.T_BOOL:
+            return unpack_bits(self.data.to_numpy(np.uint8, (self.n + 7) // 8), self.n)
+        if self.dtype == L.T_STRING:
+            return self.data.to_numpy(np.uint8, 16 * self.n).reshape(-1, 16)
+        return self.data.to_numpy(NP_OF[self.dtype], self.n)
+
+    def validity_numpy(self):
+        if self.validity is None:
+            return np.ones(self.n, dtype=bool)
+        return unpack_bits(self.validity.to_numpy(np.uint8, (self.n + 7) // 8), self.n)
+
+
+def i128_to_bytes(ints):
+    out = np.zeros((len(ints), 2), dtype=np.uint64)
+    for i, v in enumerate(ints):
+        v = int(v) & ((1 << 128) - 1)
+        out[i, 0] = v & 0xFFFFFFFFFFFFFFFF
+        out[i, 1] = v >> 64
+    return out.reshape(-1)
+
+
+def bytes_to_i128(raw):
+    w = np.frombuffer(np.ascontiguousarray(raw).tobytes(), dtype=np.uint64).reshape(-1, 2)
+    out = []
+    for lo, hi in w:
+        v = (int(hi) << 64) | int(lo)
+        if v >> 127:
+            v -= 1 << 128
+        out.append(v)
+    return out
+
+
+def _cols(cols):
+    arr = (Col * len(cols))(*[c.c() for c in cols])
+    return arr
+
+
+class RowErrors:
+    """Per-row error bitmap + count (EvalContext errors, function.rs:534-556)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.bitmap = DeviceBuffer(((n + 31) // 32) * 4 + 8)
+        self.count = DeviceBuffer(8).zero()
+
+    def error_rows(self):
+        ok = unpack_bits(self.bitmap.to_numpy(np.uint8, ((self.n + 31) // 32) * 4), self.n)
+        return np.nonzero(~ok)[0]
+
+    def num_errors(self):
+        return int(self.count.to_numpy(np.uint64, 1)[0])
+
+
+def _merged_validity(a, b, n):
+    if a.validity is None and b.validity is None:
+        return None
+    if a.validity is None or (a.is_scalar and a.validity_numpy()[0]):
+        va = None
+    else:
+        va = a
+    # validity = AND of inputs (passthrough_nullable, register_vectorize.rs:447-471), on device
+    bits = []
+    for x in (a, b):
+        if x.validity is None:
+            continue
+        if x.is_scalar:
+            bits.append(DeviceBuffer.from_numpy(pack_bits(np.repeat(x.validity_numpy()[:1], n))))
+        else:
+            bits.append(x.validity)
+    if len(bits) == 1:
+        return bits[0]
+    out = DeviceBuffer(((n + 63) // 64) * 8)
+    check(lib().dbhip_bitmap_binary(0, C.c_void_p(bits[0].ptr), C.c_void_p(bits[1].ptr), C.c_int64(n), C.c_void_p(out.ptr), None))
+    return out
+
+
+def arith(op, a, b, n=None, errors=None):
+    """plus/minus/multiply/divide/div/modulo on numeric columns -> Column."""
+    n = n if n is not None else max(a.n if not a.is_scalar else 0, b.n if not b.is_scalar else 0)
+    out_t = lib().dbhip_arith_result_type(op, a.dtype, b.dtype)
+    if out_t < 0:
+        raise L.DbhipError(L.ERR_INVALID, f"no numeric overload for op {op} on ({a.dtype},{b.dtype})")
+    out = DeviceBuffer(max(n, 1) * ELEM_SIZE[out_t] + 64)
+    ca, cb = a.c(), b.c()
+    eb = C.c_void_p(errors.bitmap.ptr) if errors else None
+    ec = C.c_void_p(errors.count.ptr) if errors else None
+    check(lib().dbhip_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), out_t, C.c_void_p(out.ptr), eb, ec, None))
+    return Column(out_t, n, out, _merged_validity(a, b, n))
+
+
+def decimal_result_size(op, a, b):
+    props = {L.T_I8: (3, 0), L.T_U8: (3, 0), L.T_I16: (5, 0), L.T_U16: (5, 0), L.T_I32: (10, 0), L.T_U32: (10, 0),
+             L.T_I64: (19, 0), L.T_U64: (20, 0)}
+    ap = (a.precision, a.scale) if a.dtype in (L.T_DEC64, L.T_DEC128) else props[a.dtype]
+    bp = (b.precision, b.scale) if b.dtype in (L.T_DEC64, L.T_DEC128) else props[b.dtype]
+    p, s = C.c_uint8(), C.c_uint8()
+    check(lib().dbhip_decimal_result_size(op, ap[0], ap[1], bp[0], bp[1], C.byref(p), C.byref(s)))
+    return p.value, s.value
+
+
+def decimal_arith(op, a, b, n=None, errors=None):
+    n = n if n is not None else max(a.n if not a.is_scalar else 0, b.n if not b.is_scalar else 0)
+    p, s = decimal_result_size(op, a, b)
+    out_t = L.T_DEC64 if p <= 18 else L.T_DEC128
+    out = DeviceBuffer(max(n, 1) * ELEM_SIZE[out_t] + 64)
+    ca, cb = a.c(), b.c()
+    eb = C.c_void_p(errors.bitmap.ptr) if errors else None
+    ec = C.c_void_p(errors.count.ptr) if errors else None
+    check(lib().dbhip_decimal_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), out_t, p, s, C.c_void_p(out.ptr), eb, ec, None))
+    return Column(out_t, n, out, _merged_validity(a, b, n), p, s)
+
+
+def cmp(op, a, b, n=None):
+    n = n if n is not None else max(a.n if not a.is_scalar else 0, b.n if not b.is_scalar else 0)
+    out = DeviceBuffer(((n + 63) // 64) * 8 + 8)
+    ca, cb = a.c(), b.c()
+    check(lib().dbhip_cmp(op, C.byref(ca), C.byref(cb), C.c_int64(n), C.c_void_p(out.ptr), None))
+    return Column(L.T_BOOL, n, out, _merged_validity(a, b, n))
+
+
+def filter_select(pred):
+    """Boolean column -> ascending u32 selection vector (device) and its length."""
+    sel = DeviceBuffer(max(pred.n, 1) * 4 + 64)
+    cnt = DeviceBuffer(8)
+    check(lib().dbhip_filter_select(C.c_void_p(pred.data.ptr), C.c_int64(0), C.c_int64(pred.n), C.c_void_p(sel.ptr), C.c_void_p(cnt.ptr), None))
+    k = int(cnt.to_numpy(np.uint64, 1)[0])
+    return sel, k
+
+
+def take(col, sel, k):
+    """DataBlock::take for one column (kernels/take.rs:43)."""
+    if col.dtype == L.T_BOOL:
+        out = DeviceBuffer(((k + 63) // 64) * 8 + 8)
+        check(lib().dbhip_take_bitmap(C.c_void_p(col.data.ptr), C.c_int64(0), C.c_void_p(sel.ptr), C.c_int64(k), C.c_void_p(out.ptr), None))
+    else:
+        es = ELEM_SIZE[col.dtype]
+        out = DeviceBuffer(max(k, 1) * es + 64)
+        check(lib().dbhip_take(C.c_void_p(col.data.ptr), es, C.c_void_p(sel.ptr), C.c_int64(k), C.c_void_p(out.ptr), None))
+    vb = None
+    if col.validity is not None:
+        vb = DeviceBuffer(((k + 63) // 64) * 8 + 8)
+        check(lib().dbhip_take_bitmap(C.c_void_p(col.validity.ptr), C.c_int64(0), C.c_void_p(sel.ptr), C.c_int64(k), C.c_void_p(vb.ptr), None))
+    return Column(col.dtype, k, out, vb, col.precision, col.scale, buffers=col.buffers, keep=(col,))
+
+
+def group_hash(cols, n):
+    out = DeviceBuffer(max(n, 1) * 8)
+    arr = _cols(cols)
+    check(lib().dbhip_group_hash(arr, len(cols), C.c_int64(n), C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.uint64, n)
+
+
+def sum_a_plus_b_mul_c(a, b, c):
+    out = DeviceBuffer(8).zero()
+    check(lib().dbhip_sum_a_plus_b_mul_c_i64(C.c_void_p(a.data.ptr), C.c_void_p(b.data.ptr), C.c_void_p(c.data.ptr), C.c_int64(a.n), C.c_void_p(out.ptr), None))
+    return int(out.to_numpy(np.int64, 1)[0])
+
+
+def column_sum(col):
+    out = DeviceBuffer(8).zero()
+    cc = col.c()
+    check(lib().dbhip_sum(C.byref(cc), C.c_int64(col.n), C.c_void_p(out.ptr), None))
+    if col.dtype in (L.T_F32, L.T_F64):
+        return float(out.to_numpy(np.float64, 1)[0])
+    if col.dtype in (L.T_U8, L.T_U16, L.T_U32, L.T_U64):
+        return int(out.to_numpy(np.uint64, 1)[0])
+    return int(out.to_numpy(np.int64, 1)[0])
+
+
+class GroupBy:
+    """Device AggregateHashTable (dbhip_groupby_*)."""
+
+    def __init__(self, key_types, aggs, key_nullable=None, capacity=1024, handle=None):
+        _ensure()
+        self.key_types = list(key_types)
+        self.aggs = list(aggs)  # (kind, arg_type, precision, scale, nullable)
+        self.key_nullable = list(key_nullable) if key_nullable else [0] * len(key_types)
+        if handle is not None:
+            self.h = handle
+        else:
+            kt = (C.c_int32 * len(key_types))(*key_types)
+            kn = (C.c_uint8 * len(key_types))(*self.key_nullable)
+            ad = (AggDesc * max(len(aggs), 1))()
+            for i, a in enumerate(aggs):
+                ad[i].kind, ad[i].arg_type, ad[i].arg_precision, ad[i].arg_scale, ad[i].arg_nullable = a
+            self.h = C.c_void_p()
+            check(lib().dbhip_groupby_create(kt, kn, len(key_types), ad, len(aggs), C.c_int64(capacity), C.byref(self.h)))
+
+    @classmethod
+    def q1(cls):
+        _ensure()
+        h = C.c_void_p()
+        check(lib().dbhip_q1_create_groupby(C.byref(h)))
+        aggs = [(L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_SUM, L.T_DEC128, 31, 4, 0),
+                (L.AGG_SUM, L.T_DEC128, 38, 6, 0), (L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_COUNT, 0, 0, 0, 0)]
+        return cls([L.T_STRING, L.T_STRING], aggs, handle=h)
+
+    def add_block(self, keys, args, n):
+        ka = _cols(keys)
+        aa = (Col * max(len(self.aggs), 1))()
+        for i, a in enumerate(args):
+            if a is not None:
+                aa[i] = a.c()
+        check(lib().dbhip_groupby_add_block(self.h, ka, aa, C.c_int64(n), None))
+
+    def num_groups(self):
+        n = C.c_int64()
+        check(lib().dbhip_groupby_num_groups(self.h, C.byref(n), None))
+        return n.value
+
+    def row_bytes(self):
+        n = C.c_int64()
+        check(lib().dbhip_groupby_row_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def flush_serialized(self):
+        """-> (rows as uint64 ndarray [n, W])"""
+        g = self.num_groups()
+        rb = self.row_bytes()
+        buf = DeviceBuffer(max(g, 1) * rb)
+        n = C.c_int64()
+        check(lib().dbhip_groupby_flush_serialized(self.h, C.c_void_p(buf.ptr), C.c_int64(g), C.byref(n), None))
+        return buf.to_numpy(np.uint64, n.value * rb // 8).reshape(n.value, rb // 8)
+
+    def merge_serialized(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        if rows.size == 0:
+            return
+        buf = DeviceBuffer.from_numpy(rows)
+        check(lib().dbhip_groupby_merge_serialized(self.h, C.c_void_p(buf.ptr), C.c_int64(rows.shape[0]), None))
+
+    def result(self):
+        """-> list of rows [(key values..., agg values...)] (order unspecified)."""
+        g = self.num_groups()
+        cap = max(g, 1)
+        key_bufs = [DeviceBuffer(cap * ELEM_SIZE.get(t, 1) + 64) for t in self.key_types]
+        key_val = [DeviceBuffer(((cap + 31) // 32) * 4 + 8) for _ in self.key_types]
+        agg_t = []
+        for a in self.aggs:
+            d = AggDesc()
+            d.kind, d.arg_type, d.arg_precision, d.arg_scale, d.arg_nullable = a
+            t, p, s = C.c_int32(), C.c_uint8(), C.c_uint8()
+            check(lib().dbhip_groupby_result_type(C.byref(d), C.byref(t), C.byref(p), C.byref(s)))
+            agg_t.append(t.value)
+        agg_bufs = [DeviceBuffer(cap * ELEM_SIZE[t] + 64) for t in agg_t]
+        hashes = DeviceBuffer(cap * 8)
+        kp = (C.c_void_p * len(key_bufs))(*[b.ptr for b in key_bufs])
+        kv = (C.c_void_p * len(key_val))(*[b.ptr for b in key_val])
+        ap = (C.c_void_p * max(len(agg_bufs), 1))(*[b.ptr for b in agg_bufs])
+        n = C.c_int64()
+        check(lib().dbhip_groupby_flush_result(self.h, kp, kv, ap, C.c_void_p(hashes.ptr), C.c_int64(cap), C.byref(n), None))
+        n = n.value
+        cols = []
+        for t, b, v in zip(self.key_types, key_bufs, key_val):
+            valid = unpack_bits(v.to_numpy(np.uint8, ((cap + 31) // 32) * 4), n)
+            if t == L.T_STRING:
+                vals = view_strings(b.to_numpy(np.uint8, 16 * n))
+            elif t == L.T_DEC128:
+                vals = bytes_to_i128(b.to_numpy(np.uint8, 16 * n))
+            elif t == L.T_BOOL:
+                vals = [bool(x) for x in b.to_numpy(np.uint8, n)]
+            else:
+                vals = b.to_numpy(NP_OF[t], n).tolist()
+            cols.append([x if ok else None for x, ok in zip(vals, valid)])
+        for t, b in zip(agg_t, agg_bufs):
+            if t == L.T_DEC128:
+                cols.append(bytes_to_i128(b.to_numpy(np.uint8, 16 * n)))
+            else:
+                cols.append(b.to_numpy(NP_OF[t], n).tolist())
+        self.last_hashes = hashes.to_numpy(np.uint64, n)
+        return [tuple(c[i] for c in cols) for i in range(n)]
+
+    def reset(self):
+        check(lib().dbhip_groupby_reset(self.h, None))
+
+    def debug_set_hash_mask(self, mask):
+        f = lib().dbhip_groupby_debug_set_hash_mask
+        f.restype = C.c_int32
+        check(f(self.h, C.c_uint64(mask)))
+
+    def destroy(self):
+        if self.h:
+            lib().dbhip_groupby_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def q1_fused(g, qty, price, disc, tax, rf, ls, shipdate, cutoff, n=None, stream=None):
+    n = qty.n if n is None else n
+    check(lib().dbhip_q1_fused(g.h, C.c_void_p(qty.data.ptr), C.c_void_p(price.data.ptr), C.c_void_p(disc.data.ptr),
+                               C.c_void_p(tax.data.ptr), C.c_void_p(rf.data.ptr), C.c_void_p(ls.data.ptr),
+                               C.c_void_p(shipdate.data.ptr), C.c_int32(cutoff), C.c_int64(n), stream))

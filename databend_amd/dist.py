@@ -1,0 +1,74 @@
+"""Multi-GPU exchange for the hash-aggregation path.
+
+One process per GPU. Each rank aggregates its row-range shard into its own device
+table; the only data-path collective is the exchange of serialized partial-state rows
+(`[keys | hash | state words]`, gb_layout.h) — the RCCL analogue of the reference's
+AggregateMeta shuffle (aggregator/aggregate_exchange_injector.rs:57-147):
+  * low cardinality (Q1: 4 groups): all-gather of every rank's rows + local merge on
+    every rank (one hop over xGMI, a few hundred bytes);
+  * high cardinality: rows are routed by `hash % world` (payload.rs:571-577 scatter
+    semantics) with all_to_all, so each rank finalises a disjoint key range.
+The exchange is expressed against a minimal `comm` interface so that the same code runs
+over torch.distributed with the nccl (= RCCL) backend on GPUs and with gloo in the CPU
+tests (which inject a stand-in table; the product path always uses the HIP table).
+"""
+import numpy as np
+
+
+def route_rows_by_hash(rows, hash_word, world):
+    """Split serialized rows [n, W] by hash % world (Payload::scan_hash_partition_transfer)."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    if rows.size == 0:
+        return [rows.reshape(0, rows.shape[1] if rows.ndim == 2 else 0) for _ in range(world)]
+    dest = (rows[:, hash_word] % np.uint64(world)).astype(np.int64)
+    return [rows[dest == r] for r in range(world)]
+
+
+def allgather_rows(rows, dist, torch, device):
+    """All-gather variable-length row sets; returns the concatenation over ranks (rank order)."""
+    world = dist.get_world_size()
+    W = rows.shape[1]
+    cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+    cnts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    mx = max(max(counts), 1)
+    buf = torch.zeros((mx, W), dtype=torch.int64, device=device)
+    if rows.shape[0]:
+        buf[: rows.shape[0]] = torch.from_numpy(rows.view(np.int64)).to(device)
+    outs = [torch.zeros((mx, W), dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    parts = [o[:c].cpu().numpy().view(np.uint64) for o, c in zip(outs, counts)]
+    return np.concatenate(parts, axis=0) if parts else rows
+
+
+def alltoall_rows(parts, dist, torch, device):
+    """parts[r] = rows destined to rank r. Returns the rows this rank receives."""
+    world = dist.get_world_size()
+    W = parts[0].shape[1]
+    send_cnt = torch.tensor([p.shape[0] for p in parts], dtype=torch.int64, device=device)
+    recv_cnt = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv_cnt, send_cnt)
+    rc = [int(x) for x in recv_cnt.tolist()]
+    send = torch.from_numpy(np.concatenate(parts, axis=0).view(np.int64)).to(device) if sum(p.shape[0] for p in parts) else torch.zeros((0, W), dtype=torch.int64, device=device)
+    recv = torch.zeros((sum(rc), W), dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=[p.shape[0] for p in parts])
+    return recv.cpu().numpy().view(np.uint64)
+
+
+def exchange_partials(table, dist, torch, device, mode="allgather", hash_word=None):
+    """Merge every rank's partial groups. `table` needs flush_serialized()/reset()/merge_serialized().
+    allgather: every rank ends with the global result. alltoall: rank r ends with the groups whose
+    hash % world == r."""
+    rows = table.flush_serialized()
+    if mode == "allgather":
+        allrows = allgather_rows(rows, dist, torch, device)
+    else:
+        allrows = alltoall_rows(route_rows_by_hash(rows, hash_word, dist.get_world_size()), dist, torch, device)
+    table.reset()
+    table.merge_serialized(allrows)
+    return table
+
+
+def exchange_partials_nccl(table, dist, torch):
+    return exchange_partials(table, dist, torch, torch.device("cuda", torch.cuda.current_device()))

@@ -1,0 +1,125 @@
+"""ctypes binding of oracle/liboracle.so — the CPU checker (tests only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+class OCol(C.Structure):
+    _fields_ = [("type", C.c_int32), ("is_scalar", C.c_int32), ("data", C.c_void_p), ("validity", C.c_void_p),
+                ("validity_offset", C.c_int64), ("buffers", C.c_void_p), ("n_buffers", C.c_int32),
+                ("precision", C.c_uint8), ("scale", C.c_uint8), ("_pad", C.c_uint8 * 2)]
+
+
+class OAgg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("arg_type", C.c_int32), ("arg_precision", C.c_uint8), ("arg_scale", C.c_uint8),
+                ("arg_nullable", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+class Q1Result(C.Structure):
+    _fields_ = [("returnflag", (C.c_uint8 * 16) * 16), ("linestatus", (C.c_uint8 * 16) * 16),
+                ("sum_qty", C.c_int64 * 16), ("sum_price", C.c_int64 * 16), ("sum_disc", C.c_int64 * 16),
+                ("sum_disc_price", (C.c_uint64 * 2) * 16), ("sum_charge", (C.c_uint64 * 2) * 16),
+                ("count", C.c_uint64 * 16)]
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(ODIR, "liboracle.so")
+    src = os.path.join(ODIR, "oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ODIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.orc_agg_hash_bytes.restype = C.c_uint64
+    L.orc_agg_hash_u64.restype = C.c_uint64
+    L.orc_agg_hash_u64.argtypes = [C.c_uint64]
+    L.orc_filter_select.restype = C.c_int64
+    L.orc_sum_a_plus_b_mul_c_i64.restype = C.c_int64
+    L.orc_hashagg_create.restype = C.c_void_p
+    L.orc_hashagg_num_groups.restype = C.c_int64
+    L.orc_join_inner_u64.restype = C.c_int64
+    _LIB = L
+    return L
+
+
+class HostCol:
+    """numpy-backed column for the oracle."""
+
+    def __init__(self, dtype, arr, validity=None, precision=0, scale=0, is_scalar=False, buffers=None):
+        self.dtype = dtype
+        self.arr = np.ascontiguousarray(arr)
+        self.validity = None
+        if validity is not None:
+            v = np.packbits(np.asarray(validity, dtype=bool), bitorder="little")
+            self.validity = np.concatenate([v, np.zeros(8, np.uint8)])
+        self.precision, self.scale, self.is_scalar = precision, scale, is_scalar
+        self.buffers = buffers  # list of numpy uint8 arrays
+        self._bufptr = None
+        if buffers:
+            self._bufptr = (C.c_void_p * len(buffers))(*[b.ctypes.data for b in buffers])
+
+    def c(self):
+        o = OCol()
+        o.type = self.dtype
+        o.is_scalar = 1 if self.is_scalar else 0
+        o.data = self.arr.ctypes.data
+        o.validity = self.validity.ctypes.data if self.validity is not None else None
+        o.validity_offset = 0
+        o.buffers = C.cast(self._bufptr, C.c_void_p) if self._bufptr is not None else None
+        o.n_buffers = len(self.buffers) if self.buffers else 0
+        o.precision, o.scale = self.precision, self.scale
+        return o
+
+
+def cols(hcols):
+    return (OCol * len(hcols))(*[h.c() for h in hcols])
+
+
+def i128_array(ints):
+    out = np.zeros((len(ints), 2), dtype=np.uint64)
+    for i, v in enumerate(ints):
+        v = int(v) & ((1 << 128) - 1)
+        out[i, 0], out[i, 1] = v & 0xFFFFFFFFFFFFFFFF, v >> 64
+    return out.reshape(-1)
+
+
+def i128_list(raw):
+    w = np.ascontiguousarray(raw).view(np.uint64).reshape(-1, 2)
+    out = []
+    for lo, hi in w:
+        v = (int(hi) << 64) | int(lo)
+        out.append(v - (1 << 128) if v >> 127 else v)
+    return out
+
+
+def q1_run(host, cutoff, threads=1, block_rows=65536, n=None):
+    """Runs the reference-shaped CPU Q1 (filter -> take -> maps -> partial/final hash-agg)."""
+    L = load()
+    n = len(host["l_quantity"]) if n is None else n
+    res = Q1Result()
+    g = L.orc_q1_run(host["l_quantity"].ctypes.data_as(C.c_void_p), host["l_extendedprice"].ctypes.data_as(C.c_void_p),
+                     host["l_discount"].ctypes.data_as(C.c_void_p), host["l_tax"].ctypes.data_as(C.c_void_p),
+                     host["l_returnflag"].ctypes.data_as(C.c_void_p), host["l_linestatus"].ctypes.data_as(C.c_void_p),
+                     host["l_shipdate"].ctypes.data_as(C.c_void_p), C.c_int32(cutoff), C.c_int64(n), C.c_int(threads),
+                     C.c_int64(block_rows), C.byref(res))
+    assert g >= 0, f"oracle q1 failed: {g}"
+    out = {}
+    for i in range(g):
+        rf = bytes(res.returnflag[i])
+        ls = bytes(res.linestatus[i])
+        rfk = rf[4:4 + int.from_bytes(rf[0:4], "little")]
+        lsk = ls[4:4 + int.from_bytes(ls[0:4], "little")]
+
+        def i128(pair):
+            v = (int(pair[1]) << 64) | int(pair[0])
+            return v - (1 << 128) if v >> 127 else v
+        out[(rfk, lsk)] = dict(sum_qty=res.sum_qty[i], sum_base_price=res.sum_price[i], sum_disc_price=i128(res.sum_disc_price[i]),
+                               sum_charge=i128(res.sum_charge[i]), sum_disc=res.sum_disc[i], count=res.count[i])
+    return out

@@ -1,0 +1,420 @@
+"""GPU: every kernel behind the C-ABI against the oracle on the same seeded inputs (bit-exact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from databend_amd import _lib as T
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+NUMS = [(T.T_I8, np.int8), (T.T_I16, np.int16), (T.T_I32, np.int32), (T.T_I64, np.int64), (T.T_U8, np.uint8),
+        (T.T_U16, np.uint16), (T.T_U32, np.uint32), (T.T_U64, np.uint64), (T.T_F32, np.float32), (T.T_F64, np.float64)]
+
+
+def rand_col(rng, code, npd, n, edge=True):
+    if np.issubdtype(npd, np.integer):
+        info = np.iinfo(npd)
+        a = rng.integers(info.min, info.max, n, dtype=npd, endpoint=True)
+        if edge and n >= 8:
+            a[:4] = [info.min, info.max, 0, info.max]
+            a[4:8] = [0, 1, info.min, 0]
+    else:
+        a = (rng.standard_normal(n) * 1000).astype(npd)
+        if edge and n >= 8:
+            a[:8] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1.5, -2.5, 0.0]
+    return a
+
+
+def same_bits(x, y):
+    return np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 1000, 100_003])
+def test_arith_all_type_pairs(gpu, oracle, n):
+    rng = np.random.default_rng(n + 1)
+    for ta, da in NUMS:
+        for tb, db in NUMS:
+            a, b = rand_col(rng, ta, da, n), rand_col(rng, tb, db, n)
+            if n > 20:
+                b[10:20] = 0  # division by zero rows
+            va = rng.integers(0, 2, n).astype(bool)
+            ga = gpu.Column.from_numpy(a, ta, validity=va)
+            gb = gpu.Column.from_numpy(b, tb)
+            ha, hb = O.HostCol(ta, a, va), O.HostCol(tb, b)
+            for op in range(6):
+                ot = oracle.orc_arith_result_type(op, ta, tb)
+                assert ot == gpu.lib().dbhip_arith_result_type(op, ta, tb)
+                npd = dict(NUMS)[ot]
+                errs = gpu.RowErrors(n)
+                out = gpu.arith(op, ga, gb, n, errors=errs)
+                exp = np.zeros(n, dtype=npd)
+                eb = np.zeros(((n + 31) // 32) * 4 + 8, np.uint8)
+                ec = C.c_uint64(0)
+                ca, cb = ha.c(), hb.c()
+                assert oracle.orc_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), ot, exp.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.byref(ec)) == 0
+                got = out.to_numpy()
+                assert same_bits(got, exp), (op, ta, tb, got[:12], exp[:12])
+                assert errs.num_errors() == ec.value, (op, ta, tb)
+                exp_err = np.nonzero(~np.unpackbits(eb, bitorder="little")[:n].astype(bool))[0]
+                assert np.array_equal(errs.error_rows(), exp_err)
+
+
+def test_scalar_operands(gpu, oracle):
+    n = 1000
+    rng = np.random.default_rng(3)
+    a = rand_col(rng, T.T_I32, np.int32, n)
+    ga, gs = gpu.Column.from_numpy(a, T.T_I32), gpu.Column.scalar(7, T.T_I64)
+    out = gpu.arith(T.OP_MULTIPLY, ga, gs, n).to_numpy()
+    assert np.array_equal(out, a.astype(np.int64) * 7)
+    out = gpu.arith(T.OP_MODULO, ga, gpu.Column.scalar(7, T.T_U8), n).to_numpy()
+    exp = np.fmod(a.astype(np.int64), 7).astype(np.int16)
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("n", [1, 1000, 50_001])
+def test_sum_a_plus_b_mul_c_wrapping(gpu, oracle, n):
+    rng = np.random.default_rng(n)
+    a, b, c = (rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64) for _ in range(3))
+    got = gpu.sum_a_plus_b_mul_c(*(gpu.Column.from_numpy(x) for x in (a, b, c)))
+    exp = oracle.orc_sum_a_plus_b_mul_c_i64(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int64(65536))
+    assert got == exp
+    # un-fused plan (one kernel per call node) gives the same wrapping sum
+    ga, gb, gc = (gpu.Column.from_numpy(x) for x in (a, b, c))
+    t = gpu.arith(T.OP_PLUS, ga, gpu.arith(T.OP_MULTIPLY, gb, gc, n), n)
+    assert gpu.column_sum(t) == exp
+
+
+def dec_cases():
+    # (lhs (type, p, s), rhs (type, p, s), op)
+    D64, D128 = T.T_DEC64, T.T_DEC128
+    cs = []
+    for op in (T.OP_PLUS, T.OP_MINUS, T.OP_MULTIPLY, T.OP_DIVIDE):
+        cs += [((D64, 15, 2), (D64, 15, 2), op), ((D64, 10, 1), (D64, 18, 4), op), ((D64, 18, 6), (D64, 18, 9), op),
+               ((D128, 31, 4), (D64, 16, 2), op), ((D128, 38, 10), (D128, 38, 10), op), ((D128, 30, 12), (D128, 20, 3), op),
+               ((T.T_U8, 0, 0), (D64, 15, 2), op), ((D64, 15, 2), (T.T_I32, 0, 0), op), ((T.T_I64, 0, 0), (D128, 25, 5), op),
+               ((D128, 38, 0), (D64, 18, 18), op)]
+    return cs
+
+
+def rand_dec(rng, spec, n, small=False):
+    t, p, s = spec
+    if t == T.T_DEC64:
+        lim = 10 ** min(p, 18) - 1
+        a = rng.integers(-lim, lim, n, dtype=np.int64, endpoint=True)
+        if small:
+            a = a % 100000
+        a[:3] = [0, lim, -lim][:min(n, 3)] if n >= 3 else a[:3]
+        return a, O.HostCol(t, a, None, p, s)
+    if t == T.T_DEC128:
+        lim = 10 ** p - 1
+        ints = [int(rng.integers(-2**62, 2**62)) * int(rng.integers(1, 2**62)) % (lim + 1) * (1 if rng.integers(0, 2) else -1) for _ in range(n)]
+        if small:
+            ints = [v % 1000003 for v in ints]
+        if n >= 3:
+            ints[:3] = [0, lim, -lim]
+        return ints, O.HostCol(t, O.i128_array(ints), None, p, s)
+    npd = dict(NUMS)[t]
+    a = rand_col(rng, t, npd, n)
+    return a, O.HostCol(t, a)
+
+
+@pytest.mark.parametrize("n", [1, 4097])
+def test_decimal_arith(gpu, oracle, n):
+    rng = np.random.default_rng(11)
+    checked = 0
+    for lhs, rhs, op in dec_cases():
+        for small in (False, True):
+            av, ha = rand_dec(rng, lhs, n, small)
+            bv, hb = rand_dec(rng, rhs, n, small)
+            if op == T.OP_DIVIDE and n > 10:
+                if rhs[0] == T.T_DEC128:
+                    bv[5] = 0
+                    hb = O.HostCol(rhs[0], O.i128_array(bv), None, rhs[1], rhs[2])
+                else:
+                    bv[5] = 0
+            p, s = C.c_int(), C.c_int()
+            props = {T.T_I8: (3, 0), T.T_U8: (3, 0), T.T_I16: (5, 0), T.T_U16: (5, 0), T.T_I32: (10, 0), T.T_U32: (10, 0), T.T_I64: (19, 0), T.T_U64: (20, 0)}
+            ap = lhs[1:] if lhs[0] in (T.T_DEC64, T.T_DEC128) else props[lhs[0]]
+            bp = rhs[1:] if rhs[0] in (T.T_DEC64, T.T_DEC128) else props[rhs[0]]
+            if oracle.orc_decimal_result_size(op, ap[0], ap[1], bp[0], bp[1], C.byref(p), C.byref(s)) != 0:
+                continue
+            ot = T.T_DEC64 if p.value <= 18 else T.T_DEC128
+            exp = np.zeros(n * (2 if ot == T.T_DEC128 else 1), dtype=np.uint64)
+            eb = np.zeros(((n + 31) // 32) * 4 + 8, np.uint8)
+            ec = C.c_uint64(0)
+            ca, cb = ha.c(), hb.c()
+            rc = oracle.orc_decimal_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), ot, p.value, s.value, exp.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.byref(ec))
+            assert rc == 0
+            def gcol(spec, v):
+                if spec[0] == T.T_DEC128:
+                    return gpu.Column.decimal128(v, spec[1], spec[2])
+                return gpu.Column.from_numpy(v, spec[0], precision=spec[1], scale=spec[2])
+            ga, gb = gcol(lhs, av), gcol(rhs, bv)
+            assert gpu.decimal_result_size(op, ga, gb) == (p.value, s.value)
+            errs = gpu.RowErrors(n)
+            out = gpu.decimal_arith(op, ga, gb, n, errors=errs)
+            got = out.data.to_numpy(np.uint64, exp.size)
+            assert np.array_equal(got, exp), (lhs, rhs, op, small)
+            assert errs.num_errors() == ec.value, (lhs, rhs, op, small, errs.num_errors(), ec.value)
+            checked += 1
+    assert checked >= 60
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 33, 4096, 100_001])
+def test_cmp_filter_take(gpu, oracle, n):
+    rng = np.random.default_rng(n + 5)
+    for code, npd in NUMS:
+        a = rand_col(rng, code, npd, n)
+        b = rand_col(rng, code, npd, n)
+        if n > 16:
+            b[8:16] = a[8:16]
+        ga, gb = gpu.Column.from_numpy(a, code), gpu.Column.from_numpy(b, code)
+        ha, hb = O.HostCol(code, a), O.HostCol(code, b)
+        for op in range(6):
+            out = gpu.cmp(op, ga, gb, n)
+            exp = np.zeros((n + 7) // 8 + 8, np.uint8)
+            ca, cb = ha.c(), hb.c()
+            oracle.orc_cmp(op, C.byref(ca), C.byref(cb), C.c_int64(n), exp.ctypes.data_as(C.c_void_p))
+            got = out.data.to_numpy(np.uint8, (n + 7) // 8)
+            assert np.array_equal(got, exp[:(n + 7) // 8]), (code, op)
+    # filter: ascending selection vector, then take on several widths
+    a = rng.integers(0, 100, n).astype(np.int32)
+    pred = gpu.cmp(T.CMP_LTE, gpu.Column.from_numpy(a, T.T_I32), gpu.Column.scalar(37, T.T_I32), n)
+    sel, k = gpu.filter_select(pred)
+    exp_sel = np.nonzero(a <= 37)[0].astype(np.uint32)
+    assert k == len(exp_sel)
+    assert np.array_equal(sel.to_numpy(np.uint32, k), exp_sel)
+    for npd in (np.uint8, np.int16, np.int32, np.int64):
+        src = rng.integers(0, 100, n).astype(npd)
+        got = gpu.take(gpu.Column.from_numpy(src), sel, k).to_numpy()
+        assert np.array_equal(got, src[exp_sel])
+    views = rng.integers(0, 255, (n, 16)).astype(np.uint8)
+    got = gpu.take(gpu.Column(T.T_STRING, n, gpu.DeviceBuffer.from_numpy(views)), sel, k).to_numpy()
+    assert np.array_equal(got, views[exp_sel])
+    bools = rng.integers(0, 2, n).astype(bool)
+    got = gpu.take(gpu.Column.boolean(bools), sel, k).to_numpy()
+    assert np.array_equal(got, bools[exp_sel])
+
+
+def test_cmp_strings_and_decimal128(gpu, oracle):
+    strs = [b"", b"a", b"ab", b"abc", b"abd", b"a" * 12, b"a" * 13, b"a" * 13 + b"b", b"zzzzzzzzzzzzzzzzzzzzzz", b"b"]
+    rng = np.random.default_rng(0)
+    A = [strs[i] for i in rng.integers(0, len(strs), 500)]
+    B = [strs[i] for i in rng.integers(0, len(strs), 500)]
+    ga, gb = gpu.Column.strings(A), gpu.Column.strings(B)
+    for op, f in ((T.CMP_EQ, lambda x, y: x == y), (T.CMP_LT, lambda x, y: x < y), (T.CMP_GTE, lambda x, y: x >= y)):
+        got = gpu.cmp(op, ga, gb, 500).to_numpy()
+        assert got.tolist() == [f(x, y) for x, y in zip(A, B)]
+    ints_a = [int(x) for x in rng.integers(-2**62, 2**62, 300)] + [2**100, -2**100, 0]
+    ints_b = [int(x) for x in rng.integers(-2**62, 2**62, 300)] + [2**100 + 1, -2**100, -1]
+    got = gpu.cmp(T.CMP_LT, gpu.Column.decimal128(ints_a, 38, 0), gpu.Column.decimal128(ints_b, 38, 0), 303).to_numpy()
+    assert got.tolist() == [x < y for x, y in zip(ints_a, ints_b)]
+
+
+def test_group_hash_matches_oracle(gpu, oracle):
+    n = 5000
+    rng = np.random.default_rng(9)
+    cols_np = [(c, rand_col(rng, c, d, n)) for c, d in NUMS]
+    valid = rng.integers(0, 2, n).astype(bool)
+    strs = [bytes(rng.integers(97, 123, int(l)).astype(np.uint8)) for l in rng.integers(0, 30, n)]
+    ints128 = [int(x) * int(y) for x, y in zip(rng.integers(-2**62, 2**62, n), rng.integers(1, 2**60, n))]
+    bools = rng.integers(0, 2, n).astype(bool)
+    gcols = [gpu.Column.from_numpy(a, c, validity=valid if i % 2 else None) for i, (c, a) in enumerate(cols_np)]
+    hcols = [O.HostCol(c, a, valid if i % 2 else None) for i, (c, a) in enumerate(cols_np)]
+    gcols += [gpu.Column.strings(strs), gpu.Column.decimal128(ints128, 38, 0), gpu.Column.boolean(bools),
+              gpu.Column.from_numpy(rng.integers(-10000, 10000, n).astype(np.int32), T.T_DATE)]
+    from databend_amd.device import make_views_general, pack_bits
+    v, buf = make_views_general(strs)
+    hcols += [O.HostCol(T.T_STRING, v, buffers=[buf]), O.HostCol(T.T_DEC128, O.i128_array(ints128)),
+              O.HostCol(T.T_BOOL, pack_bits(bools)), O.HostCol(T.T_DATE, gcols[-1].to_numpy())]
+    for k in (1, 2, len(gcols)):
+        for start in range(0, len(gcols) - k + 1, max(1, k)):
+            got = gpu.group_hash(gcols[start:start + k], n)
+            exp = np.zeros(n, np.uint64)
+            oracle.orc_group_hash(O.cols(hcols[start:start + k]), k, C.c_int64(n), exp.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(got, exp), (start, k)
+
+
+def oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n):
+    kt = (C.c_int32 * len(key_types))(*key_types)
+    kn = (C.c_uint8 * len(key_types))(*key_nullable)
+    ad = (O.OAgg * max(len(aggs), 1))()
+    for i, a in enumerate(aggs):
+        ad[i].kind, ad[i].arg_type, ad[i].arg_precision, ad[i].arg_scale, ad[i].arg_nullable = a
+    oracle.orc_hashagg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    h = C.c_void_p(oracle.orc_hashagg_create(kt, kn, len(key_types), ad, len(aggs)))
+    args = (O.OCol * max(len(aggs), 1))()
+    for i, a in enumerate(hargs):
+        if a is not None:
+            args[i] = a.c()
+    assert oracle.orc_hashagg_add_block(h, O.cols(hkeys), args, C.c_int64(n)) == 0
+    return h
+
+
+def oracle_rows(oracle, h, key_types, aggs):
+    g = oracle.orc_hashagg_num_groups(h)
+    sizes = {T.T_STRING: 16, T.T_DEC128: 16, T.T_BOOL: 1}
+    from databend_amd.device import ELEM_SIZE, NP_OF, view_strings
+    kb = [np.zeros(max(g, 1) * sizes.get(t, ELEM_SIZE.get(t, 8)) + 16, np.uint8) for t in key_types]
+    kv = [np.zeros(max(g, 1) + 8, np.uint8) for _ in key_types]
+    res_t = []
+    for a in aggs:
+        kind, at = a[0], a[1]
+        if kind == T.AGG_COUNT: res_t.append(T.T_U64)
+        elif kind == T.AGG_SUM: res_t.append(T.T_DEC128 if at == T.T_DEC128 else (T.T_F64 if at in (T.T_F32, T.T_F64) else (T.T_U64 if at in (T.T_U8, T.T_U16, T.T_U32, T.T_U64) else T.T_I64)))
+        else: res_t.append(at)
+    ab = [np.zeros(max(g, 1) * 16 + 16, np.uint8) for _ in aggs]
+    kp = (C.c_void_p * len(kb))(*[b.ctypes.data for b in kb])
+    kvp = (C.c_void_p * len(kv))(*[b.ctypes.data for b in kv])
+    ap = (C.c_void_p * max(len(ab), 1))(*[b.ctypes.data for b in ab])
+    oracle.orc_hashagg_result(h, kp, kvp, ap, None)
+    cols = []
+    for t, b, v in zip(key_types, kb, kv):
+        if t == T.T_STRING: vals = view_strings(b[:16 * g])
+        elif t == T.T_DEC128: vals = O.i128_list(b[:16 * g])
+        elif t == T.T_BOOL: vals = [bool(x) for x in b[:g]]
+        else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
+        cols.append([x if ok else None for x, ok in zip(vals, v[:g])])
+    for t, b in zip(res_t, ab):
+        if t == T.T_DEC128: cols.append(O.i128_list(b[:16 * g]))
+        else: cols.append(b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist())
+    return [tuple(c[i] for c in cols) for i in range(g)]
+
+
+def norm(rows):
+    return sorted(rows, key=lambda r: tuple((x is None, str(type(x)), x if x is not None else 0) for x in r))
+
+
+@pytest.mark.parametrize("n,card", [(1, 1), (100, 4), (10_000, 4), (100_000, 1000), (200_000, 150_000)])
+def test_groupby_matches_oracle_as_sorted_sets(gpu, oracle, n, card):
+    """Mirrors tests/it/aggregates/agg_hashtable.rs: several key types incl. NULLs, sum/count/min/max,
+    compared as sorted row sets (assert_block_value_sort_eq)."""
+    rng = np.random.default_rng(n + card)
+    k_i64 = rng.integers(0, card, n).astype(np.int64) - card // 2
+    k_i16 = (rng.integers(0, min(card, 100), n)).astype(np.int16)
+    strs = [b"s%d" % (x % 97) for x in rng.integers(0, card, n)]
+    kvalid = rng.integers(0, 8, n) > 0
+    k_f32 = rng.integers(0, 3, n).astype(np.float32)
+    a_i32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    a_u64 = rng.integers(0, 2**64 - 1, n, dtype=np.uint64)
+    a_dec64 = rng.integers(-10**15, 10**15, n).astype(np.int64)
+    a_dec128 = [int(x) * 10**9 for x in rng.integers(-10**17, 10**17, n)]
+    avalid = rng.integers(0, 4, n) > 0
+    key_types = [T.T_I64, T.T_I16, T.T_STRING, T.T_F32]
+    key_nullable = [1, 0, 0, 0]
+    aggs = [(T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_I32, 0, 0, 1), (T.AGG_SUM, T.T_U64, 0, 0, 0), (T.AGG_SUM, T.T_DEC64, 15, 2, 0),
+            (T.AGG_SUM, T.T_DEC128, 31, 4, 0), (T.AGG_MIN, T.T_I32, 0, 0, 0), (T.AGG_MAX, T.T_U64, 0, 0, 0), (T.AGG_COUNT, T.T_I32, 0, 0, 1),
+            (T.AGG_MAX, T.T_F32, 0, 0, 0)]
+    gkeys = [gpu.Column.from_numpy(k_i64, validity=kvalid), gpu.Column.from_numpy(k_i16), gpu.Column.strings(strs), gpu.Column.from_numpy(k_f32)]
+    gargs = [None, gpu.Column.from_numpy(a_i32, validity=avalid), gpu.Column.from_numpy(a_u64), gpu.Column.from_numpy(a_dec64, T.T_DEC64, precision=15, scale=2),
+             gpu.Column.decimal128(a_dec128, 31, 4), gpu.Column.from_numpy(a_i32), gpu.Column.from_numpy(a_u64), gpu.Column.from_numpy(a_i32, validity=avalid),
+             gpu.Column.from_numpy(k_f32)]
+    from databend_amd.device import make_views_general
+    v, buf = make_views_general(strs)
+    hkeys = [O.HostCol(T.T_I64, k_i64, kvalid), O.HostCol(T.T_I16, k_i16), O.HostCol(T.T_STRING, v, buffers=[buf]), O.HostCol(T.T_F32, k_f32)]
+    hargs = [None, O.HostCol(T.T_I32, a_i32, avalid), O.HostCol(T.T_U64, a_u64), O.HostCol(T.T_DEC64, a_dec64, None, 15, 2),
+             O.HostCol(T.T_DEC128, O.i128_array(a_dec128), None, 31, 4), O.HostCol(T.T_I32, a_i32), O.HostCol(T.T_U64, a_u64), O.HostCol(T.T_I32, a_i32, avalid),
+             O.HostCol(T.T_F32, k_f32)]
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    half = n // 2
+    # two blocks (exercises growth between blocks) on the GPU
+    if half:
+        def sl(c, lo, hi):
+            arr = c.to_numpy()[lo:hi] if c.dtype != T.T_DEC128 else None
+            return c
+        g.add_block(gkeys, gargs, n)  # whole block
+    else:
+        g.add_block(gkeys, gargs, n)
+    got = g.result()
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n)
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert g.num_groups() == len(exp)
+    assert norm(got) == norm(exp)
+
+
+def test_groupby_forced_hash_collisions(gpu, oracle):
+    """hash_index/index.rs:385-404 tests full tag collisions; here distinct keys are forced onto the same
+    probe hash so the verify+retry path runs."""
+    n = 3000
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 40, n).astype(np.int64)
+    a = rng.integers(-1000, 1000, n).astype(np.int64)
+    g = gpu.GroupBy([T.T_I64], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)], capacity=4096)
+    g.debug_set_hash_mask(0x3)
+    g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None], n)
+    g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None], n)
+    got = sorted(g.result())
+    exp = sorted((int(key), int(2 * a[k == key].sum()), int(2 * (k == key).sum())) for key in np.unique(k))
+    assert got == exp
+
+
+def test_groupby_serialized_roundtrip_and_merge(gpu):
+    """flush_serialized -> merge_serialized into another table == combine_payload (aggregate_hashtable.rs:349-380)."""
+    n = 50_000
+    rng = np.random.default_rng(6)
+    k = rng.integers(0, 500, n).astype(np.int32)
+    a = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    spec = ([T.T_I32], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 0)])
+    g1, g2, gall = gpu.GroupBy(*spec), gpu.GroupBy(*spec), gpu.GroupBy(*spec)
+    g1.add_block([gpu.Column.from_numpy(k[:n // 2])], [gpu.Column.from_numpy(a[:n // 2]), None, gpu.Column.from_numpy(a[:n // 2])], n // 2)
+    g2.add_block([gpu.Column.from_numpy(k[n // 2:])], [gpu.Column.from_numpy(a[n // 2:]), None, gpu.Column.from_numpy(a[n // 2:])], n - n // 2)
+    gall.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None, gpu.Column.from_numpy(a)], n)
+    g1.merge_serialized(g2.flush_serialized())
+    assert sorted(g1.result()) == sorted(gall.result())
+    exp = sorted((int(key), int(a[k == key].sum()), int((k == key).sum()), int(a[k == key].min())) for key in np.unique(k))
+    assert sorted(gall.result()) == exp
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 1000, 300_007])
+def test_q1_fused_and_operator_plans_match_oracle(gpu, oracle, n):
+    from databend_amd import tpch
+    host = tpch.gen_lineitem(n, seed=n)
+    exp = O.q1_run(host, tpch.Q1_CUTOFF, threads=2, block_rows=4096)
+    li = tpch.LineitemDevice(host)
+    fused = tpch.q1_rows(tpch.q1_fused(li))
+    assert fused == exp
+    plan = tpch.q1_rows(tpch.q1_operator_at_a_time(li))
+    assert plan == exp
+
+
+def test_q1_wrapping_and_extreme_values(gpu, oracle):
+    """Full-range i64 columns: every intermediate wraps exactly like the reference's release build."""
+    from databend_amd import tpch
+    n = 20_000
+    rng = np.random.default_rng(1)
+    host = tpch.gen_lineitem(n, seed=1)
+    for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"):
+        host[k] = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    exp = O.q1_run(host, tpch.Q1_CUTOFF, threads=1)
+    li = tpch.LineitemDevice(host)
+    assert tpch.q1_rows(tpch.q1_fused(li)) == exp
+    assert tpch.q1_rows(tpch.q1_operator_at_a_time(li)) == exp
+
+
+def test_q1_fused_capacity_fallback(gpu, oracle):
+    """More than 8 distinct groups inside a workgroup: the fused kernel refuses (DBHIP_ERR_CAPACITY) and the
+    operator-at-a-time plan gives the oracle's answer."""
+    from databend_amd import tpch
+    from databend_amd._lib import DbhipError, ERR_CAPACITY
+    n = 5000
+    host = tpch.gen_lineitem(n, seed=3)
+    rng = np.random.default_rng(3)
+    host["l_returnflag"][:, 4] = rng.integers(65, 91, n)  # 26 flags x 2 statuses
+    li = tpch.LineitemDevice(host)
+    with pytest.raises(DbhipError) as e:
+        tpch.q1_fused(li)
+    assert e.value.code == ERR_CAPACITY
+    assert tpch.q1_rows(tpch.q1_operator_at_a_time(li)) == O.q1_run(host, tpch.Q1_CUTOFF)
+
+
+def test_q1_finalize_avg_matches_sf_style_golden_shape(gpu, oracle):
+    """avg = sum / count through the decimal divide kernel: Decimal(18,2)/UInt64 -> Decimal(24,8), round half
+    away from zero (tests/sqllogictests/suites/tpch/queries.test:52-56 prints 8 fractional digits)."""
+    from databend_amd import tpch
+    rows = {(b"A", b"F"): dict(sum_qty=3773410700, sum_base_price=5658655440073, sum_disc_price=0, sum_charge=0, sum_disc=7390266, count=1478493)}
+    out = tpch.q1_finalize(rows)
+    # 37734107.00 / 1478493 = 25.52200585 ; 56586554400.73 / 1478493 = 38273.12973462 (SF1 golden row A,F)
+    assert out[0][6] == 2552200585 and out[0][7] == 3827312973462

@@ -1,0 +1,180 @@
+"""CPU: the oracle (C restatement) against the reference's golden vectors and closed forms."""
+import ctypes as C
+import json
+import os
+import re
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+from databend_amd import _lib as T
+from tests import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NUM = {"Int8": (T.T_I8, np.int8), "Int16": (T.T_I16, np.int16), "Int32": (T.T_I32, np.int32), "Int64": (T.T_I64, np.int64),
+       "UInt8": (T.T_U8, np.uint8), "UInt16": (T.T_U16, np.uint16), "UInt32": (T.T_U32, np.uint32), "UInt64": (T.T_U64, np.uint64),
+       "Float32": (T.T_F32, np.float32), "Float64": (T.T_F64, np.float64)}
+OPS = {"plus": T.OP_PLUS, "minus": T.OP_MINUS, "multiply": T.OP_MULTIPLY, "divide": T.OP_DIVIDE, "div": T.OP_INTDIV, "modulo": T.OP_MODULO}
+CMPS = {"eq": T.CMP_EQ, "noteq": T.CMP_NOTEQ, "lt": T.CMP_LT, "lte": T.CMP_LTE, "gt": T.CMP_GT, "gte": T.CMP_GTE}
+
+
+def parse_type(t):
+    t = t.replace(" NULL", "").strip()
+    m = re.fullmatch(r"Decimal\((\d+), (\d+)\)", t)
+    if m:
+        return ("dec", int(m.group(1)), int(m.group(2)))
+    return ("num", t) if t in NUM else ("other", t)
+
+
+def host_col(entry):
+    kind = parse_type(entry["type"])
+    if kind[0] == "num":
+        code, npd = NUM[kind[1]]
+        vals = [float(v) if isinstance(v, str) else v for v in entry["values"]]
+        return O.HostCol(code, np.array(vals, dtype=npd), entry.get("validity"))
+    if kind[0] == "dec" and kind[1] <= 38:
+        p, s = kind[1], kind[2]
+        ints = [int(Decimal(str(v)).scaleb(s)) for v in entry["values"]]
+        if entry["kind"] == "Decimal64":
+            return O.HostCol(T.T_DEC64, np.array(ints, dtype=np.int64), entry.get("validity"), p, s)
+        if entry["kind"] == "Decimal128":
+            return O.HostCol(T.T_DEC128, O.i128_array(ints), entry.get("validity"), p, s)
+    return None
+
+
+def simple_binary(expr):
+    """name<...>(x, y) with x,y plain column names -> (name, x, y) else None."""
+    m = re.fullmatch(r"(\w+)<.*>\((\w+), (\w+)\)", expr)
+    return m.groups() if m else None
+
+
+def golden(name):
+    return json.load(open(os.path.join(HERE, "golden", name)))["cases"]
+
+
+def test_arithmetic_golden_numeric_and_decimal():
+    L = O.load()
+    checked = 0
+    for case in golden("arithmetic.json"):
+        sb = simple_binary(case["expr"])
+        if not sb or sb[0] not in OPS:
+            continue
+        name, x, y = sb
+        cols = case["columns"]
+        if x not in cols or y not in cols:
+            continue
+        a, b = host_col(cols[x]), host_col(cols[y])
+        outc = cols["Output"]
+        ok = parse_type(outc["type"])
+        if a is None or b is None:
+            continue
+        n = case["n"]
+        err = np.zeros(((n + 31) // 32) * 4, dtype=np.uint8)
+        ca, cb = a.c(), b.c()
+        if ok[0] == "num" and parse_type(cols[x]["type"])[0] == "num" and parse_type(cols[y]["type"])[0] == "num":
+            code, npd = NUM[ok[1]]
+            assert L.orc_arith_result_type(OPS[name], a.dtype, b.dtype) == code, case["ast"]
+            out = np.zeros(n, dtype=npd)
+            assert L.orc_arith(OPS[name], C.byref(ca), C.byref(cb), C.c_int64(n), code, out.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p), None) == 0
+            exp = np.array([float(v) if isinstance(v, str) else v for v in outc["values"]], dtype=npd)
+            valid = np.array(outc.get("validity", [True] * n))
+            assert np.array_equal(out[valid], exp[valid]), (case["ast"], out, exp)
+            checked += 1
+        elif ok[0] == "dec" and ok[1] <= 38:
+            p, s = C.c_int(), C.c_int()
+            ap = (a.precision, a.scale) if a.dtype in (T.T_DEC64, T.T_DEC128) else {1: 3, 2: 5, 4: 10, 8: 19}[a.arr.itemsize] and ({T.T_I8: 3, T.T_U8: 3, T.T_I16: 5, T.T_U16: 5, T.T_I32: 10, T.T_U32: 10, T.T_I64: 19, T.T_U64: 20}[a.dtype], 0)
+            bp = (b.precision, b.scale) if b.dtype in (T.T_DEC64, T.T_DEC128) else ({T.T_I8: 3, T.T_U8: 3, T.T_I16: 5, T.T_U16: 5, T.T_I32: 10, T.T_U32: 10, T.T_I64: 19, T.T_U64: 20}[b.dtype], 0)
+            if a.dtype in (T.T_F32, T.T_F64) or b.dtype in (T.T_F32, T.T_F64):
+                continue
+            assert L.orc_decimal_result_size(OPS[name], ap[0], ap[1], bp[0], bp[1], C.byref(p), C.byref(s)) == 0
+            assert (p.value, s.value) == (ok[1], ok[2]), (case["ast"], p.value, s.value)
+            ot = T.T_DEC64 if p.value <= 18 else T.T_DEC128
+            out = np.zeros(n * (2 if ot == T.T_DEC128 else 1), dtype=np.uint64)
+            assert L.orc_decimal_arith(OPS[name], C.byref(ca), C.byref(cb), C.c_int64(n), ot, p.value, s.value, out.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p), None) == 0
+            got = O.i128_list(out) if ot == T.T_DEC128 else out.view(np.int64).tolist()
+            exp = [int(Decimal(str(v)).scaleb(ok[2])) for v in outc["values"]]
+            valid = outc.get("validity", [True] * n)
+            assert [g for g, v in zip(got, valid) if v] == [e for e, v in zip(exp, valid) if v], (case["ast"], got, exp)
+            checked += 1
+    assert checked >= 20, checked
+
+
+def test_comparison_golden():
+    L = O.load()
+    checked = 0
+    for case in golden("comparison.json"):
+        sb = simple_binary(case["expr"])
+        if not sb or sb[0] not in CMPS:
+            continue
+        name, x, y = sb
+        cols = case["columns"]
+        if x not in cols or y not in cols:
+            continue
+        a, b = host_col(cols[x]), host_col(cols[y])
+        if a is None or b is None or a.dtype != b.dtype:
+            continue
+        n = case["n"]
+        out = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+        ca, cb = a.c(), b.c()
+        assert L.orc_cmp(CMPS[name], C.byref(ca), C.byref(cb), C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
+        got = np.unpackbits(out, bitorder="little")[:n].astype(bool).tolist()
+        assert got == cols["Output"]["values"], case["ast"]
+        checked += 1
+    assert checked >= 2, checked
+
+
+def test_q1_oracle_matches_closed_form():
+    from databend_amd import tpch
+    h = tpch.gen_lineitem(100_000, seed=7)
+    r = O.q1_run(h, tpch.Q1_CUTOFF, threads=2, block_rows=8192)
+    m = h["l_shipdate"] <= tpch.Q1_CUTOFF
+    rf, ls = h["l_returnflag"][:, 4], h["l_linestatus"][:, 4]
+    exp = {}
+    for a in b"ANR":
+        for b in b"FO":
+            s = m & (rf == a) & (ls == b)
+            if not s.any():
+                continue
+            p, d, tx = (h[k][s].astype(object) for k in ("l_extendedprice", "l_discount", "l_tax"))
+            dp = p * (100 - d)
+            exp[(bytes([a]), bytes([b]))] = dict(sum_qty=int(h["l_quantity"][s].sum()), sum_base_price=int(p.sum()),
+                                                  sum_disc_price=int(dp.sum()), sum_charge=int((dp * (100 + tx)).sum()),
+                                                  sum_disc=int(d.sum()), count=int(s.sum()))
+    assert r == exp
+    assert (b"N", b"F") in r  # the rare group exists
+
+
+def test_group_hash_relative_properties():
+    """Ports the reference's own (relative) hash tests, group_hash.rs:665-908: a constant column hashes like
+    a full column, multi-column combine is h*NULL_HASH ^ h2, NULL rows hash to NULL_HASH_VAL."""
+    L = O.load()
+    n = 100
+    rng = np.random.default_rng(1)
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    b = rng.integers(0, 2**60, n).astype(np.uint64)
+    valid = rng.integers(0, 2, n).astype(bool)
+    ca, cb = O.HostCol(T.T_I32, a), O.HostCol(T.T_U64, b, valid)
+    h1 = np.zeros(n, np.uint64); h2 = np.zeros(n, np.uint64); h12 = np.zeros(n, np.uint64)
+    L.orc_group_hash(O.cols([ca]), 1, C.c_int64(n), h1.ctypes.data_as(C.c_void_p))
+    L.orc_group_hash(O.cols([cb]), 1, C.c_int64(n), h2.ctypes.data_as(C.c_void_p))
+    L.orc_group_hash(O.cols([ca, cb]), 2, C.c_int64(n), h12.ctypes.data_as(C.c_void_p))
+    NULLH = 0xd1cefa08eb382d69
+    assert all(int(h2[i]) == NULLH for i in range(n) if not valid[i])
+    for i in range(n):
+        assert int(h12[i]) == ((int(h1[i]) * NULLH) ^ int(h2[i])) & (2**64 - 1)
+        assert int(h1[i]) == L.orc_agg_hash_u64(C.c_uint64(int(a[i]) & (2**64 - 1)))
+    # const column == repeated column
+    cc = O.HostCol(T.T_I32, np.array([a[3]], np.int32), is_scalar=True)
+    hc = np.zeros(n, np.uint64)
+    L.orc_group_hash(O.cols([cc]), 1, C.c_int64(n), hc.ctypes.data_as(C.c_void_p))
+    assert (hc == h1[3]).all()
+    # bytes hash: tail is folded big-endian-ordered (the reference's deviation from Murmur64A)
+    s = b"abc"
+    M, SEED = 0xc6a4a7935bd1e995, 0xe17a1465
+    mask = 2**64 - 1
+    h = (SEED ^ (3 * M)) & mask
+    h ^= (s[0] << 16) | (s[1] << 8) | s[2]
+    h ^= h >> 47; h = (h * M) & mask; h ^= h >> 47
+    buf = np.frombuffer(s, np.uint8).copy()
+    assert L.orc_agg_hash_bytes(buf.ctypes.data_as(C.c_void_p), C.c_uint64(3)) == h
