@@ -64,19 +64,16 @@ def main():
     li = tpch.LineitemDevice(host)
     g = D.GroupBy.q1()
 
-    stream = C.c_void_p()
-    check(L.dbhip_stream_create(C.byref(stream)))
-    ev = [C.c_void_p() for _ in range(2 * (args.steps + 1))]
-    for e in ev:
-        check(L.dbhip_event_create(C.byref(e)))
+    stream = None  # the library's own stream (every dbhip call of a step is ordered on it)
+    kms = []
 
-    def step(record=None):
+    def step(record=False):
         g.reset()
-        if record is not None:
-            check(L.dbhip_event_record(record[0], stream))
         D.q1_fused(g, li.qty, li.price, li.disc, li.tax, li.rf, li.ls, li.ship, tpch.Q1_CUTOFF, stream=stream)
-        if record is not None:
-            check(L.dbhip_event_record(record[1], stream))
+        if record:
+            ms = C.c_float()
+            check(L.dbhip_last_kernel_ms(C.byref(ms)))  # HIP events around q1_fused_kernel on its stream
+            kms.append(ms.value)
         if world > 1:
             DX.exchange_partials_nccl(g, dist, torch)
         return g
@@ -89,7 +86,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step((ev[2 * i], ev[2 * i + 1]))
+        step(True)
     check(L.dbhip_stream_sync(stream))
     torch.cuda.synchronize()
     if world > 1:
@@ -100,12 +97,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-launch region of the dominant kernel (q1_fused_kernel + its tiny merge), HIP events on its stream
-    kms = []
-    for i in range(args.steps):
-        ms = C.c_float()
-        check(L.dbhip_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
-        kms.append(ms.value)
+    # average launch duration of the dominant kernel (q1_fused_kernel), HIP events on its stream
     kernel_ms = float(np.mean(kms)) if kms else 0.0
 
     rows_total = n * world * args.steps

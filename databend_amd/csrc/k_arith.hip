@@ -375,8 +375,10 @@ int32_t dbhip_sum_a_plus_b_mul_c_i64(const int64_t* a, const int64_t* b, const i
   if (n == 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
   int grid = grid_for(ceil_div(n, 8), 256);
+  kernel_timer_start(s);
   hipLaunchKernelGGL(sum_abc_kernel, dim3(grid), dim3(256), 0, s, a, b, c, n,
                      (unsigned long long*)out_sum_dev);
+  kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }

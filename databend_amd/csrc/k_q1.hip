@@ -352,7 +352,9 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   A.rf = (const U4*)l_returnflag_views; A.ls = (const U4*)l_linestatus_views;
   A.shipdate = l_shipdate; A.cutoff = shipdate_cutoff; A.n = n;
   A.partial_rows = partial; A.ctrl = ctrl;
+  kernel_timer_start(s);
   hipLaunchKernelGGL(q1_fused_kernel, dim3(grid), dim3(256), 0, s, A);
+  kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
   uint64_t host_ctrl[2];
   DBHIP_CHECK(hipMemcpyAsync(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost, s));

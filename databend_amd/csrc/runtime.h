@@ -16,6 +16,10 @@ int32_t hip_fail(hipError_t e, const char* what);
 // the same thread; callers must not hold it across dbhip calls).
 void* scratch(size_t bytes, int slot);
 
+// HIP-event bracket around the dominant kernel of a call (dbhip_last_kernel_ms).
+void kernel_timer_start(hipStream_t s);
+void kernel_timer_stop(hipStream_t s);
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid for HBM-bound grid-stride kernels: enough workgroups to fill 256 CUs

@@ -57,6 +57,23 @@ void* scratch(size_t bytes, int slot) {
   return s.p;
 }
 
+static thread_local hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+static thread_local bool g_timed = false;
+
+void kernel_timer_start(hipStream_t s) {
+  if (!g_t0) {
+    if (hipEventCreate(&g_t0) != hipSuccess || hipEventCreate(&g_t1) != hipSuccess) { g_t0 = g_t1 = nullptr; return; }
+  }
+  (void)hipEventRecord(g_t0, s);
+  g_timed = false;
+}
+
+void kernel_timer_stop(hipStream_t s) {
+  if (!g_t1) return;
+  (void)hipEventRecord(g_t1, s);
+  g_timed = true;
+}
+
 }  // namespace dbhip
 
 using namespace dbhip;
@@ -173,6 +190,14 @@ int32_t dbhip_event_record(void* event, void* stream) {
 int32_t dbhip_event_elapsed_ms(void* start, void* stop, float* out_ms) {
   DBHIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
   DBHIP_CHECK(hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_last_kernel_ms(float* out_ms) {
+  DBHIP_REQUIRE(out_ms, "dbhip_last_kernel_ms: NULL out");
+  DBHIP_REQUIRE(g_timed, "dbhip_last_kernel_ms: no timed kernel was launched on this thread");
+  DBHIP_CHECK(hipEventSynchronize(g_t1));
+  DBHIP_CHECK(hipEventElapsedTime(out_ms, g_t0, g_t1));
   return DBHIP_OK;
 }
 

@@ -115,6 +115,10 @@ int32_t dbhip_event_create(void** out_event_host);
 int32_t dbhip_event_record(void* event, void* stream);
 int32_t dbhip_event_elapsed_ms(void* start, void* stop, float* out_ms_host);
 int32_t dbhip_event_destroy(void* event);
+/* Duration (HIP events on the launch stream) of the dominant kernel launched by the
+ * most recent dbhip_q1_fused / dbhip_sum_a_plus_b_mul_c_i64 / dbhip_vec_topk call of
+ * this thread — the figure bench.py's `roofline.achieved` is computed from. */
+int32_t dbhip_last_kernel_ms(float* out_ms_host);
 
 /* ---- a2/a3: numeric arithmetic -------------------------------------------
  * Replaces the closures registered by register_plus/minus/multiply/divide/div/modulo
