@@ -1038,7 +1038,7 @@ int orc_q1_run(const int64_t* qty, const int64_t* price, const int64_t* disc, co
   int rc = ws[0].rc;
   for (int t = 1; t < threads; ++t) { int e = orc_hashagg_combine(fin, ws[t].ht); if (e) rc = e; if (ws[t].rc) rc = ws[t].rc; orc_hashagg_destroy(ws[t].ht); }
   int64_t g = orc_hashagg_num_groups(fin);
-  if (g > 16) { orc_hashagg_destroy(fin); free(ws); free(th); return -1; }
+  if (g > 64) { orc_hashagg_destroy(fin); free(ws); free(th); return -1; }
   memset(out, 0, sizeof(*out));
   void* keys[2] = {out->returnflag, out->linestatus};
   void* aggs[6] = {out->sum_qty, out->sum_price, out->sum_disc_price, out->sum_charge, out->sum_disc, out->count};

@@ -22,10 +22,10 @@ class OAgg(C.Structure):
 
 
 class Q1Result(C.Structure):
-    _fields_ = [("returnflag", (C.c_uint8 * 16) * 16), ("linestatus", (C.c_uint8 * 16) * 16),
-                ("sum_qty", C.c_int64 * 16), ("sum_price", C.c_int64 * 16), ("sum_disc", C.c_int64 * 16),
-                ("sum_disc_price", (C.c_uint64 * 2) * 16), ("sum_charge", (C.c_uint64 * 2) * 16),
-                ("count", C.c_uint64 * 16)]
+    _fields_ = [("returnflag", (C.c_uint8 * 16) * 64), ("linestatus", (C.c_uint8 * 16) * 64),
+                ("sum_qty", C.c_int64 * 64), ("sum_price", C.c_int64 * 64), ("sum_disc", C.c_int64 * 64),
+                ("sum_disc_price", (C.c_uint64 * 2) * 64), ("sum_charge", (C.c_uint64 * 2) * 64),
+                ("count", C.c_uint64 * 64)]
 
 
 def load():
@@ -109,6 +109,8 @@ def q1_run(host, cutoff, threads=1, block_rows=65536, n=None):
                      host["l_returnflag"].ctypes.data_as(C.c_void_p), host["l_linestatus"].ctypes.data_as(C.c_void_p),
                      host["l_shipdate"].ctypes.data_as(C.c_void_p), C.c_int32(cutoff), C.c_int64(n), C.c_int(threads),
                      C.c_int64(block_rows), C.byref(res))
+    if g == -105:
+        raise OverflowError("Decimal overflow in the reference-shaped CPU path (aggregate_sum.rs:203-216)")
     assert g >= 0, f"oracle q1 failed: {g}"
     out = {}
     for i in range(g):

@@ -28,7 +28,15 @@ def rand_col(rng, code, npd, n, edge=True):
 
 
 def same_bits(x, y):
-    return np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+    """Bit-exact, except that any NaN equals any NaN (Rust leaves NaN sign/payload of an arithmetic
+    result unspecified; x86 `subsd` and gfx950 `v_add_f64 -y` differ in the propagated sign)."""
+    x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+    if x.dtype.kind == "f":
+        nx, ny = np.isnan(x), np.isnan(y)
+        if not np.array_equal(nx, ny):
+            return False
+        x, y = np.where(nx, 0, x), np.where(ny, 0, y)
+    return np.array_equal(x.view(np.uint8), y.view(np.uint8))
 
 
 @pytest.mark.parametrize("n", [0, 1, 7, 1000, 100_003])
@@ -386,12 +394,32 @@ def test_q1_wrapping_and_extreme_values(gpu, oracle):
     n = 20_000
     rng = np.random.default_rng(1)
     host = tpch.gen_lineitem(n, seed=1)
-    for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"):
-        host[k] = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    host["l_quantity"] = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)     # i64 sums wrap silently
+    host["l_discount"] = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)     # 100 - d wraps
+    host["l_extendedprice"] = rng.integers(-2**40, 2**40, n, dtype=np.int64)
+    host["l_tax"] = rng.integers(-2**7, 2**7, n, dtype=np.int64)
     exp = O.q1_run(host, tpch.Q1_CUTOFF, threads=1)
     li = tpch.LineitemDevice(host)
     assert tpch.q1_rows(tpch.q1_fused(li)) == exp
     assert tpch.q1_rows(tpch.q1_operator_at_a_time(li)) == exp
+
+
+def test_q1_decimal_sum_overflow_is_an_error(gpu, oracle):
+    """DecimalSumState<true, i128> leaves [DECIMAL_MIN, DECIMAL_MAX] -> Overflow error in the reference
+    (aggregate_sum.rs:203-216); the device table reports DBHIP_ERR_OVERFLOW at merge_result."""
+    from databend_amd import tpch
+    from databend_amd._lib import DbhipError, ERR_OVERFLOW
+    n = 4096
+    host = tpch.gen_lineitem(n, seed=1)
+    host["l_extendedprice"][:] = 2**62
+    host["l_discount"][:] = -(2**62)
+    with pytest.raises(OverflowError):
+        O.q1_run(host, tpch.Q1_CUTOFF, threads=1)
+    li = tpch.LineitemDevice(host)
+    for plan in (tpch.q1_fused, tpch.q1_operator_at_a_time):
+        with pytest.raises(DbhipError) as e:
+            tpch.q1_rows(plan(li))
+        assert e.value.code == ERR_OVERFLOW
 
 
 def test_q1_fused_capacity_fallback(gpu, oracle):
