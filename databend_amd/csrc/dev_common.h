@@ -140,6 +140,23 @@ __device__ __forceinline__ u128 wave_sum_u128(u128 v) {
   return v;
 }
 
+// exact 192-bit wave sum: returns the low 128 bits, *ext accumulates bits 128..191
+__device__ __forceinline__ u128 wave_sum_u192(u128 v, uint64_t* ext) {
+  uint64_t e = *ext;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint64_t lo = __shfl_xor((uint64_t)v, off, 64);
+    uint64_t hi = __shfl_xor((uint64_t)(v >> 64), off, 64);
+    uint64_t oe = __shfl_xor(e, off, 64);
+    u128 o = ((u128)hi << 64) | lo;
+    u128 r = v + o;
+    e += oe + (r < v ? 1 : 0);
+    v = r;
+  }
+  *ext = e;
+  return v;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // ---------------------------------------------------------------------------

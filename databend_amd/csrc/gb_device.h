@@ -120,6 +120,20 @@ __device__ __forceinline__ void atomic_add_u128(uint64_t* p, uint64_t lo, uint64
   if (addhi) atomicAdd((unsigned long long*)(p + 1), (unsigned long long)addhi);
 }
 
+// 192-bit add (lo, hi, ext) with global atomics; every carry is observed by exactly one adder.
+__device__ __forceinline__ void atomic_add_u192(uint64_t* p, uint64_t lo, uint64_t hi, uint64_t ext) {
+  unsigned long long old = atomicAdd((unsigned long long*)p, (unsigned long long)lo);
+  uint64_t c1 = ((uint64_t)old + lo) < lo ? 1 : 0;
+  uint64_t addhi = hi + c1;
+  uint64_t c2 = addhi < hi ? 1 : 0;
+  if (addhi) {
+    unsigned long long oh = atomicAdd((unsigned long long*)(p + 1), (unsigned long long)addhi);
+    c2 |= ((uint64_t)oh + addhi) < addhi ? 1 : 0;
+  }
+  uint64_t addext = ext + c2;
+  if (addext) atomicAdd((unsigned long long*)(p + 2), (unsigned long long)addext);
+}
+
 // merge one state contribution `v` (agg_words words) into the state at `dst`
 __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64_t* dst,
                                                 const uint64_t* v) {
@@ -128,8 +142,8 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
       if (v[0]) atomicAdd((unsigned long long*)dst, (unsigned long long)v[0]);
       break;
     case DBHIP_AGG_SUM:
-      if (L.agg_words[a] == 2) {
-        if (v[0] | v[1]) atomic_add_u128(dst, v[0], v[1]);
+      if (L.agg_words[a] == 3) {
+        if (v[0] | v[1] | v[2]) atomic_add_u192(dst, v[0], v[1], v[2]);
       } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
         atomicAdd((double*)dst, __longlong_as_double((long long)v[0]));
       } else if (v[0]) {

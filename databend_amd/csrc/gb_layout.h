@@ -14,7 +14,10 @@
 //   COUNT                : 1 word u64
 //   SUM int/dec64        : 1 word (wrapping i64/u64)        (aggregate_sum.rs:113-129,203-216)
 //   SUM f32/f64          : 1 word f64
-//   SUM dec128           : 2 words (wrapping i128; overflow is checked at merge_result)
+//   SUM dec128           : 3 words (lo, hi, ext) = exact 192-bit two's complement sum, so that
+//                          "left [DECIMAL_MIN, DECIMAL_MAX]" is decided on the exact total
+//                          (aggregate_sum.rs:203-216 checks the running sum; for same-signed
+//                          inputs the two coincide)
 //   MIN/MAX              : 2 words [order-preserving key][has value]
 // The same row is the unit of exchange between ranks (serialized partial state).
 #pragma once

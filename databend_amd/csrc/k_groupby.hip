@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
           if (L.agg_type[a] == DBHIP_T_F32)
             w[0] = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)w[0]));
           s[0] = valid ? w[0] : 0;
-          if (L.agg_words[a] == 2) s[1] = valid ? w[1] : 0;
+          if (L.agg_words[a] == 3) {
+            s[1] = valid ? w[1] : 0;
+            s[2] = (valid && (w[1] >> 63)) ? ~0ULL : 0;  // sign extension to 192 bits
+          }
           break;
         default:  // MIN / MAX
           s[0] = ord_encode(w[0], L.agg_type[a]);
@@ -260,16 +263,27 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
       uint64_t* d = rows + (uint64_t)lpos * L.W;
       for (int a = 0; a < L.naggs; ++a) {
         const uint64_t* v = r + L.agg_off[a];
-        uint64_t out[2] = {0, 0};
+        uint64_t out[3] = {0, 0, 0};
         switch (L.agg_kind[a]) {
           case DBHIP_AGG_COUNT:
             out[0] = wave_sum_u64(mine ? v[0] : 0);
             break;
           case DBHIP_AGG_SUM:
-            if (L.agg_words[a] == 2) {
-              u128 t = wave_sum_u128(mine ? (((u128)v[1] << 64) | v[0]) : (u128)0);
+            if (L.agg_words[a] == 3) {
+              u128 t = mine ? (((u128)v[1] << 64) | v[0]) : (u128)0;
+              uint64_t e = mine ? v[2] : 0;
+#pragma unroll
+              for (int off = 32; off >= 1; off >>= 1) {
+                uint64_t olo = __shfl_xor((uint64_t)t, off, 64), ohi = __shfl_xor((uint64_t)(t >> 64), off, 64);
+                uint64_t oe = __shfl_xor(e, off, 64);
+                u128 o = ((u128)ohi << 64) | olo;
+                u128 r = t + o;
+                e += oe + (r < t ? 1 : 0);
+                t = r;
+              }
               out[0] = (uint64_t)t;
               out[1] = (uint64_t)(t >> 64);
+              out[2] = e;
             } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
               out[0] = (uint64_t)__double_as_longlong(
                   wave_sum_f64(mine ? __longlong_as_double((long long)v[0]) : 0.0));
@@ -430,12 +444,14 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           ((uint64_t*)o)[i] = s[0];
           break;
         case DBHIP_AGG_SUM:
-          if (L.agg_words[a] == 2) {
+          if (L.agg_words[a] == 3) {
             i128 v = (i128)(((u128)s[1] << 64) | s[0]);
             // DecimalSumState<true,_>::add (aggregate_sum.rs:203-216): outside
-            // [DECIMAL_MIN, DECIMAL_MAX] is an Overflow error
+            // [DECIMAL_MIN, DECIMAL_MAX] is an Overflow error. Decided on the exact
+            // 192-bit total: ext must be the sign extension of the low 128 bits.
             i128 mx = pow10_i128(38) - 1;
-            if (L.agg_precision[a] > 18 && (v > mx || v < -mx)) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
+            bool fits128 = s[2] == ((s[1] >> 63) ? ~0ULL : 0ULL);
+            if (L.agg_precision[a] > 18 && (!fits128 || v > mx || v < -mx)) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
             ((uint64_t*)o)[2 * i] = s[0];
             ((uint64_t*)o)[2 * i + 1] = s[1];
           } else {
@@ -501,7 +517,7 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
     switch (d.kind) {
       case DBHIP_AGG_COUNT: break;
       case DBHIP_AGG_SUM:
-        if (d.arg_type == DBHIP_T_DEC128) words = 2;
+        if (d.arg_type == DBHIP_T_DEC128) words = 3;
         else if (!(d.arg_type >= DBHIP_T_I8 && d.arg_type <= DBHIP_T_F64) && d.arg_type != DBHIP_T_DEC64) {
           set_error("groupby: sum() does not support type %d", d.arg_type);
           return DBHIP_ERR_INVALID;

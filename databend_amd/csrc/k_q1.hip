@@ -41,11 +41,12 @@ namespace {
 constexpr int SLOTS = 8;
 constexpr uint64_t TAB_EMPTY = 0;
 constexpr uint64_t TAB_LOCK = 1;
-constexpr int Q1_W = 13;  // words per row of the Q1 table layout (see dbhip_q1_create_groupby)
+constexpr int Q1_W = 15;  // words per row of the Q1 table layout (see dbhip_q1_create_groupby)
 
 struct Q1Acc {
   uint64_t qty, price, disc;
   u128 dp, ch;
+  int32_t dp_ext, ch_ext;  // bits 128.. of the exact sums (per lane an i32 is ample)
   uint32_t cnt;
 };
 
@@ -175,8 +176,12 @@ __device__ __forceinline__ void acc_row(Q1Acc acc[SLOTS], int slot, bool pass, i
     acc[g].qty += m ? (uint64_t)qty : 0;
     acc[g].price += m ? (uint64_t)price : 0;
     acc[g].disc += m ? (uint64_t)disc : 0;
-    acc[g].dp += m ? (u128)dp : (u128)0;
-    acc[g].ch += m ? (u128)ch : (u128)0;
+    u128 vdp = m ? (u128)dp : (u128)0, vch = m ? (u128)ch : (u128)0;
+    u128 ndp = acc[g].dp + vdp, nch = acc[g].ch + vch;
+    acc[g].dp_ext += (int32_t)(ndp < vdp) - (int32_t)(m && dp < 0);
+    acc[g].ch_ext += (int32_t)(nch < vch) - (int32_t)(m && ch < 0);
+    acc[g].dp = ndp;
+    acc[g].ch = nch;
     acc[g].cnt += m ? 1u : 0u;
   }
 }
@@ -197,7 +202,7 @@ struct Q1Args {
 
 __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
   __shared__ KeyTable T;
-  __shared__ uint64_t red[4][SLOTS][9];
+  __shared__ uint64_t red[4][SLOTS][10];
   if (threadIdx.x < SLOTS) T.hash[threadIdx.x] = TAB_EMPTY;
   __syncthreads();
 
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
 #pragma unroll
   for (int g = 0; g < SLOTS; ++g) {
     acc[g].qty = 0; acc[g].price = 0; acc[g].disc = 0; acc[g].dp = 0; acc[g].ch = 0; acc[g].cnt = 0;
+    acc[g].dp_ext = 0; acc[g].ch_ext = 0;
   }
   uint32_t flags = 0;
   const int lane = lane_id();
@@ -264,14 +270,16 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
     uint64_t a0 = wave_sum_u64(acc[g].qty);
     uint64_t a1 = wave_sum_u64(acc[g].price);
     uint64_t a2 = wave_sum_u64(acc[g].disc);
-    u128 a3 = wave_sum_u128(acc[g].dp);
-    u128 a4 = wave_sum_u128(acc[g].ch);
+    uint64_t e3 = (uint64_t)(int64_t)acc[g].dp_ext, e4 = (uint64_t)(int64_t)acc[g].ch_ext;
+    u128 a3 = wave_sum_u192(acc[g].dp, &e3);
+    u128 a4 = wave_sum_u192(acc[g].ch, &e4);
     uint64_t a5 = wave_sum_u64((uint64_t)acc[g].cnt);
     if (lane == 0) {
       red[wave][g][0] = a0; red[wave][g][1] = a1; red[wave][g][2] = a2;
       red[wave][g][3] = (uint64_t)a3; red[wave][g][4] = (uint64_t)(a3 >> 64);
       red[wave][g][5] = (uint64_t)a4; red[wave][g][6] = (uint64_t)(a4 >> 64);
       red[wave][g][7] = a5;
+      red[wave][g][8] = e3; red[wave][g][9] = e4;
     }
   }
   flags = (uint32_t)wave_sum_u64((uint64_t)((flags & 1) | ((flags & 2) << 15)));  // counts per flag
@@ -280,24 +288,26 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
   __syncthreads();
   if (threadIdx.x < SLOTS) {
     const int g = threadIdx.x;
-    uint64_t qty = 0, price = 0, disc = 0, cnt = 0;
+    uint64_t qty = 0, price = 0, disc = 0, cnt = 0, dpe = 0, che = 0;
     u128 dp = 0, ch = 0;
     for (int w = 0; w < 4; ++w) {
       qty += red[w][g][0]; price += red[w][g][1]; disc += red[w][g][2];
-      dp += ((u128)red[w][g][4] << 64) | red[w][g][3];
-      ch += ((u128)red[w][g][6] << 64) | red[w][g][5];
+      u128 vdp = ((u128)red[w][g][4] << 64) | red[w][g][3];
+      u128 vch = ((u128)red[w][g][6] << 64) | red[w][g][5];
+      dp += vdp; dpe += red[w][g][8] + (dp < vdp ? 1 : 0);
+      ch += vch; che += red[w][g][9] + (ch < vch ? 1 : 0);
       cnt += red[w][g][7];
     }
     if (T.hash[g] > TAB_LOCK && cnt != 0) {
       unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[0], 1ULL);
       uint64_t* r = A.partial_rows + idx * Q1_W;
-      // table layout: [rf view 2w][ls view 2w][hash][sum_qty][sum_price][sum_dp 2w][sum_ch 2w][sum_disc][count]
+      // table layout: [rf view 2w][ls view 2w][hash][sum_qty][sum_price][sum_dp 3w][sum_ch 3w][sum_disc][count]
       r[0] = T.key[g][0]; r[1] = T.key[g][1]; r[2] = T.key[g][2]; r[3] = T.key[g][3];
       r[4] = T.real_hash[g];
       r[5] = qty; r[6] = price;
-      r[7] = (uint64_t)dp; r[8] = (uint64_t)(dp >> 64);
-      r[9] = (uint64_t)ch; r[10] = (uint64_t)(ch >> 64);
-      r[11] = disc; r[12] = cnt;
+      r[7] = (uint64_t)dp; r[8] = (uint64_t)(dp >> 64); r[9] = dpe;
+      r[10] = (uint64_t)ch; r[11] = (uint64_t)(ch >> 64); r[12] = che;
+      r[13] = disc; r[14] = cnt;
     }
   }
 }
@@ -328,7 +338,7 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   const GbLayout* L = dbhip_groupby_layout_internal(g);
   bool layout_ok = L->nkeys == 2 && L->naggs == 6 && L->W == Q1_W && L->key_type[0] == DBHIP_T_STRING &&
                    L->key_type[1] == DBHIP_T_STRING && L->agg_off[0] == 5 && L->agg_off[2] == 7 &&
-                   L->agg_off[5] == 12 && L->agg_words[2] == 2 && L->agg_words[3] == 2;
+                   L->agg_off[5] == 14 && L->agg_words[2] == 3 && L->agg_words[3] == 3;
   DBHIP_REQUIRE(layout_ok, "dbhip_q1_fused: table was not created by dbhip_q1_create_groupby");
   if (n == 0) return DBHIP_OK;
   DBHIP_REQUIRE(l_quantity && l_extendedprice && l_discount && l_tax && l_returnflag_views &&
