@@ -38,17 +38,8 @@ const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
 
 namespace {
 
-constexpr int SLOTS = 8;
-constexpr uint64_t TAB_EMPTY = 0;
-constexpr uint64_t TAB_LOCK = 1;
+constexpr int MAX_SLOTS = 8;
 constexpr int Q1_W = 15;  // words per row of the Q1 table layout (see dbhip_q1_create_groupby)
-
-struct Q1Acc {
-  uint64_t qty, price, disc;
-  u128 dp, ch;
-  int32_t dp_ext, ch_ext;  // bits 128.. of the exact sums (per lane an i32 is ample)
-  uint32_t cnt;
-};
 
 struct alignas(16) U4 {
   uint32_t x, y, z, w;
@@ -60,130 +51,107 @@ struct alignas(8) I2 {
   int32_t a, b;
 };
 
+// Per-block key table in LDS: append-only array of the distinct group keys seen by the
+// block. Readers scan entries [0, count); a writer appends under `lock` and publishes
+// by bumping `count` after a workgroup fence, so a reader never sees a half-written key.
 struct KeyTable {
-  uint64_t hash[SLOTS];     // TAB_EMPTY / TAB_LOCK / remapped hash
-  uint64_t real_hash[SLOTS];
-  uint64_t key[SLOTS][4];
+  uint32_t count;
+  uint32_t lock;
+  uint64_t key[MAX_SLOTS][4];
 };
-
-__device__ __forceinline__ uint64_t tab_word(uint64_t h) { return h <= TAB_LOCK ? h + 2 : h; }
 
 // canonical words of an inline view (bytes past len zeroed), false if len > 12
 __device__ __forceinline__ bool view_words(U4 v, uint64_t w[2]) {
   uint32_t len = v.x;
-  if (len > 12) return false;
   uint32_t d1 = v.y, d2 = v.z, d3 = v.w;
-  if (len < 4) { d1 &= (len == 0) ? 0u : (0xffffffffu >> (8 * (4 - len))); d2 = 0; d3 = 0; }
-  else if (len < 8) { d2 &= (len == 4) ? 0u : (0xffffffffu >> (8 * (8 - len))); d3 = 0; }
-  else if (len < 12) { d3 &= (len == 8) ? 0u : (0xffffffffu >> (8 * (12 - len))); }
-  w[0] = ((uint64_t)d1 << 32) | len;
-  w[1] = ((uint64_t)d3 << 32) | d2;
-  return true;
+  uint32_t m1 = len >= 4 ? 0xffffffffu : (len == 0 ? 0u : (0xffffffffu >> (8 * (4 - len))));
+  uint32_t m2 = len >= 8 ? 0xffffffffu : (len <= 4 ? 0u : (0xffffffffu >> (8 * (8 - len))));
+  uint32_t m3 = len >= 12 ? 0xffffffffu : (len <= 8 ? 0u : (0xffffffffu >> (8 * (12 - len))));
+  w[0] = ((uint64_t)(d1 & m1) << 32) | len;
+  w[1] = ((uint64_t)(d3 & m3) << 32) | (d2 & m2);
+  return len <= 12;
 }
 
 __device__ __forceinline__ uint64_t hash_view_words(const uint64_t w[2]) {
   return agg_hash_inline_view((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
 }
 
-// fast path: read-only probe of the block's key table. Returns slot or -1.
-__device__ __forceinline__ int tab_lookup(volatile KeyTable* T, uint64_t hq, const uint64_t k[4]) {
-#pragma unroll
-  for (int p = 0; p < SLOTS; ++p) {
-    int s = (int)((hq + p) & (SLOTS - 1));
-    uint64_t th = T->hash[s];
-    if (th == hq && T->key[s][0] == k[0] && T->key[s][1] == k[1] && T->key[s][2] == k[2] &&
-        T->key[s][3] == k[3])
-      return s;
-    if (th == TAB_EMPTY || th == TAB_LOCK) return -1;
-  }
-  return -1;
-}
-
-// slow path, executed by ONE lane of a wave at a time: find or insert.
-// Returns slot, or -1 when the table is full.
-__device__ int tab_insert(KeyTable* T, uint64_t hq, uint64_t h, const uint64_t k[4]) {
-  for (int p = 0; p < SLOTS; ++p) {
-    int s = (int)((hq + p) & (SLOTS - 1));
-    while (true) {
-      unsigned long long old = atomicCAS((unsigned long long*)&T->hash[s], (unsigned long long)TAB_EMPTY,
-                                         (unsigned long long)TAB_LOCK);
-      if (old == TAB_EMPTY) {
-        T->key[s][0] = k[0]; T->key[s][1] = k[1]; T->key[s][2] = k[2]; T->key[s][3] = k[3];
-        T->real_hash[s] = h;
-        __threadfence_block();
-        atomicExch((unsigned long long*)&T->hash[s], (unsigned long long)hq);
-        return s;
-      }
-      if (old == TAB_LOCK) {  // another wave is publishing this slot
-        __builtin_amdgcn_s_sleep(1);
-        continue;
-      }
-      if (old == hq) {
-        volatile KeyTable* V = T;
-        if (V->key[s][0] == k[0] && V->key[s][1] == k[1] && V->key[s][2] == k[2] && V->key[s][3] == k[3])
-          return s;
-      }
-      break;  // occupied by another key: next slot
-    }
-  }
-  return -1;
-}
-
-// resolve the slot of one key row (wave-convergent call)
-__device__ __forceinline__ int resolve_slot(KeyTable* T, bool row_valid, U4 v0, U4 v1, uint32_t* flags) {
-  uint64_t k[4];
-  bool ok0 = view_words(v0, k);
-  bool ok1 = view_words(v1, k + 2);
-  bool ok = ok0 && ok1;
-  if (row_valid && !ok) *flags |= 2;
-  bool want = row_valid && ok;
-  uint64_t h = 0, hq = 0;
+// slow path, ONE lane of a wave at a time: find or append under the lock. -1 when full.
+template <int SLOTS>
+__device__ __forceinline__ int tab_insert(KeyTable* T, uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3) {
+  while (atomicCAS(&T->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+  volatile KeyTable* V = T;
+  uint32_t nk = V->count;
   int slot = -1;
-  if (want) {
-    h = merge_hash(hash_view_words(k), hash_view_words(k + 2));
-    hq = tab_word(h);
-    slot = tab_lookup((volatile KeyTable*)T, hq, k);
+  for (uint32_t s = 0; s < nk; ++s)
+    if (V->key[s][0] == k0 && V->key[s][1] == k1 && V->key[s][2] == k2 && V->key[s][3] == k3) slot = (int)s;
+  if (slot < 0 && nk < (uint32_t)SLOTS) {
+    V->key[nk][0] = k0; V->key[nk][1] = k1; V->key[nk][2] = k2; V->key[nk][3] = k3;
+    __threadfence_block();
+    V->count = nk + 1;
+    slot = (int)nk;
   }
-  uint64_t miss = __ballot(want && slot < 0);
-  while (miss) {
-    int leader = __ffsll((long long)miss) - 1;
-    uint64_t lk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) lk[j] = __shfl(k[j], leader, 64);
-    int ls = -1;
-    if (lane_id() == leader) {
-      ls = tab_insert(T, hq, h, k);
-      if (ls < 0) *flags |= 1;
-    }
-    ls = __shfl(ls, leader, 64);
-    bool same = want && slot < 0 && k[0] == lk[0] && k[1] == lk[1] && k[2] == lk[2] && k[3] == lk[3];
-    if (same) slot = ls >= 0 ? ls : 0xE;  // 0xE: dropped (table full), flagged above
-    miss &= ~__ballot(same);
-  }
-  return (slot < 0) ? 0xF : slot;  // 0xF: row not valid
+  __threadfence_block();
+  atomicExch(&T->lock, 0u);
+  return slot;
 }
 
-__device__ __forceinline__ void acc_row(Q1Acc acc[SLOTS], int slot, bool pass, int64_t qty, int64_t price,
-                                        int64_t disc, int64_t tax) {
-  // decimal maps (see header): all plain wrapping integer ops
-  int64_t one_minus_disc = (int64_t)(100ULL - (uint64_t)disc);
-  int64_t one_plus_tax = (int64_t)(100ULL + (uint64_t)tax);
-  i128 dp = (i128)price * (i128)one_minus_disc;
-  i128 ch = (i128)((u128)dp * (u128)(i128)one_plus_tax);
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Wave-private, scalar-register copy of the published part of the block's key table.
+template <int SLOTS>
+struct TabCache {
+  uint32_t nk;
+  uint64_t k[SLOTS][4];
+  __device__ __forceinline__ void refresh(KeyTable* T) {
+    volatile KeyTable* V = T;
+    nk = __builtin_amdgcn_readfirstlane(V->count);
 #pragma unroll
-  for (int g = 0; g < SLOTS; ++g) {
-    bool m = pass && slot == g;
-    acc[g].qty += m ? (uint64_t)qty : 0;
-    acc[g].price += m ? (uint64_t)price : 0;
-    acc[g].disc += m ? (uint64_t)disc : 0;
-    u128 vdp = m ? (u128)dp : (u128)0, vch = m ? (u128)ch : (u128)0;
-    u128 ndp = acc[g].dp + vdp, nch = acc[g].ch + vch;
-    acc[g].dp_ext += (int32_t)(ndp < vdp) - (int32_t)(m && dp < 0);
-    acc[g].ch_ext += (int32_t)(nch < vch) - (int32_t)(m && ch < 0);
-    acc[g].dp = ndp;
-    acc[g].ch = nch;
-    acc[g].cnt += m ? 1u : 0u;
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[s][j] = uniform_u64(V->key[s][j]);
   }
+  // branch-free compare against every published entry; -1 if absent
+  __device__ __forceinline__ int lookup(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3) const {
+    int slot = -1;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      bool eq = ((uint32_t)s < nk) & (k[s][0] == k0) & (k[s][1] == k1) & (k[s][2] == k2) & (k[s][3] == k3);
+      slot = eq ? s : slot;
+    }
+    return slot;
+  }
+};
+
+// resolve the slot of one key row (wave-convergent call). 0xF = row not valid, 0xE = dropped.
+template <int SLOTS>
+__device__ __forceinline__ int resolve_slot(KeyTable* T, TabCache<SLOTS>& C, bool row_valid, U4 v0, U4 v1,
+                                            uint32_t& flags) {
+  uint64_t ka[2], kb[2];
+  bool ok = view_words(v0, ka) & view_words(v1, kb);
+  flags |= (row_valid & !ok) ? 2u : 0u;
+  const bool want = row_valid & ok;
+  int slot = C.lookup(ka[0], ka[1], kb[0], kb[1]);
+  slot = want ? slot : 0xF;
+  uint64_t miss = __ballot(slot < 0);
+  while (miss) {  // rare: a key this wave has not seen published yet
+    const int leader = __ffsll((long long)miss) - 1;
+    if (lane_id() == leader) {
+      int ls = tab_insert<SLOTS>(T, ka[0], ka[1], kb[0], kb[1]);
+      if (ls < 0) flags |= 1u;
+    }
+    C.refresh(T);
+    int again = C.lookup(ka[0], ka[1], kb[0], kb[1]);
+    // after the leader's insert its key is published (or the table is full)
+    const bool full = C.nk >= (uint32_t)SLOTS;
+    if (slot < 0) slot = again >= 0 ? again : (full ? 0xE : -1);
+    miss = __ballot(slot < 0);
+  }
+  return slot;
 }
 
 struct Q1Args {
@@ -200,18 +168,59 @@ struct Q1Args {
   uint64_t* ctrl;          // [0] = #partial rows, [1] = flags (1: table full, 2: long string)
 };
 
-__global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
-  __shared__ KeyTable T;
-  __shared__ uint64_t red[4][SLOTS][10];
-  if (threadIdx.x < SLOTS) T.hash[threadIdx.x] = TAB_EMPTY;
-  __syncthreads();
+// per-lane register accumulators, one set per slot (static indexing only)
+template <int SLOTS>
+struct Q1Regs {
+  uint64_t qty[SLOTS], price[SLOTS], disc[SLOTS];
+  uint64_t dpl[SLOTS], dph[SLOTS], chl[SLOTS], chh[SLOTS];
+  int32_t dpe[SLOTS], che[SLOTS];  // bits 128.. of the exact sums (per lane an i32 is ample)
+  uint32_t cnt[SLOTS];
+};
 
-  Q1Acc acc[SLOTS];
+template <int SLOTS>
+__device__ __forceinline__ void acc_row(Q1Regs<SLOTS>& R, int slot, int64_t qty, int64_t price, int64_t disc,
+                                        int64_t tax) {
+  // decimal maps (see header): all plain wrapping integer ops
+  const int64_t one_minus_disc = (int64_t)(100ULL - (uint64_t)disc);
+  const int64_t one_plus_tax = (int64_t)(100ULL + (uint64_t)tax);
+  const i128 dp = (i128)price * (i128)one_minus_disc;
+  const i128 ch = (i128)((u128)dp * (u128)(i128)one_plus_tax);
+  const uint64_t dpl = (uint64_t)(u128)dp, dph = (uint64_t)((u128)dp >> 64);
+  const uint64_t chl = (uint64_t)(u128)ch, chh = (uint64_t)((u128)ch >> 64);
+  const int32_t dpn = (int32_t)(dph >> 63), chn = (int32_t)(chh >> 63);
 #pragma unroll
   for (int g = 0; g < SLOTS; ++g) {
-    acc[g].qty = 0; acc[g].price = 0; acc[g].disc = 0; acc[g].dp = 0; acc[g].ch = 0; acc[g].cnt = 0;
-    acc[g].dp_ext = 0; acc[g].ch_ext = 0;
+    if (slot == g) {  // divergent branch: adds only, skipped when no lane of the wave has the slot
+      R.qty[g] += (uint64_t)qty;
+      R.price[g] += (uint64_t)price;
+      R.disc[g] += (uint64_t)disc;
+      u128 a = (((u128)R.dph[g] << 64) | R.dpl[g]) + (((u128)dph << 64) | dpl);
+      u128 b = (((u128)R.chh[g] << 64) | R.chl[g]) + (((u128)chh << 64) | chl);
+      R.dpe[g] += (int32_t)((uint64_t)(a >> 64) < dph || ((uint64_t)(a >> 64) == dph && (uint64_t)a < dpl)) - dpn;
+      R.che[g] += (int32_t)((uint64_t)(b >> 64) < chh || ((uint64_t)(b >> 64) == chh && (uint64_t)b < chl)) - chn;
+      R.dpl[g] = (uint64_t)a; R.dph[g] = (uint64_t)(a >> 64);
+      R.chl[g] = (uint64_t)b; R.chh[g] = (uint64_t)(b >> 64);
+      R.cnt[g] += 1u;
+    }
   }
+}
+
+template <int SLOTS>
+__device__ __forceinline__ void q1_body(const Q1Args& A) {
+  __shared__ KeyTable T;
+  __shared__ uint64_t red[4][SLOTS][10];
+  if (threadIdx.x == 0) { T.count = 0; T.lock = 0; }
+  if (threadIdx.x < MAX_SLOTS * 4) T.key[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+  __syncthreads();
+
+  Q1Regs<SLOTS> R;
+#pragma unroll
+  for (int g = 0; g < SLOTS; ++g) {
+    R.qty[g] = 0; R.price[g] = 0; R.disc[g] = 0; R.dpl[g] = 0; R.dph[g] = 0; R.chl[g] = 0; R.chh[g] = 0;
+    R.dpe[g] = 0; R.che[g] = 0; R.cnt[g] = 0;
+  }
+  TabCache<SLOTS> C;
+  C.refresh(&T);
   uint32_t flags = 0;
   const int lane = lane_id();
   const int64_t ntiles = (A.n + 127) >> 7;
@@ -247,33 +256,35 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
       x.a = A.tax[c0]; x.b = A.tax[c1];
       sd.a = A.shipdate[c0]; sd.b = A.shipdate[c1];
     }
+    // another wave of the block may have published new keys: pick them up (uniform, rare)
+    if (__builtin_amdgcn_readfirstlane(((volatile KeyTable*)&T)->count) != C.nk) C.refresh(&T);
     // ---- keys -> slots (key layout) ----
-    int slotA = resolve_slot(&T, ra < A.n, rfA, lsA, &flags);
-    int slotB = resolve_slot(&T, rb < A.n, rfB, lsB, &flags);
+    const int slotA = resolve_slot<SLOTS>(&T, C, ra < A.n, rfA, lsA, flags);
+    const int slotB = resolve_slot<SLOTS>(&T, C, rb < A.n, rfB, lsB, flags);
     // ---- move slot ids to the value layout ----
-    int packed = slotA | (slotB << 8);
-    int g0 = __shfl(packed, (2 * lane) & 63, 64);
-    int g1 = __shfl(packed, (2 * lane + 1) & 63, 64);
-    int s0 = (lane < 32 ? g0 : (g0 >> 8)) & 0xFF;
-    int s1 = (lane < 32 ? g1 : (g1 >> 8)) & 0xFF;
+    const int packed = slotA | (slotB << 8);
+    const int g0 = __shfl(packed, (2 * lane) & 63, 64);
+    const int g1 = __shfl(packed, (2 * lane + 1) & 63, 64);
+    const int s0 = (lane < 32 ? g0 : (g0 >> 8)) & 0xFF;
+    const int s1 = (lane < 32 ? g1 : (g1 >> 8)) & 0xFF;
     // ---- filter + maps + accumulate ----
-    bool pass0 = r0 < A.n && sd.a <= A.cutoff;
-    bool pass1 = r1 < A.n && sd.b <= A.cutoff;
-    acc_row(acc, s0, pass0, q.a, p.a, d.a, x.a);
-    acc_row(acc, s1, pass1, q.b, p.b, d.b, x.b);
+    const bool pass0 = r0 < A.n && sd.a <= A.cutoff;
+    const bool pass1 = r1 < A.n && sd.b <= A.cutoff;
+    acc_row<SLOTS>(R, pass0 ? s0 : 0xF, q.a, p.a, d.a, x.a);
+    acc_row<SLOTS>(R, pass1 ? s1 : 0xF, q.b, p.b, d.b, x.b);
   }
 
   // ---- wave reduce, then block combine ----
   const int wave = threadIdx.x >> 6;
 #pragma unroll
   for (int g = 0; g < SLOTS; ++g) {
-    uint64_t a0 = wave_sum_u64(acc[g].qty);
-    uint64_t a1 = wave_sum_u64(acc[g].price);
-    uint64_t a2 = wave_sum_u64(acc[g].disc);
-    uint64_t e3 = (uint64_t)(int64_t)acc[g].dp_ext, e4 = (uint64_t)(int64_t)acc[g].ch_ext;
-    u128 a3 = wave_sum_u192(acc[g].dp, &e3);
-    u128 a4 = wave_sum_u192(acc[g].ch, &e4);
-    uint64_t a5 = wave_sum_u64((uint64_t)acc[g].cnt);
+    uint64_t a0 = wave_sum_u64(R.qty[g]);
+    uint64_t a1 = wave_sum_u64(R.price[g]);
+    uint64_t a2 = wave_sum_u64(R.disc[g]);
+    uint64_t e3 = (uint64_t)(int64_t)R.dpe[g], e4 = (uint64_t)(int64_t)R.che[g];
+    u128 a3 = wave_sum_u192(((u128)R.dph[g] << 64) | R.dpl[g], &e3);
+    u128 a4 = wave_sum_u192(((u128)R.chh[g] << 64) | R.chl[g], &e4);
+    uint64_t a5 = wave_sum_u64((uint64_t)R.cnt[g]);
     if (lane == 0) {
       red[wave][g][0] = a0; red[wave][g][1] = a1; red[wave][g][2] = a2;
       red[wave][g][3] = (uint64_t)a3; red[wave][g][4] = (uint64_t)(a3 >> 64);
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
   if (lane == 0 && flags) atomicOr((unsigned long long*)&A.ctrl[1],
                                    (unsigned long long)(((flags & 0xFFFF) ? 1 : 0) | ((flags >> 16) ? 2 : 0)));
   __syncthreads();
-  if (threadIdx.x < SLOTS) {
+  if (threadIdx.x < SLOTS && threadIdx.x < T.count) {
     const int g = threadIdx.x;
     uint64_t qty = 0, price = 0, disc = 0, cnt = 0, dpe = 0, che = 0;
     u128 dp = 0, ch = 0;
@@ -298,12 +309,13 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
       ch += vch; che += red[w][g][9] + (ch < vch ? 1 : 0);
       cnt += red[w][g][7];
     }
-    if (T.hash[g] > TAB_LOCK && cnt != 0) {
+    if (cnt != 0) {  // a key seen only in filtered-out rows creates no group
       unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[0], 1ULL);
       uint64_t* r = A.partial_rows + idx * Q1_W;
       // table layout: [rf view 2w][ls view 2w][hash][sum_qty][sum_price][sum_dp 3w][sum_ch 3w][sum_disc][count]
-      r[0] = T.key[g][0]; r[1] = T.key[g][1]; r[2] = T.key[g][2]; r[3] = T.key[g][3];
-      r[4] = T.real_hash[g];
+      uint64_t k[4] = {T.key[g][0], T.key[g][1], T.key[g][2], T.key[g][3]};
+      r[0] = k[0]; r[1] = k[1]; r[2] = k[2]; r[3] = k[3];
+      r[4] = merge_hash(hash_view_words(k), hash_view_words(k + 2));  // group_hash_entries, 2 string columns
       r[5] = qty; r[6] = price;
       r[7] = (uint64_t)dp; r[8] = (uint64_t)(dp >> 64); r[9] = dpe;
       r[10] = (uint64_t)ch; r[11] = (uint64_t)(ch >> 64); r[12] = che;
@@ -311,6 +323,9 @@ __global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) {
     }
   }
 }
+
+__global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) { q1_body<4>(A); }
+__global__ __launch_bounds__(256, 1) void q1_fused_kernel_8slots(Q1Args A) { q1_body<8>(A); }
 
 }  // namespace
 
@@ -351,30 +366,38 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   hipStream_t s = resolve_stream(stream);
   const int64_t ntiles = ceil_div(n, 128);
   int grid = (int)(ceil_div(ntiles, 4) < 2048 ? ceil_div(ntiles, 4) : 2048);
-  size_t rows_bytes = (size_t)grid * SLOTS * Q1_W * 8;
+  size_t rows_bytes = (size_t)grid * MAX_SLOTS * Q1_W * 8;
   uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 4);
   if (!ws) return DBHIP_ERR_HIP;
   uint64_t* ctrl = (uint64_t*)ws;
   uint64_t* partial = (uint64_t*)(ws + 64);
-  DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
   Q1Args A;
   A.qty = l_quantity; A.price = l_extendedprice; A.disc = l_discount; A.tax = l_tax;
   A.rf = (const U4*)l_returnflag_views; A.ls = (const U4*)l_linestatus_views;
   A.shipdate = l_shipdate; A.cutoff = shipdate_cutoff; A.n = n;
   A.partial_rows = partial; A.ctrl = ctrl;
-  kernel_timer_start(s);
-  hipLaunchKernelGGL(q1_fused_kernel, dim3(grid), dim3(256), 0, s, A);
-  kernel_timer_stop(s);
-  DBHIP_LAUNCH_CHECK();
-  uint64_t host_ctrl[2];
-  DBHIP_CHECK(hipMemcpyAsync(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
+  uint64_t host_ctrl[2] = {0, 0};
+  // Adaptive slot count (the device analogue of the reference's table growth): the 4-slot
+  // variant keeps every accumulator in registers at 4 waves/SIMD; a block that meets a 5th
+  // distinct key flags it and the pass is redone with 8 slots; beyond that the caller uses
+  // the operator-at-a-time kernels.
+  for (int variant = 0; variant < 2; ++variant) {
+    DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
+    kernel_timer_start(s);
+    if (variant == 0) hipLaunchKernelGGL(q1_fused_kernel, dim3(grid), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(q1_fused_kernel_8slots, dim3(grid), dim3(256), 0, s, A);
+    kernel_timer_stop(s);
+    DBHIP_LAUNCH_CHECK();
+    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    if (!(host_ctrl[1] & 1)) break;
+  }
   if (host_ctrl[1] & 2) {
     set_error("dbhip_q1_fused: a group key string is longer than 12 bytes; use the operator-at-a-time path");
     return DBHIP_ERR_UNSUPPORTED;
   }
   if (host_ctrl[1] & 1) {
-    set_error("dbhip_q1_fused: more than %d distinct groups inside one workgroup; use the operator-at-a-time path", SLOTS);
+    set_error("dbhip_q1_fused: more than %d distinct groups inside one workgroup; use the operator-at-a-time path", MAX_SLOTS);
     return DBHIP_ERR_CAPACITY;
   }
   return dbhip_groupby_merge_rows_internal(g, partial, (int64_t)host_ctrl[0], s);
