@@ -493,3 +493,90 @@ def q1_fused(g, qty, price, disc, tax, rf, ls, shipdate, cutoff, n=None, stream=
     check(lib().dbhip_q1_fused(g.h, C.c_void_p(qty.data.ptr), C.c_void_p(price.data.ptr), C.c_void_p(disc.data.ptr),
                                C.c_void_p(tax.data.ptr), C.c_void_p(rf.data.ptr), C.c_void_p(ls.data.ptr),
                                C.c_void_p(shipdate.data.ptr), C.c_int32(cutoff), C.c_int64(n), stream))
+
+
+class HashJoin:
+    """Device inner hash join on KeysU64 (dbhip_join_*; trait Join, new_hash_join/join.rs:26-53)."""
+
+    def __init__(self, expected_build_rows=1024):
+        _ensure()
+        self.h = C.c_void_p()
+        check(lib().dbhip_join_create(C.c_int64(expected_build_rows), C.byref(self.h)))
+
+    def add_block(self, keys_col):
+        """Join::add_block: one build chunk (u64 key column, optional validity)."""
+        v = C.c_void_p(keys_col.validity.ptr) if keys_col.validity is not None else None
+        check(lib().dbhip_join_add_build(self.h, C.c_void_p(keys_col.data.ptr), v, C.c_int64(keys_col.n), None))
+
+    def final_build(self):
+        check(lib().dbhip_join_finalize(self.h, None))
+
+    def probe_block(self, keys_col):
+        """-> (probe_idx u32[], build_row u32[]) sorted by (probe_idx, build_row)."""
+        v = C.c_void_p(keys_col.validity.ptr) if keys_col.validity is not None else None
+        total = C.c_uint64()
+        check(lib().dbhip_join_probe_count(self.h, C.c_void_p(keys_col.data.ptr), v, C.c_int64(keys_col.n), C.byref(total), None))
+        m = total.value
+        op, ob = DeviceBuffer(max(m, 1) * 4), DeviceBuffer(max(m, 1) * 4)
+        got = C.c_uint64()
+        check(lib().dbhip_join_probe(self.h, C.c_void_p(keys_col.data.ptr), v, C.c_int64(keys_col.n), C.c_void_p(op.ptr),
+                                     C.c_void_p(ob.ptr), C.c_int64(m), C.byref(got), None))
+        assert got.value == m
+        return op.to_numpy(np.uint32, m), ob.to_numpy(np.uint32, m)
+
+    def destroy(self):
+        if self.h:
+            lib().dbhip_join_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def sort_perm(cols, desc=None, nulls_first=None, limit=0):
+    """DataBlock::sort permutation (kernels/sort.rs:91-113) -> u32 row ids."""
+    n = cols[0].n
+    desc = desc or [0] * len(cols)
+    nulls_first = nulls_first or [0] * len(cols)
+    arr = _cols(cols)
+    d = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in desc])
+    nf = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in nulls_first])
+    m = limit if 0 < limit < n else n
+    out = DeviceBuffer(max(m, 1) * 4)
+    check(lib().dbhip_sort_perm(arr, d, nf, len(cols), C.c_int64(n), C.c_int64(limit), C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.uint32, m)
+
+
+class VectorColumn:
+    """Flat row-major f32 vectors in HBM (VectorColumn::Float32, types/vector.rs:377-380)."""
+
+    def __init__(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        self.n, self.dim = arr.shape
+        self.data = DeviceBuffer.from_numpy(arr.reshape(-1))
+
+
+def vec_distance(metric, base, queries):
+    out = DeviceBuffer(max(base.n * queries.n, 1) * 4)
+    check(lib().dbhip_vec_distance(metric, C.c_void_p(base.data.ptr), C.c_int64(base.n), base.dim, C.c_void_p(queries.data.ptr),
+                                   queries.n, C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.float32, base.n * queries.n).reshape(queries.n, base.n)
+
+
+def vec_topk(metric, base, queries, k):
+    oi, od = DeviceBuffer(max(queries.n * k, 1) * 4), DeviceBuffer(max(queries.n * k, 1) * 4)
+    check(lib().dbhip_vec_topk(metric, C.c_void_p(base.data.ptr), C.c_int64(base.n), base.dim, C.c_void_p(queries.data.ptr),
+                               queries.n, k, C.c_void_p(oi.ptr), C.c_void_p(od.ptr), None))
+    return oi.to_numpy(np.uint32, queries.n * k).reshape(queries.n, k), od.to_numpy(np.float32, queries.n * k).reshape(queries.n, k)
+
+
+def score_u8(is_l1, query, base):
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    base = np.ascontiguousarray(base, dtype=np.uint8)
+    n, dim = base.shape
+    q, b, out = DeviceBuffer.from_numpy(query), DeviceBuffer.from_numpy(base.reshape(-1)), DeviceBuffer(max(n, 1) * 4)
+    check(lib().dbhip_score_u8(int(is_l1), C.c_void_p(q.ptr), C.c_void_p(b.ptr), C.c_int64(n), dim, C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.float32, n)

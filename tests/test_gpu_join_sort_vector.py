@@ -1,0 +1,181 @@
+"""GPU: hash join, sort permutation, vector distances / top-k / u8 scoring against the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from databend_amd import _lib as T
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("nb,np_,card", [(0, 10, 5), (10, 0, 5), (1000, 5000, 300), (200_000, 500_000, 150_000), (50_000, 50_000, 10)])
+def test_inner_join_pairs_match_oracle(gpu, oracle, nb, np_, card):
+    rng = np.random.default_rng(nb + np_)
+    bk = rng.integers(0, card, nb).astype(np.uint64) * np.uint64(2654435761)
+    pk = rng.integers(0, card + card // 2 + 1, np_).astype(np.uint64) * np.uint64(2654435761)
+    bvalid = rng.integers(0, 10, nb) > 0
+    pvalid = rng.integers(0, 10, np_) > 0
+    j = gpu.HashJoin(16)
+    # build arrives in chunks (Join::add_block)
+    for lo in range(0, nb, 70_000):
+        hi = min(nb, lo + 70_000)
+        j.add_block(gpu.Column.from_numpy(bk[lo:hi], validity=bvalid[lo:hi]))
+    j.final_build()
+    gp, gb = j.probe_block(gpu.Column.from_numpy(pk, validity=pvalid))
+    cap = len(gp) + 16
+    ep, eb = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    bv = np.concatenate([np.packbits(bvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    pv = np.concatenate([np.packbits(pvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    total = oracle.orc_join_inner_u64(bk.ctypes.data_as(C.c_void_p), bv.ctypes.data_as(C.c_void_p), C.c_int64(nb), pk.ctypes.data_as(C.c_void_p),
+                                      pv.ctypes.data_as(C.c_void_p), C.c_int64(np_), ep.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+    assert total == len(gp)
+    assert np.array_equal(gp, ep[:total]) and np.array_equal(gb, eb[:total])
+    # every emitted pair joins equal, valid keys
+    if total:
+        assert (bk[gb] == pk[gp]).all() and bvalid[gb].all() and pvalid[gp].all()
+
+
+def sort_cases(rng, n):
+    f = (rng.standard_normal(n) * 3).astype(np.float32)
+    if n > 10:
+        f[:6] = [np.nan, -0.0, 0.0, np.inf, -np.inf, np.nan]
+    return [
+        (T.T_I64, rng.integers(-50, 50, n).astype(np.int64)), (T.T_I32, rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)),
+        (T.T_U8, rng.integers(0, 4, n).astype(np.uint8)), (T.T_F32, f), (T.T_F64, np.round(rng.standard_normal(n), 1)),
+        (T.T_U64, rng.integers(0, 2**64 - 1, n, dtype=np.uint64)), (T.T_I16, rng.integers(-3, 3, n).astype(np.int16)),
+    ]
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 2049, 100_000])
+def test_sort_perm_matches_oracle(gpu, oracle, n):
+    rng = np.random.default_rng(n)
+    cases = sort_cases(rng, n)
+    valid = rng.integers(0, 5, n) > 0
+    combos = [([0], [0], [0], 0), ([1], [1], [0], 0), ([2, 0], [0, 1], [0, 0], 0), ([3], [0], [1], 0), ([4, 2], [1, 0], [1, 0], 0),
+              ([5], [1], [0], 7), ([6, 3, 1], [0, 1, 0], [0, 1, 0], 0), ([2, 6, 0], [1, 1, 1], [0, 0, 0], 10)]
+    for idxs, desc, nf, limit in combos:
+        gcols, hcols = [], []
+        for pos, i in enumerate(idxs):
+            code, arr = cases[i]
+            v = valid if pos == 0 and i != 5 else None
+            gcols.append(gpu.Column.from_numpy(arr, code, validity=v))
+            hcols.append(O.HostCol(code, arr, v))
+        got = gpu.sort_perm(gcols, desc, nf, limit)
+        m = limit if 0 < limit < n else n
+        exp = np.zeros(max(m, 1), np.uint32)
+        d = (C.c_uint8 * len(idxs))(*desc)
+        f = (C.c_uint8 * len(idxs))(*nf)
+        oracle.orc_sort_perm(O.cols(hcols), d, f, len(idxs), C.c_int64(n), C.c_int64(limit), exp.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(got, exp[:m]), (idxs, desc, nf, limit)
+
+
+def test_sort_decimal128_and_bool(gpu, oracle):
+    rng = np.random.default_rng(4)
+    n = 5000
+    ints = [int(x) * int(y) for x, y in zip(rng.integers(-2**62, 2**62, n), rng.integers(0, 2**40, n))]
+    bools = rng.integers(0, 2, n).astype(bool)
+    got = gpu.sort_perm([gpu.Column.boolean(bools), gpu.Column.decimal128(ints, 38, 0)], [1, 0])
+    exp = sorted(range(n), key=lambda i: (-int(bools[i]), ints[i], i))
+    assert got.tolist() == exp
+
+
+def close(got, exp, tol=1e-5):
+    """f32 distances: |got - exp| <= tol * max(1, |exp|) (north_star: 1e-5 relative; the absolute floor covers
+    values that are differences of O(1) quantities, e.g. cosine distance near 0)."""
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    both_nan = np.isnan(got) & np.isnan(exp)
+    return bool(np.all(both_nan | (np.abs(got - exp) <= tol * np.maximum(1.0, np.abs(exp)))))
+
+
+@pytest.mark.parametrize("n,dim,nq", [(1, 3, 1), (100, 8, 3), (1000, 128, 17), (5000, 768, 130), (333, 100, 200)])
+def test_vec_distance_matches_oracle(gpu, oracle, n, dim, nq):
+    rng = np.random.default_rng(n + dim)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if n > 2:
+        base[1] = q[0]          # identical vectors
+        base[2] = 0.0           # zero vector -> cosine NaN
+    gb, gq = gpu.VectorColumn(base), gpu.VectorColumn(q)
+    for metric in range(4):
+        got = gpu.vec_distance(metric, gb, gq)
+        exp = np.zeros((nq, n), np.float32)
+        oracle.orc_vec_distance(metric, base.ctypes.data_as(C.c_void_p), C.c_int64(n), dim, q.ctypes.data_as(C.c_void_p), nq, exp.ctypes.data_as(C.c_void_p))
+        assert close(got, exp, 2e-5 if metric == 1 else 1e-5), (metric, np.abs(got - exp).max())
+
+
+def test_vector_golden_cases(gpu):
+    """Known answers from the reference's vector.txt (column cases; tests/golden/vector.json)."""
+    cases = json.load(open(os.path.join(HERE, "golden", "vector.json")))["cases"]
+    names = {"cosine_distance": T.VEC_COSINE, "l1_distance": T.VEC_L1, "l2_distance": T.VEC_L2, "inner_product": T.VEC_DOT}
+    checked = 0
+    for c in cases:
+        fn = c["ast"].split("(")[0]
+        cols = c["columns"]
+        if fn not in names or not all(k in cols for k in "abcd"):
+            continue
+        if any(cols[k]["type"].replace(" NULL", "") not in ("Float32", "Float64") for k in "abcd"):
+            continue
+        val = lambda k: np.array([float(x) for x in cols[k]["values"]], np.float32)
+        n = c["n"]
+        exp = np.array([float(x) for x in cols["Output"]["values"]], np.float64)
+        for r in range(n):
+            a = np.array([[val("a")[r], val("b")[r]]], np.float32)
+            b = np.array([[val("c")[r], val("d")[r]]], np.float32)
+            got = gpu.vec_distance(names[fn], gpu.VectorColumn(a), gpu.VectorColumn(b))[0, 0]
+            assert abs(float(got) - exp[r]) <= 1e-5 * max(1.0, abs(exp[r])), (c["ast"], r, got, exp[r])
+        checked += 1
+    assert checked >= 4
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(5, 16, 2, 10), (3000, 64, 33, 10), (20_000, 128, 4, 16), (70_000, 32, 300, 1)])
+def test_vec_topk_matches_exact_oracle_topk(gpu, oracle, n, dim, nq, k):
+    rng = np.random.default_rng(n + k)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    gb, gq = gpu.VectorColumn(base), gpu.VectorColumn(q)
+    for metric in (T.VEC_COSINE, T.VEC_L2, T.VEC_DOT):
+        idx, dist = gpu.vec_topk(metric, gb, gq, k)
+        full = gpu.vec_distance(metric, gb, gq)           # same kernels -> identical floats
+        for qi in range(nq):
+            order = np.lexsort((np.arange(n), full[qi]))[:k]  # ascending distance, ties by lower row id
+            kk = min(k, n)
+            assert np.array_equal(idx[qi, :kk], order[:kk].astype(np.uint32)), (metric, qi)
+            assert np.array_equal(dist[qi, :kk], full[qi, order[:kk]])
+            assert (idx[qi, kk:] == 0xFFFFFFFF).all()
+        # recall@k against the oracle's exact ordering (different summation order -> near ties may swap)
+        exp = np.zeros((nq, n), np.float32)
+        oracle.orc_vec_distance(metric, base.ctypes.data_as(C.c_void_p), C.c_int64(n), dim, q.ctypes.data_as(C.c_void_p), nq, exp.ctypes.data_as(C.c_void_p))
+        hits = sum(len(set(idx[qi, :min(k, n)].tolist()) & set(np.argsort(exp[qi], kind="stable")[:k].tolist())) for qi in range(nq))
+        assert hits >= 0.99 * nq * min(k, n)
+
+
+def test_score_u8_matches_reference_c_kernels(gpu, oracle):
+    """dot / l1 over u8-quantised vectors: exact integers; checked against the oracle restatement and, when
+    oracle/_ref/libref_u8.so was built from the reference's own cpp/avx2.c, against the real thing."""
+    rng = np.random.default_rng(8)
+    for dim in (16, 64, 768, 100):
+        n = 2000
+        base = rng.integers(0, 256, (n, dim)).astype(np.uint8)
+        q = rng.integers(0, 256, dim).astype(np.uint8)
+        for is_l1 in (0, 1):
+            got = gpu.score_u8(is_l1, q, base)
+            exp = np.zeros(n, np.float32)
+            oracle.orc_score_u8(is_l1, q.ctypes.data_as(C.c_void_p), base.ctypes.data_as(C.c_void_p), C.c_int64(n), dim, exp.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(got, exp)
+    ref = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_u8.so")
+    if os.path.exists(ref):
+        R = C.CDLL(ref)
+        R.impl_score_dot_avx.restype = C.c_float
+        R.impl_score_l1_avx.restype = C.c_float
+        dim, n = 768, 500
+        base = rng.integers(0, 256, (n, dim)).astype(np.uint8)
+        q = rng.integers(0, 256, dim).astype(np.uint8)
+        for is_l1, f in ((0, R.impl_score_dot_avx), (1, R.impl_score_l1_avx)):
+            got = gpu.score_u8(is_l1, q, base)
+            exp = np.array([f(q.ctypes.data_as(C.c_void_p), base[i].ctypes.data_as(C.c_void_p), C.c_uint32(dim)) for i in range(n)], np.float32)
+            assert np.array_equal(got, exp)
