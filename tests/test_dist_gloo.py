@@ -1,0 +1,137 @@
+"""CPU, world_size 2 over gloo: the multi-rank exchange of serialized partial aggregation states
+(databend_amd/dist.py — the RCCL path of bench.py --gpus N runs exactly this code with the nccl
+backend). The HIP table is replaced by a host stand-in with the same three methods
+(flush_serialized / reset / merge_serialized); the stand-in merges rows word-wise like the device
+merge does for COUNT / wrapping SUM states (gb_layout.h)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from databend_amd import dist as DX
+
+W = 4  # [key][hash][sum][count]
+HASH_WORD = 1
+M64 = (1 << 64) - 1
+
+
+def mix(x):
+    """the integer group hash (aggregate/group_hash.rs:555-570), python ints"""
+    x &= M64
+    x ^= x >> 32
+    x = (x * 0xD6E8FEB86659FD93) & M64
+    x ^= x >> 32
+    x = (x * 0xD6E8FEB86659FD93) & M64
+    x ^= x >> 32
+    return x
+
+
+class HostTable:
+    def __init__(self):
+        self.groups = {}
+
+    def add(self, keys, vals):
+        for k, v in zip(keys.tolist(), vals.tolist()):
+            s = self.groups.setdefault(k, [0, 0])
+            s[0] = (s[0] + v) & M64
+            s[1] += 1
+
+    def flush_serialized(self):
+        rows = np.zeros((len(self.groups), W), dtype=np.uint64)
+        for i, (k, s) in enumerate(sorted(self.groups.items())):
+            rows[i] = (k & M64, mix(k), s[0], s[1])
+        return rows
+
+    def reset(self):
+        self.groups = {}
+
+    def merge_serialized(self, rows):
+        for k, h, s, c in np.asarray(rows, dtype=np.uint64).tolist():
+            assert h == mix(k)
+            st = self.groups.setdefault(k, [0, 0])
+            st[0] = (st[0] + s) & M64
+            st[1] += c
+
+
+def shard(rank, world, n, card, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    keys = rng.integers(0, card, n, dtype=np.int64)
+    vals = rng.integers(0, 1 << 40, n, dtype=np.int64)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    return keys, vals, lo, hi
+
+
+def worker(rank, world, port, mode, n, card, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        keys, vals, lo, hi = shard(rank, world, n, card, 11)
+        t = HostTable()
+        t.add(keys[lo:hi], vals[lo:hi])
+        DX.exchange_partials(t, dist, torch, torch.device("cpu"), mode=mode, hash_word=HASH_WORD)
+        q.put((rank, {k: tuple(v) for k, v in t.groups.items()}))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run(mode, n, card, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, mode, n, card, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    keys, vals, _, _ = shard(0, world, n, card, 11)
+    full = HostTable()
+    full.add(keys, vals)
+    return got, {k: tuple(v) for k, v in full.groups.items()}
+
+
+@pytest.mark.parametrize("n,card", [(5000, 4), (20000, 3000)])
+def test_allgather_exchange_every_rank_gets_the_global_result(n, card):
+    got, exp = run("allgather", n, card)
+    assert got[0] == exp and got[1] == exp
+
+
+@pytest.mark.parametrize("n,card", [(5000, 4), (20000, 3000), (10, 1)])
+def test_alltoall_exchange_partitions_groups_by_hash(n, card):
+    got, exp = run("alltoall", n, card)
+    # every group is finalised on exactly the rank hash % world names (payload.rs:571-577)
+    for r in (0, 1):
+        for k in got[r]:
+            assert mix(k) % 2 == r
+    merged = dict(got[0])
+    assert not (set(got[0]) & set(got[1]))
+    merged.update(got[1])
+    assert merged == exp
+
+
+def test_route_rows_by_hash_is_a_partition():
+    rows = np.zeros((1000, W), dtype=np.uint64)
+    rows[:, 0] = np.arange(1000)
+    rows[:, 1] = [mix(int(k)) for k in range(1000)]
+    for world in (1, 2, 3, 8):
+        parts = DX.route_rows_by_hash(rows, HASH_WORD, world)
+        assert sum(len(p) for p in parts) == 1000
+        for r, p in enumerate(parts):
+            assert np.all(p[:, 1] % np.uint64(world) == r)
+    empty = DX.route_rows_by_hash(np.zeros((0, W), dtype=np.uint64), HASH_WORD, 2)
+    assert [p.shape for p in empty] == [(0, W), (0, W)]

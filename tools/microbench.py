@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Per-kernel-family microbenchmark on one MI355X (not the driver's bench.py contract).
+
+For every C-ABI family it times the call with HIP events on the library stream
+(dbhip_event_*), at working sets well past the 256 MiB Infinity Cache, and reports
+ALGORITHMIC bytes (or flops) / time against the HBM (8 TB/s) or FP32-MFMA (157.3 TF)
+peak. Inputs are generated on the device with torch (plumbing only) and handed to the
+library as raw device pointers.
+
+    python tools/microbench.py [--only name,name] [--out gpurun_out/microbench.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from databend_amd import _lib as L
+from databend_amd import device as D
+from databend_amd._lib import check, lib
+
+HBM, MFMA32 = 8000.0, 157.3
+
+
+class Borrowed:
+    """non-owning view of a torch tensor's storage with the DeviceBuffer surface"""
+
+    def __init__(self, t):
+        self.t = t
+        self.ptr = t.data_ptr()
+        self.nbytes = t.numel() * t.element_size()
+
+
+def col(t, dtype, **kw):
+    return D.Column(dtype, t.shape[0], Borrowed(t), **kw)
+
+
+def timed(fn, reps=5, warm=2):
+    Lb = lib()
+    torch.cuda.synchronize()
+    for _ in range(warm):
+        fn()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    check(Lb.dbhip_event_create(C.byref(e0)))
+    check(Lb.dbhip_event_create(C.byref(e1)))
+    best = 1e30
+    tot = 0.0
+    for _ in range(reps):
+        check(Lb.dbhip_event_record(e0, None))
+        fn()
+        check(Lb.dbhip_event_record(e1, None))
+        check(Lb.dbhip_stream_sync(None))
+        ms = C.c_float()
+        check(Lb.dbhip_event_elapsed_ms(e0, e1, C.byref(ms)))
+        best = min(best, ms.value)
+        tot += ms.value
+    return tot / reps, best
+
+
+def report(out, name, unit_count, unit, alg_bytes=None, flops=None, ms=None, note=""):
+    avg, best = ms
+    r = {"name": name, "ms_avg": round(avg, 4), "ms_best": round(best, 4), unit + "/s": unit_count / (avg * 1e-3), "note": note}
+    if alg_bytes is not None:
+        gbs = alg_bytes / (avg * 1e-3) / 1e9
+        r.update(bound="hbm", alg_bytes=alg_bytes, GBps=round(gbs, 1), frac=round(gbs / HBM, 4))
+    if flops is not None:
+        tf = flops / (avg * 1e-3) / 1e12
+        r.update(bound="mfma", flops=flops, TFLOPs=round(tf, 2), frac=round(tf / MFMA32, 4))
+    out.append(r)
+    print(json.dumps(r), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--scale", type=float, default=1.0)
+    args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
+    want = lambda k: not only or k in only
+    torch.cuda.set_device(0)
+    D.init(0)
+    Lb = lib()
+    dev = "cuda"
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    out = []
+    N = int(128_000_000 * args.scale)
+
+    def ri(lo, hi, n, dt=torch.int64):
+        return torch.randint(lo, hi, (n,), device=dev, dtype=dt, generator=g)
+
+    if want("arith"):
+        a, b = ri(-2**31, 2**31, N), ri(-2**31, 2**31, N)
+        ca, cb = col(a, L.T_I64), col(b, L.T_I64)
+        o = torch.empty(N + 8, dtype=torch.int64, device=dev)
+        cca, ccb = ca.c(), cb.c()
+        f = lambda: check(Lb.dbhip_arith(L.OP_PLUS, C.byref(cca), C.byref(ccb), C.c_int64(N), L.T_I64, C.c_void_p(o.data_ptr()), None, None, None))
+        report(out, "arith plus i64,i64->i64", N, "rows", alg_bytes=24 * N, ms=timed(f))
+        a32, b32 = ri(-2**31, 2**31, N, torch.int32), ri(-2**31, 2**31, N, torch.int32)
+        c1, c2 = col(a32, L.T_I32).c(), col(b32, L.T_I32).c()
+        f = lambda: check(Lb.dbhip_arith(L.OP_MULTIPLY, C.byref(c1), C.byref(c2), C.c_int64(N), L.T_I64, C.c_void_p(o.data_ptr()), None, None, None))
+        report(out, "arith multiply i32,i32->i64", N, "rows", alg_bytes=16 * N, ms=timed(f))
+        eb = torch.empty(N // 8 + 64, dtype=torch.uint8, device=dev)
+        ec = torch.zeros(1, dtype=torch.int64, device=dev)
+        bnz = b.clamp(min=1)
+        c3 = col(bnz, L.T_I64).c()
+        of = torch.empty(N + 8, dtype=torch.float64, device=dev)
+        f = lambda: check(Lb.dbhip_arith(L.OP_DIVIDE, C.byref(cca), C.byref(c3), C.c_int64(N), L.T_F64, C.c_void_p(of.data_ptr()), C.c_void_p(eb.data_ptr()), C.c_void_p(ec.data_ptr()), None))
+        report(out, "arith divide i64,i64->f64 (+err bitmap)", N, "rows", alg_bytes=24 * N + N // 8, ms=timed(f))
+        del a32, b32, of, bnz, eb
+
+    if want("sum3"):
+        n1 = 10_000_000
+        a, b, c = ri(-2**31, 2**31, N), ri(-2**31, 2**31, N), ri(-2**31, 2**31, N)
+        s = torch.zeros(1, dtype=torch.int64, device=dev)
+        for n, tag in ((n1, "C1 10M rows (L3-resident)"), (N, f"{N} rows")):
+            f = lambda: check(Lb.dbhip_sum_a_plus_b_mul_c_i64(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(c.data_ptr()), C.c_int64(n), C.c_void_p(s.data_ptr()), None))
+            report(out, "sum(a+b*c) i64 fused, " + tag, n, "rows", alg_bytes=24 * n, ms=timed(f))
+        # operator-at-a-time: multiply, plus, sum (reference plan shape, 3 kernels, 2 intermediates)
+        cb_, cc_, ca_ = col(b, L.T_I64).c(), col(c, L.T_I64).c(), col(a, L.T_I64).c()
+        t1 = torch.empty(N + 8, dtype=torch.int64, device=dev)
+        t2 = torch.empty(N + 8, dtype=torch.int64, device=dev)
+        ct1 = col(t1[:N], L.T_I64).c()
+        ct2 = col(t2[:N], L.T_I64).c()
+
+        def plan():
+            check(Lb.dbhip_arith(L.OP_MULTIPLY, C.byref(cb_), C.byref(cc_), C.c_int64(N), L.T_I64, C.c_void_p(t1.data_ptr()), None, None, None))
+            check(Lb.dbhip_arith(L.OP_PLUS, C.byref(ca_), C.byref(ct1), C.c_int64(N), L.T_I64, C.c_void_p(t2.data_ptr()), None, None, None))
+            check(Lb.dbhip_sum(C.byref(ct2), C.c_int64(N), C.c_void_p(s.data_ptr()), None))
+        report(out, "sum(a+b*c) operator-at-a-time (3 kernels)", N, "rows", alg_bytes=24 * N, ms=timed(plan), note="moves 56 B/row")
+        del t1, t2
+
+    if want("decimal"):
+        p = ri(90000, 10494951, N)
+        d = ri(0, 11, N)
+        cp = col(p, L.T_DEC64, precision=15, scale=2).c()
+        cd = col(d, L.T_DEC64, precision=16, scale=2).c()
+        o = torch.empty(2 * N + 8, dtype=torch.int64, device=dev)
+        f = lambda: check(Lb.dbhip_decimal_arith(L.OP_MULTIPLY, C.byref(cp), C.byref(cd), C.c_int64(N), L.T_DEC128, 31, 4, C.c_void_p(o.data_ptr()), None, None, None))
+        report(out, "decimal multiply dec64*dec64->dec128(31,4)", N, "rows", alg_bytes=32 * N, ms=timed(f))
+        del o
+
+    if want("cmp"):
+        N4 = 4 * N
+        sd = ri(8000, 10600, N4, torch.int32)
+        csd = col(sd, L.T_DATE).c()
+        cut = D.Column.scalar(10471, L.T_DATE)
+        ccut = cut.c()
+        bm = torch.zeros(N4 // 8 + 64, dtype=torch.uint8, device=dev)
+        f = lambda: check(Lb.dbhip_cmp(L.CMP_LTE, C.byref(csd), C.byref(ccut), C.c_int64(N4), C.c_void_p(bm.data_ptr()), None))
+        report(out, "cmp date<=scalar -> bitmap", N4, "rows", alg_bytes=N4 * 4 + N4 // 8, ms=timed(f))
+        f()
+        sel = torch.empty(N4 + 64, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        f2 = lambda: check(Lb.dbhip_filter_select(C.c_void_p(bm.data_ptr()), C.c_int64(0), C.c_int64(N4), C.c_void_p(sel.data_ptr()), C.c_void_p(cnt.data_ptr()), None))
+        ms = timed(f2)
+        k = int(cnt.item())
+        report(out, f"filter_select bitmap -> u32 selection ({k / N4:.1%} kept)", N4, "rows", alg_bytes=N4 // 8 + 4 * k, ms=ms)
+        src = ri(-2**31, 2**31, N, torch.int64)
+        sel2 = torch.sort(torch.randint(0, N, (N,), device=dev, dtype=torch.int32, generator=g))[0]
+        o = torch.empty(N + 8, dtype=torch.int64, device=dev)
+        f3 = lambda: check(Lb.dbhip_take(C.c_void_p(src.data_ptr()), 8, C.c_void_p(sel2.data_ptr()), C.c_int64(N), C.c_void_p(o.data_ptr()), None))
+        report(out, "take 8-byte, ascending selection (filter output shape)", N, "rows", alg_bytes=N * 20, ms=timed(f3))
+        selr = torch.randint(0, N, (N,), device=dev, dtype=torch.int32, generator=g)
+        f4 = lambda: check(Lb.dbhip_take(C.c_void_p(src.data_ptr()), 8, C.c_void_p(selr.data_ptr()), C.c_int64(N), C.c_void_p(o.data_ptr()), None))
+        report(out, "take 8-byte, random selection (join output shape)", N, "rows", alg_bytes=N * 20, ms=timed(f4), note="random 8-B gathers: 64-B sector per row")
+        del sd, bm, sel, src, sel2, selr, o
+
+    if want("hash"):
+        a = ri(-2**62, 2**62, N)
+        ca = col(a, L.T_I64).c()
+        o = torch.empty(N, dtype=torch.int64, device=dev)
+        arr = (L.Col * 1)(ca)
+        f = lambda: check(Lb.dbhip_group_hash(arr, 1, C.c_int64(N), C.c_void_p(o.data_ptr()), None))
+        report(out, "group_hash 1 x i64", N, "rows", alg_bytes=16 * N, ms=timed(f))
+
+    if want("groupby"):
+        n = int(60_000_000 * args.scale)
+        for card in (4, 1000, 1_000_000, 10_000_000):
+            keys = ri(0, card, n)
+            vals = ri(0, 1000, n)
+            gb = D.GroupBy([L.T_I64], [(L.AGG_SUM, L.T_I64, 0, 0, 0), (L.AGG_COUNT, 0, 0, 0, 0)], capacity=max(1024, card * 2))
+            kc, vc = col(keys, L.T_I64), col(vals, L.T_I64)
+            def f():
+                gb.reset()
+                gb.add_block([kc], [vc, None], n)
+            ms = timed(f, reps=3, warm=1)
+            report(out, f"groupby add_block i64 key, sum+count, {card} groups", n, "rows", alg_bytes=16 * n, ms=ms)
+            gb.destroy()
+            del keys, vals
+
+    if want("join"):
+        nb, npr = int(15_000_000 * args.scale), int(120_000_000 * args.scale)
+        bk = torch.randperm(nb * 4, device=dev, generator=g)[:nb].to(torch.int64)
+        pk = ri(0, nb * 4, npr)
+        j = D.HashJoin(nb)
+        bc = col(bk, L.T_U64)
+        pc = col(pk, L.T_U64)
+        def build():
+            jj = D.HashJoin(nb)
+            jj.add_block(bc)
+            jj.final_build()
+            jj.destroy()
+        report(out, f"join build {nb} u64 keys (create+insert+finalize)", nb, "rows", alg_bytes=8 * nb, ms=timed(build, reps=3, warm=1))
+        j.add_block(bc)
+        j.final_build()
+        total = C.c_uint64()
+        fcount = lambda: check(Lb.dbhip_join_probe_count(j.h, C.c_void_p(pk.data_ptr()), None, C.c_int64(npr), C.byref(total), None))
+        report(out, f"join probe_count {npr} probes vs {nb} build (25% match)", npr, "rows", alg_bytes=8 * npr, ms=timed(fcount, reps=3, warm=1))
+        m = total.value
+        op = torch.empty(m + 8, dtype=torch.int32, device=dev)
+        ob = torch.empty(m + 8, dtype=torch.int32, device=dev)
+        got = C.c_uint64()
+        fprobe = lambda: check(Lb.dbhip_join_probe(j.h, C.c_void_p(pk.data_ptr()), None, C.c_int64(npr), C.c_void_p(op.data_ptr()), C.c_void_p(ob.data_ptr()), C.c_int64(m), C.byref(got), None))
+        report(out, f"join probe (emit {m} ordered pairs)", npr, "rows", alg_bytes=8 * npr + 8 * m, ms=timed(fprobe, reps=3, warm=1))
+        j.destroy()
+        del bk, pk, op, ob
+
+    if want("sort"):
+        n = int(64_000_000 * args.scale)
+        k64 = ri(-2**62, 2**62, n)
+        kc = col(k64, L.T_I64)
+        arr = (L.Col * 1)(kc.c())
+        d0 = (C.c_uint8 * 1)(0)
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        f = lambda: check(Lb.dbhip_sort_perm(arr, d0, d0, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.data_ptr()), None))
+        report(out, f"sort_perm {n} x i64 (8 LSD passes)", n, "rows", alg_bytes=n * (8 + 4) * 2 * 8, ms=timed(f, reps=3, warm=1), note="alg = 8 passes x (read+write) x 12 B")
+        k32 = ri(0, 2**31 - 1, n, torch.int32)
+        arr32 = (L.Col * 1)(col(k32, L.T_I32).c())
+        f = lambda: check(Lb.dbhip_sort_perm(arr32, d0, d0, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.data_ptr()), None))
+        report(out, f"sort_perm {n} x i32", n, "rows", alg_bytes=n * (8 + 4) * 2 * 4, ms=timed(f, reps=3, warm=1), note="alg = 4 passes x 2 x 12 B")
+        f = lambda: check(Lb.dbhip_sort_perm(arr, d0, d0, 1, C.c_int64(n), C.c_int64(10), C.c_void_p(perm.data_ptr()), None))
+        report(out, f"sort_perm {n} x i64 LIMIT 10", n, "rows", alg_bytes=n * 8, ms=timed(f, reps=3, warm=1))
+        del k64, k32, perm
+
+    if want("vector"):
+        n, dim = int(1_250_000 * args.scale), 768
+        base = torch.randn((n, dim), device=dev, dtype=torch.float32, generator=g)
+        for nq in (1, 64, 512):
+            q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
+            oi = torch.empty(nq * 10, dtype=torch.int32, device=dev)
+            od = torch.empty(nq * 10, dtype=torch.float32, device=dev)
+            f = lambda: check(Lb.dbhip_vec_topk(L.VEC_COSINE, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.c_void_p(q.data_ptr()), nq, 10, C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+            ms = timed(f, reps=3, warm=1)
+            if nq < 40:
+                report(out, f"vec_topk cosine {n}x{dim}, nq={nq}, k=10", nq, "queries", alg_bytes=n * dim * 4, ms=ms)
+            else:
+                report(out, f"vec_topk cosine {n}x{dim}, nq={nq}, k=10", nq, "queries", flops=2.0 * n * dim * nq, ms=ms)
+        nq = 64
+        q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
+        o = torch.empty(nq * n, dtype=torch.float32, device=dev)
+        for metric, nm in ((L.VEC_L2, "l2"), (L.VEC_DOT, "dot")):
+            f = lambda: check(Lb.dbhip_vec_distance(metric, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.c_void_p(q.data_ptr()), nq, C.c_void_p(o.data_ptr()), None))
+            report(out, f"vec_distance {nm} {n}x{dim}, nq={nq}", nq, "queries", flops=(3.0 if nm == "l2" else 2.0) * n * dim * nq, ms=timed(f, reps=3, warm=1))
+        del base, o
+
+    if want("u8"):
+        n, dim = int(8_000_000 * args.scale), 768
+        b = torch.randint(0, 128, (n, dim), device=dev, dtype=torch.uint8, generator=g)
+        q = torch.randint(0, 128, (dim,), device=dev, dtype=torch.uint8, generator=g)
+        o = torch.empty(n, dtype=torch.float32, device=dev)
+        f = lambda: check(Lb.dbhip_score_u8(0, C.c_void_p(q.data_ptr()), C.c_void_p(b.data_ptr()), C.c_int64(n), dim, C.c_void_p(o.data_ptr()), None))
+        report(out, f"score_u8 dot {n}x{dim}", n, "rows", alg_bytes=n * dim + 4 * n, ms=timed(f))
+
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(out, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
