@@ -20,6 +20,8 @@
 
 #include <math.h>
 
+#include <vector>
+
 using namespace dbhip;
 
 namespace {
@@ -47,71 +49,200 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// MFMA tile kernel: 128 queries x 128 base rows per block, 4 waves as 2x2, each wave 64x64
-// = 2x2 accumulators of v_mfma_f32_32x32x2_f32.
-//   A operand (lane l): Q[q0 + (l&31)][k + (l>>5)]     B operand: Base[i0 + (l&31)][k + (l>>5)]
-//   C/D reg r: col = l&31 (base row), row = (r&3) + 8*(r>>2) + 4*(l>>5) (query)
+// MFMA tile kernel for dot / cosine. One workgroup (4 waves) owns a TQ x TI tile of the
+// (query, base row) score matrix and walks k in steps of BK = 32:
+//   * the next k-tile of both operands is prefetched from HBM into registers (16-B loads, one full
+//     128-B line per row per step) while the current one is consumed from LDS by the matrix pipe,
+//   * LDS rows are padded to 33 floats so the MFMA operand reads (lane = row) are conflict-free,
+//   * every wave holds MQ x MI accumulators of v_mfma_f32_32x32x2_f32:
+//       A operand (lane l): Q[q + (l&31)][k + (l>>5)]     B operand: Base[i + (l&31)][k + (l>>5)]
+//       C/D reg r: col = l&31 (base row), row = (r&3) + 8*(r>>2) + 4*(l>>5) (query),
+//   * the base-row norms of the cosine metric are accumulated from the very registers that stage
+//     the B tile (no second pass over the base column).
+// Tile shapes: 128 x 128 (2 x 2 waves of 64 x 64) for large query batches, 64 x 256 and 32 x 256
+// (waves side by side along the base rows) for small ones; f32 MFMA is so slow (64 cycles per
+// instruction per SIMD) that the 32-row variant still streams the base at the HBM rate.
+// blockIdx -> tile: the q-tiles of one base tile run back to back on ONE XCD (workgroup b lands on
+// XCD b % 8), so the base tile is fetched from HBM once and re-read from that XCD's L2.
+// Epilogue MODE_WRITE stores the scores; MODE_FILTER appends (score, row id) to the query's
+// candidate list when the score is not worse than the query's threshold tau (top-k, see below).
 // ---------------------------------------------------------------------------
-template <bool COSINE>
-__global__ __launch_bounds__(256) void dot_mfma_kernel(const float* __restrict__ base, int64_t n, int dim,
-                                                       const float* __restrict__ queries, int nq,
-                                                       const float* __restrict__ bnorm,
-                                                       const float* __restrict__ qnorm,
-                                                       float* __restrict__ out, int64_t out_ld, int64_t i_origin) {
-  __shared__ float As[128 * LDK];
-  __shared__ float Bs[128 * LDK];
+constexpr int MODE_WRITE = 0, MODE_FILTER = 1;
+
+struct DotArgs {
+  const float* base;      // [n][dim]
+  const float* queries;   // [nq][dim]
+  const float* qnorm;     // [nq]   (cosine)
+  int64_t n;
+  int dim, nq;
+  int vec4;               // dim % 4 == 0 and both pointers 16-byte aligned
+  int n_qtiles;
+  int64_t n_itiles;
+  float* out;             // MODE_WRITE: [nq][out_ld]
+  int64_t out_ld;
+  const float* tau;       // MODE_FILTER: threshold of query q = tau[q * tau_stride]
+  int64_t tau_stride;
+  float* cand_d;          // [nq][cand_cap]
+  uint32_t* cand_i;
+  uint32_t* cand_cnt;     // [nq]
+  uint32_t cand_cap;
+  uint32_t row_origin;    // added to the row index in candidate ids
+};
+
+// Branch-free staging load of elements k..k+3 of a row (`row` points at the row start and is always
+// a valid row; elements at or beyond dim read as zero). VEC4: dim % 4 == 0 and 16-byte aligned rows.
+template <bool VEC4>
+__device__ __forceinline__ float4 load4(const float* row, int k, int dim) {
+  float4 v;
+  if (VEC4) {
+    const int kk = k < dim ? k : dim - 4;
+    v = *(const float4*)(row + kk);
+    if (k >= dim) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    const int last = dim - 1;
+    v.x = row[k + 0 < dim ? k + 0 : last];
+    v.y = row[k + 1 < dim ? k + 1 : last];
+    v.z = row[k + 2 < dim ? k + 2 : last];
+    v.w = row[k + 3 < dim ? k + 3 : last];
+    if (k + 0 >= dim) v.x = 0.f;
+    if (k + 1 >= dim) v.y = 0.f;
+    if (k + 2 >= dim) v.z = 0.f;
+    if (k + 3 >= dim) v.w = 0.f;
+  }
+  return v;
+}
+
+template <int TQ, int TI, int WQ, bool COSINE, int MODE, bool VEC4>
+__global__ __launch_bounds__(256, (TI == 256 && TQ == 64) ? 2 : 3) void dot_tile_kernel(DotArgs A) {
+  constexpr int WI = 4 / WQ;
+  constexpr int MQ = TQ / WQ / 32, MI = TI / WI / 32;
+  constexpr int A_F4 = TQ / 32, B_F4 = TI / 32;  // float4 staged per thread and k-tile
+  __shared__ float As[TQ * LDK];
+  __shared__ float Bs[TI * LDK];
+  __shared__ float Bn[TI];
+  __shared__ float Qn[TQ];
+  __shared__ float Tau[TQ];
+
+  // XCD-aware tile mapping
+  const int64_t slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int qt = (int)(slot % A.n_qtiles);
+  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
+  if (it >= A.n_itiles) return;
+  const int64_t i0 = it * TI;
+  const int q0 = qt * TQ;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wq = (wave >> 1) * 64, wi = (wave & 1) * 64;
-  const int64_t i0 = (int64_t)blockIdx.x * 128;
-  const int q0 = blockIdx.y * 128;
-  f32x16 acc[2][2];
+  const int wq = (wave / WI) * (TQ / WQ), wi = (wave % WI) * (TI / WI);
+  const int dim = A.dim;
+
+  f32x16 acc[MQ][MI];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MQ; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < MI; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  for (int k0 = 0; k0 < dim; k0 += BK) {
-    // stage 128 x 32 floats of each operand: 4096 floats / 256 threads = 16 per thread, coalesced along k
+  float4 ra[A_F4], rb[B_F4];
+  float bsq[B_F4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      int e = t * 256 + tid;
-      int row = e >> 5, kk = e & 31;
-      int k = k0 + kk;
-      int q = q0 + row;
-      int64_t i = i0 + row;
-      As[row * LDK + kk] = (q < nq && k < dim) ? queries[(int64_t)q * dim + k] : 0.f;
-      Bs[row * LDK + kk] = (i < n && k < dim) ? base[i * dim + k] : 0.f;
+  for (int j = 0; j < B_F4; ++j) bsq[j] = 0.f;
+  // thread t stages rows (t >> 3) + 32 j of each operand, k offset (t & 7) * 4 of the k-tile.
+  // Rows past the end of either operand are clamped to the last valid row: their products land in
+  // outputs that are never stored, so no predication is needed on the loads.
+  const int kc = (tid & 7) * 4;
+  const int r0 = tid >> 3;
+  const float* atile = A.queries + (int64_t)q0 * dim;
+  const float* btile = A.base + i0 * dim;
+  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
+  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
+  uint32_t aoff[A_F4], boff[B_F4];
+#pragma unroll
+  for (int j = 0; j < A_F4; ++j) aoff[j] = (uint32_t)(r0 + 32 * j < alast ? r0 + 32 * j : alast) * (uint32_t)dim;
+#pragma unroll
+  for (int j = 0; j < B_F4; ++j) boff[j] = (uint32_t)(r0 + 32 * j < blast ? r0 + 32 * j : blast) * (uint32_t)dim;
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) ra[j] = load4<VEC4>(atile + aoff[j], k0 + kc, dim);
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) rb[j] = load4<VEC4>(btile + boff[j], k0 + kc, dim);
+  };
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+      float* d = As + (r0 + 32 * j) * LDK + kc;  // A_F4 * 32 == TQ: always a tile row
+      d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
     }
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) {
+      float* d = Bs + (r0 + 32 * j) * LDK + kc;
+      d[0] = rb[j].x; d[1] = rb[j].y; d[2] = rb[j].z; d[3] = rb[j].w;
+      if (COSINE) bsq[j] = fmaf(rb[j].x, rb[j].x, fmaf(rb[j].y, rb[j].y, fmaf(rb[j].z, rb[j].z, fmaf(rb[j].w, rb[j].w, bsq[j]))));
+    }
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < dim; k0 += BK) {
+    __syncthreads();  // every wave is done reading the previous tile
+    lds_store();
     __syncthreads();
+    if (k0 + BK < dim) gload(k0 + BK);  // in flight while the matrix pipe works on this tile
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const int kl = kk + (lane >> 5);
-      float a0 = As[(wq + (lane & 31)) * LDK + kl];
-      float a1 = As[(wq + 32 + (lane & 31)) * LDK + kl];
-      float b0 = Bs[(wi + (lane & 31)) * LDK + kl];
-      float b1 = Bs[(wi + 32 + (lane & 31)) * LDK + kl];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[MQ], b[MI];
+#pragma unroll
+      for (int x = 0; x < MQ; ++x) a[x] = As[(wq + x * 32 + (lane & 31)) * LDK + kl];
+#pragma unroll
+      for (int y = 0; y < MI; ++y) b[y] = Bs[(wi + y * 32 + (lane & 31)) * LDK + kl];
+#pragma unroll
+      for (int x = 0; x < MQ; ++x)
+#pragma unroll
+        for (int y = 0; y < MI; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
     }
-    __syncthreads();
   }
-  // epilogue: lanes with consecutive l&31 write consecutive base rows of one query (coalesced)
+
+  // per-tile side data for the epilogue
+  if (COSINE) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int j = 0; j < B_F4; ++j) {
+      float s = bsq[j];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if ((tid & 7) == 0) Bn[(tid + 256 * j) >> 3] = sqrtf(s);
+    }
+    if (tid < TQ) Qn[tid] = (q0 + tid < A.nq) ? A.qnorm[q0 + tid] : 1.f;
+  }
+  if (MODE == MODE_FILTER && tid < TQ) Tau[tid] = (q0 + tid < A.nq) ? A.tau[(int64_t)(q0 + tid) * A.tau_stride] : -INFINITY;
+  __syncthreads();
+
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int64_t i = i0 + wi + b * 32 + (lane & 31);
+  for (int x = 0; x < MQ; ++x)
+#pragma unroll
+    for (int y = 0; y < MI; ++y) {
+      const int il = wi + y * 32 + (lane & 31);
+      const int64_t i = i0 + il;
+      const float bn = COSINE ? Bn[il] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = q0 + wq + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (q < nq && i < n) {
-          float v = acc[a][b][r];
-          if (COSINE) v = 1.0f - v / (qnorm[q] * bnorm[i + i_origin]);
-          out[(int64_t)q * out_ld + i] = v;
+        const int ql = wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int q = q0 + ql;
+        float v = acc[x][y][r];
+        if (COSINE) v = 1.0f - v / (Qn[ql] * bn);
+        if (MODE == MODE_WRITE) {
+          if (q < A.nq && i < A.n) A.out[(int64_t)q * A.out_ld + i] = v;
+        } else {
+          // NaN scores and scores not above tau stay in the race (ordering: cand_less)
+          if (q < A.nq && i < A.n && !(v > Tau[ql])) {
+            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
+            if (s < A.cand_cap) {
+              A.cand_d[(int64_t)q * A.cand_cap + s] = v;
+              A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
+            }
+          }
         }
       }
     }
@@ -173,9 +304,21 @@ __global__ __launch_bounds__(256) void diff_valu_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// top-k: one block per query over a chunk of distances; merges with the running best
+// top-k selection (ORDER BY distance LIMIT k, kernels/sort_compare.rs:197-209): order is ascending
+// distance, NaN last (taken as +inf), ties by lower row id. Segment-parallel and multi-stage:
+//   stage kernel  one workgroup per (segment of SEG scores, query): k best of the segment, sorted
+//                 1. every thread takes SEG/256 scores into registers and finds its own minimum
+//                 2. T = k-th smallest of the 256 thread minima (rank counting in LDS): at least k
+//                    scores are <= T and at most k * SEG/256 can be
+//                 3. scores <= T are appended to a small LDS list
+//                 4. rank counting inside the list writes the k best in order
+//   The per-segment lists of one query form the input of the next stage until one list is left.
+// Cost per score: one load, ~3 compares. No per-thread insertion sort, no serial scan per query.
 // ---------------------------------------------------------------------------
 constexpr int KMAX = 16;
+constexpr int SEL_PER_THREAD = 32;
+constexpr int SEL_SEG = 256 * SEL_PER_THREAD;  // scores per workgroup
+constexpr int SEL_LIST = SEL_PER_THREAD * KMAX;
 
 __device__ __forceinline__ bool cand_less(float d1, uint32_t i1, float d2, uint32_t i2) {
   // ascending distance, NaN last, ties by lower row id
@@ -184,70 +327,124 @@ __device__ __forceinline__ bool cand_less(float d1, uint32_t i1, float d2, uint3
   if (!n1 && d1 != d2) return d1 < d2;
   return i1 < i2;
 }
+// strict total order on (distance, id, position): position only separates the (+inf, 0xFFFFFFFF) fillers
+__device__ __forceinline__ bool pair_less(float d1, uint32_t i1, int p1, float d2, uint32_t i2, int p2) {
+  if (d1 != d2) return d1 < d2;
+  if (i1 != i2) return i1 < i2;
+  return p1 < p2;
+}
 
-__global__ __launch_bounds__(256) void topk_chunk_kernel(const float* __restrict__ dist, int64_t chunk_n,
-                                                         int64_t ld, uint32_t row_origin, int k,
-                                                         float* best_d, uint32_t* best_i, int have_prev) {
-  const int q = blockIdx.x, tid = threadIdx.x;
-  const float* d = dist + (int64_t)q * ld;
-  float ld_[KMAX];
-  uint32_t li[KMAX];
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) { ld_[j] = INFINITY; li[j] = 0xFFFFFFFFu; }
-  auto push = [&](float v, uint32_t id) {
-    if (!cand_less(v, id, ld_[KMAX - 1], li[KMAX - 1])) return;
-#pragma unroll
-    for (int j = KMAX - 1; j >= 0; --j) {
-      bool here = (j == 0) || !cand_less(v, id, ld_[j - 1], li[j - 1]);
-      if (cand_less(v, id, ld_[j], li[j])) {
-        if (here) { ld_[j] = v; li[j] = id; }
-        else { ld_[j] = ld_[j - 1]; li[j] = li[j - 1]; }
-      }
-    }
-  };
-  // NaN sorts after +inf: represent "empty" as (+inf, 0xFFFFFFFF) and let real NaNs displace empties
-  for (int64_t i = tid; i < chunk_n; i += 256) {
-    float v = d[i];
-    push(v != v ? INFINITY : v, (v != v) ? (uint32_t)(row_origin + i) : (uint32_t)(row_origin + i));
+struct SelArgs {
+  const float* d;         // [nq][ld] scores
+  const uint32_t* ids;    // NULL: id of element i is row_origin + i; else [nq][ld]
+  const uint32_t* counts; // NULL: every row holds n elements; else row q holds min(counts[q], ld)
+  int64_t ld, n;
+  uint32_t row_origin;
+  int k;
+  int nseg;               // segments per query = gridDim.x (without the carry block)
+  const float* prev_d;    // optional carried list [nq][k] (the running best), merged as one more segment
+  const uint32_t* prev_i;
+  float* out_d;           // [nq][out_ld], segment s writes [s*k, s*k+k)
+  uint32_t* out_i;
+  int64_t out_ld;
+};
+
+__global__ __launch_bounds__(256) void select_stage_kernel(SelArgs A) {
+  __shared__ float md[256];
+  __shared__ uint32_t mi[256];
+  __shared__ float Td;
+  __shared__ uint32_t Ti;
+  __shared__ float ld_[SEL_LIST];
+  __shared__ uint32_t li_[SEL_LIST];
+  __shared__ uint32_t lcount;
+  const int seg = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, k = A.k;
+  float* od = A.out_d + (int64_t)q * A.out_ld + (int64_t)seg * k;
+  uint32_t* oi = A.out_i + (int64_t)q * A.out_ld + (int64_t)seg * k;
+  if (seg == A.nseg) {  // carry block: copies the running best into the extra segment slot
+    if (tid < k) { od[tid] = A.prev_d[(int64_t)q * k + tid]; oi[tid] = A.prev_i[(int64_t)q * k + tid]; }
+    return;
   }
-  if (have_prev && tid == 0)
-    for (int j = 0; j < k; ++j) push(best_d[(int64_t)q * k + j], best_i[(int64_t)q * k + j]);
-  // k rounds of block-wide argmin over the heads of the per-thread sorted lists
-  __shared__ float sd[4];
-  __shared__ uint32_t si[4];
-  __shared__ int sw[4];
-  __shared__ int winner;
-  int head = 0;
-  for (int round = 0; round < k; ++round) {
-    float hd = INFINITY;
-    uint32_t hi = 0xFFFFFFFFu;
+  int64_t n = A.n;
+  if (A.counts) n = A.counts[q] < (uint64_t)A.ld ? (int64_t)A.counts[q] : A.ld;
+  const float* d = A.d + (int64_t)q * A.ld;
+  const uint32_t* ids = A.ids ? A.ids + (int64_t)q * A.ld : nullptr;
+  const int64_t base = (int64_t)seg * SEL_SEG;
+
+  float v[SEL_PER_THREAD];
+  uint32_t id[SEL_PER_THREAD];
+  float bd = INFINITY;
+  uint32_t bi = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j == head) { hd = ld_[j]; hi = li[j]; }
-    if (head >= KMAX) { hd = INFINITY; hi = 0xFFFFFFFFu; }
-    float bd = hd;
-    uint32_t bi = hi;
-    int bt = tid;
+  for (int j = 0; j < SEL_PER_THREAD; ++j) {
+    const int64_t p = base + j * 256 + tid;
+    const bool in = p < n;
+    float x = in ? d[p] : INFINITY;
+    x = (x != x) ? INFINITY : x;
+    const uint32_t y = in ? (ids ? ids[p] : (uint32_t)(A.row_origin + p)) : 0xFFFFFFFFu;
+    v[j] = x; id[j] = y;
+    if (x < bd || (x == bd && y < bi)) { bd = x; bi = y; }
+  }
+  md[tid] = bd; mi[tid] = bi;
+  if (tid == 0) lcount = 0;
+  __syncthreads();
+  {  // rank of this thread's minimum among the 256 minima
+    int rank = 0;
+    for (int t = 0; t < 256; ++t) rank += pair_less(md[t], mi[t], t, bd, bi, tid) ? 1 : 0;
+    if (rank == k - 1) { Td = bd; Ti = bi; }
+  }
+  __syncthreads();
+  const float td = Td;
+  const uint32_t ti = Ti;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      float od = __shfl_xor(bd, off, 64);
-      uint32_t oi = __shfl_xor(bi, off, 64);
-      int ot = __shfl_xor(bt, off, 64);
-      if (cand_less(od, oi, bd, bi) || (od == bd && oi == bi && ot < bt)) { bd = od; bi = oi; bt = ot; }
+  for (int j = 0; j < SEL_PER_THREAD; ++j) {
+    const bool pass = id[j] != 0xFFFFFFFFu && (v[j] < td || (v[j] == td && id[j] <= ti));
+    if (pass) {
+      const uint32_t s = atomicAdd(&lcount, 1u);
+      if (s < (uint32_t)SEL_LIST) { ld_[s] = v[j]; li_[s] = id[j]; }
     }
-    if ((tid & 63) == 0) { sd[tid >> 6] = bd; si[tid >> 6] = bi; sw[tid >> 6] = bt; }
-    __syncthreads();
-    if (tid == 0) {
-      int w = 0;
-      for (int x = 1; x < 4; ++x)
-        if (cand_less(sd[x], si[x], sd[w], si[w])) w = x;
-      winner = sw[w];
-      best_d[(int64_t)q * k + round] = sd[w];
-      best_i[(int64_t)q * k + round] = si[w];
+  }
+  __syncthreads();
+  const int L = (int)(lcount < (uint32_t)SEL_LIST ? lcount : (uint32_t)SEL_LIST);
+  for (int e = tid; e < L; e += 256) {
+    const float x = ld_[e];
+    const uint32_t y = li_[e];
+    int rank = 0;
+    for (int t = 0; t < L; ++t) rank += pair_less(ld_[t], li_[t], t, x, y, e) ? 1 : 0;
+    if (rank < k) { od[rank] = x; oi[rank] = y; }
+  }
+  if (tid >= L && tid < k) { od[tid] = INFINITY; oi[tid] = 0xFFFFFFFFu; }
+}
+
+// k best of every row of `d` (optionally merged with the running best in out_d/out_i) -> out_d/out_i
+int32_t select_topk(const float* d, const uint32_t* ids, const uint32_t* counts, int64_t ld, int64_t n,
+                    uint32_t row_origin, int nq, int k, bool have_prev, float* out_d, uint32_t* out_i, hipStream_t s) {
+  int64_t nseg = ceil_div(n > 0 ? n : 1, SEL_SEG);
+  bool carry = have_prev;
+  int flip = 0;
+  for (;;) {
+    const int64_t slots = nseg + (carry ? 1 : 0);
+    const bool last = slots == 1;
+    float* sd = out_d;
+    uint32_t* si = out_i;
+    int64_t out_ld = k;
+    if (!last) {
+      uint8_t* ws = (uint8_t*)scratch((size_t)nq * slots * k * 8, 9 + flip);
+      if (!ws) return DBHIP_ERR_HIP;
+      sd = (float*)ws;
+      si = (uint32_t*)(ws + (size_t)nq * slots * k * 4);
+      out_ld = slots * k;
     }
-    __syncthreads();
-    if (tid == winner) ++head;
-    __syncthreads();
+    SelArgs A{};
+    A.d = d; A.ids = ids; A.counts = counts; A.ld = ld; A.n = n; A.row_origin = row_origin; A.k = k;
+    A.nseg = (int)nseg; A.prev_d = out_d; A.prev_i = out_i; A.out_d = sd; A.out_i = si; A.out_ld = out_ld;
+    hipLaunchKernelGGL(select_stage_kernel, dim3((unsigned)slots, (unsigned)nq), dim3(256), 0, s, A);
+    DBHIP_LAUNCH_CHECK();
+    if (last) return DBHIP_OK;
+    // next stage reads the lists just written
+    d = sd; ids = si; counts = nullptr; ld = out_ld; n = out_ld; row_origin = 0;
+    nseg = ceil_div(n, SEL_SEG);
+    carry = false;
+    flip ^= 1;
   }
 }
 
@@ -273,24 +470,118 @@ __global__ __launch_bounds__(256) void score_u8_kernel(const uint8_t* __restrict
   }
 }
 
-int32_t launch_distance(int metric, const float* base, int64_t n, int dim, const float* queries, int nq,
-                        const float* bnorm, const float* qnorm, float* out, int64_t out_ld, int64_t i_origin,
-                        hipStream_t s) {
-  if (metric == DBHIP_VEC_DOT || metric == DBHIP_VEC_COSINE) {
-    dim3 grid((unsigned)ceil_div(n, 128), (unsigned)ceil_div(nq, 128));
-    if (metric == DBHIP_VEC_COSINE)
-      hipLaunchKernelGGL(dot_mfma_kernel<true>, grid, dim3(256), 0, s, base, n, dim, queries, nq, bnorm, qnorm, out, out_ld, i_origin);
-    else
-      hipLaunchKernelGGL(dot_mfma_kernel<false>, grid, dim3(256), 0, s, base, n, dim, queries, nq, bnorm, qnorm, out, out_ld, i_origin);
+template <int TQ, int TI, int WQ, bool VEC4>
+void launch_dot_shape(bool cosine, int mode, DotArgs& A, hipStream_t s) {
+  A.n_qtiles = (int)ceil_div(A.nq, TQ);
+  A.n_itiles = ceil_div(A.n, TI);
+  const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
+  dim3 grid((unsigned)blocks), block(256);
+  if (cosine) {
+    if (mode == MODE_WRITE) hipLaunchKernelGGL((dot_tile_kernel<TQ, TI, WQ, true, MODE_WRITE, VEC4>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((dot_tile_kernel<TQ, TI, WQ, true, MODE_FILTER, VEC4>), grid, block, 0, s, A);
   } else {
-    dim3 grid((unsigned)ceil_div(n, 64), (unsigned)ceil_div(nq, 64));
-    if (metric == DBHIP_VEC_L1)
-      hipLaunchKernelGGL(diff_valu_kernel<true>, grid, dim3(256), 0, s, base, n, dim, queries, nq, out, out_ld);
-    else
-      hipLaunchKernelGGL(diff_valu_kernel<false>, grid, dim3(256), 0, s, base, n, dim, queries, nq, out, out_ld);
+    if (mode == MODE_WRITE) hipLaunchKernelGGL((dot_tile_kernel<TQ, TI, WQ, false, MODE_WRITE, VEC4>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((dot_tile_kernel<TQ, TI, WQ, false, MODE_FILTER, VEC4>), grid, block, 0, s, A);
+  }
+}
+
+// dot / cosine scores of base rows [0, n) against nq queries; tile shape by query-batch size
+int32_t launch_dot(bool cosine, int mode, DotArgs A, hipStream_t s) {
+  if (A.n <= 0 || A.nq <= 0) return DBHIP_OK;
+  A.vec4 = (A.dim % 4 == 0) && A.dim >= 4 && (((uintptr_t)A.base | (uintptr_t)A.queries) % 16 == 0);
+  if (A.vec4) {
+    if (A.nq <= 32) launch_dot_shape<32, 256, 1, true>(cosine, mode, A, s);
+    else if (A.nq <= 64) launch_dot_shape<64, 256, 1, true>(cosine, mode, A, s);
+    else launch_dot_shape<128, 128, 2, true>(cosine, mode, A, s);
+  } else {  // odd dims / unaligned columns: scalar staging loads, one shape
+    launch_dot_shape<128, 128, 2, false>(cosine, mode, A, s);
   }
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
+}
+
+int32_t launch_distance(int metric, const float* base, int64_t n, int dim, const float* queries, int nq,
+                        const float* qnorm, float* out, int64_t out_ld, hipStream_t s) {
+  if (metric == DBHIP_VEC_DOT || metric == DBHIP_VEC_COSINE) {
+    DotArgs A{};
+    A.base = base; A.queries = queries; A.qnorm = qnorm; A.n = n; A.dim = dim; A.nq = nq;
+    A.out = out; A.out_ld = out_ld;
+    return launch_dot(metric == DBHIP_VEC_COSINE, MODE_WRITE, A, s);
+  }
+  dim3 grid((unsigned)ceil_div(n, 64), (unsigned)ceil_div(nq, 64));
+  if (metric == DBHIP_VEC_L1)
+    hipLaunchKernelGGL(diff_valu_kernel<true>, grid, dim3(256), 0, s, base, n, dim, queries, nq, out, out_ld);
+  else
+    hipLaunchKernelGGL(diff_valu_kernel<false>, grid, dim3(256), 0, s, base, n, dim, queries, nq, out, out_ld);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+constexpr uint32_t CAND_CAP = 4096;  // candidates kept per query by the filtered pass
+
+// Exact top-k of one query batch (nq queries, all on the device).
+//   1. sample   : rows [0, S) are scored into scratch and reduced to their exact top-k; the k-th
+//                 best of the sample is an upper bound (tau) of the query's final k-th best.
+//   2. filter   : rows [S, n) are scored by the MFMA kernel whose epilogue appends only scores
+//                 <= tau to the query's candidate list — the n x nq matrix never exists.
+//   3. reduce   : sample top-k + candidates -> final top-k (ties by lower row id).
+// If a candidate list overflows (adversarial row order) the remaining rows are redone with the
+// chunked materialising path, which is always exact.
+int32_t topk_batch(int metric, const float* base, int64_t n, int dim, const float* queries, int nq, int k,
+                   const float* qnorm, uint32_t* out_idx, float* out_dist, hipStream_t s) {
+  const bool gemm = metric == DBHIP_VEC_DOT || metric == DBHIP_VEC_COSINE;
+  int64_t S = n;
+  if (gemm && n > 65536) {
+    S = n / 64 > 65536 ? n / 64 : 65536;
+    S = ceil_div(S, 256) * 256;
+    if (S > n) S = n;
+  }
+  // --- chunked materialising path over [lo, hi) ---
+  auto chunked = [&](int64_t lo, int64_t hi, bool have_prev) -> int32_t {
+    int64_t chunk = (int64_t)(1LL << 28) / nq;
+    chunk = chunk < 4096 ? 4096 : chunk;
+    chunk = (chunk / 256) * 256;
+    if (chunk > hi - lo) chunk = ceil_div(hi - lo > 0 ? hi - lo : 1, 256) * 256;
+    float* dist = (float*)scratch((size_t)chunk * nq * 4, 6);
+    if (!dist) return DBHIP_ERR_HIP;
+    bool first = !have_prev;
+    for (int64_t c0 = lo; c0 < hi || first; c0 += chunk) {
+      int64_t cn = hi - c0 < chunk ? hi - c0 : chunk;
+      int32_t rc = DBHIP_OK;
+      if (cn > 0) {
+        rc = launch_distance(metric, base + c0 * dim, cn, dim, queries, nq, qnorm, dist, chunk, s);
+        if (rc) return rc;
+      }
+      rc = select_topk(dist, nullptr, nullptr, chunk, cn > 0 ? cn : 0, (uint32_t)c0, nq, k, !first, out_dist, out_idx, s);
+      if (rc) return rc;
+      first = false;
+      if (hi <= lo) break;
+    }
+    return DBHIP_OK;
+  };
+  int32_t rc = chunked(0, S, false);
+  if (rc || S >= n) return rc;
+
+  uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8);
+  if (!ws) return DBHIP_ERR_HIP;
+  uint32_t* cnt = (uint32_t*)ws;
+  float* cand_d = (float*)(ws + (((size_t)nq * 4 + 63) & ~(size_t)63));
+  uint32_t* cand_i = (uint32_t*)(cand_d + (size_t)nq * CAND_CAP);
+  DBHIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nq * 4, s));
+  DotArgs A{};
+  A.base = base + S * dim; A.queries = queries; A.qnorm = qnorm; A.n = n - S; A.dim = dim; A.nq = nq;
+  A.tau = out_dist + (k - 1); A.tau_stride = k;
+  A.cand_d = cand_d; A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)S;
+  rc = launch_dot(metric == DBHIP_VEC_COSINE, MODE_FILTER, A, s);
+  if (rc) return rc;
+  static thread_local std::vector<uint32_t> hcnt;
+  hcnt.resize(nq);
+  DBHIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  bool overflow = false;
+  for (int q = 0; q < nq; ++q) overflow |= hcnt[q] > CAND_CAP;
+  if (overflow) return chunked(S, n, true);
+  return select_topk(cand_d, cand_i, cnt, CAND_CAP, CAND_CAP, 0u, nq, k, true, out_dist, out_idx, s);
 }
 
 }  // namespace
@@ -304,16 +595,16 @@ int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t
   if (n == 0 || nq == 0) return DBHIP_OK;
   DBHIP_REQUIRE(base && queries && out, "dbhip_vec_distance: NULL argument");
   hipStream_t s = resolve_stream(stream);
-  float* bnorm = nullptr;
   float* qnorm = nullptr;
   if (metric == DBHIP_VEC_COSINE) {
-    bnorm = (float*)scratch((size_t)(n + nq) * 4, 5);
-    if (!bnorm) return DBHIP_ERR_HIP;
-    qnorm = bnorm + n;
-    hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, s, base, n, dim, bnorm);
+    qnorm = (float*)scratch((size_t)nq * 4, 5);
+    if (!qnorm) return DBHIP_ERR_HIP;
     hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim, qnorm);
   }
-  return launch_distance(metric, base, n, dim, queries, nq, bnorm, qnorm, out, n, 0, s);
+  kernel_timer_start(s);
+  int32_t rc = launch_distance(metric, base, n, dim, queries, nq, qnorm, out, n, s);
+  kernel_timer_stop(s);
+  return rc;
 }
 
 int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim, const float* queries,
@@ -328,36 +619,20 @@ int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim
   if (nq == 0) return DBHIP_OK;
   DBHIP_REQUIRE(queries && out_idx && out_dist && (base || n == 0), "dbhip_vec_topk: NULL argument");
   hipStream_t s = resolve_stream(stream);
-  // chunk so that the distance scratch stays <= ~1 GiB
-  int64_t chunk = (int64_t)(1LL << 28) / (nq > 0 ? nq : 1);
-  chunk = chunk < 4096 ? 4096 : chunk;
-  chunk = (chunk / 128) * 128;
-  if (chunk > n) chunk = ((n + 127) / 128) * 128;
-  if (chunk < 128) chunk = 128;
-  float* dist = (float*)scratch((size_t)chunk * nq * 4, 6);
-  if (!dist) return DBHIP_ERR_HIP;
-  float* bnorm = nullptr;
   float* qnorm = nullptr;
   if (metric == DBHIP_VEC_COSINE) {
-    bnorm = (float*)scratch((size_t)(n + nq + 1) * 4, 5);
-    if (!bnorm) return DBHIP_ERR_HIP;
-    qnorm = bnorm + n;
-    if (n) hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, s, base, n, dim, bnorm);
+    qnorm = (float*)scratch((size_t)(nq + 1) * 4, 5);
+    if (!qnorm) return DBHIP_ERR_HIP;
     hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim, qnorm);
   }
-  bool first = true;
+  // query batches bound the scratch of the sample pass (<= 1 GiB of scores)
+  const int QB = 2048;
   kernel_timer_start(s);
-  for (int64_t c0 = 0; c0 < n || first; c0 += chunk) {
-    int64_t cn = n - c0 < chunk ? n - c0 : chunk;
-    if (cn > 0) {
-      int32_t rc = launch_distance(metric, base + c0 * dim, cn, dim, queries, nq, bnorm, qnorm, dist, chunk, c0, s);
-      if (rc) return rc;
-    }
-    hipLaunchKernelGGL(topk_chunk_kernel, dim3(nq), dim3(256), 0, s, dist, cn > 0 ? cn : 0, chunk, (uint32_t)c0, k,
-                       out_dist, out_idx, first ? 0 : 1);
-    DBHIP_LAUNCH_CHECK();
-    first = false;
-    if (n == 0) break;
+  for (int qb = 0; qb < nq; qb += QB) {
+    const int bn = nq - qb < QB ? nq - qb : QB;
+    int32_t rc = topk_batch(metric, base, n, dim, queries + (int64_t)qb * dim, bn, k, qnorm ? qnorm + qb : nullptr,
+                            out_idx + (int64_t)qb * k, out_dist + (int64_t)qb * k, s);
+    if (rc) return rc;
   }
   kernel_timer_stop(s);
   return DBHIP_OK;

@@ -19,7 +19,7 @@ struct Scratch {
   void* p = nullptr;
   size_t cap = 0;
 };
-static thread_local Scratch g_scratch[8];
+static thread_local Scratch g_scratch[16];
 
 void set_error(const char* fmt, ...) {
   va_list ap;

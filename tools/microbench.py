@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default="")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--vec-nq", default="1,32,64,128,512,2048")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda k: not only or k in only
@@ -244,7 +245,7 @@ def main():
     if want("vector"):
         n, dim = int(1_250_000 * args.scale), 768
         base = torch.randn((n, dim), device=dev, dtype=torch.float32, generator=g)
-        for nq in (1, 64, 512):
+        for nq in [int(x) for x in args.vec_nq.split(',')]:
             q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
             oi = torch.empty(nq * 10, dtype=torch.int32, device=dev)
             od = torch.empty(nq * 10, dtype=torch.float32, device=dev)
