@@ -49,6 +49,10 @@ struct dbhip_groupby {
   uint64_t* rows_in; size_t rows_in_cap;
   uint32_t* gid; size_t gid_cap;
   uint32_t* retry; size_t retry_cap;
+  // LDS pre-aggregation path (add_block on short layouts)
+  uint64_t* partial; size_t partial_cap;   // per-workgroup partial rows
+  int fast_disabled;                       // set once most rows of a chunk spilled (high NDV)
+  int fast_trusted;                        // last chunk spilled < 1 %: no more probing chunks
 };
 
 namespace {
@@ -92,11 +96,12 @@ __global__ __launch_bounds__(256) void group_hash_kernel(HashCols hc, int64_t n,
 // ---------------------------------------------------------------------------
 // serialize: columns -> rows_in
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C, int64_t n,
+__global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n,
                                                            uint64_t* rows_in, uint64_t* ctrl) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t* r = rows_in + i * L.W;
+  for (int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; li < n;
+       li += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t* r = rows_in + li * L.W;
+    const int64_t i = row0 + li;
     uint64_t h = 0, vmask = 0;
     for (int k = 0; k < L.nkeys; ++k) {
       uint64_t w[2];
@@ -634,6 +639,302 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
   return DBHIP_ERR_CAPACITY;
 }
 
+
+// ---------------------------------------------------------------------------
+// LDS pre-aggregation path of add_block ("partial aggregation inside the workgroup").
+//
+// The reference bounds its partial AggregateHashTable to the CPU cache and lets duplicates through
+// (aggregate/mod.rs:98-124, aggregate_hashtable.rs:277-290); the device analogue is a hash table in
+// the workgroup's LDS: every row is hashed, matched/claimed in the LDS table (64-bit CAS on the hash
+// word) and its state contribution merged with LDS atomics, so low- and medium-cardinality group-bys
+// touch HBM only to read the argument columns once (coalesced, 2 rows per lane in flight).
+// At the end each workgroup flushes its <= LCAP partial rows; they are merged into the HBM table by
+// the row path above, exactly like partial payloads in TransformFinalAggregate. Rows that do not
+// fit the LDS table (it is full, or a true 64-bit hash collision) are serialized to a spill buffer
+// and go through the row path as well. Layout limits of this path: <= 4 key words, <= 6 aggregates.
+// Key equality inside one tile is decided after a workgroup barrier (claim by hash, verify after the
+// barrier), so no lane ever spins on another lane.
+// ---------------------------------------------------------------------------
+constexpr int FK_MAXKW = 4;
+constexpr int FK_MAXA = 6;
+constexpr uint32_t FK_SPILL = 0xFFFFFFFFu;
+
+// Register image of one input row. KW / NA / HI are compile-time bounds of the layout class
+// (key words, aggregates, "some argument needs a second word" = Decimal128), so that the small and
+// common shapes (1-2 integer keys, sum + count) keep 8 rows per lane in flight.
+template <int KW, int NA, bool HI>
+struct FkRow {
+  uint64_t kw[KW];
+  uint64_t h;
+  uint64_t aw[NA];
+  uint64_t ah[HI ? NA : 1];
+  uint32_t avalid;
+};
+
+template <int KW>
+__device__ __forceinline__ void fk_put(uint64_t (&a)[KW], int off, uint64_t v) {
+#pragma unroll
+  for (int j = 0; j < KW; ++j) a[j] = (j == off) ? v : a[j];
+}
+
+template <int KW, int NA, bool HI>
+__device__ __forceinline__ void fk_load(const GbLayout& L, const GbCols& C, int64_t i, FkRow<KW, NA, HI>& r, uint64_t* ctrl) {
+  uint64_t h = 0, vmask = 0;
+#pragma unroll
+  for (int j = 0; j < KW; ++j) r.kw[j] = 0;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    if (k < L.nkeys) {
+      uint64_t w[2];
+      bool valid;
+      if (!gb_load_words(C.key[k], i, w, &valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+      const uint64_t hk = gb_hash_words(L.key_type[k], w, valid);
+      h = (k == 0) ? hk : merge_hash(h, hk);
+      fk_put<KW>(r.kw, L.key_off[k], w[0]);
+      if (L.key_words[k] == 2) fk_put<KW>(r.kw, L.key_off[k] + 1, w[1]);
+      if (valid) vmask |= 1ULL << k;
+    }
+  }
+  if (L.validity_word >= 0) fk_put<KW>(r.kw, L.validity_word, vmask);
+  r.h = h;
+  r.avalid = 0;
+  if (HI) {
+#pragma unroll
+    for (int a = 0; a < (HI ? NA : 1); ++a) r.ah[a] = 0;
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    r.aw[a] = 0;
+    if (a < L.naggs) {
+      uint64_t w[2] = {0, 0};
+      bool valid = true;
+      if (C.arg[a].data != nullptr) gb_load_words(C.arg[a], i, w, &valid);
+      r.aw[a] = w[0];
+      if (HI) r.ah[a] = w[1];
+      if (valid) r.avalid |= 1u << a;
+    }
+  }
+}
+
+// state contribution of one row for aggregate a (same encoding as gb_serialize_kernel)
+__device__ __forceinline__ void fk_contrib(const GbLayout& L, int a, uint64_t w0, uint64_t w1, bool valid, uint64_t v[3]) {
+  v[0] = 0; v[1] = 0; v[2] = 0;
+  switch (L.agg_kind[a]) {
+    case DBHIP_AGG_COUNT:
+      v[0] = valid ? 1 : 0;
+      break;
+    case DBHIP_AGG_SUM:
+      if (L.agg_type[a] == DBHIP_T_F32) w0 = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)w0));
+      v[0] = valid ? w0 : 0;
+      if (L.agg_words[a] == 3) {
+        v[1] = valid ? w1 : 0;
+        v[2] = (valid && (w1 >> 63)) ? ~0ULL : 0;
+      }
+      break;
+    default:
+      v[0] = ord_encode(w0, L.agg_type[a]);
+      v[1] = valid ? 1 : 0;
+      break;
+  }
+}
+
+struct FkArgs {
+  int64_t row0, n;         // rows [row0, row0 + n) of the columns
+  int64_t tiles_per_block;
+  int lcap, sw;            // LDS table capacity (pow2) and row stride in words
+  uint32_t llimit;         // max occupied LDS slots
+  uint64_t hash_mask;
+  uint64_t* partial;       // [gridDim.x * lcap][W]
+  uint64_t* spill;         // [n][W]
+  uint64_t* ctrl;          // [5] = #partial rows, [6] = #spill rows, [3] error bits
+};
+
+template <int KW, int NA, bool HI, int R>
+__global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C, FkArgs A) {
+  extern __shared__ uint64_t fk_lds[];
+  __shared__ uint32_t lcount;
+  uint64_t* lhash = fk_lds;
+  uint64_t* lrows = fk_lds + A.lcap;
+  const int tid = threadIdx.x;
+  const uint32_t lmask = (uint32_t)A.lcap - 1;
+  for (int s = tid; s < A.lcap; s += 256) lhash[s] = 0;
+  if (tid == 0) lcount = 0;
+  __syncthreads();
+
+  const int64_t tile_rows = 256 * R;
+  const int64_t t_begin = (int64_t)blockIdx.x * A.tiles_per_block;
+  const int64_t ntiles = (A.n + tile_rows - 1) / tile_rows;
+  int64_t t_end = t_begin + A.tiles_per_block;
+  if (t_end > ntiles) t_end = ntiles;
+
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    FkRow<KW, NA, HI> r[R];
+    uint32_t slot[R];
+    // ---- loads of the whole tile first (R rows per lane in flight) ----
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      const int64_t li = t * tile_rows + x * 256 + tid;
+      fk_load<KW, NA, HI>(L, C, A.row0 + (li < A.n ? li : 0), r[x], A.ctrl);
+    }
+    // ---- phase A: match-or-claim by hash ----
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      const int64_t li = t * tile_rows + x * 256 + tid;
+      slot[x] = FK_SPILL;
+      if (li < A.n) {
+        const uint64_t hw = probe_word(r[x].h, A.hash_mask);
+        uint32_t pos = (uint32_t)hw & lmask;
+        for (int step = 0; step < 64; ++step) {
+          uint64_t cur = ((volatile uint64_t*)lhash)[pos];
+          if (cur == 0) {
+            if (((volatile uint32_t*)&lcount)[0] >= A.llimit) break;
+            const unsigned long long old = atomicCAS((unsigned long long*)&lhash[pos], 0ULL, (unsigned long long)hw);
+            if (old == 0) {
+              atomicAdd(&lcount, 1u);
+              uint64_t* d = lrows + (size_t)pos * A.sw;
+#pragma unroll
+              for (int j = 0; j < KW; ++j)
+                if (j < L.nkey_words) d[j] = r[x].kw[j];
+              d[L.hash_word] = r[x].h;
+#pragma unroll
+              for (int a = 0; a < NA; ++a)
+                if (a < L.naggs) gb_state_identity(L, a, d + L.agg_off[a]);
+              slot[x] = pos;
+              break;
+            }
+            cur = old;
+          }
+          if (cur == hw) { slot[x] = pos; break; }
+          pos = (pos + 1) & lmask;
+        }
+      } else {
+        slot[x] = FK_SPILL - 1;  // padding row: neither aggregated nor spilled
+      }
+    }
+    __syncthreads();  // keys and identity states of every slot claimed in this tile are visible
+    // ---- phase B: verify keys, merge states with LDS atomics; the rest spills ----
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      bool spill = slot[x] == FK_SPILL;
+      if (slot[x] < FK_SPILL - 1) {
+        uint64_t* d = lrows + (size_t)slot[x] * A.sw;
+        bool eq = true;
+#pragma unroll
+        for (int j = 0; j < KW; ++j)
+          if (j < L.nkey_words) eq &= (d[j] == r[x].kw[j]);
+        if (eq) {
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            if (a < L.naggs) {
+              uint64_t v[3];
+              fk_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
+              gb_atomic_merge(L, a, d + L.agg_off[a], v);
+            }
+        } else {
+          spill = true;  // same probe hash, different keys
+        }
+      }
+      const uint64_t m = __ballot(spill);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane_id() == leader) base = atomicAdd((unsigned long long*)&A.ctrl[6], (unsigned long long)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (spill) {
+          uint64_t* o = A.spill + (base + __popcll(m & ((1ULL << lane_id()) - 1))) * L.W;
+#pragma unroll
+          for (int j = 0; j < KW; ++j)
+            if (j < L.nkey_words) o[j] = r[x].kw[j];
+          o[L.hash_word] = r[x].h;
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            if (a < L.naggs) {
+              uint64_t v[3];
+              fk_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
+              for (int k = 0; k < L.agg_words[a]; ++k) o[L.agg_off[a] + k] = v[k];
+            }
+        }
+      }
+    }
+    // no barrier needed here: the next tile only adds NEW slots; slots matched above never change keys
+  }
+  __syncthreads();
+  // ---- flush the workgroup's partial rows ----
+  for (int s = tid; s < A.lcap; s += 256) {
+    const bool occ = lhash[s] != 0;
+    if (occ) {
+      const unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[5], 1ULL);
+      const uint64_t* src = lrows + (size_t)s * A.sw;
+      uint64_t* o = A.partial + idx * L.W;
+      for (int k = 0; k < L.W; ++k) o[k] = src[k];
+    }
+  }
+}
+
+bool fast_layout_ok(const GbLayout& L) {
+  return L.nkey_words <= FK_MAXKW && L.nkeys <= FK_MAXKW && L.naggs <= FK_MAXA && L.W <= 24;
+}
+
+// add_block through the LDS pre-aggregation kernel, chunk by chunk. Returns -1 when the caller must
+// use the generic row path for rows [*done, n).
+int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, int64_t* done) {
+  const GbLayout& L = g->L;
+  const int sw = L.W | 1;  // odd stride (in 8-byte words): conflict-free LDS rows
+  int lcap = 64;
+  while ((size_t)(lcap * 2) * (sw + 1) * 8 <= 48 * 1024) lcap *= 2;
+  const size_t lds_bytes = (size_t)lcap * (sw + 1) * 8;
+  // layout class: small = <= 2 key words, <= 2 one-word aggregates (8 rows per lane); else general (2 rows)
+  bool hi = false;
+  for (int a = 0; a < L.naggs; ++a) hi |= L.agg_type[a] == DBHIP_T_DEC128 && L.agg_kind[a] != DBHIP_AGG_COUNT;
+  const bool small = L.nkey_words <= 2 && L.nkeys <= 2 && L.naggs <= 2 && !hi;
+  const int R = small ? 8 : 2;
+  const int64_t CHUNK = 16 << 20;
+  const int64_t tile_rows = 256 * R;
+  int blocks_per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
+  if (blocks_per_cu > 4) blocks_per_cu = 4;
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  const int max_grid = 256 * blocks_per_cu;  // every workgroup resident at once: no tail round
+  int32_t rc;
+  while (*done < n) {
+    if (g->fast_disabled) return -1;
+    // The first chunk of a big block is a small probe of the key distribution; when it spills
+    // (almost) nothing the rest of the block is one launch (its spill buffer is sized for the worst
+    // case but stays untouched), otherwise bounded chunks keep re-checking the spill ratio.
+    int64_t limit = CHUNK;
+    if (!g->fast_trusted && n - *done > (4 << 20)) limit = 1 << 20;
+    else if (g->fast_trusted) limit = n;
+    const int64_t cn = n - *done < limit ? n - *done : limit;
+    const int64_t ntiles = ceil_div(cn, tile_rows);
+    int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    const int64_t tpb = ceil_div(ntiles, grid);
+    grid = (int)ceil_div(ntiles, tpb);
+    if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * lcap * L.W * 8))) return rc;
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
+    FkArgs A;
+    A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap; A.sw = sw;
+    A.llimit = (uint32_t)(lcap - lcap / 4);
+    A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
+    if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    DBHIP_LAUNCH_CHECK();
+    uint64_t hc[8];
+    DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    if (hc[3] & 2) {
+      set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    if ((rc = merge_rows(g, g->partial, (int64_t)hc[5], s))) return rc;
+    if ((rc = merge_rows(g, g->rows_in, (int64_t)hc[6], s))) return rc;
+    *done += cn;
+    // most rows spilled: the LDS table is too small for this key distribution
+    if ((int64_t)hc[6] * 10 > cn && cn >= 65536) g->fast_disabled = 1;
+    g->fast_trusted = (int64_t)hc[6] * 100 <= cn;
+  }
+  return DBHIP_OK;
+}
+
 }  // namespace
 
 // Used by k_q1.hip: merge `n` device rows (table layout) produced by a fused kernel.
@@ -726,12 +1027,24 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
     }
     C.arg[a] = to_gbcol(args[a]);
   }
-  int32_t rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)n * g->L.W * 8);
-  if (rc) return rc;
-  hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, C, n, g->rows_in,
-                     g->ctrl);
-  DBHIP_LAUNCH_CHECK();
-  return merge_rows(g, g->rows_in, n, s);
+  int32_t rc;
+  int64_t done = 0;
+  if (fast_layout_ok(g->L)) {
+    rc = add_block_fast(g, C, n, s, &done);
+    if (rc >= 0) return rc;
+  }
+  // generic row path (any layout; high-cardinality continuation of the fast path), in bounded chunks
+  const int64_t CHUNK = 32 << 20;
+  while (done < n) {
+    const int64_t cn = n - done < CHUNK ? n - done : CHUNK;
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
+    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
+                       g->ctrl);
+    DBHIP_LAUNCH_CHECK();
+    if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
+    done += cn;
+  }
+  return DBHIP_OK;
 }
 
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, void* stream) {
@@ -845,6 +1158,8 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)g->cap * 8, s));
   DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 64, s));
   g->count_host = 0;
+  g->fast_disabled = 0;
+  g->fast_trusted = 0;
   return DBHIP_OK;
 }
 
@@ -857,6 +1172,7 @@ int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (g->rows_in) (void)hipFree(g->rows_in);
   if (g->gid) (void)hipFree(g->gid);
   if (g->retry) (void)hipFree(g->retry);
+  if (g->partial) (void)hipFree(g->partial);
   delete g;
   return DBHIP_OK;
 }

@@ -446,3 +446,56 @@ def test_q1_finalize_avg_matches_sf_style_golden_shape(gpu, oracle):
     out = tpch.q1_finalize(rows)
     # 37734107.00 / 1478493 = 25.52200585 ; 56586554400.73 / 1478493 = 38273.12973462 (SF1 golden row A,F)
     assert out[0][6] == 2552200585 and out[0][7] == 3827312973462
+
+
+@pytest.mark.parametrize("n,card", [(1, 1), (513, 3), (70_000, 4), (300_000, 700), (300_000, 5000), (400_000, 390_000)])
+def test_groupby_short_layout_lds_preaggregation_matches_oracle(gpu, oracle, n, card):
+    """Short layouts (<= 4 key words, <= 6 aggregates) go through the workgroup-LDS partial aggregation;
+    cardinalities below and far above the LDS table capacity (spill to the row path), nullable key,
+    Decimal128 sum, min/max — compared with the oracle as sorted row sets."""
+    rng = np.random.default_rng(n * 7 + card)
+    k_i64 = rng.integers(0, card, n).astype(np.int64) * 7919 - 3
+    k_date = rng.integers(0, 3, n).astype(np.int32)
+    kvalid = rng.integers(0, 16, n) > 0
+    a_i64 = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    a_dec128 = [int(x) * 10**12 for x in rng.integers(-10**17, 10**17, n)]
+    a_u32 = rng.integers(0, 2**32 - 1, n, dtype=np.uint64).astype(np.uint32)
+    avalid = rng.integers(0, 3, n) > 0
+    key_types, key_nullable = [T.T_I64, T.T_DATE], [1, 0]
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC128, 31, 4, 0), (T.AGG_MIN, T.T_U32, 0, 0, 0),
+            (T.AGG_MAX, T.T_I64, 0, 0, 0), (T.AGG_COUNT, T.T_U32, 0, 0, 1)]
+    gkeys = [gpu.Column.from_numpy(k_i64, validity=kvalid), gpu.Column.from_numpy(k_date, T.T_DATE)]
+    gargs = [gpu.Column.from_numpy(a_i64), None, gpu.Column.decimal128(a_dec128, 31, 4), gpu.Column.from_numpy(a_u32), gpu.Column.from_numpy(a_i64),
+             gpu.Column.from_numpy(a_u32, validity=avalid)]
+    hkeys = [O.HostCol(T.T_I64, k_i64, kvalid), O.HostCol(T.T_DATE, k_date)]
+    hargs = [O.HostCol(T.T_I64, a_i64), None, O.HostCol(T.T_DEC128, O.i128_array(a_dec128), None, 31, 4), O.HostCol(T.T_U32, a_u32), O.HostCol(T.T_I64, a_i64),
+             O.HostCol(T.T_U32, a_u32, avalid)]
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    g.add_block(gkeys, gargs, n)
+    got = g.result()
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n)
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert g.num_groups() == len(exp)
+    assert norm(got) == norm(exp)
+    # a second block doubles every sum / count and leaves min / max
+    g.add_block(gkeys, gargs, n)
+    got2 = {r[:2]: r for r in g.result()}
+    for r in exp:
+        r2 = got2[r[:2]]
+        assert r2[2] == ((r[2] * 2 + 2**63) % 2**64) - 2**63 and r2[3] == 2 * r[3] and r2[4] == 2 * r[4] and r2[5:7] == r[5:7] and r2[7] == 2 * r[7]
+
+
+def test_groupby_short_layout_string_key_and_f64_sum(gpu, oracle):
+    n = 120_000
+    rng = np.random.default_rng(77)
+    strs = [b"k%03d" % x for x in rng.integers(0, 400, n)]
+    a_f32 = rng.integers(-1000, 1000, n).astype(np.float32)  # integers: the f64 sum is order independent
+    g = gpu.GroupBy([T.T_STRING], [(T.AGG_SUM, T.T_F32, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)])
+    g.add_block([gpu.Column.strings(strs)], [gpu.Column.from_numpy(a_f32), None], n)
+    exp = {}
+    for s_, v in zip(strs, a_f32.tolist()):
+        e = exp.setdefault(s_, [0.0, 0])
+        e[0] += v
+        e[1] += 1
+    assert sorted(g.result()) == sorted((k, v[0], v[1]) for k, v in exp.items())

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--vec-nq", default="1,32,64,128,512,2048")
+    ap.add_argument("--gb-card", default="4,200,1000,20000,1000000,10000000")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda k: not only or k in only
@@ -185,7 +186,7 @@ def main():
 
     if want("groupby"):
         n = int(60_000_000 * args.scale)
-        for card in (4, 1000, 1_000_000, 10_000_000):
+        for card in [int(x) for x in args.gb_card.split(',')]:
             keys = ri(0, card, n)
             vals = ri(0, 1000, n)
             gb = D.GroupBy([L.T_I64], [(L.AGG_SUM, L.T_I64, 0, 0, 0), (L.AGG_COUNT, 0, 0, 0, 0)], capacity=max(1024, card * 2))
