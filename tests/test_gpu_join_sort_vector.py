@@ -189,3 +189,16 @@ def test_score_u8_matches_reference_c_kernels(gpu, oracle):
             got = gpu.score_u8(is_l1, q, base)
             exp = np.array([f(q.ctypes.data_as(C.c_void_p), base[i].ctypes.data_as(C.c_void_p), C.c_uint32(dim)) for i in range(n)], np.float32)
             assert np.array_equal(got, exp)
+
+
+def test_vec_topk_known_answers_from_sqllogictest(gpu):
+    """Exact (table t1) top-5 of the reference's 09_0000_vector_index_base.test:108-200 through
+    dbhip_vec_topk (ids and distances)."""
+    g = json.load(open(os.path.join(HERE, "golden", "vector_topk.json")))
+    base = gpu.VectorColumn(np.array(g["base"], np.float32))
+    names = {"cosine_distance": T.VEC_COSINE, "l1_distance": T.VEC_L1, "l2_distance": T.VEC_L2}
+    for q in g["queries"]:
+        idx, dist = gpu.vec_topk(names[q["fn"]], base, gpu.VectorColumn(np.array([q["query"]], np.float32)), 5)
+        assert [int(i) + 1 for i in idx[0]] == [e[0] for e in q["expected"]], q["fn"]
+        for d, (_, ev) in zip(dist[0], q["expected"]):
+            assert abs(float(d) - ev) <= 1e-5 * max(1.0, abs(ev)) + 2e-7

@@ -178,3 +178,160 @@ def test_group_hash_relative_properties():
     h ^= h >> 47; h = (h * M) & mask; h ^= h >> 47
     buf = np.frombuffer(s, np.uint8).copy()
     assert L.orc_agg_hash_bytes(buf.ctypes.data_as(C.c_void_p), C.c_uint64(3)) == h
+
+
+VEC = {"cosine_distance": T.VEC_COSINE, "l1_distance": T.VEC_L1, "l2_distance": T.VEC_L2, "inner_product": T.VEC_DOT}
+
+
+def orc_vec(metric, base, queries):
+    L = O.load()
+    base = np.ascontiguousarray(base, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    out = np.zeros((queries.shape[0], base.shape[0]), np.float32)
+    L.orc_vec_distance(metric, base.ctypes.data_as(C.c_void_p), C.c_int64(base.shape[0]), base.shape[1],
+                       queries.ctypes.data_as(C.c_void_p), queries.shape[0], out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def test_vector_golden_scalar_cases():
+    """vector.txt column cases (tests/golden/vector.json): oracle distances within 1e-5 relative."""
+    checked = 0
+    for c in golden("vector.json"):
+        fn = c["ast"].split("(")[0]
+        cols = c["columns"]
+        if fn not in VEC or not all(k in cols for k in "abcd"):
+            continue
+        if any(cols[k]["type"].replace(" NULL", "") not in ("Float32", "Float64") for k in "abcd"):
+            continue
+        val = lambda k: np.array([float(x) for x in cols[k]["values"]], np.float32)
+        exp = [float(x) for x in cols["Output"]["values"]]
+        for r in range(c["n"]):
+            got = orc_vec(VEC[fn], [[val("a")[r], val("b")[r]]], [[val("c")[r], val("d")[r]]])[0, 0]
+            assert abs(float(got) - exp[r]) <= 1e-5 * max(1.0, abs(exp[r])), (c["ast"], r)
+        checked += 1
+    assert checked >= 4
+
+
+def test_vector_topk_known_answers_from_sqllogictest():
+    """Exact (table t1) top-5 of 09_0000_vector_index_base.test:108-200 (tests/golden/vector_topk.json)."""
+    g = json.load(open(os.path.join(HERE, "golden", "vector_topk.json")))
+    base = np.array(g["base"], np.float32)
+    assert len(g["queries"]) >= 6
+    for q in g["queries"]:
+        d = orc_vec(VEC[q["fn"]], base, [q["query"]])[0]
+        order = np.lexsort((np.arange(16), d))[:5]
+        assert [int(i) + 1 for i in order] == [e[0] for e in q["expected"]], q["fn"]
+        for i, (_, ev) in zip(order, q["expected"]):
+            assert abs(float(d[i]) - ev) <= 1e-5 * max(1.0, abs(ev)) + 2e-7, (q["fn"], i, d[i], ev)
+
+
+def test_packed_join_keys_and_inner_join_against_numpy():
+    """orc_join_inner_u64 (hashjoin_hashtable.rs / fixed_keys.rs restatement) vs a sort-merge in numpy;
+    NULL keys never match (memory/inner_join.rs)."""
+    L = O.load()
+    rng = np.random.default_rng(3)
+    nb, npr = 5000, 20000
+    b = rng.integers(0, 3000, nb).astype(np.uint64)
+    p = rng.integers(0, 4000, npr).astype(np.uint64)
+    bv = rng.integers(0, 10, nb) > 0
+    pv = rng.integers(0, 10, npr) > 0
+    bvb = np.concatenate([np.packbits(bv, bitorder="little"), np.zeros(8, np.uint8)])
+    pvb = np.concatenate([np.packbits(pv, bitorder="little"), np.zeros(8, np.uint8)])
+    cap = 200000
+    op, ob = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    m = L.orc_join_inner_u64(b.ctypes.data_as(C.c_void_p), bvb.ctypes.data_as(C.c_void_p), C.c_int64(nb), p.ctypes.data_as(C.c_void_p),
+                             pvb.ctypes.data_as(C.c_void_p), C.c_int64(npr), op.ctypes.data_as(C.c_void_p), ob.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+    got = sorted(zip(op[:m].tolist(), ob[:m].tolist()))
+    by_key = {}
+    for j in range(nb):
+        if bv[j]:
+            by_key.setdefault(int(b[j]), []).append(j)
+    exp = sorted((i, j) for i in range(npr) if pv[i] for j in by_key.get(int(p[i]), []))
+    assert got == exp and m > 1000
+
+
+def test_sort_perm_against_numpy_with_nulls_desc_and_limit():
+    """orc_sort_perm (kernels/sort_compare.rs restatement): multi-key, asc/desc, nulls first/last, limit."""
+    L = O.load()
+    rng = np.random.default_rng(4)
+    n = 3000
+    k1 = rng.integers(-5, 5, n).astype(np.int32)
+    k2 = rng.standard_normal(n).astype(np.float64)
+    k2[rng.integers(0, n, 20)] = np.nan
+    v1 = rng.integers(0, 6, n) > 0
+    for desc, nf, limit in (([0, 0], [0, 0], 0), ([1, 0], [1, 0], 0), ([0, 1], [0, 1], 17), ([1, 1], [1, 1], 1)):
+        cols = O.cols([O.HostCol(T.T_I32, k1, v1), O.HostCol(T.T_F64, k2)])
+        m = limit if limit else n
+        out = np.zeros(n, np.uint32)
+        d = (C.c_uint8 * 2)(*desc)
+        f = (C.c_uint8 * 2)(*nf)
+        assert L.orc_sort_perm(cols, d, f, 2, C.c_int64(n), C.c_int64(limit), out.ctypes.data_as(C.c_void_p)) == 0
+        perm = out[:m]
+
+        def key(i):
+            # nulls first/last, then value (NaN largest: OrderedFloat), per-key direction
+            a_null = not v1[i]
+            a = (0 if (a_null == bool(nf[0])) else 1, 0 if a_null else (-int(k1[i]) if desc[0] else int(k1[i])))
+            x = k2[i]
+            xr = (1, 0.0) if np.isnan(x) else (0, float(x))
+            b_ = tuple(-t for t in xr) if desc[1] else xr
+            return (a[0] if True else 0, a[1], b_)
+        # nulls_first flag decides the rank of the null group independent of direction
+        def null_rank(i):
+            return (0 if not v1[i] else 1) if nf[0] else (1 if not v1[i] else 0)
+        ref = sorted(range(n), key=lambda i: (null_rank(i), key(i)[1], key(i)[2], i))
+        # only the key sequence is defined (sort_unstable_by): compare keys, not row ids
+        kseq = lambda idx: [(bool(v1[i]), int(k1[i]) if v1[i] else None, None if np.isnan(k2[i]) else float(k2[i])) for i in idx]
+        assert kseq(perm) == kseq(ref[:m]), (desc, nf, limit)
+
+
+def test_hashagg_oracle_matches_closed_form_like_agg_hashtable_rs():
+    """Mirrors tests/it/aggregates/agg_hashtable.rs:50+: n rows, 4 groups, expected = closed-form sums; a second
+    table combined into the first (combine_payload) doubles them."""
+    L = O.load()
+    n = 10000
+    k = (np.arange(n) % 4).astype(np.int64)
+    v = np.arange(n).astype(np.int64)
+    kt = (C.c_int32 * 1)(T.T_I64)
+    kn = (C.c_uint8 * 1)(0)
+    ad = (O.OAgg * 3)()
+    ad[0].kind, ad[0].arg_type = T.AGG_SUM, T.T_I64
+    ad[1].kind = T.AGG_COUNT
+    ad[2].kind, ad[2].arg_type = T.AGG_MAX, T.T_I64
+    L.orc_hashagg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    h1 = C.c_void_p(L.orc_hashagg_create(kt, kn, 1, ad, 3))
+    h2 = C.c_void_p(L.orc_hashagg_create(kt, kn, 1, ad, 3))
+    args = (O.OCol * 3)()
+    args[0] = O.HostCol(T.T_I64, v).c()
+    args[2] = O.HostCol(T.T_I64, v).c()
+    kc = O.cols([O.HostCol(T.T_I64, k)])
+    assert L.orc_hashagg_add_block(h1, kc, args, C.c_int64(n)) == 0
+    assert L.orc_hashagg_add_block(h2, kc, args, C.c_int64(n)) == 0
+    assert L.orc_hashagg_combine(h1, h2) == 0
+    g = L.orc_hashagg_num_groups(h1)
+    assert g == 4
+    keys = np.zeros(8, np.int64); kv = np.zeros(16, np.uint8)
+    s = np.zeros(8, np.int64); c = np.zeros(8, np.uint64); mx = np.zeros(8, np.int64)
+    kp = (C.c_void_p * 1)(keys.ctypes.data); kvp = (C.c_void_p * 1)(kv.ctypes.data)
+    ap = (C.c_void_p * 3)(s.ctypes.data, c.ctypes.data, mx.ctypes.data)
+    assert L.orc_hashagg_result(h1, kp, kvp, ap, None) == 0
+    got = sorted(zip(keys[:4].tolist(), s[:4].tolist(), c[:4].tolist(), mx[:4].tolist()))
+    exp = sorted((g_, 2 * int(v[k == g_].sum()), 2 * int((k == g_).sum()), int(v[k == g_].max())) for g_ in range(4))
+    assert got == exp
+    L.orc_hashagg_destroy(h1); L.orc_hashagg_destroy(h2)
+
+
+def test_filter_select_and_take_like_kernel_rs():
+    """FilterExecutor order + take (tests/it/kernel.rs shape): ascending ids of set bits; out[i] = src[sel[i]]."""
+    L = O.load()
+    rng = np.random.default_rng(9)
+    for n in (0, 1, 63, 64, 65, 1000):
+        bits = rng.integers(0, 2, n).astype(bool)
+        bm = np.concatenate([np.packbits(bits, bitorder="little"), np.zeros(8, np.uint8)])
+        sel = np.zeros(n + 1, np.uint32)
+        k = L.orc_filter_select(bm.ctypes.data_as(C.c_void_p), C.c_int64(0), C.c_int64(n), sel.ctypes.data_as(C.c_void_p))
+        assert sel[:k].tolist() == np.nonzero(bits)[0].tolist()
+        src = rng.integers(-2**60, 2**60, n + 1).astype(np.int64)
+        out = np.zeros(k + 1, np.int64)
+        L.orc_take(src.ctypes.data_as(C.c_void_p), 8, sel.ctypes.data_as(C.c_void_p), C.c_int64(k), out.ctypes.data_as(C.c_void_p))
+        assert out[:k].tolist() == src[sel[:k]].tolist()
