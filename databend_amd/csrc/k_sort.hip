@@ -65,6 +65,21 @@ __device__ __forceinline__ uint64_t sort_encode(const SortCol& c, uint32_t row, 
       const uint64_t* p = (const uint64_t*)c.data + 2 * (uint64_t)row;
       return part == 0 ? p[0] : (p[1] ^ 0x8000000000000000ULL);
     }
+    case DBHIP_T_STRING: {
+      // inline view {len, 12 bytes}: memcmp order of the zero-padded bytes, then the length
+      // (a proper prefix sorts first) — the image of the reference's variable row encoding
+      // (sorts/core/row_convert/variable.rs) for strings of at most 12 bytes.
+      // part 1 (most significant): bytes 0..7 big-endian; part 0: bytes 8..11 big-endian << 32 | len
+      const uint32_t* v = (const uint32_t*)c.data + 4 * (uint64_t)row;
+      const uint32_t len = v[0];
+      uint32_t d1 = v[1], d2 = v[2], d3 = v[3];
+      const uint32_t l = len > 12 ? 4 : len;  // long strings: only the 4-byte prefix is inline (flagged by the caller)
+      if (l < 4) { d1 &= (l == 0) ? 0u : (0xffffffffu >> (8 * (4 - l))); d2 = 0; d3 = 0; }
+      else if (l < 8) { d2 &= (l == 4) ? 0u : (0xffffffffu >> (8 * (8 - l))); d3 = 0; }
+      else if (l < 12) { d3 &= (l == 8) ? 0u : (0xffffffffu >> (8 * (12 - l))); }
+      if (part == 1) return ((uint64_t)__builtin_bswap32(d1) << 32) | __builtin_bswap32(d2);
+      return ((uint64_t)__builtin_bswap32(d3) << 32) | len;
+    }
   }
   return 0;
 }
@@ -76,6 +91,12 @@ __host__ __device__ inline int sort_key_bytes(int type) {
     case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_F32: case DBHIP_T_DATE: return 4;
     default: return 8;
   }
+}
+
+// flags strings that are not inline (len > 12): their order needs the data buffer, not built yet
+__global__ __launch_bounds__(256) void sort_check_inline_kernel(const uint32_t* views, int64_t n, uint32_t* flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (views[4 * i] > 12) *flag = 1u;
 }
 
 __global__ __launch_bounds__(256) void sort_iota_kernel(uint32_t* perm, int64_t n) {
@@ -174,9 +195,9 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   DBHIP_REQUIRE(out_perm, "dbhip_sort_perm: NULL out");
   for (int k = 0; k < nkeys; ++k) {
     int t = keys[k].type;
-    bool ok = (t >= DBHIP_T_BOOL && t <= DBHIP_T_DEC128) && !keys[k].is_scalar;
+    bool ok = (t >= DBHIP_T_BOOL && t <= DBHIP_T_STRING) && !keys[k].is_scalar;
     if (!ok) {
-      set_error("dbhip_sort_perm: key %d has unsupported type %d (fixed-width columns only)", k, t);
+      set_error("dbhip_sort_perm: key %d has unsupported type %d (fixed-width and short-string columns only)", k, t);
       return DBHIP_ERR_UNSUPPORTED;
     }
   }
@@ -185,8 +206,9 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   const int64_t nh = 256 * ntiles;
   // scratch: 2 key buffers, 2 perm buffers, hist, offsets, scan block sums
   size_t bytes = (size_t)n * 8 * 2 + (size_t)n * 4 * 2 + (size_t)nh * 4 + (size_t)nh * 8 + (size_t)(nh / SCAN_TILE + 2) * 8 + 1024;
-  uint8_t* ws = (uint8_t*)scratch(bytes, 7);
+  uint8_t* ws = (uint8_t*)scratch(bytes + 64, 7);
   if (!ws) return DBHIP_ERR_HIP;
+  uint32_t* long_flag = (uint32_t*)(ws + bytes);
   uint64_t* kb[2] = {(uint64_t*)ws, (uint64_t*)ws + n};
   uint64_t* offs = kb[1] + n;
   uint64_t* blk = offs + nh;
@@ -194,6 +216,21 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   uint32_t* pb[2] = {hist + nh, hist + nh + n};
   int cur = 0;
   const int grid = grid_for(n, 256);
+  bool any_string = false;
+  for (int k = 0; k < nkeys; ++k) any_string |= keys[k].type == DBHIP_T_STRING;
+  if (any_string) {
+    DBHIP_CHECK(hipMemsetAsync(long_flag, 0, 4, s));
+    for (int k = 0; k < nkeys; ++k)
+      if (keys[k].type == DBHIP_T_STRING)
+        hipLaunchKernelGGL(sort_check_inline_kernel, dim3(grid), dim3(256), 0, s, (const uint32_t*)keys[k].data, n, long_flag);
+    uint32_t f = 0;
+    DBHIP_CHECK(hipMemcpyAsync(&f, long_flag, 4, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    if (f) {
+      set_error("dbhip_sort_perm: a string sort key is longer than 12 bytes; keep the CPU operator for this block");
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+  }
   hipLaunchKernelGGL(sort_iota_kernel, dim3(grid), dim3(256), 0, s, pb[cur], n);
 
   auto radix_passes = [&](int nbytes) -> int32_t {
@@ -212,7 +249,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   for (int k = nkeys - 1; k >= 0; --k) {
     SortCol c{keys[k].data, keys[k].validity, keys[k].validity_offset, keys[k].type,
               desc_host ? desc_host[k] : 0, nulls_first_host ? nulls_first_host[k] : 0};
-    const int parts = c.type == DBHIP_T_DEC128 ? 2 : 1;
+    const int parts = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 2 : 1;
     for (int part = 0; part < parts; ++part) {
       // the permutation is shared by both buffers of a pass: encode reads pb[cur], writes kb[cur]
       hipLaunchKernelGGL(sort_encode_kernel, dim3(grid), dim3(256), 0, s, c, pb[cur], n, part, kb[cur]);

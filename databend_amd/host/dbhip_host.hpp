@@ -1,0 +1,987 @@
+// dbhip_host.hpp — C++ host mirror of the reference's operator surface on top of the C-ABI.
+//
+// The reference's host side is Rust (not available in this image), so the layer that a Databend
+// maintainer would write inside `ScalarFunction::eval` / `Transform` / `AccumulatingTransform` /
+// `Join` impls is restated here in C++17 with the SAME vocabulary, argument
+// meaning and error behaviour, so that tests read like the reference's own:
+//   DataType / Scalar / Column / Value / DataBlock   src/query/expression/src/{types.rs,values.rs,block.rs:49-59}
+//   FunctionSignature / Function / FunctionRegistry  src/query/expression/src/function.rs:87-134,275-379
+//   EvalContext::set_error / render_error            src/query/expression/src/function.rs:534-620
+//   Expr / Evaluator::run / partial_run              src/query/expression/src/{expression.rs,evaluator.rs:229-464}
+//   FilterExecutor                                   src/query/expression/src/filter/filter_executor.rs:81-118
+//   AggregateHashTable                               src/query/expression/src/aggregate/aggregate_hashtable.rs:42-519
+//   Transform / AccumulatingTransform                src/query/pipeline/transforms/src/processors/transforms/{transform.rs:30-48,transform_accumulating.rs:30-38}
+//   TransformPartialAggregate / TransformFinalAggregate / PartialSingleStateAggregator
+//                                                    src/query/service/src/pipelines/processors/transforms/aggregator/*.rs
+//   Join / JoinStream / InnerHashJoin                src/query/service/src/pipelines/processors/transforms/new_hash_join/{join.rs:22-53,memory/inner_join.rs}
+//   DataBlock::sort                                  src/query/expression/src/kernels/sort.rs:91-113
+// Every compute step goes through libdbhip.so; this file contains no arithmetic on column data.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dbhip.h"
+
+namespace dbhip_host {
+
+// ---- errors (ErrorCode, src/common/exception) ------------------------------------------------
+struct ErrorCode : std::runtime_error {
+  std::string kind;  // "BadArguments", "Overflow", "Unimplemented", "Internal"
+  ErrorCode(std::string k, const std::string& m) : std::runtime_error(m), kind(std::move(k)) {}
+  static ErrorCode BadArguments(const std::string& m) { return ErrorCode("BadArguments", m); }
+  static ErrorCode Overflow(const std::string& m) { return ErrorCode("Overflow", m); }
+  static ErrorCode Unimplemented(const std::string& m) { return ErrorCode("Unimplemented", m); }
+  static ErrorCode Internal(const std::string& m) { return ErrorCode("Internal", m); }
+};
+
+inline void check(int32_t rc) {
+  if (rc == DBHIP_OK) return;
+  std::string m = dbhip_last_error();
+  if (rc == DBHIP_ERR_OVERFLOW) throw ErrorCode::Overflow(m);
+  if (rc == DBHIP_ERR_UNSUPPORTED) throw ErrorCode::Unimplemented(m);
+  if (rc == DBHIP_ERR_INVALID) throw ErrorCode::BadArguments(m);
+  throw ErrorCode::Internal(m);
+}
+
+inline void init(int device = 0) { check(dbhip_init(device)); }
+
+// ---- device memory ---------------------------------------------------------------------------
+class DeviceBuffer {
+ public:
+  explicit DeviceBuffer(size_t bytes) : bytes_(bytes) { check(dbhip_alloc(bytes < 16 ? 16 : bytes + 16, &p_)); }
+  ~DeviceBuffer() { if (p_) dbhip_free(p_); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  void* ptr() const { return p_; }
+  size_t bytes() const { return bytes_; }
+  void upload(const void* src, size_t n) { if (n) check(dbhip_memcpy_h2d(p_, src, n, nullptr)); }
+  void download(void* dst, size_t n) const { if (n) check(dbhip_memcpy_d2h(dst, p_, n, nullptr)); }
+  void fill(int byte) { check(dbhip_memset(p_, byte, bytes_ < 16 ? 16 : bytes_, nullptr)); }
+ private:
+  void* p_ = nullptr;
+  size_t bytes_;
+};
+using Buf = std::shared_ptr<DeviceBuffer>;
+inline Buf make_buf(size_t bytes) { return std::make_shared<DeviceBuffer>(bytes); }
+
+// ---- types -----------------------------------------------------------------------------------
+struct DataType {
+  int32_t id = DBHIP_T_I64;  // dbhip_type
+  bool nullable = false;
+  uint8_t precision = 0, scale = 0;  // decimals
+  int32_t dim = 0;                   // Vector(dim) when id == DBHIP_T_F32 && dim > 0
+
+  static DataType of(int32_t id, bool nullable = false) { DataType t; t.id = id; t.nullable = nullable; return t; }
+  static DataType Decimal(uint8_t p, uint8_t s, bool nullable = false) {
+    DataType t; t.id = p <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128; t.precision = p; t.scale = s; t.nullable = nullable; return t;
+  }
+  static DataType Vector(int32_t dim) { DataType t; t.id = DBHIP_T_F32; t.dim = dim; return t; }
+  DataType wrap_nullable() const { DataType t = *this; t.nullable = true; return t; }
+  DataType remove_nullable() const { DataType t = *this; t.nullable = false; return t; }
+  bool is_decimal() const { return id == DBHIP_T_DEC64 || id == DBHIP_T_DEC128; }
+  bool is_numeric() const { return id >= DBHIP_T_I8 && id <= DBHIP_T_F64; }
+  bool same_physical(const DataType& o) const { return id == o.id && precision == o.precision && scale == o.scale && dim == o.dim; }
+  size_t elem_size() const {
+    switch (id) {
+      case DBHIP_T_I8: case DBHIP_T_U8: return 1;
+      case DBHIP_T_I16: case DBHIP_T_U16: return 2;
+      case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_F32: case DBHIP_T_DATE: return dim > 0 ? 4 * (size_t)dim : 4;
+      case DBHIP_T_DEC128: case DBHIP_T_STRING: return 16;
+      case DBHIP_T_BOOL: return 0;
+      default: return 8;
+    }
+  }
+  std::string name() const {
+    static const char* n[] = {"?", "Boolean", "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt64", "Float32",
+                              "Float64", "Date", "Timestamp", "Decimal", "Decimal", "String"};
+    std::string s = dim > 0 ? "Vector(" + std::to_string(dim) + ")" : n[id];
+    if (is_decimal()) s += "(" + std::to_string(precision) + ", " + std::to_string(scale) + ")";
+    return nullable ? s + " NULL" : s;
+  }
+};
+
+// Scalar (values.rs:122 Value::Scalar): numbers, decimals, booleans, dates; NULL.
+struct Scalar {
+  DataType type;
+  bool is_null = false;
+  int64_t i = 0;
+  uint64_t u = 0;
+  double f = 0;
+  __int128 dec = 0;
+  static Scalar Int(int32_t id, int64_t v) { Scalar s; s.type = DataType::of(id); s.i = v; s.u = (uint64_t)v; s.f = (double)v; s.dec = v; return s; }
+  static Scalar Float(int32_t id, double v) { Scalar s; s.type = DataType::of(id); s.f = v; return s; }
+  static Scalar Dec(uint8_t p, uint8_t sc, __int128 v) { Scalar s; s.type = DataType::Decimal(p, sc); s.dec = v; s.i = (int64_t)v; return s; }
+  static Scalar Null(DataType t) { Scalar s; s.type = t.wrap_nullable(); s.is_null = true; return s; }
+  // raw little-endian image in the column's physical type
+  void store(void* out) const {
+    switch (type.id) {
+      case DBHIP_T_F32: { float x = (float)f; memcpy(out, &x, 4); } break;
+      case DBHIP_T_F64: memcpy(out, &f, 8); break;
+      case DBHIP_T_DEC128: memcpy(out, &dec, 16); break;
+      case DBHIP_T_DEC64: { int64_t x = (int64_t)dec; memcpy(out, &x, 8); } break;
+      case DBHIP_T_BOOL: { uint8_t x = i != 0; memcpy(out, &x, 1); } break;
+      default: memcpy(out, &i, type.elem_size()); break;
+    }
+  }
+  std::string to_string() const {
+    if (is_null) return "NULL";
+    if (type.id == DBHIP_T_F32 || type.id == DBHIP_T_F64) { std::ostringstream o; o << f; return o.str(); }
+    if (type.id == DBHIP_T_U64) return std::to_string(u);
+    return std::to_string(type.is_decimal() ? (long long)dec : (long long)i);
+  }
+};
+
+// Column (values.rs:192): values + optional validity Bitmap, resident in HBM.
+struct Column {
+  DataType type;
+  int64_t len = 0;
+  Buf data;       // numbers: T[len]; Boolean: LSB-first bits; String: 16-byte views; Vector: f32[len][dim]
+  Buf validity;   // LSB-first bits, NULL when the column is not nullable / has no NULLs
+  Buf str_data;   // String: data buffer 0 (long strings)
+  Buf str_ptrs;   // String: device array of device pointers to the data buffers
+  bool is_const = false;  // BlockEntry::Const (block.rs): ONE stored value that stands for every row (e.g. a query vector)
+
+  template <typename T>
+  static Column from_vector(DataType t, const std::vector<T>& v, const std::vector<bool>* valid = nullptr) {
+    Column c; c.type = t; c.len = (int64_t)(t.dim > 0 ? v.size() / t.dim : v.size());
+    c.data = make_buf(v.size() * sizeof(T));
+    c.data->upload(v.data(), v.size() * sizeof(T));
+    if (valid) { c.type.nullable = true; c.validity = pack_bits(*valid); }
+    return c;
+  }
+  static Column from_bools(const std::vector<bool>& v, const std::vector<bool>* valid = nullptr) {
+    Column c; c.type = DataType::of(DBHIP_T_BOOL); c.len = (int64_t)v.size(); c.data = pack_bits(v);
+    if (valid) { c.type.nullable = true; c.validity = pack_bits(*valid); }
+    return c;
+  }
+  // strings of at most 12 bytes (inline views, binview/view.rs:30-42)
+  static Column from_short_strings(const std::vector<std::string>& v) {
+    std::vector<uint8_t> views(v.size() * 16, 0);
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (v[i].size() > 12) throw ErrorCode::Unimplemented("from_short_strings: string longer than 12 bytes");
+      uint32_t len = (uint32_t)v[i].size();
+      memcpy(&views[i * 16], &len, 4);
+      memcpy(&views[i * 16 + 4], v[i].data(), len);
+    }
+    Column c; c.type = DataType::of(DBHIP_T_STRING); c.len = (int64_t)v.size();
+    c.data = make_buf(views.size()); c.data->upload(views.data(), views.size());
+    return c;
+  }
+  static Buf pack_bits(const std::vector<bool>& v) {
+    std::vector<uint8_t> by((v.size() + 63) / 64 * 8 + 8, 0);
+    for (size_t i = 0; i < v.size(); ++i) if (v[i]) by[i >> 3] |= (uint8_t)(1u << (i & 7));
+    Buf b = make_buf(by.size()); b->upload(by.data(), by.size());
+    return b;
+  }
+  static std::vector<bool> unpack_bits(const Buf& b, int64_t n) {
+    std::vector<uint8_t> by((size_t)(n + 7) / 8);
+    b->download(by.data(), by.size());
+    std::vector<bool> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[(size_t)i] = (by[(size_t)(i >> 3)] >> (i & 7)) & 1;
+    return v;
+  }
+  template <typename T>
+  std::vector<T> to_vector() const {
+    size_t n = (size_t)len * (type.dim > 0 ? (size_t)type.dim : 1);
+    std::vector<T> v(n);
+    data->download(v.data(), n * sizeof(T));
+    return v;
+  }
+  std::vector<bool> to_bools() const { return unpack_bits(data, len); }
+  std::vector<bool> validity_to_host() const { return validity ? unpack_bits(validity, len) : std::vector<bool>((size_t)len, true); }
+  std::vector<std::string> to_short_strings() const {
+    std::vector<uint8_t> views((size_t)len * 16);
+    data->download(views.data(), views.size());
+    std::vector<std::string> out((size_t)len);
+    for (int64_t i = 0; i < len; ++i) {
+      uint32_t l; memcpy(&l, &views[(size_t)i * 16], 4);
+      out[(size_t)i] = std::string((const char*)&views[(size_t)i * 16 + 4], l);
+    }
+    return out;
+  }
+  dbhip_col c() const {
+    dbhip_col o; memset(&o, 0, sizeof(o));
+    o.type = type.id; o.is_scalar = 0; o.data = data ? data->ptr() : nullptr;
+    o.validity = validity ? (const uint8_t*)validity->ptr() : nullptr;
+    o.buffers = str_ptrs ? (const void* const*)str_ptrs->ptr() : nullptr;
+    o.n_buffers = str_ptrs ? 1 : 0;
+    o.precision = type.precision; o.scale = type.scale;
+    return o;
+  }
+};
+
+// Value<AnyType> (values.rs:122): Scalar or Column
+struct Value {
+  bool is_scalar = false;
+  Scalar scalar;
+  Column column;
+  Buf scalar_dev;  // device image of the scalar (one element)
+  static Value of(Column c) { Value v; v.column = std::move(c); return v; }
+  static Value of(Scalar s) {
+    Value v; v.is_scalar = true; v.scalar = s;
+    uint8_t raw[16] = {0};
+    s.store(raw);
+    v.scalar_dev = make_buf(16); v.scalar_dev->upload(raw, 16);
+    return v;
+  }
+  const DataType& type() const { return is_scalar ? scalar.type : column.type; }
+  dbhip_col c() const {
+    if (!is_scalar) return column.c();
+    dbhip_col o; memset(&o, 0, sizeof(o));
+    o.type = scalar.type.id; o.is_scalar = 1; o.data = scalar_dev->ptr();
+    o.precision = scalar.type.precision; o.scale = scalar.type.scale;
+    return o;
+  }
+};
+
+// DataBlock (block.rs:49-59)
+struct DataBlock {
+  std::vector<Column> columns;
+  int64_t num_rows = 0;
+  std::shared_ptr<void> meta;  // BlockMetaInfo (e.g. AggregateMeta::Serialized)
+  DataBlock() = default;
+  DataBlock(std::vector<Column> cols, int64_t n) : columns(std::move(cols)), num_rows(n) {}
+  const Column& get_by_offset(size_t i) const { return columns.at(i); }
+  size_t num_columns() const { return columns.size(); }
+  bool is_empty() const { return num_rows == 0; }
+};
+
+// ---- function machinery (function.rs) ----------------------------------------------------------
+struct EvalContext {
+  int64_t num_rows = 0;
+  Buf validity;  // rows whose bit is 0 never raise (function.rs:536-543)
+  // errors: (row validity bitmap on the device: 1 = ok, message of the FIRST error set) — function.rs:534-556
+  Buf error_bitmap;
+  std::string error_msg;
+  bool has_errors() const { return (bool)error_bitmap; }
+  void set_errors(Buf bitmap, const std::string& msg) {
+    if (!error_bitmap) { error_bitmap = std::move(bitmap); error_msg = msg; }
+  }
+};
+
+struct FunctionSignature {
+  std::string name;
+  std::vector<DataType> args_type;
+  DataType return_type;
+};
+struct ScalarFunction {
+  virtual ~ScalarFunction() = default;
+  virtual Value eval(const std::vector<Value>& args, EvalContext& ctx) const = 0;
+};
+struct Function {
+  FunctionSignature signature;
+  std::shared_ptr<ScalarFunction> eval;  // FunctionEval::Scalar
+};
+
+class FunctionRegistry {
+ public:
+  void register_function(Function f) { funcs_[f.signature.name].push_back(std::make_shared<Function>(std::move(f))); }
+  // candidates in registration order (overload id, function.rs:275-340,444-447); exact physical match,
+  // nullable arguments are accepted by the passthrough_nullable wrapper of the same overload
+  std::shared_ptr<Function> search(const std::string& name, const std::vector<DataType>& args) const {
+    auto it = funcs_.find(name);
+    if (it == funcs_.end()) throw ErrorCode::BadArguments("function `" + name + "` does not exist");
+    for (auto& f : it->second) {
+      if (f->signature.args_type.size() != args.size()) continue;
+      bool ok = true;
+      for (size_t i = 0; i < args.size(); ++i) ok &= f->signature.args_type[i].same_physical(args[i]);
+      if (ok) return f;
+    }
+    std::string s = "no overload of `" + name + "` for (";
+    for (size_t i = 0; i < args.size(); ++i) s += (i ? ", " : "") + args[i].name();
+    throw ErrorCode::BadArguments(s + ")");
+  }
+  static const FunctionRegistry& builtin();
+ private:
+  std::map<std::string, std::vector<std::shared_ptr<Function>>> funcs_;
+};
+
+// ---- expressions (expression.rs) ---------------------------------------------------------------
+struct Expr {
+  enum Kind { Constant, ColumnRef, Cast, FunctionCall } kind = Constant;
+  Scalar scalar;                         // Constant
+  size_t id = 0; std::string display;    // ColumnRef
+  DataType type;                         // data type of the node
+  std::shared_ptr<Function> function;    // FunctionCall
+  std::string fname;
+  std::vector<Expr> args;                // FunctionCall args / Cast inner
+  const DataType& data_type() const { return type; }
+  std::string sql_display() const {
+    switch (kind) {
+      case Constant: return scalar.to_string();
+      case ColumnRef: return display;
+      case Cast: return "CAST(" + args[0].sql_display() + " AS " + type.name() + ")";
+      default: {
+        static const std::map<std::string, std::string> infix = {{"plus", "+"}, {"minus", "-"}, {"multiply", "*"}, {"divide", "/"},
+            {"eq", "="}, {"noteq", "<>"}, {"lt", "<"}, {"lte", "<="}, {"gt", ">"}, {"gte", ">="}, {"modulo", "%"}, {"div", "DIV"}};
+        auto it = infix.find(fname);
+        if (it != infix.end() && args.size() == 2) return "(" + args[0].sql_display() + " " + it->second + " " + args[1].sql_display() + ")";
+        std::string s = fname + "(";
+        for (size_t i = 0; i < args.size(); ++i) s += (i ? ", " : "") + args[i].sql_display();
+        return s + ")";
+      }
+    }
+  }
+  static Expr constant(Scalar s) { Expr e; e.kind = Constant; e.scalar = s; e.type = s.type; return e; }
+  static Expr column_ref(size_t id, DataType t, std::string name) { Expr e; e.kind = ColumnRef; e.id = id; e.type = t; e.display = std::move(name); return e; }
+  static Expr cast(Expr inner, DataType dest) { Expr e; e.kind = Cast; e.type = dest; e.args.push_back(std::move(inner)); return e; }
+  // type-checks the call against the registry (type_check::check_function)
+  static Expr call(const std::string& name, std::vector<Expr> args, const FunctionRegistry& reg = FunctionRegistry::builtin());
+};
+
+// ---- small helpers over the C-ABI ---------------------------------------------------------------
+inline Buf and_validity(const Buf& a, const Buf& b, int64_t n) {
+  if (!a) return b;
+  if (!b) return a;
+  Buf out = make_buf((size_t)(n + 63) / 64 * 8 + 8);
+  check(dbhip_bitmap_binary(0, (const uint8_t*)a->ptr(), (const uint8_t*)b->ptr(), n, (uint8_t*)out->ptr(), nullptr));
+  return out;
+}
+inline Buf const_bitmap(bool v, int64_t n) {
+  Buf b = make_buf((size_t)(n + 63) / 64 * 8 + 8);
+  b->fill(v ? 0xFF : 0x00);
+  return b;
+}
+inline int64_t count_bits(const Buf& bm, int64_t n) {
+  Buf c = make_buf(8); c->fill(0);
+  check(dbhip_bitmap_count((const uint8_t*)bm->ptr(), 0, n, (uint64_t*)c->ptr(), nullptr));
+  uint64_t h = 0; c->download(&h, 8);
+  return (int64_t)h;
+}
+// validity of a Value for `n` rows (NULL scalar -> all-zero bitmap)
+inline Buf value_validity(const Value& v, int64_t n) {
+  if (v.is_scalar) return v.scalar.is_null ? const_bitmap(false, n) : Buf();
+  return v.column.validity;
+}
+
+// ---- Evaluator (evaluator.rs:229-464) ----------------------------------------------------------
+class Evaluator {
+ public:
+  Evaluator(const DataBlock& block, const FunctionRegistry& reg = FunctionRegistry::builtin()) : block_(block), reg_(reg) {}
+  // Runs `expr` over the block; a Value::Column result always has block.num_rows rows (evaluator.rs:334-349).
+  Value run(const Expr& expr) const { return partial_run(expr, Buf(), nullptr); }
+  // `selection`: rows a row error is reported for (render_error honours it, function.rs:567-620)
+  Value run_with_selection(const Expr& expr, const std::vector<uint32_t>* selection) const { return partial_run(expr, Buf(), selection); }
+
+ private:
+  Value partial_run(const Expr& e, Buf validity, const std::vector<uint32_t>* selection) const {
+    switch (e.kind) {
+      case Expr::Constant: return Value::of(e.scalar);
+      case Expr::ColumnRef: return Value::of(block_.get_by_offset(e.id));
+      case Expr::Cast: return run_cast(e, partial_run(e.args[0], validity, selection));
+      default: break;
+    }
+    if (e.fname == "and_filters") return eval_and_filters(e, validity, selection);
+    return eval_common_call(e, validity, selection);
+  }
+
+  // numeric widening casts ride on the `plus` kernel: x + 0::dest is `x as dest` whenever
+  // ResultTypeOfBinary(src, dest) == dest (numeric_basic_arithmetic.rs:255-292 casts both sides first)
+  Value run_cast(const Expr& e, Value v) const {
+    const DataType& dest = e.type;
+    if (v.type().same_physical(dest)) return v;
+    if (!(v.type().is_numeric() && dest.is_numeric()) || dbhip_arith_result_type(DBHIP_OP_PLUS, v.type().id, dest.id) != dest.id)
+      throw ErrorCode::Unimplemented("CAST(" + v.type().name() + " AS " + dest.name() + ") stays on the CPU evaluator");
+    Scalar zero = (dest.id == DBHIP_T_F32 || dest.id == DBHIP_T_F64) ? Scalar::Float(dest.id, 0.0) : Scalar::Int(dest.id, 0);
+    std::vector<Value> args = {v, Value::of(zero)};
+    EvalContext ctx; ctx.num_rows = block_.num_rows;
+    return reg_.search("plus", {v.type(), dest})->eval->eval(args, ctx);
+  }
+
+  // evaluator.rs:284-305: conjunction of boolean filters; later predicates only matter where earlier held
+  Value eval_and_filters(const Expr& e, Buf validity, const std::vector<uint32_t>* selection) const {
+    const int64_t n = block_.num_rows;
+    Buf acc;
+    for (const Expr& a : e.args) {
+      Value v = partial_run(a, validity, selection);
+      Buf bits;
+      if (v.is_scalar) bits = const_bitmap(!v.scalar.is_null && v.scalar.i != 0, n);
+      else bits = and_validity(v.column.data, v.column.validity, n);  // NULL -> false
+      acc = and_validity(acc, bits, n);
+    }
+    Column c; c.type = DataType::of(DBHIP_T_BOOL); c.len = n; c.data = acc ? acc : const_bitmap(true, n);
+    return Value::of(c);
+  }
+
+  Value eval_common_call(const Expr& e, Buf validity, const std::vector<uint32_t>* selection) const {
+    std::vector<Value> args;
+    for (const Expr& a : e.args) args.push_back(partial_run(a, validity, selection));
+    bool all_scalar = true;
+    for (const Value& v : args) {
+      all_scalar &= v.is_scalar;
+      if (!v.is_scalar && !v.column.is_const && v.column.len != block_.num_rows) throw ErrorCode::Internal("argument column length != num_rows");
+    }
+    EvalContext ctx; ctx.num_rows = block_.num_rows;
+    ctx.validity = all_scalar ? Buf() : validity;
+    Value result = e.function->eval->eval(args, ctx);
+    render_error(e, ctx, args, selection);
+    if (!result.is_scalar && result.column.len != block_.num_rows) throw ErrorCode::Internal("result length != num_rows");
+    return result;
+  }
+
+  // EvalContext::render_error (function.rs:567-620): first failing row (honouring the selection) and
+  // "<msg> while evaluating function `f(args)` in expr `...`"
+  void render_error(const Expr& e, const EvalContext& ctx, const std::vector<Value>& args, const std::vector<uint32_t>* selection) const {
+    if (!ctx.has_errors()) return;
+    std::vector<bool> ok = Column::unpack_bits(ctx.error_bitmap, ctx.num_rows);
+    int64_t first = -1;
+    if (!selection) { for (int64_t i = 0; i < ctx.num_rows && first < 0; ++i) if (!ok[(size_t)i]) first = i; }
+    else { for (uint32_t r : *selection) if (!ok[r]) { first = r; break; } }
+    if (first < 0) return;
+    std::string a;
+    for (size_t k = 0; k < args.size(); ++k) a += (k ? ", " : "") + value_at(args[k], first);
+    throw ErrorCode::BadArguments(ctx.error_msg + " while evaluating function `" + e.fname + "(" + a + ")` in expr `" + e.sql_display() + "`");
+  }
+  static std::string value_at(const Value& v, int64_t row) {
+    if (v.is_scalar) return v.scalar.to_string();
+    const Column& c = v.column;
+    if (c.validity && !Column::unpack_bits(c.validity, c.len)[(size_t)row]) return "NULL";
+    uint8_t raw[16] = {0};
+    size_t es = c.type.elem_size();
+    if (es == 0 || es > 16) return "?";
+    std::vector<uint8_t> all((size_t)c.len * es);
+    c.data->download(all.data(), all.size());
+    memcpy(raw, &all[(size_t)row * es], es);
+    switch (c.type.id) {
+      case DBHIP_T_I8: return std::to_string(*(int8_t*)raw);
+      case DBHIP_T_I16: return std::to_string(*(int16_t*)raw);
+      case DBHIP_T_I32: case DBHIP_T_DATE: return std::to_string(*(int32_t*)raw);
+      case DBHIP_T_U8: return std::to_string(*(uint8_t*)raw);
+      case DBHIP_T_U16: return std::to_string(*(uint16_t*)raw);
+      case DBHIP_T_U32: return std::to_string(*(uint32_t*)raw);
+      case DBHIP_T_U64: return std::to_string(*(uint64_t*)raw);
+      case DBHIP_T_F32: { std::ostringstream o; o << *(float*)raw; return o.str(); }
+      case DBHIP_T_F64: { std::ostringstream o; o << *(double*)raw; return o.str(); }
+      default: return std::to_string(*(int64_t*)raw);
+    }
+  }
+
+  const DataBlock& block_;
+  const FunctionRegistry& reg_;
+};
+
+// ---- built-in functions: thin adapters from ScalarFunction::eval to the C-ABI -------------------
+namespace detail {
+
+inline int64_t rows_of(const std::vector<Value>& args, const EvalContext& ctx) {
+  for (const Value& v : args) if (!v.is_scalar) return v.column.len;
+  return ctx.num_rows > 0 ? 1 : 0;  // all-scalar call: evaluated once (evaluator.rs:413-420)
+}
+
+// passthrough_nullable (register_vectorize.rs:447-471): validity = AND of the inputs
+inline Buf merged_validity(const std::vector<Value>& args, int64_t n) {
+  Buf acc;
+  for (const Value& v : args) acc = and_validity(acc, value_validity(v, n), n);
+  return acc;
+}
+
+struct ArithFn : ScalarFunction {
+  int op; DataType out;
+  ArithFn(int op_, DataType o) : op(op_), out(o) {}
+  Value eval(const std::vector<Value>& args, EvalContext& ctx) const override {
+    const int64_t n = rows_of(args, ctx);
+    Column r; r.type = out; r.len = n; r.data = make_buf((size_t)n * out.elem_size());
+    r.validity = merged_validity(args, n);
+    r.type.nullable = (bool)r.validity;
+    dbhip_col a = args[0].c(), b = args[1].c();
+    // rows that are NULL (or masked by ctx.validity) never raise: pass the effective validity
+    Buf eff = and_validity(r.validity, ctx.validity, n);
+    if (eff) { if (!a.is_scalar) a.validity = (const uint8_t*)eff->ptr(); else if (!b.is_scalar) b.validity = (const uint8_t*)eff->ptr(); }
+    const bool can_fail = op >= DBHIP_OP_DIVIDE;
+    Buf err = can_fail ? const_bitmap(true, n) : Buf();
+    Buf cnt = can_fail ? make_buf(8) : Buf();
+    if (cnt) cnt->fill(0);
+    int32_t rc = dbhip_arith(op, &a, &b, n, out.id, r.data->ptr(), err ? (uint8_t*)err->ptr() : nullptr,
+                             cnt ? (uint64_t*)cnt->ptr() : nullptr, nullptr);
+    check(rc);
+    if (can_fail) {  // EvalContext::set_error replay: the kernel cleared the bit of every failing row
+      uint64_t nerr = 0; cnt->download(&nerr, 8);
+      if (nerr) ctx.set_errors(err, op == DBHIP_OP_MODULO ? "Division by zero" : "divided by zero");
+    }
+    if (args[0].is_scalar && args[1].is_scalar) return scalar_of(r);
+    return Value::of(r);
+  }
+  static Value scalar_of(const Column& c) {  // all-scalar call -> Scalar result
+    Scalar s; s.type = c.type;
+    if (c.validity && !Column::unpack_bits(c.validity, 1)[0]) { s.is_null = true; return Value::of(s); }
+    uint8_t raw[16] = {0};
+    c.data->download(raw, c.type.elem_size());
+    switch (c.type.id) {
+      case DBHIP_T_F32: s.f = *(float*)raw; break;
+      case DBHIP_T_F64: s.f = *(double*)raw; break;
+      case DBHIP_T_DEC128: memcpy(&s.dec, raw, 16); break;
+      case DBHIP_T_I8: s.i = *(int8_t*)raw; break;
+      case DBHIP_T_I16: s.i = *(int16_t*)raw; break;
+      case DBHIP_T_I32: case DBHIP_T_DATE: s.i = *(int32_t*)raw; break;
+      case DBHIP_T_U8: s.i = *(uint8_t*)raw; break;
+      case DBHIP_T_U16: s.i = *(uint16_t*)raw; break;
+      case DBHIP_T_U32: s.i = *(uint32_t*)raw; break;
+      default: memcpy(&s.i, raw, 8); break;
+    }
+    s.u = (uint64_t)s.i; if (c.type.id == DBHIP_T_DEC64) s.dec = s.i;
+    return Value::of(s);
+  }
+};
+
+struct DecimalFn : ScalarFunction {
+  int op; DataType out;
+  DecimalFn(int op_, DataType o) : op(op_), out(o) {}
+  Value eval(const std::vector<Value>& args, EvalContext& ctx) const override {
+    const int64_t n = rows_of(args, ctx);
+    Column r; r.type = out; r.len = n; r.data = make_buf((size_t)n * out.elem_size());
+    r.validity = merged_validity(args, n);
+    r.type.nullable = (bool)r.validity;
+    dbhip_col a = args[0].c(), b = args[1].c();
+    Buf err = const_bitmap(true, n);
+    Buf cnt = make_buf(8); cnt->fill(0);
+    int32_t rc = dbhip_decimal_arith(op, &a, &b, n, out.id, out.precision, out.scale, r.data->ptr(), (uint8_t*)err->ptr(),
+                                     (uint64_t*)cnt->ptr(), nullptr);
+    check(rc);
+    uint64_t nerr = 0; cnt->download(&nerr, 8);
+    if (nerr) ctx.set_errors(err, op == DBHIP_OP_DIVIDE ? "divided by zero" : "Decimal overflow");
+    return Value::of(r);
+  }
+};
+
+struct CmpFn : ScalarFunction {
+  int op;
+  explicit CmpFn(int op_) : op(op_) {}
+  Value eval(const std::vector<Value>& args, EvalContext& ctx) const override {
+    const int64_t n = rows_of(args, ctx);
+    Column r; r.type = DataType::of(DBHIP_T_BOOL); r.len = n; r.data = make_buf((size_t)(n + 63) / 64 * 8 + 8);
+    r.validity = merged_validity(args, n);
+    r.type.nullable = (bool)r.validity;
+    dbhip_col a = args[0].c(), b = args[1].c();
+    check(dbhip_cmp(op, &a, &b, n, (uint8_t*)r.data->ptr(), nullptr));
+    return Value::of(r);
+  }
+};
+
+struct VecDistFn : ScalarFunction {
+  int metric;
+  explicit VecDistFn(int m) : metric(m) {}
+  // cosine_distance(Vector(N) column, Vector(N) scalar/column of ONE query): Float32 per row
+  // (scalars/vector.rs:497-560 evaluates the pair row by row; the query side is a constant in
+  // the ORDER BY distance plans this serves)
+  Value eval(const std::vector<Value>& args, EvalContext&) const override {
+    const Column& base = args[0].column;
+    const Column& q = args[1].column;
+    if (!q.is_const && q.len != 1) throw ErrorCode::Unimplemented("vector distance between two columns stays on the CPU evaluator");
+    Column r; r.type = DataType::of(DBHIP_T_F32); r.len = base.len; r.data = make_buf((size_t)base.len * 4);
+    check(dbhip_vec_distance(metric, (const float*)base.data->ptr(), base.len, base.type.dim, (const float*)q.data->ptr(), 1,
+                             (float*)r.data->ptr(), nullptr));
+    return Value::of(r);
+  }
+};
+
+inline void register_builtins(FunctionRegistry& reg) {
+  static const int num_types[] = {DBHIP_T_I8, DBHIP_T_I16, DBHIP_T_I32, DBHIP_T_I64, DBHIP_T_U8, DBHIP_T_U16, DBHIP_T_U32, DBHIP_T_U64,
+                                  DBHIP_T_F32, DBHIP_T_F64};
+  static const std::pair<const char*, int> ops[] = {{"plus", DBHIP_OP_PLUS}, {"minus", DBHIP_OP_MINUS}, {"multiply", DBHIP_OP_MULTIPLY},
+                                                    {"divide", DBHIP_OP_DIVIDE}, {"div", DBHIP_OP_INTDIV}, {"modulo", DBHIP_OP_MODULO}};
+  static const std::pair<const char*, int> cmps[] = {{"eq", DBHIP_CMP_EQ}, {"noteq", DBHIP_CMP_NOTEQ}, {"lt", DBHIP_CMP_LT},
+                                                     {"lte", DBHIP_CMP_LTE}, {"gt", DBHIP_CMP_GT}, {"gte", DBHIP_CMP_GTE}};
+  // register_basic_arithmetic (integer_arithmetic.rs:26-45, numeric_basic_arithmetic.rs:546-605): every numeric pair
+  for (auto& op : ops)
+    for (int l : num_types)
+      for (int r : num_types) {
+        int out = dbhip_arith_result_type(op.second, l, r);
+        if (out < 0) continue;
+        reg.register_function({{op.first, {DataType::of(l), DataType::of(r)}, DataType::of(out)},
+                               std::make_shared<ArithFn>(op.second, DataType::of(out))});
+      }
+  // comparisons: same physical type on both sides (the planner inserts casts, comparison.rs:98-112)
+  static const int cmp_types[] = {DBHIP_T_BOOL, DBHIP_T_I8, DBHIP_T_I16, DBHIP_T_I32, DBHIP_T_I64, DBHIP_T_U8, DBHIP_T_U16, DBHIP_T_U32,
+                                  DBHIP_T_U64, DBHIP_T_F32, DBHIP_T_F64, DBHIP_T_DATE, DBHIP_T_TIMESTAMP, DBHIP_T_STRING};
+  for (auto& c : cmps)
+    for (int t : cmp_types)
+      reg.register_function({{c.first, {DataType::of(t), DataType::of(t)}, DataType::of(DBHIP_T_BOOL)}, std::make_shared<CmpFn>(c.second)});
+}
+
+}  // namespace detail
+
+inline const FunctionRegistry& FunctionRegistry::builtin() {
+  static FunctionRegistry* reg = [] { auto* r = new FunctionRegistry(); detail::register_builtins(*r); return r; }();
+  return *reg;
+}
+
+// Expr::call: resolves the overload. Decimal arithmetic / decimal comparisons / vector distances are
+// "factory" functions in the reference (resolved per argument types: decimal/src/arithmetic.rs:80-139,
+// scalars/vector.rs:262-341) and are built here the same way.
+inline Expr Expr::call(const std::string& name, std::vector<Expr> args, const FunctionRegistry& reg) {
+  Expr e; e.kind = FunctionCall; e.fname = name;
+  std::vector<DataType> at;
+  for (auto& a : args) at.push_back(a.data_type());
+  e.args = std::move(args);
+  static const std::map<std::string, int> arith = {{"plus", DBHIP_OP_PLUS}, {"minus", DBHIP_OP_MINUS}, {"multiply", DBHIP_OP_MULTIPLY}, {"divide", DBHIP_OP_DIVIDE}};
+  static const std::map<std::string, int> cmps = {{"eq", DBHIP_CMP_EQ}, {"noteq", DBHIP_CMP_NOTEQ}, {"lt", DBHIP_CMP_LT}, {"lte", DBHIP_CMP_LTE}, {"gt", DBHIP_CMP_GT}, {"gte", DBHIP_CMP_GTE}};
+  static const std::map<std::string, int> vec = {{"cosine_distance", DBHIP_VEC_COSINE}, {"l2_distance", DBHIP_VEC_L2}, {"inner_product", DBHIP_VEC_DOT}, {"l1_distance", DBHIP_VEC_L1}};
+  if (name == "and_filters") { e.type = DataType::of(DBHIP_T_BOOL); return e; }
+  const bool any_decimal = at.size() == 2 && (at[0].is_decimal() || at[1].is_decimal());
+  if (any_decimal && arith.count(name)) {
+    auto props = [](const DataType& t, uint8_t& p, uint8_t& s) {  // integer -> decimal size (cast.rs:701-753)
+      if (t.is_decimal()) { p = t.precision; s = t.scale; return; }
+      static const std::map<int, int> ip = {{DBHIP_T_I8, 3}, {DBHIP_T_U8, 3}, {DBHIP_T_I16, 5}, {DBHIP_T_U16, 5}, {DBHIP_T_I32, 10}, {DBHIP_T_U32, 10}, {DBHIP_T_I64, 19}, {DBHIP_T_U64, 20}};
+      auto it = ip.find(t.id);
+      if (it == ip.end()) throw ErrorCode::BadArguments("decimal arithmetic with " + t.name());
+      p = (uint8_t)it->second; s = 0;
+    };
+    uint8_t lp, ls, rp, rs, op_, os_;
+    props(at[0], lp, ls); props(at[1], rp, rs);
+    check(dbhip_decimal_result_size(arith.at(name), lp, ls, rp, rs, &op_, &os_));
+    e.type = DataType::Decimal(op_, os_);
+    e.function = std::make_shared<Function>(Function{{name, at, e.type}, std::make_shared<detail::DecimalFn>(arith.at(name), e.type)});
+    return e;
+  }
+  if (any_decimal && cmps.count(name)) {
+    if (!at[0].same_physical(at[1])) throw ErrorCode::BadArguments("decimal comparison needs equal (precision, scale): cast first");
+    e.type = DataType::of(DBHIP_T_BOOL);
+    e.function = std::make_shared<Function>(Function{{name, at, e.type}, std::make_shared<detail::CmpFn>(cmps.at(name))});
+    return e;
+  }
+  if (vec.count(name)) {
+    if (at.size() != 2 || at[0].dim <= 0 || at[0].dim != at[1].dim) throw ErrorCode::BadArguments(name + " needs two Vector(N) arguments of equal N");
+    e.type = DataType::of(DBHIP_T_F32);
+    e.function = std::make_shared<Function>(Function{{name, at, e.type}, std::make_shared<detail::VecDistFn>(vec.at(name))});
+    return e;
+  }
+  e.function = reg.search(name, at);
+  e.type = e.function->signature.return_type;
+  for (auto& t : at) if (t.nullable) e.type.nullable = true;
+  return e;
+}
+
+// ---- FilterExecutor (filter/filter_executor.rs:81-118) + DataBlock::take -------------------------
+struct Selection { Buf sel; int64_t count = 0; };
+
+inline Selection filter_select(const Column& predicate) {
+  if (predicate.type.id != DBHIP_T_BOOL) throw ErrorCode::BadArguments("filter predicate must be Boolean");
+  Buf bits = and_validity(predicate.data, predicate.validity, predicate.len);  // NULL -> not selected
+  Selection s; s.sel = make_buf((size_t)predicate.len * 4 + 64);
+  Buf cnt = make_buf(8);
+  check(dbhip_filter_select((const uint8_t*)bits->ptr(), 0, predicate.len, (uint32_t*)s.sel->ptr(), (uint64_t*)cnt->ptr(), nullptr));
+  uint64_t h = 0; cnt->download(&h, 8);
+  s.count = (int64_t)h;
+  return s;
+}
+
+inline Column take(const Column& c, const uint32_t* selp, int64_t k) {
+  Column r; r.type = c.type; r.len = k; r.str_data = c.str_data; r.str_ptrs = c.str_ptrs;
+  if (c.type.id == DBHIP_T_BOOL) {
+    r.data = make_buf((size_t)(k + 63) / 64 * 8 + 8);
+    check(dbhip_take_bitmap((const uint8_t*)c.data->ptr(), 0, selp, k, (uint8_t*)r.data->ptr(), nullptr));
+  } else {
+    size_t es = c.type.elem_size();
+    if (es != 1 && es != 2 && es != 4 && es != 8 && es != 16) throw ErrorCode::Unimplemented("take on " + c.type.name());
+    r.data = make_buf((size_t)k * es);
+    check(dbhip_take(c.data->ptr(), (int32_t)es, selp, k, r.data->ptr(), nullptr));
+  }
+  if (c.validity) {
+    r.validity = make_buf((size_t)(k + 63) / 64 * 8 + 8);
+    check(dbhip_take_bitmap((const uint8_t*)c.validity->ptr(), 0, selp, k, (uint8_t*)r.validity->ptr(), nullptr));
+  }
+  return r;
+}
+
+inline Column take(const Column& c, const Buf& sel, int64_t k) { return take(c, (const uint32_t*)sel->ptr(), k); }
+
+inline DataBlock take_block(const DataBlock& b, const uint32_t* sel, int64_t k) {
+  DataBlock o; o.num_rows = k;
+  for (const Column& c : b.columns) o.columns.push_back(take(c, sel, k));
+  return o;
+}
+inline DataBlock take_block(const DataBlock& b, const Buf& sel, int64_t k) { return take_block(b, (const uint32_t*)sel->ptr(), k); }
+
+class FilterExecutor {
+ public:
+  explicit FilterExecutor(Expr predicate) : predicate_(std::move(predicate)) {}
+  DataBlock filter(const DataBlock& block) const {
+    Evaluator ev(block);
+    Value v = ev.run(predicate_);
+    if (v.is_scalar) return (!v.scalar.is_null && v.scalar.i != 0) ? block : DataBlock(std::vector<Column>(), 0);
+    Selection s = filter_select(v.column);
+    return take_block(block, s.sel, s.count);
+  }
+ private:
+  Expr predicate_;
+};
+
+// ---- pipeline traits (transform.rs:30-48, transform_accumulating.rs:30-38) ----------------------
+struct Transform {
+  virtual ~Transform() = default;
+  virtual const char* name() const = 0;
+  virtual DataBlock transform(DataBlock block) = 0;
+  virtual void on_start() {}
+  virtual void on_finish() {}
+};
+struct AccumulatingTransform {
+  virtual ~AccumulatingTransform() = default;
+  virtual const char* name() const = 0;
+  virtual std::vector<DataBlock> transform(DataBlock block) = 0;
+  virtual std::vector<DataBlock> on_finish(bool output) = 0;
+};
+
+class TransformFilter : public Transform {
+ public:
+  explicit TransformFilter(Expr predicate) : exec_(std::move(predicate)) {}
+  const char* name() const override { return "FilterTransform"; }
+  DataBlock transform(DataBlock block) override { return exec_.filter(block); }
+ private:
+  FilterExecutor exec_;
+};
+
+// CompoundBlockOperator::Map (src/query/sql/src/evaluator/block_operator.rs:42-85): appends one column per expr
+class TransformMap : public Transform {
+ public:
+  explicit TransformMap(std::vector<Expr> exprs) : exprs_(std::move(exprs)) {}
+  const char* name() const override { return "CompoundBlockOperator"; }
+  DataBlock transform(DataBlock block) override {
+    for (const Expr& e : exprs_) {
+      Evaluator ev(block);
+      Value v = ev.run(e);
+      if (v.is_scalar) throw ErrorCode::Unimplemented("constant map expression");
+      block.columns.push_back(v.column);
+    }
+    return block;
+  }
+ private:
+  std::vector<Expr> exprs_;
+};
+
+// ---- aggregation (aggregate_hashtable.rs, aggregator/*.rs) ---------------------------------------
+struct AggregateFunctionDesc {
+  std::string name;          // "sum" | "count" | "min" | "max"
+  std::optional<size_t> arg; // argument column offset in the input block (count(*) has none)
+  DataType arg_type;
+};
+struct AggregatorParams {  // aggregator_params.rs:16-118
+  std::vector<size_t> group_columns;
+  std::vector<DataType> group_data_types;
+  std::vector<AggregateFunctionDesc> aggregate_functions;
+};
+
+struct AggregateMetaSerialized {  // AggregateMeta::Serialized: partial states as device rows
+  Buf rows; int64_t n_rows = 0; int64_t row_bytes = 0;
+};
+
+class AggregateHashTable {
+ public:
+  explicit AggregateHashTable(const AggregatorParams& p, int64_t capacity = 1024) : params_(p) {
+    std::vector<int32_t> kt; std::vector<uint8_t> kn; std::vector<dbhip_agg_desc> ad;
+    for (auto& t : p.group_data_types) { kt.push_back(t.id); kn.push_back(t.nullable ? 1 : 0); }
+    for (auto& a : p.aggregate_functions) {
+      dbhip_agg_desc d; memset(&d, 0, sizeof(d));
+      d.kind = a.name == "count" ? DBHIP_AGG_COUNT : a.name == "sum" ? DBHIP_AGG_SUM : a.name == "min" ? DBHIP_AGG_MIN : a.name == "max" ? DBHIP_AGG_MAX : -1;
+      if (d.kind < 0) throw ErrorCode::Unimplemented("aggregate function `" + a.name + "` stays on the CPU operator");
+      d.arg_type = a.arg ? a.arg_type.id : 0; d.arg_precision = a.arg_type.precision; d.arg_scale = a.arg_type.scale;
+      d.arg_nullable = a.arg && a.arg_type.nullable;
+      ad.push_back(d);
+    }
+    descs_ = ad;
+    check(dbhip_groupby_create(kt.data(), kn.data(), (int32_t)kt.size(), ad.data(), (int32_t)ad.size(), capacity, &h_));
+  }
+  ~AggregateHashTable() { if (h_) dbhip_groupby_destroy(h_); }
+  AggregateHashTable(const AggregateHashTable&) = delete;
+
+  // add_groups (aggregate_hashtable.rs:168-207): group columns and aggregate arguments of one block
+  void add_groups(const DataBlock& block) {
+    std::vector<dbhip_col> keys, args(params_.aggregate_functions.size());
+    for (size_t g : params_.group_columns) keys.push_back(block.get_by_offset(g).c());
+    for (size_t a = 0; a < args.size(); ++a) {
+      memset(&args[a], 0, sizeof(dbhip_col));
+      if (params_.aggregate_functions[a].arg) args[a] = block.get_by_offset(*params_.aggregate_functions[a].arg).c();
+    }
+    check(dbhip_groupby_add_block(h_, keys.data(), args.data(), block.num_rows, nullptr));
+  }
+  int64_t len() const { int64_t n = 0; check(dbhip_groupby_num_groups(h_, &n, nullptr)); return n; }
+  // partial states for the exchange / final stage (Payload::aggregate_flush, payload_flush.rs:151-181)
+  AggregateMetaSerialized serialize() const {
+    AggregateMetaSerialized m;
+    check(dbhip_groupby_row_bytes(h_, &m.row_bytes));
+    int64_t g = len();
+    m.rows = make_buf((size_t)(g > 0 ? g : 1) * (size_t)m.row_bytes);
+    check(dbhip_groupby_flush_serialized(h_, m.rows->ptr(), g, &m.n_rows, nullptr));
+    return m;
+  }
+  // combine_payload (aggregate_hashtable.rs:349-380)
+  void combine(const AggregateMetaSerialized& m) { check(dbhip_groupby_merge_serialized(h_, m.rows->ptr(), m.n_rows, nullptr)); }
+  // merge_result (:382-408): [aggregate results..., group columns...]
+  DataBlock merge_result() const {
+    int64_t g = len();
+    int64_t cap = g > 0 ? g : 1;
+    std::vector<Column> keys, aggs;
+    std::vector<void*> kp, ap; std::vector<uint8_t*> kv;
+    for (auto& t : params_.group_data_types) {
+      Column c; c.type = t; c.len = g; c.data = make_buf((size_t)cap * (t.id == DBHIP_T_BOOL ? 1 : t.elem_size()));
+      c.validity = make_buf((size_t)(cap + 31) / 32 * 4 + 8);
+      kp.push_back(c.data->ptr()); kv.push_back((uint8_t*)c.validity->ptr());
+      keys.push_back(c);
+    }
+    for (auto& d : descs_) {
+      int32_t t; uint8_t p, s;
+      check(dbhip_groupby_result_type(&d, &t, &p, &s));
+      Column c; c.type = DataType::of(t); c.type.precision = p; c.type.scale = s; c.len = g;
+      c.data = make_buf((size_t)cap * c.type.elem_size());
+      ap.push_back(c.data->ptr());
+      aggs.push_back(c);
+    }
+    int64_t n = 0;
+    check(dbhip_groupby_flush_result(h_, kp.data(), kv.data(), ap.data(), nullptr, cap, &n, nullptr));
+    for (size_t k = 0; k < keys.size(); ++k) if (!params_.group_data_types[k].nullable) keys[k].validity.reset();
+    DataBlock out; out.num_rows = n;
+    for (auto& c : aggs) { c.len = n; out.columns.push_back(c); }
+    for (auto& c : keys) { c.len = n; out.columns.push_back(c); }
+    return out;
+  }
+  dbhip_groupby* handle() const { return h_; }
+ private:
+  AggregatorParams params_;
+  std::vector<dbhip_agg_desc> descs_;
+  dbhip_groupby* h_ = nullptr;
+};
+
+// TransformPartialAggregate (transform_aggregate_partial.rs:119-303): consumes blocks, emits one meta block
+class TransformPartialAggregate : public AccumulatingTransform {
+ public:
+  explicit TransformPartialAggregate(AggregatorParams p) : table_(p) {}
+  const char* name() const override { return "TransformPartialAggregate"; }
+  std::vector<DataBlock> transform(DataBlock block) override { table_.add_groups(block); return {}; }
+  std::vector<DataBlock> on_finish(bool output) override {
+    if (!output) return {};
+    DataBlock b; b.meta = std::make_shared<AggregateMetaSerialized>(table_.serialize());
+    std::vector<DataBlock> v; v.push_back(std::move(b));
+    return v;
+  }
+ private:
+  AggregateHashTable table_;
+};
+
+// TransformFinalAggregate (transform_aggregate_final.rs:69-551): merges partial states, emits the result
+class TransformFinalAggregate : public AccumulatingTransform {
+ public:
+  explicit TransformFinalAggregate(AggregatorParams p) : table_(p) {}
+  const char* name() const override { return "TransformFinalAggregate"; }
+  std::vector<DataBlock> transform(DataBlock block) override {
+    auto m = std::static_pointer_cast<AggregateMetaSerialized>(block.meta);
+    if (!m) throw ErrorCode::Internal("TransformFinalAggregate expects AggregateMeta::Serialized");
+    table_.combine(*m);
+    return {};
+  }
+  std::vector<DataBlock> on_finish(bool output) override {
+    if (!output) return {};
+    std::vector<DataBlock> v; v.push_back(table_.merge_result());
+    return v;
+  }
+ private:
+  AggregateHashTable table_;
+};
+
+// PartialSingleStateAggregator + FinalSingleStateAggregator (transform_single_key.rs:43-279): no GROUP BY,
+// `accumulate` of every block into one state per function (sum -> dbhip_sum, count -> validity popcount)
+class SingleStateAggregator : public AccumulatingTransform {
+ public:
+  explicit SingleStateAggregator(std::vector<AggregateFunctionDesc> f) : funcs_(std::move(f)), i_(funcs_.size(), 0), f_(funcs_.size(), 0.0) {}
+  const char* name() const override { return "AggregatorPartialTransform"; }
+  std::vector<DataBlock> transform(DataBlock block) override {
+    for (size_t a = 0; a < funcs_.size(); ++a) {
+      const auto& fn = funcs_[a];
+      if (fn.name == "count") {
+        if (!fn.arg || !block.get_by_offset(*fn.arg).validity) i_[a] += (uint64_t)block.num_rows;
+        else i_[a] += (uint64_t)count_bits(block.get_by_offset(*fn.arg).validity, block.num_rows);
+      } else if (fn.name == "sum") {
+        dbhip_col c = block.get_by_offset(*fn.arg).c();
+        Buf out = make_buf(8); out->fill(0);
+        check(dbhip_sum(&c, block.num_rows, out->ptr(), nullptr));
+        if (fn.arg_type.id == DBHIP_T_F32 || fn.arg_type.id == DBHIP_T_F64) { double d; out->download(&d, 8); f_[a] += d; }
+        else { uint64_t u; out->download(&u, 8); i_[a] += u; }  // wrapping, like NumberSumState (aggregate_sum.rs:113-129)
+      } else throw ErrorCode::Unimplemented("single-state `" + fn.name + "`");
+    }
+    return {};
+  }
+  std::vector<DataBlock> on_finish(bool) override { return {}; }
+  int64_t int_result(size_t a) const { return (int64_t)i_[a]; }
+  double float_result(size_t a) const { return f_[a]; }
+ private:
+  std::vector<AggregateFunctionDesc> funcs_;
+  std::vector<uint64_t> i_;
+  std::vector<double> f_;
+};
+
+// ---- hash join (new_hash_join/join.rs:22-53) -----------------------------------------------------
+struct JoinStream {
+  virtual ~JoinStream() = default;
+  virtual std::optional<DataBlock> next() = 0;
+};
+struct Join {
+  virtual ~Join() = default;
+  virtual void add_block(std::optional<DataBlock> data) = 0;
+  virtual void final_build() = 0;
+  virtual std::unique_ptr<JoinStream> probe_block(DataBlock data) = 0;
+};
+
+// InnerHashJoin on one u64/i64 key (memory/inner_join.rs:47-271): output = probe columns ++ build columns
+class InnerHashJoin : public Join {
+ public:
+  InnerHashJoin(size_t build_key, size_t probe_key, int64_t max_block_size = 65536) : bk_(build_key), pk_(probe_key), max_block_(max_block_size) {
+    check(dbhip_join_create(1024, &h_));
+  }
+  ~InnerHashJoin() override { if (h_) dbhip_join_destroy(h_); }
+  void add_block(std::optional<DataBlock> data) override {
+    if (!data) return;
+    if (!chunks_.empty()) throw ErrorCode::Unimplemented("InnerHashJoin host mirror keeps one build chunk (concat the build side first)");
+    const Column& k = data->get_by_offset(bk_);
+    check(dbhip_join_add_build(h_, (const uint64_t*)k.data->ptr(), k.validity ? (const uint8_t*)k.validity->ptr() : nullptr, k.len, nullptr));
+    chunks_.push_back(std::move(*data));
+  }
+  void final_build() override { check(dbhip_join_finalize(h_, nullptr)); }
+  std::unique_ptr<JoinStream> probe_block(DataBlock data) override {
+    const Column& k = data.get_by_offset(pk_);
+    const uint8_t* v = k.validity ? (const uint8_t*)k.validity->ptr() : nullptr;
+    uint64_t total = 0;
+    check(dbhip_join_probe_count(h_, (const uint64_t*)k.data->ptr(), v, k.len, &total, nullptr));
+    Buf pi = make_buf((size_t)total * 4), bi = make_buf((size_t)total * 4);
+    uint64_t got = 0;
+    check(dbhip_join_probe(h_, (const uint64_t*)k.data->ptr(), v, k.len, (uint32_t*)pi->ptr(), (uint32_t*)bi->ptr(), (int64_t)total, &got, nullptr));
+    return std::make_unique<Stream>(std::move(data), chunks_.empty() ? DataBlock() : chunks_[0], pi, bi, (int64_t)got, max_block_);
+  }
+ private:
+  struct Stream : JoinStream {
+    DataBlock probe, build; Buf pi, bi; int64_t total, pos = 0, max_block;
+    Stream(DataBlock p, DataBlock b, Buf pi_, Buf bi_, int64_t t, int64_t mb) : probe(std::move(p)), build(std::move(b)), pi(pi_), bi(bi_), total(t), max_block(mb) {}
+    std::optional<DataBlock> next() override {
+      if (pos >= total) return std::nullopt;
+      int64_t k = total - pos < max_block ? total - pos : max_block;
+      DataBlock out = take_block(probe, (const uint32_t*)pi->ptr() + pos, k);
+      DataBlock b = take_block(build, (const uint32_t*)bi->ptr() + pos, k);
+      for (auto& c : b.columns) out.columns.push_back(c);
+      pos += k;
+      return out;
+    }
+  };
+  size_t bk_, pk_;
+  int64_t max_block_;
+  dbhip_join* h_ = nullptr;
+  std::vector<DataBlock> chunks_;
+};
+
+// ---- sort (kernels/sort.rs:91-113) -----------------------------------------------------------------
+struct SortColumnDescription { size_t offset; bool asc = true; bool nulls_first = false; };
+
+inline DataBlock sort_block(const DataBlock& block, const std::vector<SortColumnDescription>& desc, std::optional<int64_t> limit = std::nullopt) {
+  std::vector<dbhip_col> keys; std::vector<uint8_t> d, nf;
+  for (auto& s : desc) { keys.push_back(block.get_by_offset(s.offset).c()); d.push_back(s.asc ? 0 : 1); nf.push_back(s.nulls_first ? 1 : 0); }
+  int64_t m = limit && *limit < block.num_rows ? *limit : block.num_rows;
+  Buf perm = make_buf((size_t)(m > 0 ? m : 1) * 4);
+  check(dbhip_sort_perm(keys.data(), d.data(), nf.data(), (int32_t)keys.size(), block.num_rows, limit ? *limit : 0, (uint32_t*)perm->ptr(), nullptr));
+  return take_block(block, perm, m);
+}
+
+}  // namespace dbhip_host

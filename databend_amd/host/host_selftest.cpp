@@ -1,0 +1,260 @@
+// host_selftest.cpp — drives the C++ host mirror (dbhip_host.hpp) the way the reference's pipeline
+// would, on one MI355X, and checks every result against plain host loops written here
+// (closed forms / scalar C++; independent of oracle/). Exit code 0 = all checks passed.
+//   1. BASELINE configs[0] twin: SELECT sum(a + b * c) over Int64 columns through Evaluator +
+//      the single-state aggregator (wrapping arithmetic)
+//   2. row errors: divide by zero -> "divided by zero while evaluating function `divide(..)` in expr `..`",
+//      first failing row, NULL rows never raise, selection honoured
+//   3. and_filters + FilterExecutor
+//   4. TPC-H Q1 as the reference's plan: TransformFilter -> CompoundBlockOperator (decimal maps) ->
+//      TransformPartialAggregate x2 -> TransformFinalAggregate, against an __int128 host loop
+//   5. InnerHashJoin (Join / JoinStream) and DataBlock::sort
+//   6. cosine_distance via the registry
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <set>
+#include <tuple>
+
+#include "dbhip_host.hpp"
+
+using namespace dbhip_host;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) { printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++g_fail; } \
+  } while (0)
+
+static void test_sum_a_plus_b_mul_c() {
+  const int64_t n = 1000003;
+  std::mt19937_64 rng(1);
+  std::vector<int64_t> a(n), b(n), c(n);
+  for (int64_t i = 0; i < n; ++i) { a[i] = (int64_t)rng(); b[i] = (int64_t)rng(); c[i] = (int64_t)rng(); }  // full range: wraps
+  DataBlock block({Column::from_vector(DataType::of(DBHIP_T_I64), a), Column::from_vector(DataType::of(DBHIP_T_I64), b),
+                   Column::from_vector(DataType::of(DBHIP_T_I64), c)}, n);
+  auto I64 = DataType::of(DBHIP_T_I64);
+  Expr e = Expr::call("plus", {Expr::column_ref(0, I64, "a"), Expr::call("multiply", {Expr::column_ref(1, I64, "b"), Expr::column_ref(2, I64, "c")})});
+  CHECK(e.sql_display() == "(a + (b * c))");
+  CHECK(e.data_type().id == DBHIP_T_I64);
+  Evaluator ev(block);
+  Value v = ev.run(e);
+  CHECK(!v.is_scalar && v.column.len == n);
+  std::vector<int64_t> got = v.column.to_vector<int64_t>();
+  uint64_t exp_sum = 0;
+  bool all = true;
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t x = (uint64_t)a[i] + (uint64_t)b[i] * (uint64_t)c[i];
+    all &= (uint64_t)got[i] == x;
+    exp_sum += x;
+  }
+  CHECK(all);
+  DataBlock mapped({v.column}, n);
+  SingleStateAggregator agg({{"sum", 0, I64}, {"count", std::nullopt, DataType()}});
+  agg.transform(mapped);
+  agg.transform(mapped);  // two blocks
+  CHECK((uint64_t)agg.int_result(0) == exp_sum * 2);
+  CHECK(agg.int_result(1) == 2 * n);
+  // mixed widths follow ResultTypeOfBinary: Int32 + Int32 -> Int64, UInt8 * Int8 -> Int16
+  CHECK(Expr::call("plus", {Expr::column_ref(0, DataType::of(DBHIP_T_I32), "x"), Expr::column_ref(1, DataType::of(DBHIP_T_I32), "y")}).data_type().id == DBHIP_T_I64);
+  CHECK(Expr::call("multiply", {Expr::column_ref(0, DataType::of(DBHIP_T_U8), "x"), Expr::column_ref(1, DataType::of(DBHIP_T_I8), "y")}).data_type().id == DBHIP_T_I16);
+}
+
+static void test_row_errors() {
+  std::vector<int64_t> a = {10, 20, 30, 40, 50}, b = {2, 0, 5, 0, 1};
+  std::vector<bool> bvalid = {true, false, true, true, true};  // row 1 is NULL: never raises
+  auto I64 = DataType::of(DBHIP_T_I64);
+  DataBlock block({Column::from_vector(I64, a), Column::from_vector(I64, b, &bvalid)}, 5);
+  Expr e = Expr::call("divide", {Expr::column_ref(0, I64, "a"), Expr::column_ref(1, I64.wrap_nullable(), "b")});
+  CHECK(e.data_type().id == DBHIP_T_F64 && e.data_type().nullable);
+  Evaluator ev(block);
+  bool thrown = false;
+  try { ev.run(e); } catch (const ErrorCode& err) {
+    thrown = true;
+    CHECK(err.kind == "BadArguments");
+    CHECK(std::string(err.what()) == "divided by zero while evaluating function `divide(40, 0)` in expr `(a / b)`");
+  }
+  CHECK(thrown);
+  // with a selection that excludes the failing row the expression evaluates (render_error honours it)
+  std::vector<uint32_t> sel = {0, 2, 4};
+  Value v = ev.run_with_selection(e, &sel);
+  std::vector<double> q = v.column.to_vector<double>();
+  CHECK(q[0] == 5.0 && q[2] == 6.0 && q[4] == 50.0);
+  std::vector<bool> valid = v.column.validity_to_host();
+  CHECK(valid[0] && !valid[1] && valid[2]);
+  // no error at all when the divisor is never zero on valid rows
+  std::vector<int64_t> b2 = {2, 0, 5, 4, 1};
+  DataBlock ok({Column::from_vector(I64, a), Column::from_vector(I64, b2, &bvalid)}, 5);
+  Evaluator ev2(ok);
+  CHECK(ev2.run(e).column.to_vector<double>()[3] == 10.0);
+}
+
+static void test_filter() {
+  const int64_t n = 100000;
+  std::mt19937 rng(3);
+  std::vector<int32_t> d(n); std::vector<int64_t> x(n);
+  for (int64_t i = 0; i < n; ++i) { d[i] = (int32_t)(rng() % 1000); x[i] = (int64_t)(rng() % 100) - 50; }
+  auto DATE = DataType::of(DBHIP_T_DATE); auto I64 = DataType::of(DBHIP_T_I64);
+  DataBlock block({Column::from_vector(DATE, d), Column::from_vector(I64, x)}, n);
+  Expr pred = Expr::call("and_filters", {Expr::call("lte", {Expr::column_ref(0, DATE, "d"), Expr::constant(Scalar::Int(DBHIP_T_DATE, 700))}),
+                                         Expr::call("gt", {Expr::column_ref(1, I64, "x"), Expr::constant(Scalar::Int(DBHIP_T_I64, 0))})});
+  TransformFilter tf(pred);
+  DataBlock out = tf.transform(block);
+  std::vector<int32_t> od = out.columns[0].to_vector<int32_t>(); std::vector<int64_t> ox = out.columns[1].to_vector<int64_t>();
+  std::vector<int32_t> ed; std::vector<int64_t> ex;
+  for (int64_t i = 0; i < n; ++i) if (d[i] <= 700 && x[i] > 0) { ed.push_back(d[i]); ex.push_back(x[i]); }
+  CHECK(out.num_rows == (int64_t)ed.size() && od == ed && ox == ex);
+}
+
+static void test_q1_plan() {
+  const int64_t n = 300007;
+  std::mt19937_64 rng(2);
+  std::vector<int64_t> qty(n), price(n), disc(n), tax(n); std::vector<int32_t> ship(n); std::vector<std::string> rf(n), ls(n);
+  const int32_t cutoff = 10471;
+  for (int64_t i = 0; i < n; ++i) {
+    qty[i] = (int64_t)(rng() % 50 + 1) * 100; price[i] = 90000 + (int64_t)(rng() % 10404951); disc[i] = (int64_t)(rng() % 11); tax[i] = (int64_t)(rng() % 9);
+    ship[i] = 8036 + (int32_t)(rng() % 2526);
+    rf[i] = std::string(1, "ANR"[rng() % 3]); ls[i] = std::string(1, "FO"[rng() % 2]);
+  }
+  auto D152 = DataType::Decimal(15, 2); auto DATE = DataType::of(DBHIP_T_DATE); auto STR = DataType::of(DBHIP_T_STRING);
+  // columns: 0 qty 1 price 2 disc 3 tax 4 returnflag 5 linestatus 6 shipdate
+  auto make_block = [&](int64_t lo, int64_t hi) {
+    auto sl = [&](const std::vector<int64_t>& v) { return std::vector<int64_t>(v.begin() + lo, v.begin() + hi); };
+    return DataBlock({Column::from_vector(D152, sl(qty)), Column::from_vector(D152, sl(price)), Column::from_vector(D152, sl(disc)),
+                      Column::from_vector(D152, sl(tax)), Column::from_short_strings(std::vector<std::string>(rf.begin() + lo, rf.begin() + hi)),
+                      Column::from_short_strings(std::vector<std::string>(ls.begin() + lo, ls.begin() + hi)),
+                      Column::from_vector(DATE, std::vector<int32_t>(ship.begin() + lo, ship.begin() + hi))}, hi - lo);
+  };
+  // plan (benchmark/tpch/queries/01.sql after the planner's rewrites)
+  TransformFilter filter(Expr::call("lte", {Expr::column_ref(6, DATE, "l_shipdate"), Expr::constant(Scalar::Int(DBHIP_T_DATE, cutoff))}));
+  Expr one = Expr::constant(Scalar::Int(DBHIP_T_U8, 1));
+  Expr one_minus = Expr::call("minus", {one, Expr::column_ref(2, D152, "l_discount")});
+  Expr disc_price = Expr::call("multiply", {Expr::column_ref(1, D152, "l_extendedprice"), one_minus});
+  Expr charge = Expr::call("multiply", {disc_price, Expr::call("plus", {one, Expr::column_ref(3, D152, "l_tax")})});
+  CHECK(disc_price.data_type().precision == 31 && disc_price.data_type().scale == 4 && disc_price.data_type().id == DBHIP_T_DEC128);
+  CHECK(charge.data_type().precision == 38 && charge.data_type().scale == 6);
+  TransformMap map({disc_price, charge});  // appended as columns 7, 8
+  AggregatorParams params;
+  params.group_columns = {4, 5}; params.group_data_types = {STR, STR};
+  params.aggregate_functions = {{"sum", 0, D152}, {"sum", 1, D152}, {"sum", 7, disc_price.data_type()}, {"sum", 8, charge.data_type()}, {"sum", 2, D152}, {"count", std::nullopt, DataType()}};
+  TransformPartialAggregate partial_a(params), partial_b(params);  // two pipeline lanes
+  TransformFinalAggregate final_(params);
+  const int64_t BLOCK = 65536;
+  int lane = 0;
+  for (int64_t lo = 0; lo < n; lo += BLOCK, ++lane) {
+    DataBlock b = map.transform(filter.transform(make_block(lo, std::min(n, lo + BLOCK))));
+    (lane % 2 ? partial_b : partial_a).transform(std::move(b));
+  }
+  for (auto* p : {&partial_a, &partial_b})
+    for (auto& meta : p->on_finish(true)) final_.transform(std::move(meta));
+  std::vector<DataBlock> res = final_.on_finish(true);
+  CHECK(res.size() == 1);
+  const DataBlock& r = res[0];
+  // expected
+  struct G { int64_t q = 0, p = 0, d = 0; __int128 dp = 0, ch = 0; uint64_t c = 0; };
+  std::map<std::pair<std::string, std::string>, G> exp;
+  for (int64_t i = 0; i < n; ++i) if (ship[i] <= cutoff) {
+    G& g = exp[{rf[i], ls[i]}];
+    __int128 dp = (__int128)price[i] * (100 - disc[i]);
+    g.q += qty[i]; g.p += price[i]; g.d += disc[i]; g.dp += dp; g.ch += dp * (100 + tax[i]); g.c += 1;
+  }
+  CHECK(r.num_rows == (int64_t)exp.size());
+  // result block = [aggregate results..., group columns...]
+  auto sq = r.columns[0].to_vector<int64_t>(); auto sp = r.columns[1].to_vector<int64_t>();
+  auto sdp = r.columns[2].to_vector<__int128>(); auto sch = r.columns[3].to_vector<__int128>();
+  auto sd = r.columns[4].to_vector<int64_t>(); auto cnt = r.columns[5].to_vector<uint64_t>();
+  auto krf = r.columns[6].to_short_strings(); auto kls = r.columns[7].to_short_strings();
+  CHECK(r.columns[2].type.precision == 38 && r.columns[2].type.scale == 4 && r.columns[0].type.precision == 18);
+  for (int64_t i = 0; i < r.num_rows; ++i) {
+    auto it = exp.find({krf[(size_t)i], kls[(size_t)i]});
+    CHECK(it != exp.end());
+    if (it == exp.end()) continue;
+    const G& g = it->second;
+    CHECK(sq[i] == g.q && sp[i] == g.p && sd[i] == g.d && sdp[i] == g.dp && sch[i] == g.ch && cnt[i] == g.c);
+  }
+  // ORDER BY l_returnflag, l_linestatus on the result block
+  DataBlock sorted = sort_block(r, {{6, true, false}, {7, true, false}});
+  auto s1 = sorted.columns[6].to_short_strings(); auto s2 = sorted.columns[7].to_short_strings();
+  std::vector<std::pair<std::string, std::string>> got_keys, exp_keys;
+  for (size_t i = 0; i < s1.size(); ++i) got_keys.push_back({s1[i], s2[i]});
+  for (auto& kv : exp) exp_keys.push_back(kv.first);
+  CHECK(got_keys == exp_keys);
+}
+
+static void test_join_and_sort() {
+  const int64_t nb = 20000, np = 50000;
+  std::mt19937_64 rng(5);
+  std::vector<uint64_t> bk(nb), pk(np); std::vector<int64_t> bv(nb), pv(np);
+  for (int64_t i = 0; i < nb; ++i) { bk[i] = rng() % 15000; bv[i] = i * 3; }
+  for (int64_t i = 0; i < np; ++i) { pk[i] = rng() % 30000; pv[i] = -i; }
+  auto U64 = DataType::of(DBHIP_T_U64); auto I64 = DataType::of(DBHIP_T_I64);
+  InnerHashJoin join(0, 0, 8192);
+  join.add_block(DataBlock({Column::from_vector(U64, bk), Column::from_vector(I64, bv)}, nb));
+  join.add_block(std::nullopt);
+  join.final_build();
+  auto stream = join.probe_block(DataBlock({Column::from_vector(U64, pk), Column::from_vector(I64, pv)}, np));
+  std::multiset<std::tuple<uint64_t, int64_t, int64_t>> got, exp;
+  int64_t blocks = 0;
+  while (auto b = stream->next()) {
+    ++blocks;
+    CHECK(b->num_rows <= 8192 && b->num_columns() == 4);
+    auto k1 = b->columns[0].to_vector<uint64_t>(); auto v1 = b->columns[1].to_vector<int64_t>();
+    auto k2 = b->columns[2].to_vector<uint64_t>(); auto v2 = b->columns[3].to_vector<int64_t>();
+    for (size_t i = 0; i < k1.size(); ++i) { CHECK(k1[i] == k2[i]); got.insert({k1[i], v1[i], v2[i]}); }
+  }
+  std::multimap<uint64_t, int64_t> bm;
+  for (int64_t i = 0; i < nb; ++i) bm.insert({bk[i], bv[i]});
+  for (int64_t i = 0; i < np; ++i) { auto r = bm.equal_range(pk[i]); for (auto it = r.first; it != r.second; ++it) exp.insert({pk[i], pv[i], it->second}); }
+  CHECK(got == exp && blocks > 1);
+  // sort: two keys, desc + asc, limit
+  std::vector<int32_t> k1(np); std::vector<double> k2(np);
+  for (int64_t i = 0; i < np; ++i) { k1[i] = (int32_t)(rng() % 7); k2[i] = (double)(int64_t)(rng() % 100000) / 7.0; }
+  DataBlock blk({Column::from_vector(DataType::of(DBHIP_T_I32), k1), Column::from_vector(DataType::of(DBHIP_T_F64), k2)}, np);
+  DataBlock s = sort_block(blk, {{0, false, false}, {1, true, false}}, 1000);
+  auto o1 = s.columns[0].to_vector<int32_t>(); auto o2 = s.columns[1].to_vector<double>();
+  std::vector<std::pair<int32_t, double>> ref(np);
+  for (int64_t i = 0; i < np; ++i) ref[i] = {-k1[i], k2[i]};
+  std::sort(ref.begin(), ref.end());
+  bool ok = s.num_rows == 1000;
+  for (int64_t i = 0; i < 1000 && ok; ++i) ok &= o1[i] == -ref[i].first && o2[i] == ref[i].second;
+  CHECK(ok);
+}
+
+static void test_vector_function() {
+  const int dim = 8; const int64_t n = 16;
+  std::mt19937 rng(8);
+  std::vector<float> base(n * dim), q(dim);
+  for (auto& x : base) x = (float)(rng() % 1000) / 1000.f;
+  for (auto& x : q) x = (float)(rng() % 1000) / 1000.f;
+  DataBlock block({Column::from_vector(DataType::Vector(dim), base), Column::from_vector(DataType::Vector(dim), q)}, n);
+  Expr e = Expr::call("cosine_distance", {Expr::column_ref(0, DataType::Vector(dim), "embedding"), Expr::column_ref(1, DataType::Vector(dim), "q")});
+  // the query column holds ONE vector (a constant in the plan)
+  DataBlock b2 = block; b2.columns[1].len = 1; b2.columns[1].is_const = true;
+  Evaluator ev(b2);
+  Value v = ev.run(e);
+  auto got = v.column.to_vector<float>();
+  for (int64_t i = 0; i < n; ++i) {
+    double ab = 0, aa = 0, bb = 0;
+    for (int k = 0; k < dim; ++k) { ab += (double)base[i * dim + k] * q[k]; aa += (double)base[i * dim + k] * base[i * dim + k]; bb += (double)q[k] * q[k]; }
+    double exp = 1.0 - ab / (std::sqrt(aa) * std::sqrt(bb));
+    CHECK(std::fabs(got[i] - exp) <= 1e-5 * std::max(1.0, std::fabs(exp)) + 1e-6);
+  }
+}
+
+int main() {
+  try {
+    init(0);
+    test_sum_a_plus_b_mul_c();
+    test_row_errors();
+    test_filter();
+    test_q1_plan();
+    test_join_and_sort();
+    test_vector_function();
+  } catch (const std::exception& e) {
+    printf("EXCEPTION: %s\n", e.what());
+    return 2;
+  }
+  printf(g_fail ? "host_selftest: %d check(s) FAILED\n" : "host_selftest: all checks passed\n", g_fail);
+  return g_fail ? 1 : 0;
+}

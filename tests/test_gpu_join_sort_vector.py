@@ -202,3 +202,22 @@ def test_vec_topk_known_answers_from_sqllogictest(gpu):
         assert [int(i) + 1 for i in idx[0]] == [e[0] for e in q["expected"]], q["fn"]
         for d, (_, ev) in zip(dist[0], q["expected"]):
             assert abs(float(d) - ev) <= 1e-5 * max(1.0, abs(ev)) + 2e-7
+
+
+def test_sort_short_string_keys(gpu):
+    """ORDER BY on inline (<= 12 byte) string keys: memcmp order, a proper prefix first; desc; with a second key."""
+    rng = np.random.default_rng(12)
+    alphabet = [b"", b"a", b"ab", b"abc", b"abd", b"b", b"ba", b"abcdefghijkl", b"abcdefghijk", b"abcdefgh", b"abcdefghi", b"\xff", b"a\x00", b"zz"]
+    n = 5000
+    strs = [alphabet[i] for i in rng.integers(0, len(alphabet), n)]
+    k2 = rng.integers(0, 5, n).astype(np.int32)
+    for desc in (0, 1):
+        perm = gpu.sort_perm([gpu.Column.strings(strs), gpu.Column.from_numpy(k2)], desc=[desc, 0])
+        got = [(strs[i], int(k2[i])) for i in perm]
+        exp = sorted(((s, int(b)) for s, b in zip(strs, k2)), key=lambda t: (t[0], t[1]))
+        if desc:
+            exp = sorted(exp, key=lambda t: t[1])
+            exp = sorted(exp, key=lambda t: t[0], reverse=True)
+        assert got == exp
+    with pytest.raises(Exception):
+        gpu.sort_perm([gpu.Column.strings([b"this string is longer than twelve bytes", b"x"])])
