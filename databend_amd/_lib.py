@@ -45,7 +45,7 @@ def library_path():
 
 # every symbol include/dbhip.h declares (tests check that the built library exports all of them)
 SYMBOLS = [
-    "dbhip_abi_version", "dbhip_init", "dbhip_device_count", "dbhip_last_error", "dbhip_alloc", "dbhip_free",
+    "dbhip_abi_version", "dbhip_init", "dbhip_device_count", "dbhip_last_error", "dbhip_alloc", "dbhip_free", "dbhip_trim",
     "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy",
     "dbhip_stream_sync", "dbhip_event_create", "dbhip_event_record", "dbhip_event_elapsed_ms",
     "dbhip_event_destroy", "dbhip_last_kernel_ms", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",

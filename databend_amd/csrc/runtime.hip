@@ -6,7 +6,11 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace dbhip {
 
@@ -120,16 +124,88 @@ int32_t dbhip_init(int32_t device) {
   return DBHIP_OK;
 }
 
+// Column buffers come and go with every operator of a plan; hipMalloc/hipFree of GB-sized
+// buffers cost milliseconds each, so freed blocks of >= 1 MiB are kept in size-class free
+// lists (classes: 8 steps per power of two, <= 12.5 % internal slack) up to a byte budget
+// (DBHIP_CACHE_BYTES, default 96 GiB of the 288 GB) and handed out again. A block is only
+// re-used after the device went idle at free time (hipFree's own semantics), so re-use is
+// safe for any stream. dbhip_trim() returns the cached blocks to the driver.
+namespace {
+struct AllocCache {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;                 // ptr -> class bytes (cached classes only)
+  std::unordered_map<size_t, std::vector<void*>> free_;  // class bytes -> blocks
+  size_t cached = 0, budget = 0;
+  bool init = false;
+} g_cache;
+
+size_t size_class(size_t bytes) {
+  if (bytes < (1u << 20)) return 0;
+  int top = 63 - __builtin_clzll((unsigned long long)bytes);
+  size_t step = (size_t)1 << (top - 3);
+  return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
 int32_t dbhip_alloc(size_t bytes, void** out) {
   DBHIP_REQUIRE(out, "dbhip_alloc: out is NULL");
   if (bytes == 0) bytes = 16;
+  size_t cls = size_class(bytes);
+  if (cls) {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    if (!g_cache.init) {
+      const char* e = getenv("DBHIP_CACHE_BYTES");
+      g_cache.budget = e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)96 << 30);
+      g_cache.init = true;
+    }
+    auto it = g_cache.free_.find(cls);
+    if (it != g_cache.free_.end() && !it->second.empty()) {
+      *out = it->second.back();
+      it->second.pop_back();
+      g_cache.cached -= cls;
+      g_cache.live[*out] = cls;
+      return DBHIP_OK;
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e != hipSuccess) {  // give the cache back to the driver and retry once
+      for (auto& kv : g_cache.free_) { for (void* p : kv.second) (void)hipFree(p); kv.second.clear(); }
+      g_cache.cached = 0;
+      DBHIP_CHECK(hipMalloc(out, cls));
+    }
+    g_cache.live[*out] = cls;
+    return DBHIP_OK;
+  }
   DBHIP_CHECK(hipMalloc(out, bytes));
   return DBHIP_OK;
 }
 
 int32_t dbhip_free(void* p) {
   if (!p) return DBHIP_OK;
+  {
+    std::unique_lock<std::mutex> lk(g_cache.mu);
+    auto it = g_cache.live.find(p);
+    if (it != g_cache.live.end()) {
+      size_t cls = it->second;
+      g_cache.live.erase(it);
+      if (g_cache.cached + cls <= g_cache.budget) {
+        lk.unlock();
+        DBHIP_CHECK(hipDeviceSynchronize());  // nothing in flight may still touch the block
+        lk.lock();
+        g_cache.free_[cls].push_back(p);
+        g_cache.cached += cls;
+        return DBHIP_OK;
+      }
+    }
+  }
   DBHIP_CHECK(hipFree(p));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_trim(void) {
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  DBHIP_CHECK(hipDeviceSynchronize());
+  for (auto& kv : g_cache.free_) { for (void* p : kv.second) (void)hipFree(p); kv.second.clear(); }
+  g_cache.cached = 0;
   return DBHIP_OK;
 }
 

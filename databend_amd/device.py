@@ -468,6 +468,31 @@ class GroupBy:
         self.last_hashes = hashes.to_numpy(np.uint64, n)
         return [tuple(c[i] for c in cols) for i in range(n)]
 
+    def result_columns(self):
+        """merge_result as HBM-resident Columns [keys..., aggregate results...] (group order unspecified);
+        nothing is copied to the host (the next operator — sort, projection — consumes them in place)."""
+        g = self.num_groups()
+        cap = max(g, 1)
+        key_bufs = [DeviceBuffer(cap * ELEM_SIZE.get(t, 1) + 64) for t in self.key_types]
+        key_val = [DeviceBuffer(((cap + 63) // 64) * 8 + 8) for _ in self.key_types]
+        agg_meta = []
+        for a in self.aggs:
+            d = AggDesc()
+            d.kind, d.arg_type, d.arg_precision, d.arg_scale, d.arg_nullable = a
+            t, p, s = C.c_int32(), C.c_uint8(), C.c_uint8()
+            check(lib().dbhip_groupby_result_type(C.byref(d), C.byref(t), C.byref(p), C.byref(s)))
+            agg_meta.append((t.value, p.value, s.value))
+        agg_bufs = [DeviceBuffer(cap * ELEM_SIZE[t] + 64) for t, _, _ in agg_meta]
+        kp = (C.c_void_p * len(key_bufs))(*[b.ptr for b in key_bufs])
+        kv = (C.c_void_p * len(key_val))(*[b.ptr for b in key_val])
+        ap = (C.c_void_p * max(len(agg_bufs), 1))(*[b.ptr for b in agg_bufs])
+        n = C.c_int64()
+        check(lib().dbhip_groupby_flush_result(self.h, kp, kv, ap, None, C.c_int64(cap), C.byref(n), None))
+        n = n.value
+        cols = [Column(t, n, b, v if nul else None) for t, b, v, nul in zip(self.key_types, key_bufs, key_val, self.key_nullable)]
+        cols += [Column(t, n, b, None, p, s) for (t, p, s), b in zip(agg_meta, agg_bufs)]
+        return cols
+
     def reset(self):
         check(lib().dbhip_groupby_reset(self.h, None))
 
@@ -523,6 +548,19 @@ class HashJoin:
                                      C.c_void_p(ob.ptr), C.c_int64(m), C.byref(got), None))
         assert got.value == m
         return op.to_numpy(np.uint32, m), ob.to_numpy(np.uint32, m)
+
+    def probe_block_device(self, keys_col):
+        """Join::probe_block keeping the pair lists in HBM -> (probe_idx DeviceBuffer, build_row DeviceBuffer, n_pairs)."""
+        v = C.c_void_p(keys_col.validity.ptr) if keys_col.validity is not None else None
+        total = C.c_uint64()
+        check(lib().dbhip_join_probe_count(self.h, C.c_void_p(keys_col.data.ptr), v, C.c_int64(keys_col.n), C.byref(total), None))
+        m = total.value
+        op, ob = DeviceBuffer(max(m, 1) * 4 + 64), DeviceBuffer(max(m, 1) * 4 + 64)
+        got = C.c_uint64()
+        check(lib().dbhip_join_probe(self.h, C.c_void_p(keys_col.data.ptr), v, C.c_int64(keys_col.n), C.c_void_p(op.ptr),
+                                     C.c_void_p(ob.ptr), C.c_int64(m), C.byref(got), None))
+        assert got.value == m
+        return op, ob, m
 
     def destroy(self):
         if self.h:

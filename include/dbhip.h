@@ -104,6 +104,10 @@ int32_t dbhip_device_count(int32_t* out_count_host);
 const char* dbhip_last_error(void);
 int32_t dbhip_alloc(size_t bytes, void** out_dev_ptr_host);
 int32_t dbhip_free(void* dev_ptr);
+/* dbhip_alloc/dbhip_free keep freed blocks of >= 1 MiB in size-class free lists (budget:
+ * env DBHIP_CACHE_BYTES, default 96 GiB) so that operator outputs do not pay hipMalloc per
+ * call; dbhip_trim returns the cached blocks to the driver. */
+int32_t dbhip_trim(void);
 int32_t dbhip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int32_t dbhip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int32_t dbhip_memset(void* dst_dev, int32_t byte, size_t bytes, void* stream);

@@ -1155,3 +1155,165 @@ void orc_score_u8(int is_l1, const uint8_t* q, const uint8_t* base, int64_t n, i
     out[i] = (float)s;
   }
 }
+
+/* ------------------------------------------------------------------------ */
+/* TPC-H Q3 (benchmark/tpch/queries/03.sql:1-18), reference-shaped:            */
+/*   customer: TransformFilter(c_mktsegment = seg) -> build side of join #1      */
+/*   orders:   TransformFilter(o_orderdate < date) -> probe join #1 -> build #2  */
+/*   lineitem: per block_rows block: TransformFilter(l_shipdate > date) ->       */
+/*             probe join #2 (HashJoinHashTable chains, hashjoin_hashtable.rs:   */
+/*             95-137, fixed_keys.rs:209-269) -> take both sides (inner_join.rs: */
+/*             248-268) -> decimal maps 1 - l_discount, price * (..)             */
+/*             (decimal/arithmetic.rs:190-316) -> TransformPartialAggregate on   */
+/*             (l_orderkey, o_orderdate, o_shippriority) with sum(Decimal128)    */
+/*   final merge (transform_aggregate_final.rs:160-175) -> sort by revenue desc, */
+/*   o_orderdate asc with LIMIT (kernels/sort_compare.rs:197-209).               */
+/* ------------------------------------------------------------------------ */
+typedef struct { int64_t* head; int64_t* next; const uint64_t* keys; int64_t nb; int shift; } jtab;
+static void jtab_build(jtab* t, const uint64_t* keys, int64_t nb) {
+  size_t cap = 1024; while (cap < (size_t)nb * 2) cap <<= 1;
+  t->head = (int64_t*)malloc(sizeof(int64_t) * cap);
+  t->next = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nb ? nb : 1));
+  for (size_t i = 0; i < cap; ++i) t->head[i] = -1;
+  t->shift = 64 - __builtin_ctzll(cap); t->keys = keys; t->nb = nb;
+  for (int64_t r = 0; r < nb; ++r) { size_t idx = (size_t)(orc_agg_hash_u64(keys[r]) >> t->shift); t->next[r] = t->head[idx]; t->head[idx] = r; }
+}
+/* pairs of one probe block, (probe_idx asc, build_row asc) */
+static int64_t jtab_probe(const jtab* t, const uint64_t* probe, int64_t np, uint32_t* out_p, uint32_t* out_b, int64_t cap) {
+  int64_t k = 0;
+  for (int64_t i = 0; i < np; ++i) {
+    size_t idx = (size_t)(orc_agg_hash_u64(probe[i]) >> t->shift);
+    int64_t first = k;
+    for (int64_t r = t->head[idx]; r >= 0; r = t->next[r])
+      if (t->keys[r] == probe[i]) { if (k < cap) { out_p[k] = (uint32_t)i; out_b[k] = (uint32_t)r; } k++; }
+    int64_t hi = k < cap ? k : cap;
+    for (int64_t x = first + 1; x < hi; ++x) { uint32_t v = out_b[x]; int64_t y = x - 1; while (y >= first && out_b[y] > v) { out_b[y + 1] = out_b[y]; y--; } out_b[y + 1] = v; }
+  }
+  return k;
+}
+static void jtab_free(jtab* t) { free(t->head); free(t->next); }
+
+typedef struct {
+  const int64_t *lok, *lprice, *ldisc; const int32_t* lship; int64_t n, block_rows; int32_t date;
+  const jtab* jt; const int64_t* b_orderkey; const int32_t *b_orderdate, *b_shipprio;
+  int tid, nthreads; orc_hashagg* ht; int rc;
+} q3_worker;
+
+static orc_hashagg* q3_table(void) {
+  int32_t kt[3] = {ORC_T_I64, ORC_T_DATE, ORC_T_I32};
+  orc_agg_desc ag[1]; memset(ag, 0, sizeof ag);
+  ag[0].kind = ORC_AGG_SUM; ag[0].arg_type = ORC_T_DEC128; ag[0].arg_precision = 31; ag[0].arg_scale = 4;
+  return orc_hashagg_create(kt, NULL, 3, ag, 1);
+}
+
+static void* q3_work(void* p) {
+  q3_worker* w = (q3_worker*)p;
+  int64_t B = w->block_rows;
+  uint8_t* bm = (uint8_t*)malloc((size_t)(B + 63) / 8 + 8);
+  uint32_t *sel = malloc(4 * (size_t)B), *pp = malloc(4 * (size_t)B * 2), *pb = malloc(4 * (size_t)B * 2);
+  int64_t *tok = malloc(8 * (size_t)B), *tp = malloc(8 * (size_t)B), *td = malloc(8 * (size_t)B);
+  int64_t *jok = malloc(8 * (size_t)B * 2), *jp = malloc(8 * (size_t)B * 2), *jd = malloc(8 * (size_t)B * 2), *omd = malloc(8 * (size_t)B * 2);
+  int32_t *jod = malloc(4 * (size_t)B * 2), *jsp = malloc(4 * (size_t)B * 2);
+  i128* rev = malloc(16 * (size_t)B * 2);
+  int64_t nblocks = (w->n + B - 1) / B;
+  for (int64_t b = w->tid; b < nblocks; b += w->nthreads) {
+    int64_t s = b * B, m = w->n - s < B ? w->n - s : B;
+    orc_col sd = {ORC_T_DATE, 0, w->lship + s, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+    orc_col cut = {ORC_T_DATE, 1, &w->date, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+    orc_cmp(ORC_CMP_GT, &sd, &cut, m, bm);
+    int64_t k = orc_filter_select(bm, 0, m, sel);
+    orc_take(w->lok + s, 8, sel, k, tok); orc_take(w->lprice + s, 8, sel, k, tp); orc_take(w->ldisc + s, 8, sel, k, td);
+    int64_t np = jtab_probe(w->jt, (const uint64_t*)tok, k, pp, pb, 2 * B);
+    if (np > 2 * B) { w->rc = 6; break; } /* o_orderkey is unique: cannot happen */
+    orc_take(tok, 8, pp, np, jok); orc_take(tp, 8, pp, np, jp); orc_take(td, 8, pp, np, jd);
+    orc_take(w->b_orderdate, 4, pb, np, jod); orc_take(w->b_shipprio, 4, pb, np, jsp);
+    uint8_t one = 1;
+    orc_col c_one = {ORC_T_U8, 1, &one, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+    orc_col c_disc = {ORC_T_DEC64, 0, jd, NULL, 0, NULL, 0, 15, 2, {0, 0}};
+    orc_col c_price = {ORC_T_DEC64, 0, jp, NULL, 0, NULL, 0, 15, 2, {0, 0}};
+    int e = orc_decimal_arith(ORC_OP_MINUS, &c_one, &c_disc, np, ORC_T_DEC64, 16, 2, omd, NULL, NULL);
+    orc_col c_omd = {ORC_T_DEC64, 0, omd, NULL, 0, NULL, 0, 16, 2, {0, 0}};
+    e |= orc_decimal_arith(ORC_OP_MULTIPLY, &c_price, &c_omd, np, ORC_T_DEC128, 31, 4, rev, NULL, NULL);
+    if (e) w->rc = e;
+    orc_col keys[3] = {{ORC_T_I64, 0, jok, NULL, 0, NULL, 0, 0, 0, {0, 0}}, {ORC_T_DATE, 0, jod, NULL, 0, NULL, 0, 0, 0, {0, 0}},
+                       {ORC_T_I32, 0, jsp, NULL, 0, NULL, 0, 0, 0, {0, 0}}};
+    orc_col args[1] = {{ORC_T_DEC128, 0, rev, NULL, 0, NULL, 0, 31, 4, {0, 0}}};
+    int e2 = orc_hashagg_add_block(w->ht, keys, args, np);
+    if (e2) w->rc = e2;
+  }
+  free(bm); free(sel); free(pp); free(pb); free(tok); free(tp); free(td); free(jok); free(jp); free(jd); free(omd); free(jod); free(jsp); free(rev);
+  return NULL;
+}
+
+int64_t orc_q3_run(const int64_t* c_custkey, const void* c_mktsegment_views, int64_t n_cust,
+                   const int64_t* o_orderkey, const int64_t* o_custkey, const int32_t* o_orderdate,
+                   const int32_t* o_shippriority, int64_t n_ord,
+                   const int64_t* l_orderkey, const int64_t* l_extendedprice, const int64_t* l_discount,
+                   const int32_t* l_shipdate, int64_t n_li,
+                   const char* segment, int32_t date, int64_t limit, int threads, int64_t block_rows,
+                   int64_t* out_orderkey, void* out_revenue_i128, int32_t* out_orderdate, int32_t* out_shippriority,
+                   int64_t* out_ngroups, int64_t* out_stage_rows /* [4]: customers kept, orders kept, orders joined, lineitem pairs(groups' input) or NULL */) {
+  if (threads < 1) threads = 1;
+  /* customer side */
+  uint8_t segview[16]; memset(segview, 0, 16);
+  uint32_t sl = (uint32_t)strlen(segment); if (sl > 12) return -1;
+  memcpy(segview, &sl, 4); memcpy(segview + 4, segment, sl);
+  uint8_t* bm = (uint8_t*)calloc((size_t)((n_cust > n_ord ? n_cust : n_ord) + 63) / 8 + 8, 1);
+  uint32_t* sel = (uint32_t*)malloc(4 * (size_t)((n_cust > n_ord ? n_cust : n_ord) + 1));
+  orc_col cseg = {ORC_T_STRING, 0, c_mktsegment_views, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+  orc_col sseg = {ORC_T_STRING, 1, segview, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+  orc_cmp(ORC_CMP_EQ, &cseg, &sseg, n_cust, bm);
+  int64_t kc = orc_filter_select(bm, 0, n_cust, sel);
+  int64_t* ck = (int64_t*)malloc(8 * (size_t)(kc + 1));
+  orc_take(c_custkey, 8, sel, kc, ck);
+  jtab j1; jtab_build(&j1, (const uint64_t*)ck, kc);
+  /* orders side */
+  orc_col od = {ORC_T_DATE, 0, o_orderdate, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+  orc_col cut = {ORC_T_DATE, 1, &date, NULL, 0, NULL, 0, 0, 0, {0, 0}};
+  orc_cmp(ORC_CMP_LT, &od, &cut, n_ord, bm);
+  int64_t ko = orc_filter_select(bm, 0, n_ord, sel);
+  int64_t *fok = malloc(8 * (size_t)(ko + 1)), *fck = malloc(8 * (size_t)(ko + 1));
+  int32_t *fod = malloc(4 * (size_t)(ko + 1)), *fsp = malloc(4 * (size_t)(ko + 1));
+  orc_take(o_orderkey, 8, sel, ko, fok); orc_take(o_custkey, 8, sel, ko, fck);
+  orc_take(o_orderdate, 4, sel, ko, fod); orc_take(o_shippriority, 4, sel, ko, fsp);
+  uint32_t *pp = malloc(4 * (size_t)(ko + 1)), *pb = malloc(4 * (size_t)(ko + 1));
+  int64_t kj = jtab_probe(&j1, (const uint64_t*)fck, ko, pp, pb, ko); /* c_custkey unique -> <= ko pairs */
+  if (kj > ko) kj = ko;
+  int64_t* bok = malloc(8 * (size_t)(kj + 1)); int32_t *bod = malloc(4 * (size_t)(kj + 1)), *bsp = malloc(4 * (size_t)(kj + 1));
+  orc_take(fok, 8, pp, kj, bok); orc_take(fod, 4, pp, kj, bod); orc_take(fsp, 4, pp, kj, bsp);
+  jtab j2; jtab_build(&j2, (const uint64_t*)bok, kj);
+  /* lineitem side, `threads` workers with partial tables */
+  q3_worker* ws = (q3_worker*)calloc((size_t)threads, sizeof(q3_worker));
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  for (int t = 0; t < threads; ++t) {
+    q3_worker w = {l_orderkey, l_extendedprice, l_discount, l_shipdate, n_li, block_rows, date, &j2, bok, bod, bsp, t, threads, q3_table(), 0};
+    ws[t] = w;
+    if (threads == 1) q3_work(&ws[t]); else pthread_create(&th[t], NULL, q3_work, &ws[t]);
+  }
+  if (threads > 1) for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+  orc_hashagg* fin = ws[0].ht; int rc = ws[0].rc;
+  for (int t = 1; t < threads; ++t) { int e = orc_hashagg_combine(fin, ws[t].ht); if (e) rc = e; if (ws[t].rc) rc = ws[t].rc; orc_hashagg_destroy(ws[t].ht); }
+  int64_t g = orc_hashagg_num_groups(fin);
+  if (out_ngroups) *out_ngroups = g;
+  if (out_stage_rows) { out_stage_rows[0] = kc; out_stage_rows[1] = ko; out_stage_rows[2] = kj; out_stage_rows[3] = g; }
+  int64_t m = 0;
+  if (g > 0 && !rc) {
+    int64_t* rk = malloc(8 * (size_t)g); int32_t *rd = malloc(4 * (size_t)g), *rs = malloc(4 * (size_t)g); i128* rr = malloc(16 * (size_t)g);
+    void* keys[3] = {rk, rd, rs}; void* aggs[1] = {rr};
+    orc_hashagg_result(fin, keys, NULL, aggs, NULL);
+    orc_col skeys[2] = {{ORC_T_DEC128, 0, rr, NULL, 0, NULL, 0, 38, 4, {0, 0}}, {ORC_T_DATE, 0, rd, NULL, 0, NULL, 0, 0, 0, {0, 0}}};
+    uint8_t desc[2] = {1, 0}, nf[2] = {0, 0};
+    m = (limit > 0 && limit < g) ? limit : g;
+    uint32_t* perm = malloc(4 * (size_t)g);
+    orc_sort_perm(skeys, desc, nf, 2, g, limit, perm);
+    for (int64_t i = 0; i < m; ++i) {
+      out_orderkey[i] = rk[perm[i]]; memcpy((uint8_t*)out_revenue_i128 + 16 * i, &rr[perm[i]], 16);
+      out_orderdate[i] = rd[perm[i]]; out_shippriority[i] = rs[perm[i]];
+    }
+    free(rk); free(rd); free(rs); free(rr); free(perm);
+  }
+  orc_hashagg_destroy(fin);
+  jtab_free(&j1); jtab_free(&j2);
+  free(bm); free(sel); free(ck); free(fok); free(fck); free(fod); free(fsp); free(pp); free(pb); free(bok); free(bod); free(bsp); free(ws); free(th);
+  return rc ? -(int64_t)rc - 100 : m;
+}

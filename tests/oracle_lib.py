@@ -125,3 +125,26 @@ def q1_run(host, cutoff, threads=1, block_rows=65536, n=None):
         out[(rfk, lsk)] = dict(sum_qty=res.sum_qty[i], sum_base_price=res.sum_price[i], sum_disc_price=i128(res.sum_disc_price[i]),
                                sum_charge=i128(res.sum_charge[i]), sum_disc=res.sum_disc[i], count=res.count[i])
     return out
+
+
+def q3_run(host, segment, date, limit=10, threads=1, block_rows=65536, stages=None):
+    """Reference-shaped CPU Q3 -> [(l_orderkey, revenue, o_orderdate, o_shippriority)] in output order."""
+    L = load()
+    L.orc_q3_run.restype = C.c_int64
+    c, o, li = host["customer"], host["orders"], host["lineitem"]
+    nc, no, nl = len(c["c_custkey"]), len(o["o_orderkey"]), len(li["l_orderkey"])
+    cap = max(limit if limit > 0 else no, 1)
+    ok, rev = np.zeros(cap, np.int64), np.zeros(2 * cap, np.uint64)
+    od, sp = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    ng, st = C.c_int64(), (C.c_int64 * 4)()
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)  # noqa: E731
+    keep = [np.ascontiguousarray(x) for x in (c["c_custkey"], c["c_mktsegment"], o["o_orderkey"], o["o_custkey"], o["o_orderdate"],
+                                              o["o_shippriority"], li["l_orderkey"], li["l_extendedprice"], li["l_discount"], li["l_shipdate"])]
+    m = L.orc_q3_run(p(keep[0]), p(keep[1]), C.c_int64(nc), p(keep[2]), p(keep[3]), p(keep[4]), p(keep[5]), C.c_int64(no),
+                     p(keep[6]), p(keep[7]), p(keep[8]), p(keep[9]), C.c_int64(nl), segment.encode(), C.c_int32(date),
+                     C.c_int64(limit), C.c_int(threads), C.c_int64(block_rows), p(ok), p(rev), p(od), p(sp), C.byref(ng), st)
+    assert m >= 0, f"oracle q3 failed: {m}"
+    if stages is not None:
+        stages.update(customers_kept=st[0], orders_kept=st[1], orders_joined=st[2], groups=st[3])
+    r = i128_list(rev[:2 * m])
+    return [(int(ok[i]), r[i], int(od[i]), int(sp[i])) for i in range(m)]
