@@ -53,6 +53,14 @@ struct dbhip_groupby {
   uint64_t* partial; size_t partial_cap;   // per-workgroup partial rows
   int fast_disabled;                       // set once most rows of a chunk spilled (high NDV)
   int fast_trusted;                        // last chunk spilled < 1 %: no more probing chunks
+  // radix-partitioned pre-aggregation (medium cardinality)
+  int part_bits;                           // 0 = undecided, > 0 = log2(partitions), < 0 = not worth it (row path)
+  int part_forbidden;                      // test hook: never choose the partitioned path
+  int64_t part_min_rows;                   // smallest chunk worth partitioning
+  int64_t rows_seen;                       // input rows of add_block so far (cardinality estimate)
+  uint32_t* part_meta; size_t part_meta_cap;   // hist[1024] | base[1025] | cursor[1024]
+  uint32_t* spill_idx; size_t spill_idx_cap;
+  uint64_t* spill_rows; size_t spill_rows_cap;
 };
 
 namespace {
@@ -871,6 +879,26 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
   }
 }
 
+int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
+                              int64_t* spilled);
+void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen);
+constexpr int64_t PT_CHUNK = 32 << 20;
+
+// one partitioned chunk starting at *done; widens the partitioning (or gives it up) when too many rows spilled
+int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, int64_t* done) {
+  const int64_t cn = n - *done < PT_CHUNK ? n - *done : PT_CHUNK;
+  int64_t spilled = 0;
+  int32_t rc = add_chunk_partitioned(g, C, *done, cn, s, &spilled);
+  if (rc) return rc;
+  *done += cn;
+  g->rows_seen += cn;
+  if (spilled * 20 > cn) {
+    if (g->part_bits + 2 <= 10) g->part_bits += 2;
+    else { g->part_bits = -1; g->fast_disabled = 1; }
+  }
+  return DBHIP_OK;
+}
+
 bool fast_layout_ok(const GbLayout& L) {
   return L.nkey_words <= FK_MAXKW && L.nkeys <= FK_MAXKW && L.naggs <= FK_MAXA && L.W <= 24;
 }
@@ -896,6 +924,11 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
   const int max_grid = 256 * blocks_per_cu;  // every workgroup resident at once: no tail round
   int32_t rc;
   while (*done < n) {
+    if (g->part_bits > 0) {
+      if (n - *done < g->part_min_rows) return -1;  // small remainder: row path
+      if ((rc = partitioned_step(g, C, n, s, done))) return rc;
+      continue;
+    }
     if (g->fast_disabled) return -1;
     // The first chunk of a big block is a small probe of the key distribution; when it spills
     // (almost) nothing the rest of the block is one launch (its spill buffer is sized for the worst
@@ -928,11 +961,357 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     if ((rc = merge_rows(g, g->partial, (int64_t)hc[5], s))) return rc;
     if ((rc = merge_rows(g, g->rows_in, (int64_t)hc[6], s))) return rc;
     *done += cn;
-    // most rows spilled: the LDS table is too small for this key distribution
-    if ((int64_t)hc[6] * 10 > cn && cn >= 65536) g->fast_disabled = 1;
+    g->rows_seen += cn;
+    // most rows spilled: the LDS table is too small for this key distribution -> partition by hash
+    // bits so that each partition fits, or (high cardinality) leave the rest to the row path
+    if ((int64_t)hc[6] * 10 > cn && cn >= 65536) {
+      decide_partitioning(g, g->count_host, g->rows_seen);
+      if (g->part_bits < 0) g->fast_disabled = 1;
+    }
     g->fast_trusted = (int64_t)hc[6] * 100 <= cn;
   }
   return DBHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Radix-partitioned pre-aggregation (medium cardinality: ~10^3 .. ~10^6 groups).
+//
+// Between "fits one workgroup's LDS table" and "every row is its own group" the row path contends on
+// hot addresses (global atomics serialise per address) and the LDS path spills. The reference meets
+// the same regime with radix-partitioned payloads (PartitionedPayload, partitioned_payload.rs:34-60,
+// 160-240: partition = hash bits, each partition aggregated on its own); the device analogue:
+//
+//   hist     rows per partition (partition = top `pbits` bits of the group hash), LDS histogram per
+//            workgroup, one global atomic per (workgroup, non-empty partition)
+//   scan     exclusive scan of the <= 1024 counts (one workgroup)
+//   scatter  tiles of 8192 rows: rank inside the tile by LDS atomics, ONE global cursor atomic per
+//            (tile, partition), rows serialized straight into their partition's region
+//   aggregate one workgroup per (partition, split): LDS hash table exactly as the pre-aggregation
+//            kernel above (claim by hash, verify after the barrier, LDS atomics), <= lcap partial rows
+//            per workgroup, merged into the HBM table by the row path; rows that do not fit are
+//            listed and go through the row path too.
+// Generic over the layout (rows are handled as W words in memory).
+// ---------------------------------------------------------------------------
+constexpr int PT_THREADS = 1024;
+constexpr int PT_R = 8;
+constexpr int PT_MAX_BITS = 10;
+
+__device__ __forceinline__ uint64_t gb_keys_hash(const GbLayout& L, const GbCols& C, int64_t i, uint64_t* ctrl) {
+  uint64_t h = 0;
+  for (int k = 0; k < L.nkeys; ++k) {
+    uint64_t w[2];
+    bool valid;
+    if (!gb_load_words(C.key[k], i, w, &valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+    const uint64_t hk = gb_hash_words(L.key_type[k], w, valid);
+    h = (k == 0) ? hk : merge_hash(h, hk);
+  }
+  return h;
+}
+
+__device__ __forceinline__ uint32_t part_of(uint64_t h, int pbits) { return (uint32_t)(h >> (64 - pbits)); }
+
+__global__ __launch_bounds__(256) void gb_part_hist_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n, int pbits,
+                                                           uint32_t* hist, uint64_t* ctrl) {
+  extern __shared__ uint32_t pt_lds[];
+  const int P = 1 << pbits;
+  for (int s = threadIdx.x; s < P; s += 256) pt_lds[s] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    atomicAdd(&pt_lds[part_of(gb_keys_hash(L, C, row0 + i, ctrl), pbits)], 1u);
+  __syncthreads();
+  for (int s = threadIdx.x; s < P; s += 256) {
+    const uint32_t c = pt_lds[s];
+    if (c) atomicAdd(&hist[s], c);
+  }
+}
+
+// base[0..P] = exclusive scan of hist[0..P), cursor[0..P) = 0   (P <= 1024, one workgroup of 1024)
+__global__ __launch_bounds__(1024) void gb_part_scan_kernel(const uint32_t* hist, int P, uint32_t* base, uint32_t* cursor) {
+  __shared__ uint32_t wave_tot[16];
+  const int t = threadIdx.x;
+  const uint32_t v = t < P ? hist[t] : 0;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane_id() >= d) incl += o;
+  }
+  if (lane_id() == 63) wave_tot[t >> 6] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int k = 0; k < (t >> 6); ++k) wbase += wave_tot[k];
+  if (t < P) {
+    base[t] = wbase + incl - v;
+    cursor[t] = 0;
+  }
+  if (t == P - 1) base[P] = wbase + incl;
+}
+
+// serialized image of input row i (same encoding as gb_serialize_kernel) written to `r`
+__device__ __forceinline__ void gb_serialize_row(const GbLayout& L, const GbCols& C, int64_t i, uint64_t* r,
+                                                 uint64_t* ctrl) {
+  uint64_t h = 0, vmask = 0;
+  for (int k = 0; k < L.nkeys; ++k) {
+    uint64_t w[2];
+    bool valid;
+    if (!gb_load_words(C.key[k], i, w, &valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+    const uint64_t hk = gb_hash_words(L.key_type[k], w, valid);
+    h = (k == 0) ? hk : merge_hash(h, hk);
+    r[L.key_off[k]] = w[0];
+    if (L.key_words[k] == 2) r[L.key_off[k] + 1] = w[1];
+    if (valid) vmask |= 1ULL << k;
+  }
+  if (L.validity_word >= 0) r[L.validity_word] = vmask;
+  r[L.hash_word] = h;
+  for (int a = 0; a < L.naggs; ++a) {
+    uint64_t w[2] = {0, 0};
+    bool valid = true;
+    if (C.arg[a].data != nullptr) gb_load_words(C.arg[a], i, w, &valid);
+    uint64_t v[3];
+    fk_contrib(L, a, w[0], w[1], valid, v);
+    for (int k = 0; k < L.agg_words[a]; ++k) r[L.agg_off[a] + k] = v[k];
+  }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n,
+                                                                     int pbits, const uint32_t* base,
+                                                                     uint32_t* cursor, uint64_t* rows_out,
+                                                                     uint64_t* ctrl) {
+  extern __shared__ uint32_t pt_lds[];
+  const int P = 1 << pbits;
+  uint32_t* lcnt = pt_lds;       // rows of this tile per partition
+  uint32_t* lbase = pt_lds + P;  // first output row of this tile's run in the partition
+  const int tid = threadIdx.x;
+  const int64_t tile_rows = (int64_t)PT_THREADS * PT_R;
+  const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int s = tid; s < P; s += PT_THREADS) lcnt[s] = 0;
+    __syncthreads();
+    uint32_t part[PT_R], rank[PT_R];
+#pragma unroll
+    for (int x = 0; x < PT_R; ++x) {
+      const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
+      part[x] = 0xFFFFFFFFu;
+      rank[x] = 0;
+      if (li < n) {
+        part[x] = part_of(gb_keys_hash(L, C, row0 + li, ctrl), pbits);
+        rank[x] = atomicAdd(&lcnt[part[x]], 1u);
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < P; s += PT_THREADS) {
+      const uint32_t c = lcnt[s];
+      lbase[s] = c ? base[s] + atomicAdd(&cursor[s], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < PT_R; ++x) {
+      const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
+      if (li < n) gb_serialize_row(L, C, row0 + li, rows_out + (uint64_t)(lbase[part[x]] + rank[x]) * L.W, ctrl);
+    }
+    __syncthreads();
+  }
+}
+
+struct PaArgs {
+  const uint64_t* rows;    // [n][W] grouped by partition
+  const uint32_t* base;    // [P+1]
+  int splits;              // workgroups per partition
+  int lcap, sw;
+  uint32_t llimit;
+  uint64_t hash_mask;
+  uint64_t* partial;       // [gridDim.x * lcap][W]
+  uint32_t* spill_idx;     // row indices (into rows) that did not fit
+  uint64_t* ctrl;          // [5] = #partial rows, [6] = #spilled rows
+};
+
+constexpr int PA_R = 4;
+
+__global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) {
+  extern __shared__ uint64_t fk_lds[];
+  __shared__ uint32_t lcount;
+  uint64_t* lhash = fk_lds;
+  uint64_t* lrows = fk_lds + A.lcap;
+  const int tid = threadIdx.x;
+  const uint32_t lmask = (uint32_t)A.lcap - 1;
+  const int p = blockIdx.x / A.splits, sp = blockIdx.x % A.splits;
+  const uint32_t pb = A.base[p], pe = A.base[p + 1];
+  const uint32_t len = pe - pb;
+  const uint32_t r_begin = pb + (uint32_t)(((uint64_t)len * sp) / A.splits);
+  const uint32_t r_end = pb + (uint32_t)(((uint64_t)len * (sp + 1)) / A.splits);
+  if (r_begin >= r_end) return;
+  for (int s = tid; s < A.lcap; s += 256) lhash[s] = 0;
+  if (tid == 0) lcount = 0;
+  __syncthreads();
+
+  for (uint32_t t0 = r_begin; t0 < r_end; t0 += 256 * PA_R) {
+    uint32_t slot[PA_R];
+    // ---- phase A: match-or-claim by hash ----
+#pragma unroll
+    for (int x = 0; x < PA_R; ++x) {
+      const uint32_t ri = t0 + x * 256 + tid;
+      slot[x] = FK_SPILL - 1;  // padding
+      if (ri < r_end) {
+        const uint64_t* r = A.rows + (uint64_t)ri * L.W;
+        const uint64_t h = r[L.hash_word];
+        const uint64_t hw = probe_word(h, A.hash_mask);
+        uint32_t pos = (uint32_t)hw & lmask;
+        slot[x] = FK_SPILL;
+        for (int step = 0; step < 64; ++step) {
+          uint64_t cur = ((volatile uint64_t*)lhash)[pos];
+          if (cur == 0) {
+            if (((volatile uint32_t*)&lcount)[0] >= A.llimit) break;
+            const unsigned long long old = atomicCAS((unsigned long long*)&lhash[pos], 0ULL, (unsigned long long)hw);
+            if (old == 0) {
+              atomicAdd(&lcount, 1u);
+              uint64_t* d = lrows + (size_t)pos * A.sw;
+              for (int j = 0; j < L.nkey_words; ++j) d[j] = r[j];
+              d[L.hash_word] = h;
+              for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
+              slot[x] = pos;
+              break;
+            }
+            cur = old;
+          }
+          if (cur == hw) { slot[x] = pos; break; }
+          pos = (pos + 1) & lmask;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase B: verify keys, merge with LDS atomics; the rest is listed for the row path ----
+#pragma unroll
+    for (int x = 0; x < PA_R; ++x) {
+      const uint32_t ri = t0 + x * 256 + tid;
+      bool spill = slot[x] == FK_SPILL;
+      if (slot[x] < FK_SPILL - 1) {
+        const uint64_t* r = A.rows + (uint64_t)ri * L.W;
+        uint64_t* d = lrows + (size_t)slot[x] * A.sw;
+        bool eq = true;
+        for (int j = 0; j < L.nkey_words; ++j) eq &= (d[j] == r[j]);
+        if (eq) {
+          for (int a = 0; a < L.naggs; ++a) gb_atomic_merge(L, a, d + L.agg_off[a], r + L.agg_off[a]);
+        } else {
+          spill = true;
+        }
+      }
+      const uint64_t m = __ballot(spill);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long sb = 0;
+        if (lane_id() == leader) sb = atomicAdd((unsigned long long*)&A.ctrl[6], (unsigned long long)__popcll(m));
+        sb = __shfl(sb, leader, 64);
+        if (spill) A.spill_idx[sb + __popcll(m & ((1ULL << lane_id()) - 1))] = ri;
+      }
+    }
+    // no barrier: the next tile only adds NEW slots (see gb_lds_preagg_kernel)
+  }
+  __syncthreads();
+  for (int s = tid; s < A.lcap; s += 256) {
+    if (lhash[s] != 0) {
+      const unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[5], 1ULL);
+      const uint64_t* src = lrows + (size_t)s * A.sw;
+      uint64_t* o = A.partial + idx * L.W;
+      for (int k = 0; k < L.W; ++k) o[k] = src[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gb_gather_rows_kernel(const uint64_t* rows, const uint32_t* idx, int64_t n, int W,
+                                                             uint64_t* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint64_t* r = rows + (uint64_t)idx[i] * W;
+    uint64_t* o = out + i * W;
+    for (int k = 0; k < W; ++k) o[k] = r[k];
+  }
+}
+
+// LDS table geometry of the partition-aggregate kernel for this layout (0 slots = layout too wide)
+void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
+  *sw = L.W | 1;
+  int c = 0;
+  if ((size_t)256 * (*sw + 1) * 8 <= 64 * 1024) {
+    c = 256;
+    while ((size_t)(c * 2) * (*sw + 1) * 8 <= 64 * 1024) c *= 2;
+  }
+  *lcap = c;
+  *lds_bytes = (size_t)c * (*sw + 1) * 8;
+}
+
+// One chunk [row0, row0 + cn) through hist -> scan -> scatter -> aggregate -> merge.
+// *spilled = rows that did not fit their partition's LDS table (went through the row path).
+int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
+                              int64_t* spilled) {
+  const GbLayout& L = g->L;
+  const int pbits = g->part_bits;
+  const int P = 1 << pbits;
+  int lcap, sw;
+  size_t lds_bytes;
+  part_geometry(L, &lcap, &sw, &lds_bytes);
+  int32_t rc;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
+  if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, (size_t)(3 * 1024 + 8) * 4))) return rc;
+  if ((rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
+  uint32_t* hist = g->part_meta;
+  uint32_t* base = g->part_meta + 1024;
+  uint32_t* cursor = g->part_meta + 2048 + 8;
+  DBHIP_CHECK(hipMemsetAsync(hist, 0, (size_t)P * 4, s));
+  hipLaunchKernelGGL(gb_part_hist_kernel, dim3(grid_for(cn, 256)), dim3(256), (size_t)P * 4, s, L, C, row0, cn, pbits,
+                     hist, g->ctrl);
+  hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, hist, P, base, cursor);
+  const int64_t ntiles = ceil_div(cn, (int64_t)PT_THREADS * PT_R);
+  const int sgrid = (int)(ntiles < 512 ? ntiles : 512);
+  hipLaunchKernelGGL(gb_part_scatter_kernel, dim3(sgrid), dim3(PT_THREADS), (size_t)P * 8, s, L, C, row0, cn, pbits,
+                     base, cursor, g->rows_in, g->ctrl);
+  DBHIP_LAUNCH_CHECK();
+  // workgroups per partition: fill the chip (>= ~1024 workgroups) without making splits tiny
+  int splits = 1;
+  while (P * splits < 1024 && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
+  const int agrid = P * splits;
+  if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)agrid * lcap * L.W * 8))) return rc;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
+  PaArgs A;
+  A.rows = g->rows_in; A.base = base; A.splits = splits; A.lcap = lcap; A.sw = sw;
+  A.llimit = (uint32_t)(lcap - lcap / 4);
+  A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill_idx = g->spill_idx; A.ctrl = g->ctrl;
+  hipLaunchKernelGGL(gb_part_agg_kernel, dim3(agrid), dim3(256), lds_bytes, s, L, A);
+  DBHIP_LAUNCH_CHECK();
+  uint64_t hc[8];
+  DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (hc[3] & 2) {
+    set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  const int64_t nspill = (int64_t)hc[6];
+  if (nspill > 0) {
+    // compact the listed rows BEFORE merge_rows may touch its own scratch
+    if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)nspill * L.W * 8))) return rc;
+    hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nspill, 256)), dim3(256), 0, s, g->rows_in, g->spill_idx,
+                       nspill, L.W, g->spill_rows);
+    DBHIP_LAUNCH_CHECK();
+  }
+  if ((rc = merge_rows(g, g->partial, (int64_t)hc[5], s))) return rc;
+  if (nspill > 0 && (rc = merge_rows(g, g->spill_rows, nspill, s))) return rc;
+  *spilled = nspill;
+  return DBHIP_OK;
+}
+
+// Called once the LDS pre-aggregation (or the first row-path chunk) has shown that the key
+// distribution does not fit one workgroup's table: `groups` distinct groups were seen in the first
+// `rows_seen` rows. Chooses the partition count, or gives up (row path) for high cardinality.
+void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen) {
+  int lcap, sw;
+  size_t lds_bytes;
+  part_geometry(g->L, &lcap, &sw, &lds_bytes);
+  g->part_bits = -1;
+  if (lcap == 0 || g->part_forbidden) return;
+  if (groups * 4 > rows_seen) return;  // (nearly) every row its own group: pre-aggregation buys nothing
+  const int64_t per_part = lcap * 3 / 8;  // target groups per partition: half of the LDS table's limit
+  int bits = 4;
+  while (bits < PT_MAX_BITS && ((int64_t)per_part << bits) < groups) ++bits;
+  if (((int64_t)per_part << bits) < groups) return;
+  g->part_bits = bits;
 }
 
 }  // namespace
@@ -980,6 +1359,7 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
   int64_t cap = 1024;
   while (cap < initial_capacity) cap <<= 1;
   g->hash_mask = ~0ULL;
+  g->part_min_rows = 262144;
   hipStream_t s = resolve_stream(nullptr);
   if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
   DBHIP_CHECK(hipMalloc((void**)&g->ctrl, 64));
@@ -995,6 +1375,16 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
 int32_t dbhip_groupby_debug_set_hash_mask(dbhip_groupby* g, uint64_t mask) {
   DBHIP_REQUIRE(g && g->count_host == 0, "dbhip_groupby_debug_set_hash_mask: table must be empty");
   g->hash_mask = mask;
+  return DBHIP_OK;
+}
+
+// test hook: force the radix-partitioned path with 2^bits partitions for every block size
+// (bits = 0: back to adaptive; bits < 0: never partition)
+int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits) {
+  DBHIP_REQUIRE(g && bits <= 10, "dbhip_groupby_debug_set_partition_bits: bad argument");
+  if (bits > 0) { g->part_bits = bits; g->part_min_rows = 1; g->part_forbidden = 0; }
+  else if (bits == 0) { g->part_bits = 0; g->part_min_rows = 262144; g->part_forbidden = 0; }
+  else { g->part_bits = -1; g->part_forbidden = 1; g->part_min_rows = 262144; }
   return DBHIP_OK;
 }
 
@@ -1035,14 +1425,25 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
   }
   // generic row path (any layout; high-cardinality continuation of the fast path), in bounded chunks
   const int64_t CHUNK = 32 << 20;
+  const bool probe_here = !fast_layout_ok(g->L);  // wide layouts learn their cardinality on the row path
   while (done < n) {
-    const int64_t cn = n - done < CHUNK ? n - done : CHUNK;
+    if (g->part_bits > 0 && n - done >= g->part_min_rows) {
+      if ((rc = partitioned_step(g, C, n, s, &done))) return rc;
+      continue;
+    }
+    int64_t cn = n - done < CHUNK ? n - done : CHUNK;
+    if (probe_here && g->part_bits == 0 && cn > (1 << 20)) cn = 1 << 20;
     if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
     hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
                        g->ctrl);
     DBHIP_LAUNCH_CHECK();
     if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
     done += cn;
+    g->rows_seen += cn;
+    if (probe_here && g->part_bits == 0 && g->rows_seen >= (1 << 20)) {
+      if (g->count_host > 32) decide_partitioning(g, g->count_host, g->rows_seen);
+      else g->part_bits = -1;  // a handful of groups: the wave-combining accumulate kernel is the right tool
+    }
   }
   return DBHIP_OK;
 }
@@ -1160,6 +1561,8 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->count_host = 0;
   g->fast_disabled = 0;
   g->fast_trusted = 0;
+  if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
+  g->rows_seen = 0;
   return DBHIP_OK;
 }
 
@@ -1173,6 +1576,9 @@ int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (g->gid) (void)hipFree(g->gid);
   if (g->retry) (void)hipFree(g->retry);
   if (g->partial) (void)hipFree(g->partial);
+  if (g->part_meta) (void)hipFree(g->part_meta);
+  if (g->spill_idx) (void)hipFree(g->spill_idx);
+  if (g->spill_rows) (void)hipFree(g->spill_rows);
   delete g;
   return DBHIP_OK;
 }

@@ -22,8 +22,8 @@ using namespace dbhip;
 
 namespace {
 
-constexpr int SORT_ITEMS = 8;                 // keys per thread
-constexpr int SORT_TILE = 256 * SORT_ITEMS;   // keys per block
+constexpr int SORT_ITEMS = 16;                // keys per thread
+constexpr int SORT_TILE = 256 * SORT_ITEMS;   // keys per block (4 waves x 1024 contiguous keys)
 
 struct SortCol {
   const void* data;
@@ -105,8 +105,11 @@ __global__ __launch_bounds__(256) void sort_iota_kernel(uint32_t* perm, int64_t 
 }
 
 // enc[j] = image of col[perm[j]]; mode 0: value part 0, 1: value part 1 (dec128 high), 2: null flag
+// Also reduces OR / AND over all images into span[0] / span[1]: bytes where both agree are constant
+// over the column and their radix pass is skipped.
 __global__ __launch_bounds__(256) void sort_encode_kernel(SortCol c, const uint32_t* perm, int64_t n, int mode,
-                                                          uint64_t* enc) {
+                                                          uint64_t* enc, unsigned long long* span) {
+  uint64_t acc_or = 0, acc_and = ~0ULL;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     uint32_t row = perm[j];
     bool valid = !c.validity || bit_get(c.validity, c.voff + row);
@@ -119,6 +122,17 @@ __global__ __launch_bounds__(256) void sort_encode_kernel(SortCol c, const uint3
       if (!valid) e = 0;  // NULL rows tie on the value passes; the flag pass places them
     }
     enc[j] = e;
+    acc_or |= e;
+    acc_and &= e;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    acc_or |= __shfl_xor(acc_or, off, 64);
+    acc_and &= __shfl_xor(acc_and, off, 64);
+  }
+  if (lane_id() == 0) {
+    atomicOr(&span[0], (unsigned long long)acc_or);
+    atomicAnd(&span[1], (unsigned long long)acc_and);
   }
 }
 
@@ -137,48 +151,153 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint64_t* keys, in
   hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+// One tile = 4096 keys; wave w owns the contiguous keys [w*1024, (w+1)*1024) in 16 rounds of 64.
+//   phase 1  per round: lanes holding the same digit find each other with 8 ballots; the key's rank among
+//            its wave's keys of that digit = (count so far in wcount[w][digit]) + (rank inside the round)
+//   phase 2  thread d: tile offset of digit d (block scan of the totals) and each wave's start inside it
+//   phase 3  keys and row ids are written to their digit-sorted position IN LDS
+//   phase 4  the tile leaves in digit order: lanes write consecutive addresses per digit run
+// Stable: (wave, round, lane) order is index order.
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t* keys, const uint32_t* vals, int64_t n,
                                                            int shift, const uint64_t* offs, int64_t ntiles,
                                                            uint64_t* out_keys, uint32_t* out_vals) {
-  __shared__ uint32_t running[256];     // keys of each digit already placed by earlier rounds
-  __shared__ uint32_t wave_cnt[4][256];  // per-wave digit counts of the current round
+  __shared__ uint64_t lkeys[SORT_TILE];
+  __shared__ uint32_t lvals[SORT_TILE];
+  __shared__ uint32_t wcount[4][256];  // phase 1: keys of (wave, digit); phase 2 on: first LDS slot of (wave, digit)
+  __shared__ uint32_t tile_off[256];
+  __shared__ uint32_t wave_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  running[tid] = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
+  for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
-  const uint64_t my_digit_base = offs[(int64_t)tid * ntiles + blockIdx.x];  // thread t owns digit t
-  __shared__ uint64_t digit_base[256];
-  digit_base[tid] = my_digit_base;
-  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+  uint64_t key[SORT_ITEMS];
+  uint32_t val[SORT_ITEMS];
+  uint32_t lrank[SORT_ITEMS];
+#pragma unroll
   for (int r = 0; r < SORT_ITEMS; ++r) {
-    const int64_t i = base + r * 256 + tid;
+    const int64_t i = base + r * 64 + lane;
+    key[r] = i < n ? keys[i] : ~0ULL;
+    val[r] = i < n ? vals[i] : 0;
+  }
+  volatile uint32_t* wc = wcount[wave];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
     const bool active = i < n;
-    uint64_t key = active ? keys[i] : 0;
-    uint32_t val = active ? vals[i] : 0;
-    const uint32_t digit = (uint32_t)(key >> shift) & 0xFF;
-    // lanes of this wave holding the same digit
+    const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xFF;
     uint64_t m = __ballot(active);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      uint64_t bal = __ballot((digit >> b) & 1);
+      const uint64_t bal = __ballot((digit >> b) & 1);
       m &= ((digit >> b) & 1) ? bal : ~bal;
     }
     const uint32_t rank = __popcll(m & ((1ULL << lane) - 1));
-    if (active && rank == 0) wave_cnt[wave][digit] = __popcll(m);
-    __syncthreads();
-    if (active) {
-      uint32_t before = running[digit];
-      for (int w = 0; w < wave; ++w) before += wave_cnt[w][digit];
-      uint64_t pos = digit_base[digit] + before + rank;
-      out_keys[pos] = key;
-      out_vals[pos] = val;
-    }
-    __syncthreads();
-    running[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+    const uint32_t prev = wc[digit];
+    __builtin_amdgcn_wave_barrier();
+    if (active && rank == 0) wc[digit] = prev + __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    lrank[r] = prev + rank;
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid], c3 = wcount[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    uint32_t incl = tot;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wave_cnt[w][tid] = 0;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wb = 0;
+    for (int w = 0; w < wave; ++w) wb += wave_tot[w];
+    const uint32_t off = wb + incl - tot;
+    tile_off[tid] = off;
+    wcount[0][tid] = off;
+    wcount[1][tid] = off + c0;
+    wcount[2][tid] = off + c0 + c1;
+    wcount[3][tid] = off + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    if (i < n) {
+      const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xFF;
+      const uint32_t p = wcount[wave][digit] + lrank[r];
+      lkeys[p] = key[r];
+      lvals[p] = val[r];
+    }
+  }
+  __syncthreads();
+  const int64_t tile_base = (int64_t)blockIdx.x * SORT_TILE;
+  const int tile_n = (int)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
+#pragma unroll 4
+  for (int j = tid; j < tile_n; j += 256) {
+    const uint64_t k = lkeys[j];
+    const uint32_t digit = (uint32_t)(k >> shift) & 0xFF;
+    const uint64_t pos = offs[(int64_t)digit * ntiles + blockIdx.x] + (uint32_t)(j - tile_off[digit]);
+    out_keys[pos] = k;
+    out_vals[pos] = lvals[j];
+  }
+}
+
+// ---- LIMIT: radix select on the most significant sort key --------------------------------------
+// count of images whose bits above `shift+8` equal those of `prefix`, per next byte
+__global__ __launch_bounds__(256) void sort_select_hist_kernel(const uint64_t* enc, int64_t n, uint64_t prefix, int shift,
+                                                               uint32_t* hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t himask = shift >= 56 ? 0ULL : (~0ULL << (shift + 8));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint64_t e = enc[i];
+    if ((e & himask) == (prefix & himask)) atomicAdd(&h[(e >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// cand[0..count) = ascending row ids with enc <= threshold (wave-aggregated append keeps it cheap;
+// the order of the list is irrelevant: the sort that follows is on keys, ties by row id need a stable
+// base order, so the list is produced in ascending order by a scan instead)
+__global__ __launch_bounds__(256) void sort_select_flag_kernel(const uint64_t* enc, int64_t n, uint64_t threshold,
+                                                               uint32_t* cnt) {
+  // per-tile (1024 rows) count of qualifying rows
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+  uint32_t c = 0;
+  for (int k = threadIdx.x; k < 1024; k += 256) {
+    const int64_t i = base + k;
+    if (i < n && enc[i] <= threshold) ++c;
+  }
+  c = (uint32_t)wave_sum_u64(c);
+  __shared__ uint32_t part[4];
+  if (lane_id() == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void sort_select_emit_kernel(const uint64_t* enc, int64_t n, uint64_t threshold,
+                                                               const uint64_t* tile_off, uint32_t* cand) {
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+  __shared__ uint32_t run;
+  __shared__ uint32_t wt[4];
+  if (threadIdx.x == 0) run = 0;
+  __syncthreads();
+  const uint64_t out0 = tile_off[blockIdx.x];
+  for (int chunk = 0; chunk < 1024; chunk += 256) {
+    const int64_t i = base + chunk + threadIdx.x;
+    const bool q = i < n && enc[i] <= threshold;
+    const uint64_t m = __ballot(q);
+    if (lane_id() == 0) wt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    uint32_t wb = run;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wb += wt[w];
+    if (q) cand[out0 + wb + __popcll(m & ((1ULL << lane_id()) - 1))] = (uint32_t)i;
+    __syncthreads();
+    if (threadIdx.x == 0) run += wt[0] + wt[1] + wt[2] + wt[3];
     __syncthreads();
   }
 }
@@ -202,18 +321,21 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
     }
   }
   hipStream_t s = resolve_stream(stream);
-  const int64_t ntiles = ceil_div(n, SORT_TILE);
-  const int64_t nh = 256 * ntiles;
-  // scratch: 2 key buffers, 2 perm buffers, hist, offsets, scan block sums
-  size_t bytes = (size_t)n * 8 * 2 + (size_t)n * 4 * 2 + (size_t)nh * 4 + (size_t)nh * 8 + (size_t)(nh / SCAN_TILE + 2) * 8 + 1024;
+  const int64_t ntiles_max = ceil_div(n, SORT_TILE);
+  const int64_t nh_max = 256 * ntiles_max;
+  const int64_t nflag = ceil_div(n, 1024);
+  // scratch: 2 key buffers, 2 perm buffers, hist, offsets, scan block sums, span (or/and), flags
+  const int64_t nscan = (nh_max > nflag ? nh_max : nflag);
+  size_t bytes = (size_t)n * 8 * 2 + (size_t)n * 4 * 2 + (size_t)nscan * 4 + (size_t)nscan * 8 + (size_t)(nscan / SCAN_TILE + 2) * 8 + 2048;
   uint8_t* ws = (uint8_t*)scratch(bytes + 64, 7);
   if (!ws) return DBHIP_ERR_HIP;
   uint32_t* long_flag = (uint32_t*)(ws + bytes);
   uint64_t* kb[2] = {(uint64_t*)ws, (uint64_t*)ws + n};
   uint64_t* offs = kb[1] + n;
-  uint64_t* blk = offs + nh;
-  uint32_t* hist = (uint32_t*)(blk + nh / SCAN_TILE + 2);
-  uint32_t* pb[2] = {hist + nh, hist + nh + n};
+  uint64_t* blk = offs + nscan;
+  unsigned long long* span = (unsigned long long*)(blk + nscan / SCAN_TILE + 2);
+  uint32_t* hist = (uint32_t*)(span + 4);
+  uint32_t* pb[2] = {hist + nscan + 256, hist + nscan + 256 + n};
   int cur = 0;
   const int grid = grid_for(n, 256);
   bool any_string = false;
@@ -233,12 +355,87 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   }
   hipLaunchKernelGGL(sort_iota_kernel, dim3(grid), dim3(256), 0, s, pb[cur], n);
 
-  auto radix_passes = [&](int nbytes) -> int32_t {
+  auto make_col = [&](int k) {
+    return SortCol{keys[k].data, keys[k].validity, keys[k].validity_offset, keys[k].type,
+                   desc_host ? desc_host[k] : 0, nulls_first_host ? nulls_first_host[k] : 0};
+  };
+  // enc = image of column c read through pb[cur][0..m); returns OR / AND of all images
+  auto encode = [&](const SortCol& c, int64_t m, int mode, uint64_t* v_or, uint64_t* v_and) -> int32_t {
+    DBHIP_CHECK(hipMemsetAsync(&span[0], 0x00, 8, s));
+    DBHIP_CHECK(hipMemsetAsync(&span[1], 0xFF, 8, s));
+    hipLaunchKernelGGL(sort_encode_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pb[cur], m, mode, kb[cur], span);
+    DBHIP_LAUNCH_CHECK();
+    unsigned long long h[2];
+    DBHIP_CHECK(hipMemcpyAsync(h, span, 16, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    *v_or = h[0];
+    *v_and = h[1];
+    return DBHIP_OK;
+  };
+
+  int64_t m = n;  // rows being sorted (the candidates of the LIMIT select, else all rows)
+
+  // ---- LIMIT (LimitType::LimitRows, sort_compare.rs:197-209 uses select_nth_unstable + sort):
+  // radix select on the most significant key finds a threshold image T with at least `limit` rows
+  // <= T; only those rows are sorted.
+  if (limit > 0 && limit * 4 < n && n >= 65536 && !keys[0].validity) {
+    SortCol c = make_col(0);
+    const int top_part = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 1 : 0;
+    uint64_t v_or, v_and;
+    int32_t rc = encode(c, n, top_part, &v_or, &v_and);
+    if (rc) return rc;
+    const uint64_t vary = v_or ^ v_and;
+    uint64_t prefix = v_and & ~vary;  // constant bits (exact in constant bytes; varying bytes are set below)
+    for (int b = 0; b < 8; ++b)
+      if ((vary >> (8 * b)) & 0xFF) prefix &= ~(0xFFULL << (8 * b));
+    int64_t k_rem = limit, less_total = 0, bucket = n;
+    uint64_t threshold = ~0ULL;
+    bool decided = false;
+    for (int b = 7; b >= 0 && !decided; --b) {
+      if (((vary >> (8 * b)) & 0xFF) == 0) continue;
+      DBHIP_CHECK(hipMemsetAsync(hist, 0, 256 * 4, s));
+      hipLaunchKernelGGL(sort_select_hist_kernel, dim3(grid), dim3(256), 0, s, kb[cur], n, prefix, 8 * b, hist);
+      DBHIP_LAUNCH_CHECK();
+      uint32_t hh[256];
+      DBHIP_CHECK(hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, s));
+      DBHIP_CHECK(hipStreamSynchronize(s));
+      int64_t cum = 0;
+      int d = 0;
+      for (; d < 256; ++d) {
+        if (cum + hh[d] >= k_rem) break;
+        cum += hh[d];
+      }
+      if (d == 256) d = 255;  // (cannot happen: the bucket holds >= k_rem rows)
+      prefix |= (uint64_t)d << (8 * b);
+      k_rem -= cum;
+      less_total += cum;
+      bucket = hh[d];
+      threshold = prefix | ((b == 0) ? 0ULL : ((1ULL << (8 * b)) - 1));
+      // lower constant bytes are already part of prefix; lower varying bytes: take the whole bucket
+      if (bucket <= (limit > 8192 ? limit : 8192)) decided = true;
+    }
+    if (threshold != ~0ULL) {
+      // lower bits of the threshold: all ones in varying bytes below the last decided byte
+      m = less_total + bucket;
+      uint32_t* cnt = hist;
+      hipLaunchKernelGGL(sort_select_flag_kernel, dim3((unsigned)nflag), dim3(256), 0, s, kb[cur], n, threshold, cnt);
+      rc = dbscan::exclusive_scan_u32(cnt, nflag, blk, offs, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(sort_select_emit_kernel, dim3((unsigned)nflag), dim3(256), 0, s, kb[cur], n, threshold, offs, pb[cur ^ 1]);
+      DBHIP_LAUNCH_CHECK();
+      cur ^= 1;  // pb[cur] = ascending candidate row ids
+    }
+  }
+
+  const int64_t ntiles = ceil_div(m, SORT_TILE);
+  const int64_t nh = 256 * ntiles;
+  auto radix_passes = [&](int nbytes, uint64_t vary) -> int32_t {
     for (int b = 0; b < nbytes; ++b) {
-      hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], n, 8 * b, hist, ntiles);
+      if (((vary >> (8 * b)) & 0xFF) == 0) continue;  // every image has the same byte here
+      hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], m, 8 * b, hist, ntiles);
       int32_t rc = dbscan::exclusive_scan_u32(hist, nh, blk, offs, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], pb[cur], n, 8 * b, offs,
+      hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], pb[cur], m, 8 * b, offs,
                          ntiles, kb[cur ^ 1], pb[cur ^ 1]);
       cur ^= 1;
     }
@@ -247,23 +444,23 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   };
 
   for (int k = nkeys - 1; k >= 0; --k) {
-    SortCol c{keys[k].data, keys[k].validity, keys[k].validity_offset, keys[k].type,
-              desc_host ? desc_host[k] : 0, nulls_first_host ? nulls_first_host[k] : 0};
+    SortCol c = make_col(k);
     const int parts = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 2 : 1;
+    uint64_t v_or, v_and;
     for (int part = 0; part < parts; ++part) {
       // the permutation is shared by both buffers of a pass: encode reads pb[cur], writes kb[cur]
-      hipLaunchKernelGGL(sort_encode_kernel, dim3(grid), dim3(256), 0, s, c, pb[cur], n, part, kb[cur]);
-      int32_t rc = radix_passes(sort_key_bytes(c.type));
+      int32_t rc = encode(c, m, part, &v_or, &v_and);
       if (rc) return rc;
+      if ((rc = radix_passes(sort_key_bytes(c.type), v_or ^ v_and))) return rc;
     }
     if (c.validity) {
-      hipLaunchKernelGGL(sort_encode_kernel, dim3(grid), dim3(256), 0, s, c, pb[cur], n, 2, kb[cur]);
-      int32_t rc = radix_passes(1);
+      int32_t rc = encode(c, m, 2, &v_or, &v_and);
       if (rc) return rc;
+      if ((rc = radix_passes(1, v_or ^ v_and))) return rc;
     }
   }
-  int64_t m = (limit > 0 && limit < n) ? limit : n;
-  DBHIP_CHECK(hipMemcpyAsync(out_perm, pb[cur], (size_t)m * 4, hipMemcpyDeviceToDevice, s));
+  int64_t mout = (limit > 0 && limit < m) ? limit : m;
+  DBHIP_CHECK(hipMemcpyAsync(out_perm, pb[cur], (size_t)mout * 4, hipMemcpyDeviceToDevice, s));
   DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
   return DBHIP_OK;
 }

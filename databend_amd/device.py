@@ -501,6 +501,12 @@ class GroupBy:
         f.restype = C.c_int32
         check(f(self.h, C.c_uint64(mask)))
 
+    def debug_set_partition_bits(self, bits):
+        """test hook: force (bits > 0) / forbid (bits < 0) the radix-partitioned pre-aggregation path"""
+        f = lib().dbhip_groupby_debug_set_partition_bits
+        f.restype = C.c_int32
+        check(f(self.h, C.c_int32(bits)))
+
     def destroy(self):
         if self.h:
             lib().dbhip_groupby_destroy(self.h)

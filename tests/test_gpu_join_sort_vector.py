@@ -51,7 +51,7 @@ def sort_cases(rng, n):
     ]
 
 
-@pytest.mark.parametrize("n", [1, 2, 255, 2049, 100_000])
+@pytest.mark.parametrize("n", [1, 2, 255, 2049, 4096, 12_289, 100_000])
 def test_sort_perm_matches_oracle(gpu, oracle, n):
     rng = np.random.default_rng(n)
     cases = sort_cases(rng, n)
@@ -72,6 +72,34 @@ def test_sort_perm_matches_oracle(gpu, oracle, n):
         f = (C.c_uint8 * len(idxs))(*nf)
         oracle.orc_sort_perm(O.cols(hcols), d, f, len(idxs), C.c_int64(n), C.c_int64(limit), exp.ctypes.data_as(C.c_void_p))
         assert np.array_equal(got, exp[:m]), (idxs, desc, nf, limit)
+
+
+@pytest.mark.parametrize("n", [65_536, 300_001])
+def test_sort_limit_radix_select(gpu, oracle, n):
+    """LIMIT (sort_compare.rs:197-209): the device path radix-selects a threshold on the most significant key and
+    sorts only the candidates; the result must be the first `limit` rows of the full stable sort."""
+    rng = np.random.default_rng(n + 17)
+    f = (rng.standard_normal(n) * 1e3).astype(np.float32)
+    f[:4] = [np.nan, -0.0, 0.0, -np.inf]
+    lowcard = rng.integers(0, 5, n).astype(np.int64)          # heavy ties on the first key: candidates = whole groups
+    i32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    small = rng.integers(1000, 1256, n).astype(np.int64)      # constant upper bytes: their passes are skipped
+    combos = [([(T.T_F32, f)], [1], 10), ([(T.T_F32, f)], [0], 10), ([(T.T_I64, lowcard), (T.T_I32, i32)], [0, 1], 100),
+              ([(T.T_I32, i32)], [0], 20_000), ([(T.T_I64, small), (T.T_F32, f)], [1, 0], 1), ([(T.T_I32, i32), (T.T_I64, lowcard)], [1, 0], 9000)]
+    for cols, desc, limit in combos:
+        gcols = [gpu.Column.from_numpy(a, c) for c, a in cols]
+        hcols = [O.HostCol(c, a) for c, a in cols]
+        got = gpu.sort_perm(gcols, desc, [0] * len(cols), limit)
+        exp = np.zeros(limit, np.uint32)
+        d = (C.c_uint8 * len(cols))(*desc)
+        z = (C.c_uint8 * len(cols))(*([0] * len(cols)))
+        oracle.orc_sort_perm(O.cols(hcols), d, z, len(cols), C.c_int64(n), C.c_int64(limit), exp.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(got, exp), (desc, limit)
+    # Decimal128 most significant key (two 64-bit parts; the select runs on the high part)
+    ints = [int(x) * int(y) for x, y in zip(rng.integers(-2**62, 2**62, n), rng.integers(0, 2**40, n))]
+    got = gpu.sort_perm([gpu.Column.decimal128(ints, 38, 0)], [1], [0], 10)
+    exp = sorted(range(n), key=lambda i: (-ints[i], i))[:10]
+    assert got.tolist() == exp
 
 
 def test_sort_decimal128_and_bool(gpu, oracle):

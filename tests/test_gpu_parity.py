@@ -295,10 +295,12 @@ def norm(rows):
     return sorted(rows, key=lambda r: tuple((x is None, str(type(x)), x if x is not None else 0) for x in r))
 
 
-@pytest.mark.parametrize("n,card", [(1, 1), (100, 4), (10_000, 4), (100_000, 1000), (200_000, 150_000)])
-def test_groupby_matches_oracle_as_sorted_sets(gpu, oracle, n, card):
+@pytest.mark.parametrize("n,card,pbits", [(1, 1, 0), (100, 4, 0), (10_000, 4, 0), (100_000, 1000, 0), (200_000, 150_000, 0),
+                                          (1, 1, 4), (8193, 40, 4), (100_000, 1000, 6), (200_000, 150_000, 10)])
+def test_groupby_matches_oracle_as_sorted_sets(gpu, oracle, n, card, pbits):
     """Mirrors tests/it/aggregates/agg_hashtable.rs: several key types incl. NULLs, sum/count/min/max,
-    compared as sorted row sets (assert_block_value_sort_eq)."""
+    compared as sorted row sets (assert_block_value_sort_eq). pbits > 0 forces the radix-partitioned
+    pre-aggregation path (wide layout: 6 key words, 9 aggregates)."""
     rng = np.random.default_rng(n + card)
     k_i64 = rng.integers(0, card, n).astype(np.int64) - card // 2
     k_i16 = (rng.integers(0, min(card, 100), n)).astype(np.int16)
@@ -326,15 +328,9 @@ def test_groupby_matches_oracle_as_sorted_sets(gpu, oracle, n, card):
              O.HostCol(T.T_DEC128, O.i128_array(a_dec128), None, 31, 4), O.HostCol(T.T_I32, a_i32), O.HostCol(T.T_U64, a_u64), O.HostCol(T.T_I32, a_i32, avalid),
              O.HostCol(T.T_F32, k_f32)]
     g = gpu.GroupBy(key_types, aggs, key_nullable)
-    half = n // 2
-    # two blocks (exercises growth between blocks) on the GPU
-    if half:
-        def sl(c, lo, hi):
-            arr = c.to_numpy()[lo:hi] if c.dtype != T.T_DEC128 else None
-            return c
-        g.add_block(gkeys, gargs, n)  # whole block
-    else:
-        g.add_block(gkeys, gargs, n)
+    if pbits:
+        g.debug_set_partition_bits(pbits)
+    g.add_block(gkeys, gargs, n)
     got = g.result()
     h = oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n)
     exp = oracle_rows(oracle, h, key_types, aggs)
@@ -343,7 +339,8 @@ def test_groupby_matches_oracle_as_sorted_sets(gpu, oracle, n, card):
     assert norm(got) == norm(exp)
 
 
-def test_groupby_forced_hash_collisions(gpu, oracle):
+@pytest.mark.parametrize("pbits", [0, 4])
+def test_groupby_forced_hash_collisions(gpu, oracle, pbits):
     """hash_index/index.rs:385-404 tests full tag collisions; here distinct keys are forced onto the same
     probe hash so the verify+retry path runs."""
     n = 3000
@@ -352,6 +349,8 @@ def test_groupby_forced_hash_collisions(gpu, oracle):
     a = rng.integers(-1000, 1000, n).astype(np.int64)
     g = gpu.GroupBy([T.T_I64], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)], capacity=4096)
     g.debug_set_hash_mask(0x3)
+    if pbits:
+        g.debug_set_partition_bits(pbits)
     g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None], n)
     g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None], n)
     got = sorted(g.result())
@@ -448,8 +447,9 @@ def test_q1_finalize_avg_matches_sf_style_golden_shape(gpu, oracle):
     assert out[0][6] == 2552200585 and out[0][7] == 3827312973462
 
 
-@pytest.mark.parametrize("n,card", [(1, 1), (513, 3), (70_000, 4), (300_000, 700), (300_000, 5000), (400_000, 390_000)])
-def test_groupby_short_layout_lds_preaggregation_matches_oracle(gpu, oracle, n, card):
+@pytest.mark.parametrize("n,card,pbits", [(1, 1, 0), (513, 3, 0), (70_000, 4, 0), (300_000, 700, 0), (300_000, 5000, 0), (400_000, 390_000, 0),
+                                          (513, 3, 4), (300_000, 5000, 5), (300_000, 60_000, 8), (1_500_000, 3000, 0), (1_500_000, 40_000, 0)])
+def test_groupby_short_layout_lds_preaggregation_matches_oracle(gpu, oracle, n, card, pbits):
     """Short layouts (<= 4 key words, <= 6 aggregates) go through the workgroup-LDS partial aggregation;
     cardinalities below and far above the LDS table capacity (spill to the row path), nullable key,
     Decimal128 sum, min/max — compared with the oracle as sorted row sets."""
@@ -471,6 +471,8 @@ def test_groupby_short_layout_lds_preaggregation_matches_oracle(gpu, oracle, n, 
     hargs = [O.HostCol(T.T_I64, a_i64), None, O.HostCol(T.T_DEC128, O.i128_array(a_dec128), None, 31, 4), O.HostCol(T.T_U32, a_u32), O.HostCol(T.T_I64, a_i64),
              O.HostCol(T.T_U32, a_u32, avalid)]
     g = gpu.GroupBy(key_types, aggs, key_nullable)
+    if pbits:
+        g.debug_set_partition_bits(pbits)  # force the radix-partitioned path (adaptive when n >= 1.5 M)
     g.add_block(gkeys, gargs, n)
     got = g.result()
     h = oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n)

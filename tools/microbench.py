@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--vec-nq", default="1,32,64,128,512,2048")
-    ap.add_argument("--gb-card", default="4,200,1000,20000,1000000,10000000")
+    ap.add_argument("--gb-card", default="4,200,1000,5000,20000,100000,1000000,10000000")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda k: not only or k in only
