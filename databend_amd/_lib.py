@@ -54,7 +54,8 @@ SYMBOLS = [
     "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized",
     "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized",
     "dbhip_groupby_result_type", "dbhip_groupby_flush_result", "dbhip_groupby_reset",
-    "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_join_create",
+    "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_keys_method", "dbhip_pack_keys",
+    "dbhip_join_create", "dbhip_join_create_keys", "dbhip_join_probe_mark",
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
     "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
 ]

@@ -28,6 +28,7 @@
 #include "gb_device.h"
 #include "runtime.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -890,6 +891,8 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
   int64_t spilled = 0;
   int32_t rc = add_chunk_partitioned(g, C, *done, cn, s, &spilled);
   if (rc) return rc;
+  if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby partitioned chunk: rows=%lld pbits=%d spilled=%lld groups=%lld\n",
+                                     (long long)cn, g->part_bits, (long long)spilled, (long long)g->count_host);
   *done += cn;
   g->rows_seen += cn;
   if (spilled * 20 > cn) {
@@ -968,6 +971,8 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
       decide_partitioning(g, g->count_host, g->rows_seen);
       if (g->part_bits < 0) g->fast_disabled = 1;
     }
+    if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby lds chunk: rows=%lld partial=%llu spilled=%llu groups=%lld -> pbits=%d\n",
+                                       (long long)cn, (unsigned long long)hc[5], (unsigned long long)hc[6], (long long)g->count_host, g->part_bits);
     g->fast_trusted = (int64_t)hc[6] * 100 <= cn;
   }
   return DBHIP_OK;

@@ -1,130 +1,399 @@
-// k_join.hip — inner hash join on KeysU64.
+// k_join.hip — packed fixed-width join/group keys (a14) and the hash-join table (a15).
 //
-// Reference: HashJoinHashTable<u64> (hash_join_table/hashjoin_hashtable.rs:26-137): bucket array of
-// entry pointers, capacity max(2*rows -> pow2, 1024) (:95-108), idx = hash >> (64 - log2 cap),
-// lock-free CAS prepend (:110-137); probe walks the chain comparing keys
-// (new_hash_join/hashtable/fixed_keys.rs:209-269) and emits (probe_idx, RowPtr).
-// Device geometry: head[cap] (u32 build row + 1, 0 = empty) + next[rows] chains; insertion is one
-// atomicExch per build row (prepend), chains are only walked by later launches. NULL keys never
-// match (validity bit 0 rows are neither inserted nor probed). The join hash itself is not part
-// of the parity contract (FastHash is CRC32-C or a murmur mix depending on the host CPU,
+// Reference: HashJoinHashTable<K> (hash_join_table/hashjoin_hashtable.rs:26-137): bucket array of
+// u64 = 48-bit entry pointer | 16-bit one-hot tag (1 << (48 + (hash & 15))), capacity
+// max(2*rows -> pow2, 1024) (:95-108), idx = hash >> (64 - log2 cap), lock-free CAS prepend
+// (:110-137); probe: tag early-reject, then walk the chain comparing keys
+// (new_hash_join/hashtable/fixed_keys.rs:139-142,209-269) and emit (probe_idx, RowPtr).
+// Device geometry (same ideas, 32-bit row ids instead of pointers):
+//   head[cap]   u64 = (build row + 1) | tag bits << 32; insertion = atomicExch on the low half
+//               (prepend) + atomicOr on the high half; chains are only walked by later launches
+//   ent[rows]   array of structures {key words, next, valid}: the key compare and the chain link
+//               come from ONE 64-byte sector (16 B entries for keys <= 8 bytes, 32 B for 16-byte keys)
+// NULL keys never match (validity-0 rows are neither inserted nor probed). The join hash itself is
+// not part of the parity contract (FastHash is CRC32-C or a murmur mix depending on the host CPU,
 // common/hashtable/src/traits.rs:199-211): a 64-bit multiply-xorshift is used.
 // Pair order across threads is unspecified in the reference; here pairs come out sorted by
-// (probe_idx, build_row): count per probe row -> exclusive scan -> ordered emit.
+// (probe_idx, build_row): count per probe row -> exclusive scan -> ordered emit. The count pass
+// remembers the matching build row, so for unique build keys (primary-key joins) the emit pass is a
+// pure stream compaction and the table is walked once.
 #include "dev_common.h"
 #include "dev_scan.h"
 #include "runtime.h"
 
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 using namespace dbhip;
 
 struct dbhip_join {
-  uint64_t* keys;      // all build keys in arrival order
-  uint8_t* valid;      // one byte per build row
+  int kw;              // key words (u64): 1 or 2
+  int es;              // entry stride in u64 words: 2 or 4
+  uint64_t* ent;       // [cap_rows * es]: key words, then (next | valid << 32)
   int64_t nrows, cap_rows;
-  uint32_t* head;      // [buckets]
-  uint32_t* next;      // [nrows]
+  uint64_t* head;      // [buckets]
   int64_t buckets;
   int shift;
   bool finalized;
   // probe scratch
-  uint32_t* cnt; uint64_t* off; uint64_t* blk; size_t scratch_rows;
+  uint32_t* cnt; uint32_t* firstm; uint64_t* off; uint64_t* blk; size_t scratch_rows;
   uint64_t* total_dev;
 };
 
 namespace {
 
-__device__ __forceinline__ uint64_t join_hash(uint64_t x) { return agg_hash_u64(x); }
+template <int KW>
+__device__ __forceinline__ uint64_t join_hash(const uint64_t* k) {
+  if (KW == 1) return agg_hash_u64(k[0]);
+  return agg_hash_u64(k[0] * 0x9E3779B97F4A7C15ULL ^ agg_hash_u64(k[1]));
+}
 
+template <int KW>
 __global__ __launch_bounds__(256) void join_copy_kernel(const uint64_t* keys, const uint8_t* validity, int64_t n,
-                                                        uint64_t* dst_keys, uint8_t* dst_valid) {
+                                                        uint64_t* ent) {
+  constexpr int ES = KW * 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    dst_keys[i] = keys[i];
-    dst_valid[i] = validity ? (uint8_t)bit_get(validity, i) : 1;
+    uint64_t* e = ent + i * ES;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) e[w] = keys[i * KW + w];
+    const uint64_t v = validity ? (uint64_t)bit_get(validity, i) : 1;
+    e[KW] = v << 32;
+    if (KW == 2) e[3] = 0;
   }
 }
 
-__global__ __launch_bounds__(256) void join_build_kernel(const uint64_t* keys, const uint8_t* valid, int64_t n,
-                                                         uint32_t* head, uint32_t* next, int shift) {
+template <int KW>
+__global__ __launch_bounds__(256) void join_build_kernel(uint64_t* ent, int64_t n, uint64_t* head, int shift) {
+  constexpr int ES = KW * 2;
+  uint32_t* head32 = (uint32_t*)head;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (!valid[i]) { next[i] = 0; continue; }
-    uint64_t idx = join_hash(keys[i]) >> shift;
-    next[i] = atomicExch(&head[idx], (uint32_t)(i + 1));  // prepend
+    uint64_t* e = ent + i * ES;
+    if (!(e[KW] >> 32)) continue;
+    const uint64_t h = join_hash<KW>(e);
+    const uint64_t idx = h >> shift;
+    const uint32_t old = atomicExch(&head32[2 * idx], (uint32_t)(i + 1));  // prepend
+    atomicOr(&head32[2 * idx + 1], 1u << (h & 15));
+    ((uint32_t*)&e[KW])[0] = old;
   }
 }
 
-__global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* bkeys, const uint32_t* head,
-                                                         const uint32_t* next, int shift, const uint64_t* pkeys,
-                                                         const uint8_t* pvalid, int64_t n, uint32_t* cnt,
-                                                         unsigned long long* total) {
+// walks the chain of probe key k; returns the number of matching build rows, *last = one of them
+template <int KW>
+__device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_t* head, int shift, const uint64_t* k,
+                                              uint32_t* last) {
+  constexpr int ES = KW * 2;
+  const uint64_t h = join_hash<KW>(k);
+  const uint64_t hd = head[h >> shift];
+  uint32_t c = 0;
+  if (!((hd >> (32 + (h & 15))) & 1)) return 0;  // empty bucket or tag miss (fixed_keys.rs:139-142)
+  for (uint32_t e = (uint32_t)hd; e;) {
+    const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
+    bool eq = true;
+    uint64_t link;
+    if (KW == 1) {
+      const ulonglong2 v = *(const ulonglong2*)p;
+      eq = v.x == k[0];
+      link = v.y;
+    } else {
+      const ulonglong2 v0 = *(const ulonglong2*)p;
+      eq = v0.x == k[0] && v0.y == k[1];
+      link = p[2];
+    }
+    if (eq) { ++c; *last = e - 1; }
+    e = (uint32_t)link;
+  }
+  return c;
+}
+
+template <int KW>
+__global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, const uint64_t* head, int shift,
+                                                         const uint64_t* pkeys, const uint8_t* pvalid, int64_t n,
+                                                         uint32_t* cnt, uint32_t* firstm, unsigned long long* total) {
   uint64_t local = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t c = 0;
+    uint32_t c = 0, last = 0;
     if (!pvalid || bit_get(pvalid, i)) {
-      uint64_t k = pkeys[i];
-      for (uint32_t e = head[join_hash(k) >> shift]; e; e = next[e - 1]) c += (bkeys[e - 1] == k);
+      uint64_t k[KW];
+#pragma unroll
+      for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+      c = join_walk<KW>(ent, head, shift, k, &last);
     }
-    if (cnt) cnt[i] = c;
+    if (cnt) { cnt[i] = c; firstm[i] = last; }
     local += c;
   }
   local = wave_sum_u64(local);
   if (lane_id() == 0 && local) atomicAdd(total, (unsigned long long)local);
 }
 
-__global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* bkeys, const uint32_t* head,
-                                                        const uint32_t* next, int shift, const uint64_t* pkeys,
-                                                        const uint8_t* pvalid, int64_t n, const uint32_t* cnt,
-                                                        const uint64_t* off, uint32_t* out_p, uint32_t* out_b,
-                                                        int64_t max_pairs) {
+template <int KW>
+__global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, const uint64_t* head, int shift,
+                                                        const uint64_t* pkeys, int64_t n, const uint32_t* cnt,
+                                                        const uint32_t* firstm, const uint64_t* off, uint32_t* out_p,
+                                                        uint32_t* out_b, int64_t max_pairs) {
+  constexpr int ES = KW * 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if (cnt[i] == 0) continue;
-    uint64_t k = pkeys[i], o = off[i];
-    if ((int64_t)(o + cnt[i]) > max_pairs) continue;
+    const uint32_t c = cnt[i];
+    if (c == 0) continue;
+    const uint64_t o = off[i];
+    if ((int64_t)(o + c) > max_pairs) continue;
+    if (c == 1) {  // unique build key: nothing to walk
+      out_p[o] = (uint32_t)i;
+      out_b[o] = firstm[i];
+      continue;
+    }
+    uint64_t k[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+    const uint64_t h = join_hash<KW>(k);
     uint32_t m = 0;
-    for (uint32_t e = head[join_hash(k) >> shift]; e; e = next[e - 1]) {
-      if (bkeys[e - 1] != k) continue;
-      // insert build row e-1 keeping this probe row's segment ascending (segments are tiny)
-      uint32_t b = e - 1, j = m;
-      while (j > 0 && out_b[o + j - 1] > b) { out_b[o + j] = out_b[o + j - 1]; --j; }
-      out_b[o + j] = b;
-      out_p[o + m] = (uint32_t)i;
-      ++m;
+    for (uint32_t e = (uint32_t)head[h >> shift]; e;) {
+      const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
+      bool eq = p[0] == k[0];
+      if (KW == 2) eq = eq && p[1] == k[1];
+      if (eq) {
+        // insert build row e-1 keeping this probe row's segment ascending (segments are tiny)
+        uint32_t b = e - 1, j = m;
+        while (j > 0 && out_b[o + j - 1] > b) { out_b[o + j] = out_b[o + j - 1]; --j; }
+        out_b[o + j] = b;
+        out_p[o + m] = (uint32_t)i;
+        ++m;
+      }
+      e = (uint32_t)p[KW];
     }
   }
 }
 
+// matched[i] = probe row i has at least one build match (semi / anti / left-outer bookkeeping)
+template <int KW>
+__global__ __launch_bounds__(256) void join_mark_kernel(const uint64_t* ent, const uint64_t* head, int shift,
+                                                        const uint64_t* pkeys, const uint8_t* pvalid, int64_t n,
+                                                        uint8_t* out_bitmap, unsigned long long* total) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  uint64_t local = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    bool hit = false;
+    if (i < n && (!pvalid || bit_get(pvalid, i))) {
+      uint64_t k[KW];
+#pragma unroll
+      for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+      uint32_t last;
+      hit = join_walk<KW>(ent, head, shift, k, &last) != 0;
+    }
+    const uint64_t m = __ballot(hit);
+    const int l = lane_id();
+    if ((l & 7) == 0 && i < n) out_bitmap[i >> 3] = (uint8_t)(m >> l);
+    local += hit;
+  }
+  local = wave_sum_u64(local);
+  if (lane_id() == 0 && local) atomicAdd(total, (unsigned long long)local);
+}
+
 int32_t ensure_probe_scratch(dbhip_join* j, int64_t n) {
   if (j->scratch_rows >= (size_t)n) return DBHIP_OK;
-  if (j->cnt) { DBHIP_CHECK(hipDeviceSynchronize()); (void)hipFree(j->cnt); (void)hipFree(j->off); (void)hipFree(j->blk); }
+  if (j->cnt) {
+    DBHIP_CHECK(hipDeviceSynchronize());
+    (void)hipFree(j->cnt); (void)hipFree(j->firstm); (void)hipFree(j->off); (void)hipFree(j->blk);
+  }
   size_t cap = (size_t)n + (n >> 3) + 1024;
   DBHIP_CHECK(hipMalloc((void**)&j->cnt, cap * 4));
+  DBHIP_CHECK(hipMalloc((void**)&j->firstm, cap * 4));
   DBHIP_CHECK(hipMalloc((void**)&j->off, cap * 8));
   DBHIP_CHECK(hipMalloc((void**)&j->blk, (cap / SCAN_TILE + 2) * 8));
   j->scratch_rows = cap;
   return DBHIP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// a14: packed fixed-width keys (HashMethodFixedKeys::build_keys_vec, method_fixed_keys.rs:58-78;
+// KeysVec layout :310-403): columns stably sorted by byte width, values little endian back to
+// back, then one null byte per nullable column (1 = NULL, the value bytes of a NULL stay zero).
+// ---------------------------------------------------------------------------
+constexpr int PK_MAX_COLS = 16;
+struct PackCols {
+  const void* data[PK_MAX_COLS];
+  const uint8_t* validity[PK_MAX_COLS];
+  int64_t voff[PK_MAX_COLS];
+  int32_t type[PK_MAX_COLS];
+  int32_t src_bytes[PK_MAX_COLS];   // bytes per element in the source buffer
+  int32_t key_bytes[PK_MAX_COLS];   // bytes the value occupies in the key (numeric_byte_size)
+  int32_t offset[PK_MAX_COLS];      // byte offset of the value in the key
+  int32_t null_offset[PK_MAX_COLS]; // byte offset of the null flag, -1 = not nullable
+  int32_t is_scalar[PK_MAX_COLS];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void pack_keys_kernel(PackCols P, int64_t n, int key_bytes, uint8_t* out,
+                                                        uint8_t* all_valid) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    bool allv = true;
+    if (i < n) {
+      uint64_t w[4] = {0, 0, 0, 0};  // the key as little-endian words (up to 32 bytes)
+      for (int c = 0; c < P.n; ++c) {
+        const int64_t j = P.is_scalar[c] ? 0 : i;
+        const bool valid = !P.validity[c] || bit_get(P.validity[c], P.voff[c] + j);
+        allv &= valid;
+        if (!valid) {
+          const int o = P.null_offset[c];
+          if (o >= 0) w[o >> 3] |= 1ULL << (8 * (o & 7));
+          continue;
+        }
+        uint64_t v0 = 0, v1 = 0;
+        const uint8_t* src = (const uint8_t*)P.data[c];
+        switch (P.src_bytes[c]) {
+          case 0: v0 = bit_get(src, j); break;  // Boolean
+          case 1: v0 = src[j]; break;
+          case 2: v0 = ((const uint16_t*)src)[j]; break;
+          case 4: v0 = ((const uint32_t*)src)[j]; break;
+          case 8: v0 = ((const uint64_t*)src)[j]; break;
+          default: v0 = ((const uint64_t*)src)[2 * j]; v1 = ((const uint64_t*)src)[2 * j + 1]; break;
+        }
+        // DecimalView<FROM, TO>: a wider/narrower store than the precision's carrier is converted
+        if (P.key_bytes[c] == 16 && P.src_bytes[c] == 8) v1 = (v0 >> 63) ? ~0ULL : 0ULL;  // sign extend i64 -> i128
+        const int o = P.offset[c], kb = P.key_bytes[c];
+        // place `kb` little-endian bytes at byte offset o (may straddle words)
+        for (int part = 0; part < (kb + 7) / 8; ++part) {
+          uint64_t v = part == 0 ? v0 : v1;
+          const int nb = kb - 8 * part < 8 ? kb - 8 * part : 8;
+          if (nb < 8) v &= (1ULL << (8 * nb)) - 1;
+          const int bo = o + 8 * part;
+          const int wi = bo >> 3, sh = 8 * (bo & 7);
+          w[wi] |= v << sh;
+          if (sh && wi + 1 < 4 && nb * 8 + sh > 64) w[wi + 1] |= v >> (64 - sh);
+        }
+      }
+      switch (key_bytes) {
+        case 1: out[i] = (uint8_t)w[0]; break;
+        case 2: ((uint16_t*)out)[i] = (uint16_t)w[0]; break;
+        case 4: ((uint32_t*)out)[i] = (uint32_t)w[0]; break;
+        case 8: ((uint64_t*)out)[i] = w[0]; break;
+        case 16: ((uint64_t*)out)[2 * i] = w[0]; ((uint64_t*)out)[2 * i + 1] = w[1]; break;
+        default:
+          for (int k = 0; k < 4; ++k) ((uint64_t*)out)[4 * i + k] = w[k];
+          break;
+      }
+    } else {
+      allv = false;
+    }
+    if (all_valid) {
+      const uint64_t m = __ballot(allv);
+      const int l = lane_id();
+      if ((l & 7) == 0 && i < n) all_valid[i >> 3] = (uint8_t)(m >> l);
+    }
+  }
+}
+
+// numeric_byte_size (src/query/expression/src/types.rs:606-633); 0 = not a fixed-width key type
+int key_type_bytes(const dbhip_col& c, int* src_bytes) {
+  switch (c.type) {
+    case DBHIP_T_I8: case DBHIP_T_U8: *src_bytes = 1; return 1;
+    case DBHIP_T_I16: case DBHIP_T_U16: *src_bytes = 2; return 2;
+    case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_F32: case DBHIP_T_DATE: *src_bytes = 4; return 4;
+    case DBHIP_T_I64: case DBHIP_T_U64: case DBHIP_T_F64: case DBHIP_T_TIMESTAMP: *src_bytes = 8; return 8;
+    case DBHIP_T_DEC64: *src_bytes = 8; return c.precision <= 18 ? 8 : 16;
+    case DBHIP_T_DEC128: *src_bytes = 16; return c.precision <= 18 ? 8 : 16;
+    default: *src_bytes = 0; return 0;
+  }
+}
+
+int32_t plan_pack(const dbhip_col* cols, int ncols, PackCols* P, int* total_bytes) {
+  if (ncols < 1 || ncols > PK_MAX_COLS) {
+    set_error("pack_keys: 1..%d key columns", PK_MAX_COLS);
+    return DBHIP_ERR_INVALID;
+  }
+  int order[PK_MAX_COLS], kb[PK_MAX_COLS], sb[PK_MAX_COLS];
+  for (int c = 0; c < ncols; ++c) {
+    order[c] = c;
+    kb[c] = key_type_bytes(cols[c], &sb[c]);
+    if (kb[c] == 0) {
+      set_error("pack_keys: column %d of type %d is not a fixed-width key (HashMethodSerializer stays on the CPU)", c, cols[c].type);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+  }
+  std::stable_sort(order, order + ncols, [&](int a, int b) { return kb[a] < kb[b]; });  // sort_by_key is stable
+  int off = 0;
+  memset(P, 0, sizeof(*P));
+  P->n = ncols;
+  for (int s = 0; s < ncols; ++s) {
+    const int c = order[s];
+    P->data[s] = cols[c].data; P->validity[s] = cols[c].validity; P->voff[s] = cols[c].validity_offset;
+    P->type[s] = cols[c].type; P->src_bytes[s] = sb[c]; P->key_bytes[s] = kb[c]; P->is_scalar[s] = cols[c].is_scalar;
+    P->offset[s] = off;
+    off += kb[c];
+  }
+  for (int s = 0; s < ncols; ++s) P->null_offset[s] = P->validity[s] ? off++ : -1;
+  *total_bytes = off;
+  return DBHIP_OK;
+}
+
+int method_bytes(int total) {  // choose_hash_method_with_types (kernels/group_by.rs:70-78)
+  if (total <= 1) return 1;
+  if (total <= 2) return 2;
+  if (total <= 4) return 4;
+  if (total <= 8) return 8;
+  if (total <= 16) return 16;
+  if (total <= 32) return 32;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
-int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host) {
+int32_t dbhip_keys_method(const dbhip_col* cols, int32_t ncols, int32_t* out_key_bytes_host) {
+  DBHIP_REQUIRE(cols && out_key_bytes_host, "dbhip_keys_method: NULL argument");
+  PackCols P;
+  int total = 0;
+  int32_t rc = plan_pack(cols, ncols, &P, &total);
+  if (rc == DBHIP_ERR_UNSUPPORTED) { *out_key_bytes_host = 0; return DBHIP_OK; }
+  if (rc) return rc;
+  *out_key_bytes_host = method_bytes(total);
+  return DBHIP_OK;
+}
+
+int32_t dbhip_pack_keys(const dbhip_col* cols, int32_t ncols, int64_t n, int32_t key_bytes, void* out_keys,
+                        uint8_t* out_all_valid, void* stream) {
+  DBHIP_REQUIRE(cols, "dbhip_pack_keys: NULL columns");
+  PackCols P;
+  int total = 0;
+  int32_t rc = plan_pack(cols, ncols, &P, &total);
+  if (rc) return rc;
+  if (!(key_bytes == 1 || key_bytes == 2 || key_bytes == 4 || key_bytes == 8 || key_bytes == 16 || key_bytes == 32) ||
+      key_bytes < total) {
+    set_error("dbhip_pack_keys: %d key bytes do not fit a %d-byte key", total, key_bytes);
+    return DBHIP_ERR_INVALID;
+  }
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(out_keys, "dbhip_pack_keys: NULL out");
+  hipStream_t s = resolve_stream(stream);
+  hipLaunchKernelGGL(pack_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, P, n, key_bytes, (uint8_t*)out_keys,
+                     out_all_valid);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, dbhip_join** out_host) {
   DBHIP_REQUIRE(out_host, "dbhip_join_create: NULL out");
+  DBHIP_REQUIRE(key_bytes == 8 || key_bytes == 16, "dbhip_join_create: key width must be 8 or 16 bytes (narrower keys are zero-extended by dbhip_pack_keys)");
   dbhip_join* j = new (std::nothrow) dbhip_join();
   DBHIP_REQUIRE(j, "dbhip_join_create: out of host memory");
   memset(j, 0, sizeof(*j));
+  j->kw = key_bytes / 8;
+  j->es = j->kw * 2;
   j->cap_rows = expected_build_rows > 1024 ? expected_build_rows : 1024;
-  DBHIP_CHECK(hipMalloc((void**)&j->keys, (size_t)j->cap_rows * 8));
-  DBHIP_CHECK(hipMalloc((void**)&j->valid, (size_t)j->cap_rows));
+  DBHIP_CHECK(hipMalloc((void**)&j->ent, (size_t)j->cap_rows * j->es * 8));
   DBHIP_CHECK(hipMalloc((void**)&j->total_dev, 8));
   *out_host = j;
   return DBHIP_OK;
 }
 
-int32_t dbhip_join_add_build(dbhip_join* j, const uint64_t* keys, const uint8_t* validity, int64_t n,
+int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host) {
+  return dbhip_join_create_keys(expected_build_rows, 8, out_host);
+}
+
+int32_t dbhip_join_add_build(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                              void* stream) {
   DBHIP_REQUIRE(j && !j->finalized, "dbhip_join_add_build: table missing or already finalized");
   if (n == 0) return DBHIP_OK;
@@ -133,17 +402,18 @@ int32_t dbhip_join_add_build(dbhip_join* j, const uint64_t* keys, const uint8_t*
   hipStream_t s = resolve_stream(stream);
   if (j->nrows + n > j->cap_rows) {  // grow the chunk store (BasicHashJoin::add_block squashes chunks)
     int64_t nc = j->cap_rows * 2 > j->nrows + n ? j->cap_rows * 2 : j->nrows + n;
-    uint64_t* nk; uint8_t* nv;
-    DBHIP_CHECK(hipMalloc((void**)&nk, (size_t)nc * 8));
-    DBHIP_CHECK(hipMalloc((void**)&nv, (size_t)nc));
-    DBHIP_CHECK(hipMemcpyAsync(nk, j->keys, (size_t)j->nrows * 8, hipMemcpyDeviceToDevice, s));
-    DBHIP_CHECK(hipMemcpyAsync(nv, j->valid, (size_t)j->nrows, hipMemcpyDeviceToDevice, s));
+    uint64_t* ne;
+    DBHIP_CHECK(hipMalloc((void**)&ne, (size_t)nc * j->es * 8));
+    DBHIP_CHECK(hipMemcpyAsync(ne, j->ent, (size_t)j->nrows * j->es * 8, hipMemcpyDeviceToDevice, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(j->keys); (void)hipFree(j->valid);
-    j->keys = nk; j->valid = nv; j->cap_rows = nc;
+    (void)hipFree(j->ent);
+    j->ent = ne; j->cap_rows = nc;
   }
-  hipLaunchKernelGGL(join_copy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, validity, n,
-                     j->keys + j->nrows, j->valid + j->nrows);
+  uint64_t* dst = j->ent + (size_t)j->nrows * j->es;
+  if (j->kw == 1)
+    hipLaunchKernelGGL(join_copy_kernel<1>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)keys, validity, n, dst);
+  else
+    hipLaunchKernelGGL(join_copy_kernel<2>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)keys, validity, n, dst);
   DBHIP_LAUNCH_CHECK();
   j->nrows += n;
   return DBHIP_OK;
@@ -156,26 +426,32 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   while (cap < j->nrows * 2) cap <<= 1;  // hashjoin_hashtable.rs:95-108
   j->buckets = cap;
   j->shift = 64 - __builtin_ctzll((unsigned long long)cap);
-  DBHIP_CHECK(hipMalloc((void**)&j->head, (size_t)cap * 4));
-  DBHIP_CHECK(hipMalloc((void**)&j->next, (size_t)(j->nrows ? j->nrows : 1) * 4));
-  DBHIP_CHECK(hipMemsetAsync(j->head, 0, (size_t)cap * 4, s));
+  DBHIP_CHECK(hipMalloc((void**)&j->head, (size_t)cap * 8));
+  DBHIP_CHECK(hipMemsetAsync(j->head, 0, (size_t)cap * 8, s));
   if (j->nrows) {
-    hipLaunchKernelGGL(join_build_kernel, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->keys, j->valid,
-                       j->nrows, j->head, j->next, j->shift);
+    if (j->kw == 1)
+      hipLaunchKernelGGL(join_build_kernel<1>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
+    else
+      hipLaunchKernelGGL(join_build_kernel<2>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
     DBHIP_LAUNCH_CHECK();
   }
   j->finalized = true;
   return DBHIP_OK;
 }
 
-int32_t dbhip_join_probe_count(dbhip_join* j, const uint64_t* keys, const uint8_t* validity, int64_t n,
+int32_t dbhip_join_probe_count(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                                uint64_t* out_total_host, void* stream) {
   DBHIP_REQUIRE(j && j->finalized && out_total_host, "dbhip_join_probe_count: table not finalized / NULL out");
   hipStream_t s = resolve_stream(stream);
   DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
   if (n) {
-    hipLaunchKernelGGL(join_count_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, j->keys, j->head, j->next,
-                       j->shift, keys, validity, n, (uint32_t*)nullptr, (unsigned long long*)j->total_dev);
+    const int grid = grid_for(n, 256);
+    if (j->kw == 1)
+      hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                         validity, n, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)j->total_dev);
+    else
+      hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                         validity, n, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)j->total_dev);
     DBHIP_LAUNCH_CHECK();
   }
   DBHIP_CHECK(hipMemcpyAsync(out_total_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
@@ -183,7 +459,30 @@ int32_t dbhip_join_probe_count(dbhip_join* j, const uint64_t* keys, const uint8_
   return DBHIP_OK;
 }
 
-int32_t dbhip_join_probe(dbhip_join* j, const uint64_t* keys, const uint8_t* validity, int64_t n,
+int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
+                              uint8_t* out_matched_bitmap, uint64_t* out_n_matched_host, void* stream) {
+  DBHIP_REQUIRE(j && j->finalized, "dbhip_join_probe_mark: table not finalized");
+  hipStream_t s = resolve_stream(stream);
+  if (out_n_matched_host) *out_n_matched_host = 0;
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(keys && out_matched_bitmap, "dbhip_join_probe_mark: NULL argument");
+  DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
+  const int grid = grid_for(n, 256);
+  if (j->kw == 1)
+    hipLaunchKernelGGL(join_mark_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
+  else
+    hipLaunchKernelGGL(join_mark_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
+  DBHIP_LAUNCH_CHECK();
+  if (out_n_matched_host) {
+    DBHIP_CHECK(hipMemcpyAsync(out_n_matched_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+  }
+  return DBHIP_OK;
+}
+
+int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                          uint32_t* out_probe_idx, uint32_t* out_build_row, int64_t max_pairs,
                          uint64_t* out_n_pairs_host, void* stream) {
   DBHIP_REQUIRE(j && j->finalized && out_n_pairs_host, "dbhip_join_probe: table not finalized / NULL out");
@@ -195,8 +494,12 @@ int32_t dbhip_join_probe(dbhip_join* j, const uint64_t* keys, const uint8_t* val
   if (rc) return rc;
   DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
   const int grid = grid_for(n, 256);
-  hipLaunchKernelGGL(join_count_kernel, dim3(grid), dim3(256), 0, s, j->keys, j->head, j->next, j->shift, keys,
-                     validity, n, j->cnt, (unsigned long long*)j->total_dev);
+  if (j->kw == 1)
+    hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
+  else
+    hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
   rc = dbscan::exclusive_scan_u32(j->cnt, n, j->blk, j->off, s);
   if (rc) return rc;
   uint64_t total = 0;
@@ -210,8 +513,12 @@ int32_t dbhip_join_probe(dbhip_join* j, const uint64_t* keys, const uint8_t* val
   }
   if (total) {
     DBHIP_REQUIRE(out_probe_idx && out_build_row, "dbhip_join_probe: NULL output");
-    hipLaunchKernelGGL(join_emit_kernel, dim3(grid), dim3(256), 0, s, j->keys, j->head, j->next, j->shift, keys,
-                       validity, n, j->cnt, j->off, out_probe_idx, out_build_row, max_pairs);
+    if (j->kw == 1)
+      hipLaunchKernelGGL(join_emit_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
+                         j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
+    else
+      hipLaunchKernelGGL(join_emit_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
+                         j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
     DBHIP_LAUNCH_CHECK();
   }
   return DBHIP_OK;
@@ -220,7 +527,7 @@ int32_t dbhip_join_probe(dbhip_join* j, const uint64_t* keys, const uint8_t* val
 int32_t dbhip_join_destroy(dbhip_join* j) {
   if (!j) return DBHIP_OK;
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {j->keys, j->valid, j->head, j->next, j->cnt, j->off, j->blk, j->total_dev};
+  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete j;

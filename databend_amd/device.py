@@ -526,13 +526,55 @@ def q1_fused(g, qty, price, disc, tax, rf, ls, shipdate, cutoff, n=None, stream=
                                C.c_void_p(shipdate.data.ptr), C.c_int32(cutoff), C.c_int64(n), stream))
 
 
-class HashJoin:
-    """Device inner hash join on KeysU64 (dbhip_join_*; trait Join, new_hash_join/join.rs:26-53)."""
+def keys_method(cols):
+    """choose_hash_method_with_types (kernels/group_by.rs:40-80): packed key width in bytes, 0 = Serializer."""
+    out = C.c_int32()
+    check(lib().dbhip_keys_method(_cols(cols), len(cols), C.byref(out)))
+    return out.value
 
-    def __init__(self, expected_build_rows=1024):
+
+class PackedKeys:
+    """Result of pack_keys: `key_bytes`-wide integers (HashMethodFixedKeys::build_keys_vec) + the all-valid bitmap."""
+
+    def __init__(self, data, validity, n, key_bytes):
+        self.data, self.validity, self.n, self.key_bytes = data, validity, n, key_bytes
+
+    def to_numpy(self):
+        return self.data.to_numpy(np.uint8, self.n * self.key_bytes).reshape(self.n, self.key_bytes)
+
+
+def pack_keys(cols, key_bytes=None, want_validity=True):
+    n = cols[0].n
+    kb = key_bytes or keys_method(cols)
+    if kb == 0:
+        raise L.DbhipError(L.ERR_UNSUPPORTED, "HashMethodSerializer keys stay on the CPU")
+    out = DeviceBuffer(max(n, 1) * kb + 64)
+    val = DeviceBuffer((max(n, 1) + 7) // 8 + 64) if want_validity else None
+    check(lib().dbhip_pack_keys(_cols(cols), len(cols), C.c_int64(n), C.c_int32(kb), C.c_void_p(out.ptr),
+                                C.c_void_p(val.ptr) if val else None, None))
+    return PackedKeys(out, val, n, kb)
+
+
+class HashJoin:
+    """Device hash join on packed fixed keys (dbhip_join_*; trait Join, new_hash_join/join.rs:26-53).
+    key_bytes 8 = KeysU8..U64 (zero-extended), 16 = KeysU128."""
+
+    def __init__(self, expected_build_rows=1024, key_bytes=8):
         _ensure()
         self.h = C.c_void_p()
-        check(lib().dbhip_join_create(C.c_int64(expected_build_rows), C.byref(self.h)))
+        self.key_bytes = key_bytes
+        check(lib().dbhip_join_create_keys(C.c_int64(expected_build_rows), C.c_int32(key_bytes), C.byref(self.h)))
+
+    def probe_mark(self, keys_col):
+        """-> bool[n]: probe row has a build match (semi / anti / left-outer joins)."""
+        v = C.c_void_p(keys_col.validity.ptr) if keys_col.validity is not None else None
+        n = keys_col.n
+        bm = DeviceBuffer((max(n, 1) + 7) // 8 + 64)
+        total = C.c_uint64()
+        check(lib().dbhip_join_probe_mark(self.h, C.c_void_p(keys_col.data.ptr), v, C.c_int64(n), C.c_void_p(bm.ptr), C.byref(total), None))
+        bits = unpack_bits(bm.to_numpy(np.uint8, (n + 7) // 8), n)
+        assert int(bits.sum()) == total.value
+        return bits
 
     def add_block(self, keys_col):
         """Join::add_block: one build chunk (u64 key column, optional validity)."""

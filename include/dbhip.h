@@ -284,23 +284,46 @@ int32_t dbhip_q1_fused(dbhip_groupby* g,
                        const int32_t* l_shipdate, int32_t shipdate_cutoff,
                        int64_t n, void* stream);
 
-/* ---- a14/a15: hash join -----------------------------------------------------
- * Replaces HashJoinHashTable<u64> build/probe behind trait Join
+/* ---- a14: packed fixed-width keys ---------------------------------------------
+ * Replaces DataBlock::choose_hash_method_with_types (kernels/group_by.rs:40-80) and
+ * HashMethodFixedKeys::build_keys_vec / KeysVec (group_by_hash/method_fixed_keys.rs:58-78,
+ * 310-403): numeric / date / timestamp / decimal key columns are stably sorted by byte width
+ * (numeric_byte_size, types.rs:606-633), their values written little endian back to back,
+ * followed by one null byte per nullable column (1 = NULL, value bytes of a NULL row stay 0);
+ * the row's key is that byte string read as ONE integer of 1/2/4/8/16/32 bytes
+ * (golden: tests/it/group_by.rs:52-58, three Int8 columns [1,1,1] -> 0x10101).
+ * dbhip_keys_method returns the key width the reference would choose (0 = HashMethodSerializer /
+ * SingleBinary: keep the CPU method). dbhip_pack_keys may be asked for a wider key than needed
+ * (zero-extended; the join table takes 8- and 16-byte keys). `out_all_valid` (may be NULL):
+ * LSB-first bitmap, bit = no key column is NULL in that row (join keys with a NULL never match). */
+int32_t dbhip_keys_method(const dbhip_col* cols, int32_t ncols, int32_t* out_key_bytes_host);
+int32_t dbhip_pack_keys(const dbhip_col* cols, int32_t ncols, int64_t n, int32_t key_bytes,
+                        void* out_keys, uint8_t* out_all_valid, void* stream);
+
+/* ---- a15: hash join ---------------------------------------------------------
+ * Replaces HashJoinHashTable<K> build/probe behind trait Join
  * (hash_join_table/hashjoin_hashtable.rs:26-344,
  * new_hash_join/hashtable/fixed_keys.rs:47-269, memory/inner_join.rs:122-271) for
- * KeysU64 (method_fixed_keys.rs:58-139). Inner join; emits (probe_idx, build_row)
- * pairs. Pair order is unspecified in the reference across threads; this library
- * returns them sorted by (probe_idx, build_row). */
+ * KeysU8..U64 (8-byte keys) and KeysU128 (16-byte keys; method_fixed_keys.rs:58-139).
+ * `keys` point at n keys of the width the table was created with. Inner join: emits
+ * (probe_idx, build_row) pairs. Pair order is unspecified in the reference across threads; this
+ * library returns them sorted by (probe_idx, build_row). dbhip_join_probe_mark writes the
+ * "probe row has a match" bitmap (LSB-first, ceil(n/8) bytes) that semi / anti joins filter on and
+ * left-outer joins use to append unmatched rows (new_hash_join probe_matched,
+ * fixed_keys.rs:96-167). */
 typedef struct dbhip_join dbhip_join;
-int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host);
-int32_t dbhip_join_add_build(dbhip_join* j, const uint64_t* keys, const uint8_t* validity,
+int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host);  /* 8-byte keys */
+int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, dbhip_join** out_host);
+int32_t dbhip_join_add_build(dbhip_join* j, const void* keys, const uint8_t* validity,
                              int64_t n, void* stream);
 int32_t dbhip_join_finalize(dbhip_join* j, void* stream);
-int32_t dbhip_join_probe_count(dbhip_join* j, const uint64_t* keys, const uint8_t* validity,
+int32_t dbhip_join_probe_count(dbhip_join* j, const void* keys, const uint8_t* validity,
                                int64_t n, uint64_t* out_total_host, void* stream);
-int32_t dbhip_join_probe(dbhip_join* j, const uint64_t* keys, const uint8_t* validity, int64_t n,
+int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                          uint32_t* out_probe_idx, uint32_t* out_build_row, int64_t max_pairs,
                          uint64_t* out_n_pairs_host, void* stream);
+int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
+                              uint8_t* out_matched_bitmap, uint64_t* out_n_matched_host, void* stream);
 int32_t dbhip_join_destroy(dbhip_join* j);
 
 /* ---- a16: sort / top-k --------------------------------------------------------

@@ -1317,3 +1317,80 @@ int64_t orc_q3_run(const int64_t* c_custkey, const void* c_mktsegment_views, int
   free(bm); free(sel); free(ck); free(fok); free(fck); free(fod); free(fsp); free(pp); free(pb); free(bok); free(bod); free(bsp); free(ws); free(th);
   return rc ? -(int64_t)rc - 100 : m;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * packed fixed-width keys — HashMethodFixedKeys (method_fixed_keys.rs:58-78), KeysVec (:310-403),
+ * fixed_hash (:405-512), numeric_byte_size (src/query/expression/src/types.rs:606-633),
+ * choose_hash_method_with_types (kernels/group_by.rs:40-80).
+ * ------------------------------------------------------------------------------------------- */
+static int orc_numeric_byte_size(const orc_col* c) {
+  switch (c->type) {
+    case ORC_T_I8: case ORC_T_U8: return 1;
+    case ORC_T_I16: case ORC_T_U16: return 2;
+    case ORC_T_I32: case ORC_T_U32: case ORC_T_F32: case ORC_T_DATE: return 4;
+    case ORC_T_I64: case ORC_T_U64: case ORC_T_F64: case ORC_T_TIMESTAMP: return 8;
+    case ORC_T_DEC64: case ORC_T_DEC128: return c->precision <= 18 ? 8 : 16;  /* can_carried_by_64 / _128 */
+    default: return 0;  /* not number / date / decimal -> Serializer */
+  }
+}
+
+int orc_keys_method(const orc_col* cols, int ncols) {
+  int len = 0;
+  for (int i = 0; i < ncols; ++i) {
+    int b = orc_numeric_byte_size(&cols[i]);
+    if (b == 0) return 0;
+    len += b;
+    if (cols[i].validity) len += 1; /* extra one byte for null flag (group_by.rs:62-65) */
+  }
+  if (len == 1) return 1;
+  if (len == 2) return 2;
+  if (len <= 4) return 4;
+  if (len <= 8) return 8;
+  if (len <= 16) return 16;
+  if (len <= 32) return 32;
+  return 0;
+}
+
+int orc_pack_keys(const orc_col* cols, int ncols, int64_t n, int key_bytes, uint8_t* out) {
+  int order[64], size[64], col_off[65], null_off[64];
+  if (ncols > 64) return -1;
+  for (int i = 0; i < ncols; ++i) {
+    order[i] = i;
+    size[i] = orc_numeric_byte_size(&cols[i]);
+    if (size[i] == 0) return -1;
+  }
+  /* group_columns.sort_by_key(numeric_byte_size) — stable (method_fixed_keys.rs:63-68) */
+  for (int i = 1; i < ncols; ++i) {
+    int o = order[i], j = i;
+    while (j > 0 && size[order[j - 1]] > size[o]) { order[j] = order[j - 1]; --j; }
+    order[j] = o;
+  }
+  col_off[0] = 0;
+  for (int s = 0; s < ncols; ++s) col_off[s + 1] = col_off[s] + size[order[s]];   /* KeysVec::new :326-337 */
+  int null_offset = col_off[ncols];
+  for (int s = 0; s < ncols; ++s) null_off[s] = cols[order[s]].validity ? null_offset++ : -1;  /* :342-353 */
+  if (null_offset > key_bytes) return -1;  /* "size of T too small" */
+  memset(out, 0, (size_t)n * key_bytes);
+  for (int s = 0; s < ncols; ++s) {
+    const orc_col* c = &cols[order[s]];
+    const int kb = size[order[s]];
+    for (int64_t row = 0; row < n; ++row) {
+      int64_t j = c->is_scalar ? 0 : row;
+      if (c->validity && !((c->validity[(c->validity_offset + j) >> 3] >> ((c->validity_offset + j) & 7)) & 1)) {
+        out[row * key_bytes + null_off[s]] = 1;  /* set_null :389-397 */
+        continue;
+      }
+      uint8_t* dst = out + row * key_bytes + col_off[s];
+      if (c->type == ORC_T_DEC128) {
+        /* DecimalView<FROM, TO>: marshal the value in the carrier of its precision (:486-499) */
+        memcpy(dst, (const uint8_t*)c->data + 16 * j, kb);  /* little endian: low bytes of the i128 */
+      } else if (c->type == ORC_T_DEC64 && kb == 16) {
+        __int128 v = (__int128)((const int64_t*)c->data)[j];
+        memcpy(dst, &v, 16);
+      } else {
+        memcpy(dst, (const uint8_t*)c->data + (size_t)kb * j, kb);  /* value.marshal(slice): little endian */
+      }
+    }
+  }
+  return 0;
+}

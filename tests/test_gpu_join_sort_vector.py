@@ -40,6 +40,91 @@ def test_inner_join_pairs_match_oracle(gpu, oracle, nb, np_, card):
         assert (bk[gb] == pk[gp]).all() and bvalid[gb].all() and pvalid[gp].all()
 
 
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 1000, 100_003])
+def test_pack_keys_matches_oracle(gpu, oracle, n):
+    """dbhip_pack_keys == KeysVec byte layout (method_fixed_keys.rs:310-403) for mixed widths, nullable columns,
+    decimals by precision; dbhip_keys_method == choose_hash_method_with_types."""
+    rng = np.random.default_rng(n + 3)
+    v1, v2 = rng.integers(0, 4, n) > 0, rng.integers(0, 3, n) > 0
+    i64 = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    i32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    u8 = rng.integers(0, 256, n).astype(np.uint8)
+    i16 = rng.integers(-2**15, 2**15 - 1, n).astype(np.int16)
+    f32 = rng.standard_normal(n).astype(np.float32)
+    d128 = [int(x) * 10**7 for x in rng.integers(-10**17, 10**17, n)]
+    d128s = [int(x) for x in rng.integers(-10**9, 10**9, n)]
+    sets = [
+        [(T.T_I64, i64, None, 0, 0)],
+        [(T.T_I32, i32, v1, 0, 0), (T.T_U8, u8, None, 0, 0), (T.T_I16, i16, v2, 0, 0)],
+        [(T.T_I64, i64, v1, 0, 0), (T.T_DATE, i32, None, 0, 0), (T.T_F32, f32, None, 0, 0)],
+        [(T.T_DEC128, d128, v2, 30, 4), (T.T_I16, i16, None, 0, 0)],
+        [(T.T_DEC128, d128s, None, 12, 2), (T.T_DEC64, i64, None, 15, 2), (T.T_U8, u8, v1, 0, 0)],
+        [(T.T_I64, i64, None, 0, 0), (T.T_TIMESTAMP, i64[::-1].copy(), None, 0, 0), (T.T_DEC128, d128, None, 38, 0)],
+    ]
+    for spec in sets:
+        gcols, hcols = [], []
+        for t, arr, v, p_, s_ in spec:
+            if t == T.T_DEC128:
+                gcols.append(gpu.Column.decimal128(arr, p_, s_, validity=v))
+                hcols.append(O.HostCol(t, O.i128_array(arr), v, p_, s_))
+            else:
+                gcols.append(gpu.Column.from_numpy(arr, t, validity=v, precision=p_, scale=s_))
+                hcols.append(O.HostCol(t, arr, v, p_, s_))
+        kb = oracle.orc_keys_method(O.cols(hcols), len(hcols))
+        assert gpu.keys_method(gcols) == kb and kb > 0
+        if n == 0:
+            continue
+        exp = np.zeros(n * kb, np.uint8)
+        assert oracle.orc_pack_keys(O.cols(hcols), len(hcols), C.c_int64(n), kb, exp.ctypes.data_as(C.c_void_p)) == 0
+        pk = gpu.pack_keys(gcols)
+        assert pk.key_bytes == kb
+        assert np.array_equal(pk.to_numpy().reshape(-1), exp)
+        allv = np.ones(n, bool)
+        for _, _, v, _, _ in spec:
+            if v is not None:
+                allv &= v
+        from databend_amd.device import unpack_bits
+        assert np.array_equal(unpack_bits(pk.validity.to_numpy(np.uint8, (n + 7) // 8), n), allv)
+    assert gpu.keys_method([gpu.Column.strings([b"a"] * max(n, 1))]) == 0
+
+
+@pytest.mark.parametrize("nb,np_,card", [(1000, 5000, 300), (120_000, 300_000, 90_000)])
+def test_join_on_packed_two_column_keys_u128_and_mark(gpu, oracle, nb, np_, card):
+    """Two-column join key (i64, i32 nullable) -> KeysU128 via dbhip_pack_keys; inner pairs == a dictionary join on
+    the tuples; rows with a NULL key column never match; probe_mark == 'has at least one pair' (semi/anti join filter)."""
+    rng = np.random.default_rng(nb)
+    bk1 = rng.integers(0, card, nb).astype(np.int64) * 1_000_003
+    bk2 = rng.integers(0, 3, nb).astype(np.int32)
+    pk1 = rng.integers(0, card * 2, np_).astype(np.int64) * 1_000_003
+    pk2 = rng.integers(0, 3, np_).astype(np.int32)
+    bv, pv = rng.integers(0, 10, nb) > 0, rng.integers(0, 10, np_) > 0
+    bkeys = gpu.pack_keys([gpu.Column.from_numpy(bk1), gpu.Column.from_numpy(bk2, validity=bv)], key_bytes=16)
+    pkeys = gpu.pack_keys([gpu.Column.from_numpy(pk1), gpu.Column.from_numpy(pk2, validity=pv)], key_bytes=16)
+    j = gpu.HashJoin(nb, key_bytes=16)
+    j.add_block(bkeys)
+    j.final_build()
+    gp, gb = j.probe_block(pkeys)
+    by_key = {}
+    for r in range(nb):
+        if bv[r]:
+            by_key.setdefault((int(bk1[r]), int(bk2[r])), []).append(r)
+    exp = [(i, r) for i in range(np_) if pv[i] for r in by_key.get((int(pk1[i]), int(pk2[i])), [])]
+    assert list(zip(gp.tolist(), gb.tolist())) == exp and len(exp) > 100
+    marks = j.probe_mark(pkeys)
+    em = np.zeros(np_, bool)
+    em[[i for i, _ in exp]] = True
+    assert np.array_equal(marks, em)
+    # the same join on 8-byte packed keys of a single narrow column (KeysU32 zero-extended)
+    j8 = gpu.HashJoin(nb)
+    b8 = gpu.pack_keys([gpu.Column.from_numpy(bk2, validity=bv)], key_bytes=8)
+    p8 = gpu.pack_keys([gpu.Column.from_numpy(pk2[:2000], validity=pv[:2000])], key_bytes=8)
+    j8.add_block(b8)
+    j8.final_build()
+    m8 = j8.probe_mark(p8)
+    have = set(int(x) for x, ok in zip(bk2, bv) if ok)
+    assert np.array_equal(m8, np.array([bool(ok) and int(x) in have for x, ok in zip(pk2[:2000], pv[:2000])]))
+
+
 def sort_cases(rng, n):
     f = (rng.standard_normal(n) * 3).astype(np.float32)
     if n > 10:

@@ -250,6 +250,43 @@ def test_packed_join_keys_and_inner_join_against_numpy():
     assert got == exp and m > 1000
 
 
+def test_packed_fixed_keys_golden_from_group_by_rs():
+    """The reference's own known answers for HashMethodFixedKeys (src/query/expression/tests/it/group_by.rs:40-58:
+    three Int8 columns -> KeysU32 [0x10101, 0x10101, 0x20202, 0x10101, 0x20202, 0x30303]; :61-118: Decimal(20,2) ->
+    KeysU128 with the value itself, Decimal(40,2) -> KeysU256) plus the KeysVec layout rules (method_fixed_keys.rs:
+    stable sort by byte width, null bytes after the values, value bytes of a NULL stay zero)."""
+    L = O.load()
+    a = np.array([1, 1, 2, 1, 2, 3], np.int8)
+    cols3 = [O.HostCol(T.T_I8, a), O.HostCol(T.T_I8, a), O.HostCol(T.T_I8, a)]
+    assert L.orc_keys_method(O.cols(cols3), 3) == 4           # HashMethodKeysU32
+    out = np.zeros(6 * 4, np.uint8)
+    assert L.orc_pack_keys(O.cols(cols3), 3, C.c_int64(6), 4, out.ctypes.data_as(C.c_void_p)) == 0
+    assert out.view(np.uint32).tolist() == [0x10101, 0x10101, 0x20202, 0x10101, 0x20202, 0x30303]
+    # a String column -> Serializer (group_by.rs:38-39)
+    sv = np.zeros((6, 16), np.uint8)
+    assert L.orc_keys_method(O.cols([O.HostCol(T.T_I8, a), O.HostCol(T.T_STRING, sv)]), 2) == 0
+    # Decimal(20,2) carried by i128 -> KeysU128, key == value
+    dec = O.HostCol(T.T_DEC128, O.i128_array([123456789, 987654, 123456789]), None, 20, 2)
+    assert L.orc_keys_method(O.cols([dec]), 1) == 16
+    out = np.zeros(3 * 16, np.uint8)
+    assert L.orc_pack_keys(O.cols([dec]), 1, C.c_int64(3), 16, out.ctypes.data_as(C.c_void_p)) == 0
+    assert O.i128_list(out) == [123456789, 987654, 123456789]
+    # layout: (i32 nullable, u8, i16 nullable) -> sorted by width u8 | i16 | i32 | null(i16) | null(i32) = 9 bytes -> KeysU128
+    v32 = np.array([True, False, True]); v16 = np.array([False, True, True])
+    c32 = O.HostCol(T.T_I32, np.array([0x11223344, 7, -2], np.int32), v32)
+    c8 = O.HostCol(T.T_U8, np.array([0xAA, 0xBB, 0xCC], np.uint8))
+    c16 = O.HostCol(T.T_I16, np.array([0x0102, 0x0304, -1], np.int16), v16)
+    trio = [c32, c8, c16]
+    assert L.orc_keys_method(O.cols(trio), 3) == 16
+    out = np.zeros(3 * 16, np.uint8)
+    assert L.orc_pack_keys(O.cols(trio), 3, C.c_int64(3), 16, out.ctypes.data_as(C.c_void_p)) == 0
+    rows = out.reshape(3, 16)
+    assert rows[0, :9].tolist() == [0xAA, 0, 0, 0x44, 0x33, 0x22, 0x11, 1, 0]      # i16 NULL: value bytes zero, its flag set
+    assert rows[1, :9].tolist() == [0xBB, 0x04, 0x03, 0, 0, 0, 0, 0, 1]            # i32 NULL
+    assert rows[2, :9].tolist() == [0xCC, 0xFF, 0xFF, 0xFE, 0xFF, 0xFF, 0xFF, 0, 0]
+    assert not rows[:, 9:].any()
+
+
 def test_sort_perm_against_numpy_with_nulls_desc_and_limit():
     """orc_sort_perm (kernels/sort_compare.rs restatement): multi-key, asc/desc, nulls first/last, limit."""
     L = O.load()
