@@ -942,6 +942,12 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     const int64_t cn = n - *done < limit ? n - *done : limit;
     const int64_t ntiles = ceil_div(cn, tile_rows);
     int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    if (!g->fast_trusted && ntiles >= 64) {
+      // probing chunk: >= 8 tiles per workgroup, so that its spill ratio measures the key distribution and
+      // not the tile size (one tile per workgroup pre-aggregates nothing once groups ~ rows per tile)
+      const int64_t gmax = ntiles / 8;
+      if (grid > gmax) grid = (int)gmax;
+    }
     const int64_t tpb = ceil_div(ntiles, grid);
     grid = (int)ceil_div(ntiles, tpb);
     if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * lcap * L.W * 8))) return rc;
@@ -967,13 +973,15 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     g->rows_seen += cn;
     // most rows spilled: the LDS table is too small for this key distribution -> partition by hash
     // bits so that each partition fits, or (high cardinality) leave the rest to the row path
-    if ((int64_t)hc[6] * 10 > cn && cn >= 65536) {
+    // more groups than a workgroup's table takes (it would run full everywhere and hand most rows on)
+    const bool too_many = g->count_host * 8 > (int64_t)A.llimit * 7;
+    if (((int64_t)hc[6] * 10 > cn || too_many) && cn >= 65536) {
       decide_partitioning(g, g->count_host, g->rows_seen);
       if (g->part_bits < 0) g->fast_disabled = 1;
     }
     if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby lds chunk: rows=%lld partial=%llu spilled=%llu groups=%lld -> pbits=%d\n",
                                        (long long)cn, (unsigned long long)hc[5], (unsigned long long)hc[6], (long long)g->count_host, g->part_bits);
-    g->fast_trusted = (int64_t)hc[6] * 100 <= cn;
+    g->fast_trusted = !too_many && (int64_t)hc[6] * 100 <= cn;
   }
   return DBHIP_OK;
 }

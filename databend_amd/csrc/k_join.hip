@@ -28,6 +28,8 @@
 
 using namespace dbhip;
 
+#define DBHIP_TRY(x) do { int32_t _rc = (x); if (_rc) return _rc; } while (0)
+
 struct dbhip_join {
   int kw;              // key words (u64): 1 or 2
   int es;              // entry stride in u64 words: 2 or 4
@@ -194,13 +196,13 @@ int32_t ensure_probe_scratch(dbhip_join* j, int64_t n) {
   if (j->scratch_rows >= (size_t)n) return DBHIP_OK;
   if (j->cnt) {
     DBHIP_CHECK(hipDeviceSynchronize());
-    (void)hipFree(j->cnt); (void)hipFree(j->firstm); (void)hipFree(j->off); (void)hipFree(j->blk);
+    (void)dbhip_free(j->cnt); (void)dbhip_free(j->firstm); (void)dbhip_free(j->off); (void)dbhip_free(j->blk);
   }
   size_t cap = (size_t)n + (n >> 3) + 1024;
-  DBHIP_CHECK(hipMalloc((void**)&j->cnt, cap * 4));
-  DBHIP_CHECK(hipMalloc((void**)&j->firstm, cap * 4));
-  DBHIP_CHECK(hipMalloc((void**)&j->off, cap * 8));
-  DBHIP_CHECK(hipMalloc((void**)&j->blk, (cap / SCAN_TILE + 2) * 8));
+  DBHIP_TRY(dbhip_alloc(cap * 4, (void**)&j->cnt));
+  DBHIP_TRY(dbhip_alloc(cap * 4, (void**)&j->firstm));
+  DBHIP_TRY(dbhip_alloc(cap * 8, (void**)&j->off));
+  DBHIP_TRY(dbhip_alloc((cap / SCAN_TILE + 2) * 8, (void**)&j->blk));
   j->scratch_rows = cap;
   return DBHIP_OK;
 }
@@ -383,8 +385,8 @@ int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, d
   j->kw = key_bytes / 8;
   j->es = j->kw * 2;
   j->cap_rows = expected_build_rows > 1024 ? expected_build_rows : 1024;
-  DBHIP_CHECK(hipMalloc((void**)&j->ent, (size_t)j->cap_rows * j->es * 8));
-  DBHIP_CHECK(hipMalloc((void**)&j->total_dev, 8));
+  DBHIP_TRY(dbhip_alloc((size_t)j->cap_rows * j->es * 8, (void**)&j->ent));
+  DBHIP_TRY(dbhip_alloc(8, (void**)&j->total_dev));
   *out_host = j;
   return DBHIP_OK;
 }
@@ -403,10 +405,10 @@ int32_t dbhip_join_add_build(dbhip_join* j, const void* keys, const uint8_t* val
   if (j->nrows + n > j->cap_rows) {  // grow the chunk store (BasicHashJoin::add_block squashes chunks)
     int64_t nc = j->cap_rows * 2 > j->nrows + n ? j->cap_rows * 2 : j->nrows + n;
     uint64_t* ne;
-    DBHIP_CHECK(hipMalloc((void**)&ne, (size_t)nc * j->es * 8));
+    DBHIP_TRY(dbhip_alloc((size_t)nc * j->es * 8, (void**)&ne));
     DBHIP_CHECK(hipMemcpyAsync(ne, j->ent, (size_t)j->nrows * j->es * 8, hipMemcpyDeviceToDevice, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(j->ent);
+    (void)dbhip_free(j->ent);
     j->ent = ne; j->cap_rows = nc;
   }
   uint64_t* dst = j->ent + (size_t)j->nrows * j->es;
@@ -426,7 +428,7 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   while (cap < j->nrows * 2) cap <<= 1;  // hashjoin_hashtable.rs:95-108
   j->buckets = cap;
   j->shift = 64 - __builtin_ctzll((unsigned long long)cap);
-  DBHIP_CHECK(hipMalloc((void**)&j->head, (size_t)cap * 8));
+  DBHIP_TRY(dbhip_alloc((size_t)cap * 8, (void**)&j->head));
   DBHIP_CHECK(hipMemsetAsync(j->head, 0, (size_t)cap * 8, s));
   if (j->nrows) {
     if (j->kw == 1)
@@ -529,7 +531,7 @@ int32_t dbhip_join_destroy(dbhip_join* j) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev};
   for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+    if (p) (void)dbhip_free(p);
   delete j;
   return DBHIP_OK;
 }
