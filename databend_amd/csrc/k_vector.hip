@@ -20,9 +20,19 @@
 
 #include <math.h>
 
+#include <new>
 #include <vector>
 
 using namespace dbhip;
+
+struct dbhip_vec_index {
+  int metric;
+  const float* base;   // borrowed: the f32 column (re-read for exact re-scoring)
+  int64_t n;
+  int dim, dpad;
+  uint16_t* bh;        // [n][dpad] bf16
+  float* rowA; float* rowX; float* rowY;
+};
 
 namespace {
 
@@ -519,6 +529,39 @@ int32_t launch_distance(int metric, const float* base, int64_t n, int dim, const
 
 constexpr uint32_t CAND_CAP = 4096;  // candidates kept per query by the filtered pass
 
+// chunked materialising path over base rows [lo, hi): always exact
+int32_t exact_topk_range(int metric, const float* base, int64_t lo, int64_t hi, int dim, const float* queries, int nq,
+                         int k, const float* qnorm, bool have_prev, uint32_t* out_idx, float* out_dist, hipStream_t s) {
+  int64_t chunk = (int64_t)(1LL << 28) / nq;
+  chunk = chunk < 4096 ? 4096 : chunk;
+  chunk = (chunk / 256) * 256;
+  if (chunk > hi - lo) chunk = ceil_div(hi - lo > 0 ? hi - lo : 1, 256) * 256;
+  float* dist = (float*)scratch((size_t)chunk * nq * 4, 6);
+  if (!dist) return DBHIP_ERR_HIP;
+  bool first = !have_prev;
+  for (int64_t c0 = lo; c0 < hi || first; c0 += chunk) {
+    int64_t cn = hi - c0 < chunk ? hi - c0 : chunk;
+    int32_t rc = DBHIP_OK;
+    if (cn > 0) {
+      rc = launch_distance(metric, base + c0 * dim, cn, dim, queries, nq, qnorm, dist, chunk, s);
+      if (rc) return rc;
+    }
+    rc = select_topk(dist, nullptr, nullptr, chunk, cn > 0 ? cn : 0, (uint32_t)c0, nq, k, !first, out_dist, out_idx, s);
+    if (rc) return rc;
+    first = false;
+    if (hi <= lo) break;
+  }
+  return DBHIP_OK;
+}
+
+// rows of the exactly scored sample: its k-th best is an upper bound (tau) of the final k-th best
+int64_t sample_rows(int64_t n) {
+  if (n <= 65536) return n;
+  int64_t S = n / 64 > 65536 ? n / 64 : 65536;
+  S = ceil_div(S, 256) * 256;
+  return S > n ? n : S;
+}
+
 // Exact top-k of one query batch (nq queries, all on the device).
 //   1. sample   : rows [0, S) are scored into scratch and reduced to their exact top-k; the k-th
 //                 best of the sample is an upper bound (tau) of the query's final k-th best.
@@ -530,36 +573,8 @@ constexpr uint32_t CAND_CAP = 4096;  // candidates kept per query by the filtere
 int32_t topk_batch(int metric, const float* base, int64_t n, int dim, const float* queries, int nq, int k,
                    const float* qnorm, uint32_t* out_idx, float* out_dist, hipStream_t s) {
   const bool gemm = metric == DBHIP_VEC_DOT || metric == DBHIP_VEC_COSINE;
-  int64_t S = n;
-  if (gemm && n > 65536) {
-    S = n / 64 > 65536 ? n / 64 : 65536;
-    S = ceil_div(S, 256) * 256;
-    if (S > n) S = n;
-  }
-  // --- chunked materialising path over [lo, hi) ---
-  auto chunked = [&](int64_t lo, int64_t hi, bool have_prev) -> int32_t {
-    int64_t chunk = (int64_t)(1LL << 28) / nq;
-    chunk = chunk < 4096 ? 4096 : chunk;
-    chunk = (chunk / 256) * 256;
-    if (chunk > hi - lo) chunk = ceil_div(hi - lo > 0 ? hi - lo : 1, 256) * 256;
-    float* dist = (float*)scratch((size_t)chunk * nq * 4, 6);
-    if (!dist) return DBHIP_ERR_HIP;
-    bool first = !have_prev;
-    for (int64_t c0 = lo; c0 < hi || first; c0 += chunk) {
-      int64_t cn = hi - c0 < chunk ? hi - c0 : chunk;
-      int32_t rc = DBHIP_OK;
-      if (cn > 0) {
-        rc = launch_distance(metric, base + c0 * dim, cn, dim, queries, nq, qnorm, dist, chunk, s);
-        if (rc) return rc;
-      }
-      rc = select_topk(dist, nullptr, nullptr, chunk, cn > 0 ? cn : 0, (uint32_t)c0, nq, k, !first, out_dist, out_idx, s);
-      if (rc) return rc;
-      first = false;
-      if (hi <= lo) break;
-    }
-    return DBHIP_OK;
-  };
-  int32_t rc = chunked(0, S, false);
+  const int64_t S = gemm ? sample_rows(n) : n;
+  int32_t rc = exact_topk_range(metric, base, 0, S, dim, queries, nq, k, qnorm, false, out_idx, out_dist, s);
   if (rc || S >= n) return rc;
 
   uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8);
@@ -580,13 +595,358 @@ int32_t topk_batch(int metric, const float* base, int64_t n, int dim, const floa
   DBHIP_CHECK(hipStreamSynchronize(s));
   bool overflow = false;
   for (int q = 0; q < nq; ++q) overflow |= hcnt[q] > CAND_CAP;
-  if (overflow) return chunked(S, n, true);
+  if (overflow) return exact_topk_range(metric, base, S, n, dim, queries, nq, k, qnorm, true, out_idx, out_dist, s);
+  return select_topk(cand_d, cand_i, cnt, CAND_CAP, CAND_CAP, 0u, nq, k, true, out_dist, out_idx, s);
+}
+
+// ---------------------------------------------------------------------------
+// Exact ANN index: bf16 pre-filter with a rigorous error bound + exact f32 re-scoring.
+//
+// The reference answers ORDER BY distance LIMIT k through an HNSW graph over u8-quantised vectors
+// (HNSWIndex::{build, search}, hnsw_index/hnsw.rs:62-315): approximate, recall < 1. On MI355X a
+// brute-force scan on the bf16 matrix pipe (16x the f32 MFMA rate) that can only OVER-select, followed
+// by exact re-scoring of the few survivors, returns the exact top-k (recall 1.0) at a query rate the
+// pointer-chasing graph walk cannot reach.
+//   build   Bh = bf16(B) (round to nearest even), per row: ||b||, ||bh||, ||b - bh||
+//   search  q = qh + ql, b = bh + bl:  q.b = qh.bh + (ql.bh + qh.bl + ql.bl)
+//           |q.b - qh.bh| <= ||ql|| ||bh|| + ||qh|| ||bl|| + ||ql|| ||bl||      (Cauchy-Schwarz)
+//           plus the f32 accumulation slack of the matrix pipe, c = dim * 2^-23 + 2e-4 (relative to
+//           ||qh|| ||bh||). The tile kernel computes qh.bh on v_mfma_f32_32x32x16_bf16 and keeps a row iff the
+//           LOWER bound of its distance is <= tau (the exact k-th best of a sample, as above);
+//           survivors are re-scored exactly in f32 and reduced with the sample's top-k.
+// LDS rows are padded to 72 bf16 (144 B): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B
+// slots (9 * row mod 16 is a bijection), the staging ds_write_b128 of 8 lanes covers one 128-B row.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int HBK = 64;  // bf16 elements per k-tile (one 128-B line per row)
+constexpr int HLD = 72;  // padded LDS row stride in bf16 elements
+
+struct HArgs {
+  const uint16_t* base;     // [n][dpad] bf16, rows [row_origin ..) of the index
+  const uint16_t* queries;  // [nq][dpad] bf16
+  const float* rowA; const float* rowX; const float* rowY;  // [n] per-row coefficients (see vec_to_bf16_kernel)
+  const float* qn; const float* qh; const float* qe;        // [nq] ||q||, ||qh||(1+), ||q - qh||(1+)
+  const float* tau;
+  int64_t tau_stride;
+  int64_t n;
+  int dpad, nq, n_qtiles;
+  int64_t n_itiles;
+  float c;                  // accumulation + rounding slack
+  uint32_t* cand_i;         // [nq][cand_cap]
+  uint32_t* cand_cnt;
+  uint32_t cand_cap, row_origin;
+};
+
+template <bool COSINE>
+__global__ __launch_bounds__(256, 2) void bf16_filter_kernel(HArgs A) {
+  constexpr int TQ = 128, TI = 128;
+  __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
+  __shared__ float rA[TI], rX[TI], rY[TI], qA[TQ], qB[TQ], qG[TQ], Tau[TQ];
+
+  const int64_t slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int qt = (int)(slot % A.n_qtiles);
+  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
+  if (it >= A.n_itiles) return;
+  const int64_t i0 = it * TI;
+  const int q0 = qt * TQ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = (wave >> 1) * 64, wi = (wave & 1) * 64;
+  const int dpad = A.dpad;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // thread t stages rows (t >> 3) + 32 j, 16-byte piece (t & 7) of the 128-byte k-tile row segment
+  const int kc = (tid & 7) * 8;
+  const int r0 = tid >> 3;
+  const uint16_t* atile = A.queries + (int64_t)q0 * dpad;
+  const uint16_t* btile = A.base + i0 * dpad;
+  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
+  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
+  uint32_t aoff[4], boff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    aoff[j] = (uint32_t)(r0 + 32 * j < alast ? r0 + 32 * j : alast) * (uint32_t)dpad + kc;
+    boff[j] = (uint32_t)(r0 + 32 * j < blast ? r0 + 32 * j : blast) * (uint32_t)dpad + kc;
+  }
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *(const u32x4*)(atile + aoff[j] + k0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = *(const u32x4*)(btile + boff[j] + k0);
+  };
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(u32x4*)(As + (r0 + 32 * j) * HLD + kc) = ra[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(u32x4*)(Bs + (r0 + 32 * j) * HLD + kc) = rb[j];
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < dpad; k0 += HBK) {
+    __syncthreads();
+    lds_store();
+    __syncthreads();
+    if (k0 + HBK < dpad) gload(k0 + HBK);
+#pragma unroll
+    for (int kk = 0; kk < HBK; kk += 16) {
+      const int kl = kk + (lane >> 5) * 8;
+      const u32x4 a0 = *(const u32x4*)(As + (wq + (lane & 31)) * HLD + kl);
+      const u32x4 a1 = *(const u32x4*)(As + (wq + 32 + (lane & 31)) * HLD + kl);
+      const u32x4 b0 = *(const u32x4*)(Bs + (wi + (lane & 31)) * HLD + kl);
+      const u32x4 b1 = *(const u32x4*)(Bs + (wi + 32 + (lane & 31)) * HLD + kl);
+      const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0), fa1 = __builtin_bit_cast(bf16x8, a1);
+      const bf16x8 fb0 = __builtin_bit_cast(bf16x8, b0), fb1 = __builtin_bit_cast(bf16x8, b1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  if (tid < TI) {
+    const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
+    rA[tid] = A.rowA[i]; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
+  } else {
+    const int t = tid - TI;
+    const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
+    const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
+    if (COSINE) {
+      const float al = 1.0f / n_, be = e_ * al, ga = h_ * al;
+      qA[t] = al; qB[t] = be + A.c * ga; qG[t] = ga + be;
+    } else {
+      qA[t] = 1.0f; qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
+    }
+    Tau[t] = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int il = wi + y * 32 + (lane & 31);
+      const int64_t i = i0 + il;
+      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int q = q0 + ql;
+        const float v = acc[x][y][r];
+        const float slack = fmaf(x_, qB[ql], y_ * qG[ql]);
+        // lower bound of the exact distance
+        const float lb = COSINE ? 1.0f - fmaf(v * qA[ql], a_, slack) : v - slack;
+        if (q < A.nq && i < A.n && !(lb > Tau[ql])) {  // NaN bounds stay in the race
+          const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
+          if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
+        }
+      }
+    }
+}
+
+// One wave per row: out[row][0..dpad) = bf16(x[row]) (RNE, zero padded) and the row's coefficients.
+//   mode 0 (base rows, cosine): A = 1/||b||, X = ||bh||/||b|| (1+1e-4), Y = ||b-bh||/||b|| (1+1e-4)
+//   mode 1 (base rows, dot)   : A = 1,       X = ||bh|| (1+1e-4),       Y = ||b-bh|| (1+1e-4)
+//   mode 2 (queries)          : A = ||q||,   X = ||qh|| (1+1e-4),       Y = ||q-qh|| (1+1e-4)
+__global__ __launch_bounds__(256) void vec_to_bf16_kernel(const float* __restrict__ x, int64_t n, int dim, int dpad,
+                                                          int mode, uint16_t* __restrict__ out, float* __restrict__ oA,
+                                                          float* __restrict__ oX, float* __restrict__ oY) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const float* p = x + r * dim;
+    uint16_t* o = out + r * dpad;
+    float s = 0.f, sh = 0.f, se = 0.f;
+    for (int k = lane_id(); k < dpad; k += 64) {
+      uint16_t hb = 0;
+      if (k < dim) {
+        const float v = p[k];
+        uint32_t b = __float_as_uint(v);
+        if (v != v) b |= 0x00400000u;                              // quiet NaN survives the truncation
+        else b += 0x7FFFu + ((b >> 16) & 1u);                      // round to nearest even
+        hb = (uint16_t)(b >> 16);
+        const float h = __uint_as_float((uint32_t)hb << 16);
+        const float d = v - h;
+        s = fmaf(v, v, s); sh = fmaf(h, h, sh); se = fmaf(d, d, se);
+      }
+      o[k] = hb;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off, 64); sh += __shfl_xor(sh, off, 64); se += __shfl_xor(se, off, 64);
+    }
+    if (lane_id() == 0) {
+      const float nb = sqrtf(s), nh = sqrtf(sh) * 1.0001f, ne = sqrtf(se) * 1.0001f;
+      if (mode == 0) { oA[r] = 1.0f / nb; oX[r] = nh / nb; oY[r] = ne / nb; }
+      else if (mode == 1) { oA[r] = 1.0f; oX[r] = nh; oY[r] = ne; }
+      else { oA[r] = nb; oX[r] = nh; oY[r] = ne; }
+    }
+  }
+}
+
+// exact f32 distance of every surviving (query, row) pair: one wave per pair
+__global__ __launch_bounds__(256) void rescore_kernel(int cosine, const float* __restrict__ base, int dim,
+                                                      const float* __restrict__ queries, const float* __restrict__ qnorm,
+                                                      const uint32_t* __restrict__ cand_i, const uint32_t* __restrict__ cand_cnt,
+                                                      uint32_t cap, float* __restrict__ cand_d) {
+  const int q = blockIdx.y;
+  const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t cnt = cand_cnt[q] < cap ? cand_cnt[q] : cap;
+  if (j >= cnt) return;
+  const uint32_t i = cand_i[(int64_t)q * cap + j];
+  const float* b = base + (int64_t)i * dim;
+  const float* qv = queries + (int64_t)q * dim;
+  float dot = 0.f, bsq = 0.f;
+  for (int k = lane_id(); k < dim; k += 64) {
+    const float bv = b[k];
+    dot = fmaf(qv[k], bv, dot);
+    bsq = fmaf(bv, bv, bsq);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { dot += __shfl_xor(dot, off, 64); bsq += __shfl_xor(bsq, off, 64); }
+  if (lane_id() == 0) cand_d[(int64_t)q * cap + j] = cosine ? 1.0f - dot / (qnorm[q] * sqrtf(bsq)) : dot;
+}
+
+
+// one query batch through the index (see the block comment above bf16_filter_kernel)
+int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, int k, const float* qnorm,
+                           uint32_t* out_idx, float* out_dist, hipStream_t s) {
+  const int64_t n = ix->n;
+  const int dim = ix->dim, dpad = ix->dpad;
+  const bool cosine = ix->metric == DBHIP_VEC_COSINE;
+  const int64_t S = sample_rows(n);
+  int32_t rc = exact_topk_range(ix->metric, ix->base, 0, S, dim, queries, nq, k, qnorm, false, out_idx, out_dist, s);
+  if (rc || S >= n) return rc;
+
+  // query side: bf16 image + norms
+  const size_t qh_bytes = (((size_t)nq * dpad * 2) + 255) & ~(size_t)255;
+  uint8_t* qws = (uint8_t*)scratch(qh_bytes + (size_t)nq * 12 + 256, 11);
+  if (!qws) return DBHIP_ERR_HIP;
+  uint16_t* qh = (uint16_t*)qws;
+  float* qA = (float*)(qws + qh_bytes);
+  float* qX = qA + nq;
+  float* qY = qX + nq;
+  hipLaunchKernelGGL(vec_to_bf16_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim,
+                     dpad, 2, qh, qA, qX, qY);
+
+  uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8);
+  if (!ws) return DBHIP_ERR_HIP;
+  uint32_t* cnt = (uint32_t*)ws;
+  float* cand_d = (float*)(ws + (((size_t)nq * 4 + 63) & ~(size_t)63));
+  uint32_t* cand_i = (uint32_t*)(cand_d + (size_t)nq * CAND_CAP);
+  DBHIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nq * 4, s));
+
+  HArgs A{};
+  A.base = ix->bh + S * dpad; A.queries = qh;
+  A.rowA = ix->rowA + S; A.rowX = ix->rowX + S; A.rowY = ix->rowY + S;
+  A.qn = qA; A.qh = qX; A.qe = qY;
+  A.tau = out_dist + (k - 1); A.tau_stride = k;
+  A.n = n - S; A.dpad = dpad; A.nq = nq;
+  A.n_qtiles = (int)ceil_div(nq, 128);
+  A.n_itiles = ceil_div(A.n, 128);
+  A.c = (float)dim * 1.1920929e-07f + 2e-4f;
+  A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)S;
+  const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
+  if (cosine) hipLaunchKernelGGL(bf16_filter_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+  else hipLaunchKernelGGL(bf16_filter_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+  DBHIP_LAUNCH_CHECK();
+  static thread_local std::vector<uint32_t> hcnt;
+  hcnt.resize(nq);
+  DBHIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  uint32_t maxc = 0;
+  for (int q = 0; q < nq; ++q) maxc = hcnt[q] > maxc ? hcnt[q] : maxc;
+  if (maxc > CAND_CAP)  // the bound could not separate enough rows: the exact scan is always right
+    return exact_topk_range(ix->metric, ix->base, S, n, dim, queries, nq, k, qnorm, true, out_idx, out_dist, s);
+  if (maxc > 0) {
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)ceil_div(maxc, 4), (unsigned)nq), dim3(256), 0, s, cosine ? 1 : 0, ix->base,
+                       dim, queries, qnorm, cand_i, cnt, CAND_CAP, cand_d);
+    DBHIP_LAUNCH_CHECK();
+  }
   return select_topk(cand_d, cand_i, cnt, CAND_CAP, CAND_CAP, 0u, nq, k, true, out_dist, out_idx, s);
 }
 
 }  // namespace
 
 extern "C" {
+
+int32_t dbhip_vec_index_build(int32_t metric, const float* base, int64_t n, int32_t dim, dbhip_vec_index** out_host,
+                              void* stream) {
+  DBHIP_REQUIRE(out_host, "dbhip_vec_index_build: NULL out");
+  if (metric != DBHIP_VEC_COSINE && metric != DBHIP_VEC_DOT) {
+    set_error("dbhip_vec_index_build: metric %d has no bf16 pre-filter (use dbhip_vec_topk)", metric);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  DBHIP_REQUIRE(dim > 0 && n >= 0 && n < 0xFFFFFFFFLL && (base || n == 0), "dbhip_vec_index_build: bad shape");
+  dbhip_vec_index* ix = new (std::nothrow) dbhip_vec_index();
+  DBHIP_REQUIRE(ix, "dbhip_vec_index_build: out of host memory");
+  ix->metric = metric; ix->base = base; ix->n = n; ix->dim = dim;
+  ix->dpad = (int)ceil_div(dim, HBK) * HBK;
+  ix->bh = nullptr; ix->rowA = ix->rowX = ix->rowY = nullptr;
+  const int64_t rows = n > 0 ? n : 1;
+  int32_t rc;
+  if ((rc = dbhip_alloc((size_t)rows * ix->dpad * 2, (void**)&ix->bh)) || (rc = dbhip_alloc((size_t)rows * 4, (void**)&ix->rowA)) ||
+      (rc = dbhip_alloc((size_t)rows * 4, (void**)&ix->rowX)) || (rc = dbhip_alloc((size_t)rows * 4, (void**)&ix->rowY))) {
+    dbhip_vec_index_destroy(ix);
+    return rc;
+  }
+  if (n > 0) {
+    hipStream_t s = resolve_stream(stream);
+    hipLaunchKernelGGL(vec_to_bf16_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, s, base, n, dim, ix->dpad,
+                       metric == DBHIP_VEC_COSINE ? 0 : 1, ix->bh, ix->rowA, ix->rowX, ix->rowY);
+    DBHIP_LAUNCH_CHECK();
+  }
+  *out_host = ix;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_vec_index_search(dbhip_vec_index* ix, const float* queries, int32_t nq, int32_t k, uint32_t* out_idx,
+                               float* out_dist, void* stream) {
+  DBHIP_REQUIRE(ix && nq >= 0 && k >= 1, "dbhip_vec_index_search: bad argument");
+  if (k > KMAX) {
+    set_error("dbhip_vec_index_search: k=%d > %d", k, KMAX);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (nq == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(queries && out_idx && out_dist, "dbhip_vec_index_search: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  float* qnorm = nullptr;
+  if (ix->metric == DBHIP_VEC_COSINE) {
+    qnorm = (float*)scratch((size_t)(nq + 1) * 4, 5);
+    if (!qnorm) return DBHIP_ERR_HIP;
+    hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, ix->dim, qnorm);
+  }
+  const int QB = 2048;
+  kernel_timer_start(s);
+  for (int qb = 0; qb < nq; qb += QB) {
+    const int bn = nq - qb < QB ? nq - qb : QB;
+    int32_t rc = index_search_batch(ix, queries + (int64_t)qb * ix->dim, bn, k, qnorm ? qnorm + qb : nullptr,
+                                    out_idx + (int64_t)qb * k, out_dist + (int64_t)qb * k, s);
+    if (rc) return rc;
+  }
+  kernel_timer_stop(s);
+  return DBHIP_OK;
+}
+
+int32_t dbhip_vec_index_destroy(dbhip_vec_index* ix) {
+  if (!ix) return DBHIP_OK;
+  (void)hipDeviceSynchronize();
+  if (ix->bh) (void)dbhip_free(ix->bh);
+  if (ix->rowA) (void)dbhip_free(ix->rowA);
+  if (ix->rowX) (void)dbhip_free(ix->rowX);
+  if (ix->rowY) (void)dbhip_free(ix->rowY);
+  delete ix;
+  return DBHIP_OK;
+}
 
 int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t dim, const float* queries,
                            int32_t nq, float* out, void* stream) {

@@ -659,6 +659,33 @@ def vec_topk(metric, base, queries, k):
     return oi.to_numpy(np.uint32, queries.n * k).reshape(queries.n, k), od.to_numpy(np.float32, queries.n * k).reshape(queries.n, k)
 
 
+class VectorIndex:
+    """Exact device vector index (dbhip_vec_index_*; stands where HNSWIndex::{build, search} stands in the reference,
+    hnsw_index/hnsw.rs:62-315): bf16 MFMA pre-filter with an error bound + exact f32 re-scoring."""
+
+    def __init__(self, metric, base):
+        _ensure()
+        self.base = base  # keeps the borrowed f32 column alive
+        self.h = C.c_void_p()
+        check(lib().dbhip_vec_index_build(metric, C.c_void_p(base.data.ptr), C.c_int64(base.n), base.dim, C.byref(self.h), None))
+
+    def search(self, queries, k):
+        oi, od = DeviceBuffer(max(queries.n * k, 1) * 4), DeviceBuffer(max(queries.n * k, 1) * 4)
+        check(lib().dbhip_vec_index_search(self.h, C.c_void_p(queries.data.ptr), queries.n, k, C.c_void_p(oi.ptr), C.c_void_p(od.ptr), None))
+        return oi.to_numpy(np.uint32, queries.n * k).reshape(queries.n, k), od.to_numpy(np.float32, queries.n * k).reshape(queries.n, k)
+
+    def destroy(self):
+        if self.h:
+            lib().dbhip_vec_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def score_u8(is_l1, query, base):
     query = np.ascontiguousarray(query, dtype=np.uint8)
     base = np.ascontiguousarray(base, dtype=np.uint8)

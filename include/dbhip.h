@@ -352,6 +352,19 @@ int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t
 int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim,
                        const float* queries, int32_t nq, int32_t k,
                        uint32_t* out_idx, float* out_dist, void* stream);
+/* Vector index. Replaces HNSWIndex::{build, search} (src/query/storages/common/index/src/hnsw_index/
+ * hnsw.rs:62-315: HNSW graph over u8-quantised vectors, ef = 4k, approximate) at the same call sites
+ * (one index per block of vectors, searched with a query batch and k). The device index is EXACT
+ * (recall 1.0): a bf16 image of the column is scanned on v_mfma_f32_32x32x16_bf16 with a rigorous
+ * error bound, so that rows are only ever over-selected, and the survivors are re-scored in f32 from
+ * the original column — which is borrowed and must stay valid while the index lives.
+ * Metrics: COSINE, DOT (others: DBHIP_ERR_UNSUPPORTED, use dbhip_vec_topk). Results as dbhip_vec_topk. */
+typedef struct dbhip_vec_index dbhip_vec_index;
+int32_t dbhip_vec_index_build(int32_t metric, const float* base, int64_t n, int32_t dim,
+                              dbhip_vec_index** out_host, void* stream);
+int32_t dbhip_vec_index_search(dbhip_vec_index* ix, const float* queries, int32_t nq, int32_t k,
+                               uint32_t* out_idx, float* out_dist, void* stream);
+int32_t dbhip_vec_index_destroy(dbhip_vec_index* ix);
 /* u8-quantised scoring (cpp/avx2.c:45,87 impl_score_dot_avx / impl_score_l1_avx). */
 int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base, int64_t n,
                        int32_t dim, float* out, void* stream);

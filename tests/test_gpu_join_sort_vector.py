@@ -275,6 +275,57 @@ def test_vec_topk_matches_exact_oracle_topk(gpu, oracle, n, dim, nq, k):
         assert hits >= 0.99 * nq * min(k, n)
 
 
+@pytest.mark.parametrize("n,dim,nq,k,kind", [(5, 16, 2, 10, "normal"), (3000, 64, 33, 10, "normal"), (150_000, 64, 70, 10, "normal"),
+                                             (131_072, 100, 5, 16, "normal"), (200_000, 48, 300, 3, "clustered"), (140_000, 36, 9, 10, "special")])
+def test_vec_index_is_exact(gpu, oracle, n, dim, nq, k, kind):
+    """dbhip_vec_index_search (bf16 pre-filter + exact re-score) returns the exact top-k: the same row ids as the
+    exact f32 scan dbhip_vec_topk and distances within 1e-5 relative of the oracle's f32 distances (north_star
+    tolerance). 'clustered': many near-duplicate rows (large candidate sets, candidate-list overflow fallback);
+    'special': zero vectors, huge/tiny magnitudes, NaN and Inf rows."""
+    rng = np.random.default_rng(n + dim)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if kind == "clustered":
+        centers = rng.standard_normal((8, dim)).astype(np.float32)
+        base = (centers[rng.integers(0, 8, n)] + 1e-3 * rng.standard_normal((n, dim))).astype(np.float32)
+        q[: nq // 2] = centers[rng.integers(0, 8, nq // 2)] + 1e-3 * rng.standard_normal((nq // 2, dim)).astype(np.float32)
+    if kind == "special":
+        base[7] = 0.0
+        base[70_000] = 0.0
+        base[11] *= 1e18
+        base[100_001] *= 1e-18
+        base[13, 3] = np.nan
+        base[90_000, 5] = np.inf
+        q[0] = 0.0
+        q[1] *= 1e15
+    gb, gq = gpu.VectorColumn(base), gpu.VectorColumn(q)
+    for metric in (T.VEC_COSINE, T.VEC_DOT):
+        ix = gpu.VectorIndex(metric, gb)
+        idx, dist = ix.search(gq, k)
+        eidx, edist = gpu.vec_topk(metric, gb, gq, k)
+        kk = min(k, n)
+        exp = np.zeros((nq, n), np.float32)
+        oracle.orc_vec_distance(metric, base.ctypes.data_as(C.c_void_p), C.c_int64(n), dim, q.ctypes.data_as(C.c_void_p), nq, exp.ctypes.data_as(C.c_void_p))
+        mism = 0
+        for qi in range(nq):
+            if not np.array_equal(idx[qi, :kk], eidx[qi, :kk]):
+                # the two exact paths sum in different orders: rows may swap only where their distances tie to rounding
+                a, b = np.nan_to_num(edist[qi, :kk], nan=np.inf, posinf=3e38), np.nan_to_num(dist[qi, :kk], nan=np.inf, posinf=3e38)
+                assert np.allclose(a, b, rtol=2e-5, atol=2e-6), (metric, qi)
+                mism += 1
+            for j in range(kk):
+                r = int(idx[qi, j])
+                ev, gv = float(exp[qi, r]), float(dist[qi, j])
+                if np.isfinite(ev) and abs(ev) < 1e30:
+                    sc = float(np.abs(base[r].astype(np.float64) * q[qi]).sum()) if metric == T.VEC_DOT else 1.0
+                    assert abs(gv - ev) <= 1e-5 * max(1.0, abs(ev), sc) + 2e-7, (metric, qi, j, gv, ev)
+            assert (idx[qi, kk:] == 0xFFFFFFFF).all()
+        assert mism <= max(1, nq // 4 if kind == "clustered" else nq // 50), (metric, mism)
+        ix.destroy()
+    with pytest.raises(Exception):
+        gpu.VectorIndex(T.VEC_L2, gb)
+
+
 def test_score_u8_matches_reference_c_kernels(gpu, oracle):
     """dot / l1 over u8-quantised vectors: exact integers; checked against the oracle restatement and, when
     oracle/_ref/libref_u8.so was built from the reference's own cpp/avx2.c, against the real thing."""
