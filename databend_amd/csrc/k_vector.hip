@@ -817,15 +817,17 @@ __global__ __launch_bounds__(256) void rescore_kernel(int cosine, const float* _
 }
 
 
-// one query batch through the index (see the block comment above bf16_filter_kernel)
+// one query batch through the index (see the block comment above bf16_filter_kernel). Three levels, each
+// tightening tau for the next: exact f32 scan of the first S0 = 8192 rows; bf16 filter + exact re-score of
+// [S0, S1) (S1 = sample_rows(n)); bf16 filter + exact re-score of [S1, n). Only S0 rows ever run at the f32 rate.
 int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, int k, const float* qnorm,
                            uint32_t* out_idx, float* out_dist, hipStream_t s) {
   const int64_t n = ix->n;
   const int dim = ix->dim, dpad = ix->dpad;
   const bool cosine = ix->metric == DBHIP_VEC_COSINE;
-  const int64_t S = sample_rows(n);
-  int32_t rc = exact_topk_range(ix->metric, ix->base, 0, S, dim, queries, nq, k, qnorm, false, out_idx, out_dist, s);
-  if (rc || S >= n) return rc;
+  const int64_t S0 = n < 8192 ? n : 8192;
+  int32_t rc = exact_topk_range(ix->metric, ix->base, 0, S0, dim, queries, nq, k, qnorm, false, out_idx, out_dist, s);
+  if (rc || S0 >= n) return rc;
 
   // query side: bf16 image + norms
   const size_t qh_bytes = (((size_t)nq * dpad * 2) + 255) & ~(size_t)255;
@@ -843,36 +845,44 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   uint32_t* cnt = (uint32_t*)ws;
   float* cand_d = (float*)(ws + (((size_t)nq * 4 + 63) & ~(size_t)63));
   uint32_t* cand_i = (uint32_t*)(cand_d + (size_t)nq * CAND_CAP);
-  DBHIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nq * 4, s));
-
-  HArgs A{};
-  A.base = ix->bh + S * dpad; A.queries = qh;
-  A.rowA = ix->rowA + S; A.rowX = ix->rowX + S; A.rowY = ix->rowY + S;
-  A.qn = qA; A.qh = qX; A.qe = qY;
-  A.tau = out_dist + (k - 1); A.tau_stride = k;
-  A.n = n - S; A.dpad = dpad; A.nq = nq;
-  A.n_qtiles = (int)ceil_div(nq, 128);
-  A.n_itiles = ceil_div(A.n, 128);
-  A.c = (float)dim * 1.1920929e-07f + 2e-4f;
-  A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)S;
-  const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
-  if (cosine) hipLaunchKernelGGL(bf16_filter_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A);
-  else hipLaunchKernelGGL(bf16_filter_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A);
-  DBHIP_LAUNCH_CHECK();
   static thread_local std::vector<uint32_t> hcnt;
   hcnt.resize(nq);
-  DBHIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
-  uint32_t maxc = 0;
-  for (int q = 0; q < nq; ++q) maxc = hcnt[q] > maxc ? hcnt[q] : maxc;
-  if (maxc > CAND_CAP)  // the bound could not separate enough rows: the exact scan is always right
-    return exact_topk_range(ix->metric, ix->base, S, n, dim, queries, nq, k, qnorm, true, out_idx, out_dist, s);
-  if (maxc > 0) {
+
+  auto filter_range = [&](int64_t lo, int64_t hi) -> int32_t {
+    DBHIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nq * 4, s));
+    HArgs A{};
+    A.base = ix->bh + lo * dpad; A.queries = qh;
+    A.rowA = ix->rowA + lo; A.rowX = ix->rowX + lo; A.rowY = ix->rowY + lo;
+    A.qn = qA; A.qh = qX; A.qe = qY;
+    A.tau = out_dist + (k - 1); A.tau_stride = k;
+    A.n = hi - lo; A.dpad = dpad; A.nq = nq;
+    A.n_qtiles = (int)ceil_div(nq, 128);
+    A.n_itiles = ceil_div(A.n, 128);
+    A.c = (float)dim * 1.1920929e-07f + 2e-4f;
+    A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
+    const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
+    if (cosine) hipLaunchKernelGGL(bf16_filter_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(bf16_filter_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+    DBHIP_LAUNCH_CHECK();
+    DBHIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    uint32_t maxc = 0;
+    for (int q = 0; q < nq; ++q) maxc = hcnt[q] > maxc ? hcnt[q] : maxc;
+    if (maxc > CAND_CAP)  // the bound could not separate enough rows: the exact scan is always right
+      return exact_topk_range(ix->metric, ix->base, lo, hi, dim, queries, nq, k, qnorm, true, out_idx, out_dist, s);
+    if (maxc == 0) return DBHIP_OK;
     hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)ceil_div(maxc, 4), (unsigned)nq), dim3(256), 0, s, cosine ? 1 : 0, ix->base,
                        dim, queries, qnorm, cand_i, cnt, CAND_CAP, cand_d);
     DBHIP_LAUNCH_CHECK();
+    return select_topk(cand_d, cand_i, cnt, CAND_CAP, CAND_CAP, 0u, nq, k, true, out_dist, out_idx, s);
+  };
+
+  const int64_t S1 = sample_rows(n);
+  if (S1 > S0 && S1 < n) {
+    if ((rc = filter_range(S0, S1))) return rc;
+    return filter_range(S1, n);
   }
-  return select_topk(cand_d, cand_i, cnt, CAND_CAP, CAND_CAP, 0u, nq, k, true, out_dist, out_idx, s);
+  return filter_range(S0, n);
 }
 
 }  // namespace
@@ -996,6 +1006,18 @@ int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim
   }
   kernel_timer_stop(s);
   return DBHIP_OK;
+}
+
+int32_t dbhip_vec_topk_merge(const float* dists, const uint32_t* ids, int64_t m, int32_t nq, int32_t k,
+                             uint32_t* out_idx, float* out_dist, void* stream) {
+  DBHIP_REQUIRE(nq >= 0 && m >= 0 && k >= 1, "dbhip_vec_topk_merge: bad shape");
+  if (k > KMAX) {
+    set_error("dbhip_vec_topk_merge: k=%d > %d", k, KMAX);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (nq == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(dists && ids && out_idx && out_dist, "dbhip_vec_topk_merge: NULL argument");
+  return select_topk(dists, ids, nullptr, m, m, 0u, nq, k, false, out_dist, out_idx, resolve_stream(stream));
 }
 
 int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base, int64_t n, int32_t dim,

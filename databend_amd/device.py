@@ -659,6 +659,17 @@ def vec_topk(metric, base, queries, k):
     return oi.to_numpy(np.uint32, queries.n * k).reshape(queries.n, k), od.to_numpy(np.float32, queries.n * k).reshape(queries.n, k)
 
 
+def vec_topk_merge(dists, ids, k):
+    """k best of every row of candidate lists [nq, m] (dbhip_vec_topk_merge) -> (idx [nq, k], dist [nq, k])."""
+    dists = np.ascontiguousarray(dists, dtype=np.float32)
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    nq, m = dists.shape
+    d, i = DeviceBuffer.from_numpy(dists.reshape(-1)), DeviceBuffer.from_numpy(ids.reshape(-1))
+    oi, od = DeviceBuffer(max(nq * k, 1) * 4), DeviceBuffer(max(nq * k, 1) * 4)
+    check(lib().dbhip_vec_topk_merge(C.c_void_p(d.ptr), C.c_void_p(i.ptr), C.c_int64(m), nq, k, C.c_void_p(oi.ptr), C.c_void_p(od.ptr), None))
+    return oi.to_numpy(np.uint32, nq * k).reshape(nq, k), od.to_numpy(np.float32, nq * k).reshape(nq, k)
+
+
 class VectorIndex:
     """Exact device vector index (dbhip_vec_index_*; stands where HNSWIndex::{build, search} stands in the reference,
     hnsw_index/hnsw.rs:62-315): bf16 MFMA pre-filter with an error bound + exact f32 re-scoring."""

@@ -72,3 +72,21 @@ def exchange_partials(table, dist, torch, device, mode="allgather", hash_word=No
 
 def exchange_partials_nccl(table, dist, torch):
     return exchange_partials(table, dist, torch, torch.device("cuda", torch.cuda.current_device()))
+
+
+def merge_shard_topk(idx, dst, row_offset, k, dist, torch, device, merge_fn):
+    """ANN over a row-range sharded base: queries are replicated, every rank searched its shard and
+    holds `idx` (u32 local row ids, 0xFFFFFFFF = empty) / `dst` (f32) of shape [nq, k]. One all-gather of the
+    (k ids + k distances) per query over RCCL, then the k-way merge `merge_fn(dists [nq, world*k], ids) ->
+    (idx, dist)` (the device select kernel, dbhip_vec_topk_merge). Returns global row ids."""
+    world = dist.get_world_size()
+    gid = np.where(idx == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), (idx.astype(np.int64) + row_offset).astype(np.uint32))
+    ti = torch.from_numpy(gid.view(np.int32)).to(device)
+    td = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.float32)).to(device)
+    gi = [torch.empty_like(ti) for _ in range(world)]
+    gd = [torch.empty_like(td) for _ in range(world)]
+    dist.all_gather(gi, ti)
+    dist.all_gather(gd, td)
+    all_i = torch.cat(gi, dim=1).cpu().numpy().view(np.uint32)
+    all_d = torch.cat(gd, dim=1).cpu().numpy()
+    return merge_fn(all_d, all_i, k)

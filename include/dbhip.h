@@ -352,6 +352,11 @@ int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t
 int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim,
                        const float* queries, int32_t nq, int32_t k,
                        uint32_t* out_idx, float* out_dist, void* stream);
+/* Merge of per-shard top-k lists (the final step of a row-range sharded search): every
+ * query row of `dists`/`ids` holds m candidates (id 0xFFFFFFFF = empty slot); writes the k best,
+ * ascending distance, ties by lower id, NaN last. */
+int32_t dbhip_vec_topk_merge(const float* dists, const uint32_t* ids, int64_t m, int32_t nq, int32_t k,
+                             uint32_t* out_idx, float* out_dist, void* stream);
 /* Vector index. Replaces HNSWIndex::{build, search} (src/query/storages/common/index/src/hnsw_index/
  * hnsw.rs:62-315: HNSW graph over u8-quantised vectors, ef = 4k, approximate) at the same call sites
  * (one index per block of vectors, searched with a query batch and k). The device index is EXACT
