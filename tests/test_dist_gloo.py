@@ -135,3 +135,64 @@ def test_route_rows_by_hash_is_a_partition():
             assert np.all(p[:, 1] % np.uint64(world) == r)
     empty = DX.route_rows_by_hash(np.zeros((0, W), dtype=np.uint64), HASH_WORD, 2)
     assert [p.shape for p in empty] == [(0, W), (0, W)]
+
+
+def numpy_topk_merge(dists, ids, k):
+    """stand-in for dbhip_vec_topk_merge on CPU: ascending distance, NaN last, ties by lower id, 0xFFFFFFFF = empty"""
+    out_i = np.full((dists.shape[0], k), 0xFFFFFFFF, np.uint32)
+    out_d = np.full((dists.shape[0], k), np.inf, np.float32)
+    for q in range(dists.shape[0]):
+        cand = [(np.inf if np.isnan(d) else float(d), int(i)) for d, i in zip(dists[q], ids[q]) if i != 0xFFFFFFFF]
+        cand.sort()
+        for j, (d, i) in enumerate(cand[:k]):
+            out_i[q, j], out_d[q, j] = i, d
+    return out_i, out_d
+
+
+def ann_worker(rank, world, port, n, dim, nq, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.Generator(np.random.PCG64(21))
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        d = 1.0 - (qs @ base[lo:hi].T) / (np.linalg.norm(qs, axis=1)[:, None] * np.linalg.norm(base[lo:hi], axis=1)[None, :])
+        kk = min(k, hi - lo)
+        order = np.argsort(d, axis=1, kind="stable")[:, :kk]
+        idx = np.full((nq, k), 0xFFFFFFFF, np.uint32)
+        dst = np.full((nq, k), np.inf, np.float32)
+        idx[:, :kk] = order
+        dst[:, :kk] = np.take_along_axis(d, order, axis=1)
+        gi, gd = DX.merge_shard_topk(idx, dst, lo, k, dist, torch, torch.device("cpu"), numpy_topk_merge)
+        q.put((rank, gi.tolist(), gd.tolist()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(500, 10), (7, 5)])
+def test_sharded_ann_topk_merge_equals_the_unsharded_topk(n, k):
+    """Row-range sharded ANN: all-gather of per-shard top-k + merge == top-k of the whole base,
+    with global row ids; a shard with fewer than k rows contributes empty slots."""
+    world, dim, nq = 2, 16, 9
+    ctx = mp.get_context("spawn")
+    qq = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=ann_worker, args=(r, world, port, n, dim, nq, k, qq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (i, d) for r, i, d in (qq.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.Generator(np.random.PCG64(21))
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    d = 1.0 - (qs @ base.T) / (np.linalg.norm(qs, axis=1)[:, None] * np.linalg.norm(base, axis=1)[None, :])
+    exp = np.argsort(d, axis=1, kind="stable")[:, :min(k, n)]
+    for r in range(world):
+        gi = np.array(got[r][0], np.uint32)
+        assert np.array_equal(gi[:, :min(k, n)], exp.astype(np.uint32))
+        assert (gi[:, min(k, n):] == 0xFFFFFFFF).all()
