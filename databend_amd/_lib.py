@@ -51,13 +51,13 @@ SYMBOLS = [
     "dbhip_event_destroy", "dbhip_last_kernel_ms", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",
     "dbhip_sum", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_cmp", "dbhip_bitmap_binary",
     "dbhip_bitmap_count", "dbhip_filter_select", "dbhip_take", "dbhip_take_bitmap", "dbhip_group_hash",
-    "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized",
+    "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized", "dbhip_groupby_merge_state_block",
     "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized",
     "dbhip_groupby_result_type", "dbhip_groupby_flush_result", "dbhip_groupby_reset",
     "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_keys_method", "dbhip_pack_keys",
     "dbhip_join_create", "dbhip_join_create_keys", "dbhip_join_probe_mark",
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
-    "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
+    "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
     "dbhip_vec_topk_merge", "dbhip_vec_index_build", "dbhip_vec_index_search", "dbhip_vec_index_destroy",
 ]
 

@@ -1461,6 +1461,46 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
   return DBHIP_OK;
 }
 
+// Deserializing side of the reference's state exchange (TransformDeserializer -> batch_merge,
+// aggregator/serde/transform_deserializer.rs, aggregate_sum.rs:170-181,300-312, aggregate_count.rs batch_merge):
+// a block of [state columns..., group columns...] as Payload::aggregate_flush produces it
+// (payload_flush.rs:151-181) is merged into the table. For sum the state column IS the running value (its
+// result type), for count it is the u64 count — merging adds them; i.e. add_block where every COUNT
+// aggregate behaves as SUM over its u64 state column.
+int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
+                                        int64_t n, void* stream) {
+  DBHIP_REQUIRE(g && keys && (states || g->L.naggs == 0), "dbhip_groupby_merge_state_block: NULL argument");
+  const GbLayout saved = g->L;
+  dbhip_col st[GB_MAX_AGGS];
+  for (int a = 0; a < saved.naggs; ++a) {
+    st[a] = states[a];
+    if (saved.agg_kind[a] == DBHIP_AGG_MIN || saved.agg_kind[a] == DBHIP_AGG_MAX) {
+      set_error("dbhip_groupby_merge_state_block: min/max states are exchanged as serialized rows (dbhip_groupby_merge_serialized)");
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    DBHIP_REQUIRE(states[a].data, "dbhip_groupby_merge_state_block: missing state column");
+    int32_t want;
+    uint8_t p, sc;
+    dbhip_agg_desc d = {saved.agg_kind[a], saved.agg_type[a], (uint8_t)saved.agg_precision[a], (uint8_t)saved.agg_scale[a],
+                        (uint8_t)saved.agg_nullable[a], 0};
+    int32_t rc = dbhip_groupby_result_type(&d, &want, &p, &sc);
+    if (rc) return rc;
+    if (states[a].type != want) {
+      set_error("dbhip_groupby_merge_state_block: state column %d has type %d, the aggregate's state type is %d", a, states[a].type, want);
+      return DBHIP_ERR_INVALID;
+    }
+    // the state column is summed in its own (result) type
+    g->L.agg_kind[a] = DBHIP_AGG_SUM;
+    g->L.agg_type[a] = want;
+    g->L.agg_nullable[a] = 0;
+  }
+  int32_t rc = dbhip_groupby_add_block(g, keys, st, n, stream);
+  const GbLayout after = g->L;
+  g->L = saved;
+  (void)after;
+  return rc;
+}
+
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, void* stream) {
   DBHIP_REQUIRE(g && (rows_dev || n_rows == 0), "dbhip_groupby_merge_serialized: NULL argument");
   return merge_rows(g, (const uint64_t*)rows_dev, n_rows, resolve_stream(stream));

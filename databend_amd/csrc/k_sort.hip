@@ -465,4 +465,23 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   return DBHIP_OK;
 }
 
+// k-way merge of sorted runs (a16 merge row). Reference: Merger over a SortAlgorithm (HeapSort / LoserTreeSort,
+// sorts/core/{merger.rs,algorithm.rs:33-61,loser_tree.rs}) pops the smallest cursor row of N sorted streams until
+// `limit` rows are out; equal rows have no defined order between streams (cursor order is the row order only,
+// algorithm.rs:215-223). Device: the runs sit back to back in the key columns (run r = rows
+// [run_offsets[r], run_offsets[r+1])); the merged order is the STABLE order of all rows by key, i.e. ties come
+// out by (run, position) — one of the orders the loser tree may produce. Computed with the radix machinery above
+// (constant-byte passes skipped, LIMIT by radix select): a sequential loser tree has no data-parallel analogue,
+// and a merge-path tree would read each row log2(N) times against <= 8 radix passes here.
+int32_t dbhip_merge_sorted_perm(const dbhip_col* keys, const uint8_t* desc_host, const uint8_t* nulls_first_host,
+                                int32_t nkeys, const int64_t* run_offsets_host, int32_t nruns, int64_t limit,
+                                uint32_t* out_perm, void* stream) {
+  DBHIP_REQUIRE(run_offsets_host && nruns >= 0, "dbhip_merge_sorted_perm: NULL run offsets");
+  for (int r = 0; r < nruns; ++r)
+    DBHIP_REQUIRE(run_offsets_host[r] <= run_offsets_host[r + 1], "dbhip_merge_sorted_perm: run offsets must ascend");
+  const int64_t n = nruns ? run_offsets_host[nruns] : 0;
+  DBHIP_REQUIRE(nruns == 0 || run_offsets_host[0] == 0, "dbhip_merge_sorted_perm: runs start at row 0");
+  return dbhip_sort_perm(keys, desc_host, nulls_first_host, nkeys, n, limit, out_perm, stream);
+}
+
 }  // extern "C"

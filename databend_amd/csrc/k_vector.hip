@@ -638,9 +638,14 @@ struct HArgs {
   uint32_t cand_cap, row_origin;
 };
 
-template <bool COSINE>
-__global__ __launch_bounds__(256, 2) void bf16_filter_kernel(HArgs A) {
-  constexpr int TQ = 128, TI = 128;
+// TQ = 128: 4 waves (2 x 2), TQ = 256: 8 waves (4 x 2); every wave owns 64 x 64 scores. The taller tile reads the
+// base tile (L2 -> LDS) half as often per query and amortises the LDS stores over twice the matrix work.
+template <bool COSINE, int TQ>
+__global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 256 ? 4 : 3))) void bf16_filter_kernel(HArgs A) {
+  constexpr int TI = 128;
+  constexpr int NT = TQ * 2;          // threads
+  constexpr int RS = NT / 8;          // rows staged per pass (8 lanes cover one 128-byte row segment)
+  constexpr int AJ = TQ / RS, BJ = TI / RS;
   __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
   __shared__ float rA[TI], rX[TI], rY[TI], qA[TQ], qB[TQ], qG[TQ], Tau[TQ];
@@ -664,31 +669,30 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(HArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // thread t stages rows (t >> 3) + 32 j, 16-byte piece (t & 7) of the 128-byte k-tile row segment
+  // thread t stages rows (t >> 3) + RS j, 16-byte piece (t & 7) of the 128-byte k-tile row segment
   const int kc = (tid & 7) * 8;
   const int r0 = tid >> 3;
   const uint16_t* atile = A.queries + (int64_t)q0 * dpad;
   const uint16_t* btile = A.base + i0 * dpad;
   const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
   const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
-  uint32_t aoff[4], boff[4];
+  uint32_t aoff[AJ], boff[BJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    aoff[j] = (uint32_t)(r0 + 32 * j < alast ? r0 + 32 * j : alast) * (uint32_t)dpad + kc;
-    boff[j] = (uint32_t)(r0 + 32 * j < blast ? r0 + 32 * j : blast) * (uint32_t)dpad + kc;
-  }
-  u32x4 ra[4], rb[4];
+  for (int j = 0; j < AJ; ++j) aoff[j] = (uint32_t)(r0 + RS * j < alast ? r0 + RS * j : alast) * (uint32_t)dpad + kc;
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) boff[j] = (uint32_t)(r0 + RS * j < blast ? r0 + RS * j : blast) * (uint32_t)dpad + kc;
+  u32x4 ra[AJ], rb[BJ];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = *(const u32x4*)(atile + aoff[j] + k0);
+    for (int j = 0; j < AJ; ++j) ra[j] = *(const u32x4*)(atile + aoff[j] + k0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = *(const u32x4*)(btile + boff[j] + k0);
+    for (int j = 0; j < BJ; ++j) rb[j] = *(const u32x4*)(btile + boff[j] + k0);
   };
   auto lds_store = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(u32x4*)(As + (r0 + 32 * j) * HLD + kc) = ra[j];
+    for (int j = 0; j < AJ; ++j) *(u32x4*)(As + (r0 + RS * j) * HLD + kc) = ra[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(u32x4*)(Bs + (r0 + 32 * j) * HLD + kc) = rb[j];
+    for (int j = 0; j < BJ; ++j) *(u32x4*)(Bs + (r0 + RS * j) * HLD + kc) = rb[j];
   };
 
   gload(0);
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void bf16_filter_kernel(HArgs A) {
   if (tid < TI) {
     const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
     rA[tid] = A.rowA[i]; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
-  } else {
+  } else if (tid < TI + TQ) {
     const int t = tid - TI;
     const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
     const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
@@ -856,13 +860,19 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.qn = qA; A.qh = qX; A.qe = qY;
     A.tau = out_dist + (k - 1); A.tau_stride = k;
     A.n = hi - lo; A.dpad = dpad; A.nq = nq;
-    A.n_qtiles = (int)ceil_div(nq, 128);
+    const bool tall = nq > 128;  // 256-query tiles once there are enough queries to fill them
+    A.n_qtiles = (int)ceil_div(nq, tall ? 256 : 128);
     A.n_itiles = ceil_div(A.n, 128);
     A.c = (float)dim * 1.1920929e-07f + 2e-4f;
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
-    if (cosine) hipLaunchKernelGGL(bf16_filter_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL(bf16_filter_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A);
+    if (tall) {
+      if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<true, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
+      else hipLaunchKernelGGL((bf16_filter_kernel<false, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
+    } else {
+      if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<true, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+      else hipLaunchKernelGGL((bf16_filter_kernel<false, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+    }
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));

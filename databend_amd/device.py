@@ -401,6 +401,13 @@ class GroupBy:
                 aa[i] = a.c()
         check(lib().dbhip_groupby_add_block(self.h, ka, aa, C.c_int64(n), None))
 
+    def merge_state_block(self, keys, states, n):
+        """batch_merge of a serialized-state block [state columns..., group columns...] (payload_flush.rs:151-181)."""
+        aa = (Col * max(len(self.aggs), 1))()
+        for i, a in enumerate(states):
+            aa[i] = a.c()
+        check(lib().dbhip_groupby_merge_state_block(self.h, _cols(keys), aa, C.c_int64(n), None))
+
     def num_groups(self):
         n = C.c_int64()
         check(lib().dbhip_groupby_num_groups(self.h, C.byref(n), None))
@@ -633,6 +640,20 @@ def sort_perm(cols, desc=None, nulls_first=None, limit=0):
     m = limit if 0 < limit < n else n
     out = DeviceBuffer(max(m, 1) * 4)
     check(lib().dbhip_sort_perm(arr, d, nf, len(cols), C.c_int64(n), C.c_int64(limit), C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.uint32, m)
+
+
+def merge_sorted_perm(cols, run_offsets, desc=None, nulls_first=None, limit=0):
+    """k-way merge of sorted runs laid back to back (Merger / loser tree, sorts/core/merger.rs) -> u32 row ids."""
+    n = int(run_offsets[-1]) if len(run_offsets) else 0
+    desc = desc or [0] * len(cols)
+    nulls_first = nulls_first or [0] * len(cols)
+    d = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in desc])
+    nf = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in nulls_first])
+    ro = (C.c_int64 * len(run_offsets))(*[int(x) for x in run_offsets])
+    m = limit if 0 < limit < n else n
+    out = DeviceBuffer(max(m, 1) * 4)
+    check(lib().dbhip_merge_sorted_perm(_cols(cols), d, nf, len(cols), ro, len(run_offsets) - 1, C.c_int64(limit), C.c_void_p(out.ptr), None))
     return out.to_numpy(np.uint32, m)
 
 

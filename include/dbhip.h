@@ -263,6 +263,15 @@ int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
                                    uint8_t* const* out_key_validity_host,
                                    void* const* out_aggs_host, uint64_t* out_hashes,
                                    int64_t max_rows, int64_t* out_n_rows_host, void* stream);
+/* Merge a serialized-state BLOCK, columns [state columns..., group columns...] exactly as
+ * Payload::aggregate_flush emits it (payload_flush.rs:151-181; sum: the running value in its result
+ * type, count: u64) — the reference's TransformDeserializer + AggregateFunction::batch_merge
+ * (aggregator/serde/transform_deserializer.rs; aggregate_sum.rs:170-181,300-312). Together with
+ * dbhip_groupby_flush_result (which produces that block) this lets a device partial aggregate feed the
+ * unmodified CPU final stage / Flight exchange and vice versa. min/max: DBHIP_ERR_UNSUPPORTED (use
+ * the serialized rows). */
+int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
+                                        int64_t n, void* stream);
 int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream);
 int32_t dbhip_groupby_destroy(dbhip_groupby* g);
 
@@ -336,6 +345,17 @@ int32_t dbhip_join_destroy(dbhip_join* j);
 int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host,
                         const uint8_t* nulls_first_host, int32_t nkeys, int64_t n,
                         int64_t limit, uint32_t* out_perm, void* stream);
+
+/* k-way merge of sorted runs. Replaces Merger / LoserTreeSort / HeapSort
+ * (src/query/pipeline/transforms/src/processors/transforms/sorts/core/{merger.rs,algorithm.rs:33-61,
+ * loser_tree.rs}, sort_k_way_merge.rs): the runs sit back to back in the key columns, run r = rows
+ * [run_offsets[r], run_offsets[r+1]) and each run is ordered by the same keys; out_perm = row ids in
+ * merged order (ties: lower run first, then position — equal rows have no defined order between
+ * streams in the reference), truncated to `limit` when limit > 0. */
+int32_t dbhip_merge_sorted_perm(const dbhip_col* keys, const uint8_t* desc_host,
+                                const uint8_t* nulls_first_host, int32_t nkeys,
+                                const int64_t* run_offsets_host, int32_t nruns, int64_t limit,
+                                uint32_t* out_perm, void* stream);
 
 /* ---- a17/a18: vector distance ------------------------------------------------
  * Replaces cosine_distance / l2_distance / inner_product / l1_distance

@@ -187,6 +187,35 @@ def test_sort_limit_radix_select(gpu, oracle, n):
     assert got.tolist() == exp
 
 
+@pytest.mark.parametrize("nruns,limit", [(1, 0), (3, 0), (8, 0), (8, 25), (5, 100_000)])
+def test_merge_sorted_runs_like_the_loser_tree(gpu, nruns, limit):
+    """Merger semantics (sorts/core/merger.rs, loser_tree.rs basic test :126-156): the merged key sequence of N sorted
+    streams == heapq.merge of the runs; ties between streams are unordered in the reference, so key tuples are
+    compared, plus: every run's rows appear in their original order."""
+    import heapq
+    rng = np.random.default_rng(nruns * 7 + limit)
+    runs = []
+    for r in range(nruns):
+        m = int(rng.integers(0, 60_000)) if r % 3 else int(rng.integers(0, 50))
+        a = rng.integers(-5, 6, m).astype(np.int32)
+        b = rng.integers(0, 2**40, m).astype(np.int64)
+        order = np.lexsort((-b, a))  # a asc, b desc
+        runs.append((a[order], b[order]))
+    offs = np.concatenate([[0], np.cumsum([len(a) for a, _ in runs])]).astype(np.int64)
+    ca = np.concatenate([a for a, _ in runs]) if nruns else np.zeros(0, np.int32)
+    cb = np.concatenate([b for _, b in runs]) if nruns else np.zeros(0, np.int64)
+    perm = gpu.merge_sorted_perm([gpu.Column.from_numpy(ca), gpu.Column.from_numpy(cb)], offs, desc=[0, 1], limit=limit)
+    exp = list(heapq.merge(*[[(int(x), -int(y)) for x, y in zip(a, b)] for a, b in runs]))
+    n = len(exp)
+    m = limit if 0 < limit < n else n
+    assert len(perm) == m
+    assert [(int(ca[i]), -int(cb[i])) for i in perm] == exp[:m]
+    run_of = np.searchsorted(offs, perm, side="right") - 1
+    for r in range(nruns):
+        mine = perm[run_of == r]
+        assert np.all(np.diff(mine.astype(np.int64)) > 0)          # in-run order preserved (stable merge)
+
+
 def test_sort_decimal128_and_bool(gpu, oracle):
     rng = np.random.default_rng(4)
     n = 5000

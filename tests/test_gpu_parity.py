@@ -375,6 +375,42 @@ def test_groupby_serialized_roundtrip_and_merge(gpu):
     assert sorted(gall.result()) == exp
 
 
+def test_groupby_state_block_roundtrip_partial_to_final(gpu):
+    """Two partial tables flush their serialized-state blocks ([state columns..., group columns...],
+    payload_flush.rs:151-181: sum -> value, count -> u64) as HBM columns; a final table batch_merges both blocks
+    (count states are ADDED, not counted) and equals one table over all rows — TransformPartialAggregate ->
+    exchange -> TransformFinalAggregate with column blocks instead of row payloads."""
+    n = 200_000
+    rng = np.random.default_rng(61)
+    k1 = rng.integers(0, 3000, n).astype(np.int64)
+    k2 = rng.integers(0, 3, n).astype(np.int32)
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    d = [int(x) * 10**10 for x in rng.integers(-10**15, 10**15, n)]
+    f = rng.integers(-100, 100, n).astype(np.float64)
+    av = rng.integers(0, 4, n) > 0
+    spec = ([T.T_I64, T.T_DATE], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC128, 31, 4, 0),
+                                  (T.AGG_SUM, T.T_F64, 0, 0, 0), (T.AGG_COUNT, T.T_I64, 0, 0, 1)])
+
+    def run(lo, hi):
+        g = gpu.GroupBy(*spec)
+        g.add_block([gpu.Column.from_numpy(k1[lo:hi]), gpu.Column.from_numpy(k2[lo:hi], T.T_DATE)],
+                    [gpu.Column.from_numpy(a[lo:hi]), None, gpu.Column.decimal128(d[lo:hi], 31, 4), gpu.Column.from_numpy(f[lo:hi]),
+                     gpu.Column.from_numpy(a[lo:hi], validity=av[lo:hi])], hi - lo)
+        return g
+
+    whole = run(0, n)
+    final = gpu.GroupBy(*spec)
+    for lo, hi in ((0, 70_000), (70_000, n)):
+        cols = run(lo, hi).result_columns()          # [keys..., states...] resident in HBM
+        final.merge_state_block(cols[:2], cols[2:], cols[0].n)
+    assert final.num_groups() == whole.num_groups()
+    assert sorted(final.result()) == sorted(whole.result())
+    exp_cnt = {}
+    for x, y in zip(k1.tolist(), k2.tolist()):
+        exp_cnt[(x, y)] = exp_cnt.get((x, y), 0) + 1
+    assert {r[:2]: r[3] for r in final.result()} == exp_cnt
+
+
 @pytest.mark.parametrize("n", [1, 127, 128, 129, 1000, 300_007])
 def test_q1_fused_and_operator_plans_match_oracle(gpu, oracle, n):
     from databend_amd import tpch
