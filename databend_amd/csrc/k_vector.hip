@@ -648,7 +648,7 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
   constexpr int AJ = TQ / RS, BJ = TI / RS;
   __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
-  __shared__ float rA[TI], rX[TI], rY[TI], qA[TQ], qB[TQ], qG[TQ], Tau[TQ];
+  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
 
   const int64_t slot = blockIdx.x >> 3;
   const int xcd = blockIdx.x & 7;
@@ -717,44 +717,56 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
     }
   }
 
+  // Epilogue. A row survives unless the LOWER bound of its distance exceeds tau:
+  //   cosine  1 - (v a + x B' + y G') / ||q|| > tau     <=>   v a + x B' + y G' < (1 - tau) ||q||      (a = 1/||b||)
+  //   dot     v - (x B' + y G') > tau                   <=>  -v   + x B' + y G' < -tau
+  // so per query three numbers (B', G', T') and per base row three (a, x, y). The 16 accumulator rows of a lane map to
+  // 16 queries that only depend on lane >> 5: their coefficients are fetched with 12 ds_read_b128 per 32-query slab
+  // (not 4 scalar LDS reads per score) and the test itself is three VALU operations.
   if (tid < TI) {
     const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
-    rA[tid] = A.rowA[i]; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
+    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
   } else if (tid < TI + TQ) {
     const int t = tid - TI;
     const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
     const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
-    if (COSINE) {
-      const float al = 1.0f / n_, be = e_ * al, ga = h_ * al;
-      qA[t] = al; qB[t] = be + A.c * ga; qG[t] = ga + be;
-    } else {
-      qA[t] = 1.0f; qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
-    }
-    Tau[t] = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
+    const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
+    // (both sides of the cosine test are multiplied by ||q||: B' = ||ql|| + c ||qh||, G' = ||qh|| + ||ql||)
+    qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
+    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
   }
   __syncthreads();
 
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 2; ++x) {
+    float cB[16], cG[16], cT[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qb = wq + x * 32 + 8 * j + 4 * (lane >> 5);
+      const float4 vb = *(const float4*)(qB + qb), vg = *(const float4*)(qG + qb), vt = *(const float4*)(Tau + qb);
+      cB[4 * j + 0] = vb.x; cB[4 * j + 1] = vb.y; cB[4 * j + 2] = vb.z; cB[4 * j + 3] = vb.w;
+      cG[4 * j + 0] = vg.x; cG[4 * j + 1] = vg.y; cG[4 * j + 2] = vg.z; cG[4 * j + 3] = vg.w;
+      cT[4 * j + 0] = vt.x; cT[4 * j + 1] = vt.y; cT[4 * j + 2] = vt.z; cT[4 * j + 3] = vt.w;
+    }
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       const int il = wi + y * 32 + (lane & 31);
       const int64_t i = i0 + il;
       const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
+      const bool row_ok = i < A.n;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ql = wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int q = q0 + ql;
-        const float v = acc[x][y][r];
-        const float slack = fmaf(x_, qB[ql], y_ * qG[ql]);
-        // lower bound of the exact distance
-        const float lb = COSINE ? 1.0f - fmaf(v * qA[ql], a_, slack) : v - slack;
-        if (q < A.nq && i < A.n && !(lb > Tau[ql])) {  // NaN bounds stay in the race
-          const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
-          if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
+        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
+        if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
+          const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (q < A.nq) {
+            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
+            if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
+          }
         }
       }
     }
+  }
 }
 
 // One wave per row: out[row][0..dpad) = bf16(x[row]) (RNE, zero padded) and the row's coefficients.
