@@ -160,9 +160,22 @@ __device__ __forceinline__ uint64_t probe_word(uint64_t h, uint64_t mask) {
   return hw == 0 ? 1 : hw;  // 0 is the empty marker
 }
 
+// `n_dev` (optional): the row count lives on the device (rows produced by a kernel of the same stream whose
+// count the host has not read yet); `abort_dev` (optional): non-zero low bits = the producer gave up, merge nothing.
+struct DevCount {
+  const uint64_t* n_dev;
+  const uint64_t* abort_dev;
+};
+__device__ __forceinline__ int64_t dev_rows(const DevCount& dc, int64_t n) {
+  if (dc.abort_dev && (*dc.abort_dev & 3)) return 0;
+  if (dc.n_dev) { const int64_t m = (int64_t)*dc.n_dev; return m < n ? m : n; }
+  return n;
+}
+
 __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_t* rows_in, int64_t n,
                                                        uint64_t* slot_hash, uint64_t* rows, int64_t cap,
-                                                       uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl) {
+                                                       uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc) {
+  n = dev_rows(dc, n);
   const uint64_t cmask = (uint64_t)cap - 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -209,7 +222,8 @@ __device__ __forceinline__ bool keys_equal(const GbLayout& L, const uint64_t* a,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gb_accum_kernel(GbLayout L, const uint64_t* rows_in, int64_t n,
                                                        uint64_t* rows, const uint32_t* gid,
-                                                       uint32_t* retry, uint64_t* ctrl) {
+                                                       uint32_t* retry, uint64_t* ctrl, DevCount dc) {
+  n = dev_rows(dc, n);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t* r = rows_in + i * L.W;
@@ -253,7 +267,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const uint64_t* rows_in,
                                                                int64_t n, uint64_t* rows,
                                                                const uint32_t* gid, uint32_t* retry,
-                                                               uint64_t* ctrl) {
+                                                               uint64_t* ctrl, DevCount dc) {
+  n = dev_rows(dc, n);
   const int64_t n_pad = (n + 63) & ~63LL;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -592,7 +607,8 @@ int32_t grow(dbhip_groupby* g, hipStream_t s) {
 }
 
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
-int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s) {
+int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
+                   const uint64_t* n_dev = nullptr, const uint64_t* abort_dev = nullptr) {
   if (n == 0) return DBHIP_OK;
   if (n > 0xFFFFFFF0LL) {
     set_error("groupby: more than 2^32 rows in one call");
@@ -605,11 +621,43 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
   uint64_t host_ctrl[5];
   const uint64_t* cur_rows = rows_in;
   int64_t cur_n = n;
+  const DevCount dc{n_dev, abort_dev};
+  // No growth possible even if every row were a new group: probe, accumulate and retry are queued back to back and
+  // the host reads the control block ONCE (the small merges behind the fused kernels are all host round trips).
+  if ((g->count_host + n) * 135 <= g->cap * 100) {
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[1], 0, 16, s));
+    hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash, g->rows, g->cap,
+                       g->hash_mask, g->gid, g->ctrl, dc);
+    if (g->count_host <= 32 && n <= 65536)
+      hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
+                         g->ctrl, dc);
+    else
+      hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry, g->ctrl, dc);
+    hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows, g->cap, g->hash_mask,
+                       g->gid, g->retry, g->ctrl);
+    DBHIP_LAUNCH_CHECK();
+    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, sizeof(host_ctrl), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    g->count_host = (int64_t)host_ctrl[0];
+    if (host_ctrl[3] & 2) {
+      set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    if (host_ctrl[1]) {
+      set_error("groupby: collision chain filled the table during retry; create the table with a larger capacity");
+      return DBHIP_ERR_CAPACITY;
+    }
+    return DBHIP_OK;
+  }
+  if (n_dev || abort_dev) {
+    set_error("groupby: device-side row count needs a table that cannot grow during the merge");
+    return DBHIP_ERR_INVALID;
+  }
   for (int attempt = 0; attempt < 40; ++attempt) {
     // ctrl[1] (overflow) and ctrl[2] (retry count) are per-attempt
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[1], 0, 16, s));
     hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash,
-                       g->rows, g->cap, g->hash_mask, g->gid, g->ctrl);
+                       g->rows, g->cap, g->hash_mask, g->gid, g->ctrl, dc);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, sizeof(host_ctrl), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
@@ -621,10 +669,10 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
     g->count_host = (int64_t)host_ctrl[0];
     if (g->count_host <= 32) {
       hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n,
-                         g->rows, g->gid, g->retry, g->ctrl);
+                         g->rows, g->gid, g->retry, g->ctrl, dc);
     } else {
       hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows,
-                         g->gid, g->retry, g->ctrl);
+                         g->gid, g->retry, g->ctrl, dc);
     }
     hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows,
                        g->cap, g->hash_mask, g->gid, g->retry, g->ctrl);
@@ -1333,6 +1381,13 @@ void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen) {
 int32_t dbhip_groupby_merge_rows_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n, hipStream_t s) {
   return merge_rows(g, rows, n, s);
 }
+// same, with the row count (and the producer's give-up flag) still on the device: `n_max` bounds the count
+int32_t dbhip_groupby_merge_rows_dev_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n_max, const uint64_t* n_dev,
+                                              const uint64_t* abort_dev, hipStream_t s) {
+  return merge_rows(g, rows, n_max, s, n_dev, abort_dev);
+}
+int64_t dbhip_groupby_capacity_internal(dbhip_groupby* g) { return g->cap; }
+int64_t dbhip_groupby_count_internal(dbhip_groupby* g) { return g->count_host; }
 const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g) { return &g->L; }
 
 extern "C" {

@@ -34,6 +34,10 @@
 using namespace dbhip;
 
 int32_t dbhip_groupby_merge_rows_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n, hipStream_t s);
+int32_t dbhip_groupby_merge_rows_dev_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n_max, const uint64_t* n_dev,
+                                              const uint64_t* abort_dev, hipStream_t s);
+int64_t dbhip_groupby_capacity_internal(dbhip_groupby* g);
+int64_t dbhip_groupby_count_internal(dbhip_groupby* g);
 const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
 
 namespace {
@@ -342,7 +346,9 @@ int32_t dbhip_q1_create_groupby(dbhip_groupby** out_host) {
   aggs[3] = {DBHIP_AGG_SUM, DBHIP_T_DEC128, 38, 6, 0, 0};  // sum(price*(1-disc)*(1+tax))
   aggs[4] = {DBHIP_AGG_SUM, DBHIP_T_DEC64, 15, 2, 0, 0};   // sum(l_discount)
   aggs[5] = {DBHIP_AGG_COUNT, 0, 0, 0, 0, 0};              // count(*)
-  return dbhip_groupby_create(key_types, key_nullable, 2, aggs, 6, 1024, out_host);
+  // 32768 slots: the <= 16384 partial rows of a fused pass can never push the table past its load factor, so
+  // their merge needs no growth check (one host round trip per pass, see merge_rows)
+  return dbhip_groupby_create(key_types, key_nullable, 2, aggs, 6, 32768, out_host);
 }
 
 int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_t* l_extendedprice,
@@ -381,6 +387,10 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   // variant keeps every accumulator in registers at 4 waves/SIMD; a block that meets a 5th
   // distinct key flags it and the pass is redone with 8 slots; beyond that the caller uses
   // the operator-at-a-time kernels.
+  // When the table cannot outgrow its load factor the merge of the partial rows is queued right behind the fused
+  // kernel with the row count and the give-up flags still on the device: ONE host round trip per pass.
+  const int64_t n_max4 = (int64_t)grid * 4, n_max8 = (int64_t)grid * MAX_SLOTS;
+  const bool chained = (dbhip_groupby_count_internal(g) + n_max8) * 135 <= dbhip_groupby_capacity_internal(g) * 100;
   for (int variant = 0; variant < 2; ++variant) {
     DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
     kernel_timer_start(s);
@@ -389,7 +399,13 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
     kernel_timer_stop(s);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, ctrl, 16, hipMemcpyDeviceToHost, s));
-    DBHIP_CHECK(hipStreamSynchronize(s));
+    if (chained) {
+      int32_t rc = dbhip_groupby_merge_rows_dev_internal(g, partial, variant == 0 ? n_max4 : n_max8, &ctrl[0], &ctrl[1], s);
+      if (rc) return rc;  // (synchronises the stream: host_ctrl is valid now)
+      if (!(host_ctrl[1] & 3)) return DBHIP_OK;
+    } else {
+      DBHIP_CHECK(hipStreamSynchronize(s));
+    }
     if (!(host_ctrl[1] & 1)) break;
   }
   if (host_ctrl[1] & 2) {
