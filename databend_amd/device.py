@@ -325,6 +325,13 @@ def filter_select(pred):
     return sel, k
 
 
+def bitmap_count(pred, n):
+    """number of set bits of a Boolean column (Bitmap::true_count)"""
+    out = DeviceBuffer(8)
+    check(lib().dbhip_bitmap_count(C.c_void_p(pred.data.ptr), C.c_int64(0), C.c_int64(n), C.c_void_p(out.ptr), None))
+    return int(out.to_numpy(np.uint64, 1)[0])
+
+
 def take(col, sel, k):
     """DataBlock::take for one column (kernels/take.rs:43)."""
     if col.dtype == L.T_BOOL:
