@@ -42,6 +42,9 @@ struct dbhip_join {
   // probe scratch
   uint32_t* cnt; uint32_t* firstm; uint64_t* off; uint64_t* blk; size_t scratch_rows;
   uint64_t* total_dev;
+  // the last counted probe block: dbhip_join_probe of the SAME block (count first, then emit into buffers of the
+  // right size — the only way a caller can size its outputs) reuses the counts instead of walking the table again
+  const void* prep_keys; const uint8_t* prep_valid; int64_t prep_n; uint64_t prep_total; hipStream_t prep_stream; bool prepared;
 };
 
 namespace {
@@ -441,24 +444,36 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   return DBHIP_OK;
 }
 
+// count pass + exclusive scan of one probe block into the handle's scratch
+static int32_t join_count_block(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n, hipStream_t s,
+                                uint64_t* total_host) {
+  int32_t rc = ensure_probe_scratch(j, n);
+  if (rc) return rc;
+  j->prepared = false;
+  DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
+  const int grid = grid_for(n, 256);
+  if (j->kw == 1)
+    hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
+  else
+    hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
+  rc = dbscan::exclusive_scan_u32(j->cnt, n, j->blk, j->off, s);
+  if (rc) return rc;
+  DBHIP_CHECK(hipMemcpyAsync(total_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  j->prep_keys = keys; j->prep_valid = validity; j->prep_n = n; j->prep_total = *total_host; j->prep_stream = s;
+  j->prepared = true;
+  return DBHIP_OK;
+}
+
 int32_t dbhip_join_probe_count(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                                uint64_t* out_total_host, void* stream) {
   DBHIP_REQUIRE(j && j->finalized && out_total_host, "dbhip_join_probe_count: table not finalized / NULL out");
-  hipStream_t s = resolve_stream(stream);
-  DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
-  if (n) {
-    const int grid = grid_for(n, 256);
-    if (j->kw == 1)
-      hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                         validity, n, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)j->total_dev);
-    else
-      hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                         validity, n, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)j->total_dev);
-    DBHIP_LAUNCH_CHECK();
-  }
-  DBHIP_CHECK(hipMemcpyAsync(out_total_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
-  return DBHIP_OK;
+  DBHIP_REQUIRE(n < 0xFFFFFFFFLL, "dbhip_join_probe_count: more than 2^32-1 probe rows in one block");
+  *out_total_host = 0;
+  if (n == 0) return DBHIP_OK;
+  return join_count_block(j, keys, validity, n, resolve_stream(stream), out_total_host);
 }
 
 int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
@@ -492,21 +507,15 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
   hipStream_t s = resolve_stream(stream);
   *out_n_pairs_host = 0;
   if (n == 0) return DBHIP_OK;
-  int32_t rc = ensure_probe_scratch(j, n);
-  if (rc) return rc;
-  DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
   const int grid = grid_for(n, 256);
-  if (j->kw == 1)
-    hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
-  else
-    hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
-  rc = dbscan::exclusive_scan_u32(j->cnt, n, j->blk, j->off, s);
-  if (rc) return rc;
   uint64_t total = 0;
-  DBHIP_CHECK(hipMemcpyAsync(&total, j->total_dev, 8, hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
+  int32_t rc;
+  if (j->prepared && j->prep_keys == keys && j->prep_valid == validity && j->prep_n == n && j->prep_stream == s) {
+    total = j->prep_total;  // counted by dbhip_join_probe_count just before (columns are immutable between the two)
+  } else if ((rc = join_count_block(j, keys, validity, n, s, &total))) {
+    return rc;
+  }
+  j->prepared = false;
   *out_n_pairs_host = total;
   if ((int64_t)total > max_pairs) {
     set_error("dbhip_join_probe: %llu pairs do not fit max_pairs=%lld (call dbhip_join_probe_count first)",

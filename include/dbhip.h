@@ -319,7 +319,11 @@ int32_t dbhip_pack_keys(const dbhip_col* cols, int32_t ncols, int64_t n, int32_t
  * library returns them sorted by (probe_idx, build_row). dbhip_join_probe_mark writes the
  * "probe row has a match" bitmap (LSB-first, ceil(n/8) bytes) that semi / anti joins filter on and
  * left-outer joins use to append unmatched rows (new_hash_join probe_matched,
- * fixed_keys.rs:96-167). */
+ * fixed_keys.rs:96-167).
+ * Sizing protocol: dbhip_join_probe_count(block) -> allocate -> dbhip_join_probe(same block). The probe that
+ * directly follows a count of the same (keys, validity, n) on the same stream reuses the per-row counts (the
+ * table is walked once), so the key / validity buffers must not change between the two calls (columns are
+ * immutable in the reference; a caller that recycles a staging buffer must count again). */
 typedef struct dbhip_join dbhip_join;
 int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host);  /* 8-byte keys */
 int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, dbhip_join** out_host);
