@@ -23,6 +23,8 @@ class Borrowed:
 
 
 def col(gpu, t, dtype, **kw):
+    # the library runs on its own non-blocking stream: whatever torch queued to produce `t` must be complete
+    torch.cuda.synchronize()
     return gpu.Column(dtype, t.shape[0], Borrowed(t), **kw)
 
 
@@ -162,6 +164,7 @@ def test_vector_index_10m_by_768_self_retrieval_and_exact_scan_agreement(gpu):
         def __init__(self, t):
             self.n, self.dim, self.data = t.shape[0], t.shape[1], Borrowed(t)
 
+    torch.cuda.synchronize()
     ix = gpu.VectorIndex(T.VEC_COSINE, Vec(base))
     idx, dist = ix.search(Vec(q), k)
     assert idx[: len(ids), 0].tolist() == ids.tolist()
