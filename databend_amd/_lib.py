@@ -33,6 +33,15 @@ class Col(C.Structure):
     ]
 
 
+EX_LOAD, EX_CONST, EX_PLUS, EX_MINUS, EX_MULTIPLY, EX_DIVIDE, EX_EQ, EX_NOTEQ, EX_LT, EX_LTE, EX_GT, EX_GTE, EX_AND, EX_OR, EX_NOT, EX_CAST = range(16)
+
+
+class ExprIns(C.Structure):
+    """dbhip_expr_ins"""
+    _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("type", C.c_int32), ("_pad", C.c_int32),
+                ("imm", C.c_uint64)]
+
+
 class AggDesc(C.Structure):
     """dbhip_agg_desc"""
     _fields_ = [("kind", C.c_int32), ("arg_type", C.c_int32), ("arg_precision", C.c_uint8),
@@ -49,7 +58,7 @@ SYMBOLS = [
     "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy",
     "dbhip_stream_sync", "dbhip_event_create", "dbhip_event_record", "dbhip_event_elapsed_ms",
     "dbhip_event_destroy", "dbhip_last_kernel_ms", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",
-    "dbhip_sum", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_cmp", "dbhip_bitmap_binary",
+    "dbhip_sum", "dbhip_expr_eval", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_cmp", "dbhip_bitmap_binary",
     "dbhip_bitmap_count", "dbhip_filter_select", "dbhip_take", "dbhip_take_bitmap", "dbhip_group_hash",
     "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized", "dbhip_groupby_merge_state_block",
     "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized",

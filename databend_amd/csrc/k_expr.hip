@@ -1,0 +1,332 @@
+// k_expr.hip — fused expression evaluation (SURVEY §8 a1 + §8f rank 2).
+//
+// Reference: Evaluator::run walks the Expr tree and materialises ONE column per call node
+// (src/query/expression/src/evaluator.rs:229-464; CompoundBlockOperator / BlockOperator::Map,
+// src/query/sql/src/evaluator/block_operator.rs:42-85): sum(a + b*c) is three kernels moving 56 B/row where
+// 24 B/row are needed. Here a whole expression tree is ONE launch: the host flattens the tree (post-order) into
+// a short register program, the kernel interprets it with a wave-uniform instruction stream — every lane of
+// every wave executes the same instruction, so the interpreter costs scalar-unit work only — over a register
+// file that lives in LDS ([register][row slot][lane] u64: conflict-free ds_read/ds_write_b64), two row slots
+// per lane (rows base + lane and base + 64 + lane: every column access is a fully coalesced wave load and a
+// Boolean result is exactly one ballot word). Intermediate columns never exist in HBM.
+//
+// Semantics per node are the per-node kernels' (k_arith.hip / k_cmp_filter.hip), which restate
+// numeric_basic_arithmetic.rs:255-427 and comparison.rs:98-112: operands are cast `as` the node's result type
+// (arithmetics_type.rs), integer arithmetic wraps at the result width, `/` is f64 with the "divided by zero" row
+// error (only for rows whose inputs are all valid, function.rs:534-556), floats compare as OrderedFloat. NULLs:
+// passthrough_nullable (register_vectorize.rs:447-471) — the payload is computed for all rows, the result's validity
+// is the AND of the validity of every nullable input column the program loads.
+#include "dev_common.h"
+#include "dev_load.h"
+#include "runtime.h"
+
+#include <string.h>
+
+using namespace dbhip;
+
+namespace {
+
+constexpr int EX_MAX_INS = 32;
+constexpr int EX_MAX_REGS = 8;
+constexpr int EX_MAX_INPUTS = 8;
+constexpr int EX_ROWS = 2;  // row slots per lane
+
+struct ExIns {
+  int16_t op, dst, a, b;   // a = input index for LOAD
+  int16_t type, ta, tb;    // result type, operand types
+  int16_t _pad;
+  uint64_t imm;
+};
+
+struct ExProg {
+  ExIns ins[EX_MAX_INS];
+  const void* in_data[EX_MAX_INPUTS];
+  const uint8_t* in_valid[EX_MAX_INPUTS];
+  int64_t in_voff[EX_MAX_INPUTS];
+  int32_t in_type[EX_MAX_INPUTS];
+  int32_t in_scalar[EX_MAX_INPUTS];
+  int32_t n_ins, n_inputs, out_reg, out_type;
+  int64_t n;
+  void* out_values;              // numeric: elements of out_type; BOOL: bitmap words
+  uint64_t* out_validity;        // bitmap words (may be NULL)
+  uint32_t* err_words;           // preset to all ones (may be NULL)
+  unsigned long long* err_count; // may be NULL
+  unsigned long long* sum_out;   // may be NULL: accumulate the sum of the valid rows of out_reg
+};
+
+__device__ __forceinline__ uint64_t ex_load(const void* p, int type, int64_t i) {
+  switch (type) {
+    case DBHIP_T_BOOL: return bit_get((const uint8_t*)p, i);
+    case DBHIP_T_I8: return (uint64_t)(int64_t)((const int8_t*)p)[i];
+    case DBHIP_T_I16: return (uint64_t)(int64_t)((const int16_t*)p)[i];
+    case DBHIP_T_I32: case DBHIP_T_DATE: return (uint64_t)(int64_t)((const int32_t*)p)[i];
+    case DBHIP_T_U8: return ((const uint8_t*)p)[i];
+    case DBHIP_T_U16: return ((const uint16_t*)p)[i];
+    case DBHIP_T_U32: return ((const uint32_t*)p)[i];
+    case DBHIP_T_F32: return (uint64_t)__double_as_longlong((double)((const float*)p)[i]);
+    default: return ((const uint64_t*)p)[i];  // I64, U64, F64 (bits), TIMESTAMP, DEC64
+  }
+}
+
+__device__ __forceinline__ double ex_to_f64(uint64_t w, int cls) {
+  if (cls == CLS_FLOAT) return __longlong_as_double((long long)w);
+  if (cls == CLS_SIGNED) return (double)(int64_t)w;
+  return (double)w;
+}
+
+// widened register image of `w` (an integer / float result computed in 64 bits) at the node's result type
+__device__ __forceinline__ uint64_t ex_normalise(uint64_t w, int type) {
+  switch (type) {
+    case DBHIP_T_I8: return (uint64_t)(int64_t)(int8_t)w;
+    case DBHIP_T_I16: return (uint64_t)(int64_t)(int16_t)w;
+    case DBHIP_T_I32: case DBHIP_T_DATE: return (uint64_t)(int64_t)(int32_t)w;
+    case DBHIP_T_U8: return w & 0xFFu;
+    case DBHIP_T_U16: return w & 0xFFFFu;
+    case DBHIP_T_U32: return w & 0xFFFFFFFFu;
+    case DBHIP_T_F32: return (uint64_t)__double_as_longlong((double)(float)__longlong_as_double((long long)w));
+    default: return w;
+  }
+}
+
+__device__ __forceinline__ int ex_cmp3(uint64_t a, uint64_t b, int cls) {
+  if (cls == CLS_SIGNED) return ((int64_t)a > (int64_t)b) - ((int64_t)a < (int64_t)b);
+  if (cls == CLS_UNSIGNED) return (a > b) - (a < b);
+  const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+  const bool xn = x != x, yn = y != y;
+  if (xn || yn) return (int)xn - (int)yn;  // OrderedFloat: NaN largest, NaN == NaN
+  return (x > y) - (x < y);
+}
+
+enum {
+  EX_LOAD = 0, EX_CONST = 1, EX_PLUS = 2, EX_MINUS = 3, EX_MULTIPLY = 4, EX_DIVIDE = 5,
+  EX_EQ = 6, EX_NOTEQ = 7, EX_LT = 8, EX_LTE = 9, EX_GT = 10, EX_GTE = 11,
+  EX_AND = 12, EX_OR = 13, EX_NOT = 14, EX_CAST = 15
+};
+
+__global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
+  __shared__ uint64_t regs[EX_MAX_REGS][EX_ROWS][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t rows_per_wave = 64 * EX_ROWS;
+  const int64_t nchunks = (P.n + rows_per_wave - 1) / rows_per_wave;
+  const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + tid) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int out_cls = P.out_type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(P.out_type);
+  uint64_t acc_i = 0;
+  double acc_f = 0.0;
+
+  for (int64_t c = wave_global; c < nchunks; c += nwaves) {
+    const int64_t base = c * rows_per_wave;
+    int64_t row[EX_ROWS];
+    bool in_range[EX_ROWS], valid[EX_ROWS];
+#pragma unroll
+    for (int k = 0; k < EX_ROWS; ++k) {
+      row[k] = base + 64 * k + lane;
+      in_range[k] = row[k] < P.n;
+      valid[k] = in_range[k];
+      if (!in_range[k]) row[k] = P.n - 1;  // clamp: loads stay in bounds, results are masked
+    }
+    for (int pc = 0; pc < P.n_ins; ++pc) {
+      const ExIns I = P.ins[pc];
+#pragma unroll
+      for (int k = 0; k < EX_ROWS; ++k) {
+        uint64_t r;
+        if (I.op == EX_LOAD) {
+          const int c_ = I.a;
+          const int64_t j = P.in_scalar[c_] ? 0 : row[k];
+          r = ex_load(P.in_data[c_], P.in_type[c_], j);
+          if (P.in_valid[c_]) valid[k] = valid[k] && bit_get(P.in_valid[c_], P.in_voff[c_] + j);
+        } else if (I.op == EX_CONST) {
+          r = I.imm;
+        } else {
+          const uint64_t x = regs[I.a][k][tid];
+          const uint64_t y = (I.op == EX_NOT || I.op == EX_CAST) ? 0 : regs[I.b][k][tid];
+          const int acls = I.ta == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.ta);
+          const int bcls = I.tb == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.tb);
+          const int ocls = I.type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.type);
+          switch (I.op) {
+            case EX_PLUS: case EX_MINUS: case EX_MULTIPLY:
+              if (ocls == CLS_FLOAT) {
+                const double a = ex_to_f64(x, acls), b = ex_to_f64(y, bcls);
+                const double z = I.op == EX_PLUS ? a + b : (I.op == EX_MINUS ? a - b : a * b);
+                r = (uint64_t)__double_as_longlong(z);
+              } else {
+                r = I.op == EX_PLUS ? x + y : (I.op == EX_MINUS ? x - y : x * y);
+              }
+              r = ex_normalise(r, I.type);
+              break;
+            case EX_DIVIDE: {
+              const double a = ex_to_f64(x, acls), b = ex_to_f64(y, bcls);
+              if (b == 0.0) {
+                if (valid[k]) {  // NULL rows never raise (function.rs:536-543); padding rows are not valid
+                  if (P.err_words) atomicAnd(&P.err_words[row[k] >> 5], ~(1u << (row[k] & 31)));
+                  if (P.err_count) atomicAdd(P.err_count, 1ULL);
+                }
+                r = 0;
+              } else {
+                r = (uint64_t)__double_as_longlong(a / b);
+              }
+            } break;
+            case EX_EQ: r = ex_cmp3(x, y, acls) == 0; break;
+            case EX_NOTEQ: r = ex_cmp3(x, y, acls) != 0; break;
+            case EX_LT: r = ex_cmp3(x, y, acls) < 0; break;
+            case EX_LTE: r = ex_cmp3(x, y, acls) <= 0; break;
+            case EX_GT: r = ex_cmp3(x, y, acls) > 0; break;
+            case EX_GTE: r = ex_cmp3(x, y, acls) >= 0; break;
+            case EX_AND: r = x & y & 1; break;
+            case EX_OR: r = (x | y) & 1; break;
+            case EX_NOT: r = (x ^ 1) & 1; break;
+            default:  // EX_CAST (lossless widenings only, checked on the host)
+              if (ocls == CLS_FLOAT) r = ex_normalise((uint64_t)__double_as_longlong(ex_to_f64(x, acls)), I.type);
+              else r = x;
+              break;
+          }
+        }
+        regs[I.dst][k][tid] = r;
+      }
+    }
+    // ---- result ----
+#pragma unroll
+    for (int k = 0; k < EX_ROWS; ++k) {
+      const uint64_t r = regs[P.out_reg][k][tid];
+      const int64_t word = (base >> 6) + k;  // 64-row word of this slot
+      if (P.out_values) {
+        if (P.out_type == DBHIP_T_BOOL) {
+          const uint64_t m = __ballot(in_range[k] && (r & 1));
+          if (lane == 0 && base + 64 * k < P.n) ((uint64_t*)P.out_values)[word] = m;
+        } else if (in_range[k]) {
+          switch (P.out_type) {
+            case DBHIP_T_I8: case DBHIP_T_U8: ((uint8_t*)P.out_values)[row[k]] = (uint8_t)r; break;
+            case DBHIP_T_I16: case DBHIP_T_U16: ((uint16_t*)P.out_values)[row[k]] = (uint16_t)r; break;
+            case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_DATE: ((uint32_t*)P.out_values)[row[k]] = (uint32_t)r; break;
+            case DBHIP_T_F32: ((float*)P.out_values)[row[k]] = (float)__longlong_as_double((long long)r); break;
+            default: ((uint64_t*)P.out_values)[row[k]] = r; break;
+          }
+        }
+      }
+      if (P.out_validity) {
+        const uint64_t m = __ballot(valid[k]);
+        if (lane == 0 && base + 64 * k < P.n) P.out_validity[word] = m;
+      }
+      if (P.sum_out && valid[k]) {
+        if (out_cls == CLS_FLOAT) acc_f += __longlong_as_double((long long)r);
+        else acc_i += r;
+      }
+    }
+  }
+  if (P.sum_out) {
+    if (out_cls == CLS_FLOAT) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc_f += __shfl_xor(acc_f, off, 64);
+      if (lane == 0 && acc_f != 0.0) atomicAdd((double*)P.sum_out, acc_f);
+    } else {
+      acc_i = wave_sum_u64(acc_i);
+      if (lane == 0 && acc_i) atomicAdd(P.sum_out, (unsigned long long)acc_i);
+    }
+  }
+}
+
+bool ex_numeric(int t) { return type_class(t) >= 0; }
+
+bool ex_lossless_cast(int from, int to) {
+  if (from == to) return true;
+  const int fc = type_class(from), tc = type_class(to);
+  const int fb = type_bits(from), tb = type_bits(to);
+  if (fc == CLS_FLOAT) return tc == CLS_FLOAT && tb >= fb;
+  if (tc == CLS_FLOAT) return to == DBHIP_T_F64 ? fb <= 32 : fb <= 16;  // exactly representable
+  if (fc == CLS_UNSIGNED) return tb > fb || (tc == CLS_UNSIGNED && tb == fb);
+  return tc == CLS_SIGNED && tb >= fb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const dbhip_col* inputs_host, int32_t n_inputs,
+                        int64_t n, int32_t out_reg, void* out_values, uint8_t* out_validity, uint8_t* err_bitmap,
+                        uint64_t* err_count_dev, void* sum_out_dev, void* stream) {
+  DBHIP_REQUIRE(prog_host && n_ins >= 1 && n_ins <= EX_MAX_INS, "dbhip_expr_eval: 1..32 instructions");
+  DBHIP_REQUIRE(n_inputs >= 0 && n_inputs <= EX_MAX_INPUTS && (inputs_host || n_inputs == 0), "dbhip_expr_eval: 0..8 input columns");
+  DBHIP_REQUIRE(out_reg >= 0 && out_reg < EX_MAX_REGS && n >= 0, "dbhip_expr_eval: bad out register / n");
+  ExProg P;
+  memset(&P, 0, sizeof(P));
+  int reg_type[EX_MAX_REGS];
+  for (int r = 0; r < EX_MAX_REGS; ++r) reg_type[r] = -1;
+  bool any_nullable = false, may_raise = false;
+  for (int c = 0; c < n_inputs; ++c) {
+    const dbhip_col& col = inputs_host[c];
+    if (!(ex_numeric(col.type) || col.type == DBHIP_T_BOOL)) {
+      set_error("dbhip_expr_eval: input %d has type %d (numeric, date, timestamp, decimal64-as-i64 and boolean columns only)", c, col.type);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    DBHIP_REQUIRE(col.data || n == 0, "dbhip_expr_eval: NULL input column");
+    P.in_data[c] = col.data; P.in_valid[c] = col.validity; P.in_voff[c] = col.validity_offset;
+    P.in_type[c] = col.type; P.in_scalar[c] = col.is_scalar;
+  }
+  for (int i = 0; i < n_ins; ++i) {
+    const dbhip_expr_ins& s = prog_host[i];
+    ExIns& d = P.ins[i];
+    if (s.dst < 0 || s.dst >= EX_MAX_REGS) { set_error("dbhip_expr_eval: instruction %d: register %d out of range (0..7)", i, s.dst); return DBHIP_ERR_INVALID; }
+    d.op = (int16_t)s.op; d.dst = (int16_t)s.dst; d.a = (int16_t)s.a; d.b = (int16_t)s.b; d.type = (int16_t)s.type; d.imm = s.imm;
+    auto src = [&](int r) -> int { return (r >= 0 && r < EX_MAX_REGS) ? reg_type[r] : -1; };
+    switch (s.op) {
+      case DBHIP_EX_LOAD:
+        if (s.a < 0 || s.a >= n_inputs || inputs_host[s.a].type != s.type) { set_error("dbhip_expr_eval: instruction %d: LOAD of input %d as type %d", i, s.a, s.type); return DBHIP_ERR_INVALID; }
+        any_nullable |= inputs_host[s.a].validity != nullptr;
+        break;
+      case DBHIP_EX_CONST:
+        if (!(ex_numeric(s.type) || s.type == DBHIP_T_BOOL)) { set_error("dbhip_expr_eval: instruction %d: CONST of type %d", i, s.type); return DBHIP_ERR_INVALID; }
+        break;
+      case DBHIP_EX_PLUS: case DBHIP_EX_MINUS: case DBHIP_EX_MULTIPLY: case DBHIP_EX_DIVIDE: {
+        const int ta = src(s.a), tb = src(s.b);
+        const int aop = s.op == DBHIP_EX_PLUS ? DBHIP_OP_PLUS : s.op == DBHIP_EX_MINUS ? DBHIP_OP_MINUS : s.op == DBHIP_EX_MULTIPLY ? DBHIP_OP_MULTIPLY : DBHIP_OP_DIVIDE;
+        if (ta < 0 || tb < 0 || !ex_numeric(ta) || !ex_numeric(tb) || dbhip_arith_result_type(aop, ta, tb) != s.type) {
+          set_error("dbhip_expr_eval: instruction %d: op %d on types (%d,%d) does not yield type %d (arithmetics_type.rs)", i, s.op, ta, tb, s.type);
+          return DBHIP_ERR_INVALID;
+        }
+        d.ta = (int16_t)ta; d.tb = (int16_t)tb;
+        may_raise |= s.op == DBHIP_EX_DIVIDE;
+      } break;
+      case DBHIP_EX_EQ: case DBHIP_EX_NOTEQ: case DBHIP_EX_LT: case DBHIP_EX_LTE: case DBHIP_EX_GT: case DBHIP_EX_GTE: {
+        const int ta = src(s.a), tb = src(s.b);
+        if (ta < 0 || ta != tb || s.type != DBHIP_T_BOOL) { set_error("dbhip_expr_eval: instruction %d: comparison needs equal operand types (%d,%d) and a Boolean result", i, ta, tb); return DBHIP_ERR_INVALID; }
+        d.ta = (int16_t)ta; d.tb = (int16_t)tb;
+      } break;
+      case DBHIP_EX_AND: case DBHIP_EX_OR: case DBHIP_EX_NOT: {
+        const int ta = src(s.a), tb = s.op == DBHIP_EX_NOT ? DBHIP_T_BOOL : src(s.b);
+        if (ta != DBHIP_T_BOOL || tb != DBHIP_T_BOOL || s.type != DBHIP_T_BOOL) { set_error("dbhip_expr_eval: instruction %d: Boolean operator on non-Boolean registers", i); return DBHIP_ERR_INVALID; }
+        d.ta = d.tb = DBHIP_T_BOOL;
+      } break;
+      case DBHIP_EX_CAST: {
+        const int ta = src(s.a);
+        if (ta < 0 || !ex_numeric(ta) || !ex_numeric(s.type)) { set_error("dbhip_expr_eval: instruction %d: CAST %d -> %d", i, ta, s.type); return DBHIP_ERR_INVALID; }
+        if (!ex_lossless_cast(ta, s.type)) { set_error("dbhip_expr_eval: CAST %d -> %d can overflow: keep the checked CPU cast", ta, s.type); return DBHIP_ERR_UNSUPPORTED; }
+        d.ta = (int16_t)ta;
+      } break;
+      default:
+        set_error("dbhip_expr_eval: instruction %d: unknown op %d", i, s.op);
+        return DBHIP_ERR_INVALID;
+    }
+    reg_type[s.dst] = s.type;
+  }
+  if (reg_type[out_reg] < 0) { set_error("dbhip_expr_eval: out register %d is never written", out_reg); return DBHIP_ERR_INVALID; }
+  DBHIP_REQUIRE(out_values || sum_out_dev, "dbhip_expr_eval: neither an output column nor a sum was asked for");
+  DBHIP_REQUIRE(!sum_out_dev || ex_numeric(reg_type[out_reg]), "dbhip_expr_eval: sum needs a numeric result");
+  DBHIP_REQUIRE(!any_nullable || out_validity || sum_out_dev, "dbhip_expr_eval: nullable inputs need out_validity");
+  hipStream_t s = resolve_stream(stream);
+  if (err_bitmap) DBHIP_CHECK(hipMemsetAsync(err_bitmap, 0xFF, (size_t)ceil_div(n, 32) * 4, s));
+  if (n == 0) return DBHIP_OK;
+  P.n_ins = n_ins; P.n_inputs = n_inputs; P.out_reg = out_reg; P.out_type = reg_type[out_reg]; P.n = n;
+  P.out_values = out_values; P.out_validity = (uint64_t*)out_validity;
+  P.err_words = may_raise ? (uint32_t*)err_bitmap : nullptr;
+  P.err_count = may_raise ? (unsigned long long*)err_count_dev : nullptr;
+  P.sum_out = (unsigned long long*)sum_out_dev;
+  const int64_t chunks = ceil_div(n, 64 * EX_ROWS);
+  int grid = (int)(ceil_div(chunks, 4) < 2048 ? ceil_div(chunks, 4) : 2048);
+  kernel_timer_start(s);
+  hipLaunchKernelGGL(expr_kernel, dim3(grid), dim3(256), 0, s, P);
+  kernel_timer_stop(s);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+}  // extern "C"

@@ -372,6 +372,83 @@ def column_sum(col):
     return int(out.to_numpy(np.int64, 1)[0])
 
 
+class ExprProgram:
+    """Post-order flattening of an Expr tree into the register program of dbhip_expr_eval (the job of the binding's
+    Evaluator::run replacement). Methods return the register that holds the node's value."""
+
+    ARITH = {L.EX_PLUS: L.OP_PLUS, L.EX_MINUS: L.OP_MINUS, L.EX_MULTIPLY: L.OP_MULTIPLY, L.EX_DIVIDE: L.OP_DIVIDE}
+
+    def __init__(self, inputs):
+        self.inputs = list(inputs)
+        self.ins = []
+        self.types = {}
+        self.free = list(range(8))
+
+    def _emit(self, op, a, b, typ, imm=0, release=()):
+        for r in release:
+            if r not in self.free:
+                self.free.append(r)
+        self.free.sort()
+        dst = self.free.pop(0)
+        self.ins.append((op, dst, a, b, typ, imm))
+        self.types[dst] = typ
+        return dst
+
+    def load(self, i):
+        return self._emit(L.EX_LOAD, i, 0, self.inputs[i].dtype)
+
+    def const(self, value, typ):
+        if typ in (L.T_F32, L.T_F64):
+            imm = int(np.float64(np.float32(value) if typ == L.T_F32 else value).view(np.uint64))
+        else:
+            imm = int(value) & ((1 << 64) - 1)
+        return self._emit(L.EX_CONST, 0, 0, typ, imm)
+
+    def arith(self, op, a, b):
+        typ = lib().dbhip_arith_result_type(self.ARITH[op], self.types[a], self.types[b])
+        return self._emit(op, a, b, typ, release=(a, b))
+
+    def cmp(self, op, a, b):
+        return self._emit(op, a, b, L.T_BOOL, release=(a, b))
+
+    def logic(self, op, a, b=0):
+        return self._emit(op, a, b, L.T_BOOL, release=(a,) if op == L.EX_NOT else (a, b))
+
+    def cast(self, a, typ):
+        return self._emit(L.EX_CAST, a, 0, typ, release=(a,))
+
+    def run(self, out_reg, n=None, want_values=True, want_sum=False, errors=None):
+        """-> dict(values=np array | bool array, validity=bool array | None, sum=int/float | None)"""
+        n = self.inputs[0].n if n is None else n
+        prog = (L.ExprIns * len(self.ins))()
+        for k, (op, dst, a, b, typ, imm) in enumerate(self.ins):
+            prog[k].op, prog[k].dst, prog[k].a, prog[k].b, prog[k].type, prog[k].imm = op, dst, a, b, typ, imm
+        ot = self.types[out_reg]
+        words = (max(n, 1) + 63) // 64
+        nullable = any(c.validity is not None for c in self.inputs)
+        vals = None
+        if want_values:
+            vals = DeviceBuffer(words * 8 if ot == L.T_BOOL else max(n, 1) * ELEM_SIZE[ot] + 64)
+        vbuf = DeviceBuffer(words * 8) if nullable else None
+        sbuf = None
+        if want_sum:
+            sbuf = DeviceBuffer(8)
+            sbuf.zero()
+        check(lib().dbhip_expr_eval(prog, len(self.ins), _cols(self.inputs), len(self.inputs), C.c_int64(n), out_reg,
+                                    C.c_void_p(vals.ptr) if vals else None, C.c_void_p(vbuf.ptr) if vbuf else None,
+                                    C.c_void_p(errors.bitmap.ptr) if errors else None, C.c_void_p(errors.count.ptr) if errors else None,
+                                    C.c_void_p(sbuf.ptr) if sbuf else None, None))
+        out = dict(values=None, validity=None, sum=None, type=ot)
+        if vals is not None:
+            out["values"] = unpack_bits(vals.to_numpy(np.uint8, words * 8), n) if ot == L.T_BOOL else vals.to_numpy(NP_OF[ot], n)
+        if vbuf is not None:
+            out["validity"] = unpack_bits(vbuf.to_numpy(np.uint8, words * 8), n)
+        if sbuf is not None:
+            cls_float = ot in (L.T_F32, L.T_F64)
+            out["sum"] = float(sbuf.to_numpy(np.float64, 1)[0]) if cls_float else int(sbuf.to_numpy(np.int64 if ot in (L.T_I8, L.T_I16, L.T_I32, L.T_I64, L.T_DATE, L.T_TIMESTAMP, L.T_DEC64) else np.uint64, 1)[0])
+        return out
+
+
 class GroupBy:
     """Device AggregateHashTable (dbhip_groupby_*)."""
 

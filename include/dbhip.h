@@ -153,6 +153,43 @@ int32_t dbhip_sum_a_plus_b_mul_c_i64(const int64_t* a, const int64_t* b, const i
  * (i64/u64 wrapping, f64 pairwise — see DESIGN.md for the float caveat). */
 int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stream);
 
+/* ---- a1 + §8f-2: fused expression evaluation ---------------------------------
+ * Replaces Evaluator::run over a whole Expr tree (src/query/expression/src/evaluator.rs:229-464) /
+ * BlockOperator::Map (src/query/sql/src/evaluator/block_operator.rs:42-85): instead of one kernel and one
+ * materialised column per call node, the binding flattens the tree (post-order) into a register program
+ * that ONE launch interprets; intermediates live in LDS, never in HBM. Registers 0..7; up to 32
+ * instructions and 8 input columns (numeric / Date / Timestamp / Decimal64-as-i64 / Boolean).
+ * Per-node semantics are those of dbhip_arith / dbhip_cmp (same reference lines): `type` is the node's
+ * result type and must be the ResultTypeOfBinary entry for the operand registers' types (checked);
+ * comparisons need equal operand types (the planner inserts CASTs; DBHIP_EX_CAST covers the lossless
+ * widenings, anything that can overflow returns DBHIP_ERR_UNSUPPORTED); DIVIDE raises "divided by zero"
+ * like dbhip_arith. NULLs: the result is NULL where any loaded nullable input is NULL
+ * (passthrough_nullable, register_vectorize.rs:447-471); Boolean AND/OR are strict here (the three-valued
+ * and_filters/or_filters special case, evaluator.rs:284-305, stays with dbhip_bitmap_binary).
+ * Outputs: `out_values` = elements of the out register's type, or for a Boolean result an LSB-first
+ * bitmap; `out_validity` likewise a bitmap. Bitmaps are written as whole 64-bit words: both buffers must
+ * hold ceil(n/64)*8 bytes and be 8-byte aligned; bits past n are zero. `sum_out_dev` (may be NULL): the
+ * wrapping i64/u64 (or f64) sum of the out register over the non-NULL rows is ADDED to *sum_out_dev —
+ * `SELECT sum(<expr>)` (BASELINE configs[0]) without materialising <expr>; out_values may then be NULL. */
+typedef enum {
+  DBHIP_EX_LOAD = 0,     /* dst <- input column `a`                                 */
+  DBHIP_EX_CONST = 1,    /* dst <- imm (i64 / u64 value, or f64 bits for F32/F64)   */
+  DBHIP_EX_PLUS = 2, DBHIP_EX_MINUS = 3, DBHIP_EX_MULTIPLY = 4, DBHIP_EX_DIVIDE = 5,
+  DBHIP_EX_EQ = 6, DBHIP_EX_NOTEQ = 7, DBHIP_EX_LT = 8, DBHIP_EX_LTE = 9, DBHIP_EX_GT = 10, DBHIP_EX_GTE = 11,
+  DBHIP_EX_AND = 12, DBHIP_EX_OR = 13, DBHIP_EX_NOT = 14, DBHIP_EX_CAST = 15
+} dbhip_expr_op;
+typedef struct {
+  int32_t op;            /* dbhip_expr_op                                           */
+  int32_t dst, a, b;     /* registers (a = input column index for LOAD)             */
+  int32_t type;          /* dbhip_type of the result                                */
+  int32_t _pad;
+  uint64_t imm;
+} dbhip_expr_ins;
+int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const dbhip_col* inputs_host,
+                        int32_t n_inputs, int64_t n, int32_t out_reg, void* out_values,
+                        uint8_t* out_validity, uint8_t* err_bitmap, uint64_t* err_count_dev,
+                        void* sum_out_dev, void* stream);
+
 /* ---- a4: decimal arithmetic ------------------------------------------------
  * Replaces binary_decimal (decimal/src/arithmetic.rs:190-316) after the operands
  * were brought to (left_size, right_size) by ArithmeticOp::result_size (:80-139).

@@ -537,3 +537,106 @@ def test_groupby_short_layout_string_key_and_f64_sum(gpu, oracle):
         e[0] += v
         e[1] += 1
     assert sorted(g.result()) == sorted((k, v[0], v[1]) for k, v in exp.items())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused expression evaluation (dbhip_expr_eval): one launch per Expr tree == the chain of per-node kernels, which
+# are themselves checked against the oracle above
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 63, 64, 129, 100_003])
+def test_fused_expression_equals_operator_at_a_time(gpu, oracle, n):
+    rng = np.random.default_rng(n)
+    a64 = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    b64 = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    c64 = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    a32 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    u8 = rng.integers(0, 256, n).astype(np.uint8)
+    i16 = rng.integers(-2**15, 2**15 - 1, n).astype(np.int16)
+    f32 = rng.standard_normal(n).astype(np.float32)
+    f64 = rng.standard_normal(n)
+    if n > 10:
+        f32[3], f64[4] = np.nan, np.nan
+        u8[5:9] = 0
+    va, vb = rng.integers(0, 4, n) > 0, rng.integers(0, 5, n) > 0
+    X = gpu.ExprProgram
+
+    # 1. sum(a + b * c), Int64 wrapping (BASELINE configs[0]) - values and the fused sum
+    cols = [gpu.Column.from_numpy(a64), gpu.Column.from_numpy(b64), gpu.Column.from_numpy(c64)]
+    p = X(cols)
+    r = p.arith(T.EX_PLUS, p.load(0), p.arith(T.EX_MULTIPLY, p.load(1), p.load(2)))
+    out = p.run(r, want_sum=True)
+    exp = (a64.astype(np.uint64) + b64.astype(np.uint64) * c64.astype(np.uint64)).astype(np.int64)
+    assert np.array_equal(out["values"], exp) and out["type"] == T.T_I64
+    assert out["sum"] == int(exp.astype(np.uint64).sum(dtype=np.uint64).astype(np.int64))
+    assert out["sum"] == gpu.sum_a_plus_b_mul_c(*cols)
+
+    # 2. (a32 * u8) - i16 with nullable inputs: types Int32*UInt8 -> Int64, - Int16 -> Int64; validity = AND
+    cols = [gpu.Column.from_numpy(a32, validity=va), gpu.Column.from_numpy(u8), gpu.Column.from_numpy(i16, validity=vb)]
+    p = X(cols)
+    r = p.arith(T.EX_MINUS, p.arith(T.EX_MULTIPLY, p.load(0), p.load(1)), p.load(2))
+    out = p.run(r, want_sum=True)
+    step = gpu.arith(T.OP_MINUS, gpu.arith(T.OP_MULTIPLY, cols[0], cols[1]), cols[2])
+    assert out["type"] == step.dtype and np.array_equal(out["values"], step.to_numpy())
+    assert np.array_equal(out["validity"], va & vb)
+    assert out["sum"] == int(step.to_numpy()[va & vb].astype(np.int64).sum())
+
+    # 3. f32 * f64 + i64 -> Float64; f32 + f32 stays Float32 (rounded per node like the per-node kernels)
+    cols = [gpu.Column.from_numpy(f32), gpu.Column.from_numpy(f64), gpu.Column.from_numpy(a32.astype(np.int64))]
+    p = X(cols)
+    r = p.arith(T.EX_PLUS, p.arith(T.EX_MULTIPLY, p.load(0), p.load(1)), p.load(2))
+    out = p.run(r)
+    step = gpu.arith(T.OP_PLUS, gpu.arith(T.OP_MULTIPLY, cols[0], cols[1]), cols[2])
+    assert out["type"] == T.T_F64 and np.array_equal(out["values"], step.to_numpy(), equal_nan=True)
+    p = X(cols)
+    r = p.arith(T.EX_MINUS, p.arith(T.EX_PLUS, p.load(0), p.load(0)), p.load(0))
+    out = p.run(r)
+    step = gpu.arith(T.OP_MINUS, gpu.arith(T.OP_PLUS, cols[0], cols[0]), cols[0])
+    assert out["type"] == T.T_F32 and np.array_equal(out["values"], step.to_numpy(), equal_nan=True)
+
+    # 4. a32 / u8 with zeros in u8: per-row "divided by zero" errors only on valid rows, same rows as dbhip_arith
+    cols = [gpu.Column.from_numpy(a32, validity=va), gpu.Column.from_numpy(u8)]
+    p = X(cols)
+    r = p.arith(T.EX_DIVIDE, p.load(0), p.load(1))
+    e1, e2 = gpu.RowErrors(n), gpu.RowErrors(n)
+    out = p.run(r, errors=e1)
+    step = gpu.arith(T.OP_DIVIDE, cols[0], cols[1], errors=e2)
+    assert np.array_equal(out["values"], step.to_numpy(), equal_nan=True)
+    assert e1.num_errors() == e2.num_errors() == int(((u8 == 0) & va).sum())
+    assert np.array_equal(e1.error_rows(), e2.error_rows())
+
+    # 5. predicate (i16 <= 100) AND (f64 > f64') OR NOT(u8 = 0): Boolean result as a Bitmap
+    g64 = rng.standard_normal(n)
+    cols = [gpu.Column.from_numpy(i16), gpu.Column.from_numpy(f64), gpu.Column.from_numpy(g64), gpu.Column.from_numpy(u8)]
+    p = X(cols)
+    c1 = p.cmp(T.EX_LTE, p.load(0), p.const(100, T.T_I16))
+    c2 = p.cmp(T.EX_GT, p.load(1), p.load(2))
+    c3 = p.logic(T.EX_NOT, p.cmp(T.EX_EQ, p.load(3), p.const(0, T.T_U8)))
+    r = p.logic(T.EX_OR, p.logic(T.EX_AND, c1, c2), c3)
+    out = p.run(r)
+    m1 = gpu.cmp(T.CMP_LTE, cols[0], gpu.Column.scalar(100, T.T_I16), n).to_numpy()
+    m2 = gpu.cmp(T.CMP_GT, cols[1], cols[2], n).to_numpy()
+    m3 = gpu.cmp(T.CMP_NOTEQ, cols[3], gpu.Column.scalar(0, T.T_U8), n).to_numpy()
+    assert np.array_equal(out["values"], (m1 & m2) | m3)
+
+    # 6. CAST(i32 AS Int64) = i64 ; a cast that can overflow is refused (the checked CPU cast stays)
+    cols = [gpu.Column.from_numpy(a32), gpu.Column.from_numpy(a32.astype(np.int64) + (rng.integers(0, 2, n)))]
+    p = X(cols)
+    r = p.cmp(T.EX_EQ, p.cast(p.load(0), T.T_I64), p.load(1))
+    assert np.array_equal(p.run(r)["values"], a32.astype(np.int64) == cols[1].to_numpy())
+    p = X(cols)
+    with pytest.raises(Exception):
+        p.run(p.cast(p.load(1), T.T_I32))
+
+
+def test_fused_expression_rejects_ill_typed_programs(gpu):
+    from databend_amd._lib import DbhipError
+    cols = [gpu.Column.from_numpy(np.arange(10, dtype=np.int32)), gpu.Column.from_numpy(np.arange(10, dtype=np.int64))]
+    p = gpu.ExprProgram(cols)
+    a, b = p.load(0), p.load(1)
+    with pytest.raises(DbhipError):   # comparison of different operand types: the planner must insert a CAST
+        p.run(p.cmp(T.EX_LT, a, b))
+    p = gpu.ExprProgram(cols)
+    r = p.arith(T.EX_PLUS, p.load(0), p.load(1))
+    p.ins[-1] = p.ins[-1][:4] + (T.T_I32,) + p.ins[-1][5:]   # wrong result type for Int32 + Int64
+    with pytest.raises(DbhipError):
+        p.run(r)

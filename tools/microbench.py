@@ -138,6 +138,17 @@ def main():
             check(Lb.dbhip_arith(L.OP_PLUS, C.byref(ca_), C.byref(ct1), C.c_int64(N), L.T_I64, C.c_void_p(t2.data_ptr()), None, None, None))
             check(Lb.dbhip_sum(C.byref(ct2), C.c_int64(N), C.c_void_p(s.data_ptr()), None))
         report(out, "sum(a+b*c) operator-at-a-time (3 kernels)", N, "rows", alg_bytes=24 * N, ms=timed(plan), note="moves 56 B/row")
+        # the same tree through the fused expression interpreter (dbhip_expr_eval): one launch, 24 B/row
+        prog = (L.ExprIns * 5)()
+        for k, (op, dst, x, y) in enumerate([(L.EX_LOAD, 0, 0, 0), (L.EX_LOAD, 1, 1, 0), (L.EX_LOAD, 2, 2, 0), (L.EX_MULTIPLY, 1, 1, 2), (L.EX_PLUS, 0, 0, 1)]):
+            prog[k].op, prog[k].dst, prog[k].a, prog[k].b, prog[k].type = op, dst, x, y, L.T_I64
+        cols3 = (L.Col * 3)(ca_, cb_, cc_)
+        fx = lambda: check(Lb.dbhip_expr_eval(prog, 5, cols3, 3, C.c_int64(N), 0, None, None, None, None, C.c_void_p(s.data_ptr()), None))
+        report(out, "sum(a+b*c) fused expression program (dbhip_expr_eval, sum only)", N, "rows", alg_bytes=24 * N, ms=timed(fx))
+        t3 = torch.empty(N + 8, dtype=torch.int64, device=dev)
+        fy = lambda: check(Lb.dbhip_expr_eval(prog, 5, cols3, 3, C.c_int64(N), 0, C.c_void_p(t3.data_ptr()), None, None, None, None, None))
+        report(out, "a+b*c fused expression program -> column", N, "rows", alg_bytes=32 * N, ms=timed(fy))
+        del t3
         del t1, t2
 
     if want("decimal"):
