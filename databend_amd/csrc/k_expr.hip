@@ -29,7 +29,7 @@ namespace {
 constexpr int EX_MAX_INS = 32;
 constexpr int EX_MAX_REGS = 8;
 constexpr int EX_MAX_INPUTS = 8;
-constexpr int EX_ROWS = 2;  // row slots per lane
+constexpr int EX_ROWS = 4;  // row slots per lane
 
 struct ExIns {
   int16_t op, dst, a, b;   // a = input index for LOAD
@@ -45,7 +45,7 @@ struct ExProg {
   int64_t in_voff[EX_MAX_INPUTS];
   int32_t in_type[EX_MAX_INPUTS];
   int32_t in_scalar[EX_MAX_INPUTS];
-  int32_t n_ins, n_inputs, out_reg, out_type;
+  int32_t n_ins, n_inputs, out_reg, out_type, n_temps;
   int64_t n;
   void* out_values;              // numeric: elements of out_type; BOOL: bitmap words
   uint64_t* out_validity;        // bitmap words (may be NULL)
@@ -103,8 +103,12 @@ enum {
   EX_AND = 12, EX_OR = 13, EX_NOT = 14, EX_CAST = 15
 };
 
+// Register numbering inside the kernel: 0 .. n_temps-1 are temporaries, n_temps + c is input column c. The host
+// compiles LOAD instructions away (an operand that names a loaded register is rewritten to the input register), so
+// that ALL column loads of a chunk are issued back to back before the first instruction is interpreted — with the
+// loads inside the interpreter loop every LOAD would cost a full HBM round trip of its own.
 __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
-  __shared__ uint64_t regs[EX_MAX_REGS][EX_ROWS][256];
+  extern __shared__ uint64_t ex_regs[];  // [n_temps + n_inputs][EX_ROWS][256]
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t rows_per_wave = 64 * EX_ROWS;
   const int64_t nchunks = (P.n + rows_per_wave - 1) / rows_per_wave;
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
   const int out_cls = P.out_type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(P.out_type);
   uint64_t acc_i = 0;
   double acc_f = 0.0;
+#define EX_REG(r, k) ex_regs[((r) * EX_ROWS + (k)) * 256 + tid]
 
   for (int64_t c = wave_global; c < nchunks; c += nwaves) {
     const int64_t base = c * rows_per_wave;
@@ -125,24 +130,40 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
       valid[k] = in_range[k];
       if (!in_range[k]) row[k] = P.n - 1;  // clamp: loads stay in bounds, results are masked
     }
+    // ---- all input loads of the chunk, back to back ----
+    uint64_t in[EX_MAX_INPUTS][EX_ROWS];
+#pragma unroll
+    for (int ci = 0; ci < EX_MAX_INPUTS; ++ci) {
+      if (ci < P.n_inputs) {
+#pragma unroll
+        for (int k = 0; k < EX_ROWS; ++k) {
+          const int64_t j = P.in_scalar[ci] ? 0 : row[k];
+          in[ci][k] = ex_load(P.in_data[ci], P.in_type[ci], j);
+          if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + j);
+        }
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < EX_MAX_INPUTS; ++ci) {
+      if (ci < P.n_inputs) {
+#pragma unroll
+        for (int k = 0; k < EX_ROWS; ++k) EX_REG(P.n_temps + ci, k) = in[ci][k];
+      }
+    }
+    // ---- interpret (wave-uniform instruction stream) ----
     for (int pc = 0; pc < P.n_ins; ++pc) {
       const ExIns I = P.ins[pc];
+      const int acls = I.ta == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.ta);
+      const int bcls = I.tb == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.tb);
+      const int ocls = I.type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.type);
 #pragma unroll
       for (int k = 0; k < EX_ROWS; ++k) {
         uint64_t r;
-        if (I.op == EX_LOAD) {
-          const int c_ = I.a;
-          const int64_t j = P.in_scalar[c_] ? 0 : row[k];
-          r = ex_load(P.in_data[c_], P.in_type[c_], j);
-          if (P.in_valid[c_]) valid[k] = valid[k] && bit_get(P.in_valid[c_], P.in_voff[c_] + j);
-        } else if (I.op == EX_CONST) {
+        if (I.op == EX_CONST) {
           r = I.imm;
         } else {
-          const uint64_t x = regs[I.a][k][tid];
-          const uint64_t y = (I.op == EX_NOT || I.op == EX_CAST) ? 0 : regs[I.b][k][tid];
-          const int acls = I.ta == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.ta);
-          const int bcls = I.tb == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.tb);
-          const int ocls = I.type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.type);
+          const uint64_t x = EX_REG(I.a, k);
+          const uint64_t y = (I.op == EX_NOT || I.op == EX_CAST) ? 0 : EX_REG(I.b, k);
           switch (I.op) {
             case EX_PLUS: case EX_MINUS: case EX_MULTIPLY:
               if (ocls == CLS_FLOAT) {
@@ -181,13 +202,13 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
               break;
           }
         }
-        regs[I.dst][k][tid] = r;
+        EX_REG(I.dst, k) = r;
       }
     }
     // ---- result ----
 #pragma unroll
     for (int k = 0; k < EX_ROWS; ++k) {
-      const uint64_t r = regs[P.out_reg][k][tid];
+      const uint64_t r = EX_REG(P.out_reg, k);
       const int64_t word = (base >> 6) + k;  // 64-row word of this slot
       if (P.out_values) {
         if (P.out_type == DBHIP_T_BOOL) {
@@ -213,6 +234,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
       }
     }
   }
+#undef EX_REG
   if (P.sum_out) {
     if (out_cls == CLS_FLOAT) {
 #pragma unroll
@@ -250,7 +272,9 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   ExProg P;
   memset(&P, 0, sizeof(P));
   int reg_type[EX_MAX_REGS];
-  for (int r = 0; r < EX_MAX_REGS; ++r) reg_type[r] = -1;
+  int reg_loc[EX_MAX_REGS];  // where the register's current value lives: temp r, or EX_MAX_REGS + input column
+  int n_out = 0;             // instructions kept (LOADs are compiled away)
+  for (int r = 0; r < EX_MAX_REGS; ++r) { reg_type[r] = -1; reg_loc[r] = r; }
   bool any_nullable = false, may_raise = false;
   for (int c = 0; c < n_inputs; ++c) {
     const dbhip_col& col = inputs_host[c];
@@ -264,15 +288,19 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   }
   for (int i = 0; i < n_ins; ++i) {
     const dbhip_expr_ins& s = prog_host[i];
-    ExIns& d = P.ins[i];
+    ExIns& d = P.ins[n_out];
     if (s.dst < 0 || s.dst >= EX_MAX_REGS) { set_error("dbhip_expr_eval: instruction %d: register %d out of range (0..7)", i, s.dst); return DBHIP_ERR_INVALID; }
-    d.op = (int16_t)s.op; d.dst = (int16_t)s.dst; d.a = (int16_t)s.a; d.b = (int16_t)s.b; d.type = (int16_t)s.type; d.imm = s.imm;
+    d.op = (int16_t)s.op; d.dst = (int16_t)s.dst; d.type = (int16_t)s.type; d.imm = s.imm;
+    d.a = (int16_t)((s.a >= 0 && s.a < EX_MAX_REGS) ? reg_loc[s.a] : 0);
+    d.b = (int16_t)((s.b >= 0 && s.b < EX_MAX_REGS) ? reg_loc[s.b] : 0);
     auto src = [&](int r) -> int { return (r >= 0 && r < EX_MAX_REGS) ? reg_type[r] : -1; };
     switch (s.op) {
       case DBHIP_EX_LOAD:
         if (s.a < 0 || s.a >= n_inputs || inputs_host[s.a].type != s.type) { set_error("dbhip_expr_eval: instruction %d: LOAD of input %d as type %d", i, s.a, s.type); return DBHIP_ERR_INVALID; }
         any_nullable |= inputs_host[s.a].validity != nullptr;
-        break;
+        reg_type[s.dst] = s.type;
+        reg_loc[s.dst] = EX_MAX_REGS + s.a;
+        continue;  // no instruction: the value is read straight from the input register
       case DBHIP_EX_CONST:
         if (!(ex_numeric(s.type) || s.type == DBHIP_T_BOOL)) { set_error("dbhip_expr_eval: instruction %d: CONST of type %d", i, s.type); return DBHIP_ERR_INVALID; }
         break;
@@ -307,6 +335,8 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
         return DBHIP_ERR_INVALID;
     }
     reg_type[s.dst] = s.type;
+    reg_loc[s.dst] = s.dst;
+    ++n_out;
   }
   if (reg_type[out_reg] < 0) { set_error("dbhip_expr_eval: out register %d is never written", out_reg); return DBHIP_ERR_INVALID; }
   DBHIP_REQUIRE(out_values || sum_out_dev, "dbhip_expr_eval: neither an output column nor a sum was asked for");
@@ -315,7 +345,9 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   hipStream_t s = resolve_stream(stream);
   if (err_bitmap) DBHIP_CHECK(hipMemsetAsync(err_bitmap, 0xFF, (size_t)ceil_div(n, 32) * 4, s));
   if (n == 0) return DBHIP_OK;
-  P.n_ins = n_ins; P.n_inputs = n_inputs; P.out_reg = out_reg; P.out_type = reg_type[out_reg]; P.n = n;
+  // kernel register numbering: temporaries 0..7 keep their index, input column c becomes register 8 + c -> n_temps + c
+  P.n_temps = EX_MAX_REGS;
+  P.n_ins = n_out; P.n_inputs = n_inputs; P.out_reg = reg_loc[out_reg]; P.out_type = reg_type[out_reg]; P.n = n;
   P.out_values = out_values; P.out_validity = (uint64_t*)out_validity;
   P.err_words = may_raise ? (uint32_t*)err_bitmap : nullptr;
   P.err_count = may_raise ? (unsigned long long*)err_count_dev : nullptr;
@@ -323,7 +355,22 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   const int64_t chunks = ceil_div(n, 64 * EX_ROWS);
   int grid = (int)(ceil_div(chunks, 4) < 2048 ? ceil_div(chunks, 4) : 2048);
   kernel_timer_start(s);
-  hipLaunchKernelGGL(expr_kernel, dim3(grid), dim3(256), 0, s, P);
+  // shrink the LDS register file to what the program touches: temporaries are renumbered densely
+  {
+    int remap[EX_MAX_REGS], nt = 0;
+    for (int r = 0; r < EX_MAX_REGS; ++r) remap[r] = -1;
+    for (int i = 0; i < n_out; ++i) if (remap[P.ins[i].dst] < 0) remap[P.ins[i].dst] = nt++;
+    auto mp = [&](int r) { return r >= EX_MAX_REGS ? nt + (r - EX_MAX_REGS) : (remap[r] < 0 ? 0 : remap[r]); };
+    for (int i = 0; i < n_out; ++i) { P.ins[i].a = (int16_t)mp(P.ins[i].a); P.ins[i].b = (int16_t)mp(P.ins[i].b); P.ins[i].dst = (int16_t)remap[P.ins[i].dst]; }
+    P.out_reg = mp(P.out_reg);
+    P.n_temps = nt;
+  }
+  const size_t lds = (size_t)(P.n_temps + n_inputs) * EX_ROWS * 256 * 8;
+  if (lds > 64 * 1024) {
+    set_error("dbhip_expr_eval: %d temporaries + %d inputs exceed the LDS register file; split the expression", P.n_temps, n_inputs);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(expr_kernel, dim3(grid), dim3(256), lds, s, P);
   kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
