@@ -29,12 +29,16 @@ namespace {
 constexpr int EX_MAX_INS = 32;
 constexpr int EX_MAX_REGS = 8;
 constexpr int EX_MAX_INPUTS = 8;
-constexpr int EX_ROWS = 4;  // row slots per lane
+constexpr int EX_ROWS = 2;  // row slots per lane
 
+// Everything the interpreter needs is decoded on the host: the scalar unit is shared by the CU's four SIMDs, and a
+// type switch per operand per instruction made the first version SALU bound (483 scalar instructions per 128 rows).
 struct ExIns {
   int16_t op, dst, a, b;   // a = input index for LOAD
-  int16_t type, ta, tb;    // result type, operand types
-  int16_t _pad;
+  int16_t type;            // result type (host side checks only)
+  int8_t acls, bcls, ocls; // CLS_SIGNED / CLS_UNSIGNED / CLS_FLOAT of the operands and the result
+  int8_t norm_sh;          // result width: shift that sign-/zero-extends from the result's bits (0 for 64-bit)
+  int8_t norm_signed, norm_f32;
   uint64_t imm;
 };
 
@@ -43,9 +47,10 @@ struct ExProg {
   const void* in_data[EX_MAX_INPUTS];
   const uint8_t* in_valid[EX_MAX_INPUTS];
   int64_t in_voff[EX_MAX_INPUTS];
-  int32_t in_type[EX_MAX_INPUTS];
+  int32_t in_type[EX_MAX_INPUTS];   // load kind, see ex_load
   int32_t in_scalar[EX_MAX_INPUTS];
   int32_t n_ins, n_inputs, out_reg, out_type, n_temps;
+  int32_t out_kind, out_cls;        // store width in bytes (0 = bitmap, -4 = f32), class of the result
   int64_t n;
   void* out_values;              // numeric: elements of out_type; BOOL: bitmap words
   uint64_t* out_validity;        // bitmap words (may be NULL)
@@ -54,18 +59,18 @@ struct ExProg {
   unsigned long long* sum_out;   // may be NULL: accumulate the sum of the valid rows of out_reg
 };
 
-__device__ __forceinline__ uint64_t ex_load(const void* p, int type, int64_t i) {
-  switch (type) {
-    case DBHIP_T_BOOL: return bit_get((const uint8_t*)p, i);
-    case DBHIP_T_I8: return (uint64_t)(int64_t)((const int8_t*)p)[i];
-    case DBHIP_T_I16: return (uint64_t)(int64_t)((const int16_t*)p)[i];
-    case DBHIP_T_I32: case DBHIP_T_DATE: return (uint64_t)(int64_t)((const int32_t*)p)[i];
-    case DBHIP_T_U8: return ((const uint8_t*)p)[i];
-    case DBHIP_T_U16: return ((const uint16_t*)p)[i];
-    case DBHIP_T_U32: return ((const uint32_t*)p)[i];
-    case DBHIP_T_F32: return (uint64_t)__double_as_longlong((double)((const float*)p)[i]);
-    default: return ((const uint64_t*)p)[i];  // I64, U64, F64 (bits), TIMESTAMP, DEC64
-  }
+// load kinds (host: ex_load_kind): the common 8-byte case is the first test
+enum { LK_8 = 0, LK_S4 = 1, LK_U4 = 2, LK_F4 = 3, LK_S2 = 4, LK_U2 = 5, LK_S1 = 6, LK_U1 = 7, LK_BOOL = 8 };
+__device__ __forceinline__ uint64_t ex_load(const void* p, int kind, int64_t i) {
+  if (kind == LK_8) return ((const uint64_t*)p)[i];
+  if (kind == LK_S4) return (uint64_t)(int64_t)((const int32_t*)p)[i];
+  if (kind == LK_U4) return ((const uint32_t*)p)[i];
+  if (kind == LK_F4) return (uint64_t)__double_as_longlong((double)((const float*)p)[i]);
+  if (kind == LK_S2) return (uint64_t)(int64_t)((const int16_t*)p)[i];
+  if (kind == LK_U2) return ((const uint16_t*)p)[i];
+  if (kind == LK_S1) return (uint64_t)(int64_t)((const int8_t*)p)[i];
+  if (kind == LK_U1) return ((const uint8_t*)p)[i];
+  return bit_get((const uint8_t*)p, i);
 }
 
 __device__ __forceinline__ double ex_to_f64(uint64_t w, int cls) {
@@ -74,18 +79,11 @@ __device__ __forceinline__ double ex_to_f64(uint64_t w, int cls) {
   return (double)w;
 }
 
-// widened register image of `w` (an integer / float result computed in 64 bits) at the node's result type
-__device__ __forceinline__ uint64_t ex_normalise(uint64_t w, int type) {
-  switch (type) {
-    case DBHIP_T_I8: return (uint64_t)(int64_t)(int8_t)w;
-    case DBHIP_T_I16: return (uint64_t)(int64_t)(int16_t)w;
-    case DBHIP_T_I32: case DBHIP_T_DATE: return (uint64_t)(int64_t)(int32_t)w;
-    case DBHIP_T_U8: return w & 0xFFu;
-    case DBHIP_T_U16: return w & 0xFFFFu;
-    case DBHIP_T_U32: return w & 0xFFFFFFFFu;
-    case DBHIP_T_F32: return (uint64_t)__double_as_longlong((double)(float)__longlong_as_double((long long)w));
-    default: return w;
-  }
+// widened register image of `w` at the node's result type, from the host-decoded width (no type switch)
+__device__ __forceinline__ uint64_t ex_norm(uint64_t w, const ExIns& I) {
+  if (I.norm_f32) return (uint64_t)__double_as_longlong((double)(float)__longlong_as_double((long long)w));
+  if (I.norm_sh == 0) return w;
+  return I.norm_signed ? (uint64_t)(((int64_t)(w << I.norm_sh)) >> I.norm_sh) : ((w << I.norm_sh) >> I.norm_sh);
 }
 
 __device__ __forceinline__ int ex_cmp3(uint64_t a, uint64_t b, int cls) {
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
   const int64_t nchunks = (P.n + rows_per_wave - 1) / rows_per_wave;
   const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + tid) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int out_cls = P.out_type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(P.out_type);
+  const int out_cls = P.out_cls;
   uint64_t acc_i = 0;
   double acc_f = 0.0;
 #define EX_REG(r, k) ex_regs[((r) * EX_ROWS + (k)) * 256 + tid]
@@ -153,9 +151,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
     // ---- interpret (wave-uniform instruction stream) ----
     for (int pc = 0; pc < P.n_ins; ++pc) {
       const ExIns I = P.ins[pc];
-      const int acls = I.ta == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.ta);
-      const int bcls = I.tb == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.tb);
-      const int ocls = I.type == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(I.type);
+      const int acls = I.acls, bcls = I.bcls, ocls = I.ocls;
 #pragma unroll
       for (int k = 0; k < EX_ROWS; ++k) {
         uint64_t r;
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
               } else {
                 r = I.op == EX_PLUS ? x + y : (I.op == EX_MINUS ? x - y : x * y);
               }
-              r = ex_normalise(r, I.type);
+              r = ex_norm(r, I);
               break;
             case EX_DIVIDE: {
               const double a = ex_to_f64(x, acls), b = ex_to_f64(y, bcls);
@@ -197,7 +193,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
             case EX_OR: r = (x | y) & 1; break;
             case EX_NOT: r = (x ^ 1) & 1; break;
             default:  // EX_CAST (lossless widenings only, checked on the host)
-              if (ocls == CLS_FLOAT) r = ex_normalise((uint64_t)__double_as_longlong(ex_to_f64(x, acls)), I.type);
+              if (ocls == CLS_FLOAT) r = ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls)), I);
               else r = x;
               break;
           }
@@ -211,17 +207,15 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
       const uint64_t r = EX_REG(P.out_reg, k);
       const int64_t word = (base >> 6) + k;  // 64-row word of this slot
       if (P.out_values) {
-        if (P.out_type == DBHIP_T_BOOL) {
+        if (P.out_kind == 0) {
           const uint64_t m = __ballot(in_range[k] && (r & 1));
           if (lane == 0 && base + 64 * k < P.n) ((uint64_t*)P.out_values)[word] = m;
         } else if (in_range[k]) {
-          switch (P.out_type) {
-            case DBHIP_T_I8: case DBHIP_T_U8: ((uint8_t*)P.out_values)[row[k]] = (uint8_t)r; break;
-            case DBHIP_T_I16: case DBHIP_T_U16: ((uint16_t*)P.out_values)[row[k]] = (uint16_t)r; break;
-            case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_DATE: ((uint32_t*)P.out_values)[row[k]] = (uint32_t)r; break;
-            case DBHIP_T_F32: ((float*)P.out_values)[row[k]] = (float)__longlong_as_double((long long)r); break;
-            default: ((uint64_t*)P.out_values)[row[k]] = r; break;
-          }
+          if (P.out_kind == 8) ((uint64_t*)P.out_values)[row[k]] = r;
+          else if (P.out_kind == 4) ((uint32_t*)P.out_values)[row[k]] = (uint32_t)r;
+          else if (P.out_kind == -4) ((float*)P.out_values)[row[k]] = (float)__longlong_as_double((long long)r);
+          else if (P.out_kind == 2) ((uint16_t*)P.out_values)[row[k]] = (uint16_t)r;
+          else ((uint8_t*)P.out_values)[row[k]] = (uint8_t)r;
         }
       }
       if (P.out_validity) {
@@ -248,6 +242,32 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
 }
 
 bool ex_numeric(int t) { return type_class(t) >= 0; }
+
+int ex_cls(int t) { return t == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(t); }
+
+int ex_load_kind(int t) {
+  switch (t) {
+    case DBHIP_T_BOOL: return LK_BOOL;
+    case DBHIP_T_I8: return LK_S1;
+    case DBHIP_T_U8: return LK_U1;
+    case DBHIP_T_I16: return LK_S2;
+    case DBHIP_T_U16: return LK_U2;
+    case DBHIP_T_I32: case DBHIP_T_DATE: return LK_S4;
+    case DBHIP_T_U32: return LK_U4;
+    case DBHIP_T_F32: return LK_F4;
+    default: return LK_8;
+  }
+}
+
+void ex_decode(ExIns& d, int ta, int tb) {
+  d.acls = (int8_t)(ta >= 0 ? ex_cls(ta) : 0);
+  d.bcls = (int8_t)(tb >= 0 ? ex_cls(tb) : 0);
+  d.ocls = (int8_t)ex_cls(d.type);
+  d.norm_f32 = d.type == DBHIP_T_F32;
+  d.norm_signed = d.ocls == CLS_SIGNED;
+  const int bits = d.type == DBHIP_T_BOOL ? 64 : type_bits(d.type);
+  d.norm_sh = (int8_t)((d.ocls == CLS_FLOAT) ? 0 : 64 - bits);
+}
 
 bool ex_lossless_cast(int from, int to) {
   if (from == to) return true;
@@ -284,7 +304,7 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
     }
     DBHIP_REQUIRE(col.data || n == 0, "dbhip_expr_eval: NULL input column");
     P.in_data[c] = col.data; P.in_valid[c] = col.validity; P.in_voff[c] = col.validity_offset;
-    P.in_type[c] = col.type; P.in_scalar[c] = col.is_scalar;
+    P.in_type[c] = ex_load_kind(col.type); P.in_scalar[c] = col.is_scalar;
   }
   for (int i = 0; i < n_ins; ++i) {
     const dbhip_expr_ins& s = prog_host[i];
@@ -303,6 +323,7 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
         continue;  // no instruction: the value is read straight from the input register
       case DBHIP_EX_CONST:
         if (!(ex_numeric(s.type) || s.type == DBHIP_T_BOOL)) { set_error("dbhip_expr_eval: instruction %d: CONST of type %d", i, s.type); return DBHIP_ERR_INVALID; }
+        ex_decode(d, -1, -1);
         break;
       case DBHIP_EX_PLUS: case DBHIP_EX_MINUS: case DBHIP_EX_MULTIPLY: case DBHIP_EX_DIVIDE: {
         const int ta = src(s.a), tb = src(s.b);
@@ -311,24 +332,24 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
           set_error("dbhip_expr_eval: instruction %d: op %d on types (%d,%d) does not yield type %d (arithmetics_type.rs)", i, s.op, ta, tb, s.type);
           return DBHIP_ERR_INVALID;
         }
-        d.ta = (int16_t)ta; d.tb = (int16_t)tb;
+        ex_decode(d, ta, tb);
         may_raise |= s.op == DBHIP_EX_DIVIDE;
       } break;
       case DBHIP_EX_EQ: case DBHIP_EX_NOTEQ: case DBHIP_EX_LT: case DBHIP_EX_LTE: case DBHIP_EX_GT: case DBHIP_EX_GTE: {
         const int ta = src(s.a), tb = src(s.b);
         if (ta < 0 || ta != tb || s.type != DBHIP_T_BOOL) { set_error("dbhip_expr_eval: instruction %d: comparison needs equal operand types (%d,%d) and a Boolean result", i, ta, tb); return DBHIP_ERR_INVALID; }
-        d.ta = (int16_t)ta; d.tb = (int16_t)tb;
+        ex_decode(d, ta, tb);
       } break;
       case DBHIP_EX_AND: case DBHIP_EX_OR: case DBHIP_EX_NOT: {
         const int ta = src(s.a), tb = s.op == DBHIP_EX_NOT ? DBHIP_T_BOOL : src(s.b);
         if (ta != DBHIP_T_BOOL || tb != DBHIP_T_BOOL || s.type != DBHIP_T_BOOL) { set_error("dbhip_expr_eval: instruction %d: Boolean operator on non-Boolean registers", i); return DBHIP_ERR_INVALID; }
-        d.ta = d.tb = DBHIP_T_BOOL;
+        ex_decode(d, DBHIP_T_BOOL, DBHIP_T_BOOL);
       } break;
       case DBHIP_EX_CAST: {
         const int ta = src(s.a);
         if (ta < 0 || !ex_numeric(ta) || !ex_numeric(s.type)) { set_error("dbhip_expr_eval: instruction %d: CAST %d -> %d", i, ta, s.type); return DBHIP_ERR_INVALID; }
         if (!ex_lossless_cast(ta, s.type)) { set_error("dbhip_expr_eval: CAST %d -> %d can overflow: keep the checked CPU cast", ta, s.type); return DBHIP_ERR_UNSUPPORTED; }
-        d.ta = (int16_t)ta;
+        ex_decode(d, ta, -1);
       } break;
       default:
         set_error("dbhip_expr_eval: instruction %d: unknown op %d", i, s.op);
@@ -364,6 +385,12 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
     for (int i = 0; i < n_out; ++i) { P.ins[i].a = (int16_t)mp(P.ins[i].a); P.ins[i].b = (int16_t)mp(P.ins[i].b); P.ins[i].dst = (int16_t)remap[P.ins[i].dst]; }
     P.out_reg = mp(P.out_reg);
     P.n_temps = nt;
+  }
+  P.out_cls = ex_cls(P.out_type);
+  switch (P.out_type) {
+    case DBHIP_T_BOOL: P.out_kind = 0; break;
+    case DBHIP_T_F32: P.out_kind = -4; break;
+    default: P.out_kind = type_bits(P.out_type) / 8; break;
   }
   const size_t lds = (size_t)(P.n_temps + n_inputs) * EX_ROWS * 256 * 8;
   if (lds > 64 * 1024) {
