@@ -105,6 +105,9 @@ enum {
 // compiles LOAD instructions away (an operand that names a loaded register is rewritten to the input register), so
 // that ALL column loads of a chunk are issued back to back before the first instruction is interpreted — with the
 // loads inside the interpreter loop every LOAD would cost a full HBM round trip of its own.
+// NIN: compile-time bound of the input count (unused slots cost neither code nor VGPRs); ALL8: every input is a
+// plain 8-byte non-scalar column (i64 / u64 / f64 / timestamp / decimal64) — straight-line loads, no kind tests.
+template <int NIN, bool ALL8>
 __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
   extern __shared__ uint64_t ex_regs[];  // [n_temps + n_inputs][EX_ROWS][256]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -129,20 +132,25 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
       if (!in_range[k]) row[k] = P.n - 1;  // clamp: loads stay in bounds, results are masked
     }
     // ---- all input loads of the chunk, back to back ----
-    uint64_t in[EX_MAX_INPUTS][EX_ROWS];
+    uint64_t in[NIN][EX_ROWS];
 #pragma unroll
-    for (int ci = 0; ci < EX_MAX_INPUTS; ++ci) {
+    for (int ci = 0; ci < NIN; ++ci) {
       if (ci < P.n_inputs) {
 #pragma unroll
         for (int k = 0; k < EX_ROWS; ++k) {
-          const int64_t j = P.in_scalar[ci] ? 0 : row[k];
-          in[ci][k] = ex_load(P.in_data[ci], P.in_type[ci], j);
-          if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + j);
+          if (ALL8) {
+            in[ci][k] = ((const uint64_t*)P.in_data[ci])[row[k]];
+            if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + row[k]);
+          } else {
+            const int64_t j = P.in_scalar[ci] ? 0 : row[k];
+            in[ci][k] = ex_load(P.in_data[ci], P.in_type[ci], j);
+            if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + j);
+          }
         }
       }
     }
 #pragma unroll
-    for (int ci = 0; ci < EX_MAX_INPUTS; ++ci) {
+    for (int ci = 0; ci < NIN; ++ci) {
       if (ci < P.n_inputs) {
 #pragma unroll
         for (int k = 0; k < EX_ROWS; ++k) EX_REG(P.n_temps + ci, k) = in[ci][k];
@@ -397,7 +405,16 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
     set_error("dbhip_expr_eval: %d temporaries + %d inputs exceed the LDS register file; split the expression", P.n_temps, n_inputs);
     return DBHIP_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(expr_kernel, dim3(grid), dim3(256), lds, s, P);
+  bool all8 = true;
+  for (int c = 0; c < n_inputs; ++c) all8 &= P.in_type[c] == LK_8 && !P.in_scalar[c];
+  const dim3 g(grid), b(256);
+  if (n_inputs <= 2) {
+    if (all8) hipLaunchKernelGGL((expr_kernel<2, true>), g, b, lds, s, P); else hipLaunchKernelGGL((expr_kernel<2, false>), g, b, lds, s, P);
+  } else if (n_inputs <= 4) {
+    if (all8) hipLaunchKernelGGL((expr_kernel<4, true>), g, b, lds, s, P); else hipLaunchKernelGGL((expr_kernel<4, false>), g, b, lds, s, P);
+  } else {
+    if (all8) hipLaunchKernelGGL((expr_kernel<8, true>), g, b, lds, s, P); else hipLaunchKernelGGL((expr_kernel<8, false>), g, b, lds, s, P);
+  }
   kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
