@@ -371,6 +371,85 @@ class Evaluator {
   // `selection`: rows a row error is reported for (render_error honours it, function.rs:567-620)
   Value run_with_selection(const Expr& expr, const std::vector<uint32_t>* selection) const { return partial_run(expr, Buf(), selection); }
 
+  // The whole tree in ONE launch (dbhip_expr_eval): the tree is flattened post-order into a register program —
+  // what a CompoundBlockOperator / BlockOperator::Map fusion (block_operator.rs:42-85) would hand to the device.
+  // Returns nullopt when a node is outside the fused subset (decimals, strings, modulo, checked casts, more than 8
+  // registers / input columns): the caller then uses run(), one kernel per node. Row errors of `/` are not rendered
+  // here (a failing fused program is re-run node by node to name the failing call like render_error does).
+  std::optional<Value> run_fused(const Expr& expr) const {
+    std::vector<dbhip_expr_ins> prog;
+    std::vector<size_t> inputs;           // block column ids, in input order
+    std::vector<int> free_regs = {7, 6, 5, 4, 3, 2, 1, 0};
+    bool ok = true;
+    std::function<int(const Expr&)> emit = [&](const Expr& e) -> int {
+      if (!ok) return 0;
+      auto alloc = [&]() -> int { if (free_regs.empty()) { ok = false; return 0; } int r = free_regs.back(); free_regs.pop_back(); return r; };
+      auto ins = [&](int op, int dst, int a, int b, int type, uint64_t imm) { dbhip_expr_ins i; memset(&i, 0, sizeof(i)); i.op = op; i.dst = dst; i.a = a; i.b = b; i.type = type; i.imm = imm; prog.push_back(i); };
+      const int t = e.type.id;
+      const bool plain = (t >= DBHIP_T_BOOL && t <= DBHIP_T_TIMESTAMP) && e.type.dim == 0;
+      if (!plain) { ok = false; return 0; }
+      switch (e.kind) {
+        case Expr::ColumnRef: {
+          size_t k = 0;
+          for (; k < inputs.size(); ++k) if (inputs[k] == e.id) break;
+          if (k == inputs.size()) { if (inputs.size() == 8) { ok = false; return 0; } inputs.push_back(e.id); }
+          int r = alloc();
+          ins(DBHIP_EX_LOAD, r, (int)k, 0, t, 0);
+          return r;
+        }
+        case Expr::Constant: {
+          if (e.scalar.is_null) { ok = false; return 0; }
+          uint64_t imm;
+          if (t == DBHIP_T_F32) { double d = (double)(float)e.scalar.f; memcpy(&imm, &d, 8); }
+          else if (t == DBHIP_T_F64) memcpy(&imm, &e.scalar.f, 8);
+          else imm = (uint64_t)e.scalar.i;
+          int r = alloc();
+          ins(DBHIP_EX_CONST, r, 0, 0, t, imm);
+          return r;
+        }
+        case Expr::Cast: {
+          int a = emit(e.args[0]);
+          if (!ok) return 0;
+          if (e.args[0].type.same_physical(e.type)) return a;
+          ins(DBHIP_EX_CAST, a, a, 0, t, 0);
+          return a;
+        }
+        default: break;
+      }
+      static const std::map<std::string, int> ops = {{"plus", DBHIP_EX_PLUS}, {"minus", DBHIP_EX_MINUS}, {"multiply", DBHIP_EX_MULTIPLY},
+          {"divide", DBHIP_EX_DIVIDE}, {"eq", DBHIP_EX_EQ}, {"noteq", DBHIP_EX_NOTEQ}, {"lt", DBHIP_EX_LT}, {"lte", DBHIP_EX_LTE},
+          {"gt", DBHIP_EX_GT}, {"gte", DBHIP_EX_GTE}};
+      auto it = ops.find(e.fname);
+      if (it == ops.end() || e.args.size() != 2) { ok = false; return 0; }
+      int a = emit(e.args[0]);
+      int b = emit(e.args[1]);
+      if (!ok) return 0;
+      ins(it->second, a, a, b, t, 0);
+      free_regs.push_back(b);
+      return a;
+    };
+    const int out = emit(expr);
+    if (!ok || prog.empty()) return std::nullopt;
+    const int64_t n = block_.num_rows;
+    std::vector<dbhip_col> cols;
+    bool nullable = false;
+    for (size_t id : inputs) { cols.push_back(block_.get_by_offset(id).c()); nullable |= (bool)block_.get_by_offset(id).validity; }
+    Column c; c.type = expr.type.remove_nullable(); c.len = n;
+    const size_t words = (size_t)(n + 63) / 64;
+    c.data = make_buf(c.type.id == DBHIP_T_BOOL ? words * 8 + 8 : (size_t)n * c.type.elem_size() + 16);
+    if (nullable) { c.validity = make_buf(words * 8 + 8); c.type.nullable = true; }
+    Buf err = make_buf((size_t)(n + 31) / 32 * 4 + 8);
+    Buf cnt = make_buf(8); cnt->fill(0);
+    int32_t rc = dbhip_expr_eval(prog.data(), (int32_t)prog.size(), cols.data(), (int32_t)cols.size(), n, out, c.data->ptr(),
+                                 c.validity ? (uint8_t*)c.validity->ptr() : nullptr, (uint8_t*)err->ptr(), (uint64_t*)cnt->ptr(),
+                                 nullptr, nullptr);
+    if (rc == DBHIP_ERR_UNSUPPORTED || rc == DBHIP_ERR_INVALID) return std::nullopt;
+    check(rc);
+    uint64_t nerr = 0; cnt->download(&nerr, 8);
+    if (nerr) return run(expr);  // names the failing call and row exactly like the reference
+    return Value::of(c);
+  }
+
  private:
   Value partial_run(const Expr& e, Buf validity, const std::vector<uint32_t>* selection) const {
     switch (e.kind) {

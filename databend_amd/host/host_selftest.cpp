@@ -50,6 +50,29 @@ static void test_sum_a_plus_b_mul_c() {
     exp_sum += x;
   }
   CHECK(all);
+  // the same tree as ONE launch (Evaluator::run_fused -> dbhip_expr_eval) == the node-by-node result
+  auto fused = ev.run_fused(e);
+  CHECK(fused.has_value() && fused->column.len == n && fused->column.to_vector<int64_t>() == got);
+  {  // mixed widths, a nullable input and a comparison on top: (a32 * u8 - 7) >= b64   ->  Boolean NULL
+    std::vector<int32_t> a32(n); std::vector<uint8_t> u8v(n); std::vector<bool> valid(n);
+    for (int64_t i = 0; i < n; ++i) { a32[i] = (int32_t)rng(); u8v[i] = (uint8_t)rng(); valid[i] = (rng() & 7) != 0; }
+    DataBlock blk({Column::from_vector(DataType::of(DBHIP_T_I32), a32, &valid), Column::from_vector(DataType::of(DBHIP_T_U8), u8v),
+                   Column::from_vector(I64, b)}, n);
+    Expr lhs = Expr::call("minus", {Expr::call("multiply", {Expr::column_ref(0, DataType::of(DBHIP_T_I32, true), "x"), Expr::column_ref(1, DataType::of(DBHIP_T_U8), "y")}),
+                                    Expr::constant(Scalar::Int(DBHIP_T_U8, 7))});
+    Expr pred = Expr::call("gte", {lhs, Expr::column_ref(2, I64, "b")});
+    Evaluator ev2(blk);
+    Value stepwise = ev2.run(pred);
+    auto f2 = ev2.run_fused(pred);
+    CHECK(f2.has_value());
+    if (f2) {
+      CHECK(f2->column.to_bools() == stepwise.column.to_bools());
+      CHECK(f2->column.validity_to_host() == valid);
+    }
+    // a decimal node is outside the fused subset: the caller keeps the node-by-node path
+    Expr dec = Expr::call("plus", {Expr::constant(Scalar::Dec(15, 2, 100)), Expr::constant(Scalar::Dec(15, 2, 1))});
+    CHECK(!ev2.run_fused(dec).has_value());
+  }
   DataBlock mapped({v.column}, n);
   SingleStateAggregator agg({{"sum", 0, I64}, {"count", std::nullopt, DataType()}});
   agg.transform(mapped);
