@@ -361,7 +361,7 @@ int32_t dbhip_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int6
   p.a_scalar = lhs->is_scalar; p.b_scalar = rhs->is_scalar;
   p.op = op;
   p.m_type = coerce(100, lhs->type, rhs->type);
-  int grid = grid_for(ceil_div(n, 4), 256);
+  int grid = grid_for(ceil_div(n, 4), 256, 1024);
   hipLaunchKernelGGL(arith_kernel, dim3(grid), dim3(256), 0, s, p);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
@@ -374,7 +374,7 @@ int32_t dbhip_sum_a_plus_b_mul_c_i64(const int64_t* a, const int64_t* b, const i
                 "dbhip_sum_a_plus_b_mul_c_i64: columns must be 16-byte aligned");
   if (n == 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
-  int grid = grid_for(ceil_div(n, 8), 256);
+  int grid = grid_for(ceil_div(n, 8), 256, 512);
   kernel_timer_start(s);
   hipLaunchKernelGGL(sum_abc_kernel, dim3(grid), dim3(256), 0, s, a, b, c, n,
                      (unsigned long long*)out_sum_dev);

@@ -452,7 +452,7 @@ int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int6
   if (n_sel == 0) return DBHIP_OK;
   DBHIP_REQUIRE(src && sel && out, "dbhip_take: NULL argument");
   hipStream_t s = resolve_stream(stream);
-  int grid = grid_for(ceil_div(n_sel, 4), 256);
+  int grid = grid_for(ceil_div(n_sel, 4), 256, 1024);
   switch (elem_size) {
     case 1: hipLaunchKernelGGL(take_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, sel, n_sel, (uint8_t*)out); break;
     case 2: hipLaunchKernelGGL(take_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, sel, n_sel, (uint16_t*)out); break;

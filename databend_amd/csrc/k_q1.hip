@@ -29,6 +29,7 @@
 #include "gb_device.h"
 #include "runtime.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 using namespace dbhip;
@@ -54,6 +55,25 @@ struct alignas(16) L2 {
 struct alignas(8) I2 {
   int32_t a, b;
 };
+
+// streaming loads: every byte of lineitem is read exactly once per pass, so the loads may carry the non-temporal hint
+typedef uint32_t q1_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t q1_u32x2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ U4 ld_u4(const U4* p) {
+  if (NT) return __builtin_bit_cast(U4, __builtin_nontemporal_load((const q1_u32x4*)p));
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ L2 ld_l2(const int64_t* p) {
+  if (NT) return __builtin_bit_cast(L2, __builtin_nontemporal_load((const q1_u32x4*)p));
+  return *(const L2*)p;
+}
+template <bool NT>
+__device__ __forceinline__ I2 ld_i2(const int32_t* p) {
+  if (NT) return __builtin_bit_cast(I2, __builtin_nontemporal_load((const q1_u32x2*)p));
+  return *(const I2*)p;
+}
 
 // Per-block key table in LDS: append-only array of the distinct group keys seen by the
 // block. Readers scan entries [0, count); a writer appends under `lock` and publishes
@@ -209,7 +229,7 @@ __device__ __forceinline__ void acc_row(Q1Regs<SLOTS>& R, int slot, int64_t qty,
   }
 }
 
-template <int SLOTS>
+template <int SLOTS, bool NT>
 __device__ __forceinline__ void q1_body(const Q1Args& A) {
   __shared__ KeyTable T;
   __shared__ uint64_t red[4][SLOTS][10];
@@ -241,13 +261,13 @@ __device__ __forceinline__ void q1_body(const Q1Args& A) {
     const int64_t ra = t0 + lane, rb = t0 + 64 + lane;
     const int64_t r0 = t0 + 2 * lane, r1 = r0 + 1;
     if (full) {
-      rfA = A.rf[ra]; rfB = A.rf[rb];
-      lsA = A.ls[ra]; lsB = A.ls[rb];
-      q = *(const L2*)(A.qty + r0);
-      p = *(const L2*)(A.price + r0);
-      d = *(const L2*)(A.disc + r0);
-      x = *(const L2*)(A.tax + r0);
-      sd = *(const I2*)(A.shipdate + r0);
+      rfA = ld_u4<NT>(A.rf + ra); rfB = ld_u4<NT>(A.rf + rb);
+      lsA = ld_u4<NT>(A.ls + ra); lsB = ld_u4<NT>(A.ls + rb);
+      q = ld_l2<NT>(A.qty + r0);
+      p = ld_l2<NT>(A.price + r0);
+      d = ld_l2<NT>(A.disc + r0);
+      x = ld_l2<NT>(A.tax + r0);
+      sd = ld_i2<NT>(A.shipdate + r0);
     } else {
       const int64_t last = A.n - 1;
       const int64_t ca = ra < A.n ? ra : last, cb = rb < A.n ? rb : last;
@@ -328,8 +348,9 @@ __device__ __forceinline__ void q1_body(const Q1Args& A) {
   }
 }
 
-__global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) { q1_body<4>(A); }
-__global__ __launch_bounds__(256, 1) void q1_fused_kernel_8slots(Q1Args A) { q1_body<8>(A); }
+__global__ __launch_bounds__(256, 2) void q1_fused_kernel(Q1Args A) { q1_body<4, true>(A); }
+__global__ __launch_bounds__(256, 2) void q1_fused_kernel_plain_loads(Q1Args A) { q1_body<4, false>(A); }
+__global__ __launch_bounds__(256, 1) void q1_fused_kernel_8slots(Q1Args A) { q1_body<8, true>(A); }
 
 }  // namespace
 
@@ -371,7 +392,13 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
                 "dbhip_q1_fused: columns must be 16-byte aligned (shipdate 8-byte)");
   hipStream_t s = resolve_stream(stream);
   const int64_t ntiles = ceil_div(n, 128);
-  int grid = (int)(ceil_div(ntiles, 4) < 2048 ? ceil_div(ntiles, 4) : 2048);
+  // Grid: whole multiples of the 256 CUs (a ragged last round costs up to 40 %), and only 2 workgroups per CU:
+  // measured on SF10 (r01x) 2048 WGs 0.722 ms, 1024 0.688 ms, 512 0.680 ms; with non-temporal loads 0.689 / 0.656 /
+  // 0.646 ms; 640 or 768 WGs 0.77 - 0.90 ms. Fewer workgroups also mean fewer partial rows to merge.
+  int grid = (int)(ceil_div(ntiles, 4) < 512 ? ceil_div(ntiles, 4) : 512);
+  static const int env_grid = getenv("DBHIP_Q1_GRID") ? atoi(getenv("DBHIP_Q1_GRID")) : 0;   // tuning knobs (bench experiments)
+  static const int env_nt = getenv("DBHIP_Q1_NT") ? atoi(getenv("DBHIP_Q1_NT")) : 1;
+  if (env_grid > 0) grid = (int)(ceil_div(ntiles, 4) < env_grid ? ceil_div(ntiles, 4) : env_grid);
   size_t rows_bytes = (size_t)grid * MAX_SLOTS * Q1_W * 8;
   uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 4);
   if (!ws) return DBHIP_ERR_HIP;
@@ -394,7 +421,8 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   for (int variant = 0; variant < 2; ++variant) {
     DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
     kernel_timer_start(s);
-    if (variant == 0) hipLaunchKernelGGL(q1_fused_kernel, dim3(grid), dim3(256), 0, s, A);
+    if (variant == 0 && env_nt) hipLaunchKernelGGL(q1_fused_kernel, dim3(grid), dim3(256), 0, s, A);
+    else if (variant == 0) hipLaunchKernelGGL(q1_fused_kernel_plain_loads, dim3(grid), dim3(256), 0, s, A);
     else hipLaunchKernelGGL(q1_fused_kernel_8slots, dim3(grid), dim3(256), 0, s, A);
     kernel_timer_stop(s);
     DBHIP_LAUNCH_CHECK();

@@ -32,6 +32,11 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int grid_cap_override() {
+  static const int cap = [] { const char* e = getenv("DBHIP_GRID_CAP"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  return cap;
+}
+
 int32_t hip_fail(hipError_t e, const char* what) {
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   return DBHIP_ERR_HIP;
