@@ -806,33 +806,14 @@ struct FkArgs {
   uint64_t* ctrl;          // [5] = #partial rows, [6] = #spill rows, [3] error bits
 };
 
-// REGACC (short layouts whose aggregates are all COUNT / one-word SUM): the first 8 groups a workgroup meets get a
-// dense id and are accumulated in per-lane REGISTERS (8 x NA accumulators selected by compares), reduced over the
-// wave once at the very end — with a handful of groups (TPC-H Q1: 4) every row otherwise hits the same few LDS words
-// and the LDS atomics serialise 64-way (the kernel ran at 0.12 of the HBM rate). Later groups use the LDS atomics.
-constexpr int FK_REGG = 8;
-
-template <int KW, int NA, bool HI, int R, bool REGACC>
+template <int KW, int NA, bool HI, int R>
 __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C, FkArgs A) {
   extern __shared__ uint64_t fk_lds[];
   __shared__ uint32_t lcount;
-  __shared__ uint32_t dense_pos[FK_REGG];   // LDS slot of dense group id g
   uint64_t* lhash = fk_lds;
   uint64_t* lrows = fk_lds + A.lcap;
-  uint64_t racc[REGACC ? FK_REGG : 1][REGACC ? NA : 1];
-  bool a_is_f64[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-    a_is_f64[a] = a < L.naggs && L.agg_kind[a] == DBHIP_AGG_SUM && (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64);
-  if (REGACC) {
-#pragma unroll
-    for (int g = 0; g < FK_REGG; ++g)
-#pragma unroll
-      for (int a = 0; a < NA; ++a) racc[g][a] = 0;  // 0 is also +0.0
-  }
   const int tid = threadIdx.x;
   const uint32_t lmask = (uint32_t)A.lcap - 1;
-  uint32_t* lid = (uint32_t*)(fk_lds + (size_t)A.lcap * (A.sw + 1));  // dense id of every slot (REGACC only)
   for (int s = tid; s < A.lcap; s += 256) lhash[s] = 0;
   if (tid == 0) lcount = 0;
   __syncthreads();
@@ -866,7 +847,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
             if (((volatile uint32_t*)&lcount)[0] >= A.llimit) break;
             const unsigned long long old = atomicCAS((unsigned long long*)&lhash[pos], 0ULL, (unsigned long long)hw);
             if (old == 0) {
-              const uint32_t dense = atomicAdd(&lcount, 1u);
+              atomicAdd(&lcount, 1u);
               uint64_t* d = lrows + (size_t)pos * A.sw;
 #pragma unroll
               for (int j = 0; j < KW; ++j)
@@ -875,10 +856,6 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 #pragma unroll
               for (int a = 0; a < NA; ++a)
                 if (a < L.naggs) gb_state_identity(L, a, d + L.agg_off[a]);
-              if (REGACC) {
-                lid[pos] = dense;
-                if (dense < (uint32_t)FK_REGG) dense_pos[dense] = pos;
-              }
               slot[x] = pos;
               break;
             }
@@ -903,29 +880,13 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
         for (int j = 0; j < KW; ++j)
           if (j < L.nkey_words) eq &= (d[j] == r[x].kw[j]);
         if (eq) {
-          const uint32_t dense = REGACC ? lid[slot[x]] : 0xFFFFFFFFu;
-          if (REGACC && dense < (uint32_t)FK_REGG) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a)
-              if (a < L.naggs) {
-                uint64_t v[3];
-                fk_contrib(L, a, r[x].aw[a], 0, (r[x].avalid >> a) & 1, v);
-#pragma unroll
-                for (int g = 0; g < FK_REGG; ++g) {
-                  const bool sel = dense == (uint32_t)g;
-                  if (a_is_f64[a]) racc[g][a] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)racc[g][a]) + (sel ? __longlong_as_double((long long)v[0]) : 0.0));
-                  else racc[g][a] += sel ? v[0] : 0;
-                }
-              }
-          } else {
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-              if (a < L.naggs) {
-                uint64_t v[3];
-                fk_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
-                gb_atomic_merge(L, a, d + L.agg_off[a], v);
-              }
-          }
+          for (int a = 0; a < NA; ++a)
+            if (a < L.naggs) {
+              uint64_t v[3];
+              fk_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
+              gb_atomic_merge(L, a, d + L.agg_off[a], v);
+            }
         } else {
           spill = true;  // same probe hash, different keys
         }
@@ -955,26 +916,6 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
     // no barrier needed here: the next tile only adds NEW slots; slots matched above never change keys
   }
   __syncthreads();
-  if (REGACC) {  // register accumulators -> the groups' LDS rows: one wave reduction per (group, aggregate)
-    const uint32_t ng = lcount < (uint32_t)FK_REGG ? lcount : (uint32_t)FK_REGG;
-#pragma unroll
-    for (int g = 0; g < FK_REGG; ++g) {
-      if ((uint32_t)g < ng) {
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-          if (a < L.naggs) {
-            uint64_t tot;
-            if (a_is_f64[a]) tot = (uint64_t)__double_as_longlong(wave_sum_f64(__longlong_as_double((long long)racc[g][a])));
-            else tot = wave_sum_u64(racc[g][a]);
-            if (lane_id() == 0) {
-              uint64_t v[3] = {tot, 0, 0};
-              gb_atomic_merge(L, a, lrows + (size_t)dense_pos[g] * A.sw + L.agg_off[a], v);
-            }
-          }
-      }
-    }
-    __syncthreads();
-  }
   // ---- flush the workgroup's partial rows ----
   for (int s = tid; s < A.lcap; s += 256) {
     const bool occ = lhash[s] != 0;
@@ -1020,7 +961,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
   const int sw = L.W | 1;  // odd stride (in 8-byte words): conflict-free LDS rows
   int lcap = 64;
   while ((size_t)(lcap * 2) * (sw + 1) * 8 <= 48 * 1024) lcap *= 2;
-  size_t lds_bytes = (size_t)lcap * (sw + 1) * 8;
+  const size_t lds_bytes = (size_t)lcap * (sw + 1) * 8;
   // layout class: small = <= 2 key words, <= 2 one-word aggregates (8 rows per lane); else general (2 rows)
   bool hi = false;
   for (int a = 0; a < L.naggs; ++a) hi |= L.agg_type[a] == DBHIP_T_DEC128 && L.agg_kind[a] != DBHIP_AGG_COUNT;
@@ -1064,11 +1005,8 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap; A.sw = sw;
     A.llimit = (uint32_t)(lcap - lcap / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
-    bool regacc = small;  // COUNT / one-word SUM only (MIN / MAX keep the LDS atomics)
-    for (int a = 0; a < L.naggs; ++a) regacc &= L.agg_kind[a] == DBHIP_AGG_COUNT || L.agg_kind[a] == DBHIP_AGG_SUM;
-    if (regacc) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8, true>), dim3(grid), dim3(256), lds_bytes + (size_t)lcap * 4, s, L, C, A);
-    else if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8, false>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
-    else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2, false>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     DBHIP_LAUNCH_CHECK();
     uint64_t hc[8];
     DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
