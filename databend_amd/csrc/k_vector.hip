@@ -19,6 +19,7 @@
 #include "runtime.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <new>
 #include <vector>
@@ -769,6 +770,154 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
   }
 }
 
+// ---------------------------------------------------------------------------
+// v2 of the filter kernel: the register staging (global -> VGPR -> ds_write_b128) is replaced by LDS-DMA
+// (`global_load_lds_dwordx4`: 64 lanes x 16 B land in 1 KiB of LDS straight from L2/HBM, no VGPRs, no ds_write pass —
+// the v1 PMC profile has the waves parked 39 % of the time and the LDS write path is what the tile's 48 KiB per
+// k-step are bound by) into a two-stage LDS ring: the DMA of k-tile t+1 is in flight while the matrix pipe works on
+// k-tile t. An LDS-DMA image is lane-linear (dest = base + lane x 16), so rows are NOT padded; bank conflicts of the
+// operand reads are removed with an XOR swizzle instead — slot (row r, 16-B slot t) holds k-piece t ^ ((r >> 1) & 7),
+// applied to the per-lane SOURCE address and to the ds_read_b128 address alike (for the 16 lanes of a ds_read_b128
+// group, (r & 1) * 8 + (p ^ ((r >> 1) & 7)) takes 16 distinct values). The asm loads are invisible to hipcc's waitcnt
+// bookkeeping: every stage is completed with an explicit `s_waitcnt vmcnt(0)` before the barrier that publishes it.
+// 256(q) x 128(i) tile, 8 waves of 64 x 64, one workgroup per CU (96 KiB of LDS).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <bool COSINE>
+__global__ __launch_bounds__(512) void bf16_filter_kernel_v2(HArgs A) {
+  constexpr int TQ = 256, TI = 128;
+  constexpr int A_BYTES = TQ * 128, B_BYTES = TI * 128, STAGE = A_BYTES + B_BYTES;  // 48 KiB per stage
+  __shared__ __attribute__((aligned(1024))) uint8_t ring[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
+
+  const int64_t slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int qt = (int)(slot % A.n_qtiles);
+  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
+  if (it >= A.n_itiles) return;
+  const int64_t i0 = it * TI;
+  const int q0 = qt * TQ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = (wave >> 1) * 64, wi = (wave & 1) * 64;
+  const int dpad = A.dpad;
+  const uint32_t ring_base = (uint32_t)(uintptr_t)ring;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // DMA plan: a wave-instruction fills one 8-row x 128-B sub-block (1 KiB). Wave w issues A sub-blocks w, w+8, w+16,
+  // w+24 (32 = 256 rows) and B sub-blocks w, w+8 (16 = 128 rows). Lane l: row (l >> 3) of the sub-block, slot (l & 7).
+  const uint8_t* atile = (const uint8_t*)(A.queries + (int64_t)q0 * dpad);
+  const uint8_t* btile = (const uint8_t*)(A.base + i0 * dpad);
+  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
+  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
+  const uint8_t* asrc[4];
+  const uint8_t* bsrc[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave + 8 * j) * 8 + (lane >> 3);
+    const int piece = (lane & 7) ^ ((r >> 1) & 7);
+    asrc[j] = atile + (int64_t)(r < alast ? r : alast) * dpad * 2 + piece * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave + 8 * j) * 8 + (lane >> 3);
+    const int piece = (lane & 7) ^ ((r >> 1) & 7);
+    bsrc[j] = btile + (int64_t)(r < blast ? r : blast) * dpad * 2 + piece * 16;
+  }
+  auto issue = [&](int k0, int stage) {
+    const uint32_t sa = ring_base + stage * STAGE, sb = sa + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(asrc[j] + k0 * 2, sa + (uint32_t)(wave + 8 * j) * 1024u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(bsrc[j] + k0 * 2, sb + (uint32_t)(wave + 8 * j) * 1024u);
+  };
+
+  // operand read addresses inside a stage (bytes): row * 128 + ((piece ^ swz(row)) * 16), piece = kk/8 + (lane >> 5)
+  const int ar0 = wq + (lane & 31), ar1 = ar0 + 32, br0 = wi + (lane & 31), br1 = br0 + 32;
+  const int hi = lane >> 5;
+
+  issue(0, 0);
+  int stage = 0;
+  for (int k0 = 0; k0 < dpad; k0 += HBK) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the current stage has landed
+    __syncthreads();                                   // ... and everybody else's; nobody still reads the other stage
+    if (k0 + HBK < dpad) issue(k0 + HBK, stage ^ 1);  // in flight during the matrix work below
+    const uint8_t* sa = ring + stage * STAGE;
+    const uint8_t* sb = sa + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int piece = kk * 2 + hi;
+      const u32x4 a0 = *(const u32x4*)(sa + ar0 * 128 + ((piece ^ ((ar0 >> 1) & 7)) * 16));
+      const u32x4 a1 = *(const u32x4*)(sa + ar1 * 128 + ((piece ^ ((ar1 >> 1) & 7)) * 16));
+      const u32x4 b0 = *(const u32x4*)(sb + br0 * 128 + ((piece ^ ((br0 >> 1) & 7)) * 16));
+      const u32x4 b1 = *(const u32x4*)(sb + br1 * 128 + ((piece ^ ((br1 >> 1) & 7)) * 16));
+      const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0), fa1 = __builtin_bit_cast(bf16x8, a1);
+      const bf16x8 fb0 = __builtin_bit_cast(bf16x8, b0), fb1 = __builtin_bit_cast(bf16x8, b1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+    stage ^= 1;
+  }
+
+  if (tid < TI) {
+    const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
+    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
+  } else if (tid < TI + TQ) {
+    const int t = tid - TI;
+    const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
+    const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
+    const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
+    qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
+    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    float cB[16], cG[16], cT[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qb = wq + x * 32 + 8 * j + 4 * (lane >> 5);
+      const float4 vb = *(const float4*)(qB + qb), vg = *(const float4*)(qG + qb), vt = *(const float4*)(Tau + qb);
+      cB[4 * j + 0] = vb.x; cB[4 * j + 1] = vb.y; cB[4 * j + 2] = vb.z; cB[4 * j + 3] = vb.w;
+      cG[4 * j + 0] = vg.x; cG[4 * j + 1] = vg.y; cG[4 * j + 2] = vg.z; cG[4 * j + 3] = vg.w;
+      cT[4 * j + 0] = vt.x; cT[4 * j + 1] = vt.y; cT[4 * j + 2] = vt.z; cT[4 * j + 3] = vt.w;
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int il = wi + y * 32 + (lane & 31);
+      const int64_t i = i0 + il;
+      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
+      const bool row_ok = i < A.n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
+        if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
+          const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (q < A.nq) {
+            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
+            if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
+          }
+        }
+      }
+    }
+  }
+}
+
 // One wave per row: out[row][0..dpad) = bf16(x[row]) (RNE, zero padded) and the row's coefficients.
 //   mode 0 (base rows, cosine): A = 1/||b||, X = ||bh||/||b|| (1+1e-4), Y = ||b-bh||/||b|| (1+1e-4)
 //   mode 1 (base rows, dot)   : A = 1,       X = ||bh|| (1+1e-4),       Y = ||b-bh|| (1+1e-4)
@@ -878,7 +1027,11 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.c = (float)dim * 1.1920929e-07f + 2e-4f;
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
-    if (tall) {
+    static const int kernel_version = getenv("DBHIP_BF16_V") ? atoi(getenv("DBHIP_BF16_V")) : 1;
+    if (tall && kernel_version == 2) {
+      if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v2<true>, dim3((unsigned)blocks), dim3(512), 0, s, A);
+      else hipLaunchKernelGGL(bf16_filter_kernel_v2<false>, dim3((unsigned)blocks), dim3(512), 0, s, A);
+    } else if (tall) {
       if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<true, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
       else hipLaunchKernelGGL((bf16_filter_kernel<false, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
     } else {
