@@ -774,13 +774,13 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
 // v2 of the filter kernel: the register staging (global -> VGPR -> ds_write_b128) is replaced by LDS-DMA
 // (`global_load_lds_dwordx4`: 64 lanes x 16 B land in 1 KiB of LDS straight from L2/HBM, no VGPRs, no ds_write pass —
 // the v1 PMC profile has the waves parked 39 % of the time and the LDS write path is what the tile's 48 KiB per
-// k-step are bound by) into a two-stage LDS ring: the DMA of k-tile t+1 is in flight while the matrix pipe works on
-// k-tile t. An LDS-DMA image is lane-linear (dest = base + lane x 16), so rows are NOT padded; bank conflicts of the
+// k-step are bound by) into a three-stage LDS ring: the DMA of k-tiles t+1 and t+2 is in flight while the matrix pipe
+// works on k-tile t. An LDS-DMA image is lane-linear (dest = base + lane x 16), so rows are NOT padded; bank conflicts of the
 // operand reads are removed with an XOR swizzle instead — slot (row r, 16-B slot t) holds k-piece t ^ ((r >> 1) & 7),
 // applied to the per-lane SOURCE address and to the ds_read_b128 address alike (for the 16 lanes of a ds_read_b128
 // group, (r & 1) * 8 + (p ^ ((r >> 1) & 7)) takes 16 distinct values). The asm loads are invisible to hipcc's waitcnt
 // bookkeeping: every stage is completed with an explicit `s_waitcnt vmcnt(0)` before the barrier that publishes it.
-// 256(q) x 128(i) tile, 8 waves of 64 x 64, one workgroup per CU (96 KiB of LDS).
+// 256(q) x 128(i) tile, 8 waves of 64 x 64, k-steps of 32 (three 24 KiB stages), two workgroups per CU.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
@@ -789,10 +789,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 }
 
 template <bool COSINE>
-__global__ __launch_bounds__(512) void bf16_filter_kernel_v2(HArgs A) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void bf16_filter_kernel_v2(HArgs A) {
   constexpr int TQ = 256, TI = 128;
-  constexpr int A_BYTES = TQ * 128, B_BYTES = TI * 128, STAGE = A_BYTES + B_BYTES;  // 48 KiB per stage
-  __shared__ __attribute__((aligned(1024))) uint8_t ring[2 * STAGE];
+  constexpr int KB = 32;                       // bf16 elements per k-step: 64 B per row, 4 pieces of 16 B
+  constexpr int A_BYTES = TQ * 64, B_BYTES = TI * 64, STAGE = A_BYTES + B_BYTES;  // 24 KiB per stage
+  constexpr int NSTAGE = 3;                    // two k-steps of DMA in flight behind the one being multiplied
+  __shared__ __attribute__((aligned(1024))) uint8_t ring[NSTAGE * STAGE];        // 72 KiB: two workgroups per CU
   __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
 
   const int64_t slot = blockIdx.x >> 3;
@@ -816,53 +818,55 @@ __global__ __launch_bounds__(512) void bf16_filter_kernel_v2(HArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // DMA plan: a wave-instruction fills one 8-row x 128-B sub-block (1 KiB). Wave w issues A sub-blocks w, w+8, w+16,
-  // w+24 (32 = 256 rows) and B sub-blocks w, w+8 (16 = 128 rows). Lane l: row (l >> 3) of the sub-block, slot (l & 7).
+  // DMA plan: a wave-instruction fills one 16-row x 64-B sub-block (1 KiB): lane l -> row (l >> 2), slot (l & 3).
+  // A: 16 sub-blocks (wave w issues w and w + 8), B: 8 sub-blocks (wave w issues w). Slot t of row r holds k-piece
+  // t ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots.
   const uint8_t* atile = (const uint8_t*)(A.queries + (int64_t)q0 * dpad);
   const uint8_t* btile = (const uint8_t*)(A.base + i0 * dpad);
   const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
   const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
-  const uint8_t* asrc[4];
-  const uint8_t* bsrc[2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave + 8 * j) * 8 + (lane >> 3);
-    const int piece = (lane & 7) ^ ((r >> 1) & 7);
-    asrc[j] = atile + (int64_t)(r < alast ? r : alast) * dpad * 2 + piece * 16;
-  }
+  const uint8_t* asrc[2];
+  const uint8_t* bsrc;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int r = (wave + 8 * j) * 8 + (lane >> 3);
-    const int piece = (lane & 7) ^ ((r >> 1) & 7);
-    bsrc[j] = btile + (int64_t)(r < blast ? r : blast) * dpad * 2 + piece * 16;
+    const int r = (wave + 8 * j) * 16 + (lane >> 2);
+    const int piece = (lane & 3) ^ ((r >> 2) & 3);
+    asrc[j] = atile + (int64_t)(r < alast ? r : alast) * dpad * 2 + piece * 16;
+  }
+  {
+    const int r = wave * 16 + (lane >> 2);
+    const int piece = (lane & 3) ^ ((r >> 2) & 3);
+    bsrc = btile + (int64_t)(r < blast ? r : blast) * dpad * 2 + piece * 16;
   }
   auto issue = [&](int k0, int stage) {
     const uint32_t sa = ring_base + stage * STAGE, sb = sa + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(asrc[j] + k0 * 2, sa + (uint32_t)(wave + 8 * j) * 1024u);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(bsrc[j] + k0 * 2, sb + (uint32_t)(wave + 8 * j) * 1024u);
+    glds16(asrc[0] + k0 * 2, sa + (uint32_t)wave * 1024u);
+    glds16(asrc[1] + k0 * 2, sa + (uint32_t)(wave + 8) * 1024u);
+    glds16(bsrc + k0 * 2, sb + (uint32_t)wave * 1024u);
   };
 
-  // operand read addresses inside a stage (bytes): row * 128 + ((piece ^ swz(row)) * 16), piece = kk/8 + (lane >> 5)
   const int ar0 = wq + (lane & 31), ar1 = ar0 + 32, br0 = wi + (lane & 31), br1 = br0 + 32;
   const int hi = lane >> 5;
 
   issue(0, 0);
+  if (KB < dpad) issue(KB, 1);
   int stage = 0;
-  for (int k0 = 0; k0 < dpad; k0 += HBK) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the current stage has landed
-    __syncthreads();                                   // ... and everybody else's; nobody still reads the other stage
-    if (k0 + HBK < dpad) issue(k0 + HBK, stage ^ 1);  // in flight during the matrix work below
+  for (int k0 = 0; k0 < dpad; k0 += KB) {
+    // every wave issues exactly 3 DMA instructions per stage and nothing else on vmcnt inside the loop: "at most 3
+    // outstanding" == this wave's share of the CURRENT stage has landed, the next stage may still be in flight
+    if (k0 + KB < dpad) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ... and everybody else's share; nobody still reads the stage that is refilled next
+    if (k0 + 2 * KB < dpad) issue(k0 + 2 * KB, stage == 0 ? 2 : stage - 1);  // (stage + 2) % 3
     const uint8_t* sa = ring + stage * STAGE;
     const uint8_t* sb = sa + A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 2; ++kk) {
       const int piece = kk * 2 + hi;
-      const u32x4 a0 = *(const u32x4*)(sa + ar0 * 128 + ((piece ^ ((ar0 >> 1) & 7)) * 16));
-      const u32x4 a1 = *(const u32x4*)(sa + ar1 * 128 + ((piece ^ ((ar1 >> 1) & 7)) * 16));
-      const u32x4 b0 = *(const u32x4*)(sb + br0 * 128 + ((piece ^ ((br0 >> 1) & 7)) * 16));
-      const u32x4 b1 = *(const u32x4*)(sb + br1 * 128 + ((piece ^ ((br1 >> 1) & 7)) * 16));
+      const u32x4 a0 = *(const u32x4*)(sa + ar0 * 64 + ((piece ^ ((ar0 >> 2) & 3)) * 16));
+      const u32x4 a1 = *(const u32x4*)(sa + ar1 * 64 + ((piece ^ ((ar1 >> 2) & 3)) * 16));
+      const u32x4 b0 = *(const u32x4*)(sb + br0 * 64 + ((piece ^ ((br0 >> 2) & 3)) * 16));
+      const u32x4 b1 = *(const u32x4*)(sb + br1 * 64 + ((piece ^ ((br1 >> 2) & 3)) * 16));
       const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0), fa1 = __builtin_bit_cast(bf16x8, a1);
       const bf16x8 fb0 = __builtin_bit_cast(bf16x8, b0), fb1 = __builtin_bit_cast(bf16x8, b1);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(512) void bf16_filter_kernel_v2(HArgs A) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
     }
-    stage ^= 1;
+    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
   }
 
   if (tid < TI) {
