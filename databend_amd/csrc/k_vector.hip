@@ -38,6 +38,7 @@ struct dbhip_vec_index {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;       // k-depth of one LDS tile
 constexpr int LDK = BK + 1;  // padded leading dimension: conflict-free ds_read_b32 down a column
@@ -462,6 +463,41 @@ int32_t select_topk(const float* d, const uint32_t* ids, const uint32_t* counts,
 // ---------------------------------------------------------------------------
 // u8-quantised scoring (cpp/avx2.c:45-139): one wave per base row, v_dot4-style packed dot
 // ---------------------------------------------------------------------------
+// Fast path (dim % 16 == 0, 16-byte aligned base): a QUARTER wave (16 lanes x 16 B) walks one row, four rows per
+// wave at a time, the query staged once per workgroup in LDS; every lane has 16-byte loads in flight (the one-wave-
+// per-row kernel below moves 4 bytes per lane per load and reaches 0.38 of the HBM rate).
+__global__ __launch_bounds__(256) void score_u8_q16_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ base,
+                                                           int64_t n, int dim, int is_l1, float* __restrict__ out) {
+  extern __shared__ uint32_t qs[];  // dim / 4 words
+  for (int k = threadIdx.x; k < dim / 4; k += 256) qs[k] = ((const uint32_t*)q)[k];
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  const int64_t qw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // quarter-wave id
+  const int64_t nqw = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  const int64_t n_pad = (n + 3) & ~3LL;  // the 4 quarter-waves of a wave stay convergent for the shuffles
+  for (int64_t r = qw; r < n_pad; r += nqw) {
+    uint32_t s = 0;
+    if (r < n) {
+      const uint8_t* v = base + r * dim;
+      for (int k = sub * 16; k < dim; k += 256) {
+        const u32x4 b = *(const u32x4*)(v + k);
+        const u32x4 a = *(const u32x4*)(qs + (k >> 2));
+        if (is_l1) {
+          s += __builtin_amdgcn_sad_u8(a.x, b.x, 0u) + __builtin_amdgcn_sad_u8(a.y, b.y, 0u) + __builtin_amdgcn_sad_u8(a.z, b.z, 0u) +
+               __builtin_amdgcn_sad_u8(a.w, b.w, 0u);
+        } else {
+          s = __builtin_amdgcn_udot4(a.x, b.x, s, false);
+          s = __builtin_amdgcn_udot4(a.y, b.y, s, false);
+          s = __builtin_amdgcn_udot4(a.z, b.z, s, false);
+          s = __builtin_amdgcn_udot4(a.w, b.w, s, false);
+        }
+      }
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+    if (sub == 0 && r < n) out[r] = (float)s;
+  }
+}
+
 __global__ __launch_bounds__(256) void score_u8_kernel(const uint8_t* __restrict__ q, const uint8_t* __restrict__ base,
                                                        int64_t n, int dim, int is_l1, float* __restrict__ out) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -619,7 +655,6 @@ int32_t topk_batch(int metric, const float* base, int64_t n, int dim, const floa
 // slots (9 * row mod 16 is a bijection), the staging ds_write_b128 of 8 lanes covers one 128-B row.
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int HBK = 64;  // bf16 elements per k-tile (one 128-B line per row)
 constexpr int HLD = 72;  // padded LDS row stride in bf16 elements
 
@@ -1203,8 +1238,12 @@ int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base,
                        float* out, void* stream) {
   if (n == 0) return DBHIP_OK;
   DBHIP_REQUIRE(query && base && out && dim > 0, "dbhip_score_u8: bad argument");
-  hipLaunchKernelGGL(score_u8_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, resolve_stream(stream), query, base,
-                     n, dim, is_l1, out);
+  if (dim % 16 == 0 && (((uintptr_t)base | (uintptr_t)query) & 15) == 0 && dim <= 16384)
+    hipLaunchKernelGGL(score_u8_q16_kernel, dim3(grid_for(n * 16, 256)), dim3(256), (size_t)dim, resolve_stream(stream), query, base,
+                       n, dim, is_l1, out);
+  else
+    hipLaunchKernelGGL(score_u8_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, resolve_stream(stream), query, base,
+                       n, dim, is_l1, out);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
