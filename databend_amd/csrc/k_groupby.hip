@@ -185,37 +185,45 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
                                                        uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc) {
   n = dev_rows(dc, n);
   const uint64_t cmask = (uint64_t)cap - 1;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  // wave-uniform trip count: the number of NEW groups is added to ctrl[0] once per wave and iteration (one atomic
+  // per new group on that single address serialises: 10 M new groups cost ~15 ms)
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t* r = rows_in + i * L.W;
-    const uint64_t hw = probe_word(r[L.hash_word], hash_mask);
-    uint64_t pos = hw & cmask;
-    uint32_t found = GB_INVALID_SLOT;
-    for (int64_t step = 0; step < cap; ++step) {
-      unsigned long long cur = __hip_atomic_load((unsigned long long*)&slot_hash[pos], __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-      if (cur == 0) {
-        unsigned long long old = atomicCAS((unsigned long long*)&slot_hash[pos], 0ULL, (unsigned long long)hw);
-        if (old == 0) {
-          // this lane owns the new group: write keys, hash and identity states
-          uint64_t* d = rows + pos * L.W;
-          for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
-          d[L.hash_word] = r[L.hash_word];
-          for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
-          atomicAdd((unsigned long long*)&ctrl[0], 1ULL);
+    bool claimed = false;
+    if (i < n) {
+      const uint64_t* r = rows_in + i * L.W;
+      const uint64_t hw = probe_word(r[L.hash_word], hash_mask);
+      uint64_t pos = hw & cmask;
+      uint32_t found = GB_INVALID_SLOT;
+      for (int64_t step = 0; step < cap; ++step) {
+        unsigned long long cur = __hip_atomic_load((unsigned long long*)&slot_hash[pos], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+          unsigned long long old = atomicCAS((unsigned long long*)&slot_hash[pos], 0ULL, (unsigned long long)hw);
+          if (old == 0) {
+            // this lane owns the new group: write keys, hash and identity states
+            uint64_t* d = rows + pos * L.W;
+            for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
+            d[L.hash_word] = r[L.hash_word];
+            for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
+            claimed = true;
+            found = (uint32_t)pos;
+            break;
+          }
+          cur = old;
+        }
+        if (cur == hw) {
           found = (uint32_t)pos;
           break;
         }
-        cur = old;
+        pos = (pos + 1) & cmask;
       }
-      if (cur == hw) {
-        found = (uint32_t)pos;
-        break;
-      }
-      pos = (pos + 1) & cmask;
+      if (found == GB_INVALID_SLOT) atomicOr((unsigned long long*)&ctrl[1], 1ULL);
+      gid[i] = found;
     }
-    if (found == GB_INVALID_SLOT) atomicOr((unsigned long long*)&ctrl[1], 1ULL);
-    gid[i] = found;
+    const uint64_t m = __ballot(claimed);
+    if (m && lane_id() == 0) atomicAdd((unsigned long long*)&ctrl[0], (unsigned long long)__popcll(m));
   }
 }
 
@@ -924,11 +932,15 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
     // no barrier needed here: the next tile only adds NEW slots; slots matched above never change keys
   }
   __syncthreads();
-  // ---- flush the workgroup's partial rows ----
-  for (int s = tid; s < A.lcap; s += 256) {
+  // ---- flush the workgroup's partial rows (one cursor atomic per wave, not per row) ----
+  for (int s = tid; s < A.lcap; s += 256) {  // lcap is a multiple of 256: the loop is wave-uniform
     const bool occ = lhash[s] != 0;
+    const uint64_t m = __ballot(occ);
+    unsigned long long base = 0;
+    if (m && lane_id() == 0) base = atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
     if (occ) {
-      const unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[5], 1ULL);
+      const unsigned long long idx = base + __popcll(m & ((1ULL << lane_id()) - 1));
       const uint64_t* src = lrows + (size_t)s * A.sw;
       uint64_t* o = A.partial + idx * L.W;
       for (int k = 0; k < L.W; ++k) o[k] = src[k];
@@ -1276,9 +1288,14 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
     // no barrier: the next tile only adds NEW slots (see gb_lds_preagg_kernel)
   }
   __syncthreads();
-  for (int s = tid; s < A.lcap; s += 256) {
-    if (lhash[s] != 0) {
-      const unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[5], 1ULL);
+  for (int s = tid; s < A.lcap; s += 256) {  // lcap is a multiple of 256: wave-uniform
+    const bool occ = lhash[s] != 0;
+    const uint64_t m = __ballot(occ);
+    unsigned long long base = 0;
+    if (m && lane_id() == 0) base = atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (occ) {
+      const unsigned long long idx = base + __popcll(m & ((1ULL << lane_id()) - 1));
       const uint64_t* src = lrows + (size_t)s * A.sw;
       uint64_t* o = A.partial + idx * L.W;
       for (int k = 0; k < L.W; ++k) o[k] = src[k];
