@@ -167,6 +167,12 @@ __device__ __forceinline__ uint64_t probe_word(uint64_t h, uint64_t mask) {
   uint64_t hw = h & mask;
   return hw == 0 ? 1 : hw;  // 0 is the empty marker
 }
+// Home slot = the TOP log2(cap) bits of the probe word: rows sorted by the top hash bits (the radix partitions of
+// the scatter kernel) then walk the table front to back, slice by slice — with >= 10^6 groups the table is far
+// larger than the L2 / Infinity Cache and random home slots cost one HBM sector each.
+__device__ __forceinline__ uint64_t home_slot(uint64_t hw, int64_t cap) {
+  return hw >> (__builtin_clzll((unsigned long long)cap) + 1);  // cap = 2^k: clz = 63 - k -> shift = 64 - k
+}
 
 // `n_dev` (optional): the row count lives on the device (rows produced by a kernel of the same stream whose
 // count the host has not read yet); `abort_dev` (optional): non-zero low bits = the producer gave up, merge nothing.
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
     if (i < n) {
       const uint64_t* r = rows_in + i * L.W;
       const uint64_t hw = probe_word(r[L.hash_word], hash_mask);
-      uint64_t pos = hw & cmask;
+      uint64_t pos = home_slot(hw, cap);
       uint32_t found = GB_INVALID_SLOT;
       for (int64_t step = 0; step < cap; ++step) {
         unsigned long long cur = __hip_atomic_load((unsigned long long*)&slot_hash[pos], __ATOMIC_RELAXED,
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256) void gb_rehash_kernel(GbLayout L, const uint64
     uint64_t hw = old_hash[s];
     if (hw == 0) continue;
     const uint64_t* r = old_rows + s * L.W;
-    uint64_t pos = probe_word(r[L.hash_word], hash_mask) & cmask;
+    uint64_t pos = home_slot(probe_word(r[L.hash_word], hash_mask), new_cap);
     // all old entries are distinct groups: take the first EMPTY slot
     while (true) {
       unsigned long long old = atomicCAS((unsigned long long*)&new_hash[pos], 0ULL, (unsigned long long)hw);
@@ -951,6 +957,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
                               int64_t* spilled);
 void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen);
+int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s);
 constexpr int64_t PT_CHUNK = 32 << 20;
 
 // one partitioned chunk starting at *done; widens the partitioning (or gives it up) when too many rows spilled
@@ -1326,18 +1333,14 @@ void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
 
 // One chunk [row0, row0 + cn) through hist -> scan -> scatter -> aggregate -> merge.
 // *spilled = rows that did not fit their partition's LDS table (went through the row path).
-int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
-                              int64_t* spilled) {
+// hist -> scan -> scatter: rows [row0, row0 + cn) serialized into g->rows_in grouped by the top `pbits` hash bits;
+// base[0..P] (device, g->part_meta + 1024) = first row of every partition
+int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s) {
   const GbLayout& L = g->L;
-  const int pbits = g->part_bits;
   const int P = 1 << pbits;
-  int lcap, sw;
-  size_t lds_bytes;
-  part_geometry(L, &lcap, &sw, &lds_bytes);
   int32_t rc;
   if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
   if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, (size_t)(3 * 1024 + 8) * 4))) return rc;
-  if ((rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
   uint32_t* hist = g->part_meta;
   uint32_t* base = g->part_meta + 1024;
   uint32_t* cursor = g->part_meta + 2048 + 8;
@@ -1350,6 +1353,21 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   hipLaunchKernelGGL(gb_part_scatter_kernel, dim3(sgrid), dim3(PT_THREADS), (size_t)P * 8, s, L, C, row0, cn, pbits,
                      base, cursor, g->rows_in, g->ctrl);
   DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
+                              int64_t* spilled) {
+  const GbLayout& L = g->L;
+  const int pbits = g->part_bits;
+  const int P = 1 << pbits;
+  int lcap, sw;
+  size_t lds_bytes;
+  part_geometry(L, &lcap, &sw, &lds_bytes);
+  int32_t rc;
+  if ((rc = partition_scatter(g, C, row0, cn, pbits, s))) return rc;
+  if ((rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
+  uint32_t* base = g->part_meta + 1024;
   // workgroups per partition: fill the chip (>= ~1024 workgroups) without making splits tiny
   int splits = 1;
   while (P * splits < 1024 && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
@@ -1526,10 +1544,20 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
     }
     int64_t cn = n - done < CHUNK ? n - done : CHUNK;
     if (probe_here && g->part_bits == 0 && cn > (1 << 20)) cn = 1 << 20;
-    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
-    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
-                       g->ctrl);
-    DBHIP_LAUNCH_CHECK();
+    // High cardinality: the table (slot words + rows) is far larger than the L2 / Infinity Cache. Rows are
+    // serialized in the order of their top hash bits — the table's home slots use the same bits —, so probe and
+    // accumulate walk the table slice by slice (each ~1 MiB slice stays in L2) instead of one random HBM sector per row.
+    const int64_t table_bytes = g->cap * (8 + (int64_t)g->L.W * 8);
+    if (cn >= (1 << 20) && table_bytes > (64LL << 20) && !g->part_forbidden) {
+      int pbits = 4;
+      while (pbits < PT_MAX_BITS && (table_bytes >> pbits) > (1LL << 20)) ++pbits;
+      if ((rc = partition_scatter(g, C, done, cn, pbits, s))) return rc;
+    } else {
+      if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
+      hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
+                         g->ctrl);
+      DBHIP_LAUNCH_CHECK();
+    }
     if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
     done += cn;
     g->rows_seen += cn;
