@@ -1544,20 +1544,13 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
     }
     int64_t cn = n - done < CHUNK ? n - done : CHUNK;
     if (probe_here && g->part_bits == 0 && cn > (1 << 20)) cn = 1 << 20;
-    // High cardinality: the table (slot words + rows) is far larger than the L2 / Infinity Cache. Rows are
-    // serialized in the order of their top hash bits — the table's home slots use the same bits —, so probe and
-    // accumulate walk the table slice by slice (each ~1 MiB slice stays in L2) instead of one random HBM sector per row.
-    const int64_t table_bytes = g->cap * (8 + (int64_t)g->L.W * 8);
-    if (cn >= (1 << 20) && table_bytes > (64LL << 20) && !g->part_forbidden) {
-      int pbits = 4;
-      while (pbits < PT_MAX_BITS && (table_bytes >> pbits) > (1LL << 20)) ++pbits;
-      if ((rc = partition_scatter(g, C, done, cn, pbits, s))) return rc;
-    } else {
-      if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
-      hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
-                         g->ctrl);
-      DBHIP_LAUNCH_CHECK();
-    }
+    // (Serializing the rows in the order of their top hash bits — partition_scatter, so that probe and accumulate
+    // walk the table slice by slice — was measured and does not pay: at 10^6..10^7 groups the row path is bound by
+    // the two device-scope atomics per row, not by the random sectors. r01y: 17.9 ms vs 16.4 ms at 10 M groups.)
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
+    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
+                       g->ctrl);
+    DBHIP_LAUNCH_CHECK();
     if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
     done += cn;
     g->rows_seen += cn;
