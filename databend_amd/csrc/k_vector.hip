@@ -929,6 +929,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---------------------------------------------------------------------------
+// v4: 256(q) x 256(i) block tile, 8 waves of 128 x 64. v1 / v2 / v3 all land on ~810 TF although they differ in
+// staging (registers vs LDS-DMA), ring depth and wave tile: what they share is the bytes a CU pulls through its
+// vector memory path per unit of matrix work — a 256 x 128 tile needs 48 KiB per k-step for 1024 SIMD-cycles of MFMA,
+// i.e. ~75 % of the 64 B/clk/CU the TA/L1 path delivers with two workgroups per CU. The square tile halves that.
+// ---------------------------------------------------------------------------
+template <bool COSINE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bf16_filter_kernel_v4(HArgs A) {
+  constexpr int TQ = 256, TI = 256, MQ = 4, MI = 2;
+  __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
+  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
+
+  const int64_t slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int qt = (int)(slot % A.n_qtiles);
+  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
+  if (it >= A.n_itiles) return;
+  const int64_t i0 = it * TI;
+  const int q0 = qt * TQ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = (wave >> 2) * 128, wi = (wave & 3) * 64;
+  const int dpad = A.dpad;
+
+  f32x16 acc[MQ][MI];
+#pragma unroll
+  for (int a = 0; a < MQ; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int kc = (tid & 7) * 8;
+  const int r0 = tid >> 3;  // 0..63
+  const uint16_t* atile = A.queries + (int64_t)q0 * dpad;
+  const uint16_t* btile = A.base + i0 * dpad;
+  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
+  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
+  uint32_t aoff[4], boff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(r0 + 64 * j < alast ? r0 + 64 * j : alast) * (uint32_t)dpad + kc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) boff[j] = (uint32_t)(r0 + 64 * j < blast ? r0 + 64 * j : blast) * (uint32_t)dpad + kc;
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *(const u32x4*)(atile + aoff[j] + k0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = *(const u32x4*)(btile + boff[j] + k0);
+  };
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(u32x4*)(As + (r0 + 64 * j) * HLD + kc) = ra[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(u32x4*)(Bs + (r0 + 64 * j) * HLD + kc) = rb[j];
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < dpad; k0 += HBK) {
+    __syncthreads();
+    lds_store();
+    __syncthreads();
+    if (k0 + HBK < dpad) gload(k0 + HBK);
+#pragma unroll
+    for (int kk = 0; kk < HBK; kk += 16) {
+      const int kl = kk + (lane >> 5) * 8;
+      bf16x8 fa[MQ], fb[MI];
+#pragma unroll
+      for (int x = 0; x < MQ; ++x) fa[x] = __builtin_bit_cast(bf16x8, *(const u32x4*)(As + (wq + x * 32 + (lane & 31)) * HLD + kl));
+#pragma unroll
+      for (int y = 0; y < MI; ++y) fb[y] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Bs + (wi + y * 32 + (lane & 31)) * HLD + kl));
+#pragma unroll
+      for (int x = 0; x < MQ; ++x)
+#pragma unroll
+        for (int y = 0; y < MI; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[y], acc[x][y], 0, 0, 0);
+    }
+  }
+
+  if (tid < TI) {
+    const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
+    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
+  }
+  if (tid >= 256) {
+    const int t = tid - 256;  // threads 256..511 <-> 256 queries
+    const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
+    const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
+    const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
+    qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
+    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int x = 0; x < MQ; ++x) {
+    float cB[16], cG[16], cT[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qb = wq + x * 32 + 8 * j + 4 * (lane >> 5);
+      const float4 vb = *(const float4*)(qB + qb), vg = *(const float4*)(qG + qb), vt = *(const float4*)(Tau + qb);
+      cB[4 * j + 0] = vb.x; cB[4 * j + 1] = vb.y; cB[4 * j + 2] = vb.z; cB[4 * j + 3] = vb.w;
+      cG[4 * j + 0] = vg.x; cG[4 * j + 1] = vg.y; cG[4 * j + 2] = vg.z; cG[4 * j + 3] = vg.w;
+      cT[4 * j + 0] = vt.x; cT[4 * j + 1] = vt.y; cT[4 * j + 2] = vt.z; cT[4 * j + 3] = vt.w;
+    }
+#pragma unroll
+    for (int y = 0; y < MI; ++y) {
+      const int il = wi + y * 32 + (lane & 31);
+      const int64_t i = i0 + il;
+      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
+      const bool row_ok = i < A.n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
+        if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
+          const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (q < A.nq) {
+            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
+            if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // v2 of the filter kernel: the register staging (global -> VGPR -> ds_write_b128) is replaced by LDS-DMA
 // (`global_load_lds_dwordx4`: 64 lanes x 16 B land in 1 KiB of LDS straight from L2/HBM, no VGPRs, no ds_write pass —
 // the v1 PMC profile has the waves parked 39 % of the time and the LDS write path is what the tile's 48 KiB per
@@ -1190,7 +1314,12 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
     static const int kernel_version = getenv("DBHIP_BF16_V") ? atoi(getenv("DBHIP_BF16_V")) : 1;
-    if (tall && kernel_version == 3) {
+    if (tall && kernel_version == 4) {
+      A.n_itiles = ceil_div(A.n, 256);
+      const int64_t blocks4 = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
+      if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v4<true>, dim3((unsigned)blocks4), dim3(512), 0, s, A);
+      else hipLaunchKernelGGL(bf16_filter_kernel_v4<false>, dim3((unsigned)blocks4), dim3(512), 0, s, A);
+    } else if (tall && kernel_version == 3) {
       if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v3<true>, dim3((unsigned)blocks), dim3(256), 0, s, A);
       else hipLaunchKernelGGL(bf16_filter_kernel_v3<false>, dim3((unsigned)blocks), dim3(256), 0, s, A);
     } else if (tall && kernel_version == 2) {
