@@ -38,8 +38,6 @@ struct dbhip_join {
   uint64_t* head;      // [buckets]
   int64_t buckets;
   int shift;
-  uint32_t* bloom;     // [bloom_words] one-hash membership filter over the build keys (NULL for small tables)
-  uint32_t bloom_mask; // bit index mask (bits = bloom_mask + 1)
   bool finalized;
   // probe scratch
   uint32_t* cnt; uint32_t* firstm; uint64_t* off; uint64_t* blk; size_t scratch_rows;
@@ -71,12 +69,8 @@ __global__ __launch_bounds__(256) void join_copy_kernel(const uint64_t* keys, co
   }
 }
 
-// Filter bit of a key: hash bits 8.. (the bucket index uses the top bits, the tag the low 4)
-__device__ __forceinline__ uint32_t bloom_bit(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 8) & mask; }
-
 template <int KW>
-__global__ __launch_bounds__(256) void join_build_kernel(uint64_t* ent, int64_t n, uint64_t* head, int shift, uint32_t* bloom,
-                                                         uint32_t bloom_mask) {
+__global__ __launch_bounds__(256) void join_build_kernel(uint64_t* ent, int64_t n, uint64_t* head, int shift) {
   constexpr int ES = KW * 2;
   uint32_t* head32 = (uint32_t*)head;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -87,20 +81,15 @@ __global__ __launch_bounds__(256) void join_build_kernel(uint64_t* ent, int64_t 
     const uint32_t old = atomicExch(&head32[2 * idx], (uint32_t)(i + 1));  // prepend
     atomicOr(&head32[2 * idx + 1], 1u << (h & 15));
     ((uint32_t*)&e[KW])[0] = old;
-    if (bloom) { const uint32_t b = bloom_bit(h, bloom_mask); atomicOr(&bloom[b >> 5], 1u << (b & 31)); }
   }
 }
 
 // walks the chain of probe key k; returns the number of matching build rows, *last = one of them
 template <int KW>
 __device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_t* head, int shift, const uint64_t* k,
-                                              uint32_t* last, const uint32_t* bloom, uint32_t bloom_mask) {
+                                              uint32_t* last) {
   constexpr int ES = KW * 2;
   const uint64_t h = join_hash<KW>(k);
-  if (bloom) {  // the filter (>= 16 bits per build key, a few MiB: L2 / Infinity Cache resident) answers most misses
-    const uint32_t b = bloom_bit(h, bloom_mask);  // without touching the bucket array in HBM
-    if (!((bloom[b >> 5] >> (b & 31)) & 1)) return 0;
-  }
   const uint64_t hd = head[h >> shift];
   uint32_t c = 0;
   if (!((hd >> (32 + (h & 15))) & 1)) return 0;  // empty bucket or tag miss (fixed_keys.rs:139-142)
@@ -126,8 +115,7 @@ __device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_
 template <int KW>
 __global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, const uint64_t* head, int shift,
                                                          const uint64_t* pkeys, const uint8_t* pvalid, int64_t n,
-                                                         uint32_t* cnt, uint32_t* firstm, unsigned long long* total,
-                                                         const uint32_t* bloom, uint32_t bloom_mask) {
+                                                         uint32_t* cnt, uint32_t* firstm, unsigned long long* total) {
   uint64_t local = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t c = 0, last = 0;
@@ -135,7 +123,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, co
       uint64_t k[KW];
 #pragma unroll
       for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
-      c = join_walk<KW>(ent, head, shift, k, &last, bloom, bloom_mask);
+      c = join_walk<KW>(ent, head, shift, k, &last);
     }
     if (cnt) { cnt[i] = c; firstm[i] = last; }
     local += c;
@@ -186,8 +174,7 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, con
 template <int KW>
 __global__ __launch_bounds__(256) void join_mark_kernel(const uint64_t* ent, const uint64_t* head, int shift,
                                                         const uint64_t* pkeys, const uint8_t* pvalid, int64_t n,
-                                                        uint8_t* out_bitmap, unsigned long long* total,
-                                                        const uint32_t* bloom, uint32_t bloom_mask) {
+                                                        uint8_t* out_bitmap, unsigned long long* total) {
   const int64_t n_pad = (n + 63) & ~63LL;
   uint64_t local = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
@@ -197,7 +184,7 @@ __global__ __launch_bounds__(256) void join_mark_kernel(const uint64_t* ent, con
 #pragma unroll
       for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
       uint32_t last;
-      hit = join_walk<KW>(ent, head, shift, k, &last, bloom, bloom_mask) != 0;
+      hit = join_walk<KW>(ent, head, shift, k, &last) != 0;
     }
     const uint64_t m = __ballot(hit);
     const int l = lane_id();
@@ -446,22 +433,11 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   j->shift = 64 - __builtin_ctzll((unsigned long long)cap);
   DBHIP_TRY(dbhip_alloc((size_t)cap * 8, (void**)&j->head));
   DBHIP_CHECK(hipMemsetAsync(j->head, 0, (size_t)cap * 8, s));
-  // membership filter for tables that do not fit the caches: 16+ bits per build key (power of two, <= 1 Gbit)
-  j->bloom = nullptr; j->bloom_mask = 0;
-  if (j->nrows >= (1 << 20)) {
-    uint64_t bits = 1u << 24;
-    while (bits < (uint64_t)j->nrows * 16 && bits < (1ull << 30)) bits <<= 1;
-    DBHIP_TRY(dbhip_alloc((size_t)(bits / 8), (void**)&j->bloom));
-    DBHIP_CHECK(hipMemsetAsync(j->bloom, 0, (size_t)(bits / 8), s));
-    j->bloom_mask = (uint32_t)(bits - 1);
-  }
   if (j->nrows) {
     if (j->kw == 1)
-      hipLaunchKernelGGL(join_build_kernel<1>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift,
-                         j->bloom, j->bloom_mask);
+      hipLaunchKernelGGL(join_build_kernel<1>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
     else
-      hipLaunchKernelGGL(join_build_kernel<2>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift,
-                         j->bloom, j->bloom_mask);
+      hipLaunchKernelGGL(join_build_kernel<2>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
     DBHIP_LAUNCH_CHECK();
   }
   j->finalized = true;
@@ -478,10 +454,10 @@ static int32_t join_count_block(dbhip_join* j, const void* keys, const uint8_t* 
   const int grid = grid_for(n, 256);
   if (j->kw == 1)
     hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev, j->bloom, j->bloom_mask);
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
   else
     hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev, j->bloom, j->bloom_mask);
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
   rc = dbscan::exclusive_scan_u32(j->cnt, n, j->blk, j->off, s);
   if (rc) return rc;
   DBHIP_CHECK(hipMemcpyAsync(total_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
@@ -511,10 +487,10 @@ int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* va
   const int grid = grid_for(n, 256);
   if (j->kw == 1)
     hipLaunchKernelGGL(join_mark_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev, j->bloom, j->bloom_mask);
+                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
   else
     hipLaunchKernelGGL(join_mark_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev, j->bloom, j->bloom_mask);
+                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
   DBHIP_LAUNCH_CHECK();
   if (out_n_matched_host) {
     DBHIP_CHECK(hipMemcpyAsync(out_n_matched_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
@@ -562,7 +538,7 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
 int32_t dbhip_join_destroy(dbhip_join* j) {
   if (!j) return DBHIP_OK;
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev, j->bloom};
+  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev};
   for (void* p : ptrs)
     if (p) (void)dbhip_free(p);
   delete j;
