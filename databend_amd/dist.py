@@ -70,8 +70,47 @@ def exchange_partials(table, dist, torch, device, mode="allgather", hash_word=No
     return table
 
 
+def exchange_partials_fixed(table, dist, torch, device, max_rows=256):
+    """Low-cardinality exchange in ONE fixed-size collective: every rank contributes a [max_rows + 1, W] block
+    (row 0 carries its row count), all-gathered in a single call, merged locally — no size negotiation, no per-rank
+    host synchronisation (the variable-length path above costs two collectives and a host sync per rank, which is
+    what limits weak scaling of a 0.75 ms step). Falls back to `exchange_partials` when a rank holds more rows."""
+    rows = np.ascontiguousarray(table.flush_serialized(), dtype=np.uint64)
+    world = dist.get_world_size()
+    n = rows.shape[0]
+    W = rows.shape[1] if rows.ndim == 2 and rows.shape[1] else 1
+    block = np.zeros((max_rows + 1, W), dtype=np.int64)
+    block[0, 0] = min(n, max_rows + 1)
+    if 0 < n <= max_rows:
+        block[1:1 + n] = rows.view(np.int64)
+    if n > max_rows:
+        block[0, 0] = -1
+    send = torch.from_numpy(block).to(device)
+    recv = torch.empty((world * (max_rows + 1), W), dtype=torch.int64, device=device)
+    if hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send)
+        recv = torch.cat(parts, dim=0)
+    got = recv.cpu().numpy().reshape(world, max_rows + 1, W)
+    if (got[:, 0, 0] < 0).any():  # some rank overflowed the fixed block: every rank sees it and takes the general path together
+        return _exchange_rows(table, rows, dist, torch, device)
+    allrows = np.concatenate([got[r, 1:1 + int(got[r, 0, 0])] for r in range(world)], axis=0).view(np.uint64)
+    table.reset()
+    table.merge_serialized(allrows)
+    return table
+
+
+def _exchange_rows(table, rows, dist, torch, device):
+    allrows = allgather_rows(rows, dist, torch, device)
+    table.reset()
+    table.merge_serialized(allrows)
+    return table
+
+
 def exchange_partials_nccl(table, dist, torch):
-    return exchange_partials(table, dist, torch, torch.device("cuda", torch.cuda.current_device()))
+    return exchange_partials_fixed(table, dist, torch, torch.device("cuda", torch.cuda.current_device()))
 
 
 def merge_shard_topk(idx, dst, row_offset, k, dist, torch, device, merge_fn):

@@ -73,7 +73,10 @@ def worker(rank, world, port, mode, n, card, q):
         keys, vals, lo, hi = shard(rank, world, n, card, 11)
         t = HostTable()
         t.add(keys[lo:hi], vals[lo:hi])
-        DX.exchange_partials(t, dist, torch, torch.device("cpu"), mode=mode, hash_word=HASH_WORD)
+        if mode == "fixed":
+            DX.exchange_partials_fixed(t, dist, torch, torch.device("cpu"), max_rows=64)
+        else:
+            DX.exchange_partials(t, dist, torch, torch.device("cpu"), mode=mode, hash_word=HASH_WORD)
         q.put((rank, {k: tuple(v) for k, v in t.groups.items()}))
     finally:
         dist.barrier()
@@ -108,6 +111,14 @@ def run(mode, n, card, world=2):
 @pytest.mark.parametrize("n,card", [(5000, 4), (20000, 3000)])
 def test_allgather_exchange_every_rank_gets_the_global_result(n, card):
     got, exp = run("allgather", n, card)
+    assert got[0] == exp and got[1] == exp
+
+
+@pytest.mark.parametrize("n,card", [(5000, 4), (3, 1), (20000, 3000)])
+def test_fixed_block_exchange_one_collective(n, card):
+    """bench.py's Q1 exchange: one fixed-size all-gather (row 0 of every block = row count); a rank with more rows
+    than the block holds makes EVERY rank fall back to the variable-length path in the same step."""
+    got, exp = run("fixed", n, card)
     assert got[0] == exp and got[1] == exp
 
 
