@@ -107,8 +107,11 @@ __global__ __launch_bounds__(256) void sort_iota_kernel(uint32_t* perm, int64_t 
 // enc[j] = image of col[perm[j]]; mode 0: value part 0, 1: value part 1 (dec128 high), 2: null flag
 // Also reduces OR / AND over all images into span[0] / span[1]: bytes where both agree are constant
 // over the column and their radix pass is skipped.
+// K = uint32_t for key columns of at most 4 bytes (and the null-flag pass): the radix passes then move 8 instead of
+// 12 bytes per key and pass.
+template <typename K>
 __global__ __launch_bounds__(256) void sort_encode_kernel(SortCol c, const uint32_t* perm, int64_t n, int mode,
-                                                          uint64_t* enc, unsigned long long* span) {
+                                                          K* enc, unsigned long long* span) {
   uint64_t acc_or = 0, acc_and = ~0ULL;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
     uint32_t row = perm[j];
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256) void sort_encode_kernel(SortCol c, const uint3
       if (c.desc) e = ~e;
       if (!valid) e = 0;  // NULL rows tie on the value passes; the flag pass places them
     }
-    enc[j] = e;
+    if (sizeof(K) == 4) e &= 0xFFFFFFFFull;
+    enc[j] = (K)e;
     acc_or |= e;
     acc_and &= e;
   }
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(256) void sort_encode_kernel(SortCol c, const uint3
   }
 }
 
-__global__ __launch_bounds__(256) void sort_hist_kernel(const uint64_t* keys, int64_t n, int shift, uint32_t* hist,
+template <typename K>
+__global__ __launch_bounds__(256) void sort_hist_kernel(const K* keys, int64_t n, int shift, uint32_t* hist,
                                                         int64_t ntiles) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
@@ -158,10 +163,11 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint64_t* keys, in
 //   phase 3  keys and row ids are written to their digit-sorted position IN LDS
 //   phase 4  the tile leaves in digit order: lanes write consecutive addresses per digit run
 // Stable: (wave, round, lane) order is index order.
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t* keys, const uint32_t* vals, int64_t n,
+template <typename K>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const K* keys, const uint32_t* vals, int64_t n,
                                                            int shift, const uint64_t* offs, int64_t ntiles,
-                                                           uint64_t* out_keys, uint32_t* out_vals) {
-  __shared__ uint64_t lkeys[SORT_TILE];
+                                                           K* out_keys, uint32_t* out_vals) {
+  __shared__ K lkeys[SORT_TILE];
   __shared__ uint32_t lvals[SORT_TILE];
   __shared__ uint32_t wcount[4][256];  // phase 1: keys of (wave, digit); phase 2 on: first LDS slot of (wave, digit)
   __shared__ uint32_t tile_off[256];
@@ -171,13 +177,13 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t* keys,
   for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
-  uint64_t key[SORT_ITEMS];
+  K key[SORT_ITEMS];
   uint32_t val[SORT_ITEMS];
   uint32_t lrank[SORT_ITEMS];
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS; ++r) {
     const int64_t i = base + r * 64 + lane;
-    key[r] = i < n ? keys[i] : ~0ULL;
+    key[r] = i < n ? keys[i] : (K)~0ULL;
     val[r] = i < n ? vals[i] : 0;
   }
   volatile uint32_t* wc = wcount[wave];
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t* keys,
   const int tile_n = (int)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
 #pragma unroll 4
   for (int j = tid; j < tile_n; j += 256) {
-    const uint64_t k = lkeys[j];
+    const K k = lkeys[j];
     const uint32_t digit = (uint32_t)(k >> shift) & 0xFF;
     const uint64_t pos = offs[(int64_t)digit * ntiles + blockIdx.x] + (uint32_t)(j - tile_off[digit]);
     out_keys[pos] = k;
@@ -360,10 +366,14 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
                    desc_host ? desc_host[k] : 0, nulls_first_host ? nulls_first_host[k] : 0};
   };
   // enc = image of column c read through pb[cur][0..m); returns OR / AND of all images
-  auto encode = [&](const SortCol& c, int64_t m, int mode, uint64_t* v_or, uint64_t* v_and) -> int32_t {
+  // `narrow`: 32-bit key images (columns of at most 4 bytes, null flags) in the same buffers
+  auto encode = [&](const SortCol& c, int64_t m, int mode, bool narrow, uint64_t* v_or, uint64_t* v_and) -> int32_t {
     DBHIP_CHECK(hipMemsetAsync(&span[0], 0x00, 8, s));
     DBHIP_CHECK(hipMemsetAsync(&span[1], 0xFF, 8, s));
-    hipLaunchKernelGGL(sort_encode_kernel, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pb[cur], m, mode, kb[cur], span);
+    if (narrow)
+      hipLaunchKernelGGL(sort_encode_kernel<uint32_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pb[cur], m, mode, (uint32_t*)kb[cur], span);
+    else
+      hipLaunchKernelGGL(sort_encode_kernel<uint64_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pb[cur], m, mode, kb[cur], span);
     DBHIP_LAUNCH_CHECK();
     unsigned long long h[2];
     DBHIP_CHECK(hipMemcpyAsync(h, span, 16, hipMemcpyDeviceToHost, s));
@@ -382,7 +392,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
     SortCol c = make_col(0);
     const int top_part = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 1 : 0;
     uint64_t v_or, v_and;
-    int32_t rc = encode(c, n, top_part, &v_or, &v_and);
+    int32_t rc = encode(c, n, top_part, false, &v_or, &v_and);
     if (rc) return rc;
     const uint64_t vary = v_or ^ v_and;
     uint64_t prefix = v_and & ~vary;  // constant bits (exact in constant bytes; varying bytes are set below)
@@ -429,14 +439,21 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
 
   const int64_t ntiles = ceil_div(m, SORT_TILE);
   const int64_t nh = 256 * ntiles;
-  auto radix_passes = [&](int nbytes, uint64_t vary) -> int32_t {
+  auto radix_passes = [&](int nbytes, uint64_t vary, bool narrow) -> int32_t {
     for (int b = 0; b < nbytes; ++b) {
       if (((vary >> (8 * b)) & 0xFF) == 0) continue;  // every image has the same byte here
-      hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], m, 8 * b, hist, ntiles);
+      if (narrow)
+        hipLaunchKernelGGL(sort_hist_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, (const uint32_t*)kb[cur], m, 8 * b, hist, ntiles);
+      else
+        hipLaunchKernelGGL(sort_hist_kernel<uint64_t>, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], m, 8 * b, hist, ntiles);
       int32_t rc = dbscan::exclusive_scan_u32(hist, nh, blk, offs, s);
       if (rc) return rc;
-      hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], pb[cur], m, 8 * b, offs,
-                         ntiles, kb[cur ^ 1], pb[cur ^ 1]);
+      if (narrow)
+        hipLaunchKernelGGL(sort_scatter_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, (const uint32_t*)kb[cur], pb[cur], m, 8 * b,
+                           offs, ntiles, (uint32_t*)kb[cur ^ 1], pb[cur ^ 1]);
+      else
+        hipLaunchKernelGGL(sort_scatter_kernel<uint64_t>, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], pb[cur], m, 8 * b, offs,
+                           ntiles, kb[cur ^ 1], pb[cur ^ 1]);
       cur ^= 1;
     }
     DBHIP_LAUNCH_CHECK();
@@ -447,16 +464,17 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
     SortCol c = make_col(k);
     const int parts = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 2 : 1;
     uint64_t v_or, v_and;
+    const bool narrow = sort_key_bytes(c.type) <= 4;
     for (int part = 0; part < parts; ++part) {
       // the permutation is shared by both buffers of a pass: encode reads pb[cur], writes kb[cur]
-      int32_t rc = encode(c, m, part, &v_or, &v_and);
+      int32_t rc = encode(c, m, part, narrow, &v_or, &v_and);
       if (rc) return rc;
-      if ((rc = radix_passes(sort_key_bytes(c.type), v_or ^ v_and))) return rc;
+      if ((rc = radix_passes(sort_key_bytes(c.type), v_or ^ v_and, narrow))) return rc;
     }
     if (c.validity) {
-      int32_t rc = encode(c, m, 2, &v_or, &v_and);
+      int32_t rc = encode(c, m, 2, true, &v_or, &v_and);
       if (rc) return rc;
-      if ((rc = radix_passes(1, v_or ^ v_and))) return rc;
+      if ((rc = radix_passes(1, v_or ^ v_and, true))) return rc;
     }
   }
   int64_t mout = (limit > 0 && limit < m) ? limit : m;
