@@ -54,7 +54,6 @@ struct dbhip_groupby {
   uint64_t* partial; size_t partial_cap;   // per-workgroup partial rows
   int fast_disabled;                       // set once most rows of a chunk spilled (high NDV)
   int fast_trusted;                        // last chunk spilled < 1 %: no more probing chunks
-  int fast_no_perwave;                     // the per-wave LDS tables overflowed: workgroup tables from now on
   // radix-partitioned pre-aggregation (medium cardinality)
   int part_bits;                           // 0 = undecided, > 0 = log2(partitions), < 0 = not worth it (row path)
   int part_forbidden;                      // test hook: never choose the partitioned path
@@ -829,26 +828,16 @@ struct FkArgs {
   uint64_t* ctrl;          // [5] = #partial rows, [6] = #spill rows, [3] error bits
 };
 
-// PW (per-wave tables): the LDS region is split into four independent tables, one per wave. A wave's lanes run in
-// lockstep, so "claim by hash, verify after the barrier" only needs a WAVE barrier — no workgroup barrier inside the
-// tile loop, the four waves of a workgroup drift freely and hide each other's memory and LDS latency (with a handful
-// of groups the workgroup-table version spends 64 % of its wave cycles parked at the two barriers per tile). A quarter
-// of the capacity: used while the table has few groups (the caller switches to PW = false beyond ~170 groups).
-template <int KW, int NA, bool HI, int R, bool PW>
+template <int KW, int NA, bool HI, int R>
 __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C, FkArgs A) {
   extern __shared__ uint64_t fk_lds[];
-  __shared__ uint32_t lcount4[4];
+  __shared__ uint32_t lcount;
+  uint64_t* lhash = fk_lds;
+  uint64_t* lrows = fk_lds + A.lcap;
   const int tid = threadIdx.x;
-  const int wv = PW ? (tid >> 6) : 0;
-  const int tcap = PW ? A.lcap / 4 : A.lcap;                 // slots of the table this lane works on
-  const uint32_t tlimit = PW ? A.llimit / 4 : A.llimit;
-  uint64_t* lhash = fk_lds + (PW ? (size_t)wv * tcap * (A.sw + 1) : 0);
-  uint64_t* lrows = lhash + tcap;
-  uint32_t& lcount = lcount4[wv];
-  const uint32_t lmask = (uint32_t)tcap - 1;
-  const int tstride = PW ? 64 : 256, tlane = PW ? (tid & 63) : tid;
-  for (int s = tlane; s < tcap; s += tstride) lhash[s] = 0;
-  if (tlane == 0) lcount = 0;
+  const uint32_t lmask = (uint32_t)A.lcap - 1;
+  for (int s = tid; s < A.lcap; s += 256) lhash[s] = 0;
+  if (tid == 0) lcount = 0;
   __syncthreads();
 
   const int64_t tile_rows = 256 * R;
@@ -877,7 +866,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
         for (int step = 0; step < 64; ++step) {
           uint64_t cur = ((volatile uint64_t*)lhash)[pos];
           if (cur == 0) {
-            if (((volatile uint32_t*)&lcount)[0] >= tlimit) break;
+            if (((volatile uint32_t*)&lcount)[0] >= A.llimit) break;
             const unsigned long long old = atomicCAS((unsigned long long*)&lhash[pos], 0ULL, (unsigned long long)hw);
             if (old == 0) {
               atomicAdd(&lcount, 1u);
@@ -901,13 +890,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
         slot[x] = FK_SPILL - 1;  // padding row: neither aggregated nor spilled
       }
     }
-    if (PW) {  // the wave's own LDS writes are ordered before its later reads: a wave-level fence is enough
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    } else {
-      __syncthreads();  // keys and identity states of every slot claimed in this tile are visible
-    }
+    __syncthreads();  // keys and identity states of every slot claimed in this tile are visible
     // ---- phase B: verify keys, merge states with LDS atomics; the rest spills ----
 #pragma unroll
     for (int x = 0; x < R; ++x) {
@@ -955,8 +938,8 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
     // no barrier needed here: the next tile only adds NEW slots; slots matched above never change keys
   }
   __syncthreads();
-  // ---- flush the partial rows (one cursor atomic per wave, not per row) ----
-  for (int s = tlane; s < tcap; s += tstride) {  // tcap is a multiple of the stride: the loop is wave-uniform
+  // ---- flush the workgroup's partial rows (one cursor atomic per wave, not per row) ----
+  for (int s = tid; s < A.lcap; s += 256) {  // lcap is a multiple of 256: the loop is wave-uniform
     const bool occ = lhash[s] != 0;
     const uint64_t m = __ballot(occ);
     unsigned long long base = 0;
@@ -1049,12 +1032,8 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap; A.sw = sw;
     A.llimit = (uint32_t)(lcap - lcap / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
-    // per-wave tables while the table holds few groups (and a wave's quarter still has >= 64 slots)
-    const bool pw = !g->fast_no_perwave && lcap >= 256 && g->count_host * 8 <= (int64_t)(A.llimit / 4) * 7;
-    if (small && pw) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8, true>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
-    else if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8, false>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
-    else if (pw) hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2, true>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
-    else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2, false>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     DBHIP_LAUNCH_CHECK();
     uint64_t hc[8];
     DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
@@ -1069,12 +1048,6 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     g->rows_seen += cn;
     // most rows spilled: the LDS table is too small for this key distribution -> partition by hash
     // bits so that each partition fits, or (high cardinality) leave the rest to the row path
-    // per-wave tables overflowed (groups beyond a quarter table, or many spills): workgroup tables from now on
-    if (pw && (g->count_host * 8 > (int64_t)(A.llimit / 4) * 7 || (int64_t)hc[6] * 10 > cn)) {
-      g->fast_no_perwave = 1;
-      g->fast_trusted = 0;
-      continue;  // (this chunk is done — its spills went through the row path —; the next one re-probes with workgroup tables)
-    }
     // more groups than a workgroup's table takes (it would run full everywhere and hand most rows on)
     const bool too_many = g->count_host * 8 > (int64_t)A.llimit * 7;
     if (((int64_t)hc[6] * 10 > cn || too_many) && cn >= 65536) {
@@ -1742,7 +1715,6 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->count_host = 0;
   g->fast_disabled = 0;
   g->fast_trusted = 0;
-  g->fast_no_perwave = 0;
   if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
   g->rows_seen = 0;
   return DBHIP_OK;
