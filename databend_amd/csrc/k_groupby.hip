@@ -910,14 +910,14 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
   for (int64_t t = t_begin; t < t_end; ++t) {
     FkRow<KW, NA, HI> r[R];
     uint32_t slot[R];
-    // ---- loads of the whole tile first (R rows per lane in flight) ----
-    // (the column-batched loader fk_load_tile was measured here: +76 VGPRs halve the occupancy and the kernel gets
-    // slower, 1.25 -> 2.2 ms at 200 groups)
+    // ---- loads of the whole tile first (R rows per lane in flight, column by column) ----
+    int64_t rows[R];
 #pragma unroll
     for (int x = 0; x < R; ++x) {
       const int64_t li = t * tile_rows + x * 256 + tid;
-      fk_load<KW, NA, HI>(L, C, A.row0 + (li < A.n ? li : 0), r[x], A.ctrl);
+      rows[x] = A.row0 + (li < A.n ? li : 0);
     }
+    fk_load_tile<KW, NA, HI, R>(L, C, rows, r, A.ctrl);
     // ---- phase A: match-or-claim by hash ----
 #pragma unroll
     for (int x = 0; x < R; ++x) {
@@ -1206,33 +1206,28 @@ bool few_layout_ok(const GbLayout& L) {
   return true;
 }
 
-// Rows [*done, n) through the few-groups kernel: a 1 M-row prefix first (a block with more than 8 groups shows it
-// there for ~30 us instead of a wasted full pass), then the rest. When a workgroup meets a 9th group (or a long
-// string key) nothing of that launch is merged, the kernel is switched off for this table and the caller continues
-// from *done with the LDS / row paths.
-int32_t add_block_few(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, int64_t* done) {
+// whole block through the few-groups kernel. *handled = false: a workgroup met more than 8 groups (or a long string
+// key), nothing was merged, the caller continues with the LDS / row paths from row 0.
+int32_t add_block_few(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, bool* handled) {
   const GbLayout& L = g->L;
+  *handled = false;
   const int64_t per = (int64_t)256 * FEW_ROWS;
+  int grid = (int)(ceil_div(n, per) < 512 ? ceil_div(n, per) : 512);  // 2 workgroups per CU (k_q1.hip's sweep)
   int32_t rc;
-  while (*done < n) {
-    const int64_t cn = (*done == 0 && n > (2 << 20)) ? (1 << 20) : n - *done;
-    int grid = (int)(ceil_div(cn, per) < 512 ? ceil_div(cn, per) : 512);  // 2 workgroups per CU (k_q1.hip's sweep)
-    if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * MAX_SLOTS * L.W * 8))) return rc;
-    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[8], 0, 16, s));
-    FewArgs A;
-    A.row0 = *done; A.n = cn; A.partial = g->partial; A.ctrl = g->ctrl + 8;
-    if (L.naggs <= 2) hipLaunchKernelGGL(gb_few_kernel<2>, dim3(grid), dim3(256), 0, s, L, C, A);
-    else hipLaunchKernelGGL(gb_few_kernel<FEW_MAXA>, dim3(grid), dim3(256), 0, s, L, C, A);
-    DBHIP_LAUNCH_CHECK();
-    uint64_t hc[2];
-    DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl + 8, sizeof(hc), hipMemcpyDeviceToHost, s));
-    DBHIP_CHECK(hipStreamSynchronize(s));
-    if (hc[1] & 3) { g->few_disabled = 1; return DBHIP_OK; }
-    if ((rc = merge_rows(g, g->partial, (int64_t)hc[0], s))) return rc;
-    g->rows_seen += cn;
-    *done += cn;
-    if (g->count_host > MAX_SLOTS) { g->few_disabled = 1; return DBHIP_OK; }  // different groups in different workgroups
-  }
+  if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * MAX_SLOTS * L.W * 8))) return rc;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[8], 0, 16, s));
+  FewArgs A;
+  A.row0 = 0; A.n = n; A.partial = g->partial; A.ctrl = g->ctrl + 8;
+  if (L.naggs <= 2) hipLaunchKernelGGL(gb_few_kernel<2>, dim3(grid), dim3(256), 0, s, L, C, A);
+  else hipLaunchKernelGGL(gb_few_kernel<FEW_MAXA>, dim3(grid), dim3(256), 0, s, L, C, A);
+  DBHIP_LAUNCH_CHECK();
+  uint64_t hc[2];
+  DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl + 8, sizeof(hc), hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (hc[1] & 3) { g->few_disabled = 1; return DBHIP_OK; }
+  if ((rc = merge_rows(g, g->partial, (int64_t)hc[0], s))) return rc;
+  g->rows_seen += n;
+  *handled = true;
   return DBHIP_OK;
 }
 
@@ -1791,8 +1786,9 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
   int64_t done = 0;
   if (!g->few_disabled && g->part_bits <= 0 && g->count_host <= MAX_SLOTS && n >= 65536 && few_layout_ok(g->L) &&
       g->hash_mask == ~0ULL) {
-    if ((rc = add_block_few(g, C, n, s, &done))) return rc;
-    if (done >= n) return DBHIP_OK;
+    bool handled = false;
+    if ((rc = add_block_few(g, C, n, s, &handled))) return rc;
+    if (handled) return DBHIP_OK;
   }
   if (fast_layout_ok(g->L)) {
     rc = add_block_fast(g, C, n, s, &done);
