@@ -797,65 +797,6 @@ __device__ __forceinline__ void fk_load(const GbLayout& L, const GbCols& C, int6
   }
 }
 
-// All R rows of a tile, column by column (gb_load_words_n: the R loads of a column are in flight together).
-template <int KW, int NA, bool HI, int R>
-__device__ __forceinline__ void fk_load_tile(const GbLayout& L, const GbCols& C, const int64_t (&row)[R],
-                                             FkRow<KW, NA, HI> (&r)[R], uint64_t* ctrl) {
-  uint64_t vmask[R];
-#pragma unroll
-  for (int x = 0; x < R; ++x) {
-#pragma unroll
-    for (int j = 0; j < KW; ++j) r[x].kw[j] = 0;
-    r[x].h = 0; r[x].avalid = 0; vmask[x] = 0;
-    if (HI) {
-#pragma unroll
-      for (int a = 0; a < (HI ? NA : 1); ++a) r[x].ah[a] = 0;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < KW; ++k) {
-    if (k < L.nkeys) {
-      uint64_t w0[R], w1[R];
-      bool valid[R];
-      if (!gb_load_words_n<R>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
-#pragma unroll
-      for (int x = 0; x < R; ++x) {
-        const uint64_t w[2] = {w0[x], w1[x]};
-        const uint64_t hk = gb_hash_words(L.key_type[k], w, valid[x]);
-        r[x].h = (k == 0) ? hk : merge_hash(r[x].h, hk);
-        fk_put<KW>(r[x].kw, L.key_off[k], w0[x]);
-        if (L.key_words[k] == 2) fk_put<KW>(r[x].kw, L.key_off[k] + 1, w1[x]);
-        if (valid[x]) vmask[x] |= 1ULL << k;
-      }
-    }
-  }
-  if (L.validity_word >= 0) {
-#pragma unroll
-    for (int x = 0; x < R; ++x) fk_put<KW>(r[x].kw, L.validity_word, vmask[x]);
-  }
-#pragma unroll
-  for (int a = 0; a < NA; ++a) {
-#pragma unroll
-    for (int x = 0; x < R; ++x) r[x].aw[a] = 0;
-    if (a < L.naggs) {
-      if (C.arg[a].data != nullptr) {
-        uint64_t w0[R], w1[R];
-        bool valid[R];
-        gb_load_words_n<R>(C.arg[a], row, w0, w1, valid);
-#pragma unroll
-        for (int x = 0; x < R; ++x) {
-          r[x].aw[a] = w0[x];
-          if (HI) r[x].ah[a] = w1[x];
-          if (valid[x]) r[x].avalid |= 1u << a;
-        }
-      } else {
-#pragma unroll
-        for (int x = 0; x < R; ++x) r[x].avalid |= 1u << a;
-      }
-    }
-  }
-}
-
 // state contribution of one row for aggregate a (same encoding as gb_serialize_kernel)
 __device__ __forceinline__ void fk_contrib(const GbLayout& L, int a, uint64_t w0, uint64_t w1, bool valid, uint64_t v[3]) {
   v[0] = 0; v[1] = 0; v[2] = 0;
@@ -910,14 +851,12 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
   for (int64_t t = t_begin; t < t_end; ++t) {
     FkRow<KW, NA, HI> r[R];
     uint32_t slot[R];
-    // ---- loads of the whole tile first (R rows per lane in flight, column by column) ----
-    int64_t rows[R];
+    // ---- loads of the whole tile first (R rows per lane in flight) ----
 #pragma unroll
     for (int x = 0; x < R; ++x) {
       const int64_t li = t * tile_rows + x * 256 + tid;
-      rows[x] = A.row0 + (li < A.n ? li : 0);
+      fk_load<KW, NA, HI>(L, C, A.row0 + (li < A.n ? li : 0), r[x], A.ctrl);
     }
-    fk_load_tile<KW, NA, HI, R>(L, C, rows, r, A.ctrl);
     // ---- phase A: match-or-claim by hash ----
 #pragma unroll
     for (int x = 0; x < R; ++x) {
@@ -1089,50 +1028,37 @@ __global__ __launch_bounds__(256, 2) void gb_few_kernel(GbLayout L, GbCols C, Fe
     uint64_t kw[FEW_ROWS][4], av[FEW_ROWS][NA];
     bool in[FEW_ROWS];
     uint32_t avalid[FEW_ROWS];
-    int64_t rows[FEW_ROWS];
-    uint64_t vmask[FEW_ROWS];
-    // ---- loads of all FEW_ROWS rows first, column by column ----
+    // ---- loads of all FEW_ROWS rows first ----
 #pragma unroll
     for (int u = 0; u < FEW_ROWS; ++u) {
       const int64_t li = base + (int64_t)u * TT + t;
       in[u] = li < A.n;
-      rows[u] = A.row0 + (in[u] ? li : 0);
-      vmask[u] = 0; avalid[u] = 0;
+      const int64_t i = A.row0 + (in[u] ? li : 0);
+      uint64_t vmask = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) kw[u][j] = 0;
-    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < L.nkeys) {
-        uint64_t w0[FEW_ROWS], w1[FEW_ROWS];
-        bool valid[FEW_ROWS];
-        if (!gb_load_words_n<FEW_ROWS>(C.key[k], rows, w0, w1, valid)) flags |= 2u;
-#pragma unroll
-        for (int u = 0; u < FEW_ROWS; ++u) {
-          fk_put<4>(kw[u], L.key_off[k], w0[u]);
-          if (L.key_words[k] == 2) fk_put<4>(kw[u], L.key_off[k] + 1, w1[u]);
-          if (valid[u]) vmask[u] |= 1ULL << k;
+      for (int k = 0; k < 4; ++k) {
+        if (k < L.nkeys) {
+          uint64_t w[2];
+          bool valid;
+          if (!gb_load_words(C.key[k], i, w, &valid)) flags |= 2u;
+          fk_put<4>(kw[u], L.key_off[k], w[0]);
+          if (L.key_words[k] == 2) fk_put<4>(kw[u], L.key_off[k] + 1, w[1]);
+          if (valid) vmask |= 1ULL << k;
         }
       }
-    }
-    if (L.validity_word >= 0) {
+      if (L.validity_word >= 0) fk_put<4>(kw[u], L.validity_word, vmask);
+      avalid[u] = 0;
 #pragma unroll
-      for (int u = 0; u < FEW_ROWS; ++u) fk_put<4>(kw[u], L.validity_word, vmask[u]);
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-#pragma unroll
-      for (int u = 0; u < FEW_ROWS; ++u) av[u][a] = 0;
-      if (a < L.naggs) {
-        if (C.arg[a].data != nullptr) {
-          uint64_t w0[FEW_ROWS], w1[FEW_ROWS];
-          bool valid[FEW_ROWS];
-          gb_load_words_n<FEW_ROWS>(C.arg[a], rows, w0, w1, valid);
-#pragma unroll
-          for (int u = 0; u < FEW_ROWS; ++u) { av[u][a] = w0[u]; if (valid[u]) avalid[u] |= 1u << a; }
-        } else {
-#pragma unroll
-          for (int u = 0; u < FEW_ROWS; ++u) avalid[u] |= 1u << a;
+      for (int a = 0; a < NA; ++a) {
+        av[u][a] = 0;
+        if (a < L.naggs) {
+          uint64_t w[2] = {0, 0};
+          bool valid = true;
+          if (C.arg[a].data != nullptr) gb_load_words(C.arg[a], i, w, &valid);
+          av[u][a] = w[0];
+          if (valid) avalid[u] |= 1u << a;
         }
       }
     }
