@@ -25,7 +25,6 @@
 //   Growth: when the load factor 1/1.35 (aggregate/mod.rs:55) is exceeded the table is
 //   rebuilt x4 (aggregate_hashtable.rs:314-333) and the block's probe is redone
 //   (the probe phase is idempotent; states are untouched until it succeeds).
-#include "dev_keytab.h"
 #include "gb_device.h"
 #include "runtime.h"
 
@@ -55,7 +54,6 @@ struct dbhip_groupby {
   uint64_t* partial; size_t partial_cap;   // per-workgroup partial rows
   int fast_disabled;                       // set once most rows of a chunk spilled (high NDV)
   int fast_trusted;                        // last chunk spilled < 1 %: no more probing chunks
-  int few_disabled;                        // a workgroup met more than 8 groups: the few-groups kernel is off
   // radix-partitioned pre-aggregation (medium cardinality)
   int part_bits;                           // 0 = undecided, > 0 = log2(partitions), < 0 = not worth it (row path)
   int part_forbidden;                      // test hook: never choose the partitioned path
@@ -979,184 +977,6 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
   return DBHIP_OK;
 }
 
-// ---------------------------------------------------------------------------
-// A handful of groups (<= 8 per workgroup): the fused TPC-H Q1 kernel's machinery for ANY short layout. The group
-// keys live in a tiny per-workgroup table (dev_keytab.h) mirrored in scalar registers, a row's slot is found with
-// compares against SGPRs, and every state is accumulated in per-lane REGISTERS selected by the slot id — no LDS
-// atomics on a few hot words (the LDS hash-table path runs at 0.12 of the HBM rate with 4 groups), one wave
-// reduction per (slot, aggregate) at the very end, <= 8 partial rows per workgroup for the general merge.
-// Layouts: <= 4 key words (validity word included), <= 4 aggregates, each COUNT or a one-word SUM.
-// A workgroup that meets a 9th group raises a flag: nothing is merged and the block takes the LDS path.
-// ---------------------------------------------------------------------------
-constexpr int FEW_MAXA = 4;
-constexpr int FEW_ROWS = 4;  // rows per lane and iteration (rows base + u * T + t)
-
-struct FewArgs {
-  int64_t row0, n;
-  uint64_t* partial;  // [gridDim.x * MAX_SLOTS][W]
-  uint64_t* ctrl;     // [0] = #partial rows, [1] = flags (1: more than 8 groups, 2: long string key)
-};
-
-template <int NA>
-__global__ __launch_bounds__(256, 2) void gb_few_kernel(GbLayout L, GbCols C, FewArgs A) {
-  __shared__ KeyTable T;
-  __shared__ uint64_t red[4][MAX_SLOTS][NA];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { T.count = 0; T.lock = 0; }
-  if (tid < MAX_SLOTS * 4) T.key[tid >> 2][tid & 3] = 0;
-  __syncthreads();
-  uint64_t acc[MAX_SLOTS][NA];
-#pragma unroll
-  for (int g = 0; g < MAX_SLOTS; ++g)
-#pragma unroll
-    for (int a = 0; a < NA; ++a) acc[g][a] = 0;  // 0 is also +0.0
-  bool is_f64[NA], is_cnt[NA], is_f32[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    is_cnt[a] = a < L.naggs && L.agg_kind[a] == DBHIP_AGG_COUNT;
-    is_f32[a] = a < L.naggs && !is_cnt[a] && L.agg_type[a] == DBHIP_T_F32;
-    is_f64[a] = a < L.naggs && !is_cnt[a] && (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64);
-  }
-  TabCache<MAX_SLOTS> Cc;
-  Cc.refresh(&T);
-  uint32_t flags = 0;
-  const int64_t TT = (int64_t)gridDim.x * blockDim.x;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + tid;
-  const int64_t n_pad = ((A.n + TT * FEW_ROWS - 1) / (TT * FEW_ROWS)) * (TT * FEW_ROWS);  // wave-uniform trip count
-
-  for (int64_t base = 0; base < n_pad; base += TT * FEW_ROWS) {
-    uint64_t kw[FEW_ROWS][4], av[FEW_ROWS][NA];
-    bool in[FEW_ROWS];
-    uint32_t avalid[FEW_ROWS];
-    // ---- loads of all FEW_ROWS rows first ----
-#pragma unroll
-    for (int u = 0; u < FEW_ROWS; ++u) {
-      const int64_t li = base + (int64_t)u * TT + t;
-      in[u] = li < A.n;
-      const int64_t i = A.row0 + (in[u] ? li : 0);
-      uint64_t vmask = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) kw[u][j] = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (k < L.nkeys) {
-          uint64_t w[2];
-          bool valid;
-          if (!gb_load_words(C.key[k], i, w, &valid)) flags |= 2u;
-          fk_put<4>(kw[u], L.key_off[k], w[0]);
-          if (L.key_words[k] == 2) fk_put<4>(kw[u], L.key_off[k] + 1, w[1]);
-          if (valid) vmask |= 1ULL << k;
-        }
-      }
-      if (L.validity_word >= 0) fk_put<4>(kw[u], L.validity_word, vmask);
-      avalid[u] = 0;
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        av[u][a] = 0;
-        if (a < L.naggs) {
-          uint64_t w[2] = {0, 0};
-          bool valid = true;
-          if (C.arg[a].data != nullptr) gb_load_words(C.arg[a], i, w, &valid);
-          av[u][a] = w[0];
-          if (valid) avalid[u] |= 1u << a;
-        }
-      }
-    }
-    // another wave of the block may have published new keys: pick them up (uniform, rare)
-    if (__builtin_amdgcn_readfirstlane(((volatile KeyTable*)&T)->count) != Cc.nk) Cc.refresh(&T);
-#pragma unroll
-    for (int u = 0; u < FEW_ROWS; ++u) {
-      const int slot = resolve_slot_words<MAX_SLOTS>(&T, Cc, in[u], kw[u][0], kw[u][1], kw[u][2], kw[u][3], flags);
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        if (a < L.naggs) {
-          const bool valid = (avalid[u] >> a) & 1;
-          uint64_t v = is_cnt[a] ? (valid ? 1ULL : 0ULL) : (valid ? av[u][a] : 0ULL);
-          if (is_f32[a]) v = valid ? (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)av[u][a])) : 0ULL;
-#pragma unroll
-          for (int g = 0; g < MAX_SLOTS; ++g) {
-            const bool sel = slot == g;
-            if (is_f64[a]) acc[g][a] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)acc[g][a]) + (sel ? __longlong_as_double((long long)v) : 0.0));
-            else acc[g][a] += sel ? v : 0ULL;
-          }
-        }
-      }
-    }
-  }
-  // ---- wave reduce, block combine, partial rows ----
-#pragma unroll
-  for (int g = 0; g < MAX_SLOTS; ++g)
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      uint64_t tot;
-      if (is_f64[a]) tot = (uint64_t)__double_as_longlong(wave_sum_f64(__longlong_as_double((long long)acc[g][a])));
-      else tot = wave_sum_u64(acc[g][a]);
-      if (lane == 0) red[wave][g][a] = tot;
-    }
-  flags = (uint32_t)wave_sum_u64((uint64_t)((flags & 1) | ((flags & 2) << 15)));
-  if (lane == 0 && flags) atomicOr((unsigned long long*)&A.ctrl[1], (unsigned long long)(((flags & 0xFFFF) ? 1 : 0) | ((flags >> 16) ? 2 : 0)));
-  __syncthreads();
-  if (tid < MAX_SLOTS && (uint32_t)tid < T.count) {
-    const int g = tid;
-    const unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[0], 1ULL);
-    uint64_t* r = A.partial + idx * L.W;
-    uint64_t k4[4] = {T.key[g][0], T.key[g][1], T.key[g][2], T.key[g][3]};
-    for (int j = 0; j < L.nkey_words; ++j) r[j] = k4[j];
-    const uint64_t vmask = L.validity_word >= 0 ? k4[L.validity_word] : ~0ULL;
-    uint64_t h = 0;
-    for (int k = 0; k < L.nkeys; ++k) {
-      uint64_t w[2] = {k4[L.key_off[k]], L.key_words[k] == 2 ? k4[L.key_off[k] + 1] : 0};
-      const uint64_t hk = gb_hash_words(L.key_type[k], w, (vmask >> k) & 1);
-      h = (k == 0) ? hk : merge_hash(h, hk);
-    }
-    r[L.hash_word] = h;
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      if (a < L.naggs) {
-        uint64_t tot;
-        if (is_f64[a]) tot = (uint64_t)__double_as_longlong(__longlong_as_double((long long)red[0][g][a]) + __longlong_as_double((long long)red[1][g][a]) +
-                                                             __longlong_as_double((long long)red[2][g][a]) + __longlong_as_double((long long)red[3][g][a]));
-        else tot = red[0][g][a] + red[1][g][a] + red[2][g][a] + red[3][g][a];
-        r[L.agg_off[a]] = tot;
-      }
-    }
-  }
-}
-
-bool few_layout_ok(const GbLayout& L) {
-  if (L.nkey_words > 4 || L.nkeys > 4 || L.naggs > FEW_MAXA || L.naggs < 1) return false;
-  for (int a = 0; a < L.naggs; ++a) {
-    if (L.agg_words[a] != 1) return false;
-    if (L.agg_kind[a] != DBHIP_AGG_COUNT && L.agg_kind[a] != DBHIP_AGG_SUM) return false;
-  }
-  return true;
-}
-
-// whole block through the few-groups kernel. *handled = false: a workgroup met more than 8 groups (or a long string
-// key), nothing was merged, the caller continues with the LDS / row paths from row 0.
-int32_t add_block_few(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, bool* handled) {
-  const GbLayout& L = g->L;
-  *handled = false;
-  const int64_t per = (int64_t)256 * FEW_ROWS;
-  int grid = (int)(ceil_div(n, per) < 512 ? ceil_div(n, per) : 512);  // 2 workgroups per CU (k_q1.hip's sweep)
-  int32_t rc;
-  if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * MAX_SLOTS * L.W * 8))) return rc;
-  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[8], 0, 16, s));
-  FewArgs A;
-  A.row0 = 0; A.n = n; A.partial = g->partial; A.ctrl = g->ctrl + 8;
-  if (L.naggs <= 2) hipLaunchKernelGGL(gb_few_kernel<2>, dim3(grid), dim3(256), 0, s, L, C, A);
-  else hipLaunchKernelGGL(gb_few_kernel<FEW_MAXA>, dim3(grid), dim3(256), 0, s, L, C, A);
-  DBHIP_LAUNCH_CHECK();
-  uint64_t hc[2];
-  DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl + 8, sizeof(hc), hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
-  if (hc[1] & 3) { g->few_disabled = 1; return DBHIP_OK; }
-  if ((rc = merge_rows(g, g->partial, (int64_t)hc[0], s))) return rc;
-  g->rows_seen += n;
-  *handled = true;
-  return DBHIP_OK;
-}
-
 bool fast_layout_ok(const GbLayout& L) {
   return L.nkey_words <= FK_MAXKW && L.nkeys <= FK_MAXKW && L.naggs <= FK_MAXA && L.W <= 24;
 }
@@ -1653,8 +1473,8 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
   g->part_min_rows = 262144;
   hipStream_t s = resolve_stream(nullptr);
   if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
-  DBHIP_CHECK(hipMalloc((void**)&g->ctrl, 128));
-  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 128, s));
+  DBHIP_CHECK(hipMalloc((void**)&g->ctrl, 64));
+  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 64, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
   *out_host = g;
   return DBHIP_OK;
@@ -1710,12 +1530,6 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
   }
   int32_t rc;
   int64_t done = 0;
-  if (!g->few_disabled && g->part_bits <= 0 && g->count_host <= MAX_SLOTS && n >= 65536 && few_layout_ok(g->L) &&
-      g->hash_mask == ~0ULL) {
-    bool handled = false;
-    if ((rc = add_block_few(g, C, n, s, &handled))) return rc;
-    if (handled) return DBHIP_OK;
-  }
   if (fast_layout_ok(g->L)) {
     rc = add_block_fast(g, C, n, s, &done);
     if (rc >= 0) return rc;
@@ -1901,7 +1715,6 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->count_host = 0;
   g->fast_disabled = 0;
   g->fast_trusted = 0;
-  g->few_disabled = 0;
   if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
   g->rows_seen = 0;
   return DBHIP_OK;

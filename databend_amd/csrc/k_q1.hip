@@ -26,7 +26,6 @@
 // More than SLOTS distinct keys in a block, or a key string longer than 12
 // bytes, raises DBHIP_ERR_CAPACITY/UNSUPPORTED: the caller then runs the
 // operator-at-a-time kernels (still on the GPU).
-#include "dev_keytab.h"
 #include "gb_device.h"
 #include "runtime.h"
 
@@ -44,6 +43,7 @@ const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
 
 namespace {
 
+constexpr int MAX_SLOTS = 8;
 constexpr int Q1_W = 15;  // words per row of the Q1 table layout (see dbhip_q1_create_groupby)
 
 struct alignas(16) U4 {
@@ -75,6 +75,15 @@ __device__ __forceinline__ I2 ld_i2(const int32_t* p) {
   return *(const I2*)p;
 }
 
+// Per-block key table in LDS: append-only array of the distinct group keys seen by the
+// block. Readers scan entries [0, count); a writer appends under `lock` and publishes
+// by bumping `count` after a workgroup fence, so a reader never sees a half-written key.
+struct KeyTable {
+  uint32_t count;
+  uint32_t lock;
+  uint64_t key[MAX_SLOTS][4];
+};
+
 // canonical words of an inline view (bytes past len zeroed), false if len > 12
 __device__ __forceinline__ bool view_words(U4 v, uint64_t w[2]) {
   uint32_t len = v.x;
@@ -91,6 +100,57 @@ __device__ __forceinline__ uint64_t hash_view_words(const uint64_t w[2]) {
   return agg_hash_inline_view((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
 }
 
+// slow path, ONE lane of a wave at a time: find or append under the lock. -1 when full.
+template <int SLOTS>
+__device__ __forceinline__ int tab_insert(KeyTable* T, uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3) {
+  while (atomicCAS(&T->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+  volatile KeyTable* V = T;
+  uint32_t nk = V->count;
+  int slot = -1;
+  for (uint32_t s = 0; s < nk; ++s)
+    if (V->key[s][0] == k0 && V->key[s][1] == k1 && V->key[s][2] == k2 && V->key[s][3] == k3) slot = (int)s;
+  if (slot < 0 && nk < (uint32_t)SLOTS) {
+    V->key[nk][0] = k0; V->key[nk][1] = k1; V->key[nk][2] = k2; V->key[nk][3] = k3;
+    __threadfence_block();
+    V->count = nk + 1;
+    slot = (int)nk;
+  }
+  __threadfence_block();
+  atomicExch(&T->lock, 0u);
+  return slot;
+}
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Wave-private, scalar-register copy of the published part of the block's key table.
+template <int SLOTS>
+struct TabCache {
+  uint32_t nk;
+  uint64_t k[SLOTS][4];
+  __device__ __forceinline__ void refresh(KeyTable* T) {
+    volatile KeyTable* V = T;
+    nk = __builtin_amdgcn_readfirstlane(V->count);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[s][j] = uniform_u64(V->key[s][j]);
+  }
+  // branch-free compare against every published entry; -1 if absent
+  __device__ __forceinline__ int lookup(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3) const {
+    int slot = -1;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      bool eq = ((uint32_t)s < nk) & (k[s][0] == k0) & (k[s][1] == k1) & (k[s][2] == k2) & (k[s][3] == k3);
+      slot = eq ? s : slot;
+    }
+    return slot;
+  }
+};
+
 // resolve the slot of one key row (wave-convergent call). 0xF = row not valid, 0xE = dropped.
 template <int SLOTS>
 __device__ __forceinline__ int resolve_slot(KeyTable* T, TabCache<SLOTS>& C, bool row_valid, U4 v0, U4 v1,
@@ -98,7 +158,24 @@ __device__ __forceinline__ int resolve_slot(KeyTable* T, TabCache<SLOTS>& C, boo
   uint64_t ka[2], kb[2];
   bool ok = view_words(v0, ka) & view_words(v1, kb);
   flags |= (row_valid & !ok) ? 2u : 0u;
-  return resolve_slot_words<SLOTS>(T, C, row_valid & ok, ka[0], ka[1], kb[0], kb[1], flags);
+  const bool want = row_valid & ok;
+  int slot = C.lookup(ka[0], ka[1], kb[0], kb[1]);
+  slot = want ? slot : 0xF;
+  uint64_t miss = __ballot(slot < 0);
+  while (miss) {  // rare: a key this wave has not seen published yet
+    const int leader = __ffsll((long long)miss) - 1;
+    if (lane_id() == leader) {
+      int ls = tab_insert<SLOTS>(T, ka[0], ka[1], kb[0], kb[1]);
+      if (ls < 0) flags |= 1u;
+    }
+    C.refresh(T);
+    int again = C.lookup(ka[0], ka[1], kb[0], kb[1]);
+    // after the leader's insert its key is published (or the table is full)
+    const bool full = C.nk >= (uint32_t)SLOTS;
+    if (slot < 0) slot = again >= 0 ? again : (full ? 0xE : -1);
+    miss = __ballot(slot < 0);
+  }
+  return slot;
 }
 
 struct Q1Args {
