@@ -524,6 +524,44 @@ def test_groupby_short_layout_lds_preaggregation_matches_oracle(gpu, oracle, n, 
         assert r2[2] == ((r[2] * 2 + 2**63) % 2**64) - 2**63 and r2[3] == 2 * r[3] and r2[4] == 2 * r[4] and r2[5:7] == r[5:7] and r2[7] == 2 * r[7]
 
 
+@pytest.mark.parametrize("n,card,strkey", [(65_536, 3, False), (300_001, 3, False), (300_001, 5, False), (200_000, 3, True)])
+def test_groupby_few_groups_short_count_sum_layout_matches_oracle(gpu, oracle, n, card, strkey):
+    """A handful of groups (8 with card = 3, more with card = 5) on a short COUNT / SUM layout, two blocks: nullable
+    key, nullable count argument, f64 sum of integers (order free), short string key — equal to the oracle."""
+    rng = np.random.default_rng(n + card)
+    k_i64 = rng.integers(0, card, n).astype(np.int64) * 1_000_003 - 7
+    k_date = rng.integers(0, 2, n).astype(np.int32)
+    kvalid = rng.integers(0, 16, n) > 0
+    a_i64 = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    a_f64 = rng.integers(-1000, 1000, n).astype(np.float64)
+    a_u16 = rng.integers(0, 2**16 - 1, n).astype(np.uint16)
+    avalid = rng.integers(0, 3, n) > 0
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_F64, 0, 0, 0), (T.AGG_COUNT, T.T_U16, 0, 0, 1)]
+    if strkey:
+        strs = [b"grp-%d" % (x % card) for x in rng.integers(0, 100, n)]
+        key_types, key_nullable = [T.T_STRING, T.T_DATE], [0, 0]
+        gkeys = [gpu.Column.strings(strs), gpu.Column.from_numpy(k_date, T.T_DATE)]
+        from databend_amd.device import make_views_general
+        v, buf = make_views_general(strs)
+        hkeys = [O.HostCol(T.T_STRING, v, buffers=[buf]), O.HostCol(T.T_DATE, k_date)]
+    else:
+        key_types, key_nullable = [T.T_I64, T.T_DATE], [1, 0]
+        gkeys = [gpu.Column.from_numpy(k_i64, validity=kvalid), gpu.Column.from_numpy(k_date, T.T_DATE)]
+        hkeys = [O.HostCol(T.T_I64, k_i64, kvalid), O.HostCol(T.T_DATE, k_date)]
+    gargs = [gpu.Column.from_numpy(a_i64), None, gpu.Column.from_numpy(a_f64), gpu.Column.from_numpy(a_u16, validity=avalid)]
+    hargs = [O.HostCol(T.T_I64, a_i64), None, O.HostCol(T.T_F64, a_f64), O.HostCol(T.T_U16, a_u16, avalid)]
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    g.add_block(gkeys, gargs, n)
+    g.add_block(gkeys, gargs, n)  # a second block lands on existing groups
+    got = g.result()
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n)
+    assert oracle.orc_hashagg_add_block(h, O.cols(hkeys), (O.OCol * 4)(*[a.c() if a is not None else O.OCol() for a in hargs]), C.c_int64(n)) == 0
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert g.num_groups() == len(exp)
+    assert norm(got) == norm(exp)
+
+
 def test_groupby_short_layout_string_key_and_f64_sum(gpu, oracle):
     n = 120_000
     rng = np.random.default_rng(77)
