@@ -136,16 +136,12 @@ __device__ i128 round_div_128(i128 a, i128 b, int mul_scale) {
   return neg ? (i128)((u128)0 - q.lo) : (i128)q.lo;
 }
 
-__global__ __launch_bounds__(256) void decimal_kernel(DecParams p) {
-  const bool t128 = p.t_is_128;
-  const bool a_dec = p.a_type == DBHIP_T_DEC64 || p.a_type == DBHIP_T_DEC128;
-  const bool b_dec = p.b_type == DBHIP_T_DEC64 || p.b_type == DBHIP_T_DEC128;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    i128 a, b, r = 1;
-    bool ok = convert_operand(load_operand(p.a, p.a_type, p.a_scalar, i), a_dec, p.a_from_scale,
+// one row: operands -> bound sizes -> op in T; false = the row raises (value 1 is stored, like the reference builders)
+__device__ __forceinline__ bool dec_row(const DecParams& p, i128 av, i128 bv, bool a_dec, bool b_dec, bool t128, i128* out) {
+  i128 a, b, r = 1;
+    bool ok = convert_operand(av, a_dec, p.a_from_scale,
                               p.a_to_scale, p.a_to_precision, p.a_check, t128, &a);
-    ok = convert_operand(load_operand(p.b, p.b_type, p.b_scalar, i), b_dec, p.b_from_scale,
+    ok = convert_operand(bv, b_dec, p.b_from_scale,
                          p.b_to_scale, p.b_to_precision, p.b_check, t128, &b) && ok;
     if (ok) {
       switch (p.op) {
@@ -205,12 +201,89 @@ __global__ __launch_bounds__(256) void decimal_kernel(DecParams p) {
         } break;
       }
     }
-    if (!ok) {
-      dec_raise(p, i);
-      r = 1;
+    *out = r;
+    return ok;
+}
+
+// the N loads of one operand with the type switch outside the row loop (independent loads in one basic block)
+template <int N>
+__device__ __forceinline__ void load_operand_n(const void* p, int type, bool scalar, const int64_t (&i)[N], i128 (&out)[N]) {
+  int64_t j[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) j[u] = scalar ? 0 : i[u];
+  switch (type) {
+    case DBHIP_T_DEC128:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = ((const i128*)p)[j[u]];
+      break;
+    case DBHIP_T_DEC64: case DBHIP_T_I64:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const int64_t*)p)[j[u]];
+      break;
+    case DBHIP_T_I8:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const int8_t*)p)[j[u]];
+      break;
+    case DBHIP_T_I16:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const int16_t*)p)[j[u]];
+      break;
+    case DBHIP_T_I32:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const int32_t*)p)[j[u]];
+      break;
+    case DBHIP_T_U8:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const uint8_t*)p)[j[u]];
+      break;
+    case DBHIP_T_U16:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const uint16_t*)p)[j[u]];
+      break;
+    case DBHIP_T_U32:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const uint32_t*)p)[j[u]];
+      break;
+    default:
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = (i128)((const uint64_t*)p)[j[u]];  // U64
+      break;
+  }
+}
+
+// Four rows per lane (rows base + u T + t): with one row per lane only 16 bytes per lane are in flight and the kernel
+// is latency bound (0.44 of the HBM rate on dec64 x dec64 -> dec128).
+__global__ __launch_bounds__(256) void decimal_kernel(DecParams p) {
+  const bool t128 = p.t_is_128;
+  const bool a_dec = p.a_type == DBHIP_T_DEC64 || p.a_type == DBHIP_T_DEC128;
+  const bool b_dec = p.b_type == DBHIP_T_DEC64 || p.b_type == DBHIP_T_DEC128;
+  constexpr int U = 4;
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t base = 0; base < p.n; base += U * T) {
+    int64_t row[U];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row[u] = base + u * T + t;
+      in[u] = row[u] < p.n;
+      if (!in[u]) row[u] = p.n - 1;
     }
-    if (p.out_type == DBHIP_T_DEC128) ((i128*)p.out)[i] = r;
-    else ((int64_t*)p.out)[i] = (int64_t)r;
+    i128 av[U], bv[U];
+    load_operand_n<U>(p.a, p.a_type, p.a_scalar, row, av);
+    load_operand_n<U>(p.b, p.b_type, p.b_scalar, row, bv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!in[u]) continue;
+      const int64_t i = row[u];
+      i128 r;
+      if (!dec_row(p, av[u], bv[u], a_dec, b_dec, t128, &r)) {
+        dec_raise(p, i);
+        r = 1;
+      }
+      if (p.out_type == DBHIP_T_DEC128) ((i128*)p.out)[i] = r;
+      else ((int64_t*)p.out)[i] = (int64_t)r;
+    }
   }
 }
 
@@ -339,7 +412,7 @@ int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* r
     set_error("dbhip_decimal_arith: scale shift %d outside the supported range", p.scale_mul);
     return DBHIP_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(decimal_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(decimal_kernel, dim3(grid_for(ceil_div(n, 4), 256)), dim3(256), 0, s, p);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
