@@ -74,87 +74,129 @@ struct HashCols {
   int n;
 };
 
-// Four rows per lane (rows q, q + T, q + 2T, q + 3T of a 4T-row tile, T = threads of the grid): one row per lane
-// leaves 8 bytes per lane in flight, which is latency bound (0.57 of the HBM rate on one i64 key column).
+// Four rows per lane (rows base + u T + t), column by column: the four loads of a column are independent instructions
+// in one basic block (gb_load_words_n); one row per lane leaves 8 bytes per lane in flight, which is latency bound.
 __global__ __launch_bounds__(256) void group_hash_kernel(HashCols hc, int64_t n, uint64_t* out,
                                                          unsigned long long* bad) {
+  constexpr int U = 4;
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (int64_t base = 0; base < n; base += 4 * T) {
+  for (int64_t base = 0; base < n; base += U * T) {
+    int64_t row[U];
+    bool in[U];
+    uint64_t h[U];
 #pragma unroll
-   for (int u = 0; u < 4; ++u) {
-    const int64_t i = base + u * T + t;
-    if (i >= n) continue;
-    uint64_t h = 0;
+    for (int u = 0; u < U; ++u) {
+      row[u] = base + u * T + t;
+      in[u] = row[u] < n;
+      if (!in[u]) row[u] = n - 1;
+      h[u] = 0;
+    }
     for (int k = 0; k < hc.n; ++k) {
-      uint64_t w[2];
-      bool valid;
-      uint64_t hk;
       if (hc.c[k].type == DBHIP_T_STRING) {
         // general strings (any length): hash the bytes where they live
-        int64_t j = hc.c[k].is_scalar ? 0 : i;
-        valid = !hc.c[k].validity || bit_get(hc.c[k].validity, hc.c[k].voff + j);
-        const uint32_t* v = (const uint32_t*)hc.c[k].data + 4 * j;
-        uint32_t len = v[0];
-        const uint8_t* p = len <= 12 ? (const uint8_t*)(v + 1)
-                                     : (const uint8_t*)hc.c[k].buffers[v[2]] + v[3];
-        hk = valid ? agg_hash_bytes(p, len) : DBHIP_NULL_HASH_VAL;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = hc.c[k].is_scalar ? 0 : row[u];
+          const bool valid = !hc.c[k].validity || bit_get(hc.c[k].validity, hc.c[k].voff + j);
+          const uint32_t* v = (const uint32_t*)hc.c[k].data + 4 * j;
+          const uint32_t len = v[0];
+          const uint8_t* p = len <= 12 ? (const uint8_t*)(v + 1) : (const uint8_t*)hc.c[k].buffers[v[2]] + v[3];
+          const uint64_t hk = valid ? agg_hash_bytes(p, len) : DBHIP_NULL_HASH_VAL;
+          h[u] = (k == 0) ? hk : merge_hash(h[u], hk);
+        }
       } else {
-        if (!gb_load_words(hc.c[k], i, w, &valid)) atomicAdd(bad, 1ULL);
-        hk = gb_hash_words(hc.c[k].type, w, valid);
+        uint64_t w0[U], w1[U];
+        bool valid[U];
+        if (!gb_load_words_n<U>(hc.c[k], row, w0, w1, valid)) atomicAdd(bad, 1ULL);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint64_t w[2] = {w0[u], w1[u]};
+          const uint64_t hk = gb_hash_words(hc.c[k].type, w, valid[u]);
+          h[u] = (k == 0) ? hk : merge_hash(h[u], hk);
+        }
       }
-      h = (k == 0) ? hk : merge_hash(h, hk);
     }
-    out[i] = h;
-   }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (in[u]) out[row[u]] = h[u];
   }
 }
 
 // ---------------------------------------------------------------------------
 // serialize: columns -> rows_in
 // ---------------------------------------------------------------------------
+// Four rows per lane, column by column (gb_load_words_n): the loads of a column are in flight together.
 __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n,
                                                            uint64_t* rows_in, uint64_t* ctrl) {
-  for (int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; li < n;
-       li += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t* r = rows_in + li * L.W;
-    const int64_t i = row0 + li;
-    uint64_t h = 0, vmask = 0;
-    for (int k = 0; k < L.nkeys; ++k) {
-      uint64_t w[2];
-      bool valid;
-      if (!gb_load_words(C.key[k], i, w, &valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
-      uint64_t hk = gb_hash_words(L.key_type[k], w, valid);
-      h = (k == 0) ? hk : merge_hash(h, hk);
-      r[L.key_off[k]] = w[0];
-      if (L.key_words[k] == 2) r[L.key_off[k] + 1] = w[1];
-      if (valid) vmask |= 1ULL << k;
+  constexpr int U = 4;
+  const int64_t T = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t base = 0; base < n; base += U * T) {
+    int64_t li[U], row[U];
+    bool in[U];
+    uint64_t h[U], vmask[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      li[u] = base + u * T + t;
+      in[u] = li[u] < n;
+      if (!in[u]) li[u] = n - 1;
+      row[u] = row0 + li[u];
+      h[u] = 0; vmask[u] = 0;
     }
-    if (L.validity_word >= 0) r[L.validity_word] = vmask;
-    r[L.hash_word] = h;
+    for (int k = 0; k < L.nkeys; ++k) {
+      uint64_t w0[U], w1[U];
+      bool valid[U];
+      if (!gb_load_words_n<U>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t w[2] = {w0[u], w1[u]};
+        const uint64_t hk = gb_hash_words(L.key_type[k], w, valid[u]);
+        h[u] = (k == 0) ? hk : merge_hash(h[u], hk);
+        if (in[u]) {
+          uint64_t* r = rows_in + li[u] * L.W;
+          r[L.key_off[k]] = w0[u];
+          if (L.key_words[k] == 2) r[L.key_off[k] + 1] = w1[u];
+        }
+        if (valid[u]) vmask[u] |= 1ULL << k;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (in[u]) {
+        uint64_t* r = rows_in + li[u] * L.W;
+        if (L.validity_word >= 0) r[L.validity_word] = vmask[u];
+        r[L.hash_word] = h[u];
+      }
+    }
     for (int a = 0; a < L.naggs; ++a) {
-      uint64_t* s = r + L.agg_off[a];
-      uint64_t w[2] = {0, 0};
-      bool valid = true;
-      bool has_arg = C.arg[a].data != nullptr;
-      if (has_arg) gb_load_words(C.arg[a], i, w, &valid);
-      switch (L.agg_kind[a]) {
-        case DBHIP_AGG_COUNT:
-          s[0] = valid ? 1 : 0;
-          break;
-        case DBHIP_AGG_SUM:
-          if (L.agg_type[a] == DBHIP_T_F32)
-            w[0] = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)w[0]));
-          s[0] = valid ? w[0] : 0;
-          if (L.agg_words[a] == 3) {
-            s[1] = valid ? w[1] : 0;
-            s[2] = (valid && (w[1] >> 63)) ? ~0ULL : 0;  // sign extension to 192 bits
-          }
-          break;
-        default:  // MIN / MAX
-          s[0] = ord_encode(w[0], L.agg_type[a]);
-          s[1] = valid ? 1 : 0;
-          break;
+      uint64_t w0[U], w1[U];
+      bool valid[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { w0[u] = 0; w1[u] = 0; valid[u] = true; }
+      if (C.arg[a].data != nullptr) gb_load_words_n<U>(C.arg[a], row, w0, w1, valid);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!in[u]) continue;
+        uint64_t* s = rows_in + li[u] * L.W + L.agg_off[a];
+        switch (L.agg_kind[a]) {
+          case DBHIP_AGG_COUNT:
+            s[0] = valid[u] ? 1 : 0;
+            break;
+          case DBHIP_AGG_SUM: {
+            uint64_t x = w0[u];
+            if (L.agg_type[a] == DBHIP_T_F32) x = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));
+            s[0] = valid[u] ? x : 0;
+            if (L.agg_words[a] == 3) {
+              s[1] = valid[u] ? w1[u] : 0;
+              s[2] = (valid[u] && (w1[u] >> 63)) ? ~0ULL : 0;  // sign extension to 192 bits
+            }
+          } break;
+          default:  // MIN / MAX
+            s[0] = ord_encode(w0[u], L.agg_type[a]);
+            s[1] = valid[u] ? 1 : 0;
+            break;
+        }
       }
     }
   }
@@ -1453,7 +1495,7 @@ int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n, uint64
   unsigned long long* bad = (unsigned long long*)scratch(8, 2);
   if (!bad) return DBHIP_ERR_HIP;
   DBHIP_CHECK(hipMemsetAsync(bad, 0, 8, s));
-  hipLaunchKernelGGL(group_hash_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, hc, n, out_hashes, bad);
+  hipLaunchKernelGGL(group_hash_kernel, dim3(grid_for(ceil_div(n, 4), 256)), dim3(256), 0, s, hc, n, out_hashes, bad);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
@@ -1548,7 +1590,7 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
     // walk the table slice by slice — was measured and does not pay: at 10^6..10^7 groups the row path is bound by
     // the two device-scope atomics per row, not by the random sectors. r01y: 17.9 ms vs 16.4 ms at 10 M groups.)
     if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
-    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
+    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(ceil_div(cn, 4), 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
                        g->ctrl);
     DBHIP_LAUNCH_CHECK();
     if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
