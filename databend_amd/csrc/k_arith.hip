@@ -121,6 +121,19 @@ __global__ __launch_bounds__(256) void arith_kernel(ArithParams p) {
           }
         }
         break;
+      case DBHIP_OP_DIV0:     // div0_function (numeric_basic_arithmetic.rs:441-448): x / 0 = 0, no error
+      case DBHIP_OP_DIVNULL:  // divnull_function (:450-457): x / 0 = NULL — the row's bit of `err_bitmap` is cleared
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double x = wide_to_f64(a[k], acls), y = wide_to_f64(b[k], bcls);
+          if (y == 0.0) {
+            if (p.op == DBHIP_OP_DIVNULL && i0 + k < p.n) raise_row(p, i0 + k);
+            r[k] = 0;  // F64::default()
+          } else {
+            r[k] = (uint64_t)__double_as_longlong(x / y);
+          }
+        }
+        break;
       case DBHIP_OP_INTDIV:
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -314,6 +327,8 @@ int coerce(int op, int a, int b) {
     case DBHIP_OP_MINUS:
       return make_num(next_bits(bw), true, is_float);
     case DBHIP_OP_DIVIDE:
+    case DBHIP_OP_DIV0:
+    case DBHIP_OP_DIVNULL:
       return DBHIP_T_F64;
     case DBHIP_OP_INTDIV:
       return make_num(bw, is_signed, false);

@@ -581,7 +581,10 @@ struct ArithFn : ScalarFunction {
     int32_t rc = dbhip_arith(op, &a, &b, n, out.id, r.data->ptr(), err ? (uint8_t*)err->ptr() : nullptr,
                              cnt ? (uint64_t*)cnt->ptr() : nullptr, nullptr);
     check(rc);
-    if (can_fail) {  // EvalContext::set_error replay: the kernel cleared the bit of every failing row
+    if (op == DBHIP_OP_DIVNULL) {  // x / 0 = NULL: the kernel's row bitmap is the result's validity contribution
+      uint64_t nnull = 0; cnt->download(&nnull, 8);
+      if (nnull) { r.validity = and_validity(r.validity, err, n); r.type.nullable = true; }
+    } else if (can_fail && op != DBHIP_OP_DIV0) {  // EvalContext::set_error replay: the kernel cleared the bit of every failing row
       uint64_t nerr = 0; cnt->download(&nerr, 8);
       if (nerr) ctx.set_errors(err, op == DBHIP_OP_MODULO ? "Division by zero" : "divided by zero");
     }
@@ -677,6 +680,11 @@ inline void register_builtins(FunctionRegistry& reg) {
         reg.register_function({{op.first, {DataType::of(l), DataType::of(r)}, DataType::of(out)},
                                std::make_shared<ArithFn>(op.second, DataType::of(out))});
       }
+  // div0 / divnull are registered on Float64 only (register_div_arithmetic, numeric_basic_arithmetic.rs:524-543)
+  reg.register_function({{"div0", {DataType::of(DBHIP_T_F64), DataType::of(DBHIP_T_F64)}, DataType::of(DBHIP_T_F64)},
+                         std::make_shared<ArithFn>(DBHIP_OP_DIV0, DataType::of(DBHIP_T_F64))});
+  reg.register_function({{"divnull", {DataType::of(DBHIP_T_F64), DataType::of(DBHIP_T_F64)}, DataType::of(DBHIP_T_F64, true)},
+                         std::make_shared<ArithFn>(DBHIP_OP_DIVNULL, DataType::of(DBHIP_T_F64))});
   // comparisons: same physical type on both sides (the planner inserts casts, comparison.rs:98-112)
   static const int cmp_types[] = {DBHIP_T_BOOL, DBHIP_T_I8, DBHIP_T_I16, DBHIP_T_I32, DBHIP_T_I64, DBHIP_T_U8, DBHIP_T_U16, DBHIP_T_U32,
                                   DBHIP_T_U64, DBHIP_T_F32, DBHIP_T_F64, DBHIP_T_DATE, DBHIP_T_TIMESTAMP, DBHIP_T_STRING};

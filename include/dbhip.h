@@ -67,7 +67,11 @@ typedef enum {
   DBHIP_OP_PLUS = 0, DBHIP_OP_MINUS = 1, DBHIP_OP_MULTIPLY = 2,
   DBHIP_OP_DIVIDE = 3,   /* '/' : always f64, "divided by zero" row error        */
   DBHIP_OP_INTDIV = 4,   /* 'div'                                                */
-  DBHIP_OP_MODULO = 5
+  DBHIP_OP_MODULO = 5,
+  DBHIP_OP_DIV0 = 6,     /* div0:    f64, x / 0 = 0, never raises (numeric_basic_arithmetic.rs:441-448, 524-531)   */
+  DBHIP_OP_DIVNULL = 7   /* divnull: f64, x / 0 = NULL: the row's bit of `err_bitmap` is cleared and counted in
+                            *err_count_dev — here the bitmap is the result's validity contribution, not an error
+                            (:450-457, 533-543)                                                                    */
 } dbhip_arith_op;
 
 /* comparison operators (src/query/functions/src/scalars/comparison.rs:98-112) */

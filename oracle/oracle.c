@@ -148,7 +148,7 @@ static int coerce(int op, int a, int b) {
   switch (op) {
     case ORC_OP_PLUS: case ORC_OP_MULTIPLY: return mk_num(next_bits(bw), sg, fl);
     case ORC_OP_MINUS: return mk_num(next_bits(bw), 1, fl);
-    case ORC_OP_DIVIDE: return ORC_T_F64;
+    case ORC_OP_DIVIDE: case ORC_OP_DIV0: case ORC_OP_DIVNULL: return ORC_T_F64;
     case ORC_OP_INTDIV: return mk_num(bw, sg, 0);
     case ORC_OP_MODULO:
       if (fl) return ORC_T_F64;
@@ -186,6 +186,15 @@ int orc_arith(int op, const orc_col* lhs, const orc_col* rhs, int64_t n, int out
         }
       } break;
       case ORC_OP_DIVIDE: { /* divide_function :410-427 */
+        double y = cast_val(b, ORC_T_F64).f;
+        if (y == 0.0) { raise_err(lhs, rhs, i, err, err_count); r.f = 0.0; }
+        else r.f = cast_val(a, ORC_T_F64).f / y;
+      } break;
+      case ORC_OP_DIV0: { /* div0_function :441-448: x / 0 = F64::default(), never raises */
+        double y = cast_val(b, ORC_T_F64).f;
+        r.f = y == 0.0 ? 0.0 : cast_val(a, ORC_T_F64).f / y;
+      } break;
+      case ORC_OP_DIVNULL: { /* divnull_function :450-457: x / 0 = None — reported through the row bitmap */
         double y = cast_val(b, ORC_T_F64).f;
         if (y == 0.0) { raise_err(lhs, rhs, i, err, err_count); r.f = 0.0; }
         else r.f = cast_val(a, ORC_T_F64).f / y;

@@ -678,3 +678,23 @@ def test_fused_expression_rejects_ill_typed_programs(gpu):
     p.ins[-1] = p.ins[-1][:4] + (T.T_I32,) + p.ins[-1][5:]   # wrong result type for Int32 + Int64
     with pytest.raises(DbhipError):
         p.run(r)
+
+
+def test_div0_and_divnull(gpu):
+    """div0: x / 0 = 0 without an error; divnull: x / 0 = NULL (numeric_basic_arithmetic.rs:441-457, registered on
+    Float64 :524-543; other numeric arguments are cast by the planner — the kernel converts like `/` does)."""
+    rng = np.random.default_rng(17)
+    n = 10_007
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    b = rng.integers(-3, 4, n).astype(np.int64)
+    va = rng.integers(0, 5, n) > 0
+    ca, cb = gpu.Column.from_numpy(a, validity=va), gpu.Column.from_numpy(b)
+    e0 = gpu.RowErrors(n)
+    r0 = gpu.arith(T.OP_DIV0, ca, cb, errors=e0)
+    exp = np.where(b == 0, 0.0, a.astype(np.float64) / np.where(b == 0, 1, b))
+    assert r0.dtype == T.T_F64 and np.array_equal(r0.to_numpy(), exp) and e0.num_errors() == 0
+    e1 = gpu.RowErrors(n)
+    r1 = gpu.arith(T.OP_DIVNULL, ca, cb, errors=e1)
+    assert np.array_equal(r1.to_numpy(), exp)
+    # rows with a zero divisor AND valid inputs become NULL (NULL inputs stay NULL through the operands' validity)
+    assert np.array_equal(e1.error_rows(), np.nonzero((b == 0) & va)[0]) and e1.num_errors() == int(((b == 0) & va).sum())

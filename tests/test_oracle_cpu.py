@@ -100,6 +100,23 @@ def test_arithmetic_golden_numeric_and_decimal():
     assert checked >= 20, checked
 
 
+def test_div0_and_divnull_known_answers():
+    """div0(x, 0) = 0, divnull(x, 0) = NULL (numeric_basic_arithmetic.rs:441-457); everything else is x / y in f64.
+    The reference's arithmetic.txt has no case for them, so the known answers are the definitions themselves."""
+    L = O.load()
+    a = np.array([10, -7, 3, 0, 5], np.int64)
+    b = np.array([4, 0, -2, 0, 1], np.int64)
+    for op, nulls in ((T.OP_DIV0, []), (T.OP_DIVNULL, [1, 3])):
+        out = np.zeros(5, np.float64)
+        err = np.full(8, 0xFF, np.uint8)
+        cnt = C.c_uint64(0)
+        ca, cb = O.HostCol(T.T_I64, a).c(), O.HostCol(T.T_I64, b).c()
+        assert L.orc_arith_result_type(op, T.T_I64, T.T_I64) == T.T_F64
+        assert L.orc_arith(op, C.byref(ca), C.byref(cb), C.c_int64(5), T.T_F64, out.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p), C.byref(cnt)) == 0
+        assert out.tolist() == [2.5, 0.0, -1.5, 0.0, 5.0]
+        assert [i for i in range(5) if not (err[0] >> i) & 1] == nulls and cnt.value == len(nulls)
+
+
 def test_comparison_golden():
     L = O.load()
     checked = 0
