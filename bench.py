@@ -200,12 +200,14 @@ def bench_ann(args, rank, world, torch, dist, D, DX, L, check):
     oi = torch.empty((nq, k), dtype=torch.int32, device=dev)
     od = torch.empty((nq, k), dtype=torch.float32, device=dev)
 
+    def merge_dev(d_ptr, i_ptr, nq_, m, k_, out_i_ptr, out_d_ptr):
+        check(L.dbhip_vec_topk_merge(C.c_void_p(d_ptr), C.c_void_p(i_ptr), C.c_int64(m), nq_, k_, C.c_void_p(out_i_ptr), C.c_void_p(out_d_ptr), None))
+
     def step():
         check(L.dbhip_vec_index_search(ix, C.c_void_p(queries.data_ptr()), nq, k, C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
         if world == 1:
             return oi, od
-        idx = oi.cpu().numpy().view(np.uint32)
-        return DX.merge_shard_topk(idx, od.cpu().numpy(), lo, k, dist, torch, dev, D.vec_topk_merge)
+        return DX.merge_shard_topk_device(oi, od, lo, k, dist, torch, lambda: check(L.dbhip_stream_sync(None)), merge_dev)
 
     step()
     check(L.dbhip_stream_sync(None))

@@ -129,3 +129,27 @@ def merge_shard_topk(idx, dst, row_offset, k, dist, torch, device, merge_fn):
     all_i = torch.cat(gi, dim=1).cpu().numpy().view(np.uint32)
     all_d = torch.cat(gd, dim=1).cpu().numpy()
     return merge_fn(all_d, all_i, k)
+
+
+def merge_shard_topk_device(idx_t, dst_t, row_offset, k, dist, torch, lib_sync, merge_dev):
+    """Device-resident variant of merge_shard_topk for the RCCL path: `idx_t` (int32 view of u32 ids, -1 = empty) and
+    `dst_t` (f32) are CUDA tensors [nq, k] the library just wrote; ids are globalised with torch arithmetic, both are
+    all-gathered with ONE fixed-size collective each and merged by dbhip_vec_topk_merge straight from the gathered
+    tensors — no host round trip. `lib_sync()` drains the library's stream (the search wrote the inputs there),
+    `merge_dev(d_ptr, i_ptr, nq, m, k, out_i_ptr, out_d_ptr)` calls the C-ABI."""
+    world = dist.get_world_size()
+    nq = idx_t.shape[0]
+    lib_sync()
+    gid = torch.where(idx_t == -1, idx_t, idx_t + int(row_offset)).contiguous()
+    gi = torch.empty((world, nq, k), dtype=torch.int32, device=idx_t.device)
+    gd = torch.empty((world, nq, k), dtype=torch.float32, device=idx_t.device)
+    dist.all_gather_into_tensor(gi, gid)
+    dist.all_gather_into_tensor(gd, dst_t.contiguous())
+    all_i = gi.permute(1, 0, 2).reshape(nq, world * k).contiguous()
+    all_d = gd.permute(1, 0, 2).reshape(nq, world * k).contiguous()
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=idx_t.device)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=idx_t.device)
+    torch.cuda.current_stream().synchronize()   # the gathered tensors are complete before the library reads them
+    merge_dev(all_d.data_ptr(), all_i.data_ptr(), nq, world * k, k, out_i.data_ptr(), out_d.data_ptr())
+    lib_sync()
+    return out_i, out_d

@@ -174,3 +174,50 @@ def test_vector_index_10m_by_768_self_retrieval_and_exact_scan_agreement(gpu):
     assert np.allclose(dist, edist, rtol=2e-5, atol=2e-6)
     assert np.all(np.diff(dist, axis=1) >= 0)
     ix.destroy()
+
+
+def test_sharded_topk_device_merge_path(gpu):
+    """The RCCL path's merge step (dist.merge_shard_topk_device) with a stand-in communicator of world size 3 that
+    'gathers' three different shards' lists on one GPU: equals the numpy merge of the same candidates."""
+    from databend_amd import dist as DX
+    nq, k, world = 37, 10, 3
+    g = gen(9)
+    shards_i = [torch.randint(0, 1000, (nq, k), device="cuda", dtype=torch.int32, generator=g) for _ in range(world)]
+    shards_d = [torch.rand((nq, k), device="cuda", dtype=torch.float32, generator=g).sort(dim=1)[0] for _ in range(world)]
+    shards_i[1][:, 7:] = -1  # a short shard: empty slots
+    shards_d[1][:, 7:] = float("inf")
+    offs = [0, 1000, 2000]
+
+    class FakeDist:
+        def __init__(self):
+            self.calls = 0
+
+        def get_world_size(self):
+            return world
+
+        def all_gather_into_tensor(self, out, inp):
+            # rank 0's view: its own contribution is `inp`; the other ranks' blocks are produced the way they would be
+            src = shards_i if inp.dtype == torch.int32 else shards_d
+            for r in range(world):
+                if inp.dtype == torch.int32:
+                    out[r] = torch.where(src[r] == -1, src[r], src[r] + offs[r])
+                else:
+                    out[r] = src[r]
+            self.calls += 1
+
+    def merge_dev(d_ptr, i_ptr, nq_, m, k_, oi_ptr, od_ptr):
+        T.check(T.lib().dbhip_vec_topk_merge(C.c_void_p(d_ptr), C.c_void_p(i_ptr), C.c_int64(m), nq_, k_, C.c_void_p(oi_ptr), C.c_void_p(od_ptr), None))
+
+    fd = FakeDist()
+    oi, od = DX.merge_shard_topk_device(shards_i[0], shards_d[0], offs[0], k, fd, torch, lambda: T.check(T.lib().dbhip_stream_sync(None)), merge_dev)
+    assert fd.calls == 2
+    got_i, got_d = oi.cpu().numpy().view(np.uint32), od.cpu().numpy()
+    for q in range(nq):
+        cand = []
+        for r in range(world):
+            for j in range(k):
+                i = int(shards_i[r][q, j].item())
+                if i != -1:
+                    cand.append((float(shards_d[r][q, j].item()), i + offs[r]))
+        cand.sort()
+        assert [(float(d), int(i)) for d, i in zip(got_d[q], got_i[q])] == cand[:k]

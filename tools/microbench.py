@@ -270,8 +270,6 @@ def main():
         ix = C.c_void_p()
         check(Lb.dbhip_vec_index_build(L.VEC_COSINE, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.byref(ix), None))
         for nq in [int(x) for x in args.vec_nq.split(',')]:
-            if nq < 64:
-                continue
             q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
             oi = torch.empty(nq * 10, dtype=torch.int32, device=dev)
             od = torch.empty(nq * 10, dtype=torch.float32, device=dev)
