@@ -676,7 +676,9 @@ struct HArgs {
 
 // TQ = 128: 4 waves (2 x 2), TQ = 256: 8 waves (4 x 2); every wave owns 64 x 64 scores. The taller tile reads the
 // base tile (L2 -> LDS) half as often per query and amortises the LDS stores over twice the matrix work.
-template <bool COSINE, int TQ>
+// METRIC: 0 cosine, 1 dot, 2 l2 (the squared distance ||q||^2 + ||b||^2 - 2 q.b is bounded from BELOW with the upper
+// bound of q.b; the per-row term -||b||^2 / 2 rides in rowA, see vec_to_bf16_kernel mode 3)
+template <int METRIC, int TQ>
 __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 256 ? 4 : 3))) void bf16_filter_kernel(HArgs A) {
   constexpr int TI = 128;
   constexpr int NT = TQ * 2;          // threads
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
   constexpr int AJ = TQ / RS, BJ = TI / RS;
   __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
-  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
+  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], rZ[TI], qB[TQ], qG[TQ], Tau[TQ];
 
   const int64_t slot = blockIdx.x >> 3;
   const int xcd = blockIdx.x & 7;
@@ -756,12 +758,15 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
   // Epilogue. A row survives unless the LOWER bound of its distance exceeds tau:
   //   cosine  1 - (v a + x B' + y G') / ||q|| > tau     <=>   v a + x B' + y G' < (1 - tau) ||q||      (a = 1/||b||)
   //   dot     v - (x B' + y G') > tau                   <=>  -v   + x B' + y G' < -tau
+  //   l2      ||q||^2 + ||b||^2 - 2 (v + x B' + y G') > tau^2  <=>  v + x B' + y G' - ||b||^2/2 < (||q||^2 - tau^2)/2
   // so per query three numbers (B', G', T') and per base row three (a, x, y). The 16 accumulator rows of a lane map to
   // 16 queries that only depend on lane >> 5: their coefficients are fetched with 12 ds_read_b128 per 32-query slab
   // (not 4 scalar LDS reads per score) and the test itself is three VALU operations.
   if (tid < TI) {
     const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
-    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
+    rA[tid] = METRIC == 0 ? A.rowA[i] : (METRIC == 1 ? -1.0f : 1.0f);
+    rZ[tid] = METRIC == 2 ? A.rowA[i] : 0.0f;
+    rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
   } else if (tid < TI + TQ) {
     const int t = tid - TI;
     const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
@@ -769,7 +774,9 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
     const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
     // (both sides of the cosine test are multiplied by ||q||: B' = ||ql|| + c ||qh||, G' = ||qh|| + ||ql||)
     qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
-    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
+    // l2: discard iff ||q||^2 + ||b||^2 - 2 (v + E) > tau^2  <=>  v + E - ||b||^2/2 < (||q||^2 - tau^2) / 2, with 1e-5 relative
+    // slack on both squared norms for their own f32 rounding
+    Tau[t] = METRIC == 0 ? (1.0f - tau) * n_ : (METRIC == 1 ? -tau : 0.5f * (0.99999f * n_ * n_ - 1.00001f * tau * tau));
   }
   __syncthreads();
 
@@ -788,11 +795,11 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
     for (int y = 0; y < 2; ++y) {
       const int il = wi + y * 32 + (lane & 31);
       const int64_t i = i0 + il;
-      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
+      const float a_ = rA[il], x_ = rX[il], y_ = rY[il], z_ = rZ[il];
       const bool row_ok = i < A.n;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
+        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r])) + z_;
         if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
           const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (q < A.nq) {
@@ -1208,6 +1215,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void b
 //   mode 0 (base rows, cosine): A = 1/||b||, X = ||bh||/||b|| (1+1e-4), Y = ||b-bh||/||b|| (1+1e-4)
 //   mode 1 (base rows, dot)   : A = 1,       X = ||bh|| (1+1e-4),       Y = ||b-bh|| (1+1e-4)
 //   mode 2 (queries)          : A = ||q||,   X = ||qh|| (1+1e-4),       Y = ||q-qh|| (1+1e-4)
+//   mode 3 (base rows, l2)    : A = -||b||^2 / 2 (1-1e-5), X = ||bh|| (1+1e-4), Y = ||b-bh|| (1+1e-4)
 __global__ __launch_bounds__(256) void vec_to_bf16_kernel(const float* __restrict__ x, int64_t n, int dim, int dpad,
                                                           int mode, uint16_t* __restrict__ out, float* __restrict__ oA,
                                                           float* __restrict__ oX, float* __restrict__ oY) {
@@ -1239,13 +1247,14 @@ __global__ __launch_bounds__(256) void vec_to_bf16_kernel(const float* __restric
       const float nb = sqrtf(s), nh = sqrtf(sh) * 1.0001f, ne = sqrtf(se) * 1.0001f;
       if (mode == 0) { oA[r] = 1.0f / nb; oX[r] = nh / nb; oY[r] = ne / nb; }
       else if (mode == 1) { oA[r] = 1.0f; oX[r] = nh; oY[r] = ne; }
+      else if (mode == 3) { oA[r] = -0.5f * 0.99999f * s; oX[r] = nh; oY[r] = ne; }
       else { oA[r] = nb; oX[r] = nh; oY[r] = ne; }
     }
   }
 }
 
 // exact f32 distance of every surviving (query, row) pair: one wave per pair
-__global__ __launch_bounds__(256) void rescore_kernel(int cosine, const float* __restrict__ base, int dim,
+__global__ __launch_bounds__(256) void rescore_kernel(int metric, const float* __restrict__ base, int dim,
                                                       const float* __restrict__ queries, const float* __restrict__ qnorm,
                                                       const uint32_t* __restrict__ cand_i, const uint32_t* __restrict__ cand_cnt,
                                                       uint32_t cap, float* __restrict__ cand_d) {
@@ -1257,14 +1266,22 @@ __global__ __launch_bounds__(256) void rescore_kernel(int cosine, const float* _
   const float* b = base + (int64_t)i * dim;
   const float* qv = queries + (int64_t)q * dim;
   float dot = 0.f, bsq = 0.f;
-  for (int k = lane_id(); k < dim; k += 64) {
-    const float bv = b[k];
-    dot = fmaf(qv[k], bv, dot);
-    bsq = fmaf(bv, bv, bsq);
+  if (metric == DBHIP_VEC_L2) {  // the difference form of the reference (distance.rs:65-80), never the expanded one
+    for (int k = lane_id(); k < dim; k += 64) {
+      const float d = qv[k] - b[k];
+      dot = fmaf(d, d, dot);
+    }
+  } else {
+    for (int k = lane_id(); k < dim; k += 64) {
+      const float bv = b[k];
+      dot = fmaf(qv[k], bv, dot);
+      bsq = fmaf(bv, bv, bsq);
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { dot += __shfl_xor(dot, off, 64); bsq += __shfl_xor(bsq, off, 64); }
-  if (lane_id() == 0) cand_d[(int64_t)q * cap + j] = cosine ? 1.0f - dot / (qnorm[q] * sqrtf(bsq)) : dot;
+  if (lane_id() == 0)
+    cand_d[(int64_t)q * cap + j] = metric == DBHIP_VEC_COSINE ? 1.0f - dot / (qnorm[q] * sqrtf(bsq)) : (metric == DBHIP_VEC_L2 ? sqrtf(dot) : dot);
 }
 
 
@@ -1276,6 +1293,7 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   const int64_t n = ix->n;
   const int dim = ix->dim, dpad = ix->dpad;
   const bool cosine = ix->metric == DBHIP_VEC_COSINE;
+  const bool l2 = ix->metric == DBHIP_VEC_L2;
   const int64_t S0 = n < 8192 ? n : 8192;
   int32_t rc = exact_topk_range(ix->metric, ix->base, 0, S0, dim, queries, nq, k, qnorm, false, out_idx, out_dist, s);
   if (rc || S0 >= n) return rc;
@@ -1314,7 +1332,10 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
     static const int kernel_version = getenv("DBHIP_BF16_V") ? atoi(getenv("DBHIP_BF16_V")) : 1;
-    if (tall && kernel_version == 4) {
+    if (l2) {  // (the experimental variants below cover cosine / dot only)
+      if (tall) hipLaunchKernelGGL((bf16_filter_kernel<2, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
+      else hipLaunchKernelGGL((bf16_filter_kernel<2, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+    } else if (tall && kernel_version == 4) {
       A.n_itiles = ceil_div(A.n, 256);
       const int64_t blocks4 = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
       if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v4<true>, dim3((unsigned)blocks4), dim3(512), 0, s, A);
@@ -1326,11 +1347,11 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
       if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v2<true>, dim3((unsigned)blocks), dim3(512), 0, s, A);
       else hipLaunchKernelGGL(bf16_filter_kernel_v2<false>, dim3((unsigned)blocks), dim3(512), 0, s, A);
     } else if (tall) {
-      if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<true, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
-      else hipLaunchKernelGGL((bf16_filter_kernel<false, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
+      if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<0, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
+      else hipLaunchKernelGGL((bf16_filter_kernel<1, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
     } else {
-      if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<true, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
-      else hipLaunchKernelGGL((bf16_filter_kernel<false, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+      if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<0, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+      else hipLaunchKernelGGL((bf16_filter_kernel<1, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
     }
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(hcnt.data(), cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
@@ -1340,7 +1361,7 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     if (maxc > CAND_CAP)  // the bound could not separate enough rows: the exact scan is always right
       return exact_topk_range(ix->metric, ix->base, lo, hi, dim, queries, nq, k, qnorm, true, out_idx, out_dist, s);
     if (maxc == 0) return DBHIP_OK;
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)ceil_div(maxc, 4), (unsigned)nq), dim3(256), 0, s, cosine ? 1 : 0, ix->base,
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)ceil_div(maxc, 4), (unsigned)nq), dim3(256), 0, s, ix->metric, ix->base,
                        dim, queries, qnorm, cand_i, cnt, CAND_CAP, cand_d);
     DBHIP_LAUNCH_CHECK();
     return select_topk(cand_d, cand_i, cnt, CAND_CAP, CAND_CAP, 0u, nq, k, true, out_dist, out_idx, s);
@@ -1361,7 +1382,7 @@ extern "C" {
 int32_t dbhip_vec_index_build(int32_t metric, const float* base, int64_t n, int32_t dim, dbhip_vec_index** out_host,
                               void* stream) {
   DBHIP_REQUIRE(out_host, "dbhip_vec_index_build: NULL out");
-  if (metric != DBHIP_VEC_COSINE && metric != DBHIP_VEC_DOT) {
+  if (metric != DBHIP_VEC_COSINE && metric != DBHIP_VEC_DOT && metric != DBHIP_VEC_L2) {
     set_error("dbhip_vec_index_build: metric %d has no bf16 pre-filter (use dbhip_vec_topk)", metric);
     return DBHIP_ERR_UNSUPPORTED;
   }
@@ -1381,7 +1402,7 @@ int32_t dbhip_vec_index_build(int32_t metric, const float* base, int64_t n, int3
   if (n > 0) {
     hipStream_t s = resolve_stream(stream);
     hipLaunchKernelGGL(vec_to_bf16_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, s, base, n, dim, ix->dpad,
-                       metric == DBHIP_VEC_COSINE ? 0 : 1, ix->bh, ix->rowA, ix->rowX, ix->rowY);
+                       metric == DBHIP_VEC_COSINE ? 0 : (metric == DBHIP_VEC_L2 ? 3 : 1), ix->bh, ix->rowA, ix->rowX, ix->rowY);
     DBHIP_LAUNCH_CHECK();
   }
   *out_host = ix;

@@ -428,7 +428,9 @@ int32_t dbhip_vec_topk_merge(const float* dists, const uint32_t* ids, int64_t m,
  * (recall 1.0): a bf16 image of the column is scanned on v_mfma_f32_32x32x16_bf16 with a rigorous
  * error bound, so that rows are only ever over-selected, and the survivors are re-scored in f32 from
  * the original column — which is borrowed and must stay valid while the index lives.
- * Metrics: COSINE, DOT (others: DBHIP_ERR_UNSUPPORTED, use dbhip_vec_topk). Results as dbhip_vec_topk. */
+ * Metrics: COSINE, DOT, L2 (l2 bounds ||q||^2 + ||b||^2 - 2 q.b from below and re-scores in the
+ * reference's difference form, distance.rs:65-80); L1: DBHIP_ERR_UNSUPPORTED, use dbhip_vec_topk.
+ * Results as dbhip_vec_topk. */
 typedef struct dbhip_vec_index dbhip_vec_index;
 int32_t dbhip_vec_index_build(int32_t metric, const float* base, int64_t n, int32_t dim,
                               dbhip_vec_index** out_host, void* stream);

@@ -328,7 +328,7 @@ def test_vec_index_is_exact(gpu, oracle, n, dim, nq, k, kind):
         q[0] = 0.0
         q[1] *= 1e15
     gb, gq = gpu.VectorColumn(base), gpu.VectorColumn(q)
-    for metric in (T.VEC_COSINE, T.VEC_DOT):
+    for metric in (T.VEC_COSINE, T.VEC_DOT, T.VEC_L2):
         ix = gpu.VectorIndex(metric, gb)
         idx, dist = ix.search(gq, k)
         eidx, edist = gpu.vec_topk(metric, gb, gq, k)
@@ -352,7 +352,7 @@ def test_vec_index_is_exact(gpu, oracle, n, dim, nq, k, kind):
         assert mism <= max(1, nq // 4 if kind == "clustered" else nq // 50), (metric, mism)
         ix.destroy()
     with pytest.raises(Exception):
-        gpu.VectorIndex(T.VEC_L2, gb)
+        gpu.VectorIndex(T.VEC_L1, gb)   # l1 has no inner-product form to pre-filter on
 
 
 def test_score_u8_matches_reference_c_kernels(gpu, oracle):

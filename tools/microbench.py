@@ -267,22 +267,25 @@ def main():
                 report(out, f"vec_topk cosine {n}x{dim}, nq={nq}, k=10", nq, "queries", alg_bytes=n * dim * 4, ms=ms)
             else:
                 report(out, f"vec_topk cosine {n}x{dim}, nq={nq}, k=10", nq, "queries", flops=2.0 * n * dim * nq, ms=ms)
-        ix = C.c_void_p()
-        check(Lb.dbhip_vec_index_build(L.VEC_COSINE, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.byref(ix), None))
-        for nq in [int(x) for x in args.vec_nq.split(',')]:
-            q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
-            oi = torch.empty(nq * 10, dtype=torch.int32, device=dev)
-            od = torch.empty(nq * 10, dtype=torch.float32, device=dev)
-            oi2 = torch.empty(nq * 10, dtype=torch.int32, device=dev)
-            od2 = torch.empty(nq * 10, dtype=torch.float32, device=dev)
-            f = lambda: check(Lb.dbhip_vec_index_search(ix, C.c_void_p(q.data_ptr()), nq, 10, C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
-            ms = timed(f, reps=3, warm=1)
-            check(Lb.dbhip_vec_topk(L.VEC_COSINE, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.c_void_p(q.data_ptr()), nq, 10, C.c_void_p(oi2.data_ptr()), C.c_void_p(od2.data_ptr()), None))
-            check(Lb.dbhip_stream_sync(None))
-            same = float((oi == oi2).float().mean().item())
-            report(out, f"vec_index_search cosine (bf16 prefilter + exact rescore) {n}x{dim}, nq={nq}, k=10", nq, "queries", flops=2.0 * n * dim * nq, ms=ms,
-                   note=f"frac is vs the FP32-MFMA peak the exact scan is bound by (bf16 dense peak 2500 TF); ids identical to the exact scan: {same:.4f}")
-        check(Lb.dbhip_vec_index_destroy(ix))
+        for imetric, iname in ((L.VEC_COSINE, 'cosine'), (L.VEC_L2, 'l2')):
+            ix = C.c_void_p()
+            check(Lb.dbhip_vec_index_build(imetric, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.byref(ix), None))
+            for nq in [int(x) for x in args.vec_nq.split(',')]:
+                if imetric == L.VEC_L2 and nq > 1 and nq < 2048:
+                    continue
+                q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
+                oi = torch.empty(nq * 10, dtype=torch.int32, device=dev)
+                od = torch.empty(nq * 10, dtype=torch.float32, device=dev)
+                oi2 = torch.empty(nq * 10, dtype=torch.int32, device=dev)
+                od2 = torch.empty(nq * 10, dtype=torch.float32, device=dev)
+                f = lambda: check(Lb.dbhip_vec_index_search(ix, C.c_void_p(q.data_ptr()), nq, 10, C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), None))
+                ms = timed(f, reps=3, warm=1)
+                check(Lb.dbhip_vec_topk(imetric, C.c_void_p(base.data_ptr()), C.c_int64(n), dim, C.c_void_p(q.data_ptr()), nq, 10, C.c_void_p(oi2.data_ptr()), C.c_void_p(od2.data_ptr()), None))
+                check(Lb.dbhip_stream_sync(None))
+                same = float((oi == oi2).float().mean().item())
+                report(out, f"vec_index_search {iname} (bf16 prefilter + exact rescore) {n}x{dim}, nq={nq}, k=10", nq, "queries", flops=2.0 * n * dim * nq, ms=ms,
+                       note=f"frac is vs the FP32-MFMA peak the exact scan is bound by (bf16 dense peak 2500 TF); ids identical to the exact scan: {same:.4f}")
+            check(Lb.dbhip_vec_index_destroy(ix))
         nq = 64
         q = torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=g)
         o = torch.empty(nq * n, dtype=torch.float32, device=dev)
