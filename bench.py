@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--ann-dim", type=int, default=768)
     ap.add_argument("--ann-queries", type=int, default=4096, help="queries per ANN step (replicated on every rank)")
     ap.add_argument("--ann-steps", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for a functional check)")
+    ap.add_argument("--share-gpu", action="store_true", help="functional check of the N>1 path on a 1-GPU box: every rank uses "
+                    "cuda:0 (with --backend gloo); the numbers of such a run are not a measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -53,10 +56,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdbhip has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from databend_amd import device as D, tpch
     from databend_amd import dist as DX
@@ -69,18 +77,24 @@ def main():
     li = tpch.LineitemDevice(host)
     g = D.GroupBy.q1()
 
-    stream = None  # the library's own stream (every dbhip call of a step is ordered on it)
+    # N = 1: the library's own stream (every dbhip call of a step is ordered on it). N > 1: one torch side stream is
+    # handed to the library, so that the fused kernel, the block flush, the RCCL all-gather and the merge of the other
+    # ranks' blocks are ordered on ONE stream with no host round trip between them (torch's default stream has handle
+    # 0, which the C-ABI reads as "the library's stream", hence a side stream).
+    ts = torch.cuda.Stream() if world > 1 else None
+    stream = C.c_void_p(ts.cuda_stream) if ts is not None else None
     kms = []
 
     def step(record=False):
-        g.reset()
+        g.reset(stream)
         D.q1_fused(g, li.qty, li.price, li.disc, li.tax, li.rf, li.ls, li.ship, tpch.Q1_CUTOFF, stream=stream)
         if record:
             ms = C.c_float()
             check(L.dbhip_last_kernel_ms(C.byref(ms)))  # HIP events around q1_fused_kernel on its stream
             kms.append(ms.value)
         if world > 1:
-            DX.exchange_partials_nccl(g, dist, torch)
+            with torch.cuda.stream(ts):
+                DX.exchange_partials_nccl(g, dist, torch, stream=stream)
         return g
 
     for _ in range(args.warmup):
@@ -108,6 +122,18 @@ def main():
     rows_total = n * world * args.steps
     value = rows_total / dt
     result = tpch.q1_rows(g)
+    if world > 1:
+        # every rank must hold the GLOBAL result: its count(*) equals the sum over ranks of the local (un-exchanged)
+        # counts, and all ranks agree on every aggregate (checked through a hash of the result rows)
+        local = tpch.q1_rows(tpch.q1_fused(li))
+        cnt = torch.tensor([sum(r["count"] for r in local.values())], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        assert sum(r["count"] for r in result.values()) == int(cnt.item()), "exchange lost or duplicated partial states"
+        import zlib
+        sig = zlib.crc32(repr(sorted((k, sorted(v.items())) for k, v in result.items())).encode())
+        lo_hi = torch.tensor([sig, -sig], dtype=torch.int64, device="cuda")
+        dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
+        assert int(lo_hi[0].item()) == sig and int(lo_hi[1].item()) == -sig, "ranks disagree on the merged result"
 
     ann = None
     if not args.no_ann:
@@ -158,7 +184,7 @@ def main():
         out = {
             "metric": "rows/s TPC-H Q1 hash-agg", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i64/i128 decimal", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i64/i128 decimal", "data": "synthetic" + (" (FUNCTIONAL CHECK: ranks share one GPU, not a measurement)" if args.share_gpu else ""),
             "config": {"workload": f"TPC-H Q1 hash-aggregation, SF{args.sf:g} synthetic lineitem per GPU "
                                    f"({n} rows/rank, 68 B/row, fused filter+decimal maps+group-by, "
                                    f"{'all-gather of partial states over RCCL + final merge' if world > 1 else 'single GPU'})",

@@ -61,7 +61,8 @@ SYMBOLS = [
     "dbhip_sum", "dbhip_expr_eval", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_cmp", "dbhip_bitmap_binary",
     "dbhip_bitmap_count", "dbhip_filter_select", "dbhip_take", "dbhip_take_bitmap", "dbhip_group_hash",
     "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized", "dbhip_groupby_merge_state_block",
-    "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized",
+    "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized", "dbhip_groupby_flush_block",
+    "dbhip_groupby_merge_blocks",
     "dbhip_groupby_result_type", "dbhip_groupby_flush_result", "dbhip_groupby_reset",
     "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_keys_method", "dbhip_pack_keys",
     "dbhip_join_create", "dbhip_join_create_keys", "dbhip_join_probe_mark",

@@ -488,6 +488,27 @@ __global__ __launch_bounds__(256) void gb_flush_kernel(GbLayout L, const uint64_
   }
 }
 
+// Fixed-size exchange block (multi-GPU partial-state exchange): row 0 of a block is its header
+// (word 0 = number of rows that follow, ~0 = the table held more than max_rows groups), rows 1.. are serialized rows.
+__global__ __launch_bounds__(64) void gb_block_header_kernel(uint64_t* block, int W, int64_t max_rows, const uint64_t* ctrl) {
+  const int t = threadIdx.x;
+  if (t < W) block[t] = t == 0 ? ((int64_t)ctrl[4] > max_rows ? ~0ULL : ctrl[4]) : 0;
+}
+
+// one workgroup per source block: append its rows behind those of the earlier blocks (`skip` = the caller's own block)
+__global__ __launch_bounds__(256) void gb_compact_blocks_kernel(const uint64_t* __restrict__ blocks, int64_t stride_words, int W,
+                                                                int skip, uint64_t* __restrict__ out) {
+  const int b = blockIdx.x;
+  if (b == skip) return;
+  const uint64_t cnt = blocks[(int64_t)b * stride_words];
+  uint64_t off = 0;
+  for (int p = 0; p < b; ++p)
+    if (p != skip) off += blocks[(int64_t)p * stride_words];
+  const uint64_t* src = blocks + (int64_t)b * stride_words + W;
+  uint64_t* dst = out + off * W;
+  for (uint64_t i = threadIdx.x; i < cnt * (uint64_t)W; i += blockDim.x) dst[i] = src[i];
+}
+
 struct ResultPtrs {
   void* keys[GB_MAX_KEYS];
   uint32_t* key_validity[GB_MAX_KEYS];
@@ -1683,6 +1704,46 @@ int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int
     return DBHIP_ERR_CAPACITY;
   }
   return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t max_rows, void* stream) {
+  DBHIP_REQUIRE(g && out_block_dev && max_rows >= 1, "dbhip_groupby_flush_block: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  uint64_t* block = (uint64_t*)out_block_dev;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[4], 0, 8, s));
+  hipLaunchKernelGGL(gb_flush_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap,
+                     block + g->L.W, max_rows, g->ctrl);
+  hipLaunchKernelGGL(gb_block_header_kernel, dim3(1), dim3(64), 0, s, block, g->L.W, max_rows, g->ctrl);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;  // nothing is read back: the header travels with the block
+}
+
+int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows,
+                                   int32_t skip_block, void* stream) {
+  DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_merge_blocks: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  const uint64_t* blocks = (const uint64_t*)blocks_dev;
+  std::vector<uint64_t> head((size_t)n_blocks);
+  DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 8, blocks, (size_t)stride * 8, 8, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  int64_t total = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    if (b == skip_block) continue;
+    if (head[b] == ~0ULL || (int64_t)head[b] > max_rows) {  // decided BEFORE the table is touched: the caller can still take the
+      set_error("dbhip_groupby_merge_blocks: block %d overflowed max_rows=%lld (exchange the rows with "   // variable-length path
+                "dbhip_groupby_flush_serialized / merge_serialized instead)", b, (long long)max_rows);
+      return DBHIP_ERR_CAPACITY;
+    }
+    total += (int64_t)head[b];
+  }
+  if (total == 0) return DBHIP_OK;
+  int32_t rc;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)total * W * 8))) return rc;
+  hipLaunchKernelGGL(gb_compact_blocks_kernel, dim3(n_blocks), dim3(256), 0, s, blocks, stride, W, skip_block, g->rows_in);
+  DBHIP_LAUNCH_CHECK();
+  return merge_rows(g, g->rows_in, total, s);
 }
 
 int32_t dbhip_groupby_result_type(const dbhip_agg_desc* agg, int32_t* out_type, uint8_t* out_precision,

@@ -518,6 +518,14 @@ class GroupBy:
         buf = DeviceBuffer.from_numpy(rows)
         check(lib().dbhip_groupby_merge_serialized(self.h, C.c_void_p(buf.ptr), C.c_int64(rows.shape[0]), None))
 
+    def flush_block(self, block_ptr, max_rows, stream=None):
+        """dbhip_groupby_flush_block: header row + serialized rows into a device block, no host synchronisation."""
+        check(lib().dbhip_groupby_flush_block(self.h, C.c_void_p(block_ptr), C.c_int64(max_rows), stream))
+
+    def merge_blocks(self, blocks_ptr, n_blocks, max_rows, skip_block=-1, stream=None):
+        check(lib().dbhip_groupby_merge_blocks(self.h, C.c_void_p(blocks_ptr), C.c_int32(n_blocks), C.c_int64(max_rows),
+                                               C.c_int32(skip_block), stream))
+
     def result(self):
         """-> list of rows [(key values..., agg values...)] (order unspecified)."""
         g = self.num_groups()
@@ -584,8 +592,8 @@ class GroupBy:
         cols += [Column(t, n, b, None, p, s) for (t, p, s), b in zip(agg_meta, agg_bufs)]
         return cols
 
-    def reset(self):
-        check(lib().dbhip_groupby_reset(self.h, None))
+    def reset(self, stream=None):
+        check(lib().dbhip_groupby_reset(self.h, stream))
 
     def debug_set_hash_mask(self, mask):
         f = lib().dbhip_groupby_debug_set_hash_mask

@@ -109,8 +109,39 @@ def _exchange_rows(table, rows, dist, torch, device):
     return table
 
 
-def exchange_partials_nccl(table, dist, torch):
-    return exchange_partials_fixed(table, dist, torch, torch.device("cuda", torch.cuda.current_device()))
+def exchange_partials_device(table, dist, torch, device, max_rows=256, stream=None, lib_sync=None, capacity_error=None):
+    """Device-resident low-cardinality exchange (bench.py --gpus N): the table writes its block (header row + serialized
+    rows, dbhip_groupby_flush_block — no host synchronisation), ONE all_gather_into_tensor of equal-size blocks runs
+    over RCCL, and every rank merges the other ranks' blocks straight from the gathered tensor
+    (dbhip_groupby_merge_blocks; its own states never leave the table). No row crosses PCIe.
+    `stream`: the stream handle passed to the library calls. With torch's current stream the step is ordered on one
+    stream together with the collective; with None (the library's own stream) `lib_sync()` must drain that stream
+    before the collective and torch's stream is drained before the merge.
+    A block that overflowed `max_rows` is seen by EVERY rank in the gathered headers (merge_blocks reports it before
+    touching the table, `capacity_error(exc)` recognises the error): all ranks then take the variable-length path."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    W = table.row_bytes() // 8
+    send = torch.empty((max_rows + 1, W), dtype=torch.int64, device=device)
+    table.flush_block(send.data_ptr(), max_rows, stream)
+    if stream is None and lib_sync is not None:
+        lib_sync()
+    recv = torch.empty((world * (max_rows + 1), W), dtype=torch.int64, device=device)   # rank-major concatenation
+    dist.all_gather_into_tensor(recv, send)
+    if stream is None and device.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    try:
+        table.merge_blocks(recv.data_ptr(), world, max_rows, rank, stream)
+    except Exception as e:  # noqa: BLE001 — only the overflow report is handled, everything else propagates
+        if capacity_error is None or not capacity_error(e):
+            raise
+        return exchange_partials(table, dist, torch, device, mode="allgather")
+    return table
+
+
+def exchange_partials_nccl(table, dist, torch, stream=None, lib_sync=None):
+    from ._lib import DbhipError, ERR_CAPACITY
+    return exchange_partials_device(table, dist, torch, torch.device("cuda", torch.cuda.current_device()), stream=stream,
+                                    lib_sync=lib_sync, capacity_error=lambda e: isinstance(e, DbhipError) and e.code == ERR_CAPACITY)
 
 
 def merge_shard_topk(idx, dst, row_offset, k, dist, torch, device, merge_fn):
@@ -141,12 +172,12 @@ def merge_shard_topk_device(idx_t, dst_t, row_offset, k, dist, torch, lib_sync, 
     nq = idx_t.shape[0]
     lib_sync()
     gid = torch.where(idx_t == -1, idx_t, idx_t + int(row_offset)).contiguous()
-    gi = torch.empty((world, nq, k), dtype=torch.int32, device=idx_t.device)
-    gd = torch.empty((world, nq, k), dtype=torch.float32, device=idx_t.device)
+    gi = torch.empty((world * nq, k), dtype=torch.int32, device=idx_t.device)   # rank-major concatenation
+    gd = torch.empty((world * nq, k), dtype=torch.float32, device=idx_t.device)
     dist.all_gather_into_tensor(gi, gid)
     dist.all_gather_into_tensor(gd, dst_t.contiguous())
-    all_i = gi.permute(1, 0, 2).reshape(nq, world * k).contiguous()
-    all_d = gd.permute(1, 0, 2).reshape(nq, world * k).contiguous()
+    all_i = gi.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k).contiguous()
+    all_d = gd.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k).contiguous()
     out_i = torch.empty((nq, k), dtype=torch.int32, device=idx_t.device)
     out_d = torch.empty((nq, k), dtype=torch.float32, device=idx_t.device)
     torch.cuda.current_stream().synchronize()   # the gathered tensors are complete before the library reads them

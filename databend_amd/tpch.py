@@ -206,7 +206,7 @@ Q3_AGGS = [(L.AGG_SUM, L.T_DEC128, 31, 4, 0)]
 Q3_KEYS = [L.T_I64, L.T_DATE, L.T_I32]
 
 
-def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=None):
+def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=None, bitmap_probe=True):
     """Q3 in the reference's plan shape, one C-ABI call per operator / expression node:
 
       customer -> TransformFilter(c_mktsegment = seg) -> Join#1 build (c_custkey)
@@ -225,166 +225,34 @@ def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=N
     j1 = D.HashJoin(max(kc, 16))
     j1.add_block(D.take(t.c_custkey, csel, kc))
     j1.final_build()
-    # orders: the filter's Bitmap rides into the probe as the key column's validity (rows that fail the predicate
-    # are not probed), so the 4 surviving columns are never materialised; the pairs carry ORIGINAL orders row ids
+    # orders. Two plans for filter -> probe (measured side by side by tools/bench_q3.py):
+    #   bitmap_probe (default, 21.1 ms at SF100): the filter's Bitmap rides into the probe as the key column's validity
+    #     (rows that fail the predicate are not probed), nothing is materialised and the pairs carry ORIGINAL row ids;
+    #   materialise (23.6 ms): TransformFilter's selection, take the surviving columns, probe the compacted keys.
     opred = D.cmp(L.CMP_LT, t.o_orderdate, D.Column.scalar(date, L.T_DATE), t.n_orders)
-    ko = D.bitmap_count(opred, t.n_orders) if stats is not None else 0
-    pp, _pb, kj = j1.probe_block_device(D.Column(t.o_custkey.dtype, t.n_orders, t.o_custkey.data, validity=opred.data))
-    b_ok, b_od, b_sp = (D.take(c, pp, kj) for c in (t.o_orderkey, t.o_orderdate, t.o_shippriority))
-    j2 = D.HashJoin(max(kj, 16))
-    j2.add_block(b_ok)
-    j2.final_build()
-    # lineitem: same — predicate Bitmap as probe validity, pairs carry original lineitem row ids
-    lpred = D.cmp(L.CMP_GT, t.l_shipdate, D.Column.scalar(date, L.T_DATE), t.n_lineitem)
-    kl = D.bitmap_count(lpred, t.n_lineitem) if stats is not None else 0
-    lp, lb, kp = j2.probe_block_device(D.Column(t.l_orderkey.dtype, t.n_lineitem, t.l_orderkey.data, validity=lpred.data))
-    j_ok, j_price, j_disc = (D.take(c, lp, kp) for c in (t.l_orderkey, t.l_extendedprice, t.l_discount))
-    j_od, j_sp = D.take(b_od, lb, kp), D.take(b_sp, lb, kp)
-    one_minus = D.decimal_arith(L.OP_MINUS, one, disc, k)            # Decimal(16,2)
-    disc_price = D.decimal_arith(L.OP_MULTIPLY, price, one_minus, k)  # Decimal(31,4)
-    one_plus = D.decimal_arith(L.OP_PLUS, one, tax, k)                # Decimal(16,2)
-    charge = D.decimal_arith(L.OP_MULTIPLY, disc_price, one_plus, k)  # Decimal(38,6)
-    g.add_block([rf, ls], [qty, price, disc_price, charge, disc, None], k)
-    return g
-
-
-def q1_rows(g):
-    """-> {(returnflag, linestatus): dict} from a Q1 group-by table."""
-    out = {}
-    for rf, ls, sq, sp, sdp, sch, sd, cnt in g.result():
-        out[(rf, ls)] = dict(sum_qty=sq, sum_base_price=sp, sum_disc_price=sdp, sum_charge=sch, sum_disc=sd, count=cnt)
-    return out
-
-
-def q1_finalize(rows):
-    """Post-aggregate projection of Q1 on the (<= a handful of) group rows, on the GPU:
-    avg(x) was rewritten by the planner to sum(x) / if(count(x)=0, 1, count(x))
-    (aggregate_rewriter.rs:62-66,176-177): Decimal(18,2) / UInt64 -> Decimal(24,8)
-    with round-half-away (decimal/arithmetic.rs:212-243), then ORDER BY the two keys."""
-    keys = sorted(rows)
-    if not keys:
-        return []
-    cnt = np.array([rows[k]["count"] for k in keys], dtype=np.uint64)
-    div = D.Column.from_numpy(np.where(cnt == 0, 1, cnt).astype(np.uint64), L.T_U64)
-    outs = {}
-    for name in ("sum_qty", "sum_base_price", "sum_disc"):
-        s = D.Column.from_numpy(np.array([rows[k][name] for k in keys], dtype=np.int64), L.T_DEC64, precision=18, scale=2)
-        outs[name] = D.decimal_arith(L.OP_DIVIDE, s, div, len(keys)).to_numpy()
-    res = []
-    for i, k in enumerate(keys):
-        r = rows[k]
-        res.append((k[0], k[1], r["sum_qty"], r["sum_base_price"], r["sum_disc_price"], r["sum_charge"],
-                    outs["sum_qty"][i], outs["sum_base_price"][i], outs["sum_disc"][i], r["count"]))
-    return res
-
-
-# ---------------------------------------------------------------------------------------------
-# TPC-H Q3 (BASELINE.json configs[2]; benchmark/tpch/queries/03.sql:1-18; SURVEY.md §3.3, §8d)
-# ---------------------------------------------------------------------------------------------
-SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]
-Q3_SEGMENT = "BUILDING"
-Q3_DATE = days(1995, 3, 15)
-ORDER_LO, ORDER_HI = days(1992, 1, 1), days(1998, 8, 2)
-
-
-def _views_from_short_strings(table, codes):
-    """16-byte inline views for strings of <= 12 bytes picked by `codes` from `table`."""
-    tv = np.zeros((len(table), 16), dtype=np.uint8)
-    for i, s in enumerate(table):
-        assert len(s) <= 12
-        tv[i, 0] = len(s)
-        tv[i, 4:4 + len(s)] = np.frombuffer(s, dtype=np.uint8)
-    return tv[codes]
-
-
-def gen_q3(sf, seed=3):
-    """Synthetic customer / orders / lineitem for Q3, numpy PCG64(seed).
-
-    customer: c_custkey dense 1..Nc, c_mktsegment uniform over 5 segments (16-B inline views)
-    orders:   o_orderkey sparse like dbgen (8 of every 32 keys), o_custkey uniform over customers
-              with key % 3 != 0, o_orderdate uniform 1992-01-01..1998-08-02, o_shippriority = 0
-    lineitem: 1..7 lines per order (in order-key order), price/discount as in Q1,
-              l_shipdate = o_orderdate + U[1,121]
-    """
-    rng = np.random.Generator(np.random.PCG64(seed))
-    nc, no = max(int(150_000 * sf), 5), max(int(1_500_000 * sf), 8)
-    c_custkey = np.arange(1, nc + 1, dtype=np.int64)
-    c_seg = _views_from_short_strings(SEGMENTS, rng.integers(0, 5, nc))
-    i = np.arange(no, dtype=np.int64)
-    o_orderkey = (i // 8) * 32 + (i % 8) + 1
-    ck = rng.integers(1, nc + 1, no, dtype=np.int64)
-    bad = ck % 3 == 0  # dbgen never assigns orders to every third customer
-    ck[bad] = np.where(ck[bad] + 1 > nc, 1, ck[bad] + 1)
-    o_orderdate = rng.integers(ORDER_LO, ORDER_HI + 1, no, dtype=np.int32)
-    o_shipprio = np.zeros(no, dtype=np.int32)
-    lines = rng.integers(1, 8, no)
-    l_orderkey = np.repeat(o_orderkey, lines)
-    nl = len(l_orderkey)
-    l_price = rng.integers(90000, 10494951, nl, dtype=np.int64)
-    l_disc = rng.integers(0, 11, nl, dtype=np.int64)
-    l_ship = (np.repeat(o_orderdate, lines) + rng.integers(1, 122, nl, dtype=np.int32)).astype(np.int32)
-    return {
-        "customer": {"c_custkey": c_custkey, "c_mktsegment": c_seg},
-        "orders": {"o_orderkey": o_orderkey, "o_custkey": ck, "o_orderdate": o_orderdate, "o_shippriority": o_shipprio},
-        "lineitem": {"l_orderkey": l_orderkey, "l_extendedprice": l_price, "l_discount": l_disc, "l_shipdate": l_ship},
-    }
-
-
-class Q3Device:
-    """The three Q3 tables resident in HBM (customer 24 B/row, orders 24 B/row, lineitem 28 B/row)."""
-
-    def __init__(self, host):
-        c, o, li = host["customer"], host["orders"], host["lineitem"]
-        dec = dict(precision=15, scale=2)
-        self.c_custkey = D.Column.from_numpy(c["c_custkey"], L.T_I64)
-        self.c_mktsegment = D.Column.from_views(c["c_mktsegment"])
-        self.o_orderkey = D.Column.from_numpy(o["o_orderkey"], L.T_I64)
-        self.o_custkey = D.Column.from_numpy(o["o_custkey"], L.T_I64)
-        self.o_orderdate = D.Column.from_numpy(o["o_orderdate"], L.T_DATE)
-        self.o_shippriority = D.Column.from_numpy(o["o_shippriority"], L.T_I32)
-        self.l_orderkey = D.Column.from_numpy(li["l_orderkey"], L.T_I64)
-        self.l_extendedprice = D.Column.from_numpy(li["l_extendedprice"], L.T_DEC64, **dec)
-        self.l_discount = D.Column.from_numpy(li["l_discount"], L.T_DEC64, **dec)
-        self.l_shipdate = D.Column.from_numpy(li["l_shipdate"], L.T_DATE)
-        self.n_customer, self.n_orders, self.n_lineitem = self.c_custkey.n, self.o_orderkey.n, self.l_orderkey.n
-
-
-Q3_AGGS = [(L.AGG_SUM, L.T_DEC128, 31, 4, 0)]
-Q3_KEYS = [L.T_I64, L.T_DATE, L.T_I32]
-
-
-def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=None):
-    """Q3 in the reference's plan shape, one C-ABI call per operator / expression node:
-
-      customer -> TransformFilter(c_mktsegment = seg) -> Join#1 build (c_custkey)
-      orders   -> filter predicate(o_orderdate < date) -> Join#1 probe (o_custkey, predicate as validity) -> Join#2 build (o_orderkey)
-      lineitem -> filter predicate(l_shipdate > date)  -> Join#2 probe (l_orderkey, predicate as validity)
-               -> take probe/build columns (inner_join.rs:248-268)
-               -> 1 - l_discount ; l_extendedprice * (..)   (decimal/arithmetic.rs:190-316)
-               -> TransformPartialAggregate / Final on (l_orderkey, o_orderdate, o_shippriority), sum -> Decimal128(38,4)
-               -> sort revenue DESC, o_orderdate ASC LIMIT 10 (kernels/sort.rs:91-113)
-    Returns [(l_orderkey, revenue, o_orderdate, o_shippriority)] in output order.
-    """
-    # customer
-    seg = D.Column.from_views(_views_from_short_strings([segment.encode()], np.zeros(1, dtype=np.int64)))
-    seg.is_scalar = True
-    csel, kc = D.filter_select(D.cmp(L.CMP_EQ, t.c_mktsegment, seg, t.n_customer))
-    j1 = D.HashJoin(max(kc, 16))
-    j1.add_block(D.take(t.c_custkey, csel, kc))
-    j1.final_build()
-    # orders
-    osel, ko = D.filter_select(D.cmp(L.CMP_LT, t.o_orderdate, D.Column.scalar(date, L.T_DATE), t.n_orders))
-    f_ok, f_ck, f_od, f_sp = (D.take(c, osel, ko) for c in (t.o_orderkey, t.o_custkey, t.o_orderdate, t.o_shippriority))
-    pp, _pb, kj = j1.probe_block_device(f_ck)
-    b_ok, b_od, b_sp = (D.take(c, pp, kj) for c in (f_ok, f_od, f_sp))
+    if bitmap_probe:
+        ko = D.bitmap_count(opred, t.n_orders) if stats is not None else 0
+        pp, _pb, kj = j1.probe_block_device(D.Column(t.o_custkey.dtype, t.n_orders, t.o_custkey.data, validity=opred.data))
+        b_ok, b_od, b_sp = (D.take(c, pp, kj) for c in (t.o_orderkey, t.o_orderdate, t.o_shippriority))
+    else:
+        osel, ko = D.filter_select(opred)
+        f_ok, f_ck, f_od, f_sp = (D.take(c, osel, ko) for c in (t.o_orderkey, t.o_custkey, t.o_orderdate, t.o_shippriority))
+        pp, _pb, kj = j1.probe_block_device(f_ck)
+        b_ok, b_od, b_sp = (D.take(c, pp, kj) for c in (f_ok, f_od, f_sp))
     j2 = D.HashJoin(max(kj, 16))
     j2.add_block(b_ok)
     j2.final_build()
     # lineitem
-    lsel, kl = D.filter_select(D.cmp(L.CMP_GT, t.l_shipdate, D.Column.scalar(date, L.T_DATE), t.n_lineitem))
-    f_lok, f_price, f_disc = (D.take(c, lsel, kl) for c in (t.l_orderkey, t.l_extendedprice, t.l_discount))
-    lp, lb, kp = j2.probe_block_device(f_lok)
-    j_ok, j_price, j_disc = (D.take(c, lp, kp) for c in (f_lok, f_price, f_disc))
+    lpred = D.cmp(L.CMP_GT, t.l_shipdate, D.Column.scalar(date, L.T_DATE), t.n_lineitem)
+    if bitmap_probe:
+        kl = D.bitmap_count(lpred, t.n_lineitem) if stats is not None else 0
+        lp, lb, kp = j2.probe_block_device(D.Column(t.l_orderkey.dtype, t.n_lineitem, t.l_orderkey.data, validity=lpred.data))
+        j_ok, j_price, j_disc = (D.take(c, lp, kp) for c in (t.l_orderkey, t.l_extendedprice, t.l_discount))
+    else:
+        lsel, kl = D.filter_select(lpred)
+        f_lok, f_price, f_disc = (D.take(c, lsel, kl) for c in (t.l_orderkey, t.l_extendedprice, t.l_discount))
+        lp, lb, kp = j2.probe_block_device(f_lok)
+        j_ok, j_price, j_disc = (D.take(c, lp, kp) for c in (f_lok, f_price, f_disc))
     j_od, j_sp = D.take(b_od, lb, kp), D.take(b_sp, lb, kp)
     one_minus = D.decimal_arith(L.OP_MINUS, D.Column.scalar(1, L.T_U8), j_disc, kp)   # Decimal(16,2)
     revenue = D.decimal_arith(L.OP_MULTIPLY, j_price, one_minus, kp)                   # Decimal(31,4)

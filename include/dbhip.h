@@ -294,6 +294,17 @@ int32_t dbhip_groupby_num_groups(dbhip_groupby* g, int64_t* out_host, void* stre
 int32_t dbhip_groupby_row_bytes(dbhip_groupby* g, int64_t* out_host);
 int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int64_t max_rows,
                                        int64_t* out_n_rows_host, void* stream);
+/* Fixed-size exchange of partial states between ranks (the RCCL analogue of the
+ * AggregateMeta shuffle, aggregator/aggregate_exchange_injector.rs:57-147, for low cardinality).
+ * A block is (max_rows + 1) rows of dbhip_groupby_row_bytes: row 0 is the header (u64 word 0 = rows
+ * that follow, ~0 = the table held more than max_rows groups), rows 1.. are serialized rows.
+ * flush_block writes this table's block WITHOUT any host synchronisation, so that one
+ * all_gather of equal-size blocks can follow on the same stream; merge_blocks merges `n_blocks`
+ * gathered blocks except `skip_block` (the caller's own, whose states are still in the table; -1 =
+ * none). If a block overflowed it returns DBHIP_ERR_CAPACITY before touching the table. */
+int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t max_rows, void* stream);
+int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks,
+                                   int64_t max_rows, int32_t skip_block, void* stream);
 /* merge_result (:382-408): final values as columns. out_keys[i]/out_aggs[i] are
  * device buffers of max_rows elements of the key / result type
  * (dbhip_groupby_result_type). Returns DBHIP_ERR_OVERFLOW if a checked decimal

@@ -57,6 +57,34 @@ class HostTable:
             st[1] += c
 
 
+    # --- the device-block protocol of dbhip_groupby_flush_block / merge_blocks, on host memory ---
+    def row_bytes(self):
+        return W * 8
+
+    @staticmethod
+    def _view(ptr, words):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint64 * words).from_address(ptr))
+
+    def flush_block(self, ptr, max_rows, stream=None):
+        block = self._view(ptr, (max_rows + 1) * W).reshape(max_rows + 1, W)
+        rows = self.flush_serialized()
+        block[0] = 0
+        if rows.shape[0] > max_rows:
+            block[0, 0] = M64
+        else:
+            block[0, 0] = rows.shape[0]
+            block[1:1 + rows.shape[0]] = rows
+
+    def merge_blocks(self, ptr, n_blocks, max_rows, skip, stream=None):
+        blocks = self._view(ptr, n_blocks * (max_rows + 1) * W).reshape(n_blocks, max_rows + 1, W)
+        if any(int(blocks[b, 0, 0]) == M64 for b in range(n_blocks) if b != skip):
+            raise OverflowError("block overflow")   # decided before the table is touched
+        for b in range(n_blocks):
+            if b != skip:
+                self.merge_serialized(blocks[b, 1:1 + int(blocks[b, 0, 0])])
+
+
 def shard(rank, world, n, card, seed):
     rng = np.random.Generator(np.random.PCG64(seed))
     keys = rng.integers(0, card, n, dtype=np.int64)
@@ -75,6 +103,9 @@ def worker(rank, world, port, mode, n, card, q):
         t.add(keys[lo:hi], vals[lo:hi])
         if mode == "fixed":
             DX.exchange_partials_fixed(t, dist, torch, torch.device("cpu"), max_rows=64)
+        elif mode == "device":
+            DX.exchange_partials_device(t, dist, torch, torch.device("cpu"), max_rows=64,
+                                        capacity_error=lambda e: isinstance(e, OverflowError))
         else:
             DX.exchange_partials(t, dist, torch, torch.device("cpu"), mode=mode, hash_word=HASH_WORD)
         q.put((rank, {k: tuple(v) for k, v in t.groups.items()}))
@@ -119,6 +150,15 @@ def test_fixed_block_exchange_one_collective(n, card):
     """bench.py's Q1 exchange: one fixed-size all-gather (row 0 of every block = row count); a rank with more rows
     than the block holds makes EVERY rank fall back to the variable-length path in the same step."""
     got, exp = run("fixed", n, card)
+    assert got[0] == exp and got[1] == exp
+
+
+@pytest.mark.parametrize("n,card", [(5000, 4), (3, 1), (20000, 3000)])
+def test_device_block_exchange_protocol(n, card):
+    """bench.py --gpus N: flush_block -> one all_gather_into_tensor -> merge_blocks(skip = own rank). The stand-in
+    implements the block layout of include/dbhip.h on host memory; 3000 groups overflow the 64-row block on both
+    ranks, which every rank sees in the gathered headers and answers with the variable-length exchange."""
+    got, exp = run("device", n, card)
     assert got[0] == exp and got[1] == exp
 
 

@@ -198,6 +198,7 @@ def test_sharded_topk_device_merge_path(gpu):
         def all_gather_into_tensor(self, out, inp):
             # rank 0's view: its own contribution is `inp`; the other ranks' blocks are produced the way they would be
             src = shards_i if inp.dtype == torch.int32 else shards_d
+            out = out.view(world, *inp.shape)   # rank-major concatenation, as the collective lays it out
             for r in range(world):
                 if inp.dtype == torch.int32:
                     out[r] = torch.where(src[r] == -1, src[r], src[r] + offs[r])

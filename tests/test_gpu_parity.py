@@ -411,6 +411,94 @@ def test_groupby_state_block_roundtrip_partial_to_final(gpu):
     assert {r[:2]: r[3] for r in final.result()} == exp_cnt
 
 
+@pytest.mark.parametrize("card,max_rows", [(4, 256), (200, 256), (1, 1), (3000, 256)])
+def test_groupby_exchange_blocks_device_resident(gpu, card, max_rows):
+    """The multi-GPU exchange of bench.py --gpus N on one GPU: three "ranks" (three tables over disjoint row ranges)
+    flush their blocks without a host round trip (dbhip_groupby_flush_block), the blocks are laid out the way
+    all_gather_into_tensor lays them out, and every rank merges the OTHER ranks' blocks
+    (dbhip_groupby_merge_blocks, skip = own rank): every rank must end with the table one rank computes over all rows.
+    Runs through databend_amd.dist.exchange_partials_device with a stand-in communicator, on a torch stream handed
+    to the library (the ordering the RCCL path relies on). 3000 groups overflow the 256-row block: reported before
+    any table is touched, and the exchange falls back to the variable-length path."""
+    import torch
+    from databend_amd import dist as DX
+    from databend_amd._lib import DbhipError, ERR_CAPACITY
+    n, world = 90_000, 3
+    rng = np.random.default_rng(card)
+    k1 = rng.integers(0, card, n).astype(np.int64)
+    a = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    d = [int(x) * 10**9 for x in rng.integers(-10**15, 10**15, n)]
+    spec = ([T.T_I64], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC128, 31, 4, 0),
+                        (T.AGG_MIN, T.T_I64, 0, 0, 0)])
+
+    def run(lo, hi):
+        g = gpu.GroupBy(*spec)
+        g.add_block([gpu.Column.from_numpy(k1[lo:hi])],
+                    [gpu.Column.from_numpy(a[lo:hi]), None, gpu.Column.decimal128(d[lo:hi], 31, 4), gpu.Column.from_numpy(a[lo:hi])], hi - lo)
+        return g
+
+    whole = sorted(run(0, n).result())
+    bounds = [(r * n // world, (r + 1) * n // world) for r in range(world)]
+    tables = [run(lo, hi) for lo, hi in bounds]
+    dev = torch.device("cuda", 0)
+    W = tables[0].row_bytes() // 8
+    T.check(T.lib().dbhip_stream_sync(None))
+    ts = torch.cuda.Stream()       # (torch's default stream has handle 0, which the C-ABI reads as "the library's stream")
+    st = C.c_void_p(ts.cuda_stream)
+    # what the collective would deliver: every rank's block, rank-major
+    blocks = torch.empty((world * (max_rows + 1), W), dtype=torch.int64, device=dev)
+    for r in range(world):
+        tables[r].flush_block(blocks[r * (max_rows + 1)].data_ptr(), max_rows, st)
+    torch.cuda.synchronize()
+    heads = blocks.view(world, max_rows + 1, W)[:, 0, 0].cpu().numpy()
+    groups = [len(set(k1[lo:hi].tolist())) for lo, hi in bounds]
+    assert heads.tolist() == [g if g <= max_rows else -1 for g in groups]
+
+    class FakeDist:
+        def __init__(self, rank):
+            self.rank, self.gathers, self.fallback = rank, 0, 0
+
+        def get_world_size(self):
+            return world
+
+        def get_rank(self):
+            return self.rank
+
+        def all_gather_into_tensor(self, out, inp):
+            assert torch.equal(inp[0], blocks.view(world, max_rows + 1, W)[self.rank, 0])
+            out.copy_(blocks)   # (on torch's current stream, like the collective)
+            self.gathers += 1
+
+        def all_gather(self, outs, inp):   # variable-length fallback: counts, then padded rows
+            self.fallback += 1
+            per_rank = [tables_rows[r] for r in range(world)]
+            if inp.numel() == 1:
+                for r in range(world):
+                    outs[r].fill_(per_rank[r].shape[0])
+            else:
+                for r in range(world):
+                    outs[r].zero_()
+                    outs[r][: per_rank[r].shape[0]] = torch.from_numpy(per_rank[r].view(np.int64)).to(dev)
+
+    overflow = any(g > max_rows for g in groups)
+    tables_rows = [t.flush_serialized() for t in tables] if overflow else None
+    for r in range(world):
+        fd = FakeDist(r)
+        with torch.cuda.stream(ts):
+            DX.exchange_partials_device(tables[r], fd, torch, dev, max_rows=max_rows, stream=st,
+                                        capacity_error=lambda e: isinstance(e, DbhipError) and e.code == ERR_CAPACITY)
+        ts.synchronize()
+        assert fd.gathers == 1 and (fd.fallback > 0) == overflow
+        assert sorted(tables[r].result()) == whole, r
+    # the library's own stream + explicit drains (stream=None) gives the same result
+    t2 = [run(lo, hi) for lo, hi in bounds]
+    if not overflow:
+        fd = FakeDist(1)
+        DX.exchange_partials_device(t2[1], fd, torch, dev, max_rows=max_rows, stream=None,
+                                    lib_sync=lambda: T.check(T.lib().dbhip_stream_sync(None)))
+        assert sorted(t2[1].result()) == whole
+
+
 @pytest.mark.parametrize("n", [1, 127, 128, 129, 1000, 300_007])
 def test_q1_fused_and_operator_plans_match_oracle(gpu, oracle, n):
     from databend_amd import tpch

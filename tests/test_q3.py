@@ -64,6 +64,8 @@ def test_q3_gpu_operator_plan_matches_oracle(gpu, sf, seed):
     same_result(got, exp)
     # no LIMIT: the whole result, as sorted sets + key sequence
     same_result(tpch.q3_operator_at_a_time(t, limit=0), O.q3_run(host, tpch.Q3_SEGMENT, tpch.Q3_DATE, limit=0, threads=4))
+    # the alternative filter->probe plan (filter_select + take, probe the compacted keys) gives the same rows
+    same_result(tpch.q3_operator_at_a_time(t, bitmap_probe=False), exp)
 
 
 @pytest.mark.gpu
