@@ -42,6 +42,16 @@ class ExprIns(C.Structure):
                 ("imm", C.c_uint64)]
 
 
+class PqInfo(C.Structure):
+    """dbhip_pq_info"""
+    _fields_ = [("num_values", C.c_int64), ("num_nulls", C.c_int64), ("out_type", C.c_int32), ("has_validity", C.c_int32),
+                ("out_bytes", C.c_int64), ("validity_bytes", C.c_int64), ("n_pages", C.c_int64), ("n_dict_values", C.c_int64)]
+
+
+# parquet.thrift Type numbers
+PQ_BOOLEAN, PQ_INT32, PQ_INT64, PQ_INT96, PQ_FLOAT, PQ_DOUBLE, PQ_BYTE_ARRAY, PQ_FLBA = range(8)
+
+
 class AggDesc(C.Structure):
     """dbhip_agg_desc"""
     _fields_ = [("kind", C.c_int32), ("arg_type", C.c_int32), ("arg_precision", C.c_uint8),
@@ -69,6 +79,7 @@ SYMBOLS = [
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
     "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
     "dbhip_vec_topk_merge", "dbhip_vec_index_build", "dbhip_vec_index_search", "dbhip_vec_index_destroy",
+    "dbhip_pq_chunk_open", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
 ]
 
 

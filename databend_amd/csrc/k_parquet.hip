@@ -1,0 +1,779 @@
+// k_parquet.hip — scan side: one Parquet column chunk -> one device-resident column.
+//
+// Stands where the reference hands a block's raw column chunks to arrow-rs:
+//   column_chunks_to_record_batch (src/query/storages/fuse/src/io/read/block/parquet/deserialize.rs:33-81:
+//   ParquetRecordBatchReader over an in-memory row group) followed by the arrow -> Column conversion
+//   (block_reader_parquet_deserialize.rs), i.e. `DataItem::RawData(bytes)` in, one `Column` out.
+// The decoder itself is the third-party `parquet` crate (Cargo.lock: parquet 58.1.0, datafuse-extras/arrow-rs
+// rev bbbe79543) and is absent from /root/reference; what is restated here is the published Apache Parquet
+// format (Encodings.md / thrift definitions) for exactly what the reference's WRITER emits
+// (src/query/storages/common/blocks/src/parquet_rs.rs:91-160: one row group, Encoding::PLAIN fallback, statistics
+// off, dictionary on => WriterVersion::PARQUET_2_0 (DATA_PAGE_V2 + RLE_DICTIONARY), dictionary off => DATA_PAGE
+// v1 + PLAIN), for flat columns (max repetition level 0, max definition level <= 1), TableCompression::None
+// (table_compression.rs:38). Compressed chunks, nested columns and the DELTA_* / BYTE_STREAM_SPLIT encodings
+// return DBHIP_ERR_UNSUPPORTED (the binding keeps arrow-rs for those).
+//
+// Split of work. The chunk arrives in HOST memory (object storage read). Everything inherently serial is done
+// there, touching only header bytes: thrift page headers, the varint run headers of the RLE / bit-packed hybrid
+// streams (levels and dictionary indices), the popcount of bit-packed definition levels (null count per page)
+// and, for PLAIN BYTE_ARRAY pages, the chain of 4-byte length prefixes (one u32 offset per value). The result is
+// a list of work ITEMS, each <= 2048 values of one kind with a known output position. The device expands the
+// items from the HBM-resident copy of the chunk, one wave per item:
+//   levels   -> validity bitmap (LSB first), then word popcounts -> exclusive scan = rank of every row
+//   values   -> dense array of the non-null values in the OUTPUT type (sign/zero extension, big-endian
+//               FIXED_LEN_BYTE_ARRAY decimals -> i128, dictionary gather, 16-byte string views that point INTO the
+//               resident chunk: no string byte is copied)
+//   spread   -> out[row] = valid ? dense[rank(row)] : 0 (skipped when the chunk has no nulls)
+// All three are streaming kernels: the roofline is HBM (chunk bytes in + column bytes out).
+#include "dev_common.h"
+#include "dev_scan.h"
+#include "runtime.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+using namespace dbhip;
+
+#define DBHIP_TRY(x) do { int32_t _rc = (x); if (_rc) return _rc; } while (0)
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// host: thrift compact protocol (only what PageHeader needs)
+// ---------------------------------------------------------------------------------------------
+struct Rd {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok;
+  uint8_t u8() {
+    if (p >= end) { ok = false; return 0; }
+    return *p++;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int sh = 0; sh < 64; sh += 7) {
+      const uint8_t b = u8();
+      v |= (uint64_t)(b & 0x7F) << sh;
+      if (!(b & 0x80)) return v;
+      if (!ok) return 0;
+    }
+    ok = false;
+    return 0;
+  }
+  int64_t zigzag() {
+    const uint64_t v = varint();
+    return (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
+  }
+  void skip_bytes(uint64_t n) {
+    if ((uint64_t)(end - p) < n) { ok = false; p = end; return; }
+    p += n;
+  }
+  void skip(int type, int depth = 0);
+  void skip_struct(int depth) {
+    int16_t last = 0;
+    while (ok) {
+      const uint8_t h = u8();
+      if (h == 0) return;
+      const int type = h & 0x0F;
+      if ((h >> 4) == 0) last = (int16_t)zigzag(); else last = (int16_t)(last + (h >> 4));
+      skip(type, depth + 1);
+    }
+  }
+};
+
+void Rd::skip(int type, int depth) {
+  if (depth > 16) { ok = false; return; }
+  switch (type) {
+    case 1: case 2: return;                 // bool carried in the field header
+    case 3: u8(); return;                   // byte
+    case 4: case 5: case 6: varint(); return;  // i16 / i32 / i64
+    case 7: skip_bytes(8); return;          // double
+    case 8: skip_bytes(varint()); return;   // binary
+    case 9: case 10: {                      // list / set
+      const uint8_t h = u8();
+      uint64_t n = h >> 4;
+      if (n == 15) n = varint();
+      const int et = h & 0x0F;
+      for (uint64_t i = 0; i < n && ok; ++i) {
+        if (et == 1 || et == 2) u8(); else skip(et, depth + 1);
+      }
+      return;
+    }
+    case 11: {                              // map
+      const uint64_t n = varint();
+      if (n == 0) return;
+      const uint8_t kv = u8();
+      for (uint64_t i = 0; i < n && ok; ++i) { skip(kv >> 4, depth + 1); skip(kv & 0x0F, depth + 1); }
+      return;
+    }
+    case 12: skip_struct(depth); return;
+    default: ok = false; return;
+  }
+}
+
+enum { PG_DATA = 0, PG_INDEX = 1, PG_DICT = 2, PG_DATA_V2 = 3 };
+enum { ENC_PLAIN = 0, ENC_PLAIN_DICT = 2, ENC_RLE = 3, ENC_RLE_DICT = 8 };
+enum { PT_BOOLEAN = 0, PT_INT32 = 1, PT_INT64 = 2, PT_INT96 = 3, PT_FLOAT = 4, PT_DOUBLE = 5, PT_BYTE_ARRAY = 6, PT_FLBA = 7 };
+
+struct PageHdr {
+  int32_t type = -1, uncompressed = -1, compressed = -1;
+  int32_t num_values = -1, encoding = -1, def_enc = ENC_RLE;
+  int32_t num_nulls = -1, def_len = 0, rep_len = 0;
+  bool v2_compressed = true;
+};
+
+// fields of DataPageHeader (1 num_values, 2 encoding, 3 definition_level_encoding), DictionaryPageHeader
+// (1 num_values, 2 encoding) and DataPageHeaderV2 (1 num_values, 2 num_nulls, 3 num_rows, 4 encoding,
+// 5 definition_levels_byte_length, 6 repetition_levels_byte_length, 7 is_compressed) — parquet.thrift
+void read_sub(Rd& r, PageHdr& h, int which) {
+  int16_t last = 0;
+  while (r.ok) {
+    const uint8_t b = r.u8();
+    if (b == 0) return;
+    const int type = b & 0x0F;
+    if ((b >> 4) == 0) last = (int16_t)r.zigzag(); else last = (int16_t)(last + (b >> 4));
+    const bool is_int = type == 4 || type == 5 || type == 6;
+    if (which == PG_DATA_V2) {
+      if (last == 7 && (type == 1 || type == 2)) { h.v2_compressed = type == 1; continue; }
+      if (is_int && last >= 1 && last <= 6) {
+        const int32_t v = (int32_t)r.zigzag();
+        if (last == 1) h.num_values = v; else if (last == 2) h.num_nulls = v; else if (last == 4) h.encoding = v;
+        else if (last == 5) h.def_len = v; else if (last == 6) h.rep_len = v;
+        continue;
+      }
+    } else {
+      if (is_int && last >= 1 && last <= 3) {
+        const int32_t v = (int32_t)r.zigzag();
+        if (last == 1) h.num_values = v; else if (last == 2) h.encoding = v; else if (which == PG_DATA) h.def_enc = v;
+        continue;
+      }
+    }
+    r.skip(type);
+  }
+}
+
+bool read_page_header(Rd& r, PageHdr& h) {
+  int16_t last = 0;
+  while (r.ok) {
+    const uint8_t b = r.u8();
+    if (b == 0) break;
+    const int type = b & 0x0F;
+    if ((b >> 4) == 0) last = (int16_t)r.zigzag(); else last = (int16_t)(last + (b >> 4));
+    if (type == 5 && last >= 1 && last <= 3) {
+      const int32_t v = (int32_t)r.zigzag();
+      if (last == 1) h.type = v; else if (last == 2) h.uncompressed = v; else h.compressed = v;
+    } else if (type == 12 && last == 5) {
+      read_sub(r, h, PG_DATA);
+    } else if (type == 12 && last == 7) {
+      read_sub(r, h, PG_DICT);
+    } else if (type == 12 && last == 8) {
+      read_sub(r, h, PG_DATA_V2);
+    } else {
+      r.skip(type);
+    }
+  }
+  return r.ok && h.type >= 0 && h.compressed >= 0 && h.uncompressed >= 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// work items
+// ---------------------------------------------------------------------------------------------
+enum { IT_LVL_RLE = 0, IT_LVL_BP = 1, IT_IDX_RLE = 2, IT_IDX_BP = 3, IT_PLAIN = 4, IT_STR = 5, IT_BOOL_RLE = 6, IT_BOOL_BP = 7 };
+constexpr uint32_t ITEM_MAX = 2048;  // values per item (a multiple of 8: bit-packed splits stay byte aligned)
+constexpr uint32_t ITEM_SMALL = 48;  // items up to this many values are expanded by ONE thread each, longer ones by a wave
+
+struct PqItem {
+  uint32_t kind;
+  uint32_t count;
+  uint64_t out_start;  // row index (levels) or ordinal among the non-null values (everything else)
+  uint64_t src;        // byte offset into the chunk (bit-packed / plain), or the repeated value (RLE)
+  uint32_t bitw;       // bit width (bit-packed indices), unused otherwise
+  uint32_t dict_base;  // first entry of this item's dictionary in the dictionary arrays (always 0: one dictionary page per chunk)
+};
+
+}  // namespace
+
+struct dbhip_pq_chunk {
+  int32_t physical, type_length, max_def, out_type;
+  int64_t chunk_len, rows, nulls, nonnull;
+  int64_t n_pages;
+  // dictionary
+  int64_t dict_n, dict_off, dict_bytes;   // entries, byte offset of the page payload in the chunk
+  std::vector<uint32_t> dict_str_off;      // BYTE_ARRAY dictionary: offset of every entry's bytes in the chunk
+  std::vector<PqItem> lvl_items, val_items;   // as planned, in stream order; split by size at the first decode:
+  int64_t n_lvl_small, n_val_small;             // d_lvl / d_val hold the short items first, then the long ones
+  std::vector<uint32_t> str_off;           // PLAIN BYTE_ARRAY data pages: offset of every value's bytes (by ordinal)
+  // device side (uploaded on first decode)
+  PqItem* d_lvl; PqItem* d_val; uint32_t* d_str_off; uint32_t* d_dict_str_off;
+  void* d_dict;                            // dictionary in the output type (values or 16-byte views)
+  void* d_dense;                           // non-null values, output type (only with nulls)
+  uint32_t* d_wcnt; uint64_t* d_woff; uint64_t* d_blk;
+  bool uploaded;
+};
+
+namespace {
+
+int out_elem_size(int32_t t) {
+  if (t == DBHIP_T_BOOL) return 0;  // bitmap
+  return type_size(t);
+}
+
+bool type_pair_ok(int physical, int type_length, int out_type) {
+  switch (physical) {
+    case PT_BOOLEAN: return out_type == DBHIP_T_BOOL;
+    case PT_INT32:
+      switch (out_type) {
+        case DBHIP_T_I8: case DBHIP_T_I16: case DBHIP_T_I32: case DBHIP_T_U8: case DBHIP_T_U16: case DBHIP_T_U32:
+        case DBHIP_T_DATE: case DBHIP_T_DEC64: case DBHIP_T_I64: return true;
+        default: return false;
+      }
+    case PT_INT64:
+      return out_type == DBHIP_T_I64 || out_type == DBHIP_T_U64 || out_type == DBHIP_T_TIMESTAMP || out_type == DBHIP_T_DEC64 ||
+             out_type == DBHIP_T_DEC128;
+    case PT_FLOAT: return out_type == DBHIP_T_F32;
+    case PT_DOUBLE: return out_type == DBHIP_T_F64;
+    case PT_BYTE_ARRAY: return out_type == DBHIP_T_STRING;
+    case PT_FLBA: return (out_type == DBHIP_T_DEC128 && type_length >= 1 && type_length <= 16) ||
+                         (out_type == DBHIP_T_DEC64 && type_length >= 1 && type_length <= 8);
+    default: return false;
+  }
+}
+
+__host__ __device__ inline int plain_width(int physical, int type_length) {
+  switch (physical) {
+    case PT_INT32: case PT_FLOAT: return 4;
+    case PT_INT64: case PT_DOUBLE: return 8;
+    case PT_FLBA: return type_length;
+    default: return 0;
+  }
+}
+
+// Walks one RLE / bit-packed hybrid stream of `nvals` values and appends items. `first_out` = output position of
+// its first value. rle_kind / bp_kind select levels vs indices vs booleans. Returns false on a malformed stream.
+// For levels (*ones != nullptr) counts the values equal to 1.
+bool scan_hybrid(const uint8_t* base, uint64_t off, uint64_t len, int bitw, uint64_t nvals, uint64_t first_out, uint32_t rle_kind,
+                 uint32_t bp_kind, std::vector<PqItem>& items, uint64_t* ones) {
+  Rd r{base + off, base + off + len, true};
+  const int vbytes = (bitw + 7) / 8;
+  uint64_t done = 0;
+  while (done < nvals) {
+    const uint64_t h = r.varint();
+    if (!r.ok) return false;
+    if (h & 1) {
+      const uint64_t groups = h >> 1;
+      const uint64_t bytes = groups * (uint64_t)bitw;
+      const uint64_t src0 = (uint64_t)(r.p - base);
+      if (groups == 0 || (uint64_t)(r.end - r.p) < bytes) {
+        // a writer may truncate the padding of the last group: accept if the bytes present cover the values needed
+        const uint64_t need_bits = (nvals - done) * (uint64_t)bitw;
+        if (groups == 0 || (uint64_t)(r.end - r.p) * 8 < need_bits) return false;
+      }
+      uint64_t n = groups * 8;
+      if (n > nvals - done) n = nvals - done;  // padding of the last group
+      if (ones) {
+        // popcount of the first n bits (bit width 1)
+        const uint8_t* q = base + src0;
+        uint64_t c = 0, full = n / 8;
+        for (uint64_t i = 0; i < full; ++i) c += (uint64_t)__builtin_popcount(q[i]);
+        if (n & 7) c += (uint64_t)__builtin_popcount(q[full] & ((1u << (n & 7)) - 1));
+        *ones += c;
+      }
+      for (uint64_t s = 0; s < n; s += ITEM_MAX) {
+        const uint32_t c = (uint32_t)((n - s) < ITEM_MAX ? (n - s) : ITEM_MAX);
+        items.push_back(PqItem{bp_kind, c, first_out + done + s, src0 + s / 8 * (uint64_t)bitw, (uint32_t)bitw, 0});
+      }
+      r.skip_bytes(bytes < (uint64_t)(r.end - r.p) ? bytes : (uint64_t)(r.end - r.p));
+      done += n;
+    } else {
+      uint64_t n = h >> 1;
+      uint64_t v = 0;
+      for (int b = 0; b < vbytes; ++b) v |= (uint64_t)r.u8() << (8 * b);
+      if (!r.ok || n == 0) return false;
+      if (n > nvals - done) n = nvals - done;
+      if (ones && v == 1) *ones += n;
+      for (uint64_t s = 0; s < n; s += 1u << 20) {  // an RLE item is a fill: long pieces are fine, but keep several waves busy
+        const uint32_t c = (uint32_t)((n - s) < (1u << 20) ? (n - s) : (1u << 20));
+        items.push_back(PqItem{rle_kind, c, first_out + done + s, v, (uint32_t)bitw, 0});
+      }
+      done += n;
+    }
+  }
+  return true;
+}
+
+int bits_for(int max_level) {
+  int b = 0;
+  while ((1 << b) <= max_level) ++b;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+struct PqConv {
+  int physical, type_length, out_type, esize;
+};
+
+__device__ __forceinline__ uint64_t load_le(const uint8_t* p, int n) {  // n <= 8 bytes, unaligned
+  uint64_t v = 0;
+  for (int b = 0; b < n; ++b) v |= (uint64_t)p[b] << (8 * b);
+  return v;
+}
+
+// one PLAIN-encoded value at `p` -> element `o` of `out` in the output type
+__device__ __forceinline__ void store_plain(const PqConv& cv, const uint8_t* p, void* out, uint64_t o) {
+  if (cv.physical == PT_FLBA) {
+    // big-endian two's complement of type_length bytes -> sign-extended little-endian integer (decimal)
+    const int L = cv.type_length;
+    u128 v = (p[0] & 0x80) ? ~(u128)0 : (u128)0;
+    for (int b = 0; b < L; ++b) v = (v << 8) | p[b];
+    if (cv.esize == 16) ((u128*)out)[o] = v; else ((uint64_t*)out)[o] = (uint64_t)v;
+    return;
+  }
+  if (cv.physical == PT_INT32 || cv.physical == PT_FLOAT) {
+    const uint32_t v = (uint32_t)load_le(p, 4);
+    switch (cv.esize) {
+      case 1: ((uint8_t*)out)[o] = (uint8_t)v; break;
+      case 2: ((uint16_t*)out)[o] = (uint16_t)v; break;
+      case 4: ((uint32_t*)out)[o] = v; break;
+      default: ((int64_t*)out)[o] = (int64_t)(int32_t)v; break;  // Decimal(p <= 9) / widening
+    }
+    return;
+  }
+  const uint64_t v = load_le(p, 8);
+  if (cv.esize == 16) ((i128*)out)[o] = (i128)(int64_t)v; else ((uint64_t*)out)[o] = v;
+}
+
+// 16-byte view of the string whose bytes start at chunk offset `off` (its 4-byte length prefix sits right before)
+__device__ __forceinline__ void store_view(const uint8_t* chunk, uint32_t off, void* out, uint64_t o) {
+  const uint8_t* p = chunk + off;
+  const uint32_t len = (uint32_t)load_le(p - 4, 4);
+  uint32_t w[4] = {len, 0, 0, 0};
+  if (len <= 12) {
+    for (uint32_t b = 0; b < len; ++b) w[1 + (b >> 2)] |= (uint32_t)p[b] << (8 * (b & 3));
+  } else {
+    w[1] = (uint32_t)load_le(p, 4);
+    w[2] = 0;     // buffer index: the chunk itself is buffer 0 of the column
+    w[3] = off;
+  }
+  ((uint4*)out)[o] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t extract_bits(const uint8_t* src, uint64_t i, int bitw) {
+  const uint64_t bit = i * (uint64_t)bitw;
+  const uint8_t* p = src + (bit >> 3);
+  const int sh = (int)(bit & 7);
+  const int nbytes = (sh + bitw + 7) >> 3;  // <= 5
+  const uint64_t v = load_le(p, nbytes);
+  return (uint32_t)((v >> sh) & ((bitw >= 32) ? 0xFFFFFFFFu : ((1u << bitw) - 1)));
+}
+
+// levels / booleans -> bitmap. LANES = 64: one wave per item (long items); LANES = 1: one thread per item (the short runs a
+// nullable column's level stream is made of — a wave per 8..48-value run would idle most of its lanes). Bits are OR-ed into a
+// zeroed bitmap (items do not end on word boundaries).
+template <int LANES>
+__global__ __launch_bounds__(256) void pq_bits_kernel(const PqItem* __restrict__ items, int64_t n_items,
+                                                      const uint8_t* __restrict__ chunk, uint32_t* __restrict__ bitmap) {
+  const int lane = LANES == 64 ? (threadIdx.x & 63) : 0;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t first = LANES == 64 ? (tid >> 6) : tid;
+  const int64_t step = LANES == 64 ? (((int64_t)gridDim.x * blockDim.x) >> 6) : (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = first; it < n_items; it += step) {
+    const PqItem I = items[it];
+    const bool rle = I.kind == IT_LVL_RLE || I.kind == IT_BOOL_RLE;
+    if (rle && I.src == 0) continue;  // zeros: the bitmap is already clear
+    // every lane owns one 32-bit output word per round
+    const uint64_t first_word = I.out_start >> 5, last_word = (I.out_start + I.count - 1) >> 5;
+    for (uint64_t w = first_word + lane; w <= last_word; w += LANES) {
+      const uint64_t lo = w << 5;                       // first row of the word
+      const uint64_t a = lo > I.out_start ? lo : I.out_start;
+      const uint64_t e = (lo + 32 < I.out_start + I.count) ? lo + 32 : I.out_start + I.count;
+      uint32_t bits;
+      if (rle) {
+        const int nb = (int)(e - a);
+        bits = (nb == 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)) << (a - lo);
+      } else {
+        // source bits [a - out_start, e - out_start) of the packed stream, bit width 1
+        const uint64_t s0 = a - I.out_start;
+        const uint8_t* p = chunk + I.src + (s0 >> 3);
+        const int sh = (int)(s0 & 7);
+        const int nb = (int)(e - a);
+        const uint64_t v = load_le(p, (sh + nb + 7) >> 3);
+        bits = (uint32_t)((v >> sh) & (nb == 32 ? 0xFFFFFFFFull : ((1ull << nb) - 1))) << (a - lo);
+      }
+      if (bits) {
+        if (a == lo && e == lo + 32) bitmap[w] = bits;  // whole word owned by this item
+        else atomicOr(&bitmap[w], bits);
+      }
+    }
+  }
+}
+
+// values -> dense array in the output type. LANES = 64: one wave per item; LANES = 1: one thread per (short) item.
+template <int LANES>
+__global__ __launch_bounds__(256) void pq_values_kernel(const PqItem* __restrict__ items, int64_t n_items,
+                                                        const uint8_t* __restrict__ chunk, PqConv cv,
+                                                        const void* __restrict__ dict, uint32_t dict_n,
+                                                        const uint32_t* __restrict__ str_off, void* __restrict__ out) {
+  const int lane = LANES == 64 ? (threadIdx.x & 63) : 0;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t first = LANES == 64 ? (tid >> 6) : tid;
+  const int64_t step = LANES == 64 ? (((int64_t)gridDim.x * blockDim.x) >> 6) : (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = first; it < n_items; it += step) {
+    const PqItem I = items[it];
+    for (uint32_t i = lane; i < I.count; i += LANES) {
+      const uint64_t o = I.out_start + i;
+      switch (I.kind) {
+        case IT_PLAIN:
+          store_plain(cv, chunk + I.src + (uint64_t)i * (uint64_t)I.bitw, out, o);
+          break;
+        case IT_STR:
+          store_view(chunk, str_off[o], out, o);
+          break;
+        default: {
+          uint32_t idx = I.kind == IT_IDX_RLE ? (uint32_t)I.src : extract_bits(chunk + I.src, i, (int)I.bitw);
+          if (idx >= dict_n) idx = dict_n - 1;  // a corrupt index must not read outside the dictionary (open() guarantees dict_n >= 1)
+          switch (cv.esize) {
+            case 1: ((uint8_t*)out)[o] = ((const uint8_t*)dict)[idx]; break;
+            case 2: ((uint16_t*)out)[o] = ((const uint16_t*)dict)[idx]; break;
+            case 4: ((uint32_t*)out)[o] = ((const uint32_t*)dict)[idx]; break;
+            case 8: ((uint64_t*)out)[o] = ((const uint64_t*)dict)[idx]; break;
+            default: ((uint4*)out)[o] = ((const uint4*)dict)[idx]; break;
+          }
+        }
+      }
+    }
+  }
+}
+
+// dictionary page (PLAIN) -> dictionary in the output type
+__global__ __launch_bounds__(256) void pq_dict_kernel(const uint8_t* __restrict__ chunk, uint64_t dict_off, int64_t n, PqConv cv,
+                                                      const uint32_t* __restrict__ dict_str_off, void* __restrict__ dict) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (cv.physical == PT_BYTE_ARRAY) store_view(chunk, dict_str_off[i], dict, (uint64_t)i);
+    else store_plain(cv, chunk + dict_off + (uint64_t)i * (uint64_t)plain_width(cv.physical, cv.type_length), dict, (uint64_t)i);
+  }
+}
+
+__global__ __launch_bounds__(256) void pq_popc_kernel(const uint32_t* __restrict__ bitmap, int64_t nwords, uint32_t* __restrict__ cnt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x)
+    cnt[i] = (uint32_t)__popc(bitmap[i]);
+}
+
+// out[row] = valid ? dense[rank(row)] : 0
+template <typename T>
+__global__ __launch_bounds__(256) void pq_spread_kernel(const uint32_t* __restrict__ bitmap, const uint64_t* __restrict__ woff,
+                                                        const T* __restrict__ dense, int64_t rows, T* __restrict__ out) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t w = bitmap[r >> 5];
+    const int b = (int)(r & 31);
+    T v{};
+    if ((w >> b) & 1) v = dense[woff[r >> 5] + (uint64_t)__popc(w & ((1u << b) - 1))];
+    out[r] = v;
+  }
+}
+
+// booleans: dense bitmap of the non-null values -> row bitmap
+__global__ __launch_bounds__(256) void pq_spread_bool_kernel(const uint32_t* __restrict__ bitmap, const uint64_t* __restrict__ woff,
+                                                             const uint32_t* __restrict__ dense, int64_t nwords, uint32_t* __restrict__ out) {
+  for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < nwords; wi += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t w = bitmap[wi], o = 0;
+    uint64_t k = woff[wi];
+    while (w) {
+      const int b = __ffs(w) - 1;
+      w &= w - 1;
+      o |= ((dense[k >> 5] >> (k & 31)) & 1u) << b;
+      ++k;
+    }
+    out[wi] = o;
+  }
+}
+
+}  // namespace
+
+namespace {
+
+int32_t unsupported(const char* what) {
+  set_error("dbhip_pq_chunk_open: %s (keep the CPU reader for this chunk)", what);
+  return DBHIP_ERR_UNSUPPORTED;
+}
+int32_t malformed(const char* what) {
+  set_error("dbhip_pq_chunk_open: malformed column chunk: %s", what);
+  return DBHIP_ERR_INVALID;
+}
+
+// values section of one data page: bytes [pos, endp) of the chunk hold `nn` non-null values in `enc`
+int32_t plan_values(dbhip_pq_chunk* c, const uint8_t* base, uint64_t pos, uint64_t endp, uint64_t nn, int enc) {
+  const uint64_t o0 = (uint64_t)c->nonnull;
+  if (enc == ENC_PLAIN) {
+    if (c->physical == PT_BOOLEAN) {
+      if ((endp - pos) * 8 < nn) return malformed("boolean page shorter than its values");
+      for (uint64_t s = 0; s < nn; s += ITEM_MAX)
+        c->val_items.push_back(PqItem{IT_BOOL_BP, (uint32_t)((nn - s) < ITEM_MAX ? (nn - s) : ITEM_MAX), o0 + s, pos + s / 8, 1, 0});
+      return DBHIP_OK;
+    }
+    if (c->physical == PT_BYTE_ARRAY) {
+      c->str_off.resize((size_t)(o0 + nn), 0);
+      uint64_t off = pos;
+      for (uint64_t i = 0; i < nn; ++i) {
+        if (endp - off < 4) return malformed("byte array length runs past the page");
+        uint32_t len;
+        memcpy(&len, base + off, 4);
+        if (endp - off - 4 < len) return malformed("byte array runs past the page");
+        c->str_off[(size_t)(o0 + i)] = (uint32_t)(off + 4);
+        off += 4 + (uint64_t)len;
+      }
+      for (uint64_t s = 0; s < nn; s += ITEM_MAX)
+        c->val_items.push_back(PqItem{IT_STR, (uint32_t)((nn - s) < ITEM_MAX ? (nn - s) : ITEM_MAX), o0 + s, 0, 0, 0});
+      return DBHIP_OK;
+    }
+    const uint64_t w = (uint64_t)plain_width(c->physical, c->type_length);
+    if ((endp - pos) / w < nn) return malformed("plain page shorter than its values");
+    for (uint64_t s = 0; s < nn; s += ITEM_MAX)
+      c->val_items.push_back(PqItem{IT_PLAIN, (uint32_t)((nn - s) < ITEM_MAX ? (nn - s) : ITEM_MAX), o0 + s, pos + s * w, (uint32_t)w, 0});
+    return DBHIP_OK;
+  }
+  if (enc == ENC_PLAIN_DICT || enc == ENC_RLE_DICT) {
+    if (c->dict_n < 0) return malformed("dictionary-encoded page without a dictionary page");
+    if (nn == 0) return DBHIP_OK;
+    if (c->dict_n == 0) return malformed("values refer to an empty dictionary");
+    if (endp - pos < 1) return malformed("missing index bit width");
+    const int bitw = base[pos];
+    if (bitw > 32) return malformed("index bit width > 32");
+    if (!scan_hybrid(base, pos + 1, endp - pos - 1, bitw, nn, o0, IT_IDX_RLE, IT_IDX_BP, c->val_items, nullptr))
+      return malformed("dictionary index stream");
+    return DBHIP_OK;
+  }
+  if (enc == ENC_RLE && c->physical == PT_BOOLEAN) {
+    if (endp - pos < 4) return malformed("missing RLE length");
+    uint32_t len;
+    memcpy(&len, base + pos, 4);
+    if (endp - pos - 4 < len) return malformed("RLE boolean stream runs past the page");
+    if (!scan_hybrid(base, pos + 4, len, 1, nn, o0, IT_BOOL_RLE, IT_BOOL_BP, c->val_items, nullptr)) return malformed("RLE boolean stream");
+    return DBHIP_OK;
+  }
+  return unsupported("value encoding other than PLAIN / RLE_DICTIONARY");
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
+                            int32_t max_def_level, int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
+                            dbhip_pq_info* info_host) {
+  DBHIP_REQUIRE(chunk_host && out_host && chunk_len >= 0, "dbhip_pq_chunk_open: NULL argument");
+  *out_host = nullptr;
+  if (codec != 0) return unsupported("compressed column chunk");
+  if (max_rep_level != 0 || max_def_level < 0 || max_def_level > 1) return unsupported("nested column (repetition / definition level > 1)");
+  if (chunk_len >= (1LL << 32)) return unsupported("column chunk of 4 GiB or more");
+  if (!type_pair_ok(physical_type, type_length, out_type)) {
+    set_error("dbhip_pq_chunk_open: physical type %d (length %d) cannot be decoded into dbhip type %d", physical_type, type_length, out_type);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  dbhip_pq_chunk* c = new (std::nothrow) dbhip_pq_chunk();
+  if (!c) { set_error("dbhip_pq_chunk_open: out of host memory"); return DBHIP_ERR_HIP; }
+  c->physical = physical_type; c->type_length = type_length; c->max_def = max_def_level; c->out_type = out_type;
+  c->chunk_len = chunk_len; c->rows = 0; c->nulls = 0; c->nonnull = 0; c->n_pages = 0;
+  c->dict_n = -1; c->dict_off = 0; c->dict_bytes = 0;
+  c->d_lvl = nullptr; c->d_val = nullptr; c->d_str_off = nullptr; c->d_dict_str_off = nullptr; c->d_dict = nullptr; c->d_dense = nullptr;
+  c->d_wcnt = nullptr; c->d_woff = nullptr; c->d_blk = nullptr; c->uploaded = false; c->n_lvl_small = 0; c->n_val_small = 0;
+  const uint8_t* base = chunk_host;
+  Rd r{base, base + chunk_len, true};
+  int32_t rc = DBHIP_OK;
+  while (rc == DBHIP_OK && r.p < r.end) {
+    PageHdr h;
+    if (!read_page_header(r, h)) { rc = malformed("page header"); break; }
+    if (h.compressed != h.uncompressed) { rc = unsupported("compressed page"); break; }
+    const uint64_t pos0 = (uint64_t)(r.p - base);
+    if ((uint64_t)h.compressed > (uint64_t)(r.end - r.p)) { rc = malformed("page runs past the chunk"); break; }
+    const uint64_t endp = pos0 + (uint64_t)h.compressed;
+    if (h.type == PG_DICT) {
+      if (c->dict_n >= 0 || c->n_pages > 0) { rc = malformed("dictionary page not first / repeated"); break; }
+      if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICT) { rc = unsupported("dictionary page encoding"); break; }
+      if (h.num_values < 0 || c->physical == PT_BOOLEAN) { rc = malformed("dictionary page"); break; }
+      c->dict_n = h.num_values; c->dict_off = (int64_t)pos0; c->dict_bytes = h.compressed;
+      if (c->physical == PT_BYTE_ARRAY) {
+        uint64_t off = pos0;
+        c->dict_str_off.resize((size_t)c->dict_n);
+        for (int64_t i = 0; i < c->dict_n; ++i) {
+          if (endp - off < 4) { rc = malformed("dictionary entry length"); break; }
+          uint32_t len;
+          memcpy(&len, base + off, 4);
+          if (endp - off - 4 < len) { rc = malformed("dictionary entry runs past the page"); break; }
+          c->dict_str_off[(size_t)i] = (uint32_t)(off + 4);
+          off += 4 + (uint64_t)len;
+        }
+      } else if ((uint64_t)c->dict_n * (uint64_t)plain_width(c->physical, c->type_length) > endp - pos0) {
+        rc = malformed("dictionary page shorter than its entries");
+      }
+    } else if (h.type == PG_DATA || h.type == PG_DATA_V2) {
+      if (h.num_values < 0) { rc = malformed("data page without num_values"); break; }
+      const uint64_t nv = (uint64_t)h.num_values;
+      uint64_t pos = pos0, nn = nv;
+      if (h.type == PG_DATA) {
+        if (c->max_def == 1) {
+          if (h.def_enc != ENC_RLE) { rc = unsupported("definition levels not RLE encoded"); break; }
+          if (endp - pos < 4) { rc = malformed("missing level length"); break; }
+          uint32_t len;
+          memcpy(&len, base + pos, 4);
+          if (endp - pos - 4 < len) { rc = malformed("levels run past the page"); break; }
+          uint64_t ones = 0;
+          if (!scan_hybrid(base, pos + 4, len, 1, nv, (uint64_t)c->rows, IT_LVL_RLE, IT_LVL_BP, c->lvl_items, &ones)) {
+            rc = malformed("definition level stream");
+            break;
+          }
+          nn = ones;
+          pos += 4 + (uint64_t)len;
+        }
+      } else {
+        if (h.rep_len != 0) { rc = unsupported("repetition levels"); break; }
+        if (h.def_len < 0 || (uint64_t)h.def_len > endp - pos) { rc = malformed("level byte length"); break; }
+        if (c->max_def == 1) {
+          uint64_t ones = 0;
+          if (!scan_hybrid(base, pos, (uint64_t)h.def_len, 1, nv, (uint64_t)c->rows, IT_LVL_RLE, IT_LVL_BP, c->lvl_items, &ones)) {
+            rc = malformed("definition level stream");
+            break;
+          }
+          nn = ones;
+          if (h.num_nulls >= 0 && (uint64_t)h.num_nulls != nv - nn) { rc = malformed("num_nulls disagrees with the definition levels"); break; }
+        }
+        pos += (uint64_t)h.def_len;
+      }
+      rc = plan_values(c, base, pos, endp, nn, h.encoding);
+      if (rc) break;
+      c->rows += (int64_t)nv;
+      c->nonnull += (int64_t)nn;
+      c->n_pages += 1;
+    }  // index pages and unknown page types are skipped
+    r.p = base + endp;
+  }
+  if (rc == DBHIP_OK && c->rows >= 0xFFFFFFF0LL) rc = unsupported("more than 2^32 rows in one chunk");
+  if (rc) { delete c; return rc; }
+  c->nulls = c->rows - c->nonnull;
+  if (info_host) {
+    info_host->num_values = c->rows;
+    info_host->num_nulls = c->nulls;
+    info_host->out_type = out_type;
+    info_host->has_validity = c->max_def;
+    info_host->out_bytes = out_type == DBHIP_T_BOOL ? ceil_div(c->rows, 64) * 8 : c->rows * (int64_t)out_elem_size(out_type);
+    info_host->validity_bytes = ceil_div(c->rows, 64) * 8;
+    info_host->n_pages = c->n_pages;
+    info_host->n_dict_values = c->dict_n < 0 ? 0 : c->dict_n;
+  }
+  *out_host = c;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void* out_values_dev, uint8_t* out_validity_dev,
+                              void* stream) {
+  DBHIP_REQUIRE(c, "dbhip_pq_chunk_decode: NULL handle");
+  if (c->rows == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(chunk_dev && out_values_dev, "dbhip_pq_chunk_decode: NULL buffer");
+  DBHIP_REQUIRE(c->max_def == 0 || out_validity_dev, "dbhip_pq_chunk_decode: a nullable column needs a validity buffer");
+  hipStream_t s = resolve_stream(stream);
+  const int esize = out_elem_size(c->out_type);
+  const bool is_bool = c->out_type == DBHIP_T_BOOL;
+  const int64_t nwords = ceil_div(c->rows, 32);
+  if (!c->uploaded) {
+    // short items first (stable: both halves stay in stream order, so neighbouring threads / waves write neighbouring output)
+    auto split = [](std::vector<PqItem>& v) {
+      return (int64_t)(std::stable_partition(v.begin(), v.end(), [](const PqItem& i) { return i.count <= ITEM_SMALL; }) - v.begin());
+    };
+    c->n_lvl_small = split(c->lvl_items);
+    c->n_val_small = split(c->val_items);
+    if (!c->lvl_items.empty()) {
+      DBHIP_TRY(dbhip_alloc(c->lvl_items.size() * sizeof(PqItem), (void**)&c->d_lvl));
+      DBHIP_CHECK(hipMemcpyAsync(c->d_lvl, c->lvl_items.data(), c->lvl_items.size() * sizeof(PqItem), hipMemcpyHostToDevice, s));
+    }
+    if (!c->val_items.empty()) {
+      DBHIP_TRY(dbhip_alloc(c->val_items.size() * sizeof(PqItem), (void**)&c->d_val));
+      DBHIP_CHECK(hipMemcpyAsync(c->d_val, c->val_items.data(), c->val_items.size() * sizeof(PqItem), hipMemcpyHostToDevice, s));
+    }
+    if (!c->str_off.empty()) {
+      DBHIP_TRY(dbhip_alloc(c->str_off.size() * 4, (void**)&c->d_str_off));
+      DBHIP_CHECK(hipMemcpyAsync(c->d_str_off, c->str_off.data(), c->str_off.size() * 4, hipMemcpyHostToDevice, s));
+    }
+    if (!c->dict_str_off.empty()) {
+      DBHIP_TRY(dbhip_alloc(c->dict_str_off.size() * 4, (void**)&c->d_dict_str_off));
+      DBHIP_CHECK(hipMemcpyAsync(c->d_dict_str_off, c->dict_str_off.data(), c->dict_str_off.size() * 4, hipMemcpyHostToDevice, s));
+    }
+    if (c->dict_n > 0) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
+    if (c->nulls > 0) {
+      DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->nonnull + 1, 64) * 8 : (size_t)(c->nonnull + 1) * (size_t)esize, &c->d_dense));
+      DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_wcnt));
+      DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
+      DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
+    }
+    DBHIP_CHECK(hipStreamSynchronize(s));  // the host vectors may be released by close() right after this call returns
+    c->uploaded = true;
+  }
+  const PqConv cv{c->physical, c->type_length, c->out_type, esize};
+  kernel_timer_start(s);
+  if (c->dict_n > 0) {
+    hipLaunchKernelGGL(pq_dict_kernel, dim3(grid_for(c->dict_n, 256)), dim3(256), 0, s, chunk_dev, (uint64_t)c->dict_off, c->dict_n, cv,
+                       c->d_dict_str_off, c->d_dict);
+  }
+  uint32_t* vbits = (uint32_t*)out_validity_dev;
+  if (c->max_def == 1) {
+    DBHIP_CHECK(hipMemsetAsync(vbits, 0, (size_t)ceil_div(c->rows, 64) * 8, s));
+    const int64_t ns = c->n_lvl_small, nl = (int64_t)c->lvl_items.size() - ns;
+    if (ns) hipLaunchKernelGGL(pq_bits_kernel<1>, dim3(grid_for(ns, 256)), dim3(256), 0, s, c->d_lvl, ns, chunk_dev, vbits);
+    if (nl) hipLaunchKernelGGL(pq_bits_kernel<64>, dim3(grid_for(nl * 64, 256)), dim3(256), 0, s, c->d_lvl + ns, nl, chunk_dev, vbits);
+  } else if (vbits) {
+    DBHIP_CHECK(hipMemsetAsync(vbits, 0xFF, (size_t)ceil_div(c->rows, 64) * 8, s));
+  }
+  void* target = c->nulls > 0 ? c->d_dense : out_values_dev;
+  if (!c->val_items.empty()) {
+    const int64_t ns = c->n_val_small, nl = (int64_t)c->val_items.size() - ns;
+    const uint32_t dn = (uint32_t)(c->dict_n > 0 ? c->dict_n : 1);
+    if (is_bool) {
+      DBHIP_CHECK(hipMemsetAsync(target, 0, (size_t)ceil_div(c->nulls > 0 ? c->nonnull + 1 : c->rows, 64) * 8, s));
+      if (ns) hipLaunchKernelGGL(pq_bits_kernel<1>, dim3(grid_for(ns, 256)), dim3(256), 0, s, c->d_val, ns, chunk_dev, (uint32_t*)target);
+      if (nl) hipLaunchKernelGGL(pq_bits_kernel<64>, dim3(grid_for(nl * 64, 256)), dim3(256), 0, s, c->d_val + ns, nl, chunk_dev, (uint32_t*)target);
+    } else {
+      if (ns) hipLaunchKernelGGL(pq_values_kernel<1>, dim3(grid_for(ns, 256)), dim3(256), 0, s, c->d_val, ns, chunk_dev, cv,
+                                 (const void*)c->d_dict, dn, c->d_str_off, target);
+      if (nl) hipLaunchKernelGGL(pq_values_kernel<64>, dim3(grid_for(nl * 64, 256)), dim3(256), 0, s, c->d_val + ns, nl, chunk_dev, cv,
+                                 (const void*)c->d_dict, dn, c->d_str_off, target);
+    }
+  }
+  if (c->nulls > 0) {
+    hipLaunchKernelGGL(pq_popc_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, nwords, c->d_wcnt);
+    DBHIP_TRY(dbscan::exclusive_scan_u32(c->d_wcnt, nwords, c->d_blk, c->d_woff, s));
+    const int grid = grid_for(c->rows, 256);
+    if (is_bool) {
+      hipLaunchKernelGGL(pq_spread_bool_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense,
+                         nwords, (uint32_t*)out_values_dev);
+      if (nwords & 1) DBHIP_CHECK(hipMemsetAsync((uint32_t*)out_values_dev + nwords, 0, 4, s));
+    } else if (esize == 1) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint8_t*)c->d_dense, c->rows, (uint8_t*)out_values_dev);
+    } else if (esize == 2) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint16_t*)c->d_dense, c->rows, (uint16_t*)out_values_dev);
+    } else if (esize == 4) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense, c->rows, (uint32_t*)out_values_dev);
+    } else if (esize == 8) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint64_t*)c->d_dense, c->rows, (uint64_t*)out_values_dev);
+    } else {
+      hipLaunchKernelGGL(pq_spread_kernel<uint4>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint4*)c->d_dense, c->rows, (uint4*)out_values_dev);
+    }
+  }
+  kernel_timer_stop(s);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c) {
+  if (!c) return DBHIP_OK;
+  (void)hipDeviceSynchronize();
+  void* ptrs[] = {c->d_lvl, c->d_val, c->d_str_off, c->d_dict_str_off, c->d_dict, c->d_dense, c->d_wcnt, c->d_woff, c->d_blk};
+  for (void* p : ptrs)
+    if (p) (void)dbhip_free(p);
+  delete c;
+  return DBHIP_OK;
+}
+
+}  // extern "C"

@@ -817,3 +817,50 @@ def score_u8(is_l1, query, base):
     q, b, out = DeviceBuffer.from_numpy(query), DeviceBuffer.from_numpy(base.reshape(-1)), DeviceBuffer(max(n, 1) * 4)
     check(lib().dbhip_score_u8(int(is_l1), C.c_void_p(q.ptr), C.c_void_p(b.ptr), C.c_int64(n), dim, C.c_void_p(out.ptr), None))
     return out.to_numpy(np.float32, n)
+
+
+class ParquetChunk:
+    """dbhip_pq_chunk_*: one Parquet column chunk -> one HBM-resident Column (fuse .../parquet/deserialize.rs:33-81).
+    `chunk` = the raw bytes of the column chunk (dictionary page first), as the block reader fetched them."""
+
+    def __init__(self, chunk, physical_type, out_type, type_length=0, max_def_level=0, max_rep_level=0, codec=0,
+                 precision=0, scale=0):
+        _ensure()
+        self.host = np.frombuffer(bytes(chunk), dtype=np.uint8)
+        self.out_type, self.precision, self.scale = out_type, precision, scale
+        self.h = C.c_void_p()
+        self.info = L.PqInfo()
+        hp = self.host.ctypes.data_as(C.c_void_p) if len(self.host) else C.c_void_p(0)
+        check(lib().dbhip_pq_chunk_open(hp if len(self.host) else self.host.ctypes.data_as(C.c_void_p), C.c_int64(len(self.host)),
+                                        C.c_int32(codec), C.c_int32(physical_type), C.c_int32(type_length), C.c_int32(max_def_level),
+                                        C.c_int32(max_rep_level), C.c_int32(out_type), C.byref(self.h), C.byref(self.info)))
+        self.chunk_dev = None
+
+    def upload(self):
+        """the chunk's bytes into HBM (+ 8 bytes of slack; they become buffer 0 of a string column)"""
+        if self.chunk_dev is None:
+            self.chunk_dev = DeviceBuffer.from_numpy(np.concatenate([self.host, np.zeros(8, np.uint8)]))
+        return self.chunk_dev
+
+    def decode(self, stream=None):
+        i = self.info
+        chunk_dev = self.upload()
+        out = DeviceBuffer(i.out_bytes + 16)
+        val = DeviceBuffer(i.validity_bytes + 8) if i.has_validity else None
+        check(lib().dbhip_pq_chunk_decode(self.h, C.c_void_p(chunk_dev.ptr), C.c_void_p(out.ptr),
+                                          C.c_void_p(val.ptr) if val is not None else None, stream))
+        bufs = None
+        if self.out_type == L.T_STRING:
+            bufs = DeviceBuffer.from_numpy(np.array([chunk_dev.ptr], dtype=np.uint64))
+        return Column(self.out_type, i.num_values, out, val, self.precision, self.scale, buffers=bufs, keep=(chunk_dev,))
+
+    def close(self):
+        if self.h:
+            lib().dbhip_pq_chunk_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,331 @@
+/*
+ * parquet_oracle.c — CPU restatement of the Parquet column-chunk decode.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle.h): the checker of dbhip_pq_chunk_*. Never linked into libdbhip.so.
+ *
+ * What it restates: the reference reads a block's column chunks with arrow-rs
+ * (src/query/storages/fuse/src/io/read/block/parquet/deserialize.rs:33-81, ParquetRecordBatchReader). That decoder
+ * is the third-party `parquet` crate (Cargo.lock: parquet 58.1.0, datafuse-extras/arrow-rs rev bbbe79543), absent
+ * from /root/reference, so this file follows the published Apache Parquet format instead (parquet.thrift PageHeader /
+ * DataPageHeader / DataPageHeaderV2 / DictionaryPageHeader, Encodings.md: PLAIN, RLE / bit-packed hybrid,
+ * RLE_DICTIONARY) for what the reference's writer emits (storages/common/blocks/src/parquet_rs.rs:91-160).
+ * Pinned against pyarrow 25 (the Arrow C++ implementation of the same format) on the fixtures of
+ * tests/golden/parquet/ and on files written on the fly by the tests; "parity pinned on the format's reference
+ * implementation, not on arrow-rs itself" — stated in DESIGN.md.
+ *
+ * Deliberately the simplest possible shape — one value at a time through a streaming hybrid reader — so that it
+ * shares nothing with the device plan (work items, ranks, dense + spread).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { PT_BOOLEAN = 0, PT_INT32 = 1, PT_INT64 = 2, PT_FLOAT = 4, PT_DOUBLE = 5, PT_BYTE_ARRAY = 6, PT_FLBA = 7 };
+enum { T_BOOL = 1, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F32, T_F64, T_DATE, T_TIMESTAMP, T_DEC64, T_DEC128, T_STRING };
+
+typedef struct { const uint8_t* p; const uint8_t* end; int bad; } rd_t;
+
+static uint8_t rd_u8(rd_t* r) { if (r->p >= r->end) { r->bad = 1; return 0; } return *r->p++; }
+static uint64_t rd_varint(rd_t* r) {
+  uint64_t v = 0;
+  for (int sh = 0; sh < 70; sh += 7) {
+    uint8_t b = rd_u8(r);
+    v |= (uint64_t)(b & 0x7F) << sh;
+    if (!(b & 0x80) || r->bad) return v;
+  }
+  r->bad = 1;
+  return 0;
+}
+static int64_t rd_zz(rd_t* r) { uint64_t v = rd_varint(r); return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
+static void rd_skip(rd_t* r, int type, int depth);
+static void rd_skip_struct(rd_t* r, int depth) {
+  for (;;) {
+    uint8_t h = rd_u8(r);
+    if (h == 0 || r->bad) return;
+    if ((h >> 4) == 0) (void)rd_zz(r);
+    rd_skip(r, h & 15, depth + 1);
+  }
+}
+static void rd_skip(rd_t* r, int type, int depth) {
+  if (depth > 16) { r->bad = 1; return; }
+  switch (type) {
+    case 1: case 2: return;
+    case 3: (void)rd_u8(r); return;
+    case 4: case 5: case 6: (void)rd_varint(r); return;
+    case 7: if (r->end - r->p < 8) r->bad = 1; else r->p += 8; return;
+    case 8: { uint64_t n = rd_varint(r); if ((uint64_t)(r->end - r->p) < n) r->bad = 1; else r->p += n; return; }
+    case 9: case 10: {
+      uint8_t h = rd_u8(r);
+      uint64_t n = h >> 4;
+      if (n == 15) n = rd_varint(r);
+      for (uint64_t i = 0; i < n && !r->bad; ++i) { if ((h & 15) <= 2) (void)rd_u8(r); else rd_skip(r, h & 15, depth + 1); }
+      return;
+    }
+    case 11: {
+      uint64_t n = rd_varint(r);
+      if (!n) return;
+      uint8_t kv = rd_u8(r);
+      for (uint64_t i = 0; i < n && !r->bad; ++i) { rd_skip(r, kv >> 4, depth + 1); rd_skip(r, kv & 15, depth + 1); }
+      return;
+    }
+    case 12: rd_skip_struct(r, depth); return;
+    default: r->bad = 1;
+  }
+}
+
+typedef struct {
+  int type, usize, csize;          /* PageHeader 1,2,3 */
+  int nvals, enc, def_enc;         /* (Data|Dictionary)PageHeader 1,2,3 / V2 1,4 */
+  int nnulls, def_len, rep_len;    /* V2 2,5,6 */
+} page_t;
+
+static void read_inner(rd_t* r, page_t* pg, int v2) {
+  int id = 0;
+  for (;;) {
+    uint8_t h = rd_u8(r);
+    if (h == 0 || r->bad) return;
+    int type = h & 15;
+    if ((h >> 4) == 0) id = (int)rd_zz(r); else id += h >> 4;
+    if (type >= 4 && type <= 6) {
+      int v = (int)rd_zz(r);
+      if (v2) { if (id == 1) pg->nvals = v; else if (id == 2) pg->nnulls = v; else if (id == 4) pg->enc = v; else if (id == 5) pg->def_len = v; else if (id == 6) pg->rep_len = v; }
+      else { if (id == 1) pg->nvals = v; else if (id == 2) pg->enc = v; else if (id == 3) pg->def_enc = v; }
+    } else {
+      rd_skip(r, type, 0);
+    }
+  }
+}
+
+static int read_page(rd_t* r, page_t* pg) {
+  memset(pg, 0, sizeof(*pg));
+  pg->type = pg->usize = pg->csize = pg->nvals = pg->enc = pg->nnulls = -1;
+  pg->def_enc = 3;
+  int id = 0;
+  for (;;) {
+    uint8_t h = rd_u8(r);
+    if (r->bad) return -1;
+    if (h == 0) break;
+    int type = h & 15;
+    if ((h >> 4) == 0) id = (int)rd_zz(r); else id += h >> 4;
+    if (type == 5 && id <= 3) { int v = (int)rd_zz(r); if (id == 1) pg->type = v; else if (id == 2) pg->usize = v; else pg->csize = v; }
+    else if (type == 12 && (id == 5 || id == 7)) read_inner(r, pg, 0);
+    else if (type == 12 && id == 8) read_inner(r, pg, 1);
+    else rd_skip(r, type, 0);
+  }
+  return (r->bad || pg->type < 0 || pg->csize < 0) ? -1 : 0;
+}
+
+/* streaming RLE / bit-packed hybrid reader (Encodings.md "Run Length Encoding / Bit-Packing Hybrid") */
+typedef struct {
+  rd_t r; int bitw;
+  uint64_t rle_left, rle_val;
+  uint64_t bp_left; uint64_t bitpos; const uint8_t* bp_base; uint64_t bp_bytes;
+} hyb_t;
+
+static void hyb_init(hyb_t* h, const uint8_t* p, uint64_t len, int bitw) {
+  memset(h, 0, sizeof(*h));
+  h->r.p = p; h->r.end = p + len; h->bitw = bitw;
+}
+static int hyb_next(hyb_t* h, uint32_t* out) {
+  for (;;) {
+    if (h->rle_left) { --h->rle_left; *out = (uint32_t)h->rle_val; return 0; }
+    if (h->bp_left) {
+      uint64_t v = 0;
+      for (int b = 0; b < h->bitw; ++b) {
+        uint64_t bit = h->bitpos + (uint64_t)b;
+        if ((bit >> 3) >= h->bp_bytes) return -1;
+        v |= (uint64_t)((h->bp_base[bit >> 3] >> (bit & 7)) & 1) << b;
+      }
+      h->bitpos += (uint64_t)h->bitw;
+      --h->bp_left;
+      *out = (uint32_t)v;
+      return 0;
+    }
+    uint64_t hd = rd_varint(&h->r);
+    if (h->r.bad) return -1;
+    if (hd & 1) {
+      uint64_t groups = hd >> 1, bytes = groups * (uint64_t)h->bitw;
+      uint64_t avail = (uint64_t)(h->r.end - h->r.p);
+      if (groups == 0) return -1;
+      h->bp_left = groups * 8; h->bitpos = 0; h->bp_base = h->r.p;
+      h->bp_bytes = bytes < avail ? bytes : avail;   /* a truncated final group is caught bit by bit */
+      h->r.p += h->bp_bytes;
+    } else {
+      uint64_t v = 0;
+      for (int b = 0; b < (h->bitw + 7) / 8; ++b) v |= (uint64_t)rd_u8(&h->r) << (8 * b);
+      if (h->r.bad || (hd >> 1) == 0) return -1;
+      h->rle_left = hd >> 1; h->rle_val = v;
+    }
+  }
+}
+
+static int esize_of(int t) {
+  switch (t) {
+    case T_I8: case T_U8: return 1;
+    case T_I16: case T_U16: return 2;
+    case T_I32: case T_U32: case T_F32: case T_DATE: return 4;
+    case T_I64: case T_U64: case T_F64: case T_TIMESTAMP: case T_DEC64: return 8;
+    case T_DEC128: case T_STRING: return 16;
+    default: return 0;
+  }
+}
+
+/* one PLAIN value at p -> out element `o` */
+static void put_plain(int physical, int tlen, int out_type, const uint8_t* p, uint8_t* out, int64_t o) {
+  int es = esize_of(out_type);
+  if (physical == PT_FLBA) {
+    unsigned __int128 v = (p[0] & 0x80) ? ~(unsigned __int128)0 : 0;
+    for (int b = 0; b < tlen; ++b) v = (v << 8) | p[b];
+    memcpy(out + o * es, &v, (size_t)es);  /* little endian host */
+    return;
+  }
+  if (physical == PT_INT32 || physical == PT_FLOAT) {
+    int32_t v;
+    memcpy(&v, p, 4);
+    if (es == 8) { int64_t w = v; memcpy(out + o * 8, &w, 8); }
+    else memcpy(out + o * es, &v, (size_t)es);
+    return;
+  }
+  int64_t v;
+  memcpy(&v, p, 8);
+  if (es == 16) { __int128 w = v; memcpy(out + o * 16, &w, 16); } else memcpy(out + o * 8, &v, 8);
+}
+
+static void put_view(const uint8_t* chunk, uint64_t off, uint8_t* out, int64_t o) {
+  uint32_t len, w[4] = {0, 0, 0, 0};
+  memcpy(&len, chunk + off - 4, 4);
+  w[0] = len;
+  if (len <= 12) memcpy(&w[1], chunk + off, len);
+  else { memcpy(&w[1], chunk + off, 4); w[2] = 0; w[3] = (uint32_t)off; }
+  memcpy(out + o * 16, w, 16);
+}
+
+/* Returns 0, -1 (malformed) or -2 (unsupported). out_valid: one byte per row. BOOL values: one byte per row too. */
+int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_length, int max_def, int out_type, int64_t cap_rows,
+                  uint8_t* out_values, uint8_t* out_valid, int64_t* out_rows, int64_t* out_nulls) {
+  rd_t r = {chunk, chunk + len, 0};
+  const int es = esize_of(out_type);
+  const int pw = physical == PT_INT32 || physical == PT_FLOAT ? 4 : (physical == PT_INT64 || physical == PT_DOUBLE ? 8 : type_length);
+  int64_t rows = 0, nulls = 0;
+  int64_t dict_n = -1;
+  uint8_t* dict = NULL;   /* dictionary converted to the output type */
+  int rc = 0;
+  while (r.p < r.end && rc == 0) {
+    page_t pg;
+    if (read_page(&r, &pg)) { rc = -1; break; }
+    if (pg.csize != pg.usize) { rc = -2; break; }
+    if ((int64_t)(r.end - r.p) < pg.csize) { rc = -1; break; }
+    const uint8_t* pay = r.p;
+    const uint8_t* pend = pay + pg.csize;
+    r.p = pend;
+    if (pg.type == 2) {
+      if (dict_n >= 0 || pg.nvals < 0 || (pg.enc != 0 && pg.enc != 2)) { rc = pg.enc != 0 && pg.enc != 2 ? -2 : -1; break; }
+      dict_n = pg.nvals;
+      dict = (uint8_t*)calloc((size_t)(dict_n > 0 ? dict_n : 1), 16);
+      const uint8_t* q = pay;
+      for (int64_t i = 0; i < dict_n; ++i) {
+        if (physical == PT_BYTE_ARRAY) {
+          uint32_t l;
+          if (pend - q < 4) { rc = -1; break; }
+          memcpy(&l, q, 4);
+          if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+          put_view(chunk, (uint64_t)(q + 4 - chunk), dict, i);
+          q += 4 + l;
+        } else {
+          if (pend - q < pw) { rc = -1; break; }
+          put_plain(physical, type_length, out_type, q, dict, i);
+          q += pw;
+        }
+      }
+      continue;
+    }
+    if (pg.type != 0 && pg.type != 3) continue;
+    if (pg.nvals < 0) { rc = -1; break; }
+    if (rows + pg.nvals > cap_rows) { rc = -1; break; }
+    const uint8_t* q = pay;
+    uint8_t* defs = (uint8_t*)malloc((size_t)pg.nvals + 1);
+    memset(defs, 1, (size_t)pg.nvals + 1);
+    if (pg.type == 0) {
+      if (max_def == 1) {
+        uint32_t l;
+        if (pg.def_enc != 3) { free(defs); rc = -2; break; }
+        if (pend - q < 4) { free(defs); rc = -1; break; }
+        memcpy(&l, q, 4);
+        if ((uint64_t)(pend - q - 4) < l) { free(defs); rc = -1; break; }
+        hyb_t h;
+        hyb_init(&h, q + 4, l, 1);
+        for (int i = 0; i < pg.nvals; ++i) { uint32_t v; if (hyb_next(&h, &v)) { rc = -1; break; } defs[i] = (uint8_t)v; }
+        q += 4 + l;
+      }
+    } else {
+      if (pg.rep_len != 0) { free(defs); rc = -2; break; }
+      if (pg.def_len < 0 || pend - q < pg.def_len) { free(defs); rc = -1; break; }
+      if (max_def == 1) {
+        hyb_t h;
+        hyb_init(&h, q, (uint64_t)pg.def_len, 1);
+        for (int i = 0; i < pg.nvals; ++i) { uint32_t v; if (hyb_next(&h, &v)) { rc = -1; break; } defs[i] = (uint8_t)v; }
+      }
+      q += pg.def_len;
+    }
+    if (rc) { free(defs); break; }
+    /* value reader state */
+    hyb_t vh;
+    int use_hyb = 0, boolbit = 0;
+    if (pg.enc == 2 || pg.enc == 8) {
+      if (dict_n < 0) { free(defs); rc = -1; break; }
+      if (pend - q >= 1) { hyb_init(&vh, q + 1, (uint64_t)(pend - q - 1), q[0]); if (q[0] > 32) rc = -1; }
+      else hyb_init(&vh, q, 0, 0);
+      use_hyb = 1;
+    } else if (pg.enc == 3 && physical == PT_BOOLEAN) {
+      uint32_t l;
+      if (pend - q < 4) { free(defs); rc = -1; break; }
+      memcpy(&l, q, 4);
+      if ((uint64_t)(pend - q - 4) < l) { free(defs); rc = -1; break; }
+      hyb_init(&vh, q + 4, l, 1);
+      use_hyb = 2;
+    } else if (pg.enc != 0) {
+      free(defs);
+      rc = -2;
+      break;
+    }
+    for (int i = 0; i < pg.nvals && rc == 0; ++i) {
+      const int64_t o = rows + i;
+      out_valid[o] = defs[i];
+      if (!defs[i]) {
+        ++nulls;
+        if (out_type == T_BOOL) out_values[o] = 0; else memset(out_values + o * es, 0, (size_t)es);
+        continue;
+      }
+      if (use_hyb == 1) {
+        uint32_t idx;
+        if (hyb_next(&vh, &idx) || (int64_t)idx >= dict_n) { rc = -1; break; }
+        memcpy(out_values + o * es, dict + (int64_t)idx * es, (size_t)es);
+      } else if (use_hyb == 2) {
+        uint32_t v;
+        if (hyb_next(&vh, &v)) { rc = -1; break; }
+        out_values[o] = (uint8_t)v;
+      } else if (physical == PT_BOOLEAN) {
+        if (q + (boolbit >> 3) >= pend) { rc = -1; break; }
+        out_values[o] = (uint8_t)((q[boolbit >> 3] >> (boolbit & 7)) & 1);
+        ++boolbit;
+      } else if (physical == PT_BYTE_ARRAY) {
+        uint32_t l;
+        if (pend - q < 4) { rc = -1; break; }
+        memcpy(&l, q, 4);
+        if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+        put_view(chunk, (uint64_t)(q + 4 - chunk), out_values, o);
+        q += 4 + l;
+      } else {
+        if (pend - q < pw) { rc = -1; break; }
+        put_plain(physical, type_length, out_type, q, out_values, o);
+        q += pw;
+      }
+    }
+    free(defs);
+    rows += pg.nvals;
+  }
+  free(dict);
+  *out_rows = rows;
+  *out_nulls = nulls;
+  return rc;
+}

@@ -1,0 +1,143 @@
+"""Test plumbing for the Parquet column-chunk decode: writes tables with pyarrow (the Arrow C++
+implementation of the format — an independent reader/writer, NOT the code under test), cuts the raw column chunks out of
+the file exactly as the reference's block reader fetches them (DataItem::RawData, one byte range per column) and returns
+what pyarrow itself reads back as the expected values."""
+import ctypes as C
+import io
+import os
+
+import numpy as np
+
+from databend_amd import _lib as T
+
+PHYS = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "INT96": 3, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6, "FIXED_LEN_BYTE_ARRAY": 7}
+ESIZE = {T.T_I8: 1, T.T_U8: 1, T.T_I16: 2, T.T_U16: 2, T.T_I32: 4, T.T_U32: 4, T.T_F32: 4, T.T_DATE: 4, T.T_I64: 8, T.T_U64: 8,
+         T.T_F64: 8, T.T_TIMESTAMP: 8, T.T_DEC64: 8, T.T_DEC128: 16, T.T_STRING: 16}
+NP_OF = {T.T_I8: np.int8, T.T_U8: np.uint8, T.T_I16: np.int16, T.T_U16: np.uint16, T.T_I32: np.int32, T.T_U32: np.uint32,
+         T.T_F32: np.float32, T.T_DATE: np.int32, T.T_I64: np.int64, T.T_U64: np.uint64, T.T_F64: np.float64,
+         T.T_TIMESTAMP: np.int64, T.T_DEC64: np.int64}
+
+
+def write_parquet(table, dictionary=True, v2=None, page_size=None, **kw):
+    """The reference's writer settings (storages/common/blocks/src/parquet_rs.rs:91-160): one row group, no statistics,
+    dictionary on -> data page V2, off -> V1 + PLAIN; uncompressed (TableCompression::None)."""
+    import pyarrow.parquet as pq
+    v2 = dictionary if v2 is None else v2
+    buf = io.BytesIO()
+    args = dict(compression="none", use_dictionary=dictionary, write_statistics=False, data_page_version="2.0" if v2 else "1.0",
+                row_group_size=max(table.num_rows, 1), store_schema=False)
+    if page_size:
+        args["data_page_size"] = page_size
+    args.update(kw)
+    pq.write_table(table, buf, **args)
+    return buf.getvalue()
+
+
+def column_chunks(file_bytes):
+    """-> [dict(name, chunk bytes, physical, type_length, max_def, max_rep, codec, encodings, num_values)] of row group 0"""
+    import pyarrow.parquet as pq
+    pf = pq.ParquetFile(io.BytesIO(file_bytes))
+    rg = pf.metadata.row_group(0)
+    out = []
+    for i in range(rg.num_columns):
+        c = rg.column(i)
+        sc = pf.schema.column(i)
+        offs = [o for o in (c.data_page_offset, c.dictionary_page_offset if c.has_dictionary_page else None) if o]
+        start = min(offs) if offs else 4   # (an empty chunk has no data page: data_page_offset is 0 then; 4 = behind the magic)
+        out.append(dict(name=c.path_in_schema, chunk=file_bytes[start:start + c.total_compressed_size], physical=PHYS[c.physical_type],
+                        type_length=sc.length if sc.length and sc.length > 0 else 0, max_def=sc.max_definition_level,
+                        max_rep=sc.max_repetition_level, codec=0 if c.compression == "UNCOMPRESSED" else 1,
+                        encodings=c.encodings, num_values=c.num_values))
+    return out, pf.read()
+
+
+def expected_of(arr, out_type):
+    """pyarrow ChunkedArray -> (values, valid): values as python objects comparable with decoded_to_python()"""
+    import pyarrow as pa
+    arr = arr.combine_chunks() if hasattr(arr, "combine_chunks") else arr
+    valid = np.array([v is not None for v in arr.to_pylist()], dtype=bool) if arr.null_count else np.ones(len(arr), dtype=bool)
+    if out_type == T.T_STRING:
+        vals = [v if v is None else (v.encode() if isinstance(v, str) else bytes(v)) for v in arr.to_pylist()]
+    elif out_type in (T.T_DEC64, T.T_DEC128) and pa.types.is_decimal(arr.type):
+        sc = arr.type.scale
+        vals = [None if v is None else int(v.scaleb(sc)) for v in arr.to_pylist()]
+    elif out_type == T.T_DATE:
+        vals = [None if v is None else int(v) for v in arr.cast(pa.int32()).to_pylist()]
+    elif out_type == T.T_TIMESTAMP:
+        vals = [None if v is None else int(v) for v in arr.cast(pa.int64()).to_pylist()]
+    elif out_type == T.T_BOOL:
+        vals = [None if v is None else bool(v) for v in arr.to_pylist()]
+    elif out_type in (T.T_F32, T.T_F64):
+        np_t = NP_OF[out_type]
+        vals = [None if v is None else np_t(v).tobytes() for v in arr.to_pylist()]   # bit patterns (NaN-safe)
+    else:
+        vals = [None if v is None else int(v) for v in arr.to_pylist()]
+    return vals, valid
+
+
+def decoded_to_python(values_bytes, valid, out_type, n, chunk=None):
+    """raw decoded element bytes (+ the chunk for string views) -> python objects like expected_of(); NULL -> None,
+    and checks that NULL slots decode to zero."""
+    out = []
+    if out_type == T.T_BOOL:
+        bits = np.frombuffer(values_bytes, dtype=np.uint8)
+        for i in range(n):
+            b = bool((bits[i >> 3] >> (i & 7)) & 1)
+            if not valid[i]:
+                assert not b
+            out.append(b if valid[i] else None)
+        return out
+    es = ESIZE[out_type]
+    raw = np.frombuffer(values_bytes, dtype=np.uint8)[: n * es].reshape(n, es)
+    for i in range(n):
+        e = raw[i].tobytes()
+        if not valid[i]:
+            assert e == b"\0" * es, (i, e)
+            out.append(None)
+        elif out_type == T.T_STRING:
+            ln = int.from_bytes(e[0:4], "little")
+            if ln <= 12:
+                assert e[4 + ln:] == b"\0" * (12 - ln)
+                out.append(e[4:4 + ln])
+            else:
+                assert e[8:12] == b"\0\0\0\0"
+                off = int.from_bytes(e[12:16], "little")
+                s = bytes(chunk[off:off + ln])
+                assert s[:4] == e[4:8]
+                out.append(s)
+        elif out_type in (T.T_F32, T.T_F64):
+            out.append(e)
+        elif out_type in (T.T_U8, T.T_U16, T.T_U32, T.T_U64):
+            out.append(int.from_bytes(e, "little", signed=False))
+        else:
+            out.append(int.from_bytes(e, "little", signed=True))
+    return out
+
+
+_ORC = None
+
+
+def oracle_decode(ch, out_type):
+    """oracle/parquet_oracle.c -> (python values, valid, rows, nulls, rc)"""
+    global _ORC
+    if _ORC is None:
+        from tests import oracle_lib
+        _ORC = oracle_lib.load() if hasattr(oracle_lib, "load") else oracle_lib.lib()
+        _ORC.orc_pq_decode.restype = C.c_int
+    n = ch["num_values"]
+    chunk = np.frombuffer(ch["chunk"], dtype=np.uint8)
+    es = 1 if out_type == T.T_BOOL else ESIZE[out_type]
+    vals = np.zeros(max(n, 1) * es + 16, dtype=np.uint8)
+    valid = np.zeros(max(n, 1), dtype=np.uint8)
+    rows, nulls = C.c_int64(), C.c_int64()
+    rc = _ORC.orc_pq_decode(chunk.ctypes.data_as(C.c_void_p), C.c_int64(len(chunk)), ch["physical"], ch["type_length"], ch["max_def"],
+                            out_type, C.c_int64(n), vals.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p),
+                            C.byref(rows), C.byref(nulls))
+    if rc:
+        return None, None, rows.value, nulls.value, rc
+    v = valid[:n].astype(bool)
+    if out_type == T.T_BOOL:
+        py = [bool(vals[i]) if v[i] else None for i in range(n)]
+    else:
+        py = decoded_to_python(vals.tobytes(), v, out_type, n, chunk)
+    return py, v, rows.value, nulls.value, 0

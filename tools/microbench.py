@@ -294,6 +294,55 @@ def main():
             report(out, f"vec_distance {nm} {n}x{dim}, nq={nq}", nq, "queries", flops=(3.0 if nm == "l2" else 2.0) * n * dim * nq, ms=timed(f, reps=3, warm=1))
         del base, o
 
+    if want("parquet"):
+        # scan-side decode: lineitem-shaped column chunks written by pyarrow with the reference writer's
+        # settings, chunk bytes already resident in HBM when the timed region starts. Algorithmic bytes = chunk bytes read +
+        # column (+ validity) bytes written. The host-side plan (dbhip_pq_chunk_open) and the PCIe upload are reported in the note.
+        import time as _t
+        import numpy as np
+        import pyarrow as pa
+        sys.path.insert(0, ROOT)
+        from tests import parquet_util as PU
+        n = int(60_000_000 * args.scale)
+        rng = np.random.default_rng(3)
+        price = rng.integers(90000, 10494951, n)
+        cols = [
+            ("l_extendedprice Decimal(15,2) INT64 PLAIN v1", pa.array(price, pa.int64()), False, L.T_DEC64),
+            ("l_extendedprice INT64 PLAIN v1, 3% NULL", pa.array(price, pa.int64(), mask=rng.random(n) < 0.03), False, L.T_DEC64),
+            ("l_discount INT64 RLE_DICTIONARY v2 (11 values)", pa.array(rng.integers(0, 11, n), pa.int64()), True, L.T_DEC64),
+            ("l_shipdate Date INT32 RLE_DICTIONARY v2 (2526 values)", pa.array(rng.integers(8036, 10562, n).astype(np.int32), pa.int32()).cast(pa.date32()), True, L.T_DATE),
+            ("l_returnflag String RLE_DICTIONARY v2 (3 values) -> 16-B views", pa.array(np.array(["A", "R", "N"])[rng.integers(0, 3, n)], pa.string()), True, L.T_STRING),
+            ("l_comment-like String PLAIN v1 (unique, 10-44 B) -> views into the chunk", None, False, L.T_STRING),
+        ]
+        for name, arr, dictionary, ot in cols:
+            m = n
+            if arr is None:
+                m = n // 4
+                lens = rng.integers(10, 45, m)
+                blob = rng.integers(97, 123, int(lens.sum()), dtype=np.uint8)
+                offs = np.zeros(m + 1, dtype=np.int32)
+                np.cumsum(lens, out=offs[1:])
+                arr = pa.Array.from_buffers(pa.string(), m, [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(blob.tobytes())])
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), dictionary=dictionary))
+            ch = chunks[0]
+            t0 = _t.perf_counter()
+            pc = D.ParquetChunk(ch["chunk"], ch["physical"], ot, ch["type_length"], ch["max_def"])
+            open_ms = (_t.perf_counter() - t0) * 1e3
+            t0 = _t.perf_counter()
+            cd = pc.upload()
+            check(Lb.dbhip_stream_sync(None))
+            up_ms = (_t.perf_counter() - t0) * 1e3
+            i = pc.info
+            outb = D.DeviceBuffer(i.out_bytes + 16)
+            valb = D.DeviceBuffer(i.validity_bytes + 8) if i.has_validity else None
+            f = lambda: check(Lb.dbhip_pq_chunk_decode(pc.h, C.c_void_p(cd.ptr), C.c_void_p(outb.ptr), C.c_void_p(valb.ptr) if valb else None, None))
+            ms = timed(f, reps=5, warm=2)
+            alg = len(ch["chunk"]) + i.out_bytes + (i.validity_bytes if i.has_validity else 0)
+            report(out, f"parquet decode {name}, {m} rows", m, "rows", alg_bytes=alg, ms=ms,
+                   note=f"chunk {len(ch['chunk'])} B, {i.n_pages} pages, {i.num_nulls} nulls; host plan (open) {open_ms:.1f} ms; H2D upload of the chunk {up_ms:.1f} ms "
+                        f"(pageable host memory); decode + upload + plan = {m / ((ms[0] + open_ms + up_ms) * 1e-3) / 1e9:.2f} G rows/s")
+            pc.close()
+
     if want("u8"):
         n, dim = int(8_000_000 * args.scale), 768
         b = torch.randint(0, 128, (n, dim), device=dev, dtype=torch.uint8, generator=g)
