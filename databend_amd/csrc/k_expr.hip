@@ -49,7 +49,8 @@ struct ExProg {
   int64_t in_voff[EX_MAX_INPUTS];
   int32_t in_type[EX_MAX_INPUTS];   // load kind, see ex_load
   int32_t in_scalar[EX_MAX_INPUTS];
-  int32_t n_ins, n_inputs, out_reg, out_type, n_temps;
+  int32_t n_ins, n_inputs, out_reg, out_type, n_slots;
+  int32_t in_slot[EX_MAX_INPUTS];   // LDS register of input column c (-1: the program never reads it)
   int32_t out_kind, out_cls;        // store width in bytes (0 = bitmap, -4 = f32), class of the result
   int64_t n;
   void* out_values;              // numeric: elements of out_type; BOOL: bitmap words
@@ -107,37 +108,37 @@ enum {
 // loads inside the interpreter loop every LOAD would cost a full HBM round trip of its own.
 // NIN: compile-time bound of the input count (unused slots cost neither code nor VGPRs); ALL8: every input is a
 // plain 8-byte non-scalar column (i64 / u64 / f64 / timestamp / decimal64) — straight-line loads, no kind tests.
-template <int NIN, bool ALL8>
+template <int NIN, bool ALL8, int ROWS>
 __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
-  extern __shared__ uint64_t ex_regs[];  // [n_temps + n_inputs][EX_ROWS][256]
+  extern __shared__ uint64_t ex_regs[];  // [n_slots][ROWS][256]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t rows_per_wave = 64 * EX_ROWS;
+  const int64_t rows_per_wave = 64 * ROWS;
   const int64_t nchunks = (P.n + rows_per_wave - 1) / rows_per_wave;
   const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + tid) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int out_cls = P.out_cls;
   uint64_t acc_i = 0;
   double acc_f = 0.0;
-#define EX_REG(r, k) ex_regs[((r) * EX_ROWS + (k)) * 256 + tid]
+#define EX_REG(r, k) ex_regs[((r) * ROWS + (k)) * 256 + tid]
 
   for (int64_t c = wave_global; c < nchunks; c += nwaves) {
     const int64_t base = c * rows_per_wave;
-    int64_t row[EX_ROWS];
-    bool in_range[EX_ROWS], valid[EX_ROWS];
+    int64_t row[ROWS];
+    bool in_range[ROWS], valid[ROWS];
 #pragma unroll
-    for (int k = 0; k < EX_ROWS; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
       row[k] = base + 64 * k + lane;
       in_range[k] = row[k] < P.n;
       valid[k] = in_range[k];
       if (!in_range[k]) row[k] = P.n - 1;  // clamp: loads stay in bounds, results are masked
     }
     // ---- all input loads of the chunk, back to back ----
-    uint64_t in[NIN][EX_ROWS];
+    uint64_t in[NIN][ROWS];
 #pragma unroll
     for (int ci = 0; ci < NIN; ++ci) {
       if (ci < P.n_inputs) {
 #pragma unroll
-        for (int k = 0; k < EX_ROWS; ++k) {
+        for (int k = 0; k < ROWS; ++k) {
           if (ALL8) {
             in[ci][k] = ((const uint64_t*)P.in_data[ci])[row[k]];
             if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + row[k]);
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
     for (int ci = 0; ci < NIN; ++ci) {
       if (ci < P.n_inputs) {
 #pragma unroll
-        for (int k = 0; k < EX_ROWS; ++k) EX_REG(P.n_temps + ci, k) = in[ci][k];
+        for (int k = 0; k < ROWS; ++k)
+          if (P.in_slot[ci] >= 0) EX_REG(P.in_slot[ci], k) = in[ci][k];
       }
     }
     // ---- interpret (wave-uniform instruction stream) ----
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
       const ExIns I = P.ins[pc];
       const int acls = I.acls, bcls = I.bcls, ocls = I.ocls;
 #pragma unroll
-      for (int k = 0; k < EX_ROWS; ++k) {
+      for (int k = 0; k < ROWS; ++k) {
         uint64_t r;
         if (I.op == EX_CONST) {
           r = I.imm;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
     }
     // ---- result ----
 #pragma unroll
-    for (int k = 0; k < EX_ROWS; ++k) {
+    for (int k = 0; k < ROWS; ++k) {
       const uint64_t r = EX_REG(P.out_reg, k);
       const int64_t word = (base >> 6) + k;  // 64-row word of this slot
       if (P.out_values) {
@@ -374,25 +376,61 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   hipStream_t s = resolve_stream(stream);
   if (err_bitmap) DBHIP_CHECK(hipMemsetAsync(err_bitmap, 0xFF, (size_t)ceil_div(n, 32) * 4, s));
   if (n == 0) return DBHIP_OK;
-  // kernel register numbering: temporaries 0..7 keep their index, input column c becomes register 8 + c -> n_temps + c
-  P.n_temps = EX_MAX_REGS;
-  P.n_ins = n_out; P.n_inputs = n_inputs; P.out_reg = reg_loc[out_reg]; P.out_type = reg_type[out_reg]; P.n = n;
+  P.n_ins = n_out; P.n_inputs = n_inputs; P.out_type = reg_type[out_reg]; P.n = n;
   P.out_values = out_values; P.out_validity = (uint64_t*)out_validity;
   P.err_words = may_raise ? (uint32_t*)err_bitmap : nullptr;
   P.err_count = may_raise ? (unsigned long long*)err_count_dev : nullptr;
   P.sum_out = (unsigned long long*)sum_out_dev;
-  const int64_t chunks = ceil_div(n, 64 * EX_ROWS);
-  int grid = (int)(ceil_div(chunks, 4) < 2048 ? ceil_div(chunks, 4) : 2048);
+  static const bool force2 = getenv("DBHIP_EXPR_ROWS2") != nullptr;
   kernel_timer_start(s);
-  // shrink the LDS register file to what the program touches: temporaries are renumbered densely
+  // LDS register allocation. A LOCATION is a user temporary (0..7) or an input column (EX_MAX_REGS + c); its value is live
+  // from its definition to its last read before the next definition (the out register's last value lives to the end).
+  // Slots are handed out in one forward walk; an operand that dies in an instruction frees its slot BEFORE the
+  // destination is placed, so results overwrite dead operands in place (every thread reads its own cells of a and b before
+  // it writes dst). a + b * c needs 3 slots instead of 5: the LDS footprint per wave is what bounds this kernel's
+  // occupancy, and with it how many loads are in flight.
   {
-    int remap[EX_MAX_REGS], nt = 0;
-    for (int r = 0; r < EX_MAX_REGS; ++r) remap[r] = -1;
-    for (int i = 0; i < n_out; ++i) if (remap[P.ins[i].dst] < 0) remap[P.ins[i].dst] = nt++;
-    auto mp = [&](int r) { return r >= EX_MAX_REGS ? nt + (r - EX_MAX_REGS) : (remap[r] < 0 ? 0 : remap[r]); };
-    for (int i = 0; i < n_out; ++i) { P.ins[i].a = (int16_t)mp(P.ins[i].a); P.ins[i].b = (int16_t)mp(P.ins[i].b); P.ins[i].dst = (int16_t)remap[P.ins[i].dst]; }
-    P.out_reg = mp(P.out_reg);
-    P.n_temps = nt;
+    constexpr int NLOC = EX_MAX_REGS + EX_MAX_INPUTS;
+    const int out_loc = reg_loc[out_reg];
+    int slot_of[NLOC];
+    bool used[NLOC];
+    for (int l = 0; l < NLOC; ++l) { slot_of[l] = -1; used[l] = false; }
+    int n_slots = 0;
+    auto take = [&]() { for (int q = 0; q < NLOC; ++q) if (!used[q]) { used[q] = true; if (q + 1 > n_slots) n_slots = q + 1; return q; } return -1; };
+    auto reads = [&](const ExIns& I, int loc) {
+      if (I.op == DBHIP_EX_CONST) return false;
+      if (I.a == loc) return true;
+      return I.op != DBHIP_EX_NOT && I.op != DBHIP_EX_CAST && I.b == loc;
+    };
+    // is the value that location `loc` holds right after instruction i still read later?
+    auto live_after = [&](int i, int loc) {
+      for (int j = i + 1; j < n_out; ++j) {
+        if (reads(P.ins[j], loc)) return true;
+        if (P.ins[j].dst == loc) return false;
+      }
+      return loc == out_loc;
+    };
+    // input columns the program (or the result) reads get their slots first: the kernel fills them at the top of every chunk
+    for (int c = 0; c < n_inputs; ++c) {
+      const int loc = EX_MAX_REGS + c;
+      P.in_slot[c] = -1;
+      bool any = loc == out_loc;
+      for (int j = 0; j < n_out && !any; ++j) any = reads(P.ins[j], loc);
+      if (any) { slot_of[loc] = take(); P.in_slot[c] = slot_of[loc]; }
+    }
+    for (int i = 0; i < n_out; ++i) {
+      ExIns& I = P.ins[i];
+      const int la = I.a, lb = I.b, ld = I.dst;
+      const bool ra = reads(I, la), rb = reads(I, lb) && lb != la;
+      const int sa = ra ? slot_of[la] : 0, sb = (reads(I, lb)) ? slot_of[lb] : 0;
+      if (ra && !live_after(i, la) && la != ld) { used[slot_of[la]] = false; slot_of[la] = -1; }
+      if (rb && !live_after(i, lb) && lb != ld) { used[slot_of[lb]] = false; slot_of[lb] = -1; }
+      if (slot_of[ld] >= 0) { used[slot_of[ld]] = false; slot_of[ld] = -1; }  // the old value of dst ends here (read above if it was an operand)
+      slot_of[ld] = take();
+      I.a = (int16_t)(sa < 0 ? 0 : sa); I.b = (int16_t)(sb < 0 ? 0 : sb); I.dst = (int16_t)slot_of[ld];
+    }
+    P.out_reg = slot_of[out_loc];
+    P.n_slots = n_slots;
   }
   P.out_cls = ex_cls(P.out_type);
   switch (P.out_type) {
@@ -400,21 +438,33 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
     case DBHIP_T_F32: P.out_kind = -4; break;
     default: P.out_kind = type_bits(P.out_type) / 8; break;
   }
-  const size_t lds = (size_t)(P.n_temps + n_inputs) * EX_ROWS * 256 * 8;
+  // row slots per lane: 4 (32 B per operand per lane in flight, half the per-row interpreter overhead) while the LDS register
+  // file allows it, else 2
+  int rows_per_lane = EX_ROWS;
+  if (!force2 && (size_t)P.n_slots * 4 * 256 * 8 <= 64 * 1024) rows_per_lane = 4;
+  const size_t lds = (size_t)(P.n_slots > 0 ? P.n_slots : 1) * rows_per_lane * 256 * 8;
   if (lds > 64 * 1024) {
-    set_error("dbhip_expr_eval: %d temporaries + %d inputs exceed the LDS register file; split the expression", P.n_temps, n_inputs);
+    set_error("dbhip_expr_eval: %d live registers exceed the LDS register file; split the expression", P.n_slots);
     return DBHIP_ERR_UNSUPPORTED;
   }
+  // workgroups: a power of two (r01ze sweep over 128 M rows of a + b * c: 1024 0.75 ms, 2048 0.76, 3072 0.78 — but 1280 1.01 and
+  // 1536 0.91: the waves' common stride through the three input arrays wants to be a power of two); 8 rows per lane: 0.97 ms
+  const int64_t chunks = ceil_div(n, 64 * rows_per_lane);
+  const int grid = grid_for(ceil_div(chunks, 4) * 256, 256, 1024);
   bool all8 = true;
   for (int c = 0; c < n_inputs; ++c) all8 &= P.in_type[c] == LK_8 && !P.in_scalar[c];
   const dim3 g(grid), b(256);
-  if (n_inputs <= 2) {
-    if (all8) hipLaunchKernelGGL((expr_kernel<2, true>), g, b, lds, s, P); else hipLaunchKernelGGL((expr_kernel<2, false>), g, b, lds, s, P);
-  } else if (n_inputs <= 4) {
-    if (all8) hipLaunchKernelGGL((expr_kernel<4, true>), g, b, lds, s, P); else hipLaunchKernelGGL((expr_kernel<4, false>), g, b, lds, s, P);
+#define EX_LAUNCH(NIN_, R_)                                                                   \
+  do {                                                                                        \
+    if (all8) hipLaunchKernelGGL((expr_kernel<NIN_, true, R_>), g, b, lds, s, P);              \
+    else hipLaunchKernelGGL((expr_kernel<NIN_, false, R_>), g, b, lds, s, P);                  \
+  } while (0)
+  if (rows_per_lane == 4) {
+    if (n_inputs <= 2) EX_LAUNCH(2, 4); else if (n_inputs <= 4) EX_LAUNCH(4, 4); else EX_LAUNCH(8, 4);
   } else {
-    if (all8) hipLaunchKernelGGL((expr_kernel<8, true>), g, b, lds, s, P); else hipLaunchKernelGGL((expr_kernel<8, false>), g, b, lds, s, P);
+    if (n_inputs <= 2) EX_LAUNCH(2, 2); else if (n_inputs <= 4) EX_LAUNCH(4, 2); else EX_LAUNCH(8, 2);
   }
+#undef EX_LAUNCH
   kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;

@@ -411,6 +411,51 @@ def test_groupby_state_block_roundtrip_partial_to_final(gpu):
     assert {r[:2]: r[3] for r in final.result()} == exp_cnt
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_expression_random_register_programs(gpu, seed):
+    """dbhip_expr_eval allocates its LDS registers by liveness (results overwrite dead operands in place): random i64
+    programs with register reuse, redefinition, x op x, dead stores, constants, results that ARE an input, and more live
+    values than the 4-rows-per-lane register file holds (fallback to 2 rows) — against a numpy evaluation of the same
+    program (wrapping i64)."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(1, 70_000))
+    n_in = int(rng.integers(1, 6))
+    data = [rng.integers(-2**40, 2**40, n).astype(np.int64) for _ in range(n_in)]
+    cols = [gpu.Column.from_numpy(d) for d in data]
+    pr = gpu.ExprProgram(cols)
+    regs = {}
+    ins = []
+    n_ops = int(rng.integers(0, 24))
+    many_live = seed % 3 == 2
+    for c in range(n_in):                      # load every input (some stay unused)
+        r = c if many_live else int(rng.integers(0, 8))
+        ins.append((T.EX_LOAD, r, c, 0, T.T_I64, 0))
+        regs[r] = data[c].copy()
+    with np.errstate(over="ignore"):
+        for _ in range(n_ops):
+            live = sorted(regs)
+            kind = int(rng.integers(0, 10))
+            dst = int(rng.integers(0, 8))
+            if kind == 0:
+                v = int(rng.integers(-1000, 1000))
+                ins.append((T.EX_CONST, dst, 0, 0, T.T_I64, v & ((1 << 64) - 1)))
+                regs[dst] = np.full(n, v, dtype=np.int64)
+                continue
+            a = int(rng.choice(live))
+            b = a if kind == 1 else int(rng.choice(live))
+            op = [T.EX_PLUS, T.EX_MINUS, T.EX_MULTIPLY][int(rng.integers(0, 3))]
+            ins.append((op, dst, a, b, T.T_I64, 0))
+            x, y = regs[a], regs[b]
+            regs[dst] = x + y if op == T.EX_PLUS else (x - y if op == T.EX_MINUS else x * y)
+    pr.ins = ins
+    for r in regs:
+        pr.types[r] = T.T_I64
+    out_reg = int(rng.choice(sorted(regs)))
+    got = pr.run(out_reg, n=n, want_sum=True)
+    assert np.array_equal(got["values"], regs[out_reg])
+    assert got["sum"] == int(regs[out_reg].astype(object).sum() % (1 << 64) if False else np.sum(regs[out_reg].view(np.uint64), dtype=np.uint64).astype(np.int64))
+
+
 @pytest.mark.parametrize("card,max_rows", [(4, 256), (200, 256), (1, 1), (3000, 256)])
 def test_groupby_exchange_blocks_device_resident(gpu, card, max_rows):
     """The multi-GPU exchange of bench.py --gpus N on one GPU: three "ranks" (three tables over disjoint row ranges)
