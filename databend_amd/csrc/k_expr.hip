@@ -158,58 +158,72 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
           if (P.in_slot[ci] >= 0) EX_REG(P.in_slot[ci], k) = in[ci][k];
       }
     }
-    // ---- interpret (wave-uniform instruction stream) ----
+    // ---- interpret (wave-uniform instruction stream): ONE dispatch per instruction, the row slots loop inside the case ----
     for (int pc = 0; pc < P.n_ins; ++pc) {
       const ExIns I = P.ins[pc];
       const int acls = I.acls, bcls = I.bcls, ocls = I.ocls;
+#define EX_ROWS_DO(EXPR)                                  \
+  _Pragma("unroll") for (int k = 0; k < ROWS; ++k) {      \
+    const uint64_t x = EX_REG(I.a, k);                    \
+    const uint64_t y = EX_REG(I.b, k);                    \
+    (void)x; (void)y;                                     \
+    EX_REG(I.dst, k) = (EXPR);                            \
+  }
+#define EX_ROWS_DO1(EXPR)                                 \
+  _Pragma("unroll") for (int k = 0; k < ROWS; ++k) {      \
+    const uint64_t x = EX_REG(I.a, k);                    \
+    (void)x;                                              \
+    EX_REG(I.dst, k) = (EXPR);                            \
+  }
+      switch (I.op) {
+        case EX_CONST:
 #pragma unroll
-      for (int k = 0; k < ROWS; ++k) {
-        uint64_t r;
-        if (I.op == EX_CONST) {
-          r = I.imm;
-        } else {
-          const uint64_t x = EX_REG(I.a, k);
-          const uint64_t y = (I.op == EX_NOT || I.op == EX_CAST) ? 0 : EX_REG(I.b, k);
-          switch (I.op) {
-            case EX_PLUS: case EX_MINUS: case EX_MULTIPLY:
-              if (ocls == CLS_FLOAT) {
-                const double a = ex_to_f64(x, acls), b = ex_to_f64(y, bcls);
-                const double z = I.op == EX_PLUS ? a + b : (I.op == EX_MINUS ? a - b : a * b);
-                r = (uint64_t)__double_as_longlong(z);
-              } else {
-                r = I.op == EX_PLUS ? x + y : (I.op == EX_MINUS ? x - y : x * y);
+          for (int k = 0; k < ROWS; ++k) EX_REG(I.dst, k) = I.imm;
+          break;
+        case EX_PLUS:
+          if (ocls == CLS_FLOAT) EX_ROWS_DO(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls) + ex_to_f64(y, bcls)), I))
+          else EX_ROWS_DO(ex_norm(x + y, I))
+          break;
+        case EX_MINUS:
+          if (ocls == CLS_FLOAT) EX_ROWS_DO(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls) - ex_to_f64(y, bcls)), I))
+          else EX_ROWS_DO(ex_norm(x - y, I))
+          break;
+        case EX_MULTIPLY:
+          if (ocls == CLS_FLOAT) EX_ROWS_DO(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls) * ex_to_f64(y, bcls)), I))
+          else EX_ROWS_DO(ex_norm(x * y, I))
+          break;
+        case EX_DIVIDE:
+#pragma unroll
+          for (int k = 0; k < ROWS; ++k) {
+            const double a = ex_to_f64(EX_REG(I.a, k), acls), bb = ex_to_f64(EX_REG(I.b, k), bcls);
+            uint64_t r = 0;
+            if (bb == 0.0) {
+              if (valid[k]) {  // NULL rows never raise (function.rs:536-543); padding rows are not valid
+                if (P.err_words) atomicAnd(&P.err_words[row[k] >> 5], ~(1u << (row[k] & 31)));
+                if (P.err_count) atomicAdd(P.err_count, 1ULL);
               }
-              r = ex_norm(r, I);
-              break;
-            case EX_DIVIDE: {
-              const double a = ex_to_f64(x, acls), b = ex_to_f64(y, bcls);
-              if (b == 0.0) {
-                if (valid[k]) {  // NULL rows never raise (function.rs:536-543); padding rows are not valid
-                  if (P.err_words) atomicAnd(&P.err_words[row[k] >> 5], ~(1u << (row[k] & 31)));
-                  if (P.err_count) atomicAdd(P.err_count, 1ULL);
-                }
-                r = 0;
-              } else {
-                r = (uint64_t)__double_as_longlong(a / b);
-              }
-            } break;
-            case EX_EQ: r = ex_cmp3(x, y, acls) == 0; break;
-            case EX_NOTEQ: r = ex_cmp3(x, y, acls) != 0; break;
-            case EX_LT: r = ex_cmp3(x, y, acls) < 0; break;
-            case EX_LTE: r = ex_cmp3(x, y, acls) <= 0; break;
-            case EX_GT: r = ex_cmp3(x, y, acls) > 0; break;
-            case EX_GTE: r = ex_cmp3(x, y, acls) >= 0; break;
-            case EX_AND: r = x & y & 1; break;
-            case EX_OR: r = (x | y) & 1; break;
-            case EX_NOT: r = (x ^ 1) & 1; break;
-            default:  // EX_CAST (lossless widenings only, checked on the host)
-              if (ocls == CLS_FLOAT) r = ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls)), I);
-              else r = x;
-              break;
+            } else {
+              r = (uint64_t)__double_as_longlong(a / bb);
+            }
+            EX_REG(I.dst, k) = r;
           }
-        }
-        EX_REG(I.dst, k) = r;
+          break;
+        case EX_EQ: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) == 0)) break;
+        case EX_NOTEQ: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) != 0)) break;
+        case EX_LT: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) < 0)) break;
+        case EX_LTE: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) <= 0)) break;
+        case EX_GT: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) > 0)) break;
+        case EX_GTE: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) >= 0)) break;
+        case EX_AND: EX_ROWS_DO(x & y & 1) break;
+        case EX_OR: EX_ROWS_DO((x | y) & 1) break;
+        case EX_NOT: EX_ROWS_DO1((x ^ 1) & 1) break;
+        default:  // EX_CAST (lossless widenings only, checked on the host)
+          if (ocls == CLS_FLOAT) EX_ROWS_DO1(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls)), I))
+          else EX_ROWS_DO1(x)
+          break;
       }
+#undef EX_ROWS_DO
+#undef EX_ROWS_DO1
     }
     // ---- result ----
 #pragma unroll
