@@ -683,30 +683,30 @@ int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void*
     auto split = [](std::vector<PqItem>& v) {
       return (int64_t)(std::stable_partition(v.begin(), v.end(), [](const PqItem& i) { return i.count <= ITEM_SMALL; }) - v.begin());
     };
-    c->n_lvl_small = split(c->lvl_items);
+    c->n_lvl_small = split(c->lvl_items);   // (idempotent: a retried first decode partitions the same way)
     c->n_val_small = split(c->val_items);
     if (!c->lvl_items.empty()) {
-      DBHIP_TRY(dbhip_alloc(c->lvl_items.size() * sizeof(PqItem), (void**)&c->d_lvl));
+      if (!c->d_lvl) DBHIP_TRY(dbhip_alloc(c->lvl_items.size() * sizeof(PqItem), (void**)&c->d_lvl));
       DBHIP_CHECK(hipMemcpyAsync(c->d_lvl, c->lvl_items.data(), c->lvl_items.size() * sizeof(PqItem), hipMemcpyHostToDevice, s));
     }
     if (!c->val_items.empty()) {
-      DBHIP_TRY(dbhip_alloc(c->val_items.size() * sizeof(PqItem), (void**)&c->d_val));
+      if (!c->d_val) DBHIP_TRY(dbhip_alloc(c->val_items.size() * sizeof(PqItem), (void**)&c->d_val));
       DBHIP_CHECK(hipMemcpyAsync(c->d_val, c->val_items.data(), c->val_items.size() * sizeof(PqItem), hipMemcpyHostToDevice, s));
     }
     if (!c->str_off.empty()) {
-      DBHIP_TRY(dbhip_alloc(c->str_off.size() * 4, (void**)&c->d_str_off));
+      if (!c->d_str_off) DBHIP_TRY(dbhip_alloc(c->str_off.size() * 4, (void**)&c->d_str_off));
       DBHIP_CHECK(hipMemcpyAsync(c->d_str_off, c->str_off.data(), c->str_off.size() * 4, hipMemcpyHostToDevice, s));
     }
     if (!c->dict_str_off.empty()) {
-      DBHIP_TRY(dbhip_alloc(c->dict_str_off.size() * 4, (void**)&c->d_dict_str_off));
+      if (!c->d_dict_str_off) DBHIP_TRY(dbhip_alloc(c->dict_str_off.size() * 4, (void**)&c->d_dict_str_off));
       DBHIP_CHECK(hipMemcpyAsync(c->d_dict_str_off, c->dict_str_off.data(), c->dict_str_off.size() * 4, hipMemcpyHostToDevice, s));
     }
-    if (c->dict_n > 0) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
+    if (c->dict_n > 0 && !c->d_dict) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
     if (c->nulls > 0) {
-      DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->nonnull + 1, 64) * 8 : (size_t)(c->nonnull + 1) * (size_t)esize, &c->d_dense));
-      DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_wcnt));
-      DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
-      DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
+      if (!c->d_dense) DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->nonnull + 1, 64) * 8 : (size_t)(c->nonnull + 1) * (size_t)esize, &c->d_dense));
+      if (!c->d_wcnt) DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_wcnt));
+      if (!c->d_woff) DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
+      if (!c->d_blk) DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
     }
     DBHIP_CHECK(hipStreamSynchronize(s));  // the host vectors may be released by close() right after this call returns
     c->uploaded = true;
