@@ -292,6 +292,7 @@ bool scan_hybrid(const uint8_t* base, uint64_t off, uint64_t len, int bitw, uint
       uint64_t v = 0;
       for (int b = 0; b < vbytes; ++b) v |= (uint64_t)r.u8() << (8 * b);
       if (!r.ok || n == 0) return false;
+      if (bitw < 64 && (v >> bitw) != 0) return false;  // a repeated value wider than the stream's bit width (levels: only 0 / 1)
       if (n > nvals - done) n = nvals - done;
       if (ones && v == 1) *ones += n;
       for (uint64_t s = 0; s < n; s += 1u << 20) {  // an RLE item is a fill: long pieces are fine, but keep several waves busy

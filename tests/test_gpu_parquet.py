@@ -156,3 +156,44 @@ def test_full_size_roundtrip_20m_rows(gpu):
         else:
             assert np.array_equal(got, src)
         pc.close()
+
+
+def test_mutated_chunks_never_fault(gpu):
+    """Corrupt chunks (bit flips, truncation, overwritten bytes): open() either rejects them (INVALID / UNSUPPORTED) or
+    plans a decode that stays inside the chunk, the dictionary and the output buffers — every offset the device uses is
+    validated on the host, dictionary indices are clamped. Accepted mutants are decoded; the values may be garbage, the call
+    must succeed."""
+    import pyarrow as pa
+    rng = np.random.default_rng(12)
+    seeds = []
+    for vi in (0, 1, 4, 6):
+        for name, arr, ot, wkw in PC.make_cases(seed=vi):
+            kw = dict(PC.VARIANTS[vi])
+            kw.update(wkw)
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr.slice(0, 2500)}), **kw))
+            if len(chunks[0]["chunk"]):
+                seeds.append((chunks[0], ot))
+    opened = rejected = 0
+    for it in range(1500):
+        ch, ot = seeds[it % len(seeds)]
+        b = bytearray(ch["chunk"])
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b = b[: int(rng.integers(1, len(b)))]
+        else:
+            i = int(rng.integers(0, len(b)))
+            b[i:i + 4] = bytes(rng.integers(0, 256, 4).astype(np.uint8))
+        try:
+            pc = gpu.ParquetChunk(bytes(b), ch["physical"], ot, ch["type_length"], ch["max_def"])
+        except T.DbhipError as e:
+            assert e.code in (T.ERR_INVALID, T.ERR_UNSUPPORTED)
+            rejected += 1
+            continue
+        col = pc.decode()
+        col.data.to_numpy(np.uint8, pc.info.out_bytes)     # forces completion: a device fault would surface here
+        pc.close()
+        opened += 1
+    assert opened > 100 and rejected > 100
