@@ -1071,4 +1071,43 @@ inline DataBlock sort_block(const DataBlock& block, const std::vector<SortColumn
   return take_block(block, perm, m);
 }
 
+
+// ---- scan side: one leaf column of column_chunks_to_record_batch --------------------------------
+// (fuse/src/io/read/block/parquet/deserialize.rs:33-81 + the arrow -> Column conversion). `bytes` is the column chunk as the
+// block reader fetched it (DataItem::RawData). std::nullopt = the library declines the chunk (compressed, nested, DELTA_*
+// encodings): the caller keeps the arrow-rs reader for it, exactly like a ScalarFunction falls back on DBHIP_ERR_UNSUPPORTED.
+struct ParquetLeaf {        // what ColumnDescriptor + ColumnChunkMetaData give
+  int32_t physical_type;    // parquet.thrift Type
+  int32_t type_length = 0;  // FIXED_LEN_BYTE_ARRAY
+  int32_t max_def_level = 0, max_rep_level = 0;
+  int32_t codec = 0;        // parquet.thrift CompressionCodec (0 = UNCOMPRESSED)
+};
+
+inline std::optional<Column> column_chunk_to_column(const uint8_t* bytes, size_t len, const ParquetLeaf& leaf, DataType field_type) {
+  dbhip_pq_chunk* h = nullptr;
+  dbhip_pq_info info;
+  const int32_t rc = dbhip_pq_chunk_open(bytes, (int64_t)len, leaf.codec, leaf.physical_type, leaf.type_length, leaf.max_def_level,
+                                         leaf.max_rep_level, field_type.id, &h, &info);
+  if (rc == DBHIP_ERR_UNSUPPORTED) return std::nullopt;
+  check(rc);
+  struct Closer { dbhip_pq_chunk* h; ~Closer() { dbhip_pq_chunk_close(h); } } closer{h};
+  Column c;
+  c.type = field_type;
+  c.type.nullable = info.has_validity != 0;
+  c.len = info.num_values;
+  Buf chunk = make_buf(len + 8);               // resident copy (+ slack); buffer 0 of a String column
+  chunk->upload(bytes, len);
+  c.data = make_buf((size_t)info.out_bytes);
+  if (info.has_validity) c.validity = make_buf((size_t)info.validity_bytes);
+  check(dbhip_pq_chunk_decode(h, (const uint8_t*)chunk->ptr(), c.data->ptr(), c.validity ? (uint8_t*)c.validity->ptr() : nullptr, nullptr));
+  check(dbhip_stream_sync(nullptr));
+  if (field_type.id == DBHIP_T_STRING) {
+    c.str_data = chunk;
+    void* p = chunk->ptr();
+    c.str_ptrs = make_buf(sizeof(void*));
+    c.str_ptrs->upload(&p, sizeof(void*));
+  }
+  return c;
+}
+
 }  // namespace dbhip_host

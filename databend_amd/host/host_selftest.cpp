@@ -265,6 +265,40 @@ static void test_vector_function() {
   }
 }
 
+
+// a hand-assembled column chunk: one DATA_PAGE (v1), PLAIN, optional INT64, values {7, NULL, -3, 1<<40}
+static void test_parquet_chunk() {
+  std::vector<uint8_t> ch = {
+      0x15, 0x00,              // PageHeader.type = DATA_PAGE
+      0x15, 0x3C,              // uncompressed_page_size = 30 (zigzag 60): 4 + 2 level bytes + 3 x 8 value bytes
+      0x15, 0x3C,              // compressed_page_size = 30
+      0x2C,                    // field 5: data_page_header {
+      0x15, 0x08,              //   num_values = 4
+      0x15, 0x00,              //   encoding = PLAIN
+      0x15, 0x06,              //   definition_level_encoding = RLE
+      0x15, 0x06,              //   repetition_level_encoding = RLE
+      0x00,                    // }
+      0x00,                    // end of PageHeader
+      // definition levels: u32 length = 2, then one bit-packed run of 1 group (header 0x03), bits 1,0,1,1 -> 0x0D
+      0x02, 0x00, 0x00, 0x00, 0x03, 0x0D,
+  };
+  const int64_t vals[3] = {7, -3, (int64_t)1 << 40};
+  const uint8_t* vb = (const uint8_t*)vals;
+  ch.insert(ch.end(), vb, vb + 24);
+  ParquetLeaf leaf{2 /*INT64*/, 0, 1, 0, 0};
+  auto col = column_chunk_to_column(ch.data(), ch.size(), leaf, DataType::of(DBHIP_T_I64));
+  CHECK(col.has_value());
+  if (col) {
+    CHECK(col->len == 4);
+    auto v = col->to_vector<int64_t>();
+    auto ok = col->validity_to_host();
+    CHECK(v[0] == 7 && v[1] == 0 && v[2] == -3 && v[3] == ((int64_t)1 << 40));
+    CHECK(ok[0] && !ok[1] && ok[2] && ok[3]);
+  }
+  leaf.codec = 1;  // SNAPPY: declined, the caller keeps the CPU reader
+  CHECK(!column_chunk_to_column(ch.data(), ch.size(), leaf, DataType::of(DBHIP_T_I64)).has_value());
+}
+
 int main() {
   try {
     init(0);
@@ -274,6 +308,7 @@ int main() {
     test_q1_plan();
     test_join_and_sort();
     test_vector_function();
+    test_parquet_chunk();
   } catch (const std::exception& e) {
     printf("EXCEPTION: %s\n", e.what());
     return 2;
