@@ -1297,6 +1297,13 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
 
   for (uint32_t t0 = r_begin; t0 < r_end; t0 += 256 * PA_R) {
     uint32_t slot[PA_R];
+    // the hashes of all PA_R rows of this thread first: PA_R independent loads in flight instead of one per probe
+    uint64_t hs[PA_R];
+#pragma unroll
+    for (int x = 0; x < PA_R; ++x) {
+      const uint32_t ri = t0 + x * 256 + tid;
+      hs[x] = ri < r_end ? A.rows[(uint64_t)ri * L.W + L.hash_word] : 0;
+    }
     // ---- phase A: match-or-claim by hash ----
 #pragma unroll
     for (int x = 0; x < PA_R; ++x) {
@@ -1304,7 +1311,7 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
       slot[x] = FK_SPILL - 1;  // padding
       if (ri < r_end) {
         const uint64_t* r = A.rows + (uint64_t)ri * L.W;
-        const uint64_t h = r[L.hash_word];
+        const uint64_t h = hs[x];
         const uint64_t hw = probe_word(h, A.hash_mask);
         uint32_t pos = (uint32_t)hw & lmask;
         slot[x] = FK_SPILL;
