@@ -28,6 +28,7 @@
 #include "gb_device.h"
 #include "runtime.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -59,7 +60,7 @@ struct dbhip_groupby {
   int part_forbidden;                      // test hook: never choose the partitioned path
   int64_t part_min_rows;                   // smallest chunk worth partitioning
   int64_t rows_seen;                       // input rows of add_block so far (cardinality estimate)
-  uint32_t* part_meta; size_t part_meta_cap;   // hist[1024] | base[1025] | cursor[1024]
+  uint32_t* part_meta; size_t part_meta_cap;   // hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
   uint32_t* spill_idx; size_t spill_idx_cap;
   uint64_t* spill_rows; size_t spill_rows_cap;
 };
@@ -1019,7 +1020,9 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 
 int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
                               int64_t* spilled);
-void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen);
+constexpr int PT_MAX_BITS = 13;
+constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
+void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block);
 int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s);
 constexpr int64_t PT_CHUNK = 32 << 20;
 
@@ -1034,7 +1037,7 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
   *done += cn;
   g->rows_seen += cn;
   if (spilled * 20 > cn) {
-    if (g->part_bits + 2 <= 10) g->part_bits += 2;
+    if (g->part_bits + 2 <= PT_MAX_BITS) g->part_bits += 2;
     else { g->part_bits = -1; g->fast_disabled = 1; }
   }
   return DBHIP_OK;
@@ -1114,7 +1117,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // more groups than a workgroup's table takes (it would run full everywhere and hand most rows on)
     const bool too_many = g->count_host * 8 > (int64_t)A.llimit * 7;
     if (((int64_t)hc[6] * 10 > cn || too_many) && cn >= 65536) {
-      decide_partitioning(g, g->count_host, g->rows_seen);
+      decide_partitioning(g, g->count_host, g->rows_seen, n);
       if (g->part_bits < 0) g->fast_disabled = 1;
     }
     if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby lds chunk: rows=%lld partial=%llu spilled=%llu groups=%lld -> pbits=%d\n",
@@ -1145,7 +1148,6 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
 // ---------------------------------------------------------------------------
 constexpr int PT_THREADS = 1024;
 constexpr int PT_R = 8;
-constexpr int PT_MAX_BITS = 10;
 
 __device__ __forceinline__ uint64_t gb_keys_hash(const GbLayout& L, const GbCols& C, int64_t i, uint64_t* ctrl) {
   uint64_t h = 0;
@@ -1176,12 +1178,17 @@ __global__ __launch_bounds__(256) void gb_part_hist_kernel(GbLayout L, GbCols C,
   }
 }
 
-// base[0..P] = exclusive scan of hist[0..P), cursor[0..P) = 0   (P <= 1024, one workgroup of 1024)
+// base[0..P] = exclusive scan of hist[0..P), cursor[0..P) = 0   (P <= 8192, one workgroup of 1024, 8 entries per thread)
 __global__ __launch_bounds__(1024) void gb_part_scan_kernel(const uint32_t* hist, int P, uint32_t* base, uint32_t* cursor) {
   __shared__ uint32_t wave_tot[16];
   const int t = threadIdx.x;
-  const uint32_t v = t < P ? hist[t] : 0;
-  uint32_t incl = v;
+  uint32_t v[8], tsum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = (t * 8 + k) < P ? hist[t * 8 + k] : 0;
+    tsum += v[k];
+  }
+  uint32_t incl = tsum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t o = __shfl_up(incl, d, 64);
@@ -1191,11 +1198,14 @@ __global__ __launch_bounds__(1024) void gb_part_scan_kernel(const uint32_t* hist
   __syncthreads();
   uint32_t wbase = 0;
   for (int k = 0; k < (t >> 6); ++k) wbase += wave_tot[k];
-  if (t < P) {
-    base[t] = wbase + incl - v;
-    cursor[t] = 0;
+  uint32_t run = wbase + incl - tsum;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = t * 8 + k;
+    if (i < P) { base[i] = run; cursor[i] = 0; }
+    run += v[k];
+    if (i == P - 1) base[P] = run;
   }
-  if (t == P - 1) base[P] = wbase + incl;
 }
 
 // serialized image of input row i (same encoding as gb_serialize_kernel) written to `r`
@@ -1230,8 +1240,7 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
                                                                      uint64_t* ctrl) {
   extern __shared__ uint32_t pt_lds[];
   const int P = 1 << pbits;
-  uint32_t* lcnt = pt_lds;       // rows of this tile per partition
-  uint32_t* lbase = pt_lds + P;  // first output row of this tile's run in the partition
+  uint32_t* lcnt = pt_lds;       // rows of this tile per partition, then (in place) the first output row of the tile's run
   const int tid = threadIdx.x;
   const int64_t tile_rows = (int64_t)PT_THREADS * PT_R;
   const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
@@ -1252,13 +1261,13 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
     __syncthreads();
     for (int s = tid; s < P; s += PT_THREADS) {
       const uint32_t c = lcnt[s];
-      lbase[s] = c ? base[s] + atomicAdd(&cursor[s], c) : 0;
+      lcnt[s] = c ? base[s] + atomicAdd(&cursor[s], c) : 0;
     }
     __syncthreads();
 #pragma unroll
     for (int x = 0; x < PT_R; ++x) {
       const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
-      if (li < n) gb_serialize_row(L, C, row0 + li, rows_out + (uint64_t)(lbase[part[x]] + rank[x]) * L.W, ctrl);
+      if (li < n) gb_serialize_row(L, C, row0 + li, rows_out + (uint64_t)(lcnt[part[x]] + rank[x]) * L.W, ctrl);
     }
     __syncthreads();
   }
@@ -1404,23 +1413,23 @@ void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
 // One chunk [row0, row0 + cn) through hist -> scan -> scatter -> aggregate -> merge.
 // *spilled = rows that did not fit their partition's LDS table (went through the row path).
 // hist -> scan -> scatter: rows [row0, row0 + cn) serialized into g->rows_in grouped by the top `pbits` hash bits;
-// base[0..P] (device, g->part_meta + 1024) = first row of every partition
+// base[0..P] (device, g->part_meta + PT_PMAX) = first row of every partition
 int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s) {
   const GbLayout& L = g->L;
   const int P = 1 << pbits;
   int32_t rc;
   if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
-  if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, (size_t)(3 * 1024 + 8) * 4))) return rc;
+  if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, (size_t)(3 * PT_PMAX + 8) * 4))) return rc;
   uint32_t* hist = g->part_meta;
-  uint32_t* base = g->part_meta + 1024;
-  uint32_t* cursor = g->part_meta + 2048 + 8;
+  uint32_t* base = g->part_meta + PT_PMAX;
+  uint32_t* cursor = g->part_meta + 2 * PT_PMAX + 8;
   DBHIP_CHECK(hipMemsetAsync(hist, 0, (size_t)P * 4, s));
   hipLaunchKernelGGL(gb_part_hist_kernel, dim3(grid_for(cn, 256)), dim3(256), (size_t)P * 4, s, L, C, row0, cn, pbits,
                      hist, g->ctrl);
   hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, hist, P, base, cursor);
   const int64_t ntiles = ceil_div(cn, (int64_t)PT_THREADS * PT_R);
   const int sgrid = (int)(ntiles < 512 ? ntiles : 512);
-  hipLaunchKernelGGL(gb_part_scatter_kernel, dim3(sgrid), dim3(PT_THREADS), (size_t)P * 8, s, L, C, row0, cn, pbits,
+  hipLaunchKernelGGL(gb_part_scatter_kernel, dim3(sgrid), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
                      base, cursor, g->rows_in, g->ctrl);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
@@ -1437,7 +1446,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   int32_t rc;
   if ((rc = partition_scatter(g, C, row0, cn, pbits, s))) return rc;
   if ((rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
-  uint32_t* base = g->part_meta + 1024;
+  uint32_t* base = g->part_meta + PT_PMAX;
   // workgroups per partition: fill the chip (>= ~1024 workgroups) without making splits tiny
   int splits = 1;
   while (P * splits < 1024 && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
@@ -1474,18 +1483,43 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
 // Called once the LDS pre-aggregation (or the first row-path chunk) has shown that the key
 // distribution does not fit one workgroup's table: `groups` distinct groups were seen in the first
 // `rows_seen` rows. Chooses the partition count, or gives up (row path) for high cardinality.
-void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen) {
+// Number of distinct groups the WHOLE input is likely to hold, from `d` distinct groups met in the first `s` rows: for D equally
+// likely groups E[d] = D (1 - exp(-s / D)); solved for D by bisection. (Skewed keys make this an under-estimate, which errs
+// towards partitioning; a partitioning that turns out too narrow widens itself, partitioned_step.) A prefix that is all
+// distinct tells nothing: returned as "huge".
+int64_t estimate_groups(int64_t d, int64_t s) {
+  if (s <= 0 || d <= 0) return d;
+  const double r = (double)d / (double)s;
+  if (r > 0.97) return INT64_MAX / 16;
+  double lo = 1e-6, hi = 64.0;  // x = D / s
+  for (int it = 0; it < 60; ++it) {
+    const double x = 0.5 * (lo + hi);
+    if (x * (1.0 - exp(-1.0 / x)) < r) lo = x; else hi = x;
+  }
+  const double D = 0.5 * (lo + hi) * (double)s;
+  return D < (double)d ? d : (int64_t)D;
+}
+
+// Called once the LDS pre-aggregation (or the first row-path chunk) has shown that the key
+// distribution does not fit one workgroup's table: `groups` distinct groups were seen in the first
+// `rows_seen` rows; `n_block` = rows of the add_block call that is being worked on. Chooses the partition count, or gives up
+// (row path) when fewer than ~8 rows per group are to be expected.
+void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block) {
   int lcap, sw;
   size_t lds_bytes;
   part_geometry(g->L, &lcap, &sw, &lds_bytes);
   g->part_bits = -1;
   if (lcap == 0 || g->part_forbidden) return;
-  if (groups * 4 > rows_seen) return;  // (nearly) every row its own group: pre-aggregation buys nothing
+  const int64_t est = estimate_groups(groups, rows_seen);
+  const int64_t total = n_block > rows_seen ? n_block : rows_seen;
+  if (est > total / 8) return;  // (nearly) every row its own group: pre-aggregation buys nothing
   const int64_t per_part = lcap * 3 / 8;  // target groups per partition: half of the LDS table's limit
   int bits = 4;
-  while (bits < PT_MAX_BITS && ((int64_t)per_part << bits) < groups) ++bits;
-  if (((int64_t)per_part << bits) < groups) return;
+  while (bits < PT_MAX_BITS && ((int64_t)per_part << bits) < est) ++bits;
+  if (((int64_t)per_part << bits) < est) return;
   g->part_bits = bits;
+  if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in the first %lld rows -> ~%lld groups in %lld rows, %d partition bits\n",
+                                     (long long)groups, (long long)rows_seen, (long long)est, (long long)total, bits);
 }
 
 }  // namespace
@@ -1562,7 +1596,7 @@ int32_t dbhip_groupby_debug_set_hash_mask(dbhip_groupby* g, uint64_t mask) {
 // test hook: force the radix-partitioned path with 2^bits partitions for every block size
 // (bits = 0: back to adaptive; bits < 0: never partition)
 int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits) {
-  DBHIP_REQUIRE(g && bits <= 10, "dbhip_groupby_debug_set_partition_bits: bad argument");
+  DBHIP_REQUIRE(g && bits <= PT_MAX_BITS, "dbhip_groupby_debug_set_partition_bits: bad argument");
   if (bits > 0) { g->part_bits = bits; g->part_min_rows = 1; g->part_forbidden = 0; }
   else if (bits == 0) { g->part_bits = 0; g->part_min_rows = 262144; g->part_forbidden = 0; }
   else { g->part_bits = -1; g->part_forbidden = 1; g->part_min_rows = 262144; }
@@ -1625,7 +1659,7 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
     done += cn;
     g->rows_seen += cn;
     if (probe_here && g->part_bits == 0 && g->rows_seen >= (1 << 20)) {
-      if (g->count_host > 32) decide_partitioning(g, g->count_host, g->rows_seen);
+      if (g->count_host > 32) decide_partitioning(g, g->count_host, g->rows_seen, n);
       else g->part_bits = -1;  // a handful of groups: the wave-combining accumulate kernel is the right tool
     }
   }

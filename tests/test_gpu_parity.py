@@ -296,7 +296,7 @@ def norm(rows):
 
 
 @pytest.mark.parametrize("n,card,pbits", [(1, 1, 0), (100, 4, 0), (10_000, 4, 0), (100_000, 1000, 0), (200_000, 150_000, 0),
-                                          (1, 1, 4), (8193, 40, 4), (100_000, 1000, 6), (200_000, 150_000, 10)])
+                                          (1, 1, 4), (8193, 40, 4), (100_000, 1000, 6), (200_000, 150_000, 10), (200_000, 150_000, 12), (5000, 17, 13), (200_000, 150_000, 13)])
 def test_groupby_matches_oracle_as_sorted_sets(gpu, oracle, n, card, pbits):
     """Mirrors tests/it/aggregates/agg_hashtable.rs: several key types incl. NULLs, sum/count/min/max,
     compared as sorted row sets (assert_block_value_sort_eq). pbits > 0 forces the radix-partitioned
@@ -617,7 +617,7 @@ def test_q1_finalize_avg_matches_sf_style_golden_shape(gpu, oracle):
 
 
 @pytest.mark.parametrize("n,card,pbits", [(1, 1, 0), (513, 3, 0), (70_000, 4, 0), (300_000, 700, 0), (300_000, 5000, 0), (400_000, 390_000, 0),
-                                          (513, 3, 4), (300_000, 5000, 5), (300_000, 60_000, 8), (1_500_000, 3000, 0), (1_500_000, 40_000, 0)])
+                                          (513, 3, 4), (300_000, 5000, 5), (300_000, 60_000, 8), (300_000, 60_000, 12), (1_500_000, 3000, 0), (1_500_000, 40_000, 0)])
 def test_groupby_short_layout_lds_preaggregation_matches_oracle(gpu, oracle, n, card, pbits):
     """Short layouts (<= 4 key words, <= 6 aggregates) go through the workgroup-LDS partial aggregation;
     cardinalities below and far above the LDS table capacity (spill to the row path), nullable key,
