@@ -75,3 +75,73 @@ def test_unsupported_and_malformed_are_reported():
     cut = dict(chunks[0])
     cut["chunk"] = cut["chunk"][: len(cut["chunk"]) // 2]
     assert PU.oracle_decode(cut, T.T_I64)[4] == -1              # truncated chunk
+
+
+# ---- the product's HOST-side plan (dbhip_pq_chunk_open touches no device): page / level / dictionary bookkeeping ----
+def _open(ch, out_type, chunk=None, **over):
+    import ctypes as C
+    d = dict(ch)
+    d.update(over)
+    data = d["chunk"] if chunk is None else chunk
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    h, info = C.c_void_p(), T.PqInfo()
+    rc = T.lib().dbhip_pq_chunk_open(buf, C.c_int64(len(data)), d.get("codec", 0), d["physical"], d["type_length"], d["max_def"],
+                                     d.get("max_rep", 0), out_type, C.byref(h), C.byref(info))
+    if rc == 0:
+        T.lib().dbhip_pq_chunk_close(h)
+    return rc, info
+
+
+@pytest.mark.parametrize("vi", [0, 1, 4, 6])
+def test_host_plan_counts_rows_nulls_pages_like_pyarrow(vi):
+    import io
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    for name, arr, out_type, wkw in PC.make_cases(seed=vi):
+        kw = dict(PC.VARIANTS[vi])
+        kw.update(wkw)
+        fb = PU.write_parquet(pa.table({"c": arr}), **kw)
+        chunks, back = PU.column_chunks(fb)
+        rc, info = _open(chunks[0], out_type)
+        assert rc == 0, name
+        assert info.num_values == len(arr) and info.num_nulls == arr.null_count, name
+        assert info.has_validity == chunks[0]["max_def"] and info.out_type == out_type
+        es = 0 if out_type == T.T_BOOL else PU.ESIZE[out_type]
+        assert info.out_bytes == (len(arr) * es if es else (len(arr) + 63) // 64 * 8), name
+        assert info.validity_bytes == (len(arr) + 63) // 64 * 8
+        if len(arr):
+            assert info.n_pages >= 1
+        md = pq.ParquetFile(io.BytesIO(fb)).metadata.row_group(0).column(0)
+        assert (info.n_dict_values > 0) <= md.has_dictionary_page
+
+
+def test_host_plan_survives_mutated_chunks():
+    """bit flips / truncation / overwritten bytes: open() answers OK, INVALID or UNSUPPORTED — it never reads outside the
+    chunk (a crash of this test process is the failure mode being guarded)"""
+    import pyarrow as pa
+    rng = np.random.default_rng(5)
+    seeds = []
+    for vi in (0, 1, 4, 6):
+        for name, arr, ot, wkw in PC.make_cases(seed=vi):
+            kw = dict(PC.VARIANTS[vi])
+            kw.update(wkw)
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr.slice(0, 1500)}), **kw))
+            if len(chunks[0]["chunk"]):
+                seeds.append((chunks[0], ot))
+    seen = set()
+    for it in range(4000):
+        ch, ot = seeds[it % len(seeds)]
+        b = bytearray(ch["chunk"])
+        k = it % 3
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b = b[: int(rng.integers(0, len(b)))]
+        else:
+            i = int(rng.integers(0, len(b)))
+            b[i:i + 6] = bytes(rng.integers(0, 256, 6).astype(np.uint8))
+        rc, _ = _open(ch, ot, chunk=bytes(b))
+        assert rc in (T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED), rc
+        seen.add(rc)
+    assert seen == {T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED}
