@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void cmp_narrow_kernel(CmpParams p) {
 
 template <typename T>
 void launch_cmp_narrow(const CmpParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(cmp_narrow_kernel<T>, dim3(grid_for(ceil_div(p.n, 16), 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(cmp_narrow_kernel<T>, dim3(grid_for(ceil_div(p.n, 16), 256, 1024)), dim3(256), 0, s, p);
 }
 
 __global__ __launch_bounds__(256) void bitmap_binary_kernel(const uint8_t* a, const uint8_t* b,

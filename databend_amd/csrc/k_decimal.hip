@@ -412,7 +412,7 @@ int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* r
     set_error("dbhip_decimal_arith: scale shift %d outside the supported range", p.scale_mul);
     return DBHIP_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(decimal_kernel, dim3(grid_for(ceil_div(n, 4), 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(decimal_kernel, dim3(grid_for(ceil_div(n, 4), 256, 1024)), dim3(256), 0, s, p);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }

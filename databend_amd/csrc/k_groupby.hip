@@ -1557,7 +1557,7 @@ int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n, uint64
   unsigned long long* bad = (unsigned long long*)scratch(8, 2);
   if (!bad) return DBHIP_ERR_HIP;
   DBHIP_CHECK(hipMemsetAsync(bad, 0, 8, s));
-  hipLaunchKernelGGL(group_hash_kernel, dim3(grid_for(ceil_div(n, 4), 256)), dim3(256), 0, s, hc, n, out_hashes, bad);
+  hipLaunchKernelGGL(group_hash_kernel, dim3(grid_for(ceil_div(n, 4), 256, 1024)), dim3(256), 0, s, hc, n, out_hashes, bad);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
