@@ -45,11 +45,14 @@ class ExprIns(C.Structure):
 class PqInfo(C.Structure):
     """dbhip_pq_info"""
     _fields_ = [("num_values", C.c_int64), ("num_nulls", C.c_int64), ("out_type", C.c_int32), ("has_validity", C.c_int32),
-                ("out_bytes", C.c_int64), ("validity_bytes", C.c_int64), ("n_pages", C.c_int64), ("n_dict_values", C.c_int64)]
+                ("out_bytes", C.c_int64), ("validity_bytes", C.c_int64), ("n_pages", C.c_int64), ("n_dict_values", C.c_int64),
+                ("image_bytes", C.c_int64)]
 
 
 # parquet.thrift Type numbers
 PQ_BOOLEAN, PQ_INT32, PQ_INT64, PQ_INT96, PQ_FLOAT, PQ_DOUBLE, PQ_BYTE_ARRAY, PQ_FLBA = range(8)
+# parquet.thrift CompressionCodec numbers the library decodes
+PQ_UNCOMPRESSED, PQ_SNAPPY, PQ_ZSTD, PQ_LZ4_RAW = 0, 1, 6, 7
 
 
 class AggDesc(C.Structure):
@@ -79,7 +82,7 @@ SYMBOLS = [
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
     "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
     "dbhip_vec_topk_merge", "dbhip_vec_index_build", "dbhip_vec_index_search", "dbhip_vec_index_destroy",
-    "dbhip_pq_chunk_open", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
+    "dbhip_pq_chunk_open", "dbhip_pq_chunk_image", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
 ]
 
 

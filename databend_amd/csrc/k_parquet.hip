@@ -29,6 +29,7 @@
 #include "dev_scan.h"
 #include "runtime.h"
 
+#include <dlfcn.h>
 #include <string.h>
 
 #include <algorithm>
@@ -206,6 +207,8 @@ struct dbhip_pq_chunk {
   std::vector<PqItem> lvl_items, val_items;   // as planned, in stream order; split by size at the first decode:
   int64_t n_lvl_small, n_val_small;             // d_lvl / d_val hold the short items first, then the long ones
   std::vector<uint32_t> str_off;           // PLAIN BYTE_ARRAY data pages: offset of every value's bytes (by ordinal)
+  std::vector<uint8_t> image;              // compressed chunks: the decompressed page payloads back to back — what decode() reads
+                                           // (and what String views point into) instead of the chunk itself
   // device side (uploaded on first decode)
   PqItem* d_lvl; PqItem* d_val; uint32_t* d_str_off; uint32_t* d_dict_str_off;
   void* d_dict;                            // dictionary in the output type (values or 16-byte views)
@@ -497,6 +500,100 @@ __global__ __launch_bounds__(256) void pq_spread_bool_kernel(const uint32_t* __r
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------
+// host: page decompression. The reference decompresses pages on the CPU too (the parquet crate calls the zstd / lz4 /
+// snap crates before a page reaches its decoders); here: libzstd / liblz4 of the system through dlopen (no headers in this
+// image), Snappy's raw format decoded in place (format_description.txt of google/snappy). What reaches the device is the
+// DECOMPRESSED page stream.
+// ---------------------------------------------------------------------------------------------
+enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_ZSTD = 6, CODEC_LZ4_RAW = 7 };
+
+bool snappy_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  Rd r{src, src + n, true};
+  const uint64_t total = r.varint();
+  if (!r.ok || total != cap) return false;
+  size_t o = 0;
+  while (r.p < r.end) {
+    const uint8_t tag = *r.p++;
+    size_t len, off;
+    switch (tag & 3) {
+      case 0: {
+        len = (size_t)(tag >> 2) + 1;
+        if (len > 60) {
+          const int extra = (int)len - 60;  // 1..4 length bytes follow
+          if ((size_t)(r.end - r.p) < (size_t)extra) return false;
+          len = 0;
+          for (int b = 0; b < extra; ++b) len |= (size_t)r.p[b] << (8 * b);
+          len += 1;
+          r.p += extra;
+        }
+        if ((size_t)(r.end - r.p) < len || cap - o < len) return false;
+        memcpy(dst + o, r.p, len);
+        r.p += len;
+        o += len;
+        continue;
+      }
+      case 1:
+        if (r.end - r.p < 1) return false;
+        len = (size_t)((tag >> 2) & 7) + 4;
+        off = ((size_t)(tag >> 5) << 8) | *r.p++;
+        break;
+      case 2:
+        if (r.end - r.p < 2) return false;
+        len = (size_t)(tag >> 2) + 1;
+        off = (size_t)r.p[0] | ((size_t)r.p[1] << 8);
+        r.p += 2;
+        break;
+      default:
+        if (r.end - r.p < 4) return false;
+        len = (size_t)(tag >> 2) + 1;
+        off = (size_t)r.p[0] | ((size_t)r.p[1] << 8) | ((size_t)r.p[2] << 16) | ((size_t)r.p[3] << 24);
+        r.p += 4;
+        break;
+    }
+    if (off == 0 || off > o || cap - o < len) return false;
+    for (size_t i = 0; i < len; ++i) dst[o + i] = dst[o + i - off];  // may overlap: byte by byte, forward
+    o += len;
+  }
+  return o == cap;
+}
+
+typedef size_t (*zstd_decompress_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_iserror_fn)(size_t);
+typedef int (*lz4_safe_fn)(const char*, char*, int, int);
+
+// 1 = ok, 0 = corrupt input, -1 = codec (library) not available
+int page_decompress(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  if (codec == CODEC_SNAPPY) return snappy_decompress(src, n, dst, cap) ? 1 : 0;
+  if (codec == CODEC_ZSTD) {
+    static zstd_decompress_fn dec = nullptr;
+    static zstd_iserror_fn iserr = nullptr;
+    static const bool have = [] {
+      void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (!h) return false;
+      dec = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
+      iserr = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+      return dec && iserr;
+    }();
+    if (!have) return -1;
+    const size_t got = dec(dst, cap, src, n);
+    return (!iserr(got) && got == cap) ? 1 : 0;
+  }
+  if (codec == CODEC_LZ4_RAW) {
+    static lz4_safe_fn dec = nullptr;
+    static const bool have = [] {
+      void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (!h) return false;
+      dec = (lz4_safe_fn)dlsym(h, "LZ4_decompress_safe");
+      return dec != nullptr;
+    }();
+    if (!have) return -1;
+    if (n > 0x7FFFFFFF || cap > 0x7FFFFFFF) return 0;
+    return dec((const char*)src, (char*)dst, (int)n, (int)cap) == (int)cap ? 1 : 0;
+  }
+  return -1;
+}
+
 int32_t unsupported(const char* what) {
   set_error("dbhip_pq_chunk_open: %s (keep the CPU reader for this chunk)", what);
   return DBHIP_ERR_UNSUPPORTED;
@@ -568,7 +665,8 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
                             dbhip_pq_info* info_host) {
   DBHIP_REQUIRE(chunk_host && out_host && chunk_len >= 0, "dbhip_pq_chunk_open: NULL argument");
   *out_host = nullptr;
-  if (codec != 0) return unsupported("compressed column chunk");
+  if (codec != CODEC_NONE && codec != CODEC_SNAPPY && codec != CODEC_ZSTD && codec != CODEC_LZ4_RAW)
+    return unsupported("compression codec other than UNCOMPRESSED / SNAPPY / ZSTD / LZ4_RAW");
   if (max_rep_level != 0 || max_def_level < 0 || max_def_level > 1) return unsupported("nested column (repetition / definition level > 1)");
   if (chunk_len >= (1LL << 32)) return unsupported("column chunk of 4 GiB or more");
   if (!type_pair_ok(physical_type, type_length, out_type)) {
@@ -582,21 +680,63 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
   c->dict_n = -1; c->dict_off = 0; c->dict_bytes = 0;
   c->d_lvl = nullptr; c->d_val = nullptr; c->d_str_off = nullptr; c->d_dict_str_off = nullptr; c->d_dict = nullptr; c->d_dense = nullptr;
   c->d_wcnt = nullptr; c->d_woff = nullptr; c->d_blk = nullptr; c->uploaded = false; c->n_lvl_small = 0; c->n_val_small = 0;
-  const uint8_t* base = chunk_host;
-  Rd r{base, base + chunk_len, true};
+  Rd r{chunk_host, chunk_host + chunk_len, true};
   int32_t rc = DBHIP_OK;
+  if (codec != CODEC_NONE) {
+    // size of the decompressed image: one pass over the page headers (the image must not move while offsets into it are planned)
+    Rd q = r;
+    uint64_t total = 0;
+    while (q.p < q.end) {
+      PageHdr h;
+      if (!read_page_header(q, h) || (uint64_t)h.compressed > (uint64_t)(q.end - q.p)) break;  // reported by the main pass
+      total += (uint64_t)h.uncompressed;
+      q.p += h.compressed;
+    }
+    if (total >= (1ULL << 32)) { delete c; return unsupported("column chunk that decompresses to 4 GiB or more"); }
+    try { c->image.reserve((size_t)total); } catch (...) { delete c; set_error("dbhip_pq_chunk_open: out of host memory"); return DBHIP_ERR_HIP; }
+  }
   while (rc == DBHIP_OK && r.p < r.end) {
     PageHdr h;
     if (!read_page_header(r, h)) { rc = malformed("page header"); break; }
-    if (h.compressed != h.uncompressed) { rc = unsupported("compressed page"); break; }
-    const uint64_t pos0 = (uint64_t)(r.p - base);
     if ((uint64_t)h.compressed > (uint64_t)(r.end - r.p)) { rc = malformed("page runs past the chunk"); break; }
-    const uint64_t endp = pos0 + (uint64_t)h.compressed;
+    const uint8_t* craw = r.p;                 // the page's payload as stored
+    const uint8_t* next = craw + h.compressed;
+    const uint8_t* base;                       // what the plan's offsets are relative to: the chunk, or the decompressed image
+    uint64_t pos0, endp;
+    if (codec == CODEC_NONE) {
+      if (h.compressed != h.uncompressed) { rc = unsupported("compressed page in a chunk declared UNCOMPRESSED"); break; }
+      base = chunk_host;
+      pos0 = (uint64_t)(craw - chunk_host);
+      endp = pos0 + (uint64_t)h.compressed;
+    } else {
+      // DATA_PAGE_V2 keeps its levels uncompressed in front of the (optionally) compressed values
+      const uint64_t lev = h.type == PG_DATA_V2 ? (uint64_t)(h.rep_len < 0 ? 0 : h.rep_len) + (uint64_t)(h.def_len < 0 ? 0 : h.def_len) : 0;
+      if (lev > (uint64_t)h.compressed || lev > (uint64_t)h.uncompressed) { rc = malformed("level bytes exceed the page"); break; }
+      const size_t off = c->image.size();
+      if (c->image.capacity() - off < (size_t)h.uncompressed) { rc = malformed("page sizes changed between passes"); break; }
+      c->image.resize(off + (size_t)h.uncompressed);
+      uint8_t* dst = c->image.data() + off;
+      memcpy(dst, craw, (size_t)lev);
+      const bool comp = h.type == PG_DATA_V2 ? h.v2_compressed : true;
+      if (!comp) {
+        if (h.compressed != h.uncompressed) { rc = malformed("uncompressed page with differing sizes"); break; }
+        memcpy(dst + lev, craw + lev, (size_t)h.uncompressed - (size_t)lev);
+      } else if ((uint64_t)h.uncompressed == lev) {
+        // nothing to decompress (an empty dictionary page still carries a few bytes of compressed "nothing")
+      } else {
+        const int ok = page_decompress(codec, craw + lev, (size_t)h.compressed - (size_t)lev, dst + lev, (size_t)h.uncompressed - (size_t)lev);
+        if (ok < 0) { rc = unsupported("compression library not available on this host"); break; }
+        if (ok == 0) { rc = malformed("page does not decompress to its declared size"); break; }
+      }
+      base = c->image.data();
+      pos0 = (uint64_t)off;
+      endp = pos0 + (uint64_t)h.uncompressed;
+    }
     if (h.type == PG_DICT) {
       if (c->dict_n >= 0 || c->n_pages > 0) { rc = malformed("dictionary page not first / repeated"); break; }
       if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICT) { rc = unsupported("dictionary page encoding"); break; }
       if (h.num_values < 0 || c->physical == PT_BOOLEAN) { rc = malformed("dictionary page"); break; }
-      c->dict_n = h.num_values; c->dict_off = (int64_t)pos0; c->dict_bytes = h.compressed;
+      c->dict_n = h.num_values; c->dict_off = (int64_t)pos0; c->dict_bytes = (int64_t)(endp - pos0);
       if (c->physical == PT_BYTE_ARRAY) {
         uint64_t off = pos0;
         c->dict_str_off.resize((size_t)c->dict_n);
@@ -650,7 +790,7 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
       c->nonnull += (int64_t)nn;
       c->n_pages += 1;
     }  // index pages and unknown page types are skipped
-    r.p = base + endp;
+    r.p = next;
   }
   if (rc == DBHIP_OK && c->rows >= 0xFFFFFFF0LL) rc = unsupported("more than 2^32 rows in one chunk");
   if (rc) { delete c; return rc; }
@@ -664,6 +804,7 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
     info_host->validity_bytes = ceil_div(c->rows, 64) * 8;
     info_host->n_pages = c->n_pages;
     info_host->n_dict_values = c->dict_n < 0 ? 0 : c->dict_n;
+    info_host->image_bytes = (int64_t)c->image.size();
   }
   *out_host = c;
   return DBHIP_OK;
@@ -764,6 +905,13 @@ int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void*
   }
   kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_pq_chunk_image(dbhip_pq_chunk* c, const uint8_t** out_ptr_host, int64_t* out_len_host) {
+  DBHIP_REQUIRE(c && out_ptr_host && out_len_host, "dbhip_pq_chunk_image: NULL argument");
+  *out_ptr_host = c->image.empty() ? nullptr : c->image.data();
+  *out_len_host = (int64_t)c->image.size();
   return DBHIP_OK;
 }
 

@@ -836,10 +836,18 @@ class ParquetChunk:
                                         C.c_int32(max_rep_level), C.c_int32(out_type), C.byref(self.h), C.byref(self.info)))
         self.chunk_dev = None
 
+    def image(self):
+        """what decode() reads: the chunk itself, or (compressed chunks) the decompressed page stream open() produced"""
+        if self.info.image_bytes == 0:
+            return self.host
+        p, n = C.POINTER(C.c_uint8)(), C.c_int64()
+        check(lib().dbhip_pq_chunk_image(self.h, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
     def upload(self):
-        """the chunk's bytes into HBM (+ 8 bytes of slack; they become buffer 0 of a string column)"""
+        """the image's bytes into HBM (+ 8 bytes of slack; they become buffer 0 of a string column)"""
         if self.chunk_dev is None:
-            self.chunk_dev = DeviceBuffer.from_numpy(np.concatenate([self.host, np.zeros(8, np.uint8)]))
+            self.chunk_dev = DeviceBuffer.from_numpy(np.concatenate([self.image(), np.zeros(8, np.uint8)]))
         return self.chunk_dev
 
     def decode(self, stream=None):

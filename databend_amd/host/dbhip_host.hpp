@@ -1095,8 +1095,14 @@ inline std::optional<Column> column_chunk_to_column(const uint8_t* bytes, size_t
   c.type = field_type;
   c.type.nullable = info.has_validity != 0;
   c.len = info.num_values;
-  Buf chunk = make_buf(len + 8);               // resident copy (+ slack); buffer 0 of a String column
-  chunk->upload(bytes, len);
+  // resident copy (+ slack) of what the device decodes — the chunk, or the decompressed page stream of a compressed chunk;
+  // buffer 0 of a String column
+  const uint8_t* img = nullptr;
+  int64_t img_len = 0;
+  check(dbhip_pq_chunk_image(h, &img, &img_len));
+  if (!img) { img = bytes; img_len = (int64_t)len; }
+  Buf chunk = make_buf((size_t)img_len + 8);
+  chunk->upload(img, (size_t)img_len);
   c.data = make_buf((size_t)info.out_bytes);
   if (info.has_validity) c.validity = make_buf((size_t)info.validity_bytes);
   check(dbhip_pq_chunk_decode(h, (const uint8_t*)chunk->ptr(), c.data->ptr(), c.validity ? (uint8_t*)c.validity->ptr() : nullptr, nullptr));

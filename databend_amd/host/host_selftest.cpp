@@ -295,7 +295,7 @@ static void test_parquet_chunk() {
     CHECK(v[0] == 7 && v[1] == 0 && v[2] == -3 && v[3] == ((int64_t)1 << 40));
     CHECK(ok[0] && !ok[1] && ok[2] && ok[3]);
   }
-  leaf.codec = 1;  // SNAPPY: declined, the caller keeps the CPU reader
+  leaf.codec = 2;  // GZIP: declined, the caller keeps the CPU reader
   CHECK(!column_chunk_to_column(ch.data(), ch.size(), leaf, DataType::of(DBHIP_T_I64)).has_value());
 }
 

@@ -458,9 +458,13 @@ int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base,
  * block_reader_parquet_deserialize.rs): `DataItem::RawData(bytes)` of one column chunk in, one Column
  * out. Covers what the reference's writer emits (storages/common/blocks/src/parquet_rs.rs:91-160: one
  * row group; DATA_PAGE v1 + PLAIN, or DATA_PAGE_V2 + RLE_DICTIONARY with PLAIN fallback pages; RLE
- * definition levels) for flat columns (max_rep_level 0, max_def_level <= 1) of UNCOMPRESSED chunks
- * (TableCompression::None, table_compression.rs:38). Everything else: DBHIP_ERR_UNSUPPORTED — the
- * binding keeps arrow-rs for that chunk.
+ * definition levels) for flat columns (max_rep_level 0, max_def_level <= 1), TableCompression
+ * None / Zstd (the default) / LZ4 / Snappy (table_compression.rs:38-58). Everything else (nested
+ * columns, DELTA_* encodings, other codecs): DBHIP_ERR_UNSUPPORTED — the binding keeps arrow-rs for that
+ * chunk. Pages of compressed chunks are decompressed on the HOST inside open() (libzstd / liblz4 of the
+ * system, Snappy decoded in place — the reference decompresses on the CPU as well); what the device
+ * decodes is the decompressed page stream, the IMAGE (dbhip_pq_chunk_image): for such chunks the caller
+ * uploads the image instead of the chunk, and String views point into it.
  *   open   (host)   parses the page headers and the run headers of the hybrid streams from the HOST
  *                   copy of the chunk and plans the decode; nothing touches the device.
  *   decode (device) expands the plan from the DEVICE copy of the same bytes (the caller uploads or
@@ -470,7 +474,7 @@ int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base,
  *                   DBHIP_T_STRING: 16-byte views whose long form points INTO chunk_dev — the chunk is
  *                   buffer 0 of the resulting column and must stay resident while the column lives.
  * physical_type / codec are parquet.thrift's Type / CompressionCodec numbers (BOOLEAN 0, INT32 1,
- * INT64 2, FLOAT 4, DOUBLE 5, BYTE_ARRAY 6, FIXED_LEN_BYTE_ARRAY 7; UNCOMPRESSED 0). out_type: INT32 ->
+ * INT64 2, FLOAT 4, DOUBLE 5, BYTE_ARRAY 6, FIXED_LEN_BYTE_ARRAY 7; UNCOMPRESSED 0, SNAPPY 1, ZSTD 6, LZ4_RAW 7). out_type: INT32 ->
  * I8/I16/I32/U8/U16/U32/DATE/I64/DEC64; INT64 -> I64/U64/TIMESTAMP/DEC64/DEC128; FLOAT/DOUBLE -> F32/F64;
  * BYTE_ARRAY -> STRING; FIXED_LEN_BYTE_ARRAY(n <= 16, big-endian decimal) -> DEC128 (n <= 8: DEC64). */
 typedef struct dbhip_pq_chunk dbhip_pq_chunk;
@@ -483,11 +487,16 @@ typedef struct dbhip_pq_info {
   int64_t validity_bytes;
   int64_t n_pages;        /* data pages */
   int64_t n_dict_values;
+  int64_t image_bytes;    /* compressed chunks: bytes of the decompressed image decode() reads (0: the chunk itself) */
 } dbhip_pq_info;
 int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec,
                             int32_t physical_type, int32_t type_length, int32_t max_def_level,
                             int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
                             dbhip_pq_info* info_host);
+/* Host pointer / size of the decompressed image (NULL / 0 for UNCOMPRESSED chunks: upload the chunk). Owned by
+ * the handle, valid until close. */
+int32_t dbhip_pq_chunk_image(dbhip_pq_chunk* c, const uint8_t** out_ptr_host, int64_t* out_len_host);
+/* chunk_dev: device copy of the chunk (UNCOMPRESSED) or of the image (compressed chunks). */
 int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void* out_values_dev,
                               uint8_t* out_validity_dev, void* stream);
 int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c);

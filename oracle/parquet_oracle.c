@@ -329,3 +329,21 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
   *out_nulls = nulls;
   return rc;
 }
+
+/* Concatenated page payloads (levels + values of every page, dictionary page first) of an UNCOMPRESSED column chunk — the
+ * byte stream a compressed twin of the same chunk must decompress to (the product's "image"). Returns the number of bytes
+ * written, -1 on a malformed chunk, -2 if a page is compressed. */
+int64_t orc_pq_payloads(const uint8_t* chunk, int64_t len, uint8_t* out, int64_t cap) {
+  rd_t r = {chunk, chunk + len, 0};
+  int64_t o = 0;
+  while (r.p < r.end) {
+    page_t pg;
+    if (read_page(&r, &pg)) return -1;
+    if (pg.csize != pg.usize) return -2;
+    if ((int64_t)(r.end - r.p) < pg.csize || cap - o < pg.csize) return -1;
+    memcpy(out + o, r.p, (size_t)pg.csize);
+    o += pg.csize;
+    r.p += pg.csize;
+  }
+  return o;
+}

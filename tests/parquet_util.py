@@ -24,7 +24,7 @@ def write_parquet(table, dictionary=True, v2=None, page_size=None, **kw):
     import pyarrow.parquet as pq
     v2 = dictionary if v2 is None else v2
     buf = io.BytesIO()
-    args = dict(compression="none", use_dictionary=dictionary, write_statistics=False, data_page_version="2.0" if v2 else "1.0",
+    args = dict(compression=kw.pop("compression", "none"), use_dictionary=dictionary, write_statistics=False, data_page_version="2.0" if v2 else "1.0",
                 row_group_size=max(table.num_rows, 1), store_schema=False)
     if page_size:
         args["data_page_size"] = page_size
@@ -46,7 +46,7 @@ def column_chunks(file_bytes):
         start = min(offs) if offs else 4   # (an empty chunk has no data page: data_page_offset is 0 then; 4 = behind the magic)
         out.append(dict(name=c.path_in_schema, chunk=file_bytes[start:start + c.total_compressed_size], physical=PHYS[c.physical_type],
                         type_length=sc.length if sc.length and sc.length > 0 else 0, max_def=sc.max_definition_level,
-                        max_rep=sc.max_repetition_level, codec=0 if c.compression == "UNCOMPRESSED" else 1,
+                        max_rep=sc.max_repetition_level, codec={"UNCOMPRESSED": 0, "SNAPPY": 1, "GZIP": 2, "ZSTD": 6, "LZ4": 7, "LZ4_RAW": 7}.get(c.compression, 99),
                         encodings=c.encodings, num_values=c.num_values))
     return out, pf.read()
 

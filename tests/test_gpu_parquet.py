@@ -28,7 +28,7 @@ def gpu_decode(gpu, ch, out_type):
     n = i.num_values
     valid = unpack(col.validity.to_numpy(np.uint8, i.validity_bytes).tobytes(), n) if i.has_validity else np.ones(n, dtype=bool)
     raw = col.data.to_numpy(np.uint8, i.out_bytes).tobytes()
-    py = PU.decoded_to_python(raw, valid, out_type, n, np.frombuffer(ch["chunk"], dtype=np.uint8))
+    py = PU.decoded_to_python(raw, valid, out_type, n, pc.image())   # (long String views point into the chunk / the image)
     if i.has_validity and n % 64:
         tail = unpack(col.validity.to_numpy(np.uint8, i.validity_bytes).tobytes(), i.validity_bytes * 8)[n:]
         assert not tail.any()            # padding bits of the bitmap are clear
@@ -55,6 +55,24 @@ def test_chunk_decode_matches_pyarrow_and_oracle(gpu, vi):
         assert got == exp, name
         o_got, o_valid, _, _, rc = PU.oracle_decode(ch, out_type)
         assert rc == 0 and o_got == got, name
+
+
+@pytest.mark.parametrize("cname", ["zstd", "lz4", "snappy"])
+@pytest.mark.parametrize("vi", [0, 1, 4])
+def test_compressed_chunks_decode_like_pyarrow(gpu, cname, vi):
+    """TableCompression Zstd (the reference's default) / LZ4 / Snappy: pages are decompressed on the host inside open(), the
+    device decodes the decompressed image; values, validity and String views (which point into the image) equal pyarrow's."""
+    import pyarrow as pa
+    for name, arr, out_type, wkw in PC.make_cases(seed=vi):
+        kw = dict(PC.VARIANTS[vi])
+        kw.update(wkw)
+        chunks, back = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), compression=cname, **kw))
+        ch = chunks[0]
+        exp, exp_valid = PU.expected_of(back.column(0), out_type)
+        got, valid, info = gpu_decode(gpu, ch, out_type)
+        assert info.num_values == len(exp) and info.num_nulls == int((~exp_valid).sum()), name
+        assert info.image_bytes > 0 or len(exp) == 0, name
+        assert np.array_equal(valid, exp_valid) and got == exp, name
 
 
 def test_golden_fixtures_through_the_c_abi(gpu):
@@ -84,10 +102,11 @@ def test_open_reports_what_it_does_not_decode(gpu):
         return e.value.code
 
     buf = io.BytesIO()
-    pq.write_table(t, buf, compression="snappy", use_dictionary=False)
+    pq.write_table(t, buf, compression="gzip", use_dictionary=False)
     chunks, _ = PU.column_chunks(buf.getvalue())
-    assert code(chunks[0]) == T.ERR_UNSUPPORTED                       # compressed chunk (codec in the column metadata)
-    assert code(chunks[0], codec=0) == T.ERR_UNSUPPORTED              # ... or noticed from the page sizes
+    assert chunks[0]["codec"] == 2
+    assert code(chunks[0]) == T.ERR_UNSUPPORTED                       # a codec the library does not decompress (GZIP)
+    assert code(chunks[0], codec=0) == T.ERR_UNSUPPORTED              # compressed pages in a chunk declared UNCOMPRESSED
     buf = io.BytesIO()
     pq.write_table(t, buf, compression="none", use_dictionary=False, column_encoding={"c": "DELTA_BINARY_PACKED", "l.list.element": "PLAIN"})
     chunks, _ = PU.column_chunks(buf.getvalue())

@@ -145,3 +145,81 @@ def test_host_plan_survives_mutated_chunks():
         assert rc in (T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED), rc
         seen.add(rc)
     assert seen == {T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED}
+
+
+# ---- compressed chunks: pages are decompressed on the host inside open(); the device decodes the decompressed IMAGE ----
+CODECS = [("snappy", T.PQ_SNAPPY), ("zstd", T.PQ_ZSTD), ("lz4", T.PQ_LZ4_RAW)]
+
+
+def _image(ch, out_type, codec):
+    import ctypes as C
+    data = ch["chunk"]
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    h, info = C.c_void_p(), T.PqInfo()
+    rc = T.lib().dbhip_pq_chunk_open(buf, C.c_int64(len(data)), codec, ch["physical"], ch["type_length"], ch["max_def"], 0, out_type,
+                                     C.byref(h), C.byref(info))
+    if rc:
+        return rc, None, info
+    p, n = C.POINTER(C.c_uint8)(), C.c_int64()
+    T.check(T.lib().dbhip_pq_chunk_image(h, C.byref(p), C.byref(n)))
+    img = bytes(np.ctypeslib.as_array(p, shape=(n.value,))) if n.value else b""
+    T.lib().dbhip_pq_chunk_close(h)
+    return 0, img, info
+
+
+def _payloads(chunk):
+    import ctypes as C
+    from tests import oracle_lib
+    L = oracle_lib.load()
+    L.orc_pq_payloads.restype = C.c_int64
+    src = np.frombuffer(chunk, dtype=np.uint8)
+    out = np.zeros(len(chunk) + 16, dtype=np.uint8)
+    n = L.orc_pq_payloads(src.ctypes.data_as(C.c_void_p), C.c_int64(len(chunk)), out.ctypes.data_as(C.c_void_p), C.c_int64(len(out)))
+    assert n >= 0
+    return out[:n].tobytes()
+
+
+@pytest.mark.parametrize("cname,codec", CODECS)
+@pytest.mark.parametrize("vi", [0, 1, 4, 6])
+def test_compressed_chunks_decompress_to_the_uncompressed_twins_payloads(cname, codec, vi):
+    """The same table written with and without compression has the same pages; the image open() builds from the compressed
+    chunk (own Snappy decoder, libzstd / liblz4) must be byte-identical to the page payloads of the uncompressed twin, and the
+    plan's row / null counts must agree."""
+    import pyarrow as pa
+    for name, arr, out_type, wkw in PC.make_cases(seed=vi):
+        kw = dict(PC.VARIANTS[vi])
+        kw.update(wkw)
+        t = pa.table({"c": arr})
+        plain, _ = PU.column_chunks(PU.write_parquet(t, **kw))
+        comp, _ = PU.column_chunks(PU.write_parquet(t, compression=cname, **kw))
+        assert comp[0]["codec"] != 0 or len(arr) == 0
+        rc, img, info = _image(comp[0], out_type, codec)
+        assert rc == 0, (name, rc, T.lib().dbhip_last_error())
+        assert img == _payloads(plain[0]["chunk"]), name
+        assert info.image_bytes == len(img) and info.num_values == len(arr) and info.num_nulls == arr.null_count
+
+
+def test_corrupt_compressed_pages_are_rejected_not_trusted():
+    import pyarrow as pa
+    rng = np.random.default_rng(3)
+    arr = pa.array(["row %d %s" % (i, "abc" * (i % 7)) for i in range(4000)], pa.string())
+    outcomes = set()
+    for cname, codec in CODECS:
+        comp, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), compression=cname, dictionary=False, page_size=2048))
+        good = comp[0]["chunk"]
+        assert _image(comp[0], T.T_STRING, codec)[0] == 0
+        for it in range(600):
+            b = bytearray(good)
+            for _ in range(int(rng.integers(1, 5))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            if it % 5 == 0:
+                b = b[: int(rng.integers(1, len(b)))]
+            ch = dict(comp[0])
+            ch["chunk"] = bytes(b)
+            rc, _, _ = _image(ch, T.T_STRING, codec)
+            assert rc in (T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED)
+            outcomes.add(rc)
+    assert T.ERR_INVALID in outcomes
+    # a codec the library does not know
+    ch = dict(comp[0])
+    assert _image(ch, T.T_STRING, 2)[0] == T.ERR_UNSUPPORTED     # GZIP
