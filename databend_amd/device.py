@@ -826,7 +826,7 @@ class ParquetChunk:
     def __init__(self, chunk, physical_type, out_type, type_length=0, max_def_level=0, max_rep_level=0, codec=0,
                  precision=0, scale=0):
         _ensure()
-        self.host = np.frombuffer(bytes(chunk), dtype=np.uint8)
+        self.host = np.frombuffer(chunk, dtype=np.uint8)   # zero-copy view; the bytes object stays referenced by the array
         self.out_type, self.precision, self.scale = out_type, precision, scale
         self.h = C.c_void_p()
         self.info = L.PqInfo()

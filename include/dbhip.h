@@ -493,6 +493,9 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
                             int32_t physical_type, int32_t type_length, int32_t max_def_level,
                             int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
                             dbhip_pq_info* info_host);
+/* Nullable columns: the validity bitmap open() decoded from the definition levels (host memory, LSB first, 1 = valid,
+ * ceil(rows / 64) * 8 bytes; NULL / 0 for required columns). decode() writes the same bits to out_validity_dev. */
+int32_t dbhip_pq_chunk_validity(dbhip_pq_chunk* c, const uint8_t** out_ptr_host, int64_t* out_bytes_host);
 /* Host pointer / size of the decompressed image (NULL / 0 for UNCOMPRESSED chunks: upload the chunk). Owned by
  * the handle, valid until close. */
 int32_t dbhip_pq_chunk_image(dbhip_pq_chunk* c, const uint8_t** out_ptr_host, int64_t* out_len_host);

@@ -223,3 +223,34 @@ def test_corrupt_compressed_pages_are_rejected_not_trusted():
     # a codec the library does not know
     ch = dict(comp[0])
     assert _image(ch, T.T_STRING, 2)[0] == T.ERR_UNSUPPORTED     # GZIP
+
+
+@pytest.mark.parametrize("cname,codec", [("none", T.PQ_UNCOMPRESSED), ("zstd", T.PQ_ZSTD)])
+@pytest.mark.parametrize("vi", range(len(PC.VARIANTS)))
+def test_host_decodes_definition_levels_into_the_validity_bitmap(cname, codec, vi):
+    """open() turns the definition levels (RLE / bit-packed hybrid, runs cut at page boundaries) into the column's validity bitmap
+    on the host; it must be pyarrow's validity, with the padding bits clear."""
+    import ctypes as C
+    import pyarrow as pa
+    for name, arr, out_type, wkw in PC.make_cases(seed=vi):
+        kw = dict(PC.VARIANTS[vi])
+        kw.update(wkw)
+        chunks, back = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), compression=cname, **kw))
+        ch = chunks[0]
+        data = ch["chunk"]
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+        h, info = C.c_void_p(), T.PqInfo()
+        T.check(T.lib().dbhip_pq_chunk_open(buf, C.c_int64(len(data)), codec, ch["physical"], ch["type_length"], ch["max_def"], 0, out_type,
+                                            C.byref(h), C.byref(info)))
+        p, n = C.POINTER(C.c_uint8)(), C.c_int64()
+        T.check(T.lib().dbhip_pq_chunk_validity(h, C.byref(p), C.byref(n)))
+        exp = np.array([v is not None for v in back.column(0).to_pylist()], dtype=bool)
+        if ch["max_def"] == 0 or len(exp) == 0:
+            assert n.value == 0
+        else:
+            bits = np.unpackbits(np.ctypeslib.as_array(p, shape=(n.value,)).copy(), bitorder="little").astype(bool)
+            assert n.value == (len(exp) + 63) // 64 * 8
+            assert np.array_equal(bits[: len(exp)], exp), name
+            assert not bits[len(exp):].any(), name
+            assert info.num_nulls == int((~exp).sum())
+        T.lib().dbhip_pq_chunk_close(h)
