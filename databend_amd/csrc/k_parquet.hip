@@ -726,6 +726,9 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
       q.p += h.compressed;
     }
     if (total >= (1ULL << 32)) { delete c; return unsupported("column chunk that decompresses to 4 GiB or more"); }
+    // the sizes come from untrusted headers: refuse absurd expansion before reserving host memory for it
+    // (up to 1 GiB is taken at face value — constant PLAIN columns do compress 10^4-fold —, more only at <= 1024x the chunk)
+    if (total > (1ULL << 30) && total > 1024ULL * (uint64_t)chunk_len) { delete c; return malformed("declared uncompressed size out of proportion to the chunk"); }
     try { c->image.reserve((size_t)total); } catch (...) { delete c; set_error("dbhip_pq_chunk_open: out of host memory"); return DBHIP_ERR_HIP; }
   }
   while (rc == DBHIP_OK && r.p < r.end) {
@@ -787,6 +790,8 @@ int32_t dbhip_pq_chunk_open(const uint8_t* chunk_host, int64_t chunk_len, int32_
     } else if (h.type == PG_DATA || h.type == PG_DATA_V2) {
       if (h.num_values < 0) { rc = malformed("data page without num_values"); break; }
       const uint64_t nv = (uint64_t)h.num_values;
+      // (checked per page, before anything is sized by it: an all-NULL page claims 2^31 rows with a 6-byte RLE run)
+      if ((uint64_t)c->rows + nv >= 0xFFFFFFF0ULL) { rc = unsupported("more than 2^32 rows in one chunk"); break; }
       uint64_t pos = pos0, nn = nv;
       if (h.type == PG_DATA) {
         if (c->max_def == 1) {

@@ -254,3 +254,45 @@ def test_host_decodes_definition_levels_into_the_validity_bitmap(cname, codec, v
             assert not bits[len(exp):].any(), name
             assert info.num_nulls == int((~exp).sum())
         T.lib().dbhip_pq_chunk_close(h)
+
+
+def test_headers_that_claim_absurd_sizes_are_refused_before_memory_is_reserved():
+    """page headers are untrusted: an all-NULL page can claim 2^31 rows with a 6-byte RLE run, a compressed page any
+    uncompressed size — open() must answer from the headers alone, quickly and without allocating for the claim"""
+    import time
+
+    def zz(v):          # zigzag varint
+        v = (v << 1) ^ (v >> 63)
+        out = bytearray()
+        while True:
+            b = v & 0x7F
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7F
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    nv = (1 << 31) - 1
+    levels = varint(nv << 1) + b"\x00"                      # one RLE run: nv x level 0 (all NULL)
+    payload = len(levels).to_bytes(4, "little") + levels
+    page = (b"\x15" + zz(0) + b"\x15" + zz(len(payload)) + b"\x15" + zz(len(payload)) + b"\x2c" + b"\x15" + zz(nv) + b"\x15" + zz(0) +
+            b"\x15" + zz(3) + b"\x15" + zz(3) + b"\x00" + b"\x00" + payload)
+    ch = dict(chunk=page * 3, physical=2, type_length=0, max_def=1)
+    t0 = time.perf_counter()
+    rc, info = _open(ch, T.T_I64)
+    assert rc == T.ERR_UNSUPPORTED and time.perf_counter() - t0 < 5.0       # 3 x 2^31 rows: refused at the second page
+    one = dict(ch, chunk=page)
+    rc, info = _open(one, T.T_I64)
+    assert rc == 0 and info.num_values == nv and info.num_nulls == nv            # a single such page is legitimate
+    # a "compressed" page that claims 3 GiB of output for 20 bytes of input
+    big = b"\x15" + zz(0) + b"\x15" + zz(3 << 30) + b"\x15" + zz(20) + b"\x2c" + b"\x15" + zz(10) + b"\x15" + zz(0) + b"\x15" + zz(3) + b"\x15" + zz(3) + b"\x00\x00" + b"\x00" * 20
+    rc, _ = _open(dict(chunk=big, physical=2, type_length=0, max_def=0, codec=T.PQ_ZSTD), T.T_I64)
+    assert rc == T.ERR_INVALID
