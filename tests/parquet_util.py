@@ -4,7 +4,6 @@ the file exactly as the reference's block reader fetches them (DataItem::RawData
 what pyarrow itself reads back as the expected values."""
 import ctypes as C
 import io
-import os
 
 import numpy as np
 

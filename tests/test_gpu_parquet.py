@@ -2,7 +2,6 @@
 pyarrow reads from the same file (bit-exact, NULL slots zero) and against the CPU oracle, for the writer shapes of
 storages/common/blocks/src/parquet_rs.rs:91-160 and the edge cases (empty / one row / all NULL / page-boundary runs /
 dictionary overflow / 12- vs 13-byte strings / NaN bit patterns)."""
-import ctypes as C
 import json
 import os
 
