@@ -164,21 +164,22 @@ def main():
                 if tcount > avail:
                     continue
                 c0 = time.perf_counter()
-                oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=tcount, n=probe_n)
+                oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=tcount, n=probe_n, typed=True)
                 rate = probe_n / (time.perf_counter() - c0)
                 if rate > best[0]:
                     best = (rate, tcount)
             cores = best[1]
             reps, cdt, cres = 0, 0.0, None
-            while cdt < 10.0 and reps < 64:  # ~10-20 s of wall time on all cores, whole passes only
+            while cdt < 10.0 and reps < 512:  # ~10 s of wall time on all cores, whole passes only
                 c0 = time.perf_counter()
-                cres = oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=cores, n=cn)
+                cres = oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=cores, n=cn, typed=True)
                 cdt += time.perf_counter() - c0
                 reps += 1
             cpu = {"value": cn * reps / cdt, "unit": "rows/s", "cores": cores, "kind": "port",
                    "sample": f"{reps} passes over the first {cn} rows of the same lineitem shard, {cores} threads x 65536-row "
-                             f"blocks (filter->take->decimal maps->partial AggregateHashTable->final merge), "
-                             f"C restatement of the reference (oracle/oracle.c, gcc -O2 -march=native)"}
+                             f"blocks (filter->take->decimal maps->partial AggregateHashTable->final merge), the reference's pipeline "
+                             f"with the column types fixed at compile time (oracle/q1_typed.c, gcc -O2 -march=native; "
+                             f"results identical to the generic restatement oracle/oracle.c, which is ~14x slower per row)"}
             if cn == n:
                 assert cres == result, "GPU result differs from the CPU restatement"
         out = {

@@ -99,12 +99,13 @@ def i128_list(raw):
     return out
 
 
-def q1_run(host, cutoff, threads=1, block_rows=65536, n=None):
-    """Runs the reference-shaped CPU Q1 (filter -> take -> maps -> partial/final hash-agg)."""
+def q1_run(host, cutoff, threads=1, block_rows=65536, n=None, typed=False):
+    """Runs the reference-shaped CPU Q1 (filter -> take -> maps -> partial/final hash-agg): through the generic restatements
+    (the checker), or typed=True through the type-specialised twin of the same pipeline (oracle/q1_typed.c: bench.py's baseline)."""
     L = load()
     n = len(host["l_quantity"]) if n is None else n
     res = Q1Result()
-    g = L.orc_q1_run(host["l_quantity"].ctypes.data_as(C.c_void_p), host["l_extendedprice"].ctypes.data_as(C.c_void_p),
+    g = (L.orc_q1_run_typed if typed else L.orc_q1_run)(host["l_quantity"].ctypes.data_as(C.c_void_p), host["l_extendedprice"].ctypes.data_as(C.c_void_p),
                      host["l_discount"].ctypes.data_as(C.c_void_p), host["l_tax"].ctypes.data_as(C.c_void_p),
                      host["l_returnflag"].ctypes.data_as(C.c_void_p), host["l_linestatus"].ctypes.data_as(C.c_void_p),
                      host["l_shipdate"].ctypes.data_as(C.c_void_p), C.c_int32(cutoff), C.c_int64(n), C.c_int(threads),

@@ -389,3 +389,21 @@ def test_filter_select_and_take_like_kernel_rs():
         out = np.zeros(k + 1, np.int64)
         L.orc_take(src.ctypes.data_as(C.c_void_p), 8, sel.ctypes.data_as(C.c_void_p), C.c_int64(k), out.ctypes.data_as(C.c_void_p))
         assert out[:k].tolist() == src[sel[:k]].tolist()
+
+
+def test_typed_q1_baseline_equals_the_generic_restatement():
+    """bench.py's cpu_baseline is the reference-shaped Q1 pipeline with the column types fixed at compile time
+    (oracle/q1_typed.c); it must give exactly what the generic restatement gives — on ragged sizes, one and several
+    threads, small blocks, extreme in-range values."""
+    from databend_amd import tpch
+    for n, threads, block in ((1, 1, 65536), (127, 1, 64), (65_537, 3, 4096), (300_007, 4, 65536)):
+        host = tpch.gen_lineitem(n, seed=n)
+        a = O.q1_run(host, tpch.Q1_CUTOFF, threads=threads, block_rows=block)
+        b = O.q1_run(host, tpch.Q1_CUTOFF, threads=threads, block_rows=block, typed=True)
+        assert a == b and sum(r["count"] for r in b.values()) == int((host["l_shipdate"] <= tpch.Q1_CUTOFF).sum())
+    # extreme in-range values (Decimal(15,2) maxima, discount 0, tax 8 %): the 128-bit products and sums agree too
+    host = tpch.gen_lineitem(50_000, seed=1)
+    host["l_extendedprice"][:] = 99_999_999_999_999
+    host["l_discount"][:] = 0
+    host["l_tax"][:] = 8
+    assert O.q1_run(host, tpch.Q1_CUTOFF, threads=2) == O.q1_run(host, tpch.Q1_CUTOFF, threads=2, typed=True)
