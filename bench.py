@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override rows per rank")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = the whole shard)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of the timed CPU-baseline passes")
     ap.add_argument("--no-ann", action="store_true", help="skip the secondary ANN measurement (BASELINE configs[4])")
     ap.add_argument("--ann-rows", type=int, default=10_000_000, help="base vectors of the WHOLE job (sharded by row range over the ranks)")
     ap.add_argument("--ann-dim", type=int, default=768)
@@ -170,7 +171,7 @@ def main():
                     best = (rate, tcount)
             cores = best[1]
             reps, cdt, cres = 0, 0.0, None
-            while cdt < 10.0 and reps < 512:  # ~10 s of wall time on all cores, whole passes only
+            while cdt < args.cpu_seconds and reps < 512:  # ~10 s of wall time on all cores, whole passes only
                 c0 = time.perf_counter()
                 cres = oracle_lib.q1_run(host, tpch.Q1_CUTOFF, threads=cores, n=cn, typed=True)
                 cdt += time.perf_counter() - c0
