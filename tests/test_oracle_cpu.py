@@ -407,3 +407,121 @@ def test_typed_q1_baseline_equals_the_generic_restatement():
     host["l_discount"][:] = 0
     host["l_tax"][:] = 8
     assert O.q1_run(host, tpch.Q1_CUTOFF, threads=2) == O.q1_run(host, tpch.Q1_CUTOFF, threads=2, typed=True)
+
+
+def test_decimal_arithmetic_against_exact_rational_arithmetic():
+    """An independent pin of the decimal restatement next to the reference's golden file: for random (precision, scale) pairs
+    the result size comes from orc_decimal_result_size, the operands are drawn so that nothing overflows, and every result
+    must be the exact rational value rounded half AWAY from zero at the result scale (plus / minus are exact) —
+    decimal/arithmetic.rs:190-316, types/decimal.rs:759-797,1024-1064."""
+    from fractions import Fraction
+    L = O.load()
+    rng = np.random.default_rng(11)
+
+    def rha(fr):  # round half away from zero to an integer
+        sign = -1 if fr < 0 else 1
+        a = abs(fr)
+        q, r = divmod(a.numerator, a.denominator)
+        if 2 * r >= a.denominator:
+            q += 1
+        return sign * q
+
+    def col(vals, p, s):
+        if p <= 18:
+            return O.HostCol(T.T_DEC64, np.array(vals, dtype=np.int64), None, p, s)
+        return O.HostCol(T.T_DEC128, O.i128_array(vals), None, p, s)
+
+    checked = 0
+    for _ in range(300):
+        p1, p2 = int(rng.integers(1, 39)), int(rng.integers(1, 39))
+        s1, s2 = int(rng.integers(0, min(p1, 12) + 1)), int(rng.integers(0, min(p2, 12) + 1))
+        for name, op in (("plus", T.OP_PLUS), ("minus", T.OP_MINUS), ("multiply", T.OP_MULTIPLY), ("divide", T.OP_DIVIDE)):
+            p, s = C.c_int(), C.c_int()
+            if L.orc_decimal_result_size(op, p1, s1, p2, s2, C.byref(p), C.byref(s)) != 0 or p.value > 38:
+                continue
+            n = 64
+            # operands small enough that the result (and the intermediate of divide) stays inside the result precision
+            d1 = min(p1, 17 if op != T.OP_PLUS and op != T.OP_MINUS else p1 - 1 if p1 > 1 else 1)
+            d2 = min(p2, 17 if op != T.OP_PLUS and op != T.OP_MINUS else p2 - 1 if p2 > 1 else 1)
+            xs = [int(v) for v in rng.integers(-10**min(d1, 18) + 1, 10**min(d1, 18), n)]
+            ys = [int(v) for v in rng.integers(-10**min(d2, 18) + 1, 10**min(d2, 18), n)]
+            if op == T.OP_DIVIDE:
+                ys = [y if y else 7 for y in ys]
+            exp = []
+            for x, y in zip(xs, ys):
+                fx, fy = Fraction(x, 10**s1), Fraction(y, 10**s2)
+                v = fx + fy if op == T.OP_PLUS else fx - fy if op == T.OP_MINUS else fx * fy if op == T.OP_MULTIPLY else fx / fy
+                exp.append(rha(v * 10**s.value))
+            if any(abs(e) >= 10**p.value for e in exp):
+                continue
+            ot = T.T_DEC64 if p.value <= 18 else T.T_DEC128
+            out = np.zeros(n * (2 if ot == T.T_DEC128 else 1), dtype=np.uint64)
+            err = np.zeros(((n + 31) // 32) * 4, dtype=np.uint8)
+            ca, cb = col(xs, p1, s1), col(ys, p2, s2)
+            cca, ccb = ca.c(), cb.c()
+            rc = L.orc_decimal_arith(op, C.byref(cca), C.byref(ccb), C.c_int64(n), ot, p.value, s.value, out.ctypes.data_as(C.c_void_p),
+                                     err.ctypes.data_as(C.c_void_p), None)
+            assert rc == 0, (name, p1, s1, p2, s2)
+            got = O.i128_list(out) if ot == T.T_DEC128 else out.view(np.int64).tolist()
+            ok = np.unpackbits(err, bitorder="little")[:n].astype(bool)
+            assert ok.all(), (name, p1, s1, p2, s2)
+            assert got == exp, (name, (p1, s1), (p2, s2), (p.value, s.value), [(x, y, g, e) for x, y, g, e in zip(xs, ys, got, exp) if g != e][:3])
+            checked += 1
+    assert checked >= 300, checked
+
+
+def test_group_hash_against_a_python_statement_of_the_reference_formulas():
+    """The reference holds no absolute golden hashes ("parity unpinned" for absolute values, oracle/README.md); this pins the
+    C restatement at least on a second, independent statement of the same formulas (aggregate/group_hash.rs:522-570, written
+    here from the source text: integer mix, MurmurHash64A-style byte hash with the big-endian-ordered tail, NULL constant,
+    column combine h * NULL_HASH ^ h_col)."""
+    L = O.load()
+    M64 = (1 << 64) - 1
+
+    def h_int(x):
+        x &= M64
+        x ^= x >> 32
+        x = (x * 0xD6E8FEB86659FD93) & M64
+        x ^= x >> 32
+        x = (x * 0xD6E8FEB86659FD93) & M64
+        x ^= x >> 32
+        return x
+
+    def h_bytes(b):
+        m, seed, r = 0xC6A4A7935BD1E995, 0xE17A1465, 47
+        h = (seed ^ (len(b) * m)) & M64
+        nb = len(b) // 8
+        for i in range(nb):
+            k = int.from_bytes(b[8 * i:8 * i + 8], "little")
+            k = (k * m) & M64
+            k ^= k >> r
+            k = (k * m) & M64
+            h ^= k
+            h = (h * m) & M64
+        tail = b[8 * nb:]
+        for i, c in enumerate(tail):
+            h ^= c << (8 * (len(tail) - i - 1))
+        h ^= h >> r
+        h = (h * m) & M64
+        h ^= h >> r
+        return h
+
+    rng = np.random.default_rng(2)
+    for x in [0, 1, -1, 2**63 - 1, -2**63] + [int(v) for v in rng.integers(-2**62, 2**62, 200)]:
+        assert L.orc_agg_hash_u64(C.c_uint64(x & M64)) == h_int(x)
+    for ln in list(range(0, 40)) + [63, 64, 65, 255]:
+        b = bytes(rng.integers(0, 256, ln).astype(np.uint8))
+        buf = np.frombuffer(b + b"\0", dtype=np.uint8)
+        assert L.orc_agg_hash_bytes(buf.ctypes.data_as(C.c_void_p), C.c_uint64(ln)) == h_bytes(b), ln
+    # two key columns (i64 nullable, i32): combine and NULL constant through orc_group_hash
+    n = 500
+    a = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    av = rng.random(n) > 0.2
+    b = rng.integers(-1000, 1000, n).astype(np.int32)
+    cols = O.cols([O.HostCol(T.T_I64, a, av), O.HostCol(T.T_I32, b)])
+    out = np.zeros(n, dtype=np.uint64)
+    assert L.orc_group_hash(cols, 2, C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
+    NULLH = 0xD1CEFA08EB382D69
+    for i in range(n):
+        h0 = h_int(int(a[i])) if av[i] else NULLH
+        assert int(out[i]) == ((h0 * NULLH) & M64) ^ h_int(int(b[i]))
