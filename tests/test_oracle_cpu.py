@@ -525,3 +525,71 @@ def test_group_hash_against_a_python_statement_of_the_reference_formulas():
     for i in range(n):
         h0 = h_int(int(a[i])) if av[i] else NULLH
         assert int(out[i]) == ((h0 * NULLH) & M64) ^ h_int(int(b[i]))
+
+
+def test_numeric_arithmetic_and_comparisons_against_numpy_statements():
+    """Independent numpy statements next to the golden files: integer plus / minus / multiply WRAP in the result type of
+    ResultTypeOfBinary (Cargo.toml:577 overflow-checks = false; i64 op i64 -> i64, i32 op i32 -> i64, u8 op i8 -> i16 …), `/`
+    is f64 with a row error on a zero divisor, comparisons of floats follow OrderedFloat's total order (NaN equal to itself
+    and greater than everything, types/number.rs:47-48)."""
+    L = O.load()
+    rng = np.random.default_rng(21)
+    n = 4096
+    ints = {T.T_I8: np.int8, T.T_I16: np.int16, T.T_I32: np.int32, T.T_I64: np.int64, T.T_U8: np.uint8, T.T_U16: np.uint16,
+            T.T_U32: np.uint32, T.T_U64: np.uint64}
+    np_of_code = dict(ints)
+    np_of_code.update({T.T_F32: np.float32, T.T_F64: np.float64})
+
+    def rand(dt):
+        info = np.iinfo(dt)
+        v = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+        v[:4] = [info.min, info.max, 0, 1]
+        return v
+
+    checked = 0
+    with np.errstate(over="ignore"):
+        for ta, da in ints.items():
+            for tb, db in ints.items():
+                a, b = rand(da), rand(db)
+                ca, cb = O.HostCol(ta, a).c(), O.HostCol(tb, b).c()
+                for op, f in ((T.OP_PLUS, np.add), (T.OP_MINUS, np.subtract), (T.OP_MULTIPLY, np.multiply)):
+                    rt = L.orc_arith_result_type(op, ta, tb)
+                    if rt not in np_of_code or rt in (T.T_F32, T.T_F64):
+                        continue
+                    dt = np_of_code[rt]
+                    out = np.zeros(n, dtype=dt)
+                    assert L.orc_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), rt, out.ctypes.data_as(C.c_void_p), None, None) == 0
+                    exp = f(a.astype(dt), b.astype(dt))        # `as_` both operands into the result type, then wrap
+                    assert np.array_equal(out, exp), (ta, tb, op)
+                    checked += 1
+    assert checked >= 150, checked
+    # divide: always f64, zero divisor = row error
+    a, b = rand(np.int64), rand(np.int32)
+    b[5:50] = 0
+    out = np.zeros(n, np.float64)
+    err = np.zeros(((n + 31) // 32) * 4, np.uint8)
+    cnt = C.c_uint64()
+    ca, cb = O.HostCol(T.T_I64, a).c(), O.HostCol(T.T_I32, b).c()
+    assert L.orc_arith(T.OP_DIVIDE, C.byref(ca), C.byref(cb), C.c_int64(n), T.T_F64, out.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p), C.byref(cnt)) == 0
+    ok = np.unpackbits(err, bitorder="little")[:n].astype(bool)
+    assert np.array_equal(ok, b != 0) and cnt.value == int((b == 0).sum())
+    assert np.array_equal(out[ok], a[ok].astype(np.float64) / b[ok].astype(np.float64))
+    # float comparisons: total order with NaN on top
+    x = rng.standard_normal(n)
+    y = rng.standard_normal(n)
+    x[::7] = np.nan
+    y[::11] = np.nan
+    y[::13] = x[::13]
+    x[1], y[1] = 0.0, -0.0
+    key = lambda v: np.where(np.isnan(v), np.inf, v) + 0.0      # NaN -> above every finite value; -0.0 == 0.0
+    top = lambda v: np.isnan(v)
+    kx, ky = key(x), key(y)
+    lt = (kx < ky) | ((kx == ky) & ~top(x) & top(y) & False)
+    # with NaN mapped to +inf: inf == NaN must not tie: order finite < inf(real) < NaN — no real infs are generated here
+    exp = {T.CMP_EQ: (kx == ky), T.CMP_NOTEQ: (kx != ky), T.CMP_LT: lt, T.CMP_LTE: (kx <= ky), T.CMP_GT: (kx > ky), T.CMP_GTE: (kx >= ky)}
+    cx, cy = O.HostCol(T.T_F64, x).c(), O.HostCol(T.T_F64, y).c()
+    for op, e in exp.items():
+        out = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+        assert L.orc_cmp(op, C.byref(cx), C.byref(cy), C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
+        got = np.unpackbits(out, bitorder="little")[:n].astype(bool)
+        assert np.array_equal(got, e), op
