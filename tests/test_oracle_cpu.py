@@ -593,3 +593,29 @@ def test_numeric_arithmetic_and_comparisons_against_numpy_statements():
         assert L.orc_cmp(op, C.byref(cx), C.byref(cy), C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
         got = np.unpackbits(out, bitorder="little")[:n].astype(bool)
         assert np.array_equal(got, e), op
+
+
+def test_vector_distances_against_float64_numpy():
+    """cosine / l2 / dot / l1 of the f32 restatement (common/vector/src/distance.rs:19-95) against float64 numpy on random and
+    degenerate vectors, within the north-star tolerance 1e-5 (relative to the magnitude of the terms)."""
+    L = O.load()
+    rng = np.random.default_rng(8)
+    for n, dim, nq in ((50, 3, 2), (300, 128, 4), (64, 768, 3)):
+        base = rng.standard_normal((n, dim)).astype(np.float32)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        base[0] = q[0]                    # an exact duplicate: cosine distance ~ 0, l2 = 0
+        base[1] = -q[0]                   # the antipode: cosine distance 2
+        b64, q64 = base.astype(np.float64), q.astype(np.float64)
+        exp = {
+            T.VEC_DOT: q64 @ b64.T,
+            T.VEC_L2: np.sqrt(((q64[:, None, :] - b64[None, :, :]) ** 2).sum(-1)),
+            T.VEC_L1: np.abs(q64[:, None, :] - b64[None, :, :]).sum(-1),
+            T.VEC_COSINE: 1.0 - (q64 @ b64.T) / (np.linalg.norm(q64, axis=1)[:, None] * np.linalg.norm(b64, axis=1)[None, :]),
+        }
+        scale = np.abs(q64)[:, None, :] * np.abs(b64)[None, :, :]
+        for metric, e in exp.items():
+            out = np.zeros((nq, n), np.float32)
+            L.orc_vec_distance(metric, base.ctypes.data_as(C.c_void_p), C.c_int64(n), dim, q.ctypes.data_as(C.c_void_p), nq,
+                               out.ctypes.data_as(C.c_void_p))
+            tol = 1e-5 * np.maximum(1.0, scale.sum(-1) if metric == T.VEC_DOT else np.abs(e)) + 1e-6
+            assert (np.abs(out - e) <= tol).all(), (metric, n, dim, float(np.abs(out - e).max()))
