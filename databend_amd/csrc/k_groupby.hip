@@ -669,10 +669,20 @@ int32_t ensure(void** p, size_t* cap, size_t bytes) {
   return DBHIP_OK;
 }
 
+// all or nothing: on failure the table keeps its old arrays and capacity (grow() and create() rely on that)
 int32_t alloc_table(dbhip_groupby* g, int64_t cap, hipStream_t s) {
-  DBHIP_CHECK(hipMalloc((void**)&g->slot_hash, (size_t)cap * 8));
-  DBHIP_CHECK(hipMalloc((void**)&g->rows, (size_t)cap * g->L.W * 8));
-  DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)cap * 8, s));
+  uint64_t* nh = nullptr;
+  uint64_t* nr = nullptr;
+  hipError_t e = hipMalloc((void**)&nh, (size_t)cap * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&nr, (size_t)cap * g->L.W * 8);
+  if (e == hipSuccess) e = hipMemsetAsync(nh, 0, (size_t)cap * 8, s);
+  if (e != hipSuccess) {
+    if (nh) (void)hipFree(nh);
+    if (nr) (void)hipFree(nr);
+    return hip_fail(e, "groupby: allocating the table");
+  }
+  g->slot_hash = nh;
+  g->rows = nr;
   g->cap = cap;
   return DBHIP_OK;
 }
@@ -1577,9 +1587,13 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
   g->part_min_rows = 262144;
   hipStream_t s = resolve_stream(nullptr);
   if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
-  DBHIP_CHECK(hipMalloc((void**)&g->ctrl, 64));
-  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 64, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
+  hipError_t e = hipMalloc((void**)&g->ctrl, 64);
+  if (e == hipSuccess) e = hipMemsetAsync(g->ctrl, 0, 64, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {  // nothing half-built is handed out or leaked
+    (void)dbhip_groupby_destroy(g);
+    return hip_fail(e, "dbhip_groupby_create");
+  }
   *out_host = g;
   return DBHIP_OK;
 }

@@ -200,6 +200,8 @@ int32_t ensure_probe_scratch(dbhip_join* j, int64_t n) {
   if (j->cnt) {
     DBHIP_CHECK(hipDeviceSynchronize());
     (void)dbhip_free(j->cnt); (void)dbhip_free(j->firstm); (void)dbhip_free(j->off); (void)dbhip_free(j->blk);
+    j->cnt = nullptr; j->firstm = nullptr; j->off = nullptr; j->blk = nullptr;   // (an allocation below may fail: no dangling pointers)
+    j->scratch_rows = 0;
   }
   size_t cap = (size_t)n + (n >> 3) + 1024;
   DBHIP_TRY(dbhip_alloc(cap * 4, (void**)&j->cnt));
@@ -388,8 +390,13 @@ int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, d
   j->kw = key_bytes / 8;
   j->es = j->kw * 2;
   j->cap_rows = expected_build_rows > 1024 ? expected_build_rows : 1024;
-  DBHIP_TRY(dbhip_alloc((size_t)j->cap_rows * j->es * 8, (void**)&j->ent));
-  DBHIP_TRY(dbhip_alloc(8, (void**)&j->total_dev));
+  int32_t rc = dbhip_alloc((size_t)j->cap_rows * j->es * 8, (void**)&j->ent);
+  if (!rc) rc = dbhip_alloc(8, (void**)&j->total_dev);
+  if (rc) {  // nothing half-built is handed out or leaked
+    if (j->ent) (void)dbhip_free(j->ent);
+    delete j;
+    return rc;
+  }
   *out_host = j;
   return DBHIP_OK;
 }
