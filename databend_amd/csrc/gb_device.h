@@ -227,15 +227,17 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
     case DBHIP_AGG_COUNT:
       if (v[0]) atomicAdd((unsigned long long*)dst, (unsigned long long)v[0]);
       break;
-    case DBHIP_AGG_SUM:
-      if (L.agg_words[a] == 3) {
+    case DBHIP_AGG_SUM: {
+      const int fw = L.agg_flag[a];
+      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
         if (v[0] | v[1] | v[2]) atomic_add_u192(dst, v[0], v[1], v[2]);
       } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
         atomicAdd((double*)dst, __longlong_as_double((long long)v[0]));
       } else if (v[0]) {
         atomicAdd((unsigned long long*)dst, (unsigned long long)v[0]);
       }
-      break;
+      if (fw && v[fw]) atomicOr((unsigned long long*)(dst + fw), 1ULL);
+    } break;
     case DBHIP_AGG_MIN:
       if (v[1]) {
         atomicMin((unsigned long long*)dst, (unsigned long long)v[0]);
@@ -255,4 +257,29 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
 __device__ __forceinline__ void gb_state_identity(const GbLayout& L, int a, uint64_t* dst) {
   for (int k = 0; k < L.agg_words[a]; ++k) dst[k] = 0;
   if (L.agg_kind[a] == DBHIP_AGG_MIN) dst[0] = ~0ULL;
+}
+
+// state contribution of ONE input row for aggregate a from the argument's canonical words (w0, w1) and validity
+// (count(*) passes valid = true); v holds GB_MAX_STATE_WORDS words
+__device__ __forceinline__ void gb_row_contrib(const GbLayout& L, int a, uint64_t w0, uint64_t w1, bool valid, uint64_t* v) {
+  v[0] = 0; v[1] = 0; v[2] = 0; v[3] = 0;
+  switch (L.agg_kind[a]) {
+    case DBHIP_AGG_COUNT:
+      v[0] = valid ? 1 : 0;
+      break;
+    case DBHIP_AGG_SUM: {
+      const int fw = L.agg_flag[a];
+      if (L.agg_type[a] == DBHIP_T_F32) w0 = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)w0));
+      v[0] = valid ? w0 : 0;
+      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+        v[1] = valid ? w1 : 0;
+        v[2] = (valid && (w1 >> 63)) ? ~0ULL : 0;  // sign extension to 192 bits
+      }
+      if (fw) v[fw] = valid ? 1 : 0;
+    } break;
+    default:  // MIN / MAX
+      v[0] = ord_encode(w0, L.agg_type[a]);
+      v[1] = valid ? 1 : 0;
+      break;
+  }
 }

@@ -19,6 +19,10 @@
 //                          (aggregate_sum.rs:203-216 checks the running sum; for same-signed
 //                          inputs the two coincide)
 //   MIN/MAX              : 2 words [order-preserving key][has value]
+//   SUM over a NULLABLE argument carries one more word at the end: [seen a non-NULL row] (0 / 1, OR-merged) — the
+//   device analogue of the flag byte AggregateNullUnaryAdaptor<true> appends to the nested state
+//   (adaptors/aggregate_null_adaptor.rs:366-400,508-540): a group whose argument was NULL in every row yields NULL,
+//   not 0. For MIN/MAX the [has value] word already is that flag.
 // The same row is the unit of exchange between ranks (serialized partial state).
 #pragma once
 #include <stdint.h>
@@ -27,6 +31,7 @@
 
 #define GB_MAX_KEYS 16
 #define GB_MAX_AGGS 24
+#define GB_MAX_STATE_WORDS 4   // widest state: nullable Decimal128 sum = (lo, hi, ext, flag)
 
 struct GbLayout {
   int32_t nkeys, naggs;
@@ -41,6 +46,7 @@ struct GbLayout {
   int32_t agg_type[GB_MAX_AGGS];
   int32_t agg_off[GB_MAX_AGGS];
   int32_t agg_words[GB_MAX_AGGS];
+  int32_t agg_flag[GB_MAX_AGGS];   // word (inside the state) of the "seen a non-NULL row" flag of a nullable SUM; 0 = none
   int32_t agg_nullable[GB_MAX_AGGS];
   int32_t agg_precision[GB_MAX_AGGS];
   int32_t agg_scale[GB_MAX_AGGS];
@@ -59,4 +65,8 @@ struct GbCol {  // by-value copy of dbhip_col for kernel arguments
 struct GbCols {
   GbCol key[GB_MAX_KEYS];
   GbCol arg[GB_MAX_AGGS];
+  // optional predicate Bitmap (LSB-first, read from bit filter_off): rows whose bit is 0 do not take part — the
+  // TransformFilter in front of the aggregate pushed down, so that no column is ever compacted (filter_executor.rs:81-118)
+  const uint8_t* filter;
+  int64_t filter_off;
 };

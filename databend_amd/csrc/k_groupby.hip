@@ -63,6 +63,7 @@ struct dbhip_groupby {
   uint32_t* part_meta; size_t part_meta_cap;   // hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
   uint32_t* spill_idx; size_t spill_idx_cap;
   uint64_t* spill_rows; size_t spill_rows_cap;
+  uint64_t* xcur;                          // exchange partitioning: cursor[4096] | base[4097]
 };
 
 namespace {
@@ -128,12 +129,18 @@ __global__ __launch_bounds__(256) void group_hash_kernel(HashCols hc, int64_t n,
 // serialize: columns -> rows_in
 // ---------------------------------------------------------------------------
 // Four rows per lane, column by column (gb_load_words_n): the loads of a column are in flight together.
+__device__ __forceinline__ bool gb_row_passes(const GbCols& C, int64_t row) {
+  return !C.filter || bit_get(C.filter, C.filter_off + row);
+}
+
+// With a predicate Bitmap (C.filter) the passing rows are written densely (wave ballot + one cursor atomic per wave,
+// ctrl[7] = number of rows written; their order is not the input order, which no consumer depends on).
 __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n,
                                                            uint64_t* rows_in, uint64_t* ctrl) {
   constexpr int U = 4;
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (int64_t base = 0; base < n; base += U * T) {
+  for (int64_t base = 0; base < n; base += U * T) {   // (n, T: wave-uniform trip count)
     int64_t li[U], row[U];
     bool in[U];
     uint64_t h[U], vmask[U];
@@ -144,6 +151,14 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
       if (!in[u]) li[u] = n - 1;
       row[u] = row0 + li[u];
       h[u] = 0; vmask[u] = 0;
+      if (C.filter) {
+        in[u] = in[u] && gb_row_passes(C, row[u]);
+        const uint64_t m = __ballot(in[u]);
+        unsigned long long b0 = 0;
+        if (m && lane_id() == 0) b0 = atomicAdd((unsigned long long*)&ctrl[7], (unsigned long long)__popcll(m));
+        b0 = __shfl(b0, 0, 64);
+        if (in[u]) li[u] = (int64_t)b0 + __popcll(m & ((1ULL << lane_id()) - 1));
+      }
     }
     for (int k = 0; k < L.nkeys; ++k) {
       uint64_t w0[U], w1[U];
@@ -180,24 +195,9 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
       for (int u = 0; u < U; ++u) {
         if (!in[u]) continue;
         uint64_t* s = rows_in + li[u] * L.W + L.agg_off[a];
-        switch (L.agg_kind[a]) {
-          case DBHIP_AGG_COUNT:
-            s[0] = valid[u] ? 1 : 0;
-            break;
-          case DBHIP_AGG_SUM: {
-            uint64_t x = w0[u];
-            if (L.agg_type[a] == DBHIP_T_F32) x = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)x));
-            s[0] = valid[u] ? x : 0;
-            if (L.agg_words[a] == 3) {
-              s[1] = valid[u] ? w1[u] : 0;
-              s[2] = (valid[u] && (w1[u] >> 63)) ? ~0ULL : 0;  // sign extension to 192 bits
-            }
-          } break;
-          default:  // MIN / MAX
-            s[0] = ord_encode(w0[u], L.agg_type[a]);
-            s[1] = valid[u] ? 1 : 0;
-            break;
-        }
+        uint64_t v[GB_MAX_STATE_WORDS];
+        gb_row_contrib(L, a, w0[u], w1[u], valid[u], v);
+        for (int k = 0; k < L.agg_words[a]; ++k) s[k] = v[k];
       }
     }
   }
@@ -357,13 +357,14 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
       uint64_t* d = rows + (uint64_t)lpos * L.W;
       for (int a = 0; a < L.naggs; ++a) {
         const uint64_t* v = r + L.agg_off[a];
-        uint64_t out[3] = {0, 0, 0};
+        uint64_t out[GB_MAX_STATE_WORDS] = {0, 0, 0, 0};
         switch (L.agg_kind[a]) {
           case DBHIP_AGG_COUNT:
             out[0] = wave_sum_u64(mine ? v[0] : 0);
             break;
           case DBHIP_AGG_SUM:
-            if (L.agg_words[a] == 3) {
+            if (L.agg_flag[a]) out[L.agg_flag[a]] = wave_max_u64(mine ? v[L.agg_flag[a]] : 0);
+            if (L.agg_words[a] - (L.agg_flag[a] ? 1 : 0) == 3) {
               u128 t = mine ? (((u128)v[1] << 64) | v[0]) : (u128)0;
               uint64_t e = mine ? v[2] : 0;
 #pragma unroll
@@ -514,6 +515,7 @@ struct ResultPtrs {
   void* keys[GB_MAX_KEYS];
   uint32_t* key_validity[GB_MAX_KEYS];
   void* aggs[GB_MAX_AGGS];
+  uint32_t* agg_validity[GB_MAX_AGGS];   // nullable-argument SUM / MIN / MAX: bit = the group saw a non-NULL row
   uint64_t* hashes;
 };
 
@@ -553,13 +555,20 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
     for (int a = 0; a < L.naggs; ++a) {
       const uint64_t* s = r + L.agg_off[a];
       void* o = P.aggs[a];
+      if (P.agg_validity[a]) {
+        // AggregateNullUnaryAdaptor<true>::merge_result (aggregate_null_adaptor.rs): NULL unless the flag is set
+        bool seen = true;
+        if (L.agg_kind[a] == DBHIP_AGG_SUM) seen = L.agg_flag[a] ? s[L.agg_flag[a]] != 0 : true;
+        else if (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) seen = s[1] != 0;
+        if (seen) atomicOr(&P.agg_validity[a][i >> 5], 1u << (i & 31));
+      }
       if (!o) continue;
       switch (L.agg_kind[a]) {
         case DBHIP_AGG_COUNT:
           ((uint64_t*)o)[i] = s[0];
           break;
         case DBHIP_AGG_SUM:
-          if (L.agg_words[a] == 3) {
+          if (L.agg_words[a] - (L.agg_flag[a] ? 1 : 0) == 3) {
             i128 v = (i128)(((u128)s[1] << 64) | s[0]);
             // DecimalSumState<true,_>::add (aggregate_sum.rs:203-216): outside
             // [DECIMAL_MIN, DECIMAL_MAX] is an Overflow error. Decided on the exact
@@ -573,8 +582,8 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
             ((uint64_t*)o)[i] = s[0];
           }
           break;
-        default: {  // MIN / MAX
-          uint64_t raw = ord_decode(s[0], L.agg_type[a]);
+        default: {  // MIN / MAX (no value seen: the type's default, MinMaxAnyState::merge_result push_default)
+          uint64_t raw = s[1] ? ord_decode(s[0], L.agg_type[a]) : 0;
           switch (L.agg_type[a]) {
             case DBHIP_T_I8: case DBHIP_T_U8: case DBHIP_T_BOOL: ((uint8_t*)o)[i] = (uint8_t)raw; break;
             case DBHIP_T_I16: case DBHIP_T_U16: ((uint16_t*)o)[i] = (uint16_t)raw; break;
@@ -586,6 +595,194 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// a12: hash partitioning of the table's group rows for the exchange / final merge — the device twin of
+// Payload::scan_hash_partition_transfer (payload.rs:548-589: bucket = group hash % bucket count) and
+// PartitionedPayload::repartition. Every occupied slot's row (keys, hash, states: the unit of exchange) is copied
+// to its bucket's output region; lanes of a wave that share a bucket take ONE cursor atomic together.
+//   blocks mode  (bucket_base == nullptr): bucket b -> out + b * stride_words, rows from row 1 on (row 0 = header),
+//                at most max_rows rows are written, the cursor keeps counting (overflow is seen in the header)
+//   ranges mode  (bucket_base != nullptr): bucket b -> rows [bucket_base[b], bucket_base[b + 1]) of `out`
+//   count only   (out == nullptr)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gb_partition_rows_kernel(GbLayout L, const uint64_t* slot_hash, const uint64_t* rows,
+                                                                int64_t cap, uint32_t n_buckets, int64_t max_rows,
+                                                                int64_t stride_words, const uint64_t* bucket_base,
+                                                                uint64_t* out, unsigned long long* cursor) {
+  const int64_t cap_pad = (cap + 63) & ~63LL;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap_pad; s += (int64_t)gridDim.x * blockDim.x) {
+    const bool occ = s < cap && slot_hash[s] != 0;
+    const uint64_t* r = rows + s * L.W;
+    const uint32_t bucket = occ ? (uint32_t)(r[L.hash_word] % (uint64_t)n_buckets) : 0xFFFFFFFFu;
+    uint64_t todo = __ballot(occ);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t lb = __shfl(bucket, leader, 64);
+      const bool mine = occ && bucket == lb;
+      const uint64_t m = __ballot(mine);
+      unsigned long long b0 = 0;
+      if (lane_id() == leader) b0 = atomicAdd(&cursor[lb], (unsigned long long)__popcll(m));
+      b0 = __shfl(b0, leader, 64);
+      if (mine && out) {
+        const uint64_t idx = b0 + __popcll(m & ((1ULL << lane_id()) - 1));
+        uint64_t* d = nullptr;
+        if (bucket_base) d = out + (bucket_base[lb] + idx) * L.W;
+        else if ((int64_t)idx < max_rows) d = out + (int64_t)lb * stride_words + (idx + 1) * L.W;
+        if (d) for (int k = 0; k < L.W; ++k) d[k] = r[k];
+      }
+      todo &= ~m;
+    }
+  }
+}
+
+// headers of the n_buckets blocks: word 0 = rows that follow (~0: more than max_rows), word 1 = 1 when ANY block of this
+// sender overflowed — every receiver of an all-to-all gets one block from every sender, so all ranks see the same
+// flags and take the variable-length path together
+__global__ __launch_bounds__(256) void gb_partition_headers_kernel(uint64_t* blocks, int W, int64_t stride_words, int64_t max_rows,
+                                                                   uint32_t n_buckets, const unsigned long long* cursor) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x)
+    if ((int64_t)cursor[b] > max_rows) atomicOr(&any, 1);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+    uint64_t* h = blocks + (int64_t)b * stride_words;
+    for (int k = 0; k < W; ++k) h[k] = 0;
+    h[0] = (int64_t)cursor[b] > max_rows ? ~0ULL : (uint64_t)cursor[b];
+    h[1] = (uint64_t)any;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// §8f-1: the serialized-state block of Payload::aggregate_flush (payload_flush.rs:151-181): per aggregate the fields of
+// its serialize_type(), then the group columns.
+//   count                        (UInt64)                                            aggregate_count.rs:170-186
+//   sum  -> its result type      (Int64 / UInt64 / Float64 / Decimal)                aggregate_sum.rs:155-168,281-298
+//   min / max                    (Boolean has-value, T value; default value if none) aggregate_min_max_any.rs:315-346
+//   nullable argument (sum/min/max): the nested fields + a trailing Boolean flag      aggregate_null_adaptor.rs:508-540
+// Field columns are flattened in aggregate order; Boolean fields are LSB-first bitmaps.
+// ---------------------------------------------------------------------------
+struct StateFieldPtrs {
+  void* f[GB_MAX_AGGS * 3];
+};
+
+__device__ __forceinline__ void store_typed(void* o, int64_t i, int type, uint64_t raw) {
+  switch (type) {
+    case DBHIP_T_I8: case DBHIP_T_U8: ((uint8_t*)o)[i] = (uint8_t)raw; break;
+    case DBHIP_T_I16: case DBHIP_T_U16: ((uint16_t*)o)[i] = (uint16_t)raw; break;
+    case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_F32: case DBHIP_T_DATE: ((uint32_t*)o)[i] = (uint32_t)raw; break;
+    default: ((uint64_t*)o)[i] = raw; break;
+  }
+}
+__device__ __forceinline__ void set_bit32(void* bm, int64_t i) { atomicOr((uint32_t*)bm + (i >> 5), 1u << (i & 31)); }
+
+// serialized rows -> state field columns (the key columns are written by gb_result_kernel)
+__global__ __launch_bounds__(256) void gb_state_fields_kernel(GbLayout L, const uint64_t* rows_out, int64_t n, StateFieldPtrs P,
+                                                              uint64_t* ctrl) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t* r = rows_out + i * L.W;
+    int f = 0;
+    for (int a = 0; a < L.naggs; ++a) {
+      const uint64_t* s = r + L.agg_off[a];
+      switch (L.agg_kind[a]) {
+        case DBHIP_AGG_COUNT:
+          if (P.f[f]) ((uint64_t*)P.f[f])[i] = s[0];
+          ++f;
+          break;
+        case DBHIP_AGG_SUM: {
+          const int fw = L.agg_flag[a];
+          if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+            const i128 v = (i128)(((u128)s[1] << 64) | s[0]);
+            const i128 mx = pow10_i128(38) - 1;
+            const bool fits128 = s[2] == ((s[1] >> 63) ? ~0ULL : 0ULL);
+            if (L.agg_precision[a] > 18 && (!fits128 || v > mx || v < -mx)) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
+            if (P.f[f]) { ((uint64_t*)P.f[f])[2 * i] = s[0]; ((uint64_t*)P.f[f])[2 * i + 1] = s[1]; }
+          } else if (P.f[f]) {
+            ((uint64_t*)P.f[f])[i] = s[0];
+          }
+          ++f;
+          if (fw) { if (P.f[f] && s[fw]) set_bit32(P.f[f], i); ++f; }
+        } break;
+        default: {  // MIN / MAX
+          if (P.f[f] && s[1]) set_bit32(P.f[f], i);
+          ++f;
+          if (P.f[f]) store_typed(P.f[f], i, L.agg_type[a], s[1] ? ord_decode(s[0], L.agg_type[a]) : 0);
+          ++f;
+          if (L.agg_nullable[a]) { if (P.f[f] && s[1]) set_bit32(P.f[f], i); ++f; }
+        } break;
+      }
+    }
+  }
+}
+
+struct StateFieldCols {
+  GbCol f[GB_MAX_AGGS * 3];
+};
+
+// state field columns -> the state words of rows_in (the keys were serialized by gb_serialize_kernel with no
+// aggregate arguments): what TransformDeserializer + AggregateFunction::batch_merge consume
+// (aggregator/serde/transform_deserializer.rs; batch_merge of each function, cited above)
+__global__ __launch_bounds__(256) void gb_states_from_fields_kernel(GbLayout L, StateFieldCols F, int64_t n, uint64_t* rows_in) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t* r = rows_in + i * L.W;
+    int f = 0;
+    for (int a = 0; a < L.naggs; ++a) {
+      uint64_t* s = r + L.agg_off[a];
+      uint64_t w[2];
+      bool valid;
+      switch (L.agg_kind[a]) {
+        case DBHIP_AGG_COUNT:
+          gb_load_words(F.f[f], i, w, &valid);
+          s[0] = w[0];
+          ++f;
+          break;
+        case DBHIP_AGG_SUM: {
+          const int fw = L.agg_flag[a];
+          gb_load_words(F.f[f], i, w, &valid);
+          ++f;
+          bool seen = true;
+          if (fw) { seen = bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i); ++f; }
+          // a state whose flag is clear contributes nothing (the adaptor's batch_merge filters on the flag)
+          s[0] = seen ? w[0] : 0;
+          if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+            s[1] = seen ? w[1] : 0;
+            s[2] = (seen && (w[1] >> 63)) ? ~0ULL : 0;
+          }
+          if (fw) s[fw] = seen ? 1 : 0;
+        } break;
+        default: {
+          bool has = bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i);
+          ++f;
+          gb_load_words(F.f[f], i, w, &valid);
+          ++f;
+          if (L.agg_nullable[a]) { has = has && bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i); ++f; }
+          s[0] = ord_encode(w[0], L.agg_type[a]);
+          s[1] = has ? 1 : 0;
+        } break;
+      }
+    }
+  }
+}
+
+// fields of the serialized-state block for this layout, in order; returns their number
+int state_fields(const GbLayout& L, int32_t* types, int32_t* agg_of) {
+  int f = 0;
+  for (int a = 0; a < L.naggs; ++a) {
+    dbhip_agg_desc d = {L.agg_kind[a], L.agg_type[a], (uint8_t)L.agg_precision[a], (uint8_t)L.agg_scale[a], (uint8_t)L.agg_nullable[a], 0};
+    int32_t rt = 0;
+    uint8_t p, sc;
+    (void)dbhip_groupby_result_type(&d, &rt, &p, &sc);
+    auto put = [&](int t) { if (types) types[f] = t; if (agg_of) agg_of[f] = a; ++f; };
+    switch (L.agg_kind[a]) {
+      case DBHIP_AGG_COUNT: put(DBHIP_T_U64); break;
+      case DBHIP_AGG_SUM: put(rt); if (L.agg_flag[a]) put(DBHIP_T_BOOL); break;
+      default: put(DBHIP_T_BOOL); put(rt); if (L.agg_nullable[a]) put(DBHIP_T_BOOL); break;
+    }
+  }
+  return f;
 }
 
 GbCol to_gbcol(const dbhip_col& c) {
@@ -637,10 +834,11 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
           set_error("groupby: sum() does not support type %d", d.arg_type);
           return DBHIP_ERR_INVALID;
         }
+        if (d.arg_nullable) L->agg_flag[a] = words++;   // "seen a non-NULL row" (AggregateNullUnaryAdaptor<true>)
         break;
       case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
-        if (d.arg_type == DBHIP_T_DEC128 || d.arg_type == DBHIP_T_STRING || d.arg_nullable) {
-          set_error("groupby: min/max on type %d (nullable=%d) stays on the CPU operator", d.arg_type, d.arg_nullable);
+        if (d.arg_type == DBHIP_T_DEC128 || d.arg_type == DBHIP_T_STRING || !key_type_ok(d.arg_type)) {
+          set_error("groupby: min/max on type %d stays on the CPU operator", d.arg_type);
           return DBHIP_ERR_UNSUPPORTED;
         }
         words = 2;
@@ -869,28 +1067,6 @@ __device__ __forceinline__ void fk_load(const GbLayout& L, const GbCols& C, int6
   }
 }
 
-// state contribution of one row for aggregate a (same encoding as gb_serialize_kernel)
-__device__ __forceinline__ void fk_contrib(const GbLayout& L, int a, uint64_t w0, uint64_t w1, bool valid, uint64_t v[3]) {
-  v[0] = 0; v[1] = 0; v[2] = 0;
-  switch (L.agg_kind[a]) {
-    case DBHIP_AGG_COUNT:
-      v[0] = valid ? 1 : 0;
-      break;
-    case DBHIP_AGG_SUM:
-      if (L.agg_type[a] == DBHIP_T_F32) w0 = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)w0));
-      v[0] = valid ? w0 : 0;
-      if (L.agg_words[a] == 3) {
-        v[1] = valid ? w1 : 0;
-        v[2] = (valid && (w1 >> 63)) ? ~0ULL : 0;
-      }
-      break;
-    default:
-      v[0] = ord_encode(w0, L.agg_type[a]);
-      v[1] = valid ? 1 : 0;
-      break;
-  }
-}
-
 struct FkArgs {
   int64_t row0, n;         // rows [row0, row0 + n) of the columns
   int64_t tiles_per_block;
@@ -934,7 +1110,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
     for (int x = 0; x < R; ++x) {
       const int64_t li = t * tile_rows + x * 256 + tid;
       slot[x] = FK_SPILL;
-      if (li < A.n) {
+      if (li < A.n && gb_row_passes(C, A.row0 + li)) {
         const uint64_t hw = probe_word(r[x].h, A.hash_mask);
         uint32_t pos = (uint32_t)hw & lmask;
         for (int step = 0; step < 64; ++step) {
@@ -979,8 +1155,8 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 #pragma unroll
           for (int a = 0; a < NA; ++a)
             if (a < L.naggs) {
-              uint64_t v[3];
-              fk_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
+              uint64_t v[GB_MAX_STATE_WORDS];
+              gb_row_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
               gb_atomic_merge(L, a, d + L.agg_off[a], v);
             }
         } else {
@@ -1002,8 +1178,8 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 #pragma unroll
           for (int a = 0; a < NA; ++a)
             if (a < L.naggs) {
-              uint64_t v[3];
-              fk_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
+              uint64_t v[GB_MAX_STATE_WORDS];
+              gb_row_contrib(L, a, r[x].aw[a], HI ? r[x].ah[a] : 0, (r[x].avalid >> a) & 1, v);
               for (int k = 0; k < L.agg_words[a]; ++k) o[L.agg_off[a] + k] = v[k];
             }
         }
@@ -1180,7 +1356,7 @@ __global__ __launch_bounds__(256) void gb_part_hist_kernel(GbLayout L, GbCols C,
   for (int s = threadIdx.x; s < P; s += 256) pt_lds[s] = 0;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    atomicAdd(&pt_lds[part_of(gb_keys_hash(L, C, row0 + i, ctrl), pbits)], 1u);
+    if (gb_row_passes(C, row0 + i)) atomicAdd(&pt_lds[part_of(gb_keys_hash(L, C, row0 + i, ctrl), pbits)], 1u);
   __syncthreads();
   for (int s = threadIdx.x; s < P; s += 256) {
     const uint32_t c = pt_lds[s];
@@ -1238,8 +1414,8 @@ __device__ __forceinline__ void gb_serialize_row(const GbLayout& L, const GbCols
     uint64_t w[2] = {0, 0};
     bool valid = true;
     if (C.arg[a].data != nullptr) gb_load_words(C.arg[a], i, w, &valid);
-    uint64_t v[3];
-    fk_contrib(L, a, w[0], w[1], valid, v);
+    uint64_t v[GB_MAX_STATE_WORDS];
+    gb_row_contrib(L, a, w[0], w[1], valid, v);
     for (int k = 0; k < L.agg_words[a]; ++k) r[L.agg_off[a] + k] = v[k];
   }
 }
@@ -1263,7 +1439,7 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
       const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
       part[x] = 0xFFFFFFFFu;
       rank[x] = 0;
-      if (li < n) {
+      if (li < n && gb_row_passes(C, row0 + li)) {
         part[x] = part_of(gb_keys_hash(L, C, row0 + li, ctrl), pbits);
         rank[x] = atomicAdd(&lcnt[part[x]], 1u);
       }
@@ -1277,7 +1453,7 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
 #pragma unroll
     for (int x = 0; x < PT_R; ++x) {
       const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
-      if (li < n) gb_serialize_row(L, C, row0 + li, rows_out + (uint64_t)(lcnt[part[x]] + rank[x]) * L.W, ctrl);
+      if (part[x] != 0xFFFFFFFFu) gb_serialize_row(L, C, row0 + li, rows_out + (uint64_t)(lcnt[part[x]] + rank[x]) * L.W, ctrl);
     }
     __syncthreads();
   }
@@ -1619,11 +1795,18 @@ int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits) {
 
 int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
                                 int64_t n, void* stream) {
+  return dbhip_groupby_add_block_filtered(g, keys, args, n, nullptr, 0, stream);
+}
+
+int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args, int64_t n,
+                                         const uint8_t* filter_bitmap, int64_t filter_bit_offset, void* stream) {
   DBHIP_REQUIRE(g && keys, "dbhip_groupby_add_block: NULL argument");
   if (n == 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
   GbCols C;
   memset(&C, 0, sizeof(C));
+  C.filter = filter_bitmap;
+  C.filter_off = filter_bit_offset;
   for (int k = 0; k < g->L.nkeys; ++k) {
     if (keys[k].type != g->L.key_type[k]) {
       set_error("dbhip_groupby_add_block: key %d has type %d, table expects %d", k, keys[k].type, g->L.key_type[k]);
@@ -1666,10 +1849,18 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
     // walk the table slice by slice — was measured and does not pay: at 10^6..10^7 groups the row path is bound by
     // the two device-scope atomics per row, not by the random sectors. r01y: 17.9 ms vs 16.4 ms at 10 M groups.)
     if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
+    if (C.filter) DBHIP_CHECK(hipMemsetAsync(&g->ctrl[7], 0, 8, s));
     hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(ceil_div(cn, 4), 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
                        g->ctrl);
     DBHIP_LAUNCH_CHECK();
-    if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
+    int64_t kept = cn;
+    if (C.filter) {  // the passing rows were written densely: their number comes back with one small copy
+      uint64_t k7 = 0;
+      DBHIP_CHECK(hipMemcpyAsync(&k7, &g->ctrl[7], 8, hipMemcpyDeviceToHost, s));
+      DBHIP_CHECK(hipStreamSynchronize(s));
+      kept = (int64_t)k7;
+    }
+    if ((rc = merge_rows(g, g->rows_in, kept, s))) return rc;
     done += cn;
     g->rows_seen += cn;
     if (probe_here && g->part_bits == 0 && g->rows_seen >= (1 << 20)) {
@@ -1680,44 +1871,80 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
   return DBHIP_OK;
 }
 
-// Deserializing side of the reference's state exchange (TransformDeserializer -> batch_merge,
-// aggregator/serde/transform_deserializer.rs, aggregate_sum.rs:170-181,300-312, aggregate_count.rs batch_merge):
-// a block of [state columns..., group columns...] as Payload::aggregate_flush produces it
-// (payload_flush.rs:151-181) is merged into the table. For sum the state column IS the running value (its
-// result type), for count it is the u64 count — merging adds them; i.e. add_block where every COUNT
-// aggregate behaves as SUM over its u64 state column.
+// Deserializing side of the reference's state exchange (TransformDeserializer -> AggregateFunction::batch_merge,
+// aggregator/serde/transform_deserializer.rs): a block [state fields..., group columns...] as
+// Payload::aggregate_flush produces it (payload_flush.rs:151-181) is merged into the table. The keys are serialized
+// like an input block, the state words are filled from the field columns (gb_states_from_fields_kernel) and the rows
+// go through the row merge path — the table's layout is never modified.
 int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
                                         int64_t n, void* stream) {
   DBHIP_REQUIRE(g && keys && (states || g->L.naggs == 0), "dbhip_groupby_merge_state_block: NULL argument");
-  const GbLayout saved = g->L;
-  dbhip_col st[GB_MAX_AGGS];
-  for (int a = 0; a < saved.naggs; ++a) {
-    st[a] = states[a];
-    if (saved.agg_kind[a] == DBHIP_AGG_MIN || saved.agg_kind[a] == DBHIP_AGG_MAX) {
-      set_error("dbhip_groupby_merge_state_block: min/max states are exchanged as serialized rows (dbhip_groupby_merge_serialized)");
-      return DBHIP_ERR_UNSUPPORTED;
-    }
-    DBHIP_REQUIRE(states[a].data, "dbhip_groupby_merge_state_block: missing state column");
-    int32_t want;
-    uint8_t p, sc;
-    dbhip_agg_desc d = {saved.agg_kind[a], saved.agg_type[a], (uint8_t)saved.agg_precision[a], (uint8_t)saved.agg_scale[a],
-                        (uint8_t)saved.agg_nullable[a], 0};
-    int32_t rc = dbhip_groupby_result_type(&d, &want, &p, &sc);
-    if (rc) return rc;
-    if (states[a].type != want) {
-      set_error("dbhip_groupby_merge_state_block: state column %d has type %d, the aggregate's state type is %d", a, states[a].type, want);
+  const GbLayout& L = g->L;
+  int32_t ftype[GB_MAX_AGGS * 3], fagg[GB_MAX_AGGS * 3];
+  const int nf = state_fields(L, ftype, fagg);
+  // validate everything BEFORE anything is queued
+  StateFieldCols F;
+  memset(&F, 0, sizeof(F));
+  for (int f = 0; f < nf; ++f) {
+    if (!states[f].data) {
+      set_error("dbhip_groupby_merge_state_block: missing state field %d (aggregate %d)", f, fagg[f]);
       return DBHIP_ERR_INVALID;
     }
-    // the state column is summed in its own (result) type
-    g->L.agg_kind[a] = DBHIP_AGG_SUM;
-    g->L.agg_type[a] = want;
-    g->L.agg_nullable[a] = 0;
+    if (states[f].type != ftype[f]) {
+      set_error("dbhip_groupby_merge_state_block: state field %d (aggregate %d) has type %d, the serialized state has type %d", f,
+                fagg[f], states[f].type, ftype[f]);
+      return DBHIP_ERR_INVALID;
+    }
+    F.f[f] = to_gbcol(states[f]);
+    F.f[f].validity = nullptr;  // state fields are never NULL (MinMax: the has-value field says it)
   }
-  int32_t rc = dbhip_groupby_add_block(g, keys, st, n, stream);
-  const GbLayout after = g->L;
-  g->L = saved;
-  (void)after;
-  return rc;
+  GbCols C;
+  memset(&C, 0, sizeof(C));
+  for (int k = 0; k < L.nkeys; ++k) {
+    if (keys[k].type != L.key_type[k]) {
+      set_error("dbhip_groupby_merge_state_block: key %d has type %d, table expects %d", k, keys[k].type, L.key_type[k]);
+      return DBHIP_ERR_INVALID;
+    }
+    if (keys[k].validity && !L.key_nullable[k]) {
+      set_error("dbhip_groupby_merge_state_block: key %d carries validity but was declared NOT NULL", k);
+      return DBHIP_ERR_INVALID;
+    }
+    C.key[k] = to_gbcol(keys[k]);
+  }
+  if (n == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc;
+  const int64_t CHUNK = 32 << 20;
+  for (int64_t done = 0; done < n; done += CHUNK) {
+    const int64_t cn = n - done < CHUNK ? n - done : CHUNK;
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
+    // keys + hash (argument pointers are NULL: the state words are overwritten by the next kernel)
+    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(ceil_div(cn, 4), 256)), dim3(256), 0, s, L, C, done, cn, g->rows_in, g->ctrl);
+    StateFieldCols Fc = F;
+    for (int f = 0; f < nf; ++f) {
+      if (Fc.f[f].is_scalar || done == 0) continue;
+      const int es = Fc.f[f].type == DBHIP_T_BOOL ? 0 : type_size(Fc.f[f].type);
+      if (es) Fc.f[f].data = (const uint8_t*)Fc.f[f].data + (size_t)done * es;
+      else Fc.f[f].data = (const uint8_t*)Fc.f[f].data + (done >> 3);   // CHUNK is a multiple of 8 bits
+    }
+    hipLaunchKernelGGL(gb_states_from_fields_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, L, Fc, cn, g->rows_in);
+    DBHIP_LAUNCH_CHECK();
+    if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
+  }
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_state_fields(dbhip_groupby* g, int32_t* out_types_host, int32_t* out_agg_index_host, int32_t max_fields,
+                                   int32_t* out_n_fields_host) {
+  DBHIP_REQUIRE(g && out_n_fields_host, "dbhip_groupby_state_fields: NULL argument");
+  int32_t ftype[GB_MAX_AGGS * 3], fagg[GB_MAX_AGGS * 3];
+  const int nf = state_fields(g->L, ftype, fagg);
+  *out_n_fields_host = nf;
+  for (int f = 0; f < nf && f < max_fields; ++f) {
+    if (out_types_host) out_types_host[f] = ftype[f];
+    if (out_agg_index_host) out_agg_index_host[f] = fagg[f];
+  }
+  return DBHIP_OK;
 }
 
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, void* stream) {
@@ -1784,14 +2011,16 @@ int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int
   DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 8, blocks, (size_t)stride * 8, 8, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
   int64_t total = 0;
+  // EVERY header is checked, the caller's own block included: the owner of an overflowed block must take the
+  // variable-length path together with the ranks that see the overflow in the gathered headers (otherwise the owner
+  // would merge and return while the others enter a collective). Decided BEFORE the table is touched.
   for (int b = 0; b < n_blocks; ++b) {
-    if (b == skip_block) continue;
-    if (head[b] == ~0ULL || (int64_t)head[b] > max_rows) {  // decided BEFORE the table is touched: the caller can still take the
-      set_error("dbhip_groupby_merge_blocks: block %d overflowed max_rows=%lld (exchange the rows with "   // variable-length path
+    if (head[b] == ~0ULL || (int64_t)head[b] > max_rows) {
+      set_error("dbhip_groupby_merge_blocks: block %d overflowed max_rows=%lld (exchange the rows with "
                 "dbhip_groupby_flush_serialized / merge_serialized instead)", b, (long long)max_rows);
       return DBHIP_ERR_CAPACITY;
     }
-    total += (int64_t)head[b];
+    if (b != skip_block) total += (int64_t)head[b];
   }
   if (total == 0) return DBHIP_OK;
   int32_t rc;
@@ -1831,11 +2060,9 @@ int32_t dbhip_groupby_result_type(const dbhip_agg_desc* agg, int32_t* out_type, 
   return DBHIP_OK;
 }
 
-int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
-                                   uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
-                                   uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host,
-                                   void* stream) {
-  DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result: NULL argument");
+static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8_t* const* out_key_validity_host,
+                             void* const* out_aggs_host, uint8_t* const* out_agg_validity_host, void* const* out_fields_host,
+                             uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host, void* stream) {
   hipStream_t s = resolve_stream(stream);
   uint64_t* tmp = (uint64_t*)scratch((size_t)(max_rows > 0 ? max_rows : 1) * g->L.W * 8, 3);
   if (!tmp) return DBHIP_ERR_HIP;
@@ -1845,15 +2072,31 @@ int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
   if (n == 0) return DBHIP_OK;
   ResultPtrs P;
   memset(&P, 0, sizeof(P));
+  const size_t bm_bytes = (size_t)ceil_div(max_rows, 64) * 8;
   for (int k = 0; k < g->L.nkeys; ++k) {
     P.keys[k] = out_keys_host ? out_keys_host[k] : nullptr;
     P.key_validity[k] = out_key_validity_host ? (uint32_t*)out_key_validity_host[k] : nullptr;
-    if (P.key_validity[k]) DBHIP_CHECK(hipMemsetAsync(P.key_validity[k], 0, (size_t)ceil_div(max_rows, 32) * 4, s));
+    if (P.key_validity[k]) DBHIP_CHECK(hipMemsetAsync(P.key_validity[k], 0, bm_bytes, s));
   }
-  for (int a = 0; a < g->L.naggs; ++a) P.aggs[a] = out_aggs_host ? out_aggs_host[a] : nullptr;
+  for (int a = 0; a < g->L.naggs; ++a) {
+    P.aggs[a] = out_aggs_host ? out_aggs_host[a] : nullptr;
+    P.agg_validity[a] = out_agg_validity_host ? (uint32_t*)out_agg_validity_host[a] : nullptr;
+    if (P.agg_validity[a]) DBHIP_CHECK(hipMemsetAsync(P.agg_validity[a], 0, bm_bytes, s));
+  }
   P.hashes = out_hashes;
   DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
   hipLaunchKernelGGL(gb_result_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, P, g->ctrl);
+  if (out_fields_host) {
+    int32_t ftype[GB_MAX_AGGS * 3];
+    const int nf = state_fields(g->L, ftype, nullptr);
+    StateFieldPtrs SP;
+    memset(&SP, 0, sizeof(SP));
+    for (int f = 0; f < nf; ++f) {
+      SP.f[f] = out_fields_host[f];
+      if (SP.f[f] && ftype[f] == DBHIP_T_BOOL) DBHIP_CHECK(hipMemsetAsync(SP.f[f], 0, bm_bytes, s));
+    }
+    hipLaunchKernelGGL(gb_state_fields_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, SP, g->ctrl);
+  }
   DBHIP_LAUNCH_CHECK();
   uint64_t err = 0;
   DBHIP_CHECK(hipMemcpyAsync(&err, &g->ctrl[3], 8, hipMemcpyDeviceToHost, s));
@@ -1863,6 +2106,117 @@ int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
     return DBHIP_ERR_OVERFLOW;
   }
   return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
+                                   uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
+                                   uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host,
+                                   void* stream) {
+  DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result: NULL argument");
+  return flush_columns(g, out_keys_host, out_key_validity_host, out_aggs_host, nullptr, nullptr, out_hashes, max_rows,
+                       out_n_rows_host, stream);
+}
+
+int32_t dbhip_groupby_flush_result_nullable(dbhip_groupby* g, void* const* out_keys_host,
+                                            uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
+                                            uint8_t* const* out_agg_validity_host, uint64_t* out_hashes, int64_t max_rows,
+                                            int64_t* out_n_rows_host, void* stream) {
+  DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result_nullable: NULL argument");
+  return flush_columns(g, out_keys_host, out_key_validity_host, out_aggs_host, out_agg_validity_host, nullptr, out_hashes,
+                       max_rows, out_n_rows_host, stream);
+}
+
+int32_t dbhip_groupby_flush_state_block(dbhip_groupby* g, void* const* out_keys_host, uint8_t* const* out_key_validity_host,
+                                        void* const* out_state_fields_host, uint64_t* out_hashes, int64_t max_rows,
+                                        int64_t* out_n_rows_host, void* stream) {
+  DBHIP_REQUIRE(g && out_n_rows_host && (out_state_fields_host || g->L.naggs == 0), "dbhip_groupby_flush_state_block: NULL argument");
+  return flush_columns(g, out_keys_host, out_key_validity_host, nullptr, nullptr, out_state_fields_host, out_hashes, max_rows,
+                       out_n_rows_host, stream);
+}
+
+// ---- a12: hash partitioning of the group rows (payload.rs:548-589) ------------------------------------------
+static int32_t ensure_xcur(dbhip_groupby* g) {
+  if (g->xcur) return DBHIP_OK;
+  DBHIP_CHECK(hipMalloc((void**)&g->xcur, (size_t)(2 * 4096 + 2) * 8));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void* out_blocks_dev, int64_t max_rows, void* stream) {
+  DBHIP_REQUIRE(g && out_blocks_dev && n_buckets >= 1 && n_buckets <= 4096 && max_rows >= 1, "dbhip_groupby_partition_blocks: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc = ensure_xcur(g);
+  if (rc) return rc;
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  DBHIP_CHECK(hipMemsetAsync(g->xcur, 0, (size_t)n_buckets * 8, s));
+  hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap,
+                     (uint32_t)n_buckets, max_rows, stride, (const uint64_t*)nullptr, (uint64_t*)out_blocks_dev,
+                     (unsigned long long*)g->xcur);
+  hipLaunchKernelGGL(gb_partition_headers_kernel, dim3(1), dim3(256), 0, s, (uint64_t*)out_blocks_dev, W, stride, max_rows,
+                     (uint32_t)n_buckets, (const unsigned long long*)g->xcur);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;  // nothing is read back: the headers travel with the blocks
+}
+
+int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, void* out_rows_dev, int64_t max_rows,
+                                        int64_t* out_counts_host, void* stream) {
+  DBHIP_REQUIRE(g && out_counts_host && n_buckets >= 1 && n_buckets <= 4096 && (out_rows_dev || max_rows == 0),
+                "dbhip_groupby_flush_partitioned: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc = ensure_xcur(g);
+  if (rc) return rc;
+  uint64_t* cur = g->xcur;
+  uint64_t* base = g->xcur + 4096;
+  DBHIP_CHECK(hipMemsetAsync(cur, 0, (size_t)n_buckets * 8, s));
+  const int grid = grid_for(g->cap, 256);
+  hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint32_t)n_buckets,
+                     (int64_t)0, (int64_t)0, (const uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned long long*)cur);
+  DBHIP_LAUNCH_CHECK();
+  std::vector<uint64_t> cnt((size_t)n_buckets), off((size_t)n_buckets + 1);
+  DBHIP_CHECK(hipMemcpyAsync(cnt.data(), cur, (size_t)n_buckets * 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  uint64_t total = 0;
+  for (int b = 0; b < n_buckets; ++b) { off[b] = total; total += cnt[b]; out_counts_host[b] = (int64_t)cnt[b]; }
+  off[n_buckets] = total;
+  if ((int64_t)total > max_rows) {
+    set_error("dbhip_groupby_flush_partitioned: %llu groups do not fit max_rows=%lld", (unsigned long long)total, (long long)max_rows);
+    return DBHIP_ERR_CAPACITY;
+  }
+  if (total == 0) return DBHIP_OK;
+  DBHIP_CHECK(hipMemcpyAsync(base, off.data(), (size_t)(n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+  DBHIP_CHECK(hipMemsetAsync(cur, 0, (size_t)n_buckets * 8, s));
+  hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint32_t)n_buckets,
+                     (int64_t)0, (int64_t)0, (const uint64_t*)base, (uint64_t*)out_rows_dev, (unsigned long long*)cur);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));  // `off` (pageable host memory) was the source of an async copy
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows, void* stream) {
+  DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_replace_with_blocks: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  const uint64_t* blocks = (const uint64_t*)blocks_dev;
+  std::vector<uint64_t> head((size_t)n_blocks * 2);
+  DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 16, blocks, (size_t)stride * 8, 16, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  int64_t total = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    if (head[2 * b] == ~0ULL || (int64_t)head[2 * b] > max_rows || head[2 * b + 1] != 0) {  // decided BEFORE the table is touched
+      set_error("dbhip_groupby_replace_with_blocks: the sender of block %d overflowed max_rows=%lld (exchange the rows with "
+                "dbhip_groupby_flush_partitioned / merge_serialized instead)", b, (long long)max_rows);
+      return DBHIP_ERR_CAPACITY;
+    }
+    total += (int64_t)head[2 * b];
+  }
+  int32_t rc;
+  if ((rc = dbhip_groupby_reset(g, stream))) return rc;
+  if (total == 0) return DBHIP_OK;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)total * W * 8))) return rc;
+  hipLaunchKernelGGL(gb_compact_blocks_kernel, dim3(n_blocks), dim3(256), 0, s, blocks, stride, W, -1, g->rows_in);
+  DBHIP_LAUNCH_CHECK();
+  return merge_rows(g, g->rows_in, total, s);
 }
 
 int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
@@ -1891,6 +2245,7 @@ int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (g->part_meta) (void)hipFree(g->part_meta);
   if (g->spill_idx) (void)hipFree(g->spill_idx);
   if (g->spill_rows) (void)hipFree(g->spill_rows);
+  if (g->xcur) (void)hipFree(g->xcur);
   delete g;
   return DBHIP_OK;
 }

@@ -298,15 +298,18 @@ bool scan_hybrid(const uint8_t* base, uint64_t off, uint64_t len, int bitw, uint
     if (!r.ok) return false;
     if (h & 1) {
       const uint64_t groups = h >> 1;
+      const uint64_t avail = (uint64_t)(r.end - r.p);
+      // `groups` is an untrusted 64-bit varint: groups * bitw and groups * 8 must not wrap (2^59 groups of 32 bits
+      // would wrap to 0 bytes and pass a length check). A stream of `avail` bytes holds at most avail * 8 values.
+      // (bit width 0 — a one-entry dictionary — carries no bytes; its run length is clamped to the values still missing.)
+      if (groups == 0 || groups > (UINT64_MAX / 64) || (bitw > 0 && groups > avail + 1)) return false;
       const uint64_t bytes = groups * (uint64_t)bitw;
       const uint64_t src0 = (uint64_t)(r.p - base);
-      if (groups == 0 || (uint64_t)(r.end - r.p) < bytes) {
-        // a writer may truncate the padding of the last group: accept if the bytes present cover the values needed
-        const uint64_t need_bits = (nvals - done) * (uint64_t)bitw;
-        if (groups == 0 || (uint64_t)(r.end - r.p) * 8 < need_bits) return false;
-      }
       uint64_t n = groups * 8;
       if (n > nvals - done) n = nvals - done;  // padding of the last group
+      // a writer may truncate the padding of the last group, but the bytes present must ALWAYS cover the n values that
+      // are emitted below (the device expands the items from these bytes without further checks)
+      if (n * (uint64_t)bitw > avail * 8) return false;
       if (ones) {
         // popcount of the first n bits (bit width 1)
         const uint8_t* q = base + src0;

@@ -78,6 +78,23 @@ class DeviceBuffer:
             pass
 
 
+class BorrowedBuffer:
+    """Non-owning view of HBM some other allocator of the same HIP context owns (e.g. a torch tensor's storage): the
+    DeviceBuffer surface (`ptr`, `nbytes`, `to_numpy`) without dbhip_alloc / dbhip_free. `keep` pins the owner."""
+
+    def __init__(self, ptr, nbytes, keep=None):
+        self.ptr, self.nbytes, self._keep = int(ptr), int(nbytes), keep
+
+    @classmethod
+    def of_tensor(cls, t):
+        return cls(t.data_ptr(), t.numel() * t.element_size(), keep=t)
+
+    to_numpy = DeviceBuffer.to_numpy
+
+    def free(self):
+        self._keep = None
+
+
 def pack_bits(bools):
     """bool array -> LSB-first Bitmap bytes (padded to a multiple of 8 bytes)."""
     bools = np.asarray(bools, dtype=bool)
@@ -477,20 +494,72 @@ class GroupBy:
                 (L.AGG_SUM, L.T_DEC128, 38, 6, 0), (L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_COUNT, 0, 0, 0, 0)]
         return cls([L.T_STRING, L.T_STRING], aggs, handle=h)
 
-    def add_block(self, keys, args, n):
+    def add_block(self, keys, args, n, filter=None, stream=None):
+        """AggregateHashTable::add_groups. `filter`: Boolean Column over the same (unfiltered) rows — the pushed-down
+        TransformFilter predicate (dbhip_groupby_add_block_filtered)."""
         ka = _cols(keys)
         aa = (Col * max(len(self.aggs), 1))()
         for i, a in enumerate(args):
             if a is not None:
                 aa[i] = a.c()
-        check(lib().dbhip_groupby_add_block(self.h, ka, aa, C.c_int64(n), None))
+        if filter is None:
+            check(lib().dbhip_groupby_add_block(self.h, ka, aa, C.c_int64(n), stream))
+        else:
+            check(lib().dbhip_groupby_add_block_filtered(self.h, ka, aa, C.c_int64(n), C.c_void_p(filter.data.ptr), C.c_int64(0), stream))
+
+    def state_fields(self):
+        """-> [(dbhip_type, aggregate index)] of the serialized-state block (dbhip_groupby_state_fields)."""
+        t, a, n = (C.c_int32 * 96)(), (C.c_int32 * 96)(), C.c_int32()
+        check(lib().dbhip_groupby_state_fields(self.h, t, a, 96, C.byref(n)))
+        return [(t[i], a[i]) for i in range(n.value)]
 
     def merge_state_block(self, keys, states, n):
-        """batch_merge of a serialized-state block [state columns..., group columns...] (payload_flush.rs:151-181)."""
-        aa = (Col * max(len(self.aggs), 1))()
+        """batch_merge of a serialized-state block [state fields..., group columns...] (payload_flush.rs:151-181)."""
+        aa = (Col * max(len(states), 1))()
         for i, a in enumerate(states):
             aa[i] = a.c()
         check(lib().dbhip_groupby_merge_state_block(self.h, _cols(keys), aa, C.c_int64(n), None))
+
+    def flush_state_block(self):
+        """Payload::aggregate_flush as HBM-resident Columns -> (key Columns, state field Columns)."""
+        g = self.num_groups()
+        cap = max(g, 1)
+        fields = self.state_fields()
+        key_bufs = [DeviceBuffer(cap * ELEM_SIZE.get(t, 1) + 64) for t in self.key_types]
+        key_val = [DeviceBuffer(((cap + 63) // 64) * 8 + 8) for _ in self.key_types]
+        fbufs = [DeviceBuffer((((cap + 63) // 64) * 8 + 8) if t == L.T_BOOL else cap * ELEM_SIZE[t] + 64) for t, _ in fields]
+        kp = (C.c_void_p * len(key_bufs))(*[b.ptr for b in key_bufs])
+        kv = (C.c_void_p * len(key_val))(*[b.ptr for b in key_val])
+        fp = (C.c_void_p * max(len(fbufs), 1))(*[b.ptr for b in fbufs])
+        n = C.c_int64()
+        check(lib().dbhip_groupby_flush_state_block(self.h, kp, kv, fp, None, C.c_int64(cap), C.byref(n), None))
+        n = n.value
+        keys = [Column(t, n, b, v if nul else None) for t, b, v, nul in zip(self.key_types, key_bufs, key_val, self.key_nullable)]
+        states = []
+        for (t, a), b in zip(fields, fbufs):
+            kind, at, p, sc, _nul = self.aggs[a]
+            prec, scale = (0, 0)
+            if t in (L.T_DEC64, L.T_DEC128):
+                prec, scale = ((18 if t == L.T_DEC64 else 38), sc) if kind == L.AGG_SUM else (p, sc)
+            states.append(Column(t, n, b, None, prec, scale))
+        return keys, states
+
+    def partition_blocks(self, blocks_ptr, n_buckets, max_rows, stream=None):
+        """dbhip_groupby_partition_blocks: rows routed to bucket hash % n_buckets, one fixed-size block per bucket."""
+        check(lib().dbhip_groupby_partition_blocks(self.h, C.c_int32(n_buckets), C.c_void_p(blocks_ptr), C.c_int64(max_rows), stream))
+
+    def replace_with_blocks(self, blocks_ptr, n_blocks, max_rows, stream=None):
+        check(lib().dbhip_groupby_replace_with_blocks(self.h, C.c_void_p(blocks_ptr), C.c_int32(n_blocks), C.c_int64(max_rows), stream))
+
+    def flush_partitioned(self, n_buckets, rows_ptr, max_rows, stream=None):
+        """-> counts[n_buckets]; the rows (grouped by bucket) are written to the device buffer at rows_ptr."""
+        cnt = (C.c_int64 * n_buckets)()
+        check(lib().dbhip_groupby_flush_partitioned(self.h, C.c_int32(n_buckets), C.c_void_p(rows_ptr), C.c_int64(max_rows), cnt, stream))
+        return [int(x) for x in cnt]
+
+    def merge_serialized_device(self, rows_ptr, n_rows, stream=None):
+        if n_rows:
+            check(lib().dbhip_groupby_merge_serialized(self.h, C.c_void_p(rows_ptr), C.c_int64(n_rows), stream))
 
     def num_groups(self):
         n = C.c_int64()
@@ -545,7 +614,9 @@ class GroupBy:
         kv = (C.c_void_p * len(key_val))(*[b.ptr for b in key_val])
         ap = (C.c_void_p * max(len(agg_bufs), 1))(*[b.ptr for b in agg_bufs])
         n = C.c_int64()
-        check(lib().dbhip_groupby_flush_result(self.h, kp, kv, ap, C.c_void_p(hashes.ptr), C.c_int64(cap), C.byref(n), None))
+        agg_val = [DeviceBuffer(((cap + 63) // 64) * 8 + 8) for _ in self.aggs]
+        av = (C.c_void_p * max(len(agg_val), 1))(*[b.ptr for b in agg_val])
+        check(lib().dbhip_groupby_flush_result_nullable(self.h, kp, kv, ap, av, C.c_void_p(hashes.ptr), C.c_int64(cap), C.byref(n), None))
         n = n.value
         cols = []
         for t, b, v in zip(self.key_types, key_bufs, key_val):
@@ -559,11 +630,15 @@ class GroupBy:
             else:
                 vals = b.to_numpy(NP_OF[t], n).tolist()
             cols.append([x if ok else None for x, ok in zip(vals, valid)])
-        for t, b in zip(agg_t, agg_bufs):
+        for t, b, a, v in zip(agg_t, agg_bufs, self.aggs, agg_val):
             if t == L.T_DEC128:
-                cols.append(bytes_to_i128(b.to_numpy(np.uint8, 16 * n)))
+                vals = bytes_to_i128(b.to_numpy(np.uint8, 16 * n))
             else:
-                cols.append(b.to_numpy(NP_OF[t], n).tolist())
+                vals = b.to_numpy(NP_OF[t], n).tolist()
+            if a[4] and a[0] != L.AGG_COUNT:  # nullable argument: NULL unless the group saw a non-NULL row
+                valid = unpack_bits(v.to_numpy(np.uint8, ((cap + 63) // 64) * 8), n)
+                vals = [x if ok else None for x, ok in zip(vals, valid)]
+            cols.append(vals)
         self.last_hashes = hashes.to_numpy(np.uint64, n)
         return [tuple(c[i] for c in cols) for i in range(n)]
 

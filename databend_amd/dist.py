@@ -144,6 +144,63 @@ def exchange_partials_nccl(table, dist, torch, stream=None, lib_sync=None):
                                     lib_sync=lib_sync, capacity_error=lambda e: isinstance(e, DbhipError) and e.code == ERR_CAPACITY)
 
 
+def exchange_partials_alltoall_device(table, dist, torch, device, max_rows=256, stream=None, lib_sync=None, capacity_error=None):
+    """Device-resident hash-partitioned exchange (BASELINE configs[3]; the RCCL analogue of the reference's
+    scatter by `hash % n` into the Flight exchange, payload.rs:548-589 + aggregate_exchange_injector.rs:57-147):
+    the table routes every group row to bucket hash % world on the device (dbhip_groupby_partition_blocks: `world`
+    fixed-size blocks, no host synchronisation), ONE all_to_all_single with equal splits moves block r to rank r, and
+    the receiver replaces its table with the merge of the blocks it got (dbhip_groupby_replace_with_blocks). Afterwards
+    rank r holds exactly the groups with hash % world == r, each merged over all ranks. No row crosses PCIe.
+    A sender that overflowed `max_rows` flags it in ALL its blocks, so every rank sees the same flags and all take the
+    variable-length path together (`capacity_error(exc)` recognises the report)."""
+    world = dist.get_world_size()
+    W = table.row_bytes() // 8
+    send = torch.empty((world * (max_rows + 1), W), dtype=torch.int64, device=device)
+    table.partition_blocks(send.data_ptr(), world, max_rows, stream)
+    if stream is None and lib_sync is not None:
+        lib_sync()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    if stream is None and device.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    try:
+        table.replace_with_blocks(recv.data_ptr(), world, max_rows, stream)
+    except Exception as e:  # noqa: BLE001 — only the overflow report is handled, everything else propagates
+        if capacity_error is None or not capacity_error(e):
+            raise
+        return exchange_partials_alltoall_variable(table, dist, torch, device, stream=stream, lib_sync=lib_sync)
+    return table
+
+
+def exchange_partials_alltoall_variable(table, dist, torch, device, stream=None, lib_sync=None):
+    """High-cardinality form of the same exchange: rows grouped by destination on the device
+    (dbhip_groupby_flush_partitioned -> the split sizes), one all_to_all_single for the counts and one for the rows, both on
+    device tensors; the received rows are merged straight from the receive buffer."""
+    world = dist.get_world_size()
+    W = table.row_bytes() // 8
+    g = table.num_groups()
+    send = torch.empty((max(g, 1), W), dtype=torch.int64, device=device)
+    counts = table.flush_partitioned(world, send.data_ptr(), g, stream)   # synchronises: the counts are host values
+    send_cnt = torch.tensor(counts, dtype=torch.int64, device=device)
+    recv_cnt = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv_cnt, send_cnt)
+    rc = [int(x) for x in recv_cnt.tolist()]
+    recv = torch.empty((max(sum(rc), 1), W), dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv[: sum(rc)], send[: sum(counts)], output_split_sizes=rc, input_split_sizes=counts)
+    if device.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    table.reset(stream)
+    table.merge_serialized_device(recv.data_ptr(), sum(rc), stream)
+    return table
+
+
+def exchange_partials_alltoall_nccl(table, dist, torch, stream=None, lib_sync=None, max_rows=256):
+    from ._lib import DbhipError, ERR_CAPACITY
+    return exchange_partials_alltoall_device(table, dist, torch, torch.device("cuda", torch.cuda.current_device()), max_rows=max_rows,
+                                             stream=stream, lib_sync=lib_sync,
+                                             capacity_error=lambda e: isinstance(e, DbhipError) and e.code == ERR_CAPACITY)
+
+
 def merge_shard_topk(idx, dst, row_offset, k, dist, torch, device, merge_fn):
     """ANN over a row-range sharded base: queries are replicated, every rank searched its shard and
     holds `idx` (u32 local row ids, 0xFFFFFFFF = empty) / `dst` (f32) of shape [nq, k]. One all-gather of the

@@ -77,6 +77,79 @@ class LineitemDevice:
         self.ship = D.Column.from_numpy(host["l_shipdate"], L.T_DATE)
 
 
+class LineitemTorch:
+    """lineitem generated ON THE DEVICE (torch is plumbing: an SF100 shard is 600 M rows / 40.8 GB — numpy generation plus
+    a pageable upload would take minutes). Same column definitions and the same dbgen correlation as gen_lineitem, drawn
+    from torch's Philox generator (seeded per 2^26-row chunk: the data of a row range does not depend on how many rows
+    the shard has); columns are handed to the library as raw device pointers. `host(lo, hi)` copies a row range back in
+    gen_lineitem's dict layout (CPU baseline sample / full-size check in chunks)."""
+
+    CHUNK = 1 << 26
+
+    def __init__(self, n, seed=2, torch=None, device=None, row0=0):
+        import torch as _torch
+        torch = torch or _torch
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.n, self.torch = int(n), torch
+        i64, i32 = torch.int64, torch.int32
+        self.t_qty, self.t_price = torch.empty(n, dtype=i64, device=dev), torch.empty(n, dtype=i64, device=dev)
+        self.t_disc, self.t_tax = torch.empty(n, dtype=i64, device=dev), torch.empty(n, dtype=i64, device=dev)
+        self.t_ship = torch.empty(n, dtype=i32, device=dev)
+        self.t_rf, self.t_ls = torch.zeros((n, 2), dtype=i64, device=dev), torch.zeros((n, 2), dtype=i64, device=dev)
+        g = torch.Generator(device=dev)
+        first = row0 // self.CHUNK
+        for c in range(first, (row0 + n + self.CHUNK - 1) // self.CHUNK):
+            # chunk c covers GLOBAL rows [c * CHUNK, (c + 1) * CHUNK); a shard takes the part that falls into its range
+            g.manual_seed(seed * 1_000_003 + c)
+            m = self.CHUNK
+            qty = torch.randint(1, 51, (m,), generator=g, device=dev, dtype=i64) * 100
+            price = torch.randint(90000, 10494951, (m,), generator=g, device=dev, dtype=i64)
+            disc = torch.randint(0, 11, (m,), generator=g, device=dev, dtype=i64)
+            tax = torch.randint(0, 9, (m,), generator=g, device=dev, dtype=i64)
+            ship = torch.randint(SHIP_LO, SHIP_HI + 1, (m,), generator=g, device=dev, dtype=i32)
+            receipt = ship + torch.randint(1, 31, (m,), generator=g, device=dev, dtype=i32)
+            ar = torch.where(torch.randint(0, 2, (m,), generator=g, device=dev, dtype=i32) == 0, ord("A"), ord("R"))
+            rf = torch.where(receipt <= CURRENT, ar, ord("N")).to(i64)
+            ls = torch.where(ship > CURRENT, ord("O"), ord("F")).to(i64)
+            g0 = c * self.CHUNK
+            lo, hi = max(g0, row0), min(g0 + m, row0 + n)
+            a, b, d0, d1 = lo - g0, hi - g0, lo - row0, hi - row0
+            self.t_qty[d0:d1], self.t_price[d0:d1], self.t_disc[d0:d1], self.t_tax[d0:d1] = qty[a:b], price[a:b], disc[a:b], tax[a:b]
+            self.t_ship[d0:d1] = ship[a:b]
+            # 16-byte inline view {len = 1, 'X', 0...} as two little-endian u64 words
+            self.t_rf[d0:d1, 0] = (rf[a:b] << 32) | 1
+            self.t_ls[d0:d1, 0] = (ls[a:b] << 32) | 1
+            del qty, price, disc, tax, ship, receipt, ar, rf, ls
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dec = dict(precision=15, scale=2)
+        B = D.BorrowedBuffer.of_tensor
+        self.qty, self.price = D.Column(L.T_DEC64, n, B(self.t_qty), **dec), D.Column(L.T_DEC64, n, B(self.t_price), **dec)
+        self.disc, self.tax = D.Column(L.T_DEC64, n, B(self.t_disc), **dec), D.Column(L.T_DEC64, n, B(self.t_tax), **dec)
+        self.rf, self.ls = D.Column(L.T_STRING, n, B(self.t_rf)), D.Column(L.T_STRING, n, B(self.t_ls))
+        self.ship = D.Column(L.T_DATE, n, B(self.t_ship))
+
+    def host(self, lo=0, hi=None):
+        hi = self.n if hi is None else hi
+        f = lambda t: t[lo:hi].cpu().numpy()  # noqa: E731
+        return {"l_quantity": f(self.t_qty), "l_extendedprice": f(self.t_price), "l_discount": f(self.t_disc), "l_tax": f(self.t_tax),
+                "l_returnflag": f(self.t_rf).view(np.uint8).reshape(-1, 16), "l_linestatus": f(self.t_ls).view(np.uint8).reshape(-1, 16),
+                "l_shipdate": f(self.t_ship)}
+
+    def slice(self, lo, hi):
+        """zero-copy row range [lo, hi) as a lineitem with the LineitemDevice surface (lo must keep 16-byte alignment)"""
+        assert lo % 4 == 0
+        class _S:
+            pass
+        s = _S()
+        s.n = hi - lo
+        for name in ("qty", "price", "disc", "tax", "rf", "ls", "ship"):
+            c = getattr(self, name)
+            es = D.ELEM_SIZE[c.dtype]
+            setattr(s, name, D.Column(c.dtype, hi - lo, D.BorrowedBuffer(c.data.ptr + lo * es, (hi - lo) * es, keep=self), precision=c.precision, scale=c.scale))
+        return s
+
+
 def q1_fused(li, g=None, cutoff=Q1_CUTOFF):
     """One fused kernel + merge (dbhip_q1_fused)."""
     g = g or D.GroupBy.q1()
@@ -98,6 +171,23 @@ def q1_operator_at_a_time(li, g=None, cutoff=Q1_CUTOFF):
     one_plus = D.decimal_arith(L.OP_PLUS, one, tax, k)                # Decimal(16,2)
     charge = D.decimal_arith(L.OP_MULTIPLY, disc_price, one_plus, k)  # Decimal(38,6)
     g.add_block([rf, ls], [qty, price, disc_price, charge, disc, None], k)
+    return g
+
+
+def q1_operator_pushdown(li, g=None, cutoff=Q1_CUTOFF):
+    """The same operators with the filter pushed down into the aggregate: the predicate stays a Bitmap, the decimal
+    maps and the partial aggregation read the UNFILTERED columns (dbhip_groupby_add_block_filtered) — no selection
+    vector, no take of six columns. Same result: rows that fail the predicate never reach a state, and the maps raise
+    no row errors on Q1's value ranges (a binding that cannot prove that keeps the literal plan)."""
+    g = g or D.GroupBy.q1()
+    n = li.n
+    pred = D.cmp(L.CMP_LTE, li.ship, D.Column.scalar(cutoff, L.T_DATE), n)
+    one = D.Column.scalar(1, L.T_U8)
+    one_minus = D.decimal_arith(L.OP_MINUS, one, li.disc, n)            # Decimal(16,2)
+    disc_price = D.decimal_arith(L.OP_MULTIPLY, li.price, one_minus, n)  # Decimal(31,4)
+    one_plus = D.decimal_arith(L.OP_PLUS, one, li.tax, n)                # Decimal(16,2)
+    charge = D.decimal_arith(L.OP_MULTIPLY, disc_price, one_plus, n)     # Decimal(38,6)
+    g.add_block([li.rf, li.ls], [li.qty, li.price, disc_price, charge, li.disc, None], n, filter=pred)
     return g
 
 

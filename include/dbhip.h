@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DBHIP_ABI_VERSION 1
+#define DBHIP_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -261,14 +261,15 @@ typedef enum {
   DBHIP_AGG_SUM = 1,         /* sum: i64/u64 wrapping, f64, DEC64->i64 wrapping,
                                 DEC128 -> i128 with overflow check when arg precision>18
                                 (aggregate_sum.rs:51-300,386-441)                    */
-  DBHIP_AGG_MIN = 2, DBHIP_AGG_MAX = 3
+  DBHIP_AGG_MIN = 2, DBHIP_AGG_MAX = 3  /* fixed-width arguments up to 8 bytes; Decimal128 / String: DBHIP_ERR_UNSUPPORTED */
 } dbhip_agg_kind;
 
 typedef struct {
   int32_t kind;       /* dbhip_agg_kind                                            */
   int32_t arg_type;   /* dbhip_type of the argument (ignored for count(*))         */
   uint8_t arg_precision, arg_scale; /* decimals                                    */
-  uint8_t arg_nullable;             /* count(col)/sum(col) skip NULL rows          */
+  uint8_t arg_nullable;             /* NULL rows are skipped; sum/min/max then carry a "seen a value" flag and
+                                       yield NULL for all-NULL groups (flush_result_nullable)          */
   uint8_t _pad;
 } dbhip_agg_desc;
 
@@ -284,6 +285,14 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
  * factor 1/1.35 (mod.rs:55) would be exceeded. */
 int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
                                 int64_t n, void* stream);
+/* The same with the TransformFilter in front of the aggregate pushed down (filter/filter_executor.rs:81-118 produces a
+ * selection that DataBlock::take then applies to every column): `filter_bitmap` (LSB-first, read from bit
+ * `filter_bit_offset`, NULL = every row) is the predicate's Bitmap over the UNFILTERED block; rows whose bit is 0 do not
+ * take part. Keys and arguments are the unfiltered columns: nothing is compacted or copied. Result == add_block on the
+ * taken columns. */
+int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
+                                         int64_t n, const uint8_t* filter_bitmap, int64_t filter_bit_offset,
+                                         void* stream);
 /* combine_payload (:349-380): merge serialized partial states (as produced by
  * dbhip_groupby_flush_serialized on any rank) into this table. */
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows,
@@ -305,6 +314,25 @@ int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int
 int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t max_rows, void* stream);
 int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks,
                                    int64_t max_rows, int32_t skip_block, void* stream);
+/* a12 — hash partitioning of the table's group rows for the exchange / final merge: the device twin of
+ * Payload::scan_hash_partition_transfer (payload.rs:548-589: bucket = group hash % bucket count, strength-reduced there)
+ * and PartitionedPayload::repartition (partitioned_payload.rs:204-240). The unit is the serialized row
+ * (dbhip_groupby_row_bytes).
+ *   partition_blocks   n_buckets fixed-size blocks back to back in `out_blocks_dev`, each (max_rows + 1) rows: row 0 =
+ *                      header (u64 word 0 = rows that follow, ~0 = more than max_rows; word 1 = 1 when ANY block of
+ *                      this table overflowed), rows 1.. = the bucket's rows. No host synchronisation: one
+ *                      all_to_all_single with equal splits can follow on the same stream.
+ *   replace_with_blocks  the receiving side: checks the n_blocks headers (returns DBHIP_ERR_CAPACITY before touching
+ *                      the table if any sender overflowed — every rank sees the same flags), then RESETS the table and
+ *                      merges all blocks: the rank now holds exactly the groups with hash % world == rank.
+ *   flush_partitioned  variable-length form: all rows grouped by bucket, bucket b = rows [sum(counts[0..b)),
+ *                      +counts[b]) of out_rows_dev; out_counts_host[n_buckets] (the all-to-all split sizes). */
+int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void* out_blocks_dev, int64_t max_rows,
+                                       void* stream);
+int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows,
+                                          void* stream);
+int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, void* out_rows_dev, int64_t max_rows,
+                                        int64_t* out_counts_host, void* stream);
 /* merge_result (:382-408): final values as columns. out_keys[i]/out_aggs[i] are
  * device buffers of max_rows elements of the key / result type
  * (dbhip_groupby_result_type). Returns DBHIP_ERR_OVERFLOW if a checked decimal
@@ -315,13 +343,29 @@ int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
                                    uint8_t* const* out_key_validity_host,
                                    void* const* out_aggs_host, uint64_t* out_hashes,
                                    int64_t max_rows, int64_t* out_n_rows_host, void* stream);
-/* Merge a serialized-state BLOCK, columns [state columns..., group columns...] exactly as
- * Payload::aggregate_flush emits it (payload_flush.rs:151-181; sum: the running value in its result
- * type, count: u64) — the reference's TransformDeserializer + AggregateFunction::batch_merge
- * (aggregator/serde/transform_deserializer.rs; aggregate_sum.rs:170-181,300-312). Together with
- * dbhip_groupby_flush_result (which produces that block) this lets a device partial aggregate feed the
- * unmodified CPU final stage / Flight exchange and vice versa. min/max: DBHIP_ERR_UNSUPPORTED (use
- * the serialized rows). */
+/* The same with a validity bitmap per aggregate (out_agg_validity_host[i], LSB-first, ceil(max_rows/64)*8 bytes, may be
+ * NULL): sum / min / max over a NULLABLE argument are NULL for a group whose argument was NULL in every row
+ * (AggregateNullUnaryAdaptor<true>, adaptors/aggregate_null_adaptor.rs:366-400); count is never NULL. */
+int32_t dbhip_groupby_flush_result_nullable(dbhip_groupby* g, void* const* out_keys_host,
+                                            uint8_t* const* out_key_validity_host,
+                                            void* const* out_aggs_host, uint8_t* const* out_agg_validity_host,
+                                            uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host,
+                                            void* stream);
+/* §8f-1 — the serialized-state block of Payload::aggregate_flush (payload_flush.rs:151-181): per aggregate the fields
+ * of its serialize_type(), flattened in aggregate order, then the group columns:
+ *   count                         [UInt64]                                   (aggregate_count.rs:170-186)
+ *   sum                           [result type: Int64/UInt64/Float64/Decimal] (aggregate_sum.rs:155-168,281-298)
+ *   min / max                     [Boolean has-value][T value, default if none] (aggregate_min_max_any.rs:315-346)
+ *   sum/min/max, NULLABLE argument: the fields above + a trailing [Boolean flag]  (aggregate_null_adaptor.rs:508-540)
+ * Boolean fields are LSB-first bitmaps of ceil(max_rows/64)*8 bytes. dbhip_groupby_state_fields lists the fields of a
+ * table (type and owning aggregate). flush_state_block writes the block (a device partial aggregate feeding the
+ * UNMODIFIED CPU final stage / Flight exchange); merge_state_block consumes one (TransformDeserializer +
+ * AggregateFunction::batch_merge, aggregator/serde/transform_deserializer.rs) — `states` = the flattened fields. */
+int32_t dbhip_groupby_state_fields(dbhip_groupby* g, int32_t* out_types_host, int32_t* out_agg_index_host,
+                                   int32_t max_fields, int32_t* out_n_fields_host);
+int32_t dbhip_groupby_flush_state_block(dbhip_groupby* g, void* const* out_keys_host,
+                                        uint8_t* const* out_key_validity_host, void* const* out_state_fields_host,
+                                        uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host, void* stream);
 int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
                                         int64_t n, void* stream);
 int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream);

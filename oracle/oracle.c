@@ -588,8 +588,16 @@ static int rowformat_size(int t) { /* payload_row.rs:51-83 */
     default: return t_size(t);
   }
 }
+/* sum over a Nullable argument is wrapped in AggregateNullUnaryAdaptor<true> (adaptors/aggregate_null_adaptor.rs:366-400):
+ * the nested state is followed by one flag byte "a non-NULL row was seen" (here: 8 / 16 bytes to keep alignment);
+ * merge_result yields NULL while the flag is clear. For min/max the Option's has-value word plays that role. */
+static int agg_flag_off(const orc_agg_desc* d) { /* 0 = no flag */
+  if (d->kind != ORC_AGG_SUM || !d->arg_nullable) return 0;
+  return d->arg_type == ORC_T_DEC128 ? 16 : 8;
+}
 static int agg_state_size(const orc_agg_desc* d) {
-  if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return 16;
+  if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return d->arg_nullable ? 32 : 16;
+  if (d->kind == ORC_AGG_SUM && d->arg_nullable) return 16; /* value + flag */
   if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return 16; /* value + has flag */
   return 8;
 }
@@ -726,6 +734,7 @@ static int state_add(const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int
     case ORC_AGG_COUNT: if (valid) { uint64_t c; memcpy(&c, st, 8); c++; memcpy(st, &c, 8); } return 0;
     case ORC_AGG_SUM:
       if (!valid) return 0;
+      if (agg_flag_off(d)) st[agg_flag_off(d)] = 1; /* set_flag(place, true), aggregate_null_adaptor.rs:447-452 */
       if (d->arg_type == ORC_T_DEC128) { /* DecimalSumState::add aggregate_sum.rs:203-216 */
         i128 s; memcpy(&s, st, 16);
         s = (i128)((u128)s + (u128)((const i128*)arg->data)[arg->is_scalar ? 0 : i]);
@@ -824,8 +833,15 @@ int64_t orc_hashagg_num_groups(orc_hashagg* h) { return (int64_t)h->nrows; }
 /* materialise the groups of `h` as columns (payload_flush.rs:50-240) */
 typedef struct { void* keys[MAXK]; uint8_t* valid[MAXK]; void* bufs[MAXK]; } flushed;
 
+int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* const* out_key_valid,
+                                void* const* out_aggs, uint8_t* const* out_agg_valid, uint64_t* out_hashes);
 int orc_hashagg_result(orc_hashagg* h, void* const* out_keys, uint8_t* const* out_key_valid,
                        void* const* out_aggs, uint64_t* out_hashes) {
+  return orc_hashagg_result_nullable(h, out_keys, out_key_valid, out_aggs, NULL, out_hashes);
+}
+/* out_agg_valid[a] (one byte per group, may be NULL): 0 where sum/min/max over a Nullable argument is NULL */
+int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* const* out_key_valid,
+                                void* const* out_aggs, uint8_t* const* out_agg_valid, uint64_t* out_hashes) {
   int rc = 0;
   for (size_t r = 0; r < h->nrows; ++r) {
     const uint8_t* row = h->rows + r * h->tuple_size;
@@ -847,9 +863,15 @@ int orc_hashagg_result(orc_hashagg* h, void* const* out_keys, uint8_t* const* ou
     if (!h->naggs) continue;
     uint64_t soff; memcpy(&soff, row + h->state_ptr_off, 8);
     for (int a = 0; a < h->naggs; ++a) {
-      if (!out_aggs || !out_aggs[a]) continue;
       const uint8_t* st = h->states + soff + h->state_off[a];
       const orc_agg_desc* d = &h->aggs[a];
+      if (out_agg_valid && out_agg_valid[a]) {
+        uint8_t ok = 1;
+        if (agg_flag_off(d)) ok = st[agg_flag_off(d)];
+        else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_nullable) { uint64_t hs; memcpy(&hs, st + 8, 8); ok = hs != 0; }
+        out_agg_valid[a][r] = ok;
+      }
+      if (!out_aggs || !out_aggs[a]) continue;
       if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16);
       else if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) {
         int sz = t_size(d->arg_type);
@@ -937,6 +959,10 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
         const orc_agg_desc* ad = &dst->aggs[a];
         if (ad->kind == ORC_AGG_COUNT) { uint64_t x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
         else if (ad->kind == ORC_AGG_SUM) {
+          if (agg_flag_off(ad)) { /* merge_states of the adaptor (aggregate_null_adaptor.rs:613-622): nothing to do while rhs saw no value */
+            if (!sp[agg_flag_off(ad)]) continue;
+            d[agg_flag_off(ad)] = 1;
+          }
           if (ad->arg_type == ORC_T_DEC128) { /* DecimalSumState::merge -> add (with the overflow check) */
             i128 x, y; memcpy(&x, d, 16); memcpy(&y, sp, 16); x = (i128)((u128)x + (u128)y); memcpy(d, &x, 16);
             i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;
@@ -953,6 +979,135 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
     }
   }
   for (int k = 0; k < src->nkeys; ++k) { free(kb[k]); free(kv[k]); free(kbits[k]); }
+  return rc;
+}
+
+/* ---- serialized-state block: Payload::aggregate_flush (payload_flush.rs:151-181) ----------------------------------
+ * entries = per aggregate the columns of its serialize_type() (a Tuple builder per aggregate: flattened here), then the
+ * group columns. serialize_type / batch_serialize / batch_merge per function:
+ *   count   [UInt64]                         aggregate_count.rs:170-213
+ *   sum     [result type]                    aggregate_sum.rs:155-181 (numbers), :281-312 (decimal)
+ *   min/max [Boolean, T] = Option<T>         aggregate_min_max_any.rs:315-367 (value = default when None)
+ *   Nullable argument (sum/min/max): nested fields + trailing Boolean flag   aggregate_null_adaptor.rs:508-600 */
+static int sum_result_type(int t) {
+  switch (t) {
+    case ORC_T_I8: case ORC_T_I16: case ORC_T_I32: case ORC_T_I64: return ORC_T_I64;
+    case ORC_T_U8: case ORC_T_U16: case ORC_T_U32: case ORC_T_U64: return ORC_T_U64;
+    case ORC_T_F32: case ORC_T_F64: return ORC_T_F64;
+    default: return t; /* decimals keep their storage class */
+  }
+}
+int orc_hashagg_state_fields(orc_hashagg* h, int32_t* types, int32_t* agg_of) {
+  int f = 0;
+  for (int a = 0; a < h->naggs; ++a) {
+    const orc_agg_desc* d = &h->aggs[a];
+#define PUT(T) do { if (types) types[f] = (T); if (agg_of) agg_of[f] = a; ++f; } while (0)
+    if (d->kind == ORC_AGG_COUNT) PUT(ORC_T_U64);
+    else if (d->kind == ORC_AGG_SUM) { PUT(sum_result_type(d->arg_type)); if (d->arg_nullable) PUT(ORC_T_BOOL); }
+    else { PUT(ORC_T_BOOL); PUT(d->arg_type); if (d->arg_nullable) PUT(ORC_T_BOOL); }
+#undef PUT
+  }
+  return f;
+}
+/* out_fields[f]: n elements of the field's type; Boolean fields ONE BYTE per row (0 / 1). Keys / validity / hashes as
+ * orc_hashagg_result. Row order = payload order. */
+int orc_hashagg_flush_state_block(orc_hashagg* h, void* const* out_keys, uint8_t* const* out_key_valid,
+                                  void* const* out_fields, uint64_t* out_hashes) {
+  int rc = orc_hashagg_result(h, out_keys, out_key_valid, NULL, out_hashes);
+  for (size_t r = 0; r < h->nrows; ++r) {
+    uint64_t soff; memcpy(&soff, h->rows + r * h->tuple_size + h->state_ptr_off, 8);
+    int f = 0;
+    for (int a = 0; a < h->naggs; ++a) {
+      const orc_agg_desc* d = &h->aggs[a];
+      const uint8_t* st = h->states + soff + h->state_off[a];
+      if (d->kind == ORC_AGG_COUNT) { memcpy((uint8_t*)out_fields[f] + 8 * r, st, 8); ++f; }
+      else if (d->kind == ORC_AGG_SUM) {
+        if (d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_fields[f] + 16 * r, st, 16); else memcpy((uint8_t*)out_fields[f] + 8 * r, st, 8);
+        ++f;
+        if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = st[agg_flag_off(d)]; ++f; }
+      } else {
+        uint64_t hs; memcpy(&hs, st + 8, 8);
+        ((uint8_t*)out_fields[f])[r] = hs != 0; ++f;
+        val v; memset(&v, 0, sizeof v); v.cls = t_cls(d->arg_type);
+        if (hs) { if (v.cls == 2) memcpy(&v.f, st, 8); else if (v.cls == 0) memcpy(&v.i, st, 8); else memcpy(&v.u, st, 8); } /* else push_default() */
+        store_val(out_fields[f], d->arg_type, (int64_t)r, v); ++f;
+        if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = hs != 0; ++f; }
+      }
+    }
+  }
+  return rc;
+}
+/* TransformDeserializer + batch_merge: probe / create the block's groups (probe_and_create, no accumulation), then
+ * merge every field column into the states. `fields[f]`: orc_col of the field's type; Boolean fields are LSB-first
+ * bitmaps (ORC_T_BOOL columns). */
+int orc_hashagg_merge_state_block(orc_hashagg* h, const orc_col* keys, const orc_col* fields, int64_t n) {
+  int rc = 0;
+  for (int64_t s0 = 0; s0 < n; s0 += BATCH_SIZE) {
+    size_t m = (size_t)(n - s0 < BATCH_SIZE ? n - s0 : BATCH_SIZE);
+    static __thread uint64_t hashes[BATCH_SIZE];
+    static __thread size_t slots[BATCH_SIZE], addrs[BATCH_SIZE];
+    static __thread int no_match[BATCH_SIZE], empty_v[BATCH_SIZE], cmp_v[BATCH_SIZE];
+    for (int k = 0; k < h->nkeys; ++k)
+      for (size_t r = 0; r < m; ++r) {
+        uint64_t hv = hash_col_row(&keys[k], s0 + (int64_t)r);
+        hashes[r] = k == 0 ? hv : (hashes[r] * NULL_HASH_VAL ^ hv);
+      }
+    if (m + h->count > (size_t)((double)h->capacity / LOAD_FACTOR)) {
+      size_t nc = h->resize_count < 4 ? h->capacity * 4 : h->capacity * 2; h->resize_count++; resize_index(h, nc);
+    }
+    for (size_t r = 0; r < m; ++r) { no_match[r] = (int)r; slots[r] = hashes[r] & h->mask; }
+    size_t remaining = m;
+    while (remaining > 0) {
+      int n_new = 0, n_cmp = 0, n_nomatch = 0;
+      for (size_t t = 0; t < remaining; ++t) {
+        int row = no_match[t], is_new;
+        slots[row] = find_or_insert(h, slots[row], hashes[row], &is_new);
+        if (is_new) empty_v[n_new++] = row; else cmp_v[n_cmp++] = row;
+      }
+      for (int t = 0; t < n_new; ++t) {
+        int row = empty_v[t];
+        addrs[row] = (size_t)(uintptr_t)append_row(h, keys, s0 + row, hashes[row]);
+        h->pointers[slots[row]] = (uint8_t*)(uintptr_t)addrs[row];
+      }
+      for (int t = 0; t < n_cmp; ++t) {
+        int row = cmp_v[t];
+        addrs[row] = (size_t)(uintptr_t)h->pointers[slots[row]];
+        if (!row_match(h, h->rows + (addrs[row] - 1) * h->tuple_size, keys, s0 + row)) no_match[n_nomatch++] = row;
+      }
+      for (int t = 0; t < n_nomatch; ++t) slots[no_match[t]] = (slots[no_match[t]] + 1) & h->mask;
+      h->count += (size_t)n_new;
+      remaining = (size_t)n_nomatch;
+    }
+    for (size_t r = 0; r < m; ++r) {
+      const int64_t i = s0 + (int64_t)r;
+      uint64_t so_d; memcpy(&so_d, h->rows + (addrs[r] - 1) * h->tuple_size + h->state_ptr_off, 8);
+      int f = 0;
+      for (int a = 0; a < h->naggs; ++a) {
+        uint8_t* d = h->states + so_d + h->state_off[a];
+        const orc_agg_desc* ad = &h->aggs[a];
+        if (ad->kind == ORC_AGG_COUNT) { /* aggregate_count.rs:188-213: count += other */
+          uint64_t x; memcpy(&x, d, 8); x += ((const uint64_t*)fields[f].data)[fields[f].is_scalar ? 0 : i]; memcpy(d, &x, 8); ++f;
+        } else if (ad->kind == ORC_AGG_SUM) {
+          const orc_col* vf = &fields[f]; ++f;
+          int seen = 1;
+          if (ad->arg_nullable) { seen = bit_get((const uint8_t*)fields[f].data, fields[f].is_scalar ? 0 : i); ++f; }
+          if (!seen) continue; /* the adaptor's batch_merge filters the nested merge on the flag (:542-575) */
+          if (agg_flag_off(ad)) d[agg_flag_off(ad)] = 1;
+          int64_t j = vf->is_scalar ? 0 : i;
+          if (ad->arg_type == ORC_T_DEC128) { /* DecimalSumState batch_merge -> merge -> add with the overflow check */
+            i128 x, y; memcpy(&x, d, 16); memcpy(&y, (const uint8_t*)vf->data + 16 * j, 16); x = (i128)((u128)x + (u128)y); memcpy(d, &x, 16);
+            i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;
+          } else if (t_cls(ad->arg_type) == 2) { double x, y; memcpy(&x, d, 8); memcpy(&y, (const uint8_t*)vf->data + 8 * j, 8); x += y; memcpy(d, &x, 8); }
+          else { uint64_t x, y; memcpy(&x, d, 8); memcpy(&y, (const uint8_t*)vf->data + 8 * j, 8); x += y; memcpy(d, &x, 8); }
+        } else { /* MinMaxAnyState batch_merge2: rhs = flag.then_some(value); state.merge(rhs) */
+          int has = bit_get((const uint8_t*)fields[f].data, fields[f].is_scalar ? 0 : i); ++f;
+          const orc_col* vf = &fields[f]; ++f;
+          if (ad->arg_nullable) { has = has && bit_get((const uint8_t*)fields[f].data, fields[f].is_scalar ? 0 : i); ++f; }
+          if (has) { orc_col tmp = *vf; tmp.validity = NULL; state_add(ad, d, &tmp, i); }
+        }
+      }
+    }
+  }
   return rc;
 }
 

@@ -46,7 +46,7 @@ class HostTable:
             rows[i] = (k & M64, mix(k), s[0], s[1])
         return rows
 
-    def reset(self):
+    def reset(self, stream=None):
         self.groups = {}
 
     def merge_serialized(self, rows):
@@ -78,11 +78,47 @@ class HostTable:
 
     def merge_blocks(self, ptr, n_blocks, max_rows, skip, stream=None):
         blocks = self._view(ptr, n_blocks * (max_rows + 1) * W).reshape(n_blocks, max_rows + 1, W)
-        if any(int(blocks[b, 0, 0]) == M64 for b in range(n_blocks) if b != skip):
+        # every header counts, the caller's own block included (dbhip_groupby_merge_blocks): the owner of an overflowed
+        # block must leave the fixed-size path together with the ranks that see its header
+        if any(int(blocks[b, 0, 0]) == M64 for b in range(n_blocks)):
             raise OverflowError("block overflow")   # decided before the table is touched
         for b in range(n_blocks):
             if b != skip:
                 self.merge_serialized(blocks[b, 1:1 + int(blocks[b, 0, 0])])
+
+    # --- dbhip_groupby_partition_blocks / replace_with_blocks / flush_partitioned on host memory ---
+    def num_groups(self):
+        return len(self.groups)
+
+    def partition_blocks(self, ptr, n_buckets, max_rows, stream=None):
+        blocks = self._view(ptr, n_buckets * (max_rows + 1) * W).reshape(n_buckets, max_rows + 1, W)
+        parts = DX.route_rows_by_hash(self.flush_serialized(), HASH_WORD, n_buckets)
+        over = any(p.shape[0] > max_rows for p in parts)
+        for b, p in enumerate(parts):
+            blocks[b, 0] = 0
+            blocks[b, 0, 0] = M64 if p.shape[0] > max_rows else p.shape[0]
+            blocks[b, 0, 1] = 1 if over else 0
+            if p.shape[0] <= max_rows:
+                blocks[b, 1:1 + p.shape[0]] = p
+
+    def replace_with_blocks(self, ptr, n_blocks, max_rows, stream=None):
+        blocks = self._view(ptr, n_blocks * (max_rows + 1) * W).reshape(n_blocks, max_rows + 1, W)
+        if any(int(blocks[b, 0, 0]) == M64 or int(blocks[b, 0, 1]) != 0 for b in range(n_blocks)):
+            raise OverflowError("block overflow")   # decided before the table is touched
+        self.reset()
+        for b in range(n_blocks):
+            self.merge_serialized(blocks[b, 1:1 + int(blocks[b, 0, 0])])
+
+    def flush_partitioned(self, n_buckets, ptr, max_rows, stream=None):
+        parts = DX.route_rows_by_hash(self.flush_serialized(), HASH_WORD, n_buckets)
+        allrows = np.concatenate(parts, axis=0)
+        if allrows.shape[0]:
+            self._view(ptr, allrows.shape[0] * W).reshape(-1, W)[:] = allrows
+        return [p.shape[0] for p in parts]
+
+    def merge_serialized_device(self, ptr, n_rows, stream=None):
+        if n_rows:
+            self.merge_serialized(self._view(ptr, n_rows * W).reshape(n_rows, W).copy())
 
 
 def shard(rank, world, n, card, seed):
@@ -104,6 +140,16 @@ def worker(rank, world, port, mode, n, card, q):
         if mode == "fixed":
             DX.exchange_partials_fixed(t, dist, torch, torch.device("cpu"), max_rows=64)
         elif mode == "device":
+            DX.exchange_partials_device(t, dist, torch, torch.device("cpu"), max_rows=64,
+                                        capacity_error=lambda e: isinstance(e, OverflowError))
+        elif mode == "alltoall_device":
+            DX.exchange_partials_alltoall_device(t, dist, torch, torch.device("cpu"), max_rows=64,
+                                                 capacity_error=lambda e: isinstance(e, OverflowError))
+        elif mode == "device_asym":
+            # asymmetric cardinality: only rank 0 overflows the 64-row block — BOTH ranks must leave the fixed-size path
+            if rank == 1:
+                t.reset()
+                t.add(np.arange(5, dtype=np.int64), np.arange(5, dtype=np.int64))
             DX.exchange_partials_device(t, dist, torch, torch.device("cpu"), max_rows=64,
                                         capacity_error=lambda e: isinstance(e, OverflowError))
         else:
@@ -173,6 +219,44 @@ def test_alltoall_exchange_partitions_groups_by_hash(n, card):
     assert not (set(got[0]) & set(got[1]))
     merged.update(got[1])
     assert merged == exp
+
+
+@pytest.mark.parametrize("n,card", [(5000, 4), (20000, 3000), (10, 1), (3000, 100)])
+def test_device_alltoall_exchange_protocol(n, card):
+    """bench.py --gpus N --exchange alltoall: partition_blocks -> ONE all_to_all_single of equal blocks ->
+    replace_with_blocks; 3000 groups overflow the 64-row blocks, every rank sees the senders' flags and takes the
+    variable-length all-to-all (flush_partitioned -> counts -> rows) in the same step."""
+    got, exp = run("alltoall_device", n, card)
+    for r in (0, 1):
+        for k in got[r]:
+            assert mix(k) % 2 == r
+    assert not (set(got[0]) & set(got[1]))
+    merged = dict(got[0])
+    merged.update(got[1])
+    assert merged == exp
+
+
+def test_device_block_exchange_with_asymmetric_overflow():
+    """rank 0 holds 3000 groups (its block overflows), rank 1 holds 5. The owner of the overflowed block must
+    see the overflow in its OWN header and fall back together with rank 1 — otherwise rank 1 enters the all-gather of
+    the variable-length path alone and the job hangs."""
+    n, card = 20000, 3000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, "device_asym", n, card, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    keys, vals, lo, hi = shard(0, 2, n, card, 11)
+    full = HostTable()
+    full.add(keys[lo:hi], vals[lo:hi])
+    full.add(np.arange(5, dtype=np.int64), np.arange(5, dtype=np.int64))
+    exp = {k: tuple(v) for k, v in full.groups.items()}
+    assert got[0] == exp and got[1] == exp
 
 
 def test_route_rows_by_hash_is_a_partition():

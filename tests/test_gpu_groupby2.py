@@ -1,0 +1,356 @@
+"""GPU: round-2 additions to the hash-aggregation path, against the oracle through the C-ABI —
+pushed-down filter (add_block_filtered), the "seen a non-NULL row" flag of nullable sum/min/max, the serialized-state
+block in BOTH directions (device flush -> oracle merge, oracle flush -> device merge), and the device hash partitioning
+for the exchange (a12)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from databend_amd import _lib as T
+from databend_amd.device import ELEM_SIZE, NP_OF, make_views_general, pack_bits, unpack_bits
+from tests import oracle_lib as O
+from tests.test_gpu_parity import norm, oracle_groupby, oracle_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def mix(x):
+    M = (1 << 64) - 1
+    x &= M
+    x ^= x >> 32
+    x = (x * 0xD6E8FEB86659FD93) & M
+    x ^= x >> 32
+    x = (x * 0xD6E8FEB86659FD93) & M
+    x ^= x >> 32
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pushed-down filter
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,card,pbits,wide", [(1, 1, 0, False), (1000, 4, 0, False), (300_000, 4, 0, False), (300_000, 700, 0, False),
+                                               (300_000, 5000, 0, False), (400_000, 390_000, 0, False), (300_000, 5000, 6, False),
+                                               (300_000, 40, 4, True), (200_000, 150_000, 0, True), (100_000, 1000, 10, True)])
+@pytest.mark.parametrize("keep", [0.0, 0.03, 0.986, 1.0])
+def test_groupby_filtered_equals_groupby_of_the_taken_rows(gpu, oracle, n, card, pbits, wide, keep):
+    """dbhip_groupby_add_block_filtered(block, Bitmap) == add_block(take(block, select(Bitmap))): on the LDS path, the
+    radix-partitioned path and the row path, short and wide layouts, with selectivities from 'nothing' to Q1's 98.6 %."""
+    rng = np.random.default_rng(n * 7 + card + int(keep * 1000))
+    k = (rng.integers(0, card, n).astype(np.int64) * 2654435761) % (1 << 40)
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    av = rng.integers(0, 5, n) > 0
+    passes = rng.random(n) < keep
+    key_types, key_nullable = [T.T_I64], [0]
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 1), (T.AGG_COUNT, 0, 0, 0, 0)]
+    gkeys, hk = [gpu.Column.from_numpy(k)], [k]
+    gargs, ha = [gpu.Column.from_numpy(a, validity=av), None], [(T.T_I64, a, av), None]
+    if wide:
+        k2 = rng.integers(0, 3, n).astype(np.int32)
+        d = [int(x) * 10**9 for x in rng.integers(-10**17, 10**17, n)]
+        key_types, key_nullable = [T.T_I64, T.T_DATE, T.T_I64, T.T_I64, T.T_I64], [0, 0, 0, 0, 0]
+        aggs += [(T.AGG_SUM, T.T_DEC128, 31, 4, 1), (T.AGG_MIN, T.T_I64, 0, 0, 1), (T.AGG_MAX, T.T_I64, 0, 0, 0)]
+        gkeys += [gpu.Column.from_numpy(k2, T.T_DATE), gpu.Column.from_numpy(k), gpu.Column.from_numpy(k), gpu.Column.from_numpy(k)]
+        gargs += [gpu.Column.decimal128(d, 31, 4, validity=av), gpu.Column.from_numpy(a, validity=av), gpu.Column.from_numpy(a)]
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    if pbits:
+        g.debug_set_partition_bits(pbits)
+    g.add_block(gkeys, gargs, n, filter=gpu.Column.boolean(passes))
+    got = g.result()
+    # oracle over the taken rows
+    sel = np.nonzero(passes)[0]
+    m = len(sel)
+    hkeys = [O.HostCol(T.T_I64, k[sel])]
+    hargs = [O.HostCol(T.T_I64, a[sel], av[sel]), None]
+    if wide:
+        hkeys += [O.HostCol(T.T_DATE, k2[sel]), O.HostCol(T.T_I64, k[sel]), O.HostCol(T.T_I64, k[sel]), O.HostCol(T.T_I64, k[sel])]
+        hargs += [O.HostCol(T.T_DEC128, O.i128_array([d[i] for i in sel]), av[sel], 31, 4), O.HostCol(T.T_I64, a[sel], av[sel]), O.HostCol(T.T_I64, a[sel])]
+    if m == 0:
+        assert got == [] and g.num_groups() == 0
+        return
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, m)
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert g.num_groups() == len(exp)
+    assert norm(got) == norm(exp)
+
+
+def test_q1_pushdown_plan_equals_fused_and_oracle(gpu, oracle):
+    from databend_amd import tpch
+    for n in (1, 129, 300_007):
+        host = tpch.gen_lineitem(n, seed=n)
+        li = tpch.LineitemDevice(host)
+        exp = O.q1_run(host, tpch.Q1_CUTOFF, threads=1)
+        assert tpch.q1_rows(tpch.q1_operator_pushdown(li)) == exp
+        assert tpch.q1_rows(tpch.q1_fused(li)) == exp
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# nullable sum / min / max: NULL for groups that never saw a value (AggregateNullUnaryAdaptor<true>)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,card", [(10, 3), (5000, 40), (300_000, 2000), (200_000, 150_000)])
+def test_nullable_sum_min_max_yield_null_for_all_null_groups(gpu, oracle, n, card):
+    rng = np.random.default_rng(n + card)
+    k = rng.integers(0, card, n).astype(np.int32)
+    a = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    f = rng.integers(-100, 100, n).astype(np.float64)
+    d = [int(x) * 10**9 for x in rng.integers(-10**17, 10**17, n)]
+    av = (rng.integers(0, 3, n) > 0) & (k % 3 != 0)      # every group with key % 3 == 0 sees only NULLs
+    key_types, key_nullable = [T.T_I32], [0]
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 1), (T.AGG_SUM, T.T_F64, 0, 0, 1), (T.AGG_SUM, T.T_DEC128, 31, 4, 1), (T.AGG_MIN, T.T_I64, 0, 0, 1),
+            (T.AGG_MAX, T.T_F64, 0, 0, 1), (T.AGG_COUNT, T.T_I64, 0, 0, 1), (T.AGG_SUM, T.T_I64, 0, 0, 0)]
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a, validity=av), gpu.Column.from_numpy(f, validity=av),
+                                             gpu.Column.decimal128(d, 31, 4, validity=av), gpu.Column.from_numpy(a, validity=av),
+                                             gpu.Column.from_numpy(f, validity=av), gpu.Column.from_numpy(a, validity=av), gpu.Column.from_numpy(a)], n)
+    got = g.result()
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, [O.HostCol(T.T_I32, k)],
+                       [O.HostCol(T.T_I64, a, av), O.HostCol(T.T_F64, f, av), O.HostCol(T.T_DEC128, O.i128_array(d), av, 31, 4),
+                        O.HostCol(T.T_I64, a, av), O.HostCol(T.T_F64, f, av), O.HostCol(T.T_I64, a, av), O.HostCol(T.T_I64, a)], n)
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert norm(got) == norm(exp)
+    nulls = [r for r in got if r[0] % 3 == 0]
+    assert nulls and all(r[1] is None and r[2] is None and r[3] is None and r[4] is None and r[5] is None and r[6] == 0 for r in nulls)
+    assert all(r[1] is not None for r in got if r[0] % 3 != 0 and r[6] > 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# serialized-state block (payload_flush.rs:151-181), both directions against the oracle
+# ---------------------------------------------------------------------------------------------------------------
+SB_KEYS = ([T.T_I64, T.T_STRING], [1, 0])
+SB_AGGS = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC128, 31, 4, 1), (T.AGG_SUM, T.T_F64, 0, 0, 1),
+           (T.AGG_MIN, T.T_I32, 0, 0, 0), (T.AGG_MAX, T.T_F64, 0, 0, 1), (T.AGG_COUNT, T.T_I64, 0, 0, 1), (T.AGG_SUM, T.T_DEC64, 15, 2, 1),
+           (T.AGG_MAX, T.T_DATE, 0, 0, 0)]
+
+
+def sb_data(n, card, seed):
+    rng = np.random.default_rng(seed)
+    d = dict(k=rng.integers(0, card, n).astype(np.int64), kv=rng.integers(0, 9, n) > 0, s=[b"g%d" % (x % 7) for x in rng.integers(0, card, n)],
+             a=rng.integers(-10**9, 10**9, n).astype(np.int64), dd=[int(x) * 10**9 for x in rng.integers(-10**17, 10**17, n)],
+             f=rng.integers(-1000, 1000, n).astype(np.float64), i=rng.integers(-2**31, 2**31 - 1, n).astype(np.int32),
+             dt=rng.integers(8000, 12000, n).astype(np.int32), dec=rng.integers(-10**14, 10**14, n).astype(np.int64))
+    d["av"] = (rng.integers(0, 3, n) > 0) & (d["k"] % 4 != 0)
+    return d
+
+
+def sb_gpu_cols(gpu, d, lo, hi):
+    sl = slice(lo, hi)
+    av = d["av"][sl]
+    keys = [gpu.Column.from_numpy(d["k"][sl], validity=d["kv"][sl]), gpu.Column.strings(d["s"][sl])]
+    args = [gpu.Column.from_numpy(d["a"][sl]), None, gpu.Column.decimal128(d["dd"][sl], 31, 4, validity=av), gpu.Column.from_numpy(d["f"][sl], validity=av),
+            gpu.Column.from_numpy(d["i"][sl]), gpu.Column.from_numpy(d["f"][sl], validity=av), gpu.Column.from_numpy(d["a"][sl], validity=av),
+            gpu.Column.from_numpy(d["dec"][sl], T.T_DEC64, validity=av, precision=15, scale=2), gpu.Column.from_numpy(d["dt"][sl], T.T_DATE)]
+    return keys, args
+
+
+def sb_host_cols(d, lo, hi):
+    sl = slice(lo, hi)
+    av = d["av"][sl]
+    v, buf = make_views_general(d["s"][sl])
+    keys = [O.HostCol(T.T_I64, d["k"][sl], d["kv"][sl]), O.HostCol(T.T_STRING, v, buffers=[buf])]
+    args = [O.HostCol(T.T_I64, d["a"][sl]), None, O.HostCol(T.T_DEC128, O.i128_array(d["dd"][sl]), av, 31, 4), O.HostCol(T.T_F64, d["f"][sl], av),
+            O.HostCol(T.T_I32, d["i"][sl]), O.HostCol(T.T_F64, d["f"][sl], av), O.HostCol(T.T_I64, d["a"][sl], av),
+            O.HostCol(T.T_DEC64, d["dec"][sl], av, 15, 2), O.HostCol(T.T_DATE, d["dt"][sl])]
+    return keys, args
+
+
+def oracle_table(oracle, aggs=SB_AGGS, keys=SB_KEYS):
+    kt = (C.c_int32 * len(keys[0]))(*keys[0])
+    kn = (C.c_uint8 * len(keys[0]))(*keys[1])
+    ad = (O.OAgg * len(aggs))()
+    for i, a in enumerate(aggs):
+        ad[i].kind, ad[i].arg_type, ad[i].arg_precision, ad[i].arg_scale, ad[i].arg_nullable = a
+    oracle.orc_hashagg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return C.c_void_p(oracle.orc_hashagg_create(kt, kn, len(keys[0]), ad, len(aggs)))
+
+
+def oracle_add(oracle, h, keys, args, n):
+    aa = (O.OCol * len(args))()
+    for i, a in enumerate(args):
+        if a is not None:
+            aa[i] = a.c()
+    assert oracle.orc_hashagg_add_block(h, O.cols(keys), aa, C.c_int64(n)) == 0
+
+
+def oracle_fields(oracle, h):
+    t, a = (C.c_int32 * 96)(), (C.c_int32 * 96)()
+    nf = oracle.orc_hashagg_state_fields(h, t, a)
+    return [(t[i], a[i]) for i in range(nf)]
+
+
+def test_state_fields_match_the_oracle_statement_of_serialize_type(gpu, oracle):
+    g = gpu.GroupBy(SB_KEYS[0], SB_AGGS, SB_KEYS[1])
+    h = oracle_table(oracle)
+    assert g.state_fields() == oracle_fields(oracle, h)
+    # count [u64]; sum [value] (+flag); min/max [has, value] (+flag)
+    assert [t for t, a in g.state_fields() if a == 2] == [T.T_DEC128, T.T_BOOL]
+    assert [t for t, a in g.state_fields() if a == 4] == [T.T_BOOL, T.T_I32]
+    assert [t for t, a in g.state_fields() if a == 5] == [T.T_BOOL, T.T_F64, T.T_BOOL]
+    oracle.orc_hashagg_destroy(h)
+
+
+@pytest.mark.parametrize("n,card", [(50, 5), (20_000, 300), (150_000, 40_000)])
+def test_device_state_block_feeds_the_cpu_final_stage(gpu, oracle, n, card):
+    """device partial aggregates -> dbhip_groupby_flush_state_block -> the ORACLE's TransformDeserializer/batch_merge
+    (orc_hashagg_merge_state_block) == the oracle over all rows."""
+    d = sb_data(n, card, 7 + n)
+    final = oracle_table(oracle)
+    cuts = [0, n // 3, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        g = gpu.GroupBy(SB_KEYS[0], SB_AGGS, SB_KEYS[1])
+        keys, args = sb_gpu_cols(gpu, d, lo, hi)
+        g.add_block(keys, args, hi - lo)
+        kcols, fcols = g.flush_state_block()
+        m = kcols[0].n
+        hk = [O.HostCol(T.T_I64, kcols[0].to_numpy(), kcols[0].validity_numpy()), O.HostCol(T.T_STRING, kcols[1].to_numpy())]
+        hf = []
+        for (t, _a), c in zip(g.state_fields(), fcols):
+            if t == T.T_BOOL:
+                hf.append(O.HostCol(T.T_BOOL, pack_bits(c.to_numpy())))
+            elif t == T.T_DEC128:
+                hf.append(O.HostCol(T.T_DEC128, O.i128_array(c.to_numpy()), None, c.precision, c.scale))
+            else:
+                hf.append(O.HostCol(t, c.to_numpy(), None, c.precision, c.scale))
+        assert oracle.orc_hashagg_merge_state_block(final, O.cols(hk), O.cols(hf), C.c_int64(m)) == 0
+    whole = oracle_table(oracle)
+    keys, args = sb_host_cols(d, 0, n)
+    oracle_add(oracle, whole, keys, args, n)
+    got, exp = oracle_rows(oracle, final, SB_KEYS[0], SB_AGGS), oracle_rows(oracle, whole, SB_KEYS[0], SB_AGGS)
+    oracle.orc_hashagg_destroy(final)
+    oracle.orc_hashagg_destroy(whole)
+    assert norm(got) == norm(exp)
+
+
+@pytest.mark.parametrize("n,card", [(50, 5), (20_000, 300), (150_000, 40_000)])
+def test_cpu_state_block_feeds_the_device_final_stage(gpu, oracle, n, card):
+    """the ORACLE's partial aggregates -> Payload::aggregate_flush restated (orc_hashagg_flush_state_block) ->
+    dbhip_groupby_merge_state_block == the device over all rows == the oracle over all rows."""
+    d = sb_data(n, card, 11 + n)
+    final = gpu.GroupBy(SB_KEYS[0], SB_AGGS, SB_KEYS[1])
+    cuts = [0, n // 4, n // 2, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        h = oracle_table(oracle)
+        keys, args = sb_host_cols(d, lo, hi)
+        oracle_add(oracle, h, keys, args, hi - lo)
+        m = oracle.orc_hashagg_num_groups(h)
+        fields = oracle_fields(oracle, h)
+        kb = [np.zeros(m * 8 + 16, np.uint8), np.zeros(m * 16 + 16, np.uint8)]
+        kv = [np.zeros(m + 8, np.uint8), np.zeros(m + 8, np.uint8)]
+        fb = [np.zeros(m * 16 + 16, np.uint8) for _ in fields]
+        kp = (C.c_void_p * 2)(*[b.ctypes.data for b in kb])
+        kvp = (C.c_void_p * 2)(*[b.ctypes.data for b in kv])
+        fp = (C.c_void_p * len(fb))(*[b.ctypes.data for b in fb])
+        assert oracle.orc_hashagg_flush_state_block(h, kp, kvp, fp, None) == 0
+        oracle.orc_hashagg_destroy(h)
+        gk = [gpu.Column.from_numpy(kb[0][:8 * m].view(np.int64), validity=kv[0][:m].astype(bool)), gpu.Column.from_views(kb[1][:16 * m].reshape(-1, 16))]
+        gf = []
+        for (t, a), b in zip(fields, fb):
+            if t == T.T_BOOL:
+                gf.append(gpu.Column.boolean(b[:m].astype(bool)))
+            elif t == T.T_DEC128:
+                gf.append(gpu.Column(T.T_DEC128, m, gpu.DeviceBuffer.from_numpy(b[:16 * m]), precision=38, scale=SB_AGGS[a][3]))
+            else:
+                gf.append(gpu.Column.from_numpy(b[:m * ELEM_SIZE[t]].view(NP_OF[t]), t))
+        final.merge_state_block(gk, gf, m)
+    whole = gpu.GroupBy(SB_KEYS[0], SB_AGGS, SB_KEYS[1])
+    keys, args = sb_gpu_cols(gpu, d, 0, n)
+    whole.add_block(keys, args, n)
+    ow = oracle_table(oracle)
+    hk, ha = sb_host_cols(d, 0, n)
+    oracle_add(oracle, ow, hk, ha, n)
+    exp = oracle_rows(oracle, ow, SB_KEYS[0], SB_AGGS)
+    oracle.orc_hashagg_destroy(ow)
+    assert norm(final.result()) == norm(whole.result()) == norm(exp)
+
+
+def test_merge_state_block_rejects_bad_blocks_without_touching_the_table(gpu):
+    """a rejected block must leave the table exactly as it was (layout and states)."""
+    aggs = [(T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 0)]
+    g = gpu.GroupBy([T.T_I64], aggs)
+    k = np.arange(100, dtype=np.int64) % 7
+    a = np.arange(100, dtype=np.int64)
+    g.add_block([gpu.Column.from_numpy(k)], [None, gpu.Column.from_numpy(a)], 100)
+    before = sorted(g.result())
+    cnt = gpu.Column.from_numpy(np.ones(7, np.uint64))
+    has = gpu.Column.boolean(np.ones(7, bool))
+    bad_val = gpu.Column.from_numpy(np.zeros(7, np.int32))      # wrong type for the min(i64) value field
+    with pytest.raises(T.DbhipError) as e:
+        g.merge_state_block([gpu.Column.from_numpy(np.arange(7, dtype=np.int64))], [cnt, has, bad_val], 7)
+    assert e.value.code == T.ERR_INVALID
+    assert sorted(g.result()) == before
+    g.add_block([gpu.Column.from_numpy(k)], [None, gpu.Column.from_numpy(a)], 100)   # COUNT still counts rows
+    assert sorted(r[1] for r in g.result()) == sorted(2 * int((k == key).sum()) for key in range(7))
+    # and a well-formed min/max block merges (round 1 returned UNSUPPORTED here)
+    good_val = gpu.Column.from_numpy(np.full(7, -5, np.int64))
+    g.merge_state_block([gpu.Column.from_numpy(np.arange(7, dtype=np.int64))], [cnt, has, good_val], 7)
+    assert all(r[2] == -5 for r in g.result())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a12: device hash partitioning for the exchange
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("card,nb,max_rows", [(4, 8, 16), (1000, 8, 256), (1000, 3, 512), (100_000, 8, 16384), (5000, 8, 64)])
+def test_partition_blocks_route_rows_by_hash_mod_buckets(gpu, card, nb, max_rows):
+    """payload.rs:548-589: bucket = group hash % bucket count. Blocks mode: headers, the any-overflow flag, rows; a
+    table rebuilt from its own blocks equals the original."""
+    n = max(card * 4, 1000)
+    rng = np.random.default_rng(card + nb)
+    k = rng.integers(0, card, n).astype(np.int64)
+    a = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    g = gpu.GroupBy([T.T_I64], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)])
+    g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None], n)
+    W = g.row_bytes() // 8
+    allrows = g.flush_serialized()
+    exp_parts = [allrows[allrows[:, 1] % np.uint64(nb) == b] for b in range(nb)]
+    assert all(int(r[1]) == mix(int(r[0])) for r in allrows[:50])          # word 1 is the group hash of the i64 key
+    blocks = gpu.DeviceBuffer(nb * (max_rows + 1) * W * 8)
+    g.partition_blocks(blocks.ptr, nb, max_rows)
+    got = blocks.to_numpy(np.uint64).reshape(nb, max_rows + 1, W)
+    over = any(len(p) > max_rows for p in exp_parts)
+    for b in range(nb):
+        assert int(got[b, 0, 1]) == (1 if over else 0)
+        if len(exp_parts[b]) > max_rows:
+            assert int(got[b, 0, 0]) == (1 << 64) - 1
+        else:
+            assert int(got[b, 0, 0]) == len(exp_parts[b])
+            rows = got[b, 1:1 + len(exp_parts[b])]
+            assert sorted(map(tuple, rows.tolist())) == sorted(map(tuple, exp_parts[b].tolist()))
+    before = sorted(g.result())
+    if over:
+        with pytest.raises(T.DbhipError) as e:
+            g.replace_with_blocks(blocks.ptr, nb, max_rows)
+        assert e.value.code == T.ERR_CAPACITY
+        assert sorted(g.result()) == before            # untouched
+    else:
+        g.replace_with_blocks(blocks.ptr, nb, max_rows)
+        assert sorted(g.result()) == before
+    # variable-length form
+    out = gpu.DeviceBuffer(max(len(allrows), 1) * W * 8)
+    counts = g.flush_partitioned(nb, out.ptr, len(allrows))
+    assert counts == [len(p) for p in exp_parts]
+    rows = out.to_numpy(np.uint64, len(allrows) * W).reshape(-1, W)
+    off = 0
+    for b in range(nb):
+        part = rows[off:off + counts[b]]
+        assert np.all(part[:, 1] % np.uint64(nb) == b)
+        assert sorted(map(tuple, part.tolist())) == sorted(map(tuple, exp_parts[b].tolist()))
+        off += counts[b]
+
+
+def test_merge_blocks_reports_the_callers_own_overflowed_block(gpu):
+    """the owner of an overflowed block must get DBHIP_ERR_CAPACITY too (it skips its own block's ROWS, not its
+    header), otherwise the other ranks enter the fallback collective alone."""
+    g = gpu.GroupBy([T.T_I64], [(T.AGG_COUNT, 0, 0, 0, 0)])
+    k = np.arange(500, dtype=np.int64)
+    g.add_block([gpu.Column.from_numpy(k)], [None], 500)
+    W = g.row_bytes() // 8
+    max_rows = 64
+    blocks = gpu.DeviceBuffer(2 * (max_rows + 1) * W * 8).zero()
+    g.flush_block(blocks.ptr, max_rows)                         # own block (rank 0): overflowed
+    hdr = blocks.to_numpy(np.uint64, W)
+    assert int(hdr[0]) == (1 << 64) - 1
+    with pytest.raises(T.DbhipError) as e:
+        g.merge_blocks(blocks.ptr, 2, max_rows, skip_block=0)   # block 1 is empty (count 0)
+    assert e.value.code == T.ERR_CAPACITY
+    assert g.num_groups() == 500

@@ -277,7 +277,9 @@ def oracle_rows(oracle, h, key_types, aggs):
     kp = (C.c_void_p * len(kb))(*[b.ctypes.data for b in kb])
     kvp = (C.c_void_p * len(kv))(*[b.ctypes.data for b in kv])
     ap = (C.c_void_p * max(len(ab), 1))(*[b.ctypes.data for b in ab])
-    oracle.orc_hashagg_result(h, kp, kvp, ap, None)
+    av = [np.ones(max(g, 1) + 8, np.uint8) for _ in aggs]
+    avp = (C.c_void_p * max(len(av), 1))(*[b.ctypes.data for b in av])
+    oracle.orc_hashagg_result_nullable(h, kp, kvp, ap, avp, None)
     cols = []
     for t, b, v in zip(key_types, kb, kv):
         if t == T.T_STRING: vals = view_strings(b[:16 * g])
@@ -285,9 +287,12 @@ def oracle_rows(oracle, h, key_types, aggs):
         elif t == T.T_BOOL: vals = [bool(x) for x in b[:g]]
         else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
         cols.append([x if ok else None for x, ok in zip(vals, v[:g])])
-    for t, b in zip(res_t, ab):
-        if t == T.T_DEC128: cols.append(O.i128_list(b[:16 * g]))
-        else: cols.append(b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist())
+    for t, b, a, v in zip(res_t, ab, aggs, av):
+        if t == T.T_DEC128: vals = O.i128_list(b[:16 * g])
+        else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
+        if a[4] and a[0] != T.AGG_COUNT:  # sum / min / max over a Nullable argument: NULL for all-NULL groups
+            vals = [x if ok else None for x, ok in zip(vals, v[:g])]
+        cols.append(vals)
     return [tuple(c[i] for c in cols) for i in range(g)]
 
 

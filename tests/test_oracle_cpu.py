@@ -619,3 +619,94 @@ def test_vector_distances_against_float64_numpy():
                                out.ctypes.data_as(C.c_void_p))
             tol = 1e-5 * np.maximum(1.0, scale.sum(-1) if metric == T.VEC_DOT else np.abs(e)) + 1e-6
             assert (np.abs(out - e) <= tol).all(), (metric, n, dim, float(np.abs(out - e).max()))
+
+
+def _otable(L, key_types, key_nullable, aggs):
+    kt = (C.c_int32 * len(key_types))(*key_types)
+    kn = (C.c_uint8 * len(key_types))(*key_nullable)
+    ad = (O.OAgg * len(aggs))()
+    for i, a in enumerate(aggs):
+        ad[i].kind, ad[i].arg_type, ad[i].arg_precision, ad[i].arg_scale, ad[i].arg_nullable = a
+    L.orc_hashagg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return C.c_void_p(L.orc_hashagg_create(kt, kn, len(key_types), ad, len(aggs)))
+
+
+def _oadd(L, h, keys, args, n):
+    aa = (O.OCol * len(args))()
+    for i, a in enumerate(args):
+        if a is not None:
+            aa[i] = a.c()
+    assert L.orc_hashagg_add_block(h, O.cols(keys), aa, C.c_int64(n)) == 0
+
+
+def test_nullable_sum_flag_and_state_block_closed_form():
+    """AggregateNullUnaryAdaptor<true> (adaptors/aggregate_null_adaptor.rs:366-400,508-600) and Payload::aggregate_flush
+    (payload_flush.rs:151-181) restated in the oracle, against closed-form answers: a group whose argument is NULL in
+    every row yields NULL (flag clear); the serialized-state block carries [value, flag] / [has, value] / [count] and
+    merging two partial blocks (TransformDeserializer + batch_merge) equals one table over all rows."""
+    L = O.load()
+    n = 6000
+    k = (np.arange(n) % 6).astype(np.int64)
+    a = np.arange(n, dtype=np.int64) - 3000
+    av = (k != 0) & (np.arange(n) % 5 != 0)          # group 0 never sees a value
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 1), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 1), (T.AGG_MAX, T.T_I64, 0, 0, 0),
+            (T.AGG_COUNT, T.T_I64, 0, 0, 1)]
+    t_f, a_f = (C.c_int32 * 32)(), (C.c_int32 * 32)()
+
+    def table(lo, hi):
+        h = _otable(L, [T.T_I64], [0], aggs)
+        _oadd(L, h, [O.HostCol(T.T_I64, k[lo:hi])], [O.HostCol(T.T_I64, a[lo:hi], av[lo:hi]), None, O.HostCol(T.T_I64, a[lo:hi], av[lo:hi]),
+                                                      O.HostCol(T.T_I64, a[lo:hi]), O.HostCol(T.T_I64, a[lo:hi], av[lo:hi])], hi - lo)
+        return h
+
+    def results(h):
+        g = L.orc_hashagg_num_groups(h)
+        kb = np.zeros(g, np.int64)
+        ab = [np.zeros(g, np.int64) for _ in aggs]
+        vb = [np.ones(g, np.uint8) for _ in aggs]
+        kp = (C.c_void_p * 1)(kb.ctypes.data)
+        ap = (C.c_void_p * len(ab))(*[b.ctypes.data for b in ab])
+        vp = (C.c_void_p * len(vb))(*[b.ctypes.data for b in vb])
+        assert L.orc_hashagg_result_nullable(h, kp, None, ap, vp, None) == 0
+        out = {}
+        for i in range(g):
+            out[int(kb[i])] = tuple((int(ab[j][i]) if vb[j][i] else None) for j in range(len(aggs)))
+        return out
+
+    exp = {}
+    for key in range(6):
+        m = (k == key)
+        mv = m & av
+        exp[key] = (int(a[mv].sum()) if mv.any() else None, int(m.sum()), int(a[mv].min()) if mv.any() else None, int(a[m].max()), int(mv.sum()))
+    whole = table(0, n)
+    assert results(whole) == exp
+    assert exp[0][0] is None and exp[0][2] is None and exp[0][4] == 0
+
+    # fields: sum [I64, BOOL], count [U64], min nullable [BOOL, I64, BOOL], max [BOOL, I64], count [U64]
+    nf = L.orc_hashagg_state_fields(whole, t_f, a_f)
+    assert [(t_f[i], a_f[i]) for i in range(nf)] == [(T.T_I64, 0), (T.T_BOOL, 0), (T.T_U64, 1), (T.T_BOOL, 2), (T.T_I64, 2), (T.T_BOOL, 2),
+                                                     (T.T_BOOL, 3), (T.T_I64, 3), (T.T_U64, 4)]
+    final = _otable(L, [T.T_I64], [0], aggs)
+    for lo, hi in ((0, 1000), (1000, 1003), (1003, n)):
+        part = table(lo, hi)
+        g = L.orc_hashagg_num_groups(part)
+        kb = np.zeros(g, np.int64)
+        fb = [np.zeros(g, np.int64) if t_f[i] != T.T_BOOL else np.zeros(g, np.uint8) for i in range(nf)]
+        kp = (C.c_void_p * 1)(kb.ctypes.data)
+        fp = (C.c_void_p * nf)(*[b.ctypes.data for b in fb])
+        assert L.orc_hashagg_flush_state_block(part, kp, None, fp, None) == 0
+        # closed form of the block itself: count field = rows of the group in this part, flag = any valid row
+        for i in range(g):
+            m = (k[lo:hi] == kb[i])
+            mv = m & av[lo:hi]
+            assert fb[2][i] == m.sum() and bool(fb[1][i]) == bool(mv.any()) and fb[0][i] == a[lo:hi][mv].sum()
+            assert bool(fb[3][i]) == bool(mv.any()) and (not mv.any() or fb[4][i] == a[lo:hi][mv].min()) and (mv.any() or fb[4][i] == 0)
+        cols = [O.HostCol(t_f[i], np.packbits(fb[i].astype(bool), bitorder="little") if t_f[i] == T.T_BOOL else fb[i]) for i in range(nf)]
+        for c in cols:
+            if c.dtype == T.T_BOOL:
+                c.arr = np.concatenate([c.arr, np.zeros(8, np.uint8)])
+        assert L.orc_hashagg_merge_state_block(final, O.cols([O.HostCol(T.T_I64, kb)]), O.cols(cols), C.c_int64(g)) == 0
+        L.orc_hashagg_destroy(part)
+    assert results(final) == exp
+    L.orc_hashagg_destroy(final)
+    L.orc_hashagg_destroy(whole)
