@@ -164,7 +164,11 @@ def main():
         dist.all_reduce(exp, op=dist.ReduceOp.SUM)
         dist.all_reduce(got, op=dist.ReduceOp.SUM)
         mult = world if exchange == "allgather" else 1
-        assert torch.equal(exp * mult, got), "exchange lost or duplicated partial states"
+
+        def ints(t):  # limb sums -> exact python ints (the limbs of a sum are not the sums of the limbs: recombine first)
+            x = t.tolist()
+            return [x[i] + (x[i + 1] << 42) + (x[i + 2] << 84) for i in range(0, len(x), 3)]
+        assert [v * mult for v in ints(exp)] == ints(got), "exchange lost or duplicated partial states"
         ng = torch.tensor([len(result)], dtype=torch.int64, device="cuda")
         dist.all_reduce(ng, op=dist.ReduceOp.SUM if exchange == "alltoall" else dist.ReduceOp.MAX)
         n_groups = int(ng.item())

@@ -854,15 +854,19 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
   return DBHIP_OK;
 }
 
+// Per-table scratch and the table arrays come from the library's block cache (dbhip_alloc / dbhip_free: freed blocks of
+// >= 1 MiB are kept in size-class lists), so a plan that creates a table per block does not pay hipMalloc / hipFree of
+// GB-sized buffers per call (a fresh 9 GB hipMalloc costs tens of milliseconds).
 int32_t ensure(void** p, size_t* cap, size_t bytes) {
   if (*cap >= bytes) return DBHIP_OK;
   if (*p) {
-    DBHIP_CHECK(hipDeviceSynchronize());
-    DBHIP_CHECK(hipFree(*p));
+    int32_t rc = dbhip_free(*p);  // synchronises the device before the block may be re-used
+    if (rc) return rc;
     *p = nullptr; *cap = 0;
   }
   size_t want = bytes + (bytes >> 3) + 256;
-  DBHIP_CHECK(hipMalloc(p, want));
+  int32_t rc = dbhip_alloc(want, p);
+  if (rc) { *p = nullptr; return rc; }
   *cap = want;
   return DBHIP_OK;
 }
@@ -871,13 +875,13 @@ int32_t ensure(void** p, size_t* cap, size_t bytes) {
 int32_t alloc_table(dbhip_groupby* g, int64_t cap, hipStream_t s) {
   uint64_t* nh = nullptr;
   uint64_t* nr = nullptr;
-  hipError_t e = hipMalloc((void**)&nh, (size_t)cap * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&nr, (size_t)cap * g->L.W * 8);
-  if (e == hipSuccess) e = hipMemsetAsync(nh, 0, (size_t)cap * 8, s);
-  if (e != hipSuccess) {
-    if (nh) (void)hipFree(nh);
-    if (nr) (void)hipFree(nr);
-    return hip_fail(e, "groupby: allocating the table");
+  int32_t rc = dbhip_alloc((size_t)cap * 8, (void**)&nh);
+  if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)cap * g->L.W * 8, (void**)&nr);
+  hipError_t e = rc == DBHIP_OK ? hipMemsetAsync(nh, 0, (size_t)cap * 8, s) : hipSuccess;
+  if (rc != DBHIP_OK || e != hipSuccess) {
+    if (nh) (void)dbhip_free(nh);
+    if (nr) (void)dbhip_free(nr);
+    return rc != DBHIP_OK ? rc : hip_fail(e, "groupby: allocating the table");
   }
   g->slot_hash = nh;
   g->rows = nr;
@@ -895,9 +899,8 @@ int32_t grow(dbhip_groupby* g, hipStream_t s) {
                      old_rows, old_cap, g->slot_hash, g->rows, g->cap, g->hash_mask);
   DBHIP_LAUNCH_CHECK();
   DBHIP_CHECK(hipStreamSynchronize(s));
-  DBHIP_CHECK(hipFree(old_hash));
-  DBHIP_CHECK(hipFree(old_rows));
-  return DBHIP_OK;
+  int32_t r1 = dbhip_free(old_hash), r2 = dbhip_free(old_rows);
+  return r1 ? r1 : r2;
 }
 
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
@@ -1074,7 +1077,8 @@ struct FkArgs {
   uint32_t llimit;         // max occupied LDS slots
   uint64_t hash_mask;
   uint64_t* partial;       // [gridDim.x * lcap][W]
-  uint64_t* spill;         // [n][W]
+  uint64_t* spill;         // [spill_cap][W]
+  uint64_t spill_cap;
   uint64_t* ctrl;          // [5] = #partial rows, [6] = #spill rows, [3] error bits
 };
 
@@ -1170,7 +1174,11 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
         if (lane_id() == leader) base = atomicAdd((unsigned long long*)&A.ctrl[6], (unsigned long long)__popcll(m));
         base = __shfl(base, leader, 64);
         if (spill) {
-          uint64_t* o = A.spill + (base + __popcll(m & ((1ULL << lane_id()) - 1))) * L.W;
+          const unsigned long long si = base + __popcll(m & ((1ULL << lane_id()) - 1));
+          // a chunk whose key distribution was trusted gets a small spill buffer: rows past it are dropped and flagged
+          // (ctrl[3] bit 2) — the host then discards the whole chunk's output and redoes it on another path
+          if (si >= A.spill_cap) { atomicOr((unsigned long long*)&A.ctrl[3], 4ULL); continue; }
+          uint64_t* o = A.spill + si * L.W;
 #pragma unroll
           for (int j = 0; j < KW; ++j)
             if (j < L.nkey_words) o[j] = r[x].kw[j];
@@ -1278,9 +1286,15 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     const int64_t tpb = ceil_div(ntiles, grid);
     grid = (int)ceil_div(ntiles, tpb);
     if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * lcap * L.W * 8))) return rc;
-    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
+    // spill buffer: worst case (every row) for probing chunks; a trusted chunk spilled < 1 % last time, so 1/64 of its rows
+    // (at least 4 M) is ample — and a 600 M-row block does not allocate a 72 GB buffer it never touches. Overflow is
+    // detected (ctrl[3] bit 2) and the chunk redone.
+    int64_t spill_cap = cn;
+    if (g->fast_trusted && cn > (4 << 20)) spill_cap = cn / 64 > (4 << 20) ? cn / 64 : (4 << 20);
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)spill_cap * L.W * 8))) return rc;
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
     FkArgs A;
+    A.spill_cap = (uint64_t)spill_cap;
     A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap; A.sw = sw;
     A.llimit = (uint32_t)(lcap - lcap / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
@@ -1293,6 +1307,13 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     if (hc[3] & 2) {
       set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
       return DBHIP_ERR_UNSUPPORTED;
+    }
+    if (hc[3] & 4) {
+      // the trusted chunk spilled past its buffer (the key distribution changed inside the block): nothing of this
+      // chunk has been merged yet — drop its output, stop trusting, and redo it in bounded probing chunks
+      DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+      g->fast_trusted = 0;
+      continue;
     }
     if ((rc = merge_rows(g, g->partial, (int64_t)hc[5], s))) return rc;
     if ((rc = merge_rows(g, g->rows_in, (int64_t)hc[6], s))) return rc;
@@ -2235,16 +2256,16 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
 int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (!g) return DBHIP_OK;
   (void)hipDeviceSynchronize();
-  if (g->slot_hash) (void)hipFree(g->slot_hash);
-  if (g->rows) (void)hipFree(g->rows);
+  if (g->slot_hash) (void)dbhip_free(g->slot_hash);
+  if (g->rows) (void)dbhip_free(g->rows);
   if (g->ctrl) (void)hipFree(g->ctrl);
-  if (g->rows_in) (void)hipFree(g->rows_in);
-  if (g->gid) (void)hipFree(g->gid);
-  if (g->retry) (void)hipFree(g->retry);
-  if (g->partial) (void)hipFree(g->partial);
-  if (g->part_meta) (void)hipFree(g->part_meta);
-  if (g->spill_idx) (void)hipFree(g->spill_idx);
-  if (g->spill_rows) (void)hipFree(g->spill_rows);
+  if (g->rows_in) (void)dbhip_free(g->rows_in);
+  if (g->gid) (void)dbhip_free(g->gid);
+  if (g->retry) (void)dbhip_free(g->retry);
+  if (g->partial) (void)dbhip_free(g->partial);
+  if (g->part_meta) (void)dbhip_free(g->part_meta);
+  if (g->spill_idx) (void)dbhip_free(g->spill_idx);
+  if (g->spill_rows) (void)dbhip_free(g->spill_rows);
   if (g->xcur) (void)hipFree(g->xcur);
   delete g;
   return DBHIP_OK;
