@@ -33,13 +33,13 @@ class Col(C.Structure):
     ]
 
 
-EX_LOAD, EX_CONST, EX_PLUS, EX_MINUS, EX_MULTIPLY, EX_DIVIDE, EX_EQ, EX_NOTEQ, EX_LT, EX_LTE, EX_GT, EX_GTE, EX_AND, EX_OR, EX_NOT, EX_CAST = range(16)
+EX_LOAD, EX_CONST, EX_PLUS, EX_MINUS, EX_MULTIPLY, EX_DIVIDE, EX_EQ, EX_NOTEQ, EX_LT, EX_LTE, EX_GT, EX_GTE, EX_AND, EX_OR, EX_NOT, EX_CAST, EX_IF = range(17)
 
 
 class ExprIns(C.Structure):
     """dbhip_expr_ins"""
-    _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("type", C.c_int32), ("_pad", C.c_int32),
-                ("imm", C.c_uint64)]
+    _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("type", C.c_int32),
+                ("precision", C.c_uint8), ("scale", C.c_uint8), ("_pad", C.c_uint8 * 2), ("imm", C.c_uint64)]
 
 
 class PqInfo(C.Structure):

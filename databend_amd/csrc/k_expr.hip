@@ -16,8 +16,7 @@
 // error (only for rows whose inputs are all valid, function.rs:534-556), floats compare as OrderedFloat. NULLs:
 // passthrough_nullable (register_vectorize.rs:447-471) — the payload is computed for all rows, the result's validity
 // is the AND of the validity of every nullable input column the program loads.
-#include "dev_common.h"
-#include "dev_load.h"
+#include "dev_expr.h"
 #include "runtime.h"
 
 #include <string.h>
@@ -26,97 +25,30 @@ using namespace dbhip;
 
 namespace {
 
-constexpr int EX_MAX_INS = 32;
-constexpr int EX_MAX_REGS = 8;
-constexpr int EX_MAX_INPUTS = 8;
-constexpr int EX_ROWS = 2;  // row slots per lane
-
-// Everything the interpreter needs is decoded on the host: the scalar unit is shared by the CU's four SIMDs, and a
-// type switch per operand per instruction made the first version SALU bound (483 scalar instructions per 128 rows).
-struct ExIns {
-  int16_t op, dst, a, b;   // a = input index for LOAD
-  int16_t type;            // result type (host side checks only)
-  int8_t acls, bcls, ocls; // CLS_SIGNED / CLS_UNSIGNED / CLS_FLOAT of the operands and the result
-  int8_t norm_sh;          // result width: shift that sign-/zero-extends from the result's bits (0 for 64-bit)
-  int8_t norm_signed, norm_f32;
-  uint64_t imm;
-};
-
-struct ExProg {
-  ExIns ins[EX_MAX_INS];
-  const void* in_data[EX_MAX_INPUTS];
-  const uint8_t* in_valid[EX_MAX_INPUTS];
-  int64_t in_voff[EX_MAX_INPUTS];
-  int32_t in_type[EX_MAX_INPUTS];   // load kind, see ex_load
-  int32_t in_scalar[EX_MAX_INPUTS];
-  int32_t n_ins, n_inputs, out_reg, out_type, n_slots;
-  int32_t in_slot[EX_MAX_INPUTS];   // LDS register of input column c (-1: the program never reads it)
-  int32_t out_kind, out_cls;        // store width in bytes (0 = bitmap, -4 = f32), class of the result
+struct ExOut {
+  int32_t out_slot, out_kind, out_cls;  // store width in bytes (0 = bitmap, -4 = f32, 16 = i128), class of the result
+  uint32_t out_dep;                     // nullable inputs the result depends on (validity = all of them valid)
   int64_t n;
   void* out_values;              // numeric: elements of out_type; BOOL: bitmap words
   uint64_t* out_validity;        // bitmap words (may be NULL)
-  uint32_t* err_words;           // preset to all ones (may be NULL)
-  unsigned long long* err_count; // may be NULL
-  unsigned long long* sum_out;   // may be NULL: accumulate the sum of the valid rows of out_reg
+  unsigned long long* sum_out;   // may be NULL: accumulate the sum of the valid rows of the result
 };
 
-// load kinds (host: ex_load_kind): the common 8-byte case is the first test
-enum { LK_8 = 0, LK_S4 = 1, LK_U4 = 2, LK_F4 = 3, LK_S2 = 4, LK_U2 = 5, LK_S1 = 6, LK_U1 = 7, LK_BOOL = 8 };
-__device__ __forceinline__ uint64_t ex_load(const void* p, int kind, int64_t i) {
-  if (kind == LK_8) return ((const uint64_t*)p)[i];
-  if (kind == LK_S4) return (uint64_t)(int64_t)((const int32_t*)p)[i];
-  if (kind == LK_U4) return ((const uint32_t*)p)[i];
-  if (kind == LK_F4) return (uint64_t)__double_as_longlong((double)((const float*)p)[i]);
-  if (kind == LK_S2) return (uint64_t)(int64_t)((const int16_t*)p)[i];
-  if (kind == LK_U2) return ((const uint16_t*)p)[i];
-  if (kind == LK_S1) return (uint64_t)(int64_t)((const int8_t*)p)[i];
-  if (kind == LK_U1) return ((const uint8_t*)p)[i];
-  return bit_get((const uint8_t*)p, i);
-}
-
-__device__ __forceinline__ double ex_to_f64(uint64_t w, int cls) {
-  if (cls == CLS_FLOAT) return __longlong_as_double((long long)w);
-  if (cls == CLS_SIGNED) return (double)(int64_t)w;
-  return (double)w;
-}
-
-// widened register image of `w` at the node's result type, from the host-decoded width (no type switch)
-__device__ __forceinline__ uint64_t ex_norm(uint64_t w, const ExIns& I) {
-  if (I.norm_f32) return (uint64_t)__double_as_longlong((double)(float)__longlong_as_double((long long)w));
-  if (I.norm_sh == 0) return w;
-  return I.norm_signed ? (uint64_t)(((int64_t)(w << I.norm_sh)) >> I.norm_sh) : ((w << I.norm_sh) >> I.norm_sh);
-}
-
-__device__ __forceinline__ int ex_cmp3(uint64_t a, uint64_t b, int cls) {
-  if (cls == CLS_SIGNED) return ((int64_t)a > (int64_t)b) - ((int64_t)a < (int64_t)b);
-  if (cls == CLS_UNSIGNED) return (a > b) - (a < b);
-  const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
-  const bool xn = x != x, yn = y != y;
-  if (xn || yn) return (int)xn - (int)yn;  // OrderedFloat: NaN largest, NaN == NaN
-  return (x > y) - (x < y);
-}
-
-enum {
-  EX_LOAD = 0, EX_CONST = 1, EX_PLUS = 2, EX_MINUS = 3, EX_MULTIPLY = 4, EX_DIVIDE = 5,
-  EX_EQ = 6, EX_NOTEQ = 7, EX_LT = 8, EX_LTE = 9, EX_GT = 10, EX_GTE = 11,
-  EX_AND = 12, EX_OR = 13, EX_NOT = 14, EX_CAST = 15
-};
-
-// Register numbering inside the kernel: 0 .. n_temps-1 are temporaries, n_temps + c is input column c. The host
-// compiles LOAD instructions away (an operand that names a loaded register is rewritten to the input register), so
-// that ALL column loads of a chunk are issued back to back before the first instruction is interpreted — with the
-// loads inside the interpreter loop every LOAD would cost a full HBM round trip of its own.
+// Register numbering inside the kernel: LDS slots. The host compiles LOAD instructions away (an operand that names a
+// loaded register is rewritten to the input column's slot), so that ALL column loads of a chunk are issued back to back
+// before the first instruction is interpreted — with the loads inside the interpreter loop every LOAD would cost a full
+// HBM round trip of its own.
 // NIN: compile-time bound of the input count (unused slots cost neither code nor VGPRs); ALL8: every input is a
 // plain 8-byte non-scalar column (i64 / u64 / f64 / timestamp / decimal64) — straight-line loads, no kind tests.
 template <int NIN, bool ALL8, int ROWS>
-__global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
+__global__ __launch_bounds__(256) void expr_kernel(ExProg P, ExOut O) {
   extern __shared__ uint64_t ex_regs[];  // [n_slots][ROWS][256]
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t rows_per_wave = 64 * ROWS;
-  const int64_t nchunks = (P.n + rows_per_wave - 1) / rows_per_wave;
+  const int64_t nchunks = (O.n + rows_per_wave - 1) / rows_per_wave;
   const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + tid) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int out_cls = P.out_cls;
+  const int out_cls = O.out_cls;
   uint64_t acc_i = 0;
   double acc_f = 0.0;
 #define EX_REG(r, k) ex_regs[((r) * ROWS + (k)) * 256 + tid]
@@ -124,28 +56,31 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
   for (int64_t c = wave_global; c < nchunks; c += nwaves) {
     const int64_t base = c * rows_per_wave;
     int64_t row[ROWS];
-    bool in_range[ROWS], valid[ROWS];
+    bool in_range[ROWS];
+    uint32_t vmask[ROWS];
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
       row[k] = base + 64 * k + lane;
-      in_range[k] = row[k] < P.n;
-      valid[k] = in_range[k];
-      if (!in_range[k]) row[k] = P.n - 1;  // clamp: loads stay in bounds, results are masked
+      in_range[k] = row[k] < O.n;
+      vmask[k] = 0xFFu;
+      if (!in_range[k]) row[k] = O.n - 1;  // clamp: loads stay in bounds, results are masked
     }
     // ---- all input loads of the chunk, back to back ----
-    uint64_t in[NIN][ROWS];
+    uint64_t in[NIN][ROWS], in_hi[NIN][ROWS];
 #pragma unroll
     for (int ci = 0; ci < NIN; ++ci) {
       if (ci < P.n_inputs) {
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
+          in_hi[ci][k] = 0;
           if (ALL8) {
             in[ci][k] = ((const uint64_t*)P.in_data[ci])[row[k]];
-            if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + row[k]);
+            if (P.in_valid[ci] && !bit_get(P.in_valid[ci], P.in_voff[ci] + row[k])) vmask[k] &= ~(1u << ci);
           } else {
             const int64_t j = P.in_scalar[ci] ? 0 : row[k];
             in[ci][k] = ex_load(P.in_data[ci], P.in_type[ci], j);
-            if (P.in_valid[ci]) valid[k] = valid[k] && bit_get(P.in_valid[ci], P.in_voff[ci] + j);
+            if (P.in_type[ci] == LK_16) in_hi[ci][k] = ((const uint64_t*)P.in_data[ci])[2 * j + 1];
+            if (P.in_valid[ci] && !bit_get(P.in_valid[ci], P.in_voff[ci] + j)) vmask[k] &= ~(1u << ci);
           }
         }
       }
@@ -155,119 +90,60 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P) {
       if (ci < P.n_inputs) {
 #pragma unroll
         for (int k = 0; k < ROWS; ++k)
-          if (P.in_slot[ci] >= 0) EX_REG(P.in_slot[ci], k) = in[ci][k];
+          if (P.in_slot[ci] >= 0) {
+            EX_REG(P.in_slot[ci], k) = in[ci][k];
+            if (!ALL8 && P.in_type[ci] == LK_16) EX_REG(P.in_slot[ci] + 1, k) = in_hi[ci][k];
+          }
       }
     }
     // ---- interpret (wave-uniform instruction stream): ONE dispatch per instruction, the row slots loop inside the case ----
-    for (int pc = 0; pc < P.n_ins; ++pc) {
-      const ExIns I = P.ins[pc];
-      const int acls = I.acls, bcls = I.bcls, ocls = I.ocls;
-#define EX_ROWS_DO(EXPR)                                  \
-  _Pragma("unroll") for (int k = 0; k < ROWS; ++k) {      \
-    const uint64_t x = EX_REG(I.a, k);                    \
-    const uint64_t y = EX_REG(I.b, k);                    \
-    (void)x; (void)y;                                     \
-    EX_REG(I.dst, k) = (EXPR);                            \
-  }
-#define EX_ROWS_DO1(EXPR)                                 \
-  _Pragma("unroll") for (int k = 0; k < ROWS; ++k) {      \
-    const uint64_t x = EX_REG(I.a, k);                    \
-    (void)x;                                              \
-    EX_REG(I.dst, k) = (EXPR);                            \
-  }
-      switch (I.op) {
-        case EX_CONST:
-#pragma unroll
-          for (int k = 0; k < ROWS; ++k) EX_REG(I.dst, k) = I.imm;
-          break;
-        case EX_PLUS:
-          if (ocls == CLS_FLOAT) EX_ROWS_DO(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls) + ex_to_f64(y, bcls)), I))
-          else EX_ROWS_DO(ex_norm(x + y, I))
-          break;
-        case EX_MINUS:
-          if (ocls == CLS_FLOAT) EX_ROWS_DO(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls) - ex_to_f64(y, bcls)), I))
-          else EX_ROWS_DO(ex_norm(x - y, I))
-          break;
-        case EX_MULTIPLY:
-          if (ocls == CLS_FLOAT) EX_ROWS_DO(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls) * ex_to_f64(y, bcls)), I))
-          else EX_ROWS_DO(ex_norm(x * y, I))
-          break;
-        case EX_DIVIDE:
-#pragma unroll
-          for (int k = 0; k < ROWS; ++k) {
-            const double a = ex_to_f64(EX_REG(I.a, k), acls), bb = ex_to_f64(EX_REG(I.b, k), bcls);
-            uint64_t r = 0;
-            if (bb == 0.0) {
-              if (valid[k]) {  // NULL rows never raise (function.rs:536-543); padding rows are not valid
-                if (P.err_words) atomicAnd(&P.err_words[row[k] >> 5], ~(1u << (row[k] & 31)));
-                if (P.err_count) atomicAdd(P.err_count, 1ULL);
-              }
-            } else {
-              r = (uint64_t)__double_as_longlong(a / bb);
-            }
-            EX_REG(I.dst, k) = r;
-          }
-          break;
-        case EX_EQ: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) == 0)) break;
-        case EX_NOTEQ: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) != 0)) break;
-        case EX_LT: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) < 0)) break;
-        case EX_LTE: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) <= 0)) break;
-        case EX_GT: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) > 0)) break;
-        case EX_GTE: EX_ROWS_DO((uint64_t)(ex_cmp3(x, y, acls) >= 0)) break;
-        case EX_AND: EX_ROWS_DO(x & y & 1) break;
-        case EX_OR: EX_ROWS_DO((x | y) & 1) break;
-        case EX_NOT: EX_ROWS_DO1((x ^ 1) & 1) break;
-        default:  // EX_CAST (lossless widenings only, checked on the host)
-          if (ocls == CLS_FLOAT) EX_ROWS_DO1(ex_norm((uint64_t)__double_as_longlong(ex_to_f64(x, acls)), I))
-          else EX_ROWS_DO1(x)
-          break;
-      }
-#undef EX_ROWS_DO
-#undef EX_ROWS_DO1
-    }
+    ex_interpret<ROWS>(P, ex_regs, tid, 0, P.n_ins, row, in_range, vmask);
     // ---- result ----
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
-      const uint64_t r = EX_REG(P.out_reg, k);
+      const uint64_t r = EX_REG(O.out_slot, k);
+      const bool valid = in_range[k] && ((vmask[k] & O.out_dep) == O.out_dep);
       const int64_t word = (base >> 6) + k;  // 64-row word of this slot
-      if (P.out_values) {
-        if (P.out_kind == 0) {
+      if (O.out_values) {
+        if (O.out_kind == 0) {
           const uint64_t m = __ballot(in_range[k] && (r & 1));
-          if (lane == 0 && base + 64 * k < P.n) ((uint64_t*)P.out_values)[word] = m;
+          if (lane == 0 && base + 64 * k < O.n) ((uint64_t*)O.out_values)[word] = m;
         } else if (in_range[k]) {
-          if (P.out_kind == 8) ((uint64_t*)P.out_values)[row[k]] = r;
-          else if (P.out_kind == 4) ((uint32_t*)P.out_values)[row[k]] = (uint32_t)r;
-          else if (P.out_kind == -4) ((float*)P.out_values)[row[k]] = (float)__longlong_as_double((long long)r);
-          else if (P.out_kind == 2) ((uint16_t*)P.out_values)[row[k]] = (uint16_t)r;
-          else ((uint8_t*)P.out_values)[row[k]] = (uint8_t)r;
+          if (O.out_kind == 8) ((uint64_t*)O.out_values)[row[k]] = r;
+          else if (O.out_kind == 16) { ((uint64_t*)O.out_values)[2 * row[k]] = r; ((uint64_t*)O.out_values)[2 * row[k] + 1] = EX_REG(O.out_slot + 1, k); }
+          else if (O.out_kind == 4) ((uint32_t*)O.out_values)[row[k]] = (uint32_t)r;
+          else if (O.out_kind == -4) ((float*)O.out_values)[row[k]] = (float)__longlong_as_double((long long)r);
+          else if (O.out_kind == 2) ((uint16_t*)O.out_values)[row[k]] = (uint16_t)r;
+          else ((uint8_t*)O.out_values)[row[k]] = (uint8_t)r;
         }
       }
-      if (P.out_validity) {
-        const uint64_t m = __ballot(valid[k]);
-        if (lane == 0 && base + 64 * k < P.n) P.out_validity[word] = m;
+      if (O.out_validity) {
+        const uint64_t m = __ballot(valid);
+        if (lane == 0 && base + 64 * k < O.n) O.out_validity[word] = m;
       }
-      if (P.sum_out && valid[k]) {
+      if (O.sum_out && valid) {
         if (out_cls == CLS_FLOAT) acc_f += __longlong_as_double((long long)r);
         else acc_i += r;
       }
     }
   }
 #undef EX_REG
-  if (P.sum_out) {
+  if (O.sum_out) {
     if (out_cls == CLS_FLOAT) {
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) acc_f += __shfl_xor(acc_f, off, 64);
-      if (lane == 0 && acc_f != 0.0) atomicAdd((double*)P.sum_out, acc_f);
+      if (lane == 0 && acc_f != 0.0) atomicAdd((double*)O.sum_out, acc_f);
     } else {
       acc_i = wave_sum_u64(acc_i);
-      if (lane == 0 && acc_i) atomicAdd(P.sum_out, (unsigned long long)acc_i);
+      if (lane == 0 && acc_i) atomicAdd(O.sum_out, (unsigned long long)acc_i);
     }
   }
 }
 
 bool ex_numeric(int t) { return type_class(t) >= 0; }
+bool ex_decimal(int t) { return t == DBHIP_T_DEC64 || t == DBHIP_T_DEC128; }
 
-int ex_cls(int t) { return t == DBHIP_T_BOOL ? CLS_UNSIGNED : type_class(t); }
+int ex_cls(int t) { return (t == DBHIP_T_BOOL) ? CLS_UNSIGNED : (t == DBHIP_T_DEC128 ? CLS_SIGNED : type_class(t)); }
 
 int ex_load_kind(int t) {
   switch (t) {
@@ -279,6 +155,7 @@ int ex_load_kind(int t) {
     case DBHIP_T_I32: case DBHIP_T_DATE: return LK_S4;
     case DBHIP_T_U32: return LK_U4;
     case DBHIP_T_F32: return LK_F4;
+    case DBHIP_T_DEC128: return LK_16;
     default: return LK_8;
   }
 }
@@ -289,8 +166,11 @@ void ex_decode(ExIns& d, int ta, int tb) {
   d.ocls = (int8_t)ex_cls(d.type);
   d.norm_f32 = d.type == DBHIP_T_F32;
   d.norm_signed = d.ocls == CLS_SIGNED;
-  const int bits = d.type == DBHIP_T_BOOL ? 64 : type_bits(d.type);
+  const int bits = (d.type == DBHIP_T_BOOL || d.type == DBHIP_T_DEC128) ? 64 : type_bits(d.type);
   d.norm_sh = (int8_t)((d.ocls == CLS_FLOAT) ? 0 : 64 - bits);
+  d.a_wide = ta == DBHIP_T_DEC128;
+  d.b_wide = tb == DBHIP_T_DEC128;
+  d.o_wide = d.type == DBHIP_T_DEC128;
 }
 
 bool ex_lossless_cast(int from, int to) {
@@ -303,158 +183,302 @@ bool ex_lossless_cast(int from, int to) {
   return tc == CLS_SIGNED && tb >= fb;
 }
 
+struct RegInfo {
+  int type = -1, precision = 0, scale = 0;
+  int loc = 0;        // where the register's current value lives: temp r, or EX_MAX_REGS + input column
+  uint32_t dep = 0;   // nullable inputs the value depends on
+  bool may_raise = false;  // some node below it can raise a row error
+};
+
 }  // namespace
+
+int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_ins, const dbhip_col* inputs_host, int32_t n_inputs,
+                                    ExRoot* roots, int32_t n_roots, int32_t filter_root, ExProg* out, bool* out_may_raise,
+                                    bool* out_any_nullable) {
+  DBHIP_REQUIRE(n_ins >= 0 && n_ins <= 2 * EX_MAX_INS && (prog_host || n_ins == 0), "expression program: too many instructions");
+  DBHIP_REQUIRE(n_inputs >= 0 && n_inputs <= EX_MAX_INPUTS && (inputs_host || n_inputs == 0), "expression program: 0..8 input columns");
+  DBHIP_REQUIRE(n_roots >= 1 && n_roots <= EX_MAX_ROOTS && roots, "expression program: 1..8 results");
+  ExProg& P = *out;
+  memset(&P, 0, sizeof(P));
+  RegInfo reg[EX_MAX_REGS];
+  for (int r = 0; r < EX_MAX_REGS; ++r) reg[r].loc = r;
+  int n_out = 0, n_dec = 0;
+  bool any_nullable = false, may_raise = false;
+  for (int c = 0; c < n_inputs; ++c) {
+    const dbhip_col& col = inputs_host[c];
+    if (!(ex_numeric(col.type) || col.type == DBHIP_T_BOOL || col.type == DBHIP_T_DEC128)) {
+      set_error("expression program: input %d has type %d (numeric, date, timestamp, decimal and boolean columns only)", c, col.type);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    DBHIP_REQUIRE(col.data, "expression program: NULL input column");
+    P.in_data[c] = col.data; P.in_valid[c] = col.validity; P.in_voff[c] = col.validity_offset;
+    P.in_type[c] = ex_load_kind(col.type); P.in_scalar[c] = col.is_scalar;
+  }
+  int filter_reg = filter_root >= 0 ? roots[filter_root].reg : -1;
+  int n_filter_ins_src = -1;  // source instruction after which the filter register holds its final value
+  if (filter_reg >= 0) {
+    for (int i = 0; i < n_ins; ++i) if (prog_host[i].dst == filter_reg) n_filter_ins_src = i + 1;
+  }
+  for (int i = 0; i < n_ins; ++i) {
+    const dbhip_expr_ins& s = prog_host[i];
+    if (n_out >= EX_MAX_INS) { set_error("expression program: more than %d instructions after LOAD elimination", EX_MAX_INS); return DBHIP_ERR_UNSUPPORTED; }
+    ExIns& d = P.ins[n_out];
+    memset(&d, 0, sizeof(d));
+    if (s.dst < 0 || s.dst >= EX_MAX_REGS) { set_error("expression program: instruction %d: register %d out of range (0..%d)", i, s.dst, EX_MAX_REGS - 1); return DBHIP_ERR_INVALID; }
+    const uint8_t s_prec = s.precision, s_scale = s.scale;
+    d.op = (int16_t)s.op; d.dst = (int16_t)s.dst; d.type = (int16_t)s.type; d.imm = s.imm; d.dec_idx = -1;
+    auto ok_reg = [&](int r) { return r >= 0 && r < EX_MAX_REGS && reg[r].type >= 0; };
+    d.a = (int16_t)(ok_reg(s.a) ? reg[s.a].loc : 0);
+    d.b = (int16_t)(ok_reg(s.b) ? reg[s.b].loc : 0);
+    RegInfo res;
+    res.type = s.type; res.loc = s.dst;
+    switch (s.op) {
+      case DBHIP_EX_LOAD: {
+        if (s.a < 0 || s.a >= n_inputs || inputs_host[s.a].type != s.type) { set_error("expression program: instruction %d: LOAD of input %d as type %d", i, s.a, s.type); return DBHIP_ERR_INVALID; }
+        RegInfo& r = reg[s.dst];
+        r.type = s.type; r.precision = inputs_host[s.a].precision; r.scale = inputs_host[s.a].scale;
+        r.loc = EX_MAX_REGS + s.a;
+        r.dep = inputs_host[s.a].validity ? (1u << s.a) : 0;
+        r.may_raise = false;
+        any_nullable |= inputs_host[s.a].validity != nullptr;
+        continue;  // no instruction: the value is read straight from the input's slot
+      }
+      case DBHIP_EX_CONST:
+        if (!(ex_numeric(s.type) || s.type == DBHIP_T_BOOL)) { set_error("expression program: instruction %d: CONST of type %d (Decimal128 constants: widen a Decimal64 one with CAST)", i, s.type); return DBHIP_ERR_INVALID; }
+        ex_decode(d, -1, -1);
+        res.precision = s_prec; res.scale = s_scale;
+        break;
+      case DBHIP_EX_PLUS: case DBHIP_EX_MINUS: case DBHIP_EX_MULTIPLY: case DBHIP_EX_DIVIDE: {
+        if (!ok_reg(s.a) || !ok_reg(s.b)) { set_error("expression program: instruction %d reads an unset register", i); return DBHIP_ERR_INVALID; }
+        const RegInfo &ra = reg[s.a], &rb = reg[s.b];
+        const int aop = s.op == DBHIP_EX_PLUS ? DBHIP_OP_PLUS : s.op == DBHIP_EX_MINUS ? DBHIP_OP_MINUS : s.op == DBHIP_EX_MULTIPLY ? DBHIP_OP_MULTIPLY : DBHIP_OP_DIVIDE;
+        if (ex_decimal(ra.type) || ex_decimal(rb.type)) {
+          // binary_decimal (decimal/src/arithmetic.rs:190-316); an integer operand is converted like other_to_decimal
+          if (n_dec >= EX_MAX_DEC) { set_error("expression program: more than %d decimal nodes", EX_MAX_DEC); return DBHIP_ERR_UNSUPPORTED; }
+          if ((!ex_decimal(ra.type) && (type_class(ra.type) == CLS_FLOAT || type_class(ra.type) < 0)) ||
+              (!ex_decimal(rb.type) && (type_class(rb.type) == CLS_FLOAT || type_class(rb.type) < 0))) {
+            set_error("expression program: instruction %d: decimal arithmetic with a non-integer operand (%d,%d)", i, ra.type, rb.type);
+            return DBHIP_ERR_UNSUPPORTED;
+          }
+          int ot, op_, os_;
+          int32_t rc = dbhip_decimal_decode_internal(aop, ra.type, ra.precision, ra.scale, rb.type, rb.precision, rb.scale, &P.dec[n_dec], &ot, &op_, &os_);
+          if (rc) return rc;
+          if (ot != s.type || (s_prec && (s_prec != op_ || s_scale != os_))) {
+            set_error("expression program: instruction %d: decimal op %d yields type %d Decimal(%d,%d), the node says type %d Decimal(%d,%d)", i, s.op, ot, op_, os_, s.type, s_prec, s_scale);
+            return DBHIP_ERR_INVALID;
+          }
+          ex_decode(d, ra.type, rb.type);
+          d.op = EX_DEC; d.dec_idx = (int8_t)n_dec++;
+          d.a_dec = ex_decimal(ra.type); d.b_dec = ex_decimal(rb.type);
+          res.precision = op_; res.scale = os_;
+          res.may_raise = true;
+        } else {
+          if (!ex_numeric(ra.type) || !ex_numeric(rb.type) || dbhip_arith_result_type(aop, ra.type, rb.type) != s.type) {
+            set_error("expression program: instruction %d: op %d on types (%d,%d) does not yield type %d (arithmetics_type.rs)", i, s.op, ra.type, rb.type, s.type);
+            return DBHIP_ERR_INVALID;
+          }
+          ex_decode(d, ra.type, rb.type);
+          res.may_raise = s.op == DBHIP_EX_DIVIDE;
+        }
+        res.dep = ra.dep | rb.dep;
+        res.may_raise |= ra.may_raise | rb.may_raise;
+      } break;
+      case DBHIP_EX_EQ: case DBHIP_EX_NOTEQ: case DBHIP_EX_LT: case DBHIP_EX_LTE: case DBHIP_EX_GT: case DBHIP_EX_GTE: {
+        if (!ok_reg(s.a) || !ok_reg(s.b)) { set_error("expression program: instruction %d reads an unset register", i); return DBHIP_ERR_INVALID; }
+        const RegInfo &ra = reg[s.a], &rb = reg[s.b];
+        if (ra.type != rb.type || s.type != DBHIP_T_BOOL || (ex_decimal(ra.type) && ra.scale != rb.scale)) {
+          set_error("expression program: instruction %d: comparison needs equal operand types (%d,%d; decimals: equal scales) and a Boolean result", i, ra.type, rb.type);
+          return DBHIP_ERR_INVALID;
+        }
+        ex_decode(d, ra.type, rb.type);
+        res.dep = ra.dep | rb.dep; res.may_raise = ra.may_raise | rb.may_raise;
+      } break;
+      case DBHIP_EX_AND: case DBHIP_EX_OR: case DBHIP_EX_NOT: {
+        const bool unary = s.op == DBHIP_EX_NOT;
+        if (!ok_reg(s.a) || (!unary && !ok_reg(s.b)) || reg[s.a].type != DBHIP_T_BOOL || (!unary && reg[s.b].type != DBHIP_T_BOOL) || s.type != DBHIP_T_BOOL) {
+          set_error("expression program: instruction %d: Boolean operator on non-Boolean registers", i);
+          return DBHIP_ERR_INVALID;
+        }
+        ex_decode(d, DBHIP_T_BOOL, DBHIP_T_BOOL);
+        res.dep = reg[s.a].dep | (unary ? 0 : reg[s.b].dep);
+        res.may_raise = reg[s.a].may_raise | (unary ? false : reg[s.b].may_raise);
+      } break;
+      case DBHIP_EX_CAST: {
+        if (!ok_reg(s.a)) { set_error("expression program: instruction %d reads an unset register", i); return DBHIP_ERR_INVALID; }
+        const RegInfo& ra = reg[s.a];
+        if (s.type == DBHIP_T_DEC128 || ra.type == DBHIP_T_DEC128 || (ex_decimal(s.type) != ex_decimal(ra.type))) {
+          // decimal widening keeps the scale (decimal_expand_cast faster path, cast.rs:901-979): Decimal64 -> Decimal128 only
+          if (!(ra.type == DBHIP_T_DEC64 && s.type == DBHIP_T_DEC128 && (!s_prec || (s_scale == ra.scale && s_prec >= ra.precision)))) {
+            set_error("expression program: CAST %d -> %d: only Decimal64 -> Decimal128 at the same scale is fused; keep the checked CPU cast", ra.type, s.type);
+            return DBHIP_ERR_UNSUPPORTED;
+          }
+          res.precision = s_prec ? s_prec : 38; res.scale = ra.scale;
+        } else {
+          if (!ex_numeric(ra.type) || !ex_numeric(s.type)) { set_error("expression program: instruction %d: CAST %d -> %d", i, ra.type, s.type); return DBHIP_ERR_INVALID; }
+          if (!ex_lossless_cast(ra.type, s.type)) { set_error("expression program: CAST %d -> %d can overflow: keep the checked CPU cast", ra.type, s.type); return DBHIP_ERR_UNSUPPORTED; }
+          res.precision = ra.precision; res.scale = ra.scale;
+        }
+        ex_decode(d, ra.type, -1);
+        res.dep = ra.dep; res.may_raise = ra.may_raise;
+      } break;
+      case DBHIP_EX_IF: {
+        // if(cond, then, else) (evaluator.rs:284-305 evaluates the branches under the condition's validity, so an error in
+        // the branch a row does not take is never raised): fused only when neither branch can raise — then it is a select
+        const int rc_ = (int)(s.imm & 0xFF);
+        if (!ok_reg(s.a) || !ok_reg(s.b) || !ok_reg(rc_) || reg[s.a].type != DBHIP_T_BOOL) { set_error("expression program: instruction %d: if(cond, then, else) needs a Boolean condition and two set registers", i); return DBHIP_ERR_INVALID; }
+        const RegInfo &rt = reg[s.b], &re = reg[rc_];
+        if (rt.type != re.type || rt.type != s.type || (ex_decimal(rt.type) && (rt.scale != re.scale))) { set_error("expression program: instruction %d: the branches of if() must have the node's type (%d,%d -> %d)", i, rt.type, re.type, s.type); return DBHIP_ERR_INVALID; }
+        if (rt.may_raise || re.may_raise) { set_error("expression program: a branch of if() can raise a row error; keep the CPU evaluator's lazy branches"); return DBHIP_ERR_UNSUPPORTED; }
+        if (reg[s.a].dep) { set_error("expression program: if() on a nullable condition is not fused"); return DBHIP_ERR_UNSUPPORTED; }
+        ex_decode(d, rt.type, re.type);
+        d.a = (int16_t)reg[s.a].loc; d.b = (int16_t)rt.loc; d.c = (int16_t)re.loc;
+        d.imm = 0;
+        res.precision = rt.precision > re.precision ? rt.precision : re.precision; res.scale = rt.scale;
+        res.dep = rt.dep | re.dep;
+      } break;
+      default:
+        set_error("expression program: instruction %d: unknown op %d", i, s.op);
+        return DBHIP_ERR_INVALID;
+    }
+    d.dep = (uint8_t)res.dep;
+    may_raise |= res.may_raise;
+    reg[s.dst] = res;
+    ++n_out;
+    if (i + 1 == n_filter_ins_src) P.n_filter_ins = n_out;
+  }
+  // roots
+  constexpr int NLOC = EX_MAX_REGS + EX_MAX_INPUTS;
+  int root_loc[EX_MAX_ROOTS];
+  for (int r = 0; r < n_roots; ++r) {
+    ExRoot& R = roots[r];
+    if (R.reg >= 0) {
+      if (R.reg >= EX_MAX_REGS || reg[R.reg].type < 0) { set_error("expression program: result register %d is never written", R.reg); return DBHIP_ERR_INVALID; }
+      const RegInfo& ri = reg[R.reg];
+      root_loc[r] = ri.loc; R.type = ri.type; R.precision = ri.precision; R.scale = ri.scale; R.dep = ri.dep;
+    } else {
+      const int c = -R.reg - 1;
+      if (c >= n_inputs) { set_error("expression program: result names input column %d of %d", c, n_inputs); return DBHIP_ERR_INVALID; }
+      root_loc[r] = EX_MAX_REGS + c; R.type = inputs_host[c].type; R.precision = inputs_host[c].precision; R.scale = inputs_host[c].scale;
+      R.dep = inputs_host[c].validity ? (1u << c) : 0;
+      any_nullable |= inputs_host[c].validity != nullptr;
+    }
+    R.wide = R.type == DBHIP_T_DEC128;
+  }
+  if (filter_root >= 0 && roots[filter_root].type != DBHIP_T_BOOL) { set_error("expression program: the filter must be Boolean"); return DBHIP_ERR_INVALID; }
+  // LDS slot allocation. A LOCATION is a user temporary (0..EX_MAX_REGS-1) or an input column (EX_MAX_REGS + c); its value is
+  // live from its definition to its last read before the next definition (a root's last value lives to the end). Slots
+  // are handed out in one forward walk; an operand that dies in an instruction frees its slot(s) BEFORE the destination is
+  // placed, so results overwrite dead operands in place (every thread reads its own cells of a, b, c before it writes
+  // dst). 128-bit locations take two adjacent slots. The LDS footprint per wave is what bounds the kernels' occupancy.
+  {
+    int slot_of[NLOC], width[NLOC];
+    bool used[EX_MAX_SLOTS + 2];
+    for (int l = 0; l < NLOC; ++l) { slot_of[l] = -1; width[l] = 1; }
+    for (int q = 0; q < EX_MAX_SLOTS + 2; ++q) used[q] = false;
+    int n_slots = 0;
+    auto take = [&](int w) {
+      for (int q = 0; q + w <= EX_MAX_SLOTS; ++q) {
+        bool free_ = !used[q] && (w == 1 || !used[q + 1]);
+        if (free_) { used[q] = true; if (w == 2) used[q + 1] = true; if (q + w > n_slots) n_slots = q + w; return q; }
+      }
+      return -1;
+    };
+    auto release = [&](int loc) { if (slot_of[loc] >= 0) { used[slot_of[loc]] = false; if (width[loc] == 2) used[slot_of[loc] + 1] = false; slot_of[loc] = -1; } };
+    auto reads = [&](const ExIns& I, int loc) {
+      if (I.op == EX_CONST) return false;
+      if (I.a == loc) return true;
+      if (I.op == EX_IF && I.c == loc) return true;
+      return I.op != EX_NOT && I.op != EX_CAST && I.b == loc;
+    };
+    auto is_root = [&](int loc) { for (int r = 0; r < n_roots; ++r) if (root_loc[r] == loc) return true; return false; };
+    auto live_after = [&](int i, int loc) {
+      for (int j = i + 1; j < n_out; ++j) {
+        if (reads(P.ins[j], loc)) return true;
+        if (P.ins[j].dst == loc) return false;
+      }
+      return is_root(loc);
+    };
+    bool fail = false;
+    for (int c = 0; c < n_inputs; ++c) {
+      const int loc = EX_MAX_REGS + c;
+      width[loc] = inputs_host[c].type == DBHIP_T_DEC128 ? 2 : 1;
+      P.in_slot[c] = -1;
+      bool any = is_root(loc);
+      for (int j = 0; j < n_out && !any; ++j) any = reads(P.ins[j], loc);
+      if (any) { slot_of[loc] = take(width[loc]); P.in_slot[c] = slot_of[loc]; fail |= slot_of[loc] < 0; }
+    }
+    for (int i = 0; i < n_out && !fail; ++i) {
+      ExIns& I = P.ins[i];
+      const int la = I.a, lb = I.b, lc = I.c, ld = I.dst;
+      const bool ra = reads(I, la), rb = I.op != EX_CONST && I.op != EX_NOT && I.op != EX_CAST && reads(I, lb), rc3 = I.op == EX_IF;
+      const int sa = ra ? slot_of[la] : 0, sb = rb ? slot_of[lb] : 0, sc = rc3 ? slot_of[lc] : 0;
+      if (ra && !live_after(i, la) && la != ld) release(la);
+      if (rb && lb != la && !live_after(i, lb) && lb != ld) release(lb);
+      if (rc3 && lc != la && lc != lb && !live_after(i, lc) && lc != ld) release(lc);
+      release(ld);  // the old value of dst ends here (read above if it was an operand)
+      width[ld] = I.o_wide ? 2 : 1;
+      slot_of[ld] = take(width[ld]);
+      fail |= slot_of[ld] < 0;
+      I.a = (int16_t)(sa < 0 ? 0 : sa); I.b = (int16_t)(sb < 0 ? 0 : sb); I.c = (int16_t)(sc < 0 ? 0 : sc); I.dst = (int16_t)slot_of[ld];
+    }
+    if (fail) { set_error("expression program: more than %d live LDS slots; split the expression", EX_MAX_SLOTS); return DBHIP_ERR_UNSUPPORTED; }
+    for (int r = 0; r < n_roots; ++r) roots[r].slot = slot_of[root_loc[r]];
+    P.n_slots = n_slots;
+  }
+  P.n_ins = n_out; P.n_inputs = n_inputs;
+  P.filter_slot = filter_root >= 0 ? roots[filter_root].slot : -1;
+  P.filter_dep = filter_root >= 0 ? roots[filter_root].dep : 0;
+  if (filter_root < 0) P.n_filter_ins = 0;
+  if (out_may_raise) *out_may_raise = may_raise;
+  if (out_any_nullable) *out_any_nullable = any_nullable;
+  return DBHIP_OK;
+}
 
 extern "C" {
 
 int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const dbhip_col* inputs_host, int32_t n_inputs,
                         int64_t n, int32_t out_reg, void* out_values, uint8_t* out_validity, uint8_t* err_bitmap,
                         uint64_t* err_count_dev, void* sum_out_dev, void* stream) {
-  DBHIP_REQUIRE(prog_host && n_ins >= 1 && n_ins <= EX_MAX_INS, "dbhip_expr_eval: 1..32 instructions");
-  DBHIP_REQUIRE(n_inputs >= 0 && n_inputs <= EX_MAX_INPUTS && (inputs_host || n_inputs == 0), "dbhip_expr_eval: 0..8 input columns");
+  DBHIP_REQUIRE(prog_host && n_ins >= 1, "dbhip_expr_eval: empty program");
   DBHIP_REQUIRE(out_reg >= 0 && out_reg < EX_MAX_REGS && n >= 0, "dbhip_expr_eval: bad out register / n");
+  if (n == 0) {
+    hipStream_t s0 = resolve_stream(stream);
+    (void)s0;
+  }
+  for (int c = 0; c < n_inputs; ++c) DBHIP_REQUIRE(inputs_host[c].data || n == 0, "dbhip_expr_eval: NULL input column");
   ExProg P;
-  memset(&P, 0, sizeof(P));
-  int reg_type[EX_MAX_REGS];
-  int reg_loc[EX_MAX_REGS];  // where the register's current value lives: temp r, or EX_MAX_REGS + input column
-  int n_out = 0;             // instructions kept (LOADs are compiled away)
-  for (int r = 0; r < EX_MAX_REGS; ++r) { reg_type[r] = -1; reg_loc[r] = r; }
-  bool any_nullable = false, may_raise = false;
-  for (int c = 0; c < n_inputs; ++c) {
-    const dbhip_col& col = inputs_host[c];
-    if (!(ex_numeric(col.type) || col.type == DBHIP_T_BOOL)) {
-      set_error("dbhip_expr_eval: input %d has type %d (numeric, date, timestamp, decimal64-as-i64 and boolean columns only)", c, col.type);
-      return DBHIP_ERR_UNSUPPORTED;
-    }
-    DBHIP_REQUIRE(col.data || n == 0, "dbhip_expr_eval: NULL input column");
-    P.in_data[c] = col.data; P.in_valid[c] = col.validity; P.in_voff[c] = col.validity_offset;
-    P.in_type[c] = ex_load_kind(col.type); P.in_scalar[c] = col.is_scalar;
-  }
-  for (int i = 0; i < n_ins; ++i) {
-    const dbhip_expr_ins& s = prog_host[i];
-    ExIns& d = P.ins[n_out];
-    if (s.dst < 0 || s.dst >= EX_MAX_REGS) { set_error("dbhip_expr_eval: instruction %d: register %d out of range (0..7)", i, s.dst); return DBHIP_ERR_INVALID; }
-    d.op = (int16_t)s.op; d.dst = (int16_t)s.dst; d.type = (int16_t)s.type; d.imm = s.imm;
-    d.a = (int16_t)((s.a >= 0 && s.a < EX_MAX_REGS) ? reg_loc[s.a] : 0);
-    d.b = (int16_t)((s.b >= 0 && s.b < EX_MAX_REGS) ? reg_loc[s.b] : 0);
-    auto src = [&](int r) -> int { return (r >= 0 && r < EX_MAX_REGS) ? reg_type[r] : -1; };
-    switch (s.op) {
-      case DBHIP_EX_LOAD:
-        if (s.a < 0 || s.a >= n_inputs || inputs_host[s.a].type != s.type) { set_error("dbhip_expr_eval: instruction %d: LOAD of input %d as type %d", i, s.a, s.type); return DBHIP_ERR_INVALID; }
-        any_nullable |= inputs_host[s.a].validity != nullptr;
-        reg_type[s.dst] = s.type;
-        reg_loc[s.dst] = EX_MAX_REGS + s.a;
-        continue;  // no instruction: the value is read straight from the input register
-      case DBHIP_EX_CONST:
-        if (!(ex_numeric(s.type) || s.type == DBHIP_T_BOOL)) { set_error("dbhip_expr_eval: instruction %d: CONST of type %d", i, s.type); return DBHIP_ERR_INVALID; }
-        ex_decode(d, -1, -1);
-        break;
-      case DBHIP_EX_PLUS: case DBHIP_EX_MINUS: case DBHIP_EX_MULTIPLY: case DBHIP_EX_DIVIDE: {
-        const int ta = src(s.a), tb = src(s.b);
-        const int aop = s.op == DBHIP_EX_PLUS ? DBHIP_OP_PLUS : s.op == DBHIP_EX_MINUS ? DBHIP_OP_MINUS : s.op == DBHIP_EX_MULTIPLY ? DBHIP_OP_MULTIPLY : DBHIP_OP_DIVIDE;
-        if (ta < 0 || tb < 0 || !ex_numeric(ta) || !ex_numeric(tb) || dbhip_arith_result_type(aop, ta, tb) != s.type) {
-          set_error("dbhip_expr_eval: instruction %d: op %d on types (%d,%d) does not yield type %d (arithmetics_type.rs)", i, s.op, ta, tb, s.type);
-          return DBHIP_ERR_INVALID;
-        }
-        ex_decode(d, ta, tb);
-        may_raise |= s.op == DBHIP_EX_DIVIDE;
-      } break;
-      case DBHIP_EX_EQ: case DBHIP_EX_NOTEQ: case DBHIP_EX_LT: case DBHIP_EX_LTE: case DBHIP_EX_GT: case DBHIP_EX_GTE: {
-        const int ta = src(s.a), tb = src(s.b);
-        if (ta < 0 || ta != tb || s.type != DBHIP_T_BOOL) { set_error("dbhip_expr_eval: instruction %d: comparison needs equal operand types (%d,%d) and a Boolean result", i, ta, tb); return DBHIP_ERR_INVALID; }
-        ex_decode(d, ta, tb);
-      } break;
-      case DBHIP_EX_AND: case DBHIP_EX_OR: case DBHIP_EX_NOT: {
-        const int ta = src(s.a), tb = s.op == DBHIP_EX_NOT ? DBHIP_T_BOOL : src(s.b);
-        if (ta != DBHIP_T_BOOL || tb != DBHIP_T_BOOL || s.type != DBHIP_T_BOOL) { set_error("dbhip_expr_eval: instruction %d: Boolean operator on non-Boolean registers", i); return DBHIP_ERR_INVALID; }
-        ex_decode(d, DBHIP_T_BOOL, DBHIP_T_BOOL);
-      } break;
-      case DBHIP_EX_CAST: {
-        const int ta = src(s.a);
-        if (ta < 0 || !ex_numeric(ta) || !ex_numeric(s.type)) { set_error("dbhip_expr_eval: instruction %d: CAST %d -> %d", i, ta, s.type); return DBHIP_ERR_INVALID; }
-        if (!ex_lossless_cast(ta, s.type)) { set_error("dbhip_expr_eval: CAST %d -> %d can overflow: keep the checked CPU cast", ta, s.type); return DBHIP_ERR_UNSUPPORTED; }
-        ex_decode(d, ta, -1);
-      } break;
-      default:
-        set_error("dbhip_expr_eval: instruction %d: unknown op %d", i, s.op);
-        return DBHIP_ERR_INVALID;
-    }
-    reg_type[s.dst] = s.type;
-    reg_loc[s.dst] = s.dst;
-    ++n_out;
-  }
-  if (reg_type[out_reg] < 0) { set_error("dbhip_expr_eval: out register %d is never written", out_reg); return DBHIP_ERR_INVALID; }
+  ExRoot root;
+  memset(&root, 0, sizeof(root));
+  root.reg = out_reg;
+  bool may_raise = false, any_nullable = false;
+  // (n == 0: inputs may carry NULL data pointers; give the checker a harmless address)
+  dbhip_col tmp_in[EX_MAX_INPUTS];
+  for (int c = 0; c < n_inputs && c < EX_MAX_INPUTS; ++c) { tmp_in[c] = inputs_host[c]; if (!tmp_in[c].data) tmp_in[c].data = &tmp_in[c]; }
+  int32_t rc = dbhip_expr_compile_internal(prog_host, n_ins, n_inputs ? tmp_in : nullptr, n_inputs, &root, 1, -1, &P, &may_raise, &any_nullable);
+  if (rc) return rc;
   DBHIP_REQUIRE(out_values || sum_out_dev, "dbhip_expr_eval: neither an output column nor a sum was asked for");
-  DBHIP_REQUIRE(!sum_out_dev || ex_numeric(reg_type[out_reg]), "dbhip_expr_eval: sum needs a numeric result");
+  DBHIP_REQUIRE(!sum_out_dev || (ex_numeric(root.type) && root.type != DBHIP_T_DEC128), "dbhip_expr_eval: sum needs a numeric (<= 64-bit) result");
   DBHIP_REQUIRE(!any_nullable || out_validity || sum_out_dev, "dbhip_expr_eval: nullable inputs need out_validity");
   hipStream_t s = resolve_stream(stream);
   if (err_bitmap) DBHIP_CHECK(hipMemsetAsync(err_bitmap, 0xFF, (size_t)ceil_div(n, 32) * 4, s));
   if (n == 0) return DBHIP_OK;
-  P.n_ins = n_out; P.n_inputs = n_inputs; P.out_type = reg_type[out_reg]; P.n = n;
-  P.out_values = out_values; P.out_validity = (uint64_t*)out_validity;
   P.err_words = may_raise ? (uint32_t*)err_bitmap : nullptr;
   P.err_count = may_raise ? (unsigned long long*)err_count_dev : nullptr;
-  P.sum_out = (unsigned long long*)sum_out_dev;
+  ExOut O;
+  memset(&O, 0, sizeof(O));
+  O.n = n; O.out_values = out_values; O.out_validity = (uint64_t*)out_validity; O.sum_out = (unsigned long long*)sum_out_dev;
+  O.out_slot = root.slot; O.out_dep = root.dep; O.out_cls = ex_cls(root.type);
+  switch (root.type) {
+    case DBHIP_T_BOOL: O.out_kind = 0; break;
+    case DBHIP_T_F32: O.out_kind = -4; break;
+    case DBHIP_T_DEC128: O.out_kind = 16; break;
+    default: O.out_kind = type_bits(root.type) / 8; break;
+  }
   static const bool force2 = getenv("DBHIP_EXPR_ROWS2") != nullptr;
   kernel_timer_start(s);
-  // LDS register allocation. A LOCATION is a user temporary (0..7) or an input column (EX_MAX_REGS + c); its value is live
-  // from its definition to its last read before the next definition (the out register's last value lives to the end).
-  // Slots are handed out in one forward walk; an operand that dies in an instruction frees its slot BEFORE the
-  // destination is placed, so results overwrite dead operands in place (every thread reads its own cells of a and b before
-  // it writes dst). a + b * c needs 3 slots instead of 5: the LDS footprint per wave is what bounds this kernel's
-  // occupancy, and with it how many loads are in flight.
-  {
-    constexpr int NLOC = EX_MAX_REGS + EX_MAX_INPUTS;
-    const int out_loc = reg_loc[out_reg];
-    int slot_of[NLOC];
-    bool used[NLOC];
-    for (int l = 0; l < NLOC; ++l) { slot_of[l] = -1; used[l] = false; }
-    int n_slots = 0;
-    auto take = [&]() { for (int q = 0; q < NLOC; ++q) if (!used[q]) { used[q] = true; if (q + 1 > n_slots) n_slots = q + 1; return q; } return -1; };
-    auto reads = [&](const ExIns& I, int loc) {
-      if (I.op == DBHIP_EX_CONST) return false;
-      if (I.a == loc) return true;
-      return I.op != DBHIP_EX_NOT && I.op != DBHIP_EX_CAST && I.b == loc;
-    };
-    // is the value that location `loc` holds right after instruction i still read later?
-    auto live_after = [&](int i, int loc) {
-      for (int j = i + 1; j < n_out; ++j) {
-        if (reads(P.ins[j], loc)) return true;
-        if (P.ins[j].dst == loc) return false;
-      }
-      return loc == out_loc;
-    };
-    // input columns the program (or the result) reads get their slots first: the kernel fills them at the top of every chunk
-    for (int c = 0; c < n_inputs; ++c) {
-      const int loc = EX_MAX_REGS + c;
-      P.in_slot[c] = -1;
-      bool any = loc == out_loc;
-      for (int j = 0; j < n_out && !any; ++j) any = reads(P.ins[j], loc);
-      if (any) { slot_of[loc] = take(); P.in_slot[c] = slot_of[loc]; }
-    }
-    for (int i = 0; i < n_out; ++i) {
-      ExIns& I = P.ins[i];
-      const int la = I.a, lb = I.b, ld = I.dst;
-      const bool ra = reads(I, la), rb = reads(I, lb) && lb != la;
-      const int sa = ra ? slot_of[la] : 0, sb = (reads(I, lb)) ? slot_of[lb] : 0;
-      if (ra && !live_after(i, la) && la != ld) { used[slot_of[la]] = false; slot_of[la] = -1; }
-      if (rb && !live_after(i, lb) && lb != ld) { used[slot_of[lb]] = false; slot_of[lb] = -1; }
-      if (slot_of[ld] >= 0) { used[slot_of[ld]] = false; slot_of[ld] = -1; }  // the old value of dst ends here (read above if it was an operand)
-      slot_of[ld] = take();
-      I.a = (int16_t)(sa < 0 ? 0 : sa); I.b = (int16_t)(sb < 0 ? 0 : sb); I.dst = (int16_t)slot_of[ld];
-    }
-    P.out_reg = slot_of[out_loc];
-    P.n_slots = n_slots;
-  }
-  P.out_cls = ex_cls(P.out_type);
-  switch (P.out_type) {
-    case DBHIP_T_BOOL: P.out_kind = 0; break;
-    case DBHIP_T_F32: P.out_kind = -4; break;
-    default: P.out_kind = type_bits(P.out_type) / 8; break;
-  }
   // row slots per lane: 4 (32 B per operand per lane in flight, half the per-row interpreter overhead) while the LDS register
   // file allows it, else 2
-  int rows_per_lane = EX_ROWS;
+  int rows_per_lane = 2;
   if (!force2 && (size_t)P.n_slots * 4 * 256 * 8 <= 64 * 1024) rows_per_lane = 4;
   const size_t lds = (size_t)(P.n_slots > 0 ? P.n_slots : 1) * rows_per_lane * 256 * 8;
   if (lds > 64 * 1024) {
@@ -470,8 +494,8 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   const dim3 g(grid), b(256);
 #define EX_LAUNCH(NIN_, R_)                                                                   \
   do {                                                                                        \
-    if (all8) hipLaunchKernelGGL((expr_kernel<NIN_, true, R_>), g, b, lds, s, P);              \
-    else hipLaunchKernelGGL((expr_kernel<NIN_, false, R_>), g, b, lds, s, P);                  \
+    if (all8) hipLaunchKernelGGL((expr_kernel<NIN_, true, R_>), g, b, lds, s, P, O);           \
+    else hipLaunchKernelGGL((expr_kernel<NIN_, false, R_>), g, b, lds, s, P, O);               \
   } while (0)
   if (rows_per_lane == 4) {
     if (n_inputs <= 2) EX_LAUNCH(2, 4); else if (n_inputs <= 4) EX_LAUNCH(4, 4); else EX_LAUNCH(8, 4);

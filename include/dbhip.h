@@ -161,32 +161,43 @@ int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stre
  * Replaces Evaluator::run over a whole Expr tree (src/query/expression/src/evaluator.rs:229-464) /
  * BlockOperator::Map (src/query/sql/src/evaluator/block_operator.rs:42-85): instead of one kernel and one
  * materialised column per call node, the binding flattens the tree (post-order) into a register program
- * that ONE launch interprets; intermediates live in LDS, never in HBM. Registers 0..7; up to 32
- * instructions and 8 input columns (numeric / Date / Timestamp / Decimal64-as-i64 / Boolean).
- * Per-node semantics are those of dbhip_arith / dbhip_cmp (same reference lines): `type` is the node's
- * result type and must be the ResultTypeOfBinary entry for the operand registers' types (checked);
- * comparisons need equal operand types (the planner inserts CASTs; DBHIP_EX_CAST covers the lossless
- * widenings, anything that can overflow returns DBHIP_ERR_UNSUPPORTED); DIVIDE raises "divided by zero"
- * like dbhip_arith. NULLs: the result is NULL where any loaded nullable input is NULL
- * (passthrough_nullable, register_vectorize.rs:447-471); Boolean AND/OR are strict here (the three-valued
- * and_filters/or_filters special case, evaluator.rs:284-305, stays with dbhip_bitmap_binary).
- * Outputs: `out_values` = elements of the out register's type, or for a Boolean result an LSB-first
- * bitmap; `out_validity` likewise a bitmap. Bitmaps are written as whole 64-bit words: both buffers must
+ * that ONE launch interprets; intermediates live in LDS, never in HBM. Registers 0..15; up to 24
+ * instructions (LOADs not counted) and 8 input columns (numeric / Date / Timestamp / Decimal64 / Decimal128 /
+ * Boolean).
+ * Per-node semantics are those of dbhip_arith / dbhip_cmp / dbhip_decimal_arith (same reference lines): `type`
+ * is the node's result type and must be the ResultTypeOfBinary entry for the operand registers' types
+ * (checked). PLUS / MINUS / MULTIPLY / DIVIDE with a Decimal operand are binary_decimal
+ * (decimal/src/arithmetic.rs:190-316): the other operand may be an integer (other_to_decimal), `type` must be
+ * the storage class dbhip_decimal_result_size gives and `precision` / `scale` (when non-zero) its DecimalSize;
+ * up to 6 decimal nodes per program; row errors "Decimal overflow" / "divided by zero" like
+ * dbhip_decimal_arith. Comparisons need equal operand types (decimals: equal scales; the planner inserts
+ * CASTs; DBHIP_EX_CAST covers the lossless widenings incl. Decimal64 -> Decimal128 at the same scale, anything
+ * that can overflow returns DBHIP_ERR_UNSUPPORTED); DIVIDE raises "divided by zero" like dbhip_arith.
+ * DBHIP_EX_IF: dst = a ? b : (register imm) — if(cond, then, else) (evaluator.rs:284-305) for branches that
+ * cannot raise and a non-nullable condition (else DBHIP_ERR_UNSUPPORTED: the CPU evaluator's lazy branches stay).
+ * NULLs: the result is NULL where a nullable input the RESULT depends on is NULL (passthrough_nullable,
+ * register_vectorize.rs:447-471), and a node raises only for rows where the nullable inputs IT depends on are
+ * valid; Boolean AND/OR are strict here (the three-valued and_filters/or_filters special case,
+ * evaluator.rs:284-305, stays with dbhip_bitmap_binary).
+ * Outputs: `out_values` = elements of the out register's type (Decimal128: i128), or for a Boolean result an
+ * LSB-first bitmap; `out_validity` likewise a bitmap. Bitmaps are written as whole 64-bit words: both buffers must
  * hold ceil(n/64)*8 bytes and be 8-byte aligned; bits past n are zero. `sum_out_dev` (may be NULL): the
  * wrapping i64/u64 (or f64) sum of the out register over the non-NULL rows is ADDED to *sum_out_dev —
  * `SELECT sum(<expr>)` (BASELINE configs[0]) without materialising <expr>; out_values may then be NULL. */
 typedef enum {
   DBHIP_EX_LOAD = 0,     /* dst <- input column `a`                                 */
-  DBHIP_EX_CONST = 1,    /* dst <- imm (i64 / u64 value, or f64 bits for F32/F64)   */
+  DBHIP_EX_CONST = 1,    /* dst <- imm (i64 / u64 / Decimal64 value, or f64 bits for F32/F64) */
   DBHIP_EX_PLUS = 2, DBHIP_EX_MINUS = 3, DBHIP_EX_MULTIPLY = 4, DBHIP_EX_DIVIDE = 5,
   DBHIP_EX_EQ = 6, DBHIP_EX_NOTEQ = 7, DBHIP_EX_LT = 8, DBHIP_EX_LTE = 9, DBHIP_EX_GT = 10, DBHIP_EX_GTE = 11,
-  DBHIP_EX_AND = 12, DBHIP_EX_OR = 13, DBHIP_EX_NOT = 14, DBHIP_EX_CAST = 15
+  DBHIP_EX_AND = 12, DBHIP_EX_OR = 13, DBHIP_EX_NOT = 14, DBHIP_EX_CAST = 15,
+  DBHIP_EX_IF = 16       /* dst <- a ? b : register (imm & 0xFF)                     */
 } dbhip_expr_op;
 typedef struct {
   int32_t op;            /* dbhip_expr_op                                           */
   int32_t dst, a, b;     /* registers (a = input column index for LOAD)             */
   int32_t type;          /* dbhip_type of the result                                */
-  int32_t _pad;
+  uint8_t precision, scale;  /* DecimalSize of a decimal result / constant (0,0: derive) */
+  uint8_t _pad[2];
   uint64_t imm;
 } dbhip_expr_ins;
 int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const dbhip_col* inputs_host,
