@@ -245,12 +245,17 @@ def bench_operator_plan(li, tpch, D, L, check, fused_result, fused_kernel_ms):
     kernel. Two plans, both bit-exact against the fused kernel:
       literal   the reference's operator-at-a-time shape: cmp -> filter_select -> take x6 -> 4 decimal maps -> add_block
       pushdown  cmp -> Bitmap; the decimal maps and the partial aggregation read the unfiltered columns and the Bitmap
-                (tpch.q1_operator_pushdown; only when the library has the filtered group-by entry point)"""
+                (tpch.q1_operator_pushdown: dbhip_groupby_add_block_filtered)
+      fused_program  the binding flattens the predicate and the maps into ONE register program and the GENERIC fused
+                filter -> map -> partial-aggregate kernel interprets it (tpch.q1_fused_program:
+                dbhip_groupby_add_block_program) — no query-specific device code"""
     n = li.n
     out = {}
     plans = [("literal", tpch.q1_operator_at_a_time)]
     if hasattr(tpch, "q1_operator_pushdown"):
         plans.append(("pushdown", tpch.q1_operator_pushdown))
+    if hasattr(tpch, "q1_fused_program"):
+        plans.append(("fused_program", tpch.q1_fused_program))
     for name, fn in plans:
         try:
             g = fn(li)  # warm-up: allocations land in the block cache

@@ -42,6 +42,12 @@ class ExprIns(C.Structure):
                 ("precision", C.c_uint8), ("scale", C.c_uint8), ("_pad", C.c_uint8 * 2), ("imm", C.c_uint64)]
 
 
+class AggProgram(C.Structure):
+    """dbhip_agg_program"""
+    _fields_ = [("prog", C.c_void_p), ("n_ins", C.c_int32), ("inputs", C.c_void_p), ("n_inputs", C.c_int32), ("filter_reg", C.c_int32),
+                ("arg_regs", C.c_void_p)]
+
+
 class PqInfo(C.Structure):
     """dbhip_pq_info"""
     _fields_ = [("num_values", C.c_int64), ("num_nulls", C.c_int64), ("out_type", C.c_int32), ("has_validity", C.c_int32),
@@ -77,7 +83,7 @@ SYMBOLS = [
     "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized", "dbhip_groupby_flush_block",
     "dbhip_groupby_merge_blocks", "dbhip_groupby_add_block_filtered", "dbhip_groupby_partition_blocks",
     "dbhip_groupby_replace_with_blocks", "dbhip_groupby_flush_partitioned", "dbhip_groupby_flush_result_nullable",
-    "dbhip_groupby_state_fields", "dbhip_groupby_flush_state_block",
+    "dbhip_groupby_state_fields", "dbhip_groupby_flush_state_block", "dbhip_groupby_add_block_program",
     "dbhip_groupby_result_type", "dbhip_groupby_flush_result", "dbhip_groupby_reset",
     "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_keys_method", "dbhip_pack_keys",
     "dbhip_join_create", "dbhip_join_create_keys", "dbhip_join_probe_mark",

@@ -227,9 +227,55 @@ __host__ __device__ inline u256 u256_div_128(u256 a, u128 d, u128* rem) {
   return q;
 }
 
-// 10^k as i128 for k in [0, 38]
+// 10^k as i128 for k in [0, 38]. Device: a table (k is wave-uniform at every call site -> one scalar load; the loop of up
+// to 38 128-bit multiplies cost ~100 instructions per decimal node per row); host: the loop.
+static __device__ const uint64_t kDbhipPow10[39][2] = {
+  {0x0000000000000001ULL, 0x0000000000000000ULL},
+  {0x000000000000000aULL, 0x0000000000000000ULL},
+  {0x0000000000000064ULL, 0x0000000000000000ULL},
+  {0x00000000000003e8ULL, 0x0000000000000000ULL},
+  {0x0000000000002710ULL, 0x0000000000000000ULL},
+  {0x00000000000186a0ULL, 0x0000000000000000ULL},
+  {0x00000000000f4240ULL, 0x0000000000000000ULL},
+  {0x0000000000989680ULL, 0x0000000000000000ULL},
+  {0x0000000005f5e100ULL, 0x0000000000000000ULL},
+  {0x000000003b9aca00ULL, 0x0000000000000000ULL},
+  {0x00000002540be400ULL, 0x0000000000000000ULL},
+  {0x000000174876e800ULL, 0x0000000000000000ULL},
+  {0x000000e8d4a51000ULL, 0x0000000000000000ULL},
+  {0x000009184e72a000ULL, 0x0000000000000000ULL},
+  {0x00005af3107a4000ULL, 0x0000000000000000ULL},
+  {0x00038d7ea4c68000ULL, 0x0000000000000000ULL},
+  {0x002386f26fc10000ULL, 0x0000000000000000ULL},
+  {0x016345785d8a0000ULL, 0x0000000000000000ULL},
+  {0x0de0b6b3a7640000ULL, 0x0000000000000000ULL},
+  {0x8ac7230489e80000ULL, 0x0000000000000000ULL},
+  {0x6bc75e2d63100000ULL, 0x0000000000000005ULL},
+  {0x35c9adc5dea00000ULL, 0x0000000000000036ULL},
+  {0x19e0c9bab2400000ULL, 0x000000000000021eULL},
+  {0x02c7e14af6800000ULL, 0x000000000000152dULL},
+  {0x1bcecceda1000000ULL, 0x000000000000d3c2ULL},
+  {0x161401484a000000ULL, 0x0000000000084595ULL},
+  {0xdcc80cd2e4000000ULL, 0x000000000052b7d2ULL},
+  {0x9fd0803ce8000000ULL, 0x00000000033b2e3cULL},
+  {0x3e25026110000000ULL, 0x00000000204fce5eULL},
+  {0x6d7217caa0000000ULL, 0x00000001431e0faeULL},
+  {0x4674edea40000000ULL, 0x0000000c9f2c9cd0ULL},
+  {0xc0914b2680000000ULL, 0x0000007e37be2022ULL},
+  {0x85acef8100000000ULL, 0x000004ee2d6d415bULL},
+  {0x38c15b0a00000000ULL, 0x0000314dc6448d93ULL},
+  {0x378d8e6400000000ULL, 0x0001ed09bead87c0ULL},
+  {0x2b878fe800000000ULL, 0x0013426172c74d82ULL},
+  {0xb34b9f1000000000ULL, 0x00c097ce7bc90715ULL},
+  {0x00f436a000000000ULL, 0x0785ee10d5da46d9ULL},
+  {0x098a224000000000ULL, 0x4b3b4ca85a86c47aULL}};
 __host__ __device__ __forceinline__ i128 pow10_i128(int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  k = k < 0 ? 0 : (k > 38 ? 38 : k);
+  return (i128)(((u128)kDbhipPow10[k][1] << 64) | kDbhipPow10[k][0]);
+#else
   i128 r = 1;
   for (int i = 0; i < k; ++i) r *= 10;
   return r;
+#endif
 }

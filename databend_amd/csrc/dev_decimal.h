@@ -18,14 +18,16 @@ struct DecOp {
   int ret_precision, ret_scale;
   int overflow;       // return precision == T::MAX_PRECISION
   int scale_mul;      // multiply: sa+sb-sr ; divide: sb+sr-sa
+  int trivial;        // (fused interpreter) both operands arrive at their bound sizes and the op is a plain wrapping
+                      // +, - or * in T with nothing to check: computed inline, no call
 };
 
-__device__ __forceinline__ i128 wrap_T(i128 v, bool t128) { return t128 ? v : (i128)(int64_t)v; }
+__host__ __device__ __forceinline__ i128 wrap_T(i128 v, bool t128) { return t128 ? v : (i128)(int64_t)v; }
 
-__device__ __forceinline__ i128 max_for_precision(int p) { return pow10_i128(p) - 1; }
+__host__ __device__ __forceinline__ i128 max_for_precision(int p) { return pow10_i128(p) - 1; }
 
 // checked multiply in T (i64 or i128)
-__device__ __forceinline__ bool checked_mul_T(i128 x, i128 f, bool t128, i128* out) {
+__host__ __device__ __forceinline__ bool checked_mul_T(i128 x, i128 f, bool t128, i128* out) {
   if (!t128) {
     i128 r = x * f;  // both fit in i64 -> exact in i128
     if (r > (i128)INT64_MAX || r < (i128)INT64_MIN) return false;
@@ -43,7 +45,7 @@ __device__ __forceinline__ bool checked_mul_T(i128 x, i128 f, bool t128, i128* o
 }
 
 // Brings an operand to its bound (precision, scale) in T. Returns false on "Decimal overflow".
-__device__ __forceinline__ bool convert_operand(i128 x, bool is_decimal, int from_scale, int to_scale,
+__host__ __device__ __forceinline__ bool convert_operand(i128 x, bool is_decimal, int from_scale, int to_scale,
                                                 int to_precision, int check, bool t128, i128* out) {
   if (!is_decimal) {
     // integer_to_decimal (cast.rs:701-753): scale 0 never checks
@@ -166,6 +168,34 @@ __device__ __forceinline__ bool dec_row(const DecOp& p, i128 av, i128 bv, bool a
     return ok;
 }
 
+
+// The division-free subset of dec_row, inlined by the fused interpreter (dev_expr.h): operand conversions (multiplies by
+// powers of ten with their range checks), plus / minus with the precision-38/18 check, multiply at scale_mul == 0.
+// The rounding multiply (scale_mul > 0) and divide need 128- / 256-bit divisions that the compiler expands in place
+// (~600 instructions each, half a dozen per row slot: larger than the instruction cache; as an out-of-line call they cost
+// 2 KB of scratch per lane for the callee-saved registers) — the host rejects such nodes for fused programs and the
+// binding evaluates them with dbhip_decimal_arith.
+__device__ __forceinline__ bool dec_row_nodiv(const DecOp& p, i128 av, i128 bv, bool a_dec, bool b_dec, bool t128, i128* out) {
+  i128 a, b, r = 1;
+  bool ok = convert_operand(av, a_dec, p.a_from_scale, p.a_to_scale, p.a_to_precision, p.a_check, t128, &a);
+  ok = convert_operand(bv, b_dec, p.b_from_scale, p.b_to_scale, p.b_to_precision, p.b_check, t128, &b) && ok;
+  if (ok) {
+    if (p.op == DBHIP_OP_MULTIPLY) {
+      r = wrap_T((i128)((u128)a * (u128)b), t128);   // scale_mul == 0 (checked on the host)
+    } else {
+      i128 t = p.op == DBHIP_OP_PLUS ? (i128)((u128)a + (u128)b) : (i128)((u128)a - (u128)b);
+      t = wrap_T(t, t128);
+      if (p.overflow) {
+        const i128 mx = max_for_precision(p.ret_precision);
+        if (t < -mx || t > mx) ok = false;
+      }
+      r = t;
+    }
+  }
+  *out = r;
+  return ok;
+}
+inline bool dec_op_needs_division(const DecOp& p) { return p.op == DBHIP_OP_DIVIDE || (p.op == DBHIP_OP_MULTIPLY && p.scale_mul != 0); }
 
 // host: decode one decimal call node (k_decimal.hip)
 int32_t dbhip_decimal_decode_internal(int op, int a_type, int a_prec, int a_scale, int b_type, int b_prec, int b_scale,

@@ -47,6 +47,7 @@ struct ExProg {
   int32_t in_type[EX_MAX_INPUTS];   // load kind, see ex_load
   int32_t in_scalar[EX_MAX_INPUTS];
   int32_t in_slot[EX_MAX_INPUTS];   // LDS slot of input column c (-1: the program never reads it)
+  int32_t in_wide_ord[EX_MAX_INPUTS];  // 128-bit input columns: 0 / 1 = which of the (at most two) hi-word staging registers, else -1
   int32_t n_ins, n_inputs, n_slots;
   int32_t n_filter_ins;             // leading instructions that compute the filter (0 = no filter stage)
   int32_t filter_slot;              // slot of the filter's Boolean (-1: none)
@@ -106,8 +107,10 @@ __device__ __forceinline__ void ex_interpret(const ExProg& P, uint64_t* ex_regs,
                                              const int64_t (&row)[ROWS], const bool (&live)[ROWS],
                                              const uint32_t (&vmask)[ROWS]) {
 #define EX_REG(r, k) ex_regs[((r) * ROWS + (k)) * 256 + tid]
+  ExIns nxt = P.ins[pc0 < EX_MAX_INS ? pc0 : 0];
   for (int pc = pc0; pc < pc1; ++pc) {
-    const ExIns I = P.ins[pc];
+    const ExIns I = nxt;
+    nxt = P.ins[pc + 1 < EX_MAX_INS ? pc + 1 : 0];   // the scalar load of the next instruction overlaps this one's work
     const int acls = I.acls, bcls = I.bcls, ocls = I.ocls;
 #define EX_ROWS_DO(EXPR)                                  \
   _Pragma("unroll") for (int k = 0; k < ROWS; ++k) {      \
@@ -164,17 +167,30 @@ __device__ __forceinline__ void ex_interpret(const ExProg& P, uint64_t* ex_regs,
         }
         break;
       case EX_DEC: {
-        const DecOp D = P.dec[I.dec_idx];
+        const DecOp* D = &P.dec[I.dec_idx];
+        const bool t128 = D->t_is_128 != 0;
+        if (D->trivial) {  // operands already at their bound sizes, a plain wrapping op in T (e.g. Q1's products)
+          const int dop = D->op;
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-          const i128 av = EX_RD128(I.a, I.a_wide, acls, k), bv = EX_RD128(I.b, I.b_wide, bcls, k);
-          i128 r;
-          if (!dec_row(D, av, bv, I.a_dec != 0, I.b_dec != 0, D.t_is_128 != 0, &r)) {
-            EX_RAISE(k);
-            r = 1;  // error rows hold T::one(), like the reference builders
+          for (int k = 0; k < ROWS; ++k) {
+            const i128 av = wrap_T(EX_RD128(I.a, I.a_wide, acls, k), t128), bv = wrap_T(EX_RD128(I.b, I.b_wide, bcls, k), t128);
+            const u128 ua = (u128)av, ub = (u128)bv;
+            const i128 r = wrap_T((i128)(dop == DBHIP_OP_PLUS ? ua + ub : (dop == DBHIP_OP_MINUS ? ua - ub : ua * ub)), t128);
+            EX_REG(I.dst, k) = (uint64_t)(u128)r;
+            if (I.o_wide) EX_REG(I.dst + 1, k) = (uint64_t)((u128)r >> 64);
           }
-          EX_REG(I.dst, k) = (uint64_t)(u128)r;
-          if (I.o_wide) EX_REG(I.dst + 1, k) = (uint64_t)((u128)r >> 64);
+        } else {
+#pragma unroll
+          for (int k = 0; k < ROWS; ++k) {
+            const i128 av = EX_RD128(I.a, I.a_wide, acls, k), bv = EX_RD128(I.b, I.b_wide, bcls, k);
+            i128 r;
+            if (!dec_row_nodiv(*D, av, bv, I.a_dec != 0, I.b_dec != 0, t128, &r)) {
+              EX_RAISE(k);
+              r = 1;  // error rows hold T::one(), like the reference builders
+            }
+            EX_REG(I.dst, k) = (uint64_t)(u128)r;
+            if (I.o_wide) EX_REG(I.dst + 1, k) = (uint64_t)((u128)r >> 64);
+          }
         }
       } break;
       case EX_EQ: case EX_NOTEQ: case EX_LT: case EX_LTE: case EX_GT: case EX_GTE:
@@ -228,6 +244,9 @@ __device__ __forceinline__ void ex_interpret(const ExProg& P, uint64_t* ex_regs,
 #undef EX_ROWS_DO
 #undef EX_ROWS_DO1
   }
+#undef EX_RD128
+#undef EX_RAISE
+#undef EX_REG
 }
 
 // ---- host side (k_expr.hip) -------------------------------------------------------------------------------------

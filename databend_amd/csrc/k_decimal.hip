@@ -273,6 +273,10 @@ int32_t dbhip_decimal_decode_internal(int op, int a_type, int a_prec, int a_scal
     set_error("decimal arithmetic: scale shift %d outside the supported range", p.scale_mul);
     return DBHIP_ERR_UNSUPPORTED;
   }
+  {
+    const bool pass_a = a_dec ? !p.a_check : p.a_to_scale == 0, pass_b = b_dec ? !p.b_check : p.b_to_scale == 0;
+    p.trivial = pass_a && pass_b && (((op == DBHIP_OP_PLUS || op == DBHIP_OP_MINUS) && !p.overflow) || (op == DBHIP_OP_MULTIPLY && p.scale_mul == 0));
+  }
   *out_type = ret.p <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128;
   *out_precision = ret.p;
   *out_scale = ret.s;

@@ -66,20 +66,22 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P, ExOut O) {
       if (!in_range[k]) row[k] = O.n - 1;  // clamp: loads stay in bounds, results are masked
     }
     // ---- all input loads of the chunk, back to back ----
-    uint64_t in[NIN][ROWS], in_hi[NIN][ROWS];
+    uint64_t in[NIN][ROWS], hi0[ROWS], hi1[ROWS];  // hi words of the (at most two) 128-bit input columns
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) { hi0[k] = 0; hi1[k] = 0; }
 #pragma unroll
     for (int ci = 0; ci < NIN; ++ci) {
       if (ci < P.n_inputs) {
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
-          in_hi[ci][k] = 0;
           if (ALL8) {
             in[ci][k] = ((const uint64_t*)P.in_data[ci])[row[k]];
             if (P.in_valid[ci] && !bit_get(P.in_valid[ci], P.in_voff[ci] + row[k])) vmask[k] &= ~(1u << ci);
           } else {
             const int64_t j = P.in_scalar[ci] ? 0 : row[k];
             in[ci][k] = ex_load(P.in_data[ci], P.in_type[ci], j);
-            if (P.in_type[ci] == LK_16) in_hi[ci][k] = ((const uint64_t*)P.in_data[ci])[2 * j + 1];
+            if (P.in_wide_ord[ci] == 0) hi0[k] = ((const uint64_t*)P.in_data[ci])[2 * j + 1];
+            else if (P.in_wide_ord[ci] == 1) hi1[k] = ((const uint64_t*)P.in_data[ci])[2 * j + 1];
             if (P.in_valid[ci] && !bit_get(P.in_valid[ci], P.in_voff[ci] + j)) vmask[k] &= ~(1u << ci);
           }
         }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P, ExOut O) {
         for (int k = 0; k < ROWS; ++k)
           if (P.in_slot[ci] >= 0) {
             EX_REG(P.in_slot[ci], k) = in[ci][k];
-            if (!ALL8 && P.in_type[ci] == LK_16) EX_REG(P.in_slot[ci] + 1, k) = in_hi[ci][k];
+            if (!ALL8 && P.in_wide_ord[ci] >= 0) EX_REG(P.in_slot[ci] + 1, k) = P.in_wide_ord[ci] == 0 ? hi0[k] : hi1[k];
           }
       }
     }
@@ -188,6 +190,8 @@ struct RegInfo {
   int loc = 0;        // where the register's current value lives: temp r, or EX_MAX_REGS + input column
   uint32_t dep = 0;   // nullable inputs the value depends on
   bool may_raise = false;  // some node below it can raise a row error
+  bool is_const = false;   // the register holds a CONST (its 64-bit image in cimm)
+  uint64_t cimm = 0;
 };
 
 }  // namespace
@@ -202,7 +206,8 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
   memset(&P, 0, sizeof(P));
   RegInfo reg[EX_MAX_REGS];
   for (int r = 0; r < EX_MAX_REGS; ++r) reg[r].loc = r;
-  int n_out = 0, n_dec = 0;
+  int n_out = 0, n_dec = 0, n_wide = 0, n_hidden = 0;
+  constexpr int EX_HIDDEN = 8;   // hidden locations: decimal constants converted on the host
   bool any_nullable = false, may_raise = false;
   for (int c = 0; c < n_inputs; ++c) {
     const dbhip_col& col = inputs_host[c];
@@ -213,6 +218,11 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
     DBHIP_REQUIRE(col.data, "expression program: NULL input column");
     P.in_data[c] = col.data; P.in_valid[c] = col.validity; P.in_voff[c] = col.validity_offset;
     P.in_type[c] = ex_load_kind(col.type); P.in_scalar[c] = col.is_scalar;
+    P.in_wide_ord[c] = -1;
+    if (col.type == DBHIP_T_DEC128) {
+      if (n_wide >= 2) { set_error("expression program: more than two Decimal128 input columns"); return DBHIP_ERR_UNSUPPORTED; }
+      P.in_wide_ord[c] = n_wide++;
+    }
   }
   int filter_reg = filter_root >= 0 ? roots[filter_root].reg : -1;
   int n_filter_ins_src = -1;  // source instruction after which the filter register holds its final value
@@ -247,6 +257,7 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
         if (!(ex_numeric(s.type) || s.type == DBHIP_T_BOOL)) { set_error("expression program: instruction %d: CONST of type %d (Decimal128 constants: widen a Decimal64 one with CAST)", i, s.type); return DBHIP_ERR_INVALID; }
         ex_decode(d, -1, -1);
         res.precision = s_prec; res.scale = s_scale;
+        res.is_const = true; res.cimm = s.imm;
         break;
       case DBHIP_EX_PLUS: case DBHIP_EX_MINUS: case DBHIP_EX_MULTIPLY: case DBHIP_EX_DIVIDE: {
         if (!ok_reg(s.a) || !ok_reg(s.b)) { set_error("expression program: instruction %d reads an unset register", i); return DBHIP_ERR_INVALID; }
@@ -267,11 +278,50 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
             set_error("expression program: instruction %d: decimal op %d yields type %d Decimal(%d,%d), the node says type %d Decimal(%d,%d)", i, s.op, ot, op_, os_, s.type, s_prec, s_scale);
             return DBHIP_ERR_INVALID;
           }
+          DecOp& D = P.dec[n_dec];
+          if (dec_op_needs_division(D)) {
+            set_error("expression program: instruction %d: a rounding decimal multiply (scale shift %d) / divide is not fused (128-bit division); "
+                      "evaluate the node with dbhip_decimal_arith", i, D.scale_mul);
+            return DBHIP_ERR_UNSUPPORTED;
+          }
           ex_decode(d, ra.type, rb.type);
           d.op = EX_DEC; d.dec_idx = (int8_t)n_dec++;
           d.a_dec = ex_decimal(ra.type); d.b_dec = ex_decimal(rb.type);
+          // A CONSTANT operand is brought to its bound size here, once (binary_decimal converts a Value::Scalar argument
+          // once per block, not per row): `1 - l_discount` becomes `100 - l_discount` over two values of the bound type.
+          const bool t128 = D.t_is_128 != 0;
+          for (int side = 0; side < 2; ++side) {
+            const RegInfo& ro = side == 0 ? ra : rb;
+            const bool o_dec = ex_decimal(ro.type);
+            const bool pass = side == 0 ? (o_dec ? !D.a_check : D.a_to_scale == 0) : (o_dec ? !D.b_check : D.b_to_scale == 0);
+            if (!ro.is_const || pass || ro.type == DBHIP_T_DEC128 || n_hidden >= EX_HIDDEN || n_out + 1 >= EX_MAX_INS) continue;
+            const int cls = ex_cls(ro.type);
+            const i128 x = cls == CLS_SIGNED ? (i128)(int64_t)ro.cimm : (i128)(u128)ro.cimm;
+            i128 conv;
+            const bool okc = side == 0 ? convert_operand(x, o_dec, D.a_from_scale, D.a_to_scale, D.a_to_precision, D.a_check, t128, &conv)
+                                       : convert_operand(x, o_dec, D.b_from_scale, D.b_to_scale, D.b_to_precision, D.b_check, t128, &conv);
+            if (!okc) continue;  // the conversion overflows: leave it to the kernel, which raises for the live rows
+            // a CONST into a hidden location in front of the node (this slot of P.ins is the node's: shift it by one)
+            const ExIns node = P.ins[n_out];
+            ExIns& cst = P.ins[n_out];
+            memset(&cst, 0, sizeof(cst));
+            const int hloc = EX_MAX_REGS + EX_MAX_INPUTS + n_hidden++;
+            cst.op = EX_CONST; cst.dst = (int16_t)hloc; cst.type = (int16_t)(t128 ? DBHIP_T_DEC128 : DBHIP_T_DEC64); cst.dec_idx = -1;
+            cst.imm = (uint64_t)(u128)conv; cst.imm_hi = (uint64_t)((u128)conv >> 64);
+            ex_decode(cst, -1, -1);
+            ++n_out;
+            ExIns& nd = P.ins[n_out];
+            nd = node;
+            if (side == 0) { nd.a = (int16_t)hloc; nd.a_dec = 1; nd.a_wide = t128; nd.acls = CLS_SIGNED; D.a_check = 0; D.a_from_scale = D.a_to_scale; }
+            else { nd.b = (int16_t)hloc; nd.b_dec = 1; nd.b_wide = t128; nd.bcls = CLS_SIGNED; D.b_check = 0; D.b_from_scale = D.b_to_scale; }
+          }
+          {
+            ExIns& nd = P.ins[n_out];
+            const bool pass_a = nd.a_dec ? !D.a_check : D.a_to_scale == 0, pass_b = nd.b_dec ? !D.b_check : D.b_to_scale == 0;
+            D.trivial = pass_a && pass_b && (((D.op == DBHIP_OP_PLUS || D.op == DBHIP_OP_MINUS) && !D.overflow) || D.op == DBHIP_OP_MULTIPLY);
+            res.may_raise = !D.trivial;
+          }
           res.precision = op_; res.scale = os_;
-          res.may_raise = true;
         } else {
           if (!ex_numeric(ra.type) || !ex_numeric(rb.type) || dbhip_arith_result_type(aop, ra.type, rb.type) != s.type) {
             set_error("expression program: instruction %d: op %d on types (%d,%d) does not yield type %d (arithmetics_type.rs)", i, s.op, ra.type, rb.type, s.type);
@@ -340,14 +390,14 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
         set_error("expression program: instruction %d: unknown op %d", i, s.op);
         return DBHIP_ERR_INVALID;
     }
-    d.dep = (uint8_t)res.dep;
+    P.ins[n_out].dep = (uint8_t)res.dep;   // (a folded constant may have shifted the node by one slot)
     may_raise |= res.may_raise;
     reg[s.dst] = res;
     ++n_out;
     if (i + 1 == n_filter_ins_src) P.n_filter_ins = n_out;
   }
   // roots
-  constexpr int NLOC = EX_MAX_REGS + EX_MAX_INPUTS;
+  constexpr int NLOC = EX_MAX_REGS + EX_MAX_INPUTS + EX_HIDDEN;
   int root_loc[EX_MAX_ROOTS];
   for (int r = 0; r < n_roots; ++r) {
     ExRoot& R = roots[r];

@@ -64,6 +64,7 @@ struct dbhip_groupby {
   uint32_t* spill_idx; size_t spill_idx_cap;
   uint64_t* spill_rows; size_t spill_rows_cap;
   uint64_t* xcur;                          // exchange partitioning: cursor[4096] | base[4097]
+  int fagg_disabled;                       // the fused few-groups kernel (k_fagg.hip) gave up on this table's keys / shape
 };
 
 namespace {
@@ -915,7 +916,8 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
   if ((rc = ensure((void**)&g->gid, &g->gid_cap, (size_t)n * 4))) return rc;
   if ((rc = ensure((void**)&g->retry, &g->retry_cap, (size_t)n * 4))) return rc;
   const int grid = grid_for(n, 256);
-  uint64_t host_ctrl[5];
+  uint64_t* host_ctrl = pinned_words(0);
+  if (!host_ctrl) return DBHIP_ERR_HIP;
   const uint64_t* cur_rows = rows_in;
   int64_t cur_n = n;
   const DevCount dc{n_dev, abort_dev};
@@ -933,7 +935,7 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
     hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows, g->cap, g->hash_mask,
                        g->gid, g->retry, g->ctrl);
     DBHIP_LAUNCH_CHECK();
-    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, sizeof(host_ctrl), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
     g->count_host = (int64_t)host_ctrl[0];
     if (host_ctrl[3] & 2) {
@@ -956,7 +958,7 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
     hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash,
                        g->rows, g->cap, g->hash_mask, g->gid, g->ctrl, dc);
     DBHIP_LAUNCH_CHECK();
-    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, sizeof(host_ctrl), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
     bool too_full = host_ctrl[1] != 0 || (int64_t)host_ctrl[0] * 135 > g->cap * 100;
     if (too_full) {
@@ -974,7 +976,7 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
     hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows,
                        g->cap, g->hash_mask, g->gid, g->retry, g->ctrl);
     DBHIP_LAUNCH_CHECK();
-    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, sizeof(host_ctrl), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
     g->count_host = (int64_t)host_ctrl[0];
     if (host_ctrl[3] & 2) {
@@ -1214,6 +1216,9 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 
 int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
                               int64_t* spilled);
+}  // namespace
+int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, hipStream_t s);  // k_fagg.hip
+namespace {
 constexpr int PT_MAX_BITS = 13;
 constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
 void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block);
@@ -1268,6 +1273,20 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
       continue;
     }
     if (g->fast_disabled) return -1;
+    // A handful of groups (the probing chunk showed <= 8, nothing spilled): the rest of the block goes through the fused
+    // few-groups kernel — key table in scalar registers, states in per-lane registers, no LDS atomics (k_fagg.hip; LDS
+    // atomics of 64 lanes on 4 addresses serialise: 0.12 of the HBM rate on this path at 4 groups). A workgroup that
+    // meets a 9th group makes it give up with nothing merged; the LDS path then takes the rows.
+    if (g->fast_trusted && !g->fagg_disabled && g->count_host <= 8 && n - *done >= (1 << 20)) {
+      rc = dbhip_fagg_add_columns_internal(g, C, *done, n - *done, s);
+      if (rc == DBHIP_OK) {
+        g->rows_seen += n - *done;
+        *done = n;
+        return DBHIP_OK;
+      }
+      if (rc != DBHIP_ERR_CAPACITY && rc != DBHIP_ERR_UNSUPPORTED) return rc;
+      g->fagg_disabled = 1;
+    }
     // The first chunk of a big block is a small probe of the key distribution; when it spills
     // (almost) nothing the rest of the block is one launch (its spill buffer is sized for the worst
     // case but stays untouched), otherwise bounded chunks keep re-checking the spill ratio.
@@ -2248,6 +2267,7 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->count_host = 0;
   g->fast_disabled = 0;
   g->fast_trusted = 0;
+  g->fagg_disabled = 0;
   if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
   g->rows_seen = 0;
   return DBHIP_OK;

@@ -409,7 +409,9 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   A.rf = (const U4*)l_returnflag_views; A.ls = (const U4*)l_linestatus_views;
   A.shipdate = l_shipdate; A.cutoff = shipdate_cutoff; A.n = n;
   A.partial_rows = partial; A.ctrl = ctrl;
-  uint64_t host_ctrl[2] = {0, 0};
+  uint64_t* host_ctrl = pinned_words(1);   // read back asynchronously while the merge is queued behind the kernel
+  if (!host_ctrl) return DBHIP_ERR_HIP;
+  host_ctrl[0] = host_ctrl[1] = 0;
   // Adaptive slot count (the device analogue of the reference's table growth): the 4-slot
   // variant keeps every accumulator in registers at 4 waves/SIMD; a block that meets a 5th
   // distinct key flags it and the pass is redone with 8 slots; beyond that the caller uses

@@ -16,6 +16,12 @@ int32_t hip_fail(hipError_t e, const char* what);
 // the same thread; callers must not hold it across dbhip calls).
 void* scratch(size_t bytes, int slot);
 
+// Pinned host words for small device -> host read-backs that are queued asynchronously (64 u64 per slot, 8 slots per
+// thread). Two async copies into PAGEABLE memory in flight at once — a kernel's control block, then the queued merge's —
+// made the runtime lock / unlock the same stack page twice and the second copy faulted ("write access to a read-only
+// page") once the first had completed and unlocked it; pinned memory needs no lock.
+uint64_t* pinned_words(int slot);
+
 // HIP-event bracket around the dominant kernel of a call (dbhip_last_kernel_ms).
 void kernel_timer_start(hipStream_t s);
 void kernel_timer_stop(hipStream_t s);

@@ -66,6 +66,16 @@ void* scratch(size_t bytes, int slot) {
   return s.p;
 }
 
+static thread_local uint64_t* g_pinned = nullptr;
+uint64_t* pinned_words(int slot) {
+  if (!g_pinned) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 8 * 64 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) return nullptr;
+    g_pinned = (uint64_t*)p;
+  }
+  return g_pinned + (slot & 7) * 64;
+}
+
 static thread_local hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
 static thread_local bool g_timed = false;
 

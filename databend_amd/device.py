@@ -391,55 +391,86 @@ def column_sum(col):
 
 class ExprProgram:
     """Post-order flattening of an Expr tree into the register program of dbhip_expr_eval (the job of the binding's
-    Evaluator::run replacement). Methods return the register that holds the node's value."""
+    Evaluator::run replacement). Methods return the register that holds the node's value. Decimal nodes carry their
+    DecimalSize (ArithmeticOp::result_size, decimal/src/arithmetic.rs:80-139)."""
 
     ARITH = {L.EX_PLUS: L.OP_PLUS, L.EX_MINUS: L.OP_MINUS, L.EX_MULTIPLY: L.OP_MULTIPLY, L.EX_DIVIDE: L.OP_DIVIDE}
+    INT_PROPS = {L.T_I8: (3, 0), L.T_U8: (3, 0), L.T_I16: (5, 0), L.T_U16: (5, 0), L.T_I32: (10, 0), L.T_U32: (10, 0),
+                 L.T_I64: (19, 0), L.T_U64: (20, 0)}
 
     def __init__(self, inputs):
         self.inputs = list(inputs)
         self.ins = []
         self.types = {}
-        self.free = list(range(8))
+        self.size = {}   # register -> (precision, scale) of decimal values
+        self.free = list(range(16))
 
-    def _emit(self, op, a, b, typ, imm=0, release=()):
+    def _emit(self, op, a, b, typ, imm=0, release=(), size=(0, 0)):
         for r in release:
             if r not in self.free:
                 self.free.append(r)
         self.free.sort()
         dst = self.free.pop(0)
-        self.ins.append((op, dst, a, b, typ, imm))
+        self.ins.append((op, dst, a, b, typ, imm, size))
         self.types[dst] = typ
+        self.size[dst] = size
         return dst
 
     def load(self, i):
-        return self._emit(L.EX_LOAD, i, 0, self.inputs[i].dtype)
+        c = self.inputs[i]
+        return self._emit(L.EX_LOAD, i, 0, c.dtype, size=(c.precision, c.scale))
 
-    def const(self, value, typ):
+    def const(self, value, typ, precision=0, scale=0):
         if typ in (L.T_F32, L.T_F64):
             imm = int(np.float64(np.float32(value) if typ == L.T_F32 else value).view(np.uint64))
         else:
             imm = int(value) & ((1 << 64) - 1)
-        return self._emit(L.EX_CONST, 0, 0, typ, imm)
+        return self._emit(L.EX_CONST, 0, 0, typ, imm, size=(precision, scale))
 
-    def arith(self, op, a, b):
-        typ = lib().dbhip_arith_result_type(self.ARITH[op], self.types[a], self.types[b])
-        return self._emit(op, a, b, typ, release=(a, b))
+    def _props(self, r):
+        t = self.types[r]
+        return self.size[r] if t in (L.T_DEC64, L.T_DEC128) else self.INT_PROPS[t]
 
-    def cmp(self, op, a, b):
-        return self._emit(op, a, b, L.T_BOOL, release=(a, b))
+    def arith(self, op, a, b, keep=()):
+        """`keep`: operand registers that are read again later (not released)"""
+        ta, tb = self.types[a], self.types[b]
+        rel = tuple(r for r in (a, b) if r not in keep)
+        if ta in (L.T_DEC64, L.T_DEC128) or tb in (L.T_DEC64, L.T_DEC128):
+            (ap, as_), (bp, bs) = self._props(a), self._props(b)
+            p, sc = C.c_uint8(), C.c_uint8()
+            check(lib().dbhip_decimal_result_size(self.ARITH[op], ap, as_, bp, bs, C.byref(p), C.byref(sc)))
+            typ = L.T_DEC64 if p.value <= 18 else L.T_DEC128
+            return self._emit(op, a, b, typ, release=rel, size=(p.value, sc.value))
+        typ = lib().dbhip_arith_result_type(self.ARITH[op], ta, tb)
+        return self._emit(op, a, b, typ, release=rel)
+
+    def cmp(self, op, a, b, keep=()):
+        return self._emit(op, a, b, L.T_BOOL, release=tuple(r for r in (a, b) if r not in keep))
 
     def logic(self, op, a, b=0):
         return self._emit(op, a, b, L.T_BOOL, release=(a,) if op == L.EX_NOT else (a, b))
 
-    def cast(self, a, typ):
-        return self._emit(L.EX_CAST, a, 0, typ, release=(a,))
+    def cast(self, a, typ, precision=0, scale=0):
+        size = (precision, scale) if typ in (L.T_DEC64, L.T_DEC128) else (0, 0)
+        if typ == L.T_DEC128 and not precision:
+            size = (38, self.size[a][1])
+        return self._emit(L.EX_CAST, a, 0, typ, release=(a,), size=size)
+
+    def if_(self, cond, then, other):
+        return self._emit(L.EX_IF, cond, then, self.types[then], imm=other, release=(cond, then, other), size=self.size[then])
+
+    def c_program(self):
+        prog = (L.ExprIns * max(len(self.ins), 1))()
+        for k, ins in enumerate(self.ins):
+            op, dst, a, b, typ, imm = ins[:6]
+            prog[k].op, prog[k].dst, prog[k].a, prog[k].b, prog[k].type, prog[k].imm = op, dst, a, b, typ, imm
+            prog[k].precision, prog[k].scale = ins[6] if len(ins) > 6 else (0, 0)
+        return prog
 
     def run(self, out_reg, n=None, want_values=True, want_sum=False, errors=None):
         """-> dict(values=np array | bool array, validity=bool array | None, sum=int/float | None)"""
         n = self.inputs[0].n if n is None else n
-        prog = (L.ExprIns * len(self.ins))()
-        for k, (op, dst, a, b, typ, imm) in enumerate(self.ins):
-            prog[k].op, prog[k].dst, prog[k].a, prog[k].b, prog[k].type, prog[k].imm = op, dst, a, b, typ, imm
+        prog = self.c_program()
         ot = self.types[out_reg]
         words = (max(n, 1) + 63) // 64
         nullable = any(c.validity is not None for c in self.inputs)
@@ -456,8 +487,14 @@ class ExprProgram:
                                     C.c_void_p(errors.bitmap.ptr) if errors else None, C.c_void_p(errors.count.ptr) if errors else None,
                                     C.c_void_p(sbuf.ptr) if sbuf else None, None))
         out = dict(values=None, validity=None, sum=None, type=ot)
+        out["size"] = self.size.get(out_reg, (0, 0))
         if vals is not None:
-            out["values"] = unpack_bits(vals.to_numpy(np.uint8, words * 8), n) if ot == L.T_BOOL else vals.to_numpy(NP_OF[ot], n)
+            if ot == L.T_BOOL:
+                out["values"] = unpack_bits(vals.to_numpy(np.uint8, words * 8), n)
+            elif ot == L.T_DEC128:
+                out["values"] = bytes_to_i128(vals.to_numpy(np.uint8, 16 * n))
+            else:
+                out["values"] = vals.to_numpy(NP_OF[ot], n)
         if vbuf is not None:
             out["validity"] = unpack_bits(vbuf.to_numpy(np.uint8, words * 8), n)
         if sbuf is not None:
@@ -506,6 +543,21 @@ class GroupBy:
             check(lib().dbhip_groupby_add_block(self.h, ka, aa, C.c_int64(n), stream))
         else:
             check(lib().dbhip_groupby_add_block_filtered(self.h, ka, aa, C.c_int64(n), C.c_void_p(filter.data.ptr), C.c_int64(0), stream))
+
+    def add_block_program(self, keys, program, arg_regs, n, filter_reg=-1, filter=None, stream=None):
+        """Fused TransformFilter -> maps -> partial aggregate (dbhip_groupby_add_block_program). `program`: ExprProgram;
+        `arg_regs[i]`: register of aggregate i's argument, ("input", c) for input column c as it is, None for count(*)."""
+        regs = (C.c_int32 * max(len(self.aggs), 1))()
+        for i, r in enumerate(arg_regs):
+            regs[i] = -(2 ** 31) if r is None else (-(1 + r[1]) if isinstance(r, tuple) else r)
+        ap = L.AggProgram()
+        cprog = program.c_program()
+        cin = _cols(program.inputs)
+        ap.prog, ap.n_ins = C.cast(cprog, C.c_void_p), len(program.ins)
+        ap.inputs, ap.n_inputs = C.cast(cin, C.c_void_p), len(program.inputs)
+        ap.filter_reg, ap.arg_regs = filter_reg, C.cast(regs, C.c_void_p)
+        fb = C.c_void_p(filter.data.ptr) if filter is not None else None
+        check(lib().dbhip_groupby_add_block_program(self.h, _cols(keys), C.byref(ap), C.c_int64(n), fb, C.c_int64(0), stream))
 
     def state_fields(self):
         """-> [(dbhip_type, aggregate index)] of the serialized-state block (dbhip_groupby_state_fields)."""

@@ -191,6 +191,24 @@ def q1_operator_pushdown(li, g=None, cutoff=Q1_CUTOFF):
     return g
 
 
+def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF):
+    """The whole Q1 pipeline as ONE generic launch (dbhip_groupby_add_block_program): the binding flattens the filter
+    predicate and the three decimal maps into a register program (what Evaluator::run walks node by node) and the
+    fused filter -> map -> partial-aggregate kernel interprets it — no query-specific code on the device."""
+    g = g or D.GroupBy.q1()
+    p = D.ExprProgram([li.ship, li.qty, li.price, li.disc, li.tax])
+    ship, cut = p.load(0), p.const(cutoff, L.T_DATE)
+    f = p.cmp(L.EX_LTE, ship, cut)                                   # l_shipdate <= cutoff          (filter root, first)
+    qty, price, disc, tax = p.load(1), p.load(2), p.load(3), p.load(4)
+    one = p.const(1, L.T_U8)
+    one_minus = p.arith(L.EX_MINUS, one, disc, keep=(one, disc))       # 1 - l_discount               Decimal(16,2)
+    disc_price = p.arith(L.EX_MULTIPLY, price, one_minus, keep=(price,))  # l_extendedprice * (..)     Decimal(31,4)
+    one_plus = p.arith(L.EX_PLUS, one, tax)                           # 1 + l_tax                    Decimal(16,2)
+    charge = p.arith(L.EX_MULTIPLY, disc_price, one_plus, keep=(disc_price,))  # (..) * (..)          Decimal(38,6)
+    g.add_block_program([li.rf, li.ls], p, [qty, price, disc_price, charge, disc, None], li.n, filter_reg=f)
+    return g
+
+
 def q1_rows(g):
     """-> {(returnflag, linestatus): dict} from a Q1 group-by table."""
     out = {}

@@ -304,6 +304,32 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
 int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
                                          int64_t n, const uint8_t* filter_bitmap, int64_t filter_bit_offset,
                                          void* stream);
+/* Fused TransformFilter -> BlockOperator::Map -> TransformPartialAggregate for tables with a handful of groups
+ * (filter/filter_executor.rs:81-118, sql/src/evaluator/block_operator.rs:42-85, aggregate_hashtable.rs:168-292): ONE
+ * pass over the unfiltered input columns. `prog` is a dbhip_expr_eval program over `inputs` whose results are the
+ * filter predicate (`filter_reg`, -1 = none; a NULL predicate drops the row) and one argument per aggregate
+ * (`arg_regs[i]`: a register, DBHIP_ARG_INPUT(c) = input column c as it is, DBHIP_ARG_NONE = count(*)); maps raise row
+ * errors only for rows the filter kept (the filter precedes the maps in the reference's pipeline).
+ * `filter_bitmap` (may be NULL) is an additional pushed-down predicate Bitmap as in add_block_filtered. Keys are
+ * columns (<= 4 key words; strings up to 12 bytes). Groups resolve through a per-workgroup key table of 8 slots and
+ * the states accumulate in per-lane registers, so the pass streams at the input columns' rate.
+ * Result == add_block over the taken, mapped columns. Returns DBHIP_ERR_CAPACITY when a workgroup met more than 8
+ * groups and DBHIP_ERR_ROW_ERRORS when a map raised (in both cases NOTHING was merged: the caller runs the
+ * operator-at-a-time kernels on the block), DBHIP_ERR_UNSUPPORTED for layouts / programs outside the fused subset
+ * (<= 8 aggregates, <= 12 state words, the dbhip_expr_eval subset). */
+#define DBHIP_ARG_NONE INT32_MIN
+#define DBHIP_ARG_INPUT(c) (-(1 + (c)))
+typedef struct {
+  const dbhip_expr_ins* prog;   /* host array, may be NULL when n_ins == 0 (arguments are input columns) */
+  int32_t n_ins;
+  const dbhip_col* inputs;      /* host array of n_inputs columns (<= 8)                                   */
+  int32_t n_inputs;
+  int32_t filter_reg;           /* register of the Boolean predicate, -1 = none                            */
+  const int32_t* arg_regs;      /* host array, one entry per aggregate of the table                         */
+} dbhip_agg_program;
+int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog,
+                                        int64_t n, const uint8_t* filter_bitmap, int64_t filter_bit_offset,
+                                        void* stream);
 /* combine_payload (:349-380): merge serialized partial states (as produced by
  * dbhip_groupby_flush_serialized on any rank) into this table. */
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows,

@@ -1,0 +1,281 @@
+"""GPU: the extended fused expression programs (Decimal64/128 nodes, if(), per-node NULL dependencies) and the generic fused
+filter -> map -> partial-aggregate kernel (dbhip_groupby_add_block_program), against the oracle / the per-node kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from databend_amd import _lib as T
+from tests import oracle_lib as O
+from tests.test_gpu_parity import norm, oracle_groupby, oracle_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_decimal(oracle, op, a, b, n):
+    """(values list, error rows) of the oracle's binary_decimal on two HostCols"""
+    p, s = C.c_int(), C.c_int()
+    props = {T.T_I8: (3, 0), T.T_U8: (3, 0), T.T_I16: (5, 0), T.T_U16: (5, 0), T.T_I32: (10, 0), T.T_U32: (10, 0), T.T_I64: (19, 0), T.T_U64: (20, 0)}
+    ap = (a.precision, a.scale) if a.dtype in (T.T_DEC64, T.T_DEC128) else props[a.dtype]
+    bp = (b.precision, b.scale) if b.dtype in (T.T_DEC64, T.T_DEC128) else props[b.dtype]
+    assert oracle.orc_decimal_result_size(op, ap[0], ap[1], bp[0], bp[1], C.byref(p), C.byref(s)) == 0
+    ot = T.T_DEC64 if p.value <= 18 else T.T_DEC128
+    out = np.zeros(n * (2 if ot == T.T_DEC128 else 1) + 2, np.uint64)
+    err = np.full((n + 7) // 8 + 8, 0xFF, np.uint8)
+    cnt = C.c_uint64(0)
+    ca, cb = a.c(), b.c()
+    assert oracle.orc_decimal_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), ot, p.value, s.value, out.ctypes.data_as(C.c_void_p),
+                                    err.ctypes.data_as(C.c_void_p), C.byref(cnt)) == 0
+    vals = O.i128_list(out[:2 * n]) if ot == T.T_DEC128 else out[:n].view(np.int64).tolist()
+    ok = np.unpackbits(err, bitorder="little")[:n].astype(bool)
+    return vals, ok, ot, p.value, s.value
+
+
+@pytest.mark.parametrize("n", [1, 63, 129, 50_003])
+def test_fused_decimal_program_equals_the_per_node_decimal_semantics(gpu, oracle, n):
+    """price * (1 - disc) * (1 + tax) — Q1's maps — and a rounding multiply, a Decimal128 + Decimal64 add and a decimal
+    comparison as ONE program each, against the oracle's binary_decimal applied node by node (incl. NULL rows)."""
+    rng = np.random.default_rng(n)
+    price = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    disc = rng.integers(0, 11, n).astype(np.int64)
+    tax = rng.integers(0, 9, n).astype(np.int64)
+    pv = rng.integers(0, 6, n) > 0
+    cp, cd, ct = (gpu.Column.from_numpy(x, T.T_DEC64, precision=15, scale=2) for x in (price, disc, tax))
+    cpn = gpu.Column.from_numpy(price, T.T_DEC64, validity=pv, precision=15, scale=2)
+    hp, hd, ht = (O.HostCol(T.T_DEC64, x, None, 15, 2) for x in (price, disc, tax))
+    one = O.HostCol(T.T_U8, np.array([1], np.uint8), is_scalar=True)
+
+    p = gpu.ExprProgram([cpn, cd, ct])
+    a, b, c = p.load(0), p.load(1), p.load(2)
+    k1 = p.const(1, T.T_U8)
+    om = p.arith(T.EX_MINUS, k1, b, keep=(k1,))
+    dp = p.arith(T.EX_MULTIPLY, a, om)
+    op_ = p.arith(T.EX_PLUS, k1, c)
+    ch = p.arith(T.EX_MULTIPLY, dp, op_)
+    res = p.run(ch, n)
+    assert res["type"] == T.T_DEC128 and res["size"] == (38, 6)
+    v_om, _, t_om, p_om, s_om = oracle_decimal(oracle, T.OP_MINUS, one, hd, n)
+    v_dp, _, t_dp, p_dp, s_dp = oracle_decimal(oracle, T.OP_MULTIPLY, hp, O.HostCol(t_om, np.array(v_om, np.int64), None, p_om, s_om), n)
+    v_op, _, t_op, p_op, s_op = oracle_decimal(oracle, T.OP_PLUS, one, ht, n)
+    v_ch, ok, t_ch, p_ch, s_ch = oracle_decimal(oracle, T.OP_MULTIPLY, O.HostCol(t_dp, O.i128_array(v_dp), None, p_dp, s_dp),
+                                                O.HostCol(t_op, np.array(v_op, np.int64), None, p_op, s_op), n)
+    assert (t_ch, p_ch, s_ch) == (T.T_DEC128, 38, 6) and ok.all()
+    assert res["values"] == v_ch
+    assert np.array_equal(res["validity"], pv)
+
+    # a rounding multiply (Decimal(15,8) * Decimal(15,8) -> scale 12: divides by 10^4) needs a 128-bit division: outside the
+    # fused subset, reported as UNSUPPORTED (the binding evaluates that node with dbhip_decimal_arith)
+    x = rng.integers(-10**14, 10**14, n).astype(np.int64)
+    cx = gpu.Column.from_numpy(x, T.T_DEC64, precision=15, scale=8)
+    p2 = gpu.ExprProgram([cx, cx])
+    with pytest.raises(T.DbhipError) as e2:
+        p2.run(p2.arith(T.EX_MULTIPLY, p2.load(0), p2.load(1)), n)
+    assert e2.value.code == T.ERR_UNSUPPORTED
+
+    # Decimal128 + Decimal64 (rescale of the narrower side), then a comparison of two Decimal128 values, then if()
+    big = [int(v) * 10**9 for v in rng.integers(-10**17, 10**17, n)]
+    cb128 = gpu.Column.decimal128(big, 30, 4)
+    p3 = gpu.ExprProgram([cb128, cp])
+    s128 = p3.arith(T.EX_PLUS, p3.load(0), p3.load(1), keep=())
+    r3 = p3.run(s128, n)
+    v3, ok3, t3, pp3, s3 = oracle_decimal(oracle, T.OP_PLUS, O.HostCol(T.T_DEC128, O.i128_array(big), None, 30, 4), hp, n)
+    assert r3["type"] == t3 and r3["size"] == (pp3, s3) and ok3.all() and r3["values"] == v3
+    p4 = gpu.ExprProgram([cb128, cp])
+    l0 = p4.load(0)
+    s4 = p4.arith(T.EX_PLUS, l0, p4.load(1), keep=(l0,))
+    r4 = p4.run(p4.cmp(T.EX_GT, s4, l0), n)                 # Decimal128(31,4) > Decimal128(30,4): same storage, same scale
+    assert np.array_equal(r4["values"], np.array([a_ > b_ for a_, b_ in zip(v3, big)]))
+    p5 = gpu.ExprProgram([cb128, cp])
+    l0 = p5.load(0)
+    l1 = p5.load(1)
+    s5 = p5.arith(T.EX_PLUS, l0, l1, keep=(l0, l1))
+    zero = p5.const(0, T.T_DEC64, 15, 2)
+    cnd = p5.cmp(T.EX_GTE, l1, zero)
+    r5 = p5.run(p5.if_(cnd, s5, l0), n)
+    assert r5["values"] == [a_ if pr >= 0 else b_ for a_, b_, pr in zip(v3, big, price.tolist())]
+
+
+def test_fused_decimal_program_row_errors(gpu, oracle):
+    """'Decimal overflow' rows of a fused decimal node (plus at precision 38 checks the result, arithmetic.rs:229-243): the
+    same rows as the oracle's, value 1 like the reference builders; a NULL input the node depends on never raises."""
+    n = 1000
+    rng = np.random.default_rng(3)
+    x = [int(v) * 10**20 for v in rng.integers(-10**18 + 1, 10**18 - 1, n)]          # Decimal(38,0), |x| < 10^38
+    y = [int(v) * 10**20 for v in rng.integers(-10**18 + 1, 10**18 - 1, n)]
+    yv = rng.integers(0, 3, n) > 0
+    cx, cy = gpu.Column.decimal128(x, 38, 0), gpu.Column.decimal128(y, 38, 0, validity=yv)
+    p = gpu.ExprProgram([cx, cy])
+    r = p.arith(T.EX_PLUS, p.load(0), p.load(1))
+    errs = gpu.RowErrors(n)
+    res = p.run(r, n, errors=errs)
+    v, ok, t, pp, ss = oracle_decimal(oracle, T.OP_PLUS, O.HostCol(T.T_DEC128, O.i128_array(x), None, 38, 0), O.HostCol(T.T_DEC128, O.i128_array(y), yv, 38, 0), n)
+    really = np.array([abs(a_ + b_) > 10**38 - 1 for a_, b_ in zip(x, y)])
+    bad = np.nonzero(really & yv)[0]
+    assert len(bad) > 20
+    assert np.array_equal(np.nonzero(~ok)[0], bad)       # the oracle raises for the same rows (valid inputs only)
+    assert np.array_equal(errs.error_rows(), bad) and errs.num_errors() == len(bad)
+    got = res["values"]
+    assert all(got[i] == v[i] for i in range(n) if not really[i])
+    assert all(got[i] == 1 for i in bad)
+
+
+Q_KEYS = ([T.T_I64, T.T_STRING], [1, 0])
+
+
+def fagg_case(gpu, oracle, n, card, seed, keep=0.9):
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, card, n).astype(np.int64) * 7 - 3
+    kv = rng.integers(0, 10, n) > 0
+    s = [b"x%d" % (v % 2) for v in rng.integers(0, 1000, n)]
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    b = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    bv = rng.integers(0, 4, n) > 0
+    d = rng.integers(-10**13, 10**13, n).astype(np.int64)
+    e = rng.integers(0, 1000, n).astype(np.int64)
+    f = rng.integers(-1000, 1000, n).astype(np.float64)
+    thr = int(np.quantile(a, 1 - keep)) if n > 1 else -10**10
+    return dict(k=k, kv=kv, s=s, a=a, b=b, bv=bv, d=d, e=e, f=f, thr=thr)
+
+
+FA_AGGS = [(T.AGG_SUM, T.T_I64, 0, 0, 1), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC128, 31, 4, 0), (T.AGG_MIN, T.T_I32, 0, 0, 1),
+           (T.AGG_MAX, T.T_F64, 0, 0, 0), (T.AGG_COUNT, T.T_I32, 0, 0, 1), (T.AGG_SUM, T.T_F64, 0, 0, 0)]
+
+
+def run_fagg(gpu, c, n, g=None):
+    """sum(a + b) [nullable through b], count(*), sum(d * (e + 3)) as Decimal128(31,4), min(b), max(f), count(b), sum(f)
+    WHERE a > thr GROUP BY k (nullable), s"""
+    from databend_amd.device import make_views_general
+    g = g or gpu.GroupBy(Q_KEYS[0], FA_AGGS, Q_KEYS[1])
+    ca, cb = gpu.Column.from_numpy(c["a"]), gpu.Column.from_numpy(c["b"], validity=c["bv"])
+    cd = gpu.Column.from_numpy(c["d"], T.T_DEC64, precision=15, scale=2)
+    ce = gpu.Column.from_numpy(c["e"], T.T_DEC64, precision=15, scale=2)
+    cf = gpu.Column.from_numpy(c["f"])
+    p = gpu.ExprProgram([ca, cb, cd, ce, cf])
+    la = p.load(0)
+    filt = p.cmp(T.EX_GT, la, p.const(c["thr"], T.T_I64), keep=(la,))
+    lb = p.load(1)
+    apb = p.arith(T.EX_PLUS, la, lb, keep=(lb,))                       # i64 + i32 -> i64
+    e3 = p.arith(T.EX_PLUS, p.load(3), p.const(3, T.T_U8))            # Decimal(16,2)
+    prod = p.arith(T.EX_MULTIPLY, p.load(2), e3)                       # Decimal(31,4)
+    lf = p.load(4)
+    keys = [gpu.Column.from_numpy(c["k"], validity=c["kv"]), gpu.Column.strings(c["s"])]
+    g.add_block_program(keys, p, [apb, None, prod, lb, lf, lb, lf], n, filter_reg=filt)
+    return g
+
+
+def expect_fagg(oracle, c, n):
+    from databend_amd.device import make_views_general
+    sel = np.nonzero(c["a"] > c["thr"])[0]
+    m = len(sel)
+    if m == 0:
+        return []
+    apb = (c["a"][sel] + c["b"][sel].astype(np.int64))
+    e3 = O.HostCol(T.T_DEC64, c["e"][sel] + 300, None, 16, 2)
+    vals, ok, t, pp, ss = oracle_decimal(oracle, T.OP_MULTIPLY, O.HostCol(T.T_DEC64, c["d"][sel], None, 15, 2), e3, m)
+    assert (t, pp, ss) == (T.T_DEC128, 31, 4) and ok.all()
+    v, buf = make_views_general([c["s"][i] for i in sel])
+    hkeys = [O.HostCol(T.T_I64, c["k"][sel], c["kv"][sel]), O.HostCol(T.T_STRING, v, buffers=[buf])]
+    bv = c["bv"][sel]
+    hargs = [O.HostCol(T.T_I64, apb, bv), None, O.HostCol(T.T_DEC128, O.i128_array(vals), None, 31, 4), O.HostCol(T.T_I32, c["b"][sel], bv),
+             O.HostCol(T.T_F64, c["f"][sel]), O.HostCol(T.T_I32, c["b"][sel], bv), O.HostCol(T.T_F64, c["f"][sel])]
+    h = oracle_groupby(oracle, Q_KEYS[0], Q_KEYS[1], FA_AGGS, hkeys, hargs, m)
+    exp = oracle_rows(oracle, h, Q_KEYS[0], FA_AGGS)
+    oracle.orc_hashagg_destroy(h)
+    return exp
+
+
+@pytest.mark.parametrize("n,card,keep", [(1, 1, 1.0), (127, 2, 0.5), (129, 3, 0.9), (100_003, 2, 0.986), (300_000, 3, 0.03), (70_000, 1, 0.0)])
+def test_fused_filter_map_aggregate_matches_oracle(gpu, oracle, n, card, keep):
+    """One launch == filter -> take -> maps -> hash aggregation of the oracle, compared as sorted row sets: nullable key +
+    string key (up to 2 x card x 2 groups incl. the NULL key), nullable and decimal arguments, min / max / f64 sums."""
+    c = fagg_case(gpu, oracle, n, card, 100 + n, keep)
+    g = run_fagg(gpu, c, n)
+    assert norm(g.result()) == norm(expect_fagg(oracle, c, n))
+
+
+def test_fused_aggregate_gives_up_cleanly_on_too_many_groups(gpu, oracle):
+    """> 8 groups inside a workgroup: DBHIP_ERR_CAPACITY and the table is untouched (the caller keeps the operator plan);
+    the 8-slot variant takes over between 5 and 8 groups."""
+    n = 50_000
+    c = fagg_case(gpu, oracle, n, 2, 7)       # up to 3 keys (incl. NULL) x 2 strings = 6 groups: needs the 8-slot kernel
+    g = run_fagg(gpu, c, n)
+    exp = expect_fagg(oracle, c, n)
+    assert len(exp) > 4 and norm(g.result()) == norm(exp)
+    c9 = fagg_case(gpu, oracle, n, 40, 8)
+    with pytest.raises(T.DbhipError) as e:
+        run_fagg(gpu, c9, n, g)
+    assert e.value.code == T.ERR_CAPACITY
+    assert norm(g.result()) == norm(exp)
+
+
+def test_fused_aggregate_row_errors_respect_the_filter(gpu, oracle):
+    """A map that overflows on a row the filter DROPS raises nothing (TransformFilter precedes the maps); on a kept row the
+    block fails with DBHIP_ERR_ROW_ERRORS and nothing is merged."""
+    n = 4096
+    k = np.zeros(n, np.int64)
+    x = [9 * 10**37] * n                                   # Decimal(38,0)
+    sel = np.arange(n) % 2 == 0
+    y_bad = [5 * 10**37] * n                               # x + y leaves 38 digits on every row
+    y_ok = [1 if keep else 5 * 10**37 for keep in sel]     # kept rows are fine, dropped rows would overflow
+    flag = sel.astype(np.int64)
+    aggs = [(T.AGG_SUM, T.T_DEC128, 38, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)]
+
+    def run(ycol, g=None):
+        g = g or gpu.GroupBy([T.T_I64], aggs)
+        cx, cy, cf = gpu.Column.decimal128(x, 38, 0), gpu.Column.decimal128(ycol, 38, 0), gpu.Column.from_numpy(flag)
+        p = gpu.ExprProgram([cx, cy, cf])
+        filt = p.cmp(T.EX_EQ, p.load(2), p.const(1, T.T_I64))
+        tot = p.arith(T.EX_PLUS, p.load(0), p.load(1))
+        assert p.types[tot] == T.T_DEC128
+        g.add_block_program([gpu.Column.from_numpy(k)], p, [tot, None], n, filter_reg=filt)
+        return g
+    g = run(y_ok)
+    rows = g.result()
+    assert rows == [(0, ((9 * 10**37 + 1) * (n // 2) + 2**127) % 2**128 - 2**127, n // 2)]     # the i128 state wraps; only flush checks it
+    with pytest.raises(T.DbhipError) as e:
+        run(y_bad, g)
+    assert e.value.code == T.ERR_ROW_ERRORS
+    assert g.result() == rows
+
+
+@pytest.mark.parametrize("n", [1, 129, 300_007])
+def test_q1_as_one_generic_fused_program_equals_the_oracle(gpu, oracle, n):
+    from databend_amd import tpch
+    host = tpch.gen_lineitem(n, seed=n + 5)
+    li = tpch.LineitemDevice(host)
+    exp = O.q1_run(host, tpch.Q1_CUTOFF, threads=1)
+    assert tpch.q1_rows(tpch.q1_fused_program(li)) == exp
+
+
+@pytest.mark.parametrize("card", [1, 4, 8])
+def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card):
+    """add_block on a table whose probing chunk shows <= 8 groups hands the rest of the block to the fused kernel (empty
+    program): same sorted row set as the oracle, incl. a pushed-down filter; a 9th group appearing late falls back."""
+    n = 3_000_000
+    rng = np.random.default_rng(card)
+    k = rng.integers(0, card, n).astype(np.int64)
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    av = rng.integers(0, 5, n) > 0
+    d = rng.integers(-10**14, 10**14, n).astype(np.int64)
+    keep = rng.random(n) < 0.9
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 1), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC64, 15, 2, 0), (T.AGG_MAX, T.T_I64, 0, 0, 1)]
+
+    def expect(kk, sel):
+        out = []
+        for key in np.unique(kk[sel]):
+            m = sel & (kk == key)
+            mv = m & av
+            out.append((int(key), int(a[mv].sum()) if mv.any() else None, int(m.sum()), int(d[m].sum()), int(a[mv].max()) if mv.any() else None))
+        return sorted(out)
+
+    def run(kk, filt):
+        g = gpu.GroupBy([T.T_I64], aggs)
+        g.add_block([gpu.Column.from_numpy(kk)], [gpu.Column.from_numpy(a, validity=av), None, gpu.Column.from_numpy(d, T.T_DEC64, precision=15, scale=2),
+                                                  gpu.Column.from_numpy(a, validity=av)], n, filter=gpu.Column.boolean(filt) if filt is not None else None)
+        return sorted(g.result())
+    assert run(k, None) == expect(k, np.ones(n, bool))
+    assert run(k, keep) == expect(k, keep)
+    if card == 8:
+        k2 = k.copy()
+        k2[2_500_000:] += 100       # 8 more groups show up after the probing chunk: the fused kernel gives up, the LDS path takes over
+        assert run(k2, None) == expect(k2, np.ones(n, bool))
