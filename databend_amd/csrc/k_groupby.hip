@@ -1277,7 +1277,13 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // few-groups kernel — key table in scalar registers, states in per-lane registers, no LDS atomics (k_fagg.hip; LDS
     // atomics of 64 lanes on 4 addresses serialise: 0.12 of the HBM rate on this path at 4 groups). A workgroup that
     // meets a 9th group makes it give up with nothing merged; the LDS path then takes the rows.
-    if (g->fast_trusted && !g->fagg_disabled && g->count_host <= 8 && n - *done >= (1 << 20)) {
+    // MEASURED (r02g, 60 M rows): the fused kernel's interpretive per-word metadata costs more instructions than the LDS
+    // atomics it avoids — i64 key + sum + count at 4 groups 1.34 ms vs 1.04 ms on the LDS path, Q1's six wide aggregates
+    // 8.6 ms vs 4.7 ms for the whole pushed-down plan — so add_block keeps the LDS path unless DBHIP_FAGG_AUTO=1 asks
+    // for the experiment; the fused kernel earns its place where it also replaces the filter and the maps
+    // (dbhip_groupby_add_block_program).
+    static const bool fagg_auto = getenv("DBHIP_FAGG_AUTO") != nullptr;
+    if (fagg_auto && g->fast_trusted && !g->fagg_disabled && g->count_host <= 8 && n - *done >= (1 << 20)) {
       rc = dbhip_fagg_add_columns_internal(g, C, *done, n - *done, s);
       if (rc == DBHIP_OK) {
         g->rows_seen += n - *done;
