@@ -87,6 +87,61 @@ __device__ __forceinline__ void store_nibbles(uint8_t* out, int64_t out_bytes, i
   }
 }
 
+// Decimal comparison of two different DecimalSizes / storage classes — DecimalCmp::eval + CmpOp::compare
+// (decimal/src/comparison.rs:326-384,407-441): both sides are viewed in T = storage class of calc_size (max leading
+// digits + max scale, capped at 38), f_a = 10^(s - s_a), f_b = 10^(s - s_b); values of different sign compare as they
+// are, otherwise each side is multiplied by its factor with a checked multiply whose overflow decides the order.
+struct CmpDecParams {
+  const void* a;
+  const void* b;
+  uint8_t* out;
+  int64_t n, out_bytes;
+  int a_wide, b_wide, a_scalar, b_scalar, op, t128;
+  int fa_pow, fb_pow;  // f_a = 10^fa_pow, f_b = 10^fb_pow
+};
+__device__ __forceinline__ bool dec_checked_mul(i128 x, i128 f, bool t128, i128* out) {
+  if (!t128) {
+    const i128 r = x * f;
+    if (r > (i128)INT64_MAX || r < (i128)INT64_MIN) return false;
+    *out = r;
+    return true;
+  }
+  const bool neg = (x < 0) != (f < 0);
+  const u128 ax = x < 0 ? (u128)0 - (u128)x : (u128)x, af = f < 0 ? (u128)0 - (u128)f : (u128)f;
+  const u256 pr = u256_mul_128(ax, af);
+  const u128 lim = neg ? ((u128)1 << 127) : (((u128)1 << 127) - 1);
+  if (pr.hi != 0 || pr.lo > lim) return false;
+  *out = neg ? (i128)((u128)0 - pr.lo) : (i128)pr.lo;
+  return true;
+}
+__device__ __forceinline__ int dec_cmp3(i128 a, i128 b, i128 fa, i128 fb, bool t128) {
+  const int sa = (a > 0) - (a < 0), sb = (b > 0) - (b < 0);
+  if (sa != sb) return (a > b) - (a < b);
+  i128 x = a, y = b;
+  if (fa != 1 && !dec_checked_mul(a, fa, t128, &x)) return sa > 0 ? 1 : -1;   // a is out of T's range at the common scale
+  if (fb != 1 && !dec_checked_mul(b, fb, t128, &y)) return sb > 0 ? -1 : 1;
+  return (x > y) - (x < y);
+}
+__global__ __launch_bounds__(256) void cmp_decimal_kernel(CmpDecParams p) {
+  const i128 fa = pow10_i128(p.fa_pow), fb = pow10_i128(p.fb_pow);
+  const int64_t n_pad = (p.n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    bool r = false;
+    if (i < p.n) {
+      const int64_t ja = p.a_scalar ? 0 : i, jb = p.b_scalar ? 0 : i;
+      const i128 a = p.a_wide ? ((const i128*)p.a)[ja] : (i128)((const int64_t*)p.a)[ja];
+      const i128 b = p.b_wide ? ((const i128*)p.b)[jb] : (i128)((const int64_t*)p.b)[jb];
+      r = apply_cmp(p.op, fa == fb ? cmp3_i128(a, b) : dec_cmp3(a, b, fa, fb, p.t128 != 0));
+    }
+    const uint64_t m = __ballot(r);
+    const int lane = lane_id();
+    if ((lane & 7) == 0) {
+      const int64_t byte = i >> 3;
+      if (byte < p.out_bytes) p.out[byte] = (uint8_t)(m >> lane);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cmp_kernel(CmpParams p) {
   const int cls = type_class(p.type);
   const int64_t nquads = (p.n + 3) >> 2;
@@ -358,6 +413,25 @@ int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_
                   uint8_t* out_bitmap, void* stream) {
   DBHIP_REQUIRE(lhs && rhs && (out_bitmap || n == 0), "dbhip_cmp: NULL argument");
   DBHIP_REQUIRE(op >= DBHIP_CMP_EQ && op <= DBHIP_CMP_GTE, "dbhip_cmp: bad operator");
+  const bool l_dec = lhs->type == DBHIP_T_DEC64 || lhs->type == DBHIP_T_DEC128, r_dec = rhs->type == DBHIP_T_DEC64 || rhs->type == DBHIP_T_DEC128;
+  if (l_dec && r_dec && (lhs->type != rhs->type || lhs->scale != rhs->scale)) {
+    // decimals of different DecimalSize: no cast is planned for them (register_decimal_compare_op, comparison.rs:61-99)
+    if (n == 0) return DBHIP_OK;
+    DBHIP_REQUIRE(lhs->precision >= 1 && lhs->precision <= 38 && rhs->precision >= 1 && rhs->precision <= 38 &&
+                      lhs->scale <= lhs->precision && rhs->scale <= rhs->precision, "dbhip_cmp: bad DecimalSize");
+    const int scale = lhs->scale > rhs->scale ? lhs->scale : rhs->scale;
+    const int la = lhs->precision - lhs->scale, lb = rhs->precision - rhs->scale;
+    int precision = (la > lb ? la : lb) + scale;   // calc_size (comparison.rs:369-384)
+    if (precision > 38) precision = 38;
+    CmpDecParams q;
+    q.a = lhs->data; q.b = rhs->data; q.out = out_bitmap; q.n = n; q.out_bytes = ceil_div(n, 8);
+    q.a_wide = lhs->type == DBHIP_T_DEC128; q.b_wide = rhs->type == DBHIP_T_DEC128;
+    q.a_scalar = lhs->is_scalar; q.b_scalar = rhs->is_scalar; q.op = op; q.t128 = precision > 18;
+    q.fa_pow = scale - lhs->scale; q.fb_pow = scale - rhs->scale;
+    hipLaunchKernelGGL(cmp_decimal_kernel, dim3(grid_for(n, 256)), dim3(256), 0, resolve_stream(stream), q);
+    DBHIP_LAUNCH_CHECK();
+    return DBHIP_OK;
+  }
   if (lhs->type != rhs->type) {
     set_error("dbhip_cmp: operand types differ (%d vs %d); the planner casts to a common type",
               lhs->type, rhs->type);

@@ -29,6 +29,7 @@ int32_t dbhip_groupby_merge_rows_dev_internal(dbhip_groupby* g, const uint64_t* 
                                               const uint64_t* abort_dev, hipStream_t s);
 int32_t dbhip_groupby_merge_rows_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n, hipStream_t s);
 int64_t dbhip_groupby_capacity_internal(dbhip_groupby* g);
+int32_t dbhip_groupby_reserve_merge_internal(dbhip_groupby* g, int64_t n);
 int64_t dbhip_groupby_count_internal(dbhip_groupby* g);
 const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
 
@@ -61,6 +62,7 @@ struct FaArgs {
   const uint8_t* filter_bits;         // pushed-down predicate Bitmap (may be NULL)
   int64_t filter_off;
   int64_t n;
+  int32_t debug;                      // env DBHIP_FAGG_DEBUG bits: 1 no partial rows, 2 no key resolution / accumulation, 4 (host) no merge
   uint64_t* partial_rows;             // [gridDim.x * 4 waves * SLOTS][W]
   uint64_t* ctrl;                     // [0] = #partial rows, [1] = flags (1: > SLOTS groups, 2: long string key)
 };
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256, (SLOTS * NW <= 16) ? 2 : 1) void fagg_kernel(F
           live[k] = live[k] && (EX_REG(P.filter_slot, k) & 1) && ((vmask[k] & P.filter_dep) == P.filter_dep);  // a NULL predicate drops the row
       }
     }
+    if (A.debug & 2) continue;
     // another wave of the workgroup may have published new keys: pick them up (uniform, rare)
     if (__builtin_amdgcn_readfirstlane(((volatile FaKeyTable*)&T)->count) != C.nk) C.refresh(&T);
 #pragma unroll
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256, (SLOTS * NW <= 16) ? 2 : 1) void fagg_kernel(F
 #pragma unroll
   for (int g = 0; g < SLOTS; ++g) {
     const uint64_t any = __ballot((touched >> g) & 1);
-    if (any == 0) continue;  // wave-uniform
+    if (any == 0 || (A.debug & 1)) continue;  // wave-uniform
 #pragma unroll
     for (int w = 0; w < NW; ++w) ex_regs[w * 256 + tid] = acc[g][w];
     uint64_t* r = nullptr;
@@ -420,7 +423,9 @@ __global__ __launch_bounds__(256, (SLOTS * NW <= 16) ? 2 : 1) void fagg_kernel(F
         if (j < A.nkey_words) r[j] = kk[j];
       r[A.hash_word] = h;
     }
-    r = (uint64_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)r >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)r));
+    r = (uint64_t*)fa_uniform_u64((uint64_t)r);   // lane 0's pointer for the whole wave (NOT `hi << 32 | readfirstlane(lo)`: the
+                                                  // builtin returns a signed int, whose sign extension clobbered the high half
+                                                  // whenever bit 31 of the address was set — an intermittent wild store)
     fa_emit_partial(ex_regs, tid, wm_lds, A.nwords, r + A.state_off);
   }
 #undef EX_REG
@@ -530,6 +535,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     A.key_type[k] = L.key_type[k]; A.key_off[k] = L.key_off[k]; A.key_words[k] = L.key_words[k];
   }
   A.filter_bits = filter_bitmap; A.filter_off = filter_bit_offset; A.n = n;
+  A.debug = getenv("DBHIP_FAGG_DEBUG") ? atoi(getenv("DBHIP_FAGG_DEBUG")) : 0;
   hipStream_t s = resolve_stream(stream);
   // (at least 6 slots: the end of the kernel stages one group's 12 state words per lane in the register file)
   const size_t lds = (size_t)(A.P.n_slots > 6 ? A.P.n_slots : 6) * FA_ROWS * 256 * 8;
@@ -555,6 +561,8 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   host_ctrl[0] = host_ctrl[1] = host_ctrl[2] = 0;
   const int64_t n_max = (int64_t)grid * 4 * FA_MAX_SLOTS;
   const bool chained = (dbhip_groupby_count_internal(g) + n_max) * 135 <= dbhip_groupby_capacity_internal(g) * 100;
+  if ((rc = dbhip_groupby_reserve_merge_internal(g, n_max))) return rc;
+  static const bool no_chain = getenv("DBHIP_FAGG_NOCHAIN") != nullptr;   // debugging: drain the stream between kernel and merge
   for (int variant = 0; variant < 2; ++variant) {
     DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
     kernel_timer_start(s);
@@ -571,7 +579,8 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     kernel_timer_stop(s);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, ctrl, 24, hipMemcpyDeviceToHost, s));
-    if (chained && !may_raise) {
+    if (A.debug & 4) { DBHIP_CHECK(hipStreamSynchronize(s)); return DBHIP_OK; }
+    if (chained && !may_raise && !no_chain) {
       // the merge of the partial rows is queued right behind the kernel with the row count and the give-up flags still
       // on the device: ONE host round trip per pass
       rc = dbhip_groupby_merge_rows_dev_internal(g, A.partial_rows, n_max, &ctrl[0], &ctrl[1], s);

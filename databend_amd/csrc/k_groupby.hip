@@ -1282,7 +1282,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // 8.6 ms vs 4.7 ms for the whole pushed-down plan — so add_block keeps the LDS path unless DBHIP_FAGG_AUTO=1 asks
     // for the experiment; the fused kernel earns its place where it also replaces the filter and the maps
     // (dbhip_groupby_add_block_program).
-    static const bool fagg_auto = getenv("DBHIP_FAGG_AUTO") != nullptr;
+    const bool fagg_auto = getenv("DBHIP_FAGG_AUTO") != nullptr;   // (read per call: tests toggle it)
     if (fagg_auto && g->fast_trusted && !g->fagg_disabled && g->count_host <= 8 && n - *done >= (1 << 20)) {
       rc = dbhip_fagg_add_columns_internal(g, C, *done, n - *done, s);
       if (rc == DBHIP_OK) {
@@ -1764,6 +1764,13 @@ int32_t dbhip_groupby_merge_rows_internal(dbhip_groupby* g, const uint64_t* rows
 int32_t dbhip_groupby_merge_rows_dev_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n_max, const uint64_t* n_dev,
                                               const uint64_t* abort_dev, hipStream_t s) {
   return merge_rows(g, rows, n_max, s, n_dev, abort_dev);
+}
+// allocate the merge scratch for up to n rows NOW (callers that queue a merge behind a running kernel: no hipMalloc may
+// fall between the kernel's launch and the merge's launches)
+int32_t dbhip_groupby_reserve_merge_internal(dbhip_groupby* g, int64_t n) {
+  int32_t rc;
+  if ((rc = ensure((void**)&g->gid, &g->gid_cap, (size_t)n * 4))) return rc;
+  return ensure((void**)&g->retry, &g->retry_cap, (size_t)n * 4);
 }
 int64_t dbhip_groupby_capacity_internal(dbhip_groupby* g) { return g->cap; }
 int64_t dbhip_groupby_count_internal(dbhip_groupby* g) { return g->count_host; }

@@ -223,7 +223,9 @@ int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* r
 /* ---- a5: comparisons -> Bitmap --------------------------------------------
  * Replaces vectorize_cmp_2_arg + Bitmap::collect_bool
  * (register_comparison.rs:52-96, bitmap/immutable.rs:474). Both sides must have
- * the same physical type (the planner inserts casts); floats compare as
+ * the same physical type (the planner inserts casts) — except two DECIMAL columns, which may differ in storage
+ * class and DecimalSize (no cast is planned for them: they compare at the larger scale in the storage class of
+ * calc_size, decimal/src/comparison.rs:326-441, a side that overflows there ordering by its sign); floats compare as
  * OrderedFloat (NaN largest, types/number.rs:47-48). `out_bitmap` holds
  * ceil(n/8) bytes, LSB-first, trailing bits zero. */
 int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n,

@@ -488,6 +488,59 @@ int orc_cmp(int op, const orc_col* lhs, const orc_col* rhs, int64_t n, uint8_t* 
   }
   return 0;
 }
+/* Decimal comparison of two different DecimalSizes — DecimalCmp::eval + CmpOp::compare
+ * (src/query/functions/src/scalars/decimal/src/comparison.rs:326-384 calc_size, :407-441 compare): T = storage class of
+ * (max leading digits + max scale, capped at 38); f_a = 10^(s - s_a), f_b = 10^(s - s_b); different signs compare as they
+ * are, else each side is multiplied by its factor with checked_mul, whose overflow decides the order. */
+static int dec_checked_mul_T(i128 x, i128 f, int t128, i128* out) {
+  if (!t128) { /* i64::checked_mul */
+    i128 r = x * f;
+    if (r > (i128)INT64_MAX || r < (i128)INT64_MIN) return 0;
+    *out = r; return 1;
+  }
+  i128 r;
+  if (__builtin_mul_overflow(x, f, &r)) return 0; /* i128::checked_mul */
+  *out = r; return 1;
+}
+int orc_cmp_decimal(int op, const orc_col* lhs, const orc_col* rhs, int64_t n, uint8_t* out) {
+  int l_dec = lhs->type == ORC_T_DEC64 || lhs->type == ORC_T_DEC128, r_dec = rhs->type == ORC_T_DEC64 || rhs->type == ORC_T_DEC128;
+  if (!l_dec || !r_dec) return 1;
+  int scale = lhs->scale > rhs->scale ? lhs->scale : rhs->scale;
+  int la = lhs->precision - lhs->scale, lb = rhs->precision - rhs->scale;
+  int precision = (la > lb ? la : lb) + scale;
+  if (precision > 38) precision = 38;
+  int t128 = precision > 18;
+  i128 fa = e10(scale - lhs->scale), fb = e10(scale - rhs->scale);
+  memset(out, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t ja = lhs->is_scalar ? 0 : i, jb = rhs->is_scalar ? 0 : i;
+    i128 a = lhs->type == ORC_T_DEC128 ? ((const i128*)lhs->data)[ja] : (i128)((const int64_t*)lhs->data)[ja];
+    i128 b = rhs->type == ORC_T_DEC128 ? ((const i128*)rhs->data)[jb] : (i128)((const int64_t*)rhs->data)[jb];
+    int c;
+    if (fa == fb) c = (a > b) - (a < b);
+    else {
+      int sa = (a > 0) - (a < 0), sb = (b > 0) - (b < 0);
+      if (sa != sb) c = (a > b) - (a < b);
+      else {
+        i128 x = a, y = b;
+        if (fa != 1 && !dec_checked_mul_T(a, fa, t128, &x)) c = sa > 0 ? 1 : -1;
+        else if (fb != 1 && !dec_checked_mul_T(b, fb, t128, &y)) c = sb > 0 ? -1 : 1;
+        else c = (x > y) - (x < y);
+      }
+    }
+    int r;
+    switch (op) {
+      case ORC_CMP_EQ: r = c == 0; break;
+      case ORC_CMP_NOTEQ: r = c != 0; break;
+      case ORC_CMP_LT: r = c < 0; break;
+      case ORC_CMP_LTE: r = c <= 0; break;
+      case ORC_CMP_GT: r = c > 0; break;
+      default: r = c >= 0; break;
+    }
+    if (r) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+  }
+  return 0;
+}
 int64_t orc_filter_select(const uint8_t* bm, int64_t off, int64_t n, uint32_t* out_sel) {
   int64_t k = 0;
   for (int64_t i = 0; i < n; ++i) if (bit_get(bm, off + i)) out_sel[k++] = (uint32_t)i;

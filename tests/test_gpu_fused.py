@@ -85,14 +85,19 @@ def test_fused_decimal_program_equals_the_per_node_decimal_semantics(gpu, oracle
     s4 = p4.arith(T.EX_PLUS, l0, p4.load(1), keep=(l0,))
     r4 = p4.run(p4.cmp(T.EX_GT, s4, l0), n)                 # Decimal128(31,4) > Decimal128(30,4): same storage, same scale
     assert np.array_equal(r4["values"], np.array([a_ > b_ for a_, b_ in zip(v3, big)]))
-    p5 = gpu.ExprProgram([cb128, cp])
-    l0 = p5.load(0)
-    l1 = p5.load(1)
-    s5 = p5.arith(T.EX_PLUS, l0, l1, keep=(l0, l1))
+    big2 = [int(v) * 10**9 for v in rng.integers(-10**17, 10**17, n)]
+    p5 = gpu.ExprProgram([cb128, cp, gpu.Column.decimal128(big2, 30, 4)])
+    l0, l1, l2 = p5.load(0), p5.load(1), p5.load(2)
     zero = p5.const(0, T.T_DEC64, 15, 2)
     cnd = p5.cmp(T.EX_GTE, l1, zero)
-    r5 = p5.run(p5.if_(cnd, s5, l0), n)
-    assert r5["values"] == [a_ if pr >= 0 else b_ for a_, b_, pr in zip(v3, big, price.tolist())]
+    r5 = p5.run(p5.if_(cnd, l0, l2), n)                      # if(price >= 0, big, big2) over Decimal128 values
+    assert r5["values"] == [a_ if pr >= 0 else b_ for a_, b_, pr in zip(big, big2, price.tolist())]
+    p6 = gpu.ExprProgram([cb128, cp])                          # a branch that can raise is NOT fused (lazy branches stay on the CPU)
+    l0, l1 = p6.load(0), p6.load(1)
+    s6 = p6.arith(T.EX_PLUS, l0, l1, keep=(l0, l1))
+    with pytest.raises(T.DbhipError) as e6:
+        p6.run(p6.if_(p6.cmp(T.EX_GTE, l1, p6.const(0, T.T_DEC64, 15, 2)), s6, l0), n)
+    assert e6.value.code == T.ERR_UNSUPPORTED
 
 
 def test_fused_decimal_program_row_errors(gpu, oracle):
@@ -214,7 +219,7 @@ def test_fused_aggregate_row_errors_respect_the_filter(gpu, oracle):
     n = 4096
     k = np.zeros(n, np.int64)
     x = [9 * 10**37] * n                                   # Decimal(38,0)
-    sel = np.arange(n) % 2 == 0
+    sel = np.arange(n) == 777                              # ONE kept row (two such sums would leave 38 digits at flush)
     y_bad = [5 * 10**37] * n                               # x + y leaves 38 digits on every row
     y_ok = [1 if keep else 5 * 10**37 for keep in sel]     # kept rows are fine, dropped rows would overflow
     flag = sel.astype(np.int64)
@@ -231,7 +236,7 @@ def test_fused_aggregate_row_errors_respect_the_filter(gpu, oracle):
         return g
     g = run(y_ok)
     rows = g.result()
-    assert rows == [(0, ((9 * 10**37 + 1) * (n // 2) + 2**127) % 2**128 - 2**127, n // 2)]     # the i128 state wraps; only flush checks it
+    assert rows == [(0, 9 * 10**37 + 1, 1)]
     with pytest.raises(T.DbhipError) as e:
         run(y_bad, g)
     assert e.value.code == T.ERR_ROW_ERRORS
@@ -248,9 +253,11 @@ def test_q1_as_one_generic_fused_program_equals_the_oracle(gpu, oracle, n):
 
 
 @pytest.mark.parametrize("card", [1, 4, 8])
-def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card):
-    """add_block on a table whose probing chunk shows <= 8 groups hands the rest of the block to the fused kernel (empty
-    program): same sorted row set as the oracle, incl. a pushed-down filter; a 9th group appearing late falls back."""
+def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card, monkeypatch):
+    """With DBHIP_FAGG_AUTO=1, add_block on a table whose probing chunk shows <= 8 groups hands the rest of the block to
+    the fused kernel (empty program): same sorted row set as the closed form, incl. a pushed-down filter; a 9th group
+    appearing late falls back to the LDS path."""
+    monkeypatch.setenv("DBHIP_FAGG_AUTO", "1")
     n = 3_000_000
     rng = np.random.default_rng(card)
     k = rng.integers(0, card, n).astype(np.int64)
