@@ -1164,6 +1164,59 @@ int orc_hashagg_merge_state_block(orc_hashagg* h, const orc_col* keys, const orc
   return rc;
 }
 
+/* The reference's own HashIndex test (hash_index/index.rs:252-404) restated: a table of `capacity` slots already holds the
+ * payload rows (key, hash, value) (probe_slot_and_set), then probe_and_create runs over the incoming (key, hash) pairs with
+ * an adapter that appends (key, hash, key + 20) for new rows and compares keys for tag matches. out_values[i] = the value of
+ * the row incoming[i] resolved to; returns the number of new rows. */
+int orc_hash_index_case(int capacity, const uint64_t* in_keys, const uint64_t* in_hashes, int n, const uint64_t* pay_keys,
+                        const uint64_t* pay_hashes, const uint64_t* pay_values, int m, uint64_t* out_values) {
+  int32_t kt[1] = {ORC_T_U64};
+  orc_hashagg* h = orc_hashagg_create(kt, NULL, 1, NULL, 0);
+  free(h->ctrls); free(h->pointers);
+  index_alloc(h, (size_t)capacity);
+  uint64_t vals[64];  /* payload values by row (the adapter's payload vector) */
+  int nv = 0;
+  orc_col kc; memset(&kc, 0, sizeof kc); kc.type = ORC_T_U64;
+  for (int r = 0; r < m; ++r) { /* init_hash_index: probe_slot_and_set */
+    kc.data = &pay_keys[r];
+    uint8_t* addr = append_row(h, &kc, 0, pay_hashes[r]);
+    size_t idx = probe_empty(h, pay_hashes[r]);
+    h->pointers[idx] = addr; h->count++;
+    vals[nv++] = pay_values[r];
+  }
+  size_t slots[BATCH_SIZE], addr[BATCH_SIZE];
+  int no_match[BATCH_SIZE], empty_v[BATCH_SIZE], cmp_v[BATCH_SIZE];
+  for (int r = 0; r < n; ++r) { no_match[r] = r; slots[r] = in_hashes[r] & h->mask; }
+  int remaining = n, total_new = 0;
+  while (remaining > 0) { /* probe_and_create index.rs:148-216 */
+    int n_new = 0, n_cmp = 0, n_nomatch = 0;
+    for (int t = 0; t < remaining; ++t) {
+      int row = no_match[t], is_new;
+      slots[row] = find_or_insert(h, slots[row], in_hashes[row], &is_new);
+      if (is_new) empty_v[n_new++] = row; else cmp_v[n_cmp++] = row;
+    }
+    for (int t = 0; t < n_new; ++t) { /* adapter.append_rows: value = key + 20 */
+      int row = empty_v[t];
+      kc.data = &in_keys[row];
+      addr[row] = (size_t)(uintptr_t)append_row(h, &kc, 0, in_hashes[row]);
+      h->pointers[slots[row]] = (uint8_t*)(uintptr_t)addr[row];
+      vals[nv++] = in_keys[row] + 20;
+    }
+    for (int t = 0; t < n_cmp; ++t) { /* adapter.compare */
+      int row = cmp_v[t];
+      addr[row] = (size_t)(uintptr_t)h->pointers[slots[row]];
+      uint64_t key; memcpy(&key, h->rows + (addr[row] - 1) * h->tuple_size + h->key_off[0], 8);
+      if (key != in_keys[row]) no_match[n_nomatch++] = row;
+    }
+    for (int t = 0; t < n_nomatch; ++t) slots[no_match[t]] = (slots[no_match[t]] + 1) & h->mask;
+    h->count += (size_t)n_new; total_new += n_new;
+    remaining = n_nomatch;
+  }
+  for (int r = 0; r < n; ++r) out_values[r] = vals[addr[r] - 1];
+  orc_hashagg_destroy(h);
+  return total_new;
+}
+
 void orc_hashagg_destroy(orc_hashagg* h) {
   if (!h) return;
   free(h->ctrls); free(h->pointers); free(h->rows); free(h->states); free(h->strs); free(h);
