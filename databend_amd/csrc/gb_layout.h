@@ -9,6 +9,10 @@
 //   f32/f64                        : 1 word, raw bits zero-extended
 //   dec128                         : 2 words (lo, hi)
 //   string (len <= 12)             : 2 words = the 16-byte inline view, bytes past len zeroed
+//   string (len  > 12)             : word 0 = len | first 4 bytes << 32 (the view's prefix), word 1 = where the bytes live:
+//                                    in a table row the OFFSET into the table's arena (a device bump allocator, the
+//                                    analogue of the Payload's arena, payload.rs:361-486: `(len, ptr)`); in an input /
+//                                    partial row the device ADDRESS of the bytes (column data buffer, or a peer's arena)
 //   NULL key                       : value words zeroed, bit `k` of the validity word cleared
 // state encodings:
 //   COUNT                : 1 word u64
@@ -41,6 +45,7 @@ struct GbLayout {
   int32_t key_nullable[GB_MAX_KEYS];
   int32_t validity_word;           // -1 when no key is nullable
   int32_t nkey_words;              // key words + validity word (everything compared for equality)
+  uint32_t str_w1_mask;            // bit j: word j is the SECOND word of a string key (inline bytes or arena offset / address)
   int32_t hash_word;
   int32_t agg_kind[GB_MAX_AGGS];
   int32_t agg_type[GB_MAX_AGGS];

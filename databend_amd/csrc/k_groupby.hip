@@ -63,6 +63,8 @@ struct dbhip_groupby {
   uint32_t* part_meta; size_t part_meta_cap;   // hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
   uint32_t* spill_idx; size_t spill_idx_cap;
   uint64_t* spill_rows; size_t spill_rows_cap;
+  uint8_t* arena; size_t arena_cap;        // bytes of the long (> 12 B) string keys of the groups; cursor = ctrl[8]
+  int has_long;                            // a long string key was met: the LDS / partitioned paths decline, the row path runs
   uint64_t* xcur;                          // exchange partitioning: cursor[4096] | base[4097]
   int fagg_disabled;                       // the fused few-groups kernel (k_fagg.hip) gave up on this table's keys / shape
 };
@@ -162,13 +164,43 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
       }
     }
     for (int k = 0; k < L.nkeys; ++k) {
-      uint64_t w0[U], w1[U];
-      bool valid[U];
-      if (!gb_load_words_n<U>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+      uint64_t w0[U], w1[U], hlong[U];
+      bool valid[U], is_long[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) is_long[u] = false;
+      if (L.key_type[k] == DBHIP_T_STRING) {
+        // strings of ANY length: short ones as canonical inline words, long ones as (len | prefix, address of the bytes) with
+        // the hash of the bytes (group_hash.rs:522-553); their sizes are summed so the host can make room in the arena
+        const GbCol& kc = C.key[k];
+        uint64_t long_bytes = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = kc.is_scalar ? 0 : row[u];
+          valid[u] = !kc.validity || bit_get(kc.validity, kc.voff + j);
+          const uint32_t* v = (const uint32_t*)kc.data + 4 * j;
+          const uint32_t len = v[0];
+          uint64_t ww[2] = {0, 0};
+          hlong[u] = 0;
+          if (len <= 12 || !valid[u]) {
+            bool vv;
+            gb_load_words(kc, row[u], ww, &vv);
+          } else {
+            const uint8_t* p = (const uint8_t*)kc.buffers[v[2]] + v[3];
+            ww[0] = ((uint64_t)v[1] << 32) | len;
+            ww[1] = (uint64_t)p;
+            hlong[u] = agg_hash_bytes(p, len);
+            is_long[u] = true;
+            if (in[u]) long_bytes += (len + 7) & ~7u;
+          }
+          w0[u] = ww[0]; w1[u] = ww[1];
+        }
+        long_bytes = wave_sum_u64(long_bytes);
+        if (long_bytes && lane_id() == 0) atomicAdd((unsigned long long*)&ctrl[9], (unsigned long long)long_bytes);
+      } else if (!gb_load_words_n<U>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint64_t w[2] = {w0[u], w1[u]};
-        const uint64_t hk = gb_hash_words(L.key_type[k], w, valid[u]);
+        const uint64_t hk = is_long[u] ? hlong[u] : gb_hash_words(L.key_type[k], w, valid[u]);
         h[u] = (k == 0) ? hk : merge_hash(h[u], hk);
         if (in[u]) {
           uint64_t* r = rows_in + li[u] * L.W;
@@ -230,9 +262,43 @@ __device__ __forceinline__ int64_t dev_rows(const DevCount& dc, int64_t n) {
   return n;
 }
 
+__device__ __forceinline__ bool bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len) {
+  for (uint32_t i = 0; i < len; ++i)
+    if (x[i] != y[i]) return false;
+  return true;
+}
+// `a`: an input / partial row (long strings by ADDRESS), `b`: a table row (long strings by arena OFFSET), row_match_entries
+// (payload_row.rs:324+): fixed-width words compare as words, long strings by length + prefix (word 0) and then their bytes
+__device__ __forceinline__ bool keys_equal(const GbLayout& L, const uint64_t* a, const uint64_t* b, const uint8_t* arena) {
+  bool eq = true;
+  for (int k = 0; k < L.nkey_words; ++k) {
+    if (((L.str_w1_mask >> k) & 1) && (uint32_t)a[k - 1] > 12) {
+      eq = eq && a[k - 1] == b[k - 1] && bytes_equal((const uint8_t*)a[k], arena + b[k], (uint32_t)a[k - 1]);
+      continue;
+    }
+    eq &= (a[k] == b[k]);
+  }
+  return eq;
+}
+// a lane that claimed a slot writes the group's key words; long strings are copied into the arena (bump allocation: the
+// host made room for every long byte of the chunk before the launch)
+__device__ __forceinline__ void write_group_keys(const GbLayout& L, const uint64_t* r, uint64_t* d, uint8_t* arena, uint64_t* ctrl) {
+  for (int k = 0; k < L.nkey_words; ++k) {
+    if (((L.str_w1_mask >> k) & 1) && (uint32_t)r[k - 1] > 12) {
+      const uint32_t len = (uint32_t)r[k - 1];
+      const unsigned long long off = atomicAdd((unsigned long long*)&ctrl[8], (unsigned long long)((len + 7) & ~7u));
+      const uint8_t* src = (const uint8_t*)r[k];
+      for (uint32_t i = 0; i < len; ++i) arena[off + i] = src[i];
+      d[k] = off;
+      continue;
+    }
+    d[k] = r[k];
+  }
+}
+
 __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_t* rows_in, int64_t n,
                                                        uint64_t* slot_hash, uint64_t* rows, int64_t cap,
-                                                       uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc) {
+                                                       uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc, uint8_t* arena) {
   n = dev_rows(dc, n);
   const uint64_t cmask = (uint64_t)cap - 1;
   // wave-uniform trip count: the number of NEW groups is added to ctrl[0] once per wave and iteration (one atomic
@@ -254,7 +320,7 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
           if (old == 0) {
             // this lane owns the new group: write keys, hash and identity states
             uint64_t* d = rows + pos * L.W;
-            for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
+            write_group_keys(L, r, d, arena, ctrl);
             d[L.hash_word] = r[L.hash_word];
             for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
             claimed = true;
@@ -277,25 +343,19 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
   }
 }
 
-__device__ __forceinline__ bool keys_equal(const GbLayout& L, const uint64_t* a, const uint64_t* b) {
-  bool eq = true;
-  for (int k = 0; k < L.nkey_words; ++k) eq &= (a[k] == b[k]);
-  return eq;
-}
-
 // ---------------------------------------------------------------------------
 // accumulate — direct atomics (many groups)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gb_accum_kernel(GbLayout L, const uint64_t* rows_in, int64_t n,
                                                        uint64_t* rows, const uint32_t* gid,
-                                                       uint32_t* retry, uint64_t* ctrl, DevCount dc) {
+                                                       uint32_t* retry, uint64_t* ctrl, DevCount dc, const uint8_t* arena) {
   n = dev_rows(dc, n);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t* r = rows_in + i * L.W;
     uint32_t pos = gid[i];
     uint64_t* d = rows + (uint64_t)pos * L.W;
-    if (!keys_equal(L, r, d)) {
+    if (!keys_equal(L, r, d, arena)) {
       unsigned long long k = atomicAdd((unsigned long long*)&ctrl[2], 1ULL);
       retry[k] = (uint32_t)i;
       continue;
@@ -333,7 +393,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const uint64_t* rows_in,
                                                                int64_t n, uint64_t* rows,
                                                                const uint32_t* gid, uint32_t* retry,
-                                                               uint64_t* ctrl, DevCount dc) {
+                                                               uint64_t* ctrl, DevCount dc, const uint8_t* arena) {
   n = dev_rows(dc, n);
   const int64_t n_pad = (n + 63) & ~63LL;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
@@ -343,7 +403,7 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
     uint32_t pos = active ? gid[i] : GB_INVALID_SLOT;
     if (active) {
       const uint64_t* d = rows + (uint64_t)pos * L.W;
-      if (!keys_equal(L, r, d)) {
+      if (!keys_equal(L, r, d, arena)) {
         unsigned long long k = atomicAdd((unsigned long long*)&ctrl[2], 1ULL);
         retry[k] = (uint32_t)i;
         active = false;
@@ -408,7 +468,7 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
 // ---------------------------------------------------------------------------
 __global__ void gb_retry_kernel(GbLayout L, const uint64_t* rows_in, uint64_t* slot_hash, uint64_t* rows,
                                 int64_t cap, uint64_t hash_mask, const uint32_t* gid,
-                                const uint32_t* retry, uint64_t* ctrl) {
+                                const uint32_t* retry, uint64_t* ctrl, uint8_t* arena) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const uint64_t cmask = (uint64_t)cap - 1;
   const uint64_t nretry = ctrl[2];
@@ -424,13 +484,13 @@ __global__ void gb_retry_kernel(GbLayout L, const uint64_t* rows_in, uint64_t* s
       if (cur == 0) {
         if ((int64_t)(ctrl[0] + 1) * 135 > cap * 100) break;  // would exceed the load factor
         slot_hash[pos] = hw;
-        for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
+        write_group_keys(L, r, d, arena, ctrl);
         d[L.hash_word] = r[L.hash_word];
         for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
         ctrl[0] += 1;
         cur = hw;
       }
-      if (cur == hw && keys_equal(L, r, d)) {
+      if (cur == hw && keys_equal(L, r, d, arena)) {
         for (int a = 0; a < L.naggs; ++a) gb_atomic_merge(L, a, d + L.agg_off[a], r + L.agg_off[a]);
         done = true;
       }
@@ -539,9 +599,14 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           case DBHIP_T_DEC128: case DBHIP_T_STRING: {
             uint64_t w1 = r[L.key_off[k] + 1];
             if (L.key_type[k] == DBHIP_T_STRING) {
-              // words -> 16-byte view {len, bytes[12]}
+              // words -> 16-byte view: {len, bytes[12]} inline, or {len, prefix, buffer 0, offset} into the table's arena
               uint32_t* v = (uint32_t*)o + 4 * i;
-              v[0] = (uint32_t)w0; v[1] = (uint32_t)(w0 >> 32); v[2] = (uint32_t)w1; v[3] = (uint32_t)(w1 >> 32);
+              if ((uint32_t)w0 > 12) {
+                if (w1 >> 32) atomicOr((unsigned long long*)&ctrl[3], 8ULL);   // a view's offset is 32 bits
+                v[0] = (uint32_t)w0; v[1] = (uint32_t)(w0 >> 32); v[2] = 0; v[3] = (uint32_t)w1;
+              } else {
+                v[0] = (uint32_t)w0; v[1] = (uint32_t)(w0 >> 32); v[2] = (uint32_t)w1; v[3] = (uint32_t)(w1 >> 32);
+              }
             } else {
               ((uint64_t*)o)[2 * i] = w0;
               ((uint64_t*)o)[2 * i + 1] = w1;
@@ -814,6 +879,7 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
     L->key_type[k] = key_types[k];
     L->key_off[k] = w;
     L->key_words[k] = (key_types[k] == DBHIP_T_DEC128 || key_types[k] == DBHIP_T_STRING) ? 2 : 1;
+    if (key_types[k] == DBHIP_T_STRING) L->str_w1_mask |= 1u << (w + 1);
     L->key_nullable[k] = key_nullable ? key_nullable[k] : 0;
     any_nullable |= L->key_nullable[k] != 0;
     w += L->key_words[k];
@@ -904,6 +970,38 @@ int32_t grow(dbhip_groupby* g, hipStream_t s) {
   return r1 ? r1 : r2;
 }
 
+// room for `extra` more bytes of long string keys (ctrl[8] = bytes in use); offsets into the arena stay valid when it moves
+int32_t reserve_arena(dbhip_groupby* g, uint64_t extra, hipStream_t s) {
+  if (extra == 0) return DBHIP_OK;
+  uint64_t used = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&used, &g->ctrl[8], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  const size_t need = (size_t)(used + extra);
+  if (need <= g->arena_cap) return DBHIP_OK;
+  size_t want = g->arena_cap ? g->arena_cap * 2 : ((size_t)1 << 20);
+  while (want < need) want *= 2;
+  uint8_t* na = nullptr;
+  int32_t rc = dbhip_alloc(want, (void**)&na);
+  if (rc) return rc;
+  if (used) DBHIP_CHECK(hipMemcpyAsync(na, g->arena, (size_t)used, hipMemcpyDeviceToDevice, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (g->arena) (void)dbhip_free(g->arena);
+  g->arena = na;
+  g->arena_cap = want;
+  return DBHIP_OK;
+}
+// after a kernel that summed the long-string bytes of its rows into ctrl[9]: read it, remember that the table holds long
+// strings, make room
+int32_t reserve_arena_for_chunk(dbhip_groupby* g, hipStream_t s) {
+  uint64_t lb = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&lb, &g->ctrl[9], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (lb == 0) return DBHIP_OK;
+  g->has_long = 1;
+  return reserve_arena(g, lb, s);
+}
+bool layout_has_strings(const GbLayout& L) { return L.str_w1_mask != 0; }
+
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
 int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
                    const uint64_t* n_dev = nullptr, const uint64_t* abort_dev = nullptr) {
@@ -926,14 +1024,14 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
   if ((g->count_host + n) * 135 <= g->cap * 100) {
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[1], 0, 16, s));
     hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash, g->rows, g->cap,
-                       g->hash_mask, g->gid, g->ctrl, dc);
+                       g->hash_mask, g->gid, g->ctrl, dc, g->arena);
     if (g->count_host <= 32 && n <= 65536)
       hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
-                         g->ctrl, dc);
+                         g->ctrl, dc, g->arena);
     else
-      hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry, g->ctrl, dc);
+      hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry, g->ctrl, dc, g->arena);
     hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows, g->cap, g->hash_mask,
-                       g->gid, g->retry, g->ctrl);
+                       g->gid, g->retry, g->ctrl, g->arena);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
@@ -956,7 +1054,7 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
     // ctrl[1] (overflow) and ctrl[2] (retry count) are per-attempt
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[1], 0, 16, s));
     hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash,
-                       g->rows, g->cap, g->hash_mask, g->gid, g->ctrl, dc);
+                       g->rows, g->cap, g->hash_mask, g->gid, g->ctrl, dc, g->arena);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
@@ -968,13 +1066,13 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
     g->count_host = (int64_t)host_ctrl[0];
     if (g->count_host <= 32) {
       hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n,
-                         g->rows, g->gid, g->retry, g->ctrl, dc);
+                         g->rows, g->gid, g->retry, g->ctrl, dc, g->arena);
     } else {
       hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows,
-                         g->gid, g->retry, g->ctrl, dc);
+                         g->gid, g->retry, g->ctrl, dc, g->arena);
     }
     hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows,
-                       g->cap, g->hash_mask, g->gid, g->retry, g->ctrl);
+                       g->cap, g->hash_mask, g->gid, g->retry, g->ctrl, g->arena);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
@@ -1231,6 +1329,7 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
   int64_t spilled = 0;
   int32_t rc = add_chunk_partitioned(g, C, *done, cn, s, &spilled);
   if (rc) return rc;
+  if (spilled < 0) { g->part_bits = -1; return DBHIP_OK; }   // long string keys: the caller's row path takes the rows from *done
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby partitioned chunk: rows=%lld pbits=%d spilled=%lld groups=%lld\n",
                                      (long long)cn, g->part_bits, (long long)spilled, (long long)g->count_host);
   *done += cn;
@@ -1330,8 +1429,11 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
     if (hc[3] & 2) {
-      set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
-      return DBHIP_ERR_UNSUPPORTED;
+      // a string key longer than 12 bytes: the LDS kernel's rows are two words per string; nothing of this chunk has been
+      // merged — the row path (which keeps long strings in the table's arena) takes the block from here
+      DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+      g->has_long = 1; g->fast_disabled = 1; g->part_bits = -1;
+      return -1;
     }
     if (hc[3] & 4) {
       // the trusted chunk spilled past its buffer (the key distribution changed inside the block): nothing of this
@@ -1694,9 +1796,11 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   uint64_t hc[8];
   DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
-  if (hc[3] & 2) {
-    set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
-    return DBHIP_ERR_UNSUPPORTED;
+  if (hc[3] & 2) {  // a long string key: this chunk goes to the row path (nothing was merged yet), see add_block_fast
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+    g->has_long = 1; g->fast_disabled = 1;
+    *spilled = -1;
+    return DBHIP_OK;
   }
   const int64_t nspill = (int64_t)hc[6];
   if (nspill > 0) {
@@ -1816,8 +1920,8 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
   g->part_min_rows = 262144;
   hipStream_t s = resolve_stream(nullptr);
   if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
-  hipError_t e = hipMalloc((void**)&g->ctrl, 64);
-  if (e == hipSuccess) e = hipMemsetAsync(g->ctrl, 0, 64, s);
+  hipError_t e = hipMalloc((void**)&g->ctrl, 128);   // [0..7] see above, [8] arena cursor, [9] long-string bytes of the current chunk
+  if (e == hipSuccess) e = hipMemsetAsync(g->ctrl, 0, 128, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {  // nothing half-built is handed out or leaked
     (void)dbhip_groupby_destroy(g);
@@ -1884,7 +1988,7 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
   }
   int32_t rc;
   int64_t done = 0;
-  if (fast_layout_ok(g->L)) {
+  if (fast_layout_ok(g->L) && !g->has_long) {
     rc = add_block_fast(g, C, n, s, &done);
     if (rc >= 0) return rc;
   }
@@ -1903,9 +2007,11 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
     // the two device-scope atomics per row, not by the random sectors. r01y: 17.9 ms vs 16.4 ms at 10 M groups.)
     if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
     if (C.filter) DBHIP_CHECK(hipMemsetAsync(&g->ctrl[7], 0, 8, s));
+    if (layout_has_strings(g->L)) DBHIP_CHECK(hipMemsetAsync(&g->ctrl[9], 0, 8, s));
     hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(ceil_div(cn, 4), 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
                        g->ctrl);
     DBHIP_LAUNCH_CHECK();
+    if (layout_has_strings(g->L) && (rc = reserve_arena_for_chunk(g, s))) return rc;
     int64_t kept = cn;
     if (C.filter) {  // the passing rows were written densely: their number comes back with one small copy
       uint64_t k7 = 0;
@@ -2158,7 +2264,64 @@ static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8
     set_error("Decimal overflow: sum state not in [DECIMAL_MIN, DECIMAL_MAX]");
     return DBHIP_ERR_OVERFLOW;
   }
+  if (err & 8) {
+    set_error("groupby: more than 4 GiB of long string keys: a BinaryView offset is 32 bits; flush the table in pieces");
+    return DBHIP_ERR_CAPACITY;
+  }
   return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_arena(dbhip_groupby* g, const void** out_ptr_host, int64_t* out_bytes_host, void* stream) {
+  DBHIP_REQUIRE(g && out_ptr_host && out_bytes_host, "dbhip_groupby_arena: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  uint64_t used = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&used, &g->ctrl[8], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  *out_ptr_host = g->arena;
+  *out_bytes_host = (int64_t)used;
+  return DBHIP_OK;
+}
+
+namespace {
+// serialized rows of ANOTHER table (long strings by offset into that table's arena, which the caller shipped along) ->
+// input rows (long strings by address); sums the long bytes for the arena reservation
+__global__ __launch_bounds__(256) void gb_rebase_rows_kernel(GbLayout L, const uint64_t* rows, int64_t n, const uint8_t* arena,
+                                                             uint64_t* out, uint64_t* ctrl) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t lb = 0;
+    if (i < n) {
+      const uint64_t* r = rows + i * L.W;
+      uint64_t* o = out + i * L.W;
+      for (int k = 0; k < L.W; ++k) {
+        uint64_t v = r[k];
+        if (k < L.nkey_words && ((L.str_w1_mask >> k) & 1) && (uint32_t)r[k - 1] > 12) {
+          v = (uint64_t)(arena + v);
+          lb += ((uint32_t)r[k - 1] + 7) & ~7u;
+        }
+        o[k] = v;
+      }
+    }
+    lb = wave_sum_u64(lb);
+    if (lb && lane_id() == 0) atomicAdd((unsigned long long*)&ctrl[9], (unsigned long long)lb);
+  }
+}
+}  // namespace
+
+int32_t dbhip_groupby_merge_serialized_arena(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, const void* arena_dev, void* stream) {
+  DBHIP_REQUIRE(g && (rows_dev || n_rows == 0), "dbhip_groupby_merge_serialized_arena: NULL argument");
+  if (n_rows == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  if (!layout_has_strings(g->L)) return merge_rows(g, (const uint64_t*)rows_dev, n_rows, s);
+  int32_t rc;
+  // (its own scratch: merge_rows may be handed g->rows_in by other callers, not by this one)
+  if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)n_rows * g->L.W * 8))) return rc;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[9], 0, 8, s));
+  hipLaunchKernelGGL(gb_rebase_rows_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, g->L, (const uint64_t*)rows_dev, n_rows,
+                     (const uint8_t*)arena_dev, g->spill_rows, g->ctrl);
+  DBHIP_LAUNCH_CHECK();
+  if ((rc = reserve_arena_for_chunk(g, s))) return rc;
+  return merge_rows(g, g->spill_rows, n_rows, s);
 }
 
 int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
@@ -2276,8 +2439,9 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   DBHIP_REQUIRE(g, "dbhip_groupby_reset: NULL argument");
   hipStream_t s = resolve_stream(stream);
   DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)g->cap * 8, s));
-  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 64, s));
+  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 128, s));
   g->count_host = 0;
+  g->has_long = 0;
   g->fast_disabled = 0;
   g->fast_trusted = 0;
   g->fagg_disabled = 0;
@@ -2300,6 +2464,7 @@ int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (g->spill_idx) (void)dbhip_free(g->spill_idx);
   if (g->spill_rows) (void)dbhip_free(g->spill_rows);
   if (g->xcur) (void)hipFree(g->xcur);
+  if (g->arena) (void)dbhip_free(g->arena);
   delete g;
   return DBHIP_OK;
 }

@@ -138,12 +138,17 @@ def make_views_general(strings):
     return v, np.frombuffer(bytes(buf) + b"\0" * 16, dtype=np.uint8).copy()
 
 
-def view_strings(views):
+def view_strings(views, buffer0=None):
+    """16-byte views -> bytes; long views ({len, prefix, buffer 0, offset}) read from `buffer0` (numpy uint8)"""
     views = np.asarray(views, dtype=np.uint8).reshape(-1, 16)
     out = []
     for r in views:
         ln = int(np.frombuffer(r[0:4].tobytes(), np.uint32)[0])
-        out.append(bytes(r[4:4 + ln]))
+        if ln <= 12:
+            out.append(bytes(r[4:4 + ln]))
+        else:
+            off = int(np.frombuffer(r[12:16].tobytes(), np.uint32)[0])
+            out.append(bytes(buffer0[off:off + ln]))
     return out
 
 
@@ -596,6 +601,27 @@ class GroupBy:
             states.append(Column(t, n, b, None, prec, scale))
         return keys, states
 
+    def arena(self):
+        """-> (device pointer, bytes in use) of the long string keys' bytes (dbhip_groupby_arena)"""
+        p, n = C.c_void_p(), C.c_int64()
+        check(lib().dbhip_groupby_arena(self.h, C.byref(p), C.byref(n), None))
+        return p.value, n.value
+
+    def arena_numpy(self):
+        p, n = self.arena()
+        if not n:
+            return np.zeros(0, np.uint8)
+        return BorrowedBuffer(p, n).to_numpy(np.uint8, n)
+
+    def merge_serialized_arena(self, rows, arena):
+        """rows (uint64 [n, W]) of another table + that table's arena bytes (numpy uint8)"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        if rows.size == 0:
+            return
+        buf = DeviceBuffer.from_numpy(rows)
+        ab = DeviceBuffer.from_numpy(np.concatenate([np.ascontiguousarray(arena, dtype=np.uint8), np.zeros(8, np.uint8)]))
+        check(lib().dbhip_groupby_merge_serialized_arena(self.h, C.c_void_p(buf.ptr), C.c_int64(rows.shape[0]), C.c_void_p(ab.ptr), None))
+
     def partition_blocks(self, blocks_ptr, n_buckets, max_rows, stream=None):
         """dbhip_groupby_partition_blocks: rows routed to bucket hash % n_buckets, one fixed-size block per bucket."""
         check(lib().dbhip_groupby_partition_blocks(self.h, C.c_int32(n_buckets), C.c_void_p(blocks_ptr), C.c_int64(max_rows), stream))
@@ -674,7 +700,7 @@ class GroupBy:
         for t, b, v in zip(self.key_types, key_bufs, key_val):
             valid = unpack_bits(v.to_numpy(np.uint8, ((cap + 31) // 32) * 4), n)
             if t == L.T_STRING:
-                vals = view_strings(b.to_numpy(np.uint8, 16 * n))
+                vals = view_strings(b.to_numpy(np.uint8, 16 * n), self.arena_numpy())
             elif t == L.T_DEC128:
                 vals = bytes_to_i128(b.to_numpy(np.uint8, 16 * n))
             elif t == L.T_BOOL:

@@ -288,8 +288,11 @@ typedef struct {
 
 typedef struct dbhip_groupby dbhip_groupby;  /* opaque */
 
-/* key_types: fixed-width types and DBHIP_T_STRING (strings up to 12 bytes are
- * kept inline; longer strings make add_block return DBHIP_ERR_UNSUPPORTED). */
+/* key_types: fixed-width types and DBHIP_T_STRING. Strings of up to 12 bytes stay inline in the group's row; longer ones
+ * are copied into the table's ARENA (a device bump allocator, the analogue of the Payload's arena: the row holds
+ * `(len, prefix, offset)` where the reference holds `(len, ptr)`, payload.rs:361-486, payload_row.rs:85-215) and compared by
+ * length, prefix and bytes (row_match_entries, payload_row.rs:324+). A block with long string keys is aggregated on the row
+ * path (the LDS / partitioned pre-aggregation kernels hand it over). */
 int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_nullable_host,
                              int32_t nkeys, const dbhip_agg_desc* aggs_host, int32_t naggs,
                              int64_t initial_capacity, dbhip_groupby** out_host);
@@ -336,6 +339,14 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
  * dbhip_groupby_flush_serialized on any rank) into this table. */
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows,
                                        void* stream);
+/* Long string keys. String key columns written by flush_result / flush_state_block are 16-byte views; the long form is
+ * {len, prefix, buffer 0, offset}: buffer 0 of such a column is the table's arena (dbhip_groupby_arena: device pointer and
+ * bytes in use; valid until the table is reset, destroyed or takes more rows). Serialized rows (flush_serialized /
+ * flush_block / partition_*) carry the same offsets: ship the arena with them and merge with merge_serialized_arena
+ * (`arena_dev` = the SENDER's arena bytes on this device); merge_serialized alone is for tables without long strings. */
+int32_t dbhip_groupby_arena(dbhip_groupby* g, const void** out_ptr_host, int64_t* out_bytes_host, void* stream);
+int32_t dbhip_groupby_merge_serialized_arena(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, const void* arena_dev,
+                                             void* stream);
 int32_t dbhip_groupby_num_groups(dbhip_groupby* g, int64_t* out_host, void* stream);
 /* Bytes per serialized row: [keys (fixed width, strings as 16-B inline views)]
  * [validity byte per nullable key][hash u64][state words]. */

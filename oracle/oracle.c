@@ -1035,6 +1035,24 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
   return rc;
 }
 
+/* the strings of key column k of every group, any length (the inline-view result of orc_hashagg_result holds <= 12 bytes):
+ * out_offsets[g] .. out_offsets[g + 1] delimit group g's bytes in out_bytes (NULL keys: empty). Returns the total bytes
+ * (call with out_bytes == NULL to size the buffer). */
+int64_t orc_hashagg_key_strings(orc_hashagg* h, int k, int64_t* out_offsets, uint8_t* out_bytes) {
+  int64_t total = 0;
+  for (size_t r = 0; r < h->nrows; ++r) {
+    const uint8_t* row = h->rows + r * h->tuple_size;
+    int valid = h->key_nullable[k] ? row[h->validity_off[k]] : 1;
+    uint32_t len = 0; uint64_t off = 0;
+    if (valid) { memcpy(&len, row + h->key_off[k], 4); memcpy(&off, row + h->key_off[k] + 4, 8); }
+    if (out_offsets) out_offsets[r] = total;
+    if (out_bytes && len) memcpy(out_bytes + total, h->strs + off, len);
+    total += len;
+  }
+  if (out_offsets) out_offsets[h->nrows] = total;
+  return total;
+}
+
 /* ---- serialized-state block: Payload::aggregate_flush (payload_flush.rs:151-181) ----------------------------------
  * entries = per aggregate the columns of its serialize_type() (a Tuple builder per aggregate: flattened here), then the
  * group columns. serialize_type / batch_serialize / batch_merge per function:

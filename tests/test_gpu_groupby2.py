@@ -354,3 +354,84 @@ def test_merge_blocks_reports_the_callers_own_overflowed_block(gpu):
         g.merge_blocks(blocks.ptr, 2, max_rows, skip_block=0)   # block 1 is empty (count 0)
     assert e.value.code == T.ERR_CAPACITY
     assert g.num_groups() == 500
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a9: string keys of any length (arena-backed rows)
+# ---------------------------------------------------------------------------------------------------------------
+def oracle_string_groups(oracle, h, nagg_cols):
+    """[(key string bytes | None, second key, agg values...)] of an oracle table whose key 0 is a String of any length"""
+    g = oracle.orc_hashagg_num_groups(h)
+    oracle.orc_hashagg_key_strings.restype = C.c_int64
+    total = oracle.orc_hashagg_key_strings(h, 0, None, None)
+    offs = np.zeros(g + 1, np.int64)
+    data = np.zeros(max(total, 1), np.uint8)
+    oracle.orc_hashagg_key_strings(h, 0, offs.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p))
+    return [bytes(data[offs[i]:offs[i + 1]]) for i in range(g)]
+
+
+@pytest.mark.parametrize("n,card,maxlen", [(1, 1, 40), (1000, 50, 13), (200_000, 3000, 64), (300_000, 250_000, 30), (100_000, 7, 200)])
+def test_groupby_string_keys_of_any_length(gpu, oracle, n, card, maxlen):
+    """GROUP BY c_name-style keys: strings of 0..maxlen bytes (inline and long, sharing prefixes and lengths), a nullable
+    string key plus an Int32 key, sum / count / min — the device table (arena-backed rows, payload.rs:361-486) against the
+    oracle (which keeps `(len, ptr into its arena)` like the reference), compared as sorted sets; then a second block, a
+    serialized round trip with the arena, and the result columns' long views."""
+    rng = np.random.default_rng(n + card + maxlen)
+    # pool of distinct strings: a common 12-byte prefix + varying tails, so prefix + length alone never decide equality
+    pool = []
+    for i in range(card):
+        ln = int(rng.integers(0, maxlen + 1))
+        body = (b"Customer#000" + (b"%09d" % i) + b"x" * maxlen)[:ln] if ln > 4 else (b"%d" % i)[:ln]
+        pool.append(body)
+    pool = sorted(set(pool))
+    idx = rng.integers(0, len(pool), n)
+    strs = [pool[i] for i in idx]
+    sv = rng.integers(0, 12, n) > 0
+    k2 = rng.integers(0, 3, n).astype(np.int32)
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    key_types, key_nullable = [T.T_STRING, T.T_I32], [1, 0]
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 0)]
+
+    def gcols(lo, hi):
+        return [gpu.Column.strings(strs[lo:hi], validity=sv[lo:hi]), gpu.Column.from_numpy(k2[lo:hi])], \
+               [gpu.Column.from_numpy(a[lo:hi]), None, gpu.Column.from_numpy(a[lo:hi])]
+
+    def expect(lo, hi):
+        out = {}
+        for i in range(lo, hi):
+            key = (strs[i] if sv[i] else None, int(k2[i]))
+            s = out.setdefault(key, [0, 0, None])
+            s[0] += int(a[i]); s[1] += 1; s[2] = int(a[i]) if s[2] is None else min(s[2], int(a[i]))
+        return sorted(((k[0] is None, k[0] or b"", k[1]) + tuple(v) for k, v in out.items()))
+
+    def rows_of(g):
+        return sorted(((r[0] is None, r[0] or b"", r[1]) + tuple(r[2:]) for r in g.result()))
+
+    cut = n // 2
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    keys, args = gcols(0, cut) if cut else gcols(0, n)
+    g.add_block(keys, args, cut if cut else n)
+    if cut:
+        keys, args = gcols(cut, n)
+        g.add_block(keys, args, n - cut)
+    assert rows_of(g) == expect(0, n)
+    # the oracle agrees (its own arena-backed payload rows) — group count and the multiset of key strings
+    v, buf = make_views_general(strs)
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, [O.HostCol(T.T_STRING, v, sv, buffers=[buf]), O.HostCol(T.T_I32, k2)],
+                       [O.HostCol(T.T_I64, a), None, O.HostCol(T.T_I64, a)], n)
+    okeys = oracle_string_groups(oracle, h, 3)
+    oracle.orc_hashagg_destroy(h)
+    assert g.num_groups() == len(okeys)
+    assert sorted(okeys) == sorted((r[1] for r in rows_of(g)))
+    # serialized round trip: rows + arena -> another table (combine_payload with re-based strings)
+    rows = g.flush_serialized()
+    g2 = gpu.GroupBy(key_types, aggs, key_nullable)
+    keys, args = gcols(0, min(n, 100))
+    g2.add_block(keys, args, min(n, 100))
+    g2.merge_serialized_arena(rows, g.arena_numpy())
+    exp2 = {}
+    for src in (expect(0, n), expect(0, min(n, 100))):
+        for r in src:
+            s = exp2.setdefault(r[:3], [0, 0, None])
+            s[0] += r[3]; s[1] += r[4]; s[2] = r[5] if s[2] is None else min(s[2], r[5])
+    assert rows_of(g2) == sorted(k + tuple(v) for k, v in exp2.items())
