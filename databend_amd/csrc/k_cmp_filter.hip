@@ -10,6 +10,8 @@
 #include "dev_load.h"
 #include "runtime.h"
 
+#include <vector>
+
 using namespace dbhip;
 
 namespace {
@@ -405,6 +407,50 @@ __global__ __launch_bounds__(256) void take_bitmap_kernel(const uint8_t* src, in
   }
 }
 
+// ---- take_ranges / take_compacted_indices / take_chunks (kernels/take_ranges.rs:40, take_compact.rs:38, take_chunks.rs:70-190) ----
+// Ranges and repeat lists are run-length forms of a selection vector: item r covers output rows [off[r], off[r + 1]). One
+// thread per output row finds its item by binary search over the offsets (a few thousand items at most per block) and writes
+// the source row id — after that every column is gathered by the ordinary take kernels.
+__global__ __launch_bounds__(256) void sel_expand_kernel(const uint32_t* first, const uint32_t* off, int n_items, int repeat,
+                                                         int64_t num_rows, uint32_t* out_sel) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {  // last item whose offset is <= i
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int64_t)off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    out_sel[i] = repeat ? first[lo] : first[lo] + (uint32_t)(i - off[lo]);
+  }
+}
+// (block, row) pairs -> rows of several source blocks (take_blocks / take_column_vec): out[i] = blocks[pair[i].block][pair[i].row]
+__global__ __launch_bounds__(256) void take_chunks_kernel(const void* const* blocks, int elem, const uint32_t* pairs, int64_t n, void* out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = pairs[2 * i], r = pairs[2 * i + 1];
+    const uint8_t* src = (const uint8_t*)blocks[b];
+    switch (elem) {
+      case 1: ((uint8_t*)out)[i] = src[r]; break;
+      case 2: ((uint16_t*)out)[i] = ((const uint16_t*)src)[r]; break;
+      case 4: ((uint32_t*)out)[i] = ((const uint32_t*)src)[r]; break;
+      case 8: ((uint64_t*)out)[i] = ((const uint64_t*)src)[r]; break;
+      default: ((u128*)out)[i] = ((const u128*)src)[r]; break;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void take_chunks_bitmap_kernel(const uint8_t* const* blocks, const uint32_t* pairs, int64_t n, uint8_t* out,
+                                                                 int64_t out_bytes) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    // a NULL block pointer stands for a column without validity: every row valid
+    const bool b = i < n && (blocks[pairs[2 * i]] == nullptr || bit_get(blocks[pairs[2 * i]], pairs[2 * i + 1]));
+    const uint64_t m = __ballot(b);
+    if (lane_id() == 0) {
+      const int64_t byte0 = (i >> 6) * 8;
+      for (int k = 0; k < 8; ++k)
+        if (byte0 + k < out_bytes) out[byte0 + k] = (uint8_t)(m >> (8 * k));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -548,6 +594,61 @@ int32_t dbhip_take_bitmap(const uint8_t* src, int64_t bit_offset, const uint32_t
   hipLaunchKernelGGL(take_bitmap_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0,
                      resolve_stream(stream), src, bit_offset, sel, n_sel, out, ceil_div(n_sel, 8));
   DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+static int32_t sel_expand(const uint32_t* items_host, int32_t n_items, int repeat, uint32_t* out_sel, int64_t num_rows, void* stream,
+                          const char* who) {
+  if (num_rows == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(items_host && n_items >= 1 && out_sel, "selection from ranges / repeats: NULL argument");
+  std::vector<uint32_t> host((size_t)2 * n_items);
+  uint64_t total = 0;
+  for (int r = 0; r < n_items; ++r) {
+    const uint32_t x = items_host[2 * r], y = items_host[2 * r + 1];
+    const uint64_t len = repeat ? y : (y >= x ? y - x : 0);
+    if (!repeat && y < x) { set_error("%s: range %d ends before it starts", who, r); return DBHIP_ERR_INVALID; }
+    host[r] = x;
+    host[n_items + r] = (uint32_t)total;
+    total += len;
+  }
+  if ((int64_t)total != num_rows) {  // debug_assert in the reference (take_compact.rs:43-47)
+    set_error("%s: the items cover %llu rows, num_rows is %lld", who, (unsigned long long)total, (long long)num_rows);
+    return DBHIP_ERR_INVALID;
+  }
+  hipStream_t s = resolve_stream(stream);
+  uint32_t* dev = (uint32_t*)scratch((size_t)2 * n_items * 4, 7);
+  if (!dev) return DBHIP_ERR_HIP;
+  DBHIP_CHECK(hipMemcpyAsync(dev, host.data(), (size_t)2 * n_items * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sel_expand_kernel, dim3(grid_for(num_rows, 256)), dim3(256), 0, s, dev, dev + n_items, n_items, repeat, num_rows, out_sel);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));  // `host` (pageable) was the source of an async copy
+  return DBHIP_OK;
+}
+
+int32_t dbhip_sel_from_ranges(const uint32_t* ranges_host, int32_t n_ranges, uint32_t* out_sel, int64_t num_rows, void* stream) {
+  return sel_expand(ranges_host, n_ranges, 0, out_sel, num_rows, stream, "dbhip_sel_from_ranges");
+}
+
+int32_t dbhip_sel_from_repeats(const uint32_t* repeats_host, int32_t n_repeats, uint32_t* out_sel, int64_t num_rows, void* stream) {
+  return sel_expand(repeats_host, n_repeats, 1, out_sel, num_rows, stream, "dbhip_sel_from_repeats");
+}
+
+int32_t dbhip_take_chunks(const void* const* blocks_host, int32_t n_blocks, int32_t elem_size, const uint32_t* pairs, int64_t n,
+                          void* out, void* stream) {
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(blocks_host && n_blocks >= 1 && pairs && out, "dbhip_take_chunks: NULL argument");
+  DBHIP_REQUIRE(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8 || elem_size == 16 || elem_size == 0,
+                "dbhip_take_chunks: elem_size must be 0 (bitmap), 1, 2, 4, 8 or 16");
+  hipStream_t s = resolve_stream(stream);
+  const void** dev = (const void**)scratch((size_t)n_blocks * 8, 7);
+  if (!dev) return DBHIP_ERR_HIP;
+  DBHIP_CHECK(hipMemcpyAsync(dev, blocks_host, (size_t)n_blocks * 8, hipMemcpyHostToDevice, s));
+  if (elem_size == 0)
+    hipLaunchKernelGGL(take_chunks_bitmap_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint8_t* const*)dev, pairs, n, (uint8_t*)out, ceil_div(n, 8));
+  else
+    hipLaunchKernelGGL(take_chunks_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const void* const*)dev, elem_size, pairs, n, out);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));  // the pointer table came from caller-owned pageable memory
   return DBHIP_OK;
 }
 

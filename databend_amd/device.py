@@ -370,6 +370,44 @@ def take(col, sel, k):
     return Column(col.dtype, k, out, vb, col.precision, col.scale, buffers=col.buffers, keep=(col,))
 
 
+def sel_from_ranges(ranges, num_rows):
+    """DataBlock::take_ranges as a device selection vector: ranges = [(start, end), ...]"""
+    r = np.ascontiguousarray(np.array(ranges, dtype=np.uint32).reshape(-1, 2))
+    sel = DeviceBuffer(max(num_rows, 1) * 4 + 64)
+    check(lib().dbhip_sel_from_ranges(r.ctypes.data_as(C.c_void_p), C.c_int32(len(r)), C.c_void_p(sel.ptr), C.c_int64(num_rows), None))
+    return sel
+
+
+def sel_from_repeats(repeats, num_rows):
+    """DataBlock::take_compacted_indices as a device selection vector: repeats = [(row, count), ...]"""
+    r = np.ascontiguousarray(np.array(repeats, dtype=np.uint32).reshape(-1, 2))
+    sel = DeviceBuffer(max(num_rows, 1) * 4 + 64)
+    check(lib().dbhip_sel_from_repeats(r.ctypes.data_as(C.c_void_p), C.c_int32(len(r)), C.c_void_p(sel.ptr), C.c_int64(num_rows), None))
+    return sel
+
+
+def take_chunks(cols, pairs):
+    """DataBlock::take_blocks for one column of several blocks: pairs = [(block, row), ...] -> Column"""
+    pr = np.ascontiguousarray(np.array(pairs, dtype=np.uint32).reshape(-1, 2))
+    n = len(pr)
+    dp = DeviceBuffer.from_numpy(pr.reshape(-1)) if n else DeviceBuffer(16)
+    c0 = cols[0]
+    ptrs = (C.c_void_p * len(cols))(*[c.data.ptr for c in cols])
+    if c0.dtype == L.T_BOOL:
+        out = DeviceBuffer(((n + 63) // 64) * 8 + 8)
+        check(lib().dbhip_take_chunks(ptrs, len(cols), 0, C.c_void_p(dp.ptr), C.c_int64(n), C.c_void_p(out.ptr), None))
+    else:
+        es = ELEM_SIZE[c0.dtype]
+        out = DeviceBuffer(max(n, 1) * es + 64)
+        check(lib().dbhip_take_chunks(ptrs, len(cols), es, C.c_void_p(dp.ptr), C.c_int64(n), C.c_void_p(out.ptr), None))
+    vb = None
+    if any(c.validity is not None for c in cols):
+        vptrs = (C.c_void_p * len(cols))(*[(c.validity.ptr if c.validity is not None else None) for c in cols])
+        vb = DeviceBuffer(((n + 63) // 64) * 8 + 8)
+        check(lib().dbhip_take_chunks(vptrs, len(cols), 0, C.c_void_p(dp.ptr), C.c_int64(n), C.c_void_p(vb.ptr), None))
+    return Column(c0.dtype, n, out, vb, c0.precision, c0.scale, buffers=c0.buffers, keep=tuple(cols))
+
+
 def group_hash(cols, n):
     out = DeviceBuffer(max(n, 1) * 8)
     arr = _cols(cols)

@@ -254,6 +254,24 @@ int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int6
 int32_t dbhip_take_bitmap(const uint8_t* src, int64_t bit_offset, const uint32_t* sel,
                           int64_t n_sel, uint8_t* out, void* stream);
 
+/* The other gathers of the kernels module, as selection vectors for dbhip_take / dbhip_take_bitmap:
+ *   dbhip_sel_from_ranges   DataBlock::take_ranges (kernels/take_ranges.rs:40): `ranges_host` = n_ranges pairs (start, end),
+ *                           the selection is the concatenation of the row ranges [start, end) (the block reader's pruned
+ *                           row ranges); their lengths must add up to num_rows.
+ *   dbhip_sel_from_repeats  DataBlock::take_compacted_indices (kernels/take_compact.rs:38): `repeats_host` = n pairs
+ *                           (row, count) = RepeatIndex, row `row` appears `count` times in a row (the hash join's probe
+ *                           side); the counts must add up to num_rows.
+ *   dbhip_take_chunks       DataBlock::take_blocks / take_column_vec (kernels/take_chunks.rs:70-190): `pairs` = n device
+ *                           pairs (block, row) = BlockIndex, out[i] = blocks[block][row] for ONE column of several blocks
+ *                           (`blocks_host`: n_blocks device pointers; elem_size 1/2/4/8/16, or 0 for Bitmap columns,
+ *                           where a NULL block pointer means "no validity: all valid"). */
+int32_t dbhip_sel_from_ranges(const uint32_t* ranges_host, int32_t n_ranges, uint32_t* out_sel, int64_t num_rows,
+                              void* stream);
+int32_t dbhip_sel_from_repeats(const uint32_t* repeats_host, int32_t n_repeats, uint32_t* out_sel, int64_t num_rows,
+                               void* stream);
+int32_t dbhip_take_chunks(const void* const* blocks_host, int32_t n_blocks, int32_t elem_size, const uint32_t* pairs,
+                          int64_t n, void* out, void* stream);
+
 /* ---- a7: group hash ---------------------------------------------------------
  * Replaces group_hash_entries (aggregate/group_hash.rs:40-61): per-row u64 over
  * `ncols` key columns, combined as h = h*NULL_HASH_VAL ^ h_col (:509-511), NULL ->

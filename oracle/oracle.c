@@ -550,6 +550,23 @@ void orc_take(const void* src, int es, const uint32_t* sel, int64_t n, void* out
   for (int64_t i = 0; i < n; ++i) memcpy((uint8_t*)out + i * es, (const uint8_t*)src + (size_t)sel[i] * es, (size_t)es);
 }
 
+/* take_ranges (kernels/take_ranges.rs:40) / take_compacted_indices (take_compact.rs:38) as selection vectors, take_blocks
+ * (take_chunks.rs:70-190) for one column */
+int64_t orc_sel_from_ranges(const uint32_t* ranges, int n, uint32_t* out) {
+  int64_t k = 0;
+  for (int r = 0; r < n; ++r) for (uint32_t i = ranges[2 * r]; i < ranges[2 * r + 1]; ++i) out[k++] = i;
+  return k;
+}
+int64_t orc_sel_from_repeats(const uint32_t* rep, int n, uint32_t* out) {
+  int64_t k = 0;
+  for (int r = 0; r < n; ++r) for (uint32_t c = 0; c < rep[2 * r + 1]; ++c) out[k++] = rep[2 * r];
+  return k;
+}
+void orc_take_chunks(const void* const* blocks, int es, const uint32_t* pairs, int64_t n, void* out) {
+  for (int64_t i = 0; i < n; ++i)
+    memcpy((uint8_t*)out + i * es, (const uint8_t*)blocks[pairs[2 * i]] + (size_t)pairs[2 * i + 1] * es, (size_t)es);
+}
+
 /* ------------------------------------------------------------------------ */
 /* group hash: aggregate/group_hash.rs:38,180-207,267-281,509-632              */
 /* ------------------------------------------------------------------------ */

@@ -136,7 +136,25 @@ def kernel():
             i = j2
             continue
         i += 1
-    return {"source": "src/query/expression/tests/it/testdata/kernel-pass.txt (Filter / Take sections; kernel.rs:49-566)", "cases": cases}
+    # Take Block indices / Take Block by slices: several source blocks
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^Take Block (indices|by slices \(limit: (None|Some\((\d+)\))\)):\s+\[(.*)\]\s*$", lines[i])
+        if m:
+            tuples = [tuple(int(x) for x in t.split(",")) for t in re.findall(r"\(([^()]*)\)", m.group(4))]
+            blocks, j = [], i + 1
+            hdr = None
+            while j < len(lines) and re.match(r"^Block\d+:", lines[j]):
+                hdr, rows, j = text_table(lines, j + 1)
+                blocks.append(rows)
+            assert lines[j].startswith("Result:"), lines[j]
+            _, res, j2 = text_table(lines, j + 1)
+            cases.append({"kind": "chunks" if m.group(1) == "indices" else "slices", "arg": [list(t) for t in tuples],
+                          "limit": int(m.group(3)) if m.group(3) else 0, "header": hdr, "blocks": blocks, "result": res})
+            i = j2
+            continue
+        i += 1
+    return {"source": "src/query/expression/tests/it/testdata/kernel-pass.txt (Filter / Take / Take Block sections; kernel.rs:49-566)", "cases": cases}
 
 
 def sort_cases():

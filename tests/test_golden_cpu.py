@@ -218,7 +218,7 @@ def test_aggregate_goldens_sum_count_avg_min_max():
 def test_kernel_pass_filter_and_take_goldens():
     """kernel-pass.txt Filter / Take sections: Bitmap -> selection -> take of every column, rendered like the reference."""
     L = O.load()
-    cases = golden("kernel.json")
+    cases = [c for c in golden("kernel.json") if c["kind"] in ("filter", "take")]
     assert len(cases) == 2
     for case in cases:
         src = case["source"]
@@ -239,6 +239,43 @@ def test_kernel_pass_filter_and_take_goldens():
             got = [cells[i] for i in sel]          # the rendered cell of a taken row is the source row's cell
             assert out.tolist() == [int(vals[i]) for i in sel]
             assert got == [r[c] for r in case["result"]], (case["kind"], c)
+
+
+def chunk_pairs(case):
+    """(block, row) pairs of a 'Take Block' case: indices as they are, slices (block, start, len) expanded and truncated to
+    the limit (take_by_slices_limit_from_blocks, take_chunks.rs:126-190)"""
+    if case["kind"] == "chunks":
+        return [tuple(t) for t in case["arg"]]
+    pairs = [(b, s + i) for b, s, ln in case["arg"] for i in range(ln)]
+    return pairs[:case["limit"]] if case["limit"] else pairs
+
+
+def test_kernel_pass_take_block_goldens():
+    """kernel-pass.txt 'Take Block indices' / 'Take Block by slices': rows of several blocks by (block, row) pairs."""
+    L = O.load()
+    cases = [c for c in golden("kernel.json") if c["kind"] in ("chunks", "slices")]
+    assert len(cases) == 3
+    for case in cases:
+        pairs = np.array(chunk_pairs(case), np.uint32)
+        n = len(pairs)
+        for c in range(2):  # Column 0 (Int), Column 1 (nullable Int); the Array / Tuple columns are outside the path's types
+            blocks = [np.array([0 if r[c] == "NULL" else int(r[c]) for r in b], np.int64) for b in case["blocks"]]
+            cells = [[r[c] for r in b] for b in case["blocks"]]
+            ptrs = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
+            out = np.zeros(n, np.int64)
+            L.orc_take_chunks(ptrs, 8, pairs.ctypes.data_as(C.c_void_p), C.c_int64(n), out.ctypes.data_as(C.c_void_p))
+            assert out.tolist() == [int(blocks[b][r]) for b, r in pairs.tolist()]
+            assert [cells[b][r] for b, r in pairs.tolist()] == [r[c] for r in case["result"]], (case["kind"], c)
+    # take_ranges / take_compacted_indices have no golden file: closed form
+    rng = np.array([[2, 5], [0, 1], [7, 7], [3, 9]], np.uint32)
+    out = np.zeros(16, np.uint32)
+    L.orc_sel_from_ranges.restype = C.c_int64
+    L.orc_sel_from_repeats.restype = C.c_int64
+    k = L.orc_sel_from_ranges(rng.ctypes.data_as(C.c_void_p), 4, out.ctypes.data_as(C.c_void_p))
+    assert out[:k].tolist() == [2, 3, 4, 0, 3, 4, 5, 6, 7, 8]
+    rep = np.array([[5, 2], [1, 0], [9, 3]], np.uint32)
+    k = L.orc_sel_from_repeats(rep.ctypes.data_as(C.c_void_p), 3, out.ctypes.data_as(C.c_void_p))
+    assert out[:k].tolist() == [5, 5, 9, 9, 9]
 
 
 def test_sort_goldens_from_sort_rs():

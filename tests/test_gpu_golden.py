@@ -7,7 +7,7 @@ import pytest
 
 from databend_amd import _lib as T
 from tests import golden_eval as G
-from tests.test_golden_cpu import AGG_KIND, agg_argument, agg_column, compare_agg, expected_agg, golden
+from tests.test_golden_cpu import AGG_KIND, agg_argument, agg_column, chunk_pairs, compare_agg, expected_agg, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -96,7 +96,7 @@ def test_aggregate_goldens_through_the_c_abi(gpu):
 
 def test_kernel_pass_filter_and_take_goldens_through_the_c_abi(gpu):
     D = gpu
-    for case in golden("kernel.json"):
+    for case in [c for c in golden("kernel.json") if c["kind"] in ("filter", "take")]:
         src = case["source"]
         n = len(src)
         if case["kind"] == "filter":
@@ -118,6 +118,42 @@ def test_kernel_pass_filter_and_take_goldens_through_the_c_abi(gpu):
             ov = out.validity_numpy()
             got = [v if ok else "NULL" for v, ok in zip(vals, ov)]
             assert got == [r[c] for r in case["result"]], (case["kind"], c, got)
+
+
+def test_take_block_goldens_and_range_repeat_selections_through_the_c_abi(gpu, oracle):
+    """kernel-pass.txt 'Take Block indices' / 'by slices' through dbhip_take_chunks (values and validity), and
+    dbhip_sel_from_ranges / dbhip_sel_from_repeats against the oracle on random run-length inputs."""
+    D = gpu
+    for case in [c for c in golden("kernel.json") if c["kind"] in ("chunks", "slices")]:
+        pairs = chunk_pairs(case)
+        for c in range(2):
+            cols = []
+            for b in case["blocks"]:
+                cells = [r[c] for r in b]
+                valid = np.array([x != "NULL" for x in cells])
+                cols.append(D.Column.from_numpy(np.array([int(x) if x != "NULL" else 0 for x in cells], np.int32),
+                                                validity=None if valid.all() and c == 0 else valid))
+            out = D.take_chunks(cols, pairs)
+            vals, ov = out.to_numpy().tolist(), out.validity_numpy()
+            assert [str(v) if ok else "NULL" for v, ok in zip(vals, ov)] == [r[c] for r in case["result"]], (case["kind"], c)
+    rng = np.random.default_rng(4)
+    for n_items in (1, 7, 3000):
+        starts = rng.integers(0, 1 << 20, n_items).astype(np.uint32)
+        lens = rng.integers(0, 300, n_items).astype(np.uint32)
+        ranges = np.stack([starts, starts + lens], axis=1).astype(np.uint32)
+        total = int(lens.sum())
+        exp = np.zeros(max(total, 1), np.uint32)
+        oracle.orc_sel_from_ranges.restype = C.c_int64
+        oracle.orc_sel_from_repeats.restype = C.c_int64
+        assert oracle.orc_sel_from_ranges(ranges.ctypes.data_as(C.c_void_p), n_items, exp.ctypes.data_as(C.c_void_p)) == total
+        got = D.sel_from_ranges(ranges, total).to_numpy(np.uint32, total)
+        assert np.array_equal(got, exp[:total])
+        reps = np.stack([starts, lens], axis=1).astype(np.uint32)
+        assert oracle.orc_sel_from_repeats(reps.ctypes.data_as(C.c_void_p), n_items, exp.ctypes.data_as(C.c_void_p)) == total
+        got = D.sel_from_repeats(reps, total).to_numpy(np.uint32, total)
+        assert np.array_equal(got, exp[:total])
+    with pytest.raises(T.DbhipError):     # the items must cover exactly num_rows (debug_assert in the reference)
+        D.sel_from_ranges([(0, 5)], 4)
 
 
 def test_sort_goldens_through_the_c_abi(gpu):
