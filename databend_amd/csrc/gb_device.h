@@ -253,6 +253,84 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
   }
 }
 
+// gb_atomic_merge with WORKGROUP-scope atomics: for a table slice that only one workgroup touches during the launch (the
+// partition-exclusive insert, k_groupby.hip) — the atomic is resolved in the XCD's L2 instead of travelling the fabric
+#define GB_WG_ADD(p, v) __hip_atomic_fetch_add((unsigned long long*)(p), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define GB_WG_OR(p, v) __hip_atomic_fetch_or((unsigned long long*)(p), (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* dst, const uint64_t* v) {
+  switch (L.agg_kind[a]) {
+    case DBHIP_AGG_COUNT:
+      if (v[0]) GB_WG_ADD(dst, v[0]);
+      break;
+    case DBHIP_AGG_SUM: {
+      const int fw = L.agg_flag[a];
+      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+        if (v[0] | v[1] | v[2]) {
+          const uint64_t old = GB_WG_ADD(dst, v[0]);
+          const uint64_t c1 = (old + v[0]) < v[0] ? 1 : 0;
+          const uint64_t addhi = v[1] + c1;
+          uint64_t c2 = addhi < v[1] ? 1 : 0;
+          if (addhi) {
+            const uint64_t oh = GB_WG_ADD(dst + 1, addhi);
+            c2 |= (oh + addhi) < addhi ? 1 : 0;
+          }
+          const uint64_t addext = v[2] + c2;
+          if (addext) GB_WG_ADD(dst + 2, addext);
+        }
+      } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
+        __hip_atomic_fetch_add((double*)dst, __longlong_as_double((long long)v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (v[0]) {
+        GB_WG_ADD(dst, v[0]);
+      }
+      if (fw && v[fw]) GB_WG_OR(dst + fw, 1ULL);
+    } break;
+    case DBHIP_AGG_MIN:
+      if (v[1]) {
+        __hip_atomic_fetch_min((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        GB_WG_OR(dst + 1, 1ULL);
+      }
+      break;
+    default:  // MAX
+      if (v[1]) {
+        __hip_atomic_fetch_max((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        GB_WG_OR(dst + 1, 1ULL);
+      }
+      break;
+  }
+}
+
+// the same merge without atomics: `dst` has ONE writer (the partition-exclusive merge, k_groupby.hip)
+__device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_t* dst, const uint64_t* v) {
+  switch (L.agg_kind[a]) {
+    case DBHIP_AGG_COUNT:
+      dst[0] += v[0];
+      break;
+    case DBHIP_AGG_SUM: {
+      const int fw = L.agg_flag[a];
+      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+        const uint64_t lo = dst[0] + v[0];
+        const uint64_t c1 = lo < v[0] ? 1 : 0;
+        const uint64_t h1 = dst[1] + v[1];
+        const uint64_t c2a = h1 < v[1] ? 1 : 0;
+        const uint64_t hi = h1 + c1;
+        const uint64_t c2 = c2a | (hi < h1 ? 1 : 0);
+        dst[0] = lo; dst[1] = hi; dst[2] += v[2] + c2;
+      } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
+        dst[0] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)dst[0]) + __longlong_as_double((long long)v[0]));
+      } else {
+        dst[0] += v[0];
+      }
+      if (fw && v[fw]) dst[fw] |= 1ULL;
+    } break;
+    case DBHIP_AGG_MIN:
+      if (v[1]) { dst[0] = v[0] < dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
+      break;
+    default:  // MAX
+      if (v[1]) { dst[0] = v[0] > dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
+      break;
+  }
+}
+
 // identity element of a state
 __device__ __forceinline__ void gb_state_identity(const GbLayout& L, int a, uint64_t* dst) {
   for (int k = 0; k < L.agg_words[a]; ++k) dst[k] = 0;

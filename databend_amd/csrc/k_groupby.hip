@@ -59,8 +59,10 @@ struct dbhip_groupby {
   int part_bits;                           // 0 = undecided, > 0 = log2(partitions), < 0 = not worth it (row path)
   int part_forbidden;                      // test hook: never choose the partitioned path
   int64_t part_min_rows;                   // smallest chunk worth partitioning
+  int64_t part_chunk;                      // rows per partitioned chunk (0 = PT_CHUNK)
+  int part_direct;                         // partitioned rows are inserted straight into their table slice (no LDS pre-aggregation)
   int64_t rows_seen;                       // input rows of add_block so far (cardinality estimate)
-  uint32_t* part_meta; size_t part_meta_cap;   // hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
+  uint32_t* part_meta; size_t part_meta_cap;   // tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
   uint32_t* spill_idx; size_t spill_idx_cap;
   uint64_t* spill_rows; size_t spill_rows_cap;
   uint8_t* arena; size_t arena_cap;        // bytes of the long (> 12 B) string keys of the groups; cursor = ctrl[8]
@@ -1317,15 +1319,17 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
 }  // namespace
 int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, hipStream_t s);  // k_fagg.hip
 namespace {
-constexpr int PT_MAX_BITS = 13;
-constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: hist[PT_PMAX] | base[PT_PMAX + 8] | cursor[PT_PMAX]
+constexpr int PT_MAX_BITS = 14;
+constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
 void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block);
+int64_t estimate_groups(int64_t d, int64_t s);
 int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s);
-constexpr int64_t PT_CHUNK = 32 << 20;
+constexpr int64_t PT_CHUNK = 64 << 20;
 
 // one partitioned chunk starting at *done; widens the partitioning (or gives it up) when too many rows spilled
 int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, int64_t* done) {
-  const int64_t cn = n - *done < PT_CHUNK ? n - *done : PT_CHUNK;
+  const int64_t chunk = g->part_chunk > 0 ? g->part_chunk : PT_CHUNK;
+  const int64_t cn = n - *done < chunk ? n - *done : chunk;
   int64_t spilled = 0;
   int32_t rc = add_chunk_partitioned(g, C, *done, cn, s, &spilled);
   if (rc) return rc;
@@ -1334,8 +1338,11 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
                                      (long long)cn, g->part_bits, (long long)spilled, (long long)g->count_host);
   *done += cn;
   g->rows_seen += cn;
+  if (g->part_direct) { g->part_chunk = 0; return DBHIP_OK; }
   if (spilled * 20 > cn) {
     if (g->part_bits + 2 <= PT_MAX_BITS) g->part_bits += 2;
+    else if (g->part_bits < PT_MAX_BITS) g->part_bits = PT_MAX_BITS;
+    else if (chunk > (2 << 20)) g->part_chunk = chunk / 2;   // finest partitioning already: fewer groups per chunk
     else { g->part_bits = -1; g->fast_disabled = 1; }
   }
   return DBHIP_OK;
@@ -1356,10 +1363,8 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
   // layout class: small = <= 2 key words, <= 2 one-word aggregates (8 rows per lane); else general (2 rows)
   bool hi = false;
   for (int a = 0; a < L.naggs; ++a) hi |= L.agg_type[a] == DBHIP_T_DEC128 && L.agg_kind[a] != DBHIP_AGG_COUNT;
-  const bool small = L.nkey_words <= 2 && L.nkeys <= 2 && L.naggs <= 2 && !hi;
-  const int R = small ? 8 : 2;
+  const bool small_layout = L.nkey_words <= 2 && L.nkeys <= 2 && L.naggs <= 2 && !hi;
   const int64_t CHUNK = 16 << 20;
-  const int64_t tile_rows = 256 * R;
   int blocks_per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
   if (blocks_per_cu > 4) blocks_per_cu = 4;
   if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -1396,8 +1401,16 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // (almost) nothing the rest of the block is one launch (its spill buffer is sized for the worst
     // case but stays untouched), otherwise bounded chunks keep re-checking the spill ratio.
     int64_t limit = CHUNK;
-    if (!g->fast_trusted && n - *done > (4 << 20)) limit = 1 << 20;
+    // probing chunk: 256 K rows through the 2-rows-per-lane kernel (64 workgroups x 8 tiles of 512 rows: what is to be
+    // learnt is whether the groups fit a workgroup's table, and a workgroup's 8 tiles take a quarter of the time of 8 tiles
+    // of 2048 rows — the probe runs on a quarter of the chip, r02m: 0.16 ms at 4 groups, 0.73 ms at 1000)
+    const bool probing = !g->fast_trusted && n - *done > (4 << 20);
+    if (probing) limit = 1 << 18;
     else if (g->fast_trusted) limit = n;
+    const bool small = small_layout && !probing;
+    static const int small_r = getenv("DBHIP_LDS_R") ? atoi(getenv("DBHIP_LDS_R")) : 4;   // 4 (116 VGPRs, 4 waves / SIMD) or 8 (178, 2): r02n 1.00 vs 1.68 ms at 4 groups
+    const int R = small ? (small_r == 4 ? 4 : 8) : 2;
+    const int64_t tile_rows = 256 * R;
     const int64_t cn = n - *done < limit ? n - *done : limit;
     const int64_t ntiles = ceil_div(cn, tile_rows);
     int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
@@ -1422,7 +1435,8 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap; A.sw = sw;
     A.llimit = (uint32_t)(lcap - lcap / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
-    if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    if (small && R == 4) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 4>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    else if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     DBHIP_LAUNCH_CHECK();
     uint64_t hc[8];
@@ -1481,7 +1495,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
 // Generic over the layout (rows are handled as W words in memory).
 // ---------------------------------------------------------------------------
 constexpr int PT_THREADS = 1024;
-constexpr int PT_R = 8;
+constexpr int PT_R = 4;
 
 __device__ __forceinline__ uint64_t gb_keys_hash(const GbLayout& L, const GbCols& C, int64_t i, uint64_t* ctrl) {
   uint64_t h = 0;
@@ -1497,29 +1511,63 @@ __device__ __forceinline__ uint64_t gb_keys_hash(const GbLayout& L, const GbCols
 
 __device__ __forceinline__ uint32_t part_of(uint64_t h, int pbits) { return (uint32_t)(h >> (64 - pbits)); }
 
-__global__ __launch_bounds__(256) void gb_part_hist_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n, int pbits,
-                                                           uint32_t* hist, uint64_t* ctrl) {
+// hist: workgroup b counts the rows of ITS row range [b * rows_per_wg, ...) per partition (LDS histogram) into
+// mat[b][0..P) — the scatter kernel walks the same ranges, so after the scans below mat[b][p] is the first output row of
+// workgroup b's run inside partition p and the scatter needs no global cursor (one device-scope atomic per (tile, partition)
+// is one per ROW once the partitions outnumber a tile's rows — the cost the partitioning is there to avoid).
+__global__ __launch_bounds__(PT_THREADS) void gb_part_hist_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n, int pbits,
+                                                                  int64_t rows_per_wg, uint32_t* mat, uint64_t* ctrl) {
   extern __shared__ uint32_t pt_lds[];
   const int P = 1 << pbits;
-  for (int s = threadIdx.x; s < P; s += 256) pt_lds[s] = 0;
+  for (int s = threadIdx.x; s < P; s += PT_THREADS) pt_lds[s] = 0;
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t hi = lo + rows_per_wg < n ? lo + rows_per_wg : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += PT_THREADS)
     if (gb_row_passes(C, row0 + i)) atomicAdd(&pt_lds[part_of(gb_keys_hash(L, C, row0 + i, ctrl), pbits)], 1u);
   __syncthreads();
-  for (int s = threadIdx.x; s < P; s += 256) {
-    const uint32_t c = pt_lds[s];
-    if (c) atomicAdd(&hist[s], c);
+  uint32_t* out = mat + (size_t)blockIdx.x * P;
+  for (int s = threadIdx.x; s < P; s += PT_THREADS) out[s] = pt_lds[s];
+}
+
+// One workgroup per 64 partitions, 4 lanes per partition (each a quarter of the nwg workgroup rows of the matrix, loads
+// coalesced over the 64 partitions). FINAL = false: tot[p] = sum over workgroups; FINAL = true: mat[b][p] <- base[p] +
+// sum of mat[b'][p] for b' < b.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void gb_part_colscan_kernel(uint32_t* mat, int P, int nwg, uint32_t* tot, const uint32_t* base) {
+  __shared__ uint32_t seg[4][64];
+  const int pl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + pl;
+  const int per = (nwg + 3) / 4;
+  const int b0 = q * per, b1 = (b0 + per < nwg) ? b0 + per : nwg;
+  uint32_t sum = 0;
+  if (p < P)
+    for (int b = b0; b < b1; ++b) sum += mat[(size_t)b * P + p];
+  seg[q][pl] = sum;
+  __syncthreads();
+  if (!FINAL) {
+    if (q == 0 && p < P) tot[p] = seg[0][pl] + seg[1][pl] + seg[2][pl] + seg[3][pl];
+    return;
+  }
+  if (p >= P) return;
+  uint32_t run = base[p];
+  for (int k = 0; k < q; ++k) run += seg[k][pl];
+  for (int b = b0; b < b1; ++b) {
+    const uint32_t c = mat[(size_t)b * P + p];
+    mat[(size_t)b * P + p] = run;
+    run += c;
   }
 }
 
-// base[0..P] = exclusive scan of hist[0..P), cursor[0..P) = 0   (P <= 8192, one workgroup of 1024, 8 entries per thread)
-__global__ __launch_bounds__(1024) void gb_part_scan_kernel(const uint32_t* hist, int P, uint32_t* base, uint32_t* cursor) {
+// base[0..P] = exclusive scan of hist[0..P)   (P <= 16384, one workgroup of 1024, 16 entries per thread)
+__global__ __launch_bounds__(1024) void gb_part_scan_kernel(const uint32_t* hist, int P, uint32_t* base) {
   __shared__ uint32_t wave_tot[16];
   const int t = threadIdx.x;
-  uint32_t v[8], tsum = 0;
+  constexpr int E = PT_PMAX / 1024;
+  uint32_t v[E], tsum = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    v[k] = (t * 8 + k) < P ? hist[t * 8 + k] : 0;
+  for (int k = 0; k < E; ++k) {
+    v[k] = (t * E + k) < P ? hist[t * E + k] : 0;
     tsum += v[k];
   }
   uint32_t incl = tsum;
@@ -1534,9 +1582,9 @@ __global__ __launch_bounds__(1024) void gb_part_scan_kernel(const uint32_t* hist
   for (int k = 0; k < (t >> 6); ++k) wbase += wave_tot[k];
   uint32_t run = wbase + incl - tsum;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = t * 8 + k;
-    if (i < P) { base[i] = run; cursor[i] = 0; }
+  for (int k = 0; k < E; ++k) {
+    const int i = t * E + k;
+    if (i < P) base[i] = run;
     run += v[k];
     if (i == P - 1) base[P] = run;
   }
@@ -1568,40 +1616,84 @@ __device__ __forceinline__ void gb_serialize_row(const GbLayout& L, const GbCols
   }
 }
 
+// the same image for a row whose hash is known (the keys are loaded again, from the L1, but not hashed again)
+__device__ __forceinline__ void gb_serialize_row_hashed(const GbLayout& L, const GbCols& C, int64_t i, uint64_t h, uint64_t* r) {
+  uint64_t vmask = 0;
+  for (int k = 0; k < L.nkeys; ++k) {
+    uint64_t w[2];
+    bool valid;
+    gb_load_words(C.key[k], i, w, &valid);
+    r[L.key_off[k]] = w[0];
+    if (L.key_words[k] == 2) r[L.key_off[k] + 1] = w[1];
+    if (valid) vmask |= 1ULL << k;
+  }
+  if (L.validity_word >= 0) r[L.validity_word] = vmask;
+  r[L.hash_word] = h;
+  for (int a = 0; a < L.naggs; ++a) {
+    uint64_t w[2] = {0, 0};
+    bool valid = true;
+    if (C.arg[a].data != nullptr) gb_load_words(C.arg[a], i, w, &valid);
+    uint64_t v[GB_MAX_STATE_WORDS];
+    gb_row_contrib(L, a, w[0], w[1], valid, v);
+    for (int k = 0; k < L.agg_words[a]; ++k) r[L.agg_off[a] + k] = v[k];
+  }
+}
+
+// scatter: workgroup b walks the row range it counted in the histogram kernel; lcur[p] (LDS) = next output row of its run in
+// partition p, so a row's place is ONE LDS atomic and there is no global atomic in the loop.
+// STAGED: the rows of a batch (one per thread) are serialized into LDS first and copied out by the whole workgroup, word by
+// word in row order — a row's W words leave as one contiguous piece (and neighbours in a run as one longer piece) instead of
+// W separate 8-byte stores per lane, each its own request to the L1 (r02o: 1.28 ms per 60 M rows at 16 partitions, 3.0 ms at
+// 16384; the kernel was bound by the number of store requests, not by bytes or by the hash).
+template <bool STAGED>
 __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n,
-                                                                     int pbits, const uint32_t* base,
-                                                                     uint32_t* cursor, uint64_t* rows_out,
-                                                                     uint64_t* ctrl) {
+                                                                     int pbits, int64_t rows_per_wg, const uint32_t* mat,
+                                                                     uint64_t* rows_out, uint64_t* ctrl) {
   extern __shared__ uint32_t pt_lds[];
   const int P = 1 << pbits;
-  uint32_t* lcnt = pt_lds;       // rows of this tile per partition, then (in place) the first output row of the tile's run
+  uint32_t* lcur = pt_lds;
   const int tid = threadIdx.x;
-  const int64_t tile_rows = (int64_t)PT_THREADS * PT_R;
-  const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    for (int s = tid; s < P; s += PT_THREADS) lcnt[s] = 0;
-    __syncthreads();
-    uint32_t part[PT_R], rank[PT_R];
+  const uint32_t* mine = mat + (size_t)blockIdx.x * P;
+  for (int s = tid; s < P; s += PT_THREADS) lcur[s] = mine[s];
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t hi = lo + rows_per_wg < n ? lo + rows_per_wg : n;
+  if (!STAGED) {
+    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)PT_THREADS * PT_R) {
 #pragma unroll
-    for (int x = 0; x < PT_R; ++x) {
-      const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
-      part[x] = 0xFFFFFFFFu;
-      rank[x] = 0;
-      if (li < n && gb_row_passes(C, row0 + li)) {
-        part[x] = part_of(gb_keys_hash(L, C, row0 + li, ctrl), pbits);
-        rank[x] = atomicAdd(&lcnt[part[x]], 1u);
+      for (int x = 0; x < PT_R; ++x) {
+        const int64_t li = t0 + (int64_t)x * PT_THREADS + tid;
+        if (li < hi && gb_row_passes(C, row0 + li)) {
+          const uint64_t h = gb_keys_hash(L, C, row0 + li, ctrl);
+          const uint32_t pos = atomicAdd(&lcur[part_of(h, pbits)], 1u);
+          gb_serialize_row_hashed(L, C, row0 + li, h, rows_out + (uint64_t)pos * L.W);
+        }
       }
     }
-    __syncthreads();
-    for (int s = tid; s < P; s += PT_THREADS) {
-      const uint32_t c = lcnt[s];
-      lcnt[s] = c ? base[s] + atomicAdd(&cursor[s], c) : 0;
+    return;
+  }
+  const int SW = L.W | 1;                                      // odd stride in 8-byte words: conflict-free rows
+  uint32_t* gpos = pt_lds + P;                                 // [PT_THREADS] output row of the staged row, ~0 = none
+  uint64_t* stage = (uint64_t*)(pt_lds + P + PT_THREADS);      // [PT_THREADS][SW]   (P and PT_THREADS are even: 8-byte aligned)
+  int wshift = 0;
+  while ((1 << wshift) < L.W) ++wshift;                         // copy-out: 2^wshift lanes per row, lanes >= W idle
+  const int k = tid & ((1 << wshift) - 1), rsub = tid >> wshift;
+  const int rows_per_it = PT_THREADS >> wshift;
+  for (int64_t t0 = lo; t0 < hi; t0 += PT_THREADS) {
+    const int64_t li = t0 + tid;
+    uint32_t pos = 0xFFFFFFFFu;
+    if (li < hi && gb_row_passes(C, row0 + li)) {
+      const uint64_t h = gb_keys_hash(L, C, row0 + li, ctrl);
+      pos = atomicAdd(&lcur[part_of(h, pbits)], 1u);
+      gb_serialize_row_hashed(L, C, row0 + li, h, stage + (size_t)tid * SW);
     }
+    gpos[tid] = pos;
     __syncthreads();
-#pragma unroll
-    for (int x = 0; x < PT_R; ++x) {
-      const int64_t li = t * tile_rows + (int64_t)x * PT_THREADS + tid;
-      if (part[x] != 0xFFFFFFFFu) gb_serialize_row(L, C, row0 + li, rows_out + (uint64_t)(lcnt[part[x]] + rank[x]) * L.W, ctrl);
+    if (k < L.W) {
+      for (int r = rsub; r < PT_THREADS; r += rows_per_it) {
+        const uint32_t g = gpos[r];
+        if (g != 0xFFFFFFFFu) rows_out[(uint64_t)g * L.W + k] = stage[(size_t)r * SW + k];
+      }
     }
     __syncthreads();
   }
@@ -1617,6 +1709,8 @@ struct PaArgs {
   uint64_t* partial;       // [gridDim.x * lcap][W]
   uint32_t* spill_idx;     // row indices (into rows) that did not fit
   uint64_t* ctrl;          // [5] = #partial rows, [6] = #spilled rows
+  uint32_t* pcount;        // non-NULL: workgroup b keeps its partial rows at partial[b * lcap ...] and their number here
+                           // (the partition-exclusive merge below reads them per partition); NULL: one packed list
 };
 
 constexpr int PA_R = 4;
@@ -1708,11 +1802,24 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
     // no barrier: the next tile only adds NEW slots (see gb_lds_preagg_kernel)
   }
   __syncthreads();
+  const uint32_t occupied = lcount;
+  __syncthreads();
+  if (tid == 0) {
+    lcount = 0;
+    if (A.pcount) {
+      A.pcount[blockIdx.x] = occupied;
+      if (occupied) atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)occupied);
+    }
+  }
+  __syncthreads();
   for (int s = tid; s < A.lcap; s += 256) {  // lcap is a multiple of 256: wave-uniform
     const bool occ = lhash[s] != 0;
     const uint64_t m = __ballot(occ);
     unsigned long long base = 0;
-    if (m && lane_id() == 0) base = atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)__popcll(m));
+    if (m && lane_id() == 0) {
+      if (A.pcount) base = (unsigned long long)blockIdx.x * A.lcap + atomicAdd(&lcount, (uint32_t)__popcll(m));
+      else base = atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)__popcll(m));
+    }
     base = __shfl(base, 0, 64);
     if (occ) {
       const unsigned long long idx = base + __popcll(m & ((1ULL << lane_id()) - 1));
@@ -1733,6 +1840,196 @@ __global__ __launch_bounds__(256) void gb_gather_rows_kernel(const uint64_t* row
 }
 
 // LDS table geometry of the partition-aggregate kernel for this layout (0 slots = layout too wide)
+// Partition-exclusive merge of the aggregation kernel's partial rows into the HBM table.
+//
+// The partition of a row is the TOP `pbits` bits of its hash and so is the top of its home slot (home_slot): partition p's
+// groups start their probe inside slice p = slots [p * cap / P, (p + 1) * cap / P) of the table. One workgroup per
+// partition: it alone inserts into and updates groups of its slice during this launch, so the states are merged with plain
+// loads and stores — no device-scope atomic per state word, which is what bounds the row path (two fabric atomics per
+// row: 17 ms per 60 M rows at 10^7 groups). Only the claim of an empty slot is an atomic (its neighbours may race for the
+// same slot). A probe that would leave the slice (chains of the row path may cross a boundary) and a partial row whose
+// slot holds other keys (a 64-bit hash collision) are listed in `retry` and go through the row path afterwards.
+// Claim, barrier, then verify and merge: a claimed slot's keys are written before the barrier.
+struct PmArgs {
+  const uint64_t* partial;   // [P * lcap][W]
+  const uint32_t* pcount;    // [P]
+  int lcap, pbits;
+  uint64_t* slot_hash;
+  uint64_t* rows;
+  int64_t cap;
+  uint64_t hash_mask;
+  uint32_t* retry;           // partial-row indices for the row path
+  uint64_t* ctrl;            // [0] += new groups, [2] += listed rows
+};
+
+__global__ __launch_bounds__(256) void gb_part_merge_kernel(GbLayout L, PmArgs A) {
+  extern __shared__ uint32_t pm_slot[];   // [lcap]
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  const uint32_t n = A.pcount[p];
+  if (n == 0) return;
+  const uint64_t* src = A.partial + (size_t)p * A.lcap * L.W;
+  const uint64_t slice = (uint64_t)A.cap >> A.pbits;
+  const uint64_t hi = ((uint64_t)p + 1) * slice;
+  const uint32_t n_pad = (n + 63) & ~63u;
+  for (uint32_t i = tid; i < n_pad; i += 256) {
+    bool claimed = false;
+    if (i < n) {
+      const uint64_t* r = src + (size_t)i * L.W;
+      const uint64_t hw = probe_word(r[L.hash_word], A.hash_mask);
+      uint64_t pos = home_slot(hw, A.cap);
+      uint32_t found = GB_INVALID_SLOT;
+      for (; pos < hi; ++pos) {
+        // workgroup scope: the slice has no other reader or writer during this launch, and a device-scope atomic is a trip
+        // through the fabric (the L2s of the eight XCDs are not coherent with each other) — r02n: 3.4 ms per 4.7 M rows
+        unsigned long long cur = __hip_atomic_load((unsigned long long*)&A.slot_hash[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == 0) {
+          unsigned long long old = 0ULL;
+          __hip_atomic_compare_exchange_strong((unsigned long long*)&A.slot_hash[pos], &old, (unsigned long long)hw, __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (old == 0) {
+            uint64_t* d = A.rows + pos * L.W;
+            for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
+            d[L.hash_word] = r[L.hash_word];
+            for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
+            claimed = true;
+            found = (uint32_t)pos;
+            break;
+          }
+          cur = old;
+        }
+        if (cur == hw) { found = (uint32_t)pos; break; }
+      }
+      pm_slot[i] = found;
+    }
+    const uint64_t m = __ballot(claimed);
+    if (m && lane_id() == 0) atomicAdd((unsigned long long*)&A.ctrl[0], (unsigned long long)__popcll(m));
+  }
+  __syncthreads();   // (a workgroup barrier orders this workgroup's global stores before its later loads: one CU, one L1)
+  for (uint32_t i = tid; i < n_pad; i += 256) {
+    bool listed = false;
+    if (i < n) {
+      const uint64_t* r = src + (size_t)i * L.W;
+      const uint32_t pos = pm_slot[i];
+      listed = pos == GB_INVALID_SLOT;
+      if (!listed) {
+        uint64_t* d = A.rows + (uint64_t)pos * L.W;
+        bool eq = true;
+        for (int k = 0; k < L.nkey_words; ++k) eq &= (d[k] == r[k]);
+        if (eq) {
+          for (int a = 0; a < L.naggs; ++a) gb_plain_merge(L, a, d + L.agg_off[a], r + L.agg_off[a]);
+        } else {
+          listed = true;
+        }
+      }
+    }
+    const uint64_t m = __ballot(listed);
+    if (m) {
+      unsigned long long base = 0;
+      if (lane_id() == 0) base = atomicAdd((unsigned long long*)&A.ctrl[2], (unsigned long long)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (listed) A.retry[base + __popcll(m & ((1ULL << lane_id()) - 1))] = (uint32_t)((size_t)p * A.lcap + i);
+    }
+  }
+}
+
+// Partition-exclusive INSERT: the same ownership as gb_part_merge_kernel, applied to the partition's input rows themselves —
+// for key distributions where a partition's groups do not fit an LDS table (about as many groups as rows: nothing to
+// pre-aggregate). Workgroup p walks its rows [base[p], base[p+1]) in tiles: phase A finds or claims each row's slot in
+// slice p (workgroup-scope CAS), barrier, phase B verifies the keys and merges the state contribution with workgroup-scope
+// atomics (several rows of a tile may belong to one group). Rows that leave the slice or meet other keys under their hash are
+// listed for the row path.
+struct PiArgs {
+  const uint64_t* rows;    // [n][W] grouped by partition
+  const uint32_t* base;    // [P+1]
+  int pbits;
+  uint64_t* slot_hash;
+  uint64_t* table;
+  int64_t cap;
+  uint64_t hash_mask;
+  uint32_t* spill_idx;     // rows (indices into `rows`) for the row path
+  uint64_t* ctrl;          // [0] += new groups, [6] += listed rows
+};
+constexpr int PI_R = 4;
+
+__global__ __launch_bounds__(256) void gb_part_insert_kernel(GbLayout L, PiArgs A) {
+  __shared__ uint32_t wg_new;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x;
+  const uint32_t r_begin = A.base[p], r_end = A.base[p + 1];
+  if (r_begin >= r_end) return;
+  if (tid == 0) wg_new = 0;
+  const uint64_t slice = (uint64_t)A.cap >> A.pbits;
+  const uint64_t hi = ((uint64_t)p + 1) * slice;
+  uint32_t my_new = 0;
+  for (uint32_t t0 = r_begin; t0 < r_end; t0 += 256 * PI_R) {
+    uint32_t slot[PI_R];
+    uint64_t hs[PI_R];
+#pragma unroll
+    for (int x = 0; x < PI_R; ++x) {
+      const uint32_t ri = t0 + x * 256 + tid;
+      hs[x] = ri < r_end ? A.rows[(uint64_t)ri * L.W + L.hash_word] : 0;
+    }
+#pragma unroll
+    for (int x = 0; x < PI_R; ++x) {
+      const uint32_t ri = t0 + x * 256 + tid;
+      slot[x] = GB_INVALID_SLOT - 1;   // padding
+      if (ri < r_end) {
+        const uint64_t* r = A.rows + (uint64_t)ri * L.W;
+        const uint64_t hw = probe_word(hs[x], A.hash_mask);
+        slot[x] = GB_INVALID_SLOT;
+        for (uint64_t pos = home_slot(hw, A.cap); pos < hi; ++pos) {
+          unsigned long long cur = __hip_atomic_load((unsigned long long*)&A.slot_hash[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cur == 0) {
+            unsigned long long old = 0ULL;
+            __hip_atomic_compare_exchange_strong((unsigned long long*)&A.slot_hash[pos], &old, (unsigned long long)hw, __ATOMIC_RELAXED,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 0) {
+              uint64_t* d = A.table + pos * L.W;
+              for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
+              d[L.hash_word] = hs[x];
+              for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
+              ++my_new;
+              slot[x] = (uint32_t)pos;
+              break;
+            }
+            cur = old;
+          }
+          if (cur == hw) { slot[x] = (uint32_t)pos; break; }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < PI_R; ++x) {
+      const uint32_t ri = t0 + x * 256 + tid;
+      bool listed = slot[x] == GB_INVALID_SLOT;
+      if (slot[x] < GB_INVALID_SLOT - 1) {
+        const uint64_t* r = A.rows + (uint64_t)ri * L.W;
+        uint64_t* d = A.table + (uint64_t)slot[x] * L.W;
+        bool eq = true;
+        for (int k = 0; k < L.nkey_words; ++k) eq &= (d[k] == r[k]);
+        if (eq) {
+          for (int a = 0; a < L.naggs; ++a) gb_wg_merge(L, a, d + L.agg_off[a], r + L.agg_off[a]);
+        } else {
+          listed = true;
+        }
+      }
+      const uint64_t m = __ballot(listed);
+      if (m) {
+        unsigned long long sb = 0;
+        if (lane_id() == 0) sb = atomicAdd((unsigned long long*)&A.ctrl[6], (unsigned long long)__popcll(m));
+        sb = __shfl(sb, 0, 64);
+        if (listed) A.spill_idx[sb + __popcll(m & ((1ULL << lane_id()) - 1))] = ri;
+      }
+    }
+    // no barrier: the next tile's claims touch other slots' keys only; keys of slots matched above never change
+  }
+  if (my_new) atomicAdd(&wg_new, my_new);
+  __syncthreads();
+  if (tid == 0 && wg_new) atomicAdd((unsigned long long*)&A.ctrl[0], (unsigned long long)wg_new);
+}
+
 void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
   *sw = L.W | 1;
   int c = 0;
@@ -1753,18 +2050,36 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
   const int P = 1 << pbits;
   int32_t rc;
   if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
-  if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, (size_t)(3 * PT_PMAX + 8) * 4))) return rc;
-  uint32_t* hist = g->part_meta;
+  // workgroups of the histogram / scatter pair: contiguous row ranges, at least 8192 rows each, at most two per CU
+  int64_t nwg = ceil_div(cn, (int64_t)8192);
+  if (nwg > 512) nwg = 512;
+  const int64_t rows_per_wg = ceil_div(cn, nwg);
+  nwg = ceil_div(cn, rows_per_wg);
+  if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, ((size_t)(3 * PT_PMAX + 8) + (size_t)nwg * P) * 4))) return rc;
+  uint32_t* tot = g->part_meta;
   uint32_t* base = g->part_meta + PT_PMAX;
-  uint32_t* cursor = g->part_meta + 2 * PT_PMAX + 8;
-  DBHIP_CHECK(hipMemsetAsync(hist, 0, (size_t)P * 4, s));
-  hipLaunchKernelGGL(gb_part_hist_kernel, dim3(grid_for(cn, 256)), dim3(256), (size_t)P * 4, s, L, C, row0, cn, pbits,
-                     hist, g->ctrl);
-  hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, hist, P, base, cursor);
-  const int64_t ntiles = ceil_div(cn, (int64_t)PT_THREADS * PT_R);
-  const int sgrid = (int)(ntiles < 512 ? ntiles : 512);
-  hipLaunchKernelGGL(gb_part_scatter_kernel, dim3(sgrid), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
-                     base, cursor, g->rows_in, g->ctrl);
+  uint32_t* mat = g->part_meta + 3 * PT_PMAX + 8;
+  hipLaunchKernelGGL(gb_part_hist_kernel, dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
+                     rows_per_wg, mat, g->ctrl);
+  hipLaunchKernelGGL((gb_part_colscan_kernel<false>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
+  hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, tot, P, base);
+  hipLaunchKernelGGL((gb_part_colscan_kernel<true>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
+  // staged copy-out while a batch of rows fits the LDS beside the cursors (W <= 11 words); else lanes store their rows themselves
+  static const bool no_stage = getenv("DBHIP_GB_NOSTAGE") != nullptr;
+  const size_t stage_bytes = (size_t)PT_THREADS * 4 + (size_t)PT_THREADS * (L.W | 1) * 8;
+  if (!no_stage && (size_t)P * 4 + stage_bytes > 64 * 1024 && (size_t)P * 4 + stage_bytes <= 112 * 1024) {
+    static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+    if (!raised) {
+      DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_part_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+      raised = true;
+    }
+  }
+  if (!no_stage && (size_t)P * 4 + stage_bytes <= 112 * 1024)
+    hipLaunchKernelGGL((gb_part_scatter_kernel<true>), dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4 + stage_bytes, s, L, C, row0, cn,
+                       pbits, rows_per_wg, mat, g->rows_in, g->ctrl);
+  else
+    hipLaunchKernelGGL((gb_part_scatter_kernel<false>), dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
+                       rows_per_wg, mat, g->rows_in, g->ctrl);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
@@ -1781,20 +2096,70 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   if ((rc = partition_scatter(g, C, row0, cn, pbits, s))) return rc;
   if ((rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
   uint32_t* base = g->part_meta + PT_PMAX;
+  if (g->part_direct && g->hash_mask == ~0ULL) {
+    // room: every row of the chunk may be a new group, but a table for 64 M new groups that then holds 10 M is a waste the
+    // flush pays for — size for the groups the rows seen so far predict (at least twice the chunk's share of them), and let
+    // a slice that runs full hand its rows to the row path, which grows the table for good
+    int64_t expect = cn;
+    if (g->rows_seen >= (4 << 20)) {
+      const int64_t est = estimate_groups(g->count_host, g->rows_seen);
+      const int64_t more = est > g->count_host ? est - g->count_host : 0;
+      if (more * 2 + (1 << 20) < expect) expect = more * 2 + (1 << 20);
+    }
+    while ((g->count_host + expect) * 135 > g->cap * 100 || g->cap < (int64_t)P * 64)
+      if ((rc = grow(g, s))) return rc;
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
+    PiArgs I;
+    I.rows = g->rows_in; I.base = base; I.pbits = pbits; I.slot_hash = g->slot_hash; I.table = g->rows; I.cap = g->cap;
+    I.hash_mask = g->hash_mask; I.spill_idx = g->spill_idx; I.ctrl = g->ctrl;
+    hipLaunchKernelGGL(gb_part_insert_kernel, dim3(P), dim3(256), 0, s, L, I);
+    DBHIP_LAUNCH_CHECK();
+    uint64_t* hc = pinned_words(0);
+    if (!hc) return DBHIP_ERR_HIP;
+    DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    if (hc[3] & 2) {
+      DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+      g->has_long = 1; g->fast_disabled = 1;
+      *spilled = -1;
+      return DBHIP_OK;
+    }
+    g->count_host = (int64_t)hc[0];
+    const int64_t nlist = (int64_t)hc[6];
+    if (nlist > 0) {
+      if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)nlist * L.W * 8))) return rc;
+      hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nlist, 256)), dim3(256), 0, s, g->rows_in, g->spill_idx,
+                         nlist, L.W, g->spill_rows);
+      DBHIP_LAUNCH_CHECK();
+      if ((rc = merge_rows(g, g->spill_rows, nlist, s))) return rc;
+    }
+    if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby partitioned insert: rows=%lld listed=%lld groups=%lld cap=%lld\n",
+                                       (long long)cn, (long long)nlist, (long long)g->count_host, (long long)g->cap);
+    *spilled = 0;   // (listed rows are no sign of a partitioning that is too coarse)
+    return DBHIP_OK;
+  }
   // workgroups per partition: fill the chip (>= ~1024 workgroups) without making splits tiny
   int splits = 1;
   while (P * splits < 1024 && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
   const int agrid = P * splits;
   if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)agrid * lcap * L.W * 8))) return rc;
+  // one workgroup per partition and a table at least as fine as the partitioning: the partial rows stay per partition and
+  // are merged by the partition's own workgroup (gb_part_merge_kernel); otherwise one packed list for the row path
+  static const bool no_excl = getenv("DBHIP_GB_NOEXCL") != nullptr;
+  const bool exclusive = splits == 1 && !no_excl && g->hash_mask == ~0ULL;
+  uint32_t* pcount = g->part_meta + 2 * PT_PMAX + 8;
+  if (exclusive) DBHIP_CHECK(hipMemsetAsync(pcount, 0, (size_t)P * 4, s));
   DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
   PaArgs A;
   A.rows = g->rows_in; A.base = base; A.splits = splits; A.lcap = lcap; A.sw = sw;
   A.llimit = (uint32_t)(lcap - lcap / 4);
   A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill_idx = g->spill_idx; A.ctrl = g->ctrl;
+  A.pcount = exclusive ? pcount : nullptr;
   hipLaunchKernelGGL(gb_part_agg_kernel, dim3(agrid), dim3(256), lds_bytes, s, L, A);
   DBHIP_LAUNCH_CHECK();
-  uint64_t hc[8];
-  DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, sizeof(hc), hipMemcpyDeviceToHost, s));
+  uint64_t* hc = pinned_words(0);
+  if (!hc) return DBHIP_ERR_HIP;
+  DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
   if (hc[3] & 2) {  // a long string key: this chunk goes to the row path (nothing was merged yet), see add_block_fast
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
@@ -1803,15 +2168,40 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     return DBHIP_OK;
   }
   const int64_t nspill = (int64_t)hc[6];
-  if (nspill > 0) {
-    // compact the listed rows BEFORE merge_rows may touch its own scratch
-    if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)nspill * L.W * 8))) return rc;
-    hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nspill, 256)), dim3(256), 0, s, g->rows_in, g->spill_idx,
-                       nspill, L.W, g->spill_rows);
+  const int64_t npartial = (int64_t)hc[5];
+  int64_t nlisted = 0;
+  if (exclusive && npartial > 0) {
+    // every partial row may be a new group: make room first (the slices move with the capacity, the kernel takes it as it is)
+    while ((g->count_host + npartial) * 135 > g->cap * 100 || g->cap < (int64_t)P * 64)
+      if ((rc = grow(g, s))) return rc;
+    if ((rc = ensure((void**)&g->retry, &g->retry_cap, (size_t)npartial * 4))) return rc;
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[2], 0, 8, s));
+    PmArgs M;
+    M.partial = g->partial; M.pcount = pcount; M.lcap = lcap; M.pbits = pbits;
+    M.slot_hash = g->slot_hash; M.rows = g->rows; M.cap = g->cap; M.hash_mask = g->hash_mask;
+    M.retry = g->retry; M.ctrl = g->ctrl;
+    hipLaunchKernelGGL(gb_part_merge_kernel, dim3(P), dim3(256), (size_t)lcap * 4, s, L, M);
+    DBHIP_LAUNCH_CHECK();
+    DBHIP_CHECK(hipMemcpyAsync(hc, g->ctrl, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    g->count_host = (int64_t)hc[0];
+    nlisted = (int64_t)hc[2];
+  }
+  if (nspill + nlisted > 0) {
+    // compact the listed rows BEFORE merge_rows may touch its own scratch (g->retry is part of it)
+    if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)(nspill + nlisted) * L.W * 8))) return rc;
+    if (nspill > 0)
+      hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nspill, 256)), dim3(256), 0, s, g->rows_in, g->spill_idx,
+                         nspill, L.W, g->spill_rows);
+    if (nlisted > 0)
+      hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nlisted, 256)), dim3(256), 0, s, g->partial, g->retry,
+                         nlisted, L.W, g->spill_rows + (size_t)nspill * L.W);
     DBHIP_LAUNCH_CHECK();
   }
-  if ((rc = merge_rows(g, g->partial, (int64_t)hc[5], s))) return rc;
-  if (nspill > 0 && (rc = merge_rows(g, g->spill_rows, nspill, s))) return rc;
+  if (!exclusive && (rc = merge_rows(g, g->partial, npartial, s))) return rc;
+  if (nspill + nlisted > 0 && (rc = merge_rows(g, g->spill_rows, nspill + nlisted, s))) return rc;
+  if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby partitioned merge: exclusive=%d partial=%lld listed=%lld spilled=%lld cap=%lld\n",
+                                     (int)exclusive, (long long)npartial, (long long)nlisted, (long long)nspill, (long long)g->cap);
   *spilled = nspill;
   return DBHIP_OK;
 }
@@ -1848,11 +2238,21 @@ void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, in
   if (lcap == 0 || g->part_forbidden) return;
   const int64_t est = estimate_groups(groups, rows_seen);
   const int64_t total = n_block > rows_seen ? n_block : rows_seen;
-  if (est > total / 8) return;  // (nearly) every row its own group: pre-aggregation buys nothing
   const int64_t per_part = lcap * 3 / 8;  // target groups per partition: half of the LDS table's limit
   int bits = 4;
   while (bits < PT_MAX_BITS && ((int64_t)per_part << bits) < est) ++bits;
-  if (((int64_t)per_part << bits) < est) return;
+  g->part_chunk = 0;
+  g->part_direct = 0;
+  if (((int64_t)per_part << bits) < est || est > total / 3) {
+    // more groups than the finest partitioning's LDS tables hold, or fewer than ~3 rows per group (up to: every row its own
+    // group): nothing to pre-aggregate — the partition's workgroup inserts its rows straight into its slice of the table
+    // (gb_part_insert_kernel). First a 16 M-row chunk, whose group count sizes the table for the rest.
+    static const bool no_direct = getenv("DBHIP_GB_NODIRECT") != nullptr;
+    if (no_direct) { g->part_bits = -1; return; }
+    bits = PT_MAX_BITS;
+    g->part_direct = 1;
+    g->part_chunk = 16 << 20;
+  }
   g->part_bits = bits;
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in the first %lld rows -> ~%lld groups in %lld rows, %d partition bits\n",
                                      (long long)groups, (long long)rows_seen, (long long)est, (long long)total, bits);
