@@ -61,6 +61,7 @@ struct dbhip_groupby {
   int64_t part_min_rows;                   // smallest chunk worth partitioning
   int64_t part_chunk;                      // rows per partitioned chunk (0 = PT_CHUNK)
   int part_direct;                         // partitioned rows are inserted straight into their table slice (no LDS pre-aggregation)
+  int part_adapt;                          // the chunk size follows the group estimate (more groups than one chunk's LDS tables hold)
   int64_t rows_seen;                       // input rows of add_block so far (cardinality estimate)
   uint32_t* part_meta; size_t part_meta_cap;   // tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
   uint32_t* spill_idx; size_t spill_idx_cap;
@@ -1323,8 +1324,35 @@ constexpr int PT_MAX_BITS = 14;
 constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
 void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block);
 int64_t estimate_groups(int64_t d, int64_t s);
+void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes);
 int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s);
 constexpr int64_t PT_CHUNK = 64 << 20;
+
+// After a chunk of the adaptive mode: D = groups the whole input is likely to hold (from the groups met in the rows seen so
+// far). The next chunk takes as many rows as keep a partition's groups inside its LDS table — c rows drawn from D equally
+// likely groups meet D (1 - exp(-c / D)) of them, wanted <= G = P x 0.6 x lcap — because every partial row costs a random
+// access into the table (~6 G rows/s, r02o/r02p) and a group should cost one of those per chunk, not one per row. Fewer
+// than 1.5 rows per group: nothing to pre-aggregate, the rows are inserted directly (gb_part_insert_kernel).
+void adapt_chunk(dbhip_groupby* g, int64_t n_block) {
+  int lcap, sw;
+  size_t lds_bytes;
+  part_geometry(g->L, &lcap, &sw, &lds_bytes);
+  const double G = (double)((int64_t)1 << g->part_bits) * 0.6 * lcap;
+  const int64_t est = estimate_groups(g->count_host, g->rows_seen);
+  const double D = (double)est;
+  const int64_t total = n_block > g->rows_seen ? n_block : g->rows_seen;
+  double c = (double)PT_CHUNK;
+  if (D > 64.0 * G) c = G;
+  else if (D > G) c = -D * log(1.0 - G / D);
+  if (c < (double)(1 << 20)) c = (double)(1 << 20);
+  if (c > (double)PT_CHUNK) c = (double)PT_CHUNK;
+  g->part_chunk = (int64_t)c;
+  g->part_direct = D * 1.5 > (double)total ? 1 : 0;
+  if (g->part_direct) g->part_chunk = PT_CHUNK;
+  if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby adaptive: %lld groups in %lld rows -> ~%lld groups, next chunk %lld rows%s\n",
+                                     (long long)g->count_host, (long long)g->rows_seen, (long long)est, (long long)g->part_chunk,
+                                     g->part_direct ? " (direct insert)" : "");
+}
 
 // one partitioned chunk starting at *done; widens the partitioning (or gives it up) when too many rows spilled
 int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t s, int64_t* done) {
@@ -1338,7 +1366,7 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
                                      (long long)cn, g->part_bits, (long long)spilled, (long long)g->count_host);
   *done += cn;
   g->rows_seen += cn;
-  if (g->part_direct) { g->part_chunk = 0; return DBHIP_OK; }
+  if (g->part_adapt) { adapt_chunk(g, n); return DBHIP_OK; }
   if (spilled * 20 > cn) {
     if (g->part_bits + 2 <= PT_MAX_BITS) g->part_bits += 2;
     else if (g->part_bits < PT_MAX_BITS) g->part_bits = PT_MAX_BITS;
@@ -1511,6 +1539,67 @@ __device__ __forceinline__ uint64_t gb_keys_hash(const GbLayout& L, const GbCols
 
 __device__ __forceinline__ uint32_t part_of(uint64_t h, int pbits) { return (uint32_t)(h >> (64 - pbits)); }
 
+// group hashes of R rows, column by column (gb_load_words_n: the R loads of a column are in flight together and the
+// layout is decoded once per column, not once per row)
+template <int R>
+__device__ __forceinline__ void gb_keys_hash_n(const GbLayout& L, const GbCols& C, const int64_t (&row)[R], uint64_t (&h)[R], uint64_t* ctrl) {
+#pragma unroll
+  for (int x = 0; x < R; ++x) h[x] = 0;
+  for (int k = 0; k < L.nkeys; ++k) {
+    uint64_t w0[R], w1[R];
+    bool valid[R];
+    if (!gb_load_words_n<R>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+    const int type = L.key_type[k];
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      const uint64_t w[2] = {w0[x], w1[x]};
+      const uint64_t hk = gb_hash_words(type, w, valid[x]);
+      h[x] = (k == 0) ? hk : merge_hash(h[x], hk);
+    }
+  }
+}
+// serialized images (gb_serialize_row) of R rows whose hashes are known, written to out[x] — column by column
+template <int R>
+__device__ __forceinline__ void gb_serialize_rows_n(const GbLayout& L, const GbCols& C, const int64_t (&row)[R], const uint64_t (&h)[R],
+                                                    uint64_t* const (&out)[R]) {
+  uint64_t vmask[R];
+#pragma unroll
+  for (int x = 0; x < R; ++x) vmask[x] = 0;
+  for (int k = 0; k < L.nkeys; ++k) {
+    uint64_t w0[R], w1[R];
+    bool valid[R];
+    gb_load_words_n<R>(C.key[k], row, w0, w1, valid);
+    const int off = L.key_off[k];
+    const bool two = L.key_words[k] == 2;
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      out[x][off] = w0[x];
+      if (two) out[x][off + 1] = w1[x];
+      if (valid[x]) vmask[x] |= 1ULL << k;
+    }
+  }
+  if (L.validity_word >= 0) {
+#pragma unroll
+    for (int x = 0; x < R; ++x) out[x][L.validity_word] = vmask[x];
+  }
+#pragma unroll
+  for (int x = 0; x < R; ++x) out[x][L.hash_word] = h[x];
+  for (int a = 0; a < L.naggs; ++a) {
+    uint64_t w0[R], w1[R];
+    bool valid[R];
+#pragma unroll
+    for (int x = 0; x < R; ++x) { w0[x] = 0; w1[x] = 0; valid[x] = true; }
+    if (C.arg[a].data != nullptr) gb_load_words_n<R>(C.arg[a], row, w0, w1, valid);
+    const int off = L.agg_off[a], nw = L.agg_words[a];
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      uint64_t v[GB_MAX_STATE_WORDS];
+      gb_row_contrib(L, a, w0[x], w1[x], valid[x], v);
+      for (int k = 0; k < nw; ++k) out[x][off + k] = v[k];
+    }
+  }
+}
+
 // hist: workgroup b counts the rows of ITS row range [b * rows_per_wg, ...) per partition (LDS histogram) into
 // mat[b][0..P) — the scatter kernel walks the same ranges, so after the scans below mat[b][p] is the first output row of
 // workgroup b's run inside partition p and the scatter needs no global cursor (one device-scope atomic per (tile, partition)
@@ -1523,8 +1612,21 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_hist_kernel(GbLayout L, Gb
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t hi = lo + rows_per_wg < n ? lo + rows_per_wg : n;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += PT_THREADS)
-    if (gb_row_passes(C, row0 + i)) atomicAdd(&pt_lds[part_of(gb_keys_hash(L, C, row0 + i, ctrl), pbits)], 1u);
+  for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)PT_THREADS * PT_R) {
+    int64_t row[PT_R];
+    bool in[PT_R];
+    uint64_t h[PT_R];
+#pragma unroll
+    for (int x = 0; x < PT_R; ++x) {
+      const int64_t li = t0 + (int64_t)x * PT_THREADS + threadIdx.x;
+      in[x] = li < hi;
+      row[x] = row0 + (in[x] ? li : lo);
+    }
+    gb_keys_hash_n<PT_R>(L, C, row, h, ctrl);
+#pragma unroll
+    for (int x = 0; x < PT_R; ++x)
+      if (in[x] && gb_row_passes(C, row[x])) atomicAdd(&pt_lds[part_of(h[x], pbits)], 1u);
+  }
   __syncthreads();
   uint32_t* out = mat + (size_t)blockIdx.x * P;
   for (int s = threadIdx.x; s < P; s += PT_THREADS) out[s] = pt_lds[s];
@@ -1645,7 +1747,7 @@ __device__ __forceinline__ void gb_serialize_row_hashed(const GbLayout& L, const
 // word in row order — a row's W words leave as one contiguous piece (and neighbours in a run as one longer piece) instead of
 // W separate 8-byte stores per lane, each its own request to the L1 (r02o: 1.28 ms per 60 M rows at 16 partitions, 3.0 ms at
 // 16384; the kernel was bound by the number of store requests, not by bytes or by the hash).
-template <bool STAGED>
+template <int PS_R>   // rows per thread of a staged batch; 0 = not staged
 __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L, GbCols C, int64_t row0, int64_t n,
                                                                      int pbits, int64_t rows_per_wg, const uint32_t* mat,
                                                                      uint64_t* rows_out, uint64_t* ctrl) {
@@ -1658,7 +1760,7 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t hi = lo + rows_per_wg < n ? lo + rows_per_wg : n;
-  if (!STAGED) {
+  if (PS_R == 0) {
     for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)PT_THREADS * PT_R) {
 #pragma unroll
       for (int x = 0; x < PT_R; ++x) {
@@ -1673,24 +1775,37 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
     return;
   }
   const int SW = L.W | 1;                                      // odd stride in 8-byte words: conflict-free rows
-  uint32_t* gpos = pt_lds + P;                                 // [PT_THREADS] output row of the staged row, ~0 = none
-  uint64_t* stage = (uint64_t*)(pt_lds + P + PT_THREADS);      // [PT_THREADS][SW]   (P and PT_THREADS are even: 8-byte aligned)
+  constexpr int SR = PS_R > 0 ? PS_R : 1;
+  constexpr int BR = PT_THREADS * SR;                          // rows of a batch
+  uint32_t* gpos = pt_lds + P;                                 // [BR] output row of the staged row, ~0 = none
+  uint64_t* stage = (uint64_t*)(pt_lds + P + BR);              // [BR][SW]   (P and BR are even: 8-byte aligned)
   int wshift = 0;
   while ((1 << wshift) < L.W) ++wshift;                         // copy-out: 2^wshift lanes per row, lanes >= W idle
   const int k = tid & ((1 << wshift) - 1), rsub = tid >> wshift;
   const int rows_per_it = PT_THREADS >> wshift;
-  for (int64_t t0 = lo; t0 < hi; t0 += PT_THREADS) {
-    const int64_t li = t0 + tid;
-    uint32_t pos = 0xFFFFFFFFu;
-    if (li < hi && gb_row_passes(C, row0 + li)) {
-      const uint64_t h = gb_keys_hash(L, C, row0 + li, ctrl);
-      pos = atomicAdd(&lcur[part_of(h, pbits)], 1u);
-      gb_serialize_row_hashed(L, C, row0 + li, h, stage + (size_t)tid * SW);
+  for (int64_t t0 = lo; t0 < hi; t0 += BR) {
+    int64_t row[SR];
+    bool in[SR];
+    uint64_t h[SR];
+    uint64_t* out[SR];
+#pragma unroll
+    for (int x = 0; x < SR; ++x) {
+      const int64_t li = t0 + (int64_t)x * PT_THREADS + tid;
+      in[x] = li < hi;
+      row[x] = row0 + (in[x] ? li : lo);
+      out[x] = stage + (size_t)(x * PT_THREADS + tid) * SW;
     }
-    gpos[tid] = pos;
+    gb_keys_hash_n<SR>(L, C, row, h, ctrl);
+#pragma unroll
+    for (int x = 0; x < SR; ++x) {
+      uint32_t pos = 0xFFFFFFFFu;
+      if (in[x] && gb_row_passes(C, row[x])) pos = atomicAdd(&lcur[part_of(h[x], pbits)], 1u);
+      gpos[x * PT_THREADS + tid] = pos;
+    }
+    gb_serialize_rows_n<SR>(L, C, row, h, out);   // (rows that do not take part fill their own staging row and stay there)
     __syncthreads();
     if (k < L.W) {
-      for (int r = rsub; r < PT_THREADS; r += rows_per_it) {
+      for (int r = rsub; r < BR; r += rows_per_it) {
         const uint32_t g = gpos[r];
         if (g != 0xFFFFFFFFu) rows_out[(uint64_t)g * L.W + k] = stage[(size_t)r * SW + k];
       }
@@ -1882,7 +1997,7 @@ __global__ __launch_bounds__(256) void gb_part_merge_kernel(GbLayout L, PmArgs A
       for (; pos < hi; ++pos) {
         // workgroup scope: the slice has no other reader or writer during this launch, and a device-scope atomic is a trip
         // through the fabric (the L2s of the eight XCDs are not coherent with each other) — r02n: 3.4 ms per 4.7 M rows
-        unsigned long long cur = __hip_atomic_load((unsigned long long*)&A.slot_hash[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned long long cur = A.slot_hash[pos];   // plain: a stale 0 only leads to the CAS, which returns the real content
         if (cur == 0) {
           unsigned long long old = 0ULL;
           __hip_atomic_compare_exchange_strong((unsigned long long*)&A.slot_hash[pos], &old, (unsigned long long)hw, __ATOMIC_RELAXED,
@@ -1939,6 +2054,10 @@ __global__ __launch_bounds__(256) void gb_part_merge_kernel(GbLayout L, PmArgs A
 // slice p (workgroup-scope CAS), barrier, phase B verifies the keys and merges the state contribution with workgroup-scope
 // atomics (several rows of a tile may belong to one group). Rows that leave the slice or meet other keys under their hash are
 // listed for the row path.
+// (r02t tried the other ownership split — 1024 buckets of the next hash bits, one thread per bucket walking its rows with
+// plain loads and stores, CAS only to claim: 8.0 ms per 60 M rows at 10^7 groups against 6.3 ms for this kernel; the serial
+// dependent chain per thread costs more than the atomics it saves. r02s counters for this kernel: 2.3 atomics and 2.6 L2
+// misses per row, 5.3 GB written per 60 M rows — global atomics are executed memory-side whatever their scope.)
 struct PiArgs {
   const uint64_t* rows;    // [n][W] grouped by partition
   const uint32_t* base;    // [P+1]
@@ -2064,21 +2183,25 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
   hipLaunchKernelGGL((gb_part_colscan_kernel<false>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
   hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, tot, P, base);
   hipLaunchKernelGGL((gb_part_colscan_kernel<true>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
-  // staged copy-out while a batch of rows fits the LDS beside the cursors (W <= 11 words); else lanes store their rows themselves
+  // staged copy-out while a batch of rows (2 or 1 per thread) fits the LDS beside the cursors; else lanes store their rows themselves
   static const bool no_stage = getenv("DBHIP_GB_NOSTAGE") != nullptr;
-  const size_t stage_bytes = (size_t)PT_THREADS * 4 + (size_t)PT_THREADS * (L.W | 1) * 8;
-  if (!no_stage && (size_t)P * 4 + stage_bytes > 64 * 1024 && (size_t)P * 4 + stage_bytes <= 112 * 1024) {
-    static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
-    if (!raised) {
-      DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_part_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-      raised = true;
-    }
+  const size_t row_bytes = 4 + (size_t)(L.W | 1) * 8;
+  const size_t lds2 = (size_t)P * 4 + (size_t)PT_THREADS * 2 * row_bytes, lds1 = (size_t)P * 4 + (size_t)PT_THREADS * row_bytes;
+  const size_t lds_max = 144 * 1024;
+  static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+  if (!raised) {
+    DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_part_scatter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_part_scatter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    raised = true;
   }
-  if (!no_stage && (size_t)P * 4 + stage_bytes <= 112 * 1024)
-    hipLaunchKernelGGL((gb_part_scatter_kernel<true>), dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4 + stage_bytes, s, L, C, row0, cn,
-                       pbits, rows_per_wg, mat, g->rows_in, g->ctrl);
+  if (!no_stage && lds2 <= lds_max)
+    hipLaunchKernelGGL((gb_part_scatter_kernel<2>), dim3((int)nwg), dim3(PT_THREADS), lds2, s, L, C, row0, cn, pbits, rows_per_wg, mat,
+                       g->rows_in, g->ctrl);
+  else if (!no_stage && lds1 <= lds_max)
+    hipLaunchKernelGGL((gb_part_scatter_kernel<1>), dim3((int)nwg), dim3(PT_THREADS), lds1, s, L, C, row0, cn, pbits, rows_per_wg, mat,
+                       g->rows_in, g->ctrl);
   else
-    hipLaunchKernelGGL((gb_part_scatter_kernel<false>), dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
+    hipLaunchKernelGGL((gb_part_scatter_kernel<0>), dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
                        rows_per_wg, mat, g->rows_in, g->ctrl);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
@@ -2243,15 +2366,15 @@ void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, in
   while (bits < PT_MAX_BITS && ((int64_t)per_part << bits) < est) ++bits;
   g->part_chunk = 0;
   g->part_direct = 0;
-  if (((int64_t)per_part << bits) < est || est > total / 3) {
-    // more groups than the finest partitioning's LDS tables hold, or fewer than ~3 rows per group (up to: every row its own
-    // group): nothing to pre-aggregate — the partition's workgroup inserts its rows straight into its slice of the table
-    // (gb_part_insert_kernel). First a 16 M-row chunk, whose group count sizes the table for the rest.
-    static const bool no_direct = getenv("DBHIP_GB_NODIRECT") != nullptr;
-    if (no_direct) { g->part_bits = -1; return; }
+  g->part_adapt = 0;
+  if (((int64_t)per_part << bits) < est) {
+    // more groups than the finest partitioning's LDS tables hold at once, or a probe that was (nearly) all distinct and
+    // says nothing: finest partitioning, a 4 M-row chunk to learn from, then chunks sized by the estimate (adapt_chunk)
+    static const bool no_adapt = getenv("DBHIP_GB_NODIRECT") != nullptr;
+    if (no_adapt) { g->part_bits = -1; return; }
     bits = PT_MAX_BITS;
-    g->part_direct = 1;
-    g->part_chunk = 16 << 20;
+    g->part_adapt = 1;
+    g->part_chunk = 4 << 20;
   }
   g->part_bits = bits;
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in the first %lld rows -> ~%lld groups in %lld rows, %d partition bits\n",
