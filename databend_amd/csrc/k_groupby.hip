@@ -1173,6 +1173,66 @@ __device__ __forceinline__ void fk_load(const GbLayout& L, const GbCols& C, int6
   }
 }
 
+// fk_load for the R rows of a lane's tile, column by column (gb_load_words_n): with the per-row version every load sits in
+// its own basic block behind the type switch's scalar branch and the R x (keys + arguments) loads of a tile are serialised
+// memory round trips — what bounded this path at ~1.0 ms per 60 M rows whatever the group count (r02u)
+template <int KW, int NA, bool HI, int R>
+__device__ __forceinline__ void fk_load_n(const GbLayout& L, const GbCols& C, const int64_t (&row)[R], FkRow<KW, NA, HI> (&r)[R], uint64_t* ctrl) {
+  uint64_t vmask[R];
+#pragma unroll
+  for (int x = 0; x < R; ++x) {
+    vmask[x] = 0;
+    r[x].h = 0;
+    r[x].avalid = 0;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) r[x].kw[j] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    if (k < L.nkeys) {
+      uint64_t w0[R], w1[R];
+      bool valid[R];
+      if (!gb_load_words_n<R>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
+      const int type = L.key_type[k], off = L.key_off[k];
+      const bool two = L.key_words[k] == 2;
+#pragma unroll
+      for (int x = 0; x < R; ++x) {
+        const uint64_t w[2] = {w0[x], w1[x]};
+        const uint64_t hk = gb_hash_words(type, w, valid[x]);
+        r[x].h = (k == 0) ? hk : merge_hash(r[x].h, hk);
+        fk_put<KW>(r[x].kw, off, w0[x]);
+        if (two) fk_put<KW>(r[x].kw, off + 1, w1[x]);
+        if (valid[x]) vmask[x] |= 1ULL << k;
+      }
+    }
+  }
+  if (L.validity_word >= 0) {
+#pragma unroll
+    for (int x = 0; x < R; ++x) fk_put<KW>(r[x].kw, L.validity_word, vmask[x]);
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+#pragma unroll
+    for (int x = 0; x < R; ++x) {
+      r[x].aw[a] = 0;
+      if (HI) r[x].ah[a] = 0;
+    }
+    if (a < L.naggs) {
+      uint64_t w0[R], w1[R];
+      bool valid[R];
+#pragma unroll
+      for (int x = 0; x < R; ++x) { w0[x] = 0; w1[x] = 0; valid[x] = true; }
+      if (C.arg[a].data != nullptr) gb_load_words_n<R>(C.arg[a], row, w0, w1, valid);
+#pragma unroll
+      for (int x = 0; x < R; ++x) {
+        r[x].aw[a] = w0[x];
+        if (HI) r[x].ah[a] = w1[x];
+        if (valid[x]) r[x].avalid |= 1u << a;
+      }
+    }
+  }
+}
+
 struct FkArgs {
   int64_t row0, n;         // rows [row0, row0 + n) of the columns
   int64_t tiles_per_block;
@@ -1207,10 +1267,14 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
     FkRow<KW, NA, HI> r[R];
     uint32_t slot[R];
     // ---- loads of the whole tile first (R rows per lane in flight) ----
+    {
+      int64_t row[R];
 #pragma unroll
-    for (int x = 0; x < R; ++x) {
-      const int64_t li = t * tile_rows + x * 256 + tid;
-      fk_load<KW, NA, HI>(L, C, A.row0 + (li < A.n ? li : 0), r[x], A.ctrl);
+      for (int x = 0; x < R; ++x) {
+        const int64_t li = t * tile_rows + x * 256 + tid;
+        row[x] = A.row0 + (li < A.n ? li : 0);
+      }
+      fk_load_n<KW, NA, HI, R>(L, C, row, r, A.ctrl);
     }
     // ---- phase A: match-or-claim by hash ----
 #pragma unroll
@@ -1608,17 +1672,18 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_hist_kernel(GbLayout L, Gb
                                                                   int64_t rows_per_wg, uint32_t* mat, uint64_t* ctrl) {
   extern __shared__ uint32_t pt_lds[];
   const int P = 1 << pbits;
-  for (int s = threadIdx.x; s < P; s += PT_THREADS) pt_lds[s] = 0;
+  const int T = blockDim.x;
+  for (int s = threadIdx.x; s < P; s += T) pt_lds[s] = 0;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t hi = lo + rows_per_wg < n ? lo + rows_per_wg : n;
-  for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)PT_THREADS * PT_R) {
+  for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)T * PT_R) {
     int64_t row[PT_R];
     bool in[PT_R];
     uint64_t h[PT_R];
 #pragma unroll
     for (int x = 0; x < PT_R; ++x) {
-      const int64_t li = t0 + (int64_t)x * PT_THREADS + threadIdx.x;
+      const int64_t li = t0 + (int64_t)x * T + threadIdx.x;
       in[x] = li < hi;
       row[x] = row0 + (in[x] ? li : lo);
     }
@@ -1629,7 +1694,7 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_hist_kernel(GbLayout L, Gb
   }
   __syncthreads();
   uint32_t* out = mat + (size_t)blockIdx.x * P;
-  for (int s = threadIdx.x; s < P; s += PT_THREADS) out[s] = pt_lds[s];
+  for (int s = threadIdx.x; s < P; s += T) out[s] = pt_lds[s];
 }
 
 // One workgroup per 64 partitions, 4 lanes per partition (each a quarter of the nwg workgroup rows of the matrix, loads
@@ -1755,16 +1820,17 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
   const int P = 1 << pbits;
   uint32_t* lcur = pt_lds;
   const int tid = threadIdx.x;
+  const int T = blockDim.x;   // 256 (few partitions: several workgroups per CU overlap their load / stage / copy-out phases) or 1024
   const uint32_t* mine = mat + (size_t)blockIdx.x * P;
-  for (int s = tid; s < P; s += PT_THREADS) lcur[s] = mine[s];
+  for (int s = tid; s < P; s += T) lcur[s] = mine[s];
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t hi = lo + rows_per_wg < n ? lo + rows_per_wg : n;
   if (PS_R == 0) {
-    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)PT_THREADS * PT_R) {
+    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)T * PT_R) {
 #pragma unroll
       for (int x = 0; x < PT_R; ++x) {
-        const int64_t li = t0 + (int64_t)x * PT_THREADS + tid;
+        const int64_t li = t0 + (int64_t)x * T + tid;
         if (li < hi && gb_row_passes(C, row0 + li)) {
           const uint64_t h = gb_keys_hash(L, C, row0 + li, ctrl);
           const uint32_t pos = atomicAdd(&lcur[part_of(h, pbits)], 1u);
@@ -1776,13 +1842,13 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
   }
   const int SW = L.W | 1;                                      // odd stride in 8-byte words: conflict-free rows
   constexpr int SR = PS_R > 0 ? PS_R : 1;
-  constexpr int BR = PT_THREADS * SR;                          // rows of a batch
+  const int BR = T * SR;                                       // rows of a batch
   uint32_t* gpos = pt_lds + P;                                 // [BR] output row of the staged row, ~0 = none
   uint64_t* stage = (uint64_t*)(pt_lds + P + BR);              // [BR][SW]   (P and BR are even: 8-byte aligned)
   int wshift = 0;
   while ((1 << wshift) < L.W) ++wshift;                         // copy-out: 2^wshift lanes per row, lanes >= W idle
   const int k = tid & ((1 << wshift) - 1), rsub = tid >> wshift;
-  const int rows_per_it = PT_THREADS >> wshift;
+  const int rows_per_it = T >> wshift;
   for (int64_t t0 = lo; t0 < hi; t0 += BR) {
     int64_t row[SR];
     bool in[SR];
@@ -1790,17 +1856,17 @@ __global__ __launch_bounds__(PT_THREADS) void gb_part_scatter_kernel(GbLayout L,
     uint64_t* out[SR];
 #pragma unroll
     for (int x = 0; x < SR; ++x) {
-      const int64_t li = t0 + (int64_t)x * PT_THREADS + tid;
+      const int64_t li = t0 + (int64_t)x * T + tid;
       in[x] = li < hi;
       row[x] = row0 + (in[x] ? li : lo);
-      out[x] = stage + (size_t)(x * PT_THREADS + tid) * SW;
+      out[x] = stage + (size_t)(x * T + tid) * SW;
     }
     gb_keys_hash_n<SR>(L, C, row, h, ctrl);
 #pragma unroll
     for (int x = 0; x < SR; ++x) {
       uint32_t pos = 0xFFFFFFFFu;
       if (in[x] && gb_row_passes(C, row[x])) pos = atomicAdd(&lcur[part_of(h[x], pbits)], 1u);
-      gpos[x * PT_THREADS + tid] = pos;
+      gpos[x * T + tid] = pos;
     }
     gb_serialize_rows_n<SR>(L, C, row, h, out);   // (rows that do not take part fill their own staging row and stay there)
     __syncthreads();
@@ -1830,6 +1896,19 @@ struct PaArgs {
 
 constexpr int PA_R = 4;
 
+// word `idx` (wave-uniform) of a row held in registers: a chain of selects, no dynamic register indexing
+template <int N>
+__device__ __forceinline__ uint64_t pa_pick(const uint64_t (&a)[N], int idx) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) r = (k == idx) ? a[k] : r;
+  return r;
+}
+
+// WMAX > 0: rows of at most WMAX words are loaded whole into registers at the top of a tile (PA_R x W independent loads in
+// one block) and every later use is a register; WMAX = 0: any width, words re-read from memory where they are used (each
+// such load is a round trip to the L1 behind a branch)
+template <int WMAX>
 __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) {
   extern __shared__ uint64_t fk_lds[];
   __shared__ uint32_t lcount;
@@ -1849,12 +1928,26 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
 
   for (uint32_t t0 = r_begin; t0 < r_end; t0 += 256 * PA_R) {
     uint32_t slot[PA_R];
-    // the hashes of all PA_R rows of this thread first: PA_R independent loads in flight instead of one per probe
+    constexpr int WR = WMAX > 0 ? WMAX : 1;
+    uint64_t rw[PA_R][WR];
     uint64_t hs[PA_R];
+    if (WMAX > 0) {
 #pragma unroll
-    for (int x = 0; x < PA_R; ++x) {
-      const uint32_t ri = t0 + x * 256 + tid;
-      hs[x] = ri < r_end ? A.rows[(uint64_t)ri * L.W + L.hash_word] : 0;
+      for (int x = 0; x < PA_R; ++x) {
+        const uint32_t ri = t0 + x * 256 + tid;
+        const uint64_t* r = A.rows + (uint64_t)(ri < r_end ? ri : r_begin) * L.W;
+#pragma unroll
+        for (int k = 0; k < WR; ++k) rw[x][k] = k < L.W ? r[k] : 0;
+      }
+#pragma unroll
+      for (int x = 0; x < PA_R; ++x) hs[x] = pa_pick<WR>(rw[x], L.hash_word);
+    } else {
+      // the hashes of all PA_R rows of this thread first: PA_R independent loads in flight instead of one per probe
+#pragma unroll
+      for (int x = 0; x < PA_R; ++x) {
+        const uint32_t ri = t0 + x * 256 + tid;
+        hs[x] = ri < r_end ? A.rows[(uint64_t)ri * L.W + L.hash_word] : 0;
+      }
     }
     // ---- phase A: match-or-claim by hash ----
 #pragma unroll
@@ -1875,7 +1968,13 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
             if (old == 0) {
               atomicAdd(&lcount, 1u);
               uint64_t* d = lrows + (size_t)pos * A.sw;
-              for (int j = 0; j < L.nkey_words; ++j) d[j] = r[j];
+              if (WMAX > 0) {
+#pragma unroll
+                for (int j = 0; j < WR; ++j)
+                  if (j < L.nkey_words) d[j] = rw[x][j];
+              } else {
+                for (int j = 0; j < L.nkey_words; ++j) d[j] = r[j];
+              }
               d[L.hash_word] = h;
               for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
               slot[x] = pos;
@@ -1898,9 +1997,26 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
         const uint64_t* r = A.rows + (uint64_t)ri * L.W;
         uint64_t* d = lrows + (size_t)slot[x] * A.sw;
         bool eq = true;
-        for (int j = 0; j < L.nkey_words; ++j) eq &= (d[j] == r[j]);
+        if (WMAX > 0) {
+#pragma unroll
+          for (int j = 0; j < WR; ++j)
+            if (j < L.nkey_words) eq &= (d[j] == rw[x][j]);
+        } else {
+          for (int j = 0; j < L.nkey_words; ++j) eq &= (d[j] == r[j]);
+        }
         if (eq) {
-          for (int a = 0; a < L.naggs; ++a) gb_atomic_merge(L, a, d + L.agg_off[a], r + L.agg_off[a]);
+          if (WMAX > 0) {
+            for (int a = 0; a < L.naggs; ++a) {
+              uint64_t v[GB_MAX_STATE_WORDS] = {0, 0, 0, 0};
+              const int off = L.agg_off[a], nw = L.agg_words[a];
+#pragma unroll
+              for (int j = 0; j < GB_MAX_STATE_WORDS; ++j)
+                if (j < nw) v[j] = pa_pick<WR>(rw[x], off + j);
+              gb_atomic_merge(L, a, d + off, v);
+            }
+          } else {
+            for (int a = 0; a < L.naggs; ++a) gb_atomic_merge(L, a, d + L.agg_off[a], r + L.agg_off[a]);
+          }
         } else {
           spill = true;
         }
@@ -2169,16 +2285,20 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
   const int P = 1 << pbits;
   int32_t rc;
   if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
-  // workgroups of the histogram / scatter pair: contiguous row ranges, at least 8192 rows each, at most two per CU
-  int64_t nwg = ceil_div(cn, (int64_t)8192);
-  if (nwg > 512) nwg = 512;
+  // workgroups of the histogram / scatter pair: contiguous row ranges, 1024 threads (r02x tried 256-thread workgroups for few
+  // partitions — several per CU to overlap their phases: scatter 0.90 ms against 0.78 ms per 60 M rows, and a 4 x taller
+  // histogram matrix to scan)
+  const int T = PT_THREADS;
+  const int64_t nwg_max = T == 256 ? 2048 : 512;
+  int64_t nwg = ceil_div(cn, (int64_t)T * 16);
+  if (nwg > nwg_max) nwg = nwg_max;
   const int64_t rows_per_wg = ceil_div(cn, nwg);
   nwg = ceil_div(cn, rows_per_wg);
   if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, ((size_t)(3 * PT_PMAX + 8) + (size_t)nwg * P) * 4))) return rc;
   uint32_t* tot = g->part_meta;
   uint32_t* base = g->part_meta + PT_PMAX;
   uint32_t* mat = g->part_meta + 3 * PT_PMAX + 8;
-  hipLaunchKernelGGL(gb_part_hist_kernel, dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
+  hipLaunchKernelGGL(gb_part_hist_kernel, dim3((int)nwg), dim3(T), (size_t)P * 4, s, L, C, row0, cn, pbits,
                      rows_per_wg, mat, g->ctrl);
   hipLaunchKernelGGL((gb_part_colscan_kernel<false>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
   hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, tot, P, base);
@@ -2186,7 +2306,7 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
   // staged copy-out while a batch of rows (2 or 1 per thread) fits the LDS beside the cursors; else lanes store their rows themselves
   static const bool no_stage = getenv("DBHIP_GB_NOSTAGE") != nullptr;
   const size_t row_bytes = 4 + (size_t)(L.W | 1) * 8;
-  const size_t lds2 = (size_t)P * 4 + (size_t)PT_THREADS * 2 * row_bytes, lds1 = (size_t)P * 4 + (size_t)PT_THREADS * row_bytes;
+  const size_t lds2 = (size_t)P * 4 + (size_t)T * 2 * row_bytes, lds1 = (size_t)P * 4 + (size_t)T * row_bytes;
   const size_t lds_max = 144 * 1024;
   static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
   if (!raised) {
@@ -2195,13 +2315,13 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
     raised = true;
   }
   if (!no_stage && lds2 <= lds_max)
-    hipLaunchKernelGGL((gb_part_scatter_kernel<2>), dim3((int)nwg), dim3(PT_THREADS), lds2, s, L, C, row0, cn, pbits, rows_per_wg, mat,
+    hipLaunchKernelGGL((gb_part_scatter_kernel<2>), dim3((int)nwg), dim3(T), lds2, s, L, C, row0, cn, pbits, rows_per_wg, mat,
                        g->rows_in, g->ctrl);
   else if (!no_stage && lds1 <= lds_max)
-    hipLaunchKernelGGL((gb_part_scatter_kernel<1>), dim3((int)nwg), dim3(PT_THREADS), lds1, s, L, C, row0, cn, pbits, rows_per_wg, mat,
+    hipLaunchKernelGGL((gb_part_scatter_kernel<1>), dim3((int)nwg), dim3(T), lds1, s, L, C, row0, cn, pbits, rows_per_wg, mat,
                        g->rows_in, g->ctrl);
   else
-    hipLaunchKernelGGL((gb_part_scatter_kernel<0>), dim3((int)nwg), dim3(PT_THREADS), (size_t)P * 4, s, L, C, row0, cn, pbits,
+    hipLaunchKernelGGL((gb_part_scatter_kernel<0>), dim3((int)nwg), dim3(T), (size_t)P * 4, s, L, C, row0, cn, pbits,
                        rows_per_wg, mat, g->rows_in, g->ctrl);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
@@ -2261,6 +2381,15 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     *spilled = 0;   // (listed rows are no sign of a partitioning that is too coarse)
     return DBHIP_OK;
   }
+  // the LDS table no larger than the partition's groups ask for (4 x the expected number, >= 256 slots): 12 KB instead of
+  // 48 KB lets 12 workgroups instead of 3 share a CU, and the tile loop is a chain of load -> probe -> barrier -> merge
+  {
+    const int64_t est = estimate_groups(g->count_host > 0 ? g->count_host : 1, g->rows_seen > 0 ? g->rows_seen : 1);
+    const int64_t groups = est > g->count_host ? est : g->count_host;
+    const int64_t per_part = groups / P + 8;
+    while (lcap > 256 && (int64_t)(lcap / 2) >= 4 * per_part) lcap /= 2;
+    lds_bytes = (size_t)lcap * (sw + 1) * 8;
+  }
   // workgroups per partition: fill the chip (>= ~1024 workgroups) without making splits tiny
   int splits = 1;
   while (P * splits < 1024 && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
@@ -2278,7 +2407,8 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   A.llimit = (uint32_t)(lcap - lcap / 4);
   A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill_idx = g->spill_idx; A.ctrl = g->ctrl;
   A.pcount = exclusive ? pcount : nullptr;
-  hipLaunchKernelGGL(gb_part_agg_kernel, dim3(agrid), dim3(256), lds_bytes, s, L, A);
+  if (L.W <= 8) hipLaunchKernelGGL((gb_part_agg_kernel<8>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
+  else hipLaunchKernelGGL((gb_part_agg_kernel<0>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
   DBHIP_LAUNCH_CHECK();
   uint64_t* hc = pinned_words(0);
   if (!hc) return DBHIP_ERR_HIP;
