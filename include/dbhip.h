@@ -339,7 +339,8 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
  * errors only for rows the filter kept (the filter precedes the maps in the reference's pipeline).
  * `filter_bitmap` (may be NULL) is an additional pushed-down predicate Bitmap as in add_block_filtered. Keys are
  * columns (<= 4 key words; strings up to 12 bytes). Groups resolve through a per-workgroup key table of 8 slots and
- * the states accumulate in per-lane registers, so the pass streams at the input columns' rate.
+ * the states accumulate in per-lane registers: one pass over the inputs, nothing materialised (measured: DESIGN.md 2.2 —
+ * the interpreted program is VALU bound, ~7x the hand-written Q1 kernel).
  * Result == add_block over the taken, mapped columns. Returns DBHIP_ERR_CAPACITY when a workgroup met more than 8
  * groups and DBHIP_ERR_ROW_ERRORS when a map raised (in both cases NOTHING was merged: the caller runs the
  * operator-at-a-time kernels on the block), DBHIP_ERR_UNSUPPORTED for layouts / programs outside the fused subset
