@@ -1001,6 +1001,84 @@ class VectorIndex:
             pass
 
 
+class HnswIndex:
+    """dbhip_hnsw_*: the reference's HNSW + u8-quantised index (hnsw_index/hnsw.rs:62-315). `base`: a DeviceVectors-like
+    object with .data.ptr / .n / .dim (f32 rows on the device); it is only read while the index is being built."""
+
+    def __init__(self, handle, n, dim):
+        self.h, self.n, self.dim = handle, n, dim
+
+    @classmethod
+    def build(cls, metric, base, m=10, ef_construct=40, seed=1):
+        _ensure()
+        h = C.c_void_p()
+        check(lib().dbhip_hnsw_build(C.c_void_p(base.data.ptr), C.c_int64(base.n), base.dim, metric, m, ef_construct, C.c_uint64(seed),
+                                     C.byref(h), None))
+        return cls(h, base.n, base.dim)
+
+    @classmethod
+    def from_graph(cls, metric, base, m, levels, lists, entry_point, entry_level):
+        """lists: the link lists in point-major, level-minor order (HNSWIndex::open over a given graph)"""
+        _ensure()
+        levels = np.ascontiguousarray(levels, dtype=np.int32)
+        nl = np.array([len(x) for x in lists], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in lists]) if len(lists) and nl.sum() else np.zeros(1, np.uint32),
+                                    dtype=np.uint32)
+        h = C.c_void_p()
+        check(lib().dbhip_hnsw_from_graph(C.c_void_p(base.data.ptr), C.c_int64(base.n), base.dim, metric, m, levels.ctypes.data_as(C.c_void_p),
+                                          flat.ctypes.data_as(C.c_void_p), nl.ctypes.data_as(C.c_void_p), C.c_uint32(entry_point),
+                                          C.c_int32(entry_level), C.byref(h), None))
+        return cls(h, base.n, base.dim)
+
+    def export_graph(self):
+        """-> (levels, lists, entry_point, entry_level)"""
+        levels = np.zeros(max(self.n, 1), dtype=np.int32)
+        nlists, ep, el = C.c_int64(), C.c_uint32(), C.c_int32()
+        check(lib().dbhip_hnsw_export_graph(self.h, levels.ctypes.data_as(C.c_void_p), None, None, C.byref(nlists), C.byref(ep), C.byref(el), None))
+        nl = np.zeros(max(nlists.value, 1), dtype=np.int32)
+        check(lib().dbhip_hnsw_export_graph(self.h, None, None, nl.ctypes.data_as(C.c_void_p), None, None, None, None))
+        flat = np.zeros(max(int(nl[:nlists.value].sum()), 1), dtype=np.uint32)
+        check(lib().dbhip_hnsw_export_graph(self.h, None, flat.ctypes.data_as(C.c_void_p), None, None, None, None, None))
+        lists, off = [], 0
+        for c in nl[:nlists.value]:
+            lists.append(flat[off:off + c].copy())
+            off += int(c)
+        return levels[:self.n], lists, ep.value, el.value
+
+    def search(self, queries, limit):
+        oi, od = DeviceBuffer(max(queries.n * limit, 1) * 4), DeviceBuffer(max(queries.n * limit, 1) * 4)
+        check(lib().dbhip_hnsw_search(self.h, C.c_void_p(queries.data.ptr), queries.n, limit, C.c_void_p(oi.ptr), C.c_void_p(od.ptr), None))
+        return (oi.to_numpy(np.uint32, queries.n * limit).reshape(queries.n, limit),
+                od.to_numpy(np.float32, queries.n * limit).reshape(queries.n, limit))
+
+    def scores(self, queries):
+        out = DeviceBuffer(max(queries.n * self.n, 1) * 4)
+        check(lib().dbhip_hnsw_scores(self.h, C.c_void_p(queries.data.ptr), queries.n, C.c_void_p(out.ptr), None))
+        return out.to_numpy(np.float32, queries.n * self.n).reshape(queries.n, self.n)
+
+    def meta(self):
+        a, o, m, ad = C.c_float(), C.c_float(), C.c_float(), C.c_int32()
+        check(lib().dbhip_hnsw_meta(self.h, C.byref(a), C.byref(o), C.byref(m), C.byref(ad)))
+        return np.float32(a.value), np.float32(o.value), np.float32(m.value), ad.value
+
+    def encoded(self):
+        _, _, _, ad = self.meta()
+        out = DeviceBuffer(max(self.n, 1) * (ad + 4))
+        check(lib().dbhip_hnsw_encoded(self.h, C.c_void_p(out.ptr), None))
+        return out.to_numpy(np.uint8, self.n * (ad + 4)).reshape(self.n, ad + 4)
+
+    def destroy(self):
+        if self.h:
+            lib().dbhip_hnsw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def score_u8(is_l1, query, base):
     query = np.ascontiguousarray(query, dtype=np.uint8)
     base = np.ascontiguousarray(base, dtype=np.uint8)

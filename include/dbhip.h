@@ -621,6 +621,43 @@ int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void*
                               uint8_t* out_validity_dev, void* stream);
 int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * HNSW vector index with u8 scalar quantisation — the reference's indexed ANN path
+ *   HNSWIndex::{build, open, search, generate_scores}        hnsw_index/hnsw.rs:62-315
+ *   EncodedVectorsU8::{encode, encode_query, score_point}     hnsw_index/quantization/encoded_vectors_u8.rs:54-215,301-413
+ *   GraphLayersBuilder::link_new_point (+ heuristic)          hnsw_index/graph_layers_builder.rs:343-520
+ *   GraphLayers::{search_entry, search_on_level, search}      hnsw_index/graph_layers.rs:72-247
+ * `distance`: DBHIP_VEC_COSINE (vectors and queries normalised as cosine_preprocess does, score = dot), DBHIP_VEC_L1,
+ * DBHIP_VEC_L2 — the three the reference's index option accepts. Vectors: dense row-major f32 [n][dim] on the device.
+ * build: levels drawn like get_random_layer (round(-ln(u) / ln(max(m, 2)))) from a generator seeded with `seed` (the
+ *   reference uses thread_rng()); m0 = 2 m; the first 256 points are linked one after the other, the rest concurrently (one
+ *   wave per point; the reference: one rayon task per point), scoring the ORIGINAL vectors as the reference's build does.
+ *   The graph is therefore not reproducible bit for bit in either implementation; the quantiser and the search are.
+ * from_graph: the index over a GIVEN graph (HNSWIndex::open): `levels_host[n]`, lists in point-major, level-minor order —
+ *   `nlinks_host[list]` entries each, concatenated in `links_host`.
+ * search: per query the `limit` nearest by quantised score, ef = 4 * limit (hnsw.rs:108-110), distances post-processed
+ *   (cosine |1 - s|, l1 |s|, l2 sqrt|s|, hnsw.rs:317-343). `queries_dev` are raw (preprocess_query is applied inside).
+ *   out_ids / out_dist: [nq][limit], missing results (fewer than `limit` reachable points) = 0xFFFFFFFF / NaN.
+ *   limit <= 64. Ties between equal scores resolve as std::collections::BinaryHeap resolves them in the reference.
+ * scores: generate_scores — the post-processed quantised distance of every row to every query, out [nq][n].
+ * encoded: the reference's storage layout of the quantised vectors (per vector: f32 offset, then actual_dim codes,
+ *   actual_dim = dim rounded up to 16) into `out_dev` [n][4 + actual_dim]; meta: alpha, offset, multiplier, actual_dim. */
+typedef struct dbhip_hnsw dbhip_hnsw;
+int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
+                         uint64_t seed, dbhip_hnsw** out, void* stream);
+int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m,
+                              const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host,
+                              uint32_t entry_point, int32_t entry_level, dbhip_hnsw** out, void* stream);
+int32_t dbhip_hnsw_export_graph(dbhip_hnsw* h, int32_t* levels_host, uint32_t* links_host, int32_t* nlinks_host,
+                                int64_t* out_n_lists_host, uint32_t* out_entry_point_host, int32_t* out_entry_level_host,
+                                void* stream);
+int32_t dbhip_hnsw_search(dbhip_hnsw* h, const float* queries_dev, int32_t nq, int32_t limit, uint32_t* out_ids_dev,
+                          float* out_dist_dev, void* stream);
+int32_t dbhip_hnsw_scores(dbhip_hnsw* h, const float* queries_dev, int32_t nq, float* out_dev, void* stream);
+int32_t dbhip_hnsw_encoded(dbhip_hnsw* h, void* out_dev, void* stream);
+int32_t dbhip_hnsw_meta(dbhip_hnsw* h, float* alpha_host, float* offset_host, float* multiplier_host, int32_t* actual_dim_host);
+int32_t dbhip_hnsw_destroy(dbhip_hnsw* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,191 @@
+"""GPU: the HNSW + u8-quantised index (dbhip_hnsw_*) against the CPU restatement of the reference (oracle/hnsw_oracle.c) and
+against the reference's own sqllogictest answers — all through the C-ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import hnsw_oracle as H
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+METRIC = {"cosine": 0, "l2": 1, "l1": 3}   # dbhip_vec_metric
+
+
+@pytest.fixture(scope="module")
+def L():
+    return H.lib()
+
+
+def lists_of(g, n, levels):
+    return [g.links(p, lv) for p in range(n) for lv in range(levels[p] + 1)]
+
+
+@pytest.mark.parametrize("distance", ["cosine", "l1", "l2"])
+@pytest.mark.parametrize("n,dim", [(1, 8), (53, 8), (200, 37), (300, 768), (64, 16)])
+def test_quantiser_is_bit_exact(gpu, L, distance, n, dim):
+    """EncodedVectorsU8::encode: alpha / offset / multiplier, every code, every per-vector offset; generate_scores"""
+    rng = np.random.default_rng(n * 1000 + dim)
+    raw = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 3:
+        raw[1] = 0.0                      # cosine_preprocess leaves a zero vector alone
+        raw[2] /= np.linalg.norm(raw[2])  # ... and an (almost) normalised one
+    quant = H.Quantised(L, H.preprocess(L, raw, distance), distance)
+    base = gpu.VectorColumn(raw)
+    idx = gpu.HnswIndex.from_graph(METRIC[distance], base, 10, np.zeros(n, np.int32), [np.zeros(0, np.uint32)] * n, 0, 0)
+    a, o, m, ad = idx.meta()
+    assert (a, o, m, ad) == (np.float32(quant.meta.alpha), np.float32(quant.meta.offset), np.float32(quant.meta.multiplier), quant.meta.actual_dim)
+    assert np.array_equal(idx.encoded(), quant.encoded.reshape(n, ad + 4))
+    q = rng.standard_normal((5, dim)).astype(np.float32)
+    got = idx.scores(gpu.VectorColumn(q))
+    for i in range(5):
+        exp = quant.distances(H.preprocess(L, q[i:i + 1], distance)[0])
+        assert np.array_equal(got[i].view(np.uint32), exp.view(np.uint32)), (i, np.abs(got[i] - exp).max())
+    idx.destroy()
+
+
+@pytest.mark.parametrize("distance", ["cosine", "l2", "l1"])
+@pytest.mark.parametrize("n,dim,limit", [(400, 16, 10), (2000, 32, 10), (1500, 96, 5), (300, 8, 64)])
+def test_search_on_the_oracles_graph_is_identical(gpu, L, distance, n, dim, limit):
+    """GraphLayers::search over a GIVEN graph (built by the sequential restatement of the reference's builder): ids and
+    distances equal the CPU restatement's exactly, ties included (8-d data quantised to 128 levels produces equal scores)."""
+    rng = np.random.default_rng(n + dim)
+    centers = rng.standard_normal((12, dim)).astype(np.float32) * 2
+    raw = (centers[rng.integers(0, 12, n)] + rng.standard_normal((n, dim))).astype(np.float32)
+    if distance == "cosine":
+        raw = (raw / np.linalg.norm(raw, axis=1, keepdims=True) * rng.uniform(0.97, 1.03, (n, 1))).astype(np.float32)
+    levels = H.random_levels(n, 10, rng)
+    g = H.Graph(L, n, 10, 40, levels)
+    g.build(raw, distance)
+    ep, el = g.entry()
+    quant = H.Quantised(L, H.preprocess(L, raw, distance), distance)
+    idx = gpu.HnswIndex.from_graph(METRIC[distance], gpu.VectorColumn(raw), 10, levels, lists_of(g, n, levels), ep, el)
+    nq = 40
+    queries = (centers[rng.integers(0, 12, nq)] + rng.standard_normal((nq, dim))).astype(np.float32)
+    ids, dist = idx.search(gpu.VectorColumn(queries), limit)
+    for i in range(nq):
+        eid, ed = g.search(quant, H.preprocess(L, queries[i:i + 1], distance)[0], limit)
+        k = len(eid)
+        assert np.array_equal(ids[i, :k], eid), (i, ids[i], eid)
+        assert np.array_equal(dist[i, :k].view(np.uint32), ed.view(np.uint32))
+        assert np.all(ids[i, k:] == 0xFFFFFFFF)
+    # the export is the import
+    lv2, lists2, ep2, el2 = idx.export_graph()
+    assert np.array_equal(lv2, levels) and (ep2, el2) == (ep, el)
+    assert all(np.array_equal(a, b) for a, b in zip(lists2, lists_of(g, n, levels)))
+    idx.destroy()
+    g.free()
+
+
+def exact_topk(data, q, k, distance):
+    d = {"cosine": lambda: 1.0 - data @ q, "l1": lambda: np.abs(data - q).sum(axis=1), "l2": lambda: ((data - q) ** 2).sum(axis=1)}[distance]()
+    return np.argsort(d, kind="stable")[:k]
+
+
+@pytest.mark.parametrize("distance,n,dim", [("cosine", 20000, 64), ("l2", 20000, 64), ("cosine", 5000, 768), ("l1", 3000, 32)])
+def test_device_build_has_the_structure_and_recall_of_the_reference_builder(gpu, L, distance, n, dim):
+    """dbhip_hnsw_build (one wave per point, concurrent like the reference's rayon build): structure invariants of
+    GraphLayersBuilder, the device search equals the CPU restatement's search ON THE DEVICE-BUILT GRAPH, and recall@10
+    against the exact neighbours is within 0.05 of what the sequential restatement of the reference's builder reaches."""
+    rng = np.random.default_rng(5)
+    raw = rng.standard_normal((n, dim)).astype(np.float32)
+    base = gpu.VectorColumn(raw)
+    idx = gpu.HnswIndex.build(METRIC[distance], base, m=10, ef_construct=40, seed=42)
+    levels, lists, ep, el = idx.export_graph()
+    assert el == levels.max() and levels[ep] == el
+    # level distribution of get_random_layer: P(level >= 1) = P(-ln u / ln 10 >= 0.5) = 10^-0.5
+    assert abs((levels >= 1).mean() - 10 ** -0.5) < 0.02
+    li = 0
+    deg0 = []
+    for p in range(n):
+        for lv in range(levels[p] + 1):
+            l = lists[li]
+            li += 1
+            assert len(l) <= (20 if lv == 0 else 10) and p not in l and len(set(l.tolist())) == len(l)
+            assert all(levels[x] >= lv for x in l)
+            if lv == 0:
+                deg0.append(len(l))
+    assert np.mean(deg0) > 6, np.mean(deg0)
+    data = H.preprocess(L, raw, distance)
+    quant = H.Quantised(L, data, distance)
+    nq = 100
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    ids, dist = idx.search(gpu.VectorColumn(queries), 10)
+    # the same graph on the CPU
+    g = H.Graph(L, n, 10, 40, levels)
+    li = 0
+    for p in range(n):
+        for lv in range(levels[p] + 1):
+            g.set_links(p, lv, lists[li])
+            li += 1
+    g.set_entry(ep, el)
+    hits = 0
+    pq = H.preprocess(L, queries, distance)
+    for i in range(nq):
+        eid, ed = g.search(quant, pq[i], 10)
+        assert np.array_equal(ids[i, :len(eid)], eid), i
+        hits += len(set(ids[i].tolist()) & set(exact_topk(data, pq[i], 10, distance).tolist()))
+    g.free()
+    # the reference's builder, sequential, same levels
+    g2 = H.Graph(L, n, 10, 40, levels)
+    g2.build(raw, distance)
+    hits2 = 0
+    for i in range(nq):
+        eid, _ = g2.search(quant, pq[i], 10)
+        hits2 += len(set(eid.tolist()) & set(exact_topk(data, pq[i], 10, distance).tolist()))
+    g2.free()
+    print(distance, n, dim, "recall@10 device build", hits / (10 * nq), "sequential reference builder", hits2 / (10 * nq), "mean degree", np.mean(deg0))
+    assert hits / (10 * nq) >= hits2 / (10 * nq) - 0.05
+    idx.destroy()
+
+
+def test_reference_sqllogictest_answers_through_the_c_abi(gpu, L):
+    """09_0000_vector_index_base.test (tests/golden/hnsw.json): per block a device-built index (m=10, ef_construct=40);
+    ORDER BY distance LIMIT k -> dbhip_hnsw_search(k), otherwise dbhip_hnsw_scores; exact f32 equality with the printed
+    answers (1 ulp)."""
+    g = json.load(open(os.path.join(HERE, "golden", "hnsw.json")))
+    checked = 0
+    for q in g["queries"]:
+        if q["table"] not in g["indexed_tables"]:
+            continue
+        col = 0 if q["column"] in ("embedding", "embedding1") else 1
+        rows = []
+        for bi, block in enumerate(g["tables"][q["table"]]):
+            vecs = np.array([r["vectors"][col] for r in block], dtype=np.float32)
+            idx = gpu.HnswIndex.build(METRIC[q["distance"]], gpu.VectorColumn(vecs), m=10, ef_construct=40, seed=7 + bi)
+            qv = gpu.VectorColumn(np.array([q["query"]], dtype=np.float32))
+            if q["order"] == "ASC" and q["where_gt"] is None:
+                ids, d = idx.search(qv, q["limit"])
+                rows += [(block[i]["id"], np.float32(x)) for i, x in zip(ids[0].tolist(), d[0]) if i != 0xFFFFFFFF]
+            else:
+                d = idx.scores(qv)[0]
+                rows += [(r["id"], np.float32(x)) for r, x in zip(block, d)]
+            idx.destroy()
+        if q["where_gt"] is not None:
+            rows = [r for r in rows if r[1] > np.float32(q["where_gt"])]
+        rows.sort(key=lambda r: (r[1], r[0]), reverse=q["order"] == "DESC")
+        got = rows[:q["limit"]]
+        exp = [(i, np.float32(d)) for i, d in q["expected"]]
+        assert [r[0] for r in got] == [r[0] for r in exp], (q, got, exp)
+        for (gi, gd), (ei, ed) in zip(got, exp):
+            assert gd == ed or abs(float(gd) - float(ed)) <= 1.2e-7 * max(1.0, abs(float(ed))), (q["distance"], gi, gd, ed)
+        checked += 1
+    assert checked == 11
+
+
+def test_edge_cases(gpu, L):
+    base = gpu.VectorColumn(np.zeros((0, 8), dtype=np.float32))
+    idx = gpu.HnswIndex.build(0, base)
+    ids, d = idx.search(gpu.VectorColumn(np.ones((2, 8), dtype=np.float32)), 3)
+    assert np.all(ids == 0xFFFFFFFF) and np.all(np.isnan(d))
+    idx.destroy()
+    one = gpu.VectorColumn(np.ones((1, 8), dtype=np.float32))
+    idx = gpu.HnswIndex.build(1, one)
+    ids, d = idx.search(one, 3)
+    assert ids[0, 0] == 0 and np.all(ids[0, 1:] == 0xFFFFFFFF)
+    idx.destroy()
+    with pytest.raises(Exception):
+        gpu.HnswIndex.build(2, one)          # plain dot is not an index distance of the reference
+    with pytest.raises(Exception):
+        gpu.HnswIndex.build(0, one, m=40)    # m0 = 80 > 64
