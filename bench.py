@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-opplan", action="store_true", help="skip the generic operator-plan measurement")
     ap.add_argument("--no-q3", action="store_true", help="skip TPC-H Q3 SF100 (BASELINE configs[2])")
     ap.add_argument("--q3-sf", type=float, default=100.0)
+    ap.add_argument("--no-hnsw", action="store_true", help="skip the HNSW reference-comparable mode inside the ANN measurement")
+    ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="base vectors of the HNSW reference-comparable run (the build is timed too)")
     ap.add_argument("--no-ann", action="store_true", help="skip the secondary ANN measurement (BASELINE configs[4])")
     ap.add_argument("--ann-rows", type=int, default=10_000_000, help="base vectors of the WHOLE job (sharded by row range over the ranks)")
     ap.add_argument("--ann-dim", type=int, default=768)
@@ -190,6 +192,13 @@ def main():
         torch.cuda.empty_cache()
     if not args.no_ann:
         ann = bench_ann(args, rank, world, torch, dist, D, DX, L, check)
+        if world == 1 and not args.no_hnsw:
+            # the reference's own indexed path beside the exact index: HNSW (m=10, ef_construct=40, ef=4k) over u8-quantised
+            # vectors, same distribution (SURVEY §8d C5 "reference-comparable mode"), smaller base (the build is part of it)
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_hnsw as BH
+            ann["hnsw_reference_mode"] = BH.run(rows=args.hnsw_rows, dim=args.ann_dim, queries=10_000, k=10)
 
     if rank == 0:
         achieved = (n * BYTES_PER_ROW) / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
