@@ -576,3 +576,15 @@ void orc_hnsw_link_new_point(orc_graph* g, const float* column, int dim, int dis
 void orc_hnsw_build(orc_graph* g, const float* column, int dim, int distance) {
   for (int64_t i = 0; i < g->n; ++i) orc_hnsw_link_new_point(g, column, dim, distance, (uint32_t)i);
 }
+
+/* bulk import of a graph whose lists come in point-major, level-minor order (dbhip_hnsw_export_graph's layout) */
+void orc_hnsw_graph_import(orc_graph* g, const uint32_t* links_flat, const int* nlinks, uint32_t entry_point, int entry_level) {
+  int64_t off = 0;
+  for (int64_t l = 0; l < g->nlists; ++l) {
+    memcpy(g->links + g->list_off[l], links_flat + off, sizeof(uint32_t) * (size_t)nlinks[l]);
+    g->nlinks[l] = nlinks[l];
+    off += nlinks[l];
+  }
+  memset(g->ready, 1, (size_t)g->n);
+  g->has_entry = 1; g->entry_point = entry_point; g->entry_level = entry_level;
+}

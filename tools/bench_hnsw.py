@@ -15,9 +15,38 @@ from databend_amd import _lib as T    # noqa: E402
 import ctypes as C                    # noqa: E402
 
 
-def run(rows=1_000_000, dim=768, queries=10_000, k=10, reps=3, clusters=0, metric="cosine", normalize=False):
-    a = argparse.Namespace(rows=rows, dim=dim, queries=queries, k=k, reps=reps, clusters=clusters, metric=metric, normalize=normalize)
+def run(rows=1_000_000, dim=768, queries=10_000, k=10, reps=3, clusters=0, metric="cosine", normalize=False, cpu=0):
+    a = argparse.Namespace(rows=rows, dim=dim, queries=queries, k=k, reps=reps, clusters=clusters, metric=metric, normalize=normalize, cpu=cpu)
     return _run(a)
+
+
+def cpu_search(a, idx, base, queries, dev_ids):
+    """cpu_baseline leg: the CPU restatement of GraphLayers::search + the u8 scorer (oracle/hnsw_oracle.c, one thread) over the graph
+    the device built, on the first a.cpu queries; also checks that the device returned the same ids"""
+    import ctypes as C
+    from tests import hnsw_oracle as H
+    L = H.lib()
+    levels = np.zeros(a.rows, dtype=np.int32)
+    nlists, ep, el = C.c_int64(), C.c_uint32(), C.c_int32()
+    lib = D.lib()
+    D.check(lib.dbhip_hnsw_export_graph(idx.h, levels.ctypes.data_as(C.c_void_p), None, None, C.byref(nlists), C.byref(ep), C.byref(el), None))
+    nl = np.zeros(nlists.value, dtype=np.int32)
+    D.check(lib.dbhip_hnsw_export_graph(idx.h, None, None, nl.ctypes.data_as(C.c_void_p), None, None, None, None))
+    flat = np.zeros(max(int(nl.sum()), 1), dtype=np.uint32)
+    D.check(lib.dbhip_hnsw_export_graph(idx.h, None, flat.ctypes.data_as(C.c_void_p), None, None, None, None, None))
+    g = H.Graph(L, a.rows, 10, 40, levels)
+    L.orc_hnsw_graph_import(g.h, H.ptr(flat), H.ptr(nl), C.c_uint32(ep.value), C.c_int(el.value))
+    raw = base.cpu().numpy()
+    data = H.preprocess(L, raw, a.metric)
+    quant = H.Quantised(L, data, a.metric)
+    pq = H.preprocess(L, queries[:a.cpu].cpu().numpy(), a.metric)
+    t0 = time.perf_counter()
+    out = [g.search(quant, pq[i], a.k)[0] for i in range(a.cpu)]
+    dt = time.perf_counter() - t0
+    same = all(np.array_equal(out[i], dev_ids[i][:len(out[i])]) for i in range(a.cpu))
+    g.free()
+    return {"value": a.cpu / dt, "unit": "queries/s", "cores": 1, "kind": "port", "sample": f"{a.cpu} queries, oracle/hnsw_oracle.c over the device-built graph",
+            "device_ids_equal_cpu_ids": bool(same)}
 
 
 def main():
@@ -30,6 +59,7 @@ def main():
     ap.add_argument("--clusters", type=int, default=0, help="0: i.i.d. N(0,1) (SURVEY C5); > 0: that many Gaussian clusters (centres N(0,1), spread 0.3)")
     ap.add_argument("--metric", default="cosine", choices=["cosine", "l2", "l1"])
     ap.add_argument("--normalize", action="store_true", help="unit-length base vectors (what embedding models emit)")
+    ap.add_argument("--cpu", type=int, default=0, help="time the CPU restatement of the reference's search (oracle/, one thread) on this many queries over the SAME graph")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     res = _run(a)
@@ -96,6 +126,8 @@ def _run(a):
            "recall_at_10_vs_exact": hits / (a.queries * a.k),
            "quantised_exhaustive_recall_vs_exact": hits_q / (nqx * a.k), "graph_recall_vs_quantised_exhaustive": hits_g / (nqx * a.k),
            "exact_index_queries_per_s": a.queries / tb, "exact_index_recall": 1.0}
+    if a.cpu > 0:
+        res["cpu_baseline"] = cpu_search(a, idx, base, queries, ids)
     del idx, ex, base, queries
     torch.cuda.empty_cache()
     return res
