@@ -1,10 +1,16 @@
 // dev_common.h — device-side helpers shared by the gfx950 kernels.
 // wave = 64 lanes on CDNA4; all wave-width constants are hard-coded to 64.
 #pragma once
+#ifndef __HIPCC_RTC__   // (hiprtc: the run-time compiled kernels get these from a prelude, k_fagg.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
+#ifndef __HIPCC_RTC__
 #include "../../include/dbhip.h"
+#else
+#include "dbhip.h"
+#endif
 
 typedef __int128 i128;
 typedef unsigned __int128 u128;

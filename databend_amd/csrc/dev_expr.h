@@ -102,15 +102,26 @@ enum {
 
 // Interprets instructions [pc0, pc1) for the ROWS row slots of this lane. `ex_regs` = the workgroup's LDS register file
 // ([slot][ROWS][256] u64), `live[k]`: the row may raise, `vmask[k]`: bit c = input column c is valid (or not nullable) there.
+// `P`: the program's metadata, `PA`: its pointers (the same object ahead of time; under DBHIP_JIT — the run-time compiled
+// specialisation, fagg_device.h — P is a constexpr, the pc loop is unrolled, every switch below folds, and ex_regs is a
+// per-lane array in VGPRs indexed by constants).
 template <int ROWS>
-__device__ __forceinline__ void ex_interpret(const ExProg& P, uint64_t* ex_regs, int tid, int pc0, int pc1,
+__device__ __forceinline__ void ex_interpret(const ExProg& P, const ExProg& PA, uint64_t* ex_regs, int tid, int pc0, int pc1,
                                              const int64_t (&row)[ROWS], const bool (&live)[ROWS],
                                              const uint32_t (&vmask)[ROWS]) {
+#undef EX_REG
+#ifdef DBHIP_JIT
+#define EX_REG(r, k) ex_regs[(r) * ROWS + (k)]
+  _Pragma("unroll")
+  for (int pc = pc0; pc < pc1; ++pc) {
+    const ExIns I = P.ins[pc];
+#else
 #define EX_REG(r, k) ex_regs[((r) * ROWS + (k)) * 256 + tid]
   ExIns nxt = P.ins[pc0 < EX_MAX_INS ? pc0 : 0];
   for (int pc = pc0; pc < pc1; ++pc) {
     const ExIns I = nxt;
     nxt = P.ins[pc + 1 < EX_MAX_INS ? pc + 1 : 0];   // the scalar load of the next instruction overlaps this one's work
+#endif
     const int acls = I.acls, bcls = I.bcls, ocls = I.ocls;
 #define EX_ROWS_DO(EXPR)                                  \
   _Pragma("unroll") for (int k = 0; k < ROWS; ++k) {      \
@@ -132,8 +143,8 @@ __device__ __forceinline__ void ex_interpret(const ExProg& P, uint64_t* ex_regs,
 #define EX_RAISE(k)                                                                                        \
   do {                                                                                                     \
     if (live[k] && ((vmask[k] & I.dep) == I.dep)) { /* NULL / filtered / padding rows never raise (function.rs:536-543) */ \
-      if (P.err_words) atomicAnd(&P.err_words[row[k] >> 5], ~(1u << (row[k] & 31)));                       \
-      if (P.err_count) atomicAdd(P.err_count, 1ULL);                                                       \
+      if (PA.err_words) atomicAnd(&PA.err_words[row[k] >> 5], ~(1u << (row[k] & 31)));                     \
+      if (PA.err_count) atomicAdd(PA.err_count, 1ULL);                                                     \
     }                                                                                                      \
   } while (0)
     switch (I.op) {

@@ -29,9 +29,15 @@
 //   not 0. For MIN/MAX the [has value] word already is that flag.
 // The same row is the unit of exchange between ranks (serialized partial state).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
+#ifndef __HIPCC_RTC__
 #include "../../include/dbhip.h"
+#else
+#include "dbhip.h"
+#endif
 
 #define GB_MAX_KEYS 16
 #define GB_MAX_AGGS 24

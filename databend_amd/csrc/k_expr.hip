@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P, ExOut O) {
       }
     }
     // ---- interpret (wave-uniform instruction stream): ONE dispatch per instruction, the row slots loop inside the case ----
-    ex_interpret<ROWS>(P, ex_regs, tid, 0, P.n_ins, row, in_range, vmask);
+    ex_interpret<ROWS>(P, P, ex_regs, tid, 0, P.n_ins, row, in_range, vmask);
     // ---- result ----
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {

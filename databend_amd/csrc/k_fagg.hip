@@ -16,9 +16,14 @@
 // This is the query-specific k_q1.hip generalised: any <= 4 key words, <= 8 aggregates (count / sum incl. exact
 // Decimal128 / min / max, nullable arguments), any expression program dev_expr.h interprets. A workgroup that meets a
 // 9th distinct key gives up (DBHIP_ERR_CAPACITY, nothing merged): the caller keeps the operator-at-a-time kernels.
-#include "dev_expr.h"
-#include "gb_device.h"
+#include "fagg_device.h"
 #include "runtime.h"
+
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <string>
 
 #include <stdlib.h>
 #include <string.h>
@@ -35,400 +40,146 @@ const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
 
 namespace {
 
-constexpr int FA_MAX_SLOTS = 8;
-constexpr int FA_KW = 4;     // key words (incl. the validity word of nullable keys)
-constexpr int FA_MAXW = 12;  // state words per group
-constexpr int FA_MAXA = 8;   // aggregates
-constexpr int FA_ROWS = 2;   // row slots per lane
+// ---------------------------------------------------------------------------------------------------------------------
+// run-time specialisation (see fagg_device.h): the kernel's own source, compiled by hiprtc with this query's program and
+// layout as a constexpr. Sources of the device headers are embedded at build time (build/jit_embed.inc, Makefile).
+// ---------------------------------------------------------------------------------------------------------------------
+#include "build/jit_embed.inc"   // kJitHdrName[], kJitHdrSrc[], kJitHdrCount
 
-// what one state word accumulates (wave-uniform metadata, decoded on the host)
-enum { W_NONE = 0, W_ADD1, W_ADD3, W_FADD, W_OR, W_MIN, W_MAX, W_CONT };
-// which part of the argument value feeds the word
-enum { C_LO = 0, C_HI, C_EXT, C_FLAG, C_ENC };
-
-struct FaKeyTable {
-  uint32_t count;
-  uint32_t lock;
-  uint64_t key[FA_MAX_SLOTS][FA_KW];
+struct JitOut {
+  std::string s;
+  void num(long long v) { s += std::to_string(v); s += ","; }
+  void u64(uint64_t v) { char b[40]; snprintf(b, sizeof(b), "0x%llxULL,", (unsigned long long)v); s += b; }
+  void null() { s += "nullptr,"; }
+  void open() { s += "{"; }
+  void close() { s += "},"; }
 };
 
-struct FaArgs {
-  ExProg P;
-  GbCol key[FA_KW];
-  int32_t key_type[FA_KW], key_off[FA_KW], key_words[FA_KW];
-  int32_t nkeys, nkey_words, validity_word, hash_word, W;
-  int32_t naggs, nwords, state_off;   // state words start at word `state_off` of a row
-  uint32_t wm[FA_MAXW];               // packed per-word metadata (see WM_*)
-  const uint8_t* filter_bits;         // pushed-down predicate Bitmap (may be NULL)
-  int64_t filter_off;
-  int64_t n;
-  int32_t debug;                      // env DBHIP_FAGG_DEBUG bits: 1 no partial rows, 2 no key resolution / accumulation, 4 (host) no merge
-  uint64_t* partial_rows;             // [gridDim.x * 4 waves * SLOTS][W]
-  uint64_t* ctrl;                     // [0] = #partial rows, [1] = flags (1: > SLOTS groups, 2: long string key)
-};
-static_assert(sizeof(FaArgs) <= 4000, "kernel arguments must stay below the 4 KB kernarg segment");
-
-// slow path, ONE lane of a wave at a time: find or append under the lock. -1 when full.
-template <int SLOTS>
-__device__ __forceinline__ int fa_insert(FaKeyTable* T, const uint64_t (&k)[FA_KW]) {
-  while (atomicCAS(&T->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
-  volatile FaKeyTable* V = T;
-  const uint32_t nk = V->count;
-  int slot = -1;
-  for (uint32_t s = 0; s < nk; ++s)
-    if (V->key[s][0] == k[0] && V->key[s][1] == k[1] && V->key[s][2] == k[2] && V->key[s][3] == k[3]) slot = (int)s;
-  if (slot < 0 && nk < (uint32_t)SLOTS) {
-    V->key[nk][0] = k[0]; V->key[nk][1] = k[1]; V->key[nk][2] = k[2]; V->key[nk][3] = k[3];
-    __threadfence_block();
-    V->count = nk + 1;
-    slot = (int)nk;
-  }
-  __threadfence_block();
-  atomicExch(&T->lock, 0u);
-  return slot;
+void jit_ins(JitOut& o, const ExIns& I) {
+  o.open();
+  o.num(I.op); o.num(I.dst); o.num(I.a); o.num(I.b); o.num(I.c); o.num(I.type);
+  o.num(I.acls); o.num(I.bcls); o.num(I.ocls); o.num(I.norm_sh); o.num(I.norm_signed); o.num(I.norm_f32);
+  o.num(I.a_wide); o.num(I.b_wide); o.num(I.o_wide); o.num(I.a_dec); o.num(I.b_dec); o.num(I.dec_idx); o.num(I.dep); o.num(0);
+  o.u64(I.imm); o.u64(I.imm_hi);
+  o.close();
 }
-
-__device__ __forceinline__ uint64_t fa_uniform_u64(uint64_t v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
+void jit_dec(JitOut& o, const DecOp& D) {
+  o.open();
+  o.num(D.op); o.num(D.a_from_scale); o.num(D.a_to_scale); o.num(D.a_to_precision); o.num(D.a_check);
+  o.num(D.b_from_scale); o.num(D.b_to_scale); o.num(D.b_to_precision); o.num(D.b_check);
+  o.num(D.t_is_128); o.num(D.ret_precision); o.num(D.ret_scale); o.num(D.overflow); o.num(D.scale_mul); o.num(D.trivial);
+  o.close();
 }
-
-// wave-private, scalar-register copy of the published part of the workgroup's key table
-template <int SLOTS>
-struct FaCache {
-  uint32_t nk;
-  uint64_t k[SLOTS][FA_KW];
-  __device__ __forceinline__ void refresh(FaKeyTable* T) {
-    volatile FaKeyTable* V = T;
-    nk = __builtin_amdgcn_readfirstlane(V->count);
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s)
-#pragma unroll
-      for (int j = 0; j < FA_KW; ++j) k[s][j] = fa_uniform_u64(V->key[s][j]);
-  }
-  __device__ __forceinline__ int lookup(const uint64_t (&q)[FA_KW]) const {
-    int slot = -1;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const bool eq = ((uint32_t)s < nk) & (k[s][0] == q[0]) & (k[s][1] == q[1]) & (k[s][2] == q[2]) & (k[s][3] == q[3]);
-      slot = eq ? s : slot;
-    }
-    return slot;
-  }
-};
-
-// slot of one row's key (wave-convergent call). 0xF = the row does not take part, 0xE = dropped (table full).
-template <int SLOTS>
-__device__ __forceinline__ int fa_resolve(FaKeyTable* T, FaCache<SLOTS>& C, bool want, const uint64_t (&q)[FA_KW], uint32_t& flags) {
-  int slot = C.lookup(q);
-  slot = want ? slot : 0xF;
-  uint64_t miss = __ballot(slot < 0);
-  while (miss) {  // rare: a key this wave has not seen published yet
-    const int leader = __ffsll((long long)miss) - 1;
-    if (lane_id() == leader) {
-      if (fa_insert<SLOTS>(T, q) < 0) flags |= 1u;
-    }
-    C.refresh(T);
-    const int again = C.lookup(q);
-    const bool full = C.nk >= (uint32_t)SLOTS;
-    if (slot < 0) slot = again >= 0 ? again : (full ? 0xE : -1);
-    miss = __ballot(slot < 0);
-  }
-  return slot;
-}
-
-__device__ __forceinline__ uint64_t fa_wave_or(uint64_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ uint64_t fa_wave_min(uint64_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { const uint64_t o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
-  return v;
-}
-__device__ __forceinline__ uint64_t fa_wave_max(uint64_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { const uint64_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-  return v;
-}
-__device__ __forceinline__ double fa_wave_fsum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// Packed per-word metadata (one u32 per state word, read into scalar registers ONCE before the row loop: a scalar load
-// per word per row — the first version — stalls the wave for its latency every time, and a `switch` per word per slot
-// unrolled over 12 words x 4 slots x 2 rows made the loop body larger than the instruction cache):
-//   bits 0-2 op | 3-5 comp | 6-11 LDS slot of the argument's lo word | 12 wide | 13 signed | 14 carry-in from the word
-//   before | 15 enabled | 16-23 nullable inputs the argument depends on | 24-28 dbhip_type for ord_encode
-#define WM_OP(m) ((m) & 7u)
-#define WM_COMP(m) (((m) >> 3) & 7u)
-#define WM_SLOT(m) (((m) >> 6) & 63u)
-#define WM_WIDE(m) (((m) >> 12) & 1u)
-#define WM_SIGNED(m) (((m) >> 13) & 1u)
-#define WM_CARRY(m) (((m) >> 14) & 1u)
-#define WM_EN(m) (((m) >> 15) & 1u)
-#define WM_DEP(m) (((m) >> 16) & 255u)
-#define WM_ENC(m) (((m) >> 24) & 31u)
-
-// The wave's accumulators of ONE slot, staged in the lane's own cells of the LDS register file ([w][256] u64 at `stage`),
-// reduced over the wave word by word and written as a partial row by lane 0. Rolled and out of line: it runs once per
-// (wave, touched slot) and must not bloat the row loop's code.
-__device__ __noinline__ void fa_emit_partial(const uint64_t* stage, int tid, const uint32_t* wm_lds, int nwords, uint64_t* row_states) {
-  const int lane = tid & 63;
-  for (int w = 0; w < nwords; ++w) {
-    const uint32_t m = wm_lds[w];
-    const uint64_t x = stage[w * 256 + tid];
-    switch (WM_OP(m)) {
-      case W_ADD1: { const uint64_t r = wave_sum_u64(x); if (lane == 0) row_states[w] = r; } break;
-      case W_OR: { const uint64_t r = fa_wave_or(x); if (lane == 0) row_states[w] = r ? 1 : 0; } break;   // accumulated as a count of valid rows
-      case W_FADD: { const double r = fa_wave_fsum(__longlong_as_double((long long)x)); if (lane == 0) row_states[w] = (uint64_t)__double_as_longlong(r); } break;
-      case W_ADD3: {
-        uint64_t e = stage[(w + 2) * 256 + tid];
-        const u128 t = wave_sum_u192(((u128)stage[(w + 1) * 256 + tid] << 64) | x, &e);
-        if (lane == 0) { row_states[w] = (uint64_t)t; row_states[w + 1] = (uint64_t)(t >> 64); row_states[w + 2] = e; }
-        w += 2;
-      } break;
-      case W_MIN: {
-        const uint64_t has = stage[(w + 1) * 256 + tid];
-        const uint64_t r = fa_wave_min(has ? x : ~0ULL), h = fa_wave_or(has);
-        if (lane == 0) { row_states[w] = r; row_states[w + 1] = h ? 1 : 0; }
-        w += 1;
-      } break;
-      case W_MAX: {
-        const uint64_t has = stage[(w + 1) * 256 + tid];
-        const uint64_t r = fa_wave_max(has ? x : 0ULL), h = fa_wave_or(has);
-        if (lane == 0) { row_states[w] = r; row_states[w + 1] = h ? 1 : 0; }
-        w += 1;
-      } break;
-      default: break;
-    }
-  }
-}
-
-// GENERAL: the layout has f64 sums or min / max words (uniform branches per word); otherwise every word is an integer add
-// with an optional carry-in and the accumulate step is straight-line code.
-// NW: compile-time bound of the state words per group (4 or 12): unused words would still cost registers and adds.
-// Occupancy: 2 workgroups per CU while the per-lane accumulators (SLOTS x NW x 2 VGPRs) leave room, else 1 (512 registers:
-// the first version ran at 2 with 16 bytes of scratch per lane that the loop touched ~77 times per wave row — 16x the VMEM
-// instructions of the query-specific kernel and 75 % of the wave cycles waiting).
-template <int SLOTS, bool GENERAL, int NW>
-__global__ __launch_bounds__(256, (SLOTS * NW <= 16) ? 2 : 1) void fagg_kernel(FaArgs A) {
-  extern __shared__ uint64_t ex_regs[];  // [n_slots][FA_ROWS][256]; at the end: staging of one slot's accumulators
-  __shared__ FaKeyTable T;
-  __shared__ uint32_t wm_lds[FA_MAXW];
+// `static constexpr FaArgs kM = {...};` in declaration order (ExProg, dev_expr.h; FaArgs, fagg_device.h); every pointer,
+// offset and count that differs between calls of the same query shape is null / 0 here and read from the kernel argument
+std::string jit_meta(const FaArgs& A) {
+  JitOut o;
+  o.s = "static constexpr FaArgs kM = {";
   const ExProg& P = A.P;
-  const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) { T.count = 0; T.lock = 0; }
-  if (tid < FA_MAX_SLOTS * FA_KW) T.key[tid / FA_KW][tid % FA_KW] = 0;
-  if (tid < FA_MAXW) wm_lds[tid] = A.wm[tid];
-  __syncthreads();
-#define EX_REG(r, k) ex_regs[((r) * FA_ROWS + (k)) * 256 + tid]
+  o.open();                                                           // ExProg
+  o.open(); for (int i = 0; i < EX_MAX_INS; ++i) jit_ins(o, P.ins[i]); o.close();
+  o.open(); for (int i = 0; i < EX_MAX_DEC; ++i) jit_dec(o, P.dec[i]); o.close();
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.null(); o.close();   // in_data
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.null(); o.close();   // in_valid
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(0); o.close();   // in_voff
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_type[i]); o.close();
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_scalar[i]); o.close();
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_slot[i]); o.close();
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_wide_ord[i]); o.close();
+  o.num(P.n_ins); o.num(P.n_inputs); o.num(P.n_slots); o.num(P.n_filter_ins); o.num(P.filter_slot); o.num(P.filter_dep);
+  o.null(); o.null();
+  o.close();
+  o.open();                                                           // key[FA_KW]
+  for (int k = 0; k < FA_KW; ++k) { o.open(); o.null(); o.null(); o.num(0); o.null(); o.num(A.key[k].type); o.num(A.key[k].is_scalar); o.close(); }
+  o.close();
+  o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_type[k]); o.close();
+  o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_off[k]); o.close();
+  o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_words[k]); o.close();
+  o.num(A.nkeys); o.num(A.nkey_words); o.num(A.validity_word); o.num(A.hash_word); o.num(A.W);
+  o.num(A.naggs); o.num(A.nwords); o.num(A.state_off);
+  o.open(); for (int w = 0; w < FA_MAXW; ++w) o.num(A.wm[w]); o.close();
+  o.null(); o.num(0); o.num(0); o.num(0); o.null(); o.null();
+  o.s += "};\n";
+  return o.s;
+}
 
-  uint32_t wm[NW];  // scalar registers
-#pragma unroll
-  for (int w = 0; w < NW; ++w) wm[w] = __builtin_amdgcn_readfirstlane(A.wm[w]);
-  uint64_t acc[SLOTS][NW];
-  uint32_t touched = 0;  // bit g: this lane accumulated a row into slot g
-#pragma unroll
-  for (int g = 0; g < SLOTS; ++g)
-#pragma unroll
-    for (int w = 0; w < NW; ++w) acc[g][w] = (GENERAL && WM_OP(wm[w]) == W_MIN) ? ~0ULL : 0ULL;
+const char* const kJitPrelude =
+    "#define DBHIP_JIT 1\n"
+    "typedef unsigned long uint64_t; typedef long int64_t; typedef unsigned int uint32_t; typedef int int32_t;\n"
+    "typedef unsigned short uint16_t; typedef short int16_t; typedef unsigned char uint8_t; typedef signed char int8_t;\n"
+    "typedef unsigned long size_t; typedef unsigned long uintptr_t;\n"
+    "#define INT64_MAX 9223372036854775807L\n#define INT64_MIN (-9223372036854775807L - 1)\n"
+    "#define INT32_MAX 2147483647\n#define INT32_MIN (-2147483647 - 1)\n#define UINT64_MAX 18446744073709551615UL\n"
+    "#define UINT32_MAX 4294967295U\n";
 
-  FaCache<SLOTS> C;
-  C.refresh(&T);
-  uint32_t flags = 0;
-  const int64_t rows_per_wave = 64 * FA_ROWS;
-  const int64_t nchunks = (A.n + rows_per_wave - 1) / rows_per_wave;
-  const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + tid) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+struct JitKernel { hipModule_t mod; hipFunction_t fn; };
+std::mutex g_jit_mu;
+std::map<std::string, JitKernel> g_jit_cache;     // key: the generated source (meta + variant)
+std::map<std::string, int> g_jit_failed;
 
-  for (int64_t c = wave_global; c < nchunks; c += nwaves) {
-    const int64_t base = c * rows_per_wave;
-    int64_t row[FA_ROWS];
-    bool live[FA_ROWS];
-    uint32_t vmask[FA_ROWS];
-#pragma unroll
-    for (int k = 0; k < FA_ROWS; ++k) {
-      row[k] = base + 64 * k + lane;
-      live[k] = row[k] < A.n;
-      vmask[k] = 0xFFu;
-      if (!live[k]) row[k] = A.n - 1;  // clamp: loads stay in bounds, the row takes part in nothing
-    }
-    // ---- every load of the chunk first: inputs of the program, key columns, the pushed-down predicate ----
-    uint64_t in[EX_MAX_INPUTS][FA_ROWS], hi0[FA_ROWS], hi1[FA_ROWS];  // hi words of the (at most two) 128-bit inputs
-#pragma unroll
-    for (int k = 0; k < FA_ROWS; ++k) { hi0[k] = 0; hi1[k] = 0; }
-#pragma unroll
-    for (int ci = 0; ci < EX_MAX_INPUTS; ++ci) {
-      if (ci < P.n_inputs) {
-#pragma unroll
-        for (int k = 0; k < FA_ROWS; ++k) {
-          const int64_t j = P.in_scalar[ci] ? 0 : row[k];
-          in[ci][k] = ex_load(P.in_data[ci], P.in_type[ci], j);
-          if (P.in_wide_ord[ci] == 0) hi0[k] = ((const uint64_t*)P.in_data[ci])[2 * j + 1];
-          else if (P.in_wide_ord[ci] == 1) hi1[k] = ((const uint64_t*)P.in_data[ci])[2 * j + 1];
-          if (P.in_valid[ci] && !bit_get(P.in_valid[ci], P.in_voff[ci] + j)) vmask[k] &= ~(1u << ci);
-        }
-      }
-    }
-    uint64_t kw[FA_ROWS][FA_KW];
-#pragma unroll
-    for (int k = 0; k < FA_ROWS; ++k) {
-#pragma unroll
-      for (int j = 0; j < FA_KW; ++j) kw[k][j] = 0;
-    }
-    uint64_t kvm[FA_ROWS];
-#pragma unroll
-    for (int k = 0; k < FA_ROWS; ++k) kvm[k] = 0;
-#pragma nounroll
-    for (int q = 0; q < A.nkeys; ++q) {  // rolled: ONE copy of the type switch in the loop body
-      const int off = A.key_off[q], two = A.key_words[q] == 2;
-#pragma unroll
-      for (int k = 0; k < FA_ROWS; ++k) {
-        uint64_t w[2];
-        bool valid;
-        if (!gb_load_words(A.key[q], row[k], w, &valid)) flags |= live[k] ? 2u : 0u;
-#pragma unroll
-        for (int j = 0; j < FA_KW; ++j) {
-          if (j == off) kw[k][j] = w[0];
-          if (two && j == off + 1) kw[k][j] = w[1];
-        }
-        if (valid) kvm[k] |= 1ULL << q;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < FA_ROWS; ++k) {
-#pragma unroll
-      for (int j = 0; j < FA_KW; ++j)
-        if (j == A.validity_word) kw[k][j] = kvm[k];
-      if (A.filter_bits) live[k] = live[k] && bit_get(A.filter_bits, A.filter_off + row[k]);
-    }
-#pragma unroll
-    for (int ci = 0; ci < EX_MAX_INPUTS; ++ci) {
-      if (ci < P.n_inputs && P.in_slot[ci] >= 0) {
-#pragma unroll
-        for (int k = 0; k < FA_ROWS; ++k) {
-          EX_REG(P.in_slot[ci], k) = in[ci][k];
-          if (P.in_wide_ord[ci] >= 0) EX_REG(P.in_slot[ci] + 1, k) = P.in_wide_ord[ci] == 0 ? hi0[k] : hi1[k];
-        }
-      }
-    }
-    // ---- filter expression first, then the maps only raise for rows the filter kept (TransformFilter precedes the maps);
-    //      one copy of the interpreter, two passes ----
-#pragma nounroll
-    for (int stage = 0; stage < 2; ++stage) {
-      const int pc0 = stage ? P.n_filter_ins : 0, pc1 = stage ? P.n_ins : P.n_filter_ins;
-      if (pc1 > pc0) ex_interpret<FA_ROWS>(P, ex_regs, tid, pc0, pc1, row, live, vmask);
-      if (stage == 0 && P.filter_slot >= 0) {
-#pragma unroll
-        for (int k = 0; k < FA_ROWS; ++k)
-          live[k] = live[k] && (EX_REG(P.filter_slot, k) & 1) && ((vmask[k] & P.filter_dep) == P.filter_dep);  // a NULL predicate drops the row
-      }
-    }
-    if (A.debug & 2) continue;
-    // another wave of the workgroup may have published new keys: pick them up (uniform, rare)
-    if (__builtin_amdgcn_readfirstlane(((volatile FaKeyTable*)&T)->count) != C.nk) C.refresh(&T);
-#pragma unroll
-    for (int k = 0; k < FA_ROWS; ++k) {
-      const int slot = fa_resolve<SLOTS>(&T, C, live[k], kw[k], flags);
-      // ---- contribution words of this row: branch-free selects on scalar metadata ----
-      uint64_t val[NW];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const uint32_t m = wm[w];
-        const uint32_t comp = WM_COMP(m), wide = WM_WIDE(m), sgn = WM_SIGNED(m);
-        const bool valid = WM_EN(m) && ((vmask[k] & WM_DEP(m)) == WM_DEP(m));
-        // the word's source: the argument's lo slot, or its hi slot for the HI / EXT words of a 128-bit value
-        const uint64_t raw = EX_REG(WM_SLOT(m) + ((wide && (comp == C_HI || comp == C_EXT)) ? 1u : 0u), k);
-        const uint64_t sx = (uint64_t)((int64_t)raw >> 63);   // all ones iff negative
-        uint64_t v = raw;                                                    // C_LO; C_HI of a wide value
-        if (comp == C_HI && !wide) v = sgn ? sx : 0;                         // sign / zero extension of a 64-bit value
-        if (comp == C_EXT) v = (wide || sgn) ? sx : 0;
-        if (comp == C_FLAG) v = 1;
-        if (GENERAL && comp == C_ENC) v = ord_encode(raw, (int)WM_ENC(m));
-        val[w] = valid ? v : 0;
-      }
-      // ---- accumulate into the slot's registers (divergent branch per slot, skipped when no lane of the wave has it) ----
-#pragma unroll
-      for (int g = 0; g < SLOTS; ++g) {
-        if (slot == g) {
-          touched |= 1u << g;
-          uint64_t carry = 0;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            const uint32_t m = wm[w];
-            const uint32_t op = WM_OP(m);
-            if (GENERAL && op == W_FADD) {
-              acc[g][w] = (uint64_t)__double_as_longlong(__longlong_as_double((long long)acc[g][w]) + __longlong_as_double((long long)val[w]));
-            } else if (GENERAL && (op == W_MIN || op == W_MAX)) {   // value word + has word
-              if (w + 1 < NW && val[w + 1]) {
-                const bool take = op == W_MIN ? val[w] < acc[g][w] : val[w] > acc[g][w];
-                acc[g][w] = (take || !acc[g][w + 1]) ? val[w] : acc[g][w];
-                acc[g][w + 1] = 1;
-              }
-            } else if (GENERAL && op == W_CONT && WM_COMP(m) == C_FLAG) {
-              // the has-word of a min / max: written together with its value word above
-            } else {
-              // integer add with an optional carry-in: W_ADD1, W_ADD3 and its two continuation words, flags (kept as
-              // counts of valid rows), unused words (their contribution is 0)
-              const uint64_t cin = WM_CARRY(m) ? carry : 0;
-              const uint64_t t = acc[g][w] + val[w];
-              const uint64_t r = t + cin;
-              carry = (uint64_t)((t < val[w]) | (r < cin));
-              acc[g][w] = r;
-            }
-          }
-        }
-      }
-    }
+std::string jit_tail(int slots, bool general, int nw) {
+  char tail[256];
+  snprintf(tail, sizeof(tail), "extern \"C\" __global__ __launch_bounds__(256) void fagg_jit(FaArgs A) { fagg_body<%d, %s, %d>(A); }\n", slots,
+           general ? "true" : "false", nw);
+  return tail;
+}
+// hiprtc: (meta, variant) -> code object; false + log on failure. Needs no device.
+bool jit_compile(const std::string& meta, const std::string& tail, std::vector<char>* code, std::string* log) {
+  const std::string src = std::string(kJitPrelude) + "#include \"dbhip.h\"\n#include \"fagg_device.h\"\n" + tail;
+  std::vector<const char*> names(kJitHdrName, kJitHdrName + kJitHdrCount), srcs(kJitHdrSrc, kJitHdrSrc + kJitHdrCount);
+  names.push_back("fagg_meta.inc");
+  srcs.push_back(meta.c_str());
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "fagg_jit.hip", (int)names.size(), srcs.data(), names.data()) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=4000000"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  log->assign(ls, 0);
+  if (ls) hiprtcGetProgramLog(prog, &(*log)[0]);
+  if (r != HIPRTC_SUCCESS) { hiprtcDestroyProgram(&prog); return false; }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code->resize(cs);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  return true;
+}
+
+// the specialised kernel for (A's metadata, SLOTS, GENERAL, NW), compiled on first use; nullptr: not available (the caller
+// launches the interpreting kernel)
+hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw) {
+  static const bool off = getenv("DBHIP_FAGG_JIT") && atoi(getenv("DBHIP_FAGG_JIT")) == 0;
+  if (off) return nullptr;
+  const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
+  const std::string key = meta + tail;
+  std::lock_guard<std::mutex> lock(g_jit_mu);
+  auto it = g_jit_cache.find(key);
+  if (it != g_jit_cache.end()) return it->second.fn;
+  if (g_jit_failed.count(key)) return nullptr;
+  const bool trace = getenv("DBHIP_TRACE") != nullptr;
+  auto fail = [&](const char* what, const std::string& log) {
+    g_jit_failed[key] = 1;
+    if (trace) fprintf(stderr, "[dbhip] fagg jit: %s failed; the interpreting kernel is used.\n%s\n", what, log.c_str());
+    return (hipFunction_t) nullptr;
+  };
+  std::vector<char> code;
+  std::string log;
+  if (!jit_compile(meta, tail, &code, &log)) return fail("hiprtc", log);
+  if (const char* dump = getenv("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
+    static int seq = 0;
+    char path[512];
+    snprintf(path, sizeof(path), "%s.%d.co", dump, seq);
+    if (FILE* f = fopen(path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    snprintf(path, sizeof(path), "%s.%d.meta", dump, seq++);
+    if (FILE* f = fopen(path, "wb")) { fwrite(meta.data(), 1, meta.size(), f); fwrite(tail.data(), 1, tail.size(), f); fclose(f); }
   }
-  // ---- give-up flags ----
-  flags = (uint32_t)fa_wave_or((uint64_t)flags);
-  if (lane == 0 && flags) atomicOr((unsigned long long*)&A.ctrl[1], (unsigned long long)flags);
-  // ---- one partial row per (wave, touched slot): stage the slot's accumulators in this lane's cells of the register file ----
-#pragma unroll
-  for (int g = 0; g < SLOTS; ++g) {
-    const uint64_t any = __ballot((touched >> g) & 1);
-    if (any == 0 || (A.debug & 1)) continue;  // wave-uniform
-#pragma unroll
-    for (int w = 0; w < NW; ++w) ex_regs[w * 256 + tid] = acc[g][w];
-    uint64_t* r = nullptr;
-    if (lane == 0) {
-      const unsigned long long idx = atomicAdd((unsigned long long*)&A.ctrl[0], 1ULL);
-      r = A.partial_rows + idx * A.W;
-      uint64_t kk[FA_KW];
-#pragma unroll
-      for (int j = 0; j < FA_KW; ++j) kk[j] = T.key[g][j];
-      uint64_t vmk = ~0ULL;
-#pragma unroll
-      for (int j = 0; j < FA_KW; ++j)
-        if (j == A.validity_word) vmk = kk[j];
-      uint64_t h = 0;
-      for (int q = 0; q < A.nkeys; ++q) {
-        uint64_t w2[2] = {0, 0};
-#pragma unroll
-        for (int j = 0; j < FA_KW; ++j) {
-          if (j == A.key_off[q]) w2[0] = kk[j];
-          if (A.key_words[q] == 2 && j == A.key_off[q] + 1) w2[1] = kk[j];
-        }
-        const uint64_t hk = gb_hash_words(A.key_type[q], w2, (vmk >> q) & 1);
-        h = q == 0 ? hk : merge_hash(h, hk);  // group_hash_entries (group_hash.rs:40-61)
-      }
-#pragma unroll
-      for (int j = 0; j < FA_KW; ++j)
-        if (j < A.nkey_words) r[j] = kk[j];
-      r[A.hash_word] = h;
-    }
-    r = (uint64_t*)fa_uniform_u64((uint64_t)r);   // lane 0's pointer for the whole wave (NOT `hi << 32 | readfirstlane(lo)`: the
-                                                  // builtin returns a signed int, whose sign extension clobbered the high half
-                                                  // whenever bit 31 of the address was set — an intermittent wild store)
-    fa_emit_partial(ex_regs, tid, wm_lds, A.nwords, r + A.state_off);
-  }
-#undef EX_REG
+  JitKernel k;
+  if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return fail("hipModuleLoadData", "");
+  if (hipModuleGetFunction(&k.fn, k.mod, "fagg_jit") != hipSuccess) return fail("hipModuleGetFunction", "");
+  if (trace) fprintf(stderr, "[dbhip] fagg jit: compiled a specialised kernel (%zu bytes of code)\n", code.size());
+  g_jit_cache[key] = k;
+  return k.fn;
 }
 
 bool fa_arg_type_ok(int t) { return type_class(t) >= 0 || t == DBHIP_T_BOOL || t == DBHIP_T_DEC128; }
@@ -571,7 +322,15 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     if (nwords <= 4) hipLaunchKernelGGL((fagg_kernel<SL, GEN, 4>), dim3(grid), dim3(256), lds, s, A);           \
     else hipLaunchKernelGGL((fagg_kernel<SL, GEN, FA_MAXW>), dim3(grid), dim3(256), lds, s, A);                 \
   } while (0)
-    if (variant == 0 && !general) FA_LAUNCH(4, false);
+    const int sl = variant == 0 ? 4 : 8, nw_t = nwords <= 4 ? 4 : FA_MAXW;
+    hipFunction_t jf = jit_kernel(A, sl, general, nw_t);
+    if (jf) {
+      size_t asz = sizeof(A);
+      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+      // (LDS: only the staging of one group's accumulators at the end — the register file is in VGPRs)
+      DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nw_t * 256 * 8), s, nullptr, extra));
+    }
+    else if (variant == 0 && !general) FA_LAUNCH(4, false);
     else if (variant == 0) FA_LAUNCH(4, true);
     else if (!general) FA_LAUNCH(8, false);
     else FA_LAUNCH(8, true);
@@ -665,4 +424,27 @@ int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64
   dbhip_agg_program prog;
   prog.prog = nullptr; prog.n_ins = 0; prog.inputs = inputs; prog.n_inputs = n_inputs; prog.filter_reg = -1; prog.arg_regs = arg_regs;
   return dbhip_groupby_add_block_program(g, keys, &prog, n, C.filter, C.filter_off + row0, (void*)s);
+}
+
+// Compiles the run-time specialisation of a small fixed query shape (i64 key; sum(i64 column), count(*)) and returns the
+// size of the code object (> 0) or -1 with hiprtc's log in `log_out`. Needs no device: tests/test_abi.py runs it on the CPU
+// box so that a header the specialised kernel cannot digest is caught where there is no GPU.
+extern "C" int64_t dbhip_fagg_jit_compile_check_internal(char* log_out, int64_t cap) {
+  FaArgs A;
+  memset(&A, 0, sizeof(A));
+  for (int i = 0; i < EX_MAX_INPUTS; ++i) { A.P.in_slot[i] = -1; A.P.in_wide_ord[i] = -1; }
+  A.P.n_inputs = 1; A.P.in_type[0] = LK_8; A.P.in_slot[0] = 0; A.P.n_slots = 1; A.P.filter_slot = -1;
+  // one real instruction so that the interpreter's code is compiled too: r1 = r0 + r0 (i64)
+  A.P.n_ins = 1;
+  A.P.ins[0].op = EX_PLUS; A.P.ins[0].dst = 1; A.P.ins[0].a = 0; A.P.ins[0].b = 0; A.P.ins[0].acls = A.P.ins[0].bcls = A.P.ins[0].ocls = CLS_SIGNED;
+  A.P.ins[0].dec_idx = -1; A.P.n_slots = 2;
+  A.nkeys = 1; A.nkey_words = 1; A.validity_word = -1; A.hash_word = 1; A.W = 4; A.naggs = 2; A.nwords = 2; A.state_off = 2;
+  A.key[0].type = DBHIP_T_I64; A.key_type[0] = DBHIP_T_I64; A.key_off[0] = 0; A.key_words[0] = 1;
+  A.wm[0] = (uint32_t)W_ADD1 | ((uint32_t)C_LO << 3) | (1u << 6) | (1u << 13) | (1u << 15) | ((uint32_t)DBHIP_T_I64 << 24);
+  A.wm[1] = (uint32_t)W_ADD1 | ((uint32_t)C_FLAG << 3) | (1u << 15);
+  std::vector<char> code;
+  std::string log;
+  const bool ok = jit_compile(jit_meta(A), jit_tail(4, false, 4), &code, &log);
+  if (log_out && cap > 0) { snprintf(log_out, (size_t)cap, "%s", log.c_str()); }
+  return ok ? (int64_t)code.size() : -1;
 }

@@ -31,8 +31,10 @@
 #ifndef DBHIP_H
 #define DBHIP_H
 
+#ifndef __HIPCC_RTC__   /* (run-time compiled kernels include this header for its enums; their prelude has the typedefs) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
