@@ -112,11 +112,6 @@ const char* const kJitPrelude =
     "#define INT32_MAX 2147483647\n#define INT32_MIN (-2147483647 - 1)\n#define UINT64_MAX 18446744073709551615UL\n"
     "#define UINT32_MAX 4294967295U\n";
 
-struct JitKernel { hipModule_t mod; hipFunction_t fn; };
-std::mutex g_jit_mu;
-std::map<std::string, JitKernel> g_jit_cache;     // key: the generated source (meta + variant)
-std::map<std::string, int> g_jit_failed;
-
 std::string jit_tail(int slots, bool general, int nw) {
   char tail[256];
   snprintf(tail, sizeof(tail), "extern \"C\" __global__ __launch_bounds__(256) void fagg_jit(FaArgs A) { fagg_body<%d, %s, %d>(A); }\n", slots,
@@ -146,40 +141,63 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   return true;
 }
 
-// the specialised kernel for (A's metadata, SLOTS, GENERAL, NW), compiled on first use; nullptr: not available (the caller
-// launches the interpreting kernel)
-hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw) {
-  static const bool off = getenv("DBHIP_FAGG_JIT") && atoi(getenv("DBHIP_FAGG_JIT")) == 0;
-  if (off) return nullptr;
+// One entry per (metadata, variant). The hiprtc compile (~0.5-1 s) happens in dbhip_groupby_prepare_program — the PREPARE of
+// a pipeline — on the calling thread; add_block_program uses a specialised kernel only when it finds one in the cache and
+// interprets otherwise, so a query never waits for a compiler (env DBHIP_FAGG_JIT=sync: compile on first use instead).
+// (r02j3: compiling on a detached background thread while the main thread kept launching hung inside the ROCm compiler
+// library on the GPU box — no thread of this library calls hiprtc concurrently with anything else any more.)
+struct JitEntry {
+  bool ok = false;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+};
+std::mutex g_jit_mu;   // held across the compile: one hiprtc call at a time
+std::map<std::string, JitEntry> g_jit_cache;   // key: the generated source (meta + variant)
+
+int jit_mode() {   // 0 = off, 1 = prepared kernels only (default), 2 = compile on first use
+  static const int m = [] {
+    const char* e = getenv("DBHIP_FAGG_JIT");
+    if (!e) return 1;
+    if (!strcmp(e, "sync")) return 2;
+    return atoi(e) == 0 ? 0 : 1;
+  }();
+  return m;
+}
+
+hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, bool compile) {
+  const int mode = jit_mode();
+  if (mode == 0) return nullptr;
+  if (mode == 2) compile = true;
   const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
   const std::string key = meta + tail;
+  const bool trace = getenv("DBHIP_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_jit_mu);
   auto it = g_jit_cache.find(key);
-  if (it != g_jit_cache.end()) return it->second.fn;
-  if (g_jit_failed.count(key)) return nullptr;
-  const bool trace = getenv("DBHIP_TRACE") != nullptr;
-  auto fail = [&](const char* what, const std::string& log) {
-    g_jit_failed[key] = 1;
-    if (trace) fprintf(stderr, "[dbhip] fagg jit: %s failed; the interpreting kernel is used.\n%s\n", what, log.c_str());
-    return (hipFunction_t) nullptr;
-  };
+  if (it != g_jit_cache.end()) return it->second.ok ? it->second.fn : nullptr;
+  if (!compile) return nullptr;
+  JitEntry e;
   std::vector<char> code;
   std::string log;
-  if (!jit_compile(meta, tail, &code, &log)) return fail("hiprtc", log);
-  if (const char* dump = getenv("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
-    static int seq = 0;
-    char path[512];
-    snprintf(path, sizeof(path), "%s.%d.co", dump, seq);
-    if (FILE* f = fopen(path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
-    snprintf(path, sizeof(path), "%s.%d.meta", dump, seq++);
-    if (FILE* f = fopen(path, "wb")) { fwrite(meta.data(), 1, meta.size(), f); fwrite(tail.data(), 1, tail.size(), f); fclose(f); }
+  if (!jit_compile(meta, tail, &code, &log)) {
+    if (trace) fprintf(stderr, "[dbhip] fagg jit: hiprtc failed; the interpreting kernel is used.\n%s\n", log.c_str());
+  } else {
+    if (const char* dump = getenv("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
+      static int seq = 0;
+      char path[512];
+      snprintf(path, sizeof(path), "%s.%d.co", dump, seq);
+      if (FILE* f = fopen(path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+      snprintf(path, sizeof(path), "%s.%d.meta", dump, seq++);
+      if (FILE* f = fopen(path, "wb")) { fwrite(meta.data(), 1, meta.size(), f); fwrite(tail.data(), 1, tail.size(), f); fclose(f); }
+    }
+    if (hipModuleLoadData(&e.mod, code.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, "fagg_jit") == hipSuccess) {
+      e.ok = true;
+      if (trace) fprintf(stderr, "[dbhip] fagg jit: specialised kernel ready (%zu bytes of code)\n", code.size());
+    } else if (trace) {
+      fprintf(stderr, "[dbhip] fagg jit: the code object did not load; the interpreting kernel is used\n");
+    }
   }
-  JitKernel k;
-  if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return fail("hipModuleLoadData", "");
-  if (hipModuleGetFunction(&k.fn, k.mod, "fagg_jit") != hipSuccess) return fail("hipModuleGetFunction", "");
-  if (trace) fprintf(stderr, "[dbhip] fagg jit: compiled a specialised kernel (%zu bytes of code)\n", code.size());
-  g_jit_cache[key] = k;
-  return k.fn;
+  g_jit_cache[key] = e;
+  return e.ok ? e.fn : nullptr;
 }
 
 bool fa_arg_type_ok(int t) { return type_class(t) >= 0 || t == DBHIP_T_BOOL || t == DBHIP_T_DEC128; }
@@ -197,6 +215,8 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
   }
   return words <= FA_MAXW && L.hash_word == L.nkey_words && L.agg_off[0] == L.hash_word + 1;
 }
+
+static thread_local bool t_prepare_only = false;
 
 extern "C" {
 
@@ -314,7 +334,15 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   const bool chained = (dbhip_groupby_count_internal(g) + n_max) * 135 <= dbhip_groupby_capacity_internal(g) * 100;
   if ((rc = dbhip_groupby_reserve_merge_internal(g, n_max))) return rc;
   static const bool no_chain = getenv("DBHIP_FAGG_NOCHAIN") != nullptr;   // debugging: drain the stream between kernel and merge
-  for (int variant = 0; variant < 2; ++variant) {
+  if (t_prepare_only) {
+    // dbhip_groupby_prepare_program: compile the specialised kernel of this query shape now (the 4-slot variant, or the
+    // 8-slot one when the table already holds more than 4 groups), launch nothing
+    const int nw_p = nwords <= 4 ? 4 : FA_MAXW;
+    (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nw_p, true);
+    return DBHIP_OK;
+  }
+  // a table that already holds more than 4 groups starts with the 8-slot variant
+  for (int variant = dbhip_groupby_count_internal(g) > 4 ? 1 : 0; variant < 2; ++variant) {
     DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
     kernel_timer_start(s);
 #define FA_LAUNCH(SL, GEN)                                                                                     \
@@ -323,7 +351,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     else hipLaunchKernelGGL((fagg_kernel<SL, GEN, FA_MAXW>), dim3(grid), dim3(256), lds, s, A);                 \
   } while (0)
     const int sl = variant == 0 ? 4 : 8, nw_t = nwords <= 4 ? 4 : FA_MAXW;
-    hipFunction_t jf = jit_kernel(A, sl, general, nw_t);
+    hipFunction_t jf = jit_kernel(A, sl, general, nw_t, false);
     if (jf) {
       size_t asz = sizeof(A);
       void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
@@ -365,6 +393,13 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     return DBHIP_ERR_ROW_ERRORS;
   }
   return dbhip_groupby_merge_rows_internal(g, A.partial_rows, (int64_t)host_ctrl[0], s);
+}
+
+int32_t dbhip_groupby_prepare_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog) {
+  t_prepare_only = true;
+  const int32_t rc = dbhip_groupby_add_block_program(g, keys, prog, 1, nullptr, 0, nullptr);
+  t_prepare_only = false;
+  return rc;
 }
 
 }  // extern "C"

@@ -587,7 +587,7 @@ class GroupBy:
         else:
             check(lib().dbhip_groupby_add_block_filtered(self.h, ka, aa, C.c_int64(n), C.c_void_p(filter.data.ptr), C.c_int64(0), stream))
 
-    def add_block_program(self, keys, program, arg_regs, n, filter_reg=-1, filter=None, stream=None):
+    def add_block_program(self, keys, program, arg_regs, n, filter_reg=-1, filter=None, stream=None, prepare=False):
         """Fused TransformFilter -> maps -> partial aggregate (dbhip_groupby_add_block_program). `program`: ExprProgram;
         `arg_regs[i]`: register of aggregate i's argument, ("input", c) for input column c as it is, None for count(*)."""
         regs = (C.c_int32 * max(len(self.aggs), 1))()
@@ -600,7 +600,14 @@ class GroupBy:
         ap.inputs, ap.n_inputs = C.cast(cin, C.c_void_p), len(program.inputs)
         ap.filter_reg, ap.arg_regs = filter_reg, C.cast(regs, C.c_void_p)
         fb = C.c_void_p(filter.data.ptr) if filter is not None else None
+        if prepare:
+            check(lib().dbhip_groupby_prepare_program(self.h, _cols(keys), C.byref(ap)))
+            return
         check(lib().dbhip_groupby_add_block_program(self.h, _cols(keys), C.byref(ap), C.c_int64(n), fb, C.c_int64(0), stream))
+
+    def prepare_program(self, keys, program, arg_regs, filter_reg=-1):
+        """dbhip_groupby_prepare_program: compile the run-time specialised kernel of this query shape now (blocking, cached)."""
+        self.add_block_program(keys, program, arg_regs, 1, filter_reg=filter_reg, prepare=True)
 
     def state_fields(self):
         """-> [(dbhip_type, aggregate index)] of the serialized-state block (dbhip_groupby_state_fields)."""

@@ -191,10 +191,12 @@ def q1_operator_pushdown(li, g=None, cutoff=Q1_CUTOFF):
     return g
 
 
-def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF):
+def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF, prepare=False):
     """The whole Q1 pipeline as ONE generic launch (dbhip_groupby_add_block_program): the binding flattens the filter
     predicate and the three decimal maps into a register program (what Evaluator::run walks node by node) and the
-    fused filter -> map -> partial-aggregate kernel interprets it — no query-specific code on the device."""
+    fused filter -> map -> partial-aggregate kernel runs it — interpreted, or through the kernel that the library
+    specialises for this program at run time (hiprtc; `prepare=True` = dbhip_groupby_prepare_program, the PREPARE of the
+    pipeline: waits for that kernel instead of launching). No query-specific code on the device."""
     g = g or D.GroupBy.q1()
     p = D.ExprProgram([li.ship, li.qty, li.price, li.disc, li.tax])
     ship, cut = p.load(0), p.const(cutoff, L.T_DATE)
@@ -205,6 +207,9 @@ def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF):
     disc_price = p.arith(L.EX_MULTIPLY, price, one_minus, keep=(price,))  # l_extendedprice * (..)     Decimal(31,4)
     one_plus = p.arith(L.EX_PLUS, one, tax)                           # 1 + l_tax                    Decimal(16,2)
     charge = p.arith(L.EX_MULTIPLY, disc_price, one_plus, keep=(disc_price,))  # (..) * (..)          Decimal(38,6)
+    if prepare:
+        g.prepare_program([li.rf, li.ls], p, [qty, price, disc_price, charge, disc, None], filter_reg=f)
+        return g
     g.add_block_program([li.rf, li.ls], p, [qty, price, disc_price, charge, disc, None], li.n, filter_reg=f)
     return g
 

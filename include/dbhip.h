@@ -360,6 +360,14 @@ typedef struct {
 int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog,
                                         int64_t n, const uint8_t* filter_bitmap, int64_t filter_bit_offset,
                                         void* stream);
+/* Run-time specialisation. add_block_program interprets the program. prepare_program — the PREPARE of a pipeline, same
+ * arguments (column data pointers may be NULL, types must be final) — compiles, through hiprtc, the kernel's own source with
+ * THIS program / layout as compile-time constants (what rustc's monomorphisation gives the reference's kernels): ~0.5 s on the
+ * calling thread, cached per query shape for the life of the process. Afterwards add_block_program calls of that shape launch
+ * the specialised kernel (3.6x faster on TPC-H Q1); shapes that were not prepared are interpreted — a query
+ * never waits for a compiler. If the kernel cannot be built the interpreter stays (DBHIP_OK either way).
+ * env DBHIP_FAGG_JIT=0 disables, =sync compiles on first use instead. */
+int32_t dbhip_groupby_prepare_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog);
 /* combine_payload (:349-380): merge serialized partial states (as produced by
  * dbhip_groupby_flush_serialized on any rank) into this table. */
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows,

@@ -43,3 +43,15 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "orc_" not in txt, os.path.join(dp, f)
+
+
+def test_run_time_specialisation_compiles_without_a_gpu():
+    """dbhip_groupby_add_block_program's hiprtc path: the embedded device headers + a generated constexpr program must
+    compile for gfx950 on the CPU box (the interpreter is the fallback, so a broken header would otherwise go unnoticed)."""
+    import ctypes as C
+    from databend_amd import _lib
+    L = _lib.load_library()
+    L.dbhip_fagg_jit_compile_check_internal.restype = C.c_int64
+    buf = C.create_string_buffer(1 << 16)
+    size = L.dbhip_fagg_jit_compile_check_internal(buf, C.c_int64(1 << 16))
+    assert size > 4096, buf.value.decode(errors="replace")[:4000]

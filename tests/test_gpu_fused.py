@@ -286,3 +286,20 @@ def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card, mon
         k2 = k.copy()
         k2[2_500_000:] += 100       # 8 more groups show up after the probing chunk: the fused kernel gives up, the LDS path takes over
         assert run(k2, None) == expect(k2, np.ones(n, bool))
+
+
+def test_prepared_specialised_kernel_equals_the_interpreter(gpu, oracle):
+    """dbhip_groupby_prepare_program: after PREPARE the launches go through the kernel hiprtc specialised for this program
+    (env DBHIP_TRACE shows it); results are those of the interpreter (run before the prepare) and of the query-specific kernel.
+    A second, different program shape gets its own kernel."""
+    import torch
+    from databend_amd import tpch
+    li = tpch.LineitemTorch(3_000_003, seed=9, torch=torch)
+    exp = tpch.q1_rows(tpch.q1_fused(li))
+    first = tpch.q1_rows(tpch.q1_fused_program(li))            # interpreter, or the specialised kernel if an earlier test prepared it
+    tpch.q1_fused_program(li, prepare=True)                    # blocks until the specialised kernel is loaded
+    again = tpch.q1_rows(tpch.q1_fused_program(li))
+    other = tpch.q1_rows(tpch.q1_fused_program(li, cutoff=tpch.Q1_CUTOFF - 400))   # the constant is part of the program: another kernel
+    tpch.q1_fused_program(li, cutoff=tpch.Q1_CUTOFF - 400, prepare=True)
+    other2 = tpch.q1_rows(tpch.q1_fused_program(li, cutoff=tpch.Q1_CUTOFF - 400))
+    assert first == exp and again == exp and other == other2 and other != exp
