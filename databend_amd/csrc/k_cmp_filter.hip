@@ -453,6 +453,35 @@ __global__ __launch_bounds__(256) void take_chunks_bitmap_kernel(const uint8_t* 
 
 }  // namespace
 
+// take for the nullable side of an outer join (left_join.rs:185-260: matched rows take the build columns wrapped with a true
+// validity, unmatched probe rows get a null_block): idx == 0xFFFFFFFF -> a zero value and validity 0; otherwise the source row
+// and its validity (true when the source has none). One validity word per wave (ballot).
+template <typename T>
+__global__ __launch_bounds__(256) void take_outer_kernel(const T* __restrict__ src, const uint8_t* __restrict__ src_valid, int64_t src_voff,
+                                                         const uint32_t* __restrict__ idx, int64_t n, T* __restrict__ out,
+                                                         uint64_t* __restrict__ out_valid_words, uint8_t* __restrict__ out_valid_bytes) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * 256) {
+    bool valid = false;
+    if (i < n) {
+      const uint32_t j = idx[i];
+      T v{};
+      if (j != 0xFFFFFFFFu) {
+        v = src[j];
+        valid = !src_valid || bit_get(src_valid, src_voff + j);
+      }
+      out[i] = v;
+    }
+    const uint64_t m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0) {
+      const int64_t w = i >> 6;
+      if (i + 64 <= n) out_valid_words[w] = m;   // (the buffer is 8-byte aligned and padded: dbhip.h)
+      else
+        for (int b = 0; b < (int)((n - i + 7) >> 3); ++b) out_valid_bytes[w * 8 + b] = (uint8_t)(m >> (8 * b));
+    }
+  }
+}
+
 extern "C" {
 
 int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n,
@@ -593,6 +622,30 @@ int32_t dbhip_take_bitmap(const uint8_t* src, int64_t bit_offset, const uint32_t
   DBHIP_REQUIRE(src && sel && out, "dbhip_take_bitmap: NULL argument");
   hipLaunchKernelGGL(take_bitmap_kernel, dim3(grid_for(n_sel, 256)), dim3(256), 0,
                      resolve_stream(stream), src, bit_offset, sel, n_sel, out, ceil_div(n_sel, 8));
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_take_outer(const void* src, const uint8_t* src_validity, int64_t src_validity_offset, int32_t elem_size,
+                         const uint32_t* idx, int64_t n, void* out, uint8_t* out_validity, void* stream) {
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(src && idx && out && out_validity, "dbhip_take_outer: NULL argument");
+  DBHIP_REQUIRE(((uintptr_t)out_validity & 7) == 0, "dbhip_take_outer: the validity buffer must be 8-byte aligned");
+  hipStream_t s = resolve_stream(stream);
+  const int grid = grid_for(n, 256, 1024);
+#define TO(T) hipLaunchKernelGGL(take_outer_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)src, src_validity, src_validity_offset, idx, n, (T*)out, \
+                                 (uint64_t*)out_validity, out_validity)
+  switch (elem_size) {
+    case 1: TO(uint8_t); break;
+    case 2: TO(uint16_t); break;
+    case 4: TO(uint32_t); break;
+    case 8: TO(uint64_t); break;
+    case 16: TO(B16); break;
+    default:
+      set_error("dbhip_take_outer: unsupported element size %d", elem_size);
+      return DBHIP_ERR_INVALID;
+  }
+#undef TO
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }

@@ -240,6 +240,12 @@ int32_t dbhip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
   return DBHIP_OK;
 }
 
+int32_t dbhip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+  if (bytes == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(dst_dev && src_dev, "dbhip_memcpy_d2d: NULL pointer");
+  DBHIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dbhip::resolve_stream(stream)));
+  return DBHIP_OK;
+}
 int32_t dbhip_memset(void* dst, int32_t byte, size_t bytes, void* stream) {
   if (bytes == 0) return DBHIP_OK;
   DBHIP_CHECK(hipMemsetAsync(dst, byte, bytes, resolve_stream(stream)));

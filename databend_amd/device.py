@@ -907,6 +907,56 @@ class HashJoin:
         assert got.value == m
         return op, ob, m
 
+    def join(self, kind, probe_keys, probe_cols, build_cols):
+        """Output assembly of `kind` in ("inner", "left", "left_semi", "left_anti") for ONE probe block against the finished build
+        side (new_hash_join/memory/{inner_join,left_join,left_join_semi,left_join_anti}.rs; no other conjunct):
+          inner      matched pairs: probe columns taken by probe_idx, build columns by build_row
+          left       the same, build columns Nullable with a true validity (wrap_true_validity), FOLLOWED by the unmatched
+                     probe rows with a null build block (left_join.rs:196-232)
+          left_semi  probe rows that have a match, each once;  left_anti: probe rows without one
+        -> (probe Columns, build Columns, n_rows); everything stays in HBM."""
+        n = probe_keys.n
+        v = C.c_void_p(probe_keys.validity.ptr) if probe_keys.validity is not None else None
+        if kind in ("left_semi", "left_anti", "left"):
+            words = (max(n, 1) + 63) // 64
+            bm = DeviceBuffer(words * 8 + 64)
+            bm.zero()
+            total = C.c_uint64()
+            check(lib().dbhip_join_probe_mark(self.h, C.c_void_p(probe_keys.data.ptr), v, C.c_int64(n), C.c_void_p(bm.ptr), C.byref(total), None))
+            matched = Column(L.T_BOOL, n, bm)
+            if kind == "left_semi":
+                sel, k = filter_select(matched)
+                return [take(c, sel, k) for c in probe_cols], [], k
+            # NOT matched: a ^ ones has no entry point; a Boolean equality with false is the reference's own `not`
+            false_ = Column.boolean(np.zeros(1, dtype=bool))
+            false_.is_scalar = True
+            unmatched = cmp(L.CMP_EQ, matched, false_, n)
+            usel, uk = filter_select(unmatched)
+            if kind == "left_anti":
+                return [take(c, usel, uk) for c in probe_cols], [], uk
+        op, ob, m = self.probe_block_device(probe_keys)
+        if kind == "inner":
+            return [take(c, op, m) for c in probe_cols], [take(c, ob, m) for c in build_cols], m
+        if kind != "left":
+            raise ValueError(kind)
+        rows = m + uk
+        pidx, bidx = DeviceBuffer(max(rows, 1) * 4 + 64), DeviceBuffer(max(rows, 1) * 4 + 64)
+        check(lib().dbhip_memcpy_d2d(C.c_void_p(pidx.ptr), C.c_void_p(op.ptr), C.c_size_t(m * 4), None))
+        check(lib().dbhip_memcpy_d2d(C.c_void_p(pidx.ptr + m * 4), C.c_void_p(usel.ptr), C.c_size_t(uk * 4), None))
+        check(lib().dbhip_memcpy_d2d(C.c_void_p(bidx.ptr), C.c_void_p(ob.ptr), C.c_size_t(m * 4), None))
+        if uk:
+            check(lib().dbhip_memset(C.c_void_p(bidx.ptr + m * 4), 0xFF, C.c_size_t(uk * 4), None))
+        out_b = []
+        for c in build_cols:
+            es = ELEM_SIZE[c.dtype]
+            data = DeviceBuffer(max(rows, 1) * es + 64)
+            valid = DeviceBuffer(((max(rows, 1) + 63) // 64) * 8 + 8)
+            sv = C.c_void_p(c.validity.ptr) if c.validity is not None else None
+            check(lib().dbhip_take_outer(C.c_void_p(c.data.ptr), sv, C.c_int64(0), es, C.c_void_p(bidx.ptr), C.c_int64(rows), C.c_void_p(data.ptr),
+                                         C.c_void_p(valid.ptr), None))
+            out_b.append(Column(c.dtype, rows, data, valid, c.precision, c.scale, buffers=c.buffers, keep=(c,)))
+        return [take(c, pidx, rows) for c in probe_cols], out_b, rows
+
     def destroy(self):
         if self.h:
             lib().dbhip_join_destroy(self.h)

@@ -120,6 +120,7 @@ int32_t dbhip_free(void* dev_ptr);
 int32_t dbhip_trim(void);
 int32_t dbhip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int32_t dbhip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int32_t dbhip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int32_t dbhip_memset(void* dst_dev, int32_t byte, size_t bytes, void* stream);
 int32_t dbhip_stream_create(void** out_stream_host);
 int32_t dbhip_stream_destroy(void* stream);
@@ -271,6 +272,14 @@ int32_t dbhip_sel_from_ranges(const uint32_t* ranges_host, int32_t n_ranges, uin
                               void* stream);
 int32_t dbhip_sel_from_repeats(const uint32_t* repeats_host, int32_t n_repeats, uint32_t* out_sel, int64_t num_rows,
                                void* stream);
+/* The nullable side of an outer join (new_hash_join/memory/left_join.rs:185-260: build columns of matched rows are wrapped
+ * with a true validity, unmatched probe rows get a null block): out[i] = src[idx[i]], validity = the source row's (true when
+ * `src_validity` is NULL); idx[i] == 0xFFFFFFFF -> a zero value with validity 0. `out_validity`: LSB-first bits, 8-byte
+ * aligned, ceil(n / 8) bytes. elem_size 1 / 2 / 4 / 8 / 16. Left-outer / semi / anti joins are assembled from
+ * dbhip_join_probe (pairs), dbhip_join_probe_mark (matched Bitmap), dbhip_bitmap_binary / dbhip_filter_select (the
+ * unmatched rows), dbhip_take (probe side) and this (build side): databend_amd/device.py HashJoin.join. */
+int32_t dbhip_take_outer(const void* src, const uint8_t* src_validity, int64_t src_validity_offset, int32_t elem_size,
+                         const uint32_t* idx, int64_t n, void* out, uint8_t* out_validity, void* stream);
 int32_t dbhip_take_chunks(const void* const* blocks_host, int32_t n_blocks, int32_t elem_size, const uint32_t* pairs,
                           int64_t n, void* out, void* stream);
 

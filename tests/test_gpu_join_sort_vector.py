@@ -414,3 +414,60 @@ def test_sort_short_string_keys(gpu):
         assert got == exp
     with pytest.raises(Exception):
         gpu.sort_perm([gpu.Column.strings([b"this string is longer than twelve bytes", b"x"])])
+
+
+@pytest.mark.parametrize("kind", ["inner", "left", "left_semi", "left_anti"])
+@pytest.mark.parametrize("nb,np_,card", [(0, 10, 5), (10, 0, 5), (1000, 5000, 300), (120_000, 300_000, 90_000), (5000, 5000, 7)])
+def test_join_kinds_output_assembly(gpu, oracle, kind, nb, np_, card):
+    """Inner / left-outer / left-semi / left-anti output blocks (new_hash_join/memory/{inner_join,left_join,left_join_semi,
+    left_join_anti}.rs) assembled on the device from the pairs, the matched Bitmap, take and the nullable take; expected
+    rows from the oracle's inner pairs. Row order inside a block is the library's (pairs by probe row, then the unmatched probe
+    rows — left_join.rs:196-232 emits them last too); the comparison is on the multiset of rows."""
+    rng = np.random.default_rng(nb * 3 + np_)
+    bk = rng.integers(0, card, nb).astype(np.uint64) * np.uint64(2654435761)
+    pk = rng.integers(0, card + card // 2 + 1, np_).astype(np.uint64) * np.uint64(2654435761)
+    bvalid = rng.integers(0, 10, nb) > 0
+    pvalid = rng.integers(0, 10, np_) > 0
+    bpay = rng.integers(-10**9, 10**9, nb).astype(np.int64)          # a build payload column (nullable itself)
+    bpay_valid = rng.integers(0, 5, nb) > 0
+    ppay = rng.integers(0, 2**31, np_).astype(np.int32)              # a probe payload column
+    j = gpu.HashJoin(16)
+    if nb:
+        j.add_block(gpu.Column.from_numpy(bk, validity=bvalid))
+    j.final_build()
+    probe_cols = [gpu.Column.from_numpy(ppay), gpu.Column.from_numpy(np.arange(np_, dtype=np.uint32))]
+    build_cols = [gpu.Column.from_numpy(bpay, validity=bpay_valid)]
+    pc, bc, rows = j.join(kind, gpu.Column.from_numpy(pk, validity=pvalid), probe_cols, build_cols)
+    # expected from the oracle's inner pairs
+    cap = max(nb * max(np_, 1) // max(card, 1) * 2 + np_ + 64, 1024)
+    ep, eb = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    bv = np.concatenate([np.packbits(bvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    pv = np.concatenate([np.packbits(pvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    total = oracle.orc_join_inner_u64(bk.ctypes.data_as(C.c_void_p), bv.ctypes.data_as(C.c_void_p), C.c_int64(nb), pk.ctypes.data_as(C.c_void_p),
+                                      pv.ctypes.data_as(C.c_void_p), C.c_int64(np_), ep.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+    assert total <= cap
+    ep, eb = ep[:total], eb[:total]
+    matched = np.zeros(np_, dtype=bool)
+    matched[ep] = True
+    got_p = [c.to_numpy() for c in pc]
+    if kind == "left_semi":
+        exp_rows = sorted(np.nonzero(matched)[0].tolist())
+        assert rows == len(exp_rows) and got_p[1].tolist() == exp_rows and np.array_equal(got_p[0], ppay[exp_rows])
+        return
+    if kind == "left_anti":
+        exp_rows = sorted(np.nonzero(~matched)[0].tolist())
+        assert rows == len(exp_rows) and got_p[1].tolist() == exp_rows and np.array_equal(got_p[0], ppay[exp_rows])
+        return
+    gb_vals = bc[0].to_numpy()
+    gb_valid = bc[0].validity_numpy() if hasattr(bc[0], "validity_numpy") else gpu.unpack_bits(bc[0].validity.to_numpy(np.uint8, (rows + 7) // 8), rows) \
+        if bc[0].validity is not None else np.ones(rows, dtype=bool)
+    exp = [(int(p), int(ppay[p]), (int(bpay[b]) if bpay_valid[b] else None)) for p, b in zip(ep, eb)]
+    if kind == "left":
+        exp += [(int(p), int(ppay[p]), None) for p in np.nonzero(~matched)[0]]
+        # ... and the null block's rows (the unmatched probe rows, last) hold zero values
+        assert np.all(gb_vals[total:] == 0) and not gb_valid[total:].any()
+    got = [(int(got_p[1][i]), int(got_p[0][i]), (int(gb_vals[i]) if gb_valid[i] else None)) for i in range(rows)]
+    assert rows == len(exp) and sorted(got, key=repr) == sorted(exp, key=repr)
+    if kind == "left" and rows:
+        # matched rows first (probe order), the unmatched probe rows last
+        assert np.all(np.diff(got_p[1][:total].astype(np.int64)) >= 0) and np.array_equal(got_p[1][total:], np.nonzero(~matched)[0])
