@@ -58,16 +58,23 @@ struct ExProg {
 
 // load kinds (host: ex_load_kind): the common 8-byte case is the first test
 enum { LK_8 = 0, LK_S4 = 1, LK_U4 = 2, LK_F4 = 3, LK_S2 = 4, LK_U2 = 5, LK_S1 = 6, LK_U1 = 7, LK_BOOL = 8, LK_16 = 9 };
+// input columns live in global memory; a pointer that reaches the kernel inside a by-value struct is generic to the compiler
+// (flat_load: the LDS aperture check and both wait counters). FA_JIT_GLOBAL (run-time specialised kernel): say so.
+#if defined(DBHIP_JIT) && defined(FA_JIT_GLOBAL)
+#define EX_GPTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+#else
+#define EX_GPTR(T, p) ((const T*)(p))
+#endif
 __device__ __forceinline__ uint64_t ex_load(const void* p, int kind, int64_t i) {
-  if (kind == LK_8) return ((const uint64_t*)p)[i];
-  if (kind == LK_S4) return (uint64_t)(int64_t)((const int32_t*)p)[i];
-  if (kind == LK_U4) return ((const uint32_t*)p)[i];
+  if (kind == LK_8) return EX_GPTR(uint64_t, p)[i];
+  if (kind == LK_S4) return (uint64_t)(int64_t)EX_GPTR(int32_t, p)[i];
+  if (kind == LK_U4) return EX_GPTR(uint32_t, p)[i];
   if (kind == LK_F4) return (uint64_t)__double_as_longlong((double)((const float*)p)[i]);
   if (kind == LK_S2) return (uint64_t)(int64_t)((const int16_t*)p)[i];
   if (kind == LK_U2) return ((const uint16_t*)p)[i];
   if (kind == LK_S1) return (uint64_t)(int64_t)((const int8_t*)p)[i];
   if (kind == LK_U1) return ((const uint8_t*)p)[i];
-  if (kind == LK_16) return ((const uint64_t*)p)[2 * i];
+  if (kind == LK_16) return EX_GPTR(uint64_t, p)[2 * i];
   return bit_get((const uint8_t*)p, i);
 }
 

@@ -126,8 +126,17 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   srcs.push_back(meta.c_str());
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "fagg_jit.hip", (int)names.size(), srcs.data(), names.data()) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=4000000"};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=4000000"};
+  std::vector<std::string> extra;   // experiment knobs: env DBHIP_FAGG_JIT_DEFS="-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
+  if (const char* e = getenv("DBHIP_FAGG_JIT_DEFS")) {
+    std::string t;
+    for (const char* c = e;; ++c) {
+      if (*c == ' ' || *c == 0) { if (!t.empty()) extra.push_back(t); t.clear(); if (!*c) break; }
+      else t.push_back(*c);
+    }
+  }
+  for (const std::string& x : extra) opts.push_back(x.c_str());
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   hiprtcGetProgramLogSize(prog, &ls);
   log->assign(ls, 0);
@@ -169,7 +178,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, bool 
   if (mode == 0) return nullptr;
   if (mode == 2) compile = true;
   const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
-  const std::string key = meta + tail;
+  const std::string key = meta + tail + (getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
   const bool trace = getenv("DBHIP_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_jit_mu);
   auto it = g_jit_cache.find(key);
