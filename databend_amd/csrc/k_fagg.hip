@@ -19,7 +19,12 @@
 #include "fagg_device.h"
 #include "runtime.h"
 
-#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <map>
 #include <mutex>
@@ -41,8 +46,9 @@ const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// run-time specialisation (see fagg_device.h): the kernel's own source, compiled by hiprtc with this query's program and
-// layout as a constexpr. Sources of the device headers are embedded at build time (build/jit_embed.inc, Makefile).
+// run-time specialisation (see fagg_device.h): the kernel's own source, compiled by hiprtc — in a helper process, jitc.cpp —
+// with this query's program and layout as a constexpr. Sources of the device headers are embedded at build time
+// (build/jit_embed.inc, Makefile).
 // ---------------------------------------------------------------------------------------------------------------------
 #include "build/jit_embed.inc"   // kJitHdrName[], kJitHdrSrc[], kJitHdrCount
 
@@ -118,36 +124,90 @@ std::string jit_tail(int slots, bool general, int nw) {
            general ? "true" : "false", nw);
   return tail;
 }
-// hiprtc: (meta, variant) -> code object; false + log on failure. Needs no device.
+// (meta, variant) -> code object through the out-of-process compiler driver `dbhip_jitc` (jitc.cpp: why it is a process of
+// its own) next to libdbhip.so: the sources go to a fresh temporary directory, the helper gets `deadline_s` seconds. false + log
+// on any failure (no helper, compile error, deadline). Needs no device.
+std::string jit_helper_path() {
+  Dl_info info;
+  if (!dladdr((const void*)&jit_helper_path, &info) || !info.dli_fname) return "";
+  std::string p = info.dli_fname;
+  const size_t slash = p.rfind('/');
+  return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/dbhip_jitc";
+}
+bool write_file(const std::string& path, const char* data, size_t n) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = fwrite(data, 1, n, f) == n;
+  fclose(f);
+  return ok;
+}
 bool jit_compile(const std::string& meta, const std::string& tail, std::vector<char>* code, std::string* log) {
+  const std::string helper = jit_helper_path();
+  if (helper.empty() || access(helper.c_str(), X_OK) != 0) { *log = "dbhip_jitc not found next to libdbhip.so (" + helper + ")"; return false; }
+  char tmpl[] = "/tmp/dbhip_jit_XXXXXX";
+  if (!mkdtemp(tmpl)) { *log = "mkdtemp failed"; return false; }
+  const std::string dir = tmpl;
+  auto cleanup = [&] {
+    for (int i = 0; i < kJitHdrCount; ++i) unlink((dir + "/" + kJitHdrName[i]).c_str());
+    unlink((dir + "/fagg_meta.inc").c_str()); unlink((dir + "/main.hip").c_str()); unlink((dir + "/out.co").c_str()); unlink((dir + "/log.txt").c_str());
+    rmdir(dir.c_str());
+  };
+  bool ok = true;
+  for (int i = 0; i < kJitHdrCount && ok; ++i) ok = write_file(dir + "/" + kJitHdrName[i], kJitHdrSrc[i], strlen(kJitHdrSrc[i]));
   const std::string src = std::string(kJitPrelude) + "#include \"dbhip.h\"\n#include \"fagg_device.h\"\n" + tail;
-  std::vector<const char*> names(kJitHdrName, kJitHdrName + kJitHdrCount), srcs(kJitHdrSrc, kJitHdrSrc + kJitHdrCount);
-  names.push_back("fagg_meta.inc");
-  srcs.push_back(meta.c_str());
-  hiprtcProgram prog;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "fagg_jit.hip", (int)names.size(), srcs.data(), names.data()) != HIPRTC_SUCCESS) { *log = "hiprtcCreateProgram failed"; return false; }
-  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=4000000"};
-  std::vector<std::string> extra;   // experiment knobs: env DBHIP_FAGG_JIT_DEFS="-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
-  if (const char* e = getenv("DBHIP_FAGG_JIT_DEFS")) {
+  ok = ok && write_file(dir + "/fagg_meta.inc", meta.data(), meta.size()) && write_file(dir + "/main.hip", src.data(), src.size());
+  if (!ok) { cleanup(); *log = "cannot write the sources to " + dir; return false; }
+  std::vector<std::string> args = {helper, dir + "/main.hip", dir + "/out.co", "-I" + dir, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm",
+                                   "-pragma-unroll-threshold=4000000"};
+  if (const char* e = getenv("DBHIP_FAGG_JIT_DEFS")) {   // experiment knobs, e.g. "-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
     std::string t;
     for (const char* c = e;; ++c) {
-      if (*c == ' ' || *c == 0) { if (!t.empty()) extra.push_back(t); t.clear(); if (!*c) break; }
+      if (*c == ' ' || *c == 0) { if (!t.empty()) args.push_back(t); t.clear(); if (!*c) break; }
       else t.push_back(*c);
     }
   }
-  for (const std::string& x : extra) opts.push_back(x.c_str());
-  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
-  size_t ls = 0;
-  hiprtcGetProgramLogSize(prog, &ls);
-  log->assign(ls, 0);
-  if (ls) hiprtcGetProgramLog(prog, &(*log)[0]);
-  if (r != HIPRTC_SUCCESS) { hiprtcDestroyProgram(&prog); return false; }
-  size_t cs = 0;
-  hiprtcGetCodeSize(prog, &cs);
-  code->resize(cs);
-  hiprtcGetCode(prog, code->data());
-  hiprtcDestroyProgram(&prog);
-  return true;
+  std::vector<char*> argv;
+  for (std::string& a : args) argv.push_back(&a[0]);
+  argv.push_back(nullptr);
+  const std::string logpath = dir + "/log.txt";
+  posix_spawn_file_actions_t fa;
+  posix_spawn_file_actions_init(&fa);
+  posix_spawn_file_actions_addopen(&fa, 2, logpath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+  posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+  pid_t pid = 0;
+  const int sp = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv.data(), ::environ);
+  posix_spawn_file_actions_destroy(&fa);
+  if (sp != 0) { cleanup(); *log = "posix_spawn(dbhip_jitc) failed"; return false; }
+  const int deadline_ms = 60 * 1000;
+  int status = 0, waited = 0;
+  bool done = false;
+  while (waited < deadline_ms) {
+    const pid_t w = waitpid(pid, &status, WNOHANG);
+    if (w == pid) { done = true; break; }
+    if (w < 0) break;
+    usleep(10 * 1000);
+    waited += 10;
+  }
+  if (!done) {
+    kill(pid, SIGKILL);
+    waitpid(pid, &status, 0);
+    cleanup();
+    *log = "dbhip_jitc did not finish within 60 s: killed";
+    return false;
+  }
+  {
+    FILE* f = fopen(logpath.c_str(), "rb");
+    if (f) { char buf[4096]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) log->append(buf, n); fclose(f); }
+  }
+  ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+  if (ok) {
+    FILE* f = fopen((dir + "/out.co").c_str(), "rb");
+    ok = f != nullptr;
+    if (f) { char buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) code->insert(code->end(), buf, buf + n); fclose(f); }
+    ok = ok && !code->empty();
+  }
+  cleanup();
+  return ok;
 }
 
 // One entry per (metadata, variant). The hiprtc compile (~0.5-1 s) happens in dbhip_groupby_prepare_program — the PREPARE of
