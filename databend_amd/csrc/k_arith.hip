@@ -345,6 +345,128 @@ int coerce(int op, int a, int b) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// to_<number> / try_to_<number> (register_number_to_number, scalars/arithmetic/src/arithmetic.rs:448-700): lossless -> `as`;
+// float -> integer: rounding_mode ? f64::round first : as is, then num_traits::cast; everything else lossy: num_traits::cast;
+// None -> row error "number overflowed" (cast) or NULL (try_). num_traits 0.2.19's float -> int rule: truncate, Some iff
+// MIN - 1 < x < MAX + 1 when the float type is wider than the integer, else MIN <= x < MAX + 1; unsigned: -1 < x.
+// 4 rows per lane, row = chunk + 64 k + lane: coalesced 64-row segments, one validity word per (wave, k) from a ballot.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct CastParams {
+  const void* src;
+  const uint8_t* valid;   // may be NULL
+  int64_t voff;
+  int src_type, dst_type, is_scalar, is_try, rounding, lossless;
+  int64_t n;
+  void* out;
+  uint64_t* bitmap_words;   // try_: validity out (whole words); cast: error bitmap preset to ones (may be NULL)
+  unsigned long long* err_count;
+};
+
+__device__ __forceinline__ uint64_t cast_load(const void* p, int type, int64_t j) {   // widened like load4_wide
+  switch (type) {
+    case DBHIP_T_I8: return (uint64_t)(int64_t)((const int8_t*)p)[j];
+    case DBHIP_T_I16: return (uint64_t)(int64_t)((const int16_t*)p)[j];
+    case DBHIP_T_I32: return (uint64_t)(int64_t)((const int32_t*)p)[j];
+    case DBHIP_T_I64: return ((const uint64_t*)p)[j];
+    case DBHIP_T_U8: return ((const uint8_t*)p)[j];
+    case DBHIP_T_U16: return ((const uint16_t*)p)[j];
+    case DBHIP_T_U32: return ((const uint32_t*)p)[j];
+    case DBHIP_T_U64: return ((const uint64_t*)p)[j];
+    case DBHIP_T_F32: return (uint64_t)__double_as_longlong((double)((const float*)p)[j]);
+    default: return ((const uint64_t*)p)[j];   // F64 bits
+  }
+}
+__device__ __forceinline__ void cast_store(void* p, int type, int64_t i, uint64_t r) {
+  switch (type) {
+    case DBHIP_T_I8: case DBHIP_T_U8: ((uint8_t*)p)[i] = (uint8_t)r; break;
+    case DBHIP_T_I16: case DBHIP_T_U16: ((uint16_t*)p)[i] = (uint16_t)r; break;
+    case DBHIP_T_I32: case DBHIP_T_U32: ((uint32_t*)p)[i] = (uint32_t)r; break;
+    case DBHIP_T_F32: ((float*)p)[i] = (float)__longlong_as_double((long long)r); break;
+    default: ((uint64_t*)p)[i] = r; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(CastParams P) {
+  const int lane = threadIdx.x & 63;
+  const int scls = type_class(P.src_type), dcls = type_class(P.dst_type);
+  const int sbits = type_bits(P.src_type), dbits = type_bits(P.dst_type);
+  const int64_t nchunks = (P.n + 255) >> 8;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = wave; c < nchunks; c += nwaves) {
+    uint64_t w[4];
+    bool in[4], valid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = (c << 8) + 64 * k + lane;
+      in[k] = i < P.n;
+      const int64_t j = P.is_scalar ? 0 : (in[k] ? i : 0);
+      w[k] = P.n > 0 ? cast_load(P.src, P.src_type, j) : 0;
+      valid[k] = in[k] && (!P.valid || bit_get(P.valid, P.voff + j));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = (c << 8) + 64 * k + lane;
+      uint64_t r;
+      bool some = true;
+      if (dcls == CLS_FLOAT) {   // int -> float, float -> float: always Some(`as`), one rounding
+        double d;
+        if (scls == CLS_FLOAT) d = __longlong_as_double((long long)w[k]);
+        else if (dbits == 32) d = scls == CLS_SIGNED ? (double)(float)(int64_t)w[k] : (double)(float)w[k];
+        else d = scls == CLS_SIGNED ? (double)(int64_t)w[k] : (double)w[k];
+        r = (uint64_t)__double_as_longlong(d);
+      } else if (scls != CLS_FLOAT) {   // int -> int
+        if (!P.lossless) {
+          if (dcls == CLS_SIGNED) {
+            const int64_t lo = dbits == 64 ? INT64_MIN : -(1LL << (dbits - 1)), hi = dbits == 64 ? INT64_MAX : ((1LL << (dbits - 1)) - 1);
+            some = scls == CLS_SIGNED ? ((int64_t)w[k] >= lo && (int64_t)w[k] <= hi) : (w[k] <= (uint64_t)hi);
+          } else {
+            const uint64_t hi = dbits == 64 ? UINT64_MAX : ((1ULL << dbits) - 1);
+            some = scls == CLS_SIGNED ? ((int64_t)w[k] >= 0 && w[k] <= hi) : (w[k] <= hi);
+          }
+        }
+        r = wrap_to(w[k], dbits, dcls == CLS_SIGNED);
+      } else {   // float -> int: the round cast
+        double x = __longlong_as_double((long long)w[k]);
+        int fbits = sbits;
+        if (P.rounding) { x = round(x); fbits = 64; }   // AsPrimitive::<f64>::as_(val).round(), then cast::<f64, Dest>
+        const bool wider = fbits > dbits;
+        if (dcls == CLS_SIGNED) {
+          const double mn = -ldexp(1.0, dbits - 1), mx1 = ldexp(1.0, dbits - 1);
+          some = wider ? (x > mn - 1.0 && x < mx1) : (x >= mn && x < mx1);
+        } else {
+          some = x > -1.0 && x < ldexp(1.0, dbits);
+        }
+        r = f64_to_int_sat(x, P.dst_type);
+      }
+      if (!some) r = 0;   // DestType::default()
+      if (in[k]) cast_store(P.out, P.dst_type, i, r);
+      if (P.is_try) {
+        const uint64_t m = __ballot(valid[k] && some);
+        if (lane == 0 && (c << 8) + 64 * k < P.n) P.bitmap_words[(c << 2) + k] = m;
+      } else if (!some && valid[k]) {
+        if (P.bitmap_words) atomicAnd((unsigned long long*)&P.bitmap_words[i >> 6], ~(1ULL << (i & 63)));
+        if (P.err_count) atomicAdd(P.err_count, 1ULL);
+      }
+    }
+  }
+}
+
+bool cast_lossless(int s, int d) {   // NumberDataType::can_lossless_cast_to (types/number.rs:426-443)
+  if (s == d) return true;
+  const bool sf = type_class(s) == CLS_FLOAT, df = type_class(d) == CLS_FLOAT;
+  const int sb = type_bits(s), db = type_bits(d);
+  if (sf && df) return sb <= db;
+  if (sf) return false;
+  if (df) return sb < db;
+  const bool ss = type_class(s) == CLS_SIGNED, ds = type_class(d) == CLS_SIGNED;
+  if (ss == ds) return sb <= db;
+  if (!ss && ds) return sb < 64 && sb * 2 <= db;
+  return false;
+}
+}  // namespace
+
 extern "C" {
 
 int32_t dbhip_arith_result_type(int32_t op, int32_t lhs_type, int32_t rhs_type) {
@@ -415,6 +537,29 @@ int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stre
   } else {
     hipLaunchKernelGGL(sum_int_kernel, dim3(grid), dim3(256), 0, s, p);
   }
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_cast(const dbhip_col* src, int32_t dst_type, int32_t is_try, int32_t rounding_mode, int64_t n, void* out,
+                   uint8_t* bitmap, uint64_t* err_count_dev, void* stream) {
+  DBHIP_REQUIRE(src, "dbhip_cast: NULL column");
+  auto number = [](int t) { return t >= DBHIP_T_I8 && t <= DBHIP_T_F64; };
+  if (!number(src->type) || !number(dst_type)) {
+    set_error("dbhip_cast: number types only (got %d -> %d); decimals, dates and strings stay with the CPU functions", src->type, dst_type);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(out && src->data, "dbhip_cast: NULL buffer");
+  DBHIP_REQUIRE(!is_try || bitmap, "dbhip_cast: try_ casts need the validity output");
+  DBHIP_REQUIRE(!bitmap || ((uintptr_t)bitmap & 7) == 0, "dbhip_cast: the bitmap must be 8-byte aligned (whole 64-bit words are written)");
+  hipStream_t s = resolve_stream(stream);
+  if (!is_try && bitmap) DBHIP_CHECK(hipMemsetAsync(bitmap, 0xFF, (size_t)ceil_div(n, 64) * 8, s));
+  CastParams P;
+  P.src = src->data; P.valid = src->validity; P.voff = src->validity_offset; P.src_type = src->type; P.dst_type = dst_type;
+  P.is_scalar = src->is_scalar; P.is_try = is_try; P.rounding = rounding_mode; P.lossless = cast_lossless(src->type, dst_type);
+  P.n = n; P.out = out; P.bitmap_words = (uint64_t*)bitmap; P.err_count = (unsigned long long*)err_count_dev;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(ceil_div(n, 4), 256, 1024)), dim3(256), 0, s, P);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }

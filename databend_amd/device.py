@@ -308,6 +308,22 @@ def arith(op, a, b, n=None, errors=None):
     return Column(out_t, n, out, _merged_validity(a, b, n))
 
 
+def cast(col, dst_type, is_try=False, rounding_mode=True, n=None):
+    """to_<number> / try_to_<number> (dbhip_cast). -> (Column, bool[n] ok-rows, error count): for CAST `ok` marks the rows that did
+    not raise "number overflowed"; for TRY_CAST it is the result's validity (also attached to the Column)."""
+    n = n if n is not None else col.n
+    out = DeviceBuffer(max(n, 1) * ELEM_SIZE[dst_type] + 64)
+    bm = DeviceBuffer(((max(n, 1) + 63) // 64) * 8 + 8)
+    cnt = DeviceBuffer(8)
+    cnt.zero()
+    cc = col.c()
+    check(lib().dbhip_cast(C.byref(cc), dst_type, int(is_try), int(rounding_mode), C.c_int64(n), C.c_void_p(out.ptr), C.c_void_p(bm.ptr),
+                           C.c_void_p(cnt.ptr), None))
+    ok = unpack_bits(bm.to_numpy(np.uint8, (n + 7) // 8), n) if n else np.zeros(0, dtype=bool)
+    validity = bm if is_try else col.validity
+    return Column(dst_type, n, out, validity, keep=(col,)), ok, int(cnt.to_numpy(np.uint64, 1)[0])
+
+
 def decimal_result_size(op, a, b):
     props = {L.T_I8: (3, 0), L.T_U8: (3, 0), L.T_I16: (5, 0), L.T_U16: (5, 0), L.T_I32: (10, 0), L.T_U32: (10, 0),
              L.T_I64: (19, 0), L.T_U64: (20, 0)}

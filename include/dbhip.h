@@ -150,6 +150,15 @@ int32_t dbhip_last_kernel_ms(float* out_ms_host);
 int32_t dbhip_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs,
                     int64_t n, int32_t out_type, void* out,
                     uint8_t* err_bitmap, uint64_t* err_count_dev, void* stream);
+/* to_<number> / try_to_<number> (CAST / TRY_CAST between the ten number types; register_number_to_number,
+ * src/query/functions/src/scalars/arithmetic/src/arithmetic.rs:448-700): lossless pairs are `as`; float -> integer rounds
+ * half away from zero first when `rounding_mode` (the numeric_cast_option setting) and truncates otherwise; a value the
+ * destination cannot hold (num_traits::cast = None, NaN included) raises the row error "number overflowed" — bit i of
+ * `bitmap` (preset to ones here) cleared, *err_count_dev incremented, the row holds 0; NULL input rows never raise —
+ * or, for is_try, becomes NULL: `bitmap` is then the result's validity (input validity AND "representable").
+ * `bitmap`: LSB-first, whole 64-bit words (ceil(n / 64) * 8 bytes, 8-byte aligned); required for is_try. */
+int32_t dbhip_cast(const dbhip_col* src, int32_t dst_type, int32_t is_try, int32_t rounding_mode, int64_t n, void* out,
+                   uint8_t* bitmap, uint64_t* err_count_dev, void* stream);
 /* Result type table: returns dbhip_type or -1 (arithmetics_type.rs / codegen
  * src/query/codegen/src/writes/arithmetics_type.rs:222-250). */
 int32_t dbhip_arith_result_type(int32_t op, int32_t lhs_type, int32_t rhs_type);

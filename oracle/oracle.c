@@ -125,6 +125,84 @@ static void store_val(void* out, int type, int64_t i, val v) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* to_<number> / try_to_<number> between number types: register_number_to_number                         */
+/* (src/query/functions/src/scalars/arithmetic/src/arithmetic.rs:448-700):                                */
+/*   lossless (NumberDataType::can_lossless_cast_to, types/number.rs:426-443)  -> `as`                    */
+/*   round cast (float -> integer, need_round_cast_to :445-450): rounding_mode ? f64::round first : as is, */
+/*     then num_traits::cast; None -> row error "number overflowed" (try_: NULL)                          */
+/*   lossy (everything else): num_traits::cast; None -> row error (try_: NULL)                            */
+/* num_traits::cast is the third-party crate num-traits 0.2.19 (Cargo.lock:12876; not under /root/reference); its published  */
+/* rules, restated: int -> int: Some iff the value is in the destination's range; int -> float, float -> float: always      */
+/* Some(`as`); float -> int truncates and is Some iff  MIN - 1 < x < MAX + 1  when the float is wider than the integer      */
+/* (both bounds exact), else  MIN <= x < MAX + 1  (MIN - 1 is not representable; MAX + 1 = 2^bits is); unsigned: -1 < x.    */
+/* NaN compares false everywhere -> None. Pinned by the number cases of tests/it/scalars/testdata/cast.txt.                  */
+/* ------------------------------------------------------------------------ */
+static int is_number(int t);
+static int can_lossless(int s, int d) {
+  const int sf = t_cls(s) == 2, df = t_cls(d) == 2, sb = t_bits(s), db = t_bits(d);
+  if (sf && df) return sb <= db;
+  if (sf && !df) return 0;
+  if (!sf && df) return sb < db;
+  const int ss = t_cls(s) == 0, ds = t_cls(d) == 0;
+  if (ss == ds) return sb <= db;
+  if (!ss && ds) return sb < 64 && sb * 2 <= db; /* next_bit_width(64) = None */
+  return 0;
+}
+/* num_traits::cast::<Src, Dst>(v): 1 = Some (result in *out), 0 = None */
+static int nt_cast(val v, int src_type, int dst_type, val* out) {
+  const int dc = t_cls(dst_type), db = t_bits(dst_type);
+  *out = cast_val(v, dst_type);
+  if (dc == 2) return 1;
+  if (v.cls != 2) { /* int -> int: in range? */
+    if (dc == 0) {
+      const int64_t lo = db == 64 ? INT64_MIN : -((int64_t)1 << (db - 1)), hi = db == 64 ? INT64_MAX : (((int64_t)1 << (db - 1)) - 1);
+      if (v.cls == 0) return v.i >= lo && v.i <= hi;
+      return v.u <= (uint64_t)hi;
+    }
+    const uint64_t hi = db == 64 ? UINT64_MAX : (((uint64_t)1 << db) - 1);
+    if (v.cls == 0) return v.i >= 0 && (uint64_t)v.i <= hi;
+    return v.u <= hi;
+  }
+  /* float -> int. The comparison happens in the SOURCE float type (f32 constants for an f32 source). */
+  const int fb = t_bits(src_type); /* 32 or 64 */
+  const double x = v.f;            /* exact also for f32 sources */
+  const int wider = fb > db;       /* size_of::<F>() > size_of::<I>() */
+  if (dc == 0) {
+    const double min = -ldexp(1.0, db - 1), max_p1 = ldexp(1.0, db - 1);
+    if (wider) return x > min - 1.0 && x < max_p1; /* exact: db <= 32 < 53 bits (f64), db <= 16 < 24 bits (f32) */
+    return x >= min && x < max_p1;
+  }
+  const double max_p1 = ldexp(1.0, db);
+  return x > -1.0 && x < max_p1;
+}
+/* out: dst_type values; `bitmap`: cast -> preset all ones by the caller, bit cleared for error rows (NULL input rows never
+ * raise), try_ -> the result validity (input validity AND "the cast was Some"); *n_errors counts cleared bits (cast only) */
+int orc_cast_num(const orc_col* src, int dst_type, int is_try, int rounding_mode, int64_t n, void* out, uint8_t* bitmap, uint64_t* n_errors) {
+  if (!is_number(src->type) || !is_number(dst_type)) return -1;
+  const int lossless = src->type == dst_type || can_lossless(src->type, dst_type);
+  const int round_cast = t_cls(src->type) == 2 && t_cls(dst_type) != 2;
+  for (int64_t i = 0; i < n; ++i) {
+    val v = load_val(src, i), r;
+    int some = 1;
+    if (lossless) r = cast_val(v, dst_type);
+    else {
+      if (round_cast && rounding_mode) { v.f = round(v.f); v.bits = 64; some = nt_cast(v, ORC_T_F64, dst_type, &r); } /* as_::<f64>().round() */
+      else some = nt_cast(v, src->type, dst_type, &r);
+      if (!some) memset(&r, 0, sizeof r), r.cls = t_cls(dst_type), r.bits = t_bits(dst_type); /* DestType::default() */
+    }
+    store_val(out, dst_type, i, r);
+    const int valid = col_valid(src, i);
+    if (is_try) {
+      if (valid && some) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7)); else bitmap[i >> 3] &= (uint8_t)~(1u << (i & 7));
+    } else if (!some && valid) {
+      if (bitmap) bitmap[i >> 3] &= (uint8_t)~(1u << (i & 7));
+      if (n_errors) ++*n_errors;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* numeric arithmetic: numeric_basic_arithmetic.rs:255-544, arithmetic_modulo.rs */
 /* result types: src/query/codegen/src/writes/arithmetics_type.rs:222-250      */
 /* ------------------------------------------------------------------------ */
