@@ -31,8 +31,8 @@ using namespace dbhip;
 #define DBHIP_TRY(x) do { int32_t _rc = (x); if (_rc) return _rc; } while (0)
 
 struct dbhip_join {
-  int kw;              // key words (u64): 1 or 2
-  int es;              // entry stride in u64 words: 2 or 4
+  int kw;              // key words (u64): 1, 2 or 4 (KeysU256)
+  int es;              // entry stride in u64 words: 2, 4 or 8
   uint64_t* ent;       // [cap_rows * es]: key words, then (next | valid << 32)
   int64_t nrows, cap_rows;
   uint64_t* head;      // [buckets]
@@ -52,7 +52,10 @@ namespace {
 template <int KW>
 __device__ __forceinline__ uint64_t join_hash(const uint64_t* k) {
   if (KW == 1) return agg_hash_u64(k[0]);
-  return agg_hash_u64(k[0] * 0x9E3779B97F4A7C15ULL ^ agg_hash_u64(k[1]));
+  uint64_t h = agg_hash_u64(k[0] * 0x9E3779B97F4A7C15ULL ^ agg_hash_u64(k[1]));
+#pragma unroll
+  for (int w = 2; w < KW; ++w) h = agg_hash_u64(h * 0x9E3779B97F4A7C15ULL ^ agg_hash_u64(k[w]));   // KeysU256: four words
+  return h;
 }
 
 template <int KW>
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(256) void join_copy_kernel(const uint64_t* keys, co
     for (int w = 0; w < KW; ++w) e[w] = keys[i * KW + w];
     const uint64_t v = validity ? (uint64_t)bit_get(validity, i) : 1;
     e[KW] = v << 32;
-    if (KW == 2) e[3] = 0;
+#pragma unroll
+    for (int w = KW + 1; w < ES; ++w) e[w] = 0;
   }
 }
 
@@ -104,7 +108,11 @@ __device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_
     } else {
       const ulonglong2 v0 = *(const ulonglong2*)p;
       eq = v0.x == k[0] && v0.y == k[1];
-      link = p[2];
+      if (KW == 4) {   // KeysU256: a 64-byte entry (4 key words, link, padding) = one 64-byte sector
+        const ulonglong2 v1 = *(const ulonglong2*)(p + 2);
+        eq = eq && v1.x == k[2] && v1.y == k[3];
+      }
+      link = p[KW];
     }
     if (eq) { ++c; *last = e - 1; }
     e = (uint32_t)link;
@@ -156,7 +164,8 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, con
     for (uint32_t e = (uint32_t)head[h >> shift]; e;) {
       const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
       bool eq = p[0] == k[0];
-      if (KW == 2) eq = eq && p[1] == k[1];
+#pragma unroll
+      for (int w = 1; w < KW; ++w) eq = eq && p[w] == k[w];
       if (eq) {
         // insert build row e-1 keeping this probe row's segment ascending (segments are tiny)
         uint32_t b = e - 1, j = m;
@@ -383,7 +392,7 @@ int32_t dbhip_pack_keys(const dbhip_col* cols, int32_t ncols, int64_t n, int32_t
 
 int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, dbhip_join** out_host) {
   DBHIP_REQUIRE(out_host, "dbhip_join_create: NULL out");
-  DBHIP_REQUIRE(key_bytes == 8 || key_bytes == 16, "dbhip_join_create: key width must be 8 or 16 bytes (narrower keys are zero-extended by dbhip_pack_keys)");
+  DBHIP_REQUIRE(key_bytes == 8 || key_bytes == 16 || key_bytes == 32, "dbhip_join_create: key width must be 8, 16 or 32 bytes (narrower keys are zero-extended by dbhip_pack_keys)");
   dbhip_join* j = new (std::nothrow) dbhip_join();
   DBHIP_REQUIRE(j, "dbhip_join_create: out of host memory");
   memset(j, 0, sizeof(*j));
@@ -424,8 +433,10 @@ int32_t dbhip_join_add_build(dbhip_join* j, const void* keys, const uint8_t* val
   uint64_t* dst = j->ent + (size_t)j->nrows * j->es;
   if (j->kw == 1)
     hipLaunchKernelGGL(join_copy_kernel<1>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)keys, validity, n, dst);
-  else
+  else if (j->kw == 2)
     hipLaunchKernelGGL(join_copy_kernel<2>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)keys, validity, n, dst);
+  else
+    hipLaunchKernelGGL(join_copy_kernel<4>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)keys, validity, n, dst);
   DBHIP_LAUNCH_CHECK();
   j->nrows += n;
   return DBHIP_OK;
@@ -443,8 +454,10 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   if (j->nrows) {
     if (j->kw == 1)
       hipLaunchKernelGGL(join_build_kernel<1>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
-    else
+    else if (j->kw == 2)
       hipLaunchKernelGGL(join_build_kernel<2>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
+    else
+      hipLaunchKernelGGL(join_build_kernel<4>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
     DBHIP_LAUNCH_CHECK();
   }
   j->finalized = true;
@@ -462,8 +475,11 @@ static int32_t join_count_block(dbhip_join* j, const void* keys, const uint8_t* 
   if (j->kw == 1)
     hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
                        validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
-  else
+  else if (j->kw == 2)
     hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
+  else
+    hipLaunchKernelGGL(join_count_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
                        validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
   rc = dbscan::exclusive_scan_u32(j->cnt, n, j->blk, j->off, s);
   if (rc) return rc;
@@ -495,8 +511,11 @@ int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* va
   if (j->kw == 1)
     hipLaunchKernelGGL(join_mark_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
                        validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
-  else
+  else if (j->kw == 2)
     hipLaunchKernelGGL(join_mark_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
+                       validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
+  else
+    hipLaunchKernelGGL(join_mark_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
                        validity, n, out_matched_bitmap, (unsigned long long*)j->total_dev);
   DBHIP_LAUNCH_CHECK();
   if (out_n_matched_host) {
@@ -534,8 +553,11 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
     if (j->kw == 1)
       hipLaunchKernelGGL(join_emit_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
                          j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
-    else
+    else if (j->kw == 2)
       hipLaunchKernelGGL(join_emit_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
+                         j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
+    else
+      hipLaunchKernelGGL(join_emit_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
                          j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
     DBHIP_LAUNCH_CHECK();
   }

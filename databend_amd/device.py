@@ -870,7 +870,7 @@ def pack_keys(cols, key_bytes=None, want_validity=True):
 
 class HashJoin:
     """Device hash join on packed fixed keys (dbhip_join_*; trait Join, new_hash_join/join.rs:26-53).
-    key_bytes 8 = KeysU8..U64 (zero-extended), 16 = KeysU128."""
+    key_bytes 8 = KeysU8..U64 (zero-extended), 16 = KeysU128, 32 = KeysU256."""
 
     def __init__(self, expected_build_rows=1024, key_bytes=8):
         _ensure()

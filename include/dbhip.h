@@ -523,7 +523,7 @@ int32_t dbhip_pack_keys(const dbhip_col* cols, int32_t ncols, int64_t n, int32_t
  * immutable in the reference; a caller that recycles a staging buffer must count again). */
 typedef struct dbhip_join dbhip_join;
 int32_t dbhip_join_create(int64_t expected_build_rows, dbhip_join** out_host);  /* 8-byte keys */
-int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, dbhip_join** out_host);
+int32_t dbhip_join_create_keys(int64_t expected_build_rows, int32_t key_bytes, dbhip_join** out_host);  /* 8 / 16 / 32 (KeysU256) */
 int32_t dbhip_join_add_build(dbhip_join* j, const void* keys, const uint8_t* validity,
                              int64_t n, void* stream);
 int32_t dbhip_join_finalize(dbhip_join* j, void* stream);

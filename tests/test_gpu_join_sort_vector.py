@@ -471,3 +471,32 @@ def test_join_kinds_output_assembly(gpu, oracle, kind, nb, np_, card):
     if kind == "left" and rows:
         # matched rows first (probe order), the unmatched probe rows last
         assert np.all(np.diff(got_p[1][:total].astype(np.int64)) >= 0) and np.array_equal(got_p[1][total:], np.nonzero(~matched)[0])
+
+
+@pytest.mark.parametrize("nb,np_,card", [(3000, 9000, 500), (60_000, 150_000, 20_000)])
+def test_join_on_keys_u256(gpu, oracle, nb, np_, card):
+    """Three-column join key (i64, i64, i64 nullable = 25 bytes) -> KeysU256 (method_fixed_keys.rs:58-139, 32-byte packed keys):
+    inner pairs == a dictionary join on the tuples, the matched Bitmap, and a left-anti assembly on top."""
+    rng = np.random.default_rng(nb + 1)
+    bk = [rng.integers(0, card, nb).astype(np.int64) * 7_000_003, rng.integers(-2, 2, nb).astype(np.int64), rng.integers(0, 2, nb).astype(np.int64) << 40]
+    pk = [rng.integers(0, card * 2, np_).astype(np.int64) * 7_000_003, rng.integers(-2, 2, np_).astype(np.int64), rng.integers(0, 2, np_).astype(np.int64) << 40]
+    bv, pv = rng.integers(0, 10, nb) > 0, rng.integers(0, 10, np_) > 0
+    assert gpu.keys_method([gpu.Column.from_numpy(bk[0]), gpu.Column.from_numpy(bk[1]), gpu.Column.from_numpy(bk[2], validity=bv)]) == 32
+    bkeys = gpu.pack_keys([gpu.Column.from_numpy(bk[0]), gpu.Column.from_numpy(bk[1]), gpu.Column.from_numpy(bk[2], validity=bv)], key_bytes=32)
+    pkeys = gpu.pack_keys([gpu.Column.from_numpy(pk[0]), gpu.Column.from_numpy(pk[1]), gpu.Column.from_numpy(pk[2], validity=pv)], key_bytes=32)
+    j = gpu.HashJoin(nb, key_bytes=32)
+    j.add_block(bkeys)
+    j.final_build()
+    gp, gb = j.probe_block(pkeys)
+    by_key = {}
+    for r in range(nb):
+        if bv[r]:
+            by_key.setdefault((int(bk[0][r]), int(bk[1][r]), int(bk[2][r])), []).append(r)
+    exp = [(i, r) for i in range(np_) if pv[i] for r in by_key.get((int(pk[0][i]), int(pk[1][i]), int(pk[2][i])), [])]
+    assert list(zip(gp.tolist(), gb.tolist())) == exp and len(exp) > 100
+    marks = j.probe_mark(pkeys)
+    em = np.zeros(np_, bool)
+    em[[i for i, _ in exp]] = True
+    assert np.array_equal(marks, em)
+    pc, _, rows = j.join("left_anti", pkeys, [gpu.Column.from_numpy(np.arange(np_, dtype=np.uint32))], [])
+    assert rows == int((~em).sum()) and np.array_equal(pc[0].to_numpy(), np.nonzero(~em)[0])
