@@ -829,6 +829,16 @@ void destroy_impl(dbhip_hnsw_impl* h) {
   delete h;
 }
 
+// owns a half-built index: any early return (DBHIP_CHECK, DBHIP_REQUIRE, a validation error) frees the device buffers
+struct ImplGuard {
+  dbhip_hnsw_impl* h;
+  explicit ImplGuard(dbhip_hnsw_impl* p) : h(p) {}
+  ~ImplGuard() { destroy_impl(h); }
+  dbhip_hnsw_impl* release() { dbhip_hnsw_impl* p = h; h = nullptr; return p; }
+  ImplGuard(const ImplGuard&) = delete;
+  ImplGuard& operator=(const ImplGuard&) = delete;
+};
+
 // quantiser + graph storage for `levels`
 int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t distance, int32_t m, const int32_t* levels,
                       hipStream_t s, dbhip_hnsw_impl** out) {
@@ -840,6 +850,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   if (adim > HN_MAX_ADIM) { set_error("dbhip_hnsw: dim > %d", HN_MAX_ADIM); return DBHIP_ERR_UNSUPPORTED; }
   dbhip_hnsw_impl* h = new (std::nothrow) dbhip_hnsw_impl();
   if (!h) return DBHIP_ERR_HIP;
+  ImplGuard guard(h);
   h->n_owned = 0;
   HnswView& V = h->v;
   memset(&V, 0, sizeof(V));
@@ -849,7 +860,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   h->ufirst_host.assign((size_t)n, -1);
   int64_t nu = 0;
   for (int64_t i = 0; i < n; ++i) {
-    if (levels[i] < 0 || levels[i] > 60) { destroy_impl(h); set_error("dbhip_hnsw: bad level"); return DBHIP_ERR_INVALID; }
+    if (levels[i] < 0 || levels[i] > 60) { set_error("dbhip_hnsw: bad level"); return DBHIP_ERR_INVALID; }
     if (levels[i] > 0) { h->ufirst_host[i] = nu; nu += levels[i]; }
   }
   h->n_upper = nu;
@@ -858,8 +869,8 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   const size_t nn = (size_t)(n > 0 ? n : 1);
   if ((rc = own(h, nn * adim, &codes)) || (rc = own(h, nn * 4, &voff)) || (rc = own(h, nn * V.m0 * 4, &l0)) || (rc = own(h, nn * 4, &c0)) ||
       (rc = own(h, (size_t)(nu > 0 ? nu : 1) * m * 4, &lu)) || (rc = own(h, (size_t)(nu > 0 ? nu : 1) * 4, &cu)) || (rc = own(h, nn * 8, &uf)) ||
-      (rc = own(h, nn * 4, &lv)) || (rc = own(h, nn * 4, &rd)) || (rc = own(h, nn * 4, &lk)) || (rc = own(h, 16, &en))) { destroy_impl(h); return rc; }
-  if (dc == D_DOT && (rc = own(h, nn * 4, &vlen))) { destroy_impl(h); return rc; }
+      (rc = own(h, nn * 4, &lv)) || (rc = own(h, nn * 4, &rd)) || (rc = own(h, nn * 4, &lk)) || (rc = own(h, 16, &en))) return rc;
+  if (dc == D_DOT && (rc = own(h, nn * 4, &vlen))) return rc;
   V.codes = (uint8_t*)codes; V.voff = (float*)voff; V.vlen = (float*)vlen; V.links0 = (uint32_t*)l0; V.cnt0 = (uint32_t*)c0;
   V.linksu = (uint32_t*)lu; V.cntu = (uint32_t*)cu; V.ufirst = (int64_t*)uf; V.level = (int32_t*)lv; V.ready = (uint32_t*)rd;
   V.lock = (uint32_t*)lk; V.entry = (unsigned long long*)en;
@@ -896,7 +907,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
                        V.alpha, V.offset, (uint8_t*)codes, (float*)voff);
     DBHIP_LAUNCH_CHECK();
   }
-  *out = h;
+  *out = guard.release();
   return DBHIP_OK;
 }
 
@@ -928,13 +939,14 @@ int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32
   dbhip_hnsw_impl* h = nullptr;
   int32_t rc = create_common(vectors_dev, n, dim, distance, m, levels.data(), s, &h);
   if (rc) return rc;
+  ImplGuard guard(h);
   h->ef_construct = ef_construct;
   if (n > 0) {
     const int grid = search_grid(n);
     uint32_t* vis = nullptr;
     unsigned int* ctl = nullptr;
-    if ((rc = dbhip_alloc((size_t)grid * HN_VCAP * 4, (void**)&vis)) || (rc = dbhip_alloc(16, (void**)&ctl))) { if (vis) dbhip_free(vis); destroy_impl(h); return rc; }
-    auto fail = [&](int32_t code) { dbhip_free(vis); dbhip_free(ctl); destroy_impl(h); return code; };
+    if ((rc = dbhip_alloc((size_t)grid * HN_VCAP * 4, (void**)&vis)) || (rc = dbhip_alloc(16, (void**)&ctl))) { if (vis) dbhip_free(vis); return rc; }
+    auto fail = [&](int32_t code) { dbhip_free(vis); dbhip_free(ctl); return code; };
     if (hipMemsetAsync(ctl, 0, 16, s) != hipSuccess) return fail(DBHIP_ERR_HIP);
     BuildArgs A;
     A.ef_construct = ef_construct; A.vis = vis; A.next = ctl; A.err = ctl + 1;
@@ -960,13 +972,12 @@ int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32
     if (hipMemcpyAsync(hc, ctl, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return fail(DBHIP_ERR_HIP);
     dbhip_free(vis); dbhip_free(ctl);
     if (hc[1]) {
-      destroy_impl(h);
       set_error("dbhip_hnsw_build: a walk outgrew its candidate heap / visited table (flags %u)", hc[1]);
       return DBHIP_ERR_CAPACITY;
     }
   }
   h->v.raw = nullptr;   // the caller's vectors are not kept (search uses the codes)
-  *out = (dbhip_hnsw*)h;
+  *out = (dbhip_hnsw*)guard.release();
   return DBHIP_OK;
 }
 
@@ -978,16 +989,17 @@ int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, 
   dbhip_hnsw_impl* h = nullptr;
   int32_t rc = create_common(vectors_dev, n, dim, distance, m, levels_host, s, &h);
   if (rc) return rc;
+  ImplGuard guard(h);
   const int m0 = 2 * m;
   std::vector<uint32_t> l0((size_t)n * m0, 0), c0((size_t)n, 0), lu((size_t)h->n_upper * m, 0), cu((size_t)h->n_upper, 0), rd((size_t)n, 1);
   int64_t list = 0, off = 0;
   for (int64_t p = 0; p < n; ++p)
     for (int lv = 0; lv <= levels_host[p]; ++lv, ++list) {
       const int c = nlinks_host[list];
-      if (c < 0 || c > (lv == 0 ? m0 : m)) { destroy_impl(h); set_error("dbhip_hnsw_from_graph: a list longer than m / m0"); return DBHIP_ERR_INVALID; }
+      if (c < 0 || c > (lv == 0 ? m0 : m)) { set_error("dbhip_hnsw_from_graph: a list longer than m / m0"); return DBHIP_ERR_INVALID; }
       for (int i = 0; i < c; ++i) {
         const uint32_t x = links_host[off + i];
-        if (x >= (uint64_t)n || levels_host[x] < lv) { destroy_impl(h); set_error("dbhip_hnsw_from_graph: link out of range or to a point below the list's level"); return DBHIP_ERR_INVALID; }
+        if (x >= (uint64_t)n || levels_host[x] < lv) { set_error("dbhip_hnsw_from_graph: link out of range or to a point below the list's level"); return DBHIP_ERR_INVALID; }
         if (lv == 0) l0[(size_t)p * m0 + i] = x;
         else lu[(size_t)(h->ufirst_host[p] + lv - 1) * m + i] = x;
       }
@@ -1002,14 +1014,14 @@ int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, 
       DBHIP_CHECK(hipMemcpyAsync(h->v.cntu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice, s));
     }
     DBHIP_CHECK(hipMemcpyAsync(h->v.ready, rd.data(), rd.size() * 4, hipMemcpyHostToDevice, s));
-    if (entry_point >= (uint64_t)n || entry_level < 0 || entry_level > levels_host[entry_point]) { destroy_impl(h); set_error("dbhip_hnsw_from_graph: bad entry point"); return DBHIP_ERR_INVALID; }
+    if (entry_point >= (uint64_t)n || entry_level < 0 || entry_level > levels_host[entry_point]) { set_error("dbhip_hnsw_from_graph: bad entry point"); return DBHIP_ERR_INVALID; }
     const unsigned long long ent = ((unsigned long long)(entry_level + 1) << 32) | (unsigned long long)(~entry_point);
     DBHIP_CHECK(hipMemcpyAsync(h->v.entry, &ent, 8, hipMemcpyHostToDevice, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
   }
   h->v.raw = nullptr;
   h->ef_construct = 0;
-  *out = (dbhip_hnsw*)h;
+  *out = (dbhip_hnsw*)guard.release();
   return DBHIP_OK;
 }
 

@@ -1059,6 +1059,106 @@ class InnerHashJoin : public Join {
   std::vector<DataBlock> chunks_;
 };
 
+// Left-outer / left-semi / left-anti joins on one u64/i64 key, no other conjunct (memory/left_join.rs:185-260,
+// left_join_semi.rs, left_join_anti.rs): the matched Bitmap (dbhip_join_probe_mark) selects the semi / anti rows; the outer
+// join emits the matched pairs with the build columns wrapped in a true validity and then ONE block of the unmatched probe rows
+// with a null build block (dbhip_take_outer with row id 0xFFFFFFFF).
+enum class LeftJoinKind { Outer, Semi, Anti };
+class LeftHashJoin : public Join {
+ public:
+  LeftHashJoin(LeftJoinKind kind, size_t build_key, size_t probe_key) : kind_(kind), bk_(build_key), pk_(probe_key) { check(dbhip_join_create(1024, &h_)); }
+  ~LeftHashJoin() override { if (h_) dbhip_join_destroy(h_); }
+  void add_block(std::optional<DataBlock> data) override {
+    if (!data) return;
+    if (!chunks_.empty()) throw ErrorCode::Unimplemented("LeftHashJoin host mirror keeps one build chunk (concat the build side first)");
+    const Column& k = data->get_by_offset(bk_);
+    check(dbhip_join_add_build(h_, (const uint64_t*)k.data->ptr(), k.validity ? (const uint8_t*)k.validity->ptr() : nullptr, k.len, nullptr));
+    chunks_.push_back(std::move(*data));
+  }
+  void final_build() override { check(dbhip_join_finalize(h_, nullptr)); }
+  std::unique_ptr<JoinStream> probe_block(DataBlock data) override {
+    const Column& k = data.get_by_offset(pk_);
+    const uint8_t* v = k.validity ? (const uint8_t*)k.validity->ptr() : nullptr;
+    const int64_t n = k.len;
+    // matched Bitmap -> the rows of the semi / anti result, or the unmatched tail of the outer result
+    Column matched; matched.type = DataType::of(DBHIP_T_BOOL); matched.len = n;
+    matched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64); matched.data->fill(0);
+    uint64_t nm = 0;
+    check(dbhip_join_probe_mark(h_, (const uint64_t*)k.data->ptr(), v, n, (uint8_t*)matched.data->ptr(), &nm, nullptr));
+    if (kind_ == LeftJoinKind::Semi) {
+      Selection s = filter_select(matched);
+      return std::make_unique<Once>(take_block(data, s.sel, s.count));
+    }
+    Column unmatched = matched;
+    unmatched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64);
+    {  // NOT matched: Boolean equality with a false constant, like the reference's `not`
+      Column f = Column::from_bools(std::vector<bool>{false});
+      dbhip_col a = matched.c(), b = f.c();
+      b.is_scalar = 1;
+      check(dbhip_cmp(DBHIP_CMP_EQ, &a, &b, n, (uint8_t*)unmatched.data->ptr(), nullptr));
+    }
+    Selection us = filter_select(unmatched);
+    if (kind_ == LeftJoinKind::Anti) return std::make_unique<Once>(take_block(data, us.sel, us.count));
+    uint64_t total = 0, got = 0;
+    check(dbhip_join_probe_count(h_, (const uint64_t*)k.data->ptr(), v, n, &total, nullptr));
+    const int64_t rows = (int64_t)total + us.count;
+    Buf pi = make_buf((size_t)rows * 4 + 64), bi = make_buf((size_t)rows * 4 + 64);
+    check(dbhip_join_probe(h_, (const uint64_t*)k.data->ptr(), v, n, (uint32_t*)pi->ptr(), (uint32_t*)bi->ptr(), (int64_t)total, &got, nullptr));
+    check(dbhip_memcpy_d2d((uint32_t*)pi->ptr() + total, us.sel->ptr(), (size_t)us.count * 4, nullptr));
+    check(dbhip_memset((uint32_t*)bi->ptr() + total, 0xFF, (size_t)us.count * 4, nullptr));
+    DataBlock out = take_block(data, pi, rows);
+    if (!chunks_.empty())
+      for (const Column& c : chunks_[0].columns) {
+        Column r; r.type = c.type; r.type.nullable = true; r.len = rows;
+        const size_t es = c.type.elem_size();
+        if (c.type.id == DBHIP_T_BOOL || (es != 1 && es != 2 && es != 4 && es != 8 && es != 16)) throw ErrorCode::Unimplemented("outer join build column " + c.type.name());
+        r.data = make_buf((size_t)rows * es + 64);
+        r.validity = make_buf((size_t)(rows + 63) / 64 * 8 + 8);
+        check(dbhip_take_outer(c.data->ptr(), c.validity ? (const uint8_t*)c.validity->ptr() : nullptr, 0, (int32_t)es, (const uint32_t*)bi->ptr(), rows,
+                               r.data->ptr(), (uint8_t*)r.validity->ptr(), nullptr));
+        out.columns.push_back(r);
+      }
+    return std::make_unique<Once>(std::move(out));
+  }
+ private:
+  struct Once : JoinStream {
+    std::optional<DataBlock> b;
+    explicit Once(DataBlock x) : b(std::move(x)) {}
+    std::optional<DataBlock> next() override { auto r = std::move(b); b.reset(); return r; }
+  };
+  LeftJoinKind kind_;
+  size_t bk_, pk_;
+  dbhip_join* h_ = nullptr;
+  std::vector<DataBlock> chunks_;
+};
+
+// ---- HNSW vector index (hnsw_index/hnsw.rs:62-315) ------------------------------------------------------------------
+class HNSWIndex {
+ public:
+  // HNSWIndex::build (hnsw.rs:142-305): `column` = Vector(dim) of Float32; distance: DBHIP_VEC_COSINE / L1 / L2
+  static HNSWIndex build(size_t m, size_t ef_construct, const Column& column, int32_t distance, uint64_t seed = 1) {
+    HNSWIndex ix;
+    ix.dim_ = column.type.dim;
+    check(dbhip_hnsw_build((const float*)column.data->ptr(), column.len, (int32_t)ix.dim_, distance, (int32_t)m, (int32_t)ef_construct, seed, &ix.h_, nullptr));
+    return ix;
+  }
+  HNSWIndex(HNSWIndex&& o) noexcept : h_(o.h_), dim_(o.dim_) { o.h_ = nullptr; }
+  HNSWIndex(const HNSWIndex&) = delete;
+  ~HNSWIndex() { if (h_) dbhip_hnsw_destroy(h_); }
+  // HNSWIndex::search (hnsw.rs:100-118), ef = 4 * limit inside: -> (row ids u32 [nq][limit], distances f32 [nq][limit])
+  std::pair<std::vector<uint32_t>, std::vector<float>> search(size_t limit, const Column& queries) const {
+    Buf ids = make_buf((size_t)queries.len * limit * 4 + 16), dist = make_buf((size_t)queries.len * limit * 4 + 16);
+    check(dbhip_hnsw_search(h_, (const float*)queries.data->ptr(), (int32_t)queries.len, (int32_t)limit, (uint32_t*)ids->ptr(), (float*)dist->ptr(), nullptr));
+    std::vector<uint32_t> i((size_t)queries.len * limit); std::vector<float> d(i.size());
+    ids->download(i.data(), i.size() * 4); dist->download(d.data(), d.size() * 4);
+    return {i, d};
+  }
+ private:
+  HNSWIndex() = default;
+  dbhip_hnsw* h_ = nullptr;
+  size_t dim_ = 0;
+};
+
 // ---- sort (kernels/sort.rs:91-113) -----------------------------------------------------------------
 struct SortColumnDescription { size_t offset; bool asc = true; bool nulls_first = false; };
 

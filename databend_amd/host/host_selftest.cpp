@@ -244,6 +244,68 @@ static void test_join_and_sort() {
   CHECK(ok);
 }
 
+static void test_left_joins() {
+  const int64_t nb = 5000, np = 20000;
+  std::mt19937_64 rng(9);
+  std::vector<uint64_t> bk(nb), pk(np); std::vector<int64_t> bv(nb), pv(np);
+  for (int64_t i = 0; i < nb; ++i) { bk[i] = rng() % 4000; bv[i] = i * 7 + 1; }
+  for (int64_t i = 0; i < np; ++i) { pk[i] = rng() % 8000; pv[i] = i; }
+  auto U64 = DataType::of(DBHIP_T_U64); auto I64 = DataType::of(DBHIP_T_I64);
+  std::multimap<uint64_t, int64_t> bm;
+  for (int64_t i = 0; i < nb; ++i) bm.insert({bk[i], bv[i]});
+  for (LeftJoinKind kind : {LeftJoinKind::Outer, LeftJoinKind::Semi, LeftJoinKind::Anti}) {
+    LeftHashJoin join(kind, 0, 0);
+    join.add_block(DataBlock({Column::from_vector(U64, bk), Column::from_vector(I64, bv)}, nb));
+    join.final_build();
+    auto stream = join.probe_block(DataBlock({Column::from_vector(U64, pk), Column::from_vector(I64, pv)}, np));
+    auto b = stream->next();
+    CHECK(b.has_value() && !stream->next().has_value());
+    auto k1 = b->columns[0].to_vector<uint64_t>(); auto v1 = b->columns[1].to_vector<int64_t>();
+    if (kind != LeftJoinKind::Outer) {
+      CHECK(b->num_columns() == 2);
+      std::vector<int64_t> exp;
+      for (int64_t i = 0; i < np; ++i) if ((bm.count(pk[i]) > 0) == (kind == LeftJoinKind::Semi)) exp.push_back(pv[i]);
+      CHECK(v1 == exp);
+      continue;
+    }
+    CHECK(b->num_columns() == 4 && b->columns[3].type.nullable && b->columns[3].validity);
+    auto v2 = b->columns[3].to_vector<int64_t>();
+    std::vector<uint8_t> vb((size_t)(b->num_rows + 7) / 8);
+    b->columns[3].validity->download(vb.data(), vb.size());
+    std::multiset<std::tuple<uint64_t, int64_t, int64_t>> got, exp;   // build value -1 = NULL
+    for (size_t i = 0; i < k1.size(); ++i) got.insert({k1[i], v1[i], ((vb[i >> 3] >> (i & 7)) & 1) ? v2[i] : -1});
+    for (int64_t i = 0; i < np; ++i) {
+      auto r = bm.equal_range(pk[i]);
+      if (r.first == r.second) exp.insert({pk[i], pv[i], -1});
+      for (auto it = r.first; it != r.second; ++it) exp.insert({pk[i], pv[i], it->second});
+    }
+    CHECK(got == exp);
+  }
+}
+
+static void test_hnsw_index() {
+  // HNSWIndex::build + search (m = 10, ef_construct = 40, ef = 4 k): every vector finds itself, distances ascend
+  const int dim = 16; const int64_t n = 3000;
+  std::mt19937 rng(4);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<float> base((size_t)n * dim);
+  for (auto& x : base) x = nd(rng);
+  Column col = Column::from_vector(DataType::Vector(dim), base);
+  col.len = n;
+  HNSWIndex ix = HNSWIndex::build(10, 40, col, DBHIP_VEC_L2);
+  std::vector<float> q(base.begin(), base.begin() + 64 * dim);
+  Column qc = Column::from_vector(DataType::Vector(dim), q);
+  qc.len = 64;
+  auto r = ix.search(5, qc);
+  int self = 0;
+  bool ascending = true;
+  for (int i = 0; i < 64; ++i) {
+    self += r.first[(size_t)i * 5] == (uint32_t)i;
+    for (int j = 1; j < 5; ++j) ascending &= r.second[(size_t)i * 5 + j] >= r.second[(size_t)i * 5 + j - 1];
+  }
+  CHECK(self >= 60 && ascending);
+}
+
 static void test_vector_function() {
   const int dim = 8; const int64_t n = 16;
   std::mt19937 rng(8);
@@ -307,6 +369,8 @@ int main() {
     test_filter();
     test_q1_plan();
     test_join_and_sort();
+    test_left_joins();
+    test_hnsw_index();
     test_vector_function();
     test_parquet_chunk();
   } catch (const std::exception& e) {
