@@ -812,405 +812,6 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
   }
 }
 
-// ---------------------------------------------------------------------------
-// v3: 128(q) x 64(i) WAVE tiles (4 waves, 2 x 2, over the same 256 x 128 block tile). A 64 x 64 wave tile reads one
-// 16-byte operand per MFMA from LDS; with 4 A fragments and 2 B fragments feeding 8 MFMAs it is 0.75, and a wave
-// spends twice as long in the matrix pipe between two barriers. Register staged like v1 (8 + 4 x 16 B per thread).
-// ---------------------------------------------------------------------------
-template <bool COSINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bf16_filter_kernel_v3(HArgs A) {
-  constexpr int TQ = 256, TI = 128, MQ = 4, MI = 2;
-  __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
-  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
-
-  const int64_t slot = blockIdx.x >> 3;
-  const int xcd = blockIdx.x & 7;
-  const int qt = (int)(slot % A.n_qtiles);
-  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
-  if (it >= A.n_itiles) return;
-  const int64_t i0 = it * TI;
-  const int q0 = qt * TQ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wq = (wave >> 1) * 128, wi = (wave & 1) * 64;
-  const int dpad = A.dpad;
-
-  f32x16 acc[MQ][MI];
-#pragma unroll
-  for (int a = 0; a < MQ; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int kc = (tid & 7) * 8;
-  const int r0 = tid >> 3;  // 0..31
-  const uint16_t* atile = A.queries + (int64_t)q0 * dpad;
-  const uint16_t* btile = A.base + i0 * dpad;
-  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
-  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
-  uint32_t aoff[8], boff[4];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) aoff[j] = (uint32_t)(r0 + 32 * j < alast ? r0 + 32 * j : alast) * (uint32_t)dpad + kc;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) boff[j] = (uint32_t)(r0 + 32 * j < blast ? r0 + 32 * j : blast) * (uint32_t)dpad + kc;
-  u32x4 ra[8], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ra[j] = *(const u32x4*)(atile + aoff[j] + k0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = *(const u32x4*)(btile + boff[j] + k0);
-  };
-  auto lds_store = [&]() {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *(u32x4*)(As + (r0 + 32 * j) * HLD + kc) = ra[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *(u32x4*)(Bs + (r0 + 32 * j) * HLD + kc) = rb[j];
-  };
-
-  gload(0);
-  for (int k0 = 0; k0 < dpad; k0 += HBK) {
-    __syncthreads();
-    lds_store();
-    __syncthreads();
-    if (k0 + HBK < dpad) gload(k0 + HBK);
-#pragma unroll
-    for (int kk = 0; kk < HBK; kk += 16) {
-      const int kl = kk + (lane >> 5) * 8;
-      bf16x8 fa[MQ], fb[MI];
-#pragma unroll
-      for (int x = 0; x < MQ; ++x) fa[x] = __builtin_bit_cast(bf16x8, *(const u32x4*)(As + (wq + x * 32 + (lane & 31)) * HLD + kl));
-#pragma unroll
-      for (int y = 0; y < MI; ++y) fb[y] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Bs + (wi + y * 32 + (lane & 31)) * HLD + kl));
-#pragma unroll
-      for (int x = 0; x < MQ; ++x)
-#pragma unroll
-        for (int y = 0; y < MI; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[y], acc[x][y], 0, 0, 0);
-    }
-  }
-
-  if (tid < TI) {
-    const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
-    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
-  }
-  {
-    const int t = tid;  // 256 threads <-> 256 queries
-    const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
-    const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
-    const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
-    qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
-    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
-  }
-  __syncthreads();
-
-#pragma unroll
-  for (int x = 0; x < MQ; ++x) {
-    float cB[16], cG[16], cT[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int qb = wq + x * 32 + 8 * j + 4 * (lane >> 5);
-      const float4 vb = *(const float4*)(qB + qb), vg = *(const float4*)(qG + qb), vt = *(const float4*)(Tau + qb);
-      cB[4 * j + 0] = vb.x; cB[4 * j + 1] = vb.y; cB[4 * j + 2] = vb.z; cB[4 * j + 3] = vb.w;
-      cG[4 * j + 0] = vg.x; cG[4 * j + 1] = vg.y; cG[4 * j + 2] = vg.z; cG[4 * j + 3] = vg.w;
-      cT[4 * j + 0] = vt.x; cT[4 * j + 1] = vt.y; cT[4 * j + 2] = vt.z; cT[4 * j + 3] = vt.w;
-    }
-#pragma unroll
-    for (int y = 0; y < MI; ++y) {
-      const int il = wi + y * 32 + (lane & 31);
-      const int64_t i = i0 + il;
-      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
-      const bool row_ok = i < A.n;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
-        if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
-          const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (q < A.nq) {
-            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
-            if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// v4: 256(q) x 256(i) block tile, 8 waves of 128 x 64. v1 / v2 / v3 all land on ~810 TF although they differ in
-// staging (registers vs LDS-DMA), ring depth and wave tile: what they share is the bytes a CU pulls through its
-// vector memory path per unit of matrix work — a 256 x 128 tile needs 48 KiB per k-step for 1024 SIMD-cycles of MFMA,
-// i.e. ~75 % of the 64 B/clk/CU the TA/L1 path delivers with two workgroups per CU. The square tile halves that.
-// ---------------------------------------------------------------------------
-template <bool COSINE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void bf16_filter_kernel_v4(HArgs A) {
-  constexpr int TQ = 256, TI = 256, MQ = 4, MI = 2;
-  __shared__ __attribute__((aligned(16))) uint16_t As[TQ * HLD];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[TI * HLD];
-  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
-
-  const int64_t slot = blockIdx.x >> 3;
-  const int xcd = blockIdx.x & 7;
-  const int qt = (int)(slot % A.n_qtiles);
-  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
-  if (it >= A.n_itiles) return;
-  const int64_t i0 = it * TI;
-  const int q0 = qt * TQ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wq = (wave >> 2) * 128, wi = (wave & 3) * 64;
-  const int dpad = A.dpad;
-
-  f32x16 acc[MQ][MI];
-#pragma unroll
-  for (int a = 0; a < MQ; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int kc = (tid & 7) * 8;
-  const int r0 = tid >> 3;  // 0..63
-  const uint16_t* atile = A.queries + (int64_t)q0 * dpad;
-  const uint16_t* btile = A.base + i0 * dpad;
-  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
-  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
-  uint32_t aoff[4], boff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(r0 + 64 * j < alast ? r0 + 64 * j : alast) * (uint32_t)dpad + kc;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) boff[j] = (uint32_t)(r0 + 64 * j < blast ? r0 + 64 * j : blast) * (uint32_t)dpad + kc;
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = *(const u32x4*)(atile + aoff[j] + k0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = *(const u32x4*)(btile + boff[j] + k0);
-  };
-  auto lds_store = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *(u32x4*)(As + (r0 + 64 * j) * HLD + kc) = ra[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *(u32x4*)(Bs + (r0 + 64 * j) * HLD + kc) = rb[j];
-  };
-
-  gload(0);
-  for (int k0 = 0; k0 < dpad; k0 += HBK) {
-    __syncthreads();
-    lds_store();
-    __syncthreads();
-    if (k0 + HBK < dpad) gload(k0 + HBK);
-#pragma unroll
-    for (int kk = 0; kk < HBK; kk += 16) {
-      const int kl = kk + (lane >> 5) * 8;
-      bf16x8 fa[MQ], fb[MI];
-#pragma unroll
-      for (int x = 0; x < MQ; ++x) fa[x] = __builtin_bit_cast(bf16x8, *(const u32x4*)(As + (wq + x * 32 + (lane & 31)) * HLD + kl));
-#pragma unroll
-      for (int y = 0; y < MI; ++y) fb[y] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Bs + (wi + y * 32 + (lane & 31)) * HLD + kl));
-#pragma unroll
-      for (int x = 0; x < MQ; ++x)
-#pragma unroll
-        for (int y = 0; y < MI; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[y], acc[x][y], 0, 0, 0);
-    }
-  }
-
-  if (tid < TI) {
-    const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
-    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
-  }
-  if (tid >= 256) {
-    const int t = tid - 256;  // threads 256..511 <-> 256 queries
-    const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
-    const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
-    const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
-    qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
-    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
-  }
-  __syncthreads();
-
-#pragma unroll
-  for (int x = 0; x < MQ; ++x) {
-    float cB[16], cG[16], cT[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int qb = wq + x * 32 + 8 * j + 4 * (lane >> 5);
-      const float4 vb = *(const float4*)(qB + qb), vg = *(const float4*)(qG + qb), vt = *(const float4*)(Tau + qb);
-      cB[4 * j + 0] = vb.x; cB[4 * j + 1] = vb.y; cB[4 * j + 2] = vb.z; cB[4 * j + 3] = vb.w;
-      cG[4 * j + 0] = vg.x; cG[4 * j + 1] = vg.y; cG[4 * j + 2] = vg.z; cG[4 * j + 3] = vg.w;
-      cT[4 * j + 0] = vt.x; cT[4 * j + 1] = vt.y; cT[4 * j + 2] = vt.z; cT[4 * j + 3] = vt.w;
-    }
-#pragma unroll
-    for (int y = 0; y < MI; ++y) {
-      const int il = wi + y * 32 + (lane & 31);
-      const int64_t i = i0 + il;
-      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
-      const bool row_ok = i < A.n;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
-        if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
-          const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (q < A.nq) {
-            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
-            if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// v2 of the filter kernel: the register staging (global -> VGPR -> ds_write_b128) is replaced by LDS-DMA
-// (`global_load_lds_dwordx4`: 64 lanes x 16 B land in 1 KiB of LDS straight from L2/HBM, no VGPRs, no ds_write pass —
-// the v1 PMC profile has the waves parked 39 % of the time and the LDS write path is what the tile's 48 KiB per
-// k-step are bound by) into a three-stage LDS ring: the DMA of k-tiles t+1 and t+2 is in flight while the matrix pipe
-// works on k-tile t. An LDS-DMA image is lane-linear (dest = base + lane x 16), so rows are NOT padded; bank conflicts of the
-// operand reads are removed with an XOR swizzle instead — slot (row r, 16-B slot t) holds k-piece t ^ ((r >> 1) & 7),
-// applied to the per-lane SOURCE address and to the ds_read_b128 address alike (for the 16 lanes of a ds_read_b128
-// group, (r & 1) * 8 + (p ^ ((r >> 1) & 7)) takes 16 distinct values). The asm loads are invisible to hipcc's waitcnt
-// bookkeeping: every stage is completed with an explicit `s_waitcnt vmcnt(0)` before the barrier that publishes it.
-// 256(q) x 128(i) tile, 8 waves of 64 x 64, k-steps of 32 (three 24 KiB stages), two workgroups per CU.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-template <bool COSINE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void bf16_filter_kernel_v2(HArgs A) {
-  constexpr int TQ = 256, TI = 128;
-  constexpr int KB = 32;                       // bf16 elements per k-step: 64 B per row, 4 pieces of 16 B
-  constexpr int A_BYTES = TQ * 64, B_BYTES = TI * 64, STAGE = A_BYTES + B_BYTES;  // 24 KiB per stage
-  constexpr int NSTAGE = 3;                    // two k-steps of DMA in flight behind the one being multiplied
-  __shared__ __attribute__((aligned(1024))) uint8_t ring[NSTAGE * STAGE];        // 72 KiB: two workgroups per CU
-  __shared__ __attribute__((aligned(16))) float rA[TI], rX[TI], rY[TI], qB[TQ], qG[TQ], Tau[TQ];
-
-  const int64_t slot = blockIdx.x >> 3;
-  const int xcd = blockIdx.x & 7;
-  const int qt = (int)(slot % A.n_qtiles);
-  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
-  if (it >= A.n_itiles) return;
-  const int64_t i0 = it * TI;
-  const int q0 = qt * TQ;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = (wave >> 1) * 64, wi = (wave & 1) * 64;
-  const int dpad = A.dpad;
-  const uint32_t ring_base = (uint32_t)(uintptr_t)ring;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // DMA plan: a wave-instruction fills one 16-row x 64-B sub-block (1 KiB): lane l -> row (l >> 2), slot (l & 3).
-  // A: 16 sub-blocks (wave w issues w and w + 8), B: 8 sub-blocks (wave w issues w). Slot t of row r holds k-piece
-  // t ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots.
-  const uint8_t* atile = (const uint8_t*)(A.queries + (int64_t)q0 * dpad);
-  const uint8_t* btile = (const uint8_t*)(A.base + i0 * dpad);
-  const int alast = (A.nq - q0 < TQ ? A.nq - q0 : TQ) - 1;
-  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
-  const uint8_t* asrc[2];
-  const uint8_t* bsrc;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (wave + 8 * j) * 16 + (lane >> 2);
-    const int piece = (lane & 3) ^ ((r >> 2) & 3);
-    asrc[j] = atile + (int64_t)(r < alast ? r : alast) * dpad * 2 + piece * 16;
-  }
-  {
-    const int r = wave * 16 + (lane >> 2);
-    const int piece = (lane & 3) ^ ((r >> 2) & 3);
-    bsrc = btile + (int64_t)(r < blast ? r : blast) * dpad * 2 + piece * 16;
-  }
-  auto issue = [&](int k0, int stage) {
-    const uint32_t sa = ring_base + stage * STAGE, sb = sa + A_BYTES;
-    glds16(asrc[0] + k0 * 2, sa + (uint32_t)wave * 1024u);
-    glds16(asrc[1] + k0 * 2, sa + (uint32_t)(wave + 8) * 1024u);
-    glds16(bsrc + k0 * 2, sb + (uint32_t)wave * 1024u);
-  };
-
-  const int ar0 = wq + (lane & 31), ar1 = ar0 + 32, br0 = wi + (lane & 31), br1 = br0 + 32;
-  const int hi = lane >> 5;
-
-  issue(0, 0);
-  if (KB < dpad) issue(KB, 1);
-  int stage = 0;
-  for (int k0 = 0; k0 < dpad; k0 += KB) {
-    // every wave issues exactly 3 DMA instructions per stage and nothing else on vmcnt inside the loop: "at most 3
-    // outstanding" == this wave's share of the CURRENT stage has landed, the next stage may still be in flight
-    if (k0 + KB < dpad) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // ... and everybody else's share; nobody still reads the stage that is refilled next
-    if (k0 + 2 * KB < dpad) issue(k0 + 2 * KB, stage == 0 ? 2 : stage - 1);  // (stage + 2) % 3
-    const uint8_t* sa = ring + stage * STAGE;
-    const uint8_t* sb = sa + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int piece = kk * 2 + hi;
-      const u32x4 a0 = *(const u32x4*)(sa + ar0 * 64 + ((piece ^ ((ar0 >> 2) & 3)) * 16));
-      const u32x4 a1 = *(const u32x4*)(sa + ar1 * 64 + ((piece ^ ((ar1 >> 2) & 3)) * 16));
-      const u32x4 b0 = *(const u32x4*)(sb + br0 * 64 + ((piece ^ ((br0 >> 2) & 3)) * 16));
-      const u32x4 b1 = *(const u32x4*)(sb + br1 * 64 + ((piece ^ ((br1 >> 2) & 3)) * 16));
-      const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0), fa1 = __builtin_bit_cast(bf16x8, a1);
-      const bf16x8 fb0 = __builtin_bit_cast(bf16x8, b0), fb1 = __builtin_bit_cast(bf16x8, b1);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
-    }
-    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-  }
-
-  if (tid < TI) {
-    const int64_t i = i0 + tid < A.n ? i0 + tid : A.n - 1;
-    rA[tid] = COSINE ? A.rowA[i] : -1.0f; rX[tid] = A.rowX[i]; rY[tid] = A.rowY[i];
-  } else if (tid < TI + TQ) {
-    const int t = tid - TI;
-    const int q = q0 + t < A.nq ? q0 + t : A.nq - 1;
-    const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
-    const float tau = (q0 + t < A.nq) ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
-    qB[t] = e_ + A.c * h_; qG[t] = h_ + e_;
-    Tau[t] = COSINE ? (1.0f - tau) * n_ : -tau;
-  }
-  __syncthreads();
-
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    float cB[16], cG[16], cT[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int qb = wq + x * 32 + 8 * j + 4 * (lane >> 5);
-      const float4 vb = *(const float4*)(qB + qb), vg = *(const float4*)(qG + qb), vt = *(const float4*)(Tau + qb);
-      cB[4 * j + 0] = vb.x; cB[4 * j + 1] = vb.y; cB[4 * j + 2] = vb.z; cB[4 * j + 3] = vb.w;
-      cG[4 * j + 0] = vg.x; cG[4 * j + 1] = vg.y; cG[4 * j + 2] = vg.z; cG[4 * j + 3] = vg.w;
-      cT[4 * j + 0] = vt.x; cT[4 * j + 1] = vt.y; cT[4 * j + 2] = vt.z; cT[4 * j + 3] = vt.w;
-    }
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int il = wi + y * 32 + (lane & 31);
-      const int64_t i = i0 + il;
-      const float a_ = rA[il], x_ = rX[il], y_ = rY[il];
-      const bool row_ok = i < A.n;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float f = fmaf(acc[x][y][r], a_, fmaf(x_, cB[r], y_ * cG[r]));
-        if (!(f < cT[r]) && row_ok) {  // NaN bounds stay in the race
-          const int q = q0 + wq + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (q < A.nq) {
-            const uint32_t s = atomicAdd(&A.cand_cnt[q], 1u);
-            if (s < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + s] = A.row_origin + (uint32_t)i;
-          }
-        }
-      }
-    }
-  }
-}
-
 // One wave per row: out[row][0..dpad) = bf16(x[row]) (RNE, zero padded) and the row's coefficients.
 //   mode 0 (base rows, cosine): A = 1/||b||, X = ||bh||/||b|| (1+1e-4), Y = ||b-bh||/||b|| (1+1e-4)
 //   mode 1 (base rows, dot)   : A = 1,       X = ||bh|| (1+1e-4),       Y = ||b-bh|| (1+1e-4)
@@ -1331,21 +932,9 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.c = (float)dim * 1.1920929e-07f + 2e-4f;
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
-    static const int kernel_version = getenv("DBHIP_BF16_V") ? atoi(getenv("DBHIP_BF16_V")) : 1;
-    if (l2) {  // (the experimental variants below cover cosine / dot only)
+    if (l2) {
       if (tall) hipLaunchKernelGGL((bf16_filter_kernel<2, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
       else hipLaunchKernelGGL((bf16_filter_kernel<2, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
-    } else if (tall && kernel_version == 4) {
-      A.n_itiles = ceil_div(A.n, 256);
-      const int64_t blocks4 = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
-      if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v4<true>, dim3((unsigned)blocks4), dim3(512), 0, s, A);
-      else hipLaunchKernelGGL(bf16_filter_kernel_v4<false>, dim3((unsigned)blocks4), dim3(512), 0, s, A);
-    } else if (tall && kernel_version == 3) {
-      if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v3<true>, dim3((unsigned)blocks), dim3(256), 0, s, A);
-      else hipLaunchKernelGGL(bf16_filter_kernel_v3<false>, dim3((unsigned)blocks), dim3(256), 0, s, A);
-    } else if (tall && kernel_version == 2) {
-      if (cosine) hipLaunchKernelGGL(bf16_filter_kernel_v2<true>, dim3((unsigned)blocks), dim3(512), 0, s, A);
-      else hipLaunchKernelGGL(bf16_filter_kernel_v2<false>, dim3((unsigned)blocks), dim3(512), 0, s, A);
     } else if (tall) {
       if (cosine) hipLaunchKernelGGL((bf16_filter_kernel<0, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
       else hipLaunchKernelGGL((bf16_filter_kernel<1, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the generic fused filter->map->aggregate kernel (tpch.q1_fused_program) next to the query-specific fused kernel on
-an SF10-sized lineitem (profiling driver for tools/gpu_r02d.sh)."""
+an SF10-sized lineitem (profiling driver: tools/gpu_run.sh <tag> py:tools/prof_fagg.py)."""
 import ctypes as C
 import json
 import os
