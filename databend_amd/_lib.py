@@ -16,7 +16,7 @@ class DbhipError(RuntimeError):
 OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ROW_ERRORS, ERR_OVERFLOW, ERR_CAPACITY, ERR_UNSUPPORTED = range(8)
 
 # dbhip_type
-T_BOOL, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F32, T_F64, T_DATE, T_TIMESTAMP, T_DEC64, T_DEC128, T_STRING = range(1, 17)
+T_BOOL, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F32, T_F64, T_DATE, T_TIMESTAMP, T_DEC64, T_DEC128, T_STRING, T_DEC256 = range(1, 18)
 OP_PLUS, OP_MINUS, OP_MULTIPLY, OP_DIVIDE, OP_INTDIV, OP_MODULO, OP_DIV0, OP_DIVNULL = range(8)
 CMP_EQ, CMP_NOTEQ, CMP_LT, CMP_LTE, CMP_GT, CMP_GTE = range(6)
 AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = range(4)

@@ -383,7 +383,7 @@ static i128 i256_low128(i256 a) { return (i128)(((u128)a.w[1] << 64) | a.w[0]); 
 typedef struct { int p, s; } dsize;
 static int dec_props(int type, int p, int s, dsize* o) {
   switch (type) {
-    case ORC_T_DEC64: case ORC_T_DEC128: o->p = p; o->s = s; return 1;
+    case ORC_T_DEC64: case ORC_T_DEC128: case ORC_T_DEC256: o->p = p; o->s = s; return 1;
     case ORC_T_I8: case ORC_T_U8: o->p = 3; o->s = 0; return 1; /* number.rs:452-465 */
     case ORC_T_I16: case ORC_T_U16: o->p = 5; o->s = 0; return 1;
     case ORC_T_I32: case ORC_T_U32: o->p = 10; o->s = 0; return 1;
@@ -403,7 +403,7 @@ static int result_size(int op, dsize a, dsize b, dsize* l, dsize* r, dsize* ret)
     case ORC_OP_PLUS: case ORC_OP_MINUS: scale = imax(a.s, b.s); precision = imax(la, lb) + scale + 1; break;
     default: return 0;
   }
-  precision = imin(precision, 38);
+  precision = imin(precision, (a.p <= 38 && b.p <= 38) ? 38 : 76); /* :115-121: both Decimal128 or smaller -> clamp to 38 */
   if (precision < 1 || scale > precision) return 0;
   ret->p = precision; ret->s = scale;
   if (op == ORC_OP_MULTIPLY) { l->p = precision; l->s = a.s; r->p = precision; r->s = b.s; }
@@ -412,6 +412,7 @@ static int result_size(int op, dsize a, dsize b, dsize* l, dsize* r, dsize* ret)
   return 1;
 }
 int orc_decimal_result_size(int op, int lp, int ls, int rp, int rs, int* out_p, int* out_s) {
+  /* (the 38 / 76 clamp lives in result_size) */
   dsize a = {lp, ls}, b = {rp, rs}, l, r, ret;
   if (!result_size(op, a, b, &l, &r, &ret)) return 1;
   *out_p = ret.p; *out_s = ret.s; return 0;
@@ -420,6 +421,7 @@ int orc_decimal_result_size(int op, int lp, int ls, int rp, int rs, int* out_p, 
 static i128 load_dec(const orc_col* c, int64_t i) {
   int64_t j = c->is_scalar ? 0 : i;
   if (c->type == ORC_T_DEC128) return ((const i128*)c->data)[j];
+  if (c->type == ORC_T_DEC256) return ((const i128*)c->data)[2 * j]; /* as_decimal::<T>() into a narrower T: the low bits */
   val v = load_val(c, i);
   return v.cls == 0 ? (i128)v.i : (i128)v.u;
 }
@@ -451,10 +453,12 @@ int orc_decimal_arith(int op, const orc_col* lhs, const orc_col* rhs, int64_t n,
   dsize a, b, l, r, ret;
   if (!dec_props(lhs->type, lhs->precision, lhs->scale, &a) || !dec_props(rhs->type, rhs->precision, rhs->scale, &b)) return 1;
   if (!result_size(op, a, b, &l, &r, &ret)) return 1;
+  if (ret.p > 38) /* T = i256: oracle/decimal256.c */
+    return out_type == ORC_T_DEC256 ? orc_decimal256_arith(op, lhs, rhs, n, out_p, out_s, out, err, err_count) : 1;
   int t128 = ret.p > 18;
   if (ret.p != out_p || ret.s != out_s || out_type != (t128 ? ORC_T_DEC128 : ORC_T_DEC64)) return 1;
-  int a_dec = lhs->type == ORC_T_DEC64 || lhs->type == ORC_T_DEC128;
-  int b_dec = rhs->type == ORC_T_DEC64 || rhs->type == ORC_T_DEC128;
+  int a_dec = lhs->type == ORC_T_DEC64 || lhs->type == ORC_T_DEC128 || lhs->type == ORC_T_DEC256;
+  int b_dec = rhs->type == ORC_T_DEC64 || rhs->type == ORC_T_DEC128 || rhs->type == ORC_T_DEC256;
   int overflow = ret.p == (t128 ? 38 : 18); /* binary_decimal :203 */
   if (err) memset(err, 0xFF, (size_t)((n + 31) / 32) * 4);
   for (int64_t i = 0; i < n; ++i) {

@@ -38,16 +38,17 @@ class Val:
 
     @property
     def is_decimal(self):
-        return self.dtype in (T.T_DEC64, T.T_DEC128)
+        return self.dtype in (T.T_DEC64, T.T_DEC128, T.T_DEC256)
 
     def ints(self):
         """python ints of a decimal / integer value"""
-        if self.dtype == T.T_DEC128:
-            w = np.ascontiguousarray(self.arr).view(np.uint64).reshape(-1, 2)
+        if self.dtype in (T.T_DEC128, T.T_DEC256):
+            k = 2 if self.dtype == T.T_DEC128 else 4
+            w = np.ascontiguousarray(self.arr).view(np.uint64).reshape(-1, k)
             out = []
-            for lo, hi in w:
-                v = (int(hi) << 64) | int(lo)
-                out.append(v - (1 << 128) if v >> 127 else v)
+            for row in w:
+                v = sum(int(x) << (64 * j) for j, x in enumerate(row))
+                out.append(v - (1 << (64 * k)) if v >> (64 * k - 1) else v)
             return out
         return [int(x) for x in self.arr]
 
@@ -70,12 +71,22 @@ def i128_array(ints):
     return out.reshape(-1)
 
 
+def i256_array(ints):
+    out = np.zeros((len(ints), 4), dtype=np.uint64)
+    for i, v in enumerate(ints):
+        v = int(v) & ((1 << 256) - 1)
+        for j in range(4):
+            out[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out.reshape(-1)
+
+
 def dec_val(ints, p, s, validity=None, is_scalar=False):
-    if p > 38:
-        raise Skip("Decimal256 (precision > 38): the i256 class is not built")
+    """a decimal value in the storage class of its precision (DecimalDataType::from(size), decimal.rs:1713-1722)"""
     if p <= 18:
         return Val(T.T_DEC64, np.array(ints, dtype=np.int64), validity, p, s, is_scalar)
-    return Val(T.T_DEC128, i128_array(ints), validity, p, s, is_scalar)
+    if p <= 38:
+        return Val(T.T_DEC128, i128_array(ints), validity, p, s, is_scalar)
+    return Val(T.T_DEC256, i256_array(ints), validity, p, s, is_scalar)
 
 
 def column_val(entry):
@@ -183,7 +194,7 @@ def literal(node):
     if suf in SUFFIX:
         code, npd = NUM[SUFFIX[suf]]
         return Val(code, np.array([float(txt) if "f" in suf else int(txt)], dtype=npd), is_scalar=True)
-    if suf in ("d64", "d128"):
+    if suf in ("d64", "d128", "d256"):
         p, s = int(p), int(s)
         return dec_val([int(Decimal(txt).scaleb(s))], p, s, is_scalar=True)
     raise Skip("literal suffix " + suf)
@@ -217,8 +228,10 @@ def evaluate(node, cols, backend, n):
         return out
     if name == "minus" and len(vals) == 1:
         a = vals[0]
-        if a.is_decimal:
-            raise Skip("unary minus on a decimal (keeps its DecimalSize: no C-ABI entry)")
+        if a.is_decimal:   # register_decimal_minus: the same DecimalSize and storage class (arithmetic.rs:514-590)
+            out = backend.decimal_neg(a, n)
+            out.validity = a.validity
+            return out
         # negate(x) = 0 - x in the same result type (Int8 -> Int16, UInt32 -> Int64, Float64 -> Float64)
         zero = Val(a.dtype, np.zeros(1, dtype=NP_OF_CODE[a.dtype]), is_scalar=True)
         out = backend.arith(T.OP_MINUS, zero, a, n)
@@ -242,8 +255,6 @@ def check_case(case, backend):
     """evaluates one golden case; raises Skip (with the reason) or AssertionError"""
     n = case["n"]
     kind, outc, exp_valid = expected_output(case)
-    if kind[0] == "dec" and kind[1] > 38:
-        raise Skip("Decimal256 (precision > 38): the i256 class is not built")
     node = parse_expr(case["expr"])
     if node[0] in ("lit",):
         raise Skip("constant-folded expression")

@@ -45,21 +45,29 @@ class OracleBackend:
         bp = (b.precision, b.scale) if b.is_decimal else G.INT_PROPS[b.dtype]
         p, s = C.c_int(), C.c_int()
         assert L.orc_decimal_result_size(op, ap[0], ap[1], bp[0], bp[1], C.byref(p), C.byref(s)) == 0
-        ot = T.T_DEC64 if p.value <= 18 else T.T_DEC128
-        out = np.zeros(max(n, 1) * (2 if ot == T.T_DEC128 else 1), dtype=np.uint64)
+        ot = T.T_DEC64 if p.value <= 18 else (T.T_DEC128 if p.value <= 38 else T.T_DEC256)
+        out = np.zeros(max(n, 1) * {T.T_DEC64: 1, T.T_DEC128: 2, T.T_DEC256: 4}[ot], dtype=np.uint64)
         err = np.full(((n + 31) // 32) * 4 + 8, 0xFF, dtype=np.uint8)
         ca, cb = self.host(a).c(), self.host(b).c()
         assert L.orc_decimal_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), ot, p.value, s.value, out.ctypes.data_as(C.c_void_p),
                                    err.ctypes.data_as(C.c_void_p), None) == 0
-        arr = out if ot == T.T_DEC128 else out.view(np.int64)
+        arr = out.view(np.int64) if ot == T.T_DEC64 else out
         return G.Val(ot, arr, None, p.value, s.value)
+
+    def decimal_neg(self, a, n):
+        words = {T.T_DEC64: 1, T.T_DEC128: 2, T.T_DEC256: 4}[a.dtype]
+        out = np.zeros(max(n, 1) * words, dtype=np.uint64)
+        ca = self.host(a).c()
+        assert self.L.orc_decimal_neg(C.byref(ca), C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
+        return G.Val(a.dtype, out.view(np.int64) if a.dtype == T.T_DEC64 else out, None, a.precision, a.scale)
 
     def cmp(self, op, a, b, n):
         L = self.L
         out = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
         ca, cb = self.host(a).c(), self.host(b).c()
         if a.is_decimal and b.is_decimal and (a.dtype != b.dtype or a.scale != b.scale):
-            assert L.orc_cmp_decimal(op, C.byref(ca), C.byref(cb), C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
+            fn = L.orc_cmp_decimal_any if T.T_DEC256 in (a.dtype, b.dtype) else L.orc_cmp_decimal
+            assert fn(op, C.byref(ca), C.byref(cb), C.c_int64(n), out.ctypes.data_as(C.c_void_p)) == 0
         else:
             if a.dtype != b.dtype:
                 raise G.Skip("comparison of different physical types without a CAST")
@@ -68,14 +76,15 @@ class OracleBackend:
 
 
 def test_every_arithmetic_golden_of_the_hot_path_functions():
-    """arithmetic.txt: plus / minus / multiply / divide / div / modulo and unary minus over numbers and decimals (<= 38
-    digits), with literal / scalar operands, CASTs, nested calls and nullable inputs. What is skipped is skipped by name."""
+    """arithmetic.txt: plus / minus / multiply / divide / div / modulo and unary minus over numbers and decimals of all
+    three storage classes (Decimal(76,x) included), with literal / scalar operands, CASTs, nested calls and nullable inputs.
+    What is skipped is skipped by name."""
     checked, skipped = G.run_cases(golden("arithmetic.json"), OracleBackend())
     out_of_scope = {k: v for k, v in skipped.items() if k.startswith("function")}
-    assert len(checked) >= 64, (len(checked), skipped)
-    # everything not checked is one of: another SQL function (pow, sqrt, cbrt, abs, factorial, bit_*: not in SURVEY §8a),
-    # Decimal256, unary minus on a decimal, a constant-folded expression
-    allowed = ("function", "Decimal256", "unary minus on a decimal", "constant-folded expression", "decimal div / modulo")
+    assert len(checked) >= 75, (len(checked), skipped)
+    # everything not checked is one of: another SQL function (pow, sqrt, cbrt, abs, factorial, bit_*: not in SURVEY §8a)
+    # or a constant-folded expression
+    allowed = ("function", "constant-folded expression", "decimal div / modulo")
     assert all(k.startswith(allowed) for k in skipped), skipped
     assert sum(out_of_scope.values()) == 49, out_of_scope     # pow 5, sqrt 6, cbrt 6, abs 6, factorial 2, bit_* 24
 
