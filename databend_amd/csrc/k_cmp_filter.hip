@@ -482,12 +482,22 @@ __global__ __launch_bounds__(256) void take_outer_kernel(const T* __restrict__ s
   }
 }
 
+namespace dbhip {
+int32_t cmp_decimal256(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n, uint8_t* out_bitmap, void* stream);  // k_decimal256.hip
+}
+
 extern "C" {
 
 int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n,
                   uint8_t* out_bitmap, void* stream) {
   DBHIP_REQUIRE(lhs && rhs && (out_bitmap || n == 0), "dbhip_cmp: NULL argument");
   DBHIP_REQUIRE(op >= DBHIP_CMP_EQ && op <= DBHIP_CMP_GTE, "dbhip_cmp: bad operator");
+  if ((lhs->type == DBHIP_T_DEC256 || rhs->type == DBHIP_T_DEC256)) {  // the Decimal256 class: k_decimal256.hip
+    const bool l_any = lhs->type == DBHIP_T_DEC64 || lhs->type == DBHIP_T_DEC128 || lhs->type == DBHIP_T_DEC256;
+    const bool r_any = rhs->type == DBHIP_T_DEC64 || rhs->type == DBHIP_T_DEC128 || rhs->type == DBHIP_T_DEC256;
+    DBHIP_REQUIRE(l_any && r_any, "dbhip_cmp: a Decimal256 column compares with decimals only (the planner casts the other side)");
+    return cmp_decimal256(op, lhs, rhs, n, out_bitmap, stream);
+  }
   const bool l_dec = lhs->type == DBHIP_T_DEC64 || lhs->type == DBHIP_T_DEC128, r_dec = rhs->type == DBHIP_T_DEC64 || rhs->type == DBHIP_T_DEC128;
   if (l_dec && r_dec && (lhs->type != rhs->type || lhs->scale != rhs->scale)) {
     // decimals of different DecimalSize: no cast is planned for them (register_decimal_compare_op, comparison.rs:61-99)

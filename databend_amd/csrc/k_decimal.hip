@@ -34,6 +34,7 @@ __device__ __forceinline__ i128 load_operand(const void* p, int type, bool scala
   int64_t j = scalar ? 0 : i;
   switch (type) {
     case DBHIP_T_DEC128: return ((const i128*)p)[j];
+    case DBHIP_T_DEC256: return ((const i128*)p)[2 * j];  // as_decimal::<T>() into a narrower T: the low bits
     case DBHIP_T_DEC64: case DBHIP_T_I64: return (i128)((const int64_t*)p)[j];
     case DBHIP_T_I8: return (i128)((const int8_t*)p)[j];
     case DBHIP_T_I16: return (i128)((const int16_t*)p)[j];
@@ -62,6 +63,10 @@ __device__ __forceinline__ void load_operand_n(const void* p, int type, bool sca
     case DBHIP_T_DEC128:
 #pragma unroll
       for (int u = 0; u < N; ++u) out[u] = ((const i128*)p)[j[u]];
+      break;
+    case DBHIP_T_DEC256:  // a Decimal256 operand under a result of at most 38 digits (T = i64 / i128): as_decimal::<T>()
+#pragma unroll
+      for (int u = 0; u < N; ++u) out[u] = ((const i128*)p)[2 * j[u]];
       break;
     case DBHIP_T_DEC64: case DBHIP_T_I64:
 #pragma unroll
@@ -102,8 +107,8 @@ __device__ __forceinline__ void load_operand_n(const void* p, int type, bool sca
 // is latency bound (0.44 of the HBM rate on dec64 x dec64 -> dec128).
 __global__ __launch_bounds__(256) void decimal_kernel(DecParams p) {
   const bool t128 = p.t_is_128;
-  const bool a_dec = p.a_type == DBHIP_T_DEC64 || p.a_type == DBHIP_T_DEC128;
-  const bool b_dec = p.b_type == DBHIP_T_DEC64 || p.b_type == DBHIP_T_DEC128;
+  const bool a_dec = p.a_type == DBHIP_T_DEC64 || p.a_type == DBHIP_T_DEC128 || p.a_type == DBHIP_T_DEC256;
+  const bool b_dec = p.b_type == DBHIP_T_DEC64 || p.b_type == DBHIP_T_DEC128 || p.b_type == DBHIP_T_DEC256;
   constexpr int U = 4;
   const int64_t T = (int64_t)gridDim.x * blockDim.x;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,7 +145,7 @@ struct DSize {
 
 bool decimal_props(int type, int prec, int scale, DSize* out) {
   switch (type) {
-    case DBHIP_T_DEC64: case DBHIP_T_DEC128: *out = {prec, scale}; return prec >= 1 && prec <= 38 && scale <= prec;
+    case DBHIP_T_DEC64: case DBHIP_T_DEC128: case DBHIP_T_DEC256: *out = {prec, scale}; return prec >= 1 && prec <= 76 && scale <= prec;
     case DBHIP_T_I8: case DBHIP_T_U8: *out = {3, 0}; return true;     // number.rs:452-465
     case DBHIP_T_I16: case DBHIP_T_U16: *out = {5, 0}; return true;
     case DBHIP_T_I32: case DBHIP_T_U32: *out = {10, 0}; return true;
@@ -153,7 +158,7 @@ bool decimal_props(int type, int prec, int scale, DSize* out) {
 inline int imin(int a, int b) { return a < b ? a : b; }
 inline int imax(int a, int b) { return a > b ? a : b; }
 
-// ArithmeticOp::result_size (arithmetic.rs:80-139) restricted to <=38 digits operands
+// ArithmeticOp::result_size (arithmetic.rs:80-139)
 bool result_size(int op, DSize a, DSize b, DSize* left, DSize* right, DSize* ret) {
   int precision, scale;
   int la = a.p - a.s, lb = b.p - b.s;
@@ -174,7 +179,7 @@ bool result_size(int op, DSize a, DSize b, DSize* left, DSize* right, DSize* ret
     default:
       return false;
   }
-  precision = imin(precision, 38);  // both operands are <= Decimal128
+  precision = imin(precision, (a.p <= 38 && b.p <= 38) ? 38 : 76);  // :115-121: both at most Decimal128 -> clamp to 38
   if (precision < 1 || scale > precision) return false;  // DecimalSize::new
   *ret = {precision, scale};
   switch (op) {
@@ -196,6 +201,11 @@ bool result_size(int op, DSize a, DSize b, DSize* left, DSize* right, DSize* ret
 
 }  // namespace
 
+namespace dbhip {
+int32_t decimal256_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n, int32_t out_type, uint8_t out_precision,
+                         uint8_t out_scale, void* out, uint8_t* err_bitmap, uint64_t* err_count_dev, void* stream);  // k_decimal256.hip
+}
+
 extern "C" {
 
 int32_t dbhip_decimal_result_size(int32_t op, uint8_t lp, uint8_t ls, uint8_t rp, uint8_t rs,
@@ -214,6 +224,8 @@ int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* r
                             int32_t out_type, uint8_t out_precision, uint8_t out_scale, void* out,
                             uint8_t* err_bitmap, uint64_t* err_count_dev, void* stream) {
   DBHIP_REQUIRE(lhs && rhs && (out || n == 0), "dbhip_decimal_arith: NULL argument");
+  if (out_precision > 38)  // T = i256 (an operand beyond 38 digits): the Decimal256 class, k_decimal256.hip
+    return decimal256_arith(op, lhs, rhs, n, out_type, out_precision, out_scale, out, err_bitmap, err_count_dev, stream);
   DecParams p;
   int want_type, rp, rs;
   int32_t rc = dbhip_decimal_decode_internal(op, lhs->type, lhs->precision, lhs->scale, rhs->type, rhs->precision, rhs->scale, &p,
@@ -251,12 +263,16 @@ int32_t dbhip_decimal_decode_internal(int op, int a_type, int a_prec, int a_scal
     set_error("decimal arithmetic: operand types (%d,%d) have no decimal properties", a_type, b_type);
     return DBHIP_ERR_INVALID;
   }
-  const bool a_dec = a_type == DBHIP_T_DEC64 || a_type == DBHIP_T_DEC128;
-  const bool b_dec = b_type == DBHIP_T_DEC64 || b_type == DBHIP_T_DEC128;
+  const bool a_dec = a_type == DBHIP_T_DEC64 || a_type == DBHIP_T_DEC128 || a_type == DBHIP_T_DEC256;
+  const bool b_dec = b_type == DBHIP_T_DEC64 || b_type == DBHIP_T_DEC128 || b_type == DBHIP_T_DEC256;
   DBHIP_REQUIRE(a_dec || b_dec, "decimal arithmetic: at least one side must be decimal");
   if (!result_size(op, a, b, &left, &right, &ret)) {
     set_error("decimal arithmetic: unsupported op %d", op);
     return DBHIP_ERR_INVALID;
+  }
+  if (ret.p > 38) {  // T = i256: dbhip_decimal_arith routes such nodes to k_decimal256.hip before it gets here; fused programs keep them out
+    set_error("decimal arithmetic: Decimal(%d,%d) results (T = i256) are evaluated by dbhip_decimal_arith, not inside fused programs", ret.p, ret.s);
+    return DBHIP_ERR_UNSUPPORTED;
   }
   DecOp& p = *out;
   p.op = op;

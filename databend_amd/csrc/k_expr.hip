@@ -192,6 +192,10 @@ struct RegInfo {
   bool may_raise = false;  // some node below it can raise a row error
   bool is_const = false;   // the register holds a CONST (its 64-bit image in cimm)
   uint64_t cimm = 0;
+  // The register is an AND over a nullable operand, evaluated STRICTLY (NULL as soon as one operand is NULL). The reference's
+  // `and` is three-valued (FALSE AND NULL = FALSE); strict evaluation agrees with it exactly where NULL and FALSE are not told
+  // apart: as the filter, or as an operand of another AND that ends in the filter. Anywhere else the program is refused.
+  bool strict_and = false;
 };
 
 }  // namespace
@@ -242,6 +246,15 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
     d.b = (int16_t)(ok_reg(s.b) ? reg[s.b].loc : 0);
     RegInfo res;
     res.type = s.type; res.loc = s.dst;
+    if (s.op != DBHIP_EX_AND && s.op != DBHIP_EX_LOAD && s.op != DBHIP_EX_CONST) {
+      const int rc3 = s.op == DBHIP_EX_IF ? (int)(s.imm & 0xFF) : -1;
+      const bool unary1 = s.op == DBHIP_EX_NOT || s.op == DBHIP_EX_CAST;
+      if ((ok_reg(s.a) && reg[s.a].strict_and) || (!unary1 && ok_reg(s.b) && reg[s.b].strict_and) || (rc3 >= 0 && ok_reg(rc3) && reg[rc3].strict_and)) {
+        set_error("expression program: instruction %d consumes an AND over a nullable operand; only the filter (or another AND) may — "
+                  "the reference's and / or are three-valued (evaluator.rs:284-305)", i);
+        return DBHIP_ERR_UNSUPPORTED;
+      }
+    }
     switch (s.op) {
       case DBHIP_EX_LOAD: {
         if (s.a < 0 || s.a >= n_inputs || inputs_host[s.a].type != s.type) { set_error("expression program: instruction %d: LOAD of input %d as type %d", i, s.a, s.type); return DBHIP_ERR_INVALID; }
@@ -352,6 +365,11 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
         ex_decode(d, DBHIP_T_BOOL, DBHIP_T_BOOL);
         res.dep = reg[s.a].dep | (unary ? 0 : reg[s.b].dep);
         res.may_raise = reg[s.a].may_raise | (unary ? false : reg[s.b].may_raise);
+        if (s.op == DBHIP_EX_OR && res.dep) {  // TRUE OR NULL = TRUE: a strict OR would drop / null such rows
+          set_error("expression program: instruction %d: OR over a nullable operand is three-valued in the reference (or_filters, evaluator.rs:301-303); not fused", i);
+          return DBHIP_ERR_UNSUPPORTED;
+        }
+        if (s.op == DBHIP_EX_AND) res.strict_and = res.dep != 0;
       } break;
       case DBHIP_EX_CAST: {
         if (!ok_reg(s.a)) { set_error("expression program: instruction %d reads an unset register", i); return DBHIP_ERR_INVALID; }
@@ -404,6 +422,10 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
     if (R.reg >= 0) {
       if (R.reg >= EX_MAX_REGS || reg[R.reg].type < 0) { set_error("expression program: result register %d is never written", R.reg); return DBHIP_ERR_INVALID; }
       const RegInfo& ri = reg[R.reg];
+      if (ri.strict_and && r != filter_root) {
+        set_error("expression program: result register %d is an AND over a nullable operand (FALSE AND NULL = FALSE in the reference); only the filter may be", R.reg);
+        return DBHIP_ERR_UNSUPPORTED;
+      }
       root_loc[r] = ri.loc; R.type = ri.type; R.precision = ri.precision; R.scale = ri.scale; R.dep = ri.dep;
     } else {
       const int c = -R.reg - 1;

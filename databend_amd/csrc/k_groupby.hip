@@ -2802,8 +2802,19 @@ int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int
   return DBHIP_OK;
 }
 
+// Exchange entry points move serialized rows WITHOUT the arena: a long (> 12 byte) string key in such a row is an offset into
+// the SENDER's arena, which the receiving table would read as an address. Tables that hold long strings exchange through
+// dbhip_groupby_flush_serialized + dbhip_groupby_arena -> dbhip_groupby_merge_serialized_arena (which rebases the offsets).
+static int32_t refuse_long_strings(const dbhip_groupby* g, const char* fn) {
+  if (!g->has_long) return DBHIP_OK;
+  set_error("%s: the table holds string keys longer than 12 bytes; exchange it with dbhip_groupby_flush_serialized + dbhip_groupby_arena "
+            "-> dbhip_groupby_merge_serialized_arena", fn);
+  return DBHIP_ERR_UNSUPPORTED;
+}
+
 int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t max_rows, void* stream) {
   DBHIP_REQUIRE(g && out_block_dev && max_rows >= 1, "dbhip_groupby_flush_block: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_flush_block")) return rl;
   hipStream_t s = resolve_stream(stream);
   uint64_t* block = (uint64_t*)out_block_dev;
   DBHIP_CHECK(hipMemsetAsync(&g->ctrl[4], 0, 8, s));
@@ -2817,6 +2828,7 @@ int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t
 int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows,
                                    int32_t skip_block, void* stream) {
   DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_merge_blocks: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_merge_blocks")) return rl;
   hipStream_t s = resolve_stream(stream);
   const int W = g->L.W;
   const int64_t stride = (max_rows + 1) * W;
@@ -3014,6 +3026,7 @@ static int32_t ensure_xcur(dbhip_groupby* g) {
 
 int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void* out_blocks_dev, int64_t max_rows, void* stream) {
   DBHIP_REQUIRE(g && out_blocks_dev && n_buckets >= 1 && n_buckets <= 4096 && max_rows >= 1, "dbhip_groupby_partition_blocks: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_partition_blocks")) return rl;
   hipStream_t s = resolve_stream(stream);
   int32_t rc = ensure_xcur(g);
   if (rc) return rc;
@@ -3033,6 +3046,7 @@ int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, voi
                                         int64_t* out_counts_host, void* stream) {
   DBHIP_REQUIRE(g && out_counts_host && n_buckets >= 1 && n_buckets <= 4096 && (out_rows_dev || max_rows == 0),
                 "dbhip_groupby_flush_partitioned: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_flush_partitioned")) return rl;
   hipStream_t s = resolve_stream(stream);
   int32_t rc = ensure_xcur(g);
   if (rc) return rc;
@@ -3065,6 +3079,7 @@ int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, voi
 
 int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows, void* stream) {
   DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_replace_with_blocks: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_replace_with_blocks")) return rl;
   hipStream_t s = resolve_stream(stream);
   const int W = g->L.W;
   const int64_t stride = (max_rows + 1) * W;

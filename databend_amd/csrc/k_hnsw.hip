@@ -187,6 +187,15 @@ __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
     __builtin_amdgcn_wave_barrier();                       \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
+// Orders the link words / counts a wave has just stored before the count / ready flag / lock release it stores next, for
+// readers on OTHER CUs and XCDs: an agent-scope release (buffer_wbl2 sc1 + s_waitcnt vmcnt(0)). A workgroup-scope fence is
+// nothing another CU can observe (MI355X_MICROARCH.md, inter-workgroup visibility); the explicit s_waitcnt is the guide's fix for
+// the compiler dropping the wait behind buffer_wbl2 when it can prove the vmcnt scoreboard empty.
+#define PUBLISH_RELEASE()                                   \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        \
+  } while (0)
 
 // OrderedFloat: NaN is the greatest value and equal to itself
 __device__ __forceinline__ bool sp_le(float a, float b) {
@@ -708,7 +717,7 @@ __device__ void link_point(const HnswView& H, BuildLds* B, uint32_t* vis, const 
       uint32_t* mycnt;
       uint32_t* mine = list_ptr(H, p, cl, &mycnt);
       if (l < ns) st32(mine + l, B->sel[l]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      PUBLISH_RELEASE();
       if (l == 0) st32(mycnt, (uint32_t)ns);
       for (int k = 0; k < ns; ++k) {
         const uint32_t other = B->sel[k];
@@ -722,7 +731,7 @@ __device__ void link_point(const HnswView& H, BuildLds* B, uint32_t* vis, const 
         if (on < level_m) {
           if (l == 0) {
             st32(ol + on, p);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            PUBLISH_RELEASE();
             st32(ocnt, (uint32_t)(on + 1));
           }
         } else {
@@ -753,17 +762,17 @@ __device__ void link_point(const HnswView& H, BuildLds* B, uint32_t* vis, const 
           WAVE_SYNC();
           const int n2 = select_heuristic(H, B->tmp, nc, level_m, B->sel2);
           if (l < n2) st32(ol + l, B->sel2[l]);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          PUBLISH_RELEASE();
           if (l == 0) st32(ocnt, (uint32_t)n2);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        PUBLISH_RELEASE();
         if (l == 0) __hip_atomic_store(&H.lock[other], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         WAVE_SYNC();
       }
     }
     if (l == 0 && W->flag) atomicOr(A.err, (unsigned)W->flag);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  PUBLISH_RELEASE();
   if (l == 0) {
     st32(H.ready + p, 1u);
     // entry_points.new_point (entry_points.rs:56-103): replaced only by a strictly higher level (the first one to get there
@@ -875,6 +884,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   V.linksu = (uint32_t*)lu; V.cntu = (uint32_t*)cu; V.ufirst = (int64_t*)uf; V.level = (int32_t*)lv; V.ready = (uint32_t*)rd;
   V.lock = (uint32_t*)lk; V.entry = (unsigned long long*)en;
   DBHIP_CHECK(hipMemsetAsync(c0, 0, nn * 4, s));
+  DBHIP_CHECK(hipMemsetAsync(l0, 0, nn * (size_t)V.m0 * 4, s));  // a reader that races a publish sees 0 (a valid id), never garbage
   DBHIP_CHECK(hipMemsetAsync(cu, 0, (size_t)(nu > 0 ? nu : 1) * 4, s));
   DBHIP_CHECK(hipMemsetAsync(rd, 0, nn * 4, s));
   DBHIP_CHECK(hipMemsetAsync(lk, 0, nn * 4, s));

@@ -52,6 +52,7 @@ inline int type_size(int32_t t) {
     case DBHIP_T_I64: case DBHIP_T_U64: case DBHIP_T_F64: case DBHIP_T_TIMESTAMP:
     case DBHIP_T_DEC64: return 8;
     case DBHIP_T_DEC128: case DBHIP_T_STRING: return 16;
+    case DBHIP_T_DEC256: return 32;
     default: return 0;
   }
 }

@@ -18,7 +18,7 @@ NP_OF = {
     L.T_DEC64: np.int64,
 }
 TYPE_OF_NP = {np.dtype(v): k for k, v in NP_OF.items() if k not in (L.T_DATE, L.T_TIMESTAMP, L.T_DEC64)}
-ELEM_SIZE = {L.T_DEC128: 16, L.T_STRING: 16}
+ELEM_SIZE = {L.T_DEC128: 16, L.T_STRING: 16, L.T_DEC256: 32}
 for _t, _d in NP_OF.items():
     ELEM_SIZE[_t] = np.dtype(_d).itemsize
 
@@ -175,6 +175,8 @@ class Column:
     def scalar(cls, value, dtype, precision=0, scale=0):
         if dtype == L.T_DEC128:
             arr = i128_to_bytes([int(value)])
+        elif dtype == L.T_DEC256:
+            arr = ints_to_limbs([int(value)], 256)
         else:
             arr = np.array([value], dtype=NP_OF[dtype])
         return cls(dtype, 1, DeviceBuffer.from_numpy(arr), None, precision, scale, is_scalar=True)
@@ -183,6 +185,19 @@ class Column:
     def decimal128(cls, ints, precision, scale, validity=None):
         vb = DeviceBuffer.from_numpy(pack_bits(validity)) if validity is not None else None
         return cls(L.T_DEC128, len(ints), DeviceBuffer.from_numpy(i128_to_bytes(ints)), vb, precision, scale)
+
+    @classmethod
+    def decimal256(cls, ints, precision, scale, validity=None):
+        vb = DeviceBuffer.from_numpy(pack_bits(validity)) if validity is not None else None
+        return cls(L.T_DEC256, len(ints), DeviceBuffer.from_numpy(ints_to_limbs(ints, 256)), vb, precision, scale)
+
+    @classmethod
+    def decimal(cls, ints, precision, scale, validity=None, bits=None):
+        """a decimal column in the storage class of its precision (or an explicitly wider one: legacy columns)"""
+        bits = bits or (64 if precision <= 18 else (128 if precision <= 38 else 256))
+        if bits == 64:
+            return cls.from_numpy(np.array(ints, dtype=np.int64), L.T_DEC64, validity, precision, scale)
+        return cls.decimal128(ints, precision, scale, validity) if bits == 128 else cls.decimal256(ints, precision, scale, validity)
 
     @classmethod
     def boolean(cls, bools, validity=None):
@@ -218,6 +233,8 @@ class Column:
     def to_numpy(self):
         if self.dtype == L.T_DEC128:
             return bytes_to_i128(self.data.to_numpy(np.uint8, 16 * self.n))
+        if self.dtype == L.T_DEC256:
+            return limbs_to_ints(self.data.to_numpy(np.uint64, 4 * self.n), 256)
         if self.dtype == L.T_BOOL:
             return unpack_bits(self.data.to_numpy(np.uint8, (self.n + 7) // 8), self.n)
         if self.dtype == L.T_STRING:
@@ -228,6 +245,26 @@ class Column:
         if self.validity is None:
             return np.ones(self.n, dtype=bool)
         return unpack_bits(self.validity.to_numpy(np.uint8, (self.n + 7) // 8), self.n)
+
+
+def ints_to_limbs(ints, bits):
+    """python ints -> little-endian two's complement u64 limbs, bits / 64 per value (flat)"""
+    k = bits // 64
+    out = np.zeros((len(ints), k), dtype=np.uint64)
+    for i, v in enumerate(ints):
+        v = int(v) & ((1 << bits) - 1)
+        for j in range(k):
+            out[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return out.reshape(-1)
+
+
+def limbs_to_ints(raw, bits):
+    k = bits // 64
+    out = []
+    for row in np.ascontiguousarray(raw).view(np.uint64).reshape(-1, k):
+        v = sum(int(x) << (64 * j) for j, x in enumerate(row))
+        out.append(v - (1 << bits) if v >> (bits - 1) else v)
+    return out
 
 
 def i128_to_bytes(ints):
@@ -327,8 +364,8 @@ def cast(col, dst_type, is_try=False, rounding_mode=True, n=None):
 def decimal_result_size(op, a, b):
     props = {L.T_I8: (3, 0), L.T_U8: (3, 0), L.T_I16: (5, 0), L.T_U16: (5, 0), L.T_I32: (10, 0), L.T_U32: (10, 0),
              L.T_I64: (19, 0), L.T_U64: (20, 0)}
-    ap = (a.precision, a.scale) if a.dtype in (L.T_DEC64, L.T_DEC128) else props[a.dtype]
-    bp = (b.precision, b.scale) if b.dtype in (L.T_DEC64, L.T_DEC128) else props[b.dtype]
+    ap = (a.precision, a.scale) if a.dtype in (L.T_DEC64, L.T_DEC128, L.T_DEC256) else props[a.dtype]
+    bp = (b.precision, b.scale) if b.dtype in (L.T_DEC64, L.T_DEC128, L.T_DEC256) else props[b.dtype]
     p, s = C.c_uint8(), C.c_uint8()
     check(lib().dbhip_decimal_result_size(op, ap[0], ap[1], bp[0], bp[1], C.byref(p), C.byref(s)))
     return p.value, s.value
@@ -337,13 +374,37 @@ def decimal_result_size(op, a, b):
 def decimal_arith(op, a, b, n=None, errors=None):
     n = n if n is not None else max(a.n if not a.is_scalar else 0, b.n if not b.is_scalar else 0)
     p, s = decimal_result_size(op, a, b)
-    out_t = L.T_DEC64 if p <= 18 else L.T_DEC128
+    out_t = L.T_DEC64 if p <= 18 else (L.T_DEC128 if p <= 38 else L.T_DEC256)
     out = DeviceBuffer(max(n, 1) * ELEM_SIZE[out_t] + 64)
     ca, cb = a.c(), b.c()
     eb = C.c_void_p(errors.bitmap.ptr) if errors else None
     ec = C.c_void_p(errors.count.ptr) if errors else None
     check(lib().dbhip_decimal_arith(op, C.byref(ca), C.byref(cb), C.c_int64(n), out_t, p, s, C.c_void_p(out.ptr), eb, ec, None))
     return Column(out_t, n, out, _merged_validity(a, b, n), p, s)
+
+
+def decimal_neg(col, n=None):
+    """unary minus on a decimal column (dbhip_decimal_neg): same DecimalSize and storage class"""
+    n = n if n is not None else col.n
+    out = DeviceBuffer(max(n, 1) * ELEM_SIZE[col.dtype] + 64)
+    cc = col.c()
+    check(lib().dbhip_decimal_neg(C.byref(cc), C.c_int64(n), C.c_void_p(out.ptr), None))
+    return Column(col.dtype, n, out, col.validity, col.precision, col.scale, keep=(col,))
+
+
+def decimal_cast(col, precision, scale, is_try=False, rounding_mode=False, n=None):
+    """to_decimal(p, s) / try_to_decimal(p, s) for decimal and integer columns (dbhip_decimal_cast) -> (Column, ok rows, error count)"""
+    n = n if n is not None else col.n
+    dst_type = L.T_DEC64 if precision <= 18 else (L.T_DEC128 if precision <= 38 else L.T_DEC256)
+    out = DeviceBuffer(max(n, 1) * ELEM_SIZE[dst_type] + 64)
+    bm = DeviceBuffer(((max(n, 1) + 63) // 64) * 8 + 8)
+    cnt = DeviceBuffer(8)
+    cnt.zero()
+    cc = col.c()
+    check(lib().dbhip_decimal_cast(C.byref(cc), dst_type, precision, scale, int(is_try), int(rounding_mode), C.c_int64(n), C.c_void_p(out.ptr),
+                                   C.c_void_p(bm.ptr), C.c_void_p(cnt.ptr), None))
+    ok = unpack_bits(bm.to_numpy(np.uint8, (n + 7) // 8), n) if n else np.zeros(0, dtype=bool)
+    return Column(dst_type, n, out, bm if is_try else col.validity, precision, scale, keep=(col,)), ok, int(cnt.to_numpy(np.uint64, 1)[0])
 
 
 def cmp(op, a, b, n=None):
@@ -562,6 +623,16 @@ class ExprProgram:
         return out
 
 
+def _filter_bits(pred, n):
+    """The Bitmap a pushed-down predicate hands to the aggregate: a NULL predicate row is dropped like FALSE (the reference's
+    filter treats NULL as false, filter_executor.rs), so a nullable Boolean column contributes data AND validity."""
+    if pred.validity is None:
+        return pred.data
+    out = DeviceBuffer(((n + 63) // 64) * 8 + 8)
+    check(lib().dbhip_bitmap_binary(0, C.c_void_p(pred.data.ptr), C.c_void_p(pred.validity.ptr), C.c_int64(n), C.c_void_p(out.ptr), None))
+    return out
+
+
 class GroupBy:
     """Device AggregateHashTable (dbhip_groupby_*)."""
 
@@ -601,7 +672,7 @@ class GroupBy:
         if filter is None:
             check(lib().dbhip_groupby_add_block(self.h, ka, aa, C.c_int64(n), stream))
         else:
-            check(lib().dbhip_groupby_add_block_filtered(self.h, ka, aa, C.c_int64(n), C.c_void_p(filter.data.ptr), C.c_int64(0), stream))
+            check(lib().dbhip_groupby_add_block_filtered(self.h, ka, aa, C.c_int64(n), C.c_void_p(_filter_bits(filter, n).ptr), C.c_int64(0), stream))
 
     def add_block_program(self, keys, program, arg_regs, n, filter_reg=-1, filter=None, stream=None, prepare=False):
         """Fused TransformFilter -> maps -> partial aggregate (dbhip_groupby_add_block_program). `program`: ExprProgram;
@@ -615,7 +686,7 @@ class GroupBy:
         ap.prog, ap.n_ins = C.cast(cprog, C.c_void_p), len(program.ins)
         ap.inputs, ap.n_inputs = C.cast(cin, C.c_void_p), len(program.inputs)
         ap.filter_reg, ap.arg_regs = filter_reg, C.cast(regs, C.c_void_p)
-        fb = C.c_void_p(filter.data.ptr) if filter is not None else None
+        fb = C.c_void_p(_filter_bits(filter, n).ptr) if filter is not None else None
         if prepare:
             check(lib().dbhip_groupby_prepare_program(self.h, _cols(keys), C.byref(ap)))
             return

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DBHIP_ABI_VERSION 2
+#define DBHIP_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -65,7 +65,8 @@ typedef enum {
   DBHIP_T_TIMESTAMP = 13,/* i64 micros                                           */
   DBHIP_T_DEC64 = 14,    /* DecimalColumn::Decimal64  (i64)                      */
   DBHIP_T_DEC128 = 15,   /* DecimalColumn::Decimal128 (i128, little endian)      */
-  DBHIP_T_STRING = 16    /* BinaryViewColumn: 16-byte View{len,prefix,buf,off}   */
+  DBHIP_T_STRING = 16,   /* BinaryViewColumn: 16-byte View{len,prefix,buf,off}   */
+  DBHIP_T_DEC256 = 17    /* DecimalColumn::Decimal256 (i256: 32 bytes, little endian two's complement; ABI 3) */
 } dbhip_type;
 
 /* binary operators (numeric_basic_arithmetic.rs:255-544, decimal/arithmetic.rs:44-49) */
@@ -193,8 +194,12 @@ int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stre
  * cannot raise and a non-nullable condition (else DBHIP_ERR_UNSUPPORTED: the CPU evaluator's lazy branches stay).
  * NULLs: the result is NULL where a nullable input the RESULT depends on is NULL (passthrough_nullable,
  * register_vectorize.rs:447-471), and a node raises only for rows where the nullable inputs IT depends on are
- * valid; Boolean AND/OR are strict here (the three-valued and_filters/or_filters special case,
- * evaluator.rs:284-305, stays with dbhip_bitmap_binary).
+ * valid. Boolean AND / OR are evaluated strictly (NULL as soon as an operand is NULL) while the reference's are three-valued
+ * (FALSE AND NULL = FALSE, TRUE OR NULL = TRUE; and_filters / or_filters, evaluator.rs:284-305): the compiler therefore accepts
+ * them over NULLABLE operands only where the two agree — an AND (chain) that ends in the FILTER of a fused aggregation, where
+ * NULL and FALSE both drop the row — and returns DBHIP_ERR_UNSUPPORTED for OR over a nullable operand and for an AND over a
+ * nullable operand that feeds anything else (a value result, NOT, if, a comparison); those stay with dbhip_bitmap_binary on
+ * the operator-at-a-time path.
  * Outputs: `out_values` = elements of the out register's type (Decimal128: i128), or for a Boolean result an
  * LSB-first bitmap; `out_validity` likewise a bitmap. Bitmaps are written as whole 64-bit words: both buffers must
  * hold ceil(n/64)*8 bytes and be 8-byte aligned; bits past n are zero. `sum_out_dev` (may be NULL): the
@@ -224,11 +229,15 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
 /* ---- a4: decimal arithmetic ------------------------------------------------
  * Replaces binary_decimal (decimal/src/arithmetic.rs:190-316) after the operands
  * were brought to (left_size, right_size) by ArithmeticOp::result_size (:80-139).
- * `lhs`/`rhs` are DEC64/DEC128 columns (or integer columns, converted like
+ * `lhs`/`rhs` are DEC64/DEC128/DEC256 columns (or integer columns, converted like
  * other_to_decimal) carrying their own precision/scale; the result storage class
- * and DecimalSize come from dbhip_decimal_result_size. Row errors as dbhip_arith
+ * (precision <= 18: DEC64, <= 38: DEC128, else DEC256) and DecimalSize come from
+ * dbhip_decimal_result_size (clamped to 38 digits when both operands have at most 38,
+ * to 76 otherwise, arithmetic.rs:115-121). Row errors as dbhip_arith
  * ("Decimal overflow", "Decimal multiply overflow", "divided by zero",
- * "Decimal div overflow"). */
+ * "Decimal div overflow"). The Decimal256 class (T = i256: types/decimal.rs:1282-1500 —
+ * wrapping ethnum arithmetic on the checked path, exact BigInt fallback when the 256-bit
+ * product overflows, from_bigint) is evaluated with 32-bit-limb long division, one row per lane. */
 int32_t dbhip_decimal_result_size(int32_t op, uint8_t lp, uint8_t ls, uint8_t rp, uint8_t rs,
                                   uint8_t* out_precision_host, uint8_t* out_scale_host);
 int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs,
@@ -236,11 +245,25 @@ int32_t dbhip_decimal_arith(int32_t op, const dbhip_col* lhs, const dbhip_col* r
                             uint8_t out_scale, void* out,
                             uint8_t* err_bitmap, uint64_t* err_count_dev, void* stream);
 
+/* unary minus on a decimal column (register_decimal_minus, decimal/src/arithmetic.rs:514-590): `-t` in the column's own storage
+ * class (wrapping), the DecimalSize is unchanged; `out` holds n values of src->type. Validity passes through (the binding reuses it). */
+int32_t dbhip_decimal_neg(const dbhip_col* src, int64_t n, void* out, void* stream);
+/* to_decimal(p, s) / try_to_decimal(p, s) for DECIMAL and INTEGER sources (CAST(x AS Decimal(p, s)); decimal/src/cast.rs:470-483:
+ * decimal_to_decimal :981-1035 — expand / shrink by storage class, scale increase with a checked multiply, scale reduction that
+ * truncates or, with `rounding_mode` (the numeric_cast_option setting), rounds half away from zero :790-899 — and
+ * integer_to_decimal :701-753). `dst_type` must be the storage class of dst_precision. A value the destination cannot hold
+ * raises the row error "Decimal overflow" — bit i of `bitmap` (preset to ones here; LSB-first, whole 64-bit words, 8-byte
+ * aligned) cleared, *err_count_dev incremented, the row holds 1 (T::one()); NULL input rows never raise — or, for is_try,
+ * becomes NULL: `bitmap` is then the result's validity (input validity AND "representable"). Float / String / Variant sources:
+ * DBHIP_ERR_UNSUPPORTED (not on the hot path). */
+int32_t dbhip_decimal_cast(const dbhip_col* src, int32_t dst_type, uint8_t dst_precision, uint8_t dst_scale, int32_t is_try,
+                           int32_t rounding_mode, int64_t n, void* out, uint8_t* bitmap, uint64_t* err_count_dev, void* stream);
+
 /* ---- a5: comparisons -> Bitmap --------------------------------------------
  * Replaces vectorize_cmp_2_arg + Bitmap::collect_bool
  * (register_comparison.rs:52-96, bitmap/immutable.rs:474). Both sides must have
- * the same physical type (the planner inserts casts) — except two DECIMAL columns, which may differ in storage
- * class and DecimalSize (no cast is planned for them: they compare at the larger scale in the storage class of
+ * the same physical type (the planner inserts casts) — except two DECIMAL columns (DEC64 / DEC128 / DEC256), which may differ
+ * in storage class and DecimalSize (no cast is planned for them: they compare at the larger scale in the storage class of
  * calc_size, decimal/src/comparison.rs:326-441, a side that overflows there ordering by its sign); floats compare as
  * OrderedFloat (NaN largest, types/number.rs:47-48). `out_bitmap` holds
  * ceil(n/8) bytes, LSB-first, trailing bits zero. */
@@ -392,9 +415,11 @@ int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, i
                                        void* stream);
 /* Long string keys. String key columns written by flush_result / flush_state_block are 16-byte views; the long form is
  * {len, prefix, buffer 0, offset}: buffer 0 of such a column is the table's arena (dbhip_groupby_arena: device pointer and
- * bytes in use; valid until the table is reset, destroyed or takes more rows). Serialized rows (flush_serialized /
- * flush_block / partition_*) carry the same offsets: ship the arena with them and merge with merge_serialized_arena
- * (`arena_dev` = the SENDER's arena bytes on this device); merge_serialized alone is for tables without long strings. */
+ * bytes in use; valid until the table is reset, destroyed or takes more rows). Serialized rows (flush_serialized) carry the
+ * same offsets: ship the arena with them and merge with merge_serialized_arena (`arena_dev` = the SENDER's arena bytes on this
+ * device); merge_serialized alone is for tables without long strings. The fixed-block exchange entry points (flush_block,
+ * merge_blocks, partition_blocks, replace_with_blocks, flush_partitioned) move rows WITHOUT an arena and return
+ * DBHIP_ERR_UNSUPPORTED for a table that holds a string key longer than 12 bytes. */
 int32_t dbhip_groupby_arena(dbhip_groupby* g, const void** out_ptr_host, int64_t* out_bytes_host, void* stream);
 int32_t dbhip_groupby_merge_serialized_arena(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, const void* arena_dev,
                                              void* stream);

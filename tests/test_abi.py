@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.SYMBOLS) == syms, set(_lib.SYMBOLS) ^ set(syms)
-    assert L.dbhip_abi_version() == 2
+    assert L.dbhip_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():

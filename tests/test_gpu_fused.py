@@ -303,3 +303,64 @@ def test_prepared_specialised_kernel_equals_the_interpreter(gpu, oracle):
     tpch.q1_fused_program(li, cutoff=tpch.Q1_CUTOFF - 400, prepare=True)
     other2 = tpch.q1_rows(tpch.q1_fused_program(li, cutoff=tpch.Q1_CUTOFF - 400))
     assert first == exp and again == exp and other == other2 and other != exp
+
+
+def test_and_or_over_nullable_operands_keep_three_valued_semantics(gpu):
+    """the fused interpreter evaluates AND / OR strictly while the reference's are three-valued. An AND over
+    nullable operands may end in the FILTER (NULL and FALSE both drop the row); OR over a nullable operand, and a nullable AND
+    that feeds a value result or NOT, are refused so that the binding keeps the CPU evaluator. A nullable predicate Bitmap
+    handed to add_block drops its NULL rows like FALSE ones."""
+    D = gpu
+    n = 5000
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 10, n).astype(np.int64)
+    b = rng.integers(0, 10, n).astype(np.int64)
+    va, vb = rng.integers(0, 4, n) > 0, rng.integers(0, 4, n) > 0
+    k = rng.integers(0, 3, n).astype(np.int64)
+    x = rng.integers(-100, 100, n).astype(np.int64)
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)]
+
+    def program():
+        ca, cb = D.Column.from_numpy(a, validity=va), D.Column.from_numpy(b, validity=vb)
+        p = D.ExprProgram([ca, cb, D.Column.from_numpy(x)])
+        pa = p.cmp(T.EX_GT, p.load(0), p.const(3, T.T_I64))
+        pb = p.cmp(T.EX_LT, p.load(1), p.const(8, T.T_I64))
+        return p, pa, pb
+
+    # AND ending in the filter: rows kept iff both predicates are TRUE (a NULL operand never passes a filter)
+    p, pa, pb = program()
+    f = p.logic(T.EX_AND, pa, pb)
+    g = D.GroupBy([T.T_I64], aggs)
+    g.add_block_program([D.Column.from_numpy(k)], p, [("input", 2), None], n, filter_reg=f)
+    keep = va & vb & (a > 3) & (b < 8)
+    exp = sorted((int(key), int(x[keep & (k == key)].sum()), int((keep & (k == key)).sum())) for key in np.unique(k[keep]))
+    assert sorted(g.result()) == exp
+    # OR over a nullable operand: refused (TRUE OR NULL = TRUE)
+    p, pa, pb = program()
+    f = p.logic(T.EX_OR, pa, pb)
+    with pytest.raises(T.DbhipError) as e:
+        D.GroupBy([T.T_I64], aggs).add_block_program([D.Column.from_numpy(k)], p, [("input", 2), None], n, filter_reg=f)
+    assert e.value.code == T.ERR_UNSUPPORTED
+    # NOT over a nullable AND, and a nullable AND as a value: refused (FALSE AND NULL = FALSE)
+    p, pa, pb = program()
+    f = p.logic(T.EX_NOT, p.logic(T.EX_AND, pa, pb))
+    with pytest.raises(T.DbhipError) as e:
+        D.GroupBy([T.T_I64], aggs).add_block_program([D.Column.from_numpy(k)], p, [("input", 2), None], n, filter_reg=f)
+    assert e.value.code == T.ERR_UNSUPPORTED
+    p, pa, pb = program()
+    f = p.logic(T.EX_AND, pa, pb)
+    with pytest.raises(T.DbhipError) as e:
+        p.run(f, n)
+    assert e.value.code == T.ERR_UNSUPPORTED
+    # non-nullable operands: OR and NOT stay fused
+    p = D.ExprProgram([D.Column.from_numpy(a), D.Column.from_numpy(b)])
+    f = p.logic(T.EX_NOT, p.logic(T.EX_OR, p.cmp(T.EX_GT, p.load(0), p.const(3, T.T_I64)), p.cmp(T.EX_LT, p.load(1), p.const(8, T.T_I64))))
+    out = p.run(f, n)
+    assert np.array_equal(np.asarray(out["values"], dtype=bool)[:n], ~((a > 3) | (b < 8)))
+    # a nullable predicate column pushed into add_block: NULL rows are dropped like FALSE ones
+    pred = D.cmp(T.CMP_GT, D.Column.from_numpy(a, validity=va), D.Column.scalar(3, T.T_I64))
+    g = D.GroupBy([T.T_I64], aggs)
+    g.add_block([D.Column.from_numpy(k)], [D.Column.from_numpy(x), None], n, filter=pred)
+    keep = va & (a > 3)
+    exp = sorted((int(key), int(x[keep & (k == key)].sum()), int((keep & (k == key)).sum())) for key in np.unique(k[keep]))
+    assert sorted(g.result()) == exp

@@ -20,8 +20,9 @@ class DeviceBackend:
 
     def col(self, v):
         D = self.D
-        if v.dtype == T.T_DEC128:
-            c = D.Column(T.T_DEC128, len(v.arr) // 2, D.DeviceBuffer.from_numpy(np.ascontiguousarray(v.arr)), precision=v.precision, scale=v.scale)
+        if v.dtype in (T.T_DEC128, T.T_DEC256):
+            words = 2 if v.dtype == T.T_DEC128 else 4
+            c = D.Column(v.dtype, len(v.arr) // words, D.DeviceBuffer.from_numpy(np.ascontiguousarray(v.arr)), precision=v.precision, scale=v.scale)
         elif v.dtype == T.T_BOOL:
             c = D.Column.boolean(np.asarray(v.arr, dtype=bool))
         else:
@@ -35,7 +36,14 @@ class DeviceBackend:
 
     def decimal(self, op, a, b, n):
         out = self.D.decimal_arith(op, self.col(a), self.col(b), n)
-        arr = out.data.to_numpy(np.uint64, 2 * n) if out.dtype == T.T_DEC128 else out.to_numpy()
+        words = {T.T_DEC64: 0, T.T_DEC128: 2, T.T_DEC256: 4}[out.dtype]
+        arr = out.data.to_numpy(np.uint64, words * n) if words else out.to_numpy()
+        return G.Val(out.dtype, arr, None, out.precision, out.scale)
+
+    def decimal_neg(self, a, n):
+        out = self.D.decimal_neg(self.col(a), n)
+        words = {T.T_DEC64: 0, T.T_DEC128: 2, T.T_DEC256: 4}[out.dtype]
+        arr = out.data.to_numpy(np.uint64, words * n) if words else out.to_numpy()
         return G.Val(out.dtype, arr, None, out.precision, out.scale)
 
     def cmp(self, op, a, b, n):
@@ -45,8 +53,10 @@ class DeviceBackend:
 
 
 def test_arithmetic_goldens_through_the_c_abi(gpu):
+    """all of arithmetic.txt's hot-path cases, the Decimal(76,x) ones and unary minus on decimals included"""
     checked, skipped = G.run_cases(golden("arithmetic.json"), DeviceBackend(gpu))
-    assert len(checked) >= 64, (len(checked), skipped)
+    assert len(checked) >= 75, (len(checked), skipped)
+    assert not any("Decimal256" in k or "unary minus" in k for k in skipped), skipped
 
 
 def test_comparison_goldens_through_the_c_abi(gpu):

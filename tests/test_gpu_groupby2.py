@@ -435,3 +435,41 @@ def test_groupby_string_keys_of_any_length(gpu, oracle, n, card, maxlen):
             s = exp2.setdefault(r[:3], [0, 0, None])
             s[0] += r[3]; s[1] += r[4]; s[2] = r[5] if s[2] is None else min(s[2], r[5])
     assert rows_of(g2) == sorted(k + tuple(v) for k, v in exp2.items())
+
+
+def test_fixed_block_exchange_refuses_tables_with_long_string_keys(gpu):
+    """flush_block / partition_blocks / flush_partitioned / merge_blocks / replace_with_blocks move rows without
+    the arena; a key longer than 12 bytes in such a row is an OFFSET that the receiver would read as an address. They must
+    return DBHIP_ERR_UNSUPPORTED (the table exchanges through flush_serialized + arena -> merge_serialized_arena instead);
+    a table whose strings all fit inline still goes through."""
+    from databend_amd._lib import DbhipError, ERR_UNSUPPORTED
+    D = gpu
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0)]
+    n = 1000
+    a = np.arange(n, dtype=np.int64)
+
+    def table(strs):
+        g = D.GroupBy([T.T_STRING], aggs, [0])
+        g.add_block([D.Column.strings(strs)], [D.Column.from_numpy(a)], n)
+        return g
+
+    long_t = table([b"Customer#%09d-long" % (i % 37) for i in range(n)])
+    W = long_t.row_bytes() // 8
+    buf = D.DeviceBuffer(4 * 257 * W * 8)
+    for call in (lambda: long_t.flush_block(buf.ptr, 256), lambda: long_t.partition_blocks(buf.ptr, 4, 256),
+                 lambda: long_t.flush_partitioned(4, buf.ptr, 1024), lambda: long_t.merge_blocks(buf.ptr, 1, 256),
+                 lambda: long_t.replace_with_blocks(buf.ptr, 1, 256)):
+        with pytest.raises(DbhipError) as e:
+            call()
+        assert e.value.code == ERR_UNSUPPORTED and "arena" in str(e.value)
+    assert long_t.num_groups() == 37   # nothing was touched
+    # the supported route for such a table: rows + arena
+    rows, arena = long_t.flush_serialized(), long_t.arena_numpy()
+    other = D.GroupBy([T.T_STRING], aggs, [0])
+    other.merge_serialized_arena(rows, arena)
+    assert sorted(other.result()) == sorted(long_t.result())
+    short_t = table([b"k%d" % (i % 37) for i in range(n)])
+    short_t.partition_blocks(buf.ptr, 4, 256)
+    recv = D.GroupBy([T.T_STRING], aggs, [0])
+    recv.replace_with_blocks(buf.ptr, 4, 256)
+    assert sorted(recv.result()) == sorted(short_t.result())
