@@ -48,6 +48,7 @@ struct ExProg {
   int32_t in_scalar[EX_MAX_INPUTS];
   int32_t in_slot[EX_MAX_INPUTS];   // LDS slot of input column c (-1: the program never reads it)
   int32_t in_wide_ord[EX_MAX_INPUTS];  // 128-bit input columns: 0 / 1 = which of the (at most two) hi-word staging registers, else -1
+  int32_t in_has_valid[EX_MAX_INPUTS]; // the input column carries a validity Bitmap (part of the program's shape)
   int32_t n_ins, n_inputs, n_slots;
   int32_t n_filter_ins;             // leading instructions that compute the filter (0 = no filter stage)
   int32_t filter_slot;              // slot of the filter's Boolean (-1: none)

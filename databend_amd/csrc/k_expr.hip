@@ -223,6 +223,7 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
     P.in_data[c] = col.data; P.in_valid[c] = col.validity; P.in_voff[c] = col.validity_offset;
     P.in_type[c] = ex_load_kind(col.type); P.in_scalar[c] = col.is_scalar;
     P.in_wide_ord[c] = -1;
+    P.in_has_valid[c] = col.validity != nullptr;
     if (col.type == DBHIP_T_DEC128) {
       if (n_wide >= 2) { set_error("expression program: more than two Decimal128 input columns"); return DBHIP_ERR_UNSUPPORTED; }
       P.in_wide_ord[c] = n_wide++;

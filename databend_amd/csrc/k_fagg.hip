@@ -20,6 +20,8 @@
 #include "runtime.h"
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <sys/stat.h>
 #include <fcntl.h>
 #include <signal.h>
 #include <spawn.h>
@@ -92,6 +94,7 @@ std::string jit_meta(const FaArgs& A) {
   o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_scalar[i]); o.close();
   o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_slot[i]); o.close();
   o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_wide_ord[i]); o.close();
+  o.open(); for (int i = 0; i < EX_MAX_INPUTS; ++i) o.num(P.in_has_valid[i]); o.close();
   o.num(P.n_ins); o.num(P.n_inputs); o.num(P.n_slots); o.num(P.n_filter_ins); o.num(P.filter_slot); o.num(P.filter_dep);
   o.null(); o.null();
   o.close();
@@ -101,6 +104,8 @@ std::string jit_meta(const FaArgs& A) {
   o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_type[k]); o.close();
   o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_off[k]); o.close();
   o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_words[k]); o.close();
+  o.open(); for (int k = 0; k < FA_KW; ++k) o.num(A.key_has_valid[k]); o.close();
+  o.num(A.has_filter);
   o.num(A.nkeys); o.num(A.nkey_words); o.num(A.validity_word); o.num(A.hash_word); o.num(A.W);
   o.num(A.naggs); o.num(A.nwords); o.num(A.state_off);
   o.open(); for (int w = 0; w < FA_MAXW; ++w) o.num(A.wm[w]); o.close();
@@ -141,7 +146,66 @@ bool write_file(const std::string& path, const char* data, size_t n) {
   fclose(f);
   return ok;
 }
+// gfx target of the code object: the device the library drives (hipGetDeviceProperties().gcnArchName up to the first ':'),
+// DBHIP_JIT_ARCH to override, gfx950 when no device is visible (offline compile checks)
+std::string jit_arch() {
+  if (const char* e = getenv("DBHIP_JIT_ARCH")) return e;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+    std::string a = prop.gcnArchName;
+    const size_t c = a.find(':');
+    return c == std::string::npos ? a : a.substr(0, c);
+  }
+  return "gfx950";
+}
+
+uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ULL; }
+  return h;
+}
+// On-disk cache of code objects, keyed by everything that determines the code: generated metadata + variant, the embedded
+// device headers, the compiler flags and the target. DBHIP_JIT_CACHE_DIR names the directory ("" / "off" disables); default
+// $XDG_CACHE_HOME/dbhip or ~/.cache/dbhip. A new process finds the kernels of the query shapes an earlier one PREPAREd and
+// pays a file read (tens of microseconds) instead of a 0.5 s compile.
+std::string jit_cache_dir() {
+  if (const char* e = getenv("DBHIP_JIT_CACHE_DIR")) return (!*e || !strcmp(e, "off")) ? std::string() : std::string(e);
+  if (const char* x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/dbhip";
+  if (const char* h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/dbhip";
+  return std::string();
+}
+std::string jit_cache_path(const std::string& meta, const std::string& tail, const std::string& arch, const std::string& defs) {
+  const std::string dir = jit_cache_dir();
+  if (dir.empty()) return dir;
+  uint64_t h1 = 0xcbf29ce484222325ULL, h2 = 0x84222325cbf29ce4ULL;
+  auto mix = [&](const void* d, size_t n) { h1 = fnv1a(d, n, h1); h2 = fnv1a(d, n, h2 ^ 0x9e3779b97f4a7c15ULL); };
+  mix(meta.data(), meta.size()); mix(tail.data(), tail.size()); mix(arch.data(), arch.size()); mix(defs.data(), defs.size());
+  for (int i = 0; i < kJitHdrCount; ++i) mix(kJitHdrSrc[i], strlen(kJitHdrSrc[i]));
+  char name[64];
+  snprintf(name, sizeof(name), "/fagg_%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
+  return dir + name;
+}
+bool read_file(const std::string& path, std::vector<char>* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out->insert(out->end(), buf, buf + n);
+  fclose(f);
+  return !out->empty();
+}
+void mkdir_p(const std::string& dir) {
+  for (size_t i = 1; i <= dir.size(); ++i)
+    if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
+}
+
 bool jit_compile(const std::string& meta, const std::string& tail, std::vector<char>* code, std::string* log) {
+  const std::string arch = jit_arch();
+  const std::string defs = getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
+  const std::string cached = jit_cache_path(meta, tail, arch, defs);
+  if (!cached.empty() && read_file(cached, code)) return true;   // compiled by an earlier process (or an earlier table)
+  code->clear();
   const std::string helper = jit_helper_path();
   if (helper.empty() || access(helper.c_str(), X_OK) != 0) { *log = "dbhip_jitc not found next to libdbhip.so (" + helper + ")"; return false; }
   char tmpl[] = "/tmp/dbhip_jit_XXXXXX";
@@ -157,7 +221,7 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   const std::string src = std::string(kJitPrelude) + "#include \"dbhip.h\"\n#include \"fagg_device.h\"\n" + tail;
   ok = ok && write_file(dir + "/fagg_meta.inc", meta.data(), meta.size()) && write_file(dir + "/main.hip", src.data(), src.size());
   if (!ok) { cleanup(); *log = "cannot write the sources to " + dir; return false; }
-  std::vector<std::string> args = {helper, dir + "/main.hip", dir + "/out.co", "-I" + dir, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm",
+  std::vector<std::string> args = {helper, dir + "/main.hip", dir + "/out.co", "-I" + dir, "--offload-arch=" + arch, "-O3", "-std=c++17", "-mllvm",
                                    "-pragma-unroll-threshold=4000000"};
   if (const char* e = getenv("DBHIP_FAGG_JIT_DEFS")) {   // experiment knobs, e.g. "-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
     std::string t;
@@ -180,17 +244,27 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   if (sp != 0) { cleanup(); *log = "posix_spawn(dbhip_jitc) failed"; return false; }
   const int deadline_ms = 60 * 1000;
   int status = 0, waited = 0;
-  bool done = false;
+  bool done = false, reaped_elsewhere = false;
   while (waited < deadline_ms) {
     const pid_t w = waitpid(pid, &status, WNOHANG);
     if (w == pid) { done = true; break; }
-    if (w < 0) break;
+    if (w < 0 && errno == EINTR) continue;
+    if (w < 0) { reaped_elsewhere = errno == ECHILD; break; }   // ECHILD: the host ignores SIGCHLD, the child is reaped for us
     usleep(10 * 1000);
     waited += 10;
   }
+  if (reaped_elsewhere) {
+    // no status to read (and no pid to signal: it may have been reused): wait for out.co to appear complete instead
+    for (; waited < deadline_ms && access((dir + "/out.co").c_str(), R_OK) != 0; waited += 10) usleep(10 * 1000);
+    usleep(50 * 1000);
+    status = 0;
+    done = access((dir + "/out.co").c_str(), R_OK) == 0;
+  }
   if (!done) {
-    kill(pid, SIGKILL);
-    waitpid(pid, &status, 0);
+    if (!reaped_elsewhere) {
+      kill(pid, SIGKILL);
+      while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+    }
     cleanup();
     *log = "dbhip_jitc did not finish within 60 s: killed";
     return false;
@@ -205,6 +279,11 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
     ok = f != nullptr;
     if (f) { char buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) code->insert(code->end(), buf, buf + n); fclose(f); }
     ok = ok && !code->empty();
+  }
+  if (ok && !cached.empty()) {   // publish atomically: a concurrent reader sees the whole file or none
+    mkdir_p(jit_cache_dir());
+    const std::string tmp = cached + "." + std::to_string((long long)getpid()) + ".tmp";
+    if (write_file(tmp, code->data(), code->size())) { if (rename(tmp.c_str(), cached.c_str()) != 0) unlink(tmp.c_str()); }
   }
   cleanup();
   return ok;
@@ -237,13 +316,25 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, bool 
   const int mode = jit_mode();
   if (mode == 0) return nullptr;
   if (mode == 2) compile = true;
-  const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
-  const std::string key = meta + tail + (getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
+  // in-process key: the binary image of the query shape (FaArgs with everything that varies between calls of one shape
+  // zeroed — the fields jit_meta prints as null / 0), the variant, the experiment knobs and the device the module is loaded
+  // on. (Generating the metadata TEXT per call to look the kernel up cost 0.25 ms of host time per launch.)
+  FaArgs K = A;
+  for (int i = 0; i < EX_MAX_INPUTS; ++i) { K.P.in_data[i] = nullptr; K.P.in_valid[i] = nullptr; K.P.in_voff[i] = 0; }
+  K.P.err_words = nullptr; K.P.err_count = nullptr;
+  for (int k = 0; k < FA_KW; ++k) { K.key[k].data = nullptr; K.key[k].validity = nullptr; K.key[k].voff = 0; K.key[k].buffers = nullptr; }
+  K.filter_bits = nullptr; K.filter_off = 0; K.n = 0; K.debug = 0; K.partial_rows = nullptr; K.ctrl = nullptr;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::string key((const char*)&K, sizeof(K));
+  key += "|" + std::to_string(slots) + "|" + std::to_string((int)general) + "|" + std::to_string(nw) + "|" + std::to_string(dev) + "|";
+  key += getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
   const bool trace = getenv("DBHIP_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_jit_mu);
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) return it->second.ok ? it->second.fn : nullptr;
   if (!compile) return nullptr;
+  const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
   JitEntry e;
   std::vector<char> code;
   std::string log;
@@ -287,19 +378,11 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
 
 static thread_local bool t_prepare_only = false;
 
-extern "C" {
-
-int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog, int64_t n,
-                                        const uint8_t* filter_bitmap, int64_t filter_bit_offset, void* stream) {
-  DBHIP_REQUIRE(g && keys && prog && prog->arg_regs, "dbhip_groupby_add_block_program: NULL argument");
-  const GbLayout& L = *dbhip_groupby_layout_internal(g);
-  if (!dbhip_fagg_layout_ok_internal(L)) {
-    set_error("dbhip_groupby_add_block_program: layout outside the fused kernel (<= %d key words, <= %d aggregates, <= %d state words)", FA_KW, FA_MAXA, FA_MAXW);
-    return DBHIP_ERR_UNSUPPORTED;
-  }
-  if (n == 0) return DBHIP_OK;
-  FaArgs A;
-  memset(&A, 0, sizeof(A));
+// Host side of the fused launch: compiles the program (roots = filter + one per aggregate argument), derives the per-word
+// metadata of the layout's states and copies the key columns. Touches no device: the offline compile check
+// (dbhip_fagg_jit_offline_internal, tools/jit_offline.py) goes through the same function.
+static int32_t fa_build_args(const GbLayout& L, const dbhip_col* keys, const dbhip_agg_program* prog, FaArgs& A, bool* out_general,
+                             int* out_nwords, bool* out_may_raise) {
   // ---- roots: filter + one per aggregate argument ----
   ExRoot roots[EX_MAX_ROOTS + 1];
   int n_roots = 0, filter_root = -1;
@@ -373,8 +456,33 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     c.data = keys[k].data; c.validity = keys[k].validity; c.voff = keys[k].validity_offset; c.buffers = keys[k].buffers;
     c.type = keys[k].type; c.is_scalar = keys[k].is_scalar;
     A.key_type[k] = L.key_type[k]; A.key_off[k] = L.key_off[k]; A.key_words[k] = L.key_words[k];
+    A.key_has_valid[k] = keys[k].validity != nullptr;
   }
+  *out_general = general; *out_nwords = nwords; *out_may_raise = may_raise;
+  return DBHIP_OK;
+}
+
+
+
+extern "C" {
+
+int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog, int64_t n,
+                                        const uint8_t* filter_bitmap, int64_t filter_bit_offset, void* stream) {
+  DBHIP_REQUIRE(g && keys && prog && prog->arg_regs, "dbhip_groupby_add_block_program: NULL argument");
+  const GbLayout& L = *dbhip_groupby_layout_internal(g);
+  if (!dbhip_fagg_layout_ok_internal(L)) {
+    set_error("dbhip_groupby_add_block_program: layout outside the fused kernel (<= %d key words, <= %d aggregates, <= %d state words)", FA_KW, FA_MAXA, FA_MAXW);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return DBHIP_OK;
+  FaArgs A;
+  memset(&A, 0, sizeof(A));
+  bool general = false, may_raise = false;
+  int nwords = 0;
+  int32_t rc = fa_build_args(L, keys, prog, A, &general, &nwords, &may_raise);
+  if (rc) return rc;
   A.filter_bits = filter_bitmap; A.filter_off = filter_bit_offset; A.n = n;
+  A.has_filter = filter_bitmap != nullptr;
   A.debug = getenv("DBHIP_FAGG_DEBUG") ? atoi(getenv("DBHIP_FAGG_DEBUG")) : 0;
   hipStream_t s = resolve_stream(stream);
   // (at least 6 slots: the end of the kernel stages one group's 12 state words per lane in the register file)
@@ -406,8 +514,8 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   if (t_prepare_only) {
     // dbhip_groupby_prepare_program: compile the specialised kernel of this query shape now (the 4-slot variant, or the
     // 8-slot one when the table already holds more than 4 groups), launch nothing
-    const int nw_p = nwords <= 4 ? 4 : FA_MAXW;
-    (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nw_p, true);
+    // (the specialised kernel is compiled for exactly `nwords` state words: no accumulator registers for words the layout lacks)
+    (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nwords, true);
     return DBHIP_OK;
   }
   // a table that already holds more than 4 groups starts with the 8-slot variant
@@ -419,13 +527,13 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     if (nwords <= 4) hipLaunchKernelGGL((fagg_kernel<SL, GEN, 4>), dim3(grid), dim3(256), lds, s, A);           \
     else hipLaunchKernelGGL((fagg_kernel<SL, GEN, FA_MAXW>), dim3(grid), dim3(256), lds, s, A);                 \
   } while (0)
-    const int sl = variant == 0 ? 4 : 8, nw_t = nwords <= 4 ? 4 : FA_MAXW;
-    hipFunction_t jf = jit_kernel(A, sl, general, nw_t, false);
+    const int sl = variant == 0 ? 4 : 8;
+    hipFunction_t jf = jit_kernel(A, sl, general, nwords, false);
     if (jf) {
       size_t asz = sizeof(A);
       void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
       // (LDS: only the staging of one group's accumulators at the end — the register file is in VGPRs)
-      DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nw_t * 256 * 8), s, nullptr, extra));
+      DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nwords * 256 * 8), s, nullptr, extra));
     }
     else if (variant == 0 && !general) FA_LAUNCH(4, false);
     else if (variant == 0) FA_LAUNCH(4, true);
@@ -528,6 +636,31 @@ int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64
   dbhip_agg_program prog;
   prog.prog = nullptr; prog.n_ins = 0; prog.inputs = inputs; prog.n_inputs = n_inputs; prog.filter_reg = -1; prog.arg_regs = arg_regs;
   return dbhip_groupby_add_block_program(g, keys, &prog, n, C.filter, C.filter_off + row0, (void*)s);
+}
+
+// Offline twin of dbhip_groupby_prepare_program (needs no device; tools/jit_offline.py): the specialised kernel's code object for
+// a table layout + program, written to `code_out` (returns its size, -1 with hiprtc's log in `log_out` on failure, -2 when the
+// shape is outside the fused kernel). The columns only need their types / scalar-ness / validity-ness (any non-null pointers).
+int32_t dbhip_groupby_build_layout_internal(const int32_t* key_types, const uint8_t* key_nullable, int nkeys, const dbhip_agg_desc* aggs,
+                                            int naggs, GbLayout* L);
+extern "C" int64_t dbhip_fagg_jit_offline_internal(const int32_t* key_types, const uint8_t* key_nullable, int32_t nkeys,
+                                                   const dbhip_agg_desc* aggs, int32_t naggs, const dbhip_col* keys,
+                                                   const dbhip_agg_program* prog, int32_t slots, char* code_out, int64_t code_cap,
+                                                   char* log_out, int64_t log_cap) {
+  GbLayout L;
+  if (dbhip_groupby_build_layout_internal(key_types, key_nullable, nkeys, aggs, naggs, &L) || !dbhip_fagg_layout_ok_internal(L)) return -2;
+  FaArgs A;
+  memset(&A, 0, sizeof(A));
+  bool general = false, may_raise = false;
+  int nwords = 0;
+  if (fa_build_args(L, keys, prog, A, &general, &nwords, &may_raise)) return -2;
+  std::vector<char> code;
+  std::string log;
+  const bool ok = jit_compile(jit_meta(A), jit_tail(slots, general, nwords), &code, &log);
+  if (log_out && log_cap > 0) snprintf(log_out, (size_t)log_cap, "%s", log.c_str());
+  if (!ok) return -1;
+  if ((int64_t)code.size() <= code_cap) memcpy(code_out, code.data(), code.size());
+  return (int64_t)code.size();
 }
 
 // Compiles the run-time specialisation of a small fixed query shape (i64 key; sum(i64 column), count(*)) and returns the

@@ -924,6 +924,13 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
   return DBHIP_OK;
 }
 
+}  // namespace
+int32_t dbhip_groupby_build_layout_internal(const int32_t* key_types, const uint8_t* key_nullable, int nkeys, const dbhip_agg_desc* aggs,
+                                            int naggs, GbLayout* L) {
+  return build_layout(key_types, key_nullable, nkeys, aggs, naggs, L);
+}
+namespace {
+
 // Per-table scratch and the table arrays come from the library's block cache (dbhip_alloc / dbhip_free: freed blocks of
 // >= 1 MiB are kept in size-class lists), so a plan that creates a table per block does not pay hipMalloc / hipFree of
 // GB-sized buffers per call (a fresh 9 GB hipMalloc costs tens of milliseconds).
