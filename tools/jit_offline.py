@@ -53,6 +53,14 @@ def plain4_shape():
     return [L.T_I64], [0], aggs, [FakeCol(L.T_I64)], p, [("input", 0), None], -1
 
 
+def general_shape():
+    """i64 key; sum(nullable i64), count(*), sum(Decimal64), max(nullable i64) over plain input columns (tests/test_gpu_fused.py)"""
+    a, d = FakeCol(L.T_I64, nullable=True), FakeCol(L.T_DEC64, 15, 2)
+    p = D.ExprProgram([a, d])
+    aggs = [(L.AGG_SUM, L.T_I64, 0, 0, 1), (L.AGG_COUNT, 0, 0, 0, 0), (L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_MAX, L.T_I64, 0, 0, 1)]
+    return [L.T_I64], [0], aggs, [FakeCol(L.T_I64)], p, [("input", 0), None, ("input", 1), ("input", 0)], -1
+
+
 def compile_shape(shape, slots, defs):
     key_types, key_nullable, aggs, keys, p, arg_regs, filter_reg = shape
     lib = L.load_library()
@@ -90,7 +98,7 @@ def main():
     ap.add_argument("--defs", default="")
     ap.add_argument("--keep", default="/tmp/jit_offline")
     a = ap.parse_args()
-    code = compile_shape({"q1": q1_shape, "plain4": plain4_shape}[a.shape](), a.slots, a.defs)
+    code = compile_shape({"q1": q1_shape, "plain4": plain4_shape, "general": general_shape}[a.shape](), a.slots, a.defs)
     open(a.keep + ".co", "wb").write(code)
     llvm = "/opt/rocm/lib/llvm/bin"
     asm = subprocess.run([f"{llvm}/llvm-objdump", "-d", a.keep + ".co"], capture_output=True, text=True, check=True).stdout
