@@ -939,6 +939,67 @@ def pack_keys(cols, key_bytes=None, want_validity=True):
     return PackedKeys(out, val, n, kb)
 
 
+def serialize_keys(cols, n=None):
+    """HashMethodSerializer::build_keys_state (dbhip_serialize_keys): -> (offsets DeviceBuffer [n + 1] u64, data DeviceBuffer,
+    all_valid DeviceBuffer bitmap, total bytes)"""
+    n = n if n is not None else max(c.n for c in cols if not c.is_scalar)
+    off = DeviceBuffer((n + 1) * 8 + 64)
+    allv = DeviceBuffer(((n + 63) // 64) * 8 + 8)
+    total = C.c_uint64()
+    ca = _cols(cols)
+    check(lib().dbhip_serialize_keys_offsets(ca, len(cols), C.c_int64(n), C.c_void_p(off.ptr), C.c_void_p(allv.ptr), C.byref(total), None))
+    data = DeviceBuffer(int(total.value) + 64)
+    check(lib().dbhip_serialize_keys(ca, len(cols), C.c_int64(n), C.c_void_p(off.ptr), C.c_void_p(data.ptr), None))
+    return off, data, allv, int(total.value)
+
+
+class BinaryHashJoin:
+    """Hash join on serialized keys (HashMethodSerializer: string keys of any length, keys wider than 32 bytes):
+    dbhip_join_*_binary. add_block / probe_block take the key COLUMNS and serialize them on the device."""
+
+    def __init__(self, expected_build_rows=1024):
+        _ensure()
+        self.h = C.c_void_p()
+        check(lib().dbhip_join_create_binary(C.c_int64(expected_build_rows), C.byref(self.h)))
+
+    def add_block(self, key_cols, n=None, use_validity=True):
+        n = n if n is not None else max(c.n for c in key_cols if not c.is_scalar)
+        off, data, allv, _ = serialize_keys(key_cols, n)
+        nullable = use_validity and any(c.validity is not None for c in key_cols)
+        check(lib().dbhip_join_add_build_binary(self.h, C.c_void_p(off.ptr), C.c_void_p(data.ptr), C.c_void_p(allv.ptr) if nullable else None, C.c_int64(n), None))
+
+    def final_build(self):
+        check(lib().dbhip_join_finalize_binary(self.h, None))
+
+    def probe_block(self, key_cols, n=None, use_validity=True):
+        """-> (probe_idx u32[], build_row u32[], matched bool[n])"""
+        n = n if n is not None else max(c.n for c in key_cols if not c.is_scalar)
+        off, data, allv, _ = serialize_keys(key_cols, n)
+        nullable = use_validity and any(c.validity is not None for c in key_cols)
+        vptr = C.c_void_p(allv.ptr) if nullable else None
+        cap = C.c_uint64()
+        check(lib().dbhip_join_probe_count_binary(self.h, C.c_void_p(off.ptr), C.c_void_p(data.ptr), vptr, C.c_int64(n), C.byref(cap), None))
+        m = int(cap.value)
+        pi, bi = DeviceBuffer(max(m, 1) * 4 + 64), DeviceBuffer(max(m, 1) * 4 + 64)
+        mark = DeviceBuffer(((n + 31) // 32) * 4 + 8)
+        got = C.c_uint64()
+        check(lib().dbhip_join_probe_binary(self.h, C.c_void_p(off.ptr), C.c_void_p(data.ptr), vptr, C.c_int64(n), C.c_void_p(pi.ptr), C.c_void_p(bi.ptr),
+                                            C.c_int64(m), C.byref(got), C.c_void_p(mark.ptr), None))
+        k = int(got.value)
+        return pi.to_numpy(np.uint32, k), bi.to_numpy(np.uint32, k), unpack_bits(mark.to_numpy(np.uint8, (n + 7) // 8), n)
+
+    def destroy(self):
+        if self.h:
+            lib().dbhip_join_destroy_binary(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class HashJoin:
     """Device hash join on packed fixed keys (dbhip_join_*; trait Join, new_hash_join/join.rs:26-53).
     key_bytes 8 = KeysU8..U64 (zero-extended), 16 = KeysU128, 32 = KeysU256."""

@@ -524,12 +524,25 @@ int32_t dbhip_q1_fused(dbhip_groupby* g,
  * the row's key is that byte string read as ONE integer of 1/2/4/8/16/32 bytes
  * (golden: tests/it/group_by.rs:52-58, three Int8 columns [1,1,1] -> 0x10101).
  * dbhip_keys_method returns the key width the reference would choose (0 = HashMethodSerializer /
- * SingleBinary: keep the CPU method). dbhip_pack_keys may be asked for a wider key than needed
+ * SingleBinary: dbhip_serialize_keys + dbhip_join_*_binary below). dbhip_pack_keys may be asked for a wider key than needed
  * (zero-extended; the join table takes 8- and 16-byte keys). `out_all_valid` (may be NULL):
  * LSB-first bitmap, bit = no key column is NULL in that row (join keys with a NULL never match). */
 int32_t dbhip_keys_method(const dbhip_col* cols, int32_t ncols, int32_t* out_key_bytes_host);
 int32_t dbhip_pack_keys(const dbhip_col* cols, int32_t ncols, int64_t n, int32_t key_bytes,
                         void* out_keys, uint8_t* out_all_valid, void* stream);
+
+/* HashMethodSerializer (group_by_hash/method_serializer.rs:33-52, utils.rs:33-160 serialize_group_columns): the key columns of
+ * a row serialized back to back into ONE BinaryColumn — the method choose_hash_method_with_types falls to when a key column is
+ * not a fixed-width number / date / decimal or the packed key exceeds 32 bytes (dbhip_keys_method returns 0). Per column:
+ * numbers / decimals / dates / timestamps = the value's little-endian bytes; Boolean = one byte; String = u64 length + the
+ * bytes; a nullable column = one byte `valid` followed by the value only when valid.
+ *   dbhip_serialize_keys_offsets  the BinaryColumn's offsets (n + 1 u64 on the device, offsets[0] = 0), the total byte count
+ *                                 (host) and, optionally, `out_all_valid` (LSB-first: no key column is NULL in the row — join
+ *                                 keys with a NULL never match); synchronises
+ *   dbhip_serialize_keys          writes the bytes (out_data holds offsets[n] bytes) */
+int32_t dbhip_serialize_keys_offsets(const dbhip_col* cols, int32_t ncols, int64_t n, uint64_t* out_offsets, uint8_t* out_all_valid,
+                                     uint64_t* out_total_bytes_host, void* stream);
+int32_t dbhip_serialize_keys(const dbhip_col* cols, int32_t ncols, int64_t n, const uint64_t* offsets, uint8_t* out_data, void* stream);
 
 /* ---- a15: hash join ---------------------------------------------------------
  * Replaces HashJoinHashTable<K> build/probe behind trait Join
@@ -560,6 +573,26 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
 int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                               uint8_t* out_matched_bitmap, uint64_t* out_n_matched_host, void* stream);
 int32_t dbhip_join_destroy(dbhip_join* j);
+
+/* Hash join on SERIALIZED keys (HashMethodSerializer: string keys of any length, keys wider than 32 bytes; the reference's
+ * BinaryHashJoinHashTable, hash_join_table + new_hash_join/hashtable/serialize_keys.rs): rows are (offsets[n + 1], data) as
+ * dbhip_serialize_keys produces them (any BinaryColumn works). Keys are equal iff their bytes are equal: a 128-bit hash of the
+ * bytes routes a row through the fixed-key table and every candidate pair is verified byte for byte against the build rows,
+ * which the table keeps a copy of. Same pair order as dbhip_join_probe (by probe row, then build row).
+ *   probe_count_binary  an UPPER bound of the pairs (candidates by hash) to size the buffers with
+ *   probe_binary        the verified pairs, their number, and optionally the "probe row has a match" bitmap (LSB-first,
+ *                       ceil(n / 32) * 4 bytes, 4-byte aligned) for semi / anti / left-outer assembly */
+typedef struct dbhip_join_binary dbhip_join_binary;
+int32_t dbhip_join_create_binary(int64_t expected_build_rows, dbhip_join_binary** out_host);
+int32_t dbhip_join_add_build_binary(dbhip_join_binary* j, const uint64_t* offsets, const uint8_t* data, const uint8_t* validity, int64_t n,
+                                    void* stream);
+int32_t dbhip_join_finalize_binary(dbhip_join_binary* j, void* stream);
+int32_t dbhip_join_probe_count_binary(dbhip_join_binary* j, const uint64_t* offsets, const uint8_t* data, const uint8_t* validity, int64_t n,
+                                      uint64_t* out_max_pairs_host, void* stream);
+int32_t dbhip_join_probe_binary(dbhip_join_binary* j, const uint64_t* offsets, const uint8_t* data, const uint8_t* validity, int64_t n,
+                                uint32_t* out_probe_idx, uint32_t* out_build_row, int64_t max_pairs, uint64_t* out_n_pairs_host,
+                                uint8_t* out_matched_bitmap, void* stream);
+int32_t dbhip_join_destroy_binary(dbhip_join_binary* j);
 
 /* ---- a16: sort / top-k --------------------------------------------------------
  * Replaces DataBlock::sort_with_type / SortCompare

@@ -1781,3 +1781,56 @@ int orc_pack_keys(const orc_col* cols, int ncols, int64_t n, int key_bytes, uint
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* HashMethodSerializer: serialize_group_columns / serialize_column_binary     */
+/* (src/query/expression/src/kernels/group_by_hash/utils.rs:33-160,           */
+/*  method_serializer.rs:33-52): per row, column after column — numbers /     */
+/* decimals / dates / timestamps as their little-endian bytes, Boolean as one  */
+/* byte, String as u64 length + bytes, a nullable column as one byte `valid`   */
+/* followed by the value only when valid. offsets[n + 1]; data may be NULL to  */
+/* size. Returns the total number of bytes, -1 for an unsupported column.      */
+/* ------------------------------------------------------------------------ */
+static int ser_fixed_width(int type) {
+  switch (type) {
+    case ORC_T_BOOL: case ORC_T_I8: case ORC_T_U8: return 1;
+    case ORC_T_I16: case ORC_T_U16: return 2;
+    case ORC_T_I32: case ORC_T_U32: case ORC_T_F32: case ORC_T_DATE: return 4;
+    case ORC_T_I64: case ORC_T_U64: case ORC_T_F64: case ORC_T_TIMESTAMP: case ORC_T_DEC64: return 8;
+    case ORC_T_DEC128: return 16;
+    case ORC_T_DEC256: return 32;
+    default: return 0;
+  }
+}
+int64_t orc_serialize_keys(const orc_col* cols, int ncols, int64_t n, uint64_t* offsets, uint8_t* data) {
+  uint64_t pos = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    offsets[i] = pos;
+    for (int c = 0; c < ncols; ++c) {
+      const orc_col* col = &cols[c];
+      int64_t j = col->is_scalar ? 0 : i;
+      if (col->validity) { /* Column::Nullable: push valid, then the value only when valid */
+        int valid = col_valid(col, i);
+        if (data) data[pos] = (uint8_t)valid;
+        pos += 1;
+        if (!valid) continue;
+      }
+      if (col->type == ORC_T_STRING) {
+        uint32_t len; const uint8_t* p = view_bytes((const uint32_t*)col->data + 4 * j, col->buffers, &len);
+        uint64_t l64 = len;
+        if (data) { memcpy(data + pos, &l64, 8); memcpy(data + pos + 8, p, len); }
+        pos += 8 + len;
+      } else if (col->type == ORC_T_BOOL) {
+        if (data) data[pos] = (uint8_t)bit_get((const uint8_t*)col->data, j);
+        pos += 1;
+      } else {
+        int w = ser_fixed_width(col->type);
+        if (!w) return -1;
+        if (data) memcpy(data + pos, (const uint8_t*)col->data + (size_t)j * w, (size_t)w);
+        pos += (uint64_t)w;
+      }
+    }
+  }
+  offsets[n] = pos;
+  return (int64_t)pos;
+}
