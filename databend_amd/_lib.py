@@ -89,7 +89,7 @@ SYMBOLS = [
     "dbhip_join_add_build_binary", "dbhip_join_finalize_binary", "dbhip_join_probe_count_binary", "dbhip_join_probe_binary", "dbhip_join_destroy_binary",
     "dbhip_join_create", "dbhip_join_create_keys", "dbhip_join_probe_mark",
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
-    "dbhip_join_destroy", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
+    "dbhip_join_destroy", "dbhip_join_mark_build", "dbhip_join_build_matched", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
     "dbhip_vec_topk_merge", "dbhip_vec_index_build", "dbhip_vec_index_search", "dbhip_vec_index_destroy",
     "dbhip_hnsw_build", "dbhip_hnsw_from_graph", "dbhip_hnsw_export_graph", "dbhip_hnsw_search", "dbhip_hnsw_scores",
     "dbhip_hnsw_encoded", "dbhip_hnsw_meta", "dbhip_hnsw_destroy",

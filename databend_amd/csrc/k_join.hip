@@ -45,6 +45,9 @@ struct dbhip_join {
   // the last counted probe block: dbhip_join_probe of the SAME block (count first, then emit into buffers of the
   // right size — the only way a caller can size its outputs) reuses the counts instead of walking the table again
   const void* prep_keys; const uint8_t* prep_valid; int64_t prep_n; uint64_t prep_total; hipStream_t prep_stream; bool prepared;
+  // right / full outer, right semi / anti joins: bit r = build row r was matched by some probe row of ANY probe block so far
+  // (the reference's per-row scan map, new_hash_join/memory/right_join*.rs; allocated on first use, after finalize)
+  uint32_t* bmark; int64_t bmark_rows;
 };
 
 namespace {
@@ -564,10 +567,45 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
   return DBHIP_OK;
 }
 
+// mark[b >> 5] |= 1 << (b & 31) for every build row b of the pairs
+static __global__ __launch_bounds__(256) void join_mark_build_kernel(const uint32_t* build_rows, int64_t n, int64_t nrows, uint32_t* mark) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = build_rows[i];
+    if ((int64_t)b < nrows) atomicOr(&mark[b >> 5], 1u << (b & 31));
+  }
+}
+
+int32_t dbhip_join_mark_build(dbhip_join* j, const uint32_t* build_rows, int64_t n_pairs, void* stream) {
+  DBHIP_REQUIRE(j && j->finalized && (build_rows || n_pairs == 0), "dbhip_join_mark_build: needs a finalized table and the pairs' build rows");
+  hipStream_t s = resolve_stream(stream);
+  if (!j->bmark) {
+    const size_t bytes = (size_t)ceil_div(j->nrows > 0 ? j->nrows : 1, 64) * 8;
+    int32_t rc = dbhip_alloc(bytes, (void**)&j->bmark);
+    if (rc) return rc;
+    DBHIP_CHECK(hipMemsetAsync(j->bmark, 0, bytes, s));
+    j->bmark_rows = j->nrows;
+  }
+  if (n_pairs == 0) return DBHIP_OK;
+  hipLaunchKernelGGL(join_mark_build_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, build_rows, n_pairs, j->nrows, j->bmark);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_join_build_matched(dbhip_join* j, uint8_t* out_bitmap, int64_t* out_build_rows_host, void* stream) {
+  DBHIP_REQUIRE(j && j->finalized && out_build_rows_host, "dbhip_join_build_matched: needs a finalized table");
+  *out_build_rows_host = j->nrows;
+  if (!out_bitmap || j->nrows == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  const size_t bytes = (size_t)ceil_div(j->nrows, 64) * 8;
+  if (!j->bmark) DBHIP_CHECK(hipMemsetAsync(out_bitmap, 0, bytes, s));   // no probe block marked anything yet
+  else DBHIP_CHECK(hipMemcpyAsync(out_bitmap, j->bmark, bytes, hipMemcpyDeviceToDevice, s));
+  return DBHIP_OK;
+}
+
 int32_t dbhip_join_destroy(dbhip_join* j) {
   if (!j) return DBHIP_OK;
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev};
+  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev, j->bmark};
   for (void* p : ptrs)
     if (p) (void)dbhip_free(p);
   delete j;

@@ -1000,6 +1000,16 @@ class BinaryHashJoin:
             pass
 
 
+def _with_true_validity(col, n):
+    """wrap_true_validity: the probe side of a right join becomes Nullable (all valid for matched rows)"""
+    if col.validity is not None:
+        return col
+    ones = DeviceBuffer(((max(n, 1) + 63) // 64) * 8 + 8)
+    check(lib().dbhip_memset(C.c_void_p(ones.ptr), 0xFF, C.c_size_t(((max(n, 1) + 63) // 64) * 8), None))
+    col.validity = ones
+    return col
+
+
 class HashJoin:
     """Device hash join on packed fixed keys (dbhip_join_*; trait Join, new_hash_join/join.rs:26-53).
     key_bytes 8 = KeysU8..U64 (zero-extended), 16 = KeysU128, 32 = KeysU256."""
@@ -1056,8 +1066,10 @@ class HashJoin:
         return op, ob, m
 
     def join(self, kind, probe_keys, probe_cols, build_cols):
-        """Output assembly of `kind` in ("inner", "left", "left_semi", "left_anti") for ONE probe block against the finished build
-        side (new_hash_join/memory/{inner_join,left_join,left_join_semi,left_join_anti}.rs; no other conjunct):
+        """Output assembly of `kind` in ("inner", "left", "left_semi", "left_anti", "right", "right_semi", "right_anti", "full") for
+        ONE probe block against the finished build side (new_hash_join/memory/{inner_join,left_join,left_join_semi,left_join_anti,
+        right_join,right_join_semi,right_join_anti,full_join}.rs; no other conjunct); the right / full kinds are completed by
+        final_probe() after the last block:
           inner      matched pairs: probe columns taken by probe_idx, build columns by build_row
           left       the same, build columns Nullable with a true validity (wrap_true_validity), FOLLOWED by the unmatched
                      probe rows with a null build block (left_join.rs:196-232)
@@ -1083,6 +1095,22 @@ class HashJoin:
             if kind == "left_anti":
                 return [take(c, usel, uk) for c in probe_cols], [], uk
         op, ob, m = self.probe_block_device(probe_keys)
+        if kind in ("right", "right_semi", "right_anti", "full"):
+            # the build side remembers which of its rows found a partner, across probe blocks (right_join.rs: the scan map)
+            check(lib().dbhip_join_mark_build(self.h, C.c_void_p(ob.ptr), C.c_int64(m), None))
+            if kind in ("right_semi", "right_anti"):
+                return [], [], 0     # everything comes out of final_probe
+            if kind == "right":
+                return [_with_true_validity(take(c, op, m), m) for c in probe_cols], [take(c, ob, m) for c in build_cols], m
+            kind = "left"            # full = left outer per probe block + the unmatched build rows at final_probe
+            words = (max(n, 1) + 63) // 64
+            bm = DeviceBuffer(words * 8 + 64)
+            bm.zero()
+            total = C.c_uint64()
+            check(lib().dbhip_join_probe_mark(self.h, C.c_void_p(probe_keys.data.ptr), v, C.c_int64(n), C.c_void_p(bm.ptr), C.byref(total), None))
+            false_ = Column.boolean(np.zeros(1, dtype=bool))
+            false_.is_scalar = True
+            usel, uk = filter_select(cmp(L.CMP_EQ, Column(L.T_BOOL, n, bm), false_, n))
         if kind == "inner":
             return [take(c, op, m) for c in probe_cols], [take(c, ob, m) for c in build_cols], m
         if kind != "left":
@@ -1104,6 +1132,37 @@ class HashJoin:
                                          C.c_void_p(valid.ptr), None))
             out_b.append(Column(c.dtype, rows, data, valid, c.precision, c.scale, buffers=c.buffers, keep=(c,)))
         return [take(c, pidx, rows) for c in probe_cols], out_b, rows
+
+    def final_probe(self, kind, build_cols, probe_cols_like=()):
+        """After the last probe block of a right / right_semi / right_anti / full join (Join::final_probe,
+        new_hash_join/memory/right_join*.rs, full_join.rs): the build rows that never found a partner, with a NULL probe side
+        (right, full), or alone (right_anti), or the build rows that did (right_semi). -> (probe Columns, build Columns, n)"""
+        nb = C.c_int64()
+        check(lib().dbhip_join_build_matched(self.h, None, C.byref(nb), None))
+        nb = nb.value
+        bm = DeviceBuffer(((max(nb, 1) + 63) // 64) * 8 + 8)
+        check(lib().dbhip_join_build_matched(self.h, C.c_void_p(bm.ptr), C.byref(C.c_int64()), None))
+        matched = Column(L.T_BOOL, nb, bm)
+        if kind == "right_semi":
+            sel, k = filter_select(matched)
+        else:
+            false_ = Column.boolean(np.zeros(1, dtype=bool))
+            false_.is_scalar = True
+            sel, k = filter_select(cmp(L.CMP_EQ, matched, false_, nb))
+        out_b = [take(c, sel, k) for c in build_cols]
+        if kind in ("right_semi", "right_anti"):
+            return [], out_b, k
+        none = DeviceBuffer(max(k, 1) * 4 + 64)
+        check(lib().dbhip_memset(C.c_void_p(none.ptr), 0xFF, C.c_size_t(max(k, 1) * 4), None))
+        out_p = []
+        for c in probe_cols_like:     # all-NULL columns of the probe side's types
+            es = ELEM_SIZE[c.dtype]
+            data = DeviceBuffer(max(k, 1) * es + 64)
+            valid = DeviceBuffer(((max(k, 1) + 63) // 64) * 8 + 8)
+            check(lib().dbhip_take_outer(C.c_void_p(c.data.ptr), None, C.c_int64(0), es, C.c_void_p(none.ptr), C.c_int64(k), C.c_void_p(data.ptr),
+                                         C.c_void_p(valid.ptr), None))
+            out_p.append(Column(c.dtype, k, data, valid, c.precision, c.scale))
+        return out_p, out_b, k
 
     def destroy(self):
         if self.h:

@@ -572,6 +572,13 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
                          uint64_t* out_n_pairs_host, void* stream);
 int32_t dbhip_join_probe_mark(dbhip_join* j, const void* keys, const uint8_t* validity, int64_t n,
                               uint8_t* out_matched_bitmap, uint64_t* out_n_matched_host, void* stream);
+/* Right / full outer, right semi / right anti joins (new_hash_join/memory/right_join.rs, right_join_semi.rs, right_join_anti.rs,
+ * full_join.rs): the table keeps one "matched" bit per BUILD row across all probe blocks (the reference's scan map).
+ * dbhip_join_mark_build ORs in the build rows of a probe block's pairs (after whatever conjunct filtering the binding applies);
+ * dbhip_join_build_matched copies the bitmap out (LSB-first, ceil(build_rows / 64) * 8 bytes) for final_probe: the unmatched
+ * build rows follow with a NULL probe side (right / full), or the matched / unmatched build rows alone (semi / anti). */
+int32_t dbhip_join_mark_build(dbhip_join* j, const uint32_t* build_rows, int64_t n_pairs, void* stream);
+int32_t dbhip_join_build_matched(dbhip_join* j, uint8_t* out_bitmap, int64_t* out_build_rows_host, void* stream);
 int32_t dbhip_join_destroy(dbhip_join* j);
 
 /* Hash join on SERIALIZED keys (HashMethodSerializer: string keys of any length, keys wider than 32 bytes; the reference's

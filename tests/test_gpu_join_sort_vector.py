@@ -500,3 +500,69 @@ def test_join_on_keys_u256(gpu, oracle, nb, np_, card):
     assert np.array_equal(marks, em)
     pc, _, rows = j.join("left_anti", pkeys, [gpu.Column.from_numpy(np.arange(np_, dtype=np.uint32))], [])
     assert rows == int((~em).sum()) and np.array_equal(pc[0].to_numpy(), np.nonzero(~em)[0])
+
+
+@pytest.mark.parametrize("kind", ["right", "right_semi", "right_anti", "full"])
+def test_right_and_full_join_kinds_over_two_probe_blocks(gpu, kind):
+    """Right / right-semi / right-anti / full outer joins (new_hash_join/memory/{right_join,right_join_semi,right_join_anti,
+    full_join}.rs): the table keeps one matched bit per build row across probe blocks (dbhip_join_mark_build), final_probe
+    emits the build rows by that bit with a NULL probe side. Expected rows from a plain Python statement of the join; NULL keys
+    never match; the comparison is on the multiset of (probe payload | None, build payload | None) rows."""
+    rng = np.random.default_rng(11)
+    nb, np_, card = 4000, 5000, 1500
+    bk = rng.integers(0, card, nb).astype(np.uint64)
+    bvalid = rng.integers(0, 10, nb) > 0
+    bpay = rng.integers(-10**9, 10**9, nb).astype(np.int64)
+    blocks = []
+    for _ in range(2):
+        pk = rng.integers(0, card * 2, np_).astype(np.uint64)
+        pvalid = rng.integers(0, 10, np_) > 0
+        ppay = rng.integers(0, 2**31, np_).astype(np.int32)
+        blocks.append((pk, pvalid, ppay))
+    j = gpu.HashJoin(16)
+    j.add_block(gpu.Column.from_numpy(bk, validity=bvalid))
+    j.final_build()
+    build_cols = [gpu.Column.from_numpy(bpay)]
+    got = []
+
+    def rows_of(pc, bc, n):
+        pv = [None] * n
+        bv = [None] * n
+        if pc:
+            vals, ok = pc[0].to_numpy(), pc[0].validity_numpy()
+            pv = [int(vals[i]) if ok[i] else None for i in range(n)]
+        if bc:
+            vals, ok = bc[0].to_numpy(), bc[0].validity_numpy()
+            bv = [int(vals[i]) if ok[i] else None for i in range(n)]
+        return list(zip(pv, bv))
+    like = None
+    for pk, pvalid, ppay in blocks:
+        pcols = [gpu.Column.from_numpy(ppay)]
+        like = pcols
+        pc, bc, n = j.join(kind, gpu.Column.from_numpy(pk, validity=pvalid), pcols, build_cols)
+        got += rows_of(pc, bc, n)
+    pc, bc, n = j.final_probe(kind, build_cols, like)
+    tail = rows_of(pc, bc, n)
+    got += tail
+    # the Python statement
+    table = {}
+    for b in range(nb):
+        if bvalid[b]:
+            table.setdefault(int(bk[b]), []).append(b)
+    matched_b = np.zeros(nb, bool)
+    exp = []
+    for pk, pvalid, ppay in blocks:
+        for p in range(np_):
+            bs = table.get(int(pk[p]), []) if pvalid[p] else []
+            for b in bs:
+                matched_b[b] = True
+                if kind in ("right", "full"):
+                    exp.append((int(ppay[p]), int(bpay[b])))
+            if not bs and kind == "full":
+                exp.append((int(ppay[p]), None))
+    if kind in ("right", "full", "right_anti"):
+        exp += [(None, int(bpay[b])) for b in np.nonzero(~matched_b)[0]]
+    if kind == "right_semi":
+        exp += [(None, int(bpay[b])) for b in np.nonzero(matched_b)[0]]
+    assert sorted(got, key=repr) == sorted(exp, key=repr) and len(tail) == (int(matched_b.sum()) if kind == "right_semi" else int((~matched_b).sum()))
+    assert 0 < matched_b.sum() < nb
