@@ -32,6 +32,11 @@ struct SortCol {
   int type;
   int desc;
   int nulls_first;
+  // String columns that hold a value longer than 12 bytes: nparts = 1 + ceil(max length / 8) images per value (part 0 = the
+  // length, part q = bytes [8 (nparts - 1 - q), +8) big-endian, zero padded past the end) and the column's data buffers;
+  // 0 = all values inline (the two-part image of the 16-byte view)
+  int nparts;
+  const void* const* buffers;
 };
 
 // order-preserving u64 image of one value (ascending)
@@ -66,6 +71,18 @@ __device__ __forceinline__ uint64_t sort_encode(const SortCol& c, uint32_t row, 
       return part == 0 ? p[0] : (p[1] ^ 0x8000000000000000ULL);
     }
     case DBHIP_T_STRING: {
+      if (c.nparts) {   // strings of any length: memcmp order of the bytes, then the length (variable.rs: a proper prefix sorts first)
+        const uint32_t* v = (const uint32_t*)c.data + 4 * (uint64_t)row;
+        const uint32_t len = v[0];
+        if (part == 0) return len;
+        const uint32_t at = 8u * (uint32_t)(c.nparts - 1 - part);
+        if (at >= len) return 0;
+        const uint8_t* p = len <= 12 ? (const uint8_t*)(v + 1) : (const uint8_t*)c.buffers[v[2]] + v[3];
+        const uint32_t take = len - at < 8 ? len - at : 8;
+        uint64_t img = 0;
+        for (uint32_t b = 0; b < take; ++b) img |= (uint64_t)p[at + b] << (8 * (7 - b));
+        return img;
+      }
       // inline view {len, 12 bytes}: memcmp order of the zero-padded bytes, then the length
       // (a proper prefix sorts first) — the image of the reference's variable row encoding
       // (sorts/core/row_convert/variable.rs) for strings of at most 12 bytes.
@@ -93,10 +110,13 @@ __host__ __device__ inline int sort_key_bytes(int type) {
   }
 }
 
-// flags strings that are not inline (len > 12): their order needs the data buffer, not built yet
-__global__ __launch_bounds__(256) void sort_check_inline_kernel(const uint32_t* views, int64_t n, uint32_t* flag) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if (views[4 * i] > 12) *flag = 1u;
+// the longest value of a string column (values of more than 12 bytes need the data buffers and more key images)
+__global__ __launch_bounds__(256) void sort_max_len_kernel(const uint32_t* views, int64_t n, uint32_t* out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = views[4 * i] > m ? views[4 * i] : m;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+  if (lane_id() == 0 && m) atomicMax(out, m);
 }
 
 __global__ __launch_bounds__(256) void sort_iota_kernel(uint32_t* perm, int64_t n) {
@@ -344,26 +364,26 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   uint32_t* pb[2] = {hist + nscan + 256, hist + nscan + 256 + n};
   int cur = 0;
   const int grid = grid_for(n, 256);
-  bool any_string = false;
-  for (int k = 0; k < nkeys; ++k) any_string |= keys[k].type == DBHIP_T_STRING;
-  if (any_string) {
+  // string keys: the longest value decides how many 8-byte images a value has (<= 12 bytes: the two images of the inline view)
+  int str_parts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < nkeys; ++k) {
+    if (keys[k].type != DBHIP_T_STRING) continue;
     DBHIP_CHECK(hipMemsetAsync(long_flag, 0, 4, s));
-    for (int k = 0; k < nkeys; ++k)
-      if (keys[k].type == DBHIP_T_STRING)
-        hipLaunchKernelGGL(sort_check_inline_kernel, dim3(grid), dim3(256), 0, s, (const uint32_t*)keys[k].data, n, long_flag);
-    uint32_t f = 0;
-    DBHIP_CHECK(hipMemcpyAsync(&f, long_flag, 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(sort_max_len_kernel, dim3(grid), dim3(256), 0, s, (const uint32_t*)keys[k].data, n, long_flag);
+    uint32_t mx = 0;
+    DBHIP_CHECK(hipMemcpyAsync(&mx, long_flag, 4, hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
-    if (f) {
-      set_error("dbhip_sort_perm: a string sort key is longer than 12 bytes; keep the CPU operator for this block");
-      return DBHIP_ERR_UNSUPPORTED;
+    if (mx > 12) {
+      if (!keys[k].buffers) { set_error("dbhip_sort_perm: string key %d holds values longer than 12 bytes but no data buffers", k); return DBHIP_ERR_INVALID; }
+      if (mx > 4096) { set_error("dbhip_sort_perm: string key %d holds a %u-byte value (> 4096: keep the CPU operator for this block)", k, mx); return DBHIP_ERR_UNSUPPORTED; }
+      str_parts[k] = 1 + (int)((mx + 7) / 8);
     }
   }
   hipLaunchKernelGGL(sort_iota_kernel, dim3(grid), dim3(256), 0, s, pb[cur], n);
 
   auto make_col = [&](int k) {
     return SortCol{keys[k].data, keys[k].validity, keys[k].validity_offset, keys[k].type,
-                   desc_host ? desc_host[k] : 0, nulls_first_host ? nulls_first_host[k] : 0};
+                   desc_host ? desc_host[k] : 0, nulls_first_host ? nulls_first_host[k] : 0, str_parts[k], keys[k].buffers};
   };
   // enc = image of column c read through pb[cur][0..m); returns OR / AND of all images
   // `narrow`: 32-bit key images (columns of at most 4 bytes, null flags) in the same buffers
@@ -390,7 +410,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   // <= T; only those rows are sorted.
   if (limit > 0 && limit * 4 < n && n >= 65536 && !keys[0].validity) {
     SortCol c = make_col(0);
-    const int top_part = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 1 : 0;
+    const int top_part = c.nparts ? c.nparts - 1 : ((c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 1 : 0);
     uint64_t v_or, v_and;
     int32_t rc = encode(c, n, top_part, false, &v_or, &v_and);
     if (rc) return rc;
@@ -462,7 +482,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
 
   for (int k = nkeys - 1; k >= 0; --k) {
     SortCol c = make_col(k);
-    const int parts = (c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 2 : 1;
+    const int parts = c.nparts ? c.nparts : ((c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 2 : 1);
     uint64_t v_or, v_and;
     const bool narrow = sort_key_bytes(c.type) <= 4;
     for (int part = 0; part < parts; ++part) {

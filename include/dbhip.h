@@ -604,7 +604,9 @@ int32_t dbhip_join_destroy_binary(dbhip_join_binary* j);
 /* ---- a16: sort / top-k --------------------------------------------------------
  * Replaces DataBlock::sort_with_type / SortCompare
  * (kernels/sort.rs:91-113, kernels/sort_compare.rs:33-283): permutation of row ids
- * ordered by up to 4 fixed-width key columns with per-key asc/desc and
+ * ordered by up to 8 key columns — fixed-width types and Strings of any length up to 4096 bytes (memcmp order of the bytes,
+ * a proper prefix first: sorts/core/row_convert/variable.rs; values beyond 12 bytes cost one radix key image per 8 bytes of
+ * the column's longest value, constant bytes are skipped) — with per-key asc/desc and
  * nulls_first; `limit` (0 = none) keeps the first `limit` rows (LimitType::LimitRows).
  * The reference uses sort_unstable_by, so only the key sequence is part of the
  * contract; this implementation is stable (ties by ascending row id). */

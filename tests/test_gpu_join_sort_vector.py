@@ -412,8 +412,31 @@ def test_sort_short_string_keys(gpu):
             exp = sorted(exp, key=lambda t: t[1])
             exp = sorted(exp, key=lambda t: t[0], reverse=True)
         assert got == exp
-    with pytest.raises(Exception):
-        gpu.sort_perm([gpu.Column.strings([b"this string is longer than twelve bytes", b"x"])])
+
+
+@pytest.mark.parametrize("n", [7, 5000, 200_000])
+def test_sort_string_keys_of_any_length(gpu, n):
+    """ORDER BY on String keys beyond the 12 inline bytes (sorts/core/row_convert/variable.rs: memcmp order of the bytes, a
+    proper prefix first): c_name / c_comment-like values of 0..70 bytes sharing long prefixes, embedded NULs and 0xFF bytes,
+    NULLs first / last, asc / desc, a second key behind it, and LIMIT — against Python's bytes ordering."""
+    rng = np.random.default_rng(n)
+    base = [b"", b"a", b"Customer#000000001", b"Customer#000000002", b"Customer#00000000", b"Customer#000000001\x00", b"x" * 70, b"x" * 69 + b"y",
+            b"x" * 69, b"abcdefghijkl", b"abcdefghijklm", b"\xff" * 13, b"\xff" * 12, b"a\x00b" * 9, b"mid-length value 21.."]
+    strs = [base[i] + (b"%d" % rng.integers(0, 50) if rng.random() < 0.5 else b"") for i in rng.integers(0, len(base), n)]
+    k2 = rng.integers(0, 3, n).astype(np.int32)
+    valid = rng.integers(0, 9, n) > 0
+    for desc, nulls_first in ((0, 0), (1, 1), (0, 1)):
+        perm = gpu.sort_perm([gpu.Column.strings(strs, validity=valid), gpu.Column.from_numpy(k2)], desc=[desc, 0], nulls_first=[nulls_first, 0])
+        got = [((strs[i] if valid[i] else None), int(k2[i])) for i in perm]
+        rows = sorted(zip(strs, k2.tolist(), valid.tolist()), key=lambda t: t[1])
+        nulls = [(None, b) for s_, b, v in rows if not v]
+        vals = sorted(((s_, b) for s_, b, v in rows if v), key=lambda t: t[0], reverse=bool(desc))
+        # (a stable sort on the string after sorting on k2 keeps k2 ascending inside equal strings)
+        exp = nulls + vals if nulls_first else vals + nulls
+        assert got == exp
+    if n >= 5000:
+        top = gpu.sort_perm([gpu.Column.strings(strs)], limit=25)
+        assert [strs[i] for i in top] == sorted(strs)[:25]
 
 
 @pytest.mark.parametrize("kind", ["inner", "left", "left_semi", "left_anti"])
