@@ -1238,6 +1238,27 @@ def vec_topk_merge(dists, ids, k):
     return oi.to_numpy(np.uint32, nq * k).reshape(nq, k), od.to_numpy(np.float32, nq * k).reshape(nq, k)
 
 
+def kmeans(distance_type, data, rows_per_cluster, normalize_input=False):
+    """KMeans::compute on the device (dbhip_kmeans). data: float32 [rows, dim] numpy -> (assignments u32[rows], distances f32[rows], k, iterations)"""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    rows, dim = data.shape
+    buf = DeviceBuffer.from_numpy(data)
+    a, d = DeviceBuffer(rows * 4 + 64), DeviceBuffer(rows * 4 + 64)
+    k, it = C.c_int64(), C.c_int32()
+    check(lib().dbhip_kmeans(distance_type, C.c_void_p(buf.ptr), C.c_int64(rows), dim, C.c_int64(rows_per_cluster), int(bool(normalize_input)),
+                             C.c_void_p(a.ptr), C.c_void_p(d.ptr), C.byref(k), C.byref(it), None))
+    return a.to_numpy(np.uint32, rows), d.to_numpy(np.float32, rows), int(k.value), int(it.value)
+
+
+def vec_kernel_f32(which, a, b):
+    """VectorDistanceKernel::{dot (0), l2_squared (1), l1 (2)} over the rows of two float32 [n, dim] arrays"""
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    n, dim = a.shape
+    da, db, out = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer(max(n, 1) * 4 + 64)
+    check(lib().dbhip_vec_kernel_f32(which, C.c_void_p(da.ptr), C.c_void_p(db.ptr), C.c_int64(n), dim, C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.float32, n)
+
+
 class VectorIndex:
     """Exact device vector index (dbhip_vec_index_*; stands where HNSWIndex::{build, search} stands in the reference,
     hnsw_index/hnsw.rs:62-315): bf16 MFMA pre-filter with an error bound + exact f32 re-scoring."""

@@ -664,6 +664,22 @@ int32_t dbhip_vec_index_destroy(dbhip_vec_index* ix);
 int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base, int64_t n,
                        int32_t dim, float* out, void* stream);
 
+/* ---- §8f-4: vector-cluster KMeans and the f32 VectorDistanceKernel ------------------------------------------------------------
+ * Replaces KMeans::compute (src/query/storages/common/index/src/kmeans.rs:93-291: kmeans++ initialisation with the fixed LCG seed,
+ * Lloyd iterations until nothing changes or the centroid shift is <= 1e-4, at most 100) behind TransformVectorCluster
+ * (fuse/src/operations/common/processors/transform_vector_cluster.rs: batches of <= 262,144 rows, <= 64 clusters), and
+ * VectorDistanceKernel::{dot, l2_squared, l1} (vector.rs:45-260). The reference is deterministic — fixed seed, fixed summation
+ * orders (its production kernel: Avx, 8 fused lanes + tail) — and so is this: assignments and distances are BIT-IDENTICAL to
+ * the CPU path on x86_64 with avx2 + fma.
+ *   distance_type       0 = L1, 1 = L2, 2 = Dot (VectorDistanceType); `data` = rows x dim f32, row-major, on the device
+ *   normalize_input     != 0: every row is normalised first (vector_samples does this for Dot before KMeans::compute)
+ *   out_assignments     u32[rows] cluster ids, out_distances f32[rows] distance to the own centroid (build_result), both on the
+ *                       device; *out_k_host = ceil(rows / rows_per_cluster) clamped to [1, rows]; *out_iterations_host
+ * dbhip_vec_kernel_f32: out[i] = kernel(a[i], b[i]) over n pairs of dim-vectors; which 0 = dot, 1 = l2_squared, 2 = l1. */
+int32_t dbhip_kmeans(int32_t distance_type, const float* data, int64_t rows, int32_t dim, int64_t rows_per_cluster, int32_t normalize_input,
+                     uint32_t* out_assignments, float* out_distances, int64_t* out_k_host, int32_t* out_iterations_host, void* stream);
+int32_t dbhip_vec_kernel_f32(int32_t which, const float* a, const float* b, int64_t n, int32_t dim, float* out, void* stream);
+
 /* ---- Scan side: one Parquet column chunk -> one device-resident column --------
  * Replaces, per column, column_chunks_to_record_batch + the arrow -> Column conversion
  * (src/query/storages/fuse/src/io/read/block/parquet/deserialize.rs:33-81;

@@ -33,7 +33,7 @@ def load():
     if _LIB is not None:
         return _LIB
     so = os.path.join(ODIR, "liboracle.so")
-    srcs = [os.path.join(ODIR, f) for f in ("oracle.c", "decimal256.c", "hnsw_oracle.c", "parquet_oracle.c", "q1_typed.c")]
+    srcs = [os.path.join(ODIR, f) for f in ("oracle.c", "decimal256.c", "kmeans_oracle.c", "hnsw_oracle.c", "parquet_oracle.c", "q1_typed.c")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ODIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     L = C.CDLL(so)
