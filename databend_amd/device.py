@@ -1238,6 +1238,55 @@ def vec_topk_merge(dists, ids, k):
     return oi.to_numpy(np.uint32, nq * k).reshape(nq, k), od.to_numpy(np.float32, nq * k).reshape(nq, k)
 
 
+class Comm:
+    """dbhip_comm: the RCCL communicator behind the C-ABI (one rank per GPU). Comm.local() = a world of one without RCCL;
+    Comm(rank, world, id) = ncclCommInitRank with the 128-byte id of Comm.unique_id() (drawn by rank 0, shipped by the host)."""
+
+    def __init__(self, rank=0, world=1, unique_id=None):
+        _ensure()
+        self.h = C.c_void_p()
+        self.rank, self.world = rank, world
+        idbuf = (C.c_uint8 * 128)(*unique_id) if unique_id is not None else None
+        check(lib().dbhip_comm_create(rank, world, idbuf, C.byref(self.h)))
+
+    @classmethod
+    def local(cls):
+        return cls(0, 1, None)
+
+    @staticmethod
+    def unique_id():
+        _ensure()
+        buf = (C.c_uint8 * 128)()
+        check(lib().dbhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def exchange_allgather(self, table, max_rows=256, stream=None):
+        check(lib().dbhip_groupby_exchange_allgather(table.h, self.h, C.c_int64(max_rows), stream))
+
+    def exchange_alltoall(self, table, max_rows=256, stream=None):
+        check(lib().dbhip_groupby_exchange_alltoall(table.h, self.h, C.c_int64(max_rows), stream))
+
+    def allgather(self, send_ptr, recv_ptr, bytes_per_rank, stream=None):
+        check(lib().dbhip_comm_allgather(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_int64(bytes_per_rank), stream))
+
+    def alltoall(self, send_ptr, recv_ptr, bytes_per_peer, stream=None):
+        check(lib().dbhip_comm_alltoall(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_int64(bytes_per_peer), stream))
+
+    def allreduce_sum_u64(self, send_ptr, recv_ptr, count, stream=None):
+        check(lib().dbhip_comm_allreduce_sum_u64(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_int64(count), stream))
+
+    def destroy(self):
+        if self.h:
+            lib().dbhip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def kmeans(distance_type, data, rows_per_cluster, normalize_input=False):
     """KMeans::compute on the device (dbhip_kmeans). data: float32 [rows, dim] numpy -> (assignments u32[rows], distances f32[rows], k, iterations)"""
     data = np.ascontiguousarray(data, dtype=np.float32)

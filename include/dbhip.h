@@ -664,6 +664,31 @@ int32_t dbhip_vec_index_destroy(dbhip_vec_index* ix);
 int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base, int64_t n,
                        int32_t dim, float* out, void* stream);
 
+/* ---- §8e: the communicator behind the boundary (RCCL over xGMI) ----------------------------------------------------------------
+ * One process (rank) per GPU. Rank 0 calls dbhip_comm_unique_id and the host's own control plane ships the 128 bytes to the
+ * other ranks; every rank then calls dbhip_comm_create(rank, world, id) on the thread whose current device is its GPU
+ * (ncclCommInitRank; librccl.so is loaded with dlopen on first use — a single-GPU binding never loads it). world == 1 with
+ * id == NULL gives a local communicator whose exchanges are copies (tests, single-GPU plans).
+ *   dbhip_groupby_exchange_allgather  final merge for few groups (TPC-H Q1): the table as ONE fixed-size block of max_rows rows,
+ *        ncclAllGather, merge of the other ranks' blocks — flush, collective and merge queued on one stream, no host round trip
+ *        in between; afterwards EVERY rank holds the global result. DBHIP_ERR_CAPACITY (before any table is touched, on every
+ *        rank alike) when some rank holds more than max_rows groups: take the all-to-all with a larger max_rows.
+ *   dbhip_groupby_exchange_alltoall   hash-partitioned final merge (BASELINE configs[3]; the reference scatters partial states by
+ *        hash % n into its Flight exchange, payload.rs:548-589 + aggregate_exchange_injector.rs:57-147): rows routed to bucket
+ *        hash % world on the device, one grouped ncclSend / ncclRecv all-to-all of equal blocks (every xGMI link busy at once),
+ *        the table rebuilt from the received blocks: rank r ends up owning the groups with hash % world == r, merged over all ranks.
+ *   dbhip_comm_allgather / _alltoall / _allreduce_sum_u64  the plain collectives on device buffers (equal byte counts per rank /
+ *        per peer): ANN shard top-k all-gather (dbhip_vec_topk_merge follows), result checks. */
+typedef struct dbhip_comm dbhip_comm;
+int32_t dbhip_comm_unique_id(uint8_t* out_id128_host);
+int32_t dbhip_comm_create(int32_t rank, int32_t world, const uint8_t* id128_host, dbhip_comm** out_host);
+int32_t dbhip_comm_destroy(dbhip_comm* c);
+int32_t dbhip_comm_allgather(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
+int32_t dbhip_comm_alltoall(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream);
+int32_t dbhip_comm_allreduce_sum_u64(dbhip_comm* c, const uint64_t* send_dev, uint64_t* recv_dev, int64_t count, void* stream);
+int32_t dbhip_groupby_exchange_allgather(dbhip_groupby* g, dbhip_comm* c, int64_t max_rows, void* stream);
+int32_t dbhip_groupby_exchange_alltoall(dbhip_groupby* g, dbhip_comm* c, int64_t max_rows, void* stream);
+
 /* ---- §8f-4: vector-cluster KMeans and the f32 VectorDistanceKernel ------------------------------------------------------------
  * Replaces KMeans::compute (src/query/storages/common/index/src/kmeans.rs:93-291: kmeans++ initialisation with the fixed LCG seed,
  * Lloyd iterations until nothing changes or the centroid shift is <= 1e-4, at most 100) behind TransformVectorCluster
