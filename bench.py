@@ -53,11 +53,14 @@ def main():
     ap.add_argument("--no-ann", action="store_true", help="skip the secondary ANN measurement (BASELINE configs[4])")
     ap.add_argument("--ann-rows", type=int, default=10_000_000, help="base vectors of the WHOLE job (sharded by row range over the ranks)")
     ap.add_argument("--ann-dim", type=int, default=768)
-    ap.add_argument("--ann-queries", type=int, default=4096, help="queries per ANN step (replicated on every rank)")
+    ap.add_argument("--ann-queries", type=int, default=10_000, help="queries per ANN step (replicated on every rank)")
     ap.add_argument("--ann-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for a functional check)")
     ap.add_argument("--share-gpu", action="store_true", help="functional check of the N>1 path on a 1-GPU box: every rank uses "
                     "cuda:0 (with --backend gloo); the numbers of such a run are not a measurement")
+    ap.add_argument("--exchange-impl", choices=["torch", "abi"], default="torch",
+                    help="N > 1: who owns the communicator of the partial-state exchange: torch.distributed (default), or the C-ABI's "
+                         "own RCCL communicator (dbhip_comm_*, dbhip_groupby_exchange_*: what a Rust host would call)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +108,11 @@ def main():
     ts = torch.cuda.Stream() if world > 1 else None
     stream = C.c_void_p(ts.cuda_stream) if ts is not None else None
     kms = []
+    abi_comm = None
+    if world > 1 and args.exchange_impl == "abi":
+        ids = [D.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)     # the host's control plane ships the 128 bytes
+        abi_comm = D.Comm(rank, world, ids[0])
 
     def step(record=False):
         g.reset(stream)
@@ -113,7 +121,9 @@ def main():
             ms = C.c_float()
             check(L.dbhip_last_kernel_ms(C.byref(ms)))  # HIP events around q1_fused_kernel on its stream
             kms.append(ms.value)
-        if world > 1:
+        if abi_comm is not None:
+            (abi_comm.exchange_alltoall if exchange == "alltoall" else abi_comm.exchange_allgather)(g, 256, stream)
+        elif world > 1:
             with torch.cuda.stream(ts):
                 if exchange == "alltoall":
                     DX.exchange_partials_alltoall_nccl(g, dist, torch, stream=stream)
@@ -175,6 +185,10 @@ def main():
         dist.all_reduce(ng, op=dist.ReduceOp.SUM if exchange == "alltoall" else dist.ReduceOp.MAX)
         n_groups = int(ng.item())
 
+    readiness = None
+    if world == 1 and rank == 0 and n_total >= 8 * (1 << 20):
+        readiness = bench_exchange_overhead(li, n_total // 8 & ~3, tpch, D, L, check, args.steps)
+
     opplan = None
     if not args.no_opplan and world == 1:
         opplan = bench_operator_plan(li, tpch, D, L, check, result, kernel_ms)
@@ -227,6 +241,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "q1_fused_kernel",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": n * BYTES_PER_ROW},
             "cpu_baseline": cpu,
+            "multi_gpu_readiness": readiness,
             "q1_operator_plan": opplan,
             "q3_sf100": q3,
             "ann": ann,
@@ -235,6 +250,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_exchange_overhead(li, n_shard, tpch, D, L, check, steps):
+    """What one rank of the 8-GPU strong-scaling job does per step, on ONE GPU: the fused kernel over SF/8 rows, then the whole
+    block protocol of the hash-partitioned exchange through the C-ABI's communicator (dbhip_groupby_exchange_alltoall on a local
+    world of one: partition by hash % world -> transfer (here a copy) -> rebuild the table). exchange_overhead_ms = everything in
+    a step that is not q1_fused_kernel; >= 6x at 8 GPUs leaves 0.27 ms for it. The xGMI transfer of the
+    (~ KB-sized) blocks itself is not in this number."""
+    import ctypes as _C
+    shard = li.slice(0, n_shard)
+    g = D.GroupBy.q1()
+    comm = D.Comm.local()
+    kms, wall = [], []
+
+    def step():
+        g.reset()
+        D.q1_fused(g, shard.qty, shard.price, shard.disc, shard.tax, shard.rf, shard.ls, shard.ship, tpch.Q1_CUTOFF)
+        ms = _C.c_float()
+        check(L.dbhip_last_kernel_ms(_C.byref(ms)))
+        comm.exchange_alltoall(g, 256)
+        return ms.value
+    for _ in range(3):
+        step()
+    check(L.dbhip_stream_sync(None))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        kms.append(step())
+    check(L.dbhip_stream_sync(None))
+    step_ms = (time.perf_counter() - t0) * 1e3 / steps
+    kernel_ms = sum(kms) / len(kms)
+    comm.destroy()
+    return {"rows_per_rank_at_8_gpus": n_shard, "step_ms": step_ms, "kernel_ms": kernel_ms, "exchange_overhead_ms": step_ms - kernel_ms,
+            "budget_ms_for_6x_at_8_gpus": 0.27,
+            "what": "reset + q1_fused + dbhip_groupby_exchange_alltoall (partition_blocks -> copy -> replace_with_blocks) on a local world of one"}
 
 
 def _timed_ms(fn, L, check, reps):
@@ -454,12 +503,13 @@ def bench_ann(args, rank, world, torch, dist, D, DX, L, check):
     exp = ei.cpu().numpy()
     recall = float(np.mean([len(set(got[i].tolist()) & set(exp[i].tolist())) / k for i in range(m)]))
     oracle_recall = ann_oracle_recall(torch, base, queries, oi, od, k) if (rank == 0 and not args.no_cpu) else None
+    oracle_full = ann_oracle_recall_full(torch, base, queries, oi, k) if (rank == 0 and not args.no_cpu) else None
     check(L.dbhip_vec_index_destroy(ix))
     qps = nq * args.ann_steps / dt
     search_ms = float(np.mean(kms))
     tf = 2.0 * n * dim * nq / (search_ms * 1e-3) / 1e12
     return {"metric": "ANN queries/s @ recall@10", "value": qps, "unit": "queries/s", "recall_at_10": recall,
-            "recall_at_10_vs_cpu_oracle": oracle_recall, "k": k,
+            "recall_at_10_vs_cpu_oracle": oracle_recall, "recall_at_10_vs_cpu_oracle_full_base": oracle_full, "k": k,
             "ms_per_step": dt / args.ann_steps * 1e3, "steps": args.ann_steps, "scaling": "strong", "index_build_s": build_s,
             "config": {"workload": f"exact cosine top-10, {n_total} x {dim} f32 base (N(0,1), not normalised), {nq} queries per step, "
                                    f"row-range sharded over {world} GPU(s), bf16-MFMA pre-filter + exact f32 re-score"
@@ -504,6 +554,43 @@ def ann_oracle_recall(torch, base, queries, oi, od, k, n_queries=32, window=1 <<
         hits += len(set(top) & set(int(x) for x in dev_ids))
         total += k
     return hits / total if total else None
+
+
+def ann_oracle_recall_full(torch, base, queries, oi, k, n_queries=8, slab_rows=1 << 20):
+    """recall@10 of the first 8 queries against the CPU oracle's exact top-10 over the WHOLE local base (the windowed
+    check above only lets the oracle overrule the device on 1.3 % of the rows): the base is brought to the host slab by slab,
+    every slab is scored by orc_vec_distance on the host cores (one thread per query: ctypes releases the GIL), a running
+    top-10 per query (ties: lower id) is kept. -> {"recall": .., "queries": .., "rows_scored_per_query": n, "seconds": ..}"""
+    import threading
+    import numpy as np
+    from tests import oracle_lib
+    O = oracle_lib.load()
+    n, dim = base.shape
+    nq = min(n_queries, queries.shape[0])
+    q_host = [np.ascontiguousarray(queries[i:i + 1].cpu().numpy(), dtype=np.float32) for i in range(nq)]
+    best = [(np.empty(0, np.float32), np.empty(0, np.int64)) for _ in range(nq)]
+    t0 = time.perf_counter()
+    for lo in range(0, n, slab_rows):
+        hi = min(n, lo + slab_rows)
+        slab = np.ascontiguousarray(base[lo:hi].cpu().numpy(), dtype=np.float32)
+        outs = [np.empty(hi - lo, dtype=np.float32) for _ in range(nq)]
+
+        def score(i):
+            O.orc_vec_distance(0, slab.ctypes.data_as(C.c_void_p), C.c_int64(hi - lo), C.c_int(dim), q_host[i].ctypes.data_as(C.c_void_p), C.c_int(1),
+                               outs[i].ctypes.data_as(C.c_void_p))
+        th = [threading.Thread(target=score, args=(i,)) for i in range(nq)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for i in range(nq):
+            d = np.concatenate([best[i][0], outs[i]])
+            ids = np.concatenate([best[i][1], np.arange(lo, hi, dtype=np.int64)])
+            order = np.lexsort((ids, d))[:k]
+            best[i] = (d[order], ids[order])
+    got = oi[:nq].cpu().numpy().astype(np.int64)
+    hits = sum(len(set(best[i][1].tolist()) & set(got[i].tolist())) for i in range(nq))
+    return {"recall": hits / (nq * k), "queries": nq, "rows_scored_per_query": n, "seconds": time.perf_counter() - t0}
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ struct dbhip_join {
   int shift;
   bool finalized;
   // probe scratch
-  uint32_t* cnt; uint32_t* firstm; uint64_t* off; uint64_t* blk; size_t scratch_rows;
+  uint8_t* cnt; uint32_t* firstm; uint32_t* tsum; uint64_t* off; uint64_t* blk; size_t scratch_rows;   // per row: cnt, firstm; per tile: tsum, off
   uint64_t* total_dev;
   // the last counted probe block: dbhip_join_probe of the SAME block (count first, then emit into buffers of the
   // right size — the only way a caller can size its outputs) reuses the counts instead of walking the table again
@@ -123,21 +123,47 @@ __device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_
   return c;
 }
 
+// Probe geometry: a workgroup takes TILES of 1024 consecutive probe rows (row = tile * 1024 + r * 256 + thread, r = 0..3: every
+// access to a per-row array is coalesced). The count pass leaves, per row, a saturated u8 count (always) and the matching build
+// row (only where there is one: the stores of a sparse join touch few lines), and per TILE the exact number of pairs; the
+// exclusive scan runs over the tiles (n / 1024 values, not n) and the emit pass rebuilds the row offsets inside a tile with a
+// workgroup scan. (r02: per-row u32 counts + u32 build rows + u64 offsets and a device-wide scan over all n rows cost 28 bytes
+// of traffic per probe row and ~3 ms of scan kernels per 600 M probe rows — more than the table walk itself at 1 % matches.)
+constexpr int JOIN_TILE = 1024;
+
 template <int KW>
 __global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, const uint64_t* head, int shift,
                                                          const uint64_t* pkeys, const uint8_t* pvalid, int64_t n,
-                                                         uint32_t* cnt, uint32_t* firstm, unsigned long long* total) {
+                                                         uint8_t* cnt8, uint32_t* firstm, uint32_t* tile_sum, unsigned long long* total) {
+  __shared__ uint32_t wsum[4];
+  const int64_t ntiles = (n + JOIN_TILE - 1) / JOIN_TILE;
   uint64_t local = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t c = 0, last = 0;
-    if (!pvalid || bit_get(pvalid, i)) {
-      uint64_t k[KW];
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    uint32_t tsum = 0;
 #pragma unroll
-      for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
-      c = join_walk<KW>(ent, head, shift, k, &last);
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = t * JOIN_TILE + r * 256 + threadIdx.x;
+      uint32_t c = 0, last = 0;
+      if (i < n && (!pvalid || bit_get(pvalid, i))) {
+        uint64_t k[KW];
+#pragma unroll
+        for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+        c = join_walk<KW>(ent, head, shift, k, &last);
+      }
+      if (i < n && cnt8) {
+        cnt8[i] = (uint8_t)(c < 255u ? c : 255u);
+        if (c) firstm[i] = last;
+      }
+      tsum += c;
     }
-    if (cnt) { cnt[i] = c; firstm[i] = last; }
-    local += c;
+    local += tsum;
+    if (tile_sum) {
+      tsum = (uint32_t)wave_sum_u64(tsum);
+      if (lane_id() == 0) wsum[threadIdx.x >> 6] = tsum;
+      __syncthreads();
+      if (threadIdx.x == 0) tile_sum[t] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      __syncthreads();
+    }
   }
   local = wave_sum_u64(local);
   if (lane_id() == 0 && local) atomicAdd(total, (unsigned long long)local);
@@ -145,39 +171,64 @@ __global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, co
 
 template <int KW>
 __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, const uint64_t* head, int shift,
-                                                        const uint64_t* pkeys, int64_t n, const uint32_t* cnt,
-                                                        const uint32_t* firstm, const uint64_t* off, uint32_t* out_p,
+                                                        const uint64_t* pkeys, int64_t n, const uint8_t* cnt8,
+                                                        const uint32_t* firstm, const uint32_t* tile_sum, const uint64_t* tile_off, uint32_t* out_p,
                                                         uint32_t* out_b, int64_t max_pairs) {
   constexpr int ES = KW * 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = cnt[i];
-    if (c == 0) continue;
-    const uint64_t o = off[i];
-    if ((int64_t)(o + c) > max_pairs) continue;
-    if (c == 1) {  // unique build key: nothing to walk
-      out_p[o] = (uint32_t)i;
-      out_b[o] = firstm[i];
-      continue;
-    }
-    uint64_t k[KW];
+  __shared__ uint32_t wtot[4];
+  const int64_t ntiles = (n + JOIN_TILE - 1) / JOIN_TILE;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (tile_sum[t] == 0) continue;   // (workgroup-uniform) nothing to emit in this tile
+    uint64_t base = tile_off[t];
 #pragma unroll
-    for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
-    const uint64_t h = join_hash<KW>(k);
-    uint32_t m = 0;
-    for (uint32_t e = (uint32_t)head[h >> shift]; e;) {
-      const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
-      bool eq = p[0] == k[0];
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = t * JOIN_TILE + r * 256 + threadIdx.x;
+      uint32_t c = i < n ? cnt8[i] : 0u;
+      uint64_t k[KW];
+      if (c == 255u) {   // saturated: count the chain again
 #pragma unroll
-      for (int w = 1; w < KW; ++w) eq = eq && p[w] == k[w];
-      if (eq) {
-        // insert build row e-1 keeping this probe row's segment ascending (segments are tiny)
-        uint32_t b = e - 1, j = m;
-        while (j > 0 && out_b[o + j - 1] > b) { out_b[o + j] = out_b[o + j - 1]; --j; }
-        out_b[o + j] = b;
-        out_p[o + m] = (uint32_t)i;
-        ++m;
+        for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+        uint32_t last;
+        c = join_walk<KW>(ent, head, shift, k, &last);
       }
-      e = (uint32_t)p[KW];
+      // exclusive prefix of c over the 256 rows of this quarter tile, in row order
+      uint32_t incl = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      uint32_t wbase = 0, all = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { if (w < wave) wbase += wtot[w]; all += wtot[w]; }
+      const uint64_t o = base + wbase + incl - c;
+      base += all;
+      __syncthreads();
+      if (c == 0 || (int64_t)(o + c) > max_pairs) continue;
+      if (c == 1) {  // unique build key: nothing to walk
+        out_p[o] = (uint32_t)i;
+        out_b[o] = firstm[i];
+        continue;
+      }
+#pragma unroll
+      for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+      const uint64_t h = join_hash<KW>(k);
+      uint32_t m = 0;
+      for (uint32_t e = (uint32_t)head[h >> shift]; e;) {
+        const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
+        bool eq = p[0] == k[0];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) eq = eq && p[w] == k[w];
+        if (eq) {
+          // insert build row e-1 keeping this probe row's segment ascending (segments are tiny)
+          uint32_t b = e - 1, j = m;
+          while (j > 0 && out_b[o + j - 1] > b) { out_b[o + j] = out_b[o + j - 1]; --j; }
+          out_b[o + j] = b;
+          out_p[o + m] = (uint32_t)i;
+          ++m;
+        }
+        e = (uint32_t)p[KW];
+      }
     }
   }
 }
@@ -211,15 +262,17 @@ int32_t ensure_probe_scratch(dbhip_join* j, int64_t n) {
   if (j->scratch_rows >= (size_t)n) return DBHIP_OK;
   if (j->cnt) {
     DBHIP_CHECK(hipDeviceSynchronize());
-    (void)dbhip_free(j->cnt); (void)dbhip_free(j->firstm); (void)dbhip_free(j->off); (void)dbhip_free(j->blk);
-    j->cnt = nullptr; j->firstm = nullptr; j->off = nullptr; j->blk = nullptr;   // (an allocation below may fail: no dangling pointers)
+    (void)dbhip_free(j->cnt); (void)dbhip_free(j->firstm); (void)dbhip_free(j->tsum); (void)dbhip_free(j->off); (void)dbhip_free(j->blk);
+    j->cnt = nullptr; j->firstm = nullptr; j->tsum = nullptr; j->off = nullptr; j->blk = nullptr;   // (an allocation below may fail: no dangling pointers)
     j->scratch_rows = 0;
   }
   size_t cap = (size_t)n + (n >> 3) + 1024;
-  DBHIP_TRY(dbhip_alloc(cap * 4, (void**)&j->cnt));
+  const size_t tiles = cap / JOIN_TILE + 2;
+  DBHIP_TRY(dbhip_alloc(cap, (void**)&j->cnt));
   DBHIP_TRY(dbhip_alloc(cap * 4, (void**)&j->firstm));
-  DBHIP_TRY(dbhip_alloc(cap * 8, (void**)&j->off));
-  DBHIP_TRY(dbhip_alloc((cap / SCAN_TILE + 2) * 8, (void**)&j->blk));
+  DBHIP_TRY(dbhip_alloc(tiles * 4, (void**)&j->tsum));
+  DBHIP_TRY(dbhip_alloc(tiles * 8, (void**)&j->off));
+  DBHIP_TRY(dbhip_alloc((tiles / SCAN_TILE + 2) * 8, (void**)&j->blk));
   j->scratch_rows = cap;
   return DBHIP_OK;
 }
@@ -474,17 +527,18 @@ static int32_t join_count_block(dbhip_join* j, const void* keys, const uint8_t* 
   if (rc) return rc;
   j->prepared = false;
   DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
-  const int grid = grid_for(n, 256);
+  const int64_t ntiles = ceil_div(n, JOIN_TILE);
+  const int grid = (int)(ntiles < 4096 ? ntiles : 4096);
   if (j->kw == 1)
     hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
+                       validity, n, j->cnt, j->firstm, j->tsum, (unsigned long long*)j->total_dev);
   else if (j->kw == 2)
     hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
+                       validity, n, j->cnt, j->firstm, j->tsum, (unsigned long long*)j->total_dev);
   else
     hipLaunchKernelGGL(join_count_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, (unsigned long long*)j->total_dev);
-  rc = dbscan::exclusive_scan_u32(j->cnt, n, j->blk, j->off, s);
+                       validity, n, j->cnt, j->firstm, j->tsum, (unsigned long long*)j->total_dev);
+  rc = dbscan::exclusive_scan_u32(j->tsum, ntiles, j->blk, j->off, s);
   if (rc) return rc;
   DBHIP_CHECK(hipMemcpyAsync(total_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
@@ -536,7 +590,8 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
   hipStream_t s = resolve_stream(stream);
   *out_n_pairs_host = 0;
   if (n == 0) return DBHIP_OK;
-  const int grid = grid_for(n, 256);
+  const int64_t ntiles_p = ceil_div(n, JOIN_TILE);
+  const int grid = (int)(ntiles_p < 4096 ? ntiles_p : 4096);   // the emit pass walks tiles like the count pass
   uint64_t total = 0;
   int32_t rc;
   if (j->prepared && j->prep_keys == keys && j->prep_valid == validity && j->prep_n == n && j->prep_stream == s) {
@@ -555,13 +610,13 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
     DBHIP_REQUIRE(out_probe_idx && out_build_row, "dbhip_join_probe: NULL output");
     if (j->kw == 1)
       hipLaunchKernelGGL(join_emit_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
-                         j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
+                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs);
     else if (j->kw == 2)
       hipLaunchKernelGGL(join_emit_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
-                         j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
+                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs);
     else
       hipLaunchKernelGGL(join_emit_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
-                         j->cnt, j->firstm, j->off, out_probe_idx, out_build_row, max_pairs);
+                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs);
     DBHIP_LAUNCH_CHECK();
   }
   return DBHIP_OK;
@@ -605,7 +660,7 @@ int32_t dbhip_join_build_matched(dbhip_join* j, uint8_t* out_bitmap, int64_t* ou
 int32_t dbhip_join_destroy(dbhip_join* j) {
   if (!j) return DBHIP_OK;
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->off, j->blk, j->total_dev, j->bmark};
+  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->tsum, j->off, j->blk, j->total_dev, j->bmark};
   for (void* p : ptrs)
     if (p) (void)dbhip_free(p);
   delete j;
