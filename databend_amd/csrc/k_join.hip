@@ -21,6 +21,7 @@
 #include "dev_scan.h"
 #include "runtime.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -36,6 +37,7 @@ struct dbhip_join {
   uint64_t* ent;       // [cap_rows * es]: key words, then (next | valid << 32)
   int64_t nrows, cap_rows;
   uint64_t* head;      // [buckets]
+  uint64_t* occ;       // [buckets / 64] bit b = bucket b is not empty (tables whose heads outgrow the L2 only), else NULL
   int64_t buckets;
   int shift;
   bool finalized;
@@ -76,6 +78,27 @@ __global__ __launch_bounds__(256) void join_copy_kernel(const uint64_t* keys, co
   }
 }
 
+// Bucket and tag of a key. Keys wider than one word: an ordinary hash. ONE-word keys (every integer / date / decimal join key):
+// the 64 keys that share key >> 6 take 64 CONSECUTIVE buckets starting at a hashed position. Sorted or clustered probe keys (a
+// fact table stored in the order of its foreign key, TPC-H lineitem by l_orderkey) then read a handful of 64-byte head sectors
+// per wave instead of one per row, and because build rows keep their arrival order the entries they reach are neighbours too;
+// unrelated keys still scatter like a hash (the start of every run is hashed, runs overlap freely, so bucket loads are the sums
+// of independent runs — the same occupancy statistics as hashing every key on its own). r03, SF100 lineitem probe, 600 M rows:
+// 2.9 -> see DESIGN.md.
+template <int KW>
+__device__ __forceinline__ uint64_t join_bucket(const uint64_t* k, int cfg, uint32_t* tag) {
+  const int shift = cfg & 255;   // cfg = shift | D << 8
+  if (KW == 1) {
+    const int D = cfg >> 8;      // 2^D neighbouring key values share a bucket (sparse clustered keys, see dbhip_join_finalize)
+    const uint64_t hg = agg_hash_u64(k[0] >> (6 + D));
+    *tag = (uint32_t)(hg ^ k[0]) & 15u;
+    return ((hg >> shift) + ((k[0] >> D) & 63u)) & ((~0ULL) >> shift);
+  }
+  const uint64_t h = join_hash<KW>(k);
+  *tag = (uint32_t)h & 15u;
+  return h >> shift;
+}
+
 template <int KW>
 __global__ __launch_bounds__(256) void join_build_kernel(uint64_t* ent, int64_t n, uint64_t* head, int shift) {
   constexpr int ES = KW * 2;
@@ -83,23 +106,20 @@ __global__ __launch_bounds__(256) void join_build_kernel(uint64_t* ent, int64_t 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint64_t* e = ent + i * ES;
     if (!(e[KW] >> 32)) continue;
-    const uint64_t h = join_hash<KW>(e);
-    const uint64_t idx = h >> shift;
+    uint32_t tag;
+    const uint64_t idx = join_bucket<KW>(e, shift, &tag);
     const uint32_t old = atomicExch(&head32[2 * idx], (uint32_t)(i + 1));  // prepend
-    atomicOr(&head32[2 * idx + 1], 1u << (h & 15));
+    atomicOr(&head32[2 * idx + 1], 1u << tag);
     ((uint32_t*)&e[KW])[0] = old;
   }
 }
 
-// walks the chain of probe key k; returns the number of matching build rows, *last = one of them
+// walks the chain that starts at head word hd for probe key k; returns the number of matching build rows, *last = one of them
 template <int KW>
-__device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_t* head, int shift, const uint64_t* k,
-                                              uint32_t* last) {
+__device__ __forceinline__ uint32_t join_walk_from(const uint64_t* ent, uint64_t hd, uint32_t tag, const uint64_t* k, uint32_t* last) {
   constexpr int ES = KW * 2;
-  const uint64_t h = join_hash<KW>(k);
-  const uint64_t hd = head[h >> shift];
   uint32_t c = 0;
-  if (!((hd >> (32 + (h & 15))) & 1)) return 0;  // empty bucket or tag miss (fixed_keys.rs:139-142)
+  if (!((hd >> (32 + tag)) & 1)) return 0;  // empty bucket or tag miss (fixed_keys.rs:139-142)
   for (uint32_t e = (uint32_t)hd; e;) {
     const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
     bool eq = true;
@@ -122,27 +142,142 @@ __device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_
   }
   return c;
 }
-
-// Probe geometry: a workgroup takes TILES of 1024 consecutive probe rows (row = tile * 1024 + r * 256 + thread, r = 0..3: every
-// access to a per-row array is coalesced). The count pass leaves, per row, a saturated u8 count (always) and the matching build
-// row (only where there is one: the stores of a sparse join touch few lines), and per TILE the exact number of pairs; the
-// exclusive scan runs over the tiles (n / 1024 values, not n) and the emit pass rebuilds the row offsets inside a tile with a
-// workgroup scan. (r02: per-row u32 counts + u32 build rows + u64 offsets and a device-wide scan over all n rows cost 28 bytes
-// of traffic per probe row and ~3 ms of scan kernels per 600 M probe rows — more than the table walk itself at 1 % matches.)
-constexpr int JOIN_TILE = 1024;
-
 template <int KW>
-__global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, const uint64_t* head, int shift,
-                                                         const uint64_t* pkeys, const uint8_t* pvalid, int64_t n,
-                                                         uint8_t* cnt8, uint32_t* firstm, uint32_t* tile_sum, unsigned long long* total) {
-  __shared__ uint32_t wsum[4];
-  const int64_t ntiles = (n + JOIN_TILE - 1) / JOIN_TILE;
+__device__ __forceinline__ uint32_t join_walk(const uint64_t* ent, const uint64_t* head, int shift, const uint64_t* k,
+                                              uint32_t* last) {
+  uint32_t tag;
+  const uint64_t idx = join_bucket<KW>(k, shift, &tag);
+  return join_walk_from<KW>(ent, head[idx], tag, k, last);
+}
+
+// Probe geometry: a WAVE takes TILES of 256 consecutive probe rows and a lane takes FOUR CONSECUTIVE rows of the tile
+// (row = tile * 256 + lane * 4 + r): its keys are 32 contiguous bytes (two 16-byte loads), its validity bits one nibble, its
+// four saturated u8 counts one 32-bit store, and all four bucket heads are requested before the first chain is walked. The
+// count pass leaves, per row, the u8 count (always) and the matching build row (only where there is one: the stores of a sparse
+// join touch few lines), and per TILE the exact number of pairs; the exclusive scan runs over the tiles (n / 256 values, not n)
+// and the emit pass rebuilds the row offsets inside a tile with one wave scan over the per-lane sums. Nothing in either pass
+// crosses a wave: no LDS, no barrier (r03: with 1024-row workgroup tiles the emit pass of a 600 M-row probe was 586 k barriers
+// long — 0.97 ms for 3 M pairs). (r02: per-row u32 counts + u32 build rows + u64 offsets and a device-wide scan over all n rows
+// cost 28 bytes of traffic per probe row and ~3 ms of scan kernels per 600 M probe rows — more than the table walk itself at
+// 1 % matches.)
+constexpr int JOIN_TILE = 256;
+
+__device__ __forceinline__ void join_tile_total(uint32_t tsum, uint32_t* tile_sum, int64_t t) {
+  tsum = (uint32_t)wave_sum_u64(tsum);
+  if (lane_id() == 0) tile_sum[t] = tsum;
+}
+
+// FULL tiles [0, nfull) of a key column that starts on a 16-byte boundary. The loop is bound by dependent round trips (keys ->
+// occupancy bits -> bucket heads -> chain entries), not by bytes, so everything in it is branch-free straight-line code: the four
+// heads are requested together, the keys and validity byte of the NEXT tile right after them (loads retire in order: the wait
+// for the heads leaves the younger requests in flight — any branch around a load makes the compiler wait for everything), and
+// the four chains are walked in step (a row whose chain has ended reads entry 0, one line for the whole wave).
+template <int KW, bool HASV, bool OCC>
+__global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* __restrict__ ent, const uint64_t* __restrict__ head,
+                                                         const uint64_t* __restrict__ occ, int shift,
+                                                         const uint64_t* __restrict__ pkeys, const uint8_t* __restrict__ pvalid, int64_t nfull,
+                                                         uint8_t* __restrict__ cnt8, uint32_t* __restrict__ firstm, uint32_t* __restrict__ tile_sum,
+                                                         unsigned long long* total) {
+  constexpr int ES = KW * 2;
+  typedef uint64_t jk_u64x2 __attribute__((ext_vector_type(2)));
   uint64_t local = 0;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    uint32_t tsum = 0;
+  jk_u64x2 kv[2 * KW], kvn[2 * KW];
+  uint32_t vbyte = 0xFFu, vbyte_n = 0xFFu;   // the validity byte that holds this thread's nibble
+  const int lane = lane_id();
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= nfull) return;   // (wave-uniform; nothing below crosses a wave)
+  {
+    const int64_t i0 = t * JOIN_TILE + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 2 * KW; ++q) kv[q] = __builtin_nontemporal_load((const jk_u64x2*)(pkeys + i0 * KW) + q);
+    if (HASV) vbyte = pvalid[i0 >> 3];
+  }
+  for (; t < nfull; t += tstride) {
+    const int64_t i0 = t * JOIN_TILE + lane * 4;
+    const int64_t tn = t + tstride < nfull ? t + tstride : t;   // (past the end: this tile again, the lines are in the cache)
+    const int64_t i0n = tn * JOIN_TILE + lane * 4;
+    uint64_t k[4][KW];
+#pragma unroll
+    for (int q = 0; q < 2 * KW; ++q) { (&k[0][0])[2 * q] = kv[q].x; (&k[0][0])[2 * q + 1] = kv[q].y; }
+    uint32_t vmask = HASV ? (vbyte >> (i0 & 4)) & 15u : 15u;
+    uint64_t hd[4], idx[4];
+    uint32_t tag[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) idx[r] = join_bucket<KW>(k[r], shift, &tag[r]);
+    if (OCC) {   // one bit per bucket, resident in the L2: a random probe of an empty bucket never leaves the XCD
+      uint64_t ow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ow[r] = occ[(vmask >> r) & 1 ? idx[r] >> 6 : 0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (!((ow[r] >> (idx[r] & 63)) & 1)) vmask &= ~(1u << r);
+    }
+    // (rows that are not probed read head 0: one line for the wave, no branch)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hd[r] = head[(vmask >> r) & 1 ? idx[r] : 0];
+#pragma unroll
+    for (int q = 0; q < 2 * KW; ++q) kvn[q] = __builtin_nontemporal_load((const jk_u64x2*)(pkeys + i0n * KW) + q);
+    if (HASV) vbyte_n = pvalid[i0n >> 3];
+    uint32_t e[4], c[4] = {0, 0, 0, 0}, last[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = ((vmask >> r) & (uint32_t)(hd[r] >> (32 + tag[r])) & 1u) ? (uint32_t)hd[r] : 0u;   // not probed, empty bucket or tag miss (fixed_keys.rs:139-142)
+    while (e[0] | e[1] | e[2] | e[3]) {
+      const uint64_t* p[4];
+      ulonglong2 v[4], v1[4];
+      uint64_t link[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = ent + (uint64_t)(e[r] ? e[r] - 1 : 0u) * ES; v[r] = *(const ulonglong2*)p[r]; }
+      if (KW == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v1[r] = *(const ulonglong2*)(p[r] + 2);
+      }
+      if (KW > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) link[r] = p[r][KW];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bool eq;
+        if (KW == 1) { eq = v[r].x == k[r][0]; link[r] = v[r].y; }
+        else {
+          eq = v[r].x == k[r][0] && v[r].y == k[r][1];
+          if (KW == 4) eq = eq && v1[r].x == k[r][2] && v1[r].y == k[r][3];
+        }
+        const bool live = e[r] != 0;
+        c[r] += live && eq;
+        last[r] = live && eq ? e[r] - 1 : last[r];
+        e[r] = live ? (uint32_t)link[r] : 0u;
+      }
+    }
+    uint32_t packed = 0, tsum = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t i = t * JOIN_TILE + r * 256 + threadIdx.x;
+      if (c[r] && cnt8) firstm[i0 + r] = last[r];
+      packed |= (c[r] < 255u ? c[r] : 255u) << (8 * r);
+      tsum += c[r];
+    }
+    if (cnt8) *(uint32_t*)(cnt8 + i0) = packed;
+    local += tsum;
+    if (tile_sum) join_tile_total(tsum, tile_sum, t);
+#pragma unroll
+    for (int q = 0; q < 2 * KW; ++q) kv[q] = kvn[q];
+    vbyte = vbyte_n;
+  }
+  local = wave_sum_u64(local);
+  if (lane_id() == 0 && local) atomicAdd(total, (unsigned long long)local);
+}
+
+// any tile range [t0, ntiles) of any column (the ragged last tile; every tile of a key column that starts off a 16-byte boundary)
+template <int KW>
+__global__ __launch_bounds__(256) void join_count_any_kernel(const uint64_t* ent, const uint64_t* head, int shift, const uint64_t* pkeys,
+                                                             const uint8_t* pvalid, int64_t n, int64_t t0, uint8_t* cnt8, uint32_t* firstm,
+                                                             uint32_t* tile_sum, unsigned long long* total) {
+  const int64_t ntiles = (n + JOIN_TILE - 1) / JOIN_TILE;
+  uint64_t local = 0;
+  for (int64_t t = t0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+    uint32_t tsum = 0;
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = t * JOIN_TILE + lane_id() * 4 + r;
       uint32_t c = 0, last = 0;
       if (i < n && (!pvalid || bit_get(pvalid, i))) {
         uint64_t k[KW];
@@ -157,13 +292,7 @@ __global__ __launch_bounds__(256) void join_count_kernel(const uint64_t* ent, co
       tsum += c;
     }
     local += tsum;
-    if (tile_sum) {
-      tsum = (uint32_t)wave_sum_u64(tsum);
-      if (lane_id() == 0) wsum[threadIdx.x >> 6] = tsum;
-      __syncthreads();
-      if (threadIdx.x == 0) tile_sum[t] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-      __syncthreads();
-    }
+    if (tile_sum) join_tile_total(tsum, tile_sum, t);
   }
   local = wave_sum_u64(local);
   if (lane_id() == 0 && local) atomicAdd(total, (unsigned long long)local);
@@ -175,46 +304,62 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, con
                                                         const uint32_t* firstm, const uint32_t* tile_sum, const uint64_t* tile_off, uint32_t* out_p,
                                                         uint32_t* out_b, int64_t max_pairs) {
   constexpr int ES = KW * 2;
-  __shared__ uint32_t wtot[4];
   const int64_t ntiles = (n + JOIN_TILE - 1) / JOIN_TILE;
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    if (tile_sum[t] == 0) continue;   // (workgroup-uniform) nothing to emit in this tile
-    uint64_t base = tile_off[t];
+  const int lane = lane_id();
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  // (the counts of the NEXT tile are requested before this tile is scanned: the loop is a chain of dependent round trips)
+  auto load_counts = [&](int64_t tt) -> uint32_t {
+    const int64_t j0 = tt * JOIN_TILE + lane * 4;
+    if (j0 + 4 <= n) return *(const uint32_t*)(cnt8 + j0);
+    uint32_t pk = 0;
+    for (int r = 0; r < 4 && j0 + r < n; ++r) pk |= (uint32_t)cnt8[j0 + r] << (8 * r);
+    return pk;
+  };
+  int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t ts_next = t < ntiles ? tile_sum[t] : 0u, packed_next = t < ntiles ? load_counts(t) : 0u;
+  for (; t < ntiles; t += tstride) {
+    const uint32_t ts = ts_next, packed = packed_next;
+    if (t + tstride < ntiles) { ts_next = tile_sum[t + tstride]; packed_next = load_counts(t + tstride); }
+    if (ts == 0) continue;   // (wave-uniform) nothing to emit in this tile
+    const int64_t i0 = t * JOIN_TILE + lane * 4;
+    uint32_t c[4], mine = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t i = t * JOIN_TILE + r * 256 + threadIdx.x;
-      uint32_t c = i < n ? cnt8[i] : 0u;
-      uint64_t k[KW];
-      if (c == 255u) {   // saturated: count the chain again
+      c[r] = (packed >> (8 * r)) & 255u;
+      if (c[r] == 255u) {   // saturated: count the chain again
+        uint64_t k[KW];
 #pragma unroll
-        for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
+        for (int w = 0; w < KW; ++w) k[w] = pkeys[(i0 + r) * KW + w];
         uint32_t last;
-        c = join_walk<KW>(ent, head, shift, k, &last);
+        c[r] = join_walk<KW>(ent, head, shift, k, &last);
       }
-      // exclusive prefix of c over the 256 rows of this quarter tile, in row order
-      uint32_t incl = c;
+      mine += c[r];
+    }
+    // exclusive prefix of the per-lane sums over the wave = row order
+    uint32_t incl = mine;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-      if (lane == 63) wtot[wave] = incl;
-      __syncthreads();
-      uint32_t wbase = 0, all = 0;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    uint64_t o = tile_off[t] + incl - mine;
+    if (mine == 0) continue;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { if (w < wave) wbase += wtot[w]; all += wtot[w]; }
-      const uint64_t o = base + wbase + incl - c;
-      base += all;
-      __syncthreads();
-      if (c == 0 || (int64_t)(o + c) > max_pairs) continue;
-      if (c == 1) {  // unique build key: nothing to walk
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t cr = c[r];
+      const int64_t i = i0 + r;
+      if (cr == 0) continue;
+      if ((int64_t)(o + cr) > max_pairs) { o += cr; continue; }
+      if (cr == 1) {  // unique build key: nothing to walk
         out_p[o] = (uint32_t)i;
         out_b[o] = firstm[i];
+        o += 1;
         continue;
       }
+      uint64_t k[KW];
 #pragma unroll
       for (int w = 0; w < KW; ++w) k[w] = pkeys[i * KW + w];
-      const uint64_t h = join_hash<KW>(k);
+      uint32_t tag;
+      const uint64_t idx = join_bucket<KW>(k, shift, &tag);
       uint32_t m = 0;
-      for (uint32_t e = (uint32_t)head[h >> shift]; e;) {
+      for (uint32_t e = (uint32_t)head[idx]; e;) {
         const uint64_t* p = ent + (uint64_t)(e - 1) * ES;
         bool eq = p[0] == k[0];
 #pragma unroll
@@ -229,6 +374,7 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, con
         }
         e = (uint32_t)p[KW];
       }
+      o += cr;
     }
   }
 }
@@ -256,6 +402,13 @@ __global__ __launch_bounds__(256) void join_mark_kernel(const uint64_t* ent, con
   }
   local = wave_sum_u64(local);
   if (lane_id() == 0 && local) atomicAdd(total, (unsigned long long)local);
+}
+
+__global__ __launch_bounds__(256) void join_occ_kernel(const uint64_t* head, int64_t buckets, uint64_t* occ) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < buckets; b += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t m = __ballot((uint32_t)head[b] != 0u);
+    if (lane_id() == 0) occ[b >> 6] = m;
+  }
 }
 
 int32_t ensure_probe_scratch(dbhip_join* j, int64_t n) {
@@ -505,6 +658,7 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   while (cap < j->nrows * 2) cap <<= 1;  // hashjoin_hashtable.rs:95-108
   j->buckets = cap;
   j->shift = 64 - __builtin_ctzll((unsigned long long)cap);
+  if (j->kw == 1 && getenv("DBHIP_JOIN_D")) j->shift |= atoi(getenv("DBHIP_JOIN_D")) << 8;
   DBHIP_TRY(dbhip_alloc((size_t)cap * 8, (void**)&j->head));
   DBHIP_CHECK(hipMemsetAsync(j->head, 0, (size_t)cap * 8, s));
   if (j->nrows) {
@@ -515,6 +669,13 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
     else
       hipLaunchKernelGGL(join_build_kernel<4>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
     DBHIP_LAUNCH_CHECK();
+    // JOIN_OCC_MIN_BUCKETS: 2^20 heads = 8 MB, past what one XCD's L2 keeps; DBHIP_JOIN_OCC=0 turns the filter off (measurements)
+    static const bool occ_on = !(getenv("DBHIP_JOIN_OCC") && getenv("DBHIP_JOIN_OCC")[0] == '0');
+    if (occ_on && cap >= (1 << 20)) {
+      DBHIP_TRY(dbhip_alloc((size_t)cap / 8, (void**)&j->occ));
+      hipLaunchKernelGGL(join_occ_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, s, j->head, cap, j->occ);
+      DBHIP_LAUNCH_CHECK();
+    }
   }
   j->finalized = true;
   return DBHIP_OK;
@@ -528,16 +689,36 @@ static int32_t join_count_block(dbhip_join* j, const void* keys, const uint8_t* 
   j->prepared = false;
   DBHIP_CHECK(hipMemsetAsync(j->total_dev, 0, 8, s));
   const int64_t ntiles = ceil_div(n, JOIN_TILE);
-  const int grid = (int)(ntiles < 4096 ? ntiles : 4096);
-  if (j->kw == 1)
-    hipLaunchKernelGGL(join_count_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, j->tsum, (unsigned long long*)j->total_dev);
-  else if (j->kw == 2)
-    hipLaunchKernelGGL(join_count_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, j->tsum, (unsigned long long*)j->total_dev);
-  else
-    hipLaunchKernelGGL(join_count_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys,
-                       validity, n, j->cnt, j->firstm, j->tsum, (unsigned long long*)j->total_dev);
+  const int64_t nfull = ((uintptr_t)keys & 15) == 0 ? n / JOIN_TILE : 0;
+  unsigned long long* tot = (unsigned long long*)j->total_dev;
+  if (nfull) {
+    const int grid = (int)(nfull < 4 * 4096 ? ceil_div(nfull, 4) : 4096);   // four wave tiles per workgroup at a time
+#define JOIN_COUNT_LAUNCH(KW, HASV, OCC)                                                                                         \
+  hipLaunchKernelGGL((join_count_kernel<KW, HASV, OCC>), dim3(grid), dim3(256), 0, s, j->ent, j->head, j->occ, j->shift,       \
+                     (const uint64_t*)keys, validity, nfull, j->cnt, j->firstm, j->tsum, tot)
+#define JOIN_COUNT_KW(KW)                                                                                                       \
+  do {                                                                                                                          \
+    if (validity) { if (j->occ) JOIN_COUNT_LAUNCH(KW, true, true); else JOIN_COUNT_LAUNCH(KW, true, false); }                   \
+    else { if (j->occ) JOIN_COUNT_LAUNCH(KW, false, true); else JOIN_COUNT_LAUNCH(KW, false, false); }                          \
+  } while (0)
+    if (j->kw == 1) JOIN_COUNT_KW(1);
+    else if (j->kw == 2) JOIN_COUNT_KW(2);
+    else JOIN_COUNT_KW(4);
+#undef JOIN_COUNT_KW
+#undef JOIN_COUNT_LAUNCH
+    DBHIP_LAUNCH_CHECK();
+  }
+  if (nfull < ntiles) {
+    const int64_t rest = ntiles - nfull;
+    const int grid = (int)(rest < 4 * 4096 ? ceil_div(rest, 4) : 4096);
+    if (j->kw == 1)
+      hipLaunchKernelGGL(join_count_any_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, validity, n, nfull, j->cnt, j->firstm, j->tsum, tot);
+    else if (j->kw == 2)
+      hipLaunchKernelGGL(join_count_any_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, validity, n, nfull, j->cnt, j->firstm, j->tsum, tot);
+    else
+      hipLaunchKernelGGL(join_count_any_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, validity, n, nfull, j->cnt, j->firstm, j->tsum, tot);
+    DBHIP_LAUNCH_CHECK();
+  }
   rc = dbscan::exclusive_scan_u32(j->tsum, ntiles, j->blk, j->off, s);
   if (rc) return rc;
   DBHIP_CHECK(hipMemcpyAsync(total_host, j->total_dev, 8, hipMemcpyDeviceToHost, s));
@@ -591,7 +772,7 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
   *out_n_pairs_host = 0;
   if (n == 0) return DBHIP_OK;
   const int64_t ntiles_p = ceil_div(n, JOIN_TILE);
-  const int grid = (int)(ntiles_p < 4096 ? ntiles_p : 4096);   // the emit pass walks tiles like the count pass
+  const int grid = (int)(ntiles_p < 4 * 4096 ? ceil_div(ntiles_p, 4) : 4096);   // the emit pass walks tiles like the count pass
   uint64_t total = 0;
   int32_t rc;
   if (j->prepared && j->prep_keys == keys && j->prep_valid == validity && j->prep_n == n && j->prep_stream == s) {
@@ -660,7 +841,7 @@ int32_t dbhip_join_build_matched(dbhip_join* j, uint8_t* out_bitmap, int64_t* ou
 int32_t dbhip_join_destroy(dbhip_join* j) {
   if (!j) return DBHIP_OK;
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {j->ent, j->head, j->cnt, j->firstm, j->tsum, j->off, j->blk, j->total_dev, j->bmark};
+  void* ptrs[] = {j->ent, j->head, j->occ, j->cnt, j->firstm, j->tsum, j->off, j->blk, j->total_dev, j->bmark};
   for (void* p : ptrs)
     if (p) (void)dbhip_free(p);
   delete j;
