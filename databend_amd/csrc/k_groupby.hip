@@ -40,6 +40,7 @@ using namespace dbhip;
 #define GB_INVALID_SLOT 0xFFFFFFFFu
 
 struct dbhip_groupby {
+  int64_t hint_groups;   // dbhip_groupby_create's initial_capacity: the caller's estimate of the number of groups
   GbLayout L;
   int64_t cap;            // power of two
   uint64_t* slot_hash;    // [cap]
@@ -304,13 +305,17 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
                                                        uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc, uint8_t* arena) {
   n = dev_rows(dc, n);
   const uint64_t cmask = (uint64_t)cap - 1;
-  // wave-uniform trip count: the number of NEW groups is added to ctrl[0] once per wave and iteration (one atomic
-  // per new group on that single address serialises: 10 M new groups cost ~15 ms)
-  const int64_t n_pad = (n + 63) & ~63LL;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
+  // the number of NEW groups is added to ctrl[0] ONCE PER WORKGROUP, after its last row (one atomic per new group on that
+  // single address serialises: 10 M new groups cost ~15 ms; one per wave and iteration was still 17 K atomics on one word for
+  // 1.1 M new groups — 0.2 ms of the 0.49 ms this kernel took in Q3, r03)
+  __shared__ uint32_t wg_new;
+  if (threadIdx.x == 0) wg_new = 0;
+  __syncthreads();
+  uint32_t my_new = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     bool claimed = false;
-    if (i < n) {
+    {
       const uint64_t* r = rows_in + i * L.W;
       const uint64_t hw = probe_word(r[L.hash_word], hash_mask);
       uint64_t pos = home_slot(hw, cap);
@@ -341,9 +346,12 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
       if (found == GB_INVALID_SLOT) atomicOr((unsigned long long*)&ctrl[1], 1ULL);
       gid[i] = found;
     }
-    const uint64_t m = __ballot(claimed);
-    if (m && lane_id() == 0) atomicAdd((unsigned long long*)&ctrl[0], (unsigned long long)__popcll(m));
+    my_new += claimed;
   }
+  my_new = (uint32_t)wave_sum_u64(my_new);
+  if (lane_id() == 0 && my_new) atomicAdd(&wg_new, my_new);
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_new) atomicAdd((unsigned long long*)&ctrl[0], (unsigned long long)wg_new);
 }
 
 // ---------------------------------------------------------------------------
@@ -2608,6 +2616,7 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
   while (cap < initial_capacity) cap <<= 1;
   g->hash_mask = ~0ULL;
   g->part_min_rows = 262144;
+  g->hint_groups = initial_capacity;
   hipStream_t s = resolve_stream(nullptr);
   if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
   hipError_t e = hipMalloc((void**)&g->ctrl, 128);   // [0..7] see above, [8] arena cursor, [9] long-string bytes of the current chunk
@@ -2678,7 +2687,11 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
   }
   int32_t rc;
   int64_t done = 0;
-  if (fast_layout_ok(g->L) && !g->has_long) {
+  // The caller sized the table for about as many groups as this first block has rows (a join's output grouped by the join key,
+  // TPC-H Q3: 3 M rows, 1.1 M groups): pre-aggregation has nothing to combine and costs more than the rows it saves
+  // (r03: LDS pre-aggregation 0.59 ms + merge against 0.3 ms for the row path alone), the block goes straight to the row path.
+  const bool expect_distinct = g->rows_seen == 0 && g->count_host == 0 && n >= (1 << 20) && g->hint_groups * 2 >= n && g->part_bits == 0;
+  if (fast_layout_ok(g->L) && !g->has_long && !expect_distinct) {
     rc = add_block_fast(g, C, n, s, &done);
     if (rc >= 0) return rc;
   }
