@@ -427,12 +427,14 @@ def bench_q3(args, torch, tpch, D, L, check):
     assert ok, "Q3 result differs from the independent torch statement"
     ms = min(ts)
     streamed, nl = 24 * src.nc + 24 * src.no + 28 * src.nl, src.nl
+    gather = BQ.gather_bytes(stats)
     del src, t
     check(L.dbhip_trim())
     return {"workload": f"TPC-H Q3 SF{args.q3_sf:g}, 1 MI355X, operator-at-a-time over the C-ABI (filter Bitmaps as probe-key validity -> 2 hash joins "
                         f"-> decimal maps -> 3-key group-by -> ORDER BY revenue DESC, o_orderdate LIMIT 10)",
             "ms": ms, "all_ms": ts, "lineitem_rows": nl, "lineitem_rows_per_s": nl / (ms * 1e-3), "streamed_bytes": streamed, "streamed_GBps": streamed / (ms * 1e-3) / 1e9,
-            "frac_of_hbm_peak": streamed / (ms * 1e-3) / 8e12, "stages": stats, "matches_independent_torch_statement": bool(ok),
+            "frac_of_hbm_peak": streamed / (ms * 1e-3) / 8e12, "gather_bytes": gather, "stages": stats, "matches_independent_torch_statement": bool(ok),
+            "cpu_oracle_check": "tools/bench_q3.py --oracle (the same tables through oracle/liboracle.so): profiles/r03_q3_sf100_oracle.json",
             "generate_seconds": gen_s}
 
 

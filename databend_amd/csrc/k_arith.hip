@@ -529,7 +529,7 @@ int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stre
   SumParams p{col->data, col->validity, col->validity_offset, n, out_sum_dev, col->type};
   int grid = grid_for(ceil_div(n, 16), 256);
   if (cls == CLS_FLOAT) {
-    double* partials = (double*)scratch(sizeof(double) * grid, 0);
+    double* partials = (double*)scratch(sizeof(double) * grid, 0, s);
     if (!partials) return DBHIP_ERR_HIP;
     hipLaunchKernelGGL(sum_f64_partial_kernel, dim3(grid), dim3(256), 0, s, p, partials);
     hipLaunchKernelGGL(sum_f64_final_kernel, dim3(1), dim3(64), 0, s, partials, grid,

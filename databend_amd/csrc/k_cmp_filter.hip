@@ -649,7 +649,7 @@ int32_t dbhip_filter_select(const uint8_t* bitmap, int64_t bit_offset, int64_t n
   DBHIP_REQUIRE(bitmap && out_sel, "dbhip_filter_select: NULL argument");
   int64_t nwords = ceil_div(n, 64);
   int64_t nblocks = ceil_div(nwords, SEL_WORDS_PER_BLOCK);
-  uint8_t* ws = (uint8_t*)scratch((size_t)nblocks * 12 + 64, 1);
+  uint8_t* ws = (uint8_t*)scratch((size_t)nblocks * 12 + 64, 1, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint64_t* offsets = (uint64_t*)ws;
   uint32_t* counts = (uint32_t*)(ws + nblocks * 8);
@@ -748,7 +748,7 @@ static int32_t sel_expand(const uint32_t* items_host, int32_t n_items, int repea
     return DBHIP_ERR_INVALID;
   }
   hipStream_t s = resolve_stream(stream);
-  uint32_t* dev = (uint32_t*)scratch((size_t)2 * n_items * 4, 7);
+  uint32_t* dev = (uint32_t*)scratch((size_t)2 * n_items * 4, 7, s);
   if (!dev) return DBHIP_ERR_HIP;
   DBHIP_CHECK(hipMemcpyAsync(dev, host.data(), (size_t)2 * n_items * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(sel_expand_kernel, dim3(grid_for(num_rows, 256)), dim3(256), 0, s, dev, dev + n_items, n_items, repeat, num_rows, out_sel);
@@ -772,7 +772,7 @@ int32_t dbhip_take_chunks(const void* const* blocks_host, int32_t n_blocks, int3
   DBHIP_REQUIRE(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8 || elem_size == 16 || elem_size == 0,
                 "dbhip_take_chunks: elem_size must be 0 (bitmap), 1, 2, 4, 8 or 16");
   hipStream_t s = resolve_stream(stream);
-  const void** dev = (const void**)scratch((size_t)n_blocks * 8, 7);
+  const void** dev = (const void**)scratch((size_t)n_blocks * 8, 7, s);
   if (!dev) return DBHIP_ERR_HIP;
   DBHIP_CHECK(hipMemcpyAsync(dev, blocks_host, (size_t)n_blocks * 8, hipMemcpyHostToDevice, s));
   if (elem_size == 0)

@@ -571,7 +571,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   static const int env_grid = getenv("DBHIP_FAGG_GRID") ? atoi(getenv("DBHIP_FAGG_GRID")) : 0;
   if (env_grid > 0) grid = (int)(ceil_div(nchunks, 4) < env_grid ? ceil_div(nchunks, 4) : env_grid);
   const size_t rows_bytes = (size_t)grid * 4 * FA_MAX_SLOTS * L.W * 8;
-  uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 6);
+  uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 6, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint64_t* ctrl = (uint64_t*)ws;
   A.ctrl = ctrl;

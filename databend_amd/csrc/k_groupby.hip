@@ -2595,7 +2595,7 @@ int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n, uint64
     hc.c[k] = to_gbcol(cols[k]);
   }
   hipStream_t s = resolve_stream(stream);
-  unsigned long long* bad = (unsigned long long*)scratch(8, 2);
+  unsigned long long* bad = (unsigned long long*)scratch(8, 2, s);
   if (!bad) return DBHIP_ERR_HIP;
   DBHIP_CHECK(hipMemsetAsync(bad, 0, 8, s));
   hipLaunchKernelGGL(group_hash_kernel, dim3(grid_for(ceil_div(n, 4), 256, 1024)), dim3(256), 0, s, hc, n, out_hashes, bad);
@@ -2938,7 +2938,7 @@ static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8
                              void* const* out_aggs_host, uint8_t* const* out_agg_validity_host, void* const* out_fields_host,
                              uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host, void* stream) {
   hipStream_t s = resolve_stream(stream);
-  uint64_t* tmp = (uint64_t*)scratch((size_t)(max_rows > 0 ? max_rows : 1) * g->L.W * 8, 3);
+  uint64_t* tmp = (uint64_t*)scratch((size_t)(max_rows > 0 ? max_rows : 1) * g->L.W * 8, 3, s);
   if (!tmp) return DBHIP_ERR_HIP;
   int32_t rc = dbhip_groupby_flush_serialized(g, tmp, max_rows, out_n_rows_host, stream);
   if (rc) return rc;

@@ -894,7 +894,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
     DBHIP_CHECK(hipMemcpyAsync(uf, h->ufirst_host.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
     // ---- EncodedVectorsU8::encode over the pre-processed vectors (hnsw.rs:150-157,262-283) ----
     if (dc == D_DOT) hipLaunchKernelGGL(hn_length_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, vectors, n, dim, (float*)vlen);
-    uint32_t* mm = (uint32_t*)scratch(8, 3);
+    uint32_t* mm = (uint32_t*)scratch(8, 3, s);
     const uint32_t init[2] = {0xFFFFFFFFu, 0u};
     DBHIP_CHECK(hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(hn_minmax_kernel, dim3(grid_for(n * dim, 256)), dim3(256), 0, s, vectors, (const float*)vlen, n, dim, mm);
@@ -1079,7 +1079,7 @@ int32_t dbhip_hnsw_search(dbhip_hnsw* hh, const float* queries_dev, int32_t nq, 
   dbhip_hnsw_impl* h = (dbhip_hnsw_impl*)hh;
   hipStream_t s = resolve_stream(stream);
   const int grid = search_grid(nq);
-  uint32_t* vis = (uint32_t*)scratch((size_t)grid * HN_VCAP * 4 + 64, 4);
+  uint32_t* vis = (uint32_t*)scratch((size_t)grid * HN_VCAP * 4 + 64, 4, s);
   if (!vis) return DBHIP_ERR_HIP;
   unsigned int* ctl = (unsigned int*)(vis + (size_t)grid * HN_VCAP);
   DBHIP_CHECK(hipMemsetAsync(ctl, 0, 16, s));

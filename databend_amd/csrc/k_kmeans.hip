@@ -388,7 +388,7 @@ int32_t dbhip_kmeans(int32_t distance_type, const float* data, int64_t rows, int
   // scratch: [normalised copy] cent, next, centT, mind / dists, counts, sq, ctl
   const size_t nd = (size_t)rows * dim, kd = (size_t)kk * dim;
   const size_t bytes = (normalize_input ? nd * 4 : 0) + kd * 4 * 2 + (size_t)dim * kpad * 4 + (size_t)rows * 4 + (size_t)kk * 8 + 256;
-  uint8_t* ws = (uint8_t*)scratch(bytes + 256, 15);
+  uint8_t* ws = (uint8_t*)scratch(bytes + 256, 15, s);
   if (!ws) return DBHIP_ERR_HIP;
   float* p = (float*)ws;
   const float* x = data;

@@ -400,7 +400,7 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   static const int env_nt = getenv("DBHIP_Q1_NT") ? atoi(getenv("DBHIP_Q1_NT")) : 1;
   if (env_grid > 0) grid = (int)(ceil_div(ntiles, 4) < env_grid ? ceil_div(ntiles, 4) : env_grid);
   size_t rows_bytes = (size_t)grid * MAX_SLOTS * Q1_W * 8;
-  uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 4);
+  uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 4, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint64_t* ctrl = (uint64_t*)ws;
   uint64_t* partial = (uint64_t*)(ws + 64);

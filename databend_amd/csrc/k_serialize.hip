@@ -198,7 +198,7 @@ int32_t grow(void** p, size_t old_bytes, size_t new_bytes, hipStream_t s) {
 
 // hashes of the n rows (offsets[n + 1], data) into scratch slot 12: u64[2 n]
 int32_t hash_rows(const uint64_t* off, const uint8_t* data, int64_t n, uint64_t** out, hipStream_t s) {
-  uint64_t* h = (uint64_t*)scratch((size_t)(n > 0 ? n : 1) * 16, 12);
+  uint64_t* h = (uint64_t*)scratch((size_t)(n > 0 ? n : 1) * 16, 12, s);
   if (!h) return DBHIP_ERR_HIP;
   if (n) hipLaunchKernelGGL(hash128_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, off, data, n, g_hash_mask, h);
   DBHIP_LAUNCH_CHECK();
@@ -220,7 +220,7 @@ int32_t dbhip_serialize_keys_offsets(const dbhip_col* cols, int32_t ncols, int64
   if (rc) return rc;
   hipStream_t s = resolve_stream(stream);
   // sizes of rows 0..n-1 and a trailing 0, so that the exclusive scan yields offsets[0..n]
-  uint32_t* sizes = (uint32_t*)scratch((size_t)(n + 1) * 4 + (size_t)(ceil_div(n + 1, SCAN_TILE) + 2) * 8 + 64, 13);
+  uint32_t* sizes = (uint32_t*)scratch((size_t)(n + 1) * 4 + (size_t)(ceil_div(n + 1, SCAN_TILE) + 2) * 8 + 64, 13, s);
   if (!sizes) return DBHIP_ERR_HIP;
   uint64_t* blk = (uint64_t*)((uint8_t*)sizes + (((size_t)(n + 1) * 4 + 15) & ~(size_t)15));
   DBHIP_CHECK(hipMemsetAsync(sizes + n, 0, 4, s));
@@ -320,7 +320,7 @@ int32_t dbhip_join_probe_binary(dbhip_join_binary* j, const uint64_t* offsets, c
   }
   // candidates by hash -> scratch, then verify the bytes and compact (order preserved: sorted by probe row, build row)
   const size_t np = (size_t)cand;
-  uint8_t* ws = (uint8_t*)scratch(np * 4 * 3 + (np + 1) * 8 + (size_t)(ceil_div((int64_t)np, SCAN_TILE) + 2) * 8 + 256, 14);
+  uint8_t* ws = (uint8_t*)scratch(np * 4 * 3 + (np + 1) * 8 + (size_t)(ceil_div((int64_t)np, SCAN_TILE) + 2) * 8 + 256, 14, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint32_t* cpi = (uint32_t*)ws;
   uint32_t* cbi = cpi + np;

@@ -353,7 +353,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   // scratch: 2 key buffers, 2 perm buffers, hist, offsets, scan block sums, span (or/and), flags
   const int64_t nscan = (nh_max > nflag ? nh_max : nflag);
   size_t bytes = (size_t)n * 8 * 2 + (size_t)n * 4 * 2 + (size_t)nscan * 4 + (size_t)nscan * 8 + (size_t)(nscan / SCAN_TILE + 2) * 8 + 2048;
-  uint8_t* ws = (uint8_t*)scratch(bytes + 64, 7);
+  uint8_t* ws = (uint8_t*)scratch(bytes + 64, 7, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint32_t* long_flag = (uint32_t*)(ws + bytes);
   uint64_t* kb[2] = {(uint64_t*)ws, (uint64_t*)ws + n};

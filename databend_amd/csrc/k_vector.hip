@@ -440,7 +440,7 @@ int32_t select_topk(const float* d, const uint32_t* ids, const uint32_t* counts,
     uint32_t* si = out_i;
     int64_t out_ld = k;
     if (!last) {
-      uint8_t* ws = (uint8_t*)scratch((size_t)nq * slots * k * 8, 9 + flip);
+      uint8_t* ws = (uint8_t*)scratch((size_t)nq * slots * k * 8, 9 + flip, s);
       if (!ws) return DBHIP_ERR_HIP;
       sd = (float*)ws;
       si = (uint32_t*)(ws + (size_t)nq * slots * k * 4);
@@ -573,7 +573,7 @@ int32_t exact_topk_range(int metric, const float* base, int64_t lo, int64_t hi, 
   chunk = chunk < 4096 ? 4096 : chunk;
   chunk = (chunk / 256) * 256;
   if (chunk > hi - lo) chunk = ceil_div(hi - lo > 0 ? hi - lo : 1, 256) * 256;
-  float* dist = (float*)scratch((size_t)chunk * nq * 4, 6);
+  float* dist = (float*)scratch((size_t)chunk * nq * 4, 6, s);
   if (!dist) return DBHIP_ERR_HIP;
   bool first = !have_prev;
   for (int64_t c0 = lo; c0 < hi || first; c0 += chunk) {
@@ -614,7 +614,7 @@ int32_t topk_batch(int metric, const float* base, int64_t n, int dim, const floa
   int32_t rc = exact_topk_range(metric, base, 0, S, dim, queries, nq, k, qnorm, false, out_idx, out_dist, s);
   if (rc || S >= n) return rc;
 
-  uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8);
+  uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint32_t* cnt = (uint32_t*)ws;
   float* cand_d = (float*)(ws + (((size_t)nq * 4 + 63) & ~(size_t)63));
@@ -901,7 +901,7 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
 
   // query side: bf16 image + norms
   const size_t qh_bytes = (((size_t)nq * dpad * 2) + 255) & ~(size_t)255;
-  uint8_t* qws = (uint8_t*)scratch(qh_bytes + (size_t)nq * 12 + 256, 11);
+  uint8_t* qws = (uint8_t*)scratch(qh_bytes + (size_t)nq * 12 + 256, 11, s);
   if (!qws) return DBHIP_ERR_HIP;
   uint16_t* qh = (uint16_t*)qws;
   float* qA = (float*)(qws + qh_bytes);
@@ -910,7 +910,7 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   hipLaunchKernelGGL(vec_to_bf16_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim,
                      dpad, 2, qh, qA, qX, qY);
 
-  uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8);
+  uint8_t* ws = (uint8_t*)scratch((size_t)nq * CAND_CAP * 8 + (size_t)nq * 4 + 64, 8, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint32_t* cnt = (uint32_t*)ws;
   float* cand_d = (float*)(ws + (((size_t)nq * 4 + 63) & ~(size_t)63));
@@ -1010,7 +1010,7 @@ int32_t dbhip_vec_index_search(dbhip_vec_index* ix, const float* queries, int32_
   hipStream_t s = resolve_stream(stream);
   float* qnorm = nullptr;
   if (ix->metric == DBHIP_VEC_COSINE) {
-    qnorm = (float*)scratch((size_t)(nq + 1) * 4, 5);
+    qnorm = (float*)scratch((size_t)(nq + 1) * 4, 5, s);
     if (!qnorm) return DBHIP_ERR_HIP;
     hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, ix->dim, qnorm);
   }
@@ -1046,7 +1046,7 @@ int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t
   hipStream_t s = resolve_stream(stream);
   float* qnorm = nullptr;
   if (metric == DBHIP_VEC_COSINE) {
-    qnorm = (float*)scratch((size_t)nq * 4, 5);
+    qnorm = (float*)scratch((size_t)nq * 4, 5, s);
     if (!qnorm) return DBHIP_ERR_HIP;
     hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim, qnorm);
   }
@@ -1070,7 +1070,7 @@ int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim
   hipStream_t s = resolve_stream(stream);
   float* qnorm = nullptr;
   if (metric == DBHIP_VEC_COSINE) {
-    qnorm = (float*)scratch((size_t)(nq + 1) * 4, 5);
+    qnorm = (float*)scratch((size_t)(nq + 1) * 4, 5, s);
     if (!qnorm) return DBHIP_ERR_HIP;
     hipLaunchKernelGGL(row_norm_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim, qnorm);
   }

@@ -14,7 +14,7 @@ int32_t hip_fail(hipError_t e, const char* what);
 
 // Scratch arena bound to the library (grown on demand, reused across calls on
 // the same thread; callers must not hold it across dbhip calls).
-void* scratch(size_t bytes, int slot);
+void* scratch(size_t bytes, int slot, hipStream_t stream);
 
 // Pinned host words for small device -> host read-backs that are queued asynchronously (64 u64 per slot, 8 slots per
 // thread). Two async copies into PAGEABLE memory in flight at once — a kernel's control block, then the queued merge's —

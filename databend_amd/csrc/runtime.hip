@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <new>
 #include <unordered_map>
 #include <vector>
 
@@ -23,7 +24,13 @@ struct Scratch {
   void* p = nullptr;
   size_t cap = 0;
 };
-static thread_local Scratch g_scratch[16];
+// Scratch is keyed by (thread, stream): two asynchronous calls of one thread on two streams never share a buffer, so a thread
+// may keep several streams busy at once (r02's rule "one stream at a time per thread" is gone). A buffer that has to grow is
+// released after ITS stream has drained, not after the whole device.
+struct StreamScratch {
+  Scratch slot[16];
+};
+static thread_local std::unordered_map<hipStream_t, StreamScratch>* g_scratch = nullptr;
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -47,11 +54,13 @@ hipStream_t resolve_stream(void* stream) {
   return g_stream;
 }
 
-void* scratch(size_t bytes, int slot) {
-  Scratch& s = g_scratch[slot];
+void* scratch(size_t bytes, int slot, hipStream_t stream) {
+  if (!g_scratch) g_scratch = new (std::nothrow) std::unordered_map<hipStream_t, StreamScratch>();
+  if (!g_scratch) { set_error("scratch: out of host memory"); return nullptr; }
+  Scratch& s = (*g_scratch)[stream].slot[slot];
   if (s.cap < bytes) {
     if (s.p) {
-      (void)hipDeviceSynchronize();
+      (void)hipStreamSynchronize(stream);
       (void)hipFree(s.p);
     }
     size_t cap = bytes + (bytes >> 2) + 4096;

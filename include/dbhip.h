@@ -22,8 +22,8 @@
  *     return a host value, in which case they synchronise the stream.
  *   - threading: every entry point may be called from any host thread, and different threads may be inside the
  *     library at the same time (handles — group-by tables, joins, indexes — belong to one caller at a time, like a
- *     Processor instance). Internal scratch is per THREAD: a thread that queues asynchronous calls must keep them on
- *     ONE stream at a time (drain it before switching), or use one thread per stream — the executor's model.
+ *     Processor instance). Internal scratch is keyed by (THREAD, STREAM): a thread may keep asynchronous calls in flight on
+ *     several streams at once, and several threads may share a stream (their calls are stream-ordered).
  *
  * Each group of functions cites the reference interface it replaces
  * (paths relative to the Databend source tree).

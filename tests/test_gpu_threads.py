@@ -63,3 +63,32 @@ def test_c_abi_is_reentrant_across_host_threads(gpu):
         t.join(300)
     assert not errors, errors
     assert all(not t.is_alive() for t in threads)
+
+
+def test_one_thread_may_keep_several_streams_busy(gpu):
+    """internal scratch is keyed by (thread, stream): asynchronous calls queued by ONE thread on TWO streams do not share a
+    scratch buffer (r02's rule was one stream at a time per thread). Interleaved filter_select calls of different sizes — each
+    call's block sums live in scratch until its kernels have run — and nothing is synchronised until everything is queued."""
+    D, L = gpu, lib()
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    check(L.dbhip_stream_create(C.byref(s1)))
+    check(L.dbhip_stream_create(C.byref(s2)))
+    rng = np.random.default_rng(77)
+    jobs = []
+    for r in range(12):
+        n = int(rng.integers(3_000_000, 6_000_000)) if r % 2 == 0 else int(rng.integers(50_000, 90_000))
+        bits = rng.random(n) < (0.3 if r % 3 else 0.9)
+        packed = np.packbits(bits, bitorder="little")
+        bm = D.DeviceBuffer.from_numpy(np.concatenate([packed, np.zeros(16, np.uint8)]))
+        sel, cnt = D.DeviceBuffer(n * 4 + 64), D.DeviceBuffer(8)
+        jobs.append((bits, bm, sel, cnt, n, s1 if r % 2 == 0 else s2))
+    for bits, bm, sel, cnt, n, st in jobs:   # everything queued back to back, big and small alternating between the streams
+        check(L.dbhip_filter_select(C.c_void_p(bm.ptr), C.c_int64(0), C.c_int64(n), C.c_void_p(sel.ptr), C.c_void_p(cnt.ptr), st))
+    check(L.dbhip_stream_sync(s1))
+    check(L.dbhip_stream_sync(s2))
+    for bits, bm, sel, cnt, n, st in jobs:
+        k = int(bits.sum())
+        assert int(cnt.to_numpy(np.uint64, 1)[0]) == k
+        assert np.array_equal(sel.to_numpy(np.uint32, k), np.nonzero(bits)[0].astype(np.uint32))
+    check(L.dbhip_stream_destroy(s1))
+    check(L.dbhip_stream_destroy(s2))

@@ -106,11 +106,22 @@ class Q3Torch:
         return [(int(k[j]), int(r[j]), int(d[j]), 0) for j in order.tolist()], int(gidx.numel()), int(oidx.numel())
 
 
+def gather_bytes(stats):
+    """bytes the takes of the plan move (values read + written, and the 4-byte selection / pair index each take reads):
+    c_custkey by the filter's selection; o_orderkey, o_orderdate, o_shippriority by probe #1's pairs; l_orderkey, l_extendedprice,
+    l_discount by probe #2's probe rows and the taken o_orderdate, o_shippriority by its build rows. Reported beside the streamed
+    bytes (they are not part of them)."""
+    kj, kp, kc = stats["orders_joined"], stats["lineitem_pairs"], stats["customers_kept"]
+    return kc * (8 + 8 + 4) + kj * ((8 + 4 + 4) * 2 + 3 * 4) + kp * ((8 + 8 + 8) * 2 + 3 * 4 + (4 + 4) * 2 + 2 * 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sf", type=float, default=100.0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default="")
+    ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle's Q3 (oracle/liboracle.so, all host threads) on the SAME tables "
+                    "copied back to the host and compare stage counts and the top rows (a check, ~1 min at SF100)")
     ap.add_argument("--main-only", action="store_true", help="skip the alternative (materialise) plan: for profiles of the default plan")
     args = ap.parse_args()
     D.init(0)
@@ -143,11 +154,35 @@ def main():
     exp, ngroups, njoined = src.torch_q3(tpch.Q3_DATE, 10)
     ok = [(r[1], r[2]) for r in got] == [(r[1], r[2]) for r in exp] and sorted(got) == sorted(exp) and ngroups == stats["groups"] \
         and njoined == stats["orders_joined"]
+    oracle = None
+    if args.oracle:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        h = lambda x: x.cpu().numpy()  # noqa: E731
+        host = {"customer": {"c_custkey": h(src.c_custkey), "c_mktsegment": h(src.c_seg)},
+                "orders": {"o_orderkey": h(src.o_orderkey), "o_custkey": h(src.o_custkey), "o_orderdate": h(src.o_orderdate),
+                           "o_shippriority": h(src.o_shipprio)},
+                "lineitem": {"l_orderkey": h(src.l_orderkey), "l_extendedprice": h(src.l_price), "l_discount": h(src.l_disc),
+                             "l_shipdate": h(src.l_ship)}}
+        so = {}
+        c0 = time.perf_counter()
+        threads = os.cpu_count() or 8
+        exp_o = O.q3_run(host, tpch.Q3_SEGMENT, tpch.Q3_DATE, limit=10, threads=threads, stages=so)
+        osec = time.perf_counter() - c0
+        same = [(r[1], r[2]) for r in got] == [(r[1], r[2]) for r in exp_o] and sorted(got) == sorted(exp_o)
+        stages_same = all(stats[k] == so[k] for k in ("customers_kept", "orders_kept", "orders_joined", "groups"))
+        oracle = {"matches": bool(same and stages_same), "seconds": osec, "threads": threads, "stages": so}
+        del host
+        if not oracle["matches"]:
+            print("ORACLE MISMATCH", got, exp_o, stats, so, file=sys.stderr)
+            sys.exit(1)
     best = min(times)
     streamed = 24 * src.nc + 24 * src.no + 28 * src.nl
+    gather = gather_bytes(stats)
     out = {"workload": f"TPC-H Q3 SF{args.sf:g} operator-at-a-time (customer {src.nc}, orders {src.no}, lineitem {src.nl} rows)",
            "seconds": best, "all_seconds": times, "lineitem_rows_per_s": src.nl / best, "streamed_bytes": streamed,
-           "streamed_GBps": streamed / best / 1e9, "frac_of_hbm_peak": streamed / best / 8e12, "stages": stats,
+           "streamed_GBps": streamed / best / 1e9, "frac_of_hbm_peak": streamed / best / 8e12, "gather_bytes": gather,
+           "matches_cpu_oracle_on_the_same_tables": oracle, "stages": stats,
            "plan": "predicate Bitmaps as probe-key validity (nothing materialised before the joins)",
            "materialise_plan_seconds": times_b,
            "matches_independent_torch_statement": bool(ok), "top10": got, "generate_seconds": gen_s}

@@ -9,6 +9,7 @@
 #   mb:<microbench args>      python tools/microbench.py <args>       -> mb_<tag>.json
 #   mbprof:<microbench args>  rocprofv3 --kernel-trace --stats of tools/microbench.py
 #   py:<script and args>      python <script …>                       -> py_<tag>.log
+#   mbpmc:<C1,C2..>:<microbench args>  one --pmc pass of tools/microbench.py -> <tag>_pmc_<C1>.csv
 #   pypmc:<C1,C2..>:<script and args>  one --pmc pass (kernel-trace only) of python <script …> -> <tag>_pmc_<C1>.csv
 #   pyprof:<script and args>  rocprofv3 --kernel-trace --stats of python <script …> -> <tag>_kernel_stats.csv
 TAG=$1; shift
@@ -48,6 +49,13 @@ for STEP in "$@"; do
       d=$R/gpurun_out/prof_$TAG; rm -rf $d
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $R/$ARG > $R/gpurun_out/pyprof_$TAG.log 2>&1)
       stats $d gpurun_out/${TAG}_kernel_stats.csv; rm -rf $d ;;
+    mbpmc)
+      C=${ARG%%:*}; SA=${ARG#*:}
+      d=$R/gpurun_out/pmc_${TAG}_${C%%,*}; rm -rf $d
+      (cd /tmp && timeout 900 rocprofv3 --pmc ${C//,/ } --kernel-trace --output-format csv -d $d -o p -- python $R/tools/microbench.py $SA > $d.json 2> $d.err)
+      f=$(find $d -name '*counter_collection.csv' | head -1)
+      [ -n "$f" ] && python tools/pmc_sum.py "$f" > gpurun_out/${TAG}_pmc_${C%%,*}.csv && head -20 gpurun_out/${TAG}_pmc_${C%%,*}.csv
+      rm -rf $d ;;
     pypmc)
       C=${ARG%%:*}; SA=${ARG#*:}
       d=$R/gpurun_out/pmc_${TAG}_${C%%,*}; rm -rf $d
