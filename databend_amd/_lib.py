@@ -33,7 +33,7 @@ class Col(C.Structure):
     ]
 
 
-EX_LOAD, EX_CONST, EX_PLUS, EX_MINUS, EX_MULTIPLY, EX_DIVIDE, EX_EQ, EX_NOTEQ, EX_LT, EX_LTE, EX_GT, EX_GTE, EX_AND, EX_OR, EX_NOT, EX_CAST, EX_IF = range(17)
+EX_LOAD, EX_CONST, EX_PLUS, EX_MINUS, EX_MULTIPLY, EX_DIVIDE, EX_EQ, EX_NOTEQ, EX_LT, EX_LTE, EX_GT, EX_GTE, EX_AND, EX_OR, EX_NOT, EX_CAST, EX_IF, EX_IS_TRUE = range(18)
 
 
 class ExprIns(C.Structure):

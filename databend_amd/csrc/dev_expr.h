@@ -104,7 +104,7 @@ __device__ __forceinline__ int ex_cmp3(uint64_t a, uint64_t b, int cls) {
 enum {
   EX_LOAD = 0, EX_CONST = 1, EX_PLUS = 2, EX_MINUS = 3, EX_MULTIPLY = 4, EX_DIVIDE = 5,
   EX_EQ = 6, EX_NOTEQ = 7, EX_LT = 8, EX_LTE = 9, EX_GT = 10, EX_GTE = 11,
-  EX_AND = 12, EX_OR = 13, EX_NOT = 14, EX_CAST = 15, EX_IF = 16,
+  EX_AND = 12, EX_OR = 13, EX_NOT = 14, EX_CAST = 15, EX_IF = 16, EX_IS_TRUE = 17,
   EX_DEC = 32  // internal: PLUS / MINUS / MULTIPLY / DIVIDE on decimals (the DecOp says which)
 };
 
@@ -237,6 +237,11 @@ __device__ __forceinline__ void ex_interpret(const ExProg& P, const ExProg& PA, 
       case EX_AND: EX_ROWS_DO(x & y & 1) break;
       case EX_OR: EX_ROWS_DO((x | y) & 1) break;
       case EX_NOT: EX_ROWS_DO1((x ^ 1) & 1) break;
+      case EX_IS_TRUE:  // decode_predicate: TRUE only where the operand is valid and set (imm = the nullable inputs it depends on)
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+          EX_REG(I.dst, k) = (EX_REG(I.a, k) & 1) & (uint64_t)((vmask[k] & (uint32_t)I.imm) == (uint32_t)I.imm);
+        break;
       case EX_IF:  // if(cond, then, else) over values that cannot raise (checked on the host): a select
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void bitmap_binary_kernel(const uint8_t* a, co
                                                             int is_or) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes;
        i += (int64_t)gridDim.x * blockDim.x) {
-    uint8_t v = is_or ? (a[i] | b[i]) : (a[i] & b[i]);
+    uint8_t v = is_or == 1 ? (a[i] | b[i]) : (is_or == 2 ? (a[i] & (uint8_t)~b[i]) : (a[i] & b[i]));
     if (i == nbytes - 1 && (n & 7)) v &= (uint8_t)((1u << (n & 7)) - 1);
     out[i] = v;
   }
@@ -617,6 +617,7 @@ int32_t dbhip_bitmap_binary(int32_t is_or, const uint8_t* a, const uint8_t* b, i
                             uint8_t* out, void* stream) {
   if (n == 0) return DBHIP_OK;
   DBHIP_REQUIRE(a && b && out, "dbhip_bitmap_binary: NULL argument");
+  DBHIP_REQUIRE(is_or >= 0 && is_or <= 2, "dbhip_bitmap_binary: op must be 0 (AND), 1 (OR) or 2 (AND NOT)");
   int64_t nbytes = ceil_div(n, 8);
   hipLaunchKernelGGL(bitmap_binary_kernel, dim3(grid_for(nbytes, 256)), dim3(256), 0,
                      resolve_stream(stream), a, b, out, nbytes, n, is_or);

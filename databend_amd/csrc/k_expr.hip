@@ -247,7 +247,7 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
     d.b = (int16_t)(ok_reg(s.b) ? reg[s.b].loc : 0);
     RegInfo res;
     res.type = s.type; res.loc = s.dst;
-    if (s.op != DBHIP_EX_AND && s.op != DBHIP_EX_LOAD && s.op != DBHIP_EX_CONST) {
+    if (s.op != DBHIP_EX_AND && s.op != DBHIP_EX_IS_TRUE && s.op != DBHIP_EX_LOAD && s.op != DBHIP_EX_CONST) {
       const int rc3 = s.op == DBHIP_EX_IF ? (int)(s.imm & 0xFF) : -1;
       const bool unary1 = s.op == DBHIP_EX_NOT || s.op == DBHIP_EX_CAST;
       if ((ok_reg(s.a) && reg[s.a].strict_and) || (!unary1 && ok_reg(s.b) && reg[s.b].strict_and) || (rc3 >= 0 && ok_reg(rc3) && reg[rc3].strict_and)) {
@@ -371,6 +371,17 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
           return DBHIP_ERR_UNSUPPORTED;
         }
         if (s.op == DBHIP_EX_AND) res.strict_and = res.dep != 0;
+      } break;
+      case DBHIP_EX_IS_TRUE: {
+        // decode_predicate (NULL -> FALSE): the operand's validity is folded into the value, the result depends on no nullable
+        // input any more. A strict AND below it is exact here (FALSE AND NULL and TRUE AND NULL both decode to FALSE).
+        if (!ok_reg(s.a) || reg[s.a].type != DBHIP_T_BOOL || s.type != DBHIP_T_BOOL) {
+          set_error("expression program: instruction %d: IS_TRUE needs a Boolean register and a Boolean result", i);
+          return DBHIP_ERR_INVALID;
+        }
+        ex_decode(d, DBHIP_T_BOOL, -1);
+        d.imm = reg[s.a].dep;
+        res.dep = 0; res.may_raise = reg[s.a].may_raise;
       } break;
       case DBHIP_EX_CAST: {
         if (!ok_reg(s.a)) { set_error("expression program: instruction %d reads an unset register", i); return DBHIP_ERR_INVALID; }

@@ -570,6 +570,23 @@ class ExprProgram:
     def logic(self, op, a, b=0):
         return self._emit(op, a, b, L.T_BOOL, release=(a,) if op == L.EX_NOT else (a, b))
 
+    def is_true(self, a):
+        """decode_predicate: NULL / FALSE -> FALSE, never NULL (utils/filter_helper.rs)"""
+        return self._emit(L.EX_IS_TRUE, a, 0, L.T_BOOL, release=(a,))
+
+    def or_filters(self, *regs):
+        """or_filters / and_filters (evaluator.rs:1802-1880): every argument decoded (NULL -> FALSE), then OR-ed / AND-ed"""
+        acc = self.is_true(regs[0])
+        for r in regs[1:]:
+            acc = self.logic(L.EX_OR, acc, self.is_true(r))
+        return acc
+
+    def and_filters(self, *regs):
+        acc = self.is_true(regs[0])
+        for r in regs[1:]:
+            acc = self.logic(L.EX_AND, acc, self.is_true(r))
+        return acc
+
     def cast(self, a, typ, precision=0, scale=0):
         size = (precision, scale) if typ in (L.T_DEC64, L.T_DEC128) else (0, 0)
         if typ == L.T_DEC128 and not precision:

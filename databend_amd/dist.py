@@ -241,3 +241,59 @@ def merge_shard_topk_device(idx_t, dst_t, row_offset, k, dist, torch, lib_sync, 
     merge_dev(all_d.data_ptr(), all_i.data_ptr(), nq, world * k, k, out_i.data_ptr(), out_d.data_ptr())
     lib_sync()
     return out_i, out_d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Broadcast hash join across ranks (TPC-H Q3, BASELINE configs[2] on N GPUs).
+# The reference runs a distributed inner join either by scattering both sides by the hash of the join key
+# (flight_scatter_hash.rs:57-120: hash % n per row, one flight per destination) or, when the build side is small,
+# by BROADCASTING the build side to every node (flight_scatter_broadcast.rs:22-37: every destination gets the whole
+# block; the planner picks it in hash_join.rs/`broadcast` exchanges) so that the probe side never moves. Q3's build
+# sides — customers of one market segment, then the orders that joined them — are 50x / 40x smaller than the probe sides
+# (orders, lineitem), which is the broadcast case: every rank filters its shard of the build side, the survivors are
+# all-gathered (one variable-length all-gather per column over RCCL / xGMI), every rank builds the SAME table and probes
+# its own rows. Only the final aggregation exchanges states (route by hash % world, like configs[3]).
+# ---------------------------------------------------------------------------------------------------------------------
+def allgather_columns(cols, dist, torch):
+    """Variable-length all-gather of equally long 1-D tensors (one build-side block per rank): returns the rank-major
+    concatenation of every column. One small collective for the lengths, one padded all_gather_into_tensor per column."""
+    world = dist.get_world_size()
+    n = int(cols[0].shape[0])
+    dev = cols[0].device
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    cnts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt)
+    counts = [int(x) for x in cnts.tolist()]
+    mx = max(max(counts), 1)
+    out = []
+    for c in cols:
+        assert int(c.shape[0]) == n and c.dim() == 1
+        send = torch.zeros(mx, dtype=c.dtype, device=dev)
+        send[:n] = c
+        recv = torch.empty(world * mx, dtype=c.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send)
+        out.append(torch.cat([recv[r * mx: r * mx + counts[r]] for r in range(world)]) if world > 1 else recv[:n])
+    return out
+
+
+def q3_broadcast_join(shard, ops, dist, torch, device, limit=10):
+    """Distributed Q3 over row-range shards of the three tables (any partition of the rows: the lines of one order may
+    live on different ranks). `ops` runs the single-node operators on this rank's shard (databend_amd.tpch.Q3DeviceOps on
+    a GPU; a numpy stand-in in the gloo tests):
+        ops.filter_customers(shard)                     -> [custkey]                       (1-D tensors on `device`)
+        ops.join_orders(custkeys, shard)                -> [orderkey, orderdate, shippriority] of the orders that joined
+        ops.aggregate_lineitem(okey, odate, oprio, shard) -> partial-aggregation table keyed by the three group columns
+        ops.exchange(table, dist, device)               -> routes every group to rank hash % world and merges (the configs[3]
+                                                          exchange: exchange_partials_alltoall_variable on a GPU)
+        ops.top_rows(table, limit)                      -> [(l_orderkey, revenue, o_orderdate, o_shippriority)] sorted
+    Every rank returns the same global top `limit` rows."""
+    (all_ck,) = allgather_columns(ops.filter_customers(shard), dist, torch)                  # broadcast build side #1
+    okey, odate, oprio = allgather_columns(ops.join_orders(all_ck, shard), dist, torch)      # broadcast build side #2
+    table = ops.aggregate_lineitem(okey, odate, oprio, shard)
+    ops.exchange(table, dist, device)                                                        # disjoint groups per rank
+    mine = ops.top_rows(table, limit)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, mine)                                                  # <= limit small rows per rank
+    rows = [r for part in gathered for r in part]
+    rows.sort(key=lambda r: (-r[1], r[2], r[0]))
+    return rows[:limit] if limit else rows

@@ -345,6 +345,12 @@ inline Buf and_validity(const Buf& a, const Buf& b, int64_t n) {
   check(dbhip_bitmap_binary(0, (const uint8_t*)a->ptr(), (const uint8_t*)b->ptr(), n, (uint8_t*)out->ptr(), nullptr));
   return out;
 }
+// op: 1 = a | b, 2 = a & ~b (both operands present)
+inline Buf bitmap_op(int op, const Buf& a, const Buf& b, int64_t n) {
+  Buf out = make_buf((size_t)(n + 63) / 64 * 8 + 8);
+  check(dbhip_bitmap_binary(op, (const uint8_t*)a->ptr(), (const uint8_t*)b->ptr(), n, (uint8_t*)out->ptr(), nullptr));
+  return out;
+}
 inline Buf const_bitmap(bool v, int64_t n) {
   Buf b = make_buf((size_t)(n + 63) / 64 * 8 + 8);
   b->fill(v ? 0xFF : 0x00);
@@ -419,6 +425,18 @@ class Evaluator {
       static const std::map<std::string, int> ops = {{"plus", DBHIP_EX_PLUS}, {"minus", DBHIP_EX_MINUS}, {"multiply", DBHIP_EX_MULTIPLY},
           {"divide", DBHIP_EX_DIVIDE}, {"eq", DBHIP_EX_EQ}, {"noteq", DBHIP_EX_NOTEQ}, {"lt", DBHIP_EX_LT}, {"lte", DBHIP_EX_LTE},
           {"gt", DBHIP_EX_GT}, {"gte", DBHIP_EX_GTE}};
+      if (e.fname == "and_filters" || e.fname == "or_filters") {   // AND / OR over decoded (NULL -> FALSE) arguments
+        int acc = -1;
+        for (const Expr& a : e.args) {
+          int r = emit(a);
+          if (!ok) return 0;
+          ins(DBHIP_EX_IS_TRUE, r, r, 0, DBHIP_T_BOOL, 0);
+          if (acc < 0) { acc = r; continue; }
+          ins(e.fname == "or_filters" ? DBHIP_EX_OR : DBHIP_EX_AND, acc, acc, r, DBHIP_T_BOOL, 0);
+          free_regs.push_back(r);
+        }
+        return acc;
+      }
       auto it = ops.find(e.fname);
       if (it == ops.end() || e.args.size() != 2) { ok = false; return 0; }
       int a = emit(e.args[0]);
@@ -459,6 +477,7 @@ class Evaluator {
       default: break;
     }
     if (e.fname == "and_filters") return eval_and_filters(e, validity, selection);
+    if (e.fname == "or_filters") return eval_or_filters(e, validity, selection);
     return eval_common_call(e, validity, selection);
   }
 
@@ -487,6 +506,23 @@ class Evaluator {
       acc = and_validity(acc, bits, n);
     }
     Column c; c.type = DataType::of(DBHIP_T_BOOL); c.len = n; c.data = acc ? acc : const_bitmap(true, n);
+    return Value::of(c);
+  }
+
+  // evaluator.rs:1802-1880: disjunction of decoded predicates (NULL -> false); a later argument is only evaluated (and may only
+  // raise) on the rows no earlier argument made TRUE
+  Value eval_or_filters(const Expr& e, Buf validity, const std::vector<uint32_t>* selection) const {
+    const int64_t n = block_.num_rows;
+    Buf result;
+    for (const Expr& a : e.args) {
+      Value v = partial_run(a, validity, selection);
+      Buf bits;
+      if (v.is_scalar) bits = const_bitmap(!v.scalar.is_null && v.scalar.i != 0, n);
+      else bits = and_validity(v.column.data, v.column.validity, n);  // NULL -> false
+      result = result ? bitmap_op(1, result, bits, n) : bits;
+      validity = bitmap_op(2, validity ? validity : const_bitmap(true, n), bits, n);
+    }
+    Column c; c.type = DataType::of(DBHIP_T_BOOL); c.len = n; c.data = result ? result : const_bitmap(false, n);
     return Value::of(c);
   }
 
@@ -711,7 +747,7 @@ inline Expr Expr::call(const std::string& name, std::vector<Expr> args, const Fu
   static const std::map<std::string, int> arith = {{"plus", DBHIP_OP_PLUS}, {"minus", DBHIP_OP_MINUS}, {"multiply", DBHIP_OP_MULTIPLY}, {"divide", DBHIP_OP_DIVIDE}};
   static const std::map<std::string, int> cmps = {{"eq", DBHIP_CMP_EQ}, {"noteq", DBHIP_CMP_NOTEQ}, {"lt", DBHIP_CMP_LT}, {"lte", DBHIP_CMP_LTE}, {"gt", DBHIP_CMP_GT}, {"gte", DBHIP_CMP_GTE}};
   static const std::map<std::string, int> vec = {{"cosine_distance", DBHIP_VEC_COSINE}, {"l2_distance", DBHIP_VEC_L2}, {"inner_product", DBHIP_VEC_DOT}, {"l1_distance", DBHIP_VEC_L1}};
-  if (name == "and_filters") { e.type = DataType::of(DBHIP_T_BOOL); return e; }
+  if (name == "and_filters" || name == "or_filters") { e.type = DataType::of(DBHIP_T_BOOL); return e; }
   const bool any_decimal = at.size() == 2 && (at[0].is_decimal() || at[1].is_decimal());
   if (any_decimal && arith.count(name)) {
     auto props = [](const DataType& t, uint8_t& p, uint8_t& s) {  // integer -> decimal size (cast.rs:701-753)

@@ -130,6 +130,42 @@ static void test_filter() {
   CHECK(out.num_rows == (int64_t)ed.size() && od == ed && ox == ex);
 }
 
+static void test_or_filters() {
+  // or_filters / and_filters over NULLABLE predicates (evaluator.rs:1802-1880): NULL decodes to FALSE, the result is never NULL;
+  // node by node (run) and as one fused program (run_fused) — and a later argument never raises on rows an earlier one took
+  const int64_t n = 50001;
+  std::mt19937 rng(5);
+  std::vector<int64_t> a(n), b(n); std::vector<bool> va(n), vb(n);
+  for (int64_t i = 0; i < n; ++i) { a[i] = (int64_t)(rng() % 10); b[i] = (int64_t)(rng() % 10); va[i] = rng() % 4 != 0; vb[i] = rng() % 3 != 0; }
+  auto I64 = DataType::of(DBHIP_T_I64);
+  DataBlock block({Column::from_vector(I64, a, &va), Column::from_vector(I64, b, &vb)}, n);
+  Expr pa = Expr::call("gt", {Expr::column_ref(0, I64.wrap_nullable(), "a"), Expr::constant(Scalar::Int(DBHIP_T_I64, 3))});
+  Expr pb = Expr::call("lt", {Expr::column_ref(1, I64.wrap_nullable(), "b"), Expr::constant(Scalar::Int(DBHIP_T_I64, 8))});
+  Evaluator ev(block);
+  for (int is_or = 0; is_or < 2; ++is_or) {
+    Expr e = Expr::call(is_or ? "or_filters" : "and_filters", {pa, pb});
+    std::vector<bool> exp(n);
+    for (int64_t i = 0; i < n; ++i) { bool x = va[i] && a[i] > 3, y = vb[i] && b[i] < 8; exp[i] = is_or ? (x || y) : (x && y); }
+    Value v = ev.run(e);
+    CHECK(!v.column.validity);
+    CHECK(Column::unpack_bits(v.column.data, n) == exp);
+    auto f = ev.run_fused(e);
+    CHECK(f.has_value());
+    if (f->column.validity) { std::vector<bool> vv = Column::unpack_bits(f->column.validity, n); for (int64_t i = 0; i < n; ++i) CHECK(vv[(size_t)i]); }
+    CHECK(Column::unpack_bits(f->column.data, n) == exp);
+  }
+  // or_filters(b = 0, 10 / b > 2): the division only sees the rows where b != 0
+  std::vector<int64_t> d(n);
+  for (int64_t i = 0; i < n; ++i) d[i] = (int64_t)(rng() % 5);
+  DataBlock blk2({Column::from_vector(I64, d)}, n);
+  Expr isz = Expr::call("eq", {Expr::column_ref(0, I64, "d"), Expr::constant(Scalar::Int(DBHIP_T_I64, 0))});
+  Expr quo = Expr::call("gt", {Expr::call("divide", {Expr::constant(Scalar::Int(DBHIP_T_I64, 10)), Expr::column_ref(0, I64, "d")}),
+                               Expr::constant(Scalar::Float(DBHIP_T_F64, 2.0))});
+  Value r = Evaluator(blk2).run(Expr::call("or_filters", {isz, quo}));
+  std::vector<bool> got = Column::unpack_bits(r.column.data, n);
+  for (int64_t i = 0; i < n; ++i) CHECK(got[(size_t)i] == (d[i] == 0 || 10.0 / (double)d[i] > 2.0));
+}
+
 static void test_q1_plan() {
   const int64_t n = 300007;
   std::mt19937_64 rng(2);
@@ -367,6 +403,7 @@ int main() {
     test_sum_a_plus_b_mul_c();
     test_row_errors();
     test_filter();
+    test_or_filters();
     test_q1_plan();
     test_join_and_sort();
     test_left_joins();

@@ -14,6 +14,7 @@ benchmark/tpch/create.sql:12-29 and dbgen's value rules:
 Q1 predicate: l_shipdate <= 1998-12-01 - 90 days = 1998-09-02
 (benchmark/tpch/queries/01.sql:1-16).
 """
+import ctypes as C
 import datetime as _dt
 
 import numpy as np
@@ -373,6 +374,11 @@ def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=N
     g.add_block([j_ok, j_od, j_sp], [revenue], kp)
     if stats is not None:
         stats.update(customers_kept=kc, orders_kept=ko, orders_joined=kj, lineitem_kept=kl, lineitem_pairs=kp, groups=g.num_groups())
+    return q3_top_rows(g, limit)
+
+
+def q3_top_rows(g, limit):
+    """ORDER BY revenue DESC, o_orderdate LIMIT over the table's groups -> [(l_orderkey, revenue, o_orderdate, o_shippriority)]"""
     k_ok, k_od, k_sp, rev = g.result_columns()
     ng = k_ok.n
     perm = D.sort_perm([rev, k_od], desc=[1, 0], limit=limit) if ng else np.zeros(0, np.uint32)
@@ -381,3 +387,69 @@ def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=N
     ok, od, sp = (D.take(c, psel, m).to_numpy() for c in (k_ok, k_od, k_sp))
     rv = D.take(rev, psel, m).to_numpy()
     return [(int(ok[i]), int(rv[i]), int(od[i]), int(sp[i])) for i in range(m)]
+
+
+class _Borrowed:
+    """a torch tensor's storage as a column buffer (the tensor stays alive with the column)"""
+
+    def __init__(self, t):
+        self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+
+
+class Q3DeviceOps:
+    """The single-node operators of the distributed broadcast-join plan (databend_amd.dist.q3_broadcast_join) over the C-ABI:
+    this rank's shard is a Q3Device-like object (columns resident in HBM); the columns that cross ranks are CUDA tensors
+    (torch.distributed moves them over RCCL), everything else stays inside the library."""
+
+    def __init__(self, torch, segment=Q3_SEGMENT, date=Q3_DATE):
+        self.torch, self.segment, self.date = torch, segment, date
+        self.keep = []
+
+    def _tensor(self, col, dtype):
+        t = self.torch.empty(col.n, dtype=dtype, device="cuda")
+        if col.n:
+            L.check(L.lib().dbhip_memcpy_d2d(C.c_void_p(t.data_ptr()), C.c_void_p(col.data.ptr), C.c_size_t(t.numel() * t.element_size()), None))
+        L.check(L.lib().dbhip_stream_sync(None))
+        return t
+
+    def _column(self, t, dtype):
+        self.torch.cuda.current_stream().synchronize()   # the collective that produced it has finished
+        return D.Column(dtype, int(t.shape[0]), _Borrowed(t.contiguous()))
+
+    def filter_customers(self, t):
+        seg = D.Column.from_views(_views_from_short_strings([self.segment.encode()], np.zeros(1, dtype=np.int64)))
+        seg.is_scalar = True
+        csel, kc = D.filter_select(D.cmp(L.CMP_EQ, t.c_mktsegment, seg, t.n_customer))
+        return [self._tensor(D.take(t.c_custkey, csel, kc), self.torch.int64)]
+
+    def join_orders(self, all_custkeys, t):
+        j1 = D.HashJoin(max(int(all_custkeys.shape[0]), 16))
+        j1.add_block(self._column(all_custkeys, L.T_I64))
+        j1.final_build()
+        opred = D.cmp(L.CMP_LT, t.o_orderdate, D.Column.scalar(self.date, L.T_DATE), t.n_orders)
+        pp, _pb, kj = j1.probe_block_device(D.Column(t.o_custkey.dtype, t.n_orders, t.o_custkey.data, validity=opred.data))
+        return [self._tensor(D.take(c, pp, kj), dt) for c, dt in ((t.o_orderkey, self.torch.int64), (t.o_orderdate, self.torch.int32),
+                                                                  (t.o_shippriority, self.torch.int32))]
+
+    def aggregate_lineitem(self, okey, odate, oprio, t):
+        b_ok, b_od, b_sp = self._column(okey, L.T_I64), self._column(odate, L.T_DATE), self._column(oprio, L.T_I32)
+        j2 = D.HashJoin(max(b_ok.n, 16))
+        j2.add_block(b_ok)
+        j2.final_build()
+        lpred = D.cmp(L.CMP_GT, t.l_shipdate, D.Column.scalar(self.date, L.T_DATE), t.n_lineitem)
+        lp, lb, kp = j2.probe_block_device(D.Column(t.l_orderkey.dtype, t.n_lineitem, t.l_orderkey.data, validity=lpred.data))
+        j_ok, j_price, j_disc = (D.take(c, lp, kp) for c in (t.l_orderkey, t.l_extendedprice, t.l_discount))
+        j_od, j_sp = D.take(b_od, lb, kp), D.take(b_sp, lb, kp)
+        one_minus = D.decimal_arith(L.OP_MINUS, D.Column.scalar(1, L.T_U8), j_disc, kp)
+        revenue = D.decimal_arith(L.OP_MULTIPLY, j_price, one_minus, kp)
+        g = D.GroupBy(Q3_KEYS, Q3_AGGS, capacity=max(1024, 2 * kp))
+        if kp:
+            g.add_block([j_ok, j_od, j_sp], [revenue], kp)
+        return g
+
+    def exchange(self, g, dist, device):
+        from . import dist as DX
+        return DX.exchange_partials_alltoall_variable(g, dist, self.torch, device, lib_sync=lambda: L.check(L.lib().dbhip_stream_sync(None)))
+
+    def top_rows(self, g, limit):
+        return q3_top_rows(g, limit)

@@ -198,8 +198,9 @@ int32_t dbhip_sum(const dbhip_col* col, int64_t n, void* out_sum_dev, void* stre
  * (FALSE AND NULL = FALSE, TRUE OR NULL = TRUE; and_filters / or_filters, evaluator.rs:284-305): the compiler therefore accepts
  * them over NULLABLE operands only where the two agree — an AND (chain) that ends in the FILTER of a fused aggregation, where
  * NULL and FALSE both drop the row — and returns DBHIP_ERR_UNSUPPORTED for OR over a nullable operand and for an AND over a
- * nullable operand that feeds anything else (a value result, NOT, if, a comparison); those stay with dbhip_bitmap_binary on
- * the operator-at-a-time path.
+ * nullable operand that feeds anything else (a value result, NOT, if, a comparison). DBHIP_EX_IS_TRUE makes an operand
+ * non-nullable the way the reference's filters do (NULL -> FALSE): and_filters / or_filters over nullable predicates are
+ * AND / OR over IS_TRUE operands, anywhere in a program.
  * Outputs: `out_values` = elements of the out register's type (Decimal128: i128), or for a Boolean result an
  * LSB-first bitmap; `out_validity` likewise a bitmap. Bitmaps are written as whole 64-bit words: both buffers must
  * hold ceil(n/64)*8 bytes and be 8-byte aligned; bits past n are zero. `sum_out_dev` (may be NULL): the
@@ -211,7 +212,10 @@ typedef enum {
   DBHIP_EX_PLUS = 2, DBHIP_EX_MINUS = 3, DBHIP_EX_MULTIPLY = 4, DBHIP_EX_DIVIDE = 5,
   DBHIP_EX_EQ = 6, DBHIP_EX_NOTEQ = 7, DBHIP_EX_LT = 8, DBHIP_EX_LTE = 9, DBHIP_EX_GT = 10, DBHIP_EX_GTE = 11,
   DBHIP_EX_AND = 12, DBHIP_EX_OR = 13, DBHIP_EX_NOT = 14, DBHIP_EX_CAST = 15,
-  DBHIP_EX_IF = 16       /* dst <- a ? b : register (imm & 0xFF)                     */
+  DBHIP_EX_IF = 16,      /* dst <- a ? b : register (imm & 0xFF)                     */
+  DBHIP_EX_IS_TRUE = 17  /* dst <- a is TRUE (a NULL or FALSE operand gives FALSE, the result is never NULL):
+                          * FilterHelpers::decode_predicate (utils/filter_helper.rs), what and_filters / or_filters apply to every
+                          * argument (evaluator.rs:1815-1880) — or_filters(p, q) = OR(IS_TRUE p, IS_TRUE q) */
 } dbhip_expr_op;
 typedef struct {
   int32_t op;            /* dbhip_expr_op                                           */
@@ -269,7 +273,8 @@ int32_t dbhip_decimal_cast(const dbhip_col* src, int32_t dst_type, uint8_t dst_p
  * ceil(n/8) bytes, LSB-first, trailing bits zero. */
 int32_t dbhip_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, int64_t n,
                   uint8_t* out_bitmap, void* stream);
-/* Bitmap AND / OR / NOT for and_filters / validity merging (evaluator.rs:284-305). */
+/* Bitmap AND (is_or = 0) / OR (1) / AND NOT (2: a & ~b) for and_filters / or_filters / validity merging (evaluator.rs:284-305,
+ * 1815-1880: or_filters narrows the validity of its later arguments to the rows that are not TRUE yet). */
 int32_t dbhip_bitmap_binary(int32_t is_or, const uint8_t* a, const uint8_t* b, int64_t n,
                             uint8_t* out, void* stream);
 int32_t dbhip_bitmap_count(const uint8_t* bitmap, int64_t bit_offset, int64_t n,

@@ -384,3 +384,53 @@ def test_and_or_over_nullable_operands_keep_three_valued_semantics(gpu):
     keep = va & (a > 3)
     exp = sorted((int(key), int(x[keep & (k == key)].sum()), int((keep & (k == key)).sum())) for key in np.unique(k[keep]))
     assert sorted(g.result()) == exp
+
+
+def test_or_filters_and_filters_over_nullable_predicates(gpu):
+    """or_filters / and_filters (evaluator.rs:1802-1880): every argument goes through decode_predicate (NULL -> FALSE) and the
+    result is never NULL. As a value, as the operand of NOT, and as the filter of a fused aggregation — interpreted and through
+    the run-time specialised kernel."""
+    D = gpu
+    n = 70001
+    rng = np.random.default_rng(78)
+    a = rng.integers(0, 10, n).astype(np.int64)
+    b = rng.integers(0, 10, n).astype(np.int64)
+    c = rng.integers(0, 10, n).astype(np.int32)
+    va, vb, vc = rng.integers(0, 4, n) > 0, rng.integers(0, 3, n) > 0, rng.integers(0, 5, n) > 0
+    k = rng.integers(0, 3, n).astype(np.int64)
+    x = rng.integers(-100, 100, n).astype(np.int64)
+    ta, tb, tc = va & (a > 3), vb & (b < 8), vc & (c == 5)          # decode_predicate of the three predicates
+
+    def program():
+        cols = [D.Column.from_numpy(a, validity=va), D.Column.from_numpy(b, validity=vb), D.Column.from_numpy(c, validity=vc), D.Column.from_numpy(x)]
+        p = D.ExprProgram(cols)
+        return p, (p.cmp(T.EX_GT, p.load(0), p.const(3, T.T_I64)), p.cmp(T.EX_LT, p.load(1), p.const(8, T.T_I64)),
+                   p.cmp(T.EX_EQ, p.load(2), p.const(5, T.T_I32)))
+
+    def bits(out):
+        assert out.get("validity") is None or np.asarray(out["validity"], dtype=bool)[:n].all()   # never NULL
+        return np.asarray(out["values"], dtype=bool)[:n]
+
+    p, preds = program()
+    assert np.array_equal(bits(p.run(p.or_filters(*preds), n)), ta | tb | tc)
+    p, preds = program()
+    assert np.array_equal(bits(p.run(p.and_filters(*preds), n)), ta & tb & tc)
+    p, preds = program()
+    assert np.array_equal(bits(p.run(p.logic(T.EX_NOT, p.or_filters(preds[0], preds[1])), n)), ~(ta | tb))
+    # or_filters(and_filters(p, q), r): the strict AND below IS_TRUE is exact (FALSE AND NULL and TRUE AND NULL decode to FALSE)
+    p, preds = program()
+    inner = p.logic(T.EX_AND, preds[0], preds[1])
+    assert np.array_equal(bits(p.run(p.logic(T.EX_OR, p.is_true(inner), p.is_true(preds[2])), n)), (ta & tb) | tc)
+    # as the filter of a fused aggregation
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)]
+    keep = ta | tb & tc
+    exp = sorted((int(key), int(x[keep & (k == key)].sum()), int((keep & (k == key)).sum())) for key in np.unique(k[keep]))
+    for prepare in (False, True):
+        p, preds = program()
+        f = p.logic(T.EX_OR, p.is_true(preds[0]), p.and_filters(preds[1], preds[2]))
+        g = D.GroupBy([T.T_I64], aggs)
+        if prepare:
+            g.add_block_program([D.Column.from_numpy(k)], p, [("input", 3), None], n, filter_reg=f, prepare=True)
+            g = D.GroupBy([T.T_I64], aggs)
+        g.add_block_program([D.Column.from_numpy(k)], p, [("input", 3), None], n, filter_reg=f)
+        assert sorted(g.result()) == exp, prepare

@@ -75,3 +75,31 @@ def test_q3_gpu_empty_results(gpu):
     assert tpch.q3_operator_at_a_time(t, segment="NOSUCHSEG") == []
     assert tpch.q3_operator_at_a_time(t, date=tpch.ORDER_LO) == []
     assert tpch.q3_operator_at_a_time(t, date=tpch.ORDER_HI + 200) == []
+
+
+@pytest.mark.gpu
+def test_q3_broadcast_join_plan_on_one_rank_over_rccl(gpu):
+    """the distributed plan (databend_amd.dist.q3_broadcast_join: build sides all-gathered, probe sides stay, states routed by
+    hash) with the device operators and the nccl (= RCCL) backend in a world of one: every collective really runs; the
+    multi-rank logic is covered by tests/test_dist_gloo.py with world 2 / 3."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from databend_amd import dist as DX
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        host = tpch.gen_q3(0.05, seed=21)
+        t = tpch.Q3Device(host)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        got = DX.q3_broadcast_join(t, tpch.Q3DeviceOps(torch), dist, torch, dev, limit=10)
+        same_result(got, O.q3_run(host, tpch.Q3_SEGMENT, tpch.Q3_DATE, limit=10, threads=4))
+        got_all = DX.q3_broadcast_join(t, tpch.Q3DeviceOps(torch), dist, torch, dev, limit=0)
+        same_result(got_all, O.q3_run(host, tpch.Q3_SEGMENT, tpch.Q3_DATE, limit=0, threads=4))
+    finally:
+        dist.destroy_process_group()
