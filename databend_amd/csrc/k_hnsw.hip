@@ -59,6 +59,7 @@ struct HnswView {   // by-value kernel argument
   uint32_t* ready;             // [n]
   uint32_t* lock;              // [n]
   unsigned long long* entry;   // packed (level << 32 | ~idx), 0 = none
+  int exact_scores;            // build scorer in the reference's sequential f32 order (the deterministic build)
 };
 
 struct dbhip_hnsw_impl {
@@ -247,6 +248,28 @@ __device__ bool heap_pop(SP* d, int* len, SP* out) {
   *out = item;
   return true;
 }
+// sift_down_range + into_sorted_vec of the max-heap (ascending by score; equal scores end where std's heap sort puts them)
+__device__ void heap_sift_down_range(SP* d, int pos, int end) {
+  const SP e = d[pos];
+  int child = 2 * pos + 1;
+  while (end >= 2 && child <= end - 2) {
+    child += sp_le(d[child].score, d[child + 1].score) ? 1 : 0;
+    if (sp_le(d[child].score, e.score)) { d[pos] = e; return; }   // hole.element() >= hole.get(child)
+    d[pos] = d[child];
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  if (child == end - 1 && sp_lt(e.score, d[child].score)) { d[pos] = d[child]; pos = child; }
+  d[pos] = e;
+}
+__device__ void heap_into_sorted(SP* d, int len) {
+  int end = len;
+  while (end > 1) {
+    --end;
+    const SP t = d[0]; d[0] = d[end]; d[end] = t;
+    heap_sift_down_range(d, 0, end);
+  }
+}
 // ---- BinaryHeap<Reverse<SP>>: the same with the order reversed ----
 __device__ __forceinline__ bool r_le(float a, float b) { return sp_le(b, a); }
 __device__ void rheap_sift_down_range(SP* d, int pos, int end) {
@@ -376,9 +399,31 @@ __device__ __forceinline__ void score_quant4(const HnswView& H, const WaveLds* W
     out[j] = __fadd_rn(__fadd_rn(__fmul_rn(H.mult, (float)(int32_t)s), W->qoff), vo);
   }
 }
-// original-vector score (calculate_score, point_scorer.rs:133-174) of up to 4 pairs (a[j], b[j]); the sum order is the
-// wave's, not the reference's sequential one: only the build uses it, and the reference's build is not reproducible either
+// original-vector score (calculate_score, point_scorer.rs:133-174) of up to 4 pairs (a[j], b[j]) over the PRE-PROCESSED column
+// (HNSWIndex::build normalises a cosine column first, hnsw.rs:150-157). Two forms:
+//   exact (H.exact_scores, the deterministic build): lane j computes pair j alone, element by element in the reference's order
+//     (Iterator::sum is a sequential f32 fold; every product / difference rounded on its own) — bit-identical scores;
+//   wave (the concurrent build): the 64 lanes split the dimensions and the partial sums are combined by shuffles; for cosine the
+//     raw dot product is divided by the two lengths afterwards. The reference's concurrent build is not reproducible either.
 __device__ __forceinline__ void score_orig4(const HnswView& H, const uint32_t (&a)[4], const uint32_t (&b)[4], int cnt, float (&out)[4]) {
+  if (H.exact_scores) {
+    const int j = lane();
+    float acc = 0.0f;
+    if (j < cnt) {
+      const uint32_t pa = j == 0 ? a[0] : j == 1 ? a[1] : j == 2 ? a[2] : a[3];
+      const uint32_t pb = j == 0 ? b[0] : j == 1 ? b[1] : j == 2 ? b[2] : b[3];
+      for (int i = 0; i < H.dim; ++i) {
+        const float x = hn_value(H.raw, H.vlen, pa, H.dim, i), y = hn_value(H.raw, H.vlen, pb, H.dim, i);
+        if (H.distance == D_DOT) acc = __fadd_rn(acc, __fmul_rn(x, y));
+        else if (H.distance == D_L1) acc = __fadd_rn(acc, fabsf(__fsub_rn(x, y)));
+        else { const float d = __fsub_rn(x, y); acc = __fadd_rn(acc, __fmul_rn(d, d)); }
+      }
+      if (H.distance != D_DOT) acc = -acc;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = __shfl(acc, q, 64);
+    return;
+  }
   float acc[4] = {0, 0, 0, 0};
   for (int i = lane(); i < H.dim; i += 64) {
     float x[4], y[4];
@@ -396,7 +441,11 @@ __device__ __forceinline__ void score_orig4(const HnswView& H, const uint32_t (&
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float s = wave_sum_f(acc[j]);
+    float s = wave_sum_f(acc[j]);
+    if (H.distance == D_DOT && H.vlen && j < cnt) {   // cosine: the column is normalised before the build
+      const float la = H.vlen[a[j]], lb = H.vlen[b[j]];
+      s = s / ((la == 0.0f ? 1.0f : la) * (lb == 0.0f ? 1.0f : lb));
+    }
     out[j] = H.distance == D_DOT ? s : -s;
   }
 }
@@ -743,22 +792,17 @@ __device__ void link_point(const HnswView& H, BuildLds* B, uint32_t* vis, const 
             for (int j = 0; j < c4; ++j) a[j] = (b + j == 0) ? p : ld32(ol + (b + j - 1));
             float sc[4];
             score_orig4(H, a, o, c4, sc);
+            // candidates.push(..) in the reference's order: the new point first, then other's links (BinaryHeap::push = sift_up)
             if (l == 0)
-              for (int j = 0; j < c4; ++j) { B->tmp[b + j].idx = a[j]; B->tmp[b + j].score = sc[j]; }
+              for (int j = 0; j < c4; ++j) { SP v; v.idx = a[j]; v.score = sc[j]; int len = b + j; heap_push(B->tmp, &len, v); }
+            WAVE_SYNC();
           }
-          WAVE_SYNC();
-          // rank sort, descending (ties: earlier position first)
-          SP mine_sp = {0, 0};
-          int rank = 0;
-          if (l < nc) {
-            mine_sp = B->tmp[l];
-            for (int j = 0; j < nc; ++j) {
-              const SP x = B->tmp[j];
-              rank += (sp_lt(mine_sp.score, x.score) || (!sp_lt(x.score, mine_sp.score) && j < l)) ? 1 : 0;
-            }
+          // candidates.into_sorted_vec().into_iter().rev(): std's heap sort, then descending — equal scores (duplicate vectors,
+          // a zero vector under cosine) come out in ITS order, not in insertion order
+          if (l == 0) {
+            heap_into_sorted(B->tmp, nc);
+            for (int i = 0, j = nc - 1; i < j; ++i, --j) { const SP t = B->tmp[i]; B->tmp[i] = B->tmp[j]; B->tmp[j] = t; }
           }
-          WAVE_SYNC();
-          if (l < nc) B->tmp[rank] = mine_sp;
           WAVE_SYNC();
           const int n2 = select_heuristic(H, B->tmp, nc, level_m, B->sel2);
           if (l < n2) st32(ol + l, B->sel2[l]);
@@ -931,26 +975,16 @@ int search_grid(int64_t work) {
 
 struct dbhip_hnsw { dbhip_hnsw_impl impl; };
 
-extern "C" {
-
-int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
-                         uint64_t seed, dbhip_hnsw** out, void* stream) {
-  DBHIP_REQUIRE(out && ef_construct >= 1 && ef_construct <= HN_MAX_EF, "dbhip_hnsw_build: bad argument (ef_construct <= 256)");
-  hipStream_t s = resolve_stream(stream);
-  // get_random_layer (graph_layers_builder.rs:246-255): round(-ln(u) * 1 / ln(max(m, 2))), u uniform in [0, 1)
-  std::vector<int32_t> levels((size_t)(n > 0 ? n : 0));
-  const double level_factor = 1.0 / log((double)(m > 2 ? m : 2));
-  uint64_t st = seed;
-  for (int64_t i = 0; i < n; ++i) {
-    double u = (double)(splitmix64(&st) >> 11) * (1.0 / 9007199254740992.0);
-    if (u <= 0.0) u = 1.0 / 9007199254740992.0;
-    levels[(size_t)i] = (int32_t)llround(-log(u) * level_factor);
-  }
+namespace {
+// links every point of a fresh index: `deterministic` = ONE wave links the points one after the other with the exact scorer
+int32_t build_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
+                    const int32_t* levels, bool deterministic, dbhip_hnsw** out, hipStream_t s) {
   dbhip_hnsw_impl* h = nullptr;
-  int32_t rc = create_common(vectors_dev, n, dim, distance, m, levels.data(), s, &h);
+  int32_t rc = create_common(vectors_dev, n, dim, distance, m, levels, s, &h);
   if (rc) return rc;
   ImplGuard guard(h);
   h->ef_construct = ef_construct;
+  h->v.exact_scores = deterministic ? 1 : 0;
   if (n > 0) {
     const int grid = search_grid(n);
     uint32_t* vis = nullptr;
@@ -964,7 +998,7 @@ int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32
     // are not blind to each other: [256, 512), [512, 1024), ... doubling up to 1 M points per launch
     int64_t done = 0;
     {
-      A.p_begin = 0; A.p_end = n < HN_SEQ ? n : HN_SEQ; A.sequential = 1;
+      A.p_begin = 0; A.p_end = (n < HN_SEQ || deterministic) ? n : HN_SEQ; A.sequential = 1;
       hipLaunchKernelGGL(hn_build_kernel, dim3(1), dim3(64), 0, s, h->v, A);
       done = A.p_end;
     }
@@ -987,8 +1021,34 @@ int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32
     }
   }
   h->v.raw = nullptr;   // the caller's vectors are not kept (search uses the codes)
+  h->v.exact_scores = 0;
   *out = (dbhip_hnsw*)guard.release();
   return DBHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
+                         uint64_t seed, dbhip_hnsw** out, void* stream) {
+  DBHIP_REQUIRE(out && ef_construct >= 1 && ef_construct <= HN_MAX_EF, "dbhip_hnsw_build: bad argument (ef_construct <= 256)");
+  hipStream_t s = resolve_stream(stream);
+  // get_random_layer (graph_layers_builder.rs:246-255): round(-ln(u) * 1 / ln(max(m, 2))), u uniform in [0, 1)
+  std::vector<int32_t> levels((size_t)(n > 0 ? n : 0));
+  const double level_factor = 1.0 / log((double)(m > 2 ? m : 2));
+  uint64_t st = seed;
+  for (int64_t i = 0; i < n; ++i) {
+    double u = (double)(splitmix64(&st) >> 11) * (1.0 / 9007199254740992.0);
+    if (u <= 0.0) u = 1.0 / 9007199254740992.0;
+    levels[(size_t)i] = (int32_t)llround(-log(u) * level_factor);
+  }
+  return build_graph(vectors_dev, n, dim, distance, m, ef_construct, levels.data(), false, out, s);
+}
+
+int32_t dbhip_hnsw_build_sequential(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
+                                    const int32_t* levels_host, dbhip_hnsw** out, void* stream) {
+  DBHIP_REQUIRE(out && ef_construct >= 1 && ef_construct <= HN_MAX_EF && (levels_host || n == 0), "dbhip_hnsw_build_sequential: bad argument (ef_construct <= 256, levels given)");
+  return build_graph(vectors_dev, n, dim, distance, m, ef_construct, levels_host, true, out, resolve_stream(stream));
 }
 
 int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m,

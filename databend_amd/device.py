@@ -1368,6 +1368,17 @@ class HnswIndex:
         return cls(h, base.n, base.dim)
 
     @classmethod
+    def build_sequential(cls, metric, base, levels, m=10, ef_construct=40):
+        """the deterministic build: given levels, points linked one after the other, the reference's summation order"""
+        _ensure()
+        levels = np.ascontiguousarray(levels, dtype=np.int32)
+        assert len(levels) == base.n
+        h = C.c_void_p()
+        check(lib().dbhip_hnsw_build_sequential(C.c_void_p(base.data.ptr), C.c_int64(base.n), base.dim, metric, m, ef_construct,
+                                                levels.ctypes.data_as(C.c_void_p), C.byref(h), None))
+        return cls(h, base.n, base.dim)
+
+    @classmethod
     def from_graph(cls, metric, base, m, levels, lists, entry_point, entry_level):
         """lists: the link lists in point-major, level-minor order (HNSWIndex::open over a given graph)"""
         _ensure()

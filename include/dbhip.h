@@ -786,6 +786,13 @@ int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c);
 typedef struct dbhip_hnsw dbhip_hnsw;
 int32_t dbhip_hnsw_build(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
                          uint64_t seed, dbhip_hnsw** out, void* stream);
+/* The DETERMINISTIC build: `levels_host[n]` are given (the reference draws them from thread_rng()), ONE wave links the points
+ * one after the other in row order — HNSWIndex::build's insertion loop run sequentially (hnsw.rs:158-235) — and the build
+ * scorer sums in the reference's order (calculate_score, point_scorer.rs:133-174: a sequential f32 fold over the
+ * pre-processed column). The graph equals the sequential CPU restatement (oracle/hnsw_oracle.c orc_hnsw_build) link for
+ * link (tests/test_gpu_hnsw.py); it is the mode that pins the builder, not the fast one. */
+int32_t dbhip_hnsw_build_sequential(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m, int32_t ef_construct,
+                                    const int32_t* levels_host, dbhip_hnsw** out, void* stream);
 int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m,
                               const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host,
                               uint32_t entry_point, int32_t entry_level, dbhip_hnsw** out, void* stream);

@@ -191,3 +191,38 @@ def test_edge_cases(gpu, L):
         gpu.HnswIndex.build(2, one)          # plain dot is not an index distance of the reference
     with pytest.raises(Exception):
         gpu.HnswIndex.build(0, one, m=40)    # m0 = 80 > 64
+
+
+@pytest.mark.parametrize("distance,n,dim,m,efc", [("l2", 1500, 24, 8, 32), ("cosine", 1200, 40, 10, 40), ("l1", 700, 17, 6, 24), ("cosine", 300, 8, 4, 16)])
+def test_deterministic_build_equals_the_sequential_reference_builder_link_for_link(gpu, L, distance, n, dim, m, efc):
+    """dbhip_hnsw_build_sequential: given levels, one wave links the points in row order with the build scorer summed in the
+    reference's order — the graph must equal oracle/hnsw_oracle.c's orc_hnsw_build (GraphLayersBuilder::link_new_point run
+    sequentially over the pre-processed column) in every list, in order, and in the entry point. Duplicate vectors and a
+    clustered distribution are in the data on purpose (equal scores exercise the heap / heuristic tie order)."""
+    rng = np.random.default_rng(31)
+    centers = rng.standard_normal((12, dim)).astype(np.float32) * 3
+    raw = (centers[rng.integers(0, 12, n)] + rng.standard_normal((n, dim)).astype(np.float32) * 0.4).astype(np.float32)
+    raw[n // 3] = raw[n // 7]            # exact duplicates
+    raw[n // 2] = raw[n // 7]
+    raw[5] = 0.0                          # a zero vector (cosine: left as it is)
+    u = rng.random(n)
+    levels = np.round(-np.log(np.maximum(u, 1e-12)) / np.log(max(m, 2))).astype(np.int32)
+    base = gpu.VectorColumn(raw)
+    idx = gpu.HnswIndex.build_sequential(METRIC[distance], base, levels, m=m, ef_construct=efc)
+    got_levels, lists, ep, el = idx.export_graph()
+    assert np.array_equal(got_levels, levels)
+    g = H.Graph(L, n, m, efc, levels)
+    g.build(H.preprocess(L, raw, distance), distance)
+    oep, oel = g.entry()
+    li = 0
+    diff = []
+    for p in range(n):
+        for lv in range(levels[p] + 1):
+            exp = g.links(p, lv)
+            if not np.array_equal(lists[li], exp):
+                diff.append((p, lv, lists[li].tolist(), exp.tolist()))
+            li += 1
+    g.free()
+    idx.destroy()
+    assert not diff, (len(diff), diff[:3])
+    assert (ep, el) == (oep, oel)
