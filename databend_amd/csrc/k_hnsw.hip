@@ -163,6 +163,20 @@ __global__ __launch_bounds__(256) void hn_layout_kernel(const uint8_t* codes, co
   }
 }
 
+// the inverse: the reference's storage layout (f32 offset + actual_dim codes per vector) -> codes[n][adim] + voff[n] (HNSWIndex::open)
+__global__ __launch_bounds__(256) void hn_unlayout_kernel(const uint8_t* in, int64_t n, int adim, uint8_t* codes, float* voff) {
+  const int64_t rec = adim + 4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n * rec; e += (int64_t)gridDim.x * 256) {
+    const int64_t v = e / rec;
+    const int b = (int)(e % rec);
+    if (b >= 4) codes[v * adim + (b - 4)] = in[e];
+    else if (b == 0) {
+      const uint32_t w = (uint32_t)in[e] | ((uint32_t)in[e + 1] << 8) | ((uint32_t)in[e + 2] << 16) | ((uint32_t)in[e + 3] << 24);
+      voff[v] = __uint_as_float(w);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // per-wave query state (LDS) and the scorers
 // ---------------------------------------------------------------------------------------------------------------------
@@ -893,12 +907,14 @@ struct ImplGuard {
 };
 
 // quantiser + graph storage for `levels`
+// `encoded` (HNSWIndex::open): the quantised vectors in the reference's storage layout with their metadata, instead of `vectors`
+struct EncodedIn { const uint8_t* data; float alpha, offset, multiplier; };
 int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t distance, int32_t m, const int32_t* levels,
-                      hipStream_t s, dbhip_hnsw_impl** out) {
+                      hipStream_t s, dbhip_hnsw_impl** out, const EncodedIn* encoded = nullptr) {
   const int dc = dist_code(distance);
   if (dc < 0) { set_error("dbhip_hnsw: distance must be cosine, l1 or l2 (the reference's index option)"); return DBHIP_ERR_UNSUPPORTED; }
   DBHIP_REQUIRE(n >= 0 && n < 0x7FFFFFF0LL && dim > 0 && m >= 1 && 2 * m <= HN_MAX_M0, "dbhip_hnsw: bad n / dim / m (m <= 32)");
-  DBHIP_REQUIRE(n == 0 || vectors, "dbhip_hnsw: NULL vectors");
+  DBHIP_REQUIRE(n == 0 || vectors || (encoded && encoded->data), "dbhip_hnsw: NULL vectors");
   const int adim = dim + (HN_ALIGN - dim % HN_ALIGN) % HN_ALIGN;
   if (adim > HN_MAX_ADIM) { set_error("dbhip_hnsw: dim > %d", HN_MAX_ADIM); return DBHIP_ERR_UNSUPPORTED; }
   dbhip_hnsw_impl* h = new (std::nothrow) dbhip_hnsw_impl();
@@ -923,7 +939,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   if ((rc = own(h, nn * adim, &codes)) || (rc = own(h, nn * 4, &voff)) || (rc = own(h, nn * V.m0 * 4, &l0)) || (rc = own(h, nn * 4, &c0)) ||
       (rc = own(h, (size_t)(nu > 0 ? nu : 1) * m * 4, &lu)) || (rc = own(h, (size_t)(nu > 0 ? nu : 1) * 4, &cu)) || (rc = own(h, nn * 8, &uf)) ||
       (rc = own(h, nn * 4, &lv)) || (rc = own(h, nn * 4, &rd)) || (rc = own(h, nn * 4, &lk)) || (rc = own(h, 16, &en))) return rc;
-  if (dc == D_DOT && (rc = own(h, nn * 4, &vlen))) return rc;
+  if (dc == D_DOT && !encoded && (rc = own(h, nn * 4, &vlen))) return rc;
   V.codes = (uint8_t*)codes; V.voff = (float*)voff; V.vlen = (float*)vlen; V.links0 = (uint32_t*)l0; V.cnt0 = (uint32_t*)c0;
   V.linksu = (uint32_t*)lu; V.cntu = (uint32_t*)cu; V.ufirst = (int64_t*)uf; V.level = (int32_t*)lv; V.ready = (uint32_t*)rd;
   V.lock = (uint32_t*)lk; V.entry = (unsigned long long*)en;
@@ -936,6 +952,13 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   if (n > 0) {
     DBHIP_CHECK(hipMemcpyAsync(lv, h->level_host.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
     DBHIP_CHECK(hipMemcpyAsync(uf, h->ufirst_host.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if (encoded) {   // EncodedVectorsU8::load (encoded_vectors_u8.rs:312-325): the stored codes and metadata as they are
+      V.alpha = encoded->alpha; V.offset = encoded->offset; V.mult = encoded->multiplier;
+      hipLaunchKernelGGL(hn_unlayout_kernel, dim3(grid_for(n * (adim + 4), 256)), dim3(256), 0, s, encoded->data, n, adim, (uint8_t*)codes, (float*)voff);
+      DBHIP_LAUNCH_CHECK();
+      *out = guard.release();
+      return DBHIP_OK;
+    }
     // ---- EncodedVectorsU8::encode over the pre-processed vectors (hnsw.rs:150-157,262-283) ----
     if (dc == D_DOT) hipLaunchKernelGGL(hn_length_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, vectors, n, dim, (float*)vlen);
     uint32_t* mm = (uint32_t*)scratch(8, 3, s);
@@ -1051,25 +1074,22 @@ int32_t dbhip_hnsw_build_sequential(const float* vectors_dev, int64_t n, int32_t
   return build_graph(vectors_dev, n, dim, distance, m, ef_construct, levels_host, true, out, resolve_stream(stream));
 }
 
-int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m,
-                              const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host,
-                              uint32_t entry_point, int32_t entry_level, dbhip_hnsw** out, void* stream) {
-  DBHIP_REQUIRE(out && (n == 0 || (levels_host && links_host && nlinks_host)), "dbhip_hnsw_from_graph: bad argument");
-  hipStream_t s = resolve_stream(stream);
-  dbhip_hnsw_impl* h = nullptr;
-  int32_t rc = create_common(vectors_dev, n, dim, distance, m, levels_host, s, &h);
-  if (rc) return rc;
-  ImplGuard guard(h);
+}  // extern "C"
+
+namespace {
+// copies a given graph into a fresh index (lists in point-major, level-minor order)
+int32_t install_graph(dbhip_hnsw_impl* h, int64_t n, int32_t m, const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host,
+                      uint32_t entry_point, int32_t entry_level, hipStream_t s) {
   const int m0 = 2 * m;
   std::vector<uint32_t> l0((size_t)n * m0, 0), c0((size_t)n, 0), lu((size_t)h->n_upper * m, 0), cu((size_t)h->n_upper, 0), rd((size_t)n, 1);
   int64_t list = 0, off = 0;
   for (int64_t p = 0; p < n; ++p)
     for (int lv = 0; lv <= levels_host[p]; ++lv, ++list) {
       const int c = nlinks_host[list];
-      if (c < 0 || c > (lv == 0 ? m0 : m)) { set_error("dbhip_hnsw_from_graph: a list longer than m / m0"); return DBHIP_ERR_INVALID; }
+      if (c < 0 || c > (lv == 0 ? m0 : m)) { set_error("dbhip_hnsw: a list longer than m / m0"); return DBHIP_ERR_INVALID; }
       for (int i = 0; i < c; ++i) {
         const uint32_t x = links_host[off + i];
-        if (x >= (uint64_t)n || levels_host[x] < lv) { set_error("dbhip_hnsw_from_graph: link out of range or to a point below the list's level"); return DBHIP_ERR_INVALID; }
+        if (x >= (uint64_t)n || levels_host[x] < lv) { set_error("dbhip_hnsw: link out of range or to a point below the list's level"); return DBHIP_ERR_INVALID; }
         if (lv == 0) l0[(size_t)p * m0 + i] = x;
         else lu[(size_t)(h->ufirst_host[p] + lv - 1) * m + i] = x;
       }
@@ -1084,13 +1104,44 @@ int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, 
       DBHIP_CHECK(hipMemcpyAsync(h->v.cntu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice, s));
     }
     DBHIP_CHECK(hipMemcpyAsync(h->v.ready, rd.data(), rd.size() * 4, hipMemcpyHostToDevice, s));
-    if (entry_point >= (uint64_t)n || entry_level < 0 || entry_level > levels_host[entry_point]) { set_error("dbhip_hnsw_from_graph: bad entry point"); return DBHIP_ERR_INVALID; }
+    if (entry_point >= (uint64_t)n || entry_level < 0 || entry_level > levels_host[entry_point]) { set_error("dbhip_hnsw: bad entry point"); return DBHIP_ERR_INVALID; }
     const unsigned long long ent = ((unsigned long long)(entry_level + 1) << 32) | (unsigned long long)(~entry_point);
     DBHIP_CHECK(hipMemcpyAsync(h->v.entry, &ent, 8, hipMemcpyHostToDevice, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
   }
   h->v.raw = nullptr;
   h->ef_construct = 0;
+  return DBHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m,
+                              const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host,
+                              uint32_t entry_point, int32_t entry_level, dbhip_hnsw** out, void* stream) {
+  DBHIP_REQUIRE(out && (n == 0 || (levels_host && links_host && nlinks_host)), "dbhip_hnsw_from_graph: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  dbhip_hnsw_impl* h = nullptr;
+  int32_t rc = create_common(vectors_dev, n, dim, distance, m, levels_host, s, &h);
+  if (rc) return rc;
+  ImplGuard guard(h);
+  if ((rc = install_graph(h, n, m, levels_host, links_host, nlinks_host, entry_point, entry_level, s))) return rc;
+  *out = (dbhip_hnsw*)guard.release();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_hnsw_open(const uint8_t* encoded_dev, float alpha, float offset, float multiplier, int64_t n, int32_t dim, int32_t distance,
+                        int32_t m, const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host, uint32_t entry_point,
+                        int32_t entry_level, dbhip_hnsw** out, void* stream) {
+  DBHIP_REQUIRE(out && (n == 0 || (encoded_dev && levels_host && links_host && nlinks_host)), "dbhip_hnsw_open: bad argument");
+  hipStream_t s = resolve_stream(stream);
+  dbhip_hnsw_impl* h = nullptr;
+  const EncodedIn enc{encoded_dev, alpha, offset, multiplier};
+  int32_t rc = create_common(nullptr, n, dim, distance, m, levels_host, s, &h, &enc);
+  if (rc) return rc;
+  ImplGuard guard(h);
+  if ((rc = install_graph(h, n, m, levels_host, links_host, nlinks_host, entry_point, entry_level, s))) return rc;
   *out = (dbhip_hnsw*)guard.release();
   return DBHIP_OK;
 }

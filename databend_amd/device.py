@@ -1392,6 +1392,22 @@ class HnswIndex:
                                           C.c_int32(entry_level), C.byref(h), None))
         return cls(h, base.n, base.dim)
 
+    @classmethod
+    def open(cls, metric, encoded, alpha, offset, multiplier, n, dim, m, levels, lists, entry_point, entry_level):
+        """HNSWIndex::open over the stored form (databend_amd.hnsw_format.open_index): `encoded` = the encoded_u8_data bytes"""
+        _ensure()
+        levels = np.ascontiguousarray(levels, dtype=np.int32)
+        nl = np.array([len(x) for x in lists], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in lists]) if len(lists) and nl.sum() else np.zeros(1, np.uint32),
+                                    dtype=np.uint32)
+        enc = DeviceBuffer.from_numpy(np.ascontiguousarray(encoded, dtype=np.uint8)) if n else DeviceBuffer(16)
+        h = C.c_void_p()
+        check(lib().dbhip_hnsw_open(C.c_void_p(enc.ptr), C.c_float(float(alpha)), C.c_float(float(offset)), C.c_float(float(multiplier)), C.c_int64(n), dim,
+                                    metric, m, levels.ctypes.data_as(C.c_void_p), flat.ctypes.data_as(C.c_void_p), nl.ctypes.data_as(C.c_void_p),
+                                    C.c_uint32(entry_point), C.c_int32(entry_level), C.byref(h), None))
+        check(lib().dbhip_stream_sync(None))   # `enc` is only read while the index is being made
+        return cls(h, n, dim)
+
     def export_graph(self):
         """-> (levels, lists, entry_point, entry_level)"""
         levels = np.zeros(max(self.n, 1), dtype=np.int32)

@@ -796,6 +796,14 @@ int32_t dbhip_hnsw_build_sequential(const float* vectors_dev, int64_t n, int32_t
 int32_t dbhip_hnsw_from_graph(const float* vectors_dev, int64_t n, int32_t dim, int32_t distance, int32_t m,
                               const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host,
                               uint32_t entry_point, int32_t entry_level, dbhip_hnsw** out, void* stream);
+/* HNSWIndex::open (hnsw.rs:62-98) over the STORED form of an index: `encoded_dev` = the `encoded_u8_data` column's bytes (per vector
+ * an f32 offset and actual_dim codes, quantization/encoded_storage.rs) with alpha / offset / multiplier from the `encoded_u8_meta`
+ * JSON (encoded_vectors_u8.rs:45-52), and the graph as dbhip_hnsw_from_graph takes it. The host-side reader / writer of the four
+ * binary columns (graph_links Compressed format, bincode GraphLayerData, JSON metadata) is databend_amd/hnsw_format.py. No
+ * original vectors are needed (none are stored): the index only searches. */
+int32_t dbhip_hnsw_open(const uint8_t* encoded_dev, float alpha, float offset, float multiplier, int64_t n, int32_t dim, int32_t distance,
+                        int32_t m, const int32_t* levels_host, const uint32_t* links_host, const int32_t* nlinks_host, uint32_t entry_point,
+                        int32_t entry_level, dbhip_hnsw** out, void* stream);
 int32_t dbhip_hnsw_export_graph(dbhip_hnsw* h, int32_t* levels_host, uint32_t* links_host, int32_t* nlinks_host,
                                 int64_t* out_n_lists_host, uint32_t* out_entry_point_host, int32_t* out_entry_level_host,
                                 void* stream);
