@@ -456,60 +456,58 @@ __global__ __launch_bounds__(256) void take_chunks_bitmap_kernel(const uint8_t* 
 // take for the nullable side of an outer join (left_join.rs:185-260: matched rows take the build columns wrapped with a true
 // validity, unmatched probe rows get a null_block): idx == 0xFFFFFFFF -> a zero value and validity 0; otherwise the source row
 // and its validity (true when the source has none). One validity word per wave (ballot).
-// take for selections that are LOCALLY DENSE (a TransformFilter's ascending selection, the probe side of a join's pairs: 512
-// consecutive entries that span at most LDS_ROWS source rows). A gather of such a selection asks for one 64-byte sector per
-// element although neighbouring elements share lines with rows nobody wants; reading the covered source range with coalesced
-// loads into LDS and picking the elements there moves whole lines at the streaming rate instead (r03, 14.6 M of 150 M rows,
-// 8-byte values: 1.67 ms as a gather). A workgroup whose 512 entries span more than the window gathers them directly, so any
-// selection is handled; the decision is per 512 entries.
+// take for selections that are LOCALLY DENSE (a TransformFilter's ascending selection, the probe side of a join's pairs). A gather
+// asks for one 64-byte sector per element although neighbouring elements share lines with rows nobody wants; reading the covered
+// source range with coalesced 16-byte loads into LDS and picking the elements there moves whole lines at the streaming rate
+// instead (r03, 14.6 M of 150 M rows, 8-byte values: 1.67 ms as a gather, 0.25 ms like this). The unit is a WAVE and 64 entries:
+// no barrier, no workgroup reduction (the first version reduced min / max over a workgroup's 512 entries through LDS and two
+// barriers per chunk — twice the time of a plain gather on the 98 %-dense selection of Q1's literal plan — and its 61 KB window
+// left 2 waves per SIMD; 30 KB leave 4). Per 64 entries:
+//   span <= 128 rows (at least half of the rows are wanted): a plain gather is already coalesced;
+//   span <= LDS_ROWS / 4: staged through the wave's quarter of the LDS window;
+//   else (sparse or unordered): a plain gather. Any selection is handled; the decision is per 64 entries.
 template <typename T, int LDS_ROWS>
 __global__ __launch_bounds__(256) void take_window_kernel(const T* __restrict__ src, const uint32_t* __restrict__ sel, int64_t n, T* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) T win[LDS_ROWS];
-  __shared__ uint32_t red[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t nchunks = (n + 511) / 512;
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const int64_t i0 = c * 512 + tid, i1 = i0 + 256;
-    const uint32_t s0 = i0 < n ? sel[i0] : 0xFFFFFFFFu, s1 = i1 < n ? sel[i1] : 0xFFFFFFFFu;
-    uint32_t lo = s0 < s1 ? s0 : s1;
+  __shared__ __attribute__((aligned(16))) T win_all[LDS_ROWS];
+  constexpr int WROWS = LDS_ROWS / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* win = win_all + wave * WROWS;
+  const int64_t nchunks = (n + 63) / 64;
+  for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < nchunks; c += (int64_t)gridDim.x * 4) {
+    const int64_t i0 = c * 64 + lane;
+    const uint32_t s0 = i0 < n ? sel[i0] : 0xFFFFFFFFu;
+    uint32_t lo = s0;
     uint32_t hi = (i0 < n ? s0 : 0u);
-    if (i1 < n && s1 > hi) hi = s1;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const uint32_t a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
       lo = a < lo ? a : lo;
       hi = b > hi ? b : hi;
     }
-    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
-    __syncthreads();
-    lo = red[0]; hi = red[4];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) { lo = red[w] < lo ? red[w] : lo; hi = red[4 + w] > hi ? red[4 + w] : hi; }
     constexpr uint32_t PER16 = 16 / sizeof(T);            // elements per 16-byte vector
     lo &= ~(PER16 - 1);                                     // (columns are 16-byte aligned: the window starts on a vector)
     const uint32_t span = hi - lo + 1;
-    if (span <= (uint32_t)LDS_ROWS - PER16) {
-      // the covered range, as 16-byte vectors, 8 loads per thread in flight before the first LDS store (a load per loop
-      // iteration left 4 KB per CU in flight: 0.5 TB/s)
+    if (span > 128u && span <= (uint32_t)WROWS - PER16) {
+      // the covered range as 16-byte vectors, every load of the range in flight before the first LDS store
       const uint32_t nvec = (span + PER16 - 1) / PER16;
       typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
       const tw_u32x4* gsrc = (const tw_u32x4*)(src + (uint64_t)lo);
       tw_u32x4* lwin = (tw_u32x4*)win;
-      for (uint32_t v0 = tid; v0 < nvec; v0 += 256 * 8) {
-        tw_u32x4 reg[8];
+      constexpr int MAXV = (WROWS / (int)PER16 + 63) / 64;   // vectors per lane at most
+      tw_u32x4 reg[MAXV];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t v = v0 + 256 * u; if (v < nvec) reg[u] = __builtin_nontemporal_load(gsrc + v); }
+      for (int u = 0; u < MAXV; ++u) { const uint32_t v = lane + 64 * u; if (v < nvec) reg[u] = __builtin_nontemporal_load(gsrc + v); }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t v = v0 + 256 * u; if (v < nvec) lwin[v] = reg[u]; }
-      }
-      __syncthreads();
+      for (int u = 0; u < MAXV; ++u) { const uint32_t v = lane + 64 * u; if (v < nvec) lwin[v] = reg[u]; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (i0 < n) out[i0] = win[s0 - lo];
-      if (i1 < n) out[i1] = win[s1 - lo];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next chunk
     } else {
       if (i0 < n) out[i0] = src[s0];
-      if (i1 < n) out[i1] = src[s1];
     }
-    __syncthreads();
   }
 }
 
@@ -671,13 +669,13 @@ int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int6
   hipStream_t s = resolve_stream(stream);
   int grid = grid_for(ceil_div(n_sel, 4), 256, 1024);
   if (n_sel >= (1 << 16) && (elem_size == 4 || elem_size == 8 || elem_size == 16)) {
-    // large selections: the windowed kernel (falls back to a direct gather per 512 entries that are not locally dense)
-    const int64_t nchunks = ceil_div(n_sel, 512);
+    // large selections: the windowed kernel (a wave decides per 64 entries between the LDS window and a plain gather)
+    const int64_t nchunks = ceil_div(n_sel, 256);
     const int wg = (int)(nchunks < 2048 ? nchunks : 2048);
     switch (elem_size) {
-      case 4: hipLaunchKernelGGL((take_window_kernel<uint32_t, 15360>), dim3(wg), dim3(256), 0, s, (const uint32_t*)src, sel, n_sel, (uint32_t*)out); break;
-      case 8: hipLaunchKernelGGL((take_window_kernel<uint64_t, 7680>), dim3(wg), dim3(256), 0, s, (const uint64_t*)src, sel, n_sel, (uint64_t*)out); break;
-      default: hipLaunchKernelGGL((take_window_kernel<B16, 3840>), dim3(wg), dim3(256), 0, s, (const B16*)src, sel, n_sel, (B16*)out); break;
+      case 4: hipLaunchKernelGGL((take_window_kernel<uint32_t, 7680>), dim3(wg), dim3(256), 0, s, (const uint32_t*)src, sel, n_sel, (uint32_t*)out); break;
+      case 8: hipLaunchKernelGGL((take_window_kernel<uint64_t, 3840>), dim3(wg), dim3(256), 0, s, (const uint64_t*)src, sel, n_sel, (uint64_t*)out); break;
+      default: hipLaunchKernelGGL((take_window_kernel<B16, 1920>), dim3(wg), dim3(256), 0, s, (const B16*)src, sel, n_sel, (B16*)out); break;
     }
     DBHIP_LAUNCH_CHECK();
     return DBHIP_OK;
