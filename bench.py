@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-verify-full", action="store_true", help="skip the full-size CPU check of the device result")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of the timed CPU-baseline passes")
     ap.add_argument("--no-opplan", action="store_true", help="skip the generic operator-plan measurement")
+    ap.add_argument("--no-readiness", action="store_true", help="skip the SF100/8 exchange-overhead measurement (it launches q1_fused_kernel on 1/8 of the rows: "
+                    "profiles of the headline kernel are taken without it)")
     ap.add_argument("--no-q3", action="store_true", help="skip TPC-H Q3 SF100 (BASELINE configs[2])")
     ap.add_argument("--q3-sf", type=float, default=100.0)
     ap.add_argument("--no-hnsw", action="store_true", help="skip the HNSW reference-comparable mode inside the ANN measurement")
@@ -186,7 +188,7 @@ def main():
         n_groups = int(ng.item())
 
     readiness = None
-    if world == 1 and rank == 0 and n_total >= 8 * (1 << 20):
+    if world == 1 and rank == 0 and n_total >= 8 * (1 << 20) and not args.no_readiness:
         readiness = bench_exchange_overhead(li, n_total // 8 & ~3, tpch, D, L, check, args.steps)
 
     opplan = None
