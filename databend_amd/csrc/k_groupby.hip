@@ -56,6 +56,7 @@ struct dbhip_groupby {
   uint64_t* partial; size_t partial_cap;   // per-workgroup partial rows
   int fast_disabled;                       // set once most rows of a chunk spilled (high NDV)
   int fast_trusted;                        // last chunk spilled < 1 %: no more probing chunks
+  int lds_big;                             // small layouts whose groups outgrew the 48 KB table but fit a 96 KB one (1024-thread workgroups)
   // radix-partitioned pre-aggregation (medium cardinality)
   int part_bits;                           // 0 = undecided, > 0 = log2(partitions), < 0 = not worth it (row path)
   int part_forbidden;                      // test hook: never choose the partitioned path
@@ -1283,19 +1284,19 @@ struct FkArgs {
   uint64_t* ctrl;          // [5] = #partial rows, [6] = #spill rows, [3] error bits
 };
 
-template <int KW, int NA, bool HI, int R>
-__global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C, FkArgs A) {
+template <int KW, int NA, bool HI, int R, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void gb_lds_preagg_kernel(GbLayout L, GbCols C, FkArgs A) {
   extern __shared__ uint64_t fk_lds[];
   __shared__ uint32_t lcount;
   uint64_t* lhash = fk_lds;
   uint64_t* lrows = fk_lds + A.lcap;
   const int tid = threadIdx.x;
   const uint32_t lmask = (uint32_t)A.lcap - 1;
-  for (int s = tid; s < A.lcap; s += 256) lhash[s] = 0;
+  for (int s = tid; s < A.lcap; s += THREADS) lhash[s] = 0;
   if (tid == 0) lcount = 0;
   __syncthreads();
 
-  const int64_t tile_rows = 256 * R;
+  const int64_t tile_rows = THREADS * R;
   const int64_t t_begin = (int64_t)blockIdx.x * A.tiles_per_block;
   const int64_t ntiles = (A.n + tile_rows - 1) / tile_rows;
   int64_t t_end = t_begin + A.tiles_per_block;
@@ -1309,7 +1310,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
       int64_t row[R];
 #pragma unroll
       for (int x = 0; x < R; ++x) {
-        const int64_t li = t * tile_rows + x * 256 + tid;
+        const int64_t li = t * tile_rows + x * THREADS + tid;
         row[x] = A.row0 + (li < A.n ? li : 0);
       }
       fk_load_n<KW, NA, HI, R>(L, C, row, r, A.ctrl);
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
     // ---- phase A: match-or-claim by hash ----
 #pragma unroll
     for (int x = 0; x < R; ++x) {
-      const int64_t li = t * tile_rows + x * 256 + tid;
+      const int64_t li = t * tile_rows + x * THREADS + tid;
       slot[x] = FK_SPILL;
       if (li < A.n && gb_row_passes(C, A.row0 + li)) {
         const uint64_t hw = probe_word(r[x].h, A.hash_mask);
@@ -1402,7 +1403,7 @@ __global__ __launch_bounds__(256) void gb_lds_preagg_kernel(GbLayout L, GbCols C
   }
   __syncthreads();
   // ---- flush the workgroup's partial rows (one cursor atomic per wave, not per row) ----
-  for (int s = tid; s < A.lcap; s += 256) {  // lcap is a multiple of 256: the loop is wave-uniform
+  for (int s = tid; s < A.lcap; s += THREADS) {  // lcap is a multiple of THREADS: the loop is wave-uniform
     const bool occ = lhash[s] != 0;
     const uint64_t m = __ballot(occ);
     unsigned long long base = 0;
@@ -1546,11 +1547,19 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     else if (g->fast_trusted) limit = n;
     const bool small = small_layout && !probing;
     static const int small_r = getenv("DBHIP_LDS_R") ? atoi(getenv("DBHIP_LDS_R")) : 4;   // 4 (116 VGPRs, 4 waves / SIMD) or 8 (178, 2): r02n 1.00 vs 1.68 ms at 4 groups
-    const int R = small ? (small_r == 4 ? 4 : 8) : 2;
-    const int64_t tile_rows = 256 * R;
+    // BIG table (r03): a small layout whose groups outgrew the 48 KB table (768 groups of 4 words) but fit one twice the size
+    // runs ONE 1024-thread workgroup per CU on a 96 KB table (the same 4 waves per SIMD) instead of going through the
+    // partitioning passes — 1000 groups: 1.97 ms partitioned, see DESIGN §2.3
+    const bool big = small && g->lds_big;
+    const int R = small ? ((small_r == 4 || big) ? 4 : 8) : 2;
+    const int threads = big ? 1024 : 256;
+    const int lcap_i = big ? lcap * 2 : lcap;
+    const size_t lds_i = big ? lds_bytes * 2 : lds_bytes;
+    const int max_grid_i = big ? 256 : max_grid;
+    const int64_t tile_rows = (int64_t)threads * R;
     const int64_t cn = n - *done < limit ? n - *done : limit;
     const int64_t ntiles = ceil_div(cn, tile_rows);
-    int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    int grid = (int)(ntiles < max_grid_i ? ntiles : max_grid_i);
     if (!g->fast_trusted && ntiles >= 64) {
       // probing chunk: >= 4 (8) tiles per workgroup, so that its spill ratio measures the key distribution and
       // not the tile size (one tile per workgroup pre-aggregates nothing once groups ~ rows per tile)
@@ -1559,7 +1568,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     }
     const int64_t tpb = ceil_div(ntiles, grid);
     grid = (int)ceil_div(ntiles, tpb);
-    if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * lcap * L.W * 8))) return rc;
+    if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)grid * lcap_i * L.W * 8))) return rc;
     // spill buffer: worst case (every row) for probing chunks; a trusted chunk spilled < 1 % last time, so 1/64 of its rows
     // (at least 4 M) is ample — and a 600 M-row block does not allocate a 72 GB buffer it never touches. Overflow is
     // detected (ctrl[3] bit 2) and the chunk redone.
@@ -1569,10 +1578,17 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
     FkArgs A;
     A.spill_cap = (uint64_t)spill_cap;
-    A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap; A.sw = sw;
-    A.llimit = (uint32_t)(lcap - lcap / 4);
+    A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap_i; A.sw = sw;
+    A.llimit = (uint32_t)(lcap_i - lcap_i / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
-    if (small && R == 4) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 4>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
+    if (big) {
+      static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process
+      if (!attr_set) {
+        DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_lds_preagg_kernel<2, 2, false, 4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 4, 1024>), dim3(grid), dim3(1024), lds_i, s, L, C, A);
+    } else if (small && R == 4) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 4>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     else if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     else hipLaunchKernelGGL((gb_lds_preagg_kernel<FK_MAXKW, FK_MAXA, true, 2>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     DBHIP_LAUNCH_CHECK();
@@ -1602,6 +1618,16 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // more groups than a workgroup's table takes (it would run full everywhere and hand most rows on)
     const bool too_many = g->count_host * 8 > (int64_t)A.llimit * 7;
     if (((int64_t)hc[6] * 10 > cn || too_many) && cn >= 65536) {
+      // twice the table is enough (estimated from the groups met so far): stay on the LDS path with the big table
+      const int64_t big_limit = (int64_t)(lcap * 2 - lcap / 2) * 7 / 8;
+      static const bool big_off = getenv("DBHIP_LDS_BIG") && atoi(getenv("DBHIP_LDS_BIG")) == 0;
+      if (small_layout && !g->lds_big && !big_off && lds_bytes * 2 <= 128 * 1024 && estimate_groups(g->count_host, g->rows_seen) <= big_limit) {
+        g->lds_big = 1;
+        g->fast_trusted = 1;
+        if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in %lld rows -> the 96 KB LDS table\n", (long long)g->count_host, (long long)g->rows_seen);
+        continue;
+      }
+      g->lds_big = 0;
       decide_partitioning(g, g->count_host, g->rows_seen, n);
       if (g->part_bits < 0) g->fast_disabled = 1;
     }
@@ -3162,6 +3188,7 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->has_long = 0;
   g->fast_disabled = 0;
   g->fast_trusted = 0;
+  g->lds_big = 0;
   g->fagg_disabled = 0;
   if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
   g->rows_seen = 0;
