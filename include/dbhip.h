@@ -362,7 +362,11 @@ typedef struct dbhip_groupby dbhip_groupby;  /* opaque */
  * are copied into the table's ARENA (a device bump allocator, the analogue of the Payload's arena: the row holds
  * `(len, prefix, offset)` where the reference holds `(len, ptr)`, payload.rs:361-486, payload_row.rs:85-215) and compared by
  * length, prefix and bytes (row_match_entries, payload_row.rs:324+). A block with long string keys is aggregated on the row
- * path (the LDS / partitioned pre-aggregation kernels hand it over). */
+ * path (the LDS / partitioned pre-aggregation kernels hand it over).
+ * `initial_capacity`: slots to start with (the table grows), and the caller's ESTIMATE of the number of groups (the
+ * reference sizes its tables from the planner's cardinality estimate the same way): a first block of >= 1 M rows with at most
+ * twice as many rows as this estimate is taken as "about one group per row" and skips pre-aggregation (a join's output grouped
+ * by the join key). Any value is correct; only the path differs. */
 int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_nullable_host,
                              int32_t nkeys, const dbhip_agg_desc* aggs_host, int32_t naggs,
                              int64_t initial_capacity, dbhip_groupby** out_host);

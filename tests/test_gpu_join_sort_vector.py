@@ -589,3 +589,46 @@ def test_right_and_full_join_kinds_over_two_probe_blocks(gpu, kind):
         exp += [(None, int(bpay[b])) for b in np.nonzero(matched_b)[0]]
     assert sorted(got, key=repr) == sorted(exp, key=repr) and len(tail) == (int(matched_b.sum()) if kind == "right_semi" else int((~matched_b).sum()))
     assert 0 < matched_b.sum() < nb
+
+
+@pytest.mark.parametrize("shape", ["clustered", "random", "dense"])
+def test_inner_join_on_sliced_key_columns_and_clustered_keys(gpu, oracle, shape):
+    """r03 probe: (1) a probe key column that starts 8 bytes off a 16-byte boundary (a sliced, borrowed column) takes the plain
+    kernel for every tile, a 16-byte aligned one the pipelined kernel plus the plain kernel for the ragged last tile — same pairs;
+    (2) keys stored in key order (runs of consecutive buckets), random keys and a dense 0..n range, against the oracle; the build
+    side is large enough (> 2^19 rows) for the occupancy bitmap."""
+    rng = np.random.default_rng(91)
+    nb, np_ = 600_000, 1_000_003
+    if shape == "clustered":     # dbgen-like sparse order keys, several probe rows per key, probe side sorted by key
+        bk = ((np.arange(nb, dtype=np.uint64) // 8) * 32 + np.arange(nb, dtype=np.uint64) % 8 + 1)[rng.random(nb) < 0.4]
+        pk = np.sort(rng.integers(1, int(nb // 8 * 32 + 9), np_).astype(np.uint64))
+    elif shape == "random":
+        bk = rng.integers(0, 1 << 62, nb).astype(np.uint64)
+        pk = np.concatenate([rng.choice(bk, np_ // 3), rng.integers(0, 1 << 62, np_ - np_ // 3).astype(np.uint64)])
+        rng.shuffle(pk)
+    else:
+        bk = rng.permutation(nb).astype(np.uint64)
+        pk = rng.integers(0, 2 * nb, np_).astype(np.uint64)
+    nb = len(bk)
+    pvalid = rng.integers(0, 7, np_) > 0
+    j = gpu.HashJoin(nb)
+    j.add_block(gpu.Column.from_numpy(bk))
+    j.final_build()
+    cap = int(np_ * 1.2) + 16
+    ep, eb = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    bv = np.full((nb + 7) // 8 + 8, 0xFF, np.uint8)
+    pv = np.concatenate([np.packbits(pvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    total = oracle.orc_join_inner_u64(bk.ctypes.data_as(C.c_void_p), bv.ctypes.data_as(C.c_void_p), C.c_int64(nb), pk.ctypes.data_as(C.c_void_p),
+                                      pv.ctypes.data_as(C.c_void_p), C.c_int64(np_), ep.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+    assert 0 < total <= cap
+    gp, gb = j.probe_block(gpu.Column.from_numpy(pk, validity=pvalid))
+    assert len(gp) == total and np.array_equal(gp, ep[:total]) and np.array_equal(gb, eb[:total])
+    # the same keys 8 bytes into a buffer: data pointer = base + 8 (validity bits stay at offset 0)
+    shifted = gpu.DeviceBuffer.from_numpy(np.concatenate([np.zeros(1, np.uint64), pk]))
+
+    class Off:   # a borrowed view of `shifted` one element in
+        ptr, nbytes = shifted.ptr + 8, pk.nbytes
+    sliced = gpu.Column(T.T_U64, np_, Off, validity=gpu.DeviceBuffer.from_numpy(gpu.pack_bits(pvalid)))
+    assert Off.ptr % 16 == 8
+    sp, sb = j.probe_block(sliced)
+    assert np.array_equal(sp, gp) and np.array_equal(sb, gb)
