@@ -10,6 +10,8 @@
 #include "dev_load.h"
 #include "runtime.h"
 
+#include <string.h>
+
 #include <vector>
 
 using namespace dbhip;
@@ -466,6 +468,51 @@ __global__ __launch_bounds__(256) void take_chunks_bitmap_kernel(const uint8_t* 
 //   span <= 128 rows (at least half of the rows are wanted): a plain gather is already coalesced;
 //   span <= LDS_ROWS / 4: staged through the wave's quarter of the LDS window;
 //   else (sparse or unordered): a plain gather. Any selection is handled; the decision is per 64 entries.
+// one wave, one column, 64 entries (s0 = this lane's entry, [lo, hi] = the range the 64 entries span): through the wave's LDS
+// window `win` (WROWS elements) when the entries are neither dense nor sparse, else a plain gather
+template <typename T, int WROWS>
+__device__ __forceinline__ void take_wave_step(const T* __restrict__ src, T* __restrict__ out, T* win, uint32_t s0, uint32_t lo, uint32_t hi,
+                                               int64_t i0, int64_t n, int lane) {
+  constexpr uint32_t PER16 = 16 / sizeof(T);            // elements per 16-byte vector
+  lo &= ~(PER16 - 1);                                     // (columns are 16-byte aligned: the window starts on a vector)
+  const uint32_t span = hi - lo + 1;
+  if (span > 128u && span <= (uint32_t)WROWS - PER16) {
+    // the covered range as 16-byte vectors, every load of the range in flight before the first LDS store
+    const uint32_t nvec = (span + PER16 - 1) / PER16;
+    typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
+    const tw_u32x4* gsrc = (const tw_u32x4*)(src + (uint64_t)lo);
+    tw_u32x4* lwin = (tw_u32x4*)win;
+    constexpr int MAXV = (WROWS / (int)PER16 + 63) / 64;   // vectors per lane at most
+    tw_u32x4 reg[MAXV];
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) { const uint32_t v = lane + 64 * u; if (v < nvec) reg[u] = __builtin_nontemporal_load(gsrc + v); }
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) { const uint32_t v = lane + 64 * u; if (v < nvec) lwin[v] = reg[u]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i0 < n) out[i0] = win[s0 - lo];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next step
+  } else {
+    if (i0 < n) out[i0] = src[s0];
+  }
+}
+// this lane's entry of chunk c and the range [lo, hi] of the wave's 64 entries
+__device__ __forceinline__ uint32_t take_wave_range(const uint32_t* __restrict__ sel, int64_t i0, int64_t n, uint32_t* lo_out, uint32_t* hi_out) {
+  const uint32_t s0 = i0 < n ? sel[i0] : 0xFFFFFFFFu;
+  uint32_t lo = s0;
+  uint32_t hi = (i0 < n ? s0 : 0u);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  *lo_out = lo; *hi_out = hi;
+  return s0;
+}
+
 template <typename T, int LDS_ROWS>
 __global__ __launch_bounds__(256) void take_window_kernel(const T* __restrict__ src, const uint32_t* __restrict__ sel, int64_t n, T* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) T win_all[LDS_ROWS];
@@ -475,38 +522,39 @@ __global__ __launch_bounds__(256) void take_window_kernel(const T* __restrict__ 
   const int64_t nchunks = (n + 63) / 64;
   for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < nchunks; c += (int64_t)gridDim.x * 4) {
     const int64_t i0 = c * 64 + lane;
-    const uint32_t s0 = i0 < n ? sel[i0] : 0xFFFFFFFFu;
-    uint32_t lo = s0;
-    uint32_t hi = (i0 < n ? s0 : 0u);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const uint32_t a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
-      lo = a < lo ? a : lo;
-      hi = b > hi ? b : hi;
-    }
-    constexpr uint32_t PER16 = 16 / sizeof(T);            // elements per 16-byte vector
-    lo &= ~(PER16 - 1);                                     // (columns are 16-byte aligned: the window starts on a vector)
-    const uint32_t span = hi - lo + 1;
-    if (span > 128u && span <= (uint32_t)WROWS - PER16) {
-      // the covered range as 16-byte vectors, every load of the range in flight before the first LDS store
-      const uint32_t nvec = (span + PER16 - 1) / PER16;
-      typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
-      const tw_u32x4* gsrc = (const tw_u32x4*)(src + (uint64_t)lo);
-      tw_u32x4* lwin = (tw_u32x4*)win;
-      constexpr int MAXV = (WROWS / (int)PER16 + 63) / 64;   // vectors per lane at most
-      tw_u32x4 reg[MAXV];
-#pragma unroll
-      for (int u = 0; u < MAXV; ++u) { const uint32_t v = lane + 64 * u; if (v < nvec) reg[u] = __builtin_nontemporal_load(gsrc + v); }
-#pragma unroll
-      for (int u = 0; u < MAXV; ++u) { const uint32_t v = lane + 64 * u; if (v < nvec) lwin[v] = reg[u]; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (i0 < n) out[i0] = win[s0 - lo];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next chunk
-    } else {
-      if (i0 < n) out[i0] = src[s0];
+    uint32_t lo, hi;
+    const uint32_t s0 = take_wave_range(sel, i0, n, &lo, &hi);
+    take_wave_step<T, WROWS>(src, out, win, s0, lo, hi, i0, n, lane);
+  }
+}
+
+// DataBlock::take over SEVERAL columns of a block with one selection (kernels/take.rs:43 takes every column of the block):
+// the selection is read once, its range found once per 64 entries, and the columns go through the same wave-private window
+// one after the other (r03: the eight takes behind Q3's two probes were eight launches that each re-read the pair list)
+constexpr int TAKE_MAX_COLS = 8;
+struct TakeCols {
+  const void* src[TAKE_MAX_COLS];
+  void* out[TAKE_MAX_COLS];
+  int elem[TAKE_MAX_COLS];
+  int n;
+};
+__global__ __launch_bounds__(256) void take_block_kernel(TakeCols P, const uint32_t* __restrict__ sel, int64_t n) {
+  __shared__ __attribute__((aligned(16))) uint8_t win_bytes[30720];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* win = win_bytes + wave * 7680;
+  const int64_t nchunks = (n + 63) / 64;
+  for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < nchunks; c += (int64_t)gridDim.x * 4) {
+    const int64_t i0 = c * 64 + lane;
+    uint32_t lo, hi;
+    const uint32_t s0 = take_wave_range(sel, i0, n, &lo, &hi);
+    for (int k = 0; k < P.n; ++k) {   // (uniform)
+      switch (P.elem[k]) {
+        case 4: take_wave_step<uint32_t, 1920>((const uint32_t*)P.src[k], (uint32_t*)P.out[k], (uint32_t*)win, s0, lo, hi, i0, n, lane); break;
+        case 8: take_wave_step<uint64_t, 960>((const uint64_t*)P.src[k], (uint64_t*)P.out[k], (uint64_t*)win, s0, lo, hi, i0, n, lane); break;
+        case 16: take_wave_step<B16, 480>((const B16*)P.src[k], (B16*)P.out[k], (B16*)win, s0, lo, hi, i0, n, lane); break;
+        case 2: if (i0 < n) ((uint16_t*)P.out[k])[i0] = ((const uint16_t*)P.src[k])[s0]; break;
+        default: if (i0 < n) ((uint8_t*)P.out[k])[i0] = ((const uint8_t*)P.src[k])[s0]; break;
+      }
     }
   }
 }
@@ -690,6 +738,29 @@ int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int6
       set_error("dbhip_take: unsupported element size %d", elem_size);
       return DBHIP_ERR_INVALID;
   }
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_take_block(const void* const* srcs_host, const int32_t* elem_sizes_host, int32_t ncols, const uint32_t* sel, int64_t n_sel,
+                         void* const* outs_host, void* stream) {
+  DBHIP_REQUIRE(ncols >= 0 && ncols <= TAKE_MAX_COLS && (ncols == 0 || (srcs_host && elem_sizes_host && outs_host)), "dbhip_take_block: 0..8 columns");
+  if (n_sel == 0 || ncols == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(sel, "dbhip_take_block: NULL selection");
+  TakeCols P;
+  memset(&P, 0, sizeof(P));
+  P.n = ncols;
+  for (int k = 0; k < ncols; ++k) {
+    const int e = elem_sizes_host[k];
+    if (!(e == 1 || e == 2 || e == 4 || e == 8 || e == 16) || !srcs_host[k] || !outs_host[k]) {
+      set_error("dbhip_take_block: column %d: element size %d / NULL buffer", k, e);
+      return DBHIP_ERR_INVALID;
+    }
+    P.src[k] = srcs_host[k]; P.out[k] = outs_host[k]; P.elem[k] = e;
+  }
+  hipStream_t s = resolve_stream(stream);
+  const int64_t nchunks = ceil_div(n_sel, 256);
+  hipLaunchKernelGGL(take_block_kernel, dim3((unsigned)(nchunks < 2048 ? nchunks : 2048)), dim3(256), 0, s, P, sel, n_sel);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }

@@ -836,3 +836,40 @@ def test_div0_and_divnull(gpu):
     assert np.array_equal(r1.to_numpy(), exp)
     # rows with a zero divisor AND valid inputs become NULL (NULL inputs stay NULL through the operands' validity)
     assert np.array_equal(e1.error_rows(), np.nonzero((b == 0) & va)[0]) and e1.num_errors() == int(((b == 0) & va).sum())
+
+
+@pytest.mark.parametrize("density", ["dense", "tenth", "sparse", "unordered"])
+def test_take_block_equals_column_by_column_take(gpu, density):
+    """dbhip_take_block (DataBlock::take over several columns with ONE selection, one launch) against numpy indexing, for the
+    shapes its per-wave decision distinguishes: >= half of the rows wanted (plain gather), ~10 % (LDS window), < 1 % and an
+    unordered selection (plain gather again); every element size, a Boolean column and a nullable one."""
+    D = gpu
+    rng = np.random.default_rng(17)
+    n = 700_003
+    if density == "dense":
+        sel = np.nonzero(rng.random(n) < 0.97)[0]
+    elif density == "tenth":
+        sel = np.nonzero(rng.random(n) < 0.1)[0]
+    elif density == "sparse":
+        sel = np.nonzero(rng.random(n) < 0.004)[0]
+    else:
+        sel = rng.integers(0, n, 90_001)
+    sel = sel.astype(np.uint32)
+    k = len(sel)
+    cols_np = [rng.integers(-2**62, 2**62, n).astype(np.int64), rng.integers(0, 2**31, n).astype(np.int32), rng.integers(0, 255, n).astype(np.uint8),
+               rng.integers(0, 2**15, n).astype(np.int16), rng.random(n), rng.integers(0, 2, n).astype(bool)]
+    valid = rng.integers(0, 5, n) > 0
+    cols = [D.Column.from_numpy(c) for c in cols_np[:5]] + [D.Column(T.T_BOOL, n, D.DeviceBuffer.from_numpy(D.pack_bits(cols_np[5])))]
+    cols[0] = D.Column.from_numpy(cols_np[0], validity=valid)
+    dec = D.Column.from_numpy(np.stack([cols_np[0].view(np.uint64), cols_np[0].view(np.uint64) >> np.uint64(3)], axis=1).reshape(-1), dtype=T.T_DEC128, precision=38, scale=2)
+    dec.n = n
+    dsel = D.DeviceBuffer.from_numpy(sel)
+    out = D.take_block(cols + [dec], dsel, k)
+    for c, o in zip(cols_np[:5], out[:5]):
+        assert np.array_equal(o.to_numpy()[:k], c[sel])
+    assert np.array_equal(D.unpack_bits(out[0].validity.to_numpy(np.uint8), k), valid[sel])
+    assert np.array_equal(D.unpack_bits(out[5].data.to_numpy(np.uint8), k), cols_np[5][sel])
+    got = out[6].data.to_numpy(np.uint64, 2 * k).reshape(k, 2)
+    assert np.array_equal(got[:, 0], cols_np[0].view(np.uint64)[sel]) and np.array_equal(got[:, 1], (cols_np[0].view(np.uint64) >> np.uint64(3))[sel])
+    # and the single-column entry point gives the same values
+    assert np.array_equal(D.take(cols[1], dsel, k).to_numpy()[:k], cols_np[1][sel])
