@@ -184,14 +184,17 @@ struct SP { uint32_t idx; float score; };
 
 struct WaveLds {
   SP nearest[HN_MAX_EF];       // FixedLengthPriorityQueue = BinaryHeap<Reverse<SP>>
-  SP cand[HN_CCAP];            // BinaryHeap<SP>
   uint32_t qcodes[HN_MAX_ADIM / 4];
   int nn, nc, ef;
   float qoff;
   SP cur;
-  int flag;
+  int flag;                    // bit 0: candidate heap full, bit 1: visited table full (bits 2, 3: the same in the small-search kernel)
   uint32_t vis_count;
+  int ccap;                    // capacity of `cand` in THIS kernel
+  SP cand[HN_CCAP];            // BinaryHeap<SP> — LAST: the small-search kernel allocates the struct with a shorter heap
 };
+constexpr int HN_SMALL_CCAP = 1024;   // small search (ef <= 64): candidate heap and LDS-resident visited table
+constexpr int HN_SMALL_VCAP = 2048;
 
 __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
 // lane 0 writes queue state in LDS, every lane reads it afterwards: order the accesses for the compiler (the LDS unit serves
@@ -337,37 +340,53 @@ __device__ void process_candidate(WaveLds* W, SP sp) {
   const bool full = flpq_push(W->nearest, &W->nn, W->ef, sp, &removed);
   const bool was_added = !full || removed.idx != sp.idx;
   if (was_added) {
-    if (W->nc >= HN_CCAP) { W->flag |= 1; return; }
+    if (W->nc >= W->ccap) { W->flag |= 1; return; }
     heap_push(W->cand, &W->nc, sp);
   }
 }
 
-// ---- visited table: open addressing in global memory, written by lane 0 only, read by every lane ----
+// ---- visited table: open addressing, written by lane 0 only, read by every lane. VCAP = HN_VCAP: in global memory (the build and
+// searches with ef > 64); VCAP = HN_SMALL_VCAP: in LDS (r03: a visited check is on the critical path of every step of the walk —
+// one global round trip per step — and clearing 64 KB of global memory per query with scalar sc1 stores is not free either) ----
+typedef volatile __attribute__((address_space(3))) uint32_t* HnLdsU32;
 __device__ __forceinline__ uint32_t vis_hash(uint32_t id) { return (id * 2654435761u) >> 7; }
+template <int VCAP>
+__device__ __forceinline__ uint32_t vis_ld(const uint32_t* vis, uint32_t h) {
+  if (VCAP == HN_SMALL_VCAP) return ((HnLdsU32)(uint32_t*)vis)[h];
+  return __hip_atomic_load(&vis[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int VCAP>
+__device__ __forceinline__ void vis_st(uint32_t* vis, uint32_t h, uint32_t v) {
+  if (VCAP == HN_SMALL_VCAP) ((HnLdsU32)vis)[h] = v;
+  else __hip_atomic_store(&vis[h], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int VCAP>
 __device__ __forceinline__ bool vis_check(const uint32_t* vis, uint32_t id) {
-  uint32_t h = vis_hash(id) & (HN_VCAP - 1);
-  for (int step = 0; step < HN_VCAP; ++step) {
-    const uint32_t x = __hip_atomic_load(&vis[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t h = vis_hash(id) & (VCAP - 1);
+  for (int step = 0; step < VCAP; ++step) {
+    const uint32_t x = vis_ld<VCAP>(vis, h);
     if (x == id + 1) return true;
     if (x == 0) return false;
-    h = (h + 1) & (HN_VCAP - 1);
+    h = (h + 1) & (VCAP - 1);
   }
   return false;
 }
+template <int VCAP>
 __device__ void vis_insert(uint32_t* vis, WaveLds* W, uint32_t id) {   // lane 0
-  if (W->vis_count >= HN_VCAP / 2) { W->flag |= 2; return; }
-  uint32_t h = vis_hash(id) & (HN_VCAP - 1);
+  if (W->vis_count >= (VCAP == HN_SMALL_VCAP ? VCAP * 3 / 4 : VCAP / 2)) { W->flag |= 2; return; }
+  uint32_t h = vis_hash(id) & (VCAP - 1);
   for (;;) {
-    const uint32_t x = __hip_atomic_load(&vis[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t x = vis_ld<VCAP>(vis, h);
     if (x == id + 1) return;
     if (x == 0) break;
-    h = (h + 1) & (HN_VCAP - 1);
+    h = (h + 1) & (VCAP - 1);
   }
-  __hip_atomic_store(&vis[h], id + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  vis_st<VCAP>(vis, h, id + 1);
   ++W->vis_count;
 }
+template <int VCAP>
 __device__ void vis_clear(uint32_t* vis) {
-  for (int i = lane(); i < HN_VCAP; i += 64) __hip_atomic_store(&vis[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = lane(); i < VCAP; i += 64) vis_st<VCAP>(vis, i, 0u);
 }
 
 // ---- link lists (atomic loads / stores: they change while other waves read them during a build) ----
@@ -481,7 +500,7 @@ __device__ __forceinline__ int nth_set(uint64_t m, int k) {
 
 // _search_on_level (graph_layers.rs:72-108). QUANT: quantised scorer over the finished graph; else the build's scorer over
 // the ready points (graph_layers_builder.rs:77-87)
-template <bool QUANT>
+template <bool QUANT, int VCAP = HN_VCAP>
 __device__ void search_on_level(const HnswView& H, WaveLds* W, uint32_t* vis, uint32_t self, int level) {
   const int l = lane();
   for (;;) {
@@ -503,7 +522,7 @@ __device__ void search_on_level(const HnswView& H, WaveLds* W, uint32_t* vis, ui
     bool ok = false;
     if (l < cnt) {
       id = ld32(links + l);
-      ok = id < (uint32_t)H.n && (QUANT || ld32(H.ready + id) != 0) && !vis_check(vis, id);
+      ok = id < (uint32_t)H.n && (QUANT || ld32(H.ready + id) != 0) && !vis_check<VCAP>(vis, id);
     }
     const uint64_t mask = __ballot(ok);
     const int np = __popcll(mask);
@@ -519,7 +538,7 @@ __device__ void search_on_level(const HnswView& H, WaveLds* W, uint32_t* vis, ui
         for (int j = 0; j < c4; ++j) {
           const SP sp = {ids[j], sc[j]};
           process_candidate(W, sp);
-          vis_insert(vis, W, ids[j]);
+          vis_insert<VCAP>(vis, W, ids[j]);
         }
       }
       WAVE_SYNC();
@@ -617,10 +636,17 @@ __device__ void wave_encode_query(const HnswView& H, WaveLds* W, const float* q)
   WAVE_SYNC();
 }
 
+// SMALL (ef <= 64): the candidate heap holds HN_SMALL_CCAP entries and the visited table lives in LDS (HN_SMALL_VCAP slots) — the
+// same LDS footprint per wave as the general kernel, whose visited table is in global memory. A walk that outgrows either sets
+// flag bits 2 / 3 (instead of 0 / 1) and the host runs the whole batch again through the general kernel.
+template <bool SMALL>
 __global__ __launch_bounds__(64) void hn_search_kernel(HnswView H, SearchArgs A) {
-  __shared__ WaveLds Wm;
-  WaveLds* W = &Wm;
-  uint32_t* vis = A.vis + (size_t)blockIdx.x * HN_VCAP;
+  constexpr int VCAP = SMALL ? HN_SMALL_VCAP : HN_VCAP;
+  constexpr int CCAP = SMALL ? HN_SMALL_CCAP : HN_CCAP;
+  __shared__ __attribute__((aligned(16))) uint8_t wraw[offsetof(WaveLds, cand) + sizeof(SP) * CCAP];
+  __shared__ uint32_t lvis[SMALL ? HN_SMALL_VCAP : 1];
+  WaveLds* W = (WaveLds*)wraw;
+  uint32_t* vis = SMALL ? lvis : A.vis + (size_t)blockIdx.x * HN_VCAP;
   const int l = lane();
   const unsigned long long ent = *H.entry;
   for (;;) {
@@ -636,22 +662,22 @@ __global__ __launch_bounds__(64) void hn_search_kernel(HnswView H, SearchArgs A)
     }
     const uint32_t entry = ~(uint32_t)(ent & 0xFFFFFFFFu);
     const int entry_level = (int)(ent >> 32) - 1;
-    vis_clear(vis);
-    if (l == 0) { W->nn = 0; W->nc = 0; W->flag = 0; W->vis_count = 0; W->ef = A.limit * 4 > A.limit ? A.limit * 4 : A.limit; }
+    vis_clear<VCAP>(vis);
+    if (l == 0) { W->nn = 0; W->nc = 0; W->flag = 0; W->vis_count = 0; W->ccap = CCAP; W->ef = A.limit * 4 > A.limit ? A.limit * 4 : A.limit; }
     WAVE_SYNC();
     wave_encode_query(H, W, A.queries + (size_t)qi * H.dim);
     const SP zero = search_entry<true>(H, W, 0, entry, entry_level, 0);
     if (l == 0) {
-      vis_insert(vis, W, zero.idx);
+      vis_insert<VCAP>(vis, W, zero.idx);
       SP dummy;
       flpq_push(W->nearest, &W->nn, W->ef, zero, &dummy);   // SearchContext::new
       heap_push(W->cand, &W->nc, zero);
     }
     WAVE_SYNC();
-    search_on_level<true>(H, W, vis, 0, 0);
+    search_on_level<true, VCAP>(H, W, vis, 0, 0);
     if (l == 0) {
       flpq_into_sorted(W->nearest, W->nn);
-      if (W->flag) atomicOr(A.err, (unsigned)W->flag);
+      if (W->flag) atomicOr(A.err, (unsigned)(SMALL ? W->flag << 2 : W->flag));
     }
     WAVE_SYNC();
     const int nn = ((volatile WaveLds*)W)->nn;
@@ -738,7 +764,7 @@ __device__ void link_point(const HnswView& H, BuildLds* B, uint32_t* vis, const 
   if (ent != 0) {
     const uint32_t entry = ~(uint32_t)(ent & 0xFFFFFFFFu);
     const int entry_level = (int)(ent >> 32) - 1;
-    if (l == 0) { W->flag = 0; W->ef = A.ef_construct; }
+    if (l == 0) { W->flag = 0; W->ef = A.ef_construct; W->ccap = HN_CCAP; }
     WAVE_SYNC();
     SP level_entry;
     if (entry_level > level) level_entry = search_entry<false>(H, W, p, entry, entry_level, level);
@@ -752,10 +778,10 @@ __device__ void link_point(const HnswView& H, BuildLds* B, uint32_t* vis, const 
     const int linking_level = level < entry_level ? level : entry_level;
     for (int cl = linking_level; cl >= 0; --cl) {
       // link_new_point_on_level (:418-462)
-      vis_clear(vis);
+      vis_clear<HN_VCAP>(vis);
       if (l == 0) {
         W->nn = 0; W->nc = 0; W->vis_count = 0;
-        vis_insert(vis, W, level_entry.idx);
+        vis_insert<HN_VCAP>(vis, W, level_entry.idx);
         SP dummy;
         flpq_push(W->nearest, &W->nn, W->ef, level_entry, &dummy);
         heap_push(W->cand, &W->nc, level_entry);
@@ -1197,13 +1223,23 @@ int32_t dbhip_hnsw_search(dbhip_hnsw* hh, const float* queries_dev, int32_t nq, 
   SearchArgs A;
   A.queries = queries_dev; A.nq = nq; A.limit = limit; A.out_ids = out_ids_dev; A.out_dist = out_dist_dev; A.vis = vis;
   A.next = ctl; A.err = ctl + 1;
+  static const bool small_off = getenv("DBHIP_HNSW_SMALL") && atoi(getenv("DBHIP_HNSW_SMALL")) == 0;
+  const bool small = limit * 4 <= 64 && !small_off;
+  unsigned int hc[2];
   kernel_timer_start(s);
-  hipLaunchKernelGGL(hn_search_kernel, dim3(grid), dim3(64), 0, s, h->v, A);
+  if (small) hipLaunchKernelGGL(hn_search_kernel<true>, dim3(grid), dim3(64), 0, s, h->v, A);
+  else hipLaunchKernelGGL(hn_search_kernel<false>, dim3(grid), dim3(64), 0, s, h->v, A);
   kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
-  unsigned int hc[2];
   DBHIP_CHECK(hipMemcpyAsync(hc, ctl, 8, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
+  if (small && (hc[1] & 12u)) {   // some walk outgrew the LDS-resident tables: the whole batch again, general kernel (rare)
+    DBHIP_CHECK(hipMemsetAsync(ctl, 0, 16, s));
+    hipLaunchKernelGGL(hn_search_kernel<false>, dim3(grid), dim3(64), 0, s, h->v, A);
+    DBHIP_LAUNCH_CHECK();
+    DBHIP_CHECK(hipMemcpyAsync(hc, ctl, 8, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+  }
   if (hc[1]) {
     set_error("dbhip_hnsw_search: a walk outgrew its candidate heap / visited table (flags %u)", hc[1]);
     return DBHIP_ERR_CAPACITY;
