@@ -320,7 +320,7 @@ Q3_AGGS = [(L.AGG_SUM, L.T_DEC128, 31, 4, 0)]
 Q3_KEYS = [L.T_I64, L.T_DATE, L.T_I32]
 
 
-def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=None, bitmap_probe=True, block_take=False):
+def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=None, bitmap_probe=True, block_take=True):
     """Q3 in the reference's plan shape, one C-ABI call per operator / expression node:
 
       customer -> TransformFilter(c_mktsegment = seg) -> Join#1 build (c_custkey)
@@ -347,9 +347,8 @@ def q3_operator_at_a_time(t, segment=Q3_SEGMENT, date=Q3_DATE, limit=10, stats=N
     if bitmap_probe:
         ko = D.bitmap_count(opred, t.n_orders) if stats is not None else 0
         pp, _pb, kj = j1.probe_block_device(D.Column(t.o_custkey.dtype, t.n_orders, t.o_custkey.data, validity=opred.data))
-        # (block_take: dbhip_take_block, one launch per selection. Measured r03 on one box, SF100: 11.28 ms against 11.05 ms with one
-        # dbhip_take per column — the columns of a block go through the wave's LDS window one after the other, which costs more than
-        # the selection re-reads and launches it saves; the per-column calls stay the default)
+        # (block_take: dbhip_take_block, one launch per selection instead of one dbhip_take per column. r03, SF100, same box: 9.66 ms
+        # against 9.81 ms — the first version of the kernel, at 238 VGPRs, had lost 0.2 ms instead)
         take3 = D.take_block if block_take else (lambda cols, sel, k: [D.take(c, sel, k) for c in cols])
         b_ok, b_od, b_sp = take3([t.o_orderkey, t.o_orderdate, t.o_shippriority], pp, kj)
     else:

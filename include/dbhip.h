@@ -292,8 +292,7 @@ int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int6
                    void* out, void* stream);
 /* The same gather over up to 8 columns of one block with ONE selection (DataBlock::take takes every column of the block,
  * kernels/take.rs:43): one launch, the selection read once. elem_sizes_host[k] in {1,2,4,8,16}; Bitmap columns (bool / validity)
- * still go through dbhip_take_bitmap. (Not faster than one dbhip_take per column for wide blocks — measured on Q3, DESIGN §2.8 —
- * it saves launches, which matters for many small blocks.) */
+ * still go through dbhip_take_bitmap. */
 int32_t dbhip_take_block(const void* const* srcs_host, const int32_t* elem_sizes_host, int32_t ncols, const uint32_t* sel, int64_t n_sel,
                          void* const* outs_host, void* stream);
 /* take for Bitmap columns (bool / validity). */
