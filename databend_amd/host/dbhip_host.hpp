@@ -1168,6 +1168,135 @@ class LeftHashJoin : public Join {
   std::vector<DataBlock> chunks_;
 };
 
+// Right-outer / right-semi / right-anti / full-outer joins on one u64/i64 key, no other conjunct (memory/right_join.rs,
+// right_join_semi.rs, right_join_anti.rs, full_join.rs): every probe block emits its matched pairs (right / full; full also the
+// unmatched probe rows with a null build block, like LeftHashJoin) and ORs the build rows it reached into the table's scan map
+// (dbhip_join_mark_build); after the LAST probe block final_probe() emits the build rows the map says were matched (semi), were
+// not (anti), or were not with a NULL probe side (right / full) — the reference's `final_probe` / scan-map pass.
+enum class RightJoinKind { Outer, Semi, Anti, Full };
+class RightHashJoin : public Join {
+ public:
+  RightHashJoin(RightJoinKind kind, size_t build_key, size_t probe_key) : kind_(kind), bk_(build_key), pk_(probe_key) { check(dbhip_join_create(1024, &h_)); }
+  ~RightHashJoin() override { if (h_) dbhip_join_destroy(h_); }
+  void add_block(std::optional<DataBlock> data) override {
+    if (!data) return;
+    if (!chunks_.empty()) throw ErrorCode::Unimplemented("RightHashJoin host mirror keeps one build chunk (concat the build side first)");
+    const Column& k = data->get_by_offset(bk_);
+    check(dbhip_join_add_build(h_, (const uint64_t*)k.data->ptr(), k.validity ? (const uint8_t*)k.validity->ptr() : nullptr, k.len, nullptr));
+    chunks_.push_back(std::move(*data));
+  }
+  void final_build() override { check(dbhip_join_finalize(h_, nullptr)); }
+  std::unique_ptr<JoinStream> probe_block(DataBlock data) override {
+    const Column& k = data.get_by_offset(pk_);
+    const uint8_t* v = k.validity ? (const uint8_t*)k.validity->ptr() : nullptr;
+    const int64_t n = k.len;
+    if (probe_types_.empty()) for (const Column& c : data.columns) probe_types_.push_back(c.type);
+    uint64_t total = 0, got = 0;
+    check(dbhip_join_probe_count(h_, (const uint64_t*)k.data->ptr(), v, n, &total, nullptr));
+    Buf pi = make_buf((size_t)total * 4 + 64), bi = make_buf((size_t)total * 4 + 64);
+    check(dbhip_join_probe(h_, (const uint64_t*)k.data->ptr(), v, n, (uint32_t*)pi->ptr(), (uint32_t*)bi->ptr(), (int64_t)total, &got, nullptr));
+    check(dbhip_join_mark_build(h_, (const uint32_t*)bi->ptr(), (int64_t)got, nullptr));
+    if (kind_ == RightJoinKind::Semi || kind_ == RightJoinKind::Anti) return std::make_unique<Once>(std::nullopt);   // everything comes from final_probe
+    // matched pairs: probe columns become Nullable with a true validity (the probe side is the nullable one of a right join)
+    DataBlock out = take_block(data, pi, (int64_t)got);
+    for (Column& c : out.columns) wrap_true_validity(c);
+    DataBlock b = chunks_.empty() ? DataBlock() : take_block(chunks_[0], bi, (int64_t)got);
+    if (kind_ == RightJoinKind::Full) for (Column& c : b.columns) wrap_true_validity(c);
+    for (auto& c : b.columns) out.columns.push_back(c);
+    out.num_rows = (int64_t)got;
+    if (kind_ != RightJoinKind::Full) return std::make_unique<Once>(std::move(out));
+    // full: + the unmatched probe rows with a null build block, as a second block
+    Column matched; matched.type = DataType::of(DBHIP_T_BOOL); matched.len = n;
+    matched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64); matched.data->fill(0);
+    uint64_t nm = 0;
+    check(dbhip_join_probe_mark(h_, (const uint64_t*)k.data->ptr(), v, n, (uint8_t*)matched.data->ptr(), &nm, nullptr));
+    Column unmatched = matched;
+    unmatched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64);
+    {
+      Column f = Column::from_bools(std::vector<bool>{false});
+      dbhip_col a = matched.c(), bb = f.c();
+      bb.is_scalar = 1;
+      check(dbhip_cmp(DBHIP_CMP_EQ, &a, &bb, n, (uint8_t*)unmatched.data->ptr(), nullptr));
+    }
+    Selection us = filter_select(unmatched);
+    DataBlock tail = take_block(data, us.sel, us.count);
+    for (Column& c : tail.columns) wrap_true_validity(c);
+    if (!chunks_.empty()) for (const Column& c : chunks_[0].columns) tail.columns.push_back(null_column(c.type, us.count));
+    tail.num_rows = us.count;
+    return std::make_unique<Two>(std::move(out), std::move(tail));
+  }
+  // after the last probe block (Join::final_probe): build rows by the scan map
+  std::optional<DataBlock> final_probe() {
+    if (chunks_.empty()) return std::nullopt;
+    int64_t rows = 0;
+    check(dbhip_join_build_matched(h_, nullptr, &rows, nullptr));
+    Column m; m.type = DataType::of(DBHIP_T_BOOL); m.len = rows;
+    m.data = make_buf((size_t)(rows + 63) / 64 * 8 + 64); m.data->fill(0);
+    check(dbhip_join_build_matched(h_, (uint8_t*)m.data->ptr(), &rows, nullptr));
+    Column want = m;
+    if (kind_ != RightJoinKind::Semi) {   // the UNMATCHED build rows
+      want.data = make_buf((size_t)(rows + 63) / 64 * 8 + 64);
+      Column f = Column::from_bools(std::vector<bool>{false});
+      dbhip_col a = m.c(), b = f.c();
+      b.is_scalar = 1;
+      check(dbhip_cmp(DBHIP_CMP_EQ, &a, &b, rows, (uint8_t*)want.data->ptr(), nullptr));
+    }
+    Selection s = filter_select(want);
+    DataBlock b = take_block(chunks_[0], s.sel, s.count);
+    if (kind_ == RightJoinKind::Semi || kind_ == RightJoinKind::Anti) return b;
+    DataBlock out;   // right / full: a NULL probe side in front of the unmatched build rows
+    for (const DataType& t : probe_types_) out.columns.push_back(null_column(t, s.count));
+    if (kind_ == RightJoinKind::Full) for (Column& c : b.columns) wrap_true_validity(c);
+    for (auto& c : b.columns) out.columns.push_back(c);
+    out.num_rows = s.count;
+    return out;
+  }
+ private:
+  static void wrap_true_validity(Column& c) {   // wrap_true_validity (left_join.rs:243-249)
+    if (!c.validity) { c.validity = const_bitmap(true, c.len); }
+    c.type.nullable = true;
+  }
+  static Column null_column(DataType t, int64_t n) {
+    Column c; c.type = t; c.type.nullable = true; c.len = n;
+    const size_t es = t.id == DBHIP_T_BOOL ? 1 : t.elem_size();
+    c.data = make_buf((size_t)(n > 0 ? n : 1) * (es ? es : 16) + 64); c.data->fill(0);
+    c.validity = const_bitmap(false, n > 0 ? n : 1);
+    return c;
+  }
+  struct Once : JoinStream {
+    std::optional<DataBlock> b;
+    explicit Once(std::optional<DataBlock> x) : b(std::move(x)) {}
+    std::optional<DataBlock> next() override { auto r = std::move(b); b.reset(); return r; }
+  };
+  struct Two : JoinStream {
+    std::optional<DataBlock> a, b;
+    Two(DataBlock x, DataBlock y) : a(std::move(x)), b(std::move(y)) {}
+    std::optional<DataBlock> next() override {
+      if (a) { auto r = std::move(a); a.reset(); return r; }
+      auto r = std::move(b); b.reset(); return r;
+    }
+  };
+  RightJoinKind kind_;
+  size_t bk_, pk_;
+  dbhip_join* h_ = nullptr;
+  std::vector<DataBlock> chunks_;
+  std::vector<DataType> probe_types_;
+};
+
+// ---- vector-cluster KMeans (kmeans.rs:93-291, TransformVectorCluster) ------------------------------------------------------------
+struct KMeansResult { std::vector<uint32_t> assignments; std::vector<float> distances; int64_t k = 0; int32_t iterations = 0; };
+// distance_type: 0 = L1, 1 = L2, 2 = Dot (VectorDistanceType); `column` = Vector(dim) of Float32
+inline KMeansResult kmeans(int32_t distance_type, const Column& column, int64_t rows_per_cluster, bool normalize_input) {
+  KMeansResult r;
+  const int64_t n = column.len;
+  Buf a = make_buf((size_t)(n > 0 ? n : 1) * 4 + 64), d = make_buf((size_t)(n > 0 ? n : 1) * 4 + 64);
+  check(dbhip_kmeans(distance_type, (const float*)column.data->ptr(), n, (int32_t)column.type.dim, rows_per_cluster, normalize_input ? 1 : 0,
+                     (uint32_t*)a->ptr(), (float*)d->ptr(), &r.k, &r.iterations, nullptr));
+  r.assignments.resize((size_t)n); r.distances.resize((size_t)n);
+  if (n) { a->download(r.assignments.data(), (size_t)n * 4); d->download(r.distances.data(), (size_t)n * 4); }
+  return r;
+}
+
 // ---- HNSW vector index (hnsw_index/hnsw.rs:62-315) ------------------------------------------------------------------
 class HNSWIndex {
  public:

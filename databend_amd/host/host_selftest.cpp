@@ -319,6 +319,84 @@ static void test_left_joins() {
   }
 }
 
+static void test_right_joins() {
+  // right / right-semi / right-anti / full over TWO probe blocks (the scan map lives across blocks), against std::multimap
+  const int64_t nb = 5000, np = 12000;
+  std::mt19937_64 rng(19);
+  std::vector<uint64_t> bk(nb), pk(np); std::vector<int64_t> bv(nb), pv(np);
+  for (int64_t i = 0; i < nb; ++i) { bk[i] = rng() % 6000; bv[i] = i * 5 + 2; }
+  for (int64_t i = 0; i < np; ++i) { pk[i] = rng() % 9000; pv[i] = i + 1; }
+  auto U64 = DataType::of(DBHIP_T_U64); auto I64 = DataType::of(DBHIP_T_I64);
+  std::multimap<uint64_t, int64_t> pm;
+  for (int64_t i = 0; i < np; ++i) pm.insert({pk[i], pv[i]});
+  std::multimap<uint64_t, int64_t> bm;
+  for (int64_t i = 0; i < nb; ++i) bm.insert({bk[i], bv[i]});
+  auto valid_at = [](const Column& c, size_t i) {
+    if (!c.validity) return true;
+    std::vector<uint8_t> vb((size_t)(c.len + 7) / 8 + 8);
+    c.validity->download(vb.data(), (size_t)(c.len + 7) / 8);
+    return (bool)((vb[i >> 3] >> (i & 7)) & 1);
+  };
+  for (RightJoinKind kind : {RightJoinKind::Outer, RightJoinKind::Semi, RightJoinKind::Anti, RightJoinKind::Full}) {
+    RightHashJoin join(kind, 0, 0);
+    join.add_block(DataBlock({Column::from_vector(U64, bk), Column::from_vector(I64, bv)}, nb));
+    join.final_build();
+    std::multiset<std::tuple<int64_t, int64_t>> got, exp;   // (probe value or -1 = NULL, build value or -1 = NULL)
+    auto collect = [&](const DataBlock& b) {
+      if (b.num_rows == 0) return;
+      CHECK(b.num_columns() == 4);
+      auto v1 = b.columns[1].to_vector<int64_t>(); auto v2 = b.columns[3].to_vector<int64_t>();
+      std::vector<uint8_t> p1((size_t)(b.num_rows + 7) / 8 + 8, 0xFF), p2((size_t)(b.num_rows + 7) / 8 + 8, 0xFF);
+      if (b.columns[1].validity) b.columns[1].validity->download(p1.data(), (size_t)(b.num_rows + 7) / 8);
+      if (b.columns[3].validity) b.columns[3].validity->download(p2.data(), (size_t)(b.num_rows + 7) / 8);
+      for (size_t i = 0; i < (size_t)b.num_rows; ++i)
+        got.insert({((p1[i >> 3] >> (i & 7)) & 1) ? v1[i] : -1, ((p2[i >> 3] >> (i & 7)) & 1) ? v2[i] : -1});
+    };
+    std::multiset<int64_t> got1;   // semi / anti: build values
+    for (int half = 0; half < 2; ++half) {
+      const int64_t lo = half * (np / 2), hi = half ? np : np / 2;
+      DataBlock pb({Column::from_vector(U64, std::vector<uint64_t>(pk.begin() + lo, pk.begin() + hi)),
+                    Column::from_vector(I64, std::vector<int64_t>(pv.begin() + lo, pv.begin() + hi))}, hi - lo);
+      auto stream = join.probe_block(std::move(pb));
+      while (auto b = stream->next()) collect(*b);
+    }
+    auto tail = join.final_probe();
+    if (kind == RightJoinKind::Semi || kind == RightJoinKind::Anti) {
+      CHECK(got.empty() && tail.has_value() && tail->num_columns() == 2);
+      for (int64_t v : tail->columns[1].to_vector<int64_t>()) got1.insert(v);
+      std::multiset<int64_t> exp1;
+      for (int64_t i = 0; i < nb; ++i) if ((pm.count(bk[i]) > 0) == (kind == RightJoinKind::Semi)) exp1.insert(bv[i]);
+      CHECK(got1 == exp1);
+      continue;
+    }
+    if (tail) collect(*tail);
+    for (int64_t i = 0; i < np; ++i) {
+      auto r = bm.equal_range(pk[i]);
+      if (r.first == r.second && kind == RightJoinKind::Full) exp.insert({pv[i], -1});
+      for (auto it = r.first; it != r.second; ++it) exp.insert({pv[i], it->second});
+    }
+    for (int64_t i = 0; i < nb; ++i) if (pm.count(bk[i]) == 0) exp.insert({-1, bv[i]});
+    CHECK(got == exp);
+    (void)valid_at;
+  }
+}
+
+static void test_kmeans() {
+  // TransformVectorCluster's KMeans: deterministic (fixed seed), every row assigned to its nearest centroid, k = ceil(n / rows_per_cluster)
+  const int dim = 8; const int64_t n = 4000;
+  std::mt19937 rng(6);
+  std::normal_distribution<float> nd(0.f, 0.3f);
+  std::vector<float> data((size_t)n * dim);
+  for (int64_t i = 0; i < n; ++i) for (int d = 0; d < dim; ++d) data[(size_t)i * dim + d] = (float)((i % 5) * 4) + nd(rng);   // 5 well separated blobs
+  Column col = Column::from_vector(DataType::Vector(dim), data);
+  KMeansResult a = kmeans(1, col, 800, false), b = kmeans(1, col, 800, false);
+  CHECK(a.k == 5 && a.iterations >= 1 && a.assignments == b.assignments && a.distances == b.distances);
+  std::set<std::pair<int, uint32_t>> pairs;   // every blob in exactly one cluster
+  for (int64_t i = 0; i < n; ++i) pairs.insert({(int)(i % 5), a.assignments[(size_t)i]});
+  CHECK(pairs.size() == 5);
+  for (float d : a.distances) CHECK(d >= 0.f && d < 3.f);
+}
+
 static void test_hnsw_index() {
   // HNSWIndex::build + search (m = 10, ef_construct = 40, ef = 4 k): every vector finds itself, distances ascend
   const int dim = 16; const int64_t n = 3000;
@@ -407,6 +485,8 @@ int main() {
     test_q1_plan();
     test_join_and_sort();
     test_left_joins();
+    test_right_joins();
+    test_kmeans();
     test_hnsw_index();
     test_vector_function();
     test_parquet_chunk();
