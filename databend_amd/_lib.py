@@ -78,7 +78,7 @@ SYMBOLS = [
     "dbhip_stream_sync", "dbhip_event_create", "dbhip_event_record", "dbhip_event_elapsed_ms",
     "dbhip_event_destroy", "dbhip_last_kernel_ms", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",
     "dbhip_sum", "dbhip_expr_eval", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_decimal_neg", "dbhip_decimal_cast", "dbhip_cmp", "dbhip_bitmap_binary",
-    "dbhip_bitmap_count", "dbhip_filter_select", "dbhip_take", "dbhip_take_block", "dbhip_take_bitmap", "dbhip_group_hash",
+    "dbhip_bitmap_count", "dbhip_filter_select", "dbhip_select_cmp", "dbhip_select_bool", "dbhip_take", "dbhip_take_block", "dbhip_take_bitmap", "dbhip_group_hash",
     "dbhip_groupby_create", "dbhip_groupby_add_block", "dbhip_groupby_merge_serialized", "dbhip_groupby_merge_state_block",
     "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized", "dbhip_groupby_flush_block",
     "dbhip_groupby_merge_blocks", "dbhip_groupby_add_block_filtered", "dbhip_groupby_partition_blocks",

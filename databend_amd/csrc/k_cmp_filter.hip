@@ -371,6 +371,93 @@ __global__ __launch_bounds__(256) void sel_write_kernel(const uint8_t* bm, int64
   }
 }
 
+// ---- Selector (filter/selector.rs:64-330, select_value/select_column*.rs): a predicate evaluated on the rows of a SELECTION
+// (SelectStrategy::True / False: the true or the false list of the step before; All: every row), the rows split in order into
+// a true list and — when the caller short-circuits an OR — a false list. ----
+// one 64-bit element of a column widened like load4_wide (sign / zero extension, f32 -> f64 bits)
+__device__ __forceinline__ uint64_t load1_wide(const void* p, int type, int64_t i) {
+  switch (type) {
+    case DBHIP_T_I8: return (uint64_t)(int64_t)((const int8_t*)p)[i];
+    case DBHIP_T_I16: return (uint64_t)(int64_t)((const int16_t*)p)[i];
+    case DBHIP_T_I32: case DBHIP_T_DATE: return (uint64_t)(int64_t)((const int32_t*)p)[i];
+    case DBHIP_T_I64: case DBHIP_T_TIMESTAMP: case DBHIP_T_DEC64: return (uint64_t)((const int64_t*)p)[i];
+    case DBHIP_T_U8: return ((const uint8_t*)p)[i];
+    case DBHIP_T_U16: return ((const uint16_t*)p)[i];
+    case DBHIP_T_U32: return ((const uint32_t*)p)[i];
+    case DBHIP_T_U64: return ((const uint64_t*)p)[i];
+    case DBHIP_T_F32: return (uint64_t)__double_as_longlong((double)((const float*)p)[i]);
+    default: return (uint64_t)__double_as_longlong(((const double*)p)[i]);
+  }
+}
+struct SelArgs {
+  const void* a; const void* b;                 // operands (b unused for a Boolean column)
+  const uint8_t* av; const uint8_t* bv;         // validities (NULL = none)
+  int64_t avo, bvo;
+  int type, a_scalar, b_scalar, op;             // op < 0: `a` is a Boolean column (select_boolean_column)
+  const uint32_t* sel_in;                       // NULL = SelectStrategy::All
+  int64_t n;                                    // entries of sel_in, or rows
+  uint64_t* bits;                               // out: one bit per ENTRY (whole words)
+};
+__global__ __launch_bounds__(256) void select_eval_kernel(SelArgs A) {
+  const int cls = type_class(A.type);
+  const int64_t n_pad = (A.n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * 256) {
+    bool ret = false;
+    if (i < A.n) {
+      const int64_t row = A.sel_in ? (int64_t)A.sel_in[i] : i;
+      const int64_t ra = A.a_scalar ? 0 : row, rb = A.b_scalar ? 0 : row;
+      bool valid = (!A.av || bit_get(A.av, A.avo + ra)) && (!A.bv || bit_get(A.bv, A.bvo + rb));
+      if (valid) {
+        if (A.op < 0) ret = bit_get((const uint8_t*)A.a, ra);
+        else if (A.type == DBHIP_T_DEC128) ret = apply_cmp(A.op, cmp3_i128(((const i128*)A.a)[ra], ((const i128*)A.b)[rb]));
+        else if (A.type == DBHIP_T_BOOL) ret = apply_cmp(A.op, (int)bit_get((const uint8_t*)A.a, ra) - (int)bit_get((const uint8_t*)A.b, rb));
+        else {
+          const uint64_t x = load1_wide(A.a, A.type, ra), y = load1_wide(A.b, A.type, rb);
+          int c;
+          if (cls == CLS_SIGNED) c = cmp3_i64((int64_t)x, (int64_t)y);
+          else if (cls == CLS_UNSIGNED) c = cmp3_u64(x, y);
+          else c = cmp3_f64(__longlong_as_double((long long)x), __longlong_as_double((long long)y));
+          ret = apply_cmp(A.op, c);
+        }
+      }
+    }
+    const uint64_t m = __ballot(ret);
+    if (lane_id() == 0) A.bits[i >> 6] = m;
+  }
+}
+// sel_write_kernel for a bitmap over ENTRIES: entry e of the selection goes to the true list (bit set) or the false list, both in
+// entry order; `sel_in` maps entries to row ids (NULL: the entry is the row)
+__global__ __launch_bounds__(256) void select_split_kernel(const uint64_t* bits, int64_t n, const uint64_t* block_offsets, const uint32_t* sel_in,
+                                                           uint32_t* out_true, uint32_t* out_false) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int64_t w = (int64_t)blockIdx.x * SEL_WORDS_PER_BLOCK + threadIdx.x;
+  const int64_t nwords = (n + 63) >> 6;
+  uint64_t word = w < nwords ? bits[w] : 0;
+  const uint32_t cnt = __popcll(word);
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  __shared__ uint32_t wave_tot[4];
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int k = 0; k < wave; ++k) wbase += wave_tot[k];
+  const uint64_t my_off = block_offsets[blockIdx.x] + wbase + incl - cnt;   // true entries before this word
+  for (int j = 0; j < 64; ++j) {
+    const uint64_t wj = __shfl(word, j, 64);
+    const uint64_t oj = __shfl(my_off, j, 64);
+    const int64_t e = (((int64_t)blockIdx.x * SEL_WORDS_PER_BLOCK + wave * 64 + j) << 6) + lane;
+    if (e >= n) continue;
+    const uint32_t row = sel_in ? sel_in[e] : (uint32_t)e;
+    const uint32_t before = __popcll(wj & ((1ULL << lane) - 1));
+    if ((wj >> lane) & 1) out_true[oj + before] = row;
+    else if (out_false) out_false[(uint64_t)(e - lane) - oj + (lane - before)] = row;   // false entries before e = e - true entries before e
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void take_kernel(const T* __restrict__ src,
                                                    const uint32_t* __restrict__ sel, int64_t n,
@@ -763,6 +850,61 @@ int32_t dbhip_filter_select(const uint8_t* bitmap, int64_t bit_offset, int64_t n
                      n, offsets, out_sel);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
+}
+
+static int32_t select_run(SelArgs A, uint32_t* out_true, uint32_t* out_false, uint64_t* out_counts_dev, hipStream_t s) {
+  const int64_t nwords = ceil_div(A.n, 64);
+  const int64_t nblocks = ceil_div(nwords, SEL_WORDS_PER_BLOCK);
+  uint8_t* ws = (uint8_t*)scratch((size_t)nblocks * SEL_WORDS_PER_BLOCK * 8 + (size_t)nblocks * 12 + 128, 1, s);
+  if (!ws) return DBHIP_ERR_HIP;
+  uint64_t* bits = (uint64_t*)ws;
+  uint64_t* offsets = bits + nblocks * SEL_WORDS_PER_BLOCK;
+  uint32_t* counts = (uint32_t*)(offsets + nblocks);
+  DBHIP_CHECK(hipMemsetAsync(bits + nwords, 0, (size_t)(nblocks * SEL_WORDS_PER_BLOCK - nwords) * 8, s));
+  A.bits = bits;
+  hipLaunchKernelGGL(select_eval_kernel, dim3(grid_for(A.n, 256)), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(sel_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, (const uint8_t*)bits, (int64_t)0, A.n, counts);
+  hipLaunchKernelGGL(sel_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, nblocks, (unsigned long long*)out_counts_dev);
+  hipLaunchKernelGGL(select_split_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, bits, A.n, offsets, A.sel_in, out_true, out_false);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_select_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, const uint32_t* sel_in, int64_t n, uint32_t* out_true,
+                         uint32_t* out_false, uint64_t* out_count_true_dev, void* stream) {
+  DBHIP_REQUIRE(lhs && rhs && out_count_true_dev, "dbhip_select_cmp: NULL argument");
+  DBHIP_REQUIRE(op >= DBHIP_CMP_EQ && op <= DBHIP_CMP_GTE, "dbhip_select_cmp: bad comparison");
+  DBHIP_REQUIRE(n >= 0 && n <= 0xFFFFFFFFLL, "dbhip_select_cmp: more than 2^32 entries");
+  hipStream_t s = resolve_stream(stream);
+  if (n == 0) { DBHIP_CHECK(hipMemsetAsync(out_count_true_dev, 0, 8, s)); return DBHIP_OK; }
+  DBHIP_REQUIRE(out_true && lhs->data && rhs->data, "dbhip_select_cmp: NULL buffer");
+  if (lhs->type != rhs->type || !(type_class(lhs->type) >= 0 || lhs->type == DBHIP_T_DEC128 || lhs->type == DBHIP_T_BOOL)) {
+    set_error("dbhip_select_cmp: operand types %d / %d (equal fixed-width types only; strings and decimals of different sizes go through dbhip_cmp)", lhs->type, rhs->type);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if ((lhs->type == DBHIP_T_DEC64 || lhs->type == DBHIP_T_DEC128) && lhs->scale != rhs->scale) {
+    set_error("dbhip_select_cmp: decimal operands of different scales go through dbhip_cmp");
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  SelArgs A;
+  memset(&A, 0, sizeof(A));
+  A.a = lhs->data; A.b = rhs->data; A.av = lhs->validity; A.bv = rhs->validity; A.avo = lhs->validity_offset; A.bvo = rhs->validity_offset;
+  A.type = lhs->type; A.a_scalar = lhs->is_scalar; A.b_scalar = rhs->is_scalar; A.op = op; A.sel_in = sel_in; A.n = n;
+  return select_run(A, out_true, out_false, out_count_true_dev, s);
+}
+
+int32_t dbhip_select_bool(const dbhip_col* predicate, const uint32_t* sel_in, int64_t n, uint32_t* out_true, uint32_t* out_false,
+                          uint64_t* out_count_true_dev, void* stream) {
+  DBHIP_REQUIRE(predicate && out_count_true_dev && predicate->type == DBHIP_T_BOOL, "dbhip_select_bool: a Boolean column");
+  DBHIP_REQUIRE(n >= 0 && n <= 0xFFFFFFFFLL, "dbhip_select_bool: more than 2^32 entries");
+  hipStream_t s = resolve_stream(stream);
+  if (n == 0) { DBHIP_CHECK(hipMemsetAsync(out_count_true_dev, 0, 8, s)); return DBHIP_OK; }
+  DBHIP_REQUIRE(out_true && predicate->data, "dbhip_select_bool: NULL buffer");
+  SelArgs A;
+  memset(&A, 0, sizeof(A));
+  A.a = predicate->data; A.av = predicate->validity; A.avo = predicate->validity_offset; A.type = DBHIP_T_BOOL; A.a_scalar = predicate->is_scalar;
+  A.op = -1; A.sel_in = sel_in; A.n = n;
+  return select_run(A, out_true, out_false, out_count_true_dev, s);
 }
 
 int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int64_t n_sel,

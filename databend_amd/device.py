@@ -431,6 +431,88 @@ def bitmap_count(pred, n):
     return int(out.to_numpy(np.uint64, 1)[0])
 
 
+def select_cmp(op, a, b, sel=None, n=None, want_false=False):
+    """Selector leaf (filter/select_value): `a op b` evaluated on the rows of `sel` (a DeviceBuffer of u32 row ids, `n` of them) or on
+    all n rows; -> (true list DeviceBuffer, n_true, false list DeviceBuffer | None). NULL rows do not pass."""
+    if n is None:
+        n = a.n if not a.is_scalar else b.n
+    t = DeviceBuffer(max(n, 1) * 4 + 64)
+    f = DeviceBuffer(max(n, 1) * 4 + 64) if want_false else None
+    cnt = DeviceBuffer(8)
+    ca, cb = a.c(), b.c()
+    check(lib().dbhip_select_cmp(op, C.byref(ca), C.byref(cb), C.c_void_p(sel.ptr) if sel is not None else None, C.c_int64(n), C.c_void_p(t.ptr),
+                                 C.c_void_p(f.ptr) if f is not None else None, C.c_void_p(cnt.ptr), None))
+    return t, int(cnt.to_numpy(np.uint64, 1)[0]), f
+
+
+def select_bool(pred, sel=None, n=None, want_false=False):
+    """Selector leaf for a Boolean column (select_boolean_column)"""
+    n = pred.n if n is None else n
+    t = DeviceBuffer(max(n, 1) * 4 + 64)
+    f = DeviceBuffer(max(n, 1) * 4 + 64) if want_false else None
+    cnt = DeviceBuffer(8)
+    cp = pred.c()
+    check(lib().dbhip_select_bool(C.byref(cp), C.c_void_p(sel.ptr) if sel is not None else None, C.c_int64(n), C.c_void_p(t.ptr),
+                                  C.c_void_p(f.ptr) if f is not None else None, C.c_void_p(cnt.ptr), None))
+    return t, int(cnt.to_numpy(np.uint64, 1)[0]), f
+
+
+def select_tree(expr, n):
+    """Selector::select over a tree of ("and", [..]) / ("or", [..]) / ("cmp", op, a, b) / ("bool", column) nodes
+    (filter/selector.rs:64-330: process_and narrows the TRUE list conjunct by conjunct, process_or feeds the FALSE list of one
+    disjunct to the next and concatenates the true lists): -> (row ids of the rows that pass, ascending within each OR branch's
+    contribution exactly like the reference's true_selection, count). Later predicates are evaluated only on the rows that are
+    still undecided."""
+    def run(e, sel, cnt, want_false):
+        # -> (true_ids ndarray-free: DeviceBuffer, n_true, false DeviceBuffer | None)
+        kind = e[0]
+        if kind == "cmp":
+            return select_cmp(e[1], e[2], e[3], sel, cnt, want_false)
+        if kind == "bool":
+            return select_bool(e[1], sel, cnt, want_false)
+        if kind == "and":
+            cur, k = sel, cnt
+            fparts = []
+            for child in e[1]:
+                t, kt, f = run(child, cur, k, want_false)
+                if want_false and k - kt:
+                    fparts.append((f, k - kt))
+                cur, k = t, kt
+                if k == 0:
+                    break
+            if cur is None:   # no conjunct at all: everything passes
+                cur = DeviceBuffer.from_numpy(np.arange(cnt, dtype=np.uint32))
+            return cur, k, (_concat_u32(fparts) if want_false else None)
+        if kind == "or":
+            cur, k = sel, cnt
+            tparts = []
+            f = None
+            for child in e[1]:
+                t, kt, f = run(child, cur, k, True)
+                if kt:
+                    tparts.append((t, kt))
+                cur, k = f, k - kt
+                if k == 0:
+                    break
+            tt = _concat_u32(tparts)
+            return tt, sum(c for _, c in tparts), (cur if want_false else None)
+        raise ValueError(kind)
+
+    t, k, _ = run(expr, None, n, False)
+    return t, k
+
+
+def _concat_u32(parts):
+    total = sum(c for _, c in parts)
+    out = DeviceBuffer(max(total, 1) * 4 + 64)
+    off = 0
+    for buf, c in parts:
+        if c:
+            check(lib().dbhip_memcpy_d2d(C.c_void_p(out.ptr + off * 4), C.c_void_p(buf.ptr), C.c_size_t(c * 4), None))
+        off += c
+    return out
+
+
 def take(col, sel, k):
     """DataBlock::take for one column (kernels/take.rs:43)."""
     if col.dtype == L.T_BOOL:

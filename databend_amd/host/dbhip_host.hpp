@@ -157,6 +157,16 @@ struct Column {
     if (valid) { c.type.nullable = true; c.validity = pack_bits(*valid); }
     return c;
   }
+  // a one-row column holding a scalar (the operand form of a constant: dbhip_col.is_scalar)
+  static Column from_scalar(const Scalar& sc) {
+    Column c; c.type = sc.type; c.len = 1;
+    if (sc.type.id == DBHIP_T_BOOL) { c.data = pack_bits(std::vector<bool>{sc.i != 0}); return c; }
+    uint8_t raw[32] = {0};
+    sc.store(raw);
+    c.data = make_buf(32);
+    c.data->upload(raw, 32);
+    return c;
+  }
   static Column from_bools(const std::vector<bool>& v, const std::vector<bool>* valid = nullptr) {
     Column c; c.type = DataType::of(DBHIP_T_BOOL); c.len = (int64_t)v.size(); c.data = pack_bits(v);
     if (valid) { c.type.nullable = true; c.validity = pack_bits(*valid); }
@@ -823,10 +833,124 @@ inline DataBlock take_block(const DataBlock& b, const uint32_t* sel, int64_t k) 
 }
 inline DataBlock take_block(const DataBlock& b, const Buf& sel, int64_t k) { return take_block(b, (const uint32_t*)sel->ptr(), k); }
 
+// Selector (filter/selector.rs:64-330, select_expr.rs:40-120): the filter's predicate as a tree of And / Or over comparison leaves
+// (column-or-constant operands of one fixed-width type) walks TRUE / FALSE lists of row ids instead of materialising one Boolean
+// column per node: a conjunct is evaluated only on the rows that passed the conjuncts before it, a disjunct only on the rows that
+// failed the disjuncts before it (dbhip_select_cmp). Anything else in the tree (arithmetic under a comparison, casts, strings)
+// makes build() return false and the caller keeps the Bitmap path (FilterExecutor::filter) — SelectExpr::Others in the reference.
+class Selector {
+ public:
+  explicit Selector(const DataBlock& block) : block_(block) {}
+  // -> the rows that pass, in the reference's true_selection order; nullopt = the tree is outside the leaf kernels
+  std::optional<Selection> select(const Expr& e) const {
+    if (!supported(e)) return std::nullopt;
+    Lists r = run(e, Buf(), block_.num_rows, false);
+    Selection s; s.sel = r.t; s.count = r.nt;
+    if (!s.sel) { s.sel = make_buf(64); }
+    return s;
+  }
+ private:
+  struct Lists { Buf t; int64_t nt = 0; Buf f; int64_t nf = 0; };
+  static bool is_cmp(const std::string& n) { return n == "eq" || n == "noteq" || n == "lt" || n == "lte" || n == "gt" || n == "gte"; }
+  static int cmp_code(const std::string& n) {
+    return n == "eq" ? DBHIP_CMP_EQ : n == "noteq" ? DBHIP_CMP_NOTEQ : n == "lt" ? DBHIP_CMP_LT : n == "lte" ? DBHIP_CMP_LTE : n == "gt" ? DBHIP_CMP_GT : DBHIP_CMP_GTE;
+  }
+  static bool leaf_operand(const Expr& e) { return e.kind == Expr::ColumnRef || (e.kind == Expr::Constant && !e.scalar.is_null); }
+  bool supported(const Expr& e) const {
+    if (e.kind == Expr::ColumnRef) return e.type.id == DBHIP_T_BOOL;
+    if (e.kind != Expr::FunctionCall) return false;
+    if (e.fname == "and_filters" || e.fname == "or_filters" || e.fname == "and" || e.fname == "or") {
+      for (const Expr& a : e.args) if (!supported(a)) return false;
+      return !e.args.empty();
+    }
+    if (!is_cmp(e.fname) || e.args.size() != 2 || !leaf_operand(e.args[0]) || !leaf_operand(e.args[1])) return false;
+    const DataType &a = e.args[0].type, &b = e.args[1].type;
+    const bool fixed = (a.id >= DBHIP_T_BOOL && a.id <= DBHIP_T_TIMESTAMP) || a.id == DBHIP_T_DEC64 || a.id == DBHIP_T_DEC128;
+    return fixed && a.dim == 0 && a.id == b.id && a.scale == b.scale && !(e.args[0].kind == Expr::Constant && e.args[1].kind == Expr::Constant);
+  }
+  dbhip_col operand(const Expr& e, std::vector<Column>& keep) const {
+    if (e.kind == Expr::ColumnRef) return block_.get_by_offset(e.id).c();
+    keep.push_back(Column::from_scalar(e.scalar));
+    dbhip_col c = keep.back().c();
+    c.is_scalar = 1;
+    return c;
+  }
+  Lists leaf(const Expr& e, const Buf& sel, int64_t n, bool want_false) const {
+    Lists r;
+    r.t = make_buf((size_t)(n > 0 ? n : 1) * 4 + 64);
+    if (want_false) r.f = make_buf((size_t)(n > 0 ? n : 1) * 4 + 64);
+    Buf cnt = make_buf(8);
+    const uint32_t* sp = sel ? (const uint32_t*)sel->ptr() : nullptr;
+    if (e.kind == Expr::ColumnRef) {
+      dbhip_col p = block_.get_by_offset(e.id).c();
+      check(dbhip_select_bool(&p, sp, n, (uint32_t*)r.t->ptr(), r.f ? (uint32_t*)r.f->ptr() : nullptr, (uint64_t*)cnt->ptr(), nullptr));
+    } else {
+      std::vector<Column> keep;
+      keep.reserve(2);
+      dbhip_col a = operand(e.args[0], keep), b = operand(e.args[1], keep);
+      check(dbhip_select_cmp(cmp_code(e.fname), &a, &b, sp, n, (uint32_t*)r.t->ptr(), r.f ? (uint32_t*)r.f->ptr() : nullptr, (uint64_t*)cnt->ptr(), nullptr));
+    }
+    uint64_t h = 0; cnt->download(&h, 8);
+    r.nt = (int64_t)h; r.nf = n - r.nt;
+    return r;
+  }
+  static Buf concat(const std::vector<std::pair<Buf, int64_t>>& parts, int64_t* total) {
+    int64_t n = 0;
+    for (auto& p : parts) n += p.second;
+    Buf out = make_buf((size_t)(n > 0 ? n : 1) * 4 + 64);
+    int64_t off = 0;
+    for (auto& p : parts) {
+      if (p.second) check(dbhip_memcpy_d2d((uint32_t*)out->ptr() + off, p.first->ptr(), (size_t)p.second * 4, nullptr));
+      off += p.second;
+    }
+    *total = n;
+    return out;
+  }
+  // process_select_expr: `sel` (nullptr = all rows) holds the n rows still to be decided
+  Lists run(const Expr& e, Buf sel, int64_t n, bool want_false) const {
+    const bool is_and = e.kind == Expr::FunctionCall && (e.fname == "and_filters" || e.fname == "and");
+    const bool is_or = e.kind == Expr::FunctionCall && (e.fname == "or_filters" || e.fname == "or");
+    if (!is_and && !is_or) return leaf(e, sel, n, want_false);
+    Lists out;
+    if (is_and) {   // process_and (:181-231): the true list narrows, every conjunct's false rows are false
+      Buf cur = sel; int64_t k = n;
+      std::vector<std::pair<Buf, int64_t>> fparts;
+      for (const Expr& c : e.args) {
+        Lists r = run(c, cur, k, want_false);
+        if (want_false && r.nf) fparts.push_back({r.f, r.nf});
+        cur = r.t; k = r.nt;
+        if (k == 0) break;
+      }
+      out.t = cur; out.nt = k;
+      if (want_false) out.f = concat(fparts, &out.nf);
+      return out;
+    }
+    // process_or (:233-292): the false list of a disjunct feeds the next one, the true lists are concatenated
+    Buf cur = sel; int64_t k = n;
+    std::vector<std::pair<Buf, int64_t>> tparts;
+    for (const Expr& c : e.args) {
+      Lists r = run(c, cur, k, true);
+      if (r.nt) tparts.push_back({r.t, r.nt});
+      cur = r.f; k = r.nf;
+      if (k == 0) break;
+    }
+    out.t = concat(tparts, &out.nt);
+    if (want_false) { out.f = cur; out.nf = k; }
+    return out;
+  }
+  const DataBlock& block_;
+};
+
 class FilterExecutor {
  public:
   explicit FilterExecutor(Expr predicate) : predicate_(std::move(predicate)) {}
+  // FilterExecutor::select (filter_executor.rs:81-118): the Selector's true list when the predicate is a tree of And / Or over
+  // comparison leaves, else the Bitmap of the whole predicate
   DataBlock filter(const DataBlock& block) const {
+    if (auto s = Selector(block).select(predicate_)) return take_block(block, s->sel, s->count);
+    return filter_with_bitmap(block);
+  }
+  DataBlock filter_with_bitmap(const DataBlock& block) const {
     Evaluator ev(block);
     Value v = ev.run(predicate_);
     if (v.is_scalar) return (!v.scalar.is_null && v.scalar.i != 0) ? block : DataBlock(std::vector<Column>(), 0);

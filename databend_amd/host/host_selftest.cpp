@@ -166,6 +166,43 @@ static void test_or_filters() {
   for (int64_t i = 0; i < n; ++i) CHECK(got[(size_t)i] == (d[i] == 0 || 10.0 / (double)d[i] > 2.0));
 }
 
+static void test_selector() {
+  // FilterExecutor through the Selector (true / false lists, short-circuit And / Or) == through the predicate's Bitmap, on a tree
+  // that mixes both, nullable operands and a Boolean column; a tree with arithmetic under a comparison falls back by itself
+  const int64_t n = 200003;
+  std::mt19937 rng(23);
+  std::vector<int64_t> a(n), b(n); std::vector<double> c(n); std::vector<bool> d(n), va(n);
+  for (int64_t i = 0; i < n; ++i) { a[i] = (int64_t)(rng() % 100) - 50; b[i] = (int64_t)(rng() % 100) - 50; c[i] = (double)(rng() % 1000) / 1000.0; d[i] = rng() % 2; va[i] = rng() % 5 != 0; }
+  auto I64 = DataType::of(DBHIP_T_I64); auto F64 = DataType::of(DBHIP_T_F64); auto B = DataType::of(DBHIP_T_BOOL);
+  DataBlock block({Column::from_vector(I64, a, &va), Column::from_vector(I64, b), Column::from_vector(F64, c), Column::from_bools(d)}, n);
+  auto col = [&](size_t i, DataType t, const char* nm) { return Expr::column_ref(i, t, nm); };
+  Expr p1 = Expr::call("gt", {col(0, I64.wrap_nullable(), "a"), Expr::constant(Scalar::Int(DBHIP_T_I64, 10))});
+  Expr p2 = Expr::call("lte", {col(1, I64, "b"), Expr::constant(Scalar::Int(DBHIP_T_I64, 0))});
+  Expr p3 = Expr::call("lt", {col(2, F64, "c"), Expr::constant(Scalar::Float(DBHIP_T_F64, 0.5))});
+  Expr p4 = Expr::call("noteq", {col(0, I64.wrap_nullable(), "a"), col(1, I64, "b")});
+  Expr tree = Expr::call("and_filters", {p3, Expr::call("or_filters", {p1, col(3, B, "d"), p2}), p4});
+  std::optional<Selection> s = Selector(block).select(tree);
+  CHECK(s.has_value());
+  std::vector<int64_t> exp;
+  for (int64_t i = 0; i < n; ++i) if (c[i] < 0.5 && ((va[i] && a[i] > 10) || d[i] || b[i] <= 0) && (va[i] && a[i] != b[i])) exp.push_back(b[i] * 1000 + i % 1000);
+  FilterExecutor fe(tree);
+  DataBlock out = fe.filter(block), out2 = fe.filter_with_bitmap(block);
+  CHECK(out.num_rows == (int64_t)exp.size() && out2.num_rows == out.num_rows);
+  // an And over ascending lists keeps row order only inside each Or branch: compare as multisets with the Bitmap path, and the And-only
+  // tree in exact order
+  auto key = [](const DataBlock& blk) { std::multiset<int64_t> m; auto bb = blk.columns[1].to_vector<int64_t>(); auto cc = blk.columns[2].to_vector<double>(); for (size_t i = 0; i < bb.size(); ++i) m.insert(bb[i] * 100000 + (int64_t)(cc[i] * 1000)); return m; };
+  CHECK(key(out) == key(out2));
+  Expr conj = Expr::call("and_filters", {p3, p2, p4});
+  DataBlock o3 = FilterExecutor(conj).filter(block), o4 = FilterExecutor(conj).filter_with_bitmap(block);
+  CHECK(o3.num_rows == o4.num_rows && o3.columns[1].to_vector<int64_t>() == o4.columns[1].to_vector<int64_t>() && o3.columns[2].to_vector<double>() == o4.columns[2].to_vector<double>());
+  // arithmetic under a comparison: not a Selector leaf -> the Bitmap path, same API
+  Expr other = Expr::call("gt", {Expr::call("plus", {col(1, I64, "b"), col(1, I64, "b")}), Expr::constant(Scalar::Int(DBHIP_T_I64, 10))});
+  CHECK(!Selector(block).select(other).has_value());
+  int64_t cnt = 0;
+  for (int64_t i = 0; i < n; ++i) cnt += 2 * b[i] > 10;
+  CHECK(FilterExecutor(other).filter(block).num_rows == cnt);
+}
+
 static void test_q1_plan() {
   const int64_t n = 300007;
   std::mt19937_64 rng(2);
@@ -482,6 +519,7 @@ int main() {
     test_row_errors();
     test_filter();
     test_or_filters();
+    test_selector();
     test_q1_plan();
     test_join_and_sort();
     test_left_joins();

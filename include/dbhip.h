@@ -286,6 +286,19 @@ int32_t dbhip_bitmap_count(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
  * order), count written to *out_count_dev. Scratch is managed internally. */
 int32_t dbhip_filter_select(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
                             uint32_t* out_sel, uint64_t* out_count_dev, void* stream);
+/* Selector (filter/selector.rs:64-330, filter/select_value/select_column.rs, select_column_scalar.rs): the short-circuit form of a
+ * filter. A comparison (or a Boolean column) is evaluated ONLY on the rows of `sel_in` — the true list of the conjunct before
+ * (SelectStrategy::True), the false list of the disjunct before (SelectStrategy::False) — or on all `n` rows (sel_in = NULL,
+ * SelectStrategy::All); the rows that pass go to `out_true` in order, and, when `out_false` is given (the caller is inside an OR,
+ * `has_false`), the others to `out_false` in order. A NULL operand row does not pass (validity && cmp). *out_count_true_dev = number
+ * of true rows (the false list holds n - that). Operands: equal fixed-width types (numbers, Date, Timestamp, Decimal64/128 at one
+ * scale, Boolean), either may be a scalar; other shapes return DBHIP_ERR_UNSUPPORTED and go through dbhip_cmp + dbhip_filter_select.
+ * The lists must not alias `sel_in` (the reference compacts in place; a device kernel cannot). The AND / OR walk over the lists
+ * (process_and / process_or) is host logic: databend_amd/host/dbhip_host.hpp Selector, databend_amd/device.py select_and / select_or. */
+int32_t dbhip_select_cmp(int32_t op, const dbhip_col* lhs, const dbhip_col* rhs, const uint32_t* sel_in, int64_t n, uint32_t* out_true,
+                         uint32_t* out_false, uint64_t* out_count_true_dev, void* stream);
+int32_t dbhip_select_bool(const dbhip_col* predicate, const uint32_t* sel_in, int64_t n, uint32_t* out_true, uint32_t* out_false,
+                          uint64_t* out_count_true_dev, void* stream);
 /* DataBlock::take (kernels/take.rs:43): out[i] = src[sel[i]], elem_size in
  * {1,2,4,8,16} (16 covers i128 and string views). */
 int32_t dbhip_take(const void* src, int32_t elem_size, const uint32_t* sel, int64_t n_sel,

@@ -873,3 +873,79 @@ def test_take_block_equals_column_by_column_take(gpu, density):
     assert np.array_equal(got[:, 0], cols_np[0].view(np.uint64)[sel]) and np.array_equal(got[:, 1], (cols_np[0].view(np.uint64) >> np.uint64(3))[sel])
     # and the single-column entry point gives the same values
     assert np.array_equal(D.take(cols[1], dsel, k).to_numpy()[:k], cols_np[1][sel])
+
+
+def _np_select_tree(e, rows, data):
+    """numpy statement of Selector::select: -> (true rows in the reference's order, false rows)"""
+    kind = e[0]
+    if kind in ("cmp", "bool"):
+        m = data[e[-1]](rows)
+        return rows[m], rows[~m]
+    if kind == "and":
+        cur, fall = rows, []
+        for c in e[1]:
+            t, f = _np_select_tree(c, cur, data)
+            fall.append(f)
+            cur = t
+            if len(cur) == 0:
+                break
+        return cur, (np.concatenate(fall) if fall else rows[:0])
+    cur, tall = rows, []
+    for c in e[1]:
+        t, f = _np_select_tree(c, cur, data)
+        tall.append(t)
+        cur = f
+        if len(cur) == 0:
+            break
+    return (np.concatenate(tall) if tall else rows[:0]), cur
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 300_007])
+def test_selector_lists_match_the_reference_walk(gpu, n):
+    """dbhip_select_cmp / dbhip_select_bool (the Selector's leaves) and the AND / OR walk over true and false lists
+    (device.select_tree = process_and / process_or) against a numpy statement of the same walk: the TRUE list comes out in
+    exactly the reference's order (ascending inside a conjunction, branch after branch for a disjunction), NULL rows never pass,
+    later predicates only see the rows still undecided."""
+    D = gpu
+    rng = np.random.default_rng(n)
+    a = rng.integers(-50, 50, n).astype(np.int64)
+    b = rng.integers(-50, 50, n).astype(np.int32)
+    c = rng.random(n)
+    d = rng.integers(0, 2, n).astype(bool)
+    va, vd = rng.integers(0, 5, n) > 0, rng.integers(0, 7, n) > 0
+    ca, cb, cc = D.Column.from_numpy(a, validity=va), D.Column.from_numpy(b), D.Column.from_numpy(c)
+    cd = D.Column(T.T_BOOL, n, D.DeviceBuffer.from_numpy(D.pack_bits(d)), D.DeviceBuffer.from_numpy(D.pack_bits(vd)))
+    s10, s0, shalf = D.Column.scalar(10, T.T_I64), D.Column.scalar(0, T.T_I32), D.Column.scalar(0.5, T.T_F64)
+    data = {"a>10": lambda r: va[r] & (a[r] > 10), "b<=0": lambda r: b[r] <= 0, "c<0.5": lambda r: c[r] < 0.5,
+            "d": lambda r: vd[r] & d[r], "a!=b": lambda r: va[r] & (a[r] != b[r].astype(np.int64)), "10<a": lambda r: va[r] & (10 < a[r])}
+    leaf = {"a>10": ("cmp", T.CMP_GT, ca, s10, "a>10"), "b<=0": ("cmp", T.CMP_LTE, cb, s0, "b<=0"), "c<0.5": ("cmp", T.CMP_LT, cc, shalf, "c<0.5"),
+            "d": ("bool", cd, "d"), "10<a": ("cmp", T.CMP_LT, s10, ca, "10<a"),
+            "a!=b": ("cmp", T.CMP_NOTEQ, ca, D.Column.from_numpy(b.astype(np.int64)), "a!=b")}
+    trees = [leaf["a>10"], leaf["d"], leaf["10<a"],
+             ("and", [leaf["a>10"], leaf["b<=0"]]), ("or", [leaf["a>10"], leaf["b<=0"]]),
+             ("and", [leaf["c<0.5"], ("or", [leaf["a>10"], leaf["d"], leaf["b<=0"]]), leaf["a!=b"]]),
+             ("or", [("and", [leaf["a>10"], leaf["c<0.5"]]), ("and", [leaf["b<=0"], leaf["d"]]), leaf["a!=b"]]),
+             ("and", [leaf["a>10"], leaf["10<a"], ("and", [leaf["a>10"]])])]
+    rows = np.arange(n, dtype=np.uint32)
+    for e in trees:
+        dev_tree = _strip(e)
+        t, k = D.select_tree(dev_tree, n)
+        exp, _ = _np_select_tree(e, rows, data)
+        assert k == len(exp), e
+        assert np.array_equal(t.to_numpy(np.uint32, k), exp), e
+    # a leaf on an explicit selection, both lists
+    sel = np.sort(rng.choice(n, size=max(n // 3, 1), replace=False)).astype(np.uint32)
+    t, k, f = D.select_cmp(T.CMP_GT, ca, s10, D.DeviceBuffer.from_numpy(sel), len(sel), want_false=True)
+    m = data["a>10"](sel)
+    assert k == int(m.sum()) and np.array_equal(t.to_numpy(np.uint32, k), sel[m]) and np.array_equal(f.to_numpy(np.uint32, len(sel) - k), sel[~m])
+    # shapes outside the kernel are refused, not guessed
+    with pytest.raises(T.DbhipError) as ei:
+        D.select_cmp(T.CMP_EQ, cb, ca)
+    assert ei.value.code == T.ERR_UNSUPPORTED
+
+
+def _strip(e):
+    """drop the numpy key (last element) of the leaves"""
+    if e[0] in ("cmp", "bool"):
+        return e[:-1]
+    return (e[0], [_strip(c) for c in e[1]])
