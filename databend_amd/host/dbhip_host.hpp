@@ -944,9 +944,13 @@ class Selector {
 class FilterExecutor {
  public:
   explicit FilterExecutor(Expr predicate) : predicate_(std::move(predicate)) {}
-  // FilterExecutor::select (filter_executor.rs:81-118): the Selector's true list when the predicate is a tree of And / Or over
-  // comparison leaves, else the Bitmap of the whole predicate
-  DataBlock filter(const DataBlock& block) const {
+  // FilterExecutor::select (filter_executor.rs:81-118). The reference walks true / false lists (Selector) so that a CPU core skips
+  // the rows already decided; on the device one pass per predicate over the WHOLE column at the streaming rate plus a Bitmap AND
+  // is as fast when the first conjunct keeps 5 % of 600 M rows (3.38 vs 3.49 ms) and 2.4x faster when it keeps 98 % (3.46 vs
+  // 8.19 ms; tools/bench_selector.py), so the Bitmap path is the default and the Selector — same rows, the reference's list order —
+  // is there for a caller that needs the lists themselves (filter_with_selector; falls back for SelectExpr::Others).
+  DataBlock filter(const DataBlock& block) const { return filter_with_bitmap(block); }
+  DataBlock filter_with_selector(const DataBlock& block) const {
     if (auto s = Selector(block).select(predicate_)) return take_block(block, s->sel, s->count);
     return filter_with_bitmap(block);
   }

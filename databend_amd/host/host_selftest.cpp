@@ -186,21 +186,21 @@ static void test_selector() {
   std::vector<int64_t> exp;
   for (int64_t i = 0; i < n; ++i) if (c[i] < 0.5 && ((va[i] && a[i] > 10) || d[i] || b[i] <= 0) && (va[i] && a[i] != b[i])) exp.push_back(b[i] * 1000 + i % 1000);
   FilterExecutor fe(tree);
-  DataBlock out = fe.filter(block), out2 = fe.filter_with_bitmap(block);
+  DataBlock out = fe.filter_with_selector(block), out2 = fe.filter_with_bitmap(block);
   CHECK(out.num_rows == (int64_t)exp.size() && out2.num_rows == out.num_rows);
   // an And over ascending lists keeps row order only inside each Or branch: compare as multisets with the Bitmap path, and the And-only
   // tree in exact order
   auto key = [](const DataBlock& blk) { std::multiset<int64_t> m; auto bb = blk.columns[1].to_vector<int64_t>(); auto cc = blk.columns[2].to_vector<double>(); for (size_t i = 0; i < bb.size(); ++i) m.insert(bb[i] * 100000 + (int64_t)(cc[i] * 1000)); return m; };
   CHECK(key(out) == key(out2));
   Expr conj = Expr::call("and_filters", {p3, p2, p4});
-  DataBlock o3 = FilterExecutor(conj).filter(block), o4 = FilterExecutor(conj).filter_with_bitmap(block);
+  DataBlock o3 = FilterExecutor(conj).filter_with_selector(block), o4 = FilterExecutor(conj).filter_with_bitmap(block);
   CHECK(o3.num_rows == o4.num_rows && o3.columns[1].to_vector<int64_t>() == o4.columns[1].to_vector<int64_t>() && o3.columns[2].to_vector<double>() == o4.columns[2].to_vector<double>());
   // arithmetic under a comparison: not a Selector leaf -> the Bitmap path, same API
   Expr other = Expr::call("gt", {Expr::call("plus", {col(1, I64, "b"), col(1, I64, "b")}), Expr::constant(Scalar::Int(DBHIP_T_I64, 10))});
   CHECK(!Selector(block).select(other).has_value());
   int64_t cnt = 0;
   for (int64_t i = 0; i < n; ++i) cnt += 2 * b[i] > 10;
-  CHECK(FilterExecutor(other).filter(block).num_rows == cnt);
+  CHECK(FilterExecutor(other).filter_with_selector(block).num_rows == cnt && FilterExecutor(other).filter(block).num_rows == cnt);
 }
 
 static void test_q1_plan() {
