@@ -220,6 +220,45 @@ __device__ __forceinline__ void atomic_add_u192(uint64_t* p, uint64_t lo, uint64
   if (addext) atomicAdd((unsigned long long*)(p + 2), (unsigned long long)addext);
 }
 
+// MIN / MAX over Decimal128 (r03): the state is THREE words — [0] the high 64 bits with the sign flipped (so that unsigned order
+// is value order), [1] the has-value word like every other min / max state, [2] the low 64 bits — compared lexicographically as
+// ([0], [2]). No 128-bit atomic exists, so a concurrent merge takes a PER-STATE SPIN LOCK in bit 63 of the has word: try-lock inside
+// the loop body (a lane that gets the lock does its compare-and-store and releases before the wave iterates again, so lanes of one
+// wave that want the same state cannot dead-lock each other); values go through agent-scope loads / stores, the release store of
+// the has word publishes them. After a kernel the word is 0 or 1 again. Layouts with such a state stay on the row path.
+#define GB_MM_LOCK (1ULL << 63)
+__host__ __device__ __forceinline__ bool gb_minmax_wide(const GbLayout& L, int a) {
+  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_type[a] == DBHIP_T_DEC128;
+}
+__device__ __forceinline__ bool gb_mm_better(bool is_min, uint64_t hi, uint64_t lo, uint64_t chi, uint64_t clo) {
+  return is_min ? (hi < chi || (hi == chi && lo < clo)) : (hi > chi || (hi == chi && lo > clo));
+}
+__device__ __forceinline__ void gb_minmax_wide_locked(bool is_min, uint64_t* dst, const uint64_t* v) {
+  if (!v[1]) return;
+  unsigned long long* has = (unsigned long long*)(dst + 1);
+  bool done = false;
+  while (!done) {
+    const unsigned long long old = atomicOr(has, (unsigned long long)GB_MM_LOCK);
+    if (!(old & GB_MM_LOCK)) {
+      const uint64_t chi = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t clo = __hip_atomic_load(dst + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(old & 1ULL) || gb_mm_better(is_min, v[0], v[2], chi, clo)) {
+        __hip_atomic_store(dst, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(has, 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      done = true;
+    } else {
+      __builtin_amdgcn_s_sleep(8);   // back off: thousands of waves hammering one word starve the holder's own accesses
+    }
+  }
+}
+__device__ __forceinline__ void gb_minmax_wide_plain(bool is_min, uint64_t* dst, const uint64_t* v) {   // ONE writer
+  if (!v[1]) return;
+  if (!dst[1] || gb_mm_better(is_min, v[0], v[2], dst[0], dst[2])) { dst[0] = v[0]; dst[2] = v[2]; }
+  dst[1] = 1;
+}
+
 // merge one state contribution `v` (agg_words words) into the state at `dst`
 __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64_t* dst,
                                                 const uint64_t* v) {
@@ -239,12 +278,14 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
       if (fw && v[fw]) atomicOr((unsigned long long*)(dst + fw), 1ULL);
     } break;
     case DBHIP_AGG_MIN:
+      if (L.agg_words[a] == 3) { gb_minmax_wide_locked(true, dst, v); break; }
       if (v[1]) {
         atomicMin((unsigned long long*)dst, (unsigned long long)v[0]);
         atomicOr((unsigned long long*)(dst + 1), 1ULL);
       }
       break;
     default:  // MAX
+      if (L.agg_words[a] == 3) { gb_minmax_wide_locked(false, dst, v); break; }
       if (v[1]) {
         atomicMax((unsigned long long*)dst, (unsigned long long)v[0]);
         atomicOr((unsigned long long*)(dst + 1), 1ULL);
@@ -285,12 +326,14 @@ __device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* 
       if (fw && v[fw]) GB_WG_OR(dst + fw, 1ULL);
     } break;
     case DBHIP_AGG_MIN:
+      if (L.agg_words[a] == 3) { gb_minmax_wide_locked(true, dst, v); break; }
       if (v[1]) {
         __hip_atomic_fetch_min((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         GB_WG_OR(dst + 1, 1ULL);
       }
       break;
     default:  // MAX
+      if (L.agg_words[a] == 3) { gb_minmax_wide_locked(false, dst, v); break; }
       if (v[1]) {
         __hip_atomic_fetch_max((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         GB_WG_OR(dst + 1, 1ULL);
@@ -323,9 +366,11 @@ __device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_
       if (fw && v[fw]) dst[fw] |= 1ULL;
     } break;
     case DBHIP_AGG_MIN:
+      if (L.agg_words[a] == 3) { gb_minmax_wide_plain(true, dst, v); break; }
       if (v[1]) { dst[0] = v[0] < dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
       break;
     default:  // MAX
+      if (L.agg_words[a] == 3) { gb_minmax_wide_plain(false, dst, v); break; }
       if (v[1]) { dst[0] = v[0] > dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
       break;
   }
@@ -334,7 +379,7 @@ __device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_
 // identity element of a state
 __device__ __forceinline__ void gb_state_identity(const GbLayout& L, int a, uint64_t* dst) {
   for (int k = 0; k < L.agg_words[a]; ++k) dst[k] = 0;
-  if (L.agg_kind[a] == DBHIP_AGG_MIN) dst[0] = ~0ULL;
+  if (L.agg_kind[a] == DBHIP_AGG_MIN) { dst[0] = ~0ULL; if (L.agg_words[a] == 3) dst[2] = ~0ULL; }
 }
 
 // state contribution of ONE input row for aggregate a from the argument's canonical words (w0, w1) and validity
@@ -356,7 +401,8 @@ __device__ __forceinline__ void gb_row_contrib(const GbLayout& L, int a, uint64_
       if (fw) v[fw] = valid ? 1 : 0;
     } break;
     default:  // MIN / MAX
-      v[0] = ord_encode(w0, L.agg_type[a]);
+      if (L.agg_words[a] == 3) { v[0] = w1 ^ (1ULL << 63); v[2] = w0; }   // Decimal128: (sign-flipped high word, low word)
+      else v[0] = ord_encode(w0, L.agg_type[a]);
       v[1] = valid ? 1 : 0;
       break;
   }

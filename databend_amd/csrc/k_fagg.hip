@@ -436,6 +436,7 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
   int words = 0;
   for (int a = 0; a < L.naggs; ++a) {
     if (L.agg_off[a] != L.agg_off[0] + words) return false;
+    if ((L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_words[a] == 3) return false;   // Decimal128 min / max: row path
     words += L.agg_words[a];
   }
   return words <= FA_MAXW && L.hash_word == L.nkey_words && L.agg_off[0] == L.hash_word + 1;
@@ -515,8 +516,10 @@ static int32_t fa_build_args(const GbLayout& L, const dbhip_col* keys, const dbh
         else put(W_ADD1, C_LO, 0);
         if (fw) put(W_OR, C_FLAG, 0);
         break;
-      case DBHIP_AGG_MIN: put(W_MIN, C_ENC, 0); put(W_CONT, C_FLAG, 0); general = true; break;
-      default: put(W_MAX, C_ENC, 0); put(W_CONT, C_FLAG, 0); general = true; break;
+      case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
+        if (L.agg_words[a] == 3) { set_error("fused aggregation: min / max over Decimal128 stays on the row path"); return DBHIP_ERR_UNSUPPORTED; }
+        if (L.agg_kind[a] == DBHIP_AGG_MIN) put(W_MIN, C_ENC, 0); else put(W_MAX, C_ENC, 0);
+        put(W_CONT, C_FLAG, 0); general = true; break;
     }
   }
   A.nwords = nwords;

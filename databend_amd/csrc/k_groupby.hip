@@ -462,10 +462,12 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
           case DBHIP_AGG_MIN:
             out[0] = wave_min_u64((mine && v[1]) ? v[0] : ~0ULL);
             out[1] = wave_max_u64(mine ? v[1] : 0);
+            if (L.agg_words[a] == 3) out[2] = wave_min_u64((mine && v[1] && v[0] == out[0]) ? v[2] : ~0ULL);   // low word among the rows that hold the best high word
             break;
           default:
             out[0] = wave_max_u64((mine && v[1]) ? v[0] : 0ULL);
             out[1] = wave_max_u64(mine ? v[1] : 0);
+            if (L.agg_words[a] == 3) out[2] = wave_max_u64((mine && v[1] && v[0] == out[0]) ? v[2] : 0ULL);
             break;
         }
         if (lane_id() == leader) gb_atomic_merge(L, a, d + L.agg_off[a], out);
@@ -682,6 +684,11 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           }
           break;
         default: {  // MIN / MAX (no value seen: the type's default, MinMaxAnyState::merge_result push_default)
+          if (L.agg_words[a] == 3) {   // Decimal128
+            ((uint64_t*)o)[2 * i] = s[1] ? s[2] : 0;
+            ((uint64_t*)o)[2 * i + 1] = s[1] ? (s[0] ^ (1ULL << 63)) : 0;
+            break;
+          }
           uint64_t raw = s[1] ? ord_decode(s[0], L.agg_type[a]) : 0;
           switch (L.agg_type[a]) {
             case DBHIP_T_I8: case DBHIP_T_U8: case DBHIP_T_BOOL: ((uint8_t*)o)[i] = (uint8_t)raw; break;
@@ -808,7 +815,10 @@ __global__ __launch_bounds__(256) void gb_state_fields_kernel(GbLayout L, const 
         default: {  // MIN / MAX
           if (P.f[f] && s[1]) set_bit32(P.f[f], i);
           ++f;
-          if (P.f[f]) store_typed(P.f[f], i, L.agg_type[a], s[1] ? ord_decode(s[0], L.agg_type[a]) : 0);
+          if (P.f[f]) {
+            if (L.agg_words[a] == 3) { ((uint64_t*)P.f[f])[2 * i] = s[1] ? s[2] : 0; ((uint64_t*)P.f[f])[2 * i + 1] = s[1] ? (s[0] ^ (1ULL << 63)) : 0; }
+            else store_typed(P.f[f], i, L.agg_type[a], s[1] ? ord_decode(s[0], L.agg_type[a]) : 0);
+          }
           ++f;
           if (L.agg_nullable[a]) { if (P.f[f] && s[1]) set_bit32(P.f[f], i); ++f; }
         } break;
@@ -858,7 +868,8 @@ __global__ __launch_bounds__(256) void gb_states_from_fields_kernel(GbLayout L, 
           gb_load_words(F.f[f], i, w, &valid);
           ++f;
           if (L.agg_nullable[a]) { has = has && bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i); ++f; }
-          s[0] = ord_encode(w[0], L.agg_type[a]);
+          if (L.agg_words[a] == 3) { s[0] = w[1] ^ (1ULL << 63); s[2] = w[0]; }
+          else s[0] = ord_encode(w[0], L.agg_type[a]);
           s[1] = has ? 1 : 0;
         } break;
       }
@@ -937,11 +948,11 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
         if (d.arg_nullable) L->agg_flag[a] = words++;   // "seen a non-NULL row" (AggregateNullUnaryAdaptor<true>)
         break;
       case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
-        if (d.arg_type == DBHIP_T_DEC128 || d.arg_type == DBHIP_T_STRING || !key_type_ok(d.arg_type)) {
+        if (d.arg_type == DBHIP_T_STRING || !key_type_ok(d.arg_type)) {
           set_error("groupby: min/max on type %d stays on the CPU operator", d.arg_type);
           return DBHIP_ERR_UNSUPPORTED;
         }
-        words = 2;
+        words = d.arg_type == DBHIP_T_DEC128 ? 3 : 2;   // (value, has) — Decimal128: (high word, has, low word), gb_device.h
         break;
       default:
         set_error("groupby: unknown aggregate kind %d", d.kind);
@@ -1041,6 +1052,7 @@ int32_t reserve_arena_for_chunk(dbhip_groupby* g, hipStream_t s) {
   return reserve_arena(g, lb, s);
 }
 bool layout_has_strings(const GbLayout& L) { return L.str_w1_mask != 0; }
+bool layout_has_wide_minmax(const GbLayout& L);
 
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
 int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
@@ -1067,7 +1079,8 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
                        g->hash_mask, g->gid, g->ctrl, dc, g->arena);
     // (the wave-combining kernel only where the table is known to hold a handful of groups: on an empty table the first
     // merge may bring 50 K groups, r02y: 0.11 ms there against 0.02 ms for the plain kernel)
-    if ((g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048)
+    // (a Decimal128 min / max state is merged under a lock: always combine the rows of a wave first, one acquisition per wave and state)
+    if ((g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048 || layout_has_wide_minmax(g->L))
       hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
                          g->ctrl, dc, g->arena);
     else
@@ -1106,7 +1119,7 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
       continue;  // redo the (idempotent) probe against the bigger table
     }
     g->count_host = (int64_t)host_ctrl[0];
-    if (g->count_host <= 32) {
+    if (g->count_host <= 32 || layout_has_wide_minmax(g->L)) {
       hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n,
                          g->rows, g->gid, g->retry, g->ctrl, dc, g->arena);
     } else {
@@ -1480,8 +1493,13 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
   return DBHIP_OK;
 }
 
+bool layout_has_wide_minmax(const GbLayout& L) {
+  for (int a = 0; a < L.naggs; ++a) if (gb_minmax_wide(L, a)) return true;
+  return false;
+}
 bool fast_layout_ok(const GbLayout& L) {
-  return L.nkey_words <= FK_MAXKW && L.nkeys <= FK_MAXKW && L.naggs <= FK_MAXA && L.W <= 24;
+  // (a Decimal128 min / max state is merged under a per-state lock: row path only)
+  return L.nkey_words <= FK_MAXKW && L.nkeys <= FK_MAXKW && L.naggs <= FK_MAXA && L.W <= 24 && !layout_has_wide_minmax(L);
 }
 
 // add_block through the LDS pre-aggregation kernel, chunk by chunk. Returns -1 when the caller must
@@ -2643,6 +2661,7 @@ int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_n
   g->hash_mask = ~0ULL;
   g->part_min_rows = 262144;
   g->hint_groups = initial_capacity;
+  if (layout_has_wide_minmax(g->L)) { g->part_forbidden = 1; g->part_bits = -1; }   // row path only (see gb_minmax_wide_locked)
   hipStream_t s = resolve_stream(nullptr);
   if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
   hipError_t e = hipMalloc((void**)&g->ctrl, 128);   // [0..7] see above, [8] arena cursor, [9] long-string bytes of the current chunk

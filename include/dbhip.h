@@ -362,7 +362,8 @@ typedef enum {
   DBHIP_AGG_SUM = 1,         /* sum: i64/u64 wrapping, f64, DEC64->i64 wrapping,
                                 DEC128 -> i128 with overflow check when arg precision>18
                                 (aggregate_sum.rs:51-300,386-441)                    */
-  DBHIP_AGG_MIN = 2, DBHIP_AGG_MAX = 3  /* fixed-width arguments up to 8 bytes; Decimal128 / String: DBHIP_ERR_UNSUPPORTED */
+  DBHIP_AGG_MIN = 2, DBHIP_AGG_MAX = 3  /* fixed-width arguments incl. Decimal128 (a three-word state merged under a per-state lock: such tables
+                                          * aggregate on the row path only); String: DBHIP_ERR_UNSUPPORTED */
 } dbhip_agg_kind;
 
 typedef struct {

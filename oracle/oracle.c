@@ -750,9 +750,10 @@ static int agg_flag_off(const orc_agg_desc* d) { /* 0 = no flag */
 static int agg_state_size(const orc_agg_desc* d) {
   if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return d->arg_nullable ? 32 : 16;
   if (d->kind == ORC_AGG_SUM && d->arg_nullable) return 16; /* value + flag */
-  if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return 16; /* value + has flag */
+  if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return d->arg_type == ORC_T_DEC128 ? 32 : 16; /* value + has flag (Decimal128: 16-byte value) */
   return 8;
 }
+static int mm_has_off(const orc_agg_desc* d) { return d->arg_type == ORC_T_DEC128 ? 16 : 8; } /* MinMaxAnyState: Option<value> */
 
 static void index_alloc(orc_hashagg* h, size_t cap) {
   h->capacity = cap; h->mask = cap - 1; h->count = 0;
@@ -901,8 +902,18 @@ static int state_add(const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int
         else { uint64_t s; memcpy(&s, st, 8); s += v.cls == 0 ? (uint64_t)v.i : v.u; memcpy(st, &s, 8); }
         return 0;
       }
-    default: { /* MIN / MAX over OrderedFloat / ints */
+    default: { /* MIN / MAX over OrderedFloat / ints / Decimal128 (aggregate_min_max_any.rs: MinMaxAnyState<.., CmpMin / CmpMax>) */
       if (!valid) return 0;
+      if (d->arg_type == ORC_T_DEC128) {
+        uint64_t has128; memcpy(&has128, st + 16, 8);
+        i128 v128, cur128;
+        memcpy(&v128, (const uint8_t*)arg->data + 16 * (arg->is_scalar ? 0 : i), 16);
+        memcpy(&cur128, st, 16);
+        int take128 = !has128 || (d->kind == ORC_AGG_MIN ? v128 < cur128 : v128 > cur128);
+        if (take128) memcpy(st, &v128, 16);
+        has128 = 1; memcpy(st + 16, &has128, 8);
+        return 0;
+      }
       uint64_t has; memcpy(&has, st + 8, 8);
       val v = load_val(arg, i);
       val cur; memset(&cur, 0, sizeof cur); cur.cls = v.cls; cur.bits = v.bits;
@@ -1020,12 +1031,15 @@ int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* 
       if (out_agg_valid && out_agg_valid[a]) {
         uint8_t ok = 1;
         if (agg_flag_off(d)) ok = st[agg_flag_off(d)];
-        else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_nullable) { uint64_t hs; memcpy(&hs, st + 8, 8); ok = hs != 0; }
+        else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_nullable) { uint64_t hs; memcpy(&hs, st + mm_has_off(d), 8); ok = hs != 0; }
         out_agg_valid[a][r] = ok;
       }
       if (!out_aggs || !out_aggs[a]) continue;
       if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16);
-      else if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) {
+      else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_DEC128) {
+        uint64_t hs; memcpy(&hs, st + 16, 8);
+        if (hs) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16); else memset((uint8_t*)out_aggs[a] + 16 * r, 0, 16); /* push_default() */
+      } else if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) {
         int sz = t_size(d->arg_type);
         val v; memset(&v, 0, sizeof v); v.cls = t_cls(d->arg_type);
         if (v.cls == 2) memcpy(&v.f, st, 8); else if (v.cls == 0) memcpy(&v.i, st, 8); else memcpy(&v.u, st, 8);
@@ -1120,6 +1134,9 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
             i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;
           } else if (t_cls(ad->arg_type) == 2) { double x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
           else { uint64_t x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
+        } else if (ad->arg_type == ORC_T_DEC128) {
+          uint64_t hs; memcpy(&hs, sp + 16, 8);
+          if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1; tmp.data = sp; state_add(ad, d, &tmp, 0); }
         } else {
           uint64_t hs; memcpy(&hs, sp + 8, 8);
           if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1;
@@ -1195,6 +1212,12 @@ int orc_hashagg_flush_state_block(orc_hashagg* h, void* const* out_keys, uint8_t
         if (d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_fields[f] + 16 * r, st, 16); else memcpy((uint8_t*)out_fields[f] + 8 * r, st, 8);
         ++f;
         if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = st[agg_flag_off(d)]; ++f; }
+      } else if (d->arg_type == ORC_T_DEC128) {
+        uint64_t hs; memcpy(&hs, st + 16, 8);
+        ((uint8_t*)out_fields[f])[r] = hs != 0; ++f;
+        if (hs) memcpy((uint8_t*)out_fields[f] + 16 * r, st, 16); else memset((uint8_t*)out_fields[f] + 16 * r, 0, 16);
+        ++f;
+        if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = hs != 0; ++f; }
       } else {
         uint64_t hs; memcpy(&hs, st + 8, 8);
         ((uint8_t*)out_fields[f])[r] = hs != 0; ++f;

@@ -121,7 +121,7 @@ def test_nullable_sum_min_max_yield_null_for_all_null_groups(gpu, oracle, n, car
 SB_KEYS = ([T.T_I64, T.T_STRING], [1, 0])
 SB_AGGS = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_SUM, T.T_DEC128, 31, 4, 1), (T.AGG_SUM, T.T_F64, 0, 0, 1),
            (T.AGG_MIN, T.T_I32, 0, 0, 0), (T.AGG_MAX, T.T_F64, 0, 0, 1), (T.AGG_COUNT, T.T_I64, 0, 0, 1), (T.AGG_SUM, T.T_DEC64, 15, 2, 1),
-           (T.AGG_MAX, T.T_DATE, 0, 0, 0)]
+           (T.AGG_MAX, T.T_DATE, 0, 0, 0), (T.AGG_MIN, T.T_DEC128, 31, 4, 1), (T.AGG_MAX, T.T_DEC128, 31, 4, 0)]   # r03: min / max over Decimal128
 
 
 def sb_data(n, card, seed):
@@ -140,7 +140,8 @@ def sb_gpu_cols(gpu, d, lo, hi):
     keys = [gpu.Column.from_numpy(d["k"][sl], validity=d["kv"][sl]), gpu.Column.strings(d["s"][sl])]
     args = [gpu.Column.from_numpy(d["a"][sl]), None, gpu.Column.decimal128(d["dd"][sl], 31, 4, validity=av), gpu.Column.from_numpy(d["f"][sl], validity=av),
             gpu.Column.from_numpy(d["i"][sl]), gpu.Column.from_numpy(d["f"][sl], validity=av), gpu.Column.from_numpy(d["a"][sl], validity=av),
-            gpu.Column.from_numpy(d["dec"][sl], T.T_DEC64, validity=av, precision=15, scale=2), gpu.Column.from_numpy(d["dt"][sl], T.T_DATE)]
+            gpu.Column.from_numpy(d["dec"][sl], T.T_DEC64, validity=av, precision=15, scale=2), gpu.Column.from_numpy(d["dt"][sl], T.T_DATE),
+            gpu.Column.decimal128(d["dd"][sl], 31, 4, validity=av), gpu.Column.decimal128(d["dd"][sl], 31, 4)]
     return keys, args
 
 
@@ -151,7 +152,8 @@ def sb_host_cols(d, lo, hi):
     keys = [O.HostCol(T.T_I64, d["k"][sl], d["kv"][sl]), O.HostCol(T.T_STRING, v, buffers=[buf])]
     args = [O.HostCol(T.T_I64, d["a"][sl]), None, O.HostCol(T.T_DEC128, O.i128_array(d["dd"][sl]), av, 31, 4), O.HostCol(T.T_F64, d["f"][sl], av),
             O.HostCol(T.T_I32, d["i"][sl]), O.HostCol(T.T_F64, d["f"][sl], av), O.HostCol(T.T_I64, d["a"][sl], av),
-            O.HostCol(T.T_DEC64, d["dec"][sl], av, 15, 2), O.HostCol(T.T_DATE, d["dt"][sl])]
+            O.HostCol(T.T_DEC64, d["dec"][sl], av, 15, 2), O.HostCol(T.T_DATE, d["dt"][sl]),
+            O.HostCol(T.T_DEC128, O.i128_array(d["dd"][sl]), av, 31, 4), O.HostCol(T.T_DEC128, O.i128_array(d["dd"][sl]), None, 31, 4)]
     return keys, args
 
 
@@ -473,3 +475,62 @@ def test_fixed_block_exchange_refuses_tables_with_long_string_keys(gpu):
     recv = D.GroupBy([T.T_STRING], aggs, [0])
     recv.replace_with_blocks(buf.ptr, 4, 256)
     assert sorted(recv.result()) == sorted(short_t.result())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# min / max over Decimal128 (r03): a three-word state merged under a per-state lock, row path only
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,card", [(7, 2), (5000, 3), (400_000, 4), (300_000, 2500), (200_000, 150_000)])
+def test_min_max_over_decimal128(gpu, oracle, n, card):
+    """values spread over the whole i128 range of a Decimal(38, s) — equal high words with different low words, negative values, exact
+    duplicates — in two blocks, few groups (every wave fights for the same states) and many; nullable and not; against the oracle,
+    and merged across two tables through serialized rows (what the exchange does)."""
+    rng = np.random.default_rng(n * 31 + card)
+    k = rng.integers(0, card, n).astype(np.int64)
+    hi = rng.integers(-3, 4, n)                               # few distinct high parts: the low word decides often
+    lo = rng.integers(0, 2**63, n, dtype=np.int64)
+    vals = [int(h) * 2**64 + int(l) * (1 if i % 3 else 2) % 2**64 for i, (h, l) in enumerate(zip(hi.tolist(), lo.tolist()))]
+    vals = [v if abs(v) < 10**38 else v % 10**37 for v in vals]
+    if n > 10:
+        vals[5] = vals[3]
+        vals[7] = -(10**38 - 1)
+        vals[9] = 10**38 - 1
+    av = (rng.integers(0, 4, n) > 0) & (k % 5 != 0)
+    key_types, key_nullable = [T.T_I64], [0]
+    aggs = [(T.AGG_MIN, T.T_DEC128, 38, 2, 1), (T.AGG_MAX, T.T_DEC128, 38, 2, 1), (T.AGG_MIN, T.T_DEC128, 38, 2, 0), (T.AGG_MAX, T.T_DEC128, 38, 2, 0),
+            (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MAX, T.T_I64, 0, 0, 0)]
+
+    def add(g, lo_, hi_):
+        sl = slice(lo_, hi_)
+        dn = gpu.Column.decimal128(vals[sl], 38, 2, validity=av[sl])
+        dd = gpu.Column.decimal128(vals[sl], 38, 2)
+        g.add_block([gpu.Column.from_numpy(k[sl])], [dn, dn, dd, dd, None, gpu.Column.from_numpy(k[sl])], hi_ - lo_)
+
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    half = n // 2
+    add(g, 0, half)
+    add(g, half, n)
+    got = g.result()
+    hv = O.i128_array(vals)
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, [O.HostCol(T.T_I64, k)],
+                       [O.HostCol(T.T_DEC128, hv, av, 38, 2), O.HostCol(T.T_DEC128, hv, av, 38, 2), O.HostCol(T.T_DEC128, hv, None, 38, 2),
+                        O.HostCol(T.T_DEC128, hv, None, 38, 2), None, O.HostCol(T.T_I64, k)], n)
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert norm(got) == norm(exp)
+    # python statement, independent of both
+    by = {}
+    for key, v, ok in zip(k.tolist(), vals, av.tolist()):
+        e = by.setdefault(key, [None, None, None, None])
+        if ok:
+            e[0] = v if e[0] is None else min(e[0], v)
+            e[1] = v if e[1] is None else max(e[1], v)
+        e[2] = v if e[2] is None else min(e[2], v)
+        e[3] = v if e[3] is None else max(e[3], v)
+    assert {r[0]: list(r[1:5]) for r in got} == by
+    # two tables merged through serialized rows (the exchange): same result
+    g1, g2 = gpu.GroupBy(key_types, aggs, key_nullable), gpu.GroupBy(key_types, aggs, key_nullable)
+    add(g1, 0, half)
+    add(g2, half, n)
+    g1.merge_serialized(g2.flush_serialized())
+    assert norm(g1.result()) == norm(exp)
