@@ -64,6 +64,7 @@ struct HnswView {   // by-value kernel argument
 
 struct dbhip_hnsw_impl {
   HnswView v;
+  int small_search_off;   // a batch outgrew the LDS-resident search tables on THIS index: later batches take the general kernel directly
   int ef_construct;
   int64_t n_upper;
   std::vector<int32_t> level_host;
@@ -947,6 +948,7 @@ int32_t create_common(const float* vectors, int64_t n, int32_t dim, int32_t dist
   if (!h) return DBHIP_ERR_HIP;
   ImplGuard guard(h);
   h->n_owned = 0;
+  h->small_search_off = 0;
   HnswView& V = h->v;
   memset(&V, 0, sizeof(V));
   V.n = n; V.dim = dim; V.adim = adim; V.distance = dc; V.m = m; V.m0 = 2 * m;
@@ -1224,7 +1226,7 @@ int32_t dbhip_hnsw_search(dbhip_hnsw* hh, const float* queries_dev, int32_t nq, 
   A.queries = queries_dev; A.nq = nq; A.limit = limit; A.out_ids = out_ids_dev; A.out_dist = out_dist_dev; A.vis = vis;
   A.next = ctl; A.err = ctl + 1;
   static const bool small_off = getenv("DBHIP_HNSW_SMALL") && atoi(getenv("DBHIP_HNSW_SMALL")) == 0;
-  const bool small = limit * 4 <= 64 && !small_off;
+  const bool small = limit * 4 <= 64 && !small_off && !h->small_search_off;
   unsigned int hc[2];
   kernel_timer_start(s);
   if (small) hipLaunchKernelGGL(hn_search_kernel<true>, dim3(grid), dim3(64), 0, s, h->v, A);
@@ -1233,7 +1235,8 @@ int32_t dbhip_hnsw_search(dbhip_hnsw* hh, const float* queries_dev, int32_t nq, 
   DBHIP_LAUNCH_CHECK();
   DBHIP_CHECK(hipMemcpyAsync(hc, ctl, 8, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
-  if (small && (hc[1] & 12u)) {   // some walk outgrew the LDS-resident tables: the whole batch again, general kernel (rare)
+  if (small && (hc[1] & 12u)) {   // some walk outgrew the LDS-resident tables: the whole batch again through the general kernel, and
+    h->small_search_off = 1;       // this index (its data: i.i.d. vectors make every walk long) stays on it from now on
     DBHIP_CHECK(hipMemsetAsync(ctl, 0, 16, s));
     hipLaunchKernelGGL(hn_search_kernel<false>, dim3(grid), dim3(64), 0, s, h->v, A);
     DBHIP_LAUNCH_CHECK();
