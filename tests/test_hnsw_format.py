@@ -158,3 +158,21 @@ def test_saved_index_opens_and_searches_identically(gpu, distance):
     assert F.read_graph_links(ecols[0])[0].shape == (0,)
     for x in (idx, opened, same, e):
         x.destroy()
+
+
+def test_graph_links_bytes_of_a_hand_worked_graph():
+    """Three points, m = 2 (m0 = 4), levels [0, 1, 0]; lists p0/L0 = [1, 2], p1/L0 = [0, 2], p1/L1 = [], p2/L0 = [1]. Every byte below was
+    derived BY HAND from serializer.rs / bitpacking_links.rs / bitpacking_ordered.rs (not by running the writer): back_index = [1, 0, 2]
+    (most levels first), reindex = [1, 0, 2]; level offsets [0, 3]; bits_per_unsorted = 8; each non-empty list = 5-bit header 0
+    (bits_per_sorted = 8) + 8-bit deltas, LSB first, padded to a byte; offsets [0, 3, 6, 8, 8] -> base_bits 4, delta_bits 2,
+    chunk_len_log2 1 (3 bytes, the smallest of the eight candidates) + the 7-byte 0xFF tail."""
+    levels = [0, 1, 0]
+    lists = [np.array([1, 2], np.uint32), np.array([0, 2], np.uint32), np.array([], np.uint32), np.array([1], np.uint32)]
+    header = struct.pack("<QQQQ", 3, 0xFFFFFFFFFFFFFF01, 2, 8) + struct.pack("<QBBB", 5, 4, 2, 1) + struct.pack("<QQ", 2, 4) + b"\0" * 5
+    expected = (header + struct.pack("<QQ", 0, 3) + struct.pack("<III", 1, 0, 2)
+                + bytes([0x20, 0x20, 0x00]) + bytes([0x00, 0x40, 0x00]) + bytes([0x20, 0x00])
+                + bytes([0x30, 0x26, 0x38]) + b"\xff" * 7)
+    got = F.write_graph_links(levels, lists, 2, 4)
+    assert got == expected, (got.hex(), expected.hex())
+    lv, ls, m, m0 = F.read_graph_links(expected)
+    assert lv.tolist() == levels and [x.tolist() for x in ls] == [[1, 2], [0, 2], [], [1]] and (m, m0) == (2, 4)
