@@ -1431,11 +1431,58 @@ class HNSWIndex {
   // HNSWIndex::build (hnsw.rs:142-305): `column` = Vector(dim) of Float32; distance: DBHIP_VEC_COSINE / L1 / L2
   static HNSWIndex build(size_t m, size_t ef_construct, const Column& column, int32_t distance, uint64_t seed = 1) {
     HNSWIndex ix;
-    ix.dim_ = column.type.dim;
+    ix.dim_ = column.type.dim; ix.n_ = column.len; ix.m_ = m;
     check(dbhip_hnsw_build((const float*)column.data->ptr(), column.len, (int32_t)ix.dim_, distance, (int32_t)m, (int32_t)ef_construct, seed, &ix.h_, nullptr));
     return ix;
   }
-  HNSWIndex(HNSWIndex&& o) noexcept : h_(o.h_), dim_(o.dim_) { o.h_ = nullptr; }
+  // the deterministic build (given levels, sequential insertion, the reference's summation order): dbhip_hnsw_build_sequential
+  static HNSWIndex build_sequential(size_t m, size_t ef_construct, const Column& column, int32_t distance, const std::vector<int32_t>& levels) {
+    HNSWIndex ix;
+    ix.dim_ = column.type.dim; ix.n_ = column.len; ix.m_ = m;
+    check(dbhip_hnsw_build_sequential((const float*)column.data->ptr(), column.len, (int32_t)ix.dim_, distance, (int32_t)m, (int32_t)ef_construct,
+                                      levels.data(), &ix.h_, nullptr));
+    return ix;
+  }
+  // what HNSWIndex::build hands to the index writer and HNSWIndex::open gets back (hnsw.rs:62-98, 237-300): the graph, the quantiser's
+  // metadata and the encoded vectors; the byte formats of the four Binary columns are databend_amd/hnsw_format.py's
+  struct Stored {
+    std::vector<int32_t> levels; std::vector<uint32_t> links; std::vector<int32_t> nlinks; uint32_t entry_point = 0; int32_t entry_level = 0;
+    float alpha = 0, offset = 0, multiplier = 0; int32_t actual_dim = 0; std::vector<uint8_t> encoded;
+  };
+  Stored store() const {
+    Stored s;
+    s.levels.resize((size_t)(n_ > 0 ? n_ : 1));
+    int64_t nlists = 0;
+    check(dbhip_hnsw_export_graph(h_, s.levels.data(), nullptr, nullptr, &nlists, &s.entry_point, &s.entry_level, nullptr));
+    s.levels.resize((size_t)n_);
+    s.nlinks.resize((size_t)(nlists > 0 ? nlists : 1));
+    check(dbhip_hnsw_export_graph(h_, nullptr, nullptr, s.nlinks.data(), nullptr, nullptr, nullptr, nullptr));
+    s.nlinks.resize((size_t)nlists);
+    int64_t total = 0;
+    for (int32_t c : s.nlinks) total += c;
+    s.links.resize((size_t)(total > 0 ? total : 1));
+    check(dbhip_hnsw_export_graph(h_, nullptr, s.links.data(), nullptr, nullptr, nullptr, nullptr, nullptr));
+    s.links.resize((size_t)total);
+    check(dbhip_hnsw_meta(h_, &s.alpha, &s.offset, &s.multiplier, &s.actual_dim));
+    Buf enc = make_buf((size_t)(n_ > 0 ? n_ : 1) * (size_t)(s.actual_dim + 4) + 64);
+    check(dbhip_hnsw_encoded(h_, enc->ptr(), nullptr));
+    s.encoded.resize((size_t)n_ * (size_t)(s.actual_dim + 4));
+    if (!s.encoded.empty()) enc->download(s.encoded.data(), s.encoded.size());
+    return s;
+  }
+  // HNSWIndex::open (hnsw.rs:62-98): no original vectors, the index only searches
+  static HNSWIndex open(int32_t distance, size_t dim, size_t m, const Stored& s) {
+    HNSWIndex ix;
+    ix.dim_ = dim; ix.n_ = (int64_t)s.levels.size(); ix.m_ = m;
+    Buf enc = make_buf(s.encoded.size() + 64);
+    if (!s.encoded.empty()) enc->upload(s.encoded.data(), s.encoded.size());
+    const uint32_t zero = 0; const int32_t zero_i = 0;
+    check(dbhip_hnsw_open((const uint8_t*)enc->ptr(), s.alpha, s.offset, s.multiplier, ix.n_, (int32_t)dim, distance, (int32_t)m, s.levels.empty() ? &zero_i : s.levels.data(),
+                          s.links.empty() ? &zero : s.links.data(), s.nlinks.empty() ? &zero_i : s.nlinks.data(), s.entry_point, s.entry_level, &ix.h_, nullptr));
+    check(dbhip_stream_sync(nullptr));   // `enc` is only read while the index is being made
+    return ix;
+  }
+  HNSWIndex(HNSWIndex&& o) noexcept : h_(o.h_), dim_(o.dim_), n_(o.n_), m_(o.m_) { o.h_ = nullptr; }
   HNSWIndex(const HNSWIndex&) = delete;
   ~HNSWIndex() { if (h_) dbhip_hnsw_destroy(h_); }
   // HNSWIndex::search (hnsw.rs:100-118), ef = 4 * limit inside: -> (row ids u32 [nq][limit], distances f32 [nq][limit])
@@ -1450,6 +1497,8 @@ class HNSWIndex {
   HNSWIndex() = default;
   dbhip_hnsw* h_ = nullptr;
   size_t dim_ = 0;
+  int64_t n_ = 0;
+  size_t m_ = 0;
 };
 
 // ---- sort (kernels/sort.rs:91-113) -----------------------------------------------------------------

@@ -356,6 +356,28 @@ static void test_left_joins() {
   }
 }
 
+static void test_hnsw_sequential_build_and_open() {
+  // the deterministic build gives the same graph twice; store() -> open() searches identically without the original vectors
+  const int dim = 12; const int64_t n = 1500;
+  std::mt19937 rng(8);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<float> base((size_t)n * dim);
+  for (auto& x : base) x = nd(rng);
+  std::vector<int32_t> levels((size_t)n);
+  for (auto& l : levels) { const double u = ((double)(rng() % 1000000) + 0.5) / 1000000.0; l = (int32_t)std::llround(-std::log(u) / std::log(8.0)); }
+  Column col = Column::from_vector(DataType::Vector(dim), base);
+  HNSWIndex a = HNSWIndex::build_sequential(8, 32, col, DBHIP_VEC_L2, levels), b = HNSWIndex::build_sequential(8, 32, col, DBHIP_VEC_L2, levels);
+  HNSWIndex::Stored sa = a.store(), sb = b.store();
+  CHECK(sa.levels == levels && sa.links == sb.links && sa.nlinks == sb.nlinks && sa.entry_point == sb.entry_point && sa.encoded == sb.encoded);
+  HNSWIndex o = HNSWIndex::open(DBHIP_VEC_L2, dim, 8, sa);
+  std::vector<float> q((size_t)64 * dim);
+  for (auto& x : q) x = nd(rng);
+  Column qc = Column::from_vector(DataType::Vector(dim), q);
+  auto r1 = a.search(10, qc), r2 = o.search(10, qc);
+  CHECK(r1.first == r2.first);
+  for (size_t i = 0; i < r1.second.size(); ++i) CHECK(r1.second[i] == r2.second[i] || (r1.second[i] != r1.second[i] && r2.second[i] != r2.second[i]));
+}
+
 static void test_right_joins() {
   // right / right-semi / right-anti / full over TWO probe blocks (the scan map lives across blocks), against std::multimap
   const int64_t nb = 5000, np = 12000;
@@ -523,6 +545,7 @@ int main() {
     test_q1_plan();
     test_join_and_sort();
     test_left_joins();
+    test_hnsw_sequential_build_and_open();
     test_right_joins();
     test_kmeans();
     test_hnsw_index();
