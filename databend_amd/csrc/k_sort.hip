@@ -14,6 +14,7 @@
 //               the tile; (key, row id) pairs move to their final position of this pass
 // Nullable keys get one extra (most significant) pass on the null flag. Ties end up in ascending
 // row-id order (stable), which is one of the orders the reference may produce.
+#include <string.h>
 #include "dev_common.h"
 #include "dev_scan.h"
 #include "runtime.h"
@@ -328,9 +329,154 @@ __global__ __launch_bounds__(256) void sort_select_emit_kernel(const uint64_t* e
   }
 }
 
+
+// ---- range partition of rows by sorted bounds (the distributed sort's scatter step, SURVEY §8e "sort") ----
+// Reference: a sorted stream is cut at every bound — rows <= bound[i] (in sort order) belong to partition i, rows after the last
+// bound to partition nbounds (sort_spill.rs:1008-1040 block_split_off_position / partition_point "first element that is
+// greater than bound"; BoundBlockStream :740-1005) — and partition i travels to node i % n (sort_exchange_injector.rs
+// SortBoundScatter / bound_scatter). On the device the rows need not be sorted first: partition(row) = number of bounds that
+// sort strictly before the row, a binary search per row over the bounds' order-preserving images (the same images the
+// radix sort uses, most significant first), which are staged in LDS.
+struct BoundKeys {
+  SortCol row[8];
+  SortCol bnd[8];
+  int nkeys;
+  int nimg;            // images per row: per key an optional null flag, then the value parts from the most significant down
+  uint8_t has_flag[8];
+  uint8_t parts[8];    // <= 255 only for short keys; long strings carry their count in row[k].nparts
+};
+
+__device__ __forceinline__ int bound_key_parts(const BoundKeys& bk, int k) { return bk.row[k].nparts ? bk.row[k].nparts : bk.parts[k]; }
+
+// image q of key k: q = 0 is the null flag when the key has one, then the value parts
+__device__ __forceinline__ uint64_t bound_image(const SortCol& c, uint32_t row, bool has_flag, int parts, int q) {
+  const bool valid = !c.validity || bit_get(c.validity, c.voff + row);
+  if (has_flag) {
+    if (q == 0) return (uint64_t)((valid ? 1 : 0) ^ (c.nulls_first ? 0 : 1));
+    --q;
+  }
+  if (!valid) return 0;
+  const uint64_t e = sort_encode(c, row, parts - 1 - q);
+  return c.desc ? ~e : e;
+}
+
+__global__ __launch_bounds__(256) void sort_bound_encode_kernel(BoundKeys bk, int nbounds, uint64_t* img) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nbounds) return;
+  int at = 0;
+  for (int k = 0; k < bk.nkeys; ++k) {
+    const int parts = bound_key_parts(bk, k), nq = parts + (bk.has_flag[k] ? 1 : 0);
+    for (int q = 0; q < nq; ++q) img[(size_t)j * bk.nimg + at++] = bound_image(bk.bnd[k], (uint32_t)j, bk.has_flag[k], parts, q);
+  }
+}
+
+// does bound j sort strictly before the row? `first` = the row's first image (computed once per row)
+__device__ __forceinline__ bool bound_before_row(const BoundKeys& bk, const uint64_t* img, int j, uint32_t row, uint64_t first) {
+  const uint64_t* b = img + (size_t)j * bk.nimg;
+  if (b[0] != first) return b[0] < first;
+  int at = 0;
+  for (int k = 0; k < bk.nkeys; ++k) {
+    const int parts = bound_key_parts(bk, k), nq = parts + (bk.has_flag[k] ? 1 : 0);
+    for (int q = 0; q < nq; ++q, ++at) {
+      if (at == 0) continue;
+      const uint64_t r = bound_image(bk.row[k], row, bk.has_flag[k], parts, q);
+      if (b[at] != r) return b[at] < r;
+    }
+  }
+  return false;
+}
+
+constexpr int BOUND_HIST_MAX = 2048;
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void sort_bound_partition_kernel(BoundKeys bk, int64_t n, int nbounds, const uint64_t* img_global,
+                                                                   uint32_t* out_part, unsigned long long* counts) {
+  extern __shared__ uint64_t bound_sh[];
+  const int nhist = nbounds + 1 <= BOUND_HIST_MAX ? nbounds + 1 : 0;
+  uint32_t* hist = (uint32_t*)bound_sh;
+  uint64_t* img_lds = bound_sh + (nhist + 1) / 2;
+  for (int i = threadIdx.x; i < nhist; i += blockDim.x) hist[i] = 0;
+  if (IN_LDS)
+    for (int i = threadIdx.x; i < nbounds * bk.nimg; i += blockDim.x) img_lds[i] = img_global[i];
+  __syncthreads();
+  const uint64_t* img = IN_LDS ? img_lds : img_global;
+  const int parts0 = bound_key_parts(bk, 0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t first = bound_image(bk.row[0], (uint32_t)i, bk.has_flag[0], parts0, 0);
+    int lo = 0, hi = nbounds;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bound_before_row(bk, img, mid, (uint32_t)i, first)) lo = mid + 1; else hi = mid;
+    }
+    out_part[i] = (uint32_t)lo;
+    if (nhist) atomicAdd(&hist[lo], 1u); else atomicAdd(&counts[lo], 1ULL);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nhist; i += blockDim.x)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t dbhip_sort_bound_partition(const dbhip_col* keys, const dbhip_col* bounds, const uint8_t* desc_host, const uint8_t* nulls_first_host,
+                                   int32_t nkeys, int64_t n, int64_t nbounds, uint32_t* out_part, uint64_t* out_counts, void* stream) {
+  DBHIP_REQUIRE(keys && nkeys >= 1 && nkeys <= 8, "dbhip_sort_bound_partition: 1..8 sort keys");
+  DBHIP_REQUIRE(n >= 0 && n < 0xFFFFFFFFLL && nbounds >= 0 && nbounds < (1 << 24), "dbhip_sort_bound_partition: row / bound count out of range");
+  DBHIP_REQUIRE(out_counts && (nbounds == 0 || bounds), "dbhip_sort_bound_partition: NULL buffer");
+  hipStream_t s = resolve_stream(stream);
+  DBHIP_CHECK(hipMemsetAsync(out_counts, 0, (size_t)(nbounds + 1) * 8, s));
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(out_part, "dbhip_sort_bound_partition: NULL out");
+  BoundKeys bk;
+  memset(&bk, 0, sizeof(bk));
+  bk.nkeys = nkeys;
+  const int grid = grid_for(n, 256);
+  for (int k = 0; k < nkeys; ++k) {
+    const int t = keys[k].type;
+    if (!(t >= DBHIP_T_BOOL && t <= DBHIP_T_STRING) || keys[k].is_scalar || (nbounds && (bounds[k].type != t || bounds[k].is_scalar))) {
+      set_error("dbhip_sort_bound_partition: key %d: unsupported type %d, a scalar, or the bound column has another type", k, t);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    int nparts = 0;
+    if (t == DBHIP_T_STRING) {   // the longest value of the rows AND the bounds decides the number of images, as in dbhip_sort_perm
+      uint32_t* flag = (uint32_t*)scratch(64, 7, s);
+      if (!flag) return DBHIP_ERR_HIP;
+      DBHIP_CHECK(hipMemsetAsync(flag, 0, 4, s));
+      hipLaunchKernelGGL(sort_max_len_kernel, dim3(grid), dim3(256), 0, s, (const uint32_t*)keys[k].data, n, flag);
+      if (nbounds) hipLaunchKernelGGL(sort_max_len_kernel, dim3(grid_for(nbounds, 256)), dim3(256), 0, s, (const uint32_t*)bounds[k].data, nbounds, flag);
+      uint32_t mx = 0;
+      DBHIP_CHECK(hipMemcpyAsync(&mx, flag, 4, hipMemcpyDeviceToHost, s));
+      DBHIP_CHECK(hipStreamSynchronize(s));
+      if (mx > 12) {
+        if (mx > 4096) { set_error("dbhip_sort_bound_partition: string key %d holds a %u-byte value (> 4096: keep the CPU operator for this block)", k, mx); return DBHIP_ERR_UNSUPPORTED; }
+        nparts = 1 + (int)((mx + 7) / 8);
+      }
+    }
+    const uint8_t d = desc_host ? desc_host[k] : 0, nf = nulls_first_host ? nulls_first_host[k] : 0;
+    bk.row[k] = SortCol{keys[k].data, keys[k].validity, keys[k].validity_offset, t, d, nf, nparts, keys[k].buffers};
+    if (nbounds) bk.bnd[k] = SortCol{bounds[k].data, bounds[k].validity, bounds[k].validity_offset, t, d, nf, nparts, bounds[k].buffers};
+    bk.has_flag[k] = (keys[k].validity || (nbounds && bounds[k].validity)) ? 1 : 0;
+    bk.parts[k] = (uint8_t)((t == DBHIP_T_DEC128 || t == DBHIP_T_STRING) ? 2 : 1);
+    bk.nimg += (nparts ? nparts : bk.parts[k]) + bk.has_flag[k];
+  }
+  const size_t img_bytes = (size_t)nbounds * bk.nimg * 8;
+  uint64_t* img = (uint64_t*)scratch(img_bytes + 256, 7, s);
+  if (!img) return DBHIP_ERR_HIP;
+  if (nbounds) hipLaunchKernelGGL(sort_bound_encode_kernel, dim3((unsigned)ceil_div(nbounds, 256)), dim3(256), 0, s, bk, (int)nbounds, img);
+  const int nhist = nbounds + 1 <= BOUND_HIST_MAX ? (int)nbounds + 1 : 0;
+  const size_t hist_bytes = (size_t)((nhist + 1) / 2) * 8;
+  if (img_bytes <= 32768)
+    hipLaunchKernelGGL(sort_bound_partition_kernel<true>, dim3(grid), dim3(256), hist_bytes + img_bytes, s, bk, n, (int)nbounds, img, out_part,
+                       (unsigned long long*)out_counts);
+  else
+    hipLaunchKernelGGL(sort_bound_partition_kernel<false>, dim3(grid), dim3(256), hist_bytes, s, bk, n, (int)nbounds, img, out_part,
+                       (unsigned long long*)out_counts);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
+  return DBHIP_OK;
+}
 
 int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const uint8_t* nulls_first_host,
                         int32_t nkeys, int64_t n, int64_t limit, uint32_t* out_perm, void* stream) {

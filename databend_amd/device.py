@@ -1316,6 +1316,32 @@ def sort_perm(cols, desc=None, nulls_first=None, limit=0):
     return out.to_numpy(np.uint32, m)
 
 
+def sort_perm_device(cols, desc=None, nulls_first=None, limit=0):
+    """sort_perm with the permutation left in HBM -> (DeviceBuffer of u32 row ids, their number)."""
+    n = cols[0].n
+    d = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in (desc or [0] * len(cols))])
+    nf = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in (nulls_first or [0] * len(cols))])
+    m = limit if 0 < limit < n else n
+    out = DeviceBuffer(max(m, 1) * 4)
+    check(lib().dbhip_sort_perm(_cols(cols), d, nf, len(cols), C.c_int64(n), C.c_int64(limit), C.c_void_p(out.ptr), None))
+    return out, m
+
+
+def sort_bound_partition(cols, bounds, desc=None, nulls_first=None):
+    """The distributed sort's range partition (sort_spill.rs:1008-1040 partition_point over Bounds; sort_exchange_injector.rs
+    SortBoundScatter): `bounds` = the same key columns holding the ordered bounds. Returns (DeviceBuffer of the u32 partition
+    of every row = number of bounds sorting strictly before it, numpy u64 rows per partition [nbounds + 1])."""
+    n = cols[0].n
+    nb = bounds[0].n if bounds else 0
+    d = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in (desc or [0] * len(cols))])
+    nf = (C.c_uint8 * len(cols))(*[int(bool(x)) for x in (nulls_first or [0] * len(cols))])
+    part = DeviceBuffer(max(n, 1) * 4)
+    counts = DeviceBuffer((nb + 1) * 8)
+    check(lib().dbhip_sort_bound_partition(_cols(cols), _cols(bounds) if nb else None, d, nf, len(cols), C.c_int64(n), C.c_int64(nb),
+                                           C.c_void_p(part.ptr), C.c_void_p(counts.ptr), None))
+    return part, counts.to_numpy(np.uint64, nb + 1)
+
+
 def merge_sorted_perm(cols, run_offsets, desc=None, nulls_first=None, limit=0):
     """k-way merge of sorted runs laid back to back (Merger / loser tree, sorts/core/merger.rs) -> u32 row ids."""
     n = int(run_offsets[-1]) if len(run_offsets) else 0

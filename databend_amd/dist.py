@@ -297,3 +297,79 @@ def q3_broadcast_join(shard, ops, dist, torch, device, limit=10):
     rows = [r for part in gathered for r in part]
     rows.sort(key=lambda r: (-r[1], r[2], r[0]))
     return rows[:limit] if limit else rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Distributed sort (SURVEY §8e "sort": sample -> range-partition -> all-to-all -> local sort). The reference sorts a table
+# across nodes by cutting every node's rows at the same global Bounds (sorts/sort_broadcast.rs:150-197: each node merges its
+# samples into Bounds, broadcasts them, merges + dedups what it received; sorts/sort_spill.rs:740-1040 cuts the sorted streams
+# at each bound: rows <= bound[i] belong to range i; service/.../sort/sort_exchange_injector.rs SortBoundScatter sends range i
+# to node i % n) and merges the ranges it receives. Device plan: the rows are NOT sorted before the exchange (one sort per row
+# instead of sort + merge) — every rank takes a strided sample of its key columns, the samples are all-gathered, ordered and
+# deduplicated into world - 1 bounds (sort_bounds.balanced_cuts: equal shares of the samples, so rank r receives exactly range
+# r — the fewest, largest messages on xGMI; the reference keeps every distinct sample as a bound and deals the ranges round
+# robin), one kernel gives every row its range (dbhip_sort_bound_partition), the columns are grouped by range and
+# exchanged with one all_to_all_single per column, and each rank sorts what it received. The concatenation of the ranks'
+# outputs in rank order is the sorted table.
+# ---------------------------------------------------------------------------------------------------------------------
+def alltoall_columns(cols, send_counts, dist, torch):
+    """cols = equally long 1-D tensors whose rows are grouped by destination rank (send_counts[r] rows for rank r)."""
+    world = dist.get_world_size()
+    dev = cols[0].device
+    send_cnt = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=dev)
+    recv_cnt = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_cnt, send_cnt)
+    rc = [int(x) for x in recv_cnt.tolist()]
+    out = []
+    for c in cols:
+        recv = torch.empty(sum(rc), dtype=c.dtype, device=dev)
+        dist.all_to_all_single(recv, c.contiguous(), output_split_sizes=rc, input_split_sizes=[int(x) for x in send_counts])
+        out.append(recv)
+    return out, rc
+
+
+def range_partitioned_sort(cols, keys, ops, dist, torch, desc=None, nulls_first=None, valids=None, samples_per_rank=1024):
+    """Sort the table whose rows are spread over the ranks. cols = this rank's rows as equally long 1-D tensors; keys = indices
+    of the sort key columns, most significant first; desc / nulls_first per key (SortColumnDescription); valids[c] = None or a
+    uint8 tensor (1 = the value is not NULL). `ops` runs the single-node operators (databend_amd.sort_ops.SortDeviceOps on a
+    GPU; a numpy stand-in in the gloo tests):
+        ops.ordered_rows(key_cols, key_valids, desc, nulls_first)          -> the rows as host tuples (None = NULL) in sort order
+        ops.partition(flat, kpos, kvpos, bounds, desc, nulls_first)        -> (flat grouped by range, rows per range)
+        ops.sort(flat, kpos, kvpos, desc, nulls_first)                     -> flat in sort order
+    Returns (cols, valids, bounds): rank r's rows are range r of the global order, sorted; bounds = the global cut rows."""
+    from .sort_bounds import balanced_cuts
+    world = dist.get_world_size()
+    nk = len(keys)
+    desc = list(desc or [0] * nk)
+    nulls_first = list(nulls_first or [0] * nk)
+    valids = list(valids or [None] * len(cols))
+    n = int(cols[0].shape[0])
+    dev = cols[0].device
+    flat, vpos = list(cols), [None] * len(cols)
+    for c, v in enumerate(valids):
+        if v is not None:
+            vpos[c] = len(flat)
+            flat.append(v)
+    kpos, kvpos = list(keys), [vpos[k] for k in keys]
+    cnt = min(n, int(samples_per_rank))
+    if cnt:
+        i = torch.arange(cnt, dtype=torch.int64, device=dev)
+        ids = (i * n) // cnt + n // (2 * cnt)
+    else:
+        ids = torch.zeros(0, dtype=torch.int64, device=dev)
+    sample_pos = kpos + [p for p in kvpos if p is not None]
+    gathered = allgather_columns([flat[p][ids] for p in sample_pos], dist, torch)            # every node's samples, everywhere
+    g_keys = gathered[:nk]
+    g_valids, at = [], nk
+    for p in kvpos:
+        g_valids.append(gathered[at] if p is not None else None)
+        at += 1 if p is not None else 0
+    rows = ops.ordered_rows(g_keys, g_valids, desc, nulls_first)
+    bound_rows = balanced_cuts(rows, world)                                                   # the same on every rank
+    grouped, counts = ops.partition(flat, kpos, kvpos, bound_rows, desc, nulls_first)
+    counts = [int(c) for c in counts] + [0] * (world - len(counts))                          # range i -> rank i
+    received, _rc = alltoall_columns(grouped, counts, dist, torch)
+    out = ops.sort(received, kpos, kvpos, desc, nulls_first)
+    out_cols = out[:len(cols)]
+    out_valids = [out[p] if p is not None else None for p in vpos]
+    return out_cols, out_valids, bound_rows

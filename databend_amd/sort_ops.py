@@ -1,0 +1,92 @@
+"""The single-node operators of the distributed sort (databend_amd.dist.range_partitioned_sort) over the C-ABI: the columns are
+CUDA tensors (torch.distributed moves them over RCCL), every operator is one or two library calls on them — dbhip_sort_perm,
+dbhip_sort_bound_partition, dbhip_take_block. Nothing here computes on the host except the tiny sample / bounds tables."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import device as D
+
+
+class _Borrowed:
+    """a torch tensor's storage as a column buffer (the tensor stays alive with the column)"""
+
+    def __init__(self, t):
+        self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+
+
+class SortDeviceOps:
+    def __init__(self, torch):
+        self.torch = torch
+        self.types = {torch.int8: L.T_I8, torch.int16: L.T_I16, torch.int32: L.T_I32, torch.int64: L.T_I64, torch.uint8: L.T_U8,
+                      torch.float32: L.T_F32, torch.float64: L.T_F64}
+
+    def _sync(self):
+        self.torch.cuda.current_stream().synchronize()     # torch produced the tensors; the library runs on its own stream
+
+    def _bitmap(self, valid):
+        """uint8 flags -> LSB-first Bitmap (padded: the kernels read it by words)"""
+        t = self.torch
+        n = int(valid.shape[0])
+        padded = t.zeros(((n + 63) // 64) * 64 + 64, dtype=t.uint8, device=valid.device)
+        padded[:n] = valid != 0
+        weights = t.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=t.uint8, device=valid.device)
+        return (padded.view(-1, 8) * weights).sum(1, dtype=t.uint8).contiguous()
+
+    def _column(self, tensor, valid=None):
+        tensor = tensor.contiguous()
+        vb = _Borrowed(self._bitmap(valid)) if valid is not None else None
+        return D.Column(self.types[tensor.dtype], int(tensor.shape[0]), _Borrowed(tensor), validity=vb)
+
+    def _keys(self, flat, kpos, kvpos):
+        cols = [self._column(flat[p], flat[v] if v is not None else None) for p, v in zip(kpos, kvpos)]
+        self._sync()
+        return cols
+
+    def _take(self, flat, perm, m):
+        """every column through one permutation: dbhip_take_block, 8 columns per launch, straight into new tensors"""
+        t = self.torch
+        outs = [t.empty(m, dtype=c.dtype, device=c.device) for c in flat]
+        self._sync()
+        for g0 in range(0, len(flat), 8):
+            grp, dst = [c.contiguous() for c in flat[g0:g0 + 8]], outs[g0:g0 + 8]
+            srcs = (C.c_void_p * len(grp))(*[c.data_ptr() for c in grp])
+            dsts = (C.c_void_p * len(grp))(*[o.data_ptr() for o in dst])
+            es = (C.c_int32 * len(grp))(*[c.element_size() for c in grp])
+            if m:
+                L.check(L.lib().dbhip_take_block(srcs, es, len(grp), C.c_void_p(perm.ptr), C.c_int64(m), dsts, None))
+        L.check(L.lib().dbhip_stream_sync(None))
+        return outs
+
+    def ordered_rows(self, key_cols, key_valids, desc, nulls_first):
+        n = int(key_cols[0].shape[0])
+        if n == 0:
+            return []
+        cols = [self._column(k, v) for k, v in zip(key_cols, key_valids)]
+        self._sync()
+        perm = D.sort_perm(cols, desc, nulls_first)
+        host = [k.cpu().numpy()[perm].tolist() for k in key_cols]
+        hval = [v.cpu().numpy()[perm].tolist() if v is not None else None for v in key_valids]
+        return [tuple(host[k][i] if hval[k] is None or hval[k][i] else None for k in range(len(host))) for i in range(n)]
+
+    def partition(self, flat, kpos, kvpos, bounds, desc, nulls_first):
+        n = int(flat[0].shape[0])
+        if not bounds or n == 0:
+            return list(flat), [n]
+        cols = self._keys(flat, kpos, kvpos)
+        bcols = []
+        for k, c in enumerate(cols):
+            vals = np.array([0 if r[k] is None else r[k] for r in bounds], dtype=D.NP_OF[c.dtype])
+            null = [r[k] is None for r in bounds]
+            bcols.append(D.Column.from_numpy(vals, c.dtype, validity=(np.array([not x for x in null]) if (any(null) or c.validity is not None) else None)))
+        part, counts = D.sort_bound_partition(cols, bcols, desc, nulls_first)
+        perm, m = D.sort_perm_device([D.Column(L.T_U32, n, part)])          # rows grouped by range, stable: one radix pass
+        return self._take(flat, perm, m), [int(c) for c in counts]
+
+    def sort(self, flat, kpos, kvpos, desc, nulls_first):
+        n = int(flat[0].shape[0])
+        if n == 0:
+            return list(flat)
+        perm, m = D.sort_perm_device(self._keys(flat, kpos, kvpos), desc, nulls_first)
+        return self._take(flat, perm, m)

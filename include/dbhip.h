@@ -653,6 +653,18 @@ int32_t dbhip_merge_sorted_perm(const dbhip_col* keys, const uint8_t* desc_host,
                                 const int64_t* run_offsets_host, int32_t nruns, int64_t limit,
                                 uint32_t* out_perm, void* stream);
 
+/* Range partition for the distributed sort (SURVEY §8e "sort": sample -> range-partition -> all-to-all -> local sort). Replaces the
+ * cut of sorted streams at Bounds (src/query/pipeline/transforms/src/processors/transforms/sorts/sort_spill.rs:740-1040
+ * BoundBlockStream / block_split_off_position / partition_point: rows <= bound[i] in sort order belong to partition i, rows after
+ * the last bound to partition nbounds) and SortBoundScatter (src/query/service/src/pipelines/processors/transforms/sort/
+ * sort_exchange_injector.rs: partition i goes to node i % n). `bounds` = nbounds rows of the same key columns, ORDERED by the same
+ * keys (core/bounds.rs: Bounds::from_column / merge / dedup); out_part[i] = number of bounds that sort strictly before row i;
+ * out_counts (DEVICE, nbounds + 1 u64) = rows per partition. The rows need not be sorted. Same key types, desc / nulls_first
+ * meaning and string lengths as dbhip_sort_perm. */
+int32_t dbhip_sort_bound_partition(const dbhip_col* keys, const dbhip_col* bounds, const uint8_t* desc_host,
+                                   const uint8_t* nulls_first_host, int32_t nkeys, int64_t n, int64_t nbounds,
+                                   uint32_t* out_part, uint64_t* out_counts, void* stream);
+
 /* ---- a17/a18: vector distance ------------------------------------------------
  * Replaces cosine_distance / l2_distance / inner_product / l1_distance
  * (src/common/vector/src/distance.rs:19-165) driven by

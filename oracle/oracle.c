@@ -1496,6 +1496,43 @@ int orc_sort_perm(const orc_col* keys, const uint8_t* desc, const uint8_t* nulls
   return 0;
 }
 
+/* Range partition by Bounds: sort_spill.rs:1008-1040 (block_split_off_position / partition_point = the first row GREATER than the
+ * bound, so rows <= bound[i] belong to partition i) applied to every row on its own: partition = number of bounds that sort
+ * strictly before the row. `bounds` are ordered by the same keys (core/bounds.rs). */
+static int sort_cmp_cross(const orc_col* ka, uint32_t a, const orc_col* kb, uint32_t b, const uint8_t* desc, const uint8_t* nf, int nkeys) {
+  for (int k = 0; k < nkeys; ++k) {
+    const orc_col *c = &ka[k], *d = &kb[k];
+    int va = col_valid(c, a), vb = col_valid(d, b);
+    if (!va || !vb) {
+      if (va == vb) continue;
+      int a_first = (!va) ? (nf ? nf[k] : 0) : !(nf ? nf[k] : 0);
+      return a_first ? -1 : 1;
+    }
+    int r;
+    if (c->type == ORC_T_BOOL) r = bit_get((const uint8_t*)c->data, a) - bit_get((const uint8_t*)d->data, b);
+    else {
+      orc_col ca = *c, cb = *d;
+      int es = t_size(c->type);
+      ca.is_scalar = cb.is_scalar = 1; ca.validity = cb.validity = NULL;
+      ca.data = (const uint8_t*)c->data + (size_t)a * es; cb.data = (const uint8_t*)d->data + (size_t)b * es;
+      r = cmp3_col(&ca, &cb, 0);
+    }
+    if (r) return (desc && desc[k]) ? -r : r;
+  }
+  return 0;
+}
+int orc_sort_bound_partition(const orc_col* keys, const orc_col* bounds, const uint8_t* desc, const uint8_t* nulls_first, int nkeys,
+                             int64_t n, int64_t nbounds, uint32_t* out_part, uint64_t* out_counts) {
+  for (int64_t j = 0; j <= nbounds; ++j) out_counts[j] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t p = 0;   /* linear on purpose: independent of the device's binary search */
+    while (p < nbounds && sort_cmp_cross(bounds, (uint32_t)p, keys, (uint32_t)i, desc, nulls_first, nkeys) < 0) ++p;
+    out_part[i] = (uint32_t)p;
+    out_counts[p]++;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* inner hash join on u64 keys: hashjoin_hashtable.rs:95-137 (chained buckets,  */
 /* prepend insert), fixed_keys.rs:209-269 (chain walk, key ==). Output sorted   */

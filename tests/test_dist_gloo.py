@@ -461,3 +461,122 @@ def test_q3_broadcast_join_over_shards_equals_the_single_node_query(world, sf, l
     assert [(r[1], r[2]) for r in exp] == [(r[1], r[2]) for r in ref] and sorted(exp) == sorted(ref)
     for r in range(world):
         assert got[r] == exp, f"rank {r}"
+
+
+# ---- distributed sort: sample -> Bounds -> range partition -> all-to-all -> local sort (DX.range_partitioned_sort) ----
+def sort_row_cmp(a, b, desc, nf):
+    """SortCompare's order on host tuples (None = NULL; the NULL order does not depend on asc / desc)"""
+    for x, y, d, f in zip(a, b, desc, nf):
+        if x is None or y is None:
+            if x is None and y is None:
+                continue
+            a_first = bool(f) if x is None else not f
+            return -1 if a_first else 1
+        if x != y:
+            r = -1 if x < y else 1
+            return -r if d else r
+    return 0
+
+
+class SortNumpyOps:
+    """host stand-in of databend_amd.sort_ops.SortDeviceOps: the same three operators in plain Python"""
+
+    def _rows(self, flat, kpos, kvpos):
+        cols = [flat[p].tolist() for p in kpos]
+        vals = [flat[v].tolist() if v is not None else None for v in kvpos]
+        return [tuple(cols[k][i] if vals[k] is None or vals[k][i] else None for k in range(len(kpos))) for i in range(len(cols[0]))]
+
+    def ordered_rows(self, key_cols, key_valids, desc, nulls_first):
+        import functools
+        flat = list(key_cols) + [v for v in key_valids if v is not None]
+        kv, at = [], len(key_cols)
+        for v in key_valids:
+            kv.append(at if v is not None else None)
+            at += 1 if v is not None else 0
+        rows = self._rows(flat, list(range(len(key_cols))), kv) if len(key_cols[0]) else []
+        return sorted(rows, key=functools.cmp_to_key(lambda a, b: sort_row_cmp(a, b, desc, nulls_first)))
+
+    def partition(self, flat, kpos, kvpos, bounds, desc, nulls_first):
+        n = len(flat[0])
+        if not bounds or n == 0:
+            return list(flat), [n]
+        rows = self._rows(flat, kpos, kvpos)
+        part = np.array([sum(1 for b in bounds if sort_row_cmp(b, r, desc, nulls_first) < 0) for r in rows], dtype=np.int64)
+        order = torch.from_numpy(np.argsort(part, kind="stable"))
+        return [c[order] for c in flat], np.bincount(part, minlength=len(bounds) + 1).tolist()
+
+    def sort(self, flat, kpos, kvpos, desc, nulls_first):
+        import functools
+        if len(flat[0]) == 0:
+            return list(flat)
+        rows = self._rows(flat, kpos, kvpos)
+        order = sorted(range(len(rows)), key=functools.cmp_to_key(lambda i, j: sort_row_cmp(rows[i], rows[j], desc, nulls_first)))
+        order = torch.tensor(order, dtype=torch.int64)
+        return [c[order] for c in flat]
+
+
+def sort_table(seed, n, card):
+    rng = np.random.default_rng(seed)
+    return {"k0": rng.integers(-card, card, n).astype(np.int32), "k1": rng.integers(0, 1 << 40, n).astype(np.int64),
+            "v0": (rng.random(n) > 0.15).astype(np.uint8), "pay": np.arange(n, dtype=np.int64)}
+
+
+def sort_cuts(n, world, skew):
+    if skew == "empty":                       # one rank holds nothing
+        base = np.linspace(0, n, world).astype(np.int64)
+        return [0] + base.tolist()
+    return np.linspace(0, n, world + 1).astype(np.int64).tolist() if not skew else [0] + [int(n * (0.7 + 0.3 * r / (world - 1))) for r in range(world - 1)] + [n]
+
+
+def sort_worker(rank, world, port, seed, n, card, skew, samples, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = sort_table(seed, n, card)
+        cuts = sort_cuts(n, world, skew)
+        sh = {k: torch.from_numpy(v[cuts[rank]:cuts[rank + 1]].copy()) for k, v in t.items()}
+        cols, valids, bounds = DX.range_partitioned_sort([sh["k0"], sh["k1"], sh["pay"]], [0, 1], SortNumpyOps(), dist, torch, desc=[1, 0],
+                                                         nulls_first=[1, 0], valids=[sh["v0"], None, None], samples_per_rank=samples)
+        q.put((rank, [c.numpy() for c in cols], valids[0].numpy(), bounds))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,card,skew,samples", [(2, 3000, 50, False, 64), (3, 5000, 5, True, 128), (3, 400, 1000, "empty", 16), (2, 5, 2, False, 64)])
+def test_range_partitioned_sort_concatenates_to_the_global_order(world, n, card, skew, samples):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=sort_worker, args=(r, world, port, 21, n, card, skew, samples, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, cols, v0, bounds = q.get(timeout=180)
+        got[r] = (cols, v0, bounds)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    t = sort_table(21, n, card)
+    desc, nf = [1, 0], [1, 0]
+    assert all(got[r][2] == got[0][2] for r in range(world)) and len(got[0][2]) <= world - 1        # the same bounds everywhere
+    k0 = np.concatenate([got[r][0][0] for r in range(world)])
+    k1 = np.concatenate([got[r][0][1] for r in range(world)])
+    pay = np.concatenate([got[r][0][2] for r in range(world)])
+    v0 = np.concatenate([got[r][1] for r in range(world)])
+    assert sorted(pay.tolist()) == list(range(n))                                                    # every row exactly once
+    assert np.array_equal(t["k0"][pay], k0) and np.array_equal(t["k1"][pay], k1) and np.array_equal(t["v0"][pay], v0)   # rows stay whole
+    rows = [(int(a) if v else None, int(b)) for a, b, v in zip(k0, k1, v0)]
+    assert all(sort_row_cmp(rows[i], rows[i + 1], desc, nf) <= 0 for i in range(n - 1))              # rank order IS the sort order
+    # the cut is the reference's (sort_spill.rs partition_point): a row's rank = the number of bounds sorting strictly before it
+    at = 0
+    for r in range(world):
+        m = len(got[r][0][0])
+        for row in rows[at:at + m]:
+            assert sum(1 for b in got[0][2] if sort_row_cmp(b, row, desc, nf) < 0) == r
+        at += m
+    if n >= 3000:
+        sizes = [len(got[r][0][0]) for r in range(world)]
+        assert max(sizes) <= 1.3 * n / world, sizes                                                  # the samples balance the ranges

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from databend_amd import _lib as T
+from databend_amd.device import make_views_general
 from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -157,6 +158,165 @@ def test_sort_perm_matches_oracle(gpu, oracle, n):
         f = (C.c_uint8 * len(idxs))(*nf)
         oracle.orc_sort_perm(O.cols(hcols), d, f, len(idxs), C.c_int64(n), C.c_int64(limit), exp.ctypes.data_as(C.c_void_p))
         assert np.array_equal(got, exp[:m]), (idxs, desc, nf, limit)
+
+
+def _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, desc, nf, n, nb):
+    part, counts = gpu.sort_bound_partition(gkeys, gb, desc, nf)
+    got = part.to_numpy(np.uint32, n)
+    exp, ecnt = np.zeros(max(n, 1), np.uint32), np.zeros(nb + 1, np.uint64)
+    d = (C.c_uint8 * len(desc))(*desc)
+    f = (C.c_uint8 * len(nf))(*nf)
+    assert oracle.orc_sort_bound_partition(O.cols(hkeys), O.cols(hb) if nb else None, d, f, len(desc), C.c_int64(n), C.c_int64(nb),
+                                           exp.ctypes.data_as(C.c_void_p), ecnt.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got, exp[:n]) and np.array_equal(counts, ecnt)
+    assert int(counts.sum()) == n
+    return got
+
+
+@pytest.mark.parametrize("n,nb", [(1, 1), (255, 0), (2049, 1), (12_289, 7), (100_000, 300), (50_000, 5000)])
+def test_sort_bound_partition_matches_oracle(gpu, oracle, n, nb):
+    """dbhip_sort_bound_partition (the distributed sort's range partition: sort_spill.rs:1008-1040 partition_point over Bounds,
+    rows <= bound[i] belong to range i) against the oracle's row-at-a-time statement: every key type of dbhip_sort_perm, asc /
+    desc, NULLs first / last on rows AND bounds, duplicate bounds, bounds in LDS (<= 32 KB) and in global memory, the LDS
+    histogram (<= 2048 ranges) and the global one. The bounds are rows of the same distribution, ordered by the oracle's sort."""
+    rng = np.random.default_rng(n + nb)
+    cases, bcases = sort_cases(rng, n), sort_cases(rng, max(nb, 1))
+    valid, bvalid = rng.integers(0, 5, n) > 0, rng.integers(0, 5, max(nb, 1)) > 0
+    combos = [([0], [0], [0]), ([1], [1], [0]), ([2, 0], [0, 1], [0, 0]), ([3], [0], [1]), ([4, 2], [1, 0], [1, 0]), ([5], [1], [0]),
+              ([6, 3, 1], [0, 1, 0], [0, 1, 0]), ([2, 6, 0], [1, 1, 1], [0, 0, 0])]
+    for idxs, desc, nf in combos:
+        d = (C.c_uint8 * len(idxs))(*desc)
+        f = (C.c_uint8 * len(idxs))(*nf)
+        raw = []
+        for pos, i in enumerate(idxs):
+            code, arr = bcases[i]
+            raw.append((code, arr[:nb], bvalid[:nb] if pos == 0 and i != 5 else None))
+        order = np.zeros(max(nb, 1), np.uint32)
+        if nb:
+            oracle.orc_sort_perm(O.cols([O.HostCol(c, a, v) for c, a, v in raw]), d, f, len(idxs), C.c_int64(nb), C.c_int64(0), order.ctypes.data_as(C.c_void_p))
+        order = order[:nb]
+        gkeys, hkeys, gb, hb = [], [], [], []
+        for pos, i in enumerate(idxs):
+            code, arr = cases[i]
+            v = valid if pos == 0 and i != 5 else None
+            gkeys.append(gpu.Column.from_numpy(arr, code, validity=v))
+            hkeys.append(O.HostCol(code, arr, v))
+            bc, ba, bv = raw[pos]
+            ba = np.ascontiguousarray(ba[order])
+            bv = bv[order] if bv is not None else None
+            if nb:
+                gb.append(gpu.Column.from_numpy(ba, bc, validity=bv))
+                hb.append(O.HostCol(bc, ba, bv))
+        got = _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, desc, nf, n, nb)
+        assert got.max() <= nb
+
+
+def test_sort_bound_partition_strings_and_decimal128(gpu, oracle):
+    """String keys (inline and beyond 12 bytes: memcmp order, a proper prefix first) and Decimal128 keys, NULL bounds, and rows
+    equal to a bound (they belong to the bound's own range)."""
+    rng = np.random.default_rng(77)
+    base = [b"", b"a", b"Customer#000000001", b"Customer#000000002", b"Customer#00000000", b"Customer#000000001\x00", b"x" * 70, b"x" * 69 + b"y",
+            b"abcdefghijkl", b"abcdefghijklm", b"\xff" * 13, b"\xff" * 12, b"a\x00b" * 9]
+    n = 20_000
+    for pool in (base, [b for b in base if len(b) <= 12]):        # long strings (image parts from the data buffers) / inline views only
+        strs = [pool[i] + (b"%d" % rng.integers(0, 50) if rng.random() < 0.5 else b"") for i in rng.integers(0, len(pool), n)]
+        if pool is not base:
+            strs = [x[:12] for x in strs]
+        k2 = rng.integers(0, 3, n).astype(np.int32)
+        valid = rng.integers(0, 9, n) > 0
+        for desc, nf in ((0, 0), (1, 1), (0, 1)):
+            # bounds: every 900th row of the ordered table (so many rows EQUAL a bound), incl. a NULL bound when NULLs come first
+            perm = gpu.sort_perm([gpu.Column.strings(strs, validity=valid), gpu.Column.from_numpy(k2)], desc=[desc, 0], nulls_first=[nf, 0])
+            pick = perm[::900]
+            bs, bk, bv = [strs[i] for i in pick], k2[pick], valid[pick]
+            v, buf = make_views_general(strs)
+            vb, bufb = make_views_general(bs)
+            hkeys = [O.HostCol(T.T_STRING, v, valid, buffers=[buf]), O.HostCol(T.T_I32, k2)]
+            hb = [O.HostCol(T.T_STRING, vb, bv, buffers=[bufb]), O.HostCol(T.T_I32, bk)]
+            gkeys = [gpu.Column.strings(strs, validity=valid), gpu.Column.from_numpy(k2)]
+            gb = [gpu.Column.strings(bs, validity=bv), gpu.Column.from_numpy(np.ascontiguousarray(bk))]
+            got = _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, [desc, 0], [nf, 0], n, len(pick))
+            assert all(got[i] == j for j, i in enumerate(pick) if j == 0 or (strs[pick[j - 1]], k2[pick[j - 1]], valid[pick[j - 1]]) != (strs[i], k2[i], valid[i]))
+    ints = [int(x) * int(y) for x, y in zip(rng.integers(-2**62, 2**62, n), rng.integers(0, 2**40, n))]
+    bints = sorted(ints[::1500], reverse=True)
+    got = _bound_partition_both(gpu, oracle, [gpu.Column.decimal128(ints, 38, 0)], [O.HostCol(T.T_DEC128, O.i128_array(ints))],
+                                [gpu.Column.decimal128(bints, 38, 0)], [O.HostCol(T.T_DEC128, O.i128_array(bints))], [1], [0], n, len(bints))
+    assert got.tolist() == [sum(1 for b in bints if b > x) for x in ints]
+
+
+def test_range_partitioned_sort_operators_on_the_device(gpu):
+    """databend_amd.sort_ops.SortDeviceOps — the three device operators of dist.range_partitioned_sort — driven like three ranks
+    would drive them (samples -> ordered rows -> Bounds -> partition every shard -> range r of every shard -> sort): the ranges
+    concatenate to the full sort, and the whole plan over RCCL at world size 1 returns the plain sort."""
+    import torch
+    from databend_amd.sort_bounds import balanced_cuts
+    from databend_amd.sort_ops import SortDeviceOps
+    rng = np.random.default_rng(5)
+    n, world = 90_000, 3
+    k0 = rng.integers(-40, 40, n).astype(np.int32)
+    k1 = rng.standard_normal(n)
+    v0 = (rng.random(n) > 0.1).astype(np.uint8)
+    pay = np.arange(n, dtype=np.int64)
+    cuts = [0, 20_000, 20_000, n]                                  # an empty shard in the middle
+    ops, desc, nf = SortDeviceOps(torch), [1, 0], [1, 0]
+    shards = [[torch.from_numpy(a[cuts[r]:cuts[r + 1]].copy()).cuda() for a in (k0, k1, pay, v0)] for r in range(world)]
+    samples = [[c[torch.arange(0, c.shape[0], 97, device="cuda")] for c in (s[0], s[1], s[3])] for s in shards]
+    allk0, allk1, allv = (torch.cat([s[i] for s in samples]) for i in range(3))
+    rows = ops.ordered_rows([allk0, allk1], [allv, None], desc, nf)
+    bounds = balanced_cuts(rows, world)
+    assert len(bounds) == world - 1
+    grouped = [ops.partition(s, [0, 1], [3, None], bounds, desc, nf) for s in shards]
+    outs = []
+    for r in range(world):
+        recv = []
+        for c in range(4):
+            pieces = []
+            for (flat, counts) in grouped:
+                counts = counts + [0] * (world - len(counts))
+                at = sum(counts[:r])
+                pieces.append(flat[c][at:at + counts[r]])
+            recv.append(torch.cat(pieces))
+        outs.append(ops.sort(recv, [0, 1], [3, None], desc, nf))
+    full = [torch.cat([o[c] for o in outs]).cpu().numpy() for c in range(4)]
+    exp = gpu.sort_perm([gpu.Column.from_numpy(k0, validity=v0 != 0), gpu.Column.from_numpy(k1)], desc, nf)
+    assert sorted(full[2].tolist()) == list(range(n))
+    nulls_k0 = np.where(v0[exp] != 0, k0[exp], 0)
+    assert np.array_equal(np.where(full[3] != 0, full[0], 0), nulls_k0) and np.array_equal(full[1], k1[exp]) and np.array_equal(full[3], v0[exp])
+    assert np.array_equal(k1[full[2]], full[1]) and np.array_equal(v0[full[2]], full[3])
+    sizes = [int(o[0].shape[0]) for o in outs]
+    assert max(sizes) < 0.4 * n, sizes
+
+
+def test_range_partitioned_sort_on_one_rank_over_rccl(gpu):
+    """the whole distributed sort plan with the device operators and the nccl (= RCCL) backend in a world of one: the sample
+    all-gather and the per-column all-to-all really run on device tensors; the multi-rank logic is covered by
+    tests/test_dist_gloo.py with world 2 / 3."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from databend_amd import dist as DX
+    from databend_amd.sort_ops import SortDeviceOps
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        rng = np.random.default_rng(31)
+        n = 300_000
+        k0 = rng.integers(0, 1000, n).astype(np.int64)
+        k1 = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+        pay = rng.standard_normal(n).astype(np.float32)
+        cols, valids, bounds = DX.range_partitioned_sort([torch.from_numpy(a).cuda() for a in (k0, k1, pay)], [0, 1], SortDeviceOps(torch), dist, torch,
+                                                         desc=[0, 1])
+        assert bounds == [] and valids == [None, None, None]
+        exp = gpu.sort_perm([gpu.Column.from_numpy(k0), gpu.Column.from_numpy(k1)], [0, 1])
+        for got, src in zip(cols, (k0, k1, pay)):
+            assert np.array_equal(got.cpu().numpy(), src[exp])
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("n", [65_536, 300_001])

@@ -642,3 +642,36 @@ def test_nullable_sum_flag_and_state_block_closed_form():
     assert results(final) == exp
     L.orc_hashagg_destroy(final)
     L.orc_hashagg_destroy(whole)
+
+
+def test_sort_bound_partition_against_a_python_comparator():
+    """orc_sort_bound_partition (sort_spill.rs:1008-1040: rows <= bound[i] belong to range i) against SortCompare's order written
+    as a Python comparator: two keys, asc / desc, NULLs first / last in rows and bounds."""
+    import functools
+    L = O.load()
+    rng = np.random.default_rng(1)
+    n, nb = 2000, 9
+    k1 = rng.integers(-5, 5, n).astype(np.int32)
+    k2 = rng.standard_normal(n)
+    v1 = rng.integers(0, 6, n) > 0
+    for desc, nf in (([0, 0], [0, 0]), ([1, 0], [1, 0]), ([0, 1], [0, 1]), ([1, 1], [1, 1])):
+        def cmp(a, b):
+            for x, y, d, f in zip(a, b, desc, nf):
+                if x is None or y is None:
+                    if x is None and y is None:
+                        continue
+                    return -1 if (bool(f) if x is None else not f) else 1
+                if x != y:
+                    r = -1 if x < y else 1
+                    return -r if d else r
+            return 0
+        rows = [(int(a) if v else None, float(b)) for a, b, v in zip(k1, k2, v1)]
+        bidx = sorted(rng.integers(0, n, nb).tolist(), key=functools.cmp_to_key(lambda i, j: cmp(rows[i], rows[j])))
+        b1, b2, bv = k1[bidx].copy(), k2[bidx].copy(), v1[bidx].copy()
+        out, cnt = np.zeros(n, np.uint32), np.zeros(nb + 1, np.uint64)
+        d = (C.c_uint8 * 2)(*desc)
+        f = (C.c_uint8 * 2)(*nf)
+        assert L.orc_sort_bound_partition(O.cols([O.HostCol(T.T_I32, k1, v1), O.HostCol(T.T_F64, k2)]), O.cols([O.HostCol(T.T_I32, b1, bv), O.HostCol(T.T_F64, b2)]),
+                                          d, f, 2, C.c_int64(n), C.c_int64(nb), out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)) == 0
+        exp = [sum(1 for j in bidx if cmp(rows[j], r) < 0) for r in rows]
+        assert out.tolist() == exp and cnt.tolist() == np.bincount(exp, minlength=nb + 1).tolist()
