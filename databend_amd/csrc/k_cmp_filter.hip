@@ -282,6 +282,27 @@ __device__ __forceinline__ uint64_t load_bits64(const uint8_t* bm, int64_t pos, 
   return v;
 }
 
+// bitmap[idx[i]] = 1 (OR into the words: the pair list of a join names a probe row once per match; consecutive pairs mostly
+// hit the same word, so lanes with the same word combine their bits first and one lane issues the atomic)
+__global__ __launch_bounds__(256) void bitmap_set_indices_kernel(const uint32_t* idx, int64_t n, uint32_t* words, int64_t nbits) {
+  for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = base + lane_id();
+    const bool live = i < n && (int64_t)idx[i < n ? i : 0] < nbits;
+    const uint32_t id = live ? idx[i] : 0xFFFFFFFFu;
+    const uint32_t w = id >> 5;
+    uint32_t bit = live ? 1u << (id & 31) : 0;
+    // runs of equal words are adjacent in a sorted pair list: fold a lane into its left neighbour while the word is the same
+    const uint32_t wl = __shfl_up(w, 1, 64);
+    const bool head = lane_id() == 0 || wl != w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t ob = __shfl_down(bit, off, 64), ow = __shfl_down(w, off, 64);
+      if (lane_id() + off < 64 && ow == w) bit |= ob;
+    }
+    if (live && head) atomicOr(&words[w], bit);
+  }
+}
+
 __global__ __launch_bounds__(256) void bitmap_count_kernel(const uint8_t* bm, int64_t off, int64_t n,
                                                            unsigned long long* out) {
   const int64_t nwords = (n + 63) >> 6;
@@ -809,6 +830,16 @@ int32_t dbhip_bitmap_binary(int32_t is_or, const uint8_t* a, const uint8_t* b, i
   int64_t nbytes = ceil_div(n, 8);
   hipLaunchKernelGGL(bitmap_binary_kernel, dim3(grid_for(nbytes, 256)), dim3(256), 0,
                      resolve_stream(stream), a, b, out, nbytes, n, is_or);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_bitmap_set_indices(const uint32_t* idx, int64_t n_idx, uint8_t* bitmap, int64_t nbits, void* stream) {
+  DBHIP_REQUIRE(n_idx >= 0 && nbits >= 0, "dbhip_bitmap_set_indices: negative count");
+  if (n_idx == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(idx && bitmap, "dbhip_bitmap_set_indices: NULL argument");
+  DBHIP_REQUIRE(((uintptr_t)bitmap & 3) == 0, "dbhip_bitmap_set_indices: the bitmap must be 4-byte aligned (it is written by words)");
+  hipLaunchKernelGGL(bitmap_set_indices_kernel, dim3(grid_for(n_idx, 256)), dim3(256), 0, resolve_stream(stream), idx, n_idx, (uint32_t*)bitmap, nbits);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }

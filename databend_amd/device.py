@@ -1191,7 +1191,69 @@ class HashJoin:
         assert got.value == m
         return op, ob, m
 
-    def join(self, kind, probe_keys, probe_cols, build_cols):
+    def _join_conjunct(self, kind, probe_keys, probe_cols, build_cols, conjunct):
+        """The same kinds with ANOTHER CONJUNCT on top of the key equality (the `CONJUNCT = true` streams: inner_join.rs:278-310
+        InnerHashJoinFilterStream, left_join.rs:262-292, left_join_semi.rs:320-350, left_join_anti.rs:270-300, right_join.rs:256-290):
+        the joined rows of every key match go through the conjunct's filter (a NULL result drops the pair like FALSE); a probe row
+        all of whose pairs were dropped is UNMATCHED (left: it comes back with a NULL build side; anti: it is kept; semi: it is
+        not), and only the surviving pairs mark their build rows (right / full). conjunct(probe Columns, build Columns, m) ->
+        Boolean Column over the m joined rows."""
+        n = probe_keys.n
+        op, ob, m = self.probe_block_device(probe_keys)
+        jp, jb = [take(c, op, m) for c in probe_cols], [take(c, ob, m) for c in build_cols]
+        if m:
+            pred = conjunct(jp, jb, m)
+            sel, k = filter_select(Column(L.T_BOOL, m, _filter_bits(pred, m)))
+        else:
+            sel, k = DeviceBuffer(64), 0
+        op2 = take(Column(L.T_U32, m, op), sel, k).data
+        ob2 = take(Column(L.T_U32, m, ob), sel, k).data
+        if kind == "inner":
+            return [take(c, sel, k) for c in jp], [take(c, sel, k) for c in jb], k
+        if kind in ("right", "right_semi", "right_anti", "full"):
+            check(lib().dbhip_join_mark_build(self.h, C.c_void_p(ob2.ptr), C.c_int64(k), None))
+            if kind in ("right_semi", "right_anti"):
+                return [], [], 0
+            if kind == "right":
+                return [_with_true_validity(take(c, sel, k), k) for c in jp], [take(c, sel, k) for c in jb], k
+        # the probe rows that kept a pair
+        bm = DeviceBuffer(((max(n, 1) + 63) // 64) * 8 + 64)
+        bm.zero()
+        check(lib().dbhip_bitmap_set_indices(C.c_void_p(op2.ptr), C.c_int64(k), C.c_void_p(bm.ptr), C.c_int64(n), None))
+        matched = Column(L.T_BOOL, n, bm)
+        if kind == "left_semi":
+            s2, k2 = filter_select(matched)
+            return [take(c, s2, k2) for c in probe_cols], [], k2
+        false_ = Column.boolean(np.zeros(1, dtype=bool))
+        false_.is_scalar = True
+        usel, uk = filter_select(cmp(L.CMP_EQ, matched, false_, n))
+        if kind == "left_anti":
+            return [take(c, usel, uk) for c in probe_cols], [], uk
+        if kind not in ("left", "full"):
+            raise ValueError(kind)
+        return self._left_outer_rows(probe_cols, build_cols, op2, ob2, k, usel, uk)
+
+    def _left_outer_rows(self, probe_cols, build_cols, op, ob, m, usel, uk):
+        """the m matched pairs followed by the uk unmatched probe rows with a NULL build block (left_join.rs:196-232)"""
+        rows = m + uk
+        pidx, bidx = DeviceBuffer(max(rows, 1) * 4 + 64), DeviceBuffer(max(rows, 1) * 4 + 64)
+        check(lib().dbhip_memcpy_d2d(C.c_void_p(pidx.ptr), C.c_void_p(op.ptr), C.c_size_t(m * 4), None))
+        check(lib().dbhip_memcpy_d2d(C.c_void_p(pidx.ptr + m * 4), C.c_void_p(usel.ptr), C.c_size_t(uk * 4), None))
+        check(lib().dbhip_memcpy_d2d(C.c_void_p(bidx.ptr), C.c_void_p(ob.ptr), C.c_size_t(m * 4), None))
+        if uk:
+            check(lib().dbhip_memset(C.c_void_p(bidx.ptr + m * 4), 0xFF, C.c_size_t(uk * 4), None))
+        out_b = []
+        for c in build_cols:
+            es = ELEM_SIZE[c.dtype]
+            data = DeviceBuffer(max(rows, 1) * es + 64)
+            valid = DeviceBuffer(((max(rows, 1) + 63) // 64) * 8 + 8)
+            sv = C.c_void_p(c.validity.ptr) if c.validity is not None else None
+            check(lib().dbhip_take_outer(C.c_void_p(c.data.ptr), sv, C.c_int64(0), es, C.c_void_p(bidx.ptr), C.c_int64(rows), C.c_void_p(data.ptr),
+                                         C.c_void_p(valid.ptr), None))
+            out_b.append(Column(c.dtype, rows, data, valid, c.precision, c.scale, buffers=c.buffers, keep=(c,)))
+        return [take(c, pidx, rows) for c in probe_cols], out_b, rows
+
+    def join(self, kind, probe_keys, probe_cols, build_cols, conjunct=None):
         """Output assembly of `kind` in ("inner", "left", "left_semi", "left_anti", "right", "right_semi", "right_anti", "full") for
         ONE probe block against the finished build side (new_hash_join/memory/{inner_join,left_join,left_join_semi,left_join_anti,
         right_join,right_join_semi,right_join_anti,full_join}.rs; no other conjunct); the right / full kinds are completed by
@@ -1201,6 +1263,8 @@ class HashJoin:
                      probe rows with a null build block (left_join.rs:196-232)
           left_semi  probe rows that have a match, each once;  left_anti: probe rows without one
         -> (probe Columns, build Columns, n_rows); everything stays in HBM."""
+        if conjunct is not None:
+            return self._join_conjunct(kind, probe_keys, probe_cols, build_cols, conjunct)
         n = probe_keys.n
         v = C.c_void_p(probe_keys.validity.ptr) if probe_keys.validity is not None else None
         if kind in ("left_semi", "left_anti", "left"):
@@ -1241,23 +1305,7 @@ class HashJoin:
             return [take(c, op, m) for c in probe_cols], [take(c, ob, m) for c in build_cols], m
         if kind != "left":
             raise ValueError(kind)
-        rows = m + uk
-        pidx, bidx = DeviceBuffer(max(rows, 1) * 4 + 64), DeviceBuffer(max(rows, 1) * 4 + 64)
-        check(lib().dbhip_memcpy_d2d(C.c_void_p(pidx.ptr), C.c_void_p(op.ptr), C.c_size_t(m * 4), None))
-        check(lib().dbhip_memcpy_d2d(C.c_void_p(pidx.ptr + m * 4), C.c_void_p(usel.ptr), C.c_size_t(uk * 4), None))
-        check(lib().dbhip_memcpy_d2d(C.c_void_p(bidx.ptr), C.c_void_p(ob.ptr), C.c_size_t(m * 4), None))
-        if uk:
-            check(lib().dbhip_memset(C.c_void_p(bidx.ptr + m * 4), 0xFF, C.c_size_t(uk * 4), None))
-        out_b = []
-        for c in build_cols:
-            es = ELEM_SIZE[c.dtype]
-            data = DeviceBuffer(max(rows, 1) * es + 64)
-            valid = DeviceBuffer(((max(rows, 1) + 63) // 64) * 8 + 8)
-            sv = C.c_void_p(c.validity.ptr) if c.validity is not None else None
-            check(lib().dbhip_take_outer(C.c_void_p(c.data.ptr), sv, C.c_int64(0), es, C.c_void_p(bidx.ptr), C.c_int64(rows), C.c_void_p(data.ptr),
-                                         C.c_void_p(valid.ptr), None))
-            out_b.append(Column(c.dtype, rows, data, valid, c.precision, c.scale, buffers=c.buffers, keep=(c,)))
-        return [take(c, pidx, rows) for c in probe_cols], out_b, rows
+        return self._left_outer_rows(probe_cols, build_cols, op, ob, m, usel, uk)
 
     def final_probe(self, kind, build_cols, probe_cols_like=()):
         """After the last probe block of a right / right_semi / right_anti / full join (Join::final_probe,

@@ -1178,6 +1178,42 @@ struct Join {
   virtual std::unique_ptr<JoinStream> probe_block(DataBlock data) = 0;
 };
 
+// Another conjunct on top of the key equality (the `CONJUNCT = true` streams: inner_join.rs:278-310 InnerHashJoinFilterStream,
+// left_join.rs:262-292, left_join_semi.rs:320-350, left_join_anti.rs:270-300, right_join.rs:256-290): a predicate over the JOINED
+// rows (probe columns ++ build columns) -> Boolean column; NULL drops the pair like FALSE. A probe / build row all of whose
+// pairs were dropped counts as unmatched.
+using JoinConjunct = std::function<Column(const DataBlock&)>;
+struct JoinPairs { Buf pi, bi; int64_t count = 0; };
+inline JoinPairs filter_pairs(const DataBlock& probe, const DataBlock& build, JoinPairs p, const JoinConjunct& conj) {
+  if (!conj || p.count == 0) return p;
+  DataBlock j = take_block(probe, p.pi, p.count);
+  DataBlock b = take_block(build, p.bi, p.count);
+  for (auto& c : b.columns) j.columns.push_back(c);
+  j.num_rows = p.count;
+  Selection s = filter_select(conj(j));
+  JoinPairs o; o.count = s.count;
+  o.pi = make_buf((size_t)s.count * 4 + 64); o.bi = make_buf((size_t)s.count * 4 + 64);
+  check(dbhip_take(p.pi->ptr(), 4, (const uint32_t*)s.sel->ptr(), s.count, o.pi->ptr(), nullptr));
+  check(dbhip_take(p.bi->ptr(), 4, (const uint32_t*)s.sel->ptr(), s.count, o.bi->ptr(), nullptr));
+  return o;
+}
+// Boolean column: probe row kept at least one pair (dbhip_bitmap_set_indices over the surviving pairs' probe rows)
+inline Column rows_with_pairs(const JoinPairs& p, int64_t n) {
+  Column m; m.type = DataType::of(DBHIP_T_BOOL); m.len = n;
+  m.data = make_buf((size_t)(n + 63) / 64 * 8 + 64); m.data->fill(0);
+  check(dbhip_bitmap_set_indices((const uint32_t*)p.pi->ptr(), p.count, (uint8_t*)m.data->ptr(), n, nullptr));
+  return m;
+}
+inline Column not_bitmap(const Column& m) {   // Boolean equality with a false constant, like the reference's `not`
+  Column u = m;
+  u.data = make_buf((size_t)(m.len + 63) / 64 * 8 + 64);
+  Column f = Column::from_bools(std::vector<bool>{false});
+  dbhip_col a = m.c(), b = f.c();
+  b.is_scalar = 1;
+  check(dbhip_cmp(DBHIP_CMP_EQ, &a, &b, m.len, (uint8_t*)u.data->ptr(), nullptr));
+  return u;
+}
+
 // InnerHashJoin on one u64/i64 key (memory/inner_join.rs:47-271): output = probe columns ++ build columns
 class InnerHashJoin : public Join {
  public:
@@ -1201,9 +1237,13 @@ class InnerHashJoin : public Join {
     Buf pi = make_buf((size_t)total * 4), bi = make_buf((size_t)total * 4);
     uint64_t got = 0;
     check(dbhip_join_probe(h_, (const uint64_t*)k.data->ptr(), v, k.len, (uint32_t*)pi->ptr(), (uint32_t*)bi->ptr(), (int64_t)total, &got, nullptr));
-    return std::make_unique<Stream>(std::move(data), chunks_.empty() ? DataBlock() : chunks_[0], pi, bi, (int64_t)got, max_block_);
+    JoinPairs p{pi, bi, (int64_t)got};
+    if (conj_ && !chunks_.empty()) p = filter_pairs(data, chunks_[0], p, conj_);
+    return std::make_unique<Stream>(std::move(data), chunks_.empty() ? DataBlock() : chunks_[0], p.pi, p.bi, p.count, max_block_);
   }
+  void set_conjunct(JoinConjunct c) { conj_ = std::move(c); }
  private:
+  JoinConjunct conj_;
   struct Stream : JoinStream {
     DataBlock probe, build; Buf pi, bi; int64_t total, pos = 0, max_block;
     Stream(DataBlock p, DataBlock b, Buf pi_, Buf bi_, int64_t t, int64_t mb) : probe(std::move(p)), build(std::move(b)), pi(pi_), bi(bi_), total(t), max_block(mb) {}
@@ -1244,6 +1284,7 @@ class LeftHashJoin : public Join {
     const Column& k = data.get_by_offset(pk_);
     const uint8_t* v = k.validity ? (const uint8_t*)k.validity->ptr() : nullptr;
     const int64_t n = k.len;
+    if (conj_ && !chunks_.empty()) return probe_block_conjunct(std::move(data), k, v, n);
     // matched Bitmap -> the rows of the semi / anti result, or the unmatched tail of the outer result
     Column matched; matched.type = DataType::of(DBHIP_T_BOOL); matched.len = n;
     matched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64); matched.data->fill(0);
@@ -1284,7 +1325,45 @@ class LeftHashJoin : public Join {
       }
     return std::make_unique<Once>(std::move(out));
   }
+  void set_conjunct(JoinConjunct c) { conj_ = std::move(c); }
  private:
+  // CONJUNCT = true (left_join.rs:262-292, left_join_semi.rs, left_join_anti.rs): the key matches are filtered first, the rows that
+  // kept a pair are the matched ones
+  std::unique_ptr<JoinStream> probe_block_conjunct(DataBlock data, const Column& k, const uint8_t* v, int64_t n) {
+    uint64_t total = 0, got = 0;
+    check(dbhip_join_probe_count(h_, (const uint64_t*)k.data->ptr(), v, n, &total, nullptr));
+    JoinPairs p; p.pi = make_buf((size_t)total * 4 + 64); p.bi = make_buf((size_t)total * 4 + 64);
+    check(dbhip_join_probe(h_, (const uint64_t*)k.data->ptr(), v, n, (uint32_t*)p.pi->ptr(), (uint32_t*)p.bi->ptr(), (int64_t)total, &got, nullptr));
+    p.count = (int64_t)got;
+    p = filter_pairs(data, chunks_[0], p, conj_);
+    Column matched = rows_with_pairs(p, n);
+    if (kind_ == LeftJoinKind::Semi) {
+      Selection s = filter_select(matched);
+      return std::make_unique<Once>(take_block(data, s.sel, s.count));
+    }
+    Selection us = filter_select(not_bitmap(matched));
+    if (kind_ == LeftJoinKind::Anti) return std::make_unique<Once>(take_block(data, us.sel, us.count));
+    const int64_t rows = p.count + us.count;
+    Buf pi = make_buf((size_t)rows * 4 + 64), bi = make_buf((size_t)rows * 4 + 64);
+    check(dbhip_memcpy_d2d(pi->ptr(), p.pi->ptr(), (size_t)p.count * 4, nullptr));
+    check(dbhip_memcpy_d2d(bi->ptr(), p.bi->ptr(), (size_t)p.count * 4, nullptr));
+    check(dbhip_memcpy_d2d((uint32_t*)pi->ptr() + p.count, us.sel->ptr(), (size_t)us.count * 4, nullptr));
+    check(dbhip_memset((uint32_t*)bi->ptr() + p.count, 0xFF, (size_t)us.count * 4, nullptr));
+    DataBlock out = take_block(data, pi, rows);
+    for (const Column& c : chunks_[0].columns) {
+      Column r; r.type = c.type; r.type.nullable = true; r.len = rows;
+      const size_t es = c.type.elem_size();
+      if (c.type.id == DBHIP_T_BOOL || (es != 1 && es != 2 && es != 4 && es != 8 && es != 16)) throw ErrorCode::Unimplemented("outer join build column " + c.type.name());
+      r.data = make_buf((size_t)rows * es + 64);
+      r.validity = make_buf((size_t)(rows + 63) / 64 * 8 + 8);
+      check(dbhip_take_outer(c.data->ptr(), c.validity ? (const uint8_t*)c.validity->ptr() : nullptr, 0, (int32_t)es, (const uint32_t*)bi->ptr(), rows,
+                             r.data->ptr(), (uint8_t*)r.validity->ptr(), nullptr));
+      out.columns.push_back(r);
+    }
+    out.num_rows = rows;
+    return std::make_unique<Once>(std::move(out));
+  }
+  JoinConjunct conj_;
   struct Once : JoinStream {
     std::optional<DataBlock> b;
     explicit Once(DataBlock x) : b(std::move(x)) {}
@@ -1323,6 +1402,10 @@ class RightHashJoin : public Join {
     check(dbhip_join_probe_count(h_, (const uint64_t*)k.data->ptr(), v, n, &total, nullptr));
     Buf pi = make_buf((size_t)total * 4 + 64), bi = make_buf((size_t)total * 4 + 64);
     check(dbhip_join_probe(h_, (const uint64_t*)k.data->ptr(), v, n, (uint32_t*)pi->ptr(), (uint32_t*)bi->ptr(), (int64_t)total, &got, nullptr));
+    if (conj_ && !chunks_.empty()) {   // CONJUNCT = true (right_join.rs:256-290): only the pairs that pass reach the scan map
+      JoinPairs p = filter_pairs(data, chunks_[0], JoinPairs{pi, bi, (int64_t)got}, conj_);
+      pi = p.pi; bi = p.bi; got = (uint64_t)p.count;
+    }
     check(dbhip_join_mark_build(h_, (const uint32_t*)bi->ptr(), (int64_t)got, nullptr));
     if (kind_ == RightJoinKind::Semi || kind_ == RightJoinKind::Anti) return std::make_unique<Once>(std::nullopt);   // everything comes from final_probe
     // matched pairs: probe columns become Nullable with a true validity (the probe side is the nullable one of a right join)
@@ -1337,22 +1420,16 @@ class RightHashJoin : public Join {
     Column matched; matched.type = DataType::of(DBHIP_T_BOOL); matched.len = n;
     matched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64); matched.data->fill(0);
     uint64_t nm = 0;
-    check(dbhip_join_probe_mark(h_, (const uint64_t*)k.data->ptr(), v, n, (uint8_t*)matched.data->ptr(), &nm, nullptr));
-    Column unmatched = matched;
-    unmatched.data = make_buf((size_t)(n + 63) / 64 * 8 + 64);
-    {
-      Column f = Column::from_bools(std::vector<bool>{false});
-      dbhip_col a = matched.c(), bb = f.c();
-      bb.is_scalar = 1;
-      check(dbhip_cmp(DBHIP_CMP_EQ, &a, &bb, n, (uint8_t*)unmatched.data->ptr(), nullptr));
-    }
-    Selection us = filter_select(unmatched);
+    if (conj_ && !chunks_.empty()) check(dbhip_bitmap_set_indices((const uint32_t*)pi->ptr(), (int64_t)got, (uint8_t*)matched.data->ptr(), n, nullptr));
+    else check(dbhip_join_probe_mark(h_, (const uint64_t*)k.data->ptr(), v, n, (uint8_t*)matched.data->ptr(), &nm, nullptr));
+    Selection us = filter_select(not_bitmap(matched));
     DataBlock tail = take_block(data, us.sel, us.count);
     for (Column& c : tail.columns) wrap_true_validity(c);
     if (!chunks_.empty()) for (const Column& c : chunks_[0].columns) tail.columns.push_back(null_column(c.type, us.count));
     tail.num_rows = us.count;
     return std::make_unique<Two>(std::move(out), std::move(tail));
   }
+  void set_conjunct(JoinConjunct c) { conj_ = std::move(c); }
   // after the last probe block (Join::final_probe): build rows by the scan map
   std::optional<DataBlock> final_probe() {
     if (chunks_.empty()) return std::nullopt;
@@ -1404,6 +1481,7 @@ class RightHashJoin : public Join {
       auto r = std::move(b); b.reset(); return r;
     }
   };
+  JoinConjunct conj_;
   RightJoinKind kind_;
   size_t bk_, pk_;
   dbhip_join* h_ = nullptr;

@@ -356,6 +356,105 @@ static void test_left_joins() {
   }
 }
 
+static void test_join_conjuncts() {
+  // the CONJUNCT = true streams: key equality AND `probe value < build value` (a nullable build value: NULL drops the pair);
+  // inner / left outer / left semi / left anti / right outer / right anti against a multimap statement
+  const int64_t nb = 4000, np = 9000;
+  std::mt19937_64 rng(23);
+  std::vector<uint64_t> bk(nb), pk(np); std::vector<int64_t> bv(nb), pv(np); std::vector<bool> bvalid(nb);
+  for (int64_t i = 0; i < nb; ++i) { bk[i] = rng() % 3000; bv[i] = (int64_t)(rng() % 1000); bvalid[i] = rng() % 5 != 0; }
+  for (int64_t i = 0; i < np; ++i) { pk[i] = rng() % 4500; pv[i] = (int64_t)(rng() % 1000); }
+  auto U64 = DataType::of(DBHIP_T_U64); auto I64 = DataType::of(DBHIP_T_I64); auto U32 = DataType::of(DBHIP_T_U32);
+  std::vector<uint32_t> bid(nb), pid(np);
+  for (int64_t i = 0; i < nb; ++i) bid[i] = (uint32_t)i;
+  for (int64_t i = 0; i < np; ++i) pid[i] = (uint32_t)i;
+  Column bval = Column::from_vector(I64, bv);
+  bval.validity = Column::from_bools(bvalid).data; bval.type.nullable = true;
+  DataBlock build({Column::from_vector(U64, bk), bval, Column::from_vector(U32, bid)}, nb);
+  auto probe = [&]() { return DataBlock({Column::from_vector(U64, pk), Column::from_vector(I64, pv), Column::from_vector(U32, pid)}, np); };
+  // joined block = probe columns (0..2) ++ build columns (3..5)
+  JoinConjunct conj = [](const DataBlock& j) {
+    Evaluator ev(j);
+    return ev.run(Expr::call("lt", {Expr::column_ref(1, j.columns[1].type, "p"), Expr::column_ref(4, j.columns[4].type, "b")})).column;
+  };
+  std::multimap<uint64_t, int64_t> bm;
+  for (int64_t i = 0; i < nb; ++i) bm.insert({bk[i], i});
+  std::set<std::pair<int64_t, int64_t>> pairs;
+  std::vector<bool> pm(np, false), bmatched(nb, false);
+  for (int64_t i = 0; i < np; ++i) {
+    auto r = bm.equal_range(pk[i]);
+    for (auto it = r.first; it != r.second; ++it)
+      if (bvalid[it->second] && pv[i] < bv[it->second]) { pairs.insert({i, it->second}); pm[i] = true; bmatched[it->second] = true; }
+  }
+  CHECK(!pairs.empty());
+  auto ids = [](const Column& c, int64_t n) {   // row ids, -1 where NULL
+    auto v = c.to_vector<uint32_t>();
+    std::vector<uint8_t> bits((size_t)(n + 7) / 8 + 8, 0xFF);
+    if (c.validity) c.validity->download(bits.data(), (size_t)(n + 7) / 8);
+    std::vector<int64_t> o((size_t)n);
+    for (int64_t i = 0; i < n; ++i) o[i] = ((bits[i >> 3] >> (i & 7)) & 1) ? (int64_t)v[i] : -1;
+    return o;
+  };
+  {  // inner
+    InnerHashJoin j(0, 0);
+    j.set_conjunct(conj);
+    j.add_block(build); j.final_build();
+    auto st = j.probe_block(probe());
+    std::set<std::pair<int64_t, int64_t>> got; int64_t rows = 0;
+    while (auto b = st->next()) {
+      auto p = ids(b->columns[2], b->num_rows), q = ids(b->columns[5], b->num_rows);
+      for (int64_t i = 0; i < b->num_rows; ++i) got.insert({p[i], q[i]});
+      rows += b->num_rows;
+    }
+    CHECK(got == pairs && rows == (int64_t)pairs.size());
+  }
+  for (LeftJoinKind kind : {LeftJoinKind::Outer, LeftJoinKind::Semi, LeftJoinKind::Anti}) {
+    LeftHashJoin j(kind, 0, 0);
+    j.set_conjunct(conj);
+    j.add_block(build); j.final_build();
+    auto st = j.probe_block(probe());
+    auto b = st->next();
+    CHECK(b.has_value());
+    auto p = ids(b->columns[2], b->num_rows);
+    if (kind == LeftJoinKind::Outer) {
+      auto q = ids(b->columns[5], b->num_rows);
+      std::multiset<std::pair<int64_t, int64_t>> got, exp(pairs.begin(), pairs.end());
+      for (int64_t i = 0; i < b->num_rows; ++i) got.insert({p[i], q[i]});
+      for (int64_t i = 0; i < np; ++i) if (!pm[i]) exp.insert({i, -1});
+      CHECK(got == exp);
+    } else {
+      std::vector<int64_t> exp;
+      for (int64_t i = 0; i < np; ++i) if (pm[i] == (kind == LeftJoinKind::Semi)) exp.push_back(i);
+      CHECK(p == exp);
+    }
+  }
+  for (RightJoinKind kind : {RightJoinKind::Outer, RightJoinKind::Anti}) {
+    RightHashJoin j(kind, 0, 0);
+    j.set_conjunct(conj);
+    j.add_block(build); j.final_build();
+    std::multiset<std::pair<int64_t, int64_t>> got, exp;
+    auto st = j.probe_block(probe());
+    while (auto b = st->next()) {
+      auto p = ids(b->columns[2], b->num_rows), q = ids(b->columns[5], b->num_rows);
+      for (int64_t i = 0; i < b->num_rows; ++i) got.insert({p[i], q[i]});
+    }
+    auto tail = j.final_probe();
+    CHECK(tail.has_value());
+    if (kind == RightJoinKind::Anti) {
+      auto q = ids(tail->columns[2], tail->num_rows);
+      std::vector<int64_t> want;
+      for (int64_t i = 0; i < nb; ++i) if (!bmatched[i]) want.push_back(i);
+      CHECK(got.empty() && q == want);
+      continue;
+    }
+    auto q = ids(tail->columns[5], tail->num_rows), p = ids(tail->columns[2], tail->num_rows);
+    for (int64_t i = 0; i < tail->num_rows; ++i) got.insert({p[i], q[i]});
+    exp.insert(pairs.begin(), pairs.end());
+    for (int64_t i = 0; i < nb; ++i) if (!bmatched[i]) exp.insert({-1, i});
+    CHECK(got == exp);
+  }
+}
+
 static void test_hnsw_sequential_build_and_open() {
   // the deterministic build gives the same graph twice; store() -> open() searches identically without the original vectors
   const int dim = 12; const int64_t n = 1500;
@@ -546,6 +645,7 @@ int main() {
     test_join_and_sort();
     test_left_joins();
     test_hnsw_sequential_build_and_open();
+    test_join_conjuncts();
     test_right_joins();
     test_kmeans();
     test_hnsw_index();

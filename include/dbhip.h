@@ -279,6 +279,11 @@ int32_t dbhip_bitmap_binary(int32_t is_or, const uint8_t* a, const uint8_t* b, i
                             uint8_t* out, void* stream);
 int32_t dbhip_bitmap_count(const uint8_t* bitmap, int64_t bit_offset, int64_t n,
                            uint64_t* out_count_dev, void* stream);
+/* bitmap[idx[i]] |= 1 for every i (indices >= nbits are ignored; the caller zeroes the bitmap, which must be 4-byte aligned and
+ * hold ceil(nbits / 32) words). The "this probe row kept a pair" marks of a join with another conjunct: after the joined rows
+ * went through the conjunct's filter the surviving pairs' probe rows are marked (left_join.rs:273-288 conjunct_unmatched[row] = 1,
+ * left_join_semi.rs:335-350, left_join_anti.rs:287-300), the unmarked rows are the unmatched ones. */
+int32_t dbhip_bitmap_set_indices(const uint32_t* idx, int64_t n_idx, uint8_t* bitmap, int64_t nbits, void* stream);
 
 /* ---- a6: filter -> selection vector, take ---------------------------------
  * Replaces FilterExecutor::filter/select (filter/filter_executor.rs:81-118) for a

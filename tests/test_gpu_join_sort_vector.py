@@ -656,6 +656,86 @@ def test_join_kinds_output_assembly(gpu, oracle, kind, nb, np_, card):
         assert np.all(np.diff(got_p[1][:total].astype(np.int64)) >= 0) and np.array_equal(got_p[1][total:], np.nonzero(~matched)[0])
 
 
+@pytest.mark.parametrize("kind", ["inner", "left", "left_semi", "left_anti", "right", "right_semi", "right_anti", "full"])
+@pytest.mark.parametrize("nb,np_,card", [(0, 10, 5), (1000, 5000, 300), (40_000, 100_000, 30_000), (3000, 3000, 7)])
+def test_join_kinds_with_another_conjunct(gpu, oracle, kind, nb, np_, card):
+    """The `CONJUNCT = true` streams (inner_join.rs:278-310, left_join.rs:262-292, left_join_semi.rs / left_join_anti.rs filter
+    streams, right_join.rs:256-290): the key matches go through another predicate — here `probe payload < build payload` over a
+    NULLABLE build payload, so a NULL comparison drops the pair — and a probe (build) row all of whose pairs were dropped is
+    unmatched. Expected rows from the oracle's inner pairs filtered in numpy; compared as multisets."""
+    rng = np.random.default_rng(nb * 5 + np_ + 1)
+    bk = rng.integers(0, card, nb).astype(np.uint64) * np.uint64(2654435761)
+    pk = rng.integers(0, card + card // 2 + 1, np_).astype(np.uint64) * np.uint64(2654435761)
+    bvalid, pvalid = rng.integers(0, 10, nb) > 0, rng.integers(0, 10, np_) > 0
+    bpay = rng.integers(0, 1000, nb).astype(np.int64)
+    bpay_valid = rng.integers(0, 5, nb) > 0
+    ppay = rng.integers(0, 1000, np_).astype(np.int64)
+    j = gpu.HashJoin(16)
+    if nb:
+        j.add_block(gpu.Column.from_numpy(bk, validity=bvalid))
+    j.final_build()
+    probe_cols = [gpu.Column.from_numpy(ppay), gpu.Column.from_numpy(np.arange(np_, dtype=np.uint32))]
+    build_cols = [gpu.Column.from_numpy(bpay, validity=bpay_valid), gpu.Column.from_numpy(np.arange(nb, dtype=np.uint32))]
+    conj = lambda jp, jb, m: gpu.cmp(T.CMP_LT, jp[0], jb[0], m)
+    pc, bc, rows = j.join(kind, gpu.Column.from_numpy(pk, validity=pvalid), probe_cols, build_cols, conjunct=conj)
+    cap = max(nb * max(np_, 1) // max(card, 1) * 2 + np_ + 64, 1024)
+    ep, eb = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    bv = np.concatenate([np.packbits(bvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    pv = np.concatenate([np.packbits(pvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    total = oracle.orc_join_inner_u64(bk.ctypes.data_as(C.c_void_p), bv.ctypes.data_as(C.c_void_p), C.c_int64(nb), pk.ctypes.data_as(C.c_void_p),
+                                      pv.ctypes.data_as(C.c_void_p), C.c_int64(np_), ep.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+    assert total <= cap
+    ep, eb = ep[:total].astype(np.int64), eb[:total].astype(np.int64)
+    keep = bpay_valid[eb] & (ppay[ep] < bpay[eb]) if total else np.zeros(0, dtype=bool)
+    if nb >= 1000:
+        assert 0 < keep.sum() < total                                   # the conjunct really drops pairs
+    ep, eb = ep[keep], eb[keep]
+    pmatched, bmatched = np.zeros(np_, dtype=bool), np.zeros(nb, dtype=bool)
+    pmatched[ep] = True
+    bmatched[eb] = True
+
+    def valid_of(col, n):
+        return gpu.unpack_bits(col.validity.to_numpy(np.uint8, (n + 7) // 8), n) if col.validity is not None else np.ones(n, dtype=bool)
+
+    def got_rows(pcols, bcols, n):
+        out = []
+        pid = pcols[1].to_numpy() if pcols else None
+        pvd = valid_of(pcols[1], n) if pcols else None
+        bid = bcols[1].to_numpy() if bcols else None
+        bvd = valid_of(bcols[1], n) if bcols else None
+        bp = bcols[0].to_numpy() if bcols else None
+        bpv = valid_of(bcols[0], n) if bcols else None
+        for i in range(n):
+            p = int(pid[i]) if pcols and pvd[i] else None
+            b = int(bid[i]) if bcols and bvd[i] else None
+            pay = (int(bp[i]) if bpv[i] else None) if bcols else None
+            out.append((p, b, pay))
+        return out
+
+    pairs = [(int(p), int(b), int(bpay[b])) for p, b in zip(ep, eb)]      # a surviving pair always has a valid build payload
+    got = got_rows(pc, bc, rows)
+    if kind == "inner":
+        exp = pairs
+    elif kind == "left":
+        exp = pairs + [(int(p), None, None) for p in np.nonzero(~pmatched)[0]]
+    elif kind == "left_semi":
+        exp = [(int(p), None, None) for p in np.nonzero(pmatched)[0]]
+    elif kind == "left_anti":
+        exp = [(int(p), None, None) for p in np.nonzero(~pmatched)[0]]
+    elif kind == "right":
+        exp = pairs
+    elif kind == "full":
+        exp = pairs + [(int(p), None, None) for p in np.nonzero(~pmatched)[0]]
+    else:
+        exp = []
+    assert rows == len(exp) and sorted(got, key=repr) == sorted(exp, key=repr), kind
+    if kind in ("right", "right_semi", "right_anti", "full"):
+        fp, fb, fk = j.final_probe(kind, build_cols, probe_cols_like=probe_cols)
+        tail = got_rows(fp, fb, fk)
+        want = np.nonzero(bmatched)[0] if kind == "right_semi" else np.nonzero(~bmatched)[0]
+        assert sorted(tail, key=repr) == sorted([(None, int(b), (int(bpay[b]) if bpay_valid[b] else None)) for b in want], key=repr), kind
+
+
 @pytest.mark.parametrize("nb,np_,card", [(3000, 9000, 500), (60_000, 150_000, 20_000)])
 def test_join_on_keys_u256(gpu, oracle, nb, np_, card):
     """Three-column join key (i64, i64, i64 nullable = 25 bytes) -> KeysU256 (method_fixed_keys.rs:58-139, 32-byte packed keys):
