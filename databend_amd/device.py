@@ -1350,6 +1350,28 @@ class HashJoin:
             pass
 
 
+def siphash64(col):
+    """the `siphash64` scalar function (scalars/hash.rs:323-328: SipHash-1-3, zero keys, over the value's bytes) -> numpy u64[n]
+    (0 under NULL rows; the column's validity passes through)."""
+    _ensure()
+    out = DeviceBuffer(max(col.n, 1) * 8)
+    cc = col.c()
+    check(lib().dbhip_siphash64(C.byref(cc), C.c_int64(col.n), C.c_void_p(out.ptr), None))
+    return out.to_numpy(np.uint64, col.n)
+
+
+def scatter_indices(cols, scatter_size, default_index=0):
+    """HashFlightScatter::scatter_indices (flight_scatter_hash.rs:57-330): the destination of every row of a hash-shuffle exchange
+    -> (DeviceBuffer u32[n], numpy u64 rows per destination)."""
+    _ensure()
+    n = cols[0].n
+    idx = DeviceBuffer(max(n, 1) * 4)
+    counts = DeviceBuffer(int(scatter_size) * 8)
+    check(lib().dbhip_scatter_indices(_cols(cols), len(cols), C.c_int64(n), C.c_uint32(scatter_size), C.c_uint64(default_index),
+                                      C.c_void_p(idx.ptr), C.c_void_p(counts.ptr), None))
+    return idx, counts.to_numpy(np.uint64, int(scatter_size))
+
+
 def sort_perm(cols, desc=None, nulls_first=None, limit=0):
     """DataBlock::sort permutation (kernels/sort.rs:91-113) -> u32 row ids."""
     n = cols[0].n

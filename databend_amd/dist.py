@@ -373,3 +373,41 @@ def range_partitioned_sort(cols, keys, ops, dist, torch, desc=None, nulls_first=
     out_cols = out[:len(cols)]
     out_valids = [out[p] if p is not None else None for p in vpos]
     return out_cols, out_valids, bound_rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Shuffle (co-partitioned) hash join (SURVEY §8e "hash join": "else co-partition both sides by hash(key) % n"). The reference
+# scatters BOTH sides of a join by `siphash64(key) % n` (HashFlightScatter / OneHashKeyFlightScatter,
+# servers/flight/v1/scatter/flight_scatter_hash.rs:57-330) so that equal keys meet on one node, and joins locally. Device plan:
+# dbhip_scatter_indices gives every row its destination with the reference's own hash (bit-identical: a GPU rank routes rows
+# exactly like a CPU node would), one radix pass + dbhip_take_block groups the columns by destination (DataBlock::scatter), one
+# all_to_all_single per column moves them, and each rank joins what it received. Used when the build side is too large to
+# broadcast (dist.q3_broadcast_join is the other plan).
+# ---------------------------------------------------------------------------------------------------------------------
+def shuffle_hash_join(build_cols, build_key, probe_cols, probe_key, ops, dist, torch, build_valids=None, probe_valids=None):
+    """Inner join of two tables whose rows are spread over the ranks. *_cols = this rank's rows as equally long 1-D tensors,
+    *_key = index of the (integer) join key column, *_valids[c] = None or a uint8 tensor (1 = not NULL; NULL keys never match
+    and travel to rank 0, the reference's default scatter index). `ops`:
+        ops.scatter(flat, kpos, kvpos, world)         -> (flat grouped by destination, rows per destination)
+        ops.join(build_flat, bk, bkv, probe_flat, pk, pkv) -> the joined rows: probe columns ++ build columns (flat lists)
+    Returns (probe columns, build columns) of the pairs this rank produced; the union over the ranks is the join."""
+    world = dist.get_world_size()
+
+    def flatten(cols, valids):
+        valids = list(valids or [None] * len(cols))
+        flat, vpos = list(cols), [None] * len(cols)
+        for c, v in enumerate(valids):
+            if v is not None:
+                vpos[c] = len(flat)
+                flat.append(v)
+        return flat, vpos
+
+    bflat, bv = flatten(build_cols, build_valids)
+    pflat, pv = flatten(probe_cols, probe_valids)
+    sides = []
+    for flat, key, vpos in ((bflat, build_key, bv), (pflat, probe_key, pv)):
+        grouped, counts = ops.scatter(flat, key, vpos[key], world)
+        received, _ = alltoall_columns(grouped, [int(c) for c in counts], dist, torch)
+        sides.append(received)
+    out_p, out_b = ops.join(sides[0], build_key, bv[build_key], sides[1], probe_key, pv[probe_key])
+    return out_p, out_b

@@ -90,3 +90,32 @@ class SortDeviceOps:
             return list(flat)
         perm, m = D.sort_perm_device(self._keys(flat, kpos, kvpos), desc, nulls_first)
         return self._take(flat, perm, m)
+
+
+class ShuffleDeviceOps(SortDeviceOps):
+    """The single-node operators of the shuffle hash join (databend_amd.dist.shuffle_hash_join) over the C-ABI:
+    dbhip_scatter_indices (the reference's siphash64 % n), dbhip_sort_perm + dbhip_take_block (DataBlock::scatter), dbhip_join_*."""
+
+    def scatter(self, flat, kpos, kvpos, world):
+        n = int(flat[0].shape[0])
+        if n == 0:
+            return list(flat), [0] * world
+        key = self._column(flat[kpos], flat[kvpos] if kvpos is not None else None)
+        self._sync()
+        idx, counts = D.scatter_indices([key], world, 0)
+        perm, m = D.sort_perm_device([D.Column(L.T_U32, n, idx)])
+        return self._take(flat, perm, m), [int(c) for c in counts]
+
+    def join(self, build_flat, bk, bkv, probe_flat, pk, pkv):
+        nb, npr = int(build_flat[0].shape[0]), int(probe_flat[0].shape[0])
+        j = D.HashJoin(max(nb, 16))
+        bkey = self._column(build_flat[bk], build_flat[bkv] if bkv is not None else None)
+        pkey = self._column(probe_flat[pk], probe_flat[pkv] if pkv is not None else None)
+        self._sync()
+        if nb:
+            j.add_block(bkey)
+        j.final_build()
+        if npr == 0:
+            return [c[:0] for c in probe_flat], [c[:0] for c in build_flat]
+        op, ob, m = j.probe_block_device(pkey)
+        return self._take(probe_flat, op, m), self._take(build_flat, ob, m)

@@ -352,6 +352,22 @@ int32_t dbhip_take_chunks(const void* const* blocks_host, int32_t n_blocks, int3
 int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n,
                          uint64_t* out_hashes, void* stream);
 
+/* ---- §8e: scatter indices of the hash-shuffle exchange -----------------------
+ * dbhip_siphash64 replaces the `siphash64` / `siphash` scalar function (src/query/functions/src/scalars/hash.rs:50-122,323-328,
+ * DFHash :436-545; decimals scalars/decimal/src/hash.rs:144-160): SipHash-1-3 with keys (0, 0) over the value's bytes — integers,
+ * Date, Timestamp and float bit patterns in little-endian native width, Boolean as one byte, String as its bytes, Decimal
+ * (precision <= 38; `precision` / `scale` of the column must be set) as the scale byte followed by the i128 value. out[i] under a
+ * NULL row is 0 (passthrough_nullable: the caller keeps the column's validity).
+ * dbhip_scatter_indices replaces HashFlightScatter / OneHashKeyFlightScatter::scatter_indices
+ * (src/query/service/src/servers/flight/v1/scatter/flight_scatter_hash.rs:57-330): one key -> siphash64(key) % scatter_size with a
+ * NULL key going to `default_index`; several keys -> every key's siphash64 (NULL -> 0) written into a DefaultHasher (SipHash-1-3,
+ * zero keys) and finish() % scatter_size. out_index[i] = destination of row i, out_counts (DEVICE, scatter_size u64) = rows per
+ * destination. DataBlock::scatter itself = dbhip_sort_perm over out_index (one radix pass, stable) + dbhip_take_block.
+ * The values equal the reference's bit for bit (its golden file hash.txt), so a GPU node routes rows like the CPU nodes do. */
+int32_t dbhip_siphash64(const dbhip_col* col, int64_t n, uint64_t* out, void* stream);
+int32_t dbhip_scatter_indices(const dbhip_col* keys, int32_t nkeys, int64_t n, uint32_t scatter_size, uint64_t default_index,
+                              uint32_t* out_index, uint64_t* out_counts, void* stream);
+
 /* ---- a8-a13: hash aggregation ---------------------------------------------
  * Replaces AggregateHashTable behind TransformPartialAggregate /
  * TransformFinalAggregate (aggregate_hashtable.rs:168-408,

@@ -1894,3 +1894,96 @@ int64_t orc_serialize_keys(const orc_col* cols, int ncols, int64_t n, uint64_t* 
   offsets[n] = pos;
   return (int64_t)pos;
 }
+
+
+/* ------------------------------------------------------------------------ */
+/* siphash64 and the hash-shuffle scatter indices.                             */
+/* siphash64: src/query/functions/src/scalars/hash.rs:323-328 — SipHasher13::new_with_keys(0, 0) of the `siphasher` crate      */
+/* (Cargo.lock 1.0.1; NOT in /root/reference: the published SipHash-1-3 is restated) fed by DFHash (:436-545): integers / floats  */
+/* as native-width little-endian bytes, bool one byte, strings their bytes; decimals scalars/decimal/src/hash.rs:144-160: the  */
+/* scale byte, then the i128. Pinned on the reference's golden file (tests/golden/siphash.json) and hash.rs:563-600.            */
+/* scatter indices: flight_scatter_hash.rs:133-233 (one key: siphash64 % n, NULL -> default; several: DefaultHasher over them). */
+/* ------------------------------------------------------------------------ */
+typedef struct { uint64_t v0, v1, v2, v3, tail; int ntail; uint64_t len; } sip13;
+static uint64_t rotl64(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+static void sip_round(sip13* s) {
+  s->v0 += s->v1; s->v1 = rotl64(s->v1, 13); s->v1 ^= s->v0; s->v0 = rotl64(s->v0, 32);
+  s->v2 += s->v3; s->v3 = rotl64(s->v3, 16); s->v3 ^= s->v2;
+  s->v0 += s->v3; s->v3 = rotl64(s->v3, 21); s->v3 ^= s->v0;
+  s->v2 += s->v1; s->v1 = rotl64(s->v1, 17); s->v1 ^= s->v2; s->v2 = rotl64(s->v2, 32);
+}
+static void sip_init(sip13* s) {
+  s->v0 = 0x736f6d6570736575ULL; s->v1 = 0x646f72616e646f6dULL; s->v2 = 0x6c7967656e657261ULL; s->v3 = 0x7465646279746573ULL;
+  s->tail = 0; s->ntail = 0; s->len = 0;
+}
+static void sip_write(sip13* s, const uint8_t* p, size_t n) {   /* a byte stream: Hasher::write calls concatenate */
+  for (size_t i = 0; i < n; ++i) {
+    s->tail |= (uint64_t)p[i] << (8 * s->ntail);
+    s->len++;
+    if (++s->ntail == 8) { s->v3 ^= s->tail; sip_round(s); s->v0 ^= s->tail; s->tail = 0; s->ntail = 0; }
+  }
+}
+static uint64_t sip_finish(sip13* s) {
+  uint64_t b = ((s->len & 0xff) << 56) | s->tail;
+  s->v3 ^= b; sip_round(s); s->v0 ^= b;
+  s->v2 ^= 0xff;
+  sip_round(s); sip_round(s); sip_round(s);
+  return s->v0 ^ s->v1 ^ s->v2 ^ s->v3;
+}
+static int sip_value(const orc_col* c, int64_t i, uint64_t* out) {
+  int64_t j = c->is_scalar ? 0 : i;
+  sip13 s; sip_init(&s);
+  switch (c->type) {
+    case ORC_T_BOOL: { uint8_t b = (uint8_t)bit_get((const uint8_t*)c->data, j); sip_write(&s, &b, 1); } break;
+    case ORC_T_STRING: {
+      uint32_t len; const uint8_t* p = view_bytes((const uint32_t*)c->data + 4 * j, c->buffers, &len);
+      sip_write(&s, p, len);
+    } break;
+    case ORC_T_DEC64: case ORC_T_DEC128: case ORC_T_DEC256: {
+      if (c->precision < 1 || c->precision > 38) return 1;
+      uint8_t sc = (uint8_t)c->scale;
+      i128 v = c->type == ORC_T_DEC64 ? (i128)((const int64_t*)c->data)[j]
+             : c->type == ORC_T_DEC128 ? ((const i128*)c->data)[j] : ((const i128*)c->data)[2 * j];   /* the low half of the i256 */
+      sip_write(&s, &sc, 1);
+      sip_write(&s, (const uint8_t*)&v, 16);
+    } break;
+    default: {
+      int es = t_size(c->type);
+      if (es != 1 && es != 2 && es != 4 && es != 8) return 1;
+      sip_write(&s, (const uint8_t*)c->data + (size_t)j * es, (size_t)es);
+    }
+  }
+  *out = sip_finish(&s);
+  return 0;
+}
+int orc_siphash64(const orc_col* col, int64_t n, uint64_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    out[i] = 0;
+    if (!col_valid(col, i)) continue;
+    if (sip_value(col, i, &out[i])) return 1;
+  }
+  return 0;
+}
+int orc_scatter_indices(const orc_col* keys, int nkeys, int64_t n, uint64_t scatter_size, uint64_t default_index, uint32_t* out_index,
+                        uint64_t* out_counts) {
+  for (uint64_t d = 0; d < scatter_size; ++d) out_counts[d] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t idx;
+    if (nkeys == 1) {
+      uint64_t h = 0;
+      if (!col_valid(&keys[0], i)) idx = default_index;
+      else { if (sip_value(&keys[0], i, &h)) return 1; idx = h % scatter_size; }
+    } else {
+      sip13 s; sip_init(&s);   /* DefaultHasher::default() */
+      for (int k = 0; k < nkeys; ++k) {
+        uint64_t h = 0;
+        if (col_valid(&keys[k], i) && sip_value(&keys[k], i, &h)) return 1;
+        sip_write(&s, (const uint8_t*)&h, 8);   /* write_u64 */
+      }
+      idx = sip_finish(&s) % scatter_size;
+    }
+    out_index[i] = (uint32_t)idx;
+    out_counts[idx]++;
+  }
+  return 0;
+}

@@ -580,3 +580,88 @@ def test_range_partitioned_sort_concatenates_to_the_global_order(world, n, card,
     if n >= 3000:
         sizes = [len(got[r][0][0]) for r in range(world)]
         assert max(sizes) <= 1.3 * n / world, sizes                                                  # the samples balance the ranges
+
+
+# ---- shuffle hash join: both sides scattered by siphash64(key) % world, joined locally (DX.shuffle_hash_join) ----
+class ShuffleNumpyOps:
+    """host stand-in of databend_amd.sort_ops.ShuffleDeviceOps; the routing hash is the independent Python statement of the
+    reference's siphash64 (tests/siphash_ref.py)"""
+
+    def scatter(self, flat, kpos, kvpos, world):
+        from tests import siphash_ref as R
+        n = len(flat[0])
+        keys = flat[kpos].tolist()
+        valid = flat[kvpos].tolist() if kvpos is not None else [1] * n
+        dest = np.array([R.scatter_index([R.siphash64("i64", k) if v else None], world, 0) for k, v in zip(keys, valid)], dtype=np.int64)
+        order = torch.from_numpy(np.argsort(dest, kind="stable"))
+        return [c[order] for c in flat], np.bincount(dest, minlength=world).tolist()
+
+    def join(self, build_flat, bk, bkv, probe_flat, pk, pkv):
+        by_key = {}
+        bkeys = build_flat[bk].tolist()
+        bval = build_flat[bkv].tolist() if bkv is not None else [1] * len(bkeys)
+        for r, (k, v) in enumerate(zip(bkeys, bval)):
+            if v:
+                by_key.setdefault(k, []).append(r)
+        pkeys = probe_flat[pk].tolist()
+        pval = probe_flat[pkv].tolist() if pkv is not None else [1] * len(pkeys)
+        pi, bi = [], []
+        for i, (k, v) in enumerate(zip(pkeys, pval)):
+            if v:
+                for r in by_key.get(k, []):
+                    pi.append(i)
+                    bi.append(r)
+        pi, bi = torch.tensor(pi, dtype=torch.int64), torch.tensor(bi, dtype=torch.int64)
+        return [c[pi] for c in probe_flat], [c[bi] for c in build_flat]
+
+
+def shuffle_tables(seed, nb, npr, card):
+    rng = np.random.default_rng(seed)
+    return ({"k": rng.integers(0, card, nb).astype(np.int64), "v": (rng.random(nb) > 0.1).astype(np.uint8), "id": np.arange(nb, dtype=np.int64)},
+            {"k": rng.integers(0, card * 2, npr).astype(np.int64), "v": (rng.random(npr) > 0.1).astype(np.uint8), "id": np.arange(npr, dtype=np.int64)})
+
+
+def shuffle_worker(rank, world, port, seed, nb, npr, card, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b, p = shuffle_tables(seed, nb, npr, card)
+        bc, pc = sort_cuts(nb, world, True), sort_cuts(npr, world, False)
+        bs = {k: torch.from_numpy(v[bc[rank]:bc[rank + 1]].copy()) for k, v in b.items()}
+        ps = {k: torch.from_numpy(v[pc[rank]:pc[rank + 1]].copy()) for k, v in p.items()}
+        out_p, out_b = DX.shuffle_hash_join([bs["k"], bs["id"]], 0, [ps["k"], ps["id"]], 0, ShuffleNumpyOps(), dist, torch,
+                                            build_valids=[bs["v"], None], probe_valids=[ps["v"], None])
+        q.put((rank, out_p[1].numpy(), out_b[1].numpy(), out_p[0].numpy(), out_b[0].numpy()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nb,npr,card", [(2, 2000, 6000, 400), (3, 900, 2500, 5000), (3, 50, 10, 3)])
+def test_shuffle_hash_join_union_over_ranks_is_the_join(world, nb, npr, card):
+    from tests import siphash_ref as R
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=shuffle_worker, args=(r, world, port, 77, nb, npr, card, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, pid, bid, pk, bk = q.get(timeout=180)
+        got[r] = (pid, bid, pk, bk)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    b, p = shuffle_tables(77, nb, npr, card)
+    by_key = {}
+    for r in range(nb):
+        if b["v"][r]:
+            by_key.setdefault(int(b["k"][r]), []).append(r)
+    exp = sorted((i, r) for i in range(npr) if p["v"][i] for r in by_key.get(int(p["k"][i]), []))
+    pairs = sorted((int(a), int(c)) for r in range(world) for a, c in zip(got[r][0], got[r][1]))
+    assert pairs == exp and (len(exp) > 0 or nb < 100)
+    for r in range(world):      # every pair was produced on the rank its key hashes to, with equal keys on both sides
+        assert np.array_equal(got[r][2], got[r][3])
+        assert all(R.siphash64("i64", int(k)) % world == r for k in got[r][2])
