@@ -1591,6 +1591,86 @@ inline DataBlock sort_block(const DataBlock& block, const std::vector<SortColumn
   return take_block(block, perm, m);
 }
 
+// ---- exchange scatters (servers/flight/v1/scatter/flight_scatter.rs: trait FlightScatter { fn execute(&self, DataBlock) -> Vec<DataBlock> }) ----
+struct FlightScatter {
+  virtual ~FlightScatter() = default;
+  virtual const char* name() const = 0;
+  virtual std::vector<DataBlock> execute(const DataBlock& data_block) = 0;
+};
+// DataBlock::scatter(block, indices, scatter_size): rows grouped by index (stable) — one radix pass over the indices + one
+// dbhip_take_block per 8 columns; `counts` = rows per destination (host)
+inline std::vector<DataBlock> scatter_block(const DataBlock& block, const Buf& indices, const std::vector<uint64_t>& counts) {
+  const int64_t n = block.num_rows;
+  std::vector<DataBlock> out;
+  Column idx; idx.type = DataType::of(DBHIP_T_U32); idx.len = n; idx.data = indices;
+  Buf perm = make_buf((size_t)(n > 0 ? n : 1) * 4 + 64);
+  if (n) {
+    dbhip_col key = idx.c();
+    const uint8_t zero = 0;
+    check(dbhip_sort_perm(&key, &zero, &zero, 1, n, 0, (uint32_t*)perm->ptr(), nullptr));
+  }
+  int64_t at = 0;
+  for (uint64_t c : counts) {
+    out.push_back(take_block(block, (const uint32_t*)perm->ptr() + at, (int64_t)c));
+    at += (int64_t)c;
+  }
+  return out;
+}
+// HashFlightScatter / OneHashKeyFlightScatter (flight_scatter_hash.rs:57-330): siphash64(key) % scatter_size, several keys through a
+// DefaultHasher, NULL keys to the default scatter index — dbhip_scatter_indices computes the reference's own values
+class HashFlightScatter : public FlightScatter {
+ public:
+  HashFlightScatter(std::vector<size_t> hash_keys, size_t scatter_size, uint64_t default_scatter_index = 0)
+      : keys_(std::move(hash_keys)), scatter_size_(scatter_size), default_(default_scatter_index) {}
+  const char* name() const override { return keys_.size() == 1 ? "OneHashKey" : "Hash"; }
+  // the destination of every row + rows per destination (FlightScatter::scatter_indices)
+  std::pair<Buf, std::vector<uint64_t>> scatter_indices(const DataBlock& b) const {
+    std::vector<dbhip_col> cols;
+    for (size_t k : keys_) cols.push_back(b.get_by_offset(k).c());
+    Buf idx = make_buf((size_t)(b.num_rows > 0 ? b.num_rows : 1) * 4 + 64), cnt = make_buf(scatter_size_ * 8);
+    check(dbhip_scatter_indices(cols.data(), (int32_t)cols.size(), b.num_rows, (uint32_t)scatter_size_, default_, (uint32_t*)idx->ptr(),
+                                (uint64_t*)cnt->ptr(), nullptr));
+    std::vector<uint64_t> counts(scatter_size_);
+    cnt->download(counts.data(), scatter_size_ * 8);
+    return {idx, counts};
+  }
+  std::vector<DataBlock> execute(const DataBlock& data_block) override {
+    auto ic = scatter_indices(data_block);
+    return scatter_block(data_block, ic.first, ic.second);
+  }
+ private:
+  std::vector<size_t> keys_;
+  size_t scatter_size_;
+  uint64_t default_;
+};
+// SortBoundScatter over ordered bounds (sort_exchange_injector.rs + sort_spill.rs:1008-1040): range i = rows after bound i - 1 up
+// to and including bound i, to destination i % scatter_size is the caller's choice; here one block per range
+class SortBoundScatter : public FlightScatter {
+ public:
+  SortBoundScatter(std::vector<SortColumnDescription> desc, DataBlock bounds) : desc_(std::move(desc)), bounds_(std::move(bounds)) {}
+  const char* name() const override { return "SortBound"; }
+  std::vector<DataBlock> execute(const DataBlock& b) override {
+    std::vector<dbhip_col> keys, bnd;
+    std::vector<uint8_t> d, nf;
+    for (size_t i = 0; i < desc_.size(); ++i) {
+      keys.push_back(b.get_by_offset(desc_[i].offset).c());
+      if (bounds_.num_rows) bnd.push_back(bounds_.get_by_offset(i).c());
+      d.push_back(desc_[i].asc ? 0 : 1); nf.push_back(desc_[i].nulls_first ? 1 : 0);
+    }
+    const int64_t nb = bounds_.num_rows;
+    Buf part = make_buf((size_t)(b.num_rows > 0 ? b.num_rows : 1) * 4 + 64), cnt = make_buf((size_t)(nb + 1) * 8);
+    check(dbhip_sort_bound_partition(keys.data(), nb ? bnd.data() : nullptr, d.data(), nf.data(), (int32_t)keys.size(), b.num_rows, nb,
+                                     (uint32_t*)part->ptr(), (uint64_t*)cnt->ptr(), nullptr));
+    std::vector<uint64_t> counts((size_t)nb + 1);
+    cnt->download(counts.data(), counts.size() * 8);
+    return scatter_block(b, part, counts);
+  }
+ private:
+  std::vector<SortColumnDescription> desc_;
+  DataBlock bounds_;   // column i = the bound values of sort key i, ordered by the same keys
+};
+
+
 
 // ---- scan side: one leaf column of column_chunks_to_record_batch --------------------------------
 // (fuse/src/io/read/block/parquet/deserialize.rs:33-81 + the arrow -> Column conversion). `bytes` is the column chunk as the

@@ -455,6 +455,54 @@ static void test_join_conjuncts() {
   }
 }
 
+static void test_flight_scatters() {
+  // HashFlightScatter: every row lands in the block of siphash64(key) % n (NULL keys in block `default`), nothing is lost;
+  // SortBoundScatter: block i holds the rows after bound i - 1 up to and including bound i
+  const int64_t n = 20000; const size_t parts = 5;
+  std::mt19937_64 rng(31);
+  std::vector<int64_t> key(n), pay(n); std::vector<bool> valid(n);
+  for (int64_t i = 0; i < n; ++i) { key[i] = (int64_t)(rng() % 3000) - 1500; pay[i] = i; valid[i] = rng() % 7 != 0; }
+  auto I64 = DataType::of(DBHIP_T_I64);
+  Column kc = Column::from_vector(I64, key);
+  kc.validity = Column::from_bools(valid).data; kc.type.nullable = true;
+  DataBlock block({kc, Column::from_vector(I64, pay)}, n);
+  // the hashes, through the scalar function
+  Buf hb = make_buf((size_t)n * 8);
+  dbhip_col kcol = kc.c();
+  check(dbhip_siphash64(&kcol, n, (uint64_t*)hb->ptr(), nullptr));
+  std::vector<uint64_t> h((size_t)n);
+  hb->download(h.data(), (size_t)n * 8);
+  HashFlightScatter sc({0}, parts, 2);
+  CHECK(std::string(sc.name()) == "OneHashKey");
+  auto blocks = sc.execute(block);
+  CHECK(blocks.size() == parts);
+  int64_t seen = 0;
+  for (size_t d = 0; d < parts; ++d) {
+    auto p = blocks[d].columns[1].to_vector<int64_t>();
+    int64_t prev = -1;
+    for (int64_t r : p) {
+      CHECK((valid[r] ? h[r] % parts : 2) == d);
+      CHECK(r > prev);    // DataBlock::scatter keeps the row order inside a destination
+      prev = r;
+    }
+    seen += (int64_t)p.size();
+  }
+  CHECK(seen == n);
+  // bounds -100 and 700 (ascending, NULLs last): three ranges
+  SortBoundScatter sb({SortColumnDescription{0, true, false}}, DataBlock({Column::from_vector(I64, std::vector<int64_t>{-100, 700})}, 2));
+  auto ranges = sb.execute(block);
+  CHECK(ranges.size() == 3);
+  seen = 0;
+  for (size_t d = 0; d < 3; ++d) {
+    for (int64_t r : ranges[d].columns[1].to_vector<int64_t>()) {
+      const size_t want = !valid[r] ? 2 : key[r] <= -100 ? 0 : key[r] <= 700 ? 1 : 2;
+      CHECK(want == d);
+      ++seen;
+    }
+  }
+  CHECK(seen == n);
+}
+
 static void test_hnsw_sequential_build_and_open() {
   // the deterministic build gives the same graph twice; store() -> open() searches identically without the original vectors
   const int dim = 12; const int64_t n = 1500;
@@ -646,6 +694,7 @@ int main() {
     test_left_joins();
     test_hnsw_sequential_build_and_open();
     test_join_conjuncts();
+    test_flight_scatters();
     test_right_joins();
     test_kmeans();
     test_hnsw_index();

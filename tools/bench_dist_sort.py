@@ -1,4 +1,4 @@
-"""One rank's share of the distributed sort (databend_amd.dist.range_partitioned_sort) on one MI355X: the stages a rank runs on
+"""One rank's share of the distributed sort and of the shuffle hash join's scatter (databend_amd.dist.range_partitioned_sort) on one MI355X: the stages a rank runs on
 `--rows` rows of an i64 key + an i64 payload cut at `--ranges - 1` bounds — range partition (dbhip_sort_bound_partition), grouping
 by range (one radix pass over the partition ids + dbhip_take_block), and the local sort of what a rank receives (rows / ranges
 ... here: the same rows, i.e. the balanced case) — each timed with HIP events through torch on the library's stream.
@@ -56,11 +56,18 @@ def main():
     recv = [c[:share].contiguous() for c in grouped]
     t_sort, out = wall(lambda: ops.sort(recv, [0], [None], [0], [0]))
     t_sort_all, _ = wall(lambda: ops.sort(flat, [0], [None], [0], [0]))
+    t_scat, (sidx, scnt) = wall(lambda: D.scatter_indices(kcol, a.ranges, 0))
+    from databend_amd.sort_ops import ShuffleDeviceOps
+    sops = ShuffleDeviceOps(torch)
+    t_scat_all, _ = wall(lambda: sops.scatter(flat, 0, None, a.ranges))
+    assert int(scnt.sum()) == a.rows
     assert counts.tolist() == [int(c) for c in counts2] and int(counts.sum()) == a.rows
     assert bool((out[0][1:] >= out[0][:-1]).all())
     res = {"rows": a.rows, "ranges": a.ranges, "rows_per_range": [int(c) for c in counts],
            "bound_partition_ms": round(t_part, 3), "bound_partition_GBps": round(a.rows * 12 / t_part / 1e6, 1),
            "group_by_range_perm_ms": round(t_group, 3), "take_block_2cols_ms": round(t_take, 3), "partition_operator_ms": round(t_all, 3),
+           "siphash_scatter_indices_ms": round(t_scat, 3), "siphash_scatter_indices_GBps": round(a.rows * 12 / t_scat / 1e6, 1),
+           "scatter_operator_ms": round(t_scat_all, 3), "rows_per_destination": [int(c) for c in scnt],
            "local_sort_of_one_share_ms": round(t_sort, 3), "single_gpu_sort_of_all_rows_ms": round(t_sort_all, 3),
            "note": "wall clock around synchronised library calls (includes the host-side sync of each call); one rank's stages of the distributed sort"}
     print(json.dumps(res))
