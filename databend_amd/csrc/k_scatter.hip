@@ -98,6 +98,15 @@ __global__ __launch_bounds__(256) void siphash64_kernel(SipCol c, int64_t n, uin
   }
 }
 
+// the longest value of a view column (a column handed over WITHOUT data buffers may only hold inline values)
+__global__ __launch_bounds__(256) void sip_max_len_kernel(const uint32_t* views, int64_t n, uint32_t* out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = views[4 * i] > m ? views[4 * i] : m;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+  if (lane_id() == 0 && m) atomicMax(out, m);
+}
+
 struct SipKeys { SipCol k[8]; int nkeys; };
 
 constexpr int SCATTER_HIST_MAX = 4096;
@@ -132,8 +141,19 @@ __global__ __launch_bounds__(256) void scatter_indices_kernel(SipKeys K, int64_t
   if (lds) for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += blockDim.x) if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
 }
 
-int32_t make_sip_col(const dbhip_col& c, const char* fn, int k, SipCol* out) {
+int32_t make_sip_col(const dbhip_col& c, int64_t n, hipStream_t s, const char* fn, int k, SipCol* out) {
   const int t = c.type;
+  if (t == DBHIP_T_STRING && !c.buffers && n > 0) {   // inline views only: verify, a long view would dereference a missing buffer table
+    uint32_t* flag = (uint32_t*)scratch(64, 9, s);
+    if (!flag) return DBHIP_ERR_HIP;
+    DBHIP_CHECK(hipMemsetAsync(flag, 0, 4, s));
+    const int64_t rows = c.is_scalar ? 1 : n;
+    hipLaunchKernelGGL(sip_max_len_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, s, (const uint32_t*)c.data, rows, flag);
+    uint32_t mx = 0;
+    DBHIP_CHECK(hipMemcpyAsync(&mx, flag, 4, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    if (mx > 12) { set_error("%s: string key %d holds values longer than 12 bytes but no data buffers", fn, k); return DBHIP_ERR_INVALID; }
+  }
   const bool ok = (t >= DBHIP_T_BOOL && t <= DBHIP_T_STRING) || t == DBHIP_T_DEC256;
   if (!ok) { set_error("%s: key %d has unsupported type %d", fn, k, t); return DBHIP_ERR_UNSUPPORTED; }
   if ((t == DBHIP_T_DEC64 || t == DBHIP_T_DEC128 || t == DBHIP_T_DEC256) && (c.precision < 1 || c.precision > 38)) {
@@ -154,9 +174,10 @@ int32_t dbhip_siphash64(const dbhip_col* col, int64_t n, uint64_t* out, void* st
   if (n == 0) return DBHIP_OK;
   DBHIP_REQUIRE(out && col->data, "dbhip_siphash64: NULL buffer");
   SipCol c;
-  int32_t rc = make_sip_col(*col, "dbhip_siphash64", 0, &c);
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc = make_sip_col(*col, n, s, "dbhip_siphash64", 0, &c);
   if (rc) return rc;
-  hipLaunchKernelGGL(siphash64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, resolve_stream(stream), c, n, out);
+  hipLaunchKernelGGL(siphash64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, c, n, out);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
@@ -174,7 +195,7 @@ int32_t dbhip_scatter_indices(const dbhip_col* keys, int32_t nkeys, int64_t n, u
   memset(&K, 0, sizeof(K));
   K.nkeys = nkeys;
   for (int k = 0; k < nkeys; ++k) {
-    int32_t rc = make_sip_col(keys[k], "dbhip_scatter_indices", k, &K.k[k]);
+    int32_t rc = make_sip_col(keys[k], n, s, "dbhip_scatter_indices", k, &K.k[k]);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(scatter_indices_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, K, n, (uint64_t)scatter_size, default_index, out_index,

@@ -450,6 +450,10 @@ int32_t dbhip_sort_bound_partition(const dbhip_col* keys, const dbhip_col* bound
       DBHIP_CHECK(hipMemcpyAsync(&mx, flag, 4, hipMemcpyDeviceToHost, s));
       DBHIP_CHECK(hipStreamSynchronize(s));
       if (mx > 12) {
+        if (!keys[k].buffers || (nbounds && !bounds[k].buffers)) {
+          set_error("dbhip_sort_bound_partition: string key %d holds values longer than 12 bytes but the rows or the bounds carry no data buffers", k);
+          return DBHIP_ERR_INVALID;
+        }
         if (mx > 4096) { set_error("dbhip_sort_bound_partition: string key %d holds a %u-byte value (> 4096: keep the CPU operator for this block)", k, mx); return DBHIP_ERR_UNSUPPORTED; }
         nparts = 1 + (int)((mx + 7) / 8);
       }

@@ -65,6 +65,12 @@ def test_unsupported_decimal_precision_is_refused(gpu):
     with pytest.raises(T.DbhipError) as e:
         gpu.siphash64(col)
     assert e.value.code == T.ERR_UNSUPPORTED
+    # long views without their data buffers are refused instead of dereferenced
+    views, _buf = make_views_general([b"short", b"a value of more than twelve bytes"])
+    with pytest.raises(T.DbhipError) as e2:
+        gpu.siphash64(gpu.Column.from_views(views))
+    assert e2.value.code == T.ERR_INVALID
+    assert gpu.siphash64(gpu.Column.from_views(views[:1])).shape == (1,)
 
 
 @pytest.mark.parametrize("n,m", [(0, 4), (1, 1), (50_000, 8), (300_000, 3), (100_000, 5000)])
