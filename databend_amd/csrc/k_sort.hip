@@ -271,6 +271,90 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const K* keys, const 
   }
 }
 
+// DataBlock::scatter for one value buffer: the radix scatter above with the destination index (< 256) as the digit and the
+// column's elements as the payload — rows keep their order inside a destination (stable). The index is not written back.
+template <typename V>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const uint32_t* index, const V* src, int64_t n, const uint64_t* offs, int64_t ntiles,
+                                                           V* out) {
+  __shared__ V lvals[SORT_TILE];
+  __shared__ uint8_t ldig[SORT_TILE];
+  __shared__ uint32_t wcount[4][256];
+  __shared__ uint32_t tile_off[256];
+  __shared__ uint32_t wave_tot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+  uint32_t dig[SORT_ITEMS];
+  V val[SORT_ITEMS];
+  uint32_t lrank[SORT_ITEMS];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    dig[r] = i < n ? (index[i] & 0xFF) : 0xFF;
+    val[r] = i < n ? src[i] : V{};
+  }
+  volatile uint32_t* wc = wcount[wave];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool active = i < n;
+    const uint32_t digit = dig[r];
+    uint64_t m = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t bal = __ballot((digit >> b) & 1);
+      m &= ((digit >> b) & 1) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(m & ((1ULL << lane) - 1));
+    const uint32_t prev = wc[digit];
+    __builtin_amdgcn_wave_barrier();
+    if (active && rank == 0) wc[digit] = prev + __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    lrank[r] = prev + rank;
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid], c3 = wcount[3][tid];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    uint32_t incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wb = 0;
+    for (int w = 0; w < wave; ++w) wb += wave_tot[w];
+    const uint32_t off = wb + incl - tot;
+    tile_off[tid] = off;
+    wcount[0][tid] = off;
+    wcount[1][tid] = off + c0;
+    wcount[2][tid] = off + c0 + c1;
+    wcount[3][tid] = off + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    if (i < n) {
+      const uint32_t p = wcount[wave][dig[r]] + lrank[r];
+      lvals[p] = val[r];
+      ldig[p] = (uint8_t)dig[r];
+    }
+  }
+  __syncthreads();
+  const int64_t tile_base = (int64_t)blockIdx.x * SORT_TILE;
+  const int tile_n = (int)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
+#pragma unroll 4
+  for (int j = tid; j < tile_n; j += 256) {
+    const uint32_t digit = ldig[j];
+    out[offs[(int64_t)digit * ntiles + blockIdx.x] + (uint32_t)(j - tile_off[digit])] = lvals[j];
+  }
+}
+
 // ---- LIMIT: radix select on the most significant sort key --------------------------------------
 // count of images whose bits above `shift+8` equal those of `prefix`, per next byte
 __global__ __launch_bounds__(256) void sort_select_hist_kernel(const uint64_t* enc, int64_t n, uint64_t prefix, int shift,
@@ -477,6 +561,59 @@ int32_t dbhip_sort_bound_partition(const dbhip_col* keys, const dbhip_col* bound
   else
     hipLaunchKernelGGL(sort_bound_partition_kernel<false>, dim3(grid), dim3(256), hist_bytes, s, bk, n, (int)nbounds, img, out_part,
                        (unsigned long long*)out_counts);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
+  return DBHIP_OK;
+}
+
+int32_t dbhip_scatter_block(const void* const* srcs_host, const int32_t* elem_sizes_host, int32_t ncols, const uint32_t* index, int64_t n,
+                            uint32_t scatter_size, void* const* outs_host, void* stream) {
+  DBHIP_REQUIRE(ncols >= 0 && n >= 0 && n < 0xFFFFFFFFLL && scatter_size >= 1, "dbhip_scatter_block: bad argument");
+  if (n == 0 || ncols == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(srcs_host && elem_sizes_host && outs_host && index, "dbhip_scatter_block: NULL argument");
+  bool direct = scatter_size <= 256;
+  for (int c = 0; c < ncols; ++c) {
+    const int es = elem_sizes_host[c];
+    DBHIP_REQUIRE(es == 1 || es == 2 || es == 4 || es == 8 || es == 16, "dbhip_scatter_block: elem_size must be 1, 2, 4, 8 or 16");
+    DBHIP_REQUIRE(srcs_host[c] && outs_host[c], "dbhip_scatter_block: NULL column");
+    if (es == 16) direct = false;
+  }
+  hipStream_t s = resolve_stream(stream);
+  if (!direct) {   // many destinations or 16-byte elements: the stable permutation of the rows + one gather
+    uint32_t* perm = (uint32_t*)scratch((size_t)n * 4 + 64, 10, s);
+    if (!perm) return DBHIP_ERR_HIP;
+    dbhip_col key;
+    memset(&key, 0, sizeof(key));
+    key.type = DBHIP_T_U32;
+    key.data = index;
+    const uint8_t zero = 0;
+    int32_t rc = dbhip_sort_perm(&key, &zero, &zero, 1, n, 0, perm, stream);
+    if (rc) return rc;
+    for (int c0 = 0; c0 < ncols; c0 += 8) {
+      const int g = ncols - c0 < 8 ? ncols - c0 : 8;
+      if ((rc = dbhip_take_block(srcs_host + c0, elem_sizes_host + c0, g, perm, n, outs_host + c0, stream))) return rc;
+    }
+    DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
+    return DBHIP_OK;
+  }
+  const int64_t ntiles = ceil_div(n, SORT_TILE);
+  const int64_t nh = 256 * ntiles;
+  uint8_t* ws = (uint8_t*)scratch((size_t)nh * 4 + (size_t)nh * 8 + (size_t)(nh / SCAN_TILE + 2) * 8 + 256, 10, s);
+  if (!ws) return DBHIP_ERR_HIP;
+  uint64_t* offs = (uint64_t*)ws;
+  uint64_t* blk = offs + nh;
+  uint32_t* hist = (uint32_t*)(blk + nh / SCAN_TILE + 2);
+  hipLaunchKernelGGL(sort_hist_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, index, n, 0, hist, ntiles);
+  int32_t rc = dbscan::exclusive_scan_u32(hist, nh, blk, offs, s);
+  if (rc) return rc;
+  for (int c = 0; c < ncols; ++c) {
+    switch (elem_sizes_host[c]) {
+      case 1: hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, dim3((unsigned)ntiles), dim3(256), 0, s, index, (const uint8_t*)srcs_host[c], n, offs, ntiles, (uint8_t*)outs_host[c]); break;
+      case 2: hipLaunchKernelGGL(scatter_rows_kernel<uint16_t>, dim3((unsigned)ntiles), dim3(256), 0, s, index, (const uint16_t*)srcs_host[c], n, offs, ntiles, (uint16_t*)outs_host[c]); break;
+      case 4: hipLaunchKernelGGL(scatter_rows_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, index, (const uint32_t*)srcs_host[c], n, offs, ntiles, (uint32_t*)outs_host[c]); break;
+      default: hipLaunchKernelGGL(scatter_rows_kernel<uint64_t>, dim3((unsigned)ntiles), dim3(256), 0, s, index, (const uint64_t*)srcs_host[c], n, offs, ntiles, (uint64_t*)outs_host[c]); break;
+    }
+  }
   DBHIP_LAUNCH_CHECK();
   DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
   return DBHIP_OK;

@@ -1372,6 +1372,18 @@ def scatter_indices(cols, scatter_size, default_index=0):
     return idx, counts.to_numpy(np.uint64, int(scatter_size))
 
 
+def scatter_block(cols, index, scatter_size):
+    """DataBlock::scatter (kernels/scatter.rs:20-66) for the value buffers of `cols` (no Bitmap columns): rows grouped by
+    index[i], in order inside a destination -> list of Columns (validities are not carried: scatter them as u8 columns)."""
+    n = cols[0].n
+    bufs = [DeviceBuffer(max(n, 1) * ELEM_SIZE[c.dtype] + 64) for c in cols]
+    srcs = (C.c_void_p * len(cols))(*[c.data.ptr for c in cols])
+    dsts = (C.c_void_p * len(cols))(*[b.ptr for b in bufs])
+    es = (C.c_int32 * len(cols))(*[ELEM_SIZE[c.dtype] for c in cols])
+    check(lib().dbhip_scatter_block(srcs, es, len(cols), C.c_void_p(index.ptr), C.c_int64(n), C.c_uint32(scatter_size), dsts, None))
+    return [Column(c.dtype, n, b, None, c.precision, c.scale, buffers=c.buffers, keep=(c,)) for c, b in zip(cols, bufs)]
+
+
 def sort_perm(cols, desc=None, nulls_first=None, limit=0):
     """DataBlock::sort permutation (kernels/sort.rs:91-113) -> u32 row ids."""
     n = cols[0].n

@@ -1,6 +1,6 @@
 """The single-node operators of the distributed sort (databend_amd.dist.range_partitioned_sort) over the C-ABI: the columns are
 CUDA tensors (torch.distributed moves them over RCCL), every operator is one or two library calls on them — dbhip_sort_perm,
-dbhip_sort_bound_partition, dbhip_take_block. Nothing here computes on the host except the tiny sample / bounds tables."""
+dbhip_sort_bound_partition, dbhip_scatter_block, dbhip_take_block. Nothing here computes on the host except the tiny sample / bounds tables."""
 import ctypes as C
 
 import numpy as np
@@ -59,6 +59,18 @@ class SortDeviceOps:
         L.check(L.lib().dbhip_stream_sync(None))
         return outs
 
+    def _scatter(self, flat, index, n, destinations):
+        """DataBlock::scatter of every column by the destination index (dbhip_scatter_block: one pass per column)"""
+        t = self.torch
+        outs = [t.empty(n, dtype=c.dtype, device=c.device) for c in flat]
+        srcs_t = [c.contiguous() for c in flat]
+        self._sync()
+        srcs = (C.c_void_p * len(flat))(*[c.data_ptr() for c in srcs_t])
+        dsts = (C.c_void_p * len(flat))(*[o.data_ptr() for o in outs])
+        es = (C.c_int32 * len(flat))(*[c.element_size() for c in srcs_t])
+        L.check(L.lib().dbhip_scatter_block(srcs, es, len(flat), C.c_void_p(index.ptr), C.c_int64(n), C.c_uint32(destinations), dsts, None))
+        return outs
+
     def ordered_rows(self, key_cols, key_valids, desc, nulls_first):
         n = int(key_cols[0].shape[0])
         if n == 0:
@@ -81,8 +93,7 @@ class SortDeviceOps:
             null = [r[k] is None for r in bounds]
             bcols.append(D.Column.from_numpy(vals, c.dtype, validity=(np.array([not x for x in null]) if (any(null) or c.validity is not None) else None)))
         part, counts = D.sort_bound_partition(cols, bcols, desc, nulls_first)
-        perm, m = D.sort_perm_device([D.Column(L.T_U32, n, part)])          # rows grouped by range, stable: one radix pass
-        return self._take(flat, perm, m), [int(c) for c in counts]
+        return self._scatter(flat, part, n, len(bounds) + 1), [int(c) for c in counts]
 
     def sort(self, flat, kpos, kvpos, desc, nulls_first):
         n = int(flat[0].shape[0])
@@ -94,7 +105,7 @@ class SortDeviceOps:
 
 class ShuffleDeviceOps(SortDeviceOps):
     """The single-node operators of the shuffle hash join (databend_amd.dist.shuffle_hash_join) over the C-ABI:
-    dbhip_scatter_indices (the reference's siphash64 % n), dbhip_sort_perm + dbhip_take_block (DataBlock::scatter), dbhip_join_*."""
+    dbhip_scatter_indices (the reference's siphash64 % n), dbhip_scatter_block (DataBlock::scatter), dbhip_join_*."""
 
     def scatter(self, flat, kpos, kvpos, world):
         n = int(flat[0].shape[0])
@@ -103,8 +114,7 @@ class ShuffleDeviceOps(SortDeviceOps):
         key = self._column(flat[kpos], flat[kvpos] if kvpos is not None else None)
         self._sync()
         idx, counts = D.scatter_indices([key], world, 0)
-        perm, m = D.sort_perm_device([D.Column(L.T_U32, n, idx)])
-        return self._take(flat, perm, m), [int(c) for c in counts]
+        return self._scatter(flat, idx, n, world), [int(c) for c in counts]
 
     def join(self, build_flat, bk, bkv, probe_flat, pk, pkv):
         nb, npr = int(build_flat[0].shape[0]), int(probe_flat[0].shape[0])

@@ -362,9 +362,17 @@ int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n,
  * (src/query/service/src/servers/flight/v1/scatter/flight_scatter_hash.rs:57-330): one key -> siphash64(key) % scatter_size with a
  * NULL key going to `default_index`; several keys -> every key's siphash64 (NULL -> 0) written into a DefaultHasher (SipHash-1-3,
  * zero keys) and finish() % scatter_size. out_index[i] = destination of row i, out_counts (DEVICE, scatter_size u64) = rows per
- * destination. DataBlock::scatter itself = dbhip_sort_perm over out_index (one radix pass, stable) + dbhip_take_block.
+ * destination. DataBlock::scatter itself = dbhip_scatter_block below.
  * The values equal the reference's bit for bit (its golden file hash.txt), so a GPU node routes rows like the CPU nodes do. */
 int32_t dbhip_siphash64(const dbhip_col* col, int64_t n, uint64_t* out, void* stream);
+/* DataBlock::scatter(block, indices, scatter_size) (src/query/expression/src/kernels/scatter.rs) for the value buffers of up to any
+ * number of columns: outs[c] = the rows of srcs[c] grouped by index[i] (every index < scatter_size), rows keeping their order
+ * inside a destination; destination d's rows start at sum(counts[0..d)) (dbhip_scatter_indices / dbhip_sort_bound_partition give
+ * the counts). Up to 256 destinations and elements of 1 / 2 / 4 / 8 bytes move in ONE pass per column (per-tile histogram of
+ * the indices, scan, stable in-LDS ranking); more destinations or 16-byte elements go through the stable permutation + gather.
+ * Bitmap columns: scatter the bytes of an unpacked image or use the permutation path of the caller. */
+int32_t dbhip_scatter_block(const void* const* srcs_host, const int32_t* elem_sizes_host, int32_t ncols, const uint32_t* index, int64_t n,
+                            uint32_t scatter_size, void* const* outs_host, void* stream);
 int32_t dbhip_scatter_indices(const dbhip_col* keys, int32_t nkeys, int64_t n, uint32_t scatter_size, uint64_t default_index,
                               uint32_t* out_index, uint64_t* out_counts, void* stream);
 

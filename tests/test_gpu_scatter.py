@@ -156,3 +156,25 @@ def test_shuffle_hash_join_operators_and_plan_on_one_rank(gpu):
         assert sorted(zip(out_p[1].cpu().tolist(), out_b[1].cpu().tolist())) == exp
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (4095, 2), (4097, 8), (300_000, 256), (200_000, 257), (100_000, 5000)])
+def test_scatter_block_groups_rows_stably(gpu, n, m):
+    """dbhip_scatter_block = DataBlock::scatter (kernels/scatter.rs:20-66): every column grouped by destination, row order kept
+    inside a destination — against numpy's stable argsort, for 1 / 2 / 4 / 8 / 16-byte elements, the one-pass path (<= 256
+    destinations) and the permutation path (more destinations, 16-byte elements)."""
+    rng = np.random.default_rng(n + m)
+    index = rng.integers(0, m, n).astype(np.uint32)
+    if n > 5000:
+        index[:3000] = 0                      # long runs of one destination
+    cols = [rng.integers(0, 255, n).astype(np.uint8), rng.integers(-3000, 3000, n).astype(np.int16), rng.standard_normal(n).astype(np.float32),
+            rng.integers(-2**62, 2**62, n).astype(np.int64)]
+    order = np.argsort(index, kind="stable")
+    ibuf = gpu.DeviceBuffer.from_numpy(index)
+    out = gpu.scatter_block([gpu.Column.from_numpy(c) for c in cols], ibuf, m)
+    for got, src in zip(out, cols):
+        assert np.array_equal(got.to_numpy(), src[order])
+    dec = [int(x) for x in rng.integers(-2**62, 2**62, n)]
+    out = gpu.scatter_block([gpu.Column.decimal128(dec, 38, 0), gpu.Column.from_numpy(cols[3])], ibuf, m)     # 16-byte elements
+    assert [int(x) for x in out[0].to_numpy()] == [dec[i] for i in order]
+    assert np.array_equal(out[1].to_numpy(), cols[3][order])
