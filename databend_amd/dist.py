@@ -411,3 +411,70 @@ def shuffle_hash_join(build_cols, build_key, probe_cols, probe_key, ops, dist, t
         sides.append(received)
     out_p, out_b = ops.join(sides[0], build_key, bv[build_key], sides[1], probe_key, pv[probe_key])
     return out_p, out_b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Aggregation WITHOUT keys across ranks (SURVEY §8e "`sum` without keys": BASELINE configs[0] `SELECT sum(a + b * c)` and every
+# other single-state aggregate). The reference's PartialSingleStateAggregator hands one serialized state per thread / node to the
+# FinalSingleStateAggregator, which merges them one after the other (transform_single_key.rs:43-279). Here every rank holds ONE
+# state per aggregate (the device reduced its rows: dbhip_expr_eval's sum_out, dbhip_groupby_* with no key); the states of all
+# ranks travel in ONE all-gather of three words per state and are folded IN RANK ORDER on every rank — not an all-reduce, whose
+# summation order is the library's: f64 sums are order-dependent (§8a a10) and the fold below is the one order every rank and
+# every run agrees on; i128 sums need their carry, which a per-word all-reduce would drop.
+# ---------------------------------------------------------------------------------------------------------------------
+def merge_single_states(states, dist, torch, device):
+    """states = this rank's [(kind, cls, value, has)]: kind in ("sum", "count", "min", "max"); cls in ("i64", "u64", "i128", "f64");
+    value = a Python int (two's complement of the class's width is applied) or float; has = saw a non-NULL row (count: ignored).
+    Returns the merged [(value, has)] — identical on every rank; sums wrap at the class's width like the reference's states
+    (aggregate_sum.rs:113-129; Decimal overflow is decided on the final total by the caller, as for the hash table)."""
+    import struct
+    world = dist.get_world_size()
+    M64, M128 = (1 << 64) - 1, (1 << 128) - 1
+
+    def s64(x):
+        return x - (1 << 64) if x >> 63 else x
+
+    words = []
+    for kind, cls, value, has in states:
+        if cls == "f64":
+            lo, hi = struct.unpack("<Q", struct.pack("<d", float(value)))[0], 0
+        else:
+            v = int(value) & (M128 if cls == "i128" else M64)
+            lo, hi = v & M64, v >> 64
+        words += [s64(lo), s64(hi), 1 if (has or kind == "count") else 0]
+    mine = torch.tensor(words, dtype=torch.int64, device=device)
+    gathered = torch.empty(world * max(len(words), 1), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(gathered[: world * len(words)] if words else gathered, mine if words else torch.zeros(1, dtype=torch.int64, device=device))
+    rows = gathered[: world * len(words)].view(world, -1).tolist() if words else []
+    out = []
+    for i, (kind, cls, _value, _has) in enumerate(states):
+        acc, acc_has = None, False
+        for r in range(world):
+            lo, hi, has = rows[r][3 * i] & M64, rows[r][3 * i + 1] & M64, rows[r][3 * i + 2]
+            if not has:
+                continue
+            if cls == "f64":
+                v = struct.unpack("<d", struct.pack("<Q", lo))[0]
+            else:
+                v = lo | (hi << 64)
+                width = 128 if cls == "i128" else 64
+                if cls != "u64" and v >> (width - 1):
+                    v -= 1 << width
+            if acc is None:
+                acc = v
+            elif kind in ("sum", "count"):
+                acc = acc + v
+                if cls == "i64":
+                    acc = s64(acc & M64)
+                elif cls == "u64":
+                    acc &= M64
+                elif cls == "i128":
+                    acc &= M128
+                    acc = acc - (1 << 128) if acc >> 127 else acc
+            elif kind == "min":
+                acc = v if v < acc else acc
+            else:
+                acc = v if v > acc else acc
+            acc_has = True
+        out.append(((0.0 if cls == "f64" else 0) if acc is None else acc, acc_has))
+    return out

@@ -665,3 +665,66 @@ def test_shuffle_hash_join_union_over_ranks_is_the_join(world, nb, npr, card):
     for r in range(world):      # every pair was produced on the rank its key hashes to, with equal keys on both sides
         assert np.array_equal(got[r][2], got[r][3])
         assert all(R.siphash64("i64", int(k)) % world == r for k in got[r][2])
+
+
+# ---- aggregation without keys: one state per aggregate and rank, folded in rank order (DX.merge_single_states) ----
+def single_state_inputs(rank):
+    rng = np.random.default_rng(100 + rank)
+    a, b, c = (rng.integers(-2**62, 2**62, 1000) for _ in range(3))
+    f = rng.standard_normal(1000) * 10.0 ** rng.integers(-8, 8, 1000)
+    d = [int(x) * int(y) for x, y in zip(rng.integers(-2**62, 2**62, 50), rng.integers(0, 2**60, 50))]
+    return a, b, c, f, d
+
+
+def single_state_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b, c, f, d = single_state_inputs(rank)
+        wrap = int((a.astype(np.uint64) + b.astype(np.uint64) * c.astype(np.uint64)).sum(dtype=np.uint64))      # sum(a + b * c), wrapping
+        fsum = 0.0
+        for x in f.tolist():
+            fsum += x                                                                                          # sequential, like sum_batch
+        empty = rank == 1                                                                                      # a rank without rows
+        states = [("sum", "i64", wrap, True), ("sum", "f64", fsum, True), ("sum", "i128", sum(d), True), ("count", "u64", 1000, True),
+                  ("min", "i64", int(a.min()), not empty), ("max", "f64", float(f.max()), not empty), ("sum", "i64", 0, False)]
+        q.put((rank, DX.merge_single_states(states, dist, torch, torch.device("cpu"))))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_single_state_aggregates_merge_in_rank_order(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=single_state_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    M64 = (1 << 64) - 1
+    wrap, fs, ds, mins, maxs = 0, [], 0, [], []
+    for r in range(world):
+        a, b, c, f, d = single_state_inputs(r)
+        wrap = (wrap + int((a.astype(np.uint64) + b.astype(np.uint64) * c.astype(np.uint64)).sum(dtype=np.uint64))) & M64
+        s = 0.0
+        for x in f.tolist():
+            s += x
+        fs.append(s)
+        ds += sum(d)
+        if r != 1:
+            mins.append(int(a.min()))
+            maxs.append(float(f.max()))
+    fsum = fs[0]
+    for s in fs[1:]:
+        fsum += s                                                  # rank order
+    ds &= (1 << 128) - 1
+    exp = [(wrap - (1 << 64) if wrap >> 63 else wrap, True), (fsum, True), (ds - (1 << 128) if ds >> 127 else ds, True), (1000 * world, True),
+           (min(mins), True), (max(maxs), True), (0, False)]
+    for r in range(world):
+        assert got[r] == exp, r
