@@ -500,6 +500,36 @@ __global__ __launch_bounds__(256) void sort_bound_partition_kernel(BoundKeys bk,
     if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
 }
 
+// The common shape — ONE fixed-width key without NULLs (one image per row) and at most 63 bounds: the bounds sit in registers
+// (uniform loads), a row's range is the branch-free count of bounds below its image, four rows per thread are in flight, and the
+// rows per range are counted with one ballot per range (lane d accumulates range d) instead of LDS atomics.
+constexpr int BOUND_SMALL_MAX = 63;
+template <int NB>   // NB = bounds rounded up to 8, 16, 32 or 64 (padded with ~0: never below a row)
+__global__ __launch_bounds__(256) void sort_bound_partition_small_kernel(BoundKeys bk, int64_t n, int nbounds, const uint64_t* img,
+                                                                         uint32_t* out_part, unsigned long long* counts) {
+  uint64_t b[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) b[j] = j < nbounds ? img[j] : ~0ULL;
+  const int parts0 = bound_key_parts(bk, 0);
+  const int lane = lane_id();
+  unsigned long long mine = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; base < n; base += stride) {   // whole waves iterate together
+    const int64_t i = base + lane;
+    const bool live = i < n;
+    const uint64_t x = live ? bound_image(bk.row[0], (uint32_t)i, false, parts0, 0) : 0;
+    uint32_t p = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) p += b[j] < x ? 1u : 0u;
+    if (live) out_part[i] = p;
+    for (int d = 0; d <= nbounds; ++d) {
+      const uint64_t m = __ballot(live && p == (uint32_t)d);
+      if (lane == d) mine += (unsigned long long)__popcll(m);
+    }
+  }
+  if (lane <= nbounds && mine) atomicAdd(&counts[lane], mine);
+}
+
 }  // namespace
 
 extern "C" {
@@ -555,7 +585,14 @@ int32_t dbhip_sort_bound_partition(const dbhip_col* keys, const dbhip_col* bound
   if (nbounds) hipLaunchKernelGGL(sort_bound_encode_kernel, dim3((unsigned)ceil_div(nbounds, 256)), dim3(256), 0, s, bk, (int)nbounds, img);
   const int nhist = nbounds + 1 <= BOUND_HIST_MAX ? (int)nbounds + 1 : 0;
   const size_t hist_bytes = (size_t)((nhist + 1) / 2) * 8;
-  if (img_bytes <= 32768)
+  const bool small = nkeys == 1 && bk.nimg == 1 && nbounds >= 1 && nbounds <= BOUND_SMALL_MAX && keys[0].type != DBHIP_T_STRING && keys[0].type != DBHIP_T_DEC128;
+  if (small) {
+    const dim3 g(grid_for(n, 256)), blk(256);
+    if (nbounds <= 8) hipLaunchKernelGGL(sort_bound_partition_small_kernel<8>, g, blk, 0, s, bk, n, (int)nbounds, img, out_part, (unsigned long long*)out_counts);
+    else if (nbounds <= 16) hipLaunchKernelGGL(sort_bound_partition_small_kernel<16>, g, blk, 0, s, bk, n, (int)nbounds, img, out_part, (unsigned long long*)out_counts);
+    else if (nbounds <= 32) hipLaunchKernelGGL(sort_bound_partition_small_kernel<32>, g, blk, 0, s, bk, n, (int)nbounds, img, out_part, (unsigned long long*)out_counts);
+    else hipLaunchKernelGGL(sort_bound_partition_small_kernel<64>, g, blk, 0, s, bk, n, (int)nbounds, img, out_part, (unsigned long long*)out_counts);
+  } else if (img_bytes <= 32768)
     hipLaunchKernelGGL(sort_bound_partition_kernel<true>, dim3(grid), dim3(256), hist_bytes + img_bytes, s, bk, n, (int)nbounds, img, out_part,
                        (unsigned long long*)out_counts);
   else

@@ -173,7 +173,7 @@ def _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, desc, nf, n, nb):
     return got
 
 
-@pytest.mark.parametrize("n,nb", [(1, 1), (255, 0), (2049, 1), (12_289, 7), (100_000, 300), (50_000, 5000)])
+@pytest.mark.parametrize("n,nb", [(1, 1), (255, 0), (2049, 1), (12_289, 7), (70_001, 63), (30_000, 20), (100_000, 300), (50_000, 5000)])
 def test_sort_bound_partition_matches_oracle(gpu, oracle, n, nb):
     """dbhip_sort_bound_partition (the distributed sort's range partition: sort_spill.rs:1008-1040 partition_point over Bounds,
     rows <= bound[i] belong to range i) against the oracle's row-at-a-time statement: every key type of dbhip_sort_perm, asc /
@@ -209,6 +209,18 @@ def test_sort_bound_partition_matches_oracle(gpu, oracle, n, nb):
                 hb.append(O.HostCol(bc, ba, bv))
         got = _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, desc, nf, n, nb)
         assert got.max() <= nb
+    # ONE key without NULLs and at most 63 bounds takes the register path (bounds in registers, ballot counting): every key type
+    for i, (code, arr) in enumerate(cases):
+        for desc in ([0], [1]):
+            d = (C.c_uint8 * 1)(*desc)
+            z = (C.c_uint8 * 1)(0)
+            ba = bcases[i][1][:nb]
+            order = np.zeros(max(nb, 1), np.uint32)
+            if nb:
+                oracle.orc_sort_perm(O.cols([O.HostCol(code, ba)]), d, z, 1, C.c_int64(nb), C.c_int64(0), order.ctypes.data_as(C.c_void_p))
+            ba = np.ascontiguousarray(ba[order[:nb]])
+            _bound_partition_both(gpu, oracle, [gpu.Column.from_numpy(arr, code)], [O.HostCol(code, arr)], [gpu.Column.from_numpy(ba, code)] if nb else [],
+                                  [O.HostCol(code, ba)] if nb else [], desc, [0], n, nb)
 
 
 def test_sort_bound_partition_strings_and_decimal128(gpu, oracle):
