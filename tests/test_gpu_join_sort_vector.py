@@ -173,7 +173,7 @@ def _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, desc, nf, n, nb):
     return got
 
 
-@pytest.mark.parametrize("n,nb", [(1, 1), (255, 0), (2049, 1), (12_289, 7), (70_001, 63), (30_000, 20), (100_000, 300), (50_000, 5000)])
+@pytest.mark.parametrize("n,nb", [(1, 1), (255, 0), (2049, 1), (12_289, 7), (70_001, 63), (30_000, 20), (60_000, 300), (12_000, 5000)])
 def test_sort_bound_partition_matches_oracle(gpu, oracle, n, nb):
     """dbhip_sort_bound_partition (the distributed sort's range partition: sort_spill.rs:1008-1040 partition_point over Bounds,
     rows <= bound[i] belong to range i) against the oracle's row-at-a-time statement: every key type of dbhip_sort_perm, asc /
@@ -210,7 +210,7 @@ def test_sort_bound_partition_matches_oracle(gpu, oracle, n, nb):
         got = _bound_partition_both(gpu, oracle, gkeys, hkeys, gb, hb, desc, nf, n, nb)
         assert got.max() <= nb
     # ONE key without NULLs and at most 63 bounds takes the register path (bounds in registers, ballot counting): every key type
-    for i, (code, arr) in enumerate(cases):
+    for i, (code, arr) in enumerate(cases if nb <= 63 else []):
         for desc in ([0], [1]):
             d = (C.c_uint8 * 1)(*desc)
             z = (C.c_uint8 * 1)(0)
