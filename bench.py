@@ -206,6 +206,16 @@ def main():
     if not args.no_q3 and world == 1:
         q3 = bench_q3(args, torch, tpch, D, L, check)
         torch.cuda.empty_cache()
+    plans = None
+    if world == 1 and not args.no_readiness:
+        # one rank's stages of the distributed sort and of the shuffle join's scatter (SURVEY §8e rows "sort" / "hash join") at 60 M rows
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_dist_sort as BDS
+            plans = BDS.run(torch, rows=60_000_000, ranges=8, reps=3)
+        except Exception as e:      # a secondary measurement never takes the headline line down
+            plans = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if not args.no_ann:
         ann = bench_ann(args, rank, world, torch, dist, D, DX, L, check)
         if world == 1 and not args.no_hnsw:
@@ -249,6 +259,7 @@ def main():
             "multi_gpu_readiness": readiness,
             "q1_operator_plan": opplan,
             "q3_sf100": q3,
+            "distributed_plan_stages": plans,
             "ann": ann,
         }
         print(json.dumps(out))
