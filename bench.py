@@ -350,10 +350,10 @@ def bench_operator_plan(li, tpch, D, L, check, fused_result, fused_kernel_ms):
                 t0 = time.perf_counter()
                 used = False
                 while not used and time.perf_counter() - t0 < 20.0:
-                    L.dbhip_fagg_stats_internal(st)
+                    L.dbhip_fagg_stats(st)
                     before = st[0]
                     fn(li)
-                    L.dbhip_fagg_stats_internal(st)
+                    L.dbhip_fagg_stats(st)
                     used = st[0] > before
                     if not used:
                         time.sleep(0.25)

@@ -74,7 +74,7 @@ def library_path():
 # every symbol include/dbhip.h declares (tests check that the built library exports all of them)
 SYMBOLS = [
     "dbhip_abi_version", "dbhip_init", "dbhip_device_count", "dbhip_last_error", "dbhip_alloc", "dbhip_free", "dbhip_trim",
-    "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy",
+    "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy", "dbhip_stream_release_scratch",
     "dbhip_stream_sync", "dbhip_event_create", "dbhip_event_record", "dbhip_event_elapsed_ms",
     "dbhip_event_destroy", "dbhip_last_kernel_ms", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",
     "dbhip_sum", "dbhip_expr_eval", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_decimal_neg", "dbhip_decimal_cast", "dbhip_cmp", "dbhip_bitmap_binary",
@@ -95,7 +95,12 @@ SYMBOLS = [
     "dbhip_comm_allreduce_sum_u64", "dbhip_groupby_exchange_allgather", "dbhip_groupby_exchange_alltoall", "dbhip_kmeans", "dbhip_vec_kernel_f32", "dbhip_hnsw_build", "dbhip_hnsw_build_sequential", "dbhip_hnsw_from_graph", "dbhip_hnsw_open", "dbhip_hnsw_export_graph", "dbhip_hnsw_search", "dbhip_hnsw_scores",
     "dbhip_hnsw_encoded", "dbhip_hnsw_meta", "dbhip_hnsw_destroy",
     "dbhip_pq_chunk_open", "dbhip_pq_chunk_validity", "dbhip_pq_chunk_image", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
+    "dbhip_scatter_columns", "dbhip_concat_columns",
+    # diagnostics and test hooks (declared in the header's last section)
+    "dbhip_groupby_debug_set_hash_mask", "dbhip_groupby_debug_set_partition_bits", "dbhip_join_binary_debug_set_hash_mask",
+    "dbhip_fagg_stats", "dbhip_jit_compile_check", "dbhip_jit_offline",
 ]
+_RESTYPE_I64 = {"dbhip_jit_compile_check", "dbhip_jit_offline"}
 
 
 def load_library():
@@ -112,7 +117,7 @@ def load_library():
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name != "dbhip_last_error":
-            fn.restype = C.c_int32
+            fn.restype = C.c_int64 if name in _RESTYPE_I64 else C.c_int32
     _LIB = L
     return L
 

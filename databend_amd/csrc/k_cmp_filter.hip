@@ -578,17 +578,25 @@ __global__ __launch_bounds__(256) void take_chunks_bitmap_kernel(const uint8_t* 
 //   else (sparse or unordered): a plain gather. Any selection is handled; the decision is per 64 entries.
 // one wave, one column, 64 entries (s0 = this lane's entry, [lo, hi] = the range the 64 entries span): through the wave's LDS
 // window `win` (WROWS elements) when the entries are neither dense nor sparse, else a plain gather
+template <typename T>
+__device__ __forceinline__ uint32_t take_window_shift(const T* src, uint32_t lo) {
+  return (uint32_t)(((uintptr_t)(src + (uint64_t)lo) & 15) / sizeof(T));
+}
 template <typename T, int WROWS>
 __device__ __forceinline__ void take_wave_step(const T* __restrict__ src, T* __restrict__ out, T* win, uint32_t s0, uint32_t lo, uint32_t hi,
                                                int64_t i0, int64_t n, int lane) {
   constexpr uint32_t PER16 = 16 / sizeof(T);            // elements per 16-byte vector
-  lo &= ~(PER16 - 1);                                     // (columns are 16-byte aligned: the window starts on a vector)
-  const uint32_t span = hi - lo + 1;
+  // The window starts on the 16-byte ADDRESS boundary at or below src[lo] (a column is only known to be aligned to its element
+  // size: a slice view of a 16-byte aligned buffer is not): every vector read then lies inside an aligned 16-byte granule that
+  // holds at least one wanted element, so nothing outside the granules of [lo, hi] is touched — no read past an unpadded
+  // buffer's last granule (r03 rounded the INDEX down and the count up, which assumed 16-byte aligned, padded columns).
+  const uint32_t shift = take_window_shift<T>(src, lo);   // elements between the boundary and src[lo]
+  const uint32_t span = hi - lo + 1 + shift;
   if (span > 128u && span <= (uint32_t)WROWS - PER16) {
     // the covered range as 16-byte vectors, every load of the range in flight before the first LDS store
     const uint32_t nvec = (span + PER16 - 1) / PER16;
     typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
-    const tw_u32x4* gsrc = (const tw_u32x4*)(src + (uint64_t)lo);
+    const tw_u32x4* gsrc = (const tw_u32x4*)((const T*)(src + (uint64_t)lo) - shift);
     tw_u32x4* lwin = (tw_u32x4*)win;
     constexpr int MAXV = (WROWS / (int)PER16 + 63) / 64;   // vectors per lane at most
     tw_u32x4 reg[MAXV];
@@ -599,7 +607,7 @@ __device__ __forceinline__ void take_wave_step(const T* __restrict__ src, T* __r
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (i0 < n) out[i0] = win[s0 - lo];
+    if (i0 < n) out[i0] = win[s0 - lo + shift];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next step
   } else {
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(256) void take_window_kernel(const T* __restrict__ 
     bool all_direct = true;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t span = hi[u] - (lo[u] & ~(PER16 - 1)) + 1;
+      const uint32_t span = hi[u] - lo[u] + 1 + take_window_shift<T>(src, lo[u]);
       all_direct &= !(span > 128u && span <= (uint32_t)WROWS - PER16);   // (wave-uniform)
     }
     if (all_direct) {

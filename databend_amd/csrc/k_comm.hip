@@ -104,11 +104,19 @@ int32_t alltoall_bytes(dbhip_comm* c, const void* send, void* recv, size_t bytes
     return DBHIP_OK;
   }
   NCCL_CHECK(g_rccl.GroupStart());
-  for (int p = 0; p < c->world; ++p) {
-    NCCL_CHECK(g_rccl.Send((const uint8_t*)send + (size_t)p * bytes_per_peer, bytes_per_peer, NCCL_UINT8, p, c->comm, s));
-    NCCL_CHECK(g_rccl.Recv((uint8_t*)recv + (size_t)p * bytes_per_peer, bytes_per_peer, NCCL_UINT8, p, c->comm, s));
+  // (a failing Send / Recv must not leave the thread's group open: every later collective of this thread would be queued into
+  // the dangling group and never launched — the first error is kept, the group is always closed)
+  int first = NCCL_SUCCESS;
+  const char* what = "";
+  for (int p = 0; p < c->world && first == NCCL_SUCCESS; ++p) {
+    int r = g_rccl.Send((const uint8_t*)send + (size_t)p * bytes_per_peer, bytes_per_peer, NCCL_UINT8, p, c->comm, s);
+    if (r != NCCL_SUCCESS) { first = r; what = "ncclSend"; break; }
+    r = g_rccl.Recv((uint8_t*)recv + (size_t)p * bytes_per_peer, bytes_per_peer, NCCL_UINT8, p, c->comm, s);
+    if (r != NCCL_SUCCESS) { first = r; what = "ncclRecv"; }
   }
-  NCCL_CHECK(g_rccl.GroupEnd());
+  const int e = g_rccl.GroupEnd();
+  if (first != NCCL_SUCCESS) return nccl_fail(first, what);
+  if (e != NCCL_SUCCESS) return nccl_fail(e, "ncclGroupEnd");
   return DBHIP_OK;
 }
 

@@ -19,6 +19,7 @@
 #include "fagg_device.h"
 #include "runtime.h"
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <errno.h>
 #include <sys/stat.h>
@@ -36,6 +37,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 using namespace dbhip;
 
@@ -212,6 +214,49 @@ bool read_file(const std::string& path, std::vector<char>* out) {
   fclose(f);
   return !out->empty();
 }
+// A cached code object is GPU code that will run inside the host's process: it is only loaded from a directory and a file that
+// belong to this user and that nobody else can write (a shared or world-writable cache directory would let another user plant a
+// kernel), and only if it looks like a complete code object (ELF magic; the helper publishes by rename, so a short file is a
+// crashed writer). Anything else is a cache MISS: the file is removed where that is allowed and the shape is compiled again.
+bool jit_cache_trusted(const std::string& dir, int fd) {
+  struct stat ds, fs;
+  if (stat(dir.c_str(), &ds) != 0 || !S_ISDIR(ds.st_mode) || ds.st_uid != geteuid() || (ds.st_mode & (S_IWGRP | S_IWOTH))) return false;
+  if (fstat(fd, &fs) != 0 || !S_ISREG(fs.st_mode) || fs.st_uid != geteuid() || (fs.st_mode & (S_IWGRP | S_IWOTH))) return false;
+  return true;
+}
+bool read_cached_code(const std::string& path, std::vector<char>* out) {
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  const size_t slash = path.rfind('/');
+  bool ok = jit_cache_trusted(slash == std::string::npos ? std::string(".") : path.substr(0, slash), fd);
+  if (ok) {
+    char buf[65536];
+    ssize_t n;
+    while ((n = read(fd, buf, sizeof(buf))) > 0) out->insert(out->end(), buf, buf + n);
+    ok = out->size() > 64 && !memcmp(out->data(), "\177ELF", 4);
+  }
+  close(fd);
+  if (!ok) { out->clear(); (void)unlink(path.c_str()); }   // miss (untrusted, truncated or foreign): compile again
+  return ok;
+}
+// build_XXXXXX directories of helpers that were killed before they could clean up (older than 15 minutes)
+void sweep_stale_builds(const std::string& dir) {
+  DIR* d = opendir(dir.c_str());
+  if (!d) return;
+  const time_t now = time(nullptr);
+  while (struct dirent* e = readdir(d)) {
+    if (strncmp(e->d_name, "build_", 6) != 0) continue;
+    const std::string sub = dir + "/" + e->d_name;
+    struct stat st;
+    if (lstat(sub.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || now - st.st_mtime < 15 * 60) continue;
+    if (DIR* b = opendir(sub.c_str())) {
+      while (struct dirent* f = readdir(b)) if (strcmp(f->d_name, ".") && strcmp(f->d_name, "..")) (void)unlink((sub + "/" + f->d_name).c_str());
+      closedir(b);
+    }
+    (void)rmdir(sub.c_str());
+  }
+  closedir(d);
+}
 void mkdir_p(const std::string& dir) {
   for (size_t i = 1; i <= dir.size(); ++i)
     if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
@@ -224,12 +269,16 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   const std::string arch = jit_arch();
   const std::string defs = getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
   const std::string cached = jit_cache_path(meta, tail, arch, defs);
-  if (!cached.empty() && read_file(cached, code)) return true;   // compiled by an earlier process (or an earlier table)
+  if (!cached.empty() && read_cached_code(cached, code)) return true;   // compiled by an earlier process (or an earlier table)
   code->clear();
   const std::string helper = jit_helper_path();
   if (helper.empty() || access(helper.c_str(), X_OK) != 0) { *log = "dbhip_jitc not found next to libdbhip.so (" + helper + ")"; return false; }
   if (detached && cached.empty()) { *log = "no on-disk cache directory (DBHIP_JIT_CACHE_DIR): nothing to publish a background compile into"; return false; }
-  if (detached) mkdir_p(jit_cache_dir());
+  if (detached) {
+    mkdir_p(jit_cache_dir());
+    static bool swept = false;
+    if (!swept) { swept = true; sweep_stale_builds(jit_cache_dir()); }
+  }
   std::string tmpl_s = detached ? jit_cache_dir() + "/build_XXXXXX" : std::string("/tmp/dbhip_jit_XXXXXX");
   if (!mkdtemp(&tmpl_s[0])) { *log = "mkdtemp failed"; return false; }
   const std::string dir = tmpl_s;
@@ -386,8 +435,9 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   bool have = false;
   {
     const std::string cached = jit_cache_path(meta, tail, jit_arch(), getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
-    have = !cached.empty() && read_file(cached, &code);
+    have = !cached.empty() && read_cached_code(cached, &code);
   }
+  const bool from_disk = have;
   if (!have && how == JIT_COMPILE) {
     have = jit_compile(meta, tail, &code, &log);
     if (!have) {
@@ -420,6 +470,15 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
     if (trace) fprintf(stderr, "[dbhip] fagg jit: specialised kernel ready (%zu bytes of code)\n", code.size());
     return e.fn;
   }
+  if (from_disk) {
+    // a cached file that does not load (another compiler's, corrupt): a cache miss, not a verdict on the shape — drop it so
+    // that the next PREPARE / background compile writes a fresh one
+    const std::string cached = jit_cache_path(meta, tail, jit_arch(), getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
+    if (!cached.empty()) (void)unlink(cached.c_str());
+    e.state = JitEntry::ABSENT;
+    if (trace) fprintf(stderr, "[dbhip] fagg jit: the cached code object did not load; removed, the shape will be compiled again\n");
+    return nullptr;
+  }
   e.state = JitEntry::FAILED;
   if (trace) fprintf(stderr, "[dbhip] fagg jit: the code object did not load; the interpreting kernel is used\n");
   return nullptr;
@@ -444,8 +503,10 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
 
 // launches by kind since the library was loaded (tests and benches tell which kernel a call went through)
 static std::atomic<uint64_t> g_fa_jit_launches{0}, g_fa_interp_launches{0}, g_fa_pending_refusals{0};
-extern "C" void dbhip_fagg_stats_internal(uint64_t* out3) {
-  out3[0] = g_fa_jit_launches.load(); out3[1] = g_fa_interp_launches.load(); out3[2] = g_fa_pending_refusals.load();
+extern "C" int32_t dbhip_fagg_stats(uint64_t* out3_host) {
+  DBHIP_REQUIRE(out3_host, "dbhip_fagg_stats: NULL argument");
+  out3_host[0] = g_fa_jit_launches.load(); out3_host[1] = g_fa_interp_launches.load(); out3_host[2] = g_fa_pending_refusals.load();
+  return DBHIP_OK;
 }
 
 static thread_local bool t_prepare_only = false;
@@ -455,7 +516,7 @@ static thread_local bool t_jit_may_compile = true;   // ... and whether a missin
 
 // Host side of the fused launch: compiles the program (roots = filter + one per aggregate argument), derives the per-word
 // metadata of the layout's states and copies the key columns. Touches no device: the offline compile check
-// (dbhip_fagg_jit_offline_internal, tools/jit_offline.py) goes through the same function.
+// (dbhip_jit_offline, tools/jit_offline.py) goes through the same function.
 static int32_t fa_build_args(const GbLayout& L, const dbhip_col* keys, const dbhip_agg_program* prog, FaArgs& A, bool* out_general,
                              int* out_nwords, bool* out_may_raise) {
   // ---- roots: filter + one per aggregate argument ----
@@ -737,7 +798,7 @@ bool dbhip_fagg_last_refusal_is_pending_internal() { return t_jit_pending; }
 // shape is outside the fused kernel). The columns only need their types / scalar-ness / validity-ness (any non-null pointers).
 int32_t dbhip_groupby_build_layout_internal(const int32_t* key_types, const uint8_t* key_nullable, int nkeys, const dbhip_agg_desc* aggs,
                                             int naggs, GbLayout* L);
-extern "C" int64_t dbhip_fagg_jit_offline_internal(const int32_t* key_types, const uint8_t* key_nullable, int32_t nkeys,
+extern "C" int64_t dbhip_jit_offline(const int32_t* key_types, const uint8_t* key_nullable, int32_t nkeys,
                                                    const dbhip_agg_desc* aggs, int32_t naggs, const dbhip_col* keys,
                                                    const dbhip_agg_program* prog, int32_t slots, char* code_out, int64_t code_cap,
                                                    char* log_out, int64_t log_cap) {
@@ -760,7 +821,7 @@ extern "C" int64_t dbhip_fagg_jit_offline_internal(const int32_t* key_types, con
 // Compiles the run-time specialisation of a small fixed query shape (i64 key; sum(i64 column), count(*)) and returns the
 // size of the code object (> 0) or -1 with hiprtc's log in `log_out`. Needs no device: tests/test_abi.py runs it on the CPU
 // box so that a header the specialised kernel cannot digest is caught where there is no GPU.
-extern "C" int64_t dbhip_fagg_jit_compile_check_internal(char* log_out, int64_t cap) {
+extern "C" int64_t dbhip_jit_compile_check(char* log_out, int64_t cap) {
   FaArgs A;
   memset(&A, 0, sizeof(A));
   for (int i = 0; i < EX_MAX_INPUTS; ++i) { A.P.in_slot[i] = -1; A.P.in_wide_ord[i] = -1; }

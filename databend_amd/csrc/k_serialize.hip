@@ -208,7 +208,7 @@ int32_t hash_rows(const uint64_t* off, const uint8_t* data, int64_t n, uint64_t*
 
 }  // namespace
 
-extern "C" void dbhip_join_binary_debug_hash_mask_internal(uint64_t mask) { g_hash_mask = mask; }
+extern "C" int32_t dbhip_join_binary_debug_set_hash_mask(uint64_t mask) { g_hash_mask = mask; return DBHIP_OK; }
 
 extern "C" {
 

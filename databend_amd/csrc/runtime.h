@@ -13,8 +13,11 @@ hipStream_t resolve_stream(void* stream);  // NULL -> library stream
 int32_t hip_fail(hipError_t e, const char* what);
 
 // Scratch arena bound to the library (grown on demand, reused across calls on
-// the same thread; callers must not hold it across dbhip calls).
+// the same (thread, stream); callers must not hold it across dbhip calls). Bounded: at most 8 streams' worth per thread (LRU),
+// released with the stream (dbhip_stream_destroy), on request (dbhip_stream_release_scratch) and when the thread exits.
 void* scratch(size_t bytes, int slot, hipStream_t stream);
+// Frees every thread's scratch of `stream` (the caller has drained it): dbhip_stream_destroy / dbhip_stream_release_scratch.
+void release_stream_scratch(hipStream_t stream);
 
 // Pinned host words for small device -> host read-backs that are queued asynchronously (64 u64 per slot, 8 slots per
 // thread). Two async copies into PAGEABLE memory in flight at once — a kernel's control block, then the queued merge's —

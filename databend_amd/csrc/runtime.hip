@@ -8,6 +8,11 @@
 
 #include <stdlib.h>
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -25,12 +30,56 @@ struct Scratch {
   size_t cap = 0;
 };
 // Scratch is keyed by (thread, stream): two asynchronous calls of one thread on two streams never share a buffer, so a thread
-// may keep several streams busy at once (r02's rule "one stream at a time per thread" is gone). A buffer that has to grow is
-// released after ITS stream has drained, not after the whole device.
+// may keep several streams busy at once. A buffer that has to grow is released after ITS stream has drained, not after the whole
+// device. The registry is process-wide (one mutex, taken per lookup) so that the entries have an owner who can release them:
+//   * dbhip_stream_destroy / dbhip_stream_release_scratch free every thread's entry of that stream (after draining it);
+//   * a thread that exits frees its entries (thread_local sentinel below; the main thread at process exit leaves it to the OS —
+//     the HIP runtime may already be shutting down);
+//   * a thread holds at most SCRATCH_STREAMS_PER_THREAD entries: the least recently used one is evicted (device drained first),
+//     so a host that takes a fresh stream per query — or torch's stream pool — cannot grow device memory without bound, and a
+//     recycled hipStream_t value never inherits more than that.
 struct StreamScratch {
-  Scratch slot[16];
+  Scratch slot[24];
+  uint64_t last_use = 0;
 };
-static thread_local std::unordered_map<hipStream_t, StreamScratch>* g_scratch = nullptr;
+constexpr size_t SCRATCH_STREAMS_PER_THREAD = 8;
+struct ScratchKey {
+  uint64_t tid;
+  hipStream_t stream;
+  bool operator<(const ScratchKey& o) const { return tid != o.tid ? tid < o.tid : (uintptr_t)stream < (uintptr_t)o.stream; }
+};
+static std::mutex g_scratch_mu;
+static std::map<ScratchKey, StreamScratch>* g_scratch = nullptr;   // (leaked on purpose: no static destructor races a late call)
+static std::atomic<uint64_t> g_scratch_clock{0};
+static std::atomic<uint64_t> g_next_tid{1};
+
+static void free_entry(StreamScratch& e) {
+  for (Scratch& s : e.slot) {
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr;
+    s.cap = 0;
+  }
+}
+// every entry whose key matches (tid == 0: any thread; any_stream: every stream of that thread); caller holds no lock
+static void release_scratch_entries(uint64_t tid, hipStream_t stream, bool any_stream) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch) return;
+  for (auto it = g_scratch->begin(); it != g_scratch->end();) {
+    const bool hit = (tid == 0 || it->first.tid == tid) && (any_stream || it->first.stream == stream);
+    if (hit) { free_entry(it->second); it = g_scratch->erase(it); } else ++it;
+  }
+}
+struct ThreadScratchOwner {
+  uint64_t tid = g_next_tid.fetch_add(1);
+  bool is_main = false;
+  ThreadScratchOwner() { is_main = (long)getpid() == (long)syscall(SYS_gettid); }
+  ~ThreadScratchOwner() {
+    if (is_main) return;   // process exit: the driver reclaims everything, and HIP may be tearing down
+    (void)hipDeviceSynchronize();
+    release_scratch_entries(tid, nullptr, true);
+  }
+};
+static thread_local ThreadScratchOwner t_scratch_owner;
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -55,9 +104,29 @@ hipStream_t resolve_stream(void* stream) {
 }
 
 void* scratch(size_t bytes, int slot, hipStream_t stream) {
-  if (!g_scratch) g_scratch = new (std::nothrow) std::unordered_map<hipStream_t, StreamScratch>();
+  const uint64_t tid = t_scratch_owner.tid;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch) g_scratch = new (std::nothrow) std::map<ScratchKey, StreamScratch>();
   if (!g_scratch) { set_error("scratch: out of host memory"); return nullptr; }
-  Scratch& s = (*g_scratch)[stream].slot[slot];
+  const ScratchKey key{tid, stream};
+  auto it = g_scratch->find(key);
+  if (it == g_scratch->end()) {
+    // a new (thread, stream) pair: evict this thread's least recently used entry once it holds too many
+    size_t mine = 0;
+    auto lru = g_scratch->end();
+    for (auto j = g_scratch->lower_bound(ScratchKey{tid, nullptr}); j != g_scratch->end() && j->first.tid == tid; ++j) {
+      ++mine;
+      if (lru == g_scratch->end() || j->second.last_use < lru->second.last_use) lru = j;
+    }
+    if (mine >= SCRATCH_STREAMS_PER_THREAD && lru != g_scratch->end()) {
+      (void)hipDeviceSynchronize();   // (the evicted stream may be gone already: drain the device, not the stream)
+      free_entry(lru->second);
+      g_scratch->erase(lru);
+    }
+    it = g_scratch->emplace(key, StreamScratch()).first;
+  }
+  it->second.last_use = g_scratch_clock.fetch_add(1) + 1;
+  Scratch& s = it->second.slot[slot];
   if (s.cap < bytes) {
     if (s.p) {
       (void)hipStreamSynchronize(stream);
@@ -74,6 +143,8 @@ void* scratch(size_t bytes, int slot, hipStream_t stream) {
   }
   return s.p;
 }
+
+void release_stream_scratch(hipStream_t stream) { release_scratch_entries(0, stream, false); }
 
 static thread_local uint64_t* g_pinned = nullptr;
 uint64_t* pinned_words(int slot) {
@@ -269,8 +340,17 @@ int32_t dbhip_stream_create(void** out) {
   return DBHIP_OK;
 }
 
+int32_t dbhip_stream_release_scratch(void* stream) {
+  hipStream_t s = resolve_stream(stream);
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  release_stream_scratch(s);
+  return DBHIP_OK;
+}
+
 int32_t dbhip_stream_destroy(void* stream) {
   if (!stream) return DBHIP_OK;
+  DBHIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  release_stream_scratch((hipStream_t)stream);   // every thread's scratch of this stream goes with it
   DBHIP_CHECK(hipStreamDestroy((hipStream_t)stream));
   return DBHIP_OK;
 }

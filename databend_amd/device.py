@@ -159,6 +159,9 @@ class Column:
         self.dtype, self.n, self.data, self.validity = dtype, int(n), data, validity
         self.precision, self.scale, self.is_scalar = int(precision), int(scale), bool(is_scalar)
         self.buffers = buffers  # DeviceBuffer holding an array of device pointers (strings)
+        self.n_buffers = 1 if buffers is not None else 0
+        self.voff = 0           # bit offset of the validity Bitmap (a sliced Bitmap, bitmap/immutable.rs:78-85)
+        self.boff = 0           # bit offset of a Boolean column's VALUES (only dbhip_concat_columns reads sliced Boolean values)
         self._keep = keep
 
     # ---- constructors -----------------------------------------------------------------
@@ -224,9 +227,9 @@ class Column:
         col.is_scalar = 1 if self.is_scalar else 0
         col.data = self.data.ptr
         col.validity = self.validity.ptr if self.validity is not None else None
-        col.validity_offset = 0
+        col.validity_offset = self.voff
         col.buffers = self.buffers.ptr if self.buffers is not None else None
-        col.n_buffers = 1 if self.buffers is not None else 0
+        col.n_buffers = self.n_buffers
         col.precision, col.scale = self.precision, self.scale
         return col
 
@@ -236,7 +239,7 @@ class Column:
         if self.dtype == L.T_DEC256:
             return limbs_to_ints(self.data.to_numpy(np.uint64, 4 * self.n), 256)
         if self.dtype == L.T_BOOL:
-            return unpack_bits(self.data.to_numpy(np.uint8, (self.n + 7) // 8), self.n)
+            return unpack_bits(self.data.to_numpy(np.uint8, (self.boff + self.n + 7) // 8), self.boff + self.n)[self.boff:]
         if self.dtype == L.T_STRING:
             return self.data.to_numpy(np.uint8, 16 * self.n).reshape(-1, 16)
         return self.data.to_numpy(NP_OF[self.dtype], self.n)
@@ -244,7 +247,33 @@ class Column:
     def validity_numpy(self):
         if self.validity is None:
             return np.ones(self.n, dtype=bool)
-        return unpack_bits(self.validity.to_numpy(np.uint8, (self.n + 7) // 8), self.n)
+        return unpack_bits(self.validity.to_numpy(np.uint8, (self.voff + self.n + 7) // 8), self.voff + self.n)[self.voff:]
+
+    def slice(self, lo, hi):
+        """Column::slice (values.rs): rows [lo, hi) as a view — value buffers by address, Bitmaps by bit offset"""
+        assert 0 <= lo <= hi <= self.n and not self.is_scalar
+        c = Column(self.dtype, hi - lo, self.data, self.validity, self.precision, self.scale, buffers=self.buffers, keep=(self,))
+        c.n_buffers = self.n_buffers
+        c.voff = self.voff + lo
+        if self.dtype == L.T_BOOL:
+            c.boff = self.boff + lo
+        else:
+            es = ELEM_SIZE[self.dtype]
+            c.data = BorrowedBuffer(self.data.ptr + lo * es, (hi - lo) * es, keep=self.data)
+        return c
+
+    def string_values(self):
+        """the values of a String column as bytes (views resolved through the column's buffer table)"""
+        views = self.data.to_numpy(np.uint8, 16 * self.n).reshape(-1, 16)
+        ptrs = self.buffers.to_numpy(np.uint64, self.n_buffers) if self.buffers is not None and self.n_buffers else []
+        out = []
+        for r in views:
+            ln, bi, off = (int(x) for x in np.frombuffer(r.tobytes(), np.uint32)[[0, 2, 3]])
+            if ln <= 12:
+                out.append(bytes(r[4:4 + ln]))
+            else:
+                out.append(BorrowedBuffer(int(ptrs[bi]) + off, ln).to_numpy(np.uint8, ln).tobytes())
+        return out
 
 
 def ints_to_limbs(ints, bits):
@@ -1382,6 +1411,61 @@ def scatter_block(cols, index, scatter_size):
     es = (C.c_int32 * len(cols))(*[ELEM_SIZE[c.dtype] for c in cols])
     check(lib().dbhip_scatter_block(srcs, es, len(cols), C.c_void_p(index.ptr), C.c_int64(n), C.c_uint32(scatter_size), dsts, None))
     return [Column(c.dtype, n, b, None, c.precision, c.scale, buffers=c.buffers, keep=(c,)) for c, b in zip(cols, bufs)]
+
+
+def scatter_columns(cols, index, scatter_size):
+    """DataBlock::scatter (kernels/scatter.rs:20-66) over whole columns — values, validities, Boolean / String / Decimal256 columns
+    (dbhip_scatter_columns) -> (blocks, row_starts): blocks[d] = the Columns of destination d (views into one output buffer per
+    column; every destination's Bitmaps are stand-alone, offset-0 Bitmaps)."""
+    _ensure()
+    n, S = cols[0].n, int(scatter_size)
+    bm_bytes = 8 * (n // 64 + S + 1)
+    dbufs = [DeviceBuffer(bm_bytes) if c.dtype == L.T_BOOL else DeviceBuffer(max(n, 1) * ELEM_SIZE[c.dtype] + 64) for c in cols]
+    vbufs = [DeviceBuffer(bm_bytes) if c.validity is not None else None for c in cols]
+    dsts = (C.c_void_p * len(cols))(*[b.ptr for b in dbufs])
+    vdsts = (C.c_void_p * len(cols))(*[b.ptr if b is not None else None for b in vbufs])
+    starts = (C.c_int64 * (S + 1))()
+    check(lib().dbhip_scatter_columns(_cols(cols), len(cols), C.c_void_p(index.ptr if index is not None else None), C.c_int64(n), C.c_uint32(S),
+                                      dsts, vdsts, starts, None))
+    starts = list(starts)
+    blocks = []
+    for d in range(S):
+        lo, hi = starts[d], starts[d + 1]
+        bm_at = 8 * (lo // 64 + d)
+        blk = []
+        for c, db, vb in zip(cols, dbufs, vbufs):
+            if c.dtype == L.T_BOOL:
+                data = BorrowedBuffer(db.ptr + bm_at, bm_bytes - bm_at, keep=db)
+            else:
+                data = BorrowedBuffer(db.ptr + lo * ELEM_SIZE[c.dtype], (hi - lo) * ELEM_SIZE[c.dtype], keep=db)
+            v = BorrowedBuffer(vb.ptr + bm_at, bm_bytes - bm_at, keep=vb) if vb is not None else None
+            o = Column(c.dtype, hi - lo, data, v, c.precision, c.scale, buffers=c.buffers, keep=(c, db, vb))
+            o.n_buffers = c.n_buffers
+            blk.append(o)
+        blocks.append(blk)
+    return blocks, starts
+
+
+def concat_columns(cols):
+    """DataBlock::concat for one column of several blocks (kernels/concat.rs:62-340, dbhip_concat_columns) -> Column. String blocks keep
+    their data buffers (the views are rebased onto the concatenated buffer table)."""
+    _ensure()
+    t = cols[0].dtype
+    total = sum(c.n for c in cols)
+    nbuf = sum(c.n_buffers for c in cols) if t == L.T_STRING else 0
+    out = DeviceBuffer(((total + 63) // 64) * 8 + 8) if t == L.T_BOOL else DeviceBuffer(max(total, 1) * ELEM_SIZE[t] + 64)
+    vb = DeviceBuffer(((total + 63) // 64) * 8 + 8) if any(c.validity is not None for c in cols) else None
+    bufs = DeviceBuffer(max(nbuf, 1) * 8) if nbuf else None
+    rows = (C.c_int64 * len(cols))(*[c.n for c in cols])
+    boffs = (C.c_int64 * len(cols))(*[c.boff for c in cols])
+    got = C.c_int32(0)
+    check(lib().dbhip_concat_columns(_cols(cols), rows, boffs, len(cols), C.c_void_p(out.ptr), C.c_void_p(vb.ptr if vb is not None else None),
+                                     C.c_void_p(bufs.ptr if bufs is not None else None), C.byref(got), None))
+    assert got.value == nbuf
+    check(lib().dbhip_stream_sync(None))
+    o = Column(t, total, out, vb, cols[0].precision, cols[0].scale, buffers=bufs, keep=tuple(cols))
+    o.n_buffers = nbuf
+    return o
 
 
 def sort_perm(cols, desc=None, nulls_first=None, limit=0):

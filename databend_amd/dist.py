@@ -201,13 +201,21 @@ def exchange_partials_alltoall_nccl(table, dist, torch, stream=None, lib_sync=No
                                              capacity_error=lambda e: isinstance(e, DbhipError) and e.code == ERR_CAPACITY)
 
 
+def _check_global_ids(row_offset, max_local_id):
+    """global row ids are u32 and 0xFFFFFFFF is the 'empty' sentinel: the largest id a shard can produce must stay below it"""
+    if int(row_offset) < 0 or int(row_offset) + int(max_local_id) >= 0xFFFFFFFF:
+        raise ValueError(f"global row id {int(row_offset) + int(max_local_id)} does not fit the u32 id space below the empty sentinel "
+                         f"(row_offset {int(row_offset)}): shard the index over more ranks or widen the ids")
+
+
 def merge_shard_topk(idx, dst, row_offset, k, dist, torch, device, merge_fn):
     """ANN over a row-range sharded base: queries are replicated, every rank searched its shard and
     holds `idx` (u32 local row ids, 0xFFFFFFFF = empty) / `dst` (f32) of shape [nq, k]. One all-gather of the
     (k ids + k distances) per query over RCCL, then the k-way merge `merge_fn(dists [nq, world*k], ids) ->
     (idx, dist)` (the device select kernel, dbhip_vec_topk_merge). Returns global row ids."""
     world = dist.get_world_size()
-    gid = np.where(idx == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), (idx.astype(np.int64) + row_offset).astype(np.uint32))
+    _check_global_ids(row_offset, idx[idx != 0xFFFFFFFF].max() if (idx != 0xFFFFFFFF).any() else 0)
+    gid = np.where(idx == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), (idx.astype(np.int64) + int(row_offset)).astype(np.uint32))
     ti = torch.from_numpy(gid.view(np.int32)).to(device)
     td = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.float32)).to(device)
     gi = [torch.empty_like(ti) for _ in range(world)]
@@ -228,7 +236,13 @@ def merge_shard_topk_device(idx_t, dst_t, row_offset, k, dist, torch, lib_sync, 
     world = dist.get_world_size()
     nq = idx_t.shape[0]
     lib_sync()
-    gid = torch.where(idx_t == -1, idx_t, idx_t + int(row_offset)).contiguous()
+    # ids are u32 (0xFFFFFFFF = empty) carried in an int32 view: globalise in int64 (an offset >= 2^31 is a legal u32 id but not a
+    # legal int32 scalar), check the u32 id space, and go back to the int32 view
+    wide = idx_t.to(torch.int64) & 0xFFFFFFFF
+    live = idx_t != -1
+    _check_global_ids(row_offset, int(wide[live].max()) if bool(live.any()) else 0)
+    g64 = wide + int(row_offset)
+    gid = torch.where(live, torch.where(g64 >= (1 << 31), g64 - (1 << 32), g64).to(torch.int32), idx_t).contiguous()
     gi = torch.empty((world * nq, k), dtype=torch.int32, device=idx_t.device)   # rank-major concatenation
     gd = torch.empty((world * nq, k), dtype=torch.float32, device=idx_t.device)
     dist.all_gather_into_tensor(gi, gid)

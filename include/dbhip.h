@@ -124,7 +124,12 @@ int32_t dbhip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void
 int32_t dbhip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int32_t dbhip_memset(void* dst_dev, int32_t byte, size_t bytes, void* stream);
 int32_t dbhip_stream_create(void** out_stream_host);
-int32_t dbhip_stream_destroy(void* stream);
+int32_t dbhip_stream_destroy(void* stream);        /* drains the stream, frees the library's scratch of it (every thread's), destroys it */
+/* Internal scratch is bounded — a thread keeps the scratch of at most 8 streams (least recently used evicted), a thread that
+ * exits frees its own — and can be returned at any time: drains `stream` (NULL = the library stream) and frees every thread's
+ * scratch buffers of it. For streams the library did not create (a host's or torch's stream pool) call this before the stream
+ * goes away. */
+int32_t dbhip_stream_release_scratch(void* stream);
 int32_t dbhip_stream_sync(void* stream);
 /* HIP-event timing on `stream` (bench.py's roofline figure): */
 int32_t dbhip_event_create(void** out_event_host);
@@ -375,6 +380,26 @@ int32_t dbhip_scatter_block(const void* const* srcs_host, const int32_t* elem_si
                             uint32_t scatter_size, void* const* outs_host, void* stream);
 int32_t dbhip_scatter_indices(const dbhip_col* keys, int32_t nkeys, int64_t n, uint32_t scatter_size, uint64_t default_index,
                               uint32_t* out_index, uint64_t* out_counts, void* stream);
+/* DataBlock::scatter over WHOLE columns (kernels/scatter.rs:20-66: divide_indices_by_scatter_size + take of every column) — values,
+ * validity Bitmaps, Boolean, String (views; the data buffers are shared with the source, as take.rs does for view columns) and
+ * Decimal256 columns: destination d holds the rows whose index is d, in row order. out_row_starts_host[scatter_size + 1]: destination
+ * d's rows are [starts[d], starts[d + 1]) of every output value buffer (n elements each). Bitmaps — the values of a Boolean column and
+ * the validity of a nullable one (out_validity_host[c] may be NULL for a column without validity) — are written as ONE STAND-ALONE,
+ * offset-0 Bitmap per destination: destination d's starts at byte 8 * (starts[d] / 64 + d) of the output buffer, which must hold
+ * 8 * (n / 64 + scatter_size + 1) bytes and be 8-byte aligned (destinations never share a 64-bit word, so every destination's columns
+ * can go straight into any other entry point). An index >= scatter_size is DBHIP_ERR_INVALID. Checked against the reference's
+ * fixture (kernel-pass.txt 'Scatter') and its round-trip property scatter -> concat == take (tests/it/kernel.rs:519-566). */
+int32_t dbhip_scatter_columns(const dbhip_col* cols, int32_t ncols, const uint32_t* index, int64_t n, uint32_t scatter_size,
+                              void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_row_starts_host, void* stream);
+/* DataBlock::concat for ONE column of `nblocks` blocks (kernels/concat.rs:62-340): cols[b] (rows_host[b] rows) back to back into
+ * out_data; out_validity (needed when any block has a validity; a block without one counts as all valid) and Boolean values are
+ * concatenated bit by bit from any bit offset (validity_offset; bool_bit_offsets_host[b] for the values of a Boolean block, NULL = 0)
+ * into 8-byte aligned Bitmaps of ceil(total / 64) * 8 bytes. String blocks: the views are copied with the buffer index of long values
+ * rebased, and the blocks' buffer tables are written back to back into out_buffers_dev (device array of sum(n_buffers) pointers;
+ * *out_n_buffers_host = that sum) — the bytes themselves do not move (the reference's builder copies them; column VALUES are equal).
+ * A constant (is_scalar) block of a fixed-width type is expanded. */
+int32_t dbhip_concat_columns(const dbhip_col* cols, const int64_t* rows_host, const int64_t* bool_bit_offsets_host, int32_t nblocks,
+                             void* out_data, uint8_t* out_validity, const void** out_buffers_dev, int32_t* out_n_buffers_host, void* stream);
 
 /* ---- a8-a13: hash aggregation ---------------------------------------------
  * Replaces AggregateHashTable behind TransformPartialAggregate /
@@ -877,6 +902,25 @@ int32_t dbhip_hnsw_scores(dbhip_hnsw* h, const float* queries_dev, int32_t nq, f
 int32_t dbhip_hnsw_encoded(dbhip_hnsw* h, void* out_dev, void* stream);
 int32_t dbhip_hnsw_meta(dbhip_hnsw* h, float* alpha_host, float* offset_host, float* multiplier_host, int32_t* actual_dim_host);
 int32_t dbhip_hnsw_destroy(dbhip_hnsw* h);
+
+/* ---- diagnostics and test hooks (exported, not part of the drop-in surface) -------------------------------------------------
+ * The library exports exactly the functions this header declares (csrc/Makefile builds its export list from it). */
+/* restrict the probe hash of an EMPTY table to `mask`, so that distinct keys share a hash word and the collision path runs (the
+ * reference tests the same with hand-made tags, hash_index/index.rs:385-404); the binary join's twin is process-wide */
+int32_t dbhip_groupby_debug_set_hash_mask(dbhip_groupby* g, uint64_t mask);
+int32_t dbhip_join_binary_debug_set_hash_mask(uint64_t mask);
+/* force the radix-partitioned path with 2^bits partitions (0: back to adaptive, < 0: never partition) */
+int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits);
+/* launches of the fused-aggregation kernel since the library was loaded: out3_host = {run-time specialised, interpreted, refused
+ * because the specialised kernel was still being compiled} — how a bench or a test tells which kernel a call went through */
+int32_t dbhip_fagg_stats(uint64_t* out3_host);
+/* Offline compile checks of the run-time specialisation (need no device; the CPU test-suite runs them): the code object of a small
+ * fixed query shape / of a table layout + program -> its size in bytes, -1 with the compiler's log in log_out_host, -2 when the shape
+ * is outside the fused kernel. */
+int64_t dbhip_jit_compile_check(char* log_out_host, int64_t log_cap);
+int64_t dbhip_jit_offline(const int32_t* key_types_host, const uint8_t* key_nullable_host, int32_t nkeys, const dbhip_agg_desc* aggs_host,
+                          int32_t naggs, const dbhip_col* keys, const dbhip_agg_program* prog, int32_t slots, char* code_out_host,
+                          int64_t code_cap, char* log_out_host, int64_t log_cap);
 
 #ifdef __cplusplus
 }

@@ -649,6 +649,43 @@ void orc_take_chunks(const void* const* blocks, int es, const uint32_t* pairs, i
     memcpy((uint8_t*)out + i * es, (const uint8_t*)blocks[pairs[2 * i]] + (size_t)pairs[2 * i + 1] * es, (size_t)es);
 }
 
+/* DataBlock::scatter (kernels/scatter.rs:20-66): divide_indices_by_scatter_size counts the rows per destination, then pushes every
+ * row id onto its destination's list in row order (:46-66); each destination is take_with_optimize_size of its list. out_rows = the
+ * lists back to back, out_starts[d] .. out_starts[d + 1] = destination d's slice. */
+void orc_divide_indices(const uint32_t* indices, int64_t n, int scatter_size, uint32_t* out_rows, int64_t* out_starts) {
+  int64_t* cur = (int64_t*)calloc((size_t)scatter_size + 1, sizeof(int64_t));
+  for (int64_t i = 0; i < n; ++i) cur[indices[i] + 1]++;              /* scatter_num_rows */
+  for (int d = 0; d < scatter_size; ++d) cur[d + 1] += cur[d];
+  memcpy(out_starts, cur, ((size_t)scatter_size + 1) * sizeof(int64_t));
+  for (int64_t i = 0; i < n; ++i) out_rows[cur[indices[i]]++] = (uint32_t)i;   /* scatter_indices[index].push(i) */
+  free(cur);
+}
+/* Bitmap / Boolean columns under take (kernels/take.rs: take_boolean_types / the validity of a NullableColumn): bit `sel[i]` of the
+ * source (read from bit_offset) becomes bit i of the output (written from out_bit_offset; other bits of `out` are left alone) */
+void orc_take_bitmap(const uint8_t* src, int64_t bit_offset, const uint32_t* sel, int64_t n_sel, uint8_t* out, int64_t out_bit_offset) {
+  for (int64_t i = 0; i < n_sel; ++i) {
+    const int64_t sb = bit_offset + sel[i], ob = out_bit_offset + i;
+    const int bit = (src[sb >> 3] >> (sb & 7)) & 1;
+    out[ob >> 3] = (uint8_t)((out[ob >> 3] & ~(1u << (ob & 7))) | ((unsigned)bit << (ob & 7)));
+  }
+}
+/* DataBlock::concat for one column (kernels/concat.rs:62-110): fixed-width values back to back (concat_primitive_types :262-274);
+ * Boolean values and the validity of a NullableColumn bit by bit (concat_boolean_types :307-320; a block without validity counts
+ * as all valid). */
+void orc_concat_fixed(const void* const* blocks, const int64_t* rows, int nblocks, int elem_size, void* out) {
+  uint8_t* o = (uint8_t*)out;
+  for (int b = 0; b < nblocks; ++b) { memcpy(o, blocks[b], (size_t)rows[b] * elem_size); o += (size_t)rows[b] * elem_size; }
+}
+void orc_concat_bitmap(const uint8_t* const* blocks, const int64_t* bit_offsets, const int64_t* rows, int nblocks, uint8_t* out) {
+  int64_t ob = 0;
+  for (int b = 0; b < nblocks; ++b)
+    for (int64_t i = 0; i < rows[b]; ++i, ++ob) {
+      const int64_t sb = (bit_offsets ? bit_offsets[b] : 0) + i;
+      const int bit = blocks[b] ? (blocks[b][sb >> 3] >> (sb & 7)) & 1 : 1;
+      out[ob >> 3] = (uint8_t)((out[ob >> 3] & ~(1u << (ob & 7))) | ((unsigned)bit << (ob & 7)));
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* group hash: aggregate/group_hash.rs:38,180-207,267-281,509-632              */
 /* ------------------------------------------------------------------------ */

@@ -154,7 +154,59 @@ def kernel():
             i = j2
             continue
         i += 1
-    return {"source": "src/query/expression/tests/it/testdata/kernel-pass.txt (Filter / Take / Take Block sections; kernel.rs:49-566)", "cases": cases}
+    # Scatter: one source block, one result block per destination (kernel.rs test_pass, DataBlock::scatter)
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^Scatter:\s+\[(.*)\]\s*$", lines[i])
+        if m and lines[i + 1].startswith("Source:"):
+            arg = [int(t) for t in m.group(1).split(",") if t.strip()]
+            hdr, src, j = text_table(lines, i + 2)
+            results = []
+            while j < len(lines) and re.match(r"^Result-\d+:", lines[j]):
+                _, res, j = text_table(lines, j + 1)
+                results.append(res)
+            cases.append({"kind": "scatter", "arg": arg, "header": hdr, "source": src, "results": results})
+            i = j
+            continue
+        i += 1
+    # Concat: 'Concat-Column k' = block k as a (Column ID | Type | Column Data) table; columns of the path's types are parsed,
+    # the others (Null, Array(Nothing)) are kept as text
+    i = 0
+    while i < len(lines):
+        if lines[i].startswith("Concat-Column 0:"):
+            blocks, j = [], i
+            while j < len(lines) and re.match(r"^Concat-Column \d+:", lines[j]):
+                _, rows, j = text_table(lines, j + 1)
+                blocks.append([concat_column(r[1], r[2]) for r in rows])
+            assert lines[j].startswith("Result:"), lines[j]
+            hdr, res, j2 = text_table(lines, j + 1)
+            cases.append({"kind": "concat", "header": hdr, "blocks": blocks, "result": res})
+            i = j2
+            continue
+        i += 1
+    return {"source": "src/query/expression/tests/it/testdata/kernel-pass.txt (Filter / Take / Take Block / Scatter / Concat sections; "
+                      "kernel.rs:49-566)", "cases": cases}
+
+
+def concat_column(type_text, data_text):
+    """'Column(NullableColumn { column: UInt8([10, 11]), validity: [0b______10] })' -> {type, values, validity}"""
+    out = {"type": type_text, "text": data_text}
+    m = re.search(r"(Int32|UInt8)\(\[([^\]]*)\]\)", data_text)
+    ms = re.search(r"StringColumn\[([^\]]*)\]", data_text)
+    if m:
+        out["values"] = [int(x) for x in m.group(2).split(",") if x.strip()]
+    elif ms:
+        out["values"] = [x.strip() for x in ms.group(1).split(",")]
+    else:
+        return out
+    mv = re.search(r"validity: \[([^\]]*)\]", data_text)
+    if mv:
+        bits = []
+        for byte in mv.group(1).split(","):
+            v = int(byte.strip().replace("0b", "").replace("_", "") or "0", 2)
+            bits += [(v >> k) & 1 for k in range(8)]
+        out["validity"] = bits[:len(out["values"])]
+    return out
 
 
 def sort_cases():

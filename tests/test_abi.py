@@ -51,9 +51,9 @@ def test_run_time_specialisation_compiles_without_a_gpu():
     import ctypes as C
     from databend_amd import _lib
     L = _lib.load_library()
-    L.dbhip_fagg_jit_compile_check_internal.restype = C.c_int64
+    L.dbhip_jit_compile_check.restype = C.c_int64
     buf = C.create_string_buffer(1 << 16)
-    size = L.dbhip_fagg_jit_compile_check_internal(buf, C.c_int64(1 << 16))
+    size = L.dbhip_jit_compile_check(buf, C.c_int64(1 << 16))
     assert size > 4096, buf.value.decode(errors="replace")[:4000]
 
 
@@ -64,20 +64,20 @@ def test_specialised_kernels_are_cached_on_disk(tmp_path, monkeypatch):
     import time
     from databend_amd import _lib
     L = _lib.load_library()
-    L.dbhip_fagg_jit_compile_check_internal.restype = C.c_int64
+    L.dbhip_jit_compile_check.restype = C.c_int64
     buf = C.create_string_buffer(1 << 16)
     monkeypatch.setenv("DBHIP_JIT_CACHE_DIR", str(tmp_path / "cache"))
     t0 = time.perf_counter()
-    size = L.dbhip_fagg_jit_compile_check_internal(buf, C.c_int64(1 << 16))
+    size = L.dbhip_jit_compile_check(buf, C.c_int64(1 << 16))
     t1 = time.perf_counter()
     assert size > 4096
     files = sorted(os.listdir(tmp_path / "cache"))
     assert len(files) == 1 and files[0].startswith("fagg_") and files[0].endswith(".co")
     assert os.path.getsize(tmp_path / "cache" / files[0]) == size
-    again = L.dbhip_fagg_jit_compile_check_internal(buf, C.c_int64(1 << 16))
+    again = L.dbhip_jit_compile_check(buf, C.c_int64(1 << 16))
     t2 = time.perf_counter()
     assert again == size and (t2 - t1) < (t1 - t0) / 5, (t1 - t0, t2 - t1)
     # a corrupted / foreign cache directory never breaks a compile: disabled cache still compiles
     monkeypatch.setenv("DBHIP_JIT_CACHE_DIR", "off")
-    assert L.dbhip_fagg_jit_compile_check_internal(buf, C.c_int64(1 << 16)) == size
+    assert L.dbhip_jit_compile_check(buf, C.c_int64(1 << 16)) == size
     assert sorted(os.listdir(tmp_path / "cache")) == files

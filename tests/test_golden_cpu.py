@@ -330,3 +330,135 @@ def test_hash_index_cases_of_index_rs():
                                     ph.ctypes.data_as(C.c_void_p), pv.ctypes.data_as(C.c_void_p), len(pay), outv.ctypes.data_as(C.c_void_p))
         assert new == 3
         assert dict(zip(ik.tolist(), outv.tolist())) == {1: 21, 2: 22, 3: 23, 4: 77}
+
+
+def test_kernel_pass_scatter_and_concat_goldens():
+    """kernel-pass.txt 'Scatter' (:211+) and 'Concat' (:21-53) through the oracle's statement of DataBlock::scatter
+    (divide_indices_by_scatter_size + take, scatter.rs:20-66) and DataBlock::concat (concat.rs:62-340): values, validities, strings."""
+    from tests import scatter_cases as SC
+    L = O.load()
+    cases = golden("kernel.json")
+    sc = [c for c in cases if c["kind"] == "scatter"]
+    cc = [c for c in cases if c["kind"] == "concat"]
+    assert len(sc) == 1 and len(cc) == 1
+    for case in sc:
+        cols = SC.cells_to_columns(case["header"], case["source"])
+        views = {}
+        spec = []
+        for kind, vals, valid in cols:
+            if kind == "str":
+                from databend_amd.device import make_views
+                spec.append({"values": make_views(vals), "bits": [valid]})
+            else:
+                spec.append({"values": vals, "bits": [valid]})
+        S = len(case["results"])
+        out, starts, _ = SC.oracle_scatter(L, case["arg"], S, spec)
+        assert starts == [0, 2, 4, 5]
+        for d in range(S):
+            for c, (kind, _, _) in enumerate(cols):
+                o = out[d][c]
+                vals = [bytes(v[4:4 + int(v[0])]) for v in o["values"]] if kind == "str" else o["values"].tolist()
+                assert SC.render(kind, vals, o["bits"][0]) == [r[c] for r in case["results"][d]], (d, c)
+    for case in cc:
+        ncols = len(case["header"])
+        for c in range(ncols):
+            blks = [b[c] for b in case["blocks"]]
+            if "values" not in blks[0]:
+                continue          # Null / Array(Nothing) columns: outside the path's types
+            rows = [len(b["values"]) for b in blks]
+            valid = SC.oracle_concat_bits(L, [np.array(b["validity"], bool) if "validity" in b else None for b in blks], rows)
+            if isinstance(blks[0]["values"][0], str):
+                from databend_amd.device import make_views
+                v = SC.oracle_concat_fixed(L, [make_views([x.encode() for x in b["values"]]) for b in blks])
+                vals = [bytes(r[4:4 + int(r[0])]) for r in v]
+                kind = "str"
+            else:
+                vals = SC.oracle_concat_fixed(L, [np.array(b["values"], np.int32) for b in blks]).tolist()
+                kind = "int"
+            assert SC.render(kind, vals, valid) == [r[c] for r in case["result"]], c
+
+
+def test_scatter_then_concat_equals_take_oracle():
+    """tests/it/kernel.rs:519-566 (test_scatter): scatter a random block by random indices, concat the pieces == take by the indices
+    grouped by destination. Here over the oracle's own statements (the device runs the same property in test_gpu_scatter.py)."""
+    from tests import scatter_cases as SC
+    L = O.load()
+    rng = np.random.default_rng(5)
+    for _ in range(12):
+        n = int(rng.integers(2, 300))
+        S = int(rng.integers(2, 25))
+        idx = rng.integers(0, S, n).astype(np.uint32)
+        vals = rng.integers(-1000, 1000, n).astype(np.int64)
+        valid = rng.random(n) > 0.3
+        out, starts, rows = SC.oracle_scatter(L, idx, S, [{"values": vals, "bits": [valid]}])
+        take_indices = [j for d in range(S) for j in range(n) if idx[j] == d]
+        assert rows.tolist() == take_indices
+        cat = SC.oracle_concat_fixed(L, [out[d][0]["values"] for d in range(S)])
+        catv = SC.oracle_concat_bits(L, [out[d][0]["bits"][0] for d in range(S)], [starts[d + 1] - starts[d] for d in range(S)])
+        assert np.array_equal(cat, vals[take_indices]) and np.array_equal(catv, valid[take_indices])
+
+
+def test_multi_key_scatter_hash_is_pinned_to_the_golden_siphash():
+    """HashFlightScatter::combine_hash_keys (flight_scatter_hash.rs:213-233) writes every key's u64 into ONE std DefaultHasher
+    (`write_u64` = the 8 little-endian bytes, SipHash-1-3 with zero keys) and takes finish() % scatter_size. The reference holds no
+    expected values for it; it is pinned here three ways:
+      (1) the identity DefaultHasher{write_u64(h1); ...; write_u64(hk)}.finish() == siphash64(le(h1) || ... || le(hk)) ties it to the
+          byte-string siphash64 that IS pinned on the reference's golden vectors (tests/golden/siphash.json: 0-, 3-, 4-, 8-, 9- and
+          11-byte inputs, i.e. the block loop, the tail and the length byte): the oracle's combine equals the oracle's siphash64 of the
+          concatenated bytes;
+      (2) an independent second statement (tests/siphash_ref.py) agrees on random inputs;
+      (3) a hand-worked vector: two keys 1 and 2 -> the 16-byte message 01 00.. 02 00.., worked through the paper's round function
+          below with plain Python integers (no shared code with (1) or (2))."""
+    from tests import siphash_ref as R
+    L = O.load()
+    rng = np.random.default_rng(11)
+    # (3) hand-worked: SipHash-1-3, k0 = k1 = 0, message = le64(1) || le64(2), length 16
+    M64 = (1 << 64) - 1
+    rot = lambda x, b: ((x << b) | (x >> (64 - b))) & M64
+    v0, v1, v2, v3 = 0x736f6d6570736575, 0x646f72616e646f6d, 0x6c7967656e657261, 0x7465646279746573
+
+    def sipround(v0, v1, v2, v3):
+        v0 = (v0 + v1) & M64; v1 = rot(v1, 13) ^ v0; v0 = rot(v0, 32)
+        v2 = (v2 + v3) & M64; v3 = rot(v3, 16) ^ v2
+        v0 = (v0 + v3) & M64; v3 = rot(v3, 21) ^ v0
+        v2 = (v2 + v1) & M64; v1 = rot(v1, 17) ^ v2; v2 = rot(v2, 32)
+        return v0, v1, v2, v3
+    for m in (1, 2, 16 << 56):          # two message words, then the final word = length 16 in the top byte, no tail bytes
+        v3 ^= m
+        v0, v1, v2, v3 = sipround(v0, v1, v2, v3)
+        v0 ^= m
+    v2 ^= 0xFF
+    for _ in range(3):
+        v0, v1, v2, v3 = sipround(v0, v1, v2, v3)
+    hand = v0 ^ v1 ^ v2 ^ v3
+    assert hand == 18088007599891946824 == R.siphash13(np.array([1, 2], "<u8").tobytes())      # the committed known answer
+    for nkeys in (2, 3, 5):
+        n = 257
+        hs = [rng.integers(0, 1 << 63, n, dtype=np.uint64) for _ in range(nkeys)]
+        if nkeys == 2:
+            hs[0][0], hs[1][0] = 1, 2
+        cols = [O.HostCol(T.T_U64, h) for h in hs]
+        # orc_scatter_indices over u64 KEY columns: every key is hashed (siphash64) and the hashes are combined; checked row by row
+        # against both restatements of the combine
+        idx = np.zeros(n, np.uint32)
+        cnt = np.zeros(7, np.uint64)
+        assert L.orc_scatter_indices(O.cols(cols), nkeys, C.c_int64(n), C.c_uint64(7), C.c_uint64(0), idx.ctypes.data_as(C.c_void_p),
+                                     cnt.ctypes.data_as(C.c_void_p)) == 0
+        for i in range(0, n, 16):
+            key_hashes = [R.siphash64("u64", int(h[i])) for h in hs]
+            msg = b"".join(int(x).to_bytes(8, "little") for x in key_hashes)
+            # (1) the byte-string siphash64 of the oracle over the concatenated bytes
+            from databend_amd.device import make_views_general
+            views, buf = make_views_general([msg])
+            out = np.zeros(1, np.uint64)
+            sc = O.HostCol(T.T_STRING, views, None, buffers=[buf]).c()
+            assert L.orc_siphash64(C.byref(sc), C.c_int64(1), out.ctypes.data_as(C.c_void_p)) == 0
+            assert int(out[0]) % 7 == int(idx[i]), (nkeys, i)
+            # (2) the independent statement
+            assert R.scatter_index(key_hashes, 7) == int(idx[i])
+    # the hand-worked value through the oracle's byte-string siphash64 as well
+    views, buf = make_views_general([np.array([1, 2], "<u8").tobytes()])
+    out = np.zeros(1, np.uint64)
+    sc = O.HostCol(T.T_STRING, views, None, buffers=[buf]).c()
+    assert L.orc_siphash64(C.byref(sc), C.c_int64(1), out.ctypes.data_as(C.c_void_p)) == 0
+    assert int(out[0]) == hand

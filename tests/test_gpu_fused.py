@@ -255,7 +255,7 @@ def test_q1_as_one_generic_fused_program_equals_the_oracle(gpu, oracle, n):
 def fagg_stats():
     import ctypes as C
     out = (C.c_uint64 * 3)()
-    T.lib().dbhip_fagg_stats_internal(out)
+    T.lib().dbhip_fagg_stats(out)
     return dict(jit=out[0], interpreted=out[1], pending=out[2])
 
 

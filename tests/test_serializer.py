@@ -117,8 +117,8 @@ def test_join_on_serialized_keys_equals_a_join_on_the_bytes(gpu, mask):
     thousands of different keys share a routing key and the byte-for-byte verification decides every pair"""
     D = gpu
     L = T.lib()
-    L.dbhip_join_binary_debug_hash_mask_internal.argtypes = [C.c_uint64]
-    L.dbhip_join_binary_debug_hash_mask_internal(C.c_uint64(0xFFFFFFFFFFFFFFFF if mask is None else mask))
+    L.dbhip_join_binary_debug_set_hash_mask.argtypes = [C.c_uint64]
+    L.dbhip_join_binary_debug_set_hash_mask(C.c_uint64(0xFFFFFFFFFFFFFFFF if mask is None else mask))
     try:
         rng = np.random.default_rng(5)
         nb, npb = (4000, 9000) if mask is None else (300, 500)
@@ -144,7 +144,7 @@ def test_join_on_serialized_keys_equals_a_join_on_the_bytes(gpu, mask):
         assert got == sorted(exp) and len(got) > 50
         assert np.array_equal(matched, np.isin(np.arange(npb), [p for p, _ in exp]))
     finally:
-        L.dbhip_join_binary_debug_hash_mask_internal(C.c_uint64(0xFFFFFFFFFFFFFFFF))
+        L.dbhip_join_binary_debug_set_hash_mask(C.c_uint64(0xFFFFFFFFFFFFFFFF))
 
 
 def rows_strings(hcol):

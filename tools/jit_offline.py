@@ -83,7 +83,7 @@ def compile_shape(shape, slots, defs):
     ck = (L.Col * len(keys))(*[c.c() for c in keys])
     code = C.create_string_buffer(1 << 20)
     log = C.create_string_buffer(1 << 16)
-    fn = lib.dbhip_fagg_jit_offline_internal
+    fn = lib.dbhip_jit_offline
     fn.restype = C.c_int64
     n = fn(kt, kn, len(key_types), ad, len(aggs), ck, C.byref(ap), slots, code, C.c_int64(len(code)), log, C.c_int64(len(log)))
     if n < 0:
