@@ -97,8 +97,8 @@ SYMBOLS = [
     "dbhip_pq_chunk_open", "dbhip_pq_chunk_validity", "dbhip_pq_chunk_image", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
     "dbhip_scatter_columns", "dbhip_concat_columns",
     # diagnostics and test hooks (declared in the header's last section)
-    "dbhip_groupby_debug_set_hash_mask", "dbhip_groupby_debug_set_partition_bits", "dbhip_join_binary_debug_set_hash_mask",
-    "dbhip_fagg_stats", "dbhip_jit_compile_check", "dbhip_jit_offline",
+    "dbhip_groupby_debug_set_hash_mask", "dbhip_groupby_debug_set_partition_bits", "dbhip_groupby_debug_set_compact", "dbhip_join_binary_debug_set_hash_mask",
+    "dbhip_fagg_stats", "dbhip_scratch_stats", "dbhip_jit_compile_check", "dbhip_jit_offline",
 ]
 _RESTYPE_I64 = {"dbhip_jit_compile_check", "dbhip_jit_offline"}
 

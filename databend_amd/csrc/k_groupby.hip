@@ -72,6 +72,14 @@ struct dbhip_groupby {
   int has_long;                            // a long string key was met: the LDS / partitioned paths decline, the row path runs
   uint64_t* xcur;                          // exchange partitioning: cursor[4096] | base[4097]
   int fagg_disabled;                       // the fused few-groups kernel (k_fagg.hip) gave up on this table's keys / shape
+  // compact-row kernels (gb_compact.h, round 4)
+  int gbc_off;                             // test hook / fallback: never use them for this table
+  int gbc_active;                          // the add_block call being worked on goes through them (layout AND columns qualify)
+  int gbc_lcap;                            // LDS table slots of the no-partition path (0 = not chosen yet)
+  int gbc_nodirect;                        // a partition outgrew its fixed region once (heavy keys): histogram path from now on
+  int gbc_part_lcap_max;                   // largest partition table of the compact kernels, chosen with the partitioning (0 = default)
+  uint32_t gbc_part_cap;                   // rows of a partition's region when the last scatter was the direct one, else 0
+  uint64_t* gbc_spill; size_t gbc_spill_cap;   // rows (table layout) that did not fit an LDS table
 };
 
 namespace {
@@ -1437,11 +1445,29 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
 int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t n, bool may_compile, hipStream_t s);  // k_fagg.hip
 bool dbhip_fagg_last_refusal_is_pending_internal();
 namespace {
+__device__ __forceinline__ uint32_t part_of(uint64_t h, int pbits) { return (uint32_t)(h >> (64 - pbits)); }
+#include "gb_compact.h"
+
+bool gbc_enabled(const dbhip_groupby* g) {
+  static const bool off = getenv("DBHIP_GBC") && atoi(getenv("DBHIP_GBC")) == 0;
+  return !off && !g->gbc_off && g->hash_mask == ~0ULL && !g->has_long;
+}
+
+// the kernels are instantiated for 1-2 key words and 1 / 2 / 4 value words (a layout without value words runs as NV = 1)
+#define GBC_DISPATCH(D, CALL)                                                     \
+  do {                                                                            \
+    const int nv_ = (D).nv <= 1 ? 1 : ((D).nv == 2 ? 2 : 4);                      \
+    if ((D).kw == 1) { if (nv_ == 1) { CALL(1, 1); } else if (nv_ == 2) { CALL(1, 2); } else { CALL(1, 4); } } \
+    else { if (nv_ == 1) { CALL(2, 1); } else if (nv_ == 2) { CALL(2, 2); } else { CALL(2, 4); } }             \
+  } while (0)
+inline int gbc_row_words(const GbcDesc& D) { return D.kw + (D.nv <= 1 ? 1 : (D.nv == 2 ? 2 : 4)); }
+
 constexpr int PT_MAX_BITS = 14;
 constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
 void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block);
 int64_t estimate_groups(int64_t d, int64_t s);
 void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes);
+void table_geometry(const dbhip_groupby* g, int* lcap, int* sw, size_t* lds_bytes);   // part_geometry, or the compact kernels' tables
 int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64_t cn, int pbits, hipStream_t s);
 constexpr int64_t PT_CHUNK = 64 << 20;
 
@@ -1453,7 +1479,7 @@ constexpr int64_t PT_CHUNK = 64 << 20;
 void adapt_chunk(dbhip_groupby* g, int64_t n_block) {
   int lcap, sw;
   size_t lds_bytes;
-  part_geometry(g->L, &lcap, &sw, &lds_bytes);
+  table_geometry(g, &lcap, &sw, &lds_bytes);
   const double G = (double)((int64_t)1 << g->part_bits) * 0.6 * lcap;
   const int64_t est = estimate_groups(g->count_host, g->rows_seen);
   const double D = (double)est;
@@ -1514,6 +1540,10 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
   bool hi = false;
   for (int a = 0; a < L.naggs; ++a) hi |= L.agg_type[a] == DBHIP_T_DEC128 && L.agg_kind[a] != DBHIP_AGG_COUNT;
   const bool small_layout = L.nkey_words <= 2 && L.nkeys <= 2 && L.naggs <= 2 && !hi;
+  // compact-row kernels (gb_compact.h): this call's layout AND columns qualify
+  GbcDesc GD;
+  const bool gbc = fast_layout_ok(L) && gbc_enabled(g) && gbc_describe(L, C, &GD);
+  g->gbc_active = gbc ? 1 : 0;
   const int64_t CHUNK = 16 << 20;
   int blocks_per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
   if (blocks_per_cu > 4) blocks_per_cu = 4;
@@ -1568,17 +1598,23 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // BIG table (r03): a small layout whose groups outgrew the 48 KB table (768 groups of 4 words) but fit one twice the size
     // runs ONE 1024-thread workgroup per CU on a 96 KB table (the same 4 waves per SIMD) instead of going through the
     // partitioning passes — 1000 groups: 1.97 ms partitioned, see DESIGN §2.3
-    const bool big = small && g->lds_big;
-    const int R = small ? ((small_r == 4 || big) ? 4 : 8) : 2;
-    const int threads = big ? 1024 : 256;
-    const int lcap_i = big ? lcap * 2 : lcap;
-    const size_t lds_i = big ? lds_bytes * 2 : lds_bytes;
-    const int max_grid_i = big ? 256 : max_grid;
+    const bool big = small && g->lds_big && !gbc;
+    // compact kernel: ONE 1024-thread workgroup per CU, 4 rows per lane, a table sized for the groups the probing chunk predicted
+    // (the largest table, gbc_max_lcap = 4096 slots / 112 KB for key + sum + count, while nothing is known)
+    const int gbc_lcap = gbc ? (g->gbc_lcap ? g->gbc_lcap : gbc_max_lcap(GD)) : 0;   // (nothing known yet: the largest table)
+    const int R = gbc ? 4 : (small ? ((small_r == 4 || big) ? 4 : 8) : 2);
+    const int threads = (big || gbc) ? 1024 : 256;
+    const int lcap_i = gbc ? gbc_lcap : (big ? lcap * 2 : lcap);
+    const size_t lds_i = gbc ? gbc_agg_lds_bytes(GD, gbc_lcap, GBC_T) : (big ? lds_bytes * 2 : lds_bytes);
+    const int max_grid_i = (big || gbc) ? 256 : max_grid;
     const int64_t tile_rows = (int64_t)threads * R;
     const int64_t cn = n - *done < limit ? n - *done : limit;
     const int64_t ntiles = ceil_div(cn, tile_rows);
     int grid = (int)(ntiles < max_grid_i ? ntiles : max_grid_i);
-    if (!g->fast_trusted && ntiles >= 64) {
+    // (the compact kernel's probing chunk: one 4096-row tile per workgroup — the table takes a tile's groups whatever they are, nothing
+    // spills, and what is learnt is the number of groups in the chunk, not a spill ratio; r04f: 0.2 ms at 10^4 groups with 16 workgroups
+    // x 4 tiles, most rows of which met full tables)
+    if (!gbc && !g->fast_trusted && ntiles >= 64) {
       // probing chunk: >= 4 (8) tiles per workgroup, so that its spill ratio measures the key distribution and
       // not the tile size (one tile per workgroup pre-aggregates nothing once groups ~ rows per tile)
       const int64_t gmax = probing ? ntiles / 4 : ntiles / 8;   // (probing: 4 tiles of 512 rows against a table of 768 groups tell as much)
@@ -1599,7 +1635,24 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     A.row0 = *done; A.n = cn; A.tiles_per_block = tpb; A.lcap = lcap_i; A.sw = sw;
     A.llimit = (uint32_t)(lcap_i - lcap_i / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
-    if (big) {
+    if (gbc) {
+      static bool gbc_attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process and kernel
+      if (!gbc_attr_set) {
+#define GBC_RAISE(KW_, NV_) DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_agg_kernel<KW_, NV_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        GBC_RAISE(1, 1) GBC_RAISE(1, 2) GBC_RAISE(1, 4) GBC_RAISE(2, 1) GBC_RAISE(2, 2) GBC_RAISE(2, 4)
+#undef GBC_RAISE
+        gbc_attr_set = true;
+      }
+      GbcAggArgs G;
+      memset(&G, 0, sizeof(G));
+      G.row0 = *done; G.n = cn; G.lcap = lcap_i; G.llimit = A.llimit; G.partial = g->partial; G.pcount = nullptr;
+      G.spill = g->rows_in; G.spill_cap = (uint64_t)spill_cap; G.ctrl = g->ctrl;
+      static const int gbc_debug = getenv("DBHIP_GBC_DEBUG") ? atoi(getenv("DBHIP_GBC_DEBUG")) : 0;
+      G.debug = gbc_debug;
+#define GBC_AGG(KW_, NV_) hipLaunchKernelGGL((gbc_agg_kernel<KW_, NV_, true>), dim3(grid), dim3(1024), lds_i, s, GD, C, G)
+      GBC_DISPATCH(GD, GBC_AGG);
+#undef GBC_AGG
+    } else if (big) {
       static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process
       if (!attr_set) {
         DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_lds_preagg_kernel<2, 2, false, 4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -1635,6 +1688,25 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // bits so that each partition fits, or (high cardinality) leave the rest to the row path
     // more groups than a workgroup's table takes (it would run full everywhere and hand most rows on)
     const bool too_many = g->count_host * 8 > (int64_t)A.llimit * 7;
+    if (gbc && cn >= 65536) {
+      // size the workgroups' tables for the groups the rows seen so far predict (load <= 0.6); more than the largest table holds:
+      // partition (below)
+      int64_t est = estimate_groups(g->count_host, g->rows_seen);
+      if (est > ((int64_t)1 << 40)) est = (int64_t)1 << 40;   // ("all distinct so far" comes back as a huge number)
+      // (a quarter full where the LDS allows it: a lane's first probe then settles ~9 rows in 10, and the rest walk one slot on)
+      int want = 256;
+      while (want < gbc_max_lcap(GD) && (int64_t)want < est * 4) want *= 2;
+      const bool fits = (int64_t)want * 6 >= est * 10;
+      if (fits && want != gbc_lcap) {
+        g->gbc_lcap = want;
+        if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in %lld rows -> ~%lld groups: compact LDS table of %d slots\n",
+                                           (long long)g->count_host, (long long)g->rows_seen, (long long)est, want);
+      }
+      if (fits) {
+        g->fast_trusted = (int64_t)hc[6] * 100 <= cn || want > gbc_lcap;
+        continue;
+      }
+    }
     if (((int64_t)hc[6] * 10 > cn || too_many) && cn >= 65536) {
       // twice the table is enough (estimated from the groups met so far): stay on the LDS path with the big table
       const int64_t big_limit = (int64_t)(lcap * 2 - lcap / 2) * 7 / 8;
@@ -1690,7 +1762,6 @@ __device__ __forceinline__ uint64_t gb_keys_hash(const GbLayout& L, const GbCols
   return h;
 }
 
-__device__ __forceinline__ uint32_t part_of(uint64_t h, int pbits) { return (uint32_t)(h >> (64 - pbits)); }
 
 // group hashes of R rows, column by column (gb_load_words_n: the R loads of a column are in flight together and the
 // layout is decoded once per column, not once per row)
@@ -2184,10 +2255,13 @@ struct PmArgs {
 
 __global__ __launch_bounds__(256) void gb_part_merge_kernel(GbLayout L, PmArgs A) {
   extern __shared__ uint32_t pm_slot[];   // [lcap]
+  __shared__ uint32_t pm_new;
   const int tid = threadIdx.x;
   const int p = blockIdx.x;
   const uint32_t n = A.pcount[p];
   if (n == 0) return;
+  if (tid == 0) pm_new = 0;
+  __syncthreads();
   const uint64_t* src = A.partial + (size_t)p * A.lcap * L.W;
   const uint64_t slice = (uint64_t)A.cap >> A.pbits;
   const uint64_t hi = ((uint64_t)p + 1) * slice;
@@ -2208,12 +2282,13 @@ __global__ __launch_bounds__(256) void gb_part_merge_kernel(GbLayout L, PmArgs A
           __hip_atomic_compare_exchange_strong((unsigned long long*)&A.slot_hash[pos], &old, (unsigned long long)hw, __ATOMIC_RELAXED,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (old == 0) {
+            // a new group: the partial row IS its state — written whole, nothing to merge in the second phase (r04: the table of
+            // 10^7 groups is far larger than any cache, every touch of a row is its own HBM sector; claim + identity + read back +
+            // merge were ~7 of them per group, this is 3)
             uint64_t* d = A.rows + pos * L.W;
-            for (int k = 0; k < L.nkey_words; ++k) d[k] = r[k];
-            d[L.hash_word] = r[L.hash_word];
-            for (int a = 0; a < L.naggs; ++a) gb_state_identity(L, a, d + L.agg_off[a]);
+            for (int k = 0; k < L.W; ++k) d[k] = r[k];
             claimed = true;
-            found = (uint32_t)pos;
+            found = GB_INVALID_SLOT - 1;   // done
             break;
           }
           cur = old;
@@ -2223,16 +2298,19 @@ __global__ __launch_bounds__(256) void gb_part_merge_kernel(GbLayout L, PmArgs A
       pm_slot[i] = found;
     }
     const uint64_t m = __ballot(claimed);
-    if (m && lane_id() == 0) atomicAdd((unsigned long long*)&A.ctrl[0], (unsigned long long)__popcll(m));
+    if (m && lane_id() == 0) atomicAdd(&pm_new, (uint32_t)__popcll(m));
   }
   __syncthreads();   // (a workgroup barrier orders this workgroup's global stores before its later loads: one CU, one L1)
+  // the new groups of the WORKGROUP in one atomic: ctrl[0] is one address, and an atomic per wave and pass — 131 K of them at 16384
+  // partitions — serialises at ~9 ns each (r04j: 1.2 of the 1.5 ms of this kernel per 5 M partial rows)
+  if (tid == 0 && pm_new) atomicAdd((unsigned long long*)&A.ctrl[0], (unsigned long long)pm_new);
   for (uint32_t i = tid; i < n_pad; i += 256) {
     bool listed = false;
     if (i < n) {
       const uint64_t* r = src + (size_t)i * L.W;
       const uint32_t pos = pm_slot[i];
       listed = pos == GB_INVALID_SLOT;
-      if (!listed) {
+      if (!listed && pos != GB_INVALID_SLOT - 1) {
         uint64_t* d = A.rows + (uint64_t)pos * L.W;
         bool eq = true;
         for (int k = 0; k < L.nkey_words; ++k) eq &= (d[k] == r[k]);
@@ -2354,6 +2432,77 @@ __global__ __launch_bounds__(256) void gb_part_insert_kernel(GbLayout L, PiArgs 
   if (tid == 0 && wg_new) atomicAdd((unsigned long long*)&A.ctrl[0], (unsigned long long)wg_new);
 }
 
+// hist -> scans -> scatter with compact rows: rows [row0, row0 + cn) into g->rows_in grouped by the top `pbits` hash bits;
+// base[0..P] (device, g->part_meta + PT_PMAX) = first row of every partition
+int32_t gbc_partition_scatter(dbhip_groupby* g, const GbCols& C, const GbcDesc& D, int64_t row0, int64_t cn, int pbits, hipStream_t s) {
+  const int P = 1 << pbits;
+  const int RW = gbc_row_words(D);
+  int32_t rc;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * RW * 8 + 64))) return rc;
+  // two 512-thread workgroups per CU while the cursors leave room for two staging areas (the phases of a batch — load, rank, stage,
+  // barrier, copy out, barrier — of one workgroup overlap with the other's; r04d counters: 73 % of the wave cycles parked with one
+  // 1024-thread workgroup per CU), one of 1024 threads beyond
+  // (r04e: two 512-thread workgroups per CU instead of one of 1024 — 1024 row ranges instead of 512 — were SLOWER: 0.41 vs 0.38 ms at
+  // 16 partitions, 0.69 vs 0.55 ms at 256: a workgroup's run inside a partition gets half as long)
+  static const int gbc_t = getenv("DBHIP_GBC_T") ? atoi(getenv("DBHIP_GBC_T")) : GBC_T;
+  const int T = gbc_t;
+  int64_t nwg = ceil_div(cn, (int64_t)T * 16);
+  if (nwg > 512) nwg = 512;
+  const int64_t rows_per_wg = ceil_div(cn, nwg);
+  nwg = ceil_div(cn, rows_per_wg);
+  if ((rc = ensure((void**)&g->part_meta, &g->part_meta_cap, ((size_t)(3 * PT_PMAX + 8) + (size_t)nwg * P) * 4))) return rc;
+  uint32_t* tot = g->part_meta;
+  uint32_t* base = g->part_meta + PT_PMAX;
+  uint32_t* mat = g->part_meta + 3 * PT_PMAX + 8;
+  static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+  if (!raised) {
+#define GBC_RAISE(KW_, NV_)                                                                                                             \
+    DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_scatter_direct_kernel<KW_, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+    DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_scatter_kernel<KW_, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+    DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_hist_kernel<KW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    GBC_RAISE(1, 1) GBC_RAISE(1, 2) GBC_RAISE(1, 4) GBC_RAISE(2, 1) GBC_RAISE(2, 2) GBC_RAISE(2, 4)
+#undef GBC_RAISE
+    raised = true;
+  }
+  const int SR = RW <= 2 ? 4 : (RW <= 4 ? 2 : 1);
+  // up to 1024 partitions: no histogram pass — fixed regions (the uniform share + 5 % + 16 K rows) and one global atomic per
+  // (batch, partition); a region that overflows is found after the chunk's first read-back and the chunk redone the exact way
+  static const bool no_direct = getenv("DBHIP_GBC_DIRECT") && atoi(getenv("DBHIP_GBC_DIRECT")) == 0;
+  g->gbc_part_cap = 0;
+  if (P <= 1024 && !g->gbc_nodirect && !no_direct && cn < ((int64_t)1 << 31)) {
+    // a partition's share of the rows follows its share of the GROUPS: with G groups spread over P partitions a partition holds
+    // G / P +- sqrt(G / P) of them (10^4 groups, 16 partitions: +-4 % — r04h: a flat 5 % of slack overflowed there); five sigma + 5 %
+    int64_t est = estimate_groups(g->count_host > 0 ? g->count_host : 1, g->rows_seen > 0 ? g->rows_seen : 1);
+    if (est < g->count_host) est = g->count_host;
+    double per_part = (double)est / P;
+    if (per_part < 1.0) per_part = 1.0;
+    double slack = 0.05 + 5.0 / sqrt(per_part);
+    if (slack > 1.0) slack = 1.0;
+    const int64_t cap = cn / P + (int64_t)((double)(cn / P) * slack) + 16384;
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cap * P * RW * 8 + 64))) return rc;
+    DBHIP_CHECK(hipMemsetAsync(tot, 0, (size_t)P * 4, s));
+    const size_t lds_d = (size_t)2 * P * 4 + (size_t)T * SR * 4 + (size_t)T * SR * RW * 8;
+#define GBC_SCATTER_D(KW_, NV_) hipLaunchKernelGGL((gbc_scatter_direct_kernel<KW_, NV_>), dim3((int)nwg), dim3(T), lds_d, s, D, C, row0, cn, pbits, rows_per_wg, (uint32_t)cap, tot, g->rows_in, g->ctrl)
+    GBC_DISPATCH(D, GBC_SCATTER_D);
+#undef GBC_SCATTER_D
+    DBHIP_LAUNCH_CHECK();
+    g->gbc_part_cap = (uint32_t)cap;
+    return DBHIP_OK;
+  }
+  if (D.kw == 1) hipLaunchKernelGGL(gbc_hist_kernel<1>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat);
+  else hipLaunchKernelGGL(gbc_hist_kernel<2>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat);
+  hipLaunchKernelGGL((gb_part_colscan_kernel<false>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
+  hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, tot, P, base);
+  hipLaunchKernelGGL((gb_part_colscan_kernel<true>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
+  const size_t lds = (size_t)P * 4 + (size_t)T * SR * 4 + (size_t)T * SR * RW * 8;
+  if (lds > 150 * 1024) { set_error("groupby: compact scatter needs %zu bytes of LDS", lds); return DBHIP_ERR_INVALID; }
+#define GBC_SCATTER(KW_, NV_) hipLaunchKernelGGL((gbc_scatter_kernel<KW_, NV_>), dim3((int)nwg), dim3(T), lds, s, D, C, row0, cn, pbits, rows_per_wg, mat, g->rows_in)
+  GBC_DISPATCH(D, GBC_SCATTER);
+#undef GBC_SCATTER
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
 void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
   *sw = L.W | 1;
   int c = 0;
@@ -2363,6 +2512,33 @@ void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
   }
   *lcap = c;
   *lds_bytes = (size_t)c * (*sw + 1) * 8;
+}
+
+// The compact kernels' partition tables: up to 2048 slots (56 KB for key + sum + count: two 512-thread workgroups per CU), i.e.
+// a quarter of the partitions the generic kernels' 1024-slot tables of 48-byte rows ask for — the scatter gets cheaper with every
+// halving of the partition count (longer runs per workgroup and partition).
+int gbc_part_threads(int lcap) { return lcap >= 4096 ? 1024 : (lcap >= 2048 ? 512 : 256); }
+int gbc_part_lcap(const GbLayout& L, int lcap_max) {
+  static const int env_c = getenv("DBHIP_GBC_PARTLCAP") ? atoi(getenv("DBHIP_GBC_PARTLCAP")) : 0;   // (experiments)
+  const int max_c = env_c ? env_c : (lcap_max ? lcap_max : 2048);
+  const size_t slot = (size_t)(L.nkey_words + (L.W - L.agg_off[0])) * 8 + 4;
+  const size_t qrow = (size_t)(L.nkey_words + 4) * 8;   // (a deferred-row queue per wave: at most key words + 4 value words per row)
+  // two workgroups per CU (75 KB each) up to 2048 slots, one (150 KB) for 4096
+  int c = 256;
+  while (c < max_c) {
+    const int n = c * 2;
+    const size_t bytes = (size_t)n * slot + (size_t)(gbc_part_threads(n) / 64) * GBC_QCAP * qrow;
+    if (bytes > (n >= 4096 ? (size_t)150 : (size_t)75) * 1024) break;
+    c = n;
+  }
+  return c;
+}
+void table_geometry(const dbhip_groupby* g, int* lcap, int* sw, size_t* lds_bytes) {
+  part_geometry(g->L, lcap, sw, lds_bytes);
+  if (g->gbc_active) {
+    *lcap = gbc_part_lcap(g->L, g->gbc_part_lcap_max);
+    *lds_bytes = (size_t)*lcap * ((size_t)(g->L.nkey_words + (g->L.W - g->L.agg_off[0])) * 8 + 4);
+  }
 }
 
 // One chunk [row0, row0 + cn) through hist -> scan -> scatter -> aggregate -> merge.
@@ -2423,10 +2599,16 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   const int P = 1 << pbits;
   int lcap, sw;
   size_t lds_bytes;
-  part_geometry(L, &lcap, &sw, &lds_bytes);
   int32_t rc;
-  if ((rc = partition_scatter(g, C, row0, cn, pbits, s))) return rc;
-  if ((rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
+  // compact rows (gb_compact.h) when the layout and the columns qualify; the direct-insert mode consumes serialized rows
+  GbcDesc D;
+  const bool gbc = g->gbc_active && !g->part_direct && gbc_enabled(g) && gbc_describe(L, C, &D);
+  if (!gbc) g->gbc_active = 0;   // (the geometry of everything that follows is the generic kernels')
+  table_geometry(g, &lcap, &sw, &lds_bytes);
+  if (gbc) rc = gbc_partition_scatter(g, C, D, row0, cn, pbits, s);
+  else rc = partition_scatter(g, C, row0, cn, pbits, s);
+  if (rc) return rc;
+  if (!gbc && (rc = ensure((void**)&g->spill_idx, &g->spill_idx_cap, (size_t)cn * 4))) return rc;
   uint32_t* base = g->part_meta + PT_PMAX;
   if (g->part_direct && g->hash_mask == ~0ULL) {
     // room: every row of the chunk may be a new group, but a table for 64 M new groups that then holds 10 M is a waste the
@@ -2477,11 +2659,12 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     const int64_t groups = est > g->count_host ? est : g->count_host;
     const int64_t per_part = groups / P + 8;
     while (lcap > 256 && (int64_t)(lcap / 2) >= 4 * per_part) lcap /= 2;
-    lds_bytes = (size_t)lcap * (sw + 1) * 8;
+    lds_bytes = gbc ? gbc_agg_lds_bytes(D, lcap, lcap >= 2048 ? 512 : 256) : (size_t)lcap * (sw + 1) * 8;
   }
   // workgroups per partition: fill the chip (>= ~1024 workgroups) without making splits tiny
   int splits = 1;
-  while (P * splits < 1024 && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
+  const int want_wgs = gbc ? 512 : 1024;   // (every workgroup hands on a partial row per group it met: half the workgroups, half the rows to merge)
+  while (P * splits < want_wgs && cn / ((int64_t)P * splits * 2) >= 4096) splits *= 2;
   const int agrid = P * splits;
   if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)agrid * lcap * L.W * 8))) return rc;
   // one workgroup per partition and a table at least as fine as the partitioning: the partial rows stay per partition and
@@ -2496,7 +2679,28 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   A.llimit = (uint32_t)(lcap - lcap / 4);
   A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill_idx = g->spill_idx; A.ctrl = g->ctrl;
   A.pcount = exclusive ? pcount : nullptr;
-  if (L.W <= 8) hipLaunchKernelGGL((gb_part_agg_kernel<8>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
+  const int64_t gbc_spill_cap = cn / 16 + 65536;
+  if (gbc) {
+    if ((rc = ensure((void**)&g->gbc_spill, &g->gbc_spill_cap, (size_t)gbc_spill_cap * L.W * 8))) return rc;
+    GbcAggArgs G;
+    memset(&G, 0, sizeof(G));
+    G.rows = g->rows_in; G.base = base; G.splits = splits; G.lcap = lcap; G.llimit = A.llimit; G.partial = g->partial;
+    if (g->gbc_part_cap) { G.pcursor = g->part_meta; G.part_cap = g->gbc_part_cap; }   // (the direct scatter's cursors: part_meta[0..P))
+    G.pcount = A.pcount; G.spill = g->gbc_spill; G.spill_cap = (uint64_t)gbc_spill_cap; G.ctrl = g->ctrl;
+    static const int agg_t = getenv("DBHIP_GBC_AGGT") ? atoi(getenv("DBHIP_GBC_AGGT")) : 0;   // (experiments)
+    const int threads = agg_t ? agg_t : gbc_part_threads(lcap);
+    lds_bytes = gbc_agg_lds_bytes(D, lcap, threads);
+    static bool agg_raised = false;
+    if (!agg_raised) {
+#define GBC_RAISE(KW_, NV_) DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_agg_kernel<KW_, NV_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      GBC_RAISE(1, 1) GBC_RAISE(1, 2) GBC_RAISE(1, 4) GBC_RAISE(2, 1) GBC_RAISE(2, 2) GBC_RAISE(2, 4)
+#undef GBC_RAISE
+      agg_raised = true;
+    }
+#define GBC_AGG(KW_, NV_) hipLaunchKernelGGL((gbc_agg_kernel<KW_, NV_, false>), dim3(agrid), dim3(threads), lds_bytes, s, D, C, G)
+    GBC_DISPATCH(D, GBC_AGG);
+#undef GBC_AGG
+  } else if (L.W <= 8) hipLaunchKernelGGL((gb_part_agg_kernel<8>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
   else hipLaunchKernelGGL((gb_part_agg_kernel<0>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
   DBHIP_LAUNCH_CHECK();
   uint64_t* hc = pinned_words(0);
@@ -2508,6 +2712,21 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     g->has_long = 1; g->fast_disabled = 1;
     *spilled = -1;
     return DBHIP_OK;
+  }
+  if (gbc && (hc[3] & 8)) {
+    // a partition outgrew the fixed region of the histogram-less scatter (heavy keys): nothing of this chunk has been merged —
+    // redo it with the exact histogram
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+    g->gbc_nodirect = 1;
+    if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: a partition outgrew its region, chunk redone with the histogram pass\n");
+    return add_chunk_partitioned(g, C, row0, cn, s, spilled);
+  }
+  if (gbc && (hc[3] & 4)) {
+    // more rows than the compact kernels' spill buffer holds met full tables (the estimate behind the partitioning was far off):
+    // nothing of this chunk has been merged — redo it with the generic kernels, whose spill list covers every row
+    DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+    g->gbc_active = 0; g->gbc_off = 1;
+    return add_chunk_partitioned(g, C, row0, cn, s, spilled);
   }
   const int64_t nspill = (int64_t)hc[6];
   const int64_t npartial = (int64_t)hc[5];
@@ -2529,19 +2748,21 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     g->count_host = (int64_t)hc[0];
     nlisted = (int64_t)hc[2];
   }
-  if (nspill + nlisted > 0) {
+  const int64_t ngather = gbc ? 0 : nspill;   // (the compact kernels wrote their spilled rows in table layout already: g->gbc_spill)
+  if (ngather + nlisted > 0) {
     // compact the listed rows BEFORE merge_rows may touch its own scratch (g->retry is part of it)
-    if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)(nspill + nlisted) * L.W * 8))) return rc;
-    if (nspill > 0)
-      hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nspill, 256)), dim3(256), 0, s, g->rows_in, g->spill_idx,
-                         nspill, L.W, g->spill_rows);
+    if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)(ngather + nlisted) * L.W * 8))) return rc;
+    if (ngather > 0)
+      hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(ngather, 256)), dim3(256), 0, s, g->rows_in, g->spill_idx,
+                         ngather, L.W, g->spill_rows);
     if (nlisted > 0)
       hipLaunchKernelGGL(gb_gather_rows_kernel, dim3(grid_for(nlisted, 256)), dim3(256), 0, s, g->partial, g->retry,
-                         nlisted, L.W, g->spill_rows + (size_t)nspill * L.W);
+                         nlisted, L.W, g->spill_rows + (size_t)ngather * L.W);
     DBHIP_LAUNCH_CHECK();
   }
   if (!exclusive && (rc = merge_rows(g, g->partial, npartial, s))) return rc;
-  if (nspill + nlisted > 0 && (rc = merge_rows(g, g->spill_rows, nspill + nlisted, s))) return rc;
+  if (ngather + nlisted > 0 && (rc = merge_rows(g, g->spill_rows, ngather + nlisted, s))) return rc;
+  if (gbc && nspill > 0 && (rc = merge_rows(g, g->gbc_spill, nspill, s))) return rc;
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby partitioned merge: exclusive=%d partial=%lld listed=%lld spilled=%lld cap=%lld\n",
                                      (int)exclusive, (long long)npartial, (long long)nlisted, (long long)nspill, (long long)g->cap);
   *spilled = nspill;
@@ -2575,10 +2796,16 @@ int64_t estimate_groups(int64_t d, int64_t s) {
 void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, int64_t n_block) {
   int lcap, sw;
   size_t lds_bytes;
-  part_geometry(g->L, &lcap, &sw, &lds_bytes);
+  const int64_t est = estimate_groups(groups, rows_seen);
+  // compact kernels: 4096-slot tables (one 1024-thread workgroup per CU) once the groups would otherwise ask for more than 1024
+  // partitions — the scatter loses more with every doubling of the partition count than the aggregation gains from the second
+  // workgroup per CU (r04 sweep, 10^6 groups: 1.69 ms against 2.11 ms; 10^4 / 10^5 groups: 2048 slots win, 1.15 / 1.33 against 1.29 / 1.45)
+  // (only where that keeps the partitions at <= 1024, the histogram-less scatter: at 10^7 groups 16384 workgroups each setting up and
+  // flushing a 112 KB table cost more than they save — 6.6 against 6.2 ms)
+  g->gbc_part_lcap_max = (g->gbc_active && est > 500000 && est <= 1500000) ? 4096 : 0;
+  table_geometry(g, &lcap, &sw, &lds_bytes);
   g->part_bits = -1;
   if (lcap == 0 || g->part_forbidden) return;
-  const int64_t est = estimate_groups(groups, rows_seen);
   const int64_t total = n_block > rows_seen ? n_block : rows_seen;
   const int64_t per_part = lcap * 3 / 8;  // target groups per partition: half of the LDS table's limit
   int bits = 4;
@@ -2694,6 +2921,14 @@ int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits) {
   return DBHIP_OK;
 }
 
+// test hook: keep this table off (0) / on (1, the default) the compact-row kernels (gb_compact.h), so that both the generic and the
+// compact kernels can be driven through the same cases
+int32_t dbhip_groupby_debug_set_compact(dbhip_groupby* g, int32_t on) {
+  DBHIP_REQUIRE(g, "dbhip_groupby_debug_set_compact: NULL argument");
+  g->gbc_off = on ? 0 : 1;
+  return DBHIP_OK;
+}
+
 int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
                                 int64_t n, void* stream) {
   return dbhip_groupby_add_block_filtered(g, keys, args, n, nullptr, 0, stream);
@@ -2732,6 +2967,7 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
   }
   int32_t rc;
   int64_t done = 0;
+  g->gbc_active = 0;   // (add_block_fast decides per call whether layout and columns qualify for the compact-row kernels)
   // The caller sized the table for about as many groups as this first block has rows (a join's output grouped by the join key,
   // TPC-H Q3: 3 M rows, 1.1 M groups): pre-aggregation has nothing to combine and costs more than the rows it saves
   // (r03: LDS pre-aggregation 0.59 ms + merge against 0.3 ms for the row path alone), the block goes straight to the row path.
@@ -3209,6 +3445,9 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->fast_trusted = 0;
   g->lds_big = 0;
   g->fagg_disabled = 0;
+  g->gbc_lcap = 0;
+  g->gbc_active = 0;
+  g->gbc_part_lcap_max = 0;
   if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
   g->rows_seen = 0;
   return DBHIP_OK;
@@ -3227,6 +3466,7 @@ int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (g->part_meta) (void)dbhip_free(g->part_meta);
   if (g->spill_idx) (void)dbhip_free(g->spill_idx);
   if (g->spill_rows) (void)dbhip_free(g->spill_rows);
+  if (g->gbc_spill) (void)dbhip_free(g->gbc_spill);
   if (g->xcur) (void)hipFree(g->xcur);
   if (g->arena) (void)dbhip_free(g->arena);
   delete g;

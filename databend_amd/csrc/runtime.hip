@@ -340,6 +340,18 @@ int32_t dbhip_stream_create(void** out) {
   return DBHIP_OK;
 }
 
+int32_t dbhip_scratch_stats(uint64_t* out2_host) {
+  DBHIP_REQUIRE(out2_host, "dbhip_scratch_stats: NULL argument");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  out2_host[0] = out2_host[1] = 0;
+  if (!g_scratch) return DBHIP_OK;
+  for (auto& kv : *g_scratch) {
+    out2_host[0] += 1;
+    for (const Scratch& sl : kv.second.slot) out2_host[1] += sl.cap;
+  }
+  return DBHIP_OK;
+}
+
 int32_t dbhip_stream_release_scratch(void* stream) {
   hipStream_t s = resolve_stream(stream);
   DBHIP_CHECK(hipStreamSynchronize(s));

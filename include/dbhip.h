@@ -911,9 +911,14 @@ int32_t dbhip_groupby_debug_set_hash_mask(dbhip_groupby* g, uint64_t mask);
 int32_t dbhip_join_binary_debug_set_hash_mask(uint64_t mask);
 /* force the radix-partitioned path with 2^bits partitions (0: back to adaptive, < 0: never partition) */
 int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits);
+/* keep a table off (0) / on (1, default) the compact-row kernels of the partitioned and LDS aggregation paths (both kernel families
+ * are driven through the same parity cases) */
+int32_t dbhip_groupby_debug_set_compact(dbhip_groupby* g, int32_t on);
 /* launches of the fused-aggregation kernel since the library was loaded: out3_host = {run-time specialised, interpreted, refused
  * because the specialised kernel was still being compiled} — how a bench or a test tells which kernel a call went through */
 int32_t dbhip_fagg_stats(uint64_t* out3_host);
+/* internal scratch held right now: out2_host = {(thread, stream) entries, bytes} */
+int32_t dbhip_scratch_stats(uint64_t* out2_host);
 /* Offline compile checks of the run-time specialisation (need no device; the CPU test-suite runs them): the code object of a small
  * fixed query shape / of a table layout + program -> its size in bytes, -1 with the compiler's log in log_out_host, -2 when the shape
  * is outside the fused kernel. */

@@ -372,32 +372,38 @@ def test_take_of_an_unaligned_column_view_does_not_read_past_the_buffer(gpu):
 def test_stream_scratch_is_released_with_the_stream(gpu):
     """scratch keyed by (thread, stream) was never freed. A stream's scratch now goes with dbhip_stream_destroy /
     dbhip_stream_release_scratch, and a thread keeps at most 8 streams' worth: many short-lived streams do not grow device memory."""
-    import torch
     n = 2_000_000
     keys = gpu.Column.from_numpy(np.random.default_rng(1).integers(0, 1 << 40, n).astype(np.int64))
     L = T.lib()
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+
+    def stats():
+        out = (C.c_uint64 * 2)()
+        T.check(L.dbhip_scratch_stats(out))
+        return int(out[0]), int(out[1])
     arr = (T.Col * 1)(keys.c())
     zero = (C.c_uint8 * 1)(0)
     perm = gpu.DeviceBuffer(n * 4)
-    for _ in range(24):                       # every iteration: a fresh stream, a sort (48 MB of scratch), destroy
+    e0, b0 = stats()
+    for _ in range(24):                       # every iteration: a fresh stream, a sort (~50 MB of scratch), destroy
         s = C.c_void_p()
         T.check(L.dbhip_stream_create(C.byref(s)))
         T.check(L.dbhip_sort_perm(arr, zero, zero, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.ptr), s))
+        assert stats()[1] > b0
         T.check(L.dbhip_stream_destroy(s))
-    torch.cuda.synchronize()
-    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
+        assert stats() == (e0, b0)
     streams = []
     for _ in range(20):                       # foreign streams that are never handed back: the per-thread LRU bounds them
         s = C.c_void_p()
         T.check(L.dbhip_stream_create(C.byref(s)))
         streams.append(s)
         T.check(L.dbhip_sort_perm(arr, zero, zero, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.ptr), s))
-    torch.cuda.synchronize()
-    assert free0 - torch.cuda.mem_get_info()[0] < 9 * (64 << 20)
+        assert stats()[0] <= 8
+    per_stream = (stats()[1] - b0) / max(stats()[0] - e0, 1)
+    assert stats()[1] <= b0 + 8 * per_stream * 1.01
     for s in streams:
         T.check(L.dbhip_stream_release_scratch(s))
         T.check(L.dbhip_stream_destroy(s))
-    torch.cuda.synchronize()
-    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
+    assert stats()[0] <= e0 and stats()[1] <= b0
+    exp = np.argsort(keys.to_numpy(), kind="stable").astype(np.uint32)
+    T.check(L.dbhip_sort_perm(arr, zero, zero, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.ptr), None))
+    assert np.array_equal(perm.to_numpy(np.uint32, n), exp)

@@ -22,7 +22,7 @@ for STEP in "$@"; do
   KIND=${STEP%%:*}; ARG=""; [ "$STEP" != "$KIND" ] && ARG=${STEP#*:}
   case $KIND in
     tests)
-      timeout 1500 python -m pytest ${ARG:-tests} -m gpu -q -x --timeout 300 2>&1 | tail -8 | tee gpurun_out/pytest_$TAG.log ;;
+      timeout 1500 python -m pytest ${ARG:-tests} -m gpu -q -x --timeout 300 > gpurun_out/pytest_full_$TAG.log 2>&1; tail -60 gpurun_out/pytest_full_$TAG.log | cut -c1-400 > gpurun_out/pytest_$TAG.log; tail -8 gpurun_out/pytest_$TAG.log ;;
     bench)
       timeout 900 python bench.py $ARG > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
       tail -2 gpurun_out/bench_$TAG.err | cut -c1-300; cut -c1-1200 gpurun_out/bench_$TAG.json ;;
