@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only for a functional check)")
     ap.add_argument("--share-gpu", action="store_true", help="functional check of the N>1 path on a 1-GPU box: every rank uses "
                     "cuda:0 (with --backend gloo); the numbers of such a run are not a measurement")
+    ap.add_argument("--headline", choices=["program", "hand"], default="program",
+                    help="what `value` / `roofline` time: the generic fused program through dbhip_groupby_add_block_program (default), or the "
+                         "query-specific hand-written kernel dbhip_q1_fused")
     ap.add_argument("--exchange-impl", choices=["torch", "abi"], default="torch",
                     help="N > 1: who owns the communicator of the partial-state exchange: torch.distributed (default), or the C-ABI's "
                          "own RCCL communicator (dbhip_comm_*, dbhip_groupby_exchange_*: what a Rust host would call)")
@@ -116,13 +119,32 @@ def main():
         dist.broadcast_object_list(ids, src=0)     # the host's control plane ships the 128 bytes
         abi_comm = D.Comm(rank, world, ids[0])
 
-    def step(record=False):
-        g.reset(stream)
-        D.q1_fused(g, li.qty, li.price, li.disc, li.tax, li.rf, li.ls, li.ship, tpch.Q1_CUTOFF, stream=stream)
+    # THE HEADLINE PATH is the generic one: the binding flattens Q1's predicate and decimal maps into one register
+    # program and dbhip_groupby_add_block_program runs the fused filter -> map -> partial-aggregate kernel the library specialised
+    # for it at PREPARE time (hiprtc) — what a physical plan can dispatch to. The query-specific hand-written kernel (k_q1.hip,
+    # dbhip_q1_fused) is measured beside it as the ceiling (`hand_written_kernel`); `--headline hand` swaps the two.
+    plan = tpch.q1_program(li)
+    prepare_ms = None
+    if args.headline == "program":
+        t0p = time.perf_counter()
+        tpch.q1_fused_program(li, g, prepare=True, plan=plan)     # PREPARE of the pipeline: compile / load the specialised kernel
+        prepare_ms = (time.perf_counter() - t0p) * 1e3
+
+    def launch(record, into):
+        if args.headline == "program":
+            tpch.q1_fused_program(li, g, plan=plan, stream=stream)
+        else:
+            D.q1_fused(g, li.qty, li.price, li.disc, li.tax, li.rf, li.ls, li.ship, tpch.Q1_CUTOFF, stream=stream)
         if record:
             ms = C.c_float()
-            check(L.dbhip_last_kernel_ms(C.byref(ms)))  # HIP events around q1_fused_kernel on its stream
-            kms.append(ms.value)
+            check(L.dbhip_last_kernel_ms(C.byref(ms)))  # HIP events around the fused kernel on its stream
+            into.append(ms.value)
+
+    def step(record=False):
+        g.reset(stream)
+        launch(record, kms)
+        if False:
+            pass
         if abi_comm is not None:
             (abi_comm.exchange_alltoall if exchange == "alltoall" else abi_comm.exchange_allgather)(g, 256, stream)
         elif world > 1:
@@ -152,8 +174,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # average launch duration of the dominant kernel (q1_fused_kernel), HIP events on its stream
+    # average launch duration of the dominant kernel (the specialised fused-program kernel, or q1_fused_kernel), HIP events on its stream
     kernel_ms = float(np.mean(kms)) if kms else 0.0
+    dominant = "fagg_jit (run-time specialised fused filter+map+aggregate program)" if args.headline == "program" else "q1_fused_kernel"
+    result_headline = tpch.q1_rows(g)
+    # the OTHER kernel beside it, same rows, same steps: its per-launch duration and wall time
+    other = None
+    if world == 1:
+        okms = []
+        g2 = D.GroupBy.q1()
+
+        def other_step(rec):
+            g2.reset(stream)
+            if args.headline == "program":
+                D.q1_fused(g2, li.qty, li.price, li.disc, li.tax, li.rf, li.ls, li.ship, tpch.Q1_CUTOFF, stream=stream)
+            else:
+                tpch.q1_fused_program(li, g2, plan=plan, stream=stream)
+            if rec:
+                ms = C.c_float()
+                check(L.dbhip_last_kernel_ms(C.byref(ms)))
+                okms.append(ms.value)
+        if args.headline == "hand":
+            tpch.q1_fused_program(li, g2, prepare=True, plan=plan)
+        for _ in range(max(args.warmup, 1)):
+            other_step(False)
+        check(L.dbhip_stream_sync(stream))
+        t0o = time.perf_counter()
+        for _ in range(args.steps):
+            other_step(True)
+        check(L.dbhip_stream_sync(stream))
+        oms = (time.perf_counter() - t0o) * 1e3 / args.steps
+        okm = float(np.mean(okms))
+        same = tpch.q1_rows(g2) == result_headline
+        other = {"name": "q1_fused_kernel (query-specific, k_q1.hip: the ceiling)" if args.headline == "program" else "fagg_jit (generic fused program)",
+                 "ms_per_step": oms, "kernel_ms": okm, "rows_per_s": n_total / (oms * 1e-3),
+                 "hbm_frac": n * BYTES_PER_ROW / (okm * 1e-3) / 1e9 / HBM_PEAK_GBS if okm else None,
+                 "headline_kernel_slowdown": kernel_ms / okm if okm else None, "equals_headline_result": bool(same)}
+        assert same, "the generic fused program and the hand-written kernel disagree"
+        g2.destroy()
 
     value = n_total * args.steps / dt
     result = tpch.q1_rows(g)
@@ -232,7 +290,7 @@ def main():
     if rank == 0:
         achieved = (n * BYTES_PER_ROW) / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "q1_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "q1_traffic_program.json" if args.headline == "program" else "q1_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
@@ -244,17 +302,20 @@ def main():
         out = {
             "metric": "rows/s TPC-H Q1 hash-agg", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",   # one SF100 table whatever N: the rows per GPU shrink as N grows
             "vs_baseline": None, "dtype": "i64/i128 decimal", "data": "synthetic" + (" (FUNCTIONAL CHECK: ranks share one GPU, not a measurement)" if args.share_gpu else ""),
             "config": {"workload": f"TPC-H Q1 hash-aggregation, {sf_txt} synthetic lineitem ({n_total} rows, 68 B/row, resident in HBM), "
-                                   f"fused filter+decimal maps+group-by, "
+                                   f"fused filter+decimal maps+group-by ({'generic register program through dbhip_groupby_add_block_program' if args.headline == 'program' else 'hand-written dbhip_q1_fused'}), "
                                    + (f"row-range sharded over {world} GPUs ({n} rows on rank 0), {exchange} of partial states over RCCL + final merge"
                                       if world > 1 else "1 MI355X"),
                        "rows_total": n_total, "rows_per_rank": n, "groups": n_groups, "exchange": exchange or None,
                        "generate_seconds": gen_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "q1_fused_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dominant,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": n * BYTES_PER_ROW},
+            "headline_path": {"what": "dbhip_groupby_add_block_program (generic fused program, PREPAREd)" if args.headline == "program" else "dbhip_q1_fused (hand-written)",
+                              "prepare_ms_cold_or_cached": prepare_ms},
+            "hand_written_kernel" if args.headline == "program" else "generic_program_kernel": other,
             "cpu_baseline": cpu,
             "multi_gpu_readiness": readiness,
             "q1_operator_plan": opplan,
@@ -543,6 +604,14 @@ def bench_ann(args, rank, world, torch, dist, D, DX, L, check):
     check(L.dbhip_vec_index_destroy(ix))
     qps = nq * args.ann_steps / dt
     search_ms = float(np.mean(kms))
+    # HBM bytes per search step from the committed PMC passes of THIS configuration (profiles/ann_traffic.json), else null
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "ann_traffic.json")))
+        if world == 1 and n_total == 10_000_000 and dim == 768 and nq == 10_000:
+            traffic, traffic_src = tj.get("hbm_bytes_per_step"), tj.get("source")
+    except Exception:
+        traffic = None
     tf = 2.0 * n * dim * nq / (search_ms * 1e-3) / 1e12
     return {"metric": "ANN queries/s @ recall@10", "value": qps, "unit": "queries/s", "recall_at_10": recall,
             "recall_at_10_vs_cpu_oracle": oracle_recall, "recall_at_10_vs_cpu_oracle_full_base": oracle_full, "k": k,
@@ -552,8 +621,9 @@ def bench_ann(args, rank, world, torch, dist, D, DX, L, check):
                                    + (", all-gather of per-shard top-10 over RCCL + merge" if world > 1 else ""),
                        "rows_per_rank": n, "dim": dim, "queries_per_step": nq},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
-                         "kernel": "bf16_filter_kernel (+ exact seed scan, re-score, select)", "search_ms": search_ms,
-                         "algorithmic_flops_per_step": 2.0 * n * dim * nq, "traffic": None,
+                         "kernel": "bf16_filter256_kernel (+ exact seed scan, re-score, select)", "search_ms": search_ms,
+                         "algorithmic_flops_per_step": 2.0 * n * dim * nq, "traffic": traffic, "traffic_unit": "HBM bytes per search step",
+                         "traffic_source": traffic_src,
                          "note": "per-rank dbhip_vec_index_search time (HIP events on the library stream); peak = dense bf16 MFMA"}}
 
 

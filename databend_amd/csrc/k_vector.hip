@@ -672,7 +672,20 @@ struct HArgs {
   uint32_t* cand_i;         // [nq][cand_cap]
   uint32_t* cand_cnt;
   uint32_t cand_cap, row_origin;
+  const float* qcB; const float* qcG; const float* qcT;   // bf16_filter256_kernel: per query B', G', T' (bf16_qcoef_kernel), padded to whole q-tiles
 };
+
+// the three per-query numbers of the bound test (see bf16_filter_kernel's epilogue), once per search range instead of once per tile
+template <int METRIC>
+__global__ __launch_bounds__(256) void bf16_qcoef_kernel(HArgs A, int nq_pad, float* qcB, float* qcG, float* qcT) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nq_pad) return;
+  const int q = t < A.nq ? t : A.nq - 1;
+  const float n_ = A.qn[q], h_ = A.qh[q], e_ = A.qe[q];
+  const float tau = t < A.nq ? A.tau[(int64_t)q * A.tau_stride] : -INFINITY;
+  qcB[t] = e_ + A.c * h_; qcG[t] = h_ + e_;
+  qcT[t] = METRIC == 0 ? (1.0f - tau) * n_ : (METRIC == 1 ? -tau : 0.5f * (0.99999f * n_ * n_ - 1.00001f * tau * tau));
+}
 
 // TQ = 128: 4 waves (2 x 2), TQ = 256: 8 waves (4 x 2); every wave owns 64 x 64 scores. The taller tile reads the
 // base tile (L2 -> LDS) half as often per query and amortises the LDS stores over twice the matrix work.
@@ -812,6 +825,241 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the 256 x 256 tile, 8-phase schedule (cdna_hip_programming.md "The 256^2 8-phase template") for the bf16 filter.
+//
+// Eight waves (2 query halves x 4 base quarters), each owning 128 queries x 64 base rows = 8 x 4 fragments of
+// v_mfma_f32_16x16x32_bf16; BK = 64; the operands of a k-tile are staged with global_load_lds (16 B per lane, no VGPR staging, no
+// LDS stores by the VALU) into a double-buffered 128 KB LDS image, in four UNITS of 128 rows x 128 B per k-tile:
+//     A0 / A1 = the first / second 64 query rows of both query halves,   B0 / B1 = the first / second 32 base rows of all four quarters
+// — a unit is exactly what one phase's prefetch moves (2 x 512 lanes x 16 B), and every wave reads a unit in ONE phase:
+//     phase 1  reads A0        MFMA quadrant (A0, B0)       phase 3  reads A1             quadrant (A1, B1)
+//     phase 2  reads B1        quadrant (A0, B1)             phase 4  reads B0 of tile t+1  quadrant (A1, B0)   (B0 stays in registers)
+// (phases 5-8: the same on the other buffer). So a unit is dead one phase after it was needed and is restaged two phases later; every
+// unit is issued six phases before the phase that reads it, and ONE counted wait per phase, s_waitcnt vmcnt(10) (five units = 10 loads
+// may stay in flight), retires exactly the unit the NEXT phase reads; the barrier that follows publishes it (RAW) and fences the
+// restaging of the unit read two phases ago (WAR).
+// Never vmcnt(0) in the loop. LDS rows are 128 B with the 16-byte slot XOR-swizzled by (row >> 1) & 7: the 16 lanes of a
+// ds_read_b128 group (16 consecutive rows, one slot) land on 16 distinct 16-byte positions of the 256-byte bank row; global_load_lds
+// writes linearly, so the swizzle is applied to the per-lane GLOBAL address. Fragment layout (A and B alike): lane l holds row l & 15,
+// k = 8 (l >> 4) .. + 8; C: column l & 15, rows 4 (l >> 4) + j.
+// The epilogue is the bound test of bf16_filter_kernel on the 16 x 16 fragment layout.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int METRIC>
+__global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
+  extern __shared__ __attribute__((aligned(1024))) uint8_t fsm[];   // 2 buffers x 4 units x 16 KB
+  constexpr int TQ = 256, TI = 256;
+  // One output tile (256 queries x 256 base rows) per workgroup; the q-tiles of one base tile run back to back on one XCD (workgroup
+  // b -> XCD b mod 8), so the base tile is fetched from HBM about once. (r04q tried the workgroup PERSISTENT over the query tiles of a
+  // base tile — the pipeline filled once, the bound test of a finished tile overlapping the next tile's loads: with the test inside
+  // the loop the kernel needs more than its 256 registers, spills into the k-loop and runs at 4.65 ms instead of 3.65 ms.)
+  const int64_t slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int qt = (int)(slot % A.n_qtiles);
+  const int64_t it = (slot / A.n_qtiles) * 8 + xcd;
+  if (it >= A.n_itiles) return;
+  const int64_t i0 = it * TI;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int dpad = A.dpad;
+  const int nkt = dpad / HBK;   // k-tiles per output tile (even: checked by the host)
+  const int gtot = nkt;
+
+  // ---- staging: this thread's two 16-byte pieces of every unit ----
+  // piece j of a unit: unit row u = 64 j + (tid >> 3), physical slot tid & 7 = logical slot ^ ((u >> 1) & 7)
+  // (the query image is padded to whole 256-row tiles with zero rows: no clamp on that side)
+  const int blast = (int)(A.n - i0 < TI ? A.n - i0 : TI) - 1;
+  uint32_t goff[4][2];   // [unit][piece]: element offset of the piece's first bf16 inside the query / base tile at k-tile 0
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int u = 64 * j + (tid >> 3);
+    const int sl = (tid & 7) ^ ((u >> 1) & 7);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ra = (u >> 6) * 128 + s * 64 + (u & 63);      // A_s: both query halves' rows [64 s, 64 s + 64)
+      int rb = (u >> 5) * 64 + s * 32 + (u & 31);             // B_s: all four base quarters' rows [32 s, 32 s + 32)
+      rb = rb < blast ? rb : blast;
+      goff[s][j] = (uint32_t)ra * (uint32_t)dpad + sl * 8;
+      goff[2 + s][j] = (uint32_t)rb * (uint32_t)dpad + sl * 8;
+    }
+  }
+  const uint16_t* btile = A.base + i0 * dpad;
+  const int64_t qtile_elems = (int64_t)TQ * dpad;
+  // unit `un` (0 A0, 1 A1, 2 B0, 3 B1) of global k-tile `g` into buffer `buf`; k-tiles past the end re-load the last one (the slot
+  // is dead by construction, the data is never read) so that the load count per phase stays uniform
+  auto stage = [&](int un, int buf, int g) {
+    g = g < gtot ? g : gtot - 1;
+    const int k0 = g * HBK;
+    const uint16_t* src = un < 2 ? A.queries + qt * qtile_elems : btile;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t go = un == 0 ? goff[0][j] : (un == 1 ? goff[1][j] : (un == 2 ? goff[2][j] : goff[3][j]));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + go + k0),
+                                       (__attribute__((address_space(3))) void*)(fsm + buf * 65536 + un * 16384 + j * 8192 + wave * 1024), 16, 0, 0);
+    }
+  };
+  // ---- fragment reads ----
+  const int fr = lane & 15, fg = lane >> 4;
+  auto frag_off = [&](int u, int sl) { return u * 128 + ((sl ^ ((u >> 1) & 7)) << 4); };
+  uint32_t aoffs[4][2], boffs[2][2];   // [fragment][k half]
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) aoffs[m][kk] = (uint32_t)frag_off(wr * 64 + m * 16 + fr, kk * 4 + fg);
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) boffs[nn][kk] = (uint32_t)frag_off(wc * 32 + nn * 16 + fr, kk * 4 + fg);
+  }
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  auto read_a = [&](int buf, int un) {
+    const uint8_t* base = fsm + buf * 65536 + un * 16384;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[m][kk] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + aoffs[m][kk]));
+  };
+  auto read_b = [&](int buf, int un, bf16x8 (&fb)[2][2]) {
+    const uint8_t* base = fsm + buf * 65536 + un * 16384;
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb[nn][kk] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + boffs[nn][kk]));
+  };
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) acc[m][nn] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // 16 MFMAs: quadrant (sa, sb) of the wave's 8 x 4 fragments
+  auto mfma_quadrant = [&](int sa, int sb, const bf16x8 (&fb)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+          acc[sa * 4 + m][sb * 2 + nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[sa * 4 + m][sb * 2 + nn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // Per phase: [LDS reads of this phase's operands | this phase's unit prefetch | counted wait] BARRIER [16 MFMAs] BARRIER. The second
+  // barrier exists for the STAGGER: the four waves of the second query half run one barrier behind the first half's (one extra
+  // barrier before the loop, one for the first half after it), so while one half issues its MFMAs the other half — the other wave of
+  // every SIMD: wave w and w + 4 share SIMD w & 3 — does its LDS reads and prefetches.
+  // RAW: a unit is waited for before the first barrier of phase p by every wave that issued a piece of it and read in phase p + 1,
+  // i.e. at least two barriers later for either half. WAR: a unit is restaged two phases after its last read.
+#define F256_MEM_SYNC()                              \
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  \
+  __builtin_amdgcn_s_barrier();                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define F256_END_SYNC() __builtin_amdgcn_s_barrier()
+
+  // LDS reads per phase are BALANCED (8 / 4 / 8 / 4 ds_read_b128 per wave): B0 of the NEXT k-tile is read in phase 4, whose own MFMAs
+  // work from registers, into the B register set that B1 has just left. Per k-tile g:
+  //     phase 1  reads A0(g)     MFMA (A0, B0)         issue A1(g+1)        phase 3  reads A1(g)     MFMA (A1, B1)   issue A0(g+2)
+  //     phase 2  reads B1(g)     MFMA (A0, B1)         issue B0(g+2)        phase 4  reads B0(g+1)   MFMA (A1, B0)   issue B1(g+2)
+  // every unit is issued six phases before the phase that reads it and two after the last read of the unit it replaces; the one
+  // counted wait per phase is vmcnt(10): five units may stay in flight, the sixth-youngest — the one the next phase reads — has landed.
+  // B0 lives in set X on even k-tiles and in Y on odd ones.
+  bf16x8 (&bx)[2][2] = fb0;
+  bf16x8 (&by)[2][2] = fb1;
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0); stage(2, 1, 1); stage(0, 1, 1); stage(3, 1, 1);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // B0(0) has landed
+  __builtin_amdgcn_s_barrier();
+  read_b(0, 2, bx);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A0(0) has landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // the second half starts one barrier behind
+  {
+    for (int t = 0; t < nkt; t += 2) {
+      const int g = t;
+      // ---- k-tile g in buffer 0 (B0 in X, B1 in Y) ----
+      read_a(0, 0);
+      stage(1, 1, g + 1);
+      F256_MEM_SYNC();
+      mfma_quadrant(0, 0, bx);
+      F256_END_SYNC();
+      read_b(0, 3, by);
+      stage(2, 0, g + 2);
+      F256_MEM_SYNC();
+      mfma_quadrant(0, 1, by);
+      F256_END_SYNC();
+      read_a(0, 1);
+      stage(0, 0, g + 2);
+      F256_MEM_SYNC();
+      mfma_quadrant(1, 1, by);
+      F256_END_SYNC();
+      read_b(1, 2, by);            // B0(g + 1) into Y (B1(g) has had its last use)
+      stage(3, 0, g + 2);
+      F256_MEM_SYNC();
+      mfma_quadrant(1, 0, bx);
+      F256_END_SYNC();
+      // ---- k-tile g + 1 in buffer 1 (B0 in Y, B1 in X) ----
+      read_a(1, 0);
+      stage(1, 0, g + 2);
+      F256_MEM_SYNC();
+      mfma_quadrant(0, 0, by);
+      F256_END_SYNC();
+      read_b(1, 3, bx);
+      stage(2, 1, g + 3);
+      F256_MEM_SYNC();
+      mfma_quadrant(0, 1, bx);
+      F256_END_SYNC();
+      read_a(1, 1);
+      stage(0, 1, g + 3);
+      F256_MEM_SYNC();
+      mfma_quadrant(1, 1, bx);
+      F256_END_SYNC();
+      read_b(0, 2, bx);            // B0(g + 2) into X
+      stage(3, 1, g + 3);
+      F256_MEM_SYNC();
+      mfma_quadrant(1, 0, by);
+      F256_END_SYNC();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // (the barrier the second half's last phase pairs with)
+    // ---- the bound test of bf16_filter_kernel; the per-query numbers come precomputed (bf16_qcoef_kernel), the per-row ones from
+    // the index ----
+    const int q0 = qt * TQ;
+    // (the base rows' coefficients come from the L2 every output tile rather than living in 16 registers through the k-loop: with
+    // them the kernel needed 256 registers + scratch, r04q)
+    float ba[4], bx_[4], by_[4], bz[4];
+    bool bok[4];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+      const int64_t i = i0 + wc * 64 + nn * 16 + fr;
+      bok[nn] = i < A.n;
+      const int64_t ic = bok[nn] ? i : A.n - 1;
+      ba[nn] = METRIC == 0 ? A.rowA[ic] : (METRIC == 1 ? -1.0f : 1.0f);
+      bz[nn] = METRIC == 2 ? A.rowA[ic] : 0.0f;
+      bx_[nn] = A.rowX[ic]; by_[nn] = A.rowY[ic];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int ql = q0 + wr * 128 + m * 16 + fg * 4;   // this lane's 4 queries of fragment row m
+      const float4 vb = *(const float4*)(A.qcB + ql), vg = *(const float4*)(A.qcG + ql), vt = *(const float4*)(A.qcT + ql);
+      const float cB[4] = {vb.x, vb.y, vb.z, vb.w}, cG[4] = {vg.x, vg.y, vg.z, vg.w}, cT[4] = {vt.x, vt.y, vt.z, vt.w};
+#pragma unroll
+      for (int nn = 0; nn < 4; ++nn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f = fmaf(acc[m][nn][j], ba[nn], fmaf(bx_[nn], cB[j], by_[nn] * cG[j])) + bz[nn];
+          if (!(f < cT[j]) && bok[nn]) {  // NaN bounds stay in the race
+            const int q = ql + j;
+            if (q < A.nq) {
+              const uint32_t sidx = atomicAdd(&A.cand_cnt[q], 1u);
+              if (sidx < A.cand_cap) A.cand_i[(int64_t)q * A.cand_cap + sidx] = A.row_origin + (uint32_t)(i0 + wc * 64 + nn * 16 + fr);
+            }
+          }
+        }
+      }
+    }
+  }
+#undef F256_MEM_SYNC
+#undef F256_END_SYNC
+}
+
 // One wave per row: out[row][0..dpad) = bf16(x[row]) (RNE, zero padded) and the row's coefficients.
 //   mode 0 (base rows, cosine): A = 1/||b||, X = ||bh||/||b|| (1+1e-4), Y = ||b-bh||/||b|| (1+1e-4)
 //   mode 1 (base rows, dot)   : A = 1,       X = ||bh|| (1+1e-4),       Y = ||b-bh|| (1+1e-4)
@@ -900,13 +1148,19 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   if (rc || S0 >= n) return rc;
 
   // query side: bf16 image + norms
-  const size_t qh_bytes = (((size_t)nq * dpad * 2) + 255) & ~(size_t)255;
-  uint8_t* qws = (uint8_t*)scratch(qh_bytes + (size_t)nq * 12 + 256, 11, s);
+  // (the bf16 image of the queries is padded with zero rows to whole 256-row tiles: the 8-phase filter kernel stages them unclamped)
+  const int nq_pad = (int)ceil_div(nq, 256) * 256;
+  const size_t qh_bytes = (((size_t)nq_pad * dpad * 2) + 255) & ~(size_t)255;
+  uint8_t* qws = (uint8_t*)scratch(qh_bytes + (size_t)nq * 12 + (size_t)nq_pad * 12 + 256, 11, s);
   if (!qws) return DBHIP_ERR_HIP;
   uint16_t* qh = (uint16_t*)qws;
   float* qA = (float*)(qws + qh_bytes);
   float* qX = qA + nq;
   float* qY = qX + nq;
+  float* qcB = qY + nq;
+  float* qcG = qcB + nq_pad;
+  float* qcT = qcG + nq_pad;
+  if (nq_pad > nq) DBHIP_CHECK(hipMemsetAsync(qh + (size_t)nq * dpad, 0, (size_t)(nq_pad - nq) * dpad * 2, s));
   hipLaunchKernelGGL(vec_to_bf16_kernel, dim3(grid_for((int64_t)nq * 64, 256)), dim3(256), 0, s, queries, (int64_t)nq, dim,
                      dpad, 2, qh, qA, qX, qY);
 
@@ -927,12 +1181,35 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.tau = out_dist + (k - 1); A.tau_stride = k;
     A.n = hi - lo; A.dpad = dpad; A.nq = nq;
     const bool tall = nq > 128;  // 256-query tiles once there are enough queries to fill them
+    // the 256 x 256 8-phase kernel (round 4) when the k-tiles pair up and the range fills the chip; DBHIP_BF16_256=0: the r01 kernel
+    static const bool f256_off = getenv("DBHIP_BF16_256") && atoi(getenv("DBHIP_BF16_256")) == 0;
+    const bool f256 = tall && !f256_off && (dpad / HBK) % 2 == 0 && dpad >= 128 && A.n >= 256;
     A.n_qtiles = (int)ceil_div(nq, tall ? 256 : 128);
-    A.n_itiles = ceil_div(A.n, 128);
+    A.n_itiles = ceil_div(A.n, f256 ? 256 : 128);
     A.c = (float)dim * 1.1920929e-07f + 2e-4f;
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
-    if (l2) {
+    if (f256) {
+      static bool raised = false;
+      if (!raised) {
+        DBHIP_CHECK(hipFuncSetAttribute((const void*)bf16_filter256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        DBHIP_CHECK(hipFuncSetAttribute((const void*)bf16_filter256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        DBHIP_CHECK(hipFuncSetAttribute((const void*)bf16_filter256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        raised = true;
+      }
+      A.qcB = qcB; A.qcG = qcG; A.qcT = qcT;
+      const dim3 cg((unsigned)ceil_div(nq_pad, 256)), fg((unsigned)blocks);
+      if (l2) {
+        hipLaunchKernelGGL((bf16_qcoef_kernel<2>), cg, dim3(256), 0, s, A, nq_pad, qcB, qcG, qcT);
+        hipLaunchKernelGGL((bf16_filter256_kernel<2>), fg, dim3(512), 131072, s, A);
+      } else if (cosine) {
+        hipLaunchKernelGGL((bf16_qcoef_kernel<0>), cg, dim3(256), 0, s, A, nq_pad, qcB, qcG, qcT);
+        hipLaunchKernelGGL((bf16_filter256_kernel<0>), fg, dim3(512), 131072, s, A);
+      } else {
+        hipLaunchKernelGGL((bf16_qcoef_kernel<1>), cg, dim3(256), 0, s, A, nq_pad, qcB, qcG, qcT);
+        hipLaunchKernelGGL((bf16_filter256_kernel<1>), fg, dim3(512), 131072, s, A);
+      }
+    } else if (l2) {
       if (tall) hipLaunchKernelGGL((bf16_filter_kernel<2, 256>), dim3((unsigned)blocks), dim3(512), 0, s, A);
       else hipLaunchKernelGGL((bf16_filter_kernel<2, 128>), dim3((unsigned)blocks), dim3(256), 0, s, A);
     } else if (tall) {

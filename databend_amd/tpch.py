@@ -192,13 +192,10 @@ def q1_operator_pushdown(li, g=None, cutoff=Q1_CUTOFF):
     return g
 
 
-def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF, prepare=False):
-    """The whole Q1 pipeline as ONE generic launch (dbhip_groupby_add_block_program): the binding flattens the filter
-    predicate and the three decimal maps into a register program (what Evaluator::run walks node by node) and the
-    fused filter -> map -> partial-aggregate kernel runs it — interpreted, or through the kernel that the library
-    specialises for this program at run time (hiprtc; `prepare=True` = dbhip_groupby_prepare_program, the PREPARE of the
-    pipeline: waits for that kernel instead of launching). No query-specific code on the device."""
-    g = g or D.GroupBy.q1()
+def q1_program(li, cutoff=Q1_CUTOFF):
+    """Q1's filter predicate and decimal maps flattened into ONE register program (what Evaluator::run walks node by node,
+    block_operator.rs:42-85) -> (program, key columns, aggregate argument registers, filter register): the arguments of
+    dbhip_groupby_add_block_program / dbhip_groupby_prepare_program. Built once per pipeline, launched per block."""
     p = D.ExprProgram([li.ship, li.qty, li.price, li.disc, li.tax])
     ship, cut = p.load(0), p.const(cutoff, L.T_DATE)
     f = p.cmp(L.EX_LTE, ship, cut)                                   # l_shipdate <= cutoff          (filter root, first)
@@ -208,10 +205,21 @@ def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF, prepare=False):
     disc_price = p.arith(L.EX_MULTIPLY, price, one_minus, keep=(price,))  # l_extendedprice * (..)     Decimal(31,4)
     one_plus = p.arith(L.EX_PLUS, one, tax)                           # 1 + l_tax                    Decimal(16,2)
     charge = p.arith(L.EX_MULTIPLY, disc_price, one_plus, keep=(disc_price,))  # (..) * (..)          Decimal(38,6)
+    return p, [li.rf, li.ls], [qty, price, disc_price, charge, disc, None], f
+
+
+def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF, prepare=False, plan=None, stream=None):
+    """The whole Q1 pipeline as ONE generic launch (dbhip_groupby_add_block_program): the binding flattens the filter
+    predicate and the three decimal maps into a register program and the fused filter -> map -> partial-aggregate kernel runs
+    it — interpreted, or through the kernel that the library specialises for this program at run time (hiprtc; `prepare=True` =
+    dbhip_groupby_prepare_program, the PREPARE of the pipeline: waits for that kernel instead of launching). No query-specific
+    code on the device. `plan` = a q1_program() result to launch again (a pipeline builds its program once)."""
+    g = g or D.GroupBy.q1()
+    p, keys, regs, f = plan or q1_program(li, cutoff)
     if prepare:
-        g.prepare_program([li.rf, li.ls], p, [qty, price, disc_price, charge, disc, None], filter_reg=f)
+        g.prepare_program(keys, p, regs, filter_reg=f)
         return g
-    g.add_block_program([li.rf, li.ls], p, [qty, price, disc_price, charge, disc, None], li.n, filter_reg=f)
+    g.add_block_program(keys, p, regs, li.n, filter_reg=f, stream=stream)
     return g
 
 

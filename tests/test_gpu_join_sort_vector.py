@@ -477,7 +477,10 @@ def test_vec_topk_matches_exact_oracle_topk(gpu, oracle, n, dim, nq, k):
 
 
 @pytest.mark.parametrize("n,dim,nq,k,kind", [(5, 16, 2, 10, "normal"), (3000, 64, 33, 10, "normal"), (150_000, 64, 70, 10, "normal"),
-                                             (131_072, 100, 5, 16, "normal"), (200_000, 48, 300, 3, "clustered"), (140_000, 36, 9, 10, "special")])
+                                             (131_072, 100, 5, 16, "normal"), (200_000, 48, 300, 3, "clustered"), (140_000, 36, 9, 10, "special"),
+                                             # the 256 x 256 8-phase filter kernel (k-tiles pair up, > 128 queries): ragged query / base tiles
+                                             (150_000, 128, 300, 10, "normal"), (70_001, 200, 513, 5, "normal"), (40_000, 768, 257, 10, "clustered"),
+                                             (140_000, 128, 200, 10, "special")])
 def test_vec_index_is_exact(gpu, oracle, n, dim, nq, k, kind):
     """dbhip_vec_index_search (bf16 pre-filter + exact re-score) returns the exact top-k: the same row ids as the
     exact f32 scan dbhip_vec_topk and distances within 1e-5 relative of the oracle's f32 distances (north_star
