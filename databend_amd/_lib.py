@@ -13,7 +13,7 @@ class DbhipError(RuntimeError):
 
 
 # status codes (include/dbhip.h)
-OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ROW_ERRORS, ERR_OVERFLOW, ERR_CAPACITY, ERR_UNSUPPORTED = range(8)
+OK, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_ROW_ERRORS, ERR_OVERFLOW, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_CANCELLED = range(9)
 
 # dbhip_type
 T_BOOL, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F32, T_F64, T_DATE, T_TIMESTAMP, T_DEC64, T_DEC128, T_STRING, T_DEC256 = range(1, 18)
@@ -74,7 +74,7 @@ def library_path():
 # every symbol include/dbhip.h declares (tests check that the built library exports all of them)
 SYMBOLS = [
     "dbhip_abi_version", "dbhip_init", "dbhip_device_count", "dbhip_last_error", "dbhip_alloc", "dbhip_free", "dbhip_trim",
-    "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy", "dbhip_stream_release_scratch",
+    "dbhip_memcpy_h2d", "dbhip_memcpy_d2h", "dbhip_memset", "dbhip_stream_create", "dbhip_stream_destroy", "dbhip_stream_release_scratch", "dbhip_stream_cancel", "dbhip_stream_cancel_clear",
     "dbhip_stream_sync", "dbhip_event_create", "dbhip_event_record", "dbhip_event_elapsed_ms",
     "dbhip_event_destroy", "dbhip_last_kernel_ms", "dbhip_arith", "dbhip_arith_result_type", "dbhip_sum_a_plus_b_mul_c_i64",
     "dbhip_sum", "dbhip_expr_eval", "dbhip_decimal_result_size", "dbhip_decimal_arith", "dbhip_decimal_neg", "dbhip_decimal_cast", "dbhip_cmp", "dbhip_bitmap_binary",
@@ -95,7 +95,7 @@ SYMBOLS = [
     "dbhip_comm_allreduce_sum_u64", "dbhip_groupby_exchange_allgather", "dbhip_groupby_exchange_alltoall", "dbhip_kmeans", "dbhip_vec_kernel_f32", "dbhip_hnsw_build", "dbhip_hnsw_build_sequential", "dbhip_hnsw_from_graph", "dbhip_hnsw_open", "dbhip_hnsw_export_graph", "dbhip_hnsw_search", "dbhip_hnsw_scores",
     "dbhip_hnsw_encoded", "dbhip_hnsw_meta", "dbhip_hnsw_destroy",
     "dbhip_pq_chunk_open", "dbhip_pq_chunk_validity", "dbhip_pq_chunk_image", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
-    "dbhip_scatter_columns", "dbhip_concat_columns",
+    "dbhip_scatter_columns", "dbhip_concat_columns", "dbhip_comm_create_loopback", "dbhip_exchange_begin", "dbhip_exchange_finish", "dbhip_exchange_destroy", "dbhip_vec_topk_allgather",
     # diagnostics and test hooks (declared in the header's last section)
     "dbhip_groupby_debug_set_hash_mask", "dbhip_groupby_debug_set_partition_bits", "dbhip_groupby_debug_set_compact", "dbhip_join_binary_debug_set_hash_mask",
     "dbhip_fagg_stats", "dbhip_scratch_stats", "dbhip_jit_compile_check", "dbhip_jit_offline",

@@ -16,7 +16,11 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <map>
+#include <mutex>
 #include <new>
+#include <vector>
 
 using namespace dbhip;
 
@@ -75,8 +79,27 @@ int32_t nccl_fail(int r, const char* what) {
 
 }  // namespace
 
+// An in-process world (dbhip_comm_create_loopback): `world` communicators of ONE process — one per host thread, all on the same GPU —
+// whose collectives are device-to-device copies made by the last rank to arrive at a rendezvous. It exists so that the multi-rank
+// protocols of this file (block exchange, shard top-k merge, partial-state exchange) run with world > 1 on the one-GPU boxes the
+// tests get; it is not a transport anybody should ship data over.
+struct LoopOp {
+  int kind = 0;                       // 1 all-gather (bytes per rank), 2 grouped pieces
+  const uint8_t* send = nullptr; uint8_t* recv = nullptr; size_t bytes = 0;
+  const void* pieces = nullptr;       // std::vector<XPiece>*
+};
+struct LoopGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, arrived = 0, refs = 0;
+  uint64_t generation = 0;
+  int32_t status = 0;
+  std::vector<LoopOp> ops;
+};
+
 struct dbhip_comm {
   ncclComm_t comm = nullptr;
+  LoopGroup* loop = nullptr;
   int rank = 0, world = 1;
   void* send = nullptr;      // exchange staging (blocks), grown on demand
   void* recv = nullptr;
@@ -98,7 +121,10 @@ int32_t ensure_staging(dbhip_comm* c, size_t bytes) {
 }
 
 // equal-split all-to-all of `bytes_per_peer` bytes per rank pair: one group of send / recv pairs (every xGMI link busy at once)
+struct XPiece;
+int32_t alltoall_bytes_loop(dbhip_comm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t s);
 int32_t alltoall_bytes(dbhip_comm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t s) {
+  if (c->loop) return alltoall_bytes_loop(c, send, recv, bytes_per_peer, s);
   if (!c->comm) {   // a local world of one: the exchange is a copy
     if (send != recv) DBHIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, s));
     return DBHIP_OK;
@@ -120,9 +146,289 @@ int32_t alltoall_bytes(dbhip_comm* c, const void* send, void* recv, size_t bytes
   return DBHIP_OK;
 }
 
+// variable-size pieces between all ranks in ONE group: piece p of every entry goes to / comes from rank p (a local world of one: copies)
+struct XPiece { const uint8_t* send; uint8_t* recv; const size_t* send_off; const size_t* send_bytes; const size_t* recv_off; const size_t* recv_bytes; };
+
+// loopback rendezvous: every rank drains its stream and posts its operation; the last one to arrive makes all the copies
+int32_t loop_collective(dbhip_comm* c, const LoopOp& mine, hipStream_t s) {
+  LoopGroup* g = c->loop;
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->ops[c->rank] = mine;
+  const uint64_t gen = g->generation;
+  if (++g->arrived == g->world) {
+    int32_t st = DBHIP_OK;
+    for (int a = 0; a < g->world && st == DBHIP_OK; ++a) {          // a: source rank
+      for (int b = 0; b < g->world && st == DBHIP_OK; ++b) {        // b: destination rank
+        const LoopOp &A = g->ops[a], &B = g->ops[b];
+        if (A.kind != B.kind) { set_error("dbhip_comm loopback: ranks %d and %d are in different collectives", a, b); st = DBHIP_ERR_INVALID; break; }
+        if (A.kind == 1) {
+          if (A.bytes != B.bytes) { set_error("dbhip_comm loopback: all-gather sizes differ"); st = DBHIP_ERR_INVALID; break; }
+          if (A.bytes && hipMemcpyAsync(B.recv + (size_t)a * A.bytes, A.send, A.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) st = DBHIP_ERR_HIP;
+        } else {
+          const std::vector<XPiece>& xa = *(const std::vector<XPiece>*)A.pieces;
+          const std::vector<XPiece>& xb = *(const std::vector<XPiece>*)B.pieces;
+          if (xa.size() != xb.size()) { set_error("dbhip_comm loopback: ranks post different numbers of pieces"); st = DBHIP_ERR_INVALID; break; }
+          for (size_t e = 0; e < xa.size() && st == DBHIP_OK; ++e) {
+            if (xa[e].send_bytes[b] != xb[e].recv_bytes[a]) {
+              set_error("dbhip_comm loopback: rank %d sends %zu bytes to rank %d, which expects %zu", a, xa[e].send_bytes[b], b, xb[e].recv_bytes[a]);
+              st = DBHIP_ERR_INVALID;
+              break;
+            }
+            if (xa[e].send_bytes[b] &&
+                hipMemcpyAsync(xb[e].recv + xb[e].recv_off[a], xa[e].send + xa[e].send_off[b], xa[e].send_bytes[b], hipMemcpyDeviceToDevice, s) != hipSuccess)
+              st = DBHIP_ERR_HIP;
+          }
+        }
+      }
+    }
+    if (st == DBHIP_OK && hipStreamSynchronize(s) != hipSuccess) st = DBHIP_ERR_HIP;
+    g->status = st;
+    g->arrived = 0;
+    ++g->generation;
+    g->cv.notify_all();
+    return st;
+  }
+  g->cv.wait(lk, [&] { return g->generation != gen; });
+  return g->status;
+}
+
+int32_t alltoallv_group(dbhip_comm* c, const std::vector<XPiece>& xs, hipStream_t s) {
+  if (c->loop) { LoopOp op; op.kind = 2; op.pieces = &xs; return loop_collective(c, op, s); }
+  if (!c->comm) {
+    for (const XPiece& x : xs)
+      if (x.send_bytes[0]) DBHIP_CHECK(hipMemcpyAsync(x.recv + x.recv_off[0], x.send + x.send_off[0], x.send_bytes[0], hipMemcpyDeviceToDevice, s));
+    return DBHIP_OK;
+  }
+  NCCL_CHECK(g_rccl.GroupStart());
+  int first = NCCL_SUCCESS;
+  const char* what = "";
+  for (const XPiece& x : xs) {
+    for (int p = 0; p < c->world && first == NCCL_SUCCESS; ++p) {
+      int r = NCCL_SUCCESS;
+      if (x.send_bytes[p]) r = g_rccl.Send(x.send + x.send_off[p], x.send_bytes[p], NCCL_UINT8, p, c->comm, s);
+      if (r != NCCL_SUCCESS) { first = r; what = "ncclSend"; break; }
+      if (x.recv_bytes[p]) r = g_rccl.Recv(x.recv + x.recv_off[p], x.recv_bytes[p], NCCL_UINT8, p, c->comm, s);
+      if (r != NCCL_SUCCESS) { first = r; what = "ncclRecv"; }
+    }
+  }
+  const int e = g_rccl.GroupEnd();
+  if (first != NCCL_SUCCESS) return nccl_fail(first, what);
+  if (e != NCCL_SUCCESS) return nccl_fail(e, "ncclGroupEnd");
+  return DBHIP_OK;
+}
+
+int32_t alltoall_bytes_loop(dbhip_comm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t s) {
+  std::vector<size_t> off(c->world), len(c->world, bytes_per_peer);
+  for (int p = 0; p < c->world; ++p) off[p] = (size_t)p * bytes_per_peer;
+  std::vector<XPiece> xs{XPiece{(const uint8_t*)send, (uint8_t*)recv, off.data(), len.data(), off.data(), len.data()}};
+  return alltoallv_group(c, xs, s);
+}
+
+__global__ __launch_bounds__(256) void topk_globalise_kernel(const uint32_t* __restrict__ idx, int64_t n, uint64_t row_offset, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t v = idx[i];
+    out[i] = v == 0xFFFFFFFFu ? v : (uint32_t)((uint64_t)v + row_offset);
+  }
+}
+// [world][nq][k] (rank-major, what the all-gather produces) -> [nq][world * k] (what dbhip_vec_topk_merge takes)
+template <typename T>
+__global__ __launch_bounds__(256) void topk_regroup_kernel(const T* __restrict__ in, int world, int nq, int k, T* __restrict__ out) {
+  const int64_t total = (int64_t)world * nq * k;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % k);
+    const int64_t t = i / k;
+    const int q = (int)(t % nq), r = (int)(t / nq);
+    out[((int64_t)q * world + r) * k + j] = in[i];
+  }
+}
+
 }  // namespace
 
+// One exchange of a block between all ranks (see dbhip.h): the scattered columns and the counts between begin and finish
+struct dbhip_exchange {
+  dbhip_comm* c = nullptr;
+  int64_t n = 0, recv_total = 0;
+  std::vector<dbhip_col> cols;
+  std::vector<void*> sdata;
+  std::vector<uint8_t*> svalid;
+  std::vector<int64_t> send_start, recv_start;   // [world + 1] rows
+  void* counts_dev = nullptr;
+};
+
 extern "C" {
+
+int32_t dbhip_exchange_destroy(dbhip_exchange* x) {
+  if (!x) return DBHIP_OK;
+  for (void* p : x->sdata) if (p) (void)dbhip_free(p);
+  for (uint8_t* p : x->svalid) if (p) (void)dbhip_free(p);
+  if (x->counts_dev) (void)dbhip_free(x->counts_dev);
+  delete x;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
+                             dbhip_exchange** out_host, void* stream) {
+  DBHIP_REQUIRE(c && out_recv_rows_host && out_host && ncols >= 0 && n >= 0 && (ncols == 0 || cols), "dbhip_exchange_begin: bad argument");
+  for (int k = 0; k < ncols; ++k) {
+    if (cols[k].type == DBHIP_T_STRING && cols[k].n_buffers > 0) {
+      set_error("dbhip_exchange_begin: column %d holds strings with data buffers (only inline views travel as 16-byte values); exchange the "
+                "serialized form (dbhip_serialize_keys) or keep the CPU exchange for this block", k);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+  }
+  dbhip_exchange* x = new (std::nothrow) dbhip_exchange();
+  if (!x) return DBHIP_ERR_HIP;
+  x->c = c; x->n = n;
+  x->cols.assign(cols, cols + ncols);
+  x->sdata.assign(ncols, nullptr);
+  x->svalid.assign(ncols, nullptr);
+  const int W = c->world;
+  x->send_start.assign(W + 1, 0);
+  x->recv_start.assign(W + 1, 0);
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc = DBHIP_OK;
+  const size_t bm_bytes = (size_t)8 * ((size_t)(n >> 6) + W + 1);
+  for (int k = 0; k < ncols && rc == DBHIP_OK; ++k) {
+    const int t = cols[k].type;
+    const size_t bytes = t == DBHIP_T_BOOL ? bm_bytes : (size_t)(n > 0 ? n : 1) * type_size(t) + 64;
+    rc = dbhip_alloc(bytes, &x->sdata[k]);
+    if (rc == DBHIP_OK && cols[k].validity) rc = dbhip_alloc(bm_bytes, (void**)&x->svalid[k]);
+  }
+  if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)W * 16, &x->counts_dev);
+  if (rc == DBHIP_OK)
+    rc = dbhip_scatter_columns(cols, ncols, dest_index, n, (uint32_t)W, x->sdata.data(), x->svalid.data(), x->send_start.data(), stream);
+  if (rc == DBHIP_OK) {
+    // the rows every rank sends to every other: one 8-byte all-to-all, read back once (the receiver sizes its buffers from it)
+    std::vector<uint64_t> sc(W), rcv(W);
+    for (int p = 0; p < W; ++p) sc[p] = (uint64_t)(x->send_start[p + 1] - x->send_start[p]);
+    uint64_t* d = (uint64_t*)x->counts_dev;
+    rc = dbhip_memcpy_h2d(d, sc.data(), (size_t)W * 8, stream);
+    if (rc == DBHIP_OK) rc = alltoall_bytes(c, d, d + W, 8, s);
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(rcv.data(), d + W, (size_t)W * 8, stream);
+    for (int p = 0; p < W; ++p) x->recv_start[p + 1] = x->recv_start[p] + (int64_t)rcv[p];
+    x->recv_total = x->recv_start[W];
+  }
+  if (rc != DBHIP_OK) { (void)dbhip_exchange_destroy(x); return rc; }
+  *out_recv_rows_host = x->recv_total;
+  *out_host = x;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_src_starts_host,
+                              void* stream) {
+  DBHIP_REQUIRE(x && (x->cols.empty() || (out_data_host && out_validity_host)), "dbhip_exchange_finish: bad argument");
+  dbhip_comm* c = x->c;
+  const int W = c->world, ncols = (int)x->cols.size();
+  hipStream_t s = resolve_stream(stream);
+  if (out_src_starts_host) for (int p = 0; p <= W; ++p) out_src_starts_host[p] = x->recv_start[p];
+  // byte offsets / sizes of every piece. Value buffers: rows x element size. Bitmaps (Boolean values, validities): every destination's
+  // piece is a stand-alone Bitmap on a 64-bit word of its own (dbhip_scatter_columns); the received pieces land word-aligned in a
+  // temporary and are concatenated bit by bit (dbhip_concat_columns)
+  std::vector<size_t> so_b(W), sb_b(W), ro_b(W), rb_b(W);
+  size_t rwords = 0;
+  for (int p = 0; p < W; ++p) {
+    so_b[p] = (size_t)8 * ((size_t)(x->send_start[p] >> 6) + p);
+    sb_b[p] = (size_t)8 * (size_t)((x->send_start[p + 1] - x->send_start[p] + 63) >> 6);
+    ro_b[p] = rwords * 8;
+    rb_b[p] = (size_t)8 * (size_t)((x->recv_start[p + 1] - x->recv_start[p] + 63) >> 6);
+    rwords += rb_b[p] / 8;
+  }
+  std::vector<std::vector<size_t>> offs;   // keeps the per-column offset arrays alive until the group has been issued
+  offs.reserve((size_t)ncols * 4);
+  std::vector<XPiece> xs;
+  std::vector<uint8_t*> tmp_bits;           // per bitmap piece set: the word-aligned receive image
+  struct BitJob { uint8_t* tmp; uint8_t* out; };
+  std::vector<BitJob> jobs;
+  int32_t rc = DBHIP_OK;
+  auto add_bits = [&](const uint8_t* send, uint8_t* out) -> int32_t {
+    DBHIP_REQUIRE(out && ((uintptr_t)out & 7) == 0, "dbhip_exchange_finish: Bitmap outputs must be non-NULL and 8-byte aligned");
+    void* t = nullptr;
+    int32_t r = dbhip_alloc(rwords * 8 + 64, &t);
+    if (r) return r;
+    tmp_bits.push_back((uint8_t*)t);
+    xs.push_back(XPiece{send, (uint8_t*)t, so_b.data(), sb_b.data(), ro_b.data(), rb_b.data()});
+    jobs.push_back(BitJob{(uint8_t*)t, out});
+    return DBHIP_OK;
+  };
+  for (int k = 0; k < ncols && rc == DBHIP_OK; ++k) {
+    const int t = x->cols[k].type;
+    if (t == DBHIP_T_BOOL) rc = add_bits((const uint8_t*)x->sdata[k], (uint8_t*)out_data_host[k]);
+    else {
+      if (x->recv_total > 0 && !out_data_host[k]) { set_error("dbhip_exchange_finish: NULL output for column %d", k); rc = DBHIP_ERR_INVALID; break; }
+      const size_t es = (size_t)type_size(t);
+      offs.emplace_back(W); offs.emplace_back(W); offs.emplace_back(W); offs.emplace_back(W);
+      std::vector<size_t>&so = offs[offs.size() - 4], &sb = offs[offs.size() - 3], &ro = offs[offs.size() - 2], &rb = offs[offs.size() - 1];
+      for (int p = 0; p < W; ++p) {
+        so[p] = (size_t)x->send_start[p] * es; sb[p] = (size_t)(x->send_start[p + 1] - x->send_start[p]) * es;
+        ro[p] = (size_t)x->recv_start[p] * es; rb[p] = (size_t)(x->recv_start[p + 1] - x->recv_start[p]) * es;
+      }
+      xs.push_back(XPiece{(const uint8_t*)x->sdata[k], (uint8_t*)out_data_host[k], so.data(), sb.data(), ro.data(), rb.data()});
+    }
+    if (rc == DBHIP_OK && x->svalid[k]) rc = add_bits(x->svalid[k], out_validity_host[k]);
+  }
+  if (rc == DBHIP_OK) rc = alltoallv_group(c, xs, s);   // ONE group: every column, every peer
+  for (size_t j = 0; j < jobs.size() && rc == DBHIP_OK; ++j) {
+    std::vector<dbhip_col> pc(W);
+    std::vector<int64_t> rows(W);
+    for (int p = 0; p < W; ++p) {
+      memset(&pc[p], 0, sizeof(dbhip_col));
+      pc[p].type = DBHIP_T_BOOL;
+      pc[p].data = jobs[j].tmp + ro_b[p];
+      rows[p] = x->recv_start[p + 1] - x->recv_start[p];
+    }
+    if (x->recv_total > 0) rc = dbhip_concat_columns(pc.data(), rows.data(), nullptr, W, jobs[j].out, nullptr, nullptr, nullptr, stream);
+  }
+  if (rc == DBHIP_OK && hipStreamSynchronize(s) != hipSuccess) rc = DBHIP_ERR_HIP;   // the temporaries go away below
+  for (uint8_t* t : tmp_bits) (void)dbhip_free(t);
+  return rc;
+}
+
+int32_t dbhip_vec_topk_allgather(dbhip_comm* c, const uint32_t* idx_dev, const float* dist_dev, int32_t nq, int32_t k, uint64_t row_offset,
+                                 uint32_t* out_idx_dev, float* out_dist_dev, void* stream) {
+  DBHIP_REQUIRE(c && nq >= 0 && k >= 1, "dbhip_vec_topk_allgather: bad argument");
+  if (nq == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(idx_dev && dist_dev && out_idx_dev && out_dist_dev, "dbhip_vec_topk_allgather: NULL argument");
+  DBHIP_REQUIRE(row_offset < 0xFFFFFFFFULL, "dbhip_vec_topk_allgather: the shard's row offset does not fit the u32 id space");
+  const int W = c->world;
+  const int64_t per = (int64_t)nq * k;
+  hipStream_t s = resolve_stream(stream);
+  // staging: [mine: ids | dists] [gathered ids: W x per] [gathered dists] [regrouped ids] [regrouped dists]
+  uint8_t* ws = (uint8_t*)scratch((size_t)per * 8 + (size_t)W * per * 16 + 256, 18, s);
+  if (!ws) return DBHIP_ERR_HIP;
+  uint32_t* my_i = (uint32_t*)ws;
+  uint32_t* all_i = my_i + per;
+  float* all_d = (float*)(all_i + (size_t)W * per);
+  uint32_t* grp_i = (uint32_t*)(all_d + (size_t)W * per);
+  float* grp_d = (float*)(grp_i + (size_t)W * per);
+  hipLaunchKernelGGL(topk_globalise_kernel, dim3(grid_for(per, 256)), dim3(256), 0, s, idx_dev, per, row_offset, my_i);
+  DBHIP_LAUNCH_CHECK();
+  if (c->loop) {
+    LoopOp a; a.kind = 1; a.send = (const uint8_t*)my_i; a.recv = (uint8_t*)all_i; a.bytes = (size_t)per * 4;
+    int32_t rc = loop_collective(c, a, s);
+    if (rc) return rc;
+    LoopOp b; b.kind = 1; b.send = (const uint8_t*)dist_dev; b.recv = (uint8_t*)all_d; b.bytes = (size_t)per * 4;
+    if ((rc = loop_collective(c, b, s))) return rc;
+  } else if (!c->comm) {
+    DBHIP_CHECK(hipMemcpyAsync(all_i, my_i, (size_t)per * 4, hipMemcpyDeviceToDevice, s));
+    DBHIP_CHECK(hipMemcpyAsync(all_d, dist_dev, (size_t)per * 4, hipMemcpyDeviceToDevice, s));
+  } else {   // both all-gathers in one group: one launch on the wire
+    NCCL_CHECK(g_rccl.GroupStart());
+    const int r1 = g_rccl.AllGather(my_i, all_i, (size_t)per * 4, NCCL_UINT8, c->comm, s);
+    const int r2 = r1 == NCCL_SUCCESS ? g_rccl.AllGather(dist_dev, all_d, (size_t)per * 4, NCCL_UINT8, c->comm, s) : NCCL_SUCCESS;
+    const int e = g_rccl.GroupEnd();
+    if (r1 != NCCL_SUCCESS) return nccl_fail(r1, "ncclAllGather");
+    if (r2 != NCCL_SUCCESS) return nccl_fail(r2, "ncclAllGather");
+    if (e != NCCL_SUCCESS) return nccl_fail(e, "ncclGroupEnd");
+  }
+  hipLaunchKernelGGL(topk_regroup_kernel<uint32_t>, dim3(grid_for((int64_t)W * per, 256)), dim3(256), 0, s, all_i, W, nq, k, grp_i);
+  hipLaunchKernelGGL(topk_regroup_kernel<float>, dim3(grid_for((int64_t)W * per, 256)), dim3(256), 0, s, all_d, W, nq, k, grp_d);
+  DBHIP_LAUNCH_CHECK();
+  int32_t rc = dbhip_vec_topk_merge(grp_d, grp_i, (int64_t)W * k, nq, k, out_idx_dev, out_dist_dev, stream);
+  if (rc) return rc;
+  DBHIP_CHECK(hipStreamSynchronize(s));   // scratch is reused by the next call
+  return DBHIP_OK;
+}
 
 int32_t dbhip_comm_unique_id(uint8_t* out_id128_host) {
   DBHIP_REQUIRE(out_id128_host, "dbhip_comm_unique_id: NULL argument");
@@ -151,8 +457,31 @@ int32_t dbhip_comm_create(int32_t rank, int32_t world, const uint8_t* id128_host
   return DBHIP_OK;
 }
 
+static std::mutex g_loop_mu;
+static std::map<uint64_t, LoopGroup*> g_loops;
+int32_t dbhip_comm_create_loopback(uint64_t group_id, int32_t rank, int32_t world, dbhip_comm** out_host) {
+  DBHIP_REQUIRE(out_host && world >= 1 && world <= 64 && rank >= 0 && rank < world, "dbhip_comm_create_loopback: bad argument");
+  dbhip_comm* c = new (std::nothrow) dbhip_comm();
+  if (!c) return DBHIP_ERR_HIP;
+  std::lock_guard<std::mutex> lk(g_loop_mu);
+  LoopGroup*& g = g_loops[group_id];
+  if (!g) { g = new (std::nothrow) LoopGroup(); if (!g) { delete c; return DBHIP_ERR_HIP; } g->world = world; g->ops.resize(world); }
+  if (g->world != world) { delete c; set_error("dbhip_comm_create_loopback: group %llu exists with another world size", (unsigned long long)group_id); return DBHIP_ERR_INVALID; }
+  ++g->refs;
+  c->loop = g; c->rank = rank; c->world = world;
+  *out_host = c;
+  return DBHIP_OK;
+}
+
 int32_t dbhip_comm_destroy(dbhip_comm* c) {
   if (!c) return DBHIP_OK;
+  if (c->loop) {
+    std::lock_guard<std::mutex> lk(g_loop_mu);
+    if (--c->loop->refs == 0) {
+      for (auto it = g_loops.begin(); it != g_loops.end(); ++it) if (it->second == c->loop) { g_loops.erase(it); break; }
+      delete c->loop;
+    }
+  }
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   if (c->send) (void)dbhip_free(c->send);
   if (c->recv) (void)dbhip_free(c->recv);
@@ -164,6 +493,7 @@ int32_t dbhip_comm_allgather(dbhip_comm* c, const void* send_dev, void* recv_dev
   DBHIP_REQUIRE(c && send_dev && recv_dev && bytes_per_rank >= 0, "dbhip_comm_allgather: bad argument");
   hipStream_t s = resolve_stream(stream);
   if (bytes_per_rank == 0) return DBHIP_OK;
+  if (c->loop) { LoopOp a; a.kind = 1; a.send = (const uint8_t*)send_dev; a.recv = (uint8_t*)recv_dev; a.bytes = (size_t)bytes_per_rank; return loop_collective(c, a, s); }
   if (!c->comm) {
     DBHIP_CHECK(hipMemcpyAsync((uint8_t*)recv_dev + (size_t)c->rank * bytes_per_rank, send_dev, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, s));
     return DBHIP_OK;
@@ -182,6 +512,7 @@ int32_t dbhip_comm_allreduce_sum_u64(dbhip_comm* c, const uint64_t* send_dev, ui
   DBHIP_REQUIRE(c && send_dev && recv_dev && count >= 0, "dbhip_comm_allreduce_sum_u64: bad argument");
   hipStream_t s = resolve_stream(stream);
   if (count == 0) return DBHIP_OK;
+  if (c->loop) { set_error("dbhip_comm_allreduce_sum_u64: not part of the in-process loopback world"); return DBHIP_ERR_UNSUPPORTED; }
   if (!c->comm) {
     if (send_dev != recv_dev) DBHIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, (size_t)count * 8, hipMemcpyDeviceToDevice, s));
     return DBHIP_OK;

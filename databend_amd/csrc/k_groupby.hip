@@ -1551,6 +1551,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
   const int max_grid = 256 * blocks_per_cu;  // every workgroup resident at once: no tail round
   int32_t rc;
   while (*done < n) {
+    DBHIP_POLL_CANCEL(s, "dbhip_groupby_add_block");
     if (g->part_bits > 0) {
       if (n - *done < g->part_min_rows) return -1;  // small remainder: row path
       if ((rc = partitioned_step(g, C, n, s, done))) return rc;
@@ -2980,6 +2981,7 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
   const int64_t CHUNK = 32 << 20;
   const bool probe_here = !fast_layout_ok(g->L);  // wide layouts learn their cardinality on the row path
   while (done < n) {
+    DBHIP_POLL_CANCEL(s, "dbhip_groupby_add_block");
     if (g->part_bits > 0 && n - done >= g->part_min_rows) {
       if ((rc = partitioned_step(g, C, n, s, &done))) return rc;
       continue;

@@ -786,6 +786,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   auto radix_passes = [&](int nbytes, uint64_t vary, bool narrow) -> int32_t {
     for (int b = 0; b < nbytes; ++b) {
       if (((vary >> (8 * b)) & 0xFF) == 0) continue;  // every image has the same byte here
+      DBHIP_POLL_CANCEL(s, "dbhip_sort_perm");
       if (narrow)
         hipLaunchKernelGGL(sort_hist_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, (const uint32_t*)kb[cur], m, 8 * b, hist, ntiles);
       else

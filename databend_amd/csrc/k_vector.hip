@@ -1173,6 +1173,7 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   hcnt.resize(nq);
 
   auto filter_range = [&](int64_t lo, int64_t hi) -> int32_t {
+    DBHIP_POLL_CANCEL(s, "dbhip_vec_index_search");
     DBHIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nq * 4, s));
     HArgs A{};
     A.base = ix->bh + lo * dpad; A.queries = qh;
@@ -1294,6 +1295,7 @@ int32_t dbhip_vec_index_search(dbhip_vec_index* ix, const float* queries, int32_
   const int QB = 2048;
   kernel_timer_start(s);
   for (int qb = 0; qb < nq; qb += QB) {
+    DBHIP_POLL_CANCEL(s, "dbhip_vec_index_search");
     const int bn = nq - qb < QB ? nq - qb : QB;
     int32_t rc = index_search_batch(ix, queries + (int64_t)qb * ix->dim, bn, k, qnorm ? qnorm + qb : nullptr,
                                     out_idx + (int64_t)qb * k, out_dist + (int64_t)qb * k, s);

@@ -19,6 +19,9 @@ void* scratch(size_t bytes, int slot, hipStream_t stream);
 // Frees every thread's scratch of `stream` (the caller has drained it): dbhip_stream_destroy / dbhip_stream_release_scratch.
 void release_stream_scratch(hipStream_t stream);
 
+// dbhip_stream_cancel: true once the stream has been marked (one relaxed atomic load when nothing is cancelled anywhere)
+bool cancel_requested(hipStream_t stream);
+
 // Pinned host words for small device -> host read-backs that are queued asynchronously (64 u64 per slot, 8 slots per
 // thread). Two async copies into PAGEABLE memory in flight at once — a kernel's control block, then the queued merge's —
 // made the runtime lock / unlock the same stack page twice and the second copy faulted ("write access to a read-only
@@ -77,3 +80,12 @@ inline int type_size(int32_t t) {
   } while (0)
 
 #define DBHIP_LAUNCH_CHECK() DBHIP_CHECK(hipGetLastError())
+
+// between two launches of a multi-launch operator
+#define DBHIP_POLL_CANCEL(stream, what)                                              \
+  do {                                                                               \
+    if (dbhip::cancel_requested(stream)) {                                           \
+      dbhip::set_error("%s: cancelled (dbhip_stream_cancel)", what);                 \
+      return DBHIP_ERR_CANCELLED;                                                    \
+    }                                                                                \
+  } while (0)

@@ -146,6 +146,23 @@ void* scratch(size_t bytes, int slot, hipStream_t stream) {
 
 void release_stream_scratch(hipStream_t stream) { release_scratch_entries(0, stream, false); }
 
+// ---- cancellation marks (dbhip_stream_cancel) ----
+static std::atomic<int> g_cancel_any{0};
+static std::mutex g_cancel_mu;
+static std::unordered_map<hipStream_t, int>* g_cancelled = nullptr;
+bool cancel_requested(hipStream_t stream) {
+  if (g_cancel_any.load(std::memory_order_relaxed) == 0) return false;
+  std::lock_guard<std::mutex> lk(g_cancel_mu);
+  return g_cancelled && g_cancelled->count(stream) != 0;
+}
+static void set_cancel(hipStream_t stream, bool on) {
+  std::lock_guard<std::mutex> lk(g_cancel_mu);
+  if (!g_cancelled) g_cancelled = new (std::nothrow) std::unordered_map<hipStream_t, int>();
+  if (!g_cancelled) return;
+  if (on) (*g_cancelled)[stream] = 1; else g_cancelled->erase(stream);
+  g_cancel_any.store((int)g_cancelled->size(), std::memory_order_relaxed);
+}
+
 static thread_local uint64_t* g_pinned = nullptr;
 uint64_t* pinned_words(int slot) {
   if (!g_pinned) {
@@ -363,9 +380,13 @@ int32_t dbhip_stream_destroy(void* stream) {
   if (!stream) return DBHIP_OK;
   DBHIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   release_stream_scratch((hipStream_t)stream);   // every thread's scratch of this stream goes with it
+  set_cancel((hipStream_t)stream, false);          // (a recycled handle value must not inherit a mark)
   DBHIP_CHECK(hipStreamDestroy((hipStream_t)stream));
   return DBHIP_OK;
 }
+
+int32_t dbhip_stream_cancel(void* stream) { set_cancel(resolve_stream(stream), true); return DBHIP_OK; }
+int32_t dbhip_stream_cancel_clear(void* stream) { set_cancel(resolve_stream(stream), false); return DBHIP_OK; }
 
 int32_t dbhip_stream_sync(void* stream) {
   DBHIP_CHECK(hipStreamSynchronize(resolve_stream(stream)));

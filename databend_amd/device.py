@@ -1571,6 +1571,16 @@ class Comm:
     def local(cls):
         return cls(0, 1, None)
 
+    @classmethod
+    def loopback(cls, group_id, rank, world):
+        """one rank of an IN-PROCESS world (dbhip_comm_create_loopback): `world` host threads of this process, one Comm each"""
+        _ensure()
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        self.rank, self.world = rank, world
+        check(lib().dbhip_comm_create_loopback(C.c_uint64(group_id), rank, world, C.byref(self.h)))
+        return self
+
     @staticmethod
     def unique_id():
         _ensure()
@@ -1583,6 +1593,34 @@ class Comm:
 
     def exchange_alltoall(self, table, max_rows=256, stream=None):
         check(lib().dbhip_groupby_exchange_alltoall(table.h, self.h, C.c_int64(max_rows), stream))
+
+    def exchange_block(self, cols, dest_index, stream=None):
+        """The ABI-owned exchange of a block (dbhip_exchange_begin / _finish: DataBlock::scatter by destination, ONE grouped all-to-all
+        of every column) -> (received Columns, source starts [world + 1]). `dest_index`: DeviceBuffer of u32 destinations < world."""
+        n = cols[0].n
+        x = C.c_void_p()
+        rows = C.c_int64()
+        check(lib().dbhip_exchange_begin(self.h, _cols(cols), len(cols), C.c_void_p(dest_index.ptr if dest_index is not None else None), C.c_int64(n),
+                                         C.byref(rows), C.byref(x), stream))
+        try:
+            m = rows.value
+            outs = [DeviceBuffer(((m + 63) // 64) * 8 + 8) if c.dtype == L.T_BOOL else DeviceBuffer(max(m, 1) * ELEM_SIZE[c.dtype] + 64) for c in cols]
+            vouts = [DeviceBuffer(((m + 63) // 64) * 8 + 8) if c.validity is not None else None for c in cols]
+            dp = (C.c_void_p * len(cols))(*[b.ptr for b in outs])
+            vp = (C.c_void_p * len(cols))(*[b.ptr if b is not None else None for b in vouts])
+            starts = (C.c_int64 * (self.world + 1))()
+            check(lib().dbhip_exchange_finish(x, dp, vp, starts, stream))
+        finally:
+            lib().dbhip_exchange_destroy(x)
+        return [Column(c.dtype, m, o, v, c.precision, c.scale) for c, o, v in zip(cols, outs, vouts)], list(starts)
+
+    def topk_allgather(self, idx, dist, nq, k, row_offset, stream=None):
+        """dbhip_vec_topk_allgather: per-shard top-k (DeviceBuffers: u32 local ids, f32 distances, [nq][k]) -> global top-k on every rank
+        -> (numpy u32 [nq, k], numpy f32 [nq, k])"""
+        oi, od = DeviceBuffer(max(nq * k, 1) * 4), DeviceBuffer(max(nq * k, 1) * 4)
+        check(lib().dbhip_vec_topk_allgather(self.h, C.c_void_p(idx.ptr), C.c_void_p(dist.ptr), nq, k, C.c_uint64(row_offset), C.c_void_p(oi.ptr),
+                                             C.c_void_p(od.ptr), stream))
+        return oi.to_numpy(np.uint32, nq * k).reshape(nq, k), od.to_numpy(np.float32, nq * k).reshape(nq, k)
 
     def allgather(self, send_ptr, recv_ptr, bytes_per_rank, stream=None):
         check(lib().dbhip_comm_allgather(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), C.c_int64(bytes_per_rank), stream))

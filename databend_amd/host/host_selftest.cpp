@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <random>
 #include <set>
+#include <thread>
 #include <tuple>
 
 #include "dbhip_host.hpp"
@@ -503,6 +504,85 @@ static void test_flight_scatters() {
   CHECK(seen == n);
 }
 
+// The ABI-owned exchange between TWO ranks without Python or torch: two host threads, one loopback communicator each (an in-process
+// world, dbhip_comm_create_loopback), every rank shuffles its shard by siphash64(key) % 2 and both exchange in one grouped all-to-all
+// (dbhip_exchange_begin / _finish); then the shard top-k merge (dbhip_vec_topk_allgather). Checked against host loops.
+static void test_two_rank_exchange() {
+  const int world = 2;
+  const int64_t n[2] = {30000, 17001};
+  std::vector<int64_t> key[2], pay[2];
+  std::vector<uint32_t> dest[2];
+  std::vector<int64_t> got_key[2], got_pay[2];
+  std::vector<int64_t> starts[2];
+  std::mt19937_64 rng(77);
+  for (int r = 0; r < world; ++r) {
+    key[r].resize(n[r]); pay[r].resize(n[r]);
+    for (int64_t i = 0; i < n[r]; ++i) { key[r][i] = (int64_t)(rng() % 4096); pay[r][i] = (int64_t)r * 1000000 + i; }
+  }
+  const int nq = 5, k = 4;
+  std::vector<uint32_t> tid[2], gid[2];
+  std::vector<float> tdist[2], gdist[2];
+  for (int r = 0; r < world; ++r) {
+    tid[r].resize(nq * k); tdist[r].resize(nq * k); gid[r].resize(nq * k); gdist[r].resize(nq * k);
+    for (int q = 0; q < nq; ++q)
+      for (int j = 0; j < k; ++j) { tid[r][q * k + j] = (uint32_t)(q * 100 + j * 7 + r); tdist[r][q * k + j] = 0.1f * j + 0.03f * r + 0.001f * q; }
+  }
+  std::string err[2];
+  auto rank_fn = [&](int r) {
+    try {
+      dbhip_comm* c = nullptr;
+      check(dbhip_comm_create_loopback(4242, r, world, &c));
+      auto I64 = DataType::of(DBHIP_T_I64);
+      Column kc = Column::from_vector(I64, key[r]), pc = Column::from_vector(I64, pay[r]);
+      Buf db = make_buf((size_t)n[r] * 4 + 64), cb = make_buf((size_t)world * 8);
+      dbhip_col kcol = kc.c();
+      check(dbhip_scatter_indices(&kcol, 1, n[r], (uint32_t)world, 0, (uint32_t*)db->ptr(), (uint64_t*)cb->ptr(), nullptr));
+      dest[r].resize(n[r]);
+      db->download(dest[r].data(), (size_t)n[r] * 4);
+      dbhip_col cols[2] = {kc.c(), pc.c()};
+      int64_t rows = 0;
+      dbhip_exchange* x = nullptr;
+      check(dbhip_exchange_begin(c, cols, 2, (const uint32_t*)db->ptr(), n[r], &rows, &x, nullptr));
+      Buf ok = make_buf((size_t)rows * 8 + 64), op = make_buf((size_t)rows * 8 + 64);
+      void* outs[2] = {ok->ptr(), op->ptr()};
+      uint8_t* vouts[2] = {nullptr, nullptr};
+      starts[r].resize(world + 1);
+      check(dbhip_exchange_finish(x, outs, vouts, starts[r].data(), nullptr));
+      check(dbhip_exchange_destroy(x));
+      got_key[r].resize(rows); got_pay[r].resize(rows);
+      ok->download(got_key[r].data(), (size_t)rows * 8);
+      op->download(got_pay[r].data(), (size_t)rows * 8);
+      Buf ib = make_buf(nq * k * 4), dbf = make_buf(nq * k * 4), oi = make_buf(nq * k * 4), od = make_buf(nq * k * 4);
+      ib->upload(tid[r].data(), nq * k * 4); dbf->upload(tdist[r].data(), nq * k * 4);
+      check(dbhip_vec_topk_allgather(c, (const uint32_t*)ib->ptr(), (const float*)dbf->ptr(), nq, k, (uint64_t)r * 5000000ULL, (uint32_t*)oi->ptr(),
+                                     (float*)od->ptr(), nullptr));
+      oi->download(gid[r].data(), nq * k * 4); od->download(gdist[r].data(), nq * k * 4);
+      check(dbhip_comm_destroy(c));
+    } catch (const std::exception& e) { err[r] = e.what(); }
+  };
+  std::thread t0(rank_fn, 0), t1(rank_fn, 1);
+  t0.join(); t1.join();
+  CHECK(err[0].empty() && err[1].empty());
+  if (!err[0].empty() || !err[1].empty()) { printf("  exchange threads: %s | %s\n", err[0].c_str(), err[1].c_str()); return; }
+  for (int r = 0; r < world; ++r) {
+    std::vector<int64_t> ek, ep;
+    for (int s = 0; s < world; ++s)
+      for (int64_t i = 0; i < n[s]; ++i)
+        if ((int)dest[s][i] == r) { ek.push_back(key[s][i]); ep.push_back(pay[s][i]); }
+    CHECK(got_key[r] == ek);
+    CHECK(got_pay[r] == ep);
+    CHECK(starts[r][world] == (int64_t)ek.size());
+    for (int q = 0; q < nq; ++q) {   // the k smallest of both shards' candidates, ids made global
+      std::vector<std::pair<float, uint32_t>> all;
+      for (int s = 0; s < world; ++s)
+        for (int j = 0; j < k; ++j) all.push_back({tdist[s][q * k + j], tid[s][q * k + j] + (uint32_t)(s * 5000000)});
+      std::sort(all.begin(), all.end());
+      for (int j = 0; j < k; ++j) { CHECK(gid[r][q * k + j] == all[j].second); CHECK(gdist[r][q * k + j] == all[j].first); }
+    }
+  }
+  CHECK((int64_t)(got_key[0].size() + got_key[1].size()) == n[0] + n[1]);
+}
+
 static void test_hnsw_sequential_build_and_open() {
   // the deterministic build gives the same graph twice; store() -> open() searches identically without the original vectors
   const int dim = 12; const int64_t n = 1500;
@@ -695,6 +775,7 @@ int main() {
     test_hnsw_sequential_build_and_open();
     test_join_conjuncts();
     test_flight_scatters();
+    test_two_rank_exchange();
     test_right_joins();
     test_kmeans();
     test_hnsw_index();

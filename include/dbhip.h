@@ -51,7 +51,8 @@ enum {
   DBHIP_ERR_ROW_ERRORS = 4,   /* per-row errors were raised (see err bitmap)     */
   DBHIP_ERR_OVERFLOW = 5,     /* aggregate decimal overflow (aggregate_sum.rs:203-216) */
   DBHIP_ERR_CAPACITY = 6,     /* fixed-capacity fast path overflowed; retry general path */
-  DBHIP_ERR_UNSUPPORTED = 7   /* caller must keep the CPU closure for this case  */
+  DBHIP_ERR_UNSUPPORTED = 7,  /* caller must keep the CPU closure for this case  */
+  DBHIP_ERR_CANCELLED = 8     /* dbhip_stream_cancel was called for the stream: the operator stopped between two launches */
 };
 
 /* ---- physical types (src/query/expression/src/types.rs:234 DataType,
@@ -131,6 +132,15 @@ int32_t dbhip_stream_destroy(void* stream);        /* drains the stream, frees t
  * goes away. */
 int32_t dbhip_stream_release_scratch(void* stream);
 int32_t dbhip_stream_sync(void* stream);
+/* Cancellation (the reference polls check_interrupt() inside its long loops, src/query/pipeline/src/core/processor.rs:36-41,
+ * new_hash_join/memory/inner_join.rs:296): dbhip_stream_cancel marks `stream` (NULL = the library stream) — callable from ANY thread,
+ * typically the one that kills the query — and every multi-launch operator working on that stream (group-by add_block and its chunk
+ * loops, the vector-index search's query batches and ranges, the sort's passes, the partitioned exchange) returns
+ * DBHIP_ERR_CANCELLED at its next poll, between two launches: at most one kernel (a few ms) later. What the operator had built so far
+ * is left consistent but incomplete (a group-by table holds the chunks merged so far): the caller drops or resets the handle. The mark
+ * stays until dbhip_stream_cancel_clear (a killed pipeline's stream is usually destroyed instead, which clears it too). */
+int32_t dbhip_stream_cancel(void* stream);
+int32_t dbhip_stream_cancel_clear(void* stream);
 /* HIP-event timing on `stream` (bench.py's roofline figure): */
 int32_t dbhip_event_create(void** out_event_host);
 int32_t dbhip_event_record(void* event, void* stream);
@@ -776,12 +786,40 @@ int32_t dbhip_score_u8(int32_t is_l1, const uint8_t* query, const uint8_t* base,
 typedef struct dbhip_comm dbhip_comm;
 int32_t dbhip_comm_unique_id(uint8_t* out_id128_host);
 int32_t dbhip_comm_create(int32_t rank, int32_t world, const uint8_t* id128_host, dbhip_comm** out_host);
+/* An IN-PROCESS world for tests (no RCCL): `world` communicators created by `world` host threads of one process on one GPU under the
+ * same group_id; their collectives are device-to-device copies made at a rendezvous. It lets the multi-rank protocols run with
+ * world > 1 where only one GPU exists (tests/test_gpu_comm.py); every rank must call the same collective, from its own thread. */
+int32_t dbhip_comm_create_loopback(uint64_t group_id, int32_t rank, int32_t world, dbhip_comm** out_host);
 int32_t dbhip_comm_destroy(dbhip_comm* c);
 int32_t dbhip_comm_allgather(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
 int32_t dbhip_comm_alltoall(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream);
 int32_t dbhip_comm_allreduce_sum_u64(dbhip_comm* c, const uint64_t* send_dev, uint64_t* recv_dev, int64_t count, void* stream);
 int32_t dbhip_groupby_exchange_allgather(dbhip_groupby* g, dbhip_comm* c, int64_t max_rows, void* stream);
 int32_t dbhip_groupby_exchange_alltoall(dbhip_groupby* g, dbhip_comm* c, int64_t max_rows, void* stream);
+/* The exchange of a BLOCK between all ranks, owned by the ABI (round 4; no torch.distributed, no per-column collective in the host):
+ * the shuffle of the hash join (HashFlightScatter, flight_scatter_hash.rs:57-330: dest = dbhip_scatter_indices) and the exchange of the
+ * distributed sort (sorts/sort_broadcast.rs:150-197 + the range exchange: dest = dbhip_sort_bound_partition) are the same three calls.
+ *   dbhip_exchange_begin   DataBlock::scatter of `cols` by dest_index[i] < world (dbhip_scatter_columns: values, validities, Boolean,
+ *                          inline-String and Decimal columns; String columns WITH data buffers: DBHIP_ERR_UNSUPPORTED) and one 8-byte
+ *                          all-to-all of the row counts -> *out_recv_rows_host = rows this rank receives (the host sizes the output
+ *                          columns from it)
+ *   dbhip_exchange_finish  every column of every destination in ONE ncclGroup of send / recv pairs (one launch on the wire whatever
+ *                          the width of the block; every xGMI link busy at once); out_data_host[c] = recv_rows elements in source-rank
+ *                          order, rows of one source in their order; validity / Boolean Bitmaps arrive as per-source pieces and are
+ *                          concatenated bit by bit into out_validity_host[c] / out_data_host[c] (8-byte aligned, ceil(rows / 64) * 8
+ *                          bytes). out_src_starts_host[world + 1] (may be NULL): where every source rank's rows start.
+ *   dbhip_exchange_destroy frees the scattered image (also after a failed finish).
+ * A local communicator (world of one) makes the exchange a copy. dbhip_vec_topk_allgather is the merge of the row-range sharded vector
+ * search: per-shard top-k ids (u32, 0xFFFFFFFF = empty, LOCAL row numbers) + distances [nq][k] -> ids made global
+ * (+ row_offset), both all-gathered in one group, k-way merged (dbhip_vec_topk_merge) -> the global top-k on every rank. */
+typedef struct dbhip_exchange dbhip_exchange;
+int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
+                             dbhip_exchange** out_host, void* stream);
+int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_src_starts_host,
+                              void* stream);
+int32_t dbhip_exchange_destroy(dbhip_exchange* x);
+int32_t dbhip_vec_topk_allgather(dbhip_comm* c, const uint32_t* idx_dev, const float* dist_dev, int32_t nq, int32_t k, uint64_t row_offset,
+                                 uint32_t* out_idx_dev, float* out_dist_dev, void* stream);
 
 /* ---- §8f-4: vector-cluster KMeans and the f32 VectorDistanceKernel ------------------------------------------------------------
  * Replaces KMeans::compute (src/query/storages/common/index/src/kmeans.rs:93-291: kmeans++ initialisation with the fixed LCG seed,

@@ -81,3 +81,24 @@ def test_specialised_kernels_are_cached_on_disk(tmp_path, monkeypatch):
     monkeypatch.setenv("DBHIP_JIT_CACHE_DIR", "off")
     assert L.dbhip_jit_compile_check(buf, C.c_int64(1 << 16)) == size
     assert sorted(os.listdir(tmp_path / "cache")) == files
+
+
+def test_rust_binding_file_matches_the_header():
+    """bindings/dbhip_sys.rs (the `extern "C"` block + #[repr(C)] structs a Rust host links against) is generated from
+    include/dbhip.h by tools/gen_rust_bindings.py: the committed file must be what the header produces today, bind every exported
+    function exactly once, and carry the struct layouts of the ctypes mirror."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_bindings as G
+    text, funcs = G.render(open(os.path.join(ROOT, "include", "dbhip.h")).read())
+    assert open(os.path.join(ROOT, "bindings", "dbhip_sys.rs")).read() == text, "stale bindings: run python tools/gen_rust_bindings.py"
+    assert sorted(funcs) == header_symbols() and len(set(funcs)) == len(funcs)
+    # struct fields in declaration order == the ctypes mirror's (_lib.py), so both bindings agree on the layout
+    from databend_amd import _lib
+    for rust_name, ct in (("dbhip_col", _lib.Col), ("dbhip_agg_desc", _lib.AggDesc), ("dbhip_expr_ins", _lib.ExprIns),
+                          ("dbhip_agg_program", _lib.AggProgram), ("dbhip_pq_info", _lib.PqInfo)):
+        body = re.search(r"pub struct %s \{(.*?)\}" % rust_name, text, flags=re.S).group(1)
+        fields = [f.replace("r#", "") for f in re.findall(r"pub (\S+):", body)]
+        assert fields == [f[0] for f in ct._fields_], (rust_name, fields)
+    for const, val in (("DBHIP_T_DEC256", 17), ("DBHIP_ERR_UNSUPPORTED", 7), ("DBHIP_AGG_MAX", 3), ("DBHIP_ABI_VERSION", 3)):
+        assert re.search(r"pub const %s: i32 = %d;" % (const, val), text), const

@@ -52,3 +52,121 @@ def test_exchanges_in_a_world_of_one_leave_the_result_unchanged(gpu, real_rccl):
     comm.allreduce_sum_u64(send.ptr, recv.ptr, 1000)
     assert np.array_equal(recv.to_numpy(np.uint64, 1000), x)
     comm.destroy()
+
+
+# ---- world > 1 on one GPU: the in-process loopback world (dbhip_comm_create_loopback), one host thread per rank ---------------------
+def run_ranks(world, fn):
+    """fn(rank) on `world` threads; returns the results by rank, re-raises the first failure"""
+    import threading
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_block_exchange_between_ranks_routes_every_row_once(gpu, world):
+    """dbhip_exchange_begin / _finish (the shuffle of the hash join and the exchange of the distributed sort behind the ABI): every
+    rank scatters its shard by siphash64(key) % world (dbhip_scatter_indices, the reference's HashFlightScatter) and ONE grouped
+    all-to-all moves all columns — values, validities, a Boolean column, a Decimal128 column, inline strings. Rank r must end with
+    exactly the rows whose destination is r, grouped by source rank, in their order inside a source."""
+    D = gpu
+    rng = np.random.default_rng(100 + world)
+    sizes = [int(x) for x in rng.integers(0, 40_000, world)]
+    sizes[0] = 0 if world > 2 else sizes[0]                      # an empty shard
+    shards = []
+    for r in range(world):
+        n = sizes[r]
+        key = rng.integers(0, 5000, n).astype(np.int64)
+        kv = rng.random(n) > 0.1
+        pay = rng.integers(-2**40, 2**40, n).astype(np.int64)
+        flag = rng.random(n) > 0.5
+        dec = [int(x) * 10**20 + 3 for x in rng.integers(-10**6, 10**6, n)]
+        tag = [b"r%d-%d" % (r, i % 997) for i in range(n)]
+        shards.append((key, kv, pay, flag, dec, tag))
+    gid = 7000 + world
+
+    def rank_fn(r):
+        key, kv, pay, flag, dec, tag = shards[r]
+        n = len(key)
+        comm = D.Comm.loopback(gid, r, world)
+        cols = [D.Column.from_numpy(key, validity=kv), D.Column.from_numpy(pay), D.Column.boolean(flag, validity=kv),
+                D.Column.decimal128(dec, 38, 2), D.Column.from_views(D.make_views(tag))]
+        if n:
+            dest, counts = D.scatter_indices([cols[0]], world, default_index=world - 1)
+        else:
+            dest, counts = D.DeviceBuffer(16), np.zeros(world, np.uint64)
+        got, starts = comm.exchange_block(cols, dest)
+        d = dest.to_numpy(np.uint32, n)
+        res = (d, [c.to_numpy() for c in got], [c.validity_numpy() for c in got], starts)
+        comm.destroy()
+        return res
+    outs = run_ranks(world, rank_fn)
+    for r in range(world):
+        _, cols, valids, starts = outs[r]
+        exp_rows = [(s, i) for s in range(world) for i in np.nonzero(outs[s][0] == r)[0].tolist()]
+        assert starts == [sum(int((outs[s][0] == r).sum()) for s in range(q)) for q in range(world + 1)]
+        assert len(exp_rows) == starts[-1]
+        ek = np.array([shards[s][0][i] for s, i in exp_rows], np.int64)
+        ekv = np.array([shards[s][1][i] for s, i in exp_rows], bool)
+        assert np.array_equal(cols[0], ek) and np.array_equal(valids[0], ekv)
+        assert np.array_equal(cols[1], np.array([shards[s][2][i] for s, i in exp_rows], np.int64))
+        assert np.array_equal(cols[2], np.array([shards[s][3][i] for s, i in exp_rows], bool)) and np.array_equal(valids[2], ekv)
+        assert [int(x) for x in cols[3]] == [shards[s][4][i] for s, i in exp_rows]
+        assert D.view_strings(cols[4]) == [shards[s][5][i] for s, i in exp_rows]
+    assert sum(o[3][-1] for o in outs) == sum(sizes)
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_shard_topk_allgather_and_partial_state_exchange_between_ranks(gpu, world):
+    """dbhip_vec_topk_allgather: every rank's local top-k (local row numbers) -> the global top-k on every rank == the k smallest of
+    all shards' candidates with ids made global; and dbhip_groupby_exchange_alltoall between `world` ranks: rank r ends up owning the
+    groups with hash % world == r, the union is the single-table result."""
+    D = gpu
+    rng = np.random.default_rng(world)
+    nq, k = 37, 10
+    dists = [np.sort(rng.random((nq, k)).astype(np.float32), axis=1) for _ in range(world)]
+    ids = [np.stack([rng.permutation(10_000)[:k] for _ in range(nq)]).astype(np.uint32) for _ in range(world)]
+    ids[world - 1][:, k - 3:] = 0xFFFFFFFF                        # a shard with fewer than k answers
+    dists[world - 1][:, k - 3:] = np.inf
+    offs = [r * 1_000_000 for r in range(world)]
+    n_rows = 60_000
+    keys = [rng.integers(0, 300, n_rows).astype(np.int64) for _ in range(world)]
+    vals = [rng.integers(-1000, 1000, n_rows).astype(np.int64) for _ in range(world)]
+    gid = 9000 + world
+
+    def rank_fn(r):
+        comm = D.Comm.loopback(gid, r, world)
+        gi, gd = comm.topk_allgather(D.DeviceBuffer.from_numpy(ids[r]), D.DeviceBuffer.from_numpy(dists[r]), nq, k, offs[r])
+        g = D.GroupBy([T.T_I64], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)])
+        g.add_block([D.Column.from_numpy(keys[r])], [D.Column.from_numpy(vals[r]), None], n_rows)
+        comm.exchange_alltoall(g, max_rows=512)
+        rows = sorted(g.result())
+        g.destroy()
+        comm.destroy()
+        return gi, gd, rows
+    outs = run_ranks(world, rank_fn)
+    allc = [[(float(dists[r][q, j]), int(ids[r][q, j]) + offs[r]) for r in range(world) for j in range(k) if ids[r][q, j] != 0xFFFFFFFF] for q in range(nq)]
+    for gi, gd, _ in outs:
+        for q in range(nq):
+            exp = sorted(allc[q])[:k]
+            assert [int(x) for x in gi[q]] == [e[1] for e in exp] and np.array_equal(gd[q], np.array([e[0] for e in exp], np.float32))
+    merged = {}
+    for _, _, rows in outs:
+        for key, sm, cnt in rows:
+            assert key not in merged
+            merged[key] = (sm, cnt)
+    allk, allv = np.concatenate(keys), np.concatenate(vals)
+    assert merged == {int(u): (int(allv[allk == u].sum()), int((allk == u).sum())) for u in np.unique(allk)}

@@ -407,3 +407,37 @@ def test_stream_scratch_is_released_with_the_stream(gpu):
     exp = np.argsort(keys.to_numpy(), kind="stable").astype(np.uint32)
     T.check(L.dbhip_sort_perm(arr, zero, zero, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.ptr), None))
     assert np.array_equal(perm.to_numpy(np.uint32, n), exp)
+
+
+def test_stream_cancel_stops_multi_launch_operators(gpu):
+    """dbhip_stream_cancel (processor.rs:36-41 check_interrupt): a marked stream makes the chunk loops of add_block, the query batches
+    of the vector-index search and the sort's passes return DBHIP_ERR_CANCELLED at their next poll; other streams are not affected,
+    dbhip_stream_cancel_clear (or destroying the stream) lifts the mark."""
+    L = T.lib()
+    rng = np.random.default_rng(2)
+    n = 1 << 20
+    k = gpu.Column.from_numpy(rng.integers(0, 5000, n).astype(np.int64))
+    a = gpu.Column.from_numpy(rng.integers(0, 100, n).astype(np.int64))
+    s = C.c_void_p()
+    T.check(L.dbhip_stream_create(C.byref(s)))
+    g = gpu.GroupBy([T.T_I64], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)])
+    T.check(L.dbhip_stream_cancel(s))
+    with pytest.raises(T.DbhipError) as e:
+        g.add_block([k], [a, None], n, stream=s)
+    assert e.value.code == T.ERR_CANCELLED
+    arr = (T.Col * 1)(k.c())
+    zero = (C.c_uint8 * 1)(0)
+    perm = gpu.DeviceBuffer(n * 4)
+    assert L.dbhip_sort_perm(arr, zero, zero, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.ptr), s) == T.ERR_CANCELLED
+    # the library stream is another stream: unaffected
+    g2 = gpu.GroupBy([T.T_I64], [(T.AGG_COUNT, 0, 0, 0, 0)])
+    g2.add_block([k], [None], n)
+    assert sum(r[1] for r in g2.result()) == n
+    T.check(L.dbhip_stream_cancel_clear(s))
+    g.reset(s)
+    g.add_block([k], [a, None], n, stream=s)
+    T.check(L.dbhip_stream_sync(s))
+    assert sum(r[2] for r in g.result()) == n
+    T.check(L.dbhip_stream_cancel(s))
+    T.check(L.dbhip_stream_destroy(s))          # destroying the stream clears the mark
+    g.destroy(); g2.destroy()
