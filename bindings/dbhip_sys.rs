@@ -70,6 +70,7 @@ pub const DBHIP_VEC_COSINE: i32 = 0;   // dbhip_vec_metric
 pub const DBHIP_VEC_L2: i32 = 1;   // dbhip_vec_metric
 pub const DBHIP_VEC_DOT: i32 = 2;   // dbhip_vec_metric
 pub const DBHIP_VEC_L1: i32 = 3;   // dbhip_vec_metric
+pub const DBHIP_VEC_NORM: i32 = 4;   // dbhip_vec_metric
 pub const DBHIP_ABI_VERSION: i32 = 3;
 
 #[repr(C)]
@@ -256,6 +257,7 @@ extern "C" {
     pub fn dbhip_sort_perm(keys: *const dbhip_col, desc_host: *const u8, nulls_first_host: *const u8, nkeys: i32, n: i64, limit: i64, out_perm: *mut u32, stream: *mut c_void) -> i32;
     pub fn dbhip_merge_sorted_perm(keys: *const dbhip_col, desc_host: *const u8, nulls_first_host: *const u8, nkeys: i32, run_offsets_host: *const i64, nruns: i32, limit: i64, out_perm: *mut u32, stream: *mut c_void) -> i32;
     pub fn dbhip_sort_bound_partition(keys: *const dbhip_col, bounds: *const dbhip_col, desc_host: *const u8, nulls_first_host: *const u8, nkeys: i32, n: i64, nbounds: i64, out_part: *mut u32, out_counts: *mut u64, stream: *mut c_void) -> i32;
+    pub fn dbhip_vec_distance_rows(metric: i32, elem_type: i32, lhs: *const c_void, lhs_is_scalar: i32, rhs: *const c_void, rhs_is_scalar: i32, n: i64, dim: i32, out: *mut c_void, stream: *mut c_void) -> i32;
     pub fn dbhip_vec_distance(metric: i32, base: *const f32, n: i64, dim: i32, queries: *const f32, nq: i32, out: *mut f32, stream: *mut c_void) -> i32;
     pub fn dbhip_vec_topk(metric: i32, base: *const f32, n: i64, dim: i32, queries: *const f32, nq: i32, k: i32, out_idx: *mut u32, out_dist: *mut f32, stream: *mut c_void) -> i32;
     pub fn dbhip_vec_topk_merge(dists: *const f32, ids: *const u32, m: i64, nq: i32, k: i32, out_idx: *mut u32, out_dist: *mut f32, stream: *mut c_void) -> i32;

@@ -20,7 +20,7 @@ T_BOOL, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F32, T_F64, T_DA
 OP_PLUS, OP_MINUS, OP_MULTIPLY, OP_DIVIDE, OP_INTDIV, OP_MODULO, OP_DIV0, OP_DIVNULL = range(8)
 CMP_EQ, CMP_NOTEQ, CMP_LT, CMP_LTE, CMP_GT, CMP_GTE = range(6)
 AGG_COUNT, AGG_SUM, AGG_MIN, AGG_MAX = range(4)
-VEC_COSINE, VEC_L2, VEC_DOT, VEC_L1 = range(4)
+VEC_COSINE, VEC_L2, VEC_DOT, VEC_L1, VEC_NORM = range(5)
 
 
 class Col(C.Structure):
@@ -89,7 +89,7 @@ SYMBOLS = [
     "dbhip_join_add_build_binary", "dbhip_join_finalize_binary", "dbhip_join_probe_count_binary", "dbhip_join_probe_binary", "dbhip_join_destroy_binary",
     "dbhip_join_create", "dbhip_join_create_keys", "dbhip_join_probe_mark",
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
-    "dbhip_join_destroy", "dbhip_join_mark_build", "dbhip_join_build_matched", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_sort_bound_partition", "dbhip_bitmap_set_indices", "dbhip_siphash64", "dbhip_scatter_indices", "dbhip_scatter_block", "dbhip_vec_distance", "dbhip_vec_topk", "dbhip_score_u8",
+    "dbhip_join_destroy", "dbhip_join_mark_build", "dbhip_join_build_matched", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_sort_bound_partition", "dbhip_bitmap_set_indices", "dbhip_siphash64", "dbhip_scatter_indices", "dbhip_scatter_block", "dbhip_vec_distance", "dbhip_vec_distance_rows", "dbhip_vec_topk", "dbhip_score_u8",
     "dbhip_vec_topk_merge", "dbhip_vec_index_build", "dbhip_vec_index_search", "dbhip_vec_index_destroy",
     "dbhip_comm_unique_id", "dbhip_comm_create", "dbhip_comm_destroy", "dbhip_comm_allgather", "dbhip_comm_alltoall",
     "dbhip_comm_allreduce_sum_u64", "dbhip_groupby_exchange_allgather", "dbhip_groupby_exchange_alltoall", "dbhip_kmeans", "dbhip_vec_kernel_f32", "dbhip_hnsw_build", "dbhip_hnsw_build_sequential", "dbhip_hnsw_from_graph", "dbhip_hnsw_open", "dbhip_hnsw_export_graph", "dbhip_hnsw_search", "dbhip_hnsw_scores",

@@ -1242,6 +1242,50 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   return filter_range(S0, n);
 }
 
+// Row by row: out[i] = distance(lhs[i], rhs[i]) — the column-vs-column form of the vector scalar functions (scalars/vector.rs:59-260
+// Array(Float32 / Float64), :490-560 Vector(Float32 / Int8)). HBM bound (two rows of dim elements per result): G lanes per row
+// (G = the power of two that gives every lane ~4 elements, at most a wave), coalesced element-strided loads, a shuffle reduction per
+// group. T = element type in memory, F = arithmetic type (f32 for f32 / i8 rows, f64 for f64 rows: the *_64 functions of distance.rs).
+template <typename T, typename F>
+__global__ __launch_bounds__(256) void vec_rows_kernel(int metric, const T* __restrict__ lhs, int lhs_scalar, const T* __restrict__ rhs, int rhs_scalar,
+                                                       int64_t n, int dim, int gshift, F* __restrict__ out) {
+  const int G = 1 << gshift;
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t groups_per_block = 256 >> gshift;
+  for (int64_t row = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> gshift); row < ((n + groups_per_block - 1) / groups_per_block) * groups_per_block;
+       row += (int64_t)gridDim.x * groups_per_block) {
+    const bool live = row < n;
+    const int64_t r = live ? row : 0;
+    const T* a = lhs + (lhs_scalar ? 0 : r * dim);
+    const T* b = rhs ? rhs + (rhs_scalar ? 0 : r * dim) : a;
+    F s0 = 0, s1 = 0, s2 = 0;
+    for (int k = lane; k < dim; k += G) {
+      const F x = (F)a[k], y = (F)b[k];
+      switch (metric) {   // (uniform)
+        case 0: s0 += x * y; s1 += x * x; s2 += y * y; break;
+        case 1: { const F d = x - y; s0 += d * d; } break;
+        case 2: s0 += x * y; break;
+        case 3: { const F d = x - y; s0 += d < 0 ? -d : d; } break;
+        default: s0 += x * x; break;
+      }
+    }
+    for (int off = G >> 1; off >= 1; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64);
+      if (metric == 0) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    }
+    if (live && lane == 0) {
+      F res;
+      switch (metric) {
+        case 0: res = (F)1 - s0 / (sqrt(s1) * sqrt(s2)); break;
+        case 1: res = sqrt(s0); break;
+        case 4: res = sqrt(s0); break;
+        default: res = s0; break;
+      }
+      out[row] = res;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1333,6 +1377,33 @@ int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t
   int32_t rc = launch_distance(metric, base, n, dim, queries, nq, qnorm, out, n, s);
   kernel_timer_stop(s);
   return rc;
+}
+
+int32_t dbhip_vec_distance_rows(int32_t metric, int32_t elem_type, const void* lhs, int32_t lhs_is_scalar, const void* rhs, int32_t rhs_is_scalar,
+                                int64_t n, int32_t dim, void* out, void* stream) {
+  DBHIP_REQUIRE(metric >= DBHIP_VEC_COSINE && metric <= DBHIP_VEC_NORM, "dbhip_vec_distance_rows: bad metric");
+  DBHIP_REQUIRE(dim > 0 && n >= 0, "dbhip_vec_distance_rows: bad shape");
+  if (elem_type != DBHIP_T_F32 && elem_type != DBHIP_T_F64 && elem_type != DBHIP_T_I8) {
+    set_error("dbhip_vec_distance_rows: element type %d (Float32, Float64 and Int8 vectors exist in the reference)", elem_type);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(lhs && out && (rhs || metric == DBHIP_VEC_NORM), "dbhip_vec_distance_rows: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  int gshift = 0;
+  while (gshift < 6 && (4 << gshift) < dim) ++gshift;   // ~4 elements per lane, at most one wave per row
+  const int64_t groups = 256 >> gshift;
+  const dim3 grid((unsigned)grid_for(ceil_div(n, groups) * 256, 256)), blk(256);
+  kernel_timer_start(s);
+  if (elem_type == DBHIP_T_F32)
+    hipLaunchKernelGGL((vec_rows_kernel<float, float>), grid, blk, 0, s, metric, (const float*)lhs, lhs_is_scalar, (const float*)rhs, rhs_is_scalar, n, dim, gshift, (float*)out);
+  else if (elem_type == DBHIP_T_F64)
+    hipLaunchKernelGGL((vec_rows_kernel<double, double>), grid, blk, 0, s, metric, (const double*)lhs, lhs_is_scalar, (const double*)rhs, rhs_is_scalar, n, dim, gshift, (double*)out);
+  else
+    hipLaunchKernelGGL((vec_rows_kernel<int8_t, float>), grid, blk, 0, s, metric, (const int8_t*)lhs, lhs_is_scalar, (const int8_t*)rhs, rhs_is_scalar, n, dim, gshift, (float*)out);
+  kernel_timer_stop(s);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
 }
 
 int32_t dbhip_vec_topk(int32_t metric, const float* base, int64_t n, int32_t dim, const float* queries,

@@ -1379,6 +1379,19 @@ class HashJoin:
             pass
 
 
+def vec_distance_rows(metric, lhs, rhs, n, dim, elem=L.T_F32, lhs_scalar=False, rhs_scalar=False):
+    """the vector scalar functions row by row (dbhip_vec_distance_rows; scalars/vector.rs:59-260,490-560): lhs / rhs = numpy arrays
+    [n, dim] (or [dim] with *_scalar) of f32 / f64 / i8 -> numpy f32[n] (f64[n] for f64 rows)"""
+    _ensure()
+    a = DeviceBuffer.from_numpy(np.ascontiguousarray(lhs))
+    b = DeviceBuffer.from_numpy(np.ascontiguousarray(rhs)) if rhs is not None else None
+    odt = np.float64 if elem == L.T_F64 else np.float32
+    out = DeviceBuffer(max(n, 1) * np.dtype(odt).itemsize)
+    check(lib().dbhip_vec_distance_rows(metric, elem, C.c_void_p(a.ptr), 1 if lhs_scalar else 0, C.c_void_p(b.ptr if b is not None else None),
+                                        1 if rhs_scalar else 0, C.c_int64(n), dim, C.c_void_p(out.ptr), None))
+    return out.to_numpy(odt, n)
+
+
 def siphash64(col):
     """the `siphash64` scalar function (scalars/hash.rs:323-328: SipHash-1-3, zero keys, over the value's bytes) -> numpy u64[n]
     (0 under NULL rows; the column's validity passes through)."""

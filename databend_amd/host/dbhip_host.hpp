@@ -702,7 +702,13 @@ struct VecDistFn : ScalarFunction {
   Value eval(const std::vector<Value>& args, EvalContext&) const override {
     const Column& base = args[0].column;
     const Column& q = args[1].column;
-    if (!q.is_const && q.len != 1) throw ErrorCode::Unimplemented("vector distance between two columns stays on the CPU evaluator");
+    if (!q.is_const && q.len != 1) {
+      // two columns: row by row (calculate_distance, scalars/vector.rs:490-560)
+      if (q.len != base.len || q.type.dim != base.type.dim) throw ErrorCode::BadArguments("Vector length not equal");
+      Column r; r.type = DataType::of(DBHIP_T_F32); r.len = base.len; r.data = make_buf((size_t)base.len * 4 + 16);
+      check(dbhip_vec_distance_rows(metric, DBHIP_T_F32, base.data->ptr(), 0, q.data->ptr(), 0, base.len, base.type.dim, r.data->ptr(), nullptr));
+      return Value::of(r);
+    }
     Column r; r.type = DataType::of(DBHIP_T_F32); r.len = base.len; r.data = make_buf((size_t)base.len * 4);
     check(dbhip_vec_distance(metric, (const float*)base.data->ptr(), base.len, base.type.dim, (const float*)q.data->ptr(), 1,
                              (float*)r.data->ptr(), nullptr));

@@ -736,7 +736,16 @@ int32_t dbhip_sort_bound_partition(const dbhip_col* keys, const dbhip_col* bound
  * out[q*n + i] = metric(base[i], query[q]) for flat row-major f32
  * (VectorColumn::Float32, types/vector.rs:377-380). The dot products run on
  * v_mfma_f32_32x32x2_f32 (exact f32). */
-typedef enum { DBHIP_VEC_COSINE = 0, DBHIP_VEC_L2 = 1, DBHIP_VEC_DOT = 2, DBHIP_VEC_L1 = 3 } dbhip_vec_metric;
+typedef enum { DBHIP_VEC_COSINE = 0, DBHIP_VEC_L2 = 1, DBHIP_VEC_DOT = 2, DBHIP_VEC_L1 = 3, DBHIP_VEC_NORM = 4 /* vector_norm(lhs): dbhip_vec_distance_rows only */ } dbhip_vec_metric;
+/* The scalar functions row by row (scalars/vector.rs:59-260: cosine_distance / l1_distance / l2_distance / inner_product over two
+ * Array(Float32) or Array(Float64) COLUMNS; :490-560 calculate_distance / calculate_norm over Vector(Float32 | Int8) columns):
+ * out[i] = f(lhs[i], rhs[i]) for dense row-major [n][dim] columns; a side with *_is_scalar set is ONE vector for every row (a constant
+ * argument). elem_type DBHIP_T_F32 -> f32 out, DBHIP_T_F64 (the *_64 functions, distance.rs:97-165) -> f64 out, DBHIP_T_I8 (Int8
+ * vectors are widened to f32 first) -> f32 out. DBHIP_VEC_NORM ignores rhs. NULL rows / NULL elements are the caller's: the reference
+ * raises "Vector contain null values" for an element NULL and passes row NULLs through (the result's validity = the AND of the
+ * arguments'). 1e-5 relative to the reference's summation order (north_star). */
+int32_t dbhip_vec_distance_rows(int32_t metric, int32_t elem_type, const void* lhs, int32_t lhs_is_scalar, const void* rhs, int32_t rhs_is_scalar,
+                                int64_t n, int32_t dim, void* out, void* stream);
 int32_t dbhip_vec_distance(int32_t metric, const float* base, int64_t n, int32_t dim,
                            const float* queries, int32_t nq, float* out, void* stream);
 /* ORDER BY distance LIMIT k (sort_compare.rs:197-209): per query the k smallest

@@ -1631,6 +1631,53 @@ void orc_vec_distance(int metric, const float* base, int64_t n, int dim, const f
     }
   }
 }
+/* Row by row: out[i] = distance(lhs[i], rhs[i]) — the column-vs-column form of the scalar functions (scalars/vector.rs:59-260 over
+ * Array(Float32) / Array(Float64), :490-560 calculate_distance over Vector(Float32 | Int8): Int8 elements are widened to f32 first),
+ * a side with `*_scalar` set is one vector for every row. elem: 0 f32, 1 f64 (the *_64 functions of distance.rs:97-165, f64 result),
+ * 2 i8. metric 0 cosine, 1 l2, 2 inner product, 3 l1, 4 vector_norm(lhs) (distance.rs:167-170). */
+static double nd_sum_prod64(const double* a, const double* b, int n) {
+  double p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc = 0.0;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) for (int j = 0; j < 8; ++j) p[j] = p[j] + a[i + j] * b[i + j];
+  acc = acc + (p[0] + p[4]); acc = acc + (p[1] + p[5]); acc = acc + (p[2] + p[6]); acc = acc + (p[3] + p[7]);
+  for (; i < n; ++i) acc = acc + a[i] * b[i];
+  return acc;
+}
+void orc_vec_distance_rows(int metric, int elem, const void* lhs, int lhs_scalar, const void* rhs, int rhs_scalar, int64_t n, int dim, void* out) {
+  float* fa = (float*)malloc(sizeof(float) * (size_t)(dim ? dim : 1));
+  float* fb = (float*)malloc(sizeof(float) * (size_t)(dim ? dim : 1));
+  for (int64_t i = 0; i < n; ++i) {
+    const size_t ia = lhs_scalar ? 0 : (size_t)i * dim, ib = rhs_scalar ? 0 : (size_t)i * dim;
+    if (elem == 1) {
+      const double* a = (const double*)lhs + ia; const double* b = rhs ? (const double*)rhs + ib : a;
+      double r;
+      switch (metric) {
+        case 0: { double aa = nd_sum_prod64(a, a, dim), bb = nd_sum_prod64(b, b, dim); r = 1.0 - nd_sum_prod64(a, b, dim) / (sqrt(aa) * sqrt(bb)); } break;
+        case 1: { double s = 0.0; for (int k = 0; k < dim; ++k) { double d = a[k] - b[k]; s += d * d; } r = sqrt(s); } break;
+        case 2: r = nd_sum_prod64(a, b, dim); break;
+        case 3: { double s = 0.0; for (int k = 0; k < dim; ++k) s += fabs(a[k] - b[k]); r = s; } break;
+        default: r = sqrt(nd_sum_prod64(a, a, dim)); break;
+      }
+      ((double*)out)[i] = r;
+      continue;
+    }
+    const float *a, *b;
+    if (elem == 2) {
+      for (int k = 0; k < dim; ++k) { fa[k] = (float)((const int8_t*)lhs)[ia + k]; fb[k] = rhs ? (float)((const int8_t*)rhs)[ib + k] : fa[k]; }
+      a = fa; b = fb;
+    } else { a = (const float*)lhs + ia; b = rhs ? (const float*)rhs + ib : a; }
+    float r;
+    switch (metric) {
+      case 0: { float aa = nd_sum_prod(a, a, dim), bb = nd_sum_prod(b, b, dim); r = 1.0f - nd_sum_prod(a, b, dim) / (sqrtf(aa) * sqrtf(bb)); } break;
+      case 1: { float s = 0.0f; for (int k = 0; k < dim; ++k) { float d = a[k] - b[k]; s += d * d; } r = sqrtf(s); } break;
+      case 2: r = nd_sum_prod(a, b, dim); break;
+      case 3: { float s = 0.0f; for (int k = 0; k < dim; ++k) s += fabsf(a[k] - b[k]); r = s; } break;
+      default: r = sqrtf(nd_sum_prod(a, a, dim)); break;
+    }
+    ((float*)out)[i] = r;
+  }
+  free(fa); free(fb);
+}
 /* scalar statement of cpp/avx2.c:45-139 impl_score_dot_avx / impl_score_l1_avx (exact integer sums) */
 void orc_score_u8(int is_l1, const uint8_t* q, const uint8_t* base, int64_t n, int dim, float* out) {
   for (int64_t i = 0; i < n; ++i) {

@@ -201,9 +201,53 @@ static void put_view(const uint8_t* chunk, uint64_t off, uint8_t* out, int64_t o
 }
 
 /* Returns 0, -1 (malformed) or -2 (unsupported). out_valid: one byte per row. BOOL values: one byte per row too. */
+/* Snappy raw format (google/snappy format_description.txt): varint uncompressed length, then literal / copy elements.
+ * -> bytes written, -1 on malformed input. Used for the SNAPPY-compressed chunks of the reference's own test files. */
+static int64_t snappy_raw(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap) {
+  int64_t ip = 0, op = 0;
+  uint64_t ulen = 0; int sh = 0;
+  for (;;) { if (ip >= n || sh > 35) return -1; uint8_t b = in[ip++]; ulen |= (uint64_t)(b & 0x7f) << sh; if (!(b & 0x80)) break; sh += 7; }
+  if ((int64_t)ulen > cap) return -1;
+  while (ip < n) {
+    const uint8_t tag = in[ip++];
+    int64_t l, off = 0;
+    if ((tag & 3) == 0) {
+      l = (tag >> 2) + 1;
+      if (l > 60) { const int nb = (int)l - 60; if (ip + nb > n) return -1; l = 0; for (int k = 0; k < nb; ++k) l |= (int64_t)in[ip + k] << (8 * k); l += 1; ip += nb; }
+      if (ip + l > n || op + l > (int64_t)ulen) return -1;
+      memcpy(out + op, in + ip, (size_t)l); ip += l; op += l;
+      continue;
+    }
+    if ((tag & 3) == 1) { if (ip + 1 > n) return -1; l = 4 + ((tag >> 2) & 7); off = ((int64_t)(tag >> 5) << 8) | in[ip]; ip += 1; }
+    else if ((tag & 3) == 2) { if (ip + 2 > n) return -1; l = (tag >> 2) + 1; off = in[ip] | ((int64_t)in[ip + 1] << 8); ip += 2; }
+    else { if (ip + 4 > n) return -1; l = (tag >> 2) + 1; off = in[ip] | ((int64_t)in[ip + 1] << 8) | ((int64_t)in[ip + 2] << 16) | ((int64_t)in[ip + 3] << 24); ip += 4; }
+    if (off == 0 || off > op || op + l > (int64_t)ulen) return -1;
+    for (int64_t k = 0; k < l; ++k) out[op + k] = out[op + k - off];   /* byte by byte: the copy may overlap itself */
+    op += l;
+  }
+  return op == (int64_t)ulen ? op : -1;
+}
+
+static int g_pq_codec = 0;   /* parquet.thrift CompressionCodec of the chunk orc_pq_decode_codec is working on (0 UNCOMPRESSED, 1 SNAPPY) */
+int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_length, int max_def, int out_type, int64_t cap_rows,
+                  uint8_t* out_values, uint8_t* out_valid, int64_t* out_rows, int64_t* out_nulls);
+/* the same for a SNAPPY chunk of DATA_PAGE v1 / dictionary pages (what parquet-cpp wrote into the reference's tests/data files): every
+ * page payload is inflated first. Long strings (> 12 bytes) of such chunks are refused (-2): their views would have to point into an
+ * image this function does not keep. */
+int orc_pq_decode_codec(const uint8_t* chunk, int64_t len, int codec, int physical, int type_length, int max_def, int out_type, int64_t cap_rows,
+                        uint8_t* out_values, uint8_t* out_valid, int64_t* out_rows, int64_t* out_nulls) {
+  if (codec != 0 && codec != 1) return -2;
+  g_pq_codec = codec;
+  const int rc = orc_pq_decode(chunk, len, physical, type_length, max_def, out_type, cap_rows, out_values, out_valid, out_rows, out_nulls);
+  g_pq_codec = 0;
+  return rc;
+}
+
 int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_length, int max_def, int out_type, int64_t cap_rows,
                   uint8_t* out_values, uint8_t* out_valid, int64_t* out_rows, int64_t* out_nulls) {
   rd_t r = {chunk, chunk + len, 0};
+  uint8_t* inflated[64];
+  int n_inflated = 0;
   const int es = esize_of(out_type);
   const int pw = physical == PT_INT32 || physical == PT_FLOAT ? 4 : (physical == PT_INT64 || physical == PT_DOUBLE ? 8 : type_length);
   int64_t rows = 0, nulls = 0;
@@ -213,11 +257,18 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
   while (r.p < r.end && rc == 0) {
     page_t pg;
     if (read_page(&r, &pg)) { rc = -1; break; }
-    if (pg.csize != pg.usize) { rc = -2; break; }
     if ((int64_t)(r.end - r.p) < pg.csize) { rc = -1; break; }
     const uint8_t* pay = r.p;
     const uint8_t* pend = pay + pg.csize;
     r.p = pend;
+    const uint8_t* view_base = chunk;
+    if (g_pq_codec == 1) {
+      if (pg.type == 3 || pg.usize < 0 || n_inflated >= 64) { rc = -2; break; }   /* v2 pages compress the values only: not in the reference's files */
+      uint8_t* buf = (uint8_t*)malloc((size_t)pg.usize + 16);
+      inflated[n_inflated++] = buf;
+      if (snappy_raw(pay, pg.csize, buf, pg.usize) != pg.usize) { rc = -1; break; }
+      pay = buf; pend = buf + pg.usize; view_base = NULL;
+    } else if (pg.csize != pg.usize) { rc = -2; break; }
     if (pg.type == 2) {
       if (dict_n >= 0 || pg.nvals < 0 || (pg.enc != 0 && pg.enc != 2)) { rc = pg.enc != 0 && pg.enc != 2 ? -2 : -1; break; }
       dict_n = pg.nvals;
@@ -229,6 +280,7 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
           if (pend - q < 4) { rc = -1; break; }
           memcpy(&l, q, 4);
           if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+          if (!view_base && l > 12) { rc = -2; break; }   /* a long view would have to point into the inflated page */
           put_view(chunk, (uint64_t)(q + 4 - chunk), dict, i);
           q += 4 + l;
         } else {
@@ -313,6 +365,7 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
         if (pend - q < 4) { rc = -1; break; }
         memcpy(&l, q, 4);
         if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+        if (!view_base && l > 12) { rc = -2; break; }
         put_view(chunk, (uint64_t)(q + 4 - chunk), out_values, o);
         q += 4 + l;
       } else {
@@ -325,6 +378,7 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
     rows += pg.nvals;
   }
   free(dict);
+  for (int k = 0; k < n_inflated; ++k) free(inflated[k]);
   *out_rows = rows;
   *out_nulls = nulls;
   return rc;

@@ -1,0 +1,98 @@
+"""Test infrastructure: the reference-held Parquet fixtures (tests/golden/parquet_ref, cut from /root/reference/tests/data by
+tests/golden/make_parquet_ref_golden.py) and the checks of a decoder's output against what the REFERENCE's sqllogictests print for those
+files. `decode(ch, out_type) -> (python values, valid)` is the decoder under test: the oracle on the CPU, the device through the C-ABI."""
+import datetime
+import glob
+import json
+import os
+
+import numpy as np
+
+from databend_amd import _lib as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_OF_PHYS = {0: T.T_BOOL, 1: T.T_I32, 2: T.T_I64, 4: T.T_F32, 5: T.T_F64, 6: T.T_STRING}
+
+
+def fixtures():
+    out = {}
+    for f in sorted(glob.glob(os.path.join(HERE, "golden", "parquet_ref", "*.json"))):
+        d = json.load(open(f))
+        blob = open(f[:-5] + ".bin", "rb").read()
+        for ch in d["chunks"]:
+            ch["chunk"] = blob[ch["offset"]:ch["offset"] + ch["length"]]
+        out[os.path.basename(f)[:-5]] = d
+    return out
+
+
+def column(d, name, decode):
+    """all row groups of one column, concatenated"""
+    vals = []
+    for ch in d["chunks"]:
+        if ch["column"] != name:
+            continue
+        v, valid = decode(ch, OUT_OF_PHYS[ch["physical"]])
+        assert valid.all()
+        vals += v
+    return vals
+
+
+def render(v, kind):
+    """a decoded value as the reference's sqllogictest prints it"""
+    if kind == "bool":
+        return "1" if v else "0"
+    if kind in ("f32", "f64"):
+        x = float(np.frombuffer(v, np.float32 if kind == "f32" else np.float64)[0])
+        return repr(round(x, 6)) if kind == "f32" else repr(x)      # (f32 1.1 prints as 1.1: shortest round-trip of the f32)
+    if kind == "str":
+        return v.decode()
+    if kind == "ts_ns":
+        t = datetime.datetime(1970, 1, 1) + datetime.timedelta(microseconds=v // 1000)
+        return t.strftime("%Y-%m-%d %H:%M:%S.%f")
+    return str(v)
+
+
+def check_all(decode):
+    fx = fixtures()
+    checked = 0
+    # alltypes_plain: the whole table the reference prints (select_parquet.test:6-16)
+    d = fx["alltypes_plain"]
+    kinds = {"id": "int", "bool_col": "bool", "tinyint_col": "int", "smallint_col": "int", "int_col": "int", "bigint_col": "int", "float_col": "f32",
+             "double_col": "f64", "date_string_col": "str", "string_col": "str", "timestamp_col": "ts_ns"}
+    for name, kind in kinds.items():
+        got = [render(v, kind) for v in column(d, name, decode)]
+        assert got == d["expected"][name], (name, got, d["expected"][name])
+        checked += 1
+    # binary_view.parquet, written by parquet-rs 58.1.0 (parquet_field_types.test:214-219): the binary column in hex
+    d = fx["binary_view"]
+    got = [v.hex().upper() for v in column(d, d["chunks"][0]["column"], decode)]
+    assert got == d["expected"]["hex"], got
+    checked += 1
+    # timestamp_{s,ms,us,ns}: four distinct instants, 300 rows each over the 8 row groups (timestamp.test:1-36)
+    for unit in ("s", "ms", "us", "ns"):
+        d = fx["timestamp_" + unit]
+        vals = column(d, "col_timestamp", decode)
+        per = d["expected"]["units_per_second"]
+        counts = {}
+        for v in vals:
+            assert v % per == 0
+            t = (datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=v // per)).strftime("%Y-%m-%d %H:%M:%S")
+            counts[t] = counts.get(t, 0) + 1
+        assert counts == d["expected"]["groups"], (unit, counts)
+        checked += 1
+    # multi_page_{1..4}: 400 rows over the four files (select_parquet.test:69-72), col_int = 0, 1, 0, 1, ... (gen.py)
+    total = 0
+    for k in (1, 2, 3, 4):
+        d = fx[f"multi_page_{k}"]
+        vals = column(d, "col_int", decode)
+        assert len(vals) == d["expected"]["rows"] and vals == [0, 1] * (len(vals) // 2)
+        total += len(vals)
+        checked += 1
+    assert total == 400
+    # ontime_200 (on_time.test:1-12,54-61)
+    d = fx["ontime_200"]
+    day, tail, month = column(d, "DayofMonth", decode), column(d, "Tail_Number", decode), column(d, "Month", decode)
+    assert len(day) == d["expected"]["rows"] and set(month) == {d["expected"]["month_all"]}
+    assert [t.decode() for t, dd in zip(tail, day) if dd == 1] == d["expected"]["tail_number_where_dayofmonth_1"]
+    checked += 1
+    return checked

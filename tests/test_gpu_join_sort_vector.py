@@ -887,3 +887,34 @@ def test_inner_join_on_sliced_key_columns_and_clustered_keys(gpu, oracle, shape)
     assert Off.ptr % 16 == 8
     sp, sb = j.probe_block(sliced)
     assert np.array_equal(sp, gp) and np.array_equal(sb, gb)
+
+
+@pytest.mark.parametrize("n,dim", [(1, 3), (1000, 16), (3000, 100), (500, 768), (257, 1537)])
+def test_vector_functions_row_by_row_over_two_columns(gpu, oracle, n, dim):
+    """cosine_distance / l1_distance / l2_distance / inner_product / vector_norm over two COLUMNS (scalars/vector.rs:59-260 Array(Float32) and
+    Array(Float64), :490-560 Vector(Float32 | Int8)), one side optionally a constant: within 1e-5 relative of the oracle's statement of
+    distance.rs (the ndarray summation order) for f32 / i8 rows, 1e-12 for the *_64 functions."""
+    rng = np.random.default_rng(n + dim)
+    for elem, dt, tol in ((T.T_F32, np.float32, 1e-5), (T.T_F64, np.float64, 1e-12), (T.T_I8, np.int8, 1e-5)):
+        if dt == np.int8:
+            a, b = rng.integers(-128, 128, (n, dim)).astype(dt), rng.integers(-128, 128, (n, dim)).astype(dt)
+        else:
+            a, b = rng.standard_normal((n, dim)).astype(dt), rng.standard_normal((n, dim)).astype(dt)
+        odt = np.float64 if elem == T.T_F64 else np.float32
+        code = {T.T_F32: 0, T.T_F64: 1, T.T_I8: 2}[elem]
+        for metric in (T.VEC_COSINE, T.VEC_L2, T.VEC_DOT, T.VEC_L1, T.VEC_NORM):
+            for ls, rs in ((False, False), (False, True), (True, False)):
+                if metric == T.VEC_NORM and (ls or rs):
+                    continue
+                la, rb = (a[0] if ls else a), (b[1 % n] if rs else b)
+                got = gpu.vec_distance_rows(metric, la, None if metric == T.VEC_NORM else rb, n, dim, elem, ls, rs)
+                exp = np.zeros(n, odt)
+                la_c, rb_c = np.ascontiguousarray(la), np.ascontiguousarray(rb)
+                oracle.orc_vec_distance_rows(metric, code, la_c.ctypes.data_as(C.c_void_p), int(ls), None if metric == T.VEC_NORM else rb_c.ctypes.data_as(C.c_void_p),
+                                             int(rs), C.c_int64(n), dim, exp.ctypes.data_as(C.c_void_p))
+                scale = np.maximum(1.0, np.abs(exp))
+                if metric == T.VEC_DOT:      # an inner product near zero is judged against the size of its terms
+                    scale = np.maximum(scale, (np.abs(np.atleast_2d(la).astype(np.float64)) * np.abs(np.atleast_2d(rb).astype(np.float64))).sum(-1))
+                assert np.all(np.abs(got.astype(np.float64) - exp.astype(np.float64)) <= tol * scale + 1e-30), (elem, metric, ls, rs)
+    with pytest.raises(T.DbhipError):
+        gpu.vec_distance_rows(T.VEC_L2, np.zeros((2, 4), np.int32), np.zeros((2, 4), np.int32), 2, 4, T.T_I32)

@@ -215,3 +215,18 @@ def test_mutated_chunks_never_fault(gpu):
         pc.close()
         opened += 1
     assert opened > 100 and rejected > 100
+
+
+def test_reference_held_parquet_files_decode_to_what_the_reference_tests_print(gpu):
+    """The scan-side decode PINNED ON THE REFERENCE (not on pyarrow's reader): column chunks of the Parquet files under the reference's
+    tests/data — written by parquet-cpp, parquet-mr and parquet-rs 58.1.0, the crate the reference links — through dbhip_pq_chunk_open /
+    _decode give exactly what the reference's sqllogictests print for those files (select_parquet.test:6-16,69-72,
+    parquet_field_types.test:214-219, timestamp.test:1-36, on_time.test:1-12,54-61): SNAPPY v1 pages, dictionary-encoded INT32 / INT64 /
+    FLOAT / DOUBLE / BYTE_ARRAY, PLAIN Booleans, an uncompressed BYTE_ARRAY with a value longer than 12 bytes, 8-row-group files."""
+    from tests import parquet_ref as PR
+
+    def decode(ch, out_type):
+        py, valid, info = gpu_decode(gpu, ch, out_type)
+        assert info.num_values == ch["num_values"]
+        return py, valid
+    assert PR.check_all(decode) == 21

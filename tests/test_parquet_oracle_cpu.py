@@ -296,3 +296,31 @@ def test_headers_that_claim_absurd_sizes_are_refused_before_memory_is_reserved()
     big = b"\x15" + zz(0) + b"\x15" + zz(3 << 30) + b"\x15" + zz(20) + b"\x2c" + b"\x15" + zz(10) + b"\x15" + zz(0) + b"\x15" + zz(3) + b"\x15" + zz(3) + b"\x00\x00" + b"\x00" * 20
     rc, _ = _open(dict(chunk=big, physical=2, type_length=0, max_def=0, codec=T.PQ_ZSTD), T.T_I64)
     assert rc == T.ERR_INVALID
+
+
+def test_oracle_decodes_the_reference_held_parquet_files_to_what_its_tests_print():
+    """The pin of the scan-side decode that does not go through pyarrow's reader: column chunks cut from the Parquet files the reference
+    keeps under tests/data (written by parquet-cpp, parquet-mr and parquet-rs 58.1.0 — the crate the reference links) must decode to the
+    values the reference's own sqllogictests print (select_parquet.test:6-16,69-72, parquet_field_types.test:214-219, timestamp.test:1-36,
+    on_time.test:1-12,54-61). Fixtures: tests/golden/parquet_ref (make_parquet_ref_golden.py)."""
+    from tests import parquet_ref as PR
+
+    import ctypes as C
+
+    def decode(ch, out_type):
+        from tests import oracle_lib
+        L = oracle_lib.load()
+        L.orc_pq_decode_codec.restype = C.c_int
+        n = ch["num_values"]
+        chunk = np.frombuffer(ch["chunk"], dtype=np.uint8)
+        es = 1 if out_type == T.T_BOOL else PU.ESIZE[out_type]
+        vals = np.zeros(max(n, 1) * es + 16, dtype=np.uint8)
+        valid = np.zeros(max(n, 1), dtype=np.uint8)
+        rows, nulls = C.c_int64(), C.c_int64()
+        rc = L.orc_pq_decode_codec(chunk.ctypes.data_as(C.c_void_p), C.c_int64(len(chunk)), ch["codec"], ch["physical"], ch["type_length"], ch["max_def"],
+                                   out_type, C.c_int64(n), vals.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p), C.byref(rows), C.byref(nulls))
+        assert rc == 0 and rows.value == n, (ch["column"], rc)
+        v = valid[:n].astype(bool)
+        py = [bool(vals[i]) for i in range(n)] if out_type == T.T_BOOL else PU.decoded_to_python(vals.tobytes(), v, out_type, n, chunk)
+        return py, v
+    assert PR.check_all(decode) == 21
