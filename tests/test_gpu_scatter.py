@@ -398,8 +398,7 @@ def test_stream_scratch_is_released_with_the_stream(gpu):
         streams.append(s)
         T.check(L.dbhip_sort_perm(arr, zero, zero, 1, C.c_int64(n), C.c_int64(0), C.c_void_p(perm.ptr), s))
         assert stats()[0] <= 8
-    per_stream = (stats()[1] - b0) / max(stats()[0] - e0, 1)
-    assert stats()[1] <= b0 + 8 * per_stream * 1.01
+    assert stats()[1] <= b0 + 8 * (100 << 20)      # (the LRU may also have evicted older entries of this thread: never more than 8 remain)
     for s in streams:
         T.check(L.dbhip_stream_release_scratch(s))
         T.check(L.dbhip_stream_destroy(s))
