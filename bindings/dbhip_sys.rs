@@ -284,6 +284,8 @@ extern "C" {
     pub fn dbhip_pq_chunk_validity(c: *mut dbhip_pq_chunk, out_ptr_host: *mut *const u8, out_bytes_host: *mut i64) -> i32;
     pub fn dbhip_pq_chunk_image(c: *mut dbhip_pq_chunk, out_ptr_host: *mut *const u8, out_len_host: *mut i64) -> i32;
     pub fn dbhip_pq_chunk_decode(c: *mut dbhip_pq_chunk, chunk_dev: *const u8, out_values_dev: *mut c_void, out_validity_dev: *mut u8, stream: *mut c_void) -> i32;
+    pub fn dbhip_pq_chunk_open_device(chunk_host: *const u8, chunk_len: i64, codec: i32, physical_type: i32, type_length: i32, max_def_level: i32, max_rep_level: i32, out_type: i32, out_host: *mut *mut dbhip_pq_chunk, info_host: *mut dbhip_pq_info) -> i32;
+    pub fn dbhip_pq_chunk_decode_device(c: *mut dbhip_pq_chunk, chunk_dev: *const u8, image_dev: *mut u8, out_values_dev: *mut c_void, out_validity_dev: *mut u8, out_nulls_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_pq_chunk_close(c: *mut dbhip_pq_chunk) -> i32;
     pub fn dbhip_hnsw_build(vectors_dev: *const f32, n: i64, dim: i32, distance: i32, m: i32, ef_construct: i32, seed: u64, out: *mut *mut dbhip_hnsw, stream: *mut c_void) -> i32;
     pub fn dbhip_hnsw_build_sequential(vectors_dev: *const f32, n: i64, dim: i32, distance: i32, m: i32, ef_construct: i32, levels_host: *const i32, out: *mut *mut dbhip_hnsw, stream: *mut c_void) -> i32;

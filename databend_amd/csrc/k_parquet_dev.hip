@@ -1,0 +1,875 @@
+// k_parquet_dev.hip — scan side, DEVICE mode: the page payload of a Parquet column chunk never passes through
+// the host.
+//
+// Stands where the reference hands a block's raw column chunks to arrow-rs (column_chunks_to_record_batch,
+// src/query/storages/fuse/src/io/read/block/parquet/deserialize.rs:33-81, then block_reader_parquet_deserialize.rs) — the same
+// boundary as k_parquet.hip, whose open() walks run headers, length prefixes and (for compressed chunks) decompresses every page
+// on the CPU. Here the host reads the thrift PAGE HEADERS only (a few dozen bytes per page: sizes, value counts, encodings) and
+// uploads that page table; everything that touches payload bytes runs on the GPU from the HBM copy of the chunk as stored:
+//   dv_inflate_kernel   one wave per page: Snappy raw format (google/snappy format_description.txt) or LZ4 block format
+//                       (lz4_Block_format.md) -> the decompressed IMAGE in HBM. The sequence stream is inherently serial, so the
+//                       wave parses it from an LDS-staged copy of the input and keeps the last 64 KiB of output in an LDS ring
+//                       (both formats' back-references reach at most 65535 bytes with the writers the reference links: snap
+//                       compresses 64 KiB blocks, LZ4 offsets are 16 bits); literal and match bytes are moved by the 64 lanes,
+//                       the ring is written to HBM 16 KiB at a time with 16-byte stores.
+//   dv_levels_kernel    one workgroup per data page of a nullable column: the RLE / bit-packed hybrid walk of the definition
+//                       levels (Encodings.md "RLE/bit-packing hybrid") -> validity bits at the page's rows + the page's count
+//                       of non-null values.
+//   dv_scan_kernel      exclusive scan of those counts: where each page's values start among the non-null values.
+//   dv_dict_kernel      the dictionary page -> dictionary in the output type (PLAIN; BYTE_ARRAY: the length-prefix chain).
+//   dv_values_kernel    one workgroup per data page: PLAIN (fixed width, BOOLEAN bits, BYTE_ARRAY length chain -> 16-byte views
+//                       that point into the image), PLAIN_DICTIONARY / RLE_DICTIONARY (hybrid walk of the indices + gather), RLE
+//                       booleans, DELTA_BINARY_PACKED (INT32 / INT64: block / miniblock walk, workgroup prefix sum of the deltas).
+//   pq_popc / scan / pq_spread (pq_common.h)   nullable columns: dense values -> rows.
+// Nothing is validated on the host beyond the page table, so every device access is checked against the page payload, the
+// dictionary and the output size; the first violation is recorded in a device word and decode returns DBHIP_ERR_INVALID.
+// ZSTD pages (FSE / Huffman entropy stages) stay with dbhip_pq_chunk_open (host libzstd): DBHIP_ERR_UNSUPPORTED here.
+#include "pq_common.h"
+
+namespace {
+
+enum { DV_OK = 0, DV_CORRUPT = 1, DV_UNSUPPORTED = 2 };
+enum { ENC_DELTA_BINARY_PACKED = 5 };
+enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_ZSTD = 6, CODEC_LZ4_RAW = 7 };
+
+__device__ __forceinline__ void dv_fail(uint32_t* ctl, uint32_t code) { atomicCAS(&ctl[0], 0u, code); }
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ---------------------------------------------------------------------------------------------
+// page decompression: one wave per page
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t DW = 65536, DWM = DW - 1;    // output ring (the window back-references read from)
+constexpr uint32_t DI = 8192, DIM = DI - 1;     // input ring
+constexpr uint32_t DV_PIECE = 4096;             // bytes moved between two looks at the flush / refill state
+constexpr uint32_t DV_FLUSH = 16384;            // ring bytes written to HBM at a time
+
+struct DvInflate {
+  const uint8_t* srcA;      // 16-byte aligned address at or before the first compressed byte
+  uint32_t q, qend, qload;  // read position / end of input / staged up to (bytes from srcA)
+  uint8_t* dst;             // output in HBM
+  uint32_t cap, op, flushed, sh;  // output size / write position / written to HBM up to / (dst & 15): ring index of byte p = (p + sh) & DWM
+  uint8_t* win;
+  uint8_t* inb;
+  uint32_t lane;
+  bool bad;
+
+  __device__ __forceinline__ void refill() {
+    // as many 1 KiB rows as fit in front of q (everything in [q, qload) stays staged)
+    while (qload < qend && qload + 1024 - (q & ~15u) <= DI) {
+      const uint32_t a = qload + lane * 16;
+      if (a < qend) *(uint4*)(inb + (a & DIM)) = *(const uint4*)(srcA + a);
+      qload += 1024;
+    }
+  }
+  __device__ __forceinline__ void need(uint32_t n) {
+    const uint32_t want = (qend - q) < n ? qend : q + n;
+    if (qload < want) refill();
+  }
+  // byte k after the read position (the caller made sure q + k < qend and called need())
+  __device__ __forceinline__ uint32_t in(uint32_t k) const { return uni((uint32_t)inb[(q + k) & DIM]); }
+
+  __device__ __forceinline__ void flush(bool force) {
+    const uint32_t target = op;
+    const uint32_t a = (flushed + sh) & 15u;
+    if (a && flushed < target) {
+      const uint32_t h = (16 - a) < (target - flushed) ? (16 - a) : (target - flushed);
+      if (lane < h) dst[flushed + lane] = win[(flushed + sh + lane) & DWM];
+      flushed += h;
+    }
+    const uint32_t nvec = (target - flushed) >> 4;
+    if (((flushed + sh) & 15u) == 0) {
+      for (uint32_t v = lane; v < nvec; v += 64)
+        *(uint4*)(dst + flushed + 16 * v) = *(const uint4*)(win + ((flushed + sh + 16 * v) & DWM));
+      flushed += nvec << 4;
+    }
+    if (force) {
+      for (uint32_t i = flushed + lane; i < target; i += 64) dst[i] = win[(i + sh) & DWM];
+      flushed = target;
+    }
+  }
+  // `len` input bytes -> output
+  __device__ __forceinline__ void literal(uint32_t len) {
+    if (len > cap - op) { bad = true; return; }
+    while (len) {
+      if (q >= qend) { bad = true; return; }
+      need(DV_PIECE);
+      uint32_t n = (qload < qend ? qload : qend) - q;
+      if (n > len) n = len;
+      if (n > DV_PIECE) n = DV_PIECE;
+      for (uint32_t i = lane; i < n; i += 64) win[(op + sh + i) & DWM] = inb[(q + i) & DIM];
+      __builtin_amdgcn_wave_barrier();
+      q += n; op += n; len -= n;
+      if (op - flushed >= DV_FLUSH) flush(false);
+    }
+  }
+  // `len` bytes that repeat the output `off` bytes back (they may overlap what is being written: byte i = byte i - off)
+  __device__ __forceinline__ void match(uint32_t len, uint32_t off) {
+    if (off == 0 || off > op || off > 65535u || len > cap - op) { bad = true; return; }
+    while (len) {
+      const uint32_t n = len < DV_PIECE ? len : DV_PIECE;
+      for (uint32_t b = 0; b < n; b += 64) {
+        // by periodicity out[cur + l] = out[cur - off + (l mod off)]: every source lies before `cur`, so the 64 lanes read
+        // (one LDS instruction) before any of them writes
+        const uint32_t cur = op + b;
+        const uint32_t j = off >= 64 ? lane : lane % off;
+        if (b + lane < n) {
+          const uint8_t v = win[(cur - off + j + sh) & DWM];
+          win[(cur + lane + sh) & DWM] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      op += n; len -= n;
+      if (op - flushed >= DV_FLUSH) flush(false);
+    }
+  }
+};
+
+__global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict__ pages, const uint8_t* __restrict__ chunk,
+                                                        uint8_t* __restrict__ image, int codec, uint32_t* __restrict__ ctl) {
+  extern __shared__ __align__(16) uint8_t dv_lds[];
+  const DvPage P = pages[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  const uint8_t* src = chunk + P.src_off;
+  uint8_t* dst = image + P.img_off;
+  const uint32_t lev = P.lev_len;
+  // levels of a v2 page / a payload stored uncompressed: copied as they are
+  const uint32_t raw = P.compressed ? lev : P.uncomp_len;
+  for (uint32_t i = lane; i < raw; i += 64) dst[i] = src[i];
+  if (!P.compressed || P.uncomp_len == lev) return;
+  DvInflate z;
+  const uint8_t* s0 = src + lev;
+  const uint32_t a0 = (uint32_t)((uintptr_t)s0 & 15u);
+  z.srcA = s0 - a0;
+  z.q = a0; z.qend = a0 + (P.comp_len - lev); z.qload = 0;
+  z.dst = dst + lev; z.cap = P.uncomp_len - lev; z.op = 0; z.flushed = 0; z.sh = (uint32_t)((uintptr_t)z.dst & 15u);
+  z.win = dv_lds; z.inb = dv_lds + DW; z.lane = lane; z.bad = false;
+  z.refill();
+  if (codec == CODEC_SNAPPY) {
+    // preamble: the uncompressed length as a varint
+    uint64_t total = 0;
+    bool fin = false;
+    for (int k = 0; k < 5 && z.q < z.qend; ++k) {
+      const uint32_t b = z.in(0);
+      z.q += 1;
+      total |= (uint64_t)(b & 0x7F) << (7 * k);
+      if (!(b & 0x80)) { fin = true; break; }
+    }
+    if (!fin || total != (uint64_t)z.cap) z.bad = true;
+    while (!z.bad && z.q < z.qend) {
+      z.need(8);
+      const uint32_t left = z.qend - z.q;
+      const uint32_t tag = z.in(0);
+      const uint32_t kind = tag & 3u;
+      if (kind == 0) {
+        uint32_t len = (tag >> 2) + 1, hdr = 1;
+        if (len > 60) {
+          const uint32_t extra = len - 60;  // 1..4 length bytes
+          if (left < 1 + extra) { z.bad = true; break; }
+          uint32_t v = 0;
+          for (uint32_t b = 0; b < extra; ++b) v |= z.in(1 + b) << (8 * b);
+          if (v == 0xFFFFFFFFu) { z.bad = true; break; }
+          len = v + 1;
+          hdr = 1 + extra;
+        }
+        z.q += hdr;
+        z.literal(len);
+      } else if (kind == 1) {
+        if (left < 2) { z.bad = true; break; }
+        const uint32_t len = ((tag >> 2) & 7u) + 4, off = ((tag >> 5) << 8) | z.in(1);
+        z.q += 2;
+        z.match(len, off);
+      } else if (kind == 2) {
+        if (left < 3) { z.bad = true; break; }
+        const uint32_t len = (tag >> 2) + 1, off = z.in(1) | (z.in(2) << 8);
+        z.q += 3;
+        z.match(len, off);
+      } else {
+        if (left < 5) { z.bad = true; break; }
+        const uint32_t len = (tag >> 2) + 1, off = z.in(1) | (z.in(2) << 8) | (z.in(3) << 16) | (z.in(4) << 24);
+        z.q += 5;
+        if (off > 65535u && off <= z.op) { dv_fail(ctl, DV_UNSUPPORTED); return; }  // legal, but no writer the reference links emits it
+        z.match(len, off);
+      }
+    }
+  } else {  // LZ4 block format
+    while (!z.bad && z.q < z.qend) {
+      z.need(8);
+      const uint32_t token = z.in(0);
+      z.q += 1;
+      uint32_t lit = token >> 4;
+      if (lit == 15) {
+        for (;;) {
+          if (z.q >= z.qend) { z.bad = true; break; }
+          z.need(8);
+          const uint32_t b = z.in(0);
+          z.q += 1;
+          if (lit > 0x7FFFFFFFu - b) { z.bad = true; break; }
+          lit += b;
+          if (b != 255) break;
+        }
+        if (z.bad) break;
+      }
+      if (lit) z.literal(lit);
+      if (z.bad || z.q >= z.qend) break;  // the last sequence ends with its literals
+      z.need(8);
+      if (z.qend - z.q < 2) { z.bad = true; break; }
+      const uint32_t off = z.in(0) | (z.in(1) << 8);
+      z.q += 2;
+      uint32_t ml = token & 15u;
+      if (ml == 15) {
+        for (;;) {
+          if (z.q >= z.qend) { z.bad = true; break; }
+          z.need(8);
+          const uint32_t b = z.in(0);
+          z.q += 1;
+          if (ml > 0x7FFFFFFFu - b - 4) { z.bad = true; break; }
+          ml += b;
+          if (b != 255) break;
+        }
+        if (z.bad) break;
+      }
+      z.match(ml + 4, off);
+    }
+  }
+  if (!z.bad && z.op != z.cap) z.bad = true;
+  z.flush(true);
+  if (z.bad) dv_fail(ctl, DV_CORRUPT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RLE / bit-packed hybrid streams, walked by a whole workgroup (every thread follows the same headers)
+// ---------------------------------------------------------------------------------------------
+// up to 8 bytes at s[pos ..) as a little-endian word; bytes at or past `len` read as 0
+__device__ __forceinline__ uint64_t dv_peek8(const uint8_t* __restrict__ s, uint32_t pos, uint32_t len) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (pos + (uint32_t)k < len) v |= (uint64_t)s[pos + k] << (8 * k);
+  return v;
+}
+
+// varint at s[*pos ..): false when it runs past `len` or is longer than 8 bytes (56 bits: no count in a page needs more)
+__device__ __forceinline__ bool dv_varint(const uint8_t* __restrict__ s, uint32_t* pos, uint32_t len, uint64_t* out) {
+  const uint64_t w = dv_peek8(s, *pos, len);
+  uint64_t v = 0;
+  for (int k = 0; k < 8; ++k) {
+    if (*pos + (uint32_t)k >= len) return false;
+    const uint32_t b = (uint32_t)(w >> (8 * k)) & 0xFFu;
+    v |= (uint64_t)(b & 0x7F) << (7 * k);
+    if (!(b & 0x80)) { *pos += (uint32_t)k + 1; *out = v; return true; }
+  }
+  return false;
+}
+
+// rle(first, n, value) / bp(first, n, packed bytes): called by every thread of the workgroup with the same arguments
+template <class Rle, class Bp>
+__device__ __forceinline__ bool dv_walk_hybrid(const uint8_t* __restrict__ s, uint32_t len, int bitw, uint32_t nvals, Rle&& rle, Bp&& bp) {
+  uint32_t pos = 0, done = 0;
+  const uint32_t vbytes = (uint32_t)(bitw + 7) >> 3;
+  while (done < nvals) {
+    uint64_t h;
+    if (!dv_varint(s, &pos, len, &h)) return false;
+    const uint32_t avail = len - pos;
+    if (h & 1) {
+      const uint64_t groups = h >> 1;
+      if (groups == 0 || groups > 0x1FFFFFFFull) return false;
+      uint64_t n64 = groups * 8;
+      const uint32_t n = n64 > (uint64_t)(nvals - done) ? nvals - done : (uint32_t)n64;
+      if ((uint64_t)n * (uint64_t)bitw > (uint64_t)avail * 8) return false;  // the bytes present cover the n values that are expanded
+      bp(done, n, s + pos);
+      const uint64_t bytes = groups * (uint64_t)bitw;
+      pos += bytes < (uint64_t)avail ? (uint32_t)bytes : avail;
+      done += n;
+    } else {
+      const uint64_t n64 = h >> 1;
+      if (n64 == 0 || avail < vbytes) return false;
+      const uint64_t w = dv_peek8(s, pos, len);
+      const uint64_t v = vbytes >= 8 ? w : (w & ((1ull << (8 * vbytes)) - 1));
+      pos += vbytes;
+      if (bitw < 64 && (v >> bitw) != 0) return false;
+      const uint32_t n = n64 > (uint64_t)(nvals - done) ? nvals - done : (uint32_t)n64;
+      rle(done, n, (uint32_t)v);
+      done += n;
+    }
+  }
+  return true;
+}
+
+// bits [dst0, dst0 + n) of the zeroed LSB-first bitmap := the first n bits of `src` (packed, bit width 1; src == nullptr: ones).
+// Returns this thread's share of the number of ones. Called by all `nthr` threads.
+__device__ __forceinline__ uint32_t dv_put_bits(uint32_t* __restrict__ bitmap, uint64_t dst0, uint32_t n, const uint8_t* __restrict__ src,
+                                                uint32_t tid, uint32_t nthr) {
+  if (n == 0) return 0;
+  uint32_t ones = 0;
+  const uint64_t first_word = dst0 >> 5, last_word = (dst0 + n - 1) >> 5;
+  for (uint64_t w = first_word + tid; w <= last_word; w += nthr) {
+    const uint64_t lo = w << 5;
+    const uint64_t a = lo > dst0 ? lo : dst0;
+    const uint64_t e = (lo + 32 < dst0 + n) ? lo + 32 : dst0 + n;
+    const int nb = (int)(e - a);
+    uint32_t bits;
+    if (!src) {
+      bits = (nb == 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)) << (a - lo);
+    } else {
+      const uint64_t s0 = a - dst0;
+      const uint8_t* p = src + (s0 >> 3);
+      const int sh = (int)(s0 & 7);
+      const uint64_t v = load_le(p, (sh + nb + 7) >> 3);
+      bits = (uint32_t)((v >> sh) & (nb == 32 ? 0xFFFFFFFFull : ((1ull << nb) - 1))) << (a - lo);
+    }
+    if (bits) {
+      if (nb == 32) bitmap[w] = bits; else atomicOr(&bitmap[w], bits);
+      ones += (uint32_t)__popc(bits);
+    }
+  }
+  return ones;
+}
+
+__device__ __forceinline__ uint32_t dv_block_sum(uint32_t v, uint32_t* sh4) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+// definition levels of one data page -> validity bits + the page's non-null count and the offset of its values
+__global__ __launch_bounds__(256) void dv_levels_kernel(const DvPage* __restrict__ pages, const uint32_t* __restrict__ dp,
+                                                        const uint8_t* __restrict__ img, uint32_t* __restrict__ nn,
+                                                        uint32_t* __restrict__ voff, uint32_t* __restrict__ bitmap,
+                                                        uint32_t* __restrict__ ctl) {
+  __shared__ uint32_t sh4[4];
+  const uint32_t d = blockIdx.x;
+  const DvPage P = pages[dp[d]];
+  const uint8_t* s = img + P.img_off;
+  uint32_t len, vo;
+  const uint8_t* stream;
+  if (P.type == PG_DATA) {
+    if (P.uncomp_len < 4) { dv_fail(ctl, DV_CORRUPT); if (threadIdx.x == 0) { nn[d] = 0; voff[d] = P.uncomp_len; } return; }
+    len = (uint32_t)load_le(s, 4);
+    if (len > P.uncomp_len - 4) { dv_fail(ctl, DV_CORRUPT); if (threadIdx.x == 0) { nn[d] = 0; voff[d] = P.uncomp_len; } return; }
+    stream = s + 4;
+    vo = 4 + len;
+  } else {
+    len = P.lev_len;  // (the host checked lev_len <= uncomp_len)
+    stream = s;
+    vo = len;
+  }
+  uint32_t mine = 0, runs = 0;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t r0 = P.row_start;
+  const bool ok = dv_walk_hybrid(
+      stream, len, 1, P.num_values,
+      [&](uint32_t first, uint32_t n, uint32_t v) {
+        if (v == 1) { (void)dv_put_bits(bitmap, r0 + first, n, nullptr, tid, 256); runs += n; }
+      },
+      [&](uint32_t first, uint32_t n, const uint8_t* src) { mine += dv_put_bits(bitmap, r0 + first, n, src, tid, 256); });
+  const uint32_t total = dv_block_sum(mine, sh4) + runs;
+  if (!ok) dv_fail(ctl, DV_CORRUPT);
+  if (tid == 0) { nn[d] = ok ? total : 0; voff[d] = ok ? vo : P.uncomp_len; }
+}
+
+// vbase[d] = number of non-null values in the data pages before d; vbase[n] = all of them
+__global__ __launch_bounds__(256) void dv_scan_kernel(const uint32_t* __restrict__ nn, uint32_t n, uint64_t* __restrict__ vbase) {
+  __shared__ uint64_t wt[4];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t c = 0; c < n; c += 256) {
+    const uint32_t i = c + threadIdx.x;
+    uint64_t v = i < n ? nn[i] : 0, incl = v;
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const uint64_t t = __shfl_up(incl, dd, 64);
+      if ((int)(threadIdx.x & 63) >= dd) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wt[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t wb = carry;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) wb += wt[k];
+    if (i < n) vbase[i] = wb + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = wb + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) vbase[n] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// values
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SW_TILE = 16384;  // bytes of a BYTE_ARRAY page staged in LDS at a time
+
+struct DvStrShared {
+  uint32_t queue[256];
+  uint32_t cur, cnt, err;
+  __align__(16) uint8_t tile[SW_TILE];
+};
+
+// PLAIN BYTE_ARRAY: `count` values at img[base ..) (region of `rlen` bytes) -> views out[o0 ..). The chain of 4-byte length
+// prefixes is serial: the region is staged in LDS 16 KiB at a time, thread 0 follows the lengths inside the staged tile (an LDS
+// round trip per value instead of an L2 one) and queues up to 256 value offsets, then every thread turns one offset into a view.
+__device__ bool dv_walk_strings(const uint8_t* __restrict__ img, uint64_t base, uint32_t rlen, uint32_t count, void* __restrict__ out,
+                                uint64_t o0, DvStrShared* S) {
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) { S->cur = 0; S->err = 0; }
+  __syncthreads();
+  uint32_t k = 0;
+  while (k < count) {
+    const uint32_t cur0 = S->cur;
+    // stage [cur0, cur0 + SW_TILE) of the region, from the 16-byte aligned address at or before it
+    const uint8_t* p0 = img + base + cur0;
+    const uint32_t x0 = (uint32_t)((uintptr_t)p0 & 15u);
+    const uint8_t* pa = p0 - x0;
+    const uint32_t have = rlen - cur0 + x0;  // staged bytes that belong to the region (+ the x0 bytes in front)
+    __syncthreads();
+    for (uint32_t x = tid * 16; x < SW_TILE && x < have; x += 256 * 16) *(uint4*)(S->tile + x) = *(const uint4*)(pa + x);
+    __syncthreads();
+    // several rounds of (walk, emit) per staged tile
+    for (;;) {
+      if (tid == 0) {
+        uint32_t cur = S->cur, c = 0, e = 0;
+        while (k + c < count && c < 256) {
+          const uint32_t x = cur - cur0 + x0;
+          if (x + 4 > SW_TILE) break;  // the next length prefix is not (entirely) staged
+          if (rlen - cur < 4) { e = 1; break; }
+          uint32_t len;
+          memcpy(&len, S->tile + x, 4);
+          if (rlen - cur - 4 < len) { e = 1; break; }
+          S->queue[c++] = cur + 4;
+          cur += 4 + len;
+        }
+        S->cur = cur; S->cnt = c; S->err = e;
+      }
+      __syncthreads();
+      const uint32_t c = S->cnt;
+      if (S->err) return false;
+      if (tid < c) store_view(img, (uint32_t)(base + S->queue[tid]), out, o0 + k + tid);
+      k += c;
+      __syncthreads();
+      if (c == 0 || k >= count) break;  // c == 0: restage from S->cur (its prefix then lies at x0 <= 15: the walk advances)
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ void dv_store_int(const PqConv& cv, void* out, uint64_t o, uint64_t v) {
+  if (cv.physical == PT_INT32) {
+    const uint32_t x = (uint32_t)v;
+    switch (cv.esize) {
+      case 1: ((uint8_t*)out)[o] = (uint8_t)x; break;
+      case 2: ((uint16_t*)out)[o] = (uint16_t)x; break;
+      case 4: ((uint32_t*)out)[o] = x; break;
+      default: ((int64_t*)out)[o] = (int64_t)(int32_t)x; break;
+    }
+  } else if (cv.esize == 16) {
+    ((i128*)out)[o] = (i128)(int64_t)v;
+  } else {
+    ((uint64_t*)out)[o] = v;
+  }
+}
+
+__device__ __forceinline__ uint64_t dv_unpack64(const uint8_t* __restrict__ src, uint32_t i, uint32_t b) {
+  if (b == 0) return 0;
+  const uint64_t bit = (uint64_t)i * b;
+  const uint8_t* p = src + (bit >> 3);
+  const uint32_t sh = (uint32_t)(bit & 7);
+  const uint32_t nb = (sh + b + 7) >> 3;  // <= 9
+  uint64_t v = load_le(p, nb < 8 ? (int)nb : 8) >> sh;
+  if (nb > 8) v |= (uint64_t)p[8] << (64 - sh);
+  return b >= 64 ? v : (v & ((1ull << b) - 1));
+}
+
+struct DvDeltaShared {
+  uint64_t wt[4];
+};
+
+// DELTA_BINARY_PACKED (Encodings.md): <block size> <miniblocks per block> <total count> <first value>, then per block
+// <min delta> <bit width per miniblock> <miniblocks>. `count` values -> out[o0 ..).
+__device__ bool dv_delta(const uint8_t* __restrict__ s, uint32_t rlen, uint32_t count, const PqConv& cv, void* __restrict__ out, uint64_t o0,
+                         DvDeltaShared* S) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t pos = 0;
+  uint64_t bs, mb, total, zz;
+  if (!dv_varint(s, &pos, rlen, &bs) || !dv_varint(s, &pos, rlen, &mb) || !dv_varint(s, &pos, rlen, &total) || !dv_varint(s, &pos, rlen, &zz))
+    return false;
+  if (mb == 0 || mb > 4096 || bs == 0 || bs > (1u << 24) || bs % mb != 0) return false;
+  const uint32_t vpm = (uint32_t)(bs / mb);
+  if (vpm % 8 != 0) return false;
+  if (total < (uint64_t)count) return false;
+  if (count == 0) return true;
+  uint64_t last = (zz >> 1) ^ (0 - (zz & 1));
+  if (tid == 0) dv_store_int(cv, out, o0, last);
+  uint32_t produced = 1;
+  while (produced < count) {
+    uint64_t mz;
+    if (!dv_varint(s, &pos, rlen, &mz)) return false;
+    const uint64_t min_delta = (mz >> 1) ^ (0 - (mz & 1));
+    if (rlen - pos < (uint32_t)mb) return false;
+    const uint32_t bwpos = pos;
+    pos += (uint32_t)mb;
+    for (uint32_t m = 0; m < (uint32_t)mb && produced < count; ++m) {
+      const uint32_t b = s[bwpos + m];
+      if (b > 64) return false;
+      const uint32_t need = (count - produced) < vpm ? (count - produced) : vpm;
+      const uint64_t need_bytes = ((uint64_t)need * b + 7) >> 3;
+      if ((uint64_t)(rlen - pos) < need_bytes) return false;
+      for (uint32_t c0 = 0; c0 < need; c0 += 256) {
+        const uint32_t i = c0 + tid;
+        const uint64_t dlt = i < need ? min_delta + dv_unpack64(s + pos, i, b) : 0;
+        uint64_t incl = dlt;
+        for (int dd = 1; dd < 64; dd <<= 1) {
+          const uint64_t t = __shfl_up(incl, dd, 64);
+          if ((int)(tid & 63) >= dd) incl += t;
+        }
+        __syncthreads();
+        if ((tid & 63) == 63) S->wt[tid >> 6] = incl;
+        __syncthreads();
+        uint64_t wb = last;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) wb += S->wt[w];
+        if (i < need) dv_store_int(cv, out, o0 + produced + i, wb + incl);
+        last += S->wt[0] + S->wt[1] + S->wt[2] + S->wt[3];
+      }
+      const uint64_t mbytes = ((uint64_t)vpm * b) >> 3;
+      pos += mbytes < (uint64_t)(rlen - pos) ? (uint32_t)mbytes : rlen - pos;
+      produced += need;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ void dv_put_dict(const PqConv& cv, const void* __restrict__ dict, uint32_t idx, void* __restrict__ out, uint64_t o) {
+  switch (cv.esize) {
+    case 1: ((uint8_t*)out)[o] = ((const uint8_t*)dict)[idx]; break;
+    case 2: ((uint16_t*)out)[o] = ((const uint16_t*)dict)[idx]; break;
+    case 4: ((uint32_t*)out)[o] = ((const uint32_t*)dict)[idx]; break;
+    case 8: ((uint64_t*)out)[o] = ((const uint64_t*)dict)[idx]; break;
+    default: ((uint4*)out)[o] = ((const uint4*)dict)[idx]; break;
+  }
+}
+
+union DvValShared {
+  DvStrShared str;
+  DvDeltaShared delta;
+};
+
+// the dictionary page (PLAIN) -> dictionary in the output type
+__global__ __launch_bounds__(256) void dv_dict_kernel(const DvPage* __restrict__ pages, uint32_t page, const uint8_t* __restrict__ img, PqConv cv,
+                                                      void* __restrict__ dict, uint32_t* __restrict__ ctl) {
+  __shared__ DvStrShared S;
+  const DvPage P = pages[page];
+  if (P.num_values == 0) return;
+  if (cv.physical == PT_BYTE_ARRAY) {
+    if (!dv_walk_strings(img, P.img_off, P.uncomp_len, P.num_values, dict, 0, &S)) dv_fail(ctl, DV_CORRUPT);
+    return;
+  }
+  const uint32_t w = (uint32_t)plain_width(cv.physical, cv.type_length);
+  if (w == 0 || P.uncomp_len / w < P.num_values) { dv_fail(ctl, DV_CORRUPT); return; }
+  for (uint32_t i = threadIdx.x; i < P.num_values; i += 256) store_plain(cv, img + P.img_off + (uint64_t)i * w, dict, i);
+}
+
+// one workgroup per (data page, slice): blockIdx.y splits PLAIN fixed-width pages; the serial encodings run in slice 0
+__global__ __launch_bounds__(256) void dv_values_kernel(const DvPage* __restrict__ pages, const uint32_t* __restrict__ dp,
+                                                        const uint8_t* __restrict__ img, const uint32_t* __restrict__ nn,
+                                                        const uint32_t* __restrict__ voff, const uint64_t* __restrict__ vbase, PqConv cv,
+                                                        const void* __restrict__ dict, uint32_t dict_n, void* __restrict__ out,
+                                                        uint64_t out_cap, uint32_t* __restrict__ ctl) {
+  __shared__ DvValShared S;
+  const uint32_t d = blockIdx.x, tid = threadIdx.x;
+  const DvPage P = pages[dp[d]];
+  const uint32_t n = nn[d], vo = voff[d];
+  const uint64_t o0 = vbase[d];
+  if (n == 0) return;
+  if (vo > P.uncomp_len || n > P.num_values || o0 + n > out_cap) { dv_fail(ctl, DV_CORRUPT); return; }
+  const uint8_t* s = img + P.img_off + vo;
+  const uint32_t rlen = P.uncomp_len - vo;
+  const uint32_t enc = P.enc;
+  if (enc == ENC_PLAIN && cv.physical != PT_BOOLEAN && cv.physical != PT_BYTE_ARRAY) {
+    const uint32_t w = (uint32_t)plain_width(cv.physical, cv.type_length);
+    if (w == 0 || rlen / w < n) { dv_fail(ctl, DV_CORRUPT); return; }
+    const uint32_t lo = (uint32_t)((uint64_t)n * blockIdx.y / gridDim.y), hi = (uint32_t)((uint64_t)n * (blockIdx.y + 1) / gridDim.y);
+    for (uint32_t i = lo + tid; i < hi; i += 256) store_plain(cv, s + (uint64_t)i * w, out, o0 + i);
+    return;
+  }
+  if (blockIdx.y != 0) return;
+  bool ok = true;
+  if (enc == ENC_PLAIN && cv.physical == PT_BOOLEAN) {
+    if ((uint64_t)rlen * 8 < n) { dv_fail(ctl, DV_CORRUPT); return; }
+    (void)dv_put_bits((uint32_t*)out, o0, n, s, tid, 256);
+  } else if (enc == ENC_PLAIN) {
+    ok = dv_walk_strings(img, P.img_off + vo, rlen, n, out, o0, &S.str);
+  } else if (enc == ENC_PLAIN_DICT || enc == ENC_RLE_DICT) {
+    if (rlen < 1 || dict_n == 0 || !dict) { dv_fail(ctl, DV_CORRUPT); return; }
+    const int bitw = s[0];
+    if (bitw > 32) { dv_fail(ctl, DV_CORRUPT); return; }
+    ok = dv_walk_hybrid(
+        s + 1, rlen - 1, bitw, n,
+        [&](uint32_t first, uint32_t cnt, uint32_t v) {
+          const uint32_t idx = v < dict_n ? v : dict_n - 1;
+          for (uint32_t i = tid; i < cnt; i += 256) dv_put_dict(cv, dict, idx, out, o0 + first + i);
+        },
+        [&](uint32_t first, uint32_t cnt, const uint8_t* src) {
+          for (uint32_t i = tid; i < cnt; i += 256) {
+            uint32_t idx = extract_bits(src, i, bitw);
+            if (idx >= dict_n) idx = dict_n - 1;
+            dv_put_dict(cv, dict, idx, out, o0 + first + i);
+          }
+        });
+  } else if (enc == ENC_RLE && cv.physical == PT_BOOLEAN) {
+    if (rlen < 4) { dv_fail(ctl, DV_CORRUPT); return; }
+    const uint32_t len = (uint32_t)load_le(s, 4);
+    if (len > rlen - 4) { dv_fail(ctl, DV_CORRUPT); return; }
+    ok = dv_walk_hybrid(
+        s + 4, len, 1, n,
+        [&](uint32_t first, uint32_t cnt, uint32_t v) { if (v == 1) (void)dv_put_bits((uint32_t*)out, o0 + first, cnt, nullptr, tid, 256); },
+        [&](uint32_t first, uint32_t cnt, const uint8_t* src) { (void)dv_put_bits((uint32_t*)out, o0 + first, cnt, src, tid, 256); });
+  } else if (enc == ENC_DELTA_BINARY_PACKED && (cv.physical == PT_INT32 || cv.physical == PT_INT64)) {
+    ok = dv_delta(s, rlen, n, cv, out, o0, &S.delta);
+  } else {
+    dv_fail(ctl, DV_UNSUPPORTED);
+    return;
+  }
+  if (!ok) dv_fail(ctl, DV_CORRUPT);
+}
+
+int32_t dv_unsupported(const char* what) {
+  set_error("dbhip_pq_chunk_open_device: %s (use dbhip_pq_chunk_open, or keep the CPU reader for this chunk)", what);
+  return DBHIP_ERR_UNSUPPORTED;
+}
+int32_t dv_malformed(const char* what) {
+  set_error("dbhip_pq_chunk_open_device: malformed column chunk: %s", what);
+  return DBHIP_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
+                                   int32_t max_def_level, int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
+                                   dbhip_pq_info* info_host) {
+  DBHIP_REQUIRE(chunk_host && out_host && chunk_len >= 0, "dbhip_pq_chunk_open_device: NULL argument");
+  *out_host = nullptr;
+  if (codec == CODEC_ZSTD) return dv_unsupported("ZSTD pages are decompressed on the host");
+  if (codec != CODEC_NONE && codec != CODEC_SNAPPY && codec != CODEC_LZ4_RAW)
+    return dv_unsupported("compression codec other than UNCOMPRESSED / SNAPPY / LZ4_RAW");
+  if (max_rep_level != 0 || max_def_level < 0 || max_def_level > 1) return dv_unsupported("nested column (repetition / definition level > 1)");
+  if (chunk_len >= (1LL << 32)) return dv_unsupported("column chunk of 4 GiB or more");
+  if (!type_pair_ok(physical_type, type_length, out_type)) {
+    set_error("dbhip_pq_chunk_open_device: physical type %d (length %d) cannot be decoded into dbhip type %d", physical_type, type_length, out_type);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  dbhip_pq_chunk* c = new (std::nothrow) dbhip_pq_chunk();
+  if (!c) { set_error("dbhip_pq_chunk_open_device: out of host memory"); return DBHIP_ERR_HIP; }
+  c->device_mode = true; c->codec = codec;
+  c->physical = physical_type; c->type_length = type_length; c->max_def = max_def_level; c->out_type = out_type;
+  c->chunk_len = chunk_len; c->rows = 0; c->nulls = -1; c->nonnull = 0; c->n_pages = 0;
+  c->dict_n = -1; c->dict_off = 0; c->dict_bytes = 0;
+  c->d_valid = nullptr; c->d_val = nullptr; c->d_str_off = nullptr; c->d_dict_str_off = nullptr; c->d_dict = nullptr; c->d_dense = nullptr;
+  c->d_wcnt = nullptr; c->d_woff = nullptr; c->d_blk = nullptr; c->uploaded = false; c->n_val_small = 0;
+  Rd r{chunk_host, chunk_host + chunk_len, true};
+  int32_t rc = DBHIP_OK;
+  uint64_t img = 0;
+  bool all_v2_no_nulls = true;
+  while (rc == DBHIP_OK && r.p < r.end) {
+    PageHdr h;
+    if (!read_page_header(r, h)) { rc = dv_malformed("page header"); break; }
+    if ((uint64_t)h.compressed > (uint64_t)(r.end - r.p)) { rc = dv_malformed("page runs past the chunk"); break; }
+    DvPage P{};
+    P.type = (uint32_t)h.type;
+    P.enc = (uint32_t)h.encoding;
+    P.src_off = (uint64_t)(r.p - chunk_host);
+    P.comp_len = (uint32_t)h.compressed;
+    P.uncomp_len = (uint32_t)h.uncompressed;
+    P.def_enc = (uint32_t)h.def_enc;
+    const uint8_t* next = r.p + h.compressed;
+    if (h.type == PG_DICT || h.type == PG_DATA || h.type == PG_DATA_V2) {
+      if (h.num_values < 0) { rc = dv_malformed("page without num_values"); break; }
+      P.num_values = (uint32_t)h.num_values;
+      if (h.type == PG_DATA_V2) {
+        if (h.rep_len != 0) { rc = dv_unsupported("repetition levels"); break; }
+        if (h.def_len < 0) { rc = dv_malformed("level byte length"); break; }
+        P.lev_len = (uint32_t)h.def_len;
+        if (c->max_def == 0 && P.lev_len != 0) { rc = dv_malformed("definition levels in a required column"); break; }
+        if (P.lev_len > P.comp_len || P.lev_len > P.uncomp_len) { rc = dv_malformed("level bytes exceed the page"); break; }
+      }
+      if (codec == CODEC_NONE) {
+        if (h.compressed != h.uncompressed) { rc = dv_unsupported("compressed page in a chunk declared UNCOMPRESSED"); break; }
+        P.compressed = 0;
+        P.img_off = P.src_off;
+      } else {
+        P.compressed = (h.type == PG_DATA_V2) ? (h.v2_compressed ? 1u : 0u) : 1u;
+        if (!P.compressed && h.compressed != h.uncompressed) { rc = dv_malformed("uncompressed page with differing sizes"); break; }
+        img = (img + 15) & ~15ull;
+        P.img_off = img;
+        img += (uint64_t)P.uncomp_len;
+      }
+      if (h.type == PG_DICT) {
+        if (c->dict_page >= 0 || c->n_pages > 0) { rc = dv_malformed("dictionary page not first / repeated"); break; }
+        if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICT) { rc = dv_unsupported("dictionary page encoding"); break; }
+        if (c->physical == PT_BOOLEAN) { rc = dv_malformed("dictionary page"); break; }
+        // (the dictionary is allocated on this count's word: every entry takes at least its PLAIN width / a length prefix in the page)
+        const uint64_t per = c->physical == PT_BYTE_ARRAY ? 4 : (uint64_t)plain_width(c->physical, c->type_length);
+        if (per == 0 || (uint64_t)h.num_values * per > (uint64_t)P.uncomp_len) { rc = dv_malformed("dictionary page shorter than its entries"); break; }
+        c->dict_page = (int64_t)c->pages.size();
+        c->dict_n = h.num_values;
+      } else {
+        const int e = h.encoding;
+        const bool enc_ok = e == ENC_PLAIN || e == ENC_PLAIN_DICT || e == ENC_RLE_DICT || (e == ENC_RLE && c->physical == PT_BOOLEAN) ||
+                            (e == ENC_DELTA_BINARY_PACKED && (c->physical == PT_INT32 || c->physical == PT_INT64));
+        if (!enc_ok) { rc = dv_unsupported("value encoding other than PLAIN / RLE_DICTIONARY / RLE (BOOLEAN) / DELTA_BINARY_PACKED (INT32, INT64)"); break; }
+        if ((e == ENC_PLAIN_DICT || e == ENC_RLE_DICT) && c->dict_page < 0) { rc = dv_malformed("dictionary-encoded page without a dictionary page"); break; }
+        if (h.type == PG_DATA && c->max_def == 1 && h.def_enc != ENC_RLE) { rc = dv_unsupported("definition levels not RLE encoded"); break; }
+        if ((uint64_t)c->rows + (uint64_t)P.num_values >= 0xFFFFFFF0ULL) { rc = dv_unsupported("more than 2^32 rows in one chunk"); break; }
+        P.row_start = (uint64_t)c->rows;
+        if (!(h.type == PG_DATA_V2 && h.num_nulls == 0)) all_v2_no_nulls = false;
+        c->data_pages.push_back((uint32_t)c->pages.size());
+        c->nn_init.push_back(P.num_values);
+        c->voff_init.push_back(h.type == PG_DATA_V2 ? P.lev_len : 0u);
+        c->rows += (int64_t)P.num_values;
+        c->n_pages += 1;
+      }
+      c->pages.push_back(P);
+    }  // index pages and unknown page types are skipped
+    r.p = next;
+  }
+  if (rc == DBHIP_OK && codec != CODEC_NONE) {
+    if (img + 16 >= (1ULL << 32)) rc = dv_unsupported("column chunk that decompresses to 4 GiB or more");
+    // the sizes come from untrusted headers: the caller allocates image_bytes of HBM on their word
+    else if (img > (1ULL << 30) && img > 1024ULL * (uint64_t)chunk_len) rc = dv_malformed("declared uncompressed size out of proportion to the chunk");
+  }
+  if (rc) { delete c; return rc; }
+  c->image_len = codec == CODEC_NONE ? 0 : (int64_t)img + 16;
+  c->known_no_nulls = c->max_def == 0 || all_v2_no_nulls;
+  if (c->known_no_nulls) { c->nulls = 0; c->nonnull = c->rows; }
+  if (info_host) {
+    info_host->num_values = c->rows;
+    info_host->num_nulls = c->known_no_nulls ? 0 : -1;  // known after decode (dbhip_pq_chunk_decode_device's out_nulls_host)
+    info_host->out_type = out_type;
+    info_host->has_validity = c->max_def;
+    info_host->out_bytes = out_type == DBHIP_T_BOOL ? ceil_div(c->rows, 64) * 8 : c->rows * (int64_t)out_elem_size(out_type);
+    info_host->validity_bytes = ceil_div(c->rows, 64) * 8;
+    info_host->n_pages = c->n_pages;
+    info_host->n_dict_values = c->dict_n < 0 ? 0 : c->dict_n;
+    info_host->image_bytes = c->image_len;
+  }
+  *out_host = c;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, void* out_values_dev,
+                                     uint8_t* out_validity_dev, int64_t* out_nulls_host, void* stream) {
+  DBHIP_REQUIRE(c && c->device_mode, "dbhip_pq_chunk_decode_device: the handle was not opened by dbhip_pq_chunk_open_device");
+  if (out_nulls_host) *out_nulls_host = 0;
+  if (c->rows == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(chunk_dev && out_values_dev, "dbhip_pq_chunk_decode_device: NULL buffer");
+  DBHIP_REQUIRE(c->codec == CODEC_NONE || image_dev, "dbhip_pq_chunk_decode_device: a compressed chunk needs an image buffer (info.image_bytes)");
+  DBHIP_REQUIRE(c->codec == CODEC_NONE || ((uintptr_t)image_dev & 15) == 0, "dbhip_pq_chunk_decode_device: the image buffer must be 16-byte aligned");
+  DBHIP_REQUIRE(c->max_def == 0 || out_validity_dev, "dbhip_pq_chunk_decode_device: a nullable column needs a validity buffer");
+  hipStream_t s = resolve_stream(stream);
+  const int esize = out_elem_size(c->out_type);
+  const bool is_bool = c->out_type == DBHIP_T_BOOL;
+  const int64_t nwords = ceil_div(c->rows, 32);
+  const uint32_t nd = (uint32_t)c->data_pages.size();
+  const bool spread = c->max_def == 1 && !c->known_no_nulls;
+  if (!c->uploaded) {
+    DBHIP_TRY(dbhip_alloc(c->pages.size() * sizeof(DvPage), (void**)&c->dv_pages));
+    DBHIP_CHECK(hipMemcpyAsync(c->dv_pages, c->pages.data(), c->pages.size() * sizeof(DvPage), hipMemcpyHostToDevice, s));
+    DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_dp));
+    DBHIP_CHECK(hipMemcpyAsync(c->dv_dp, c->data_pages.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
+    DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_nn));
+    DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_voff));
+    DBHIP_TRY(dbhip_alloc((size_t)(nd + 1) * 8, (void**)&c->dv_vbase));
+    DBHIP_TRY(dbhip_alloc(16, (void**)&c->dv_ctl));
+    if (c->dict_n > 0) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
+    if (spread) {
+      DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->rows + 1, 64) * 8 : (size_t)(c->rows + 1) * (size_t)esize, &c->d_dense));
+      DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_wcnt));
+      DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
+      DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
+    }
+    static const bool lds_ok = [] {
+      return hipFuncSetAttribute((const void*)dv_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DW + DI)) == hipSuccess;
+    }();
+    if (!lds_ok) { set_error("dbhip_pq_chunk_decode_device: cannot reserve %u bytes of LDS", DW + DI); return DBHIP_ERR_HIP; }
+    c->uploaded = true;
+  }
+  // (every call: the per-page counts are overwritten by the levels kernel of a nullable column)
+  DBHIP_CHECK(hipMemcpyAsync(c->dv_nn, c->nn_init.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
+  DBHIP_CHECK(hipMemcpyAsync(c->dv_voff, c->voff_init.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
+  DBHIP_CHECK(hipMemsetAsync(c->dv_ctl, 0, 16, s));
+  const PqConv cv{c->physical, c->type_length, c->out_type, esize};
+  const uint8_t* img = c->codec == CODEC_NONE ? chunk_dev : image_dev;
+  kernel_timer_start(s);
+  if (c->codec != CODEC_NONE)
+    hipLaunchKernelGGL(dv_inflate_kernel, dim3((unsigned)c->pages.size()), dim3(64), DW + DI, s, c->dv_pages, chunk_dev, image_dev, c->codec, c->dv_ctl);
+  if (c->dict_n > 0)
+    hipLaunchKernelGGL(dv_dict_kernel, dim3(1), dim3(256), 0, s, c->dv_pages, (uint32_t)c->dict_page, img, cv, c->d_dict, c->dv_ctl);
+  uint32_t* vbits = (uint32_t*)out_validity_dev;
+  if (c->max_def == 1) {
+    DBHIP_CHECK(hipMemsetAsync(vbits, 0, (size_t)ceil_div(c->rows, 64) * 8, s));
+    hipLaunchKernelGGL(dv_levels_kernel, dim3(nd), dim3(256), 0, s, c->dv_pages, c->dv_dp, img, c->dv_nn, c->dv_voff, vbits, c->dv_ctl);
+  } else if (vbits) {
+    DBHIP_CHECK(hipMemsetAsync(vbits, 0xFF, (size_t)ceil_div(c->rows, 64) * 8, s));
+  }
+  hipLaunchKernelGGL(dv_scan_kernel, dim3(1), dim3(256), 0, s, c->dv_nn, nd, c->dv_vbase);
+  void* target = spread ? c->d_dense : out_values_dev;
+  if (is_bool) DBHIP_CHECK(hipMemsetAsync(target, 0, (size_t)ceil_div(spread ? c->rows + 1 : c->rows, 64) * 8, s));
+  // slices of a PLAIN fixed-width page: enough workgroups to fill the chip even from a few large pages
+  const bool fixed = c->physical != PT_BOOLEAN && c->physical != PT_BYTE_ARRAY;
+  unsigned slices = 1;
+  if (fixed && nd > 0) {
+    const int64_t per_page = c->rows / (int64_t)nd;
+    while (slices < 64 && (int64_t)nd * slices < 2048 && per_page / (int64_t)slices > 4096) slices <<= 1;
+  }
+  hipLaunchKernelGGL(dv_values_kernel, dim3(nd, slices), dim3(256), 0, s, c->dv_pages, c->dv_dp, img, c->dv_nn, c->dv_voff, c->dv_vbase, cv,
+                     (const void*)c->d_dict, (uint32_t)(c->dict_n > 0 ? c->dict_n : 0), target, (uint64_t)c->rows, c->dv_ctl);
+  if (spread) {
+    hipLaunchKernelGGL(pq_popc_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, nwords, c->d_wcnt);
+    DBHIP_TRY(dbscan::exclusive_scan_u32(c->d_wcnt, nwords, c->d_blk, c->d_woff, s));
+    const int grid = grid_for(c->rows, 256);
+    if (is_bool) {
+      hipLaunchKernelGGL(pq_spread_bool_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense,
+                         nwords, (uint32_t*)out_values_dev);
+      if (nwords & 1) DBHIP_CHECK(hipMemsetAsync((uint32_t*)out_values_dev + nwords, 0, 4, s));
+    } else if (esize == 1) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint8_t*)c->d_dense, c->rows, (uint8_t*)out_values_dev);
+    } else if (esize == 2) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint16_t*)c->d_dense, c->rows, (uint16_t*)out_values_dev);
+    } else if (esize == 4) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense, c->rows, (uint32_t*)out_values_dev);
+    } else if (esize == 8) {
+      hipLaunchKernelGGL(pq_spread_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint64_t*)c->d_dense, c->rows, (uint64_t*)out_values_dev);
+    } else {
+      hipLaunchKernelGGL(pq_spread_kernel<uint4>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint4*)c->d_dense, c->rows, (uint4*)out_values_dev);
+    }
+  }
+  kernel_timer_stop(s);
+  DBHIP_LAUNCH_CHECK();
+  // the verdict of the device-side checks (and the null count) is only known once the kernels ran
+  uint32_t ctl[4] = {0, 0, 0, 0};
+  uint64_t nonnull = 0;
+  DBHIP_CHECK(hipMemcpyAsync(ctl, c->dv_ctl, 16, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipMemcpyAsync(&nonnull, c->dv_vbase + nd, 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (ctl[0] == DV_UNSUPPORTED) {
+    set_error("dbhip_pq_chunk_decode_device: the chunk uses a form the device path does not decode (a Snappy back-reference beyond 64 KiB, "
+              "or an encoding that changes between pages); use dbhip_pq_chunk_open");
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (ctl[0] != DV_OK) {
+    set_error("dbhip_pq_chunk_decode_device: malformed column chunk (a page does not decompress to its declared size, or a level / "
+              "index / length stream runs past its page)");
+    return DBHIP_ERR_INVALID;
+  }
+  if (c->known_no_nulls && (int64_t)nonnull != c->rows) {
+    set_error("dbhip_pq_chunk_decode_device: malformed column chunk (the pages say num_nulls = 0, the definition levels disagree)");
+    return DBHIP_ERR_INVALID;
+  }
+  c->nonnull = (int64_t)nonnull;
+  c->nulls = c->rows - c->nonnull;
+  if (out_nulls_host) *out_nulls_host = c->nulls;
+  return DBHIP_OK;
+}
+
+}  // extern "C"

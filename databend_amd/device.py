@@ -1823,17 +1823,23 @@ class ParquetChunk:
     `chunk` = the raw bytes of the column chunk (dictionary page first), as the block reader fetched them."""
 
     def __init__(self, chunk, physical_type, out_type, type_length=0, max_def_level=0, max_rep_level=0, codec=0,
-                 precision=0, scale=0):
+                 precision=0, scale=0, device=False):
+        """device=True: dbhip_pq_chunk_open_device / _decode_device — the host reads the page headers only; decompression (SNAPPY /
+        LZ4_RAW), run headers, length prefixes and DELTA blocks are walked on the GPU from the chunk as stored."""
         _ensure()
         self.host = np.frombuffer(chunk, dtype=np.uint8)   # zero-copy view; the bytes object stays referenced by the array
         self.out_type, self.precision, self.scale = out_type, precision, scale
+        self.device = bool(device)
         self.h = C.c_void_p()
         self.info = L.PqInfo()
         hp = self.host.ctypes.data_as(C.c_void_p) if len(self.host) else C.c_void_p(0)
-        check(lib().dbhip_pq_chunk_open(hp if len(self.host) else self.host.ctypes.data_as(C.c_void_p), C.c_int64(len(self.host)),
-                                        C.c_int32(codec), C.c_int32(physical_type), C.c_int32(type_length), C.c_int32(max_def_level),
-                                        C.c_int32(max_rep_level), C.c_int32(out_type), C.byref(self.h), C.byref(self.info)))
+        fn = lib().dbhip_pq_chunk_open_device if self.device else lib().dbhip_pq_chunk_open
+        check(fn(hp if len(self.host) else self.host.ctypes.data_as(C.c_void_p), C.c_int64(len(self.host)),
+                 C.c_int32(codec), C.c_int32(physical_type), C.c_int32(type_length), C.c_int32(max_def_level),
+                 C.c_int32(max_rep_level), C.c_int32(out_type), C.byref(self.h), C.byref(self.info)))
         self.chunk_dev = None
+        self.image_dev = None
+        self.nulls = self.info.num_nulls
 
     def image(self):
         """what decode() reads: the chunk itself, or (compressed chunks) the decompressed page stream open() produced"""
@@ -1844,22 +1850,41 @@ class ParquetChunk:
         return np.ctypeslib.as_array(p, shape=(n.value,))
 
     def upload(self):
-        """the image's bytes into HBM (+ 8 bytes of slack; they become buffer 0 of a string column)"""
+        """the image's bytes into HBM (+ 16 bytes of slack; they become buffer 0 of a string column). Device mode: the chunk AS STORED."""
         if self.chunk_dev is None:
-            self.chunk_dev = DeviceBuffer.from_numpy(np.concatenate([self.image(), np.zeros(8, np.uint8)]))
+            src = self.host if self.device else self.image()
+            self.chunk_dev = DeviceBuffer.from_numpy(np.concatenate([src, np.zeros(16, np.uint8)]))
         return self.chunk_dev
+
+    def device_image(self):
+        """device mode, after decode(): the decompressed pages as the GPU wrote them (host copy; UNCOMPRESSED chunks: the chunk)"""
+        if self.image_dev is None:
+            return self.host
+        return self.image_dev.to_numpy(np.uint8, self.info.image_bytes)
 
     def decode(self, stream=None):
         i = self.info
         chunk_dev = self.upload()
         out = DeviceBuffer(i.out_bytes + 16)
         val = DeviceBuffer(i.validity_bytes + 8) if i.has_validity else None
-        check(lib().dbhip_pq_chunk_decode(self.h, C.c_void_p(chunk_dev.ptr), C.c_void_p(out.ptr),
-                                          C.c_void_p(val.ptr) if val is not None else None, stream))
+        buf0 = chunk_dev
+        if self.device:
+            if i.image_bytes and self.image_dev is None:
+                self.image_dev = DeviceBuffer(i.image_bytes)
+            nulls = C.c_int64(0)
+            check(lib().dbhip_pq_chunk_decode_device(self.h, C.c_void_p(chunk_dev.ptr), C.c_void_p(self.image_dev.ptr) if self.image_dev else None,
+                                                     C.c_void_p(out.ptr), C.c_void_p(val.ptr) if val is not None else None,
+                                                     C.byref(nulls), stream))
+            self.nulls = nulls.value
+            if self.image_dev is not None:
+                buf0 = self.image_dev
+        else:
+            check(lib().dbhip_pq_chunk_decode(self.h, C.c_void_p(chunk_dev.ptr), C.c_void_p(out.ptr),
+                                              C.c_void_p(val.ptr) if val is not None else None, stream))
         bufs = None
         if self.out_type == L.T_STRING:
-            bufs = DeviceBuffer.from_numpy(np.array([chunk_dev.ptr], dtype=np.uint64))
-        return Column(self.out_type, i.num_values, out, val, self.precision, self.scale, buffers=bufs, keep=(chunk_dev,))
+            bufs = DeviceBuffer.from_numpy(np.array([buf0.ptr], dtype=np.uint64))
+        return Column(self.out_type, i.num_values, out, val, self.precision, self.scale, buffers=bufs, keep=(buf0,))
 
     def close(self):
         if self.h:

@@ -896,6 +896,25 @@ int32_t dbhip_pq_chunk_image(dbhip_pq_chunk* c, const uint8_t** out_ptr_host, in
 /* chunk_dev: device copy of the chunk (UNCOMPRESSED) or of the image (compressed chunks). */
 int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void* out_values_dev,
                               uint8_t* out_validity_dev, void* stream);
+/* DEVICE mode of the same boundary: the page payload never passes through the host. open_device reads the thrift page headers
+ * only (sizes, value counts, encodings: a few dozen bytes per page); decode_device decompresses the pages (SNAPPY / LZ4_RAW: one
+ * wave per page, LDS-resident 64 KiB window), walks the run headers of the RLE / bit-packed hybrid streams (definition levels,
+ * dictionary indices, RLE booleans), the length prefixes of PLAIN BYTE_ARRAY pages and DELTA_BINARY_PACKED blocks (INT32 /
+ * INT64) on the GPU, from the HBM copy of the chunk AS STORED. ZSTD chunks: DBHIP_ERR_UNSUPPORTED (dbhip_pq_chunk_open
+ * decompresses them with the host's libzstd). Same type pairs, same output layout as open / decode.
+ *   chunk_dev    the chunk as stored (the bytes given to open_device), readable up to the next 16-byte boundary past its end
+ *   image_dev    compressed chunks: info.image_bytes bytes, 16-byte aligned, caller-owned — receives the decompressed pages;
+ *                DBHIP_T_STRING views point into it (it is buffer 0 of the column; UNCOMPRESSED chunks: chunk_dev is, pass NULL)
+ *   info.num_nulls is -1 when the page headers do not tell (v1 pages of a nullable column); out_nulls_host (may be NULL) gets
+ *   the count. Nothing about the payload is validated on the host, so the device checks every access against the page, the
+ *   dictionary and the output; decode_device synchronises `stream` and returns DBHIP_ERR_INVALID for a chunk that fails a check. */
+int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec,
+                                   int32_t physical_type, int32_t type_length, int32_t max_def_level,
+                                   int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
+                                   dbhip_pq_info* info_host);
+int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev,
+                                     void* out_values_dev, uint8_t* out_validity_dev, int64_t* out_nulls_host,
+                                     void* stream);
 int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c);
 
 /* ---------------------------------------------------------------------------------------------------------------------

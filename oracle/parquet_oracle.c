@@ -228,6 +228,50 @@ static int64_t snappy_raw(const uint8_t* in, int64_t n, uint8_t* out, int64_t ca
   return op == (int64_t)ulen ? op : -1;
 }
 
+/* DELTA_BINARY_PACKED (Apache Parquet Encodings.md, "Delta Encoding"): header <block size> <miniblocks per block> <total count>
+ * <first value (zigzag)>; each block <min delta (zigzag)> <one bit width per miniblock> <bit-packed deltas>. One value per call. */
+typedef struct { rd_t r; uint64_t vpm, mb, total, produced; uint64_t last, min_delta; uint8_t bw[4096]; uint64_t mini, in_mini; const uint8_t* mp; } delta_t;
+static int delta_init(delta_t* d, const uint8_t* p, const uint8_t* end) {
+  d->r.p = p; d->r.end = end; d->r.bad = 0;
+  const uint64_t bs = rd_varint(&d->r);
+  d->mb = rd_varint(&d->r);
+  d->total = rd_varint(&d->r);
+  d->last = (uint64_t)rd_zz(&d->r);
+  if (d->r.bad || d->mb == 0 || d->mb > 4096 || bs == 0 || bs > (1u << 24) || bs % d->mb) return -1;
+  d->vpm = bs / d->mb;
+  if (d->vpm % 8) return -1;
+  d->produced = 0; d->mini = d->mb; d->in_mini = 0; d->mp = NULL;
+  return 0;
+}
+static int delta_next(delta_t* d, uint64_t* out) {
+  if (d->produced >= d->total) return -1;
+  if (d->produced == 0) { d->produced = 1; *out = d->last; return 0; }
+  if (d->mp == NULL || d->in_mini == d->vpm) {
+    if (d->mp) { d->r.p = d->mp + d->vpm * d->bw[d->mini] / 8 <= d->r.end ? d->mp + d->vpm * d->bw[d->mini] / 8 : d->r.end; d->mini++; }
+    if (d->mini >= d->mb) {   /* next block */
+      d->min_delta = (uint64_t)rd_zz(&d->r);
+      for (uint64_t m = 0; m < d->mb; ++m) d->bw[m] = rd_u8(&d->r);
+      if (d->r.bad) return -1;
+      d->mini = 0;
+    }
+    if (d->bw[d->mini] > 64) return -1;
+    d->mp = d->r.p;
+    d->in_mini = 0;
+  }
+  const unsigned b = d->bw[d->mini];
+  uint64_t v = 0;
+  for (unsigned k = 0; k < b; ++k) {
+    const uint64_t bit = d->in_mini * b + k;
+    if (d->mp + (bit >> 3) >= d->r.end) return -1;
+    v |= (uint64_t)((d->mp[bit >> 3] >> (bit & 7)) & 1) << k;
+  }
+  d->in_mini++;
+  d->last += d->min_delta + v;
+  d->produced++;
+  *out = d->last;
+  return 0;
+}
+
 static int g_pq_codec = 0;   /* parquet.thrift CompressionCodec of the chunk orc_pq_decode_codec is working on (0 UNCOMPRESSED, 1 SNAPPY) */
 int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_length, int max_def, int out_type, int64_t cap_rows,
                   uint8_t* out_values, uint8_t* out_valid, int64_t* out_rows, int64_t* out_nulls);
@@ -322,6 +366,7 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
     if (rc) { free(defs); break; }
     /* value reader state */
     hyb_t vh;
+    delta_t dl;
     int use_hyb = 0, boolbit = 0;
     if (pg.enc == 2 || pg.enc == 8) {
       if (dict_n < 0) { free(defs); rc = -1; break; }
@@ -335,6 +380,9 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
       if ((uint64_t)(pend - q - 4) < l) { free(defs); rc = -1; break; }
       hyb_init(&vh, q + 4, l, 1);
       use_hyb = 2;
+    } else if (pg.enc == 5 && (physical == PT_INT32 || physical == PT_INT64)) {
+      if (delta_init(&dl, q, pend)) { free(defs); rc = -1; break; }
+      use_hyb = 3;
     } else if (pg.enc != 0) {
       free(defs);
       rc = -2;
@@ -356,6 +404,13 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
         uint32_t v;
         if (hyb_next(&vh, &v)) { rc = -1; break; }
         out_values[o] = (uint8_t)v;
+      } else if (use_hyb == 3) {
+        uint64_t v;
+        uint8_t le[8];
+        if (delta_next(&dl, &v)) { rc = -1; break; }
+        if (physical == PT_INT32) v = (uint64_t)(uint32_t)v;
+        memcpy(le, &v, 8);
+        put_plain(physical, type_length, out_type, le, out_values, o);
       } else if (physical == PT_BOOLEAN) {
         if (q + (boolbit >> 3) >= pend) { rc = -1; break; }
         out_values[o] = (uint8_t)((q[boolbit >> 3] >> (boolbit & 7)) & 1);

@@ -20,14 +20,19 @@ def unpack(bits, n):
     return np.unpackbits(np.frombuffer(bits, dtype=np.uint8), bitorder="little")[:n].astype(bool)
 
 
-def gpu_decode(gpu, ch, out_type):
-    pc = gpu.ParquetChunk(ch["chunk"], ch["physical"], out_type, ch["type_length"], ch["max_def"], ch.get("max_rep", 0), ch.get("codec", 0))
+def gpu_decode(gpu, ch, out_type, device=False):
+    """device=True: dbhip_pq_chunk_open_device / _decode_device (the payload is decompressed and walked on the GPU)"""
+    pc = gpu.ParquetChunk(ch["chunk"], ch["physical"], out_type, ch["type_length"], ch["max_def"], ch.get("max_rep", 0), ch.get("codec", 0),
+                          device=device)
     i = pc.info
     col = pc.decode()
+    if device:
+        assert i.num_nulls in (-1, pc.nulls)
+        i.num_nulls = pc.nulls           # (v1 pages of a nullable column: only known once the levels were walked)
     n = i.num_values
     valid = unpack(col.validity.to_numpy(np.uint8, i.validity_bytes).tobytes(), n) if i.has_validity else np.ones(n, dtype=bool)
     raw = col.data.to_numpy(np.uint8, i.out_bytes).tobytes()
-    py = PU.decoded_to_python(raw, valid, out_type, n, pc.image())   # (long String views point into the chunk / the image)
+    py = PU.decoded_to_python(raw, valid, out_type, n, pc.device_image() if device else pc.image())   # (long String views point into the chunk / the image)
     if i.has_validity and n % 64:
         tail = unpack(col.validity.to_numpy(np.uint8, i.validity_bytes).tobytes(), i.validity_bytes * 8)[n:]
         assert not tail.any()            # padding bits of the bitmap are clear

@@ -1,0 +1,234 @@
+"""GPU parity of the DEVICE mode of the scan-side decode: dbhip_pq_chunk_open_device / _decode_device. The host reads the
+thrift page headers only; Snappy / LZ4 page decompression, the run headers of the RLE / bit-packed hybrid streams, the BYTE_ARRAY length
+chain and DELTA_BINARY_PACKED blocks are walked on the GPU. Same fixtures as the host-planned mode (tests/test_gpu_parquet.py): pyarrow's
+reader, the CPU oracle, the committed golden chunks and the Parquet files the reference keeps under tests/data with the values its own
+sqllogictests print for them."""
+import io
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from databend_amd import _lib as T
+from tests import parquet_cases as PC
+from tests import parquet_util as PU
+from tests.test_gpu_parquet import GOLD, gpu_decode, unpack
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("vi", range(len(PC.VARIANTS)))
+def test_device_mode_matches_pyarrow_and_oracle(gpu, vi):
+    import pyarrow as pa
+    for name, arr, out_type, wkw in PC.make_cases(seed=vi):
+        kw = dict(PC.VARIANTS[vi])
+        kw.update(wkw)
+        chunks, back = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), **kw))
+        ch = chunks[0]
+        exp, exp_valid = PU.expected_of(back.column(0), out_type)
+        got, valid, info = gpu_decode(gpu, ch, out_type, device=True)
+        assert info.num_values == len(exp) and info.num_nulls == int((~exp_valid).sum()), name
+        assert np.array_equal(valid, exp_valid), name
+        assert got == exp, name
+        o_got, _, _, _, rc = PU.oracle_decode(ch, out_type)
+        assert rc == 0 and o_got == got, name
+
+
+@pytest.mark.parametrize("cname", ["lz4", "snappy"])
+@pytest.mark.parametrize("vi", [0, 1, 2, 4, 5])
+def test_device_side_decompression_matches_pyarrow(gpu, cname, vi):
+    """TableCompression LZ4 / Snappy (table_compression.rs:38-58): one wave per page decompresses into the HBM image; values, validity and
+    String views (which point into that image) equal pyarrow's, and the image equals the page payloads of the uncompressed twin."""
+    import pyarrow as pa
+    for name, arr, out_type, wkw in PC.make_cases(seed=vi):
+        kw = dict(PC.VARIANTS[vi])
+        kw.update(wkw)
+        chunks, back = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), compression=cname, **kw))
+        ch = chunks[0]
+        exp, exp_valid = PU.expected_of(back.column(0), out_type)
+        got, valid, info = gpu_decode(gpu, ch, out_type, device=True)
+        assert info.num_values == len(exp) and info.num_nulls == int((~exp_valid).sum()), name
+        assert info.image_bytes > 0 or len(exp) == 0, name
+        assert np.array_equal(valid, exp_valid) and got == exp, name
+
+
+def test_zstd_and_nested_chunks_are_left_to_the_host_mode(gpu):
+    import pyarrow as pa
+    t = pa.table({"c": pa.array(list(range(5000)), pa.int64())})
+    chunks, _ = PU.column_chunks(PU.write_parquet(t, compression="zstd"))
+    ch = chunks[0]
+    with pytest.raises(T.DbhipError) as e:
+        gpu.ParquetChunk(ch["chunk"], ch["physical"], T.T_I64, ch["type_length"], ch["max_def"], 0, ch["codec"], device=True)
+    assert e.value.code == T.ERR_UNSUPPORTED
+    got, valid, info = gpu_decode(gpu, ch, T.T_I64)          # the host-planned mode takes it
+    assert got == list(range(5000))
+    # a handle of one mode is refused by the other mode's decode
+    chunks, _ = PU.column_chunks(PU.write_parquet(t))
+    ch = chunks[0]
+    pc = gpu.ParquetChunk(ch["chunk"], ch["physical"], T.T_I64, ch["type_length"], ch["max_def"], device=True)
+    pc.device = False
+    with pytest.raises(T.DbhipError):
+        pc.decode()
+    pc.close()
+
+
+@pytest.mark.parametrize("cname", ["none", "snappy", "lz4"])
+def test_delta_binary_packed(gpu, cname):
+    """DELTA_BINARY_PACKED INT32 / INT64 (not in the reference writer's repertoire, but in files it reads): several pages, NULLs, runs of
+    equal deltas (bit width 0), full-width deltas, against pyarrow and the oracle's statement of Encodings.md."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    rng = np.random.default_rng(5)
+    for typ, ot, hi in ((pa.int64(), T.T_I64, 2**62), (pa.int32(), T.T_I32, 2**30), (pa.int64(), T.T_DEC128, 2**40), (pa.int32(), T.T_I64, 2**20)):
+        for n, frac in ((1, 0.0), (129, 0.0), (70_000, 0.07), (5000, 1.0)):
+            a = rng.integers(-hi, hi, n)
+            a[n // 4: n // 2] = np.arange(n // 2 - n // 4) * 3 + 7      # constant delta
+            a[n // 2: n // 2 + n // 8] = 42                             # zero delta
+            mask = rng.random(n) < frac
+            t = pa.table({"c": pa.array(a, typ, mask=mask)})
+            buf = io.BytesIO()
+            pq.write_table(t, buf, compression=cname, use_dictionary=False, column_encoding={"c": "DELTA_BINARY_PACKED"}, data_page_size=20_000,
+                           write_statistics=False, row_group_size=n)
+            chunks, back = PU.column_chunks(buf.getvalue())
+            ch = chunks[0]
+            assert "DELTA_BINARY_PACKED" in ch["encodings"]
+            exp, exp_valid = PU.expected_of(back.column(0), ot)
+            got, valid, info = gpu_decode(gpu, ch, ot, device=True)
+            assert np.array_equal(valid, exp_valid) and got == exp, (str(typ), n)
+            if cname == "none":
+                o_got, _, _, _, rc = PU.oracle_decode(ch, ot)
+                assert rc == 0 and o_got == got
+
+
+@pytest.mark.parametrize("cname", ["snappy", "lz4"])
+def test_large_compressible_pages(gpu, cname):
+    """Pages far larger than the 64 KiB LDS window, with the back-reference shapes real data produces: long runs (overlapping matches at
+    distance 1..8), repeated rows at 16-bit distances, incompressible stretches (long literals), Booleans, repetitive strings longer than 12
+    bytes (views into the decompressed image)."""
+    import pyarrow as pa
+    rng = np.random.default_rng(8)
+    n = 600_000
+    runs = np.repeat(rng.integers(0, 1000, n // 500 + 1), 500)[:n].astype(np.int64)
+    mixed = np.where(rng.random(n) < 0.5, rng.integers(0, 2**60, n), 7).astype(np.int64)
+    period = np.tile(rng.integers(0, 2**40, 3001), n // 3001 + 1)[:n].astype(np.int64)
+    words = np.array([b"lineitem-comment-%06d-abcdefghijklmnop" % i for i in range(997)], dtype=object)
+    strs = words[rng.integers(0, 997, 200_000)]
+    cases = [("runs", pa.array(runs, pa.int64()), T.T_I64), ("mixed", pa.array(mixed, pa.int64(), mask=rng.random(n) < 0.02), T.T_I64),
+             ("period", pa.array(period, pa.int64()), T.T_I64), ("bool", pa.array(rng.random(n) < 0.01, pa.bool_()), T.T_BOOL),
+             ("strings", pa.array(list(strs), pa.binary()), T.T_STRING), ("f64", pa.array(rng.random(n // 4)), T.T_F64)]
+    for name, arr, ot in cases:
+        for dictionary in (False, True):
+            chunks, back = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), dictionary=dictionary, compression=cname, page_size=1 << 20))
+            ch = chunks[0]
+            exp, exp_valid = PU.expected_of(back.column(0), ot)
+            got, valid, info = gpu_decode(gpu, ch, ot, device=True)
+            assert np.array_equal(valid, exp_valid), name
+            assert got == exp, (name, dictionary)
+
+
+def test_golden_and_reference_held_chunks_in_device_mode(gpu):
+    from tests import parquet_ref as PR
+    names = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith(".json"))
+    for nm in names:
+        meta = json.load(open(os.path.join(GOLD, nm + ".json")))
+        chunk = open(os.path.join(GOLD, nm + ".bin"), "rb").read()
+        ch = dict(chunk=chunk, physical=meta["physical"], type_length=meta["type_length"], max_def=meta["max_def"])
+        got, valid, info = gpu_decode(gpu, ch, meta["out_type"], device=True)
+        assert info.num_values == meta["rows"] and info.num_nulls == meta["nulls"], nm
+        norm = [None if v is None else (v.hex() if isinstance(v, bytes) else (int(v) if not isinstance(v, bool) else v)) for v in got]
+        assert norm == meta["values"], nm
+
+    # the Parquet files under the reference's tests/data (parquet-cpp, parquet-mr and parquet-rs 58.1.0 writers; SNAPPY v1 pages) against
+    # what the reference's sqllogictests print for them
+    def decode(ch, out_type):
+        py, valid, info = gpu_decode(gpu, ch, out_type, device=True)
+        assert info.num_values == ch["num_values"]
+        return py, valid
+    assert PR.check_all(decode) == 21
+
+
+def test_mutated_chunks_never_fault_in_device_mode(gpu):
+    """Nothing but the page table is validated on the host here, so the kernels themselves must stay inside the page, the window, the
+    dictionary and the output for ANY bytes: bit flips, truncation and overwritten words in plain, Snappy and LZ4 chunks. A mutant is either
+    refused (open: header damage; decode: a device-side check) or decodes to (possibly garbage) values; the device must stay healthy."""
+    import pyarrow as pa
+    rng = np.random.default_rng(13)
+    seeds = []
+    for vi, cname in ((0, "none"), (1, "none"), (4, "snappy"), (1, "snappy"), (0, "lz4"), (5, "lz4")):
+        for name, arr, ot, wkw in PC.make_cases(seed=vi):
+            kw = dict(PC.VARIANTS[vi])
+            kw.update(wkw)
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr.slice(0, 2500)}), compression=cname, **kw))
+            if len(chunks[0]["chunk"]):
+                seeds.append((chunks[0], ot))
+    opened = rejected = failed = 0
+    for it in range(1500):
+        ch, ot = seeds[it % len(seeds)]
+        b = bytearray(ch["chunk"])
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b = b[: int(rng.integers(1, len(b)))]
+        else:
+            i = int(rng.integers(0, len(b)))
+            b[i:i + 4] = bytes(rng.integers(0, 256, 4).astype(np.uint8))
+        try:
+            pc = gpu.ParquetChunk(bytes(b), ch["physical"], ot, ch["type_length"], ch["max_def"], 0, ch["codec"], device=True)
+        except T.DbhipError as e:
+            assert e.code in (T.ERR_INVALID, T.ERR_UNSUPPORTED)
+            rejected += 1
+            continue
+        try:
+            col = pc.decode()
+            col.data.to_numpy(np.uint8, pc.info.out_bytes)     # forces completion: a device fault would surface here
+            opened += 1
+        except T.DbhipError as e:
+            assert e.code in (T.ERR_INVALID, T.ERR_UNSUPPORTED)
+            failed += 1
+        pc.close()
+    assert opened > 100 and rejected > 100 and failed > 50
+    # the device is still healthy: an intact chunk decodes right after
+    ch, ot = seeds[0]
+    gpu_decode(gpu, ch, ot, device=True)
+
+
+def test_full_size_device_mode_20m_rows(gpu):
+    """BASELINE-sized chunk (20 M Decimal(15,2) values of lineitem, 3 % NULLs, PLAIN v1 pages of 1 MiB) stored uncompressed, with Snappy and
+    with LZ4: write -> decode is the identity; the rates (bytes of the chunk as stored per second of the decode call) go to
+    gpurun_out/pq_device_rates.json."""
+    import pyarrow as pa
+    n = 20_000_000
+    rng = np.random.default_rng(4)
+    price = rng.integers(90000, 10494951, n)
+    mask = rng.random(n) < 0.03
+    disc = rng.integers(0, 11, n)
+    rates = {}
+    for cname in ("none", "snappy", "lz4"):
+        for label, arr, dictionary, src, m in (("price_plain_nullable", pa.array(price, pa.int64(), mask=mask), False, price, mask),
+                                               ("discount_dictionary", pa.array(disc, pa.int64()), True, disc, None)):
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), dictionary=dictionary, compression=cname))
+            ch = chunks[0]
+            pc = gpu.ParquetChunk(ch["chunk"], ch["physical"], T.T_DEC64, ch["type_length"], ch["max_def"], 0, ch["codec"], precision=15, scale=2, device=True)
+            col = pc.decode()
+            got = col.data.to_numpy(np.int64, n)
+            if m is not None:
+                valid = unpack(col.validity.to_numpy(np.uint8, pc.info.validity_bytes).tobytes(), n)
+                assert np.array_equal(valid, ~m) and np.array_equal(got, np.where(m, 0, src)) and pc.nulls == int(m.sum())
+            else:
+                assert np.array_equal(got, src)
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                pc.decode()                                   # (decode_device synchronises its stream)
+                best = min(best, time.perf_counter() - t0)
+            rates[f"{label}/{cname}"] = dict(chunk_bytes=len(ch["chunk"]), image_bytes=int(pc.info.image_bytes), pages=int(pc.info.n_pages),
+                                             decode_ms=round(best * 1e3, 3), stored_GBps=round(len(ch["chunk"]) / best / 1e9, 2),
+                                             out_GBps=round(n * 8 / best / 1e9, 2))
+            pc.close()
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rates, open("gpurun_out/pq_device_rates.json", "w"), indent=1)
+    print(json.dumps(rates))

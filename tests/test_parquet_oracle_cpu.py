@@ -67,9 +67,10 @@ def test_unsupported_and_malformed_are_reported():
     assert chunks[0]["codec"] != 0
     assert PU.oracle_decode(chunks[0], T.T_I64)[4] == -2        # compressed page: sizes differ
     buf = io.BytesIO()
-    pq.write_table(t, buf, compression="none", use_dictionary=False, column_encoding={"c": "DELTA_BINARY_PACKED"})
+    ts = pa.table({"c": pa.array([b"abc%d" % i for i in range(5000)], pa.binary())})
+    pq.write_table(ts, buf, compression="none", use_dictionary=False, column_encoding={"c": "DELTA_LENGTH_BYTE_ARRAY"})
     chunks, _ = PU.column_chunks(buf.getvalue())
-    assert PU.oracle_decode(chunks[0], T.T_I64)[4] == -2        # encoding outside the writer's repertoire
+    assert PU.oracle_decode(chunks[0], T.T_STRING)[4] == -2     # an encoding that is not decoded (DELTA_LENGTH_BYTE_ARRAY)
     fb = PU.write_parquet(t, dictionary=True)
     chunks, _ = PU.column_chunks(fb)
     cut = dict(chunks[0])
@@ -324,3 +325,60 @@ def test_oracle_decodes_the_reference_held_parquet_files_to_what_its_tests_print
         py = [bool(vals[i]) for i in range(n)] if out_type == T.T_BOOL else PU.decoded_to_python(vals.tobytes(), v, out_type, n, chunk)
         return py, v
     assert PR.check_all(decode) == 21
+
+
+def test_oracle_delta_binary_packed_matches_pyarrow():
+    """DELTA_BINARY_PACKED INT32 / INT64 pages (Encodings.md "Delta Encoding"): the oracle's statement against pyarrow's reader."""
+    import io
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    rng = np.random.default_rng(3)
+    for typ, ot, hi in ((pa.int64(), T.T_I64, 2**62), (pa.int32(), T.T_I32, 2**30), (pa.int32(), T.T_I64, 2**20)):
+        for n, frac in ((1, 0.0), (129, 0.0), (9000, 0.1)):
+            a = rng.integers(-hi, hi, n)
+            a[n // 4: n // 2] = np.arange(n // 2 - n // 4) * 3 + 7
+            a[n // 2: n // 2 + n // 8] = 42
+            t = pa.table({"c": pa.array(a, typ, mask=rng.random(n) < frac)})
+            buf = io.BytesIO()
+            pq.write_table(t, buf, compression="none", use_dictionary=False, column_encoding={"c": "DELTA_BINARY_PACKED"}, data_page_size=3000,
+                           write_statistics=False)
+            chunks, back = PU.column_chunks(buf.getvalue())
+            assert "DELTA_BINARY_PACKED" in chunks[0]["encodings"]
+            exp, _ = PU.expected_of(back.column(0), ot)
+            got, _, rows, _, rc = PU.oracle_decode(chunks[0], ot)
+            assert rc == 0 and rows == n and got == exp
+
+
+def test_device_mode_open_reads_only_the_page_headers():
+    """dbhip_pq_chunk_open_device needs no device: rows / pages / dictionary size come from the thrift headers alone; the null count of v1
+    pages is not known before the levels are walked (-1); ZSTD is left to the host mode; the image is the 16-byte aligned page payloads."""
+    import ctypes as C
+    import pyarrow as pa
+    rng = np.random.default_rng(2)
+    n = 30_000
+    arr = pa.array(rng.integers(0, 50, n), pa.int64(), mask=rng.random(n) < 0.1)
+
+    def open_dev(ch):
+        data = ch["chunk"]
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data)
+        h, info = C.c_void_p(), T.PqInfo()
+        rc = T.lib().dbhip_pq_chunk_open_device(buf, C.c_int64(len(data)), ch["codec"], ch["physical"], ch["type_length"], ch["max_def"], 0, T.T_I64,
+                                                C.byref(h), C.byref(info))
+        if rc == 0:
+            T.lib().dbhip_pq_chunk_close(h)
+        return rc, info
+    for cname in ("none", "snappy", "lz4"):
+        for dictionary in (True, False):
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), dictionary=dictionary, compression=cname, page_size=8192))
+            rc, info = open_dev(chunks[0])
+            assert rc == 0 and info.num_values == n and info.has_validity == 1 and info.n_pages > 1
+            assert info.num_nulls == -1 and (info.n_dict_values == 50) == dictionary
+            assert (info.image_bytes > 0) == (cname != "none")
+    chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), compression="zstd"))
+    assert open_dev(chunks[0])[0] == T.ERR_UNSUPPORTED
+    chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": pa.array(np.arange(n), pa.int64())})))
+    rc, info = open_dev(chunks[0])
+    assert rc == 0 and info.num_nulls == 0 and info.image_bytes == 0
+    cut = dict(chunks[0])
+    cut["chunk"] = cut["chunk"][: len(cut["chunk"]) // 2]
+    assert open_dev(cut)[0] == T.ERR_INVALID
