@@ -66,8 +66,43 @@ struct DvInflate {
     const uint32_t want = (qend - q) < n ? qend : q + n;
     if (qload < want) refill();
   }
-  // byte k after the read position (the caller made sure q + k < qend and called need())
-  __device__ __forceinline__ uint32_t in(uint32_t k) const { return uni((uint32_t)inb[(q + k) & DIM]); }
+  // byte k after the read position (the caller made sure q + k < qend). The next 64 input bytes sit one per lane in a register
+  // (`la`, lane 0 = position `laq`): headers are parsed with v_readlane instead of an LDS round trip per byte.
+  uint32_t la, laq;
+  __device__ __forceinline__ void look() {
+    need(192);
+    laq = q;
+    la = (uint32_t)inb[(q + lane) & DIM];
+  }
+  __device__ __forceinline__ uint32_t in(uint32_t k) {
+    if (q + k - laq >= 64) look();
+    return (uint32_t)__builtin_amdgcn_readlane((int)la, (int)(q + k - laq));
+  }
+
+  __device__ __forceinline__ uint32_t peek(uint32_t w) const { return (uint32_t)__builtin_amdgcn_readlane((int)la, (int)w); }
+
+  // the common case of match(): len <= 64, 1 <= off <= op, len <= cap - op (checked by the caller) — one LDS read, one LDS write
+  __device__ __forceinline__ void match64(uint32_t len, uint32_t off) {
+    uint32_t j = lane;
+    if (off < 64) {
+      // lane mod off without an integer division: (lane + 0.5) / off is at least 0.5 / 63 away from an integer, far more than
+      // the error of v_rcp_f32, so the truncation is exact
+      const float r = __builtin_amdgcn_rcpf((float)off);
+      j = lane - off * (uint32_t)(((float)lane + 0.5f) * r);
+    }
+    if (lane < len) {
+      const uint8_t v = win[(op - off + j + sh) & DWM];
+      win[(op + lane + sh) & DWM] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    op += len;
+  }
+  // the common case of literal(): len <= 64 staged bytes at input position q + skip
+  __device__ __forceinline__ void literal64(uint32_t len, uint32_t skip) {
+    if (lane < len) win[(op + sh + lane) & DWM] = inb[(q + skip + lane) & DIM];
+    __builtin_amdgcn_wave_barrier();
+    op += len;
+  }
 
   __device__ __forceinline__ void flush(bool force) {
     const uint32_t target = op;
@@ -79,6 +114,7 @@ struct DvInflate {
     }
     const uint32_t nvec = (target - flushed) >> 4;
     if (((flushed + sh) & 15u) == 0) {
+#pragma clang loop unroll(disable)
       for (uint32_t v = lane; v < nvec; v += 64)
         *(uint4*)(dst + flushed + 16 * v) = *(const uint4*)(win + ((flushed + sh + 16 * v) & DWM));
       flushed += nvec << 4;
@@ -97,6 +133,7 @@ struct DvInflate {
       uint32_t n = (qload < qend ? qload : qend) - q;
       if (n > len) n = len;
       if (n > DV_PIECE) n = DV_PIECE;
+#pragma clang loop unroll(disable) vectorize(disable)
       for (uint32_t i = lane; i < n; i += 64) win[(op + sh + i) & DWM] = inb[(q + i) & DIM];
       __builtin_amdgcn_wave_barrier();
       q += n; op += n; len -= n;
@@ -108,11 +145,13 @@ struct DvInflate {
     if (off == 0 || off > op || off > 65535u || len > cap - op) { bad = true; return; }
     while (len) {
       const uint32_t n = len < DV_PIECE ? len : DV_PIECE;
+#pragma clang loop unroll(disable) vectorize(disable)
       for (uint32_t b = 0; b < n; b += 64) {
         // by periodicity out[cur + l] = out[cur - off + (l mod off)]: every source lies before `cur`, so the 64 lanes read
         // (one LDS instruction) before any of them writes
         const uint32_t cur = op + b;
-        const uint32_t j = off >= 64 ? lane : lane % off;
+        uint32_t j = lane;
+        if (off < 64) j = lane % off;
         if (b + lane < n) {
           const uint8_t v = win[(cur - off + j + sh) & DWM];
           win[(cur + lane + sh) & DWM] = v;
@@ -145,6 +184,7 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
   z.dst = dst + lev; z.cap = P.uncomp_len - lev; z.op = 0; z.flushed = 0; z.sh = (uint32_t)((uintptr_t)z.dst & 15u);
   z.win = dv_lds; z.inb = dv_lds + DW; z.lane = lane; z.bad = false;
   z.refill();
+  z.look();
   if (codec == CODEC_SNAPPY) {
     // preamble: the uncompressed length as a varint
     uint64_t total = 0;
@@ -157,10 +197,33 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
     }
     if (!fin || total != (uint64_t)z.cap) z.bad = true;
     while (!z.bad && z.q < z.qend) {
-      z.need(8);
       const uint32_t left = z.qend - z.q;
-      const uint32_t tag = z.in(0);
+      if (z.q - z.laq > 58) z.look();
+      const uint32_t w = z.q - z.laq;
+      const uint32_t tag = z.peek(w);
       const uint32_t kind = tag & 3u;
+      // fast path: a short element that lies whole in the look-ahead register and the staged input, away from the end
+      if (left >= 70 && z.qload - z.q > 64) {
+        if (kind == 0) {
+          const uint32_t len = (tag >> 2) + 1;
+          if (len <= 60 && len <= z.cap - z.op) {
+            z.literal64(len, 1);
+            z.q += 1 + len;
+            if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
+            continue;
+          }
+        } else if (kind != 3) {
+          uint32_t len, off, hdr;
+          if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | z.peek(w + 1); hdr = 2; }
+          else { len = (tag >> 2) + 1; off = z.peek(w + 1) | (z.peek(w + 2) << 8); hdr = 3; }
+          if (off != 0 && off <= z.op && len <= z.cap - z.op) {
+            z.q += hdr;
+            z.match64(len, off);
+            if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
+            continue;
+          }
+        }
+      }
       if (kind == 0) {
         uint32_t len = (tag >> 2) + 1, hdr = 1;
         if (len > 60) {
@@ -194,14 +257,29 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
     }
   } else {  // LZ4 block format
     while (!z.bad && z.q < z.qend) {
-      z.need(8);
+      if (z.q - z.laq > 40) z.look();
+      {
+        // fast path: literal and match lengths without extension bytes, the sequence whole in the look-ahead register and the
+        // staged input, away from the end of the block
+        const uint32_t w = z.q - z.laq;
+        const uint32_t t = z.peek(w);
+        const uint32_t lit = t >> 4, ml = t & 15u;
+        if (lit < 15 && ml < 15 && z.qend - z.q >= 96 && z.qload - z.q > 64 && lit <= z.cap - z.op) {
+          if (lit) z.literal64(lit, 1);
+          const uint32_t off = z.peek(w + 1 + lit) | (z.peek(w + 2 + lit) << 8);
+          z.q += 3 + lit;
+          if (off == 0 || off > z.op || ml + 4 > z.cap - z.op) { z.bad = true; break; }
+          z.match64(ml + 4, off);
+          if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
+          continue;
+        }
+      }
       const uint32_t token = z.in(0);
       z.q += 1;
       uint32_t lit = token >> 4;
       if (lit == 15) {
         for (;;) {
           if (z.q >= z.qend) { z.bad = true; break; }
-          z.need(8);
           const uint32_t b = z.in(0);
           z.q += 1;
           if (lit > 0x7FFFFFFFu - b) { z.bad = true; break; }
@@ -212,7 +290,6 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
       }
       if (lit) z.literal(lit);
       if (z.bad || z.q >= z.qend) break;  // the last sequence ends with its literals
-      z.need(8);
       if (z.qend - z.q < 2) { z.bad = true; break; }
       const uint32_t off = z.in(0) | (z.in(1) << 8);
       z.q += 2;
@@ -220,7 +297,6 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
       if (ml == 15) {
         for (;;) {
           if (z.q >= z.qend) { z.bad = true; break; }
-          z.need(8);
           const uint32_t b = z.in(0);
           z.q += 1;
           if (ml > 0x7FFFFFFFu - b - 4) { z.bad = true; break; }
@@ -249,13 +325,20 @@ __device__ __forceinline__ uint64_t dv_peek8(const uint8_t* __restrict__ s, uint
   return v;
 }
 
-// varint at s[*pos ..): false when it runs past `len` or is longer than 8 bytes (56 bits: no count in a page needs more)
+// varint at s[*pos ..): false when it runs past `len` or does not end within 10 bytes
 __device__ __forceinline__ bool dv_varint(const uint8_t* __restrict__ s, uint32_t* pos, uint32_t len, uint64_t* out) {
   const uint64_t w = dv_peek8(s, *pos, len);
   uint64_t v = 0;
   for (int k = 0; k < 8; ++k) {
     if (*pos + (uint32_t)k >= len) return false;
     const uint32_t b = (uint32_t)(w >> (8 * k)) & 0xFFu;
+    v |= (uint64_t)(b & 0x7F) << (7 * k);
+    if (!(b & 0x80)) { *pos += (uint32_t)k + 1; *out = v; return true; }
+  }
+  // bytes 9 and 10 (a zigzag 64-bit first value / min delta)
+  for (int k = 8; k < 10; ++k) {
+    if (*pos + (uint32_t)k >= len) return false;
+    const uint32_t b = s[*pos + k];
     v |= (uint64_t)(b & 0x7F) << (7 * k);
     if (!(b & 0x80)) { *pos += (uint32_t)k + 1; *out = v; return true; }
   }
