@@ -169,12 +169,12 @@ __device__ __forceinline__ bool dec_row(const DecOp& p, i128 av, i128 bv, bool a
 }
 
 
-// The division-free subset of dec_row, inlined by the fused interpreter (dev_expr.h): operand conversions (multiplies by
-// powers of ten with their range checks), plus / minus with the precision-38/18 check, multiply at scale_mul == 0.
-// The rounding multiply (scale_mul > 0) and divide need 128- / 256-bit divisions that the compiler expands in place
-// (~600 instructions each, half a dozen per row slot: larger than the instruction cache; as an out-of-line call they cost
-// 2 KB of scratch per lane for the callee-saved registers) — the host rejects such nodes for fused programs and the
-// binding evaluates them with dbhip_decimal_arith.
+// The division-free subset of dec_row, inlined by the fused interpreter (dev_expr.h) for every node that does not divide: operand
+// conversions (multiplies by powers of ten with their range checks), plus / minus with the precision-38/18 check, multiply at
+// scale_mul == 0. The rounding multiply (scale_mul > 0) and divide need 128- / 256-bit divisions that the compiler expands in place
+// (~600 instructions each); nodes that need them (dec_op_needs_division) go through the full dec_row — in the interpreter ONE
+// copy inside a rolled loop over the lane's row slots, in the run-time specialised kernels per slot with the DecOp folded to
+// constants (decimal/src/arithmetic.rs:212-243).
 __device__ __forceinline__ bool dec_row_nodiv(const DecOp& p, i128 av, i128 bv, bool a_dec, bool b_dec, bool t128, i128* out) {
   i128 a, b, r = 1;
   bool ok = convert_operand(av, a_dec, p.a_from_scale, p.a_to_scale, p.a_to_precision, p.a_check, t128, &a);
@@ -195,7 +195,7 @@ __device__ __forceinline__ bool dec_row_nodiv(const DecOp& p, i128 av, i128 bv, 
   *out = r;
   return ok;
 }
-inline bool dec_op_needs_division(const DecOp& p) { return p.op == DBHIP_OP_DIVIDE || (p.op == DBHIP_OP_MULTIPLY && p.scale_mul != 0); }
+__host__ __device__ inline bool dec_op_needs_division(const DecOp& p) { return p.op == DBHIP_OP_DIVIDE || (p.op == DBHIP_OP_MULTIPLY && p.scale_mul != 0); }
 
 // host: decode one decimal call node (k_decimal.hip)
 int32_t dbhip_decimal_decode_internal(int op, int a_type, int a_prec, int a_scale, int b_type, int b_prec, int b_scale,

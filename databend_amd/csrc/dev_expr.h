@@ -113,7 +113,9 @@ enum {
 // `P`: the program's metadata, `PA`: its pointers (the same object ahead of time; under DBHIP_JIT — the run-time compiled
 // specialisation, fagg_device.h — P is a constexpr, the pc loop is unrolled, every switch below folds, and ex_regs is a
 // per-lane array in VGPRs indexed by constants).
-template <int ROWS>
+// DIV: the instantiation carries the long divisions of the rounding decimal multiply / divide (only programs with such a node launch
+// it: ~16 more VGPRs); the run-time specialised kernels always do (their DecOps are constants: nothing is paid by programs without one).
+template <int ROWS, bool DIV = false>
 __device__ __forceinline__ void ex_interpret(const ExProg& P, const ExProg& PA, uint64_t* ex_regs, int tid, int pc0, int pc1,
                                              const int64_t (&row)[ROWS], const bool (&live)[ROWS],
                                              const uint32_t (&vmask)[ROWS]) {
@@ -198,6 +200,34 @@ __device__ __forceinline__ void ex_interpret(const ExProg& P, const ExProg& PA, 
             EX_REG(I.dst, k) = (uint64_t)(u128)r;
             if (I.o_wide) EX_REG(I.dst + 1, k) = (uint64_t)((u128)r >> 64);
           }
+#ifdef DBHIP_JIT
+#define EX_DIV_OK true
+#else
+#define EX_DIV_OK DIV
+#endif
+        } else if (EX_DIV_OK && dec_op_needs_division(*D)) {
+          // rounding multiply / divide (do_round_mul / do_round_div, types/decimal.rs:759-797,1024-1064): the long divisions of
+          // dec_row. Interpreter: the register file is LDS, so the slots can be walked by a ROLLED loop — one copy of the
+          // division code, not ROWS; specialised kernel: registers indexed by constants, unrolled, the divisor 10^k a constant.
+          uint32_t bad = 0;
+#ifdef DBHIP_JIT
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+          for (int k = 0; k < ROWS; ++k) {
+            const i128 av = EX_RD128(I.a, I.a_wide, acls, k), bv = EX_RD128(I.b, I.b_wide, bcls, k);
+            i128 r;
+            if (!dec_row(*D, av, bv, I.a_dec != 0, I.b_dec != 0, t128, &r)) {
+              bad |= 1u << k;
+              r = 1;  // error rows hold T::one(), like the reference builders
+            }
+            EX_REG(I.dst, k) = (uint64_t)(u128)r;
+            if (I.o_wide) EX_REG(I.dst + 1, k) = (uint64_t)((u128)r >> 64);
+          }
+#pragma unroll
+          for (int k = 0; k < ROWS; ++k)
+            if ((bad >> k) & 1u) EX_RAISE(k);
         } else {
 #pragma unroll
           for (int k = 0; k < ROWS; ++k) {

@@ -40,7 +40,7 @@ struct ExOut {
 // HBM round trip of its own.
 // NIN: compile-time bound of the input count (unused slots cost neither code nor VGPRs); ALL8: every input is a
 // plain 8-byte non-scalar column (i64 / u64 / f64 / timestamp / decimal64) — straight-line loads, no kind tests.
-template <int NIN, bool ALL8, int ROWS>
+template <int NIN, bool ALL8, int ROWS, bool DIV = false>
 __global__ __launch_bounds__(256) void expr_kernel(ExProg P, ExOut O) {
   extern __shared__ uint64_t ex_regs[];  // [n_slots][ROWS][256]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void expr_kernel(ExProg P, ExOut O) {
       }
     }
     // ---- interpret (wave-uniform instruction stream): ONE dispatch per instruction, the row slots loop inside the case ----
-    ex_interpret<ROWS>(P, P, ex_regs, tid, 0, P.n_ins, row, in_range, vmask);
+    ex_interpret<ROWS, DIV>(P, P, ex_regs, tid, 0, P.n_ins, row, in_range, vmask);
     // ---- result ----
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
@@ -293,11 +293,6 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
             return DBHIP_ERR_INVALID;
           }
           DecOp& D = P.dec[n_dec];
-          if (dec_op_needs_division(D)) {
-            set_error("expression program: instruction %d: a rounding decimal multiply (scale shift %d) / divide is not fused (128-bit division); "
-                      "evaluate the node with dbhip_decimal_arith", i, D.scale_mul);
-            return DBHIP_ERR_UNSUPPORTED;
-          }
           ex_decode(d, ra.type, rb.type);
           d.op = EX_DEC; d.dec_idx = (int8_t)n_dec++;
           d.a_dec = ex_decimal(ra.type); d.b_dec = ex_decimal(rb.type);
@@ -332,7 +327,7 @@ int32_t dbhip_expr_compile_internal(const dbhip_expr_ins* prog_host, int32_t n_i
           {
             ExIns& nd = P.ins[n_out];
             const bool pass_a = nd.a_dec ? !D.a_check : D.a_to_scale == 0, pass_b = nd.b_dec ? !D.b_check : D.b_to_scale == 0;
-            D.trivial = pass_a && pass_b && (((D.op == DBHIP_OP_PLUS || D.op == DBHIP_OP_MINUS) && !D.overflow) || D.op == DBHIP_OP_MULTIPLY);
+            D.trivial = pass_a && pass_b && !dec_op_needs_division(D) && (((D.op == DBHIP_OP_PLUS || D.op == DBHIP_OP_MINUS) && !D.overflow) || D.op == DBHIP_OP_MULTIPLY);
             res.may_raise = !D.trivial;
           }
           res.precision = op_; res.scale = os_;
@@ -562,8 +557,11 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
   kernel_timer_start(s);
   // row slots per lane: 4 (32 B per operand per lane in flight, half the per-row interpreter overhead) while the LDS register
   // file allows it, else 2
+  // a program with a rounding decimal multiply / divide runs the one instantiation that carries the long divisions
+  bool has_div = false;
+  for (int i = 0; i < P.n_ins; ++i) has_div |= P.ins[i].op == EX_DEC && dec_op_needs_division(P.dec[P.ins[i].dec_idx]);
   int rows_per_lane = 2;
-  if (!force2 && (size_t)P.n_slots * 4 * 256 * 8 <= 64 * 1024) rows_per_lane = 4;
+  if (!force2 && !has_div && (size_t)P.n_slots * 4 * 256 * 8 <= 64 * 1024) rows_per_lane = 4;
   const size_t lds = (size_t)(P.n_slots > 0 ? P.n_slots : 1) * rows_per_lane * 256 * 8;
   if (lds > 64 * 1024) {
     set_error("dbhip_expr_eval: %d live registers exceed the LDS register file; split the expression", P.n_slots);
@@ -581,7 +579,9 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
     if (all8) hipLaunchKernelGGL((expr_kernel<NIN_, true, R_>), g, b, lds, s, P, O);           \
     else hipLaunchKernelGGL((expr_kernel<NIN_, false, R_>), g, b, lds, s, P, O);               \
   } while (0)
-  if (rows_per_lane == 4) {
+  if (has_div) {
+    hipLaunchKernelGGL((expr_kernel<8, false, 2, true>), g, b, lds, s, P, O);
+  } else if (rows_per_lane == 4) {
     if (n_inputs <= 2) EX_LAUNCH(2, 4); else if (n_inputs <= 4) EX_LAUNCH(4, 4); else EX_LAUNCH(8, 4);
   } else {
     if (n_inputs <= 2) EX_LAUNCH(2, 2); else if (n_inputs <= 4) EX_LAUNCH(4, 2); else EX_LAUNCH(8, 2);

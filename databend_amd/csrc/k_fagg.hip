@@ -684,7 +684,12 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     } else {
       ++g_fa_interp_launches;
     }
+    // (interpreted) a program with a rounding decimal multiply / divide: the instantiations that carry the long divisions
+    bool has_div = false;
+    for (int i = 0; i < A.P.n_ins; ++i) has_div |= A.P.ins[i].op == EX_DEC && dec_op_needs_division(A.P.dec[A.P.ins[i].dec_idx]);
     if (jf) {}
+    else if (has_div && variant == 0) hipLaunchKernelGGL((fagg_kernel<4, true, FA_MAXW, true>), dim3(grid), dim3(256), lds, s, A);
+    else if (has_div) hipLaunchKernelGGL((fagg_kernel<8, true, FA_MAXW, true>), dim3(grid), dim3(256), lds, s, A);
     else if (variant == 0 && !general) FA_LAUNCH(4, false);
     else if (variant == 0) FA_LAUNCH(4, true);
     else if (!general) FA_LAUNCH(8, false);

@@ -63,14 +63,14 @@ def test_fused_decimal_program_equals_the_per_node_decimal_semantics(gpu, oracle
     assert res["values"] == v_ch
     assert np.array_equal(res["validity"], pv)
 
-    # a rounding multiply (Decimal(15,8) * Decimal(15,8) -> scale 12: divides by 10^4) needs a 128-bit division: outside the
-    # fused subset, reported as UNSUPPORTED (the binding evaluates that node with dbhip_decimal_arith)
+    # a rounding multiply (Decimal(15,8) * Decimal(15,8) -> scale 12: divides by 10^4, arithmetic.rs:212-243) is fused since round 4
     x = rng.integers(-10**14, 10**14, n).astype(np.int64)
     cx = gpu.Column.from_numpy(x, T.T_DEC64, precision=15, scale=8)
     p2 = gpu.ExprProgram([cx, cx])
-    with pytest.raises(T.DbhipError) as e2:
-        p2.run(p2.arith(T.EX_MULTIPLY, p2.load(0), p2.load(1)), n)
-    assert e2.value.code == T.ERR_UNSUPPORTED
+    r2 = p2.run(p2.arith(T.EX_MULTIPLY, p2.load(0), p2.load(1)), n)
+    hx = O.HostCol(T.T_DEC64, x, None, 15, 8)
+    v2, ok2, t2, pp2, ss2 = oracle_decimal(oracle, T.OP_MULTIPLY, hx, hx, n)
+    assert ss2 == 12 and r2["type"] == t2 and r2["size"] == (pp2, ss2) and ok2.all() and r2["values"] == v2
 
     # Decimal128 + Decimal64 (rescale of the narrower side), then a comparison of two Decimal128 values, then if()
     big = [int(v) * 10**9 for v in rng.integers(-10**17, 10**17, n)]
@@ -122,6 +122,111 @@ def test_fused_decimal_program_row_errors(gpu, oracle):
     got = res["values"]
     assert all(got[i] == v[i] for i in range(n) if not really[i])
     assert all(got[i] == 1 for i in bad)
+
+
+DIV_CASES = [
+    # (op, a: (type, precision, scale, lo, hi), b: likewise) — every branch of dec_row that divides
+    (T.OP_MULTIPLY, (T.T_DEC64, 9, 6, -10**8, 10**8), (T.T_DEC64, 9, 6, -10**8, 10**8)),          # T = i64, rounding multiply, checked range
+    (T.OP_MULTIPLY, (T.T_DEC64, 15, 8, -10**14, 10**14), (T.T_DEC64, 15, 8, -10**14, 10**14)),    # T = i128, no overflow check
+    (T.OP_MULTIPLY, (T.T_DEC128, 38, 10, -10**30, 10**30), (T.T_DEC64, 18, 10, -10**17, 10**17)),  # T = i128 at precision 38: 256-bit product, may overflow
+    (T.OP_DIVIDE, (T.T_DEC64, 9, 2, -10**8, 10**8), (T.T_DEC64, 9, 4, -300, 300)),                # divide, zero divisors raise
+    (T.OP_DIVIDE, (T.T_DEC64, 15, 2, -10**14, 10**14), (T.T_DEC64, 15, 2, -10**6, 10**6)),        # divide in i128
+    (T.OP_DIVIDE, (T.T_DEC128, 30, 4, -10**27, 10**27), (T.T_DEC64, 15, 8, -10**10, 10**10)),
+    (T.OP_DIVIDE, (T.T_DEC64, 15, 2, -10**14, 10**14), (T.T_I32, 0, 0, -5, 5)),                   # integer operand (other_to_decimal)
+]
+
+
+@pytest.mark.parametrize("ci", range(len(DIV_CASES)))
+def test_fused_rounding_multiply_and_divide_equal_the_oracle(gpu, oracle, ci):
+    """The rounding decimal multiply (scale shift > 0) and the decimal divide INSIDE a fused program (decimal/src/arithmetic.rs:212-243,
+    types/decimal.rs:759-797,1024-1064: do_round_mul / do_round_div): values, result size and the raising rows (division by zero, results
+    beyond the precision) equal the oracle's binary_decimal; NULL rows of a nullable operand never raise."""
+    op, (ta, pa, sa, loa, hia), (tb, pb, sb, lob, hib) = DIV_CASES[ci]
+    n = 20_011
+    rng = np.random.default_rng(40 + ci)
+
+    def make(t, pr, sc, lo, hi, validity=None):
+        if t == T.T_DEC128:
+            vals = [int(v) * (hi // 10**17 or 1) for v in rng.integers(-10**17, 10**17, n)]
+            vals = [max(min(v, hi - 1), lo) for v in vals]
+            return gpu.Column.decimal128(vals, pr, sc, validity=validity), O.HostCol(T.T_DEC128, O.i128_array(vals), validity, pr, sc)
+        if t == T.T_I32:
+            v = rng.integers(lo, hi + 1, n).astype(np.int32)
+            return gpu.Column.from_numpy(v, validity=validity), O.HostCol(T.T_I32, v, validity)
+        v = rng.integers(lo, hi, n).astype(np.int64)
+        v[::97] = 0
+        return gpu.Column.from_numpy(v, T.T_DEC64, validity=validity, precision=pr, scale=sc), O.HostCol(T.T_DEC64, v, validity, pr, sc)
+    bvalid = rng.integers(0, 8, n) > 0
+    ca, ha = make(ta, pa, sa, loa, hia)
+    cb, hb = make(tb, pb, sb, lob, hib, validity=bvalid)
+    p = gpu.ExprProgram([ca, cb])
+    ex = {T.OP_MULTIPLY: T.EX_MULTIPLY, T.OP_DIVIDE: T.EX_DIVIDE}[op]
+    errs = gpu.RowErrors(n)
+    res = p.run(p.arith(ex, p.load(0), p.load(1)), n, errors=errs)
+    v, ok, t, pp, ss = oracle_decimal(oracle, op, ha, hb, n)
+    assert res["type"] == t and res["size"] == (pp, ss)
+    bad = np.nonzero(~ok)[0]                                  # (the oracle skips NULL rows like the reference's evaluator)
+    assert np.array_equal(errs.error_rows(), bad) and errs.num_errors() == len(bad)
+    if op == T.OP_DIVIDE:
+        assert len(bad) > 0
+    got = res["values"]
+    live = ok & bvalid
+    assert all(got[i] == v[i] for i in np.nonzero(live)[0])
+    assert all(got[i] == 1 for i in bad)
+    assert np.array_equal(res["validity"], bvalid)
+
+
+def test_fused_aggregation_over_a_rescaling_q1_variant(gpu, oracle):
+    """A Q1-like query whose scales force a rescale — sum(price * discount) with Decimal(15,8) columns (a rounding multiply) and
+    sum(quantity / price) (a divide) — stays ONE fused filter + map + aggregate program: interpreted first, then PREPAREd (run-time
+    specialised, the divisors folded to constants); both equal filter -> maps -> hash aggregation of the oracle."""
+    n = 120_007
+    rng = np.random.default_rng(77)
+    k = rng.integers(0, 3, n).astype(np.int64)
+    ship = rng.integers(8000, 10600, n).astype(np.int32)
+    qty = (rng.integers(1, 51, n) * 100).astype(np.int64)
+    price = rng.integers(10**8, 10**13, n).astype(np.int64)
+    disc = rng.integers(0, 10**7, n).astype(np.int64)
+    aggs = None
+
+    def run(prepare):
+        nonlocal aggs
+        cs = gpu.Column.from_numpy(ship, T.T_DATE)
+        cq = gpu.Column.from_numpy(qty, T.T_DEC64, precision=15, scale=2)
+        cp = gpu.Column.from_numpy(price, T.T_DEC64, precision=15, scale=8)
+        cd = gpu.Column.from_numpy(disc, T.T_DEC64, precision=15, scale=8)
+        p = gpu.ExprProgram([cs, cq, cp, cd])
+        f = p.cmp(T.EX_LTE, p.load(0), p.const(10471, T.T_DATE))
+        q, pr, di = p.load(1), p.load(2), p.load(3)
+        prod = p.arith(T.EX_MULTIPLY, pr, di, keep=(pr,))
+        quo = p.arith(T.EX_DIVIDE, q, pr, keep=(q,))
+        aggs = [(T.AGG_SUM, T.T_DEC64, 15, 2, 0), (T.AGG_SUM, p.types[prod], p.size[prod][0], p.size[prod][1], 0),
+                (T.AGG_SUM, p.types[quo], p.size[quo][0], p.size[quo][1], 0), (T.AGG_COUNT, 0, 0, 0, 0)]
+        g = gpu.GroupBy([T.T_I64], aggs)
+        if prepare:
+            g.prepare_program([gpu.Column.from_numpy(k)], p, [q, prod, quo, None], filter_reg=f)    # blocks until the kernel is loaded
+        g.add_block_program([gpu.Column.from_numpy(k)], p, [q, prod, quo, None], n, filter_reg=f)
+        return g, (p.types[prod], p.size[prod]), (p.types[quo], p.size[quo])
+    before = fagg_stats()
+    g0, tprod, tquo = run(False)
+    mid = fagg_stats()
+    g1, _, _ = run(True)
+    after = fagg_stats()
+    assert mid["interpreted"] > before["interpreted"] or mid["jit"] > before["jit"]     # (an earlier run may have left the kernel in the cache)
+    assert after["jit"] > mid["jit"]
+    sel = np.nonzero(ship <= 10471)[0]
+    m = len(sel)
+    hq = O.HostCol(T.T_DEC64, qty[sel], None, 15, 2)
+    hp, hd = O.HostCol(T.T_DEC64, price[sel], None, 15, 8), O.HostCol(T.T_DEC64, disc[sel], None, 15, 8)
+    vprod, okp, t1, p1, s1 = oracle_decimal(oracle, T.OP_MULTIPLY, hp, hd, m)
+    vquo, okq, t2, p2, s2 = oracle_decimal(oracle, T.OP_DIVIDE, hq, hp, m)
+    assert okp.all() and okq.all() and (t1, (p1, s1)) == tprod and (t2, (p2, s2)) == tquo
+    harg = lambda vals, t, pp, ss: O.HostCol(t, O.i128_array(vals) if t == T.T_DEC128 else np.array(vals, np.int64), None, pp, ss)
+    h = oracle_groupby(oracle, [T.T_I64], [0], aggs, [O.HostCol(T.T_I64, k[sel])], [hq, harg(vprod, t1, p1, s1), harg(vquo, t2, p2, s2), None], m)
+    exp = oracle_rows(oracle, h, [T.T_I64], aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert norm(g0.result()) == norm(exp)
+    assert norm(g1.result()) == norm(exp)
 
 
 Q_KEYS = ([T.T_I64, T.T_STRING], [1, 0])

@@ -46,6 +46,20 @@ def q1_shape():
     return [L.T_STRING, L.T_STRING], [0, 0], aggs, [FakeCol(L.T_STRING), FakeCol(L.T_STRING)], p, [q, pr, dp, ch, di, None], f
 
 
+def q1_rescale_shape():
+    """Q1 with scales that force a rescale: extendedprice / discount as Decimal(15,8) — their product is a ROUNDING multiply
+    (scale 16 -> 12: divides by 10^4, decimal/src/arithmetic.rs:212-243) — and sum(quantity / price), a decimal divide"""
+    ship, qty, price, disc = FakeCol(L.T_DATE), FakeCol(L.T_DEC64, 15, 2), FakeCol(L.T_DEC64, 15, 8), FakeCol(L.T_DEC64, 15, 8)
+    p = D.ExprProgram([ship, qty, price, disc])
+    f = p.cmp(L.EX_LTE, p.load(0), p.const(10471, L.T_DATE))
+    q, pr, di = p.load(1), p.load(2), p.load(3)
+    prod = p.arith(L.EX_MULTIPLY, pr, di, keep=(pr,))
+    quo = p.arith(L.EX_DIVIDE, q, pr, keep=(q,))
+    aggs = [(L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_SUM, p.types[prod], p.size[prod][0], p.size[prod][1], 0),
+            (L.AGG_SUM, p.types[quo], p.size[quo][0], p.size[quo][1], 0), (L.AGG_COUNT, 0, 0, 0, 0)]
+    return [L.T_STRING, L.T_STRING], [0, 0], aggs, [FakeCol(L.T_STRING), FakeCol(L.T_STRING)], p, [q, prod, quo, None], f
+
+
 def plain4_shape():
     a = FakeCol(L.T_I64)
     p = D.ExprProgram([a])
@@ -98,7 +112,7 @@ def main():
     ap.add_argument("--defs", default="")
     ap.add_argument("--keep", default="/tmp/jit_offline")
     a = ap.parse_args()
-    code = compile_shape({"q1": q1_shape, "plain4": plain4_shape, "general": general_shape}[a.shape](), a.slots, a.defs)
+    code = compile_shape({"q1": q1_shape, "q1rescale": q1_rescale_shape, "plain4": plain4_shape, "general": general_shape}[a.shape](), a.slots, a.defs)
     open(a.keep + ".co", "wb").write(code)
     llvm = "/opt/rocm/lib/llvm/bin"
     asm = subprocess.run([f"{llvm}/llvm-objdump", "-d", a.keep + ".co"], capture_output=True, text=True, check=True).stdout
