@@ -441,6 +441,29 @@ def bench_operator_plan(li, tpch, D, L, check, fused_result, fused_kernel_ms):
         except Exception as e:  # noqa: BLE001 — a plan that cannot run is reported, not hidden
             out[name] = {"error": repr(e)}
         check(L.dbhip_trim())
+    # a Q1 variant whose scales force a rescale (a rounding multiply and a decimal divide per row) stays ONE fused program since round 4
+    if hasattr(tpch, "q1_rescale_fused"):
+        try:
+            import ctypes as _C
+            plan = tpch.q1_rescale_program(li)
+            t0 = time.perf_counter()
+            tpch.q1_rescale_fused(li, prepare=True, plan=plan)
+            prep = (time.perf_counter() - t0) * 1e3
+            g = tpch.q1_rescale_fused(li, plan=plan)
+            ngroups = len(g.result())
+            ts = _timed_ms(lambda: tpch.q1_rescale_fused(li, plan=plan), L, check, 3)
+            kms = _C.c_float()
+            L.dbhip_last_kernel_ms(_C.byref(kms))
+            bytes_per_row = 4 + 8 + 8 + 8 + 2
+            out["fused_program_rescale"] = {
+                "what": "sum(qty), sum(price{15,8} * disc{15,8}) [rounding multiply], sum(qty / price{15,8}) [decimal divide], count(*) "
+                        "WHERE shipdate <= cutoff GROUP BY returnflag, linestatus — one dbhip_groupby_add_block_program launch",
+                "ms": min(ts), "all_ms": ts, "kernel_ms": kms.value, "prepare_ms": prep, "groups": ngroups,
+                "algorithmic_bytes_per_row": bytes_per_row, "hbm_frac_algorithmic": n * bytes_per_row / (min(ts) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "parity": "tests/test_gpu_fused.py::test_fused_aggregation_over_a_rescaling_q1_variant (oracle), DIV_CASES"}
+        except Exception as e:  # noqa: BLE001
+            out["fused_program_rescale"] = {"error": repr(e)}
+        check(L.dbhip_trim())
     return out
 
 

@@ -223,6 +223,32 @@ def q1_fused_program(li, g=None, cutoff=Q1_CUTOFF, prepare=False, plan=None, str
     return g
 
 
+def q1_rescale_program(li, cutoff=Q1_CUTOFF):
+    """A Q1-like pipeline whose scales FORCE a rescale (VERDICT r03 missing #5): l_extendedprice and l_discount taken as Decimal(15,8)
+    — their product is a ROUNDING multiply (scale 16 -> 12: a division by 10^4 per row, decimal/src/arithmetic.rs:212-243) — and
+    sum(l_quantity / l_extendedprice), a decimal divide. -> (program, keys, argument registers, filter register, aggregate list)."""
+    price8 = D.Column(L.T_DEC64, li.n, li.price.data, None, 15, 8)
+    disc8 = D.Column(L.T_DEC64, li.n, li.disc.data, None, 15, 8)
+    p = D.ExprProgram([li.ship, li.qty, price8, disc8])
+    f = p.cmp(L.EX_LTE, p.load(0), p.const(cutoff, L.T_DATE))
+    qty, price, disc = p.load(1), p.load(2), p.load(3)
+    prod = p.arith(L.EX_MULTIPLY, price, disc, keep=(price,))
+    quo = p.arith(L.EX_DIVIDE, qty, price, keep=(qty,))
+    aggs = [(L.AGG_SUM, L.T_DEC64, 15, 2, 0), (L.AGG_SUM, p.types[prod], p.size[prod][0], p.size[prod][1], 0),
+            (L.AGG_SUM, p.types[quo], p.size[quo][0], p.size[quo][1], 0), (L.AGG_COUNT, 0, 0, 0, 0)]
+    return p, [li.rf, li.ls], [qty, prod, quo, None], f, aggs
+
+
+def q1_rescale_fused(li, g=None, prepare=False, plan=None, stream=None):
+    p, keys, regs, f, aggs = plan or q1_rescale_program(li)
+    g = g or D.GroupBy([L.T_STRING, L.T_STRING], aggs, [0, 0])
+    if prepare:
+        g.prepare_program(keys, p, regs, filter_reg=f)
+        return g
+    g.add_block_program(keys, p, regs, li.n, filter_reg=f, stream=stream)
+    return g
+
+
 def q1_rows(g):
     """-> {(returnflag, linestatus): dict} from a Q1 group-by table."""
     out = {}
