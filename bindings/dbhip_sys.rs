@@ -275,6 +275,8 @@ extern "C" {
     pub fn dbhip_groupby_exchange_allgather(g: *mut dbhip_groupby, c: *mut dbhip_comm, max_rows: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_groupby_exchange_alltoall(g: *mut dbhip_groupby, c: *mut dbhip_comm, max_rows: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_exchange_begin(c: *mut dbhip_comm, cols: *const dbhip_col, ncols: i32, dest_index: *const u32, n: i64, out_recv_rows_host: *mut i64, out_host: *mut *mut dbhip_exchange, stream: *mut c_void) -> i32;
+    pub fn dbhip_shuffle_exchange_begin(c: *mut dbhip_comm, keys: *const dbhip_col, nkeys: i32, cols: *const dbhip_col, ncols: i32, n: i64, out_recv_rows_host: *mut i64, out_host: *mut *mut dbhip_exchange, stream: *mut c_void) -> i32;
+    pub fn dbhip_sort_exchange_begin(c: *mut dbhip_comm, keys: *const dbhip_col, bounds: *const dbhip_col, desc_host: *const u8, nulls_first_host: *const u8, nkeys: i32, nbounds: i64, cols: *const dbhip_col, ncols: i32, n: i64, out_recv_rows_host: *mut i64, out_host: *mut *mut dbhip_exchange, stream: *mut c_void) -> i32;
     pub fn dbhip_exchange_finish(x: *mut dbhip_exchange, out_data_host: *const *mut c_void, out_validity_host: *const *mut u8, out_src_starts_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_exchange_destroy(x: *mut dbhip_exchange) -> i32;
     pub fn dbhip_vec_topk_allgather(c: *mut dbhip_comm, idx_dev: *const u32, dist_dev: *const f32, nq: i32, k: i32, row_offset: u64, out_idx_dev: *mut u32, out_dist_dev: *mut f32, stream: *mut c_void) -> i32;

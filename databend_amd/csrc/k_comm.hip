@@ -315,6 +315,46 @@ int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols
   return DBHIP_OK;
 }
 
+// The two plans that sit on the exchange, as single calls (SURVEY §8e "hash join: shuffle" and "sort"): where each row goes is decided
+// by the reference's own rules — dbhip_scatter_indices (flight_scatter_hash.rs: siphash64 of the keys % nodes) / dbhip_sort_bound_partition
+// (sort_spill.rs BoundBlockStream + sort_exchange_injector.rs: partition i -> node i % n) — then dbhip_exchange_begin.
+int32_t dbhip_shuffle_exchange_begin(dbhip_comm* c, const dbhip_col* keys, int32_t nkeys, const dbhip_col* cols, int32_t ncols, int64_t n,
+                                     int64_t* out_recv_rows_host, dbhip_exchange** out_host, void* stream) {
+  DBHIP_REQUIRE(c && keys && nkeys >= 1 && n >= 0, "dbhip_shuffle_exchange_begin: bad argument");
+  uint32_t* index = nullptr;
+  uint64_t* counts = nullptr;
+  int32_t rc = dbhip_alloc((size_t)(n > 0 ? n : 1) * 4, (void**)&index);
+  if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)c->world * 8, (void**)&counts);
+  if (rc == DBHIP_OK) rc = dbhip_scatter_indices(keys, nkeys, n, (uint32_t)c->world, 0, index, counts, stream);
+  if (rc == DBHIP_OK) rc = dbhip_exchange_begin(c, cols, ncols, index, n, out_recv_rows_host, out_host, stream);
+  if (index) (void)dbhip_free(index);      // (dbhip_free drains the device: the scatter that read `index` has finished)
+  if (counts) (void)dbhip_free(counts);
+  return rc;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void part_to_rank_kernel(uint32_t* part, int64_t n, uint32_t world) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) part[i] %= world;
+}
+}  // namespace
+
+int32_t dbhip_sort_exchange_begin(dbhip_comm* c, const dbhip_col* keys, const dbhip_col* bounds, const uint8_t* desc_host,
+                                  const uint8_t* nulls_first_host, int32_t nkeys, int64_t nbounds, const dbhip_col* cols, int32_t ncols,
+                                  int64_t n, int64_t* out_recv_rows_host, dbhip_exchange** out_host, void* stream) {
+  DBHIP_REQUIRE(c && keys && nkeys >= 1 && n >= 0 && nbounds >= 0 && (nbounds == 0 || bounds), "dbhip_sort_exchange_begin: bad argument");
+  uint32_t* part = nullptr;
+  uint64_t* counts = nullptr;
+  int32_t rc = dbhip_alloc((size_t)(n > 0 ? n : 1) * 4, (void**)&part);
+  if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)(nbounds + 1) * 8, (void**)&counts);
+  if (rc == DBHIP_OK) rc = dbhip_sort_bound_partition(keys, bounds, desc_host, nulls_first_host, nkeys, n, nbounds, part, counts, stream);
+  if (rc == DBHIP_OK && n > 0 && nbounds + 1 > c->world)   // more partitions than nodes: SortBoundScatter sends partition i to node i % n
+    hipLaunchKernelGGL(part_to_rank_kernel, dim3(grid_for(n, 256)), dim3(256), 0, resolve_stream(stream), part, n, (uint32_t)c->world);
+  if (rc == DBHIP_OK) rc = dbhip_exchange_begin(c, cols, ncols, part, n, out_recv_rows_host, out_host, stream);
+  if (part) (void)dbhip_free(part);
+  if (counts) (void)dbhip_free(counts);
+  return rc;
+}
+
 int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_src_starts_host,
                               void* stream) {
   DBHIP_REQUIRE(x && (x->cols.empty() || (out_data_host && out_validity_host)), "dbhip_exchange_finish: bad argument");

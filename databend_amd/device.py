@@ -1615,6 +1615,29 @@ class Comm:
         rows = C.c_int64()
         check(lib().dbhip_exchange_begin(self.h, _cols(cols), len(cols), C.c_void_p(dest_index.ptr if dest_index is not None else None), C.c_int64(n),
                                          C.byref(rows), C.byref(x), stream))
+        return self._finish_exchange(x, rows, cols, stream)
+
+    def shuffle_exchange_block(self, keys, cols, stream=None):
+        """dbhip_shuffle_exchange_begin + _finish: the hash shuffle as ONE plan call — destination = siphash64(keys) % world
+        (flight_scatter_hash.rs), then the exchange of `cols`. -> (received Columns, source starts)"""
+        x, rows = C.c_void_p(), C.c_int64()
+        check(lib().dbhip_shuffle_exchange_begin(self.h, _cols(keys), len(keys), _cols(cols), len(cols), C.c_int64(cols[0].n), C.byref(rows),
+                                                 C.byref(x), stream))
+        return self._finish_exchange(x, rows, cols, stream)
+
+    def sort_exchange_block(self, keys, bounds, cols, desc=None, nulls_first=None, stream=None):
+        """dbhip_sort_exchange_begin + _finish: the range partition of the distributed sort as ONE plan call — partition = bounds that sort
+        strictly before the row (sort_spill.rs), sent to rank partition % world (sort_exchange_injector.rs)."""
+        nk = len(keys)
+        d = (C.c_uint8 * nk)(*(desc or [0] * nk))
+        nf = (C.c_uint8 * nk)(*(nulls_first or [0] * nk))
+        nb = bounds[0].n if bounds else 0
+        x, rows = C.c_void_p(), C.c_int64()
+        check(lib().dbhip_sort_exchange_begin(self.h, _cols(keys), _cols(bounds) if bounds else None, d, nf, nk, C.c_int64(nb), _cols(cols), len(cols),
+                                              C.c_int64(cols[0].n), C.byref(rows), C.byref(x), stream))
+        return self._finish_exchange(x, rows, cols, stream)
+
+    def _finish_exchange(self, x, rows, cols, stream):
         try:
             m = rows.value
             outs = [DeviceBuffer(((m + 63) // 64) * 8 + 8) if c.dtype == L.T_BOOL else DeviceBuffer(max(m, 1) * ELEM_SIZE[c.dtype] + 64) for c in cols]

@@ -824,6 +824,19 @@ int32_t dbhip_groupby_exchange_alltoall(dbhip_groupby* g, dbhip_comm* c, int64_t
 typedef struct dbhip_exchange dbhip_exchange;
 int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
                              dbhip_exchange** out_host, void* stream);
+/* The two distributed plans that sit on the exchange, as single calls: the destination of every row by the reference's own rule, then
+ * dbhip_exchange_begin (finish / destroy as above).
+ *   dbhip_shuffle_exchange_begin  hash shuffle (flight_scatter_hash.rs:57-330): destination = siphash64 of the key columns % world
+ *                                 (dbhip_scatter_indices: bit-exact on the reference's golden values, so GPU and CPU nodes agree);
+ *                                 `cols` = the block to move (usually including the keys). Both sides of a shuffle join call it.
+ *   dbhip_sort_exchange_begin     range partition of the distributed sort (sort_spill.rs:740-1040, sort_exchange_injector.rs):
+ *                                 partition = number of bounds that sort strictly before the row (dbhip_sort_bound_partition),
+ *                                 sent to rank partition % world; the receiver sorts what arrives (dbhip_sort_perm). */
+int32_t dbhip_shuffle_exchange_begin(dbhip_comm* c, const dbhip_col* keys, int32_t nkeys, const dbhip_col* cols, int32_t ncols, int64_t n,
+                                     int64_t* out_recv_rows_host, dbhip_exchange** out_host, void* stream);
+int32_t dbhip_sort_exchange_begin(dbhip_comm* c, const dbhip_col* keys, const dbhip_col* bounds, const uint8_t* desc_host,
+                                  const uint8_t* nulls_first_host, int32_t nkeys, int64_t nbounds, const dbhip_col* cols, int32_t ncols,
+                                  int64_t n, int64_t* out_recv_rows_host, dbhip_exchange** out_host, void* stream);
 int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_src_starts_host,
                               void* stream);
 int32_t dbhip_exchange_destroy(dbhip_exchange* x);

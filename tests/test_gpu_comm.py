@@ -129,6 +129,54 @@ def test_block_exchange_between_ranks_routes_every_row_once(gpu, world):
     assert sum(o[3][-1] for o in outs) == sum(sizes)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_shuffle_and_sort_exchange_plans_behind_the_abi(gpu, world):
+    """dbhip_shuffle_exchange_begin / dbhip_sort_exchange_begin: the two distributed plans as single calls, no torch and no Python
+    plan logic. Shuffle: every received row hashes to the receiving rank (the reference's siphash64 % world) and the union of what the
+    ranks hold is the input. Sort: rank r receives exactly the rows of range partition r (rows <= bound[r] after bound[r - 1], in the
+    keys' order incl. NULLs-last), so sorting each rank locally and reading the ranks in order is the globally sorted column."""
+    D = gpu
+    rng = np.random.default_rng(300 + world)
+    gid = 7400 + world
+    sizes = [int(x) for x in rng.integers(1000, 30_000, world)]
+    keys = [rng.integers(-10**6, 10**6, n).astype(np.int64) for n in sizes]
+    kvalid = [rng.random(n) > 0.05 for n in sizes]
+    pays = [rng.integers(0, 2**50, n).astype(np.int64) for n in sizes]
+    allk = np.concatenate([np.where(v, k, 2**62) for k, v in zip(keys, kvalid)])        # (NULLs sort last: stand-in value for the bounds)
+    qs = np.sort(allk)[[len(allk) * (i + 1) // world for i in range(world - 1)]]
+    bounds = np.array(qs, np.int64)
+
+    def rank_fn(r):
+        comm = D.Comm.loopback(gid, r, world)
+        ck, cp = D.Column.from_numpy(keys[r], validity=kvalid[r]), D.Column.from_numpy(pays[r])
+        got, starts = comm.shuffle_exchange_block([ck], [ck, cp])
+        rk, rkv, rp = got[0].to_numpy(), got[0].validity_numpy(), got[1].to_numpy()
+        dest, _ = D.scatter_indices([got[0]], world, default_index=0) if got[0].n else (None, None)
+        d = dest.to_numpy(np.uint32, got[0].n) if dest is not None else np.zeros(0, np.uint32)
+        got2, _ = comm.sort_exchange_block([ck], [D.Column.from_numpy(bounds)], [ck, cp])
+        sk, skv, sp = got2[0].to_numpy(), got2[0].validity_numpy(), got2[1].to_numpy()
+        comm.destroy()
+        return (rk, rkv, rp, d, starts), (sk, skv, sp)
+    outs = run_ranks(world, rank_fn)
+    # shuffle: routed by the reference's hash, nothing lost, payload travels with its key
+    for r in range(world):
+        rk, rkv, rp, d, starts = outs[r][0]
+        assert (d == r).all() and starts[-1] == len(rk)
+    as_set = lambda ks, vs, ps: sorted((int(k) if v else None, int(p)) for k, v, p in zip(ks, vs, ps))
+    assert as_set(np.concatenate([o[0][0] for o in outs]), np.concatenate([o[0][1] for o in outs]), np.concatenate([o[0][2] for o in outs])) == \
+        as_set(np.concatenate(keys), np.concatenate(kvalid), np.concatenate(pays))
+    # sort: rank r holds range r
+    merged = []
+    for r in range(world):
+        sk, skv, sp = outs[r][1]
+        img = np.where(skv, sk, 2**62)
+        lo = bounds[r - 1] if r > 0 else -2**63
+        hi = bounds[r] if r < world - 1 else 2**63 - 1
+        assert ((img > lo) | (r == 0)).all() and (img <= hi).all()
+        merged.append(np.sort(img))
+    assert np.array_equal(np.concatenate(merged), np.sort(allk))
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_shard_topk_allgather_and_partial_state_exchange_between_ranks(gpu, world):
     """dbhip_vec_topk_allgather: every rank's local top-k (local row numbers) -> the global top-k on every rank == the k smallest of
