@@ -162,7 +162,7 @@ def test_shuffle_and_sort_exchange_plans_behind_the_abi(gpu, world):
     for r in range(world):
         rk, rkv, rp, d, starts = outs[r][0]
         assert (d == r).all() and starts[-1] == len(rk)
-    as_set = lambda ks, vs, ps: sorted((int(k) if v else None, int(p)) for k, v, p in zip(ks, vs, ps))
+    as_set = lambda ks, vs, ps: sorted((bool(v), int(k) if v else 0, int(p)) for k, v, p in zip(ks, vs, ps))
     assert as_set(np.concatenate([o[0][0] for o in outs]), np.concatenate([o[0][1] for o in outs]), np.concatenate([o[0][2] for o in outs])) == \
         as_set(np.concatenate(keys), np.concatenate(kvalid), np.concatenate(pays))
     # sort: rank r holds range r
