@@ -204,12 +204,59 @@ __host__ __device__ __forceinline__ u256 u256_sub_128(u256 a, u128 b) {
   return r;
 }
 
-// q = a / d (d != 0), binary long division; *rem gets the remainder.
+// (u1 : u0) / v for u1 < v (the quotient fits 64 bits): Knuth's algorithm D with two 32-bit quotient digits (Hacker's Delight, divlu) —
+// two 64 / 32 divisions and their corrections instead of the 128-step shift-subtract loop the compiler expands a 128-bit `/` into
+__host__ __device__ inline uint64_t udiv_2by1(uint64_t u1, uint64_t u0, uint64_t v, uint64_t* rem) {
+  const uint64_t b = 1ULL << 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int s = __clzll((long long)v);
+#else
+  const int s = __builtin_clzll(v);
+#endif
+  v <<= s;
+  const uint64_t vn1 = v >> 32, vn0 = v & 0xFFFFFFFFULL;
+  const uint64_t un32 = s ? ((u1 << s) | (u0 >> (64 - s))) : u1;
+  const uint64_t un10 = u0 << s;
+  const uint64_t un1 = un10 >> 32, un0 = un10 & 0xFFFFFFFFULL;
+  uint64_t q1 = un32 / vn1, rhat = un32 - q1 * vn1;
+  while (q1 >= b || q1 * vn0 > b * rhat + un1) {
+    --q1;
+    rhat += vn1;
+    if (rhat >= b) break;
+  }
+  const uint64_t un21 = un32 * b + un1 - q1 * v;
+  uint64_t q0 = un21 / vn1;
+  rhat = un21 - q0 * vn1;
+  while (q0 >= b || q0 * vn0 > b * rhat + un0) {
+    --q0;
+    rhat += vn1;
+    if (rhat >= b) break;
+  }
+  if (rem) *rem = (un21 * b + un0 - q0 * v) >> s;
+  return q1 * b + q0;
+}
+
+// n / d for a divisor that fits 64 bits
+__host__ __device__ inline u128 udiv128_by_64(u128 n, uint64_t d, uint64_t* rem) {
+  const uint64_t nh = (uint64_t)(n >> 64), nl = (uint64_t)n;
+  const uint64_t qh = nh / d, r = nh - qh * d;
+  const uint64_t ql = udiv_2by1(r, nl, d, rem);
+  return ((u128)qh << 64) | ql;
+}
+
+// q = a / d (d != 0); *rem gets the remainder. Numerators below 2^128 over divisors below 2^64 — every decimal division whose
+// operands come from Decimal64 columns, and most others — take the two-digit path above; the rest the binary long division.
 __host__ __device__ inline u256 u256_div_128(u256 a, u128 d, u128* rem) {
   u256 q;
   q.lo = 0;
   q.hi = 0;
   if (a.hi == 0) {
+    if ((uint64_t)(d >> 64) == 0) {
+      uint64_t r64;
+      q.lo = udiv128_by_64(a.lo, (uint64_t)d, &r64);
+      if (rem) *rem = r64;
+      return q;
+    }
     q.lo = a.lo / d;
     if (rem) *rem = a.lo % d;
     return q;
