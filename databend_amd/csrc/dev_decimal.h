@@ -74,6 +74,19 @@ __host__ __device__ __forceinline__ bool convert_operand(i128 x, bool is_decimal
   return true;
 }
 
+// num / d truncated toward zero like the `/` of i128 (what the reference's `/` on i64 / i128 does); divisors that fit 64 bits — every
+// power of ten up to 10^19, every Decimal64 divisor — take the two-digit division of dev_common.h instead of the 128-step loop the
+// compiler expands a 128-bit `/` into
+__host__ __device__ __forceinline__ i128 sdiv128(i128 num, i128 d) {
+  const bool neg = (num < 0) != (d < 0);
+  const u128 un = num < 0 ? (u128)0 - (u128)num : (u128)num;
+  const u128 ud = d < 0 ? (u128)0 - (u128)d : (u128)d;
+  u128 q;
+  if ((uint64_t)(ud >> 64) == 0) q = udiv128_by_64(un, (uint64_t)ud, nullptr);
+  else q = un / ud;
+  return neg ? (i128)((u128)0 - q) : (i128)q;
+}
+
 // i128 path of do_round_mul with overflow (decimal.rs:1040-1054): 256-bit intermediate
 __device__ bool round_mul_128_overflow(i128 a, i128 b, int shift, i128* out) {
   bool neg = (a < 0) != (b < 0);
@@ -132,7 +145,7 @@ __device__ __forceinline__ bool dec_row(const DecOp& p, i128 av, i128 bv, bool a
               r = (i128)(num / d);
             } else {
               i128 num = ((a < 0) == (b < 0)) ? a * b + div / 2 : a * b - div / 2;
-              i128 res = num / div;
+              i128 res = sdiv128(num, div);
               i128 mx = max_for_precision(18);  // i64::DECIMAL_MAX
               if (res < -mx || res > mx) ok = false;
               r = res;
@@ -143,7 +156,7 @@ __device__ __forceinline__ bool dec_row(const DecOp& p, i128 av, i128 bv, bool a
               i128 prod = (i128)((u128)a * (u128)b);
               i128 num = ((a < 0) == (b < 0)) ? (i128)((u128)prod + (u128)(div / 2))
                                               : (i128)((u128)prod - (u128)(div / 2));
-              r = num / div;
+              r = sdiv128(num, div);
             } else {
               ok = round_mul_128_overflow(a, b, p.scale_mul, &r);
             }
@@ -157,7 +170,7 @@ __device__ __forceinline__ bool dec_row(const DecOp& p, i128 av, i128 bv, bool a
             i128 am = (i128)((u128)a * (u128)mul);
             i128 num = ((a < 0) == (b < 0)) ? (i128)((u128)am + (u128)(b / 2))
                                             : (i128)((u128)am - (u128)(b / 2));
-            r = (i128)(int64_t)(num / b);
+            r = (i128)(int64_t)sdiv128(num, b);
           } else {
             r = round_div_128(a, b, p.scale_mul);
           }
