@@ -227,8 +227,11 @@ __device__ __forceinline__ void atomic_add_u192(uint64_t* p, uint64_t lo, uint64
 // wave that want the same state cannot dead-lock each other); values go through agent-scope loads / stores, the release store of
 // the has word publishes them. After a kernel the word is 0 or 1 again. Layouts with such a state stay on the row path.
 #define GB_MM_LOCK (1ULL << 63)
+__host__ __device__ __forceinline__ bool gb_minmax_str(const GbLayout& L, int a) {
+  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_type[a] == DBHIP_T_STRING;
+}
 __host__ __device__ __forceinline__ bool gb_minmax_wide(const GbLayout& L, int a) {
-  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_type[a] == DBHIP_T_DEC128;
+  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && (L.agg_type[a] == DBHIP_T_DEC128 || L.agg_type[a] == DBHIP_T_STRING);
 }
 __device__ __forceinline__ bool gb_mm_better(bool is_min, uint64_t hi, uint64_t lo, uint64_t chi, uint64_t clo) {
   return is_min ? (hi < chi || (hi == chi && lo < clo)) : (hi > chi || (hi == chi && lo > clo));
@@ -253,6 +256,59 @@ __device__ __forceinline__ void gb_minmax_wide_locked(bool is_min, uint64_t* dst
     }
   }
 }
+// MIN / MAX over String (r04; aggregate_min_max_any.rs:62-110, StringState): THREE words like the Decimal128 state and merged under
+// the same per-state lock — [0] the view's first 8 bytes (len | first four bytes << 32), [1] the has-value / lock word, [2] bytes
+// 4..11 of a string of at most 12 bytes, or the device ADDRESS of the bytes of a longer one. While a block is being added the address
+// may point into the block's own data buffers (or another table's arena); before the call returns the winners are copied into this
+// table's arena (gb_pin_strings_*, k_groupby.hip), so a state never outlives the bytes it refers to. Order: bytes, then length
+// (Rust's `str` / `[u8]` Ord).
+__device__ __forceinline__ uint32_t gb_str_byte(uint64_t w0, uint64_t w2, uint32_t len, uint32_t i) {
+  if (len <= 12) return (uint32_t)((i < 4 ? (w0 >> (32 + 8 * i)) : (w2 >> (8 * (i - 4)))) & 0xFFu);
+  return ((const uint8_t*)w2)[i];
+}
+// -1 / 0 / 1
+__device__ __forceinline__ int gb_str_cmp(uint64_t a0, uint64_t a2, uint64_t b0, uint64_t b2) {
+  const uint32_t la = (uint32_t)a0, lb = (uint32_t)b0;
+  // the first four bytes, zero padded (a pad byte against a real byte orders the shorter string first, which is right)
+  const uint32_t pa = __builtin_bswap32((uint32_t)(a0 >> 32)), pb = __builtin_bswap32((uint32_t)(b0 >> 32));
+  if (pa != pb) return pa < pb ? -1 : 1;
+  const uint32_t m = la < lb ? la : lb;
+  for (uint32_t i = 4; i < m; ++i) {
+    const uint32_t x = gb_str_byte(a0, a2, la, i), y = gb_str_byte(b0, b2, lb, i);
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return la == lb ? 0 : (la < lb ? -1 : 1);
+}
+__device__ __forceinline__ void gb_minmax_str_locked(bool is_min, uint64_t* dst, const uint64_t* v) {
+  if (!v[1]) return;
+  unsigned long long* has = (unsigned long long*)(dst + 1);
+  bool done = false;
+  while (!done) {
+    const unsigned long long old = atomicOr(has, (unsigned long long)GB_MM_LOCK);
+    if (!(old & GB_MM_LOCK)) {
+      const uint64_t c0 = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t c2 = __hip_atomic_load(dst + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool better = !(old & 1ULL);
+      if (!better) { const int c = gb_str_cmp(v[0], v[2], c0, c2); better = is_min ? c < 0 : c > 0; }
+      if (better) {
+        __hip_atomic_store(dst, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(has, 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      done = true;
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+__device__ __forceinline__ void gb_minmax_str_plain(bool is_min, uint64_t* dst, const uint64_t* v) {   // ONE writer
+  if (!v[1]) return;
+  bool better = !dst[1];
+  if (!better) { const int c = gb_str_cmp(v[0], v[2], dst[0], dst[2]); better = is_min ? c < 0 : c > 0; }
+  if (better) { dst[0] = v[0]; dst[2] = v[2]; }
+  dst[1] = 1;
+}
+
 __device__ __forceinline__ void gb_minmax_wide_plain(bool is_min, uint64_t* dst, const uint64_t* v) {   // ONE writer
   if (!v[1]) return;
   if (!dst[1] || gb_mm_better(is_min, v[0], v[2], dst[0], dst[2])) { dst[0] = v[0]; dst[2] = v[2]; }
@@ -278,6 +334,7 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
       if (fw && v[fw]) atomicOr((unsigned long long*)(dst + fw), 1ULL);
     } break;
     case DBHIP_AGG_MIN:
+      if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(true, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(true, dst, v); break; }
       if (v[1]) {
         atomicMin((unsigned long long*)dst, (unsigned long long)v[0]);
@@ -285,6 +342,7 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
       }
       break;
     default:  // MAX
+      if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(false, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(false, dst, v); break; }
       if (v[1]) {
         atomicMax((unsigned long long*)dst, (unsigned long long)v[0]);
@@ -326,6 +384,7 @@ __device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* 
       if (fw && v[fw]) GB_WG_OR(dst + fw, 1ULL);
     } break;
     case DBHIP_AGG_MIN:
+      if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(true, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(true, dst, v); break; }
       if (v[1]) {
         __hip_atomic_fetch_min((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -333,6 +392,7 @@ __device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* 
       }
       break;
     default:  // MAX
+      if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(false, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(false, dst, v); break; }
       if (v[1]) {
         __hip_atomic_fetch_max((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -366,10 +426,12 @@ __device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_
       if (fw && v[fw]) dst[fw] |= 1ULL;
     } break;
     case DBHIP_AGG_MIN:
+      if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_plain(true, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_plain(true, dst, v); break; }
       if (v[1]) { dst[0] = v[0] < dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
       break;
     default:  // MAX
+      if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_plain(false, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_plain(false, dst, v); break; }
       if (v[1]) { dst[0] = v[0] > dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
       break;
@@ -379,7 +441,7 @@ __device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_
 // identity element of a state
 __device__ __forceinline__ void gb_state_identity(const GbLayout& L, int a, uint64_t* dst) {
   for (int k = 0; k < L.agg_words[a]; ++k) dst[k] = 0;
-  if (L.agg_kind[a] == DBHIP_AGG_MIN) { dst[0] = ~0ULL; if (L.agg_words[a] == 3) dst[2] = ~0ULL; }
+  if (L.agg_kind[a] == DBHIP_AGG_MIN && L.agg_type[a] != DBHIP_T_STRING) { dst[0] = ~0ULL; if (L.agg_words[a] == 3) dst[2] = ~0ULL; }   // (a String state without a value is all zero)
 }
 
 // state contribution of ONE input row for aggregate a from the argument's canonical words (w0, w1) and validity
@@ -401,7 +463,8 @@ __device__ __forceinline__ void gb_row_contrib(const GbLayout& L, int a, uint64_
       if (fw) v[fw] = valid ? 1 : 0;
     } break;
     default:  // MIN / MAX
-      if (L.agg_words[a] == 3) { v[0] = w1 ^ (1ULL << 63); v[2] = w0; }   // Decimal128: (sign-flipped high word, low word)
+      if (L.agg_type[a] == DBHIP_T_STRING) { v[0] = valid ? w0 : 0; v[2] = valid ? w1 : 0; }   // String: (len | prefix, tail or address)
+      else if (L.agg_words[a] == 3) { v[0] = w1 ^ (1ULL << 63); v[2] = w0; }   // Decimal128: (sign-flipped high word, low word)
       else v[0] = ord_encode(w0, L.agg_type[a]);
       v[1] = valid ? 1 : 0;
       break;

@@ -236,7 +236,28 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
       bool valid[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) { w0[u] = 0; w1[u] = 0; valid[u] = true; }
-      if (C.arg[a].data != nullptr) gb_load_words_n<U>(C.arg[a], row, w0, w1, valid);
+      if (C.arg[a].data != nullptr && C.arg[a].type == DBHIP_T_STRING) {
+        // a String argument (min / max): short values as the canonical inline words, long ones as (len | prefix, ADDRESS of the bytes)
+        const GbCol& ac = C.arg[a];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = ac.is_scalar ? 0 : row[u];
+          valid[u] = !ac.validity || bit_get(ac.validity, ac.voff + j);
+          const uint32_t* v = (const uint32_t*)ac.data + 4 * j;
+          const uint32_t len = v[0];
+          uint64_t ww[2] = {0, 0};
+          if (len <= 12 || !valid[u]) {
+            bool vv;
+            gb_load_words(ac, row[u], ww, &vv);
+          } else if (ac.buffers) {
+            ww[0] = ((uint64_t)v[1] << 32) | len;
+            ww[1] = (uint64_t)((const uint8_t*)ac.buffers[v[2]] + v[3]);
+          } else {
+            atomicOr((unsigned long long*)&ctrl[3], 2ULL);   // a long view without data buffers
+          }
+          w0[u] = ww[0]; w1[u] = ww[1];
+        }
+      } else if (C.arg[a].data != nullptr) gb_load_words_n<U>(C.arg[a], row, w0, w1, valid);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!in[u]) continue;
@@ -439,6 +460,10 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
       for (int a = 0; a < L.naggs; ++a) {
         const uint64_t* v = r + L.agg_off[a];
         uint64_t out[GB_MAX_STATE_WORDS] = {0, 0, 0, 0};
+        if (gb_minmax_str(L, a)) {   // no word-wise reduction exists for strings: every row of the group takes the state's lock in turn
+          if (mine) gb_minmax_str_locked(L.agg_kind[a] == DBHIP_AGG_MIN, d + L.agg_off[a], v);
+          continue;
+        }
         switch (L.agg_kind[a]) {
           case DBHIP_AGG_COUNT:
             out[0] = wave_sum_u64(mine ? v[0] : 0);
@@ -621,6 +646,7 @@ struct ResultPtrs {
   void* aggs[GB_MAX_AGGS];
   uint32_t* agg_validity[GB_MAX_AGGS];   // nullable-argument SUM / MIN / MAX: bit = the group saw a non-NULL row
   uint64_t* hashes;
+  const uint8_t* arena;                  // min / max over String: a long value's state holds the ADDRESS of its bytes inside the arena
 };
 
 // rows -> result columns (merge_result, aggregate_hashtable.rs:382-408)
@@ -692,6 +718,19 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           }
           break;
         default: {  // MIN / MAX (no value seen: the type's default, MinMaxAnyState::merge_result push_default)
+          if (L.agg_type[a] == DBHIP_T_STRING) {
+            // -> 16-byte view: {len, bytes[12]} inline, or {len, prefix, buffer 0, offset into the table's arena} (dbhip_groupby_arena)
+            uint32_t* v = (uint32_t*)o + 4 * i;
+            const uint32_t len = s[1] ? (uint32_t)s[0] : 0;
+            if (len > 12) {
+              const uint64_t off = s[2] - (uint64_t)P.arena;
+              if (off >> 32) atomicOr((unsigned long long*)&ctrl[3], 8ULL);   // a view's offset is 32 bits
+              v[0] = len; v[1] = (uint32_t)(s[0] >> 32); v[2] = 0; v[3] = (uint32_t)off;
+            } else {
+              v[0] = len; v[1] = s[1] ? (uint32_t)(s[0] >> 32) : 0; v[2] = s[1] ? (uint32_t)s[2] : 0; v[3] = s[1] ? (uint32_t)(s[2] >> 32) : 0;
+            }
+            break;
+          }
           if (L.agg_words[a] == 3) {   // Decimal128
             ((uint64_t*)o)[2 * i] = s[1] ? s[2] : 0;
             ((uint64_t*)o)[2 * i + 1] = s[1] ? (s[0] ^ (1ULL << 63)) : 0;
@@ -956,11 +995,12 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
         if (d.arg_nullable) L->agg_flag[a] = words++;   // "seen a non-NULL row" (AggregateNullUnaryAdaptor<true>)
         break;
       case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
-        if (d.arg_type == DBHIP_T_STRING || !key_type_ok(d.arg_type)) {
+        if (!key_type_ok(d.arg_type)) {
           set_error("groupby: min/max on type %d stays on the CPU operator", d.arg_type);
           return DBHIP_ERR_UNSUPPORTED;
         }
-        words = d.arg_type == DBHIP_T_DEC128 ? 3 : 2;   // (value, has) — Decimal128: (high word, has, low word), gb_device.h
+        // (value, has) — Decimal128: (high word, has, low word); String: (len | prefix, has, tail or address of the bytes), gb_device.h
+        words = (d.arg_type == DBHIP_T_DEC128 || d.arg_type == DBHIP_T_STRING) ? 3 : 2;
         break;
       default:
         set_error("groupby: unknown aggregate kind %d", d.kind);
@@ -1029,6 +1069,48 @@ int32_t grow(dbhip_groupby* g, hipStream_t s) {
   return r1 ? r1 : r2;
 }
 
+// ---- min / max over String: the winners' bytes move into the table's arena before a call returns (gb_device.h) ----
+bool layout_has_str_minmax(const GbLayout& L) {
+  for (int a = 0; a < L.naggs; ++a) if (gb_minmax_str(L, a)) return true;
+  return false;
+}
+int32_t refuse_str_minmax_state(const GbLayout& L, const char* fn) {
+  if (!layout_has_str_minmax(L)) return DBHIP_OK;
+  set_error("%s: the serialized-state block of min / max over String (a borsh Option<String> per group) is not produced on the device; "
+            "keep the CPU operator for the exchange of this aggregate", fn);
+  return DBHIP_ERR_UNSUPPORTED;
+}
+// mode 0: sum the (8-byte rounded) sizes of the long values whose bytes lie outside [lo, hi) into *acc;
+// mode 1: copy them into the arena (bump cursor ctrl[8]) and point the state at the copy;
+// mode 2: the arena moved from [lo, hi) by `delta`: states that point into the old range follow it.
+__global__ __launch_bounds__(256) void gb_pin_strings_kernel(GbLayout L, const uint64_t* __restrict__ slot_hash, uint64_t* __restrict__ rows,
+                                                             int64_t cap, uint64_t lo, uint64_t hi, int mode, uint8_t* arena, int64_t delta,
+                                                             uint64_t* ctrl, unsigned long long* acc) {
+  uint64_t mine = 0;
+  for (int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sl < cap; sl += (int64_t)gridDim.x * blockDim.x) {
+    if (slot_hash[sl] == 0) continue;
+    for (int a = 0; a < L.naggs; ++a) {
+      if (!gb_minmax_str(L, a)) continue;
+      uint64_t* st = rows + sl * L.W + L.agg_off[a];
+      const uint32_t len = (uint32_t)st[0];
+      if (!st[1] || len <= 12) continue;
+      const bool inside = st[2] >= lo && st[2] < hi;
+      if (mode == 2) { if (inside) st[2] = (uint64_t)((int64_t)st[2] + delta); continue; }
+      if (inside) continue;
+      const uint64_t room = ((uint64_t)len + 7) & ~7ULL;
+      if (mode == 0) { mine += room; continue; }
+      const uint64_t off = atomicAdd((unsigned long long*)&ctrl[8], (unsigned long long)room);
+      const uint8_t* src = (const uint8_t*)st[2];
+      for (uint32_t i = 0; i < len; ++i) arena[off + i] = src[i];
+      st[2] = (uint64_t)(arena + off);
+    }
+  }
+  if (mode == 0) {
+    mine = wave_sum_u64(mine);
+    if (mine && lane_id() == 0) atomicAdd(acc, (unsigned long long)mine);
+  }
+}
+
 // room for `extra` more bytes of long string keys (ctrl[8] = bytes in use); offsets into the arena stay valid when it moves
 int32_t reserve_arena(dbhip_groupby* g, uint64_t extra, hipStream_t s) {
   if (extra == 0) return DBHIP_OK;
@@ -1043,10 +1125,35 @@ int32_t reserve_arena(dbhip_groupby* g, uint64_t extra, hipStream_t s) {
   int32_t rc = dbhip_alloc(want, (void**)&na);
   if (rc) return rc;
   if (used) DBHIP_CHECK(hipMemcpyAsync(na, g->arena, (size_t)used, hipMemcpyDeviceToDevice, s));
+  if (g->arena && layout_has_str_minmax(g->L))   // min / max String states hold ADDRESSES into the arena: they follow it
+    hipLaunchKernelGGL(gb_pin_strings_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap,
+                       (uint64_t)g->arena, (uint64_t)g->arena + g->arena_cap, 2, na, (int64_t)((intptr_t)na - (intptr_t)g->arena), g->ctrl,
+                       (unsigned long long*)nullptr);
   DBHIP_CHECK(hipStreamSynchronize(s));
   if (g->arena) (void)dbhip_free(g->arena);
   g->arena = na;
   g->arena_cap = want;
+  return DBHIP_OK;
+}
+// min / max over String: after rows were merged, every long winner whose bytes still lie in a caller's buffer (or another table's
+// arena) is copied into this table's arena. One counting pass, the reservation, one copying pass — per merge_rows call.
+int32_t pin_string_states(dbhip_groupby* g, hipStream_t s) {
+  if (!layout_has_str_minmax(g->L)) return DBHIP_OK;
+  unsigned long long* acc = (unsigned long long*)&g->ctrl[10];
+  DBHIP_CHECK(hipMemsetAsync(acc, 0, 8, s));
+  const int grid = grid_for(g->cap, 256);
+  hipLaunchKernelGGL(gb_pin_strings_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint64_t)g->arena,
+                     (uint64_t)g->arena + g->arena_cap, 0, g->arena, (int64_t)0, g->ctrl, acc);
+  DBHIP_LAUNCH_CHECK();
+  uint64_t bytes = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&bytes, acc, 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (bytes == 0) return DBHIP_OK;
+  int32_t rc = reserve_arena(g, bytes, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gb_pin_strings_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint64_t)g->arena,
+                     (uint64_t)g->arena + g->arena_cap, 1, g->arena, (int64_t)0, g->ctrl, acc);
+  DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;
 }
 // after a kernel that summed the long-string bytes of its rows into ctrl[9]: read it, remember that the table holds long
@@ -1063,8 +1170,15 @@ bool layout_has_strings(const GbLayout& L) { return L.str_w1_mask != 0; }
 bool layout_has_wide_minmax(const GbLayout& L);
 
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
+int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s, const uint64_t* n_dev, const uint64_t* abort_dev);
 int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
                    const uint64_t* n_dev = nullptr, const uint64_t* abort_dev = nullptr) {
+  int32_t rc = merge_rows_unpinned(g, rows_in, n, s, n_dev, abort_dev);
+  if (rc == DBHIP_OK && n > 0) rc = pin_string_states(g, s);
+  return rc;
+}
+int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
+                            const uint64_t* n_dev, const uint64_t* abort_dev) {
   if (n == 0) return DBHIP_OK;
   if (n > 0xFFFFFFF0LL) {
     set_error("groupby: more than 2^32 rows in one call");
@@ -3024,6 +3138,7 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
 int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
                                         int64_t n, void* stream) {
   DBHIP_REQUIRE(g && keys && (states || g->L.naggs == 0), "dbhip_groupby_merge_state_block: NULL argument");
+  if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_merge_state_block")) return rs;
   const GbLayout& L = g->L;
   int32_t ftype[GB_MAX_AGGS * 3], fagg[GB_MAX_AGGS * 3];
   const int nf = state_fields(L, ftype, fagg);
@@ -3082,6 +3197,7 @@ int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys,
 int32_t dbhip_groupby_state_fields(dbhip_groupby* g, int32_t* out_types_host, int32_t* out_agg_index_host, int32_t max_fields,
                                    int32_t* out_n_fields_host) {
   DBHIP_REQUIRE(g && out_n_fields_host, "dbhip_groupby_state_fields: NULL argument");
+  if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_state_fields")) return rs;
   int32_t ftype[GB_MAX_AGGS * 3], fagg[GB_MAX_AGGS * 3];
   const int nf = state_fields(g->L, ftype, fagg);
   *out_n_fields_host = nf;
@@ -3137,6 +3253,11 @@ int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int
 // the SENDER's arena, which the receiving table would read as an address. Tables that hold long strings exchange through
 // dbhip_groupby_flush_serialized + dbhip_groupby_arena -> dbhip_groupby_merge_serialized_arena (which rebases the offsets).
 static int32_t refuse_long_strings(const dbhip_groupby* g, const char* fn) {
+  if (layout_has_str_minmax(g->L)) {
+    set_error("%s: a min / max over String state refers to bytes in this table's arena; such tables are merged in process "
+              "(dbhip_groupby_merge_serialized from a live table) and do not travel", fn);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
   if (!g->has_long) return DBHIP_OK;
   set_error("%s: the table holds string keys longer than 12 bytes; exchange it with dbhip_groupby_flush_serialized + dbhip_groupby_arena "
             "-> dbhip_groupby_merge_serialized_arena", fn);
@@ -3241,6 +3362,7 @@ static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8
     if (P.agg_validity[a]) DBHIP_CHECK(hipMemsetAsync(P.agg_validity[a], 0, bm_bytes, s));
   }
   P.hashes = out_hashes;
+  P.arena = g->arena;
   DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
   hipLaunchKernelGGL(gb_result_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, P, g->ctrl);
   if (out_fields_host) {
@@ -3344,6 +3466,7 @@ int32_t dbhip_groupby_flush_state_block(dbhip_groupby* g, void* const* out_keys_
                                         void* const* out_state_fields_host, uint64_t* out_hashes, int64_t max_rows,
                                         int64_t* out_n_rows_host, void* stream) {
   DBHIP_REQUIRE(g && out_n_rows_host && (out_state_fields_host || g->L.naggs == 0), "dbhip_groupby_flush_state_block: NULL argument");
+  if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_flush_state_block")) return rs;
   return flush_columns(g, out_keys_host, out_key_validity_host, nullptr, nullptr, out_state_fields_host, out_hashes, max_rows,
                        out_n_rows_host, stream);
 }

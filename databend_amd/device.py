@@ -998,6 +998,8 @@ class GroupBy:
         for t, b, a, v in zip(agg_t, agg_bufs, self.aggs, agg_val):
             if t == L.T_DEC128:
                 vals = bytes_to_i128(b.to_numpy(np.uint8, 16 * n))
+            elif t == L.T_STRING:   # min / max over String: views whose long form points into the table's arena
+                vals = view_strings(b.to_numpy(np.uint8, 16 * n), self.arena_numpy())
             else:
                 vals = b.to_numpy(NP_OF[t], n).tolist()
             if a[4] and a[0] != L.AGG_COUNT:  # nullable argument: NULL unless the group saw a non-NULL row

@@ -787,10 +787,10 @@ static int agg_flag_off(const orc_agg_desc* d) { /* 0 = no flag */
 static int agg_state_size(const orc_agg_desc* d) {
   if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return d->arg_nullable ? 32 : 16;
   if (d->kind == ORC_AGG_SUM && d->arg_nullable) return 16; /* value + flag */
-  if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return d->arg_type == ORC_T_DEC128 ? 32 : 16; /* value + has flag (Decimal128: 16-byte value) */
+  if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return (d->arg_type == ORC_T_DEC128 || d->arg_type == ORC_T_STRING) ? 32 : 16; /* value + has flag (Decimal128: 16-byte value; String: offset + length into the table's bytes) */
   return 8;
 }
-static int mm_has_off(const orc_agg_desc* d) { return d->arg_type == ORC_T_DEC128 ? 16 : 8; } /* MinMaxAnyState: Option<value> */
+static int mm_has_off(const orc_agg_desc* d) { return (d->arg_type == ORC_T_DEC128 || d->arg_type == ORC_T_STRING) ? 16 : 8; } /* MinMaxAnyState: Option<value> */
 
 static void index_alloc(orc_hashagg* h, size_t cap) {
   h->capacity = cap; h->mask = cap - 1; h->count = 0;
@@ -918,7 +918,7 @@ static void resize_index(orc_hashagg* h, size_t new_cap) { /* aggregate_hashtabl
 }
 
 /* accumulate one row into one state (accumulate_keys: aggregate_unary.rs:208-222) */
-static int state_add(const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int64_t i) {
+static int state_add(orc_hashagg* h, const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int64_t i) {
   int valid = !arg || !arg->data || col_valid(arg, i);
   switch (d->kind) {
     case ORC_AGG_COUNT: if (valid) { uint64_t c; memcpy(&c, st, 8); c++; memcpy(st, &c, 8); } return 0;
@@ -941,6 +941,28 @@ static int state_add(const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int
       }
     default: { /* MIN / MAX over OrderedFloat / ints / Decimal128 (aggregate_min_max_any.rs: MinMaxAnyState<.., CmpMin / CmpMax>) */
       if (!valid) return 0;
+      if (d->arg_type == ORC_T_STRING) {
+        /* aggregate_min_max_any.rs:62-110 (StringState): Option<Vec<u8>>, replaced when the new value is smaller / larger in byte order
+         * (then length: Rust's Ord on [u8]); the bytes are copied into the table (h->strs), the state keeps (offset, length) */
+        uint64_t hs; memcpy(&hs, st + 16, 8);
+        uint32_t len; const uint8_t* p = view_bytes((const uint32_t*)arg->data + 4 * (arg->is_scalar ? 0 : i), arg->buffers, &len);
+        uint64_t coff, clen; memcpy(&coff, st, 8); memcpy(&clen, st + 8, 8);
+        int take = !hs;
+        if (!take) {
+          size_t m = len < clen ? len : (size_t)clen;
+          int c = m ? memcmp(p, h->strs + coff, m) : 0;
+          if (c == 0) c = (len > clen) - (len < clen);
+          take = d->kind == ORC_AGG_MIN ? c < 0 : c > 0;
+        }
+        if (take) {
+          if (h->strs_len + len > h->strs_cap) { h->strs_cap = (h->strs_len + len) * 2 + 64; h->strs = (uint8_t*)realloc(h->strs, h->strs_cap); }
+          if (len) memcpy(h->strs + h->strs_len, p, len);
+          coff = h->strs_len; clen = len; h->strs_len += len;
+          memcpy(st, &coff, 8); memcpy(st + 8, &clen, 8);
+        }
+        hs = 1; memcpy(st + 16, &hs, 8);
+        return 0;
+      }
       if (d->arg_type == ORC_T_DEC128) {
         uint64_t has128; memcpy(&has128, st + 16, 8);
         i128 v128, cur128;
@@ -1013,7 +1035,7 @@ static int add_groups_inner(orc_hashagg* h, const orc_col* keys, const orc_col* 
   for (int a = 0; a < h->naggs; ++a)
     for (int64_t r = 0; r < rc; ++r) {
       uint64_t soff; memcpy(&soff, h->rows + (addr[r] - 1) * h->tuple_size + h->state_ptr_off, 8);
-      int e = state_add(&h->aggs[a], h->states + soff + h->state_off[a], args ? &args[a] : NULL, start + r);
+      int e = state_add(h, &h->aggs[a], h->states + soff + h->state_off[a], args ? &args[a] : NULL, start + r);
       if (e) rcode = e;
     }
   return rcode;
@@ -1073,6 +1095,15 @@ int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* 
       }
       if (!out_aggs || !out_aggs[a]) continue;
       if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16);
+      else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_STRING) {
+        /* 16 bytes per group: u32 length, then the bytes when they fit 12, else u32 0, u64 offset into the table's bytes (orc_hashagg_bytes) */
+        uint8_t* v = (uint8_t*)out_aggs[a] + 16 * r; memset(v, 0, 16);
+        uint64_t hs, coff, clen; memcpy(&hs, st + 16, 8); memcpy(&coff, st, 8); memcpy(&clen, st + 8, 8);
+        if (hs) {
+          uint32_t l32 = (uint32_t)clen; memcpy(v, &l32, 4);
+          if (clen <= 12) memcpy(v + 4, h->strs + coff, (size_t)clen); else memcpy(v + 8, &coff, 8);
+        }
+      }
       else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_DEC128) {
         uint64_t hs; memcpy(&hs, st + 16, 8);
         if (hs) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16); else memset((uint8_t*)out_aggs[a] + 16 * r, 0, 16); /* push_default() */
@@ -1086,6 +1117,9 @@ int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* 
   }
   return rc;
 }
+
+/* the table's byte store (long string keys, min / max over String values): results refer to it by offset */
+const uint8_t* orc_hashagg_bytes(orc_hashagg* h, int64_t* out_len) { if (out_len) *out_len = (int64_t)h->strs_len; return h->strs; }
 
 /* combine_payload aggregate_hashtable.rs:349-380: re-probe the other table's groups and merge states */
 int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
@@ -1171,15 +1205,25 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
             i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;
           } else if (t_cls(ad->arg_type) == 2) { double x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
           else { uint64_t x, y; memcpy(&x, d, 8); memcpy(&y, sp, 8); x += y; memcpy(d, &x, 8); }
+        } else if (ad->arg_type == ORC_T_STRING) {   /* StringState::merge: the other side's value as one more candidate */
+          uint64_t hs, coff, clen; memcpy(&hs, sp + 16, 8); memcpy(&coff, sp, 8); memcpy(&clen, sp + 8, 8);
+          if (hs) {
+            uint8_t view[16]; memset(view, 0, 16);
+            uint32_t l32 = (uint32_t)clen; memcpy(view, &l32, 4);
+            const void* bufs[1] = {src->strs + coff};
+            if (clen <= 12) memcpy(view + 4, src->strs + coff, (size_t)clen); else memcpy(view + 4, src->strs + coff, 4);
+            orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ORC_T_STRING; tmp.is_scalar = 1; tmp.data = view; tmp.buffers = bufs;
+            state_add(dst, ad, d, &tmp, 0);
+          }
         } else if (ad->arg_type == ORC_T_DEC128) {
           uint64_t hs; memcpy(&hs, sp + 16, 8);
-          if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1; tmp.data = sp; state_add(ad, d, &tmp, 0); }
+          if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1; tmp.data = sp; state_add(dst, ad, d, &tmp, 0); }
         } else {
           uint64_t hs; memcpy(&hs, sp + 8, 8);
           if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1;
             uint8_t buf[8]; val v; memset(&v, 0, sizeof v); v.cls = t_cls(ad->arg_type);
             if (v.cls == 2) memcpy(&v.f, sp, 8); else if (v.cls == 0) memcpy(&v.i, sp, 8); else memcpy(&v.u, sp, 8);
-            store_val(buf, ad->arg_type, 0, v); tmp.data = buf; state_add(ad, d, &tmp, 0); }
+            store_val(buf, ad->arg_type, 0, v); tmp.data = buf; state_add(dst, ad, d, &tmp, 0); }
         }
       }
     }
@@ -1333,7 +1377,7 @@ int orc_hashagg_merge_state_block(orc_hashagg* h, const orc_col* keys, const orc
           int has = bit_get((const uint8_t*)fields[f].data, fields[f].is_scalar ? 0 : i); ++f;
           const orc_col* vf = &fields[f]; ++f;
           if (ad->arg_nullable) { has = has && bit_get((const uint8_t*)fields[f].data, fields[f].is_scalar ? 0 : i); ++f; }
-          if (has) { orc_col tmp = *vf; tmp.validity = NULL; state_add(ad, d, &tmp, i); }
+          if (has) { orc_col tmp = *vf; tmp.validity = NULL; state_add(h, ad, d, &tmp, i); }
         }
       }
     }

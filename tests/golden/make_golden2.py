@@ -58,6 +58,12 @@ def parse_data(d):
     m = re.fullmatch(r"NullableColumn \{ column: (.*), validity: (\[.*\]) \}", d)
     if m:
         d, vtxt = m.group(1).strip(), m.group(2)
+    ms = re.fullmatch(r"StringColumn\[(.*)\]", d)      # min(s) / max(s): 'StringColumn[delta, bravo, charlie, alpha]'
+    if ms:
+        e = {"kind": "String", "values": [x.strip() for x in ms.group(1).split(",") if x.strip()]}
+        if vtxt is not None:
+            e["validity"] = parse_validity(vtxt, len(e["values"]))
+        return e
     m = re.fullmatch(r"(\w+)\(\[(.*)\]\)", d)
     if not m:
         return None

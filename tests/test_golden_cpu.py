@@ -98,7 +98,7 @@ def test_every_comparison_golden():
 # ---- aggregates: {sum,count,avg,min,max}[_group_by].txt ------------------------------------------------------------------
 AGG_KIND = {"sum": T.AGG_SUM, "count": T.AGG_COUNT, "min": T.AGG_MIN, "max": T.AGG_MAX}
 KIND_CODE = {"Int64": T.T_I64, "Int32": T.T_I32, "UInt64": T.T_U64, "UInt8": T.T_U8, "Float64": T.T_F64, "Decimal64": T.T_DEC64, "Decimal128": T.T_DEC128,
-             "Int8": T.T_I8, "Int16": T.T_I16, "UInt16": T.T_U16, "UInt32": T.T_U32, "Float32": T.T_F32}
+             "Int8": T.T_I8, "Int16": T.T_I16, "UInt16": T.T_U16, "UInt32": T.T_U32, "Float32": T.T_F32, "String": T.T_STRING}
 
 
 def agg_argument(case):
@@ -130,6 +130,8 @@ def agg_column(spec, n):
         return np.full(n, int(spec["const"]), G.NP_OF_CODE[code]), None, code, 0, 0
     vals = spec["values"]
     validity = np.array(spec["validity"][:n], bool) if "validity" in spec else None
+    if kind == "String":     # min(s) / max(s) (aggregate_min_max_any.rs StringState): the values as bytes
+        return [str(v).encode() for v in vals], validity, code, 0, 0
     if kind in ("Decimal64", "Decimal128"):
         scale = max((len(str(v).split(".")[1]) if "." in str(v) else 0) for v in vals)
         from decimal import Decimal
@@ -172,6 +174,11 @@ def run_agg_case_oracle(L, case):
         if f in ("min", "max") and code in (T.T_DEC128,):
             raise G.Skip("min/max on Decimal128")
         aggs.append((AGG_KIND[f], code, prec, scale, 1 if validity is not None else 0))
+        if code == T.T_STRING:
+            from databend_amd.device import make_views_general
+            v, buf = make_views_general(arr)
+            hargs.append(O.HostCol(T.T_STRING, v, validity, buffers=[buf]))
+            continue
         data = O.i128_array(arr) if code == T.T_DEC128 else (np.array(arr, np.int64) if code == T.T_DEC64 else arr)
         hargs.append(O.HostCol(code, data, validity, prec, scale))
     groups = (np.arange(n) % 2).astype(np.uint8) if case["grouped"] else np.zeros(n, np.uint8)
@@ -201,7 +208,9 @@ def compare_agg(func, rows, kind, exp_vals, exp_valid, scale, ast):
         if not valid:
             assert got is None or func == "count", (ast, rows)
             continue
-        if kind.startswith("Decimal"):
+        if kind == "String":
+            assert got == str(exp_vals[g]).encode(), (ast, got, exp_vals)
+        elif kind.startswith("Decimal"):
             assert got == int(Decimal(str(exp_vals[g])).scaleb(scale)), (ast, got, exp_vals)
         elif kind.startswith("Float"):
             assert got == float(exp_vals[g]), (ast, got, exp_vals)
@@ -221,7 +230,42 @@ def test_aggregate_goldens_sum_count_avg_min_max():
             checked.append((case["file"], case["ast"]))
         except G.Skip as e:
             skipped[e.args[0].split(" ")[0] + " " + e.args[0].split(" ")[-1].split("(")[0]] = skipped.get(e.args[0], 0) + 1
-    assert len(checked) >= 50, (len(checked), skipped)
+    assert len(checked) >= 54, (len(checked), skipped)
+    for f in ("min.txt", "min_group_by.txt", "max.txt", "max_group_by.txt"):        # min(s) / max(s): the String states (round 4)
+        assert (f, f.split(".")[0].split("_")[0] + "(s)") in checked
+
+
+def test_oracle_min_max_over_strings_against_python():
+    """aggregate_min_max_any.rs:62-110 (StringState) in the oracle: byte order then length (Rust's Ord on [u8]), NULL rows skipped, a
+    group without a value is NULL; values of any length (the bytes are copied into the table); also through combine()."""
+    from databend_amd.device import make_views_general
+    from tests.test_gpu_parity import oracle_groupby, oracle_rows
+    L = O.load()
+    rng = np.random.default_rng(21)
+    n = 20_000
+    keys = rng.integers(0, 300, n).astype(np.int64)
+    alphabet = [bytes([c]) for c in b"ab\x00\xffz"]
+    vals = [b"".join(alphabet[int(x)] for x in rng.integers(0, len(alphabet), int(ln))) for ln in rng.integers(0, 30, n)]
+    valid = rng.random(n) > 0.2
+    valid[keys == 7] = False                                                        # a group whose argument is NULL everywhere
+    aggs = [(T.AGG_MIN, T.T_STRING, 0, 0, 1), (T.AGG_MAX, T.T_STRING, 0, 0, 1), (T.AGG_COUNT, 0, 0, 0, 0)]
+    halves = []
+    for lo, hi in ((0, n // 2), (n // 2, n)):
+        v, buf = make_views_general(vals[lo:hi])
+        col = O.HostCol(T.T_STRING, v, valid[lo:hi], buffers=[buf])
+        halves.append(oracle_groupby(L, [T.T_I64], [0], aggs, [O.HostCol(T.T_I64, keys[lo:hi])], [col, col, None], hi - lo))
+    assert L.orc_hashagg_combine(halves[0], halves[1]) == 0
+    rows = {r[0]: r[1:] for r in oracle_rows(L, halves[0], [T.T_I64], aggs)}
+    exp = {}
+    for k, s, ok in zip(keys.tolist(), vals, valid.tolist()):
+        e = exp.setdefault(k, [None, None, 0])
+        e[2] += 1
+        if ok:
+            e[0] = s if e[0] is None or s < e[0] else e[0]
+            e[1] = s if e[1] is None or s > e[1] else e[1]
+    assert rows == {k: tuple(v) for k, v in exp.items()} and rows[7][0] is None
+    for h in halves:
+        L.orc_hashagg_destroy(h)
 
 
 def test_kernel_pass_filter_and_take_goldens():

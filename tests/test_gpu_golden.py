@@ -87,7 +87,9 @@ def test_aggregate_goldens_through_the_c_abi(gpu):
                 if f in ("min", "max") and code == T.T_DEC128:
                     raise G.Skip("min/max on Decimal128")
                 aggs.append((AGG_KIND[f], code, prec, scale, 1 if validity is not None else 0))
-                if code == T.T_DEC128:
+                if code == T.T_STRING:
+                    args.append(D.Column.strings(arr, validity=validity))
+                elif code == T.T_DEC128:
                     args.append(D.Column.decimal128(arr, prec, scale, validity=validity))
                 elif code == T.T_DEC64:
                     args.append(D.Column.from_numpy(np.array(arr, np.int64), T.T_DEC64, validity=validity, precision=prec, scale=scale))
@@ -101,7 +103,7 @@ def test_aggregate_goldens_through_the_c_abi(gpu):
             checked.append(case["ast"])
         except G.Skip as e:
             skipped[e.args[0]] = skipped.get(e.args[0], 0) + 1
-    assert len(checked) >= 76, (len(checked), skipped)
+    assert len(checked) >= 80 and "min(s)" in checked and "max(s)" in checked, (len(checked), skipped)
 
 
 def test_kernel_pass_filter_and_take_goldens_through_the_c_abi(gpu):

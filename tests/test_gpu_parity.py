@@ -288,7 +288,17 @@ def oracle_rows(oracle, h, key_types, aggs):
         else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
         cols.append([x if ok else None for x, ok in zip(vals, v[:g])])
     for t, b, a, v in zip(res_t, ab, aggs, av):
-        if t == T.T_DEC128: vals = O.i128_list(b[:16 * g])
+        if t == T.T_STRING:     # min / max over String: (u32 length, inline bytes | u64 offset into the oracle table's byte store)
+            oracle.orc_hashagg_bytes.restype = C.c_void_p
+            blen = C.c_int64()
+            base = oracle.orc_hashagg_bytes(h, C.byref(blen))
+            store = C.string_at(base, blen.value) if blen.value else b""
+            vals = []
+            for i in range(g):
+                ln = int(b[16 * i:16 * i + 4].view(np.uint32)[0])
+                off = int(b[16 * i + 8:16 * i + 16].view(np.uint64)[0])
+                vals.append(bytes(b[16 * i + 4:16 * i + 4 + ln]) if ln <= 12 else store[off:off + ln])
+        elif t == T.T_DEC128: vals = O.i128_list(b[:16 * g])
         else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
         if a[4] and a[0] != T.AGG_COUNT:  # sum / min / max over a Nullable argument: NULL for all-NULL groups
             vals = [x if ok else None for x, ok in zip(vals, v[:g])]
