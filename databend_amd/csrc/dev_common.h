@@ -94,6 +94,28 @@ __device__ __forceinline__ uint64_t agg_hash_inline_view(uint32_t len, uint32_t 
   return h;
 }
 
+// i256 hashes as its 32 little-endian bytes (group_hash.rs:593-597): four 8-byte blocks, no tail.
+__host__ __device__ __forceinline__ uint64_t agg_hash_i256(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
+  const uint64_t M = 0xc6a4a7935bd1e995ULL;
+  const uint64_t SEED = 0xe17a1465ULL;
+  const int R = 47;
+  uint64_t h = SEED ^ (32ULL * M);
+  const uint64_t w[4] = {w0, w1, w2, w3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint64_t k = w[i];
+    k *= M;
+    k ^= k >> R;
+    k *= M;
+    h ^= k;
+    h *= M;
+  }
+  h ^= h >> R;
+  h *= M;
+  h ^= h >> R;
+  return h;
+}
+
 // i128 hashes as its 16 little-endian bytes (group_hash.rs:587-591).
 __device__ __forceinline__ uint64_t agg_hash_i128(i128 v) {
   const uint64_t M = 0xc6a4a7935bd1e995ULL;

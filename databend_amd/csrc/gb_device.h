@@ -220,6 +220,49 @@ __device__ __forceinline__ void atomic_add_u192(uint64_t* p, uint64_t lo, uint64
   if (addext) atomicAdd((unsigned long long*)(p + 2), (unsigned long long)addext);
 }
 
+// SUM over Decimal256 (r04; aggregate_sum.rs:183-300 with T = i256): FIVE words = the exact 320-bit two's complement total (the value's
+// four words + its sign extension), so that "left [DECIMAL_MIN, DECIMAL_MAX]" is decided on the exact total like the Decimal128 sum.
+// Word-by-word atomic adds; every carry is observed by exactly one adder.
+#define GB_SUM256_WORDS 5
+__device__ __forceinline__ void atomic_add_words(uint64_t* p, const uint64_t* v, int n) {
+  uint64_t carry = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t add = v[i] + carry;
+    uint64_t c = add < carry ? 1 : 0;   // v[i] = ~0 and a carry in: nothing to add here, the carry moves on
+    if (add) {
+      const unsigned long long old = atomicAdd((unsigned long long*)(p + i), (unsigned long long)add);
+      c |= ((uint64_t)old + add) < add ? 1 : 0;
+    }
+    carry = c;
+  }
+}
+__device__ __forceinline__ void wg_add_words(uint64_t* p, const uint64_t* v, int n) {
+  uint64_t carry = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t add = v[i] + carry;
+    uint64_t c = add < carry ? 1 : 0;
+    if (add) {
+      const uint64_t old = __hip_atomic_fetch_add((unsigned long long*)(p + i), (unsigned long long)add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      c |= (old + add) < add ? 1 : 0;
+    }
+    carry = c;
+  }
+}
+__device__ __forceinline__ void plain_add_words(uint64_t* p, const uint64_t* v, int n) {
+  uint64_t carry = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t a = p[i] + v[i];
+    const uint64_t c1 = a < v[i] ? 1 : 0;
+    const uint64_t b = a + carry;
+    const uint64_t c2 = b < a ? 1 : 0;
+    p[i] = b;
+    carry = c1 | c2;
+  }
+}
+__host__ __device__ __forceinline__ bool gb_sum256(const GbLayout& L, int a) {
+  return L.agg_kind[a] == DBHIP_AGG_SUM && L.agg_type[a] == DBHIP_T_DEC256;
+}
+
 // MIN / MAX over Decimal128 (r03): the state is THREE words — [0] the high 64 bits with the sign flipped (so that unsigned order
 // is value order), [1] the has-value word like every other min / max state, [2] the low 64 bits — compared lexicographically as
 // ([0], [2]). No 128-bit atomic exists, so a concurrent merge takes a PER-STATE SPIN LOCK in bit 63 of the has word: try-lock inside
@@ -324,7 +367,9 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
       break;
     case DBHIP_AGG_SUM: {
       const int fw = L.agg_flag[a];
-      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+      if (L.agg_type[a] == DBHIP_T_DEC256) {
+        atomic_add_words(dst, v, GB_SUM256_WORDS);
+      } else if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
         if (v[0] | v[1] | v[2]) atomic_add_u192(dst, v[0], v[1], v[2]);
       } else if (L.agg_type[a] == DBHIP_T_F32 || L.agg_type[a] == DBHIP_T_F64) {
         atomicAdd((double*)dst, __longlong_as_double((long long)v[0]));
@@ -363,7 +408,9 @@ __device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* 
       break;
     case DBHIP_AGG_SUM: {
       const int fw = L.agg_flag[a];
-      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+      if (L.agg_type[a] == DBHIP_T_DEC256) {
+        wg_add_words(dst, v, GB_SUM256_WORDS);
+      } else if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
         if (v[0] | v[1] | v[2]) {
           const uint64_t old = GB_WG_ADD(dst, v[0]);
           const uint64_t c1 = (old + v[0]) < v[0] ? 1 : 0;
@@ -410,7 +457,9 @@ __device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_
       break;
     case DBHIP_AGG_SUM: {
       const int fw = L.agg_flag[a];
-      if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+      if (L.agg_type[a] == DBHIP_T_DEC256) {
+        plain_add_words(dst, v, GB_SUM256_WORDS);
+      } else if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
         const uint64_t lo = dst[0] + v[0];
         const uint64_t c1 = lo < v[0] ? 1 : 0;
         const uint64_t h1 = dst[1] + v[1];

@@ -8,6 +8,7 @@
 //   ints/date/timestamp/dec64/bool : 1 word, value widened (sign-/zero-extended)
 //   f32/f64                        : 1 word, raw bits zero-extended
 //   dec128                         : 2 words (lo, hi)
+//   dec256                         : 4 words (little endian limbs; r04)
 //   string (len <= 12)             : 2 words = the 16-byte inline view, bytes past len zeroed
 //   string (len  > 12)             : word 0 = len | first 4 bytes << 32 (the view's prefix), word 1 = where the bytes live:
 //                                    in a table row the OFFSET into the table's arena (a device bump allocator, the
@@ -22,7 +23,8 @@
 //                          "left [DECIMAL_MIN, DECIMAL_MAX]" is decided on the exact total
 //                          (aggregate_sum.rs:203-216 checks the running sum; for same-signed
 //                          inputs the two coincide)
-//   MIN/MAX              : 2 words [order-preserving key][has value]
+//   SUM dec256           : 5 words = exact 320-bit two's complement sum (r04), row path only
+//   MIN/MAX              : 2 words [order-preserving key][has value]; Decimal128 / String: 3 words (gb_device.h)
 //   SUM over a NULLABLE argument carries one more word at the end: [seen a non-NULL row] (0 / 1, OR-merged) — the
 //   device analogue of the flag byte AggregateNullUnaryAdaptor<true> appends to the nested state
 //   (adaptors/aggregate_null_adaptor.rs:366-400,508-540): a group whose argument was NULL in every row yields NULL,

@@ -492,10 +492,13 @@ bool fa_arg_type_ok(int t) { return type_class(t) >= 0 || t == DBHIP_T_BOOL || t
 // state words laid out back to back)
 bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
   if (L.nkeys > FA_KW || L.nkey_words > FA_KW || L.naggs > FA_MAXA || L.naggs < 1) return false;
+  for (int k = 0; k < L.nkeys; ++k)
+    if (L.key_type[k] == DBHIP_T_DEC256) return false;   // four-word keys: row path
   int words = 0;
   for (int a = 0; a < L.naggs; ++a) {
     if (L.agg_off[a] != L.agg_off[0] + words) return false;
-    if ((L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_words[a] == 3) return false;   // Decimal128 min / max: row path
+    if ((L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_words[a] == 3) return false;   // Decimal128 / String min / max: row path
+    if (L.agg_type[a] == DBHIP_T_DEC256 && L.agg_kind[a] != DBHIP_AGG_COUNT) return false;                           // Decimal256 sum: row path
     words += L.agg_words[a];
   }
   return words <= FA_MAXW && L.hash_word == L.nkey_words && L.agg_off[0] == L.hash_word + 1;

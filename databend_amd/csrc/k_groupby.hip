@@ -209,6 +209,25 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
         }
         long_bytes = wave_sum_u64(long_bytes);
         if (long_bytes && lane_id() == 0) atomicAdd((unsigned long long*)&ctrl[9], (unsigned long long)long_bytes);
+      } else if (L.key_type[k] == DBHIP_T_DEC256) {
+        // four little-endian words; the hash is AggHash for i256 = its 32 bytes through the byte hash (group_hash.rs:593-597)
+        const GbCol& kc = C.key[k];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t j = kc.is_scalar ? 0 : row[u];
+          valid[u] = !kc.validity || bit_get(kc.validity, kc.voff + j);
+          const uint64_t* p = (const uint64_t*)kc.data + 4 * j;
+          uint64_t q[4] = {p[0], p[1], p[2], p[3]};
+          if (!valid[u]) { q[0] = 0; q[1] = 0; q[2] = 0; q[3] = 0; }
+          const uint64_t hk = valid[u] ? agg_hash_i256(q[0], q[1], q[2], q[3]) : DBHIP_NULL_HASH_VAL;
+          h[u] = (k == 0) ? hk : merge_hash(h[u], hk);
+          if (in[u]) {
+            uint64_t* r = rows_in + li[u] * L.W + L.key_off[k];
+            r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+          }
+          if (valid[u]) vmask[u] |= 1ULL << k;
+        }
+        continue;
       } else if (!gb_load_words_n<U>(C.key[k], row, w0, w1, valid)) atomicOr((unsigned long long*)&ctrl[3], 2ULL);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -236,6 +255,23 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
       bool valid[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) { w0[u] = 0; w1[u] = 0; valid[u] = true; }
+      if (C.arg[a].data != nullptr && gb_sum256(L, a)) {
+        // SUM over Decimal256: the row's contribution is the value's four words + its sign extension (+ the adaptor's flag)
+        const GbCol& ac = C.arg[a];
+        const int fw = L.agg_flag[a];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!in[u]) continue;
+          const int64_t j = ac.is_scalar ? 0 : row[u];
+          const bool ok = !ac.validity || bit_get(ac.validity, ac.voff + j);
+          const uint64_t* p = (const uint64_t*)ac.data + 4 * j;
+          uint64_t* st = rows_in + li[u] * L.W + L.agg_off[a];
+          st[0] = ok ? p[0] : 0; st[1] = ok ? p[1] : 0; st[2] = ok ? p[2] : 0; st[3] = ok ? p[3] : 0;
+          st[4] = (ok && (p[3] >> 63)) ? ~0ULL : 0;
+          if (fw) st[fw] = ok ? 1 : 0;
+        }
+        continue;
+      }
       if (C.arg[a].data != nullptr && C.arg[a].type == DBHIP_T_STRING) {
         // a String argument (min / max): short values as the canonical inline words, long ones as (len | prefix, ADDRESS of the bytes)
         const GbCol& ac = C.arg[a];
@@ -464,6 +500,10 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
           if (mine) gb_minmax_str_locked(L.agg_kind[a] == DBHIP_AGG_MIN, d + L.agg_off[a], v);
           continue;
         }
+        if (gb_sum256(L, a)) {       // five-word totals: every row adds its own words (the wave reduction below is four words wide)
+          if (mine) gb_atomic_merge(L, a, d + L.agg_off[a], v);
+          continue;
+        }
         switch (L.agg_kind[a]) {
           case DBHIP_AGG_COUNT:
             out[0] = wave_sum_u64(mine ? v[0] : 0);
@@ -665,6 +705,9 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           case DBHIP_T_I16: case DBHIP_T_U16: ((uint16_t*)o)[i] = (uint16_t)w0; break;
           case DBHIP_T_I32: case DBHIP_T_U32: case DBHIP_T_F32: case DBHIP_T_DATE:
             ((uint32_t*)o)[i] = (uint32_t)w0; break;
+          case DBHIP_T_DEC256:
+            for (int q = 0; q < 4; ++q) ((uint64_t*)o)[4 * i + q] = r[L.key_off[k] + q];
+            break;
           case DBHIP_T_DEC128: case DBHIP_T_STRING: {
             uint64_t w1 = r[L.key_off[k] + 1];
             if (L.key_type[k] == DBHIP_T_STRING) {
@@ -703,6 +746,24 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           ((uint64_t*)o)[i] = s[0];
           break;
         case DBHIP_AGG_SUM:
+          if (L.agg_type[a] == DBHIP_T_DEC256) {
+            // DecimalSumState<true, i256>::add: outside [DECIMAL_MIN, DECIMAL_MAX] (precision 76) is an Overflow error — decided on the
+            // exact 320-bit total: the fifth word must be the sign extension and |total| <= 10^76 - 1
+            const bool neg = (s[3] >> 63) != 0;
+            bool bad = s[4] != (neg ? ~0ULL : 0ULL);
+            uint64_t m[4] = {s[0], s[1], s[2], s[3]};
+            if (neg) {   // magnitude
+              uint64_t c = 1;
+              for (int q = 0; q < 4; ++q) { const uint64_t t = ~m[q] + c; c = (c && t == 0) ? 1 : 0; m[q] = t; }
+            }
+            // 10^76 - 1 = 0x161BCCA7119915B5_0764B4ABE8652979_7775A5F171950FFF_FFFFFFFFFFFFFFFF (little-endian words)
+            const uint64_t mx[4] = {0xFFFFFFFFFFFFFFFFULL, 0x7775A5F171950FFFULL, 0x0764B4ABE8652979ULL, 0x161BCCA7119915B5ULL};
+            bool gt = false, decided = false;
+            for (int q = 3; q >= 0 && !decided; --q) if (m[q] != mx[q]) { gt = m[q] > mx[q]; decided = true; }
+            if (bad || gt) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
+            for (int q = 0; q < 4; ++q) ((uint64_t*)o)[4 * i + q] = s[q];
+            break;
+          }
           if (L.agg_words[a] - (L.agg_flag[a] ? 1 : 0) == 3) {
             i128 v = (i128)(((u128)s[1] << 64) | s[0]);
             // DecimalSumState<true,_>::add (aggregate_sum.rs:203-216): outside
@@ -949,7 +1010,7 @@ GbCol to_gbcol(const dbhip_col& c) {
   return g;
 }
 
-bool key_type_ok(int t) { return t >= DBHIP_T_BOOL && t <= DBHIP_T_STRING; }
+bool key_type_ok(int t) { return t >= DBHIP_T_BOOL && t <= DBHIP_T_DEC256; }
 
 int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int nkeys,
                      const dbhip_agg_desc* aggs, int naggs, GbLayout* L) {
@@ -969,7 +1030,7 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
     }
     L->key_type[k] = key_types[k];
     L->key_off[k] = w;
-    L->key_words[k] = (key_types[k] == DBHIP_T_DEC128 || key_types[k] == DBHIP_T_STRING) ? 2 : 1;
+    L->key_words[k] = key_types[k] == DBHIP_T_DEC256 ? 4 : ((key_types[k] == DBHIP_T_DEC128 || key_types[k] == DBHIP_T_STRING) ? 2 : 1);
     if (key_types[k] == DBHIP_T_STRING) L->str_w1_mask |= 1u << (w + 1);
     L->key_nullable[k] = key_nullable ? key_nullable[k] : 0;
     any_nullable |= L->key_nullable[k] != 0;
@@ -988,6 +1049,7 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
       case DBHIP_AGG_COUNT: break;
       case DBHIP_AGG_SUM:
         if (d.arg_type == DBHIP_T_DEC128) words = 3;
+        else if (d.arg_type == DBHIP_T_DEC256) words = GB_SUM256_WORDS;   // exact 320-bit total (gb_device.h)
         else if (!(d.arg_type >= DBHIP_T_I8 && d.arg_type <= DBHIP_T_F64) && d.arg_type != DBHIP_T_DEC64) {
           set_error("groupby: sum() does not support type %d", d.arg_type);
           return DBHIP_ERR_INVALID;
@@ -995,7 +1057,7 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
         if (d.arg_nullable) L->agg_flag[a] = words++;   // "seen a non-NULL row" (AggregateNullUnaryAdaptor<true>)
         break;
       case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
-        if (!key_type_ok(d.arg_type)) {
+        if (!key_type_ok(d.arg_type) || d.arg_type == DBHIP_T_DEC256) {
           set_error("groupby: min/max on type %d stays on the CPU operator", d.arg_type);
           return DBHIP_ERR_UNSUPPORTED;
         }
@@ -1075,6 +1137,16 @@ bool layout_has_str_minmax(const GbLayout& L) {
   return false;
 }
 int32_t refuse_str_minmax_state(const GbLayout& L, const char* fn) {
+  for (int a = 0; a < L.naggs; ++a)
+    if (gb_sum256(L, a)) {
+      set_error("%s: the serialized-state block of sum(Decimal256) is not produced on the device; exchange the table's rows (flush_block / partition_blocks)", fn);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+  for (int k = 0; k < L.nkeys; ++k)
+    if (L.key_type[k] == DBHIP_T_DEC256) {
+      set_error("%s: Decimal256 group keys in the serialized-state block are not produced on the device; exchange the table's rows", fn);
+      return DBHIP_ERR_UNSUPPORTED;
+    }
   if (!layout_has_str_minmax(L)) return DBHIP_OK;
   set_error("%s: the serialized-state block of min / max over String (a borsh Option<String> per group) is not produced on the device; "
             "keep the CPU operator for the exchange of this aggregate", fn);
@@ -1633,8 +1705,9 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
   return DBHIP_OK;
 }
 
-bool layout_has_wide_minmax(const GbLayout& L) {
-  for (int a = 0; a < L.naggs; ++a) if (gb_minmax_wide(L, a)) return true;
+bool layout_has_wide_minmax(const GbLayout& L) {   // "row path only": locked min / max states, Decimal256 sums and keys
+  for (int a = 0; a < L.naggs; ++a) if (gb_minmax_wide(L, a) || gb_sum256(L, a)) return true;
+  for (int k = 0; k < L.nkeys; ++k) if (L.key_type[k] == DBHIP_T_DEC256) return true;
   return false;
 }
 bool fast_layout_ok(const GbLayout& L) {
@@ -3322,6 +3395,7 @@ int32_t dbhip_groupby_result_type(const dbhip_agg_desc* agg, int32_t* out_type, 
         case DBHIP_T_F32: case DBHIP_T_F64: t = DBHIP_T_F64; break;
         case DBHIP_T_DEC64: t = DBHIP_T_DEC64; p = 18; sc = agg->arg_scale; break;   // aggregate_sum.rs:404-406
         case DBHIP_T_DEC128: t = DBHIP_T_DEC128; p = 38; sc = agg->arg_scale; break;
+        case DBHIP_T_DEC256: t = DBHIP_T_DEC256; p = 76; sc = agg->arg_scale; break;
       }
       break;
     case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:

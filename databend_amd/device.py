@@ -990,6 +990,8 @@ class GroupBy:
                 vals = view_strings(b.to_numpy(np.uint8, 16 * n), self.arena_numpy())
             elif t == L.T_DEC128:
                 vals = bytes_to_i128(b.to_numpy(np.uint8, 16 * n))
+            elif t == L.T_DEC256:
+                vals = limbs_to_ints(b.to_numpy(np.uint8, 32 * n), 256)
             elif t == L.T_BOOL:
                 vals = [bool(x) for x in b.to_numpy(np.uint8, n)]
             else:
@@ -998,6 +1000,8 @@ class GroupBy:
         for t, b, a, v in zip(agg_t, agg_bufs, self.aggs, agg_val):
             if t == L.T_DEC128:
                 vals = bytes_to_i128(b.to_numpy(np.uint8, 16 * n))
+            elif t == L.T_DEC256:
+                vals = limbs_to_ints(b.to_numpy(np.uint8, 32 * n), 256)
             elif t == L.T_STRING:   # min / max over String: views whose long form points into the table's arena
                 vals = view_strings(b.to_numpy(np.uint8, 16 * n), self.arena_numpy())
             else:

@@ -43,6 +43,7 @@ static int t_bits(int t) {
   }
 }
 static int t_size(int t) {
+  if (t == ORC_T_DEC256) return 32;
   if (t == ORC_T_DEC128 || t == ORC_T_STRING) return 16;
   return t_bits(t) / 8;
 }
@@ -724,6 +725,7 @@ static uint64_t hash_col_row(const orc_col* c, int64_t i) {
       return orc_agg_hash_u64(b);
     }
     case ORC_T_DEC128: return orc_agg_hash_bytes((const uint8_t*)c->data + 16 * j, 16); /* :587-591 */
+    case ORC_T_DEC256: return orc_agg_hash_bytes((const uint8_t*)c->data + 32 * j, 32); /* :593-597 */
     case ORC_T_STRING: { uint32_t len; const uint8_t* p = view_bytes((const uint32_t*)c->data + 4 * j, c->buffers, &len);
                          return orc_agg_hash_bytes(p, len); }
   }
@@ -774,6 +776,7 @@ static int rowformat_size(int t) { /* payload_row.rs:51-83 */
     case ORC_T_BOOL: return 1;
     case ORC_T_STRING: return 12; /* u32 len + address */
     case ORC_T_DEC128: return 16;
+    case ORC_T_DEC256: return 32;
     default: return t_size(t);
   }
 }
@@ -782,9 +785,10 @@ static int rowformat_size(int t) { /* payload_row.rs:51-83 */
  * merge_result yields NULL while the flag is clear. For min/max the Option's has-value word plays that role. */
 static int agg_flag_off(const orc_agg_desc* d) { /* 0 = no flag */
   if (d->kind != ORC_AGG_SUM || !d->arg_nullable) return 0;
-  return d->arg_type == ORC_T_DEC128 ? 16 : 8;
+  return d->arg_type == ORC_T_DEC256 ? 32 : (d->arg_type == ORC_T_DEC128 ? 16 : 8);
 }
 static int agg_state_size(const orc_agg_desc* d) {
+  if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC256) return d->arg_nullable ? 40 : 32; /* DecimalSumState<_, i256>: [u64; 4] */
   if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return d->arg_nullable ? 32 : 16;
   if (d->kind == ORC_AGG_SUM && d->arg_nullable) return 16; /* value + flag */
   if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return (d->arg_type == ORC_T_DEC128 || d->arg_type == ORC_T_STRING) ? 32 : 16; /* value + has flag (Decimal128: 16-byte value; String: offset + length into the table's bytes) */
@@ -879,7 +883,7 @@ static int row_match(const orc_hashagg* h, const uint8_t* row, const orc_col* ke
       uint64_t off; memcpy(&off, f + 4, 8);
       if (memcmp(h->strs + off, p, len)) return 0;
     } else {
-      uint8_t tmp[16]; key_field(h, &keys[k], k, i, tmp, NULL);
+      uint8_t tmp[32]; key_field(h, &keys[k], k, i, tmp, NULL);
       if (memcmp(tmp, f, (size_t)h->key_size[k])) return 0;
     }
   }
@@ -918,6 +922,19 @@ static void resize_index(orc_hashagg* h, size_t new_cap) { /* aggregate_hashtabl
 }
 
 /* accumulate one row into one state (accumulate_keys: aggregate_unary.rs:208-222) */
+/* i256 as four little-endian u64 (ethnum::i256 through T::U64Array, aggregate_sum.rs:183-216): wrapping add, then the range check
+ * of DecimalSumState<true, i256>::add against +-(10^76 - 1) */
+static void i256w_add(uint64_t* s, const uint64_t* v) {
+  unsigned __int128 c = 0;
+  for (int q = 0; q < 4; ++q) { c += (unsigned __int128)s[q] + v[q]; s[q] = (uint64_t)c; c >>= 64; }
+}
+static int i256w_out_of_range(const uint64_t* s) {
+  static const uint64_t mx[4] = {0xFFFFFFFFFFFFFFFFULL, 0x7775A5F171950FFFULL, 0x0764B4ABE8652979ULL, 0x161BCCA7119915B5ULL}; /* 10^76 - 1 */
+  uint64_t m[4] = {s[0], s[1], s[2], s[3]};
+  if (s[3] >> 63) { unsigned __int128 c = 1; for (int q = 0; q < 4; ++q) { c += (uint64_t)~m[q]; m[q] = (uint64_t)c; c >>= 64; } }
+  for (int q = 3; q >= 0; --q) if (m[q] != mx[q]) return m[q] > mx[q];
+  return 0;
+}
 static int state_add(orc_hashagg* h, const orc_agg_desc* d, uint8_t* st, const orc_col* arg, int64_t i) {
   int valid = !arg || !arg->data || col_valid(arg, i);
   switch (d->kind) {
@@ -925,6 +942,13 @@ static int state_add(orc_hashagg* h, const orc_agg_desc* d, uint8_t* st, const o
     case ORC_AGG_SUM:
       if (!valid) return 0;
       if (agg_flag_off(d)) st[agg_flag_off(d)] = 1; /* set_flag(place, true), aggregate_null_adaptor.rs:447-452 */
+      if (d->arg_type == ORC_T_DEC256) {
+        uint64_t sum[4], v[4];
+        memcpy(sum, st, 32); memcpy(v, (const uint8_t*)arg->data + 32 * (arg->is_scalar ? 0 : i), 32);
+        i256w_add(sum, v);
+        memcpy(st, sum, 32);
+        return i256w_out_of_range(sum) ? 5 : 0;
+      }
       if (d->arg_type == ORC_T_DEC128) { /* DecimalSumState::add aggregate_sum.rs:203-216 */
         i128 s; memcpy(&s, st, 16);
         s = (i128)((u128)s + (u128)((const i128*)arg->data)[arg->is_scalar ? 0 : i]);
@@ -1094,7 +1118,8 @@ int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* 
         out_agg_valid[a][r] = ok;
       }
       if (!out_aggs || !out_aggs[a]) continue;
-      if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16);
+      if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC256) memcpy((uint8_t*)out_aggs[a] + 32 * r, st, 32);
+      else if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16);
       else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_STRING) {
         /* 16 bytes per group: u32 length, then the bytes when they fit 12, else u32 0, u64 offset into the table's bytes (orc_hashagg_bytes) */
         uint8_t* v = (uint8_t*)out_aggs[a] + 16 * r; memset(v, 0, 16);
@@ -1200,6 +1225,10 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
             if (!sp[agg_flag_off(ad)]) continue;
             d[agg_flag_off(ad)] = 1;
           }
+          if (ad->arg_type == ORC_T_DEC256) {
+            uint64_t x[4], y[4]; memcpy(x, d, 32); memcpy(y, sp, 32); i256w_add(x, y); memcpy(d, x, 32);
+            if (i256w_out_of_range(x)) rc = 5;
+          } else
           if (ad->arg_type == ORC_T_DEC128) { /* DecimalSumState::merge -> add (with the overflow check) */
             i128 x, y; memcpy(&x, d, 16); memcpy(&y, sp, 16); x = (i128)((u128)x + (u128)y); memcpy(d, &x, 16);
             i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;

@@ -268,6 +268,53 @@ def test_oracle_min_max_over_strings_against_python():
         L.orc_hashagg_destroy(h)
 
 
+def test_oracle_decimal256_keys_and_sums_against_python_integers():
+    """aggregate_sum.rs:183-300 with T = i256 and group_hash.rs:593-597 in the oracle: Decimal256 group keys (32-byte rows, the byte hash)
+    and sum(Decimal256) with its range check, against Python's integers; also through combine()."""
+    from databend_amd.device import ints_to_limbs
+    from tests.test_gpu_parity import oracle_groupby, oracle_rows
+    L = O.load()
+    rng = np.random.default_rng(1)
+    n = 6000
+    keys = [int(x) * 10**50 for x in rng.integers(-20, 20, n)]
+    vals = [int(a) * 10**52 + int(b) for a, b in zip(rng.integers(-10**17, 10**17, n), rng.integers(0, 10**9, n))]
+    valid = rng.random(n) > 0.2
+    aggs = [(T.AGG_SUM, T.T_DEC256, 76, 4, 1), (T.AGG_COUNT, 0, 0, 0, 0)]
+    hs = []
+    for lo, hi in ((0, n // 2), (n // 2, n)):
+        hk = O.HostCol(T.T_DEC256, ints_to_limbs(keys[lo:hi], 256), None, 76, 0)
+        ha = O.HostCol(T.T_DEC256, ints_to_limbs(vals[lo:hi], 256), valid[lo:hi], 76, 4)
+        hs.append(oracle_groupby(L, [T.T_DEC256], [0], aggs, [hk], [ha, None], hi - lo))
+    assert L.orc_hashagg_combine(hs[0], hs[1]) == 0
+    rows = oracle_rows(L, hs[0], [T.T_DEC256], aggs)
+    exp = {}
+    for k, v, ok in zip(keys, vals, valid.tolist()):
+        e = exp.setdefault(k, [None, 0])
+        e[1] += 1
+        if ok:
+            e[0] = (e[0] or 0) + v
+    assert {r[0]: [r[1], r[2]] for r in rows} == exp
+    for h in hs:
+        L.orc_hashagg_destroy(h)
+    # the range check: +-(10^76 - 1)
+    mx = 10**76 - 1
+    import ctypes as C
+    h = oracle_groupby(L, [T.T_I64], [0], [(T.AGG_SUM, T.T_DEC256, 76, 0, 0)], [O.HostCol(T.T_I64, np.zeros(2, np.int64))],
+                       [O.HostCol(T.T_DEC256, ints_to_limbs([mx, -mx], 256), None, 76, 0)], 2)
+    assert oracle_rows(L, h, [T.T_I64], [(T.AGG_SUM, T.T_DEC256, 76, 0, 0)]) == [(0, 0)]
+    L.orc_hashagg_destroy(h)
+    kt, kn = (C.c_int32 * 1)(T.T_I64), (C.c_uint8 * 1)(0)
+    ad = (O.OAgg * 1)()
+    ad[0].kind, ad[0].arg_type, ad[0].arg_precision, ad[0].arg_scale, ad[0].arg_nullable = T.AGG_SUM, T.T_DEC256, 76, 0, 0
+    L.orc_hashagg_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    h = C.c_void_p(L.orc_hashagg_create(kt, kn, 1, ad, 1))
+    args = (O.OCol * 1)()
+    col = O.HostCol(T.T_DEC256, ints_to_limbs([mx, 1], 256), None, 76, 0)
+    args[0] = col.c()
+    assert L.orc_hashagg_add_block(h, O.cols([O.HostCol(T.T_I64, np.zeros(2, np.int64))]), args, C.c_int64(2)) == 5     # Overflow
+    L.orc_hashagg_destroy(h)
+
+
 def test_kernel_pass_filter_and_take_goldens():
     """kernel-pass.txt Filter / Take sections: Bitmap -> selection -> take of every column, rendered like the reference."""
     L = O.load()

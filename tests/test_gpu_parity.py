@@ -263,17 +263,17 @@ def oracle_groupby(oracle, key_types, key_nullable, aggs, hkeys, hargs, n):
 
 def oracle_rows(oracle, h, key_types, aggs):
     g = oracle.orc_hashagg_num_groups(h)
-    sizes = {T.T_STRING: 16, T.T_DEC128: 16, T.T_BOOL: 1}
-    from databend_amd.device import ELEM_SIZE, NP_OF, view_strings
+    sizes = {T.T_STRING: 16, T.T_DEC128: 16, T.T_BOOL: 1, T.T_DEC256: 32}
+    from databend_amd.device import ELEM_SIZE, NP_OF, limbs_to_ints, view_strings
     kb = [np.zeros(max(g, 1) * sizes.get(t, ELEM_SIZE.get(t, 8)) + 16, np.uint8) for t in key_types]
     kv = [np.zeros(max(g, 1) + 8, np.uint8) for _ in key_types]
     res_t = []
     for a in aggs:
         kind, at = a[0], a[1]
         if kind == T.AGG_COUNT: res_t.append(T.T_U64)
-        elif kind == T.AGG_SUM: res_t.append(T.T_DEC128 if at == T.T_DEC128 else (T.T_F64 if at in (T.T_F32, T.T_F64) else (T.T_U64 if at in (T.T_U8, T.T_U16, T.T_U32, T.T_U64) else T.T_I64)))
+        elif kind == T.AGG_SUM: res_t.append(T.T_DEC256 if at == T.T_DEC256 else T.T_DEC128 if at == T.T_DEC128 else (T.T_F64 if at in (T.T_F32, T.T_F64) else (T.T_U64 if at in (T.T_U8, T.T_U16, T.T_U32, T.T_U64) else T.T_I64)))
         else: res_t.append(at)
-    ab = [np.zeros(max(g, 1) * 16 + 16, np.uint8) for _ in aggs]
+    ab = [np.zeros(max(g, 1) * 32 + 32, np.uint8) for _ in aggs]
     kp = (C.c_void_p * len(kb))(*[b.ctypes.data for b in kb])
     kvp = (C.c_void_p * len(kv))(*[b.ctypes.data for b in kv])
     ap = (C.c_void_p * max(len(ab), 1))(*[b.ctypes.data for b in ab])
@@ -284,6 +284,7 @@ def oracle_rows(oracle, h, key_types, aggs):
     for t, b, v in zip(key_types, kb, kv):
         if t == T.T_STRING: vals = view_strings(b[:16 * g])
         elif t == T.T_DEC128: vals = O.i128_list(b[:16 * g])
+        elif t == T.T_DEC256: vals = limbs_to_ints(b[:32 * g], 256)
         elif t == T.T_BOOL: vals = [bool(x) for x in b[:g]]
         else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
         cols.append([x if ok else None for x, ok in zip(vals, v[:g])])
@@ -299,6 +300,7 @@ def oracle_rows(oracle, h, key_types, aggs):
                 off = int(b[16 * i + 8:16 * i + 16].view(np.uint64)[0])
                 vals.append(bytes(b[16 * i + 4:16 * i + 4 + ln]) if ln <= 12 else store[off:off + ln])
         elif t == T.T_DEC128: vals = O.i128_list(b[:16 * g])
+        elif t == T.T_DEC256: vals = limbs_to_ints(b[:32 * g], 256)
         else: vals = b[:g * ELEM_SIZE[t]].view(NP_OF[t]).tolist()
         if a[4] and a[0] != T.AGG_COUNT:  # sum / min / max over a Nullable argument: NULL for all-NULL groups
             vals = [x if ok else None for x, ok in zip(vals, v[:g])]
