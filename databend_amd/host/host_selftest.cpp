@@ -513,6 +513,7 @@ static void test_two_rank_exchange() {
   std::vector<int64_t> key[2], pay[2];
   std::vector<uint32_t> dest[2];
   std::vector<int64_t> got_key[2], got_pay[2];
+  std::vector<int64_t> shuf_key[2], shuf_pay[2], sort_key[2], sort_pay[2];   // the same block through the two plan calls
   std::vector<int64_t> starts[2];
   std::mt19937_64 rng(77);
   for (int r = 0; r < world; ++r) {
@@ -552,6 +553,30 @@ static void test_two_rank_exchange() {
       got_key[r].resize(rows); got_pay[r].resize(rows);
       ok->download(got_key[r].data(), (size_t)rows * 8);
       op->download(got_pay[r].data(), (size_t)rows * 8);
+      // the hash shuffle and the range partition of the distributed sort as single plan calls (no index computed by the caller)
+      for (int plan = 0; plan < 2; ++plan) {
+        int64_t prow = 0;
+        dbhip_exchange* px = nullptr;
+        if (plan == 0) {
+          check(dbhip_shuffle_exchange_begin(c, &kcol, 1, cols, 2, n[r], &prow, &px, nullptr));
+        } else {
+          const std::vector<int64_t> bound = {2047};    // one bound: keys <= 2047 -> rank 0, the rest -> rank 1
+          Column bc = Column::from_vector(I64, bound);
+          dbhip_col bcol = bc.c();
+          const uint8_t desc[1] = {0}, nf[1] = {0};
+          check(dbhip_sort_exchange_begin(c, &kcol, &bcol, desc, nf, 1, 1, cols, 2, n[r], &prow, &px, nullptr));
+        }
+        Buf pk = make_buf((size_t)prow * 8 + 64), pp = make_buf((size_t)prow * 8 + 64);
+        void* pouts[2] = {pk->ptr(), pp->ptr()};
+        uint8_t* pv[2] = {nullptr, nullptr};
+        check(dbhip_exchange_finish(px, pouts, pv, nullptr, nullptr));
+        check(dbhip_exchange_destroy(px));
+        std::vector<int64_t>& dk = plan == 0 ? shuf_key[r] : sort_key[r];
+        std::vector<int64_t>& dp = plan == 0 ? shuf_pay[r] : sort_pay[r];
+        dk.resize(prow); dp.resize(prow);
+        pk->download(dk.data(), (size_t)prow * 8);
+        pp->download(dp.data(), (size_t)prow * 8);
+      }
       Buf ib = make_buf(nq * k * 4), dbf = make_buf(nq * k * 4), oi = make_buf(nq * k * 4), od = make_buf(nq * k * 4);
       ib->upload(tid[r].data(), nq * k * 4); dbf->upload(tdist[r].data(), nq * k * 4);
       check(dbhip_vec_topk_allgather(c, (const uint32_t*)ib->ptr(), (const float*)dbf->ptr(), nq, k, (uint64_t)r * 5000000ULL, (uint32_t*)oi->ptr(),
@@ -572,6 +597,12 @@ static void test_two_rank_exchange() {
     CHECK(got_key[r] == ek);
     CHECK(got_pay[r] == ep);
     CHECK(starts[r][world] == (int64_t)ek.size());
+    CHECK(shuf_key[r] == ek && shuf_pay[r] == ep);      // dbhip_shuffle_exchange_begin = scatter_indices + exchange
+    std::vector<int64_t> sk, sp;                        // dbhip_sort_exchange_begin: the rows of range r, by source rank, in order
+    for (int s2 = 0; s2 < world; ++s2)
+      for (int64_t i = 0; i < n[s2]; ++i)
+        if ((key[s2][i] <= 2047 ? 0 : 1) == r) { sk.push_back(key[s2][i]); sp.push_back(pay[s2][i]); }
+    CHECK(sort_key[r] == sk && sort_pay[r] == sp);
     for (int q = 0; q < nq; ++q) {   // the k smallest of both shards' candidates, ids made global
       std::vector<std::pair<float, uint32_t>> all;
       for (int s = 0; s < world; ++s)
