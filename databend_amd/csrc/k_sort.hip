@@ -161,20 +161,20 @@ __global__ __launch_bounds__(256) void sort_encode_kernel(SortCol c, const uint3
   }
 }
 
-template <typename K>
-__global__ __launch_bounds__(256) void sort_hist_kernel(const K* keys, int64_t n, int shift, uint32_t* hist,
-                                                        int64_t ntiles) {
+template <typename K, int NT = 256>
+__global__ __launch_bounds__(NT) void sort_hist_kernel(const K* keys, int64_t n, int shift, uint32_t* hist,
+                                                       int64_t ntiles) {
   __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < 256) h[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+  const int64_t base = (int64_t)blockIdx.x * (NT * SORT_ITEMS);
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS; ++r) {
-    int64_t i = base + r * 256 + threadIdx.x;
+    int64_t i = base + r * NT + threadIdx.x;
     if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
   }
   __syncthreads();
-  hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
 // One tile = 4096 keys; wave w owns the contiguous keys [w*1024, (w+1)*1024) in 16 rounds of 64.
@@ -184,20 +184,23 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const K* keys, int64_t n
 //   phase 3  keys and row ids are written to their digit-sorted position IN LDS
 //   phase 4  the tile leaves in digit order: lanes write consecutive addresses per digit run
 // Stable: (wave, round, lane) order is index order.
-template <typename K>
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const K* keys, const uint32_t* vals, int64_t n,
-                                                           int shift, const uint64_t* offs, int64_t ntiles,
-                                                           K* out_keys, uint32_t* out_vals) {
-  __shared__ K lkeys[SORT_TILE];
-  __shared__ uint32_t lvals[SORT_TILE];
-  __shared__ uint32_t wcount[4][256];  // phase 1: keys of (wave, digit); phase 2 on: first LDS slot of (wave, digit)
+template <typename K, int NT = 256>
+__global__ __launch_bounds__(NT) void sort_scatter_kernel(const K* keys, const uint32_t* vals, int64_t n,
+                                                          int shift, const uint64_t* offs, int64_t ntiles,
+                                                          K* out_keys, uint32_t* out_vals) {
+  constexpr int NW = NT / 64, TILE = NT * SORT_ITEMS;   // NT = 512: 8192-key tiles (twice the run length per digit: 256-byte key runs)
+  __shared__ K lkeys[TILE];
+  __shared__ uint32_t lvals[TILE];
+  __shared__ uint32_t wcount[NW][256];  // phase 1: keys of (wave, digit); phase 2 on: first LDS slot of (wave, digit)
   __shared__ uint32_t tile_off[256];
   __shared__ uint32_t wave_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 256) {
 #pragma unroll
-  for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+    for (int w = 0; w < NW; ++w) wcount[w][tid] = 0;
+  }
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (64 * SORT_ITEMS);
+  const int64_t base = (int64_t)blockIdx.x * TILE + (int64_t)wave * (64 * SORT_ITEMS);
   K key[SORT_ITEMS];
   uint32_t val[SORT_ITEMS];
   uint32_t lrank[SORT_ITEMS];
@@ -228,24 +231,29 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const K* keys, const 
   }
   __syncthreads();
   {
-    const uint32_t c0 = wcount[0][tid], c1 = wcount[1][tid], c2 = wcount[2][tid], c3 = wcount[3][tid];
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    uint32_t incl = tot;
+    // threads 0..255 (waves 0..3): one digit each — its count over the tile's waves, the exclusive scan over the digits
+    uint32_t cw[NW];
+    uint32_t tot = 0, incl = 0;
+    if (tid < 256) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
+      for (int w = 0; w < NW; ++w) { cw[w] = wcount[w][tid]; tot += cw[w]; }
+      incl = tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
     }
-    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    uint32_t wb = 0;
-    for (int w = 0; w < wave; ++w) wb += wave_tot[w];
-    const uint32_t off = wb + incl - tot;
-    tile_off[tid] = off;
-    wcount[0][tid] = off;
-    wcount[1][tid] = off + c0;
-    wcount[2][tid] = off + c0 + c1;
-    wcount[3][tid] = off + c0 + c1 + c2;
+    if (tid < 256) {
+      uint32_t wb = 0;
+      for (int w = 0; w < wave; ++w) wb += wave_tot[w];
+      uint32_t off = wb + incl - tot;
+      tile_off[tid] = off;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { wcount[w][tid] = off; off += cw[w]; }
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -259,14 +267,14 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const K* keys, const 
     }
   }
   __syncthreads();
-  const int64_t tile_base = (int64_t)blockIdx.x * SORT_TILE;
-  const int tile_n = (int)((n - tile_base) < SORT_TILE ? (n - tile_base) : SORT_TILE);
+  const int64_t tile_base = (int64_t)blockIdx.x * TILE;
+  const int tile_n = (int)((n - tile_base) < TILE ? (n - tile_base) : TILE);
 #pragma unroll 4
-  for (int j = tid; j < tile_n; j += 256) {
+  for (int j = tid; j < tile_n; j += NT) {
     const K k = lkeys[j];
     const uint32_t digit = (uint32_t)(k >> shift) & 0xFF;
     const uint64_t pos = offs[(int64_t)digit * ntiles + blockIdx.x] + (uint32_t)(j - tile_off[digit]);
-    out_keys[pos] = k;
+    if (out_keys) out_keys[pos] = k;   // (the last pass over a key image: only the permutation is still needed)
     out_vals[pos] = lvals[j];
   }
 }
@@ -781,30 +789,39 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
     }
   }
 
-  const int64_t ntiles = ceil_div(m, SORT_TILE);
+  // 8192-key tiles of 512 threads (DBHIP_SORT_NT=256: the 4096-key tiles of rounds 1-3)
+  static const int rs_nt = getenv("DBHIP_SORT_NT") ? atoi(getenv("DBHIP_SORT_NT")) : 512;
+  const bool big_tiles = rs_nt == 512;
+  const int64_t ntiles = ceil_div(m, big_tiles ? 512 * SORT_ITEMS : SORT_TILE);
   const int64_t nh = 256 * ntiles;
-  auto radix_passes = [&](int nbytes, uint64_t vary, bool narrow) -> int32_t {
+  // `final_vals`: this call holds the LAST pass of the whole sort — its permutation goes straight to the caller's buffer
+  bool wrote_final = false;
+  auto radix_passes = [&](int nbytes, uint64_t vary, bool narrow, uint32_t* final_vals = nullptr) -> int32_t {
+    int last_b = -1;
+    for (int b = 0; b < nbytes; ++b) if (((vary >> (8 * b)) & 0xFF) != 0) last_b = b;
     for (int b = 0; b < nbytes; ++b) {
       if (((vary >> (8 * b)) & 0xFF) == 0) continue;  // every image has the same byte here
       DBHIP_POLL_CANCEL(s, "dbhip_sort_perm");
-      if (narrow)
-        hipLaunchKernelGGL(sort_hist_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, (const uint32_t*)kb[cur], m, 8 * b, hist, ntiles);
-      else
-        hipLaunchKernelGGL(sort_hist_kernel<uint64_t>, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], m, 8 * b, hist, ntiles);
-      int32_t rc = dbscan::exclusive_scan_u32(hist, nh, blk, offs, s);
-      if (rc) return rc;
-      if (narrow)
-        hipLaunchKernelGGL(sort_scatter_kernel<uint32_t>, dim3((unsigned)ntiles), dim3(256), 0, s, (const uint32_t*)kb[cur], pb[cur], m, 8 * b,
-                           offs, ntiles, (uint32_t*)kb[cur ^ 1], pb[cur ^ 1]);
-      else
-        hipLaunchKernelGGL(sort_scatter_kernel<uint64_t>, dim3((unsigned)ntiles), dim3(256), 0, s, kb[cur], pb[cur], m, 8 * b, offs,
-                           ntiles, kb[cur ^ 1], pb[cur ^ 1]);
+#define RS_PASS(K_, NT_, KEYS_, OUT_)                                                                                                     \
+  do {                                                                                                                                    \
+    hipLaunchKernelGGL((sort_hist_kernel<K_, NT_>), dim3((unsigned)ntiles), dim3(NT_), 0, s, (const K_*)(KEYS_), m, 8 * b, hist, ntiles);  \
+    int32_t rc_ = dbscan::exclusive_scan_u32(hist, nh, blk, offs, s);                                                                     \
+    if (rc_) return rc_;                                                                                                                  \
+    hipLaunchKernelGGL((sort_scatter_kernel<K_, NT_>), dim3((unsigned)ntiles), dim3(NT_), 0, s, (const K_*)(KEYS_), pb[cur], m, 8 * b,    \
+                       offs, ntiles, b == last_b ? (K_*)nullptr : (K_*)(OUT_), (b == last_b && final_vals) ? final_vals : pb[cur ^ 1]);   \
+  } while (0)
+      if (narrow) { if (big_tiles) RS_PASS(uint32_t, 512, kb[cur], kb[cur ^ 1]); else RS_PASS(uint32_t, 256, kb[cur], kb[cur ^ 1]); }
+      else { if (big_tiles) RS_PASS(uint64_t, 512, kb[cur], kb[cur ^ 1]); else RS_PASS(uint64_t, 256, kb[cur], kb[cur ^ 1]); }
+#undef RS_PASS
+      if (b == last_b && final_vals) wrote_final = true;
       cur ^= 1;
     }
     DBHIP_LAUNCH_CHECK();
     return DBHIP_OK;
   };
 
+  const int64_t mout = (limit > 0 && limit < m) ? limit : m;
+  const bool direct_out = mout == m;   // (a LIMIT copies its first rows out of the scratch permutation instead)
   for (int k = nkeys - 1; k >= 0; --k) {
     SortCol c = make_col(k);
     const int parts = c.nparts ? c.nparts : ((c.type == DBHIP_T_DEC128 || c.type == DBHIP_T_STRING) ? 2 : 1);
@@ -814,16 +831,16 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
       // the permutation is shared by both buffers of a pass: encode reads pb[cur], writes kb[cur]
       int32_t rc = encode(c, m, part, narrow, &v_or, &v_and);
       if (rc) return rc;
-      if ((rc = radix_passes(sort_key_bytes(c.type), v_or ^ v_and, narrow))) return rc;
+      const bool last_call = k == 0 && part == parts - 1 && !c.validity && direct_out;
+      if ((rc = radix_passes(sort_key_bytes(c.type), v_or ^ v_and, narrow, last_call ? out_perm : nullptr))) return rc;
     }
     if (c.validity) {
       int32_t rc = encode(c, m, 2, true, &v_or, &v_and);
       if (rc) return rc;
-      if ((rc = radix_passes(1, v_or ^ v_and, true))) return rc;
+      if ((rc = radix_passes(1, v_or ^ v_and, true, (k == 0 && direct_out) ? out_perm : nullptr))) return rc;
     }
   }
-  int64_t mout = (limit > 0 && limit < m) ? limit : m;
-  DBHIP_CHECK(hipMemcpyAsync(out_perm, pb[cur], (size_t)mout * 4, hipMemcpyDeviceToDevice, s));
+  if (!wrote_final) DBHIP_CHECK(hipMemcpyAsync(out_perm, pb[cur], (size_t)mout * 4, hipMemcpyDeviceToDevice, s));
   DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
   return DBHIP_OK;
 }
