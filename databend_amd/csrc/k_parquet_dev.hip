@@ -856,20 +856,21 @@ int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev
   const uint32_t nd = (uint32_t)c->data_pages.size();
   const bool spread = c->max_def == 1 && !c->known_no_nulls;
   if (!c->uploaded) {
-    DBHIP_TRY(dbhip_alloc(c->pages.size() * sizeof(DvPage), (void**)&c->dv_pages));
+    // (every buffer is taken once: a call that failed half-way is repeated without leaking what it had got)
+    if (!c->dv_pages) DBHIP_TRY(dbhip_alloc(c->pages.size() * sizeof(DvPage), (void**)&c->dv_pages));
     DBHIP_CHECK(hipMemcpyAsync(c->dv_pages, c->pages.data(), c->pages.size() * sizeof(DvPage), hipMemcpyHostToDevice, s));
-    DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_dp));
+    if (!c->dv_dp) DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_dp));
     DBHIP_CHECK(hipMemcpyAsync(c->dv_dp, c->data_pages.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
-    DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_nn));
-    DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_voff));
-    DBHIP_TRY(dbhip_alloc((size_t)(nd + 1) * 8, (void**)&c->dv_vbase));
-    DBHIP_TRY(dbhip_alloc(16, (void**)&c->dv_ctl));
-    if (c->dict_n > 0) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
+    if (!c->dv_nn) DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_nn));
+    if (!c->dv_voff) DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_voff));
+    if (!c->dv_vbase) DBHIP_TRY(dbhip_alloc((size_t)(nd + 1) * 8, (void**)&c->dv_vbase));
+    if (!c->dv_ctl) DBHIP_TRY(dbhip_alloc(16, (void**)&c->dv_ctl));
+    if (c->dict_n > 0 && !c->d_dict) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
     if (spread) {
-      DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->rows + 1, 64) * 8 : (size_t)(c->rows + 1) * (size_t)esize, &c->d_dense));
-      DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_wcnt));
-      DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
-      DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
+      if (!c->d_dense) DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->rows + 1, 64) * 8 : (size_t)(c->rows + 1) * (size_t)esize, &c->d_dense));
+      if (!c->d_wcnt) DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_wcnt));
+      if (!c->d_woff) DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
+      if (!c->d_blk) DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
     }
     static const bool lds_ok = [] {
       return hipFuncSetAttribute((const void*)dv_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DW + DI)) == hipSuccess;
