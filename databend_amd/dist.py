@@ -265,12 +265,13 @@ def merge_shard_topk_device(idx_t, dst_t, row_offset, k, dist, torch, lib_sync, 
 # block; the planner picks it in hash_join.rs/`broadcast` exchanges) so that the probe side never moves. Q3's build
 # sides — customers of one market segment, then the orders that joined them — are 50x / 40x smaller than the probe sides
 # (orders, lineitem), which is the broadcast case: every rank filters its shard of the build side, the survivors are
-# all-gathered (one variable-length all-gather per column over RCCL / xGMI), every rank builds the SAME table and probes
+# all-gathered (ONE variable-length all-gather of a packed image over RCCL / xGMI), every rank builds the SAME table and probes
 # its own rows. Only the final aggregation exchanges states (route by hash % world, like configs[3]).
 # ---------------------------------------------------------------------------------------------------------------------
 def allgather_columns(cols, dist, torch):
     """Variable-length all-gather of equally long 1-D tensors (one build-side block per rank): returns the rank-major
-    concatenation of every column. One small collective for the lengths, one padded all_gather_into_tensor per column."""
+    concatenation of every column. One small collective for the lengths, then ONE padded all_gather_into_tensor of a packed image
+    (every column padded to the longest rank's rows and to 8 bytes, back to back) whatever the number of columns."""
     world = dist.get_world_size()
     n = int(cols[0].shape[0])
     dev = cols[0].device
@@ -279,14 +280,24 @@ def allgather_columns(cols, dist, torch):
     dist.all_gather_into_tensor(cnts, cnt)
     counts = [int(x) for x in cnts.tolist()]
     mx = max(max(counts), 1)
-    out = []
-    for c in cols:
+    isz = [c.element_size() for c in cols]
+    col_bytes = [(mx * z + 7) & ~7 for z in isz]
+    img = sum(col_bytes)
+    send = torch.zeros(img, dtype=torch.uint8, device=dev)
+    off = 0
+    for c, z, cb in zip(cols, isz, col_bytes):
         assert int(c.shape[0]) == n and c.dim() == 1
-        send = torch.zeros(mx, dtype=c.dtype, device=dev)
-        send[:n] = c
-        recv = torch.empty(world * mx, dtype=c.dtype, device=dev)
-        dist.all_gather_into_tensor(recv, send)
-        out.append(torch.cat([recv[r * mx: r * mx + counts[r]] for r in range(world)]) if world > 1 else recv[:n])
+        if n:
+            send[off:off + n * z] = c.contiguous().view(torch.uint8)
+        off += cb
+    recv = torch.empty(world * img, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    out = []
+    off = 0
+    for c, z, cb in zip(cols, isz, col_bytes):
+        parts = [recv[r * img + off: r * img + off + counts[r] * z].view(c.dtype) for r in range(world)]
+        out.append(torch.cat(parts) if world > 1 else parts[0].clone())
+        off += cb
     return out
 
 
@@ -323,23 +334,44 @@ def q3_broadcast_join(shard, ops, dist, torch, device, limit=10):
 # deduplicated into world - 1 bounds (sort_bounds.balanced_cuts: equal shares of the samples, so rank r receives exactly range
 # r — the fewest, largest messages on xGMI; the reference keeps every distinct sample as a bound and deals the ranges round
 # robin), one kernel gives every row its range (dbhip_sort_bound_partition), the columns are grouped by range and
-# exchanged with one all_to_all_single per column, and each rank sorts what it received. The concatenation of the ranks'
+# exchanged with ONE all_to_all_single of a packed row image (alltoall_columns), and each rank sorts what it received. The concatenation of the ranks'
 # outputs in rank order is the sorted table.
 # ---------------------------------------------------------------------------------------------------------------------
 def alltoall_columns(cols, send_counts, dist, torch):
-    """cols = equally long 1-D tensors whose rows are grouped by destination rank (send_counts[r] rows for rank r)."""
+    """cols = equally long 1-D tensors whose rows are grouped by destination rank (send_counts[r] rows for rank r).
+    ONE collective for the counts and ONE for the data of all columns: what goes to rank r is packed as a row image (every column's
+    slice for r, each padded to 8 bytes, back to back), so the width of the block does not multiply the number of RCCL launches."""
     world = dist.get_world_size()
     dev = cols[0].device
-    send_cnt = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=dev)
+    sc = [int(c) for c in send_counts]
+    send_cnt = torch.tensor(sc, dtype=torch.int64, device=dev)
     recv_cnt = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv_cnt, send_cnt)
     rc = [int(x) for x in recv_cnt.tolist()]
-    out = []
-    for c in cols:
-        recv = torch.empty(sum(rc), dtype=c.dtype, device=dev)
-        dist.all_to_all_single(recv, c.contiguous(), output_split_sizes=rc, input_split_sizes=[int(x) for x in send_counts])
-        out.append(recv)
-    return out, rc
+    isz = [c.element_size() for c in cols]
+    pad8 = lambda nb: (nb + 7) & ~7
+    seg_bytes = lambda rows: sum(pad8(rows * z) for z in isz)
+    send = torch.zeros(max(sum(seg_bytes(r) for r in sc), 8), dtype=torch.uint8, device=dev)
+    off, start = 0, 0
+    for r in range(world):
+        for c, z in zip(cols, isz):
+            nb = sc[r] * z
+            if nb:
+                send[off:off + nb] = c[start:start + sc[r]].contiguous().view(torch.uint8)
+            off += pad8(nb)
+        start += sc[r]
+    in_split = [seg_bytes(r) for r in sc]
+    out_split = [seg_bytes(r) for r in rc]
+    recv = torch.empty(max(sum(out_split), 8), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv[:sum(out_split)], send[:sum(in_split)], output_split_sizes=out_split, input_split_sizes=in_split)
+    pieces = [[] for _ in cols]
+    off = 0
+    for r in range(world):
+        for k, (c, z) in enumerate(zip(cols, isz)):
+            nb = rc[r] * z
+            pieces[k].append(recv[off:off + nb].view(c.dtype) if nb else torch.empty(0, dtype=c.dtype, device=dev))
+            off += pad8(nb)
+    return [torch.cat(p) if len(p) > 1 else p[0].clone() for p in pieces], rc
 
 
 def range_partitioned_sort(cols, keys, ops, dist, torch, desc=None, nulls_first=None, valids=None, samples_per_rank=1024):
@@ -395,7 +427,7 @@ def range_partitioned_sort(cols, keys, ops, dist, torch, desc=None, nulls_first=
 # servers/flight/v1/scatter/flight_scatter_hash.rs:57-330) so that equal keys meet on one node, and joins locally. Device plan:
 # dbhip_scatter_indices gives every row its destination with the reference's own hash (bit-identical: a GPU rank routes rows
 # exactly like a CPU node would), one radix pass + dbhip_take_block groups the columns by destination (DataBlock::scatter), one
-# all_to_all_single per column moves them, and each rank joins what it received. Used when the build side is too large to
+# all_to_all_single of a packed row image (alltoall_columns) moves them, and each rank joins what it received. Used when the build side is too large to
 # broadcast (dist.q3_broadcast_join is the other plan).
 # ---------------------------------------------------------------------------------------------------------------------
 def shuffle_hash_join(build_cols, build_key, probe_cols, probe_key, ops, dist, torch, build_valids=None, probe_valids=None):
