@@ -73,6 +73,7 @@ struct DvInflate {
     need(192);
     laq = q;
     la = (uint32_t)inb[(q + lane) & DIM];
+    limits();
   }
   __device__ __forceinline__ uint32_t in(uint32_t k) {
     if (q + k - laq >= 64) look();
@@ -102,6 +103,38 @@ struct DvInflate {
     if (lane < len) win[(op + sh + lane) & DWM] = inb[(q + skip + lane) & DIM];
     __builtin_amdgcn_wave_barrier();
     op += len;
+  }
+
+  // Folded bounds of the fast paths, recomputed only when the staging moves (look()): a sequence may take the fast path while
+  // q <= qlim (>= 96 input bytes left and > 64 of them staged) and op <= oplim (>= 96 output bytes of room: a fast sequence writes
+  // at most 60 + 64 of them, checked where it matters)
+  int32_t qlim, oplim;
+  __device__ __forceinline__ void limits() {
+    const int32_t a = (int32_t)qend - 96, b = (int32_t)qload - 65;
+    qlim = a < b ? a : b;
+    oplim = (int32_t)cap - 128;
+  }
+  // literal of `lit` bytes (input position q + skip) followed by a match of `mlen` (both <= 64, the output room checked by the caller;
+  // 1 <= off <= op + lit checked by the caller). When the match cannot see the literal's bytes (its source ends at or before op) both
+  // LDS reads are issued before either write: one LDS round trip for the pair instead of two.
+  __device__ __forceinline__ void pair64(uint32_t lit, uint32_t skip, uint32_t mlen, uint32_t off) {
+    const uint32_t span = mlen < off ? mlen : off;   // distinct source bytes of the match
+    if (off >= lit + span) {
+      uint32_t j = lane;
+      if (off < 64) {
+        const float r = __builtin_amdgcn_rcpf((float)off);
+        j = lane - off * (uint32_t)(((float)lane + 0.5f) * r);
+      }
+      const uint8_t vl = inb[(q + skip + lane) & DIM];
+      const uint8_t vm = win[(op + lit - off + j + sh) & DWM];
+      if (lane < lit) win[(op + sh + lane) & DWM] = vl;
+      if (lane < mlen) win[(op + lit + lane + sh) & DWM] = vm;
+      __builtin_amdgcn_wave_barrier();
+      op += lit + mlen;
+    } else {
+      if (lit) literal64(lit, skip);
+      match64(mlen, off);
+    }
   }
 
   __device__ __forceinline__ void flush(bool force) {
@@ -202,11 +235,26 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
       const uint32_t w = z.q - z.laq;
       const uint32_t tag = z.peek(w);
       const uint32_t kind = tag & 3u;
-      // fast path: a short element that lies whole in the look-ahead register and the staged input, away from the end
-      if (left >= 70 && z.qload - z.q > 64) {
+      // fast path: a short element that lies whole in the look-ahead register and the staged input, away from both ends (folded
+      // bounds: limits()); a short literal and the copy behind it go as a pair (one LDS round trip)
+      if ((int32_t)z.q <= z.qlim && (int32_t)z.op <= z.oplim) {
         if (kind == 0) {
           const uint32_t len = (tag >> 2) + 1;
-          if (len <= 60 && len <= z.cap - z.op) {
+          if (w + len + 3 < 64) {                                     // the header behind the literal still lies in the look-ahead register
+            const uint32_t t2 = z.peek(w + 1 + len), k2 = t2 & 3u;
+            if (k2 == 1 || k2 == 2) {
+              uint32_t mlen, off, hdr;
+              if (k2 == 1) { mlen = ((t2 >> 2) & 7u) + 4; off = ((t2 >> 5) << 8) | z.peek(w + 2 + len); hdr = 2; }
+              else { mlen = (t2 >> 2) + 1; off = z.peek(w + 2 + len) | (z.peek(w + 3 + len) << 8); hdr = 3; }
+              if (off != 0 && off <= z.op + len) {
+                z.pair64(len, 1, mlen, off);
+                z.q += 1 + len + hdr;
+                if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
+                continue;
+              }
+            }
+          }
+          if (len <= 60) {
             z.literal64(len, 1);
             z.q += 1 + len;
             if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
@@ -216,7 +264,7 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
           uint32_t len, off, hdr;
           if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | z.peek(w + 1); hdr = 2; }
           else { len = (tag >> 2) + 1; off = z.peek(w + 1) | (z.peek(w + 2) << 8); hdr = 3; }
-          if (off != 0 && off <= z.op && len <= z.cap - z.op) {
+          if (off != 0 && off <= z.op) {
             z.q += hdr;
             z.match64(len, off);
             if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
@@ -264,12 +312,12 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
         const uint32_t w = z.q - z.laq;
         const uint32_t t = z.peek(w);
         const uint32_t lit = t >> 4, ml = t & 15u;
-        if (lit < 15 && ml < 15 && z.qend - z.q >= 96 && z.qload - z.q > 64 && lit <= z.cap - z.op) {
-          if (lit) z.literal64(lit, 1);
+        const uint32_t ext = (((t & 15u) + 1) | ((t >> 4) + 1)) & 16u;    // either length nibble is 15
+        if (ext == 0 && (int32_t)z.q <= z.qlim && (int32_t)z.op <= z.oplim) {
           const uint32_t off = z.peek(w + 1 + lit) | (z.peek(w + 2 + lit) << 8);
+          if (off == 0 || off > z.op + lit) { z.bad = true; break; }
+          z.pair64(lit, 1, ml + 4, off);
           z.q += 3 + lit;
-          if (off == 0 || off > z.op || ml + 4 > z.cap - z.op) { z.bad = true; break; }
-          z.match64(ml + 4, off);
           if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
           continue;
         }
