@@ -71,7 +71,7 @@ pub const DBHIP_VEC_L2: i32 = 1;   // dbhip_vec_metric
 pub const DBHIP_VEC_DOT: i32 = 2;   // dbhip_vec_metric
 pub const DBHIP_VEC_L1: i32 = 3;   // dbhip_vec_metric
 pub const DBHIP_VEC_NORM: i32 = 4;   // dbhip_vec_metric
-pub const DBHIP_ABI_VERSION: i32 = 3;
+pub const DBHIP_ABI_VERSION: i32 = 4;
 
 #[repr(C)]
 pub struct dbhip_groupby { _private: [u8; 0] }

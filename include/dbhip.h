@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DBHIP_ABI_VERSION 3
+#define DBHIP_ABI_VERSION 4   /* 4 (round 4): block scatter / concat, exchange and plan calls, device-mode scan, cancellation, row-wise vector distance */
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
