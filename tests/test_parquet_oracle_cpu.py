@@ -382,3 +382,44 @@ def test_device_mode_open_reads_only_the_page_headers():
     cut = dict(chunks[0])
     cut["chunk"] = cut["chunk"][: len(cut["chunk"]) // 2]
     assert open_dev(cut)[0] == T.ERR_INVALID
+
+
+def test_device_mode_open_survives_mutated_chunks():
+    """bit flips / truncation / overwritten bytes through dbhip_pq_chunk_open_device (the thrift header walk is all it does): OK, INVALID or
+    UNSUPPORTED — it never reads outside the chunk and never sizes an image out of proportion to it (a crash or a hang of this process is
+    what is being guarded)"""
+    import ctypes as C
+    import pyarrow as pa
+    rng = np.random.default_rng(6)
+    seeds = []
+    for vi, cname in ((0, "none"), (1, "snappy"), (4, "lz4"), (6, "none")):
+        for name, arr, ot, wkw in PC.make_cases(seed=vi):
+            kw = dict(PC.VARIANTS[vi])
+            kw.update(wkw)
+            chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr.slice(0, 1500)}), compression=cname, **kw))
+            if len(chunks[0]["chunk"]):
+                seeds.append((chunks[0], ot))
+    seen = set()
+    for it in range(4000):
+        ch, ot = seeds[it % len(seeds)]
+        b = bytearray(ch["chunk"])
+        k = it % 3
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b = b[: int(rng.integers(0, len(b)))]
+        else:
+            i = int(rng.integers(0, len(b)))
+            b[i:i + 6] = bytes(rng.integers(0, 256, 6).astype(np.uint8))
+        data = bytes(b)
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+        h, info = C.c_void_p(), T.PqInfo()
+        rc = T.lib().dbhip_pq_chunk_open_device(buf, C.c_int64(len(data)), ch["codec"], ch["physical"], ch["type_length"], ch["max_def"], 0, ot,
+                                                C.byref(h), C.byref(info))
+        assert rc in (T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED), rc
+        if rc == T.OK:
+            assert 0 <= info.image_bytes <= max(1 << 30, 1024 * len(data)) + 16 and info.num_values >= 0
+            T.lib().dbhip_pq_chunk_close(h)
+        seen.add(rc)
+    assert T.OK in seen and T.ERR_INVALID in seen
