@@ -728,3 +728,59 @@ def test_single_state_aggregates_merge_in_rank_order(world):
            (min(mins), True), (max(maxs), True), (0, False)]
     for r in range(world):
         assert got[r] == exp, r
+
+
+# ---- the packed collectives of the plans (round 4): ONE collective whatever the width of the block ---------------------------------
+def packed_inputs(rank, world):
+    rng = np.random.default_rng(900 + rank)
+    counts = [int(x) for x in rng.integers(0, 700, world)]
+    if rank == 1:
+        counts[0] = 0                                            # nothing for rank 0 from rank 1
+    n = sum(counts)
+    cols = [rng.integers(0, 256, n).astype(np.uint8), rng.integers(-2**15, 2**15, n).astype(np.int16), rng.integers(-2**31, 2**31, n).astype(np.int32),
+            rng.integers(-2**62, 2**62, n).astype(np.int64), rng.standard_normal(n)]
+    return counts, cols
+
+
+def packed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts, cols = packed_inputs(rank, world)
+        tcols = [torch.from_numpy(c) for c in cols]
+        recv, rc = DX.alltoall_columns(tcols, counts, dist, torch)
+        gathered = DX.allgather_columns(tcols, dist, torch)
+        q.put((rank, ([r.numpy().copy() for r in recv], rc, [g.numpy().copy() for g in gathered])))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_packed_collectives_move_every_column_of_a_block_at_once(world):
+    """dist.alltoall_columns / allgather_columns: columns of 1 / 2 / 4 / 8-byte elements (odd row counts, an empty slice) packed into ONE
+    all_to_all_single / all_gather_into_tensor each: every rank receives, per column, the slices the others addressed to it, by source
+    rank; the all-gather gives every rank the rank-major concatenation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=packed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    inputs = [packed_inputs(r, world) for r in range(world)]
+    for r in range(world):
+        recv, rc, gathered = got[r]
+        assert rc == [inputs[s][0][r] for s in range(world)]
+        for k in range(5):
+            exp = []
+            for s in range(world):
+                counts, cols = inputs[s]
+                start = sum(counts[:r])
+                exp.append(cols[k][start:start + counts[r]])
+            assert np.array_equal(recv[k], np.concatenate(exp)) and recv[k].dtype == inputs[0][1][k].dtype
+            assert np.array_equal(gathered[k], np.concatenate([inputs[s][1][k] for s in range(world)]))
