@@ -33,6 +33,37 @@ BYTES_PER_ROW = 68  # 4 x Decimal64 + 2 x 16-B view + Date32
 HBM_PEAK_GBS = 8000.0
 
 
+def launcher_command(n_gpus, argv, port=None, python=None):
+    """The command line `python bench.py --gpus N` re-executes itself under when N > 1 and no launcher set WORLD_SIZE: one rank
+    per GPU on THIS node through torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve).
+    `argv` = this process's own arguments (sys.argv[1:]), passed through unchanged."""
+    if port is None:
+        import socket
+        with socket.socket() as s:          # a free port of the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args, argv):
+    """`--gpus N` with N > 1 outside a launcher: start the N ranks ourselves and hand their exit code back. Never falls through
+    to a one-rank run (a line with n_gpus = 1 for an N > 1 request would void the scaling measurement)."""
+    import subprocess
+    if not args.share_gpu:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to run fewer ranks than asked "
+                             f"(--share-gpu --backend gloo runs a FUNCTIONAL check of the N-rank path on one GPU)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launcher_command(args.gpus, argv)
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,11 +99,13 @@ def main():
                          "own RCCL communicator (dbhip_comm_*, dbhip_groupby_exchange_*: what a Rust host would call)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])       # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
 
     import numpy as np
     import torch
@@ -88,6 +121,18 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    # who really takes part: one all-reduce of ones over the process group's own backend (nccl = RCCL), and the distinct
+    # (PCI bus id) devices behind the ranks — a line from ranks that share a GPU says so
+    ranks_seen, devices_seen = 1, 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
+        ids = [None] * world
+        dist.all_gather_object(ids, str(getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", local_rank))
+                               + ":" + str(getattr(torch.cuda.get_device_properties(local_rank), "uuid", "")))
+        devices_seen = len(set(ids))
 
     from databend_amd import device as D, tpch
     from databend_amd import dist as DX
@@ -307,6 +352,8 @@ def main():
         sf_txt = f"SF{args.sf:g}" if not args.rows else f"{n_total} rows"
         out = {
             "metric": "rows/s TPC-H Q1 hash-agg", "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "rccl_ranks_seen": ranks_seen if args.backend == "nccl" else 0, "ranks_seen": ranks_seen, "distinct_devices_seen": devices_seen,
+            "backend": args.backend if world > 1 else None,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong",   # one SF100 table whatever N: the rows per GPU shrink as N grows
             "vs_baseline": None, "dtype": "i64/i128 decimal", "data": "synthetic" + (" (FUNCTIONAL CHECK: ranks share one GPU, not a measurement)" if args.share_gpu else ""),
