@@ -23,8 +23,13 @@
 //   pq_popc / scan / pq_spread (pq_common.h)   nullable columns: dense values -> rows.
 // Nothing is validated on the host beyond the page table, so every device access is checked against the page payload, the
 // dictionary and the output size; the first violation is recorded in a device word and decode returns DBHIP_ERR_INVALID.
-// ZSTD pages (FSE / Huffman entropy stages) stay with dbhip_pq_chunk_open (host libzstd): DBHIP_ERR_UNSUPPORTED here.
+//   dv_inflate_zstd_kernel   ZSTD (the reference's DEFAULT codec, table_compression.rs:27-28): one wave per page walks the frame with
+//                       zstd_core.h (Huffman literals by up to four lanes, FSE sequences from a look-ahead window in registers, an 8 KiB
+//                       LDS ring + far references from the image: dv_wave.h).
+// dbhip_pq_chunks_decode_device decodes MANY chunks with one launch set (one inflate launch per codec family over all their pages, one
+// levels / scan / dictionary / values launch over all their data pages, one read-back): a scan keeps dozens of column chunks in flight.
 #include "pq_common.h"
+#include "dv_wave.h"
 
 namespace {
 
@@ -197,13 +202,14 @@ struct DvInflate {
   }
 };
 
-__global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict__ pages, const uint8_t* __restrict__ chunk,
-                                                        uint8_t* __restrict__ image, int codec, uint32_t* __restrict__ ctl) {
+__global__ __launch_bounds__(64) void dv_inflate_kernel(const DvJob* __restrict__ jobs) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
-  const DvPage P = pages[blockIdx.x];
+  const DvJob P = jobs[blockIdx.x];
   const uint32_t lane = threadIdx.x;
-  const uint8_t* src = chunk + P.src_off;
-  uint8_t* dst = image + P.img_off;
+  const uint8_t* src = P.src;
+  uint8_t* dst = P.dst;
+  uint32_t* ctl = P.ctl;
+  const int codec = (int)P.codec;
   const uint32_t lev = P.lev_len;
   // levels of a v2 page / a payload stored uncompressed: copied as they are
   const uint32_t raw = P.compressed ? lev : P.uncomp_len;
@@ -361,6 +367,35 @@ __global__ __launch_bounds__(64) void dv_inflate_kernel(const DvPage* __restrict
   if (z.bad) dv_fail(ctl, DV_CORRUPT);
 }
 
+// ZSTD: one wave per page (dv_wave.h, zstd_core.h)
+__global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __restrict__ jobs) {
+  extern __shared__ __align__(16) uint8_t dv_lds[];
+  const DvJob P = jobs[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lev = P.lev_len;
+  const uint32_t raw = P.compressed ? lev : P.uncomp_len;
+  for (uint32_t i = lane; i < raw; i += 64) P.dst[i] = P.src[i];
+  if (!P.compressed || P.uncomp_len == lev) return;
+  ZWave w;
+  const uint8_t* s0 = P.src + lev;
+  w.a0 = (uint32_t)((uintptr_t)s0 & 3u);
+  w.srcA = s0 - w.a0;
+  w.in_len = P.comp_len - lev;
+  w.safeA = (P.src_safe - lev + w.a0) & ~3u;
+  w.lane = lane;
+  w.slide(0);
+  w.dst = P.dst + lev;
+  w.cap_ = P.uncomp_len - lev; w.op_ = 0; w.flushed = 0; w.frame0 = 0;
+  w.sh = (uint32_t)((uintptr_t)w.dst & 15u);
+  w.win = dv_lds; w.WM = ZW_RING - 1; w.WF = ZW_RING / 2;
+  w.tab = dv_lds + ZW_RING;
+  w.stores_pending = false;
+  int rc = zc::decode_frames(w, w.in_len);
+  if (rc == zc::OK && w.op_ != w.cap_) rc = zc::CORRUPT_;
+  w.flush(true);
+  if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
+}
+
 // ---------------------------------------------------------------------------------------------
 // RLE / bit-packed hybrid streams, walked by a whole workgroup (every thread follows the same headers)
 // ---------------------------------------------------------------------------------------------
@@ -465,14 +500,37 @@ __device__ __forceinline__ uint32_t dv_block_sum(uint32_t v, uint32_t* sh4) {
   return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
+// one chunk of a batch as the decode kernels see it (device copy; the arrays sit in the batch's blob)
+struct DvChunkD {
+  const DvPage* pages;
+  const uint32_t* dp;      // index into `pages` of every data page
+  uint32_t* nn;            // per data page: non-null values
+  uint32_t* voff;          // per data page: where the values start in the page
+  uint64_t* vbase;         // per data page: values before it (+ the total)
+  const uint8_t* img;      // what is decoded: the decompressed image, or the chunk itself (UNCOMPRESSED)
+  const void* dict;
+  void* dict_out;
+  void* target;            // values: the output, or the dense buffer of a column with NULLs
+  uint32_t* bitmap;        // validity (nullable columns)
+  uint32_t* hdr;           // [0] first failure (DV_*), [2..3] non-null values of the chunk (u64)
+  PqConv cv;
+  uint32_t dict_n, dict_page, nd, slices;
+  uint64_t rows;
+};
+
 // definition levels of one data page -> validity bits + the page's non-null count and the offset of its values
-__global__ __launch_bounds__(256) void dv_levels_kernel(const DvPage* __restrict__ pages, const uint32_t* __restrict__ dp,
-                                                        const uint8_t* __restrict__ img, uint32_t* __restrict__ nn,
-                                                        uint32_t* __restrict__ voff, uint32_t* __restrict__ bitmap,
-                                                        uint32_t* __restrict__ ctl) {
+__global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restrict__ cds, const uint2* __restrict__ map) {
   __shared__ uint32_t sh4[4];
-  const uint32_t d = blockIdx.x;
-  const DvPage P = pages[dp[d]];
+  const uint2 m = map[blockIdx.x];
+  const DvChunkD& C = cds[m.x];
+  const uint32_t d = m.y;
+  const DvPage* __restrict__ pages = C.pages;
+  const uint8_t* __restrict__ img = C.img;
+  uint32_t* __restrict__ nn = C.nn;
+  uint32_t* __restrict__ voff = C.voff;
+  uint32_t* __restrict__ bitmap = C.bitmap;
+  uint32_t* __restrict__ ctl = C.hdr;
+  const DvPage P = pages[C.dp[d]];
   const uint8_t* s = img + P.img_off;
   uint32_t len, vo;
   const uint8_t* stream;
@@ -501,8 +559,12 @@ __global__ __launch_bounds__(256) void dv_levels_kernel(const DvPage* __restrict
   if (tid == 0) { nn[d] = ok ? total : 0; voff[d] = ok ? vo : P.uncomp_len; }
 }
 
-// vbase[d] = number of non-null values in the data pages before d; vbase[n] = all of them
-__global__ __launch_bounds__(256) void dv_scan_kernel(const uint32_t* __restrict__ nn, uint32_t n, uint64_t* __restrict__ vbase) {
+// vbase[d] = number of non-null values in the data pages before d; vbase[n] = all of them (also into the chunk's header). One workgroup per chunk.
+__global__ __launch_bounds__(256) void dv_scan_kernel(const DvChunkD* __restrict__ cds) {
+  const DvChunkD& C = cds[blockIdx.x];
+  const uint32_t* __restrict__ nn = C.nn;
+  const uint32_t n = C.nd;
+  uint64_t* __restrict__ vbase = C.vbase;
   __shared__ uint64_t wt[4];
   __shared__ uint64_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -523,7 +585,7 @@ __global__ __launch_bounds__(256) void dv_scan_kernel(const uint32_t* __restrict
     if (threadIdx.x == 255) carry = wb + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) vbase[n] = carry;
+  if (threadIdx.x == 0) { vbase[n] = carry; *(uint64_t*)(C.hdr + 2) = carry; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,11 +746,15 @@ union DvValShared {
   DvDeltaShared delta;
 };
 
-// the dictionary page (PLAIN) -> dictionary in the output type
-__global__ __launch_bounds__(256) void dv_dict_kernel(const DvPage* __restrict__ pages, uint32_t page, const uint8_t* __restrict__ img, PqConv cv,
-                                                      void* __restrict__ dict, uint32_t* __restrict__ ctl) {
+// the dictionary page (PLAIN) -> dictionary in the output type. One workgroup per chunk that has one.
+__global__ __launch_bounds__(256) void dv_dict_kernel(const DvChunkD* __restrict__ cds, const uint32_t* __restrict__ list) {
   __shared__ DvStrShared S;
-  const DvPage P = pages[page];
+  const DvChunkD& C = cds[list[blockIdx.x]];
+  const uint8_t* __restrict__ img = C.img;
+  const PqConv cv = C.cv;
+  void* __restrict__ dict = C.dict_out;
+  uint32_t* __restrict__ ctl = C.hdr;
+  const DvPage P = C.pages[C.dict_page];
   if (P.num_values == 0) return;
   if (cv.physical == PT_BYTE_ARRAY) {
     if (!dv_walk_strings(img, P.img_off, P.uncomp_len, P.num_values, dict, 0, &S)) dv_fail(ctl, DV_CORRUPT);
@@ -700,16 +766,22 @@ __global__ __launch_bounds__(256) void dv_dict_kernel(const DvPage* __restrict__
 }
 
 // one workgroup per (data page, slice): blockIdx.y splits PLAIN fixed-width pages; the serial encodings run in slice 0
-__global__ __launch_bounds__(256) void dv_values_kernel(const DvPage* __restrict__ pages, const uint32_t* __restrict__ dp,
-                                                        const uint8_t* __restrict__ img, const uint32_t* __restrict__ nn,
-                                                        const uint32_t* __restrict__ voff, const uint64_t* __restrict__ vbase, PqConv cv,
-                                                        const void* __restrict__ dict, uint32_t dict_n, void* __restrict__ out,
-                                                        uint64_t out_cap, uint32_t* __restrict__ ctl) {
+__global__ __launch_bounds__(256) void dv_values_kernel(const DvChunkD* __restrict__ cds, const uint2* __restrict__ map) {
   __shared__ DvValShared S;
-  const uint32_t d = blockIdx.x, tid = threadIdx.x;
-  const DvPage P = pages[dp[d]];
-  const uint32_t n = nn[d], vo = voff[d];
-  const uint64_t o0 = vbase[d];
+  const uint2 m = map[blockIdx.x];
+  const DvChunkD& C = cds[m.x];
+  if (blockIdx.y >= C.slices) return;
+  const uint32_t d = m.y, tid = threadIdx.x;
+  const uint8_t* __restrict__ img = C.img;
+  const PqConv cv = C.cv;
+  const void* __restrict__ dict = C.dict;
+  const uint32_t dict_n = C.dict_n;
+  void* __restrict__ out = C.target;
+  const uint64_t out_cap = C.rows;
+  uint32_t* __restrict__ ctl = C.hdr;
+  const DvPage P = C.pages[C.dp[d]];
+  const uint32_t n = C.nn[d], vo = C.voff[d];
+  const uint64_t o0 = C.vbase[d];
   if (n == 0) return;
   if (vo > P.uncomp_len || n > P.num_values || o0 + n > out_cap) { dv_fail(ctl, DV_CORRUPT); return; }
   const uint8_t* s = img + P.img_off + vo;
@@ -718,7 +790,7 @@ __global__ __launch_bounds__(256) void dv_values_kernel(const DvPage* __restrict
   if (enc == ENC_PLAIN && cv.physical != PT_BOOLEAN && cv.physical != PT_BYTE_ARRAY) {
     const uint32_t w = (uint32_t)plain_width(cv.physical, cv.type_length);
     if (w == 0 || rlen / w < n) { dv_fail(ctl, DV_CORRUPT); return; }
-    const uint32_t lo = (uint32_t)((uint64_t)n * blockIdx.y / gridDim.y), hi = (uint32_t)((uint64_t)n * (blockIdx.y + 1) / gridDim.y);
+    const uint32_t lo = (uint32_t)((uint64_t)n * blockIdx.y / C.slices), hi = (uint32_t)((uint64_t)n * (blockIdx.y + 1) / C.slices);
     for (uint32_t i = lo + tid; i < hi; i += 256) store_plain(cv, s + (uint64_t)i * w, out, o0 + i);
     return;
   }
@@ -736,13 +808,14 @@ __global__ __launch_bounds__(256) void dv_values_kernel(const DvPage* __restrict
     ok = dv_walk_hybrid(
         s + 1, rlen - 1, bitw, n,
         [&](uint32_t first, uint32_t cnt, uint32_t v) {
+          if (v >= dict_n) dv_fail(ctl, DV_CORRUPT);             // (parquet-rs raises; the index is clamped for memory safety only)
           const uint32_t idx = v < dict_n ? v : dict_n - 1;
           for (uint32_t i = tid; i < cnt; i += 256) dv_put_dict(cv, dict, idx, out, o0 + first + i);
         },
         [&](uint32_t first, uint32_t cnt, const uint8_t* src) {
           for (uint32_t i = tid; i < cnt; i += 256) {
             uint32_t idx = extract_bits(src, i, bitw);
-            if (idx >= dict_n) idx = dict_n - 1;
+            if (idx >= dict_n) { dv_fail(ctl, DV_CORRUPT); idx = dict_n - 1; }
             dv_put_dict(cv, dict, idx, out, o0 + first + i);
           }
         });
@@ -781,9 +854,8 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
                                    dbhip_pq_info* info_host) {
   DBHIP_REQUIRE(chunk_host && out_host && chunk_len >= 0, "dbhip_pq_chunk_open_device: NULL argument");
   *out_host = nullptr;
-  if (codec == CODEC_ZSTD) return dv_unsupported("ZSTD pages are decompressed on the host");
-  if (codec != CODEC_NONE && codec != CODEC_SNAPPY && codec != CODEC_LZ4_RAW)
-    return dv_unsupported("compression codec other than UNCOMPRESSED / SNAPPY / LZ4_RAW");
+  if (codec != CODEC_NONE && codec != CODEC_SNAPPY && codec != CODEC_LZ4_RAW && codec != CODEC_ZSTD)
+    return dv_unsupported("compression codec other than UNCOMPRESSED / SNAPPY / ZSTD / LZ4_RAW");
   if (max_rep_level != 0 || max_def_level < 0 || max_def_level > 1) return dv_unsupported("nested column (repetition / definition level > 1)");
   if (chunk_len >= (1LL << 32)) return dv_unsupported("column chunk of 4 GiB or more");
   if (!type_pair_ok(physical_type, type_length, out_type)) {
@@ -888,31 +960,45 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
   return DBHIP_OK;
 }
 
-int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, void* out_values_dev,
-                                     uint8_t* out_validity_dev, int64_t* out_nulls_host, void* stream) {
-  DBHIP_REQUIRE(c && c->device_mode, "dbhip_pq_chunk_decode_device: the handle was not opened by dbhip_pq_chunk_open_device");
-  if (out_nulls_host) *out_nulls_host = 0;
-  if (c->rows == 0) return DBHIP_OK;
-  DBHIP_REQUIRE(chunk_dev && out_values_dev, "dbhip_pq_chunk_decode_device: NULL buffer");
-  DBHIP_REQUIRE(c->codec == CODEC_NONE || image_dev, "dbhip_pq_chunk_decode_device: a compressed chunk needs an image buffer (info.image_bytes)");
-  DBHIP_REQUIRE(c->codec == CODEC_NONE || ((uintptr_t)image_dev & 15) == 0, "dbhip_pq_chunk_decode_device: the image buffer must be 16-byte aligned");
-  DBHIP_REQUIRE(c->max_def == 0 || out_validity_dev, "dbhip_pq_chunk_decode_device: a nullable column needs a validity buffer");
+}  // extern "C"
+
+// ---- the batch: one launch set for many chunks ------------------------------------------------------------------------------
+namespace {
+
+struct BlobLayout {
+  size_t hdr, cds, dict_list, lv_map, val_map, jobs, per_chunk, total;
+};
+inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* chunk_dev, uint8_t* const* image_dev, void* const* out_values_dev,
+                    uint8_t* const* out_validity_dev, int64_t* out_nulls_host, int32_t* out_status_host, void* stream) {
+  const char* who = "dbhip_pq_chunks_decode_device";
+  if (n <= 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
-  const int esize = out_elem_size(c->out_type);
-  const bool is_bool = c->out_type == DBHIP_T_BOOL;
-  const int64_t nwords = ceil_div(c->rows, 32);
-  const uint32_t nd = (uint32_t)c->data_pages.size();
-  const bool spread = c->max_def == 1 && !c->known_no_nulls;
-  if (!c->uploaded) {
-    // (every buffer is taken once: a call that failed half-way is repeated without leaking what it had got)
-    if (!c->dv_pages) DBHIP_TRY(dbhip_alloc(c->pages.size() * sizeof(DvPage), (void**)&c->dv_pages));
-    DBHIP_CHECK(hipMemcpyAsync(c->dv_pages, c->pages.data(), c->pages.size() * sizeof(DvPage), hipMemcpyHostToDevice, s));
-    if (!c->dv_dp) DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_dp));
-    DBHIP_CHECK(hipMemcpyAsync(c->dv_dp, c->data_pages.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
-    if (!c->dv_nn) DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_nn));
-    if (!c->dv_voff) DBHIP_TRY(dbhip_alloc((size_t)nd * 4, (void**)&c->dv_voff));
-    if (!c->dv_vbase) DBHIP_TRY(dbhip_alloc((size_t)(nd + 1) * 8, (void**)&c->dv_vbase));
-    if (!c->dv_ctl) DBHIP_TRY(dbhip_alloc(16, (void**)&c->dv_ctl));
+  // ---- checks + what has to be allocated once per chunk
+  size_t n_jobs = 0, n_lv = 0, n_dp = 0, per_chunk = 0;
+  std::vector<int> live;      // chunks with rows
+  for (int i = 0; i < n; ++i) {
+    dbhip_pq_chunk* c = cs[i];
+    if (out_nulls_host) out_nulls_host[i] = 0;
+    if (out_status_host) out_status_host[i] = DBHIP_OK;
+    DBHIP_REQUIRE(c && c->device_mode, "dbhip_pq_chunk_decode_device: the handle was not opened by dbhip_pq_chunk_open_device");
+    if (c->rows == 0) continue;
+    DBHIP_REQUIRE(chunk_dev[i] && out_values_dev[i], "dbhip_pq_chunk_decode_device: NULL buffer");
+    DBHIP_REQUIRE(((uintptr_t)chunk_dev[i] & 15) == 0, "dbhip_pq_chunk_decode_device: chunk_dev must be 16-byte aligned");
+    DBHIP_REQUIRE(c->codec == CODEC_NONE || image_dev[i], "dbhip_pq_chunk_decode_device: a compressed chunk needs an image buffer (info.image_bytes)");
+    DBHIP_REQUIRE(c->codec == CODEC_NONE || ((uintptr_t)image_dev[i] & 15) == 0, "dbhip_pq_chunk_decode_device: the image buffer must be 16-byte aligned");
+    DBHIP_REQUIRE(c->max_def == 0 || out_validity_dev[i], "dbhip_pq_chunk_decode_device: a nullable column needs a validity buffer");
+    live.push_back(i);
+    const size_t nd = c->data_pages.size();
+    if (c->codec != CODEC_NONE) n_jobs += c->pages.size();
+    if (c->max_def == 1) n_lv += nd;
+    n_dp += nd;
+    per_chunk += up16(c->pages.size() * sizeof(DvPage)) + 3 * up16(nd * 4) + up16((nd + 1) * 8);
+    const int esize = out_elem_size(c->out_type);
+    const bool is_bool = c->out_type == DBHIP_T_BOOL;
+    const bool spread = c->max_def == 1 && !c->known_no_nulls;
+    const int64_t nwords = ceil_div(c->rows, 32);
     if (c->dict_n > 0 && !c->d_dict) DBHIP_TRY(dbhip_alloc((size_t)c->dict_n * (size_t)esize, &c->d_dict));
     if (spread) {
       if (!c->d_dense) DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)ceil_div(c->rows + 1, 64) * 8 : (size_t)(c->rows + 1) * (size_t)esize, &c->d_dense));
@@ -920,88 +1006,190 @@ int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev
       if (!c->d_woff) DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_woff));
       if (!c->d_blk) DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_blk));
     }
-    static const bool lds_ok = [] {
-      return hipFuncSetAttribute((const void*)dv_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DW + DI)) == hipSuccess;
-    }();
-    if (!lds_ok) { set_error("dbhip_pq_chunk_decode_device: cannot reserve %u bytes of LDS", DW + DI); return DBHIP_ERR_HIP; }
-    c->uploaded = true;
   }
-  // (every call: the per-page counts are overwritten by the levels kernel of a nullable column)
-  DBHIP_CHECK(hipMemcpyAsync(c->dv_nn, c->nn_init.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
-  DBHIP_CHECK(hipMemcpyAsync(c->dv_voff, c->voff_init.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
-  DBHIP_CHECK(hipMemsetAsync(c->dv_ctl, 0, 16, s));
-  const PqConv cv{c->physical, c->type_length, c->out_type, esize};
-  const uint8_t* img = c->codec == CODEC_NONE ? chunk_dev : image_dev;
+  if (live.empty()) return DBHIP_OK;
+  static const bool lds_ok = [] {
+    return hipFuncSetAttribute((const void*)dv_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DW + DI)) == hipSuccess &&
+           hipFuncSetAttribute((const void*)dv_inflate_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW_LDS) == hipSuccess;
+  }();
+  if (!lds_ok) { set_error("%s: cannot reserve LDS for the decompression kernels", who); return DBHIP_ERR_HIP; }
+  // ---- the blob: everything the kernels read about the batch, one upload
+  const size_t nl = live.size();
+  BlobLayout L;
+  L.hdr = 0;
+  L.cds = up16(nl * 32);
+  L.dict_list = L.cds + up16(nl * sizeof(DvChunkD));
+  L.lv_map = L.dict_list + up16(nl * 4);
+  L.val_map = L.lv_map + up16(n_lv * 8);
+  L.jobs = L.val_map + up16(n_dp * 8);
+  L.per_chunk = L.jobs + up16(n_jobs * sizeof(DvJob));
+  L.total = L.per_chunk + per_chunk;
+  uint8_t* blob = (uint8_t*)scratch(L.total, 20, s);
+  if (!blob) { set_error("%s: out of device memory (%zu bytes of page tables)", who, L.total); return DBHIP_ERR_HIP; }
+  std::vector<uint8_t> H(L.total, 0);
+  DvChunkD* cds = (DvChunkD*)(H.data() + L.cds);
+  uint32_t* dict_list = (uint32_t*)(H.data() + L.dict_list);
+  uint2* lv_map = (uint2*)(H.data() + L.lv_map);
+  uint2* val_map = (uint2*)(H.data() + L.val_map);
+  DvJob* jobs = (DvJob*)(H.data() + L.jobs);
+  size_t at = L.per_chunk, n_dict = 0, k_lv = 0, k_dp = 0;
+  // jobs: ZSTD pages first (their own kernel), then Snappy / LZ4
+  size_t n_z = 0;
+  for (int i : live)
+    if (cs[i]->codec == CODEC_ZSTD) n_z += cs[i]->pages.size();
+  size_t jz = 0, jo = n_z;
+  unsigned max_slices = 1;
+  for (size_t k = 0; k < nl; ++k) {
+    const int i = live[k];
+    dbhip_pq_chunk* c = cs[i];
+    const uint32_t nd = (uint32_t)c->data_pages.size();
+    const int esize = out_elem_size(c->out_type);
+    const bool spread = c->max_def == 1 && !c->known_no_nulls;
+    DvChunkD& D = cds[k];
+    auto place = [&](const void* src, size_t bytes) {
+      const size_t o = at;
+      if (src && bytes) memcpy(H.data() + o, src, bytes);
+      at += up16(bytes);
+      return blob + o;
+    };
+    D.pages = (const DvPage*)place(c->pages.data(), c->pages.size() * sizeof(DvPage));
+    D.dp = (const uint32_t*)place(c->data_pages.data(), (size_t)nd * 4);
+    D.nn = (uint32_t*)place(c->nn_init.data(), (size_t)nd * 4);
+    D.voff = (uint32_t*)place(c->voff_init.data(), (size_t)nd * 4);
+    D.vbase = (uint64_t*)place(nullptr, (size_t)(nd + 1) * 8);
+    D.img = c->codec == CODEC_NONE ? chunk_dev[i] : image_dev[i];
+    D.dict = c->d_dict; D.dict_out = c->d_dict;
+    D.target = spread ? c->d_dense : out_values_dev[i];
+    D.bitmap = (uint32_t*)out_validity_dev[i];
+    D.hdr = (uint32_t*)(blob + L.hdr + k * 32);
+    D.cv = PqConv{c->physical, c->type_length, c->out_type, esize};
+    D.dict_n = (uint32_t)(c->dict_n > 0 ? c->dict_n : 0);
+    D.dict_page = (uint32_t)(c->dict_page >= 0 ? c->dict_page : 0);
+    D.nd = nd;
+    D.rows = (uint64_t)c->rows;
+    // slices of a PLAIN fixed-width page: enough workgroups to fill the chip even from a few large pages
+    unsigned slices = 1;
+    const bool fixed = c->physical != PT_BOOLEAN && c->physical != PT_BYTE_ARRAY;
+    if (fixed && nd > 0) {
+      const int64_t per_page = c->rows / (int64_t)nd;
+      while (slices < 64 && (int64_t)n_dp * slices < 2048 && per_page / (int64_t)slices > 4096) slices <<= 1;
+    }
+    D.slices = slices;
+    if (slices > max_slices) max_slices = slices;
+    if (c->dict_n > 0) dict_list[n_dict++] = (uint32_t)k;
+    for (uint32_t d = 0; d < nd; ++d) {
+      if (c->max_def == 1) lv_map[k_lv++] = make_uint2((unsigned)k, d);
+      val_map[k_dp++] = make_uint2((unsigned)k, d);
+    }
+    if (c->codec != CODEC_NONE) {
+      const uint64_t safe_end = ((uint64_t)c->chunk_len + 15) & ~15ull;   // chunk_dev is readable up to here
+      for (const DvPage& P : c->pages) {
+        DvJob& J = c->codec == CODEC_ZSTD ? jobs[jz++] : jobs[jo++];
+        J.src = chunk_dev[i] + P.src_off;
+        J.dst = image_dev[i] + P.img_off;
+        J.comp_len = P.comp_len; J.uncomp_len = P.uncomp_len; J.lev_len = P.lev_len; J.compressed = P.compressed;
+        J.src_safe = (uint32_t)(safe_end - P.src_off);
+        J.codec = (uint32_t)c->codec;
+        J.ctl = D.hdr;
+      }
+    }
+  }
+  DBHIP_CHECK(hipMemcpyAsync(blob, H.data(), L.total, hipMemcpyHostToDevice, s));
+  const DvChunkD* d_cds = (const DvChunkD*)(blob + L.cds);
+  const DvJob* d_jobs = (const DvJob*)(blob + L.jobs);
+  // validity / BOOLEAN targets start from zero (the kernels OR bits in)
+  for (int i : live) {
+    dbhip_pq_chunk* c = cs[i];
+    const bool spread = c->max_def == 1 && !c->known_no_nulls;
+    uint32_t* vbits = (uint32_t*)out_validity_dev[i];
+    if (c->max_def == 1) DBHIP_CHECK(hipMemsetAsync(vbits, 0, (size_t)ceil_div(c->rows, 64) * 8, s));
+    else if (vbits) DBHIP_CHECK(hipMemsetAsync(vbits, 0xFF, (size_t)ceil_div(c->rows, 64) * 8, s));
+    if (c->out_type == DBHIP_T_BOOL)
+      DBHIP_CHECK(hipMemsetAsync(spread ? c->d_dense : out_values_dev[i], 0, (size_t)ceil_div(spread ? c->rows + 1 : c->rows, 64) * 8, s));
+  }
   kernel_timer_start(s);
-  if (c->codec != CODEC_NONE)
-    hipLaunchKernelGGL(dv_inflate_kernel, dim3((unsigned)c->pages.size()), dim3(64), DW + DI, s, c->dv_pages, chunk_dev, image_dev, c->codec, c->dv_ctl);
-  if (c->dict_n > 0)
-    hipLaunchKernelGGL(dv_dict_kernel, dim3(1), dim3(256), 0, s, c->dv_pages, (uint32_t)c->dict_page, img, cv, c->d_dict, c->dv_ctl);
-  uint32_t* vbits = (uint32_t*)out_validity_dev;
-  if (c->max_def == 1) {
-    DBHIP_CHECK(hipMemsetAsync(vbits, 0, (size_t)ceil_div(c->rows, 64) * 8, s));
-    hipLaunchKernelGGL(dv_levels_kernel, dim3(nd), dim3(256), 0, s, c->dv_pages, c->dv_dp, img, c->dv_nn, c->dv_voff, vbits, c->dv_ctl);
-  } else if (vbits) {
-    DBHIP_CHECK(hipMemsetAsync(vbits, 0xFF, (size_t)ceil_div(c->rows, 64) * 8, s));
-  }
-  hipLaunchKernelGGL(dv_scan_kernel, dim3(1), dim3(256), 0, s, c->dv_nn, nd, c->dv_vbase);
-  void* target = spread ? c->d_dense : out_values_dev;
-  if (is_bool) DBHIP_CHECK(hipMemsetAsync(target, 0, (size_t)ceil_div(spread ? c->rows + 1 : c->rows, 64) * 8, s));
-  // slices of a PLAIN fixed-width page: enough workgroups to fill the chip even from a few large pages
-  const bool fixed = c->physical != PT_BOOLEAN && c->physical != PT_BYTE_ARRAY;
-  unsigned slices = 1;
-  if (fixed && nd > 0) {
-    const int64_t per_page = c->rows / (int64_t)nd;
-    while (slices < 64 && (int64_t)nd * slices < 2048 && per_page / (int64_t)slices > 4096) slices <<= 1;
-  }
-  hipLaunchKernelGGL(dv_values_kernel, dim3(nd, slices), dim3(256), 0, s, c->dv_pages, c->dv_dp, img, c->dv_nn, c->dv_voff, c->dv_vbase, cv,
-                     (const void*)c->d_dict, (uint32_t)(c->dict_n > 0 ? c->dict_n : 0), target, (uint64_t)c->rows, c->dv_ctl);
-  if (spread) {
+  if (n_z) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), ZW_LDS, s, d_jobs);
+  if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), DW + DI, s, d_jobs + n_z);
+  if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
+  if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));
+  hipLaunchKernelGGL(dv_scan_kernel, dim3((unsigned)nl), dim3(256), 0, s, d_cds);
+  if (n_dp) hipLaunchKernelGGL(dv_values_kernel, dim3((unsigned)n_dp, max_slices), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.val_map));
+  for (int i : live) {
+    dbhip_pq_chunk* c = cs[i];
+    if (!(c->max_def == 1 && !c->known_no_nulls)) continue;
+    const int esize = out_elem_size(c->out_type);
+    const int64_t nwords = ceil_div(c->rows, 32);
+    uint32_t* vbits = (uint32_t*)out_validity_dev[i];
+    void* out = out_values_dev[i];
     hipLaunchKernelGGL(pq_popc_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, nwords, c->d_wcnt);
     DBHIP_TRY(dbscan::exclusive_scan_u32(c->d_wcnt, nwords, c->d_blk, c->d_woff, s));
     const int grid = grid_for(c->rows, 256);
-    if (is_bool) {
-      hipLaunchKernelGGL(pq_spread_bool_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense,
-                         nwords, (uint32_t*)out_values_dev);
-      if (nwords & 1) DBHIP_CHECK(hipMemsetAsync((uint32_t*)out_values_dev + nwords, 0, 4, s));
+    if (c->out_type == DBHIP_T_BOOL) {
+      hipLaunchKernelGGL(pq_spread_bool_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense, nwords, (uint32_t*)out);
+      if (nwords & 1) DBHIP_CHECK(hipMemsetAsync((uint32_t*)out + nwords, 0, 4, s));
     } else if (esize == 1) {
-      hipLaunchKernelGGL(pq_spread_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint8_t*)c->d_dense, c->rows, (uint8_t*)out_values_dev);
+      hipLaunchKernelGGL(pq_spread_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint8_t*)c->d_dense, c->rows, (uint8_t*)out);
     } else if (esize == 2) {
-      hipLaunchKernelGGL(pq_spread_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint16_t*)c->d_dense, c->rows, (uint16_t*)out_values_dev);
+      hipLaunchKernelGGL(pq_spread_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint16_t*)c->d_dense, c->rows, (uint16_t*)out);
     } else if (esize == 4) {
-      hipLaunchKernelGGL(pq_spread_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense, c->rows, (uint32_t*)out_values_dev);
+      hipLaunchKernelGGL(pq_spread_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint32_t*)c->d_dense, c->rows, (uint32_t*)out);
     } else if (esize == 8) {
-      hipLaunchKernelGGL(pq_spread_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint64_t*)c->d_dense, c->rows, (uint64_t*)out_values_dev);
+      hipLaunchKernelGGL(pq_spread_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint64_t*)c->d_dense, c->rows, (uint64_t*)out);
     } else {
-      hipLaunchKernelGGL(pq_spread_kernel<uint4>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint4*)c->d_dense, c->rows, (uint4*)out_values_dev);
+      hipLaunchKernelGGL(pq_spread_kernel<uint4>, dim3(grid), dim3(256), 0, s, vbits, c->d_woff, (const uint4*)c->d_dense, c->rows, (uint4*)out);
     }
   }
   kernel_timer_stop(s);
   DBHIP_LAUNCH_CHECK();
-  // the verdict of the device-side checks (and the null count) is only known once the kernels ran
-  uint32_t ctl[4] = {0, 0, 0, 0};
-  uint64_t nonnull = 0;
-  DBHIP_CHECK(hipMemcpyAsync(ctl, c->dv_ctl, 16, hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipMemcpyAsync(&nonnull, c->dv_vbase + nd, 8, hipMemcpyDeviceToHost, s));
+  // the verdict of the device-side checks (and the null counts) is only known once the kernels ran: one read-back for the batch
+  std::vector<uint32_t> hdr(nl * 8, 0);
+  DBHIP_CHECK(hipMemcpyAsync(hdr.data(), blob + L.hdr, nl * 32, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
-  if (ctl[0] == DV_UNSUPPORTED) {
-    set_error("dbhip_pq_chunk_decode_device: the chunk uses a form the device path does not decode (a Snappy back-reference beyond 64 KiB, "
-              "or an encoding that changes between pages); use dbhip_pq_chunk_open");
-    return DBHIP_ERR_UNSUPPORTED;
+  int32_t first_rc = DBHIP_OK;
+  for (size_t k = 0; k < nl; ++k) {
+    const int i = live[k];
+    dbhip_pq_chunk* c = cs[i];
+    const uint32_t verdict = hdr[k * 8];
+    uint64_t nonnull;
+    memcpy(&nonnull, &hdr[k * 8 + 2], 8);
+    int32_t rc = DBHIP_OK;
+    if (verdict == DV_UNSUPPORTED) {
+      set_error("dbhip_pq_chunk_decode_device: chunk %d uses a form the device path does not decode (a Snappy back-reference beyond 64 KiB, a ZSTD "
+                "dictionary, or an encoding that changes between pages); use dbhip_pq_chunk_open", i);
+      rc = DBHIP_ERR_UNSUPPORTED;
+    } else if (verdict != DV_OK) {
+      set_error("dbhip_pq_chunk_decode_device: malformed column chunk %d (a page does not decompress to its declared size, or a level / index / "
+                "length stream runs past its page)", i);
+      rc = DBHIP_ERR_INVALID;
+    } else if (c->known_no_nulls && (int64_t)nonnull != c->rows) {
+      set_error("dbhip_pq_chunk_decode_device: malformed column chunk %d (the pages say num_nulls = 0, the definition levels disagree)", i);
+      rc = DBHIP_ERR_INVALID;
+    } else {
+      c->nonnull = (int64_t)nonnull;
+      c->nulls = c->rows - c->nonnull;
+      if (out_nulls_host) out_nulls_host[i] = c->nulls;
+    }
+    if (out_status_host) out_status_host[i] = rc;
+    if (rc && !first_rc) first_rc = rc;
   }
-  if (ctl[0] != DV_OK) {
-    set_error("dbhip_pq_chunk_decode_device: malformed column chunk (a page does not decompress to its declared size, or a level / "
-              "index / length stream runs past its page)");
-    return DBHIP_ERR_INVALID;
-  }
-  if (c->known_no_nulls && (int64_t)nonnull != c->rows) {
-    set_error("dbhip_pq_chunk_decode_device: malformed column chunk (the pages say num_nulls = 0, the definition levels disagree)");
-    return DBHIP_ERR_INVALID;
-  }
-  c->nonnull = (int64_t)nonnull;
-  c->nulls = c->rows - c->nonnull;
-  if (out_nulls_host) *out_nulls_host = c->nulls;
-  return DBHIP_OK;
+  return first_rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, void* out_values_dev,
+                                     uint8_t* out_validity_dev, int64_t* out_nulls_host, void* stream) {
+  return decode_many(&c, 1, &chunk_dev, &image_dev, &out_values_dev, &out_validity_dev, out_nulls_host, nullptr, stream);
+}
+
+int32_t dbhip_pq_chunks_decode_device(dbhip_pq_chunk* const* chunks, int32_t n_chunks, const uint8_t* const* chunk_dev, uint8_t* const* image_dev,
+                                      void* const* out_values_dev, uint8_t* const* out_validity_dev, int64_t* out_nulls_host,
+                                      int32_t* out_status_host, void* stream) {
+  DBHIP_REQUIRE(n_chunks >= 0 && (n_chunks == 0 || (chunks && chunk_dev && image_dev && out_values_dev && out_validity_dev)),
+                "dbhip_pq_chunks_decode_device: NULL argument");
+  return decode_many(chunks, n_chunks, chunk_dev, image_dev, out_values_dev, out_validity_dev, out_nulls_host, out_status_host, stream);
 }
 
 }  // extern "C"

@@ -1853,7 +1853,7 @@ class ParquetChunk:
 
     def __init__(self, chunk, physical_type, out_type, type_length=0, max_def_level=0, max_rep_level=0, codec=0,
                  precision=0, scale=0, device=False):
-        """device=True: dbhip_pq_chunk_open_device / _decode_device — the host reads the page headers only; decompression (SNAPPY /
+        """device=True: dbhip_pq_chunk_open_device / _decode_device — the host reads the page headers only; decompression (ZSTD / SNAPPY /
         LZ4_RAW), run headers, length prefixes and DELTA blocks are walked on the GPU from the chunk as stored."""
         _ensure()
         self.host = np.frombuffer(chunk, dtype=np.uint8)   # zero-copy view; the bytes object stays referenced by the array
@@ -1914,6 +1914,49 @@ class ParquetChunk:
         if self.out_type == L.T_STRING:
             bufs = DeviceBuffer.from_numpy(np.array([buf0.ptr], dtype=np.uint64))
         return Column(self.out_type, i.num_values, out, val, self.precision, self.scale, buffers=bufs, keep=(buf0,))
+
+    @staticmethod
+    def decode_many(chunks, stream=None, statuses=None):
+        """dbhip_pq_chunks_decode_device: the column chunks of a block (or of several blocks) decoded by ONE launch set. `chunks` were
+        opened with device=True. -> [Column]; `statuses` (a list) receives the per-chunk status codes instead of an exception for a
+        chunk that fails its device checks (its Column is None then)."""
+        n = len(chunks)
+        if n == 0:
+            return []
+        outs, vals = [], []
+        for pc in chunks:
+            assert pc.device, "decode_many takes device-mode chunks"
+            i = pc.info
+            pc.upload()
+            if i.image_bytes and pc.image_dev is None:
+                pc.image_dev = DeviceBuffer(i.image_bytes)
+            outs.append(DeviceBuffer(i.out_bytes + 16))
+            vals.append(DeviceBuffer(i.validity_bytes + 8) if i.has_validity else None)
+        P = C.c_void_p * n
+        hs = P(*[pc.h for pc in chunks])
+        cd = P(*[C.c_void_p(pc.chunk_dev.ptr) for pc in chunks])
+        im = P(*[C.c_void_p(pc.image_dev.ptr) if pc.image_dev is not None else C.c_void_p(0) for pc in chunks])
+        ov = P(*[C.c_void_p(o.ptr) for o in outs])
+        vv = P(*[C.c_void_p(v.ptr) if v is not None else C.c_void_p(0) for v in vals])
+        nulls = (C.c_int64 * n)()
+        st = (C.c_int32 * n)()
+        rc = lib().dbhip_pq_chunks_decode_device(hs, C.c_int32(n), cd, im, ov, vv, nulls, st, stream)
+        if statuses is None:
+            check(rc)
+        else:
+            statuses[:] = list(st)
+            if rc and all(x == 0 for x in st):
+                check(rc)
+        cols = []
+        for k, pc in enumerate(chunks):
+            if st[k]:
+                cols.append(None)
+                continue
+            pc.nulls = nulls[k]
+            buf0 = pc.image_dev if pc.image_dev is not None else pc.chunk_dev
+            bufs = DeviceBuffer.from_numpy(np.array([buf0.ptr], dtype=np.uint64)) if pc.out_type == L.T_STRING else None
+            cols.append(Column(pc.out_type, pc.info.num_values, outs[k], vals[k], pc.precision, pc.scale, buffers=bufs, keep=(buf0,)))
+        return cols
 
     def close(self):
         if self.h:

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DBHIP_ABI_VERSION 4   /* 4 (round 4): block scatter / concat, exchange and plan calls, device-mode scan, cancellation, row-wise vector distance */
+#define DBHIP_ABI_VERSION 5   /* 5 (round 5): ZSTD on the device, batched chunk decode (dbhip_pq_chunks_decode_device); 4 (round 4): block scatter / concat, exchange and plan calls, device-mode scan, cancellation, row-wise vector distance */
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -910,12 +910,13 @@ int32_t dbhip_pq_chunk_image(dbhip_pq_chunk* c, const uint8_t** out_ptr_host, in
 int32_t dbhip_pq_chunk_decode(dbhip_pq_chunk* c, const uint8_t* chunk_dev, void* out_values_dev,
                               uint8_t* out_validity_dev, void* stream);
 /* DEVICE mode of the same boundary: the page payload never passes through the host. open_device reads the thrift page headers
- * only (sizes, value counts, encodings: a few dozen bytes per page); decode_device decompresses the pages (SNAPPY / LZ4_RAW: one
- * wave per page, LDS-resident 64 KiB window), walks the run headers of the RLE / bit-packed hybrid streams (definition levels,
- * dictionary indices, RLE booleans), the length prefixes of PLAIN BYTE_ARRAY pages and DELTA_BINARY_PACKED blocks (INT32 /
- * INT64) on the GPU, from the HBM copy of the chunk AS STORED. ZSTD chunks: DBHIP_ERR_UNSUPPORTED (dbhip_pq_chunk_open
- * decompresses them with the host's libzstd). Same type pairs, same output layout as open / decode.
- *   chunk_dev    the chunk as stored (the bytes given to open_device), readable up to the next 16-byte boundary past its end
+ * only (sizes, value counts, encodings: a few dozen bytes per page); decode_device decompresses the pages (one wave per page —
+ * ZSTD, the reference's default TableCompression: Huffman literals + FSE sequences walked on the GPU, frames with a dictionary
+ * id are DBHIP_ERR_UNSUPPORTED; SNAPPY / LZ4_RAW), walks the run headers of the RLE / bit-packed hybrid streams (definition
+ * levels, dictionary indices, RLE booleans), the length prefixes of PLAIN BYTE_ARRAY pages and DELTA_BINARY_PACKED blocks
+ * (INT32 / INT64) on the GPU, from the HBM copy of the chunk AS STORED. Same type pairs, same output layout as open / decode.
+ *   chunk_dev    the chunk as stored (the bytes given to open_device), 16-byte aligned, readable up to the next 16-byte
+ *                boundary past its end
  *   image_dev    compressed chunks: info.image_bytes bytes, 16-byte aligned, caller-owned — receives the decompressed pages;
  *                DBHIP_T_STRING views point into it (it is buffer 0 of the column; UNCOMPRESSED chunks: chunk_dev is, pass NULL)
  *   info.num_nulls is -1 when the page headers do not tell (v1 pages of a nullable column); out_nulls_host (may be NULL) gets
@@ -928,6 +929,16 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
 int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev,
                                      void* out_values_dev, uint8_t* out_validity_dev, int64_t* out_nulls_host,
                                      void* stream);
+/* MANY chunks, one launch set (what a scan does: the column chunks of a block — or of several blocks — together): the pages of all
+ * chunks are decompressed by ONE launch per codec family (ZSTD; SNAPPY + LZ4_RAW), their levels / dictionaries / values by one
+ * launch each over all data pages, and the verdicts and null counts come back in one read-back. Arrays of n_chunks entries, as the
+ * arguments of dbhip_pq_chunk_decode_device (image_dev[i] / out_validity_dev[i] NULL where that call takes NULL);
+ * out_nulls_host / out_status_host may be NULL. A chunk that fails its device checks gets its own status in out_status_host[i]
+ * (the others are decoded); the call returns the first such status. Handles must be distinct. */
+int32_t dbhip_pq_chunks_decode_device(dbhip_pq_chunk* const* chunks, int32_t n_chunks, const uint8_t* const* chunk_dev,
+                                      uint8_t* const* image_dev, void* const* out_values_dev,
+                                      uint8_t* const* out_validity_dev, int64_t* out_nulls_host,
+                                      int32_t* out_status_host, void* stream);
 int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c);
 
 /* ---------------------------------------------------------------------------------------------------------------------

@@ -50,6 +50,31 @@ def column_chunks(file_bytes):
     return out, pf.read()
 
 
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _zz32(v):
+    return _varint(((v << 1) ^ (v >> 31)) & 0xFFFFFFFF)
+
+
+def raw_page_chunk(compressed_payload, uncompressed_size, num_values, encoding=0):
+    """A column chunk of ONE v1 data page (required column: no levels) around a payload that was compressed elsewhere — how the tests
+    feed Zstandard frames the reference holds (tests/golden/zstd_ref) to the device decompressor: thrift compact PageHeader
+    {1: DATA_PAGE, 2: uncompressed_page_size, 3: compressed_page_size, 5: DataPageHeader{1: num_values, 2: encoding, 3: RLE, 4: RLE}}."""
+    hdr = (b"\x15" + _zz32(0) + b"\x15" + _zz32(uncompressed_size) + b"\x15" + _zz32(len(compressed_payload)) +
+           b"\x2c" + b"\x15" + _zz32(num_values) + b"\x15" + _zz32(encoding) + b"\x15" + _zz32(3) + b"\x15" + _zz32(3) + b"\x00" + b"\x00")
+    return hdr + bytes(compressed_payload)
+
+
 def expected_of(arr, out_type):
     """pyarrow ChunkedArray -> (values, valid): values as python objects comparable with decoded_to_python()"""
     import pyarrow as pa

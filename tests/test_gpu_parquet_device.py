@@ -36,11 +36,12 @@ def test_device_mode_matches_pyarrow_and_oracle(gpu, vi):
         assert rc == 0 and o_got == got, name
 
 
-@pytest.mark.parametrize("cname", ["lz4", "snappy"])
+@pytest.mark.parametrize("cname", ["zstd", "lz4", "snappy"])
 @pytest.mark.parametrize("vi", [0, 1, 2, 4, 5])
 def test_device_side_decompression_matches_pyarrow(gpu, cname, vi):
-    """TableCompression LZ4 / Snappy (table_compression.rs:38-58): one wave per page decompresses into the HBM image; values, validity and
-    String views (which point into that image) equal pyarrow's, and the image equals the page payloads of the uncompressed twin."""
+    """TableCompression Zstd (the default) / LZ4 / Snappy (table_compression.rs:27-58): one wave per page decompresses into the HBM image;
+    values, validity and String views (which point into that image) equal pyarrow's, and the image equals the page payloads of the
+    uncompressed twin."""
     import pyarrow as pa
     for name, arr, out_type, wkw in PC.make_cases(seed=vi):
         kw = dict(PC.VARIANTS[vi])
@@ -54,16 +55,104 @@ def test_device_side_decompression_matches_pyarrow(gpu, cname, vi):
         assert np.array_equal(valid, exp_valid) and got == exp, name
 
 
-def test_zstd_and_nested_chunks_are_left_to_the_host_mode(gpu):
+def _zstd():
+    import ctypes
+    Z = ctypes.CDLL("libzstd.so.1")
+    Z.ZSTD_compress.restype = ctypes.c_size_t
+    Z.ZSTD_compressBound.restype = ctypes.c_size_t
+    Z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+
+    def compress(data, level):
+        cap = Z.ZSTD_compressBound(len(data))
+        buf = ctypes.create_string_buffer(cap)
+        n = Z.ZSTD_compress(buf, ctypes.c_size_t(cap), data, ctypes.c_size_t(len(data)), ctypes.c_int(level))
+        assert n <= cap
+        return buf.raw[:n]
+    return compress
+
+
+def _decode_frames_as_page(gpu, frames, plain):
+    """a payload compressed elsewhere, wrapped as the one v1 PLAIN INT64 page of a required column -> (values, decompressed image)"""
+    n = len(plain) // 8
+    chunk = PU.raw_page_chunk(frames, len(plain), n)
+    pc = gpu.ParquetChunk(chunk, PU.PHYS["INT64"], T.T_I64, 0, 0, 0, 6, device=True)
+    col = pc.decode()
+    vals = col.data.to_numpy(np.int64, n)
+    img = pc.device_image()
+    pc.close()
+    return vals, bytes(img[:len(plain)])
+
+
+def test_zstd_frames_the_reference_holds(gpu):
+    """Known-answer vectors for the ZSTD path: the frames under the reference's tests/data (tests/golden/zstd_ref; ontime_200.csv.zst with the
+    plaintext the reference keeps beside it, a 2.9 MB wasm module compressed at a high level: many blocks, treeless literals, repeat offsets,
+    references far beyond the 8 KiB ring) decompressed on the GPU."""
+    import hashlib
+    gold = os.path.join(os.path.dirname(GOLD), "zstd_ref")
+    index = json.load(open(os.path.join(gold, "index.json")))
+    for name, meta in index.items():
+        z = open(os.path.join(gold, name + ".zst"), "rb").read()
+        chunk = PU.raw_page_chunk(z, meta["decoded_bytes"], meta["decoded_bytes"] // 8)
+        pc = gpu.ParquetChunk(chunk, PU.PHYS["INT64"], T.T_I64, 0, 0, 0, 6, device=True)
+        pc.decode()
+        img = bytes(pc.device_image()[:meta["decoded_bytes"]])
+        pc.close()
+        assert hashlib.sha256(img).hexdigest() == meta["sha256"], name
+
+
+@pytest.mark.parametrize("level", [1, 3, 9, 19, -3])
+def test_zstd_levels_and_block_shapes(gpu, level):
+    """What libzstd (the library behind the reference's zstd crate) emits at several levels over the shapes pages take: raw / RLE /
+    compressed blocks, single- and four-stream Huffman literals, predefined / RLE / FSE / repeat sequence tables, several frames in one
+    page; the GPU's bytes are the input's."""
+    compress = _zstd()
+    rng = np.random.default_rng(100 + level)
+    n = 40_000
+    cases = {
+        "random": rng.integers(0, 256, n * 8, dtype=np.uint8).tobytes(),
+        "zeros": bytes(n * 8),
+        "prices": rng.integers(90000, 10494951, n).astype(np.int64).tobytes(),
+        "skewed": np.minimum(rng.geometric(0.3, n * 8), 255).astype(np.uint8).tobytes(),
+        "packed2bit": rng.integers(0, 4, n * 8, dtype=np.uint8).tobytes(),
+        "period": np.tile(rng.integers(0, 2**40, 3001), n // 3001 + 1)[:n].astype(np.int64).tobytes(),
+        "runs": np.repeat(rng.integers(0, 1000, n // 500 + 1), 500)[:n].astype(np.int64).tobytes(),
+        "tiny": b"abcdefgh" * 3,
+        "text": (b"lineitem|orders|DELIVER IN PERSON|TRUCK|furiously final packages|1996-03-13|" * 4000)[: n * 8],
+    }
+    for name, plain in cases.items():
+        vals, img = _decode_frames_as_page(gpu, compress(plain, level), plain)
+        assert img == plain, (name, level)
+        assert np.array_equal(vals, np.frombuffer(plain, np.int64)), name
+    # two frames in one page (the format allows concatenation; back-references do not cross the frame boundary)
+    a, b = cases["prices"][:100_000], cases["text"][:160_000]
+    vals, img = _decode_frames_as_page(gpu, compress(a, level) + compress(b, level), a + b)
+    assert img == a + b
+
+
+def test_zstd_dictionary_frames_and_nested_chunks_are_refused(gpu):
     import pyarrow as pa
-    t = pa.table({"c": pa.array(list(range(5000)), pa.int64())})
-    chunks, _ = PU.column_chunks(PU.write_parquet(t, compression="zstd"))
-    ch = chunks[0]
+    compress = _zstd()
+    plain = bytes(range(256)) * 64
+    z = bytearray(compress(plain, 3))
+    # Frame_Header_Descriptor: set Dictionary_ID_flag = 1 and insert a non-zero one-byte dictionary id behind the (optional) window byte
+    single = (z[4] >> 5) & 1
+    z[4] |= 1
+    z.insert(5 if single else 6, 7)
+    chunk = PU.raw_page_chunk(bytes(z), len(plain), len(plain) // 8)
+    pc = gpu.ParquetChunk(chunk, PU.PHYS["INT64"], T.T_I64, 0, 0, 0, 6, device=True)
     with pytest.raises(T.DbhipError) as e:
-        gpu.ParquetChunk(ch["chunk"], ch["physical"], T.T_I64, ch["type_length"], ch["max_def"], 0, ch["codec"], device=True)
+        pc.decode()
     assert e.value.code == T.ERR_UNSUPPORTED
-    got, valid, info = gpu_decode(gpu, ch, T.T_I64)          # the host-planned mode takes it
-    assert got == list(range(5000))
+    pc.close()
+    # a wrong uncompressed_page_size in the page header is a malformed chunk, not an overrun
+    z = compress(plain, 3)
+    for wrong in (len(plain) - 8, len(plain) + 8):
+        pc = gpu.ParquetChunk(PU.raw_page_chunk(z, wrong, wrong // 8), PU.PHYS["INT64"], T.T_I64, 0, 0, 0, 6, device=True)
+        with pytest.raises(T.DbhipError) as e:
+            pc.decode()
+        assert e.value.code == T.ERR_INVALID
+        pc.close()
+    t = pa.table({"c": pa.array(list(range(5000)), pa.int64())})
     # a handle of one mode is refused by the other mode's decode
     chunks, _ = PU.column_chunks(PU.write_parquet(t))
     ch = chunks[0]
@@ -74,7 +163,7 @@ def test_zstd_and_nested_chunks_are_left_to_the_host_mode(gpu):
     pc.close()
 
 
-@pytest.mark.parametrize("cname", ["none", "snappy", "lz4"])
+@pytest.mark.parametrize("cname", ["none", "snappy", "lz4", "zstd"])
 def test_delta_binary_packed(gpu, cname):
     """DELTA_BINARY_PACKED INT32 / INT64 (not in the reference writer's repertoire, but in files it reads): several pages, NULLs, runs of
     equal deltas (bit width 0), full-width deltas, against pyarrow and the oracle's statement of Encodings.md."""
@@ -102,7 +191,7 @@ def test_delta_binary_packed(gpu, cname):
                 assert rc == 0 and o_got == got
 
 
-@pytest.mark.parametrize("cname", ["snappy", "lz4"])
+@pytest.mark.parametrize("cname", ["snappy", "lz4", "zstd"])
 def test_large_compressible_pages(gpu, cname):
     """Pages far larger than the 64 KiB LDS window, with the back-reference shapes real data produces: long runs (overlapping matches at
     distance 1..8), repeated rows at 16-bit distances, incompressible stretches (long literals), Booleans, repetitive strings longer than 12
@@ -156,7 +245,7 @@ def test_mutated_chunks_never_fault_in_device_mode(gpu):
     import pyarrow as pa
     rng = np.random.default_rng(13)
     seeds = []
-    for vi, cname in ((0, "none"), (1, "none"), (4, "snappy"), (1, "snappy"), (0, "lz4"), (5, "lz4")):
+    for vi, cname in ((0, "none"), (1, "none"), (4, "snappy"), (1, "snappy"), (0, "lz4"), (5, "lz4"), (0, "zstd"), (4, "zstd"), (5, "zstd")):
         for name, arr, ot, wkw in PC.make_cases(seed=vi):
             kw = dict(PC.VARIANTS[vi])
             kw.update(wkw)
@@ -164,7 +253,7 @@ def test_mutated_chunks_never_fault_in_device_mode(gpu):
             if len(chunks[0]["chunk"]):
                 seeds.append((chunks[0], ot))
     opened = rejected = failed = 0
-    for it in range(1500):
+    for it in range(2200):
         ch, ot = seeds[it % len(seeds)]
         b = bytearray(ch["chunk"])
         k = int(rng.integers(0, 3))
@@ -196,9 +285,53 @@ def test_mutated_chunks_never_fault_in_device_mode(gpu):
     gpu_decode(gpu, ch, ot, device=True)
 
 
+def test_many_chunks_one_launch_set(gpu):
+    """dbhip_pq_chunks_decode_device: the column chunks of several blocks (all four codecs, every encoding of make_cases, NULLs, strings,
+    Booleans) decoded by one launch set equal their one-by-one decodes; a corrupt chunk in the batch gets its own status and the others
+    still decode."""
+    import pyarrow as pa
+    opened, singles = [], []
+    for vi, cname in ((0, "zstd"), (1, "snappy"), (2, "none"), (4, "lz4"), (5, "zstd")):
+        for name, arr, ot, wkw in PC.make_cases(seed=vi):
+            kw = dict(PC.VARIANTS[vi])
+            kw.update(wkw)
+            chunks, back = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), compression=cname, **kw))
+            ch = chunks[0]
+            if not len(ch["chunk"]):
+                continue
+            exp, exp_valid = PU.expected_of(back.column(0), ot)
+            opened.append((gpu.ParquetChunk(ch["chunk"], ch["physical"], ot, ch["type_length"], ch["max_def"], 0, ch["codec"], device=True), ot, exp,
+                           exp_valid, name))
+    assert len(opened) > 40
+    cols = gpu.ParquetChunk.decode_many([o[0] for o in opened])
+    for (pc, ot, exp, exp_valid, name), col in zip(opened, cols):
+        n = pc.info.num_values
+        valid = unpack(col.validity.to_numpy(np.uint8, pc.info.validity_bytes).tobytes(), n) if col.validity is not None else np.ones(n, bool)
+        raw = col.data.to_numpy(np.uint8, pc.info.out_bytes).tobytes()
+        got = PU.decoded_to_python(raw, valid, ot, n, chunk=pc.device_image())
+        assert np.array_equal(valid, exp_valid) and got == exp, name
+        assert pc.nulls == int((~exp_valid).sum()), name
+    # one corrupt chunk (a ZSTD frame that loses its last bytes) among intact ones
+    compress = _zstd()
+    plain = np.arange(50_000, dtype=np.int64).tobytes()
+    z = compress(plain, 3)[:-5]
+    bad = gpu.ParquetChunk(PU.raw_page_chunk(z, len(plain), len(plain) // 8), PU.PHYS["INT64"], T.T_I64, 0, 0, 0, 6, device=True)
+    good = gpu.ParquetChunk(PU.raw_page_chunk(compress(plain, 3), len(plain), len(plain) // 8), PU.PHYS["INT64"], T.T_I64, 0, 0, 0, 6, device=True)
+    st = []
+    cols = gpu.ParquetChunk.decode_many([good, bad, opened[0][0]], statuses=st)
+    assert st[0] == 0 and st[2] == 0 and st[1] == T.ERR_INVALID and cols[1] is None
+    assert np.array_equal(cols[0].data.to_numpy(np.int64, 50_000), np.arange(50_000))
+    with pytest.raises(T.DbhipError):
+        gpu.ParquetChunk.decode_many([good, bad])
+    for o in opened:
+        o[0].close()
+    bad.close()
+    good.close()
+
+
 def test_full_size_device_mode_20m_rows(gpu):
-    """BASELINE-sized chunk (20 M Decimal(15,2) values of lineitem, 3 % NULLs, PLAIN v1 pages of 1 MiB) stored uncompressed, with Snappy and
-    with LZ4: write -> decode is the identity; the rates (bytes of the chunk as stored per second of the decode call) go to
+    """BASELINE-sized chunk (20 M Decimal(15,2) values of lineitem, 3 % NULLs, PLAIN v1 pages of 1 MiB) stored uncompressed, with Snappy,
+    LZ4 and ZSTD: write -> decode is the identity; the rates (bytes of the chunk as stored per second of the decode call) go to
     gpurun_out/pq_device_rates.json."""
     import pyarrow as pa
     n = 20_000_000
@@ -207,7 +340,7 @@ def test_full_size_device_mode_20m_rows(gpu):
     mask = rng.random(n) < 0.03
     disc = rng.integers(0, 11, n)
     rates = {}
-    for cname in ("none", "snappy", "lz4"):
+    for cname in ("none", "snappy", "lz4", "zstd"):
         for label, arr, dictionary, src, m in (("price_plain_nullable", pa.array(price, pa.int64(), mask=mask), False, price, mask),
                                                ("discount_dictionary", pa.array(disc, pa.int64()), True, disc, None)):
             chunks, _ = PU.column_chunks(PU.write_parquet(pa.table({"c": arr}), dictionary=dictionary, compression=cname))

@@ -1,0 +1,45 @@
+"""The Zstandard frame parser the device kernel instantiates (databend_amd/csrc/zstd_core.h), run over plain host memory by
+tests/zstd_host_check.cpp (TEST INFRASTRUCTURE — the product instantiates the header on the device only):
+  * the frames the REFERENCE keeps under tests/data (tests/golden/zstd_ref, cut by make_zstd_ref_golden.py) decode to the bytes the
+    reference keeps beside them (ontime_200.csv) / to what libzstd makes of them (sha256 in index.json);
+  * generated inputs x compression levels round-trip through the system's libzstd (the library behind the reference's `zstd` crate,
+    Cargo.lock: zstd-sys 2.0.16+zstd.1.5.7; here 1.4.8) and this parser; mutated frames are accepted / refused like libzstd does, apart
+    from the checks the FORMAT demands and that library version lacks (counted, not hidden)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "zstd_ref")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("zstd") / "zstd_host_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "zstd_host_check.cpp"), "-ldl"])
+    return exe
+
+
+def test_reference_held_frames(checker, tmp_path):
+    index = json.load(open(os.path.join(GOLD, "index.json")))
+    assert index["ontime_200_csv"]["reference_plaintext"] == "tests/data/ontime_200.csv"
+    for name, meta in index.items():
+        out = str(tmp_path / (name + ".out"))
+        r = subprocess.run([checker, "file", os.path.join(GOLD, name + ".zst"), str(meta["decoded_bytes"]), out], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stdout)
+        data = open(out, "rb").read()
+        assert len(data) == meta["decoded_bytes"] and hashlib.sha256(data).hexdigest() == meta["sha256"], name
+    # a wrong declared size is an error
+    r = subprocess.run([checker, "file", os.path.join(GOLD, "ontime_200_csv.zst"), "90806"], capture_output=True, text=True)
+    assert r.returncode != 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_round_trips_and_mutations_against_libzstd(checker, seed):
+    r = subprocess.run([checker, str(seed), "150"], capture_output=True, text=True, timeout=600)
+    if r.stdout.startswith("skip"):
+        pytest.skip(r.stdout.strip())
+    assert r.returncode == 0 and r.stdout.startswith("ok 150 cases"), r.stdout
