@@ -1,12 +1,14 @@
 // dv_wave.h — one wave decompresses one page (k_parquet_dev.hip): how the wave reads its input and where its output lives.
 //
-//   input    a 256-byte look-ahead WINDOW of the compressed payload held in one VGPR (lane l = dword l): headers, FSE / Huffman table
-//            descriptions and the backward bitstream of the sequences are read with v_readlane (scalar results, no memory round trip per
-//            field); the window slides forward or backward with one coalesced 256-byte load.
-//   output   an LDS RING of the last W bytes (W = 8 KiB for ZSTD, whose tables take another 14 KiB of LDS) written to the HBM image in
-//            16-byte stores; a back-reference that reaches further than the ring reads the image itself — those bytes left the ring, so
-//            they were flushed long ago (the wave waits for its own stores once per far reference, nothing else).
-// With 22 KiB of LDS per wave seven pages are resident per CU (the round-4 kernel kept a 64 KiB window + 8 KiB input ring: two).
+//   input    look-ahead WINDOWS of the compressed payload held in VGPRs (lane l = dword l): headers, FSE / Huffman table descriptions
+//            and the backward bitstream of the ZSTD sequences are read with v_readlane (scalar results, no memory round trip per
+//            field); literal bytes are moved from a window to the output with ds_bpermute. A window slides with one coalesced load;
+//            the FORWARD streams (the literals of a ZSTD block, the whole LZ4 / Snappy payload) keep the next 256 bytes loaded ahead,
+//            so a sequence never waits for HBM.
+//   output   an LDS RING of the last W bytes (8 KiB for ZSTD, whose tables take another 14 KiB of LDS; 16 KiB for LZ4 / Snappy)
+//            written to the HBM image in 16-byte stores; a back-reference that reaches further than the ring reads the image itself —
+//            those bytes left the ring, so they were flushed long ago (the wave waits for its own stores once per far reference).
+// 22 / 16 KiB of LDS per wave: seven / ten pages resident per CU (the round-4 kernel kept a 64 KiB window + 8 KiB input ring: two).
 #pragma once
 #include "zstd_core.h"
 
@@ -23,6 +25,89 @@ struct DvJob {
 
 namespace {
 
+// global-memory accesses through pointers that came out of a struct (the compiler would use flat instructions, which tie up the LDS
+// counter as well)
+typedef const __attribute__((address_space(1))) uint8_t* gcptr8;
+__device__ __forceinline__ uint32_t gload32(const uint8_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)(uintptr_t)p; }
+__device__ __forceinline__ uint8_t gload8(const uint8_t* p) { return *(const __attribute__((address_space(1))) uint8_t*)(uintptr_t)p; }
+__device__ __forceinline__ uint64_t gload64u(const uint8_t* p) {   // unaligned
+  uint64_t v;
+  __builtin_memcpy(&v, (const __attribute__((address_space(1))) uint8_t*)(uintptr_t)p, 8);
+  return v;
+}
+__device__ __forceinline__ void gstore8(uint8_t* p, uint8_t v) { *(__attribute__((address_space(1))) uint8_t*)(uintptr_t)p = v; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gstore128(uint8_t* p, u32x4 v) { *(__attribute__((address_space(1))) u32x4*)(uintptr_t)p = v; }
+
+// Divergence hygiene: the parser state of a wave (positions, counters, window origins) is SCALAR. The compiler keeps it on the scalar unit
+// only while no scalar variable is assigned inside a region whose join coincides with the join of a per-lane branch — one guarded
+// per-lane load inside a uniform `if` turned `wlo` into a vector PHI and with it every header field and branch of the kernel (464
+// exec-mask branches in the first build). Hence: guarded loads are branch-free (clamped address + select), and scalar updates happen in
+// straight-line code after the per-lane part.
+// dword at gA + o if it lies inside [0, safe) else 0; safe is a multiple of 4 and >= 4
+__device__ __forceinline__ uint32_t guarded32(const uint8_t* gA, uint32_t o, uint32_t safe) {
+  const bool in = o + 4 <= safe;
+  const uint32_t v = gload32(gA + (in ? o : safe - 4));
+  return in ? v : 0u;
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// A FORWARD stream of global bytes read through two 256-byte chunks held in registers (chunk k = bytes [256 k, 256 k + 256) from the
+// 4-byte aligned address gA; the chunk after it is loaded when the stream enters chunk k, i.e. one chunk ahead of its use).
+struct FwdStream {
+  const uint8_t* gA;
+  uint32_t safe;       // bytes readable from gA (a multiple of 4)
+  uint32_t k;          // chunk held in `cur`
+  uint32_t cur, nxt;   // this lane's dword of chunk k / k + 1
+  uint32_t lane;
+  __device__ __forceinline__ uint32_t fetch(uint32_t chunk) const {
+    return guarded32(gA, chunk * 256 + 4 * lane, safe);
+  }
+  __device__ __forceinline__ void open(const uint8_t* g, uint32_t safe_bytes, uint32_t a, uint32_t ln) {
+    gA = g; safe = safe_bytes & ~3u; lane = ln;
+    k = rfl(a >> 8);
+    cur = fetch(k); nxt = fetch(k + 1);
+  }
+  // make byte offset a (from gA) lie in chunk k
+  __device__ __forceinline__ void seek(uint32_t a) {
+    const uint32_t want = rfl(a >> 8);
+    if (want != k) {
+      if (want == k + 1) { cur = nxt; nxt = fetch(want + 1); }
+      else { cur = fetch(want); nxt = fetch(want + 1); }
+    }
+    k = want;
+  }
+  // 8 bytes at offset a (scalar). The chunk loaded ahead is only touched when the read reaches into it (its load may still be in flight).
+  __device__ __forceinline__ uint64_t u64(uint32_t a) {
+    seek(a);
+    const uint32_t i = rfl((a & 255) >> 2);
+    uint32_t d0, d1, d2;
+    if (i < 62) {
+      d0 = rdl(cur, i); d1 = rdl(cur, i + 1); d2 = rdl(cur, i + 2);
+    } else {
+      d0 = rdl(cur, i);
+      d1 = i == 62 ? rdl(cur, 63) : rdl(nxt, 0);
+      d2 = rdl(nxt, i - 62);
+    }
+    const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
+    const uint32_t s = 8 * (a & 3);
+    return s ? (lo >> s) | ((uint64_t)d2 << (64 - s)) : lo;
+  }
+  // byte a + lane for the first n lanes (a in chunk k after seek(a); a + n may reach into chunk k + 1)
+  __device__ __forceinline__ uint8_t lane_byte(uint32_t a, uint32_t n) const {
+    const uint32_t t = (a & 255) + lane;                      // 0..318
+    const uint32_t idx = (t >> 2) & 63;
+    uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)cur);
+    if ((a & 255) + n > 256) {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)nxt);
+      v = t < 256 ? v : x;
+    }
+    return (uint8_t)(v >> (8 * (t & 3)));
+  }
+};
+
 struct ZWave {
   // ---- input
   const uint8_t* srcA;   // 4-byte aligned address at or below the payload
@@ -30,6 +115,9 @@ struct ZWave {
   uint32_t in_len;
   uint32_t safeA;        // bytes readable from srcA, a multiple of 4
   uint32_t la, wlo;      // the window: this lane holds bytes [wlo + 4 lane, + 4) from srcA; wlo is a multiple of 4
+  // ---- the literal stream of the current block (ZSTD)
+  FwdStream lit;
+  uint32_t lit_kind, lit_at, lit_left;   // kind 2: lit_at is the byte; else offset of the next literal from lit.gA
   // ---- output
   uint8_t* dst;
   uint32_t cap_, op_, flushed, sh, frame0;
@@ -43,10 +131,8 @@ struct ZWave {
   __device__ __forceinline__ bool lead() const { return lane == 0; }
   __device__ __forceinline__ void sync() const { __builtin_amdgcn_wave_barrier(); }
   __device__ __forceinline__ bool bcast(bool b) const { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
-  __device__ __forceinline__ uint32_t uni(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-  __device__ __forceinline__ uint64_t uni64(uint64_t v) const {
-    return (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
-  }
+  __device__ __forceinline__ uint32_t uni(uint32_t v) const { return rfl(v); }
+  __device__ __forceinline__ uint64_t uni64(uint64_t v) const { return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32); }
   __device__ __forceinline__ uint16_t* huf() const { return (uint16_t*)tab; }
   __device__ __forceinline__ uint64_t* llt() const { return (uint64_t*)(tab + 4096); }
   __device__ __forceinline__ uint64_t* mlt() const { return (uint64_t*)(tab + 8192); }
@@ -56,11 +142,10 @@ struct ZWave {
   __device__ __forceinline__ uint32_t cap() const { return cap_; }
   __device__ __forceinline__ void frame_begin() { frame0 = op_; }
 
-  // ---- the window
+  // ---- the window (headers, table descriptions, backward bitstreams)
   __device__ __forceinline__ void slide(uint32_t wl) {
-    wlo = wl;
-    const uint32_t o = wl + 4 * lane;
-    la = (o + 4 <= safeA) ? *(const uint32_t*)(srcA + o) : 0u;
+    wlo = rfl(wl);
+    la = guarded32(srcA, wlo + 4 * lane, safeA);
   }
   // bytes [a, a + n) from srcA inside the window (n <= 8)
   __device__ __forceinline__ void ensure(uint32_t a, uint32_t n) {
@@ -72,60 +157,52 @@ struct ZWave {
     }
   }
   __device__ __forceinline__ uint32_t in8(uint32_t pos) {
-    const uint32_t a = uni(pos + a0);
+    const uint32_t a = rfl(pos + a0);
     ensure(a, 1);
-    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)la, (int)((a - wlo) >> 2));
-    return (d >> (8 * (a & 3))) & 0xFF;
+    return (rdl(la, (a - wlo) >> 2) >> (8 * (a & 3))) & 0xFF;
   }
   __device__ __forceinline__ uint64_t in64(uint32_t pos) {
-    const uint32_t a = uni(pos + a0);
+    const uint32_t a = rfl(pos + a0);
     ensure(a, 8);
     const uint32_t i = (a - wlo) >> 2;
-    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)la, (int)i);
-    const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)la, (int)(i + 1));
-    const uint32_t i2 = i + 2 < 64 ? i + 2 : 63;
-    const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)la, (int)i2);
+    const uint32_t d0 = rdl(la, i), d1 = rdl(la, i + 1), d2 = rdl(la, i + 2 < 64 ? i + 2 : 63);
     const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
     const uint32_t s = 8 * (a & 3);
     return s ? (lo >> s) | ((uint64_t)d2 << (64 - s)) : lo;
   }
   // per-lane reads of the payload (the Huffman streams: up to four lanes, each at its own address)
-  __device__ __forceinline__ uint32_t lane_in8(uint32_t pos) const { return pos + a0 < safeA ? srcA[a0 + pos] : 0u; }
+  __device__ __forceinline__ uint32_t lane_in8(uint32_t pos) const { return pos + a0 < safeA ? gload8(srcA + a0 + pos) : 0u; }
   __device__ __forceinline__ uint64_t lane_in64(uint32_t pos) const {
     const uint8_t* p = srcA + a0 + pos;
+    if (pos + a0 + 8 <= safeA) return gload64u(p);
     uint64_t v = 0;
-    if (pos + a0 + 8 <= safeA) {
-      __builtin_memcpy(&v, p, 8);
-    } else {
-      for (uint32_t k = 0; k < 8; ++k)
-        if (pos + a0 + k < safeA) v |= (uint64_t)p[k] << (8 * k);
-    }
+    for (uint32_t k = 0; k < 8; ++k)
+      if (pos + a0 + k < safeA) v |= (uint64_t)gload8(p + k) << (8 * k);
     return v;
   }
   __device__ __forceinline__ void lane_store(uint32_t p, uint8_t b) const {
-    if (p < cap_) dst[p] = b;
+    if (p < cap_) gstore8(dst + p, b);
   }
 
   // ---- the ring
   __device__ __forceinline__ void flush(bool force) {
     const uint32_t target = op_;
+    // head: up to the next 16-byte boundary of the image
     const uint32_t a = (flushed + sh) & 15u;
-    if (a && flushed < target) {
-      const uint32_t h = (16 - a) < (target - flushed) ? (16 - a) : (target - flushed);
-      if (lane < h) dst[flushed + lane] = win[(flushed + sh + lane) & WM];
-      flushed += h;
-    }
-    const uint32_t nvec = (target - flushed) >> 4;
-    if (((flushed + sh) & 15u) == 0 && nvec) {
+    const uint32_t room = target - flushed;
+    const uint32_t h = a ? ((16 - a) < room ? (16 - a) : room) : 0u;
+    if (lane < h) gstore8(dst + flushed + lane, win[(flushed + sh + lane) & WM]);
+    const uint32_t f1 = flushed + h;
+    // body: whole 16-byte vectors
+    const uint32_t nvec = ((f1 + sh) & 15u) == 0 ? (target - f1) >> 4 : 0u;
 #pragma clang loop unroll(disable)
-      for (uint32_t v = lane; v < nvec; v += 64)
-        *(uint4*)(dst + flushed + 16 * v) = *(const uint4*)(win + ((flushed + sh + 16 * v) & WM));
-      flushed += nvec << 4;
-    }
-    if (force) {
-      for (uint32_t i = flushed + lane; i < target; i += 64) dst[i] = win[(i + sh) & WM];
-      flushed = target;
-    }
+    for (uint32_t v = lane; v < nvec; v += 64)
+      gstore128(dst + f1 + 16 * v, *(const u32x4*)(win + ((f1 + sh + 16 * v) & WM)));
+    const uint32_t f2 = f1 + (nvec << 4);
+    // tail (only at the end of the page)
+    const uint32_t tail = force ? target - f2 : 0u;
+    for (uint32_t i = lane; i < tail; i += 64) gstore8(dst + f2 + i, win[(f2 + i + sh) & WM]);
+    flushed = rfl(f2 + tail);
     stores_pending = true;
   }
   __device__ __forceinline__ void wait_stores() {
@@ -135,18 +212,18 @@ struct ZWave {
     }
   }
   __device__ __forceinline__ void advance(uint32_t n) {
-    op_ += n;
+    op_ = rfl(op_ + n);
     if (op_ - flushed >= WF) flush(false);
   }
 
-  // `len` bytes from global memory at g (the payload, or the literals the Huffman stage left in the image's tail)
+  // `len` bytes from global memory at g (long literals; Raw_Blocks)
   __device__ __forceinline__ void copy_in(const uint8_t* g, uint32_t len) {
 #pragma clang loop unroll(disable)
     for (uint32_t i = 0; i < len; i += 256) {
       const uint32_t n = len - i < 256 ? len - i : 256;
       uint8_t b[4];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) b[k] = (64 * k + lane < n) ? g[i + 64 * k + lane] : (uint8_t)0;
+      for (uint32_t k = 0; k < 4; ++k) b[k] = (64 * k + lane < n) ? gload8(g + i + 64 * k + lane) : (uint8_t)0;
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k)
         if (64 * k + lane < n) win[(op_ + 64 * k + lane + sh) & WM] = b[k];
@@ -157,11 +234,6 @@ struct ZWave {
   __device__ __forceinline__ bool put_in(uint32_t pos, uint32_t len) {
     if (len > cap_ - op_ || pos > in_len || len > in_len - pos) return false;
     copy_in(srcA + a0 + pos, len);
-    return true;
-  }
-  __device__ __forceinline__ bool put_out(uint32_t pos, uint32_t len) {
-    if (len > cap_ - op_ || pos > cap_ || len > cap_ - pos) return false;
-    copy_in(dst + pos, len);   // (huf_streams waited for the stores that put them there)
     return true;
   }
   __device__ __forceinline__ bool put_fill(uint32_t byte, uint32_t len) {
@@ -175,6 +247,75 @@ struct ZWave {
     }
     return true;
   }
+  // <= 64 bytes of a forward stream -> the output
+  __device__ __forceinline__ void put_stream64(FwdStream& f, uint32_t a, uint32_t n) {
+    f.seek(a);
+    const uint8_t v = f.lane_byte(a, n);
+    if (lane < n) win[(op_ + lane + sh) & WM] = v;
+    __builtin_amdgcn_wave_barrier();
+    advance(n);
+  }
+
+  // ---- the literals of a ZSTD block
+  __device__ __forceinline__ void lit_begin(uint32_t kind, uint32_t pos, uint32_t n) {
+    lit_kind = kind; lit_left = n; lit_at = pos;
+    if (kind != 2 && n) {
+      // kind 0: the payload at `pos`; kind 1: the page's own image at `pos` (huf_streams waited for the stores that put them there)
+      const uint8_t* g = kind == 0 ? srcA + a0 + pos : dst + pos;
+      const uint32_t x = (uint32_t)((uintptr_t)g & 3u);
+      // readable: the payload to the end of the chunk's slack / the image to the end of the page (+ the buffer's 16 bytes of slack)
+      const uint32_t room = kind == 0 ? safeA - (a0 + pos) + x : cap_ - pos + x + 4;
+      lit_at = x;
+      lit.open(g - x, room, x, lane);
+    }
+  }
+  // literals + match of one ZSTD sequence (ll > 0)
+  __device__ __forceinline__ bool put_seq(uint32_t ll, uint32_t off, uint32_t ml) {
+    if (ll <= 8 && ll + ml <= 64 && lit_kind != 2 && off <= WM - 127) {
+      if (ll > lit_left || ll + ml > cap_ - op_ || off == 0 || off > op_ - frame0 + ll) return false;
+      const uint64_t bits = lit.u64(lit_at);
+      lit_left -= ll;
+      lit_at = rfl(lit_at + ll);
+      pair_small(bits, ll, off, ml);
+      return true;
+    }
+    return put_lit(ll) && put_match(off, ml);
+  }
+  __device__ __forceinline__ bool put_lit(uint32_t len) {
+    if (len > lit_left || len > cap_ - op_) return false;
+    lit_left -= len;
+    if (lit_kind == 2) return put_fill(lit_at, len);
+    if (len <= 64) {
+      put_stream64(lit, lit_at, len);
+    } else {
+      copy_in(lit.gA + lit_at, len);
+    }
+    lit_at = rfl(lit_at + len);
+    return true;
+  }
+
+  // THE COMMON SEQUENCE in one LDS round trip: up to 8 literal bytes that the caller holds as a scalar (`litbits`, byte i = bits [8 i, 8 i + 8))
+  // followed by a back-reference of `mlen` bytes, lit + mlen <= 64, the source inside the ring (1 <= off <= W - 128, off <= bytes written
+  // + lit: checked by the caller). Lane l < lit writes literal byte l; lane lit + m writes match byte m, whose source lies `off` back:
+  // either among the bytes already in the ring (one ds_read for all lanes) or among the literal bytes of this very sequence (taken from
+  // the scalar, no LDS access) — by periodicity out[x] = out[x - off (1 + floor(m / off))].
+  __device__ __forceinline__ void pair_small(uint64_t litbits, uint32_t lit, uint32_t off, uint32_t mlen) {
+    const int32_t m = (int32_t)lane - (int32_t)lit;                 // match byte index (negative: a literal lane)
+    uint32_t mm = m > 0 ? (uint32_t)m : 0u;
+    if (off < 64) {
+      const float r = __builtin_amdgcn_rcpf((float)off);          // mm mod off (see put_match)
+      mm = mm - off * (uint32_t)(((float)mm + 0.5f) * r);
+    }
+    const int32_t rel = (int32_t)lit - (int32_t)off + (int32_t)mm;  // source relative to op_: < 0 in the ring, >= 0 a literal of this sequence
+    const uint32_t from_ring = win[(op_ + (uint32_t)rel + sh) & WM];
+    const uint32_t li = m < 0 ? lane : (uint32_t)rel;             // which literal byte this lane takes if it takes one
+    const uint32_t from_lit = (uint32_t)(litbits >> (8 * (li & 7))) & 0xFF;
+    const uint32_t v = (m < 0 || rel >= 0) ? from_lit : from_ring;
+    if (lane < lit + mlen) win[(op_ + lane + sh) & WM] = (uint8_t)v;
+    __builtin_amdgcn_wave_barrier();
+    advance(lit + mlen);
+  }
+
   __device__ __forceinline__ bool put_match(uint32_t off, uint32_t len) {
     if (off == 0 || off > op_ - frame0 || len > cap_ - op_) return false;
     if (off <= WM - 63) {
@@ -198,15 +339,14 @@ struct ZWave {
         advance(n);
       }
     } else {
-      // the source left the ring: it is in the image (flushed at least WF + 64 bytes ago: WF <= W - 256)
-      wait_stores();
+      // the source left the ring: it is in the image (flushed at least WF + 64 bytes ago: WF <= W - 512)
 #pragma clang loop unroll(disable)
       for (uint32_t i = 0; i < len; i += 64) {
         const uint32_t n = len - i < 64 ? len - i : 64;
-        if (lane < n) win[(op_ + lane + sh) & WM] = dst[op_ - off + lane];
+        wait_stores();
+        if (lane < n) win[(op_ + lane + sh) & WM] = gload8(dst + op_ - off + lane);
         __builtin_amdgcn_wave_barrier();
         advance(n);
-        wait_stores();   // (a flush inside advance(): the next piece may read what it stored — only when off < 64 + WF, never here, but cheap)
       }
     }
     return true;
@@ -225,14 +365,158 @@ struct ZWave {
       ok = zc::huf_stream(*this, huf(), maxbits, pos, len, n, outp + lane * seg);
     }
     const bool all = __builtin_amdgcn_ballot_w64(!ok) == 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the literals are read back (put_out) by other lanes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the literals are read back (lit_begin) by other lanes
     stores_pending = false;
     return all;
+  }
+
+  __device__ __forceinline__ void begin(const DvJob& P, uint8_t* lds, uint32_t ring_bytes, uint32_t ln) {
+    const uint32_t lev = P.lev_len;
+    const uint8_t* s0 = P.src + lev;
+    a0 = (uint32_t)((uintptr_t)s0 & 3u);
+    srcA = s0 - a0;
+    in_len = P.comp_len - lev;
+    safeA = (P.src_safe - lev + a0) & ~3u;
+    lane = ln;
+    slide(0);
+    dst = P.dst + lev;
+    cap_ = P.uncomp_len - lev; op_ = 0; flushed = 0; frame0 = 0;
+    sh = (uint32_t)((uintptr_t)dst & 15u);
+    win = lds; WM = ring_bytes - 1; WF = ring_bytes / 2;
+    tab = lds + ring_bytes;
+    stores_pending = false;
+    lit_kind = 2; lit_at = 0; lit_left = 0;
   }
 };
 
 constexpr uint32_t ZW_RING = 8192;                          // ZSTD: ring bytes
 constexpr uint32_t ZW_TABLES = 13312 + zc::SCR_BYTES;       // Huffman 4 KiB + LL 4 KiB + ML 4 KiB + OF 1 KiB + scratch
 constexpr uint32_t ZW_LDS = ZW_RING + ZW_TABLES;
+constexpr uint32_t LZ_RING = 16384;                         // LZ4 / Snappy: ring bytes (nothing else in LDS)
+
+// ---------------------------------------------------------------------------------------------
+// LZ4 block format (lz4_Block_format.md) and Snappy raw format (format_description.txt) on the same wave: the payload is ONE forward
+// stream — tokens / tags are read from its register chunks (scalar), literals move from the chunks to the ring.
+// ---------------------------------------------------------------------------------------------
+// -> false: malformed
+__device__ __forceinline__ bool lz4_block(ZWave& w, FwdStream& in) {
+  uint32_t p = 0;
+  const uint32_t n = w.in_len, a0 = w.a0;
+  while (p < n) {
+    const uint64_t h = in.u64(a0 + p);
+    const uint32_t tok = (uint32_t)h & 0xFF;
+    uint32_t lit = tok >> 4, ml = tok & 15u;
+    p += 1;
+    // the common sequence: <= 5 literal bytes, no length extension, the two offset bytes still inside `h`, away from the end of the block
+    if (lit <= 5 && ml != 15 && n - p >= lit + 2 + 12) {
+      const uint32_t off = (uint32_t)(h >> (8 + 8 * lit)) & 0xFFFF;
+      if (off != 0 && off <= w.WM - 127) {
+        if (off > w.op_ - w.frame0 + lit || lit + ml + 4 > w.cap_ - w.op_) return false;
+        w.pair_small(h >> 8, lit, off, ml + 4);
+        p = rfl(p + lit + 2);
+        continue;
+      }
+    }
+    if (lit == 15) {
+      for (;;) {
+        if (p >= n) return false;
+        const uint32_t b = (uint32_t)in.u64(a0 + p) & 0xFF;
+        p += 1;
+        if (lit > 0x7FFFFFFFu - b) return false;
+        lit += b;
+        if (b != 255) break;
+      }
+    }
+    if (lit) {
+      if (lit > n - p || lit > w.cap_ - w.op_) return false;
+      if (lit <= 64) w.put_stream64(in, a0 + p, lit);
+      else w.copy_in(w.srcA + a0 + p, lit);
+      p = rfl(p + lit);
+    }
+    if (p >= n) break;   // the last sequence ends with its literals
+    if (n - p < 2) return false;
+    const uint32_t off = (uint32_t)in.u64(a0 + p) & 0xFFFF;
+    p += 2;
+    if (ml == 15) {
+      for (;;) {
+        if (p >= n) return false;
+        const uint32_t b = (uint32_t)in.u64(a0 + p) & 0xFF;
+        p += 1;
+        if (ml > 0x7FFFFFFFu - b - 4) return false;
+        ml += b;
+        if (b != 255) break;
+      }
+    }
+    if (!w.put_match(off, ml + 4)) return false;
+  }
+  return true;
+}
+
+__device__ __forceinline__ bool snappy_raw(ZWave& w, FwdStream& in) {
+  uint32_t p = 0;
+  const uint32_t n = w.in_len, a0 = w.a0;
+  // preamble: the uncompressed length as a varint
+  uint64_t total = 0;
+  bool fin = false;
+  for (int k = 0; k < 5 && p < n; ++k) {
+    const uint32_t b = (uint32_t)in.u64(a0 + p) & 0xFF;
+    p += 1;
+    total |= (uint64_t)(b & 0x7F) << (7 * k);
+    if (!(b & 0x80)) { fin = true; break; }
+  }
+  if (!fin || total != (uint64_t)w.cap_) return false;
+  while (p < n) {
+    const uint64_t h = in.u64(a0 + p);
+    const uint32_t tag = (uint32_t)h & 0xFF, kind = tag & 3u, left = n - p;
+    if (kind == 0 && (tag >> 2) < 4 && left >= 24) {
+      // a literal of 1..4 bytes with the copy element behind it inside `h`: one LDS round trip for the pair
+      const uint32_t len = (tag >> 2) + 1;
+      const uint32_t t2 = (uint32_t)(h >> (8 + 8 * len)) & 0xFF, k2 = t2 & 3u;
+      if (k2 == 1 || (k2 == 2 && len <= 3)) {
+        uint32_t mlen, off, hdr2;
+        if (k2 == 1) { mlen = ((t2 >> 2) & 7u) + 4; off = ((t2 >> 5) << 8) | ((uint32_t)(h >> (16 + 8 * len)) & 0xFF); hdr2 = 2; }
+        else { mlen = (t2 >> 2) + 1; off = (uint32_t)(h >> (16 + 8 * len)) & 0xFFFF; hdr2 = 3; }
+        if (off != 0 && off <= w.WM - 127 && len + mlen <= 64) {
+          if (off > w.op_ - w.frame0 + len || len + mlen > w.cap_ - w.op_) return false;
+          w.pair_small(h >> 8, len, off, mlen);
+          p = rfl(p + 1 + len + hdr2);
+          continue;
+        }
+      }
+    }
+    if (kind == 0) {
+      uint32_t len = (tag >> 2) + 1, hdr = 1;
+      if (len > 60) {
+        const uint32_t extra = len - 60;   // 1..4 length bytes
+        if (left < 1 + extra) return false;
+        const uint32_t v = (uint32_t)(h >> 8) & (extra == 4 ? 0xFFFFFFFFu : ((1u << (8 * extra)) - 1));
+        if (v == 0xFFFFFFFFu) return false;
+        len = v + 1;
+        hdr = 1 + extra;
+      }
+      p += hdr;
+      if (len > n - p || len > w.cap_ - w.op_) return false;
+      if (len <= 64) w.put_stream64(in, a0 + p, len);
+      else w.copy_in(w.srcA + a0 + p, len);
+      p = rfl(p + len);
+    } else if (kind == 1) {
+      if (left < 2) return false;
+      const uint32_t len = ((tag >> 2) & 7u) + 4, off = ((tag >> 5) << 8) | ((uint32_t)(h >> 8) & 0xFF);
+      p += 2;
+      if (!w.put_match(off, len)) return false;
+    } else if (kind == 2) {
+      if (left < 3) return false;
+      const uint32_t len = (tag >> 2) + 1, off = (uint32_t)(h >> 8) & 0xFFFF;
+      p += 3;
+      if (!w.put_match(off, len)) return false;
+    } else {
+      if (left < 5) return false;
+      const uint32_t len = (tag >> 2) + 1, off = (uint32_t)(h >> 8);
+      p += 5;
+      if (!w.put_match(off, len)) return false;
+    }
+  }
+  return true;
+}
 
 }  // namespace

@@ -29,6 +29,8 @@
 // dbhip_pq_chunks_decode_device decodes MANY chunks with one launch set (one inflate launch per codec family over all their pages, one
 // levels / scan / dictionary / values launch over all their data pages, one read-back): a scan keeps dozens of column chunks in flight.
 #include "pq_common.h"
+
+#include <stdlib.h>
 #include "dv_wave.h"
 
 namespace {
@@ -377,23 +379,30 @@ __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __rest
   for (uint32_t i = lane; i < raw; i += 64) P.dst[i] = P.src[i];
   if (!P.compressed || P.uncomp_len == lev) return;
   ZWave w;
-  const uint8_t* s0 = P.src + lev;
-  w.a0 = (uint32_t)((uintptr_t)s0 & 3u);
-  w.srcA = s0 - w.a0;
-  w.in_len = P.comp_len - lev;
-  w.safeA = (P.src_safe - lev + w.a0) & ~3u;
-  w.lane = lane;
-  w.slide(0);
-  w.dst = P.dst + lev;
-  w.cap_ = P.uncomp_len - lev; w.op_ = 0; w.flushed = 0; w.frame0 = 0;
-  w.sh = (uint32_t)((uintptr_t)w.dst & 15u);
-  w.win = dv_lds; w.WM = ZW_RING - 1; w.WF = ZW_RING / 2;
-  w.tab = dv_lds + ZW_RING;
-  w.stores_pending = false;
+  w.begin(P, dv_lds, ZW_RING, lane);
   int rc = zc::decode_frames(w, w.in_len);
   if (rc == zc::OK && w.op_ != w.cap_) rc = zc::CORRUPT_;
   w.flush(true);
   if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
+}
+
+// LZ4 / Snappy on the same wave (16 KiB ring, the payload as one forward stream in registers)
+__global__ __launch_bounds__(64) void dv_inflate_lz_kernel(const DvJob* __restrict__ jobs) {
+  extern __shared__ __align__(16) uint8_t dv_lds[];
+  const DvJob P = jobs[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lev = P.lev_len;
+  const uint32_t raw = P.compressed ? lev : P.uncomp_len;
+  for (uint32_t i = lane; i < raw; i += 64) P.dst[i] = P.src[i];
+  if (!P.compressed || P.uncomp_len == lev) return;
+  ZWave w;
+  w.begin(P, dv_lds, LZ_RING, lane);
+  FwdStream in;
+  in.open(w.srcA, w.safeA, w.a0, lane);
+  bool ok = P.codec == CODEC_SNAPPY ? snappy_raw(w, in) : lz4_block(w, in);
+  if (ok && w.op_ != w.cap_) ok = false;
+  w.flush(true);
+  if (!ok) dv_fail(P.ctl, DV_CORRUPT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1010,6 +1019,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   if (live.empty()) return DBHIP_OK;
   static const bool lds_ok = [] {
     return hipFuncSetAttribute((const void*)dv_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DW + DI)) == hipSuccess &&
+           hipFuncSetAttribute((const void*)dv_inflate_lz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_RING) == hipSuccess &&
            hipFuncSetAttribute((const void*)dv_inflate_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW_LDS) == hipSuccess;
   }();
   if (!lds_ok) { set_error("%s: cannot reserve LDS for the decompression kernels", who); return DBHIP_ERR_HIP; }
@@ -1094,6 +1104,10 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
       }
     }
   }
+  // the longest pages first: a page is one wave's serial work, the short ones fill the slots the long ones leave
+  auto by_size = [](const DvJob& a, const DvJob& b) { return a.uncomp_len > b.uncomp_len; };
+  std::sort(jobs, jobs + n_z, by_size);
+  std::sort(jobs + n_z, jobs + n_jobs, by_size);
   DBHIP_CHECK(hipMemcpyAsync(blob, H.data(), L.total, hipMemcpyHostToDevice, s));
   const DvChunkD* d_cds = (const DvChunkD*)(blob + L.cds);
   const DvJob* d_jobs = (const DvJob*)(blob + L.jobs);
@@ -1109,7 +1123,11 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   }
   kernel_timer_start(s);
   if (n_z) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), ZW_LDS, s, d_jobs);
-  if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), DW + DI, s, d_jobs + n_z);
+  static const bool old_lz = getenv("DBHIP_PQ_OLD_INFLATE") != nullptr;   // (round-4 kernel, kept for one A/B measurement)
+  if (n_jobs > n_z) {
+    if (old_lz) hipLaunchKernelGGL(dv_inflate_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), DW + DI, s, d_jobs + n_z);
+    else hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), LZ_RING, s, d_jobs + n_z);
+  }
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
   if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));
   hipLaunchKernelGGL(dv_scan_kernel, dim3((unsigned)nl), dim3(256), 0, s, d_cds);

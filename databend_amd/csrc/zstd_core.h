@@ -6,9 +6,11 @@
 // sequences section with its three FSE tables, the repeat-offset rules), not libzstd's code: the entropy tables are laid out for a
 // 64-lane wave that walks one page (LDS-resident, 8-byte sequence entries carrying base value and extra bits so that a sequence costs
 // one LDS round trip), and every byte that moves goes through four primitives of the caller:
-//     put_in(pos, len)      literals that sit in the compressed input (Raw_Literals_Block, Raw_Block)
-//     put_out(pos, len)     literals decoded by the Huffman stage into the TAIL of the page's own output region (see decode_block)
-//     put_fill(byte, len)   RLE literals / RLE_Block
+//     lit_begin(kind, pos, n) the block's literals as one forward stream: in the compressed input (Raw_Literals_Block), decoded by the
+//                           Huffman stage into the TAIL of the page's own output region (see decode_block), or one repeated byte
+//     put_lit(len)          the next len bytes of that stream
+//     put_in(pos, len)      a Raw_Block
+//     put_fill(byte, len)   an RLE_Block
 //     put_match(off, len)   a back-reference
 // The file compiles for the device (k_parquet_dev.hip: W = the wave of dv_inflate_zstd_kernel) and for the host
 // (tests/zstd_host_check.cpp: W = plain memory), so that the parse logic is fuzzed against the system's libzstd on the CPU; the
@@ -279,6 +281,39 @@ struct BackBits {
   }
 };
 
+// The same stream for the SEQUENCES section, where it is the inner loop: the unread bits sit MSB-aligned in one scalar register pair
+// (bit off-1 of the stream = bit 63 of c), a field is a shift, and the register is refilled from the look-ahead window once per sequence
+// (57..64 bits each time) instead of being tested per field. Bits past the start of the stream read as zero and leave off < 0.
+template <class W>
+struct SeqBits {
+  uint32_t base;
+  int32_t off;    // unread bits of the stream
+  int32_t have;   // of which this many sit at the top of c
+  uint64_t c;
+  ZC_MEM bool init(W& w, uint32_t b, uint32_t len) {
+    base = b;
+    have = 0; c = 0; off = 0;
+    if (len == 0) return false;
+    const uint32_t last = w.in8(b + len - 1);
+    if (last == 0) return false;
+    off = (int32_t)(len * 8) - (int32_t)(8 - hibit(last));
+    return true;
+  }
+  ZC_MEM void refill(W& w) {
+    const int32_t b = off > 57 ? (off - 57) >> 3 : 0;
+    const int32_t h = off - 8 * b;        // 57..64, or what is left of the stream, or <= 0
+    have = (int32_t)w.uni((uint32_t)(h > 0 ? h : 0));
+    c = have > 0 ? w.uni64(w.in64(base + (uint32_t)b) << (uint32_t)(64 - have)) : 0;
+  }
+  ZC_MEM uint32_t read(uint32_t n) {   // n <= 32, and n <= have unless the stream is exhausted
+    const uint32_t v = (uint32_t)((c >> 1) >> (63 - n));
+    c <<= n;
+    have -= (int32_t)n;
+    off -= (int32_t)n;
+    return v;
+  }
+};
+
 // Huffman tree description (4.2.1) at input [pos, end) -> table w.huf()[1 << maxbits] of (symbol | nbits << 8); -> bytes used, 0: corrupt
 template <class W>
 ZC_FN uint32_t huf_read_table(W& w, uint32_t pos, uint32_t end, uint32_t* maxbits_out) {
@@ -411,6 +446,31 @@ ZC_INL bool huf_stream(W& w, const uint16_t* T, uint32_t maxbits, uint32_t pos, 
   return off == -(int32_t)maxbits;   // the stream ends exactly where its last symbol does
 }
 
+// one of the three sequence tables of a block, by its Symbol_Compression_Mode (3.1.1.3.2.1)
+template <class W, int KIND>
+ZC_FN int seq_table(W& w, uint32_t mode, uint32_t& al, uint32_t& tag, uint32_t& p, uint32_t end) {
+  if (mode == 0) {
+    if (tag != TAG_PREDEF) {
+      if (!fse_default(w, KIND)) return CORRUPT;
+      tag = TAG_PREDEF;
+    }
+    al = KIND == K_OF ? 5 : 6;
+  } else if (mode == 1) {
+    if (p >= end) return CORRUPT;
+    if (!fse_rle(w, w.in8(p), KIND)) return CORRUPT;
+    p += 1; al = 0; tag = TAG_OTHER;
+  } else if (mode == 2) {
+    uint32_t nsym = 0, next = 0;
+    const uint32_t a = read_ncount(w, p, end, KIND == K_OF ? 8 : 9, KIND == K_LL ? 35 : KIND == K_OF ? 31 : 52, &nsym, &next);
+    if (a == 0) return CORRUPT;
+    if (!fse_build(w, nsym, a, KIND)) return CORRUPT;
+    p = next; al = a; tag = TAG_OTHER;
+  } else if (tag == TAG_NONE) {
+    return CORRUPT;   // Repeat_Mode with nothing to repeat
+  }
+  return OK;
+}
+
 // one Compressed_Block (3.1.1.2 / 3.1.1.3): input [pos, pos + bsize)
 template <class W>
 ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
@@ -477,6 +537,8 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
     }
     p = lend;
   }
+  // the literals of the block are one forward stream from here on: put_lit(n) moves its next n bytes to the output
+  w.lit_begin(lit_kind, lit_pos, regen);
   // ---- sequences section header
   if (p >= end) return CORRUPT;
   uint32_t nseq = w.in8(p);
@@ -499,86 +561,76 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
     const uint32_t modes = w.in8(p);
     p += 1;
     if (modes & 3) return CORRUPT_STRICT;   // Reserved bits (libzstd >= 1.5.6)
-    for (int k = 0; k < 3; ++k) {
-      const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
-      uint32_t* al = k == 0 ? &F.ll_al : k == 1 ? &F.of_al : &F.ml_al;
-      uint32_t* tag = k == 0 ? &F.ll_tag : k == 1 ? &F.of_tag : &F.ml_tag;
-      if (mode == 0) {
-        if (*tag != TAG_PREDEF) {
-          if (!fse_default(w, k)) return CORRUPT;
-          *tag = TAG_PREDEF;
-        }
-        *al = k == K_OF ? 5 : 6;
-      } else if (mode == 1) {
-        if (p >= end) return CORRUPT;
-        if (!fse_rle(w, w.in8(p), k)) return CORRUPT;
-        p += 1; *al = 0; *tag = TAG_OTHER;
-      } else if (mode == 2) {
-        uint32_t nsym = 0, next = 0;
-        const uint32_t a = read_ncount(w, p, end, k == K_OF ? 8 : 9, k == K_LL ? 35 : k == K_OF ? 31 : 52, &nsym, &next);
-        if (a == 0) return CORRUPT;
-        if (!fse_build(w, nsym, a, k)) return CORRUPT;
-        p = next; *al = a; *tag = TAG_OTHER;
-      } else if (*tag == TAG_NONE) {
-        return CORRUPT;   // Repeat_Mode with nothing to repeat
-      }
-    }
+    // (three explicit calls, the fields passed by reference: a loop over pointers to F's members would put F into private memory,
+    // whose loads the compiler treats as per-lane values — the whole parser left the scalar unit that way in the first build)
+    int trc = seq_table<W, K_LL>(w, (modes >> 6) & 3, F.ll_al, F.ll_tag, p, end);
+    if (trc) return trc;
+    trc = seq_table<W, K_OF>(w, (modes >> 4) & 3, F.of_al, F.of_tag, p, end);
+    if (trc) return trc;
+    trc = seq_table<W, K_ML>(w, (modes >> 2) & 3, F.ml_al, F.ml_tag, p, end);
+    if (trc) return trc;
     // ---- the sequences: one backward bitstream
-    BackBits<W> bs;
+    SeqBits<W> bs;
     if (p >= end || !bs.init(w, p, end - p)) return CORRUPT;
-    uint32_t ls = bs.read(w, F.ll_al), os = bs.read(w, F.of_al), ms = bs.read(w, F.ml_al);
+    bs.refill(w);
+    uint32_t ls = bs.read(F.ll_al), os = bs.read(F.of_al), ms = bs.read(F.ml_al);   // <= 26 bits
     if (bs.off < 0) return CORRUPT;
     const uint64_t* LLT = w.llt();
     const uint64_t* MLT = w.mlt();
     const uint32_t* OFT = w.oft();
+    uint32_t r0 = F.rep[0], r1 = F.rep[1], r2 = F.rep[2];
+    // the table entries of a sequence are read (LDS) while the sequence before it is copied
+    uint64_t le_raw = LLT[ls], me_raw = MLT[ms];
+    uint32_t oe_raw = OFT[os];
     for (uint32_t i = 0; i < nseq; ++i) {
-      const uint64_t le = w.uni64(LLT[ls]), me = w.uni64(MLT[ms]);
-      const uint32_t oe = w.uni(OFT[os]);
+      const uint64_t le = w.uni64(le_raw), me = w.uni64(me_raw);
+      const uint32_t oe = w.uni(oe_raw);
       const uint32_t ocode = oe >> 24;
+      bs.refill(w);   // >= 57 bits (or all that is left): offset (<= 24 here) + match length (<= 16) + literals length (<= 16)
       // offset, match length, literals length — in this order (3.1.1.3.2.1.1)
-      uint32_t ov = (1u << ocode) + bs.read(w, ocode);
-      const uint32_t ml = (uint32_t)(me >> 32) + bs.read(w, (uint32_t)(me >> 24) & 0xFF);
-      const uint32_t ll = (uint32_t)(le >> 32) + bs.read(w, (uint32_t)(le >> 24) & 0xFF);
+      const uint32_t ov = (1u << ocode) + bs.read(ocode);
+      if (ocode > 24) bs.refill(w);
+      const uint32_t ml = (uint32_t)(me >> 32) + bs.read((uint32_t)(me >> 24) & 0xFF);
+      const uint32_t ll = (uint32_t)(le >> 32) + bs.read((uint32_t)(le >> 24) & 0xFF);
       if (bs.off < 0) return CORRUPT_STRICT;   // (libzstd < 1.5 reads zeros past the start and only checks the end; 1.5.7 checks for the exact end)
       // repeat offsets (3.1.1.5)
       uint32_t off;
       if (ov > 3) {
         off = ov - 3;
-        F.rep[2] = F.rep[1]; F.rep[1] = F.rep[0]; F.rep[0] = off;
+        r2 = r1; r1 = r0; r0 = off;
       } else {
         const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);   // 0..3
         if (idx == 0) {
-          off = F.rep[0];
+          off = r0;
         } else {
-          off = idx == 3 ? F.rep[0] - 1 : idx == 1 ? F.rep[1] : F.rep[2];   // (no dynamic index: the state stays in registers)
+          off = idx == 3 ? r0 - 1 : idx == 1 ? r1 : r2;
           if (off == 0) return CORRUPT;
-          if (idx != 1) F.rep[2] = F.rep[1];
-          F.rep[1] = F.rep[0];
-          F.rep[0] = off;
+          if (idx != 1) r2 = r1;
+          r1 = r0;
+          r0 = off;
         }
       }
-      if (i + 1 < nseq) {   // states are updated between sequences: literals length, match length, offset
-        ls = ((uint32_t)le & 0xFFFF) + bs.read(w, ((uint32_t)le >> 16) & 0xFF);
-        ms = ((uint32_t)me & 0xFFFF) + bs.read(w, ((uint32_t)me >> 16) & 0xFF);
-        os = (oe & 0xFFFF) + bs.read(w, (oe >> 16) & 0xFF);
+      if (i + 1 < nseq) {   // states are updated between sequences: literals length, match length, offset (<= 26 bits)
+        if (bs.have < 26) bs.refill(w);
+        ls = w.uni(((uint32_t)le & 0xFFFF) + bs.read(((uint32_t)le >> 16) & 0xFF));
+        ms = w.uni(((uint32_t)me & 0xFFFF) + bs.read(((uint32_t)me >> 16) & 0xFF));
+        os = w.uni((oe & 0xFFFF) + bs.read((oe >> 16) & 0xFF));
         if (bs.off < 0) return CORRUPT_STRICT;
+        le_raw = LLT[ls]; me_raw = MLT[ms]; oe_raw = OFT[os];
       }
       // execute
       if (ll > lit_left) return CORRUPT;
       if (ll) {
-        const bool ok = lit_kind == 0 ? w.put_in(lit_pos, ll) : lit_kind == 1 ? w.put_out(lit_pos, ll) : w.put_fill(lit_pos, ll);
-        if (!ok) return CORRUPT;
-        if (lit_kind != 2) lit_pos += ll;
+        if (!w.put_seq(ll, off, ml)) return CORRUPT;   // (a short literal and its match go as one step)
         lit_left -= ll;
+      } else if (!w.put_match(off, ml)) {
+        return CORRUPT;
       }
-      if (!w.put_match(off, ml)) return CORRUPT;
     }
+    F.rep[0] = r0; F.rep[1] = r1; F.rep[2] = r2;
     if (bs.off != 0) return CORRUPT_STRICT;   // every bit of the stream belongs to a sequence
   }
-  if (lit_left) {
-    const bool ok = lit_kind == 0 ? w.put_in(lit_pos, lit_left) : lit_kind == 1 ? w.put_out(lit_pos, lit_left) : w.put_fill(lit_pos, lit_left);
-    if (!ok) return CORRUPT;
-  }
+  if (lit_left && !w.put_lit(lit_left)) return CORRUPT;
   return OK;
 }
 

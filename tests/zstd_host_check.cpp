@@ -72,6 +72,17 @@ struct HostWave {
     op_ += len;
     return true;
   }
+  uint32_t lkind = 0, lpos = 0, lleft = 0;
+  void lit_begin(uint32_t kind, uint32_t pos, uint32_t n) { lkind = kind; lpos = pos; lleft = n; }
+  bool put_lit(uint32_t len) {
+    if (len > lleft) return false;
+    lleft -= len;
+    if (lkind == 2) return put_fill(lpos, len);
+    const bool ok = lkind == 0 ? put_in(lpos, len) : put_out(lpos, len);
+    lpos += len;
+    return ok;
+  }
+  bool put_seq(uint32_t ll, uint32_t off, uint32_t ml) { return put_lit(ll) && put_match(off, ml); }
   bool put_match(uint32_t off, uint32_t len) {
     if (off == 0 || off > op_ - frame0 || len > cap_ - op_) return false;
     for (uint32_t i = 0; i < len; ++i) out[op_ + i] = out[op_ + i - off];
