@@ -273,8 +273,12 @@ __host__ __device__ __forceinline__ bool gb_sum256(const GbLayout& L, int a) {
 __host__ __device__ __forceinline__ bool gb_minmax_str(const GbLayout& L, int a) {
   return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_type[a] == DBHIP_T_STRING;
 }
+__host__ __device__ __forceinline__ bool gb_minmax256(const GbLayout& L, int a) {
+  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_type[a] == DBHIP_T_DEC256;
+}
 __host__ __device__ __forceinline__ bool gb_minmax_wide(const GbLayout& L, int a) {
-  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && (L.agg_type[a] == DBHIP_T_DEC128 || L.agg_type[a] == DBHIP_T_STRING);
+  return (L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) &&
+         (L.agg_type[a] == DBHIP_T_DEC128 || L.agg_type[a] == DBHIP_T_STRING || L.agg_type[a] == DBHIP_T_DEC256);
 }
 __device__ __forceinline__ bool gb_mm_better(bool is_min, uint64_t hi, uint64_t lo, uint64_t chi, uint64_t clo) {
   return is_min ? (hi < chi || (hi == chi && lo < clo)) : (hi > chi || (hi == chi && lo > clo));
@@ -352,6 +356,46 @@ __device__ __forceinline__ void gb_minmax_str_plain(bool is_min, uint64_t* dst, 
   dst[1] = 1;
 }
 
+// MIN / MAX over Decimal256 (r05; aggregate_min_max_any_decimal.rs:45-138 with T = i256): FIVE words — [0] the top 64 bits with the sign
+// flipped, [1] the has-value / lock word, [2] [3] [4] the lower words from high to low — compared lexicographically as ([0], [2], [3], [4]),
+// merged under the same per-state lock as the three-word states.
+#define GB_MM256_WORDS 5
+__device__ __forceinline__ bool gb_mm256_better(bool is_min, const uint64_t* v, uint64_t c0, uint64_t c2, uint64_t c3, uint64_t c4) {
+  const uint64_t a[4] = {v[0], v[2], v[3], v[4]}, b[4] = {c0, c2, c3, c4};
+  for (int q = 0; q < 4; ++q)
+    if (a[q] != b[q]) return is_min ? a[q] < b[q] : a[q] > b[q];
+  return false;
+}
+__device__ __forceinline__ void gb_minmax256_locked(bool is_min, uint64_t* dst, const uint64_t* v) {
+  if (!v[1]) return;
+  unsigned long long* has = (unsigned long long*)(dst + 1);
+  bool done = false;
+  while (!done) {
+    const unsigned long long old = atomicOr(has, (unsigned long long)GB_MM_LOCK);
+    if (!(old & GB_MM_LOCK)) {
+      const uint64_t c0 = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t c2 = __hip_atomic_load(dst + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t c3 = __hip_atomic_load(dst + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t c4 = __hip_atomic_load(dst + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(old & 1ULL) || gb_mm256_better(is_min, v, c0, c2, c3, c4)) {
+        __hip_atomic_store(dst, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 3, v[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 4, v[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(has, 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      done = true;
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+__device__ __forceinline__ void gb_minmax256_plain(bool is_min, uint64_t* dst, const uint64_t* v) {   // ONE writer
+  if (!v[1]) return;
+  if (!dst[1] || gb_mm256_better(is_min, v, dst[0], dst[2], dst[3], dst[4])) { dst[0] = v[0]; dst[2] = v[2]; dst[3] = v[3]; dst[4] = v[4]; }
+  dst[1] = 1;
+}
+
 __device__ __forceinline__ void gb_minmax_wide_plain(bool is_min, uint64_t* dst, const uint64_t* v) {   // ONE writer
   if (!v[1]) return;
   if (!dst[1] || gb_mm_better(is_min, v[0], v[2], dst[0], dst[2])) { dst[0] = v[0]; dst[2] = v[2]; }
@@ -380,6 +424,7 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
     } break;
     case DBHIP_AGG_MIN:
       if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(true, dst, v); break; }
+      if (L.agg_type[a] == DBHIP_T_DEC256) { gb_minmax256_locked(true, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(true, dst, v); break; }
       if (v[1]) {
         atomicMin((unsigned long long*)dst, (unsigned long long)v[0]);
@@ -388,6 +433,7 @@ __device__ __forceinline__ void gb_atomic_merge(const GbLayout& L, int a, uint64
       break;
     default:  // MAX
       if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(false, dst, v); break; }
+      if (L.agg_type[a] == DBHIP_T_DEC256) { gb_minmax256_locked(false, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(false, dst, v); break; }
       if (v[1]) {
         atomicMax((unsigned long long*)dst, (unsigned long long)v[0]);
@@ -432,6 +478,7 @@ __device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* 
     } break;
     case DBHIP_AGG_MIN:
       if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(true, dst, v); break; }
+      if (L.agg_type[a] == DBHIP_T_DEC256) { gb_minmax256_locked(true, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(true, dst, v); break; }
       if (v[1]) {
         __hip_atomic_fetch_min((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -440,6 +487,7 @@ __device__ __forceinline__ void gb_wg_merge(const GbLayout& L, int a, uint64_t* 
       break;
     default:  // MAX
       if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_locked(false, dst, v); break; }
+      if (L.agg_type[a] == DBHIP_T_DEC256) { gb_minmax256_locked(false, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_locked(false, dst, v); break; }
       if (v[1]) {
         __hip_atomic_fetch_max((unsigned long long*)dst, (unsigned long long)v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -476,11 +524,13 @@ __device__ __forceinline__ void gb_plain_merge(const GbLayout& L, int a, uint64_
     } break;
     case DBHIP_AGG_MIN:
       if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_plain(true, dst, v); break; }
+      if (L.agg_type[a] == DBHIP_T_DEC256) { gb_minmax256_plain(true, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_plain(true, dst, v); break; }
       if (v[1]) { dst[0] = v[0] < dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
       break;
     default:  // MAX
       if (L.agg_type[a] == DBHIP_T_STRING) { gb_minmax_str_plain(false, dst, v); break; }
+      if (L.agg_type[a] == DBHIP_T_DEC256) { gb_minmax256_plain(false, dst, v); break; }
       if (L.agg_words[a] == 3) { gb_minmax_wide_plain(false, dst, v); break; }
       if (v[1]) { dst[0] = v[0] > dst[0] ? v[0] : dst[0]; dst[1] |= 1ULL; }
       break;

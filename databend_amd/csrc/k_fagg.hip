@@ -497,7 +497,7 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
   int words = 0;
   for (int a = 0; a < L.naggs; ++a) {
     if (L.agg_off[a] != L.agg_off[0] + words) return false;
-    if ((L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_words[a] == 3) return false;   // Decimal128 / String min / max: row path
+    if ((L.agg_kind[a] == DBHIP_AGG_MIN || L.agg_kind[a] == DBHIP_AGG_MAX) && L.agg_words[a] >= 3) return false;   // Decimal128 / Decimal256 / String min / max: row path
     if (L.agg_type[a] == DBHIP_T_DEC256 && L.agg_kind[a] != DBHIP_AGG_COUNT) return false;                           // Decimal256 sum: row path
     words += L.agg_words[a];
   }
@@ -581,7 +581,7 @@ static int32_t fa_build_args(const GbLayout& L, const dbhip_col* keys, const dbh
         if (fw) put(W_OR, C_FLAG, 0);
         break;
       case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
-        if (L.agg_words[a] == 3) { set_error("fused aggregation: min / max over Decimal128 stays on the row path"); return DBHIP_ERR_UNSUPPORTED; }
+        if (L.agg_words[a] >= 3) { set_error("fused aggregation: min / max over Decimal128 / Decimal256 / String stays on the row path"); return DBHIP_ERR_UNSUPPORTED; }
         if (L.agg_kind[a] == DBHIP_AGG_MIN) put(W_MIN, C_ENC, 0); else put(W_MAX, C_ENC, 0);
         put(W_CONT, C_FLAG, 0); general = true; break;
     }

@@ -272,6 +272,20 @@ __global__ __launch_bounds__(256) void gb_serialize_kernel(GbLayout L, GbCols C,
         }
         continue;
       }
+      if (C.arg[a].data != nullptr && gb_minmax256(L, a)) {
+        // MIN / MAX over Decimal256: (top word with the sign flipped, has, the three lower words from high to low)
+        const GbCol& ac = C.arg[a];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!in[u]) continue;
+          const int64_t j = ac.is_scalar ? 0 : row[u];
+          const bool ok = !ac.validity || bit_get(ac.validity, ac.voff + j);
+          const uint64_t* p = (const uint64_t*)ac.data + 4 * j;
+          uint64_t* st = rows_in + li[u] * L.W + L.agg_off[a];
+          st[0] = ok ? (p[3] ^ (1ULL << 63)) : 0; st[1] = ok ? 1 : 0; st[2] = ok ? p[2] : 0; st[3] = ok ? p[1] : 0; st[4] = ok ? p[0] : 0;
+        }
+        continue;
+      }
       if (C.arg[a].data != nullptr && C.arg[a].type == DBHIP_T_STRING) {
         // a String argument (min / max): short values as the canonical inline words, long ones as (len | prefix, ADDRESS of the bytes)
         const GbCol& ac = C.arg[a];
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
           if (mine) gb_minmax_str_locked(L.agg_kind[a] == DBHIP_AGG_MIN, d + L.agg_off[a], v);
           continue;
         }
-        if (gb_sum256(L, a)) {       // five-word totals: every row adds its own words (the wave reduction below is four words wide)
+        if (gb_sum256(L, a) || gb_minmax256(L, a)) {   // five-word states: every row merges its own words (the wave reduction below is four words wide)
           if (mine) gb_atomic_merge(L, a, d + L.agg_off[a], v);
           continue;
         }
@@ -689,6 +703,23 @@ struct ResultPtrs {
   const uint8_t* arena;                  // min / max over String: a long value's state holds the ADDRESS of its bytes inside the arena
 };
 
+// DecimalSumState<true, i256>::add: outside [DECIMAL_MIN, DECIMAL_MAX] (precision 76) is an Overflow error — decided on the exact 320-bit
+// total s[0..5): the fifth word must be the sign extension and |total| <= 10^76 - 1
+__device__ __forceinline__ bool gb_sum256_out_of_range(const uint64_t* s) {
+  const bool neg = (s[3] >> 63) != 0;
+  if (s[4] != (neg ? ~0ULL : 0ULL)) return true;
+  uint64_t m[4] = {s[0], s[1], s[2], s[3]};
+  if (neg) {   // magnitude
+    uint64_t c = 1;
+    for (int q = 0; q < 4; ++q) { const uint64_t t = ~m[q] + c; c = (c && t == 0) ? 1 : 0; m[q] = t; }
+  }
+  // 10^76 - 1 = 0x161BCCA7119915B5_0764B4ABE8652979_7775A5F171950FFF_FFFFFFFFFFFFFFFF (little-endian words)
+  const uint64_t mx[4] = {0xFFFFFFFFFFFFFFFFULL, 0x7775A5F171950FFFULL, 0x0764B4ABE8652979ULL, 0x161BCCA7119915B5ULL};
+  for (int q = 3; q >= 0; --q)
+    if (m[q] != mx[q]) return m[q] > mx[q];
+  return false;
+}
+
 // rows -> result columns (merge_result, aggregate_hashtable.rs:382-408)
 __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64_t* rows_out, int64_t n,
                                                         ResultPtrs P, uint64_t* ctrl) {
@@ -747,20 +778,7 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
           break;
         case DBHIP_AGG_SUM:
           if (L.agg_type[a] == DBHIP_T_DEC256) {
-            // DecimalSumState<true, i256>::add: outside [DECIMAL_MIN, DECIMAL_MAX] (precision 76) is an Overflow error — decided on the
-            // exact 320-bit total: the fifth word must be the sign extension and |total| <= 10^76 - 1
-            const bool neg = (s[3] >> 63) != 0;
-            bool bad = s[4] != (neg ? ~0ULL : 0ULL);
-            uint64_t m[4] = {s[0], s[1], s[2], s[3]};
-            if (neg) {   // magnitude
-              uint64_t c = 1;
-              for (int q = 0; q < 4; ++q) { const uint64_t t = ~m[q] + c; c = (c && t == 0) ? 1 : 0; m[q] = t; }
-            }
-            // 10^76 - 1 = 0x161BCCA7119915B5_0764B4ABE8652979_7775A5F171950FFF_FFFFFFFFFFFFFFFF (little-endian words)
-            const uint64_t mx[4] = {0xFFFFFFFFFFFFFFFFULL, 0x7775A5F171950FFFULL, 0x0764B4ABE8652979ULL, 0x161BCCA7119915B5ULL};
-            bool gt = false, decided = false;
-            for (int q = 3; q >= 0 && !decided; --q) if (m[q] != mx[q]) { gt = m[q] > mx[q]; decided = true; }
-            if (bad || gt) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
+            if (gb_sum256_out_of_range(s)) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
             for (int q = 0; q < 4; ++q) ((uint64_t*)o)[4 * i + q] = s[q];
             break;
           }
@@ -790,6 +808,11 @@ __global__ __launch_bounds__(256) void gb_result_kernel(GbLayout L, const uint64
             } else {
               v[0] = len; v[1] = s[1] ? (uint32_t)(s[0] >> 32) : 0; v[2] = s[1] ? (uint32_t)s[2] : 0; v[3] = s[1] ? (uint32_t)(s[2] >> 32) : 0;
             }
+            break;
+          }
+          if (L.agg_type[a] == DBHIP_T_DEC256) {
+            uint64_t* q = (uint64_t*)o + 4 * i;
+            q[0] = s[1] ? s[4] : 0; q[1] = s[1] ? s[3] : 0; q[2] = s[1] ? s[2] : 0; q[3] = s[1] ? (s[0] ^ (1ULL << 63)) : 0;
             break;
           }
           if (L.agg_words[a] == 3) {   // Decimal128
@@ -895,7 +918,7 @@ __device__ __forceinline__ void set_bit32(void* bm, int64_t i) { atomicOr((uint3
 
 // serialized rows -> state field columns (the key columns are written by gb_result_kernel)
 __global__ __launch_bounds__(256) void gb_state_fields_kernel(GbLayout L, const uint64_t* rows_out, int64_t n, StateFieldPtrs P,
-                                                              uint64_t* ctrl) {
+                                                              uint64_t* ctrl, const uint8_t* arena) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t* r = rows_out + i * L.W;
     int f = 0;
@@ -908,7 +931,11 @@ __global__ __launch_bounds__(256) void gb_state_fields_kernel(GbLayout L, const 
           break;
         case DBHIP_AGG_SUM: {
           const int fw = L.agg_flag[a];
-          if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
+          if (L.agg_type[a] == DBHIP_T_DEC256) {
+            // DecimalSumState<true, i256>: the state IS the running total; outside +-(10^76 - 1) is the Overflow error of add()
+            if (gb_sum256_out_of_range(s)) atomicOr((unsigned long long*)&ctrl[3], 1ULL);
+            if (P.f[f]) for (int q = 0; q < 4; ++q) ((uint64_t*)P.f[f])[4 * i + q] = s[q];
+          } else if (L.agg_words[a] - (fw ? 1 : 0) == 3) {
             const i128 v = (i128)(((u128)s[1] << 64) | s[0]);
             const i128 mx = pow10_i128(38) - 1;
             const bool fits128 = s[2] == ((s[1] >> 63) ? ~0ULL : 0ULL);
@@ -924,7 +951,22 @@ __global__ __launch_bounds__(256) void gb_state_fields_kernel(GbLayout L, const 
           if (P.f[f] && s[1]) set_bit32(P.f[f], i);
           ++f;
           if (P.f[f]) {
-            if (L.agg_words[a] == 3) { ((uint64_t*)P.f[f])[2 * i] = s[1] ? s[2] : 0; ((uint64_t*)P.f[f])[2 * i + 1] = s[1] ? (s[0] ^ (1ULL << 63)) : 0; }
+            if (L.agg_type[a] == DBHIP_T_STRING) {
+              // the value column of the Nullable(String) state: a 16-byte view, long strings by offset into the table's arena (buffer 0)
+              uint32_t* v = (uint32_t*)P.f[f] + 4 * i;
+              const uint32_t len = s[1] ? (uint32_t)s[0] : 0;
+              if (len > 12) {
+                const uint64_t off = s[2] - (uint64_t)arena;
+                if (off >> 32) atomicOr((unsigned long long*)&ctrl[3], 8ULL);
+                v[0] = len; v[1] = (uint32_t)(s[0] >> 32); v[2] = 0; v[3] = (uint32_t)off;
+              } else {
+                v[0] = len; v[1] = s[1] ? (uint32_t)(s[0] >> 32) : 0; v[2] = s[1] ? (uint32_t)s[2] : 0; v[3] = s[1] ? (uint32_t)(s[2] >> 32) : 0;
+              }
+            } else if (L.agg_type[a] == DBHIP_T_DEC256) {
+              uint64_t* q = (uint64_t*)P.f[f] + 4 * i;
+              q[0] = s[1] ? s[4] : 0; q[1] = s[1] ? s[3] : 0; q[2] = s[1] ? s[2] : 0; q[3] = s[1] ? (s[0] ^ (1ULL << 63)) : 0;
+            }
+            else if (L.agg_words[a] == 3) { ((uint64_t*)P.f[f])[2 * i] = s[1] ? s[2] : 0; ((uint64_t*)P.f[f])[2 * i + 1] = s[1] ? (s[0] ^ (1ULL << 63)) : 0; }
             else store_typed(P.f[f], i, L.agg_type[a], s[1] ? ord_decode(s[0], L.agg_type[a]) : 0);
           }
           ++f;
@@ -942,7 +984,7 @@ struct StateFieldCols {
 // state field columns -> the state words of rows_in (the keys were serialized by gb_serialize_kernel with no
 // aggregate arguments): what TransformDeserializer + AggregateFunction::batch_merge consume
 // (aggregator/serde/transform_deserializer.rs; batch_merge of each function, cited above)
-__global__ __launch_bounds__(256) void gb_states_from_fields_kernel(GbLayout L, StateFieldCols F, int64_t n, uint64_t* rows_in) {
+__global__ __launch_bounds__(256) void gb_states_from_fields_kernel(GbLayout L, StateFieldCols F, int64_t n, uint64_t* rows_in, uint64_t* ctrl) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint64_t* r = rows_in + i * L.W;
     int f = 0;
@@ -958,6 +1000,16 @@ __global__ __launch_bounds__(256) void gb_states_from_fields_kernel(GbLayout L, 
           break;
         case DBHIP_AGG_SUM: {
           const int fw = L.agg_flag[a];
+          if (L.agg_type[a] == DBHIP_T_DEC256) {
+            const uint64_t* p = (const uint64_t*)F.f[f].data + 4 * (F.f[f].is_scalar ? 0 : i);
+            ++f;
+            bool seen256 = true;
+            if (fw) { seen256 = bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i); ++f; }
+            for (int q = 0; q < 4; ++q) s[q] = seen256 ? p[q] : 0;
+            s[4] = (seen256 && (p[3] >> 63)) ? ~0ULL : 0;
+            if (fw) s[fw] = seen256 ? 1 : 0;
+            break;
+          }
           gb_load_words(F.f[f], i, w, &valid);
           ++f;
           bool seen = true;
@@ -973,11 +1025,29 @@ __global__ __launch_bounds__(256) void gb_states_from_fields_kernel(GbLayout L, 
         default: {
           bool has = bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i);
           ++f;
-          gb_load_words(F.f[f], i, w, &valid);
+          const GbCol& vc = F.f[f];
           ++f;
           if (L.agg_nullable[a]) { has = has && bit_get((const uint8_t*)F.f[f].data, F.f[f].is_scalar ? 0 : i); ++f; }
-          if (L.agg_words[a] == 3) { s[0] = w[1] ^ (1ULL << 63); s[2] = w[0]; }
-          else s[0] = ord_encode(w[0], L.agg_type[a]);
+          if (L.agg_type[a] == DBHIP_T_STRING) {
+            // the Nullable(String) state column: short values as the canonical inline words, long ones as (len | prefix, ADDRESS)
+            const int64_t j = vc.is_scalar ? 0 : i;
+            const uint32_t* v = (const uint32_t*)vc.data + 4 * j;
+            const uint32_t len = v[0];
+            uint64_t ww[2] = {0, 0};
+            if (has) {
+              if (len <= 12) { bool vv; gb_load_words(vc, i, ww, &vv); }
+              else if (vc.buffers) { ww[0] = ((uint64_t)v[1] << 32) | len; ww[1] = (uint64_t)((const uint8_t*)vc.buffers[v[2]] + v[3]); }
+              else { has = false; atomicOr((unsigned long long*)&ctrl[3], 2ULL); }   // a long view without data buffers: the merge reports it
+            }
+            s[0] = has ? ww[0] : 0; s[2] = has ? ww[1] : 0;
+          } else if (L.agg_type[a] == DBHIP_T_DEC256) {
+            const uint64_t* p = (const uint64_t*)vc.data + 4 * (vc.is_scalar ? 0 : i);
+            s[0] = p[3] ^ (1ULL << 63); s[2] = p[2]; s[3] = p[1]; s[4] = p[0];
+          } else {
+            gb_load_words(vc, i, w, &valid);
+            if (L.agg_words[a] == 3) { s[0] = w[1] ^ (1ULL << 63); s[2] = w[0]; }
+            else s[0] = ord_encode(w[0], L.agg_type[a]);
+          }
           s[1] = has ? 1 : 0;
         } break;
       }
@@ -1057,12 +1127,13 @@ int32_t build_layout(const int32_t* key_types, const uint8_t* key_nullable, int 
         if (d.arg_nullable) L->agg_flag[a] = words++;   // "seen a non-NULL row" (AggregateNullUnaryAdaptor<true>)
         break;
       case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
-        if (!key_type_ok(d.arg_type) || d.arg_type == DBHIP_T_DEC256) {
+        if (!key_type_ok(d.arg_type)) {
           set_error("groupby: min/max on type %d stays on the CPU operator", d.arg_type);
           return DBHIP_ERR_UNSUPPORTED;
         }
-        // (value, has) — Decimal128: (high word, has, low word); String: (len | prefix, has, tail or address of the bytes), gb_device.h
-        words = (d.arg_type == DBHIP_T_DEC128 || d.arg_type == DBHIP_T_STRING) ? 3 : 2;
+        // (value, has) — Decimal128: (high word, has, low word); String: (len | prefix, has, tail or address of the bytes); Decimal256:
+        // (top word, has, three lower words), gb_device.h
+        words = d.arg_type == DBHIP_T_DEC256 ? GB_MM256_WORDS : (d.arg_type == DBHIP_T_DEC128 || d.arg_type == DBHIP_T_STRING) ? 3 : 2;
         break;
       default:
         set_error("groupby: unknown aggregate kind %d", d.kind);
@@ -1137,20 +1208,8 @@ bool layout_has_str_minmax(const GbLayout& L) {
   return false;
 }
 int32_t refuse_str_minmax_state(const GbLayout& L, const char* fn) {
-  for (int a = 0; a < L.naggs; ++a)
-    if (gb_sum256(L, a)) {
-      set_error("%s: the serialized-state block of sum(Decimal256) is not produced on the device; exchange the table's rows (flush_block / partition_blocks)", fn);
-      return DBHIP_ERR_UNSUPPORTED;
-    }
-  for (int k = 0; k < L.nkeys; ++k)
-    if (L.key_type[k] == DBHIP_T_DEC256) {
-      set_error("%s: Decimal256 group keys in the serialized-state block are not produced on the device; exchange the table's rows", fn);
-      return DBHIP_ERR_UNSUPPORTED;
-    }
-  if (!layout_has_str_minmax(L)) return DBHIP_OK;
-  set_error("%s: the serialized-state block of min / max over String (a borsh Option<String> per group) is not produced on the device; "
-            "keep the CPU operator for the exchange of this aggregate", fn);
-  return DBHIP_ERR_UNSUPPORTED;
+  (void)L; (void)fn;   // (round 5: String min / max, Decimal256 sums, min / max and keys all have their state-block form)
+  return DBHIP_OK;
 }
 // mode 0: sum the (8-byte rounded) sizes of the long values whose bytes lie outside [lo, hi) into *acc;
 // mode 1: copy them into the arena (bump cursor ctrl[8]) and point the state at the copy;
@@ -3260,7 +3319,7 @@ int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys,
       if (es) Fc.f[f].data = (const uint8_t*)Fc.f[f].data + (size_t)done * es;
       else Fc.f[f].data = (const uint8_t*)Fc.f[f].data + (done >> 3);   // CHUNK is a multiple of 8 bits
     }
-    hipLaunchKernelGGL(gb_states_from_fields_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, L, Fc, cn, g->rows_in);
+    hipLaunchKernelGGL(gb_states_from_fields_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, L, Fc, cn, g->rows_in, g->ctrl);
     DBHIP_LAUNCH_CHECK();
     if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
   }
@@ -3448,7 +3507,7 @@ static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8
       SP.f[f] = out_fields_host[f];
       if (SP.f[f] && ftype[f] == DBHIP_T_BOOL) DBHIP_CHECK(hipMemsetAsync(SP.f[f], 0, bm_bytes, s));
     }
-    hipLaunchKernelGGL(gb_state_fields_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, SP, g->ctrl);
+    hipLaunchKernelGGL(gb_state_fields_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, SP, g->ctrl, (const uint8_t*)g->arena);
   }
   DBHIP_LAUNCH_CHECK();
   uint64_t err = 0;

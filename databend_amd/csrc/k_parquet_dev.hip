@@ -6,12 +6,11 @@
 // boundary as k_parquet.hip, whose open() walks run headers, length prefixes and (for compressed chunks) decompresses every page
 // on the CPU. Here the host reads the thrift PAGE HEADERS only (a few dozen bytes per page: sizes, value counts, encodings) and
 // uploads that page table; everything that touches payload bytes runs on the GPU from the HBM copy of the chunk as stored:
-//   dv_inflate_kernel   one wave per page: Snappy raw format (google/snappy format_description.txt) or LZ4 block format
-//                       (lz4_Block_format.md) -> the decompressed IMAGE in HBM. The sequence stream is inherently serial, so the
-//                       wave parses it from an LDS-staged copy of the input and keeps the last 64 KiB of output in an LDS ring
-//                       (both formats' back-references reach at most 65535 bytes with the writers the reference links: snap
-//                       compresses 64 KiB blocks, LZ4 offsets are 16 bits); literal and match bytes are moved by the 64 lanes,
-//                       the ring is written to HBM 16 KiB at a time with 16-byte stores.
+//   dv_inflate_lz_kernel   one wave per page: Snappy raw format (google/snappy format_description.txt) or LZ4 block format
+//                       (lz4_Block_format.md) -> the decompressed IMAGE in HBM. The sequence stream is inherently serial: the wave
+//                       parses it on the scalar unit from register-held chunks of the payload (dv_wave.h), the 64 lanes move literal
+//                       and match bytes through a 16 KiB LDS ring (a short literal and the match behind it in ONE LDS round trip),
+//                       references that reach further back read the image; the ring is written to HBM with 16-byte stores.
 //   dv_levels_kernel    one workgroup per data page of a nullable column: the RLE / bit-packed hybrid walk of the definition
 //                       levels (Encodings.md "RLE/bit-packing hybrid") -> validity bits at the page's rows + the page's count
 //                       of non-null values.
@@ -44,331 +43,8 @@ __device__ __forceinline__ void dv_fail(uint32_t* ctl, uint32_t code) { atomicCA
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ---------------------------------------------------------------------------------------------
-// page decompression: one wave per page
+// page decompression: one wave per page (dv_wave.h)
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t DW = 65536, DWM = DW - 1;    // output ring (the window back-references read from)
-constexpr uint32_t DI = 8192, DIM = DI - 1;     // input ring
-constexpr uint32_t DV_PIECE = 4096;             // bytes moved between two looks at the flush / refill state
-constexpr uint32_t DV_FLUSH = 16384;            // ring bytes written to HBM at a time
-
-struct DvInflate {
-  const uint8_t* srcA;      // 16-byte aligned address at or before the first compressed byte
-  uint32_t q, qend, qload;  // read position / end of input / staged up to (bytes from srcA)
-  uint8_t* dst;             // output in HBM
-  uint32_t cap, op, flushed, sh;  // output size / write position / written to HBM up to / (dst & 15): ring index of byte p = (p + sh) & DWM
-  uint8_t* win;
-  uint8_t* inb;
-  uint32_t lane;
-  bool bad;
-
-  __device__ __forceinline__ void refill() {
-    // as many 1 KiB rows as fit in front of q (everything in [q, qload) stays staged)
-    while (qload < qend && qload + 1024 - (q & ~15u) <= DI) {
-      const uint32_t a = qload + lane * 16;
-      if (a < qend) *(uint4*)(inb + (a & DIM)) = *(const uint4*)(srcA + a);
-      qload += 1024;
-    }
-  }
-  __device__ __forceinline__ void need(uint32_t n) {
-    const uint32_t want = (qend - q) < n ? qend : q + n;
-    if (qload < want) refill();
-  }
-  // byte k after the read position (the caller made sure q + k < qend). The next 64 input bytes sit one per lane in a register
-  // (`la`, lane 0 = position `laq`): headers are parsed with v_readlane instead of an LDS round trip per byte.
-  uint32_t la, laq;
-  __device__ __forceinline__ void look() {
-    need(192);
-    laq = q;
-    la = (uint32_t)inb[(q + lane) & DIM];
-    limits();
-  }
-  __device__ __forceinline__ uint32_t in(uint32_t k) {
-    if (q + k - laq >= 64) look();
-    return (uint32_t)__builtin_amdgcn_readlane((int)la, (int)(q + k - laq));
-  }
-
-  __device__ __forceinline__ uint32_t peek(uint32_t w) const { return (uint32_t)__builtin_amdgcn_readlane((int)la, (int)w); }
-
-  // the common case of match(): len <= 64, 1 <= off <= op, len <= cap - op (checked by the caller) — one LDS read, one LDS write
-  __device__ __forceinline__ void match64(uint32_t len, uint32_t off) {
-    uint32_t j = lane;
-    if (off < 64) {
-      // lane mod off without an integer division: (lane + 0.5) / off is at least 0.5 / 63 away from an integer, far more than
-      // the error of v_rcp_f32, so the truncation is exact
-      const float r = __builtin_amdgcn_rcpf((float)off);
-      j = lane - off * (uint32_t)(((float)lane + 0.5f) * r);
-    }
-    if (lane < len) {
-      const uint8_t v = win[(op - off + j + sh) & DWM];
-      win[(op + lane + sh) & DWM] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    op += len;
-  }
-  // the common case of literal(): len <= 64 staged bytes at input position q + skip
-  __device__ __forceinline__ void literal64(uint32_t len, uint32_t skip) {
-    if (lane < len) win[(op + sh + lane) & DWM] = inb[(q + skip + lane) & DIM];
-    __builtin_amdgcn_wave_barrier();
-    op += len;
-  }
-
-  // Folded bounds of the fast paths, recomputed only when the staging moves (look()): a sequence may take the fast path while
-  // q <= qlim (>= 96 input bytes left and > 64 of them staged) and op <= oplim (>= 96 output bytes of room: a fast sequence writes
-  // at most 60 + 64 of them, checked where it matters)
-  int32_t qlim, oplim;
-  __device__ __forceinline__ void limits() {
-    const int32_t a = (int32_t)qend - 96, b = (int32_t)qload - 65;
-    qlim = a < b ? a : b;
-    oplim = (int32_t)cap - 128;
-  }
-  // literal of `lit` bytes (input position q + skip) followed by a match of `mlen` (both <= 64, the output room checked by the caller;
-  // 1 <= off <= op + lit checked by the caller). When the match cannot see the literal's bytes (its source ends at or before op) both
-  // LDS reads are issued before either write: one LDS round trip for the pair instead of two.
-  __device__ __forceinline__ void pair64(uint32_t lit, uint32_t skip, uint32_t mlen, uint32_t off) {
-    const uint32_t span = mlen < off ? mlen : off;   // distinct source bytes of the match
-    if (off >= lit + span) {
-      uint32_t j = lane;
-      if (off < 64) {
-        const float r = __builtin_amdgcn_rcpf((float)off);
-        j = lane - off * (uint32_t)(((float)lane + 0.5f) * r);
-      }
-      const uint8_t vl = inb[(q + skip + lane) & DIM];
-      const uint8_t vm = win[(op + lit - off + j + sh) & DWM];
-      if (lane < lit) win[(op + sh + lane) & DWM] = vl;
-      if (lane < mlen) win[(op + lit + lane + sh) & DWM] = vm;
-      __builtin_amdgcn_wave_barrier();
-      op += lit + mlen;
-    } else {
-      if (lit) literal64(lit, skip);
-      match64(mlen, off);
-    }
-  }
-
-  __device__ __forceinline__ void flush(bool force) {
-    const uint32_t target = op;
-    const uint32_t a = (flushed + sh) & 15u;
-    if (a && flushed < target) {
-      const uint32_t h = (16 - a) < (target - flushed) ? (16 - a) : (target - flushed);
-      if (lane < h) dst[flushed + lane] = win[(flushed + sh + lane) & DWM];
-      flushed += h;
-    }
-    const uint32_t nvec = (target - flushed) >> 4;
-    if (((flushed + sh) & 15u) == 0) {
-#pragma clang loop unroll(disable)
-      for (uint32_t v = lane; v < nvec; v += 64)
-        *(uint4*)(dst + flushed + 16 * v) = *(const uint4*)(win + ((flushed + sh + 16 * v) & DWM));
-      flushed += nvec << 4;
-    }
-    if (force) {
-      for (uint32_t i = flushed + lane; i < target; i += 64) dst[i] = win[(i + sh) & DWM];
-      flushed = target;
-    }
-  }
-  // `len` input bytes -> output
-  __device__ __forceinline__ void literal(uint32_t len) {
-    if (len > cap - op) { bad = true; return; }
-    while (len) {
-      if (q >= qend) { bad = true; return; }
-      need(DV_PIECE);
-      uint32_t n = (qload < qend ? qload : qend) - q;
-      if (n > len) n = len;
-      if (n > DV_PIECE) n = DV_PIECE;
-#pragma clang loop unroll(disable) vectorize(disable)
-      for (uint32_t i = lane; i < n; i += 64) win[(op + sh + i) & DWM] = inb[(q + i) & DIM];
-      __builtin_amdgcn_wave_barrier();
-      q += n; op += n; len -= n;
-      if (op - flushed >= DV_FLUSH) flush(false);
-    }
-  }
-  // `len` bytes that repeat the output `off` bytes back (they may overlap what is being written: byte i = byte i - off)
-  __device__ __forceinline__ void match(uint32_t len, uint32_t off) {
-    if (off == 0 || off > op || off > 65535u || len > cap - op) { bad = true; return; }
-    while (len) {
-      const uint32_t n = len < DV_PIECE ? len : DV_PIECE;
-#pragma clang loop unroll(disable) vectorize(disable)
-      for (uint32_t b = 0; b < n; b += 64) {
-        // by periodicity out[cur + l] = out[cur - off + (l mod off)]: every source lies before `cur`, so the 64 lanes read
-        // (one LDS instruction) before any of them writes
-        const uint32_t cur = op + b;
-        uint32_t j = lane;
-        if (off < 64) j = lane % off;
-        if (b + lane < n) {
-          const uint8_t v = win[(cur - off + j + sh) & DWM];
-          win[(cur + lane + sh) & DWM] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      op += n; len -= n;
-      if (op - flushed >= DV_FLUSH) flush(false);
-    }
-  }
-};
-
-__global__ __launch_bounds__(64) void dv_inflate_kernel(const DvJob* __restrict__ jobs) {
-  extern __shared__ __align__(16) uint8_t dv_lds[];
-  const DvJob P = jobs[blockIdx.x];
-  const uint32_t lane = threadIdx.x;
-  const uint8_t* src = P.src;
-  uint8_t* dst = P.dst;
-  uint32_t* ctl = P.ctl;
-  const int codec = (int)P.codec;
-  const uint32_t lev = P.lev_len;
-  // levels of a v2 page / a payload stored uncompressed: copied as they are
-  const uint32_t raw = P.compressed ? lev : P.uncomp_len;
-  for (uint32_t i = lane; i < raw; i += 64) dst[i] = src[i];
-  if (!P.compressed || P.uncomp_len == lev) return;
-  DvInflate z;
-  const uint8_t* s0 = src + lev;
-  const uint32_t a0 = (uint32_t)((uintptr_t)s0 & 15u);
-  z.srcA = s0 - a0;
-  z.q = a0; z.qend = a0 + (P.comp_len - lev); z.qload = 0;
-  z.dst = dst + lev; z.cap = P.uncomp_len - lev; z.op = 0; z.flushed = 0; z.sh = (uint32_t)((uintptr_t)z.dst & 15u);
-  z.win = dv_lds; z.inb = dv_lds + DW; z.lane = lane; z.bad = false;
-  z.refill();
-  z.look();
-  if (codec == CODEC_SNAPPY) {
-    // preamble: the uncompressed length as a varint
-    uint64_t total = 0;
-    bool fin = false;
-    for (int k = 0; k < 5 && z.q < z.qend; ++k) {
-      const uint32_t b = z.in(0);
-      z.q += 1;
-      total |= (uint64_t)(b & 0x7F) << (7 * k);
-      if (!(b & 0x80)) { fin = true; break; }
-    }
-    if (!fin || total != (uint64_t)z.cap) z.bad = true;
-    while (!z.bad && z.q < z.qend) {
-      const uint32_t left = z.qend - z.q;
-      if (z.q - z.laq > 58) z.look();
-      const uint32_t w = z.q - z.laq;
-      const uint32_t tag = z.peek(w);
-      const uint32_t kind = tag & 3u;
-      // fast path: a short element that lies whole in the look-ahead register and the staged input, away from both ends (folded
-      // bounds: limits()); a short literal and the copy behind it go as a pair (one LDS round trip)
-      if ((int32_t)z.q <= z.qlim && (int32_t)z.op <= z.oplim) {
-        if (kind == 0) {
-          const uint32_t len = (tag >> 2) + 1;
-          if (w + len + 3 < 64) {                                     // the header behind the literal still lies in the look-ahead register
-            const uint32_t t2 = z.peek(w + 1 + len), k2 = t2 & 3u;
-            if (k2 == 1 || k2 == 2) {
-              uint32_t mlen, off, hdr;
-              if (k2 == 1) { mlen = ((t2 >> 2) & 7u) + 4; off = ((t2 >> 5) << 8) | z.peek(w + 2 + len); hdr = 2; }
-              else { mlen = (t2 >> 2) + 1; off = z.peek(w + 2 + len) | (z.peek(w + 3 + len) << 8); hdr = 3; }
-              if (off != 0 && off <= z.op + len) {
-                z.pair64(len, 1, mlen, off);
-                z.q += 1 + len + hdr;
-                if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
-                continue;
-              }
-            }
-          }
-          if (len <= 60) {
-            z.literal64(len, 1);
-            z.q += 1 + len;
-            if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
-            continue;
-          }
-        } else if (kind != 3) {
-          uint32_t len, off, hdr;
-          if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | z.peek(w + 1); hdr = 2; }
-          else { len = (tag >> 2) + 1; off = z.peek(w + 1) | (z.peek(w + 2) << 8); hdr = 3; }
-          if (off != 0 && off <= z.op) {
-            z.q += hdr;
-            z.match64(len, off);
-            if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
-            continue;
-          }
-        }
-      }
-      if (kind == 0) {
-        uint32_t len = (tag >> 2) + 1, hdr = 1;
-        if (len > 60) {
-          const uint32_t extra = len - 60;  // 1..4 length bytes
-          if (left < 1 + extra) { z.bad = true; break; }
-          uint32_t v = 0;
-          for (uint32_t b = 0; b < extra; ++b) v |= z.in(1 + b) << (8 * b);
-          if (v == 0xFFFFFFFFu) { z.bad = true; break; }
-          len = v + 1;
-          hdr = 1 + extra;
-        }
-        z.q += hdr;
-        z.literal(len);
-      } else if (kind == 1) {
-        if (left < 2) { z.bad = true; break; }
-        const uint32_t len = ((tag >> 2) & 7u) + 4, off = ((tag >> 5) << 8) | z.in(1);
-        z.q += 2;
-        z.match(len, off);
-      } else if (kind == 2) {
-        if (left < 3) { z.bad = true; break; }
-        const uint32_t len = (tag >> 2) + 1, off = z.in(1) | (z.in(2) << 8);
-        z.q += 3;
-        z.match(len, off);
-      } else {
-        if (left < 5) { z.bad = true; break; }
-        const uint32_t len = (tag >> 2) + 1, off = z.in(1) | (z.in(2) << 8) | (z.in(3) << 16) | (z.in(4) << 24);
-        z.q += 5;
-        if (off > 65535u && off <= z.op) { dv_fail(ctl, DV_UNSUPPORTED); return; }  // legal, but no writer the reference links emits it
-        z.match(len, off);
-      }
-    }
-  } else {  // LZ4 block format
-    while (!z.bad && z.q < z.qend) {
-      if (z.q - z.laq > 40) z.look();
-      {
-        // fast path: literal and match lengths without extension bytes, the sequence whole in the look-ahead register and the
-        // staged input, away from the end of the block
-        const uint32_t w = z.q - z.laq;
-        const uint32_t t = z.peek(w);
-        const uint32_t lit = t >> 4, ml = t & 15u;
-        const uint32_t ext = (((t & 15u) + 1) | ((t >> 4) + 1)) & 16u;    // either length nibble is 15
-        if (ext == 0 && (int32_t)z.q <= z.qlim && (int32_t)z.op <= z.oplim) {
-          const uint32_t off = z.peek(w + 1 + lit) | (z.peek(w + 2 + lit) << 8);
-          if (off == 0 || off > z.op + lit) { z.bad = true; break; }
-          z.pair64(lit, 1, ml + 4, off);
-          z.q += 3 + lit;
-          if (z.op - z.flushed >= DV_FLUSH) z.flush(false);
-          continue;
-        }
-      }
-      const uint32_t token = z.in(0);
-      z.q += 1;
-      uint32_t lit = token >> 4;
-      if (lit == 15) {
-        for (;;) {
-          if (z.q >= z.qend) { z.bad = true; break; }
-          const uint32_t b = z.in(0);
-          z.q += 1;
-          if (lit > 0x7FFFFFFFu - b) { z.bad = true; break; }
-          lit += b;
-          if (b != 255) break;
-        }
-        if (z.bad) break;
-      }
-      if (lit) z.literal(lit);
-      if (z.bad || z.q >= z.qend) break;  // the last sequence ends with its literals
-      if (z.qend - z.q < 2) { z.bad = true; break; }
-      const uint32_t off = z.in(0) | (z.in(1) << 8);
-      z.q += 2;
-      uint32_t ml = token & 15u;
-      if (ml == 15) {
-        for (;;) {
-          if (z.q >= z.qend) { z.bad = true; break; }
-          const uint32_t b = z.in(0);
-          z.q += 1;
-          if (ml > 0x7FFFFFFFu - b - 4) { z.bad = true; break; }
-          ml += b;
-          if (b != 255) break;
-        }
-        if (z.bad) break;
-      }
-      z.match(ml + 4, off);
-    }
-  }
-  if (!z.bad && z.op != z.cap) z.bad = true;
-  z.flush(true);
-  if (z.bad) dv_fail(ctl, DV_CORRUPT);
-}
-
 // ZSTD: one wave per page (dv_wave.h, zstd_core.h)
 __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __restrict__ jobs) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
@@ -1018,8 +694,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   }
   if (live.empty()) return DBHIP_OK;
   static const bool lds_ok = [] {
-    return hipFuncSetAttribute((const void*)dv_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DW + DI)) == hipSuccess &&
-           hipFuncSetAttribute((const void*)dv_inflate_lz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_RING) == hipSuccess &&
+    return hipFuncSetAttribute((const void*)dv_inflate_lz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_RING) == hipSuccess &&
            hipFuncSetAttribute((const void*)dv_inflate_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW_LDS) == hipSuccess;
   }();
   if (!lds_ok) { set_error("%s: cannot reserve LDS for the decompression kernels", who); return DBHIP_ERR_HIP; }
@@ -1123,11 +798,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   }
   kernel_timer_start(s);
   if (n_z) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), ZW_LDS, s, d_jobs);
-  static const bool old_lz = getenv("DBHIP_PQ_OLD_INFLATE") != nullptr;   // (round-4 kernel, kept for one A/B measurement)
-  if (n_jobs > n_z) {
-    if (old_lz) hipLaunchKernelGGL(dv_inflate_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), DW + DI, s, d_jobs + n_z);
-    else hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), LZ_RING, s, d_jobs + n_z);
-  }
+  if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), LZ_RING, s, d_jobs + n_z);
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
   if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));
   hipLaunchKernelGGL(dv_scan_kernel, dim3((unsigned)nl), dim3(256), 0, s, d_cds);

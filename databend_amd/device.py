@@ -880,12 +880,20 @@ class GroupBy:
         n = n.value
         keys = [Column(t, n, b, v if nul else None) for t, b, v, nul in zip(self.key_types, key_bufs, key_val, self.key_nullable)]
         states = []
+        arena_ptrs = None
         for (t, a), b in zip(fields, fbufs):
             kind, at, p, sc, _nul = self.aggs[a]
             prec, scale = (0, 0)
-            if t in (L.T_DEC64, L.T_DEC128):
-                prec, scale = ((18 if t == L.T_DEC64 else 38), sc) if kind == L.AGG_SUM else (p, sc)
-            states.append(Column(t, n, b, None, prec, scale))
+            if t in (L.T_DEC64, L.T_DEC128, L.T_DEC256):
+                prec, scale = ({L.T_DEC64: 18, L.T_DEC128: 38, L.T_DEC256: 76}[t], sc) if kind == L.AGG_SUM else (p, sc)
+            if t == L.T_STRING:
+                # the value buffer of a Nullable(String) state (min / max over String): long views point into the table's arena
+                # (buffer 0; valid until the table is reset, destroyed or takes more rows)
+                if arena_ptrs is None:
+                    arena_ptrs = DeviceBuffer.from_numpy(np.array([self.arena()[0] or 0], dtype=np.uint64))
+                states.append(Column(t, n, b, None, buffers=arena_ptrs))
+            else:
+                states.append(Column(t, n, b, None, prec, scale))
         return keys, states
 
     def arena(self):

@@ -791,10 +791,17 @@ static int agg_state_size(const orc_agg_desc* d) {
   if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC256) return d->arg_nullable ? 40 : 32; /* DecimalSumState<_, i256>: [u64; 4] */
   if (d->kind == ORC_AGG_SUM && d->arg_type == ORC_T_DEC128) return d->arg_nullable ? 32 : 16;
   if (d->kind == ORC_AGG_SUM && d->arg_nullable) return 16; /* value + flag */
+  if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_DEC256) return 48; /* Option<[u64; 4]> (aggregate_min_max_any_decimal.rs:40-43): value + has */
   if (d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) return (d->arg_type == ORC_T_DEC128 || d->arg_type == ORC_T_STRING) ? 32 : 16; /* value + has flag (Decimal128: 16-byte value; String: offset + length into the table's bytes) */
   return 8;
 }
-static int mm_has_off(const orc_agg_desc* d) { return (d->arg_type == ORC_T_DEC128 || d->arg_type == ORC_T_STRING) ? 16 : 8; } /* MinMaxAnyState: Option<value> */
+static int mm_has_off(const orc_agg_desc* d) { return d->arg_type == ORC_T_DEC256 ? 32 : (d->arg_type == ORC_T_DEC128 || d->arg_type == ORC_T_STRING) ? 16 : 8; } /* MinMaxAnyState: Option<value> */
+/* i256 order on four little-endian u64: the top word signed, the rest unsigned */
+static int i256w_cmp(const uint64_t* a, const uint64_t* b) {
+  if (a[3] != b[3]) return (int64_t)a[3] < (int64_t)b[3] ? -1 : 1;
+  for (int q = 2; q >= 0; --q) if (a[q] != b[q]) return a[q] < b[q] ? -1 : 1;
+  return 0;
+}
 
 static void index_alloc(orc_hashagg* h, size_t cap) {
   h->capacity = cap; h->mask = cap - 1; h->count = 0;
@@ -987,6 +994,16 @@ static int state_add(orc_hashagg* h, const orc_agg_desc* d, uint8_t* st, const o
         hs = 1; memcpy(st + 16, &hs, 8);
         return 0;
       }
+      if (d->arg_type == ORC_T_DEC256) { /* MinMaxAnyDecimalState<i256>::add (aggregate_min_max_any_decimal.rs:61-76): change_if = new < / > current */
+        uint64_t has256; memcpy(&has256, st + 32, 8);
+        uint64_t v[4], cur[4];
+        memcpy(v, (const uint8_t*)arg->data + 32 * (arg->is_scalar ? 0 : i), 32);
+        memcpy(cur, st, 32);
+        int c = i256w_cmp(v, cur);
+        if (!has256 || (d->kind == ORC_AGG_MIN ? c < 0 : c > 0)) memcpy(st, v, 32);
+        has256 = 1; memcpy(st + 32, &has256, 8);
+        return 0;
+      }
       if (d->arg_type == ORC_T_DEC128) {
         uint64_t has128; memcpy(&has128, st + 16, 8);
         i128 v128, cur128;
@@ -1129,6 +1146,10 @@ int orc_hashagg_result_nullable(orc_hashagg* h, void* const* out_keys, uint8_t* 
           if (clen <= 12) memcpy(v + 4, h->strs + coff, (size_t)clen); else memcpy(v + 8, &coff, 8);
         }
       }
+      else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_DEC256) {
+        uint64_t hs; memcpy(&hs, st + 32, 8);
+        if (hs) memcpy((uint8_t*)out_aggs[a] + 32 * r, st, 32); else memset((uint8_t*)out_aggs[a] + 32 * r, 0, 32); /* push_default() */
+      }
       else if ((d->kind == ORC_AGG_MIN || d->kind == ORC_AGG_MAX) && d->arg_type == ORC_T_DEC128) {
         uint64_t hs; memcpy(&hs, st + 16, 8);
         if (hs) memcpy((uint8_t*)out_aggs[a] + 16 * r, st, 16); else memset((uint8_t*)out_aggs[a] + 16 * r, 0, 16); /* push_default() */
@@ -1244,8 +1265,8 @@ int orc_hashagg_combine(orc_hashagg* dst, orc_hashagg* src) {
             orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ORC_T_STRING; tmp.is_scalar = 1; tmp.data = view; tmp.buffers = bufs;
             state_add(dst, ad, d, &tmp, 0);
           }
-        } else if (ad->arg_type == ORC_T_DEC128) {
-          uint64_t hs; memcpy(&hs, sp + 16, 8);
+        } else if (ad->arg_type == ORC_T_DEC128 || ad->arg_type == ORC_T_DEC256) {
+          uint64_t hs; memcpy(&hs, sp + mm_has_off(ad), 8);
           if (hs) { orc_col tmp; memset(&tmp, 0, sizeof tmp); tmp.type = ad->arg_type; tmp.is_scalar = 1; tmp.data = sp; state_add(dst, ad, d, &tmp, 0); }
         } else {
           uint64_t hs; memcpy(&hs, sp + 8, 8);
@@ -1319,9 +1340,29 @@ int orc_hashagg_flush_state_block(orc_hashagg* h, void* const* out_keys, uint8_t
       const uint8_t* st = h->states + soff + h->state_off[a];
       if (d->kind == ORC_AGG_COUNT) { memcpy((uint8_t*)out_fields[f] + 8 * r, st, 8); ++f; }
       else if (d->kind == ORC_AGG_SUM) {
-        if (d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_fields[f] + 16 * r, st, 16); else memcpy((uint8_t*)out_fields[f] + 8 * r, st, 8);
+        if (d->arg_type == ORC_T_DEC256) memcpy((uint8_t*)out_fields[f] + 32 * r, st, 32);
+        else if (d->arg_type == ORC_T_DEC128) memcpy((uint8_t*)out_fields[f] + 16 * r, st, 16); else memcpy((uint8_t*)out_fields[f] + 8 * r, st, 8);
         ++f;
         if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = st[agg_flag_off(d)]; ++f; }
+      } else if (d->arg_type == ORC_T_STRING) {
+        /* MinMaxStringState: serialize_type = [Nullable(String)] (aggregate_min_max_any.rs:163-181) — here its two buffers as two fields:
+         * the validity (has a value) and the values, 16 bytes per group in orc_hashagg_result's form (u32 length, the bytes when they fit
+         * 12, else at +8 the u64 offset into orc_hashagg_bytes) */
+        uint64_t hs, coff, clen; memcpy(&hs, st + 16, 8); memcpy(&coff, st, 8); memcpy(&clen, st + 8, 8);
+        ((uint8_t*)out_fields[f])[r] = hs != 0; ++f;
+        uint8_t* v = (uint8_t*)out_fields[f] + 16 * r; memset(v, 0, 16);
+        if (hs) {
+          uint32_t l32 = (uint32_t)clen; memcpy(v, &l32, 4);
+          if (clen <= 12) memcpy(v + 4, h->strs + coff, (size_t)clen); else memcpy(v + 8, &coff, 8);
+        }
+        ++f;
+        if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = hs != 0; ++f; }
+      } else if (d->arg_type == ORC_T_DEC256) { /* [Nullable(Decimal256)] (aggregate_min_max_any_decimal.rs:140-147): validity, values */
+        uint64_t hs; memcpy(&hs, st + 32, 8);
+        ((uint8_t*)out_fields[f])[r] = hs != 0; ++f;
+        if (hs) memcpy((uint8_t*)out_fields[f] + 32 * r, st, 32); else memset((uint8_t*)out_fields[f] + 32 * r, 0, 32);
+        ++f;
+        if (d->arg_nullable) { ((uint8_t*)out_fields[f])[r] = hs != 0; ++f; }
       } else if (d->arg_type == ORC_T_DEC128) {
         uint64_t hs; memcpy(&hs, st + 16, 8);
         ((uint8_t*)out_fields[f])[r] = hs != 0; ++f;
@@ -1397,6 +1438,10 @@ int orc_hashagg_merge_state_block(orc_hashagg* h, const orc_col* keys, const orc
           if (!seen) continue; /* the adaptor's batch_merge filters the nested merge on the flag (:542-575) */
           if (agg_flag_off(ad)) d[agg_flag_off(ad)] = 1;
           int64_t j = vf->is_scalar ? 0 : i;
+          if (ad->arg_type == ORC_T_DEC256) {
+            uint64_t x[4], y[4]; memcpy(x, d, 32); memcpy(y, (const uint8_t*)vf->data + 32 * j, 32); i256w_add(x, y); memcpy(d, x, 32);
+            if (i256w_out_of_range(x)) rc = 5;
+          } else
           if (ad->arg_type == ORC_T_DEC128) { /* DecimalSumState batch_merge -> merge -> add with the overflow check */
             i128 x, y; memcpy(&x, d, 16); memcpy(&y, (const uint8_t*)vf->data + 16 * j, 16); x = (i128)((u128)x + (u128)y); memcpy(d, &x, 16);
             i128 mx = e10(38) - 1; if (ad->arg_precision > 18 && (x > mx || x < -mx)) rc = 5;

@@ -67,7 +67,8 @@ def test_min_max_over_strings_equal_the_oracle(gpu, oracle, n, card, maxlen):
 def test_string_states_merge_between_live_tables_and_do_not_travel(gpu, oracle):
     """TransformFinalAggregate's merge of partial tables (dbhip_groupby_flush_serialized -> dbhip_groupby_merge_serialized, both tables
     alive in this process): the receiving table copies the winners into ITS arena, so the result survives the source table. The exchange
-    forms that would carry an address out of the process (blocks, partitions, the serialized-state block) are refused."""
+    forms that would carry an address out of the process (fixed-size blocks, partitions) are refused; the serialized-state block is the
+    form that travels (a Nullable(String) column with the table's arena as its data buffer)."""
     D = gpu
     rng = np.random.default_rng(5)
     n = 30_000
@@ -94,5 +95,6 @@ def test_string_states_merge_between_live_tables_and_do_not_travel(gpu, oracle):
     import ctypes as C
     block = D.DeviceBuffer(8 * 64 * 1024)
     assert T.lib().dbhip_groupby_flush_block(final.h, C.c_void_p(block.ptr), C.c_int64(1000), None) == T.ERR_UNSUPPORTED
+    # (round 5: the serialized-state block carries the strings as a Nullable(String) column — tests/test_gpu_state_block_wide.py)
     nf = C.c_int32()
-    assert T.lib().dbhip_groupby_state_fields(final.h, None, None, 0, C.byref(nf)) == T.ERR_UNSUPPORTED
+    assert T.lib().dbhip_groupby_state_fields(final.h, None, None, 0, C.byref(nf)) == 0 and nf.value == 5

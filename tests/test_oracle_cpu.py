@@ -675,3 +675,95 @@ def test_sort_bound_partition_against_a_python_comparator():
                                           d, f, 2, C.c_int64(n), C.c_int64(nb), out.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)) == 0
         exp = [sum(1 for j in bidx if cmp(rows[j], r) < 0) for r in rows]
         assert out.tolist() == exp and cnt.tolist() == np.bincount(exp, minlength=nb + 1).tolist()
+
+
+def test_min_max_over_decimal256_and_the_wide_state_blocks_closed_form():
+    """MinMaxAnyDecimalState<i256> (aggregate_min_max_any_decimal.rs:45-138) and the state-block forms of the wide states — min / max over
+    String as [validity][Nullable(String) values] (aggregate_min_max_any.rs:163-205), sum / min / max over Decimal256 — in the oracle against
+    plain Python: partial tables -> flush_state_block -> merge_state_block into a final table == Python's min / max / sum per group."""
+    import ctypes as C
+    from databend_amd.device import ints_to_limbs, limbs_to_ints, make_views_general, pack_bits
+    L = O.load()
+    rng = np.random.default_rng(77)
+    n, card = 6000, 9
+    aggs = [(T.AGG_MIN, T.T_DEC256, 76, 2, 0), (T.AGG_MAX, T.T_DEC256, 76, 2, 1), (T.AGG_SUM, T.T_DEC256, 76, 2, 0), (T.AGG_MAX, T.T_STRING, 0, 0, 1)]
+    keys = rng.integers(0, card, n).astype(np.int64)
+    vals = [int(a) * 10**40 + int(b) for a, b in zip(rng.integers(-10**17, 10**17, n), rng.integers(0, 10**18, n))]
+    valid = rng.random(n) > 0.3
+    valid[keys == 4] = False
+    strs = [b"value-%05d-long-enough-to-leave-the-view" % int(i) if i % 3 else b"s%d" % int(i) for i in rng.integers(0, 10**5, n)]
+
+    def table():
+        kt = (C.c_int32 * 1)(T.T_I64)
+        ad = (O.OAgg * len(aggs))()
+        for i, a in enumerate(aggs):
+            ad[i].kind, ad[i].arg_type, ad[i].arg_precision, ad[i].arg_scale, ad[i].arg_nullable = a
+        L.orc_hashagg_create.restype = C.c_void_p
+        return C.c_void_p(L.orc_hashagg_create(kt, None, 1, ad, len(aggs)))
+    L.orc_hashagg_bytes.restype = C.c_void_p
+    final = table()
+    nf = L.orc_hashagg_state_fields(final, None, None)
+    ft = (C.c_int32 * nf)()
+    L.orc_hashagg_state_fields(final, ft, None)
+    assert list(ft) == [T.T_BOOL, T.T_DEC256, T.T_BOOL, T.T_DEC256, T.T_BOOL, T.T_DEC256, T.T_BOOL, T.T_STRING, T.T_BOOL]
+    for lo, hi in ((0, 1000), (1000, 2500), (2500, n)):
+        part = table()
+        v, buf = make_views_general(strs[lo:hi])
+        hv = O.HostCol(T.T_DEC256, ints_to_limbs(vals[lo:hi], 256), None, 76, 2)
+        hvn = O.HostCol(T.T_DEC256, ints_to_limbs(vals[lo:hi], 256), valid[lo:hi], 76, 2)
+        hs = O.HostCol(T.T_STRING, v, valid[lo:hi], buffers=[buf])
+        args = (O.OCol * 4)(hv.c(), hvn.c(), hv.c(), hs.c())
+        assert L.orc_hashagg_add_block(part, O.cols([O.HostCol(T.T_I64, keys[lo:hi])]), args, C.c_int64(hi - lo)) == 0
+        m = L.orc_hashagg_num_groups(part)
+        kb = np.zeros(m * 8 + 16, np.uint8)
+        fb = [np.zeros(m * 32 + 32, np.uint8) for _ in range(nf)]
+        kp = (C.c_void_p * 1)(kb.ctypes.data)
+        fp = (C.c_void_p * nf)(*[b.ctypes.data for b in fb])
+        assert L.orc_hashagg_flush_state_block(part, kp, None, fp, None) == 0
+        blen = C.c_int64()
+        base = L.orc_hashagg_bytes(part, C.byref(blen))
+        store = np.frombuffer(C.string_at(base, blen.value) if blen.value else b"\0" * 16, np.uint8).copy()
+        cols = []
+        for t, b in zip(ft, fb):
+            if t == T.T_BOOL:
+                cols.append(O.HostCol(T.T_BOOL, np.concatenate([pack_bits(b[:m].astype(bool)), np.zeros(8, np.uint8)])))
+            elif t == T.T_STRING:
+                vv = b[:16 * m].reshape(-1, 16).copy()
+                for i in range(m):
+                    ln = int(vv[i, :4].view(np.uint32)[0])
+                    if ln > 12:
+                        off = int(vv[i, 8:16].view(np.uint64)[0])
+                        vv[i, 4:8] = store[off:off + 4]
+                        vv[i, 8:12] = 0
+                        vv[i, 12:16] = np.frombuffer(np.uint32(off).tobytes(), np.uint8)
+                cols.append(O.HostCol(T.T_STRING, vv, buffers=[store]))
+            else:
+                cols.append(O.HostCol(T.T_DEC256, b[:32 * m].copy(), None, 76, 2))
+        assert L.orc_hashagg_merge_state_block(final, O.cols([O.HostCol(T.T_I64, kb[:8 * m].view(np.int64).copy())]), O.cols(cols), C.c_int64(m)) == 0
+        L.orc_hashagg_destroy(part)
+    g = L.orc_hashagg_num_groups(final)
+    assert g == card
+    kb = np.zeros(g * 8 + 16, np.uint8)
+    ab = [np.zeros(g * 32 + 32, np.uint8) for _ in aggs]
+    av = [np.ones(g + 8, np.uint8) for _ in aggs]
+    assert L.orc_hashagg_result_nullable(final, (C.c_void_p * 1)(kb.ctypes.data), None, (C.c_void_p * 4)(*[b.ctypes.data for b in ab]),
+                                         (C.c_void_p * 4)(*[b.ctypes.data for b in av]), None) == 0
+    blen = C.c_int64()
+    base = L.orc_hashagg_bytes(final, C.byref(blen))
+    store = C.string_at(base, blen.value) if blen.value else b""
+    gk = kb[:8 * g].view(np.int64)
+    mins, maxs, sums = limbs_to_ints(ab[0][:32 * g], 256), limbs_to_ints(ab[1][:32 * g], 256), limbs_to_ints(ab[2][:32 * g], 256)
+    for i in range(g):
+        k = int(gk[i])
+        rows = [j for j in range(n) if keys[j] == k]
+        assert mins[i] == min(vals[j] for j in rows) and sums[i] == sum(vals[j] for j in rows)
+        vr = [j for j in rows if valid[j]]
+        ln = int(ab[3][16 * i:16 * i + 4].view(np.uint32)[0])
+        off = int(ab[3][16 * i + 8:16 * i + 16].view(np.uint64)[0])
+        got_s = bytes(ab[3][16 * i + 4:16 * i + 4 + ln]) if ln <= 12 else store[off:off + ln]
+        if vr:
+            assert av[1][i] == 1 and maxs[i] == max(vals[j] for j in vr)
+            assert av[3][i] == 1 and got_s == max(strs[j] for j in vr)
+        else:
+            assert k == 4 and av[1][i] == 0 and av[3][i] == 0
+    L.orc_hashagg_destroy(final)
