@@ -573,8 +573,17 @@ int32_t dbhip_groupby_flush_result_nullable(dbhip_groupby* g, void* const* out_k
  * of its serialize_type(), flattened in aggregate order, then the group columns:
  *   count                         [UInt64]                                   (aggregate_count.rs:170-186)
  *   sum                           [result type: Int64/UInt64/Float64/Decimal] (aggregate_sum.rs:155-168,281-298)
- *   min / max                     [Boolean has-value][T value, default if none] (aggregate_min_max_any.rs:315-346)
+ *   min / max (numbers, dates)    [Boolean has-value][T value, default if none] (aggregate_min_max_any.rs:315-346)
+ *   min / max over Decimal        ONE Nullable(Decimal) column (aggregate_min_max_any_decimal.rs:140-190) — its two buffers as two fields:
+ *                                 [Boolean validity = has-value][Decimal values, 0 if none]; Decimal256 values are 32 bytes
+ *   min / max over String         ONE Nullable(String) column (aggregate_min_max_any.rs:163-205, NOT borsh) — [Boolean validity]
+ *                                 [String values]: 16-byte views, the long form {len, prefix, buffer 0, offset} with buffer 0 = the
+ *                                 table's arena (dbhip_groupby_arena); merge_state_block takes such a field as a String dbhip_col with
+ *                                 its `buffers`, and copies the winners into the receiving table's arena
+ *   sum over Decimal256           [Decimal256 total] (aggregate_sum.rs:281-298 with T = i256; DBHIP_ERR_OVERFLOW outside +-(10^76 - 1))
  *   sum/min/max, NULLABLE argument: the fields above + a trailing [Boolean flag]  (aggregate_null_adaptor.rs:508-540)
+ * (A binding that builds the reference's block wraps a [Boolean validity][T values] pair of a Decimal / String min / max into one
+ * NullableColumn; for numbers and dates the two fields stay two columns, as the reference's serialize_type says.)
  * Boolean fields are LSB-first bitmaps of ceil(max_rows/64)*8 bytes. dbhip_groupby_state_fields lists the fields of a
  * table (type and owning aggregate). flush_state_block writes the block (a device partial aggregate feeding the
  * UNMODIFIED CPU final stage / Flight exchange); merge_state_block consumes one (TransformDeserializer +
