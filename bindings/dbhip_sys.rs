@@ -278,6 +278,8 @@ extern "C" {
     pub fn dbhip_shuffle_exchange_begin(c: *mut dbhip_comm, keys: *const dbhip_col, nkeys: i32, cols: *const dbhip_col, ncols: i32, n: i64, out_recv_rows_host: *mut i64, out_host: *mut *mut dbhip_exchange, stream: *mut c_void) -> i32;
     pub fn dbhip_sort_exchange_begin(c: *mut dbhip_comm, keys: *const dbhip_col, bounds: *const dbhip_col, desc_host: *const u8, nulls_first_host: *const u8, nkeys: i32, nbounds: i64, cols: *const dbhip_col, ncols: i32, n: i64, out_recv_rows_host: *mut i64, out_host: *mut *mut dbhip_exchange, stream: *mut c_void) -> i32;
     pub fn dbhip_exchange_finish(x: *mut dbhip_exchange, out_data_host: *const *mut c_void, out_validity_host: *const *mut u8, out_src_starts_host: *mut i64, stream: *mut c_void) -> i32;
+    pub fn dbhip_exchange_string_bytes(x: *mut dbhip_exchange, out_bytes_host: *mut i64) -> i32;
+    pub fn dbhip_exchange_finish_strings(x: *mut dbhip_exchange, out_data_host: *const *mut c_void, out_validity_host: *const *mut u8, out_string_bytes_host: *const *mut u8, out_src_starts_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_exchange_destroy(x: *mut dbhip_exchange) -> i32;
     pub fn dbhip_vec_topk_allgather(c: *mut dbhip_comm, idx_dev: *const u32, dist_dev: *const f32, nq: i32, k: i32, row_offset: u64, out_idx_dev: *mut u32, out_dist_dev: *mut f32, stream: *mut c_void) -> i32;
     pub fn dbhip_kmeans(distance_type: i32, data: *const f32, rows: i64, dim: i32, rows_per_cluster: i64, normalize_input: i32, out_assignments: *mut u32, out_distances: *mut f32, out_k_host: *mut i64, out_iterations_host: *mut i32, stream: *mut c_void) -> i32;

@@ -12,6 +12,7 @@
 // loads it. xGMI is point to point (7 links per GPU): the all-to-all is ncclSend / ncclRecv pairs inside one group so that all
 // links carry traffic at once; blocks are fixed-size so the collective needs no size negotiation.
 #include "runtime.h"
+#include "dev_scan.h"
 
 #include <dlfcn.h>
 #include <string.h>
@@ -52,7 +53,12 @@ int32_t load_rccl() {
   if (g_rccl.lib) return DBHIP_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
-  for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  // an RCCL the host process already holds (a PyTorch host ships its own librccl.so) is the one to use: two copies in one process
+  // tear each other's state down at exit (seen as "double free or corruption" when the tests of this file and torch-using ones share
+  // a process)
+  for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  if (!h)
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!h) { set_error("dbhip_comm: librccl.so not found (%s)", dlerror()); return DBHIP_ERR_UNSUPPORTED; }
 #define SYM(field, name)                                                                                   \
   do {                                                                                                     \
@@ -243,6 +249,70 @@ __global__ __launch_bounds__(256) void topk_regroup_kernel(const T* __restrict__
   }
 }
 
+// ---- long strings in the exchange (round 5; flight_scatter_hash.rs:57-120 moves whole blocks, strings included) ----------------------
+// views (16 bytes) -> bytes of the long form per row (0 for inline strings)
+__global__ __launch_bounds__(256) void xs_long_len_kernel(const uint32_t* __restrict__ views, int64_t n, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t len = views[4 * i];
+    out[i] = len > 12 ? len : 0u;
+  }
+}
+// the long strings of the scattered rows, copied back to back in row order into `packed` (off[i] = where row i's bytes go), and the view
+// rewritten to {len, prefix, buffer 0, offset inside its DESTINATION's piece}. One wave per 64 rows: the lanes copy one row's bytes together.
+__global__ __launch_bounds__(256) void xs_pack_kernel(uint32_t* __restrict__ views, int64_t n, const uint64_t* __restrict__ off,
+                                                      const void* const* __restrict__ buffers, const int64_t* __restrict__ dest_start, int world,
+                                                      uint8_t* __restrict__ packed, uint32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const int64_t i = base + lane;
+    uint32_t len = 0, bufi = 0, boff = 0;
+    uint64_t o = 0;
+    if (i < n) { len = views[4 * i]; bufi = views[4 * i + 2]; boff = views[4 * i + 3]; o = off[i]; }
+    const bool lng = len > 12;
+    // the destination whose piece row i belongs to: the last d with dest_start[d] <= i
+    uint64_t piece0 = 0;
+    if (lng) {
+      int lo = 0, hi = world;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (dest_start[mid] <= i) lo = mid; else hi = mid; }
+      piece0 = off[dest_start[lo]];
+    }
+    uint64_t todo = __ballot(lng);
+    while (todo) {
+      const int r = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t rl = __shfl(len, r, 64);
+      const uint8_t* src = (const uint8_t*)buffers[__shfl(bufi, r, 64)] + __shfl(boff, r, 64);
+      uint8_t* dst = packed + __shfl(o, r, 64);
+      for (uint32_t b = lane; b < rl; b += 64) dst[b] = src[b];
+    }
+    if (lng) {
+      const uint64_t rel = o - piece0;
+      if (rel >> 32) atomicOr(err, 1u);   // a piece of 4 GiB or more: a view's offset is 32 bits
+      views[4 * i + 2] = 0;
+      views[4 * i + 3] = (uint32_t)rel;
+    }
+  }
+}
+// out[p] = off[idx[p]] for a handful of positions (the byte offset at which every destination's piece starts)
+__global__ void xs_pick_kernel(const uint64_t* __restrict__ off, const int64_t* __restrict__ idx, int n, uint64_t* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) out[p] = off[idx[p]];
+}
+// received views of source p (rows [row_start[p], row_start[p + 1])): offsets were relative to p's piece -> relative to the packed buffer
+__global__ __launch_bounds__(256) void xs_rebase_kernel(uint32_t* __restrict__ views, int64_t n, const int64_t* __restrict__ row_start,
+                                                        const uint64_t* __restrict__ byte_start, int world, uint32_t* __restrict__ err) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (views[4 * i] <= 12) continue;
+    int lo = 0, hi = world;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_start[mid] <= i) lo = mid; else hi = mid; }
+    const uint64_t o = (uint64_t)views[4 * i + 3] + byte_start[lo];
+    if (o >> 32) atomicOr(err, 1u);
+    views[4 * i + 2] = 0;
+    views[4 * i + 3] = (uint32_t)o;
+  }
+}
+
 }  // namespace
 
 // One exchange of a block between all ranks (see dbhip.h): the scattered columns and the counts between begin and finish
@@ -254,6 +324,11 @@ struct dbhip_exchange {
   std::vector<uint8_t*> svalid;
   std::vector<int64_t> send_start, recv_start;   // [world + 1] rows
   void* counts_dev = nullptr;
+  // String columns with data buffers: the long bytes of every destination's rows, packed (begin), and how many arrive from whom
+  std::vector<int> str_cols;                       // columns that carry long strings
+  std::vector<uint8_t*> spacked;                   // per such column: the packed send bytes
+  std::vector<std::vector<uint64_t>> sbyte_start;  // per such column: [world + 1] byte offsets of the destinations' pieces in spacked
+  std::vector<std::vector<uint64_t>> rbyte_start;  // per such column: [world + 1] byte offsets of the sources' pieces in the output buffer
 };
 
 extern "C" {
@@ -262,6 +337,7 @@ int32_t dbhip_exchange_destroy(dbhip_exchange* x) {
   if (!x) return DBHIP_OK;
   for (void* p : x->sdata) if (p) (void)dbhip_free(p);
   for (uint8_t* p : x->svalid) if (p) (void)dbhip_free(p);
+  for (uint8_t* p : x->spacked) if (p) (void)dbhip_free(p);
   if (x->counts_dev) (void)dbhip_free(x->counts_dev);
   delete x;
   return DBHIP_OK;
@@ -270,13 +346,8 @@ int32_t dbhip_exchange_destroy(dbhip_exchange* x) {
 int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
                              dbhip_exchange** out_host, void* stream) {
   DBHIP_REQUIRE(c && out_recv_rows_host && out_host && ncols >= 0 && n >= 0 && (ncols == 0 || cols), "dbhip_exchange_begin: bad argument");
-  for (int k = 0; k < ncols; ++k) {
-    if (cols[k].type == DBHIP_T_STRING && cols[k].n_buffers > 0) {
-      set_error("dbhip_exchange_begin: column %d holds strings with data buffers (only inline views travel as 16-byte values); exchange the "
-                "serialized form (dbhip_serialize_keys) or keep the CPU exchange for this block", k);
-      return DBHIP_ERR_UNSUPPORTED;
-    }
-  }
+  for (int k = 0; k < ncols; ++k)
+    DBHIP_REQUIRE(!(cols[k].type == DBHIP_T_STRING && cols[k].n_buffers > 0 && !cols[k].buffers), "dbhip_exchange_begin: a String column with n_buffers > 0 needs its buffers");
   dbhip_exchange* x = new (std::nothrow) dbhip_exchange();
   if (!x) return DBHIP_ERR_HIP;
   x->c = c; x->n = n;
@@ -298,15 +369,76 @@ int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols
   if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)W * 16, &x->counts_dev);
   if (rc == DBHIP_OK)
     rc = dbhip_scatter_columns(cols, ncols, dest_index, n, (uint32_t)W, x->sdata.data(), x->svalid.data(), x->send_start.data(), stream);
+  // String columns with data buffers: every destination's long strings packed back to back, the scattered views re-based onto their piece
+  for (int k = 0; k < ncols && rc == DBHIP_OK; ++k) {
+    // EVERY String column takes part in the byte-count exchange (the schema decides, so that all ranks agree on the size of the counts
+    // message); a shard without rows, or whose values are all inline (no data buffers), simply has no bytes to send
+    if (cols[k].type != DBHIP_T_STRING) continue;
+    if (cols[k].n_buffers <= 0 || n == 0) {
+      x->str_cols.push_back(k);
+      x->spacked.push_back(nullptr);
+      x->sbyte_start.emplace_back(W + 1, 0);
+      x->rbyte_start.emplace_back(W + 1, 0);
+      continue;
+    }
+    uint32_t* lens = nullptr;
+    uint64_t *offs = nullptr, *blk = nullptr;
+    int64_t* dstart = nullptr;
+    uint32_t* err = nullptr;
+    uint8_t* packed = nullptr;
+    std::vector<uint64_t> bstart(W + 1, 0);
+    rc = dbhip_alloc((size_t)(n + 1) * 4, (void**)&lens);
+    if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)(n + 1) * 8, (void**)&offs);
+    if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)(ceil_div(n + 1, SCAN_TILE) + 2) * 8, (void**)&blk);
+    if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)(W + 1) * 16 + 8, (void**)&dstart);
+    uint64_t* picked = nullptr;
+    if (rc == DBHIP_OK) {
+      picked = (uint64_t*)(dstart + W + 1);
+      err = (uint32_t*)(picked + W + 1);
+      hipLaunchKernelGGL(xs_long_len_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t*)x->sdata[k], n, lens);
+      if (hipMemsetAsync(lens + n, 0, 4, s) != hipSuccess || hipMemsetAsync(err, 0, 8, s) != hipSuccess) rc = DBHIP_ERR_HIP;
+    }
+    if (rc == DBHIP_OK) rc = dbscan::exclusive_scan_u32(lens, n + 1, blk, offs, s);   // offs[n] = all long bytes
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_h2d(dstart, x->send_start.data(), (size_t)(W + 1) * 8, stream);
+    uint64_t total = 0;
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(&total, offs + n, 8, stream);
+    if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)total + 64, (void**)&packed);
+    if (rc == DBHIP_OK) {
+      // where every destination's piece starts: the scan at its first row
+      hipLaunchKernelGGL(xs_pick_kernel, dim3(ceil_div(W + 1, 64)), dim3(64), 0, s, offs, dstart, W + 1, picked);
+      hipLaunchKernelGGL(xs_pack_kernel, dim3(grid_for(ceil_div(n, 64) * 64, 256)), dim3(256), 0, s, (uint32_t*)x->sdata[k], n, offs,
+                         (const void* const*)cols[k].buffers, dstart, W, packed, err);
+      uint32_t e = 0;
+      if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(bstart.data(), picked, (size_t)(W + 1) * 8, stream);
+      if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(&e, err, 4, stream);
+      if (rc == DBHIP_OK && e) { set_error("dbhip_exchange_begin: column %d sends 4 GiB or more of string bytes to one rank (a view's offset is 32 bits)", k); rc = DBHIP_ERR_CAPACITY; }
+    }
+    for (void* p : {(void*)lens, (void*)offs, (void*)blk, (void*)dstart}) if (p) (void)dbhip_free(p);
+    x->str_cols.push_back(k);
+    x->spacked.push_back(packed);
+    x->sbyte_start.push_back(bstart);
+    x->rbyte_start.emplace_back(W + 1, 0);
+  }
   if (rc == DBHIP_OK) {
-    // the rows every rank sends to every other: one 8-byte all-to-all, read back once (the receiver sizes its buffers from it)
-    std::vector<uint64_t> sc(W), rcv(W);
-    for (int p = 0; p < W; ++p) sc[p] = (uint64_t)(x->send_start[p + 1] - x->send_start[p]);
+    // what every rank sends to every other — rows, then the long-string bytes of every String column — in ONE small all-to-all, read back
+    // once (the receiver sizes its buffers from it)
+    const size_t per = 1 + x->str_cols.size();
+    std::vector<uint64_t> sc((size_t)W * per), rcv((size_t)W * per);
+    for (int p = 0; p < W; ++p) {
+      sc[(size_t)p * per] = (uint64_t)(x->send_start[p + 1] - x->send_start[p]);
+      for (size_t j = 0; j < x->str_cols.size(); ++j) sc[(size_t)p * per + 1 + j] = x->sbyte_start[j][p + 1] - x->sbyte_start[j][p];
+    }
+    (void)dbhip_free(x->counts_dev);
+    x->counts_dev = nullptr;
+    rc = dbhip_alloc((size_t)W * per * 16, &x->counts_dev);
     uint64_t* d = (uint64_t*)x->counts_dev;
-    rc = dbhip_memcpy_h2d(d, sc.data(), (size_t)W * 8, stream);
-    if (rc == DBHIP_OK) rc = alltoall_bytes(c, d, d + W, 8, s);
-    if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(rcv.data(), d + W, (size_t)W * 8, stream);
-    for (int p = 0; p < W; ++p) x->recv_start[p + 1] = x->recv_start[p] + (int64_t)rcv[p];
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_h2d(d, sc.data(), (size_t)W * per * 8, stream);
+    if (rc == DBHIP_OK) rc = alltoall_bytes(c, d, d + (size_t)W * per, 8 * per, s);
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(rcv.data(), d + (size_t)W * per, (size_t)W * per * 8, stream);
+    for (int p = 0; p < W; ++p) {
+      x->recv_start[p + 1] = x->recv_start[p] + (int64_t)rcv[(size_t)p * per];
+      for (size_t j = 0; j < x->str_cols.size(); ++j) x->rbyte_start[j][p + 1] = x->rbyte_start[j][p] + rcv[(size_t)p * per + 1 + j];
+    }
     x->recv_total = x->recv_start[W];
   }
   if (rc != DBHIP_OK) { (void)dbhip_exchange_destroy(x); return rc; }
@@ -355,9 +487,27 @@ int32_t dbhip_sort_exchange_begin(dbhip_comm* c, const dbhip_col* keys, const db
   return rc;
 }
 
+int32_t dbhip_exchange_string_bytes(dbhip_exchange* x, int64_t* out_bytes_host) {
+  DBHIP_REQUIRE(x && (out_bytes_host || x->cols.empty()), "dbhip_exchange_string_bytes: NULL argument");
+  for (size_t k = 0; k < x->cols.size(); ++k) out_bytes_host[k] = 0;
+  for (size_t j = 0; j < x->str_cols.size(); ++j) out_bytes_host[x->str_cols[j]] = (int64_t)x->rbyte_start[j][x->c->world];
+  return DBHIP_OK;
+}
+
 int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_src_starts_host,
                               void* stream) {
+  return dbhip_exchange_finish_strings(x, out_data_host, out_validity_host, nullptr, out_src_starts_host, stream);
+}
+
+int32_t dbhip_exchange_finish_strings(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host,
+                                      uint8_t* const* out_string_bytes_host, int64_t* out_src_starts_host, void* stream) {
   DBHIP_REQUIRE(x && (x->cols.empty() || (out_data_host && out_validity_host)), "dbhip_exchange_finish: bad argument");
+  for (size_t j = 0; j < x->str_cols.size(); ++j)
+    if (x->rbyte_start[j][x->c->world] > 0 && !(out_string_bytes_host && out_string_bytes_host[x->str_cols[j]])) {
+      set_error("dbhip_exchange_finish: column %d receives %llu bytes of long strings: pass a buffer for them (dbhip_exchange_string_bytes, "
+                "dbhip_exchange_finish_strings)", x->str_cols[j], (unsigned long long)x->rbyte_start[j][x->c->world]);
+      return DBHIP_ERR_INVALID;
+    }
   dbhip_comm* c = x->c;
   const int W = c->world, ncols = (int)x->cols.size();
   hipStream_t s = resolve_stream(stream);
@@ -407,7 +557,40 @@ int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uin
     }
     if (rc == DBHIP_OK && x->svalid[k]) rc = add_bits(x->svalid[k], out_validity_host[k]);
   }
+  // the packed long-string bytes of every String column: one more piece per column in the same group
+  std::vector<std::vector<size_t>> soffs;
+  soffs.reserve(x->str_cols.size() * 4);
+  for (size_t j = 0; j < x->str_cols.size() && rc == DBHIP_OK; ++j) {
+    if (x->rbyte_start[j][W] == 0 && x->sbyte_start[j][W] == 0) continue;
+    soffs.emplace_back(W); soffs.emplace_back(W); soffs.emplace_back(W); soffs.emplace_back(W);
+    std::vector<size_t>&so = soffs[soffs.size() - 4], &sb = soffs[soffs.size() - 3], &ro = soffs[soffs.size() - 2], &rb = soffs[soffs.size() - 1];
+    for (int p = 0; p < W; ++p) {
+      so[p] = (size_t)x->sbyte_start[j][p]; sb[p] = (size_t)(x->sbyte_start[j][p + 1] - x->sbyte_start[j][p]);
+      ro[p] = (size_t)x->rbyte_start[j][p]; rb[p] = (size_t)(x->rbyte_start[j][p + 1] - x->rbyte_start[j][p]);
+    }
+    uint8_t* out = out_string_bytes_host ? out_string_bytes_host[x->str_cols[j]] : nullptr;
+    xs.push_back(XPiece{x->spacked[j], out, so.data(), sb.data(), ro.data(), rb.data()});
+  }
   if (rc == DBHIP_OK) rc = alltoallv_group(c, xs, s);   // ONE group: every column, every peer
+  // received views: offsets inside the sender's piece -> inside the packed output buffer (buffer 0 of the received column)
+  for (size_t j = 0; j < x->str_cols.size() && rc == DBHIP_OK; ++j) {
+    if (x->rbyte_start[j][W] == 0 || x->recv_total == 0) continue;
+    int64_t* rs = nullptr;
+    rc = dbhip_alloc((size_t)(W + 1) * 16 + 8, (void**)&rs);
+    if (rc) break;
+    uint64_t* bs = (uint64_t*)(rs + W + 1);
+    uint32_t* err = (uint32_t*)(bs + W + 1);
+    rc = dbhip_memcpy_h2d(rs, x->recv_start.data(), (size_t)(W + 1) * 8, stream);
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_h2d(bs, x->rbyte_start[j].data(), (size_t)(W + 1) * 8, stream);
+    if (rc == DBHIP_OK && hipMemsetAsync(err, 0, 4, s) != hipSuccess) rc = DBHIP_ERR_HIP;
+    if (rc == DBHIP_OK)
+      hipLaunchKernelGGL(xs_rebase_kernel, dim3(grid_for(x->recv_total, 256)), dim3(256), 0, s, (uint32_t*)out_data_host[x->str_cols[j]], x->recv_total,
+                         rs, bs, W, err);
+    uint32_t e = 0;
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(&e, err, 4, stream);
+    (void)dbhip_free(rs);
+    if (rc == DBHIP_OK && e) { set_error("dbhip_exchange_finish: column %d receives 4 GiB or more of string bytes (a view's offset is 32 bits)", x->str_cols[j]); rc = DBHIP_ERR_CAPACITY; }
+  }
   for (size_t j = 0; j < jobs.size() && rc == DBHIP_OK; ++j) {
     std::vector<dbhip_col> pc(W);
     std::vector<int64_t> rows(W);

@@ -244,6 +244,17 @@ class Column:
             return self.data.to_numpy(np.uint8, 16 * self.n).reshape(-1, 16)
         return self.data.to_numpy(NP_OF[self.dtype], self.n)
 
+    def to_strings(self):
+        """the values of a String column as bytes (test / debugging aid): inline views as they are, long views through buffer 0 — the
+        DeviceBuffer this Column keeps alive (Column.strings, the received columns of an exchange)"""
+        assert self.dtype == L.T_STRING
+        buf0 = None
+        for k in self._keep:
+            if isinstance(k, DeviceBuffer):
+                buf0 = k.to_numpy(np.uint8, k.nbytes)
+                break
+        return view_strings(self.to_numpy(), buf0)
+
     def validity_numpy(self):
         if self.validity is None:
             return np.ones(self.n, dtype=bool)
@@ -1659,10 +1670,22 @@ class Comm:
             dp = (C.c_void_p * len(cols))(*[b.ptr for b in outs])
             vp = (C.c_void_p * len(cols))(*[b.ptr if b is not None else None for b in vouts])
             starts = (C.c_int64 * (self.world + 1))()
-            check(lib().dbhip_exchange_finish(x, dp, vp, starts, stream))
+            # String columns with data buffers: the long values arrive packed in one buffer per column (buffer 0 of the received column)
+            sbytes = (C.c_int64 * max(len(cols), 1))()
+            check(lib().dbhip_exchange_string_bytes(x, sbytes))
+            sbufs = [DeviceBuffer(sbytes[k] + 64) if sbytes[k] else None for k in range(len(cols))]
+            sp = (C.c_void_p * max(len(cols), 1))(*[b.ptr if b is not None else None for b in sbufs])
+            check(lib().dbhip_exchange_finish_strings(x, dp, vp, sp, starts, stream))
         finally:
             lib().dbhip_exchange_destroy(x)
-        return [Column(c.dtype, m, o, v, c.precision, c.scale) for c, o, v in zip(cols, outs, vouts)], list(starts)
+        out = []
+        for k, (c, o, v) in enumerate(zip(cols, outs, vouts)):
+            if sbufs[k] is not None:
+                ptrs = DeviceBuffer.from_numpy(np.array([sbufs[k].ptr], dtype=np.uint64))
+                out.append(Column(c.dtype, m, o, v, c.precision, c.scale, buffers=ptrs, keep=(sbufs[k],)))
+            else:
+                out.append(Column(c.dtype, m, o, v, c.precision, c.scale))
+        return out, list(starts)
 
     def topk_allgather(self, idx, dist, nq, k, row_offset, stream=None):
         """dbhip_vec_topk_allgather: per-shard top-k (DeviceBuffers: u32 local ids, f32 distances, [nq][k]) -> global top-k on every rank

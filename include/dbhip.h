@@ -818,9 +818,13 @@ int32_t dbhip_groupby_exchange_alltoall(dbhip_groupby* g, dbhip_comm* c, int64_t
  * the shuffle of the hash join (HashFlightScatter, flight_scatter_hash.rs:57-330: dest = dbhip_scatter_indices) and the exchange of the
  * distributed sort (sorts/sort_broadcast.rs:150-197 + the range exchange: dest = dbhip_sort_bound_partition) are the same three calls.
  *   dbhip_exchange_begin   DataBlock::scatter of `cols` by dest_index[i] < world (dbhip_scatter_columns: values, validities, Boolean,
- *                          inline-String and Decimal columns; String columns WITH data buffers: DBHIP_ERR_UNSUPPORTED) and one 8-byte
- *                          all-to-all of the row counts -> *out_recv_rows_host = rows this rank receives (the host sizes the output
- *                          columns from it)
+ *                          String and Decimal columns) and ONE small all-to-all of what every rank sends every other (rows, and per String
+ *                          column with data buffers the bytes of its long values) -> *out_recv_rows_host = rows this rank receives (the
+ *                          host sizes the output columns from it). String columns WITH data buffers (round 5): the long (> 12 byte)
+ *                          values of every destination's rows are packed back to back, the views re-based onto that piece — the form the
+ *                          reference's exchange serializer ships (whole blocks, exchange/serde/exchange_serializer.rs);
+ *                          dbhip_exchange_string_bytes then tells how many bytes arrive per column and dbhip_exchange_finish_strings
+ *                          takes the buffers for them (plain dbhip_exchange_finish is for blocks whose strings are all inline)
  *   dbhip_exchange_finish  every column of every destination in ONE ncclGroup of send / recv pairs (one launch on the wire whatever
  *                          the width of the block; every xGMI link busy at once); out_data_host[c] = recv_rows elements in source-rank
  *                          order, rows of one source in their order; validity / Boolean Bitmaps arrive as per-source pieces and are
@@ -848,6 +852,12 @@ int32_t dbhip_sort_exchange_begin(dbhip_comm* c, const dbhip_col* keys, const db
                                   int64_t n, int64_t* out_recv_rows_host, dbhip_exchange** out_host, void* stream);
 int32_t dbhip_exchange_finish(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_src_starts_host,
                               void* stream);
+/* Long strings (round 5). out_bytes_host[c] = bytes of long-string data column c receives (0 for other columns). finish_strings =
+ * finish with out_string_bytes_host[c]: a device buffer of at least that many bytes per such column — it becomes buffer 0 of the received
+ * String column (the received views are {len, prefix, 0, offset into it}). */
+int32_t dbhip_exchange_string_bytes(dbhip_exchange* x, int64_t* out_bytes_host);
+int32_t dbhip_exchange_finish_strings(dbhip_exchange* x, void* const* out_data_host, uint8_t* const* out_validity_host,
+                                      uint8_t* const* out_string_bytes_host, int64_t* out_src_starts_host, void* stream);
 int32_t dbhip_exchange_destroy(dbhip_exchange* x);
 int32_t dbhip_vec_topk_allgather(dbhip_comm* c, const uint32_t* idx_dev, const float* dist_dev, int32_t nq, int32_t k, uint64_t row_offset,
                                  uint32_t* out_idx_dev, float* out_dist_dev, void* stream);

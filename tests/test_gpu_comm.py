@@ -129,6 +129,68 @@ def test_block_exchange_between_ranks_routes_every_row_once(gpu, world):
     assert sum(o[3][-1] for o in outs) == sum(sizes)
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_block_exchange_moves_strings_with_data_buffers(gpu, world):
+    """Round 5: String columns whose values live in data buffers (longer than 12 bytes) travel in the exchange — every destination's long
+    values packed back to back, the views re-based, the byte counts exchanged with the row counts, all pieces in the one grouped
+    all-to-all (the reference ships whole blocks, flight_scatter_hash.rs:57-120 + exchange/serde). Two String columns (one nullable, with
+    empty / inline / long values mixed; one all long), an Int64 column beside them; rank r must end with exactly its rows, strings intact."""
+    D = gpu
+    rng = np.random.default_rng(300 + world)
+    sizes = [int(x) for x in rng.integers(1, 30_000, world)]
+    if world > 2:
+        sizes[1] = 0
+    shards = []
+    for r in range(world):
+        n = sizes[r]
+        key = rng.integers(0, 7000, n).astype(np.int64)
+        mixed = [(b"" if i % 11 == 0 else b"s%d" % i if i % 3 == 0 else b"rank-%d-row-%07d-" % (r, i) + b"x" * int(i % 50)) for i in range(n)]
+        mv = rng.random(n) > 0.15
+        long_ = [b"a-long-comment-of-rank-%d-for-row-%09d" % (r, i) for i in range(n)]
+        shards.append((key, mixed, mv, long_))
+    gid = 9100 + world
+
+    def rank_fn(r):
+        key, mixed, mv, long_ = shards[r]
+        n = len(key)
+        comm = D.Comm.loopback(gid, r, world) if world > 1 else D.Comm.local()
+        cols = [D.Column.from_numpy(key), D.Column.strings(mixed, validity=mv), D.Column.strings(long_)]
+        if n:
+            dest, _ = D.scatter_indices([cols[0]], world)
+        else:
+            dest = D.DeviceBuffer(16)
+        got, starts = comm.exchange_block(cols, dest)
+        d = dest.to_numpy(np.uint32, n)
+        m = got[0].n
+        res = (d, got[0].to_numpy(), got[1].to_strings(), got[1].validity_numpy(), got[2].to_strings(), starts, m)
+        comm.destroy()
+        return res
+    outs = run_ranks(world, rank_fn) if world > 1 else [rank_fn(0)]
+    for r in range(world):
+        _, k, s1, v1, s2, starts, m = outs[r]
+        exp_rows = [(s, i) for s in range(world) for i in np.nonzero(outs[s][0] == r)[0].tolist()]
+        assert len(exp_rows) == starts[-1] == m
+        assert np.array_equal(k, np.array([shards[s][0][i] for s, i in exp_rows], np.int64))
+        ev = np.array([shards[s][2][i] for s, i in exp_rows], bool)
+        assert np.array_equal(v1, ev)
+        assert [x for x, ok in zip(s1, ev) if ok] == [shards[s][1][i] for s, i in exp_rows if shards[s][2][i]]
+        assert s2 == [shards[s][3][i] for s, i in exp_rows]
+    assert sum(o[6] for o in outs) == sum(sizes)
+    # plain finish refuses a block whose strings need a buffer, before anything is sent
+    if world == 1:
+        import ctypes as C
+        comm = D.Comm.local()
+        cols = [D.Column.strings([b"a value that is longer than twelve bytes"] * 5)]
+        x, rows = C.c_void_p(), C.c_int64()
+        dest = D.DeviceBuffer.from_numpy(np.zeros(5, np.uint32))
+        T.check(T.lib().dbhip_exchange_begin(comm.h, D._cols(cols), 1, C.c_void_p(dest.ptr), C.c_int64(5), C.byref(rows), C.byref(x), None))
+        out = D.DeviceBuffer(5 * 16 + 64)
+        dp, vp, st = (C.c_void_p * 1)(out.ptr), (C.c_void_p * 1)(None), (C.c_int64 * 2)()
+        assert T.lib().dbhip_exchange_finish(x, dp, vp, st, None) == T.ERR_INVALID
+        T.lib().dbhip_exchange_destroy(x)
+        comm.destroy()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_shuffle_and_sort_exchange_plans_behind_the_abi(gpu, world):
     """dbhip_shuffle_exchange_begin / dbhip_sort_exchange_begin: the two distributed plans as single calls, no torch and no Python
