@@ -185,6 +185,40 @@ struct Column {
     c.data = make_buf(views.size()); c.data->upload(views.data(), views.size());
     return c;
   }
+  // strings of any length: inline views up to 12 bytes, {len, prefix, buffer 0, offset} into ONE data buffer beyond (binview/view.rs)
+  static Column from_strings(const std::vector<std::string>& v) {
+    std::vector<uint8_t> views(v.size() * 16, 0), bytes;
+    for (size_t i = 0; i < v.size(); ++i) {
+      const uint32_t len = (uint32_t)v[i].size();
+      memcpy(&views[i * 16], &len, 4);
+      if (len <= 12) { memcpy(&views[i * 16 + 4], v[i].data(), len); continue; }
+      const uint32_t off = (uint32_t)bytes.size(), zero = 0;
+      memcpy(&views[i * 16 + 4], v[i].data(), 4);
+      memcpy(&views[i * 16 + 8], &zero, 4);
+      memcpy(&views[i * 16 + 12], &off, 4);
+      bytes.insert(bytes.end(), v[i].begin(), v[i].end());
+    }
+    Column c; c.type = DataType::of(DBHIP_T_STRING); c.len = (int64_t)v.size();
+    c.data = make_buf(views.size() + 16); c.data->upload(views.data(), views.size());
+    c.str_data = make_buf(bytes.size() + 16);
+    if (!bytes.empty()) c.str_data->upload(bytes.data(), bytes.size());
+    const void* p = c.str_data->ptr();
+    c.str_ptrs = make_buf(sizeof(void*));
+    c.str_ptrs->upload(&p, sizeof(void*));
+    return c;
+  }
+  // the values of `n` views at `views_dev` whose long form points into the `nbytes` bytes at `bytes_dev`
+  static std::vector<std::string> strings_to_host(const void* views_dev, int64_t n, const void* bytes_dev, int64_t nbytes) {
+    std::vector<uint8_t> views((size_t)n * 16), bytes((size_t)nbytes);
+    if (n) check(dbhip_memcpy_d2h(views.data(), views_dev, views.size(), nullptr));
+    if (nbytes) check(dbhip_memcpy_d2h(bytes.data(), bytes_dev, bytes.size(), nullptr));
+    std::vector<std::string> out((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      uint32_t l, off; memcpy(&l, &views[(size_t)i * 16], 4); memcpy(&off, &views[(size_t)i * 16 + 12], 4);
+      out[(size_t)i] = l <= 12 ? std::string((const char*)&views[(size_t)i * 16 + 4], l) : std::string((const char*)&bytes[off], l);
+    }
+    return out;
+  }
   static Buf pack_bits(const std::vector<bool>& v) {
     std::vector<uint8_t> by((v.size() + 63) / 64 * 8 + 8, 0);
     for (size_t i = 0; i < v.size(); ++i) if (v[i]) by[i >> 3] |= (uint8_t)(1u << (i & 7));

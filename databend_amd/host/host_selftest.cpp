@@ -515,10 +515,14 @@ static void test_two_rank_exchange() {
   std::vector<int64_t> got_key[2], got_pay[2];
   std::vector<int64_t> shuf_key[2], shuf_pay[2], sort_key[2], sort_pay[2];   // the same block through the two plan calls
   std::vector<int64_t> starts[2];
+  std::vector<std::string> tag[2], got_tag[2];     // a String column whose values are mostly longer than 12 bytes (they travel packed)
   std::mt19937_64 rng(77);
   for (int r = 0; r < world; ++r) {
     key[r].resize(n[r]); pay[r].resize(n[r]);
     for (int64_t i = 0; i < n[r]; ++i) { key[r][i] = (int64_t)(rng() % 4096); pay[r][i] = (int64_t)r * 1000000 + i; }
+    tag[r].resize(n[r]);
+    for (int64_t i = 0; i < n[r]; ++i)
+      tag[r][i] = i % 7 == 0 ? std::string("t") + std::to_string(i % 90) : "rank-" + std::to_string(r) + "-row-" + std::to_string(i) + std::string((size_t)(i % 40), 'y');
   }
   const int nq = 5, k = 4;
   std::vector<uint32_t> tid[2], gid[2];
@@ -553,6 +557,22 @@ static void test_two_rank_exchange() {
       got_key[r].resize(rows); got_pay[r].resize(rows);
       ok->download(got_key[r].data(), (size_t)rows * 8);
       op->download(got_pay[r].data(), (size_t)rows * 8);
+      {   // the same rows with a String column beside the key: long values are packed per destination and re-based at the receiver
+        Column tc = Column::from_strings(tag[r]);
+        dbhip_col scols[2] = {kc.c(), tc.c()};
+        int64_t srows = 0;
+        dbhip_exchange* sx = nullptr;
+        check(dbhip_exchange_begin(c, scols, 2, (const uint32_t*)db->ptr(), n[r], &srows, &sx, nullptr));
+        int64_t sbytes[2] = {0, 0};
+        check(dbhip_exchange_string_bytes(sx, sbytes));
+        Buf sk = make_buf((size_t)srows * 8 + 64), sv = make_buf((size_t)srows * 16 + 64), sb = make_buf((size_t)sbytes[1] + 64);
+        void* souts[2] = {sk->ptr(), sv->ptr()};
+        uint8_t* svalid[2] = {nullptr, nullptr};
+        uint8_t* sbufs[2] = {nullptr, (uint8_t*)sb->ptr()};
+        check(dbhip_exchange_finish_strings(sx, souts, svalid, sbufs, nullptr, nullptr));
+        check(dbhip_exchange_destroy(sx));
+        got_tag[r] = Column::strings_to_host(sv->ptr(), srows, sb->ptr(), sbytes[1]);
+      }
       // the hash shuffle and the range partition of the distributed sort as single plan calls (no index computed by the caller)
       for (int plan = 0; plan < 2; ++plan) {
         int64_t prow = 0;
@@ -596,6 +616,13 @@ static void test_two_rank_exchange() {
         if ((int)dest[s][i] == r) { ek.push_back(key[s][i]); ep.push_back(pay[s][i]); }
     CHECK(got_key[r] == ek);
     CHECK(got_pay[r] == ep);
+    {
+      std::vector<std::string> et;
+      for (int s = 0; s < world; ++s)
+        for (int64_t i = 0; i < n[s]; ++i)
+          if ((int)dest[s][i] == r) et.push_back(tag[s][i]);
+      CHECK(got_tag[r] == et);
+    }
     CHECK(starts[r][world] == (int64_t)ek.size());
     CHECK(shuf_key[r] == ek && shuf_pay[r] == ep);      // dbhip_shuffle_exchange_begin = scatter_indices + exchange
     std::vector<int64_t> sk, sp;                        // dbhip_sort_exchange_begin: the rows of range r, by source rank, in order
