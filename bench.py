@@ -252,7 +252,8 @@ def main():
         okm = float(np.mean(okms))
         same = tpch.q1_rows(g2) == result_headline
         other = {"name": "q1_fused_kernel (query-specific, k_q1.hip: the ceiling)" if args.headline == "program" else "fagg_jit (generic fused program)",
-                 "ms_per_step": oms, "kernel_ms": okm, "rows_per_s": n_total / (oms * 1e-3),
+                 "ms_per_step": oms, "kernel_ms": okm, "kernel_ms_min_median_max": [float(np.min(okms)), float(np.median(okms)), float(np.max(okms))],
+                 "rows_per_s": n_total / (oms * 1e-3),
                  "hbm_frac": n * BYTES_PER_ROW / (okm * 1e-3) / 1e9 / HBM_PEAK_GBS if okm else None,
                  "headline_kernel_slowdown": kernel_ms / okm if okm else None, "equals_headline_result": bool(same)}
         assert same, "the generic fused program and the hand-written kernel disagree"
@@ -365,7 +366,8 @@ def main():
                        "generate_seconds": gen_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dominant,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": n * BYTES_PER_ROW},
+                         "kernel_ms": kernel_ms, "kernel_ms_min_median_max": [float(np.min(kms)), float(np.median(kms)), float(np.max(kms))] if kms else None,
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_ROW},
             "headline_path": {"what": "dbhip_groupby_add_block_program (generic fused program, PREPAREd)" if args.headline == "program" else "dbhip_q1_fused (hand-written)",
                               "prepare_ms_cold_or_cached": prepare_ms},
             "hand_written_kernel" if args.headline == "program" else "generic_program_kernel": other,

@@ -97,7 +97,11 @@ int jit_rows(const FaArgs& A) {
     }
   }
   for (int k = 0; k < A.nkeys; ++k) bytes += type_size(A.key[k].type) > 0 ? type_size(A.key[k].type) : 1;
-  return bytes >= 64 ? 4 : (bytes >= 32 ? 8 : 16);
+  // 64-byte rows and wider: THREE rows per lane (round 5). With 4 (a 256-row chunk: every column of a wave's chunk starts on a multiple of
+  // 1 / 2 / 4 KiB) the Q1 kernel ran 6.45 .. 7.6 ms from process to process on one box — the seven column streams fall on the same
+  // HBM channels or not, depending on where the allocator put the columns — against 6.30 .. 6.50 ms with 3 (192-row chunks), every
+  // run; 2 measured 6.8 ms, 1 8.7 ms (profiles/r05_fagg_rows_sweep.txt).
+  return bytes >= 64 ? 3 : (bytes >= 32 ? 8 : 16);
 }
 std::string jit_meta(const FaArgs& A) {
   JitOut o;
