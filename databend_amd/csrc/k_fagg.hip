@@ -101,6 +101,11 @@ int jit_rows(const FaArgs& A) {
   // 1 / 2 / 4 KiB) the Q1 kernel ran 6.45 .. 7.6 ms from process to process on one box — the seven column streams fall on the same
   // HBM channels or not, depending on where the allocator put the columns — against 6.30 .. 6.50 ms with 3 (192-row chunks), every
   // run; 2 measured 6.8 ms, 1 8.7 ms (profiles/r05_fagg_rows_sweep.txt).
+  // a program that divides (a rounding decimal multiply, a decimal divide) is ALU bound, not load bound: with the 16 row slots its narrow
+  // rows would get, the kernel needs 310 VGPRs (one wave per SIMD) and 3 s of hiprtc; 3 slots: 10.4 ms instead of 15.2 ms on the rescaling
+  // Q1 variant, 1.1 s cold PREPARE (r05 sweep: 2 -> 10.9 ms / 0.85 s, 3 -> 10.4 / 1.14, 4 -> 10.3 / 1.42, 6 -> 14.4 / 2.2, 8 -> 15.2 / 3.0)
+  for (int i = 0; i < A.P.n_ins; ++i)
+    if (A.P.ins[i].op == EX_DEC && dec_op_needs_division(A.P.dec[A.P.ins[i].dec_idx])) return 3;
   return bytes >= 64 ? 3 : (bytes >= 32 ? 8 : 16);
 }
 std::string jit_meta(const FaArgs& A) {
