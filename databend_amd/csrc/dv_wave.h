@@ -5,10 +5,10 @@
 //            field); literal bytes are moved from a window to the output with ds_bpermute. A window slides with one coalesced load;
 //            the FORWARD streams (the literals of a ZSTD block, the whole LZ4 / Snappy payload) keep the next 256 bytes loaded ahead,
 //            so a sequence never waits for HBM.
-//   output   an LDS RING of the last W bytes (8 KiB for ZSTD, whose tables take another 14 KiB of LDS; 16 KiB for LZ4 / Snappy)
+//   output   an LDS RING of the last W bytes (8 KiB; ZSTD's tables take another 14 KiB of LDS)
 //            written to the HBM image in 16-byte stores; a back-reference that reaches further than the ring reads the image itself —
 //            those bytes left the ring, so they were flushed long ago (the wave waits for its own stores once per far reference).
-// 22 / 16 KiB of LDS per wave: seven / ten pages resident per CU (the round-4 kernel kept a 64 KiB window + 8 KiB input ring: two).
+// 22 / 8 KiB of LDS per wave: seven / twenty pages resident per CU (the round-4 kernel kept a 64 KiB window + 8 KiB input ring: two).
 #pragma once
 #include "zstd_core.h"
 
@@ -44,11 +44,11 @@ __device__ __forceinline__ void gstore128(uint8_t* p, u32x4 v) { *(__attribute__
 // per-lane load inside a uniform `if` turned `wlo` into a vector PHI and with it every header field and branch of the kernel (464
 // exec-mask branches in the first build). Hence: guarded loads are branch-free (clamped address + select), and scalar updates happen in
 // straight-line code after the per-lane part.
-// dword at gA + o if it lies inside [0, safe) else 0; safe is a multiple of 4 and >= 4
+// dword at gA + o, or (past the readable region) the last readable dword again; safe is a multiple of 4 and >= 4. No select on the loaded
+// value: it would make the wave wait for the load where it is ISSUED, and the chunk loaded ahead would not be ahead any more. What lies
+// past the payload is never interpreted as anything but bytes of a (then malformed) stream.
 __device__ __forceinline__ uint32_t guarded32(const uint8_t* gA, uint32_t o, uint32_t safe) {
-  const bool in = o + 4 <= safe;
-  const uint32_t v = gload32(gA + (in ? o : safe - 4));
-  return in ? v : 0u;
+  return gload32(gA + (o + 4 <= safe ? o : safe - 4));
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -392,7 +392,8 @@ struct ZWave {
 constexpr uint32_t ZW_RING = 8192;                          // ZSTD: ring bytes
 constexpr uint32_t ZW_TABLES = 13312 + zc::SCR_BYTES;       // Huffman 4 KiB + LL 4 KiB + ML 4 KiB + OF 1 KiB + scratch
 constexpr uint32_t ZW_LDS = ZW_RING + ZW_TABLES;
-constexpr uint32_t LZ_RING = 16384;                         // LZ4 / Snappy: ring bytes (nothing else in LDS)
+constexpr uint32_t LZ_RING = 8192;                          // LZ4 / Snappy: ring bytes (nothing else in LDS). r05 sweep on the 7-column lineitem set:
+                                                            // 16 KiB 19.2 / 21.1 ms (LZ4 / Snappy), 8 KiB 14.3 / 16.3, 4 KiB 14.8 / 17.1
 
 // ---------------------------------------------------------------------------------------------
 // LZ4 block format (lz4_Block_format.md) and Snappy raw format (format_description.txt) on the same wave: the payload is ONE forward

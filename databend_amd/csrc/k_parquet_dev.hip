@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // page decompression: one wave per page (dv_wave.h)
 // ---------------------------------------------------------------------------------------------
 // ZSTD: one wave per page (dv_wave.h, zstd_core.h)
-__global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __restrict__ jobs) {
+__global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
   const DvJob P = jobs[blockIdx.x];
   const uint32_t lane = threadIdx.x;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __rest
   for (uint32_t i = lane; i < raw; i += 64) P.dst[i] = P.src[i];
   if (!P.compressed || P.uncomp_len == lev) return;
   ZWave w;
-  w.begin(P, dv_lds, ZW_RING, lane);
+  w.begin(P, dv_lds, ring, lane);
   int rc = zc::decode_frames(w, w.in_len);
   if (rc == zc::OK && w.op_ != w.cap_) rc = zc::CORRUPT_;
   w.flush(true);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __rest
 }
 
 // LZ4 / Snappy on the same wave (16 KiB ring, the payload as one forward stream in registers)
-__global__ __launch_bounds__(64) void dv_inflate_lz_kernel(const DvJob* __restrict__ jobs) {
+__global__ __launch_bounds__(64) void dv_inflate_lz_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
   const DvJob P = jobs[blockIdx.x];
   const uint32_t lane = threadIdx.x;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void dv_inflate_lz_kernel(const DvJob* __restri
   for (uint32_t i = lane; i < raw; i += 64) P.dst[i] = P.src[i];
   if (!P.compressed || P.uncomp_len == lev) return;
   ZWave w;
-  w.begin(P, dv_lds, LZ_RING, lane);
+  w.begin(P, dv_lds, ring, lane);
   FwdStream in;
   in.open(w.srcA, w.safeA, w.a0, lane);
   bool ok = P.codec == CODEC_SNAPPY ? snappy_raw(w, in) : lz4_block(w, in);
@@ -650,6 +650,14 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
 // ---- the batch: one launch set for many chunks ------------------------------------------------------------------------------
 namespace {
 
+uint32_t ring_from_env(const char* name, uint32_t dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const long v = atol(e);
+  if (v < 1024 || v > 65536 || (v & (v - 1))) return dflt;
+  return (uint32_t)v;
+}
+
 struct BlobLayout {
   size_t hdr, cds, dict_list, lv_map, val_map, jobs, per_chunk, total;
 };
@@ -797,8 +805,11 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
       DBHIP_CHECK(hipMemsetAsync(spread ? c->d_dense : out_values_dev[i], 0, (size_t)ceil_div(spread ? c->rows + 1 : c->rows, 64) * 8, s));
   }
   kernel_timer_start(s);
-  if (n_z) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), ZW_LDS, s, d_jobs);
-  if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), LZ_RING, s, d_jobs + n_z);
+  // ring sizes (powers of two >= 1 KiB; env overrides for experiments): smaller rings = more pages resident per CU, more back-references
+  // served from the image instead of the ring
+  static const uint32_t z_ring = ring_from_env("DBHIP_PQ_ZSTD_RING", ZW_RING), lz_ring = ring_from_env("DBHIP_PQ_LZ_RING", LZ_RING);
+  if (n_z) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
+  if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), lz_ring, s, d_jobs + n_z, lz_ring);
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
   if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));
   hipLaunchKernelGGL(dv_scan_kernel, dim3((unsigned)nl), dim3(256), 0, s, d_cds);
