@@ -25,6 +25,7 @@
 //   Growth: when the load factor 1/1.35 (aggregate/mod.rs:55) is exceeded the table is
 //   rebuilt x4 (aggregate_hashtable.rs:314-333) and the block's probe is redone
 //   (the probe phase is idempotent; states are untouched until it succeeds).
+#include <mutex>
 #include "gb_device.h"
 #include "runtime.h"
 
@@ -64,6 +65,7 @@ struct dbhip_groupby {
   int64_t part_chunk;                      // rows per partitioned chunk (0 = PT_CHUNK)
   int part_direct;                         // partitioned rows are inserted straight into their table slice (no LDS pre-aggregation)
   int part_adapt;                          // the chunk size follows the group estimate (more groups than one chunk's LDS tables hold)
+  int part_validate, part_validated;       // the next partitioned chunk is a 4 M-row check of an estimate extrapolated from a mostly-distinct probe
   int64_t rows_seen;                       // input rows of add_block so far (cardinality estimate)
   uint32_t* part_meta; size_t part_meta_cap;   // tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
   uint32_t* spill_idx; size_t spill_idx_cap;
@@ -80,6 +82,8 @@ struct dbhip_groupby {
   int gbc_part_lcap_max;                   // largest partition table of the compact kernels, chosen with the partitioning (0 = default)
   uint32_t gbc_part_cap;                   // rows of a partition's region when the last scatter was the direct one, else 0
   uint64_t* gbc_spill; size_t gbc_spill_cap;   // rows (table layout) that did not fit an LDS table
+  int gbc_skip;                                // this chunk goes through the generic kernels (its spill list covers every row)
+  uint32_t* gbc_split; size_t gbc_split_cap;   // heavy partitions (gbc_split_map_kernel): nsp[P] | cursor, extra workgroups | map[extra]
 };
 
 namespace {
@@ -1698,14 +1702,20 @@ bool gbc_enabled(const dbhip_groupby* g) {
   return !off && !g->gbc_off && g->hash_mask == ~0ULL && !g->has_long;
 }
 
-// the kernels are instantiated for 1-2 key words and 1 / 2 / 4 value words (a layout without value words runs as NV = 1)
+// the kernels are instantiated for 1-4 key words and 1 / 2 / 4 / 8 value words (a layout without value words runs as NV = 1)
+#define GBC_NV_DISPATCH(KW_, nv_, CALL)                                                                          \
+  do { if (nv_ == 1) { CALL(KW_, 1); } else if (nv_ == 2) { CALL(KW_, 2); } else if (nv_ == 4) { CALL(KW_, 4); } else { CALL(KW_, 8); } } while (0)
 #define GBC_DISPATCH(D, CALL)                                                     \
   do {                                                                            \
-    const int nv_ = (D).nv <= 1 ? 1 : ((D).nv == 2 ? 2 : 4);                      \
-    if ((D).kw == 1) { if (nv_ == 1) { CALL(1, 1); } else if (nv_ == 2) { CALL(1, 2); } else { CALL(1, 4); } } \
-    else { if (nv_ == 1) { CALL(2, 1); } else if (nv_ == 2) { CALL(2, 2); } else { CALL(2, 4); } }             \
+    const int nvc_ = gbc_nv_class(D);                                             \
+    switch ((D).kw) {                                                             \
+      case 1: GBC_NV_DISPATCH(1, nvc_, CALL); break;                              \
+      case 2: GBC_NV_DISPATCH(2, nvc_, CALL); break;                              \
+      case 3: GBC_NV_DISPATCH(3, nvc_, CALL); break;                              \
+      default: GBC_NV_DISPATCH(4, nvc_, CALL); break;                             \
+    }                                                                             \
   } while (0)
-inline int gbc_row_words(const GbcDesc& D) { return D.kw + (D.nv <= 1 ? 1 : (D.nv == 2 ? 2 : 4)); }
+#define GBC_FOR_ALL(M) M(1, 1) M(1, 2) M(1, 4) M(1, 8) M(2, 1) M(2, 2) M(2, 4) M(2, 8) M(3, 1) M(3, 2) M(3, 4) M(3, 8) M(4, 1) M(4, 2) M(4, 4) M(4, 8)
 
 constexpr int PT_MAX_BITS = 14;
 constexpr int PT_PMAX = 1 << PT_MAX_BITS;   // part_meta: tot[PT_PMAX] | base[PT_PMAX + 8] | pcount[PT_PMAX] | mat[nwg][P]
@@ -1754,6 +1764,12 @@ int32_t partitioned_step(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream
                                      (long long)cn, g->part_bits, (long long)spilled, (long long)g->count_host);
   *done += cn;
   g->rows_seen += cn;
+  if (g->part_validate) {   // the check chunk of an extrapolated estimate: choose again with what it found
+    g->part_validate = 0; g->part_validated = 1;
+    decide_partitioning(g, g->count_host, g->rows_seen, n);
+    if (g->part_bits < 0) g->fast_disabled = 1;
+    return DBHIP_OK;
+  }
   if (g->part_adapt) { adapt_chunk(g, n); return DBHIP_OK; }
   if (spilled * 20 > cn) {
     if (g->part_bits + 2 <= PT_MAX_BITS) g->part_bits += 2;
@@ -1788,8 +1804,10 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
   const bool small_layout = L.nkey_words <= 2 && L.nkeys <= 2 && L.naggs <= 2 && !hi;
   // compact-row kernels (gb_compact.h): this call's layout AND columns qualify
   GbcDesc GD;
-  const bool gbc = fast_layout_ok(L) && gbc_enabled(g) && gbc_describe(L, C, &GD);
+  const bool gbc = !layout_has_wide_minmax(L) && gbc_enabled(g) && gbc_describe(L, C, &GD);
+  GD.ctrl = g->ctrl;
   g->gbc_active = gbc ? 1 : 0;
+  if (!gbc && !fast_layout_ok(L)) return -1;   // (the generic LDS kernel is instantiated up to FK_MAXKW key words / FK_MAXA aggregates)
   const int64_t CHUNK = 16 << 20;
   int blocks_per_cu = (int)((160 * 1024) / (lds_bytes + 1024));
   if (blocks_per_cu > 4) blocks_per_cu = 4;
@@ -1849,7 +1867,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // compact kernel: ONE 1024-thread workgroup per CU, 4 rows per lane, a table sized for the groups the probing chunk predicted
     // (the largest table, gbc_max_lcap = 4096 slots / 112 KB for key + sum + count, while nothing is known)
     const int gbc_lcap = gbc ? (g->gbc_lcap ? g->gbc_lcap : gbc_max_lcap(GD)) : 0;   // (nothing known yet: the largest table)
-    const int R = gbc ? 4 : (small ? ((small_r == 4 || big) ? 4 : 8) : 2);
+    const int R = gbc ? gbc_rows_per_lane(gbc_row_words(GD)) : (small ? ((small_r == 4 || big) ? 4 : 8) : 2);
     const int threads = (big || gbc) ? 1024 : 256;
     const int lcap_i = gbc ? gbc_lcap : (big ? lcap * 2 : lcap);
     const size_t lds_i = gbc ? gbc_agg_lds_bytes(GD, gbc_lcap, GBC_T) : (big ? lds_bytes * 2 : lds_bytes);
@@ -1883,13 +1901,15 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     A.llimit = (uint32_t)(lcap_i - lcap_i / 4);
     A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill = g->rows_in; A.ctrl = g->ctrl;
     if (gbc) {
-      static bool gbc_attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process and kernel
-      if (!gbc_attr_set) {
-#define GBC_RAISE(KW_, NV_) DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_agg_kernel<KW_, NV_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        GBC_RAISE(1, 1) GBC_RAISE(1, 2) GBC_RAISE(1, 4) GBC_RAISE(2, 1) GBC_RAISE(2, 2) GBC_RAISE(2, 4)
+      // > 64 KB of dynamic LDS needs the attribute once per process and kernel
+      static std::once_flag gbc_attr_once;
+      static hipError_t gbc_attr_err = hipSuccess;
+      std::call_once(gbc_attr_once, [] {
+#define GBC_RAISE(KW_, NV_) if (gbc_attr_err == hipSuccess) gbc_attr_err = hipFuncSetAttribute((const void*)gbc_agg_kernel<KW_, NV_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        GBC_FOR_ALL(GBC_RAISE)
 #undef GBC_RAISE
-        gbc_attr_set = true;
-      }
+      });
+      DBHIP_CHECK(gbc_attr_err);
       GbcAggArgs G;
       memset(&G, 0, sizeof(G));
       G.row0 = *done; G.n = cn; G.lcap = lcap_i; G.llimit = A.llimit; G.partial = g->partial; G.pcount = nullptr;
@@ -2692,7 +2712,7 @@ int32_t gbc_partition_scatter(dbhip_groupby* g, const GbCols& C, const GbcDesc& 
   // (r04e: two 512-thread workgroups per CU instead of one of 1024 — 1024 row ranges instead of 512 — were SLOWER: 0.41 vs 0.38 ms at
   // 16 partitions, 0.69 vs 0.55 ms at 256: a workgroup's run inside a partition gets half as long)
   static const int gbc_t = getenv("DBHIP_GBC_T") ? atoi(getenv("DBHIP_GBC_T")) : GBC_T;
-  const int T = gbc_t;
+  const int T = (RW > 8 && P > 1024) ? 512 : gbc_t;   // (rows of 9 ... 12 words beside 16 K cursors: 512 staged rows fit the LDS)
   int64_t nwg = ceil_div(cn, (int64_t)T * 16);
   if (nwg > 512) nwg = 512;
   const int64_t rows_per_wg = ceil_div(cn, nwg);
@@ -2701,16 +2721,19 @@ int32_t gbc_partition_scatter(dbhip_groupby* g, const GbCols& C, const GbcDesc& 
   uint32_t* tot = g->part_meta;
   uint32_t* base = g->part_meta + PT_PMAX;
   uint32_t* mat = g->part_meta + 3 * PT_PMAX + 8;
-  static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
-  if (!raised) {
-#define GBC_RAISE(KW_, NV_)                                                                                                             \
-    DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_scatter_direct_kernel<KW_, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-    DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_scatter_kernel<KW_, NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
-    DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_hist_kernel<KW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    GBC_RAISE(1, 1) GBC_RAISE(1, 2) GBC_RAISE(1, 4) GBC_RAISE(2, 1) GBC_RAISE(2, 2) GBC_RAISE(2, 4)
+  // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+  static std::once_flag raised_once;
+  static hipError_t raised_err = hipSuccess;
+  std::call_once(raised_once, [] {
+    auto raise = [](const void* f, int bytes) { if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+#define GBC_RAISE(KW_, NV_)                                                        \
+    raise((const void*)gbc_scatter_direct_kernel<KW_, NV_>, 150 * 1024);           \
+    raise((const void*)gbc_scatter_kernel<KW_, NV_>, 150 * 1024);                  \
+    raise((const void*)gbc_hist_kernel<KW_>, 64 * 1024);
+    GBC_FOR_ALL(GBC_RAISE)
 #undef GBC_RAISE
-    raised = true;
-  }
+  });
+  DBHIP_CHECK(raised_err);
   const int SR = RW <= 2 ? 4 : (RW <= 4 ? 2 : 1);
   // up to 1024 partitions: no histogram pass — fixed regions (the uniform share + 5 % + 16 K rows) and one global atomic per
   // (batch, partition); a region that overflows is found after the chunk's first read-back and the chunk redone the exact way
@@ -2736,8 +2759,12 @@ int32_t gbc_partition_scatter(dbhip_groupby* g, const GbCols& C, const GbcDesc& 
     g->gbc_part_cap = (uint32_t)cap;
     return DBHIP_OK;
   }
-  if (D.kw == 1) hipLaunchKernelGGL(gbc_hist_kernel<1>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat);
-  else hipLaunchKernelGGL(gbc_hist_kernel<2>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat);
+  switch (D.kw) {
+    case 1: hipLaunchKernelGGL(gbc_hist_kernel<1>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat); break;
+    case 2: hipLaunchKernelGGL(gbc_hist_kernel<2>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat); break;
+    case 3: hipLaunchKernelGGL(gbc_hist_kernel<3>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat); break;
+    default: hipLaunchKernelGGL(gbc_hist_kernel<4>, dim3((int)nwg), dim3(T), (size_t)P * 4, s, D, C, row0, cn, pbits, rows_per_wg, mat); break;
+  }
   hipLaunchKernelGGL((gb_part_colscan_kernel<false>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
   hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, tot, P, base);
   hipLaunchKernelGGL((gb_part_colscan_kernel<true>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
@@ -2769,7 +2796,7 @@ int gbc_part_lcap(const GbLayout& L, int lcap_max) {
   static const int env_c = getenv("DBHIP_GBC_PARTLCAP") ? atoi(getenv("DBHIP_GBC_PARTLCAP")) : 0;   // (experiments)
   const int max_c = env_c ? env_c : (lcap_max ? lcap_max : 2048);
   const size_t slot = (size_t)(L.nkey_words + (L.W - L.agg_off[0])) * 8 + 4;
-  const size_t qrow = (size_t)(L.nkey_words + 4) * 8;   // (a deferred-row queue per wave: at most key words + 4 value words per row)
+  const size_t qrow = 48;   // (a deferred-row queue per wave: rows of up to 6 words, or the positions of wider rows)
   // two workgroups per CU (75 KB each) up to 2048 slots, one (150 KB) for 4096
   int c = 256;
   while (c < max_c) {
@@ -2849,7 +2876,8 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   int32_t rc;
   // compact rows (gb_compact.h) when the layout and the columns qualify; the direct-insert mode consumes serialized rows
   GbcDesc D;
-  const bool gbc = g->gbc_active && !g->part_direct && gbc_enabled(g) && gbc_describe(L, C, &D);
+  const bool gbc = g->gbc_active && !g->gbc_skip && !g->part_direct && gbc_enabled(g) && gbc_describe(L, C, &D);
+  D.ctrl = g->ctrl;
   if (!gbc) g->gbc_active = 0;   // (the geometry of everything that follows is the generic kernels')
   table_geometry(g, &lcap, &sw, &lds_bytes);
   if (gbc) rc = gbc_partition_scatter(g, C, D, row0, cn, pbits, s);
@@ -2920,13 +2948,13 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   const bool exclusive = splits == 1 && !no_excl && g->hash_mask == ~0ULL;
   uint32_t* pcount = g->part_meta + 2 * PT_PMAX + 8;
   if (exclusive) DBHIP_CHECK(hipMemsetAsync(pcount, 0, (size_t)P * 4, s));
-  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 16, s));
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[5], 0, 24, s));   // [5] partial rows, [6] spilled rows, [7] rows of the packed list of heavy partitions
   PaArgs A;
   A.rows = g->rows_in; A.base = base; A.splits = splits; A.lcap = lcap; A.sw = sw;
   A.llimit = (uint32_t)(lcap - lcap / 4);
   A.hash_mask = g->hash_mask; A.partial = g->partial; A.spill_idx = g->spill_idx; A.ctrl = g->ctrl;
   A.pcount = exclusive ? pcount : nullptr;
-  const int64_t gbc_spill_cap = cn / 16 + 65536;
+  const int64_t gbc_spill_cap = cn / 8 + 65536;
   if (gbc) {
     if ((rc = ensure((void**)&g->gbc_spill, &g->gbc_spill_cap, (size_t)gbc_spill_cap * L.W * 8))) return rc;
     GbcAggArgs G;
@@ -2934,17 +2962,36 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     G.rows = g->rows_in; G.base = base; G.splits = splits; G.lcap = lcap; G.llimit = A.llimit; G.partial = g->partial;
     if (g->gbc_part_cap) { G.pcursor = g->part_meta; G.part_cap = g->gbc_part_cap; }   // (the direct scatter's cursors: part_meta[0..P))
     G.pcount = A.pcount; G.spill = g->gbc_spill; G.spill_cap = (uint64_t)gbc_spill_cap; G.ctrl = g->ctrl;
+    // HEAVY partitions (one key with a large share of the rows — NULLs, a default value — lands in ONE partition, and with one
+    // workgroup per sub-range that workgroup is the whole kernel's tail: r05, 25 % NULL keys: 8.6 ms at 2 x 10^4 groups, 128 ms at
+    // 10^6 where the partition has one workgroup): a partition longer than twice the average sub-range gets more sub-ranges, worked
+    // on by EXTRA workgroups behind the regular P x splits (at most cn / max_rows of them; those not needed leave at once). Their
+    // partial rows go to a packed list behind the per-partition lists and through the row path.
+    static const bool no_heavy = getenv("DBHIP_GBC_HEAVY") && atoi(getenv("DBHIP_GBC_HEAVY")) == 0;
+    int extra_max = 0;
+    if (!no_heavy) {
+      int64_t max_rows = 2 * (cn / agrid);
+      if (max_rows < 32768) max_rows = 32768;
+      extra_max = (int)(cn / max_rows) + 1;
+      if ((rc = ensure((void**)&g->gbc_split, &g->gbc_split_cap, ((size_t)P + 2 + (size_t)extra_max) * 4))) return rc;
+      if ((rc = ensure((void**)&g->partial, &g->partial_cap, ((size_t)agrid + 2 * (size_t)extra_max) * lcap * L.W * 8))) return rc;
+      G.partial = g->partial;
+      G.nsp = g->gbc_split; G.extra_n = g->gbc_split + P + 1; G.extra_map = g->gbc_split + P + 2;
+      G.nparts = P; G.packed_base = (uint64_t)agrid * lcap;
+      hipLaunchKernelGGL(gbc_split_map_kernel, dim3(1), dim3(1024), 0, s, G.pcursor, G.part_cap, base, P, splits, (uint32_t)max_rows, (uint32_t)extra_max, g->gbc_split);
+    }
     static const int agg_t = getenv("DBHIP_GBC_AGGT") ? atoi(getenv("DBHIP_GBC_AGGT")) : 0;   // (experiments)
     const int threads = agg_t ? agg_t : gbc_part_threads(lcap);
     lds_bytes = gbc_agg_lds_bytes(D, lcap, threads);
-    static bool agg_raised = false;
-    if (!agg_raised) {
-#define GBC_RAISE(KW_, NV_) DBHIP_CHECK(hipFuncSetAttribute((const void*)gbc_agg_kernel<KW_, NV_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      GBC_RAISE(1, 1) GBC_RAISE(1, 2) GBC_RAISE(1, 4) GBC_RAISE(2, 1) GBC_RAISE(2, 2) GBC_RAISE(2, 4)
+    static std::once_flag agg_raised_once;
+    static hipError_t agg_raised_err = hipSuccess;
+    std::call_once(agg_raised_once, [] {
+#define GBC_RAISE(KW_, NV_) if (agg_raised_err == hipSuccess) agg_raised_err = hipFuncSetAttribute((const void*)gbc_agg_kernel<KW_, NV_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      GBC_FOR_ALL(GBC_RAISE)
 #undef GBC_RAISE
-      agg_raised = true;
-    }
-#define GBC_AGG(KW_, NV_) hipLaunchKernelGGL((gbc_agg_kernel<KW_, NV_, false>), dim3(agrid), dim3(threads), lds_bytes, s, D, C, G)
+    });
+    DBHIP_CHECK(agg_raised_err);
+#define GBC_AGG(KW_, NV_) hipLaunchKernelGGL((gbc_agg_kernel<KW_, NV_, false>), dim3(agrid + extra_max), dim3(threads), lds_bytes, s, D, C, G)
     GBC_DISPATCH(D, GBC_AGG);
 #undef GBC_AGG
   } else if (L.W <= 8) hipLaunchKernelGGL((gb_part_agg_kernel<8>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
@@ -2972,11 +3019,15 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     // more rows than the compact kernels' spill buffer holds met full tables (the estimate behind the partitioning was far off):
     // nothing of this chunk has been merged — redo it with the generic kernels, whose spill list covers every row
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
-    g->gbc_active = 0; g->gbc_off = 1;
-    return add_chunk_partitioned(g, C, row0, cn, s, spilled);
+    g->gbc_skip = 1;   // (this chunk only: the partitioning is widened by the caller on what the redone chunk reports)
+    rc = add_chunk_partitioned(g, C, row0, cn, s, spilled);
+    g->gbc_skip = 0;
+    g->gbc_active = 1;
+    return rc;
   }
   const int64_t nspill = (int64_t)hc[6];
   const int64_t npartial = (int64_t)hc[5];
+  const int64_t npacked = (gbc && exclusive) ? (int64_t)hc[7] : 0;   // (partial rows of heavy partitions' sub-ranges, behind the per-partition lists)
   int64_t nlisted = 0;
   if (exclusive && npartial > 0) {
     // every partial row may be a new group: make room first (the slices move with the capacity, the kernel takes it as it is)
@@ -3009,6 +3060,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   }
   if (!exclusive && (rc = merge_rows(g, g->partial, npartial, s))) return rc;
   if (ngather + nlisted > 0 && (rc = merge_rows(g, g->spill_rows, ngather + nlisted, s))) return rc;
+  if (npacked > 0 && (rc = merge_rows(g, g->partial + (size_t)agrid * lcap * L.W, npacked, s))) return rc;
   if (gbc && nspill > 0 && (rc = merge_rows(g, g->gbc_spill, nspill, s))) return rc;
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby partitioned merge: exclusive=%d partial=%lld listed=%lld spilled=%lld cap=%lld\n",
                                      (int)exclusive, (long long)npartial, (long long)nlisted, (long long)nspill, (long long)g->cap);
@@ -3070,6 +3122,15 @@ void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, in
     g->part_chunk = 4 << 20;
   }
   g->part_bits = bits;
+  // An estimate EXTRAPOLATED from a probe that met a new group in more than every fourth row is only as good as its assumption of
+  // equally likely groups: one heavy key (25 % NULLs) made 10^6 groups look like 3 x 10^5 (r05), the partitioning came out four times
+  // too coarse and 9 M of 60 M rows left the full tables for the row path (124 ms). Such an estimate is checked on a 4 M-row chunk
+  // first; the partitioning of the rest follows what that chunk found (partitioned_step).
+  static const bool no_validate = getenv("DBHIP_GB_VALIDATE") && atoi(getenv("DBHIP_GB_VALIDATE")) == 0;
+  if (!g->part_adapt && !g->part_validated && !no_validate && groups * 4 > rows_seen && total - rows_seen > (16 << 20)) {
+    g->part_validate = 1;
+    g->part_chunk = 4 << 20;
+  }
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in the first %lld rows -> ~%lld groups in %lld rows, %d partition bits\n",
                                      (long long)groups, (long long)rows_seen, (long long)est, (long long)total, bits);
 }
@@ -3219,7 +3280,8 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
   // TPC-H Q3: 3 M rows, 1.1 M groups): pre-aggregation has nothing to combine and costs more than the rows it saves
   // (r03: LDS pre-aggregation 0.59 ms + merge against 0.3 ms for the row path alone), the block goes straight to the row path.
   const bool expect_distinct = g->rows_seen == 0 && g->count_host == 0 && n >= (1 << 20) && g->hint_groups * 2 >= n && g->part_bits == 0;
-  if (fast_layout_ok(g->L) && !g->has_long && !expect_distinct) {
+  // (layouts past the generic LDS kernel's limits — e.g. eight aggregates — may still qualify for the compact-row kernels: add_block_fast decides)
+  if ((fast_layout_ok(g->L) || !layout_has_wide_minmax(g->L)) && !g->has_long && !expect_distinct) {
     rc = add_block_fast(g, C, n, s, &done);
     if (rc >= 0) return rc;
   }
@@ -3706,6 +3768,7 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   g->gbc_lcap = 0;
   g->gbc_active = 0;
   g->gbc_part_lcap_max = 0;
+  g->part_validate = 0; g->part_validated = 0;
   if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
   g->rows_seen = 0;
   return DBHIP_OK;
@@ -3725,6 +3788,7 @@ int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (g->spill_idx) (void)dbhip_free(g->spill_idx);
   if (g->spill_rows) (void)dbhip_free(g->spill_rows);
   if (g->gbc_spill) (void)dbhip_free(g->gbc_spill);
+  if (g->gbc_split) (void)dbhip_free(g->gbc_split);
   if (g->xcur) (void)hipFree(g->xcur);
   if (g->arena) (void)dbhip_free(g->arena);
   delete g;

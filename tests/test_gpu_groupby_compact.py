@@ -115,3 +115,165 @@ def test_adaptive_path_choice_over_the_cardinality_range(gpu, oracle, card):
     a = rng.integers(0, 1000, n).astype(np.int64)
     got = run_case(gpu, oracle, [T.T_I64], [k], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)], [a, None], n)
     assert sum(r[2] for r in got) == n
+
+
+# ---- round 5: the layouts plans actually produce --------------------------------------------------------------------------------------
+def _both(gpu, kind, data, validity=None):
+    """one column for the device and the oracle: kind = a dbhip type, or ("dec128", p, s) / "str" """
+    from databend_amd.device import make_views_general
+    if kind == "str":
+        v, buf = make_views_general(data)
+        return T.T_STRING, gpu.Column.strings(data, validity=validity), O.HostCol(T.T_STRING, v, validity, buffers=[buf])
+    if isinstance(kind, tuple):
+        _, p, s = kind
+        return T.T_DEC128, gpu.Column.decimal128(data, p, s, validity=validity), O.HostCol(T.T_DEC128, O.i128_array(data), validity, p, s)
+    return kind, gpu.Column.from_numpy(data, kind, validity=validity), O.HostCol(kind, data, validity)
+
+
+def run_layout(gpu, oracle, keys, key_nullable, aggs, args, n, compact=True, pbits=None, blocks=1):
+    """keys / args: [(kind, data, validity or None)] (None = count(*)); slices the columns into `blocks` add_block calls"""
+    key_types = [_both(gpu, k, d[:1], None)[0] for k, d, _v in keys]
+    g = gpu.GroupBy(key_types, aggs, key_nullable)
+    set_compact(g, compact)
+    if pbits is not None:
+        g.debug_set_partition_bits(pbits)
+    cuts = [n * b // blocks for b in range(blocks + 1)]
+    sl = lambda x, lo, hi: None if x is None else x[lo:hi]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        kc = [_both(gpu, k, d[lo:hi], sl(v, lo, hi))[1] for k, d, v in keys]
+        ac = [None if a is None else _both(gpu, a[0], a[1][lo:hi], sl(a[2], lo, hi))[1] for a in args]
+        g.add_block(kc, ac, hi - lo)
+    got = g.result()
+    assert g.num_groups() == len(got)
+    g.destroy()
+    hk = [_both(gpu, k, d, v)[2] for k, d, v in keys]
+    ha = [None if a is None else _both(gpu, a[0], a[1], a[2])[2] for a in args]
+    h = oracle_groupby(oracle, key_types, key_nullable, aggs, hk, ha, n)
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert norm(got) == norm(exp)
+    return got
+
+
+def layout_cases(rng, n, card):
+    """name -> (keys, key_nullable, aggs, args)"""
+    base = rng.integers(0, card, n)
+    kv = rng.random(n) > 0.06            # 6 % NULL keys
+    av = rng.random(n) > 0.25            # 25 % NULL arguments
+    av2 = rng.random(n) > 0.5
+    i64 = (base * 7919 - 3).astype(np.int64)
+    a1 = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    a2 = rng.integers(-1000, 1000, n).astype(np.int32)
+    f = rng.integers(-500, 500, n).astype(np.float64)
+    f32 = rng.integers(-500, 500, n).astype(np.float32)
+    d128 = [int(x) * 10**11 + 7 for x in rng.integers(-10**17, 10**17, n)]        # |v| up to 1e28: two words, both signs
+    c3 = max(2, round(card ** (1 / 3)))
+    k3 = [(base % c3).astype(np.int64), ((base // c3) % c3).astype(np.int32), (base // (c3 * c3)).astype(np.int32)]
+    strs = [b"k%d" % x for x in base]                                            # inline views (<= 12 bytes)
+    strs2 = [b"F" if x & 1 else b"O" for x in base]
+    SUM, CNT, MIN, MAX = T.AGG_SUM, T.AGG_COUNT, T.AGG_MIN, T.AGG_MAX
+    return {
+        "nullable key, nullable sum + count(col) + count(*)": (
+            [(T.T_I64, i64, kv)], [1], [(SUM, T.T_I64, 0, 0, 1), (CNT, T.T_I64, 0, 0, 1), (CNT, 0, 0, 0, 0)], [(T.T_I64, a1, av), (T.T_I64, a1, av), None]),
+        "nullable min max over two nullable columns": (
+            [(T.T_I32, i64.astype(np.int32), None)], [0], [(MIN, T.T_I64, 0, 0, 1), (MAX, T.T_F64, 0, 0, 1), (SUM, T.T_F64, 0, 0, 1), (MAX, T.T_I64, 0, 0, 1)],
+            [(T.T_I64, a1, av), (T.T_F64, f, av2), (T.T_F64, f, av2), (T.T_I64, a1, av)]),
+        "three keys (Q3's group-by), sum(Decimal128)": (
+            [(T.T_I64, k3[0], None), (T.T_DATE, k3[1], None), (T.T_I32, k3[2], None)], [0, 0, 0], [(SUM, T.T_DEC128, 31, 4, 0)], [(("dec128", 31, 4), d128, None)]),
+        "three keys, one nullable; nullable Decimal128 sum + min": (
+            [(T.T_I64, k3[0], kv), (T.T_DATE, k3[1], None), (T.T_I32, k3[2], None)], [1, 0, 0], [(SUM, T.T_DEC128, 31, 4, 1), (MIN, T.T_I32, 0, 0, 0), (CNT, 0, 0, 0, 0)],
+            [(("dec128", 31, 4), d128, av), (T.T_I32, a2, None), None]),
+        "Decimal128 key; sum, count": (
+            [(("dec128", 38, 0), [int(x) * 10**20 - 5 for x in base], None)], [0], [(SUM, T.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [(T.T_I64, a1, None), None]),
+        "nullable Decimal128 key + i16 key; max(u16)": (
+            [(("dec128", 38, 0), [int(x) * 10**20 - 5 for x in base // 7], kv), (T.T_I16, (base % 7).astype(np.int16), None)], [1, 0],
+            [(MAX, T.T_U16, 0, 0, 0), (SUM, T.T_F32, 0, 0, 0)], [(T.T_U16, (a2 & 0xffff).astype(np.uint16), None), (T.T_F32, f32, None)]),
+        "inline String key; sum, count": (
+            [("str", strs, None)], [0], [(SUM, T.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [(T.T_I64, a1, None), None]),
+        "two String keys, Q1's six aggregates": (
+            [("str", strs, None), ("str", strs2, None)], [0, 0],
+            [(SUM, T.T_DEC64, 15, 2, 0), (SUM, T.T_DEC64, 15, 2, 0), (SUM, T.T_DEC128, 31, 4, 0), (SUM, T.T_DEC128, 38, 6, 0), (SUM, T.T_DEC64, 15, 2, 0), (CNT, 0, 0, 0, 0)],
+            [(T.T_DEC64, a1, None), (T.T_DEC64, a1 * 3, None), (("dec128", 31, 4), d128, None), (("dec128", 38, 6), [x * 3 for x in d128], None), (T.T_DEC64, a2.astype(np.int64), None), None]),
+        "eight aggregates over two columns": (
+            [(T.T_I64, i64, None)], [0],
+            [(SUM, T.T_I64, 0, 0, 0), (SUM, T.T_I32, 0, 0, 0), (MIN, T.T_I64, 0, 0, 0), (MAX, T.T_I64, 0, 0, 0), (SUM, T.T_I64, 0, 0, 0), (MIN, T.T_I32, 0, 0, 0), (MAX, T.T_I32, 0, 0, 0),
+             (CNT, 0, 0, 0, 0)],
+            [(T.T_I64, a1, None), (T.T_I32, a2, None), (T.T_I64, a1, None), (T.T_I64, a1, None), (T.T_I64, a1, None), (T.T_I32, a2, None), (T.T_I32, a2, None), None]),
+        "eight aggregates over six columns, some nullable": (
+            [(T.T_U16, (base % 60000).astype(np.uint16), None), (T.T_I64, (base // 60000).astype(np.int64), kv)], [0, 1],
+            [(SUM, T.T_I64, 0, 0, 1), (SUM, T.T_F64, 0, 0, 0), (MIN, T.T_F32, 0, 0, 0), (MAX, T.T_I32, 0, 0, 1), (SUM, T.T_DEC128, 31, 4, 0), (CNT, T.T_I32, 0, 0, 1), (MIN, T.T_I64, 0, 0, 1),
+             (SUM, T.T_I32, 0, 0, 0)],
+            [(T.T_I64, a1, av), (T.T_F64, f, None), (T.T_F32, f32, None), (T.T_I32, a2, av2), (("dec128", 31, 4), d128, None), (T.T_I32, a2, av2), (T.T_I64, a1, av), (T.T_I32, a2, None)]),
+    }
+
+
+LAYOUT_NAMES = list(layout_cases(np.random.default_rng(0), 8, 3).keys())
+
+
+@pytest.mark.parametrize("name", LAYOUT_NAMES)
+@pytest.mark.parametrize("n,card", [(1, 1), (4000, 30), (200_000, 900), (250_000, 30_000)])
+def test_compact_kernels_on_the_layouts_plans_produce(gpu, oracle, name, n, card):
+    """nullable keys and arguments, 16-byte keys, three keys, eight aggregates, Decimal128 sums: the LDS path (and, at 30 K groups, whatever
+    the library chooses) against the oracle's AggregateHashTable"""
+    rng = np.random.default_rng(n + card)
+    keys, kn, aggs, args = layout_cases(rng, n, card)[name]
+    run_layout(gpu, oracle, keys, kn, aggs, args, n, blocks=2 if n > 1000 else 1)
+
+
+@pytest.mark.parametrize("name", LAYOUT_NAMES)
+@pytest.mark.parametrize("pbits", [4, 11])
+def test_compact_layouts_through_forced_partitionings(gpu, oracle, name, pbits):
+    """the same layouts through scatter (histogram-less at 16 partitions, histogram + scans at 2048) -> per-partition tables -> merge, three
+    blocks so that earlier partial states are merged into; and once more with the compact kernels off (the generic kernels agree with the oracle too)"""
+    n, card = 300_000, 20_000
+    rng = np.random.default_rng(pbits)
+    keys, kn, aggs, args = layout_cases(rng, n, card)[name]
+    run_layout(gpu, oracle, keys, kn, aggs, args, n, pbits=pbits, blocks=3)
+    if pbits == 4:
+        run_layout(gpu, oracle, keys, kn, aggs, args, n, pbits=pbits, compact=False)
+
+
+def test_compact_layouts_spill_and_long_strings_leave_the_fast_path(gpu, oracle):
+    """(a) a wide layout whose groups overflow the tables of a forced 16-way partitioning: rows leave in table layout (positions queue,
+    Decimal128 states, not-NULL bits) and the result is the oracle's; (b) a String key that turns out longer than an inline view: the compact
+    kernels raise the long-string bit, nothing of the chunk is merged, the row path takes the block"""
+    n = 600_000
+    rng = np.random.default_rng(3)
+    keys, kn, aggs, args = layout_cases(rng, n, 150_000)["eight aggregates over six columns, some nullable"]
+    run_layout(gpu, oracle, keys, kn, aggs, args, n, pbits=4)
+    ids = rng.integers(0, 500, n)
+    strs = [b"group-%d" % x for x in ids]
+    long_key = b"a key that does not fit an inline view"
+    strs[n // 2] = long_key
+    a = rng.integers(0, 100, n).astype(np.int64)
+    g = gpu.GroupBy([T.T_STRING], [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)], [0])
+    g.add_block([gpu.Column.strings(strs)], [gpu.Column.from_numpy(a), None], n)
+    got = {r[0]: (r[1], r[2]) for r in g.result()}
+    g.destroy()
+    exp = {}
+    for s_, v in zip(strs, a.tolist()):          # (the oracle's result decoder reads inline views only: a plain dictionary is the reference here)
+        t = exp.get(s_, (0, 0))
+        exp[s_] = (t[0] + v, t[1] + 1)
+    assert got == exp and got[long_key][1] == 1
+
+
+@pytest.mark.parametrize("card,null", [(30_000, True), (30_000, False), (1_500_000, True), (400_000, False)])
+def test_one_heavy_group_among_many(gpu, oracle, card, null):
+    """a quarter of the rows carry ONE key (NULL, or a value): its partition is worked on in sub-ranges by extra workgroups
+    (gbc_split_map_kernel) whose partial rows travel in the packed list — next to per-partition lists (10^5+ groups: one workgroup per
+    partition) and inside the one packed list (few partitions, several workgroups each)"""
+    n = 6_000_000
+    rng = np.random.default_rng(card)
+    k = rng.integers(0, card, n).astype(np.int64)
+    heavy = rng.random(n) < 0.25
+    a = rng.integers(-1000, 1000, n).astype(np.int64)
+    if null:
+        keys, kn = [(T.T_I64, k, ~heavy)], [1]
+    else:
+        k[heavy] = card + 11
+        keys, kn = [(T.T_I64, k, None)], [0]
+    got = run_layout(gpu, oracle, keys, kn, [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 0)],
+                     [(T.T_I64, a, None), None, (T.T_I64, a, None)], n)
+    hk = None if null else card + 11
+    row = [r for r in got if r[0] == hk]
+    assert len(row) == 1 and row[0][2] == int(heavy.sum())

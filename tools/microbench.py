@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--vec-nq", default="1,32,64,128,512,2048")
     ap.add_argument("--gb-card", default="4,200,1000,5000,20000,100000,1000000,10000000")
+    ap.add_argument("--gbl-card", default="200,20000,1000000")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     want = lambda k: not only or k in only
@@ -225,6 +226,58 @@ def main():
             report(out, f"groupby add_block i64 key, sum+count, {card} groups", n, "rows", alg_bytes=16 * n, ms=ms, note=note)
             gb.destroy()
             del keys, vals
+
+    if want("gblayouts"):
+        # the layouts plans actually produce, beside the one-i64-key sum + count of the sweep above: nullable keys / arguments, three keys
+        # (TPC-H Q3's group-by), a 16-byte key, eight aggregates, and TPC-H Q1's group-by WITHOUT its fused program (two String keys, six
+        # aggregates, two of them Decimal128 sums). alg_bytes = the bytes of the key and argument columns.
+        n = int(60_000_000 * args.scale)
+        vbits = torch.randint(0, 256, (n // 8 + 64,), device=dev, dtype=torch.uint8, generator=g) | 0x0f   # ~3 % NULL
+        v1 = ri(0, 1000, n); v2 = ri(-500, 500, n)
+        d128 = torch.stack([ri(0, 10**9, n), torch.zeros(n, dtype=torch.int64, device=dev)], dim=1).contiguous()
+        SUM, CNT, MIN, MAX = L.AGG_SUM, L.AGG_COUNT, L.AGG_MIN, L.AGG_MAX
+        for card in [int(x) for x in args.gbl_card.split(',')]:
+            k1 = ri(0, card, n)
+            c3 = max(2, round(card ** (1 / 3)))
+            ka, kb, kc3 = ri(0, c3, n), ri(0, c3, n, torch.int32), ri(0, max(card // (c3 * c3), 1), n, torch.int32)
+            k128 = torch.stack([k1, torch.zeros_like(k1)], dim=1).contiguous()
+            cases = [
+                ("i64 key; sum, count", [L.T_I64], None, [(SUM, L.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [col(k1, L.T_I64)], [col(v1, L.T_I64), None], 16),
+                ("nullable i64 key; sum(nullable), count", [L.T_I64], [1], [(SUM, L.T_I64, 0, 0, 1), (CNT, 0, 0, 0, 0)],
+                 [col(k1, L.T_I64, validity=Borrowed(vbits))], [col(v1, L.T_I64, validity=Borrowed(vbits)), None], 16.25),
+                ("3 keys (i64, date, i32); sum(Decimal128)", [L.T_I64, L.T_DATE, L.T_I32], None, [(SUM, L.T_DEC128, 31, 4, 0)],
+                 [col(ka, L.T_I64), col(kb, L.T_DATE), col(kc3, L.T_I32)], [col(d128, L.T_DEC128)], 32),
+                ("Decimal128 key; sum, count", [L.T_DEC128], None, [(SUM, L.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [col(k128, L.T_DEC128)], [col(v1, L.T_I64), None], 24),
+                ("i64 key; 8 aggregates", [L.T_I64], None,
+                 [(SUM, L.T_I64, 0, 0, 0), (SUM, L.T_I64, 0, 0, 0), (MIN, L.T_I64, 0, 0, 0), (MAX, L.T_I64, 0, 0, 0), (SUM, L.T_I64, 0, 0, 0), (MIN, L.T_I64, 0, 0, 0),
+                  (MAX, L.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [col(k1, L.T_I64)],
+                 [col(v1, L.T_I64), col(v2, L.T_I64), col(v1, L.T_I64), col(v1, L.T_I64), col(v2, L.T_I64), col(v2, L.T_I64), col(v2, L.T_I64), None], 24),
+            ]
+            for name, kt, kn, aggs, kcols, acols, bpr in cases:
+                gb = D.GroupBy(kt, aggs, key_nullable=kn, capacity=max(1024, card * 2))
+                def f():
+                    gb.reset()
+                    gb.add_block(kcols, acols, n)
+                ms = timed(f, reps=3, warm=2)
+                ng = gb.num_groups()
+                report(out, f"groupby layouts: {name}, {card} groups", n, "rows", alg_bytes=bpr * n, ms=ms, note=f"{ng} groups met")
+                gb.destroy()
+            del k1, ka, kb, kc3, k128
+        # TPC-H Q1's group-by without the fused program: the aggregate arguments arrive as columns
+        rf = torch.zeros((n, 4), dtype=torch.int32, device=dev); rf[:, 0] = 1; rf[:, 1] = ri(65, 68, n, torch.int32)
+        ls = torch.zeros((n, 4), dtype=torch.int32, device=dev); ls[:, 0] = 1; ls[:, 1] = ri(70, 72, n, torch.int32)
+        gb = D.GroupBy([L.T_STRING, L.T_STRING], [(SUM, L.T_DEC64, 15, 2, 0), (SUM, L.T_DEC64, 15, 2, 0), (SUM, L.T_DEC128, 31, 4, 0), (SUM, L.T_DEC128, 38, 6, 0),
+                                                 (SUM, L.T_DEC64, 15, 2, 0), (CNT, 0, 0, 0, 0)], capacity=1024)
+        kcols = [col(rf, L.T_STRING), col(ls, L.T_STRING)]
+        acols = [col(v1, L.T_DEC64), col(v2, L.T_DEC64), col(d128, L.T_DEC128), col(d128, L.T_DEC128), col(v1, L.T_DEC64), None]
+        def f():
+            gb.reset()
+            gb.add_block(kcols, acols, n)
+        ms = timed(f, reps=3, warm=2)
+        report(out, "groupby layouts: TPC-H Q1's table from columns (2 String keys; 3 Decimal64 + 2 Decimal128 sums, count), 6 groups", n, "rows",
+               alg_bytes=(32 + 24 + 32) * n, ms=ms, note=f"{gb.num_groups()} groups met")
+        gb.destroy()
+        del rf, ls, d128, v1, v2, vbits
 
     if want("join"):
         nb, npr = int(15_000_000 * args.scale), int(120_000_000 * args.scale)
