@@ -269,6 +269,7 @@ extern "C" {
     pub fn dbhip_comm_create(rank: i32, world: i32, id128_host: *const u8, out_host: *mut *mut dbhip_comm) -> i32;
     pub fn dbhip_comm_create_loopback(group_id: u64, rank: i32, world: i32, out_host: *mut *mut dbhip_comm) -> i32;
     pub fn dbhip_comm_destroy(c: *mut dbhip_comm) -> i32;
+    pub fn dbhip_comm_abort(c: *mut dbhip_comm) -> i32;
     pub fn dbhip_comm_allgather(c: *mut dbhip_comm, send_dev: *const c_void, recv_dev: *mut c_void, bytes_per_rank: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_comm_alltoall(c: *mut dbhip_comm, send_dev: *const c_void, recv_dev: *mut c_void, bytes_per_peer: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_comm_allreduce_sum_u64(c: *mut dbhip_comm, send_dev: *const u64, recv_dev: *mut u64, count: i64, stream: *mut c_void) -> i32;

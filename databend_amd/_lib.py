@@ -91,7 +91,7 @@ SYMBOLS = [
     "dbhip_join_add_build", "dbhip_join_finalize", "dbhip_join_probe_count", "dbhip_join_probe",
     "dbhip_join_destroy", "dbhip_join_mark_build", "dbhip_join_build_matched", "dbhip_sort_perm", "dbhip_merge_sorted_perm", "dbhip_sort_bound_partition", "dbhip_bitmap_set_indices", "dbhip_siphash64", "dbhip_scatter_indices", "dbhip_scatter_block", "dbhip_vec_distance", "dbhip_vec_distance_rows", "dbhip_vec_topk", "dbhip_score_u8",
     "dbhip_vec_topk_merge", "dbhip_vec_index_build", "dbhip_vec_index_search", "dbhip_vec_index_destroy",
-    "dbhip_comm_unique_id", "dbhip_comm_create", "dbhip_comm_destroy", "dbhip_comm_allgather", "dbhip_comm_alltoall",
+    "dbhip_comm_unique_id", "dbhip_comm_create", "dbhip_comm_destroy", "dbhip_comm_abort", "dbhip_comm_allgather", "dbhip_comm_alltoall",
     "dbhip_comm_allreduce_sum_u64", "dbhip_groupby_exchange_allgather", "dbhip_groupby_exchange_alltoall", "dbhip_kmeans", "dbhip_vec_kernel_f32", "dbhip_hnsw_build", "dbhip_hnsw_build_sequential", "dbhip_hnsw_from_graph", "dbhip_hnsw_open", "dbhip_hnsw_export_graph", "dbhip_hnsw_search", "dbhip_hnsw_scores",
     "dbhip_hnsw_encoded", "dbhip_hnsw_meta", "dbhip_hnsw_destroy",
     "dbhip_pq_chunk_open", "dbhip_pq_chunk_validity", "dbhip_pq_chunk_image", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",

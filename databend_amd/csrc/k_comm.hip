@@ -17,7 +17,9 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <string>
 #include <map>
 #include <mutex>
 #include <new>
@@ -39,6 +41,7 @@ struct Rccl {
   int (*GetUniqueId)(ncclUniqueId*) = nullptr;
   int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;          // (optional)
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -69,6 +72,7 @@ int32_t load_rccl() {
   SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
   SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+  g_rccl.CommAbort = (int (*)(ncclComm_t))dlsym(h, "ncclCommAbort");
   g_rccl.lib = h;
   return DBHIP_OK;
 }
@@ -100,6 +104,9 @@ struct LoopGroup {
   int world = 0, arrived = 0, refs = 0;
   uint64_t generation = 0;
   int32_t status = 0;
+  std::string status_msg;        // the message behind `status` (set_error is per thread: the ranks that waited get it from here)
+  bool failed = false;           // a rank gave up (dbhip_comm_abort, a failed exchange, a rendezvous that timed out): every waiter and
+  std::string why;               // every later collective of the group returns an error instead of waiting for a rank that will not come
   std::vector<LoopOp> ops;
 };
 
@@ -155,11 +162,36 @@ int32_t alltoall_bytes(dbhip_comm* c, const void* send, void* recv, size_t bytes
 // variable-size pieces between all ranks in ONE group: piece p of every entry goes to / comes from rank p (a local world of one: copies)
 struct XPiece { const uint8_t* send; uint8_t* recv; const size_t* send_off; const size_t* send_bytes; const size_t* recv_off; const size_t* recv_bytes; };
 
-// loopback rendezvous: every rank drains its stream and posts its operation; the last one to arrive makes all the copies
+int32_t loop_failed(LoopGroup* g) {
+  set_error("dbhip_comm loopback: the group was aborted (%s)", g->why.c_str());
+  return DBHIP_ERR_INVALID;
+}
+// marks the group failed and wakes every rank waiting in a rendezvous
+void loop_abort(dbhip_comm* c, const char* why) {
+  LoopGroup* g = c->loop;
+  if (!g) return;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (!g->failed) {
+    g->failed = true;
+    char buf[400];
+    snprintf(buf, sizeof(buf), "rank %d: %s", c->rank, why ? why : "");
+    g->why = buf;
+  }
+  g->cv.notify_all();
+}
+int loop_timeout_seconds() {
+  static const int t = [] { const char* e = getenv("DBHIP_COMM_TIMEOUT_S"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 600; }();
+  return t;
+}
+
+// loopback rendezvous: every rank drains its stream and posts its operation; the last one to arrive makes all the copies. A rank
+// that will not arrive must not leave the others waiting: an aborted group (loop_abort) and a wait past DBHIP_COMM_TIMEOUT_S
+// (default 600 s) end the rendezvous with an error on every rank.
 int32_t loop_collective(dbhip_comm* c, const LoopOp& mine, hipStream_t s) {
   LoopGroup* g = c->loop;
   DBHIP_CHECK(hipStreamSynchronize(s));
   std::unique_lock<std::mutex> lk(g->mu);
+  if (g->failed) return loop_failed(g);
   g->ops[c->rank] = mine;
   const uint64_t gen = g->generation;
   if (++g->arrived == g->world) {
@@ -189,14 +221,28 @@ int32_t loop_collective(dbhip_comm* c, const LoopOp& mine, hipStream_t s) {
       }
     }
     if (st == DBHIP_OK && hipStreamSynchronize(s) != hipSuccess) st = DBHIP_ERR_HIP;
+    if (st == DBHIP_ERR_HIP) set_error("dbhip_comm loopback: a device copy of the rendezvous failed");
     g->status = st;
+    g->status_msg = st == DBHIP_OK ? "" : dbhip_last_error();
     g->arrived = 0;
     ++g->generation;
     g->cv.notify_all();
     return st;
   }
-  g->cv.wait(lk, [&] { return g->generation != gen; });
-  return g->status;
+  const bool in_time = g->cv.wait_for(lk, std::chrono::seconds(loop_timeout_seconds()), [&] { return g->generation != gen || g->failed; });
+  if (g->generation != gen) {   // the rendezvous completed (its status is every rank's status)
+    if (g->status != DBHIP_OK) set_error("%s", g->status_msg.c_str());
+    return g->status;
+  }
+  if (!in_time && !g->failed) {
+    g->failed = true;
+    char buf[200];
+    snprintf(buf, sizeof(buf), "rank %d waited %d s for %d of %d ranks", c->rank, loop_timeout_seconds(), g->world - g->arrived, g->world);
+    g->why = buf;
+    g->cv.notify_all();
+  }
+  --g->arrived;   // (this rank's post is withdrawn: the group is dead, nobody will complete it)
+  return loop_failed(g);
 }
 
 int32_t alltoallv_group(dbhip_comm* c, const std::vector<XPiece>& xs, hipStream_t s) {
@@ -231,11 +277,16 @@ int32_t alltoall_bytes_loop(dbhip_comm* c, const void* send, void* recv, size_t 
   return alltoallv_group(c, xs, s);
 }
 
-__global__ __launch_bounds__(256) void topk_globalise_kernel(const uint32_t* __restrict__ idx, int64_t n, uint64_t row_offset, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void topk_globalise_kernel(const uint32_t* __restrict__ idx, int64_t n, uint64_t row_offset, uint32_t* __restrict__ out,
+                                                             uint32_t* __restrict__ overflow) {
+  bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t v = idx[i];
-    out[i] = v == 0xFFFFFFFFu ? v : (uint32_t)((uint64_t)v + row_offset);
+    const uint64_t gid = (uint64_t)v + row_offset;
+    bad |= v != 0xFFFFFFFFu && gid > 0xFFFFFFFEULL;   // (0xFFFFFFFF is "no neighbour": a real id must stay below it)
+    out[i] = v == 0xFFFFFFFFu ? v : (uint32_t)gid;
   }
+  if (__ballot(bad) && lane_id() == 0) atomicOr(overflow, 1u);
 }
 // [world][nq][k] (rank-major, what the all-gather produces) -> [nq][world * k] (what dbhip_vec_topk_merge takes)
 template <typename T>
@@ -343,8 +394,21 @@ int32_t dbhip_exchange_destroy(dbhip_exchange* x) {
   return DBHIP_OK;
 }
 
+static int32_t exchange_begin_impl(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
+                                   dbhip_exchange** out_host, void* stream);
+// A rank whose exchange fails — bad arguments, an allocation, the scatter — would leave the other ranks of a loopback group in the
+// rendezvous of the counts: it aborts the group instead, and they return DBHIP_ERR_INVALID with this rank's message.
 int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
                              dbhip_exchange** out_host, void* stream) {
+  const int32_t rc = exchange_begin_impl(c, cols, ncols, dest_index, n, out_recv_rows_host, out_host, stream);
+  if (rc != DBHIP_OK && c && c->loop) {
+    const std::string why = dbhip_last_error();   // (loop_abort must not disturb this rank's own message)
+    loop_abort(c, why.c_str());
+  }
+  return rc;
+}
+static int32_t exchange_begin_impl(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
+                                   dbhip_exchange** out_host, void* stream) {
   DBHIP_REQUIRE(c && out_recv_rows_host && out_host && ncols >= 0 && n >= 0 && (ncols == 0 || cols), "dbhip_exchange_begin: bad argument");
   for (int k = 0; k < ncols; ++k)
     DBHIP_REQUIRE(!(cols[k].type == DBHIP_T_STRING && cols[k].n_buffers > 0 && !cols[k].buffers), "dbhip_exchange_begin: a String column with n_buffers > 0 needs its buffers");
@@ -617,14 +681,16 @@ int32_t dbhip_vec_topk_allgather(dbhip_comm* c, const uint32_t* idx_dev, const f
   const int64_t per = (int64_t)nq * k;
   hipStream_t s = resolve_stream(stream);
   // staging: [mine: ids | dists] [gathered ids: W x per] [gathered dists] [regrouped ids] [regrouped dists]
-  uint8_t* ws = (uint8_t*)scratch((size_t)per * 8 + (size_t)W * per * 16 + 256, 18, s);
+  uint8_t* ws = (uint8_t*)scratch((size_t)per * 8 + (size_t)W * per * 16 + 512, 18, s);
   if (!ws) return DBHIP_ERR_HIP;
+  uint32_t* overflow = (uint32_t*)(ws + (((size_t)per * 8 + (size_t)W * per * 16 + 255) & ~(size_t)255));
+  DBHIP_CHECK(hipMemsetAsync(overflow, 0, 4, s));
   uint32_t* my_i = (uint32_t*)ws;
   uint32_t* all_i = my_i + per;
   float* all_d = (float*)(all_i + (size_t)W * per);
   uint32_t* grp_i = (uint32_t*)(all_d + (size_t)W * per);
   float* grp_d = (float*)(grp_i + (size_t)W * per);
-  hipLaunchKernelGGL(topk_globalise_kernel, dim3(grid_for(per, 256)), dim3(256), 0, s, idx_dev, per, row_offset, my_i);
+  hipLaunchKernelGGL(topk_globalise_kernel, dim3(grid_for(per, 256)), dim3(256), 0, s, idx_dev, per, row_offset, my_i, overflow);
   DBHIP_LAUNCH_CHECK();
   if (c->loop) {
     LoopOp a; a.kind = 1; a.send = (const uint8_t*)my_i; a.recv = (uint8_t*)all_i; a.bytes = (size_t)per * 4;
@@ -649,7 +715,13 @@ int32_t dbhip_vec_topk_allgather(dbhip_comm* c, const uint32_t* idx_dev, const f
   DBHIP_LAUNCH_CHECK();
   int32_t rc = dbhip_vec_topk_merge(grp_d, grp_i, (int64_t)W * k, nq, k, out_idx_dev, out_dist_dev, stream);
   if (rc) return rc;
+  uint32_t over = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&over, overflow, 4, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));   // scratch is reused by the next call
+  if (over) {   // (found after the collectives so that every rank takes part in them whatever its own ids are)
+    set_error("dbhip_vec_topk_allgather: a row id of this shard + its row offset %llu does not fit the u32 id space", (unsigned long long)row_offset);
+    return DBHIP_ERR_INVALID;
+  }
   return DBHIP_OK;
 }
 
@@ -709,6 +781,13 @@ int32_t dbhip_comm_destroy(dbhip_comm* c) {
   if (c->send) (void)dbhip_free(c->send);
   if (c->recv) (void)dbhip_free(c->recv);
   delete c;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_comm_abort(dbhip_comm* c) {
+  DBHIP_REQUIRE(c, "dbhip_comm_abort: NULL argument");
+  if (c->loop) loop_abort(c, "dbhip_comm_abort");
+  else if (c->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm), c->comm = nullptr;
   return DBHIP_OK;
 }
 

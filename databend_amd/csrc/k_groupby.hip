@@ -82,6 +82,7 @@ struct dbhip_groupby {
   int gbc_part_lcap_max;                   // largest partition table of the compact kernels, chosen with the partitioning (0 = default)
   uint32_t gbc_part_cap;                   // rows of a partition's region when the last scatter was the direct one, else 0
   uint64_t* gbc_spill; size_t gbc_spill_cap;   // rows (table layout) that did not fit an LDS table
+  uint64_t arena_pinned, arena_live;           // bytes pinned since the arena's live bytes were last counted; that count
   int gbc_skip;                                // this chunk goes through the generic kernels (its spill list covers every row)
   uint32_t* gbc_split; size_t gbc_split_cap;   // heavy partitions (gbc_split_map_kernel): nsp[P] | cursor, extra workgroups | map[extra]
 };
@@ -1218,12 +1219,29 @@ int32_t refuse_str_minmax_state(const GbLayout& L, const char* fn) {
 // mode 0: sum the (8-byte rounded) sizes of the long values whose bytes lie outside [lo, hi) into *acc;
 // mode 1: copy them into the arena (bump cursor ctrl[8]) and point the state at the copy;
 // mode 2: the arena moved from [lo, hi) by `delta`: states that point into the old range follow it.
+// mode 0 / 1: count / copy the long min / max String winners that still lie OUTSIDE the arena [lo, hi); mode 2: the arena moved by
+// `delta`; mode 3: count the LIVE bytes of the arena — long keys and the winners inside it — into acc; mode 4: move the live bytes
+// from the old arena at `lo` into the new one at `arena` (cursor ctrl[8], zeroed by the host) and rewrite key offsets / winner addresses
 __global__ __launch_bounds__(256) void gb_pin_strings_kernel(GbLayout L, const uint64_t* __restrict__ slot_hash, uint64_t* __restrict__ rows,
                                                              int64_t cap, uint64_t lo, uint64_t hi, int mode, uint8_t* arena, int64_t delta,
                                                              uint64_t* ctrl, unsigned long long* acc) {
   uint64_t mine = 0;
   for (int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sl < cap; sl += (int64_t)gridDim.x * blockDim.x) {
     if (slot_hash[sl] == 0) continue;
+    if (mode >= 3) {
+      uint64_t* r = rows + sl * L.W;
+      for (int k = 1; k < L.nkey_words; ++k) {
+        if (!((L.str_w1_mask >> k) & 1)) continue;
+        const uint32_t len = (uint32_t)r[k - 1];
+        if (len <= 12) continue;
+        const uint64_t room = ((uint64_t)len + 7) & ~7ULL;
+        if (mode == 3) { mine += room; continue; }
+        const uint64_t off = atomicAdd((unsigned long long*)&ctrl[8], (unsigned long long)room);
+        const uint8_t* src = (const uint8_t*)lo + r[k];
+        for (uint32_t i = 0; i < len; ++i) arena[off + i] = src[i];
+        r[k] = off;
+      }
+    }
     for (int a = 0; a < L.naggs; ++a) {
       if (!gb_minmax_str(L, a)) continue;
       uint64_t* st = rows + sl * L.W + L.agg_off[a];
@@ -1231,8 +1249,9 @@ __global__ __launch_bounds__(256) void gb_pin_strings_kernel(GbLayout L, const u
       if (!st[1] || len <= 12) continue;
       const bool inside = st[2] >= lo && st[2] < hi;
       if (mode == 2) { if (inside) st[2] = (uint64_t)((int64_t)st[2] + delta); continue; }
-      if (inside) continue;
       const uint64_t room = ((uint64_t)len + 7) & ~7ULL;
+      if (mode == 3) { if (inside) mine += room; continue; }
+      if (mode == 4 ? !inside : inside) continue;
       if (mode == 0) { mine += room; continue; }
       const uint64_t off = atomicAdd((unsigned long long*)&ctrl[8], (unsigned long long)room);
       const uint8_t* src = (const uint8_t*)st[2];
@@ -1240,7 +1259,7 @@ __global__ __launch_bounds__(256) void gb_pin_strings_kernel(GbLayout L, const u
       st[2] = (uint64_t)(arena + off);
     }
   }
-  if (mode == 0) {
+  if (mode == 0 || mode == 3) {
     mine = wave_sum_u64(mine);
     if (mine && lane_id() == 0) atomicAdd(acc, (unsigned long long)mine);
   }
@@ -1289,6 +1308,36 @@ int32_t pin_string_states(dbhip_groupby* g, hipStream_t s) {
   hipLaunchKernelGGL(gb_pin_strings_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint64_t)g->arena,
                      (uint64_t)g->arena + g->arena_cap, 1, g->arena, (int64_t)0, g->ctrl, acc);
   DBHIP_LAUNCH_CHECK();
+  // Displaced winners stay behind in the arena (max() over an ascending column pins a new string per group and block): once as
+  // many bytes were pinned as the arena held live at the last look (at least 1 MiB), the live bytes are counted, and an arena more
+  // than twice that size is rebuilt from the current keys and winners.
+  g->arena_pinned += bytes;
+  if (g->arena_pinned < (g->arena_live > ((uint64_t)1 << 20) ? g->arena_live : ((uint64_t)1 << 20))) return DBHIP_OK;
+  g->arena_pinned = 0;
+  DBHIP_CHECK(hipMemsetAsync(acc, 0, 8, s));
+  hipLaunchKernelGGL(gb_pin_strings_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint64_t)g->arena,
+                     (uint64_t)g->arena + g->arena_cap, 3, g->arena, (int64_t)0, g->ctrl, acc);
+  DBHIP_LAUNCH_CHECK();
+  uint64_t two[2] = {0, 0};   // live bytes, bytes in use
+  DBHIP_CHECK(hipMemcpyAsync(&two[0], acc, 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipMemcpyAsync(&two[1], &g->ctrl[8], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  g->arena_live = two[0];
+  if (two[1] <= 2 * two[0] + ((uint64_t)1 << 20)) return DBHIP_OK;
+  size_t want = (size_t)1 << 20;
+  while (want < 2 * two[0]) want *= 2;
+  uint8_t* na = nullptr;
+  if ((rc = dbhip_alloc(want, (void**)&na))) return rc;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[8], 0, 8, s));
+  hipLaunchKernelGGL(gb_pin_strings_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint64_t)g->arena,
+                     (uint64_t)g->arena + g->arena_cap, 4, na, (int64_t)0, g->ctrl, acc);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: string arena compacted, %llu bytes in use -> %llu live (capacity %zu -> %zu)\n",
+                                     (unsigned long long)two[1], (unsigned long long)two[0], g->arena_cap, want);
+  (void)dbhip_free(g->arena);
+  g->arena = na;
+  g->arena_cap = want;
   return DBHIP_OK;
 }
 // after a kernel that summed the long-string bytes of its rows into ctrl[9]: read it, remember that the table holds long
@@ -1920,11 +1969,10 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
       GBC_DISPATCH(GD, GBC_AGG);
 #undef GBC_AGG
     } else if (big) {
-      static bool attr_set = false;   // > 64 KB of dynamic LDS needs the attribute once per process
-      if (!attr_set) {
-        DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_lds_preagg_kernel<2, 2, false, 4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-      }
+      static std::once_flag attr_once;   // > 64 KB of dynamic LDS needs the attribute once per process
+      static hipError_t attr_err = hipSuccess;
+      std::call_once(attr_once, [] { attr_err = hipFuncSetAttribute((const void*)gb_lds_preagg_kernel<2, 2, false, 4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); });
+      DBHIP_CHECK(attr_err);
       hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 4, 1024>), dim3(grid), dim3(1024), lds_i, s, L, C, A);
     } else if (small && R == 4) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 4>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
     else if (small) hipLaunchKernelGGL((gb_lds_preagg_kernel<2, 2, false, 8>), dim3(grid), dim3(256), lds_bytes, s, L, C, A);
@@ -2847,12 +2895,13 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
   const size_t row_bytes = 4 + (size_t)(L.W | 1) * 8;
   const size_t lds2 = (size_t)P * 4 + (size_t)T * 2 * row_bytes, lds1 = (size_t)P * 4 + (size_t)T * row_bytes;
   const size_t lds_max = 144 * 1024;
-  static bool raised = false;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
-  if (!raised) {
-    DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_part_scatter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    DBHIP_CHECK(hipFuncSetAttribute((const void*)gb_part_scatter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    raised = true;
-  }
+  static std::once_flag raised_once;   // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+  static hipError_t raised_err = hipSuccess;
+  std::call_once(raised_once, [] {
+    raised_err = hipFuncSetAttribute((const void*)gb_part_scatter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)gb_part_scatter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+  });
+  DBHIP_CHECK(raised_err);
   if (!no_stage && lds2 <= lds_max)
     hipLaunchKernelGGL((gb_part_scatter_kernel<2>), dim3((int)nwg), dim3(T), lds2, s, L, C, row0, cn, pbits, rows_per_wg, mat,
                        g->rows_in, g->ctrl);

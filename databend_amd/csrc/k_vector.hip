@@ -15,6 +15,7 @@
 //                  (dist, row id) per query; the n x nq matrix is never materialised.
 // f32 results depend on summation order; parity with the reference (ndarray's 8-lane unrolled
 // sum) is a tolerance, not bit equality — see DESIGN.md.
+#include <mutex>
 #include "dev_common.h"
 #include "runtime.h"
 
@@ -1151,13 +1152,16 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
   // (the bf16 image of the queries is padded with zero rows to whole 256-row tiles: the 8-phase filter kernel stages them unclamped)
   const int nq_pad = (int)ceil_div(nq, 256) * 256;
   const size_t qh_bytes = (((size_t)nq_pad * dpad * 2) + 255) & ~(size_t)255;
-  uint8_t* qws = (uint8_t*)scratch(qh_bytes + (size_t)nq * 12 + (size_t)nq_pad * 12 + 256, 11, s);
+  // (qA / qX / qY hold nq floats each in slots of nq4 = nq rounded up to 4: the coefficient arrays behind them are read as float4
+  //  by bf16_filter256_kernel and have to start on 16 bytes whatever nq is)
+  const size_t nq4 = ((size_t)nq + 3) & ~(size_t)3;
+  uint8_t* qws = (uint8_t*)scratch(qh_bytes + nq4 * 12 + (size_t)nq_pad * 12 + 256, 11, s);
   if (!qws) return DBHIP_ERR_HIP;
   uint16_t* qh = (uint16_t*)qws;
   float* qA = (float*)(qws + qh_bytes);
-  float* qX = qA + nq;
-  float* qY = qX + nq;
-  float* qcB = qY + nq;
+  float* qX = qA + nq4;
+  float* qY = qX + nq4;
+  float* qcB = qY + nq4;
   float* qcG = qcB + nq_pad;
   float* qcT = qcG + nq_pad;
   if (nq_pad > nq) DBHIP_CHECK(hipMemsetAsync(qh + (size_t)nq * dpad, 0, (size_t)(nq_pad - nq) * dpad * 2, s));
@@ -1191,13 +1195,14 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.cand_i = cand_i; A.cand_cnt = cnt; A.cand_cap = CAND_CAP; A.row_origin = (uint32_t)lo;
     const int64_t blocks = ceil_div(A.n_itiles, 8) * 8 * A.n_qtiles;
     if (f256) {
-      static bool raised = false;
-      if (!raised) {
-        DBHIP_CHECK(hipFuncSetAttribute((const void*)bf16_filter256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        DBHIP_CHECK(hipFuncSetAttribute((const void*)bf16_filter256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        DBHIP_CHECK(hipFuncSetAttribute((const void*)bf16_filter256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        raised = true;
-      }
+      static std::once_flag raised_once;
+      static hipError_t raised_err = hipSuccess;
+      std::call_once(raised_once, [] {
+        raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      });
+      DBHIP_CHECK(raised_err);
       A.qcB = qcB; A.qcG = qcG; A.qcT = qcT;
       const dim3 cg((unsigned)ceil_div(nq_pad, 256)), fg((unsigned)blocks);
       if (l2) {

@@ -31,7 +31,8 @@ struct Scratch {
 };
 // Scratch is keyed by (thread, stream): two asynchronous calls of one thread on two streams never share a buffer, so a thread
 // may keep several streams busy at once. A buffer that has to grow is released after ITS stream has drained, not after the whole
-// device. The registry is process-wide (one mutex, taken per lookup) so that the entries have an owner who can release them:
+// device. The registry is process-wide (one mutex, taken per lookup and never held across a HIP call that can wait) so that the
+// entries have an owner who can release them:
 //   * dbhip_stream_destroy / dbhip_stream_release_scratch free every thread's entry of that stream (after draining it);
 //   * a thread that exits frees its entries (thread_local sentinel below; the main thread at process exit leaves it to the OS —
 //     the HIP runtime may already be shutting down);
@@ -103,30 +104,45 @@ hipStream_t resolve_stream(void* stream) {
   return g_stream;
 }
 
+// The map is only looked up / changed under g_scratch_mu; the device work (synchronise, free, allocate) happens AFTER the lock is
+// dropped, on state only this thread uses: an entry belongs to the (thread, stream) pair of its key, std::map nodes do not move,
+// and the one cross-thread path — dbhip_stream_release_scratch / dbhip_stream_destroy — requires that no thread is inside a dbhip
+// call on that stream (dbhip.h). A host thread that grows a buffer behind a long kernel therefore no longer blocks every other
+// thread's scratch() call.
 void* scratch(size_t bytes, int slot, hipStream_t stream) {
   const uint64_t tid = t_scratch_owner.tid;
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  if (!g_scratch) g_scratch = new (std::nothrow) std::map<ScratchKey, StreamScratch>();
-  if (!g_scratch) { set_error("scratch: out of host memory"); return nullptr; }
-  const ScratchKey key{tid, stream};
-  auto it = g_scratch->find(key);
-  if (it == g_scratch->end()) {
-    // a new (thread, stream) pair: evict this thread's least recently used entry once it holds too many
-    size_t mine = 0;
-    auto lru = g_scratch->end();
-    for (auto j = g_scratch->lower_bound(ScratchKey{tid, nullptr}); j != g_scratch->end() && j->first.tid == tid; ++j) {
-      ++mine;
-      if (lru == g_scratch->end() || j->second.last_use < lru->second.last_use) lru = j;
+  Scratch* sp = nullptr;
+  StreamScratch evicted;
+  bool have_evicted = false;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch) g_scratch = new (std::nothrow) std::map<ScratchKey, StreamScratch>();
+    if (!g_scratch) { set_error("scratch: out of host memory"); return nullptr; }
+    const ScratchKey key{tid, stream};
+    auto it = g_scratch->find(key);
+    if (it == g_scratch->end()) {
+      // a new (thread, stream) pair: evict this thread's least recently used entry once it holds too many
+      size_t mine = 0;
+      auto lru = g_scratch->end();
+      for (auto j = g_scratch->lower_bound(ScratchKey{tid, nullptr}); j != g_scratch->end() && j->first.tid == tid; ++j) {
+        ++mine;
+        if (lru == g_scratch->end() || j->second.last_use < lru->second.last_use) lru = j;
+      }
+      if (mine >= SCRATCH_STREAMS_PER_THREAD && lru != g_scratch->end()) {
+        evicted = lru->second;   // (plain pointers: freed below, outside the lock)
+        have_evicted = true;
+        g_scratch->erase(lru);
+      }
+      it = g_scratch->emplace(key, StreamScratch()).first;
     }
-    if (mine >= SCRATCH_STREAMS_PER_THREAD && lru != g_scratch->end()) {
-      (void)hipDeviceSynchronize();   // (the evicted stream may be gone already: drain the device, not the stream)
-      free_entry(lru->second);
-      g_scratch->erase(lru);
-    }
-    it = g_scratch->emplace(key, StreamScratch()).first;
+    it->second.last_use = g_scratch_clock.fetch_add(1) + 1;
+    sp = &it->second.slot[slot];
   }
-  it->second.last_use = g_scratch_clock.fetch_add(1) + 1;
-  Scratch& s = it->second.slot[slot];
+  if (have_evicted) {
+    (void)hipDeviceSynchronize();   // (the evicted stream may be gone already: drain the device, not the stream)
+    free_entry(evicted);
+  }
+  Scratch& s = *sp;
   if (s.cap < bytes) {
     if (s.p) {
       (void)hipStreamSynchronize(stream);

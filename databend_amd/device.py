@@ -1626,6 +1626,10 @@ class Comm:
         check(lib().dbhip_comm_unique_id(buf))
         return bytes(buf)
 
+    def abort(self):
+        """dbhip_comm_abort: this rank gives up; the other ranks' waiting (and later) collectives return an error instead of hanging"""
+        check(lib().dbhip_comm_abort(self.h))
+
     def exchange_allgather(self, table, max_rows=256, stream=None):
         check(lib().dbhip_groupby_exchange_allgather(table.h, self.h, C.c_int64(max_rows), stream))
 

@@ -129,7 +129,8 @@ int32_t dbhip_stream_destroy(void* stream);        /* drains the stream, frees t
 /* Internal scratch is bounded — a thread keeps the scratch of at most 8 streams (least recently used evicted), a thread that
  * exits frees its own — and can be returned at any time: drains `stream` (NULL = the library stream) and frees every thread's
  * scratch buffers of it. For streams the library did not create (a host's or torch's stream pool) call this before the stream
- * goes away. */
+ * goes away. REQUIREMENT (also of dbhip_stream_destroy): no thread may be inside a dbhip call on `stream` while this runs — the
+ * buffers of other threads are freed without their taking part; calls on OTHER streams may run concurrently. */
 int32_t dbhip_stream_release_scratch(void* stream);
 int32_t dbhip_stream_sync(void* stream);
 /* Cancellation (the reference polls check_interrupt() inside its long loops, src/query/pipeline/src/core/processor.rs:36-41,
@@ -809,6 +810,11 @@ int32_t dbhip_comm_create(int32_t rank, int32_t world, const uint8_t* id128_host
  * world > 1 where only one GPU exists (tests/test_gpu_comm.py); every rank must call the same collective, from its own thread. */
 int32_t dbhip_comm_create_loopback(uint64_t group_id, int32_t rank, int32_t world, dbhip_comm** out_host);
 int32_t dbhip_comm_destroy(dbhip_comm* c);
+/* A rank that gives up (its part of the plan failed, the query was cancelled) tells the others instead of leaving them waiting:
+ * loopback — the group is marked failed, every rank waiting in a rendezvous and every later collective of the group returns
+ * DBHIP_ERR_INVALID with the aborting rank's message (a failed dbhip_exchange_begin does this by itself; a rendezvous also gives up
+ * after DBHIP_COMM_TIMEOUT_S seconds, default 600); RCCL — ncclCommAbort, the communicator is gone afterwards. */
+int32_t dbhip_comm_abort(dbhip_comm* c);
 int32_t dbhip_comm_allgather(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
 int32_t dbhip_comm_alltoall(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream);
 int32_t dbhip_comm_allreduce_sum_u64(dbhip_comm* c, const uint64_t* send_dev, uint64_t* recv_dev, int64_t count, void* stream);

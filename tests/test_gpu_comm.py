@@ -3,6 +3,8 @@ of one, both as the local object (no RCCL) and as a REAL RCCL communicator of on
 ncclAllGather / grouped ncclSend + ncclRecv / ncclAllReduce through librccl.so): the exchanges must leave the table's result
 unchanged, report an overflowing block before touching the table, and the plain collectives must be identities. The N > 1
 behaviour of the same block protocol is covered over gloo by tests/test_dist_gloo.py (world size 2)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -280,3 +282,73 @@ def test_shard_topk_allgather_and_partial_state_exchange_between_ranks(gpu, worl
             merged[key] = (sm, cnt)
     allk, allv = np.concatenate(keys), np.concatenate(vals)
     assert merged == {int(u): (int(allv[allk == u].sum()), int((allk == u).sum())) for u in np.unique(allk)}
+
+
+def test_a_rank_that_gives_up_wakes_the_others(gpu):
+    """(a) dbhip_comm_abort while the other rank waits in an all-gather; (b) an exchange that fails on ONE rank (its String column claims
+    data buffers it does not have) while the other rank is already in the rendezvous of the counts: nobody hangs, the waiting rank gets
+    DBHIP_ERR_INVALID with the failing rank's message, and the group stays failed for later collectives."""
+    import time
+    D = gpu
+    for case in ("abort", "failed exchange"):
+        gid = 9900 + (1 if case == "abort" else 2)
+        n = 1000
+        vals = np.arange(n, dtype=np.int64)
+        dest = (np.arange(n) % 2).astype(np.uint32)
+
+        def rank_fn(r):
+            comm = D.Comm.loopback(gid, r, 2)
+            try:
+                if case == "abort":
+                    if r == 1:
+                        time.sleep(0.5)
+                        comm.abort()
+                        return "aborted"
+                    buf = D.DeviceBuffer(64)
+                    out = D.DeviceBuffer(128)
+                    comm.allgather(buf.ptr, out.ptr, 64)
+                    return "completed"
+                col = D.Column.from_numpy(vals)
+                if r == 1:
+                    time.sleep(0.5)
+                    bad = D.Column.strings([b"x" * 20] * n)
+                    c = bad.c()
+                    c.buffers = None                                   # n_buffers > 0 without the buffers: refused before any collective
+                    x, rows = C.c_void_p(), C.c_int64()
+                    T.check(T.lib().dbhip_exchange_begin(comm.h, (type(c) * 1)(c), 1, C.c_void_p(D.DeviceBuffer.from_numpy(dest).ptr), C.c_int64(n),
+                                                         C.byref(rows), C.byref(x), None))
+                    return "completed"
+                comm.exchange_block([col], D.DeviceBuffer.from_numpy(dest))
+                return "completed"
+            except T.DbhipError as e:
+                try:                                                    # the group is dead for good
+                    buf = D.DeviceBuffer(64)
+                    keep = D.DeviceBuffer(128)
+                    comm.allgather(buf.ptr, keep.ptr, 64)
+                    later = "later collective completed"
+                except T.DbhipError as e2:
+                    later = str(e2)
+                return (e.code, str(e), later)
+            finally:
+                comm.destroy()
+        t0 = time.time()
+        outs = run_ranks(2, rank_fn)
+        assert time.time() - t0 < 60
+        code, msg, later = outs[0]
+        assert code == T.ERR_INVALID and "aborted" in msg and "rank 1" in msg and "aborted" in later, (case, outs)
+        if case == "failed exchange":
+            assert outs[1][0] == T.ERR_INVALID and "needs its buffers" in outs[1][1] and "needs its buffers" in msg
+
+
+def test_topk_allgather_refuses_ids_past_the_u32_space(gpu):
+    D = gpu
+    comm = D.Comm.local()
+    nq, k = 4, 3
+    ids = np.arange(nq * k, dtype=np.uint32).reshape(nq, k)
+    ids[0, 2] = 0xFFFFFFFF                                           # "no neighbour" stays what it is
+    dist = np.sort(np.random.default_rng(0).random((nq, k)).astype(np.float32), axis=1)
+    gi, _ = comm.topk_allgather(D.DeviceBuffer.from_numpy(ids), D.DeviceBuffer.from_numpy(dist), nq, k, 2**32 - 20)
+    assert int(gi[1][0]) == 3 + 2**32 - 20
+    with pytest.raises(T.DbhipError, match="does not fit the u32 id space"):
+        comm.topk_allgather(D.DeviceBuffer.from_numpy(ids), D.DeviceBuffer.from_numpy(dist), nq, k, 2**32 - 8)
+    comm.destroy()

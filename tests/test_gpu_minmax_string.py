@@ -98,3 +98,24 @@ def test_string_states_merge_between_live_tables_and_do_not_travel(gpu, oracle):
     # (round 5: the serialized-state block carries the strings as a Nullable(String) column — tests/test_gpu_state_block_wide.py)
     nf = C.c_int32()
     assert T.lib().dbhip_groupby_state_fields(final.h, None, None, 0, C.byref(nf)) == 0 and nf.value == 5
+
+
+def test_the_arena_does_not_keep_displaced_winners_forever(gpu):
+    """max() over a column whose strings grow block after block replaces every group's long winner per block: the bytes of the displaced
+    winners are reclaimed once the arena holds more than twice its live bytes — 60 blocks pin ~5 MB, the arena stays near
+    its live size, and the result is the last block's strings."""
+    D = gpu
+    groups, blocks = 2000, 60
+    g = D.GroupBy([T.T_I64], [(T.AGG_MAX, T.T_STRING, 0, 0, 0)])
+    keys = np.arange(groups, dtype=np.int64)
+    last = None
+    for b in range(blocks):
+        strs = [b"block %04d group %06d padded to forty bytes." % (b, k) for k in keys]
+        g.add_block([D.Column.from_numpy(keys)], [D.Column.strings(strs)], groups)
+        last = strs
+    _, used = g.arena()
+    got = dict(g.result())
+    g.destroy()
+    assert got == {int(k): s for k, s in zip(keys, last)}
+    live = groups * 48
+    assert used < 2 * live + (3 << 20), (used, live)          # (without compaction: blocks x groups x 48 = 5.8 MB)
