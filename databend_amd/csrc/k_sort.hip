@@ -4,7 +4,8 @@
 // kernels/sort_compare.rs:33-283): a u32 permutation refined column by column with
 // sort_unstable_by, asc/desc and nulls-first/last per column, optional row limit
 // (LimitType::LimitRows, :197-209). Only the KEY SEQUENCE is defined (ties are unordered there).
-// Device algorithm: LSD radix sort, stable, 8 bits per pass, over order-preserving u64 encodings
+// Device algorithm: LSD radix sort, stable, 8 bits per pass (round 5: onesweep passes for 64-bit images of 2^20 rows and more,
+// see sort_onesweep_kernel), over order-preserving u64 encodings
 // (the device analogue of the reference's fixed-width row encoding, sorts/core/row_convert/fixed.rs):
 // keys are processed from the last to the first; for each key an encode kernel reads the column
 // THROUGH the current permutation, then one pass per key byte:
@@ -275,6 +276,163 @@ __global__ __launch_bounds__(NT) void sort_scatter_kernel(const K* keys, const u
     const uint32_t digit = (uint32_t)(k >> shift) & 0xFF;
     const uint64_t pos = offs[(int64_t)digit * ntiles + blockIdx.x] + (uint32_t)(j - tile_off[digit]);
     if (out_keys) out_keys[pos] = k;   // (the last pass over a key image: only the permutation is still needed)
+    out_vals[pos] = lvals[j];
+  }
+}
+
+// ---- onesweep (round 5) -------------------------------------------------------------------------------------------------------
+// The passes over ONE key image share a single up-front histogram (all digits of the image: the keys are read once instead of once
+// per pass), and a pass finds where its tiles go without a histogram matrix and a device-wide scan: tile t publishes its digit
+// counts, then looks back over the tiles before it until it meets one that already knows its inclusive prefix (decoupled
+// look-back). Per key and pass 12 B in + 12 B out instead of 8 + 12 + 12, and three launches per pass become one.
+//   status[pass][tile][digit] (u64): bits 63..62 = 0 nothing yet / 1 the tile's own count / 2 the inclusive prefix up to this tile
+//   tiles take their number from a ticket counter, so a tile only ever waits for tiles that are already running
+//   the wait is bounded: a look-back that does not get an answer in ~2^24 polls raises ctl[1], every tile leaves, and the call
+//   fails with an error instead of hanging the device
+constexpr uint64_t OS_FLAG_AGG = 1ULL << 62, OS_FLAG_PREFIX = 2ULL << 62, OS_COUNT_MASK = (1ULL << 62) - 1;
+
+template <typename K, int NB>
+__global__ __launch_bounds__(256) void sort_onesweep_hist_kernel(const K* __restrict__ keys, int64_t n, uint32_t vary_bytes, unsigned long long* __restrict__ ghist) {
+  __shared__ uint32_t h[NB][256];
+  for (int i = threadIdx.x; i < NB * 256; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const K k = keys[i];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if ((vary_bytes >> b) & 1u) atomicAdd(&h[b][(uint32_t)(k >> (8 * b)) & 0xFF], 1u);   // (uniform: bytes that are the same in every key have no pass)
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB * 256; i += 256) {
+    const uint32_t c = (&h[0][0])[i];
+    if (c) atomicAdd(&ghist[i], (unsigned long long)c);
+  }
+}
+
+template <typename K, int NT>
+__global__ __launch_bounds__(NT) void sort_onesweep_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int shift,
+                                                           const unsigned long long* __restrict__ ghist, unsigned long long* __restrict__ status,
+                                                           uint32_t* __restrict__ ctl, K* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+  constexpr int NW = NT / 64, TILE = NT * SORT_ITEMS;
+  __shared__ K lkeys[TILE];
+  __shared__ uint32_t lvals[TILE];
+  __shared__ uint32_t wcount[NW][256];
+  __shared__ uint32_t tile_off[256];
+  __shared__ unsigned long long gpos[256];   // where the tile's keys of a digit go in the output
+  __shared__ unsigned long long wave_tot64[4];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t tile_id;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) tile_id = atomicAdd(&ctl[0], 1u);
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wcount[w][tid] = 0;
+  }
+  __syncthreads();
+  const uint32_t tile = tile_id;
+  const int64_t tile_base = (int64_t)tile * TILE;
+  const int64_t base = tile_base + (int64_t)wave * (64 * SORT_ITEMS);
+  K key[SORT_ITEMS];
+  uint32_t val[SORT_ITEMS];
+  uint32_t lrank[SORT_ITEMS];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    key[r] = i < n ? keys[i] : (K)~0ULL;
+    val[r] = i < n ? vals[i] : 0;
+  }
+  volatile uint32_t* wc = wcount[wave];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool active = i < n;
+    const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xFF;
+    uint64_t m = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t bal = __ballot((digit >> b) & 1);
+      m &= ((digit >> b) & 1) ? bal : ~bal;
+    }
+    const uint32_t rank = __popcll(m & ((1ULL << lane) - 1));
+    const uint32_t prev = wc[digit];
+    __builtin_amdgcn_wave_barrier();
+    if (active && rank == 0) wc[digit] = prev + __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    lrank[r] = prev + rank;
+  }
+  __syncthreads();
+  {
+    uint32_t cw[NW];
+    uint32_t tot = 0, incl = 0;
+    unsigned long long gh = 0, gincl = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { cw[w] = wcount[w][tid]; tot += cw[w]; }
+      // this tile's count is public before anything else: the tiles behind it may already be looking
+      unsigned long long* st = status + (size_t)tile * 256 + tid;
+      if (tile == 0) __hip_atomic_store(st, OS_FLAG_PREFIX | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(st, OS_FLAG_AGG | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      incl = tot;
+      gh = ghist[tid];
+      gincl = gh;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        const unsigned long long go = __shfl_up(gincl, d, 64);
+        if (lane >= d) { incl += o; gincl += go; }
+      }
+      if (lane == 63) { wave_tot[wave] = incl; wave_tot64[wave] = gincl; }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t wb = 0;
+      unsigned long long gwb = 0;
+      for (int w = 0; w < wave; ++w) { wb += wave_tot[w]; gwb += wave_tot64[w]; }
+      uint32_t off = wb + incl - tot;
+      tile_off[tid] = off;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { wcount[w][tid] = off; off += cw[w]; }
+      // look back: keys of this digit in the tiles before this one
+      unsigned long long before = 0;
+      bool stalled = false;
+      for (int64_t t = (int64_t)tile - 1; t >= 0; --t) {
+        const unsigned long long* sp = status + (size_t)t * 256 + tid;
+        unsigned long long v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t polls = 0;
+        while ((v >> 62) == 0) {
+          if ((++polls & 0x3FFu) == 0 && (polls >= (1u << 24) || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { stalled = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (stalled) break;
+        before += v & OS_COUNT_MASK;
+        if ((v >> 62) == 2) break;
+      }
+      if (stalled) __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (tile != 0) __hip_atomic_store(status + (size_t)tile * 256 + tid, OS_FLAG_PREFIX | (before + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gpos[tid] = (gwb + gincl - gh) + before;   // keys of smaller digits anywhere + keys of this digit in earlier tiles
+    }
+  }
+  __syncthreads();
+  if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (a stalled look-back: the host reports it; nothing is written)
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    if (i < n) {
+      const uint32_t digit = (uint32_t)(key[r] >> shift) & 0xFF;
+      const uint32_t p = wcount[wave][digit] + lrank[r];
+      lkeys[p] = key[r];
+      lvals[p] = val[r];
+    }
+  }
+  __syncthreads();
+  const int tile_n = (int)((n - tile_base) < TILE ? (n - tile_base) : TILE);
+#pragma unroll 4
+  for (int j = tid; j < tile_n; j += NT) {
+    const K k = lkeys[j];
+    const uint32_t digit = (uint32_t)(k >> shift) & 0xFF;
+    const uint64_t pos = gpos[digit] + (uint32_t)(j - tile_off[digit]);
+    if (out_keys) out_keys[pos] = k;
     out_vals[pos] = lvals[j];
   }
 }
@@ -796,7 +954,54 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   const int64_t nh = 256 * ntiles;
   // `final_vals`: this call holds the LAST pass of the whole sort — its permutation goes straight to the caller's buffer
   bool wrote_final = false;
+  // onesweep (above) for sorts of 2^20 rows and more in 8192-key tiles; DBHIP_SORT_ONESWEEP=0: the histogram / scan / scatter passes
+  static const bool onesweep_off = getenv("DBHIP_SORT_ONESWEEP") && atoi(getenv("DBHIP_SORT_ONESWEEP")) == 0;
+  const bool onesweep = !onesweep_off && big_tiles && m >= (1 << 20);
+  unsigned long long* os_ws = nullptr;   // [8][256] digit histograms | [8] x (ticket, stall flag) | [8][ntiles][256] status words
+  const size_t os_words = (size_t)8 * 256 + 16 + (size_t)8 * ntiles * 256;
+  if (onesweep) {
+    os_ws = (unsigned long long*)scratch(os_words * 8, 19, s);
+    if (!os_ws) return DBHIP_ERR_HIP;
+  }
+  auto onesweep_passes = [&](int nbytes, uint64_t vary, bool narrow, uint32_t* final_vals) -> int32_t {
+    int last_b = -1, npass = 0;
+    uint32_t vary_bytes = 0;
+    for (int b = 0; b < nbytes; ++b) if (((vary >> (8 * b)) & 0xFF) != 0) { last_b = b; vary_bytes |= 1u << b; ++npass; }
+    if (npass == 0) return DBHIP_OK;
+    DBHIP_POLL_CANCEL(s, "dbhip_sort_perm");
+    DBHIP_CHECK(hipMemsetAsync(os_ws, 0, ((size_t)8 * 256 + 16 + (size_t)npass * ntiles * 256) * 8, s));
+    unsigned long long* ghist = os_ws;
+    uint32_t* ctl = (uint32_t*)(os_ws + 8 * 256);            // per pass: ticket, stall flag
+    unsigned long long* status = os_ws + 8 * 256 + 16;
+    const int hgrid = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (narrow) hipLaunchKernelGGL((sort_onesweep_hist_kernel<uint32_t, 4>), dim3(hgrid), dim3(256), 0, s, (const uint32_t*)kb[cur], m, vary_bytes, ghist);
+    else hipLaunchKernelGGL((sort_onesweep_hist_kernel<uint64_t, 8>), dim3(hgrid), dim3(256), 0, s, (const uint64_t*)kb[cur], m, vary_bytes, ghist);
+    int pass = 0;
+    for (int b = 0; b < nbytes; ++b) {
+      if (!((vary_bytes >> b) & 1u)) continue;
+      uint32_t* ov = (b == last_b && final_vals) ? final_vals : pb[cur ^ 1];
+      if (narrow)
+        hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, 512>), dim3((unsigned)ntiles), dim3(512), 0, s, (const uint32_t*)kb[cur], pb[cur], m, 8 * b, ghist + 256 * b,
+                           status + (size_t)pass * ntiles * 256, ctl + 2 * pass, b == last_b ? (uint32_t*)nullptr : (uint32_t*)kb[cur ^ 1], ov);
+      else
+        hipLaunchKernelGGL((sort_onesweep_kernel<uint64_t, 512>), dim3((unsigned)ntiles), dim3(512), 0, s, (const uint64_t*)kb[cur], pb[cur], m, 8 * b, ghist + 256 * b,
+                           status + (size_t)pass * ntiles * 256, ctl + 2 * pass, b == last_b ? (uint64_t*)nullptr : (uint64_t*)kb[cur ^ 1], ov);
+      if (b == last_b && final_vals) wrote_final = true;
+      cur ^= 1;
+      ++pass;
+    }
+    DBHIP_LAUNCH_CHECK();
+    uint32_t hctl[16];
+    DBHIP_CHECK(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    for (int p = 0; p < npass; ++p)
+      if (hctl[2 * p + 1]) { set_error("dbhip_sort_perm: a tile's look-back got no answer (pass %d); set DBHIP_SORT_ONESWEEP=0", p); return DBHIP_ERR_HIP; }
+    return DBHIP_OK;
+  };
   auto radix_passes = [&](int nbytes, uint64_t vary, bool narrow, uint32_t* final_vals = nullptr) -> int32_t {
+    // (64-bit images only: r05, 64 M keys — 0.535 ms per onesweep pass against 0.725 for histogram + scan + scatter; on 32-bit images
+    //  the look-back pass takes 0.49 ms against 0.45 for the three kernels, whose scatter moves 16 B per key in 0.35 ms)
+    if (onesweep && !narrow) return onesweep_passes(nbytes, vary, narrow, final_vals);
     int last_b = -1;
     for (int b = 0; b < nbytes; ++b) if (((vary >> (8 * b)) & 0xFF) != 0) last_b = b;
     for (int b = 0; b < nbytes; ++b) {

@@ -918,3 +918,27 @@ def test_vector_functions_row_by_row_over_two_columns(gpu, oracle, n, dim):
                 assert np.all(np.abs(got.astype(np.float64) - exp.astype(np.float64)) <= tol * scale + 1e-30), (elem, metric, ls, rs)
     with pytest.raises(T.DbhipError):
         gpu.vec_distance_rows(T.VEC_L2, np.zeros((2, 4), np.int32), np.zeros((2, 4), np.int32), 2, 4, T.T_I32)
+
+
+@pytest.mark.parametrize("n", [1 << 20, 2_500_001])
+def test_sort_perm_onesweep_sizes_match_oracle(gpu, oracle, n):
+    """2^20 rows and more go through the onesweep passes (one histogram per key image, decoupled look-back between the tiles of a
+    pass): 64- and 32-bit images, nullable keys (the extra pass on the NULL flag), descending keys, several keys, constant bytes
+    (skipped passes), a ragged last tile — the permutation is the oracle's, tie order included."""
+    rng = np.random.default_rng(n)
+    cases = sort_cases(rng, n)
+    valid = rng.integers(0, 5, n) > 0
+    combos = [([0], [0], [0], 0), ([1], [1], [0], 0), ([2, 0], [0, 1], [0, 0], 0), ([4, 2], [1, 0], [1, 0], 0), ([6, 3, 1], [0, 1, 0], [0, 1, 0], 0)]
+    for idxs, desc, nf, limit in combos:
+        gcols, hcols = [], []
+        for pos, i in enumerate(idxs):
+            code, arr = cases[i]
+            v = valid if pos == 0 and i != 5 else None
+            gcols.append(gpu.Column.from_numpy(arr, code, validity=v))
+            hcols.append(O.HostCol(code, arr, v))
+        got = gpu.sort_perm(gcols, desc, nf, limit)
+        exp = np.zeros(n, np.uint32)
+        d = (C.c_uint8 * len(idxs))(*desc)
+        f = (C.c_uint8 * len(idxs))(*nf)
+        oracle.orc_sort_perm(O.cols(hcols), d, f, len(idxs), C.c_int64(n), C.c_int64(limit), exp.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(got, exp), (idxs, desc, nf)
