@@ -292,6 +292,8 @@ extern "C" {
     pub fn dbhip_pq_chunk_open_device(chunk_host: *const u8, chunk_len: i64, codec: i32, physical_type: i32, type_length: i32, max_def_level: i32, max_rep_level: i32, out_type: i32, out_host: *mut *mut dbhip_pq_chunk, info_host: *mut dbhip_pq_info) -> i32;
     pub fn dbhip_pq_chunk_decode_device(c: *mut dbhip_pq_chunk, chunk_dev: *const u8, image_dev: *mut u8, out_values_dev: *mut c_void, out_validity_dev: *mut u8, out_nulls_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_pq_chunks_decode_device(chunks: *const *mut dbhip_pq_chunk, n_chunks: i32, chunk_dev: *const *const u8, image_dev: *const *mut u8, out_values_dev: *const *mut c_void, out_validity_dev: *const *mut u8, out_nulls_host: *mut i64, out_status_host: *mut i32, stream: *mut c_void) -> i32;
+    pub fn dbhip_pq_chunk_open_device_list(chunk_host: *const u8, chunk_len: i64, codec: i32, physical_type: i32, type_length: i32, list_nullable: i32, element_nullable: i32, out_type: i32, out_host: *mut *mut dbhip_pq_chunk, info_host: *mut dbhip_pq_info) -> i32;
+    pub fn dbhip_pq_chunk_decode_device_list(c: *mut dbhip_pq_chunk, chunk_dev: *const u8, image_dev: *mut u8, out_offsets_dev: *mut u64, out_list_validity_dev: *mut u8, out_values_dev: *mut c_void, out_elem_validity_dev: *mut u8, out_rows_host: *mut i64, out_elems_host: *mut i64, out_null_lists_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_pq_chunk_close(c: *mut dbhip_pq_chunk) -> i32;
     pub fn dbhip_hnsw_build(vectors_dev: *const f32, n: i64, dim: i32, distance: i32, m: i32, ef_construct: i32, seed: u64, out: *mut *mut dbhip_hnsw, stream: *mut c_void) -> i32;
     pub fn dbhip_hnsw_build_sequential(vectors_dev: *const f32, n: i64, dim: i32, distance: i32, m: i32, ef_construct: i32, levels_host: *const i32, out: *mut *mut dbhip_hnsw, stream: *mut c_void) -> i32;

@@ -95,7 +95,7 @@ SYMBOLS = [
     "dbhip_comm_allreduce_sum_u64", "dbhip_groupby_exchange_allgather", "dbhip_groupby_exchange_alltoall", "dbhip_kmeans", "dbhip_vec_kernel_f32", "dbhip_hnsw_build", "dbhip_hnsw_build_sequential", "dbhip_hnsw_from_graph", "dbhip_hnsw_open", "dbhip_hnsw_export_graph", "dbhip_hnsw_search", "dbhip_hnsw_scores",
     "dbhip_hnsw_encoded", "dbhip_hnsw_meta", "dbhip_hnsw_destroy",
     "dbhip_pq_chunk_open", "dbhip_pq_chunk_validity", "dbhip_pq_chunk_image", "dbhip_pq_chunk_decode", "dbhip_pq_chunk_close",
-    "dbhip_pq_chunk_open_device", "dbhip_pq_chunk_decode_device", "dbhip_pq_chunks_decode_device",
+    "dbhip_pq_chunk_open_device", "dbhip_pq_chunk_decode_device", "dbhip_pq_chunks_decode_device", "dbhip_pq_chunk_open_device_list", "dbhip_pq_chunk_decode_device_list",
     "dbhip_scatter_columns", "dbhip_concat_columns", "dbhip_comm_create_loopback", "dbhip_exchange_begin", "dbhip_shuffle_exchange_begin", "dbhip_sort_exchange_begin", "dbhip_exchange_finish", "dbhip_exchange_string_bytes", "dbhip_exchange_finish_strings", "dbhip_exchange_destroy", "dbhip_vec_topk_allgather",
     # diagnostics and test hooks (declared in the header's last section)
     "dbhip_groupby_debug_set_hash_mask", "dbhip_groupby_debug_set_partition_bits", "dbhip_groupby_debug_set_compact", "dbhip_join_binary_debug_set_hash_mask",

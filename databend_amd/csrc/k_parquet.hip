@@ -650,7 +650,8 @@ int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c) {
   if (!c) return DBHIP_OK;
   (void)hipDeviceSynchronize();
   void* ptrs[] = {c->d_valid, c->d_val, c->d_str_off, c->d_dict_str_off, c->d_dict, c->d_dense, c->d_wcnt, c->d_woff, c->d_blk,
-                  c->dv_pages, c->dv_dp, c->dv_nn, c->dv_voff, c->dv_vbase, c->dv_ctl};
+                  c->dv_pages, c->dv_dp, c->dv_nn, c->dv_voff, c->dv_vbase, c->dv_ctl,
+                  c->d_isrep, c->d_iselem, c->d_lvalid, c->d_ent_valid, c->d_ent_values, c->d_rcnt, c->d_ecnt, c->d_roff, c->d_eoff, c->d_lblk, c->d_lcounts};
   for (void* p : ptrs)
     if (p) (void)dbhip_free(p);
   delete c;

@@ -201,7 +201,42 @@ struct DvChunkD {
   PqConv cv;
   uint32_t dict_n, dict_page, nd, slices;
   uint64_t rows;
+  // List columns: bit width of the definition levels (0 = a flat column), the largest level, the list's own nullability, and the
+  // entry bitmaps next to `bitmap` (= the entry carries a value): continues a row / is an element (NULL or not) / the list is not NULL
+  uint32_t ldw, lmax, lnull, lpad;
+  uint32_t* isrep;
+  uint32_t* iselem;
+  uint32_t* lvalid;
 };
+
+// definition levels of `n` entries from dst0 on — packed at width dw (src) or a run of `run` — into the three entry bitmaps; returns this
+// thread's share of the entries that carry a value. *bad: a level above the column's maximum
+__device__ __forceinline__ uint32_t dv_put_def(const DvChunkD& C, uint64_t dst0, uint32_t n, const uint8_t* __restrict__ src, uint32_t run, uint32_t tid,
+                                               uint32_t nthr, bool* bad) {
+  if (n == 0) return 0;
+  uint32_t ones = 0;
+  const uint32_t D = C.lmax, L = C.lnull;
+  const uint64_t first_word = dst0 >> 5, last_word = (dst0 + n - 1) >> 5;
+  for (uint64_t w = first_word + tid; w <= last_word; w += nthr) {
+    const uint64_t lo = w << 5;
+    const uint64_t a = lo > dst0 ? lo : dst0;
+    const uint64_t e = (lo + 32 < dst0 + n) ? lo + 32 : dst0 + n;
+    uint32_t bv = 0, be = 0, bl = 0;
+    for (uint64_t x = a; x < e; ++x) {
+      const uint32_t v = src ? extract_bits(src, (uint32_t)(x - dst0), (int)C.ldw) : run;
+      const uint32_t bit = 1u << (uint32_t)(x - lo);
+      if (v > D) *bad = true;
+      if (v == D) bv |= bit;
+      if (v >= L + 1) be |= bit;
+      if (v >= L) bl |= bit;
+    }
+    if (bv) atomicOr(&C.bitmap[w], bv);
+    if (be) atomicOr(&C.iselem[w], be);
+    if (bl && L) atomicOr(&C.lvalid[w], bl);
+    ones += (uint32_t)__popc(bv);
+  }
+  return ones;
+}
 
 // definition levels of one data page -> validity bits + the page's non-null count and the offset of its values
 __global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restrict__ cds, const uint2* __restrict__ map) {
@@ -219,6 +254,43 @@ __global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restri
   const uint8_t* s = img + P.img_off;
   uint32_t len, vo;
   const uint8_t* stream;
+  if (C.ldw) {
+    // a List column's page: repetition levels (width 1), then definition levels (width ldw), then the values
+    const uint8_t* rep;
+    uint32_t rlen;
+    bool ok = true;
+    if (P.type == PG_DATA) {
+      ok = P.uncomp_len >= 8;
+      rlen = ok ? (uint32_t)load_le(s, 4) : 0;
+      ok = ok && rlen <= P.uncomp_len - 8;
+      rep = s + 4;
+      len = ok ? (uint32_t)load_le(s + 4 + rlen, 4) : 0;
+      ok = ok && len <= P.uncomp_len - 8 - rlen;
+      stream = s + 8 + rlen;
+      vo = 8 + rlen + len;
+    } else {
+      rlen = P.rep_len; rep = s;              // (the host checked rep_len <= lev_len <= uncomp_len)
+      len = P.lev_len - P.rep_len; stream = s + rlen;
+      vo = P.lev_len;
+    }
+    if (!ok) { dv_fail(ctl, DV_CORRUPT); if (threadIdx.x == 0) { nn[d] = 0; voff[d] = P.uncomp_len; } return; }
+    const uint32_t tid = threadIdx.x;
+    const uint64_t r0 = P.row_start;
+    bool bad = false;
+    ok = dv_walk_hybrid(
+        rep, rlen, 1, P.num_values,
+        [&](uint32_t first, uint32_t n, uint32_t v) { if (v == 1) (void)dv_put_bits(C.isrep, r0 + first, n, nullptr, tid, 256); },
+        [&](uint32_t first, uint32_t n, const uint8_t* src) { (void)dv_put_bits(C.isrep, r0 + first, n, src, tid, 256); });
+    uint32_t mine = 0;
+    ok = ok && dv_walk_hybrid(
+        stream, len, (int)C.ldw, P.num_values,
+        [&](uint32_t first, uint32_t n, uint32_t v) { mine += dv_put_def(C, r0 + first, n, nullptr, v, tid, 256, &bad); },
+        [&](uint32_t first, uint32_t n, const uint8_t* src) { mine += dv_put_def(C, r0 + first, n, src, 0, tid, 256, &bad); });
+    const uint32_t total = dv_block_sum(mine, sh4);
+    if (!ok || __syncthreads_or(bad ? 1 : 0)) { dv_fail(ctl, DV_CORRUPT); ok = false; }
+    if (tid == 0) { nn[d] = ok ? total : 0; voff[d] = ok ? vo : P.uncomp_len; }
+    return;
+  }
   if (P.type == PG_DATA) {
     if (P.uncomp_len < 4) { dv_fail(ctl, DV_CORRUPT); if (threadIdx.x == 0) { nn[d] = 0; voff[d] = P.uncomp_len; } return; }
     len = (uint32_t)load_le(s, 4);
@@ -534,14 +606,20 @@ int32_t dv_malformed(const char* what) {
 
 extern "C" {
 
-int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
-                                   int32_t max_def_level, int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
-                                   dbhip_pq_info* info_host) {
+}  // extern "C"
+namespace {
+// list_mode: a List<primitive> leaf (one repeated ancestor): max_def_level = list_nullable + 1 + element_nullable, max_rep_level = 1
+int32_t open_device_impl(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
+                         int32_t max_def_level, int32_t max_rep_level, int32_t out_type, bool list_mode, int32_t list_nullable, int32_t elem_nullable,
+                         dbhip_pq_chunk** out_host, dbhip_pq_info* info_host) {
   DBHIP_REQUIRE(chunk_host && out_host && chunk_len >= 0, "dbhip_pq_chunk_open_device: NULL argument");
   *out_host = nullptr;
   if (codec != CODEC_NONE && codec != CODEC_SNAPPY && codec != CODEC_LZ4_RAW && codec != CODEC_ZSTD)
     return dv_unsupported("compression codec other than UNCOMPRESSED / SNAPPY / ZSTD / LZ4_RAW");
-  if (max_rep_level != 0 || max_def_level < 0 || max_def_level > 1) return dv_unsupported("nested column (repetition / definition level > 1)");
+  if (!list_mode && (max_rep_level != 0 || max_def_level < 0 || max_def_level > 1))
+    return dv_unsupported("nested column (repetition / definition level > 1; List<primitive>: dbhip_pq_chunk_open_device_list)");
+  const int32_t list_max_def = list_mode ? max_def_level : 0;
+  if (list_mode) max_def_level = 1;   // (for the flat pipeline the leaf is a nullable column over the level entries)
   if (chunk_len >= (1LL << 32)) return dv_unsupported("column chunk of 4 GiB or more");
   if (!type_pair_ok(physical_type, type_length, out_type)) {
     set_error("dbhip_pq_chunk_open_device: physical type %d (length %d) cannot be decoded into dbhip type %d", physical_type, type_length, out_type);
@@ -551,6 +629,7 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
   if (!c) { set_error("dbhip_pq_chunk_open_device: out of host memory"); return DBHIP_ERR_HIP; }
   c->device_mode = true; c->codec = codec;
   c->physical = physical_type; c->type_length = type_length; c->max_def = max_def_level; c->out_type = out_type;
+  c->list = list_mode; c->list_nullable = list_nullable; c->elem_nullable = elem_nullable; c->list_max_def = list_max_def;
   c->chunk_len = chunk_len; c->rows = 0; c->nulls = -1; c->nonnull = 0; c->n_pages = 0;
   c->dict_n = -1; c->dict_off = 0; c->dict_bytes = 0;
   c->d_valid = nullptr; c->d_val = nullptr; c->d_str_off = nullptr; c->d_dict_str_off = nullptr; c->d_dict = nullptr; c->d_dense = nullptr;
@@ -575,9 +654,10 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
       if (h.num_values < 0) { rc = dv_malformed("page without num_values"); break; }
       P.num_values = (uint32_t)h.num_values;
       if (h.type == PG_DATA_V2) {
-        if (h.rep_len != 0) { rc = dv_unsupported("repetition levels"); break; }
-        if (h.def_len < 0) { rc = dv_malformed("level byte length"); break; }
-        P.lev_len = (uint32_t)h.def_len;
+        if (h.rep_len != 0 && !list_mode) { rc = dv_unsupported("repetition levels"); break; }
+        if (h.def_len < 0 || h.rep_len < 0) { rc = dv_malformed("level byte length"); break; }
+        P.rep_len = (uint32_t)h.rep_len;
+        P.lev_len = (uint32_t)h.def_len + (uint32_t)h.rep_len;
         if (c->max_def == 0 && P.lev_len != 0) { rc = dv_malformed("definition levels in a required column"); break; }
         if (P.lev_len > P.comp_len || P.lev_len > P.uncomp_len) { rc = dv_malformed("level bytes exceed the page"); break; }
       }
@@ -610,7 +690,7 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
         if (h.type == PG_DATA && c->max_def == 1 && h.def_enc != ENC_RLE) { rc = dv_unsupported("definition levels not RLE encoded"); break; }
         if ((uint64_t)c->rows + (uint64_t)P.num_values >= 0xFFFFFFF0ULL) { rc = dv_unsupported("more than 2^32 rows in one chunk"); break; }
         P.row_start = (uint64_t)c->rows;
-        if (!(h.type == PG_DATA_V2 && h.num_nulls == 0)) all_v2_no_nulls = false;
+        if (!(h.type == PG_DATA_V2 && h.num_nulls == 0) || list_mode) all_v2_no_nulls = false;
         c->data_pages.push_back((uint32_t)c->pages.size());
         c->nn_init.push_back(P.num_values);
         c->voff_init.push_back(h.type == PG_DATA_V2 ? P.lev_len : 0u);
@@ -644,6 +724,25 @@ int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len,
   *out_host = c;
   return DBHIP_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int32_t dbhip_pq_chunk_open_device(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
+                                   int32_t max_def_level, int32_t max_rep_level, int32_t out_type, dbhip_pq_chunk** out_host,
+                                   dbhip_pq_info* info_host) {
+  return open_device_impl(chunk_host, chunk_len, codec, physical_type, type_length, max_def_level, max_rep_level, out_type, false, 0, 0, out_host, info_host);
+}
+
+int32_t dbhip_pq_chunk_open_device_list(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
+                                        int32_t list_nullable, int32_t element_nullable, int32_t out_type, dbhip_pq_chunk** out_host,
+                                        dbhip_pq_info* info_host) {
+  DBHIP_REQUIRE((list_nullable == 0 || list_nullable == 1) && (element_nullable == 0 || element_nullable == 1), "dbhip_pq_chunk_open_device_list: nullability flags are 0 / 1");
+  int32_t rc = open_device_impl(chunk_host, chunk_len, codec, physical_type, type_length, list_nullable + 1 + element_nullable, 1, out_type, true, list_nullable,
+                                element_nullable, out_host, info_host);
+  if (rc == DBHIP_OK && info_host) info_host->has_validity = element_nullable;   // (num_values = level entries: the bound of rows and of elements)
+  return rc;
+}
 
 }  // extern "C"
 
@@ -664,7 +763,7 @@ struct BlobLayout {
 inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* chunk_dev, uint8_t* const* image_dev, void* const* out_values_dev,
-                    uint8_t* const* out_validity_dev, int64_t* out_nulls_host, int32_t* out_status_host, void* stream) {
+                    uint8_t* const* out_validity_dev, int64_t* out_nulls_host, int32_t* out_status_host, void* stream, bool list_pass = false) {
   const char* who = "dbhip_pq_chunks_decode_device";
   if (n <= 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
@@ -676,6 +775,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
     if (out_nulls_host) out_nulls_host[i] = 0;
     if (out_status_host) out_status_host[i] = DBHIP_OK;
     DBHIP_REQUIRE(c && c->device_mode, "dbhip_pq_chunk_decode_device: the handle was not opened by dbhip_pq_chunk_open_device");
+    DBHIP_REQUIRE(!c->list || list_pass, "dbhip_pq_chunk_decode_device: a List chunk is decoded by dbhip_pq_chunk_decode_device_list");
     if (c->rows == 0) continue;
     DBHIP_REQUIRE(chunk_dev[i] && out_values_dev[i], "dbhip_pq_chunk_decode_device: NULL buffer");
     DBHIP_REQUIRE(((uintptr_t)chunk_dev[i] & 15) == 0, "dbhip_pq_chunk_decode_device: chunk_dev must be 16-byte aligned");
@@ -769,6 +869,10 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
     }
     D.slices = slices;
     if (slices > max_slices) max_slices = slices;
+    if (c->list) {
+      D.ldw = c->list_max_def > 1 ? 2u : 1u; D.lmax = (uint32_t)c->list_max_def; D.lnull = (uint32_t)c->list_nullable;
+      D.isrep = c->d_isrep; D.iselem = c->d_iselem; D.lvalid = c->d_lvalid;
+    }
     if (c->dict_n > 0) dict_list[n_dict++] = (uint32_t)k;
     for (uint32_t d = 0; d < nd; ++d) {
       if (c->max_def == 1) lv_map[k_lv++] = make_uint2((unsigned)k, d);
@@ -877,7 +981,149 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
 
 }  // namespace
 
+namespace {
+// ---- List<primitive> (round 5; the reference reads nested columns through arrow-rs, deserialize.rs:33-81) ---------------------------
+// per 32-entry word: rows that start in it (entries that do not continue a row) and element slots in it
+__global__ __launch_bounds__(256) void pq_list_count_kernel(const uint32_t* __restrict__ isrep, const uint32_t* __restrict__ iselem, int64_t entries, int64_t nwords,
+                                                            uint32_t* __restrict__ rcnt, uint32_t* __restrict__ ecnt) {
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
+    const int64_t left = entries - w * 32;
+    const uint32_t live = left >= 32 ? 0xFFFFFFFFu : ((1u << (uint32_t)left) - 1u);
+    rcnt[w] = (uint32_t)__popc(~isrep[w] & live);
+    ecnt[w] = (uint32_t)__popc(iselem[w] & live);
+  }
+}
+// entry e: an element slot -> its value moves to the element's place (+ its validity bit); a row start -> offsets[row] = elements before it
+// (+ the list's validity bit). counts: [0] rows, [1] elements, [2] NULL lists, [3] != 0: the first entry continues a row (malformed)
+template <typename V>
+__global__ __launch_bounds__(256) void pq_list_finish_kernel(int64_t entries, const uint32_t* __restrict__ isrep, const uint32_t* __restrict__ iselem,
+                                                             const uint32_t* __restrict__ lvalid, const uint32_t* __restrict__ valid,
+                                                             const uint64_t* __restrict__ roff, const uint64_t* __restrict__ eoff, const V* __restrict__ ent_values,
+                                                             uint64_t* __restrict__ out_offsets, uint32_t* __restrict__ out_lvalid, V* __restrict__ out_values,
+                                                             uint32_t* __restrict__ out_evalid, unsigned long long* __restrict__ counts, int move_values) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < entries; e += (int64_t)gridDim.x * 256) {
+    const int64_t w = e >> 5;
+    const uint32_t b = (uint32_t)(e & 31), below = (1u << b) - 1u, bit = 1u << b;
+    const uint32_t rep = isrep[w], el = iselem[w];
+    const uint64_t erank = eoff[w] + (uint32_t)__popc(el & below);
+    if (el & bit) {
+      if (move_values) out_values[erank] = ent_values[e];
+      if (out_evalid && (valid[w] & bit)) atomicOr(&out_evalid[erank >> 5], 1u << (uint32_t)(erank & 31));
+    }
+    if (!(rep & bit)) {
+      const uint64_t rrank = roff[w] + (uint32_t)__popc(~rep & below);
+      out_offsets[rrank] = erank;
+      if (lvalid) {
+        if (lvalid[w] & bit) { if (out_lvalid) atomicOr(&out_lvalid[rrank >> 5], 1u << (uint32_t)(rrank & 31)); }
+        else atomicAdd(&counts[2], 1ULL);
+      }
+    } else if (e == 0) counts[3] = 1;
+    if (e == entries - 1) {
+      const uint64_t rows = roff[w] + (uint32_t)__popc(~rep & (below | bit));
+      const uint64_t elems = erank + ((el & bit) ? 1 : 0);
+      out_offsets[rows] = elems;
+      counts[0] = rows; counts[1] = elems;
+    }
+  }
+}
+// BOOLEAN elements: the values are a bitmap over the entries
+__global__ __launch_bounds__(256) void pq_list_finish_bool_kernel(int64_t entries, const uint32_t* __restrict__ iselem, const uint64_t* __restrict__ eoff,
+                                                                  const uint32_t* __restrict__ ent_bits, uint32_t* __restrict__ out_bits) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < entries; e += (int64_t)gridDim.x * 256) {
+    const int64_t w = e >> 5;
+    const uint32_t b = (uint32_t)(e & 31), bit = 1u << b;
+    if ((iselem[w] & bit) && (ent_bits[w] & bit)) {
+      const uint64_t erank = eoff[w] + (uint32_t)__popc(iselem[w] & (bit - 1u));
+      atomicOr(&out_bits[erank >> 5], 1u << (uint32_t)(erank & 31));
+    }
+  }
+}
+
+int32_t decode_list(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, uint64_t* out_offsets_dev, uint8_t* out_list_validity_dev,
+                    void* out_values_dev, uint8_t* out_elem_validity_dev, int64_t* out_rows_host, int64_t* out_elems_host, int64_t* out_null_lists_host,
+                    void* stream) {
+  const char* who = "dbhip_pq_chunk_decode_device_list";
+  DBHIP_REQUIRE(c && c->device_mode && c->list, "dbhip_pq_chunk_decode_device_list: the handle was not opened by dbhip_pq_chunk_open_device_list");
+  DBHIP_REQUIRE(out_offsets_dev && out_rows_host && out_elems_host, "dbhip_pq_chunk_decode_device_list: NULL argument");
+  DBHIP_REQUIRE(!c->list_nullable || out_list_validity_dev, "dbhip_pq_chunk_decode_device_list: a nullable list needs a validity buffer");
+  DBHIP_REQUIRE(!c->elem_nullable || out_elem_validity_dev, "dbhip_pq_chunk_decode_device_list: nullable elements need a validity buffer");
+  hipStream_t s = resolve_stream(stream);
+  *out_rows_host = 0; *out_elems_host = 0;
+  if (out_null_lists_host) *out_null_lists_host = 0;
+  const int64_t entries = c->rows;
+  if (entries == 0) { DBHIP_CHECK(hipMemsetAsync(out_offsets_dev, 0, 8, s)); DBHIP_CHECK(hipStreamSynchronize(s)); return DBHIP_OK; }
+  DBHIP_REQUIRE(out_values_dev, "dbhip_pq_chunk_decode_device_list: NULL values buffer");
+  const int esize = out_elem_size(c->out_type);
+  const bool is_bool = c->out_type == DBHIP_T_BOOL;
+  const int64_t nwords = ceil_div(entries, 32), wbytes = ceil_div(entries, 64) * 8;
+  if (!c->d_isrep) {
+    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_isrep));
+    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_iselem));
+    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_lvalid));
+    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_ent_valid));
+    DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)wbytes : (size_t)entries * (size_t)esize, &c->d_ent_values));
+    DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_rcnt));
+    DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_ecnt));
+    DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_roff));
+    DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_eoff));
+    DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_lblk));
+    DBHIP_TRY(dbhip_alloc(64, (void**)&c->d_lcounts));
+  }
+  DBHIP_CHECK(hipMemsetAsync(c->d_isrep, 0, (size_t)wbytes, s));
+  DBHIP_CHECK(hipMemsetAsync(c->d_iselem, 0, (size_t)wbytes, s));
+  DBHIP_CHECK(hipMemsetAsync(c->d_lvalid, 0, (size_t)wbytes, s));
+  DBHIP_CHECK(hipMemsetAsync(c->d_lcounts, 0, 64, s));
+  // the leaf as a nullable column over the level entries (the flat pipeline; its levels kernel fills the entry bitmaps)
+  void* ent_values = c->d_ent_values;
+  uint8_t* ent_valid = (uint8_t*)c->d_ent_valid;
+  int64_t nulls = 0;
+  int32_t rc = decode_many(&c, 1, &chunk_dev, &image_dev, &ent_values, &ent_valid, &nulls, nullptr, stream, true);
+  if (rc) return rc;
+  // entries -> rows and elements
+  hipLaunchKernelGGL(pq_list_count_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, s, c->d_isrep, c->d_iselem, entries, nwords, c->d_rcnt, c->d_ecnt);
+  DBHIP_TRY(dbscan::exclusive_scan_u32(c->d_rcnt, nwords, c->d_lblk, c->d_roff, s));
+  DBHIP_TRY(dbscan::exclusive_scan_u32(c->d_ecnt, nwords, c->d_lblk, c->d_eoff, s));
+  if (out_list_validity_dev) DBHIP_CHECK(hipMemsetAsync(out_list_validity_dev, c->list_nullable ? 0 : 0xFF, (size_t)wbytes, s));
+  if (out_elem_validity_dev) DBHIP_CHECK(hipMemsetAsync(out_elem_validity_dev, c->elem_nullable ? 0 : 0xFF, (size_t)wbytes, s));
+  const uint32_t* lv = c->list_nullable ? c->d_lvalid : nullptr;
+  uint32_t* olv = c->list_nullable ? (uint32_t*)out_list_validity_dev : nullptr;
+  uint32_t* oev = c->elem_nullable ? (uint32_t*)out_elem_validity_dev : nullptr;
+  unsigned long long* counts = (unsigned long long*)c->d_lcounts;
+  const int grid = grid_for(entries, 256);
+#define LIST_FINISH(V_) hipLaunchKernelGGL(pq_list_finish_kernel<V_>, dim3(grid), dim3(256), 0, s, entries, c->d_isrep, c->d_iselem, lv, c->d_ent_valid, c->d_roff, \
+                                           c->d_eoff, (const V_*)c->d_ent_values, out_offsets_dev, olv, (V_*)out_values_dev, oev, counts, 1)
+  if (is_bool) {
+    DBHIP_CHECK(hipMemsetAsync(out_values_dev, 0, (size_t)wbytes, s));
+    // (the value bits by their own kernel; offsets, validities and counts from the generic one, which moves no values here)
+    hipLaunchKernelGGL(pq_list_finish_bool_kernel, dim3(grid), dim3(256), 0, s, entries, c->d_iselem, c->d_eoff, (const uint32_t*)c->d_ent_values, (uint32_t*)out_values_dev);
+    hipLaunchKernelGGL(pq_list_finish_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, entries, c->d_isrep, c->d_iselem, lv, c->d_ent_valid, c->d_roff, c->d_eoff,
+                       (const uint8_t*)nullptr, out_offsets_dev, olv, (uint8_t*)nullptr, oev, counts, 0);
+  } else if (esize == 1) LIST_FINISH(uint8_t);
+  else if (esize == 2) LIST_FINISH(uint16_t);
+  else if (esize == 4) LIST_FINISH(uint32_t);
+  else if (esize == 8) LIST_FINISH(uint64_t);
+  else LIST_FINISH(uint4);
+#undef LIST_FINISH
+  DBHIP_LAUNCH_CHECK();
+  unsigned long long hc[4] = {0, 0, 0, 0};
+  DBHIP_CHECK(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (hc[3]) { set_error("%s: malformed column chunk (the first level entry continues a row)", who); return DBHIP_ERR_INVALID; }
+  *out_rows_host = (int64_t)hc[0];
+  *out_elems_host = (int64_t)hc[1];
+  if (out_null_lists_host) *out_null_lists_host = (int64_t)hc[2];
+  return DBHIP_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int32_t dbhip_pq_chunk_decode_device_list(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, uint64_t* out_offsets_dev,
+                                          uint8_t* out_list_validity_dev, void* out_values_dev, uint8_t* out_elem_validity_dev,
+                                          int64_t* out_rows_host, int64_t* out_elems_host, int64_t* out_null_lists_host, void* stream) {
+  return decode_list(c, chunk_dev, image_dev, out_offsets_dev, out_list_validity_dev, out_values_dev, out_elem_validity_dev, out_rows_host, out_elems_host,
+                     out_null_lists_host, stream);
+}
 
 int32_t dbhip_pq_chunk_decode_device(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, void* out_values_dev,
                                      uint8_t* out_validity_dev, int64_t* out_nulls_host, void* stream) {

@@ -185,7 +185,8 @@ struct DvPage {
   uint32_t lev_len;     // DATA_PAGE_V2: bytes of definition levels in front of the values (never compressed)
   uint32_t compressed;  // the bytes after the levels are compressed
   uint32_t def_enc;     // v1: encoding of the definition levels
-  uint64_t row_start;   // first row of a data page
+  uint32_t rep_len;     // DATA_PAGE_V2 of a List column: bytes of repetition levels (the first rep_len of the lev_len level bytes)
+  uint64_t row_start;   // first row of a data page (List columns: first level entry)
 };
 
 struct dbhip_pq_chunk {
@@ -217,6 +218,15 @@ struct dbhip_pq_chunk {
   void* d_dense;                           // non-null values, output type (only with nulls)
   uint32_t* d_wcnt; uint64_t* d_woff; uint64_t* d_blk;
   bool uploaded;
+  // List<primitive> columns (dbhip_pq_chunk_open_device_list, round 5): `rows` counts LEVEL ENTRIES; the flat pipeline decodes the leaf
+  // as a nullable column over the entries (valid = the entry carries a value) into d_ent_values / d_ent_valid, the list pass
+  // (pq_list_finish_kernel) then drops the entries that are not elements and builds offsets and validities
+  bool list = false;
+  int32_t list_nullable = 0, elem_nullable = 0, list_max_def = 0;
+  uint32_t* d_isrep = nullptr; uint32_t* d_iselem = nullptr; uint32_t* d_lvalid = nullptr; uint32_t* d_ent_valid = nullptr;
+  void* d_ent_values = nullptr;
+  uint32_t* d_rcnt = nullptr; uint32_t* d_ecnt = nullptr; uint64_t* d_roff = nullptr; uint64_t* d_eoff = nullptr; uint64_t* d_lblk = nullptr;
+  uint64_t* d_lcounts = nullptr;
 };
 
 namespace {

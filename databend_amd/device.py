@@ -1887,20 +1887,27 @@ class ParquetChunk:
     `chunk` = the raw bytes of the column chunk (dictionary page first), as the block reader fetched them."""
 
     def __init__(self, chunk, physical_type, out_type, type_length=0, max_def_level=0, max_rep_level=0, codec=0,
-                 precision=0, scale=0, device=False):
+                 precision=0, scale=0, device=False, list_of=None):
         """device=True: dbhip_pq_chunk_open_device / _decode_device — the host reads the page headers only; decompression (ZSTD / SNAPPY /
-        LZ4_RAW), run headers, length prefixes and DELTA blocks are walked on the GPU from the chunk as stored."""
+        LZ4_RAW), run headers, length prefixes and DELTA blocks are walked on the GPU from the chunk as stored.
+        list_of=(list_nullable, element_nullable): a List<primitive> leaf (dbhip_pq_chunk_open_device_list; decode with decode_list())."""
         _ensure()
         self.host = np.frombuffer(chunk, dtype=np.uint8)   # zero-copy view; the bytes object stays referenced by the array
         self.out_type, self.precision, self.scale = out_type, precision, scale
-        self.device = bool(device)
+        self.device = bool(device) or list_of is not None
+        self.list_of = list_of
         self.h = C.c_void_p()
         self.info = L.PqInfo()
         hp = self.host.ctypes.data_as(C.c_void_p) if len(self.host) else C.c_void_p(0)
-        fn = lib().dbhip_pq_chunk_open_device if self.device else lib().dbhip_pq_chunk_open
-        check(fn(hp if len(self.host) else self.host.ctypes.data_as(C.c_void_p), C.c_int64(len(self.host)),
-                 C.c_int32(codec), C.c_int32(physical_type), C.c_int32(type_length), C.c_int32(max_def_level),
-                 C.c_int32(max_rep_level), C.c_int32(out_type), C.byref(self.h), C.byref(self.info)))
+        if list_of is not None:
+            check(lib().dbhip_pq_chunk_open_device_list(hp, C.c_int64(len(self.host)), C.c_int32(codec), C.c_int32(physical_type), C.c_int32(type_length),
+                                                        C.c_int32(1 if list_of[0] else 0), C.c_int32(1 if list_of[1] else 0), C.c_int32(out_type),
+                                                        C.byref(self.h), C.byref(self.info)))
+        else:
+            fn = lib().dbhip_pq_chunk_open_device if self.device else lib().dbhip_pq_chunk_open
+            check(fn(hp if len(self.host) else self.host.ctypes.data_as(C.c_void_p), C.c_int64(len(self.host)),
+                     C.c_int32(codec), C.c_int32(physical_type), C.c_int32(type_length), C.c_int32(max_def_level),
+                     C.c_int32(max_rep_level), C.c_int32(out_type), C.byref(self.h), C.byref(self.info)))
         self.chunk_dev = None
         self.image_dev = None
         self.nulls = self.info.num_nulls
@@ -1949,6 +1956,27 @@ class ParquetChunk:
         if self.out_type == L.T_STRING:
             bufs = DeviceBuffer.from_numpy(np.array([buf0.ptr], dtype=np.uint64))
         return Column(self.out_type, i.num_values, out, val, self.precision, self.scale, buffers=bufs, keep=(buf0,))
+
+    def decode_list(self, stream=None):
+        """dbhip_pq_chunk_decode_device_list -> (offsets numpy u64 [rows + 1], list validity numpy bool [rows] or None, element Column)"""
+        i = self.info
+        chunk_dev = self.upload()
+        if i.image_bytes and self.image_dev is None:
+            self.image_dev = DeviceBuffer(i.image_bytes)
+        offs = DeviceBuffer((i.num_values + 1) * 8 + 16)
+        lval = DeviceBuffer(i.validity_bytes + 8) if self.list_of[0] else None
+        out = DeviceBuffer(i.out_bytes + 16)
+        eval_ = DeviceBuffer(i.validity_bytes + 8) if self.list_of[1] else None
+        rows, elems, nl = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().dbhip_pq_chunk_decode_device_list(self.h, C.c_void_p(chunk_dev.ptr), C.c_void_p(self.image_dev.ptr) if self.image_dev else None,
+                                                      C.c_void_p(offs.ptr), C.c_void_p(lval.ptr) if lval is not None else None, C.c_void_p(out.ptr),
+                                                      C.c_void_p(eval_.ptr) if eval_ is not None else None, C.byref(rows), C.byref(elems), C.byref(nl), stream))
+        self.rows, self.elems, self.null_lists = rows.value, elems.value, nl.value
+        buf0 = self.image_dev if self.image_dev is not None else chunk_dev
+        bufs = DeviceBuffer.from_numpy(np.array([buf0.ptr], dtype=np.uint64)) if self.out_type == L.T_STRING else None
+        col = Column(self.out_type, elems.value, out, eval_, self.precision, self.scale, buffers=bufs, keep=(buf0,))
+        lv = unpack_bits(lval.to_numpy(np.uint8, (rows.value + 7) // 8), rows.value) if lval is not None else None
+        return offs.to_numpy(np.uint64, rows.value + 1), lv, col
 
     @staticmethod
     def decode_many(chunks, stream=None, statuses=None):

@@ -964,6 +964,22 @@ int32_t dbhip_pq_chunks_decode_device(dbhip_pq_chunk* const* chunks, int32_t n_c
                                       uint8_t* const* image_dev, void* const* out_values_dev,
                                       uint8_t* const* out_validity_dev, int64_t* out_nulls_host,
                                       int32_t* out_status_host, void* stream);
+/* List<primitive> columns (one repeated ancestor: max_rep_level 1, max_def_level = list_nullable + 1 + element_nullable — the
+ * three-level LIST of parquet's LogicalTypes.md that the reference writes for Array(T), read there through arrow-rs,
+ * storages/common/.../deserialize.rs:33-81). open_device_list reads the page headers like open_device; info.num_values is the
+ * number of LEVEL ENTRIES, the bound of both the rows and the elements: size offsets for (num_values + 1) u64, the element values
+ * for info.out_bytes and each validity for info.validity_bytes. decode_device_list decodes the repetition / definition levels and
+ * the leaf values on the device: out_offsets[r] .. out_offsets[r + 1] are row r's elements (Databend's ArrayColumn offsets),
+ * out_list_validity (list_nullable; a NULL list is an empty run), out_values the elements back to back in the output type (a NULL
+ * element decodes to 0), out_elem_validity (element_nullable); the row / element / NULL-list counts come back to the host. String
+ * elements are views into chunk_dev / the image like a flat String chunk's. Deeper nesting (List<List<..>>, Map, Tuple members):
+ * DBHIP_ERR_UNSUPPORTED from the flat open — the binding keeps arrow-rs. */
+int32_t dbhip_pq_chunk_open_device_list(const uint8_t* chunk_host, int64_t chunk_len, int32_t codec, int32_t physical_type, int32_t type_length,
+                                        int32_t list_nullable, int32_t element_nullable, int32_t out_type, dbhip_pq_chunk** out_host,
+                                        dbhip_pq_info* info_host);
+int32_t dbhip_pq_chunk_decode_device_list(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_dev, uint64_t* out_offsets_dev,
+                                          uint8_t* out_list_validity_dev, void* out_values_dev, uint8_t* out_elem_validity_dev,
+                                          int64_t* out_rows_host, int64_t* out_elems_host, int64_t* out_null_lists_host, void* stream);
 int32_t dbhip_pq_chunk_close(dbhip_pq_chunk* c);
 
 /* ---------------------------------------------------------------------------------------------------------------------
