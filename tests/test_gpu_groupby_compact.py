@@ -277,3 +277,30 @@ def test_one_heavy_group_among_many(gpu, oracle, card, null):
     hk = None if null else card + 11
     row = [r for r in got if r[0] == hk]
     assert len(row) == 1 and row[0][2] == int(heavy.sum())
+
+
+@pytest.mark.parametrize("card", [50, 40_000])
+def test_float_sums_agree_with_the_oracle_within_the_stated_tolerance(gpu, oracle, card):
+    """DESIGN §3's only carve-out: sum() over Float64 / Float32 adds in an order neither the reference nor the device fixes — per group
+    |device - oracle| <= 1e-9 x sum(|x|); counts and the integer sum beside them are exact."""
+    n = 300_000
+    rng = np.random.default_rng(card)
+    k = rng.integers(0, card, n).astype(np.int64)
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)
+    x32 = rng.standard_normal(n).astype(np.float32)
+    i = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    aggs = [(T.AGG_SUM, T.T_F64, 0, 0, 0), (T.AGG_SUM, T.T_F32, 0, 0, 0), (T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0)]
+    g = gpu.GroupBy([T.T_I64], aggs, [0])
+    g.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(x), gpu.Column.from_numpy(x32), gpu.Column.from_numpy(i), None], n)
+    got = {r[0]: r[1:] for r in g.result()}
+    g.destroy()
+    h = oracle_groupby(oracle, [T.T_I64], [0], aggs, [O.HostCol(T.T_I64, k)], [O.HostCol(T.T_F64, x), O.HostCol(T.T_F32, x32), O.HostCol(T.T_I64, i), None], n)
+    exp = {r[0]: r[1:] for r in oracle_rows(oracle, h, [T.T_I64], aggs)}
+    oracle.orc_hashagg_destroy(h)
+    assert got.keys() == exp.keys()
+    mag = np.zeros(card); np.add.at(mag, k, np.abs(x))
+    mag32 = np.zeros(card); np.add.at(mag32, k, np.abs(x32.astype(np.float64)))
+    for key, (s64, s32, si, c) in got.items():
+        e64, e32, ei, ec = exp[key]
+        assert (si, c) == (ei, ec)
+        assert abs(s64 - e64) <= 1e-9 * mag[key] and abs(s32 - e32) <= 1e-9 * mag32[key]
