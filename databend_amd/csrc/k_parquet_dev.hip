@@ -62,6 +62,38 @@ __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __rest
   if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
 }
 
+// ZSTD, two waves per page: wave 0 parses (ZProd), wave 1 copies (dv_wave.h)
+__global__ __launch_bounds__(128) void dv_inflate_zstd2_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
+  extern __shared__ __align__(16) uint8_t dv_lds[];
+  const DvJob P = jobs[blockIdx.x];
+  const uint32_t ring_arg = ring;
+  ring &= 0x7FFFFFFFu;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lev = P.lev_len;
+  const uint32_t raw = P.compressed ? lev : P.uncomp_len;
+  for (uint32_t i = threadIdx.x; i < raw; i += 128) P.dst[i] = P.src[i];
+  if (!P.compressed || P.uncomp_len == lev) return;
+  ZQueue Q;
+  Q.slots = (u32x4q*)(dv_lds + ring + ZW_TABLES);
+  Q.ctl = (uint32_t*)(dv_lds + ring + ZW_TABLES + ZQ_CAP * 16);
+  if (threadIdx.x < 4) Q.ctl[threadIdx.x] = 0;
+  __syncthreads();
+  if (wave == 0) {
+    ZProd a;
+    a.begin(P, dv_lds, ring, lane);
+    a.qbegin(Q);
+    int rc = zc::decode_frames(a, a.in_len);
+    if (rc == zc::OK && a.op_ != a.cap_) rc = zc::CORRUPT_;
+    a.end((uint32_t)rc);
+  } else {
+    ZWave b;
+    b.begin(P, dv_lds, ring, lane);
+    const int rc = (int)zq_consume(b, Q, (ring_arg >> 31) != 0);
+    b.flush(true);
+    if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
+  }
+}
+
 // LZ4 / Snappy on the same wave (16 KiB ring, the payload as one forward stream in registers)
 __global__ __launch_bounds__(64) void dv_inflate_lz_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
@@ -803,7 +835,8 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   if (live.empty()) return DBHIP_OK;
   static const bool lds_ok = [] {
     return hipFuncSetAttribute((const void*)dv_inflate_lz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_RING) == hipSuccess &&
-           hipFuncSetAttribute((const void*)dv_inflate_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW_LDS) == hipSuccess;
+           hipFuncSetAttribute((const void*)dv_inflate_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW_LDS) == hipSuccess &&
+           hipFuncSetAttribute((const void*)dv_inflate_zstd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW2_LDS) == hipSuccess;
   }();
   if (!lds_ok) { set_error("%s: cannot reserve LDS for the decompression kernels", who); return DBHIP_ERR_HIP; }
   // ---- the blob: everything the kernels read about the batch, one upload
@@ -912,7 +945,13 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   // ring sizes (powers of two >= 1 KiB; env overrides for experiments): smaller rings = more pages resident per CU, more back-references
   // served from the image instead of the ring
   static const uint32_t z_ring = ring_from_env("DBHIP_PQ_ZSTD_RING", ZW_RING), lz_ring = ring_from_env("DBHIP_PQ_LZ_RING", LZ_RING);
-  if (n_z) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
+  // (two waves per page — parse | copy — unless DBHIP_PQ_ZSTD_WAVES=1 asks for the one-wave kernel)
+  static const bool z_one_wave = getenv("DBHIP_PQ_ZSTD_WAVES") && atoi(getenv("DBHIP_PQ_ZSTD_WAVES")) == 1;
+  if (n_z && z_one_wave) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
+  else if (n_z) {
+    static const uint32_t z_dry = (getenv("DBHIP_PQ_ZSTD_DRY") && atoi(getenv("DBHIP_PQ_ZSTD_DRY"))) ? 0x80000000u : 0u;   // (experiment: sequences are parsed, not copied)
+    hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring | z_dry);
+  }
   if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), lz_ring, s, d_jobs + n_z, lz_ring);
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
   if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));

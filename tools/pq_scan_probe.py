@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--page-rows", type=int, default=20_000)
     ap.add_argument("--one-by-one", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-check", action="store_true", help="skip the identity check (experiments that decode wrongly on purpose)")
     args = ap.parse_args()
     rng = np.random.default_rng(7)
     D.init(0)
@@ -73,7 +74,7 @@ def main():
         return D.ParquetChunk.decode_many(pcs)
     cols = run()
     # the decode is the identity on what was written
-    for (name, ot, src), col, pc in list(zip(srcs, cols, pcs))[:: args.blocks]:
+    for (name, ot, src), col, pc in ([] if args.no_check else list(zip(srcs, cols, pcs))[:: args.blocks]):
         if ot == T.T_STRING:
             v = col.data.to_numpy(np.uint8, 16 * len(src)).reshape(-1, 16)
             assert (v[:, 0] == 1).all() and np.array_equal(v[:, 4], np.frombuffer(b"".join(src), np.uint8)), name
