@@ -170,6 +170,20 @@ struct ZWave {
     const uint32_t s = 8 * (a & 3);
     return s ? (lo >> s) | ((uint64_t)d2 << (64 - s)) : lo;
   }
+  // in64 for a reader that only moves DOWN from a position the window already covers (the sequence bitstream after its first
+  // refill): the window's upper end needs no test
+  __device__ __forceinline__ uint64_t in64_back(uint32_t pos) {
+    const uint32_t a = rfl(pos + a0);
+    if (a < wlo) {
+      const uint32_t e = (a + 8 + 3) & ~3u;
+      slide(e > 256 ? e - 256 : 0);
+    }
+    const uint32_t i = (a - wlo) >> 2;
+    const uint32_t d0 = rdl(la, i), d1 = rdl(la, i + 1), d2 = rdl(la, i + 2 < 64 ? i + 2 : 63);
+    const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
+    const uint32_t s = 8 * (a & 3);
+    return s ? (lo >> s) | ((uint64_t)d2 << (64 - s)) : lo;
+  }
   // per-lane reads of the payload (the Huffman streams: up to four lanes, each at its own address)
   __device__ __forceinline__ uint32_t lane_in8(uint32_t pos) const { return pos + a0 < safeA ? gload8(srcA + a0 + pos) : 0u; }
   __device__ __forceinline__ uint64_t lane_in64(uint32_t pos) const {
@@ -440,7 +454,10 @@ struct ZProd : ZWave {
     __hip_atomic_store(&q.ctl[0], qtail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __device__ __forceinline__ void push(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-    const bool mine = lane == qn;   // (one compare + four selects: this clang has no writelane builtin)
+    // (one compare + four selects: this clang has no writelane builtin. r05: writing each command to the queue at once — lane 0, one
+    //  16-byte LDS store per sequence — measured 49.8 ms against 41.8 ms on the 7-column set: the store sits in the same LDS queue as
+    //  the table reads of the next sequence)
+    const bool mine = lane == qn;
     b0 = mine ? w0 : b0; b1 = mine ? w1 : b1; b2 = mine ? w2 : b2; b3 = mine ? w3 : b3;
     qn = rfl(qn + 1);
     if (qn == 64) qflush();

@@ -305,6 +305,13 @@ struct SeqBits {
     have = (int32_t)w.uni((uint32_t)(h > 0 ? h : 0));
     c = have > 0 ? w.uni64(w.in64(base + (uint32_t)b) << (uint32_t)(64 - have)) : 0;
   }
+  // the same after the first refill of a stream: the reads only move DOWN from there, which is all the window has to follow
+  ZC_MEM void refill_back(W& w) {
+    const int32_t b = off > 57 ? (off - 57) >> 3 : 0;
+    const int32_t h = off - 8 * b;
+    have = (int32_t)w.uni((uint32_t)(h > 0 ? h : 0));
+    c = have > 0 ? w.uni64(w.in64_back(base + (uint32_t)b) << (uint32_t)(64 - have)) : 0;
+  }
   ZC_MEM uint32_t read(uint32_t n) {   // n <= 32, and n <= have unless the stream is exhausted
     const uint32_t v = (uint32_t)((c >> 1) >> (63 - n));
     c <<= n;
@@ -586,32 +593,28 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
       const uint64_t le = w.uni64(le_raw), me = w.uni64(me_raw);
       const uint32_t oe = w.uni(oe_raw);
       const uint32_t ocode = oe >> 24;
-      bs.refill(w);   // >= 57 bits (or all that is left): offset (<= 24 here) + match length (<= 16) + literals length (<= 16)
+      // the register holds 57..64 bits after a refill: offset (<= 24 here) + match length (<= 16) + literals length (<= 16) fit; it is
+      // refilled when this sequence's fields do not fit what is left (every second sequence or so on short fields), not every time
+      const uint32_t need = ocode > 24 ? ocode : ocode + ((uint32_t)(me >> 24) & 0xFF) + ((uint32_t)(le >> 24) & 0xFF);
+      if (bs.have < (int32_t)need) bs.refill_back(w);
       // offset, match length, literals length — in this order (3.1.1.3.2.1.1)
       const uint32_t ov = (1u << ocode) + bs.read(ocode);
-      if (ocode > 24) bs.refill(w);
+      if (ocode > 24) bs.refill_back(w);
       const uint32_t ml = (uint32_t)(me >> 32) + bs.read((uint32_t)(me >> 24) & 0xFF);
       const uint32_t ll = (uint32_t)(le >> 32) + bs.read((uint32_t)(le >> 24) & 0xFF);
       if (bs.off < 0) return CORRUPT_STRICT;   // (libzstd < 1.5 reads zeros past the start and only checks the end; 1.5.7 checks for the exact end)
-      // repeat offsets (3.1.1.5)
-      uint32_t off;
-      if (ov > 3) {
-        off = ov - 3;
-        r2 = r1; r1 = r0; r0 = off;
-      } else {
-        const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);   // 0..3
-        if (idx == 0) {
-          off = r0;
-        } else {
-          off = idx == 3 ? r0 - 1 : idx == 1 ? r1 : r2;
-          if (off == 0) return CORRUPT;
-          if (idx != 1) r2 = r1;
-          r1 = r0;
-          r0 = off;
-        }
-      }
+      // repeat offsets (3.1.1.5), as selects: the branchy form cost ~50 scalar instructions of flag shuffling per sequence (r05 ISA)
+      const bool rep = ov <= 3;
+      const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);   // 0..3 when rep
+      const uint32_t cand = idx == 0 ? r0 : (idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1));
+      const uint32_t off = rep ? cand : ov - 3;
+      if (off == 0) return CORRUPT;                        // (only a repeat offset can be 0: r0 - 1 with r0 = 1)
+      const bool shift2 = !rep || idx >= 2, shift1 = !rep || idx != 0;
+      r2 = shift2 ? r1 : r2;
+      r1 = shift1 ? r0 : r1;
+      r0 = off;
       if (i + 1 < nseq) {   // states are updated between sequences: literals length, match length, offset (<= 26 bits)
-        if (bs.have < 26) bs.refill(w);
+        if (bs.have < 26) bs.refill_back(w);
         ls = w.uni(((uint32_t)le & 0xFFFF) + bs.read(((uint32_t)le >> 16) & 0xFF));
         ms = w.uni(((uint32_t)me & 0xFFFF) + bs.read(((uint32_t)me >> 16) & 0xFF));
         os = w.uni((oe & 0xFFFF) + bs.read((oe >> 16) & 0xFF));

@@ -50,6 +50,7 @@ struct HostWave {
   }
   uint32_t lane_in8(uint32_t p) const { return in8(p); }
   uint64_t lane_in64(uint32_t p) const { return in64(p); }
+  uint64_t in64_back(uint32_t p) const { return in64(p); }
   void lane_store(uint32_t p, uint8_t b) {
     if (p >= cap_) abort();
     out[p] = b;
