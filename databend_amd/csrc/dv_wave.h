@@ -528,7 +528,7 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, bool d
     for (uint32_t polls = 0; tail == head; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
       if (q.dead()) return (uint32_t)zc::CORRUPT_;
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(16);   // (a batch of 64 commands takes the producer ~10^5 cycles: a poll every ~1000 costs the CU's shared scalar unit next to nothing)
       tail = q.tail();
     }
     const uint32_t m = rfl(tail - head < 64 ? tail - head : 64);
