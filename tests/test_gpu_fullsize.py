@@ -150,14 +150,16 @@ def test_join_150m_probe_rows_against_15m_build_rows(gpu):
     assert np.array_equal(marks, present[pk[:1_000_003]].cpu().numpy())
 
 
-def test_vector_index_10m_by_768_self_retrieval_and_exact_scan_agreement(gpu):
+@pytest.mark.parametrize("n_random", [56, 292])
+def test_vector_index_10m_by_768_self_retrieval_and_exact_scan_agreement(gpu, n_random):
     """configs[4] on one GPU: 10,000,000 x 768 f32. Queries that ARE base rows must come back as their own nearest
     neighbour at cosine distance ~0 (self-retrieval), and the index must return the same ids as the exact f32 scan
-    for random queries (recall@10 = 1.0)."""
+    for random queries (recall@10 = 1.0). 64 queries go through the 128 x 128 filter kernel; 300 queries (a ragged second 256-query
+    tile) through bf16_filter256_kernel, the kernel of the headline configuration, at its real base size."""
     n, dim, k = 10_000_000, 768, 10
     base = torch.randn((n, dim), device="cuda", dtype=torch.float32, generator=gen(5))
     ids = torch.tensor([0, 1, 8191, 8192, 156_249, 156_250, 4_999_999, n - 1], device="cuda")
-    q = torch.cat([base[ids], torch.randn((56, dim), device="cuda", dtype=torch.float32, generator=gen(6))])
+    q = torch.cat([base[ids], torch.randn((n_random, dim), device="cuda", dtype=torch.float32, generator=gen(6))])
     nq = q.shape[0]
 
     class Vec:
