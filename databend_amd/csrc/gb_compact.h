@@ -73,7 +73,7 @@ inline bool gbc_same_col(const GbCol& a, const GbCol& b) {
 inline bool gbc_describe(const GbLayout& L, const GbCols& C, GbcDesc* D) {
   memset(D, 0, sizeof(*D));
   if (L.nkeys < 1 || L.nkeys > GBC_MAX_KEYS || L.nkey_words > GBC_MAX_KW || L.naggs < 1 || L.naggs > GBC_MAX_AGGS) return false;
-  if (L.hash_word != L.nkey_words || L.agg_off[0] != L.hash_word + 1 || C.filter) return false;
+  if (L.hash_word != L.nkey_words || L.agg_off[0] != L.hash_word + 1) return false;
   D->nkeys = L.nkeys; D->kw = L.nkey_words; D->vword = L.validity_word;
   D->simple_keys = L.validity_word < 0 ? 1 : 0;
   for (int k = 0; k < L.nkeys; ++k) {
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(GBC_T) void gbc_hist_kernel(GbcDesc D, GbCols C, in
       const int64_t li = t0 + (int64_t)x * T + threadIdx.x;
       in[x] = li < hi;
       row[x] = row0 + (in[x] ? li : lo);
+      in[x] = in[x] && gb_row_passes(C, row[x]);   // (the pushed-down predicate Bitmap: rows that fail it do not take part)
     }
     gbc_load_keys<KW, R>(D, C, row, k);
 #pragma unroll
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(GBC_T) void gbc_scatter_kernel(GbcDesc D, GbCols C,
       const int64_t li = t0 + (int64_t)x * T + tid;
       in[x] = li < hi;
       row[x] = row0 + (in[x] ? li : lo);
+      in[x] = in[x] && gb_row_passes(C, row[x]);
     }
     gbc_load_keys<KW, SR>(D, C, row, k);
     gbc_load_values<NV, SR>(D, C, row, v);
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(GBC_T) void gbc_scatter_direct_kernel(GbcDesc D, Gb
       const int64_t li = t0 + (int64_t)x * T + tid;
       in[x] = li < hi;
       row[x] = row0 + (in[x] ? li : lo);
+      in[x] = in[x] && gb_row_passes(C, row[x]);
     }
     gbc_load_keys<KW, SR>(D, C, row, k);
     gbc_load_values<NV, SR>(D, C, row, v);
@@ -664,6 +667,7 @@ __device__ __forceinline__ void gbc_load_tile(const GbcDesc& D, const GbCols& C,
       const int64_t li = t0 + (int64_t)x * T + tid;
       in[x] = li < t_end;
       row[x] = A.row0 + (in[x] ? li : 0);
+      in[x] = in[x] && gb_row_passes(C, row[x]);
     }
     gbc_load_keys<KW, R>(D, C, row, k);
     gbc_load_values<NV, R>(D, C, row, v);

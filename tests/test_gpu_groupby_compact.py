@@ -304,3 +304,36 @@ def test_float_sums_agree_with_the_oracle_within_the_stated_tolerance(gpu, oracl
         e64, e32, ei, ec = exp[key]
         assert (si, c) == (ei, ec)
         assert abs(s64 - e64) <= 1e-9 * mag[key] and abs(s32 - e32) <= 1e-9 * mag32[key]
+
+
+@pytest.mark.parametrize("name", ["nullable key, nullable sum + count(col) + count(*)", "three keys (Q3's group-by), sum(Decimal128)",
+                                  "eight aggregates over six columns, some nullable", "inline String key; sum, count"])
+@pytest.mark.parametrize("n,card,pbits", [(4000, 30, None), (250_000, 900, None), (300_000, 20_000, 4), (300_000, 20_000, 11), (2_000_000, 150_000, None)])
+def test_compact_kernels_with_a_pushed_down_filter(gpu, oracle, name, n, card, pbits):
+    """dbhip_groupby_add_block_filtered (the TransformFilter in front of the aggregate pushed down as a Bitmap, filter_executor.rs:81-118)
+    through the compact kernels: LDS tables, both scatters, the aggregation of partitions — equal to the oracle over the rows that pass."""
+    rng = np.random.default_rng(n + card)
+    keys, kn, aggs, args = layout_cases(rng, n, card)[name]
+    keep = rng.random(n) < 0.6
+    keep[: n // 50] = False                      # a run of rejected rows (whole tiles fail)
+    key_types = [_both(gpu, k, d[:1], None)[0] for k, d, _v in keys]
+    g = gpu.GroupBy(key_types, aggs, kn)
+    if pbits is not None:
+        g.debug_set_partition_bits(pbits)
+    half = n // 2
+    for lo, hi in ((0, half), (half, n)):
+        sl = lambda x: None if x is None else x[lo:hi]
+        kc = [_both(gpu, k, d[lo:hi], sl(v))[1] for k, d, v in keys]
+        ac = [None if a is None else _both(gpu, a[0], a[1][lo:hi], sl(a[2]))[1] for a in args]
+        if hi > lo:
+            g.add_block(kc, ac, hi - lo, filter=gpu.Column.boolean(keep[lo:hi]))
+    got = g.result()
+    g.destroy()
+    idx = np.flatnonzero(keep)
+    pick = lambda d: [d[i] for i in idx] if isinstance(d, list) else d[idx]
+    hk = [_both(gpu, k, pick(d), None if v is None else v[idx])[2] for k, d, v in keys]
+    ha = [None if a is None else _both(gpu, a[0], pick(a[1]), None if a[2] is None else a[2][idx])[2] for a in args]
+    h = oracle_groupby(oracle, key_types, kn, aggs, hk, ha, len(idx))
+    exp = oracle_rows(oracle, h, key_types, aggs)
+    oracle.orc_hashagg_destroy(h)
+    assert norm(got) == norm(exp)
