@@ -253,11 +253,15 @@ def main():
                   (MAX, L.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [col(k1, L.T_I64)],
                  [col(v1, L.T_I64), col(v2, L.T_I64), col(v1, L.T_I64), col(v1, L.T_I64), col(v2, L.T_I64), col(v2, L.T_I64), col(v2, L.T_I64), None], 24),
             ]
+            fbits = D.Column(L.T_BOOL, n, Borrowed(torch.randint(0, 256, (n // 8 + 64,), device=dev, dtype=torch.uint8, generator=g)))   # ~50 % pass
+            cases.append(("i64 key; sum, count; pushed-down filter (50 % pass)", [L.T_I64], None, [(SUM, L.T_I64, 0, 0, 0), (CNT, 0, 0, 0, 0)], [col(k1, L.T_I64)],
+                          [col(v1, L.T_I64), None], 16.125))
             for name, kt, kn, aggs, kcols, acols, bpr in cases:
                 gb = D.GroupBy(kt, aggs, key_nullable=kn, capacity=max(1024, card * 2))
+                flt = fbits if "filter" in name else None
                 def f():
                     gb.reset()
-                    gb.add_block(kcols, acols, n)
+                    gb.add_block(kcols, acols, n, filter=flt)
                 ms = timed(f, reps=3, warm=2)
                 ng = gb.num_groups()
                 report(out, f"groupby layouts: {name}, {card} groups", n, "rows", alg_bytes=bpr * n, ms=ms, note=f"{ng} groups met")
