@@ -1756,4 +1756,113 @@ inline std::optional<Column> column_chunk_to_column(const uint8_t* bytes, size_t
   return c;
 }
 
+// ---- the same for a whole block, device mode (round 5): every leaf's page headers are read on the host, the chunks go to HBM AS
+// STORED, and ONE dbhip_pq_chunks_decode_device call decompresses (ZSTD / LZ4 / Snappy) and decodes all of them. A leaf the library
+// declines (std::nullopt in the result) stays with the arrow-rs reader; a malformed chunk raises like any decode error.
+struct ChunkBytes { const uint8_t* bytes; size_t len; };
+inline std::vector<std::optional<Column>> column_chunks_to_columns(const std::vector<ChunkBytes>& chunks, const std::vector<ParquetLeaf>& leaves,
+                                                                   const std::vector<DataType>& field_types) {
+  const size_t n = chunks.size();
+  std::vector<std::optional<Column>> out(n);
+  std::vector<dbhip_pq_chunk*> h;
+  std::vector<size_t> which;
+  std::vector<dbhip_pq_info> info;
+  struct Closer { std::vector<dbhip_pq_chunk*>& v; ~Closer() { for (auto* c : v) dbhip_pq_chunk_close(c); } } closer{h};
+  for (size_t i = 0; i < n; ++i) {
+    dbhip_pq_chunk* c = nullptr;
+    dbhip_pq_info f;
+    const int32_t rc = dbhip_pq_chunk_open_device(chunks[i].bytes, (int64_t)chunks[i].len, leaves[i].codec, leaves[i].physical_type, leaves[i].type_length,
+                                                  leaves[i].max_def_level, leaves[i].max_rep_level, field_types[i].id, &c, &f);
+    if (rc == DBHIP_ERR_UNSUPPORTED) continue;
+    check(rc);
+    h.push_back(c); which.push_back(i); info.push_back(f);
+  }
+  const size_t m = h.size();
+  if (m == 0) return out;
+  std::vector<Buf> chunk_dev(m), image_dev(m);
+  std::vector<const uint8_t*> cd(m);
+  std::vector<uint8_t*> im(m), val(m);
+  std::vector<void*> ov(m);
+  std::vector<Column> cols(m);
+  for (size_t k = 0; k < m; ++k) {
+    const size_t i = which[k];
+    chunk_dev[k] = make_buf(chunks[i].len + 32);          // (16-byte aligned allocation, readable past the end to a multiple of 16)
+    chunk_dev[k]->upload(chunks[i].bytes, chunks[i].len);
+    if (info[k].image_bytes) image_dev[k] = make_buf((size_t)info[k].image_bytes);
+    Column& c = cols[k];
+    c.type = field_types[i];
+    c.type.nullable = info[k].has_validity != 0;
+    c.len = info[k].num_values;
+    c.data = make_buf((size_t)info[k].out_bytes + 16);
+    if (info[k].has_validity) c.validity = make_buf((size_t)info[k].validity_bytes + 8);
+    cd[k] = (const uint8_t*)chunk_dev[k]->ptr();
+    im[k] = image_dev[k] ? (uint8_t*)image_dev[k]->ptr() : nullptr;
+    ov[k] = c.data->ptr();
+    val[k] = c.validity ? (uint8_t*)c.validity->ptr() : nullptr;
+  }
+  std::vector<int64_t> nulls(m);
+  std::vector<int32_t> status(m);
+  const int32_t rc = dbhip_pq_chunks_decode_device(h.data(), (int32_t)m, cd.data(), im.data(), ov.data(), val.data(), nulls.data(), status.data(), nullptr);
+  for (size_t k = 0; k < m; ++k) {
+    if (status[k] == DBHIP_ERR_UNSUPPORTED) continue;     // (a form found on the device that stays with the CPU reader)
+    if (status[k] != DBHIP_OK) check(rc);
+    Column& c = cols[k];
+    if (field_types[which[k]].id == DBHIP_T_STRING) {      // views point into the decompressed image (or the chunk itself)
+      c.str_data = image_dev[k] ? image_dev[k] : chunk_dev[k];
+      void* p = c.str_data->ptr();
+      c.str_ptrs = make_buf(sizeof(void*));
+      c.str_ptrs->upload(&p, sizeof(void*));
+    }
+    out[which[k]] = std::move(c);
+  }
+  return out;
+}
+
+// Array(T) of a primitive leaf (one repeated ancestor): -> { offsets [rows + 1] (host), NULL lists (host, empty when the list is
+// required), the element column }; std::nullopt when the library declines the chunk
+struct ListColumn {
+  std::vector<uint64_t> offsets;
+  std::vector<uint8_t> list_valid;   // one byte per row, empty = no NULL lists possible
+  Column elements;
+};
+inline std::optional<ListColumn> list_chunk_to_column(const uint8_t* bytes, size_t len, const ParquetLeaf& leaf, bool list_nullable, bool element_nullable,
+                                                      DataType element_type) {
+  dbhip_pq_chunk* h = nullptr;
+  dbhip_pq_info info;
+  const int32_t rc = dbhip_pq_chunk_open_device_list(bytes, (int64_t)len, leaf.codec, leaf.physical_type, leaf.type_length, list_nullable ? 1 : 0,
+                                                     element_nullable ? 1 : 0, element_type.id, &h, &info);
+  if (rc == DBHIP_ERR_UNSUPPORTED) return std::nullopt;
+  check(rc);
+  struct Closer { dbhip_pq_chunk* h; ~Closer() { dbhip_pq_chunk_close(h); } } closer{h};
+  Buf chunk = make_buf(len + 32), image = info.image_bytes ? make_buf((size_t)info.image_bytes) : nullptr;
+  chunk->upload(bytes, len);
+  Buf offs = make_buf((size_t)(info.num_values + 1) * 8 + 16), lval = list_nullable ? make_buf((size_t)info.validity_bytes + 8) : nullptr;
+  ListColumn L;
+  Column& c = L.elements;
+  c.type = element_type;
+  c.type.nullable = element_nullable;
+  c.data = make_buf((size_t)info.out_bytes + 16);
+  if (element_nullable) c.validity = make_buf((size_t)info.validity_bytes + 8);
+  int64_t rows = 0, elems = 0, null_lists = 0;
+  check(dbhip_pq_chunk_decode_device_list(h, (const uint8_t*)chunk->ptr(), image ? (uint8_t*)image->ptr() : nullptr, (uint64_t*)offs->ptr(),
+                                          lval ? (uint8_t*)lval->ptr() : nullptr, c.data->ptr(), c.validity ? (uint8_t*)c.validity->ptr() : nullptr,
+                                          &rows, &elems, &null_lists, nullptr));
+  c.len = elems;
+  L.offsets.resize((size_t)rows + 1);
+  offs->download(L.offsets.data(), L.offsets.size() * 8);
+  if (lval) {
+    std::vector<uint8_t> bits((size_t)(rows + 7) / 8);
+    if (!bits.empty()) lval->download(bits.data(), bits.size());
+    L.list_valid.resize((size_t)rows);
+    for (int64_t r = 0; r < rows; ++r) L.list_valid[(size_t)r] = (bits[(size_t)r >> 3] >> (r & 7)) & 1;
+  }
+  if (element_type.id == DBHIP_T_STRING) {
+    c.str_data = image ? image : chunk;
+    void* p = c.str_data->ptr();
+    c.str_ptrs = make_buf(sizeof(void*));
+    c.str_ptrs->upload(&p, sizeof(void*));
+  }
+  return L;
+}
+
 }  // namespace dbhip_host

@@ -819,6 +819,48 @@ static void test_parquet_chunk() {
   CHECK(!column_chunk_to_column(ch.data(), ch.size(), leaf, DataType::of(DBHIP_T_I64)).has_value());
 }
 
+// the device-mode scan of a block (two leaves in one dbhip_pq_chunks_decode_device call) and a List<Int64> leaf; pages written by hand
+static void test_parquet_device_mode() {
+  std::vector<uint8_t> ch = {
+      0x15, 0x00, 0x15, 0x3C, 0x15, 0x3C, 0x2C, 0x15, 0x08, 0x15, 0x00, 0x15, 0x06, 0x15, 0x06, 0x00, 0x00,   // DATA_PAGE, 30 bytes, 4 values, PLAIN, RLE levels
+      0x02, 0x00, 0x00, 0x00, 0x03, 0x0D,                                                                 // definition levels 1,0,1,1
+  };
+  const int64_t vals[3] = {7, -3, (int64_t)1 << 40};
+  ch.insert(ch.end(), (const uint8_t*)vals, (const uint8_t*)vals + 24);
+  std::vector<uint8_t> req = {
+      0x15, 0x00, 0x15, 0x20, 0x15, 0x20, 0x2C, 0x15, 0x04, 0x15, 0x00, 0x15, 0x06, 0x15, 0x06, 0x00, 0x00,   // a required INT64 column: 16 bytes, 2 values
+  };
+  const int64_t two[2] = {11, 12};
+  req.insert(req.end(), (const uint8_t*)two, (const uint8_t*)two + 16);
+  auto cols = column_chunks_to_columns({{ch.data(), ch.size()}, {req.data(), req.size()}}, {ParquetLeaf{2, 0, 1, 0, 0}, ParquetLeaf{2, 0, 0, 0, 0}},
+                                       {DataType::of(DBHIP_T_I64), DataType::of(DBHIP_T_I64)});
+  CHECK(cols.size() == 2 && cols[0].has_value() && cols[1].has_value());
+  if (cols[0] && cols[1]) {
+    auto v = cols[0]->to_vector<int64_t>();
+    auto ok = cols[0]->validity_to_host();
+    CHECK(cols[0]->len == 4 && v[0] == 7 && v[1] == 0 && v[2] == -3 && v[3] == ((int64_t)1 << 40) && ok[0] && !ok[1] && ok[2] && ok[3]);
+    auto w = cols[1]->to_vector<int64_t>();
+    CHECK(cols[1]->len == 2 && w[0] == 11 && w[1] == 12);
+  }
+  // List<Int64>, list and elements nullable (max_def 3): rows [5, NULL], NULL, [], [6] -> entries (rep, def): (0,3) (1,2) (0,0) (0,1) (0,3)
+  std::vector<uint8_t> li = {
+      0x15, 0x00, 0x15, 0x3A, 0x15, 0x3A, 0x2C, 0x15, 0x0A, 0x15, 0x00, 0x15, 0x06, 0x15, 0x06, 0x00, 0x00,   // DATA_PAGE, 29 bytes, 5 entries
+      0x02, 0x00, 0x00, 0x00, 0x03, 0x02,          // repetition levels, width 1: one bit-packed group, bits 0,1,0,0,0 -> 0x02
+      0x03, 0x00, 0x00, 0x00, 0x03, 0x4B, 0x03,    // definition levels, width 2: one group of 8: 3,2,0,1,3,0,0,0 -> bytes 0x4B 0x03
+  };
+  const int64_t el[2] = {5, 6};
+  li.insert(li.end(), (const uint8_t*)el, (const uint8_t*)el + 16);
+  auto L = list_chunk_to_column(li.data(), li.size(), ParquetLeaf{2, 0, 3, 1, 0}, true, true, DataType::of(DBHIP_T_I64));
+  CHECK(L.has_value());
+  if (L) {
+    CHECK(L->offsets == (std::vector<uint64_t>{0, 2, 2, 2, 3}));
+    CHECK(L->list_valid == (std::vector<uint8_t>{1, 0, 1, 1}));
+    auto v = L->elements.to_vector<int64_t>();
+    auto ok = L->elements.validity_to_host();
+    CHECK(L->elements.len == 3 && v[0] == 5 && v[1] == 0 && v[2] == 6 && ok[0] && !ok[1] && ok[2]);
+  }
+}
+
 int main() {
   try {
     init(0);
@@ -839,6 +881,7 @@ int main() {
     test_hnsw_index();
     test_vector_function();
     test_parquet_chunk();
+    test_parquet_device_mode();
   } catch (const std::exception& e) {
     printf("EXCEPTION: %s\n", e.what());
     return 2;
