@@ -521,7 +521,7 @@ struct ZProd : ZWave {
 };
 
 // the consumer: replays the commands until END; -> the producer's status
-__device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, bool dry = false) {
+__device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q) {
   uint32_t head = 0;
   for (;;) {
     uint32_t tail = q.tail();
@@ -536,7 +536,6 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, bool d
     for (uint32_t i = 0; i < m; ++i) {
       const uint32_t w0 = rdl(e.x, i), w1 = rdl(e.y, i), off = rdl(e.z, i), w3 = rdl(e.w, i);
       if (off) {                       // a sequence: w0 literals, then w1 bytes from `off` back
-        if (dry) continue;             // (experiment: the producer's time alone; WRONG OUTPUT)
         if (w0) (void)w.put_seq(w0, off, w1);
         else (void)w.put_match(off, w1);
         continue;

@@ -66,8 +66,6 @@ __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __rest
 __global__ __launch_bounds__(128) void dv_inflate_zstd2_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
   const DvJob P = jobs[blockIdx.x];
-  const uint32_t ring_arg = ring;
-  ring &= 0x7FFFFFFFu;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t lev = P.lev_len;
   const uint32_t raw = P.compressed ? lev : P.uncomp_len;
@@ -88,7 +86,7 @@ __global__ __launch_bounds__(128) void dv_inflate_zstd2_kernel(const DvJob* __re
   } else {
     ZWave b;
     b.begin(P, dv_lds, ring, lane);
-    const int rc = (int)zq_consume(b, Q, (ring_arg >> 31) != 0);
+    const int rc = (int)zq_consume(b, Q);
     b.flush(true);
     if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
   }
@@ -948,10 +946,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   // (two waves per page — parse | copy — unless DBHIP_PQ_ZSTD_WAVES=1 asks for the one-wave kernel)
   static const bool z_one_wave = getenv("DBHIP_PQ_ZSTD_WAVES") && atoi(getenv("DBHIP_PQ_ZSTD_WAVES")) == 1;
   if (n_z && z_one_wave) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
-  else if (n_z) {
-    static const uint32_t z_dry = (getenv("DBHIP_PQ_ZSTD_DRY") && atoi(getenv("DBHIP_PQ_ZSTD_DRY"))) ? 0x80000000u : 0u;   // (experiment: sequences are parsed, not copied)
-    hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring | z_dry);
-  }
+  else if (n_z) hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring);
   if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), lz_ring, s, d_jobs + n_z, lz_ring);
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
   if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));
