@@ -521,7 +521,6 @@ struct GbcAggArgs {
   uint64_t* spill;         // [spill_cap][W] rows that did not fit, table layout
   uint64_t spill_cap;
   uint64_t* ctrl;          // [5] += partial rows, [6] += spilled rows, [3] |= 4 when the spill buffer overflowed
-  int debug;               // experiments (env DBHIP_GBC_DEBUG; WRONG RESULTS): 1 = no state merges, 2 = no probe (slot = home slot)
   // heavy partitions (gbc_split_map_kernel): partition p is worked on in nsp[p] >= splits sub-ranges; sub-ranges splits .. nsp[p] - 1 belong to
   // EXTRA workgroups (blockIdx.x >= nparts * splits), extra_map[e] = p | sub-range << 16, *extra_n of them. With per-partition lists
   // (pcount) the partial rows of a partition in more than one sub-range go to a packed list at partial[packed_base ...] (cursor: ctrl[7]).
@@ -898,7 +897,6 @@ __global__ __launch_bounds__(GBC_T) void gbc_agg_kernel(GbcDesc D, GbCols C, Gbc
           for (int j = 0; j < KW; ++j) hit &= __hip_atomic_load(&d[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == k[x][j];
         }
       }
-      if (A.debug & 2) hit = true;
       slot[x] = (in[x] && hit) ? pos[x] : GBC_NONE;
       const bool defer = in[x] && !hit;
       const uint64_t m = __ballot(defer);
@@ -925,7 +923,7 @@ __global__ __launch_bounds__(GBC_T) void gbc_agg_kernel(GbcDesc D, GbCols C, Gbc
         }
       }
     }
-    if (!(A.debug & 1)) gbc_merge<KW, NV, R>(D, lrow, LS, slot, v);
+    gbc_merge<KW, NV, R>(D, lrow, LS, slot, v);
     if (more) {
 #pragma unroll
       for (int x = 0; x < R; ++x) {

@@ -1963,8 +1963,6 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
       memset(&G, 0, sizeof(G));
       G.row0 = *done; G.n = cn; G.lcap = lcap_i; G.llimit = A.llimit; G.partial = g->partial; G.pcount = nullptr;
       G.spill = g->rows_in; G.spill_cap = (uint64_t)spill_cap; G.ctrl = g->ctrl;
-      static const int gbc_debug = getenv("DBHIP_GBC_DEBUG") ? atoi(getenv("DBHIP_GBC_DEBUG")) : 0;
-      G.debug = gbc_debug;
 #define GBC_AGG(KW_, NV_) hipLaunchKernelGGL((gbc_agg_kernel<KW_, NV_, true>), dim3(grid), dim3(1024), lds_i, s, GD, C, G)
       GBC_DISPATCH(GD, GBC_AGG);
 #undef GBC_AGG
