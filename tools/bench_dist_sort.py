@@ -49,6 +49,34 @@ def run(torch, rows=60_000_000, ranges=8, reps=5):
     t_sort_all, _ = wall(lambda: ops.sort(flat, [0], [None], [0], [0]))
     t_scat, (_sidx, scnt) = wall(lambda: D.scatter_indices(kcol, ranges, 0))
     t_scat_all, _ = wall(lambda: sops.scatter(flat, 0, None, ranges))
+    # the ABI-owned block exchange (dbhip_exchange_begin / _finish) of this rank, in a world of ONE: everything a rank does around the
+    # wire — scatter by destination, the counts read back and exchanged, the payload pieces "sent" (device copies), the concat of what
+    # arrived — with nothing on the wire; begin (incl. its host round trip) and finish timed apart
+    import ctypes as C
+    comm = D.Comm.local()
+    pcol = D.Column(L.T_I64, rows, type("B", (), {"ptr": pay.data_ptr(), "nbytes": rows * 8})())
+    dest = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    dbuf = type("B", (), {"ptr": dest.data_ptr(), "nbytes": rows * 4})()
+    xcols = [kcol[0], pcol]
+    outs = [D.DeviceBuffer(rows * 8 + 64) for _ in xcols]
+    t_begin, t_finish = 1e9, 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        x, got = C.c_void_p(), C.c_int64()
+        t0 = time.perf_counter()
+        L.check(L.lib().dbhip_exchange_begin(comm.h, D._cols(xcols), len(xcols), C.c_void_p(dbuf.ptr), C.c_int64(rows), C.byref(got), C.byref(x), None))
+        L.check(L.lib().dbhip_stream_sync(None))
+        t1 = time.perf_counter()
+        dp = (C.c_void_p * 2)(*[b.ptr for b in outs])
+        vp = (C.c_void_p * 2)(None, None)
+        starts = (C.c_int64 * 2)()
+        L.check(L.lib().dbhip_exchange_finish(x, dp, vp, starts, None))
+        L.check(L.lib().dbhip_stream_sync(None))
+        t2 = time.perf_counter()
+        L.lib().dbhip_exchange_destroy(x)
+        assert got.value == rows
+        t_begin, t_finish = min(t_begin, (t1 - t0) * 1e3), min(t_finish, (t2 - t1) * 1e3)
+    comm.destroy()
     assert int(scnt.sum()) == rows
     assert counts.tolist() == [int(c) for c in counts2] and int(counts.sum()) == rows
     assert bool((out[0][1:] >= out[0][:-1]).all())
@@ -58,6 +86,10 @@ def run(torch, rows=60_000_000, ranges=8, reps=5):
             "siphash_scatter_indices_ms": round(t_scat, 3), "siphash_scatter_indices_GBps": round(rows * 12 / t_scat / 1e6, 1),
             "scatter_operator_ms": round(t_scat_all, 3), "rows_per_destination": [int(c) for c in scnt],
             "local_sort_of_one_share_ms": round(t_sort, 3), "single_gpu_sort_of_all_rows_ms": round(t_sort_all, 3),
+            "abi_exchange_world_of_one": {"begin_ms": round(t_begin, 3), "finish_ms": round(t_finish, 3), "GBps": round(rows * 16 * 2 / (t_begin + t_finish) / 1e6, 1),
+                                          "what": "dbhip_exchange_begin (scatter_columns of two 8-byte columns by destination + the counts' device-to-host copy + "
+                                                  "the count all-to-all) and dbhip_exchange_finish (the grouped send / recv of every column = device copies here, "
+                                                  "+ concat_columns), the whole block to one destination; no wire"},
             "what": "one rank's stages of the distributed sort (sample -> Bounds -> dbhip_sort_bound_partition -> dbhip_scatter_block | all-to-all | "
                     "dbhip_sort_perm) and of the shuffle hash join's scatter (dbhip_scatter_indices = the reference's siphash64 % n -> "
                     "dbhip_scatter_block) on (i64 key, i64 payload) rows; wall clock around synchronised library calls"}
