@@ -2365,6 +2365,14 @@ struct PaArgs {
   uint64_t* ctrl;          // [5] = #partial rows, [6] = #spilled rows
   uint32_t* pcount;        // non-NULL: workgroup b keeps its partial rows at partial[b * lcap ...] and their number here
                            // (the partition-exclusive merge below reads them per partition); NULL: one packed list
+  // heavy partitions (round 5, the scheme of gb_compact.h's GbcAggArgs): partition p is worked on in nsp[p] >= splits sub-ranges, the
+  // ones beyond `splits` by EXTRA workgroups (blockIdx.x >= nparts * splits; extra_map[e] = p | sub-range << 16, *extra_n of them);
+  // with per-partition lists the partial rows of a split partition go to a packed list at partial[packed_base ...] (cursor ctrl[7])
+  const uint32_t* nsp;
+  const uint32_t* extra_n;
+  const uint32_t* extra_map;
+  int nparts;
+  uint64_t packed_base;
 };
 
 constexpr int PA_R = 4;
@@ -2389,11 +2397,21 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
   uint64_t* lrows = fk_lds + A.lcap;
   const int tid = threadIdx.x;
   const uint32_t lmask = (uint32_t)A.lcap - 1;
-  const int p = blockIdx.x / A.splits, sp = blockIdx.x % A.splits;
+  int p, sp;
+  const int regular = A.nsp ? A.nparts * A.splits : (int)gridDim.x;
+  if ((int)blockIdx.x < regular) { p = blockIdx.x / A.splits; sp = blockIdx.x % A.splits; }
+  else {
+    const uint32_t e = blockIdx.x - (uint32_t)regular;
+    if (e >= *A.extra_n) return;
+    const uint32_t m = A.extra_map[e];
+    p = (int)(m & 0xFFFFu); sp = (int)(m >> 16);
+  }
+  const uint32_t nsp = A.nsp ? A.nsp[p] : (uint32_t)A.splits;
+  const bool own_list = A.pcount && nsp == 1;      // the partition's own list (partition-exclusive merge); else a packed list
   const uint32_t pb = A.base[p], pe = A.base[p + 1];
   const uint32_t len = pe - pb;
-  const uint32_t r_begin = pb + (uint32_t)(((uint64_t)len * sp) / A.splits);
-  const uint32_t r_end = pb + (uint32_t)(((uint64_t)len * (sp + 1)) / A.splits);
+  const uint32_t r_begin = pb + (uint32_t)(((uint64_t)len * (uint32_t)sp) / nsp);
+  const uint32_t r_end = pb + (uint32_t)(((uint64_t)len * ((uint32_t)sp + 1)) / nsp);
   if (r_begin >= r_end) return;
   for (int s = tid; s < A.lcap; s += 256) lhash[s] = 0;
   if (tid == 0) lcount = 0;
@@ -2508,10 +2526,12 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
   __syncthreads();
   const uint32_t occupied = lcount;
   __syncthreads();
+  __shared__ unsigned long long pa_wg_base;
   if (tid == 0) {
     lcount = 0;
     if (A.pcount) {
-      A.pcount[blockIdx.x] = occupied;
+      if (own_list) { A.pcount[blockIdx.x] = occupied; pa_wg_base = (unsigned long long)blockIdx.x * A.lcap; }
+      else pa_wg_base = A.packed_base + (occupied ? atomicAdd((unsigned long long*)&A.ctrl[7], (unsigned long long)occupied) : 0ULL);
       if (occupied) atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)occupied);
     }
   }
@@ -2521,7 +2541,7 @@ __global__ __launch_bounds__(256) void gb_part_agg_kernel(GbLayout L, PaArgs A) 
     const uint64_t m = __ballot(occ);
     unsigned long long base = 0;
     if (m && lane_id() == 0) {
-      if (A.pcount) base = (unsigned long long)blockIdx.x * A.lcap + atomicAdd(&lcount, (uint32_t)__popcll(m));
+      if (A.pcount) base = pa_wg_base + atomicAdd(&lcount, (uint32_t)__popcll(m));
       else base = atomicAdd((unsigned long long*)&A.ctrl[5], (unsigned long long)__popcll(m));
     }
     base = __shfl(base, 0, 64);
@@ -3041,8 +3061,24 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
 #define GBC_AGG(KW_, NV_) hipLaunchKernelGGL((gbc_agg_kernel<KW_, NV_, false>), dim3(agrid + extra_max), dim3(threads), lds_bytes, s, D, C, G)
     GBC_DISPATCH(D, GBC_AGG);
 #undef GBC_AGG
-  } else if (L.W <= 8) hipLaunchKernelGGL((gb_part_agg_kernel<8>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
-  else hipLaunchKernelGGL((gb_part_agg_kernel<0>), dim3(agrid), dim3(256), lds_bytes, s, L, A);
+  } else {
+    // heavy partitions: the same split as for the compact kernels (the generic partitions are exact: base[], from the histogram pass)
+    static const bool no_heavy = getenv("DBHIP_GBC_HEAVY") && atoi(getenv("DBHIP_GBC_HEAVY")) == 0;
+    int extra_max = 0;
+    A.nsp = nullptr; A.extra_n = nullptr; A.extra_map = nullptr; A.nparts = P; A.packed_base = (uint64_t)agrid * lcap;
+    if (!no_heavy) {
+      int64_t max_rows = 2 * (cn / agrid);
+      if (max_rows < 32768) max_rows = 32768;
+      extra_max = (int)(cn / max_rows) + 1;
+      if ((rc = ensure((void**)&g->gbc_split, &g->gbc_split_cap, ((size_t)P + 2 + (size_t)extra_max) * 4))) return rc;
+      if ((rc = ensure((void**)&g->partial, &g->partial_cap, ((size_t)agrid + 2 * (size_t)extra_max) * lcap * L.W * 8))) return rc;
+      A.partial = g->partial;
+      A.nsp = g->gbc_split; A.extra_n = g->gbc_split + P + 1; A.extra_map = g->gbc_split + P + 2;
+      hipLaunchKernelGGL(gbc_split_map_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)nullptr, 0u, base, P, splits, (uint32_t)max_rows, (uint32_t)extra_max, g->gbc_split);
+    }
+    if (L.W <= 8) hipLaunchKernelGGL((gb_part_agg_kernel<8>), dim3(agrid + extra_max), dim3(256), lds_bytes, s, L, A);
+    else hipLaunchKernelGGL((gb_part_agg_kernel<0>), dim3(agrid + extra_max), dim3(256), lds_bytes, s, L, A);
+  }
   DBHIP_LAUNCH_CHECK();
   uint64_t* hc = pinned_words(0);
   if (!hc) return DBHIP_ERR_HIP;
@@ -3074,7 +3110,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   }
   const int64_t nspill = (int64_t)hc[6];
   const int64_t npartial = (int64_t)hc[5];
-  const int64_t npacked = (gbc && exclusive) ? (int64_t)hc[7] : 0;   // (partial rows of heavy partitions' sub-ranges, behind the per-partition lists)
+  const int64_t npacked = exclusive ? (int64_t)hc[7] : 0;   // (partial rows of heavy partitions' sub-ranges, behind the per-partition lists)
   int64_t nlisted = 0;
   if (exclusive && npartial > 0) {
     // every partial row may be a new group: make room first (the slices move with the capacity, the kernel takes it as it is)

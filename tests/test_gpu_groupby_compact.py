@@ -257,11 +257,12 @@ def test_compact_layouts_spill_and_long_strings_leave_the_fast_path(gpu, oracle)
     assert got == exp and got[long_key][1] == 1
 
 
+@pytest.mark.parametrize("compact", [True, False], ids=["compact", "generic"])
 @pytest.mark.parametrize("card,null", [(30_000, True), (30_000, False), (1_500_000, True), (400_000, False)])
-def test_one_heavy_group_among_many(gpu, oracle, card, null):
+def test_one_heavy_group_among_many(gpu, oracle, card, null, compact):
     """a quarter of the rows carry ONE key (NULL, or a value): its partition is worked on in sub-ranges by extra workgroups
     (gbc_split_map_kernel) whose partial rows travel in the packed list — next to per-partition lists (10^5+ groups: one workgroup per
-    partition) and inside the one packed list (few partitions, several workgroups each)"""
+    partition) and inside the one packed list (few partitions, several workgroups each); the compact kernels and the generic ones"""
     n = 6_000_000
     rng = np.random.default_rng(card)
     k = rng.integers(0, card, n).astype(np.int64)
@@ -273,7 +274,7 @@ def test_one_heavy_group_among_many(gpu, oracle, card, null):
         k[heavy] = card + 11
         keys, kn = [(T.T_I64, k, None)], [0]
     got = run_layout(gpu, oracle, keys, kn, [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 0)],
-                     [(T.T_I64, a, None), None, (T.T_I64, a, None)], n)
+                     [(T.T_I64, a, None), None, (T.T_I64, a, None)], n, compact=compact)
     hk = None if null else card + 11
     row = [r for r in got if r[0] == hk]
     assert len(row) == 1 and row[0][2] == int(heavy.sum())
