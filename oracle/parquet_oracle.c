@@ -439,6 +439,149 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
   return rc;
 }
 
+/* List<primitive> (round 5): a leaf under ONE repeated ancestor (max_rep = 1, max_def = list_nullable + 1 + elem_nullable), the
+ * three-level LIST of LogicalTypes.md that the reference writes for Array(T) and reads through arrow-rs (deserialize.rs:33-81; the
+ * record assembly is parquet's "Dremel" levels: a repetition level of 0 starts a row, a definition level below list_nullable + 1 is a
+ * NULL / empty list without an element, max_def is a value, the level in between a NULL element). One level entry at a time:
+ *   out_offsets[r] .. out_offsets[r + 1]  the elements of row r (Databend's ArrayColumn offsets), out_list_valid[r] = the list is not NULL,
+ *   out_values / out_elem_valid           the elements back to back in the output type (a NULL element: zero bytes).
+ * UNCOMPRESSED chunks, PLAIN / dictionary / RLE-Boolean / DELTA_BINARY_PACKED values, v1 and v2 pages. -> 0, -1 malformed, -2 not handled */
+int orc_pq_decode_list(const uint8_t* chunk, int64_t len, int physical, int type_length, int list_nullable, int elem_nullable, int out_type,
+                       int64_t cap_entries, uint64_t* out_offsets, uint8_t* out_list_valid, uint8_t* out_values, uint8_t* out_elem_valid,
+                       int64_t* out_rows, int64_t* out_elems) {
+  rd_t r = {chunk, chunk + len, 0};
+  const int es = esize_of(out_type);
+  const int pw = physical == PT_INT32 || physical == PT_FLOAT ? 4 : (physical == PT_INT64 || physical == PT_DOUBLE ? 8 : type_length);
+  const int max_def = list_nullable + 1 + elem_nullable;
+  const int dw = max_def > 1 ? 2 : 1;
+  int64_t rows = 0, elems = 0, entries = 0;
+  int64_t dict_n = -1;
+  uint8_t* dict = NULL;
+  int rc = 0;
+  while (r.p < r.end && rc == 0) {
+    page_t pg;
+    if (read_page(&r, &pg)) { rc = -1; break; }
+    if ((int64_t)(r.end - r.p) < pg.csize) { rc = -1; break; }
+    const uint8_t* pay = r.p;
+    const uint8_t* pend = pay + pg.csize;
+    r.p = pend;
+    if (pg.csize != pg.usize) { rc = -2; break; }
+    if (pg.type == 2) {
+      if (dict_n >= 0 || pg.nvals < 0 || (pg.enc != 0 && pg.enc != 2)) { rc = pg.enc != 0 && pg.enc != 2 ? -2 : -1; break; }
+      dict_n = pg.nvals;
+      dict = (uint8_t*)calloc((size_t)(dict_n > 0 ? dict_n : 1), 16);
+      const uint8_t* q = pay;
+      for (int64_t i = 0; i < dict_n; ++i) {
+        if (physical == PT_BYTE_ARRAY) {
+          uint32_t l;
+          if (pend - q < 4) { rc = -1; break; }
+          memcpy(&l, q, 4);
+          if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+          put_view(chunk, (uint64_t)(q + 4 - chunk), dict, i);
+          q += 4 + l;
+        } else {
+          if (pend - q < pw) { rc = -1; break; }
+          put_plain(physical, type_length, out_type, q, dict, i);
+          q += pw;
+        }
+      }
+      continue;
+    }
+    if (pg.type != 0 && pg.type != 3) continue;
+    if (pg.nvals < 0 || entries + pg.nvals > cap_entries) { rc = -1; break; }
+    const uint8_t* q = pay;
+    hyb_t rh, dh;
+    if (pg.type == 0) {   /* v1: [u32 length][repetition levels][u32 length][definition levels][values] */
+      uint32_t l;
+      if (pend - q < 4) { rc = -1; break; }
+      memcpy(&l, q, 4);
+      if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+      hyb_init(&rh, q + 4, l, 1);
+      q += 4 + l;
+      if (pend - q < 4) { rc = -1; break; }
+      memcpy(&l, q, 4);
+      if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+      hyb_init(&dh, q + 4, l, dw);
+      q += 4 + l;
+    } else {              /* v2: the byte lengths come from the header, no prefixes */
+      if (pg.rep_len < 0 || pg.def_len < 0 || pend - q < (int64_t)pg.rep_len + pg.def_len) { rc = -1; break; }
+      hyb_init(&rh, q, (uint64_t)pg.rep_len, 1);
+      hyb_init(&dh, q + pg.rep_len, (uint64_t)pg.def_len, dw);
+      q += pg.rep_len + pg.def_len;
+    }
+    hyb_t vh;
+    delta_t dl;
+    int use_hyb = 0, boolbit = 0;
+    if (pg.enc == 2 || pg.enc == 8) {
+      if (dict_n < 0) { rc = -1; break; }
+      if (pend - q >= 1) { hyb_init(&vh, q + 1, (uint64_t)(pend - q - 1), q[0]); if (q[0] > 32) rc = -1; }
+      else hyb_init(&vh, q, 0, 0);
+      use_hyb = 1;
+    } else if (pg.enc == 3 && physical == PT_BOOLEAN) {
+      uint32_t l;
+      if (pend - q < 4) { rc = -1; break; }
+      memcpy(&l, q, 4);
+      if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+      hyb_init(&vh, q + 4, l, 1);
+      use_hyb = 2;
+    } else if (pg.enc == 5 && (physical == PT_INT32 || physical == PT_INT64)) {
+      if (delta_init(&dl, q, pend)) { rc = -1; break; }
+      use_hyb = 3;
+    } else if (pg.enc != 0) { rc = -2; break; }
+    for (int i = 0; i < pg.nvals && rc == 0; ++i) {
+      uint32_t rep, def;
+      if (hyb_next(&rh, &rep) || hyb_next(&dh, &def) || rep > 1 || (int)def > max_def) { rc = -1; break; }
+      if (rep == 0) {                       /* a new row */
+        out_offsets[rows] = (uint64_t)elems;
+        out_list_valid[rows] = (uint8_t)((int)def >= list_nullable);
+        ++rows;
+      } else if (entries + i == 0) { rc = -1; break; }   /* the first entry of a chunk starts a row */
+      if ((int)def < list_nullable + 1) continue;        /* NULL or empty list: no element */
+      const int64_t o = elems++;
+      const int present = (int)def == max_def;
+      out_elem_valid[o] = (uint8_t)present;
+      if (!present) { if (out_type == T_BOOL) out_values[o] = 0; else memset(out_values + o * es, 0, (size_t)es); continue; }
+      if (use_hyb == 1) {
+        uint32_t idx;
+        if (hyb_next(&vh, &idx) || (int64_t)idx >= dict_n) { rc = -1; break; }
+        memcpy(out_values + o * es, dict + (int64_t)idx * es, (size_t)es);
+      } else if (use_hyb == 2) {
+        uint32_t v;
+        if (hyb_next(&vh, &v)) { rc = -1; break; }
+        out_values[o] = (uint8_t)v;
+      } else if (use_hyb == 3) {
+        uint64_t v;
+        uint8_t le[8];
+        if (delta_next(&dl, &v)) { rc = -1; break; }
+        if (physical == PT_INT32) v = (uint64_t)(uint32_t)v;
+        memcpy(le, &v, 8);
+        put_plain(physical, type_length, out_type, le, out_values, o);
+      } else if (physical == PT_BOOLEAN) {
+        if (q + (boolbit >> 3) >= pend) { rc = -1; break; }
+        out_values[o] = (uint8_t)((q[boolbit >> 3] >> (boolbit & 7)) & 1);
+        ++boolbit;
+      } else if (physical == PT_BYTE_ARRAY) {
+        uint32_t l;
+        if (pend - q < 4) { rc = -1; break; }
+        memcpy(&l, q, 4);
+        if ((uint64_t)(pend - q - 4) < l) { rc = -1; break; }
+        put_view(chunk, (uint64_t)(q + 4 - chunk), out_values, o);
+        q += 4 + l;
+      } else {
+        if (pend - q < pw) { rc = -1; break; }
+        put_plain(physical, type_length, out_type, q, out_values, o);
+        q += pw;
+      }
+    }
+    entries += pg.nvals;
+  }
+  free(dict);
+  out_offsets[rows] = (uint64_t)elems;
+  *out_rows = rows;
+  *out_elems = elems;
+  return rc;
+}
+
 /* Concatenated page payloads (levels + values of every page, dictionary page first) of an UNCOMPRESSED column chunk — the
  * byte stream a compressed twin of the same chunk must decompress to (the product's "image"). Returns the number of bytes
  * written, -1 on a malformed chunk, -2 if a page is compressed. */

@@ -3,6 +3,7 @@ thrift page headers only; Snappy / LZ4 page decompression, the run headers of th
 chain and DELTA_BINARY_PACKED blocks are walked on the GPU. Same fixtures as the host-planned mode (tests/test_gpu_parquet.py): pyarrow's
 reader, the CPU oracle, the committed golden chunks and the Parquet files the reference keeps under tests/data with the values its own
 sqllogictests print for them."""
+import ctypes as C
 import io
 import json
 import os
@@ -461,3 +462,44 @@ def test_list_chunks_malformed_or_deeper_nesting(gpu):
         except T.DbhipError as e:
             assert e.code in (T.ERR_INVALID, T.ERR_UNSUPPORTED)
         pc.close()
+
+
+@pytest.mark.parametrize("name", LIST_NAMES)
+def test_list_columns_equal_the_oracle(gpu, oracle, name):
+    """the device's List decode against oracle/parquet_oracle.c::orc_pq_decode_list (itself pinned on pyarrow in the CPU suite): offsets,
+    list validity, element validity and the element bytes, bit for bit (uncompressed v1 chunk of several pages, PLAIN values)"""
+    import pyarrow as pa
+    n = 30_000
+    rng = np.random.default_rng(len(name))
+    arr, ln, en, ot = _list_cases(rng, n)[name]
+    table = pa.Table.from_arrays([arr], schema=pa.schema([pa.field("c", arr.type, nullable=bool(ln))]))
+    ch = PU.column_chunks(PU.write_parquet(table, dictionary=False, v2=False, page_size=4096))[0][0]
+    ent = ch["num_values"]
+    chunk = np.frombuffer(ch["chunk"], dtype=np.uint8)
+    es = 1 if ot == T.T_BOOL else PU.ESIZE[ot]
+    offs = np.zeros(ent + 2, np.uint64)
+    lval = np.zeros(ent + 1, np.uint8)
+    vals = np.zeros(max(ent, 1) * es + 16, np.uint8)
+    ev = np.zeros(ent + 1, np.uint8)
+    rows, elems = C.c_int64(), C.c_int64()
+    oracle.orc_pq_decode_list.restype = C.c_int
+    rc = oracle.orc_pq_decode_list(chunk.ctypes.data_as(C.c_void_p), C.c_int64(len(chunk)), ch["physical"], ch["type_length"], ln, en, ot, C.c_int64(ent),
+                                   offs.ctypes.data_as(C.c_void_p), lval.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p),
+                                   C.byref(rows), C.byref(elems))
+    assert rc == 0 and rows.value == n
+    pc = gpu.ParquetChunk(ch["chunk"], ch["physical"], ot, ch["type_length"], codec=ch["codec"], list_of=(ln, en))
+    goffs, glv, col = pc.decode_list()
+    m = elems.value
+    assert pc.rows == n and pc.elems == m and np.array_equal(goffs, offs[: n + 1])
+    if ln:
+        assert np.array_equal(glv, lval[:n].astype(bool))
+    if en:
+        assert np.array_equal(col.validity_numpy(), ev[:m].astype(bool))
+    if ot == T.T_BOOL:
+        assert np.array_equal(col.to_numpy(), vals[:m].astype(bool))
+    elif ot == T.T_STRING:      # (views point into different copies of the chunk: compare the strings)
+        ovalid = ev[:m].astype(bool)
+        assert [s if ok else None for s, ok in zip(col.to_strings(), ovalid)] == PU.decoded_to_python(vals.tobytes(), ovalid, ot, m, chunk)
+    else:
+        assert col.data.to_numpy(np.uint8, m * es).tobytes() == vals[: m * es].tobytes()
+    pc.close()

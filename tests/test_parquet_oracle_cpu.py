@@ -3,6 +3,8 @@ against the committed fixtures of tests/golden/parquet/ (made by tests/golden/ma
 import json
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -423,3 +425,64 @@ def test_device_mode_open_survives_mutated_chunks():
             T.lib().dbhip_pq_chunk_close(h)
         seen.add(rc)
     assert T.OK in seen and T.ERR_INVALID in seen
+
+
+# ---- List<primitive> (round 5): the oracle's record assembly against pyarrow's reading of the same file -------------------------------
+def _list_arrays(rng, n):
+    import pyarrow as pa
+    lens = rng.integers(0, 6, n)
+    lens[rng.random(n) < 0.1] = 0
+    null_list = rng.random(n) < 0.08
+
+    def lists(make, elem_null, list_null=True):
+        return [None if (list_null and null_list[i]) else [None if (elem_null and rng.random() < 0.2) else make() for _ in range(lens[i])] for i in range(n)]
+    return {
+        "list<int64> both nullable": (pa.array(lists(lambda: int(rng.integers(-10**12, 10**12)), True), pa.list_(pa.int64())), 1, 1, T.T_I64),
+        "list<int32 not null> nullable": (pa.array(lists(lambda: int(rng.integers(0, 50)), False), pa.list_(pa.field("item", pa.int32(), nullable=False))), 1, 0, T.T_I32),
+        "required list<double>": (pa.array(lists(lambda: float(rng.integers(-1000, 1000)) / 8, True, False), pa.list_(pa.float64())), 0, 1, T.T_F64),
+        "required list<int64 not null>": (pa.array(lists(lambda: int(rng.integers(0, 2**31)), False, False), pa.list_(pa.field("item", pa.int64(), nullable=False))), 0, 0, T.T_I64),
+        "list<binary> both nullable": (pa.array(lists(lambda: (b"s%d" % rng.integers(0, 10**6)) * int(rng.integers(1, 4)), True), pa.list_(pa.binary())), 1, 1, T.T_STRING),
+        "list<bool> both nullable": (pa.array(lists(lambda: bool(rng.integers(0, 2)), True), pa.list_(pa.bool_())), 1, 1, T.T_BOOL),
+    }
+
+
+@pytest.mark.parametrize("v2,dictionary", [(False, False), (True, True), (True, False)])
+@pytest.mark.parametrize("n", [1, 300, 20_000])
+def test_oracle_list_decode_equals_pyarrow(n, v2, dictionary):
+    """orc_pq_decode_list (repetition / definition levels -> offsets, list validity, elements, element validity) == pyarrow's reading of
+    the same file, for every nullability combination of the three-level LIST, v1 / v2 pages, PLAIN and dictionary values, several pages"""
+    import io
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from tests import oracle_lib
+    orc = oracle_lib.load()
+    orc.orc_pq_decode_list.restype = C.c_int
+    rng = np.random.default_rng(n + 7 * v2 + dictionary)
+    for name, (arr, ln, en, ot) in _list_arrays(rng, n).items():
+        table = pa.Table.from_arrays([arr], schema=pa.schema([pa.field("c", arr.type, nullable=bool(ln))]))
+        data = PU.write_parquet(table, dictionary=dictionary, v2=v2, page_size=4096)
+        ch = PU.column_chunks(data)[0][0]
+        assert ch["max_rep"] == 1 and ch["max_def"] == ln + 1 + en
+        back = pq.read_table(io.BytesIO(data)).column(0).to_pylist()
+        ent = ch["num_values"]
+        chunk = np.frombuffer(ch["chunk"], dtype=np.uint8)
+        es = 1 if ot == T.T_BOOL else PU.ESIZE[ot]
+        offs = np.zeros(ent + 2, np.uint64)
+        lval = np.zeros(ent + 1, np.uint8)
+        vals = np.zeros(max(ent, 1) * es + 16, np.uint8)
+        ev = np.zeros(ent + 1, np.uint8)
+        rows, elems = C.c_int64(), C.c_int64()
+        rc = orc.orc_pq_decode_list(chunk.ctypes.data_as(C.c_void_p), C.c_int64(len(chunk)), ch["physical"], ch["type_length"], ln, en, ot, C.c_int64(ent),
+                                    offs.ctypes.data_as(C.c_void_p), lval.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), ev.ctypes.data_as(C.c_void_p),
+                                    C.byref(rows), C.byref(elems))
+        assert rc == 0 and rows.value == n and int(offs[n]) == elems.value, (name, rc)
+        m = elems.value
+        valid = ev[:m].astype(bool)
+        if ot == T.T_BOOL:
+            py = [bool(vals[i]) if valid[i] else None for i in range(m)]
+        elif ot == T.T_F64:
+            py = [float(np.frombuffer(vals[8 * i:8 * i + 8].tobytes(), np.float64)[0]) if valid[i] else None for i in range(m)]
+        else:
+            py = PU.decoded_to_python(vals.tobytes(), valid, ot, m, chunk)
+        got = [None if (ln and not lval[r]) else py[int(offs[r]):int(offs[r + 1])] for r in range(n)]
+        assert got == back, name
