@@ -288,6 +288,7 @@ def test_a_rank_that_gives_up_wakes_the_others(gpu):
     """(a) dbhip_comm_abort while the other rank waits in an all-gather; (b) an exchange that fails on ONE rank (its String column claims
     data buffers it does not have) while the other rank is already in the rendezvous of the counts: nobody hangs, the waiting rank gets
     DBHIP_ERR_INVALID with the failing rank's message, and the group stays failed for later collectives."""
+    import threading
     import time
     D = gpu
     for case in ("abort", "failed exchange"):
@@ -295,9 +296,11 @@ def test_a_rank_that_gives_up_wakes_the_others(gpu):
         n = 1000
         vals = np.arange(n, dtype=np.int64)
         dest = (np.arange(n) % 2).astype(np.uint32)
+        both_joined = threading.Barrier(2)          # (the group must hold both ranks before one of them leaves it again)
 
-        def rank_fn(r):
+        def rank_fn(r, both_joined=both_joined):
             comm = D.Comm.loopback(gid, r, 2)
+            both_joined.wait(60)
             try:
                 if case == "abort":
                     if r == 1:
