@@ -486,3 +486,73 @@ def test_oracle_list_decode_equals_pyarrow(n, v2, dictionary):
             py = PU.decoded_to_python(vals.tobytes(), valid, ot, m, chunk)
         got = [None if (ln and not lval[r]) else py[int(offs[r]):int(offs[r + 1])] for r in range(n)]
         assert got == back, name
+
+
+def _open_list(ch, ln, en, ot):
+    data = ch["chunk"]
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    h, info = C.c_void_p(), T.PqInfo()
+    rc = T.lib().dbhip_pq_chunk_open_device_list(buf, C.c_int64(len(data)), C.c_int32(ch["codec"]), C.c_int32(ch["physical"]), C.c_int32(ch["type_length"]),
+                                                 C.c_int32(ln), C.c_int32(en), C.c_int32(ot), C.byref(h), C.byref(info))
+    if rc == 0:
+        T.lib().dbhip_pq_chunk_close(h)
+    return rc, info
+
+
+@pytest.mark.parametrize("cname", ["none", "snappy", "lz4", "zstd"])
+def test_device_mode_list_open_reads_only_the_page_headers(cname):
+    """dbhip_pq_chunk_open_device_list needs no device either: it walks the thrift page headers of a List<primitive> leaf. num_values is
+    the number of LEVEL ENTRIES of the leaf (what pyarrow's column-chunk metadata calls num_values), several pages, an image only for
+    compressed chunks; the flat open refuses the same chunk (max_rep 1) and names the List entry point; a truncated chunk is INVALID."""
+    import pyarrow as pa
+    rng = np.random.default_rng(11)
+    n = 6000
+    for name, (arr, ln, en, ot) in _list_arrays(rng, n).items():
+        table = pa.Table.from_arrays([arr], schema=pa.schema([pa.field("c", arr.type, nullable=bool(ln))]))
+        for v2 in (False, True):
+            ch = PU.column_chunks(PU.write_parquet(table, dictionary=(ot != T.T_BOOL), v2=v2, page_size=4096, compression=cname))[0][0]
+            rc, info = _open_list(ch, ln, en, ot)
+            assert rc == 0, (name, v2, T.lib().dbhip_last_error())
+            assert info.num_values == ch["num_values"] and info.n_pages >= (1 if ot == T.T_BOOL else 2), (name, info.num_values, ch["num_values"], info.n_pages)
+            assert (info.image_bytes > 0) == (cname != "none")
+            buf = (C.c_uint8 * len(ch["chunk"])).from_buffer_copy(ch["chunk"])
+            h, finfo = C.c_void_p(), T.PqInfo()
+            rc = T.lib().dbhip_pq_chunk_open_device(buf, C.c_int64(len(ch["chunk"])), ch["codec"], ch["physical"], ch["type_length"], ch["max_def"], ch["max_rep"], ot,
+                                                    C.byref(h), C.byref(finfo))
+            assert rc == T.ERR_UNSUPPORTED and b"open_device_list" in T.lib().dbhip_last_error()
+            cut = dict(ch)
+            cut["chunk"] = ch["chunk"][: len(ch["chunk"]) // 2]
+            assert _open_list(cut, ln, en, ot)[0] == T.ERR_INVALID
+
+
+def test_device_mode_list_open_survives_mutated_chunks():
+    """the List open under bit flips / truncation / overwritten bytes: OK, INVALID or UNSUPPORTED, an image in proportion to the chunk"""
+    import pyarrow as pa
+    rng = np.random.default_rng(12)
+    seeds = []
+    for cname in ("none", "snappy", "zstd"):
+        for name, (arr, ln, en, ot) in _list_arrays(rng, 1200).items():
+            table = pa.Table.from_arrays([arr], schema=pa.schema([pa.field("c", arr.type, nullable=bool(ln))]))
+            ch = PU.column_chunks(PU.write_parquet(table, dictionary=False, v2=(cname == "snappy"), page_size=2048, compression=cname))[0][0]
+            seeds.append((ch, ln, en, ot))
+    seen = set()
+    for it in range(3000):
+        ch, ln, en, ot = seeds[it % len(seeds)]
+        b = bytearray(ch["chunk"])
+        k = it % 3
+        if k == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            b = b[: int(rng.integers(0, len(b)))]
+        else:
+            i = int(rng.integers(0, len(b)))
+            b[i:i + 6] = bytes(rng.integers(0, 256, 6).astype(np.uint8))
+        m = dict(ch)
+        m["chunk"] = bytes(b)
+        rc, info = _open_list(m, ln, en, ot)
+        assert rc in (T.OK, T.ERR_INVALID, T.ERR_UNSUPPORTED), rc
+        if rc == T.OK:
+            assert 0 <= info.image_bytes <= max(1 << 30, 1024 * len(b)) + 16 and info.num_values >= 0
+        seen.add(rc)
+    assert T.OK in seen and T.ERR_INVALID in seen
