@@ -553,3 +553,33 @@ def test_multi_key_scatter_hash_is_pinned_to_the_golden_siphash():
     sc = O.HostCol(T.T_STRING, views, None, buffers=[buf]).c()
     assert L.orc_siphash64(C.byref(sc), C.c_int64(1), out.ctypes.data_as(C.c_void_p)) == 0
     assert int(out[0]) == hand
+
+
+def test_arithmetic_decimal_txt_the_q1_shaped_expression_and_the_folded_constant():
+    """arithmetic_decimal.txt (tests/golden/make_golden_arith_decimal.py): `l_extendedprice + (1 - l_discount) - l_quantity` over
+    Decimal(15, 2) columns — the expression shape of TPC-H Q1's maps, with an integer operand — and the constant
+    `1964831797.0000 - 0.0214642400000` (Decimal(14, 4) - Decimal(13, 13) -> Decimal(24, 13): the operands are rescaled by 10^9 and 1
+    into a 128-bit result). The oracle evaluates the checked expression node by node; every node's DecimalSize must be the one the
+    reference's type checker printed in the parent's signature."""
+    from decimal import Decimal
+    data = json.load(open(os.path.join(HERE, "golden", "arithmetic_decimal.json")))
+    be = OracleBackend()
+    seen_sizes = []
+
+    class Recording(OracleBackend):
+        def decimal(self, op, a, b, n):
+            out = OracleBackend.decimal(self, op, a, b, n)
+            seen_sizes.append((out.precision, out.scale))
+            return out
+    rec = Recording()
+    checked, skipped = G.run_cases(data["cases"], rec)
+    assert len(checked) == 1 and not skipped, skipped
+    # post-order: minus<UInt8, Decimal(15,2)> -> (16,2); plus<Decimal(15,2), Decimal(16,2)> -> (17,2); minus<Decimal(17,2), Decimal(15,2)> -> (18,2)
+    assert seen_sizes == [(16, 2), (17, 2), (18, 2)], seen_sizes
+    for f in data["folded"]:
+        node = G.parse_expr(f["expr"])
+        got = G.evaluate(node, {}, be, 1)
+        kind = G.parse_type(f["output_type"])
+        assert kind[0] == "dec" and (got.precision, got.scale) == (kind[1], kind[2]), (f["ast"], got.precision, got.scale)
+        assert got.ints()[:1] == [int(Decimal(f["output"]).scaleb(kind[2]))], (f["ast"], got.ints())
+    assert len(data["folded"]) == 1
