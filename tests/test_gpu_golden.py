@@ -204,3 +204,36 @@ def test_hash_index_cases_through_merge_serialized(gpu):
         g.merge_serialized(np.array([[k, h, (k + 20 if k != 4 else 0)] for k, h in inc], np.uint64))
         assert g.num_groups() - before == 3
         assert dict((r[0], r[1]) for r in g.result()) == {1: 21, 2: 22, 3: 23, 4: 77}
+
+
+def test_arithmetic_decimal_golden_through_the_c_abi(gpu):
+    """arithmetic_decimal.txt: `l_extendedprice + (1 - l_discount) - l_quantity` over Decimal(15, 2) columns through dbhip_decimal_arith,
+    node by node, with the DecimalSize of every node (tests/test_golden_cpu.py runs the same fixture through the oracle)"""
+    import json
+    import os
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arithmetic_decimal.json")))
+    sizes = []
+
+    class Recording(DeviceBackend):
+        def decimal(self, op, a, b, n):
+            out = DeviceBackend.decimal(self, op, a, b, n)
+            sizes.append((out.precision, out.scale))
+            return out
+    checked, skipped = G.run_cases(data["cases"], Recording(gpu))
+    assert len(checked) == 1 and not skipped, skipped
+    assert sizes == [(16, 2), (17, 2), (18, 2)], sizes
+
+
+def test_arithmetic_decimal_folded_constant_through_the_c_abi(gpu):
+    """the constant the reference folds, `1964831797.0000 - 0.0214642400000` (Decimal(14, 4) - Decimal(13, 13) -> Decimal(24, 13)), as a
+    one-row evaluation with two scalar operands"""
+    import json
+    import os
+    from decimal import Decimal
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arithmetic_decimal.json")))
+    be = DeviceBackend(gpu)
+    for f in data["folded"]:
+        got = G.evaluate(G.parse_expr(f["expr"]), {}, be, 1)
+        kind = G.parse_type(f["output_type"])
+        assert (got.precision, got.scale) == (kind[1], kind[2]), (f["ast"], got.precision, got.scale)
+        assert got.ints()[:1] == [int(Decimal(f["output"]).scaleb(kind[2]))], (f["ast"], got.ints())
