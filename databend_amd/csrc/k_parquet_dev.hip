@@ -240,30 +240,52 @@ struct DvChunkD {
 };
 
 // definition levels of `n` entries from dst0 on — packed at width dw (src) or a run of `run` — into the three entry bitmaps; returns this
-// thread's share of the entries that carry a value. *bad: a level above the column's maximum
+// thread's share of the entries that carry a value. *bad: a level above the column's maximum. Called by all `nthr` threads (whole waves).
+// A run of one level fills whole words, one per thread. Packed levels take ONE ENTRY PER LANE: a wave extracts 64 levels at once, three
+// ballots are the 64 bits of the three bitmaps, and lanes 0..2 put the (at most three) 32-bit words they touch — a page's levels are
+// mostly short packed runs between RLE runs, where one thread extracting a word's 32 levels one after the other was the whole cost
+// (12.8 of the 16.1 ms of a 6 M-row List<Int64> chunk, profiles/r05_pq_list_kernel_stats.csv).
 __device__ __forceinline__ uint32_t dv_put_def(const DvChunkD& C, uint64_t dst0, uint32_t n, const uint8_t* __restrict__ src, uint32_t run, uint32_t tid,
                                                uint32_t nthr, bool* bad) {
   if (n == 0) return 0;
   uint32_t ones = 0;
   const uint32_t D = C.lmax, L = C.lnull;
-  const uint64_t first_word = dst0 >> 5, last_word = (dst0 + n - 1) >> 5;
-  for (uint64_t w = first_word + tid; w <= last_word; w += nthr) {
-    const uint64_t lo = w << 5;
-    const uint64_t a = lo > dst0 ? lo : dst0;
-    const uint64_t e = (lo + 32 < dst0 + n) ? lo + 32 : dst0 + n;
-    uint32_t bv = 0, be = 0, bl = 0;
-    for (uint64_t x = a; x < e; ++x) {
-      const uint32_t v = src ? extract_bits(src, (uint32_t)(x - dst0), (int)C.ldw) : run;
-      const uint32_t bit = 1u << (uint32_t)(x - lo);
-      if (v > D) *bad = true;
-      if (v == D) bv |= bit;
-      if (v >= L + 1) be |= bit;
-      if (v >= L) bl |= bit;
+  if (!src) {
+    if (run > D) *bad = true;
+    const bool isv = run == D, ise = run >= L + 1, isl = run >= L && L;
+    const uint64_t first_word = dst0 >> 5, last_word = (dst0 + n - 1) >> 5;
+    for (uint64_t w = first_word + tid; w <= last_word; w += nthr) {
+      const uint64_t lo = w << 5;
+      const uint64_t a = lo > dst0 ? lo : dst0;
+      const uint64_t e = (lo + 32 < dst0 + n) ? lo + 32 : dst0 + n;
+      const int nb = (int)(e - a);
+      const uint32_t bits = (nb == 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)) << (a - lo);
+      if (isv) { atomicOr(&C.bitmap[w], bits); ones += (uint32_t)__popc(bits); }
+      if (ise) atomicOr(&C.iselem[w], bits);
+      if (isl) atomicOr(&C.lvalid[w], bits);
     }
-    if (bv) atomicOr(&C.bitmap[w], bv);
-    if (be) atomicOr(&C.iselem[w], be);
-    if (bl && L) atomicOr(&C.lvalid[w], bl);
-    ones += (uint32_t)__popc(bv);
+    return ones;
+  }
+  const uint32_t lane = tid & 63u;
+  for (uint32_t base = tid & ~63u; base < n; base += nthr) {          // (wave-uniform: this wave's entries base .. base + 63 of the run)
+    const uint32_t x = base + lane;
+    const bool in = x < n;
+    const uint32_t v = in ? extract_bits(src, x, (int)C.ldw) : 0u;
+    if (in && v > D) *bad = true;
+    const uint64_t mv = __ballot(in && v == D), me = __ballot(in && v >= L + 1), ml = L ? __ballot(in && v >= L) : 0ull;
+    if (lane < 3) {
+      const uint64_t p0 = dst0 + base;                                 // entry of mask bit 0
+      const uint32_t sh = (uint32_t)(p0 & 31);
+      const uint64_t w = (p0 >> 5) + lane;
+      // word `lane` of the 96-bit value (mask << sh)
+      const uint32_t bv = lane == 0 ? (uint32_t)(mv << sh) : lane == 1 ? (uint32_t)(mv >> (32 - sh)) : (sh ? (uint32_t)(mv >> (64 - sh)) : 0u);
+      const uint32_t be = lane == 0 ? (uint32_t)(me << sh) : lane == 1 ? (uint32_t)(me >> (32 - sh)) : (sh ? (uint32_t)(me >> (64 - sh)) : 0u);
+      const uint32_t bl = lane == 0 ? (uint32_t)(ml << sh) : lane == 1 ? (uint32_t)(ml >> (32 - sh)) : (sh ? (uint32_t)(ml >> (64 - sh)) : 0u);
+      if (bv) atomicOr(&C.bitmap[w], bv);
+      if (be) atomicOr(&C.iselem[w], be);
+      if (bl) atomicOr(&C.lvalid[w], bl);
+      if (lane == 0) ones += (uint32_t)__popcll(mv);
+    }
   }
   return ones;
 }
@@ -1044,14 +1066,21 @@ __global__ __launch_bounds__(256) void pq_list_finish_kernel(int64_t entries, co
       if (move_values) out_values[erank] = ent_values[e];
       if (out_evalid && (valid[w] & bit)) atomicOr(&out_evalid[erank >> 5], 1u << (uint32_t)(erank & 31));
     }
+    bool null_list = false;
     if (!(rep & bit)) {
       const uint64_t rrank = roff[w] + (uint32_t)__popc(~rep & below);
       out_offsets[rrank] = erank;
       if (lvalid) {
         if (lvalid[w] & bit) { if (out_lvalid) atomicOr(&out_lvalid[rrank >> 5], 1u << (uint32_t)(rrank & 31)); }
-        else atomicAdd(&counts[2], 1ULL);
+        else null_list = true;
       }
     } else if (e == 0) counts[3] = 1;
+    // (the NULL lists of a wave's 64 entries: ONE add on the counter — 480 K single adds on one word were most of this kernel's 3.1 ms)
+    const uint64_t nulls = __ballot(null_list);
+    if (nulls) {
+      const uint64_t act = __ballot(true);
+      if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)act) - 1u) atomicAdd(&counts[2], (unsigned long long)__popcll(nulls));
+    }
     if (e == entries - 1) {
       const uint64_t rows = roff[w] + (uint32_t)__popc(~rep & (below | bit));
       const uint64_t elems = erank + ((el & bit) ? 1 : 0);
