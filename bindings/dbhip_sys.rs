@@ -71,7 +71,7 @@ pub const DBHIP_VEC_L2: i32 = 1;   // dbhip_vec_metric
 pub const DBHIP_VEC_DOT: i32 = 2;   // dbhip_vec_metric
 pub const DBHIP_VEC_L1: i32 = 3;   // dbhip_vec_metric
 pub const DBHIP_VEC_NORM: i32 = 4;   // dbhip_vec_metric
-pub const DBHIP_ABI_VERSION: i32 = 5;
+pub const DBHIP_ABI_VERSION: i32 = 6;
 
 #[repr(C)]
 pub struct dbhip_groupby { _private: [u8; 0] }
@@ -213,6 +213,8 @@ extern "C" {
     pub fn dbhip_groupby_add_block_filtered(g: *mut dbhip_groupby, keys: *const dbhip_col, args: *const dbhip_col, n: i64, filter_bitmap: *const u8, filter_bit_offset: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_groupby_add_block_program(g: *mut dbhip_groupby, keys: *const dbhip_col, prog: *const dbhip_agg_program, n: i64, filter_bitmap: *const u8, filter_bit_offset: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_groupby_prepare_program(g: *mut dbhip_groupby, keys: *const dbhip_col, prog: *const dbhip_agg_program) -> i32;
+    pub fn dbhip_groupby_set_pipelined(g: *mut dbhip_groupby, on: i32, stream: *mut c_void) -> i32;
+    pub fn dbhip_groupby_checkpoint(g: *mut dbhip_groupby, out_blocks_committed_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_groupby_merge_serialized(g: *mut dbhip_groupby, rows_dev: *const c_void, n_rows: i64, stream: *mut c_void) -> i32;
     pub fn dbhip_groupby_arena(g: *mut dbhip_groupby, out_ptr_host: *mut *const c_void, out_bytes_host: *mut i64, stream: *mut c_void) -> i32;
     pub fn dbhip_groupby_merge_serialized_arena(g: *mut dbhip_groupby, rows_dev: *const c_void, n_rows: i64, arena_dev: *const c_void, stream: *mut c_void) -> i32;

@@ -83,7 +83,7 @@ SYMBOLS = [
     "dbhip_groupby_num_groups", "dbhip_groupby_row_bytes", "dbhip_groupby_flush_serialized", "dbhip_groupby_flush_block",
     "dbhip_groupby_merge_blocks", "dbhip_groupby_add_block_filtered", "dbhip_groupby_partition_blocks",
     "dbhip_groupby_replace_with_blocks", "dbhip_groupby_flush_partitioned", "dbhip_groupby_flush_result_nullable",
-    "dbhip_groupby_state_fields", "dbhip_groupby_flush_state_block", "dbhip_groupby_add_block_program", "dbhip_groupby_prepare_program", "dbhip_groupby_arena", "dbhip_groupby_merge_serialized_arena", "dbhip_sel_from_ranges", "dbhip_sel_from_repeats", "dbhip_take_chunks", "dbhip_take_outer", "dbhip_cast", "dbhip_memcpy_d2d",
+    "dbhip_groupby_state_fields", "dbhip_groupby_flush_state_block", "dbhip_groupby_add_block_program", "dbhip_groupby_prepare_program", "dbhip_groupby_set_pipelined", "dbhip_groupby_checkpoint", "dbhip_groupby_arena", "dbhip_groupby_merge_serialized_arena", "dbhip_sel_from_ranges", "dbhip_sel_from_repeats", "dbhip_take_chunks", "dbhip_take_outer", "dbhip_cast", "dbhip_memcpy_d2d",
     "dbhip_groupby_result_type", "dbhip_groupby_flush_result", "dbhip_groupby_reset",
     "dbhip_groupby_destroy", "dbhip_q1_create_groupby", "dbhip_q1_fused", "dbhip_keys_method", "dbhip_pack_keys", "dbhip_serialize_keys_offsets", "dbhip_serialize_keys", "dbhip_join_create_binary",
     "dbhip_join_add_build_binary", "dbhip_join_finalize_binary", "dbhip_join_probe_count_binary", "dbhip_join_probe_binary", "dbhip_join_destroy_binary",

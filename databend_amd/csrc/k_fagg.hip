@@ -31,6 +31,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -48,6 +49,12 @@ int64_t dbhip_groupby_capacity_internal(dbhip_groupby* g);
 int32_t dbhip_groupby_reserve_merge_internal(dbhip_groupby* g, int64_t n);
 int64_t dbhip_groupby_count_internal(dbhip_groupby* g);
 const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g);
+int32_t dbhip_groupby_merge_rows_deferred_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n_max, const uint64_t* n_dev,
+                                                   const uint64_t* abort_dev, hipStream_t s);
+int32_t dbhip_groupby_ensure_room_internal(dbhip_groupby* g, int64_t extra, hipStream_t s);
+uint64_t* dbhip_groupby_ctrl_internal(dbhip_groupby* g);
+void dbhip_groupby_set_count_internal(dbhip_groupby* g, int64_t count);
+void** dbhip_groupby_pipe_slot_internal(dbhip_groupby* g);
 
 namespace {
 
@@ -137,7 +144,7 @@ std::string jit_meta(const FaArgs& A) {
   o.num(A.nkeys); o.num(A.nkey_words); o.num(A.validity_word); o.num(A.hash_word); o.num(A.W);
   o.num(A.naggs); o.num(A.nwords); o.num(A.state_off);
   o.open(); for (int w = 0; w < FA_MAXW; ++w) o.num(A.wm[w]); o.close();
-  o.null(); o.num(0); o.num(0); o.num(0); o.null(); o.null();
+  o.null(); o.num(0); o.num(0); o.null(); o.null();
   o.s += "};\n";
   return o.s;
 }
@@ -417,7 +424,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   for (int i = 0; i < EX_MAX_INPUTS; ++i) { K.P.in_data[i] = nullptr; K.P.in_valid[i] = nullptr; K.P.in_voff[i] = 0; }
   K.P.err_words = nullptr; K.P.err_count = nullptr;
   for (int k = 0; k < FA_KW; ++k) { K.key[k].data = nullptr; K.key[k].validity = nullptr; K.key[k].voff = 0; K.key[k].buffers = nullptr; }
-  K.filter_bits = nullptr; K.filter_off = 0; K.n = 0; K.debug = 0; K.partial_rows = nullptr; K.ctrl = nullptr;
+  K.filter_bits = nullptr; K.filter_off = 0; K.n = 0; K.partial_rows = nullptr; K.ctrl = nullptr;
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::string key((const char*)&K, sizeof(K));
@@ -613,6 +620,258 @@ static int32_t fa_build_args(const GbLayout& L, const dbhip_col* keys, const dbh
 }
 
 
+// One launch of the fused kernel over a block: the specialised kernel of (shape, SLOTS) when the in-process / on-disk cache has it —
+// an un-PREPAREd program is interpreted now and compiled in the background for the calls to come — else the interpreting kernel.
+// DBHIP_ERR_UNSUPPORTED (t_jit_only, plain add_block's use of this kernel: only the specialised form beats the LDS path).
+static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, int grid, size_t lds, hipStream_t s) {
+  bool jit_pending = false;
+  hipFunction_t jf = jit_kernel(A, slots, general, nwords, (t_jit_only && !t_jit_may_compile) ? JIT_LOOKUP : JIT_BACKGROUND, &jit_pending);
+  if (!jf && t_jit_only) {
+    t_jit_pending = jit_pending;
+    if (jit_pending) ++g_fa_pending_refusals;
+    set_error("dbhip_fagg: the specialised kernel of this shape is %s", jit_pending ? "being compiled in the background" : "not available");
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (jf) {
+    size_t asz = sizeof(A);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)&A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    // (LDS: only the staging of one group's accumulators at the end — the register file is in VGPRs)
+    DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nwords * 256 * 8), s, nullptr, extra));
+    ++g_fa_jit_launches;
+    return DBHIP_OK;
+  }
+  ++g_fa_interp_launches;
+#define FA_LAUNCH(SL, GEN)                                                                                     \
+  do {                                                                                                         \
+    if (nwords <= 4) hipLaunchKernelGGL((fagg_kernel<SL, GEN, 4>), dim3(grid), dim3(256), lds, s, A);           \
+    else hipLaunchKernelGGL((fagg_kernel<SL, GEN, FA_MAXW>), dim3(grid), dim3(256), lds, s, A);                 \
+  } while (0)
+  // (interpreted) a program with a rounding decimal multiply / divide: the instantiations that carry the long divisions
+  bool has_div = false;
+  for (int i = 0; i < A.P.n_ins; ++i) has_div |= A.P.ins[i].op == EX_DEC && dec_op_needs_division(A.P.dec[A.P.ins[i].dec_idx]);
+  if (has_div && slots == 4) hipLaunchKernelGGL((fagg_kernel<4, true, FA_MAXW, true>), dim3(grid), dim3(256), lds, s, A);
+  else if (has_div) hipLaunchKernelGGL((fagg_kernel<8, true, FA_MAXW, true>), dim3(grid), dim3(256), lds, s, A);
+  else if (slots == 4 && !general) FA_LAUNCH(4, false);
+  else if (slots == 4) FA_LAUNCH(4, true);
+  else if (!general) FA_LAUNCH(8, false);
+  else FA_LAUNCH(8, true);
+#undef FA_LAUNCH
+  return DBHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PIPELINED mode (dbhip_groupby_set_pipelined / dbhip_groupby_checkpoint; round 6).
+// The reference's pipeline hands TransformPartialAggregate one DataBlock of <= 65,536 rows at a time (max_block_size,
+// settings_default.rs:142-148; transform_aggregate_partial.rs:262-270). At that size the fused kernel is a few microseconds of
+// work, and a call that reads the kernel's control block back and waits for the merge is all round trip. In pipelined mode a block
+// costs ONE kernel launch and no synchronisation:
+//   * the partial rows of successive blocks are APPENDED to a buffer the table owns (cursor, give-up flags and the row-error count
+//     live on the device and are sticky);
+//   * when the buffer could overflow (the host keeps an upper bound: workgroups x 4 waves x 8 slots per block) the merge of the
+//     whole window is queued behind the kernels — seal (row errors -> flag), probe / accumulate / retry with the row count and the
+//     abort flags still on the device, commit (cursor back to 0, the window's blocks counted as committed unless a flag is up);
+//     the commit kernel writes the table's group count into mapped host memory, from which the host bounds the table's fill without
+//     waiting (it synchronises only when that bound says the table might have to grow);
+//   * dbhip_groupby_checkpoint drains the stream and reports: DBHIP_OK (every block merged), or the error a synchronous call would
+//     have returned plus the number of blocks that WERE merged — windows commit in order and a window with a raised flag, and every
+//     window behind it, merges nothing, so the blocks from that index on can be handed to the operator-at-a-time path exactly like a
+//     block that the synchronous call gave back. A "more than 4 groups in one workgroup" give-up of the 4-slot kernel is replayed
+//     here with the 8-slot kernel first (the library keeps the launch arguments of unconfirmed blocks).
+// The caller keeps the blocks' buffers alive until the checkpoint (they are inputs of queued kernels), which is also what makes the
+// replay possible. One stream per pipelined table (the reference's partial tables are per pipeline thread as well).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int FA_PIPE_WINDOW = 32;
+struct FaPending { FaArgs A; int grid; size_t lds; bool general; int nwords; };
+struct FaMerge { uint64_t seq; int64_t rows_ub; int64_t blocks; };
+struct FaPipe {
+  bool on = false, bound = false, slots8 = false;
+  hipStream_t stream = nullptr;
+  uint64_t* rows = nullptr;          // device [cap_rows][W]
+  int64_t cap_rows = 0;
+  uint64_t* ctrl = nullptr;          // device, 64 B: [0] rows appended since the last merge [1] flags (sticky) [2] row errors (sticky) [3] blocks committed since the last checkpoint
+  uint64_t* status_host = nullptr;   // mapped pinned host memory: [0] seq of the last merge that finished, [1] groups in the table then (bit 63: a flag was up)
+  uint64_t* status_dev = nullptr;
+  int64_t rows_ub = 0, window_blocks = 0;   // of the window that is being filled
+  uint64_t seq = 0;
+  std::deque<FaMerge> merges;        // queued, not yet seen finished
+  int64_t count_seen = 0;            // groups after the last merge seen finished
+  std::deque<FaPending> retained;    // launch arguments of the blocks [retained_base, submitted) since the last checkpoint
+  int64_t retained_base = 0, submitted = 0;
+};
+
+__global__ void fa_pipe_seal_kernel(uint64_t* ctrl) {
+  if (ctrl[2]) ctrl[1] |= 4;
+}
+__global__ void fa_pipe_commit_kernel(uint64_t* ctrl, const uint64_t* gctrl, uint64_t* status, uint64_t seq, uint64_t blocks) {
+  if (gctrl[1]) ctrl[1] |= 8;   // the merge ran out of table (cannot happen: the host reserved room for every row of the window)
+  const bool dirty = (ctrl[1] & 15) != 0;
+  if (!dirty) ctrl[3] += blocks;
+  ctrl[0] = 0;                  // rows of a window that did not commit are dropped with it
+  __hip_atomic_store(&status[1], gctrl[0] | (dirty ? (1ULL << 63) : 0ULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&status[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// what the mapped status words say right now: merges that finished leave the queue; the launch arguments of blocks that are known
+// to be merged are dropped
+void fa_pipe_poll(FaPipe* pp) {
+  uint64_t seq0, cnt, seq1;
+  do {
+    seq0 = __atomic_load_n(&pp->status_host[0], __ATOMIC_ACQUIRE);
+    cnt = __atomic_load_n(&pp->status_host[1], __ATOMIC_ACQUIRE);
+    seq1 = __atomic_load_n(&pp->status_host[0], __ATOMIC_ACQUIRE);
+  } while (seq0 != seq1);
+  const bool dirty = (cnt >> 63) != 0;
+  while (!pp->merges.empty() && pp->merges.front().seq <= seq0) {
+    if (!dirty) {
+      int64_t drop = pp->merges.front().blocks;
+      while (drop-- > 0 && !pp->retained.empty()) { pp->retained.pop_front(); ++pp->retained_base; }
+    }
+    pp->merges.pop_front();
+    pp->count_seen = (int64_t)(cnt & ~(1ULL << 63));
+  }
+}
+
+int32_t fa_pipe_queue_merge(dbhip_groupby* g, FaPipe* pp) {
+  if (pp->window_blocks == 0) return DBHIP_OK;
+  hipStream_t s = pp->stream;
+  fa_pipe_poll(pp);
+  int64_t ub = pp->count_seen + pp->rows_ub;
+  for (const FaMerge& m : pp->merges) ub += m.rows_ub;
+  if (ub * 135 > dbhip_groupby_capacity_internal(g) * 100) {
+    // the bound says the table might fill: look (drains the stream) and grow if it really has to
+    const int32_t rc = dbhip_groupby_ensure_room_internal(g, pp->rows_ub, s);
+    if (rc) return rc;
+    fa_pipe_poll(pp);
+    pp->merges.clear();
+    pp->count_seen = dbhip_groupby_count_internal(g);
+  }
+  hipLaunchKernelGGL(fa_pipe_seal_kernel, dim3(1), dim3(1), 0, s, pp->ctrl);
+  int32_t rc = dbhip_groupby_merge_rows_deferred_internal(g, pp->rows, pp->rows_ub, &pp->ctrl[0], &pp->ctrl[1], s);
+  if (rc) return rc;
+  ++pp->seq;
+  hipLaunchKernelGGL(fa_pipe_commit_kernel, dim3(1), dim3(1), 0, s, pp->ctrl, dbhip_groupby_ctrl_internal(g), pp->status_dev, pp->seq,
+                     (uint64_t)pp->window_blocks);
+  DBHIP_LAUNCH_CHECK();
+  pp->merges.push_back({pp->seq, pp->rows_ub, pp->window_blocks});
+  pp->rows_ub = 0;
+  pp->window_blocks = 0;
+  return DBHIP_OK;
+}
+
+int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s) {
+  if (pp->bound && pp->stream != s) {
+    set_error("dbhip_groupby_add_block_program: a pipelined table takes its blocks on ONE stream (checkpoint before changing it)");
+    return DBHIP_ERR_INVALID;
+  }
+  pp->bound = true; pp->stream = s;
+  const int64_t n_max = (int64_t)P.grid * 4 * FA_MAX_SLOTS;
+  if (n_max > pp->cap_rows) { set_error("dbhip_groupby_add_block_program: grid too large for the pipeline's row buffer"); return DBHIP_ERR_INVALID; }
+  // a window closes when the row buffer could overflow, and after FA_PIPE_WINDOW blocks at the latest: that bounds what one raised
+  // flag gives back to the caller (and the launch arguments kept for a replay) while one merge still serves dozens of launches
+  if (pp->rows_ub + n_max > pp->cap_rows || pp->window_blocks >= FA_PIPE_WINDOW) {
+    const int32_t rc = fa_pipe_queue_merge(g, pp);
+    if (rc) return rc;
+  }
+  P.A.ctrl = pp->ctrl;
+  P.A.partial_rows = pp->rows;
+  P.A.P.err_words = nullptr;
+  P.A.P.err_count = (unsigned long long*)&pp->ctrl[2];
+  const int32_t rc = fa_launch(P.A, (pp->slots8 || pp->count_seen > 4) ? 8 : 4, P.general, P.nwords, P.grid, P.lds, s);
+  if (rc) return rc;
+  DBHIP_LAUNCH_CHECK();
+  pp->rows_ub += n_max;
+  ++pp->window_blocks;
+  ++pp->submitted;
+  pp->retained.push_back(P);
+  return DBHIP_OK;
+}
+
+void fa_pipe_forget(FaPipe* pp) {
+  pp->retained.clear(); pp->retained_base = 0; pp->submitted = 0; pp->merges.clear(); pp->rows_ub = 0; pp->window_blocks = 0;
+}
+
+int32_t fa_pipe_checkpoint(dbhip_groupby* g, FaPipe* pp, int64_t* out_committed, bool may_replay) {
+  if (out_committed) *out_committed = 0;
+  if (!pp->bound || (pp->submitted == 0 && pp->window_blocks == 0)) return DBHIP_OK;
+  hipStream_t s = pp->stream;
+  int32_t rc = fa_pipe_queue_merge(g, pp);
+  if (rc) return rc;
+  uint64_t* h = pinned_words(2);
+  if (!h) return DBHIP_ERR_HIP;
+  DBHIP_CHECK(hipMemcpyAsync(h, pp->ctrl, 32, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipMemcpyAsync(h + 4, dbhip_groupby_ctrl_internal(g), 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  const uint64_t flags = h[1], errs = h[2];
+  const int64_t committed = (int64_t)h[3];
+  dbhip_groupby_set_count_internal(g, (int64_t)h[4]);
+  pp->merges.clear();
+  pp->count_seen = (int64_t)h[4];
+  if (!(flags & 15)) {
+    fa_pipe_forget(pp);
+    DBHIP_CHECK(hipMemsetAsync(pp->ctrl, 0, 64, s));
+    if (out_committed) *out_committed = committed;
+    return DBHIP_OK;
+  }
+  if ((flags & 15) == 1 && !pp->slots8 && may_replay) {
+    // the 4-slot kernel met a fifth group inside one workgroup: the blocks that did not commit go through the 8-slot kernel,
+    // as the synchronous call's second pass does
+    pp->slots8 = true;
+    std::deque<FaPending> again;
+    const int64_t skip = committed - pp->retained_base;
+    for (int64_t i = skip < 0 ? 0 : skip; i < (int64_t)pp->retained.size(); ++i) again.push_back(pp->retained[(size_t)i]);
+    DBHIP_CHECK(hipMemsetAsync(pp->ctrl, 0, 24, s));   // cursor, flags, errors; [3] (committed blocks) stays
+    pp->retained.clear(); pp->retained_base = committed; pp->submitted = committed; pp->rows_ub = 0; pp->window_blocks = 0;
+    for (FaPending& P : again)
+      if ((rc = fa_pipe_submit(g, pp, P, s))) return rc;
+    return fa_pipe_checkpoint(g, pp, out_committed, false);
+  }
+  const int64_t submitted = pp->submitted;
+  fa_pipe_forget(pp);
+  DBHIP_CHECK(hipMemsetAsync(pp->ctrl, 0, 64, s));
+  if (out_committed) *out_committed = committed;
+  if (flags & 2) {
+    set_error("dbhip_groupby_checkpoint: a group key string is longer than 12 bytes; pipelined blocks [%lld, %lld) were not merged",
+              (long long)committed, (long long)submitted);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (flags & 4) {
+    set_error("dbhip_groupby_checkpoint: %llu row error(s) in the fused maps (Decimal overflow / divided by zero); pipelined blocks [%lld, %lld) were "
+              "not merged: evaluate their maps with dbhip_expr_eval to get the rows", (unsigned long long)errs, (long long)committed, (long long)submitted);
+    return DBHIP_ERR_ROW_ERRORS;
+  }
+  set_error("dbhip_groupby_checkpoint: more than %d distinct groups inside one workgroup%s; pipelined blocks [%lld, %lld) were not merged: use the "
+            "operator-at-a-time path for them", FA_MAX_SLOTS, (flags & 8) ? " (and the table filled during a merge)" : "", (long long)committed,
+            (long long)submitted);
+  return DBHIP_ERR_CAPACITY;
+}
+}  // namespace
+
+// every other entry point that reads or changes a pipelined table's groups passes through here first (GB_DRAIN, k_groupby.hip)
+int32_t dbhip_fagg_pipe_drain_internal(dbhip_groupby* g, void* pipe, hipStream_t) {
+  FaPipe* pp = (FaPipe*)pipe;
+  if (!pp->bound || (pp->submitted == 0 && pp->window_blocks == 0)) return DBHIP_OK;
+  int64_t committed = 0;
+  return fa_pipe_checkpoint(g, pp, &committed, true);
+}
+int32_t dbhip_fagg_pipe_reset_internal(void* pipe, hipStream_t s) {
+  FaPipe* pp = (FaPipe*)pipe;
+  if (pp->bound) DBHIP_CHECK(hipStreamSynchronize(pp->stream));
+  fa_pipe_forget(pp);
+  pp->count_seen = 0; pp->slots8 = false; pp->bound = false;
+  DBHIP_CHECK(hipMemsetAsync(pp->ctrl, 0, 64, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  return DBHIP_OK;
+}
+void dbhip_fagg_pipe_destroy_internal(void* pipe) {
+  FaPipe* pp = (FaPipe*)pipe;
+  if (!pp) return;
+  if (pp->rows) (void)dbhip_free(pp->rows);
+  if (pp->ctrl) (void)hipFree(pp->ctrl);
+  if (pp->status_host) (void)hipHostFree(pp->status_host);
+  delete pp;
+}
+
 
 extern "C" {
 
@@ -633,7 +892,6 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   if (rc) return rc;
   A.filter_bits = filter_bitmap; A.filter_off = filter_bit_offset; A.n = n;
   A.has_filter = filter_bitmap != nullptr;
-  A.debug = getenv("DBHIP_FAGG_DEBUG") ? atoi(getenv("DBHIP_FAGG_DEBUG")) : 0;
   hipStream_t s = resolve_stream(stream);
   // (at least 6 slots: the end of the kernel stages one group's 12 state words per lane in the register file)
   const size_t lds = (size_t)(A.P.n_slots > 6 ? A.P.n_slots : 6) * FA_ROWS * 256 * 8;
@@ -646,6 +904,15 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   int grid = (int)(ceil_div(nchunks, 4) < 512 ? ceil_div(nchunks, 4) : 512);
   static const int env_grid = getenv("DBHIP_FAGG_GRID") ? atoi(getenv("DBHIP_FAGG_GRID")) : 0;
   if (env_grid > 0) grid = (int)(ceil_div(nchunks, 4) < env_grid ? ceil_div(nchunks, 4) : env_grid);
+  if (FaPipe* pp = (FaPipe*)*dbhip_groupby_pipe_slot_internal(g); pp && !t_prepare_only) {
+    if (pp->on && !t_jit_only) {   // pipelined: one launch, nothing read back (see above)
+      FaPending P;
+      P.A = A; P.grid = grid; P.lds = lds; P.general = general; P.nwords = nwords;
+      return fa_pipe_submit(g, pp, P, s);
+    }
+    int64_t committed = 0;         // a synchronous call on a table that still has queued blocks: those first
+    if ((rc = fa_pipe_checkpoint(g, pp, &committed, true))) return rc;
+  }
   const size_t rows_bytes = (size_t)grid * 4 * FA_MAX_SLOTS * L.W * 8;
   uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 6, s);
   if (!ws) return DBHIP_ERR_HIP;
@@ -672,45 +939,10 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   for (int variant = dbhip_groupby_count_internal(g) > 4 ? 1 : 0; variant < 2; ++variant) {
     DBHIP_CHECK(hipMemsetAsync(ctrl, 0, 64, s));
     kernel_timer_start(s);
-#define FA_LAUNCH(SL, GEN)                                                                                     \
-  do {                                                                                                         \
-    if (nwords <= 4) hipLaunchKernelGGL((fagg_kernel<SL, GEN, 4>), dim3(grid), dim3(256), lds, s, A);           \
-    else hipLaunchKernelGGL((fagg_kernel<SL, GEN, FA_MAXW>), dim3(grid), dim3(256), lds, s, A);                 \
-  } while (0)
-    const int sl = variant == 0 ? 4 : 8;
-    bool jit_pending = false;
-    // an un-PREPAREd program is interpreted now and compiled in the background for the calls to come
-    hipFunction_t jf = jit_kernel(A, sl, general, nwords, (t_jit_only && !t_jit_may_compile) ? JIT_LOOKUP : JIT_BACKGROUND, &jit_pending);
-    if (!jf && t_jit_only) {   // plain add_block's use of this kernel: only the specialised form beats the LDS path
-      t_jit_pending = jit_pending;
-      if (jit_pending) ++g_fa_pending_refusals;
-      set_error("dbhip_fagg: the specialised kernel of this shape is %s", jit_pending ? "being compiled in the background" : "not available");
-      return DBHIP_ERR_UNSUPPORTED;
-    }
-    if (jf) {
-      size_t asz = sizeof(A);
-      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-      // (LDS: only the staging of one group's accumulators at the end — the register file is in VGPRs)
-      DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nwords * 256 * 8), s, nullptr, extra));
-      ++g_fa_jit_launches;
-    } else {
-      ++g_fa_interp_launches;
-    }
-    // (interpreted) a program with a rounding decimal multiply / divide: the instantiations that carry the long divisions
-    bool has_div = false;
-    for (int i = 0; i < A.P.n_ins; ++i) has_div |= A.P.ins[i].op == EX_DEC && dec_op_needs_division(A.P.dec[A.P.ins[i].dec_idx]);
-    if (jf) {}
-    else if (has_div && variant == 0) hipLaunchKernelGGL((fagg_kernel<4, true, FA_MAXW, true>), dim3(grid), dim3(256), lds, s, A);
-    else if (has_div) hipLaunchKernelGGL((fagg_kernel<8, true, FA_MAXW, true>), dim3(grid), dim3(256), lds, s, A);
-    else if (variant == 0 && !general) FA_LAUNCH(4, false);
-    else if (variant == 0) FA_LAUNCH(4, true);
-    else if (!general) FA_LAUNCH(8, false);
-    else FA_LAUNCH(8, true);
-#undef FA_LAUNCH
+    if ((rc = fa_launch(A, variant == 0 ? 4 : 8, general, nwords, grid, lds, s))) return rc;
     kernel_timer_stop(s);
     DBHIP_LAUNCH_CHECK();
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, ctrl, 24, hipMemcpyDeviceToHost, s));
-    if (A.debug & 4) { DBHIP_CHECK(hipStreamSynchronize(s)); return DBHIP_OK; }
     if (chained && !may_raise && !no_chain) {
       // the merge of the partial rows is queued right behind the kernel with the row count and the give-up flags still
       // on the device: ONE host round trip per pass
@@ -737,6 +969,59 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     return DBHIP_ERR_ROW_ERRORS;
   }
   return dbhip_groupby_merge_rows_internal(g, A.partial_rows, (int64_t)host_ctrl[0], s);
+}
+
+int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream) {
+  DBHIP_REQUIRE(g, "dbhip_groupby_set_pipelined: NULL argument");
+  void** slot = dbhip_groupby_pipe_slot_internal(g);
+  FaPipe* pp = (FaPipe*)*slot;
+  if (!on) {
+    if (!pp) return DBHIP_OK;
+    int64_t committed = 0;
+    const int32_t rc = fa_pipe_checkpoint(g, pp, &committed, true);
+    pp->on = false; pp->bound = false;
+    return rc;
+  }
+  const GbLayout& L = *dbhip_groupby_layout_internal(g);
+  if (!dbhip_fagg_layout_ok_internal(L)) {
+    set_error("dbhip_groupby_set_pipelined: layout outside the fused kernel (<= %d key words, <= %d aggregates, <= %d state words)", FA_KW, FA_MAXA, FA_MAXW);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (pp) { pp->on = true; return DBHIP_OK; }
+  pp = new (std::nothrow) FaPipe();
+  DBHIP_REQUIRE(pp, "dbhip_groupby_set_pipelined: out of host memory");
+  hipStream_t s = resolve_stream(stream);
+  // 65,536 partial rows: 4 blocks of the largest grid (512 workgroups x 4 waves x 8 slots), ~24 blocks of 65,536 input rows
+  pp->cap_rows = 65536;
+  int32_t rc = dbhip_alloc((size_t)pp->cap_rows * L.W * 8, (void**)&pp->rows);
+  hipError_t e = rc == DBHIP_OK ? hipMalloc((void**)&pp->ctrl, 64) : hipSuccess;
+  if (rc == DBHIP_OK && e == hipSuccess) e = hipHostMalloc((void**)&pp->status_host, 64, hipHostMallocMapped);
+  if (rc == DBHIP_OK && e == hipSuccess) e = hipHostGetDevicePointer((void**)&pp->status_dev, pp->status_host, 0);
+  if (rc == DBHIP_OK && e == hipSuccess) { memset(pp->status_host, 0, 64); e = hipMemsetAsync(pp->ctrl, 0, 64, s); }
+  if (rc == DBHIP_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+  if (rc == DBHIP_OK && e == hipSuccess) rc = dbhip_groupby_reserve_merge_internal(g, pp->cap_rows);
+  if (rc != DBHIP_OK || e != hipSuccess) {
+    dbhip_fagg_pipe_destroy_internal(pp);
+    return rc != DBHIP_OK ? rc : hip_fail(e, "dbhip_groupby_set_pipelined");
+  }
+  pp->count_seen = dbhip_groupby_count_internal(g);
+  pp->on = true;
+  *slot = pp;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_checkpoint(dbhip_groupby* g, int64_t* out_blocks_committed_host, void* stream) {
+  DBHIP_REQUIRE(g, "dbhip_groupby_checkpoint: NULL argument");
+  if (out_blocks_committed_host) *out_blocks_committed_host = 0;
+  FaPipe* pp = (FaPipe*)*dbhip_groupby_pipe_slot_internal(g);
+  if (!pp) return DBHIP_OK;
+  if (pp->bound && stream && pp->stream != resolve_stream(stream)) {
+    set_error("dbhip_groupby_checkpoint: the table's blocks were queued on another stream");
+    return DBHIP_ERR_INVALID;
+  }
+  const int32_t rc = fa_pipe_checkpoint(g, pp, out_blocks_committed_host, true);
+  pp->bound = false;   // nothing queued any more: the next block may come on another stream
+  return rc;
 }
 
 int32_t dbhip_groupby_prepare_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog) {

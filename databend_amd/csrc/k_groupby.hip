@@ -85,7 +85,20 @@ struct dbhip_groupby {
   uint64_t arena_pinned, arena_live;           // bytes pinned since the arena's live bytes were last counted; that count
   int gbc_skip;                                // this chunk goes through the generic kernels (its spill list covers every row)
   uint32_t* gbc_split; size_t gbc_split_cap;   // heavy partitions (gbc_split_map_kernel): nsp[P] | cursor, extra workgroups | map[extra]
+  void* fa_pipe;                               // pipelined fused aggregation (k_fagg.hip, dbhip_groupby_set_pipelined): blocks queued, not yet checked
 };
+
+// k_fagg.hip: a pipelined table owes the host a checkpoint before anything else looks at (or changes) its groups
+int32_t dbhip_fagg_pipe_drain_internal(dbhip_groupby* g, void* pipe, hipStream_t s);
+void dbhip_fagg_pipe_destroy_internal(void* pipe);
+int32_t dbhip_fagg_pipe_reset_internal(void* pipe, hipStream_t s);
+#define GB_DRAIN(g, s)                                                                   \
+  do {                                                                                   \
+    if ((g) && (g)->fa_pipe) {                                                           \
+      const int32_t _rc = dbhip_fagg_pipe_drain_internal((g), (g)->fa_pipe, (s));        \
+      if (_rc) return _rc;                                                               \
+    }                                                                                    \
+  } while (0)
 
 namespace {
 
@@ -346,7 +359,7 @@ struct DevCount {
   const uint64_t* abort_dev;
 };
 __device__ __forceinline__ int64_t dev_rows(const DevCount& dc, int64_t n) {
-  if (dc.abort_dev && (*dc.abort_dev & 3)) return 0;
+  if (dc.abort_dev && (*dc.abort_dev & 7)) return 0;   // 1: too many groups, 2: long string key, 4: row errors (sealed by the pipeline)
   if (dc.n_dev) { const int64_t m = (int64_t)*dc.n_dev; return m < n ? m : n; }
   return n;
 }
@@ -1354,15 +1367,18 @@ bool layout_has_strings(const GbLayout& L) { return L.str_w1_mask != 0; }
 bool layout_has_wide_minmax(const GbLayout& L);
 
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
-int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s, const uint64_t* n_dev, const uint64_t* abort_dev);
+int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s, const uint64_t* n_dev, const uint64_t* abort_dev,
+                            bool deferred = false);
 int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
                    const uint64_t* n_dev = nullptr, const uint64_t* abort_dev = nullptr) {
   int32_t rc = merge_rows_unpinned(g, rows_in, n, s, n_dev, abort_dev);
   if (rc == DBHIP_OK && n > 0) rc = pin_string_states(g, s);
   return rc;
 }
+// `deferred` (the pipelined fused aggregation): the caller has made sure that the table cannot outgrow its load factor whatever the
+// rows hold; the three kernels are queued and NOTHING is read back — the table's count_host is stale until the caller's checkpoint
 int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
-                            const uint64_t* n_dev, const uint64_t* abort_dev) {
+                            const uint64_t* n_dev, const uint64_t* abort_dev, bool deferred) {
   if (n == 0) return DBHIP_OK;
   if (n > 0xFFFFFFF0LL) {
     set_error("groupby: more than 2^32 rows in one call");
@@ -1379,14 +1395,14 @@ int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n
   const DevCount dc{n_dev, abort_dev};
   // No growth possible even if every row were a new group: probe, accumulate and retry are queued back to back and
   // the host reads the control block ONCE (the small merges behind the fused kernels are all host round trips).
-  if ((g->count_host + n) * 135 <= g->cap * 100) {
+  if (deferred || (g->count_host + n) * 135 <= g->cap * 100) {
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[1], 0, 16, s));
     hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash, g->rows, g->cap,
                        g->hash_mask, g->gid, g->ctrl, dc, g->arena);
     // (the wave-combining kernel only where the table is known to hold a handful of groups: on an empty table the first
     // merge may bring 50 K groups, r02y: 0.11 ms there against 0.02 ms for the plain kernel)
     // (a Decimal128 min / max state is merged under a lock: always combine the rows of a wave first, one acquisition per wave and state)
-    if ((g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048 || layout_has_wide_minmax(g->L))
+    if (deferred || (g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048 || layout_has_wide_minmax(g->L))
       hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
                          g->ctrl, dc, g->arena);
     else
@@ -1394,6 +1410,7 @@ int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n
     hipLaunchKernelGGL(gb_retry_kernel, dim3(1), dim3(64), 0, s, g->L, cur_rows, g->slot_hash, g->rows, g->cap, g->hash_mask,
                        g->gid, g->retry, g->ctrl, g->arena);
     DBHIP_LAUNCH_CHECK();
+    if (deferred) return DBHIP_OK;
     DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
     g->count_host = (int64_t)host_ctrl[0];
@@ -3239,6 +3256,26 @@ int32_t dbhip_groupby_reserve_merge_internal(dbhip_groupby* g, int64_t n) {
   if ((rc = ensure((void**)&g->gid, &g->gid_cap, (size_t)n * 4))) return rc;
   return ensure((void**)&g->retry, &g->retry_cap, (size_t)n * 4);
 }
+// the pipelined fused aggregation (k_fagg.hip): merge with nothing read back (see merge_rows_unpinned)
+int32_t dbhip_groupby_merge_rows_deferred_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n_max, const uint64_t* n_dev,
+                                                   const uint64_t* abort_dev, hipStream_t s) {
+  return merge_rows_unpinned(g, rows, n_max, s, n_dev, abort_dev, true);
+}
+// drains the stream, reads the exact number of groups and grows the table until `extra` more groups cannot push it past its load factor
+int32_t dbhip_groupby_ensure_room_internal(dbhip_groupby* g, int64_t extra, hipStream_t s) {
+  uint64_t cnt = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&cnt, &g->ctrl[0], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  g->count_host = (int64_t)cnt;
+  while ((g->count_host + extra) * 135 > g->cap * 100) {
+    const int32_t rc = grow(g, s);
+    if (rc) return rc;
+  }
+  return DBHIP_OK;
+}
+uint64_t* dbhip_groupby_ctrl_internal(dbhip_groupby* g) { return g->ctrl; }
+void dbhip_groupby_set_count_internal(dbhip_groupby* g, int64_t count) { g->count_host = count; }
+void** dbhip_groupby_pipe_slot_internal(dbhip_groupby* g) { return &g->fa_pipe; }
 int64_t dbhip_groupby_capacity_internal(dbhip_groupby* g) { return g->cap; }
 int64_t dbhip_groupby_count_internal(dbhip_groupby* g) { return g->count_host; }
 const GbLayout* dbhip_groupby_layout_internal(dbhip_groupby* g) { return &g->L; }
@@ -3330,6 +3367,7 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
 
 int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args, int64_t n,
                                          const uint8_t* filter_bitmap, int64_t filter_bit_offset, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && keys, "dbhip_groupby_add_block: NULL argument");
   if (n == 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
@@ -3417,6 +3455,7 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
 // go through the row merge path — the table's layout is never modified.
 int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
                                         int64_t n, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && keys && (states || g->L.naggs == 0), "dbhip_groupby_merge_state_block: NULL argument");
   if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_merge_state_block")) return rs;
   const GbLayout& L = g->L;
@@ -3489,11 +3528,13 @@ int32_t dbhip_groupby_state_fields(dbhip_groupby* g, int32_t* out_types_host, in
 }
 
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && (rows_dev || n_rows == 0), "dbhip_groupby_merge_serialized: NULL argument");
   return merge_rows(g, (const uint64_t*)rows_dev, n_rows, resolve_stream(stream));
 }
 
 int32_t dbhip_groupby_num_groups(dbhip_groupby* g, int64_t* out_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_host, "dbhip_groupby_num_groups: NULL argument");
   hipStream_t s = resolve_stream(stream);
   uint64_t c = 0;
@@ -3512,6 +3553,7 @@ int32_t dbhip_groupby_row_bytes(dbhip_groupby* g, int64_t* out_host) {
 
 int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int64_t max_rows,
                                        int64_t* out_n_rows_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_n_rows_host && (out_rows_dev || max_rows == 0), "dbhip_groupby_flush_serialized: NULL argument");
   hipStream_t s = resolve_stream(stream);
   DBHIP_CHECK(hipMemsetAsync(&g->ctrl[4], 0, 8, s));
@@ -3545,6 +3587,7 @@ static int32_t refuse_long_strings(const dbhip_groupby* g, const char* fn) {
 }
 
 int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t max_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_block_dev && max_rows >= 1, "dbhip_groupby_flush_block: bad argument");
   if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_flush_block")) return rl;
   hipStream_t s = resolve_stream(stream);
@@ -3559,6 +3602,7 @@ int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t
 
 int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows,
                                    int32_t skip_block, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_merge_blocks: bad argument");
   if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_merge_blocks")) return rl;
   hipStream_t s = resolve_stream(stream);
@@ -3673,6 +3717,7 @@ static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8
 }
 
 int32_t dbhip_groupby_arena(dbhip_groupby* g, const void** out_ptr_host, int64_t* out_bytes_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_ptr_host && out_bytes_host, "dbhip_groupby_arena: NULL argument");
   hipStream_t s = resolve_stream(stream);
   uint64_t used = 0;
@@ -3710,6 +3755,7 @@ __global__ __launch_bounds__(256) void gb_rebase_rows_kernel(GbLayout L, const u
 }  // namespace
 
 int32_t dbhip_groupby_merge_serialized_arena(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, const void* arena_dev, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && (rows_dev || n_rows == 0), "dbhip_groupby_merge_serialized_arena: NULL argument");
   if (n_rows == 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
@@ -3729,6 +3775,7 @@ int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
                                    uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
                                    uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host,
                                    void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result: NULL argument");
   return flush_columns(g, out_keys_host, out_key_validity_host, out_aggs_host, nullptr, nullptr, out_hashes, max_rows,
                        out_n_rows_host, stream);
@@ -3738,6 +3785,7 @@ int32_t dbhip_groupby_flush_result_nullable(dbhip_groupby* g, void* const* out_k
                                             uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
                                             uint8_t* const* out_agg_validity_host, uint64_t* out_hashes, int64_t max_rows,
                                             int64_t* out_n_rows_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result_nullable: NULL argument");
   return flush_columns(g, out_keys_host, out_key_validity_host, out_aggs_host, out_agg_validity_host, nullptr, out_hashes,
                        max_rows, out_n_rows_host, stream);
@@ -3746,6 +3794,7 @@ int32_t dbhip_groupby_flush_result_nullable(dbhip_groupby* g, void* const* out_k
 int32_t dbhip_groupby_flush_state_block(dbhip_groupby* g, void* const* out_keys_host, uint8_t* const* out_key_validity_host,
                                         void* const* out_state_fields_host, uint64_t* out_hashes, int64_t max_rows,
                                         int64_t* out_n_rows_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_n_rows_host && (out_state_fields_host || g->L.naggs == 0), "dbhip_groupby_flush_state_block: NULL argument");
   if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_flush_state_block")) return rs;
   return flush_columns(g, out_keys_host, out_key_validity_host, nullptr, nullptr, out_state_fields_host, out_hashes, max_rows,
@@ -3760,6 +3809,7 @@ static int32_t ensure_xcur(dbhip_groupby* g) {
 }
 
 int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void* out_blocks_dev, int64_t max_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_blocks_dev && n_buckets >= 1 && n_buckets <= 4096 && max_rows >= 1, "dbhip_groupby_partition_blocks: bad argument");
   if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_partition_blocks")) return rl;
   hipStream_t s = resolve_stream(stream);
@@ -3779,6 +3829,7 @@ int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void
 
 int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, void* out_rows_dev, int64_t max_rows,
                                         int64_t* out_counts_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && out_counts_host && n_buckets >= 1 && n_buckets <= 4096 && (out_rows_dev || max_rows == 0),
                 "dbhip_groupby_flush_partitioned: bad argument");
   if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_flush_partitioned")) return rl;
@@ -3813,6 +3864,7 @@ int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, voi
 }
 
 int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_replace_with_blocks: bad argument");
   if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_replace_with_blocks")) return rl;
   hipStream_t s = resolve_stream(stream);
@@ -3843,6 +3895,7 @@ int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_d
 int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   DBHIP_REQUIRE(g, "dbhip_groupby_reset: NULL argument");
   hipStream_t s = resolve_stream(stream);
+  if (g->fa_pipe) { const int32_t rc = dbhip_fagg_pipe_reset_internal(g->fa_pipe, s); if (rc) return rc; }   // queued blocks are dropped with the groups
   DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)g->cap * 8, s));
   DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 128, s));
   g->count_host = 0;
@@ -3863,6 +3916,7 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
 int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
   if (!g) return DBHIP_OK;
   (void)hipDeviceSynchronize();
+  if (g->fa_pipe) dbhip_fagg_pipe_destroy_internal(g->fa_pipe);
   if (g->slot_hash) (void)dbhip_free(g->slot_hash);
   if (g->rows) (void)dbhip_free(g->rows);
   if (g->ctrl) (void)hipFree(g->ctrl);

@@ -858,6 +858,20 @@ class GroupBy:
             return
         check(lib().dbhip_groupby_add_block_program(self.h, _cols(keys), C.byref(ap), C.c_int64(n), fb, C.c_int64(0), stream))
 
+    def set_pipelined(self, on=True, stream=None):
+        """dbhip_groupby_set_pipelined: add_block_program calls queue one launch each and return; `checkpoint` reports."""
+        check(lib().dbhip_groupby_set_pipelined(self.h, C.c_int32(1 if on else 0), stream))
+
+    def checkpoint(self, stream=None, raise_on_error=True):
+        """dbhip_groupby_checkpoint -> blocks merged since the previous checkpoint (raises the deferred error unless
+        raise_on_error=False: then -> (rc, committed))."""
+        n = C.c_int64()
+        rc = lib().dbhip_groupby_checkpoint(self.h, C.byref(n), stream)
+        if not raise_on_error:
+            return rc, n.value
+        check(rc)
+        return n.value
+
     def prepare_program(self, keys, program, arg_regs, filter_reg=-1):
         """dbhip_groupby_prepare_program: compile the run-time specialised kernel of this query shape now (blocking, cached)."""
         self.add_block_program(keys, program, arg_regs, 1, filter_reg=filter_reg, prepare=True)

@@ -1,0 +1,400 @@
+// block_sweep.cpp — what the drop-in costs at the block size the reference hands over (VERDICT r05 "missing #1").
+//
+// The reference's pipeline calls every operator with DataBlocks of <= 65,536 rows (max_block_size,
+// src/query/settings/src/settings_default.rs:142-148; TransformPartialAggregate::transform per block,
+// transform_aggregate_partial.rs:262-270). This binary feeds the C-ABI the SAME table cut into blocks of
+// 65,536 / 262,144 / 1 Mi / 16 Mi / all rows, from 1 and from 8 host threads (each with its own stream and its own partial
+// table, like the reference's pipeline threads), and reports rows/s and the fixed cost per call for
+//   q1_sync       dbhip_groupby_add_block_program, one synchronous call per block (rounds 2-5)
+//   q1_pipelined  the same call on a table in pipelined mode (round 6): one launch per block, checkpoint at the end
+//   q1_squash_*   65,536-row blocks concatenated (device-to-device) into 1 Mi / 4 Mi-row staging blocks first — the block
+//                 accumulator a binding would put in front of the operator (the reference's own join build squashes,
+//                 new_hash_join/memory/basic.rs:78-89)
+//   filter_take   dbhip_cmp -> dbhip_filter_select -> dbhip_take of one 8-byte column (TransformFilter on one column)
+//   decimal_map   two dbhip_decimal_arith calls: price * (1 - discount)
+//   join_probe    dbhip_join_probe_count + dbhip_join_probe against a 1 Mi-key build side
+// Every Q1 variant's result is compared with the whole-table synchronous call. Output: one JSON object (--out FILE).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dbhip.h"
+
+#define CK(x)                                                                                   \
+  do {                                                                                          \
+    int32_t _rc = (x);                                                                          \
+    if (_rc != DBHIP_OK) { fprintf(stderr, "%s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #x, _rc, dbhip_last_error()); exit(2); } \
+  } while (0)
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static uint64_t mix(uint64_t x) { x += 0x9e3779b97f4a7c15ULL; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL; x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL; return x ^ (x >> 31); }
+
+struct Lineitem {
+  int64_t n = 0;
+  int64_t *qty = nullptr, *price = nullptr, *disc = nullptr, *tax = nullptr;
+  int32_t* ship = nullptr;
+  uint8_t *rf = nullptr, *ls = nullptr;   // 16-byte views
+};
+static const int32_t kCutoff = 10471;   // 1998-09-02
+static const int32_t kShipLo = 8035, kShipHi = 10561, kCurrent = 9298;   // databend_amd/tpch.py's ranges
+
+static void* dalloc(size_t bytes) { void* p = nullptr; CK(dbhip_alloc(bytes < 64 ? 64 : bytes, &p)); return p; }
+
+static Lineitem gen_lineitem(int64_t n) {
+  Lineitem li; li.n = n;
+  std::vector<int64_t> qty(n), price(n), disc(n), tax(n);
+  std::vector<int32_t> ship(n);
+  std::vector<uint8_t> rf((size_t)n * 16, 0), ls((size_t)n * 16, 0);
+  const int T = 8;
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+    for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+      uint64_t r = mix((uint64_t)i * 7 + 1);
+      qty[i] = (int64_t)(1 + r % 50) * 100; r = mix(r);
+      price[i] = (int64_t)(90000 + r % 10404951); r = mix(r);
+      disc[i] = (int64_t)(r % 11); r = mix(r);
+      tax[i] = (int64_t)(r % 9); r = mix(r);
+      ship[i] = kShipLo + (int32_t)(r % (uint64_t)(kShipHi - kShipLo + 1)); r = mix(r);
+      const int32_t receipt = ship[i] + 1 + (int32_t)(r % 30); r = mix(r);
+      const char f = receipt <= kCurrent ? ((r & 1) ? 'A' : 'R') : 'N';
+      const char s = ship[i] > kCurrent ? 'O' : 'F';
+      uint32_t one = 1;
+      memcpy(&rf[(size_t)i * 16], &one, 4); rf[(size_t)i * 16 + 4] = (uint8_t)f;
+      memcpy(&ls[(size_t)i * 16], &one, 4); ls[(size_t)i * 16 + 4] = (uint8_t)s;
+    }
+  });
+  for (auto& x : th) x.join();
+  auto up = [&](const void* src, size_t bytes) { void* d = dalloc(bytes); CK(dbhip_memcpy_h2d(d, src, bytes, nullptr)); return d; };
+  li.qty = (int64_t*)up(qty.data(), (size_t)n * 8); li.price = (int64_t*)up(price.data(), (size_t)n * 8);
+  li.disc = (int64_t*)up(disc.data(), (size_t)n * 8); li.tax = (int64_t*)up(tax.data(), (size_t)n * 8);
+  li.ship = (int32_t*)up(ship.data(), (size_t)n * 4);
+  li.rf = (uint8_t*)up(rf.data(), (size_t)n * 16); li.ls = (uint8_t*)up(ls.data(), (size_t)n * 16);
+  CK(dbhip_stream_sync(nullptr));
+  return li;
+}
+
+static dbhip_col col(int32_t type, const void* data, uint8_t p = 0, uint8_t s = 0) {
+  dbhip_col c; memset(&c, 0, sizeof(c)); c.type = type; c.data = data; c.precision = p; c.scale = s; return c;
+}
+
+// Q1's filter + maps as a register program over rows [row0, row0 + n) (what tpch.q1_program builds in Python)
+struct Q1Program {
+  dbhip_expr_ins ins[16];
+  int n_ins = 0;
+  dbhip_col inputs[5], keys[2];
+  int32_t arg_regs[6];
+  int32_t filter_reg = -1;
+  dbhip_agg_program ap;
+  int32_t emit(int32_t op, int32_t dst, int32_t a, int32_t b, int32_t type, uint64_t imm = 0, uint8_t p = 0, uint8_t s = 0) {
+    dbhip_expr_ins& I = ins[n_ins++]; memset(&I, 0, sizeof(I));
+    I.op = op; I.dst = dst; I.a = a; I.b = b; I.type = type; I.imm = imm; I.precision = p; I.scale = s; return dst;
+  }
+  void build(const Lineitem& li, int64_t row0) {
+    inputs[0] = col(DBHIP_T_DATE, li.ship + row0);
+    inputs[1] = col(DBHIP_T_DEC64, li.qty + row0, 15, 2); inputs[2] = col(DBHIP_T_DEC64, li.price + row0, 15, 2);
+    inputs[3] = col(DBHIP_T_DEC64, li.disc + row0, 15, 2); inputs[4] = col(DBHIP_T_DEC64, li.tax + row0, 15, 2);
+    keys[0] = col(DBHIP_T_STRING, li.rf + row0 * 16); keys[1] = col(DBHIP_T_STRING, li.ls + row0 * 16);
+    if (n_ins == 0) {
+      uint8_t p, s;
+      // registers as the Python ExprProgram allocates them (lowest free register first)
+      emit(DBHIP_EX_LOAD, 0, 0, 0, DBHIP_T_DATE);
+      emit(DBHIP_EX_CONST, 1, 0, 0, DBHIP_T_DATE, (uint64_t)kCutoff);
+      filter_reg = emit(DBHIP_EX_LTE, 0, 0, 1, DBHIP_T_BOOL);                       // r0 = ship <= cutoff
+      emit(DBHIP_EX_LOAD, 1, 1, 0, DBHIP_T_DEC64, 0, 15, 2);                        // r1 qty
+      emit(DBHIP_EX_LOAD, 2, 2, 0, DBHIP_T_DEC64, 0, 15, 2);                        // r2 price
+      emit(DBHIP_EX_LOAD, 3, 3, 0, DBHIP_T_DEC64, 0, 15, 2);                        // r3 disc
+      emit(DBHIP_EX_LOAD, 4, 4, 0, DBHIP_T_DEC64, 0, 15, 2);                        // r4 tax
+      emit(DBHIP_EX_CONST, 5, 0, 0, DBHIP_T_U8, 1);                                 // r5 = 1
+      CK(dbhip_decimal_result_size(1 /*minus*/, 3, 0, 15, 2, &p, &s));
+      emit(DBHIP_EX_MINUS, 6, 5, 3, p <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128, 0, p, s);   // r6 = 1 - disc
+      uint8_t p2, s2;
+      CK(dbhip_decimal_result_size(2 /*multiply*/, 15, 2, p, s, &p2, &s2));
+      emit(DBHIP_EX_MULTIPLY, 7, 2, 6, p2 <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128, 0, p2, s2);   // r7 = price * (1 - disc)
+      uint8_t p3, s3;
+      CK(dbhip_decimal_result_size(0 /*plus*/, 3, 0, 15, 2, &p3, &s3));
+      emit(DBHIP_EX_PLUS, 6, 5, 4, p3 <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128, 0, p3, s3);       // r6 = 1 + tax
+      uint8_t p4, s4;
+      CK(dbhip_decimal_result_size(2, p2, s2, p3, s3, &p4, &s4));
+      emit(DBHIP_EX_MULTIPLY, 4, 7, 6, p4 <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128, 0, p4, s4);   // r4 = r7 * (1 + tax)
+      arg_regs[0] = 1; arg_regs[1] = 2; arg_regs[2] = 7; arg_regs[3] = 4; arg_regs[4] = 3; arg_regs[5] = DBHIP_ARG_NONE;
+    }
+    ap.prog = ins; ap.n_ins = n_ins; ap.inputs = inputs; ap.n_inputs = 5; ap.filter_reg = filter_reg; ap.arg_regs = arg_regs;
+  }
+};
+
+struct Q1Result { uint64_t groups = 0; std::vector<uint64_t> words; };
+// the table's serialized rows, sorted: equal tables give equal bytes whatever the order the groups were met in
+static Q1Result q1_result(dbhip_groupby* g) {
+  Q1Result r;
+  int64_t n = 0, rb = 0;
+  CK(dbhip_groupby_num_groups(g, &n, nullptr));
+  CK(dbhip_groupby_row_bytes(g, &rb));
+  void* d = dalloc((size_t)(n > 0 ? n : 1) * rb);
+  int64_t m = 0;
+  CK(dbhip_groupby_flush_serialized(g, d, n, &m, nullptr));
+  std::vector<uint8_t> h((size_t)m * rb);
+  if (m) CK(dbhip_memcpy_d2h(h.data(), d, h.size(), nullptr));
+  CK(dbhip_free(d));
+  std::vector<std::string> rows;
+  for (int64_t i = 0; i < m; ++i) rows.emplace_back((const char*)&h[(size_t)i * rb], (size_t)rb);
+  std::sort(rows.begin(), rows.end());
+  r.groups = (uint64_t)m;
+  for (auto& s : rows) { for (size_t k = 0; k + 8 <= s.size(); k += 8) { uint64_t w; memcpy(&w, &s[k], 8); r.words.push_back(w); } }
+  return r;
+}
+
+struct Line { std::string op; int64_t block; int threads; double secs; int64_t rows; int64_t calls; bool ok; std::string note; };
+static std::vector<Line> g_lines;
+static void report(const Line& l) {
+  g_lines.push_back(l);
+  fprintf(stderr, "%-18s block %10lld threads %d : %8.3f ms  %8.2f G rows/s  %8.2f us/call  %s %s\n", l.op.c_str(), (long long)l.block, l.threads,
+          l.secs * 1e3, l.rows / l.secs / 1e9, l.secs / (double)(l.calls ? l.calls : 1) * 1e6 * l.threads, l.ok ? "ok" : "MISMATCH", l.note.c_str());
+}
+
+enum Q1Mode { Q1_SYNC = 0, Q1_PIPE = 1, Q1_SQUASH = 2, Q1_SQUASH_PIPE = 3 };
+
+// thread t takes blocks t, t + T, ... ; returns the seconds of the slowest thread between a common start and its own end
+static double run_q1(const Lineitem& li, int64_t B, int T, Q1Mode mode, int64_t squash_rows, const Q1Result& expect, bool* ok, int64_t* calls_out) {
+  const int64_t nblocks = (li.n + B - 1) / B;
+  std::vector<dbhip_groupby*> tables(T);
+  std::vector<void*> streams(T);
+  for (int t = 0; t < T; ++t) { CK(dbhip_q1_create_groupby(&tables[t])); CK(dbhip_stream_create(&streams[t])); }
+  // staging blocks of the squash variants: per thread, 4 buffers round robin (a pipelined kernel may still be reading the last ones)
+  const int NST = 4;
+  std::vector<Lineitem> staging;
+  if (mode >= Q1_SQUASH) {
+    for (int t = 0; t < T * NST; ++t) {
+      Lineitem s; s.n = squash_rows;
+      s.qty = (int64_t*)dalloc((size_t)squash_rows * 8); s.price = (int64_t*)dalloc((size_t)squash_rows * 8);
+      s.disc = (int64_t*)dalloc((size_t)squash_rows * 8); s.tax = (int64_t*)dalloc((size_t)squash_rows * 8);
+      s.ship = (int32_t*)dalloc((size_t)squash_rows * 4); s.rf = (uint8_t*)dalloc((size_t)squash_rows * 16); s.ls = (uint8_t*)dalloc((size_t)squash_rows * 16);
+      staging.push_back(s);
+    }
+  }
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  std::vector<double> t_end(T, 0.0);
+  std::vector<int64_t> calls(T, 0);
+  double t_start = 0;
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+    dbhip_groupby* g = tables[t];
+    void* s = streams[t];
+    Q1Program P;
+    if (mode == Q1_PIPE || mode == Q1_SQUASH_PIPE) CK(dbhip_groupby_set_pipelined(g, 1, s));
+    P.build(li, 0);
+    CK(dbhip_groupby_prepare_program(g, P.keys, &P.ap));
+    ++ready;
+    while (!go.load(std::memory_order_acquire)) {}
+    if (mode == Q1_SYNC || mode == Q1_PIPE) {
+      for (int64_t b = t; b < nblocks; b += T) {
+        const int64_t row0 = b * B, n = row0 + B <= li.n ? B : li.n - row0;
+        P.build(li, row0);
+        CK(dbhip_groupby_add_block_program(g, P.keys, &P.ap, n, nullptr, 0, s));
+        ++calls[t];
+      }
+    } else {
+      int64_t fill = 0; int cur = 0, since_ckpt = 0;
+      auto flush = [&] {
+        if (!fill) return;
+        Lineitem& S = staging[(size_t)t * NST + cur];
+        P.build(S, 0);
+        CK(dbhip_groupby_add_block_program(g, P.keys, &P.ap, fill, nullptr, 0, s));
+        ++calls[t];
+        fill = 0; cur = (cur + 1) % NST;
+        if (mode == Q1_SQUASH_PIPE && ++since_ckpt == NST - 1) { int64_t c; CK(dbhip_groupby_checkpoint(g, &c, s)); since_ckpt = 0; }
+      };
+      for (int64_t b = t; b < nblocks; b += T) {
+        const int64_t row0 = b * B, n = row0 + B <= li.n ? B : li.n - row0;
+        if (fill + n > squash_rows) flush();
+        Lineitem& S = staging[(size_t)t * NST + cur];
+        CK(dbhip_memcpy_d2d(S.qty + fill, li.qty + row0, (size_t)n * 8, s)); CK(dbhip_memcpy_d2d(S.price + fill, li.price + row0, (size_t)n * 8, s));
+        CK(dbhip_memcpy_d2d(S.disc + fill, li.disc + row0, (size_t)n * 8, s)); CK(dbhip_memcpy_d2d(S.tax + fill, li.tax + row0, (size_t)n * 8, s));
+        CK(dbhip_memcpy_d2d(S.ship + fill, li.ship + row0, (size_t)n * 4, s));
+        CK(dbhip_memcpy_d2d(S.rf + fill * 16, li.rf + row0 * 16, (size_t)n * 16, s)); CK(dbhip_memcpy_d2d(S.ls + fill * 16, li.ls + row0 * 16, (size_t)n * 16, s));
+        fill += n;
+      }
+      flush();
+    }
+    if (mode == Q1_PIPE || mode == Q1_SQUASH_PIPE) { int64_t c = 0; CK(dbhip_groupby_checkpoint(g, &c, s)); }
+    CK(dbhip_stream_sync(s));
+    t_end[t] = now_s();
+  });
+  while (ready.load() < T) {}
+  t_start = now_s();
+  go.store(true, std::memory_order_release);
+  for (auto& x : th) x.join();
+  double secs = 0;
+  for (int t = 0; t < T; ++t) secs = t_end[t] - t_start > secs ? t_end[t] - t_start : secs;
+  // TransformFinalAggregate: the threads' partial tables into one
+  dbhip_groupby* fin = tables[0];
+  for (int t = 1; t < T; ++t) {
+    int64_t n = 0, rb = 0, m = 0;
+    CK(dbhip_groupby_num_groups(tables[t], &n, nullptr)); CK(dbhip_groupby_row_bytes(tables[t], &rb));
+    void* d = dalloc((size_t)(n > 0 ? n : 1) * rb);
+    CK(dbhip_groupby_flush_serialized(tables[t], d, n, &m, nullptr));
+    CK(dbhip_groupby_merge_serialized(fin, d, m, nullptr));
+    CK(dbhip_stream_sync(nullptr));
+    CK(dbhip_free(d));
+  }
+  const Q1Result got = q1_result(fin);
+  *ok = got.groups == expect.groups && got.words == expect.words;
+  *calls_out = 0;
+  for (int t = 0; t < T; ++t) *calls_out += calls[t];
+  for (int t = 0; t < T; ++t) { CK(dbhip_groupby_destroy(tables[t])); CK(dbhip_stream_destroy(streams[t])); }
+  for (auto& S : staging) { dbhip_free(S.qty); dbhip_free(S.price); dbhip_free(S.disc); dbhip_free(S.tax); dbhip_free(S.ship); dbhip_free(S.rf); dbhip_free(S.ls); }
+  return secs;
+}
+
+// generic per-block operator loop: fn(thread, stream, row0, n)
+template <class F>
+static double run_blocks(int64_t total, int64_t B, int T, F fn, int64_t* calls_out) {
+  const int64_t nblocks = (total + B - 1) / B;
+  std::vector<void*> streams(T);
+  for (int t = 0; t < T; ++t) CK(dbhip_stream_create(&streams[t]));
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  std::vector<double> t_end(T, 0.0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+    ++ready;
+    while (!go.load(std::memory_order_acquire)) {}
+    for (int64_t b = t; b < nblocks; b += T) {
+      const int64_t row0 = b * B, n = row0 + B <= total ? B : total - row0;
+      fn(t, streams[t], row0, n);
+    }
+    CK(dbhip_stream_sync(streams[t]));
+    t_end[t] = now_s();
+  });
+  while (ready.load() < T) {}
+  const double t0 = now_s();
+  go.store(true, std::memory_order_release);
+  for (auto& x : th) x.join();
+  double secs = 0;
+  for (int t = 0; t < T; ++t) secs = t_end[t] - t0 > secs ? t_end[t] - t0 : secs;
+  for (int t = 0; t < T; ++t) CK(dbhip_stream_destroy(streams[t]));
+  *calls_out = nblocks;
+  return secs;
+}
+
+int main(int argc, char** argv) {
+  int64_t N = 64LL << 20;
+  const char* out = nullptr;
+  bool quick = false;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--rows") && i + 1 < argc) N = atoll(argv[++i]);
+    else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+    else if (!strcmp(argv[i], "--quick")) quick = true;
+  }
+  CK(dbhip_init(0));
+  fprintf(stderr, "generating %lld lineitem rows ...\n", (long long)N);
+  Lineitem li = gen_lineitem(N);
+
+  // ---- reference result: the whole table in one synchronous call ----
+  Q1Result expect;
+  {
+    dbhip_groupby* g; CK(dbhip_q1_create_groupby(&g));
+    Q1Program P; P.build(li, 0);
+    CK(dbhip_groupby_prepare_program(g, P.keys, &P.ap));
+    CK(dbhip_groupby_add_block_program(g, P.keys, &P.ap, N, nullptr, 0, nullptr));
+    expect = q1_result(g);
+    CK(dbhip_groupby_destroy(g));
+    fprintf(stderr, "whole-table result: %llu groups\n", (unsigned long long)expect.groups);
+  }
+  std::vector<int64_t> sizes = {65536, 262144, 1 << 20, 16 << 20, N};
+  std::vector<int> threads = {1, 8};
+  if (quick) { sizes = {65536, 1 << 20}; }
+  for (int rep = 0; rep < 2; ++rep) {   // the first round warms every path (code objects, scratch, the block cache); the second is reported
+    if (rep == 1) g_lines.clear();
+    for (int64_t B : sizes)
+      for (int T : threads) {
+        if (B >= N && T > 1) continue;
+        for (Q1Mode mode : {Q1_SYNC, Q1_PIPE}) {
+          bool ok = false; int64_t calls = 0;
+          const double secs = run_q1(li, B, T, mode, 0, expect, &ok, &calls);
+          report({mode == Q1_SYNC ? "q1_sync" : "q1_pipelined", B, T, secs, N, calls, ok, ""});
+        }
+      }
+    for (int T : threads)
+      for (int64_t S : {(int64_t)1 << 20, (int64_t)4 << 20})
+        for (Q1Mode mode : {Q1_SQUASH, Q1_SQUASH_PIPE}) {
+          bool ok = false; int64_t calls = 0;
+          const double secs = run_q1(li, 65536, T, mode, S, expect, &ok, &calls);
+          report({std::string(mode == Q1_SQUASH ? "q1_squash_" : "q1_squashpipe_") + (S == (1 << 20) ? "1Mi" : "4Mi"), 65536, T, secs, N, calls, ok, "device-to-device concat of 7 columns, then the call"});
+        }
+  }
+
+  // ---- the other per-block operators (each thread its own output buffers, sized for the largest block) ----
+  {
+    const int TMAX = 8;
+    std::vector<uint8_t*> bm(TMAX); std::vector<uint32_t*> sel(TMAX); std::vector<uint64_t*> cnt(TMAX); std::vector<int64_t*> o8(TMAX);
+    std::vector<void*> d64(TMAX), d128(TMAX);
+    for (int t = 0; t < TMAX; ++t) {
+      const int64_t cap = t == 0 ? N : (16 << 20);   // (thread 0 also runs the whole-table line)
+      bm[t] = (uint8_t*)dalloc((size_t)cap / 8 + 64); sel[t] = (uint32_t*)dalloc((size_t)cap * 4); cnt[t] = (uint64_t*)dalloc(64);
+      o8[t] = (int64_t*)dalloc((size_t)cap * 8); d64[t] = dalloc((size_t)cap * 8); d128[t] = dalloc((size_t)cap * 16);
+    }
+    uint8_t p1, s1, p2, s2;
+    CK(dbhip_decimal_result_size(1, 3, 0, 15, 2, &p1, &s1)); CK(dbhip_decimal_result_size(2, 15, 2, p1, s1, &p2, &s2));
+    uint8_t one_h = 1; void* one_d = dalloc(64); CK(dbhip_memcpy_h2d(one_d, &one_h, 1, nullptr));
+    void* cut_d = dalloc(64); CK(dbhip_memcpy_h2d(cut_d, &kCutoff, 4, nullptr)); CK(dbhip_stream_sync(nullptr));
+    // join: 1 Mi distinct build keys; probe keys = price column mod 2 Mi (about half match)
+    const int64_t NB = 1 << 20;
+    std::vector<int64_t> bk(NB); for (int64_t i = 0; i < NB; ++i) bk[i] = i * 2;
+    void* bk_d = dalloc((size_t)NB * 8); CK(dbhip_memcpy_h2d(bk_d, bk.data(), (size_t)NB * 8, nullptr));
+    dbhip_join* J; CK(dbhip_join_create(NB, &J)); CK(dbhip_join_add_build(J, bk_d, nullptr, NB, nullptr)); CK(dbhip_join_finalize(J, nullptr));
+    // probe keys: qty / 100 * 40000 + disc ... keep it simple: reuse `price` (90000 .. 10.5 M): keys below 2 Mi that are even match
+    std::vector<uint32_t*> pi(TMAX), bi(TMAX);
+    for (int t = 0; t < TMAX; ++t) { const int64_t cap = t == 0 ? N : (16 << 20); pi[t] = (uint32_t*)dalloc((size_t)cap * 4); bi[t] = (uint32_t*)dalloc((size_t)cap * 4); }
+    for (int rep = 0; rep < 2; ++rep)
+      for (int64_t B : sizes)
+        for (int T : threads) {
+          if (B >= N && T > 1) continue;
+          int64_t calls = 0;
+          double secs = run_blocks(N, B, T, [&](int t, void* s, int64_t row0, int64_t n) {
+            dbhip_col a = col(DBHIP_T_DATE, li.ship + row0), b = col(DBHIP_T_DATE, cut_d); b.is_scalar = 1;
+            CK(dbhip_cmp(DBHIP_CMP_LTE, &a, &b, n, bm[t], s));
+            CK(dbhip_filter_select(bm[t], 0, n, sel[t], cnt[t], s));
+            uint64_t k = 0; CK(dbhip_memcpy_d2h(&k, cnt[t], 8, s)); CK(dbhip_stream_sync(s));
+            CK(dbhip_take(li.qty + row0, 8, sel[t], (int64_t)k, o8[t], s));
+          }, &calls);
+          if (rep) report({"filter_take", B, T, secs, N, calls, true, "cmp + filter_select + count read-back + take of one 8-byte column"});
+          secs = run_blocks(N, B, T, [&](int t, void* s, int64_t row0, int64_t n) {
+            dbhip_col one = col(DBHIP_T_U8, one_d); one.is_scalar = 1;
+            dbhip_col disc = col(DBHIP_T_DEC64, li.disc + row0, 15, 2), price = col(DBHIP_T_DEC64, li.price + row0, 15, 2);
+            CK(dbhip_decimal_arith(1, &one, &disc, n, p1 <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128, p1, s1, d64[t], nullptr, nullptr, s));
+            dbhip_col om = col(DBHIP_T_DEC64, d64[t], p1, s1);
+            CK(dbhip_decimal_arith(2, &price, &om, n, p2 <= 18 ? DBHIP_T_DEC64 : DBHIP_T_DEC128, p2, s2, d128[t], nullptr, nullptr, s));
+          }, &calls);
+          if (rep) report({"decimal_map", B, T, secs, N, calls, true, "price * (1 - discount): two dbhip_decimal_arith calls"});
+          secs = run_blocks(N, B, T, [&](int t, void* s, int64_t row0, int64_t n) {
+            uint64_t total = 0, np = 0;
+            CK(dbhip_join_probe_count(J, li.price + row0, nullptr, n, &total, s));
+            CK(dbhip_join_probe(J, li.price + row0, nullptr, n, pi[t], bi[t], (int64_t)total, &np, s));
+          }, &calls);
+          if (rep) report({"join_probe", B, T, secs, N, calls, true, "probe_count + probe against 1 Mi build keys"});
+        }
+    CK(dbhip_join_destroy(J));
+  }
+
+  FILE* f = out ? fopen(out, "w") : stdout;
+  fprintf(f, "{\"what\": \"block-size sweep through the C-ABI (databend_amd/host/block_sweep.cpp)\", \"rows\": %lld, \"row_bytes_q1\": 68,\n \"lines\": [\n", (long long)N);
+  for (size_t i = 0; i < g_lines.size(); ++i) {
+    const Line& l = g_lines[i];
+    fprintf(f, "  {\"op\": \"%s\", \"block_rows\": %lld, \"threads\": %d, \"ms\": %.3f, \"g_rows_per_s\": %.3f, \"calls\": %lld, \"us_per_call_per_thread\": %.2f, \"equals_whole_table\": %s, \"note\": \"%s\"}%s\n",
+            l.op.c_str(), (long long)l.block, l.threads, l.secs * 1e3, l.rows / l.secs / 1e9, (long long)l.calls,
+            l.secs / (double)(l.calls ? l.calls : 1) * 1e6 * l.threads, l.ok ? "true" : "false", l.note.c_str(), i + 1 < g_lines.size() ? "," : "");
+  }
+  fprintf(f, " ]}\n");
+  if (out) fclose(f);
+  for (const Line& l : g_lines) if (!l.ok) return 1;
+  return 0;
+}

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DBHIP_ABI_VERSION 5   /* 5 (round 5): ZSTD on the device, batched chunk decode (dbhip_pq_chunks_decode_device); 4 (round 4): block scatter / concat, exchange and plan calls, device-mode scan, cancellation, row-wise vector distance */
+#define DBHIP_ABI_VERSION 6   /* 6 (round 6): pipelined fused aggregation (dbhip_groupby_set_pipelined / dbhip_groupby_checkpoint); 5 (round 5): ZSTD on the device, batched chunk decode (dbhip_pq_chunks_decode_device); 4 (round 4): block scatter / concat, exchange and plan calls, device-mode scan, cancellation, row-wise vector distance */
 
 /* ---- status codes ------------------------------------------------------- */
 enum {
@@ -502,6 +502,26 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
  * never waits for a compiler. If the kernel cannot be built the interpreter stays (DBHIP_OK either way).
  * env DBHIP_FAGG_JIT=0 disables, =sync compiles on first use instead. */
 int32_t dbhip_groupby_prepare_program(dbhip_groupby* g, const dbhip_col* keys, const dbhip_agg_program* prog);
+/* PIPELINED fused aggregation (round 6): the call shape for a host that hands over the reference's own DataBlocks — <= 65,536
+ * rows each (max_block_size, src/query/settings/src/settings_default.rs:142-148), one TransformPartialAggregate::transform per
+ * block (transform_aggregate_partial.rs:262-270). At that size the kernel is a few microseconds of work and a synchronous call is
+ * all round trip. After set_pipelined(g, 1) a dbhip_groupby_add_block_program call queues ONE kernel launch and returns: the
+ * partial rows of successive blocks are appended to a buffer the table owns, merged window by window by kernels queued behind
+ * them, and nothing is read back (argument / program errors are still returned by the call itself).
+ * dbhip_groupby_checkpoint drains the table's stream and reports what a synchronous call would have: DBHIP_OK, or
+ * DBHIP_ERR_CAPACITY / DBHIP_ERR_ROW_ERRORS / DBHIP_ERR_UNSUPPORTED with *out_blocks_committed_host = the number of blocks (counted
+ * from the previous checkpoint, in call order) that WERE merged. Windows commit in order, and a window in which any block raised a
+ * flag — and every block queued behind it — merges nothing: blocks [committed, queued) go to the operator-at-a-time path exactly
+ * like a block the synchronous call gave back. (A "fifth group in one workgroup" give-up of the 4-slot kernel is replayed inside the
+ * checkpoint with the 8-slot kernel first, as the synchronous call's second pass does.)
+ * Contract: the blocks' buffers (columns, validity, filter Bitmaps) stay alive and unchanged until the checkpoint — they are
+ * inputs of queued kernels; one stream per pipelined table between checkpoints (the reference's partial tables are per pipeline
+ * thread as well). Every other entry point that reads or changes the table's groups (flush_*, num_groups, merge_*, plain
+ * add_block, the exchange calls) checkpoints first and returns the checkpoint's error if there is one; dbhip_groupby_reset drops
+ * queued blocks with the groups. set_pipelined(g, 0) checkpoints and returns to synchronous calls.
+ * Measured (profiles/r06_block_size_sweep.json): DESIGN.md 2.2b. */
+int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream);
+int32_t dbhip_groupby_checkpoint(dbhip_groupby* g, int64_t* out_blocks_committed_host, void* stream);
 /* combine_payload (:349-380): merge serialized partial states (as produced by
  * dbhip_groupby_flush_serialized on any rank) into this table. */
 int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(_lib.SYMBOLS) == syms, set(_lib.SYMBOLS) ^ set(syms)
-    assert L.dbhip_abi_version() == 5
+    assert L.dbhip_abi_version() == 6
 
 
 def test_no_cpu_fallback_without_device():
@@ -100,5 +100,5 @@ def test_rust_binding_file_matches_the_header():
         body = re.search(r"pub struct %s \{(.*?)\}" % rust_name, text, flags=re.S).group(1)
         fields = [f.replace("r#", "") for f in re.findall(r"pub (\S+):", body)]
         assert fields == [f[0] for f in ct._fields_], (rust_name, fields)
-    for const, val in (("DBHIP_T_DEC256", 17), ("DBHIP_ERR_UNSUPPORTED", 7), ("DBHIP_AGG_MAX", 3), ("DBHIP_ABI_VERSION", 5)):
+    for const, val in (("DBHIP_T_DEC256", 17), ("DBHIP_ERR_UNSUPPORTED", 7), ("DBHIP_AGG_MAX", 3), ("DBHIP_ABI_VERSION", 6)):
         assert re.search(r"pub const %s: i32 = %d;" % (const, val), text), const
