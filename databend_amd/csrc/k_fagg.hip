@@ -635,8 +635,8 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
   if (jf) {
     size_t asz = sizeof(A);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)&A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-    // (LDS: only the staging of one group's accumulators at the end — the register file is in VGPRs)
-    DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, (unsigned)((size_t)nwords * 256 * 8), s, nullptr, extra));
+    // (no dynamic LDS: the register file is in VGPRs, and since round 6 the end of the kernel folds in registers too)
+    DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra));
     ++g_fa_jit_launches;
     return DBHIP_OK;
   }
@@ -667,7 +667,7 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 // costs ONE kernel launch and no synchronisation:
 //   * the partial rows of successive blocks are APPENDED to a buffer the table owns (cursor, give-up flags and the row-error count
 //     live on the device and are sticky);
-//   * when the buffer could overflow (the host keeps an upper bound: workgroups x 4 waves x 8 slots per block) the merge of the
+//   * when the buffer could overflow (the host keeps an upper bound: workgroups x 8 slots per block) the merge of the
 //     whole window is queued behind the kernels — seal (row errors -> flag), probe / accumulate / retry with the row count and the
 //     abort flags still on the device, commit (cursor back to 0, the window's blocks counted as committed unless a flag is up);
 //     the commit kernel writes the table's group count into mapped host memory, from which the host bounds the table's fill without
@@ -765,7 +765,7 @@ int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s
     return DBHIP_ERR_INVALID;
   }
   pp->bound = true; pp->stream = s;
-  const int64_t n_max = (int64_t)P.grid * 4 * FA_MAX_SLOTS;
+  const int64_t n_max = (int64_t)P.grid * FA_MAX_SLOTS;   // one partial row per (workgroup, slot)
   if (n_max > pp->cap_rows) { set_error("dbhip_groupby_add_block_program: grid too large for the pipeline's row buffer"); return DBHIP_ERR_INVALID; }
   // a window closes when the row buffer could overflow, and after FA_PIPE_WINDOW blocks at the latest: that bounds what one raised
   // flag gives back to the caller (and the launch arguments kept for a replay) while one merge still serves dozens of launches
@@ -913,7 +913,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     int64_t committed = 0;         // a synchronous call on a table that still has queued blocks: those first
     if ((rc = fa_pipe_checkpoint(g, pp, &committed, true))) return rc;
   }
-  const size_t rows_bytes = (size_t)grid * 4 * FA_MAX_SLOTS * L.W * 8;
+  const size_t rows_bytes = (size_t)grid * FA_MAX_SLOTS * L.W * 8;   // one partial row per (workgroup, slot)
   uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 6, s);
   if (!ws) return DBHIP_ERR_HIP;
   uint64_t* ctrl = (uint64_t*)ws;
@@ -924,7 +924,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   uint64_t* host_ctrl = pinned_words(1);   // read back asynchronously while the merge is queued behind the kernel
   if (!host_ctrl) return DBHIP_ERR_HIP;
   host_ctrl[0] = host_ctrl[1] = host_ctrl[2] = 0;
-  const int64_t n_max = (int64_t)grid * 4 * FA_MAX_SLOTS;
+  const int64_t n_max = (int64_t)grid * FA_MAX_SLOTS;
   const bool chained = (dbhip_groupby_count_internal(g) + n_max) * 135 <= dbhip_groupby_capacity_internal(g) * 100;
   if ((rc = dbhip_groupby_reserve_merge_internal(g, n_max))) return rc;
   static const bool no_chain = getenv("DBHIP_FAGG_NOCHAIN") != nullptr;   // debugging: drain the stream between kernel and merge
@@ -991,7 +991,7 @@ int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream) 
   pp = new (std::nothrow) FaPipe();
   DBHIP_REQUIRE(pp, "dbhip_groupby_set_pipelined: out of host memory");
   hipStream_t s = resolve_stream(stream);
-  // 65,536 partial rows: 4 blocks of the largest grid (512 workgroups x 4 waves x 8 slots), ~24 blocks of 65,536 input rows
+  // 65,536 partial rows: 16 blocks of the largest grid (512 workgroups x 8 slots); small blocks close their window by count (FA_PIPE_WINDOW)
   pp->cap_rows = 65536;
   int32_t rc = dbhip_alloc((size_t)pp->cap_rows * L.W * 8, (void**)&pp->rows);
   hipError_t e = rc == DBHIP_OK ? hipMalloc((void**)&pp->ctrl, 64) : hipSuccess;

@@ -151,12 +151,13 @@ static Q1Result q1_result(dbhip_groupby* g) {
   return r;
 }
 
-struct Line { std::string op; int64_t block; int threads; double secs; int64_t rows; int64_t calls; bool ok; std::string note; };
+struct Line { std::string op; int64_t block; int threads; double secs; int64_t rows; int64_t calls; bool ok; std::string note; double host_us = 0; };
+static double g_host_us = 0;   // of the last run_q1: mean host time inside one add_block_program call
 static std::vector<Line> g_lines;
 static void report(const Line& l) {
   g_lines.push_back(l);
-  fprintf(stderr, "%-18s block %10lld threads %d : %8.3f ms  %8.2f G rows/s  %8.2f us/call  %s %s\n", l.op.c_str(), (long long)l.block, l.threads,
-          l.secs * 1e3, l.rows / l.secs / 1e9, l.secs / (double)(l.calls ? l.calls : 1) * 1e6 * l.threads, l.ok ? "ok" : "MISMATCH", l.note.c_str());
+  fprintf(stderr, "%-18s block %10lld threads %d : %8.3f ms  %8.2f G rows/s  %8.2f us/call (%6.2f us inside the call)  %s %s\n", l.op.c_str(), (long long)l.block, l.threads,
+          l.secs * 1e3, l.rows / l.secs / 1e9, l.secs / (double)(l.calls ? l.calls : 1) * 1e6 * l.threads, l.host_us, l.ok ? "ok" : "MISMATCH", l.note.c_str());
 }
 
 enum Q1Mode { Q1_SYNC = 0, Q1_PIPE = 1, Q1_SQUASH = 2, Q1_SQUASH_PIPE = 3 };
@@ -183,6 +184,7 @@ static double run_q1(const Lineitem& li, int64_t B, int T, Q1Mode mode, int64_t 
   std::atomic<bool> go{false};
   std::vector<double> t_end(T, 0.0);
   std::vector<int64_t> calls(T, 0);
+  std::vector<double> in_call(T, 0.0);
   double t_start = 0;
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
@@ -198,7 +200,9 @@ static double run_q1(const Lineitem& li, int64_t B, int T, Q1Mode mode, int64_t 
       for (int64_t b = t; b < nblocks; b += T) {
         const int64_t row0 = b * B, n = row0 + B <= li.n ? B : li.n - row0;
         P.build(li, row0);
+        const double c0 = now_s();
         CK(dbhip_groupby_add_block_program(g, P.keys, &P.ap, n, nullptr, 0, s));
+        in_call[t] += now_s() - c0;
         ++calls[t];
       }
     } else {
@@ -249,6 +253,7 @@ static double run_q1(const Lineitem& li, int64_t B, int T, Q1Mode mode, int64_t 
   *ok = got.groups == expect.groups && got.words == expect.words;
   *calls_out = 0;
   for (int t = 0; t < T; ++t) *calls_out += calls[t];
+  { double tot = 0; for (int t = 0; t < T; ++t) tot += in_call[t]; g_host_us = *calls_out ? tot / (double)*calls_out * 1e6 : 0; }
   for (int t = 0; t < T; ++t) { CK(dbhip_groupby_destroy(tables[t])); CK(dbhip_stream_destroy(streams[t])); }
   for (auto& S : staging) { dbhip_free(S.qty); dbhip_free(S.price); dbhip_free(S.disc); dbhip_free(S.tax); dbhip_free(S.ship); dbhip_free(S.rf); dbhip_free(S.ls); }
   return secs;
@@ -288,11 +293,12 @@ static double run_blocks(int64_t total, int64_t B, int T, F fn, int64_t* calls_o
 int main(int argc, char** argv) {
   int64_t N = 64LL << 20;
   const char* out = nullptr;
-  bool quick = false;
+  bool quick = false, only_q1 = false;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--rows") && i + 1 < argc) N = atoll(argv[++i]);
     else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
     else if (!strcmp(argv[i], "--quick")) quick = true;
+    else if (!strcmp(argv[i], "--only-q1")) only_q1 = true;
   }
   CK(dbhip_init(0));
   fprintf(stderr, "generating %lld lineitem rows ...\n", (long long)N);
@@ -320,10 +326,12 @@ int main(int argc, char** argv) {
         for (Q1Mode mode : {Q1_SYNC, Q1_PIPE}) {
           bool ok = false; int64_t calls = 0;
           const double secs = run_q1(li, B, T, mode, 0, expect, &ok, &calls);
-          report({mode == Q1_SYNC ? "q1_sync" : "q1_pipelined", B, T, secs, N, calls, ok, ""});
+          Line l{mode == Q1_SYNC ? "q1_sync" : "q1_pipelined", B, T, secs, N, calls, ok, ""};
+          l.host_us = g_host_us;
+          report(l);
         }
       }
-    for (int T : threads)
+    if (!only_q1) for (int T : threads)
       for (int64_t S : {(int64_t)1 << 20, (int64_t)4 << 20})
         for (Q1Mode mode : {Q1_SQUASH, Q1_SQUASH_PIPE}) {
           bool ok = false; int64_t calls = 0;
@@ -333,7 +341,7 @@ int main(int argc, char** argv) {
   }
 
   // ---- the other per-block operators (each thread its own output buffers, sized for the largest block) ----
-  {
+  if (!only_q1) {
     const int TMAX = 8;
     std::vector<uint8_t*> bm(TMAX); std::vector<uint32_t*> sel(TMAX); std::vector<uint64_t*> cnt(TMAX); std::vector<int64_t*> o8(TMAX);
     std::vector<void*> d64(TMAX), d128(TMAX);
@@ -389,9 +397,9 @@ int main(int argc, char** argv) {
   fprintf(f, "{\"what\": \"block-size sweep through the C-ABI (databend_amd/host/block_sweep.cpp)\", \"rows\": %lld, \"row_bytes_q1\": 68,\n \"lines\": [\n", (long long)N);
   for (size_t i = 0; i < g_lines.size(); ++i) {
     const Line& l = g_lines[i];
-    fprintf(f, "  {\"op\": \"%s\", \"block_rows\": %lld, \"threads\": %d, \"ms\": %.3f, \"g_rows_per_s\": %.3f, \"calls\": %lld, \"us_per_call_per_thread\": %.2f, \"equals_whole_table\": %s, \"note\": \"%s\"}%s\n",
+    fprintf(f, "  {\"op\": \"%s\", \"block_rows\": %lld, \"threads\": %d, \"ms\": %.3f, \"g_rows_per_s\": %.3f, \"calls\": %lld, \"us_per_call_per_thread\": %.2f, \"host_us_inside_call\": %.2f, \"equals_whole_table\": %s, \"note\": \"%s\"}%s\n",
             l.op.c_str(), (long long)l.block, l.threads, l.secs * 1e3, l.rows / l.secs / 1e9, (long long)l.calls,
-            l.secs / (double)(l.calls ? l.calls : 1) * 1e6 * l.threads, l.ok ? "true" : "false", l.note.c_str(), i + 1 < g_lines.size() ? "," : "");
+            l.secs / (double)(l.calls ? l.calls : 1) * 1e6 * l.threads, l.host_us, l.ok ? "true" : "false", l.note.c_str(), i + 1 < g_lines.size() ? "," : "");
   }
   fprintf(f, " ]}\n");
   if (out) fclose(f);
