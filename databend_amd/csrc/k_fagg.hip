@@ -115,9 +115,9 @@ int jit_rows(const FaArgs& A) {
     if (A.P.ins[i].op == EX_DEC && dec_op_needs_division(A.P.dec[A.P.ins[i].dec_idx])) return 3;
   return bytes >= 64 ? 3 : (bytes >= 32 ? 8 : 16);
 }
-std::string jit_meta(const FaArgs& A) {
+std::string jit_meta(const FaArgs& A, bool multi = false) {
   JitOut o;
-  o.s = "#define FA_META_ROWS " + std::to_string(jit_rows(A)) + "\nstatic constexpr FaArgs kM = {";
+  o.s = std::string(multi ? "#define FA_MULTI 1\n" : "") + "#define FA_META_ROWS " + std::to_string(jit_rows(A)) + "\nstatic constexpr FaArgs kM = {";
   const ExProg& P = A.P;
   o.open();                                                           // ExProg
   o.open(); for (int i = 0; i < EX_MAX_INS; ++i) jit_ins(o, P.ins[i]); o.close();
@@ -145,6 +145,7 @@ std::string jit_meta(const FaArgs& A) {
   o.num(A.naggs); o.num(A.nwords); o.num(A.state_off);
   o.open(); for (int w = 0; w < FA_MAXW; ++w) o.num(A.wm[w]); o.close();
   o.null(); o.num(0); o.num(0); o.null(); o.null();
+  o.null(); o.num(0); o.num(0);   // blocks, wgs_per_block, _pad
   o.s += "};\n";
   return o.s;
 }
@@ -412,7 +413,16 @@ enum { JIT_LOOKUP = 0, JIT_COMPILE = 1, JIT_BACKGROUND = 2 };
 // -> the specialised kernel of (shape, variant), or nullptr. how = JIT_LOOKUP: only what the in-process cache or the on-disk
 // cache holds; JIT_COMPILE: compile now if needed (PREPARE; blocks ~0.5 s); JIT_BACKGROUND: if it is nowhere yet, start the
 // compile in a detached helper and return nullptr now — *pending says so, a later call finds the result on disk.
-hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int how, bool* pending = nullptr) {
+// the binary image of a query shape: FaArgs with everything that varies between calls of one shape zeroed (the fields jit_meta prints
+// as null / 0)
+void fa_shape(const FaArgs& A, FaArgs& K) {
+  K = A;
+  for (int i = 0; i < EX_MAX_INPUTS; ++i) { K.P.in_data[i] = nullptr; K.P.in_valid[i] = nullptr; K.P.in_voff[i] = 0; }
+  K.P.err_words = nullptr; K.P.err_count = nullptr;
+  for (int k = 0; k < FA_KW; ++k) { K.key[k].data = nullptr; K.key[k].validity = nullptr; K.key[k].voff = 0; K.key[k].buffers = nullptr; }
+  K.filter_bits = nullptr; K.filter_off = 0; K.n = 0; K.partial_rows = nullptr; K.ctrl = nullptr; K.blocks = nullptr; K.wgs_per_block = 0;
+}
+hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int how, bool* pending = nullptr, bool multi = false) {
   if (pending) *pending = false;
   const int mode = jit_mode();
   if (mode == 0) return nullptr;
@@ -420,15 +430,12 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   // in-process key: the binary image of the query shape (FaArgs with everything that varies between calls of one shape
   // zeroed — the fields jit_meta prints as null / 0), the variant, the experiment knobs and the device the module is loaded
   // on. (Generating the metadata TEXT per call to look the kernel up cost 0.25 ms of host time per launch.)
-  FaArgs K = A;
-  for (int i = 0; i < EX_MAX_INPUTS; ++i) { K.P.in_data[i] = nullptr; K.P.in_valid[i] = nullptr; K.P.in_voff[i] = 0; }
-  K.P.err_words = nullptr; K.P.err_count = nullptr;
-  for (int k = 0; k < FA_KW; ++k) { K.key[k].data = nullptr; K.key[k].validity = nullptr; K.key[k].voff = 0; K.key[k].buffers = nullptr; }
-  K.filter_bits = nullptr; K.filter_off = 0; K.n = 0; K.partial_rows = nullptr; K.ctrl = nullptr;
+  FaArgs K;
+  fa_shape(A, K);
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::string key((const char*)&K, sizeof(K));
-  key += "|" + std::to_string(slots) + "|" + std::to_string((int)general) + "|" + std::to_string(nw) + "|" + std::to_string(dev) + "|";
+  key += "|" + std::to_string(slots) + "|" + std::to_string((int)general) + "|" + std::to_string(nw) + "|" + std::to_string(dev) + "|" + (multi ? "m|" : "|");
   key += getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
   const bool trace = getenv("DBHIP_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_jit_mu);
@@ -445,7 +452,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   }
   JitEntry& e = g_jit_cache[key];
   e.checked = now;
-  const std::string meta = jit_meta(A), tail = jit_tail(slots, general, nw);
+  const std::string meta = jit_meta(A, multi), tail = jit_tail(slots, general, nw);
   std::vector<char> code;
   std::string log;
   bool have = false;
@@ -521,7 +528,7 @@ bool dbhip_fagg_layout_ok_internal(const GbLayout& L) {
 }
 
 // launches by kind since the library was loaded (tests and benches tell which kernel a call went through)
-static std::atomic<uint64_t> g_fa_jit_launches{0}, g_fa_interp_launches{0}, g_fa_pending_refusals{0};
+static std::atomic<uint64_t> g_fa_jit_launches{0}, g_fa_interp_launches{0}, g_fa_pending_refusals{0}, g_fa_multi_blocks{0};
 extern "C" int32_t dbhip_fagg_stats(uint64_t* out3_host) {
   DBHIP_REQUIRE(out3_host, "dbhip_fagg_stats: NULL argument");
   out3_host[0] = g_fa_jit_launches.load(); out3_host[1] = g_fa_interp_launches.load(); out3_host[2] = g_fa_pending_refusals.load();
@@ -682,6 +689,9 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int FA_PIPE_WINDOW = 32;
+constexpr int FA_PIPE_RING = 8;
+constexpr int64_t FA_PIPE_BIG = 1 << 20;          // a block of this many rows is a launch of its own
+constexpr int64_t FA_PIPE_BATCH_ROWS = 4 << 20;   // rows after which a batch goes without waiting for more blocks
 struct FaPending { FaArgs A; int grid; size_t lds; bool general; int nwords; };
 struct FaMerge { uint64_t seq; int64_t rows_ub; int64_t blocks; };
 struct FaPipe {
@@ -698,6 +708,16 @@ struct FaPipe {
   int64_t count_seen = 0;            // groups after the last merge seen finished
   std::deque<FaPending> retained;    // launch arguments of the blocks [retained_base, submitted) since the last checkpoint
   int64_t retained_base = 0, submitted = 0;
+  // multi-block launches: blocks below FA_PIPE_BIG rows wait here until FA_PIPE_WINDOW of them (or FA_PIPE_BATCH_ROWS rows) can go
+  // in ONE launch; their pointer tables travel through a ring of pinned staging / device buffers
+  std::vector<FaPending> batch;
+  int64_t batch_rows = 0;
+  FaArgs batch_shape;
+  FaBlock* tab_host[FA_PIPE_RING] = {};
+  FaBlock* tab_dev[FA_PIPE_RING] = {};
+  hipEvent_t tab_ev[FA_PIPE_RING] = {};
+  bool tab_used[FA_PIPE_RING] = {};
+  int tab_next = 0;
 };
 
 __global__ void fa_pipe_seal_kernel(uint64_t* ctrl) {
@@ -787,16 +807,99 @@ int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s
   return DBHIP_OK;
 }
 
+// Launches the queued blocks together (see FaBlock). Needs the FA_MULTI specialisation of the shape: while that is being compiled
+// (or cannot be), the blocks go one launch each.
+int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
+  if (pp->batch.empty()) return DBHIP_OK;
+  std::vector<FaPending> blocks;
+  blocks.swap(pp->batch);
+  pp->batch_rows = 0;
+  hipStream_t s = pp->stream;
+  const int nb = (int)blocks.size();
+  const int slots = (pp->slots8 || pp->count_seen > 4) ? 8 : 4;
+  hipFunction_t jf = nb > 1 ? jit_kernel(blocks[0].A, slots, blocks[0].general, blocks[0].nwords, JIT_BACKGROUND, nullptr, true) : nullptr;
+  if (!jf) {
+    for (FaPending& P : blocks) { const int32_t rc = fa_pipe_submit(g, pp, P, s); if (rc) return rc; }
+    return DBHIP_OK;
+  }
+  const int64_t rpw = 64 * (int64_t)jit_rows(blocks[0].A);
+  int64_t max_chunks = 1;
+  for (const FaPending& P : blocks) { const int64_t c = ceil_div(P.A.n, rpw); max_chunks = c > max_chunks ? c : max_chunks; }
+  int wpb = (int)(ceil_div(max_chunks, 4) < 512 / nb ? ceil_div(max_chunks, 4) : 512 / nb);
+  if (wpb < 1) wpb = 1;
+  const int grid = wpb * nb;
+  const int64_t n_max = (int64_t)grid * FA_MAX_SLOTS;
+  if (pp->rows_ub + n_max > pp->cap_rows || pp->window_blocks >= FA_PIPE_WINDOW) {
+    const int32_t rc = fa_pipe_queue_merge(g, pp);
+    if (rc) return rc;
+  }
+  const int slot = pp->tab_next;
+  pp->tab_next = (pp->tab_next + 1) % FA_PIPE_RING;
+  if (pp->tab_used[slot]) DBHIP_CHECK(hipEventSynchronize(pp->tab_ev[slot]));   // the copy that last read this staging buffer has run
+  FaBlock* T = pp->tab_host[slot];
+  for (int i = 0; i < nb; ++i) {
+    const FaArgs& A = blocks[i].A;
+    memset(&T[i], 0, sizeof(FaBlock));
+    for (int c = 0; c < EX_MAX_INPUTS; ++c) { T[i].in_data[c] = A.P.in_data[c]; T[i].in_valid[c] = A.P.in_valid[c]; T[i].in_voff[c] = A.P.in_voff[c]; }
+    for (int k = 0; k < FA_KW; ++k) { T[i].key_data[k] = A.key[k].data; T[i].key_valid[k] = A.key[k].validity; T[i].key_voff[k] = A.key[k].voff; }
+    T[i].filter_bits = A.filter_bits; T[i].filter_off = A.filter_off; T[i].n = A.n;
+  }
+  DBHIP_CHECK(hipMemcpyAsync(pp->tab_dev[slot], T, (size_t)nb * sizeof(FaBlock), hipMemcpyHostToDevice, s));
+  DBHIP_CHECK(hipEventRecord(pp->tab_ev[slot], s));
+  pp->tab_used[slot] = true;
+  FaArgs A = blocks[0].A;
+  A.ctrl = pp->ctrl; A.partial_rows = pp->rows;
+  A.P.err_words = nullptr; A.P.err_count = (unsigned long long*)&pp->ctrl[2];
+  A.blocks = pp->tab_dev[slot]; A.wgs_per_block = wpb;
+  size_t asz = sizeof(A);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)&A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+  DBHIP_CHECK(hipModuleLaunchKernel(jf, grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra));
+  g_fa_jit_launches += 1;
+  g_fa_multi_blocks += (uint64_t)nb;
+  pp->rows_ub += n_max;
+  pp->window_blocks += nb;
+  pp->submitted += nb;
+  for (FaPending& P : blocks) pp->retained.push_back(P);
+  return DBHIP_OK;
+}
+
+// a block enters a pipelined table: large ones are launched at once, small ones wait for company
+int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s) {
+  if (pp->bound && pp->stream != s) {
+    set_error("dbhip_groupby_add_block_program: a pipelined table takes its blocks on ONE stream (checkpoint before changing it)");
+    return DBHIP_ERR_INVALID;
+  }
+  pp->bound = true; pp->stream = s;
+  static const bool no_batch = getenv("DBHIP_FAGG_PIPE_BATCH") && atoi(getenv("DBHIP_FAGG_PIPE_BATCH")) == 0;
+  if (P.A.n >= FA_PIPE_BIG || no_batch || jit_mode() == 0) {
+    const int32_t rc = fa_pipe_flush_batch(g, pp);   // (blocks stay in call order)
+    return rc ? rc : fa_pipe_submit(g, pp, P, s);
+  }
+  FaArgs K;
+  fa_shape(P.A, K);
+  if (!pp->batch.empty() && (memcmp(&K, &pp->batch_shape, sizeof(K)) != 0 || P.general != pp->batch[0].general || P.nwords != pp->batch[0].nwords)) {
+    const int32_t rc = fa_pipe_flush_batch(g, pp);   // another query shape: its own launch
+    if (rc) return rc;
+  }
+  if (pp->batch.empty()) pp->batch_shape = K;
+  pp->batch.push_back(P);
+  pp->batch_rows += P.A.n;
+  if ((int)pp->batch.size() >= FA_PIPE_WINDOW || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
+  return DBHIP_OK;
+}
+
 void fa_pipe_forget(FaPipe* pp) {
+  pp->batch.clear(); pp->batch_rows = 0;
   pp->retained.clear(); pp->retained_base = 0; pp->submitted = 0; pp->merges.clear(); pp->rows_ub = 0; pp->window_blocks = 0;
 }
 
 int32_t fa_pipe_checkpoint(dbhip_groupby* g, FaPipe* pp, int64_t* out_committed, bool may_replay) {
   if (out_committed) *out_committed = 0;
-  if (!pp->bound || (pp->submitted == 0 && pp->window_blocks == 0)) return DBHIP_OK;
+  if (!pp->bound || (pp->submitted == 0 && pp->window_blocks == 0 && pp->batch.empty())) return DBHIP_OK;
   hipStream_t s = pp->stream;
-  int32_t rc = fa_pipe_queue_merge(g, pp);
+  int32_t rc = fa_pipe_flush_batch(g, pp);
   if (rc) return rc;
+  if ((rc = fa_pipe_queue_merge(g, pp))) return rc;
   uint64_t* h = pinned_words(2);
   if (!h) return DBHIP_ERR_HIP;
   DBHIP_CHECK(hipMemcpyAsync(h, pp->ctrl, 32, hipMemcpyDeviceToHost, s));
@@ -850,7 +953,7 @@ int32_t fa_pipe_checkpoint(dbhip_groupby* g, FaPipe* pp, int64_t* out_committed,
 // every other entry point that reads or changes a pipelined table's groups passes through here first (GB_DRAIN, k_groupby.hip)
 int32_t dbhip_fagg_pipe_drain_internal(dbhip_groupby* g, void* pipe, hipStream_t) {
   FaPipe* pp = (FaPipe*)pipe;
-  if (!pp->bound || (pp->submitted == 0 && pp->window_blocks == 0)) return DBHIP_OK;
+  if (!pp->bound || (pp->submitted == 0 && pp->window_blocks == 0 && pp->batch.empty())) return DBHIP_OK;
   int64_t committed = 0;
   return fa_pipe_checkpoint(g, pp, &committed, true);
 }
@@ -869,6 +972,11 @@ void dbhip_fagg_pipe_destroy_internal(void* pipe) {
   if (pp->rows) (void)dbhip_free(pp->rows);
   if (pp->ctrl) (void)hipFree(pp->ctrl);
   if (pp->status_host) (void)hipHostFree(pp->status_host);
+  for (int i = 0; i < FA_PIPE_RING; ++i) {
+    if (pp->tab_host[i]) (void)hipHostFree(pp->tab_host[i]);
+    if (pp->tab_dev[i]) (void)hipFree(pp->tab_dev[i]);
+    if (pp->tab_ev[i]) (void)hipEventDestroy(pp->tab_ev[i]);
+  }
   delete pp;
 }
 
@@ -908,7 +1016,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     if (pp->on && !t_jit_only) {   // pipelined: one launch, nothing read back (see above)
       FaPending P;
       P.A = A; P.grid = grid; P.lds = lds; P.general = general; P.nwords = nwords;
-      return fa_pipe_submit(g, pp, P, s);
+      return fa_pipe_enqueue(g, pp, P, s);
     }
     int64_t committed = 0;         // a synchronous call on a table that still has queued blocks: those first
     if ((rc = fa_pipe_checkpoint(g, pp, &committed, true))) return rc;
@@ -933,6 +1041,9 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     // 8-slot one when the table already holds more than 4 groups), launch nothing
     // (the specialised kernel is compiled for exactly `nwords` state words: no accumulator registers for words the layout lacks)
     (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nwords, JIT_COMPILE);
+    // a pipelined table launches its small blocks together: that kernel is a specialisation of its own (FA_MULTI)
+    if (FaPipe* pq = (FaPipe*)*dbhip_groupby_pipe_slot_internal(g); pq && pq->on)
+      (void)jit_kernel(A, dbhip_groupby_count_internal(g) > 4 ? 8 : 4, general, nwords, JIT_COMPILE, nullptr, true);
     return DBHIP_OK;
   }
   // a table that already holds more than 4 groups starts with the 8-slot variant
@@ -999,6 +1110,11 @@ int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream) 
   if (rc == DBHIP_OK && e == hipSuccess) e = hipHostGetDevicePointer((void**)&pp->status_dev, pp->status_host, 0);
   if (rc == DBHIP_OK && e == hipSuccess) { memset(pp->status_host, 0, 64); e = hipMemsetAsync(pp->ctrl, 0, 64, s); }
   if (rc == DBHIP_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+  for (int i = 0; i < FA_PIPE_RING && rc == DBHIP_OK && e == hipSuccess; ++i) {
+    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_WINDOW * sizeof(FaBlock), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_WINDOW * sizeof(FaBlock));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pp->tab_ev[i], hipEventDisableTiming);
+  }
   if (rc == DBHIP_OK && e == hipSuccess) rc = dbhip_groupby_reserve_merge_internal(g, pp->cap_rows);
   if (rc != DBHIP_OK || e != hipSuccess) {
     dbhip_fagg_pipe_destroy_internal(pp);
@@ -1113,7 +1229,9 @@ extern "C" int64_t dbhip_jit_offline(const int32_t* key_types, const uint8_t* ke
   if (fa_build_args(L, keys, prog, A, &general, &nwords, &may_raise)) return -2;
   std::vector<char> code;
   std::string log;
-  const bool ok = jit_compile(jit_meta(A), jit_tail(slots, general, nwords), &code, &log);
+  const bool multi = (slots & 0x100) != 0;   // slots | 0x100: the FA_MULTI specialisation (multi-block launches of a pipelined table)
+  slots &= 0xFF;
+  const bool ok = jit_compile(jit_meta(A, multi), jit_tail(slots, general, nwords), &code, &log);
   if (log_out && log_cap > 0) snprintf(log_out, (size_t)log_cap, "%s", log.c_str());
   if (!ok) return -1;
   if ((int64_t)code.size() <= code_cap) memcpy(code_out, code.data(), code.size());

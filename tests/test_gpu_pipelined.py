@@ -59,6 +59,7 @@ def test_q1_as_65536_row_blocks_from_four_threads_equals_the_oracle(gpu):
             check(lib().dbhip_stream_create(C.byref(stream)))
             g = tables[t]
             g.set_pipelined(True, stream=stream)
+            tpch.q1_fused_program(li, g, prepare=True)    # PREPARE: the specialised kernels of the shape, incl. the multi-block one
             keep = []
             for lo, hi in blocks[t::nthreads]:
                 s = _li_slice(D, li, lo, hi)
@@ -106,6 +107,9 @@ def test_pipelined_blocks_equal_numpy_incl_the_eight_slot_replay(gpu, groups):
     n, nb = 30_000, 37
     g = D.GroupBy([T.T_I64], AGGS)
     g.set_pipelined(True)
+    if groups != 6:   # PREPAREd: the blocks go 32 to a launch (FA_MULTI); groups == 6 leaves them to single launches + the background compile
+        ck, cx, p, regs, f = _small_program(D, np.zeros(1, np.int64), np.zeros(1, np.int64), flt=-5 * 10**8)
+        g.prepare_program([ck], p, regs, filter_reg=f)
     keep, ks, xs = [], [], []
     for b in range(nb):
         k = rng.integers(0, groups, n).astype(np.int64) * 1_000_003
@@ -135,6 +139,8 @@ def test_a_block_with_too_many_groups_is_given_back_with_the_blocks_behind_it(gp
     n, nb, bad = 65536, 100, 70
     g = D.GroupBy([T.T_I64], AGGS)
     g.set_pipelined(True)
+    ck, cx, p, regs, f = _small_program(D, np.zeros(1, np.int64), np.zeros(1, np.int64))
+    g.prepare_program([ck], p, regs)
     keep, ks, xs = [], [], []
     for b in range(nb):
         k = rng.integers(0, 200 if b == bad else 4, n).astype(np.int64)
