@@ -690,9 +690,14 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 namespace {
 constexpr int FA_PIPE_WINDOW = 32;
 constexpr int FA_PIPE_RING = 8;
-constexpr int64_t FA_PIPE_BIG = 1 << 20;          // a block of this many rows is a launch of its own
-constexpr int64_t FA_PIPE_BATCH_ROWS = 4 << 20;   // rows after which a batch goes without waiting for more blocks
-struct FaPending { FaArgs A; int grid; size_t lds; bool general; int nwords; };
+constexpr int64_t FA_PIPE_BIG = 8 << 20;          // a block of this many rows is a launch of its own
+constexpr int64_t FA_PIPE_BATCH_ROWS = 8 << 20;   // rows after which a batch goes without waiting for more blocks
+// A query shape as the pipeline keeps it: the compiled launch arguments with every per-block pointer null, and the bytes the shape
+// was recognised by (`sig`: program, column types / scalar-ness / validity-ness, argument registers). A block is then 328 bytes: its
+// pointers and its shape's index — the per-call host work of a pipelined table is one signature compare and one FaBlock fill
+// (compiling the program and copying the 4 KB argument block per call was 3 us of a 65,536-row call, 21 G rows/s per thread at most).
+struct FaShape { FaArgs A; bool general; int nwords; size_t lds; std::string sig; };
+struct FaPending { int shape; FaBlock b; };
 struct FaMerge { uint64_t seq; int64_t rows_ub; int64_t blocks; };
 struct FaPipe {
   bool on = false, bound = false, slots8 = false;
@@ -712,7 +717,7 @@ struct FaPipe {
   // in ONE launch; their pointer tables travel through a ring of pinned staging / device buffers
   std::vector<FaPending> batch;
   int64_t batch_rows = 0;
-  FaArgs batch_shape;
+  std::vector<FaShape> shapes;       // shapes of the blocks since the last checkpoint (normally one)
   FaBlock* tab_host[FA_PIPE_RING] = {};
   FaBlock* tab_dev[FA_PIPE_RING] = {};
   hipEvent_t tab_ev[FA_PIPE_RING] = {};
@@ -779,13 +784,21 @@ int32_t fa_pipe_queue_merge(dbhip_groupby* g, FaPipe* pp) {
   return DBHIP_OK;
 }
 
-int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s) {
-  if (pp->bound && pp->stream != s) {
-    set_error("dbhip_groupby_add_block_program: a pipelined table takes its blocks on ONE stream (checkpoint before changing it)");
-    return DBHIP_ERR_INVALID;
-  }
-  pp->bound = true; pp->stream = s;
-  const int64_t n_max = (int64_t)P.grid * FA_MAX_SLOTS;   // one partial row per (workgroup, slot)
+// the launch arguments of one block: its shape with the block's pointers put back
+void fa_pipe_args(const FaPipe* pp, const FaPending& P, FaArgs& A) {
+  A = pp->shapes[(size_t)P.shape].A;
+  for (int c = 0; c < EX_MAX_INPUTS; ++c) { A.P.in_data[c] = P.b.in_data[c]; A.P.in_valid[c] = P.b.in_valid[c]; A.P.in_voff[c] = P.b.in_voff[c]; }
+  for (int k = 0; k < FA_KW; ++k) { A.key[k].data = P.b.key_data[k]; A.key[k].validity = P.b.key_valid[k]; A.key[k].voff = P.b.key_voff[k]; }
+  A.filter_bits = P.b.filter_bits; A.filter_off = P.b.filter_off; A.n = P.b.n;
+}
+// one block, one launch
+int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStream_t s) {
+  const FaShape& S = pp->shapes[(size_t)P.shape];
+  FaArgs A;
+  fa_pipe_args(pp, P, A);
+  const int64_t nchunks = ceil_div(A.n, 64 * FA_ROWS);
+  const int grid = (int)(ceil_div(nchunks, 4) < 512 ? ceil_div(nchunks, 4) : 512);
+  const int64_t n_max = (int64_t)grid * FA_MAX_SLOTS;   // one partial row per (workgroup, slot)
   if (n_max > pp->cap_rows) { set_error("dbhip_groupby_add_block_program: grid too large for the pipeline's row buffer"); return DBHIP_ERR_INVALID; }
   // a window closes when the row buffer could overflow, and after FA_PIPE_WINDOW blocks at the latest: that bounds what one raised
   // flag gives back to the caller (and the launch arguments kept for a replay) while one merge still serves dozens of launches
@@ -793,11 +806,11 @@ int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s
     const int32_t rc = fa_pipe_queue_merge(g, pp);
     if (rc) return rc;
   }
-  P.A.ctrl = pp->ctrl;
-  P.A.partial_rows = pp->rows;
-  P.A.P.err_words = nullptr;
-  P.A.P.err_count = (unsigned long long*)&pp->ctrl[2];
-  const int32_t rc = fa_launch(P.A, (pp->slots8 || pp->count_seen > 4) ? 8 : 4, P.general, P.nwords, P.grid, P.lds, s);
+  A.ctrl = pp->ctrl;
+  A.partial_rows = pp->rows;
+  A.P.err_words = nullptr;
+  A.P.err_count = (unsigned long long*)&pp->ctrl[2];
+  const int32_t rc = fa_launch(A, (pp->slots8 || pp->count_seen > 4) ? 8 : 4, S.general, S.nwords, grid, S.lds, s);
   if (rc) return rc;
   DBHIP_LAUNCH_CHECK();
   pp->rows_ub += n_max;
@@ -817,14 +830,15 @@ int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
   hipStream_t s = pp->stream;
   const int nb = (int)blocks.size();
   const int slots = (pp->slots8 || pp->count_seen > 4) ? 8 : 4;
-  hipFunction_t jf = nb > 1 ? jit_kernel(blocks[0].A, slots, blocks[0].general, blocks[0].nwords, JIT_BACKGROUND, nullptr, true) : nullptr;
+  const FaShape& S = pp->shapes[(size_t)blocks[0].shape];
+  hipFunction_t jf = nb > 1 ? jit_kernel(S.A, slots, S.general, S.nwords, JIT_BACKGROUND, nullptr, true) : nullptr;
   if (!jf) {
-    for (FaPending& P : blocks) { const int32_t rc = fa_pipe_submit(g, pp, P, s); if (rc) return rc; }
+    for (const FaPending& P : blocks) { const int32_t rc = fa_pipe_submit(g, pp, P, s); if (rc) return rc; }
     return DBHIP_OK;
   }
-  const int64_t rpw = 64 * (int64_t)jit_rows(blocks[0].A);
+  const int64_t rpw = 64 * (int64_t)jit_rows(S.A);
   int64_t max_chunks = 1;
-  for (const FaPending& P : blocks) { const int64_t c = ceil_div(P.A.n, rpw); max_chunks = c > max_chunks ? c : max_chunks; }
+  for (const FaPending& P : blocks) { const int64_t c = ceil_div(P.b.n, rpw); max_chunks = c > max_chunks ? c : max_chunks; }
   int wpb = (int)(ceil_div(max_chunks, 4) < 512 / nb ? ceil_div(max_chunks, 4) : 512 / nb);
   if (wpb < 1) wpb = 1;
   const int grid = wpb * nb;
@@ -837,17 +851,11 @@ int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
   pp->tab_next = (pp->tab_next + 1) % FA_PIPE_RING;
   if (pp->tab_used[slot]) DBHIP_CHECK(hipEventSynchronize(pp->tab_ev[slot]));   // the copy that last read this staging buffer has run
   FaBlock* T = pp->tab_host[slot];
-  for (int i = 0; i < nb; ++i) {
-    const FaArgs& A = blocks[i].A;
-    memset(&T[i], 0, sizeof(FaBlock));
-    for (int c = 0; c < EX_MAX_INPUTS; ++c) { T[i].in_data[c] = A.P.in_data[c]; T[i].in_valid[c] = A.P.in_valid[c]; T[i].in_voff[c] = A.P.in_voff[c]; }
-    for (int k = 0; k < FA_KW; ++k) { T[i].key_data[k] = A.key[k].data; T[i].key_valid[k] = A.key[k].validity; T[i].key_voff[k] = A.key[k].voff; }
-    T[i].filter_bits = A.filter_bits; T[i].filter_off = A.filter_off; T[i].n = A.n;
-  }
+  for (int i = 0; i < nb; ++i) T[i] = blocks[i].b;
   DBHIP_CHECK(hipMemcpyAsync(pp->tab_dev[slot], T, (size_t)nb * sizeof(FaBlock), hipMemcpyHostToDevice, s));
   DBHIP_CHECK(hipEventRecord(pp->tab_ev[slot], s));
   pp->tab_used[slot] = true;
-  FaArgs A = blocks[0].A;
+  FaArgs A = S.A;
   A.ctrl = pp->ctrl; A.partial_rows = pp->rows;
   A.P.err_words = nullptr; A.P.err_count = (unsigned long long*)&pp->ctrl[2];
   A.blocks = pp->tab_dev[slot]; A.wgs_per_block = wpb;
@@ -859,37 +867,29 @@ int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
   pp->rows_ub += n_max;
   pp->window_blocks += nb;
   pp->submitted += nb;
-  for (FaPending& P : blocks) pp->retained.push_back(P);
+  for (const FaPending& P : blocks) pp->retained.push_back(P);
   return DBHIP_OK;
 }
 
 // a block enters a pipelined table: large ones are launched at once, small ones wait for company
-int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, FaPending& P, hipStream_t s) {
-  if (pp->bound && pp->stream != s) {
-    set_error("dbhip_groupby_add_block_program: a pipelined table takes its blocks on ONE stream (checkpoint before changing it)");
-    return DBHIP_ERR_INVALID;
-  }
-  pp->bound = true; pp->stream = s;
+int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStream_t s) {
   static const bool no_batch = getenv("DBHIP_FAGG_PIPE_BATCH") && atoi(getenv("DBHIP_FAGG_PIPE_BATCH")) == 0;
-  if (P.A.n >= FA_PIPE_BIG || no_batch || jit_mode() == 0) {
+  if (P.b.n >= FA_PIPE_BIG || no_batch || jit_mode() == 0) {
     const int32_t rc = fa_pipe_flush_batch(g, pp);   // (blocks stay in call order)
     return rc ? rc : fa_pipe_submit(g, pp, P, s);
   }
-  FaArgs K;
-  fa_shape(P.A, K);
-  if (!pp->batch.empty() && (memcmp(&K, &pp->batch_shape, sizeof(K)) != 0 || P.general != pp->batch[0].general || P.nwords != pp->batch[0].nwords)) {
+  if (!pp->batch.empty() && pp->batch[0].shape != P.shape) {
     const int32_t rc = fa_pipe_flush_batch(g, pp);   // another query shape: its own launch
     if (rc) return rc;
   }
-  if (pp->batch.empty()) pp->batch_shape = K;
   pp->batch.push_back(P);
-  pp->batch_rows += P.A.n;
+  pp->batch_rows += P.b.n;
   if ((int)pp->batch.size() >= FA_PIPE_WINDOW || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
   return DBHIP_OK;
 }
 
 void fa_pipe_forget(FaPipe* pp) {
-  pp->batch.clear(); pp->batch_rows = 0;
+  pp->batch.clear(); pp->batch_rows = 0; pp->shapes.clear();
   pp->retained.clear(); pp->retained_base = 0; pp->submitted = 0; pp->merges.clear(); pp->rows_ub = 0; pp->window_blocks = 0;
 }
 
@@ -925,8 +925,8 @@ int32_t fa_pipe_checkpoint(dbhip_groupby* g, FaPipe* pp, int64_t* out_committed,
     for (int64_t i = skip < 0 ? 0 : skip; i < (int64_t)pp->retained.size(); ++i) again.push_back(pp->retained[(size_t)i]);
     DBHIP_CHECK(hipMemsetAsync(pp->ctrl, 0, 24, s));   // cursor, flags, errors; [3] (committed blocks) stays
     pp->retained.clear(); pp->retained_base = committed; pp->submitted = committed; pp->rows_ub = 0; pp->window_blocks = 0;
-    for (FaPending& P : again)
-      if ((rc = fa_pipe_submit(g, pp, P, s))) return rc;
+    for (const FaPending& P : again)
+      if ((rc = fa_pipe_enqueue(g, pp, P, s))) return rc;
     return fa_pipe_checkpoint(g, pp, out_committed, false);
   }
   const int64_t submitted = pp->submitted;
@@ -992,6 +992,65 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
     return DBHIP_ERR_UNSUPPORTED;
   }
   if (n == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  if (FaPipe* pp = (FaPipe*)*dbhip_groupby_pipe_slot_internal(g); pp && pp->on && !t_prepare_only && !t_jit_only) {
+    // ---- pipelined: recognise the query shape by its signature, fill the block's pointers, queue (see above) ----
+    if (pp->bound && pp->stream != s) {
+      set_error("dbhip_groupby_add_block_program: a pipelined table takes its blocks on ONE stream (checkpoint before changing it)");
+      return DBHIP_ERR_INVALID;
+    }
+    DBHIP_REQUIRE(prog->n_inputs >= 0 && prog->n_inputs <= EX_MAX_INPUTS && (prog->inputs || prog->n_inputs == 0), "expression program: 0..8 input columns");
+    DBHIP_REQUIRE(prog->n_ins >= 0 && prog->n_ins <= 2 * EX_MAX_INS && (prog->prog || prog->n_ins == 0), "expression program: too many instructions");
+    static thread_local std::string sig;
+    sig.clear();
+    auto put = [&](const void* p, size_t nb) { sig.append((const char*)p, nb); };
+    put(&prog->n_ins, 4); put(&prog->n_inputs, 4); put(&prog->filter_reg, 4);
+    if (prog->n_ins) put(prog->prog, (size_t)prog->n_ins * sizeof(dbhip_expr_ins));
+    for (int c = 0; c < prog->n_inputs; ++c) {
+      const dbhip_col& col = prog->inputs[c];
+      DBHIP_REQUIRE(col.data, "expression program: NULL input column");
+      const int32_t t[3] = {col.type, col.is_scalar, (int32_t)(col.validity != nullptr) | ((int32_t)col.precision << 8) | ((int32_t)col.scale << 16)};
+      put(t, sizeof(t));
+    }
+    for (int k = 0; k < L.nkeys; ++k) {
+      const int32_t t[3] = {keys[k].type, keys[k].is_scalar, (int32_t)(keys[k].validity != nullptr)};
+      put(t, sizeof(t));
+    }
+    put(prog->arg_regs, (size_t)L.naggs * 4);
+    const char hf = filter_bitmap != nullptr;
+    put(&hf, 1);
+    int sh = -1;
+    for (int i = (int)pp->shapes.size() - 1; i >= 0 && sh < 0; --i)
+      if (pp->shapes[(size_t)i].sig == sig) sh = i;
+    if (sh < 0) {
+      FaShape S;
+      FaArgs A;
+      memset(&A, 0, sizeof(A));
+      bool may_raise = false;
+      const int32_t rc = fa_build_args(L, keys, prog, A, &S.general, &S.nwords, &may_raise);
+      if (rc) return rc;
+      A.has_filter = filter_bitmap != nullptr;
+      S.lds = (size_t)(A.P.n_slots > 6 ? A.P.n_slots : 6) * FA_ROWS * 256 * 8;
+      if (S.lds > 60 * 1024) {
+        set_error("dbhip_groupby_add_block_program: %d live LDS slots exceed the register file; split the expression", A.P.n_slots);
+        return DBHIP_ERR_UNSUPPORTED;
+      }
+      fa_shape(A, S.A);
+      S.sig = sig;
+      pp->shapes.push_back(std::move(S));
+      sh = (int)pp->shapes.size() - 1;
+    }
+    FaPending P;
+    memset(&P.b, 0, sizeof(P.b));
+    P.shape = sh;
+    for (int c = 0; c < prog->n_inputs; ++c) {
+      P.b.in_data[c] = prog->inputs[c].data; P.b.in_valid[c] = prog->inputs[c].validity; P.b.in_voff[c] = prog->inputs[c].validity_offset;
+    }
+    for (int k = 0; k < L.nkeys; ++k) { P.b.key_data[k] = keys[k].data; P.b.key_valid[k] = keys[k].validity; P.b.key_voff[k] = keys[k].validity_offset; }
+    P.b.filter_bits = filter_bitmap; P.b.filter_off = filter_bit_offset; P.b.n = n;
+    pp->bound = true; pp->stream = s;
+    return fa_pipe_enqueue(g, pp, P, s);
+  }
   FaArgs A;
   memset(&A, 0, sizeof(A));
   bool general = false, may_raise = false;
@@ -1000,7 +1059,6 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   if (rc) return rc;
   A.filter_bits = filter_bitmap; A.filter_off = filter_bit_offset; A.n = n;
   A.has_filter = filter_bitmap != nullptr;
-  hipStream_t s = resolve_stream(stream);
   // (at least 6 slots: the end of the kernel stages one group's 12 state words per lane in the register file)
   const size_t lds = (size_t)(A.P.n_slots > 6 ? A.P.n_slots : 6) * FA_ROWS * 256 * 8;
   if (lds > 60 * 1024) {
@@ -1013,11 +1071,6 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   static const int env_grid = getenv("DBHIP_FAGG_GRID") ? atoi(getenv("DBHIP_FAGG_GRID")) : 0;
   if (env_grid > 0) grid = (int)(ceil_div(nchunks, 4) < env_grid ? ceil_div(nchunks, 4) : env_grid);
   if (FaPipe* pp = (FaPipe*)*dbhip_groupby_pipe_slot_internal(g); pp && !t_prepare_only) {
-    if (pp->on && !t_jit_only) {   // pipelined: one launch, nothing read back (see above)
-      FaPending P;
-      P.A = A; P.grid = grid; P.lds = lds; P.general = general; P.nwords = nwords;
-      return fa_pipe_enqueue(g, pp, P, s);
-    }
     int64_t committed = 0;         // a synchronous call on a table that still has queued blocks: those first
     if ((rc = fa_pipe_checkpoint(g, pp, &committed, true))) return rc;
   }
