@@ -688,7 +688,8 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 // replay possible. One stream per pipelined table (the reference's partial tables are per pipeline thread as well).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int FA_PIPE_WINDOW = 32;
+constexpr int FA_PIPE_WINDOW = 128;   // blocks per window (one merge; what one raised flag gives back)
+constexpr int FA_PIPE_BATCH = 32;     // blocks per multi-block launch
 constexpr int FA_PIPE_RING = 8;
 constexpr int64_t FA_PIPE_BIG = 8 << 20;          // a block of this many rows is a launch of its own
 constexpr int64_t FA_PIPE_BATCH_ROWS = 8 << 20;   // rows after which a batch goes without waiting for more blocks
@@ -713,7 +714,7 @@ struct FaPipe {
   int64_t count_seen = 0;            // groups after the last merge seen finished
   std::deque<FaPending> retained;    // launch arguments of the blocks [retained_base, submitted) since the last checkpoint
   int64_t retained_base = 0, submitted = 0;
-  // multi-block launches: blocks below FA_PIPE_BIG rows wait here until FA_PIPE_WINDOW of them (or FA_PIPE_BATCH_ROWS rows) can go
+  // multi-block launches: blocks below FA_PIPE_BIG rows wait here until FA_PIPE_BATCH of them (or FA_PIPE_BATCH_ROWS rows) can go
   // in ONE launch; their pointer tables travel through a ring of pinned staging / device buffers
   std::vector<FaPending> batch;
   int64_t batch_rows = 0;
@@ -884,7 +885,7 @@ int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStr
   }
   pp->batch.push_back(P);
   pp->batch_rows += P.b.n;
-  if ((int)pp->batch.size() >= FA_PIPE_WINDOW || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
+  if ((int)pp->batch.size() >= FA_PIPE_BATCH || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
   return DBHIP_OK;
 }
 
@@ -1164,8 +1165,8 @@ int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream) 
   if (rc == DBHIP_OK && e == hipSuccess) { memset(pp->status_host, 0, 64); e = hipMemsetAsync(pp->ctrl, 0, 64, s); }
   if (rc == DBHIP_OK && e == hipSuccess) e = hipStreamSynchronize(s);
   for (int i = 0; i < FA_PIPE_RING && rc == DBHIP_OK && e == hipSuccess; ++i) {
-    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_WINDOW * sizeof(FaBlock), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_WINDOW * sizeof(FaBlock));
+    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_BATCH * sizeof(FaBlock), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_BATCH * sizeof(FaBlock));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pp->tab_ev[i], hipEventDisableTiming);
   }
   if (rc == DBHIP_OK && e == hipSuccess) rc = dbhip_groupby_reserve_merge_internal(g, pp->cap_rows);

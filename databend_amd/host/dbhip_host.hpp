@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 #include <optional>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -1153,6 +1154,262 @@ class TransformPartialAggregate : public AccumulatingTransform {
   }
  private:
   AggregateHashTable table_;
+};
+
+// ---- the drop-in at the reference's block size (round 6) ------------------------------------------------------------------------
+// The reference's pipeline hands every processor DataBlocks of <= max_block_size = 65,536 rows (settings_default.rs:142-148;
+// TransformPartialAggregate::transform per block, transform_aggregate_partial.rs:262-270). A device call that size is a few
+// microseconds of kernel: what a binding does about that decides whether the device's rate is reachable at all
+// (profiles/r06_block_size_sweep.json). Two tools:
+//   * TransformFusedPartialAggregate — TransformFilter -> CompoundBlockOperator::Map -> TransformPartialAggregate as ONE
+//     operator over a PIPELINED table (dbhip_groupby_set_pipelined): a block costs one queued descriptor, 32 blocks one launch,
+//     and the error a block may raise arrives at the checkpoint together with the number of blocks that were merged — the rest
+//     is replayed here through the three separate operators, exactly what the synchronous call's caller does per block.
+//   * BlockAccumulator — the squash in front of operators that have no pipelined form (the reference's own join build squashes
+//     its input the same way, new_hash_join/memory/basic.rs:78-89): blocks are concatenated on the device up to `target_rows`.
+
+// A filter predicate + one argument expression per aggregate, flattened post-order into ONE dbhip_expr_eval register program
+// (16 registers, numeric / date / decimal / boolean nodes: what dbhip_groupby_add_block_program takes). Built once per pipeline.
+class AggregateProgram {
+ public:
+  AggregateProgram(const std::optional<Expr>& filter, const std::vector<std::optional<Expr>>& args) {
+    for (int r = 15; r >= 0; --r) free_.push_back(r);
+    if (filter) { filter_reg_ = emit(*filter); keep(*filter, filter_reg_); }
+    for (const auto& a : args) {
+      if (!a) { arg_regs_.push_back(DBHIP_ARG_NONE); continue; }
+      if (a->kind == Expr::ColumnRef) { arg_regs_.push_back(DBHIP_ARG_INPUT(input_of(a->id))); continue; }
+      const int r = emit(*a);
+      keep(*a, r);   // a result stays in its register; a later expression that contains it (Q1's charge contains disc_price) reads it there
+      arg_regs_.push_back(r);
+    }
+  }
+  bool ok() const { return ok_; }
+  const std::vector<size_t>& inputs() const { return inputs_; }   // block column offsets, in program input order
+  // the program over THIS block's columns
+  void bind(const DataBlock& block, std::vector<dbhip_col>& cols, dbhip_agg_program& ap) const {
+    cols.clear();
+    for (size_t id : inputs_) cols.push_back(block.get_by_offset(id).c());
+    ap.prog = ins_.empty() ? nullptr : ins_.data(); ap.n_ins = (int32_t)ins_.size();
+    ap.inputs = cols.data(); ap.n_inputs = (int32_t)cols.size();
+    ap.filter_reg = filter_reg_; ap.arg_regs = arg_regs_.data();
+  }
+ private:
+  int input_of(size_t id) {
+    for (size_t k = 0; k < inputs_.size(); ++k) if (inputs_[k] == id) return (int)k;
+    if (inputs_.size() == 8) { ok_ = false; return 0; }
+    inputs_.push_back(id);
+    return (int)inputs_.size() - 1;
+  }
+  int alloc() { if (free_.empty()) { ok_ = false; return 0; } int r = free_.back(); free_.pop_back(); return r; }
+  void release(int r) { if (!kept_regs_.count(r)) free_.push_back(r); }
+  void keep(const Expr& e, int r) { kept_[e.sql_display() + ":" + e.type.name()] = r; kept_regs_.insert(r); }
+  void ins(int op, int dst, int a, int b, const DataType& t, uint64_t imm) {
+    dbhip_expr_ins i; memset(&i, 0, sizeof(i));
+    i.op = op; i.dst = dst; i.a = a; i.b = b; i.type = t.id; i.imm = imm; i.precision = t.precision; i.scale = t.scale;
+    ins_.push_back(i);
+  }
+  int emit(const Expr& e) {
+    if (!ok_) return 0;
+    const DataType& t = e.type;
+    if (e.kind == Expr::FunctionCall) {
+      auto k = kept_.find(e.sql_display() + ":" + t.name());
+      if (k != kept_.end()) return k->second;
+    }
+    const bool plain = ((t.id >= DBHIP_T_BOOL && t.id <= DBHIP_T_TIMESTAMP) || t.is_decimal()) && t.dim == 0;
+    if (!plain) { ok_ = false; return 0; }
+    switch (e.kind) {
+      case Expr::ColumnRef: { const int k = input_of(e.id); const int r = alloc(); ins(DBHIP_EX_LOAD, r, k, 0, t, 0); return r; }
+      case Expr::Constant: {
+        if (e.scalar.is_null) { ok_ = false; return 0; }
+        uint64_t imm;
+        if (t.id == DBHIP_T_F32) { double d = (double)(float)e.scalar.f; memcpy(&imm, &d, 8); }
+        else if (t.id == DBHIP_T_F64) memcpy(&imm, &e.scalar.f, 8);
+        else imm = (uint64_t)e.scalar.i;
+        const int r = alloc(); ins(DBHIP_EX_CONST, r, 0, 0, t, imm); return r;
+      }
+      case Expr::Cast: {
+        const int a = emit(e.args[0]);
+        if (!ok_ || e.args[0].type.same_physical(t)) return a;
+        ins(DBHIP_EX_CAST, a, a, 0, t, 0);
+        return a;
+      }
+      default: break;
+    }
+    static const std::map<std::string, int> ops = {{"plus", DBHIP_EX_PLUS}, {"minus", DBHIP_EX_MINUS}, {"multiply", DBHIP_EX_MULTIPLY},
+        {"divide", DBHIP_EX_DIVIDE}, {"eq", DBHIP_EX_EQ}, {"noteq", DBHIP_EX_NOTEQ}, {"lt", DBHIP_EX_LT}, {"lte", DBHIP_EX_LTE},
+        {"gt", DBHIP_EX_GT}, {"gte", DBHIP_EX_GTE}};
+    if (e.fname == "and_filters" || e.fname == "or_filters") {
+      int acc = -1;
+      for (const Expr& a : e.args) {
+        const int r = emit(a);
+        if (!ok_) return 0;
+        ins(DBHIP_EX_IS_TRUE, r, r, 0, DataType::of(DBHIP_T_BOOL), 0);
+        if (acc < 0) { acc = r; continue; }
+        ins(e.fname == "or_filters" ? DBHIP_EX_OR : DBHIP_EX_AND, acc, acc, r, DataType::of(DBHIP_T_BOOL), 0);
+        release(r);
+      }
+      return acc;
+    }
+    auto it = ops.find(e.fname);
+    if (it == ops.end() || e.args.size() != 2) { ok_ = false; return 0; }
+    const int a = emit(e.args[0]);
+    const int b = emit(e.args[1]);
+    if (!ok_) return 0;
+    // a fresh destination: an operand may be a column another result needs as it is (the compiler eliminates the moves)
+    const int d = alloc();
+    ins(it->second, d, a, b, t, 0);
+    release(a);
+    if (b != a) release(b);
+    return d;
+  }
+  std::vector<dbhip_expr_ins> ins_;
+  std::vector<size_t> inputs_;
+  std::vector<int32_t> arg_regs_;
+  std::vector<int> free_;
+  std::map<std::string, int> kept_;
+  std::set<int> kept_regs_;
+  int32_t filter_reg_ = -1;
+  bool ok_ = true;
+};
+
+// BlockAccumulator: squashes incoming blocks on the device until `target_rows` rows are together (fixed-width and Boolean
+// columns, validity, strings: dbhip_concat_columns). add() returns the squashed block when one is full; finish() the rest.
+class BlockAccumulator {
+ public:
+  explicit BlockAccumulator(int64_t target_rows) : target_(target_rows) {}
+  std::optional<DataBlock> add(DataBlock b) {
+    if (b.num_rows == 0) return std::nullopt;
+    rows_ += b.num_rows;
+    parts_.push_back(std::move(b));
+    if (rows_ < target_) return std::nullopt;
+    return flush();
+  }
+  std::optional<DataBlock> finish() { return parts_.empty() ? std::nullopt : std::optional<DataBlock>(flush()); }
+ private:
+  DataBlock flush() {
+    DataBlock out; out.num_rows = rows_;
+    if (parts_.size() == 1) { out = std::move(parts_[0]); parts_.clear(); rows_ = 0; return out; }
+    const size_t ncols = parts_[0].columns.size();
+    for (size_t c = 0; c < ncols; ++c) {
+      std::vector<dbhip_col> cols; std::vector<int64_t> rows;
+      bool any_valid = false; int nbuf = 0;
+      for (const DataBlock& p : parts_) { cols.push_back(p.columns[c].c()); rows.push_back(p.num_rows); any_valid |= (bool)p.columns[c].validity; nbuf += cols.back().n_buffers; }
+      const Column& first = parts_[0].columns[c];
+      Column r; r.type = first.type; r.len = rows_;
+      const size_t words = (size_t)(rows_ + 63) / 64;
+      r.data = make_buf(first.type.id == DBHIP_T_BOOL ? words * 8 + 8 : (size_t)rows_ * first.type.elem_size() + 16);
+      if (any_valid) { r.validity = make_buf(words * 8 + 8); r.type.nullable = true; }
+      if (first.type.id == DBHIP_T_STRING && nbuf > 0) throw ErrorCode::Unimplemented("BlockAccumulator: long strings (pass such blocks through)");
+      int32_t nb_out = 0;
+      check(dbhip_concat_columns(cols.data(), rows.data(), nullptr, (int32_t)cols.size(), r.data->ptr(), r.validity ? (uint8_t*)r.validity->ptr() : nullptr,
+                                 nullptr, &nb_out, nullptr));
+      out.columns.push_back(std::move(r));
+    }
+    check(dbhip_stream_sync(nullptr));   // the parts' buffers may go now
+    parts_.clear(); rows_ = 0;
+    return out;
+  }
+  int64_t target_, rows_ = 0;
+  std::vector<DataBlock> parts_;
+};
+
+// TransformFilter -> CompoundBlockOperator::Map -> TransformPartialAggregate as one operator (see above). `filter`: the
+// predicate over the INPUT block; `args[i]`: aggregate i's argument as an expression over the input block (nullopt = count(*)).
+// Groups beyond the fused kernel's reach (more than 8 per workgroup), row errors and unsupported shapes fall back — block by
+// block — to the three operators, which raise the reference's own error text where there is one.
+class TransformFusedPartialAggregate : public AccumulatingTransform {
+ public:
+  TransformFusedPartialAggregate(AggregatorParams p, std::optional<Expr> filter, std::vector<std::optional<Expr>> args, bool pipelined = true,
+                                 void* stream = nullptr)
+      : params_(std::move(p)), filter_(std::move(filter)), args_(std::move(args)), prog_(filter_, args_), table_(params_), stream_(stream) {
+    fused_ = prog_.ok();
+    if (fused_ && pipelined) {
+      const int32_t rc = dbhip_groupby_set_pipelined(table_.handle(), 1, stream_);
+      if (rc == DBHIP_ERR_UNSUPPORTED) fused_ = false; else check(rc);
+      pipelined_ = fused_;
+    }
+  }
+  const char* name() const override { return "TransformFusedPartialAggregate"; }
+  // PREPARE: the run-time specialised kernels of this pipeline's shape (dbhip_groupby_prepare_program), from one sample block
+  void prepare(const DataBlock& sample) {
+    if (!fused_) return;
+    std::vector<dbhip_col> cols, keys; dbhip_agg_program ap;
+    bind(sample, cols, keys, ap);
+    const int32_t rc = dbhip_groupby_prepare_program(table_.handle(), keys.data(), &ap);
+    if (rc == DBHIP_ERR_UNSUPPORTED || rc == DBHIP_ERR_INVALID) fused_ = false; else check(rc);
+  }
+  std::vector<DataBlock> transform(DataBlock block) override {
+    if (block.num_rows == 0) return {};
+    if (!fused_) { slow_path(block); return {}; }
+    std::vector<dbhip_col> cols, keys; dbhip_agg_program ap;
+    bind(block, cols, keys, ap);
+    const int32_t rc = dbhip_groupby_add_block_program(table_.handle(), keys.data(), &ap, block.num_rows, nullptr, 0, stream_);
+    if (rc == DBHIP_ERR_CAPACITY || rc == DBHIP_ERR_ROW_ERRORS || rc == DBHIP_ERR_UNSUPPORTED) {
+      // (synchronous mode, or a shape the kernel refuses at the call) nothing of the block was merged
+      if (rc != DBHIP_ERR_ROW_ERRORS) fused_ = false;
+      drain();
+      slow_path(block);
+      return {};
+    }
+    check(rc);
+    if (pipelined_) retained_.push_back(std::move(block));   // inputs of queued kernels: alive until the checkpoint
+    return {};
+  }
+  std::vector<DataBlock> on_finish(bool output) override {
+    drain();
+    if (!output) return {};
+    DataBlock b; b.meta = std::make_shared<AggregateMetaSerialized>(table_.serialize());
+    std::vector<DataBlock> v; v.push_back(std::move(b));
+    return v;
+  }
+  int64_t blocks_replayed() const { return replayed_; }
+  AggregateHashTable& table() { return table_; }
+ private:
+  void bind(const DataBlock& block, std::vector<dbhip_col>& cols, std::vector<dbhip_col>& keys, dbhip_agg_program& ap) const {
+    prog_.bind(block, cols, ap);
+    keys.clear();
+    for (size_t gcol : params_.group_columns) keys.push_back(block.get_by_offset(gcol).c());
+  }
+  // the checkpoint of a pipelined table: blocks [committed, queued) were not merged -> the three operators take them
+  void drain() {
+    if (!pipelined_ || retained_.empty()) return;
+    int64_t committed = 0;
+    const int32_t rc = dbhip_groupby_checkpoint(table_.handle(), &committed, stream_);
+    std::vector<DataBlock> blocks;
+    blocks.swap(retained_);
+    if (rc == DBHIP_OK) return;
+    if (rc != DBHIP_ERR_CAPACITY && rc != DBHIP_ERR_ROW_ERRORS && rc != DBHIP_ERR_UNSUPPORTED) check(rc);
+    if (rc != DBHIP_ERR_ROW_ERRORS) fused_ = false;   // the keys (or the shape) are not for this kernel: the rest of the stream goes the slow way
+    for (size_t i = (size_t)committed; i < blocks.size(); ++i) { slow_path(blocks[i]); ++replayed_; }
+  }
+  // TransformFilter -> maps -> add_groups, one kernel per node: raises the reference's row errors where the fused kernel only counted them
+  void slow_path(const DataBlock& block) {
+    DataBlock b = filter_ ? FilterExecutor(*filter_).filter(block) : block;
+    if (b.num_rows == 0) return;
+    std::vector<dbhip_col> keys, aggs(args_.size());
+    std::vector<Column> hold;
+    hold.reserve(args_.size());
+    for (size_t gcol : params_.group_columns) keys.push_back(b.get_by_offset(gcol).c());
+    for (size_t a = 0; a < args_.size(); ++a) {
+      memset(&aggs[a], 0, sizeof(dbhip_col));
+      if (!args_[a]) continue;
+      Evaluator ev(b);
+      Value v = ev.run(*args_[a]);
+      if (v.is_scalar) throw ErrorCode::Unimplemented("constant aggregate argument");
+      hold.push_back(v.column);
+      aggs[a] = hold.back().c();
+    }
+    check(dbhip_groupby_add_block(table_.handle(), keys.data(), aggs.data(), b.num_rows, stream_));
+  }
+  AggregatorParams params_;
+  std::optional<Expr> filter_;
+  std::vector<std::optional<Expr>> args_;
+  AggregateProgram prog_;
+  AggregateHashTable table_;
+  void* stream_;
+  bool fused_ = false, pipelined_ = false;
+  std::vector<DataBlock> retained_;
+  int64_t replayed_ = 0;
 };
 
 // TransformFinalAggregate (transform_aggregate_final.rs:69-551): merges partial states, emits the result

@@ -279,6 +279,120 @@ static void test_q1_plan() {
   CHECK(got_keys == exp_keys);
 }
 
+// Round 6: the drop-in at the reference's block size. Q1 fed as 65,536-row... here 20,000-row blocks through
+// TransformFusedPartialAggregate (pipelined table, multi-block launches, checkpoint at on_finish) from two pipeline lanes, against
+// the three-operator plan of test_q1_plan's shape and an __int128 host loop; then a stream whose 12th block holds 60 groups: the
+// checkpoint gives the uncommitted blocks back and the operator replays them through TransformFilter -> maps -> add_groups;
+// and BlockAccumulator: squashed blocks == the concatenation.
+static void test_fused_partial_aggregate() {
+  const int64_t n = 400003, BLOCK = 20000;
+  std::mt19937_64 rng(12);
+  std::vector<int64_t> qty(n), price(n), disc(n), tax(n); std::vector<int32_t> ship(n); std::vector<std::string> rf(n), ls(n);
+  const int32_t cutoff = 10471;
+  for (int64_t i = 0; i < n; ++i) {
+    qty[i] = (int64_t)(rng() % 50 + 1) * 100; price[i] = 90000 + (int64_t)(rng() % 10404951); disc[i] = (int64_t)(rng() % 11); tax[i] = (int64_t)(rng() % 9);
+    ship[i] = 8036 + (int32_t)(rng() % 2526);
+    rf[i] = std::string(1, "ANR"[rng() % 3]); ls[i] = std::string(1, "FO"[rng() % 2]);
+  }
+  auto D152 = DataType::Decimal(15, 2); auto DATE = DataType::of(DBHIP_T_DATE); auto STR = DataType::of(DBHIP_T_STRING);
+  auto make_block = [&](int64_t lo, int64_t hi) {
+    auto sl = [&](const std::vector<int64_t>& v) { return std::vector<int64_t>(v.begin() + lo, v.begin() + hi); };
+    return DataBlock({Column::from_vector(D152, sl(qty)), Column::from_vector(D152, sl(price)), Column::from_vector(D152, sl(disc)),
+                      Column::from_vector(D152, sl(tax)), Column::from_short_strings(std::vector<std::string>(rf.begin() + lo, rf.begin() + hi)),
+                      Column::from_short_strings(std::vector<std::string>(ls.begin() + lo, ls.begin() + hi)),
+                      Column::from_vector(DATE, std::vector<int32_t>(ship.begin() + lo, ship.begin() + hi))}, hi - lo);
+  };
+  Expr pred = Expr::call("lte", {Expr::column_ref(6, DATE, "l_shipdate"), Expr::constant(Scalar::Int(DBHIP_T_DATE, cutoff))});
+  Expr one = Expr::constant(Scalar::Int(DBHIP_T_U8, 1));
+  Expr disc_price = Expr::call("multiply", {Expr::column_ref(1, D152, "l_extendedprice"), Expr::call("minus", {one, Expr::column_ref(2, D152, "l_discount")})});
+  Expr charge = Expr::call("multiply", {disc_price, Expr::call("plus", {one, Expr::column_ref(3, D152, "l_tax")})});
+  AggregatorParams params;
+  params.group_columns = {4, 5}; params.group_data_types = {STR, STR};
+  params.aggregate_functions = {{"sum", 0, D152}, {"sum", 1, D152}, {"sum", std::nullopt, disc_price.data_type()}, {"sum", std::nullopt, charge.data_type()},
+                                {"sum", 2, D152}, {"count", std::nullopt, DataType()}};
+  params.aggregate_functions[2].arg = 0; params.aggregate_functions[3].arg = 0;   // (has an argument; the fused operator takes it from `args`)
+  std::vector<std::optional<Expr>> args = {Expr::column_ref(0, D152, "l_quantity"), Expr::column_ref(1, D152, "l_extendedprice"), disc_price, charge,
+                                           Expr::column_ref(2, D152, "l_discount"), std::nullopt};
+  void* s1 = nullptr; void* s2 = nullptr;
+  check(dbhip_stream_create(&s1)); check(dbhip_stream_create(&s2));
+  {
+    TransformFusedPartialAggregate lane_a(params, pred, args, true, s1), lane_b(params, pred, args, true, s2);
+    lane_a.prepare(make_block(0, 16)); lane_b.prepare(make_block(0, 16));
+    TransformFinalAggregate final_(params);
+    int lane = 0;
+    for (int64_t lo = 0; lo < n; lo += BLOCK, ++lane) (lane % 2 ? lane_b : lane_a).transform(make_block(lo, std::min(n, lo + BLOCK)));
+    for (auto* p : {&lane_a, &lane_b})
+      for (auto& meta : p->on_finish(true)) final_.transform(std::move(meta));
+    CHECK(lane_a.blocks_replayed() == 0 && lane_b.blocks_replayed() == 0);
+    std::vector<DataBlock> res = final_.on_finish(true);
+    CHECK(res.size() == 1);
+    const DataBlock& r = res[0];
+    struct G { int64_t q = 0, p = 0, d = 0; __int128 dp = 0, ch = 0; uint64_t c = 0; };
+    std::map<std::pair<std::string, std::string>, G> exp;
+    for (int64_t i = 0; i < n; ++i) if (ship[i] <= cutoff) {
+      G& g = exp[{rf[i], ls[i]}];
+      __int128 dp = (__int128)price[i] * (100 - disc[i]);
+      g.q += qty[i]; g.p += price[i]; g.d += disc[i]; g.dp += dp; g.ch += dp * (100 + tax[i]); g.c += 1;
+    }
+    CHECK(r.num_rows == (int64_t)exp.size());
+    auto sq = r.columns[0].to_vector<int64_t>(); auto sp = r.columns[1].to_vector<int64_t>();
+    auto sdp = r.columns[2].to_vector<__int128>(); auto sch = r.columns[3].to_vector<__int128>();
+    auto sd = r.columns[4].to_vector<int64_t>(); auto cnt = r.columns[5].to_vector<uint64_t>();
+    auto krf = r.columns[6].to_short_strings(); auto kls = r.columns[7].to_short_strings();
+    for (int64_t i = 0; i < r.num_rows; ++i) {
+      auto it = exp.find({krf[(size_t)i], kls[(size_t)i]});
+      CHECK(it != exp.end());
+      if (it == exp.end()) continue;
+      const G& g = it->second;
+      CHECK(sq[i] == g.q && sp[i] == g.p && sd[i] == g.d && sdp[i] == g.dp && sch[i] == g.ch && cnt[i] == g.c);
+    }
+  }
+  // ---- a block the fused kernel gives back: the operator replays it (and what was queued behind it) the slow way ----
+  {
+    const int64_t m = 30000, nb = 20;
+    auto I64 = DataType::of(DBHIP_T_I64);
+    AggregatorParams p2;
+    p2.group_columns = {0}; p2.group_data_types = {I64};
+    p2.aggregate_functions = {{"sum", 1, I64}, {"count", std::nullopt, DataType()}};
+    Expr f2 = Expr::call("gte", {Expr::column_ref(1, I64, "x"), Expr::constant(Scalar::Int(DBHIP_T_I64, -500))});
+    std::vector<std::optional<Expr>> a2 = {Expr::call("plus", {Expr::column_ref(1, I64, "x"), Expr::column_ref(1, I64, "x")}), std::nullopt};
+    p2.aggregate_functions[0].arg_type = I64;
+    TransformFusedPartialAggregate op(p2, f2, a2, true, s1);
+    std::map<int64_t, std::pair<int64_t, uint64_t>> exp;
+    for (int64_t b = 0; b < nb; ++b) {
+      std::vector<int64_t> k(m), x(m);
+      for (int64_t i = 0; i < m; ++i) { k[i] = (int64_t)(rng() % (b == 11 ? 60 : 3)); x[i] = (int64_t)(rng() % 2000) - 1000; }
+      for (int64_t i = 0; i < m; ++i) if (x[i] >= -500) { exp[k[i]].first += 2 * x[i]; exp[k[i]].second += 1; }
+      op.transform(DataBlock({Column::from_vector(I64, k), Column::from_vector(I64, x)}, m));
+    }
+    auto metas = op.on_finish(true);
+    CHECK(op.blocks_replayed() == nb);   // one window: nothing of it committed
+    DataBlock r = op.table().merge_result();
+    CHECK(r.num_rows == (int64_t)exp.size());
+    auto sx = r.columns[0].to_vector<int64_t>(); auto cx = r.columns[1].to_vector<uint64_t>(); auto kx = r.columns[2].to_vector<int64_t>();
+    for (int64_t i = 0; i < r.num_rows; ++i) {
+      auto it = exp.find(kx[(size_t)i]);
+      CHECK(it != exp.end());
+      if (it != exp.end()) CHECK(sx[(size_t)i] == it->second.first && cx[(size_t)i] == it->second.second);
+    }
+  }
+  // ---- BlockAccumulator ----
+  {
+    BlockAccumulator acc(50000);
+    std::vector<DataBlock> out;
+    for (int64_t lo = 0; lo < 130000; lo += 20000) if (auto b = acc.add(make_block(lo, lo + 20000))) out.push_back(std::move(*b));
+    if (auto b = acc.finish()) out.push_back(std::move(*b));
+    CHECK(out.size() == 3 && out[0].num_rows == 60000 && out[1].num_rows == 60000 && out[2].num_rows == 20000);
+    int64_t at = 0;
+    for (const DataBlock& b : out) {
+      auto q = b.columns[0].to_vector<int64_t>(); auto d = b.columns[6].to_vector<int32_t>(); auto f = b.columns[4].to_short_strings();
+      for (int64_t i = 0; i < b.num_rows; ++i) CHECK(q[(size_t)i] == qty[at + i] && d[(size_t)i] == ship[at + i] && f[(size_t)i] == rf[at + i]);
+      at += b.num_rows;
+    }
+  }
+  check(dbhip_stream_destroy(s1)); check(dbhip_stream_destroy(s2));
+}
+
 static void test_join_and_sort() {
   const int64_t nb = 20000, np = 50000;
   std::mt19937_64 rng(5);
@@ -870,6 +984,7 @@ int main() {
     test_or_filters();
     test_selector();
     test_q1_plan();
+    test_fused_partial_aggregate();
     test_join_and_sort();
     test_left_joins();
     test_hnsw_sequential_build_and_open();

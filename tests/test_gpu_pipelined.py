@@ -136,7 +136,7 @@ def test_a_block_with_too_many_groups_is_given_back_with_the_blocks_behind_it(gp
     blocks, and the caller hands blocks [committed, queued) to the operator-at-a-time path (here: plain add_block)."""
     D = gpu
     rng = np.random.default_rng(5)
-    n, nb, bad = 65536, 100, 70
+    n, nb, bad = 20_000, 300, 200
     g = D.GroupBy([T.T_I64], AGGS)
     g.set_pipelined(True)
     ck, cx, p, regs, f = _small_program(D, np.zeros(1, np.int64), np.zeros(1, np.int64))
@@ -151,7 +151,7 @@ def test_a_block_with_too_many_groups_is_given_back_with_the_blocks_behind_it(gp
         ks.append(k), xs.append(x)
     rc, committed = g.checkpoint(raise_on_error=False)
     assert rc == T.ERR_CAPACITY
-    assert committed == 64               # whole windows (32 blocks each) before the offending block's window
+    assert committed == 128              # whole windows (128 blocks each) before the offending block's window
     assert b"were not merged" in lib().dbhip_last_error()
     assert sorted(g.result()) == _expected(np.concatenate(ks[:committed]), np.concatenate(xs[:committed]))
     # the caller's fallback for the rest: the operator-at-a-time path on the same (still pipelined) table
@@ -225,14 +225,14 @@ def test_many_windows_and_a_table_that_has_to_grow(gpu):
     """Blocks whose workgroups each see <= 8 groups while the table as a whole collects thousands (a clustered key): the merges
     queued behind the windows must never push the table past its load factor — the host's bound makes it look (and grow) in time."""
     D = gpu
-    n, nb = 65536, 80
+    n, nb = 16384, 300
     g = D.GroupBy([T.T_I64], AGGS, capacity=1024)
     g.set_pipelined(True)
     keep, ks, xs = [], [], []
     rng = np.random.default_rng(8)
     for b in range(nb):
-        # rows in runs of 16384 equal keys: a workgroup's chunk range meets one or two of them
-        k = (np.arange(n, dtype=np.int64) // 16384) + 4 * b
+        # rows in runs of 4096 equal keys: a workgroup's chunk range meets one or two of them
+        k = (np.arange(n, dtype=np.int64) // 4096) + 4 * b
         x = rng.integers(-10**6, 10**6, n).astype(np.int64)
         ck, cx, p, regs, f = _small_program(D, k, x)
         g.add_block_program([ck], p, regs, n)
