@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-readiness", action="store_true", help="skip the SF100/8 exchange-overhead measurement (it launches q1_fused_kernel on 1/8 of the rows: "
                     "profiles of the headline kernel are taken without it)")
     ap.add_argument("--no-q3", action="store_true", help="skip TPC-H Q3 SF100 (BASELINE configs[2])")
+    ap.add_argument("--no-blocks", action="store_true", help="skip the block-size sweep (Q1 fed as 65,536 ... all-row blocks through the C-ABI from 1 and 8 host threads)")
     ap.add_argument("--q3-sf", type=float, default=100.0)
     ap.add_argument("--no-hnsw", action="store_true", help="skip the HNSW reference-comparable mode inside the ANN measurement")
     ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="base vectors of the HNSW reference-comparable run (the build is timed too)")
@@ -188,8 +189,6 @@ def main():
     def step(record=False):
         g.reset(stream)
         launch(record, kms)
-        if False:
-            pass
         if abi_comm is not None:
             (abi_comm.exchange_alltoall if exchange == "alltoall" else abi_comm.exchange_allgather)(g, 256, stream)
         elif world > 1:
@@ -339,6 +338,9 @@ def main():
             # nothing to find): unit-length vectors around 1024 centres, the shape embedding models emit
             ann["hnsw_reference_mode_clustered"] = BH.run(rows=args.hnsw_rows, dim=args.ann_dim, queries=10_000, k=10, clusters=1024, normalize=True)
 
+    blocks = None
+    if rank == 0 and world == 1 and not args.no_blocks:
+        blocks = bench_block_sizes(cpu)
     if rank == 0:
         achieved = (n * BYTES_PER_ROW) / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
         traffic, traffic_src = None, None
@@ -374,6 +376,7 @@ def main():
             "cpu_baseline": cpu,
             "multi_gpu_readiness": readiness,
             "q1_operator_plan": opplan,
+            "q1_block_size_sweep": blocks,
             "q3_sf100": q3,
             "distributed_plan_stages": plans,
             "ann": ann,
@@ -514,6 +517,35 @@ def bench_operator_plan(li, tpch, D, L, check, fused_result, fused_kernel_ms):
             out["fused_program_rescale"] = {"error": repr(e)}
         check(L.dbhip_trim())
     return out
+
+
+def bench_block_sizes(cpu):
+    """The drop-in at the block size the reference hands over: the same Q1 program fed through the C-ABI as blocks of
+    65,536 (max_block_size, settings_default.rs:142-148) / 262,144 / 1 Mi / 16 Mi / all rows, from 1 and from 8 host threads with their
+    own streams and partial tables — synchronous calls and the pipelined table (dbhip_groupby_set_pipelined) side by side. Runs
+    databend_amd/host/block_sweep (C++: a Python loop would measure ctypes) in a process of its own, outside every timed region;
+    every line's result equals the whole-table call's. The CPU baseline runs 65,536-row blocks too: quoted beside it."""
+    exe = os.path.join(ROOT, "databend_amd", "host", "block_sweep")
+    if not os.path.exists(exe):
+        return {"skipped": "databend_amd/host/block_sweep is not built"}
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        outp = os.path.join(td, "sweep.json")
+        try:
+            r = subprocess.run([exe, "--only-q1", "--rows", str(32 << 20), "--out", outp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+        except subprocess.TimeoutExpired:
+            return {"skipped": "block_sweep timed out"}
+        if r.returncode != 0 or not os.path.exists(outp):
+            return {"failed": r.stderr.decode("utf-8", "replace")[-400:]}
+        j = json.load(open(outp))
+    lines = [{k: ln[k] for k in ("op", "block_rows", "threads", "g_rows_per_s", "us_per_call_per_thread", "host_us_inside_call", "equals_whole_table")} for ln in j["lines"]]
+    whole = max((ln["g_rows_per_s"] for ln in lines if ln["block_rows"] >= j["rows"]), default=None)
+    return {"rows": j["rows"], "whole_table_g_rows_per_s": whole, "lines": lines,
+            "cpu_baseline_g_rows_per_s_at_65536_row_blocks": (cpu["value"] / 1e9 if cpu else None), "cpu_threads": (cpu["cores"] if cpu else None),
+            "what": "rows/s of TPC-H Q1 (same program as the headline) when the table arrives as blocks of `block_rows` rows on `threads` host threads; "
+                    "q1_sync = one synchronous dbhip_groupby_add_block_program per block, q1_pipelined = the same call on a pipelined table "
+                    "(blocks queued, 32 per launch, one checkpoint at the end)"}
 
 
 def cpu_baseline(args, li, n, tpch, result):
