@@ -114,12 +114,21 @@ struct dbhip_comm {
   ncclComm_t comm = nullptr;
   LoopGroup* loop = nullptr;
   int rank = 0, world = 1;
+  bool aborted = false;      // dbhip_comm_abort ran on an RCCL communicator: every later collective returns an error (a NULL `comm` alone
+                             // means "a local world of one", whose collectives are copies)
   void* send = nullptr;      // exchange staging (blocks), grown on demand
   void* recv = nullptr;
   size_t cap = 0;
 };
 
 namespace {
+
+// `comm == nullptr` is the single-rank copy path ONLY for a world of one; an aborted communicator answers every collective with an error
+int32_t comm_usable(const dbhip_comm* c, const char* what) {
+  if (c->aborted) { set_error("%s: the communicator was aborted (dbhip_comm_abort)", what); return DBHIP_ERR_INVALID; }
+  if (!c->comm && !c->loop && c->world != 1) { set_error("%s: the communicator of a world of %d has no RCCL handle", what, c->world); return DBHIP_ERR_INVALID; }
+  return DBHIP_OK;
+}
 
 int32_t ensure_staging(dbhip_comm* c, size_t bytes) {
   if (c->cap >= bytes) return DBHIP_OK;
@@ -138,6 +147,7 @@ struct XPiece;
 int32_t alltoall_bytes_loop(dbhip_comm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t s);
 int32_t alltoall_bytes(dbhip_comm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t s) {
   if (c->loop) return alltoall_bytes_loop(c, send, recv, bytes_per_peer, s);
+  if (const int32_t u = comm_usable(c, "all-to-all")) return u;
   if (!c->comm) {   // a local world of one: the exchange is a copy
     if (send != recv) DBHIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, s));
     return DBHIP_OK;
@@ -247,6 +257,7 @@ int32_t loop_collective(dbhip_comm* c, const LoopOp& mine, hipStream_t s) {
 
 int32_t alltoallv_group(dbhip_comm* c, const std::vector<XPiece>& xs, hipStream_t s) {
   if (c->loop) { LoopOp op; op.kind = 2; op.pieces = &xs; return loop_collective(c, op, s); }
+  if (const int32_t u = comm_usable(c, "all-to-all (variable)")) return u;
   if (!c->comm) {
     for (const XPiece& x : xs)
       if (x.send_bytes[0]) DBHIP_CHECK(hipMemcpyAsync(x.recv + x.recv_off[0], x.send + x.send_off[0], x.send_bytes[0], hipMemcpyDeviceToDevice, s));
@@ -400,6 +411,9 @@ static int32_t exchange_begin_impl(dbhip_comm* c, const dbhip_col* cols, int32_t
 // rendezvous of the counts: it aborts the group instead, and they return DBHIP_ERR_INVALID with this rank's message.
 int32_t dbhip_exchange_begin(dbhip_comm* c, const dbhip_col* cols, int32_t ncols, const uint32_t* dest_index, int64_t n, int64_t* out_recv_rows_host,
                              dbhip_exchange** out_host, void* stream) {
+  // (ANY failure aborts the group, argument errors included: the peers enter the same exchange on their own threads and may already
+  // be waiting in the rendezvous of the counts for a rank that has just decided not to come — tests/test_gpu_comm.py holds that case.
+  // The price: a group is dead after one bad call; it is per query, like the reference's exchange channels.)
   const int32_t rc = exchange_begin_impl(c, cols, ncols, dest_index, n, out_recv_rows_host, out_host, stream);
   if (rc != DBHIP_OK && c && c->loop) {
     const std::string why = dbhip_last_error();   // (loop_abort must not disturb this rank's own message)
@@ -625,7 +639,9 @@ int32_t dbhip_exchange_finish_strings(dbhip_exchange* x, void* const* out_data_h
   std::vector<std::vector<size_t>> soffs;
   soffs.reserve(x->str_cols.size() * 4);
   for (size_t j = 0; j < x->str_cols.size() && rc == DBHIP_OK; ++j) {
-    if (x->rbyte_start[j][W] == 0 && x->sbyte_start[j][W] == 0) continue;
+    // (posted for EVERY String column, also when this rank neither sends nor receives long bytes for it: the loopback rendezvous
+    // needs the same number of pieces from every rank, and another rank may well move bytes of this column; zero-byte transfers
+    // are skipped by both transports and their pointers never dereferenced)
     soffs.emplace_back(W); soffs.emplace_back(W); soffs.emplace_back(W); soffs.emplace_back(W);
     std::vector<size_t>&so = soffs[soffs.size() - 4], &sb = soffs[soffs.size() - 3], &ro = soffs[soffs.size() - 2], &rb = soffs[soffs.size() - 1];
     for (int p = 0; p < W; ++p) {
@@ -698,6 +714,8 @@ int32_t dbhip_vec_topk_allgather(dbhip_comm* c, const uint32_t* idx_dev, const f
     if (rc) return rc;
     LoopOp b; b.kind = 1; b.send = (const uint8_t*)dist_dev; b.recv = (uint8_t*)all_d; b.bytes = (size_t)per * 4;
     if ((rc = loop_collective(c, b, s))) return rc;
+  } else if (const int32_t u = comm_usable(c, "dbhip_vec_topk_allgather")) {
+    return u;
   } else if (!c->comm) {
     DBHIP_CHECK(hipMemcpyAsync(all_i, my_i, (size_t)per * 4, hipMemcpyDeviceToDevice, s));
     DBHIP_CHECK(hipMemcpyAsync(all_d, dist_dev, (size_t)per * 4, hipMemcpyDeviceToDevice, s));
@@ -786,8 +804,16 @@ int32_t dbhip_comm_destroy(dbhip_comm* c) {
 
 int32_t dbhip_comm_abort(dbhip_comm* c) {
   DBHIP_REQUIRE(c, "dbhip_comm_abort: NULL argument");
-  if (c->loop) loop_abort(c, "dbhip_comm_abort");
-  else if (c->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm), c->comm = nullptr;
+  if (c->loop) { loop_abort(c, "dbhip_comm_abort"); return DBHIP_OK; }
+  if (!c->comm) { c->aborted = c->world > 1; return DBHIP_OK; }   // (a world of one has nobody to tell)
+  c->aborted = true;   // whatever happens below: no later collective of this handle runs
+  if (!g_rccl.CommAbort) {
+    set_error("dbhip_comm_abort: this librccl has no ncclCommAbort; the communicator is marked aborted on this rank only — peers blocked "
+              "in a collective stay blocked");
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  (void)g_rccl.CommAbort(c->comm);
+  c->comm = nullptr;
   return DBHIP_OK;
 }
 
@@ -796,6 +822,7 @@ int32_t dbhip_comm_allgather(dbhip_comm* c, const void* send_dev, void* recv_dev
   hipStream_t s = resolve_stream(stream);
   if (bytes_per_rank == 0) return DBHIP_OK;
   if (c->loop) { LoopOp a; a.kind = 1; a.send = (const uint8_t*)send_dev; a.recv = (uint8_t*)recv_dev; a.bytes = (size_t)bytes_per_rank; return loop_collective(c, a, s); }
+  if (const int32_t u = comm_usable(c, "dbhip_comm_allgather")) return u;
   if (!c->comm) {
     DBHIP_CHECK(hipMemcpyAsync((uint8_t*)recv_dev + (size_t)c->rank * bytes_per_rank, send_dev, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, s));
     return DBHIP_OK;
@@ -815,6 +842,7 @@ int32_t dbhip_comm_allreduce_sum_u64(dbhip_comm* c, const uint64_t* send_dev, ui
   hipStream_t s = resolve_stream(stream);
   if (count == 0) return DBHIP_OK;
   if (c->loop) { set_error("dbhip_comm_allreduce_sum_u64: not part of the in-process loopback world"); return DBHIP_ERR_UNSUPPORTED; }
+  if (const int32_t u = comm_usable(c, "dbhip_comm_allreduce_sum_u64")) return u;
   if (!c->comm) {
     if (send_dev != recv_dev) DBHIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, (size_t)count * 8, hipMemcpyDeviceToDevice, s));
     return DBHIP_OK;

@@ -740,6 +740,9 @@ int32_t open_device_impl(const uint8_t* chunk_host, int64_t chunk_len, int32_t c
         if (!enc_ok) { rc = dv_unsupported("value encoding other than PLAIN / RLE_DICTIONARY / RLE (BOOLEAN) / DELTA_BINARY_PACKED (INT32, INT64)"); break; }
         if ((e == ENC_PLAIN_DICT || e == ENC_RLE_DICT) && c->dict_page < 0) { rc = dv_malformed("dictionary-encoded page without a dictionary page"); break; }
         if (h.type == PG_DATA && c->max_def == 1 && h.def_enc != ENC_RLE) { rc = dv_unsupported("definition levels not RLE encoded"); break; }
+        // List mode, v1 pages: dv_levels_kernel reads BOTH level streams as <4-byte length><RLE / bit-packed hybrid runs>; a legacy
+        // BIT_PACKED stream (no length prefix) would be read as a length and runs
+        if (list_mode && h.type == PG_DATA && (h.def_enc != ENC_RLE || h.rep_enc != ENC_RLE)) { rc = dv_unsupported("List column: definition / repetition levels not RLE encoded"); break; }
         if ((uint64_t)c->rows + (uint64_t)P.num_values >= 0xFFFFFFF0ULL) { rc = dv_unsupported("more than 2^32 rows in one chunk"); break; }
         P.row_start = (uint64_t)c->rows;
         if (!(h.type == PG_DATA_V2 && h.num_nulls == 0) || list_mode) all_v2_no_nulls = false;
@@ -1119,19 +1122,18 @@ int32_t decode_list(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_
   const int esize = out_elem_size(c->out_type);
   const bool is_bool = c->out_type == DBHIP_T_BOOL;
   const int64_t nwords = ceil_div(entries, 32), wbytes = ceil_div(entries, 64) * 8;
-  if (!c->d_isrep) {
-    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_isrep));
-    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_iselem));
-    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_lvalid));
-    DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_ent_valid));
-    DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)wbytes : (size_t)entries * (size_t)esize, &c->d_ent_values));
-    DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_rcnt));
-    DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_ecnt));
-    DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_roff));
-    DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_eoff));
-    DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_lblk));
-    DBHIP_TRY(dbhip_alloc(64, (void**)&c->d_lcounts));
-  }
+  // (each buffer behind its own check: an allocation that fails part way leaves the handle retryable, not half-built)
+  if (!c->d_isrep) DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_isrep));
+  if (!c->d_iselem) DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_iselem));
+  if (!c->d_lvalid) DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_lvalid));
+  if (!c->d_ent_valid) DBHIP_TRY(dbhip_alloc((size_t)wbytes, (void**)&c->d_ent_valid));
+  if (!c->d_ent_values) DBHIP_TRY(dbhip_alloc(is_bool ? (size_t)wbytes : (size_t)entries * (size_t)esize, &c->d_ent_values));
+  if (!c->d_rcnt) DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_rcnt));
+  if (!c->d_ecnt) DBHIP_TRY(dbhip_alloc((size_t)nwords * 4, (void**)&c->d_ecnt));
+  if (!c->d_roff) DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_roff));
+  if (!c->d_eoff) DBHIP_TRY(dbhip_alloc((size_t)nwords * 8, (void**)&c->d_eoff));
+  if (!c->d_lblk) DBHIP_TRY(dbhip_alloc((size_t)(ceil_div(nwords, SCAN_TILE) + 2) * 8, (void**)&c->d_lblk));
+  if (!c->d_lcounts) DBHIP_TRY(dbhip_alloc(64, (void**)&c->d_lcounts));
   DBHIP_CHECK(hipMemsetAsync(c->d_isrep, 0, (size_t)wbytes, s));
   DBHIP_CHECK(hipMemsetAsync(c->d_iselem, 0, (size_t)wbytes, s));
   DBHIP_CHECK(hipMemsetAsync(c->d_lvalid, 0, (size_t)wbytes, s));

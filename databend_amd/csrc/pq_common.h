@@ -97,12 +97,12 @@ enum { PT_BOOLEAN = 0, PT_INT32 = 1, PT_INT64 = 2, PT_INT96 = 3, PT_FLOAT = 4, P
 
 struct PageHdr {
   int32_t type = -1, uncompressed = -1, compressed = -1;
-  int32_t num_values = -1, encoding = -1, def_enc = ENC_RLE;
+  int32_t num_values = -1, encoding = -1, def_enc = ENC_RLE, rep_enc = ENC_RLE;
   int32_t num_nulls = -1, def_len = 0, rep_len = 0;
   bool v2_compressed = true;
 };
 
-// fields of DataPageHeader (1 num_values, 2 encoding, 3 definition_level_encoding), DictionaryPageHeader
+// fields of DataPageHeader (1 num_values, 2 encoding, 3 definition_level_encoding, 4 repetition_level_encoding), DictionaryPageHeader
 // (1 num_values, 2 encoding) and DataPageHeaderV2 (1 num_values, 2 num_nulls, 3 num_rows, 4 encoding,
 // 5 definition_levels_byte_length, 6 repetition_levels_byte_length, 7 is_compressed) — parquet.thrift
 void read_sub(Rd& r, PageHdr& h, int which) {
@@ -122,9 +122,10 @@ void read_sub(Rd& r, PageHdr& h, int which) {
         continue;
       }
     } else {
-      if (is_int && last >= 1 && last <= 3) {
+      if (is_int && last >= 1 && last <= 4) {
         const int32_t v = (int32_t)r.zigzag();
-        if (last == 1) h.num_values = v; else if (last == 2) h.encoding = v; else if (which == PG_DATA) h.def_enc = v;
+        if (last == 1) h.num_values = v; else if (last == 2) h.encoding = v; else if (which == PG_DATA && last == 3) h.def_enc = v;
+        else if (which == PG_DATA && last == 4) h.rep_enc = v;
         continue;
       }
     }

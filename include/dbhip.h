@@ -833,7 +833,10 @@ int32_t dbhip_comm_destroy(dbhip_comm* c);
 /* A rank that gives up (its part of the plan failed, the query was cancelled) tells the others instead of leaving them waiting:
  * loopback — the group is marked failed, every rank waiting in a rendezvous and every later collective of the group returns
  * DBHIP_ERR_INVALID with the aborting rank's message (a failed dbhip_exchange_begin does this by itself; a rendezvous also gives up
- * after DBHIP_COMM_TIMEOUT_S seconds, default 600); RCCL — ncclCommAbort, the communicator is gone afterwards. */
+ * after DBHIP_COMM_TIMEOUT_S seconds, default 600); RCCL — ncclCommAbort: the handle is marked aborted and every later collective on it returns DBHIP_ERR_INVALID (never a
+ * silent single-rank copy); DBHIP_ERR_UNSUPPORTED when this librccl has no ncclCommAbort (the handle is still marked aborted on
+ * this rank, peers blocked in a collective stay blocked). Under RCCL a FAILED dbhip_exchange_begin notifies nobody by itself: the
+ * host calls dbhip_comm_abort on that rank (the peers' collectives then fail) — there is no timeout inside RCCL collectives. */
 int32_t dbhip_comm_abort(dbhip_comm* c);
 int32_t dbhip_comm_allgather(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
 int32_t dbhip_comm_alltoall(dbhip_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_peer, void* stream);
