@@ -445,7 +445,22 @@ int orc_pq_decode(const uint8_t* chunk, int64_t len, int physical, int type_leng
  * NULL / empty list without an element, max_def is a value, the level in between a NULL element). One level entry at a time:
  *   out_offsets[r] .. out_offsets[r + 1]  the elements of row r (Databend's ArrayColumn offsets), out_list_valid[r] = the list is not NULL,
  *   out_values / out_elem_valid           the elements back to back in the output type (a NULL element: zero bytes).
- * UNCOMPRESSED chunks, PLAIN / dictionary / RLE-Boolean / DELTA_BINARY_PACKED values, v1 and v2 pages. -> 0, -1 malformed, -2 not handled */
+ * UNCOMPRESSED chunks (SNAPPY v1 pages through orc_pq_decode_list_codec: the List<Int64> column of the reference's
+ * tests/data/parquet/multi_page files, fixed-width values only), PLAIN / dictionary / RLE-Boolean / DELTA_BINARY_PACKED values, v1 and
+ * v2 pages. -> 0, -1 malformed, -2 not handled */
+int orc_pq_decode_list(const uint8_t* chunk, int64_t len, int physical, int type_length, int list_nullable, int elem_nullable, int out_type,
+                       int64_t cap_entries, uint64_t* out_offsets, uint8_t* out_list_valid, uint8_t* out_values, uint8_t* out_elem_valid,
+                       int64_t* out_rows, int64_t* out_elems);
+int orc_pq_decode_list_codec(const uint8_t* chunk, int64_t len, int codec, int physical, int type_length, int list_nullable, int elem_nullable, int out_type,
+                             int64_t cap_entries, uint64_t* out_offsets, uint8_t* out_list_valid, uint8_t* out_values, uint8_t* out_elem_valid,
+                             int64_t* out_rows, int64_t* out_elems) {
+  if ((codec != 0 && codec != 1) || (codec == 1 && physical == PT_BYTE_ARRAY)) return -2;
+  g_pq_codec = codec;
+  const int rc = orc_pq_decode_list(chunk, len, physical, type_length, list_nullable, elem_nullable, out_type, cap_entries, out_offsets, out_list_valid,
+                                    out_values, out_elem_valid, out_rows, out_elems);
+  g_pq_codec = 0;
+  return rc;
+}
 int orc_pq_decode_list(const uint8_t* chunk, int64_t len, int physical, int type_length, int list_nullable, int elem_nullable, int out_type,
                        int64_t cap_entries, uint64_t* out_offsets, uint8_t* out_list_valid, uint8_t* out_values, uint8_t* out_elem_valid,
                        int64_t* out_rows, int64_t* out_elems) {
@@ -454,6 +469,8 @@ int orc_pq_decode_list(const uint8_t* chunk, int64_t len, int physical, int type
   const int pw = physical == PT_INT32 || physical == PT_FLOAT ? 4 : (physical == PT_INT64 || physical == PT_DOUBLE ? 8 : type_length);
   const int max_def = list_nullable + 1 + elem_nullable;
   const int dw = max_def > 1 ? 2 : 1;
+  uint8_t* inflated[256];
+  int n_inflated = 0;
   int64_t rows = 0, elems = 0, entries = 0;
   int64_t dict_n = -1;
   uint8_t* dict = NULL;
@@ -465,7 +482,13 @@ int orc_pq_decode_list(const uint8_t* chunk, int64_t len, int physical, int type
     const uint8_t* pay = r.p;
     const uint8_t* pend = pay + pg.csize;
     r.p = pend;
-    if (pg.csize != pg.usize) { rc = -2; break; }
+    if (g_pq_codec == 1) {   /* SNAPPY v1 / dictionary pages: the whole payload is inflated first */
+      if (pg.type == 3 || pg.usize < 0 || n_inflated >= 256) { rc = -2; break; }
+      uint8_t* buf = (uint8_t*)malloc((size_t)pg.usize + 16);
+      inflated[n_inflated++] = buf;
+      if (snappy_raw(pay, pg.csize, buf, pg.usize) != pg.usize) { rc = -1; break; }
+      pay = buf; pend = buf + pg.usize;
+    } else if (pg.csize != pg.usize) { rc = -2; break; }
     if (pg.type == 2) {
       if (dict_n >= 0 || pg.nvals < 0 || (pg.enc != 0 && pg.enc != 2)) { rc = pg.enc != 0 && pg.enc != 2 ? -2 : -1; break; }
       dict_n = pg.nvals;
@@ -576,6 +599,7 @@ int orc_pq_decode_list(const uint8_t* chunk, int64_t len, int physical, int type
     entries += pg.nvals;
   }
   free(dict);
+  for (int i = 0; i < n_inflated; ++i) free(inflated[i]);
   out_offsets[rows] = (uint64_t)elems;
   *out_rows = rows;
   *out_elems = elems;

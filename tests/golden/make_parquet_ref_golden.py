@@ -14,6 +14,8 @@ Files and what the reference's tests say about them:
       timestamp.test:1-36: four timestamps (2023-10-13 10:00 ... 2023-10-16 12:00), 300 rows each, all 1200 rows
   tests/data/parquet/multi_page/multi_page_{1..4}.parquet (parquet-cpp-arrow 11, SNAPPY, data_page_size 128: many pages per chunk)
       select_parquet.test:69-72 count() = 400 over the four files; gen.py: col_int = [0, 1] * rows
+      the SAME files hold col_arr = [[1], [1, 2]] * rows (gen.py:12, "we need multi pages in a column chunk for list type"):
+      List<Int64> leaves col_arr.list.item (max_def 3, max_rep 1) whose rows span many 128-byte pages -> multi_page_{k}_col_arr
   tests/data/ontime_200.parquet (parquet-cpp-arrow 14, SNAPPY)
       on_time.test:1-12: the nine tail_number values where dayofmonth = 1; :54-61 month = 12"""
 import json
@@ -102,6 +104,13 @@ def main():
              "tests/sqllogictests/suites/stage/formats/parquet/select_parquet.test:69-72 (400 rows over the four files); tests/data/parquet/multi_page/gen.py "
              "(col_int = [0, 1] * rows, 20-row row groups, data_page_size 128)",
              chunks_of(os.path.join(REF, f"parquet/multi_page/multi_page_{k}.parquet"), columns=["col_int"]), {"rows": nrows, "pattern": [0, 1]})
+    for k, nrows in ((1, 40), (2, 120), (3, 80), (4, 160)):
+        # the List<Int64> column of the same files: the known answer is gen.py's own literal (the reference's tests only count these rows)
+        emit(f"multi_page_{k}_col_arr", f"tests/data/parquet/multi_page/multi_page_{k}.parquet",
+             "tests/data/parquet/multi_page/gen.py:12 (col_arr = [[1], [1, 2]] * num_row: 'multi pages in a column chunk for list type', "
+             "databend PR 11271); rows counted by tests/sqllogictests/suites/stage/formats/parquet/select_parquet.test:69-72",
+             chunks_of(os.path.join(REF, f"parquet/multi_page/multi_page_{k}.parquet"), columns=["col_arr.list.item"]),
+             {"rows": nrows, "pattern": [[1], [1, 2]], "list_nullable": 1, "element_nullable": 1})
     emit("ontime_200", "tests/data/ontime_200.parquet", "tests/sqllogictests/suites/stage/formats/parquet/on_time.test:1-12,54-61",
          chunks_of(os.path.join(REF, "ontime_200.parquet"), columns=["DayofMonth", "Tail_Number", "Month"]),
          {"tail_number_where_dayofmonth_1": ["N315PQ", "N835AY", "N606LR", "N606LR", "N301PQ", "N176PQ", "N336PQ", "N901XJ", "N909XJ"], "month_all": 12,

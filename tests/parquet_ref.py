@@ -96,3 +96,21 @@ def check_all(decode):
     assert [t.decode() for t, dd in zip(tail, day) if dd == 1] == d["expected"]["tail_number_where_dayofmonth_1"]
     checked += 1
     return checked
+
+
+def check_lists(decode_list):
+    """The List<Int64> column of the reference's multi_page_{1..4}.parquet (col_arr = [[1], [1, 2]] * num_row, gen.py:12; SNAPPY, 128-byte
+    data pages: a row group's rows span many pages). `decode_list(ch, list_nullable, element_nullable, out_type) -> python list of lists`."""
+    fx = fixtures()
+    total = 0
+    for k in (1, 2, 3, 4):
+        d = fx[f"multi_page_{k}_col_arr"]
+        e = d["expected"]
+        rows = []
+        for ch in d["chunks"]:
+            assert ch["max_rep"] == 1 and ch["max_def"] == e["list_nullable"] + 1 + e["element_nullable"]
+            rows += decode_list(ch, e["list_nullable"], e["element_nullable"], OUT_OF_PHYS[ch["physical"]])
+        assert len(rows) == e["rows"] and rows == e["pattern"] * (e["rows"] // 2), (k, rows[:6])
+        total += len(rows)
+    assert total == 400
+    return 4

@@ -503,3 +503,21 @@ def test_list_columns_equal_the_oracle(gpu, oracle, name):
     else:
         assert col.data.to_numpy(np.uint8, m * es).tobytes() == vals[: m * es].tobytes()
     pc.close()
+
+
+def test_list_column_of_the_reference_held_multi_page_files(gpu):
+    """col_arr of tests/data/parquet/multi_page/multi_page_{1..4}.parquet through dbhip_pq_chunk_open_device_list / decode_device_list:
+    [[1], [1, 2]] * num_row (gen.py:12), SNAPPY dictionary-encoded v1 pages, rows spanning pages — the reference-held pin of the List
+    decode (the CPU suite runs the same fixtures through the oracle)."""
+    from tests import parquet_ref as PR
+
+    def decode_list(ch, ln, en, ot):
+        pc = gpu.ParquetChunk(ch["chunk"], ch["physical"], ot, ch["type_length"], codec=ch["codec"], list_of=(ln, en))
+        offs, lv, col = pc.decode_list()
+        assert int(offs[-1]) == pc.elems == col.n and pc.null_lists == 0
+        ev = col.validity_numpy() if en else np.ones(col.n, bool)
+        vals = col.to_numpy().tolist()
+        out = [None if (lv is not None and not lv[r]) else [vals[x] if ev[x] else None for x in range(int(offs[r]), int(offs[r + 1]))] for r in range(pc.rows)]
+        pc.close()
+        return out
+    assert PR.check_lists(decode_list) == 4

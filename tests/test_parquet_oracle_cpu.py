@@ -556,3 +556,29 @@ def test_device_mode_list_open_survives_mutated_chunks():
             assert 0 <= info.image_bytes <= max(1 << 30, 1024 * len(b)) + 16 and info.num_values >= 0
         seen.add(rc)
     assert T.OK in seen and T.ERR_INVALID in seen
+
+
+def test_oracle_reads_the_list_column_of_the_reference_held_files():
+    """The List<Int64> column the reference keeps in tests/data/parquet/multi_page/multi_page_{1..4}.parquet (col_arr = [[1], [1, 2]] * num_row,
+    gen.py:12 — written "to test multi pages in a column chunk for list type"; SNAPPY, dictionary-encoded v1 pages of 128 bytes): the
+    List decode's pin on a reference-held fixture (rounds 4-5 pinned it on pyarrow's reading only)."""
+    from tests import oracle_lib
+    from tests import parquet_ref as PR
+    orc = oracle_lib.load()
+    orc.orc_pq_decode_list_codec.restype = C.c_int
+
+    def decode_list(ch, ln, en, ot):
+        ent = ch["num_values"]
+        chunk = np.frombuffer(ch["chunk"], dtype=np.uint8)
+        es = PU.ESIZE[ot]
+        offs, lval = np.zeros(ent + 2, np.uint64), np.zeros(ent + 1, np.uint8)
+        vals, ev = np.zeros(max(ent, 1) * es + 16, np.uint8), np.zeros(ent + 1, np.uint8)
+        rows, elems = C.c_int64(), C.c_int64()
+        rc = orc.orc_pq_decode_list_codec(chunk.ctypes.data_as(C.c_void_p), C.c_int64(len(chunk)), ch["codec"], ch["physical"], ch["type_length"], ln, en, ot,
+                                          C.c_int64(ent), offs.ctypes.data_as(C.c_void_p), lval.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                          ev.ctypes.data_as(C.c_void_p), C.byref(rows), C.byref(elems))
+        assert rc == 0 and int(offs[rows.value]) == elems.value
+        m = elems.value
+        py = PU.decoded_to_python(vals.tobytes(), ev[:m].astype(bool), ot, m, chunk)
+        return [None if (ln and not lval[r]) else py[int(offs[r]):int(offs[r + 1])] for r in range(rows.value)]
+    assert PR.check_lists(decode_list) == 4
