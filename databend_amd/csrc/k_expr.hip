@@ -553,7 +553,7 @@ int32_t dbhip_expr_eval(const dbhip_expr_ins* prog_host, int32_t n_ins, const db
     case DBHIP_T_DEC128: O.out_kind = 16; break;
     default: O.out_kind = type_bits(root.type) / 8; break;
   }
-  static const bool force2 = getenv("DBHIP_EXPR_ROWS2") != nullptr;
+  static const bool force2 = exp_env("DBHIP_EXPR_ROWS2") != nullptr;
   kernel_timer_start(s);
   // row slots per lane: 4 (32 B per operand per lane in flight, half the per-row interpreter overhead) while the LDS register
   // file allows it, else 2

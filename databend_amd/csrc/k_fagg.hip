@@ -284,7 +284,7 @@ void mkdir_p(const std::string& dir) {
 // sources lives inside it, so that the helper's rename stays on one file system).
 bool jit_compile(const std::string& meta, const std::string& tail, std::vector<char>* code, std::string* log, bool detached = false) {
   const std::string arch = jit_arch();
-  const std::string defs = getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
+  const std::string defs = exp_env("DBHIP_FAGG_JIT_DEFS") ? exp_env("DBHIP_FAGG_JIT_DEFS") : "";
   const std::string cached = jit_cache_path(meta, tail, arch, defs);
   if (!cached.empty() && read_cached_code(cached, code)) return true;   // compiled by an earlier process (or an earlier table)
   code->clear();
@@ -313,7 +313,7 @@ bool jit_compile(const std::string& meta, const std::string& tail, std::vector<c
   if (detached) { args.push_back("--detach"); args.push_back("--publish"); args.push_back(cached); args.push_back("--rmdir"); args.push_back(dir); }
   for (const std::string& a : {dir + "/main.hip", dir + "/out.co", "-I" + dir, "--offload-arch=" + arch, std::string("-O3"), std::string("-std=c++17"),
                                std::string("-mllvm"), std::string("-pragma-unroll-threshold=4000000")}) args.push_back(a);
-  if (const char* e = getenv("DBHIP_FAGG_JIT_DEFS")) {   // experiment knobs, e.g. "-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
+  if (const char* e = exp_env("DBHIP_FAGG_JIT_DEFS")) {   // experiment knobs, e.g. "-DFA_JIT_ROWS=4 -DFA_JIT_GLOBAL" (read per compile)
     std::string t;
     for (const char* c = e;; ++c) {
       if (*c == ' ' || *c == 0) { if (!t.empty()) args.push_back(t); t.clear(); if (!*c) break; }
@@ -436,7 +436,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   (void)hipGetDevice(&dev);
   std::string key((const char*)&K, sizeof(K));
   key += "|" + std::to_string(slots) + "|" + std::to_string((int)general) + "|" + std::to_string(nw) + "|" + std::to_string(dev) + "|" + (multi ? "m|" : "|");
-  key += getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "";
+  key += exp_env("DBHIP_FAGG_JIT_DEFS") ? exp_env("DBHIP_FAGG_JIT_DEFS") : "";
   const bool trace = getenv("DBHIP_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_jit_mu);
   auto it = g_jit_cache.find(key);
@@ -457,7 +457,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   std::string log;
   bool have = false;
   {
-    const std::string cached = jit_cache_path(meta, tail, jit_arch(), getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
+    const std::string cached = jit_cache_path(meta, tail, jit_arch(), exp_env("DBHIP_FAGG_JIT_DEFS") ? exp_env("DBHIP_FAGG_JIT_DEFS") : "");
     have = !cached.empty() && read_cached_code(cached, &code);
   }
   const bool from_disk = have;
@@ -480,7 +480,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
     if (pending) *pending = e.state == JitEntry::PENDING;
     return nullptr;
   }
-  if (const char* dump = getenv("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
+  if (const char* dump = exp_env("DBHIP_FAGG_JIT_DUMP")) {   // code object (and the generated metadata) for offline disassembly
     static int seq = 0;
     char path[512];
     snprintf(path, sizeof(path), "%s.%d.co", dump, seq);
@@ -496,7 +496,7 @@ hipFunction_t jit_kernel(const FaArgs& A, int slots, bool general, int nw, int h
   if (from_disk) {
     // a cached file that does not load (another compiler's, corrupt): a cache miss, not a verdict on the shape — drop it so
     // that the next PREPARE / background compile writes a fresh one
-    const std::string cached = jit_cache_path(meta, tail, jit_arch(), getenv("DBHIP_FAGG_JIT_DEFS") ? getenv("DBHIP_FAGG_JIT_DEFS") : "");
+    const std::string cached = jit_cache_path(meta, tail, jit_arch(), exp_env("DBHIP_FAGG_JIT_DEFS") ? exp_env("DBHIP_FAGG_JIT_DEFS") : "");
     if (!cached.empty()) (void)unlink(cached.c_str());
     e.state = JitEntry::ABSENT;
     if (trace) fprintf(stderr, "[dbhip] fagg jit: the cached code object did not load; removed, the shape will be compiled again\n");
@@ -874,7 +874,7 @@ int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
 
 // a block enters a pipelined table: large ones are launched at once, small ones wait for company
 int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStream_t s) {
-  static const bool no_batch = getenv("DBHIP_FAGG_PIPE_BATCH") && atoi(getenv("DBHIP_FAGG_PIPE_BATCH")) == 0;
+  static const bool no_batch = exp_env("DBHIP_FAGG_PIPE_BATCH") && atoi(exp_env("DBHIP_FAGG_PIPE_BATCH")) == 0;
   if (P.b.n >= FA_PIPE_BIG || no_batch || jit_mode() == 0) {
     const int32_t rc = fa_pipe_flush_batch(g, pp);   // (blocks stay in call order)
     return rc ? rc : fa_pipe_submit(g, pp, P, s);
@@ -1069,7 +1069,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   // grid: whole multiples of the 256 CUs, 2 workgroups per CU (k_q1.hip's sweep: fewer, longer-running workgroups stream best)
   const int64_t nchunks = ceil_div(n, 64 * FA_ROWS);
   int grid = (int)(ceil_div(nchunks, 4) < 512 ? ceil_div(nchunks, 4) : 512);
-  static const int env_grid = getenv("DBHIP_FAGG_GRID") ? atoi(getenv("DBHIP_FAGG_GRID")) : 0;
+  static const int env_grid = exp_env("DBHIP_FAGG_GRID") ? atoi(exp_env("DBHIP_FAGG_GRID")) : 0;
   if (env_grid > 0) grid = (int)(ceil_div(nchunks, 4) < env_grid ? ceil_div(nchunks, 4) : env_grid);
   if (FaPipe* pp = (FaPipe*)*dbhip_groupby_pipe_slot_internal(g); pp && !t_prepare_only) {
     int64_t committed = 0;         // a synchronous call on a table that still has queued blocks: those first
@@ -1089,7 +1089,7 @@ int32_t dbhip_groupby_add_block_program(dbhip_groupby* g, const dbhip_col* keys,
   const int64_t n_max = (int64_t)grid * FA_MAX_SLOTS;
   const bool chained = (dbhip_groupby_count_internal(g) + n_max) * 135 <= dbhip_groupby_capacity_internal(g) * 100;
   if ((rc = dbhip_groupby_reserve_merge_internal(g, n_max))) return rc;
-  static const bool no_chain = getenv("DBHIP_FAGG_NOCHAIN") != nullptr;   // debugging: drain the stream between kernel and merge
+  static const bool no_chain = exp_env("DBHIP_FAGG_NOCHAIN") != nullptr;   // debugging: drain the stream between kernel and merge
   if (t_prepare_only) {
     // dbhip_groupby_prepare_program: compile the specialised kernel of this query shape now (the 4-slot variant, or the
     // 8-slot one when the table already holds more than 4 groups), launch nothing

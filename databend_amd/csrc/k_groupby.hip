@@ -1764,7 +1764,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t h, int pbits) { return (uin
 #include "gb_compact.h"
 
 bool gbc_enabled(const dbhip_groupby* g) {
-  static const bool off = getenv("DBHIP_GBC") && atoi(getenv("DBHIP_GBC")) == 0;
+  static const bool off = exp_env("DBHIP_GBC") && atoi(exp_env("DBHIP_GBC")) == 0;
   return !off && !g->gbc_off && g->hash_mask == ~0ULL && !g->has_long;
 }
 
@@ -1896,7 +1896,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     // per 60 M rows; specialised, with every load of a chunk issued up front, r03: see DESIGN §2.3). Plain add_block has no
     // PREPARE, so the kernel is looked up in the in-process / on-disk caches; when it is nowhere yet a detached helper compiles it
     // into the on-disk cache and THIS block takes the LDS path — a query never waits for a compiler. DBHIP_FAGG_AUTO=0 disables.
-    static const bool fagg_auto_off = getenv("DBHIP_FAGG_AUTO") && atoi(getenv("DBHIP_FAGG_AUTO")) == 0;
+    static const bool fagg_auto_off = exp_env("DBHIP_FAGG_AUTO") && atoi(exp_env("DBHIP_FAGG_AUTO")) == 0;
     // A table that has not seen a row yet tries the kernel OPTIMISTICALLY, without the probing chunk, when the kernel already
     // exists (no compile is started for a shape whose cardinality is unknown): a workgroup that meets a 9th group stops at
     // once and nothing is merged, so a high-cardinality block loses a few microseconds and goes on to probe as before.
@@ -1925,7 +1925,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     if (probing) limit = 1 << 18;
     else if (g->fast_trusted) limit = n;
     const bool small = small_layout && !probing;
-    static const int small_r = getenv("DBHIP_LDS_R") ? atoi(getenv("DBHIP_LDS_R")) : 4;   // 4 (116 VGPRs, 4 waves / SIMD) or 8 (178, 2): r02n 1.00 vs 1.68 ms at 4 groups
+    static const int small_r = exp_env("DBHIP_LDS_R") ? atoi(exp_env("DBHIP_LDS_R")) : 4;   // 4 (116 VGPRs, 4 waves / SIMD) or 8 (178, 2): r02n 1.00 vs 1.68 ms at 4 groups
     // BIG table (r03): a small layout whose groups outgrew the 48 KB table (768 groups of 4 words) but fit one twice the size
     // runs ONE 1024-thread workgroup per CU on a 96 KB table (the same 4 waves per SIMD) instead of going through the
     // partitioning passes — 1000 groups: 1.97 ms partitioned, see DESIGN §2.3
@@ -2040,7 +2040,7 @@ int32_t add_block_fast(dbhip_groupby* g, const GbCols& C, int64_t n, hipStream_t
     if (((int64_t)hc[6] * 10 > cn || too_many) && cn >= 65536) {
       // twice the table is enough (estimated from the groups met so far): stay on the LDS path with the big table
       const int64_t big_limit = (int64_t)(lcap * 2 - lcap / 2) * 7 / 8;
-      static const bool big_off = getenv("DBHIP_LDS_BIG") && atoi(getenv("DBHIP_LDS_BIG")) == 0;
+      static const bool big_off = exp_env("DBHIP_LDS_BIG") && atoi(exp_env("DBHIP_LDS_BIG")) == 0;
       if (small_layout && !g->lds_big && !big_off && lds_bytes * 2 <= 128 * 1024 && estimate_groups(g->count_host, g->rows_seen) <= big_limit) {
         g->lds_big = 1;
         g->fast_trusted = 1;
@@ -2794,7 +2794,7 @@ int32_t gbc_partition_scatter(dbhip_groupby* g, const GbCols& C, const GbcDesc& 
   // 1024-thread workgroup per CU), one of 1024 threads beyond
   // (r04e: two 512-thread workgroups per CU instead of one of 1024 — 1024 row ranges instead of 512 — were SLOWER: 0.41 vs 0.38 ms at
   // 16 partitions, 0.69 vs 0.55 ms at 256: a workgroup's run inside a partition gets half as long)
-  static const int gbc_t = getenv("DBHIP_GBC_T") ? atoi(getenv("DBHIP_GBC_T")) : GBC_T;
+  static const int gbc_t = exp_env("DBHIP_GBC_T") ? atoi(exp_env("DBHIP_GBC_T")) : GBC_T;
   const int T = (RW > 8 && P > 1024) ? 512 : gbc_t;   // (rows of 9 ... 12 words beside 16 K cursors: 512 staged rows fit the LDS)
   int64_t nwg = ceil_div(cn, (int64_t)T * 16);
   if (nwg > 512) nwg = 512;
@@ -2820,7 +2820,7 @@ int32_t gbc_partition_scatter(dbhip_groupby* g, const GbCols& C, const GbcDesc& 
   const int SR = RW <= 2 ? 4 : (RW <= 4 ? 2 : 1);
   // up to 1024 partitions: no histogram pass — fixed regions (the uniform share + 5 % + 16 K rows) and one global atomic per
   // (batch, partition); a region that overflows is found after the chunk's first read-back and the chunk redone the exact way
-  static const bool no_direct = getenv("DBHIP_GBC_DIRECT") && atoi(getenv("DBHIP_GBC_DIRECT")) == 0;
+  static const bool no_direct = exp_env("DBHIP_GBC_DIRECT") && atoi(exp_env("DBHIP_GBC_DIRECT")) == 0;
   g->gbc_part_cap = 0;
   if (P <= 1024 && !g->gbc_nodirect && !no_direct && cn < ((int64_t)1 << 31)) {
     // a partition's share of the rows follows its share of the GROUPS: with G groups spread over P partitions a partition holds
@@ -2876,7 +2876,7 @@ void part_geometry(const GbLayout& L, int* lcap, int* sw, size_t* lds_bytes) {
 // halving of the partition count (longer runs per workgroup and partition).
 int gbc_part_threads(int lcap) { return lcap >= 4096 ? 1024 : (lcap >= 2048 ? 512 : 256); }
 int gbc_part_lcap(const GbLayout& L, int lcap_max) {
-  static const int env_c = getenv("DBHIP_GBC_PARTLCAP") ? atoi(getenv("DBHIP_GBC_PARTLCAP")) : 0;   // (experiments)
+  static const int env_c = exp_env("DBHIP_GBC_PARTLCAP") ? atoi(exp_env("DBHIP_GBC_PARTLCAP")) : 0;   // (experiments)
   const int max_c = env_c ? env_c : (lcap_max ? lcap_max : 2048);
   const size_t slot = (size_t)(L.nkey_words + (L.W - L.agg_off[0])) * 8 + 4;
   const size_t qrow = 48;   // (a deferred-row queue per wave: rows of up to 6 words, or the positions of wider rows)
@@ -2926,7 +2926,7 @@ int32_t partition_scatter(dbhip_groupby* g, const GbCols& C, int64_t row0, int64
   hipLaunchKernelGGL(gb_part_scan_kernel, dim3(1), dim3(1024), 0, s, tot, P, base);
   hipLaunchKernelGGL((gb_part_colscan_kernel<true>), dim3((P + 63) / 64), dim3(256), 0, s, mat, P, (int)nwg, tot, base);
   // staged copy-out while a batch of rows (2 or 1 per thread) fits the LDS beside the cursors; else lanes store their rows themselves
-  static const bool no_stage = getenv("DBHIP_GB_NOSTAGE") != nullptr;
+  static const bool no_stage = exp_env("DBHIP_GB_NOSTAGE") != nullptr;
   const size_t row_bytes = 4 + (size_t)(L.W | 1) * 8;
   const size_t lds2 = (size_t)P * 4 + (size_t)T * 2 * row_bytes, lds1 = (size_t)P * 4 + (size_t)T * row_bytes;
   const size_t lds_max = 144 * 1024;
@@ -3028,7 +3028,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
   if ((rc = ensure((void**)&g->partial, &g->partial_cap, (size_t)agrid * lcap * L.W * 8))) return rc;
   // one workgroup per partition and a table at least as fine as the partitioning: the partial rows stay per partition and
   // are merged by the partition's own workgroup (gb_part_merge_kernel); otherwise one packed list for the row path
-  static const bool no_excl = getenv("DBHIP_GB_NOEXCL") != nullptr;
+  static const bool no_excl = exp_env("DBHIP_GB_NOEXCL") != nullptr;
   const bool exclusive = splits == 1 && !no_excl && g->hash_mask == ~0ULL;
   uint32_t* pcount = g->part_meta + 2 * PT_PMAX + 8;
   if (exclusive) DBHIP_CHECK(hipMemsetAsync(pcount, 0, (size_t)P * 4, s));
@@ -3051,7 +3051,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
     // 10^6 where the partition has one workgroup): a partition longer than twice the average sub-range gets more sub-ranges, worked
     // on by EXTRA workgroups behind the regular P x splits (at most cn / max_rows of them; those not needed leave at once). Their
     // partial rows go to a packed list behind the per-partition lists and through the row path.
-    static const bool no_heavy = getenv("DBHIP_GBC_HEAVY") && atoi(getenv("DBHIP_GBC_HEAVY")) == 0;
+    static const bool no_heavy = exp_env("DBHIP_GBC_HEAVY") && atoi(exp_env("DBHIP_GBC_HEAVY")) == 0;
     int extra_max = 0;
     if (!no_heavy) {
       int64_t max_rows = 2 * (cn / agrid);
@@ -3064,7 +3064,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
       G.nparts = P; G.packed_base = (uint64_t)agrid * lcap;
       hipLaunchKernelGGL(gbc_split_map_kernel, dim3(1), dim3(1024), 0, s, G.pcursor, G.part_cap, base, P, splits, (uint32_t)max_rows, (uint32_t)extra_max, g->gbc_split);
     }
-    static const int agg_t = getenv("DBHIP_GBC_AGGT") ? atoi(getenv("DBHIP_GBC_AGGT")) : 0;   // (experiments)
+    static const int agg_t = exp_env("DBHIP_GBC_AGGT") ? atoi(exp_env("DBHIP_GBC_AGGT")) : 0;   // (experiments)
     const int threads = agg_t ? agg_t : gbc_part_threads(lcap);
     lds_bytes = gbc_agg_lds_bytes(D, lcap, threads);
     static std::once_flag agg_raised_once;
@@ -3080,7 +3080,7 @@ int32_t add_chunk_partitioned(dbhip_groupby* g, const GbCols& C, int64_t row0, i
 #undef GBC_AGG
   } else {
     // heavy partitions: the same split as for the compact kernels (the generic partitions are exact: base[], from the histogram pass)
-    static const bool no_heavy = getenv("DBHIP_GBC_HEAVY") && atoi(getenv("DBHIP_GBC_HEAVY")) == 0;
+    static const bool no_heavy = exp_env("DBHIP_GBC_HEAVY") && atoi(exp_env("DBHIP_GBC_HEAVY")) == 0;
     int extra_max = 0;
     A.nsp = nullptr; A.extra_n = nullptr; A.extra_map = nullptr; A.nparts = P; A.packed_base = (uint64_t)agrid * lcap;
     if (!no_heavy) {
@@ -3215,7 +3215,7 @@ void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, in
   if (((int64_t)per_part << bits) < est) {
     // more groups than the finest partitioning's LDS tables hold at once, or a probe that was (nearly) all distinct and
     // says nothing: finest partitioning, a 4 M-row chunk to learn from, then chunks sized by the estimate (adapt_chunk)
-    static const bool no_adapt = getenv("DBHIP_GB_NODIRECT") != nullptr;
+    static const bool no_adapt = exp_env("DBHIP_GB_NODIRECT") != nullptr;
     if (no_adapt) { g->part_bits = -1; return; }
     bits = PT_MAX_BITS;
     g->part_adapt = 1;
@@ -3226,12 +3226,12 @@ void decide_partitioning(dbhip_groupby* g, int64_t groups, int64_t rows_seen, in
   // equally likely groups: one heavy key (25 % NULLs) made 10^6 groups look like 3 x 10^5 (r05), the partitioning came out four times
   // too coarse and 9 M of 60 M rows left the full tables for the row path (124 ms). Such an estimate is checked on a 4 M-row chunk
   // first; the partitioning of the rest follows what that chunk found (partitioned_step).
-  static const bool no_validate = getenv("DBHIP_GB_VALIDATE") && atoi(getenv("DBHIP_GB_VALIDATE")) == 0;
+  static const bool no_validate = exp_env("DBHIP_GB_VALIDATE") && atoi(exp_env("DBHIP_GB_VALIDATE")) == 0;
   if (!g->part_adapt && !g->part_validated && !no_validate && groups * 4 > rows_seen && total - rows_seen > (16 << 20)) {
     g->part_validate = 1;
     // (1 M rows by default, DBHIP_GB_VALIDATE_ROWS: at 10^6 groups under a 25 % heavy key they put the estimate within 1.3 x, which the
     // tables' slack absorbs — a partition is sized for 3/8 of its table and spills at 3/4; 4 M rows cost the uniform 10^6 case 0.3 ms)
-    static const int64_t vrows = [] { const char* e = getenv("DBHIP_GB_VALIDATE_ROWS"); const long long v = e ? atoll(e) : 0; return (int64_t)(v >= (1 << 18) ? v : (1 << 20)); }();
+    static const int64_t vrows = [] { const char* e = exp_env("DBHIP_GB_VALIDATE_ROWS"); const long long v = e ? atoll(e) : 0; return (int64_t)(v >= (1 << 18) ? v : (1 << 20)); }();
     g->part_chunk = vrows;
   }
   if (getenv("DBHIP_TRACE")) fprintf(stderr, "[dbhip] groupby: %lld groups in the first %lld rows -> ~%lld groups in %lld rows, %d partition bits\n",

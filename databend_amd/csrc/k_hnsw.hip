@@ -1225,7 +1225,7 @@ int32_t dbhip_hnsw_search(dbhip_hnsw* hh, const float* queries_dev, int32_t nq, 
   SearchArgs A;
   A.queries = queries_dev; A.nq = nq; A.limit = limit; A.out_ids = out_ids_dev; A.out_dist = out_dist_dev; A.vis = vis;
   A.next = ctl; A.err = ctl + 1;
-  static const bool small_off = getenv("DBHIP_HNSW_SMALL") && atoi(getenv("DBHIP_HNSW_SMALL")) == 0;
+  static const bool small_off = exp_env("DBHIP_HNSW_SMALL") && atoi(exp_env("DBHIP_HNSW_SMALL")) == 0;
   const bool small = limit * 4 <= 64 && !small_off && !h->small_search_off;
   unsigned int hc[2];
   kernel_timer_start(s);

@@ -658,7 +658,7 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
   while (cap < j->nrows * 2) cap <<= 1;  // hashjoin_hashtable.rs:95-108
   j->buckets = cap;
   j->shift = 64 - __builtin_ctzll((unsigned long long)cap);
-  if (j->kw == 1 && getenv("DBHIP_JOIN_D")) j->shift |= atoi(getenv("DBHIP_JOIN_D")) << 8;
+  if (j->kw == 1 && exp_env("DBHIP_JOIN_D")) j->shift |= atoi(exp_env("DBHIP_JOIN_D")) << 8;
   DBHIP_TRY(dbhip_alloc((size_t)cap * 8, (void**)&j->head));
   DBHIP_CHECK(hipMemsetAsync(j->head, 0, (size_t)cap * 8, s));
   if (j->nrows) {
@@ -670,7 +670,7 @@ int32_t dbhip_join_finalize(dbhip_join* j, void* stream) {
       hipLaunchKernelGGL(join_build_kernel<4>, dim3(grid_for(j->nrows, 256)), dim3(256), 0, s, j->ent, j->nrows, j->head, j->shift);
     DBHIP_LAUNCH_CHECK();
     // JOIN_OCC_MIN_BUCKETS: 2^20 heads = 8 MB, past what one XCD's L2 keeps; DBHIP_JOIN_OCC=0 turns the filter off (measurements)
-    static const bool occ_on = !(getenv("DBHIP_JOIN_OCC") && getenv("DBHIP_JOIN_OCC")[0] == '0');
+    static const bool occ_on = !(exp_env("DBHIP_JOIN_OCC") && exp_env("DBHIP_JOIN_OCC")[0] == '0');
     if (occ_on && cap >= (1 << 20)) {
       DBHIP_TRY(dbhip_alloc((size_t)cap / 8, (void**)&j->occ));
       hipLaunchKernelGGL(join_occ_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, s, j->head, cap, j->occ);

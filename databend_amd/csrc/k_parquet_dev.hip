@@ -805,7 +805,7 @@ int32_t dbhip_pq_chunk_open_device_list(const uint8_t* chunk_host, int64_t chunk
 namespace {
 
 uint32_t ring_from_env(const char* name, uint32_t dflt) {
-  const char* e = getenv(name);
+  const char* e = exp_env(name);   // (DBHIP_PQ_LZ_RING / DBHIP_PQ_ZSTD_RING: sweep knobs, experiments build only)
   if (!e) return dflt;
   const long v = atol(e);
   if (v < 1024 || v > 65536 || (v & (v - 1))) return dflt;
@@ -969,7 +969,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   // served from the image instead of the ring
   static const uint32_t z_ring = ring_from_env("DBHIP_PQ_ZSTD_RING", ZW_RING), lz_ring = ring_from_env("DBHIP_PQ_LZ_RING", LZ_RING);
   // (two waves per page — parse | copy — unless DBHIP_PQ_ZSTD_WAVES=1 asks for the one-wave kernel)
-  static const bool z_one_wave = getenv("DBHIP_PQ_ZSTD_WAVES") && atoi(getenv("DBHIP_PQ_ZSTD_WAVES")) == 1;
+  static const bool z_one_wave = exp_env("DBHIP_PQ_ZSTD_WAVES") && atoi(exp_env("DBHIP_PQ_ZSTD_WAVES")) == 1;
   if (n_z && z_one_wave) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
   else if (n_z) hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring);
   if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), lz_ring, s, d_jobs + n_z, lz_ring);

@@ -396,8 +396,8 @@ int32_t dbhip_q1_fused(dbhip_groupby* g, const int64_t* l_quantity, const int64_
   // measured on SF10 (r01x) 2048 WGs 0.722 ms, 1024 0.688 ms, 512 0.680 ms; with non-temporal loads 0.689 / 0.656 /
   // 0.646 ms; 640 or 768 WGs 0.77 - 0.90 ms. Fewer workgroups also mean fewer partial rows to merge.
   int grid = (int)(ceil_div(ntiles, 4) < 512 ? ceil_div(ntiles, 4) : 512);
-  static const int env_grid = getenv("DBHIP_Q1_GRID") ? atoi(getenv("DBHIP_Q1_GRID")) : 0;   // tuning knobs (bench experiments)
-  static const int env_nt = getenv("DBHIP_Q1_NT") ? atoi(getenv("DBHIP_Q1_NT")) : 1;
+  static const int env_grid = exp_env("DBHIP_Q1_GRID") ? atoi(exp_env("DBHIP_Q1_GRID")) : 0;   // tuning knobs (bench experiments)
+  static const int env_nt = exp_env("DBHIP_Q1_NT") ? atoi(exp_env("DBHIP_Q1_NT")) : 1;
   if (env_grid > 0) grid = (int)(ceil_div(ntiles, 4) < env_grid ? ceil_div(ntiles, 4) : env_grid);
   size_t rows_bytes = (size_t)grid * MAX_SLOTS * Q1_W * 8;
   uint8_t* ws = (uint8_t*)scratch(rows_bytes + 64, 4, s);

@@ -948,14 +948,14 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
   }
 
   // 8192-key tiles of 512 threads (DBHIP_SORT_NT=256: the 4096-key tiles of rounds 1-3)
-  static const int rs_nt = getenv("DBHIP_SORT_NT") ? atoi(getenv("DBHIP_SORT_NT")) : 512;
+  static const int rs_nt = exp_env("DBHIP_SORT_NT") ? atoi(exp_env("DBHIP_SORT_NT")) : 512;
   const bool big_tiles = rs_nt == 512;
   const int64_t ntiles = ceil_div(m, big_tiles ? 512 * SORT_ITEMS : SORT_TILE);
   const int64_t nh = 256 * ntiles;
   // `final_vals`: this call holds the LAST pass of the whole sort — its permutation goes straight to the caller's buffer
   bool wrote_final = false;
   // onesweep (above) for sorts of 2^20 rows and more in 8192-key tiles; DBHIP_SORT_ONESWEEP=0: the histogram / scan / scatter passes
-  static const bool onesweep_off = getenv("DBHIP_SORT_ONESWEEP") && atoi(getenv("DBHIP_SORT_ONESWEEP")) == 0;
+  static const bool onesweep_off = exp_env("DBHIP_SORT_ONESWEEP") && atoi(exp_env("DBHIP_SORT_ONESWEEP")) == 0;
   const bool onesweep = !onesweep_off && big_tiles && m >= (1 << 20);
   unsigned long long* os_ws = nullptr;   // [8][256] digit histograms | [8] x (ticket, stall flag) | [ntiles][256] status words (cleared per pass)
   const size_t os_words = (size_t)8 * 256 + 16 + (size_t)ntiles * 256;
@@ -997,7 +997,7 @@ int32_t dbhip_sort_perm(const dbhip_col* keys, const uint8_t* desc_host, const u
     DBHIP_CHECK(hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, s));
     DBHIP_CHECK(hipStreamSynchronize(s));
     for (int p = 0; p < npass; ++p)
-      if (hctl[2 * p + 1]) { set_error("dbhip_sort_perm: a tile's look-back got no answer (pass %d); set DBHIP_SORT_ONESWEEP=0", p); return DBHIP_ERR_HIP; }
+      if (hctl[2 * p + 1]) { set_error("dbhip_sort_perm: a tile's look-back got no answer within its bounded wait (pass %d); the output buffer is undefined, the call can be repeated", p); return DBHIP_ERR_HIP; }
     return DBHIP_OK;
   };
   auto radix_passes = [&](int nbytes, uint64_t vary, bool narrow, uint32_t* final_vals = nullptr) -> int32_t {

@@ -1187,7 +1187,7 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
     A.n = hi - lo; A.dpad = dpad; A.nq = nq;
     const bool tall = nq > 128;  // 256-query tiles once there are enough queries to fill them
     // the 256 x 256 8-phase kernel (round 4) when the k-tiles pair up and the range fills the chip; DBHIP_BF16_256=0: the r01 kernel
-    static const bool f256_off = getenv("DBHIP_BF16_256") && atoi(getenv("DBHIP_BF16_256")) == 0;
+    static const bool f256_off = exp_env("DBHIP_BF16_256") && atoi(exp_env("DBHIP_BF16_256")) == 0;
     const bool f256 = tall && !f256_off && (dpad / HBK) % 2 == 0 && dpad >= 128 && A.n >= 256;
     A.n_qtiles = (int)ceil_div(nq, tall ? 256 : 128);
     A.n_itiles = ceil_div(A.n, f256 ? 256 : 128);

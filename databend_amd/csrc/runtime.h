@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/dbhip.h"
 
@@ -31,6 +32,16 @@ uint64_t* pinned_words(int slot);
 // HIP-event bracket around the dominant kernel of a call (dbhip_last_kernel_ms).
 void kernel_timer_start(hipStream_t s);
 void kernel_timer_stop(hipStream_t s);
+
+// Tuning knobs of the development sweeps (grid sizes, kernel variants, thresholds; DESIGN.md names them where it quotes a sweep): compiled
+// in only with -DDBHIP_EXPERIMENTS (`make EXPERIMENTS=1`). The shipped library does not read them — its behaviour is a function of its
+// arguments and of the documented configuration variables (DBHIP_TRACE, DBHIP_JIT_CACHE_DIR, DBHIP_JIT_ARCH, DBHIP_FAGG_JIT,
+// DBHIP_COMM_TIMEOUT_S, DBHIP_CACHE_BYTES) only, and no variable of either kind skips work (tests/test_abi.py checks the binary).
+#ifdef DBHIP_EXPERIMENTS
+inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -90,7 +90,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int grid_cap_override() {
-  static const int cap = [] { const char* e = getenv("DBHIP_GRID_CAP"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  static const int cap = [] { const char* e = exp_env("DBHIP_GRID_CAP"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
   return cap;
 }
 

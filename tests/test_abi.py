@@ -102,3 +102,19 @@ def test_rust_binding_file_matches_the_header():
         assert fields == [f[0] for f in ct._fields_], (rust_name, fields)
     for const, val in (("DBHIP_T_DEC256", 17), ("DBHIP_ERR_UNSUPPORTED", 7), ("DBHIP_AGG_MAX", 3), ("DBHIP_ABI_VERSION", 6)):
         assert re.search(r"pub const %s: i32 = %d;" % (const, val), text), const
+
+
+def test_the_shipped_library_reads_no_experiment_knob():
+    """the development sweeps' knobs (grid sizes, kernel variants, thresholds — and the work-skipping
+    DBHIP_FAGG_DEBUG of rounds 2-5, deleted) are compiled in only with -DDBHIP_EXPERIMENTS (csrc/runtime.h exp_env). The shipped binary
+    names exactly the documented configuration variables, none of which skips work."""
+    import subprocess
+    from databend_amd import _lib
+    out = subprocess.run(["strings", "-n", "6", _lib.library_path()], capture_output=True, text=True, check=True).stdout
+    names = set(re.findall(r"\bDBHIP_[A-Z0-9_]{3,}\b", out))
+    env_like = {n for n in names if not n.startswith(("DBHIP_T_", "DBHIP_ERR_", "DBHIP_EX_", "DBHIP_AGG_", "DBHIP_OP_", "DBHIP_CMP_", "DBHIP_VEC_", "DBHIP_ARG_",
+                                                      "DBHIP_JOIN_", "DBHIP_OK", "DBHIP_ABI", "DBHIP_NULL", "DBHIP_H", "DBHIP_JIT\b"))}
+    env_like -= {"DBHIP_JIT", "DBHIP_WAVE", "DBHIP_EXPERIMENTS", "DBHIP_REQUIRE", "DBHIP_CHECK", "DBHIP_TRY", "DBHIP_LAUNCH_CHECK", "DBHIP_POLL_CANCEL"}   # macro names inside the embedded JIT headers
+    allowed = {"DBHIP_TRACE", "DBHIP_JIT_CACHE_DIR", "DBHIP_JIT_ARCH", "DBHIP_FAGG_JIT", "DBHIP_COMM_TIMEOUT_S", "DBHIP_CACHE_BYTES"}
+    assert env_like <= allowed, sorted(env_like - allowed)
+    assert "FAGG_DEBUG" not in out and "FA_X_SKIP" not in out

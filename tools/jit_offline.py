@@ -4,6 +4,9 @@ reports what the hardware will run: registers, scratch, and the instruction mix 
 the specialised kernels are optimised offline; one GPU run then confirms the time.
 
     python tools/jit_offline.py [q1|plain4] [--slots 4] [--defs "-DFA_JIT_ROWS=4"] [--keep /tmp/out]
+
+(--defs goes through DBHIP_FAGG_JIT_DEFS, which only an experiments build of the library reads: `make -C databend_amd/csrc clean all EXPERIMENTS=1`;
+--slots 260 = 4 slots + 0x100: the FA_MULTI specialisation of a pipelined table's multi-block launches.)
 """
 import argparse
 import ctypes as C
