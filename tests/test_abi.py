@@ -118,3 +118,26 @@ def test_the_shipped_library_reads_no_experiment_knob():
     allowed = {"DBHIP_TRACE", "DBHIP_JIT_CACHE_DIR", "DBHIP_JIT_ARCH", "DBHIP_FAGG_JIT", "DBHIP_COMM_TIMEOUT_S", "DBHIP_CACHE_BYTES"}
     assert env_like <= allowed, sorted(env_like - allowed)
     assert "FAGG_DEBUG" not in out and "FA_X_SKIP" not in out
+
+
+def test_the_rust_shim_source_calls_only_declared_functions():
+    """bindings/shim (the Rust side as source; not compilable here) may only call what include/dbhip.h declares and
+    what the generated FFI (bindings/dbhip_sys.rs) binds, with the same struct fields."""
+    shim = os.path.join(ROOT, "bindings", "shim", "src")
+    declared = set(header_symbols())
+    sys_rs = open(os.path.join(ROOT, "bindings", "dbhip_sys.rs")).read()
+    bound = set(re.findall(r"pub fn (dbhip_\w+)\(", sys_rs))
+    types = set(re.findall(r"pub struct (dbhip_\w+)", sys_rs))
+    files = [f for f in sorted(os.listdir(shim)) if f.endswith(".rs")]
+    assert {"lib.rs", "device.rs", "scalar.rs", "aggregate.rs", "join.rs"} <= set(files)
+    for f in files:
+        src = re.sub(r"//[^\n]*", "", open(os.path.join(shim, f)).read())
+        for name in set(re.findall(r"\b(dbhip_\w+)\s*\(", src)):
+            assert name in declared and name in bound, (f, name)
+        for name in set(re.findall(r"\b(dbhip_\w+)\s*\{", src)):   # struct literals
+            assert name in types, (f, name)
+    # the three trait impls the hot path dispatches through
+    allsrc = "".join(open(os.path.join(shim, f)).read() for f in files)
+    for needle in ("impl ScalarFunction for HipArith", "impl AccumulatingTransform for HipTransformPartialAggregate", "impl Join for HipInnerHashJoin",
+                   "impl JoinStream for HipJoinStream"):
+        assert needle in allsrc, needle
