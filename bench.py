@@ -160,10 +160,18 @@ def main():
     stream = C.c_void_p(ts.cuda_stream) if ts is not None else None
     kms = []
     abi_comm = None
-    if world > 1 and args.exchange_impl == "abi":
+    # N > 1 over RCCL: BOTH exchange implementations are set up — the one `--exchange-impl` names carries the headline, the other is
+    # timed right after it (same steps) and reported beside it (`exchange_impl_other`): torch.distributed's collectives on the
+    # library's buffers, and the C-ABI's own communicator (dbhip_comm_*: what a Rust host would call). (Ranks that SHARE a GPU cannot
+    # form an RCCL communicator — RCCL refuses duplicate devices — so `--share-gpu` runs the selected implementation only.)
+    both_impls = world > 1 and args.backend == "nccl" and not args.share_gpu
+    abi_handle = None
+    if world > 1 and (args.exchange_impl == "abi" or both_impls):
         ids = [D.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)     # the host's control plane ships the 128 bytes
-        abi_comm = D.Comm(rank, world, ids[0])
+        abi_handle = D.Comm(rank, world, ids[0])
+    if args.exchange_impl == "abi":
+        abi_comm = abi_handle
 
     # THE HEADLINE PATH is the generic one: the binding flattens Q1's predicate and decimal maps into one register
     # program and dbhip_groupby_add_block_program runs the fused filter -> map -> partial-aggregate kernel the library specialised
@@ -186,11 +194,12 @@ def main():
             check(L.dbhip_last_kernel_ms(C.byref(ms)))  # HIP events around the fused kernel on its stream
             into.append(ms.value)
 
-    def step(record=False):
+    def step(record=False, use_abi=None):
         g.reset(stream)
         launch(record, kms)
-        if abi_comm is not None:
-            (abi_comm.exchange_alltoall if exchange == "alltoall" else abi_comm.exchange_allgather)(g, 256, stream)
+        comm = abi_comm if use_abi is None else (abi_handle if use_abi else None)
+        if comm is not None:
+            (comm.exchange_alltoall if exchange == "alltoall" else comm.exchange_allgather)(g, 256, stream)
         elif world > 1:
             with torch.cuda.stream(ts):
                 if exchange == "alltoall":
@@ -218,10 +227,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the OTHER exchange implementation, same steps, same barriers (N > 1 over RCCL only)
+    other_impl = None
+    if both_impls:
+        use_abi = args.exchange_impl != "abi"
+        for _ in range(args.warmup):
+            step(False, use_abi)
+        check(L.dbhip_stream_sync(stream))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(False, use_abi)
+        check(L.dbhip_stream_sync(stream))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        other_impl = {"impl": "abi" if use_abi else "torch", "ms_per_step": float(t.item()) / args.steps * 1e3,
+                      "rows_per_s": n_total * args.steps / float(t.item()), "_rows": tpch.q1_rows(g)}
+        step(False)   # (leave the table as the selected implementation's step leaves it: the result checks below read it)
+        check(L.dbhip_stream_sync(stream))
     # average launch duration of the dominant kernel (the specialised fused-program kernel, or q1_fused_kernel), HIP events on its stream
     kernel_ms = float(np.mean(kms)) if kms else 0.0
     dominant = "fagg_jit (run-time specialised fused filter+map+aggregate program)" if args.headline == "program" else "q1_fused_kernel"
     result_headline = tpch.q1_rows(g)
+    if other_impl is not None:
+        other_impl["equals_headline_result"] = other_impl.pop("_rows") == result_headline
     # the OTHER kernel beside it, same rows, same steps: its per-launch duration and wall time
     other = None
     if world == 1:
@@ -374,6 +406,8 @@ def main():
                               "prepare_ms_cold_or_cached": prepare_ms},
             "hand_written_kernel" if args.headline == "program" else "generic_program_kernel": other,
             "cpu_baseline": cpu,
+            "exchange_impl": (args.exchange_impl if world > 1 else None),
+            "exchange_impl_other": other_impl,
             "multi_gpu_readiness": readiness,
             "q1_operator_plan": opplan,
             "q1_block_size_sweep": blocks,
