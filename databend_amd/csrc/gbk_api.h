@@ -1,0 +1,661 @@
+// gbk_api.h — a fragment of k_groupby.hip (ONE translation unit: the kernels share the anonymous namespace's helpers and the table struct;
+// split by kernel family in round 6, VERDICT r05 hygiene #18): the C-ABI entry points of the aggregation (extern "C").
+// Included by k_groupby.hip only, in this order: gbk_rows.h, gbk_merge_lds.h, gbk_partitioned.h, gbk_api.h.
+
+extern "C" {
+
+int32_t dbhip_group_hash(const dbhip_col* cols, int32_t ncols, int64_t n, uint64_t* out_hashes,
+                         void* stream) {
+  DBHIP_REQUIRE(cols && ncols >= 1 && ncols <= GB_MAX_KEYS, "dbhip_group_hash: bad column list");
+  if (n == 0) return DBHIP_OK;
+  DBHIP_REQUIRE(out_hashes, "dbhip_group_hash: NULL out");
+  HashCols hc;
+  hc.n = ncols;
+  for (int k = 0; k < ncols; ++k) {
+    if (!key_type_ok(cols[k].type)) {
+      set_error("dbhip_group_hash: unsupported type %d", cols[k].type);
+      return DBHIP_ERR_INVALID;
+    }
+    hc.c[k] = to_gbcol(cols[k]);
+  }
+  hipStream_t s = resolve_stream(stream);
+  unsigned long long* bad = (unsigned long long*)scratch(8, 2, s);
+  if (!bad) return DBHIP_ERR_HIP;
+  DBHIP_CHECK(hipMemsetAsync(bad, 0, 8, s));
+  hipLaunchKernelGGL(group_hash_kernel, dim3(grid_for(ceil_div(n, 4), 256, 1024)), dim3(256), 0, s, hc, n, out_hashes, bad);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_create(const int32_t* key_types_host, const uint8_t* key_nullable_host,
+                             int32_t nkeys, const dbhip_agg_desc* aggs_host, int32_t naggs,
+                             int64_t initial_capacity, dbhip_groupby** out_host) {
+  DBHIP_REQUIRE(out_host && key_types_host, "dbhip_groupby_create: NULL argument");
+  dbhip_groupby* g = new (std::nothrow) dbhip_groupby();
+  DBHIP_REQUIRE(g, "dbhip_groupby_create: out of host memory");
+  memset(g, 0, sizeof(*g));
+  int32_t rc = build_layout(key_types_host, key_nullable_host, nkeys, aggs_host, naggs, &g->L);
+  if (rc) { delete g; return rc; }
+  int64_t cap = 1024;
+  while (cap < initial_capacity) cap <<= 1;
+  g->hash_mask = ~0ULL;
+  g->part_min_rows = 262144;
+  g->hint_groups = initial_capacity;
+  if (layout_has_wide_minmax(g->L)) { g->part_forbidden = 1; g->part_bits = -1; }   // row path only (see gb_minmax_wide_locked)
+  hipStream_t s = resolve_stream(nullptr);
+  if ((rc = alloc_table(g, cap, s))) { delete g; return rc; }
+  hipError_t e = hipMalloc((void**)&g->ctrl, 128);   // [0..7] see above, [8] arena cursor, [9] long-string bytes of the current chunk
+  if (e == hipSuccess) e = hipMemsetAsync(g->ctrl, 0, 128, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {  // nothing half-built is handed out or leaked
+    (void)dbhip_groupby_destroy(g);
+    return hip_fail(e, "dbhip_groupby_create");
+  }
+  *out_host = g;
+  return DBHIP_OK;
+}
+
+// test hook (not part of the drop-in surface): restrict the probe hash to `mask`
+// so that distinct keys share a hash word and the collision path is exercised
+// (the reference tests the same situation with hand-made tags, hash_index/index.rs:385-404).
+int32_t dbhip_groupby_debug_set_hash_mask(dbhip_groupby* g, uint64_t mask) {
+  DBHIP_REQUIRE(g && g->count_host == 0, "dbhip_groupby_debug_set_hash_mask: table must be empty");
+  g->hash_mask = mask;
+  return DBHIP_OK;
+}
+
+// test hook: force the radix-partitioned path with 2^bits partitions for every block size
+// (bits = 0: back to adaptive; bits < 0: never partition)
+int32_t dbhip_groupby_debug_set_partition_bits(dbhip_groupby* g, int32_t bits) {
+  DBHIP_REQUIRE(g && bits <= PT_MAX_BITS, "dbhip_groupby_debug_set_partition_bits: bad argument");
+  if (bits > 0) { g->part_bits = bits; g->part_min_rows = 1; g->part_forbidden = 0; }
+  else if (bits == 0) { g->part_bits = 0; g->part_min_rows = 262144; g->part_forbidden = 0; }
+  else { g->part_bits = -1; g->part_forbidden = 1; g->part_min_rows = 262144; }
+  return DBHIP_OK;
+}
+
+// test hook: keep this table off (0) / on (1, the default) the compact-row kernels (gb_compact.h), so that both the generic and the
+// compact kernels can be driven through the same cases
+int32_t dbhip_groupby_debug_set_compact(dbhip_groupby* g, int32_t on) {
+  DBHIP_REQUIRE(g, "dbhip_groupby_debug_set_compact: NULL argument");
+  g->gbc_off = on ? 0 : 1;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args,
+                                int64_t n, void* stream) {
+  return dbhip_groupby_add_block_filtered(g, keys, args, n, nullptr, 0, stream);
+}
+
+int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args, int64_t n,
+                                         const uint8_t* filter_bitmap, int64_t filter_bit_offset, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && keys, "dbhip_groupby_add_block: NULL argument");
+  if (n == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  GbCols C;
+  memset(&C, 0, sizeof(C));
+  C.filter = filter_bitmap;
+  C.filter_off = filter_bit_offset;
+  for (int k = 0; k < g->L.nkeys; ++k) {
+    if (keys[k].type != g->L.key_type[k]) {
+      set_error("dbhip_groupby_add_block: key %d has type %d, table expects %d", k, keys[k].type, g->L.key_type[k]);
+      return DBHIP_ERR_INVALID;
+    }
+    if (keys[k].validity && !g->L.key_nullable[k]) {
+      set_error("dbhip_groupby_add_block: key %d carries validity but was declared NOT NULL", k);
+      return DBHIP_ERR_INVALID;
+    }
+    C.key[k] = to_gbcol(keys[k]);
+  }
+  for (int a = 0; a < g->L.naggs; ++a) {
+    bool count_star = g->L.agg_kind[a] == DBHIP_AGG_COUNT && (!args || !args[a].data);
+    if (count_star) continue;
+    DBHIP_REQUIRE(args && args[a].data, "dbhip_groupby_add_block: missing aggregate argument column");
+    if (g->L.agg_kind[a] != DBHIP_AGG_COUNT && args[a].type != g->L.agg_type[a]) {
+      set_error("dbhip_groupby_add_block: aggregate %d argument has type %d, table expects %d", a, args[a].type,
+                g->L.agg_type[a]);
+      return DBHIP_ERR_INVALID;
+    }
+    C.arg[a] = to_gbcol(args[a]);
+  }
+  int32_t rc;
+  int64_t done = 0;
+  g->gbc_active = 0;   // (add_block_fast decides per call whether layout and columns qualify for the compact-row kernels)
+  // The caller sized the table for about as many groups as this first block has rows (a join's output grouped by the join key,
+  // TPC-H Q3: 3 M rows, 1.1 M groups): pre-aggregation has nothing to combine and costs more than the rows it saves
+  // (r03: LDS pre-aggregation 0.59 ms + merge against 0.3 ms for the row path alone), the block goes straight to the row path.
+  const bool expect_distinct = g->rows_seen == 0 && g->count_host == 0 && n >= (1 << 20) && g->hint_groups * 2 >= n && g->part_bits == 0;
+  // (layouts past the generic LDS kernel's limits — e.g. eight aggregates — may still qualify for the compact-row kernels: add_block_fast decides)
+  if ((fast_layout_ok(g->L) || !layout_has_wide_minmax(g->L)) && !g->has_long && !expect_distinct) {
+    rc = add_block_fast(g, C, n, s, &done);
+    if (rc >= 0) return rc;
+  }
+  // generic row path (any layout; high-cardinality continuation of the fast path), in bounded chunks
+  const int64_t CHUNK = 32 << 20;
+  const bool probe_here = !fast_layout_ok(g->L);  // wide layouts learn their cardinality on the row path
+  while (done < n) {
+    DBHIP_POLL_CANCEL(s, "dbhip_groupby_add_block");
+    if (g->part_bits > 0 && n - done >= g->part_min_rows) {
+      if ((rc = partitioned_step(g, C, n, s, &done))) return rc;
+      continue;
+    }
+    int64_t cn = n - done < CHUNK ? n - done : CHUNK;
+    if (probe_here && g->part_bits == 0 && cn > (1 << 20)) cn = 1 << 20;
+    // (Serializing the rows in the order of their top hash bits — partition_scatter, so that probe and accumulate
+    // walk the table slice by slice — was measured and does not pay: at 10^6..10^7 groups the row path is bound by
+    // the two device-scope atomics per row, not by the random sectors. r01y: 17.9 ms vs 16.4 ms at 10 M groups.)
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * g->L.W * 8))) return rc;
+    if (C.filter) DBHIP_CHECK(hipMemsetAsync(&g->ctrl[7], 0, 8, s));
+    if (layout_has_strings(g->L)) DBHIP_CHECK(hipMemsetAsync(&g->ctrl[9], 0, 8, s));
+    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(ceil_div(cn, 4), 256)), dim3(256), 0, s, g->L, C, done, cn, g->rows_in,
+                       g->ctrl);
+    DBHIP_LAUNCH_CHECK();
+    if (layout_has_strings(g->L) && (rc = reserve_arena_for_chunk(g, s))) return rc;
+    int64_t kept = cn;
+    if (C.filter) {  // the passing rows were written densely: their number comes back with one small copy
+      uint64_t k7 = 0;
+      DBHIP_CHECK(hipMemcpyAsync(&k7, &g->ctrl[7], 8, hipMemcpyDeviceToHost, s));
+      DBHIP_CHECK(hipStreamSynchronize(s));
+      kept = (int64_t)k7;
+    }
+    if ((rc = merge_rows(g, g->rows_in, kept, s))) return rc;
+    done += cn;
+    g->rows_seen += cn;
+    if (probe_here && g->part_bits == 0 && g->rows_seen >= (1 << 20)) {
+      if (g->count_host > 32) decide_partitioning(g, g->count_host, g->rows_seen, n);
+      else g->part_bits = -1;  // a handful of groups: the wave-combining accumulate kernel is the right tool
+    }
+  }
+  return DBHIP_OK;
+}
+
+// Deserializing side of the reference's state exchange (TransformDeserializer -> AggregateFunction::batch_merge,
+// aggregator/serde/transform_deserializer.rs): a block [state fields..., group columns...] as
+// Payload::aggregate_flush produces it (payload_flush.rs:151-181) is merged into the table. The keys are serialized
+// like an input block, the state words are filled from the field columns (gb_states_from_fields_kernel) and the rows
+// go through the row merge path — the table's layout is never modified.
+int32_t dbhip_groupby_merge_state_block(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* states,
+                                        int64_t n, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && keys && (states || g->L.naggs == 0), "dbhip_groupby_merge_state_block: NULL argument");
+  if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_merge_state_block")) return rs;
+  const GbLayout& L = g->L;
+  int32_t ftype[GB_MAX_AGGS * 3], fagg[GB_MAX_AGGS * 3];
+  const int nf = state_fields(L, ftype, fagg);
+  // validate everything BEFORE anything is queued
+  StateFieldCols F;
+  memset(&F, 0, sizeof(F));
+  for (int f = 0; f < nf; ++f) {
+    if (!states[f].data) {
+      set_error("dbhip_groupby_merge_state_block: missing state field %d (aggregate %d)", f, fagg[f]);
+      return DBHIP_ERR_INVALID;
+    }
+    if (states[f].type != ftype[f]) {
+      set_error("dbhip_groupby_merge_state_block: state field %d (aggregate %d) has type %d, the serialized state has type %d", f,
+                fagg[f], states[f].type, ftype[f]);
+      return DBHIP_ERR_INVALID;
+    }
+    F.f[f] = to_gbcol(states[f]);
+    F.f[f].validity = nullptr;  // state fields are never NULL (MinMax: the has-value field says it)
+  }
+  GbCols C;
+  memset(&C, 0, sizeof(C));
+  for (int k = 0; k < L.nkeys; ++k) {
+    if (keys[k].type != L.key_type[k]) {
+      set_error("dbhip_groupby_merge_state_block: key %d has type %d, table expects %d", k, keys[k].type, L.key_type[k]);
+      return DBHIP_ERR_INVALID;
+    }
+    if (keys[k].validity && !L.key_nullable[k]) {
+      set_error("dbhip_groupby_merge_state_block: key %d carries validity but was declared NOT NULL", k);
+      return DBHIP_ERR_INVALID;
+    }
+    C.key[k] = to_gbcol(keys[k]);
+  }
+  if (n == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc;
+  const int64_t CHUNK = 32 << 20;
+  for (int64_t done = 0; done < n; done += CHUNK) {
+    const int64_t cn = n - done < CHUNK ? n - done : CHUNK;
+    if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)cn * L.W * 8))) return rc;
+    // keys + hash (argument pointers are NULL: the state words are overwritten by the next kernel)
+    hipLaunchKernelGGL(gb_serialize_kernel, dim3(grid_for(ceil_div(cn, 4), 256)), dim3(256), 0, s, L, C, done, cn, g->rows_in, g->ctrl);
+    StateFieldCols Fc = F;
+    for (int f = 0; f < nf; ++f) {
+      if (Fc.f[f].is_scalar || done == 0) continue;
+      const int es = Fc.f[f].type == DBHIP_T_BOOL ? 0 : type_size(Fc.f[f].type);
+      if (es) Fc.f[f].data = (const uint8_t*)Fc.f[f].data + (size_t)done * es;
+      else Fc.f[f].data = (const uint8_t*)Fc.f[f].data + (done >> 3);   // CHUNK is a multiple of 8 bits
+    }
+    hipLaunchKernelGGL(gb_states_from_fields_kernel, dim3(grid_for(cn, 256)), dim3(256), 0, s, L, Fc, cn, g->rows_in, g->ctrl);
+    DBHIP_LAUNCH_CHECK();
+    if ((rc = merge_rows(g, g->rows_in, cn, s))) return rc;
+  }
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_state_fields(dbhip_groupby* g, int32_t* out_types_host, int32_t* out_agg_index_host, int32_t max_fields,
+                                   int32_t* out_n_fields_host) {
+  DBHIP_REQUIRE(g && out_n_fields_host, "dbhip_groupby_state_fields: NULL argument");
+  if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_state_fields")) return rs;
+  int32_t ftype[GB_MAX_AGGS * 3], fagg[GB_MAX_AGGS * 3];
+  const int nf = state_fields(g->L, ftype, fagg);
+  *out_n_fields_host = nf;
+  for (int f = 0; f < nf && f < max_fields; ++f) {
+    if (out_types_host) out_types_host[f] = ftype[f];
+    if (out_agg_index_host) out_agg_index_host[f] = fagg[f];
+  }
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_merge_serialized(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && (rows_dev || n_rows == 0), "dbhip_groupby_merge_serialized: NULL argument");
+  return merge_rows(g, (const uint64_t*)rows_dev, n_rows, resolve_stream(stream));
+}
+
+int32_t dbhip_groupby_num_groups(dbhip_groupby* g, int64_t* out_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_host, "dbhip_groupby_num_groups: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  uint64_t c = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&c, g->ctrl, 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  g->count_host = (int64_t)c;
+  *out_host = (int64_t)c;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_row_bytes(dbhip_groupby* g, int64_t* out_host) {
+  DBHIP_REQUIRE(g && out_host, "dbhip_groupby_row_bytes: NULL argument");
+  *out_host = (int64_t)g->L.W * 8;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_flush_serialized(dbhip_groupby* g, void* out_rows_dev, int64_t max_rows,
+                                       int64_t* out_n_rows_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_n_rows_host && (out_rows_dev || max_rows == 0), "dbhip_groupby_flush_serialized: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[4], 0, 8, s));
+  hipLaunchKernelGGL(gb_flush_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash,
+                     g->rows, g->cap, (uint64_t*)out_rows_dev, max_rows, g->ctrl);
+  DBHIP_LAUNCH_CHECK();
+  uint64_t nflush = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&nflush, &g->ctrl[4], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  *out_n_rows_host = (int64_t)nflush;
+  if ((int64_t)nflush > max_rows) {
+    set_error("dbhip_groupby_flush_serialized: %lld groups do not fit max_rows=%lld", (long long)nflush, (long long)max_rows);
+    return DBHIP_ERR_CAPACITY;
+  }
+  return DBHIP_OK;
+}
+
+// Exchange entry points move serialized rows WITHOUT the arena: a long (> 12 byte) string key in such a row is an offset into
+// the SENDER's arena, which the receiving table would read as an address. Tables that hold long strings exchange through
+// dbhip_groupby_flush_serialized + dbhip_groupby_arena -> dbhip_groupby_merge_serialized_arena (which rebases the offsets).
+static int32_t refuse_long_strings(const dbhip_groupby* g, const char* fn) {
+  if (layout_has_str_minmax(g->L)) {
+    set_error("%s: a min / max over String state refers to bytes in this table's arena; such tables are merged in process "
+              "(dbhip_groupby_merge_serialized from a live table) and do not travel", fn);
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (!g->has_long) return DBHIP_OK;
+  set_error("%s: the table holds string keys longer than 12 bytes; exchange it with dbhip_groupby_flush_serialized + dbhip_groupby_arena "
+            "-> dbhip_groupby_merge_serialized_arena", fn);
+  return DBHIP_ERR_UNSUPPORTED;
+}
+
+int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t max_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_block_dev && max_rows >= 1, "dbhip_groupby_flush_block: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_flush_block")) return rl;
+  hipStream_t s = resolve_stream(stream);
+  uint64_t* block = (uint64_t*)out_block_dev;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[4], 0, 8, s));
+  hipLaunchKernelGGL(gb_flush_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap,
+                     block + g->L.W, max_rows, g->ctrl);
+  hipLaunchKernelGGL(gb_block_header_kernel, dim3(1), dim3(64), 0, s, block, g->L.W, max_rows, g->ctrl);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;  // nothing is read back: the header travels with the block
+}
+
+int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows,
+                                   int32_t skip_block, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_merge_blocks: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_merge_blocks")) return rl;
+  hipStream_t s = resolve_stream(stream);
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  const uint64_t* blocks = (const uint64_t*)blocks_dev;
+  std::vector<uint64_t> head((size_t)n_blocks);
+  DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 8, blocks, (size_t)stride * 8, 8, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  int64_t total = 0;
+  // EVERY header is checked, the caller's own block included: the owner of an overflowed block must take the
+  // variable-length path together with the ranks that see the overflow in the gathered headers (otherwise the owner
+  // would merge and return while the others enter a collective). Decided BEFORE the table is touched.
+  for (int b = 0; b < n_blocks; ++b) {
+    if (head[b] == ~0ULL || (int64_t)head[b] > max_rows) {
+      set_error("dbhip_groupby_merge_blocks: block %d overflowed max_rows=%lld (exchange the rows with "
+                "dbhip_groupby_flush_serialized / merge_serialized instead)", b, (long long)max_rows);
+      return DBHIP_ERR_CAPACITY;
+    }
+    if (b != skip_block) total += (int64_t)head[b];
+  }
+  if (total == 0) return DBHIP_OK;
+  int32_t rc;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)total * W * 8))) return rc;
+  hipLaunchKernelGGL(gb_compact_blocks_kernel, dim3(n_blocks), dim3(256), 0, s, blocks, stride, W, skip_block, g->rows_in);
+  DBHIP_LAUNCH_CHECK();
+  return merge_rows(g, g->rows_in, total, s);
+}
+
+int32_t dbhip_groupby_result_type(const dbhip_agg_desc* agg, int32_t* out_type, uint8_t* out_precision,
+                                  uint8_t* out_scale) {
+  DBHIP_REQUIRE(agg && out_type, "dbhip_groupby_result_type: NULL argument");
+  uint8_t p = 0, sc = 0;
+  int t = -1;
+  switch (agg->kind) {
+    case DBHIP_AGG_COUNT: t = DBHIP_T_U64; break;
+    case DBHIP_AGG_SUM:
+      switch (agg->arg_type) {  // ResultTypeOfUnary::Sum, sum_coercion
+        case DBHIP_T_I8: case DBHIP_T_I16: case DBHIP_T_I32: case DBHIP_T_I64: t = DBHIP_T_I64; break;
+        case DBHIP_T_U8: case DBHIP_T_U16: case DBHIP_T_U32: case DBHIP_T_U64: t = DBHIP_T_U64; break;
+        case DBHIP_T_F32: case DBHIP_T_F64: t = DBHIP_T_F64; break;
+        case DBHIP_T_DEC64: t = DBHIP_T_DEC64; p = 18; sc = agg->arg_scale; break;   // aggregate_sum.rs:404-406
+        case DBHIP_T_DEC128: t = DBHIP_T_DEC128; p = 38; sc = agg->arg_scale; break;
+        case DBHIP_T_DEC256: t = DBHIP_T_DEC256; p = 76; sc = agg->arg_scale; break;
+      }
+      break;
+    case DBHIP_AGG_MIN: case DBHIP_AGG_MAX:
+      t = agg->arg_type; p = agg->arg_precision; sc = agg->arg_scale;
+      break;
+  }
+  if (t < 0) {
+    set_error("dbhip_groupby_result_type: unsupported aggregate (%d on type %d)", agg->kind, agg->arg_type);
+    return DBHIP_ERR_INVALID;
+  }
+  *out_type = t;
+  if (out_precision) *out_precision = p;
+  if (out_scale) *out_scale = sc;
+  return DBHIP_OK;
+}
+
+static int32_t flush_columns(dbhip_groupby* g, void* const* out_keys_host, uint8_t* const* out_key_validity_host,
+                             void* const* out_aggs_host, uint8_t* const* out_agg_validity_host, void* const* out_fields_host,
+                             uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host, void* stream) {
+  hipStream_t s = resolve_stream(stream);
+  uint64_t* tmp = (uint64_t*)scratch((size_t)(max_rows > 0 ? max_rows : 1) * g->L.W * 8, 3, s);
+  if (!tmp) return DBHIP_ERR_HIP;
+  int32_t rc = dbhip_groupby_flush_serialized(g, tmp, max_rows, out_n_rows_host, stream);
+  if (rc) return rc;
+  int64_t n = *out_n_rows_host;
+  if (n == 0) return DBHIP_OK;
+  ResultPtrs P;
+  memset(&P, 0, sizeof(P));
+  const size_t bm_bytes = (size_t)ceil_div(max_rows, 64) * 8;
+  for (int k = 0; k < g->L.nkeys; ++k) {
+    P.keys[k] = out_keys_host ? out_keys_host[k] : nullptr;
+    P.key_validity[k] = out_key_validity_host ? (uint32_t*)out_key_validity_host[k] : nullptr;
+    if (P.key_validity[k]) DBHIP_CHECK(hipMemsetAsync(P.key_validity[k], 0, bm_bytes, s));
+  }
+  for (int a = 0; a < g->L.naggs; ++a) {
+    P.aggs[a] = out_aggs_host ? out_aggs_host[a] : nullptr;
+    P.agg_validity[a] = out_agg_validity_host ? (uint32_t*)out_agg_validity_host[a] : nullptr;
+    if (P.agg_validity[a]) DBHIP_CHECK(hipMemsetAsync(P.agg_validity[a], 0, bm_bytes, s));
+  }
+  P.hashes = out_hashes;
+  P.arena = g->arena;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[3], 0, 8, s));
+  hipLaunchKernelGGL(gb_result_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, P, g->ctrl);
+  if (out_fields_host) {
+    int32_t ftype[GB_MAX_AGGS * 3];
+    const int nf = state_fields(g->L, ftype, nullptr);
+    StateFieldPtrs SP;
+    memset(&SP, 0, sizeof(SP));
+    for (int f = 0; f < nf; ++f) {
+      SP.f[f] = out_fields_host[f];
+      if (SP.f[f] && ftype[f] == DBHIP_T_BOOL) DBHIP_CHECK(hipMemsetAsync(SP.f[f], 0, bm_bytes, s));
+    }
+    hipLaunchKernelGGL(gb_state_fields_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g->L, tmp, n, SP, g->ctrl, (const uint8_t*)g->arena);
+  }
+  DBHIP_LAUNCH_CHECK();
+  uint64_t err = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&err, &g->ctrl[3], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (err & 1) {
+    set_error("Decimal overflow: sum state not in [DECIMAL_MIN, DECIMAL_MAX]");
+    return DBHIP_ERR_OVERFLOW;
+  }
+  if (err & 8) {
+    set_error("groupby: more than 4 GiB of long string keys: a BinaryView offset is 32 bits; flush the table in pieces");
+    return DBHIP_ERR_CAPACITY;
+  }
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_arena(dbhip_groupby* g, const void** out_ptr_host, int64_t* out_bytes_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_ptr_host && out_bytes_host, "dbhip_groupby_arena: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  uint64_t used = 0;
+  DBHIP_CHECK(hipMemcpyAsync(&used, &g->ctrl[8], 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  *out_ptr_host = g->arena;
+  *out_bytes_host = (int64_t)used;
+  return DBHIP_OK;
+}
+
+namespace {
+// serialized rows of ANOTHER table (long strings by offset into that table's arena, which the caller shipped along) ->
+// input rows (long strings by address); sums the long bytes for the arena reservation
+__global__ __launch_bounds__(256) void gb_rebase_rows_kernel(GbLayout L, const uint64_t* rows, int64_t n, const uint8_t* arena,
+                                                             uint64_t* out, uint64_t* ctrl) {
+  const int64_t n_pad = (n + 63) & ~63LL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t lb = 0;
+    if (i < n) {
+      const uint64_t* r = rows + i * L.W;
+      uint64_t* o = out + i * L.W;
+      for (int k = 0; k < L.W; ++k) {
+        uint64_t v = r[k];
+        if (k < L.nkey_words && ((L.str_w1_mask >> k) & 1) && (uint32_t)r[k - 1] > 12) {
+          v = (uint64_t)(arena + v);
+          lb += ((uint32_t)r[k - 1] + 7) & ~7u;
+        }
+        o[k] = v;
+      }
+    }
+    lb = wave_sum_u64(lb);
+    if (lb && lane_id() == 0) atomicAdd((unsigned long long*)&ctrl[9], (unsigned long long)lb);
+  }
+}
+}  // namespace
+
+int32_t dbhip_groupby_merge_serialized_arena(dbhip_groupby* g, const void* rows_dev, int64_t n_rows, const void* arena_dev, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && (rows_dev || n_rows == 0), "dbhip_groupby_merge_serialized_arena: NULL argument");
+  if (n_rows == 0) return DBHIP_OK;
+  hipStream_t s = resolve_stream(stream);
+  if (!layout_has_strings(g->L)) return merge_rows(g, (const uint64_t*)rows_dev, n_rows, s);
+  int32_t rc;
+  // (its own scratch: merge_rows may be handed g->rows_in by other callers, not by this one)
+  if ((rc = ensure((void**)&g->spill_rows, &g->spill_rows_cap, (size_t)n_rows * g->L.W * 8))) return rc;
+  DBHIP_CHECK(hipMemsetAsync(&g->ctrl[9], 0, 8, s));
+  hipLaunchKernelGGL(gb_rebase_rows_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, g->L, (const uint64_t*)rows_dev, n_rows,
+                     (const uint8_t*)arena_dev, g->spill_rows, g->ctrl);
+  DBHIP_LAUNCH_CHECK();
+  if ((rc = reserve_arena_for_chunk(g, s))) return rc;
+  return merge_rows(g, g->spill_rows, n_rows, s);
+}
+
+int32_t dbhip_groupby_flush_result(dbhip_groupby* g, void* const* out_keys_host,
+                                   uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
+                                   uint64_t* out_hashes, int64_t max_rows, int64_t* out_n_rows_host,
+                                   void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result: NULL argument");
+  return flush_columns(g, out_keys_host, out_key_validity_host, out_aggs_host, nullptr, nullptr, out_hashes, max_rows,
+                       out_n_rows_host, stream);
+}
+
+int32_t dbhip_groupby_flush_result_nullable(dbhip_groupby* g, void* const* out_keys_host,
+                                            uint8_t* const* out_key_validity_host, void* const* out_aggs_host,
+                                            uint8_t* const* out_agg_validity_host, uint64_t* out_hashes, int64_t max_rows,
+                                            int64_t* out_n_rows_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_n_rows_host, "dbhip_groupby_flush_result_nullable: NULL argument");
+  return flush_columns(g, out_keys_host, out_key_validity_host, out_aggs_host, out_agg_validity_host, nullptr, out_hashes,
+                       max_rows, out_n_rows_host, stream);
+}
+
+int32_t dbhip_groupby_flush_state_block(dbhip_groupby* g, void* const* out_keys_host, uint8_t* const* out_key_validity_host,
+                                        void* const* out_state_fields_host, uint64_t* out_hashes, int64_t max_rows,
+                                        int64_t* out_n_rows_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_n_rows_host && (out_state_fields_host || g->L.naggs == 0), "dbhip_groupby_flush_state_block: NULL argument");
+  if (int32_t rs = refuse_str_minmax_state(g->L, "dbhip_groupby_flush_state_block")) return rs;
+  return flush_columns(g, out_keys_host, out_key_validity_host, nullptr, nullptr, out_state_fields_host, out_hashes, max_rows,
+                       out_n_rows_host, stream);
+}
+
+// ---- a12: hash partitioning of the group rows (payload.rs:548-589) ------------------------------------------
+static int32_t ensure_xcur(dbhip_groupby* g) {
+  if (g->xcur) return DBHIP_OK;
+  DBHIP_CHECK(hipMalloc((void**)&g->xcur, (size_t)(2 * 4096 + 2) * 8));
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void* out_blocks_dev, int64_t max_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_blocks_dev && n_buckets >= 1 && n_buckets <= 4096 && max_rows >= 1, "dbhip_groupby_partition_blocks: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_partition_blocks")) return rl;
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc = ensure_xcur(g);
+  if (rc) return rc;
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  DBHIP_CHECK(hipMemsetAsync(g->xcur, 0, (size_t)n_buckets * 8, s));
+  hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap,
+                     (uint32_t)n_buckets, max_rows, stride, (const uint64_t*)nullptr, (uint64_t*)out_blocks_dev,
+                     (unsigned long long*)g->xcur);
+  hipLaunchKernelGGL(gb_partition_headers_kernel, dim3(1), dim3(256), 0, s, (uint64_t*)out_blocks_dev, W, stride, max_rows,
+                     (uint32_t)n_buckets, (const unsigned long long*)g->xcur);
+  DBHIP_LAUNCH_CHECK();
+  return DBHIP_OK;  // nothing is read back: the headers travel with the blocks
+}
+
+int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, void* out_rows_dev, int64_t max_rows,
+                                        int64_t* out_counts_host, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && out_counts_host && n_buckets >= 1 && n_buckets <= 4096 && (out_rows_dev || max_rows == 0),
+                "dbhip_groupby_flush_partitioned: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_flush_partitioned")) return rl;
+  hipStream_t s = resolve_stream(stream);
+  int32_t rc = ensure_xcur(g);
+  if (rc) return rc;
+  uint64_t* cur = g->xcur;
+  uint64_t* base = g->xcur + 4096;
+  DBHIP_CHECK(hipMemsetAsync(cur, 0, (size_t)n_buckets * 8, s));
+  const int grid = grid_for(g->cap, 256);
+  hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint32_t)n_buckets,
+                     (int64_t)0, (int64_t)0, (const uint64_t*)nullptr, (uint64_t*)nullptr, (unsigned long long*)cur);
+  DBHIP_LAUNCH_CHECK();
+  std::vector<uint64_t> cnt((size_t)n_buckets), off((size_t)n_buckets + 1);
+  DBHIP_CHECK(hipMemcpyAsync(cnt.data(), cur, (size_t)n_buckets * 8, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  uint64_t total = 0;
+  for (int b = 0; b < n_buckets; ++b) { off[b] = total; total += cnt[b]; out_counts_host[b] = (int64_t)cnt[b]; }
+  off[n_buckets] = total;
+  if ((int64_t)total > max_rows) {
+    set_error("dbhip_groupby_flush_partitioned: %llu groups do not fit max_rows=%lld", (unsigned long long)total, (long long)max_rows);
+    return DBHIP_ERR_CAPACITY;
+  }
+  if (total == 0) return DBHIP_OK;
+  DBHIP_CHECK(hipMemcpyAsync(base, off.data(), (size_t)(n_buckets + 1) * 8, hipMemcpyHostToDevice, s));
+  DBHIP_CHECK(hipMemsetAsync(cur, 0, (size_t)n_buckets * 8, s));
+  hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint32_t)n_buckets,
+                     (int64_t)0, (int64_t)0, (const uint64_t*)base, (uint64_t*)out_rows_dev, (unsigned long long*)cur);
+  DBHIP_LAUNCH_CHECK();
+  DBHIP_CHECK(hipStreamSynchronize(s));  // `off` (pageable host memory) was the source of an async copy
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows, void* stream) {
+  GB_DRAIN(g, resolve_stream(stream));
+  DBHIP_REQUIRE(g && blocks_dev && n_blocks >= 1 && n_blocks <= 4096 && max_rows >= 1, "dbhip_groupby_replace_with_blocks: bad argument");
+  if (int32_t rl = refuse_long_strings(g, "dbhip_groupby_replace_with_blocks")) return rl;
+  hipStream_t s = resolve_stream(stream);
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  const uint64_t* blocks = (const uint64_t*)blocks_dev;
+  std::vector<uint64_t> head((size_t)n_blocks * 2);
+  DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 16, blocks, (size_t)stride * 8, 16, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  int64_t total = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    if (head[2 * b] == ~0ULL || (int64_t)head[2 * b] > max_rows || head[2 * b + 1] != 0) {  // decided BEFORE the table is touched
+      set_error("dbhip_groupby_replace_with_blocks: the sender of block %d overflowed max_rows=%lld (exchange the rows with "
+                "dbhip_groupby_flush_partitioned / merge_serialized instead)", b, (long long)max_rows);
+      return DBHIP_ERR_CAPACITY;
+    }
+    total += (int64_t)head[2 * b];
+  }
+  int32_t rc;
+  if ((rc = dbhip_groupby_reset(g, stream))) return rc;
+  if (total == 0) return DBHIP_OK;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)total * W * 8))) return rc;
+  hipLaunchKernelGGL(gb_compact_blocks_kernel, dim3(n_blocks), dim3(256), 0, s, blocks, stride, W, -1, g->rows_in);
+  DBHIP_LAUNCH_CHECK();
+  return merge_rows(g, g->rows_in, total, s);
+}
+
+int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
+  DBHIP_REQUIRE(g, "dbhip_groupby_reset: NULL argument");
+  hipStream_t s = resolve_stream(stream);
+  if (g->fa_pipe) { const int32_t rc = dbhip_fagg_pipe_reset_internal(g->fa_pipe, s); if (rc) return rc; }   // queued blocks are dropped with the groups
+  DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)g->cap * 8, s));
+  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 128, s));
+  g->count_host = 0;
+  g->has_long = 0;
+  g->fast_disabled = 0;
+  g->fast_trusted = 0;
+  g->lds_big = 0;
+  g->fagg_disabled = 0;
+  g->gbc_lcap = 0;
+  g->gbc_active = 0;
+  g->gbc_part_lcap_max = 0;
+  g->part_validate = 0; g->part_validated = 0;
+  if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
+  g->rows_seen = 0;
+  return DBHIP_OK;
+}
+
+int32_t dbhip_groupby_destroy(dbhip_groupby* g) {
+  if (!g) return DBHIP_OK;
+  (void)hipDeviceSynchronize();
+  if (g->fa_pipe) dbhip_fagg_pipe_destroy_internal(g->fa_pipe);
+  if (g->slot_hash) (void)dbhip_free(g->slot_hash);
+  if (g->rows) (void)dbhip_free(g->rows);
+  if (g->ctrl) (void)hipFree(g->ctrl);
+  if (g->rows_in) (void)dbhip_free(g->rows_in);
+  if (g->gid) (void)dbhip_free(g->gid);
+  if (g->retry) (void)dbhip_free(g->retry);
+  if (g->partial) (void)dbhip_free(g->partial);
+  if (g->part_meta) (void)dbhip_free(g->part_meta);
+  if (g->spill_idx) (void)dbhip_free(g->spill_idx);
+  if (g->spill_rows) (void)dbhip_free(g->spill_rows);
+  if (g->gbc_spill) (void)dbhip_free(g->gbc_spill);
+  if (g->gbc_split) (void)dbhip_free(g->gbc_split);
+  if (g->xcur) (void)hipFree(g->xcur);
+  if (g->arena) (void)dbhip_free(g->arena);
+  delete g;
+  return DBHIP_OK;
+}
+
+}  // extern "C"
+
