@@ -847,7 +847,12 @@ __global__ __launch_bounds__(TQ * 2) __attribute__((amdgpu_waves_per_eu(TQ == 25
 // The epilogue is the bound test of bf16_filter_kernel on the 16 x 16 fragment layout.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int METRIC>
+// V = 1 (round 6): a phase's fragment reads are split at the k half. The k = 0 half is read before the phase's first barrier as before;
+// the k = 1 half is issued right AFTER the cluster's first MFMA pair and lands behind the k = 0 MFMAs — the matrix pipe starts after 4 (2)
+// ds_read_b128 instead of 8 (4), and half of every phase's LDS latency disappears behind MFMA issue. (The compiler waits lgkmcnt(0)
+// before the first MFMA that uses a pending fragment and does not count: reads issued before that MFMA would be waited for as well,
+// hence the placement behind it, pinned with sched_barrier.) V = 0: rounds 4-5.
+template <int METRIC, int V = 1>
 __global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t fsm[];   // 2 buffers x 4 units x 16 KB
   constexpr int TQ = 256, TI = 256;
@@ -903,28 +908,41 @@ __global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
   // ---- fragment reads ----
   const int fr = lane & 15, fg = lane >> 4;
   auto frag_off = [&](int u, int sl) { return u * 128 + ((sl ^ ((u >> 1) & 7)) << 4); };
-  uint32_t aoffs[4][2], boffs[2][2];   // [fragment][k half]
+  // [k half] of fragment 0; fragment m lies m * 16 rows = m * 2048 bytes further with the SAME swizzle term ((u >> 1) & 7 does not see
+  // multiples of 16 rows): an immediate offset of the ds_read instead of a register per fragment (round 6: the registers this frees are
+  // what the split-half schedule needs)
+  uint32_t aoff0[2], boff0[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) aoffs[m][kk] = (uint32_t)frag_off(wr * 64 + m * 16 + fr, kk * 4 + fg);
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) boffs[nn][kk] = (uint32_t)frag_off(wc * 32 + nn * 16 + fr, kk * 4 + fg);
+    aoff0[kk] = (uint32_t)frag_off(wr * 64 + fr, kk * 4 + fg);
+    boff0[kk] = (uint32_t)frag_off(wc * 32 + fr, kk * 4 + fg);
   }
+#define aoffs(m, kk) (aoff0[kk] + (uint32_t)(m) * 2048u)
+#define boffs(nn, kk) (boff0[kk] + (uint32_t)(nn) * 2048u)
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-  auto read_a = [&](int buf, int un) {
+  auto read_a = [&](int buf, int un, int half = 0) {
     const uint8_t* base = fsm + buf * 65536 + un * 16384;
+    if (V == 1) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fa[m][half] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + aoffs(m, half)));
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fa[m][kk] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + aoffs[m][kk]));
+      for (int kk = 0; kk < 2; ++kk) fa[m][kk] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + aoffs(m, kk)));
   };
-  auto read_b = [&](int buf, int un, bf16x8 (&fb)[2][2]) {
+  auto read_b = [&](int buf, int un, bf16x8 (&fb)[2][2], int half = -1) {
     const uint8_t* base = fsm + buf * 65536 + un * 16384;
+    if (V == 1 && half >= 0) {
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) fb[nn][half] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + boffs(nn, half)));
+      return;
+    }
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) fb[nn][kk] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + boffs[nn][kk]));
+      for (int kk = 0; kk < 2; ++kk) fb[nn][kk] = __builtin_bit_cast(bf16x8, *(const u32x4*)(base + boffs(nn, kk)));
   };
   f32x4v acc[8][4];
 #pragma unroll
@@ -932,15 +950,23 @@ __global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
 #pragma unroll
     for (int nn = 0; nn < 4; ++nn) acc[m][nn] = f32x4v{0.f, 0.f, 0.f, 0.f};
   // 16 MFMAs: quadrant (sa, sb) of the wave's 8 x 4 fragments
-  auto mfma_quadrant = [&](int sa, int sb, const bf16x8 (&fb)[2][2]) {
+  // `fresh` (V = 1): what this phase's own reads deliver — 1: the A fragments of unit (rbuf, run), 2: the B fragments of unit (rbuf, run)
+  // into `fb`, 0: nothing the cluster uses (the phase that reads B0 of the NEXT k-tile works from registers and reads both halves up front)
+  auto mfma_quadrant = [&](int sa, int sb, bf16x8 (&fb)[2][2], int fresh = 0, int rbuf = 0, int run = 0) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn)
           acc[sa * 4 + m][sb * 2 + nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][kk], fb[nn][kk], acc[sa * 4 + m][sb * 2 + nn], 0, 0, 0);
+        if (V == 1 && fresh != 0 && kk == 0 && m == 0) {   // the k = 1 half, behind the first MFMA pair
+          __builtin_amdgcn_sched_barrier(0);
+          if (fresh == 1) read_a(rbuf, run, 1); else read_b(rbuf, run, fb, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -953,7 +979,7 @@ __global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
 #define F256_MEM_SYNC()                              \
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  \
   __builtin_amdgcn_s_barrier();                      \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  if (V == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define F256_END_SYNC() __builtin_amdgcn_s_barrier()
 
   // LDS reads per phase are BALANCED (8 / 4 / 8 / 4 ds_read_b128 per wave): B0 of the NEXT k-tile is read in phase 4, whose own MFMAs
@@ -980,43 +1006,43 @@ __global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
       read_a(0, 0);
       stage(1, 1, g + 1);
       F256_MEM_SYNC();
-      mfma_quadrant(0, 0, bx);
+      mfma_quadrant(0, 0, bx, 1, 0, 0);
       F256_END_SYNC();
-      read_b(0, 3, by);
+      read_b(0, 3, by, V == 1 ? 0 : -1);
       stage(2, 0, g + 2);
       F256_MEM_SYNC();
-      mfma_quadrant(0, 1, by);
+      mfma_quadrant(0, 1, by, 2, 0, 3);
       F256_END_SYNC();
       read_a(0, 1);
       stage(0, 0, g + 2);
       F256_MEM_SYNC();
-      mfma_quadrant(1, 1, by);
+      mfma_quadrant(1, 1, by, 1, 0, 1);
       F256_END_SYNC();
       read_b(1, 2, by);            // B0(g + 1) into Y (B1(g) has had its last use)
       stage(3, 0, g + 2);
       F256_MEM_SYNC();
-      mfma_quadrant(1, 0, bx);
+      mfma_quadrant(1, 0, bx, 0);
       F256_END_SYNC();
       // ---- k-tile g + 1 in buffer 1 (B0 in Y, B1 in X) ----
       read_a(1, 0);
       stage(1, 0, g + 2);
       F256_MEM_SYNC();
-      mfma_quadrant(0, 0, by);
+      mfma_quadrant(0, 0, by, 1, 1, 0);
       F256_END_SYNC();
-      read_b(1, 3, bx);
+      read_b(1, 3, bx, V == 1 ? 0 : -1);
       stage(2, 1, g + 3);
       F256_MEM_SYNC();
-      mfma_quadrant(0, 1, bx);
+      mfma_quadrant(0, 1, bx, 2, 1, 3);
       F256_END_SYNC();
       read_a(1, 1);
       stage(0, 1, g + 3);
       F256_MEM_SYNC();
-      mfma_quadrant(1, 1, bx);
+      mfma_quadrant(1, 1, bx, 1, 1, 1);
       F256_END_SYNC();
       read_b(0, 2, bx);            // B0(g + 2) into X
       stage(3, 1, g + 3);
       F256_MEM_SYNC();
-      mfma_quadrant(1, 0, by);
+      mfma_quadrant(1, 0, by, 0);
       F256_END_SYNC();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();          // (the barrier the second half's last phase pairs with)
@@ -1059,6 +1085,8 @@ __global__ __launch_bounds__(512) void bf16_filter256_kernel(HArgs A) {
   }
 #undef F256_MEM_SYNC
 #undef F256_END_SYNC
+#undef aoffs
+#undef boffs
 }
 
 // One wave per row: out[row][0..dpad) = bf16(x[row]) (RNE, zero padded) and the row's coefficients.
@@ -1198,9 +1226,10 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
       static std::once_flag raised_once;
       static hipError_t raised_err = hipSuccess;
       std::call_once(raised_once, [] {
-        raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (raised_err == hipSuccess) raised_err = hipFuncSetAttribute((const void*)bf16_filter256_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       });
       DBHIP_CHECK(raised_err);
       A.qcB = qcB; A.qcG = qcG; A.qcT = qcT;
@@ -1210,7 +1239,10 @@ int32_t index_search_batch(dbhip_vec_index* ix, const float* queries, int nq, in
         hipLaunchKernelGGL((bf16_filter256_kernel<2>), fg, dim3(512), 131072, s, A);
       } else if (cosine) {
         hipLaunchKernelGGL((bf16_qcoef_kernel<0>), cg, dim3(256), 0, s, A, nq_pad, qcB, qcG, qcT);
-        hipLaunchKernelGGL((bf16_filter256_kernel<0>), fg, dim3(512), 131072, s, A);
+        // (experiments build: DBHIP_BF16_V=0 runs the rounds-4-5 schedule of the cosine kernel for a same-process A/B)
+        static const bool v0 = exp_env("DBHIP_BF16_V") && atoi(exp_env("DBHIP_BF16_V")) == 0;
+        if (v0) hipLaunchKernelGGL((bf16_filter256_kernel<0, 0>), fg, dim3(512), 131072, s, A);
+        else hipLaunchKernelGGL((bf16_filter256_kernel<0, 1>), fg, dim3(512), 131072, s, A);
       } else {
         hipLaunchKernelGGL((bf16_qcoef_kernel<1>), cg, dim3(256), 0, s, A, nq_pad, qcB, qcG, qcT);
         hipLaunchKernelGGL((bf16_filter256_kernel<1>), fg, dim3(512), 131072, s, A);

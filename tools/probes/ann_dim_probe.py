@@ -21,7 +21,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(7)
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-for dim in (768, 1536, 3072):
+for dim in [int(x) for x in os.environ.get("ANN_DIMS", "768,1536,3072").split(",")]:
     n = 1_250_000 * 768 // dim
     n -= n % 256
     base = torch.randn((n, dim), device=dev, dtype=torch.float32, generator=g)
