@@ -16,8 +16,16 @@ Files and what the reference's tests say about them:
       select_parquet.test:69-72 count() = 400 over the four files; gen.py: col_int = [0, 1] * rows
       the SAME files hold col_arr = [[1], [1, 2]] * rows (gen.py:12, "we need multi pages in a column chunk for list type"):
       List<Int64> leaves col_arr.list.item (max_def 3, max_rep 1) whose rows span many 128-byte pages -> multi_page_{k}_col_arr
+  tests/data/parquet/tuple.parquet (parquet-cpp-arrow 14, SNAPPY; id INT32 NOT NULL, t Tuple(A INT32, B STRING) NOT NULL: leaves of max_def 0)
+      parquet_transform.test:8-17 `select (t.id+1)` -> 2, 3, 4: id = 1, 2, 3; the members t.A / t.B are flat leaves (a NOT NULL struct
+      adds no level): their values (1, 3, 3 / a, b, c) are pyarrow's reading — the reference's tests do not print them
+  tests/data/parquet/no-stats.parquet (parquet-mr 1.12.2, SNAPPY; four Map(String, ..) columns): `product` is the one with entries
+      (188,558 in 25,825 rows). A Map is List<Struct<key NOT NULL, value>>: its two leaves are List leaves that share their levels — key
+      (max_def 2 = list_nullable 1 + 1 + element_nullable 0), value (max_def 3) — so a binding decodes a Map with two List decodes;
+      the expected entries are pyarrow's reading (select_parquet.test:53-66 only counts this file's rows: 25,825 = the lists' count)
   tests/data/ontime_200.parquet (parquet-cpp-arrow 14, SNAPPY)
       on_time.test:1-12: the nine tail_number values where dayofmonth = 1; :54-61 month = 12"""
+import hashlib
 import json
 import os
 
@@ -111,6 +119,16 @@ def main():
              "databend PR 11271); rows counted by tests/sqllogictests/suites/stage/formats/parquet/select_parquet.test:69-72",
              chunks_of(os.path.join(REF, f"parquet/multi_page/multi_page_{k}.parquet"), columns=["col_arr.list.item"]),
              {"rows": nrows, "pattern": [[1], [1, 2]], "list_nullable": 1, "element_nullable": 1})
+    emit("tuple", "tests/data/parquet/tuple.parquet", "tests/sqllogictests/suites/stage/formats/parquet/parquet_transform.test:8-17 (id + 1 = 2, 3, 4); t.A / t.B: pyarrow",
+         chunks_of(os.path.join(REF, "parquet/tuple.parquet")), {"id": [1, 2, 3], "t.A": [1, 3, 3], "t.B": ["a", "b", "c"]})
+    prod = pq.read_table(os.path.join(REF, "parquet/no-stats.parquet"), columns=["product"]).column(0).to_pylist()
+    emit("no_stats_product_map", "tests/data/parquet/no-stats.parquet", "pyarrow's reading of the Map column `product`; rows counted by "
+         "tests/sqllogictests/suites/stage/formats/parquet/select_parquet.test:53-66",
+         chunks_of(os.path.join(REF, "parquet/no-stats.parquet"), columns=["product.key_value.key", "product.key_value.value"]),
+         {"rows": len(prod), "entries": sum(len(m) for m in prod if m is not None),
+          "maps_head": [None if m is None else [[k, v] for k, v in m] for m in prod[:40]],
+          # every row, canonically serialised (the fixture stays small): sha256 of json.dumps([[k, v], ...] | None per row)
+          "sha256": hashlib.sha256(json.dumps([None if m is None else [[k, v] for k, v in m] for m in prod]).encode()).hexdigest()})
     emit("ontime_200", "tests/data/ontime_200.parquet", "tests/sqllogictests/suites/stage/formats/parquet/on_time.test:1-12,54-61",
          chunks_of(os.path.join(REF, "ontime_200.parquet"), columns=["DayofMonth", "Tail_Number", "Month"]),
          {"tail_number_where_dayofmonth_1": ["N315PQ", "N835AY", "N606LR", "N606LR", "N301PQ", "N176PQ", "N336PQ", "N901XJ", "N909XJ"], "month_all": 12,
