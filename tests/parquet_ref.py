@@ -114,3 +114,46 @@ def check_lists(decode_list):
         total += len(rows)
     assert total == 400
     return 4
+
+
+def check_tuple(decode):
+    """tests/data/parquet/tuple.parquet: `id` as the reference's test implies it (parquet_transform.test:8-17: id + 1 = 2, 3, 4) and the two
+    members of the NOT NULL Tuple column t — flat leaves of max_def 0 (a required struct adds no level): a Tuple(..) column is its member
+    columns decoded one by one (t.A / t.B expected from pyarrow's reading: the reference's tests do not print them)."""
+    d = fixtures()["tuple"]
+    e = d["expected"]
+    for ch in d["chunks"]:
+        assert ch["max_def"] == 0 and ch["max_rep"] == 0
+    assert column(d, "id", decode) == e["id"]
+    assert column(d, "t.A", decode) == e["t.A"]
+    assert [v.decode() for v in column(d, "t.B", decode)] == e["t.B"]
+    return 3
+
+
+def check_map(decode_list):
+    """tests/data/parquet/no-stats.parquet, Map(String, String) column `product`: a Map is List<Struct<key NOT NULL, value>>, so its two
+    leaves are List leaves over the SAME repetition / definition structure — key: (list_nullable 1, element_nullable 0), value: (1, 1).
+    Two List decodes give the Map: equal offsets and list validity, entries = zip(keys, values). 25,825 rows (the count the reference's
+    select_parquet.test:53-66 relies on), 188,558 entries; every row against pyarrow's reading (digest) and the first 40 literally."""
+    import hashlib
+    import json as _json
+    d = fixtures()["no_stats_product_map"]
+    e = d["expected"]
+    kch = [c for c in d["chunks"] if c["column"].endswith(".key")][0]
+    vch = [c for c in d["chunks"] if c["column"].endswith(".value")][0]
+    assert (kch["max_rep"], kch["max_def"], vch["max_rep"], vch["max_def"]) == (1, 2, 1, 3)
+    keys = decode_list(kch, 1, 0, T.T_STRING)
+    vals = decode_list(vch, 1, 1, T.T_STRING)
+    assert len(keys) == len(vals) == e["rows"]
+    maps = []
+    for k, v in zip(keys, vals):
+        if k is None:
+            assert v is None
+            maps.append(None)
+            continue
+        assert v is not None and len(k) == len(v)
+        maps.append([[a.decode(), None if b is None else b.decode()] for a, b in zip(k, v)])
+    assert sum(len(m) for m in maps if m is not None) == e["entries"]
+    assert maps[:40] == e["maps_head"]
+    assert hashlib.sha256(_json.dumps(maps).encode()).hexdigest() == e["sha256"]
+    return 1

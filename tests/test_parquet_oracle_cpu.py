@@ -327,6 +327,7 @@ def test_oracle_decodes_the_reference_held_parquet_files_to_what_its_tests_print
         py = [bool(vals[i]) for i in range(n)] if out_type == T.T_BOOL else PU.decoded_to_python(vals.tobytes(), v, out_type, n, chunk)
         return py, v
     assert PR.check_all(decode) == 21
+    assert PR.check_tuple(decode) == 3     # (round 6) the members of a NOT NULL Tuple column are flat leaves
 
 
 def test_oracle_delta_binary_packed_matches_pyarrow():
