@@ -89,7 +89,6 @@ int32_t dbhip_groupby_add_block(dbhip_groupby* g, const dbhip_col* keys, const d
 
 int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys, const dbhip_col* args, int64_t n,
                                          const uint8_t* filter_bitmap, int64_t filter_bit_offset, void* stream) {
-  GB_DRAIN(g, resolve_stream(stream));
   DBHIP_REQUIRE(g && keys, "dbhip_groupby_add_block: NULL argument");
   if (n == 0) return DBHIP_OK;
   hipStream_t s = resolve_stream(stream);
@@ -120,6 +119,13 @@ int32_t dbhip_groupby_add_block_filtered(dbhip_groupby* g, const dbhip_col* keys
     C.arg[a] = to_gbcol(args[a]);
   }
   int32_t rc;
+  if (g->fa_pipe) {
+    // a pipelined table queues the block like a fused program without instructions (few groups, <= 4 key words, <= 8 aggregates);
+    // anything else is checkpointed first and then takes the synchronous paths below
+    rc = dbhip_fagg_pipe_add_columns_internal(g, g->fa_pipe, C, n, s);
+    if (rc != -1) return rc;
+    GB_DRAIN(g, s);
+  }
   int64_t done = 0;
   g->gbc_active = 0;   // (add_block_fast decides per call whether layout and columns qualify for the compact-row kernels)
   // The caller sized the table for about as many groups as this first block has rows (a join's output grouped by the join key,

@@ -702,6 +702,7 @@ struct FaPending { int shape; FaBlock b; };
 struct FaMerge { uint64_t seq; int64_t rows_ub; int64_t blocks; };
 struct FaPipe {
   bool on = false, bound = false, slots8 = false;
+  bool given_up = false;             // a checkpoint returned DBHIP_ERR_CAPACITY: plain add_block calls stop queueing (the keys are not for this kernel)
   hipStream_t stream = nullptr;
   uint64_t* rows = nullptr;          // device [cap_rows][W]
   int64_t cap_rows = 0;
@@ -944,6 +945,7 @@ int32_t fa_pipe_checkpoint(dbhip_groupby* g, FaPipe* pp, int64_t* out_committed,
               "not merged: evaluate their maps with dbhip_expr_eval to get the rows", (unsigned long long)errs, (long long)committed, (long long)submitted);
     return DBHIP_ERR_ROW_ERRORS;
   }
+  pp->given_up = true;
   set_error("dbhip_groupby_checkpoint: more than %d distinct groups inside one workgroup%s; pipelined blocks [%lld, %lld) were not merged: use the "
             "operator-at-a-time path for them", FA_MAX_SLOTS, (flags & 8) ? " (and the table filled during a merge)" : "", (long long)committed,
             (long long)submitted);
@@ -962,7 +964,7 @@ int32_t dbhip_fagg_pipe_reset_internal(void* pipe, hipStream_t s) {
   FaPipe* pp = (FaPipe*)pipe;
   if (pp->bound) DBHIP_CHECK(hipStreamSynchronize(pp->stream));
   fa_pipe_forget(pp);
-  pp->count_seen = 0; pp->slots8 = false; pp->bound = false;
+  pp->count_seen = 0; pp->slots8 = false; pp->bound = false; pp->given_up = false;
   DBHIP_CHECK(hipMemsetAsync(pp->ctrl, 0, 64, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
   return DBHIP_OK;
@@ -1262,6 +1264,49 @@ int32_t dbhip_fagg_add_columns_internal(dbhip_groupby* g, const GbCols& C, int64
   t_jit_only = false;
   return rc;
 }
+// Plain add_block / add_block_filtered on a PIPELINED table (k_groupby.hip calls this first): the block's key and argument columns as a
+// program without instructions, queued like any other block. -1: not taken (the table is not pipelined, gave up earlier, or the
+// shape is outside the fused kernel) — the caller checkpoints and runs its synchronous paths.
+int32_t dbhip_fagg_pipe_add_columns_internal(dbhip_groupby* g, void* pipe, const GbCols& C, int64_t n, hipStream_t s) {
+  FaPipe* pp = (FaPipe*)pipe;
+  if (!pp || !pp->on || pp->given_up || jit_mode() == 0) return -1;
+  const GbLayout& L = *dbhip_groupby_layout_internal(g);
+  if (!dbhip_fagg_layout_ok_internal(L)) return -1;
+  dbhip_col keys[FA_KW], inputs[EX_MAX_INPUTS];
+  int32_t arg_regs[FA_MAXA];
+  int n_inputs = 0;
+  for (int k = 0; k < L.nkeys; ++k)
+    if (!fa_offset_col(C.key[k], 0, &keys[k])) return -1;
+  bool any_arg = false;
+  for (int a = 0; a < L.naggs; ++a) {
+    arg_regs[a] = DBHIP_ARG_NONE;
+    if (C.arg[a].data == nullptr) {
+      if (L.agg_kind[a] != DBHIP_AGG_COUNT) return -1;
+      continue;
+    }
+    if (!fa_arg_type_ok(C.arg[a].type)) return -1;
+    dbhip_col col;
+    if (!fa_offset_col(C.arg[a], 0, &col)) return -1;
+    int found = -1;
+    for (int c = 0; c < n_inputs && found < 0; ++c)
+      if (inputs[c].data == col.data && inputs[c].type == col.type && inputs[c].validity == col.validity &&
+          inputs[c].validity_offset == col.validity_offset && inputs[c].is_scalar == col.is_scalar) found = c;
+    if (found < 0) {
+      if (n_inputs >= EX_MAX_INPUTS) return -1;
+      if (col.type == DBHIP_T_DEC128) { int wide = 0; for (int c = 0; c < n_inputs; ++c) wide += inputs[c].type == DBHIP_T_DEC128; if (wide >= 2) return -1; }
+      inputs[n_inputs] = col;
+      found = n_inputs++;
+    }
+    arg_regs[a] = DBHIP_ARG_INPUT(found);
+    any_arg = true;
+  }
+  if (!any_arg) return -1;   // count(*) only
+  dbhip_agg_program prog;
+  prog.prog = nullptr; prog.n_ins = 0; prog.inputs = inputs; prog.n_inputs = n_inputs; prog.filter_reg = -1; prog.arg_regs = arg_regs;
+  const int32_t rc = dbhip_groupby_add_block_program(g, keys, &prog, n, C.filter, C.filter_off, (void*)s);
+  return rc == DBHIP_ERR_UNSUPPORTED ? -1 : rc;
+}
+
 // after DBHIP_ERR_UNSUPPORTED from dbhip_fagg_add_columns_internal: true = only for now (the kernel is being compiled)
 bool dbhip_fagg_last_refusal_is_pending_internal() { return t_jit_pending; }
 

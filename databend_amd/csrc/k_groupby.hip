@@ -92,6 +92,8 @@ struct dbhip_groupby {
 int32_t dbhip_fagg_pipe_drain_internal(dbhip_groupby* g, void* pipe, hipStream_t s);
 void dbhip_fagg_pipe_destroy_internal(void* pipe);
 int32_t dbhip_fagg_pipe_reset_internal(void* pipe, hipStream_t s);
+struct GbCols;
+int32_t dbhip_fagg_pipe_add_columns_internal(dbhip_groupby* g, void* pipe, const GbCols& C, int64_t n, hipStream_t s);
 #define GB_DRAIN(g, s)                                                                   \
   do {                                                                                   \
     if ((g) && (g)->fa_pipe) {                                                           \

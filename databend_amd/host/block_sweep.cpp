@@ -7,6 +7,8 @@
 // table, like the reference's pipeline threads), and reports rows/s and the fixed cost per call for
 //   q1_sync       dbhip_groupby_add_block_program, one synchronous call per block (rounds 2-5)
 //   q1_pipelined  the same call on a table in pipelined mode (round 6): one launch per block, checkpoint at the end
+//   plain_sync / plain_pipelined   dbhip_groupby_add_block (GROUP BY one Int64 key with four values: sum(Int64), count(*)) — no fused
+//                 program, the call TransformPartialAggregate makes today — synchronous, and on a pipelined table
 //   q1_squash_*   65,536-row blocks concatenated (device-to-device) into 1 Mi / 4 Mi-row staging blocks first — the block
 //                 accumulator a binding would put in front of the operator (the reference's own join build squashes,
 //                 new_hash_join/memory/basic.rs:78-89)
@@ -40,6 +42,7 @@ static uint64_t mix(uint64_t x) { x += 0x9e3779b97f4a7c15ULL; x = (x ^ (x >> 30)
 struct Lineitem {
   int64_t n = 0;
   int64_t *qty = nullptr, *price = nullptr, *disc = nullptr, *tax = nullptr;
+  int64_t* k4 = nullptr;   // a four-valued Int64 key for the plain GROUP BY lines
   int32_t* ship = nullptr;
   uint8_t *rf = nullptr, *ls = nullptr;   // 16-byte views
 };
@@ -50,7 +53,7 @@ static void* dalloc(size_t bytes) { void* p = nullptr; CK(dbhip_alloc(bytes < 64
 
 static Lineitem gen_lineitem(int64_t n) {
   Lineitem li; li.n = n;
-  std::vector<int64_t> qty(n), price(n), disc(n), tax(n);
+  std::vector<int64_t> qty(n), price(n), disc(n), tax(n), k4(n);
   std::vector<int32_t> ship(n);
   std::vector<uint8_t> rf((size_t)n * 16, 0), ls((size_t)n * 16, 0);
   const int T = 8;
@@ -62,6 +65,7 @@ static Lineitem gen_lineitem(int64_t n) {
       price[i] = (int64_t)(90000 + r % 10404951); r = mix(r);
       disc[i] = (int64_t)(r % 11); r = mix(r);
       tax[i] = (int64_t)(r % 9); r = mix(r);
+      k4[i] = (int64_t)((r >> 17) & 3) * 1000003;
       ship[i] = kShipLo + (int32_t)(r % (uint64_t)(kShipHi - kShipLo + 1)); r = mix(r);
       const int32_t receipt = ship[i] + 1 + (int32_t)(r % 30); r = mix(r);
       const char f = receipt <= kCurrent ? ((r & 1) ? 'A' : 'R') : 'N';
@@ -75,6 +79,7 @@ static Lineitem gen_lineitem(int64_t n) {
   auto up = [&](const void* src, size_t bytes) { void* d = dalloc(bytes); CK(dbhip_memcpy_h2d(d, src, bytes, nullptr)); return d; };
   li.qty = (int64_t*)up(qty.data(), (size_t)n * 8); li.price = (int64_t*)up(price.data(), (size_t)n * 8);
   li.disc = (int64_t*)up(disc.data(), (size_t)n * 8); li.tax = (int64_t*)up(tax.data(), (size_t)n * 8);
+  li.k4 = (int64_t*)up(k4.data(), (size_t)n * 8);
   li.ship = (int32_t*)up(ship.data(), (size_t)n * 4);
   li.rf = (uint8_t*)up(rf.data(), (size_t)n * 16); li.ls = (uint8_t*)up(ls.data(), (size_t)n * 16);
   CK(dbhip_stream_sync(nullptr));
@@ -337,6 +342,86 @@ int main(int argc, char** argv) {
           bool ok = false; int64_t calls = 0;
           const double secs = run_q1(li, 65536, T, mode, S, expect, &ok, &calls);
           report({std::string(mode == Q1_SQUASH ? "q1_squash_" : "q1_squashpipe_") + (S == (1 << 20) ? "1Mi" : "4Mi"), 65536, T, secs, N, calls, ok, "device-to-device concat of 7 columns, then the call"});
+        }
+  }
+
+  // ---- plain add_block (no program): GROUP BY k4 -> sum(price as Int64), count(*) ----
+  {
+    auto make_table = [&](dbhip_groupby** g) {
+      int32_t kt[1] = {DBHIP_T_I64}; uint8_t kn[1] = {0};
+      dbhip_agg_desc ad[2]; memset(ad, 0, sizeof(ad));
+      ad[0].kind = DBHIP_AGG_SUM; ad[0].arg_type = DBHIP_T_I64; ad[1].kind = DBHIP_AGG_COUNT;
+      CK(dbhip_groupby_create(kt, kn, 1, ad, 2, 1024, g));
+    };
+    auto run_plain = [&](int64_t B, int T, bool pipelined, const Q1Result* expect, Q1Result* out_res, int64_t* calls_out) -> double {
+      const int64_t nblocks = (li.n + B - 1) / B;
+      std::vector<dbhip_groupby*> tables(T); std::vector<void*> streams(T);
+      for (int t = 0; t < T; ++t) { make_table(&tables[t]); CK(dbhip_stream_create(&streams[t])); if (pipelined) CK(dbhip_groupby_set_pipelined(tables[t], 1, streams[t])); }
+      // warm the shape's kernels ONCE (the specialised kernels are compiled in the background on first sight: wait until launches go
+      // through them, single- and multi-block), then reset
+      static bool warmed = false;
+      for (int t = 0; t < 1 && !warmed; ++t) {
+        dbhip_col k = col(DBHIP_T_I64, li.k4), a[2]; a[0] = col(DBHIP_T_I64, li.price); memset(&a[1], 0, sizeof(a[1]));
+        for (int w = 0; w < 40; ++w) { CK(dbhip_groupby_add_block(tables[t], &k, a, 65536, streams[t])); int64_t c; CK(dbhip_groupby_checkpoint(tables[t], &c, streams[t])); CK(dbhip_stream_sync(streams[t])); uint64_t st[3]; dbhip_fagg_stats(st); if (st[0] > 0 && w > 2) break; std::this_thread::sleep_for(std::chrono::milliseconds(100)); }
+        for (int w = 0; w < 40 && pipelined; ++w) {   // ... and the multi-block form (two queued blocks per checkpoint)
+          uint64_t s0[3], s1[3]; dbhip_fagg_stats(s0);
+          for (int q = 0; q < 2; ++q) CK(dbhip_groupby_add_block(tables[t], &k, a, 65536, streams[t]));
+          int64_t c; CK(dbhip_groupby_checkpoint(tables[t], &c, streams[t]));
+          dbhip_fagg_stats(s1);
+          if (s1[0] - s0[0] == 1) break;   // one launch for two blocks
+          std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        CK(dbhip_groupby_reset(tables[t], streams[t]));
+        warmed = pipelined;
+      }
+      std::atomic<int> ready{0}; std::atomic<bool> go{false};
+      std::vector<double> t_end(T, 0.0);
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+        ++ready;
+        while (!go.load(std::memory_order_acquire)) {}
+        for (int64_t b = t; b < nblocks; b += T) {
+          const int64_t row0 = b * B, n = row0 + B <= li.n ? B : li.n - row0;
+          dbhip_col k = col(DBHIP_T_I64, li.k4 + row0), a[2]; a[0] = col(DBHIP_T_I64, li.price + row0); memset(&a[1], 0, sizeof(a[1]));
+          CK(dbhip_groupby_add_block(tables[t], &k, a, n, streams[t]));
+        }
+        if (pipelined) { int64_t c = 0; CK(dbhip_groupby_checkpoint(tables[t], &c, streams[t])); }
+        CK(dbhip_stream_sync(streams[t]));
+        t_end[t] = now_s();
+      });
+      while (ready.load() < T) {}
+      const double t0 = now_s();
+      go.store(true, std::memory_order_release);
+      for (auto& x : th) x.join();
+      double secs = 0;
+      for (int t = 0; t < T; ++t) secs = t_end[t] - t0 > secs ? t_end[t] - t0 : secs;
+      for (int t = 1; t < T; ++t) {
+        int64_t n = 0, rb = 0, m = 0;
+        CK(dbhip_groupby_num_groups(tables[t], &n, nullptr)); CK(dbhip_groupby_row_bytes(tables[t], &rb));
+        void* d = dalloc((size_t)(n > 0 ? n : 1) * rb);
+        CK(dbhip_groupby_flush_serialized(tables[t], d, n, &m, nullptr));
+        CK(dbhip_groupby_merge_serialized(tables[0], d, m, nullptr));
+        CK(dbhip_stream_sync(nullptr));
+        CK(dbhip_free(d));
+      }
+      *out_res = q1_result(tables[0]);
+      (void)expect;
+      *calls_out = nblocks;
+      for (int t = 0; t < T; ++t) { CK(dbhip_groupby_destroy(tables[t])); CK(dbhip_stream_destroy(streams[t])); }
+      return secs;
+    };
+    Q1Result whole; int64_t calls = 0;
+    (void)run_plain(N, 1, false, nullptr, &whole, &calls);
+    for (int rep = 0; rep < 2; ++rep)
+      for (int64_t B : sizes)
+        for (int T : threads) {
+          if (B >= N && T > 1) continue;
+          for (int pipelined = 0; pipelined < 2; ++pipelined) {
+            Q1Result got;
+            const double secs = run_plain(B, T, pipelined != 0, &whole, &got, &calls);
+            if (rep) report({pipelined ? "plain_pipelined" : "plain_sync", B, T, secs, N, calls, got.groups == whole.groups && got.words == whole.words,
+                             "dbhip_groupby_add_block: GROUP BY one Int64 key (4 values), sum(Int64), count(*); 24 B per row"});
+          }
         }
   }
 

@@ -515,7 +515,9 @@ int32_t dbhip_groupby_prepare_program(dbhip_groupby* g, const dbhip_col* keys, c
  * like a block the synchronous call gave back. (A "fifth group in one workgroup" give-up of the 4-slot kernel is replayed inside the
  * checkpoint with the 8-slot kernel first, as the synchronous call's second pass does.)
  * Contract: the blocks' buffers (columns, validity, filter Bitmaps) stay alive and unchanged until the checkpoint — they are
- * inputs of queued kernels; one stream per pipelined table between checkpoints (the reference's partial tables are per pipeline
+ * inputs of queued kernels; plain dbhip_groupby_add_block / _add_block_filtered calls on a pipelined table are queued the same way (the
+ * block's columns as a program without instructions) while layout and columns qualify for the few-groups kernel — otherwise, and
+ * after a checkpoint has returned DBHIP_ERR_CAPACITY, they checkpoint and take the synchronous paths; one stream per pipelined table between checkpoints (the reference's partial tables are per pipeline
  * thread as well). Every other entry point that reads or changes the table's groups (flush_*, num_groups, merge_*, plain
  * add_block, the exchange calls) checkpoints first and returns the checkpoint's error if there is one; dbhip_groupby_reset drops
  * queued blocks with the groups. set_pipelined(g, 0) checkpoints and returns to synchronous calls.

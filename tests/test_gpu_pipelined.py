@@ -240,3 +240,47 @@ def test_many_windows_and_a_table_that_has_to_grow(gpu):
         ks.append(k), xs.append(x)
     assert g.checkpoint() == nb
     assert sorted(g.result()) == _expected(np.concatenate(ks), np.concatenate(xs))
+
+
+def test_plain_add_block_queues_on_a_pipelined_table(gpu):
+    """dbhip_groupby_add_block (no fused program: what TransformPartialAggregate::transform calls per block) on a pipelined table goes
+    through the same queue — the block's columns as a program without instructions — incl. a pushed-down filter Bitmap; a block whose
+    keys are not for the few-groups kernel makes the checkpoint give the window back, after which the table takes blocks synchronously
+    (and correctly) by itself."""
+    D = gpu
+    rng = np.random.default_rng(21)
+    n, nb = 40_000, 50
+    g = D.GroupBy([T.T_I64], AGGS)
+    g.set_pipelined(True)
+    keep, ks, xs, fs = [], [], [], []
+    for b in range(nb):
+        k = rng.integers(0, 5, n).astype(np.int64) - 2
+        x = rng.integers(-10**9, 10**9, n).astype(np.int64)
+        f = rng.random(n) < 0.7
+        ck, cx = D.Column.from_numpy(k), D.Column.from_numpy(x)
+        fb = D.Column.boolean(f)
+        if b % 2:
+            g.add_block([ck], [cx, None], n, filter=fb)
+            fs.append(f)
+        else:
+            g.add_block([ck], [cx, None], n)
+            fs.append(np.ones(n, bool))
+        keep.append((ck, cx, fb))
+        ks.append(k), xs.append(x)
+    assert g.checkpoint() == nb
+    K, X, F = np.concatenate(ks), np.concatenate(xs), np.concatenate(fs)
+    exp = sorted((int(key), int(X[F & (K == key)].sum()), int((F & (K == key)).sum())) for key in np.unique(K[F]))
+    assert sorted(g.result()) == exp
+    # many groups: the window is given back once, then the table stops queueing plain blocks
+    k = rng.integers(0, 5000, n).astype(np.int64)
+    x = rng.integers(-100, 100, n).astype(np.int64)
+    ck, cx = D.Column.from_numpy(k), D.Column.from_numpy(x)
+    g2 = D.GroupBy([T.T_I64], AGGS)
+    g2.set_pipelined(True)
+    g2.add_block([ck], [cx, None], n)
+    rc, committed = g2.checkpoint(raise_on_error=False)
+    assert rc == T.ERR_CAPACITY and committed == 0
+    g2.add_block([ck], [cx, None], n)            # synchronous now (LDS / partitioned paths)
+    g2.add_block([ck], [cx, None], n)
+    assert g2.checkpoint() == 0
+    assert sorted(g2.result()) == _expected(np.concatenate([k, k]), np.concatenate([x, x]))
