@@ -236,7 +236,9 @@ int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n
     // merge may bring 50 K groups, r02y: 0.11 ms there against 0.02 ms for the plain kernel)
     // (a Decimal128 min / max state is merged under a lock: always combine the rows of a wave first, one acquisition per wave and state)
     if (deferred || (g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048 || layout_has_wide_minmax(g->L))
-      hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
+      // (deferred = the pipelined fused aggregation's window merge: a handful of groups, every wave's leader lane ends in atomics on the
+      // SAME few rows — 256 waves cost 30 us of serialised atomics for 16 K partial rows; 16 workgroups walk them grid-stride instead)
+      hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(deferred && grid > 16 ? 16 : grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
                          g->ctrl, dc, g->arena);
     else
       hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry, g->ctrl, dc, g->arena);
