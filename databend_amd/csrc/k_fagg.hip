@@ -690,6 +690,7 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 namespace {
 constexpr int FA_PIPE_WINDOW = 128;   // blocks per window (one merge; what one raised flag gives back)
 constexpr int FA_PIPE_BATCH = 32;     // blocks per multi-block launch
+constexpr int FA_PIPE_BATCH_MAX = 128; // what the block tables are sized for (DBHIP_FAGG_PIPE_BATCH sweeps up to it: experiments build)
 constexpr int FA_PIPE_RING = 8;
 constexpr int64_t FA_PIPE_BIG = 8 << 20;          // a block of this many rows is a launch of its own
 constexpr int64_t FA_PIPE_BATCH_ROWS = 8 << 20;   // rows after which a batch goes without waiting for more blocks
@@ -886,7 +887,8 @@ int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStr
   }
   pp->batch.push_back(P);
   pp->batch_rows += P.b.n;
-  if ((int)pp->batch.size() >= FA_PIPE_BATCH || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
+  static const int batch_n = [] { const char* e = exp_env("DBHIP_FAGG_PIPE_BATCH"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= FA_PIPE_BATCH_MAX ? v : FA_PIPE_BATCH; }();
+  if ((int)pp->batch.size() >= batch_n || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
   return DBHIP_OK;
 }
 
@@ -1167,8 +1169,8 @@ int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream) 
   if (rc == DBHIP_OK && e == hipSuccess) { memset(pp->status_host, 0, 64); e = hipMemsetAsync(pp->ctrl, 0, 64, s); }
   if (rc == DBHIP_OK && e == hipSuccess) e = hipStreamSynchronize(s);
   for (int i = 0; i < FA_PIPE_RING && rc == DBHIP_OK && e == hipSuccess; ++i) {
-    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_BATCH * sizeof(FaBlock), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_BATCH * sizeof(FaBlock));
+    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_BATCH_MAX * sizeof(FaBlock), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_BATCH_MAX * sizeof(FaBlock));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pp->tab_ev[i], hipEventDisableTiming);
   }
   if (rc == DBHIP_OK && e == hipSuccess) rc = dbhip_groupby_reserve_merge_internal(g, pp->cap_rows);

@@ -307,7 +307,7 @@ template <int KW>
 __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, const uint64_t* head, int shift,
                                                         const uint64_t* pkeys, int64_t n, const uint8_t* cnt8,
                                                         const uint32_t* firstm, const uint32_t* tile_sum, const uint64_t* tile_off, uint32_t* out_p,
-                                                        uint32_t* out_b, int64_t max_pairs) {
+                                                        uint32_t* out_b, int64_t max_pairs, int G) {
   constexpr int ES = KW * 2;
   const int64_t ntiles = (n + JOIN_TILE - 1) / JOIN_TILE;
   const int lane = lane_id();
@@ -323,11 +323,13 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, con
   // Round 6: a wave takes 64 CONSECUTIVE tiles at a time — one coalesced load brings their 64 pair counts, a ballot names the tiles that
   // have pairs, and only those are visited (their row counts and output offset requested one tile ahead). Rounds 3-5 walked every tile
   // with a dependent load each: a selective join (TPC-H Q3's lineitem probe: 3 M pairs in 2.3 M tiles of 600 M rows) spent its emit
-  // pass — 0.8 ms — on tiles with nothing to emit.
+  // pass — 0.8 ms — on tiles with nothing to emit. G (1 .. 64, chosen by the host) = consecutive tiles per wave and step: 64 when there
+  // are tiles for every wave of the grid many times over, fewer for small probe blocks — a block of 196 tiles whose every row matches
+  // thousands of build rows must still spread over 196 waves, not sit on four.
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   (void)tstride;
-  for (int64_t tb = wave0 * 64; tb < ntiles; tb += (int64_t)gridDim.x * 4 * 64) {
-    const uint32_t my_ts = tb + lane < ntiles ? tile_sum[tb + lane] : 0u;
+  for (int64_t tb = wave0 * G; tb < ntiles; tb += (int64_t)gridDim.x * 4 * G) {
+    const uint32_t my_ts = (lane < G && tb + lane < ntiles) ? tile_sum[tb + lane] : 0u;
     uint64_t todo = __ballot(my_ts != 0);
     if (todo == 0) continue;
     int nxt = __ffsll((long long)todo) - 1;
@@ -383,15 +385,21 @@ __global__ __launch_bounds__(256) void join_emit_kernel(const uint64_t* ent, con
         bool eq = p[0] == k[0];
 #pragma unroll
         for (int w = 1; w < KW; ++w) eq = eq && p[w] == k[w];
-        if (eq) {
-          // insert build row e-1 keeping this probe row's segment ascending (segments are tiny)
-          uint32_t b = e - 1, j = m;
-          while (j > 0 && out_b[o + j - 1] > b) { out_b[o + j] = out_b[o + j - 1]; --j; }
-          out_b[o + j] = b;
+        if (eq && m < cr) {
+          // the chain runs from the newest build row to the oldest (rows are prepended): written back to front the segment comes out
+          // ascending, or nearly so (the build's atomics race within a wave) — the insertion pass below then moves almost nothing.
+          // (Rounds 1-5 inserted from the front: a probe row with 4,500 matches cost 10 M moves — a 50 k x 50 k join on 10 keys took 74 s.)
+          out_b[o + cr - 1 - m] = e - 1;
           out_p[o + m] = (uint32_t)i;
           ++m;
         }
         e = (uint32_t)p[KW];
+      }
+      for (uint32_t a = 1; a < cr; ++a) {   // keep this probe row's segment ascending by build row
+        const uint32_t b = out_b[o + a];
+        uint32_t j = a;
+        while (j > 0 && out_b[o + j - 1] > b) { out_b[o + j] = out_b[o + j - 1]; --j; }
+        out_b[o + j] = b;
       }
       o += cr;
     }
@@ -793,6 +801,8 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
   if (n == 0) return DBHIP_OK;
   const int64_t ntiles_p = ceil_div(n, JOIN_TILE);
   const int grid = (int)(ntiles_p < 4 * 4096 ? ceil_div(ntiles_p, 4) : 4096);   // the emit pass walks tiles like the count pass
+  int G = 1;   // tiles per wave and step (join_emit_kernel)
+  while (G < 64 && (int64_t)grid * 4 * (G * 2) <= ntiles_p) G *= 2;
   uint64_t total = 0;
   int32_t rc;
   if (j->prepared && j->prep_keys == keys && j->prep_valid == validity && j->prep_n == n && j->prep_stream == s) {
@@ -811,13 +821,13 @@ int32_t dbhip_join_probe(dbhip_join* j, const void* keys, const uint8_t* validit
     DBHIP_REQUIRE(out_probe_idx && out_build_row, "dbhip_join_probe: NULL output");
     if (j->kw == 1)
       hipLaunchKernelGGL(join_emit_kernel<1>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
-                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs);
+                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs, G);
     else if (j->kw == 2)
       hipLaunchKernelGGL(join_emit_kernel<2>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
-                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs);
+                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs, G);
     else
       hipLaunchKernelGGL(join_emit_kernel<4>, dim3(grid), dim3(256), 0, s, j->ent, j->head, j->shift, (const uint64_t*)keys, n,
-                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs);
+                         j->cnt, j->firstm, j->tsum, j->off, out_probe_idx, out_build_row, max_pairs, G);
     DBHIP_LAUNCH_CHECK();
   }
   return DBHIP_OK;
