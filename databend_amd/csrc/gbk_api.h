@@ -328,6 +328,69 @@ int32_t dbhip_groupby_flush_block(dbhip_groupby* g, void* out_block_dev, int64_t
   return DBHIP_OK;  // nothing is read back: the header travels with the block
 }
 
+// the host half of dbhip_groupby_reset (the device half: slot hashes and the control block zeroed)
+static void reset_host_state(dbhip_groupby* g) {
+  g->count_host = 0;
+  g->has_long = 0;
+  g->fast_disabled = 0;
+  g->fast_trusted = 0;
+  g->lds_big = 0;
+  g->fagg_disabled = 0;
+  g->gbc_lcap = 0;
+  g->gbc_active = 0;
+  g->gbc_part_lcap_max = 0;
+  g->part_validate = 0; g->part_validated = 0;
+  if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
+  g->rows_seen = 0;
+}
+static int32_t ensure_xcur(dbhip_groupby* g);
+constexpr int GB_CTRL_XSTATUS = 12;   // ctrl[12..15): the queued exchange's verdict on the headers (words 0..9 and 10: see dbhip_groupby_create / pin_string_states)
+// ---- the queued form of merge_blocks / replace_with_blocks (no host round trip between the collective and the merge) ----
+// When the table has room for every row the blocks COULD hold (n_blocks x max_rows: the fixed-slot exchange of a low-cardinality
+// aggregation, 8 ranks x 256 rows against a 4,096-slot table), nothing needs to be known on the host before the merge is queued: the
+// headers are judged on the device by every kernel that needs them (the same words on every rank, so every rank takes the same
+// decision), an overflowed sender turns the merge — and the reset of replace_with_blocks — into no-ops through the DevCount pair, and
+// the host reads the outcome ONCE, after the last kernel: count, row flags and the verdict on the headers in one copy. Rounds 2-5
+// read the headers (a drain), then the merge's control block (a second drain).
+static int32_t blocks_queued(dbhip_groupby* g, const uint64_t* blocks, int32_t n_blocks, int64_t max_rows, int32_t skip, bool replace,
+                             const char* who, hipStream_t s) {
+  const int W = g->L.W;
+  const int64_t stride = (max_rows + 1) * W;
+  const int64_t ub = (int64_t)(n_blocks - (skip >= 0 && skip < n_blocks ? 1 : 0)) * max_rows;
+  if (ub == 0) return DBHIP_OK;
+  int32_t rc;
+  if ((rc = ensure_xcur(g))) return rc;
+  if ((rc = ensure((void**)&g->rows_in, &g->rows_in_cap, (size_t)ub * W * 8))) return rc;
+  if ((rc = ensure((void**)&g->gid, &g->gid_cap, (size_t)ub * 4))) return rc;      // (no allocation may fall between the launches below)
+  if ((rc = ensure((void**)&g->retry, &g->retry_cap, (size_t)ub * 4))) return rc;
+  uint64_t* host = pinned_words(0);
+  if (!host) return DBHIP_ERR_HIP;
+  uint64_t* xst = g->ctrl + GB_CTRL_XSTATUS;   // (inside the control block: the outcome is ONE copy)
+  if (replace)
+    hipLaunchKernelGGL(gb_reset_unless_off_kernel, dim3(grid_for(g->cap, 256, 256)), dim3(256), 0, s, blocks, stride, n_blocks, max_rows, g->slot_hash, g->cap, g->ctrl);
+  hipLaunchKernelGGL(gb_compact_blocks_kernel, dim3(n_blocks), dim3(256), 0, s, blocks, stride, W, skip, g->rows_in, xst, n_blocks, max_rows, replace ? 1 : 0);
+  DBHIP_LAUNCH_CHECK();
+  if ((rc = merge_rows_unpinned(g, g->rows_in, ub, s, xst, xst + 1, 2))) return rc;
+  DBHIP_CHECK(hipMemcpyAsync(host, g->ctrl, (GB_CTRL_XSTATUS + 3) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (host[GB_CTRL_XSTATUS + 1]) {   // the table was not touched
+    set_error("%s: block %d overflowed max_rows=%lld (exchange the rows with dbhip_groupby_flush_partitioned / flush_serialized + "
+              "merge_serialized instead)", who, (int)host[GB_CTRL_XSTATUS + 2] - 1, (long long)max_rows);
+    return DBHIP_ERR_CAPACITY;
+  }
+  if (replace) reset_host_state(g);
+  g->count_host = (int64_t)host[0];
+  if (host[3] & 2) {
+    set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
+    return DBHIP_ERR_UNSUPPORTED;
+  }
+  if (host[1]) {
+    set_error("groupby: collision chain filled the table during retry; create the table with a larger capacity");
+    return DBHIP_ERR_CAPACITY;
+  }
+  return host[GB_CTRL_XSTATUS] ? pin_string_states(g, s) : DBHIP_OK;
+}
+
 int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int32_t n_blocks, int64_t max_rows,
                                    int32_t skip_block, void* stream) {
   GB_DRAIN(g, resolve_stream(stream));
@@ -337,6 +400,9 @@ int32_t dbhip_groupby_merge_blocks(dbhip_groupby* g, const void* blocks_dev, int
   const int W = g->L.W;
   const int64_t stride = (max_rows + 1) * W;
   const uint64_t* blocks = (const uint64_t*)blocks_dev;
+  const bool only_own = n_blocks == 1 && skip_block == 0;   // (nothing to merge, but the own header still decides: the read-back form below)
+  if (!only_own && (g->count_host + (int64_t)n_blocks * max_rows) * 135 <= g->cap * 100)
+    return blocks_queued(g, blocks, n_blocks, max_rows, skip_block, false, "dbhip_groupby_merge_blocks", s);
   std::vector<uint64_t> head((size_t)n_blocks);
   DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 8, blocks, (size_t)stride * 8, 8, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
@@ -533,6 +599,7 @@ int32_t dbhip_groupby_flush_state_block(dbhip_groupby* g, void* const* out_keys_
 static int32_t ensure_xcur(dbhip_groupby* g) {
   if (g->xcur) return DBHIP_OK;
   DBHIP_CHECK(hipMalloc((void**)&g->xcur, (size_t)(2 * 4096 + 2) * 8));
+  g->xcur_dirty = 1;
   return DBHIP_OK;
 }
 
@@ -545,12 +612,14 @@ int32_t dbhip_groupby_partition_blocks(dbhip_groupby* g, int32_t n_buckets, void
   if (rc) return rc;
   const int W = g->L.W;
   const int64_t stride = (max_rows + 1) * W;
-  DBHIP_CHECK(hipMemsetAsync(g->xcur, 0, (size_t)n_buckets * 8, s));
+  // (the headers kernel leaves the cursors zeroed for the next call: one launch less per exchange)
+  if (g->xcur_dirty) DBHIP_CHECK(hipMemsetAsync(g->xcur, 0, (size_t)4096 * 8, s));
+  g->xcur_dirty = 0;
   hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid_for(g->cap, 256)), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap,
                      (uint32_t)n_buckets, max_rows, stride, (const uint64_t*)nullptr, (uint64_t*)out_blocks_dev,
                      (unsigned long long*)g->xcur);
   hipLaunchKernelGGL(gb_partition_headers_kernel, dim3(1), dim3(256), 0, s, (uint64_t*)out_blocks_dev, W, stride, max_rows,
-                     (uint32_t)n_buckets, (const unsigned long long*)g->xcur);
+                     (uint32_t)n_buckets, (unsigned long long*)g->xcur);
   DBHIP_LAUNCH_CHECK();
   return DBHIP_OK;  // nothing is read back: the headers travel with the blocks
 }
@@ -566,6 +635,7 @@ int32_t dbhip_groupby_flush_partitioned(dbhip_groupby* g, int32_t n_buckets, voi
   if (rc) return rc;
   uint64_t* cur = g->xcur;
   uint64_t* base = g->xcur + 4096;
+  g->xcur_dirty = 1;
   DBHIP_CHECK(hipMemsetAsync(cur, 0, (size_t)n_buckets * 8, s));
   const int grid = grid_for(g->cap, 256);
   hipLaunchKernelGGL(gb_partition_rows_kernel, dim3(grid), dim3(256), 0, s, g->L, g->slot_hash, g->rows, g->cap, (uint32_t)n_buckets,
@@ -599,6 +669,8 @@ int32_t dbhip_groupby_replace_with_blocks(dbhip_groupby* g, const void* blocks_d
   const int W = g->L.W;
   const int64_t stride = (max_rows + 1) * W;
   const uint64_t* blocks = (const uint64_t*)blocks_dev;
+  if ((int64_t)n_blocks * max_rows * 135 <= g->cap * 100 && !g->fa_pipe)
+    return blocks_queued(g, blocks, n_blocks, max_rows, -1, true, "dbhip_groupby_replace_with_blocks", s);
   std::vector<uint64_t> head((size_t)n_blocks * 2);
   DBHIP_CHECK(hipMemcpy2DAsync(head.data(), 16, blocks, (size_t)stride * 8, 16, (size_t)n_blocks, hipMemcpyDeviceToHost, s));
   DBHIP_CHECK(hipStreamSynchronize(s));
@@ -624,20 +696,15 @@ int32_t dbhip_groupby_reset(dbhip_groupby* g, void* stream) {
   DBHIP_REQUIRE(g, "dbhip_groupby_reset: NULL argument");
   hipStream_t s = resolve_stream(stream);
   if (g->fa_pipe) { const int32_t rc = dbhip_fagg_pipe_reset_internal(g->fa_pipe, s); if (rc) return rc; }   // queued blocks are dropped with the groups
-  DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)g->cap * 8, s));
-  DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 128, s));
-  g->count_host = 0;
-  g->has_long = 0;
-  g->fast_disabled = 0;
-  g->fast_trusted = 0;
-  g->lds_big = 0;
-  g->fagg_disabled = 0;
-  g->gbc_lcap = 0;
-  g->gbc_active = 0;
-  g->gbc_part_lcap_max = 0;
-  g->part_validate = 0; g->part_validated = 0;
-  if (g->part_min_rows > 1) g->part_bits = 0;  // (a forced partitioning — test hook — survives reset)
-  g->rows_seen = 0;
+  if (g->cap <= (1 << 20)) {   // one launch instead of two fills (a small table's reset is the host's cost per queued operation)
+    hipLaunchKernelGGL(gb_reset_unless_off_kernel, dim3(grid_for(g->cap, 256, 256)), dim3(256), 0, s, (const uint64_t*)nullptr, (int64_t)0, 0, (int64_t)0,
+                       g->slot_hash, g->cap, g->ctrl);
+    DBHIP_LAUNCH_CHECK();
+  } else {
+    DBHIP_CHECK(hipMemsetAsync(g->slot_hash, 0, (size_t)g->cap * 8, s));
+    DBHIP_CHECK(hipMemsetAsync(g->ctrl, 0, 128, s));
+  }
+  reset_host_state(g);
   return DBHIP_OK;
 }
 

@@ -201,7 +201,7 @@ bool layout_has_wide_minmax(const GbLayout& L);
 
 // probe + accumulate + retry over rows_in[n] (device rows in table layout)
 int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s, const uint64_t* n_dev, const uint64_t* abort_dev,
-                            bool deferred = false);
+                            int deferred = 0);
 int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
                    const uint64_t* n_dev = nullptr, const uint64_t* abort_dev = nullptr) {
   int32_t rc = merge_rows_unpinned(g, rows_in, n, s, n_dev, abort_dev);
@@ -209,9 +209,11 @@ int32_t merge_rows(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStre
   return rc;
 }
 // `deferred` (the pipelined fused aggregation): the caller has made sure that the table cannot outgrow its load factor whatever the
-// rows hold; the three kernels are queued and NOTHING is read back — the table's count_host is stale until the caller's checkpoint
+// rows hold; the three kernels are queued and NOTHING is read back — the table's count_host is stale until the caller's checkpoint.
+// deferred == 2 (the queued partial-state exchange, gbk_api.h): the same, but the rows are other ranks' groups — any number of them —
+// so the accumulate kernel is chosen by the bound n as on the synchronous path, not pinned to the handful-of-groups kernel
 int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n, hipStream_t s,
-                            const uint64_t* n_dev, const uint64_t* abort_dev, bool deferred) {
+                            const uint64_t* n_dev, const uint64_t* abort_dev, int deferred) {
   if (n == 0) return DBHIP_OK;
   if (n > 0xFFFFFFF0LL) {
     set_error("groupby: more than 2^32 rows in one call");
@@ -228,6 +230,29 @@ int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n
   const DevCount dc{n_dev, abort_dev};
   // No growth possible even if every row were a new group: probe, accumulate and retry are queued back to back and
   // the host reads the control block ONCE (the small merges behind the fused kernels are all host round trips).
+  // (n is the caller's BOUND: one workgroup walks 256 rows per step at ~25 us a step — 2,048 partial rows behind dbhip_q1_fused took 240 us
+  //  this way against 70 us through the three kernels, r06 probe — so only merges of at most one step take it)
+  static const int64_t small_n = exp_env("DBHIP_GB_SMALL_MERGE") ? atoll(exp_env("DBHIP_GB_SMALL_MERGE")) : 256;
+  if ((deferred || (g->count_host + n) * 135 <= g->cap * 100) && n <= small_n) {
+    // one launch of one workgroup instead of a memset and three kernels (gb_merge_small_kernel: such a merge is bound by the host's cost per
+    // queued operation)
+    hipLaunchKernelGGL(gb_merge_small_kernel, dim3(1), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash, g->rows, g->cap, g->hash_mask, g->gid,
+                       g->retry, g->ctrl, dc, g->arena);
+    DBHIP_LAUNCH_CHECK();
+    if (deferred) return DBHIP_OK;
+    DBHIP_CHECK(hipMemcpyAsync(host_ctrl, g->ctrl, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+    g->count_host = (int64_t)host_ctrl[0];
+    if (host_ctrl[3] & 2) {
+      set_error("groupby: a string key longer than 12 bytes was met; keep the CPU operator for this block");
+      return DBHIP_ERR_UNSUPPORTED;
+    }
+    if (host_ctrl[1]) {
+      set_error("groupby: collision chain filled the table during retry; create the table with a larger capacity");
+      return DBHIP_ERR_CAPACITY;
+    }
+    return DBHIP_OK;
+  }
   if (deferred || (g->count_host + n) * 135 <= g->cap * 100) {
     DBHIP_CHECK(hipMemsetAsync(&g->ctrl[1], 0, 16, s));
     hipLaunchKernelGGL(gb_probe_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->slot_hash, g->rows, g->cap,
@@ -235,10 +260,10 @@ int32_t merge_rows_unpinned(dbhip_groupby* g, const uint64_t* rows_in, int64_t n
     // (the wave-combining kernel only where the table is known to hold a handful of groups: on an empty table the first
     // merge may bring 50 K groups, r02y: 0.11 ms there against 0.02 ms for the plain kernel)
     // (a Decimal128 min / max state is merged under a lock: always combine the rows of a wave first, one acquisition per wave and state)
-    if (deferred || (g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048 || layout_has_wide_minmax(g->L))
+    if (deferred == 1 || (!deferred && g->count_host > 0 && g->count_host <= 32 && n <= 65536) || n <= 2048 || layout_has_wide_minmax(g->L))
       // (deferred = the pipelined fused aggregation's window merge: a handful of groups, every wave's leader lane ends in atomics on the
       // SAME few rows — 256 waves cost 30 us of serialised atomics for 16 K partial rows; 16 workgroups walk them grid-stride instead)
-      hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(deferred && grid > 16 ? 16 : grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
+      hipLaunchKernelGGL(gb_accum_lowcard_kernel, dim3(deferred == 1 && grid > 16 ? 16 : grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry,
                          g->ctrl, dc, g->arena);
     else
       hipLaunchKernelGGL(gb_accum_kernel, dim3(grid), dim3(256), 0, s, g->L, cur_rows, cur_n, g->rows, g->gid, g->retry, g->ctrl, dc, g->arena);

@@ -300,10 +300,10 @@ __device__ __forceinline__ void write_group_keys(const GbLayout& L, const uint64
   }
 }
 
-__global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_t* rows_in, int64_t n,
-                                                       uint64_t* slot_hash, uint64_t* rows, int64_t cap,
-                                                       uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc, uint8_t* arena) {
-  n = dev_rows(dc, n);
+// (bodies as device functions: the three kernels below, and ONE single-workgroup kernel that runs them back to back for small merges)
+__device__ __forceinline__ void gb_probe_body(const GbLayout& L, const uint64_t* rows_in, int64_t n,
+                                              uint64_t* slot_hash, uint64_t* rows, int64_t cap,
+                                              uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, uint8_t* arena) {
   const uint64_t cmask = (uint64_t)cap - 1;
   // the number of NEW groups is added to ctrl[0] ONCE PER WORKGROUP, after its last row (one atomic per new group on that
   // single address serialises: 10 M new groups cost ~15 ms; one per wave and iteration was still 17 K atomics on one word for
@@ -353,6 +353,11 @@ __global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_
   __syncthreads();
   if (threadIdx.x == 0 && wg_new) atomicAdd((unsigned long long*)&ctrl[0], (unsigned long long)wg_new);
 }
+__global__ __launch_bounds__(256) void gb_probe_kernel(GbLayout L, const uint64_t* rows_in, int64_t n,
+                                                       uint64_t* slot_hash, uint64_t* rows, int64_t cap,
+                                                       uint64_t hash_mask, uint32_t* gid, uint64_t* ctrl, DevCount dc, uint8_t* arena) {
+  gb_probe_body(L, rows_in, dev_rows(dc, n), slot_hash, rows, cap, hash_mask, gid, ctrl, arena);
+}
 
 // ---------------------------------------------------------------------------
 // accumulate — direct atomics (many groups)
@@ -401,11 +406,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const uint64_t* rows_in,
-                                                               int64_t n, uint64_t* rows,
-                                                               const uint32_t* gid, uint32_t* retry,
-                                                               uint64_t* ctrl, DevCount dc, const uint8_t* arena) {
-  n = dev_rows(dc, n);
+__device__ __forceinline__ void gb_accum_lowcard_body(const GbLayout& L, const uint64_t* rows_in,
+                                                      int64_t n, uint64_t* rows,
+                                                      const uint32_t* gid, uint32_t* retry,
+                                                      uint64_t* ctrl, const uint8_t* arena) {
   const int64_t n_pad = (n + 63) & ~63LL;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -483,14 +487,19 @@ __global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const
     }
   }
 }
+__global__ __launch_bounds__(256) void gb_accum_lowcard_kernel(GbLayout L, const uint64_t* rows_in,
+                                                               int64_t n, uint64_t* rows,
+                                                               const uint32_t* gid, uint32_t* retry,
+                                                               uint64_t* ctrl, DevCount dc, const uint8_t* arena) {
+  gb_accum_lowcard_body(L, rows_in, dev_rows(dc, n), rows, gid, retry, ctrl, arena);
+}
 
 // ---------------------------------------------------------------------------
 // retry — serial continuation of the probe for true hash collisions
 // ---------------------------------------------------------------------------
-__global__ void gb_retry_kernel(GbLayout L, const uint64_t* rows_in, uint64_t* slot_hash, uint64_t* rows,
-                                int64_t cap, uint64_t hash_mask, const uint32_t* gid,
-                                const uint32_t* retry, uint64_t* ctrl, uint8_t* arena) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void gb_retry_body(const GbLayout& L, const uint64_t* rows_in, uint64_t* slot_hash, uint64_t* rows,
+                                              int64_t cap, uint64_t hash_mask, const uint32_t* gid,
+                                              const uint32_t* retry, uint64_t* ctrl, uint8_t* arena) {
   const uint64_t cmask = (uint64_t)cap - 1;
   const uint64_t nretry = ctrl[2];
   for (uint64_t t = 0; t < nretry; ++t) {
@@ -519,6 +528,33 @@ __global__ void gb_retry_kernel(GbLayout L, const uint64_t* rows_in, uint64_t* s
     }
     if (!done) ctrl[1] |= 2;  // table full inside retry: host grows and replays the leftovers
   }
+}
+__global__ void gb_retry_kernel(GbLayout L, const uint64_t* rows_in, uint64_t* slot_hash, uint64_t* rows,
+                                int64_t cap, uint64_t hash_mask, const uint32_t* gid,
+                                const uint32_t* retry, uint64_t* ctrl, uint8_t* arena) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  gb_retry_body(L, rows_in, slot_hash, rows, cap, hash_mask, gid, retry, ctrl, arena);
+}
+
+// Small merges (the partial rows behind a fused kernel, the blocks of a fixed-slot exchange: tens to a few thousand rows): the three
+// steps above in ONE launch of ONE workgroup, the per-merge control words cleared by the kernel itself. Such a merge is bound by what the
+// host pays per queued operation (~5 us each on this stack), not by the device: one launch where rounds 1-5 queued a memset and three
+// kernels. Between the steps: a device-scope fence and the workgroup barrier (the claimed rows' keys and identity states are plain
+// stores that the accumulate step compares against and adds to with atomics).
+__global__ __launch_bounds__(256) void gb_merge_small_kernel(GbLayout L, const uint64_t* rows_in, int64_t n, uint64_t* slot_hash, uint64_t* rows,
+                                                             int64_t cap, uint64_t hash_mask, uint32_t* gid, uint32_t* retry, uint64_t* ctrl,
+                                                             DevCount dc, uint8_t* arena) {
+  n = dev_rows(dc, n);
+  if (threadIdx.x < 2) ctrl[1 + threadIdx.x] = 0;   // overflow flags, retry count
+  __threadfence();
+  __syncthreads();
+  gb_probe_body(L, rows_in, n, slot_hash, rows, cap, hash_mask, gid, ctrl, arena);
+  __threadfence();
+  __syncthreads();
+  gb_accum_lowcard_body(L, rows_in, n, rows, gid, retry, ctrl, arena);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) gb_retry_body(L, rows_in, slot_hash, rows, cap, hash_mask, gid, retry, ctrl, arena);
 }
 
 // ---------------------------------------------------------------------------
@@ -600,10 +636,25 @@ __global__ __launch_bounds__(64) void gb_block_header_kernel(uint64_t* block, in
   if (t < W) block[t] = t == 0 ? ((int64_t)ctrl[4] > max_rows ? ~0ULL : ctrl[4]) : 0;
 }
 
-// one workgroup per source block: append its rows behind those of the earlier blocks (`skip` = the caller's own block)
+// one workgroup per source block: append its rows behind those of the earlier blocks (`skip` = the caller's own block).
+// `xst` (optional, the queued exchange): nothing was read back, so every workgroup judges ALL the headers itself (the same words on every rank)
+// — a sender that overflowed (`check_w1`: or says that one of its other blocks did) => nothing is copied; workgroup 0 leaves
+// xst[0] = the rows of all blocks, xst[1] = 1 if the exchange is off (the DevCount pair of the merge queued behind), xst[2] = the offending block + 1
 __global__ __launch_bounds__(256) void gb_compact_blocks_kernel(const uint64_t* __restrict__ blocks, int64_t stride_words, int W,
-                                                                int skip, uint64_t* __restrict__ out) {
+                                                                int skip, uint64_t* __restrict__ out, uint64_t* __restrict__ xst = nullptr,
+                                                                int n_blocks = 0, int64_t max_rows = 0, int check_w1 = 0) {
   const int b = blockIdx.x;
+  if (xst) {
+    uint64_t total = 0;
+    int bad = 0;
+    for (int p = 0; p < n_blocks; ++p) {
+      const uint64_t c = blocks[(int64_t)p * stride_words];
+      if (c == ~0ULL || (int64_t)c > max_rows || (check_w1 && blocks[(int64_t)p * stride_words + 1] != 0)) { if (!bad) bad = p + 1; }
+      else if (p != skip) total += c;
+    }
+    if (b == 0 && threadIdx.x == 0) { xst[0] = bad ? 0 : total; xst[1] = bad ? 1 : 0; xst[2] = (uint64_t)bad; }
+    if (bad) return;
+  }
   if (b == skip) return;
   const uint64_t cnt = blocks[(int64_t)b * stride_words];
   uint64_t off = 0;
@@ -612,6 +663,18 @@ __global__ __launch_bounds__(256) void gb_compact_blocks_kernel(const uint64_t* 
   const uint64_t* src = blocks + (int64_t)b * stride_words + W;
   uint64_t* dst = out + off * W;
   for (uint64_t i = threadIdx.x; i < cnt * (uint64_t)W; i += blockDim.x) dst[i] = src[i];
+}
+
+// the queued exchange's dbhip_groupby_reset: the table is emptied on the device unless the headers say that the exchange is off (then it
+// must stay as it was: the caller falls back to the variable-length path with its groups intact)
+__global__ __launch_bounds__(256) void gb_reset_unless_off_kernel(const uint64_t* __restrict__ blocks, int64_t stride_words, int n_blocks,
+                                                                  int64_t max_rows, uint64_t* __restrict__ slot_hash, int64_t cap, uint64_t* __restrict__ ctrl) {
+  for (int p = 0; p < n_blocks; ++p) {
+    const uint64_t c = blocks[(int64_t)p * stride_words];
+    if (c == ~0ULL || (int64_t)c > max_rows || blocks[(int64_t)p * stride_words + 1] != 0) return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) slot_hash[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 16) ctrl[threadIdx.x] = 0;
 }
 
 struct ResultPtrs {
@@ -798,7 +861,7 @@ __global__ __launch_bounds__(256) void gb_partition_rows_kernel(GbLayout L, cons
 // sender overflowed — every receiver of an all-to-all gets one block from every sender, so all ranks see the same
 // flags and take the variable-length path together
 __global__ __launch_bounds__(256) void gb_partition_headers_kernel(uint64_t* blocks, int W, int64_t stride_words, int64_t max_rows,
-                                                                   uint32_t n_buckets, const unsigned long long* cursor) {
+                                                                   uint32_t n_buckets, unsigned long long* cursor) {
   __shared__ int any;
   if (threadIdx.x == 0) any = 0;
   __syncthreads();
@@ -810,6 +873,7 @@ __global__ __launch_bounds__(256) void gb_partition_headers_kernel(uint64_t* blo
     for (int k = 0; k < W; ++k) h[k] = 0;
     h[0] = (int64_t)cursor[b] > max_rows ? ~0ULL : (uint64_t)cursor[b];
     h[1] = (uint64_t)any;
+    cursor[b] = 0;   // (this thread is the only reader of cursor[b] after the barrier above)
   }
 }
 

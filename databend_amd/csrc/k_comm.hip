@@ -444,8 +444,31 @@ static int32_t exchange_begin_impl(dbhip_comm* c, const dbhip_col* cols, int32_t
     rc = dbhip_alloc(bytes, &x->sdata[k]);
     if (rc == DBHIP_OK && cols[k].validity) rc = dbhip_alloc(bm_bytes, (void**)&x->svalid[k]);
   }
-  if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)W * 16, &x->counts_dev);
-  if (rc == DBHIP_OK)
+  bool any_string = false;
+  for (int k = 0; k < ncols; ++k) any_string |= cols[k].type == DBHIP_T_STRING;
+  if (rc == DBHIP_OK) rc = dbhip_alloc((size_t)(2 * W + 2) * 8, &x->counts_dev);
+  // Fixed-width columns only: the rows-per-destination histogram stays on the device, the all-to-all of the counts is
+  // posted from there BEFORE any column is scattered, and the host reads what it sends and what it will receive in ONE copy — the peers
+  // have this rank's counts while it is still scattering. (Rounds 3-5: histogram -> host -> scatter -> host -> device -> all-to-all -> host.)
+  // String columns add their byte counts to the message, known only after the scatter: they keep that order.
+  bool counts_done = false;
+  if (rc == DBHIP_OK && !any_string) {
+    uint64_t* d = (uint64_t*)x->counts_dev;          // [W] sent rows | [1] out-of-range indices | [W] received rows
+    std::vector<uint64_t> hc((size_t)2 * W + 1);
+    rc = dbhip_scatter_count_internal(dest_index, n, (uint32_t)W, d, s);
+    if (rc == DBHIP_OK) rc = alltoall_bytes(c, d, d + W + 1, 8, s);
+    if (rc == DBHIP_OK) rc = dbhip_memcpy_d2h(hc.data(), d, hc.size() * 8, stream);
+    if (rc == DBHIP_OK && hc[W]) {
+      set_error("dbhip_exchange_begin: %llu destination indices are not below the world size %d", (unsigned long long)hc[W], W);
+      rc = DBHIP_ERR_INVALID;
+    }
+    if (rc == DBHIP_OK) {
+      for (int p = 0; p < W; ++p) x->recv_start[p + 1] = x->recv_start[p] + (int64_t)hc[(size_t)W + 1 + p];
+      x->recv_total = x->recv_start[W];
+      rc = dbhip_scatter_columns_counted_internal(cols, ncols, dest_index, n, (uint32_t)W, x->sdata.data(), x->svalid.data(), x->send_start.data(), hc.data(), stream);
+      counts_done = true;
+    }
+  } else if (rc == DBHIP_OK)
     rc = dbhip_scatter_columns(cols, ncols, dest_index, n, (uint32_t)W, x->sdata.data(), x->svalid.data(), x->send_start.data(), stream);
   // String columns with data buffers: every destination's long strings packed back to back, the scattered views re-based onto their piece
   for (int k = 0; k < ncols && rc == DBHIP_OK; ++k) {
@@ -497,7 +520,7 @@ static int32_t exchange_begin_impl(dbhip_comm* c, const dbhip_col* cols, int32_t
     x->sbyte_start.push_back(bstart);
     x->rbyte_start.emplace_back(W + 1, 0);
   }
-  if (rc == DBHIP_OK) {
+  if (rc == DBHIP_OK && !counts_done) {
     // what every rank sends to every other — rows, then the long-string bytes of every String column — in ONE small all-to-all, read back
     // once (the receiver sizes its buffers from it)
     const size_t per = 1 + x->str_cols.size();

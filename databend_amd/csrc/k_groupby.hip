@@ -72,7 +72,8 @@ struct dbhip_groupby {
   uint64_t* spill_rows; size_t spill_rows_cap;
   uint8_t* arena; size_t arena_cap;        // bytes of the long (> 12 B) string keys of the groups; cursor = ctrl[8]
   int has_long;                            // a long string key was met: the LDS / partitioned paths decline, the row path runs
-  uint64_t* xcur;                          // exchange partitioning: cursor[4096] | base[4097]
+  uint64_t* xcur;                          // exchange partitioning: cursor[4096] | base[4097] | status of the queued exchange
+  int xcur_dirty;                          // the cursors are not known to be zero
   int fagg_disabled;                       // the fused few-groups kernel (k_fagg.hip) gave up on this table's keys / shape
   // compact-row kernels (gb_compact.h, round 4)
   int gbc_off;                             // test hook / fallback: never use them for this table
@@ -131,7 +132,7 @@ int32_t dbhip_groupby_reserve_merge_internal(dbhip_groupby* g, int64_t n) {
 // the pipelined fused aggregation (k_fagg.hip): merge with nothing read back (see merge_rows_unpinned)
 int32_t dbhip_groupby_merge_rows_deferred_internal(dbhip_groupby* g, const uint64_t* rows, int64_t n_max, const uint64_t* n_dev,
                                                    const uint64_t* abort_dev, hipStream_t s) {
-  return merge_rows_unpinned(g, rows, n_max, s, n_dev, abort_dev, true);
+  return merge_rows_unpinned(g, rows, n_max, s, n_dev, abort_dev, 1);
 }
 // drains the stream, reads the exact number of groups and grows the table until `extra` more groups cannot push it past its load factor
 int32_t dbhip_groupby_ensure_room_internal(dbhip_groupby* g, int64_t extra, hipStream_t s) {

@@ -316,6 +316,26 @@ int32_t dbhip_scatter_indices(const dbhip_col* keys, int32_t nkeys, int64_t n, u
 
 int32_t dbhip_scatter_columns(const dbhip_col* cols, int32_t ncols, const uint32_t* index, int64_t n, uint32_t scatter_size,
                               void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_row_starts_host, void* stream) {
+  return dbhip_scatter_columns_counted_internal(cols, ncols, index, n, scatter_size, out_data_host, out_validity_host, out_row_starts_host, nullptr, stream);
+}
+
+}  // extern "C"
+// rows per destination, left on the device: counts_dev[scatter_size] + one counter of indices that are not below scatter_size
+// (k_comm.hip posts the exchange of the counts from here, before any column is scattered)
+int32_t dbhip_scatter_count_internal(const uint32_t* index, int64_t n, uint32_t scatter_size, uint64_t* counts_dev, hipStream_t s) {
+  DBHIP_REQUIRE(n >= 0 && n < 0xFFFFFFFFLL && scatter_size >= 1 && scatter_size <= (1u << 24) && counts_dev && (index || n == 0), "dbhip_exchange_begin: bad argument");
+  DBHIP_CHECK(hipMemsetAsync(counts_dev, 0, (size_t)(scatter_size + 1) * 8, s));
+  if (n > 0) {
+    hipLaunchKernelGGL(sc_hist_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, index, n, scatter_size, (unsigned long long*)counts_dev,
+                       (unsigned long long*)counts_dev + scatter_size);
+    DBHIP_LAUNCH_CHECK();
+  }
+  return DBHIP_OK;
+}
+// `known_counts_host` (scatter_size + 1 words of dbhip_scatter_count_internal, already read back by the caller): no histogram, no drain here
+int32_t dbhip_scatter_columns_counted_internal(const dbhip_col* cols, int32_t ncols, const uint32_t* index, int64_t n, uint32_t scatter_size,
+                                               void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_row_starts_host,
+                                               const uint64_t* known_counts_host, void* stream) {
   DBHIP_REQUIRE(ncols >= 0 && n >= 0 && n < 0xFFFFFFFFLL && scatter_size >= 1 && scatter_size <= (1u << 24), "dbhip_scatter_columns: bad argument");
   DBHIP_REQUIRE(out_row_starts_host && (ncols == 0 || (cols && out_data_host && out_validity_host)), "dbhip_scatter_columns: NULL argument");
   for (int c = 0; c < ncols; ++c) {
@@ -336,15 +356,16 @@ int32_t dbhip_scatter_columns(const dbhip_col* cols, int32_t ncols, const uint32
   if (!meta) return DBHIP_ERR_HIP;
   unsigned long long* counts = (unsigned long long*)meta;          // [scatter_size] + [1] out-of-range counter
   int64_t* row_start = (int64_t*)(meta + (size_t)(scatter_size + 1) * 8);   // [scatter_size + 1]
-  DBHIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(scatter_size + 1) * 8, s));
-  if (n > 0) {
-    DBHIP_REQUIRE(index, "dbhip_scatter_columns: NULL index");
-    hipLaunchKernelGGL(sc_hist_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, index, n, scatter_size, counts, counts + scatter_size);
-    DBHIP_LAUNCH_CHECK();
-  }
   std::vector<unsigned long long> hc((size_t)scatter_size + 1);
-  DBHIP_CHECK(hipMemcpyAsync(hc.data(), counts, hc.size() * 8, hipMemcpyDeviceToHost, s));
-  DBHIP_CHECK(hipStreamSynchronize(s));
+  if (known_counts_host) {
+    DBHIP_REQUIRE(n == 0 || index, "dbhip_scatter_columns: NULL index");
+    for (size_t d = 0; d < hc.size(); ++d) hc[d] = known_counts_host[d];
+  } else {
+    int32_t rc = dbhip_scatter_count_internal(index, n, scatter_size, (uint64_t*)counts, s);
+    if (rc) return rc;
+    DBHIP_CHECK(hipMemcpyAsync(hc.data(), counts, hc.size() * 8, hipMemcpyDeviceToHost, s));
+    DBHIP_CHECK(hipStreamSynchronize(s));
+  }
   if (hc[scatter_size]) {
     set_error("dbhip_scatter_columns: %llu indices are not below scatter_size %u", hc[scatter_size], scatter_size);
     return DBHIP_ERR_INVALID;
@@ -401,6 +422,7 @@ int32_t dbhip_scatter_columns(const dbhip_col* cols, int32_t ncols, const uint32
   DBHIP_CHECK(hipStreamSynchronize(s));  // scratch is reused by the next call
   return DBHIP_OK;
 }
+extern "C" {
 
 int32_t dbhip_concat_columns(const dbhip_col* cols, const int64_t* rows_host, const int64_t* bool_bit_offsets_host, int32_t nblocks,
                              void* out_data, uint8_t* out_validity, const void** out_buffers_dev, int32_t* out_n_buffers_host, void* stream) {

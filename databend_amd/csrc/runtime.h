@@ -76,6 +76,13 @@ inline int type_size(int32_t t) {
 
 }  // namespace dbhip
 
+// k_scatter.hip, for k_comm.hip's exchange: the rows-per-destination histogram left on the device (counts_dev[scatter_size + 1], the last word
+// counts indices that are out of range), and dbhip_scatter_columns given those counts already on the host (no histogram, no drain for them)
+int32_t dbhip_scatter_count_internal(const uint32_t* index, int64_t n, uint32_t scatter_size, uint64_t* counts_dev, hipStream_t s);
+int32_t dbhip_scatter_columns_counted_internal(const dbhip_col* cols, int32_t ncols, const uint32_t* index, int64_t n, uint32_t scatter_size,
+                                               void* const* out_data_host, uint8_t* const* out_validity_host, int64_t* out_row_starts_host,
+                                               const uint64_t* known_counts_host, void* stream);
+
 #define DBHIP_CHECK(expr)                                   \
   do {                                                      \
     hipError_t _e = (expr);                                 \

@@ -477,6 +477,57 @@ def test_fixed_block_exchange_refuses_tables_with_long_string_keys(gpu):
     assert sorted(recv.result()) == sorted(short_t.result())
 
 
+@pytest.mark.parametrize("card,nb,max_rows", [(6, 8, 256), (1500, 8, 256), (3000, 8, 256), (40, 3, 64)])
+def test_block_exchange_queued_and_read_back_forms_agree(gpu, card, nb, max_rows):
+    """a table with room for every row the blocks COULD hold (nb x max_rows) merges / is rebuilt with the headers judged
+    on the device and ONE read-back at the end (gbk_api.h blocks_queued); a table without that room reads the headers first (rounds 2-5).
+    Both forms: the same groups, the same refusal of an overflowed sender with the table left as it was, the same count on the host."""
+    rng = np.random.default_rng(card * nb)
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 0), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 0)]
+    n = 20_000
+    k = rng.integers(0, card, n).astype(np.int64)
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    src = gpu.GroupBy([T.T_I64], aggs)
+    src.add_block([gpu.Column.from_numpy(k)], [gpu.Column.from_numpy(a), None, gpu.Column.from_numpy(a)], n)
+    W = src.row_bytes() // 8
+    blocks = gpu.DeviceBuffer(nb * (max_rows + 1) * W * 8)
+    src.partition_blocks(blocks.ptr, nb, max_rows)
+    src.partition_blocks(blocks.ptr, nb, max_rows)     # twice: the cursors are left zeroed by the first call's header kernel
+    heads = blocks.to_numpy(np.uint64).reshape(nb, max_rows + 1, W)[:, 0, 0]
+    over = bool((heads == np.uint64((1 << 64) - 1)).any())
+    assert over == (card == 3000)
+    expect = sorted(src.result())
+    # some other content in the receiving tables: replace must drop it, merge must keep it
+    k2 = rng.integers(card, card + 17, 500).astype(np.int64)
+    a2 = rng.integers(-100, 100, 500).astype(np.int64)
+
+    def table(capacity):
+        g = gpu.GroupBy([T.T_I64], aggs, capacity=capacity)
+        g.add_block([gpu.Column.from_numpy(k2)], [gpu.Column.from_numpy(a2), None, gpu.Column.from_numpy(a2)], 500)
+        return g
+    own = sorted(table(1024).result())
+    for capacity in (1024, 1 << 16):                   # 1024 slots < nb x max_rows x 1.35: headers read first; 65,536: queued
+        for replace in (True, False):
+            g = table(capacity)
+            if over:
+                with pytest.raises(T.DbhipError) as e:
+                    g.replace_with_blocks(blocks.ptr, nb, max_rows) if replace else g.merge_blocks(blocks.ptr, nb, max_rows)
+                assert e.value.code == T.ERR_CAPACITY and "overflowed" in str(e.value)
+                assert sorted(g.result()) == own and g.num_groups() == len(own)
+            elif replace:
+                g.replace_with_blocks(blocks.ptr, nb, max_rows)
+                assert sorted(g.result()) == expect and g.num_groups() == len(expect)
+            else:
+                g.merge_blocks(blocks.ptr, nb, max_rows, skip_block=1)
+                got = blocks.to_numpy(np.uint64).reshape(nb, max_rows + 1, W)
+                skipped = {int(r[0]) for r in got[1, 1:1 + int(got[1, 0, 0])].view(np.int64)}
+                assert sorted(g.result()) == sorted(own + [r for r in expect if r[0] not in skipped])
+            # the table keeps working after either form
+            g.add_block([gpu.Column.from_numpy(k2)], [gpu.Column.from_numpy(a2), None, gpu.Column.from_numpy(a2)], 500)
+            g.destroy()
+    src.destroy()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # min / max over Decimal128 (r03): a three-word state merged under a per-state lock, row path only
 # ---------------------------------------------------------------------------------------------------------------
