@@ -64,10 +64,29 @@ struct FaArgs {
   int64_t n;
   uint64_t* partial_rows;             // [gridDim.x * 4 waves * SLOTS][W]
   uint64_t* ctrl;                     // [0] = #partial rows, [1] = flags (1: > SLOTS groups, 2: long string key)
-  const FaBlock* blocks;              // FA_MULTI kernels: the launch's blocks (device memory), gridDim.x = nblocks * wgs_per_block
+  const uint64_t* blocks;             // FA_MULTI kernels: the launch's packed block table (device memory, fa_blk_words(shape) words per block), gridDim.x = nblocks * wgs_per_block
   int32_t wgs_per_block, _pad;
 };
 static_assert(sizeof(FaArgs) <= 4000, "kernel arguments must stay below the 4 KB kernarg segment");
+
+// The block table of a FA_MULTI launch is PACKED by the query shape (host: fa_pack_block, k_fagg.hip; kernel: constant offsets): per block
+//   [n] [input ci: data (, validity, validity offset when the shape says the input has a Bitmap)]... [key q: likewise]... [(filter bits, offset)]
+// u64 words. TPC-H Q1 (7 inputs, nothing nullable): 8 words = 64 B per block against the 512-byte FaBlock — 128 blocks are 8 KB. That
+// matters beyond the bytes: a pinned-host -> device hipMemcpyAsync of 16 KB < size <= 64 KB BLOCKS the calling thread on this stack (158 us
+// per 32 KB copy on a busy stream against 4 us for 16 KB, tools/probes/h2d_small_copy.hip) — 64 FaBlocks per launch took the 8-thread
+// sweep from 43 to 3.8 G rows/s (r06).
+__host__ __device__ constexpr int fa_blk_in_off(const FaArgs& M, int ci) {
+  int o = 1;
+  for (int c = 0; c < ci; ++c) o += M.P.in_has_valid[c] ? 3 : 1;
+  return o;
+}
+__host__ __device__ constexpr int fa_blk_key_off(const FaArgs& M, int q) {
+  int o = fa_blk_in_off(M, M.P.n_inputs);
+  for (int k = 0; k < q; ++k) o += M.key_has_valid[k] ? 3 : 1;
+  return o;
+}
+__host__ __device__ constexpr int fa_blk_filter_off(const FaArgs& M) { return fa_blk_key_off(M, M.nkeys); }
+__host__ __device__ constexpr int fa_blk_words(const FaArgs& M) { return fa_blk_filter_off(M) + (M.has_filter ? 2 : 0); }
 
 #ifdef DBHIP_JIT
 // `static constexpr FaArgs kM = {...};` — this query's program / layout / per-word metadata (pointers and row counts null:
@@ -408,18 +427,18 @@ __device__ __forceinline__ void fagg_body(const FaArgs& A) {
   // this workgroup's block: its pointers come from the block table (uniform address, constant address space: scalar loads)
   const int wpb = A.wgs_per_block;
   const int blk = (int)blockIdx.x / wpb;
-  const __attribute__((address_space(4))) FaBlock* const B = (const __attribute__((address_space(4))) FaBlock*)(A.blocks + blk);
-  const int64_t blk_n = B->n;
+  const __attribute__((address_space(4))) uint64_t* const B = (const __attribute__((address_space(4))) uint64_t*)(A.blocks + (int64_t)blk * fa_blk_words(M));
+  const int64_t blk_n = (int64_t)B[0];
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((int)((((int64_t)blockIdx.x - (int64_t)blk * wpb) * blockDim.x + tid) >> 6));
   const int64_t nwaves = ((int64_t)wpb * blockDim.x) >> 6;
-#define FA_IN_DATA(ci) (B->in_data[ci])
-#define FA_IN_VALID(ci) (B->in_valid[ci])
-#define FA_IN_VOFF(ci) (B->in_voff[ci])
-#define FA_KEY_DATA(q) (B->key_data[q])
-#define FA_KEY_VALID(q) (B->key_valid[q])
-#define FA_KEY_VOFF(q) (B->key_voff[q])
-#define FA_FILTER_BITS (B->filter_bits)
-#define FA_FILTER_OFF (B->filter_off)
+#define FA_IN_DATA(ci) ((const void*)B[fa_blk_in_off(M, ci)])
+#define FA_IN_VALID(ci) ((const uint8_t*)B[fa_blk_in_off(M, ci) + 1])
+#define FA_IN_VOFF(ci) ((int64_t)B[fa_blk_in_off(M, ci) + 2])
+#define FA_KEY_DATA(q) ((const void*)B[fa_blk_key_off(M, q)])
+#define FA_KEY_VALID(q) ((const uint8_t*)B[fa_blk_key_off(M, q) + 1])
+#define FA_KEY_VOFF(q) ((int64_t)B[fa_blk_key_off(M, q) + 2])
+#define FA_FILTER_BITS ((const uint8_t*)B[fa_blk_filter_off(M)])
+#define FA_FILTER_OFF ((int64_t)B[fa_blk_filter_off(M) + 1])
 #else
   const int64_t blk_n = A.n;
   const int64_t wave_global = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + tid) >> 6));   // scalar

@@ -689,8 +689,10 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int FA_PIPE_WINDOW = 128;   // blocks per window (one merge; what one raised flag gives back)
-constexpr int FA_PIPE_BATCH = 32;     // blocks per multi-block launch
-constexpr int FA_PIPE_BATCH_MAX = 128; // what the block tables are sized for (DBHIP_FAGG_PIPE_BATCH sweeps up to it: experiments build)
+constexpr int FA_PIPE_BATCH = 128;    // blocks per multi-block launch (r06 sweep at 65,536-row blocks, one thread: 32 -> 25, 64 -> 33, 128 -> 40 G rows/s)
+constexpr int FA_PIPE_BATCH_MAX = 128; // (DBHIP_FAGG_PIPE_BATCH sweeps 2..128: experiments build)
+constexpr size_t FA_PIPE_TABLE_BYTES = 16384;   // one launch's packed block table: a pinned -> device hipMemcpyAsync above 16 KB blocks the
+                                                // calling thread on this stack (fagg_device.h, tools/probes/h2d_small_copy.hip); wide shapes get fewer blocks per launch
 constexpr int FA_PIPE_RING = 8;
 constexpr int64_t FA_PIPE_BIG = 8 << 20;          // a block of this many rows is a launch of its own
 constexpr int64_t FA_PIPE_BATCH_ROWS = 8 << 20;   // rows after which a batch goes without waiting for more blocks
@@ -721,8 +723,8 @@ struct FaPipe {
   std::vector<FaPending> batch;
   int64_t batch_rows = 0;
   std::vector<FaShape> shapes;       // shapes of the blocks since the last checkpoint (normally one)
-  FaBlock* tab_host[FA_PIPE_RING] = {};
-  FaBlock* tab_dev[FA_PIPE_RING] = {};
+  uint64_t* tab_host[FA_PIPE_RING] = {};
+  uint64_t* tab_dev[FA_PIPE_RING] = {};
   hipEvent_t tab_ev[FA_PIPE_RING] = {};
   bool tab_used[FA_PIPE_RING] = {};
   int tab_next = 0;
@@ -825,6 +827,22 @@ int32_t fa_pipe_submit(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStre
 
 // Launches the queued blocks together (see FaBlock). Needs the FA_MULTI specialisation of the shape: while that is being compiled
 // (or cannot be), the blocks go one launch each.
+// one block's pointers in the shape's packed layout (fagg_device.h: fa_blk_in_off / fa_blk_key_off / fa_blk_filter_off)
+void fa_pack_block(const FaArgs& M, const FaBlock& b, uint64_t* w) {
+  w[0] = (uint64_t)b.n;
+  for (int ci = 0; ci < M.P.n_inputs; ++ci) {
+    const int o = fa_blk_in_off(M, ci);
+    w[o] = (uint64_t)b.in_data[ci];
+    if (M.P.in_has_valid[ci]) { w[o + 1] = (uint64_t)b.in_valid[ci]; w[o + 2] = (uint64_t)b.in_voff[ci]; }
+  }
+  for (int q = 0; q < M.nkeys; ++q) {
+    const int o = fa_blk_key_off(M, q);
+    w[o] = (uint64_t)b.key_data[q];
+    if (M.key_has_valid[q]) { w[o + 1] = (uint64_t)b.key_valid[q]; w[o + 2] = (uint64_t)b.key_voff[q]; }
+  }
+  if (M.has_filter) { const int o = fa_blk_filter_off(M); w[o] = (uint64_t)b.filter_bits; w[o + 1] = (uint64_t)b.filter_off; }
+}
+
 int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
   if (pp->batch.empty()) return DBHIP_OK;
   std::vector<FaPending> blocks;
@@ -853,9 +871,10 @@ int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
   const int slot = pp->tab_next;
   pp->tab_next = (pp->tab_next + 1) % FA_PIPE_RING;
   if (pp->tab_used[slot]) DBHIP_CHECK(hipEventSynchronize(pp->tab_ev[slot]));   // the copy that last read this staging buffer has run
-  FaBlock* T = pp->tab_host[slot];
-  for (int i = 0; i < nb; ++i) T[i] = blocks[i].b;
-  DBHIP_CHECK(hipMemcpyAsync(pp->tab_dev[slot], T, (size_t)nb * sizeof(FaBlock), hipMemcpyHostToDevice, s));
+  uint64_t* T = pp->tab_host[slot];
+  const int bw = fa_blk_words(S.A);
+  for (int i = 0; i < nb; ++i) fa_pack_block(S.A, blocks[i].b, T + (size_t)i * bw);
+  DBHIP_CHECK(hipMemcpyAsync(pp->tab_dev[slot], T, (size_t)nb * bw * 8, hipMemcpyHostToDevice, s));
   DBHIP_CHECK(hipEventRecord(pp->tab_ev[slot], s));
   pp->tab_used[slot] = true;
   FaArgs A = S.A;
@@ -888,7 +907,8 @@ int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStr
   pp->batch.push_back(P);
   pp->batch_rows += P.b.n;
   static const int batch_n = [] { const char* e = exp_env("DBHIP_FAGG_PIPE_BATCH"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= FA_PIPE_BATCH_MAX ? v : FA_PIPE_BATCH; }();
-  if ((int)pp->batch.size() >= batch_n || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
+  const int fit = (int)(FA_PIPE_TABLE_BYTES / ((size_t)fa_blk_words(pp->shapes[(size_t)P.shape].A) * 8));   // >= 52: a block is at most 39 words
+  if ((int)pp->batch.size() >= (batch_n < fit ? batch_n : fit) || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
   return DBHIP_OK;
 }
 
@@ -1169,8 +1189,8 @@ int32_t dbhip_groupby_set_pipelined(dbhip_groupby* g, int32_t on, void* stream) 
   if (rc == DBHIP_OK && e == hipSuccess) { memset(pp->status_host, 0, 64); e = hipMemsetAsync(pp->ctrl, 0, 64, s); }
   if (rc == DBHIP_OK && e == hipSuccess) e = hipStreamSynchronize(s);
   for (int i = 0; i < FA_PIPE_RING && rc == DBHIP_OK && e == hipSuccess; ++i) {
-    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_BATCH_MAX * sizeof(FaBlock), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_BATCH_MAX * sizeof(FaBlock));
+    e = hipHostMalloc((void**)&pp->tab_host[i], FA_PIPE_TABLE_BYTES, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&pp->tab_dev[i], FA_PIPE_TABLE_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&pp->tab_ev[i], hipEventDisableTiming);
   }
   if (rc == DBHIP_OK && e == hipSuccess) rc = dbhip_groupby_reserve_merge_internal(g, pp->cap_rows);
