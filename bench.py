@@ -567,7 +567,7 @@ def bench_block_sizes(cpu):
     with tempfile.TemporaryDirectory() as td:
         outp = os.path.join(td, "sweep.json")
         try:
-            r = subprocess.run([exe, "--only-q1", "--rows", str(32 << 20), "--out", outp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            r = subprocess.run([exe, "--only-q1", "--rows", str(512 << 20), "--out", outp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
         except subprocess.TimeoutExpired:
             return {"skipped": "block_sweep timed out"}
         if r.returncode != 0 or not os.path.exists(outp):
@@ -579,7 +579,7 @@ def bench_block_sizes(cpu):
             "cpu_baseline_g_rows_per_s_at_65536_row_blocks": (cpu["value"] / 1e9 if cpu else None), "cpu_threads": (cpu["cores"] if cpu else None),
             "what": "rows/s of TPC-H Q1 (same program as the headline) when the table arrives as blocks of `block_rows` rows on `threads` host threads; "
                     "q1_sync = one synchronous dbhip_groupby_add_block_program per block, q1_pipelined = the same call on a pipelined table "
-                    "(blocks queued, 32 per launch, one checkpoint at the end)"}
+                    "(blocks queued, up to 512 / 32 Mi rows per launch, one checkpoint at the end; 512 Mi rows so that every one of 8 threads streams several launches)"}
 
 
 def cpu_baseline(args, li, n, tpch, result):

@@ -688,14 +688,18 @@ static int32_t fa_launch(const FaArgs& A, int slots, bool general, int nwords, i
 // replay possible. One stream per pipelined table (the reference's partial tables are per pipeline thread as well).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-constexpr int FA_PIPE_WINDOW = 128;   // blocks per window (one merge; what one raised flag gives back)
-constexpr int FA_PIPE_BATCH = 128;    // blocks per multi-block launch (r06 sweep at 65,536-row blocks, one thread: 32 -> 25, 64 -> 33, 128 -> 40 G rows/s)
-constexpr int FA_PIPE_BATCH_MAX = 128; // (DBHIP_FAGG_PIPE_BATCH sweeps 2..128: experiments build)
-constexpr size_t FA_PIPE_TABLE_BYTES = 16384;   // one launch's packed block table: a pinned -> device hipMemcpyAsync above 16 KB blocks the
-                                                // calling thread on this stack (fagg_device.h, tools/probes/h2d_small_copy.hip); wide shapes get fewer blocks per launch
+constexpr int FA_PIPE_WINDOW = 2048;  // blocks per window at most (one merge; what one raised flag gives back). r06: 128 = one merge chain (five
+                                      // dependent small kernels, ~30 us) behind EVERY 128-block launch; a window also closes when its launches could
+                                      // fill the row buffer (16 launches of the full grid)
+constexpr int FA_PIPE_BATCH = 512;    // blocks per multi-block launch (r06 sweeps at 65,536-row blocks, one thread: 32 -> 25, 64 -> 33, 128 -> 40-43 G rows/s;
+                                      // a launch costs ~40 us whatever it holds: 8 Mi rows per launch stream at 54 G rows/s, 32 Mi at 70+)
+constexpr int FA_PIPE_BATCH_MAX = 512; // (DBHIP_FAGG_PIPE_BATCH sweeps 2..512: experiments build)
+constexpr size_t FA_PIPE_COPY_BYTES = 16384;    // a pinned -> device hipMemcpyAsync above 16 KB blocks the calling thread on this stack (fagg_device.h,
+                                                // tools/probes/h2d_small_copy.hip): a launch's packed block table is uploaded in pieces of this size
+constexpr size_t FA_PIPE_TABLE_BYTES = 65536;   // one launch's packed block table (512 blocks of 16 words; wide shapes get fewer blocks per launch)
 constexpr int FA_PIPE_RING = 8;
 constexpr int64_t FA_PIPE_BIG = 8 << 20;          // a block of this many rows is a launch of its own
-constexpr int64_t FA_PIPE_BATCH_ROWS = 8 << 20;   // rows after which a batch goes without waiting for more blocks
+constexpr int64_t FA_PIPE_BATCH_ROWS = 32 << 20;  // rows after which a batch goes without waiting for more blocks
 // A query shape as the pipeline keeps it: the compiled launch arguments with every per-block pointer null, and the bytes the shape
 // was recognised by (`sig`: program, column types / scalar-ness / validity-ness, argument registers). A block is then 328 bytes: its
 // pointers and its shape's index — the per-call host work of a pipelined table is one signature compare and one FaBlock fill
@@ -874,7 +878,9 @@ int32_t fa_pipe_flush_batch(dbhip_groupby* g, FaPipe* pp) {
   uint64_t* T = pp->tab_host[slot];
   const int bw = fa_blk_words(S.A);
   for (int i = 0; i < nb; ++i) fa_pack_block(S.A, blocks[i].b, T + (size_t)i * bw);
-  DBHIP_CHECK(hipMemcpyAsync(pp->tab_dev[slot], T, (size_t)nb * bw * 8, hipMemcpyHostToDevice, s));
+  for (size_t at = 0, all = (size_t)nb * bw * 8; at < all; at += FA_PIPE_COPY_BYTES)
+    DBHIP_CHECK(hipMemcpyAsync((uint8_t*)pp->tab_dev[slot] + at, (const uint8_t*)T + at, all - at < FA_PIPE_COPY_BYTES ? all - at : FA_PIPE_COPY_BYTES,
+                               hipMemcpyHostToDevice, s));
   DBHIP_CHECK(hipEventRecord(pp->tab_ev[slot], s));
   pp->tab_used[slot] = true;
   FaArgs A = S.A;
@@ -907,7 +913,7 @@ int32_t fa_pipe_enqueue(dbhip_groupby* g, FaPipe* pp, const FaPending& P, hipStr
   pp->batch.push_back(P);
   pp->batch_rows += P.b.n;
   static const int batch_n = [] { const char* e = exp_env("DBHIP_FAGG_PIPE_BATCH"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= FA_PIPE_BATCH_MAX ? v : FA_PIPE_BATCH; }();
-  const int fit = (int)(FA_PIPE_TABLE_BYTES / ((size_t)fa_blk_words(pp->shapes[(size_t)P.shape].A) * 8));   // >= 52: a block is at most 39 words
+  const int fit = (int)(FA_PIPE_TABLE_BYTES / ((size_t)fa_blk_words(pp->shapes[(size_t)P.shape].A) * 8));   // >= 210: a block is at most 39 words
   if ((int)pp->batch.size() >= (batch_n < fit ? batch_n : fit) || pp->batch_rows >= FA_PIPE_BATCH_ROWS) return fa_pipe_flush_batch(g, pp);
   return DBHIP_OK;
 }

@@ -136,7 +136,7 @@ def test_a_block_with_too_many_groups_is_given_back_with_the_blocks_behind_it(gp
     blocks, and the caller hands blocks [committed, queued) to the operator-at-a-time path (here: plain add_block)."""
     D = gpu
     rng = np.random.default_rng(5)
-    n, nb, bad = 20_000, 300, 200
+    n, nb, bad = 3_000, 4500, 4200
     g = D.GroupBy([T.T_I64], AGGS)
     g.set_pipelined(True)
     ck, cx, p, regs, f = _small_program(D, np.zeros(1, np.int64), np.zeros(1, np.int64))
@@ -151,7 +151,7 @@ def test_a_block_with_too_many_groups_is_given_back_with_the_blocks_behind_it(gp
         ks.append(k), xs.append(x)
     rc, committed = g.checkpoint(raise_on_error=False)
     assert rc == T.ERR_CAPACITY
-    assert committed == 128              # whole windows (128 blocks each) before the offending block's window
+    assert committed == 4096             # whole windows (2,048 blocks each) before the offending block's window
     assert b"were not merged" in lib().dbhip_last_error()
     assert sorted(g.result()) == _expected(np.concatenate(ks[:committed]), np.concatenate(xs[:committed]))
     # the caller's fallback for the rest: the operator-at-a-time path on the same (still pipelined) table
