@@ -284,3 +284,68 @@ def test_plain_add_block_queues_on_a_pipelined_table(gpu):
     g2.add_block([ck], [cx, None], n)
     assert g2.checkpoint() == 0
     assert sorted(g2.result()) == _expected(np.concatenate([k, k]), np.concatenate([x, x]))
+
+
+def test_multi_block_launches_carry_nullable_keys_arguments_and_filters(gpu):
+    """The block table of a multi-block launch is packed by the query shape (fagg_device.h fa_blk_in_off / fa_blk_key_off /
+    fa_blk_filter_off: validity pointers and offsets only where the shape has a Bitmap, the filter last). A shape that uses every part of
+    the layout — nullable key, nullable arguments, a pushed-down filter on every block — queued as 40 blocks of one launch must equal
+    the synchronous table fed the same blocks, and numpy."""
+    import time
+    D = gpu
+    rng = np.random.default_rng(77)
+    aggs = [(T.AGG_SUM, T.T_I64, 0, 0, 1), (T.AGG_COUNT, 0, 0, 0, 0), (T.AGG_MIN, T.T_I64, 0, 0, 1)]
+    n, nb = 30_000, 40
+
+    def table(pipelined):
+        g = D.GroupBy([T.T_I64], aggs, [1])
+        if pipelined:
+            g.set_pipelined(True)
+        return g
+
+    def block():
+        k = rng.integers(0, 3, n).astype(np.int64) * 7 - 7
+        kv = rng.random(n) < 0.9
+        x = rng.integers(-10**9, 10**9, n).astype(np.int64)
+        xv = rng.random(n) < 0.8
+        f = rng.random(n) < 0.6
+        cols = (D.Column.from_numpy(k, validity=kv), D.Column.from_numpy(x, validity=xv), D.Column.boolean(f))
+        return (k, kv, x, xv, f), cols
+
+    def launches():
+        out = (C.c_uint64 * 3)()
+        check(lib().dbhip_fagg_stats(out))
+        return out[0]
+
+    # the multi-block kernel of this shape is compiled in the background on first sight: wait until two queued blocks take ONE launch
+    warm = table(True)
+    _, (ck, cx, fb) = block()
+    for _ in range(240):
+        before = launches()
+        warm.add_block([ck], [cx, None, cx], n, filter=fb)
+        warm.add_block([ck], [cx, None, cx], n, filter=fb)
+        warm.checkpoint()
+        if launches() - before == 1:
+            break
+        time.sleep(0.5)
+    else:
+        pytest.fail("the multi-block specialisation never arrived")
+    pipe, sync = table(True), table(False)
+    data, keep = [], []
+    before = launches()
+    for _ in range(nb):
+        d, (ck, cx, fb) = block()
+        pipe.add_block([ck], [cx, None, cx], n, filter=fb)
+        data.append(d), keep.append((ck, cx, fb))
+    assert pipe.checkpoint() == nb
+    assert launches() - before == 1                      # 40 blocks, one launch
+    for ck, cx, fb in keep:
+        sync.add_block([ck], [cx, None, cx], n, filter=fb)
+    got = sorted(pipe.result(), key=repr)
+    assert got == sorted(sync.result(), key=repr) and len(got) == 4          # -7, 0, 7 and the NULL key
+    K, KV, X, XV, F = (np.concatenate([d[i] for d in data]) for i in range(5))
+    assert sum(r[2] for r in got) == int(F.sum())                             # count(*) over the rows the filter keeps
+    assert sum(r[1] for r in got if r[1] is not None) == int(X[F & XV].sum())
+    for r in got:
+        sel = F & (~KV if r[0] is None else (KV & (K == r[0])))
+        assert r[2] == int(sel.sum()) and r[1] == int(X[sel & XV].sum()) and r[3] == int(X[sel & XV].min())
