@@ -41,6 +41,46 @@ def test_inner_join_pairs_match_oracle(gpu, oracle, nb, np_, card):
         assert (bk[gb] == pk[gp]).all() and bvalid[gb].all() and pvalid[gp].all()
 
 
+@pytest.mark.parametrize("shape", ["dense", "dense_offset", "wide"])
+def test_inner_join_large_tables_behind_the_occupancy_filter(gpu, oracle, shape):
+    """Tables of >= 2^19 build rows filter the probe side before a head sector is fetched (one bit per bucket, dbhip_join_finalize; the
+    smaller parity cases never build it). Against the oracle's hash join: sparse ids in a bounded span (TPC-H's order keys), the same far
+    from zero, and keys all over the u64 range; duplicate build keys, NULLs on both sides, probe keys below the smallest / above the
+    largest build key and in the gaps."""
+    rng = np.random.default_rng(len(shape))
+    nb, np_ = 600_000, 1_500_000
+    if shape == "wide":
+        universe = rng.integers(0, 2**63, 400_000, dtype=np.uint64)                      # span >> 64 bits per build row
+        bk = universe[rng.integers(0, len(universe), nb)]
+        pk = np.where(rng.random(np_) < 0.5, universe[rng.integers(0, len(universe), np_)], rng.integers(0, 2**63, np_, dtype=np.uint64))
+    else:
+        base = np.uint64(0) if shape == "dense" else np.uint64(2**40 + 12345)
+        bk = base + np.uint64(1000) + rng.integers(0, 3_000_000, nb).astype(np.uint64) * np.uint64(4)   # sparse ids (TPC-H orderkeys), duplicates
+        pk = base + rng.integers(0, 12_008_000, np_).astype(np.uint64)                                    # below, inside (gaps too), above
+    bvalid = rng.random(nb) < 0.95
+    pvalid = rng.random(np_) < 0.9
+    j = gpu.HashJoin(nb)
+    for lo in range(0, nb, 250_000):
+        hi = min(nb, lo + 250_000)
+        j.add_block(gpu.Column.from_numpy(bk[lo:hi], validity=bvalid[lo:hi]))
+    j.final_build()
+    gp, gb = j.probe_block(gpu.Column.from_numpy(pk, validity=pvalid))
+    cap = len(gp) + 16
+    ep, eb = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    bv = np.concatenate([np.packbits(bvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    pv = np.concatenate([np.packbits(pvalid, bitorder="little"), np.zeros(8, np.uint8)])
+    total = oracle.orc_join_inner_u64(bk.ctypes.data_as(C.c_void_p), bv.ctypes.data_as(C.c_void_p), C.c_int64(nb), pk.ctypes.data_as(C.c_void_p),
+                                      pv.ctypes.data_as(C.c_void_p), C.c_int64(np_), ep.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+    assert total == len(gp) and total > 10_000
+    assert np.array_equal(gp, ep[:total]) and np.array_equal(gb, eb[:total])
+    assert (bk[gb] == pk[gp]).all() and bvalid[gb].all() and pvalid[gp].all()
+    # the mark form agrees
+    marks = j.probe_mark(gpu.Column.from_numpy(pk, validity=pvalid))
+    exp = np.zeros(np_, bool)
+    exp[gp] = True
+    assert np.array_equal(marks, exp)
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 1000, 100_003])
 def test_pack_keys_matches_oracle(gpu, oracle, n):
     """dbhip_pack_keys == KeysVec byte layout (method_fixed_keys.rs:310-403) for mixed widths, nullable columns,
