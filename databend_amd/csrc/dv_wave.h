@@ -138,6 +138,9 @@ struct ZWave {
   __device__ __forceinline__ uint64_t* mlt() const { return (uint64_t*)(tab + 8192); }
   __device__ __forceinline__ uint32_t* oft() const { return (uint32_t*)(tab + 12288); }
   __device__ __forceinline__ uint8_t* scr() const { return tab + 13312; }
+  // parking slots (zstd_core.h decode_frames): stored by lane 0, read back by the wave; volatile so that the value is really re-loaded
+  __device__ __forceinline__ void park(uint32_t i, uint32_t v) const { if (lane == 0) ((volatile uint32_t*)(scr() + zc::SCR_PARK))[i] = v; }
+  __device__ __forceinline__ uint32_t unpark(uint32_t i) const { return rfl(((volatile uint32_t*)(scr() + zc::SCR_PARK))[i]); }
   __device__ __forceinline__ uint32_t op() const { return op_; }
   __device__ __forceinline__ uint32_t cap() const { return cap_; }
   __device__ __forceinline__ void frame_begin() { frame0 = op_; }
@@ -295,6 +298,12 @@ struct ZWave {
     }
     return put_lit(ll) && put_match(off, ml);
   }
+  // one sequence of a ZSTD block (zstd_core.h): ll literals (possibly none), then ml bytes from `off` back
+  __device__ __forceinline__ bool seq(uint32_t ll, uint32_t off, uint32_t ml) { return ll ? put_seq(ll, off, ml) : put_match(off, ml); }
+  __device__ __forceinline__ uint32_t lit_rest() const { return lit_left; }
+  __device__ __forceinline__ int sequences(uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0, uint32_t& r1, uint32_t& r2) {
+    return zc::seq_loop(*this, p, len, nseq, als, r0, r1, r2);
+  }
   __device__ __forceinline__ bool put_lit(uint32_t len) {
     if (len > lit_left || len > cap_ - op_) return false;
     lit_left -= len;
@@ -416,8 +425,12 @@ struct ZWave {
 // One rendezvous per block: Huffman literals are decoded into the TAIL of the page's output region, where the previous block's
 // literals may still be waiting to be consumed, so the producer lets the queue drain before it writes them.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t ZW_RING = 8192;                          // ZSTD: ring bytes
+constexpr uint32_t ZW_TABLES = 13312 + zc::SCR_BYTES;       // Huffman 4 KiB + LL 4 KiB + ML 4 KiB + OF 1 KiB + scratch
+constexpr uint32_t ZW_LDS = ZW_RING + ZW_TABLES;
 constexpr uint32_t ZQ_CAP = 256;             // commands in the queue (16 bytes each)
 constexpr uint32_t ZQ_BYTES = ZQ_CAP * 16 + 16;
+constexpr uint32_t ZW2_LDS = ZW_RING + ZW_TABLES + ZQ_BYTES;   // the two-wave kernel: + the command queue
 enum { ZC_SEQ = 0, ZC_LIT_BEGIN = 1, ZC_LIT = 2, ZC_IN = 3, ZC_FILL = 4, ZC_END = 5 };
 typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
 
@@ -433,15 +446,40 @@ struct ZQueue {
 };
 constexpr uint32_t ZQ_POLLS = 1u << 24;
 
+// The producer's sequence loop as a function of its own (round 6). The decoder is one inlined function whose outer loops keep ~65
+// loop-invariant scalars alive; inlined into it, the sequence loop had its own values — the bit register, the repeat offsets, the
+// sequence counter — spilled to VGPR lanes and read back every iteration (71 v_readlane / v_writelane in the loop). A function that is
+// NOT inlined gets an allocation of its own: the caller's scalars wait in callee-saved registers, which the function parks in VGPR
+// lanes once, at its entry. The state it needs crosses the call through the LDS scratch area of zstd_core.h, which only the table
+// builders use and which is idle while sequences are decoded: bytes [0, 1280) five per-lane words (the input window and the four
+// words of the collected commands), [1280, 1408) the scalars.
+__device__ __attribute__((noinline)) void zprod_sequences(uint32_t tab_lds);
+enum { ZH_SRC_LO = 0, ZH_SRC_HI, ZH_A0, ZH_SAFE, ZH_WLO, ZH_QN, ZH_QTAIL, ZH_OP, ZH_FRAME0, ZH_CAP, ZH_LIT_LEFT, ZH_VIOL, ZH_FAILED, ZH_R0, ZH_R1,
+       ZH_R2, ZH_P, ZH_LEN, ZH_NSEQ, ZH_ALS, ZH_RC, ZH_WORDS };
+static_assert(1280 + 4 * ZH_WORDS <= zc::SCR_PARK, "the hand-over block must fit the scratch area below the parking slots");
+
 struct ZProd : ZWave {
   ZQueue q;
   uint32_t qn;                 // commands collected in registers (uniform)
   uint32_t qtail;              // this side's copy of the tail
   uint32_t b0, b1, b2, b3;     // lane i: words of collected command i
+  // Sequences are validated BY THE BATCH (round 6): a sequence only adds to op_, takes from lit_left (kept signed) and ORs its reach
+  // test into `viol`; the batch of <= 64 collected commands is judged as a whole when it leaves for the queue — op_ <= cap_,
+  // lit_left >= 0, viol == 0 — and a batch that fails is dropped, so the consumer still never sees a command it cannot execute.
+  // (Everything is monotonic between two flushes: op_ grows by < 2^18 per sequence and cap_ < 2^31, lit_left starts below 2^17 and
+  // falls by < 2^17 per sequence, viol is sticky.) Per sequence that is 5 scalar instructions instead of five compares and branches.
+  uint32_t viol;
+  bool failed;                 // a batch was refused: every later call fails
 
-  __device__ __forceinline__ void qbegin(const ZQueue& Q) { q = Q; qn = 0; qtail = 0; b0 = b1 = b2 = b3 = 0; }
-  // the collected commands -> the queue (waits for room)
-  __device__ __forceinline__ void qflush() {
+  __device__ __forceinline__ void qbegin(const ZQueue& Q) { q = Q; qn = 0; qtail = 0; b0 = b1 = b2 = b3 = 0; viol = cap_ >> 31; failed = false; }
+  __device__ __forceinline__ bool batch_ok() const {   // (selects between integers: a bool turned into an integer leaves the scalar unit)
+    uint32_t bad = viol;
+    bad = op_ > cap_ ? 1u : bad;
+    bad = (int32_t)lit_left < 0 ? 1u : bad;
+    return bad == 0;
+  }
+  // the collected commands -> the queue (waits for room), unchecked
+  __device__ __forceinline__ void qsend() {
     if (qn == 0) return;
     for (uint32_t polls = 0; qtail + qn - q.head() > ZQ_CAP; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
@@ -452,6 +490,10 @@ struct ZProd : ZWave {
     qtail = rfl(qtail + qn);
     qn = 0;
     __hip_atomic_store(&q.ctl[0], qtail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void qflush() {
+    if (!batch_ok()) { failed = true; qn = 0; return; }
+    qsend();
   }
   __device__ __forceinline__ void push(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
     // (one compare + four selects: this clang has no writelane builtin. r05: writing each command to the queue at once — lane 0, one
@@ -465,6 +507,7 @@ struct ZProd : ZWave {
   // every queued command has been executed
   __device__ __forceinline__ void drain() {
     qflush();
+    if (failed) return;
     for (uint32_t polls = 0; q.head() != qtail; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
       if (q.dead()) return;
@@ -474,51 +517,114 @@ struct ZProd : ZWave {
 
   // ---- the output half of the interface zstd_core.h expects: validate against the producer's own position, queue, count
   __device__ __forceinline__ void lit_begin(uint32_t kind, uint32_t pos, uint32_t n) {
+    viol = (int32_t)lit_left < 0 ? 1u : viol;   // (the block before this one took more literals than it had)
     lit_left = n;
     push(ZC_LIT_BEGIN | (kind << 8), pos, 0, n);
   }
-  __device__ __forceinline__ bool put_seq(uint32_t ll, uint32_t off, uint32_t ml) {
-    if (ll > lit_left || ml > cap_ - op_ || ll > cap_ - op_ - ml || off == 0 || off > op_ - frame0 + ll) return false;
+  // a sequence: command words (ll, ml, off != 0); the consumer ignores the fourth word of a lane that holds one
+  __device__ __forceinline__ bool seq(uint32_t ll, uint32_t off, uint32_t ml) {
+    // off == 0 or off > bytes of this frame written so far + ll  <=>  off - 1 >= that sum (unsigned)
+    viol = (off - 1u >= op_ - frame0 + ll) ? 1u : viol;
     lit_left -= ll;
-    push(ll, ml, off, 0);
-    op_ = rfl(op_ + ll + ml);
-    return true;
+    const bool mine = lane == qn;
+    b0 = mine ? ll : b0; b1 = mine ? ml : b1; b2 = mine ? off : b2;
+    op_ += ll + ml;
+    qn += 1;
+    if (qn == 64) qflush();
+    return !failed;
   }
-  __device__ __forceinline__ bool put_match(uint32_t off, uint32_t ml) {
-    if (off == 0 || off > op_ - frame0 || ml > cap_ - op_) return false;
-    push(0, ml, off, 0);
-    op_ = rfl(op_ + ml);
-    return true;
+  // ---- the hand-over (see zprod_sequences)
+  __device__ __forceinline__ uint32_t* hot_words() const { return (uint32_t*)(scr() + 1280); }
+  __device__ __forceinline__ void hot_put_lanes() const {
+    uint32_t* L = (uint32_t*)scr();
+    L[lane] = la; L[64 + lane] = b0; L[128 + lane] = b1; L[192 + lane] = b2; L[256 + lane] = b3;
+  }
+  __device__ __forceinline__ void hot_get_lanes() {
+    const uint32_t* L = (const uint32_t*)scr();
+    la = L[lane]; b0 = L[64 + lane]; b1 = L[128 + lane]; b2 = L[192 + lane]; b3 = L[256 + lane];
+  }
+  // what the sequence loop changes: written by one side of the call, read by the other
+  __device__ __forceinline__ void hot_put_state() const {
+    uint32_t* H = hot_words();
+    if (lane == 0) {
+      H[ZH_WLO] = wlo; H[ZH_QN] = qn; H[ZH_QTAIL] = qtail; H[ZH_OP] = op_; H[ZH_LIT_LEFT] = lit_left; H[ZH_VIOL] = viol;
+      H[ZH_FAILED] = failed ? 1u : 0u;
+    }
+    hot_put_lanes();
+  }
+  __device__ __forceinline__ void hot_get_state() {
+    const uint32_t* H = hot_words();
+    wlo = rfl(H[ZH_WLO]); qn = rfl(H[ZH_QN]); qtail = rfl(H[ZH_QTAIL]); op_ = rfl(H[ZH_OP]); lit_left = rfl(H[ZH_LIT_LEFT]);
+    viol = rfl(H[ZH_VIOL]); failed = rfl(H[ZH_FAILED]) != 0;
+    hot_get_lanes();
+  }
+  __device__ __forceinline__ int sequences(uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0, uint32_t& r1, uint32_t& r2) {
+    uint32_t* H = hot_words();
+    if (lane == 0) {
+      H[ZH_SRC_LO] = (uint32_t)(uintptr_t)srcA; H[ZH_SRC_HI] = (uint32_t)((uintptr_t)srcA >> 32); H[ZH_A0] = a0; H[ZH_SAFE] = safeA;
+      H[ZH_FRAME0] = frame0; H[ZH_CAP] = cap_; H[ZH_R0] = r0; H[ZH_R1] = r1; H[ZH_R2] = r2;
+      H[ZH_P] = p; H[ZH_LEN] = len; H[ZH_NSEQ] = nseq; H[ZH_ALS] = als;
+    }
+    hot_put_state();
+    zprod_sequences((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)tab);
+    hot_get_state();
+    r0 = rfl(H[ZH_R0]); r1 = rfl(H[ZH_R1]); r2 = rfl(H[ZH_R2]);
+    return (int)rfl(H[ZH_RC]);
+  }
+  __device__ __forceinline__ uint32_t lit_rest() {
+    viol = (int32_t)lit_left < 0 ? 1u : viol;
+    return (int32_t)lit_left < 0 ? 0u : lit_left;
   }
   __device__ __forceinline__ bool put_lit(uint32_t len) {
-    if (len > lit_left || len > cap_ - op_) return false;
+    if (failed || (lit_left >> 31) || len > lit_left || op_ > cap_ || len > cap_ - op_) return false;
     lit_left -= len;
     push(ZC_LIT, len, 0, 0);
     op_ = rfl(op_ + len);
-    return true;
+    return !failed;
   }
   __device__ __forceinline__ bool put_in(uint32_t pos, uint32_t len) {
-    if (len > cap_ - op_ || pos > in_len || len > in_len - pos) return false;
+    if (failed || op_ > cap_ || len > cap_ - op_ || pos > in_len || len > in_len - pos) return false;
     push(ZC_IN, pos, 0, len);
     op_ = rfl(op_ + len);
-    return true;
+    return !failed;
   }
   __device__ __forceinline__ bool put_fill(uint32_t byte, uint32_t len) {
-    if (len > cap_ - op_) return false;
+    if (failed || op_ > cap_ || len > cap_ - op_) return false;
     push(ZC_FILL, byte, 0, len);
     op_ = rfl(op_ + len);
-    return true;
+    return !failed;
   }
   __device__ __forceinline__ bool huf_streams(uint32_t streams, uint32_t sp, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4, uint32_t seg,
                                               uint32_t regen, uint32_t maxbits, uint32_t outp) {
     drain();   // the tail of the output region may still hold the previous block's literals
+    if (failed || regen > cap_ || outp != cap_ - regen) return false;
     return ZWave::huf_streams(streams, sp, l1, l2, l3, l4, seg, regen, maxbits, outp);
   }
   __device__ __forceinline__ void end(uint32_t status) {
+    if (failed || !batch_ok()) {   // (what is still collected belongs to a refused batch)
+      qn = 0;
+      if (status == (uint32_t)zc::OK) status = (uint32_t)zc::CORRUPT_;
+    }
     push(ZC_END, status, 0, 0);
-    qflush();
+    qsend();
   }
 };
+
+__device__ __attribute__((noinline)) void zprod_sequences(uint32_t tab_lds) {
+  ZProd a;
+  a.tab = (uint8_t*)(__attribute__((address_space(3))) uint8_t*)(uintptr_t)rfl(tab_lds);
+  a.lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  uint32_t* H = a.hot_words();
+  a.srcA = (const uint8_t*)(uintptr_t)((uint64_t)rfl(H[ZH_SRC_LO]) | ((uint64_t)rfl(H[ZH_SRC_HI]) << 32));
+  a.a0 = rfl(H[ZH_A0]); a.safeA = rfl(H[ZH_SAFE]); a.frame0 = rfl(H[ZH_FRAME0]); a.cap_ = rfl(H[ZH_CAP]);
+  a.q.slots = (u32x4q*)(a.tab + ZW_TABLES);
+  a.q.ctl = (uint32_t*)(a.tab + ZW_TABLES + ZQ_CAP * 16);
+  a.hot_get_state();
+  uint32_t r0 = rfl(H[ZH_R0]), r1 = rfl(H[ZH_R1]), r2 = rfl(H[ZH_R2]);
+  const int rc = zc::seq_loop(a, rfl(H[ZH_P]), rfl(H[ZH_LEN]), rfl(H[ZH_NSEQ]), rfl(H[ZH_ALS]), r0, r1, r2);
+  if (a.lane == 0) { H[ZH_R0] = r0; H[ZH_R1] = r1; H[ZH_R2] = r2; H[ZH_RC] = (uint32_t)rc; }
+  a.hot_put_state();
+}
 
 // the consumer: replays the commands until END; -> the producer's status
 __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q) {
@@ -555,10 +661,6 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q) {
   }
 }
 
-constexpr uint32_t ZW_RING = 8192;                          // ZSTD: ring bytes
-constexpr uint32_t ZW_TABLES = 13312 + zc::SCR_BYTES;       // Huffman 4 KiB + LL 4 KiB + ML 4 KiB + OF 1 KiB + scratch
-constexpr uint32_t ZW_LDS = ZW_RING + ZW_TABLES;
-constexpr uint32_t ZW2_LDS = ZW_RING + ZW_TABLES + ZQ_BYTES;   // the two-wave kernel: + the command queue
 constexpr uint32_t LZ_RING = 8192;                          // LZ4 / Snappy: ring bytes (nothing else in LDS). r05 sweep on the 7-column lineitem set:
                                                             // 16 KiB 19.2 / 21.1 ms (LZ4 / Snappy), 8 KiB 14.3 / 16.3, 4 KiB 14.8 / 17.1
 

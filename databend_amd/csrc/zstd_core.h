@@ -72,20 +72,24 @@ constexpr uint32_t SCR_WTAB = 768;      // u32[64]   FSE table of the Huffman we
 constexpr uint32_t SCR_WEIGHTS = 1024;  // u8[256]   Huffman weights
 constexpr uint32_t SCR_RANK = 1280;     // u32[16]   first table index of every weight
 constexpr uint32_t SCR_CNT = 1344;      // u32[16]   symbols per weight
-constexpr uint32_t SCR_BYTES = 1408;
+constexpr uint32_t SCR_PARK = 1408;     // u32[8]    W::park slots
+constexpr uint32_t SCR_BYTES = 1440;
 
 constexpr uint32_t HUF_MAXBITS = 11;
 constexpr uint32_t BLOCK_MAX = 128 * 1024;
 
 ZC_INL uint32_t hibit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }   // v != 0
 
-// state of one frame (page) between blocks; all scalar
+// state of one frame (page) between blocks; all scalar. What the sequence tables and the Huffman table in LDS hold is ONE packed word
+// (it is live across the sequence loop, where every scalar register counts): accuracy logs in bits 0-3 / 4-7 / 8-11 (LL / OF / ML),
+// tags in bits 12-13 / 14-15 / 16-17, Max_Number_of_Bits of the Huffman table in bits 18-21 (0: none yet).
 struct Frame {
   uint32_t rep[3];
-  uint32_t ll_al, of_al, ml_al;      // accuracy logs of the tables now in LDS
-  uint32_t ll_tag, of_tag, ml_tag;   // what they hold (Repeat_Mode needs "something")
-  uint32_t huf_bits;                 // Max_Number_of_Bits of the Huffman table now in LDS (0: none yet)
+  uint32_t tabs;
 };
+ZC_INL uint32_t tabs_pack(uint32_t ll_al, uint32_t of_al, uint32_t ml_al, uint32_t ll_tag, uint32_t of_tag, uint32_t ml_tag, uint32_t huf_bits) {
+  return ll_al | (of_al << 4) | (ml_al << 8) | (ll_tag << 12) | (of_tag << 14) | (ml_tag << 16) | (huf_bits << 18);
+}
 
 // forward bit reader over the input (FSE table descriptions): LSB first
 template <class W>
@@ -281,43 +285,45 @@ struct BackBits {
   }
 };
 
-// The same stream for the SEQUENCES section, where it is the inner loop: the unread bits sit MSB-aligned in one scalar register pair
-// (bit off-1 of the stream = bit 63 of c), a field is a shift, and the register is refilled from the look-ahead window once per sequence
-// (57..64 bits each time) instead of being tested per field. Bits past the start of the stream read as zero and leave off < 0.
+// The same stream for the SEQUENCES section, where it is the inner loop. The unread bits sit at the BOTTOM of one scalar register pair:
+// c = input bytes [base + bb / 8, + 8), of which stream bits [bb, bb + have) are unread, so a field is `have -= n; (c >> have) & mask`
+// (four scalar instructions, nothing to shift back) and the only bookkeeping per field is `have`. The register is refilled (56..63
+// bits) when a whole sequence — its three fields and the three state updates, whose widths are all known from the table entries
+// before the first bit is read — does not fit what is left: one test per sequence instead of one per field.
 template <class W>
 struct SeqBits {
   uint32_t base;
-  int32_t off;    // unread bits of the stream
-  int32_t have;   // of which this many sit at the top of c
+  int32_t bb;     // stream bit index of bit 0 of c (a multiple of 8)
+  int32_t have;   // unread bits in c
   uint64_t c;
+  ZC_MEM int32_t left() const { return bb + have; }   // unread bits of the stream
   ZC_MEM bool init(W& w, uint32_t b, uint32_t len) {
     base = b;
-    have = 0; c = 0; off = 0;
+    have = 0; c = 0; bb = 0;
     if (len == 0) return false;
     const uint32_t last = w.in8(b + len - 1);
     if (last == 0) return false;
-    off = (int32_t)(len * 8) - (int32_t)(8 - hibit(last));
+    have = (int32_t)(len * 8) - (int32_t)(8 - hibit(last));   // (not in c yet: refill() brings the top of the stream in)
     return true;
   }
   ZC_MEM void refill(W& w) {
-    const int32_t b = off > 57 ? (off - 57) >> 3 : 0;
-    const int32_t h = off - 8 * b;        // 57..64, or what is left of the stream, or <= 0
-    have = (int32_t)w.uni((uint32_t)(h > 0 ? h : 0));
-    c = have > 0 ? w.uni64(w.in64(base + (uint32_t)b) << (uint32_t)(64 - have)) : 0;
+    const int32_t off = bb + have;
+    const int32_t b = off > 56 ? (off - 56) >> 3 : 0;
+    bb = 8 * b;
+    have = off - bb;                                         // 56..63, or what is left of the stream
+    c = w.uni64(w.in64(base + (uint32_t)b));
   }
   // the same after the first refill of a stream: the reads only move DOWN from there, which is all the window has to follow
   ZC_MEM void refill_back(W& w) {
-    const int32_t b = off > 57 ? (off - 57) >> 3 : 0;
-    const int32_t h = off - 8 * b;
-    have = (int32_t)w.uni((uint32_t)(h > 0 ? h : 0));
-    c = have > 0 ? w.uni64(w.in64_back(base + (uint32_t)b) << (uint32_t)(64 - have)) : 0;
+    const int32_t off = bb + have;
+    const int32_t b = off > 56 ? (off - 56) >> 3 : 0;
+    bb = 8 * b;
+    have = off - bb;
+    c = w.uni64(w.in64_back(base + (uint32_t)b));
   }
-  ZC_MEM uint32_t read(uint32_t n) {   // n <= 32, and n <= have unless the stream is exhausted
-    const uint32_t v = (uint32_t)((c >> 1) >> (63 - n));
-    c <<= n;
+  ZC_MEM uint32_t read(uint32_t n) {   // n <= 31 and n <= have
     have -= (int32_t)n;
-    off -= (int32_t)n;
-    return v;
+    return (uint32_t)(c >> (uint32_t)have) & ((1u << n) - 1u);
   }
 };
 
@@ -478,11 +484,86 @@ ZC_FN int seq_table(W& w, uint32_t mode, uint32_t& al, uint32_t& tag, uint32_t& 
   return OK;
 }
 
+// The sequences of one block: the backward bitstream at input [p, p + len), nseq > 0 sequences, accuracy logs packed as
+// ll | of << 4 | ml << 8, the repeat offsets in and out. Everything the loop touches goes through W: in8 / in64 / in64_back (the
+// bitstream), llt / mlt / oft (the tables), seq (one decoded sequence).
+template <class W>
+ZC_FN int seq_loop(W& w, uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0_, uint32_t& r1_, uint32_t& r2_) {
+  const uint32_t ll_al = als & 15, of_al = (als >> 4) & 15, ml_al = (als >> 8) & 15;
+  SeqBits<W> bs;
+  if (!bs.init(w, p, len)) return CORRUPT;
+  bs.refill(w);
+  if (bs.left() < (int32_t)(ll_al + of_al + ml_al)) return CORRUPT;
+  uint32_t ls = bs.read(ll_al), os = bs.read(of_al), ms = bs.read(ml_al);   // <= 26 bits
+  const uint64_t* LLT = w.llt();
+  const uint64_t* MLT = w.mlt();
+  const uint32_t* OFT = w.oft();
+  uint32_t r0 = r0_, r1 = r1_, r2 = r2_;
+  // the table entries of a sequence are read (LDS) while the sequence before it is validated and queued / copied
+  uint64_t le_raw = LLT[ls], me_raw = MLT[ms];
+  uint32_t oe_raw = OFT[os];
+  for (uint32_t left = nseq; left != 0; --left) {
+    const uint64_t le = w.uni64(le_raw), me = w.uni64(me_raw);
+    const uint32_t oe = w.uni(oe_raw);
+    // every width of this sequence is in the three entries: offset code, extra bits of the match / literals length, and — between
+    // sequences — the bits of the three state updates (literals length, match length, offset: 3.1.1.3.2.1.1)
+    const uint32_t ocode = oe >> 24, mlb = (uint32_t)(me >> 24) & 0xFF, llb = (uint32_t)(le >> 24) & 0xFF;
+    const uint32_t upd = left != 1 ? 0xFFu : 0u;
+    const uint32_t lnb = ((uint32_t)le >> 16) & upd, mnb = ((uint32_t)me >> 16) & upd, onb = (oe >> 16) & upd;
+    const uint32_t tot = ocode + mlb + llb + lnb + mnb + onb;   // <= 31 + 16 + 16 + 26
+    if (bs.have < (int32_t)tot) {
+      bs.refill_back(w);
+      if (bs.left() < (int32_t)tot) return CORRUPT_STRICT;   // (libzstd < 1.5 reads zeros past the start and only checks the end; 1.5.7 checks for the exact end)
+    }
+    uint32_t ofx, mlx, llx, lsx, msx, osx;
+    if (bs.have >= (int32_t)tot) {
+      ofx = bs.read(ocode); mlx = bs.read(mlb); llx = bs.read(llb);
+      lsx = bs.read(lnb); msx = bs.read(mnb); osx = bs.read(onb);
+    } else {
+      // more than 56 bits in one sequence (an offset code above ~14 together with long length codes): field by field
+#if defined(ZC_TRACE)
+      zc_trace_wide();
+#endif
+      ofx = bs.read(ocode);
+      bs.refill_back(w);
+      mlx = bs.read(mlb); llx = bs.read(llb);
+      bs.refill_back(w);
+      lsx = bs.read(lnb); msx = bs.read(mnb); osx = bs.read(onb);
+    }
+    const uint32_t ov = (1u << ocode) + ofx;
+    const uint32_t ml = (uint32_t)(me >> 32) + mlx;
+    const uint32_t ll = (uint32_t)(le >> 32) + llx;
+    ls = ((uint32_t)le & 0xFFFF) + lsx;
+    ms = ((uint32_t)me & 0xFFFF) + msx;
+    os = (oe & 0xFFFF) + osx;
+    le_raw = LLT[ls]; me_raw = MLT[ms]; oe_raw = OFT[os];   // (after the last sequence: the entries at the states' bases, unused)
+    // repeat offsets (3.1.1.5) as selects on j = 0..3 (a repeat code, shifted by one when there are no literals) / 4 (a new offset):
+    //   j = 0 offset r0, history unchanged; j = 1 r1, swapped to the front; j = 2 r2, j = 3 r0 - 1, j = 4 ov - 3: pushed to the front
+    uint32_t j = ov - 1 + (ll == 0 ? 1u : 0u);
+    j = ov > 3 ? 4u : j;
+    uint32_t off = ov - 3;
+    off = j == 0 ? r0 : off;
+    off = j == 1 ? r1 : off;
+    off = j == 2 ? r2 : off;
+    off = j == 3 ? r0 - 1 : off;
+    r2 = j >= 2 ? r1 : r2;
+    r1 = j >= 1 ? r0 : r1;
+    r0 = off;
+    // execute (a W refuses an offset of 0 — r0 - 1 with r0 = 1 — and literals past the block's; it may do so a few sequences late)
+    if (!w.seq(ll, off, ml)) return CORRUPT;
+  }
+  r0_ = r0; r1_ = r1; r2_ = r2;
+  if (bs.left() != 0) return CORRUPT_STRICT;   // every bit of the stream belongs to a sequence
+  return OK;
+}
+
 // one Compressed_Block (3.1.1.2 / 3.1.1.3): input [pos, pos + bsize)
 template <class W>
 ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
   const uint32_t end = pos + bsize;
   if (bsize < 2) return CORRUPT;
+  uint32_t ll_al = F.tabs & 15, of_al = (F.tabs >> 4) & 15, ml_al = (F.tabs >> 8) & 15;
+  uint32_t ll_tag = (F.tabs >> 12) & 3, of_tag = (F.tabs >> 14) & 3, ml_tag = (F.tabs >> 16) & 3, huf_bits = (F.tabs >> 18) & 15;
   // ---- literals section header
   const uint32_t b0 = w.in8(pos);
   const uint32_t ltype = b0 & 3, sf = (b0 >> 2) & 3;
@@ -515,9 +596,9 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
       uint32_t mb = 0;
       const uint32_t used = huf_read_table(w, p, lend, &mb);
       if (used == 0) return CORRUPT;
-      F.huf_bits = mb;
+      huf_bits = mb;
       p += used;
-    } else if (F.huf_bits == 0) {
+    } else if (huf_bits == 0) {
       return CORRUPT;   // Treeless_Literals_Block with no earlier tree
     }
     // The decoded literals go to the TAIL of this page's output region, [cap - regen, cap): a sequence never writes past the literals
@@ -540,7 +621,7 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
       }
       // (a stream that ends before its last symbol is refused here; libzstd's double-symbol decoder, when its heuristic picks it,
       // lets the LAST symbol of such a stream through from zero bits — malformed by the format either way)
-      if (!w.huf_streams(streams, sp, l1, l2, l3, l4, seg, regen, F.huf_bits, lit_pos)) return CORRUPT_STRICT;
+      if (!w.huf_streams(streams, sp, l1, l2, l3, l4, seg, regen, huf_bits, lit_pos)) return CORRUPT_STRICT;
     }
     p = lend;
   }
@@ -562,7 +643,6 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
     nseq = w.in8(p + 1) + (w.in8(p + 2) << 8) + 0x7F00;
     p += 3;
   }
-  uint32_t lit_left = regen;
   if (nseq) {
     if (p >= end) return CORRUPT;
     const uint32_t modes = w.in8(p);
@@ -570,69 +650,25 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
     if (modes & 3) return CORRUPT_STRICT;   // Reserved bits (libzstd >= 1.5.6)
     // (three explicit calls, the fields passed by reference: a loop over pointers to F's members would put F into private memory,
     // whose loads the compiler treats as per-lane values — the whole parser left the scalar unit that way in the first build)
-    int trc = seq_table<W, K_LL>(w, (modes >> 6) & 3, F.ll_al, F.ll_tag, p, end);
+    int trc = seq_table<W, K_LL>(w, (modes >> 6) & 3, ll_al, ll_tag, p, end);
     if (trc) return trc;
-    trc = seq_table<W, K_OF>(w, (modes >> 4) & 3, F.of_al, F.of_tag, p, end);
+    trc = seq_table<W, K_OF>(w, (modes >> 4) & 3, of_al, of_tag, p, end);
     if (trc) return trc;
-    trc = seq_table<W, K_ML>(w, (modes >> 2) & 3, F.ml_al, F.ml_tag, p, end);
+    trc = seq_table<W, K_ML>(w, (modes >> 2) & 3, ml_al, ml_tag, p, end);
     if (trc) return trc;
-    // ---- the sequences: one backward bitstream
-    SeqBits<W> bs;
-    if (p >= end || !bs.init(w, p, end - p)) return CORRUPT;
-    bs.refill(w);
-    uint32_t ls = bs.read(F.ll_al), os = bs.read(F.of_al), ms = bs.read(F.ml_al);   // <= 26 bits
-    if (bs.off < 0) return CORRUPT;
-    const uint64_t* LLT = w.llt();
-    const uint64_t* MLT = w.mlt();
-    const uint32_t* OFT = w.oft();
+    // ---- the sequences: one backward bitstream, walked by W::sequences (= seq_loop above; the two-wave producer runs it as a
+    // function of its own so that the loop gets a register allocation of its own)
+    F.tabs = tabs_pack(ll_al, of_al, ml_al, ll_tag, of_tag, ml_tag, huf_bits);
+    if (p >= end) return CORRUPT;
     uint32_t r0 = F.rep[0], r1 = F.rep[1], r2 = F.rep[2];
-    // the table entries of a sequence are read (LDS) while the sequence before it is copied
-    uint64_t le_raw = LLT[ls], me_raw = MLT[ms];
-    uint32_t oe_raw = OFT[os];
-    for (uint32_t i = 0; i < nseq; ++i) {
-      const uint64_t le = w.uni64(le_raw), me = w.uni64(me_raw);
-      const uint32_t oe = w.uni(oe_raw);
-      const uint32_t ocode = oe >> 24;
-      // the register holds 57..64 bits after a refill: offset (<= 24 here) + match length (<= 16) + literals length (<= 16) fit; it is
-      // refilled when this sequence's fields do not fit what is left (every second sequence or so on short fields), not every time
-      const uint32_t need = ocode > 24 ? ocode : ocode + ((uint32_t)(me >> 24) & 0xFF) + ((uint32_t)(le >> 24) & 0xFF);
-      if (bs.have < (int32_t)need) bs.refill_back(w);
-      // offset, match length, literals length — in this order (3.1.1.3.2.1.1)
-      const uint32_t ov = (1u << ocode) + bs.read(ocode);
-      if (ocode > 24) bs.refill_back(w);
-      const uint32_t ml = (uint32_t)(me >> 32) + bs.read((uint32_t)(me >> 24) & 0xFF);
-      const uint32_t ll = (uint32_t)(le >> 32) + bs.read((uint32_t)(le >> 24) & 0xFF);
-      if (bs.off < 0) return CORRUPT_STRICT;   // (libzstd < 1.5 reads zeros past the start and only checks the end; 1.5.7 checks for the exact end)
-      // repeat offsets (3.1.1.5), as selects: the branchy form cost ~50 scalar instructions of flag shuffling per sequence (r05 ISA)
-      const bool rep = ov <= 3;
-      const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);   // 0..3 when rep
-      const uint32_t cand = idx == 0 ? r0 : (idx == 1 ? r1 : (idx == 2 ? r2 : r0 - 1));
-      const uint32_t off = rep ? cand : ov - 3;
-      if (off == 0) return CORRUPT;                        // (only a repeat offset can be 0: r0 - 1 with r0 = 1)
-      const bool shift2 = !rep || idx >= 2, shift1 = !rep || idx != 0;
-      r2 = shift2 ? r1 : r2;
-      r1 = shift1 ? r0 : r1;
-      r0 = off;
-      if (i + 1 < nseq) {   // states are updated between sequences: literals length, match length, offset (<= 26 bits)
-        if (bs.have < 26) bs.refill_back(w);
-        ls = w.uni(((uint32_t)le & 0xFFFF) + bs.read(((uint32_t)le >> 16) & 0xFF));
-        ms = w.uni(((uint32_t)me & 0xFFFF) + bs.read(((uint32_t)me >> 16) & 0xFF));
-        os = w.uni((oe & 0xFFFF) + bs.read((oe >> 16) & 0xFF));
-        if (bs.off < 0) return CORRUPT_STRICT;
-        le_raw = LLT[ls]; me_raw = MLT[ms]; oe_raw = OFT[os];
-      }
-      // execute
-      if (ll > lit_left) return CORRUPT;
-      if (ll) {
-        if (!w.put_seq(ll, off, ml)) return CORRUPT;   // (a short literal and its match go as one step)
-        lit_left -= ll;
-      } else if (!w.put_match(off, ml)) {
-        return CORRUPT;
-      }
-    }
+    trc = w.sequences(p, end - p, nseq, ll_al | (of_al << 4) | (ml_al << 8), r0, r1, r2);
+    if (trc) return trc;
     F.rep[0] = r0; F.rep[1] = r1; F.rep[2] = r2;
-    if (bs.off != 0) return CORRUPT_STRICT;   // every bit of the stream belongs to a sequence
   }
+  else {
+    F.tabs = tabs_pack(ll_al, of_al, ml_al, ll_tag, of_tag, ml_tag, huf_bits);   // (a block without sequences may still bring a Huffman table)
+  }
+  const uint32_t lit_left = w.lit_rest();
   if (lit_left && !w.put_lit(lit_left)) return CORRUPT;
   return OK;
 }
@@ -640,7 +676,8 @@ ZC_FN int decode_block(W& w, Frame& F, uint32_t pos, uint32_t bsize) {
 // the whole compressed payload of a page: one or more frames (3.1), skippable frames skipped (3.1.2). The output must come to exactly
 // w.cap() bytes (the caller checks op == cap).
 template <class W>
-ZC_FN int decode_frames(W& w, uint32_t in_len) {
+ZC_FN int decode_frames(W& w, uint32_t in_len_) {
+  uint32_t in_len = in_len_;
   uint32_t p = 0;
   while (p < in_len) {
     if (in_len - p < 4) return CORRUPT;
@@ -657,7 +694,8 @@ ZC_FN int decode_frames(W& w, uint32_t in_len) {
     if (p >= in_len) return CORRUPT;
     const uint32_t fhd = w.in8(p);
     p += 1;
-    const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+    const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    uint32_t checksum = (fhd >> 2) & 1;
     if (fhd & 0x08) return CORRUPT;   // reserved bit
     uint64_t window = 0;
     if (!single) {
@@ -676,7 +714,7 @@ ZC_FN int decode_frames(W& w, uint32_t in_len) {
       p += n;
       if (id != 0) return UNSUPPORTED;   // a dictionary: the reference's writer never uses one
     }
-    const uint32_t fn = fcs_flag == 0 ? (single ? 1u : 0u) : fcs_flag == 1 ? 2u : fcs_flag == 2 ? 4u : 8u;
+    uint32_t fn = fcs_flag == 0 ? (single ? 1u : 0u) : fcs_flag == 1 ? 2u : fcs_flag == 2 ? 4u : 8u;
     uint64_t fcs = 0;
     if (fn) {
       if (in_len - p < fn) return CORRUPT;
@@ -685,20 +723,20 @@ ZC_FN int decode_frames(W& w, uint32_t in_len) {
       p += fn;
     }
     if (single) window = fcs;
-    const uint32_t frame_start = w.op();
+    uint32_t frame_start = w.op();
     if (fn && fcs > (uint64_t)(w.cap() - w.op())) return CORRUPT;
     w.frame_begin();   // back-references do not reach across frames
     Frame F;
     F.rep[0] = 1; F.rep[1] = 4; F.rep[2] = 8;
-    F.ll_al = F.of_al = F.ml_al = 0;
-    F.ll_tag = F.of_tag = F.ml_tag = TAG_NONE;
-    F.huf_bits = 0;
-    const uint64_t bmax = window < BLOCK_MAX ? window : BLOCK_MAX;
+    F.tabs = 0;   // no tables yet (TAG_NONE)
+    uint32_t bmax = window < BLOCK_MAX ? (uint32_t)window : BLOCK_MAX;
+    uint32_t fcs32 = (uint32_t)fcs;   // (checked against the room of the page above: it fits)
     for (;;) {
       if (in_len - p < 3) return CORRUPT;
       const uint32_t bh = (uint32_t)w.in64(p) & 0xFFFFFF;
       p += 3;
-      const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+      const uint32_t btype = (bh >> 1) & 3;
+      uint32_t last = bh & 1, bsize = bh >> 3;
       if (btype == 3) return CORRUPT;
       if (btype == 1) {
         if (p >= in_len) return CORRUPT;
@@ -711,16 +749,22 @@ ZC_FN int decode_frames(W& w, uint32_t in_len) {
           if (bsize > bmax) return CORRUPT;
           if (bsize && !w.put_in(p, bsize)) return CORRUPT;
         } else {
-          const uint32_t before = w.op();
+          // (what this loop keeps between blocks waits in W's parking slots while the block is decoded: the sequence loop needs
+          //  every scalar register it can get, and a value that is only STORED and re-LOADED around it is not live inside it)
+          w.park(0, p); w.park(1, in_len); w.park(2, bsize); w.park(3, bmax); w.park(4, fcs32); w.park(5, frame_start);
+          w.park(6, fn | (checksum << 4) | (last << 5)); w.park(7, w.op());
           const int rc = decode_block(w, F, p, bsize);
           if (rc) return rc;
-          if ((uint64_t)(w.op() - before) > bmax) return CORRUPT;
+          p = w.unpark(0); in_len = w.unpark(1); bsize = w.unpark(2); bmax = w.unpark(3); fcs32 = w.unpark(4); frame_start = w.unpark(5);
+          const uint32_t fl = w.unpark(6);
+          fn = fl & 15; checksum = (fl >> 4) & 1; last = fl >> 5;
+          if (w.op() - w.unpark(7) > bmax) return CORRUPT;
         }
         p += bsize;
       }
       if (last) break;
     }
-    if (fn && (uint64_t)(w.op() - frame_start) != fcs) return CORRUPT;
+    if (fn && w.op() - frame_start != fcs32) return CORRUPT;
     if (checksum) {
       if (in_len - p < 4) return CORRUPT;
       p += 4;   // XXH64 of the content: not verified here (the parquet page's own size check stands in)
