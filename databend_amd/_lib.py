@@ -68,7 +68,8 @@ class AggDesc(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libdbhip.so")
+    # DBHIP_LIBRARY: another build of the same library (tools/probes A/B runs: an experiments build beside the shipped one)
+    return os.environ.get("DBHIP_LIBRARY") or os.path.join(_HERE, "libdbhip.so")
 
 
 # every symbol include/dbhip.h declares (tests check that the built library exports all of them)

@@ -95,6 +95,18 @@ struct FwdStream {
     const uint32_t s = 8 * (a & 3);
     return s ? (lo >> s) | ((uint64_t)d2 << (64 - s)) : lo;
   }
+  // byte a + li of the stream for a per-lane li < 64 (a in chunk k after seek(a); the bytes asked for lie in [a, a + n), which may reach
+  // into chunk k + 1)
+  __device__ __forceinline__ uint32_t lane_byte_at(uint32_t a, uint32_t li, uint32_t n) const {
+    const uint32_t t = (a & 255) + li;                        // 0..318
+    const uint32_t sel = t & 0xFCu;                           // (dword index within its chunk) * 4
+    uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)sel, (int)cur);
+    if ((a & 255) + n > 256) {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)sel, (int)nxt);
+      v = t < 256 ? v : x;
+    }
+    return (v >> (8 * (t & 3))) & 0xFFu;
+  }
   // byte a + lane for the first n lanes (a in chunk k after seek(a); a + n may reach into chunk k + 1)
   __device__ __forceinline__ uint8_t lane_byte(uint32_t a, uint32_t n) const {
     const uint32_t t = (a & 255) + lane;                      // 0..318
@@ -128,6 +140,8 @@ struct ZWave {
   uint8_t* tab;
   uint32_t lane;
 
+  static constexpr bool RESOLVES_OFFSETS = false;   // zstd_core.h hands seq() the resolved offset
+  __device__ __forceinline__ bool seq_raw(uint32_t, uint32_t, uint32_t) { return false; }
   __device__ __forceinline__ bool lead() const { return lane == 0; }
   __device__ __forceinline__ void sync() const { __builtin_amdgcn_wave_barrier(); }
   __device__ __forceinline__ bool bcast(bool b) const { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
@@ -138,6 +152,10 @@ struct ZWave {
   __device__ __forceinline__ uint64_t* mlt() const { return (uint64_t*)(tab + 8192); }
   __device__ __forceinline__ uint32_t* oft() const { return (uint32_t*)(tab + 12288); }
   __device__ __forceinline__ uint8_t* scr() const { return tab + 13312; }
+  // entry of a sequence table at a (uniform) state number
+  __device__ __forceinline__ uint64_t ll_at(uint32_t st) const { return llt()[st]; }
+  __device__ __forceinline__ uint64_t ml_at(uint32_t st) const { return mlt()[st]; }
+  __device__ __forceinline__ uint32_t of_at(uint32_t st) const { return oft()[st]; }
   // parking slots (zstd_core.h decode_frames): stored by lane 0, read back by the wave; volatile so that the value is really re-loaded
   __device__ __forceinline__ void park(uint32_t i, uint32_t v) const { if (lane == 0) ((volatile uint32_t*)(scr() + zc::SCR_PARK))[i] = v; }
   __device__ __forceinline__ uint32_t unpark(uint32_t i) const { return rfl(((volatile uint32_t*)(scr() + zc::SCR_PARK))[i]); }
@@ -248,13 +266,15 @@ struct ZWave {
       advance(n);
     }
   }
+  template <bool CK = true>
   __device__ __forceinline__ bool put_in(uint32_t pos, uint32_t len) {
-    if (len > cap_ - op_ || pos > in_len || len > in_len - pos) return false;
+    if (CK && (len > cap_ - op_ || pos > in_len || len > in_len - pos)) return false;
     copy_in(srcA + a0 + pos, len);
     return true;
   }
+  template <bool CK = true>
   __device__ __forceinline__ bool put_fill(uint32_t byte, uint32_t len) {
-    if (len > cap_ - op_) return false;
+    if (CK && len > cap_ - op_) return false;
 #pragma clang loop unroll(disable)
     for (uint32_t i = 0; i < len; i += 64) {
       const uint32_t n = len - i < 64 ? len - i : 64;
@@ -286,6 +306,34 @@ struct ZWave {
       lit.open(g - x, room, x, lane);
     }
   }
+  // ONE SEQUENCE of a ZSTD block whose ll literals and ml match bytes fit the wave (ll + ml <= 64, ll may be 0), the source inside the
+  // ring (off <= W - 128), the literals a stream (lit_kind 0 / 1) — replayed by the consumer of the two-wave kernel, whose producer has
+  // validated it: no checks here. Everything per byte is per LANE: lane l < ll takes literal l; lane ll + m takes match byte m from
+  // `off` back — in the ring (one ds_read for all lanes) or, when the match overlaps the literals of this very sequence, one of those
+  // literals (out[x] = out[x - off (1 + floor(m / off))]). The literal bytes come out of the stream's register window with ONE
+  // ds_bpermute at a per-lane index (round 5 took 8 bytes as a scalar: ~30 scalar instructions per sequence, and the scalar unit is
+  // what the two waves of every page on the CU share).
+  template <bool FLUSH = true>
+  __device__ __forceinline__ void seq_small(uint32_t ll, uint32_t off, uint32_t ml) {
+    const int32_t m = (int32_t)lane - (int32_t)ll;                 // match byte index (negative: a literal lane)
+    uint32_t mm = m > 0 ? (uint32_t)m : 0u;
+    // mm mod off without a division (exact: see put_match; for off >= 64 the quotient is 0)
+    mm = mm - off * (uint32_t)(((float)mm + 0.5f) * __builtin_amdgcn_rcpf((float)off));
+    const int32_t rel = (int32_t)ll - (int32_t)off + (int32_t)mm;  // source relative to op_: < 0 in the ring, >= 0 a literal of this sequence
+    const uint32_t from_ring = win[(op_ + (uint32_t)rel + sh) & WM];
+    uint32_t from_lit = 0;
+    if (ll) {
+      lit.seek(lit_at);
+      from_lit = lit.lane_byte_at(lit_at, (m < 0 ? lane : (uint32_t)rel) & 63u, ll);
+      lit_left -= ll;
+      lit_at = rfl(lit_at + ll);
+    }
+    const uint32_t v = (m < 0 || rel >= 0) ? from_lit : from_ring;
+    if (lane < ll + ml) win[(op_ + lane + sh) & WM] = (uint8_t)v;
+    __builtin_amdgcn_wave_barrier();
+    if (FLUSH) advance(ll + ml);
+    else op_ += ll + ml;           // (the caller has flushed and keeps to 64 of these: see zq_consume)
+  }
   // literals + match of one ZSTD sequence (ll > 0)
   __device__ __forceinline__ bool put_seq(uint32_t ll, uint32_t off, uint32_t ml) {
     if (ll <= 8 && ll + ml <= 64 && lit_kind != 2 && off <= WM - 127) {
@@ -304,10 +352,11 @@ struct ZWave {
   __device__ __forceinline__ int sequences(uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0, uint32_t& r1, uint32_t& r2) {
     return zc::seq_loop(*this, p, len, nseq, als, r0, r1, r2);
   }
+  template <bool CK = true>
   __device__ __forceinline__ bool put_lit(uint32_t len) {
-    if (len > lit_left || len > cap_ - op_) return false;
+    if (CK && (len > lit_left || len > cap_ - op_)) return false;
     lit_left -= len;
-    if (lit_kind == 2) return put_fill(lit_at, len);
+    if (lit_kind == 2) return put_fill<CK>(lit_at, len);
     if (len <= 64) {
       put_stream64(lit, lit_at, len);
     } else {
@@ -339,8 +388,9 @@ struct ZWave {
     advance(lit + mlen);
   }
 
+  template <bool CK = true>
   __device__ __forceinline__ bool put_match(uint32_t off, uint32_t len) {
-    if (off == 0 || off > op_ - frame0 || len > cap_ - op_) return false;
+    if (CK && (off == 0 || off > op_ - frame0 || len > cap_ - op_)) return false;
     if (off <= WM - 63) {
       // the source lies in the ring. By periodicity out[cur + l] = out[cur - off + (l mod off)]: every source byte lies before `cur`,
       // so the 64 lanes read (one LDS instruction) before any of them writes
@@ -431,7 +481,7 @@ constexpr uint32_t ZW_LDS = ZW_RING + ZW_TABLES;
 constexpr uint32_t ZQ_CAP = 256;             // commands in the queue (16 bytes each)
 constexpr uint32_t ZQ_BYTES = ZQ_CAP * 16 + 16;
 constexpr uint32_t ZW2_LDS = ZW_RING + ZW_TABLES + ZQ_BYTES;   // the two-wave kernel: + the command queue
-enum { ZC_SEQ = 0, ZC_LIT_BEGIN = 1, ZC_LIT = 2, ZC_IN = 3, ZC_FILL = 4, ZC_END = 5 };
+enum { ZC_SEQ = 0, ZC_LIT_BEGIN = 1, ZC_LIT = 2, ZC_IN = 3, ZC_FILL = 4, ZC_END = 5, ZC_FRAME = 6 };
 typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
 
 struct ZQueue {
@@ -455,7 +505,7 @@ constexpr uint32_t ZQ_POLLS = 1u << 24;
 // words of the collected commands), [1280, 1408) the scalars.
 __device__ __attribute__((noinline)) void zprod_sequences(uint32_t tab_lds);
 enum { ZH_SRC_LO = 0, ZH_SRC_HI, ZH_A0, ZH_SAFE, ZH_WLO, ZH_QN, ZH_QTAIL, ZH_OP, ZH_FRAME0, ZH_CAP, ZH_LIT_LEFT, ZH_VIOL, ZH_FAILED, ZH_R0, ZH_R1,
-       ZH_R2, ZH_P, ZH_LEN, ZH_NSEQ, ZH_ALS, ZH_RC, ZH_WORDS };
+       ZH_R2, ZH_P, ZH_LEN, ZH_NSEQ, ZH_ALS, ZH_RC, ZH_XW_LO, ZH_XW_HI, ZH_WORDS };
 static_assert(1280 + 4 * ZH_WORDS <= zc::SCR_PARK, "the hand-over block must fit the scratch area below the parking slots");
 
 struct ZProd : ZWave {
@@ -463,13 +513,22 @@ struct ZProd : ZWave {
   uint32_t qn;                 // commands collected in registers (uniform)
   uint32_t qtail;              // this side's copy of the tail
   uint32_t b0, b1, b2, b3;     // lane i: words of collected command i
-  // Sequences are validated BY THE BATCH (round 6): a sequence only adds to op_, takes from lit_left (kept signed) and ORs its reach
-  // test into `viol`; the batch of <= 64 collected commands is judged as a whole when it leaves for the queue — op_ <= cap_,
-  // lit_left >= 0, viol == 0 — and a batch that fails is dropped, so the consumer still never sees a command it cannot execute.
-  // (Everything is monotonic between two flushes: op_ grows by < 2^18 per sequence and cap_ < 2^31, lit_left starts below 2^17 and
-  // falls by < 2^17 per sequence, viol is sticky.) Per sequence that is 5 scalar instructions instead of five compares and branches.
+  // Sequences are validated BY THE BATCH (round 6): a sequence only adds to op_ and takes from lit_left (kept signed); the batch of
+  // <= 64 collected commands is judged as a whole when it leaves for the queue — op_ <= cap_, lit_left >= 0 (`viol` keeps what a
+  // block's end found) — and a batch that fails is dropped, so the consumer never sees a command that writes past the page or takes
+  // literals the block does not have. (Everything is monotonic between two flushes: op_ grows by < 2^18 per sequence and cap_ < 2^31,
+  // lit_left starts below 2^17 and falls by < 2^17 per sequence.) The third test — the offset stays inside the frame — is the
+  // consumer's, together with the repeat-offset history (seq_raw below).
   uint32_t viol;
   bool failed;                 // a batch was refused: every later call fails
+#ifdef DBHIP_EXPERIMENTS
+  uint64_t x_wait = 0;         // cycles spent waiting for the consumer (queue full / drain)
+#define ZX_T0 const uint64_t zx_t0 = __builtin_readcyclecounter();
+#define ZX_ADD(acc) acc += __builtin_readcyclecounter() - zx_t0;
+#else
+#define ZX_T0
+#define ZX_ADD(acc)
+#endif
 
   __device__ __forceinline__ void qbegin(const ZQueue& Q) { q = Q; qn = 0; qtail = 0; b0 = b1 = b2 = b3 = 0; viol = cap_ >> 31; failed = false; }
   __device__ __forceinline__ bool batch_ok() const {   // (selects between integers: a bool turned into an integer leaves the scalar unit)
@@ -481,11 +540,13 @@ struct ZProd : ZWave {
   // the collected commands -> the queue (waits for room), unchecked
   __device__ __forceinline__ void qsend() {
     if (qn == 0) return;
+    ZX_T0
     for (uint32_t polls = 0; qtail + qn - q.head() > ZQ_CAP; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
       if (q.dead()) { qn = 0; return; }
       __builtin_amdgcn_s_sleep(2);
     }
+    ZX_ADD(x_wait)
     if (lane < qn) q.slots[(qtail + lane) & (ZQ_CAP - 1)] = u32x4q{b0, b1, b2, b3};
     qtail = rfl(qtail + qn);
     qn = 0;
@@ -508,11 +569,13 @@ struct ZProd : ZWave {
   __device__ __forceinline__ void drain() {
     qflush();
     if (failed) return;
+    ZX_T0
     for (uint32_t polls = 0; q.head() != qtail; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
       if (q.dead()) return;
       __builtin_amdgcn_s_sleep(2);
     }
+    ZX_ADD(x_wait)
   }
 
   // ---- the output half of the interface zstd_core.h expects: validate against the producer's own position, queue, count
@@ -521,18 +584,30 @@ struct ZProd : ZWave {
     lit_left = n;
     push(ZC_LIT_BEGIN | (kind << 8), pos, 0, n);
   }
-  // a sequence: command words (ll, ml, off != 0); the consumer ignores the fourth word of a lane that holds one
-  __device__ __forceinline__ bool seq(uint32_t ll, uint32_t off, uint32_t ml) {
-    // off == 0 or off > bytes of this frame written so far + ll  <=>  off - 1 >= that sum (unsigned)
-    viol = (off - 1u >= op_ - frame0 + ll) ? 1u : viol;
+  // a sequence: command words (ll, ml, ov != 0); the consumer ignores the fourth word of a lane that holds one. ov is the offset VALUE
+  // of the format (1..3: a repeat code, else offset + 3): the repeat-offset history lives in the CONSUMER, which also checks that the
+  // offset stays inside the frame — 23 scalar instructions per sequence that the wave with time to spare now carries (round 6: the
+  // page's latency is the producer's; with those it was 115 : 35 instructions per sequence, now 92 : 58).
+  static constexpr bool RESOLVES_OFFSETS = true;
+  __device__ __forceinline__ bool seq_raw(uint32_t ll, uint32_t ov, uint32_t ml) {
     lit_left -= ll;
     const bool mine = lane == qn;
-    b0 = mine ? ll : b0; b1 = mine ? ml : b1; b2 = mine ? off : b2;
+    b0 = mine ? ll : b0; b1 = mine ? ml : b1; b2 = mine ? ov : b2;
     op_ += ll + ml;
     qn += 1;
-    if (qn == 64) qflush();
-    return !failed;
+    if (__builtin_expect(qn == 64, 0)) qflush();
+    return true;   // (a refused batch is reported when the block's sequences are done: `failed` — what follows it is dropped batch by batch)
   }
+  __device__ __forceinline__ bool seq(uint32_t, uint32_t, uint32_t) { return false; }   // (not used: RESOLVES_OFFSETS)
+  __device__ __forceinline__ void frame_begin() {
+    frame0 = op_;
+    push(ZC_FRAME, 0, 0, 0);
+  }
+  // the same with the address arithmetic on the VECTOR unit (the state number is copied to a VGPR behind an opaque asm: shift + add
+  // are then one v_lshl_add_u32 instead of four scalar instructions per table, and scalar issue slots are what this wave runs out of)
+  __device__ __forceinline__ uint64_t ll_at(uint32_t st) const { uint32_t v = st; asm("" : "+v"(v)); return llt()[v]; }
+  __device__ __forceinline__ uint64_t ml_at(uint32_t st) const { uint32_t v = st; asm("" : "+v"(v)); return mlt()[v]; }
+  __device__ __forceinline__ uint32_t of_at(uint32_t st) const { uint32_t v = st; asm("" : "+v"(v)); return oft()[v]; }
   // ---- the hand-over (see zprod_sequences)
   __device__ __forceinline__ uint32_t* hot_words() const { return (uint32_t*)(scr() + 1280); }
   __device__ __forceinline__ void hot_put_lanes() const {
@@ -549,6 +624,9 @@ struct ZProd : ZWave {
     if (lane == 0) {
       H[ZH_WLO] = wlo; H[ZH_QN] = qn; H[ZH_QTAIL] = qtail; H[ZH_OP] = op_; H[ZH_LIT_LEFT] = lit_left; H[ZH_VIOL] = viol;
       H[ZH_FAILED] = failed ? 1u : 0u;
+#ifdef DBHIP_EXPERIMENTS
+      H[ZH_XW_LO] = (uint32_t)x_wait; H[ZH_XW_HI] = (uint32_t)(x_wait >> 32);
+#endif
     }
     hot_put_lanes();
   }
@@ -556,6 +634,9 @@ struct ZProd : ZWave {
     const uint32_t* H = hot_words();
     wlo = rfl(H[ZH_WLO]); qn = rfl(H[ZH_QN]); qtail = rfl(H[ZH_QTAIL]); op_ = rfl(H[ZH_OP]); lit_left = rfl(H[ZH_LIT_LEFT]);
     viol = rfl(H[ZH_VIOL]); failed = rfl(H[ZH_FAILED]) != 0;
+#ifdef DBHIP_EXPERIMENTS
+    x_wait = (uint64_t)rfl(H[ZH_XW_LO]) | ((uint64_t)rfl(H[ZH_XW_HI]) << 32);
+#endif
     hot_get_lanes();
   }
   __device__ __forceinline__ int sequences(uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0, uint32_t& r1, uint32_t& r2) {
@@ -569,7 +650,8 @@ struct ZProd : ZWave {
     zprod_sequences((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)tab);
     hot_get_state();
     r0 = rfl(H[ZH_R0]); r1 = rfl(H[ZH_R1]); r2 = rfl(H[ZH_R2]);
-    return (int)rfl(H[ZH_RC]);
+    const int rc = (int)rfl(H[ZH_RC]);
+    return failed && rc == zc::OK ? (int)zc::CORRUPT_ : rc;
   }
   __device__ __forceinline__ uint32_t lit_rest() {
     viol = (int32_t)lit_left < 0 ? 1u : viol;
@@ -627,34 +709,101 @@ __device__ __attribute__((noinline)) void zprod_sequences(uint32_t tab_lds) {
 }
 
 // the consumer: replays the commands until END; -> the producer's status
-__device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q) {
+__device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32_t xmode, uint64_t* xwait = nullptr) {
   uint32_t head = 0;
+  uint32_t r0 = 1, r1 = 4, r2 = 8;   // the repeat offsets of the frame being replayed
+  uint32_t bad = 0;                  // an offset reached before its frame: nothing is executed from there on
   for (;;) {
     uint32_t tail = q.tail();
+#ifdef DBHIP_EXPERIMENTS
+    const uint64_t zx_c0 = __builtin_readcyclecounter();
+#endif
     for (uint32_t polls = 0; tail == head; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
       if (q.dead()) return (uint32_t)zc::CORRUPT_;
       __builtin_amdgcn_s_sleep(16);   // (a batch of 64 commands takes the producer ~10^5 cycles: a poll every ~1000 costs the CU's shared scalar unit next to nothing)
       tail = q.tail();
     }
+#ifdef DBHIP_EXPERIMENTS
+    if (xwait) *xwait += __builtin_readcyclecounter() - zx_c0;
+#endif
     const uint32_t m = rfl(tail - head < 64 ? tail - head : 64);
     const u32x4q e = q.slots[(head + (w.lane < m ? w.lane : 0)) & (ZQ_CAP - 1)];
+    // THE COMMON BATCH: nothing but sequences. It runs as one straight loop: no command dispatch, the repeat-offset history and the
+    // reach test as selects (an offset that fails the test still reads and writes inside the ring when the sequence fits the wave;
+    // anything else is skipped from there on, the page is reported malformed at the end), the sequence that fits the wave with its
+    // source in the ring (seq_small) in line, everything else — long literals, long or far matches, RLE literals — behind one
+    // not-taken branch. The general loop below, with its dozen exits, cost the consumer ~1400 cycles per sequence in register
+    // shuffling at its joins (measured with the cycle counter: it was the wave the page waited for).
+    if (__builtin_amdgcn_ballot_w64(w.lane < m && e.z == 0) == 0 && !(xmode & 1)) {
+#ifdef DBHIP_EXPERIMENTS
+      if (xwait) xwait[1] += m;
+#endif
+      const uint32_t lim = w.lit_kind != 2 ? w.WM - 127 : 0u;   // (RLE literals: no sequence takes the in-line form)
+#pragma clang loop unroll(disable)
+      for (uint32_t i = 0; i < m; ++i) {
+        const uint32_t ll = rdl(e.x, i), ml = rdl(e.y, i), ov = rdl(e.z, i);
+        uint32_t j = ov - 1 + (ll == 0 ? 1u : 0u);
+        j = ov > 3 ? 4u : j;
+        uint32_t off = ov - 3;
+        off = j == 0 ? r0 : off;
+        off = j == 1 ? r1 : off;
+        off = j == 2 ? r2 : off;
+        off = j == 3 ? r0 - 1 : off;
+        r2 = j >= 2 ? r1 : r2;
+        r1 = j >= 1 ? r0 : r1;
+        r0 = off;
+        bad = (off - 1u >= w.op_ - w.frame0 + ll) ? 1u : bad;
+        if (__builtin_expect(ll + ml <= 64, 1) && __builtin_expect(off <= lim, 1)) {
+          w.seq_small(ll, off, ml);
+        } else if (!bad) {               // (validated by the producer as far as sizes go: the unchecked forms)
+          if (ll) (void)w.put_lit<false>(ll);
+          (void)w.put_match<false>(off, ml);
+        }
+      }
+      head = rfl(head + m);
+      __hip_atomic_store(&q.ctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
+    }
     for (uint32_t i = 0; i < m; ++i) {
-      const uint32_t w0 = rdl(e.x, i), w1 = rdl(e.y, i), off = rdl(e.z, i), w3 = rdl(e.w, i);
-      if (off) {                       // a sequence: w0 literals, then w1 bytes from `off` back
-        if (w0) (void)w.put_seq(w0, off, w1);
-        else (void)w.put_match(off, w1);
+      const uint32_t w0 = rdl(e.x, i), w1 = rdl(e.y, i), ov = rdl(e.z, i), w3 = rdl(e.w, i);
+      if (ov) {                        // a sequence: w0 literals, then w1 bytes from an offset back
+        if (xmode & 1) continue;       // (experiments build only: xmode is 0 otherwise)
+        // repeat offsets (RFC 8878 3.1.1.5) as selects on j = 0..3 (a repeat code, shifted by one when there are no literals) / 4
+        // (a new offset): j = 0 offset r0, history unchanged; j = 1 r1, swapped to the front; j = 2 r2, j = 3 r0 - 1, j = 4 ov - 3
+        uint32_t j = ov - 1 + (w0 == 0 ? 1u : 0u);
+        j = ov > 3 ? 4u : j;
+        uint32_t off = ov - 3;
+        off = j == 0 ? r0 : off;
+        off = j == 1 ? r1 : off;
+        off = j == 2 ? r2 : off;
+        off = j == 3 ? r0 - 1 : off;
+        r2 = j >= 2 ? r1 : r2;
+        r1 = j >= 1 ? r0 : r1;
+        r0 = off;
+        // off == 0 or off > bytes of this frame written so far + the literals  <=>  off - 1 >= that sum (unsigned). From the first
+        // such sequence on nothing is executed any more (the queue is still drained: the producer must never wait for good)
+        bad = (off - 1u >= w.op_ - w.frame0 + w0) ? 1u : bad;
+        if (bad) continue;
+        if (w0 + w1 <= 64 && off <= w.WM - 127 && w.lit_kind != 2) {
+          w.seq_small(w0, off, w1);
+        } else {                       // (validated by the producer: the unchecked forms)
+          if (w0) (void)w.put_lit<false>(w0);
+          (void)w.put_match<false>(off, w1);
+        }
         continue;
       }
       const uint32_t cmd = w0 & 0xFF;
-      if (cmd == ZC_LIT) (void)w.put_lit(w1);
-      else if (cmd == ZC_LIT_BEGIN) w.lit_begin(w0 >> 8, w1, w3);
-      else if (cmd == ZC_IN) (void)w.put_in(w1, w3);
-      else if (cmd == ZC_FILL) (void)w.put_fill(w1, w3);
-      else {                           // ZC_END
+      if (cmd == ZC_END) {
         __hip_atomic_store(&q.ctl[1], head + m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return w1;
+        return bad && w1 == (uint32_t)zc::OK ? (uint32_t)zc::CORRUPT_ : w1;
       }
+      if (bad) continue;
+      if (cmd == ZC_LIT) (void)w.put_lit<false>(w1);
+      else if (cmd == ZC_LIT_BEGIN) w.lit_begin(w0 >> 8, w1, w3);
+      else if (cmd == ZC_IN) (void)w.put_in<false>(w1, w3);
+      else if (cmd == ZC_FILL) (void)w.put_fill<false>(w1, w3);
+      else if (cmd == ZC_FRAME) { w.frame0 = w.op_; r0 = 1; r1 = 4; r2 = 8; }   // back-references and the history do not reach across frames
     }
     head = rfl(head + m);
     __hip_atomic_store(&q.ctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

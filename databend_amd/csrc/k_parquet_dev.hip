@@ -71,6 +71,12 @@ __global__ __launch_bounds__(128) void dv_inflate_zstd2_kernel(const DvJob* __re
   const uint32_t raw = P.compressed ? lev : P.uncomp_len;
   for (uint32_t i = threadIdx.x; i < raw; i += 128) P.dst[i] = P.src[i];
   if (!P.compressed || P.uncomp_len == lev) return;
+#ifdef DBHIP_EXPERIMENTS
+  const uint32_t xmode = ring >> 24;   // DBHIP_PQ_ZSTD_X: 1 = the consumer drains the queue without executing (wrong output on purpose)
+  ring &= 0xFFFFFFu;
+#else
+  const uint32_t xmode = 0;
+#endif
   ZQueue Q;
   Q.slots = (u32x4q*)(dv_lds + ring + ZW_TABLES);
   Q.ctl = (uint32_t*)(dv_lds + ring + ZW_TABLES + ZQ_CAP * 16);
@@ -80,13 +86,30 @@ __global__ __launch_bounds__(128) void dv_inflate_zstd2_kernel(const DvJob* __re
     ZProd a;
     a.begin(P, dv_lds, ring, lane);
     a.qbegin(Q);
+#ifdef DBHIP_EXPERIMENTS
+    const uint64_t x_t0 = __builtin_readcyclecounter();
+#endif
     int rc = zc::decode_frames(a, a.in_len);
     if (rc == zc::OK && a.op_ != a.cap_) rc = zc::CORRUPT_;
     a.end((uint32_t)rc);
+#ifdef DBHIP_EXPERIMENTS
+    if ((xmode & 32) && blockIdx.x < 4 && lane == 0)
+      printf("zstd2 page %u (%u -> %u bytes): producer %llu cycles, of which waiting for the consumer %llu\n", blockIdx.x, P.comp_len, P.uncomp_len,
+             (unsigned long long)(__builtin_readcyclecounter() - x_t0), (unsigned long long)a.x_wait);
+#endif
   } else {
     ZWave b;
     b.begin(P, dv_lds, ring, lane);
-    const int rc = (int)zq_consume(b, Q);
+#ifdef DBHIP_EXPERIMENTS
+    const uint64_t x_t0 = __builtin_readcyclecounter();
+    uint64_t x_cw[3] = {0, 0, 0};
+    const int rc = (int)zq_consume(b, Q, xmode, x_cw);
+    if ((xmode & 32) && blockIdx.x < 4 && lane == 0)
+      printf("zstd2 page %u: consumer %llu cycles, of which waiting for commands %llu; %llu sequences in straight batches, flushes in front of them %llu cycles\n", blockIdx.x,
+             (unsigned long long)(__builtin_readcyclecounter() - x_t0), (unsigned long long)x_cw[0], (unsigned long long)x_cw[1], (unsigned long long)x_cw[2]);
+#else
+    const int rc = (int)zq_consume(b, Q, xmode);
+#endif
     b.flush(true);
     if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
   }
@@ -971,7 +994,10 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   // (two waves per page — parse | copy — unless DBHIP_PQ_ZSTD_WAVES=1 asks for the one-wave kernel)
   static const bool z_one_wave = exp_env("DBHIP_PQ_ZSTD_WAVES") && atoi(exp_env("DBHIP_PQ_ZSTD_WAVES")) == 1;
   if (n_z && z_one_wave) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
-  else if (n_z) hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring);
+  else if (n_z) {
+    static const uint32_t z_x = exp_env("DBHIP_PQ_ZSTD_X") ? (uint32_t)atoi(exp_env("DBHIP_PQ_ZSTD_X")) << 24 : 0u;
+    hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring | z_x);
+  }
   if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), lz_ring, s, d_jobs + n_z, lz_ring);
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
   if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));

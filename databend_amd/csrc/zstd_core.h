@@ -33,6 +33,9 @@
 #define ZC_CONST static const
 #endif
 
+#define ZC_LIKELY(x) __builtin_expect(!!(x), 1)
+#define ZC_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 namespace zc {
 
 enum { OK = 0, CORRUPT_ = 1, UNSUPPORTED = 2 };
@@ -484,76 +487,96 @@ ZC_FN int seq_table(W& w, uint32_t mode, uint32_t& al, uint32_t& tag, uint32_t& 
   return OK;
 }
 
-// The sequences of one block: the backward bitstream at input [p, p + len), nseq > 0 sequences, accuracy logs packed as
-// ll | of << 4 | ml << 8, the repeat offsets in and out. Everything the loop touches goes through W: in8 / in64 / in64_back (the
-// bitstream), llt / mlt / oft (the tables), seq (one decoded sequence).
+// What the sequence loop carries from one sequence to the next
 template <class W>
-ZC_FN int seq_loop(W& w, uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0_, uint32_t& r1_, uint32_t& r2_) {
-  const uint32_t ll_al = als & 15, of_al = (als >> 4) & 15, ml_al = (als >> 8) & 15;
+struct SeqState {
   SeqBits<W> bs;
-  if (!bs.init(w, p, len)) return CORRUPT;
-  bs.refill(w);
-  if (bs.left() < (int32_t)(ll_al + of_al + ml_al)) return CORRUPT;
-  uint32_t ls = bs.read(ll_al), os = bs.read(of_al), ms = bs.read(ml_al);   // <= 26 bits
-  const uint64_t* LLT = w.llt();
-  const uint64_t* MLT = w.mlt();
-  const uint32_t* OFT = w.oft();
-  uint32_t r0 = r0_, r1 = r1_, r2 = r2_;
-  // the table entries of a sequence are read (LDS) while the sequence before it is validated and queued / copied
-  uint64_t le_raw = LLT[ls], me_raw = MLT[ms];
-  uint32_t oe_raw = OFT[os];
-  for (uint32_t left = nseq; left != 0; --left) {
-    const uint64_t le = w.uni64(le_raw), me = w.uni64(me_raw);
-    const uint32_t oe = w.uni(oe_raw);
-    // every width of this sequence is in the three entries: offset code, extra bits of the match / literals length, and — between
-    // sequences — the bits of the three state updates (literals length, match length, offset: 3.1.1.3.2.1.1)
-    const uint32_t ocode = oe >> 24, mlb = (uint32_t)(me >> 24) & 0xFF, llb = (uint32_t)(le >> 24) & 0xFF;
-    const uint32_t upd = left != 1 ? 0xFFu : 0u;
-    const uint32_t lnb = ((uint32_t)le >> 16) & upd, mnb = ((uint32_t)me >> 16) & upd, onb = (oe >> 16) & upd;
-    const uint32_t tot = ocode + mlb + llb + lnb + mnb + onb;   // <= 31 + 16 + 16 + 26
-    if (bs.have < (int32_t)tot) {
-      bs.refill_back(w);
-      if (bs.left() < (int32_t)tot) return CORRUPT_STRICT;   // (libzstd < 1.5 reads zeros past the start and only checks the end; 1.5.7 checks for the exact end)
-    }
-    uint32_t ofx, mlx, llx, lsx, msx, osx;
-    if (bs.have >= (int32_t)tot) {
-      ofx = bs.read(ocode); mlx = bs.read(mlb); llx = bs.read(llb);
-      lsx = bs.read(lnb); msx = bs.read(mnb); osx = bs.read(onb);
-    } else {
-      // more than 56 bits in one sequence (an offset code above ~14 together with long length codes): field by field
+  uint64_t le_raw, me_raw;   // the table entries of the coming sequence, as read (LDS) while the sequence before it was executed
+  uint32_t oe_raw;
+  uint32_t r0, r1, r2;       // repeat offsets
+};
+
+// ONE sequence. LAST: the last one of the block, which has no state updates behind its fields (3.1.1.3.2.1.1) — a copy of its own,
+// so that the loop over the others carries no test for it.
+template <class W, bool LAST>
+ZC_FN int seq_one(W& w, SeqState<W>& S) {
+  SeqBits<W>& bs = S.bs;
+  const uint64_t le = w.uni64(S.le_raw), me = w.uni64(S.me_raw);
+  const uint32_t oe = w.uni(S.oe_raw);
+  // every width of this sequence is in the three entries: offset code, extra bits of the match / literals length, and — between
+  // sequences — the bits of the three state updates (literals length, match length, offset)
+  const uint32_t ocode = oe >> 24, mlb = (uint32_t)(me >> 24) & 0xFF, llb = (uint32_t)(le >> 24) & 0xFF;
+  const uint32_t lnb = LAST ? 0u : ((uint32_t)le >> 16) & 0xFF, mnb = LAST ? 0u : ((uint32_t)me >> 16) & 0xFF, onb = LAST ? 0u : (oe >> 16) & 0xFF;
+  const uint32_t tot = ocode + mlb + llb + lnb + mnb + onb;   // <= 31 + 16 + 16 + 26
+  if (ZC_UNLIKELY(bs.have < (int32_t)tot)) {
+    bs.refill_back(w);
+    if (bs.left() < (int32_t)tot) return CORRUPT_STRICT;   // (libzstd < 1.5 reads zeros past the start and only checks the end; 1.5.7 checks for the exact end)
+  }
+  uint32_t ofx, mlx, llx, lsx = 0, msx = 0, osx = 0;
+  if (ZC_LIKELY(bs.have >= (int32_t)tot)) {
+    ofx = bs.read(ocode); mlx = bs.read(mlb); llx = bs.read(llb);
+    if (!LAST) { lsx = bs.read(lnb); msx = bs.read(mnb); osx = bs.read(onb); }
+  } else {
+    // more than 56 bits in one sequence (an offset code above ~14 together with long length codes): field by field
 #if defined(ZC_TRACE)
-      zc_trace_wide();
+    zc_trace_wide();
 #endif
-      ofx = bs.read(ocode);
-      bs.refill_back(w);
-      mlx = bs.read(mlb); llx = bs.read(llb);
-      bs.refill_back(w);
-      lsx = bs.read(lnb); msx = bs.read(mnb); osx = bs.read(onb);
-    }
-    const uint32_t ov = (1u << ocode) + ofx;
-    const uint32_t ml = (uint32_t)(me >> 32) + mlx;
-    const uint32_t ll = (uint32_t)(le >> 32) + llx;
-    ls = ((uint32_t)le & 0xFFFF) + lsx;
-    ms = ((uint32_t)me & 0xFFFF) + msx;
-    os = (oe & 0xFFFF) + osx;
-    le_raw = LLT[ls]; me_raw = MLT[ms]; oe_raw = OFT[os];   // (after the last sequence: the entries at the states' bases, unused)
+    ofx = bs.read(ocode);
+    bs.refill_back(w);
+    mlx = bs.read(mlb); llx = bs.read(llb);
+    bs.refill_back(w);
+    if (!LAST) { lsx = bs.read(lnb); msx = bs.read(mnb); osx = bs.read(onb); }
+  }
+  const uint32_t ov = (1u << ocode) + ofx;
+  const uint32_t ml = (uint32_t)(me >> 32) + mlx;
+  const uint32_t ll = (uint32_t)(le >> 32) + llx;
+  if (!LAST) {
+    S.le_raw = w.ll_at(((uint32_t)le & 0xFFFF) + lsx);
+    S.me_raw = w.ml_at(((uint32_t)me & 0xFFFF) + msx);
+    S.oe_raw = w.of_at((oe & 0xFFFF) + osx);
+  }
+  if constexpr (W::RESOLVES_OFFSETS) {
+    // (the two-wave producer sends the offset VALUE: its consumer keeps the repeat-offset history and checks the reach)
+    return w.seq_raw(ll, ov, ml) ? OK : CORRUPT;
+  } else {
     // repeat offsets (3.1.1.5) as selects on j = 0..3 (a repeat code, shifted by one when there are no literals) / 4 (a new offset):
     //   j = 0 offset r0, history unchanged; j = 1 r1, swapped to the front; j = 2 r2, j = 3 r0 - 1, j = 4 ov - 3: pushed to the front
     uint32_t j = ov - 1 + (ll == 0 ? 1u : 0u);
     j = ov > 3 ? 4u : j;
     uint32_t off = ov - 3;
-    off = j == 0 ? r0 : off;
-    off = j == 1 ? r1 : off;
-    off = j == 2 ? r2 : off;
-    off = j == 3 ? r0 - 1 : off;
-    r2 = j >= 2 ? r1 : r2;
-    r1 = j >= 1 ? r0 : r1;
-    r0 = off;
+    off = j == 0 ? S.r0 : off;
+    off = j == 1 ? S.r1 : off;
+    off = j == 2 ? S.r2 : off;
+    off = j == 3 ? S.r0 - 1 : off;
+    S.r2 = j >= 2 ? S.r1 : S.r2;
+    S.r1 = j >= 1 ? S.r0 : S.r1;
+    S.r0 = off;
     // execute (a W refuses an offset of 0 — r0 - 1 with r0 = 1 — and literals past the block's; it may do so a few sequences late)
-    if (!w.seq(ll, off, ml)) return CORRUPT;
+    return w.seq(ll, off, ml) ? OK : CORRUPT;
   }
-  r0_ = r0; r1_ = r1; r2_ = r2;
-  if (bs.left() != 0) return CORRUPT_STRICT;   // every bit of the stream belongs to a sequence
+}
+
+// The sequences of one block: the backward bitstream at input [p, p + len), nseq > 0 sequences, accuracy logs packed as
+// ll | of << 4 | ml << 8, the repeat offsets in and out. Everything the loop touches goes through W: in8 / in64 / in64_back (the
+// bitstream), ll_at / ml_at / of_at (the tables), seq or seq_raw (one decoded sequence).
+template <class W>
+ZC_FN int seq_loop(W& w, uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0_, uint32_t& r1_, uint32_t& r2_) {
+  const uint32_t ll_al = als & 15, of_al = (als >> 4) & 15, ml_al = (als >> 8) & 15;
+  SeqState<W> S;
+  if (!S.bs.init(w, p, len)) return CORRUPT;
+  S.bs.refill(w);
+  if (S.bs.left() < (int32_t)(ll_al + of_al + ml_al)) return CORRUPT;
+  const uint32_t ls = S.bs.read(ll_al), os = S.bs.read(of_al), ms = S.bs.read(ml_al);   // <= 26 bits
+  S.r0 = r0_; S.r1 = r1_; S.r2 = r2_;
+  S.le_raw = w.ll_at(ls); S.me_raw = w.ml_at(ms); S.oe_raw = w.of_at(os);
+  for (uint32_t left = nseq; left > 1; --left) {
+    const int rc = seq_one<W, false>(w, S);
+    if (rc) return rc;
+  }
+  const int rc = seq_one<W, true>(w, S);
+  if (rc) return rc;
+  r0_ = S.r0; r1_ = S.r1; r2_ = S.r2;
+  if (S.bs.left() != 0) return CORRUPT_STRICT;   // every bit of the stream belongs to a sequence
   return OK;
 }
 

@@ -21,6 +21,8 @@ static void zc_trace_wide() { ++g_wide_sequences; }
 #include "../databend_amd/csrc/zstd_core.h"
 
 struct HostWave {
+  static constexpr bool RESOLVES_OFFSETS = false;
+  bool seq_raw(uint32_t, uint32_t, uint32_t) { return false; }
   const uint8_t* in;
   uint32_t in_len;
   std::vector<uint8_t> out;
@@ -39,6 +41,9 @@ struct HostWave {
   uint64_t* llt() { return llt_; }
   uint64_t* mlt() { return mlt_; }
   uint32_t* oft() { return oft_; }
+  uint64_t ll_at(uint32_t st) const { return llt_[st]; }
+  uint64_t ml_at(uint32_t st) const { return mlt_[st]; }
+  uint32_t of_at(uint32_t st) const { return oft_[st]; }
   uint8_t* scr() { return scr_; }
   int sequences(uint32_t p, uint32_t len, uint32_t nseq, uint32_t als, uint32_t& r0, uint32_t& r1, uint32_t& r2) {
     return zc::seq_loop(*this, p, len, nseq, als, r0, r1, r2);
