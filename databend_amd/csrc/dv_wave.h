@@ -53,6 +53,8 @@ __device__ __forceinline__ uint32_t guarded32(const uint8_t* gA, uint32_t o, uin
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// v of lane `l` (per-lane l; only its low six bits count)
+__device__ __forceinline__ uint32_t bperm(uint32_t l, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)v); }
 
 // A FORWARD stream of global bytes read through two 256-byte chunks held in registers (chunk k = bytes [256 k, 256 k + 256) from the
 // 4-byte aligned address gA; the chunk after it is loaded when the stream enters chunk k, i.e. one chunk ahead of its use).
@@ -729,20 +731,30 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
 #endif
     const uint32_t m = rfl(tail - head < 64 ? tail - head : 64);
     const u32x4q e = q.slots[(head + (w.lane < m ? w.lane : 0)) & (ZQ_CAP - 1)];
-    // THE COMMON BATCH: nothing but sequences. It runs as one straight loop: no command dispatch, the repeat-offset history and the
-    // reach test as selects (an offset that fails the test still reads and writes inside the ring when the sequence fits the wave;
-    // anything else is skipped from there on, the page is reported malformed at the end), the sequence that fits the wave with its
-    // source in the ring (seq_small) in line, everything else — long literals, long or far matches, RLE literals — behind one
-    // not-taken branch. The general loop below, with its dozen exits, cost the consumer ~1400 cycles per sequence in register
-    // shuffling at its joins (measured with the cycle counter: it was the wave the page waited for).
+    // THE COMMON BATCH: nothing but sequences — replayed BY THE BYTE, not by the sequence (round 6). One sequence per step is a chain
+    // of LDS round trips (ring read -> literal permute -> ring write, ~1 200 cycles each with the CU's other waves in the way: the
+    // consumer was the wave the page waited for, `profiles/r06_pq_device_zstd_waves.txt`); the sequences of TPC-H's decimal pages are
+    // 8 bytes long, so a step of 64 lanes has room for eight of them. Three phases:
+    //   A  the repeat-offset history, the only thing that is serial: one scalar pass over the batch, no memory access; the resolved
+    //      offset of sequence i lands in lane i.
+    //   B  two wave scans over the batch (lane i = sequence i): where its output starts / ends, where its literals start. The reach
+    //      test (offset <= bytes of the frame before the match) is then one vector compare; a batch that fails it is not executed
+    //      at all — the page is reported malformed, what its image holds does not matter.
+    //   C  the output of the batch, 64 bytes per step, one lane per byte: the lane finds its sequence (the scalar end positions of the
+    //      few sequences that touch the step against its own position), takes the sequence's fields with ds_bpermute and is either a
+    //      literal (its byte comes out of the stream's register window) or a match byte `off` back: in the ring (written by an
+    //      earlier step), in the image (far offsets) or — the source is a byte of this very step — another lane, followed by pointer
+    //      jumping (<= 6 rounds; none when no match of the step reaches into the step itself).
+    // Any sequence length and any offset takes this path: a long match is simply many steps of one sequence.
     if (__builtin_amdgcn_ballot_w64(w.lane < m && e.z == 0) == 0 && !(xmode & 1)) {
 #ifdef DBHIP_EXPERIMENTS
       if (xwait) xwait[1] += m;
 #endif
-      const uint32_t lim = w.lit_kind != 2 ? w.WM - 127 : 0u;   // (RLE literals: no sequence takes the in-line form)
+      // ---- A
+      uint32_t offv = 0;
 #pragma clang loop unroll(disable)
       for (uint32_t i = 0; i < m; ++i) {
-        const uint32_t ll = rdl(e.x, i), ml = rdl(e.y, i), ov = rdl(e.z, i);
+        const uint32_t ll = rdl(e.x, i), ov = rdl(e.z, i);
         uint32_t j = ov - 1 + (ll == 0 ? 1u : 0u);
         j = ov > 3 ? 4u : j;
         uint32_t off = ov - 3;
@@ -753,13 +765,72 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
         r2 = j >= 2 ? r1 : r2;
         r1 = j >= 1 ? r0 : r1;
         r0 = off;
-        bad = (off - 1u >= w.op_ - w.frame0 + ll) ? 1u : bad;
-        if (__builtin_expect(ll + ml <= 64, 1) && __builtin_expect(off <= lim, 1)) {
-          w.seq_small(ll, off, ml);
-        } else if (!bad) {               // (validated by the producer as far as sizes go: the unchecked forms)
-          if (ll) (void)w.put_lit<false>(ll);
-          (void)w.put_match<false>(off, ml);
+        offv = w.lane == i ? off : offv;
+      }
+      // ---- B
+      const bool act = w.lane < m;
+      const uint32_t llv = act ? e.x : 0u, lenv = act ? e.x + e.y : 0u;   // (a sequence is < 2^18 bytes: no overflow over 64 of them)
+      uint32_t Ei = lenv, Li = llv;                                        // inclusive scans
+#pragma unroll
+      for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t pe = bperm(w.lane - d, Ei), pl = bperm(w.lane - d, Li);
+        Ei += w.lane >= d ? pe : 0u;
+        Li += w.lane >= d ? pl : 0u;
+      }
+      const uint32_t Sx = Ei - lenv, Lx = Li - llv;
+      const uint32_t T = rdl(Ei, 63), TL = rdl(Li, 63);
+      // off == 0 or off > bytes of this frame written before the match  <=>  off - 1 >= that count (unsigned)
+      if (__builtin_amdgcn_ballot_w64(act && offv - 1u >= w.op_ - w.frame0 + Sx + llv) != 0) bad = 1;
+      // ---- C
+      if (!bad) {
+        const uint32_t lit_base = w.lit_at, lim = w.WM - 127;
+#pragma clang loop unroll(disable)
+        for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+          const uint32_t n = T - c0 < 64 ? T - c0 : 64;
+          const uint32_t b = c0 + w.lane;
+          const bool live = w.lane < n;
+          // the sequences that touch this step: f .. g - 1 (those before f ended at or before c0, those from g on start behind it)
+          const uint32_t f = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && Ei <= c0));
+          const uint32_t g = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && Sx < c0 + n));
+          uint32_t idx = f;
+#pragma clang loop unroll(disable)
+          for (uint32_t k = f; k + 1 < g; ++k) idx += b >= rdl(Ei, k) ? 1u : 0u;
+          const uint32_t Si = bperm(idx, Sx), Lxi = bperm(idx, Lx), lli = bperm(idx, llv), offi = bperm(idx, offv);
+          const uint32_t kk = b - Si;            // byte of the sequence
+          const bool isl = kk < lli;
+          const uint32_t lidx = Lxi + kk;        // a literal lane: which literal of the batch
+          uint32_t from_lit = w.lit_at;          // (RLE literals: lit_at is the byte)
+          const uint64_t lmask = __builtin_amdgcn_ballot_w64(live && isl);
+          if (lmask != 0 && w.lit_kind != 2) {
+            // the literals of a step are consecutive bytes of the stream: the first literal lane holds the lowest index
+            const uint32_t la0 = lit_base + rdl(lidx, (uint32_t)__builtin_ctzll(lmask));
+            w.lit.seek(la0);
+            from_lit = w.lit.lane_byte_at(la0, (lit_base + lidx - la0) & 63u, (uint32_t)__builtin_popcountll(lmask));
+          }
+          const bool ism = live && !isl;
+          const bool inch = ism && offi <= w.lane;     // the source is a byte of this very step (lane - offi)
+          const bool far = ism && offi > lim;          // the source left the ring: it is in the image, flushed long ago (see put_match)
+          uint32_t from_out = w.win[(w.op_ + w.lane - offi + w.sh) & w.WM];
+          if (__builtin_amdgcn_ballot_w64(far) != 0) {
+            w.wait_stores();
+            if (far) from_out = gload8(w.dst + w.op_ + w.lane - offi);
+          }
+          uint32_t v = isl ? from_lit : from_out;
+          if (__builtin_amdgcn_ballot_w64(inch) != 0) {
+            uint32_t pend = inch ? 1u : 0u, sl = w.lane - offi;
+            while (__builtin_amdgcn_ballot_w64(pend != 0) != 0) {
+              const uint32_t pv = bperm(sl, v), pp = bperm(sl, pend), ps = bperm(sl, sl);
+              v = (pend && !pp) ? pv : v;
+              sl = (pend && pp) ? ps : sl;
+              pend = (pend && !pp) ? 0u : pend;
+            }
+          }
+          if (live) w.win[(w.op_ + w.lane + w.sh) & w.WM] = (uint8_t)v;
+          __builtin_amdgcn_wave_barrier();
+          w.advance(n);
         }
+        if (w.lit_kind != 2) w.lit_at = rfl(lit_base + TL);
+        w.lit_left -= TL;
       }
       head = rfl(head + m);
       __hip_atomic_store(&q.ctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
