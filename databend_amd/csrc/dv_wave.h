@@ -390,6 +390,102 @@ struct ZWave {
     advance(lit + mlen);
   }
 
+  // A BATCH OF m <= 64 SEQUENCES REPLAYED BY THE BYTE (round 6). Lane i < m holds sequence i: `ll` literals, then `ml` bytes from `off`
+  // back (off resolved; ml may be 0, then off is not looked at as long as it is 1). Its literals are bytes of the stream `ls`:
+  //   SCAN_LITS  the batch's literals follow each other from `lp` (uniform) on — a ZSTD block; `rle`: they are all the byte `lp`;
+  //   otherwise  [lp, lp + ll) per lane — LZ4 / Snappy, whose literals lie between the tokens.
+  // The caller has checked that the batch fits the page and that the literals exist, and keeps the batch's output below 2^31 bytes.
+  // One sequence per step is a chain of LDS round trips (ring read -> literal permute -> ring write: ~1 200 cycles each with the CU's
+  // other waves in the way); the sequences of TPC-H's decimal pages are 8 bytes long, so a step of 64 lanes has room for eight of them:
+  //   B  wave scans over the batch: where a sequence's output starts / ends (where its literals start). The reach test (offset <=
+  //      bytes of the frame before the match) is one vector compare; a batch that fails it is not executed at all (-> false: the
+  //      page is malformed, what its image holds does not matter).
+  //   C  the output of the batch, 64 bytes per step, one lane per byte: the lane finds its sequence (the scalar end positions of the
+  //      few sequences that touch the step against its own position), takes the sequence's fields with ds_bpermute and is either a
+  //      literal (its byte comes out of the stream's register window) or a match byte `off` back: in the ring (written by an
+  //      earlier step), in the image (far offsets) or — the source is a byte of this very step — another lane, followed by pointer
+  //      jumping (<= 6 rounds; none when no match of the step reaches into the step itself).
+  // Any sequence length and any offset takes this path: a long match is simply many steps of one sequence.
+  template <bool SCAN_LITS>
+  __device__ __forceinline__ bool replay(FwdStream& ls, uint32_t m, uint32_t ll, uint32_t ml, uint32_t off, uint32_t lp, bool rle, uint32_t& lits_total) {
+    // ---- B
+    const bool act = lane < m;
+    const uint32_t llv = act ? ll : 0u, lenv = act ? ll + ml : 0u;
+    uint32_t Ei = lenv, Li = llv;                                        // inclusive scans
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t pe = bperm(lane - d, Ei);
+      Ei += lane >= d ? pe : 0u;
+      if (SCAN_LITS) {
+        const uint32_t pl = bperm(lane - d, Li);
+        Li += lane >= d ? pl : 0u;
+      }
+    }
+    const uint32_t Sx = Ei - lenv;
+    const uint32_t Lx = SCAN_LITS ? (rle ? 0u : lp + Li - llv) : lp;     // where the sequence's literals start (from ls.gA)
+    const uint32_t T = rdl(Ei, 63);
+    if (SCAN_LITS) lits_total = rdl(Li, 63);
+    // off == 0 or off > bytes of this frame written before the match  <=>  off - 1 >= that count (unsigned)
+    if (__builtin_amdgcn_ballot_w64(act && off - 1u >= op_ - frame0 + Sx + llv) != 0) return false;
+    // ---- C
+    const uint32_t lim = WM - 127;
+#pragma clang loop unroll(disable)
+    for (uint32_t c0 = 0; c0 < T; c0 += 64) {
+      const uint32_t n = T - c0 < 64 ? T - c0 : 64;
+      const uint32_t b = c0 + lane;
+      const bool live = lane < n;
+      // the sequences that touch this step: f .. g - 1 (those before f ended at or before c0, those from g on start behind it)
+      const uint32_t f = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && Ei <= c0));
+      const uint32_t g = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && Sx < c0 + n));
+      uint32_t idx = f;
+#pragma clang loop unroll(disable)
+      for (uint32_t k = f; k + 1 < g; ++k) idx += b >= rdl(Ei, k) ? 1u : 0u;
+      const uint32_t Si = bperm(idx, Sx), Lxi = bperm(idx, Lx), lli = bperm(idx, llv), offi = bperm(idx, off);
+      const uint32_t kk = b - Si;            // byte of the sequence
+      const bool isl = live && kk < lli;
+      const uint32_t lidx = Lxi + kk;        // a literal lane: its byte of the stream
+      uint32_t from_lit = lp;                // (RLE literals: lp is the byte)
+      uint64_t lmask = __builtin_amdgcn_ballot_w64(isl);
+      if (!(SCAN_LITS && rle)) {
+        // the literals of a step lie in stream order: the first literal lane holds the lowest position, the last one the highest; between
+        // them lie, besides literals, only the tokens of the sequences that start in the step — one window of 256 bytes from the first
+        // position on holds them all for whatever an encoder writes (a Snappy stream of one-byte literals with five-byte headers is
+        // legal, though: the loop takes as many windows as it needs)
+        while (lmask != 0) {
+          const uint32_t la0 = rdl(lidx, (uint32_t)__builtin_ctzll(lmask));
+          const uint32_t reach = rdl(lidx, 63u - (uint32_t)__builtin_clzll(lmask)) - la0 + 1;
+          const bool now = isl && lidx - la0 < 256u;
+          ls.seek(la0);
+          const uint32_t x = ls.lane_byte_at(la0, (lidx - la0) & 255u, reach < 256u ? reach : 256u);
+          from_lit = now ? x : from_lit;
+          lmask &= ~__builtin_amdgcn_ballot_w64(now);
+        }
+      }
+      const bool ism = live && !isl;
+      const bool inch = ism && offi <= lane;     // the source is a byte of this very step (lane - offi)
+      const bool far = ism && offi > lim;        // the source left the ring: it is in the image, flushed long ago (see put_match)
+      uint32_t from_out = win[(op_ + lane - offi + sh) & WM];
+      if (__builtin_amdgcn_ballot_w64(far) != 0) {
+        wait_stores();
+        if (far) from_out = gload8(dst + op_ + lane - offi);
+      }
+      uint32_t v = isl ? from_lit : from_out;
+      if (__builtin_amdgcn_ballot_w64(inch) != 0) {
+        uint32_t pend = inch ? 1u : 0u, sl = lane - offi;
+        while (__builtin_amdgcn_ballot_w64(pend != 0) != 0) {
+          const uint32_t pv = bperm(sl, v), pp = bperm(sl, pend), ps = bperm(sl, sl);
+          v = (pend && !pp) ? pv : v;
+          sl = (pend && pp) ? ps : sl;
+          pend = (pend && !pp) ? 0u : pend;
+        }
+      }
+      if (live) win[(op_ + lane + sh) & WM] = (uint8_t)v;
+      __builtin_amdgcn_wave_barrier();
+      advance(n);
+    }
+    return true;
+  }
+
   template <bool CK = true>
   __device__ __forceinline__ bool put_match(uint32_t off, uint32_t len) {
     if (CK && (off == 0 || off > op_ - frame0 || len > cap_ - op_)) return false;
@@ -731,21 +827,9 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
 #endif
     const uint32_t m = rfl(tail - head < 64 ? tail - head : 64);
     const u32x4q e = q.slots[(head + (w.lane < m ? w.lane : 0)) & (ZQ_CAP - 1)];
-    // THE COMMON BATCH: nothing but sequences — replayed BY THE BYTE, not by the sequence (round 6). One sequence per step is a chain
-    // of LDS round trips (ring read -> literal permute -> ring write, ~1 200 cycles each with the CU's other waves in the way: the
-    // consumer was the wave the page waited for, `profiles/r06_pq_device_zstd_waves.txt`); the sequences of TPC-H's decimal pages are
-    // 8 bytes long, so a step of 64 lanes has room for eight of them. Three phases:
-    //   A  the repeat-offset history, the only thing that is serial: one scalar pass over the batch, no memory access; the resolved
-    //      offset of sequence i lands in lane i.
-    //   B  two wave scans over the batch (lane i = sequence i): where its output starts / ends, where its literals start. The reach
-    //      test (offset <= bytes of the frame before the match) is then one vector compare; a batch that fails it is not executed
-    //      at all — the page is reported malformed, what its image holds does not matter.
-    //   C  the output of the batch, 64 bytes per step, one lane per byte: the lane finds its sequence (the scalar end positions of the
-    //      few sequences that touch the step against its own position), takes the sequence's fields with ds_bpermute and is either a
-    //      literal (its byte comes out of the stream's register window) or a match byte `off` back: in the ring (written by an
-    //      earlier step), in the image (far offsets) or — the source is a byte of this very step — another lane, followed by pointer
-    //      jumping (<= 6 rounds; none when no match of the step reaches into the step itself).
-    // Any sequence length and any offset takes this path: a long match is simply many steps of one sequence.
+    // THE COMMON BATCH: nothing but sequences — replayed BY THE BYTE, not by the sequence (ZWave::replay; one sequence per step made the
+    // consumer the wave the page waited for). What is left to do here is the only serial part, phase A: the repeat-offset history
+    // (RFC 8878 3.1.1.5) as one scalar pass over the batch without a memory access; the resolved offset of sequence i lands in lane i.
     if (__builtin_amdgcn_ballot_w64(w.lane < m && e.z == 0) == 0 && !(xmode & 1)) {
 #ifdef DBHIP_EXPERIMENTS
       if (xwait) xwait[1] += m;
@@ -767,70 +851,14 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
         r0 = off;
         offv = w.lane == i ? off : offv;
       }
-      // ---- B
-      const bool act = w.lane < m;
-      const uint32_t llv = act ? e.x : 0u, lenv = act ? e.x + e.y : 0u;   // (a sequence is < 2^18 bytes: no overflow over 64 of them)
-      uint32_t Ei = lenv, Li = llv;                                        // inclusive scans
-#pragma unroll
-      for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t pe = bperm(w.lane - d, Ei), pl = bperm(w.lane - d, Li);
-        Ei += w.lane >= d ? pe : 0u;
-        Li += w.lane >= d ? pl : 0u;
-      }
-      const uint32_t Sx = Ei - lenv, Lx = Li - llv;
-      const uint32_t T = rdl(Ei, 63), TL = rdl(Li, 63);
-      // off == 0 or off > bytes of this frame written before the match  <=>  off - 1 >= that count (unsigned)
-      if (__builtin_amdgcn_ballot_w64(act && offv - 1u >= w.op_ - w.frame0 + Sx + llv) != 0) bad = 1;
-      // ---- C
+      // ---- B, C
       if (!bad) {
-        const uint32_t lit_base = w.lit_at, lim = w.WM - 127;
-#pragma clang loop unroll(disable)
-        for (uint32_t c0 = 0; c0 < T; c0 += 64) {
-          const uint32_t n = T - c0 < 64 ? T - c0 : 64;
-          const uint32_t b = c0 + w.lane;
-          const bool live = w.lane < n;
-          // the sequences that touch this step: f .. g - 1 (those before f ended at or before c0, those from g on start behind it)
-          const uint32_t f = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && Ei <= c0));
-          const uint32_t g = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(act && Sx < c0 + n));
-          uint32_t idx = f;
-#pragma clang loop unroll(disable)
-          for (uint32_t k = f; k + 1 < g; ++k) idx += b >= rdl(Ei, k) ? 1u : 0u;
-          const uint32_t Si = bperm(idx, Sx), Lxi = bperm(idx, Lx), lli = bperm(idx, llv), offi = bperm(idx, offv);
-          const uint32_t kk = b - Si;            // byte of the sequence
-          const bool isl = kk < lli;
-          const uint32_t lidx = Lxi + kk;        // a literal lane: which literal of the batch
-          uint32_t from_lit = w.lit_at;          // (RLE literals: lit_at is the byte)
-          const uint64_t lmask = __builtin_amdgcn_ballot_w64(live && isl);
-          if (lmask != 0 && w.lit_kind != 2) {
-            // the literals of a step are consecutive bytes of the stream: the first literal lane holds the lowest index
-            const uint32_t la0 = lit_base + rdl(lidx, (uint32_t)__builtin_ctzll(lmask));
-            w.lit.seek(la0);
-            from_lit = w.lit.lane_byte_at(la0, (lit_base + lidx - la0) & 63u, (uint32_t)__builtin_popcountll(lmask));
-          }
-          const bool ism = live && !isl;
-          const bool inch = ism && offi <= w.lane;     // the source is a byte of this very step (lane - offi)
-          const bool far = ism && offi > lim;          // the source left the ring: it is in the image, flushed long ago (see put_match)
-          uint32_t from_out = w.win[(w.op_ + w.lane - offi + w.sh) & w.WM];
-          if (__builtin_amdgcn_ballot_w64(far) != 0) {
-            w.wait_stores();
-            if (far) from_out = gload8(w.dst + w.op_ + w.lane - offi);
-          }
-          uint32_t v = isl ? from_lit : from_out;
-          if (__builtin_amdgcn_ballot_w64(inch) != 0) {
-            uint32_t pend = inch ? 1u : 0u, sl = w.lane - offi;
-            while (__builtin_amdgcn_ballot_w64(pend != 0) != 0) {
-              const uint32_t pv = bperm(sl, v), pp = bperm(sl, pend), ps = bperm(sl, sl);
-              v = (pend && !pp) ? pv : v;
-              sl = (pend && pp) ? ps : sl;
-              pend = (pend && !pp) ? 0u : pend;
-            }
-          }
-          if (live) w.win[(w.op_ + w.lane + w.sh) & w.WM] = (uint8_t)v;
-          __builtin_amdgcn_wave_barrier();
-          w.advance(n);
+        uint32_t TL = 0;
+        if (!w.replay<true>(w.lit, m, e.x, e.y, offv, w.lit_at, w.lit_kind == 2, TL)) bad = 1;
+        else {
+          if (w.lit_kind != 2) w.lit_at = rfl(w.lit_at + TL);
+          w.lit_left -= TL;
         }
-        if (w.lit_kind != 2) w.lit_at = rfl(lit_base + TL);
-        w.lit_left -= TL;
       }
       head = rfl(head + m);
       __hip_atomic_store(&q.ctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -888,6 +916,10 @@ constexpr uint32_t LZ_RING = 8192;                          // LZ4 / Snappy: rin
 // LZ4 block format (lz4_Block_format.md) and Snappy raw format (format_description.txt) on the same wave: the payload is ONE forward
 // stream — tokens / tags are read from its register chunks (scalar), literals move from the chunks to the ring.
 // ---------------------------------------------------------------------------------------------
+// (Round 6 tried the ZSTD consumer's byte-parallel replay here too — parse up to 64 sequences ahead into lane registers, then
+// ZWave::replay<false> with the literals' payload positions per sequence; parity green, LZ4 14.2 -> 14.9 ms, Snappy 16.1 -> 21.4 ms on
+// the 7-column set: with 20 one-wave pages per CU the LDS round trips of pair_small are hidden by the other waves and the
+// INSTRUCTION COUNT rules, and the parse-ahead loop compiled to ~110 instructions per sequence, as many as the whole r05 loop. Taken out.)
 // -> false: malformed
 __device__ __forceinline__ bool lz4_block(ZWave& w, FwdStream& in) {
   uint32_t p = 0;
