@@ -573,10 +573,14 @@ struct ZWave {
 // One rendezvous per block: Huffman literals are decoded into the TAIL of the page's output region, where the previous block's
 // literals may still be waiting to be consumed, so the producer lets the queue drain before it writes them.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t ZW_RING = 8192;                          // ZSTD: ring bytes
+constexpr uint32_t ZW_RING = 4096;                          // ZSTD: ring bytes (r06 sweep on the 7-column set, tools/probes/r06_zstd_ring.sh: 16 KiB 22.4 ms, 8 KiB 20.0, 4 KiB 16.8, 2 KiB 17.8 — pages per CU by LDS)
 constexpr uint32_t ZW_TABLES = 13312 + zc::SCR_BYTES;       // Huffman 4 KiB + LL 4 KiB + ML 4 KiB + OF 1 KiB + scratch
 constexpr uint32_t ZW_LDS = ZW_RING + ZW_TABLES;
-constexpr uint32_t ZQ_CAP = 256;             // commands in the queue (16 bytes each)
+#ifndef DBHIP_ZQ_CAP
+#define DBHIP_ZQ_CAP 64
+#endif
+constexpr uint32_t ZQ_CAP = DBHIP_ZQ_CAP;    // commands in the queue (16 bytes each): ONE batch — the consumer takes a batch into registers and gives
+                                             // the slots back before it executes it, the producer collects the next one in registers meanwhile
 constexpr uint32_t ZQ_BYTES = ZQ_CAP * 16 + 16;
 constexpr uint32_t ZW2_LDS = ZW_RING + ZW_TABLES + ZQ_BYTES;   // the two-wave kernel: + the command queue
 enum { ZC_SEQ = 0, ZC_LIT_BEGIN = 1, ZC_LIT = 2, ZC_IN = 3, ZC_FILL = 4, ZC_END = 5, ZC_FRAME = 6 };
@@ -584,9 +588,12 @@ typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
 
 struct ZQueue {
   u32x4q* slots;      // [ZQ_CAP]
-  uint32_t* ctl;      // [0] tail (written by the producer), [1] head (written by the consumer)
+  uint32_t* ctl;      // [0] tail (written by the producer), [1] head: commands TAKEN, [3] commands EXECUTED (written by the consumer)
   __device__ __forceinline__ uint32_t tail() const { return __hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
   __device__ __forceinline__ uint32_t head() const { return __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ __forceinline__ uint32_t done() const { return __hip_atomic_load(&ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ __forceinline__ void take(uint32_t h) const { __hip_atomic_store(&ctl[1], h, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  __device__ __forceinline__ void executed(uint32_t h) const { __hip_atomic_store(&ctl[3], h, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
   // Belt and braces: a wait that sees no progress for ~2^24 polls (seconds) raises ctl[2]; both waves then leave and the page is
   // reported malformed — a logic error in the hand-shake must not be able to hang the device.
   __device__ __forceinline__ bool dead() const { return __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
@@ -668,7 +675,7 @@ struct ZProd : ZWave {
     qflush();
     if (failed) return;
     ZX_T0
-    for (uint32_t polls = 0; q.head() != qtail; ++polls) {
+    for (uint32_t polls = 0; q.done() != qtail; ++polls) {
       if (polls >= ZQ_POLLS) q.kill();
       if (q.dead()) return;
       __builtin_amdgcn_s_sleep(2);
@@ -827,6 +834,8 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
 #endif
     const uint32_t m = rfl(tail - head < 64 ? tail - head : 64);
     const u32x4q e = q.slots[(head + (w.lane < m ? w.lane : 0)) & (ZQ_CAP - 1)];
+    head = rfl(head + m);
+    q.take(head);       // (a release store: the slots have been read; what follows works on `e`)
     // THE COMMON BATCH: nothing but sequences — replayed BY THE BYTE, not by the sequence (ZWave::replay; one sequence per step made the
     // consumer the wave the page waited for). What is left to do here is the only serial part, phase A: the repeat-offset history
     // (RFC 8878 3.1.1.5) as one scalar pass over the batch without a memory access; the resolved offset of sequence i lands in lane i.
@@ -860,8 +869,7 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
           w.lit_left -= TL;
         }
       }
-      head = rfl(head + m);
-      __hip_atomic_store(&q.ctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      q.executed(head);
       continue;
     }
     for (uint32_t i = 0; i < m; ++i) {
@@ -894,7 +902,7 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
       }
       const uint32_t cmd = w0 & 0xFF;
       if (cmd == ZC_END) {
-        __hip_atomic_store(&q.ctl[1], head + m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q.executed(head);
         return bad && w1 == (uint32_t)zc::OK ? (uint32_t)zc::CORRUPT_ : w1;
       }
       if (bad) continue;
@@ -904,8 +912,7 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
       else if (cmd == ZC_FILL) (void)w.put_fill<false>(w1, w3);
       else if (cmd == ZC_FRAME) { w.frame0 = w.op_; r0 = 1; r1 = 4; r2 = 8; }   // back-references and the history do not reach across frames
     }
-    head = rfl(head + m);
-    __hip_atomic_store(&q.ctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    q.executed(head);
   }
 }
 

@@ -11,7 +11,7 @@ for f in *.hip; do
   n=${f%.hip}; o=build/$n.o
   for x in "$@"; do
     if [ "$x" = "$n" ]; then
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -I../../include -DDBHIP_EXPERIMENTS -c $f -o build_exp/$n.o
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -I../../include -DDBHIP_EXPERIMENTS $EXP_DEFS -c $f -o build_exp/$n.o
       o=build_exp/$n.o
     fi
   done
