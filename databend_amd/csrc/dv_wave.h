@@ -923,29 +923,67 @@ constexpr uint32_t LZ_RING = 8192;                          // LZ4 / Snappy: rin
 // LZ4 block format (lz4_Block_format.md) and Snappy raw format (format_description.txt) on the same wave: the payload is ONE forward
 // stream — tokens / tags are read from its register chunks (scalar), literals move from the chunks to the ring.
 // ---------------------------------------------------------------------------------------------
-// (Round 6 tried the ZSTD consumer's byte-parallel replay here too — parse up to 64 sequences ahead into lane registers, then
-// ZWave::replay<false> with the literals' payload positions per sequence; parity green, LZ4 14.2 -> 14.9 ms, Snappy 16.1 -> 21.4 ms on
-// the 7-column set: with 20 one-wave pages per CU the LDS round trips of pair_small are hidden by the other waves and the
-// INSTRUCTION COUNT rules, and the parse-ahead loop compiled to ~110 instructions per sequence, as many as the whole r05 loop. Taken out.)
+// LZ4 parses UP TO 64 SEQUENCES AHEAD — scalar work on the stream's register window, no LDS round trip — collecting (literals, match
+// length, offset, where the literals lie in the payload) in lane i of four registers, and hands the batch to ZWave::replay, which moves
+// 64 output bytes per step through a second view of the same stream (the literals lie behind the parser's position). With 20 one-wave
+// pages per CU the INSTRUCTION COUNT rules, not the latency: the common token (<= 5 literals, no length extension, everything inside
+// the chunk the stream holds) has a loop of its own with one exit; every other case leaves it for one pass of the general code.
+struct LzBatch {
+  uint32_t m;                // sequences collected (uniform)
+  uint32_t ll, ml, off, lp;  // lane i: sequence i
+  uint32_t room;             // bytes the page still has room for behind the collected sequences
+  __device__ __forceinline__ void begin(const ZWave& w) { m = 0; ll = ml = off = lp = 0; room = w.cap_ - w.op_; }
+  __device__ __forceinline__ void put(uint32_t lane, uint32_t l, uint32_t n, uint32_t o, uint32_t p) {   // (the caller has checked l + n <= room)
+    const bool mine = lane == m;
+    ll = mine ? l : ll; ml = mine ? n : ml; off = mine ? o : off; lp = mine ? p : lp;
+    room -= l + n;
+    m += 1;
+  }
+  // -> false: the sequence does not fit the page
+  __device__ __forceinline__ bool push(uint32_t lane, uint32_t l, uint32_t n, uint32_t o, uint32_t p) {
+    if (l > room || n > room - l) return false;
+    put(lane, l, n, o, p);
+    return true;
+  }
+  __device__ __forceinline__ bool run(ZWave& w, FwdStream& lits) {
+    uint32_t unused;
+    const bool ok = m == 0 || w.replay<false>(lits, m, ll, ml, off, lp, false, unused);
+    begin(w);
+    return ok;
+  }
+};
+
 // -> false: malformed
 __device__ __forceinline__ bool lz4_block(ZWave& w, FwdStream& in) {
   uint32_t p = 0;
   const uint32_t n = w.in_len, a0 = w.a0;
-  while (p < n) {
+  FwdStream lits = in;
+  LzBatch B;
+  B.begin(w);
+  for (;;) {
+    // the common token, as long as it lasts
+    for (;;) {
+      const uint32_t a = a0 + p;
+      if (B.m >= 64 || p + 24 > n || (a >> 8) != in.k || (a & 255u) > 244u) break;
+      const uint32_t i = (a & 255u) >> 2;
+      const uint32_t d0 = rdl(in.cur, i), d1 = rdl(in.cur, i + 1), d2 = rdl(in.cur, i + 2);
+      const uint32_t sft = 8 * (a & 3u);
+      const uint64_t h = (((uint64_t)d0 | ((uint64_t)d1 << 32)) >> sft) | (((uint64_t)d2 << 1) << (63 - sft));
+      const uint32_t lit = ((uint32_t)h >> 4) & 15u, ml = (uint32_t)h & 15u;
+      if (lit > 5 || ml == 15 || lit + ml + 4 > B.room) break;
+      B.put(w.lane, lit, ml + 4, (uint32_t)(h >> (8 + 8 * lit)) & 0xFFFF, a + 1);
+      p += lit + 3;
+    }
+    if (B.m >= 64) {
+      if (!B.run(w, lits)) return false;
+      continue;
+    }
+    if (p >= n) break;
+    // one sequence the general way
     const uint64_t h = in.u64(a0 + p);
     const uint32_t tok = (uint32_t)h & 0xFF;
     uint32_t lit = tok >> 4, ml = tok & 15u;
     p += 1;
-    // the common sequence: <= 5 literal bytes, no length extension, the two offset bytes still inside `h`, away from the end of the block
-    if (lit <= 5 && ml != 15 && n - p >= lit + 2 + 12) {
-      const uint32_t off = (uint32_t)(h >> (8 + 8 * lit)) & 0xFFFF;
-      if (off != 0 && off <= w.WM - 127) {
-        if (off > w.op_ - w.frame0 + lit || lit + ml + 4 > w.cap_ - w.op_) return false;
-        w.pair_small(h >> 8, lit, off, ml + 4);
-        p = rfl(p + lit + 2);
-        continue;
-      }
-    }
     if (lit == 15) {
       for (;;) {
         if (p >= n) return false;
@@ -956,13 +994,13 @@ __device__ __forceinline__ bool lz4_block(ZWave& w, FwdStream& in) {
         if (b != 255) break;
       }
     }
-    if (lit) {
-      if (lit > n - p || lit > w.cap_ - w.op_) return false;
-      if (lit <= 64) w.put_stream64(in, a0 + p, lit);
-      else w.copy_in(w.srcA + a0 + p, lit);
-      p = rfl(p + lit);
+    if (lit > n - p) return false;
+    const uint32_t lp = a0 + p;
+    p = rfl(p + lit);
+    if (p >= n) {              // the last sequence ends with its literals
+      if (lit && !B.push(w.lane, lit, 0, 1, lp)) return false;
+      break;
     }
-    if (p >= n) break;   // the last sequence ends with its literals
     if (n - p < 2) return false;
     const uint32_t off = (uint32_t)in.u64(a0 + p) & 0xFFFF;
     p += 2;
@@ -976,9 +1014,9 @@ __device__ __forceinline__ bool lz4_block(ZWave& w, FwdStream& in) {
         if (b != 255) break;
       }
     }
-    if (!w.put_match(off, ml + 4)) return false;
+    if (!B.push(w.lane, lit, ml + 4, off, lp)) return false;
   }
-  return true;
+  return B.run(w, lits);
 }
 
 __device__ __forceinline__ bool snappy_raw(ZWave& w, FwdStream& in) {
