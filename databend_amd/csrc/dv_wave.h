@@ -957,14 +957,19 @@ struct LzBatch {
 __device__ __forceinline__ bool lz4_block(ZWave& w, FwdStream& in) {
   uint32_t p = 0;
   const uint32_t n = w.in_len, a0 = w.a0;
+  const int32_t plim = (int32_t)n - 24;
   FwdStream lits = in;
   LzBatch B;
   B.begin(w);
   for (;;) {
     // the common token, as long as it lasts
+    const uint32_t kbase = in.k << 8;   // (the chunk the stream holds: it only moves in the general code below)
     for (;;) {
       const uint32_t a = a0 + p;
-      if (B.m >= 64 || p + 24 > n || (a >> 8) != in.k || (a & 255u) > 244u) break;
+      // a batch is full / fewer than 24 bytes are left / the 8 bytes at `a` do not lie in dwords 0..63 of the chunk
+      if (B.m >= 64) break;
+      if ((int32_t)p > plim) break;
+      if (a - kbase > 244u) break;
       const uint32_t i = (a & 255u) >> 2;
       const uint32_t d0 = rdl(in.cur, i), d1 = rdl(in.cur, i + 1), d2 = rdl(in.cur, i + 2);
       const uint32_t sft = 8 * (a & 3u);
@@ -1032,58 +1037,89 @@ __device__ __forceinline__ bool snappy_raw(ZWave& w, FwdStream& in) {
     if (!(b & 0x80)) { fin = true; break; }
   }
   if (!fin || total != (uint64_t)w.cap_) return false;
-  while (p < n) {
-    const uint64_t h = in.u64(a0 + p);
-    const uint32_t tag = (uint32_t)h & 0xFF, kind = tag & 3u, left = n - p;
-    if (kind == 0 && (tag >> 2) < 4 && left >= 24) {
-      // a literal of 1..4 bytes with the copy element behind it inside `h`: one LDS round trip for the pair
-      const uint32_t len = (tag >> 2) + 1;
-      const uint32_t t2 = (uint32_t)(h >> (8 + 8 * len)) & 0xFF, k2 = t2 & 3u;
-      if (k2 == 1 || (k2 == 2 && len <= 3)) {
-        uint32_t mlen, off, hdr2;
-        if (k2 == 1) { mlen = ((t2 >> 2) & 7u) + 4; off = ((t2 >> 5) << 8) | ((uint32_t)(h >> (16 + 8 * len)) & 0xFF); hdr2 = 2; }
-        else { mlen = (t2 >> 2) + 1; off = (uint32_t)(h >> (16 + 8 * len)) & 0xFFFF; hdr2 = 3; }
-        if (off != 0 && off <= w.WM - 127 && len + mlen <= 64) {
-          if (off > w.op_ - w.frame0 + len || len + mlen > w.cap_ - w.op_) return false;
-          w.pair_small(h >> 8, len, off, mlen);
-          p = rfl(p + 1 + len + hdr2);
-          continue;
-        }
-      }
+  // A sequence = a literal element (possibly none) + the copy element behind it (possibly none). Parsed ahead like LZ4's: the common
+  // pair (a literal of <= 4 bytes, a copy with a one- or two-byte offset, all inside the 8 bytes at the tag) in a loop of its own.
+  const int32_t plim = (int32_t)n - 24;
+  FwdStream lits = in;
+  LzBatch B;
+  B.begin(w);
+  for (;;) {
+    const uint32_t kbase = in.k << 8;
+    for (;;) {
+      const uint32_t a = a0 + p;
+      if (B.m >= 64) break;
+      if ((int32_t)p > plim) break;
+      if (a - kbase > 244u) break;
+      const uint32_t i = (a & 255u) >> 2;
+      const uint32_t d0 = rdl(in.cur, i), d1 = rdl(in.cur, i + 1), d2 = rdl(in.cur, i + 2);
+      const uint32_t sft = 8 * (a & 3u);
+      const uint64_t h = (((uint64_t)d0 | ((uint64_t)d1 << 32)) >> sft) | (((uint64_t)d2 << 1) << (63 - sft));
+      const uint32_t tag = (uint32_t)h & 0xFF;
+      const bool has_lit = (tag & 3u) == 0;
+      const uint32_t ll = has_lit ? (tag >> 2) + 1 : 0u;          // (> 4: not this loop's)
+      const uint32_t adv = has_lit ? 1 + ll : 0u;
+      if (ll > 4) break;
+      const uint32_t hb = (uint32_t)(h >> (8 * adv));              // the copy's tag and the two bytes behind it
+      const uint32_t t2 = hb & 0xFF, k2 = t2 & 3u;
+      if (k2 == 0 || k2 == 3) break;
+      const uint32_t mlen = k2 == 1 ? ((t2 >> 2) & 7u) + 4 : (t2 >> 2) + 1;
+      const uint32_t off = k2 == 1 ? ((t2 >> 5) << 8) | ((hb >> 8) & 0xFF) : (hb >> 8) & 0xFFFF;
+      if (off == 0 || ll + mlen > B.room) break;
+      B.put(w.lane, ll, mlen, off, a + 1);
+      p += adv + 1 + k2;
     }
-    if (kind == 0) {
+    if (B.m >= 64) {
+      if (!B.run(w, lits)) return false;
+      continue;
+    }
+    if (p >= n) break;
+    // one sequence the general way
+    uint64_t h = in.u64(a0 + p);
+    uint32_t tag = (uint32_t)h & 0xFF, ll = 0, lp = 0;
+    if ((tag & 3u) == 0) {
       uint32_t len = (tag >> 2) + 1, hdr = 1;
       if (len > 60) {
         const uint32_t extra = len - 60;   // 1..4 length bytes
-        if (left < 1 + extra) return false;
+        if (n - p < 1 + extra) return false;
         const uint32_t v = (uint32_t)(h >> 8) & (extra == 4 ? 0xFFFFFFFFu : ((1u << (8 * extra)) - 1));
         if (v == 0xFFFFFFFFu) return false;
         len = v + 1;
         hdr = 1 + extra;
       }
-      p += hdr;
-      if (len > n - p || len > w.cap_ - w.op_) return false;
-      if (len <= 64) w.put_stream64(in, a0 + p, len);
-      else w.copy_in(w.srcA + a0 + p, len);
-      p = rfl(p + len);
-    } else if (kind == 1) {
+      if (len > n - p - hdr) return false;
+      lp = a0 + p + hdr;
+      ll = len;
+      p = rfl(p + hdr + len);
+      bool lone = p >= n;                  // nothing behind it,
+      if (!lone) {
+        h = in.u64(a0 + p);
+        tag = (uint32_t)h & 0xFF;
+        lone = (tag & 3u) == 0;            // or another literal: a sequence without a copy
+      }
+      if (lone) {
+        if (!B.push(w.lane, ll, 0, 1, lp)) return false;
+        continue;
+      }
+    }
+    const uint32_t kind = tag & 3u, left = n - p;
+    uint32_t len, off;
+    if (kind == 1) {
       if (left < 2) return false;
-      const uint32_t len = ((tag >> 2) & 7u) + 4, off = ((tag >> 5) << 8) | ((uint32_t)(h >> 8) & 0xFF);
+      len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | ((uint32_t)(h >> 8) & 0xFF);
       p += 2;
-      if (!w.put_match(off, len)) return false;
     } else if (kind == 2) {
       if (left < 3) return false;
-      const uint32_t len = (tag >> 2) + 1, off = (uint32_t)(h >> 8) & 0xFFFF;
+      len = (tag >> 2) + 1; off = (uint32_t)(h >> 8) & 0xFFFF;
       p += 3;
-      if (!w.put_match(off, len)) return false;
     } else {
       if (left < 5) return false;
-      const uint32_t len = (tag >> 2) + 1, off = (uint32_t)(h >> 8);
+      len = (tag >> 2) + 1; off = (uint32_t)(h >> 8);
       p += 5;
-      if (!w.put_match(off, len)) return false;
     }
+    if (off == 0) return false;
+    if (!B.push(w.lane, ll, len, off, lp)) return false;
   }
-  return true;
+  return B.run(w, lits);
 }
 
 }  // namespace
