@@ -84,6 +84,124 @@ def _decode_frames_as_page(gpu, frames, plain):
     return vals, bytes(img[:len(plain)])
 
 
+def _odd_snappy(rng, total):
+    """(stream, plaintext): a legal Snappy raw stream no encoder writes — literal headers longer than they need to be (1..4 length bytes in
+    front of a few bytes), runs of one-byte literals with five-byte headers, copies of every kind (1-, 2- and 4-byte offsets), copies that
+    overlap their own output (offset < length), offsets far behind the decompressor's LDS ring"""
+    s, out = bytearray(), bytearray()
+
+    def literal(data):
+        n = len(data)
+        forms = [f for f, lim in ((0, 60), (1, 256), (2, 65536), (3, 1 << 24), (4, 1 << 32)) if n <= lim]
+        f = int(rng.choice(forms))
+        if f == 0:
+            s.append((n - 1) << 2)
+        else:
+            s.append((59 + f) << 2)
+            s.extend((n - 1).to_bytes(f, "little"))
+        s.extend(data)
+        out.extend(data)
+
+    def copy(off, ln):
+        kinds = [3] + ([2] if off < 65536 else []) + ([1] if 4 <= ln <= 11 and off < 2048 else [])
+        k = int(rng.choice(kinds))
+        if k == 1:
+            s.extend([1 | ((ln - 4) << 2) | ((off >> 8) << 5), off & 0xFF])
+        elif k == 2:
+            s.append(2 | ((ln - 1) << 2))
+            s.extend(off.to_bytes(2, "little"))
+        else:
+            s.append(3 | ((ln - 1) << 2))
+            s.extend(off.to_bytes(4, "little"))
+        for _ in range(ln):
+            out.append(out[-off])
+
+    while len(out) < total:
+        r = rng.random()
+        if len(out) == 0 or r < 0.25:
+            literal(rng.integers(0, 256, int(rng.choice([1, 1, 2, 3, 4, 5, 17, 60, 61, 100, 300, 5000])), dtype=np.uint8).tobytes())
+        elif r < 0.28:
+            for _ in range(int(rng.integers(70, 200))):      # one-byte literals, five header bytes each
+                s.extend([63 << 2, 0, 0, 0, 0])
+                b = int(rng.integers(0, 256))
+                s.append(b)
+                out.append(b)
+        else:
+            far = min(len(out), 70000)
+            off = int(rng.choice([1, 2, 3, 7, int(rng.integers(1, min(len(out), 64) + 1)), int(rng.integers(1, far + 1))]))
+            copy(min(off, len(out)), int(rng.integers(1, 65)))
+    if len(out) % 8:
+        literal(bytes(8 - len(out) % 8))
+    n, pre = len(out), bytearray()
+    while True:
+        pre.append((n & 0x7F) | (0x80 if n > 0x7F else 0))
+        n >>= 7
+        if not n:
+            break
+    return bytes(pre + s), bytes(out)
+
+
+def _odd_lz4(rng, total):
+    """(block, plaintext): an LZ4 block with every length form (15 exactly: one extension byte 0; 15 + 255 k: a chain of 255s closed by 0;
+    long literals and matches), overlapping matches and offsets up to 65535"""
+    s, out = bytearray(), bytearray()
+
+    def ext(v):
+        while v >= 255:
+            s.append(255)
+            v -= 255
+        s.append(v)
+
+    def seq(lit, ml, off):
+        s.append((min(lit, 15) << 4) | (min(ml - 4, 15) if ml else 0))
+        if lit >= 15:
+            ext(lit - 15)
+        data = rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+        s.extend(data)
+        out.extend(data)
+        if ml:
+            s.extend(off.to_bytes(2, "little"))
+            if ml - 4 >= 15:
+                ext(ml - 4 - 15)
+            for _ in range(ml):
+                out.append(out[-off])
+
+    while len(out) < total:
+        lit = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 6, 14, 15, 16, 15 + 255, 15 + 255 + 3, 15 + 510, 700]))
+        if len(out) == 0 and lit == 0:
+            lit = 3
+        ml = int(rng.choice([4, 4, 5, 8, 18, 19, 20, 19 + 255, 19 + 255 + 9, 19 + 510, 1000]))
+        far = min(len(out) + lit, 65535)
+        off = int(rng.choice([1, 2, 3, 7, int(rng.integers(1, min(far, 64) + 1)), int(rng.integers(1, far + 1))]))
+        seq(lit, ml, min(off, far))
+    tail = 16 + (-(len(out) + 16)) % 8
+    s.append(min(tail, 15) << 4)              # the last sequence: literals only
+    if tail >= 15:
+        ext(tail - 15)
+    s.extend(bytes(tail))
+    out.extend(bytes(tail))
+    return bytes(s), bytes(out)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_legal_streams_no_encoder_writes(gpu, seed):
+    """Snappy (format_description.txt) and LZ4 (lz4_Block_format.md) streams built element by element from the format documents — forms that
+    are legal but that the encoders behind the parquet crate never emit — decompress on the GPU to the plaintext they were built from; the
+    system's own decoders (through pyarrow) agree that the streams are legal."""
+    import pyarrow as pa
+    rng = np.random.default_rng(seed)
+    for codec, name, make in ((1, "snappy", _odd_snappy), (7, "lz4_raw", _odd_lz4)):
+        for total in (700, 40_000, 400_000):
+            z, plain = make(rng, total)
+            assert pa.Codec(name).decompress(z, len(plain)).to_pybytes() == plain, (name, total)
+            chunk = PU.raw_page_chunk(z, len(plain), len(plain) // 8)
+            pc = gpu.ParquetChunk(chunk, PU.PHYS["INT64"], T.T_I64, 0, 0, 0, codec, device=True)
+            pc.decode()
+            img = bytes(pc.device_image()[:len(plain)])
+            pc.close()
+            assert img == plain, (name, total, seed)
+
+
 def test_zstd_frames_the_reference_holds(gpu):
     """Known-answer vectors for the ZSTD path: the frames under the reference's tests/data (tests/golden/zstd_ref; ontime_200.csv.zst with the
     plaintext the reference keeps beside it, a 2.9 MB wasm module compressed at a high level: many blocks, treeless literals, repeat offsets,
