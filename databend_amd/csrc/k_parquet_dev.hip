@@ -314,7 +314,13 @@ __device__ __forceinline__ uint32_t dv_put_def(const DvChunkD& C, uint64_t dst0,
 }
 
 // definition levels of one data page -> validity bits + the page's non-null count and the offset of its values
-__global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restrict__ cds, const uint2* __restrict__ map) {
+// A List page's level streams are thousands of short runs, and the walk is a chain: header -> position of the next header. Read from the
+// image every hop is an HBM / L2 round trip (plus one for the run's payload): 9.7 ms for the 300 pages of a 6 M-row List<Int64> chunk,
+// ~1 us per run. With `lds_bytes` of dynamic LDS (batches that hold a List chunk) the workgroup first copies both streams into LDS — they
+// are contiguous in the page, 25-35 KB for a 1 MiB page — and walks them there; streams that do not fit are walked in place as before.
+constexpr uint32_t LV_LDS = 40960;
+__global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restrict__ cds, const uint2* __restrict__ map, uint32_t lds_bytes) {
+  extern __shared__ __align__(16) uint8_t lv_lds[];
   __shared__ uint32_t sh4[4];
   const uint2 m = map[blockIdx.x];
   const DvChunkD& C = cds[m.x];
@@ -352,6 +358,23 @@ __global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restri
     const uint32_t tid = threadIdx.x;
     const uint64_t r0 = P.row_start;
     bool bad = false;
+    {
+      const uint32_t span = (uint32_t)((stream + len) - rep);       // repetition levels, (v1: the 4-byte length,) definition levels
+      const uint32_t k = (uint32_t)((uintptr_t)rep & 3u);           // the copy keeps the address modulo 4: whole dwords in the middle
+      if (span + k + 4 <= lds_bytes) {
+        const uint32_t head = ((4u - k) & 3u) < span ? ((4u - k) & 3u) : span;
+        if (tid < head) lv_lds[k + tid] = rep[tid];
+        const uint32_t nw = (span - head) >> 2;
+        const uint32_t* __restrict__ gw = (const uint32_t*)(rep + head);
+        uint32_t* lw = (uint32_t*)(lv_lds + k + head);
+        for (uint32_t w = tid; w < nw; w += 256) lw[w] = gw[w];
+        const uint32_t done = head + 4 * nw;
+        if (tid < span - done) lv_lds[k + done + tid] = rep[done + tid];
+        __syncthreads();
+        stream = lv_lds + k + (uint32_t)(stream - rep);
+        rep = lv_lds + k;
+      }
+    }
     ok = dv_walk_hybrid(
         rep, rlen, 1, P.num_values,
         [&](uint32_t first, uint32_t n, uint32_t v) { if (v == 1) (void)dv_put_bits(C.isrep, r0 + first, n, nullptr, tid, 256); },
@@ -910,6 +933,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   for (int i : live)
     if (cs[i]->codec == CODEC_ZSTD) n_z += cs[i]->pages.size();
   size_t jz = 0, jo = n_z;
+  bool any_list = false;
   unsigned max_slices = 1;
   for (size_t k = 0; k < nl; ++k) {
     const int i = live[k];
@@ -949,6 +973,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
     D.slices = slices;
     if (slices > max_slices) max_slices = slices;
     if (c->list) {
+      any_list = true;
       D.ldw = c->list_max_def > 1 ? 2u : 1u; D.lmax = (uint32_t)c->list_max_def; D.lnull = (uint32_t)c->list_nullable;
       D.isrep = c->d_isrep; D.iselem = c->d_iselem; D.lvalid = c->d_lvalid;
     }
@@ -1000,7 +1025,7 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   }
   if (n_jobs > n_z) hipLaunchKernelGGL(dv_inflate_lz_kernel, dim3((unsigned)(n_jobs - n_z)), dim3(64), lz_ring, s, d_jobs + n_z, lz_ring);
   if (n_dict) hipLaunchKernelGGL(dv_dict_kernel, dim3((unsigned)n_dict), dim3(256), 0, s, d_cds, (const uint32_t*)(blob + L.dict_list));
-  if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.lv_map));
+  if (n_lv) hipLaunchKernelGGL(dv_levels_kernel, dim3((unsigned)n_lv), dim3(256), any_list ? LV_LDS : 0u, s, d_cds, (const uint2*)(blob + L.lv_map), any_list ? LV_LDS : 0u);
   hipLaunchKernelGGL(dv_scan_kernel, dim3((unsigned)nl), dim3(256), 0, s, d_cds);
   if (n_dp) hipLaunchKernelGGL(dv_values_kernel, dim3((unsigned)n_dp, max_slices), dim3(256), 0, s, d_cds, (const uint2*)(blob + L.val_map));
   for (int i : live) {
