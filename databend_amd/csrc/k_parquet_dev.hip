@@ -1105,36 +1105,62 @@ __global__ __launch_bounds__(256) void pq_list_count_kernel(const uint32_t* __re
 }
 // entry e: an element slot -> its value moves to the element's place (+ its validity bit); a row start -> offsets[row] = elements before it
 // (+ the list's validity bit). counts: [0] rows, [1] elements, [2] NULL lists, [3] != 0: the first entry continues a row (malformed)
+// bit `rank` of `bitmap` := 1 for the lanes with `set`; the ranks of a wave's setting lanes lie within 64 of each other. Called by whole
+// waves (lanes past the end of the data call it with set = false).
+__device__ __forceinline__ void list_put_bits(uint32_t* __restrict__ bitmap, bool set, uint64_t rank) {
+  const uint64_t any = __ballot(set);
+  if (any == 0) return;
+  if (__ballot(true) != ~0ull) {   // (the last, partial wave of the data: its idle lanes hold nothing a shuffle may read)
+    if (set) atomicOr(&bitmap[rank >> 5], 1u << (uint32_t)(rank & 31));
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t r0 = __shfl(rank, (int)__ffsll((long long)any) - 1, 64);      // the lowest rank: ranks grow with the lane
+  const uint64_t w0 = r0 >> 5;
+  const uint32_t pos = set ? (uint32_t)(rank - (w0 << 5)) : 0u;                 // 0 .. 95
+  uint32_t m0 = set && pos < 32 ? 1u << pos : 0u, m1 = set && pos >= 32 && pos < 64 ? 1u << (pos - 32) : 0u, m2 = set && pos >= 64 ? 1u << (pos - 64) : 0u;
+  for (int d = 32; d >= 1; d >>= 1) {
+    m0 |= (uint32_t)__shfl_xor((int)m0, d, 64);
+    m1 |= (uint32_t)__shfl_xor((int)m1, d, 64);
+    m2 |= (uint32_t)__shfl_xor((int)m2, d, 64);
+  }
+  const uint32_t m = lane == 0 ? m0 : lane == 1 ? m1 : m2;
+  if (lane < 3 && m) atomicOr(&bitmap[w0 + lane], m);
+}
+
 template <typename V>
 __global__ __launch_bounds__(256) void pq_list_finish_kernel(int64_t entries, const uint32_t* __restrict__ isrep, const uint32_t* __restrict__ iselem,
                                                              const uint32_t* __restrict__ lvalid, const uint32_t* __restrict__ valid,
                                                              const uint64_t* __restrict__ roff, const uint64_t* __restrict__ eoff, const V* __restrict__ ent_values,
                                                              uint64_t* __restrict__ out_offsets, uint32_t* __restrict__ out_lvalid, V* __restrict__ out_values,
                                                              uint32_t* __restrict__ out_evalid, unsigned long long* __restrict__ counts, int move_values) {
+  uint32_t wave_nulls = 0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < entries; e += (int64_t)gridDim.x * 256) {
     const int64_t w = e >> 5;
     const uint32_t b = (uint32_t)(e & 31), below = (1u << b) - 1u, bit = 1u << b;
     const uint32_t rep = isrep[w], el = iselem[w];
     const uint64_t erank = eoff[w] + (uint32_t)__popc(el & below);
+    bool ev = false, lv = false;
     if (el & bit) {
       if (move_values) out_values[erank] = ent_values[e];
-      if (out_evalid && (valid[w] & bit)) atomicOr(&out_evalid[erank >> 5], 1u << (uint32_t)(erank & 31));
+      ev = out_evalid && (valid[w] & bit);
     }
     bool null_list = false;
+    uint64_t rrank = 0;
     if (!(rep & bit)) {
-      const uint64_t rrank = roff[w] + (uint32_t)__popc(~rep & below);
+      rrank = roff[w] + (uint32_t)__popc(~rep & below);
       out_offsets[rrank] = erank;
       if (lvalid) {
-        if (lvalid[w] & bit) { if (out_lvalid) atomicOr(&out_lvalid[rrank >> 5], 1u << (uint32_t)(rrank & 31)); }
+        if (lvalid[w] & bit) lv = out_lvalid != nullptr;
         else null_list = true;
       }
     } else if (e == 0) counts[3] = 1;
-    // (the NULL lists of a wave's 64 entries: ONE add on the counter — 480 K single adds on one word were most of this kernel's 3.1 ms)
-    const uint64_t nulls = __ballot(null_list);
-    if (nulls) {
-      const uint64_t act = __ballot(true);
-      if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)act) - 1u) atomicAdd(&counts[2], (unsigned long long)__popcll(nulls));
-    }
+    // The validity bits of a wave's 64 entries land in at most three consecutive words of each output bitmap (the ranks of the wave's
+    // elements / rows are consecutive): the wave ORs them together and lanes 0..2 put the words — one atomic per entry on two or three
+    // words was most of this kernel's 3.1 ms per 20 M entries.
+    list_put_bits(out_evalid, ev, erank);
+    list_put_bits(out_lvalid, lv, rrank);
+    wave_nulls += (uint32_t)__popcll(__ballot(null_list));
     if (e == entries - 1) {
       const uint64_t rows = roff[w] + (uint32_t)__popc(~rep & (below | bit));
       const uint64_t elems = erank + ((el & bit) ? 1 : 0);
@@ -1142,6 +1168,12 @@ __global__ __launch_bounds__(256) void pq_list_finish_kernel(int64_t entries, co
       counts[0] = rows; counts[1] = elems;
     }
   }
+  // the NULL lists: ONE add per workgroup on the counter, and a grid of at most 2 048 workgroups — adds on one word are serialised in L2
+  // (round 5: one per entry, 480 K; then one per wave and iteration, 320 K: still the 3 ms this kernel took for 20 M entries)
+  __shared__ uint32_t wn[4];
+  if ((threadIdx.x & 63u) == 0) wn[threadIdx.x >> 6] = wave_nulls;
+  __syncthreads();
+  if (threadIdx.x == 0 && wn[0] + wn[1] + wn[2] + wn[3]) atomicAdd(&counts[2], (unsigned long long)(wn[0] + wn[1] + wn[2] + wn[3]));
 }
 // BOOLEAN elements: the values are a bitmap over the entries
 __global__ __launch_bounds__(256) void pq_list_finish_bool_kernel(int64_t entries, const uint32_t* __restrict__ iselem, const uint64_t* __restrict__ eoff,
@@ -1205,7 +1237,7 @@ int32_t decode_list(dbhip_pq_chunk* c, const uint8_t* chunk_dev, uint8_t* image_
   uint32_t* olv = c->list_nullable ? (uint32_t*)out_list_validity_dev : nullptr;
   uint32_t* oev = c->elem_nullable ? (uint32_t*)out_elem_validity_dev : nullptr;
   unsigned long long* counts = (unsigned long long*)c->d_lcounts;
-  const int grid = grid_for(entries, 256);
+  const int grid = grid_for(entries, 256) < 2048 ? grid_for(entries, 256) : 2048;
 #define LIST_FINISH(V_) hipLaunchKernelGGL(pq_list_finish_kernel<V_>, dim3(grid), dim3(256), 0, s, entries, c->d_isrep, c->d_iselem, lv, c->d_ent_valid, c->d_roff, \
                                            c->d_eoff, (const V_*)c->d_ent_values, out_offsets_dev, olv, (V_*)out_values_dev, oev, counts, 1)
   if (is_bool) {
