@@ -200,6 +200,82 @@ __device__ __forceinline__ bool dv_walk_hybrid(const uint8_t* __restrict__ s, ui
   return true;
 }
 
+// The same walk by ONE WAVE over streams staged in LDS, with the run headers read out of a 256-byte register window (lane l = dword l,
+// v_readlane: scalar results, no memory round trip per header — the chain header -> next header is what a List page's thousands of
+// short runs wait for). Positions are byte offsets from the start of the staged region.
+struct LvWin {
+  const uint8_t* sA;     // 4-byte aligned LDS address at or below the staged bytes
+  uint32_t a0, lim;      // first staged byte - sA; bytes readable from sA (a multiple of 4)
+  uint32_t wlo, w, lane;
+  __device__ __forceinline__ void slide(uint32_t wl) {
+    wlo = rfl(wl);
+    const uint32_t o = wlo + 4 * lane;
+    w = *(const uint32_t*)(sA + (o + 4 <= lim ? o : lim - 4));
+  }
+  __device__ __forceinline__ void open(const uint8_t* s, const uint8_t* end, uint32_t ln) {
+    a0 = (uint32_t)((uintptr_t)s & 3u); sA = s - a0; lim = (uint32_t)(end - sA) & ~3u; lane = ln;
+    slide(0);
+  }
+  __device__ __forceinline__ uint64_t u64(uint32_t pos) {
+    const uint32_t a = rfl(pos + a0);
+    if (a < wlo || a + 8 > wlo + 256) slide(a & ~3u);
+    const uint32_t i = (a - wlo) >> 2;
+    const uint32_t d0 = rdl(w, i), d1 = rdl(w, i + 1), d2 = rdl(w, i + 2 < 64 ? i + 2 : 63);
+    const uint64_t lo = (uint64_t)d0 | ((uint64_t)d1 << 32);
+    const uint32_t sft = 8 * (a & 3);
+    return sft ? (lo >> sft) | ((uint64_t)d2 << (64 - sft)) : lo;
+  }
+};
+
+// the stream is the `len` bytes at offset `at` of the staged region (whose bytes are at `base`); bit width <= 8
+template <class Rle, class Bp>
+__device__ __forceinline__ bool dv_walk_hybrid_wave(LvWin& W, const uint8_t* base, uint32_t at, uint32_t len, int bitw, uint32_t nvals, Rle&& rle, Bp&& bp) {
+  uint32_t pos = 0, done = 0;
+  while (done < nvals) {
+    if (pos >= len) return false;
+    const uint64_t h8 = W.u64(at + pos);
+    uint64_t h;
+    uint32_t used;
+    if (!(h8 & 0x80u)) { h = h8 & 0x7F; used = 1; }
+    else if (!(h8 & 0x8000u)) { h = (h8 & 0x7F) | ((h8 >> 1) & 0x3F80); used = 2; }
+    else if (!(h8 & 0x800000u)) { h = (h8 & 0x7F) | ((h8 >> 1) & 0x3F80) | ((h8 >> 2) & 0x1FC000); used = 3; }
+    else {
+      h = 0; used = 0;
+      for (uint32_t k = 0; k < 10; ++k) {
+        if (pos + k >= len) return false;
+        const uint32_t b = (uint32_t)W.u64(at + pos + k) & 0xFFu;
+        h |= (uint64_t)(b & 0x7F) << (7 * k);
+        if (!(b & 0x80)) { used = k + 1; break; }
+      }
+      if (used == 0) return false;
+    }
+    if (used > len - pos) return false;
+    pos = rfl(pos + used);
+    const uint32_t avail = len - pos;
+    if (h & 1) {
+      const uint64_t groups = h >> 1;
+      if (groups == 0 || groups > 0x1FFFFFFFull) return false;
+      const uint64_t n64 = groups * 8;
+      const uint32_t n = n64 > (uint64_t)(nvals - done) ? nvals - done : (uint32_t)n64;
+      if ((uint64_t)n * (uint64_t)bitw > (uint64_t)avail * 8) return false;
+      bp(done, n, base + at + pos);
+      const uint64_t bytes = groups * (uint64_t)bitw;
+      pos = rfl(pos + (bytes < (uint64_t)avail ? (uint32_t)bytes : avail));
+      done = rfl(done + n);
+    } else {
+      const uint64_t n64 = h >> 1;
+      if (n64 == 0 || avail < 1) return false;
+      const uint32_t v = (uint32_t)W.u64(at + pos) & 0xFFu;
+      pos += 1;
+      if ((v >> bitw) != 0) return false;
+      const uint32_t n = n64 > (uint64_t)(nvals - done) ? nvals - done : (uint32_t)n64;
+      rle(done, n, v);
+      done = rfl(done + n);
+    }
+  }
+  return true;
+}
+
 // bits [dst0, dst0 + n) of the zeroed LSB-first bitmap := the first n bits of `src` (packed, bit width 1; src == nullptr: ones).
 // Returns this thread's share of the number of ones. Called by all `nthr` threads.
 __device__ __forceinline__ uint32_t dv_put_bits(uint32_t* __restrict__ bitmap, uint64_t dst0, uint32_t n, const uint8_t* __restrict__ src,
@@ -371,8 +447,24 @@ __global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restri
         const uint32_t done = head + 4 * nw;
         if (tid < span - done) lv_lds[k + done + tid] = rep[done + tid];
         __syncthreads();
-        stream = lv_lds + k + (uint32_t)(stream - rep);
-        rep = lv_lds + k;
+        if (tid >= 64) return;             // one wave walks the page: its runs are a chain (no barrier follows on this path)
+        LvWin W;
+        W.open(lv_lds + k, lv_lds + lds_bytes, tid);
+        const uint8_t* base = lv_lds + k;
+        const uint32_t dat = (uint32_t)(stream - rep);
+        ok = dv_walk_hybrid_wave(
+            W, base, 0, rlen, 1, P.num_values,
+            [&](uint32_t first, uint32_t n, uint32_t v) { if (v == 1) (void)dv_put_bits(C.isrep, r0 + first, n, nullptr, tid, 64); },
+            [&](uint32_t first, uint32_t n, const uint8_t* src) { (void)dv_put_bits(C.isrep, r0 + first, n, src, tid, 64); });
+        uint32_t mine = 0;
+        ok = ok && dv_walk_hybrid_wave(
+            W, base, dat, len, (int)C.ldw, P.num_values,
+            [&](uint32_t first, uint32_t n, uint32_t v) { mine += dv_put_def(C, r0 + first, n, nullptr, v, tid, 64, &bad); },
+            [&](uint32_t first, uint32_t n, const uint8_t* src) { mine += dv_put_def(C, r0 + first, n, src, 0, tid, 64, &bad); });
+        for (int dd = 32; dd >= 1; dd >>= 1) mine += __shfl_xor(mine, dd, 64);
+        if (!ok || __ballot(bad) != 0) { dv_fail(ctl, DV_CORRUPT); ok = false; }
+        if (tid == 0) { nn[d] = ok ? mine : 0; voff[d] = ok ? vo : P.uncomp_len; }
+        return;
       }
     }
     ok = dv_walk_hybrid(
