@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--no-hnsw", action="store_true", help="skip the HNSW reference-comparable mode inside the ANN measurement")
     ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="base vectors of the HNSW reference-comparable run (the build is timed too)")
     ap.add_argument("--no-ann", action="store_true", help="skip the secondary ANN measurement (BASELINE configs[4])")
+    ap.add_argument("--no-scan", action="store_true", help="skip the scan-side measurement (Q1's seven columns as ZSTD Parquet pages -> HBM columns)")
     ap.add_argument("--ann-rows", type=int, default=10_000_000, help="base vectors of the WHOLE job (sharded by row range over the ranks)")
     ap.add_argument("--ann-dim", type=int, default=768)
     ap.add_argument("--ann-queries", type=int, default=10_000, help="queries per ANN step (replicated on every rank)")
@@ -357,6 +358,19 @@ def main():
         except Exception as e:      # a secondary measurement never takes the headline line down
             plans = {"error": repr(e)}
         torch.cuda.empty_cache()
+    scan = None
+    if not args.no_scan and world == 1:
+        # the scan side in front of the hot path: Q1's seven lineitem columns as the reference's writer lays them out —
+        # ZSTD level 1 (its default codec), DATA_PAGE_V2, 20 000-row pages — 8 blocks of 6 M rows decoded by ONE dbhip_pq_chunks_decode_device
+        # call from the stored bytes resident in HBM; the decode is checked to be the identity on what was written
+        try:
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pq_scan_probe as PSP
+            scan = PSP.run(codec="zstd", reps=3)
+        except Exception as e:      # a secondary measurement never takes the headline line down
+            scan = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if not args.no_ann:
         ann = bench_ann(args, rank, world, torch, dist, D, DX, L, check)
         if world == 1 and not args.no_hnsw:
@@ -413,6 +427,7 @@ def main():
             "q1_block_size_sweep": blocks,
             "q3_sf100": q3,
             "distributed_plan_stages": plans,
+            "scan_side_zstd": scan,
             "ann": ann,
         }
         print(json.dumps(out))

@@ -28,12 +28,12 @@ for STEP in "$@"; do
       tail -2 gpurun_out/bench_$TAG.err | cut -c1-300; cut -c1-1200 gpurun_out/bench_$TAG.json ;;
     prof)
       d=$R/gpurun_out/prof_$TAG; rm -rf $d
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $R/bench.py ${ARG:---steps 10 --warmup 2 --no-cpu --no-ann --no-q3 --no-opplan --no-readiness --no-blocks} > $R/gpurun_out/prof_bench_$TAG.json 2> $R/gpurun_out/prof_bench_$TAG.err)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $R/bench.py ${ARG:---steps 10 --warmup 2 --no-cpu --no-ann --no-q3 --no-opplan --no-readiness --no-blocks --no-scan} > $R/gpurun_out/prof_bench_$TAG.json 2> $R/gpurun_out/prof_bench_$TAG.err)
       stats $d gpurun_out/${TAG}_kernel_stats.csv; rm -rf $d ;;
     pmc)
       C=${ARG%%:*}; BA=""; [ "$ARG" != "$C" ] && BA=${ARG#*:}
       d=$R/gpurun_out/pmc_${TAG}_${C%%,*}; rm -rf $d
-      (cd /tmp && timeout 600 rocprofv3 --pmc ${C//,/ } --kernel-trace --output-format csv -d $d -o p -- python $R/bench.py ${BA:---steps 3 --warmup 1 --no-cpu --no-ann --no-q3 --no-opplan --no-readiness --no-blocks} > $d.json 2> $d.err)
+      (cd /tmp && timeout 600 rocprofv3 --pmc ${C//,/ } --kernel-trace --output-format csv -d $d -o p -- python $R/bench.py ${BA:---steps 3 --warmup 1 --no-cpu --no-ann --no-q3 --no-opplan --no-readiness --no-blocks --no-scan} > $d.json 2> $d.err)
       f=$(find $d -name '*counter_collection.csv' | head -1)
       [ -n "$f" ] && python tools/pmc_sum.py "$f" > gpurun_out/${TAG}_pmc_${C%%,*}.csv && head -20 gpurun_out/${TAG}_pmc_${C%%,*}.csv
       rm -rf $d ;;

@@ -35,7 +35,6 @@ def lineitem_block(rng, n):
 
 
 def main():
-    import pyarrow as pa
     ap = argparse.ArgumentParser()
     ap.add_argument("--codec", default="zstd")
     ap.add_argument("--blocks", type=int, default=8)
@@ -46,6 +45,17 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--no-check", action="store_true", help="skip the identity check (experiments that decode wrongly on purpose)")
     args = ap.parse_args()
+    res = run(args)
+    print(json.dumps(res))
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+def run(args=None, **kw_args):
+    """-> the result record; `args`: the parsed command line, or keywords (codec, blocks, rows, reps, page_rows, one_by_one, no_check) from bench.py"""
+    import pyarrow as pa
+    if args is None:
+        args = argparse.Namespace(**dict(dict(codec="zstd", blocks=8, rows=6_000_000, reps=5, page_rows=20_000, one_by_one=False, no_check=False), **kw_args))
     rng = np.random.default_rng(7)
     D.init(0)
     pcs, srcs = [], []
@@ -95,9 +105,9 @@ def main():
                out_bytes=out_bytes, ms=round(best * 1e3, 3), all_ms=[round(t * 1e3, 3) for t in ts], stored_GBps=round(stored / best / 1e9, 2),
                image_GBps=round((image or stored) / best / 1e9, 2), out_GBps=round(out_bytes / best / 1e9, 2),
                rows_per_s=round(args.rows * args.blocks / best), write_seconds=round(write_s, 1))
-    print(json.dumps(res))
-    if args.out:
-        json.dump(res, open(args.out, "w"), indent=1)
+    for pc in pcs:
+        pc.close()
+    return res
 
 
 if __name__ == "__main__":
