@@ -210,7 +210,7 @@ struct LvWin {
   __device__ __forceinline__ void slide(uint32_t wl) {
     wlo = rfl(wl);
     const uint32_t o = wlo + 4 * lane;
-    w = *(const uint32_t*)(sA + (o + 4 <= lim ? o : lim - 4));
+    w = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(sA + (o + 4 <= lim ? o : lim - 4));
   }
   __device__ __forceinline__ void open(const uint8_t* s, const uint8_t* end, uint32_t ln) {
     a0 = (uint32_t)((uintptr_t)s & 3u); sA = s - a0; lim = (uint32_t)(end - sA) & ~3u; lane = ln;
@@ -276,8 +276,27 @@ __device__ __forceinline__ bool dv_walk_hybrid_wave(LvWin& W, const uint8_t* bas
   return true;
 }
 
+// n <= 8 bytes at p, little-endian. LDS = true: p points into the workgroup's LDS (a staged level stream) and the bytes are read with
+// ds_read — a flat load would do, but it counts on vmcnt as well, and the wave would wait for the atomics of the run before at every run.
+template <bool LDS>
+__device__ __forceinline__ uint64_t lv_load_le(const uint8_t* p, int n) {
+  if (!LDS) return load_le(p, n);
+  const __attribute__((address_space(3))) uint8_t* q = (const __attribute__((address_space(3))) uint8_t*)(uintptr_t)p;
+  uint64_t v = 0;
+  for (int b = 0; b < n; ++b) v |= (uint64_t)q[b] << (8 * b);
+  return v;
+}
+template <bool LDS>
+__device__ __forceinline__ uint32_t lv_extract_bits(const uint8_t* src, uint64_t i, int bitw) {
+  const uint64_t bit = i * (uint64_t)bitw;
+  const int sh = (int)(bit & 7);
+  const uint64_t v = lv_load_le<LDS>(src + (bit >> 3), (sh + bitw + 7) >> 3);
+  return (uint32_t)((v >> sh) & ((bitw >= 32) ? 0xFFFFFFFFu : ((1u << bitw) - 1)));
+}
+
 // bits [dst0, dst0 + n) of the zeroed LSB-first bitmap := the first n bits of `src` (packed, bit width 1; src == nullptr: ones).
 // Returns this thread's share of the number of ones. Called by all `nthr` threads.
+template <bool LDS = false>
 __device__ __forceinline__ uint32_t dv_put_bits(uint32_t* __restrict__ bitmap, uint64_t dst0, uint32_t n, const uint8_t* __restrict__ src,
                                                 uint32_t tid, uint32_t nthr) {
   if (n == 0) return 0;
@@ -295,7 +314,7 @@ __device__ __forceinline__ uint32_t dv_put_bits(uint32_t* __restrict__ bitmap, u
       const uint64_t s0 = a - dst0;
       const uint8_t* p = src + (s0 >> 3);
       const int sh = (int)(s0 & 7);
-      const uint64_t v = load_le(p, (sh + nb + 7) >> 3);
+      const uint64_t v = lv_load_le<LDS>(p, (sh + nb + 7) >> 3);
       bits = (uint32_t)((v >> sh) & (nb == 32 ? 0xFFFFFFFFull : ((1ull << nb) - 1))) << (a - lo);
     }
     if (bits) {
@@ -344,6 +363,7 @@ struct DvChunkD {
 // ballots are the 64 bits of the three bitmaps, and lanes 0..2 put the (at most three) 32-bit words they touch — a page's levels are
 // mostly short packed runs between RLE runs, where one thread extracting a word's 32 levels one after the other was the whole cost
 // (12.8 of the 16.1 ms of a 6 M-row List<Int64> chunk, profiles/r05_pq_list_kernel_stats.csv).
+template <bool LDS = false>
 __device__ __forceinline__ uint32_t dv_put_def(const DvChunkD& C, uint64_t dst0, uint32_t n, const uint8_t* __restrict__ src, uint32_t run, uint32_t tid,
                                                uint32_t nthr, bool* bad) {
   if (n == 0) return 0;
@@ -369,7 +389,7 @@ __device__ __forceinline__ uint32_t dv_put_def(const DvChunkD& C, uint64_t dst0,
   for (uint32_t base = tid & ~63u; base < n; base += nthr) {          // (wave-uniform: this wave's entries base .. base + 63 of the run)
     const uint32_t x = base + lane;
     const bool in = x < n;
-    const uint32_t v = in ? extract_bits(src, x, (int)C.ldw) : 0u;
+    const uint32_t v = in ? lv_extract_bits<LDS>(src, x, (int)C.ldw) : 0u;
     if (in && v > D) *bad = true;
     const uint64_t mv = __ballot(in && v == D), me = __ballot(in && v >= L + 1), ml = L ? __ballot(in && v >= L) : 0ull;
     if (lane < 3) {
@@ -455,12 +475,12 @@ __global__ __launch_bounds__(256) void dv_levels_kernel(const DvChunkD* __restri
         ok = dv_walk_hybrid_wave(
             W, base, 0, rlen, 1, P.num_values,
             [&](uint32_t first, uint32_t n, uint32_t v) { if (v == 1) (void)dv_put_bits(C.isrep, r0 + first, n, nullptr, tid, 64); },
-            [&](uint32_t first, uint32_t n, const uint8_t* src) { (void)dv_put_bits(C.isrep, r0 + first, n, src, tid, 64); });
+            [&](uint32_t first, uint32_t n, const uint8_t* src) { (void)dv_put_bits<true>(C.isrep, r0 + first, n, src, tid, 64); });
         uint32_t mine = 0;
         ok = ok && dv_walk_hybrid_wave(
             W, base, dat, len, (int)C.ldw, P.num_values,
             [&](uint32_t first, uint32_t n, uint32_t v) { mine += dv_put_def(C, r0 + first, n, nullptr, v, tid, 64, &bad); },
-            [&](uint32_t first, uint32_t n, const uint8_t* src) { mine += dv_put_def(C, r0 + first, n, src, 0, tid, 64, &bad); });
+            [&](uint32_t first, uint32_t n, const uint8_t* src) { mine += dv_put_def<true>(C, r0 + first, n, src, 0, tid, 64, &bad); });
         for (int dd = 32; dd >= 1; dd >>= 1) mine += __shfl_xor(mine, dd, 64);
         if (!ok || __ballot(bad) != 0) { dv_fail(ctl, DV_CORRUPT); ok = false; }
         if (tid == 0) { nn[d] = ok ? mine : 0; voff[d] = ok ? vo : P.uncomp_len; }
