@@ -843,23 +843,50 @@ __device__ __forceinline__ uint32_t zq_consume(ZWave& w, const ZQueue& q, uint32
 #ifdef DBHIP_EXPERIMENTS
       if (xwait) xwait[1] += m;
 #endif
-      // ---- A
-      uint32_t offv = 0;
-#pragma clang loop unroll(disable)
-      for (uint32_t i = 0; i < m; ++i) {
-        const uint32_t ll = rdl(e.x, i), ov = rdl(e.z, i);
-        uint32_t j = ov - 1 + (ll == 0 ? 1u : 0u);
-        j = ov > 3 ? 4u : j;
-        uint32_t off = ov - 3;
-        off = j == 0 ? r0 : off;
-        off = j == 1 ? r1 : off;
-        off = j == 2 ? r2 : off;
-        off = j == 3 ? r0 - 1 : off;
-        r2 = j >= 2 ? r1 : r2;
-        r1 = j >= 1 ? r0 : r1;
-        r0 = off;
-        offv = w.lane == i ? off : offv;
+      // ---- A: the repeat-offset history of the batch as a SCAN (lane i = sequence i). A sequence maps the history (r0, r1, r2) to a new
+      // one whose components are each an old component (+ 0 or - 1) or a constant:
+      //   j = 0: (r0, r1, r2)   1: (r1, r0, r2)   2: (r2, r0, r1)   3: (r0 - 1, r0, r1)   4, a new offset c: (c, r0, r1)
+      // Such maps compose — component = (which old component | constant, value to add | the constant) — so six rounds of a wave scan
+      // give every lane the history in front of its sequence; a scalar loop over the batch (16 scalar instructions per sequence) was
+      // the consumer's largest share of the scalar unit, which every wave of the CU waits for.
+      const bool act_a = w.lane < m;
+      const uint32_t ov_l = act_a ? e.z : 1u, ll_l = act_a ? e.x : 1u;            // (idle lanes: j = 0, the identity)
+      const uint32_t jj = ov_l > 3 ? 4u : ov_l - 1 + (ll_l == 0 ? 1u : 0u);
+      // this sequence's map: packed component kinds (2 bits each: 0..2 = that old component, 3 = a constant) and the three values
+      uint32_t mk = jj == 0 ? 0x24u : jj == 1 ? 0x21u : jj == 2 ? 0x12u : jj == 3 ? 0x10u : 0x13u;
+      uint32_t v0 = jj == 3 ? 0xFFFFFFFFu : jj == 4 ? ov_l - 3 : 0u, v1 = 0, v2 = 0;
+#pragma unroll
+      for (uint32_t d = 1; d < 64; d <<= 1) {
+        // the map of the d lanes in front (already combined), applied FIRST: component c of the result = own component c with its
+        // reference into the old history followed through the other map
+        const uint32_t pk = bperm(w.lane - d, mk), p0 = bperm(w.lane - d, v0), p1 = bperm(w.lane - d, v1), p2 = bperm(w.lane - d, v2);
+        if (w.lane >= d) {
+          uint32_t nk = 0, n0, n1, n2;
+#define ZQ_COMPOSE(C_, VC_, NC_)                                                                   \
+          {                                                                                          \
+            const uint32_t k = (mk >> (2 * C_)) & 3u;                                                \
+            const uint32_t pkind = k == 0 ? pk & 3u : k == 1 ? (pk >> 2) & 3u : (pk >> 4) & 3u;      \
+            const uint32_t pval = k == 0 ? p0 : k == 1 ? p1 : p2;                                    \
+            nk |= (k == 3 ? 3u : pkind) << (2 * C_);                                                 \
+            NC_ = k == 3 ? VC_ : pval + VC_;                                                         \
+          }
+          ZQ_COMPOSE(0, v0, n0)
+          ZQ_COMPOSE(1, v1, n1)
+          ZQ_COMPOSE(2, v2, n2)
+#undef ZQ_COMPOSE
+          mk = nk; v0 = n0; v1 = n1; v2 = n2;
+        }
       }
+      // history behind this lane's sequence (inclusive) and in front of it (the lane before; lane 0: the batch's start)
+      const uint32_t k0 = mk & 3u, k1 = (mk >> 2) & 3u, k2 = (mk >> 4) & 3u;
+      const uint32_t a0 = (k0 == 3 ? 0u : k0 == 0 ? r0 : k0 == 1 ? r1 : r2) + v0;
+      const uint32_t a1 = (k1 == 3 ? 0u : k1 == 0 ? r0 : k1 == 1 ? r1 : r2) + v1;
+      const uint32_t a2 = (k2 == 3 ? 0u : k2 == 0 ? r0 : k2 == 1 ? r1 : r2) + v2;
+      // (the permutes by every lane: a lane that is masked off gives its neighbour nothing to read)
+      const uint32_t q0 = bperm(w.lane - 1, a0), q1 = bperm(w.lane - 1, a1), q2 = bperm(w.lane - 1, a2);
+      const uint32_t b0 = w.lane ? q0 : r0, b1 = w.lane ? q1 : r1, b2 = w.lane ? q2 : r2;
+      const uint32_t offv = jj == 0 ? b0 : jj == 1 ? b1 : jj == 2 ? b2 : jj == 3 ? b0 - 1 : ov_l - 3;
+      r0 = rdl(a0, 63); r1 = rdl(a1, 63); r2 = rdl(a2, 63);                         // (idle lanes are identities: lane 63 holds the batch's end)
       // ---- B, C
       if (!bad) {
         uint32_t TL = 0;
