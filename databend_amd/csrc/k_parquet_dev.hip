@@ -45,7 +45,9 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // ---------------------------------------------------------------------------------------------
 // page decompression: one wave per page (dv_wave.h)
 // ---------------------------------------------------------------------------------------------
-// ZSTD: one wave per page (dv_wave.h, zstd_core.h)
+// ZSTD: one wave per page (dv_wave.h, zstd_core.h) — the round-5 form, kept for A/B runs in the experiments build only (DBHIP_PQ_ZSTD_WAVES=1):
+// the shipped library always takes the two-wave kernel below
+#ifdef DBHIP_EXPERIMENTS
 __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
   extern __shared__ __align__(16) uint8_t dv_lds[];
   const DvJob P = jobs[blockIdx.x];
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(64) void dv_inflate_zstd_kernel(const DvJob* __rest
   w.flush(true);
   if (rc) dv_fail(P.ctl, rc == zc::UNSUPPORTED ? DV_UNSUPPORTED : DV_CORRUPT);
 }
+#endif
 
 // ZSTD, two waves per page: wave 0 parses (ZProd), wave 1 copies (dv_wave.h)
 __global__ __launch_bounds__(128) void dv_inflate_zstd2_kernel(const DvJob* __restrict__ jobs, uint32_t ring) {
@@ -1016,7 +1019,9 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   if (live.empty()) return DBHIP_OK;
   static const bool lds_ok = [] {
     return hipFuncSetAttribute((const void*)dv_inflate_lz_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_RING) == hipSuccess &&
+#ifdef DBHIP_EXPERIMENTS
            hipFuncSetAttribute((const void*)dv_inflate_zstd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW_LDS) == hipSuccess &&
+#endif
            hipFuncSetAttribute((const void*)dv_inflate_zstd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZW2_LDS) == hipSuccess;
   }();
   if (!lds_ok) { set_error("%s: cannot reserve LDS for the decompression kernels", who); return DBHIP_ERR_HIP; }
@@ -1129,9 +1134,12 @@ int32_t decode_many(dbhip_pq_chunk* const* cs, int32_t n, const uint8_t* const* 
   // served from the image instead of the ring
   static const uint32_t z_ring = ring_from_env("DBHIP_PQ_ZSTD_RING", ZW_RING), lz_ring = ring_from_env("DBHIP_PQ_LZ_RING", LZ_RING);
   // (two waves per page — parse | copy — unless DBHIP_PQ_ZSTD_WAVES=1 asks for the one-wave kernel)
+#ifdef DBHIP_EXPERIMENTS
   static const bool z_one_wave = exp_env("DBHIP_PQ_ZSTD_WAVES") && atoi(exp_env("DBHIP_PQ_ZSTD_WAVES")) == 1;
   if (n_z && z_one_wave) hipLaunchKernelGGL(dv_inflate_zstd_kernel, dim3((unsigned)n_z), dim3(64), z_ring + ZW_TABLES, s, d_jobs, z_ring);
-  else if (n_z) {
+  else
+#endif
+  if (n_z) {
     static const uint32_t z_x = exp_env("DBHIP_PQ_ZSTD_X") ? (uint32_t)atoi(exp_env("DBHIP_PQ_ZSTD_X")) << 24 : 0u;
     hipLaunchKernelGGL(dv_inflate_zstd2_kernel, dim3((unsigned)n_z), dim3(128), z_ring + ZW_TABLES + ZQ_BYTES, s, d_jobs, z_ring | z_x);
   }
